@@ -1,0 +1,123 @@
+"""CPU restatement of the SparseGCM step and the sparse TemporalEdge selector.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows src/gcm/sparse_gcm.py:55-212, src/gcm/sparse_edge_selectors/temporal.py:11-63
+and the helpers src/gcm/util.py:176-240,287-304,426-452.  The hidden adjacency
+is a torch.sparse_coo tensor with indices (batch, sink, source), as in the
+reference.
+"""
+import torch
+
+from . import pyg
+
+
+def initial_hidden(x, graph_size):
+    """sparse_gcm.py:55-70."""
+    B, _, F = x.shape
+    nodes = torch.zeros(B, graph_size, F)
+    adj = torch.zeros((B, graph_size, graph_size), layout=torch.sparse_coo)
+    return nodes, adj, torch.zeros(B, dtype=torch.long)
+
+
+def _ragged_arange(start, count):
+    """(batch ids, start[b] + 0..count[b]-1) for every b - util.py:176-231
+    build these with a Python list comprehension over B."""
+    b_ids = torch.repeat_interleave(torch.arange(count.numel()), count)
+    offs = torch.cumsum(count, 0) - count
+    within = torch.arange(int(count.sum())) - offs[b_ids]
+    return b_ids, start[b_ids] + within
+
+
+def batch_offsets(lengths):
+    """util.py:234-240."""
+    ends = lengths.cumsum(0)
+    return ends - lengths, ends
+
+
+class TemporalEdge:
+    """sparse_edge_selectors/temporal.py:18-63 - for every new node t in
+    [T_b, T_b + tau_b) and every hop h: edge (b, sink=t, source=t-h) when
+    source >= 0 and sink > 0."""
+
+    def __init__(self, hops=(1,)):
+        self.hops = torch.tensor(list(hops))
+
+    def __call__(self, nodes, T, taus, B):
+        b_ids, sinks = _ragged_arange(T, taus)
+        H = self.hops.numel()
+        sink = sinks.repeat_interleave(H)
+        src = sink - self.hops.repeat(sinks.numel())
+        bat = b_ids.repeat_interleave(H)
+        ok = (src >= 0) & (sink > 0)
+        idx = torch.stack([bat[ok], sink[ok], src[ok]])
+        return torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), size=(B, int(1e5), int(1e5)))
+
+
+def sparse_step(x, taus, hidden, gnn, graph_size=128, edge_selectors=None,
+                preprocessor=None, aux_edge_selectors=None, positional_encoder=None,
+                max_hops=None):
+    """sparse_gcm.py:72-212 - one SparseGCM.forward.
+    x [B, t, F] zero padded, taus [B] -> (mx_dense [B, t, H], hidden')."""
+    if hidden is None:
+        hidden = initial_hidden(x, graph_size)
+    nodes, adj, T = hidden
+    adj = adj.coalesce()
+    B, N = x.shape[0], nodes.shape[1]
+
+    new_b, new_t = _ragged_arange(T, taus)                       # util.py:191-208
+    pad_b, pad_t = _ragged_arange(torch.zeros_like(T), taus)     # util.py:176-188
+    if int(new_t.max()) >= N:                                    # sparse_gcm.py:120-121
+        raise Exception("Overflow")
+    nodes = nodes.clone().index_put((new_b, new_t), x[pad_b, pad_t])
+    dirty = nodes.clone()
+
+    def merge(adj, sel, seen):
+        add = sel(seen, T, taus, B).coalesce()
+        idx = torch.cat([adj.indices(), add.indices()], dim=-1)
+        val = torch.cat([adj.values(), add.values()], dim=-1)
+        return torch.sparse_coo_tensor(idx, val, size=adj.shape).coalesce()
+
+    if edge_selectors is not None:                               # :130-139
+        adj = merge(adj, edge_selectors, dirty)
+    if preprocessor is not None:
+        dirty = preprocessor(dirty)
+    if positional_encoder is not None:
+        dirty = positional_encoder(dirty, T + taus)
+    if aux_edge_selectors is not None:
+        adj = merge(adj, aux_edge_selectors, dirty)
+    v = adj.values()
+    adj = torch.sparse_coo_tensor(adj.indices(), v / v.detach(), size=adj.shape)  # :160-164
+
+    starts, _ = batch_offsets(T + taus)
+    live_b, live_t = _ragged_arange(torch.zeros_like(T), T + taus)   # util.py:211-231
+    flat_nodes = dirty[live_b, live_t]                               # util.py:426-452
+    _, out_idx = _ragged_arange(starts + T, taus)
+    ac = adj.coalesce()                                              # util.py:287-304
+    flat_edges = ac.indices()[1:] + starts[ac.indices()[0]]
+    weights = ac.values()
+    edges = torch.flip(flat_edges, (0,))                             # (sink,source)->(source,sink)
+    assert torch.all(edges[0] < edges[1]), "Causality violated"
+    if edges.numel() > 0:
+        edges, weights = pyg.coalesce(edges, weights, num_nodes=int((T + taus).sum()),
+                                      reduce="mean")
+    if max_hops is None:
+        mx = gnn(flat_nodes, edges, weights)[out_idx]
+    else:
+        sub, sub_edges, node_map, emask = pyg.k_hop_subgraph(
+            out_idx, max_hops, edges, relabel_nodes=True, num_nodes=int((T + taus).sum()))
+        mx = gnn(flat_nodes[sub], sub_edges, weights[emask])[node_map]
+    assert torch.all(torch.isfinite(mx)), "Got NaN in returned memory, try using tanh activation"
+    mx_dense = torch.zeros((*x.shape[:-1], mx.shape[-1]))
+    mx_dense = mx_dense.index_put((pad_b, pad_t), mx)
+    return mx_dense, (nodes, adj, T + taus)
+
+
+def canonical_gnn(F, H, act=torch.nn.Tanh, layers=2):
+    """ray_sparse_gcm.py:37-39 / tests/test_sparse_gcm.py:310-323 - GraphConv + act."""
+    mods, cin = [], F
+    for _ in range(layers):
+        mods.append((pyg.GraphConv(cin, H), "x, edges, weights -> x"))
+        if act is not None:
+            mods.append(act())
+        cin = H
+    return pyg.Sequential("x, edges, weights", mods)

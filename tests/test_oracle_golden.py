@@ -1,0 +1,118 @@
+"""Pin the CPU oracle against golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from _golden import Fixture, oracle_selector
+from oracle import dense as od, pyg, sparse as osp
+
+DENSE = ["g1_temporal_h1", "g2_temporal_h124_both", "g1b_cfg1", "g3_euclid", "g3_euclid_mixed",
+         "g3_euclid_learned", "g4_spatial", "g4_spatial_ab", "g4_cosine", "g5_dense_edge"]
+
+
+def _run_dense(fx, gnn, sel):
+    m = fx.meta
+    obs = fx["obs"].clone().requires_grad_(True)
+    hidden, mxs, sums = fx.h0(), [], []
+    for t in range(m["T"]):
+        mx, hidden = od.dense_step(obs[t], hidden, gnn, graph_size=m["N"], edge_selectors=sel)
+        mxs.append(mx)
+        sums.append(hidden[1].detach().sum(dim=(1, 2)))
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    return obs, mxs, hidden, torch.stack(sums)
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_oracle_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    gnn = od.canonical_gnn(m["F"], m["H"])
+    gnn.load_state_dict(fx.group("param:"))
+    sel = oracle_selector(m, fx.group("sel_param:"))
+    obs, mxs, hidden, sums = _run_dense(fx, gnn, sel)
+    assert torch.equal(hidden[0], fx["hT_nodes"])
+    assert torch.equal(hidden[1], fx["hT_adj"])          # adjacency: bit exact
+    assert torch.equal(hidden[3], fx["hT_num_nodes"])
+    assert torch.equal(sums, fx["adj_sums"])
+    torch.testing.assert_close(mxs, fx["mx"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+    for k, p in gnn.named_parameters():
+        torch.testing.assert_close(p.grad, fx["grad:" + k], rtol=1e-5, atol=1e-7)
+
+
+def test_learned_edge_oracle_matches_reference():
+    fx = Fixture("g6_learned")
+    m = fx.meta
+    gnn = od.canonical_gnn(m["F"], m["H"])
+    gnn.load_state_dict(fx.group("param:"))
+    net = od.build_edge_network(m["F"])
+    net.load_state_dict({k[len("edge_network."):]: v for k, v in fx.group("sel_param:").items()})
+    step = {"t": 0}
+
+    def noise(shape):
+        return fx[f"noise_{step['t']}"][:, : shape[1]]
+
+    sel = od.LearnedEdge(net, m["num_edge_samples"], noise_fn=noise)
+    obs = fx["obs"].clone().requires_grad_(True)
+    hidden, mxs = None, []
+    for t in range(m["T"]):
+        step["t"] = t
+        mx, hidden = od.dense_step(obs[t], hidden, gnn, graph_size=m["N"], edge_selectors=sel)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    assert torch.equal(hidden[1].detach(), fx["hT_adj"])
+    torch.testing.assert_close(mxs, fx["mx"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+    for k, p in net.named_parameters():
+        torch.testing.assert_close(p.grad, fx["sel_grad:edge_network." + k], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["g7_wrap_weights", "g7_wrap_noweights"])
+def test_wrap_overflow_oracle(name):
+    fx = Fixture(name)
+    g = pyg.Sequential("x, adj, weights, B, N",
+                       [(pyg.DenseGraphConv(5, 5), "x, adj -> x"), torch.nn.ReLU()])
+    g.load_state_dict(fx.group("param:"))
+    mx, (n2, a2, w2, nn2) = od.dense_step(fx["obs"], fx.h0(), g, graph_size=7)
+    assert torch.equal(n2, fx["hT_nodes"]) and torch.equal(a2, fx["hT_adj"])
+    assert torch.equal(w2, fx["hT_weights"]) and torch.equal(nn2, fx["hT_num_nodes"])
+    torch.testing.assert_close(mx, fx["mx"], rtol=1e-6, atol=1e-6)
+    # gcm.py:354 quirk - the reference decremented the CALLER's num_nodes in place
+    assert fx["caller_num_nodes_after"].tolist() == [1, 6]
+
+
+SPARSE = ["g8_sparse_oneshot", "g8_sparse_oneshot_2hop", "g8_sparse_stepwise",
+          "g8_sparse_ragged", "g8_sparse_ragged_2hop"]
+
+
+@pytest.mark.parametrize("name", SPARSE)
+def test_sparse_oracle_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    gnn = osp.canonical_gnn(m["F"], m["H"], act=torch.nn.Tanh if m["act"] else None)
+    gnn.load_state_dict(fx.group("param:"))
+    sel = osp.TemporalEdge(m["hops"])
+    obs = fx["obs"].clone().requires_grad_(True)
+    B = m["B"]
+    hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
+    for taus in fx["taus"]:
+        t = int(taus.max())
+        x = torch.zeros(B, t, m["F"])
+        for b in range(B):
+            x[b, : taus[b]] = obs[b, pos[b]: pos[b] + taus[b]]
+        out, hidden = osp.sparse_step(x, taus, hidden, gnn, graph_size=m["N"], edge_selectors=sel,
+                                      max_hops=m["max_hops"])
+        outs.append(out)
+        pos = pos + taus
+    loss = sum(o.sum() for o in outs) / sum(o.numel() for o in outs)
+    loss.backward()
+    for i, o in enumerate(outs):
+        torch.testing.assert_close(o, fx[f"out{i}"], rtol=1e-6, atol=1e-6)
+    assert torch.equal(hidden[0], fx["hT_nodes"])
+    assert torch.equal(hidden[1].coalesce().indices(), fx["hT_adj_indices"])   # bit exact
+    assert torch.equal(hidden[2], fx["hT_T"])
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+    for k, p in gnn.named_parameters():
+        torch.testing.assert_close(p.grad, fx["grad:" + k], rtol=1e-5, atol=1e-6)
