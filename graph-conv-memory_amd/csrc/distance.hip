@@ -1,0 +1,172 @@
+// Fused pairwise-distance + threshold + adjacency-row write for the Distance
+// edge selectors (edge_selectors/distance.py:18-81).
+//
+//   EUCLID_CROSSBATCH  d[b,j] = mean_{b'} || cur[b'] - nodes[b,j] ||        (EuclideanEdge: the
+//                      reference's cdist([B,F],[B,N,F]).mean(1) averages over ALL graphs b')
+//   L2_PERGRAPH        d[b,j] = || cur[b, a0:a1] - nodes[b, j, b0:b1] ||     (SpatialEdge)
+//   COSINE_SIM         d[b,j] = <cur[b]/max(|cur[b]|,eps), nodes[b,j]/max(|nodes[b,j]|,eps)>
+//
+// then adj[b, cur_b, j] = 1 for every j < cur_b with d[b,j] < max_distance.
+// The distance matrix never leaves the chip unless dist_out is given.
+#include "gcm_common.h"
+
+namespace {
+
+// gather cur rows (scaled) into workspace: ws_cur [B, F]
+__global__ void k_gather_cur(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
+                             const float* __restrict__ dist_param, float* __restrict__ ws_cur,
+                             int B, int N, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * F) return;
+  const int b = i / F, f = i - b * F;
+  int64_t c = cur_idx[b];
+  c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+  const float v = nodes[((size_t)b * N + c) * F + f];
+  ws_cur[i] = dist_param ? v / dist_param[0] : v;
+}
+
+// One workgroup = 128 threads = 128 node rows j of one graph b; each thread keeps its
+// (scaled) node row in registers (FP floats), the cur rows stream through LDS in chunks
+// and are read as broadcast 16-byte vectors.
+template <int FP>
+__global__ __launch_bounds__(128) void k_euclid_crossbatch(
+    const float* __restrict__ nodes, const float* __restrict__ ws_cur,
+    const int64_t* __restrict__ cur_idx, const float* __restrict__ dist_param,
+    float* __restrict__ adj, float* __restrict__ dist_out, float max_distance, int bidirectional,
+    int B, int N, int F) {
+  constexpr int CH = 32;  // cur rows per LDS chunk
+  __shared__ __attribute__((aligned(16))) float sC[CH * FP];
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  int64_t cur = cur_idx[b];
+  cur = cur < 0 ? 0 : (cur > N - 1 ? N - 1 : cur);
+  // rows >= cur can never become edges (distance.py:31-33); skip whole blocks of them
+  const bool block_live = (int64_t)blockIdx.x * 128 < cur || dist_out != nullptr;
+  if (!block_live) return;
+  const bool live = j < N && (j < cur || dist_out != nullptr);
+
+  float n[FP];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    float v = (live && f < F) ? nodes[((size_t)b * N + j) * F + f] : 0.f;
+    n[f] = dist_param ? v / dist_param[0] : v;
+  }
+  float total = 0.f;
+  for (int c0 = 0; c0 < B; c0 += CH) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < CH * FP; e += 128) {
+      const int r = e / FP, f = e - r * FP;
+      sC[e] = (c0 + r < B && f < F) ? ws_cur[(size_t)(c0 + r) * F + f] : 0.f;
+    }
+    __syncthreads();
+    const int rows = min(CH, B - c0);
+    for (int r = 0; r < rows; ++r) {
+      const f32x4* cp = reinterpret_cast<const f32x4*>(sC + r * FP);
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < FP / 4; ++q) {
+        const f32x4 c = cp[q];
+        const float d0 = c[0] - n[4 * q], d1 = c[1] - n[4 * q + 1];
+        const float d2 = c[2] - n[4 * q + 2], d3 = c[3] - n[4 * q + 3];
+        s = fmaf(d0, d0, s);
+        s = fmaf(d1, d1, s);
+        s = fmaf(d2, d2, s);
+        s = fmaf(d3, d3, s);
+      }
+      total += sqrtf(s);
+    }
+  }
+  if (!live) return;
+  const float d = total / (float)B;
+  if (dist_out) dist_out[(size_t)b * N + j] = d;
+  if (j < cur && d < max_distance) {
+    adj[((size_t)b * N + cur) * N + j] = 1.f;
+    if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
+  }
+}
+
+// per-graph modes: one thread per (b, j)
+__global__ void k_pergraph(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
+                           const float* __restrict__ dist_param, float* __restrict__ adj,
+                           float* __restrict__ dist_out, int mode, float max_distance, int a0,
+                           int a1, int b0, int bidirectional, int B, int N, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  const int b = i / N, j = i - b * N;
+  int64_t cur = cur_idx[b];
+  cur = cur < 0 ? 0 : (cur > N - 1 ? N - 1 : cur);
+  if (j >= cur && dist_out == nullptr) return;
+  const float* c = nodes + ((size_t)b * N + cur) * F;
+  const float* n = nodes + ((size_t)b * N + j) * F;
+  const float sc = dist_param ? dist_param[0] : 1.f;
+  float d;
+  if (mode == GCM_DIST_L2_PERGRAPH) {
+    float s = 0.f;
+    for (int f = 0; f < a1 - a0; ++f) {
+      const float t = c[a0 + f] / sc - n[b0 + f] / sc;
+      s = fmaf(t, t, s);
+    }
+    d = sqrtf(s);
+  } else {  // cosine similarity, torch semantics: normalise each side by max(norm, eps) first
+    float cc = 0.f, nn = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const float cv = c[f] / sc, nv = n[f] / sc;
+      cc = fmaf(cv, cv, cc);
+      nn = fmaf(nv, nv, nn);
+    }
+    const float ic = 1.f / fmaxf(sqrtf(cc), 1e-8f), in = 1.f / fmaxf(sqrtf(nn), 1e-8f);
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s = fmaf((c[f] / sc) * ic, (n[f] / sc) * in, s);
+    d = s;
+  }
+  if (dist_out) dist_out[i] = d;
+  if (j < cur && d < max_distance) {
+    adj[((size_t)b * N + cur) * N + j] = 1.f;
+    if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t gcm_edge_distance_workspace_bytes(int mode, int B, int N, int F) {
+  (void)N;
+  if (mode != GCM_DIST_EUCLID_CROSSBATCH || B <= 0 || F <= 0) return 0;
+  return (size_t)B * F * sizeof(float);
+}
+
+extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* cur_idx, int mode,
+                                 float max_distance, const float* dist_param, int a0, int a1,
+                                 int b0, int b1, int bidirectional, float* dist_out,
+                                 void* workspace, size_t workspace_bytes, int B, int N, int F,
+                                 gcm_stream_t stream) {
+  GCM_REQUIRE(nodes && adj && cur_idx && B > 0 && N > 0 && F > 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == GCM_DIST_EUCLID_CROSSBATCH) {
+    if (F > 128 || B > 65535) return GCM_EUNSUPPORTED;
+    GCM_REQUIRE(workspace);
+    if (workspace_bytes < (size_t)B * F * sizeof(float)) return GCM_EWORKSPACE;
+    float* ws_cur = (float*)workspace;
+    hipLaunchKernelGGL(k_gather_cur, dim3((B * F + 255) / 256), dim3(256), 0, s, nodes, cur_idx,
+                       dist_param, ws_cur, B, N, F);
+    dim3 grid((N + 127) / 128, B);
+#define GCM_EUCLID(FP)                                                                       \
+  hipLaunchKernelGGL(k_euclid_crossbatch<FP>, grid, dim3(128), 0, s, nodes, ws_cur, cur_idx, \
+                     dist_param, adj, dist_out, max_distance, bidirectional, B, N, F)
+    if (F <= 16) GCM_EUCLID(16);
+    else if (F <= 32) GCM_EUCLID(32);
+    else if (F <= 64) GCM_EUCLID(64);
+    else GCM_EUCLID(128);
+#undef GCM_EUCLID
+    return gcm_launch_status();
+  }
+  if (mode == GCM_DIST_L2_PERGRAPH) {
+    GCM_REQUIRE(a0 >= 0 && a1 > a0 && a1 <= F && b0 >= 0 && b1 <= F && (b1 - b0) == (a1 - a0));
+  } else if (mode != GCM_DIST_COSINE_SIM) {
+    return GCM_EINVAL;
+  }
+  const int total = B * N;
+  hipLaunchKernelGGL(k_pergraph, dim3((total + 255) / 256), dim3(256), 0, s, nodes, cur_idx,
+                     dist_param, adj, dist_out, mode, max_distance, a0, a1, b0, bidirectional, B,
+                     N, F);
+  return gcm_launch_status();
+}

@@ -1,0 +1,478 @@
+// DenseGraphConv forward / backward on the fp32 matrix cores of gfx950.
+//
+//   out = act( (adj @ x) @ w_rel^T + b_rel + x @ w_root^T )          (PyG DenseGraphConv)
+//
+// All products run on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, so results
+// stay inside the 1e-5 rtol contract).  One workgroup = WAVES waves = 32*WAVES
+// rows of ONE graph; every wave owns a 32-row strip.  Operands are staged through
+// LDS with row strides that are odd in dwords so that the per-lane fragment reads
+// (lane = matrix row or column) are bank-conflict free with ds_read_b32.
+//
+// Shapes are arbitrary (tests use N=7, F=3 ...): tiles are zero padded in LDS and
+// stores are masked.  Fi, Fo <= 128.
+#include "gcm_common.h"
+
+namespace {
+
+constexpr int KT = 32;  // K tile of the N-long contractions
+
+__host__ __device__ constexpr int round32(int v) { return (v + 31) & ~31; }
+
+// acc(32x32) += A(32 x K) * B(K x 32), operands in LDS.
+//   A(i,k) = a[i*ais + k*aks]      B(k,j) = b[k*bks + j*bjs]
+// Fragment map of v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31].
+__device__ __forceinline__ void mma32(f32x16& acc, const float* a, int ais, int aks,
+                                      const float* b, int bks, int bjs, int K, int li, int lh) {
+  const float* ap = a + li * ais + lh * aks;
+  const float* bp = b + lh * bks + li * bjs;
+#pragma unroll 4
+  for (int k = 0; k < K; k += 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * aks], bp[k * bks], acc, 0, 0, 0);
+  }
+}
+
+// accumulator element r of lane (li, lh) is C[row = (r&3) + 8*(r>>2) + 4*lh][col = li]
+__device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// cooperative zero-padded 2-D copy global -> LDS: dst[r*dstride + c] = src[(r0+r)*sstride + c0+c]
+__device__ __forceinline__ void stage(float* dst, int dstride, const float* src, int sstride,
+                                      int r0, int c0, int rows, int cols, int rmax, int cmax) {
+  const int total = rows * cols;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e / cols, c = e - r * cols;
+    const int gr = r0 + r, gc = c0 + c;
+    dst[r * dstride + c] = (gr < rmax && gc < cmax) ? src[(size_t)gr * sstride + gc] : 0.f;
+  }
+}
+// transposed variant: dst[c*dstride + r] = src[(r0+r)*sstride + c0+c]
+__device__ __forceinline__ void stage_t(float* dst, int dstride, const float* src, int sstride,
+                                        int r0, int c0, int rows, int cols, int rmax, int cmax) {
+  const int total = rows * cols;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e / cols, c = e - r * cols;
+    const int gr = r0 + r, gc = c0 + c;
+    dst[c * dstride + r] = (gr < rmax && gc < cmax) ? src[(size_t)gr * sstride + gc] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int WAVES, int NCT>
+__global__ __launch_bounds__(64 * WAVES) void k_graphconv_fwd(
+    const float* __restrict__ x, const float* __restrict__ adj, const float* __restrict__ w_rel,
+    const float* __restrict__ b_rel, const float* __restrict__ w_root, float* __restrict__ out,
+    float* __restrict__ agg_out, int N, int Fi, int Fo, int act) {
+  constexpr int RB = 32 * WAVES;
+  constexpr int FiP = 32 * NCT;
+  const int b = blockIdx.y, r0 = blockIdx.x * RB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const float* xg = x + (size_t)b * N * Fi;
+  const float* ag = adj + (size_t)b * N * N;
+
+  extern __shared__ float smem[];
+  float* sAdj = smem;                       // [RB][KT+1]
+  float* sX = sAdj + RB * (KT + 1);         // [KT][FiP]
+  float* sAgg = sX + KT * FiP;              // [RB][FiP+1]
+  float* sXr = sAgg + RB * (FiP + 1);       // [RB][FiP+1]
+  float* sWrel = sXr + RB * (FiP + 1);      // [FiP][33]   (w_rel^T tile: [k][n])
+  float* sWroot = sWrel + FiP * 33;         // [FiP][33]
+
+  // ---- phase A: agg = adj[rows, :] @ x -------------------------------------
+  f32x16 acc[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  for (int k0 = 0; k0 < N; k0 += KT) {
+    stage(sAdj, KT + 1, ag, N, r0, k0, RB, KT, N, N);
+    stage(sX, FiP, xg, Fi, k0, 0, KT, FiP, N, Fi);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+      mma32(acc[c], sAdj + wave * 32 * (KT + 1), KT + 1, 1, sX + c * 32, FiP, 1, KT, li, lh);
+    __syncthreads();
+  }
+
+  // ---- hand agg over to LDS (it becomes an A operand), stage x rows --------
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + acc_row(r, lh), col = c * 32 + li;
+      sAgg[row * (FiP + 1) + col] = acc[c][r];
+      if (agg_out && r0 + row < N && col < Fi)
+        agg_out[((size_t)b * N + r0 + row) * Fi + col] = acc[c][r];
+    }
+  stage(sXr, FiP + 1, xg, Fi, r0, 0, RB, FiP, N, Fi);
+
+  // ---- phase B: out = agg @ w_rel^T + x @ w_root^T + b ---------------------
+  for (int o0 = 0; o0 < Fo; o0 += 32) {
+    __syncthreads();
+    stage_t(sWrel, 33, w_rel, Fi, o0, 0, 32, FiP, Fo, Fi);
+    stage_t(sWroot, 33, w_root, Fi, o0, 0, 32, FiP, Fo, Fi);
+    __syncthreads();
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    mma32(o, sAgg + wave * 32 * (FiP + 1), FiP + 1, 1, sWrel, 33, 1, FiP, li, lh);
+    mma32(o, sXr + wave * 32 * (FiP + 1), FiP + 1, 1, sWroot, 33, 1, FiP, li, lh);
+    const int col = o0 + li;
+    const float bias = (b_rel && col < Fo) ? b_rel[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + wave * 32 + acc_row(r, lh);
+      if (row < N && col < Fo) out[((size_t)b * N + row) * Fo + col] = gcm_act(o[r] + bias, act);
+    }
+  }
+}
+
+size_t fwd_lds_bytes(int waves, int FiP) {
+  const int RB = 32 * waves;
+  return sizeof(float) * ((size_t)RB * (KT + 1) + KT * FiP + 2 * RB * (FiP + 1) + 2 * FiP * 33);
+}
+
+template <int WAVES>
+int launch_fwd(int nct, dim3 grid, size_t lds, hipStream_t s, const float* x, const float* adj,
+               const float* w_rel, const float* b_rel, const float* w_root, float* out, float* agg,
+               int N, int Fi, int Fo, int act) {
+#define GCM_FWD_CASE(NCT)                                                                      \
+  case NCT: {                                                                                  \
+    auto kern = k_graphconv_fwd<WAVES, NCT>;                                                   \
+    if (lds > 64 * 1024)                                                                       \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, s, x, adj, w_rel, b_rel, w_root, out, \
+                       agg, N, Fi, Fo, act);                                                   \
+    break;                                                                                     \
+  }
+  switch (nct) {
+    GCM_FWD_CASE(1)
+    GCM_FWD_CASE(2)
+    GCM_FWD_CASE(3)
+    GCM_FWD_CASE(4)
+    default: return GCM_EUNSUPPORTED;
+  }
+#undef GCM_FWD_CASE
+  return gcm_launch_status();
+}
+
+int pick_waves(int N, int FiP, size_t (*lds_fn)(int, int)) {
+  const int want = N > 64 ? 4 : (N > 32 ? 2 : 1);
+  for (int w = want; w >= 1; w >>= 1)
+    if (lds_fn(w, FiP) <= 160 * 1024) return w;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// backward, kernel 1 (row-local):  G = g_out * act'(out)
+//   dAgg = G @ w_rel        -> ws_dagg [B,N,Fi]
+//   g_x  = G @ w_root       (kernel 2 adds adj^T @ dAgg)
+//   slab[b, blk] = { G^T @ agg, G^T @ x, colsum(G) }      (reduced by kernel 3)
+//   g_adj[rows, :] = dAgg @ x^T                              (optional)
+// ---------------------------------------------------------------------------
+template <int WAVES, int NCT>
+__global__ __launch_bounds__(64 * WAVES) void k_graphconv_bwd_rows(
+    const float* __restrict__ g_out, const float* __restrict__ out, const float* __restrict__ x,
+    const float* __restrict__ agg, const float* __restrict__ w_rel,
+    const float* __restrict__ w_root, float* __restrict__ g_x, float* __restrict__ g_adj,
+    float* __restrict__ ws_dagg, float* __restrict__ slabs, int N, int Fi, int Fo, int act,
+    int want_w) {
+  constexpr int RB = 32 * WAVES;
+  constexpr int FiP = 32 * NCT;
+  const int FoP = round32(Fo);
+  const int b = blockIdx.y, r0 = blockIdx.x * RB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const float* xg = x + (size_t)b * N * Fi;
+
+  extern __shared__ float smem[];
+  float* sG = smem;                          // [RB][FoP+1]
+  float* sW = sG + RB * (FoP + 1);           // [FoP][FiP+1]  w (natural [fo][fi]) - reused rel/root
+  float* sAgg = sW + FoP * (FiP + 1);        // [RB][FiP+1]   agg rows, later dAgg rows
+  float* sXr = sAgg + RB * (FiP + 1);        // [RB][FiP+1]   x rows
+  float* sXk = sXr + RB * (FiP + 1);         // [32][FiP+1]   x tile for g_adj
+
+  // G = g_out * act'(out), zero padded
+  {
+    const int total = RB * FoP;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int r = e / FoP, c = e - r * FoP;
+      float v = 0.f;
+      if (r0 + r < N && c < Fo) {
+        const size_t g = ((size_t)b * N + r0 + r) * Fo + c;
+        v = g_out[g] * gcm_act_grad(out[g], act);
+      }
+      sG[r * (FoP + 1) + c] = v;
+    }
+  }
+  stage(sAgg, FiP + 1, agg + (size_t)b * N * Fi, Fi, r0, 0, RB, FiP, N, Fi);
+  stage(sXr, FiP + 1, xg, Fi, r0, 0, RB, FiP, N, Fi);
+  stage(sW, FiP + 1, w_rel, Fi, 0, 0, FoP, FiP, Fo, Fi);
+  __syncthreads();
+
+  // ---- parameter-gradient slabs: [Fo x Fi] = G^T(Fo x RB) @ {agg, x}(RB x Fi), K = RB rows
+  if (want_w) {
+    float* slab = slabs + ((size_t)b * gridDim.x + blockIdx.x) * (2 * (size_t)Fo * Fi + Fo);
+    const int n_ot = FoP / 32;
+    const int tiles = n_ot * NCT * 2;  // (fo tile, fi tile, which operand)
+    for (int t = wave; t < tiles; t += WAVES) {
+      const int which = t & 1, ct = (t >> 1) % NCT, ot = (t >> 1) / NCT;
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+      // A(i=fo,k=row) = sG[row][ot*32+fo];  B(k=row,j=fi) = src[row][ct*32+fi]
+      mma32(a, sG + ot * 32, 1, FoP + 1, (which ? sXr : sAgg) + ct * 32, FiP + 1, 1, RB, li, lh);
+      float* dst = slab + (which ? (size_t)Fo * Fi : 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int fo = ot * 32 + acc_row(r, lh), fi = ct * 32 + li;
+        if (fo < Fo && fi < Fi) dst[(size_t)fo * Fi + fi] = a[r];
+      }
+    }
+    for (int c = threadIdx.x; c < Fo; c += blockDim.x) {
+      float s = 0.f;
+      for (int r = 0; r < RB; ++r) s += sG[r * (FoP + 1) + c];
+      slab[2 * (size_t)Fo * Fi + c] = s;
+    }
+  }
+  __syncthreads();  // everyone is done reading sAgg as `agg`
+
+  // ---- dAgg = G @ w_rel  (K = Fo) -> LDS + workspace ------------------------
+  f32x16 d[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[c][r] = 0.f;
+    mma32(d[c], sG + wave * 32 * (FoP + 1), FoP + 1, 1, sW + c * 32, FiP + 1, 1, FoP, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + acc_row(r, lh), col = c * 32 + li;
+      sAgg[row * (FiP + 1) + col] = d[c][r];
+      if (r0 + row < N && col < Fi) ws_dagg[((size_t)b * N + r0 + row) * Fi + col] = d[c][r];
+    }
+  }
+  __syncthreads();
+  // ---- g_x (root part) = G @ w_root -----------------------------------------
+  stage(sW, FiP + 1, w_root, Fi, 0, 0, FoP, FiP, Fo, Fi);
+  __syncthreads();
+  if (g_x) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[c][r] = 0.f;
+      mma32(d[c], sG + wave * 32 * (FoP + 1), FoP + 1, 1, sW + c * 32, FiP + 1, 1, FoP, li, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + wave * 32 + acc_row(r, lh), col = c * 32 + li;
+        if (row < N && col < Fi) g_x[((size_t)b * N + row) * Fi + col] = d[c][r];
+      }
+    }
+  }
+  // ---- g_adj[rows, j] = dAgg[rows, :] . x[j, :]  (K = Fi) --------------------
+  if (g_adj) {
+    for (int j0 = 0; j0 < N; j0 += 32) {
+      __syncthreads();
+      stage(sXk, FiP + 1, xg, Fi, j0, 0, 32, FiP, N, Fi);
+      __syncthreads();
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+      // A(i=row,k=fi) = sAgg[row][fi];  B(k=fi,j) = sXk[j][fi]
+      mma32(a, sAgg + wave * 32 * (FiP + 1), FiP + 1, 1, sXk, 1, FiP + 1, FiP, li, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + wave * 32 + acc_row(r, lh), col = j0 + li;
+        if (row < N && col < N) g_adj[((size_t)b * N + row) * N + col] = a[r];
+      }
+    }
+  }
+}
+
+size_t bwd_rows_lds_bytes(int waves, int FiP, int FoP) {
+  const int RB = 32 * waves;
+  return sizeof(float) *
+         ((size_t)RB * (FoP + 1) + FoP * (FiP + 1) + 2 * RB * (FiP + 1) + 32 * (FiP + 1));
+}
+
+// ---------------------------------------------------------------------------
+// backward, kernel 2:  g_x[cols blk] += adj[:, blk]^T @ dAgg      (K = N)
+// ---------------------------------------------------------------------------
+template <int WAVES, int NCT>
+__global__ __launch_bounds__(64 * WAVES) void k_graphconv_bwd_adjT(
+    const float* __restrict__ adj, const float* __restrict__ ws_dagg, float* __restrict__ g_x,
+    int N, int Fi) {
+  constexpr int RB = 32 * WAVES;
+  constexpr int FiP = 32 * NCT;
+  const int b = blockIdx.y, i0 = blockIdx.x * RB;  // i0: block of adj COLUMNS = rows of g_x
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const float* ag = adj + (size_t)b * N * N;
+  const float* dg = ws_dagg + (size_t)b * N * Fi;
+
+  extern __shared__ float smem[];
+  float* sA = smem;               // [KT][RB]     adj[k0+k][i0+i]  (A(i,k) read down a column)
+  float* sD = sA + KT * RB;       // [KT][FiP]    dAgg[k0+k][:]
+
+  f32x16 acc[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  for (int k0 = 0; k0 < N; k0 += KT) {
+    stage(sA, RB, ag, N, k0, i0, KT, RB, N, N);
+    stage(sD, FiP, dg, Fi, k0, 0, KT, FiP, N, Fi);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+      mma32(acc[c], sA + wave * 32, 1, RB, sD + c * 32, FiP, 1, KT, li, lh);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + wave * 32 + acc_row(r, lh), col = c * 32 + li;
+      if (row < N && col < Fi) g_x[((size_t)b * N + row) * Fi + col] += acc[c][r];
+    }
+}
+
+size_t bwd_adjT_lds_bytes(int waves, int FiP) {
+  return sizeof(float) * ((size_t)KT * 32 * waves + KT * FiP);
+}
+
+// ---------------------------------------------------------------------------
+// backward, kernel 3: sum the per-(graph, row block) slabs -> g_w_rel, g_w_root, g_b_rel
+// deterministic (fixed order), no atomics
+// ---------------------------------------------------------------------------
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, int n_slabs, int slab_len,
+                               float* __restrict__ g_w_rel, float* __restrict__ g_w_root,
+                               float* __restrict__ g_b_rel, int FoFi, int Fo) {
+  // 4 partial sums per element, interleaved over slabs, combined through LDS
+  __shared__ float part[256];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < slab_len)
+    for (int i = q; i < n_slabs; i += 4) s += slabs[(size_t)i * slab_len + e];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (q == 0 && e < slab_len) {
+    const float v = (part[threadIdx.x] + part[threadIdx.x + 64]) +
+                    (part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+    if (e < FoFi) { if (g_w_rel) g_w_rel[e] = v; }
+    else if (e < 2 * FoFi) { if (g_w_root) g_w_root[e - FoFi] = v; }
+    else if (g_b_rel) g_b_rel[e - 2 * FoFi] = v;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int gcm_dense_graphconv_fwd(const float* x, const float* adj, const float* w_rel,
+                                       const float* b_rel, const float* w_root, float* out,
+                                       float* agg, int B, int N, int Fi, int Fo, int act,
+                                       gcm_stream_t stream) {
+  GCM_REQUIRE(x && adj && w_rel && w_root && out);
+  GCM_REQUIRE(B > 0 && N > 0 && Fi > 0 && Fo > 0);
+  if (Fi > 128 || Fo > 128 || B > 65535) return GCM_EUNSUPPORTED;
+  const int FiP = round32(Fi);
+  const int waves = pick_waves(N, FiP, fwd_lds_bytes);
+  if (!waves) return GCM_EUNSUPPORTED;
+  const int RB = 32 * waves;
+  dim3 grid((N + RB - 1) / RB, B);
+  const size_t lds = fwd_lds_bytes(waves, FiP);
+  hipStream_t s = (hipStream_t)stream;
+  switch (waves) {
+    case 4: return launch_fwd<4>(FiP / 32, grid, lds, s, x, adj, w_rel, b_rel, w_root, out, agg, N, Fi, Fo, act);
+    case 2: return launch_fwd<2>(FiP / 32, grid, lds, s, x, adj, w_rel, b_rel, w_root, out, agg, N, Fi, Fo, act);
+    default: return launch_fwd<1>(FiP / 32, grid, lds, s, x, adj, w_rel, b_rel, w_root, out, agg, N, Fi, Fo, act);
+  }
+}
+
+namespace {
+struct BwdPlan {
+  int waves, RB, nblk;
+  size_t dagg_bytes, slab_len, slabs_bytes;
+};
+BwdPlan bwd_plan(int B, int N, int Fi, int Fo) {
+  BwdPlan p;
+  const int FiP = round32(Fi), FoP = round32(Fo);
+  const int want = N > 64 ? 4 : (N > 32 ? 2 : 1);
+  p.waves = 0;
+  for (int w = want; w >= 1; w >>= 1)
+    if (bwd_rows_lds_bytes(w, FiP, FoP) <= 160 * 1024) { p.waves = w; break; }
+  p.RB = 32 * (p.waves ? p.waves : 1);
+  p.nblk = (N + p.RB - 1) / p.RB;
+  p.dagg_bytes = (((size_t)B * N * Fi * sizeof(float)) + 255) & ~(size_t)255;
+  p.slab_len = 2 * (size_t)Fo * Fi + Fo;
+  p.slabs_bytes = (size_t)B * p.nblk * p.slab_len * sizeof(float);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t gcm_dense_graphconv_bwd_workspace_bytes(int B, int N, int Fi, int Fo) {
+  if (B <= 0 || N <= 0 || Fi <= 0 || Fo <= 0) return 0;
+  BwdPlan p = bwd_plan(B, N, Fi, Fo);
+  return p.dagg_bytes + p.slabs_bytes;
+}
+
+extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, const float* x,
+                                       const float* adj, const float* agg, const float* w_rel,
+                                       const float* w_root, float* g_x, float* g_adj,
+                                       float* g_w_rel, float* g_b_rel, float* g_w_root,
+                                       void* workspace, size_t workspace_bytes, int B, int N,
+                                       int Fi, int Fo, int act, gcm_stream_t stream) {
+  GCM_REQUIRE(g_out && out && x && adj && agg && w_rel && w_root && workspace);
+  GCM_REQUIRE(B > 0 && N > 0 && Fi > 0 && Fo > 0);
+  if (Fi > 128 || Fo > 128 || B > 65535) return GCM_EUNSUPPORTED;
+  BwdPlan p = bwd_plan(B, N, Fi, Fo);
+  if (!p.waves) return GCM_EUNSUPPORTED;
+  if (workspace_bytes < p.dagg_bytes + p.slabs_bytes) return GCM_EWORKSPACE;
+  float* ws_dagg = (float*)workspace;
+  float* slabs = (float*)((char*)workspace + p.dagg_bytes);
+  const int FiP = round32(Fi), FoP = round32(Fo), nct = FiP / 32;
+  const int want_w = (g_w_rel || g_w_root || g_b_rel) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(p.nblk, B);
+  const size_t lds1 = bwd_rows_lds_bytes(p.waves, FiP, FoP);
+  const size_t lds2 = bwd_adjT_lds_bytes(p.waves, FiP);
+
+#define GCM_BWD_LAUNCH(W, C)                                                                      \
+  {                                                                                               \
+    auto k1 = k_graphconv_bwd_rows<W, C>;                                                         \
+    if (lds1 > 64 * 1024)                                                                         \
+      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)lds1);                                                       \
+    hipLaunchKernelGGL(k1, grid, dim3(64 * W), lds1, s, g_out, out, x, agg, w_rel, w_root, g_x,   \
+                       g_adj, ws_dagg, slabs, N, Fi, Fo, act, want_w);                            \
+    if (g_x) {                                                                                    \
+      auto k2 = k_graphconv_bwd_adjT<W, C>;                                                       \
+      hipLaunchKernelGGL(k2, grid, dim3(64 * W), lds2, s, adj, ws_dagg, g_x, N, Fi);              \
+    }                                                                                             \
+  }
+#define GCM_BWD_W(W)                                  \
+  switch (nct) {                                      \
+    case 1: GCM_BWD_LAUNCH(W, 1) break;               \
+    case 2: GCM_BWD_LAUNCH(W, 2) break;               \
+    case 3: GCM_BWD_LAUNCH(W, 3) break;               \
+    default: GCM_BWD_LAUNCH(W, 4) break;              \
+  }
+  switch (p.waves) {
+    case 4: GCM_BWD_W(4) break;
+    case 2: GCM_BWD_W(2) break;
+    default: GCM_BWD_W(1) break;
+  }
+#undef GCM_BWD_W
+#undef GCM_BWD_LAUNCH
+  int rc = gcm_launch_status();
+  if (rc != GCM_OK) return rc;
+  if (want_w) {
+    const int slab_len = (int)p.slab_len;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 63) / 64), dim3(256), 0, s, slabs,
+                       B * p.nblk, slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
+    rc = gcm_launch_status();
+  }
+  return rc;
+}

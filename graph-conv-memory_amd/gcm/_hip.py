@@ -1,0 +1,89 @@
+"""ctypes binding of libgcm_hip.so (C ABI: include/gcm_hip.h).
+
+There is NO CPU fallback: importing is always allowed (so host-side logic can
+be inspected anywhere) but the first kernel call raises if the library is
+missing or a tensor is not on a HIP device.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libgcm_hip.so")
+_lib = None
+
+# constants mirrored from include/gcm_hip.h
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+DIR = {"forward": 1, "backward": 2, "both": 3}
+DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
+FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
+
+_P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes).  Kept in one table so tests can check that every
+# symbol declared in include/gcm_hip.h is exported and bound.
+PROTOTYPES = {
+    "gcm_version": (_I, []),
+    "gcm_status_string": (ctypes.c_char_p, [_I]),
+    "gcm_state_advance_fwd": (_I, [_P] * 11 + [_I, _I, _I, _P]),
+    "gcm_state_advance_bwd": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "gcm_gather_rows_fwd": (_I, [_P] * 4 + [_I, _I, _I, _P]),
+    "gcm_gather_rows_bwd": (_I, [_P] * 3 + [_I, _I, _I, _P]),
+    "gcm_edge_temporal": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "gcm_edge_dense": (_I, [_P, _P, _I, _I, _P]),
+    "gcm_edge_distance_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "gcm_edge_distance": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _I, _I, _I, _P]),
+    "gcm_dense_graphconv_fwd": (_I, [_P] * 7 + [_I] * 5 + [_P]),
+    "gcm_dense_graphconv_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "gcm_dense_graphconv_bwd": (_I, [_P] * 13 + [_Z] + [_I] * 5 + [_P]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raises HipLibraryError if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipLibraryError(
+                f"{_LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                "`make -C graph-conv-memory_amd/csrc` (hipcc, --offload-arch=gfx950). "
+                "This package has no CPU fallback."
+            )
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gcm_status_string(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(*tensors):
+    """Validate that every given tensor lives on a HIP device and is contiguous."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipLibraryError(
+                "gcm (MI355X build) runs on HIP devices only; got a tensor on "
+                f"'{t.device}'. There is no CPU fallback."
+            )
+        if not t.is_contiguous():
+            raise ValueError("gcm kernels need contiguous tensors")

@@ -1,0 +1,191 @@
+"""DenseGCM - the dense graph memory step (reference: src/gcm/gcm.py:151-355).
+
+Same constructor, call surface and hidden-state layout as the reference:
+
+    belief, m_t = DenseGCM(gnn, edge_selectors=...)(obs, m_t)
+    m_t = (nodes f32[B,N,F], adj f32[B,N,N], weights f32[B,N,N] | f32[0], num_nodes i64[B])
+
+What differs is where the work runs: the node insert + overflow roll, the edge
+selectors, DenseGraphConv and the belief-row extract are gfx950 kernels
+(include/gcm_hip.h) launched on the current stream, and the step never blocks
+on the device: the reference's two host syncs per step (gcm.py:263, 316-318)
+are replaced by a device-side flag word that is polled without blocking
+(`finite_check="deferred"`, default), checked every step (`"sync"`, the
+reference's exact raise point) or not at all (`"off"`).
+"""
+from typing import Tuple, Union
+
+import torch
+
+from . import _hip, _ops
+
+
+class DenseGCM(torch.nn.Module):
+    """Graph Associative Memory (dense adjacency)."""
+
+    did_warn = False
+
+    def __init__(
+        self,
+        gnn: torch.nn.Module,
+        preprocessor: torch.nn.Module = None,
+        edge_selectors: torch.nn.Module = None,
+        aux_edge_selectors: torch.nn.Module = None,
+        graph_size: int = 128,
+        pooled: bool = False,
+        positional_encoder: torch.nn.Module = None,
+        edge_weights: bool = False,
+        finite_check: str = "deferred",
+        poll_interval: int = 16,
+        mutate_num_nodes_on_overflow: bool = False,
+    ):
+        super().__init__()
+        assert finite_check in ("deferred", "sync", "off")
+        self.preprocessor = preprocessor
+        self.gnn = gnn
+        self.graph_size = graph_size
+        self.edge_selectors = edge_selectors
+        self.aux_edge_selectors = aux_edge_selectors
+        self.pooled = pooled
+        self.edge_weights = edge_weights
+        self.positional_encoder = positional_encoder
+        self.finite_check = finite_check
+        self.poll_interval = poll_interval
+        # gcm.py:354 decrements the CALLER's num_nodes in place when a graph wraps;
+        # off by default (the returned values are identical either way)
+        self.mutate_num_nodes_on_overflow = mutate_num_nodes_on_overflow
+        self._flags = {}      # device -> uint32[1] flag word written by the kernels
+        self._pending = []    # [(pinned host copy, event)] of flag words in flight
+        self._steps = 0
+
+    # -- state ---------------------------------------------------------------
+    def get_initial_hidden_state(self, x):
+        """gcm.py:194-211 - zero (nodes, adj, weights, num_nodes) for a dummy x [B, feats]."""
+        assert x.dim() == 2
+        B, feats = x.shape
+        edges = torch.zeros(B, self.graph_size, self.graph_size, device=x.device)
+        nodes = torch.zeros(B, self.graph_size, feats, device=x.device)
+        if self.edge_weights:
+            weights = torch.zeros(B, self.graph_size, self.graph_size, device=x.device)
+        else:
+            weights = torch.zeros(0, device=x.device)
+        num_nodes = torch.zeros(B, dtype=torch.long, device=x.device)
+        return nodes, edges, weights, num_nodes
+
+    # -- device flag word ------------------------------------------------------
+    def _flag_word(self, device):
+        f = self._flags.get(device)
+        if f is None:
+            f = torch.zeros(1, dtype=torch.int32, device=device)
+            self._flags[device] = f
+        return f
+
+    def _raise_for(self, bits):
+        if bits & _hip.FLAG_BAD_COUNT:
+            raise AssertionError("num_nodes outside [0, graph_size]")
+        if bits & _hip.FLAG_WRAPPED and not DenseGCM.did_warn:
+            print("Overflow detected, wrapping around. Will not warn again")
+            DenseGCM.did_warn = True
+        if bits & _hip.FLAG_NONFINITE:
+            raise AssertionError("Got NaN in returned memory, try using tanh activation")
+
+    def check_flags(self, block=True):
+        """Surface anything the kernels flagged so far.  block=False only looks at
+        flag copies that have already landed on the host."""
+        if block:
+            for dev, f in self._flags.items():
+                bits = int(f.item())
+                f.zero_()
+                self._pending.clear()
+                self._raise_for(bits)
+            return
+        while self._pending and self._pending[0][1].query():
+            host, _ = self._pending.pop(0)
+            self._raise_for(int(host.item()))
+
+    def _poll(self, flags):
+        self._steps += 1
+        if self.finite_check == "sync":
+            bits = int(flags.item())
+            if bits:
+                flags.zero_()
+            self._raise_for(bits)
+        elif self.finite_check == "deferred":
+            self.check_flags(block=False)
+            if self._steps % self.poll_interval == 0:
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(flags, non_blocking=True)
+                flags.zero_()
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending.append((host, ev))
+
+    # -- the step --------------------------------------------------------------
+    def forward(
+        self,
+        x,
+        hidden: Union[None, Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]],
+    ) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """x [B, feat]; hidden = (nodes [B,N,feat], adj [B,N,N], weights [B,N,N] | [0],
+        num_nodes [B]) or None.  Returns (belief [B, H], new hidden)."""
+        if hidden is None:
+            hidden = self.get_initial_hidden_state(x)
+        nodes, adj, weights, num_nodes = hidden
+
+        assert x.dtype == torch.float32
+        assert nodes.dtype == torch.float
+        assert adj.dtype == torch.float, "adj must be float32"
+        assert weights.dtype == torch.float
+        assert num_nodes.dtype == torch.long
+        assert num_nodes.dim() == 1
+        N = nodes.shape[1]
+        B = x.shape[0]
+        assert N == adj.shape[1] == adj.shape[2], "N must be equal for adj mat and node mat"
+
+        flags = self._flag_word(x.device)
+        # insert x at row num_nodes (after the overflow roll); fresh nodes/adj/weights buffers
+        nodes, adj, weights, cur, num_nodes_next = _ops.state_advance(
+            nodes, adj, weights, num_nodes, x, flags)
+        if self.mutate_num_nodes_on_overflow:
+            num_nodes.copy_(cur)          # == num_nodes unless the graph wrapped (gcm.py:354)
+
+        # The returned `nodes` must stay clean (gcm.py:275-278): hand user modules a copy
+        # because they may write in place; native selectors/GNN layers never mutate nodes.
+        user_code = self.preprocessor is not None or self.positional_encoder is not None
+        dirty_nodes = nodes.clone() if user_code else nodes
+
+        if self.edge_selectors:
+            adj, weights = self.edge_selectors(dirty_nodes, adj, weights, cur, B)
+        if self.preprocessor:
+            dirty_nodes = self.preprocessor(dirty_nodes)
+        if self.aux_edge_selectors:
+            seen = dirty_nodes
+            if self.positional_encoder:
+                seen = self.positional_encoder(dirty_nodes, cur)
+            adj, weights = self.aux_edge_selectors(seen, adj, weights, cur, B)
+
+        node_feats = self.gnn(dirty_nodes, adj, weights, B, N)
+        if self.pooled:
+            mx = node_feats
+            if self.finite_check != "off":   # gcm.py:316-318 on the pooled output
+                flags.bitwise_or_((~torch.isfinite(mx)).any().to(torch.int32) * _hip.FLAG_NONFINITE)
+        else:
+            mx = _ops.gather_rows(node_feats, cur, flags)
+        if self.finite_check != "off":
+            self._poll(flags)
+        return mx, (nodes, adj, weights, num_nodes_next)
+
+    def wrap_overflow(self, nodes, adj, weights, num_nodes):
+        """gcm.py:323-355 as a standalone call: returns rolled copies (inputs untouched,
+        unless mutate_num_nodes_on_overflow)."""
+        B, N, F = nodes.shape
+        full = num_nodes + 1 > N
+        x = torch.zeros(B, F, device=nodes.device)
+        flags = self._flag_word(nodes.device)
+        n2, a2, w2, cur, _ = _ops.state_advance(nodes, adj, weights, num_nodes, x, flags)
+        # undo the insert of the dummy x for graphs that did not wrap
+        keep = (~full).view(B, 1, 1)
+        n2 = torch.where(keep, nodes, n2)
+        if self.mutate_num_nodes_on_overflow:
+            num_nodes.copy_(cur)
+        return n2, a2, w2, cur

@@ -1,0 +1,306 @@
+"""Parity of the HIP DenseGCM path (through the C ABI) against the CPU oracle and
+the golden vectors captured from the reference.  Needs an MI355X."""
+import pytest
+import torch
+
+from _golden import Fixture, oracle_selector
+from oracle import dense as od, pyg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL, ATOL = 1e-5, 1e-6   # north_star: 1e-5 rtol fp32 on outputs; adjacency bit exact
+
+
+def dev_gnn_from(ref_gnn, spec):
+    """Product GNN with the oracle GNN's weights. spec: [(Fi, Fo, act_cls|None), ...]"""
+    from gcm import nn as G
+
+    mods = []
+    for fi, fo, act in spec:
+        mods.append((G.DenseGraphConv(fi, fo), "x, adj -> x"))
+        if act is not None:
+            mods.append(act())
+    g = G.Sequential("x, adj, weights, B, N", mods)
+    g.load_state_dict(ref_gnn.state_dict())
+    return g.to(DEV)
+
+
+def product_selector(meta, sel_params=None):
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.dense import DenseEdge
+    from gcm.edge_selectors.distance import EuclideanEdge, CosineEdge, SpatialEdge
+
+    kind = meta["selector"]
+    if kind == "temporal":
+        return TemporalBackedge(meta["hops"], direction=meta["direction"])
+    if kind == "dense":
+        return DenseEdge()
+    learned = bool(meta.get("learned"))
+    if kind == "euclid":
+        s = EuclideanEdge(meta["max_distance"], learned=learned)
+    elif kind == "cosine":
+        s = CosineEdge(meta["max_distance"], learned=learned)
+    else:
+        s = SpatialEdge(meta["max_distance"], slice(*meta["a"]), slice(*meta["b"]), learned=learned)
+    if learned:
+        s.load_state_dict(sel_params)
+    return s.to(DEV)
+
+
+# --------------------------------------------------------------------------
+# DenseGraphConv kernel: forward + every gradient, odd shapes included
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,Fi,Fo,act", [
+    (2, 7, 5, 5, "relu"), (3, 8, 3, 3, None), (5, 10, 11, 11, "relu"), (4, 32, 8, 32, "tanh"),
+    (2, 33, 20, 40, "tanh"), (3, 100, 64, 32, "tanh"), (2, 128, 32, 32, "tanh"),
+    (1, 130, 33, 65, None), (2, 64, 128, 128, "tanh"), (1, 257, 96, 16, "relu"),
+])
+def test_graphconv_kernel(B, N, Fi, Fo, act):
+    from gcm import nn as G
+    torch.manual_seed(B * 1000 + N)
+    ref = pyg.DenseGraphConv(Fi, Fo)
+    dev = G.DenseGraphConv(Fi, Fo)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.to(DEV)
+    x = torch.randn(B, N, Fi)
+    adj = (torch.rand(B, N, N) < 0.2).float() * torch.rand(B, N, N).round(decimals=1)
+    acts = {"tanh": torch.tanh, "relu": torch.relu, None: lambda t: t}
+    code = {"tanh": 1, "relu": 2, None: 0}[act]
+    xc, ac = x.clone().requires_grad_(True), adj.clone().requires_grad_(True)
+    xd, ad = x.to(DEV).requires_grad_(True), adj.to(DEV).requires_grad_(True)
+    yc = acts[act](ref(xc, ac))
+    yd = dev(xd, ad, _act=code)
+    torch.testing.assert_close(yd.cpu(), yc, rtol=RTOL, atol=1e-5)
+    g = torch.randn_like(yc)
+    yc.backward(g)
+    yd.backward(g.to(DEV))
+    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ad.grad.cpu(), ac.grad, rtol=1e-4, atol=1e-4)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
+        scale = float(pc.grad.abs().max()) + 1e-6
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
+
+
+def test_graphconv_identity_known_answer():
+    """tests/test_gcm.py:282-323 - identity lin_root, identity lin_rel, no edges => out == obs."""
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    feats, B, N = 11, 5, 10
+    g = G.Sequential("x, adj, weights, B, N", [
+        (G.DenseGraphConv(feats, feats), "x, adj -> x"), torch.nn.ReLU(),
+        (G.DenseGraphConv(feats, feats), "x, adj -> x"), torch.nn.ReLU()])
+    for m in g.modules():
+        if isinstance(m, G.DenseGraphConv):
+            m.lin_root.weight = torch.nn.Parameter(torch.eye(feats))
+            m.lin_rel.weight = torch.nn.Parameter(torch.eye(feats))
+            m.lin_rel.bias = torch.nn.Parameter(torch.zeros(feats))
+    s = DenseGCM(g.to(DEV))
+    hidden = (torch.zeros(B, N, feats, device=DEV), torch.zeros(B, N, N, device=DEV),
+              torch.ones(B, N, N, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV))
+    for k in (1, 2, 3):
+        obs = k * torch.ones(B, feats, device=DEV)
+        out, hidden = s(obs, hidden)
+        assert torch.equal(out, obs)
+    want = torch.zeros(B, N, feats)
+    want[:, 0], want[:, 1], want[:, 2] = 1, 2, 3
+    assert torch.equal(hidden[0].cpu(), want)
+
+
+# --------------------------------------------------------------------------
+# state advance / wrap overflow (tests/test_gcm.py:105-184)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g7_wrap_weights", "g7_wrap_noweights"])
+def test_wrap_overflow_golden(name):
+    from gcm.gcm import DenseGCM
+    fx = Fixture(name)
+    ref = pyg.Sequential("x, adj, weights, B, N",
+                         [(pyg.DenseGraphConv(5, 5), "x, adj -> x"), torch.nn.ReLU()])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(5, 5, torch.nn.ReLU)])
+    for mutate in (False, True):
+        s = DenseGCM(g, mutate_num_nodes_on_overflow=mutate, finite_check="sync")
+        h0 = tuple(t.to(DEV) for t in fx.h0())
+        mx, (n2, a2, w2, nn2) = s(fx["obs"].to(DEV), h0)
+        assert torch.equal(n2.cpu(), fx["hT_nodes"]) and torch.equal(a2.cpu(), fx["hT_adj"])
+        assert torch.equal(w2.cpu(), fx["hT_weights"]) and torch.equal(nn2.cpu(), fx["hT_num_nodes"])
+        torch.testing.assert_close(mx.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+        # inputs are never modified ... except the reference's num_nodes quirk when asked for
+        assert torch.equal(h0[0].cpu(), fx["h0_nodes"]) and torch.equal(h0[1].cpu(), fx["h0_adj"])
+        want_nn = fx["caller_num_nodes_after"] if mutate else fx["h0_num_nodes"]
+        assert torch.equal(h0[3].cpu(), want_nn)
+
+
+def test_state_advance_random_vs_oracle():
+    from gcm import _ops
+    torch.manual_seed(3)
+    B, N, F = 9, 13, 6
+    nodes, adj, w = torch.randn(B, N, F), torch.rand(B, N, N), torch.rand(B, N, N)
+    nn_ = torch.tensor([0, 1, 5, 12, 13, 13, 7, 13, 2])
+    x = torch.randn(B, F)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for weights in (w, torch.zeros(0)):
+        n2, a2, w2, cur, nxt = _ops.state_advance(nodes.to(DEV), adj.to(DEV), weights.to(DEV),
+                                                  nn_.to(DEV), x.to(DEV), flags)
+        rn, ra, rw, rnn = od.wrap_overflow(nodes, adj, weights, nn_)
+        rn = rn.index_put((torch.arange(B), rnn), x)
+        assert torch.equal(n2.cpu(), rn) and torch.equal(a2.cpu(), ra) and torch.equal(w2.cpu(), rw)
+        assert torch.equal(cur.cpu(), rnn) and torch.equal(nxt.cpu(), rnn + 1)
+    assert int(flags.item()) & 1
+
+
+# --------------------------------------------------------------------------
+# full rollouts against the reference's golden vectors
+# --------------------------------------------------------------------------
+DENSE = ["g1_temporal_h1", "g2_temporal_h124_both", "g1b_cfg1", "g3_euclid", "g3_euclid_mixed",
+         "g3_euclid_learned", "g4_spatial", "g4_spatial_ab", "g4_cosine", "g5_dense_edge"]
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_rollout_matches_reference(name):
+    from gcm.gcm import DenseGCM
+    fx = Fixture(name)
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    mem = DenseGCM(g, edge_selectors=product_selector(m, fx.group("sel_param:")), graph_size=m["N"])
+    obs = fx["obs"].to(DEV).requires_grad_(True)
+    h0 = fx.h0()
+    hidden = None if h0 is None else tuple(t.to(DEV) for t in h0)
+    mxs, sums = [], []
+    for t in range(m["T"]):
+        mx, hidden = mem(obs[t], hidden)
+        mxs.append(mx)
+        sums.append(hidden[1].sum(dim=(1, 2)))
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    mem.check_flags()
+    assert torch.equal(hidden[1].cpu(), fx["hT_adj"])            # adjacency: bit exact
+    assert torch.equal(torch.stack(sums).cpu(), fx["adj_sums"])
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])
+    assert torch.equal(hidden[3].cpu(), fx["hT_num_nodes"])
+    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+    gscale = float(fx["grad_obs"].abs().max())
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gscale)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+
+
+def test_distance_matrix_matches_oracle():
+    """The thresholded quantity itself (all three dist_fn variants) vs the oracle."""
+    from gcm.edge_selectors.distance import EuclideanEdge, CosineEdge, SpatialEdge
+    torch.manual_seed(0)
+    B, N, F = 6, 40, 24
+    nodes = torch.randn(B, N, F)
+    nn_ = torch.tensor([0, 1, 13, 39, 20, 7])
+    pairs = [(EuclideanEdge(1.0), od.EuclideanEdge(1.0)), (CosineEdge(0.1), od.CosineEdge(0.1)),
+             (SpatialEdge(1.0, slice(2, 9), slice(11, 18)), od.SpatialEdge(1.0, slice(2, 9), slice(11, 18)))]
+    for dev_sel, ref_sel in pairs:
+        d = dev_sel.distances(nodes.to(DEV), nn_.to(DEV)).cpu()
+        want = ref_sel.distances(nodes, nn_)
+        # entry (b, cur_b) contains a zero self-distance: torch.cdist's matmul formulation
+        # (|a|^2+|b|^2-2ab, used above 25 rows) cancels there with ~1e-3 absolute error, the
+        # kernel's direct sum does not.  That entry is never thresholded (distance.py:31-33).
+        self_entry = torch.zeros(B, N, dtype=torch.bool)
+        self_entry[torch.arange(B), nn_] = True
+        torch.testing.assert_close(d[~self_entry], want[~self_entry], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(d[self_entry], want[self_entry], rtol=1e-3, atol=2e-3)
+
+
+# --------------------------------------------------------------------------
+# known answers ported from the reference's unit tests
+# --------------------------------------------------------------------------
+def _identity_gcm(sel, feats=11, N=10):
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(feats, feats), "x, adj -> x"),
+                                                torch.nn.ReLU()])
+    return DenseGCM(g.to(DEV), edge_selectors=sel, graph_size=N)
+
+
+def test_temporal_known_answers():
+    """tests/test_gcm.py:581-617."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    B, feats, N = 5, 11, 10
+    s = _identity_gcm(TemporalBackedge([1]))
+    hidden = None
+    for _ in range(2):
+        _, hidden = s(torch.ones(B, feats, device=DEV), hidden)
+    want = torch.zeros(B, N, N)
+    want[:, 1, 0] = 1
+    assert torch.equal(hidden[1].cpu(), want)
+    s = _identity_gcm(TemporalBackedge([4]))
+    hidden = None
+    for _ in range(10):
+        _, hidden = s(torch.ones(B, feats, device=DEV), hidden)
+    want = torch.zeros(B, N, N)
+    for i in range(4, 10):
+        want[:, i, i - 4] = 1
+    assert torch.equal(hidden[1].cpu(), want)
+
+
+def test_distance_known_answers():
+    """tests/test_gcm.py:708-729 - zero distance => edge [b,1,0]; distance sqrt(11) > 1 => none."""
+    from gcm.edge_selectors.distance import EuclideanEdge
+    B, feats, N = 5, 11, 10
+    s = _identity_gcm(EuclideanEdge(max_distance=1))
+    hidden = None
+    for _ in range(2):
+        _, hidden = s(torch.ones(B, feats, device=DEV), hidden)
+    want = torch.zeros(B, N, N)
+    want[:, 1, 0] = 1
+    assert torch.equal(hidden[1].cpu(), want)
+    s = _identity_gcm(EuclideanEdge(max_distance=1))
+    _, hidden = s(torch.zeros(B, feats, device=DEV), None)
+    _, hidden = s(torch.ones(B, feats, device=DEV), hidden)
+    assert torch.equal(hidden[1].cpu(), torch.zeros(B, N, N))
+
+
+def test_dense_edge_known_answer():
+    """tests/test_gcm.py:784-801."""
+    from gcm.edge_selectors.dense import DenseEdge
+    B, feats, N = 5, 11, 10
+    s = _identity_gcm(DenseEdge())
+    hidden = None
+    for _ in range(2):
+        _, hidden = s(torch.ones(B, feats, device=DEV), hidden)
+    want = torch.zeros(B, N, N)
+    want[:, 0, 0] = want[:, 1, 1] = want[:, 0, 1] = want[:, 1, 0] = 1
+    assert torch.equal(hidden[1].cpu(), want)
+
+
+def test_chained_selectors():
+    """tests/test_gcm.py:646-682 - two selectors chained through Sequential."""
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    B, feats, N = 3, 4, 6
+    sel = G.Sequential("x, adj, weights, num_nodes, B", [
+        (TemporalBackedge([1]), "x, adj, weights, num_nodes, B -> adj, weights"),
+        (TemporalBackedge([2]), "x, adj, weights, num_nodes, B -> adj, weights")])
+    g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(feats, feats), "x, adj -> x")])
+    s = DenseGCM(g.to(DEV), edge_selectors=sel, graph_size=N)
+    hidden = None
+    for _ in range(4):
+        _, hidden = s(torch.ones(B, feats, device=DEV), hidden)
+    want = torch.zeros(B, N, N)
+    for i in range(1, 4):
+        want[:, i, i - 1] = 1
+    for i in range(2, 4):
+        want[:, i, i - 2] = 1
+    assert torch.equal(hidden[1].cpu(), want)
+
+
+def test_nonfinite_is_reported():
+    """gcm.py:316-318 - same AssertionError text, raised at the step in sync mode."""
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(4, 4), "x, adj -> x")])
+    s = DenseGCM(g.to(DEV), graph_size=4, finite_check="sync")
+    with pytest.raises(AssertionError, match="Got NaN in returned memory"):
+        s(torch.full((2, 4), float("nan"), device=DEV), None)
+    s = DenseGCM(g.to(DEV), graph_size=4, finite_check="deferred")
+    s(torch.full((2, 4), float("inf"), device=DEV), None)
+    with pytest.raises(AssertionError, match="Got NaN in returned memory"):
+        s.check_flags()
