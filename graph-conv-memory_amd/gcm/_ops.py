@@ -12,6 +12,39 @@ from . import _hip
 _f32 = torch.float32
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py uses it
+    for the roofline figures).  Disabled (None) in normal operation: zero overhead."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def launch(self, name, fn, *args):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        self.spans.setdefault(name, []).append((a, b))
+        return rc
+
+    def summary(self):
+        """name -> (launches, mean ms).  Call after a device synchronize."""
+        out = {}
+        for name, spans in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in spans]
+            out[name] = (len(ms), sum(ms) / len(ms))
+        return out
+
+
+TIMER = None
+
+
+def _call(name, *args):
+    fn = getattr(_hip.lib(), name)
+    rc = TIMER.launch(name, fn, *args) if TIMER is not None else fn(*args)
+    _hip.check(rc, name)
+
+
 def _empty_like(t):
     return torch.empty_like(t, memory_format=torch.contiguous_format)
 
@@ -31,12 +64,11 @@ class _StateAdvance(torch.autograd.Function):
         weights_out = _empty_like(weights)
         cur = torch.empty_like(num_nodes)
         nn_out = torch.empty_like(num_nodes)
-        rc = _hip.lib().gcm_state_advance_fwd(
-            _hip.ptr(nodes), _hip.ptr(adj), _hip.ptr(weights) if has_w else None,
+        _call(
+            "gcm_state_advance_fwd", _hip.ptr(nodes), _hip.ptr(adj), _hip.ptr(weights) if has_w else None,
             _hip.ptr(num_nodes), _hip.ptr(x), _hip.ptr(nodes_out), _hip.ptr(adj_out),
             _hip.ptr(weights_out) if has_w else None, _hip.ptr(cur), _hip.ptr(nn_out),
             _hip.ptr(flags), B, N, F, _hip.stream())
-        _hip.check(rc, "gcm_state_advance_fwd")
         ctx.save_for_backward(num_nodes)
         ctx.shape = (B, N, F)
         ctx.has_w = has_w
@@ -139,10 +171,9 @@ class _DenseGraphConv(torch.autograd.Function):
         out = torch.empty(B, N, Fo, device=x.device, dtype=_f32)
         need_bwd = any(ctx.needs_input_grad)
         agg = torch.empty(B, N, Fi, device=x.device, dtype=_f32) if need_bwd else None
-        rc = _hip.lib().gcm_dense_graphconv_fwd(
-            _hip.ptr(x), _hip.ptr(adj), _hip.ptr(w_rel), _hip.ptr(b_rel), _hip.ptr(w_root),
+        _call(
+            "gcm_dense_graphconv_fwd", _hip.ptr(x), _hip.ptr(adj), _hip.ptr(w_rel), _hip.ptr(b_rel), _hip.ptr(w_root),
             _hip.ptr(out), _hip.ptr(agg), B, N, Fi, Fo, act, _hip.stream())
-        _hip.check(rc, "gcm_dense_graphconv_fwd")
         ctx.save_for_backward(x, adj, w_rel, w_root, out, agg)
         ctx.act = act
         ctx.has_bias = b_rel is not None
@@ -165,12 +196,11 @@ class _DenseGraphConv(torch.autograd.Function):
         g_b = torch.empty(Fo, device=dev, dtype=_f32) if need_b else None
         ws_bytes = lib.gcm_dense_graphconv_bwd_workspace_bytes(B, N, Fi, Fo)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        rc = lib.gcm_dense_graphconv_bwd(
-            _hip.ptr(g_out), _hip.ptr(out), _hip.ptr(x), _hip.ptr(adj), _hip.ptr(agg),
+        _call(
+            "gcm_dense_graphconv_bwd", _hip.ptr(g_out), _hip.ptr(out), _hip.ptr(x), _hip.ptr(adj), _hip.ptr(agg),
             _hip.ptr(w_rel), _hip.ptr(w_root), _hip.ptr(g_x), _hip.ptr(g_adj), _hip.ptr(g_wrel),
             _hip.ptr(g_b), _hip.ptr(g_wroot), _hip.ptr(ws), ws_bytes, B, N, Fi, Fo, ctx.act,
             _hip.stream())
-        _hip.check(rc, "gcm_dense_graphconv_bwd")
         return g_x, g_adj, g_wrel, g_b, g_wroot, None
 
 
