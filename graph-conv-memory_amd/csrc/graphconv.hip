@@ -75,8 +75,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_graphconv_fwd(
   float* sX = sAdj + RB * (KT + 1);         // [KT][FiP]
   float* sAgg = sX + KT * FiP;              // [RB][FiP+1]
   float* sXr = sAgg + RB * (FiP + 1);       // [RB][FiP+1]
-  float* sWrel = sXr + RB * (FiP + 1);      // [FiP][33]   (w_rel^T tile: [k][n])
-  float* sWroot = sWrel + FiP * 33;         // [FiP][33]
+  float* sW = sXr + RB * (FiP + 1);         // [FiP][33]   one w^T tile ([k][n]) at a time: rel, then root
 
   // ---- phase A: agg = adj[rows, :] @ x -------------------------------------
   f32x16 acc[NCT];
@@ -110,14 +109,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_graphconv_fwd(
   // ---- phase B: out = agg @ w_rel^T + x @ w_root^T + b ---------------------
   for (int o0 = 0; o0 < Fo; o0 += 32) {
     __syncthreads();
-    stage_t(sWrel, 33, w_rel, Fi, o0, 0, 32, FiP, Fo, Fi);
-    stage_t(sWroot, 33, w_root, Fi, o0, 0, 32, FiP, Fo, Fi);
+    stage_t(sW, 33, w_rel, Fi, o0, 0, 32, FiP, Fo, Fi);
     __syncthreads();
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    mma32(o, sAgg + wave * 32 * (FiP + 1), FiP + 1, 1, sWrel, 33, 1, FiP, li, lh);
-    mma32(o, sXr + wave * 32 * (FiP + 1), FiP + 1, 1, sWroot, 33, 1, FiP, li, lh);
+    mma32(o, sAgg + wave * 32 * (FiP + 1), FiP + 1, 1, sW, 33, 1, FiP, li, lh);
+    __syncthreads();
+    stage_t(sW, 33, w_root, Fi, o0, 0, 32, FiP, Fo, Fi);
+    __syncthreads();
+    mma32(o, sXr + wave * 32 * (FiP + 1), FiP + 1, 1, sW, 33, 1, FiP, li, lh);
     const int col = o0 + li;
     const float bias = (b_rel && col < Fo) ? b_rel[col] : 0.f;
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_graphconv_fwd(
 
 size_t fwd_lds_bytes(int waves, int FiP) {
   const int RB = 32 * waves;
-  return sizeof(float) * ((size_t)RB * (KT + 1) + KT * FiP + 2 * RB * (FiP + 1) + 2 * FiP * 33);
+  return sizeof(float) * ((size_t)RB * (KT + 1) + KT * FiP + 2 * RB * (FiP + 1) + FiP * 33);
 }
 
 template <int WAVES>
@@ -365,6 +366,118 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, int n_slabs, int
   }
 }
 
+
+// ===========================================================================
+// GraphConv over CSR (sparse path).  The neighbour reduction is a gather of whole
+// feature rows (coalesced 4*Fi-byte reads, L2-served for temporal graphs) into an LDS
+// tile; the two linears then run on the matrix cores exactly like the dense layer.
+// ===========================================================================
+template <int NCT>
+__global__ __launch_bounds__(256) void k_csr_graphconv_fwd(
+    const float* __restrict__ x, const int64_t* __restrict__ row_ptr,
+    const int64_t* __restrict__ col, const float* __restrict__ w,
+    const uint8_t* __restrict__ mask, const float* __restrict__ w_rel,
+    const float* __restrict__ b_rel, const float* __restrict__ w_root, float* __restrict__ out,
+    float* __restrict__ agg_out, int64_t M, int Fi, int Fo, int act) {
+  constexpr int RB = 128;
+  constexpr int FiP = 32 * NCT;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+
+  extern __shared__ float smem[];
+  float* sAgg = smem;                     // [RB][FiP+1]
+  float* sXr = sAgg + RB * (FiP + 1);     // [RB][FiP+1]
+  float* sW = sXr + RB * (FiP + 1);       // [FiP][33]  one weight tile at a time (rel, then root)
+
+  for (int idx = threadIdx.x; idx < RB * FiP; idx += 256) {
+    const int r = idx / FiP, f = idx - r * FiP;
+    const int64_t row = r0 + r;
+    float a = 0.f, xv = 0.f;
+    if (row < M && f < Fi && (!mask || mask[row])) {
+      xv = x[(size_t)row * Fi + f];
+      const int64_t e1 = row_ptr[row + 1];
+      for (int64_t e = row_ptr[row]; e < e1; ++e) {
+        const int64_t c = col[e];
+        if (mask && !mask[c]) continue;
+        const float m = x[(size_t)c * Fi + f];
+        // mul then add, separately rounded: same arithmetic as msg = x_j * w; index_add
+        a = __fadd_rn(a, w ? __fmul_rn(w[e], m) : m);
+      }
+      if (agg_out) agg_out[(size_t)row * Fi + f] = a;
+    } else if (row < M && f < Fi && agg_out) {
+      agg_out[(size_t)row * Fi + f] = 0.f;
+    }
+    sAgg[r * (FiP + 1) + f] = a;
+    sXr[r * (FiP + 1) + f] = xv;
+  }
+
+  for (int o0 = 0; o0 < Fo; o0 += 32) {
+    __syncthreads();
+    stage_t(sW, 33, w_rel, Fi, o0, 0, 32, FiP, Fo, Fi);
+    __syncthreads();
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    mma32(o, sAgg + wave * 32 * (FiP + 1), FiP + 1, 1, sW, 33, 1, FiP, li, lh);
+    __syncthreads();
+    stage_t(sW, 33, w_root, Fi, o0, 0, 32, FiP, Fo, Fi);
+    __syncthreads();
+    mma32(o, sXr + wave * 32 * (FiP + 1), FiP + 1, 1, sW, 33, 1, FiP, li, lh);
+    const int c = o0 + li;
+    const float bias = (b_rel && c < Fo) ? b_rel[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = r0 + wave * 32 + acc_row(r, lh);
+      if (row < M && c < Fo) {
+        const bool live = !mask || mask[row];
+        out[(size_t)row * Fo + c] = live ? gcm_act(o[r] + bias, act) : 0.f;
+      }
+    }
+  }
+}
+
+size_t csr_fwd_lds_bytes(int FiP) {
+  return sizeof(float) * ((size_t)2 * 128 * (FiP + 1) + FiP * 33);
+}
+
+// transpose aggregation through the CSC view:  g_x[j] += sum_{k in col j} w * dAgg[rows[k]]
+__global__ void k_csr_scatter_T(const float* __restrict__ dagg, const int64_t* __restrict__ col_ptr,
+                                const int64_t* __restrict__ rows, const int64_t* __restrict__ perm,
+                                const float* __restrict__ w, const uint8_t* __restrict__ mask,
+                                float* __restrict__ g_x, int64_t M, int Fi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * Fi) return;
+  const int64_t j = i / Fi;
+  const int f = i - j * Fi;
+  if (mask && !mask[j]) return;
+  float a = g_x[i];
+  const int64_t k1 = col_ptr[j + 1];
+  for (int64_t k = col_ptr[j]; k < k1; ++k) {
+    const int64_t d = rows[k];
+    if (mask && !mask[d]) continue;
+    const float wv = w ? w[perm[k]] : 1.f;
+    a = fmaf(wv, dagg[(size_t)d * Fi + f], a);
+  }
+  g_x[i] = a;
+}
+
+// edge-weight gradient: g_w[e] = < x[src(e)], dAgg[dst(e)] >
+__global__ void k_csr_edge_grad(const float* __restrict__ x, const float* __restrict__ dagg,
+                                const int64_t* __restrict__ col_ptr,
+                                const int64_t* __restrict__ rows, const int64_t* __restrict__ perm,
+                                const uint8_t* __restrict__ mask, float* __restrict__ g_w,
+                                int64_t M, int Fi) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  for (int64_t k = col_ptr[j]; k < col_ptr[j + 1]; ++k) {
+    const int64_t d = rows[k];
+    float s = 0.f;
+    if (!mask || (mask[j] && mask[d]))
+      for (int f = 0; f < Fi; ++f) s = fmaf(x[(size_t)j * Fi + f], dagg[(size_t)d * Fi + f], s);
+    g_w[perm[k]] = s;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -475,4 +588,114 @@ extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, con
     rc = gcm_launch_status();
   }
   return rc;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: GraphConv over CSR
+// ---------------------------------------------------------------------------
+extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, const int64_t* col,
+                                     const float* w, const uint8_t* mask, const float* w_rel,
+                                     const float* b_rel, const float* w_root, float* out,
+                                     float* agg, int64_t M, int Fi, int Fo, int act,
+                                     gcm_stream_t stream) {
+  GCM_REQUIRE(row_ptr && w_rel && w_root && M >= 0 && Fi > 0 && Fo > 0);
+  if (M == 0) return GCM_OK;
+  GCM_REQUIRE(x && out);
+  if (Fi > 128 || Fo > 128 || M > (int64_t)2147483647 - 256) return GCM_EUNSUPPORTED;
+  const int FiP = round32(Fi);
+  const size_t lds = csr_fwd_lds_bytes(FiP);
+  dim3 grid((unsigned)((M + 127) / 128));
+  hipStream_t s = (hipStream_t)stream;
+#define GCM_CSR_FWD(NCT)                                                                        \
+  {                                                                                             \
+    auto kern = k_csr_graphconv_fwd<NCT>;                                                       \
+    if (lds > 64 * 1024)                                                                        \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds);                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, row_ptr, col, w, mask, w_rel, b_rel,   \
+                       w_root, out, agg, M, Fi, Fo, act);                                       \
+  }
+  switch (FiP / 32) {
+    case 1: GCM_CSR_FWD(1) break;
+    case 2: GCM_CSR_FWD(2) break;
+    case 3: GCM_CSR_FWD(3) break;
+    default: GCM_CSR_FWD(4) break;
+  }
+#undef GCM_CSR_FWD
+  return gcm_launch_status();
+}
+
+extern "C" size_t gcm_csr_graphconv_bwd_workspace_bytes(int64_t M, int Fi, int Fo) {
+  if (M <= 0 || Fi <= 0 || Fo <= 0 || M > (int64_t)2147483647 - 256) return 0;
+  BwdPlan p = bwd_plan(1, (int)M, Fi, Fo);
+  return p.dagg_bytes + p.slabs_bytes;
+}
+
+extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const float* x,
+                                     const float* agg, const int64_t* row_ptr, const int64_t* col,
+                                     const int64_t* col_ptr, const int64_t* rows,
+                                     const int64_t* perm, const float* w, const uint8_t* mask,
+                                     const float* w_rel, const float* w_root, float* g_x,
+                                     float* g_w, float* g_w_rel, float* g_b_rel, float* g_w_root,
+                                     void* workspace, size_t workspace_bytes, int64_t M, int64_t E,
+                                     int Fi, int Fo, int act, gcm_stream_t stream) {
+  (void)row_ptr;
+  (void)col;
+  GCM_REQUIRE(g_out && out && x && agg && w_rel && w_root && workspace);
+  GCM_REQUIRE(M > 0 && E >= 0 && Fi > 0 && Fo > 0);
+  GCM_REQUIRE((col_ptr && rows) || E == 0 || (!g_x && !g_w));
+  GCM_REQUIRE(!w || perm);
+  if (Fi > 128 || Fo > 128 || M > (int64_t)2147483647 - 256) return GCM_EUNSUPPORTED;
+  BwdPlan p = bwd_plan(1, (int)M, Fi, Fo);
+  if (!p.waves) return GCM_EUNSUPPORTED;
+  if (workspace_bytes < p.dagg_bytes + p.slabs_bytes) return GCM_EWORKSPACE;
+  float* ws_dagg = (float*)workspace;
+  float* slabs = (float*)((char*)workspace + p.dagg_bytes);
+  const int FiP = round32(Fi), FoP = round32(Fo), nct = FiP / 32;
+  const int want_w = (g_w_rel || g_w_root || g_b_rel) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(p.nblk, 1);
+  const size_t lds1 = bwd_rows_lds_bytes(p.waves, FiP, FoP);
+  const int N = (int)M;
+  float* no_adj = nullptr;
+#define GCM_CSR_BWD(W, C)                                                                       \
+  {                                                                                             \
+    auto k1 = k_graphconv_bwd_rows<W, C>;                                                       \
+    if (lds1 > 64 * 1024)                                                                       \
+      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)lds1);                                                     \
+    hipLaunchKernelGGL(k1, grid, dim3(64 * W), lds1, s, g_out, out, x, agg, w_rel, w_root, g_x, \
+                       no_adj, ws_dagg, slabs, N, Fi, Fo, act, want_w);                         \
+  }
+#define GCM_CSR_BWD_W(W)                           \
+  switch (nct) {                                   \
+    case 1: GCM_CSR_BWD(W, 1) break;               \
+    case 2: GCM_CSR_BWD(W, 2) break;               \
+    case 3: GCM_CSR_BWD(W, 3) break;               \
+    default: GCM_CSR_BWD(W, 4) break;              \
+  }
+  switch (p.waves) {
+    case 4: GCM_CSR_BWD_W(4) break;
+    case 2: GCM_CSR_BWD_W(2) break;
+    default: GCM_CSR_BWD_W(1) break;
+  }
+#undef GCM_CSR_BWD_W
+#undef GCM_CSR_BWD
+  int rc = gcm_launch_status();
+  if (rc != GCM_OK) return rc;
+  if (g_x && E > 0) {
+    const int64_t total = M * Fi;
+    hipLaunchKernelGGL(k_csr_scatter_T, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       ws_dagg, col_ptr, rows, perm, w, mask, g_x, M, Fi);
+  }
+  if (g_w && E > 0) {
+    hipLaunchKernelGGL(k_csr_edge_grad, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, x,
+                       ws_dagg, col_ptr, rows, perm, mask, g_w, M, Fi);
+  }
+  if (want_w) {
+    const int slab_len = (int)p.slab_len;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 63) / 64), dim3(256), 0, s, slabs, p.nblk,
+                       slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
+  }
+  return gcm_launch_status();
 }

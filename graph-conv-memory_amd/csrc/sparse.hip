@@ -1,0 +1,459 @@
+// SparseGCM packing / index kernels (src/gcm/sparse_gcm.py:72-212 and the util.py helpers
+// it calls).  Everything here is HBM-bound index and row movement: the per-graph Python
+// loops of the reference (util.py:181-187,202-207,222-230,442-451; temporal.py:35-36)
+// become closed-form kernels over (graph, node) / (graph, edge) with coalesced row copies.
+#include "gcm_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// plan: exclusive prefix sums over B (one workgroup; B is at most a few thousand)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sparse_plan(const int64_t* __restrict__ T,
+                                                     const int64_t* __restrict__ taus,
+                                                     int64_t* __restrict__ node_off,
+                                                     int64_t* __restrict__ new_off,
+                                                     int64_t* __restrict__ totals, int B) {
+  __shared__ int64_t sA[256], sB[256], sMaxA[256], sMaxB[256];
+  const int tid = threadIdx.x;
+  const int per = (B + 255) / 256;
+  const int lo = min(B, tid * per), hi = min(B, lo + per);
+  int64_t a = 0, c = 0, ma = 0, mc = 0;
+  for (int b = lo; b < hi; ++b) {
+    const int64_t n = T[b] + taus[b];
+    a += n;
+    c += taus[b];
+    ma = n > ma ? n : ma;
+    mc = taus[b] > mc ? taus[b] : mc;
+  }
+  sA[tid] = a; sB[tid] = c; sMaxA[tid] = ma; sMaxB[tid] = mc;
+  __syncthreads();
+  if (tid == 0) {  // 256-element serial scan: negligible
+    int64_t ra = 0, rc = 0, xa = 0, xc = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int64_t ta = sA[i], tc = sB[i];
+      sA[i] = ra; sB[i] = rc;
+      ra += ta; rc += tc;
+      xa = sMaxA[i] > xa ? sMaxA[i] : xa;
+      xc = sMaxB[i] > xc ? sMaxB[i] : xc;
+    }
+    node_off[B] = ra; new_off[B] = rc;
+    totals[0] = ra; totals[1] = rc; totals[2] = xa; totals[3] = xc;
+  }
+  __syncthreads();
+  a = sA[tid]; c = sB[tid];
+  for (int b = lo; b < hi; ++b) {
+    node_off[b] = a; new_off[b] = c;
+    a += T[b] + taus[b];
+    c += taus[b];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// insert new observations into the node matrix (sparse_gcm.py:116-128) + adjoint
+// ---------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_sparse_insert(
+    const float* __restrict__ src, const float* __restrict__ x, const int64_t* __restrict__ T,
+    const int64_t* __restrict__ taus, float* __restrict__ dst, float* __restrict__ g_x,
+    uint32_t* __restrict__ flags, int N, int F, int t_pad, int rows_per_block) {
+  const int b = blockIdx.y;
+  const int64_t t0 = T[b];
+  int64_t tau = taus[b];
+  if (!BWD && blockIdx.x == 0 && threadIdx.x == 0 && (t0 < 0 || tau < 0 || t0 + tau > N))
+    atomicOr(flags, GCM_FLAG_SPARSE_OVERFLOW);
+  if (tau < 0) tau = 0;
+  if (tau > t_pad) tau = t_pad;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+  const int total = (r1 - r0) * F;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = r0 + e / F, f = e % F;
+    const int64_t k = r - t0;
+    const bool fresh = k >= 0 && k < tau;
+    const size_t at = ((size_t)b * N + r) * F + f;
+    if (!BWD) {
+      dst[at] = fresh ? x[((size_t)b * t_pad + k) * F + f] : src[at];
+    } else {
+      dst[at] = fresh ? 0.f : src[at];
+    }
+  }
+  if (BWD && g_x) {  // g_x[b, k] = g_nodes_out[b, T+k] for k < tau, else 0 (only for rows in range)
+    const int k0 = blockIdx.x * rows_per_block, k1 = min(t_pad, k0 + rows_per_block);
+    const int tot = max(0, k1 - k0) * F;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+      const int k = k0 + e / F, f = e % F;
+      const int64_t r = t0 + k;
+      const bool ok = k < tau && r >= 0 && r < N;
+      g_x[((size_t)b * t_pad + k) * F + f] = ok ? src[((size_t)b * N + r) * F + f] : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TemporalEdge closed form (sparse_edge_selectors/temporal.py:18-63)
+// ---------------------------------------------------------------------------
+struct Hops16 {
+  int32_t h[16];
+};
+
+// edges of new node t (absolute index): hops h with t - h >= 0, and t > 0
+__device__ __forceinline__ int temporal_degree(int64_t t, const Hops16& hops, int n_hops) {
+  if (t <= 0) return 0;
+  int d = 0;
+  for (int i = 0; i < n_hops; ++i) d += (hops.h[i] >= 0 && t - hops.h[i] >= 0) ? 1 : 0;
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_temporal_count(const int64_t* __restrict__ T,
+                                                        const int64_t* __restrict__ taus,
+                                                        Hops16 hops, int n_hops,
+                                                        int64_t* __restrict__ edge_off, int B) {
+  // one workgroup: per-graph counts (closed loop over tau), then a serial scan by thread 0
+  extern __shared__ int64_t cnt[];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int64_t c = 0;
+    const int64_t t0 = T[b], tau = taus[b];
+    for (int64_t k = 0; k < tau; ++k) c += temporal_degree(t0 + k, hops, n_hops);
+    cnt[b] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int b = 0; b < B; ++b) {
+      edge_off[b] = run;
+      run += cnt[b];
+    }
+    edge_off[B] = run;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_temporal_fill(const int64_t* __restrict__ T,
+                                                       const int64_t* __restrict__ taus,
+                                                       Hops16 hops, int n_hops,
+                                                       const int64_t* __restrict__ edge_off,
+                                                       int64_t* __restrict__ indices, int64_t E) {
+  // one workgroup per graph; thread k walks new node T+k.  Position inside the graph =
+  // sum of degrees of earlier new nodes; degrees are < n_hops only for the first max(hops)
+  // nodes of an episode, so the prefix is closed form after a short serial head.
+  const int b = blockIdx.x;
+  const int64_t t0 = T[b], tau = taus[b];
+  const int64_t base = edge_off[b];
+  for (int64_t k = threadIdx.x; k < tau; k += blockDim.x) {
+    // prefix: sum_{k'<k} degree(t0+k')
+    int64_t pos = 0;
+    for (int i = 0; i < n_hops; ++i) {
+      const int64_t h = hops.h[i];
+      if (h < 0) continue;
+      // nodes t in [t0, t0+k) with t >= max(h, 1)
+      const int64_t first = (h > 1 ? h : 1) > t0 ? (h > 1 ? h : 1) : t0;
+      const int64_t n = t0 + k - first;
+      pos += n > 0 ? n : 0;
+    }
+    const int64_t t = t0 + k;
+    if (t <= 0) continue;
+    int64_t w = base + pos;
+    for (int i = 0; i < n_hops; ++i) {  // hops descending -> sources ascending
+      const int64_t h = hops.h[i];
+      if (h < 0 || t - h < 0) continue;
+      if (w < E) {
+        indices[w] = b;
+        indices[E + w] = t;
+        indices[2 * E + w] = t - h;
+      }
+      ++w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// flatten nodes (util.py:426-452) + adjoint
+// ---------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_flatten(const float* __restrict__ src,
+                                                 const int64_t* __restrict__ T,
+                                                 const int64_t* __restrict__ taus,
+                                                 const int64_t* __restrict__ node_off,
+                                                 float* __restrict__ dst, int N, int F, int64_t M,
+                                                 int rows_per_block) {
+  const int b = blockIdx.y;
+  int64_t live = T[b] + taus[b];
+  live = live < 0 ? 0 : (live > N ? N : live);
+  const int64_t off = node_off[b];
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+  const int total = (r1 - r0) * F;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = r0 + e / F, f = e % F;
+    const bool ok = r < live && off + r < M;
+    if (!BWD) {
+      if (ok) dst[(size_t)(off + r) * F + f] = src[((size_t)b * N + r) * F + f];
+    } else {
+      dst[((size_t)b * N + r) * F + f] = ok ? src[(size_t)(off + r) * F + f] : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// COO (batch, sink, source) -> flat (source, sink) edge list + CSR row_ptr by destination
+// ---------------------------------------------------------------------------
+__global__ void k_edges_flat(const int64_t* __restrict__ coo, const int64_t* __restrict__ node_off,
+                             int64_t* __restrict__ edge_index, uint32_t* __restrict__ flags,
+                             int64_t E, int B) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (e < E) {
+    int64_t b = coo[e];
+    b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+    const int64_t sink = coo[E + e], src = coo[2 * E + e];
+    const int64_t off = node_off[b];
+    edge_index[e] = src + off;
+    edge_index[E + e] = sink + off;
+    bad = !(src < sink);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, GCM_FLAG_ACAUSAL);
+}
+
+__global__ void k_ptr_from_sorted(const int64_t* __restrict__ keys, int64_t* __restrict__ ptr,
+                                  int64_t E, int64_t M) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > M) return;
+  int64_t lo = 0, hi = E;  // first position with key >= r
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  ptr[r] = lo;
+}
+
+// ---------------------------------------------------------------------------
+// k-hop mask (sparse_gcm.py:192-198)
+// ---------------------------------------------------------------------------
+__global__ void k_khop_seed(const int64_t* __restrict__ node_off, const int64_t* __restrict__ T,
+                            const int64_t* __restrict__ taus, uint8_t* __restrict__ mask,
+                            uint8_t* __restrict__ frontier, int64_t M, int t_max) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= t_max || k >= taus[b]) return;
+  const int64_t i = node_off[b] + T[b] + k;
+  if (i >= 0 && i < M) {
+    mask[i] = 1;
+    frontier[i] = 1;
+  }
+}
+
+// one BFS round against the edges: every source of a frontier row joins mask and next
+__global__ void k_khop_round(const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ col,
+                             const uint8_t* __restrict__ frontier, uint8_t* __restrict__ next,
+                             uint8_t* __restrict__ mask, int64_t M) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M || !frontier[i]) return;
+  for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+    const int64_t s = col[e];
+    if (s >= 0 && s < M) {
+      next[s] = 1;
+      mask[s] = 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// output rows (sparse_gcm.py:176-208) + adjoint
+// ---------------------------------------------------------------------------
+__global__ void k_extract_fwd(const float* __restrict__ feats, const int64_t* __restrict__ T,
+                              const int64_t* __restrict__ taus,
+                              const int64_t* __restrict__ node_off, float* __restrict__ out,
+                              uint32_t* __restrict__ flags, int B, int t_pad, int H, int64_t M) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool nonfinite = false;
+  if (i < (int64_t)B * t_pad * H) {
+    const int f = i % H;
+    const int k = (i / H) % t_pad;
+    const int b = i / ((int64_t)H * t_pad);
+    float v = 0.f;
+    const int64_t row = node_off[b] + T[b] + k;
+    if (k < taus[b] && row >= 0 && row < M) {
+      v = feats[(size_t)row * H + f];
+      nonfinite = !isfinite(v);
+    }
+    out[i] = v;
+  }
+  if (__any(nonfinite) && (threadIdx.x & 63) == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+}
+
+__global__ void k_extract_bwd(const float* __restrict__ g_out, const int64_t* __restrict__ T,
+                              const int64_t* __restrict__ taus,
+                              const int64_t* __restrict__ node_off, float* __restrict__ g_feats,
+                              int B, int t_pad, int H, int64_t M) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * t_pad * H) return;
+  const int f = i % H;
+  const int k = (i / H) % t_pad;
+  const int b = i / ((int64_t)H * t_pad);
+  const int64_t row = node_off[b] + T[b] + k;
+  if (k < taus[b] && row >= 0 && row < M) g_feats[(size_t)row * H + f] = g_out[i];
+}
+
+Hops16 pack_hops(const int32_t* hops_host, int n_hops) {
+  Hops16 h;
+  for (int i = 0; i < 16; ++i) h.h[i] = i < n_hops ? hops_host[i] : -1;
+  return h;
+}
+
+}  // namespace
+
+extern "C" int gcm_sparse_plan(const int64_t* T, const int64_t* taus, int64_t* node_off,
+                               int64_t* new_off, int64_t* totals, int B, gcm_stream_t stream) {
+  GCM_REQUIRE(T && taus && node_off && new_off && totals && B > 0);
+  hipLaunchKernelGGL(k_sparse_plan, dim3(1), dim3(256), 0, (hipStream_t)stream, T, taus, node_off,
+                     new_off, totals, B);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_insert_fwd(const float* nodes_in, const float* x, const int64_t* T,
+                                     const int64_t* taus, float* nodes_out, uint32_t* flags, int B,
+                                     int N, int F, int t_pad, gcm_stream_t stream) {
+  GCM_REQUIRE(nodes_in && x && T && taus && nodes_out && flags);
+  GCM_REQUIRE(B > 0 && N > 0 && F > 0 && t_pad > 0);
+  if (B > 65535) return GCM_EUNSUPPORTED;
+  const int rpb = 32;
+  hipLaunchKernelGGL(k_sparse_insert<false>, dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                     (hipStream_t)stream, nodes_in, x, T, taus, nodes_out, (float*)nullptr, flags,
+                     N, F, t_pad, rpb);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_insert_bwd(const float* g_nodes_out, const int64_t* T,
+                                     const int64_t* taus, float* g_nodes_in, float* g_x, int B,
+                                     int N, int F, int t_pad, gcm_stream_t stream) {
+  GCM_REQUIRE(g_nodes_out && T && taus && g_nodes_in);
+  GCM_REQUIRE(B > 0 && N > 0 && F > 0 && t_pad > 0);
+  if (B > 65535) return GCM_EUNSUPPORTED;
+  const int rpb = 32;
+  const int blocks = (max(N, t_pad) + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_sparse_insert<true>, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream,
+                     g_nodes_out, (const float*)nullptr, T, taus, g_nodes_in, g_x,
+                     (uint32_t*)nullptr, N, F, t_pad, rpb);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_temporal_count(const int64_t* T, const int64_t* taus,
+                                         const int32_t* hops_host, int n_hops, int64_t* edge_off,
+                                         int B, gcm_stream_t stream) {
+  GCM_REQUIRE(T && taus && hops_host && edge_off && B > 0 && n_hops > 0);
+  if (n_hops > 16 || (size_t)B * sizeof(int64_t) > 64 * 1024) return GCM_EUNSUPPORTED;
+  for (int i = 1; i < n_hops; ++i) GCM_REQUIRE(hops_host[i] < hops_host[i - 1]);
+  hipLaunchKernelGGL(k_temporal_count, dim3(1), dim3(256), (size_t)B * sizeof(int64_t),
+                     (hipStream_t)stream, T, taus, pack_hops(hops_host, n_hops), n_hops, edge_off,
+                     B);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_temporal_fill(const int64_t* T, const int64_t* taus,
+                                        const int32_t* hops_host, int n_hops,
+                                        const int64_t* edge_off, int64_t* indices, int64_t E,
+                                        int B, gcm_stream_t stream) {
+  GCM_REQUIRE(T && taus && hops_host && edge_off && B > 0 && n_hops > 0 && E >= 0);
+  if (n_hops > 16) return GCM_EUNSUPPORTED;
+  if (E == 0) return GCM_OK;
+  GCM_REQUIRE(indices);
+  hipLaunchKernelGGL(k_temporal_fill, dim3(B), dim3(256), 0, (hipStream_t)stream, T, taus,
+                     pack_hops(hops_host, n_hops), n_hops, edge_off, indices, E);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_flatten_fwd(const float* nodes, const int64_t* T, const int64_t* taus,
+                                      const int64_t* node_off, float* flat, int B, int N, int F,
+                                      int64_t M, gcm_stream_t stream) {
+  GCM_REQUIRE(nodes && T && taus && node_off && B > 0 && N > 0 && F > 0 && M >= 0);
+  if (B > 65535) return GCM_EUNSUPPORTED;
+  if (M == 0) return GCM_OK;
+  GCM_REQUIRE(flat);
+  const int rpb = 32;
+  hipLaunchKernelGGL(k_flatten<false>, dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                     (hipStream_t)stream, nodes, T, taus, node_off, flat, N, F, M, rpb);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_flatten_bwd(const float* g_flat, const int64_t* T, const int64_t* taus,
+                                      const int64_t* node_off, float* g_nodes, int B, int N, int F,
+                                      int64_t M, gcm_stream_t stream) {
+  GCM_REQUIRE(T && taus && node_off && g_nodes && B > 0 && N > 0 && F > 0 && M >= 0);
+  GCM_REQUIRE(g_flat || M == 0);
+  if (B > 65535) return GCM_EUNSUPPORTED;
+  const int rpb = 32;
+  hipLaunchKernelGGL(k_flatten<true>, dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                     (hipStream_t)stream, g_flat, T, taus, node_off, g_nodes, N, F, M, rpb);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_ptr_from_sorted(const int64_t* keys, int64_t* ptr, int64_t E, int64_t M,
+                                   gcm_stream_t stream) {
+  GCM_REQUIRE(ptr && E >= 0 && M >= 0 && (keys || E == 0));
+  hipLaunchKernelGGL(k_ptr_from_sorted, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, keys, ptr, E, M);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_edges_to_csr(const int64_t* coo, const int64_t* node_off,
+                                       int64_t* edge_index, int64_t* row_ptr, uint32_t* flags,
+                                       int64_t E, int64_t M, int B, gcm_stream_t stream) {
+  GCM_REQUIRE(node_off && row_ptr && flags && E >= 0 && M >= 0 && B > 0);
+  GCM_REQUIRE((coo && edge_index) || E == 0);
+  if (E > 0) {
+    hipLaunchKernelGGL(k_edges_flat, dim3((unsigned)((E + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, coo, node_off, edge_index, flags, E, B);
+  }
+  // sinks ascend in (batch, sink, source) order once the per-graph offsets are added
+  return gcm_ptr_from_sorted(edge_index ? edge_index + E : nullptr, row_ptr, E, M, stream);
+}
+
+extern "C" int gcm_khop_mask(const int64_t* row_ptr, const int64_t* col, const int64_t* node_off,
+                             const int64_t* T, const int64_t* taus, int hops, uint8_t* mask,
+                             uint8_t* scratch, int64_t M, int B, int t_pad, gcm_stream_t stream) {
+  GCM_REQUIRE(row_ptr && node_off && T && taus && mask && scratch && M > 0 && B > 0 && hops >= 0);
+  GCM_REQUIRE(t_pad > 0 && (col || hops == 0));
+  if (B > 65535) return GCM_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t* fr[2] = {scratch, scratch + M};
+  hipError_t e = hipMemsetAsync(mask, 0, (size_t)M, s);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(scratch, 0, 2 * (size_t)M, s);
+  if (e != hipSuccess) return (int)e;
+  const int t_cap = t_pad;
+  hipLaunchKernelGGL(k_khop_seed, dim3((unsigned)((t_cap + 127) / 128), B), dim3(128), 0, s,
+                     node_off, T, taus, mask, fr[0], M, (int)t_cap);
+  for (int h = 0; h < hops; ++h) {
+    hipLaunchKernelGGL(k_khop_round, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, row_ptr,
+                       col, fr[h & 1], fr[(h + 1) & 1], mask, M);
+    if (h + 1 < hops) {
+      e = hipMemsetAsync(fr[h & 1], 0, (size_t)M, s);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_extract_fwd(const float* feats, const int64_t* T, const int64_t* taus,
+                                      const int64_t* node_off, float* out, uint32_t* flags, int B,
+                                      int t_pad, int H, int64_t M, gcm_stream_t stream) {
+  GCM_REQUIRE(T && taus && node_off && out && flags && B > 0 && t_pad > 0 && H > 0 && M >= 0);
+  GCM_REQUIRE(feats || M == 0);
+  const int64_t total = (int64_t)B * t_pad * H;
+  hipLaunchKernelGGL(k_extract_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, feats, T, taus, node_off, out, flags, B, t_pad, H, M);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_extract_bwd(const float* g_out, const int64_t* T, const int64_t* taus,
+                                      const int64_t* node_off, float* g_feats, int B, int t_pad,
+                                      int H, int64_t M, gcm_stream_t stream) {
+  GCM_REQUIRE(g_out && T && taus && node_off && B > 0 && t_pad > 0 && H > 0 && M >= 0);
+  if (M == 0) return GCM_OK;
+  GCM_REQUIRE(g_feats);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(g_feats, 0, (size_t)M * H * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)B * t_pad * H;
+  hipLaunchKernelGGL(k_extract_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_out,
+                     T, taus, node_off, g_feats, B, t_pad, H, M);
+  return gcm_launch_status();
+}

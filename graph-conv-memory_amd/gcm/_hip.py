@@ -17,8 +17,10 @@ ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 DIR = {"forward": 1, "backward": 2, "both": 3}
 DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
 FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
+FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL = 8, 16
 
-_P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
+                     ctypes.c_int64)
 
 # name -> (restype, argtypes).  Kept in one table so tests can check that every
 # symbol declared in include/gcm_hip.h is exported and bound.
@@ -36,6 +38,21 @@ PROTOTYPES = {
     "gcm_dense_graphconv_fwd": (_I, [_P] * 7 + [_I] * 5 + [_P]),
     "gcm_dense_graphconv_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "gcm_dense_graphconv_bwd": (_I, [_P] * 13 + [_Z] + [_I] * 5 + [_P]),
+    "gcm_sparse_plan": (_I, [_P] * 5 + [_I, _P]),
+    "gcm_sparse_insert_fwd": (_I, [_P] * 6 + [_I] * 4 + [_P]),
+    "gcm_sparse_insert_bwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "gcm_sparse_temporal_count": (_I, [_P, _P, _P, _I, _P, _I, _P]),
+    "gcm_sparse_temporal_fill": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _P]),
+    "gcm_sparse_flatten_fwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
+    "gcm_sparse_flatten_bwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
+    "gcm_sparse_edges_to_csr": (_I, [_P] * 5 + [_L, _L, _I, _P]),
+    "gcm_ptr_from_sorted": (_I, [_P, _P, _L, _L, _P]),
+    "gcm_khop_mask": (_I, [_P] * 5 + [_I, _P, _P, _L, _I, _I, _P]),
+    "gcm_sparse_extract_fwd": (_I, [_P] * 6 + [_I, _I, _I, _L, _P]),
+    "gcm_sparse_extract_bwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
+    "gcm_csr_graphconv_fwd": (_I, [_P] * 10 + [_L, _I, _I, _I, _P]),
+    "gcm_csr_graphconv_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
+    "gcm_csr_graphconv_bwd": (_I, [_P] * 19 + [_Z, _L, _L, _I, _I, _I, _P]),
 }
 
 

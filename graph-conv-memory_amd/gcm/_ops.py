@@ -244,3 +244,249 @@ def edge_distance_(nodes, adj, cur, mode, max_distance, dist_param=None, a=(0, 0
                                _hip.stream())
     _hip.check(rc, "gcm_edge_distance")
     return adj, dist
+
+
+# ===========================================================================
+# sparse path (sparse_gcm.py:72-212)
+# ===========================================================================
+_i64 = torch.int64
+
+
+def _hops_arg(hops):
+    return (ctypes.c_int32 * len(hops))(*hops)
+
+
+def sparse_plan(T, taus):
+    """-> node_off [B+1], new_off [B+1], totals [4] (all device int64); no host sync."""
+    _hip.on_device(T, taus)
+    B = T.numel()
+    node_off = torch.empty(B + 1, dtype=_i64, device=T.device)
+    new_off = torch.empty(B + 1, dtype=_i64, device=T.device)
+    totals = torch.empty(4, dtype=_i64, device=T.device)
+    _call("gcm_sparse_plan", _hip.ptr(T), _hip.ptr(taus), _hip.ptr(node_off), _hip.ptr(new_off),
+          _hip.ptr(totals), B, _hip.stream())
+    return node_off, new_off, totals
+
+
+class _SparseInsert(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nodes, x, T, taus, flags):
+        nodes, x = nodes.contiguous(), x.contiguous()
+        _hip.on_device(nodes, x, T, taus, flags)
+        B, N, F = nodes.shape
+        t_pad = x.shape[1]
+        out = torch.empty_like(nodes)
+        _call("gcm_sparse_insert_fwd", _hip.ptr(nodes), _hip.ptr(x), _hip.ptr(T), _hip.ptr(taus),
+              _hip.ptr(out), _hip.ptr(flags), B, N, F, t_pad, _hip.stream())
+        ctx.save_for_backward(T, taus)
+        ctx.dims = (B, N, F, t_pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        T, taus = ctx.saved_tensors
+        B, N, F, t_pad = ctx.dims
+        g_out = g_out.contiguous()
+        g_nodes = torch.empty_like(g_out)
+        g_x = torch.empty(B, t_pad, F, device=g_out.device, dtype=_f32)
+        _call("gcm_sparse_insert_bwd", _hip.ptr(g_out), _hip.ptr(T), _hip.ptr(taus),
+              _hip.ptr(g_nodes), _hip.ptr(g_x), B, N, F, t_pad, _hip.stream())
+        return g_nodes, g_x, None, None, None
+
+
+def sparse_insert(nodes, x, T, taus, flags):
+    return _SparseInsert.apply(nodes, x, T, taus, flags)
+
+
+def sparse_temporal_edges(T, taus, hops_desc):
+    """COO indices [3, E] (batch, sink, source) of the TemporalEdge selector, already in
+    coalesced order.  One host sync (E)."""
+    _hip.on_device(T, taus)
+    B = T.numel()
+    edge_off = torch.empty(B + 1, dtype=_i64, device=T.device)
+    arr = _hops_arg(hops_desc)
+    _call("gcm_sparse_temporal_count", _hip.ptr(T), _hip.ptr(taus), ctypes.addressof(arr),
+          len(hops_desc), _hip.ptr(edge_off), B, _hip.stream())
+    E = int(edge_off[B].item())
+    idx = torch.empty(3, E, dtype=_i64, device=T.device)
+    _call("gcm_sparse_temporal_fill", _hip.ptr(T), _hip.ptr(taus), ctypes.addressof(arr),
+          len(hops_desc), _hip.ptr(edge_off), _hip.ptr(idx), E, B, _hip.stream())
+    return idx
+
+
+class _SparseFlatten(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nodes, T, taus, node_off, M):
+        nodes = nodes.contiguous()
+        _hip.on_device(nodes, T, taus, node_off)
+        B, N, F = nodes.shape
+        flat = torch.empty(M, F, device=nodes.device, dtype=_f32)
+        _call("gcm_sparse_flatten_fwd", _hip.ptr(nodes), _hip.ptr(T), _hip.ptr(taus),
+              _hip.ptr(node_off), _hip.ptr(flat), B, N, F, M, _hip.stream())
+        ctx.save_for_backward(T, taus, node_off)
+        ctx.dims = (B, N, F, M)
+        return flat
+
+    @staticmethod
+    def backward(ctx, g_flat):
+        T, taus, node_off = ctx.saved_tensors
+        B, N, F, M = ctx.dims
+        g_flat = g_flat.contiguous()
+        g_nodes = torch.empty(B, N, F, device=g_flat.device, dtype=_f32)
+        _call("gcm_sparse_flatten_bwd", _hip.ptr(g_flat), _hip.ptr(T), _hip.ptr(taus),
+              _hip.ptr(node_off), _hip.ptr(g_nodes), B, N, F, M, _hip.stream())
+        return g_nodes, None, None, None, None
+
+
+def sparse_flatten(nodes, T, taus, node_off, M):
+    return _SparseFlatten.apply(nodes, T, taus, node_off, M)
+
+
+def ptr_from_sorted(keys, M):
+    keys = keys.contiguous()
+    ptr = torch.empty(M + 1, dtype=_i64, device=keys.device)
+    _call("gcm_ptr_from_sorted", _hip.ptr(keys), _hip.ptr(ptr), keys.numel(), M, _hip.stream())
+    return ptr
+
+
+class GraphIndex:
+    """Device-resident index of one flat edge list: CSR by destination (forward gather) and,
+    built lazily, CSC by source (backward gather).  Attached to the edge_index tensor handed
+    to the GNN (attribute `gcm_graph`) so GraphConv layers share it."""
+
+    def __init__(self, edge_index, row_ptr, M, csr_perm=None, mask=None):
+        self.edge_index = edge_index            # [2, E] (source, sink); CSR order unless csr_perm
+        self.csr_perm = csr_perm                # positions of the CSR entries in edge_index
+        self.row_ptr, self.M, self.mask = row_ptr, M, mask
+        src = edge_index[0] if csr_perm is None else edge_index[0][csr_perm]
+        self.col = src.contiguous()
+        self._csc = None
+
+    @property
+    def E(self):
+        return self.col.numel()
+
+    def dst_csr(self):
+        d = self.edge_index[1] if self.csr_perm is None else self.edge_index[1][self.csr_perm]
+        return d.contiguous()
+
+    def csc(self):
+        """(col_ptr [M+1], rows [E], perm [E]): entry k of the CSC is CSR entry perm[k]."""
+        if self._csc is None:
+            src_sorted, perm = torch.sort(self.col, stable=True)
+            rows = self.dst_csr()[perm].contiguous()
+            self._csc = (ptr_from_sorted(src_sorted, self.M), rows, perm.contiguous())
+        return self._csc
+
+    @staticmethod
+    def from_edge_index(edge_index, M):
+        """Generic entry: any [2, E] (source, sink) list -> CSR by destination."""
+        dst_sorted, perm = torch.sort(edge_index[1], stable=True)
+        return GraphIndex(edge_index, ptr_from_sorted(dst_sorted, M), M, csr_perm=perm)
+
+
+def sparse_edges_to_csr(coo, node_off, M, B, flags):
+    """coo [3,E] sorted (batch, sink, source) -> (edge_index [2,E] (source, sink), GraphIndex)."""
+    coo = coo.contiguous()
+    _hip.on_device(coo, node_off, flags)
+    E = coo.shape[1]
+    edge_index = torch.empty(2, E, dtype=_i64, device=coo.device)
+    row_ptr = torch.empty(M + 1, dtype=_i64, device=coo.device)
+    _call("gcm_sparse_edges_to_csr", _hip.ptr(coo), _hip.ptr(node_off), _hip.ptr(edge_index),
+          _hip.ptr(row_ptr), _hip.ptr(flags), E, M, B, _hip.stream())
+    return edge_index, GraphIndex(edge_index, row_ptr, M)
+
+
+def khop_mask(graph, node_off, T, taus, hops, B, t_pad):
+    M = graph.M
+    mask = torch.empty(M, dtype=torch.uint8, device=graph.row_ptr.device)
+    scratch = torch.empty(2 * M, dtype=torch.uint8, device=mask.device)
+    _call("gcm_khop_mask", _hip.ptr(graph.row_ptr), _hip.ptr(graph.col), _hip.ptr(node_off),
+          _hip.ptr(T), _hip.ptr(taus), hops, _hip.ptr(mask), _hip.ptr(scratch), M, B, t_pad,
+          _hip.stream())
+    return mask
+
+
+class _SparseExtract(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, T, taus, node_off, B, t_pad, flags):
+        feats = feats.contiguous()
+        M, H = feats.shape
+        out = torch.empty(B, t_pad, H, device=feats.device, dtype=_f32)
+        _call("gcm_sparse_extract_fwd", _hip.ptr(feats), _hip.ptr(T), _hip.ptr(taus),
+              _hip.ptr(node_off), _hip.ptr(out), _hip.ptr(flags), B, t_pad, H, M, _hip.stream())
+        ctx.save_for_backward(T, taus, node_off)
+        ctx.dims = (B, t_pad, H, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        T, taus, node_off = ctx.saved_tensors
+        B, t_pad, H, M = ctx.dims
+        g_out = g_out.contiguous()
+        g_feats = torch.empty(M, H, device=g_out.device, dtype=_f32)
+        _call("gcm_sparse_extract_bwd", _hip.ptr(g_out), _hip.ptr(T), _hip.ptr(taus),
+              _hip.ptr(node_off), _hip.ptr(g_feats), B, t_pad, H, M, _hip.stream())
+        return g_feats, None, None, None, None, None, None
+
+
+def sparse_extract(feats, T, taus, node_off, B, t_pad, flags):
+    return _SparseExtract.apply(feats, T, taus, node_off, B, t_pad, flags)
+
+
+class _CsrGraphConv(torch.autograd.Function):
+    """x [M,Fi]; w_edge [E] in CSR order or None."""
+
+    @staticmethod
+    def forward(ctx, x, w_edge, w_rel, b_rel, w_root, graph, act):
+        x = x.contiguous()
+        w_rel, w_root = w_rel.contiguous(), w_root.contiguous()
+        b_rel = None if b_rel is None else b_rel.contiguous()
+        w_edge = None if w_edge is None else w_edge.contiguous()
+        _hip.on_device(x, w_edge, w_rel, b_rel, w_root)
+        M, Fi = x.shape
+        Fo = w_rel.shape[0]
+        assert M == graph.M
+        out = torch.empty(M, Fo, device=x.device, dtype=_f32)
+        need_bwd = any(ctx.needs_input_grad)
+        agg = torch.empty(M, Fi, device=x.device, dtype=_f32) if need_bwd else None
+        _call("gcm_csr_graphconv_fwd", _hip.ptr(x), _hip.ptr(graph.row_ptr), _hip.ptr(graph.col),
+              _hip.ptr(w_edge), _hip.ptr(graph.mask), _hip.ptr(w_rel), _hip.ptr(b_rel),
+              _hip.ptr(w_root), _hip.ptr(out), _hip.ptr(agg), M, Fi, Fo, act, _hip.stream())
+        ctx.save_for_backward(x, w_edge, w_rel, w_root, out, agg)
+        ctx.graph, ctx.act, ctx.has_bias = graph, act, b_rel is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, w_edge, w_rel, w_root, out, agg = ctx.saved_tensors
+        graph = ctx.graph
+        M, Fi = x.shape
+        Fo = w_rel.shape[0]
+        need_x, need_we, need_wrel, need_b, need_wroot, _, _ = ctx.needs_input_grad
+        need_b = need_b and ctx.has_bias
+        need_we = need_we and w_edge is not None
+        g_out = g_out.contiguous()
+        dev = x.device
+        lib = _hip.lib()
+        E = graph.E
+        col_ptr = rows = perm = None
+        if (need_x or need_we) and E > 0:
+            col_ptr, rows, perm = graph.csc()
+        g_x = torch.empty_like(x) if need_x else None
+        g_we = torch.zeros_like(w_edge) if need_we else None
+        g_wrel = torch.empty_like(w_rel) if need_wrel else None
+        g_wroot = torch.empty_like(w_root) if need_wroot else None
+        g_b = torch.empty(Fo, device=dev, dtype=_f32) if need_b else None
+        ws_bytes = lib.gcm_csr_graphconv_bwd_workspace_bytes(M, Fi, Fo)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _call("gcm_csr_graphconv_bwd", _hip.ptr(g_out), _hip.ptr(out), _hip.ptr(x), _hip.ptr(agg),
+              _hip.ptr(graph.row_ptr), _hip.ptr(graph.col), _hip.ptr(col_ptr), _hip.ptr(rows),
+              _hip.ptr(perm), _hip.ptr(w_edge), _hip.ptr(graph.mask), _hip.ptr(w_rel),
+              _hip.ptr(w_root), _hip.ptr(g_x), _hip.ptr(g_we), _hip.ptr(g_wrel), _hip.ptr(g_b),
+              _hip.ptr(g_wroot), _hip.ptr(ws), ws_bytes, M, E, Fi, Fo, ctx.act, _hip.stream())
+        return g_x, g_we, g_wrel, g_b, g_wroot, None, None
+
+
+def csr_graphconv(x, w_edge, w_rel, b_rel, w_root, graph, act=_hip.ACT_NONE):
+    return _CsrGraphConv.apply(x, w_edge, w_rel, b_rel, w_root, graph, act)

@@ -47,6 +47,41 @@ class DenseGraphConv(torch.nn.Module):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
 
 
+class GraphConv(torch.nn.Module):
+    """out[i] = lin_rel(sum_{(j->i)} w_ji * x_j) + lin_root(x_i);  edge_index [2,E] = (source,
+    sink), x [M,F].  The neighbour reduction is a CSR gather fused with the two linears on
+    the matrix cores (csrc/graphconv.hip, k_csr_graphconv_fwd).  When SparseGCM built the
+    edge list it attaches a ready CSR (`edge_index.gcm_graph`); any other edge_index is
+    indexed here on the device."""
+
+    def __init__(self, in_channels, out_channels, aggr="add", bias=True):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' (the reference's usage) is implemented")
+        self.in_channels, self.out_channels, self.aggr = in_channels, out_channels, aggr
+        self.lin_rel = torch.nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin_root = torch.nn.Linear(in_channels, out_channels, bias=False)
+
+    def reset_parameters(self):
+        self.lin_rel.reset_parameters()
+        self.lin_root.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight=None, _act=_hip.ACT_NONE):
+        graph = getattr(edge_index, "gcm_graph", None)
+        if graph is None or graph.M != x.shape[0]:
+            graph = _ops.GraphIndex.from_edge_index(edge_index, x.shape[0])
+        w = edge_weight
+        if w is not None and w.numel() != graph.E:
+            w = None                      # PyG: a weight vector of the wrong length is ignored
+        if w is not None and graph.csr_perm is not None:
+            w = w[graph.csr_perm]
+        return _ops.csr_graphconv(x, w, self.lin_rel.weight, self.lin_rel.bias,
+                                  self.lin_root.weight, graph, _act)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
+
+
 class Sequential(torch.nn.Module):
     """Stand-in for torch_geometric.nn.Sequential: a chain of modules wired by
     name, e.g. Sequential("x, adj, weights, B, N", [(conv, "x, adj -> x"), Tanh()]).
@@ -82,7 +117,7 @@ class Sequential(torch.nn.Module):
             name, ins, outs = plan[i]
             mod = getattr(self, name)
             fused = None
-            if isinstance(mod, DenseGraphConv) and len(ins) == 2 and i + 1 < len(plan):
+            if isinstance(mod, (DenseGraphConv, GraphConv)) and i + 1 < len(plan):
                 nxt_name, nxt_in, nxt_out = plan[i + 1]
                 nxt = getattr(self, nxt_name)
                 if type(nxt) in _FUSABLE and nxt_in == outs and nxt_out == outs:

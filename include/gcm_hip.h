@@ -125,6 +125,97 @@ int gcm_dense_graphconv_bwd(const float* g_out, const float* out, const float* x
                             void* workspace, size_t workspace_bytes, int B, int N, int Fi, int Fo,
                             int act, gcm_stream_t stream);
 
+/* ---- SparseGCM (src/gcm/sparse_gcm.py:72-212) -------------------------------- */
+
+/* bits OR-ed into `flags` by the sparse kernels */
+#define GCM_FLAG_SPARSE_OVERFLOW 8u  /* T_b + tau_b > N  (sparse_gcm.py:120-121)   */
+#define GCM_FLAG_ACAUSAL 16u         /* an edge with source >= sink (sparse_gcm.py:171) */
+
+/* Per-call plan, replaces the Python loops over B of util.py:176-240:
+ *   node_off[b]  = sum_{b'<b} (T+taus)[b']   (flat node offsets, util.get_batch_offsets), [B+1]
+ *   new_off[b]   = sum_{b'<b} taus[b']       (offsets of the new nodes in output order), [B+1]
+ *   totals[0] = node_off[B], totals[1] = new_off[B], totals[2] = max_b (T+taus)[b],
+ *   totals[3] = max_b taus[b]                                                      */
+int gcm_sparse_plan(const int64_t* T, const int64_t* taus, int64_t* node_off, int64_t* new_off,
+                    int64_t* totals, int B, gcm_stream_t stream);
+
+/* sparse_gcm.py:116-128: nodes_out = nodes_in with x[b, k, :] written to row T[b]+k for
+ * k < taus[b] (x is [B, t_pad, F], zero padded).  ORs GCM_FLAG_SPARSE_OVERFLOW. */
+int gcm_sparse_insert_fwd(const float* nodes_in, const float* x, const int64_t* T,
+                          const int64_t* taus, float* nodes_out, uint32_t* flags, int B, int N,
+                          int F, int t_pad, gcm_stream_t stream);
+int gcm_sparse_insert_bwd(const float* g_nodes_out, const int64_t* T, const int64_t* taus,
+                          float* g_nodes_in, float* g_x, int B, int N, int F, int t_pad,
+                          gcm_stream_t stream);
+
+/* sparse_edge_selectors/temporal.py:18-63, closed form.  hops_host: HOST array, must be
+ * sorted DESCENDING and unique (so that sources ascend inside a sink: coalesced order).
+ * count: edge_off[b] = number of edges of graphs < b, [B+1].
+ * fill : indices [3, E] rows (batch, sink, source), E = edge_off[B]. */
+int gcm_sparse_temporal_count(const int64_t* T, const int64_t* taus, const int32_t* hops_host,
+                              int n_hops, int64_t* edge_off, int B, gcm_stream_t stream);
+int gcm_sparse_temporal_fill(const int64_t* T, const int64_t* taus, const int32_t* hops_host,
+                             int n_hops, const int64_t* edge_off, int64_t* indices, int64_t E,
+                             int B, gcm_stream_t stream);
+
+/* util.flatten_nodes util.py:426-452: flat[node_off[b] + i] = nodes[b, i] for i < (T+taus)[b]. */
+int gcm_sparse_flatten_fwd(const float* nodes, const int64_t* T, const int64_t* taus,
+                           const int64_t* node_off, float* flat, int B, int N, int F, int64_t M,
+                           gcm_stream_t stream);
+int gcm_sparse_flatten_bwd(const float* g_flat, const int64_t* T, const int64_t* taus,
+                           const int64_t* node_off, float* g_nodes, int B, int N, int F, int64_t M,
+                           gcm_stream_t stream);
+
+/* util.flatten_adj util.py:287-304 + flip (sparse_gcm.py:167-171): coo [3,E] (batch, sink,
+ * source), sorted by (batch, sink, source) -> edge_index [2,E] = (source, sink) + node_off[b]
+ * and CSR-by-destination row_ptr [M+1].  ORs GCM_FLAG_ACAUSAL when source >= sink. */
+int gcm_sparse_edges_to_csr(const int64_t* coo, const int64_t* node_off, int64_t* edge_index,
+                            int64_t* row_ptr, uint32_t* flags, int64_t E, int64_t M, int B,
+                            gcm_stream_t stream);
+/* generic: ptr[r] = first position in sorted keys[0..E) with key >= r, r in [0, M]. */
+int gcm_ptr_from_sorted(const int64_t* keys, int64_t* ptr, int64_t E, int64_t M,
+                        gcm_stream_t stream);
+
+/* torch_geometric.utils.k_hop_subgraph (sparse_gcm.py:192-198) without relabelling:
+ * mask[i] = 1 for every node within `hops` steps AGAINST the edges from a new node.
+ * row_ptr/col: CSR by destination (col = source).  mask is [M] bytes, overwritten;
+ * scratch is 2*M bytes; t_pad >= max(taus) (the padded time length of x). */
+int gcm_khop_mask(const int64_t* row_ptr, const int64_t* col, const int64_t* node_off,
+                  const int64_t* T, const int64_t* taus, int hops, uint8_t* mask, uint8_t* scratch,
+                  int64_t M, int B, int t_pad, gcm_stream_t stream);
+
+/* sparse_gcm.py:176-208: out[b, k, :] = feats[node_off[b] + T[b] + k, :] for k < taus[b],
+ * zero elsewhere; ORs GCM_FLAG_NONFINITE. */
+int gcm_sparse_extract_fwd(const float* feats, const int64_t* T, const int64_t* taus,
+                           const int64_t* node_off, float* out, uint32_t* flags, int B, int t_pad,
+                           int H, int64_t M, gcm_stream_t stream);
+int gcm_sparse_extract_bwd(const float* g_out, const int64_t* T, const int64_t* taus,
+                           const int64_t* node_off, float* g_feats, int B, int t_pad, int H,
+                           int64_t M, gcm_stream_t stream);
+
+/* ---- GraphConv over CSR (PyG GraphConv; call sites ray_sparse_gcm.py:37-39) ------ */
+
+/* out[i] = act( (sum_{e in row i} w[e] * x[col[e]]) @ w_rel^T + b_rel + x[i] @ w_root^T ).
+ * x [M,Fi]; row_ptr [M+1], col [E] = CSR by destination; w [E] or NULL (=1);
+ * mask [M] bytes or NULL: rows with mask 0 are skipped (out = 0) and so are edges whose
+ * source has mask 0 (= the conv restricted to the k-hop subgraph).  agg (may be NULL)
+ * receives the aggregated neighbours [M,Fi] for the backward pass. */
+int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, const int64_t* col,
+                          const float* w, const uint8_t* mask, const float* w_rel,
+                          const float* b_rel, const float* w_root, float* out, float* agg,
+                          int64_t M, int Fi, int Fo, int act, gcm_stream_t stream);
+
+/* Backward.  col_ptr/rows/perm: the same edges as CSC by source (perm[k] = position of CSC
+ * entry k in the CSR edge order, for w and g_w).  Outputs may be NULL to skip. */
+size_t gcm_csr_graphconv_bwd_workspace_bytes(int64_t M, int Fi, int Fo);
+int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const float* x, const float* agg,
+                          const int64_t* row_ptr, const int64_t* col, const int64_t* col_ptr,
+                          const int64_t* rows, const int64_t* perm, const float* w,
+                          const uint8_t* mask, const float* w_rel, const float* w_root, float* g_x,
+                          float* g_w, float* g_w_rel, float* g_b_rel, float* g_w_root,
+                          void* workspace, size_t workspace_bytes, int64_t M, int64_t E, int Fi,
+                          int Fo, int act, gcm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

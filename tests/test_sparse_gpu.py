@@ -1,0 +1,207 @@
+"""Parity of the HIP SparseGCM path against the CPU oracle and the reference's golden
+vectors.  Needs an MI355X."""
+import pytest
+import torch
+
+from _golden import Fixture
+from oracle import pyg, sparse as osp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev_sparse_gnn(ref, F, H, act, layers=2):
+    from gcm import nn as G
+    mods, cin = [], F
+    for _ in range(layers):
+        mods.append((G.GraphConv(cin, H), "x, edges, weights -> x"))
+        if act is not None:
+            mods.append(act())
+        cin = H
+    g = G.Sequential("x, edges, weights", mods)
+    g.load_state_dict(ref.state_dict())
+    return g.to(DEV)
+
+
+@pytest.mark.parametrize("M,E,Fi,Fo,act,weighted", [
+    (5, 0, 3, 3, None, False), (40, 90, 8, 16, "tanh", True), (300, 1500, 32, 32, "tanh", False),
+    (1000, 4000, 33, 70, "relu", True), (129, 700, 128, 128, "tanh", True),
+])
+def test_csr_graphconv_kernel(M, E, Fi, Fo, act, weighted):
+    """Generic edge_index (unsorted, duplicates allowed) through gcm.nn.GraphConv."""
+    from gcm import nn as G
+    torch.manual_seed(M + E)
+    ref = pyg.GraphConv(Fi, Fo)
+    dev = G.GraphConv(Fi, Fo)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.to(DEV)
+    x = torch.randn(M, Fi)
+    ei = torch.randint(0, M, (2, E))
+    w = torch.rand(E) if weighted else None
+    acts = {"tanh": torch.tanh, "relu": torch.relu, None: lambda t: t}
+    code = {"tanh": 1, "relu": 2, None: 0}[act]
+    xc = x.clone().requires_grad_(True)
+    wc = w.clone().requires_grad_(True) if weighted else None
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True) if weighted else None
+    yc = acts[act](ref(xc, ei, wc))
+    yd = dev(xd, ei.to(DEV), wd, _act=code)
+    torch.testing.assert_close(yd.cpu(), yc, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(yc)
+    yc.backward(g)
+    yd.backward(g.to(DEV))
+    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
+    if weighted and E:
+        torch.testing.assert_close(wd.grad.cpu(), wc.grad, rtol=1e-4, atol=1e-4)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
+        scale = float(pc.grad.abs().max()) + 1e-6
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
+
+
+def test_temporal_edge_matches_oracle():
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    T = torch.tensor([0, 3, 0, 10, 1, 0])
+    taus = torch.tensor([5, 2, 0, 7, 1, 1])
+    for hops in ([1], [1, 2], [4], [3, 1], [2, 7, 1]):
+        want = osp.TemporalEdge(hops)(None, T, taus, 6).coalesce()
+        got = TemporalEdge(hops)(None, T.to(DEV), taus.to(DEV), 6)
+        assert got.is_coalesced()
+        assert torch.equal(got.indices().cpu(), want.indices()), hops
+        assert torch.equal(got.values().cpu(), want.values())
+        assert tuple(got.shape) == tuple(want.shape)
+
+
+def test_khop_mask_matches_k_hop_subgraph():
+    from gcm import _ops
+    torch.manual_seed(1)
+    B = 4
+    T = torch.tensor([6, 0, 9, 3])
+    taus = torch.tensor([2, 4, 1, 3])
+    tot = T + taus
+    off = torch.cat([torch.zeros(1, dtype=torch.long), tot.cumsum(0)])
+    M = int(off[-1])
+    coo = osp.TemporalEdge([1, 3])(None, torch.zeros(B, dtype=torch.long), tot, B).coalesce().indices()
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    edges, graph = _ops.sparse_edges_to_csr(coo.to(DEV), off.to(DEV), M, B, flags)
+    out_idx = torch.cat([torch.arange(off[b] + T[b], off[b] + tot[b]) for b in range(B)])
+    ref_edges = torch.stack([coo[2] + off[coo[0]], coo[1] + off[coo[0]]])
+    assert torch.equal(edges.cpu(), ref_edges)
+    for hops in (0, 1, 2, 3):
+        mask = _ops.khop_mask(graph, off.to(DEV), T.to(DEV), taus.to(DEV), hops, B, 4).cpu().bool()
+        subset, _, _, _ = pyg.k_hop_subgraph(out_idx, hops, ref_edges, relabel_nodes=True, num_nodes=M)
+        want = torch.zeros(M, dtype=torch.bool)
+        want[subset] = True
+        assert torch.equal(mask, want), hops
+    assert int(flags.item()) == 0
+
+
+SPARSE = ["g8_sparse_oneshot", "g8_sparse_oneshot_2hop", "g8_sparse_stepwise",
+          "g8_sparse_ragged", "g8_sparse_ragged_2hop"]
+
+
+@pytest.mark.parametrize("name", SPARSE)
+def test_sparse_rollout_matches_reference(name):
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    fx = Fixture(name)
+    m = fx.meta
+    act = torch.nn.Tanh if m["act"] else None
+    ref = osp.canonical_gnn(m["F"], m["H"], act=act)
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_sparse_gnn(ref, m["F"], m["H"], act)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge(m["hops"]), graph_size=m["N"], max_hops=m["max_hops"])
+    obs = fx["obs"].to(DEV).requires_grad_(True)
+    B = m["B"]
+    hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
+    for taus in fx["taus"]:
+        t = int(taus.max())
+        rows = [torch.cat([obs[b, pos[b]: pos[b] + taus[b]],
+                           torch.zeros(t - int(taus[b]), m["F"], device=DEV)]) for b in range(B)]
+        x = torch.stack(rows)
+        out, hidden = mem(x, taus.to(DEV), hidden)
+        outs.append(out)
+        pos = pos + taus
+    loss = sum(o.sum() for o in outs) / sum(o.numel() for o in outs)
+    loss.backward()
+    for i, o in enumerate(outs):
+        torch.testing.assert_close(o.cpu(), fx[f"out{i}"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])
+    assert torch.equal(hidden[1].coalesce().indices().cpu(), fx["hT_adj_indices"])   # bit exact
+    assert torch.equal(hidden[1].coalesce().values().cpu(), fx["hT_adj_values"])
+    assert torch.equal(hidden[2].cpu(), fx["hT_T"])
+    gs = float(fx["grad_obs"].abs().max())
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=k)
+
+
+def test_dense_equals_sparse():
+    """tests/test_sparse_gcm.py:395-429 - same weights, TemporalBackedge([1,2]) vs
+    TemporalEdge([1,2]): equal node matrices, equal edge sets, equal outputs."""
+    from gcm.gcm import DenseGCM
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    F, B, ts = 3, 3, 8
+    torch.manual_seed(0)
+    dense_g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(F, F), "x, adj -> x"),
+                                                      (G.DenseGraphConv(F, F), "x, adj -> x")])
+    sparse_g = G.Sequential("x, edges, weights", [(G.GraphConv(F, F), "x, edges, weights -> x"),
+                                                   (G.GraphConv(F, F), "x, edges, weights -> x")])
+    sparse_g.load_state_dict(dense_g.state_dict())
+    dense = DenseGCM(dense_g.to(DEV), edge_selectors=TemporalBackedge([1, 2]), graph_size=8)
+    obs = torch.arange(B * ts * F, dtype=torch.float32).reshape(B, ts, F).to(DEV)
+    dh, douts = None, []
+    for i in range(ts):
+        o, dh = dense(obs[:, i], dh)
+        douts.append(o)
+    douts = torch.stack(douts, dim=1)
+    taus = torch.full((B,), ts, dtype=torch.long, device=DEV)
+    for max_hops in (None, 2):
+        sparse = SparseGCM(sparse_g.to(DEV), edge_selectors=TemporalEdge([1, 2]), graph_size=8,
+                           max_hops=max_hops)
+        souts, sh = sparse(obs, taus, None)
+        assert torch.equal(dh[0], sh[0])
+        assert torch.equal(dh[1].nonzero().T, sh[1].coalesce().indices())
+        torch.testing.assert_close(souts, douts, rtol=1e-6, atol=1e-3)   # values reach ~1e4 here
+
+
+def test_sparse_overflow_raises():
+    """sparse_gcm.py:120-121."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(2, 2), "x, edges, weights -> x")]).to(DEV)
+    mem = SparseGCM(g, graph_size=4)
+    with pytest.raises(Exception, match="Overflow"):
+        mem(torch.zeros(2, 5, 2, device=DEV), torch.tensor([5, 1], device=DEV), None)
+
+
+def test_user_gnn_gets_plain_tensors():
+    """Plugin API #2 (sparse): an arbitrary GNN sees (flat_nodes [M,F], edge_index [2,E]
+    (source, sink), weights [E]) and max_hops hands it the relabelled subgraph."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    torch.manual_seed(0)
+    ref = pyg.GraphConv(4, 4)
+
+    class UserGNN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inner = pyg.GraphConv(4, 4)
+            self.inner.load_state_dict(ref.state_dict())
+        def forward(self, x, edge_index, w):
+            assert x.dim() == 2 and edge_index.shape[0] == 2 and w.shape[0] == edge_index.shape[1]
+            assert bool((edge_index[0] < edge_index[1]).all())
+            return self.inner(x, edge_index, w)
+
+    x = torch.rand(3, 6, 4)
+    taus = torch.tensor([6, 4, 5])
+    want, _ = osp.sparse_step(x, taus, None, lambda a, b, c: ref(a, b, c), graph_size=8,
+                              edge_selectors=osp.TemporalEdge([1, 2]))
+    for max_hops in (None, 1):
+        mem = SparseGCM(UserGNN().to(DEV), edge_selectors=TemporalEdge([1, 2]), graph_size=8,
+                        max_hops=max_hops)
+        got, _ = mem(x.to(DEV), taus.to(DEV), None)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6)
