@@ -53,6 +53,10 @@ PROTOTYPES = {
     "gcm_csr_graphconv_fwd": (_I, [_P] * 10 + [_L, _I, _I, _I, _P]),
     "gcm_csr_graphconv_bwd_workspace_bytes": (_Z, [_L, _I, _I]),
     "gcm_csr_graphconv_bwd": (_I, [_P] * 19 + [_Z, _L, _L, _I, _I, _I, _P]),
+    "gcm_learned_pairs_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "gcm_learned_pairs_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "gcm_learned_select_fwd": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
+    "gcm_learned_select_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
 }
 
 

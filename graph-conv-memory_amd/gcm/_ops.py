@@ -490,3 +490,67 @@ class _CsrGraphConv(torch.autograd.Function):
 
 def csr_graphconv(x, w_edge, w_rel, b_rel, w_root, graph, act=_hip.ACT_NONE):
     return _CsrGraphConv.apply(x, w_edge, w_rel, b_rel, w_root, graph, act)
+
+
+# ===========================================================================
+# LearnedEdge (edge_selectors/learned.py:53-125)
+# ===========================================================================
+class _LearnedPairs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nodes, cur):
+        nodes = nodes.contiguous()
+        _hip.on_device(nodes, cur)
+        B, N, F = nodes.shape
+        pairs = torch.empty(B, N, 2 * F, device=nodes.device, dtype=_f32)
+        _call("gcm_learned_pairs_fwd", _hip.ptr(nodes), _hip.ptr(cur), _hip.ptr(pairs), B, N, F,
+              _hip.stream())
+        ctx.save_for_backward(cur)
+        ctx.dims = (B, N, F)
+        return pairs
+
+    @staticmethod
+    def backward(ctx, g_pairs):
+        (cur,) = ctx.saved_tensors
+        B, N, F = ctx.dims
+        g_pairs = g_pairs.contiguous()
+        g_nodes = torch.empty(B, N, F, device=g_pairs.device, dtype=_f32)
+        _call("gcm_learned_pairs_bwd", _hip.ptr(g_pairs), _hip.ptr(cur), _hip.ptr(g_nodes), B, N, F,
+              _hip.stream())
+        return g_nodes, None
+
+
+def learned_pairs(nodes, cur):
+    return _LearnedPairs.apply(nodes, cur)
+
+
+class _LearnedSelect(torch.autograd.Function):
+    """new_adj = adj with row cur rewritten (in place on `adj`, which the caller owns)."""
+
+    @staticmethod
+    def forward(ctx, adj, logits, noise, cur, cutoff):
+        logits, noise = logits.contiguous(), noise.contiguous()
+        _hip.on_device(adj, logits, noise, cur)
+        B, N, _ = adj.shape
+        soft = torch.empty(B, N, device=adj.device, dtype=_f32)
+        _call("gcm_learned_select_fwd", _hip.ptr(logits), _hip.ptr(noise), _hip.ptr(cur),
+              float(cutoff), _hip.ptr(adj), _hip.ptr(soft), B, N, _hip.stream())
+        ctx.mark_dirty(adj)
+        ctx.save_for_backward(soft, cur)
+        return adj
+
+    @staticmethod
+    def backward(ctx, g_adj):
+        soft, cur = ctx.saved_tensors
+        B, N = soft.shape
+        g_adj = g_adj.contiguous()
+        g_logits = torch.empty(B, N, device=g_adj.device, dtype=_f32)
+        _call("gcm_learned_select_bwd", _hip.ptr(g_adj), _hip.ptr(soft), _hip.ptr(cur),
+              _hip.ptr(g_logits), B, N, _hip.stream())
+        # both straight-through estimators are identities, so the incoming adjacency receives
+        # g_adj unchanged - also at the rewritten entries (learned.py:108-110 adds adj inside
+        # the STE)
+        return g_adj, g_logits, None, None, None
+
+
+def learned_select_(adj, logits, noise, cur, cutoff):
+    return _LearnedSelect.apply(adj, logits, noise, cur, cutoff)

@@ -216,6 +216,28 @@ int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const float* x, 
                           void* workspace, size_t workspace_bytes, int64_t M, int64_t E, int Fi,
                           int Fo, int act, gcm_stream_t stream);
 
+/* ---- LearnedEdge (src/gcm/edge_selectors/learned.py:53-125) ------------------- */
+
+/* learned.py:66-72: pairs[b, j, :] = cat(nodes[b, cur_b], nodes[b, j]) for j < cur_b, zero rows
+ * otherwise ([B, N, 2F]: the edge network's input, one row per candidate edge; replaces
+ * util.idxs_up_to_num_nodes util.py:501-522 + two advanced-index gathers + cat). */
+int gcm_learned_pairs_fwd(const float* nodes, const int64_t* cur_idx, float* pairs, int B, int N,
+                          int F, gcm_stream_t stream);
+/* adjoint: g_nodes [B,N,F] is overwritten. */
+int gcm_learned_pairs_bwd(const float* g_pairs, const int64_t* cur_idx, float* g_nodes, int B,
+                          int N, int F, gcm_stream_t stream);
+
+/* learned.py:76-111 (non-deterministic branch), fused: per graph soft = softmax_j<cur(logits +
+ * noise) (gumbel_softmax tau=1 with caller-supplied gumbel noise), edge_j = soft_j > cutoff
+ * (STE forward, util.py:9-18), adj[b, cur, j] = (edge_j + adj[b, cur, j] > 0) for j < cur.
+ * adj is updated IN PLACE; soft [B,N] is kept for the backward pass. */
+int gcm_learned_select_fwd(const float* logits, const float* noise, const int64_t* cur_idx,
+                           float cutoff, float* adj, float* soft, int B, int N,
+                           gcm_stream_t stream);
+/* STE backward is the identity, so d soft_j = g_adj[b, cur, j]; g_logits = softmax backward. */
+int gcm_learned_select_bwd(const float* g_adj, const float* soft, const int64_t* cur_idx,
+                           float* g_logits, int B, int N, gcm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

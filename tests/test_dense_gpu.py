@@ -304,3 +304,68 @@ def test_nonfinite_is_reported():
     s(torch.full((2, 4), float("inf"), device=DEV), None)
     with pytest.raises(AssertionError, match="Got NaN in returned memory"):
         s.check_flags()
+
+
+# --------------------------------------------------------------------------
+# LearnedEdge against the reference run with recorded gumbel noise
+# --------------------------------------------------------------------------
+def test_learned_edge_matches_reference():
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.learned import LearnedEdge
+    fx = Fixture("g6_learned")
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    sel = LearnedEdge(m["F"], num_edge_samples=m["num_edge_samples"])
+    sel.load_state_dict(fx.group("sel_param:"))
+    sel = sel.to(DEV)
+    step = {"t": 0}
+
+    def noise(logits):   # the reference drew nothing at t = 0 (learned.py:120-121)
+        key = f"noise_{step['t']}"
+        return fx[key].to(DEV) if key in fx else torch.zeros_like(logits)
+
+    sel.noise_fn = noise
+    mem = DenseGCM(g, edge_selectors=sel, graph_size=m["N"])
+    obs = fx["obs"].to(DEV).requires_grad_(True)
+    hidden, mxs = None, []
+    for t in range(m["T"]):
+        step["t"] = t
+        mx, hidden = mem(obs[t], hidden)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    mem.check_flags()
+    assert hidden[1].requires_grad                                   # adj carries grad (test_gcm.py:851-862)
+    assert torch.equal(hidden[1].detach().cpu(), fx["hT_adj"])       # sampled edges: bit exact
+    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+    gs = float(fx["grad_obs"].abs().max())
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+    for k, p in sel.named_parameters():
+        want = fx["sel_grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
+
+
+def test_learned_edge_default_noise_runs():
+    """Device-RNG gumbel draws: adjacency stays binary, new edges only in row cur, grads flow."""
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.learned import LearnedEdge
+    from gcm import nn as G
+    torch.manual_seed(0)
+    B, N, F = 8, 16, 8
+    g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(F, F), "x, adj -> x"), torch.nn.Tanh()])
+    sel = LearnedEdge(F, num_edge_samples=3)
+    mem = DenseGCM(g.to(DEV), edge_selectors=sel.to(DEV), graph_size=N)
+    hidden, outs = None, []
+    for t in range(6):
+        mx, hidden = mem(torch.randn(B, F, device=DEV), hidden)
+        outs.append(mx)
+    torch.stack(outs).sum().backward()
+    adj = hidden[1].detach()
+    assert set(adj.unique().tolist()) <= {0.0, 1.0}
+    assert float(adj.triu().sum()) == 0.0            # only past -> current edges
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sel.parameters())
