@@ -1,0 +1,95 @@
+// Time-batched DenseGCM rollout: the canonical caller is a Python `for t in range(T)` loop
+// over DenseGCM.forward (ray_gcm.py:200-202, README.md:79-82).  Here the T steps are enqueued
+// from one C call - per step: state advance, the native selector chain, the fused GNN kernel -
+// so the device never waits for host dispatch.  Pure launch sequencing; no new kernels.
+#include "gcm_common.h"
+
+extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all,
+                                     int64_t* count_all, int64_t* cur_all,
+                                     const gcm_selector_desc* selectors, int n_selectors,
+                                     const float* w_rel1, const float* b_rel1,
+                                     const float* w_root1, int act1, const float* w_rel2,
+                                     const float* b_rel2, const float* w_root2, int act2,
+                                     float* mx_all, float* h1_all, float* agg1_all,
+                                     float* agg2_all, uint32_t* flags, void* workspace,
+                                     size_t workspace_bytes, int T, int B, int N, int F, int H1,
+                                     int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_all && adj_all && count_all && cur_all && mx_all && flags);
+  GCM_REQUIRE(T > 0 && B > 0 && (selectors || n_selectors == 0));
+  if (!gcm_dense_gnn2_row_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
+  for (int t = 0; t < T; ++t) {
+    const float* nodes_in = nodes_all + (size_t)t * nodes_sz;
+    float* nodes_out = nodes_all + (size_t)(t + 1) * nodes_sz;
+    const float* adj_in = adj_all + (size_t)t * adj_sz;
+    float* adj_out = adj_all + (size_t)(t + 1) * adj_sz;
+    int64_t* cur = cur_all + (size_t)t * B;
+    int rc = gcm_state_advance_fwd(nodes_in, adj_in, nullptr, count_all + (size_t)t * B,
+                                   obs + (size_t)t * B * F, nodes_out, adj_out, nullptr, cur,
+                                   count_all + (size_t)(t + 1) * B, flags, B, N, F, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_selectors; ++i) {
+      const gcm_selector_desc& d = selectors[i];
+      if (d.kind == GCM_SEL_TEMPORAL)
+        rc = gcm_edge_temporal(adj_out, cur, d.hops, d.n_hops, d.direction, B, N, stream);
+      else if (d.kind == GCM_SEL_DENSE)
+        rc = gcm_edge_dense(adj_out, cur, B, N, stream);
+      else if (d.kind == GCM_SEL_DISTANCE)
+        rc = gcm_edge_distance(nodes_out, adj_out, cur, d.mode, d.max_distance, d.dist_param, d.a0,
+                               d.a1, d.b0, d.b1, d.bidirectional, nullptr, workspace,
+                               workspace_bytes, B, N, F, stream);
+      else
+        rc = GCM_EINVAL;
+      if (rc) return rc;
+    }
+    rc = gcm_dense_gnn2_row_fwd(
+        nodes_out, adj_out, cur, w_rel1, b_rel1, w_root1, act1, w_rel2, b_rel2, w_root2, act2,
+        mx_all + (size_t)t * B * H2, h1_all ? h1_all + (size_t)t * B * N * H1 : nullptr,
+        agg1_all ? agg1_all + (size_t)t * nodes_sz : nullptr,
+        agg2_all ? agg2_all + (size_t)t * B * H1 : nullptr, flags, B, N, F, H1, H2, stream);
+    if (rc) return rc;
+  }
+  return GCM_OK;
+}
+
+extern "C" size_t gcm_dense_rollout_bwd_workspace_bytes(int B, int N, int F, int H1, int H2) {
+  if (B <= 0 || N <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
+  return sizeof(float) * (2 * (size_t)B * N * F + (size_t)B * gcm_dense_gnn2_param_count(F, H1, H2));
+}
+
+extern "C" int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T,
+                                     const float* nodes_all, const float* adj_all,
+                                     const int64_t* count_all, const int64_t* cur_all,
+                                     const float* w_rel1, const float* b_rel1,
+                                     const float* w_root1, int act1, const float* w_rel2,
+                                     const float* b_rel2, const float* w_root2, int act2,
+                                     const float* mx_all, const float* h1_all,
+                                     const float* agg1_all, const float* agg2_all,
+                                     float* g_obs_all, float* g_nodes_0, float* g_params,
+                                     void* workspace, size_t workspace_bytes, int T, int B, int N,
+                                     int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(g_mx_all && nodes_all && adj_all && count_all && cur_all && mx_all && h1_all &&
+              agg1_all && agg2_all && g_obs_all && g_nodes_0 && g_params && workspace);
+  GCM_REQUIRE(T > 0 && B > 0);
+  if (!gcm_dense_gnn2_row_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  if (workspace_bytes < gcm_dense_rollout_bwd_workspace_bytes(B, N, F, H1, H2))
+    return GCM_EWORKSPACE;
+  const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
+  float* ping[2] = {(float*)workspace, (float*)workspace + nodes_sz};
+  float* slabs = (float*)workspace + 2 * nodes_sz;
+  const size_t P = gcm_dense_gnn2_param_count(F, H1, H2);
+  const float* g_next = g_nodes_T;  // gradient w.r.t. the nodes returned by step t
+  for (int t = T - 1; t >= 0; --t) {
+    float* g_prev = t == 0 ? g_nodes_0 : ping[t & 1];
+    int rc = gcm_dense_gnn2_row_bwd(
+        g_mx_all + (size_t)t * B * H2, g_next, nodes_all + (size_t)(t + 1) * nodes_sz,
+        adj_all + (size_t)(t + 1) * adj_sz, cur_all + (size_t)t * B, count_all + (size_t)t * B,
+        w_rel1, b_rel1, w_root1, act1, w_rel2, b_rel2, w_root2, act2, mx_all + (size_t)t * B * H2,
+        h1_all + (size_t)t * B * N * H1, agg1_all + (size_t)t * nodes_sz,
+        agg2_all + (size_t)t * B * H1, g_prev, g_obs_all + (size_t)t * B * F, slabs,
+        /*accumulate=*/t != T - 1, B, N, F, H1, H2, stream);
+    if (rc) return rc;
+    g_next = g_prev;
+  }
+  return gcm_sum_slabs(slabs, B, (int)P, g_params, stream);
+}

@@ -57,7 +57,27 @@ PROTOTYPES = {
     "gcm_learned_pairs_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gcm_learned_select_fwd": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "gcm_learned_select_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "gcm_dense_gnn2_row_supported": (_I, [_I, _I, _I, _I]),
+    "gcm_dense_gnn2_param_count": (_Z, [_I, _I, _I]),
+    "gcm_dense_gnn2_row_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 5 + [_I] * 5 + [_P]),
+    "gcm_dense_gnn2_row_bwd": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] + [_P] * 7 + [_I] * 6 + [_P]),
+    "gcm_sum_slabs": (_I, [_P, _I, _I, _P, _P]),
+    "gcm_dense_rollout_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 3 + [_I] + [_P] * 6
+                              + [_Z] + [_I] * 6 + [_P]),
+    "gcm_dense_rollout_bwd_workspace_bytes": (_Z, [_I] * 5),
+    "gcm_dense_rollout_bwd": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] + [_P] * 8 + [_Z] + [_I] * 6
+                              + [_P]),
 }
+
+
+class SelectorDesc(ctypes.Structure):
+    """struct gcm_selector_desc (include/gcm_hip.h)."""
+    _fields_ = [("kind", _I), ("n_hops", _I), ("hops", ctypes.c_int32 * 16), ("direction", _I),
+                ("mode", _I), ("max_distance", _F), ("dist_param", _P), ("a0", _I), ("a1", _I),
+                ("b0", _I), ("b1", _I), ("bidirectional", _I)]
+
+
+SEL_TEMPORAL, SEL_DENSE, SEL_DISTANCE = 1, 2, 3
 
 
 class HipLibraryError(RuntimeError):

@@ -554,3 +554,176 @@ class _LearnedSelect(torch.autograd.Function):
 
 def learned_select_(adj, logits, noise, cur, cutoff):
     return _LearnedSelect.apply(adj, logits, noise, cur, cutoff)
+
+
+# ===========================================================================
+# fused canonical step / time-batched rollout (csrc/fused.hip, csrc/rollout.hip)
+# ===========================================================================
+def gnn2_supported(N, F, H1, H2):
+    return bool(_hip.lib().gcm_dense_gnn2_row_supported(N, F, H1, H2))
+
+
+def _split_params(flat, F, H1, H2):
+    """views of a flat slab: dW_rel1, dW_root1, db1, dW_rel2, dW_root2, db2"""
+    sizes = [H1 * F, H1 * F, H1, H2 * H1, H2 * H1, H2]
+    shapes = [(H1, F), (H1, F), (H1,), (H2, H1), (H2, H1), (H2,)]
+    out, off = [], 0
+    for n, shp in zip(sizes, shapes):
+        out.append(flat[off:off + n].view(shp))
+        off += n
+    return out
+
+
+def state_advance_raw(nodes, adj, num_nodes, x, flags):
+    """gcm_state_advance_fwd outside autograd (no weights plane)."""
+    nodes, adj, x = nodes.contiguous(), adj.contiguous(), x.contiguous()
+    _hip.on_device(nodes, adj, num_nodes, x, flags)
+    B, N, F = nodes.shape
+    nodes_out, adj_out = torch.empty_like(nodes), torch.empty_like(adj)
+    cur, nn_out = torch.empty_like(num_nodes), torch.empty_like(num_nodes)
+    _call("gcm_state_advance_fwd", _hip.ptr(nodes), _hip.ptr(adj), None, _hip.ptr(num_nodes),
+          _hip.ptr(x), _hip.ptr(nodes_out), _hip.ptr(adj_out), None, _hip.ptr(cur),
+          _hip.ptr(nn_out), _hip.ptr(flags), B, N, F, _hip.stream())
+    return nodes_out, adj_out, cur, nn_out
+
+
+class _FusedStep(torch.autograd.Function):
+    """One DenseGCM step as ONE autograd node: (obs, nodes_in, params) -> (mx, nodes_out).
+    nodes_out/adj_out/cur were produced by state_advance_raw + the (non-differentiable)
+    selectors; this node runs the fused two-layer GNN and owns the whole adjoint."""
+
+    @staticmethod
+    def forward(ctx, obs, nodes_in, nodes_out, adj_out, cur, num_nodes_in, flags, acts,
+                w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2):
+        B, N, F = nodes_out.shape
+        H1, H2 = w_rel1.shape[0], w_rel2.shape[0]
+        dev = nodes_out.device
+        need_bwd = any(ctx.needs_input_grad)
+        mx = torch.empty(B, H2, device=dev, dtype=_f32)
+        h1 = torch.empty(B, N, H1, device=dev, dtype=_f32) if need_bwd else None
+        agg1 = torch.empty(B, N, F, device=dev, dtype=_f32) if need_bwd else None
+        agg2 = torch.empty(B, H1, device=dev, dtype=_f32) if need_bwd else None
+        _call("gcm_dense_gnn2_row_fwd", _hip.ptr(nodes_out), _hip.ptr(adj_out), _hip.ptr(cur),
+              _hip.ptr(w_rel1), _hip.ptr(b_rel1), _hip.ptr(w_root1), acts[0], _hip.ptr(w_rel2),
+              _hip.ptr(b_rel2), _hip.ptr(w_root2), acts[1], _hip.ptr(mx), _hip.ptr(h1),
+              _hip.ptr(agg1), _hip.ptr(agg2), _hip.ptr(flags), B, N, F, H1, H2, _hip.stream())
+        ctx.save_for_backward(nodes_out, adj_out, cur, num_nodes_in, mx, h1, agg1, agg2,
+                              w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2)
+        ctx.acts = acts
+        ctx.dims = (B, N, F, H1, H2)
+        return mx, nodes_out
+
+    @staticmethod
+    def backward(ctx, g_mx, g_nodes_out):
+        (nodes_out, adj_out, cur, nn_in, mx, h1, agg1, agg2,
+         w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2) = ctx.saved_tensors
+        B, N, F, H1, H2 = ctx.dims
+        dev = nodes_out.device
+        lib = _hip.lib()
+        P = lib.gcm_dense_gnn2_param_count(F, H1, H2)
+        if g_mx is None:
+            g_mx = torch.zeros(B, H2, device=dev)
+        g_mx = g_mx.contiguous()
+        g_nodes_out = None if g_nodes_out is None else g_nodes_out.contiguous()
+        g_nodes_in = torch.empty(B, N, F, device=dev, dtype=_f32)
+        g_obs = torch.empty(B, F, device=dev, dtype=_f32)
+        slabs = torch.empty(B, P, device=dev, dtype=_f32)
+        _call("gcm_dense_gnn2_row_bwd", _hip.ptr(g_mx), _hip.ptr(g_nodes_out), _hip.ptr(nodes_out),
+              _hip.ptr(adj_out), _hip.ptr(cur), _hip.ptr(nn_in), _hip.ptr(w_rel1), _hip.ptr(b_rel1),
+              _hip.ptr(w_root1), ctx.acts[0], _hip.ptr(w_rel2), _hip.ptr(b_rel2), _hip.ptr(w_root2),
+              ctx.acts[1], _hip.ptr(mx), _hip.ptr(h1), _hip.ptr(agg1), _hip.ptr(agg2),
+              _hip.ptr(g_nodes_in), _hip.ptr(g_obs), _hip.ptr(slabs), 0, B, N, F, H1, H2,
+              _hip.stream())
+        flat = torch.empty(P, device=dev, dtype=_f32)
+        _call("gcm_sum_slabs", _hip.ptr(slabs), B, P, _hip.ptr(flat), _hip.stream())
+        g = _split_params(flat, F, H1, H2)
+        need = ctx.needs_input_grad
+        return (g_obs if need[0] else None, g_nodes_in if need[1] else None, None, None, None,
+                None, None, None,
+                g[0], g[2] if b_rel1 is not None else None, g[1],
+                g[3], g[5] if b_rel2 is not None else None, g[4])
+
+
+def fused_step(obs, nodes_in, nodes_out, adj_out, cur, num_nodes_in, flags, acts, params):
+    return _FusedStep.apply(obs, nodes_in, nodes_out, adj_out, cur, num_nodes_in, flags, acts,
+                            *params)
+
+
+class _FusedRollout(torch.autograd.Function):
+    """T DenseGCM steps as ONE autograd node (gcm_dense_rollout_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, obs, nodes0, adj0, num_nodes0, flags, descs, acts,
+                w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2):
+        obs = obs.contiguous()
+        _hip.on_device(obs, nodes0, adj0, num_nodes0, flags)
+        T, B, F = obs.shape
+        N = nodes0.shape[1]
+        H1, H2 = w_rel1.shape[0], w_rel2.shape[0]
+        dev = obs.device
+        lib = _hip.lib()
+        need_bwd = any(ctx.needs_input_grad)
+        nodes_all = torch.empty(T + 1, B, N, F, device=dev, dtype=_f32)
+        adj_all = torch.empty(T + 1, B, N, N, device=dev, dtype=_f32)
+        count_all = torch.empty(T + 1, B, device=dev, dtype=torch.int64)
+        nodes_all[0].copy_(nodes0)
+        adj_all[0].copy_(adj0)
+        count_all[0].copy_(num_nodes0)
+        cur_all = torch.empty(T, B, device=dev, dtype=torch.int64)
+        mx_all = torch.empty(T, B, H2, device=dev, dtype=_f32)
+        h1_all = torch.empty(T, B, N, H1, device=dev, dtype=_f32) if need_bwd else None
+        agg1_all = torch.empty(T, B, N, F, device=dev, dtype=_f32) if need_bwd else None
+        agg2_all = torch.empty(T, B, H1, device=dev, dtype=_f32) if need_bwd else None
+        arr = (_hip.SelectorDesc * max(1, len(descs)))(*descs)
+        ws_bytes = 0
+        for d in descs:
+            if d.kind == _hip.SEL_DISTANCE:
+                ws_bytes = max(ws_bytes, lib.gcm_edge_distance_workspace_bytes(d.mode, B, N, F))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        _call("gcm_dense_rollout_fwd", _hip.ptr(obs), _hip.ptr(nodes_all), _hip.ptr(adj_all),
+              _hip.ptr(count_all), _hip.ptr(cur_all), ctypes.addressof(arr), len(descs),
+              _hip.ptr(w_rel1), _hip.ptr(b_rel1), _hip.ptr(w_root1), acts[0], _hip.ptr(w_rel2),
+              _hip.ptr(b_rel2), _hip.ptr(w_root2), acts[1], _hip.ptr(mx_all), _hip.ptr(h1_all),
+              _hip.ptr(agg1_all), _hip.ptr(agg2_all), _hip.ptr(flags), _hip.ptr(ws), ws_bytes,
+              T, B, N, F, H1, H2, _hip.stream())
+        ctx.save_for_backward(nodes_all, adj_all, count_all, cur_all, mx_all, h1_all, agg1_all,
+                              agg2_all, w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2)
+        ctx.acts, ctx.dims = acts, (T, B, N, F, H1, H2)
+        # clones: a view would pin the whole [T+1, ...] history for as long as the hidden lives
+        nodes_T, adj_T, count_T = nodes_all[T].clone(), adj_all[T].clone(), count_all[T].clone()
+        ctx.mark_non_differentiable(adj_T, count_T)
+        return mx_all, nodes_T, adj_T, count_T
+
+    @staticmethod
+    def backward(ctx, g_mx_all, g_nodes_T, _g_adj, _g_count):
+        (nodes_all, adj_all, count_all, cur_all, mx_all, h1_all, agg1_all, agg2_all,
+         w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2) = ctx.saved_tensors
+        T, B, N, F, H1, H2 = ctx.dims
+        dev = nodes_all.device
+        lib = _hip.lib()
+        P = lib.gcm_dense_gnn2_param_count(F, H1, H2)
+        if g_mx_all is None:
+            g_mx_all = torch.zeros(T, B, H2, device=dev)
+        g_mx_all = g_mx_all.contiguous()
+        g_nodes_T = None if g_nodes_T is None else g_nodes_T.contiguous()
+        g_obs = torch.empty(T, B, F, device=dev, dtype=_f32)
+        g_nodes0 = torch.empty(B, N, F, device=dev, dtype=_f32)
+        flat = torch.empty(P, device=dev, dtype=_f32)
+        ws_bytes = lib.gcm_dense_rollout_bwd_workspace_bytes(B, N, F, H1, H2)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _call("gcm_dense_rollout_bwd", _hip.ptr(g_mx_all), _hip.ptr(g_nodes_T), _hip.ptr(nodes_all),
+              _hip.ptr(adj_all), _hip.ptr(count_all), _hip.ptr(cur_all), _hip.ptr(w_rel1),
+              _hip.ptr(b_rel1), _hip.ptr(w_root1), ctx.acts[0], _hip.ptr(w_rel2), _hip.ptr(b_rel2),
+              _hip.ptr(w_root2), ctx.acts[1], _hip.ptr(mx_all), _hip.ptr(h1_all),
+              _hip.ptr(agg1_all), _hip.ptr(agg2_all), _hip.ptr(g_obs), _hip.ptr(g_nodes0),
+              _hip.ptr(flat), _hip.ptr(ws), ws_bytes, T, B, N, F, H1, H2, _hip.stream())
+        g = _split_params(flat, F, H1, H2)
+        need = ctx.needs_input_grad
+        return (g_obs if need[0] else None, g_nodes0 if need[1] else None, None, None, None, None,
+                None,
+                g[0], g[2] if b_rel1 is not None else None, g[1],
+                g[3], g[5] if b_rel2 is not None else None, g[4])
+
+
+def fused_rollout(obs, nodes0, adj0, num_nodes0, flags, descs, acts, params):
+    return _FusedRollout.apply(obs, nodes0, adj0, num_nodes0, flags, descs, acts, *params)

@@ -26,6 +26,13 @@ class Distance(torch.nn.Module):
     def _slices(self, F):
         return (0, F), (0, F)
 
+    def native_desc(self, F):
+        a, b = self._slices(F)
+        return _hip.SelectorDesc(
+            kind=_hip.SEL_DISTANCE, mode=self.mode, max_distance=float(self.max_distance),
+            dist_param=self.dist_param.data_ptr() if self.learned else None,
+            a0=a[0], a1=a[1], b0=b[0], b1=b[1], bidirectional=int(self.bidirectional))
+
     def forward(self, nodes, adj_mats, edge_weights, num_nodes, B):
         a, b = self._slices(nodes.shape[-1])
         param = self.dist_param.detach() if self.learned else None

@@ -23,6 +23,15 @@ class TemporalBackedge(torch.nn.Module):
         self.direction = direction
         self.learned = False
 
+    def native_desc(self):
+        """Descriptor for the fused / rollout paths (struct gcm_selector_desc)."""
+        from .. import _hip
+        d = _hip.SelectorDesc(kind=_hip.SEL_TEMPORAL, n_hops=len(self.hops),
+                              direction=_hip.DIR[self.direction])
+        for i, h in enumerate(self.hops):
+            d.hops[i] = h
+        return d if len(self.hops) <= 16 else None
+
     def forward(self, nodes, adj_mats, edge_weights, num_nodes, B):
         """temporal.py:72-88: for every hop and every graph with num_nodes >= hop set
         adj[b, n, n-hop] (forward/both) and/or adj[b, n-hop, n] (backward/both)."""

@@ -38,6 +38,7 @@ class DenseGCM(torch.nn.Module):
         finite_check: str = "deferred",
         poll_interval: int = 16,
         mutate_num_nodes_on_overflow: bool = False,
+        fused: bool = True,
     ):
         super().__init__()
         assert finite_check in ("deferred", "sync", "off")
@@ -54,6 +55,11 @@ class DenseGCM(torch.nn.Module):
         # gcm.py:354 decrements the CALLER's num_nodes in place when a graph wraps;
         # off by default (the returned values are identical either way)
         self.mutate_num_nodes_on_overflow = mutate_num_nodes_on_overflow
+        # fused=True: when the GNN is the canonical two DenseGraphConv(+Tanh/ReLU) stack and the
+        # selectors are native non-differentiable ones, a step runs as state-advance + selector
+        # kernels + ONE fused GNN kernel under ONE autograd node (csrc/fused.hip)
+        self.fused = fused
+        self._plan_cache = None
         self._flags = {}      # device -> uint32[1] flag word written by the kernels
         self._pending = []    # [(pinned host copy, event)] of flag words in flight
         self._steps = 0
@@ -120,6 +126,118 @@ class DenseGCM(torch.nn.Module):
                 ev.record()
                 self._pending.append((host, ev))
 
+
+    # -- fused fast path -----------------------------------------------------------
+    def _structure(self):
+        """(convs, acts, selector modules) when the module tree qualifies for the fused
+        kernels, else None.  Structure is analysed once (modules are assumed static)."""
+        if self._plan_cache is not None:
+            return self._plan_cache[0]
+        from . import nn as G
+        from .edge_selectors.temporal import TemporalBackedge
+        from .edge_selectors.dense import DenseEdge
+        from .edge_selectors.distance import Distance
+
+        def analyse():
+            if (not self.fused or self.pooled or self.preprocessor is not None
+                    or self.positional_encoder is not None or self.aux_edge_selectors is not None):
+                return None
+            g = self.gnn
+            if not isinstance(g, G.Sequential) or len(g.arg_names) < 2:
+                return None
+            xn, an = g.arg_names[0], g.arg_names[1]
+            convs, acts = [], []
+            for mod, ins, outs in g.stages():
+                if isinstance(mod, G.DenseGraphConv):
+                    if ins != [xn, an] or outs != [xn] or len(convs) == 2:
+                        return None
+                    convs.append(mod)
+                    acts.append(_hip.ACT_NONE)
+                elif type(mod) in G._FUSABLE and convs and ins == [xn] and outs == [xn] \
+                        and acts[-1] == _hip.ACT_NONE:
+                    acts[-1] = G._FUSABLE[type(mod)]
+                else:
+                    return None
+            if len(convs) != 2 or convs[0].out_channels != convs[1].in_channels:
+                return None
+            native = (TemporalBackedge, DenseEdge, Distance)
+            sel = self.edge_selectors
+            if sel is None:
+                mods = []
+            elif isinstance(sel, native):
+                mods = [sel]
+            elif isinstance(sel, G.Sequential):
+                mods = []
+                names = sel.arg_names
+                for mod, ins, outs in sel.stages():
+                    if not isinstance(mod, native) or ins != names or outs != names[1:3]:
+                        return None
+                    mods.append(mod)
+            else:
+                return None
+            return convs, tuple(acts), mods
+
+        self._plan_cache = (analyse(),)
+        return self._plan_cache[0]
+
+    def _fused_plan(self, nodes, adj, weights, F):
+        st = self._structure()
+        if st is None or weights.numel() != 0 or adj.requires_grad or not nodes.is_cuda:
+            return None
+        convs, acts, mods = st
+        if convs[0].in_channels != F:
+            return None
+        if not _ops.gnn2_supported(nodes.shape[1], F, convs[0].out_channels,
+                                   convs[1].out_channels):
+            return None
+        params = (convs[0].lin_rel.weight, convs[0].lin_rel.bias, convs[0].lin_root.weight,
+                  convs[1].lin_rel.weight, convs[1].lin_rel.bias, convs[1].lin_root.weight)
+        return acts, params, mods
+
+    def _forward_fused(self, x, nodes, adj, weights, num_nodes, plan, flags):
+        acts, params, mods = plan
+        B = x.shape[0]
+        with torch.no_grad():
+            nodes_out, adj_out, cur, num_nodes_next = _ops.state_advance_raw(
+                nodes.detach(), adj, num_nodes, x.detach(), flags)
+            if self.mutate_num_nodes_on_overflow:
+                num_nodes.copy_(cur)
+            for m in mods:
+                adj_out, weights = m(nodes_out, adj_out, weights, cur, B)
+        mx, nodes_out = _ops.fused_step(x, nodes, nodes_out, adj_out, cur, num_nodes, flags, acts,
+                                        params)
+        if self.finite_check != "off":
+            self._poll(flags)
+        return mx, (nodes_out, adj_out, weights, num_nodes_next)
+
+    def rollout(self, obs, hidden=None):
+        """T memory steps at once: obs [T, B, feat] -> (beliefs [T, B, H],
+        hidden after the last step).  Identical in result to T calls of forward(); when the
+        module tree qualifies for the fused kernels the whole rollout is enqueued by one C call
+        and is one autograd node, otherwise it is the plain Python loop."""
+        assert obs.dim() == 3 and obs.dtype == torch.float32
+        if hidden is None:
+            hidden = self.get_initial_hidden_state(obs[0])
+        nodes, adj, weights, num_nodes = hidden
+        plan = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
+        native_only = plan is not None and all(hasattr(m, "native_desc") for m in plan[2])
+        if not native_only:
+            outs = []
+            for t in range(obs.shape[0]):
+                mx, hidden = self(obs[t], hidden)
+                outs.append(mx)
+            return torch.stack(outs), hidden
+        from .edge_selectors.distance import Distance
+        acts, params, mods = plan
+        descs = [m.native_desc(obs.shape[-1]) if isinstance(m, Distance) else m.native_desc()
+                 for m in mods]
+        flags = self._flag_word(obs.device)
+        mx_all, nodes_T, adj_T, count_T = _ops.fused_rollout(
+            obs, nodes, adj, num_nodes, flags, descs, acts, params)
+        if self.finite_check == "sync":
+            self.check_flags()
+        return mx_all, (nodes_T, adj_T, weights, count_T)
+
     # -- the step --------------------------------------------------------------
     def forward(
         self,
@@ -143,6 +261,9 @@ class DenseGCM(torch.nn.Module):
         assert N == adj.shape[1] == adj.shape[2], "N must be equal for adj mat and node mat"
 
         flags = self._flag_word(x.device)
+        plan = self._fused_plan(nodes, adj, weights, x.shape[-1])
+        if plan is not None:
+            return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
         # insert x at row num_nodes (after the overflow roll); fresh nodes/adj/weights buffers
         nodes, adj, weights, cur, num_nodes_next = _ops.state_advance(
             nodes, adj, weights, num_nodes, x, flags)

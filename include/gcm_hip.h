@@ -238,6 +238,86 @@ int gcm_learned_select_fwd(const float* logits, const float* noise, const int64_
 int gcm_learned_select_bwd(const float* g_adj, const float* soft, const int64_t* cur_idx,
                            float* g_logits, int B, int N, gcm_stream_t stream);
 
+/* ---- fused DenseGCM step for the canonical GNN (README.md:52-62, gcm.py:308-314) ------ */
+
+/* 1 when the fused kernels cover this shape (N <= 128, F <= 64, H1 <= 64, H2 <= 256 and the
+ * LDS images fit 160 KB); otherwise use the layered gcm_dense_graphconv_* path. */
+int gcm_dense_gnn2_row_supported(int N, int F, int H1, int H2);
+/* number of floats in one parameter-gradient slab:
+ * dW_rel1 [H1*F] | dW_root1 [H1*F] | db1 [H1] | dW_rel2 [H2*H1] | dW_root2 [H2*H1] | db2 [H2] */
+size_t gcm_dense_gnn2_param_count(int F, int H1, int H2);
+
+/* mx[b] = act2(gc2(act1(gc1(x, adj)), adj))[b, cur_idx[b]]  - two DenseGraphConv layers in one
+ * kernel, adj and x resident in LDS, the second layer evaluated only on the kept row.
+ * Saved for backward (each may be NULL when no gradient is needed): h1 [B,N,H1] (post
+ * activation), agg1 = adj@x [B,N,F], agg2 = adj[cur]@h1 [B,H1].  ORs GCM_FLAG_NONFINITE. */
+int gcm_dense_gnn2_row_fwd(const float* x, const float* adj, const int64_t* cur_idx,
+                           const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
+                           const float* w_rel2, const float* b_rel2, const float* w_root2, int act2,
+                           float* mx, float* h1, float* agg1, float* agg2, uint32_t* flags, int B,
+                           int N, int F, int H1, int H2, gcm_stream_t stream);
+
+/* Backward of the above with the adjoint of gcm_state_advance_fwd folded in:
+ * g_nodes_out [B,N,F] (gradient w.r.t. the nodes returned by the step, NULL = 0) and g_mx [B,H2]
+ * -> g_nodes_in [B,N,F], g_obs [B,F] and one parameter-gradient slab per graph
+ * (slabs [B, gcm_dense_gnn2_param_count]; accumulate != 0 adds to what is there). */
+int gcm_dense_gnn2_row_bwd(const float* g_mx, const float* g_nodes_out, const float* x,
+                           const float* adj, const int64_t* cur_idx, const int64_t* num_nodes_in,
+                           const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
+                           const float* w_rel2, const float* b_rel2, const float* w_root2, int act2,
+                           const float* mx, const float* h1, const float* agg1, const float* agg2,
+                           float* g_nodes_in, float* g_obs, float* slabs, int accumulate, int B,
+                           int N, int F, int H1, int H2, gcm_stream_t stream);
+
+/* out[e] = sum_i slabs[i, e]  (fixed order, deterministic) */
+int gcm_sum_slabs(const float* slabs, int n_slabs, int len, float* out, gcm_stream_t stream);
+
+/* ---- time-batched rollout (caller loop ray_gcm.py:200-202) --------- */
+
+/* One native edge selector of the per-step chain (host struct). */
+#define GCM_SEL_TEMPORAL 1
+#define GCM_SEL_DENSE 2
+#define GCM_SEL_DISTANCE 3
+typedef struct gcm_selector_desc {
+  int kind;               /* GCM_SEL_*                                              */
+  int n_hops;             /* temporal                                                */
+  int32_t hops[16];       /* temporal                                                */
+  int direction;          /* temporal: GCM_DIR_*                                     */
+  int mode;               /* distance: GCM_DIST_*                                    */
+  float max_distance;     /* distance                                                */
+  const float* dist_param;/* distance: device pointer or NULL                        */
+  int a0, a1, b0, b1;     /* distance: pose slices                                   */
+  int bidirectional;      /* distance                                                */
+} gcm_selector_desc;
+
+/* T DenseGCM steps in one call: for t in [0,T): state advance, the selector chain, fused GNN,
+ * exactly what T calls of DenseGCM.forward do.  State arrays hold every step (needed by BPTT):
+ * nodes_all [T+1,B,N,F], adj_all [T+1,B,N,N], count_all [T+1,B] with slot 0 = the incoming
+ * hidden state (caller fills it); cur_all [T,B]; mx_all [T,B,H2]; h1_all [T,B,N,H1];
+ * agg1_all [T,B,N,F]; agg2_all [T,B,H1] (the last three may be NULL when no backward follows).
+ * workspace: gcm_edge_distance_workspace_bytes of the largest distance selector (or 0). */
+int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all, int64_t* count_all,
+                          int64_t* cur_all, const gcm_selector_desc* selectors, int n_selectors,
+                          const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
+                          const float* w_rel2, const float* b_rel2, const float* w_root2, int act2,
+                          float* mx_all, float* h1_all, float* agg1_all, float* agg2_all,
+                          uint32_t* flags, void* workspace, size_t workspace_bytes, int T, int B,
+                          int N, int F, int H1, int H2, gcm_stream_t stream);
+
+/* BPTT over the arrays written by gcm_dense_rollout_fwd.  g_mx_all [T,B,H2]; g_nodes_T
+ * [B,N,F] = gradient w.r.t. the final nodes (NULL = 0).  Outputs: g_obs_all [T,B,F],
+ * g_nodes_0 [B,N,F], g_params [gcm_dense_gnn2_param_count] (summed over graphs and steps).
+ * workspace: 2*B*N*F floats (ping-pong) + B*param_count floats (slabs). */
+size_t gcm_dense_rollout_bwd_workspace_bytes(int B, int N, int F, int H1, int H2);
+int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const float* nodes_all,
+                          const float* adj_all, const int64_t* count_all, const int64_t* cur_all,
+                          const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
+                          const float* w_rel2, const float* b_rel2, const float* w_root2, int act2,
+                          const float* mx_all, const float* h1_all, const float* agg1_all,
+                          const float* agg2_all, float* g_obs_all, float* g_nodes_0,
+                          float* g_params, void* workspace, size_t workspace_bytes, int T, int B,
+                          int N, int F, int H1, int H2, gcm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

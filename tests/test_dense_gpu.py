@@ -369,3 +369,93 @@ def test_learned_edge_default_noise_runs():
     assert set(adj.unique().tolist()) <= {0.0, 1.0}
     assert float(adj.triu().sum()) == 0.0            # only past -> current edges
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sel.parameters())
+
+
+# --------------------------------------------------------------------------
+# fused step kernels and the time-batched rollout entry
+# --------------------------------------------------------------------------
+def _mk(F, H1, H2, act1, act2, sel, N, fused, seed=0):
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    torch.manual_seed(seed)
+    mods = [(G.DenseGraphConv(F, H1), "x, adj -> x")]
+    if act1:
+        mods.append(act1())
+    mods.append((G.DenseGraphConv(H1, H2), "x, adj -> x"))
+    if act2:
+        mods.append(act2())
+    g = G.Sequential("x, adj, weights, B, N", mods).to(DEV)
+    return DenseGCM(g, edge_selectors=sel, graph_size=N, fused=fused), g
+
+
+def _run(mem, g, obs, h0, rollout=False):
+    obs = obs.clone().requires_grad_(True)
+    g.zero_grad(set_to_none=True)
+    if rollout:
+        out, hid = mem.rollout(obs, h0)
+    else:
+        hid, outs = h0, []
+        for t in range(obs.shape[0]):
+            mx, hid = mem(obs[t], hid)
+            outs.append(mx)
+        out = torch.stack(outs)
+    (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
+    mem.check_flags()
+    return out.detach(), hid, obs.grad, {k: p.grad.clone() for k, p in g.named_parameters()}
+
+
+@pytest.mark.parametrize("B,N,F,H1,H2,T,sel_kind", [
+    (3, 7, 5, 6, 4, 10, "temporal"), (4, 32, 8, 32, 32, 40, "temporal_both"),
+    (2, 33, 20, 40, 8, 36, "dense"), (5, 128, 32, 32, 32, 6, "temporal"),
+    (3, 64, 64, 32, 16, 70, "temporal"), (4, 16, 8, 16, 16, 20, "spatial"),
+    (2, 100, 33, 64, 70, 5, "none"),
+])
+def test_fused_matches_layered_and_rollout(B, N, F, H1, H2, T, sel_kind):
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.dense import DenseEdge
+    from gcm.edge_selectors.distance import SpatialEdge
+
+    def sel():
+        return {"temporal": lambda: TemporalBackedge([1, 2, 4]),
+                "temporal_both": lambda: TemporalBackedge([1, 3], direction="both"),
+                "dense": lambda: DenseEdge(), "spatial": lambda: SpatialEdge(0.8, slice(0, 3)),
+                "none": lambda: None}[sel_kind]()
+
+    torch.manual_seed(B * N + T)
+    obs = torch.rand(T, B, F, device=DEV)
+    starts = torch.randint(0, N + 1, (B,), device=DEV)
+    nodes0 = torch.rand(B, N, F, device=DEV) * (torch.arange(N, device=DEV)[None, :, None] < starts[:, None, None])
+    adj0 = ((torch.rand(B, N, N, device=DEV) < 0.1) & (torch.arange(N, device=DEV)[None, :, None] < starts[:, None, None])
+            & (torch.arange(N, device=DEV)[None, None, :] < starts[:, None, None])).float()
+    nodes0.requires_grad_(True)
+    h0 = (nodes0, adj0, torch.zeros(0, device=DEV), starts)
+    lay, g_lay = _mk(F, H1, H2, torch.nn.Tanh, torch.nn.ReLU, sel(), N, fused=False)
+    fus, g_fus = _mk(F, H1, H2, torch.nn.Tanh, torch.nn.ReLU, sel(), N, fused=True)
+    assert lay._structure() is None and fus._structure() is not None
+    want = _run(lay, g_lay, obs, h0)
+    want_g0 = nodes0.grad.clone(); nodes0.grad = None
+    for rollout in (False, True):
+        got = _run(fus, g_fus, obs, h0, rollout=rollout)
+        got_g0 = nodes0.grad.clone(); nodes0.grad = None
+        # two fp32 implementations with different summation orders (dense rows sum ~N terms)
+        torch.testing.assert_close(got[0], want[0], rtol=1e-5, atol=1e-5)
+        for a, b in zip(got[1], want[1]):
+            assert torch.equal(a, b)                       # state: bit exact
+        torch.testing.assert_close(got[2], want[2], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(got_g0, want_g0, rtol=1e-4, atol=1e-6)
+        for k in want[3]:
+            scale = float(want[3][k].abs().max()) + 1e-12
+            torch.testing.assert_close(got[3][k], want[3][k], rtol=1e-4, atol=1e-5 * scale, msg=k)
+
+
+def test_rollout_falls_back_for_non_native_trees():
+    """rollout() on a tree the fused kernels do not cover = the plain loop."""
+    from gcm.edge_selectors.learned import LearnedEdge
+    from gcm import nn as G
+    from gcm.gcm import DenseGCM
+    torch.manual_seed(0)
+    g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(4, 4), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+    mem = DenseGCM(g, edge_selectors=LearnedEdge(4).to(DEV), graph_size=6)
+    obs = torch.rand(5, 2, 4, device=DEV)
+    out, hid = mem.rollout(obs)
+    assert out.shape == (5, 2, 4) and hid[3].tolist() == [5, 5]
