@@ -86,6 +86,15 @@ struct Stage {
   }
 };
 
+// index-writing selectors folded into the step kernel (temporal hops + dense), by value
+struct Edits {
+  int n_hops;        // temporal back edges (temporal.py:72-88)
+  int hops[16];
+  int dir[16];       // GCM_DIR_* per hop entry (several TemporalBackedge selectors may be chained)
+  int dense;         // DenseEdge (dense.py:16-21)
+};
+
+
 // This wave's 32 adjacency rows as 16-byte loads: tile t (32 columns), 8 rows per instruction.
 template <int NT, bool EXACT>
 struct AdjRows {
@@ -119,6 +128,82 @@ struct AdjRows {
           if (r >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         buf[t * 4 + q] = v;
+      }
+  }
+  // Same rows taken from the PREVIOUS state with the overflow roll applied (gcm.py:323-355):
+  // out[r][c] = wrap ? in[r+1][c+1] (last row / column zero) : in[r][c].  vec path only (N%4==0).
+  __device__ __forceinline__ void load_advanced(const float* __restrict__ ag, int N, int r_base,
+                                                int lane, bool wrap) {
+    const int sh = wrap ? 1 : 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r_base + (lane >> 3) + 8 * q, c = t * 32 + (lane & 7) * 4;
+        const int rs = r + sh < N ? r + sh : N - 1;
+        const int cc = c < N ? c : N - 4;
+        // last 4 columns of a wrapped row: load in place and shift in registers (in[.][N] does
+        // not exist); elsewhere read one element to the right (dword-aligned 16-byte load)
+        const bool tail = wrap && cc + 4 >= N;
+        const float* p = ag + rs * N + cc + (tail ? 0 : sh);
+        float4 v;   // dword-aligned 16-byte load
+        __builtin_memcpy(&v, p, sizeof(float4));
+        if (tail) v = make_float4(v.y, v.z, v.w, 0.f);
+        if (r + sh >= N || c >= N || r >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        buf[t * 4 + q] = v;
+      }
+  }
+  // selector writes on the freshly advanced adjacency, in registers (cur = new node's row)
+  __device__ __forceinline__ void apply_edits(const Edits& E, int cur, int r_base, int lane) {
+    // wave-uniform early out: does any edit touch this wave's 32 rows?
+    bool touched = (cur >> 5) == (r_base >> 5);
+    for (int i = 0; i < E.n_hops; ++i)
+      touched |= (E.dir[i] & GCM_DIR_BACKWARD) && cur >= E.hops[i] &&
+                 ((cur - E.hops[i]) >> 5) == (r_base >> 5);
+    touched |= E.dense && (r_base < cur);
+    if (!touched) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r_base + (lane >> 3) + 8 * q, c = t * 32 + (lane & 7) * 4;
+        float4 v = buf[t * 4 + q];
+        // component k of v <- 1 (selects, no runtime-indexed register access)
+        auto set1 = [&v](int k) {
+          v.x = k == 0 ? 1.f : v.x;
+          v.y = k == 1 ? 1.f : v.y;
+          v.z = k == 2 ? 1.f : v.z;
+          v.w = k == 3 ? 1.f : v.w;
+        };
+        for (int i = 0; i < E.n_hops; ++i) {
+          const int h = E.hops[i];
+          if (h < 0 || cur < h) continue;   // uniform
+          const int past = cur - h;
+          if ((E.dir[i] & GCM_DIR_FORWARD) && r == cur) set1(past - c);
+          if ((E.dir[i] & GCM_DIR_BACKWARD) && r == past) set1(cur - c);
+        }
+        if (E.dense) {
+          if (r == cur) {   // row cur: columns 0..cur (self edge included)
+            v.x = c <= cur ? 1.f : v.x;
+            v.y = c + 1 <= cur ? 1.f : v.y;
+            v.z = c + 2 <= cur ? 1.f : v.z;
+            v.w = c + 3 <= cur ? 1.f : v.w;
+          } else if (r < cur) {   // column cur: rows 0..cur-1
+            set1(cur - c);
+          }
+        }
+        buf[t * 4 + q] = v;
+      }
+  }
+  // write this wave's rows to the new adjacency in HBM (16-byte stores)
+  __device__ __forceinline__ void store_global(float* __restrict__ ag, int N, int r_base,
+                                               int lane) const {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r_base + (lane >> 3) + 8 * q, c = t * 32 + (lane & 7) * 4;
+        if (EXACT || (r < N && c < N)) *reinterpret_cast<float4*>(ag + r * N + c) = buf[t * 4 + q];
       }
   }
   // true when any element of this wave's tile t is non-zero (wave-uniform)

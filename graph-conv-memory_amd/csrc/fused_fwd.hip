@@ -10,11 +10,27 @@ extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
 
 namespace gcm_fused {
 
-template <int NT, int NCT, int NHT, int N2T, bool EXACT>
-__global__ __launch_bounds__(256) void k_gnn2_row_fwd(
+// state of the previous step + what the advance needs (ADV variant: gcm.py:262-287 folded in)
+struct Advance {
+  const float* obs;            // [B,F]
+  const int64_t* count_in;     // [B]
+  float* nodes_out;            // [B,N,F]
+  float* adj_out;              // [B,N,N]
+  int64_t* cur_out;            // [B]
+  int64_t* count_out;          // [B]
+  Edits edits;
+};
+
+// ADV = false: x / adj are the already advanced state (nodes_out, adj_out), cur_idx given.
+// ADV = true : x / adj are the PREVIOUS state; the kernel inserts obs, rolls on overflow, applies
+//              the folded selectors, writes nodes_out / adj_out / cur / count and runs the GNN -
+//              one kernel per forward step (needs N % 4 == 0 and F % 4 == 0).
+template <int NT, int NCT, int NHT, int N2T, bool EXACT, bool ADV>
+__device__ __forceinline__ void gnn2_row_fwd_body(
     const float* __restrict__ x, const float* __restrict__ adj, const int64_t* __restrict__ cur_idx,
-    Gnn2 P, float* __restrict__ mx_out, float* __restrict__ h1_out, float* __restrict__ agg1_out,
-    float* __restrict__ agg2_out, uint32_t* __restrict__ flags, int N_, int F_, int H1_, int H2_) {
+    const Advance& A, const Gnn2& P, float* __restrict__ mx_out, float* __restrict__ h1_out,
+    float* __restrict__ agg1_out, float* __restrict__ agg2_out, uint32_t* __restrict__ flags,
+    int N_, int F_, int H1_, int H2_) {
   using L = Lds<NT, NCT, NHT, N2T>;
   constexpr int NP = L::NP, FP = L::FP, HP = L::HP, H2P = L::H2P;
   constexpr int FS = L::FS, HS = L::HS, AS = L::AS, W2S = L::W2S;
@@ -26,8 +42,23 @@ __global__ __launch_bounds__(256) void k_gnn2_row_fwd(
   const float* ag = adj + (size_t)b * N * N;
   float* h1g = h1_out ? h1_out + (size_t)b * N * H1 : nullptr;
   float* a1g = agg1_out ? agg1_out + (size_t)b * N * F : nullptr;
-  int64_t cur64 = cur_idx[b];
-  const int cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
+  bool wrap = false;
+  int cur;
+  if (ADV) {
+    const int64_t n_in = A.count_in[b];
+    wrap = n_in + 1 > N;
+    int64_t c64 = wrap ? n_in - 1 : n_in;
+    cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+    if (tid == 0) {
+      A.cur_out[b] = cur;
+      A.count_out[b] = cur + 1;
+      const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
+      if (f) atomicOr(flags, f);
+    }
+  } else {
+    const int64_t cur64 = cur_idx[b];
+    cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
+  }
 
   extern __shared__ float smem[];
   float* sAdj = smem;
@@ -46,13 +77,38 @@ __global__ __launch_bounds__(256) void k_gnn2_row_fwd(
   Stage<HP, FP, true, EXACT> st_wr, st_wo;
   Stage<H2P, HP, false, EXACT> st_w2r, st_w2o;
   AdjRows<NT, EXACT> rows;
-  st_x.load(xg, N, F, F, tid);
+  if (ADV) {
+    // previous nodes with the roll applied; row cur takes the observation (gcm.py:274)
+    const float ob = A.obs[(size_t)b * F + min(tid % FP, F - 1)];   // 256 % FP == 0: fixed column
+#pragma unroll
+    for (int i = 0; i < st_x.PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, c = e % FP;
+      const int rs = r + (wrap ? 1 : 0);
+      const float t = xg[(rs < N ? rs : N - 1) * F + (c < F ? c : F - 1)];
+      float v = (rs < N && r < N && c < F) ? t : 0.f;
+      if (r == cur && c < F) v = ob;
+      st_x.v[i] = v;
+    }
+  } else {
+    st_x.load(xg, N, F, F, tid);
+  }
   st_wr.load(P.w_rel1, H1, F, F, tid);
   st_wo.load(P.w_root1, H1, F, F, tid);
-  if (wave_live) rows.load(ag, N, r_base, lane);
+  if (wave_live) {
+    if (ADV) rows.load_advanced(ag, N, r_base, lane, wrap);
+    else rows.load(ag, N, r_base, lane);
+  }
   st_w2r.load(P.w_rel2, H2, H1, H1, tid);
   st_w2o.load(P.w_root2, H2, H1, H1, tid);
   STAMP(1);
+  if (ADV) {  // the new node matrix goes back to HBM as it lands in LDS
+    float* no = A.nodes_out + (size_t)b * N * F;
+#pragma unroll
+    for (int i = 0; i < st_x.PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, c = e % FP;
+      if (EXACT || (r < N && c < F)) no[r * F + c] = st_x.v[i];
+    }
+  }
   st_x.store(sX, FS, tid);
   st_wr.store(sW1, HS, tid);
   st_wo.store(sW1 + FP * HS, HS, tid);
@@ -61,6 +117,10 @@ __global__ __launch_bounds__(256) void k_gnn2_row_fwd(
   STAMP(3);
 
   if (wave_live) {
+    if (ADV) {
+      rows.apply_edits(A.edits, cur, r_base, lane);
+      rows.store_global(A.adj_out + (size_t)b * N * N, N, r_base, lane);
+    }
     // ---- layer 1, aggregation: agg = adj[rows,:] @ x, K tile by K tile ------------------
     f32x16 acc[NCT];
 #pragma unroll
@@ -170,6 +230,45 @@ __global__ __launch_bounds__(256) void k_gnn2_row_fwd(
   }
 }
 
+template <int NT, int NCT, int NHT, int N2T, bool EXACT>
+__global__ __launch_bounds__(256) void k_gnn2_row_fwd(
+    const float* __restrict__ x, const float* __restrict__ adj, const int64_t* __restrict__ cur_idx,
+    Gnn2 P, float* __restrict__ mx_out, float* __restrict__ h1_out, float* __restrict__ agg1_out,
+    float* __restrict__ agg2_out, uint32_t* __restrict__ flags, int N, int F, int H1, int H2) {
+  Advance none{};
+  gnn2_row_fwd_body<NT, NCT, NHT, N2T, EXACT, false>(x, adj, cur_idx, none, P, mx_out, h1_out,
+                                                     agg1_out, agg2_out, flags, N, F, H1, H2);
+}
+
+template <int NT, int NCT, int NHT, int N2T, bool EXACT>
+__global__ __launch_bounds__(256) void k_step_fwd(
+    const float* __restrict__ nodes_in, const float* __restrict__ adj_in, Advance A, Gnn2 P,
+    float* __restrict__ mx_out, float* __restrict__ h1_out, float* __restrict__ agg1_out,
+    float* __restrict__ agg2_out, uint32_t* __restrict__ flags, int N, int F, int H1, int H2) {
+  gnn2_row_fwd_body<NT, NCT, NHT, N2T, EXACT, true>(nodes_in, adj_in, nullptr, A, P, mx_out,
+                                                    h1_out, agg1_out, agg2_out, flags, N, F, H1,
+                                                    H2);
+}
+
+template <int NT, int NCT, int NHT, int N2T>
+int launch_step(hipStream_t s, const float* nodes_in, const float* adj_in, Advance A, Gnn2 P,
+                float* mx, float* h1, float* agg1, float* agg2, uint32_t* flags, int B, int N,
+                int F, int H1, int H2) {
+  using L = Lds<NT, NCT, NHT, N2T>;
+  constexpr size_t lds = sizeof(float) * (size_t)L::FWD;
+  const bool exact = N == L::NP && F == L::FP && H1 == L::HP && H2 == L::H2P;
+  auto kern = exact ? k_step_fwd<NT, NCT, NHT, N2T, true> : k_step_fwd<NT, NCT, NHT, N2T, false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[exact] && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set[exact] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, nodes_in, adj_in, A, P, mx, h1, agg1, agg2,
+                     flags, N, F, H1, H2);
+  return gcm_launch_status();
+}
+
 template <int NT, int NCT, int NHT, int N2T>
 int launch_fwd(hipStream_t s, const float* x, const float* adj, const int64_t* cur, Gnn2 P,
                float* mx, float* h1, float* agg1, float* agg2, uint32_t* flags, int B, int N,
@@ -223,5 +322,52 @@ extern "C" int gcm_dense_gnn2_row_fwd(const float* x, const float* adj, const in
                                               flags, B, N, F, H1, H2);
   GCM_SHAPES(GCM_F)
 #undef GCM_F
+  return GCM_EUNSUPPORTED;
+}
+
+/* One kernel per forward step: state advance (gcm.py:262-278, 323-355) + temporal/dense selector
+ * writes + fused GNN.  Only index-writing selectors can be folded (GCM_SEL_TEMPORAL /
+ * GCM_SEL_DENSE); returns GCM_EUNSUPPORTED otherwise or when N % 4 or F % 4 != 0 - the caller
+ * then uses the three-kernel sequence. */
+extern "C" int gcm_dense_step_fused_fwd(const float* obs, const float* nodes_in,
+                                        const float* adj_in, const int64_t* count_in,
+                                        float* nodes_out, float* adj_out, int64_t* cur_out,
+                                        int64_t* count_out, const gcm_selector_desc* selectors,
+                                        int n_selectors, const float* w_rel1, const float* b_rel1,
+                                        const float* w_root1, int act1, const float* w_rel2,
+                                        const float* b_rel2, const float* w_root2, int act2,
+                                        float* mx, float* h1, float* agg1, float* agg2,
+                                        uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                        gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_in && adj_in && count_in && nodes_out && adj_out && cur_out &&
+              count_out && w_rel1 && w_root1 && w_rel2 && w_root2 && mx && flags);
+  GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0));
+  if (!gcm_dense_gnn2_row_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
+  gcm_fused::Advance A{};
+  A.obs = obs; A.count_in = count_in; A.nodes_out = nodes_out; A.adj_out = adj_out;
+  A.cur_out = cur_out; A.count_out = count_out;
+  for (int i = 0; i < n_selectors; ++i) {
+    const gcm_selector_desc& d = selectors[i];
+    if (d.kind == GCM_SEL_TEMPORAL) {
+      for (int k = 0; k < d.n_hops; ++k) {
+        if (A.edits.n_hops >= 16) return GCM_EUNSUPPORTED;
+        A.edits.hops[A.edits.n_hops] = d.hops[k];
+        A.edits.dir[A.edits.n_hops++] = d.direction;
+      }
+    } else if (d.kind == GCM_SEL_DENSE) {
+      A.edits.dense = 1;
+    } else {
+      return GCM_EUNSUPPORTED;
+    }
+  }
+  gcm_fused::Gnn2 P{w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2, act1, act2};
+  hipStream_t s = (hipStream_t)stream;
+  const int NT = (N + 31) / 32, NCT = (F + 31) / 32, NHT = (H1 + 31) / 32, N2T = (H2 + 31) / 32;
+#define GCM_S(a, b_, c, d)                                                                    \
+  if (NT == a && NCT == b_ && NHT == c && N2T == d)                                           \
+    return gcm_fused::launch_step<a, b_, c, d>(s, nodes_in, adj_in, A, P, mx, h1, agg1, agg2, \
+                                               flags, B, N, F, H1, H2);
+  GCM_SHAPES(GCM_S)
+#undef GCM_S
   return GCM_EUNSUPPORTED;
 }

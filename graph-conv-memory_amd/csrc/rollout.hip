@@ -4,6 +4,94 @@
 // so the device never waits for host dispatch.  Pure launch sequencing; no new kernels.
 #include "gcm_common.h"
 
+namespace {
+struct Unpacked {
+  const float *w_rel1, *w_root1, *b1, *w_rel2, *w_root2, *b2;
+};
+Unpacked unpack(const float* p, int has_bias, int F, int H1, int H2) {
+  Unpacked u;
+  u.w_rel1 = p;
+  u.w_root1 = u.w_rel1 + (size_t)H1 * F;
+  const float* b1 = u.w_root1 + (size_t)H1 * F;
+  u.w_rel2 = b1 + H1;
+  u.w_root2 = u.w_rel2 + (size_t)H2 * H1;
+  const float* b2 = u.w_root2 + (size_t)H2 * H1;
+  u.b1 = (has_bias & 1) ? b1 : nullptr;
+  u.b2 = (has_bias & 2) ? b2 : nullptr;
+  return u;
+}
+
+int run_selectors(const gcm_selector_desc* selectors, int n_selectors, const float* nodes_out,
+                  float* adj_out, const int64_t* cur, void* workspace, size_t workspace_bytes,
+                  int B, int N, int F, gcm_stream_t stream) {
+  for (int i = 0; i < n_selectors; ++i) {
+    const gcm_selector_desc& d = selectors[i];
+    int rc;
+    if (d.kind == GCM_SEL_TEMPORAL)
+      rc = gcm_edge_temporal(adj_out, cur, d.hops, d.n_hops, d.direction, B, N, stream);
+    else if (d.kind == GCM_SEL_DENSE)
+      rc = gcm_edge_dense(adj_out, cur, B, N, stream);
+    else if (d.kind == GCM_SEL_DISTANCE)
+      rc = gcm_edge_distance(nodes_out, adj_out, cur, d.mode, d.max_distance, d.dist_param, d.a0,
+                             d.a1, d.b0, d.b1, d.bidirectional, nullptr, workspace,
+                             workspace_bytes, B, N, F, stream);
+    else
+      rc = GCM_EINVAL;
+    if (rc) return rc;
+  }
+  return GCM_OK;
+}
+}  // namespace
+
+extern "C" int gcm_dense_step_fwd(const float* obs, const float* nodes_in, const float* adj_in,
+                                  const int64_t* count_in, float* nodes_out, float* adj_out,
+                                  int64_t* cur_out, int64_t* count_out,
+                                  const gcm_selector_desc* selectors, int n_selectors,
+                                  const float* params, int has_bias, int act1, int act2, float* mx,
+                                  float* h1, float* agg1, float* agg2, uint32_t* flags,
+                                  void* workspace, size_t workspace_bytes, int B, int N, int F,
+                                  int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_in && adj_in && count_in && nodes_out && adj_out && cur_out &&
+              count_out && params && mx && flags);
+  GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0));
+  if (!gcm_dense_gnn2_row_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  const Unpacked u = unpack(params, has_bias, F, H1, H2);
+  int rc = gcm_dense_step_fused_fwd(obs, nodes_in, adj_in, count_in, nodes_out, adj_out, cur_out,
+                                    count_out, selectors, n_selectors, u.w_rel1, u.b1, u.w_root1,
+                                    act1, u.w_rel2, u.b2, u.w_root2, act2, mx, h1, agg1, agg2,
+                                    flags, B, N, F, H1, H2, stream);
+  if (rc != GCM_EUNSUPPORTED) return rc;   // done in one kernel (or a real error)
+  rc = gcm_state_advance_fwd(nodes_in, adj_in, nullptr, count_in, obs, nodes_out, adj_out,
+                             nullptr, cur_out, count_out, flags, B, N, F, stream);
+  if (rc) return rc;
+  rc = run_selectors(selectors, n_selectors, nodes_out, adj_out, cur_out, workspace,
+                     workspace_bytes, B, N, F, stream);
+  if (rc) return rc;
+  return gcm_dense_gnn2_row_fwd(nodes_out, adj_out, cur_out, u.w_rel1, u.b1, u.w_root1, act1,
+                                u.w_rel2, u.b2, u.w_root2, act2, mx, h1, agg1, agg2, flags, B, N,
+                                F, H1, H2, stream);
+}
+
+extern "C" int gcm_dense_step_bwd(const float* g_mx, const float* g_nodes_out,
+                                  const float* nodes_out, const float* adj_out,
+                                  const int64_t* cur, const int64_t* count_in, const float* params,
+                                  int has_bias, int act1, int act2, const float* mx,
+                                  const float* h1, const float* agg1, const float* agg2,
+                                  float* g_nodes_in, float* g_obs, float* g_params,
+                                  void* workspace, size_t workspace_bytes, int B, int N, int F,
+                                  int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(params && g_params && workspace);
+  const size_t P = gcm_dense_gnn2_param_count(F, H1, H2);
+  if (workspace_bytes < sizeof(float) * (size_t)B * P) return GCM_EWORKSPACE;
+  const Unpacked u = unpack(params, has_bias, F, H1, H2);
+  float* slabs = (float*)workspace;
+  int rc = gcm_dense_gnn2_row_bwd(g_mx, g_nodes_out, nodes_out, adj_out, cur, count_in, u.w_rel1,
+                                  u.b1, u.w_root1, act1, u.w_rel2, u.b2, u.w_root2, act2, mx, h1,
+                                  agg1, agg2, g_nodes_in, g_obs, slabs, 0, B, N, F, H1, H2, stream);
+  if (rc) return rc;
+  return gcm_sum_slabs(slabs, B, (int)P, g_params, stream);
+}
+
 extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all,
                                      int64_t* count_all, int64_t* cur_all,
                                      const gcm_selector_desc* selectors, int n_selectors,
@@ -24,29 +112,27 @@ extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* 
     const float* adj_in = adj_all + (size_t)t * adj_sz;
     float* adj_out = adj_all + (size_t)(t + 1) * adj_sz;
     int64_t* cur = cur_all + (size_t)t * B;
-    int rc = gcm_state_advance_fwd(nodes_in, adj_in, nullptr, count_all + (size_t)t * B,
-                                   obs + (size_t)t * B * F, nodes_out, adj_out, nullptr, cur,
-                                   count_all + (size_t)(t + 1) * B, flags, B, N, F, stream);
+    float* mx_t = mx_all + (size_t)t * B * H2;
+    float* h1_t = h1_all ? h1_all + (size_t)t * B * N * H1 : nullptr;
+    float* agg1_t = agg1_all ? agg1_all + (size_t)t * nodes_sz : nullptr;
+    float* agg2_t = agg2_all ? agg2_all + (size_t)t * B * H1 : nullptr;
+    int rc = gcm_dense_step_fused_fwd(obs + (size_t)t * B * F, nodes_in, adj_in,
+                                      count_all + (size_t)t * B, nodes_out, adj_out, cur,
+                                      count_all + (size_t)(t + 1) * B, selectors, n_selectors,
+                                      w_rel1, b_rel1, w_root1, act1, w_rel2, b_rel2, w_root2, act2,
+                                      mx_t, h1_t, agg1_t, agg2_t, flags, B, N, F, H1, H2, stream);
+    if (rc == GCM_OK) continue;              // the whole step ran as one kernel
+    if (rc != GCM_EUNSUPPORTED) return rc;
+    rc = gcm_state_advance_fwd(nodes_in, adj_in, nullptr, count_all + (size_t)t * B,
+                               obs + (size_t)t * B * F, nodes_out, adj_out, nullptr, cur,
+                               count_all + (size_t)(t + 1) * B, flags, B, N, F, stream);
     if (rc) return rc;
-    for (int i = 0; i < n_selectors; ++i) {
-      const gcm_selector_desc& d = selectors[i];
-      if (d.kind == GCM_SEL_TEMPORAL)
-        rc = gcm_edge_temporal(adj_out, cur, d.hops, d.n_hops, d.direction, B, N, stream);
-      else if (d.kind == GCM_SEL_DENSE)
-        rc = gcm_edge_dense(adj_out, cur, B, N, stream);
-      else if (d.kind == GCM_SEL_DISTANCE)
-        rc = gcm_edge_distance(nodes_out, adj_out, cur, d.mode, d.max_distance, d.dist_param, d.a0,
-                               d.a1, d.b0, d.b1, d.bidirectional, nullptr, workspace,
-                               workspace_bytes, B, N, F, stream);
-      else
-        rc = GCM_EINVAL;
-      if (rc) return rc;
-    }
-    rc = gcm_dense_gnn2_row_fwd(
-        nodes_out, adj_out, cur, w_rel1, b_rel1, w_root1, act1, w_rel2, b_rel2, w_root2, act2,
-        mx_all + (size_t)t * B * H2, h1_all ? h1_all + (size_t)t * B * N * H1 : nullptr,
-        agg1_all ? agg1_all + (size_t)t * nodes_sz : nullptr,
-        agg2_all ? agg2_all + (size_t)t * B * H1 : nullptr, flags, B, N, F, H1, H2, stream);
+    rc = run_selectors(selectors, n_selectors, nodes_out, adj_out, cur, workspace, workspace_bytes,
+                       B, N, F, stream);
+    if (rc) return rc;
+    rc = gcm_dense_gnn2_row_fwd(nodes_out, adj_out, cur, w_rel1, b_rel1, w_root1, act1, w_rel2,
+                                b_rel2, w_root2, act2, mx_t, h1_t, agg1_t, agg2_t, flags, B, N, F,
+                                H1, H2, stream);
     if (rc) return rc;
   }
   return GCM_OK;

@@ -563,105 +563,131 @@ def gnn2_supported(N, F, H1, H2):
     return bool(_hip.lib().gcm_dense_gnn2_row_supported(N, F, H1, H2))
 
 
-def _split_params(flat, F, H1, H2):
-    """views of a flat slab: dW_rel1, dW_root1, db1, dW_rel2, dW_root2, db2"""
-    sizes = [H1 * F, H1 * F, H1, H2 * H1, H2 * H1, H2]
-    shapes = [(H1, F), (H1, F), (H1,), (H2, H1), (H2, H1), (H2,)]
-    out, off = [], 0
-    for n, shp in zip(sizes, shapes):
-        out.append(flat[off:off + n].view(shp))
-        off += n
-    return out
+class StepConfig:
+    """Everything static about a fused DenseGCM configuration (built once per module/shape)."""
+
+    def __init__(self, descs, acts, has_bias, N, F, H1, H2, device):
+        lib = _hip.lib()
+        self.descs = descs
+        self.arr = (_hip.SelectorDesc * max(1, len(descs)))(*descs)
+        self.arr_ptr = ctypes.addressof(self.arr)
+        self.n_desc = len(descs)
+        self.acts, self.has_bias = acts, has_bias
+        self.N, self.F, self.H1, self.H2 = N, F, H1, H2
+        self.P = lib.gcm_dense_gnn2_param_count(F, H1, H2)
+        self.ws_bytes = 0
+        self.ws = None
+        self.device = device
+
+    def workspace(self, B):
+        need = 0
+        for d in self.descs:
+            if d.kind == _hip.SEL_DISTANCE:
+                need = max(need, _hip.lib().gcm_edge_distance_workspace_bytes(d.mode, B, self.N, self.F))
+        if need > self.ws_bytes:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.ws_bytes = need
+        return (self.ws.data_ptr() if self.ws is not None else None), self.ws_bytes
+
+    def unpack_ptrs(self, packed):
+        """device pointers (w_rel1, b1, w_root1, w_rel2, b2, w_root2) into the packed vector"""
+        F, H1, H2 = self.F, self.H1, self.H2
+        base = packed.data_ptr()
+        w_rel1 = base
+        w_root1 = w_rel1 + 4 * H1 * F
+        b1 = w_root1 + 4 * H1 * F
+        w_rel2 = b1 + 4 * H1
+        w_root2 = w_rel2 + 4 * H2 * H1
+        b2 = w_root2 + 4 * H2 * H1
+        return (w_rel1, b1 if self.has_bias & 1 else None, w_root1,
+                w_rel2, b2 if self.has_bias & 2 else None, w_root2)
 
 
-def state_advance_raw(nodes, adj, num_nodes, x, flags):
-    """gcm_state_advance_fwd outside autograd (no weights plane)."""
-    nodes, adj, x = nodes.contiguous(), adj.contiguous(), x.contiguous()
-    _hip.on_device(nodes, adj, num_nodes, x, flags)
-    B, N, F = nodes.shape
-    nodes_out, adj_out = torch.empty_like(nodes), torch.empty_like(adj)
-    cur, nn_out = torch.empty_like(num_nodes), torch.empty_like(num_nodes)
-    _call("gcm_state_advance_fwd", _hip.ptr(nodes), _hip.ptr(adj), None, _hip.ptr(num_nodes),
-          _hip.ptr(x), _hip.ptr(nodes_out), _hip.ptr(adj_out), None, _hip.ptr(cur),
-          _hip.ptr(nn_out), _hip.ptr(flags), B, N, F, _hip.stream())
-    return nodes_out, adj_out, cur, nn_out
+def _pad64(n):
+    return (n + 63) & ~63
 
 
 class _FusedStep(torch.autograd.Function):
-    """One DenseGCM step as ONE autograd node: (obs, nodes_in, params) -> (mx, nodes_out).
-    nodes_out/adj_out/cur were produced by state_advance_raw + the (non-differentiable)
-    selectors; this node runs the fused two-layer GNN and owns the whole adjoint."""
+    """One DenseGCM step as ONE autograd node and ONE C call per direction
+    (gcm_dense_step_fwd / gcm_dense_step_bwd): (obs, nodes_in, packed params) ->
+    (mx, nodes_out, adj_out, cur, count_out).  Outputs and the activations saved for backward
+    live in one allocation."""
 
     @staticmethod
-    def forward(ctx, obs, nodes_in, nodes_out, adj_out, cur, num_nodes_in, flags, acts,
-                w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2):
-        B, N, F = nodes_out.shape
-        H1, H2 = w_rel1.shape[0], w_rel2.shape[0]
-        dev = nodes_out.device
+    def forward(ctx, obs, nodes_in, packed, adj_in, count_in, flags, cfg):
+        obs, nodes_in, adj_in = obs.contiguous(), nodes_in.contiguous(), adj_in.contiguous()
+        B = obs.shape[0]
+        N, F, H1, H2 = cfg.N, cfg.F, cfg.H1, cfg.H2
+        dev = obs.device
         need_bwd = any(ctx.needs_input_grad)
-        mx = torch.empty(B, H2, device=dev, dtype=_f32)
-        h1 = torch.empty(B, N, H1, device=dev, dtype=_f32) if need_bwd else None
-        agg1 = torch.empty(B, N, F, device=dev, dtype=_f32) if need_bwd else None
-        agg2 = torch.empty(B, H1, device=dev, dtype=_f32) if need_bwd else None
-        _call("gcm_dense_gnn2_row_fwd", _hip.ptr(nodes_out), _hip.ptr(adj_out), _hip.ptr(cur),
-              _hip.ptr(w_rel1), _hip.ptr(b_rel1), _hip.ptr(w_root1), acts[0], _hip.ptr(w_rel2),
-              _hip.ptr(b_rel2), _hip.ptr(w_root2), acts[1], _hip.ptr(mx), _hip.ptr(h1),
-              _hip.ptr(agg1), _hip.ptr(agg2), _hip.ptr(flags), B, N, F, H1, H2, _hip.stream())
-        ctx.save_for_backward(nodes_out, adj_out, cur, num_nodes_in, mx, h1, agg1, agg2,
-                              w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2)
-        ctx.acts = acts
-        ctx.dims = (B, N, F, H1, H2)
-        return mx, nodes_out
+        n_nodes, n_adj, n_mx = _pad64(B * N * F), _pad64(B * N * N), _pad64(B * H2)
+        n_h1, n_agg2 = _pad64(B * N * H1), _pad64(B * H1)
+        total = n_nodes + n_adj + n_mx + ((n_h1 + n_nodes + n_agg2) if need_bwd else 0)
+        buf = torch.empty(total, device=dev, dtype=_f32)
+        ibuf = torch.empty(2, B, device=dev, dtype=torch.int64)
+        base = buf.data_ptr()
+        p_nodes = base
+        p_adj = p_nodes + 4 * n_nodes
+        p_mx = p_adj + 4 * n_adj
+        p_h1 = p_mx + 4 * n_mx if need_bwd else None
+        p_agg1 = p_h1 + 4 * n_h1 if need_bwd else None
+        p_agg2 = p_agg1 + 4 * n_nodes if need_bwd else None
+        ws_ptr, ws_bytes = cfg.workspace(B)
+        ib = ibuf.data_ptr()
+        _call("gcm_dense_step_fwd", obs.data_ptr(), nodes_in.data_ptr(), adj_in.data_ptr(),
+              count_in.data_ptr(), p_nodes, p_adj, ib, ib + 8 * B, cfg.arr_ptr, cfg.n_desc,
+              packed.data_ptr(), cfg.has_bias, cfg.acts[0], cfg.acts[1], p_mx, p_h1, p_agg1, p_agg2,
+              flags.data_ptr(), ws_ptr, ws_bytes, B, N, F, H1, H2, _hip.stream())
+        nodes_out = buf[:B * N * F].view(B, N, F)
+        adj_out = buf[n_nodes:n_nodes + B * N * N].view(B, N, N)
+        mx = buf[n_nodes + n_adj:n_nodes + n_adj + B * H2].view(B, H2)
+        cur, count_out = ibuf[0], ibuf[1]
+        ctx.save_for_backward(buf, ibuf, count_in, packed)
+        ctx.cfg, ctx.B = cfg, B
+        ctx.ptrs = (p_nodes, p_adj, p_mx, p_h1, p_agg1, p_agg2)
+        ctx.mark_non_differentiable(adj_out, cur, count_out)
+        return mx, nodes_out, adj_out, cur, count_out
 
     @staticmethod
-    def backward(ctx, g_mx, g_nodes_out):
-        (nodes_out, adj_out, cur, nn_in, mx, h1, agg1, agg2,
-         w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2) = ctx.saved_tensors
-        B, N, F, H1, H2 = ctx.dims
-        dev = nodes_out.device
-        lib = _hip.lib()
-        P = lib.gcm_dense_gnn2_param_count(F, H1, H2)
+    def backward(ctx, g_mx, g_nodes_out, _ga, _gc, _gn):
+        buf, ibuf, count_in, packed = ctx.saved_tensors
+        cfg, B = ctx.cfg, ctx.B
+        N, F, H1, H2, P = cfg.N, cfg.F, cfg.H1, cfg.H2, cfg.P
+        dev = buf.device
+        p_nodes, p_adj, p_mx, p_h1, p_agg1, p_agg2 = ctx.ptrs
         if g_mx is None:
             g_mx = torch.zeros(B, H2, device=dev)
         g_mx = g_mx.contiguous()
-        g_nodes_out = None if g_nodes_out is None else g_nodes_out.contiguous()
-        g_nodes_in = torch.empty(B, N, F, device=dev, dtype=_f32)
-        g_obs = torch.empty(B, F, device=dev, dtype=_f32)
-        slabs = torch.empty(B, P, device=dev, dtype=_f32)
-        _call("gcm_dense_gnn2_row_bwd", _hip.ptr(g_mx), _hip.ptr(g_nodes_out), _hip.ptr(nodes_out),
-              _hip.ptr(adj_out), _hip.ptr(cur), _hip.ptr(nn_in), _hip.ptr(w_rel1), _hip.ptr(b_rel1),
-              _hip.ptr(w_root1), ctx.acts[0], _hip.ptr(w_rel2), _hip.ptr(b_rel2), _hip.ptr(w_root2),
-              ctx.acts[1], _hip.ptr(mx), _hip.ptr(h1), _hip.ptr(agg1), _hip.ptr(agg2),
-              _hip.ptr(g_nodes_in), _hip.ptr(g_obs), _hip.ptr(slabs), 0, B, N, F, H1, H2,
-              _hip.stream())
-        flat = torch.empty(P, device=dev, dtype=_f32)
-        _call("gcm_sum_slabs", _hip.ptr(slabs), B, P, _hip.ptr(flat), _hip.stream())
-        g = _split_params(flat, F, H1, H2)
+        g_no = None if g_nodes_out is None else g_nodes_out.contiguous()
+        n_nodes, n_obs, n_p = _pad64(B * N * F), _pad64(B * F), _pad64(P)
+        out = torch.empty(n_nodes + n_obs + n_p + B * P, device=dev, dtype=_f32)
+        ob = out.data_ptr()
+        _call("gcm_dense_step_bwd", g_mx.data_ptr(), None if g_no is None else g_no.data_ptr(),
+              p_nodes, p_adj, ibuf.data_ptr(), count_in.data_ptr(), packed.data_ptr(), cfg.has_bias,
+              cfg.acts[0], cfg.acts[1], p_mx, p_h1, p_agg1, p_agg2, ob, ob + 4 * n_nodes,
+              ob + 4 * (n_nodes + n_obs), ob + 4 * (n_nodes + n_obs + n_p), 4 * B * P, B, N, F, H1,
+              H2, _hip.stream())
         need = ctx.needs_input_grad
-        return (g_obs if need[0] else None, g_nodes_in if need[1] else None, None, None, None,
-                None, None, None,
-                g[0], g[2] if b_rel1 is not None else None, g[1],
-                g[3], g[5] if b_rel2 is not None else None, g[4])
+        g_nodes_in = out[:B * N * F].view(B, N, F) if need[1] else None
+        g_obs = out[n_nodes:n_nodes + B * F].view(B, F) if need[0] else None
+        g_params = out[n_nodes + n_obs:n_nodes + n_obs + P] if need[2] else None
+        return g_obs, g_nodes_in, g_params, None, None, None, None
 
 
-def fused_step(obs, nodes_in, nodes_out, adj_out, cur, num_nodes_in, flags, acts, params):
-    return _FusedStep.apply(obs, nodes_in, nodes_out, adj_out, cur, num_nodes_in, flags, acts,
-                            *params)
+def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg):
+    return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg)
 
 
 class _FusedRollout(torch.autograd.Function):
     """T DenseGCM steps as ONE autograd node (gcm_dense_rollout_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, obs, nodes0, adj0, num_nodes0, flags, descs, acts,
-                w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2):
+    def forward(ctx, obs, nodes0, packed, adj0, num_nodes0, flags, cfg):
         obs = obs.contiguous()
         _hip.on_device(obs, nodes0, adj0, num_nodes0, flags)
         T, B, F = obs.shape
-        N = nodes0.shape[1]
-        H1, H2 = w_rel1.shape[0], w_rel2.shape[0]
+        N, H1, H2 = cfg.N, cfg.H1, cfg.H2
         dev = obs.device
-        lib = _hip.lib()
         need_bwd = any(ctx.needs_input_grad)
         nodes_all = torch.empty(T + 1, B, N, F, device=dev, dtype=_f32)
         adj_all = torch.empty(T + 1, B, N, N, device=dev, dtype=_f32)
@@ -674,21 +700,16 @@ class _FusedRollout(torch.autograd.Function):
         h1_all = torch.empty(T, B, N, H1, device=dev, dtype=_f32) if need_bwd else None
         agg1_all = torch.empty(T, B, N, F, device=dev, dtype=_f32) if need_bwd else None
         agg2_all = torch.empty(T, B, H1, device=dev, dtype=_f32) if need_bwd else None
-        arr = (_hip.SelectorDesc * max(1, len(descs)))(*descs)
-        ws_bytes = 0
-        for d in descs:
-            if d.kind == _hip.SEL_DISTANCE:
-                ws_bytes = max(ws_bytes, lib.gcm_edge_distance_workspace_bytes(d.mode, B, N, F))
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        ws_ptr, ws_bytes = cfg.workspace(B)
+        w = cfg.unpack_ptrs(packed)
         _call("gcm_dense_rollout_fwd", _hip.ptr(obs), _hip.ptr(nodes_all), _hip.ptr(adj_all),
-              _hip.ptr(count_all), _hip.ptr(cur_all), ctypes.addressof(arr), len(descs),
-              _hip.ptr(w_rel1), _hip.ptr(b_rel1), _hip.ptr(w_root1), acts[0], _hip.ptr(w_rel2),
-              _hip.ptr(b_rel2), _hip.ptr(w_root2), acts[1], _hip.ptr(mx_all), _hip.ptr(h1_all),
-              _hip.ptr(agg1_all), _hip.ptr(agg2_all), _hip.ptr(flags), _hip.ptr(ws), ws_bytes,
-              T, B, N, F, H1, H2, _hip.stream())
+              _hip.ptr(count_all), _hip.ptr(cur_all), cfg.arr_ptr, cfg.n_desc,
+              w[0], w[1], w[2], cfg.acts[0], w[3], w[4], w[5], cfg.acts[1], _hip.ptr(mx_all),
+              _hip.ptr(h1_all), _hip.ptr(agg1_all), _hip.ptr(agg2_all), _hip.ptr(flags), ws_ptr,
+              ws_bytes, T, B, N, F, H1, H2, _hip.stream())
         ctx.save_for_backward(nodes_all, adj_all, count_all, cur_all, mx_all, h1_all, agg1_all,
-                              agg2_all, w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2)
-        ctx.acts, ctx.dims = acts, (T, B, N, F, H1, H2)
+                              agg2_all, packed)
+        ctx.cfg, ctx.dims = cfg, (T, B)
         # clones: a view would pin the whole [T+1, ...] history for as long as the hidden lives
         nodes_T, adj_T, count_T = nodes_all[T].clone(), adj_all[T].clone(), count_all[T].clone()
         ctx.mark_non_differentiable(adj_T, count_T)
@@ -697,11 +718,12 @@ class _FusedRollout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_mx_all, g_nodes_T, _g_adj, _g_count):
         (nodes_all, adj_all, count_all, cur_all, mx_all, h1_all, agg1_all, agg2_all,
-         w_rel1, b_rel1, w_root1, w_rel2, b_rel2, w_root2) = ctx.saved_tensors
-        T, B, N, F, H1, H2 = ctx.dims
+         packed) = ctx.saved_tensors
+        cfg = ctx.cfg
+        T, B = ctx.dims
+        N, F, H1, H2, P = cfg.N, cfg.F, cfg.H1, cfg.H2, cfg.P
         dev = nodes_all.device
         lib = _hip.lib()
-        P = lib.gcm_dense_gnn2_param_count(F, H1, H2)
         if g_mx_all is None:
             g_mx_all = torch.zeros(T, B, H2, device=dev)
         g_mx_all = g_mx_all.contiguous()
@@ -711,19 +733,16 @@ class _FusedRollout(torch.autograd.Function):
         flat = torch.empty(P, device=dev, dtype=_f32)
         ws_bytes = lib.gcm_dense_rollout_bwd_workspace_bytes(B, N, F, H1, H2)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        w = cfg.unpack_ptrs(packed)
         _call("gcm_dense_rollout_bwd", _hip.ptr(g_mx_all), _hip.ptr(g_nodes_T), _hip.ptr(nodes_all),
-              _hip.ptr(adj_all), _hip.ptr(count_all), _hip.ptr(cur_all), _hip.ptr(w_rel1),
-              _hip.ptr(b_rel1), _hip.ptr(w_root1), ctx.acts[0], _hip.ptr(w_rel2), _hip.ptr(b_rel2),
-              _hip.ptr(w_root2), ctx.acts[1], _hip.ptr(mx_all), _hip.ptr(h1_all),
+              _hip.ptr(adj_all), _hip.ptr(count_all), _hip.ptr(cur_all), w[0], w[1], w[2],
+              cfg.acts[0], w[3], w[4], w[5], cfg.acts[1], _hip.ptr(mx_all), _hip.ptr(h1_all),
               _hip.ptr(agg1_all), _hip.ptr(agg2_all), _hip.ptr(g_obs), _hip.ptr(g_nodes0),
               _hip.ptr(flat), _hip.ptr(ws), ws_bytes, T, B, N, F, H1, H2, _hip.stream())
-        g = _split_params(flat, F, H1, H2)
         need = ctx.needs_input_grad
-        return (g_obs if need[0] else None, g_nodes0 if need[1] else None, None, None, None, None,
-                None,
-                g[0], g[2] if b_rel1 is not None else None, g[1],
-                g[3], g[5] if b_rel2 is not None else None, g[4])
+        return (g_obs if need[0] else None, g_nodes0 if need[1] else None,
+                flat if need[2] else None, None, None, None, None)
 
 
-def fused_rollout(obs, nodes0, adj0, num_nodes0, flags, descs, acts, params):
-    return _FusedRollout.apply(obs, nodes0, adj0, num_nodes0, flags, descs, acts, *params)
+def fused_rollout(obs, nodes0, packed, adj0, num_nodes0, flags, cfg):
+    return _FusedRollout.apply(obs, nodes0, packed, adj0, num_nodes0, flags, cfg)

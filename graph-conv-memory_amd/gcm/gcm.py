@@ -60,6 +60,8 @@ class DenseGCM(torch.nn.Module):
         # kernels + ONE fused GNN kernel under ONE autograd node (csrc/fused.hip)
         self.fused = fused
         self._plan_cache = None
+        self._cfg_cache = {}
+        self._packed_cache = None
         self._flags = {}      # device -> uint32[1] flag word written by the kernels
         self._pending = []    # [(pinned host copy, event)] of flag words in flight
         self._steps = 0
@@ -181,31 +183,57 @@ class DenseGCM(torch.nn.Module):
         return self._plan_cache[0]
 
     def _fused_plan(self, nodes, adj, weights, F):
+        """StepConfig for the fused kernels, or None when this call must take the layered path."""
         st = self._structure()
         if st is None or weights.numel() != 0 or adj.requires_grad or not nodes.is_cuda:
             return None
+        key = (nodes.shape[1], F, nodes.device)
+        cached = self._cfg_cache.get(key)
+        if cached is not None:
+            return cached if cached is not False else None
+        from .edge_selectors.distance import Distance
         convs, acts, mods = st
-        if convs[0].in_channels != F:
-            return None
-        if not _ops.gnn2_supported(nodes.shape[1], F, convs[0].out_channels,
-                                   convs[1].out_channels):
-            return None
-        params = (convs[0].lin_rel.weight, convs[0].lin_rel.bias, convs[0].lin_root.weight,
-                  convs[1].lin_rel.weight, convs[1].lin_rel.bias, convs[1].lin_root.weight)
-        return acts, params, mods
+        N, H1, H2 = nodes.shape[1], convs[0].out_channels, convs[1].out_channels
+        cfg = False
+        if convs[0].in_channels == F and _ops.gnn2_supported(N, F, H1, H2):
+            descs = [m.native_desc(F) if isinstance(m, Distance) else m.native_desc() for m in mods]
+            if all(d is not None for d in descs):
+                has_bias = (1 if convs[0].lin_rel.bias is not None else 0) | \
+                           (2 if convs[1].lin_rel.bias is not None else 0)
+                cfg = _ops.StepConfig(descs, acts, has_bias, N, F, H1, H2, nodes.device)
+                cfg.convs = convs
+        self._cfg_cache[key] = cfg
+        return cfg if cfg is not False else None
 
-    def _forward_fused(self, x, nodes, adj, weights, num_nodes, plan, flags):
-        acts, params, mods = plan
-        B = x.shape[0]
-        with torch.no_grad():
-            nodes_out, adj_out, cur, num_nodes_next = _ops.state_advance_raw(
-                nodes.detach(), adj, num_nodes, x.detach(), flags)
-            if self.mutate_num_nodes_on_overflow:
-                num_nodes.copy_(cur)
-            for m in mods:
-                adj_out, weights = m(nodes_out, adj_out, weights, cur, B)
-        mx, nodes_out = _ops.fused_step(x, nodes, nodes_out, adj_out, cur, num_nodes, flags, acts,
-                                        params)
+    def _packed_params(self, cfg):
+        """The six GNN tensors as one flat vector (layout of include/gcm_hip.h "packed parameter
+        vector"), so that a step returns ONE gradient tensor.  Rebuilt when a parameter changed
+        or after the previous vector took part in a backward pass."""
+        c0, c1 = cfg.convs
+        tensors = (c0.lin_rel.weight, c0.lin_root.weight, c0.lin_rel.bias,
+                   c1.lin_rel.weight, c1.lin_root.weight, c1.lin_rel.bias)
+        key = tuple((id(t), t._version) for t in tensors if t is not None) + \
+            (torch.is_grad_enabled(),)
+        cache = self._packed_cache
+        if cache is not None and cache[0] == key and not cache[2][0]:
+            return cache[1]
+        sizes = (cfg.H1 * cfg.F, cfg.H1 * cfg.F, cfg.H1, cfg.H2 * cfg.H1, cfg.H2 * cfg.H1, cfg.H2)
+        dev = c0.lin_rel.weight.device
+        parts = [t.reshape(-1) if t is not None else torch.zeros(n, device=dev)
+                 for t, n in zip(tensors, sizes)]
+        packed = torch.cat(parts)
+        used = [False]
+        if packed.requires_grad:
+            packed.register_hook(lambda g: used.__setitem__(0, True))
+        self._packed_cache = (key, packed, used)
+        return packed
+
+    def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags):
+        packed = self._packed_params(cfg)
+        mx, nodes_out, adj_out, cur, num_nodes_next = _ops.fused_step(
+            x, nodes, packed, adj, num_nodes, flags, cfg)
+        if self.mutate_num_nodes_on_overflow:
+            num_nodes.copy_(cur)
         if self.finite_check != "off":
             self._poll(flags)
         return mx, (nodes_out, adj_out, weights, num_nodes_next)
@@ -219,21 +247,16 @@ class DenseGCM(torch.nn.Module):
         if hidden is None:
             hidden = self.get_initial_hidden_state(obs[0])
         nodes, adj, weights, num_nodes = hidden
-        plan = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
-        native_only = plan is not None and all(hasattr(m, "native_desc") for m in plan[2])
-        if not native_only:
+        cfg = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
+        if cfg is None:
             outs = []
             for t in range(obs.shape[0]):
                 mx, hidden = self(obs[t], hidden)
                 outs.append(mx)
             return torch.stack(outs), hidden
-        from .edge_selectors.distance import Distance
-        acts, params, mods = plan
-        descs = [m.native_desc(obs.shape[-1]) if isinstance(m, Distance) else m.native_desc()
-                 for m in mods]
         flags = self._flag_word(obs.device)
         mx_all, nodes_T, adj_T, count_T = _ops.fused_rollout(
-            obs, nodes, adj, num_nodes, flags, descs, acts, params)
+            obs, nodes, self._packed_params(cfg), adj, num_nodes, flags, cfg)
         if self.finite_check == "sync":
             self.check_flags()
         return mx_all, (nodes_T, adj_T, weights, count_T)

@@ -272,8 +272,6 @@ int gcm_dense_gnn2_row_bwd(const float* g_mx, const float* g_nodes_out, const fl
 /* out[e] = sum_i slabs[i, e]  (fixed order, deterministic) */
 int gcm_sum_slabs(const float* slabs, int n_slabs, int len, float* out, gcm_stream_t stream);
 
-/* ---- time-batched rollout (SURVEY 8f rank 1; caller loop ray_gcm.py:200-202) --------- */
-
 /* One native edge selector of the per-step chain (host struct). */
 #define GCM_SEL_TEMPORAL 1
 #define GCM_SEL_DENSE 2
@@ -289,6 +287,48 @@ typedef struct gcm_selector_desc {
   int a0, a1, b0, b1;     /* distance: pose slices                                   */
   int bidirectional;      /* distance                                                */
 } gcm_selector_desc;
+
+/* ---- one DenseGCM step per call (the per-step drop-in API, gcm.py:213-321) ------------ */
+
+/* Packed parameter vector used by the step/rollout drivers (same layout as a gradient slab):
+ * w_rel1 [H1*F] | w_root1 [H1*F] | b_rel1 [H1] | w_rel2 [H2*H1] | w_root2 [H2*H1] | b_rel2 [H2]. */
+
+/* state advance + native selector chain + fused GNN, enqueued by ONE call (what
+ * DenseGCM.forward does on the fused path).  has_bias: bit0 = layer 1, bit1 = layer 2. */
+int gcm_dense_step_fwd(const float* obs, const float* nodes_in, const float* adj_in,
+                       const int64_t* count_in, float* nodes_out, float* adj_out,
+                       int64_t* cur_out, int64_t* count_out, const gcm_selector_desc* selectors,
+                       int n_selectors, const float* params, int has_bias, int act1, int act2,
+                       float* mx, float* h1, float* agg1, float* agg2, uint32_t* flags,
+                       void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
+                       int H2, gcm_stream_t stream);
+
+/* ONE kernel per forward step: state advance (gcm.py:262-278, 323-355) + temporal/dense selector
+ * writes + fused GNN (k_step_fwd).  Only the index-writing selectors can be folded
+ * (GCM_SEL_TEMPORAL / GCM_SEL_DENSE) and N % 4 == F % 4 == 0 is required; returns
+ * GCM_EUNSUPPORTED otherwise - gcm_dense_step_fwd / gcm_dense_rollout_fwd then use the
+ * three-kernel sequence themselves. */
+int gcm_dense_step_fused_fwd(const float* obs, const float* nodes_in, const float* adj_in,
+                             const int64_t* count_in, float* nodes_out, float* adj_out,
+                             int64_t* cur_out, int64_t* count_out,
+                             const gcm_selector_desc* selectors, int n_selectors,
+                             const float* w_rel1, const float* b_rel1, const float* w_root1,
+                             int act1, const float* w_rel2, const float* b_rel2,
+                             const float* w_root2, int act2, float* mx, float* h1, float* agg1,
+                             float* agg2, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                             gcm_stream_t stream);
+
+/* gcm_dense_gnn2_row_bwd + gcm_sum_slabs in one call: g_params [param_count] is overwritten.
+ * workspace: B * param_count floats. */
+int gcm_dense_step_bwd(const float* g_mx, const float* g_nodes_out, const float* nodes_out,
+                       const float* adj_out, const int64_t* cur, const int64_t* count_in,
+                       const float* params, int has_bias, int act1, int act2, const float* mx,
+                       const float* h1, const float* agg1, const float* agg2, float* g_nodes_in,
+                       float* g_obs, float* g_params, void* workspace, size_t workspace_bytes,
+                       int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+
+/* ---- time-batched rollout (SURVEY 8f rank 1; caller loop ray_gcm.py:200-202) --------- */
+
 
 /* T DenseGCM steps in one call: for t in [0,T): state advance, the selector chain, fused GNN,
  * exactly what T calls of DenseGCM.forward do.  State arrays hold every step (needed by BPTT):
