@@ -26,6 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak; no TF32 on gfx950
 B, N, F, H = 256, 128, 32, 32
 HOPS = [1, 2, 4]
@@ -97,8 +98,24 @@ def time_dominant_kernels(mem, obs, reps=200):
                                           w[3], w[4], w[5], 1, p(mx), p(h1), p(agg1), p(agg2), p(g_ni),
                                           p(g_obs), p(slabs), 0, B, N, F, H, H, st)
 
+    # the one-kernel forward step (advance + selector + GNN) on the state one step earlier
+    with torch.no_grad():
+        hid = None
+        for t in range(obs.shape[0] - 1):
+            _, hid = mem(obs[t], hid)
+    n_in, a_in, _, c_in = hid
+    n_out, a_out = torch.empty_like(n_in), torch.empty_like(a_in)
+    ibuf = torch.empty(2, B, dtype=torch.int64, device=dev)
+    x_last = obs[-1].contiguous()
+
+    def step():
+        return lib.gcm_dense_step_fused_fwd(p(x_last), p(n_in), p(a_in), p(c_in), p(n_out), p(a_out),
+                                            ibuf.data_ptr(), ibuf.data_ptr() + 8 * B, cfg.arr_ptr, cfg.n_desc,
+                                            w[0], w[1], w[2], 1, w[3], w[4], w[5], 1, p(mx), p(h1), p(agg1),
+                                            p(agg2), p(flags), B, N, F, H, H, st)
+
     out = {}
-    for name, fn in (("k_gnn2_row_fwd", fwd), ("k_gnn2_row_bwd", bwd)):
+    for name, fn in (("k_step_fwd", step), ("k_gnn2_row_fwd", fwd), ("k_gnn2_row_bwd", bwd)):
         for _ in range(10):
             assert fn() == 0
         torch.cuda.synchronize()
@@ -239,25 +256,44 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath))
 
-        def roof(name, kernel, full, execd):
-            n_launch, ms = kern[name]
+        def mfma_view(kernel, full, execd):
+            n_launch, ms = kern[kernel]
             sec = ms * 1e-3
             return {"bound": "mfma", "kernel": kernel, "achieved": B * full / sec / 1e12,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": B * full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": traffic.get(kernel),
-                    "flops_per_launch": B * full, "avg_launch_ms": ms, "launches_timed": n_launch,
+                    "traffic": traffic.get(kernel), "flops_per_launch": B * full,
+                    "avg_launch_ms": ms, "launches_timed": n_launch,
                     "achieved_executed": B * execd / sec / 1e12,
-                    "frac_executed": B * execd / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "note": "achieved/frac use SURVEY 8(d)'s full-dense FLOPs (2 layers x all N rows); "
-                            "the kernel evaluates layer 2 only on the kept row (gcm.py:314) and skips "
-                            "all-zero 32x32 adjacency tiles: achieved_executed/frac_executed count the "
-                            "dense-layer-1 + row-layer-2 FLOPs (an upper bound of what was issued). "
-                            "avg_launch_ms: back-to-back launches on the end-of-rollout state (full graph)"}
+                    "frac_executed": B * execd / sec / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
-        r_f = roof("k_gnn2_row_fwd", "k_gnn2_row_fwd", fwd_full, fwd_exec)
-        r_b = roof("k_gnn2_row_bwd", "k_gnn2_row_bwd", 2 * fwd_full, bwd_exec)
-        dominant, other = (r_b, r_f) if r_b["avg_launch_ms"] >= r_f["avg_launch_ms"] else (r_f, r_b)
+        # Dominant kernel = k_step_fwd (one kernel per forward step).  It is HBM-bound in practice
+        # (AI 8-17 FLOP/B < ridge 20-25): SURVEY 8(d)'s compulsory bytes per belief state
+        # (adj once, x once, obs in, belief out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2)
+        # over its mean launch time; `functional` adds what the reference's functional state
+        # semantics force through HBM (adj + nodes copied out every step) and the activations
+        # saved for BPTT.
+        alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
+        func_bytes = B * (2 * 4 * N * N + 2 * 4 * N * F + 4 * F + 4 * H + 16 + 4 * N * H + 4 * N * F + 4 * H)
+        n_launch, ms = kern["k_step_fwd"]
+        sec = ms * 1e-3
+        dominant = {"bound": "hbm", "kernel": "k_step_fwd", "achieved": alg_bytes / sec / 1e9,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS,
+                    "traffic": traffic.get("k_step_fwd"), "bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": ms, "launches_timed": n_launch,
+                    "achieved_functional": func_bytes / sec / 1e9,
+                    "frac_functional": func_bytes / sec / 1e9 / PEAK_HBM_GBS,
+                    "functional_bytes_per_launch": func_bytes,
+                    "note": "bytes_per_launch = SURVEY 8(d) compulsory bytes (in-place state); the kernel "
+                            "also copies adj+nodes out (functional hidden state, gcm.py:262-286) and saves "
+                            "h1/agg1 for BPTT = functional_bytes_per_launch, which is what `traffic` "
+                            "(PMC: 2*FETCH_SIZE+WRITE_SIZE) measures. avg_launch_ms: 200 back-to-back "
+                            "launches on the end-of-rollout state, one HIP event pair"}
+        note = ("flops: SURVEY 8(d) full-dense (2 layers x all N rows); *_executed: dense layer 1 + "
+                "row-only layer 2 (gcm.py:314), an upper bound since all-zero 32x32 adjacency tiles are skipped")
+        other = [dict(mfma_view("k_gnn2_row_bwd", 2 * fwd_full, bwd_exec), note=note),
+                 dict(mfma_view("k_step_fwd", fwd_full, fwd_exec), note=note),
+                 dict(mfma_view("k_gnn2_row_fwd", fwd_full, fwd_exec), note=note)]
         line = {
             "metric": "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 F=32",
             "value": states / dt, "unit": "belief-states/s", "n_gpus": world,
@@ -269,7 +305,7 @@ def main():
                                    "through the per-step drop-in API `for t: mx, m = gcm(obs[t], m)` + backward" % T,
                        "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": T,
                        "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
-            "roofline": dominant, "roofline_other": other,
+            "roofline": dominant, "roofline_mfma_view": other,
             "kernel_ms": {k: round(v[1], 5) for k, v in kern.items()},
             "rollout_api": {"value": states / dt_roll, "unit": "belief-states/s",
                             "ms_per_step": dt_roll / args.steps * 1e3,
