@@ -644,7 +644,7 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
   GCM_REQUIRE(g_out && out && x && agg && w_rel && w_root && workspace);
   GCM_REQUIRE(M > 0 && E >= 0 && Fi > 0 && Fo > 0);
   GCM_REQUIRE((col_ptr && rows) || E == 0 || (!g_x && !g_w));
-  GCM_REQUIRE(!w || perm);
+  GCM_REQUIRE(!(w && (g_x || g_w) && E > 0) || perm);   // perm maps CSC entries to the CSR weights
   if (Fi > 128 || Fo > 128 || M > (int64_t)2147483647 - 256) return GCM_EUNSUPPORTED;
   BwdPlan p = bwd_plan(1, (int)M, Fi, Fo);
   if (!p.waves) return GCM_EUNSUPPORTED;

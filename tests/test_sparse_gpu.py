@@ -205,3 +205,17 @@ def test_user_gnn_gets_plain_tensors():
                         max_hops=max_hops)
         got, _ = mem(x.to(DEV), taus.to(DEV), None)
         torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_sparse_backward_without_input_grad():
+    """Regression: parameters are the only tensors that need gradients (obs without grad)."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    from gcm import nn as G
+    torch.manual_seed(0)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(4, 4), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(4, 4), "x, edges, weights -> x")]).to(DEV)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1]), graph_size=8)
+    out, _ = mem(torch.rand(3, 8, 4, device=DEV), torch.full((3,), 8, device=DEV), None)
+    out.mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in g.parameters())
