@@ -85,6 +85,127 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// EUCLID_CROSSBATCH on the matrix cores (B >= 32): the [N x B] block of squared distances of
+// one graph's nodes against ALL current rows is |n|^2 + |c|^2 - 2 n.c^T, i.e. a [N x F] x [F x B]
+// product (v_mfma_f32_32x32x2_f32) - the formulation torch.cdist itself switches to above 25
+// rows.  One workgroup = one graph x 128 node rows; the (scaled) current rows of all graphs sit
+// transposed in LDS ([F][B], shared by the four waves), each wave owns 32 node rows.  sqrt and
+// the mean over b' run on the accumulators; rows >= cur are skipped (distance.py:31-33).
+// ---------------------------------------------------------------------------
+template <int FT>   // F padded to 32*FT
+__global__ __launch_bounds__(256) void k_euclid_mfma(
+    const float* __restrict__ nodes, const float* __restrict__ ws_curT /* [F][B] */,
+    const float* __restrict__ ws_cnorm /* [B] */, const int64_t* __restrict__ cur_idx,
+    const float* __restrict__ dist_param, float* __restrict__ adj, float* __restrict__ dist_out,
+    float max_distance, int bidirectional, int B, int N, int F) {
+  constexpr int FP = 32 * FT, NS = FP + 1;
+  constexpr int CB = FT >= 4 ? 128 : 256;   // graphs per LDS chunk of current rows (fits 160 KB)
+  const int b = blockIdx.y, j0 = blockIdx.x * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int64_t cur64 = cur_idx[b];
+  const int cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
+  if (j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows
+
+  extern __shared__ float smem[];
+  float* sN = smem;                 // [128][NS]  node rows (scaled)
+  float* sC = sN + 128 * NS;        // [FP][CB]   current rows, transposed, one chunk of CB graphs
+  float* sNn = sC + FP * CB;        // [128] |n|^2
+  float* sCn = sNn + 128;           // [CB]  |c|^2
+
+  const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
+  // node rows of this block
+  for (int e = tid; e < 128 * FP; e += 256) {
+    const int r = e / FP, f = e % FP;
+    const int j = j0 + r;
+    const float t = nodes[((size_t)b * N + (j < N ? j : N - 1)) * F + (f < F ? f : F - 1)];
+    sN[r * NS + f] = (j < N && f < F) ? (dist_param ? t / inv_scale_den : t) : 0.f;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    float s = 0.f;
+    for (int f = 0; f < FP; ++f) s = fmaf(sN[tid * NS + f], sN[tid * NS + f], s);
+    sNn[tid] = s;
+  }
+  const int r_base = wave * 32;
+  const bool wave_live = (j0 + r_base < cur) || dist_out != nullptr;
+  float rowsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
+
+  for (int c0 = 0; c0 < B; c0 += CB) {
+    __syncthreads();
+    for (int e = tid; e < FP * CB; e += 256) {
+      const int f = e / CB, c = e % CB;
+      const float t = ws_curT[(size_t)(f < F ? f : F - 1) * B + (c0 + c < B ? c0 + c : B - 1)];
+      sC[e] = (f < F && c0 + c < B) ? t : 0.f;
+    }
+    for (int c = tid; c < CB; c += 256) sCn[c] = c0 + c < B ? ws_cnorm[c0 + c] : 0.f;
+    __syncthreads();
+    if (wave_live) {
+      const int tiles = (min(CB, B - c0) + 31) / 32;
+      for (int ct = 0; ct < tiles; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* ap = sN + (r_base + li) * NS + lh;        // A(i=row, k=f)
+        const float* bp = sC + lh * CB + ct * 32 + li;         // B(k=f, j=b')
+#pragma unroll 8
+        for (int k = 0; k < FP; k += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * CB], acc, 0, 0, 0);
+        const int col = c0 + ct * 32 + li;
+        const float cn = sCn[ct * 32 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float d2 = sNn[row] + cn - 2.f * acc[r];
+          rowsum[r] += col < B ? sqrtf(fmaxf(d2, 0.f)) : 0.f;
+        }
+      }
+    }
+  }
+  if (!wave_live) return;
+  // sum over the 32 columns held by the lanes of each half-wave
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = rowsum[r];
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    rowsum[r] = v;
+  }
+  if (li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + r_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (j >= N) continue;
+      const float d = rowsum[r] / (float)B;
+      if (dist_out) dist_out[(size_t)b * N + j] = d;
+      if (j < cur && d < max_distance) {
+        adj[((size_t)b * N + cur) * N + j] = 1.f;
+        if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
+      }
+    }
+  }
+}
+
+// current rows (scaled) transposed to [F][B] + their squared norms
+__global__ void k_gather_curT(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
+                              const float* __restrict__ dist_param, float* __restrict__ ws_curT,
+                              float* __restrict__ ws_cnorm, int B, int N, int F) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t c = cur_idx[b];
+  c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+  float s = 0.f;
+  for (int f = 0; f < F; ++f) {
+    float v = nodes[((size_t)b * N + c) * F + f];
+    if (dist_param) v = v / dist_param[0];
+    ws_curT[(size_t)f * B + b] = v;
+    s = fmaf(v, v, s);
+  }
+  ws_cnorm[b] = s;
+}
+
 // per-graph modes: one thread per (b, j)
 __global__ void k_pergraph(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
                            const float* __restrict__ dist_param, float* __restrict__ adj,
@@ -131,7 +252,7 @@ __global__ void k_pergraph(const float* __restrict__ nodes, const int64_t* __res
 extern "C" size_t gcm_edge_distance_workspace_bytes(int mode, int B, int N, int F) {
   (void)N;
   if (mode != GCM_DIST_EUCLID_CROSSBATCH || B <= 0 || F <= 0) return 0;
-  return (size_t)B * F * sizeof(float);
+  return ((size_t)B * F + B) * sizeof(float);
 }
 
 extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* cur_idx, int mode,
@@ -144,8 +265,37 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
   if (mode == GCM_DIST_EUCLID_CROSSBATCH) {
     if (F > 128 || B > 65535) return GCM_EUNSUPPORTED;
     GCM_REQUIRE(workspace);
-    if (workspace_bytes < (size_t)B * F * sizeof(float)) return GCM_EWORKSPACE;
+    if (workspace_bytes < ((size_t)B * F + B) * sizeof(float)) return GCM_EWORKSPACE;
     float* ws_cur = (float*)workspace;
+    if (B >= 32) {   // matrix-core path (torch.cdist's own switch to the mm formulation is at 25)
+      float* ws_cnorm = ws_cur + (size_t)B * F;
+      hipLaunchKernelGGL(k_gather_curT, dim3((B + 127) / 128), dim3(128), 0, s, nodes, cur_idx,
+                         dist_param, ws_cur, ws_cnorm, B, N, F);
+      dim3 grid((N + 127) / 128, B);
+      const int FT = (F + 31) / 32;
+      const int CBv = FT >= 4 ? 128 : 256;
+      const size_t lds = sizeof(float) * ((size_t)128 * (32 * FT + 1) + (size_t)32 * FT * CBv + 128 + CBv);
+#define GCM_EUCLID_MFMA(FTv)                                                                     \
+  {                                                                                              \
+    auto kern = k_euclid_mfma<FTv>;                                                              \
+    static bool attr_set = false;                                                                \
+    if (!attr_set && lds > 64 * 1024) {                                                          \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                       \
+      attr_set = true;                                                                           \
+    }                                                                                            \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, nodes, ws_cur, ws_cnorm, cur_idx,          \
+                       dist_param, adj, dist_out, max_distance, bidirectional, B, N, F);         \
+  }
+      switch (FT) {
+        case 1: GCM_EUCLID_MFMA(1) break;
+        case 2: GCM_EUCLID_MFMA(2) break;
+        case 3: GCM_EUCLID_MFMA(3) break;
+        default: GCM_EUCLID_MFMA(4) break;
+      }
+#undef GCM_EUCLID_MFMA
+      return gcm_launch_status();
+    }
     hipLaunchKernelGGL(k_gather_cur, dim3((B * F + 255) / 256), dim3(256), 0, s, nodes, cur_idx,
                        dist_param, ws_cur, B, N, F);
     dim3 grid((N + 127) / 128, B);

@@ -208,6 +208,32 @@ def test_distance_matrix_matches_oracle():
         torch.testing.assert_close(d[self_entry], want[self_entry], rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,N,F,learned", [(40, 50, 24, False), (64, 128, 64, True), (33, 20, 100, False),
+                                            (300, 16, 128, False)])
+def test_euclid_matrix_core_path(B, N, F, learned):
+    """B >= 32 runs the MFMA formulation (|n|^2+|c|^2-2nc, like torch.cdist above 25 rows)."""
+    from gcm.edge_selectors.distance import EuclideanEdge
+    torch.manual_seed(B + N)
+    nodes = torch.randn(B, N, F)
+    nn_ = torch.randint(0, N, (B,))
+    thr = float(torch.cdist(nodes[:, 0], nodes[:1]).mean()) * (0.5 if learned else 1.0)
+    dev_sel = EuclideanEdge(thr, learned=learned).to(DEV)
+    ref_sel = od.EuclideanEdge(thr, dist_param=torch.tensor([thr]) if learned else None)
+    d = dev_sel.distances(nodes.to(DEV), nn_.to(DEV)).cpu()
+    want = ref_sel.distances(nodes, nn_)
+    torch.testing.assert_close(d, want, rtol=1e-4, atol=1e-4)
+    # thresholded result, away from the threshold
+    adj = torch.zeros(B, N, N, device=DEV)
+    got, _ = dev_sel(nodes.to(DEV), adj, torch.zeros(0, device=DEV), nn_.to(DEV), B)
+    ref, _ = ref_sel(nodes, torch.zeros(B, N, N), torch.zeros(0), nn_, B)
+    live = torch.arange(N)[None, :] < nn_[:, None]
+    safe = ((want - ref_sel.max_distance).abs() > 1e-3) & live
+    rows = got.cpu()[torch.arange(B), nn_]
+    ref_rows = ref[torch.arange(B), nn_]
+    assert torch.equal(rows[safe], ref_rows[safe])
+    assert float(got.cpu().sum()) >= float(rows[safe].sum())
+
+
 # --------------------------------------------------------------------------
 # known answers ported from the reference's unit tests
 # --------------------------------------------------------------------------

@@ -20,6 +20,7 @@ from gcm.edge_selectors.learned import LearnedEdge  # noqa: E402
 from gcm.sparse_edge_selectors.temporal import TemporalEdge  # noqa: E402
 
 dev = "cuda:0"
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""   # substring filter on the config name
 
 
 def dense_gnn(F, H):
@@ -40,6 +41,8 @@ def timeit(fn, iters, warm=2):
 
 
 def run_dense(name, B, N, F, H, T, sel, obs, iters=5):
+    if ONLY not in name:
+        return
     torch.manual_seed(0)
     gnn = dense_gnn(F, H)
     mem = DenseGCM(gnn, edge_selectors=sel, graph_size=N)
@@ -80,6 +83,8 @@ B, N, F, H, T = 256, 128, 32, 32, 64
 run_dense("cfg5/GPU LearnedEdge(32)", B, N, F, H, T, LearnedEdge(32).to(dev), torch.rand(T, B, F, device=dev), iters=3)
 
 # cfg4 sparse
+if ONLY not in 'cfg4':
+    sys.exit(0)
 B, N, F, H = 512, 512, 32, 32
 torch.manual_seed(0)
 g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
