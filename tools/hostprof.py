@@ -33,4 +33,4 @@ pr.enable()
 bench.rollout(mem, obs, bucket, 1.0)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)
