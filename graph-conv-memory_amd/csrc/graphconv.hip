@@ -12,6 +12,16 @@
 // stores are masked.  Fi, Fo <= 128.
 #include "gcm_common.h"
 
+// single-workgroup-per-graph kernels (fused_layer.hip), used whenever the graph fits one
+int gcm_layer_fits(int N, int Fi, int Fo, int which);
+int gcm_layer_fwd(const float* x, const float* adj, const float* w_rel, const float* b_rel,
+                  const float* w_root, float* out, float* agg, int B, int N, int Fi, int Fo,
+                  int act, hipStream_t s);
+int gcm_layer_bwd(const float* g_out, const float* out, const float* x, const float* adj,
+                  const float* agg, const float* w_rel, const float* w_root, float* g_x,
+                  float* g_adj, float* slabs, int want_w, int B, int N, int Fi, int Fo, int act,
+                  hipStream_t s);
+
 namespace {
 
 constexpr int KT = 32;  // K tile of the N-long contractions
@@ -490,6 +500,9 @@ extern "C" int gcm_dense_graphconv_fwd(const float* x, const float* adj, const f
   GCM_REQUIRE(x && adj && w_rel && w_root && out);
   GCM_REQUIRE(B > 0 && N > 0 && Fi > 0 && Fo > 0);
   if (Fi > 128 || Fo > 128 || B > 65535) return GCM_EUNSUPPORTED;
+  if (gcm_layer_fits(N, Fi, Fo, 0))
+    return gcm_layer_fwd(x, adj, w_rel, b_rel, w_root, out, agg, B, N, Fi, Fo, act,
+                         (hipStream_t)stream);
   const int FiP = round32(Fi);
   const int waves = pick_waves(N, FiP, fwd_lds_bytes);
   if (!waves) return GCM_EUNSUPPORTED;
@@ -548,6 +561,14 @@ extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, con
   const int FiP = round32(Fi), FoP = round32(Fo), nct = FiP / 32;
   const int want_w = (g_w_rel || g_w_root || g_b_rel) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  if (gcm_layer_fits(N, Fi, Fo, g_adj ? 2 : 1)) {   // one kernel per layer + the slab reduction
+    int rc = gcm_layer_bwd(g_out, out, x, adj, agg, w_rel, w_root, g_x, g_adj, slabs, want_w, B, N,
+                           Fi, Fo, act, s);
+    if (rc != GCM_OK || !want_w) return rc;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(((int)p.slab_len + 63) / 64), dim3(256), 0, s, slabs, B,
+                       (int)p.slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
+    return gcm_launch_status();
+  }
   dim3 grid(p.nblk, B);
   const size_t lds1 = bwd_rows_lds_bytes(p.waves, FiP, FoP);
   const size_t lds2 = bwd_adjT_lds_bytes(p.waves, FiP);
