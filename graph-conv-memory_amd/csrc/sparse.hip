@@ -292,6 +292,28 @@ __global__ void k_extract_bwd(const float* __restrict__ g_out, const int64_t* __
   if (k < taus[b] && row >= 0 && row < M) g_feats[(size_t)row * H + f] = g_out[i];
 }
 
+// util.pack_hidden (util.py:323-351): one thread per COO entry
+__global__ void k_pack_hidden(const int64_t* __restrict__ coo, const float* __restrict__ values,
+                              const int64_t* __restrict__ batch_ptr,
+                              int64_t* __restrict__ dense_edges, float* __restrict__ dense_weights,
+                              uint32_t* __restrict__ flags, int64_t E, int B, int max_edges) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool over = false;
+  if (e < E) {
+    int64_t b = coo[e];
+    b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+    const int64_t pos = e - batch_ptr[b];
+    // the reference requires count < max_edges (strict)
+    over = batch_ptr[b + 1] - batch_ptr[b] >= max_edges;
+    if (pos >= 0 && pos < max_edges) {
+      dense_edges[((size_t)b * 2 + 0) * max_edges + pos] = coo[E + e];
+      dense_edges[((size_t)b * 2 + 1) * max_edges + pos] = coo[2 * E + e];
+      dense_weights[(size_t)b * max_edges + pos] = values[e];
+    }
+  }
+  if (__any(over) && (threadIdx.x & 63) == 0) atomicOr(flags, GCM_FLAG_PACK_OVERFLOW);
+}
+
 Hops16 pack_hops(const int32_t* hops_host, int n_hops) {
   Hops16 h;
   for (int i = 0; i < 16; ++i) h.h[i] = i < n_hops ? hops_host[i] : -1;
@@ -455,5 +477,18 @@ extern "C" int gcm_sparse_extract_bwd(const float* g_out, const int64_t* T, cons
   const int64_t total = (int64_t)B * t_pad * H;
   hipLaunchKernelGGL(k_extract_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_out,
                      T, taus, node_off, g_feats, B, t_pad, H, M);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_pack_hidden(const int64_t* coo, const float* values, const int64_t* batch_ptr,
+                               int64_t* dense_edges, float* dense_weights, uint32_t* flags,
+                               int64_t E, int B, int max_edges, gcm_stream_t stream) {
+  GCM_REQUIRE(batch_ptr && dense_edges && dense_weights && flags && E >= 0 && B > 0 &&
+              max_edges > 0);
+  if (E == 0) return GCM_OK;
+  GCM_REQUIRE(coo && values);
+  hipLaunchKernelGGL(k_pack_hidden, dim3((unsigned)((E + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, coo, values, batch_ptr, dense_edges, dense_weights, flags,
+                     E, B, max_edges);
   return gcm_launch_status();
 }

@@ -219,6 +219,27 @@ extern "C" int gcm_edge_dense(float* adj, const int64_t* cur_idx, int B, int N,
   return gcm_launch_status();
 }
 
+// PositionalEncoding mode="add" (gcm.py:120-131)
+__global__ void k_posenc_add(float* __restrict__ x, const float* __restrict__ pe,
+                             const int64_t* __restrict__ num_nodes, int N, int F, int d_model,
+                             int max_len) {
+  const int b = blockIdx.y;
+  const int64_t last = num_nodes[b];   // rows 0..last inclusive are live
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * F) return;
+  const int n = i / F, f = i - n * F;
+  if (n <= last && n < max_len) x[(size_t)b * N * F + i] += pe[(size_t)n * d_model + f];
+}
+
+extern "C" int gcm_posenc_add(float* x, const float* pe, const int64_t* num_nodes, int B, int N,
+                              int F, int d_model, int max_len, gcm_stream_t stream) {
+  GCM_REQUIRE(x && pe && num_nodes && B > 0 && N > 0 && F > 0 && d_model >= F && max_len > 0);
+  if (B > 65535) return GCM_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_posenc_add, dim3((N * F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                     x, pe, num_nodes, N, F, d_model, max_len);
+  return gcm_launch_status();
+}
+
 extern "C" int gcm_version(void) { return 100; }
 
 extern "C" const char* gcm_status_string(int code) {

@@ -17,7 +17,7 @@ ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 DIR = {"forward": 1, "backward": 2, "both": 3}
 DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
 FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
-FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL = 8, 16
+FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW = 8, 16, 32
 
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                      ctypes.c_int64)
@@ -57,6 +57,8 @@ PROTOTYPES = {
     "gcm_learned_pairs_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gcm_learned_select_fwd": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "gcm_learned_select_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "gcm_posenc_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "gcm_pack_hidden": (_I, [_P] * 6 + [_L, _I, _I, _P]),
     "gcm_dense_gnn2_row_supported": (_I, [_I, _I, _I, _I]),
     "gcm_dense_gnn2_param_count": (_Z, [_I, _I, _I]),
     "gcm_dense_gnn2_row_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 5 + [_I] * 5 + [_P]),

@@ -746,3 +746,47 @@ class _FusedRollout(torch.autograd.Function):
 
 def fused_rollout(obs, nodes0, packed, adj0, num_nodes0, flags, cfg):
     return _FusedRollout.apply(obs, nodes0, packed, adj0, num_nodes0, flags, cfg)
+
+
+# ===========================================================================
+# SURVEY 8(f) "next" rows: positional encoding, packed sparse hidden state
+# ===========================================================================
+class _PosEncAdd(torch.autograd.Function):
+    """x[b, n] += pe[n] for n <= num_nodes[b], in place (gcm.py:120-131); backward = identity."""
+
+    @staticmethod
+    def forward(ctx, x, pe, num_nodes):
+        _hip.on_device(x, pe, num_nodes)
+        B, N, F = x.shape
+        _call("gcm_posenc_add", _hip.ptr(x), _hip.ptr(pe), _hip.ptr(num_nodes), B, N, F, pe.shape[1],
+              pe.shape[0], _hip.stream())
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def posenc_add_(x, pe, num_nodes):
+    return _PosEncAdd.apply(x, pe, num_nodes)
+
+
+def pack_hidden(coo, values, B, max_edges, edge_fill, weight_fill):
+    """-> dense_edges [B,2,max_edges] i64, dense_weights [B,1,max_edges] f32 (util.py:323-351).
+    One host readback (the per-graph counts, for the reference's assertion)."""
+    coo, values = coo.contiguous(), values.contiguous()
+    _hip.on_device(coo, values)
+    E = coo.shape[1]
+    dev = coo.device
+    dense_edges = torch.full((B, 2, max_edges), edge_fill, dtype=_i64, device=dev)
+    dense_weights = torch.full((B, 1, max_edges), weight_fill, dtype=_f32, device=dev)
+    batch_ptr = ptr_from_sorted(coo[0], B)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    _call("gcm_pack_hidden", _hip.ptr(coo), _hip.ptr(values), _hip.ptr(batch_ptr),
+          _hip.ptr(dense_edges), _hip.ptr(dense_weights), _hip.ptr(flags), E, B, max_edges,
+          _hip.stream())
+    counts = (batch_ptr[1:] - batch_ptr[:-1]).tolist()
+    for n in counts:
+        assert n < max_edges, f"Cannot pack {n} edges into {max_edges}, increase max edges"
+    return dense_edges, dense_weights

@@ -13,11 +13,54 @@ are replaced by a device-side flag word that is polled without blocking
 (`finite_check="deferred"`, default), checked every step (`"sync"`, the
 reference's exact raise point) or not at all (`"off"`).
 """
+import math
 from typing import Tuple, Union
 
 import torch
 
 from . import _hip, _ops
+
+
+class PositionalEncoding(torch.nn.Module):
+    """Embed a sin/cos positional encoding into the graph without touching future nodes
+    (node index > num_nodes).  Reference: src/gcm/gcm.py:92-143 (same constructor, same lazily
+    built `pe` buffer and `reproject` layer).  mode="add" is one in-place kernel
+    (gcm_posenc_add); mode="cat" re-projects the features with a library GEMM and writes the
+    first cat_dim columns from the table."""
+
+    def __init__(self, max_len: int = 5000, mode="add", cat_dim: int = 8):
+        super().__init__()
+        self.max_len = max_len
+        self.mode = mode
+        self.cat_dim = cat_dim
+        assert mode in ["add", "cat"]
+
+    def run_once(self, x: torch.Tensor) -> None:
+        d_model = math.ceil(x.shape[-1] / 2) * 2          # gcm.py:103-112, table built on the host
+        position = torch.arange(self.max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(self.max_len, d_model)
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.to(x.device))
+        if self.mode == "cat":
+            self.reproject = torch.nn.Linear(x.shape[-1], x.shape[-1] - self.cat_dim,
+                                             device=x.device)
+
+    def forward(self, x: torch.Tensor, num_nodes: torch.Tensor) -> torch.Tensor:
+        """x [B, N, F], num_nodes [B]: rows 0..num_nodes[b] (inclusive) are encoded."""
+        if not hasattr(self, "pe"):
+            self.run_once(x)
+        if self.mode == "add":
+            if x.is_leaf and x.requires_grad:
+                x = x.clone()
+            return _ops.posenc_add_(x.contiguous() if not x.is_contiguous() else x, self.pe,
+                                    num_nodes)
+        N, F = x.shape[1], x.shape[2]
+        live = (torch.arange(N, device=x.device)[None, :] <= num_nodes[:, None]).unsqueeze(-1)
+        pe = self.pe[:N, : self.cat_dim].unsqueeze(0).expand(x.shape[0], -1, -1)
+        enc = torch.cat((pe, self.reproject(x)), dim=-1)
+        return torch.where(live, enc, x)
 
 
 class DenseGCM(torch.nn.Module):

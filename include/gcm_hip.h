@@ -358,6 +358,24 @@ int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const f
                           float* g_params, void* workspace, size_t workspace_bytes, int T, int B,
                           int N, int F, int H1, int H2, gcm_stream_t stream);
 
+/* ---- SURVEY 8(f) "next" rows ---------------------------------------------------------- */
+
+/* PositionalEncoding mode="add" (src/gcm/gcm.py:120-131, util.idxs_up_to_including_num_nodes
+ * util.py:478-498): x[b, n, :] += pe[n, :F] for every n <= num_nodes[b], IN PLACE on x.
+ * pe is the [max_len, d_model] sin/cos table (d_model = F rounded up to even). */
+int gcm_posenc_add(float* x, const float* pe, const int64_t* num_nodes, int B, int N, int F,
+                   int d_model, int max_len, gcm_stream_t stream);
+
+/* util.pack_hidden (src/gcm/util.py:323-351): coalesced COO (batch, i, j) -> dense_edges
+ * [B, 2, max_edges] (pre-filled by the caller with edge_fill) and dense_weights [B, 1, max_edges]
+ * (pre-filled with weight_fill).  batch_ptr [B+1] = gcm_ptr_from_sorted over coo[0].  Edges
+ * beyond max_edges-1 of a graph are dropped and GCM_FLAG_PACK_OVERFLOW is raised (the reference
+ * asserts count < max_edges). */
+#define GCM_FLAG_PACK_OVERFLOW 32u
+int gcm_pack_hidden(const int64_t* coo, const float* values, const int64_t* batch_ptr,
+                    int64_t* dense_edges, float* dense_weights, uint32_t* flags, int64_t E, int B,
+                    int max_edges, gcm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

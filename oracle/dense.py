@@ -203,21 +203,39 @@ def chain(*selectors):
 
 
 # --------------------------------------------------------------------------
-# positional encoding (gcm.py:92-143, mode="add" only)
+# positional encoding (gcm.py:92-143)
 # --------------------------------------------------------------------------
-def positional_encoding_add(x, num_nodes, max_len=5000):
-    import math
+class PositionalEncoding:
+    """gcm.py:92-143.  mode "add": rows 0..num_nodes[b] get pe[n, :F] added (the reference does
+    it in place on the dirty node matrix, so the GNN sees the encoded rows too); mode "cat": the
+    first cat_dim columns become pe, the rest a learned re-projection of the features."""
 
-    F = x.shape[-1]
-    d_model = math.ceil(F / 2) * 2
-    pos = torch.arange(max_len).unsqueeze(1)
-    div = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
-    pe = torch.zeros(max_len, d_model)
-    pe[:, 0::2] = torch.sin(pos * div)
-    pe[:, 1::2] = torch.cos(pos * div)
-    N = x.shape[1]
-    live = torch.arange(N)[None, :] <= num_nodes[:, None]
-    return x + live.unsqueeze(-1) * pe[:N, :F].unsqueeze(0)
+    def __init__(self, max_len=5000, mode="add", cat_dim=8, reproject=None):
+        import math
+        self.max_len, self.mode, self.cat_dim, self.reproject = max_len, mode, cat_dim, reproject
+        self._math = math
+        self.pe = None
+
+    def table(self, F):
+        math = self._math
+        d_model = math.ceil(F / 2) * 2
+        pos = torch.arange(self.max_len).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(self.max_len, d_model)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe
+
+    def __call__(self, x, num_nodes):
+        B, N, F = x.shape
+        if self.pe is None:
+            self.pe = self.table(F)
+        live = (torch.arange(N)[None, :] <= num_nodes[:, None]).unsqueeze(-1)
+        if self.mode == "add":
+            return x + live * self.pe[:N, :F].unsqueeze(0)
+        enc = torch.cat((self.pe[:N, : self.cat_dim].unsqueeze(0).expand(B, -1, -1),
+                         self.reproject(x)), dim=-1)
+        return torch.where(live, enc, x)
 
 
 # --------------------------------------------------------------------------
@@ -246,7 +264,11 @@ def dense_step(x, hidden, gnn, graph_size=128, edge_selectors=None, preprocessor
     if preprocessor is not None:                                 # gcm.py:290-291
         dirty = preprocessor(dirty)
     if aux_edge_selectors is not None:                           # gcm.py:294-306
-        seen = positional_encoder(dirty, num_nodes) if positional_encoder else dirty
+        seen = dirty
+        if positional_encoder is not None:
+            seen = positional_encoder(dirty, num_nodes)
+            if getattr(positional_encoder, "mode", None) == "add":
+                dirty = seen        # the reference adds IN PLACE on dirty_nodes (gcm.py:131)
         adj, weights = aux_edge_selectors(seen, adj.clone(), weights.clone(), num_nodes, B)
     feats = gnn(dirty, adj, weights, B, N)                       # gcm.py:308
     mx = feats if pooled else feats[rows, num_nodes]             # gcm.py:309-314

@@ -121,3 +121,27 @@ def canonical_gnn(F, H, act=torch.nn.Tanh, layers=2):
             mods.append(act())
         cin = H
     return pyg.Sequential("x, edges, weights", mods)
+
+
+def pack_hidden(hidden, B, max_edges, edge_fill=-1, weight_fill=1.0):
+    """util.py:323-351."""
+    nodes, adj, T = hidden
+    adj = adj.coalesce()
+    idx, val = adj.indices(), adj.values()
+    dense_edges = torch.full((B, 2, max_edges), edge_fill, dtype=torch.long)
+    dense_weights = torch.full((B, 1, max_edges), weight_fill, dtype=torch.float)
+    for b in range(B):
+        sel = torch.nonzero(idx[0] == b).reshape(-1)
+        assert sel.numel() < max_edges, f"Cannot pack {sel.numel()} edges into {max_edges}"
+        dense_edges[b, :, : sel.numel()] = idx[1:, sel]
+        dense_weights[b, 0, : sel.numel()] = val[sel]
+    return nodes, dense_edges, dense_weights, T
+
+
+def unpack_hidden(hidden, B):
+    """util.py:353-382."""
+    nodes, edges, weights, T = hidden
+    b_idx, e_idx = (edges[:, 0] >= 0).nonzero().T.unbind()
+    idx = torch.stack([b_idx, edges[b_idx, 0, e_idx], edges[b_idx, 1, e_idx]])
+    adj = torch.sparse_coo_tensor(idx, weights[b_idx, 0, e_idx], size=(B, nodes.shape[1], nodes.shape[1]))
+    return nodes, adj, T

@@ -275,6 +275,42 @@ def main():
              h0_num_nodes=torch.tensor([1, 7]), mx=mx, hT_nodes=n2, hT_adj=a2, hT_weights=w2,
              hT_num_nodes=nn2, caller_num_nodes_after=num_nodes, **params_of(g))
 
+    # ---- G10: PositionalEncoding in the step ----------------
+    from gcm.gcm import PositionalEncoding
+    for mode in ("add", "cat"):
+        torch.manual_seed(0)
+        B, N, F, H, T = 3, 10, 6, 5, 13
+        gnn = od.canonical_gnn(F, H)
+        pe = PositionalEncoding(max_len=N, mode=mode, cat_dim=2)
+        m = DenseGCM(gnn, edge_selectors=TemporalBackedge([1]), aux_edge_selectors=TemporalBackedge([2]),
+                     positional_encoder=pe, graph_size=N)
+        obs = torch.rand(T, B, F)
+        torch.manual_seed(7)            # the lazily created reproject layer (mode="cat")
+        run_dense(f"g10_posenc_{mode}", m, obs, None, gnn, sel_module=pe if mode == "cat" else None,
+                  meta=dict(B=B, N=N, F=F, H=H, T=T, mode=mode, cat_dim=2))
+    pe = PositionalEncoding(max_len=7, mode="add")
+    enc0 = pe(torch.zeros(2, 7, 5), torch.tensor([0, 7]))
+    enc1 = pe(torch.zeros(2, 7, 5), torch.tensor([1, 8]))
+    save("g10_posenc_table", dict(N=7, F=5), enc0=enc0, enc1=enc1, pe=pe.pe)
+
+    # ---- G11: pack_hidden / unpack_hidden --------------------
+    gen = torch.Generator().manual_seed(11)
+    B, N, F, max_edges = 4, 9, 3, 12
+    counts = [5, 0, 11, 3]
+    idx = []
+    for b, c in enumerate(counts):
+        pairs = torch.randperm(N * N, generator=gen)[:c].sort().values
+        idx.append(torch.stack([torch.full((c,), b), pairs // N, pairs % N]))
+    idx = torch.cat(idx, dim=1)
+    vals = torch.rand(idx.shape[1], generator=gen)
+    adj = torch.sparse_coo_tensor(idx, vals, size=(B, N, N)).coalesce()
+    nodes, Tt = torch.rand(B, N, F, generator=gen), torch.tensor([3, 0, 9, 2])
+    pn, pe_, pw, pT = gcm.util.pack_hidden((nodes, adj, Tt), B, max_edges)
+    un, uadj, uT = gcm.util.unpack_hidden((pn, pe_, pw, pT), B)
+    save("g11_pack", dict(B=B, N=N, F=F, max_edges=max_edges), coo=adj.indices(), values=adj.values(),
+         nodes=nodes, T=Tt, dense_edges=pe_, dense_weights=pw, un_idx=uadj.coalesce().indices(),
+         un_val=uadj.coalesce().values())
+
     # ---- G8: SparseGCM + TemporalEdge ----------------------------------------
     def run_sparse(name, B, N, F, H, hops, obs, tau_plan, max_hops=None, act=None):
         torch.manual_seed(0)

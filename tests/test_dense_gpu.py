@@ -485,3 +485,56 @@ def test_rollout_falls_back_for_non_native_trees():
     obs = torch.rand(5, 2, 4, device=DEV)
     out, hid = mem.rollout(obs)
     assert out.shape == (5, 2, 4) and hid[3].tolist() == [5, 5]
+
+
+# --------------------------------------------------------------------------
+# PositionalEncoding (gcm.py:92-143)
+# --------------------------------------------------------------------------
+def test_posenc_known_answers():
+    """tests/test_gcm.py:39-86."""
+    import math
+    from gcm.gcm import PositionalEncoding
+    fx = Fixture("g10_posenc_table")
+    pe = PositionalEncoding(max_len=7, mode="add")
+    nodes = torch.zeros(2, 7, 5, device=DEV)
+    enc = pe(nodes.clone(), torch.tensor([0, 7], device=DEV))
+    assert torch.equal(enc.cpu(), fx["enc0"])                    # same table, same rows touched
+    assert torch.all(enc[0, 1, :] == 0) and not torch.all(enc[0, 0, :] == 0)
+    enc = pe(nodes.clone(), torch.tensor([1, 8], device=DEV))
+    assert torch.equal(enc.cpu(), fx["enc1"])
+    want = torch.tensor([math.sin(1.0), math.cos(1.0), math.sin((1 / 10000) ** (2 / 6)),
+                         math.cos((1 / 10000) ** (2 / 6)), math.sin((1 / 10000) ** (4 / 6))])
+    assert float((enc[0, 1].cpu() - want).abs().sum()) < 0.01
+
+
+@pytest.mark.parametrize("mode", ["add", "cat"])
+def test_posenc_in_step_matches_reference(mode):
+    from gcm.gcm import DenseGCM, PositionalEncoding
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    fx = Fixture(f"g10_posenc_{mode}")
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    pe = PositionalEncoding(max_len=m["N"], mode=mode, cat_dim=m["cat_dim"])
+    if mode == "cat":
+        pe.run_once(torch.zeros(1, 1, m["F"], device=DEV))
+        pe.load_state_dict(fx.group("sel_param:"))
+    mem = DenseGCM(g, edge_selectors=TemporalBackedge([1]), aux_edge_selectors=TemporalBackedge([2]),
+                   positional_encoder=pe, graph_size=m["N"])
+    obs = fx["obs"].to(DEV).requires_grad_(True)
+    hidden, mxs = None, []
+    for t in range(m["T"]):
+        mx, hidden = mem(obs[t], hidden)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    mem.check_flags()
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])          # returned nodes stay un-encoded
+    assert torch.equal(hidden[1].cpu(), fx["hT_adj"])
+    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+    gs = float(fx["grad_obs"].abs().max())
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)

@@ -30,7 +30,7 @@ def test_argument_errors_without_gpu():
     assert lib.gcm_dense_graphconv_fwd(None, None, None, None, None, None, None, 1, 1, 1, 1, 0, None) == -1
     assert lib.gcm_edge_dense(None, None, 1, 1, None) == -1
     assert lib.gcm_dense_graphconv_bwd_workspace_bytes(256, 128, 32, 32) > 0
-    assert lib.gcm_edge_distance_workspace_bytes(0, 256, 128, 64) == 256 * 64 * 4
+    assert lib.gcm_edge_distance_workspace_bytes(0, 256, 128, 64) == (256 * 64 + 256) * 4   # rows + norms
 
 
 def test_no_cpu_fallback():

@@ -116,3 +116,50 @@ def test_sparse_oracle_matches_reference(name):
     torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
     for k, p in gnn.named_parameters():
         torch.testing.assert_close(p.grad, fx["grad:" + k], rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------
+# SURVEY 8(f) "next" rows: PositionalEncoding in the step, pack/unpack_hidden
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["add", "cat"])
+def test_posenc_oracle_matches_reference(mode):
+    fx = Fixture(f"g10_posenc_{mode}")
+    m = fx.meta
+    gnn = od.canonical_gnn(m["F"], m["H"])
+    gnn.load_state_dict(fx.group("param:"))
+    reproject = None
+    if mode == "cat":
+        reproject = torch.nn.Linear(m["F"], m["F"] - m["cat_dim"])
+        reproject.load_state_dict({k[len("reproject."):]: v for k, v in fx.group("sel_param:").items()
+                                   if k.startswith("reproject.")})
+    pe = od.PositionalEncoding(max_len=m["N"], mode=mode, cat_dim=m["cat_dim"], reproject=reproject)
+    obs = fx["obs"].clone().requires_grad_(True)
+    hidden, mxs = None, []
+    for t in range(m["T"]):
+        mx, hidden = od.dense_step(obs[t], hidden, gnn, graph_size=m["N"],
+                                   edge_selectors=od.TemporalBackedge([1]),
+                                   aux_edge_selectors=od.TemporalBackedge([2]), positional_encoder=pe)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    assert torch.equal(hidden[0], fx["hT_nodes"]) and torch.equal(hidden[1], fx["hT_adj"])
+    torch.testing.assert_close(mxs, fx["mx"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+
+
+def test_posenc_table_oracle():
+    fx = Fixture("g10_posenc_table")
+    pe = od.PositionalEncoding(max_len=7, mode="add")
+    assert torch.equal(pe(torch.zeros(2, 7, 5), torch.tensor([0, 7])), fx["enc0"])
+    assert torch.equal(pe(torch.zeros(2, 7, 5), torch.tensor([1, 8])), fx["enc1"])
+
+
+def test_pack_hidden_oracle():
+    fx = Fixture("g11_pack")
+    m = fx.meta
+    adj = torch.sparse_coo_tensor(fx["coo"], fx["values"], size=(m["B"], m["N"], m["N"]))
+    n, e, w, T = osp.pack_hidden((fx["nodes"], adj, fx["T"]), m["B"], m["max_edges"])
+    assert torch.equal(e, fx["dense_edges"]) and torch.equal(w, fx["dense_weights"])
+    _, uadj, _ = osp.unpack_hidden((n, e, w, T), m["B"])
+    assert torch.equal(uadj.coalesce().indices(), fx["un_idx"])
+    assert torch.equal(uadj.coalesce().values(), fx["un_val"])

@@ -219,3 +219,41 @@ def test_sparse_backward_without_input_grad():
     out, _ = mem(torch.rand(3, 8, 4, device=DEV), torch.full((3,), 8, device=DEV), None)
     out.mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in g.parameters())
+
+
+# --------------------------------------------------------------------------
+# packed sparse hidden state (util.py:323-382)
+# --------------------------------------------------------------------------
+def test_pack_unpack_hidden_matches_reference():
+    from gcm import util
+    fx = Fixture("g11_pack")
+    m = fx.meta
+    adj = torch.sparse_coo_tensor(fx["coo"], fx["values"], size=(m["B"], m["N"], m["N"])).to(DEV)
+    hidden = (fx["nodes"].to(DEV), adj, fx["T"].to(DEV))
+    n, e, w, T = util.pack_hidden(hidden, m["B"], m["max_edges"])
+    assert torch.equal(e.cpu(), fx["dense_edges"]) and torch.equal(w.cpu(), fx["dense_weights"])
+    assert torch.equal(n.cpu(), fx["nodes"]) and torch.equal(T.cpu(), fx["T"])
+    _, uadj, _ = util.unpack_hidden((n, e, w, T), m["B"])
+    assert torch.equal(uadj.coalesce().indices().cpu(), fx["un_idx"])
+    assert torch.equal(uadj.coalesce().values().cpu(), fx["un_val"])
+    with pytest.raises(AssertionError, match="Cannot pack"):
+        util.pack_hidden(hidden, m["B"], 11)            # graph 2 holds 11 edges: needs max_edges > 11
+
+
+def test_pack_unpack_round_trips():
+    """tests/test_sparse_gcm.py:82-133 - empty and small packed states survive unpack -> pack."""
+    from gcm import util
+    B, N, F, ME = 3, 5, 4, 10
+    nodes = torch.zeros(B, N, F, device=DEV)
+    for fill in (False, True):
+        edge = torch.full((B, 2, ME), -1, dtype=torch.long, device=DEV)
+        weight = torch.ones(B, 1, ME, device=DEV)
+        if fill:
+            edge[0, :, 0] = torch.tensor([0, 1]); edge[1, :, 0] = torch.tensor([0, 1])
+            edge[1, :, 1] = torch.tensor([1, 2])
+            weight[0, 0, 0], weight[1, 0, 0], weight[1, 0, 1] = 0.5, 0.33, 0.25
+        T = torch.tensor([2, 3, 0], device=DEV)
+        packed = (nodes, edge, weight, T)
+        again = util.pack_hidden(util.unpack_hidden(packed, B), B, ME)
+        for a, b in zip(packed, again):
+            assert torch.equal(a, b)
