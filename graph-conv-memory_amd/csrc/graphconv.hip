@@ -10,7 +10,7 @@
 //
 // Shapes are arbitrary (tests use N=7, F=3 ...): tiles are zero padded in LDS and
 // stores are masked.  Fi, Fo <= 128.
-#include "gcm_common.h"
+#include "fused_common.h"
 
 // single-workgroup-per-graph kernels (fused_layer.hip), used whenever the graph fits one
 int gcm_layer_fits(int N, int Fi, int Fo, int which);
@@ -355,27 +355,39 @@ size_t bwd_adjT_lds_bytes(int waves, int FiP) {
 // backward, kernel 3: sum the per-(graph, row block) slabs -> g_w_rel, g_w_root, g_b_rel
 // deterministic (fixed order), no atomics
 // ---------------------------------------------------------------------------
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, int n_slabs, int slab_len,
-                               float* __restrict__ g_w_rel, float* __restrict__ g_w_root,
-                               float* __restrict__ g_b_rel, int FoFi, int Fo) {
-  // 4 partial sums per element, interleaved over slabs, combined through LDS
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int n_slabs,
+                                                      int slab_len, float* __restrict__ g_w_rel,
+                                                      float* __restrict__ g_w_root,
+                                                      float* __restrict__ g_b_rel, int FoFi, int Fo) {
+  // block = 16 elements x 16 slab groups; every thread sums its slabs with 8 loads in flight,
+  // the 16 partials of an element meet in LDS (fixed order => deterministic)
   __shared__ float part[256];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int q = threadIdx.x >> 6;
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  const int ec = e < slab_len ? e : slab_len - 1;
   float s = 0.f;
-  if (e < slab_len)
-    for (int i = q; i < n_slabs; i += 4) s += slabs[(size_t)i * slab_len + e];
+  for (int i0 = grp; i0 < n_slabs; i0 += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 16 * u;
+      const float t = slabs[(size_t)(i < n_slabs ? i : n_slabs - 1) * slab_len + ec];
+      v[u] = i < n_slabs ? t : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   part[threadIdx.x] = s;
   __syncthreads();
-  if (q == 0 && e < slab_len) {
-    const float v = (part[threadIdx.x] + part[threadIdx.x + 64]) +
-                    (part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+  if (grp == 0 && e < slab_len) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += part[g * 16 + el];
     if (e < FoFi) { if (g_w_rel) g_w_rel[e] = v; }
     else if (e < 2 * FoFi) { if (g_w_root) g_w_root[e - FoFi] = v; }
     else if (g_b_rel) g_b_rel[e - 2 * FoFi] = v;
   }
 }
-
 
 // ===========================================================================
 // GraphConv over CSR (sparse path).  The neighbour reduction is a gather of whole
@@ -488,6 +500,260 @@ __global__ void k_csr_edge_grad(const float* __restrict__ x, const float* __rest
   }
 }
 
+
+// ===========================================================================
+// Flat-row kernels of the CSR path, second generation (Fi, Fo <= 64): every global load of a
+// phase is issued before its first use (register staging with fixed trip counts, clamped
+// unconditional addresses) - the first generation spent most of its time in per-element
+// load -> store chains.
+// ===========================================================================
+
+// CSR GraphConv forward.  One workgroup = 128 destination rows.  The block's row_ptr slice and
+// its (contiguous) col / w slices go to LDS first, so the neighbour gather has ONE level of
+// dependent global loads (x rows) and the 16 row elements a thread owns are gathered together.
+template <int NCT, int NHT>
+__global__ __launch_bounds__(256) void k_csr_fwd2(
+    const float* __restrict__ x, const int64_t* __restrict__ row_ptr,
+    const int64_t* __restrict__ col, const float* __restrict__ w,
+    const uint8_t* __restrict__ mask, const float* __restrict__ w_rel,
+    const float* __restrict__ b_rel, const float* __restrict__ w_root, float* __restrict__ out,
+    float* __restrict__ agg_out, int64_t M, int Fi, int Fo, int act) {
+  using namespace gcm_fused;
+  constexpr int RB = 128, FP = 32 * NCT, HP = 32 * NHT, FS = FP + 1, HS = HP + 1;
+  constexpr int ECAP = 1024;             // edges of the block kept in LDS
+  constexpr int PER = RB * FP / 256;     // (row, feature) elements per thread
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int rows = (int)min((int64_t)RB, M - r0);
+
+  extern __shared__ float smem[];
+  float* sAgg = smem;                     // [RB][FS]   agg, then (second phase) the x rows
+  float* sW = sAgg + RB * FS;             // w_rel^T [f][HS] | w_root^T [f][HS]
+  int64_t* sE0 = reinterpret_cast<int64_t*>(sW + 2 * FP * HS + ((2 * FP * HS) & 1));   // 8-B aligned
+  int* sPtr = reinterpret_cast<int*>(sE0 + 1);            // [RB+1] edge offsets relative to e0
+  int* sCol = sPtr + RB + 2;              // [ECAP] source rows (32-bit: M < 2^31)
+  float* sWe = reinterpret_cast<float*>(sCol + ECAP);     // [ECAP] edge weights
+
+  // ---- weights, own rows, row_ptr slice --------------------------------------------------
+  Stage<HP, FP, true, false> st_wr, st_wo;
+  st_wr.load(w_rel, Fo, Fi, Fi, tid);
+  st_wo.load(w_root, Fo, Fi, Fi, tid);
+  int64_t my_ptr = 0;
+  if (tid <= RB) my_ptr = row_ptr[r0 + (tid < rows ? tid : rows)];
+  float xv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 256 * i, r = e / FP, f = e % FP;
+    const float t = x[(size_t)(r0 + (r < rows ? r : rows - 1)) * Fi + (f < Fi ? f : Fi - 1)];
+    const bool live = r < rows && f < Fi && (!mask || mask[r0 + (r < rows ? r : rows - 1)]);
+    xv[i] = live ? t : 0.f;
+  }
+  st_wr.store(sW, HS, tid);
+  st_wo.store(sW + FP * HS, HS, tid);
+  if (tid == 0) *sE0 = my_ptr;
+  __syncthreads();
+  const int64_t e0 = *sE0;
+  if (tid <= RB) sPtr[tid] = (int)(my_ptr - e0);
+  __syncthreads();
+  const int n_edges = sPtr[rows];
+  const int n_lds = min(n_edges, ECAP);
+  for (int k = tid; k < n_lds; k += 256) {
+    sCol[k] = (int)col[e0 + k];
+    sWe[k] = w ? w[e0 + k] : 1.f;
+  }
+  __syncthreads();
+  // ---- gather: agg[r][f] = sum_e w_e * x[col_e][f], my PER elements advance together ---------
+  float ag[PER];
+  int beg[PER], deg[PER], dmax = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 256 * i, r = e / FP;
+    ag[i] = 0.f;
+    const bool row_live = r < rows && (!mask || mask[r0 + (r < rows ? r : 0)]);
+    beg[i] = sPtr[r < rows ? r : 0];
+    deg[i] = row_live ? sPtr[(r < rows ? r : 0) + 1] - beg[i] : 0;
+    dmax = max(dmax, deg[i]);
+  }
+  // wave-wide maximum degree so that every lane runs the same trip count
+  for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+  const int f_mine = (tid % FP) < Fi ? (tid % FP) : Fi - 1;   // 256 % FP == 0: fixed column
+  // The hot loop holds ONLY unconditional loads (LDS index -> one global x read per element):
+  // every data-dependent choice (mask present, weights present, edge list fits LDS) is made by
+  // block-uniform branches outside it.
+  const bool fits = n_edges <= ECAP;
+  if (fits && !mask) {
+    for (int d = 0; d < dmax; ++d) {
+      float m[PER], we[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const bool on = d < deg[i];
+        const int k = on ? beg[i] + d : 0;
+        const int c = n_edges > 0 ? sCol[k] : 0;
+        we[i] = on ? sWe[k] : 0.f;
+        const float t = x[(size_t)c * Fi + f_mine];
+        m[i] = on ? t : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i)   // mul then add, separately rounded (msg = x_j * w; index_add)
+        ag[i] = __fadd_rn(ag[i], w ? __fmul_rn(we[i], m[i]) : m[i]);
+    }
+  } else {
+    // general path: masked subgraph and / or more edges than the LDS slice holds
+    for (int d = 0; d < dmax; ++d) {
+#pragma unroll 1
+      for (int i = 0; i < PER; ++i) {
+        if (d >= deg[i]) continue;
+        const int k = beg[i] + d;
+        const int64_t c = col[e0 + k];
+        if (mask && !mask[c]) continue;
+        const float t = x[(size_t)c * Fi + f_mine];
+        ag[i] = __fadd_rn(ag[i], w ? __fmul_rn(w[e0 + k], t) : t);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 256 * i, r = e / FP, f = e % FP;
+    const float a = (f < Fi) ? ag[i] : 0.f;
+    sAgg[r * FS + f] = a;
+    if (agg_out && r < rows && f < Fi) agg_out[(size_t)(r0 + r) * Fi + f] = a;
+  }
+  __syncthreads();
+  // ---- the two linears on the matrix cores: agg @ W_rel^T first, then the image is reused
+  //      for the x rows and x @ W_root^T is added ------------------------------------------------
+  f32x16 oo[NHT];
+#pragma unroll
+  for (int t = 0; t < NHT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oo[t][r] = 0.f;
+    mma32(oo[t], sAgg + wave * 32 * FS, FS, 1, sW + t * 32, HS, 1, FP, li, lh);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 256 * i, r = e / FP, f = e % FP;
+    sAgg[r * FS + f] = xv[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NHT; ++t) {
+    f32x16 o = oo[t];
+    mma32(o, sAgg + wave * 32 * FS, FS, 1, sW + FP * HS + t * 32, HS, 1, FP, li, lh);
+    const int c = t * 32 + li;
+    const float bias = (b_rel && c < Fo) ? b_rel[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + acc_row(r, lh);
+      if (row < rows && c < Fo) {
+        const bool live = !mask || mask[r0 + row];
+        out[(size_t)(r0 + row) * Fo + c] = live ? gcm_act(o[r] + bias, act) : 0.f;
+      }
+    }
+  }
+}
+
+// Row-local part of the backward for flat rows:  G = g_out * act'(out);
+//   ws_dagg = G @ W_rel ; g_x = G @ W_root (the transpose aggregation is added later) ;
+//   slab[block] = { G^T agg , G^T x , colsum G }.
+template <int NCT, int NHT>
+__global__ __launch_bounds__(256) void k_rows_bwd2(
+    const float* __restrict__ g_out, const float* __restrict__ out, const float* __restrict__ x,
+    const float* __restrict__ agg, const float* __restrict__ w_rel,
+    const float* __restrict__ w_root, float* __restrict__ g_x, float* __restrict__ ws_dagg,
+    float* __restrict__ slabs, int64_t M, int Fi, int Fo, int act, int want_w) {
+  using namespace gcm_fused;
+  constexpr int RB = 128, FP = 32 * NCT, HP = 32 * NHT, FS = FP + 1, HS = HP + 1;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int rows = (int)min((int64_t)RB, M - r0);
+  const float* gog = g_out + (size_t)r0 * Fo;
+  const float* og = out + (size_t)r0 * Fo;
+  const float* xg = x + (size_t)r0 * Fi;
+  const float* a1g = agg + (size_t)r0 * Fi;
+
+  extern __shared__ float smem[];
+  float* sG = smem;                  // [RB][HS]
+  float* sW = sG + RB * HS;          // w_rel [h][FS] | w_root [h][FS]
+  float* sR = sW + 2 * HP * FS;      // [4][1024]
+  float* sV = sR + 4 * 1024;         // [256]
+
+  Stage<RB, HP, false, false> st_go, st_o;
+  Stage<HP, FP, false, false> st_wr, st_wo;
+  st_go.load(gog, rows, Fo, Fo, tid);
+  st_o.load(og, rows, Fo, Fo, tid);
+  st_wr.load(w_rel, Fo, Fi, Fi, tid);
+  st_wo.load(w_root, Fo, Fi, Fi, tid);
+  float part = 0.f;
+#pragma unroll
+  for (int i = 0; i < st_go.PER; ++i) {
+    const float v = st_go.v[i] * gcm_act_grad(st_o.v[i], act);
+    st_go.v[i] = v;
+    part += v;
+  }
+  st_go.store(sG, HS, tid);
+  sV[tid] = part;
+  st_wr.store(sW, FS, tid);
+  st_wo.store(sW + HP * FS, FS, tid);
+  __syncthreads();
+  const int r_base = wave * 32;
+  if (want_w) {
+    float* slab = slabs + (size_t)blockIdx.x * (2 * (size_t)Fo * Fi + Fo);
+    if (tid < Fo) {
+      constexpr int G = 256 / HP;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < G; ++q) t += sV[q * HP + tid];
+      slab[2 * (size_t)Fo * Fi + tid] = t;
+    }
+#pragma unroll 1
+    for (int job = 0; job < 2 * NHT * NCT; ++job) {
+      const int which = job & 1, ct = (job >> 1) % NCT, ht = (job >> 1) / NCT;
+      const float* src = which ? xg : a1g;
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+      float bq[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int row = r_base + 2 * s + lh, f = ct * 32 + li;
+        const float t = src[(size_t)(row < rows ? row : rows - 1) * Fi + (f < Fi ? f : Fi - 1)];
+        bq[s] = (row < rows && f < Fi) ? t : 0.f;
+      }
+      const float* ap = sG + (r_base + lh) * HS + ht * 32 + li;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        a = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * HS], bq[s], a, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[wave * 1024 + acc_row(r, lh) * 32 + li] = a[r];
+      __syncthreads();
+      float* dst = slab + (which ? (size_t)Fo * Fi : 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, hh = ht * 32 + (e >> 5), ff = ct * 32 + (e & 31);
+        if (hh < Fo && ff < Fi)
+          dst[(size_t)hh * Fi + ff] = (sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    f32x16 d, g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { d[r] = 0.f; g[r] = 0.f; }
+    mma32(d, sG + r_base * HS, HS, 1, sW + c * 32, FS, 1, HP, li, lh);
+    mma32(g, sG + r_base * HS, HS, 1, sW + HP * FS + c * 32, FS, 1, HP, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r_base + acc_row(r, lh), col = c * 32 + li;
+      if (row < rows && col < Fi) {
+        ws_dagg[(size_t)(r0 + row) * Fi + col] = d[r];
+        if (g_x) g_x[(size_t)(r0 + row) * Fi + col] = g[r];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -565,7 +831,7 @@ extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, con
     int rc = gcm_layer_bwd(g_out, out, x, adj, agg, w_rel, w_root, g_x, g_adj, slabs, want_w, B, N,
                            Fi, Fo, act, s);
     if (rc != GCM_OK || !want_w) return rc;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(((int)p.slab_len + 63) / 64), dim3(256), 0, s, slabs, B,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(((int)p.slab_len + 15) / 16), dim3(256), 0, s, slabs, B,
                        (int)p.slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
     return gcm_launch_status();
   }
@@ -604,7 +870,7 @@ extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, con
   if (rc != GCM_OK) return rc;
   if (want_w) {
     const int slab_len = (int)p.slab_len;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 63) / 64), dim3(256), 0, s, slabs,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 15) / 16), dim3(256), 0, s, slabs,
                        B * p.nblk, slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
     rc = gcm_launch_status();
   }
@@ -624,9 +890,29 @@ extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, con
   GCM_REQUIRE(x && out);
   if (Fi > 128 || Fo > 128 || M > (int64_t)2147483647 - 256) return GCM_EUNSUPPORTED;
   const int FiP = round32(Fi);
-  const size_t lds = csr_fwd_lds_bytes(FiP);
   dim3 grid((unsigned)((M + 127) / 128));
   hipStream_t s = (hipStream_t)stream;
+  if (Fi <= 64 && Fo <= 64) {   // second-generation kernel
+    const int NCT = FiP / 32, NHT = round32(Fo) / 32;
+    const size_t lds2 = sizeof(float) * ((size_t)128 * (FiP + 1) + 2 * FiP * (32 * NHT + 1) + 1) + 8 +
+                        sizeof(int) * (128 + 2 + 1024) + sizeof(float) * 1024;
+#define GCM_CSR2(a, b_)                                                                         \
+  if (NCT == a && NHT == b_) {                                                                  \
+    auto kern = k_csr_fwd2<a, b_>;                                                              \
+    static bool attr_set = false;                                                               \
+    if (!attr_set && lds2 > 64 * 1024) {                                                        \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds2);                                                     \
+      attr_set = true;                                                                          \
+    }                                                                                           \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds2, s, x, row_ptr, col, w, mask, w_rel, b_rel,  \
+                       w_root, out, agg, M, Fi, Fo, act);                                       \
+    return gcm_launch_status();                                                                 \
+  }
+    GCM_CSR2(1, 1) GCM_CSR2(1, 2) GCM_CSR2(2, 1) GCM_CSR2(2, 2)
+#undef GCM_CSR2
+  }
+  const size_t lds = csr_fwd_lds_bytes(FiP);
 #define GCM_CSR_FWD(NCT)                                                                        \
   {                                                                                             \
     auto kern = k_csr_graphconv_fwd<NCT>;                                                       \
@@ -679,6 +965,27 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
   const size_t lds1 = bwd_rows_lds_bytes(p.waves, FiP, FoP);
   const int N = (int)M;
   float* no_adj = nullptr;
+  bool rows_done = false;
+  if (Fi <= 64 && Fo <= 64 && p.waves == 4) {   // second-generation row-local kernel
+    const int NCT = FiP / 32, NHT = FoP / 32;
+    const size_t lds2 = sizeof(float) * ((size_t)128 * (FoP + 1) + 2 * FoP * (FiP + 1) + 4 * 1024 + 256);
+#define GCM_ROWS2(a, b_)                                                                        \
+  if (NCT == a && NHT == b_) {                                                                  \
+    auto kern = k_rows_bwd2<a, b_>;                                                             \
+    static bool attr_set = false;                                                               \
+    if (!attr_set && lds2 > 64 * 1024) {                                                        \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds2);                                                     \
+      attr_set = true;                                                                          \
+    }                                                                                           \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds2, s, g_out, out, x, agg, w_rel, w_root, g_x,  \
+                       ws_dagg, slabs, M, Fi, Fo, act, want_w);                                 \
+    rows_done = true;                                                                           \
+  }
+    GCM_ROWS2(1, 1) GCM_ROWS2(1, 2) GCM_ROWS2(2, 1) GCM_ROWS2(2, 2)
+#undef GCM_ROWS2
+  }
+  if (!rows_done) {
 #define GCM_CSR_BWD(W, C)                                                                       \
   {                                                                                             \
     auto k1 = k_graphconv_bwd_rows<W, C>;                                                       \
@@ -702,6 +1009,7 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
   }
 #undef GCM_CSR_BWD_W
 #undef GCM_CSR_BWD
+  }
   int rc = gcm_launch_status();
   if (rc != GCM_OK) return rc;
   if (g_x && E > 0) {
@@ -715,7 +1023,7 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
   }
   if (want_w) {
     const int slab_len = (int)p.slab_len;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 63) / 64), dim3(256), 0, s, slabs, p.nblk,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 15) / 16), dim3(256), 0, s, slabs, p.nblk,
                        slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
   }
   return gcm_launch_status();

@@ -108,23 +108,39 @@ __global__ __launch_bounds__(256) void k_temporal_count(const int64_t* __restric
                                                         const int64_t* __restrict__ taus,
                                                         Hops16 hops, int n_hops,
                                                         int64_t* __restrict__ edge_off, int B) {
-  // one workgroup: per-graph counts (closed loop over tau), then a serial scan by thread 0
+  // one workgroup: per-graph counts in closed form (per hop: new nodes t >= max(h, 1)), then a
+  // two-level scan (per-thread chunks, 256 partials by thread 0)
   extern __shared__ int64_t cnt[];
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+  __shared__ int64_t chunk_sum[256];
+  const int per = (B + 255) / 256;
+  const int lo = min(B, (int)threadIdx.x * per), hi = min(B, lo + per);
+  int64_t run = 0;
+  for (int b = lo; b < hi; ++b) {
+    const int64_t t0 = T[b], tau = taus[b] > 0 ? taus[b] : 0;
     int64_t c = 0;
-    const int64_t t0 = T[b], tau = taus[b];
-    for (int64_t k = 0; k < tau; ++k) c += temporal_degree(t0 + k, hops, n_hops);
-    cnt[b] = c;
+    for (int i = 0; i < n_hops; ++i) {
+      const int64_t h = hops.h[i];
+      if (h < 0) continue;
+      const int64_t first = (h > 1 ? h : 1) > t0 ? (h > 1 ? h : 1) : t0;
+      const int64_t n = t0 + tau - first;
+      c += n > 0 ? n : 0;
+    }
+    cnt[b] = run;      // exclusive within the chunk
+    run += c;
   }
+  chunk_sum[threadIdx.x] = run;
   __syncthreads();
   if (threadIdx.x == 0) {
-    int64_t run = 0;
-    for (int b = 0; b < B; ++b) {
-      edge_off[b] = run;
-      run += cnt[b];
+    int64_t acc = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int64_t t = chunk_sum[i];
+      chunk_sum[i] = acc;
+      acc += t;
     }
-    edge_off[B] = run;
+    edge_off[B] = acc;
   }
+  __syncthreads();
+  for (int b = lo; b < hi; ++b) edge_off[b] = cnt[b] + chunk_sum[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_temporal_fill(const int64_t* __restrict__ T,
