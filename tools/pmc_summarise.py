@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -19,8 +20,9 @@ def per_kernel(d, counter):
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == counter:
-                acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+            m = re.search(r"\b(k_[A-Za-z0-9_]+)", row["Kernel_Name"])
+            if m and row.get("Counter_Name") == counter:
+                acc[m.group(1)].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
@@ -28,9 +30,7 @@ fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
 write, _ = per_kernel(write_dir, "WRITE_SIZE")
 out = {}
 for k in sorted(fetch):
-    short = k.split("::")[-1].split("<")[0]
-    if not short.startswith("k_"):
-        continue
+    short = k
     f_kib, w_kib = fetch[k], write.get(k, 0.0)
     out.setdefault(short, {
         "kernel": k, "launches": nf[k],
