@@ -78,6 +78,59 @@ __global__ __launch_bounds__(256) void k_state_advance(
   }
 }
 
+
+// 16-byte version of the forward copy (N % 4 == 0 and F % 4 == 0): one float4 per thread and
+// step; the rolled source (one row down, one column right) is read with a dword-aligned
+// 16-byte load, the last column group is shifted in registers.
+__global__ __launch_bounds__(256) void k_state_advance_vec(
+    const float* __restrict__ nodes_in, const float* __restrict__ adj_in,
+    const float* __restrict__ w_in, const int64_t* __restrict__ num_nodes_in,
+    const float* __restrict__ x, float* __restrict__ nodes_out, float* __restrict__ adj_out,
+    float* __restrict__ w_out, int64_t* __restrict__ cur_idx_out,
+    int64_t* __restrict__ num_nodes_out, uint32_t* __restrict__ flags, int N, int F,
+    int rows_per_block) {
+  const int b = blockIdx.y;
+  const int plane = blockIdx.z;
+  const int64_t n_in = num_nodes_in[b];
+  const bool bad = n_in < 0 || n_in > N;
+  const bool wrap = n_in + 1 > N;
+  int64_t cur64 = wrap ? n_in - 1 : n_in;
+  const int cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
+  const float* src;
+  float* dst;
+  int W;
+  bool square;
+  if (plane == 0) { src = nodes_in; dst = nodes_out; W = F; square = false; }
+  else if (plane == 1) { src = adj_in; dst = adj_out; W = N; square = true; }
+  else { src = w_in; dst = w_out; W = N; square = true; }
+  if (src == nullptr || dst == nullptr) return;
+  src += (size_t)b * N * W;
+  dst += (size_t)b * N * W;
+  if (plane == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    cur_idx_out[b] = cur;
+    num_nodes_out[b] = cur + 1;
+    const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u);
+    if (f) atomicOr(flags, f);
+  }
+  const int W4 = W >> 2;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(N, r0 + rows_per_block);
+  const int total = (r1 - r0) * W4;
+  const int sh = wrap ? 1 : 0;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = r0 + e / W4, c = (e % W4) * 4;
+    const int rs = r + sh < N ? r + sh : N - 1;
+    const int csh = square ? sh : 0;
+    const bool tail = csh && c + 4 >= W;
+    float4 v;
+    __builtin_memcpy(&v, src + (size_t)rs * W + c + (tail ? 0 : csh), sizeof(float4));
+    if (tail) v = make_float4(v.y, v.z, v.w, 0.f);
+    if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (plane == 0 && r == cur) v = *reinterpret_cast<const float4*>(x + (size_t)b * F + c);
+    *reinterpret_cast<float4*>(dst + (size_t)r * W + c) = v;
+  }
+}
+
 extern "C" int gcm_state_advance_fwd(const float* nodes_in, const float* adj_in,
                                      const float* weights_in, const int64_t* num_nodes_in,
                                      const float* x, float* nodes_out, float* adj_out,
@@ -91,6 +144,14 @@ extern "C" int gcm_state_advance_fwd(const float* nodes_in, const float* adj_in,
   const int rows_per_block = 16;
   const int planes = weights_in ? 3 : (adj_in ? 2 : 1);
   dim3 grid((N + rows_per_block - 1) / rows_per_block, B, planes);
+  auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  if ((N & 3) == 0 && (F & 3) == 0 && aligned16(nodes_in) && aligned16(nodes_out) && aligned16(x) &&
+      aligned16(adj_in) && aligned16(adj_out) && aligned16(weights_in) && aligned16(weights_out)) {
+    hipLaunchKernelGGL(k_state_advance_vec, grid, dim3(256), 0, (hipStream_t)stream, nodes_in,
+                       adj_in, weights_in, num_nodes_in, x, nodes_out, adj_out, weights_out,
+                       cur_idx_out, num_nodes_out, flags, N, F, rows_per_block);
+    return gcm_launch_status();
+  }
   hipLaunchKernelGGL(k_state_advance<false>, grid, dim3(256), 0, (hipStream_t)stream, nodes_in,
                      adj_in, weights_in, num_nodes_in, x, nodes_out, adj_out, weights_out,
                      (float*)nullptr, cur_idx_out, num_nodes_out, flags, N, F, rows_per_block);
