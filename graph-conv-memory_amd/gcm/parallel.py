@@ -17,6 +17,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    if os.environ.get("GCM_SINGLE_DEVICE") == "1":
+        local_rank = 0          # test hook: every rank on cuda:0 (with GCM_DIST_BACKEND=gloo)
+    backend = backend or os.environ.get("GCM_DIST_BACKEND")
     if use_cuda:
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
