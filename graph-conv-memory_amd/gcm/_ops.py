@@ -578,8 +578,14 @@ class StepConfig:
         self.ws_bytes = 0
         self.ws = None
         self.device = device
+        self._layouts = {}
+        self.fn_fwd = lib.gcm_dense_step_fwd
+        self.fn_bwd = lib.gcm_dense_step_bwd
+        self.has_distance = any(d.kind == _hip.SEL_DISTANCE for d in descs)
 
     def workspace(self, B):
+        if not self.has_distance:
+            return None, 0
         need = 0
         for d in self.descs:
             if d.kind == _hip.SEL_DISTANCE:
@@ -588,6 +594,26 @@ class StepConfig:
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self.ws_bytes = need
         return (self.ws.data_ptr() if self.ws is not None else None), self.ws_bytes
+
+    def layout(self, B, need_bwd):
+        """(total floats, float offsets of nodes|adj|mx|h1|agg1|agg2, bwd layout) for a batch size"""
+        key = (B, need_bwd)
+        lay = self._layouts.get(key)
+        if lay is None:
+            N, F, H1, H2, P = self.N, self.F, self.H1, self.H2, self.P
+            n_nodes, n_adj, n_mx = _pad64(B * N * F), _pad64(B * N * N), _pad64(B * H2)
+            n_h1, n_agg2 = _pad64(B * N * H1), _pad64(B * H1)
+            o_adj = n_nodes
+            o_mx = o_adj + n_adj
+            o_h1 = o_mx + n_mx
+            o_agg1 = o_h1 + n_h1
+            o_agg2 = o_agg1 + n_nodes
+            total = (o_agg2 + n_agg2) if need_bwd else o_h1
+            n_obs, n_p = _pad64(B * F), _pad64(P)
+            bwd = (n_nodes + n_obs + n_p + B * P, n_nodes, n_nodes + n_obs, n_nodes + n_obs + n_p)
+            lay = (total, o_adj, o_mx, o_h1, o_agg1, o_agg2, bwd)
+            self._layouts[key] = lay
+        return lay
 
     def unpack_ptrs(self, packed):
         """device pointers (w_rel1, b1, w_root1, w_rel2, b2, w_root2) into the packed vector"""
@@ -611,40 +637,41 @@ class _FusedStep(torch.autograd.Function):
     """One DenseGCM step as ONE autograd node and ONE C call per direction
     (gcm_dense_step_fwd / gcm_dense_step_bwd): (obs, nodes_in, packed params) ->
     (mx, nodes_out, adj_out, cur, count_out).  Outputs and the activations saved for backward
-    live in one allocation."""
+    live in one allocation.  (This is the per-step hot loop of the host: no helper layers.)"""
 
     @staticmethod
     def forward(ctx, obs, nodes_in, packed, adj_in, count_in, flags, cfg):
-        obs, nodes_in, adj_in = obs.contiguous(), nodes_in.contiguous(), adj_in.contiguous()
+        if not (obs.is_contiguous() and nodes_in.is_contiguous() and adj_in.is_contiguous()):
+            obs, nodes_in, adj_in = obs.contiguous(), nodes_in.contiguous(), adj_in.contiguous()
         B = obs.shape[0]
-        N, F, H1, H2 = cfg.N, cfg.F, cfg.H1, cfg.H2
-        dev = obs.device
-        need_bwd = any(ctx.needs_input_grad)
-        n_nodes, n_adj, n_mx = _pad64(B * N * F), _pad64(B * N * N), _pad64(B * H2)
-        n_h1, n_agg2 = _pad64(B * N * H1), _pad64(B * H1)
-        total = n_nodes + n_adj + n_mx + ((n_h1 + n_nodes + n_agg2) if need_bwd else 0)
-        buf = torch.empty(total, device=dev, dtype=_f32)
-        ibuf = torch.empty(2, B, device=dev, dtype=torch.int64)
+        N, F, H2 = cfg.N, cfg.F, cfg.H2
+        need = ctx.needs_input_grad
+        need_bwd = need[0] or need[1] or need[2]
+        total, o_adj, o_mx, o_h1, o_agg1, o_agg2, _ = cfg.layout(B, need_bwd)
+        buf = torch.empty(total, device=obs.device, dtype=_f32)
+        ibuf = torch.empty(2, B, device=obs.device, dtype=torch.int64)
         base = buf.data_ptr()
-        p_nodes = base
-        p_adj = p_nodes + 4 * n_nodes
-        p_mx = p_adj + 4 * n_adj
-        p_h1 = p_mx + 4 * n_mx if need_bwd else None
-        p_agg1 = p_h1 + 4 * n_h1 if need_bwd else None
-        p_agg2 = p_agg1 + 4 * n_nodes if need_bwd else None
-        ws_ptr, ws_bytes = cfg.workspace(B)
         ib = ibuf.data_ptr()
-        _call("gcm_dense_step_fwd", obs.data_ptr(), nodes_in.data_ptr(), adj_in.data_ptr(),
-              count_in.data_ptr(), p_nodes, p_adj, ib, ib + 8 * B, cfg.arr_ptr, cfg.n_desc,
-              packed.data_ptr(), cfg.has_bias, cfg.acts[0], cfg.acts[1], p_mx, p_h1, p_agg1, p_agg2,
-              flags.data_ptr(), ws_ptr, ws_bytes, B, N, F, H1, H2, _hip.stream())
+        if need_bwd:
+            p_h1, p_agg1, p_agg2 = base + 4 * o_h1, base + 4 * o_agg1, base + 4 * o_agg2
+        else:
+            p_h1 = p_agg1 = p_agg2 = None
+        ws_ptr, ws_bytes = cfg.workspace(B)
+        args = (obs.data_ptr(), nodes_in.data_ptr(), adj_in.data_ptr(), count_in.data_ptr(), base,
+                base + 4 * o_adj, ib, ib + 8 * B, cfg.arr_ptr, cfg.n_desc, packed.data_ptr(),
+                cfg.has_bias, cfg.acts[0], cfg.acts[1], base + 4 * o_mx, p_h1, p_agg1, p_agg2,
+                flags.data_ptr(), ws_ptr, ws_bytes, B, N, F, cfg.H1, H2,
+                torch.cuda.current_stream().cuda_stream)
+        rc = TIMER.launch("gcm_dense_step_fwd", cfg.fn_fwd, *args) if TIMER is not None \
+            else cfg.fn_fwd(*args)
+        if rc:
+            _hip.check(rc, "gcm_dense_step_fwd")
         nodes_out = buf[:B * N * F].view(B, N, F)
-        adj_out = buf[n_nodes:n_nodes + B * N * N].view(B, N, N)
-        mx = buf[n_nodes + n_adj:n_nodes + n_adj + B * H2].view(B, H2)
+        adj_out = buf[o_adj:o_adj + B * N * N].view(B, N, N)
+        mx = buf[o_mx:o_mx + B * H2].view(B, H2)
         cur, count_out = ibuf[0], ibuf[1]
         ctx.save_for_backward(buf, ibuf, count_in, packed)
         ctx.cfg, ctx.B = cfg, B
-        ctx.ptrs = (p_nodes, p_adj, p_mx, p_h1, p_agg1, p_agg2)
         ctx.mark_non_differentiable(adj_out, cur, count_out)
         return mx, nodes_out, adj_out, cur, count_out
 
@@ -652,25 +679,32 @@ class _FusedStep(torch.autograd.Function):
     def backward(ctx, g_mx, g_nodes_out, _ga, _gc, _gn):
         buf, ibuf, count_in, packed = ctx.saved_tensors
         cfg, B = ctx.cfg, ctx.B
-        N, F, H1, H2, P = cfg.N, cfg.F, cfg.H1, cfg.H2, cfg.P
-        dev = buf.device
-        p_nodes, p_adj, p_mx, p_h1, p_agg1, p_agg2 = ctx.ptrs
+        N, F, H2, P = cfg.N, cfg.F, cfg.H2, cfg.P
+        _, o_adj, o_mx, o_h1, o_agg1, o_agg2, (tot_b, o_obs, o_par, o_ws) = cfg.layout(B, True)
         if g_mx is None:
-            g_mx = torch.zeros(B, H2, device=dev)
-        g_mx = g_mx.contiguous()
-        g_no = None if g_nodes_out is None else g_nodes_out.contiguous()
-        n_nodes, n_obs, n_p = _pad64(B * N * F), _pad64(B * F), _pad64(P)
-        out = torch.empty(n_nodes + n_obs + n_p + B * P, device=dev, dtype=_f32)
+            g_mx = torch.zeros(B, H2, device=buf.device)
+        elif not g_mx.is_contiguous():
+            g_mx = g_mx.contiguous()
+        if g_nodes_out is None:
+            g_no = None
+        else:
+            g_no = (g_nodes_out if g_nodes_out.is_contiguous() else g_nodes_out.contiguous()).data_ptr()
+        out = torch.empty(tot_b, device=buf.device, dtype=_f32)
         ob = out.data_ptr()
-        _call("gcm_dense_step_bwd", g_mx.data_ptr(), None if g_no is None else g_no.data_ptr(),
-              p_nodes, p_adj, ibuf.data_ptr(), count_in.data_ptr(), packed.data_ptr(), cfg.has_bias,
-              cfg.acts[0], cfg.acts[1], p_mx, p_h1, p_agg1, p_agg2, ob, ob + 4 * n_nodes,
-              ob + 4 * (n_nodes + n_obs), ob + 4 * (n_nodes + n_obs + n_p), 4 * B * P, B, N, F, H1,
-              H2, _hip.stream())
+        base = buf.data_ptr()
+        args = (g_mx.data_ptr(), g_no, base, base + 4 * o_adj, ibuf.data_ptr(), count_in.data_ptr(),
+                packed.data_ptr(), cfg.has_bias, cfg.acts[0], cfg.acts[1], base + 4 * o_mx,
+                base + 4 * o_h1, base + 4 * o_agg1, base + 4 * o_agg2, ob, ob + 4 * o_obs,
+                ob + 4 * o_par, ob + 4 * o_ws, 4 * B * P, B, N, F, cfg.H1, H2,
+                torch.cuda.current_stream().cuda_stream)
+        rc = TIMER.launch("gcm_dense_step_bwd", cfg.fn_bwd, *args) if TIMER is not None \
+            else cfg.fn_bwd(*args)
+        if rc:
+            _hip.check(rc, "gcm_dense_step_bwd")
         need = ctx.needs_input_grad
         g_nodes_in = out[:B * N * F].view(B, N, F) if need[1] else None
-        g_obs = out[n_nodes:n_nodes + B * F].view(B, F) if need[0] else None
-        g_params = out[n_nodes + n_obs:n_nodes + n_obs + P] if need[2] else None
+        g_obs = out[o_obs:o_obs + B * F].view(B, F) if need[0] else None
+        g_params = out[o_par:o_par + P] if need[2] else None
         return g_obs, g_nodes_in, g_params, None, None, None, None
 
 
