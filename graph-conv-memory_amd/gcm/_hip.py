@@ -57,6 +57,12 @@ PROTOTYPES = {
     "gcm_learned_pairs_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gcm_learned_select_fwd": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "gcm_learned_select_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "gcm_causal_count": (_I, [_P, _P, _I, _P, _P, _I, _P]),
+    "gcm_causal_fill": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _L, _I, _P]),
+    "gcm_causal_pairs_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "gcm_causal_pairs_bwd": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "gcm_segment_softmax_fwd": (_I, [_P] * 5 + [_L, _L, _P]),
+    "gcm_segment_softmax_bwd": (_I, [_P] * 8 + [_L, _L, _P]),
     "gcm_posenc_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gcm_pack_hidden": (_I, [_P] * 6 + [_L, _I, _I, _P]),
     "gcm_dense_gnn2_row_supported": (_I, [_I, _I, _I, _I]),

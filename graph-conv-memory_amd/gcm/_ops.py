@@ -824,3 +824,86 @@ def pack_hidden(coo, values, B, max_edges, edge_fill, weight_fill):
     for n in counts:
         assert n < max_edges, f"Cannot pack {n} edges into {max_edges}, increase max edges"
     return dense_edges, dense_weights
+
+
+# ===========================================================================
+# sparse LearnedEdge (sparse_edge_selectors/learned.py:90-160)
+# ===========================================================================
+class CausalEdges:
+    """Closed-form causal candidate edges of a batch (util.get_causal_edges util.py:242-282):
+    indices [3, E] (batch, sink, source) in coalesced order + the sink-row segments."""
+
+    def __init__(self, T, taus, window):
+        _hip.on_device(T, taus)
+        B = T.numel()
+        dev = T.device
+        self.T, self.taus, self.B = T, taus, B
+        self.window = -1 if window is None else int(window)
+        offs = torch.empty(2, B + 1, dtype=_i64, device=dev)
+        self.edge_off, self.seg_off = offs[0], offs[1]
+        _call("gcm_causal_count", _hip.ptr(T), _hip.ptr(taus), self.window, _hip.ptr(self.edge_off),
+              _hip.ptr(self.seg_off), B, _hip.stream())
+        self.E, self.S = (int(v) for v in offs[:, B].tolist())           # one readback
+        self.indices = torch.empty(3, self.E, dtype=_i64, device=dev)
+        self.seg_ptr = torch.empty(self.S + 1, dtype=_i64, device=dev)
+        _call("gcm_causal_fill", _hip.ptr(T), _hip.ptr(taus), self.window, _hip.ptr(self.edge_off),
+              _hip.ptr(self.seg_off), _hip.ptr(self.indices), _hip.ptr(self.seg_ptr), self.E,
+              self.S, B, _hip.stream())
+
+
+class _CausalPairs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nodes, edges):
+        nodes = nodes.contiguous()
+        B, N, F = nodes.shape
+        pairs = torch.empty(edges.E, 2 * F, device=nodes.device, dtype=_f32)
+        _call("gcm_causal_pairs_fwd", _hip.ptr(nodes), _hip.ptr(edges.indices), _hip.ptr(pairs),
+              edges.E, B, N, F, _hip.stream())
+        ctx.edges, ctx.dims = edges, (B, N, F)
+        return pairs
+
+    @staticmethod
+    def backward(ctx, g_pairs):
+        e = ctx.edges
+        B, N, F = ctx.dims
+        g_pairs = g_pairs.contiguous()
+        g_nodes = torch.empty(B, N, F, device=g_pairs.device, dtype=_f32)
+        _call("gcm_causal_pairs_bwd", _hip.ptr(g_pairs), _hip.ptr(e.T), _hip.ptr(e.taus), e.window,
+              _hip.ptr(e.edge_off), _hip.ptr(g_nodes), e.E, B, N, F, _hip.stream())
+        return g_nodes, None
+
+
+def causal_pairs(nodes, edges):
+    return _CausalPairs.apply(nodes, edges)
+
+
+class _SegmentSoftmax(torch.autograd.Function):
+    """soft = softmax over each sink row of (logits + noise) / tau  (util.py:89-113, hard=False)."""
+
+    @staticmethod
+    def forward(ctx, logits, tau, noise, edges):
+        logits, noise = logits.contiguous(), noise.contiguous()
+        tau_d = tau.detach().to(device=logits.device, dtype=_f32).contiguous()
+        soft = torch.empty_like(logits)
+        _call("gcm_segment_softmax_fwd", _hip.ptr(logits), _hip.ptr(noise), _hip.ptr(tau_d),
+              _hip.ptr(edges.seg_ptr), _hip.ptr(soft), edges.S, edges.E, _hip.stream())
+        ctx.save_for_backward(soft, logits, noise, tau_d)
+        ctx.edges, ctx.tau_shape = edges, tau.shape
+        return soft
+
+    @staticmethod
+    def backward(ctx, g_soft):
+        soft, logits, noise, tau_d = ctx.saved_tensors
+        e = ctx.edges
+        g_soft = g_soft.contiguous()
+        g_logits = torch.empty_like(logits)
+        g_tau_rows = torch.zeros(max(e.S, 1), device=logits.device, dtype=_f32)
+        _call("gcm_segment_softmax_bwd", _hip.ptr(g_soft), _hip.ptr(soft), _hip.ptr(logits),
+              _hip.ptr(noise), _hip.ptr(tau_d), _hip.ptr(e.seg_ptr), _hip.ptr(g_logits),
+              _hip.ptr(g_tau_rows), e.S, e.E, _hip.stream())
+        g_tau = g_tau_rows.sum().reshape(ctx.tau_shape) if ctx.needs_input_grad[1] else None
+        return g_logits, g_tau, None, None
+
+
+def segment_softmax(logits, tau, noise, edges):
+    return _SegmentSoftmax.apply(logits, tau, noise, edges)

@@ -53,3 +53,36 @@ def unpack_hidden(hidden, B):
     adj = torch.sparse_coo_tensor(indices=adj_idx, values=weights[batch_idx, 0, edge_idx],
                                   size=(B, nodes.shape[1], nodes.shape[1]))
     return nodes, adj, T
+
+
+def get_causal_edges(T, taus, window=None):
+    """util.py:242-282 - every (batch, sink, source) pair with sink a new node (T <= sink <
+    T + tau), source < sink and, with a window, source >= max(0, T - window); coalesced order.
+    Closed form on the device instead of a Python loop over tril_indices."""
+    from . import _ops
+    return _ops.CausalEdges(T, taus, window).indices
+
+
+def sparse_gumbel_softmax(logits, dim, tau=1, hard=False, noise=None):
+    """util.py:89-130 for the layout this path uses: logits a coalesced torch.sparse_coo
+    [B,N,N] with indices (batch, sink, source), softmax over dim=2 inside every (batch, sink)
+    row.  hard=True (scatter_max over rows) is not implemented."""
+    from . import _ops
+    if hard or dim not in (2, -1):
+        raise NotImplementedError("only the soft, dim=2 form used by LearnedEdge is implemented")
+    logits = logits.coalesce()
+    idx, vals = logits.indices(), logits.values()
+    key = idx[0] * logits.shape[1] + idx[1]
+    first = torch.ones_like(key, dtype=torch.bool)
+    first[1:] = key[1:] != key[:-1]
+    seg_ptr = torch.cat([first.nonzero().flatten(), torch.tensor([key.numel()], device=key.device)])
+
+    class _Rows:
+        pass
+    rows = _Rows()
+    rows.seg_ptr, rows.S, rows.E = seg_ptr.contiguous(), seg_ptr.numel() - 1, key.numel()
+    if noise is None:
+        noise = -torch.empty_like(vals).exponential_().log()
+    tau_t = tau if torch.is_tensor(tau) else torch.tensor([float(tau)], device=vals.device)
+    soft = _ops.segment_softmax(vals, tau_t, noise, rows)
+    return torch.sparse_coo_tensor(idx, soft, size=logits.shape)

@@ -376,6 +376,40 @@ int gcm_pack_hidden(const int64_t* coo, const float* values, const int64_t* batc
                     int64_t* dense_edges, float* dense_weights, uint32_t* flags, int64_t E, int B,
                     int max_edges, gcm_stream_t stream);
 
+/* ---- sparse LearnedEdge (src/gcm/sparse_edge_selectors/learned.py:90-160) -------------- */
+
+/* util.get_causal_edges (util.py:242-282) in closed form: for graph b the candidate edges are
+ * (sink i, source j) with i in [T_b, T_b+tau_b), lo_b <= j < i, lo_b = window < 0 ? 0 :
+ * max(0, T_b - window); ordered by (batch, sink, source) = coalesced COO order.
+ * count: edge_off [B+1] (edges before graph b) and seg_off [B+1] (sink rows before graph b).
+ * fill : indices [3, E] rows (batch, sink, source) and seg_ptr [S+1] (S = seg_off[B] sink rows;
+ *        seg_ptr[s] = first edge of sink row s). */
+int gcm_causal_count(const int64_t* T, const int64_t* taus, int window, int64_t* edge_off,
+                     int64_t* seg_off, int B, gcm_stream_t stream);
+int gcm_causal_fill(const int64_t* T, const int64_t* taus, int window, const int64_t* edge_off,
+                    const int64_t* seg_off, int64_t* indices, int64_t* seg_ptr, int64_t E,
+                    int64_t S, int B, gcm_stream_t stream);
+
+/* learned.py:121-124: pairs[e, :] = cat(nodes[b, sink_e], nodes[b, source_e])  ([E, 2F]). */
+int gcm_causal_pairs_fwd(const float* nodes, const int64_t* indices, float* pairs, int64_t E,
+                         int B, int N, int F, gcm_stream_t stream);
+/* adjoint; the source half is gathered through the closed-form edge positions (no atomics).
+ * g_nodes [B,N,F] is overwritten. */
+int gcm_causal_pairs_bwd(const float* g_pairs, const int64_t* T, const int64_t* taus, int window,
+                         const int64_t* edge_off, float* g_nodes, int64_t E, int B, int N, int F,
+                         gcm_stream_t stream);
+
+/* util.sparse_gumbel_softmax (util.py:89-113, hard=False) over the sink rows:
+ * soft[e] = softmax over the row's edges of (logits[e] + noise[e]) / tau.  tau: device scalar. */
+int gcm_segment_softmax_fwd(const float* logits, const float* noise, const float* tau,
+                            const int64_t* seg_ptr, float* soft, int64_t S, int64_t E,
+                            gcm_stream_t stream);
+/* backward: g_logits [E]; g_tau_rows [S] = per-row contribution to d tau (caller sums). */
+int gcm_segment_softmax_bwd(const float* g_soft, const float* soft, const float* logits,
+                            const float* noise, const float* tau, const int64_t* seg_ptr,
+                            float* g_logits, float* g_tau_rows, int64_t S, int64_t E,
+                            gcm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,51 @@ def unpack_hidden(hidden, B):
     idx = torch.stack([b_idx, edges[b_idx, 0, e_idx], edges[b_idx, 1, e_idx]])
     adj = torch.sparse_coo_tensor(idx, weights[b_idx, 0, e_idx], size=(B, nodes.shape[1], nodes.shape[1]))
     return nodes, adj, T
+
+
+# --------------------------------------------------------------------------
+# sparse LearnedEdge (sparse_edge_selectors/learned.py:90-160) - SURVEY 8(f) rank 3
+# --------------------------------------------------------------------------
+def get_causal_edges(T, taus, window=None):
+    """util.py:242-282."""
+    out = []
+    for b in range(T.numel()):
+        t, tau = int(T[b]), int(taus[b])
+        edge = torch.tril_indices(t + tau, t + tau, offset=-1)
+        if window is not None:
+            edge = edge[:, edge[1] >= max(0, t - window)]
+        edge = edge[:, edge[0] >= t]
+        out.append(torch.cat((torch.full((1, edge.shape[1]), b, dtype=torch.long), edge), dim=0))
+    return torch.cat(out, dim=-1)
+
+
+def sparse_gumbel_softmax(logits, dim, tau=1.0, noise=None):
+    """util.py:89-113 (hard=False)."""
+    logits = logits.coalesce()
+    g = noise if noise is not None else -torch.empty_like(logits.values()).exponential_().log()
+    z = torch.sparse_coo_tensor(logits.indices(), (logits.values() + g) / tau, size=logits.shape)
+    return torch.sparse.softmax(z, dim=dim).coalesce()
+
+
+class LearnedEdge:
+    """sparse_edge_selectors/learned.py:90-160 (non-deterministic branch); `noise_fn(n)` supplies
+    the gumbel draws."""
+
+    def __init__(self, edge_network, num_edge_samples=5, window=None, tau=1.0, noise_fn=None):
+        self.net, self.k, self.window, self.tau = edge_network, num_edge_samples, window, tau
+        self.noise_fn = noise_fn
+
+    def __call__(self, nodes, T, taus, B):
+        N = nodes.shape[1]
+        if int((T + taus).max()) <= 1:
+            return torch.sparse_coo_tensor(torch.zeros(3, 0, dtype=torch.long), torch.zeros(0),
+                                           size=(B, N, N))
+        idx = get_causal_edges(T, taus, self.window)
+        b, sink, src = idx.unbind()
+        logits = self.net(torch.cat((nodes[b, sink], nodes[b, src]), dim=-1)).squeeze()
+        gs_in = torch.sparse_coo_tensor(idx, logits, size=(B, N, N))
+        noise = self.noise_fn(logits.numel()) if self.noise_fn else None
+        soft = sparse_gumbel_softmax(gs_in, 2, self.tau, noise)
+        keep = soft.values() > 1 / (1 + self.k)
+        v = soft.values()[keep]
+        return torch.sparse_coo_tensor(soft.indices()[:, keep], v / v.detach(), size=(B, N, N))

@@ -311,6 +311,63 @@ def main():
          nodes=nodes, T=Tt, dense_edges=pe_, dense_weights=pw, un_idx=uadj.coalesce().indices(),
          un_val=uadj.coalesce().values())
 
+    # ---- G12: SparseGCM + sparse LearnedEdge with recorded gumbel noise ----
+    from gcm.sparse_edge_selectors.learned import LearnedEdge as SparseLearnedEdge
+    real_sgs = gcm.util.sparse_gumbel_softmax
+    for name, window in [("g12_sparse_learned", None), ("g12_sparse_learned_win3", 3)]:
+        torch.manual_seed(0)
+        B, N, F, H = 3, 12, 4, 5
+        gnn = osp.canonical_gnn(F, H, act=torch.nn.Tanh)
+        sel = SparseLearnedEdge(F, num_edge_samples=3, window=window, store_grads=False)
+        noises = []
+
+        def recording(logits, dim, tau=1, hard=False):
+            state = torch.get_rng_state()
+            out = real_sgs(logits, dim=dim, tau=tau, hard=hard)
+            after = torch.get_rng_state()
+            torch.set_rng_state(state)
+            noises.append(-torch.empty_like(logits.coalesce().values()).exponential_().log())
+            torch.set_rng_state(after)
+            return out
+
+        gcm.util.sparse_gumbel_softmax = recording
+        try:
+            m = SparseGCM(gnn, edge_selectors=sel, graph_size=N)
+            obs = torch.randn(B, 9, F).requires_grad_(True)
+            plan = [torch.tensor([3, 1, 2]), torch.tensor([2, 2, 2]), torch.tensor([4, 1, 3])]
+            hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
+            for taus in plan:
+                t = int(taus.max())
+                x = torch.zeros(B, t, F)
+                for b in range(B):
+                    x[b, : taus[b]] = obs[b, pos[b]: pos[b] + taus[b]]
+                out, hidden = m(x, taus, hidden)
+                outs.append(out)
+                pos = pos + taus
+            loss = sum(o.sum() for o in outs) / sum(o.numel() for o in outs)
+            loss.backward()
+        finally:
+            gcm.util.sparse_gumbel_softmax = real_sgs
+        arrays = dict(obs=obs.detach(), grad_obs=obs.grad, taus=torch.stack(plan), hT_nodes=hidden[0],
+                      hT_adj_indices=hidden[1].coalesce().indices(),
+                      hT_adj_values=hidden[1].coalesce().values().detach(), hT_T=hidden[2])
+        for i, o in enumerate(outs):
+            arrays[f"out{i}"] = o
+        for i, g in enumerate(noises):
+            arrays[f"noise_{i}"] = g
+        arrays.update(params_of(gnn))
+        arrays.update(params_of(sel, "sel_param:"))
+        for k, p in gnn.named_parameters():
+            arrays["grad:" + k] = p.grad.clone()
+        for k, p in sel.named_parameters():
+            if p.grad is not None:
+                arrays["sel_grad:" + k] = p.grad.clone()
+        save(name, dict(B=B, N=N, F=F, H=H, window=window, num_edge_samples=3), **arrays)
+    # candidate enumeration alone
+    Tq, tq = torch.tensor([0, 3, 7, 1, 0]), torch.tensor([4, 2, 0, 1, 1])
+    save("g12_causal_edges", dict(), T=Tq, taus=tq, all=gcm.util.get_causal_edges(Tq, tq),
+         win2=gcm.util.get_causal_edges(Tq, tq, window=2), win0=gcm.util.get_causal_edges(Tq, tq, window=0))
+
     # ---- G8: SparseGCM + TemporalEdge ----------------------------------------
     def run_sparse(name, B, N, F, H, hops, obs, tau_plan, max_hops=None, act=None):
         torch.manual_seed(0)

@@ -163,3 +163,51 @@ def test_pack_hidden_oracle():
     _, uadj, _ = osp.unpack_hidden((n, e, w, T), m["B"])
     assert torch.equal(uadj.coalesce().indices(), fx["un_idx"])
     assert torch.equal(uadj.coalesce().values(), fx["un_val"])
+
+
+# --------------------------------------------------------------------------
+# sparse LearnedEdge
+# --------------------------------------------------------------------------
+def test_causal_edges_oracle():
+    fx = Fixture("g12_causal_edges")
+    assert torch.equal(osp.get_causal_edges(fx["T"], fx["taus"]), fx["all"])
+    assert torch.equal(osp.get_causal_edges(fx["T"], fx["taus"], window=2), fx["win2"])
+    assert torch.equal(osp.get_causal_edges(fx["T"], fx["taus"], window=0), fx["win0"])
+
+
+@pytest.mark.parametrize("name", ["g12_sparse_learned", "g12_sparse_learned_win3"])
+def test_sparse_learned_oracle_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    gnn = osp.canonical_gnn(m["F"], m["H"], act=torch.nn.Tanh)
+    gnn.load_state_dict(fx.group("param:"))
+    net = od.build_edge_network(m["F"])
+    sp = fx.group("sel_param:")
+    net.load_state_dict({k[len("edge_network."):]: v for k, v in sp.items() if k.startswith("edge_network.")})
+    call = {"i": 0}
+
+    def noise(n):
+        g = fx[f"noise_{call['i']}"]
+        call["i"] += 1
+        assert g.numel() == n
+        return g
+
+    sel = osp.LearnedEdge(net, m["num_edge_samples"], window=m["window"], tau=sp["tau_param"], noise_fn=noise)
+    obs = fx["obs"].clone().requires_grad_(True)
+    B = m["B"]
+    hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
+    for taus in fx["taus"]:
+        t = int(taus.max())
+        x = torch.zeros(B, t, m["F"])
+        for b in range(B):
+            x[b, : taus[b]] = obs[b, pos[b]: pos[b] + taus[b]]
+        out, hidden = osp.sparse_step(x, taus, hidden, gnn, graph_size=m["N"], edge_selectors=sel)
+        outs.append(out)
+        pos = pos + taus
+    (sum(o.sum() for o in outs) / sum(o.numel() for o in outs)).backward()
+    for i, o in enumerate(outs):
+        torch.testing.assert_close(o, fx[f"out{i}"], rtol=1e-6, atol=1e-6)
+    assert torch.equal(hidden[1].coalesce().indices(), fx["hT_adj_indices"])
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-4, atol=1e-7)
+    for k, p in net.named_parameters():
+        torch.testing.assert_close(p.grad, fx["sel_grad:edge_network." + k], rtol=1e-4, atol=1e-7)

@@ -257,3 +257,98 @@ def test_pack_unpack_round_trips():
         again = util.pack_hidden(util.unpack_hidden(packed, B), B, ME)
         for a, b in zip(packed, again):
             assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------
+# sparse LearnedEdge (sparse_edge_selectors/learned.py, util.py:89-113,242-282)
+# --------------------------------------------------------------------------
+def test_causal_edges_match_reference():
+    from gcm import util
+    fx = Fixture("g12_causal_edges")
+    T, taus = fx["T"].to(DEV), fx["taus"].to(DEV)
+    assert torch.equal(util.get_causal_edges(T, taus).cpu(), fx["all"])
+    assert torch.equal(util.get_causal_edges(T, taus, window=2).cpu(), fx["win2"])
+    assert torch.equal(util.get_causal_edges(T, taus, window=0).cpu(), fx["win0"])
+
+
+def test_sparse_gumbel_softmax_matches_torch_sparse_softmax():
+    from gcm import util
+    torch.manual_seed(0)
+    idx = osp.get_causal_edges(torch.tensor([2, 0, 5]), torch.tensor([3, 4, 1]))
+    vals = torch.randn(idx.shape[1])
+    noise = torch.randn(idx.shape[1])
+    logits = torch.sparse_coo_tensor(idx, vals, size=(3, 8, 8))
+    want = osp.sparse_gumbel_softmax(logits, 2, tau=0.7, noise=noise)
+    got = util.sparse_gumbel_softmax(logits.to(DEV), 2, tau=0.7, noise=noise.to(DEV)).coalesce()
+    assert torch.equal(got.indices().cpu(), want.indices())
+    torch.testing.assert_close(got.values().cpu(), want.values(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["g12_sparse_learned", "g12_sparse_learned_win3"])
+def test_sparse_learned_edge_matches_reference(name):
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.learned import LearnedEdge
+    fx = Fixture(name)
+    m = fx.meta
+    ref = osp.canonical_gnn(m["F"], m["H"], act=torch.nn.Tanh)
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_sparse_gnn(ref, m["F"], m["H"], torch.nn.Tanh)
+    sel = LearnedEdge(m["F"], num_edge_samples=m["num_edge_samples"], window=m["window"], store_grads=False)
+    sel.load_state_dict(fx.group("sel_param:"))
+    sel = sel.to(DEV)
+    call = {"i": 0}
+
+    def noise(logits):
+        gz = fx[f"noise_{call['i']}"].to(DEV)
+        call["i"] += 1
+        assert gz.numel() == logits.numel()
+        return gz
+
+    sel.noise_fn = noise
+    mem = SparseGCM(g, edge_selectors=sel, graph_size=m["N"])
+    obs = fx["obs"].to(DEV).requires_grad_(True)
+    B = m["B"]
+    hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
+    for taus in fx["taus"]:
+        t = int(taus.max())
+        rows = [torch.cat([obs[b, pos[b]: pos[b] + taus[b]],
+                           torch.zeros(t - int(taus[b]), m["F"], device=DEV)]) for b in range(B)]
+        out, hidden = mem(torch.stack(rows), taus.to(DEV), hidden)
+        outs.append(out)
+        pos = pos + taus
+    (sum(o.sum() for o in outs) / sum(o.numel() for o in outs)).backward()
+    for i, o in enumerate(outs):
+        torch.testing.assert_close(o.cpu(), fx[f"out{i}"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(hidden[1].coalesce().indices().cpu(), fx["hT_adj_indices"])   # sampled edges: bit exact
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"]) and torch.equal(hidden[2].cpu(), fx["hT_T"])
+    gs = float(fx["grad_obs"].abs().max())
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=k)
+    for k, p in sel.named_parameters():
+        want = fx["sel_grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
+    assert {"edges_per_node", "edge_density", "logits_mean", "logits_var", "temperature"} <= set(sel.stats)
+
+
+def test_sparse_learned_edge_default_noise_runs():
+    """tests/test_sparse_gcm.py:822-852 style smoke: device-RNG gumbel draws, grads reach the MLP."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.learned import LearnedEdge
+    from gcm import nn as G
+    torch.manual_seed(0)
+    B, N, F = 8, 64, 16
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, F), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(F, F), "x, edges, weights -> x"), torch.nn.Tanh()]).to(DEV)
+    sel = LearnedEdge(F, num_edge_samples=4, window=16).to(DEV)
+    mem = SparseGCM(g, edge_selectors=sel, graph_size=N)
+    hidden, outs = None, []
+    for _ in range(3):
+        out, hidden = mem(torch.randn(B, 10, F, device=DEV), torch.full((B,), 10, device=DEV), hidden)
+        outs.append(out)
+    torch.cat(outs, 1).mean().backward()
+    idx = hidden[1].coalesce().indices()
+    assert bool((idx[2] < idx[1]).all())                      # causal
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sel.edge_network.parameters())
+    assert any(k.startswith("gnorm_") for k in sel.stats)     # grad hooks (store_grads)
