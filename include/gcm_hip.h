@@ -12,8 +12,8 @@
  *     fp32 / int64 exactly like the reference's hidden state;
  *   - nothing is allocated inside; kernels that need scratch take
  *     `workspace` + `workspace_bytes`, sized by the matching *_workspace_bytes;
- *   - `stream` is a hipStream_t; calls are asynchronous, re-entrant, hold no
- *     global state and are HIP-graph capturable;
+ *   - `stream` is a hipStream_t; calls are asynchronous and HIP-graph capturable; the
+ *     only process state is a one-time "dynamic LDS size allowed" attribute per kernel;
  *   - return 0 on success, GCM_E* (<0) for an argument error detected on the
  *     host, or a positive hipError_t from the launch.
  */
