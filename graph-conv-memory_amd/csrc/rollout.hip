@@ -105,6 +105,13 @@ extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* 
   GCM_REQUIRE(obs && nodes_all && adj_all && count_all && cur_all && mx_all && flags);
   GCM_REQUIRE(T > 0 && B > 0 && (selectors || n_selectors == 0));
   if (!gcm_dense_gnn2_row_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  {  // one persistent launch when the selectors are index writes and the shape is tile-exact
+    const int rc = gcm_dense_rollout_persistent_fwd(
+        obs, nodes_all, adj_all, count_all, cur_all, selectors, n_selectors, w_rel1, b_rel1,
+        w_root1, act1, w_rel2, b_rel2, w_root2, act2, mx_all, h1_all, agg1_all, agg2_all, flags, T,
+        B, N, F, H1, H2, stream);
+    if (rc != GCM_EUNSUPPORTED) return rc;
+  }
   const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
   for (int t = 0; t < T; ++t) {
     const float* nodes_in = nodes_all + (size_t)t * nodes_sz;
@@ -138,6 +145,13 @@ extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* 
   return GCM_OK;
 }
 
+extern "C" size_t gcm_dense_rollout_bwd_batched_workspace_bytes(int T, int B, int N, int F, int H1,
+                                                                int H2) {
+  if (T <= 0 || B <= 0 || N <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
+  return sizeof(float) * (size_t)T * B *
+         ((size_t)N * F + F + gcm_dense_gnn2_param_count(F, H1, H2));
+}
+
 extern "C" size_t gcm_dense_rollout_bwd_workspace_bytes(int B, int N, int F, int H1, int H2) {
   if (B <= 0 || N <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
   return sizeof(float) * (2 * (size_t)B * N * F + (size_t)B * gcm_dense_gnn2_param_count(F, H1, H2));
@@ -161,6 +175,38 @@ extern "C" int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes
   if (workspace_bytes < gcm_dense_rollout_bwd_workspace_bytes(B, N, F, H1, H2))
     return GCM_EWORKSPACE;
   const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
+  if (T > 1 && (size_t)N * F <= 8192 &&
+      workspace_bytes >= gcm_dense_rollout_bwd_batched_workspace_bytes(T, B, N, F, H1, H2) &&
+      (size_t)T * B < (1u << 31)) {
+    // time-parallel BPTT: the GNN adjoint of step t needs g_mx[t] only, so all T*B graph-steps go
+    // in ONE launch (the per-step arrays are contiguous in t); what is sequential is the cheap
+    // reverse scan of the node gradient through the state advance.
+    const size_t Pn = gcm_dense_gnn2_param_count(F, H1, H2);
+    float* Q_all = (float*)workspace;                       // [T,B,N,F]  U_t(dX_t)
+    float* pobs = Q_all + (size_t)T * nodes_sz;             // [T,B,F]    dX_t[cur_t]
+    float* slabs_all = pobs + (size_t)T * B * F;            // [T*B, Pn]
+    // persistent live-tile kernel (one slab per workgroup) when the shape is tile-exact, else the
+    // per-graph kernel over all T*B graph-steps (one slab each)
+    int n_slabs = gcm_dense_bptt_batched_slabs(T * B);
+    int rc = n_slabs > 0 ? gcm_dense_bptt_batched(g_mx_all, nodes_all + nodes_sz, adj_all + adj_sz,
+                                                  cur_all, count_all, w_rel1, b_rel1, w_root1, act1,
+                                                  w_rel2, b_rel2, w_root2, act2, mx_all, h1_all,
+                                                  agg1_all, agg2_all, Q_all, pobs, slabs_all,
+                                                  n_slabs, T * B, N, F, H1, H2, stream)
+                         : GCM_EUNSUPPORTED;
+    if (rc == GCM_EUNSUPPORTED) {
+      n_slabs = T * B;
+      rc = gcm_dense_gnn2_row_bwd(g_mx_all, nullptr, nodes_all + nodes_sz, adj_all + adj_sz,
+                                  cur_all, count_all, w_rel1, b_rel1, w_root1, act1, w_rel2,
+                                  b_rel2, w_root2, act2, mx_all, h1_all, agg1_all, agg2_all,
+                                  Q_all, pobs, slabs_all, 0, T * B, N, F, H1, H2, stream);
+    }
+    if (rc) return rc;
+    rc = gcm_dense_gnodes_scan(Q_all, pobs, g_nodes_T, cur_all, count_all, g_obs_all, g_nodes_0, T,
+                               B, N, F, stream);
+    if (rc) return rc;
+    return gcm_sum_slabs(slabs_all, n_slabs, (int)Pn, g_params, stream);
+  }
   float* ping[2] = {(float*)workspace, (float*)workspace + nodes_sz};
   float* slabs = (float*)workspace + 2 * nodes_sz;
   const size_t P = gcm_dense_gnn2_param_count(F, H1, H2);

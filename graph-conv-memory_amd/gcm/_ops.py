@@ -712,6 +712,11 @@ def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg):
     return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg)
 
 
+# Time-parallel BPTT keeps T*B*(N*F + F + P) floats of scratch; above this many bytes the
+# rollout backward runs step by step instead (2*B*N*F + B*P floats).  0 forces the sequential one.
+ROLLOUT_BWD_BATCHED_MAX_BYTES = 16 << 30
+
+
 class _FusedRollout(torch.autograd.Function):
     """T DenseGCM steps as ONE autograd node (gcm_dense_rollout_fwd/bwd)."""
 
@@ -765,7 +770,9 @@ class _FusedRollout(torch.autograd.Function):
         g_obs = torch.empty(T, B, F, device=dev, dtype=_f32)
         g_nodes0 = torch.empty(B, N, F, device=dev, dtype=_f32)
         flat = torch.empty(P, device=dev, dtype=_f32)
-        ws_bytes = lib.gcm_dense_rollout_bwd_workspace_bytes(B, N, F, H1, H2)
+        ws_bytes = lib.gcm_dense_rollout_bwd_batched_workspace_bytes(T, B, N, F, H1, H2)
+        if ws_bytes > ROLLOUT_BWD_BATCHED_MAX_BYTES:
+            ws_bytes = lib.gcm_dense_rollout_bwd_workspace_bytes(B, N, F, H1, H2)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         w = cfg.unpack_ptrs(packed)
         _call("gcm_dense_rollout_bwd", _hip.ptr(g_mx_all), _hip.ptr(g_nodes_T), _hip.ptr(nodes_all),

@@ -344,11 +344,52 @@ int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all, in
                           uint32_t* flags, void* workspace, size_t workspace_bytes, int T, int B,
                           int N, int F, int H1, int H2, gcm_stream_t stream);
 
+/* The same T steps as ONE persistent launch: a workgroup per graph keeps the graph's adjacency and
+ * node matrix in LDS for the whole rollout (no per-step state reads from HBM).  Index-writing
+ * selectors only (temporal / dense) and N, F, H1, H2 multiples of 32 within the fused limits;
+ * GCM_EUNSUPPORTED otherwise (gcm_dense_rollout_fwd tries this first and falls back itself). */
+int gcm_dense_rollout_persistent_fwd(const float* obs, float* nodes_all, float* adj_all,
+                                     int64_t* count_all, int64_t* cur_all,
+                                     const gcm_selector_desc* selectors, int n_selectors,
+                                     const float* w_rel1, const float* b_rel1, const float* w_root1,
+                                     int act1, const float* w_rel2, const float* b_rel2,
+                                     const float* w_root2, int act2, float* mx_all, float* h1_all,
+                                     float* agg1_all, float* agg2_all, uint32_t* flags, int T,
+                                     int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+
+/* Reverse scan of the node gradient through the state advance (adjoint of gcm.py:262-278 /
+ * 323-355), the sequential part of time-parallel BPTT:
+ *   C_t = U_t(C_{t+1}) + Q_all[t],  g_obs_all[t] = C_{t+1}[cur_t] + pobs_all[t],  C_T = g_nodes_T
+ * with Q_all [T,B,N,F] / pobs_all [T,B,F] = g_nodes_in / g_obs of gcm_dense_gnn2_row_bwd run over
+ * all T*B graph-steps with no incoming node gradient.  N*F <= 8192. */
+int gcm_dense_gnodes_scan(const float* Q_all, const float* pobs_all, const float* g_nodes_T,
+                          const int64_t* cur_all, const int64_t* count_all, float* g_obs_all,
+                          float* g_nodes_0, int T, int B, int N, int F, gcm_stream_t stream);
+
+/* Time-parallel GNN adjoint over `items` = T*B independent graph-steps (arrays as for
+ * gcm_dense_gnn2_row_bwd with B = items and no incoming node gradient): a persistent grid of
+ * n_slabs workgroups (gcm_dense_bptt_batched_slabs(items)) walks the items, touching only the
+ * 32-row tiles that can carry gradient (the tiles holding row cur and the non-zeros of
+ * adj[cur,:]) and writing ONE parameter-gradient slab per workgroup: slabs [n_slabs, param_count].
+ * Q [items,N,F] / pobs [items,F] feed gcm_dense_gnodes_scan.  N, F, H1, H2 multiples of 32 within
+ * the fused limits, else GCM_EUNSUPPORTED. */
+int gcm_dense_bptt_batched_slabs(int items);
+int gcm_dense_bptt_batched(const float* g_mx, const float* x, const float* adj,
+                           const int64_t* cur_idx, const int64_t* num_nodes_in,
+                           const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
+                           const float* w_rel2, const float* b_rel2, const float* w_root2, int act2,
+                           const float* mx, const float* h1, const float* agg1, const float* agg2,
+                           float* Q, float* pobs, float* slabs, int n_slabs, int items, int N,
+                           int F, int H1, int H2, gcm_stream_t stream);
+
 /* BPTT over the arrays written by gcm_dense_rollout_fwd.  g_mx_all [T,B,H2]; g_nodes_T
  * [B,N,F] = gradient w.r.t. the final nodes (NULL = 0).  Outputs: g_obs_all [T,B,F],
  * g_nodes_0 [B,N,F], g_params [gcm_dense_gnn2_param_count] (summed over graphs and steps).
  * workspace: 2*B*N*F floats (ping-pong) + B*param_count floats (slabs). */
 size_t gcm_dense_rollout_bwd_workspace_bytes(int B, int N, int F, int H1, int H2);
+/* A workspace of at least this size selects the time-parallel schedule: one gnn2_row_bwd launch
+ * over T*B graph-steps, gcm_dense_gnodes_scan, one slab sum (T*B*(N*F + F + param_count) floats). */
+size_t gcm_dense_rollout_bwd_batched_workspace_bytes(int T, int B, int N, int F, int H1, int H2);
 int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const float* nodes_all,
                           const float* adj_all, const int64_t* count_all, const int64_t* cur_all,
                           const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
