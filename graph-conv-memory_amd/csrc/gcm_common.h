@@ -37,6 +37,21 @@ __device__ __forceinline__ float gcm_act(float v, int act) {
   if (act == GCM_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
+// Same function with the activation code in a VGPR (gcm_vgpr): compiles to selects instead of the
+// scalar branch tree above - for latency-bound single-wave code, where taken branches cost more
+// than the few extra VALU instructions.
+__device__ __forceinline__ int gcm_vgpr(int x) {
+  int y;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "s"(x));
+  return y;
+}
+__device__ __forceinline__ float gcm_act_sel(float v, int act_v) {
+  const float t = gcm_tanh(v);
+  const float r = v > 0.f ? v : 0.f;
+  float out = act_v == GCM_ACT_TANH ? t : v;
+  out = act_v == GCM_ACT_RELU ? r : out;
+  return out;
+}
 // d act / d pre, expressed through the activation OUTPUT y
 __device__ __forceinline__ float gcm_act_grad(float y, int act) {
   if (act == GCM_ACT_TANH) return 1.f - y * y;

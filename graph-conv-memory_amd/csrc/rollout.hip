@@ -108,8 +108,8 @@ extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* 
   {  // one persistent launch when the selectors are index writes and the shape is tile-exact
     const int rc = gcm_dense_rollout_persistent_fwd(
         obs, nodes_all, adj_all, count_all, cur_all, selectors, n_selectors, w_rel1, b_rel1,
-        w_root1, act1, w_rel2, b_rel2, w_root2, act2, mx_all, h1_all, agg1_all, agg2_all, flags, T,
-        B, N, F, H1, H2, stream);
+        w_root1, act1, w_rel2, b_rel2, w_root2, act2, mx_all, h1_all, agg1_all, agg2_all, flags,
+        /*history=*/1, T, B, N, F, H1, H2, stream);
     if (rc != GCM_EUNSUPPORTED) return rc;
   }
   const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;

@@ -11,26 +11,61 @@
 // Shapes: EXACT only (N, F, H1, H2 multiples of 32); other shapes use the per-step launches.
 #include "fused_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps2): phase stamps of step GCM_STAMP_STEP
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#define RSTAMP(i) do { if (t == GCM_STAMP_STEP) STAMP(i); } while (0)
+#else
+#define RSTAMP(i)
+#endif
+
 namespace gcm_fused {
 
 template <int NT, int NCT, int NHT, int N2T>
 struct LdsRoll {
   using L = Lds<NT, NCT, NHT, N2T>;
-  static constexpr int TOTAL = L::ADJ + L::X + L::AH + L::W1F + L::W2 + L::SV;
+  static constexpr int BASE = L::ADJ + L::X + L::AH + L::W1F + L::W2 + L::SV;
+  // observation ring: two chunks of CH steps.  Global loads share the wave's in-order vmcnt with
+  // the history stores, so waiting for a load drains every store issued before it: the ring makes
+  // that happen once per CH steps instead of every step.
+  static constexpr int ROOM = (160 * 1024 / 4 - BASE) / (2 * L::FP);
+  static constexpr int CH = ROOM >= 16 ? 16 : (ROOM >= 8 ? 8 : (ROOM >= 4 ? 4 : (ROOM >= 2 ? 2 : 1)));
+  static constexpr int TOTAL = BASE + 2 * CH * L::FP;
 };
+
+// 16x16 output block += A(16xK) * B(Kx16), operands in LDS (v_mfma_f32_16x16x4_f32: lane l holds
+// A[l&15][4s + (l>>4)] and B[4s + (l>>4)][l&15]; acc[r] = C[4*(l>>4) + r][l&15]).
+template <int K>
+__device__ __forceinline__ void mma16(f32x4& acc, const float* a, int ais, const float* b, int bks,
+                                      int m, int kq) {
+  const float* ap = a + m * ais + kq;
+  const float* bp = b + kq * bks + m;
+  float av[K / 4], bv[K / 4];   // every LDS read in flight before the first MFMA
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) {
+    av[s] = ap[4 * s];
+    bv[s] = bp[4 * s * bks];
+  }
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+}
 
 template <int NT, int NCT, int NHT, int N2T>
 __global__ __launch_bounds__(256) void k_rollout_fwd(
     const float* __restrict__ obs, float* __restrict__ nodes_all, float* __restrict__ adj_all,
     int64_t* __restrict__ count_all, int64_t* __restrict__ cur_all, Edits E, Gnn2 P,
     float* __restrict__ mx_all, float* __restrict__ h1_all, float* __restrict__ agg1_all,
-    float* __restrict__ agg2_all, uint32_t* __restrict__ flags, int T, int B) {
+    float* __restrict__ agg2_all, uint32_t* __restrict__ flags, int T, int B, int hist) {
   using L = Lds<NT, NCT, NHT, N2T>;
   constexpr int N = L::NP, F = L::FP, H1 = L::HP, H2 = L::H2P;
   constexpr int NP = N, FP = F, HP = H1, H2P = H2;
   constexpr int FS = L::FS, HS = L::HS, AS = L::AS, W2S = L::W2S;
   const int b = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m16 = lane & 15, kq = lane >> 4;   // 16x16x4 MFMA lane coordinates
   const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
 
   extern __shared__ float smem[];
@@ -39,11 +74,14 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
   float* sAH = sX + L::X;                // agg, then h1 (stride AS)
   float* sW1 = sAH + L::AH;              // w_rel1^T | w_root1^T  [f][HS]
   float* sW2 = sW1 + L::W1F;             // [o][rel k | root k], stride W2S
-  float* sV = sW2 + L::W2;               // partials | v
+  float* sV = sW2 + L::W2;               // scratch: tile flags | v
   float* sVv = sV + 256;
+  float* sObs = sV + L::SV;              // [2][CH][FP] observation ring
+  constexpr int CH = LdsRoll<NT, NCT, NHT, N2T>::CH;
+  constexpr int OPER = (CH * FP + 255) / 256;   // ring-chunk elements per thread
 
   const int r_base = wave * 32;
-  const bool wave_live = wave < NT;
+  const bool wave_rows = wave < NT;      // rows [r_base, r_base+32) exist (roll / prologue ownership)
 
   // ---- prologue: weights and the incoming state into LDS -----------------------------------
   {
@@ -56,26 +94,91 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     st_wo.load(P.w_root1, H1, F, F, tid);
     st_w2r.load(P.w_rel2, H2, H1, H1, tid);
     st_w2o.load(P.w_root2, H2, H1, H1, tid);
-    if (wave_live) rows.load(adj_all + (size_t)b * N * N, N, r_base, lane);
+    if (wave_rows) rows.load(adj_all + (size_t)b * N * N, N, r_base, lane);
     st_x.store(sX, FS, tid);
     st_wr.store(sW1, HS, tid);
     st_wo.store(sW1 + FP * HS, HS, tid);
     st_w2r.store(sW2, W2S, tid);
     st_w2o.store(sW2 + HP, W2S, tid);
-    if (wave_live) {
+    if (tid < 16) sV[tid] = 0.f;
+    __syncthreads();
+    if (wave_rows) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) rows.template store_tile<NP>(sAdj, t, r_base, lane);
+      for (int t = 0; t < NT; ++t) {
+        rows.template store_tile<NP>(sAdj, t, r_base, lane);
+        const bool nz = rows.tile_nonzero(t);
+        if (lane == 0) sV[wave * 4 + t] = nz ? 1.f : 0.f;
+      }
     }
   }
+  // h1 rows of tiles that are not live in a step keep older (finite) values; they only ever meet
+  // adj[cur][j] == 0 in layer 2, so they must start finite too
+  for (int e = tid; e < L::AH; e += 256) sAH[e] = 0.f;
   int64_t n = count_all[b];
-  const float bias1 = (P.b_rel1 && li < H1) ? P.b_rel1[li] : 0.f;   // NHT == 1 fast path below uses it
-  float ob_next = obs[(size_t)b * F + (tid % FP)];
+  // every per-step operand that lives in HBM is read once, here (a global load inside the loop
+  // would share the in-order vmcnt with the history stores and wait for all of them)
+  float bias1[NHT];
+#pragma unroll
+  for (int bi = 0; bi < NHT; ++bi) {
+    const int blk = wave + 4 * bi, h0 = (blk >> 1) * 16;
+    bias1[bi] = P.b_rel1 ? P.b_rel1[h0 + m16] : 0.f;
+  }
+  const float bias2 = P.b_rel2 ? P.b_rel2[lane < H2 ? lane : H2 - 1] : 0.f;
+  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  const int nh = E.n_hops;
+  int hop_s[16], dir_s[16];   // uniform copies for the tile-mask update
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    hop_s[i] = E.hops[i];
+    dir_s[i] = E.dir[i];
+  }
+  const int my_hop = tid < E.n_hops ? E.hops[tid < 16 ? tid : 0] : -1;
+  const int my_dir = tid < E.n_hops ? E.dir[tid < 16 ? tid : 0] : 0;
+  // observations: chunk 0 into the ring now, chunk 1 into registers
+  float ob_regs[OPER];
+#pragma unroll
+  for (int i = 0; i < OPER; ++i) {
+    const int e = tid + 256 * i, st = e / FP, c = e % FP;
+    const int tt = st < T ? st : T - 1;
+    ob_regs[i] = obs[((size_t)tt * B + b) * F + c];
+  }
+#pragma unroll
+  for (int i = 0; i < OPER; ++i) {
+    const int e = tid + 256 * i;
+    if (e < CH * FP) sObs[e] = ob_regs[i];
+  }
+#pragma unroll
+  for (int i = 0; i < OPER; ++i) {
+    const int e = tid + 256 * i, st = CH + e / FP, c = e % FP;
+    const int tt = st < T ? st : T - 1;
+    ob_regs[i] = obs[((size_t)tt * B + b) * F + c];
+  }
+  __syncthreads();
+  // non-zero 32x32 tiles of the resident adjacency, bit R*4 + C (workgroup-uniform, kept up to date
+  // by the edits and the roll; a superset would only cost MFMAs on zero tiles)
+  unsigned nzmask = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nzmask |= (sV[i] != 0.f ? 1u : 0u) << i;
   __syncthreads();
 
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
-    const float ob = ob_next;
-    if (t + 1 < T) ob_next = obs[((size_t)(t + 1) * B + b) * F + (tid % FP)];   // prefetch
+    RSTAMP(0);
+    if (t % CH == 0 && t > 0) {   // next ring chunk: registers -> LDS, then fetch the one after
+      const int k = t / CH;
+#pragma unroll
+      for (int i = 0; i < OPER; ++i) {
+        const int e = tid + 256 * i;
+        if (e < CH * FP) sObs[(k & 1) * CH * FP + e] = ob_regs[i];
+      }
+#pragma unroll
+      for (int i = 0; i < OPER; ++i) {
+        const int e = tid + 256 * i, st = (k + 1) * CH + e / FP, c = e % FP;
+        const int tt = st < T ? st : T - 1;
+        ob_regs[i] = obs[((size_t)tt * B + b) * F + c];
+      }
+      __syncthreads();
+    }
     const bool bad = n < 0 || n > N;
     const bool wrap = n + 1 > N;
     int64_t c64 = wrap ? n - 1 : n;
@@ -84,16 +187,22 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     // ---- overflow: rotate both images one slot towards index 0 (registers as the bounce buffer)
     if (wrap) {   // workgroup-uniform
       float av[NT * 16], xv[NP * FP / 256];
-      if (wave_live) {
+      if (wave_rows) {
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
+        for (int tt = 0; tt < NT; ++tt) {
+          bool nz = false;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int r = r_base + (lane >> 3) + 8 * q + 1, c = tt * 32 + (lane & 7) * 4 + k + 1;
-              av[(tt * 4 + q) * 4 + k] = (r < N && c < N) ? sAdj[adj_at<NP>(r, c)] : 0.f;
+              const float v = (r < N && c < N) ? sAdj[adj_at<NP>(r, c)] : 0.f;
+              av[(tt * 4 + q) * 4 + k] = v;
+              nz |= v != 0.f;
             }
+          nz = __any(nz);
+          if (lane == 0) sV[wave * 4 + tt] = nz ? 1.f : 0.f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NP * FP / 256; ++i) {
@@ -101,7 +210,7 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
         xv[i] = r < N ? sX[r * FS + c] : 0.f;
       }
       __syncthreads();
-      if (wave_live) {
+      if (wave_rows) {
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -117,16 +226,31 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
         const int e = tid + 256 * i, r = e / FP, c = e % FP;
         sX[r * FS + c] = xv[i];
       }
+      nzmask = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if ((i >> 2) < NT && (i & 3) < NT) nzmask |= (sV[i] != 0.f ? 1u : 0u) << i;
       __syncthreads();
     }
     // ---- insert the observation, apply the selector writes ---------------------------------
-    if (tid < FP) sX[cur * FS + tid] = ob;
-    if (tid < E.n_hops) {
-      const int h = E.hops[tid];
-      if (h >= 0 && cur >= h) {
-        if (E.dir[tid] & GCM_DIR_FORWARD) sAdj[adj_at<NP>(cur, cur - h)] = 1.f;
-        if (E.dir[tid] & GCM_DIR_BACKWARD) sAdj[adj_at<NP>(cur - h, cur)] = 1.f;
+    if (tid < FP) sX[cur * FS + tid] = sObs[((t / CH) & 1) * CH * FP + (t % CH) * FP + tid];
+    if (my_hop >= 0 && cur >= my_hop) {
+      if (my_dir & GCM_DIR_FORWARD) sAdj[adj_at<NP>(cur, cur - my_hop)] = 1.f;
+      if (my_dir & GCM_DIR_BACKWARD) sAdj[adj_at<NP>(cur - my_hop, cur)] = 1.f;
+    }
+    {   // the same writes on the tile mask (uniform: kernel arguments through the scalar path)
+      const int ct = cur >> 5;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int h = hop_s[i];
+        if (i < nh && h >= 0 && cur >= h) {
+          const int pt = (cur - h) >> 5;
+          if (dir_s[i] & GCM_DIR_FORWARD) nzmask |= 1u << (ct * 4 + pt);
+          if (dir_s[i] & GCM_DIR_BACKWARD) nzmask |= 1u << (pt * 4 + ct);
+        }
       }
+      if (E.dense)
+        for (int r = 0; r <= ct; ++r) nzmask |= (1u << (ct * 4 + r)) | (1u << (r * 4 + ct));
     }
     if (E.dense) {
       for (int j = tid; j <= cur; j += 256) {
@@ -135,136 +259,184 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
       }
     }
     if (tid == 0) {
-      cur_all[(size_t)t * B + b] = cur;
-      count_all[(size_t)(t + 1) * B + b] = cur + 1;
+      if (hist) {
+        cur_all[(size_t)t * B + b] = cur;
+        count_all[(size_t)(t + 1) * B + b] = cur + 1;
+      } else if (t == T - 1) {
+        count_all[(size_t)B + b] = cur + 1;
+      }
       const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u);
       if (f) atomicOr(flags, f);
     }
     __syncthreads();
-
-    // ---- the step's state goes to HBM (functional history for BPTT): fire-and-forget stores ----
-    {
-      float* no = nodes_all + (size_t)(t + 1) * nodes_sz + (size_t)b * N * F;
+    RSTAMP(1);
+    // ---- which 32-row tiles matter this step: the ones holding row cur and the non-zeros of
+    // adj[cur,:].  Only their h1 rows reach the belief (gcm.py:314 keeps row cur of the last layer)
+    // and only they carry gradient in BPTT, so only they are computed and written to the history.
+    // All four waves share each live tile: 16x16 output blocks on the 16x16x4 MFMA.
+    unsigned live = 1u << (cur >> 5);
 #pragma unroll
-      for (int i = 0; i < NP * FP / 1024; ++i) {   // one float4 per thread and pass
-        const int e4 = tid + 256 * i, r = e4 / (FP / 4), c = (e4 % (FP / 4)) * 4;
-        const float* s = sX + r * FS + c;
-        *reinterpret_cast<float4*>(no + r * F + c) = make_float4(s[0], s[1], s[2], s[3]);
+    for (int tt = 0; tt < NT; ++tt)
+      live |= (__any(sAdj[adj_at<NP>(cur, tt * 32 + (lane & 31))] != 0.f) ? 1u : 0u) << tt;
+    // per-tile flags as separate scalars (one bit test per use; hipcc 7.2 inverted the third test of
+    // `(live >> R) & 1` on the same mask for NT >= 3)
+    bool lvt[NT];
+#pragma unroll
+    for (int R = 0; R < NT; ++R) lvt[R] = __builtin_amdgcn_readfirstlane((live >> R) & 1u) != 0;
+    const bool last = t == T - 1;
+    const size_t slot = hist ? (size_t)(t + 1) : 1;
+    float* no = nodes_all + slot * nodes_sz + (size_t)b * N * F;
+    float* ao = adj_all + slot * adj_sz + (size_t)b * N * N;
+    float* a1g = agg1_all ? agg1_all + (size_t)t * nodes_sz + (size_t)b * N * F : nullptr;
+    float* h1g = h1_all ? h1_all + ((size_t)t * B + b) * N * H1 : nullptr;
+#pragma unroll
+    for (int R = 0; R < NT; ++R) {
+      const bool lv = lvt[R];
+      if (last || (hist && lv)) {   // fire-and-forget stores: 8 rows of the tile per wave
+        const int row8 = R * 32 + wave * 8;
+#pragma unroll
+        for (int i = 0; i < FP / 32; ++i) {
+          const int e4 = lane + 64 * i, r = row8 + e4 / (FP / 4), c = (e4 % (FP / 4)) * 4;
+          const float* s = sX + r * FS + c;
+          *reinterpret_cast<float4*>(no + r * F + c) = make_float4(s[0], s[1], s[2], s[3]);
+        }
+        const int r = row8 + (lane >> 3);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const float* s = sAdj + (tt * NP + r) * 33 + (lane & 7) * 4;
+          *reinterpret_cast<float4*>(ao + r * N + tt * 32 + (lane & 7) * 4) =
+              make_float4(s[0], s[1], s[2], s[3]);
+        }
+      }
+      if (lv) {   // layer 1 aggregation of this tile's rows, zero tiles skipped
+#pragma unroll
+        for (int bi = 0; bi < NCT; ++bi) {
+          const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, c0 = (blk >> 1) * 16;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt)
+            if ((nzmask >> (R * 4 + tt)) & 1u)
+              mma16<32>(acc, sAdj + (tt * NP + r0) * 33, 33, sX + (tt * 32) * FS + c0, FS, m16, kq);
+          float* d = sAH + (r0 + 4 * kq) * AS + c0 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[r * AS] = acc[r];
+          if (a1g) {
+            float* g = a1g + (r0 + 4 * kq) * F + c0 + m16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r * F] = acc[r];
+          }
+        }
       }
     }
-    f32x16 acc[NCT];
+    RSTAMP(2);
+    __syncthreads();   // every wave's agg blocks are in LDS
+    RSTAMP(3);
+    f32x4 o[NT][NHT];
 #pragma unroll
-    for (int c = 0; c < NCT; ++c)
+    for (int R = 0; R < NT; ++R) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    if (wave_live) {
-      float* ao = adj_all + (size_t)(t + 1) * adj_sz + (size_t)b * N * N;
+      for (int bi = 0; bi < NHT; ++bi) o[R][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (lvt[R]) {
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        bool nz = false;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = r_base + (lane >> 3) + 8 * q, c = tt * 32 + (lane & 7) * 4;
-          const float* s = sAdj + (tt * NP + r) * 33 + (lane & 7) * 4;
-          const float4 v = make_float4(s[0], s[1], s[2], s[3]);
-          *reinterpret_cast<float4*>(ao + r * N + c) = v;
-          nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
-        }
-        // ---- layer 1 aggregation on the resident image, zero tiles skipped ---------------------
-        if (__any(nz)) {
-#pragma unroll
-          for (int c = 0; c < NCT; ++c)
-            mma32(acc[c], sAdj + (tt * NP + r_base) * 33, 33, 1, sX + (tt * 32) * FS + c * 32, FS, 1,
-                  32, li, lh);
+        for (int bi = 0; bi < NHT; ++bi) {
+          const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          mma16<FP>(acc, sAH + r0 * AS, AS, sW1 + h0, HS, m16, kq);
+          mma16<FP>(acc, sX + r0 * FS, FS, sW1 + FP * HS + h0, HS, m16, kq);
+          o[R][bi] = acc;
         }
       }
-      float* a1g = agg1_all ? agg1_all + (size_t)t * nodes_sz + (size_t)b * N * F : nullptr;
+    }
+    RSTAMP(4);
+    __syncthreads();   // nobody reads agg any more: h1 takes its place
+    RSTAMP(5);
 #pragma unroll
-      for (int c = 0; c < NCT; ++c)
+    for (int R = 0; R < NT; ++R)
+      if (lvt[R]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = r_base + acc_row(r, lh), col = c * 32 + li;
-          sAH[row * AS + col] = acc[c][r];
-          if (a1g) a1g[row * F + col] = acc[c][r];
+        for (int bi = 0; bi < NHT; ++bi) {
+          const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gcm_act_sel(o[R][bi][r] + bias1[bi], act1_v);
+          float* d = sAH + (r0 + 4 * kq) * AS + h0 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[r * AS] = v[r];
+          if (h1g) {
+            float* g = h1g + (r0 + 4 * kq) * H1 + h0 + m16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r * H1] = v[r];
+          }
         }
+      }
+    RSTAMP(6);
+    __syncthreads();
+    RSTAMP(7);
+    // ---- layer 2 on row `cur`: wave 0 alone, no workgroup barriers ------------------------------
+    if (wave == 0) {
+      constexpr int PA = 64 / HP;            // lanes per h (1 or 2): split of the j range
+      constexpr int JN = 32 / PA;
+      const int h = lane & (HP - 1), part = lane / HP;
+      float s = 0.f;
+#pragma unroll
+      for (int R = 0; R < NT; ++R)
+        if (lvt[R]) {
+          const float* arow = sAdj + (R * NP + cur) * 33 + part;    // adj[cur][R*32 + part + PA*i]
+          const float* hcol = sAH + (R * 32 + part) * AS + h;       // h1[R*32 + part + PA*i][h]
+          float av[JN], hv[JN];
+#pragma unroll
+          for (int i = 0; i < JN; ++i) {
+            av[i] = arow[PA * i];
+            hv[i] = hcol[PA * i * AS];
+          }
+#pragma unroll
+          for (int i = 0; i < JN; ++i) s = fmaf(av[i], hv[i], s);
+        }
+      if (PA == 2) s += __shfl_xor(s, 32);
+      const float hc = sAH[cur * AS + h];
+      if (part == 0) {
+        sVv[h] = s;              // v[0:HP)   = agg2
+        sVv[HP + h] = hc;        // v[HP:2HP) = h1[cur]
+        if (agg2_all) agg2_all[((size_t)t * B + b) * H1 + h] = s;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      f32x16 o[NHT];
+      // pre2[o] = b2[o] + sum_k W2c[o][k] * v[k], K = 2*HP
+      constexpr int PB = 64 / H2P;           // lanes per output (1 or 2): split of K
+      constexpr int KC = 2 * HP / PB;
+      const int o2 = lane & (H2P - 1), kp = lane / H2P;
+      const float* wrow = sW2 + o2 * W2S + kp * KC;
+      const float* vv = sVv + kp * KC;
+      float a = 0.f;
 #pragma unroll
-      for (int ht = 0; ht < NHT; ++ht) {
+      for (int k0 = 0; k0 < KC; k0 += 16) {
+        float wv[16], xv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[ht][r] = 0.f;
-        mma32(o[ht], sAH + r_base * AS, AS, 1, sW1 + ht * 32, HS, 1, FP, li, lh);
-        mma32(o[ht], sX + r_base * FS, FS, 1, sW1 + FP * HS + ht * 32, HS, 1, FP, li, lh);
-      }
-      __builtin_amdgcn_wave_barrier();
-      float* h1g = h1_all ? h1_all + ((size_t)t * B + b) * N * H1 : nullptr;
-#pragma unroll
-      for (int ht = 0; ht < NHT; ++ht) {
-        const int col = ht * 32 + li;
-        const float bias = NHT == 1 ? bias1 : (P.b_rel1 ? P.b_rel1[col] : 0.f);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = r_base + acc_row(r, lh);
-          const float v = gcm_act(o[ht][r] + bias, P.act1);
-          sAH[row * AS + col] = v;
-          if (h1g) h1g[row * H1 + col] = v;
+        for (int k = 0; k < 16; ++k) {
+          wv[k] = wrow[k0 + k];
+          xv[k] = vv[k0 + k];
         }
-      }
-    }
-    __syncthreads();
-    // ---- layer 2 on row `cur` -------------------------------------------------------------------
-    {
-      constexpr int G = 256 / HP;
-      const int g = tid / HP, h = tid - g * HP;
-      float s = 0.f;
-#pragma unroll 4
-      for (int j = g; j < N; j += G) s = fmaf(sAdj[adj_at<NP>(cur, j)], sAH[j * AS + h], s);
-      sV[tid] = s;
-      __syncthreads();
-      if (tid < HP) {
-        float a2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < G; ++q) a2 += sV[q * HP + tid];
-        sVv[tid] = a2;
-        sVv[HP + tid] = sAH[cur * AS + tid];
-        if (agg2_all) agg2_all[((size_t)t * B + b) * H1 + tid] = a2;
+        for (int k = 0; k < 16; ++k) a = fmaf(wv[k], xv[k], a);
       }
-    }
-    __syncthreads();
-    {
-      constexpr int G2 = 256 / H2P, KC = (2 * HP) / G2;
-      const int g = tid / H2P, o2 = tid - g * H2P;
-      float s = 0.f;
-      const float* wrow = sW2 + o2 * W2S + g * KC;
-      const float* vv = sVv + g * KC;
-#pragma unroll
-      for (int k = 0; k < KC; ++k) s = fmaf(wrow[k], vv[k], s);
-      sV[tid] = s;
-      __syncthreads();
-      bool nonfinite = false;
-      if (tid < H2) {
-        float a = P.b_rel2 ? P.b_rel2[tid] : 0.f;
-#pragma unroll
-        for (int q = 0; q < G2; ++q) a += sV[q * H2P + tid];
-        const float v = gcm_act(a, P.act2);
-        mx_all[((size_t)t * B + b) * H2 + tid] = v;
-        nonfinite = !isfinite(v);
-      }
-      if (wave == 0) {
-        const bool any_bad = __any(nonfinite);
-        if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
-      }
+      if (PB == 2) a += __shfl_xor(a, 32);
+      const float v = gcm_act_sel(a + bias2, act2_v);
+      if (lane < H2) mx_all[((size_t)t * B + b) * H2 + lane] = v;
+      const bool any_bad = __any(lane < H2 && !isfinite(v));
+      if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
     }
     n = cur + 1;
+    RSTAMP(8);
     __syncthreads();   // the next step rewrites sX / sAdj / sAH / sV
+    RSTAMP(9);
   }
 }
 
 template <int NT, int NCT, int NHT, int N2T>
 int launch_rollout(hipStream_t s, const float* obs, float* nodes_all, float* adj_all,
                    int64_t* count_all, int64_t* cur_all, Edits E, Gnn2 P, float* mx_all,
-                   float* h1_all, float* agg1_all, float* agg2_all, uint32_t* flags, int T, int B) {
+                   float* h1_all, float* agg1_all, float* agg2_all, uint32_t* flags, int T, int B,
+                   int hist) {
   constexpr size_t lds = sizeof(float) * (size_t)LdsRoll<NT, NCT, NHT, N2T>::TOTAL;
   if (lds > 160 * 1024) return GCM_EUNSUPPORTED;
   auto kern = k_rollout_fwd<NT, NCT, NHT, N2T>;
@@ -275,7 +447,7 @@ int launch_rollout(hipStream_t s, const float* obs, float* nodes_all, float* adj
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, obs, nodes_all, adj_all, count_all, cur_all,
-                     E, P, mx_all, h1_all, agg1_all, agg2_all, flags, T, B);
+                     E, P, mx_all, h1_all, agg1_all, agg2_all, flags, T, B, hist);
   return gcm_launch_status();
 }
 
@@ -359,10 +531,10 @@ extern "C" int gcm_dense_rollout_persistent_fwd(const float* obs, float* nodes_a
                                const float* w_rel1, const float* b_rel1, const float* w_root1,
                                int act1, const float* w_rel2, const float* b_rel2,
                                const float* w_root2, int act2, float* mx_all, float* h1_all,
-                               float* agg1_all, float* agg2_all, uint32_t* flags, int T, int B,
-                               int N, int F, int H1, int H2, gcm_stream_t stream) {
-  GCM_REQUIRE(obs && nodes_all && adj_all && count_all && cur_all && mx_all && flags && w_rel1 &&
-              w_root1 && w_rel2 && w_root2);
+                               float* agg1_all, float* agg2_all, uint32_t* flags, int history,
+                               int T, int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_all && adj_all && count_all && mx_all && flags && w_rel1 && w_root1 &&
+              w_rel2 && w_root2 && (cur_all || !history));
   GCM_REQUIRE(T > 0 && B > 0 && (selectors || n_selectors == 0));
   hipStream_t s = (hipStream_t)stream;
   if ((N & 31) || (F & 31) || (H1 & 31) || (H2 & 31) || N > 128 || F > 64 || H1 > 64 || H2 > 64)
@@ -388,7 +560,7 @@ extern "C" int gcm_dense_rollout_persistent_fwd(const float* obs, float* nodes_a
   if (NT == a && NCT == b_ && NHT == c && N2T == d)                                            \
     return gcm_fused::launch_rollout<a, b_, c, d>(s, obs, nodes_all, adj_all, count_all,       \
                                                   cur_all, E, P, mx_all, h1_all, agg1_all,     \
-                                                  agg2_all, flags, T, B);
+                                                  agg2_all, flags, T, B, history);
   GCM_RSHAPES(GCM_R)
 #undef GCM_R
   return GCM_EUNSUPPORTED;

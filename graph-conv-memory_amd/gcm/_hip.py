@@ -77,7 +77,7 @@ PROTOTYPES = {
     "gcm_dense_rollout_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 3 + [_I] + [_P] * 6
                               + [_Z] + [_I] * 6 + [_P]),
     "gcm_dense_rollout_persistent_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 3 + [_I]
-                                         + [_P] * 5 + [_I] * 6 + [_P]),
+                                         + [_P] * 5 + [_I] * 7 + [_P]),
     "gcm_dense_bptt_batched_slabs": (_I, [_I]),
     "gcm_dense_bptt_batched": (_I, [_P] * 7 + [_I] + [_P] * 3 + [_I] + [_P] * 7 + [_I] * 6 + [_P]),
     "gcm_dense_gnodes_scan": (_I, [_P] * 7 + [_I] * 4 + [_P]),
@@ -96,6 +96,9 @@ class SelectorDesc(ctypes.Structure):
 
 
 SEL_TEMPORAL, SEL_DENSE, SEL_DISTANCE = 1, 2, 3
+
+
+GCM_EUNSUPPORTED = -2   # include/gcm_hip.h
 
 
 class HipLibraryError(RuntimeError):

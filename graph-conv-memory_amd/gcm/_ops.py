@@ -728,6 +728,29 @@ class _FusedRollout(torch.autograd.Function):
         N, H1, H2 = cfg.N, cfg.H1, cfg.H2
         dev = obs.device
         need_bwd = any(ctx.needs_input_grad)
+        w = cfg.unpack_ptrs(packed)
+        if not need_bwd:
+            # inference: no history.  The persistent kernel keeps the state in LDS and writes the
+            # final hidden state once (two-slot arrays); shapes / selectors it does not cover take
+            # the general path below.
+            nodes2 = torch.empty(2, B, N, F, device=dev, dtype=_f32)
+            adj2 = torch.empty(2, B, N, N, device=dev, dtype=_f32)
+            count2 = torch.empty(2, B, device=dev, dtype=torch.int64)
+            nodes2[0].copy_(nodes0)
+            adj2[0].copy_(adj0)
+            count2[0].copy_(num_nodes0)
+            mx_all = torch.empty(T, B, H2, device=dev, dtype=_f32)
+            fn = _hip.lib().gcm_dense_rollout_persistent_fwd
+            rc = fn(_hip.ptr(obs), _hip.ptr(nodes2), _hip.ptr(adj2), _hip.ptr(count2), None,
+                    cfg.arr_ptr, cfg.n_desc, w[0], w[1], w[2], cfg.acts[0], w[3], w[4], w[5],
+                    cfg.acts[1], _hip.ptr(mx_all), None, None, None, _hip.ptr(flags), 0, T, B, N, F,
+                    H1, H2, _hip.stream())
+            if rc == 0:
+                adj_T, count_T = adj2[1], count2[1]
+                ctx.mark_non_differentiable(adj_T, count_T)
+                return mx_all, nodes2[1], adj_T, count_T
+            if rc != _hip.GCM_EUNSUPPORTED:
+                _hip.check(rc, "gcm_dense_rollout_persistent_fwd")
         nodes_all = torch.empty(T + 1, B, N, F, device=dev, dtype=_f32)
         adj_all = torch.empty(T + 1, B, N, N, device=dev, dtype=_f32)
         count_all = torch.empty(T + 1, B, device=dev, dtype=torch.int64)
@@ -740,7 +763,6 @@ class _FusedRollout(torch.autograd.Function):
         agg1_all = torch.empty(T, B, N, F, device=dev, dtype=_f32) if need_bwd else None
         agg2_all = torch.empty(T, B, H1, device=dev, dtype=_f32) if need_bwd else None
         ws_ptr, ws_bytes = cfg.workspace(B)
-        w = cfg.unpack_ptrs(packed)
         _call("gcm_dense_rollout_fwd", _hip.ptr(obs), _hip.ptr(nodes_all), _hip.ptr(adj_all),
               _hip.ptr(count_all), _hip.ptr(cur_all), cfg.arr_ptr, cfg.n_desc,
               w[0], w[1], w[2], cfg.acts[0], w[3], w[4], w[5], cfg.acts[1], _hip.ptr(mx_all),

@@ -347,15 +347,21 @@ int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all, in
 /* The same T steps as ONE persistent launch: a workgroup per graph keeps the graph's adjacency and
  * node matrix in LDS for the whole rollout (no per-step state reads from HBM).  Index-writing
  * selectors only (temporal / dense) and N, F, H1, H2 multiples of 32 within the fused limits;
- * GCM_EUNSUPPORTED otherwise (gcm_dense_rollout_fwd tries this first and falls back itself). */
+ * GCM_EUNSUPPORTED otherwise (gcm_dense_rollout_fwd tries this first and falls back itself).
+ * history != 0: arrays as for gcm_dense_rollout_fwd, but of the intermediate slots 1..T-1 (and of
+ *   h1_all / agg1_all) only the 32-row tiles BPTT reads are written - the tiles holding row cur and
+ *   the non-zeros of adj[cur,:]; slot T (the returned hidden state) is complete.
+ * history == 0 (inference): nodes_all / adj_all / count_all have TWO slots, 0 = incoming state,
+ *   1 = state after T steps; cur_all, h1_all, agg1_all, agg2_all may be NULL. */
 int gcm_dense_rollout_persistent_fwd(const float* obs, float* nodes_all, float* adj_all,
                                      int64_t* count_all, int64_t* cur_all,
                                      const gcm_selector_desc* selectors, int n_selectors,
                                      const float* w_rel1, const float* b_rel1, const float* w_root1,
                                      int act1, const float* w_rel2, const float* b_rel2,
                                      const float* w_root2, int act2, float* mx_all, float* h1_all,
-                                     float* agg1_all, float* agg2_all, uint32_t* flags, int T,
-                                     int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+                                     float* agg1_all, float* agg2_all, uint32_t* flags,
+                                     int history, int T, int B, int N, int F, int H1, int H2,
+                                     gcm_stream_t stream);
 
 /* Reverse scan of the node gradient through the state advance (adjoint of gcm.py:262-278 /
  * 323-355), the sequential part of time-parallel BPTT:

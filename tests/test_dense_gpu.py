@@ -497,6 +497,30 @@ def test_rollout_bptt_schedules_agree(monkeypatch):
         torch.testing.assert_close(res[0][3][k], res[1][3][k], rtol=1e-5, atol=1e-6 * scale, msg=k)
 
 
+@pytest.mark.parametrize("N,F,H,T,sel_kind", [(32, 32, 32, 45, "temporal"), (64, 32, 64, 80, "dense"),
+                                              (128, 32, 32, 140, "temporal")])
+def test_rollout_inference_keeps_no_history(N, F, H, T, sel_kind):
+    """no_grad rollout = persistent kernel without the per-step history; same beliefs and final
+    hidden state as the step-by-step loop (state bit exact), overflow included."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.dense import DenseEdge
+    sel = TemporalBackedge([1, 2, 4]) if sel_kind == "temporal" else DenseEdge()
+    mem, g = _mk(F, H, H, torch.nn.Tanh, torch.nn.Tanh, sel, N, fused=True)
+    B = 3
+    obs = torch.rand(T, B, F, device=DEV)
+    with torch.no_grad():
+        out, hid = mem.rollout(obs)
+        h, outs = None, []
+        for t in range(T):
+            mx, h = mem(obs[t], h)
+            outs.append(mx)
+    mem.check_flags()
+    # two fp32 summation orders; dense rows add up to N terms before the tanh
+    torch.testing.assert_close(out, torch.stack(outs), rtol=1e-5, atol=1e-6 if sel_kind == "temporal" else 3e-5)
+    for a, b in zip(hid, h):
+        assert torch.equal(a, b)
+
+
 def test_rollout_falls_back_for_non_native_trees():
     """rollout() on a tree the fused kernels do not cover = the plain loop."""
     from gcm.edge_selectors.learned import LearnedEdge
