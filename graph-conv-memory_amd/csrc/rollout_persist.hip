@@ -48,6 +48,7 @@ __device__ __forceinline__ void mma16(f32x4& acc, const float* a, int ais, const
     av[s] = ap[4 * s];
     bv[s] = bp[4 * s * bks];
   }
+  __builtin_amdgcn_sched_barrier(0);   // keep the reads batched: one LDS round trip, not K/8
 #pragma unroll
   for (int s = 0; s < K / 4; ++s)
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
@@ -74,8 +75,11 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
   float* sAH = sX + L::X;                // agg, then h1 (stride AS)
   float* sW1 = sAH + L::AH;              // w_rel1^T | w_root1^T  [f][HS]
   float* sW2 = sW1 + L::W1F;             // [o][rel k | root k], stride W2S
-  float* sV = sW2 + L::W2;               // scratch: tile flags | v
+  float* sV = sW2 + L::W2;               // scratch: tile mask | v
   float* sVv = sV + 256;
+  // non-zero 32x32 tiles of the resident adjacency: word R holds the bits of row tile R.  Kept up to
+  // date by the edits (LDS atomics) and the roll; a superset would only cost MFMAs on zero tiles.
+  unsigned* sMask = reinterpret_cast<unsigned*>(sV);
   float* sObs = sV + L::SV;              // [2][CH][FP] observation ring
   constexpr int CH = LdsRoll<NT, NCT, NHT, N2T>::CH;
   constexpr int OPER = (CH * FP + 255) / 256;   // ring-chunk elements per thread
@@ -100,16 +104,15 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     st_wo.store(sW1 + FP * HS, HS, tid);
     st_w2r.store(sW2, W2S, tid);
     st_w2o.store(sW2 + HP, W2S, tid);
-    if (tid < 16) sV[tid] = 0.f;
-    __syncthreads();
+    unsigned bits = 0;
     if (wave_rows) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         rows.template store_tile<NP>(sAdj, t, r_base, lane);
-        const bool nz = rows.tile_nonzero(t);
-        if (lane == 0) sV[wave * 4 + t] = nz ? 1.f : 0.f;
+        bits |= (rows.tile_nonzero(t) ? 1u : 0u) << t;
       }
     }
+    if (lane == 0) sMask[wave] = bits;
   }
   // h1 rows of tiles that are not live in a step keep older (finite) values; they only ever meet
   // adj[cur][j] == 0 in layer 2, so they must start finite too
@@ -125,13 +128,6 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
   }
   const float bias2 = P.b_rel2 ? P.b_rel2[lane < H2 ? lane : H2 - 1] : 0.f;
   const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
-  const int nh = E.n_hops;
-  int hop_s[16], dir_s[16];   // uniform copies for the tile-mask update
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    hop_s[i] = E.hops[i];
-    dir_s[i] = E.dir[i];
-  }
   const int my_hop = tid < E.n_hops ? E.hops[tid < 16 ? tid : 0] : -1;
   const int my_dir = tid < E.n_hops ? E.dir[tid < 16 ? tid : 0] : 0;
   // observations: chunk 0 into the ring now, chunk 1 into registers
@@ -154,13 +150,6 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     ob_regs[i] = obs[((size_t)tt * B + b) * F + c];
   }
   __syncthreads();
-  // non-zero 32x32 tiles of the resident adjacency, bit R*4 + C (workgroup-uniform, kept up to date
-  // by the edits and the roll; a superset would only cost MFMAs on zero tiles)
-  unsigned nzmask = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) nzmask |= (sV[i] != 0.f ? 1u : 0u) << i;
-  __syncthreads();
-
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
     RSTAMP(0);
@@ -187,6 +176,7 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     // ---- overflow: rotate both images one slot towards index 0 (registers as the bounce buffer)
     if (wrap) {   // workgroup-uniform
       float av[NT * 16], xv[NP * FP / 256];
+      unsigned rbits = 0;
       if (wave_rows) {
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -200,8 +190,7 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
               av[(tt * 4 + q) * 4 + k] = v;
               nz |= v != 0.f;
             }
-          nz = __any(nz);
-          if (lane == 0) sV[wave * 4 + tt] = nz ? 1.f : 0.f;
+          rbits |= (__any(nz) ? 1u : 0u) << tt;
         }
       }
 #pragma unroll
@@ -226,36 +215,30 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
         const int e = tid + 256 * i, r = e / FP, c = e % FP;
         sX[r * FS + c] = xv[i];
       }
-      nzmask = 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if ((i >> 2) < NT && (i & 3) < NT) nzmask |= (sV[i] != 0.f ? 1u : 0u) << i;
+      if (lane == 0) sMask[wave] = rbits;
       __syncthreads();
     }
     // ---- insert the observation, apply the selector writes ---------------------------------
     if (tid < FP) sX[cur * FS + tid] = sObs[((t / CH) & 1) * CH * FP + (t % CH) * FP + tid];
     if (my_hop >= 0 && cur >= my_hop) {
-      if (my_dir & GCM_DIR_FORWARD) sAdj[adj_at<NP>(cur, cur - my_hop)] = 1.f;
-      if (my_dir & GCM_DIR_BACKWARD) sAdj[adj_at<NP>(cur - my_hop, cur)] = 1.f;
-    }
-    {   // the same writes on the tile mask (uniform: kernel arguments through the scalar path)
-      const int ct = cur >> 5;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int h = hop_s[i];
-        if (i < nh && h >= 0 && cur >= h) {
-          const int pt = (cur - h) >> 5;
-          if (dir_s[i] & GCM_DIR_FORWARD) nzmask |= 1u << (ct * 4 + pt);
-          if (dir_s[i] & GCM_DIR_BACKWARD) nzmask |= 1u << (pt * 4 + ct);
-        }
+      const int past = cur - my_hop;
+      if (my_dir & GCM_DIR_FORWARD) {
+        sAdj[adj_at<NP>(cur, past)] = 1.f;
+        atomicOr(&sMask[cur >> 5], 1u << (past >> 5));
       }
-      if (E.dense)
-        for (int r = 0; r <= ct; ++r) nzmask |= (1u << (ct * 4 + r)) | (1u << (r * 4 + ct));
+      if (my_dir & GCM_DIR_BACKWARD) {
+        sAdj[adj_at<NP>(past, cur)] = 1.f;
+        atomicOr(&sMask[past >> 5], 1u << (cur >> 5));
+      }
     }
     if (E.dense) {
       for (int j = tid; j <= cur; j += 256) {
         sAdj[adj_at<NP>(cur, j)] = 1.f;
         if (j < cur) sAdj[adj_at<NP>(j, cur)] = 1.f;
+      }
+      if (tid <= (cur >> 5)) {
+        atomicOr(&sMask[cur >> 5], 1u << tid);
+        atomicOr(&sMask[tid], 1u << (cur >> 5));
       }
     }
     if (tid == 0) {
@@ -274,6 +257,10 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     // adj[cur,:].  Only their h1 rows reach the belief (gcm.py:314 keeps row cur of the last layer)
     // and only they carry gradient in BPTT, so only they are computed and written to the history.
     // All four waves share each live tile: 16x16 output blocks on the 16x16x4 MFMA.
+    unsigned nzmask = 0;
+#pragma unroll
+    for (int R = 0; R < NT; ++R) nzmask |= sMask[R] << (4 * R);
+    nzmask = __builtin_amdgcn_readfirstlane(nzmask);
     unsigned live = 1u << (cur >> 5);
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)

@@ -1,0 +1,178 @@
+// Host side of the per-step hot loop as a C++ autograd node.
+//
+// `for t: belief, m = gcm(obs[t], m)` (README.md:79-82, ray_gcm.py:200-202) is host-bound once the
+// step is one kernel per direction: a Python torch.autograd.Function costs ~38 us forward and ~44 us
+// backward per step in interpreter / trampoline overhead, more than the kernels take.  This node does
+// exactly what gcm/_ops.py:_FusedStep does (same buffers, same C-ABI calls into libgcm_hip.so:
+// gcm_dense_step_fwd / gcm_dense_step_bwd), without the interpreter on the path - in particular the
+// backward runs on the autograd engine thread without taking the GIL.
+//
+// No device code here: PyTorch is plumbing (allocation, autograd graph, stream); the product is the
+// C-ABI library this file links against.
+#include <torch/extension.h>
+
+#include <cstring>
+#include <vector>
+
+#include "gcm_hip.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+inline int64_t pad64(int64_t n) { return (n + 63) & ~int64_t(63); }
+
+struct StepCfg {
+  std::vector<gcm_selector_desc> descs;
+  int act1, act2, has_bias, N, F, H1, H2;
+  int64_t P;
+  bool has_distance = false;
+  at::Tensor ws;   // scratch of the distance selectors
+  size_t ws_bytes = 0;
+
+  StepCfg(int64_t desc_ptr, int n_desc, int act1_, int act2_, int has_bias_, int N_, int F_,
+          int H1_, int H2_)
+      : act1(act1_), act2(act2_), has_bias(has_bias_), N(N_), F(F_), H1(H1_), H2(H2_) {
+    descs.resize(n_desc);
+    if (n_desc) std::memcpy(descs.data(), reinterpret_cast<const void*>(desc_ptr),
+                            sizeof(gcm_selector_desc) * n_desc);
+    for (const auto& d : descs) has_distance |= d.kind == GCM_SEL_DISTANCE;
+    P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2);
+  }
+
+  void* workspace(int B, const at::Tensor& like, size_t* bytes) {
+    *bytes = 0;
+    if (!has_distance) return nullptr;
+    size_t need = 0;
+    for (const auto& d : descs)
+      if (d.kind == GCM_SEL_DISTANCE)
+        need = std::max(need, gcm_edge_distance_workspace_bytes(d.mode, B, N, F));
+    if (need > ws_bytes) {
+      ws = at::empty({(int64_t)need}, like.options().dtype(at::kByte));
+      ws_bytes = need;
+    }
+    *bytes = ws_bytes;
+    return ws.defined() ? ws.data_ptr() : nullptr;
+  }
+};
+
+void check(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed: ", gcm_status_string(rc), " (code ", rc, ")");
+}
+
+// float offsets inside the forward buffer: nodes | adj | mx | h1 | agg1 | agg2 (64-float aligned)
+struct Layout {
+  int64_t total, o_adj, o_mx, o_h1, o_agg1, o_agg2;
+  Layout(int64_t B, int64_t N, int64_t F, int64_t H1, int64_t H2, bool need_bwd) {
+    const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * N * N), n_mx = pad64(B * H2);
+    const int64_t n_h1 = pad64(B * N * H1), n_agg2 = pad64(B * H1);
+    o_adj = n_nodes;
+    o_mx = o_adj + n_adj;
+    o_h1 = o_mx + n_mx;
+    o_agg1 = o_h1 + n_h1;
+    o_agg2 = o_agg1 + n_nodes;
+    total = need_bwd ? o_agg2 + n_agg2 : o_h1;
+  }
+};
+
+struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
+  static variable_list forward(AutogradContext* ctx, at::Tensor obs, at::Tensor nodes_in,
+                               at::Tensor packed, at::Tensor adj_in, at::Tensor count_in,
+                               at::Tensor flags, int64_t cfg_handle, int64_t stream,
+                               int64_t need_bwd_) {
+    StepCfg* cfg = reinterpret_cast<StepCfg*>(cfg_handle);
+    obs = obs.contiguous();
+    nodes_in = nodes_in.contiguous();
+    adj_in = adj_in.contiguous();
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = need_bwd_ != 0;   // decided by the caller: grad mode is off in here
+    const Layout L(B, N, F, H1, H2, need_bwd);
+    at::Tensor buf = at::empty({L.total}, obs.options());
+    at::Tensor ibuf = at::empty({2, B}, count_in.options());
+    float* base = buf.data_ptr<float>();
+    int64_t* ib = ibuf.data_ptr<int64_t>();
+    size_t ws_bytes = 0;
+    void* ws = cfg->workspace((int)B, obs, &ws_bytes);
+    const int rc = gcm_dense_step_fwd(
+        obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+        count_in.data_ptr<int64_t>(), base, base + L.o_adj, ib, ib + B,
+        cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
+        packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2, base + L.o_mx,
+        need_bwd ? base + L.o_h1 : nullptr, need_bwd ? base + L.o_agg1 : nullptr,
+        need_bwd ? base + L.o_agg2 : nullptr, reinterpret_cast<uint32_t*>(flags.data_ptr()), ws,
+        ws_bytes, (int)B, N, F, H1, H2, reinterpret_cast<gcm_stream_t>(stream));
+    check(rc, "gcm_dense_step_fwd");
+    at::Tensor nodes_out = buf.narrow(0, 0, B * N * F).view({B, N, F});
+    at::Tensor adj_out = buf.narrow(0, L.o_adj, B * N * N).view({B, N, N});
+    at::Tensor mx = buf.narrow(0, L.o_mx, B * H2).view({B, H2});
+    at::Tensor cur = ibuf.select(0, 0), count_out = ibuf.select(0, 1);
+    if (need_bwd) {
+      ctx->save_for_backward({buf, ibuf, count_in, packed});
+      auto& sd = ctx->saved_data;
+      sd["dims"] = std::vector<int64_t>{B, N, F, H1, H2, cfg->P, cfg->has_bias, cfg->act1,
+                                        cfg->act2, stream};
+    }
+    ctx->mark_non_differentiable({adj_out, cur, count_out});
+    return {mx, nodes_out, adj_out, cur, count_out};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &buf = saved[0], &ibuf = saved[1], &count_in = saved[2], &packed = saved[3];
+    const auto d = ctx->saved_data["dims"].toIntVector();
+    const int64_t B = d[0], N = d[1], F = d[2], H1 = d[3], H2 = d[4], P = d[5];
+    const int has_bias = (int)d[6], act1 = (int)d[7], act2 = (int)d[8];
+    const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(d[9]);
+    const Layout L(B, N, F, H1, H2, true);
+    at::Tensor g_mx = grads[0].defined() ? grads[0].contiguous() : at::zeros({B, H2}, buf.options());
+    at::Tensor g_no = grads[1].defined() ? grads[1].contiguous() : at::Tensor();
+    // outputs + slab scratch in one allocation: g_nodes_in | g_obs | g_params | slabs
+    const int64_t n_nodes = pad64(B * N * F), n_obs = pad64(B * F), n_p = pad64(P);
+    at::Tensor out = at::empty({n_nodes + n_obs + n_p + B * P}, buf.options());
+    float* ob = out.data_ptr<float>();
+    const float* base = buf.data_ptr<float>();
+    const int rc = gcm_dense_step_bwd(
+        g_mx.data_ptr<float>(), g_no.defined() ? g_no.data_ptr<float>() : nullptr, base,
+        base + L.o_adj, ibuf.data_ptr<int64_t>(), count_in.data_ptr<int64_t>(),
+        packed.data_ptr<float>(), has_bias, act1, act2, base + L.o_mx, base + L.o_h1,
+        base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes, ob + n_nodes + n_obs,
+        ob + n_nodes + n_obs + n_p, sizeof(float) * (size_t)(B * P), (int)B, (int)N, (int)F,
+        (int)H1, (int)H2, stream);
+    check(rc, "gcm_dense_step_bwd");
+    at::Tensor g_obs, g_nodes_in, g_params;
+    if (ctx->needs_input_grad(0)) g_obs = out.narrow(0, n_nodes, B * F).view({B, F});
+    if (ctx->needs_input_grad(1)) g_nodes_in = out.narrow(0, 0, B * N * F).view({B, N, F});
+    if (ctx->needs_input_grad(2)) g_params = out.narrow(0, n_nodes + n_obs, P);
+    return {g_obs, g_nodes_in, g_params, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor(), at::Tensor()};
+  }
+};
+
+std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& nodes_in,
+                                   const at::Tensor& packed, const at::Tensor& adj_in,
+                                   const at::Tensor& count_in, const at::Tensor& flags,
+                                   int64_t cfg_handle, int64_t stream) {
+  TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && packed.is_cuda() && adj_in.is_cuda() &&
+                  count_in.is_cuda() && flags.is_cuda(),
+              "fused_step: every tensor must live on a HIP device (no CPU fallback)");
+  TORCH_CHECK(obs.scalar_type() == at::kFloat && nodes_in.scalar_type() == at::kFloat &&
+              adj_in.scalar_type() == at::kFloat && packed.scalar_type() == at::kFloat &&
+              count_in.scalar_type() == at::kLong && packed.is_contiguous() &&
+              count_in.is_contiguous());
+  const bool need_bwd = at::GradMode::is_enabled() &&
+                        (obs.requires_grad() || nodes_in.requires_grad() || packed.requires_grad());
+  return FusedStepFn::apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg_handle, stream,
+                            (int64_t)need_bwd);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "C++ autograd node of the fused DenseGCM step (host side of libgcm_hip.so)";
+  pybind11::class_<StepCfg>(m, "StepCfg")
+      .def(pybind11::init<int64_t, int, int, int, int, int, int, int, int>())
+      .def("handle", [](StepCfg& c) { return reinterpret_cast<int64_t>(&c); });
+  m.def("fused_step", &fused_step);
+}

@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from . import _hip
+from . import _ext, _hip
 
 _f32 = torch.float32
 
@@ -582,6 +582,21 @@ class StepConfig:
         self.fn_fwd = lib.gcm_dense_step_fwd
         self.fn_bwd = lib.gcm_dense_step_bwd
         self.has_distance = any(d.kind == _hip.SEL_DISTANCE for d in descs)
+        self._cpp, self._cpp_handle = None, None
+
+    def cpp_handle(self):
+        """address of the C++ twin of this config (0 when the torch extension is not built)"""
+        h = self._cpp_handle
+        if h is None:
+            ext = _ext.module()
+            if ext is None:
+                h = 0
+            else:
+                self._cpp = ext.StepCfg(self.arr_ptr, self.n_desc, self.acts[0], self.acts[1],
+                                        self.has_bias, self.N, self.F, self.H1, self.H2)
+                h = self._cpp.handle()
+            self._cpp_handle = h
+        return h
 
     def workspace(self, B):
         if not self.has_distance:
@@ -709,6 +724,14 @@ class _FusedStep(torch.autograd.Function):
 
 
 def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg):
+    """The per-step node: the C++ autograd node when gcm/_lib/ext is built (same C-ABI calls,
+    no interpreter on the path), else the Python Function above.  Kernel timing (TIMER) goes
+    through the Python one, whose launches it can bracket."""
+    if TIMER is None:
+        handle = cfg.cpp_handle()
+        if handle:
+            return _ext.module().fused_step(obs, nodes_in, packed, adj_in, count_in, flags, handle,
+                                            torch._C._cuda_getCurrentRawStream(obs.device.index))
     return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg)
 
 

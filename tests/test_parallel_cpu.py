@@ -37,7 +37,8 @@ def _worker(rank, world, port, q):
     out.mean().backward()
     bucket = parallel.GradBucket(gnn)
     bucket.all_reduce_mean((hi - lo) / Bg)
-    q.put((rank, [p.grad.clone() for p in gnn.parameters()], out.detach()))
+    # by value (numpy), not as shared-memory tensors: those need the sender alive at receive time
+    q.put((rank, [p.grad.numpy().copy() for p in gnn.parameters()], out.detach().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +51,7 @@ def test_sharded_rollout_equals_global_batch():
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    got = [(r, [torch.from_numpy(g) for g in gs], torch.from_numpy(o)) for r, gs, o in got]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -36,9 +36,14 @@ def timed(label, fn, n=5):
 
 timed("forward loop, no_grad", lambda: fwd(False))
 outs = timed("forward loop, grad", lambda: fwd(True))
+FW = []
 def fb():
-    o = fwd(True)
     torch.cuda.synchronize()
+    tf = time.perf_counter()
+    o = fwd(True)
+    tf1 = time.perf_counter() - tf
+    torch.cuda.synchronize()
+    FW.append((tf1, time.perf_counter() - tf))
     t0 = time.perf_counter()
     torch.stack(o).mean().backward()
     t1 = time.perf_counter() - t0
@@ -47,6 +52,7 @@ def fb():
     gnn.zero_grad(set_to_none=True)
     return t1, t2
 rs = [fb() for _ in range(5)]
+print(f"{'forward (memory recycled by backward)':38s} host {sum(r[0] for r in FW)/5*1e3:7.2f} ms  ({sum(r[0] for r in FW)/5/T*1e6:6.1f} us/step)   host+gpu {sum(r[1] for r in FW)/5*1e3:7.2f} ms")
 print(f"{'backward only':38s} host {sum(r[0] for r in rs)/5*1e3:7.2f} ms  ({sum(r[0] for r in rs)/5/T*1e6:6.1f} us/step)   host+gpu {sum(r[1] for r in rs)/5*1e3:7.2f} ms")
 # raw C call cost
 cfg = mem._fused_plan(*mem.get_initial_hidden_state(obs[0])[:3], bench.F)
