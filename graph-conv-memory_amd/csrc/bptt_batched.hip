@@ -15,6 +15,16 @@
 // pobs = dX_t[cur].  EXACT shapes only; everything else uses k_gnn2_row_bwd over T*B.
 #include "fused_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps3): phase stamps of one item of workgroup 0
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#define BSTAMP(i) do { if (item == GCM_STAMP_ITEM) STAMP(i); } while (0)
+#else
+#define BSTAMP(i)
+#endif
+
 namespace gcm_fused {
 
 template <int NT, int NCT, int NHT, int N2T>
@@ -93,6 +103,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
     const float* h1g = h1 + (size_t)item * N * H1;
     const float* a1g = agg1 + (size_t)item * N * F;
     float* gin = Q + (size_t)item * N * F;
+    BSTAMP(0);
     int64_t cur64 = cur_idx[item];
     const int cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
     const bool wrap = num_nodes_in[item] + 1 > N;
@@ -110,7 +121,9 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
       if (tid < 2 * HP) sVv[tid] = tid < HP ? a2 : hc;
       if (tid < N) sRow[tid] = ar;
     }
+    BSTAMP(1);
     __syncthreads();
+    BSTAMP(2);
     {  // u[m] = sum_o W2c[o][m] * d2[o]
       constexpr int G = 256 / (2 * HP), OC = H2P / G;
       const int g = tid / (2 * HP), m = tid - g * (2 * HP);
@@ -129,6 +142,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
 #pragma unroll
     for (int t = 0; t < NT; ++t) live |= (__any(sRow[t * 32 + li] != 0.f) ? 1u : 0u) << t;
     constexpr int PERG = 32 * HP / 256;
+    BSTAMP(3);
     __syncthreads();
     if (tid < 2 * HP) {
       constexpr int G = 256 / (2 * HP);
@@ -138,6 +152,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
       sU[tid] = t;
     }
     __syncthreads();
+    BSTAMP(4);
     // ---- G1[j][h] = (adj[cur][j] * dagg2[h] + [j==cur] dh1cur[h]) * act1'(h1[j][h]) --------------
 #pragma unroll 1
     for (int t = 0; t < NT; ++t)
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
         }
       }
     __syncthreads();
+    BSTAMP(5);
     // ---- layer-1 parameter gradients: G1^T (H1 x live rows) @ {agg1, x}, jobs dealt to the 4 waves
 #pragma unroll
     for (int which = 0; which < 2; ++which)
@@ -179,6 +195,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
             }
           }
         }
+    BSTAMP(6);
     // ---- dAgg1 = G1 @ W_rel1 -> LDS ;  acc = G1 @ W_root1 (root part of dX), live tiles only -----
     const bool my_rows_live = (live >> wave) & 1u;
     f32x16 acc[NCT];
@@ -197,6 +214,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
       }
     }
     __syncthreads();
+    BSTAMP(7);
     // ---- dX[i] += sum_k adj[k][i] * dAgg1[k], k over the live row tiles --------------------------
     if (wave_rows) {
 #pragma unroll 1
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
           }
         }
       }
+      BSTAMP(8);
       // epilogue: undo insert + roll (gcm.py:262-278)
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
@@ -238,7 +257,9 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
         }
     }
     if (wrap && tid < F) gin[tid] = 0.f;
-    __syncthreads();   // sG / sD / sRow / sV are rewritten by the next item
+    BSTAMP(9);
+    __syncthreads();
+    BSTAMP(10);   // sG / sD / sRow / sV are rewritten by the next item
   }
 
   // ---- one slab per workgroup ------------------------------------------------------------------

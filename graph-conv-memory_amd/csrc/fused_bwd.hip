@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
 // block = 16 elements x 16 slab groups, every thread sums its slabs with the loads in flight
 // together, the 16 partials of an element meet in LDS.
 __global__ __launch_bounds__(256) void k_sum_slabs(const float* __restrict__ slabs, int n_slabs,
-                                                   int len, float* __restrict__ out) {
+                                                   int len, const float* __restrict__ prev,
+                                                   float* __restrict__ out) {
   __shared__ float part[256];
   const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int e = blockIdx.x * 16 + el;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float* __restrict__ sla
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += part[g * 16 + el];
-    out[e] = t;
+    out[e] = prev ? prev[e] + t : t;
   }
 }
 
@@ -364,8 +365,13 @@ extern "C" int gcm_dense_gnn2_row_bwd(const float* g_mx, const float* g_nodes_ou
 
 extern "C" int gcm_sum_slabs(const float* slabs, int n_slabs, int len, float* out,
                              gcm_stream_t stream) {
+  return gcm_sum_slabs_acc(slabs, n_slabs, len, nullptr, out, stream);
+}
+
+extern "C" int gcm_sum_slabs_acc(const float* slabs, int n_slabs, int len, const float* prev,
+                                 float* out, gcm_stream_t stream) {
   GCM_REQUIRE(slabs && out && n_slabs > 0 && len > 0);
   hipLaunchKernelGGL(gcm_fused::k_sum_slabs, dim3((len + 15) / 16), dim3(256), 0,
-                     (hipStream_t)stream, slabs, n_slabs, len, out);
+                     (hipStream_t)stream, slabs, n_slabs, len, prev, out);
   return gcm_launch_status();
 }

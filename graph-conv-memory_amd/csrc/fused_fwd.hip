@@ -250,6 +250,238 @@ __global__ __launch_bounds__(256) void k_step_fwd(
                                                     H2);
 }
 
+
+// ---------------------------------------------------------------------------
+// One forward step, live-tile variant (tile-exact shapes).  The state copy (gcm.py:262-286 hands
+// back fresh nodes / adjacency) streams HBM -> registers -> HBM; the GNN is evaluated only on the
+// 32-row tiles that reach the belief (the tiles holding row cur and the non-zeros of adj[cur,:],
+// gcm.py:314), shared by all four waves as 16x16 blocks on the 16x16x4 MFMA, and only those tiles
+// of h1 / agg1 are saved for the backward (which reads no others).  Layer 2 runs on one wave.
+// ---------------------------------------------------------------------------
+template <int NT, int NCT, int NHT, int N2T>
+struct LdsLive {
+  using L = Lds<NT, NCT, NHT, N2T>;
+  static constexpr int TOTAL = L::ADJ + L::X + L::AH + L::W1F + L::W2 + L::SV;
+};
+
+template <int NT, int NCT, int NHT, int N2T>
+__global__ __launch_bounds__(256) void k_step_fwd_live(
+    const float* __restrict__ nodes_in, const float* __restrict__ adj_in, Advance A, Gnn2 P,
+    float* __restrict__ mx_out, float* __restrict__ h1_out, float* __restrict__ agg1_out,
+    float* __restrict__ agg2_out, uint32_t* __restrict__ flags) {
+  using L = Lds<NT, NCT, NHT, N2T>;
+  constexpr int N = L::NP, F = L::FP, H1 = L::HP, H2 = L::H2P;
+  constexpr int NP = N, FP = F, HP = H1, H2P = H2;
+  constexpr int FS = L::FS, HS = L::HS, AS = L::AS, W2S = L::W2S;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m16 = lane & 15, kq = lane >> 4;
+  const float* xg = nodes_in + (size_t)b * N * F;
+  const float* ag = adj_in + (size_t)b * N * N;
+  const int64_t n_in = A.count_in[b];
+  const bool wrap = n_in + 1 > N;
+  int64_t c64 = wrap ? n_in - 1 : n_in;
+  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  if (tid == 0) {
+    A.cur_out[b] = cur;
+    A.count_out[b] = cur + 1;
+    const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
+    if (f) atomicOr(flags, f);
+  }
+
+  extern __shared__ float smem[];
+  float* sAdj = smem;                    // [col tile][row][33]
+  float* sX = sAdj + L::ADJ;             // [N][FS]
+  float* sAH = sX + L::X;                // agg, then h1 (stride AS), live tiles only
+  float* sW1 = sAH + L::AH;              // w_rel1^T | w_root1^T  [f][HS]
+  float* sW2 = sW1 + L::W1F;             // [o][rel k | root k], stride W2S
+  float* sV = sW2 + L::W2;
+  float* sVv = sV + 256;
+  unsigned* sMask = reinterpret_cast<unsigned*>(sV);   // word R: non-zero col tiles of row tile R
+
+  // ---- every load, then the state copy ------------------------------------------------------
+  const int r_base = wave * 32;
+  const bool wave_rows = wave < NT;
+  Stage<NP, FP, false, true> st_x;
+  Stage<HP, FP, true, true> st_wr, st_wo;
+  Stage<H2P, HP, false, true> st_w2r, st_w2o;
+  AdjRows<NT, true> rows;
+  {
+    const float ob = A.obs[(size_t)b * F + (tid % FP)];   // 256 % FP == 0: fixed column
+#pragma unroll
+    for (int i = 0; i < st_x.PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, c = e % FP;
+      const int rs = r + (wrap ? 1 : 0);
+      const float t = xg[(rs < N ? rs : N - 1) * F + c];
+      float v = rs < N ? t : 0.f;
+      if (r == cur) v = ob;
+      st_x.v[i] = v;
+    }
+  }
+  st_wr.load(P.w_rel1, H1, F, F, tid);
+  st_wo.load(P.w_root1, H1, F, F, tid);
+  if (wave_rows) rows.load_advanced(ag, N, r_base, lane, wrap);
+  st_w2r.load(P.w_rel2, H2, H1, H1, tid);
+  st_w2o.load(P.w_root2, H2, H1, H1, tid);
+  float bias1[NHT];
+#pragma unroll
+  for (int bi = 0; bi < NHT; ++bi) {
+    const int blk = wave + 4 * bi, h0 = (blk >> 1) * 16;
+    bias1[bi] = P.b_rel1 ? P.b_rel1[h0 + m16] : 0.f;
+  }
+  const float bias2 = P.b_rel2 ? P.b_rel2[lane < H2 ? lane : H2 - 1] : 0.f;
+  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  {
+    float* no = A.nodes_out + (size_t)b * N * F;
+#pragma unroll
+    for (int i = 0; i < st_x.PER; ++i) no[tid + 256 * i] = st_x.v[i];
+  }
+  st_x.store(sX, FS, tid);
+  st_wr.store(sW1, HS, tid);
+  st_wo.store(sW1 + FP * HS, HS, tid);
+  st_w2r.store(sW2, W2S, tid);
+  st_w2o.store(sW2 + HP, W2S, tid);
+  {
+    unsigned bits = 0;
+    if (wave_rows) {
+      rows.apply_edits(A.edits, cur, r_base, lane);
+      rows.store_global(A.adj_out + (size_t)b * N * N, N, r_base, lane);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        rows.template store_tile<NP>(sAdj, t, r_base, lane);
+        bits |= (rows.tile_nonzero(t) ? 1u : 0u) << t;
+      }
+    }
+    if (lane == 0) sMask[wave] = bits;
+  }
+  __syncthreads();
+
+  // ---- the live tiles ---------------------------------------------------------------------------
+  unsigned nzmask = 0;
+#pragma unroll
+  for (int R = 0; R < NT; ++R) nzmask |= sMask[R] << (4 * R);
+  nzmask = __builtin_amdgcn_readfirstlane(nzmask);
+  unsigned live = 1u << (cur >> 5);
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+    live |= (__any(sAdj[adj_at<NP>(cur, tt * 32 + (lane & 31))] != 0.f) ? 1u : 0u) << tt;
+  bool lvt[NT];   // separate scalars per tile (see rollout_persist.hip)
+#pragma unroll
+  for (int R = 0; R < NT; ++R) lvt[R] = __builtin_amdgcn_readfirstlane((live >> R) & 1u) != 0;
+  float* a1g = agg1_out ? agg1_out + (size_t)b * N * F : nullptr;
+  float* h1g = h1_out ? h1_out + (size_t)b * N * H1 : nullptr;
+#pragma unroll
+  for (int R = 0; R < NT; ++R) {
+    if (lvt[R]) {   // layer 1 aggregation of this tile's rows, zero tiles skipped
+#pragma unroll
+      for (int bi = 0; bi < NCT; ++bi) {
+        const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, c0 = (blk >> 1) * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          if ((nzmask >> (R * 4 + tt)) & 1u)
+            mma16<32>(acc, sAdj + (tt * NP + r0) * 33, 33, sX + (tt * 32) * FS + c0, FS, m16, kq);
+        float* d = sAH + (r0 + 4 * kq) * AS + c0 + m16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r * AS] = acc[r];
+        if (a1g) {
+          float* g = a1g + (r0 + 4 * kq) * F + c0 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g[r * F] = acc[r];
+        }
+      }
+    }
+  }
+  __syncthreads();   // every wave's agg blocks are in LDS
+  f32x4 o[NT][NHT];
+#pragma unroll
+  for (int R = 0; R < NT; ++R) {
+#pragma unroll
+    for (int bi = 0; bi < NHT; ++bi) o[R][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (lvt[R]) {
+#pragma unroll
+      for (int bi = 0; bi < NHT; ++bi) {
+        const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma16<FP>(acc, sAH + r0 * AS, AS, sW1 + h0, HS, m16, kq);
+        mma16<FP>(acc, sX + r0 * FS, FS, sW1 + FP * HS + h0, HS, m16, kq);
+        o[R][bi] = acc;
+      }
+    }
+  }
+  __syncthreads();   // nobody reads agg any more: h1 takes its place
+#pragma unroll
+  for (int R = 0; R < NT; ++R)
+    if (lvt[R]) {
+#pragma unroll
+      for (int bi = 0; bi < NHT; ++bi) {
+        const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gcm_act_sel(o[R][bi][r] + bias1[bi], act1_v);
+        float* d = sAH + (r0 + 4 * kq) * AS + h0 + m16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r * AS] = v[r];
+        if (h1g) {
+          float* g = h1g + (r0 + 4 * kq) * H1 + h0 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g[r * H1] = v[r];
+        }
+      }
+    }
+  __syncthreads();
+  // ---- layer 2 on row `cur`: wave 0 alone ---------------------------------------------------------
+  if (wave == 0) {
+    constexpr int PA = 64 / HP, JN = 32 / PA;
+    const int h = lane & (HP - 1), part = lane / HP;
+    float s = 0.f;
+#pragma unroll
+    for (int R = 0; R < NT; ++R)
+      if (lvt[R]) {
+        const float* arow = sAdj + (R * NP + cur) * 33 + part;
+        const float* hcol = sAH + (R * 32 + part) * AS + h;
+        float av[JN], hv[JN];
+#pragma unroll
+        for (int i = 0; i < JN; ++i) {
+          av[i] = arow[PA * i];
+          hv[i] = hcol[PA * i * AS];
+        }
+#pragma unroll
+        for (int i = 0; i < JN; ++i) s = fmaf(av[i], hv[i], s);
+      }
+    if (PA == 2) s += __shfl_xor(s, 32);
+    const float hc = sAH[cur * AS + h];
+    if (part == 0) {
+      sVv[h] = s;
+      sVv[HP + h] = hc;
+      if (agg2_out) agg2_out[(size_t)b * H1 + h] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PB = 64 / H2P, KC = 2 * HP / PB;
+    const int o2 = lane & (H2P - 1), kp = lane / H2P;
+    const float* wrow = sW2 + o2 * W2S + kp * KC;
+    const float* vv = sVv + kp * KC;
+    float a = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 16) {
+      float wv[16], xv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        wv[k] = wrow[k0 + k];
+        xv[k] = vv[k0 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a = fmaf(wv[k], xv[k], a);
+    }
+    if (PB == 2) a += __shfl_xor(a, 32);
+    const float v = gcm_act_sel(a + bias2, act2_v);
+    if (lane < H2) mx_out[(size_t)b * H2 + lane] = v;
+    const bool any_bad = __any(lane < H2 && !isfinite(v));
+    if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+  }
+}
+
 template <int NT, int NCT, int NHT, int N2T>
 int launch_step(hipStream_t s, const float* nodes_in, const float* adj_in, Advance A, Gnn2 P,
                 float* mx, float* h1, float* agg1, float* agg2, uint32_t* flags, int B, int N,
@@ -257,6 +489,19 @@ int launch_step(hipStream_t s, const float* nodes_in, const float* adj_in, Advan
   using L = Lds<NT, NCT, NHT, N2T>;
   constexpr size_t lds = sizeof(float) * (size_t)L::FWD;
   const bool exact = N == L::NP && F == L::FP && H1 == L::HP && H2 == L::H2P;
+  constexpr size_t lds_live = sizeof(float) * (size_t)LdsLive<NT, NCT, NHT, N2T>::TOTAL;
+  if (exact && lds_live <= 160 * 1024) {   // live-tile kernel
+    auto kl = k_step_fwd_live<NT, NCT, NHT, N2T>;
+    static bool live_attr = false;
+    if (!live_attr && lds_live > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_live);
+      live_attr = true;
+    }
+    hipLaunchKernelGGL(kl, dim3(B), dim3(256), lds_live, s, nodes_in, adj_in, A, P, mx, h1, agg1,
+                       agg2, flags);
+    return gcm_launch_status();
+  }
   auto kern = exact ? k_step_fwd<NT, NCT, NHT, N2T, true> : k_step_fwd<NT, NCT, NHT, N2T, false>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[exact] && lds > 64 * 1024) {

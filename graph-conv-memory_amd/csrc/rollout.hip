@@ -80,6 +80,21 @@ extern "C" int gcm_dense_step_bwd(const float* g_mx, const float* g_nodes_out,
                                   float* g_nodes_in, float* g_obs, float* g_params,
                                   void* workspace, size_t workspace_bytes, int B, int N, int F,
                                   int H1, int H2, gcm_stream_t stream) {
+  return gcm_dense_step_bwd_acc(g_mx, g_nodes_out, nodes_out, adj_out, cur, count_in, params,
+                                has_bias, act1, act2, mx, h1, agg1, agg2, g_nodes_in, g_obs,
+                                nullptr, g_params, workspace, workspace_bytes, B, N, F, H1, H2,
+                                stream);
+}
+
+extern "C" int gcm_dense_step_bwd_acc(const float* g_mx, const float* g_nodes_out,
+                                      const float* nodes_out, const float* adj_out,
+                                      const int64_t* cur, const int64_t* count_in,
+                                      const float* params, int has_bias, int act1, int act2,
+                                      const float* mx, const float* h1, const float* agg1,
+                                      const float* agg2, float* g_nodes_in, float* g_obs,
+                                      const float* g_params_prev, float* g_params, void* workspace,
+                                      size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                                      gcm_stream_t stream) {
   GCM_REQUIRE(params && g_params && workspace);
   const size_t P = gcm_dense_gnn2_param_count(F, H1, H2);
   if (workspace_bytes < sizeof(float) * (size_t)B * P) return GCM_EWORKSPACE;
@@ -89,7 +104,7 @@ extern "C" int gcm_dense_step_bwd(const float* g_mx, const float* g_nodes_out,
                                   u.b1, u.w_root1, act1, u.w_rel2, u.b2, u.w_root2, act2, mx, h1,
                                   agg1, agg2, g_nodes_in, g_obs, slabs, 0, B, N, F, H1, H2, stream);
   if (rc) return rc;
-  return gcm_sum_slabs(slabs, B, (int)P, g_params, stream);
+  return gcm_sum_slabs_acc(slabs, B, (int)P, g_params_prev, g_params, stream);
 }
 
 extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all,

@@ -35,25 +35,6 @@ struct LdsRoll {
   static constexpr int TOTAL = BASE + 2 * CH * L::FP;
 };
 
-// 16x16 output block += A(16xK) * B(Kx16), operands in LDS (v_mfma_f32_16x16x4_f32: lane l holds
-// A[l&15][4s + (l>>4)] and B[4s + (l>>4)][l&15]; acc[r] = C[4*(l>>4) + r][l&15]).
-template <int K>
-__device__ __forceinline__ void mma16(f32x4& acc, const float* a, int ais, const float* b, int bks,
-                                      int m, int kq) {
-  const float* ap = a + m * ais + kq;
-  const float* bp = b + kq * bks + m;
-  float av[K / 4], bv[K / 4];   // every LDS read in flight before the first MFMA
-#pragma unroll
-  for (int s = 0; s < K / 4; ++s) {
-    av[s] = ap[4 * s];
-    bv[s] = bp[4 * s * bks];
-  }
-  __builtin_amdgcn_sched_barrier(0);   // keep the reads batched: one LDS round trip, not K/8
-#pragma unroll
-  for (int s = 0; s < K / 4; ++s)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
-}
-
 template <int NT, int NCT, int NHT, int N2T>
 __global__ __launch_bounds__(256) void k_rollout_fwd(
     const float* __restrict__ obs, float* __restrict__ nodes_all, float* __restrict__ adj_all,

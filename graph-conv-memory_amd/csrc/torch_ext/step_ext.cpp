@@ -7,6 +7,11 @@
 // gcm_dense_step_fwd / gcm_dense_step_bwd), without the interpreter on the path - in particular the
 // backward runs on the autograd engine thread without taking the GIL.
 //
+// The parameter gradient is threaded through the chain of step nodes: a node hands the packed
+// parameter vector on as a sixth output (an alias), the next step consumes that one, and in the
+// backward each node adds its own gradient to the running total inside gcm_sum_slabs_acc.  The
+// autograd engine would otherwise sum T separate [param_count] tensors with one tiny kernel each.
+//
 // No device code here: PyTorch is plumbing (allocation, autograd graph, stream); the product is the
 // C-ABI library this file links against.
 #include <torch/extension.h>
@@ -115,7 +120,12 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
                                         cfg->act2, stream};
     }
     ctx->mark_non_differentiable({adj_out, cur, count_out});
-    return {mx, nodes_out, adj_out, cur, count_out};
+    // undefined output gradients stay undefined (backward handles them): the engine would
+    // otherwise launch one zero-fill per output and step
+    ctx->set_materialize_grads(false);
+    // the parameter vector, handed on to the next step (same storage; nobody writes to it)
+    at::Tensor packed_out = packed.alias();
+    return {mx, nodes_out, adj_out, cur, count_out, packed_out};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -126,6 +136,10 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
     const int has_bias = (int)d[6], act1 = (int)d[7], act2 = (int)d[8];
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(d[9]);
     const Layout L(B, N, F, H1, H2, true);
+    at::Tensor g_par = grads.size() > 5 && grads[5].defined() ? grads[5].contiguous() : at::Tensor();
+    if (!grads[0].defined() && !grads[1].defined())   // this step feeds nothing: pass the total on
+      return {at::Tensor(), at::Tensor(), g_par, at::Tensor(), at::Tensor(), at::Tensor(),
+              at::Tensor(), at::Tensor(), at::Tensor()};
     at::Tensor g_mx = grads[0].defined() ? grads[0].contiguous() : at::zeros({B, H2}, buf.options());
     at::Tensor g_no = grads[1].defined() ? grads[1].contiguous() : at::Tensor();
     // outputs + slab scratch in one allocation: g_nodes_in | g_obs | g_params | slabs
@@ -133,18 +147,20 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
     at::Tensor out = at::empty({n_nodes + n_obs + n_p + B * P}, buf.options());
     float* ob = out.data_ptr<float>();
     const float* base = buf.data_ptr<float>();
-    const int rc = gcm_dense_step_bwd(
+    const int rc = gcm_dense_step_bwd_acc(
         g_mx.data_ptr<float>(), g_no.defined() ? g_no.data_ptr<float>() : nullptr, base,
         base + L.o_adj, ibuf.data_ptr<int64_t>(), count_in.data_ptr<int64_t>(),
         packed.data_ptr<float>(), has_bias, act1, act2, base + L.o_mx, base + L.o_h1,
-        base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes, ob + n_nodes + n_obs,
+        base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes,
+        g_par.defined() ? g_par.data_ptr<float>() : nullptr, ob + n_nodes + n_obs,
         ob + n_nodes + n_obs + n_p, sizeof(float) * (size_t)(B * P), (int)B, (int)N, (int)F,
         (int)H1, (int)H2, stream);
-    check(rc, "gcm_dense_step_bwd");
+    check(rc, "gcm_dense_step_bwd_acc");
     at::Tensor g_obs, g_nodes_in, g_params;
     if (ctx->needs_input_grad(0)) g_obs = out.narrow(0, n_nodes, B * F).view({B, F});
     if (ctx->needs_input_grad(1)) g_nodes_in = out.narrow(0, 0, B * N * F).view({B, N, F});
     if (ctx->needs_input_grad(2)) g_params = out.narrow(0, n_nodes + n_obs, P);
+    else if (g_par.defined()) g_params = g_par;
     return {g_obs, g_nodes_in, g_params, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
             at::Tensor(), at::Tensor()};
   }

@@ -688,6 +688,7 @@ class _FusedStep(torch.autograd.Function):
         ctx.save_for_backward(buf, ibuf, count_in, packed)
         ctx.cfg, ctx.B = cfg, B
         ctx.mark_non_differentiable(adj_out, cur, count_out)
+        ctx.set_materialize_grads(False)   # backward handles None: no zero-fill launches
         return mx, nodes_out, adj_out, cur, count_out
 
     @staticmethod
@@ -726,13 +727,15 @@ class _FusedStep(torch.autograd.Function):
 def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg):
     """The per-step node: the C++ autograd node when gcm/_lib/ext is built (same C-ABI calls,
     no interpreter on the path), else the Python Function above.  Kernel timing (TIMER) goes
-    through the Python one, whose launches it can bracket."""
+    through the Python one, whose launches it can bracket.
+    -> (mx, nodes_out, adj_out, cur, count_out, packed_out); packed_out (C++ node, grad mode) is
+    the parameter vector to feed the NEXT step of the same chain, or None."""
     if TIMER is None:
         handle = cfg.cpp_handle()
         if handle:
             return _ext.module().fused_step(obs, nodes_in, packed, adj_in, count_in, flags, handle,
                                             torch._C._cuda_getCurrentRawStream(obs.device.index))
-    return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg)
+    return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg) + (None,)
 
 
 # Time-parallel BPTT keeps T*B*(N*F + F + P) floats of scratch; above this many bytes the

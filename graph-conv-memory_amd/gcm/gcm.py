@@ -292,9 +292,17 @@ class DenseGCM(torch.nn.Module):
         return packed
 
     def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags):
-        packed = self._packed_params(cfg)
-        mx, nodes_out, adj_out, cur, num_nodes_next = _ops.fused_step(
+        root = self._packed_params(cfg)
+        # Steps of one rollout share the parameter vector through a chain (each step hands it to
+        # the next as an alias), so the backward adds the T parameter gradients inside the step
+        # kernels instead of T tiny engine-side sums.  The link travels on the hidden state the
+        # caller passes back; a detached / foreign hidden state simply starts a new chain.
+        chain = getattr(nodes, "_gcm_chain", None)
+        packed = chain[0] if chain is not None and chain[1] is root else root
+        mx, nodes_out, adj_out, cur, num_nodes_next, packed_out = _ops.fused_step(
             x, nodes, packed, adj, num_nodes, flags, cfg)
+        if packed_out is not None and packed_out.requires_grad:
+            nodes_out._gcm_chain = (packed_out, root)
         if self.mutate_num_nodes_on_overflow:
             num_nodes.copy_(cur)
         if self.finite_check != "off":

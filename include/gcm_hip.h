@@ -271,6 +271,9 @@ int gcm_dense_gnn2_row_bwd(const float* g_mx, const float* g_nodes_out, const fl
 
 /* out[e] = sum_i slabs[i, e]  (fixed order, deterministic) */
 int gcm_sum_slabs(const float* slabs, int n_slabs, int len, float* out, gcm_stream_t stream);
+/* ... plus a running total: out[e] = prev[e] + sum_i slabs[i, e]  (prev may be NULL or == out) */
+int gcm_sum_slabs_acc(const float* slabs, int n_slabs, int len, const float* prev, float* out,
+                      gcm_stream_t stream);
 
 /* One native edge selector of the per-step chain (host struct). */
 #define GCM_SEL_TEMPORAL 1
@@ -326,6 +329,17 @@ int gcm_dense_step_bwd(const float* g_mx, const float* g_nodes_out, const float*
                        const float* h1, const float* agg1, const float* agg2, float* g_nodes_in,
                        float* g_obs, float* g_params, void* workspace, size_t workspace_bytes,
                        int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+
+/* gcm_dense_step_bwd with the parameter gradient of the LATER steps folded in:
+ * g_params = g_params_prev (NULL = 0) + this step's gradient.  Lets a caller thread the parameter
+ * gradient through the chain of step nodes instead of summing T separate [param_count] tensors. */
+int gcm_dense_step_bwd_acc(const float* g_mx, const float* g_nodes_out, const float* nodes_out,
+                           const float* adj_out, const int64_t* cur, const int64_t* count_in,
+                           const float* params, int has_bias, int act1, int act2, const float* mx,
+                           const float* h1, const float* agg1, const float* agg2,
+                           float* g_nodes_in, float* g_obs, const float* g_params_prev,
+                           float* g_params, void* workspace, size_t workspace_bytes, int B, int N,
+                           int F, int H1, int H2, gcm_stream_t stream);
 
 /* ---- time-batched rollout (caller loop ray_gcm.py:200-202) --------- */
 
