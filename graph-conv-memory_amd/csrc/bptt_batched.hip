@@ -32,15 +32,15 @@ struct LdsBptt {
   using L = Lds<NT, NCT, NHT, N2T>;
   static constexpr int G = L::NP * L::HS, D = L::NP * L::FS;
   static constexpr int MISC = L::NP + 256 + 4 * L::HP + L::H2P;
-  static constexpr int TOTAL = G + D + L::W1B + L::W2 + MISC;
+  static constexpr int TOTAL = G + 2 * D + L::W1B + L::W2 + MISC;
   // waves per SIMD the LDS footprint allows (a workgroup puts one wave on each SIMD)
   static constexpr int WAVES = (TOTAL * 4 <= 80 * 1024 && NCT * NHT * N2T == 1) ? 2 : 1;
-  static_assert(G + D + L::W1B >= 4096, "the end-of-kernel reduction buffer aliases sG | sD | sW1");
 };
 
 template <int NT, int NCT, int NHT, int N2T>
 __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bptt_batched(
-    const float* __restrict__ g_mx, const float* __restrict__ x, const float* __restrict__ adj,
+    const float* __restrict__ g_mx, const float* __restrict__ g_nodes_out,
+    const float* __restrict__ x, const float* __restrict__ adj,
     const int64_t* __restrict__ cur_idx, const int64_t* __restrict__ num_nodes_in, Gnn2 P,
     const float* __restrict__ mx, const float* __restrict__ h1, const float* __restrict__ agg1,
     const float* __restrict__ agg2, float* __restrict__ Q, float* __restrict__ pobs,
@@ -51,18 +51,19 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
   constexpr int NP = N, FP = F, HP = H1, H2P = H2;
   constexpr int FS = L::FS, HS = L::HS, W2S = L::W2S;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int m16 = lane & 15, kq = lane >> 4;   // 16x16x4 MFMA lane coordinates
 
   extern __shared__ float smem[];
   float* sG = smem;                     // [NP][HS]  G1 = dh1 * act1'(h1), live row tiles only
-  float* sD = sG + LB::G;               // [NP][FS]  dAgg1, live row tiles only
-  float* sW1 = sD + LB::D;              // w_rel1 [h][FS] | w_root1 [h][FS]
+  float* sD = sG + LB::G;               // [NP][FS]  dAgg1 = G1 @ W_rel1, live row tiles only
+  float* sRt = sD + LB::D;              // [NP][FS]  G1 @ W_root1 (root part of dX), live tiles only
+  float* sW1 = sRt + LB::D;             // w_rel1 [h][FS] | w_root1 [h][FS]
   float* sW2 = sW1 + L::W1B;            // [o][rel k | root k], stride W2S
   float* sRow = sW2 + L::W2;            // adj[cur][:]
   float* sV = sRow + NP;                // [256] partials
   float* sVv = sV + 256;                // v = agg2 | h1[cur]   [2*HP]
   float* sD2 = sVv + 2 * HP;            // d2                   [H2P]
   float* sU = sD2 + H2P;                // u = dagg2 | dh1cur   [2*HP]
-  float* sR = smem;                     // end of kernel: [4][1024] cross-wave reduction (over sG..sW1)
 
   {  // weights: once per workgroup
     Stage<HP, FP, false, true> st_wr, st_wo;
@@ -76,38 +77,45 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
     st_w2r.store(sW2, W2S, tid);
     st_w2o.store(sW2 + HP, W2S, tid);
   }
-  // parameter-gradient accumulators, live across items
-  f32x16 accW[2][NHT][NCT];
+  // parameter-gradient accumulators, live across items.  Layer 1: [H1 x F] as 16x16 blocks, block
+  // id = wave + 4*bi -> (h0, c0); one accumulator per block and operand (agg1 / x).
+  constexpr int NBW = NHT * NCT;        // blocks per wave
+  constexpr int CB = FP / 16;           // column blocks
+  f32x4 accW[2][NBW];
 #pragma unroll
   for (int w = 0; w < 2; ++w)
 #pragma unroll
-    for (int a = 0; a < NHT; ++a)
-#pragma unroll
-      for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accW[w][a][c][r] = 0.f;
+    for (int bi = 0; bi < NBW; ++bi) accW[w][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int PER2 = H2P * 2 * HP / 256;
   float dw2[PER2];
 #pragma unroll
   for (int i = 0; i < PER2; ++i) dw2[i] = 0.f;
   float db1 = 0.f, db2 = 0.f;
+  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
   __syncthreads();
 
   const int r_base = wave * 32;
-  const bool wave_rows = wave < NT;   // this wave owns output rows [r_base, r_base + 32)
+  const bool wave_rows = wave < NT;   // this wave owns output rows [r_base, r_base + 32) of dX
+
+  // cur / wrap of the next item are fetched one item ahead (the row addresses depend on them)
+  int curN;
+  bool wrapN;
+  {
+    int64_t c64 = cur_idx[blockIdx.x];
+    curN = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+    wrapN = num_nodes_in[blockIdx.x] + 1 > N;
+  }
 
 #pragma unroll 1
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    BSTAMP(0);
     const float* xg = x + (size_t)item * N * F;
     const float* ag = adj + (size_t)item * N * N;
     const float* h1g = h1 + (size_t)item * N * H1;
     const float* a1g = agg1 + (size_t)item * N * F;
     float* gin = Q + (size_t)item * N * F;
-    BSTAMP(0);
-    int64_t cur64 = cur_idx[item];
-    const int cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
-    const bool wrap = num_nodes_in[item] + 1 > N;
-
+    const int cur = curN;
+    const bool wrap = wrapN;
     // ---- phase 0: the kept row ---------------------------------------------------------------
     {
       const int o = tid < H2 ? tid : H2 - 1;
@@ -117,13 +125,33 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
       const float a2 = agg2[(size_t)item * H1 + k];
       const float hc = h1g[cur * H1 + k];
       const float ar = ag[cur * N + (tid < N ? tid : N - 1)];
-      if (tid < H2P) sD2[tid] = gm * gcm_act_grad(mv, P.act2);
+      {   // next item's cur (scalar path), in flight for the whole item
+        const int nxt = item + gridDim.x, ic = nxt < items ? nxt : items - 1;
+        int64_t c64 = cur_idx[ic];
+        curN = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+        wrapN = num_nodes_in[ic] + 1 > N;
+      }
+      const float ga = act2_v == GCM_ACT_TANH ? 1.f - mv * mv : (act2_v == GCM_ACT_RELU ? (mv > 0.f ? 1.f : 0.f) : 1.f);
+      if (tid < H2P) sD2[tid] = gm * ga;
       if (tid < 2 * HP) sVv[tid] = tid < HP ? a2 : hc;
       if (tid < N) sRow[tid] = ar;
     }
     BSTAMP(1);
     __syncthreads();
     BSTAMP(2);
+    unsigned live = 1u << (cur >> 5);   // bit t: row tile t can carry gradient (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) live |= (__any(sRow[t * 32 + li] != 0.f) ? 1u : 0u) << t;
+    live = __builtin_amdgcn_readfirstlane(live);
+    // h1 of the live row tiles: loads in flight under the layer-2 arithmetic
+    constexpr int PERG = 32 * HP / 256;
+    float hv[NT][PERG];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if ((live >> t) & 1u) {
+#pragma unroll
+        for (int i = 0; i < PERG; ++i) hv[t][i] = h1g[t * 32 * H1 + tid + 256 * i];
+      }
     {  // u[m] = sum_o W2c[o][m] * d2[o]
       constexpr int G = 256 / (2 * HP), OC = H2P / G;
       const int g = tid / (2 * HP), m = tid - g * (2 * HP);
@@ -138,10 +166,6 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
       dw2[i] = fmaf(sD2[o], sVv[k], dw2[i]);
     }
     if (tid < H2) db2 += sD2[tid];
-    unsigned live = 1u << (cur >> 5);   // bit t: row tile t can carry gradient (wave-uniform)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) live |= (__any(sRow[t * 32 + li] != 0.f) ? 1u : 0u) << t;
-    constexpr int PERG = 32 * HP / 256;
     BSTAMP(3);
     __syncthreads();
     if (tid < 2 * HP) {
@@ -154,73 +178,84 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
     __syncthreads();
     BSTAMP(4);
     // ---- G1[j][h] = (adj[cur][j] * dagg2[h] + [j==cur] dh1cur[h]) * act1'(h1[j][h]) --------------
-#pragma unroll 1
+#pragma unroll
     for (int t = 0; t < NT; ++t)
       if ((live >> t) & 1u) {
-        float hv[PERG];   // h1 of this live row tile
-#pragma unroll
-        for (int i = 0; i < PERG; ++i) hv[i] = h1g[t * 32 * H1 + tid + 256 * i];
 #pragma unroll
         for (int i = 0; i < PERG; ++i) {
           const int e = tid + 256 * i, j = t * 32 + e / HP, h = e % HP;
           const float d = sRow[j] * sU[h] + (j == cur ? sU[HP + h] : 0.f);
-          float v = d * gcm_act_grad(hv[i], P.act1);
+          const float y = hv[t][i];
+          const float ga = act1_v == GCM_ACT_TANH ? 1.f - y * y : (act1_v == GCM_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : 1.f);
+          float v = d * ga;
           if (d == 0.f) v = 0.f;
           sG[j * HS + h] = v;
           db1 += v;   // 256 % HP == 0: a thread always sees the same h
         }
       }
-    __syncthreads();
     BSTAMP(5);
-    // ---- layer-1 parameter gradients: G1^T (H1 x live rows) @ {agg1, x}, jobs dealt to the 4 waves
-#pragma unroll
-    for (int which = 0; which < 2; ++which)
-#pragma unroll
-      for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int jobidx = which + 2 * (ht * NCT + ct);
-          const float* src = which ? xg : a1g;
+    __syncthreads();
+    BSTAMP(6);
+    // ---- layer-1 parameter gradients: dW[h][f] += sum_rows G1[row][h] * {agg1, x}[row][f], 16x16
+    // blocks shared by the four waves; B operands straight from HBM (each element used once)
 #pragma unroll 1
-          for (int t = 0; t < NT; ++t) {
-            if (((live >> t) & 1u) && ((t + jobidx) & 3) == wave) {
-              float bq[16];
+    for (int t = 0; t < NT; ++t)
+      if ((live >> t) & 1u) {
 #pragma unroll
-              for (int s = 0; s < 16; ++s) bq[s] = src[(t * 32 + 2 * s + lh) * F + ct * 32 + li];
-              const float* ap = sG + (t * 32 + lh) * HS + ht * 32 + li;   // A(i=h, k=row)
+        for (int bi = 0; bi < NBW; ++bi) {
+          const int blk = wave + 4 * bi, h0 = (blk / CB) * 16, c0 = (blk % CB) * 16;
+          float ga[8], b0[8], b1[8];
+          const float* ap = sG + (t * 32 + kq) * HS + h0 + m16;        // A(i=h, k=row)
+          const float* p0 = a1g + (t * 32 + kq) * F + c0 + m16;        // B(k=row, j=f)
+          const float* p1 = xg + (t * 32 + kq) * F + c0 + m16;
 #pragma unroll
-              for (int s = 0; s < 16; ++s)
-                accW[which][ht][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                    ap[2 * s * HS], bq[s], accW[which][ht][ct], 0, 0, 0);
-            }
+          for (int s = 0; s < 8; ++s) {
+            ga[s] = ap[4 * s * HS];
+            b0[s] = p0[4 * s * F];
+            b1[s] = p1[4 * s * F];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            accW[0][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], b0[s], accW[0][bi], 0, 0, 0);
+            accW[1][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], b1[s], accW[1][bi], 0, 0, 0);
           }
         }
-    BSTAMP(6);
-    // ---- dAgg1 = G1 @ W_rel1 -> LDS ;  acc = G1 @ W_root1 (root part of dX), live tiles only -----
-    const bool my_rows_live = (live >> wave) & 1u;
-    f32x16 acc[NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-      if (wave_rows && my_rows_live) {
-        f32x16 d;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] = 0.f;
-        mma32(d, sG + r_base * HS, HS, 1, sW1 + c * 32, FS, 1, HP, li, lh);
-        mma32(acc[c], sG + r_base * HS, HS, 1, sW1 + HP * FS + c * 32, FS, 1, HP, li, lh);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sD[(r_base + acc_row(r, lh)) * FS + c * 32 + li] = d[r];
       }
-    }
-    __syncthreads();
     BSTAMP(7);
-    // ---- dX[i] += sum_k adj[k][i] * dAgg1[k], k over the live row tiles --------------------------
+    // ---- dAgg1 = G1 @ W_rel1, root = G1 @ W_root1 for the live tiles: [32 x F] as 16x16 blocks ----
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t)
+      if ((live >> t) & 1u) {
+#pragma unroll
+        for (int bi = 0; bi < NCT; ++bi) {
+          const int blk = wave + 4 * bi, r0 = t * 32 + (blk & 1) * 16, c0 = (blk >> 1) * 16;
+          f32x4 d = {0.f, 0.f, 0.f, 0.f}, rt = {0.f, 0.f, 0.f, 0.f};
+          mma16<HP>(d, sG + r0 * HS, HS, sW1 + c0, FS, m16, kq);
+          mma16<HP>(rt, sG + r0 * HS, HS, sW1 + HP * FS + c0, FS, m16, kq);
+          float* pd = sD + (r0 + 4 * kq) * FS + c0 + m16;
+          float* pr = sRt + (r0 + 4 * kq) * FS + c0 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pd[r * FS] = d[r];
+            pr[r * FS] = rt[r];
+          }
+        }
+      }
+    BSTAMP(8);
+    __syncthreads();
+    BSTAMP(9);
+    // ---- dX[i] = sum_k adj[k][i] * dAgg1[k] (k over the live row tiles) + root[i] -----------------
     if (wave_rows) {
+      f32x16 acc[NCT];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 #pragma unroll 1
       for (int t = 0; t < NT; ++t) {
         if ((live >> t) & 1u) {
-          // this wave's column strip of adjacency row tile t: the A operands, straight from HBM
+          // this wave's column strip of adjacency row tile t: the A operands, HBM -> registers
           float av[16];
 #pragma unroll
           for (int s = 0; s < 16; ++s) av[s] = ag[(t * 32 + lh + 2 * s) * N + r_base + li];
@@ -231,35 +266,38 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
               const float* bp = sD + (t * 32 + lh) * FS + c * 32 + li;
+              float bv[16];
+#pragma unroll
+              for (int s = 0; s < 16; ++s) bv[s] = bp[2 * s * FS];
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int s = 0; s < 16; ++s)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bp[2 * s * FS], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[c], 0, 0, 0);
             }
           }
         }
       }
-      BSTAMP(8);
-      // epilogue: undo insert + roll (gcm.py:262-278)
+      // epilogue: root part, incoming gradient, undo insert + roll (gcm.py:262-278); no branches
+      const bool mine = (live >> wave) & 1u;
+      const float* gg = g_nodes_out ? g_nodes_out + (size_t)item * N * F : nullptr;
+      const int sh = wrap ? 1 : 0;
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = r_base + acc_row(r, lh), col = c * 32 + li;
-          const float v = acc[c][r];
-          if (row == cur) {
-            pobs[(size_t)item * F + col] = v;
-            if (!wrap) gin[row * F + col] = 0.f;
-          } else if (!wrap) {
-            gin[row * F + col] = v;
-          } else {
-            gin[(row + 1) * F + col] = v;
-          }
+          float v = acc[c][r];
+          if (gg) v += gg[row * F + col];   // gradient from later steps (per-step use only)
+          if (mine) v += sRt[row * FS + col];
+          const bool is_cur = row == cur;
+          if (is_cur) pobs[(size_t)item * F + col] = v;   // the inserted row belongs to the observation
+          const int dst = row + sh;                        // out[r] = in[r+1] on overflow
+          if (dst < N) gin[dst * F + col] = is_cur ? 0.f : v;
         }
     }
-    if (wrap && tid < F) gin[tid] = 0.f;
-    BSTAMP(9);
-    __syncthreads();
-    BSTAMP(10);   // sG / sD / sRow / sV are rewritten by the next item
+    if (wrap && tid < F) gin[tid] = 0.f;   // in[0] was dropped by the roll: no gradient
+    BSTAMP(10);
+    __syncthreads();   // sG / sD / sRt / sRow / sV are rewritten by the next item
   }
 
   // ---- one slab per workgroup ------------------------------------------------------------------
@@ -271,22 +309,14 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
   float* sl_root2 = sl_rel2 + H2 * H1;
   float* sl_b2 = sl_root2 + H2 * H1;
 #pragma unroll
-  for (int which = 0; which < 2; ++which)
+  for (int w = 0; w < 2; ++w)
 #pragma unroll
-    for (int ht = 0; ht < NHT; ++ht)
+    for (int bi = 0; bi < NBW; ++bi) {   // every block has exactly one owner wave: plain stores
+      const int blk = wave + 4 * bi, h0 = (blk / CB) * 16, c0 = (blk % CB) * 16;
+      float* dst = (w ? sl_root1 : sl_rel1) + (h0 + 4 * kq) * F + c0 + m16;
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sR[wave * 1024 + acc_row(r, lh) * 32 + li] = accW[which][ht][ct][r];
-        __syncthreads();
-        float* dst = which ? sl_root1 : sl_rel1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int e = tid + 256 * i, hh = ht * 32 + (e >> 5), ff = ct * 32 + (e & 31);
-          dst[hh * F + ff] = (sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]);
-        }
-        __syncthreads();
-      }
+      for (int r = 0; r < 4; ++r) dst[r * F] = accW[w][bi][r];
+    }
 #pragma unroll
   for (int i = 0; i < PER2; ++i) {
     const int e = tid + 256 * i, o = e / (2 * HP), k = e % (2 * HP);
@@ -305,7 +335,8 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
 }
 
 template <int NT, int NCT, int NHT, int N2T>
-int launch_bptt(hipStream_t s, int grid, const float* g_mx, const float* x, const float* adj,
+int launch_bptt(hipStream_t s, int grid, const float* g_mx, const float* g_no, const float* x,
+                const float* adj,
                 const int64_t* cur, const int64_t* nn_in, Gnn2 P, const float* mx, const float* h1,
                 const float* agg1, const float* agg2, float* Q, float* pobs, float* slabs,
                 int items) {
@@ -318,8 +349,8 @@ int launch_bptt(hipStream_t s, int grid, const float* g_mx, const float* x, cons
                               (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g_mx, x, adj, cur, nn_in, P, mx, h1, agg1,
-                     agg2, Q, pobs, slabs, items);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g_mx, g_no, x, adj, cur, nn_in, P, mx, h1,
+                     agg1, agg2, Q, pobs, slabs, items);
   return gcm_launch_status();
 }
 
@@ -343,7 +374,8 @@ extern "C" int gcm_dense_bptt_batched_slabs(int items) {
   return items < g ? items : g;
 }
 
-extern "C" int gcm_dense_bptt_batched(const float* g_mx, const float* x, const float* adj,
+extern "C" int gcm_dense_bptt_batched(const float* g_mx, const float* g_nodes_out, const float* x,
+                                      const float* adj,
                                       const int64_t* cur_idx, const int64_t* num_nodes_in,
                                       const float* w_rel1, const float* b_rel1,
                                       const float* w_root1, int act1, const float* w_rel2,
@@ -362,8 +394,9 @@ extern "C" int gcm_dense_bptt_batched(const float* g_mx, const float* x, const f
   const int NT = N / 32, NCT = F / 32, NHT = H1 / 32, N2T = H2 / 32;
 #define GCM_B(a, b_, c, d)                                                                      \
   if (NT == a && NCT == b_ && NHT == c && N2T == d)                                             \
-    return gcm_fused::launch_bptt<a, b_, c, d>(s, n_slabs, g_mx, x, adj, cur_idx, num_nodes_in, \
-                                               P, mx, h1, agg1, agg2, Q, pobs, slabs, items);
+    return gcm_fused::launch_bptt<a, b_, c, d>(s, n_slabs, g_mx, g_nodes_out, x, adj, cur_idx,  \
+                                               num_nodes_in, P, mx, h1, agg1, agg2, Q, pobs,    \
+                                               slabs, items);
   GCM_BSHAPES(GCM_B)
 #undef GCM_B
   return GCM_EUNSUPPORTED;

@@ -69,6 +69,24 @@ __device__ __forceinline__ void mma16(f32x4& acc, const float* a, int ais, const
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
 }
 
+// general strides: A(i,k) = a[i*ais + k*aks], B(k,j) = b[k*bks + j]
+template <int K>
+__device__ __forceinline__ void mma16g(f32x4& acc, const float* a, int ais, int aks, const float* b,
+                                       int bks, int m, int kq) {
+  const float* ap = a + m * ais + kq * aks;
+  const float* bp = b + kq * bks + m;
+  float av[K / 4], bv[K / 4];
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) {
+    av[s] = ap[4 * s * aks];
+    bv[s] = bp[4 * s * bks];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+}
+
 struct Gnn2 {
   const float *w_rel1, *b_rel1, *w_root1;  // [H1,F], [H1], [H1,F]
   const float *w_rel2, *b_rel2, *w_root2;  // [H2,H1], [H2], [H2,H1]

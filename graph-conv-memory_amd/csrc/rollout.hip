@@ -100,11 +100,14 @@ extern "C" int gcm_dense_step_bwd_acc(const float* g_mx, const float* g_nodes_ou
   if (workspace_bytes < sizeof(float) * (size_t)B * P) return GCM_EWORKSPACE;
   const Unpacked u = unpack(params, has_bias, F, H1, H2);
   float* slabs = (float*)workspace;
+  // (the live-tile kernel of the time-parallel schedule chains several dependent loads per item:
+  // with ONE item per workgroup it is slower than this one, which issues every load up front)
+  const int n_slabs = B;
   int rc = gcm_dense_gnn2_row_bwd(g_mx, g_nodes_out, nodes_out, adj_out, cur, count_in, u.w_rel1,
                                   u.b1, u.w_root1, act1, u.w_rel2, u.b2, u.w_root2, act2, mx, h1,
                                   agg1, agg2, g_nodes_in, g_obs, slabs, 0, B, N, F, H1, H2, stream);
   if (rc) return rc;
-  return gcm_sum_slabs_acc(slabs, B, (int)P, g_params_prev, g_params, stream);
+  return gcm_sum_slabs_acc(slabs, n_slabs, (int)P, g_params_prev, g_params, stream);
 }
 
 extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all,
@@ -203,7 +206,8 @@ extern "C" int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes
     // persistent live-tile kernel (one slab per workgroup) when the shape is tile-exact, else the
     // per-graph kernel over all T*B graph-steps (one slab each)
     int n_slabs = gcm_dense_bptt_batched_slabs(T * B);
-    int rc = n_slabs > 0 ? gcm_dense_bptt_batched(g_mx_all, nodes_all + nodes_sz, adj_all + adj_sz,
+    int rc = n_slabs > 0 ? gcm_dense_bptt_batched(g_mx_all, nullptr, nodes_all + nodes_sz,
+                                                  adj_all + adj_sz,
                                                   cur_all, count_all, w_rel1, b_rel1, w_root1, act1,
                                                   w_rel2, b_rel2, w_root2, act2, mx_all, h1_all,
                                                   agg1_all, agg2_all, Q_all, pobs, slabs_all,

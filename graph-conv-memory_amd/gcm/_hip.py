@@ -81,7 +81,7 @@ PROTOTYPES = {
     "gcm_dense_rollout_persistent_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 3 + [_I]
                                          + [_P] * 5 + [_I] * 7 + [_P]),
     "gcm_dense_bptt_batched_slabs": (_I, [_I]),
-    "gcm_dense_bptt_batched": (_I, [_P] * 7 + [_I] + [_P] * 3 + [_I] + [_P] * 7 + [_I] * 6 + [_P]),
+    "gcm_dense_bptt_batched": (_I, [_P] * 8 + [_I] + [_P] * 3 + [_I] + [_P] * 7 + [_I] * 6 + [_P]),
     "gcm_dense_gnodes_scan": (_I, [_P] * 7 + [_I] * 4 + [_P]),
     "gcm_dense_rollout_bwd_workspace_bytes": (_Z, [_I] * 5),
     "gcm_dense_rollout_bwd_batched_workspace_bytes": (_Z, [_I] * 6),

@@ -391,10 +391,13 @@ int gcm_dense_gnodes_scan(const float* Q_all, const float* pobs_all, const float
  * n_slabs workgroups (gcm_dense_bptt_batched_slabs(items)) walks the items, touching only the
  * 32-row tiles that can carry gradient (the tiles holding row cur and the non-zeros of
  * adj[cur,:]) and writing ONE parameter-gradient slab per workgroup: slabs [n_slabs, param_count].
+ * g_nodes_out [items,N,F] = gradient w.r.t. each item's nodes from elsewhere (NULL = 0: the
+ * time-parallel schedule adds it in the scan; the per-step backward passes the next step's).
  * Q [items,N,F] / pobs [items,F] feed gcm_dense_gnodes_scan.  N, F, H1, H2 multiples of 32 within
  * the fused limits, else GCM_EUNSUPPORTED. */
 int gcm_dense_bptt_batched_slabs(int items);
-int gcm_dense_bptt_batched(const float* g_mx, const float* x, const float* adj,
+int gcm_dense_bptt_batched(const float* g_mx, const float* g_nodes_out, const float* x,
+                           const float* adj,
                            const int64_t* cur_idx, const int64_t* num_nodes_in,
                            const float* w_rel1, const float* b_rel1, const float* w_root1, int act1,
                            const float* w_rel2, const float* b_rel2, const float* w_root2, int act2,

@@ -472,8 +472,11 @@ def test_fused_matches_layered_and_rollout(B, N, F, H1, H2, T, sel_kind):
                                    atol=1e-5 * max(1.0, float(want[0].abs().max())))
         for a, b in zip(got[1], want[1]):
             assert torch.equal(a, b)                       # state: bit exact
-        torch.testing.assert_close(got[2], want[2], rtol=1e-4, atol=1e-6)
-        torch.testing.assert_close(got_g0, want_g0, rtol=1e-4, atol=1e-6)
+        # dense rows sum ~N terms in a different order; the test GNN ends in a ReLU, whose mask can
+        # flip for a pre-activation within that noise of zero
+        g_atol = 2e-5 if sel_kind == "dense" else 5e-6
+        torch.testing.assert_close(got[2], want[2], rtol=1e-4, atol=g_atol)
+        torch.testing.assert_close(got_g0, want_g0, rtol=1e-4, atol=g_atol)
         for k in want[3]:
             scale = float(want[3][k].abs().max()) + 1e-12
             torch.testing.assert_close(got[3][k], want[3][k], rtol=1e-4, atol=1e-5 * scale, msg=k)

@@ -35,12 +35,12 @@ base = packed.data_ptr()
 w = [base, base + 4 * 2 * H * F, base + 4 * H * F, base + 4 * (2 * H * F + H), base + 4 * (2 * H * F + H + 2 * H * H),
      base + 4 * (2 * H * F + H + H * H)]
 st = V(torch.cuda.current_stream().cuda_stream)
-names = ["phase-0 loads (cur -> row) + LDS", "barrier", "u, dW2, live", "barrier + sU + barrier", "h1 tile loads + G1",
-         "(barrier) dW1 jobs", "dAgg / root MFMA", "(barrier) adj strip loads + dX MFMA", "epilogue stores", "end barrier"]
+names = ["phase-0 loads (row of cur) + LDS", "barrier", "live, h1 loads issued, u, dW2", "barrier + sU + barrier", "G1",
+         "barrier", "dW1 blocks (16x16x4)", "dAgg / root blocks", "barrier", "adj strip loads + dX MFMA + epilogue"]
 acc = [0.0] * 10
 R = 10
 for it in range(R + 2):
-    rc = lib.gcm_dense_bptt_batched(p(g_mx), V(nodes_all.data_ptr() + 4 * B * N * F), V(adj_all.data_ptr() + 4 * B * N * N),
+    rc = lib.gcm_dense_bptt_batched(p(g_mx), None, V(nodes_all.data_ptr() + 4 * B * N * F), V(adj_all.data_ptr() + 4 * B * N * N),
                                     p(cur_all), p(count_all), V(w[0]), V(w[1]), V(w[2]), 1, V(w[3]), V(w[4]), V(w[5]), 1,
                                     p(mx_all), p(h1_all), p(agg1_all), p(agg2_all), p(Q), p(pobs), p(slabs), n_slabs, items,
                                     N, F, H, H, st)
