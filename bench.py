@@ -65,7 +65,8 @@ def rollout_api(mem, obs, bucket, weight):
 
 
 def time_dominant_kernels(mem, obs, reps=200):
-    """Mean launch duration of k_gnn2_row_fwd / k_gnn2_row_bwd on the real end-of-rollout state."""
+    """Mean launch duration of the one-kernel forward step (k_step_fwd_live) and of the GNN-only
+    kernels k_gnn2_row_fwd / k_gnn2_row_bwd on the real end-of-rollout state."""
     from gcm import _hip, _ops
 
     lib = _hip.lib()
@@ -115,7 +116,7 @@ def time_dominant_kernels(mem, obs, reps=200):
                                             p(agg2), p(flags), B, N, F, H, H, st)
 
     out = {}
-    for name, fn in (("k_step_fwd", step), ("k_gnn2_row_fwd", fwd), ("k_gnn2_row_bwd", bwd)):
+    for name, fn in (("k_step_fwd_live", step), ("k_gnn2_row_fwd", fwd), ("k_gnn2_row_bwd", bwd)):
         for _ in range(10):
             assert fn() == 0
         torch.cuda.synchronize()
@@ -267,33 +268,39 @@ def main():
                     "achieved_executed": B * execd / sec / 1e12,
                     "frac_executed": B * execd / sec / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
-        # Dominant kernel = k_step_fwd (one kernel per forward step).  It is HBM-bound in practice
+        # Dominant kernel = k_step_fwd_live (one kernel per forward step).  It is HBM-bound
         # (AI 8-17 FLOP/B < ridge 20-25): SURVEY 8(d)'s compulsory bytes per belief state
         # (adj once, x once, obs in, belief out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2)
         # over its mean launch time; `functional` adds what the reference's functional state
-        # semantics force through HBM (adj + nodes copied out every step) and the activations
-        # saved for BPTT.
+        # semantics force through HBM (adj + nodes copied out every step, gcm.py:262-286) and the
+        # activations saved for BPTT - only the live 32-row tiles of h1 / agg1 (1 of 4 on the timed
+        # state: node 127 links to 126, 125, 123).
         alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
-        func_bytes = B * (2 * 4 * N * N + 2 * 4 * N * F + 4 * F + 4 * H + 16 + 4 * N * H + 4 * N * F + 4 * H)
-        n_launch, ms = kern["k_step_fwd"]
+        live_rows = 32
+        func_bytes = B * (2 * 4 * N * N + 2 * 4 * N * F + 4 * F + 4 * H + 16
+                          + 4 * live_rows * H + 4 * live_rows * F + 4 * H)
+        n_launch, ms = kern["k_step_fwd_live"]
         sec = ms * 1e-3
-        dominant = {"bound": "hbm", "kernel": "k_step_fwd", "achieved": alg_bytes / sec / 1e9,
+        dominant = {"bound": "hbm", "kernel": "k_step_fwd_live", "achieved": alg_bytes / sec / 1e9,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS,
-                    "traffic": traffic.get("k_step_fwd"), "bytes_per_launch": alg_bytes,
+                    "traffic": traffic.get("k_step_fwd_live"), "bytes_per_launch": alg_bytes,
                     "avg_launch_ms": ms, "launches_timed": n_launch,
                     "achieved_functional": func_bytes / sec / 1e9,
                     "frac_functional": func_bytes / sec / 1e9 / PEAK_HBM_GBS,
                     "functional_bytes_per_launch": func_bytes,
                     "note": "bytes_per_launch = SURVEY 8(d) compulsory bytes (in-place state); the kernel "
                             "also copies adj+nodes out (functional hidden state, gcm.py:262-286) and saves "
-                            "h1/agg1 for BPTT = functional_bytes_per_launch, which is what `traffic` "
-                            "(PMC: 2*FETCH_SIZE+WRITE_SIZE) measures. avg_launch_ms: 200 back-to-back "
-                            "launches on the end-of-rollout state, one HIP event pair"}
-        note = ("flops: SURVEY 8(d) full-dense (2 layers x all N rows); *_executed: dense layer 1 + "
-                "row-only layer 2 (gcm.py:314), an upper bound since all-zero 32x32 adjacency tiles are skipped")
+                            "the live tiles of h1/agg1 for BPTT = functional_bytes_per_launch, which is what "
+                            "`traffic` (PMC: 2*FETCH_SIZE+WRITE_SIZE) measures. avg_launch_ms: 200 "
+                            "back-to-back launches on the end-of-rollout state, one HIP event pair"}
+        note = ("flops: SURVEY 8(d) full-dense (2 layers x all N rows); *_executed: what the kernel can "
+                "execute at most - layer 1 on all rows (GNN-only kernels) or on the live 32-row tile "
+                "(k_step_fwd_live), row-only layer 2 (gcm.py:314); all-zero 32x32 adjacency tiles are skipped")
+        fwd_live = 2 * live_rows * N * F + 4 * live_rows * F * H + 2 * N * H + 4 * H * H
         other = [dict(mfma_view("k_gnn2_row_bwd", 2 * fwd_full, bwd_exec), note=note),
-                 dict(mfma_view("k_step_fwd", fwd_full, fwd_exec), note=note),
+                 dict(mfma_view("k_step_fwd_live", fwd_full, fwd_live), note=note),
                  dict(mfma_view("k_gnn2_row_fwd", fwd_full, fwd_exec), note=note)]
+        from gcm import _ext
         line = {
             "metric": "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 F=32",
             "value": states / dt, "unit": "belief-states/s", "n_gpus": world,
@@ -305,12 +312,16 @@ def main():
                                    "through the per-step drop-in API `for t: mx, m = gcm(obs[t], m)` + backward" % T,
                        "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": T,
                        "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
+            "host_path": "c++ autograd node (gcm/_lib/ext)" if _ext.module() is not None
+                         else "python autograd function",
             "roofline": dominant, "roofline_mfma_view": other,
             "kernel_ms": {k: round(v[1], 5) for k, v in kern.items()},
             "rollout_api": {"value": states / dt_roll, "unit": "belief-states/s",
                             "ms_per_step": dt_roll / args.steps * 1e3,
                             "note": "same workload and results through the additive DenseGCM.rollout(obs[T,B,F]) "
-                                    "entry: T steps enqueued by one C call, one autograd node"},
+                                    "entry, one autograd node: persistent forward kernel (graph state resident "
+                                    "in LDS for all T steps), time-parallel BPTT (one launch over T*B graph-steps "
+                                    "+ reverse scan of the node gradient)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T)

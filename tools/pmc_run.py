@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Short cfg2 workload for rocprofv3 --pmc passes (HBM traffic of the dominant kernels):
-2 per-step rollouts fwd+bwd, T=128.  Run once per counter:
+2 per-step rollouts fwd+bwd and 2 rollout-API calls, T=128.  Run once per counter:
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py
 then tools/pmc_summarise.py writes profiles/traffic.json."""
@@ -20,6 +20,10 @@ bucket = parallel.GradBucket(gnn)
 obs = torch.rand(128, bench.B, bench.F).to(dev)
 for _ in range(2):
     bench.rollout(mem, obs, bucket, 1.0)
+    gnn.zero_grad(set_to_none=True)
+# the rollout entry: persistent forward, time-parallel BPTT, reverse scan
+for _ in range(2):
+    bench.rollout_api(mem, obs, bucket, 1.0)
     gnn.zero_grad(set_to_none=True)
 # the non-advance forward kernel too (what bench.py's roofline block times)
 bench.time_dominant_kernels(mem, obs, reps=20)
