@@ -60,7 +60,12 @@ def install_placeholders():
     sys.path.insert(0, REF)
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""   # substring filter: regenerate matching fixtures only
+
+
 def save(name, meta, **arrays):
+    if ONLY and ONLY not in name:
+        return
     out = {"meta": np.array(json.dumps(meta))}
     for k, v in arrays.items():
         if isinstance(v, torch.Tensor):
@@ -207,6 +212,24 @@ def main():
         assert margin >= 1e-3, (name, margin)
         meta = dict(meta, B=B, N=N, F=F, H=H, T=T, margin=margin)
         run_dense(name, m, obs, None, gnn, sel_module=sel, meta=meta)
+
+    # ---- G13: tile-exact shapes (N, F, H multiples of 32): the shapes the live-tile / persistent
+    # kernels are specialised for.  Staggered starts, runs through the overflow. ----------------
+    torch.manual_seed(13)
+    gen = torch.Generator().manual_seed(14)
+    B, N, F, H, T = 3, 64, 32, 32, 80
+    gnn = od.canonical_gnn(F, H)
+    m = DenseGCM(gnn, edge_selectors=TemporalBackedge([1, 2, 4]), graph_size=N)
+    h0 = staggered_state(B, N, F, [0, 40, 64], gen)
+    run_dense("g13_exact_temporal", m, torch.rand(T, B, F, generator=gen), h0, gnn,
+              meta=dict(B=B, N=N, F=F, H=H, T=T, selector="temporal", hops=[1, 2, 4], direction="forward"))
+    torch.manual_seed(15)
+    gen = torch.Generator().manual_seed(16)
+    B, N, F, H, T = 2, 32, 32, 64, 40
+    gnn = od.canonical_gnn(F, H)
+    m = DenseGCM(gnn, edge_selectors=DenseEdge(), graph_size=N)
+    run_dense("g13_exact_dense", m, torch.rand(T, B, F, generator=gen), None, gnn,
+              meta=dict(B=B, N=N, F=F, H=H, T=T, selector="dense"))
 
     # ---- G5: DenseEdge --------------------------------------------------------
     torch.manual_seed(0)

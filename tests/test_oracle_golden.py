@@ -7,7 +7,8 @@ from _golden import Fixture, oracle_selector
 from oracle import dense as od, pyg, sparse as osp
 
 DENSE = ["g1_temporal_h1", "g2_temporal_h124_both", "g1b_cfg1", "g3_euclid", "g3_euclid_mixed",
-         "g3_euclid_learned", "g4_spatial", "g4_spatial_ab", "g4_cosine", "g5_dense_edge"]
+         "g3_euclid_learned", "g4_spatial", "g4_spatial_ab", "g4_cosine", "g5_dense_edge",
+         "g13_exact_temporal", "g13_exact_dense"]
 
 
 def _run_dense(fx, gnn, sel):
