@@ -194,6 +194,7 @@ extern "C" int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes
     return GCM_EWORKSPACE;
   const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
   if (T > 1 && (size_t)N * F <= 8192 &&
+      sizeof(float) * 2 * (size_t)N * F + sizeof(int) * (size_t)T <= 160 * 1024 &&   // scan's LDS
       workspace_bytes >= gcm_dense_rollout_bwd_batched_workspace_bytes(T, B, N, F, H1, H2) &&
       (size_t)T * B < (1u << 31)) {
     // time-parallel BPTT: the GNN adjoint of step t needs g_mx[t] only, so all T*B graph-steps go

@@ -428,62 +428,91 @@ int launch_rollout(hipStream_t s, const float* obs, float* nodes_all, float* adj
 // gcm_dense_gnn2_row_bwd with no incoming node gradient).
 // One workgroup per graph, the running gradient lives in LDS.
 // ---------------------------------------------------------------------------
+template <int PER>   // ceil(N*F / 256) for the common sizes, 32 = any N*F <= 8192
 __global__ __launch_bounds__(256) void k_gnodes_scan(
     const float* __restrict__ Q_all, const float* __restrict__ pobs_all,
     const float* __restrict__ g_nodes_T, const int64_t* __restrict__ cur_all,
     const int64_t* __restrict__ count_all, float* __restrict__ g_obs_all,
     float* __restrict__ g_nodes_0, int T, int B, int N, int F) {
-  extern __shared__ float sG[];   // [N*F] gradient w.r.t. the nodes after step t (from steps > t)
+  // LDS: two copies of the running gradient (ping-pong: one barrier per step) + every step's
+  // (cur | wrap << 16), read once up front - a scalar global load per step would sit on the
+  // critical path of a loop that has nothing else to wait for
+  extern __shared__ float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int NF = N * F;
+  float* sG0 = smem;
+  int* sCur = reinterpret_cast<int*>(smem + 2 * NF);
   const size_t nodes_sz = (size_t)B * NF;
-  constexpr int PER = 32;   // N*F <= 128*64
-  for (int e = tid; e < NF; e += 256) sG[e] = g_nodes_T ? g_nodes_T[(size_t)b * NF + e] : 0.f;
-  float q[PER];
-  {
-    const float* Qt = Q_all + (size_t)(T - 1) * nodes_sz + (size_t)b * NF;
+  for (int t = tid; t < T; t += 256) {
+    int64_t c64 = cur_all[(size_t)t * B + b];
+    const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+    const int wrap = count_all[(size_t)t * B + b] + 1 > N ? 1 : 0;
+    sCur[t] = cur | (wrap << 16);
+  }
+  for (int e = tid; e < NF; e += 256) sG0[e] = g_nodes_T ? g_nodes_T[(size_t)b * NF + e] : 0.f;
+
+  // Q and pobs D steps ahead of their use: every step reads a fresh 16 KB from a new region
+  // (HBM + TLB latency is several steps of this loop)
+  constexpr int D = PER <= 16 ? 6 : 3;
+  float q[D][PER], po[D];
+  // (unconditional, clamped: with skipped fetches on some path hipcc must assume the minimum
+  // number of younger loads and waits for all but the last fetch - an effective depth of one;
+  // pobs first, so that waiting for it never covers the Q loads issued with it)
+  auto fetch = [&](float (&q)[PER], float& po_, int t_) {
+    const int t = t_ < 0 ? 0 : t_;
+    po_ = pobs_all[((size_t)t * B + b) * F + (tid < F ? tid : F - 1)];
+    const float* Qt = Q_all + (size_t)t * nodes_sz + (size_t)b * NF;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = tid + 256 * i;
       q[i] = Qt[e < NF ? e : NF - 1];
     }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    po[d] = 0.f;
+    fetch(q[d], po[d], T - 1 - d);
   }
   __syncthreads();
-  for (int t = T - 1; t >= 0; --t) {
-    int64_t c64 = cur_all[(size_t)t * B + b];
-    const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
-    const bool wrap = count_all[(size_t)t * B + b] + 1 > N;
-    if (tid < F)
-      g_obs_all[((size_t)t * B + b) * F + tid] = sG[cur * F + tid] + pobs_all[((size_t)t * B + b) * F + tid];
-    float v[PER];
+
+  // ping-pong by OFFSET into the one LDS array: swapping two pointers makes hipcc fall back to flat
+  // loads/stores, whose waits also cover the global prefetches in flight
+  int so = 0, dof = NF;
+  auto step = [&](float (&q)[PER], float po_, int t) {
+    const int cw = sCur[t], cur = cw & 0xffff;
+    const bool wrap = (cw >> 16) != 0;
+    if (tid < F) g_obs_all[((size_t)t * B + b) * F + tid] = smem[so + cur * F + tid] + po_;
+    // C_t[r] = U(C_{t+1})[r] + Q_t[r];  U(G)[r] = wrap ? (r >= 1 ? G[r-1] : 0) : (r == cur ? 0 : G[r])
+    // (no division: row r == cur <=> e - cur*F in [0, F); r >= 1 <=> e >= F)
+    const int sh = wrap ? F : 0;
+    const unsigned c0 = (unsigned)(cur * F);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = tid + 256 * i;
-      float u = 0.f;
       if (e < NF) {
-        const int r = e / F;
-        if (wrap) u = r >= 1 ? sG[e - F] : 0.f;
-        else u = r == cur ? 0.f : sG[e];
-      }
-      v[i] = u + q[i];
-    }
-    if (t > 0) {   // next step's Q while this one settles
-      const float* Qt = Q_all + (size_t)(t - 1) * nodes_sz + (size_t)b * NF;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int e = tid + 256 * i;
-        q[i] = Qt[e < NF ? e : NF - 1];
+        const int es = e - sh;
+        float u = smem[so + (es < 0 ? 0 : es)];
+        const bool zero = wrap ? e < F : ((unsigned)e - c0) < (unsigned)F;
+        smem[dof + e] = (zero ? 0.f : u) + q[i];
       }
     }
     __syncthreads();
+    const int tmp = so;
+    so = dof;
+    dof = tmp;
+  };
+  int t0 = T - 1;
+  for (; t0 >= D - 1; t0 -= D) {   // full groups of D steps: no conditionals around the loads
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i;
-      if (e < NF) sG[e] = v[i];
+    for (int d = 0; d < D; ++d) {
+      step(q[d], po[d], t0 - d);
+      fetch(q[d], po[d], t0 - d - D);
     }
-    __syncthreads();
   }
-  for (int e = tid; e < NF; e += 256) g_nodes_0[(size_t)b * NF + e] = sG[e];
+#pragma unroll
+  for (int d = 0; d < D; ++d)      // the last < D steps (their operands are already in registers)
+    if (t0 - d >= 0) step(q[d], po[d], t0 - d);
+  for (int e = tid; e < NF; e += 256) g_nodes_0[(size_t)b * NF + e] = smem[so + e];
 }
 
 }  // namespace gcm_fused
@@ -543,9 +572,24 @@ extern "C" int gcm_dense_gnodes_scan(const float* Q_all, const float* pobs_all,
   GCM_REQUIRE(T > 0 && B > 0 && N > 0 && F > 0);
   if ((size_t)N * F > 8192) return GCM_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = sizeof(float) * (size_t)N * F;
-  if (lds > 64 * 1024) return GCM_EUNSUPPORTED;
-  hipLaunchKernelGGL(gcm_fused::k_gnodes_scan, dim3(B), dim3(256), lds, s, Q_all, pobs_all,
-                     g_nodes_T, cur_all, count_all, g_obs_all, g_nodes_0, T, B, N, F);
-  return gcm_launch_status();
+  const size_t lds = sizeof(float) * 2 * (size_t)N * F + sizeof(int) * (size_t)T;
+  if (lds > 160 * 1024) return GCM_EUNSUPPORTED;   // T > ~24k steps: the caller's step-by-step schedule
+  const int nper = (N * F + 255) / 256;
+#define GCM_SCAN(P)                                                                              \
+  {                                                                                              \
+    static size_t lds_attr = 64 * 1024;                                                          \
+    if (lds > lds_attr) {                                                                        \
+      (void)hipFuncSetAttribute((const void*)gcm_fused::k_gnodes_scan<P>,                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      lds_attr = lds;                                                                            \
+    }                                                                                            \
+    hipLaunchKernelGGL(gcm_fused::k_gnodes_scan<P>, dim3(B), dim3(256), lds, s, Q_all, pobs_all, \
+                       g_nodes_T, cur_all, count_all, g_obs_all, g_nodes_0, T, B, N, F);         \
+    return gcm_launch_status();                                                                  \
+  }
+  if (nper <= 4) GCM_SCAN(4)
+  if (nper <= 8) GCM_SCAN(8)
+  if (nper <= 16) GCM_SCAN(16)
+  GCM_SCAN(32)
+#undef GCM_SCAN
 }
