@@ -1,5 +1,5 @@
 // Fused two-layer DenseGraphConv step, forward (see fused_common.h for the design notes).
-#include "fused_common.h"
+#include "live_gnn.h"
 
 #ifdef GCM_STAMPS
 __device__ unsigned long long g_stamps[32];
@@ -272,10 +272,9 @@ __global__ __launch_bounds__(256) void k_step_fwd_live(
   using L = Lds<NT, NCT, NHT, N2T>;
   constexpr int N = L::NP, F = L::FP, H1 = L::HP, H2 = L::H2P;
   constexpr int NP = N, FP = F, HP = H1, H2P = H2;
-  constexpr int FS = L::FS, HS = L::HS, AS = L::AS, W2S = L::W2S;
+  constexpr int FS = L::FS, HS = L::HS, W2S = L::W2S;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m16 = lane & 15, kq = lane >> 4;
   const float* xg = nodes_in + (size_t)b * N * F;
   const float* ag = adj_in + (size_t)b * N * N;
   const int64_t n_in = A.count_in[b];
@@ -323,14 +322,9 @@ __global__ __launch_bounds__(256) void k_step_fwd_live(
   if (wave_rows) rows.load_advanced(ag, N, r_base, lane, wrap);
   st_w2r.load(P.w_rel2, H2, H1, H1, tid);
   st_w2o.load(P.w_root2, H2, H1, H1, tid);
-  float bias1[NHT];
-#pragma unroll
-  for (int bi = 0; bi < NHT; ++bi) {
-    const int blk = wave + 4 * bi, h0 = (blk >> 1) * 16;
-    bias1[bi] = P.b_rel1 ? P.b_rel1[h0 + m16] : 0.f;
-  }
-  const float bias2 = P.b_rel2 ? P.b_rel2[lane < H2 ? lane : H2 - 1] : 0.f;
-  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  LiveGnn<NT, NCT, NHT, N2T> G;
+  G.sAdj = sAdj; G.sX = sX; G.sAH = sAH; G.sW1 = sW1; G.sW2 = sW2; G.sVv = sVv; G.sMask = sMask;
+  G.init_lane(P, tid);
   {
     float* no = A.nodes_out + (size_t)b * N * F;
 #pragma unroll
@@ -356,130 +350,13 @@ __global__ __launch_bounds__(256) void k_step_fwd_live(
   }
   __syncthreads();
 
-  // ---- the live tiles ---------------------------------------------------------------------------
-  unsigned nzmask = 0;
-#pragma unroll
-  for (int R = 0; R < NT; ++R) nzmask |= sMask[R] << (4 * R);
-  nzmask = __builtin_amdgcn_readfirstlane(nzmask);
-  unsigned live = 1u << (cur >> 5);
-#pragma unroll
-  for (int tt = 0; tt < NT; ++tt)
-    live |= (__any(sAdj[adj_at<NP>(cur, tt * 32 + (lane & 31))] != 0.f) ? 1u : 0u) << tt;
-  bool lvt[NT];   // separate scalars per tile (see rollout_persist.hip)
-#pragma unroll
-  for (int R = 0; R < NT; ++R) lvt[R] = __builtin_amdgcn_readfirstlane((live >> R) & 1u) != 0;
-  float* a1g = agg1_out ? agg1_out + (size_t)b * N * F : nullptr;
-  float* h1g = h1_out ? h1_out + (size_t)b * N * H1 : nullptr;
-#pragma unroll
-  for (int R = 0; R < NT; ++R) {
-    if (lvt[R]) {   // layer 1 aggregation of this tile's rows, zero tiles skipped
-#pragma unroll
-      for (int bi = 0; bi < NCT; ++bi) {
-        const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, c0 = (blk >> 1) * 16;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-          if ((nzmask >> (R * 4 + tt)) & 1u)
-            mma16<32>(acc, sAdj + (tt * NP + r0) * 33, 33, sX + (tt * 32) * FS + c0, FS, m16, kq);
-        float* d = sAH + (r0 + 4 * kq) * AS + c0 + m16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r * AS] = acc[r];
-        if (a1g) {
-          float* g = a1g + (r0 + 4 * kq) * F + c0 + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) g[r * F] = acc[r];
-        }
-      }
-    }
-  }
-  __syncthreads();   // every wave's agg blocks are in LDS
-  f32x4 o[NT][NHT];
-#pragma unroll
-  for (int R = 0; R < NT; ++R) {
-#pragma unroll
-    for (int bi = 0; bi < NHT; ++bi) o[R][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (lvt[R]) {
-#pragma unroll
-      for (int bi = 0; bi < NHT; ++bi) {
-        const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mma16<FP>(acc, sAH + r0 * AS, AS, sW1 + h0, HS, m16, kq);
-        mma16<FP>(acc, sX + r0 * FS, FS, sW1 + FP * HS + h0, HS, m16, kq);
-        o[R][bi] = acc;
-      }
-    }
-  }
-  __syncthreads();   // nobody reads agg any more: h1 takes its place
-#pragma unroll
-  for (int R = 0; R < NT; ++R)
-    if (lvt[R]) {
-#pragma unroll
-      for (int bi = 0; bi < NHT; ++bi) {
-        const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gcm_act_sel(o[R][bi][r] + bias1[bi], act1_v);
-        float* d = sAH + (r0 + 4 * kq) * AS + h0 + m16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r * AS] = v[r];
-        if (h1g) {
-          float* g = h1g + (r0 + 4 * kq) * H1 + h0 + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) g[r * H1] = v[r];
-        }
-      }
-    }
-  __syncthreads();
-  // ---- layer 2 on row `cur`: wave 0 alone ---------------------------------------------------------
-  if (wave == 0) {
-    constexpr int PA = 64 / HP, JN = 32 / PA;
-    const int h = lane & (HP - 1), part = lane / HP;
-    float s = 0.f;
-#pragma unroll
-    for (int R = 0; R < NT; ++R)
-      if (lvt[R]) {
-        const float* arow = sAdj + (R * NP + cur) * 33 + part;
-        const float* hcol = sAH + (R * 32 + part) * AS + h;
-        float av[JN], hv[JN];
-#pragma unroll
-        for (int i = 0; i < JN; ++i) {
-          av[i] = arow[PA * i];
-          hv[i] = hcol[PA * i * AS];
-        }
-#pragma unroll
-        for (int i = 0; i < JN; ++i) s = fmaf(av[i], hv[i], s);
-      }
-    if (PA == 2) s += __shfl_xor(s, 32);
-    const float hc = sAH[cur * AS + h];
-    if (part == 0) {
-      sVv[h] = s;
-      sVv[HP + h] = hc;
-      if (agg2_out) agg2_out[(size_t)b * H1 + h] = s;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    constexpr int PB = 64 / H2P, KC = 2 * HP / PB;
-    const int o2 = lane & (H2P - 1), kp = lane / H2P;
-    const float* wrow = sW2 + o2 * W2S + kp * KC;
-    const float* vv = sVv + kp * KC;
-    float a = 0.f;
-#pragma unroll
-    for (int k0 = 0; k0 < KC; k0 += 16) {
-      float wv[16], xv[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        wv[k] = wrow[k0 + k];
-        xv[k] = vv[k0 + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a = fmaf(wv[k], xv[k], a);
-    }
-    if (PB == 2) a += __shfl_xor(a, 32);
-    const float v = gcm_act_sel(a + bias2, act2_v);
-    if (lane < H2) mx_out[(size_t)b * H2 + lane] = v;
-    const bool any_bad = __any(lane < H2 && !isfinite(v));
-    if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
-  }
+  // ---- the live tiles (live_gnn.h) ------------------------------------------------------------
+  unsigned nzmask;
+  bool lvt[NT];
+  G.flags(cur, nzmask, lvt);
+  G.run(cur, nzmask, lvt, agg1_out ? agg1_out + (size_t)b * N * F : nullptr,
+        h1_out ? h1_out + (size_t)b * N * H1 : nullptr,
+        agg2_out ? agg2_out + (size_t)b * H1 : nullptr, mx_out + (size_t)b * H2, flags);
 }
 
 template <int NT, int NCT, int NHT, int N2T>

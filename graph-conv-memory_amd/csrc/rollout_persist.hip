@@ -9,7 +9,7 @@
 // critical path (the next observation row is prefetched one step ahead).
 //
 // Shapes: EXACT only (N, F, H1, H2 multiples of 32); other shapes use the per-step launches.
-#include "fused_common.h"
+#include "live_gnn.h"
 
 #ifdef GCM_STAMPS   // diagnostic build only (make stamps2): phase stamps of step GCM_STAMP_STEP
 __device__ unsigned long long g_stamps[32];
@@ -44,10 +44,9 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
   using L = Lds<NT, NCT, NHT, N2T>;
   constexpr int N = L::NP, F = L::FP, H1 = L::HP, H2 = L::H2P;
   constexpr int NP = N, FP = F, HP = H1, H2P = H2;
-  constexpr int FS = L::FS, HS = L::HS, AS = L::AS, W2S = L::W2S;
+  constexpr int FS = L::FS, HS = L::HS, W2S = L::W2S;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m16 = lane & 15, kq = lane >> 4;   // 16x16x4 MFMA lane coordinates
   const size_t nodes_sz = (size_t)B * N * F, adj_sz = (size_t)B * N * N;
 
   extern __shared__ float smem[];
@@ -101,14 +100,9 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
   int64_t n = count_all[b];
   // every per-step operand that lives in HBM is read once, here (a global load inside the loop
   // would share the in-order vmcnt with the history stores and wait for all of them)
-  float bias1[NHT];
-#pragma unroll
-  for (int bi = 0; bi < NHT; ++bi) {
-    const int blk = wave + 4 * bi, h0 = (blk >> 1) * 16;
-    bias1[bi] = P.b_rel1 ? P.b_rel1[h0 + m16] : 0.f;
-  }
-  const float bias2 = P.b_rel2 ? P.b_rel2[lane < H2 ? lane : H2 - 1] : 0.f;
-  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  LiveGnn<NT, NCT, NHT, N2T> G;
+  G.sAdj = sAdj; G.sX = sX; G.sAH = sAH; G.sW1 = sW1; G.sW2 = sW2; G.sVv = sVv; G.sMask = sMask;
+  G.init_lane(P, tid);
   const int my_hop = tid < E.n_hops ? E.hops[tid < 16 ? tid : 0] : -1;
   const int my_dir = tid < E.n_hops ? E.dir[tid < 16 ? tid : 0] : 0;
   // observations: chunk 0 into the ring now, chunk 1 into registers
@@ -234,33 +228,17 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
     }
     __syncthreads();
     RSTAMP(1);
-    // ---- which 32-row tiles matter this step: the ones holding row cur and the non-zeros of
-    // adj[cur,:].  Only their h1 rows reach the belief (gcm.py:314 keeps row cur of the last layer)
-    // and only they carry gradient in BPTT, so only they are computed and written to the history.
-    // All four waves share each live tile: 16x16 output blocks on the 16x16x4 MFMA.
-    unsigned nzmask = 0;
-#pragma unroll
-    for (int R = 0; R < NT; ++R) nzmask |= sMask[R] << (4 * R);
-    nzmask = __builtin_amdgcn_readfirstlane(nzmask);
-    unsigned live = 1u << (cur >> 5);
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-      live |= (__any(sAdj[adj_at<NP>(cur, tt * 32 + (lane & 31))] != 0.f) ? 1u : 0u) << tt;
-    // per-tile flags as separate scalars (one bit test per use; hipcc 7.2 inverted the third test of
-    // `(live >> R) & 1` on the same mask for NT >= 3)
+    // ---- the live tiles (live_gnn.h): history stores first (fire-and-forget), then the GNN --------
+    unsigned nzmask;
     bool lvt[NT];
-#pragma unroll
-    for (int R = 0; R < NT; ++R) lvt[R] = __builtin_amdgcn_readfirstlane((live >> R) & 1u) != 0;
+    G.flags(cur, nzmask, lvt);
     const bool last = t == T - 1;
     const size_t slot = hist ? (size_t)(t + 1) : 1;
     float* no = nodes_all + slot * nodes_sz + (size_t)b * N * F;
     float* ao = adj_all + slot * adj_sz + (size_t)b * N * N;
-    float* a1g = agg1_all ? agg1_all + (size_t)t * nodes_sz + (size_t)b * N * F : nullptr;
-    float* h1g = h1_all ? h1_all + ((size_t)t * B + b) * N * H1 : nullptr;
 #pragma unroll
-    for (int R = 0; R < NT; ++R) {
-      const bool lv = lvt[R];
-      if (last || (hist && lv)) {   // fire-and-forget stores: 8 rows of the tile per wave
+    for (int R = 0; R < NT; ++R)
+      if (last || (hist && lvt[R])) {   // 8 rows of the tile per wave
         const int row8 = R * 32 + wave * 8;
 #pragma unroll
         for (int i = 0; i < FP / 32; ++i) {
@@ -276,123 +254,11 @@ __global__ __launch_bounds__(256) void k_rollout_fwd(
               make_float4(s[0], s[1], s[2], s[3]);
         }
       }
-      if (lv) {   // layer 1 aggregation of this tile's rows, zero tiles skipped
-#pragma unroll
-        for (int bi = 0; bi < NCT; ++bi) {
-          const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, c0 = (blk >> 1) * 16;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int tt = 0; tt < NT; ++tt)
-            if ((nzmask >> (R * 4 + tt)) & 1u)
-              mma16<32>(acc, sAdj + (tt * NP + r0) * 33, 33, sX + (tt * 32) * FS + c0, FS, m16, kq);
-          float* d = sAH + (r0 + 4 * kq) * AS + c0 + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) d[r * AS] = acc[r];
-          if (a1g) {
-            float* g = a1g + (r0 + 4 * kq) * F + c0 + m16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r * F] = acc[r];
-          }
-        }
-      }
-    }
     RSTAMP(2);
-    __syncthreads();   // every wave's agg blocks are in LDS
-    RSTAMP(3);
-    f32x4 o[NT][NHT];
-#pragma unroll
-    for (int R = 0; R < NT; ++R) {
-#pragma unroll
-      for (int bi = 0; bi < NHT; ++bi) o[R][bi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (lvt[R]) {
-#pragma unroll
-        for (int bi = 0; bi < NHT; ++bi) {
-          const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          mma16<FP>(acc, sAH + r0 * AS, AS, sW1 + h0, HS, m16, kq);
-          mma16<FP>(acc, sX + r0 * FS, FS, sW1 + FP * HS + h0, HS, m16, kq);
-          o[R][bi] = acc;
-        }
-      }
-    }
-    RSTAMP(4);
-    __syncthreads();   // nobody reads agg any more: h1 takes its place
-    RSTAMP(5);
-#pragma unroll
-    for (int R = 0; R < NT; ++R)
-      if (lvt[R]) {
-#pragma unroll
-        for (int bi = 0; bi < NHT; ++bi) {
-          const int blk = wave + 4 * bi, r0 = R * 32 + (blk & 1) * 16, h0 = (blk >> 1) * 16;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gcm_act_sel(o[R][bi][r] + bias1[bi], act1_v);
-          float* d = sAH + (r0 + 4 * kq) * AS + h0 + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) d[r * AS] = v[r];
-          if (h1g) {
-            float* g = h1g + (r0 + 4 * kq) * H1 + h0 + m16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r * H1] = v[r];
-          }
-        }
-      }
-    RSTAMP(6);
-    __syncthreads();
-    RSTAMP(7);
-    // ---- layer 2 on row `cur`: wave 0 alone, no workgroup barriers ------------------------------
-    if (wave == 0) {
-      constexpr int PA = 64 / HP;            // lanes per h (1 or 2): split of the j range
-      constexpr int JN = 32 / PA;
-      const int h = lane & (HP - 1), part = lane / HP;
-      float s = 0.f;
-#pragma unroll
-      for (int R = 0; R < NT; ++R)
-        if (lvt[R]) {
-          const float* arow = sAdj + (R * NP + cur) * 33 + part;    // adj[cur][R*32 + part + PA*i]
-          const float* hcol = sAH + (R * 32 + part) * AS + h;       // h1[R*32 + part + PA*i][h]
-          float av[JN], hv[JN];
-#pragma unroll
-          for (int i = 0; i < JN; ++i) {
-            av[i] = arow[PA * i];
-            hv[i] = hcol[PA * i * AS];
-          }
-#pragma unroll
-          for (int i = 0; i < JN; ++i) s = fmaf(av[i], hv[i], s);
-        }
-      if (PA == 2) s += __shfl_xor(s, 32);
-      const float hc = sAH[cur * AS + h];
-      if (part == 0) {
-        sVv[h] = s;              // v[0:HP)   = agg2
-        sVv[HP + h] = hc;        // v[HP:2HP) = h1[cur]
-        if (agg2_all) agg2_all[((size_t)t * B + b) * H1 + h] = s;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // pre2[o] = b2[o] + sum_k W2c[o][k] * v[k], K = 2*HP
-      constexpr int PB = 64 / H2P;           // lanes per output (1 or 2): split of K
-      constexpr int KC = 2 * HP / PB;
-      const int o2 = lane & (H2P - 1), kp = lane / H2P;
-      const float* wrow = sW2 + o2 * W2S + kp * KC;
-      const float* vv = sVv + kp * KC;
-      float a = 0.f;
-#pragma unroll
-      for (int k0 = 0; k0 < KC; k0 += 16) {
-        float wv[16], xv[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          wv[k] = wrow[k0 + k];
-          xv[k] = vv[k0 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a = fmaf(wv[k], xv[k], a);
-      }
-      if (PB == 2) a += __shfl_xor(a, 32);
-      const float v = gcm_act_sel(a + bias2, act2_v);
-      if (lane < H2) mx_all[((size_t)t * B + b) * H2 + lane] = v;
-      const bool any_bad = __any(lane < H2 && !isfinite(v));
-      if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
-    }
+    G.run(cur, nzmask, lvt, agg1_all ? agg1_all + (size_t)t * nodes_sz + (size_t)b * N * F : nullptr,
+          h1_all ? h1_all + ((size_t)t * B + b) * N * H1 : nullptr,
+          agg2_all ? agg2_all + ((size_t)t * B + b) * H1 : nullptr, mx_all + ((size_t)t * B + b) * H2,
+          flags);
     n = cur + 1;
     RSTAMP(8);
     __syncthreads();   // the next step rewrites sX / sAdj / sAH / sV
