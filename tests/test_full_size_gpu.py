@@ -1,0 +1,210 @@
+"""BASELINE.json's full sizes through size-independent properties (the CPU oracle cannot run these
+configurations in test time as a whole):
+
+* closed forms the domain offers (TemporalBackedge adjacency is a band, the node matrix is the
+  last N observations, num_nodes saturates at N) - bit exact;
+* batch independence: per-graph selectors never mix graphs, so (a) permuting the batch permutes the
+  result bit for bit and (b) the oracle run on a SLICE of the batch must reproduce that slice,
+  gradients included (the loss is restricted to the slice);
+* linearity of the backward pass in the incoming gradient;
+* equality of the entry points (per-step loop, rollout(), inference rollout; sparse one-shot vs
+  the dense path on the same data).
+
+Needs an MI355X."""
+import pytest
+import torch
+
+from oracle import dense as od, sparse as osp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# cfg2 (BASELINE.json configs[1], the bench workload)
+B2, N2, F2, H2, HOPS = 256, 128, 32, 32, [1, 2, 4]
+
+
+def _dense_pair(F, H, N, selector_dev, seed=0):
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    torch.manual_seed(seed)
+    ref = od.canonical_gnn(F, H)
+    g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+                                               (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()])
+    g.load_state_dict(ref.state_dict())
+    g = g.to(DEV)
+    return DenseGCM(g, edge_selectors=selector_dev, graph_size=N), g, ref
+
+
+def _loop(mem, obs):
+    hid, outs = None, []
+    for t in range(obs.shape[0]):
+        mx, hid = mem(obs[t], hid)
+        outs.append(mx)
+    return torch.stack(outs), hid
+
+
+def _band(N, hops, rows):
+    i = torch.arange(N)[:, None]
+    j = torch.arange(N)[None, :]
+    a = torch.zeros(N, N)
+    for h in hops:
+        a += ((i - j) == h).float()
+    a[rows:] = 0
+    return a
+
+
+@pytest.mark.parametrize("T", [128, 200])
+def test_cfg2_closed_forms_and_entry_points(T):
+    """T = 128 fills the graph exactly; T = 200 spends 72 steps in steady-state overflow."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, _ = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    torch.manual_seed(1)
+    obs = torch.rand(T, B2, F2, device=DEV)
+    out_s, hid_s = _loop(mem, obs)
+    out_r, hid_r = mem.rollout(obs)
+    with torch.no_grad():
+        out_i, hid_i = mem.rollout(obs)
+    mem.check_flags()
+    # closed forms, bit exact
+    nodes, adj, _, count = hid_s
+    assert torch.equal(count.cpu(), torch.full((B2,), min(T, N2)))
+    assert torch.equal(nodes, obs[T - N2:].transpose(0, 1))      # the last N observations, in order
+    band = _band(N2, HOPS, min(T, N2)).to(DEV)
+    assert torch.equal(adj, band.expand(B2, N2, N2))
+    # the three entry points agree: state bit exact, beliefs to fp32 summation order
+    for hid in (hid_r, hid_i):
+        assert torch.equal(hid[0], nodes) and torch.equal(hid[1], adj) and torch.equal(hid[3], count)
+    torch.testing.assert_close(out_r, out_s, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out_i, out_s, rtol=1e-5, atol=1e-6)
+    # a checksum of checksums that any dropped / duplicated step would move
+    assert torch.isfinite(out_s).all() and float(out_s.detach().abs().sum()) > 0
+
+
+def test_cfg2_batch_permutation_is_bit_exact():
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, _ = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    torch.manual_seed(2)
+    T = 140
+    obs = torch.rand(T, B2, F2, device=DEV)
+    perm = torch.randperm(B2, device=DEV)
+    with torch.no_grad():
+        out_a, hid_a = _loop(mem, obs)
+        out_b, hid_b = _loop(mem, obs[:, perm])
+        out_c, hid_c = mem.rollout(obs[:, perm])
+    assert torch.equal(out_a[:, perm], out_b)
+    assert torch.equal(hid_a[0][perm], hid_b[0]) and torch.equal(hid_a[1][perm], hid_b[1])
+    assert torch.equal(hid_a[1][perm], hid_c[1])
+    torch.testing.assert_close(out_a[:, perm], out_c, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("entry", ["step", "rollout"])
+def test_cfg2_slice_matches_oracle(entry):
+    """Oracle on 3 of the 256 graphs for the full T (overflow included); loss restricted to them."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, ref = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    torch.manual_seed(3)
+    T, pick = 150, [0, 117, 255]
+    obs = torch.rand(T, B2, F2)
+    obs_d = obs.to(DEV).requires_grad_(True)
+    out, hid = _loop(mem, obs_d) if entry == "step" else mem.rollout(obs_d)
+    w = torch.linspace(0.5, 1.5, T * len(pick) * H2).view(T, len(pick), H2)
+    (out[:, pick] * w.to(DEV)).sum().backward()
+    obs_c = obs[:, pick].clone().requires_grad_(True)
+    out_c, hid_c = od.dense_rollout(obs_c, None, ref, graph_size=N2, edge_selectors=od.TemporalBackedge(HOPS))
+    (out_c * w).sum().backward()
+    torch.testing.assert_close(out[:, pick].detach().cpu(), out_c.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(hid[1][pick].cpu(), hid_c[1]) and torch.equal(hid[0][pick].cpu(), hid_c[0])
+    gs = float(obs_c.grad.abs().max())
+    torch.testing.assert_close(obs_d.grad[:, pick].cpu(), obs_c.grad, rtol=1e-4, atol=1e-5 * gs)
+    rest = [b for b in range(B2) if b not in pick]
+    assert float(obs_d.grad[:, rest].abs().max()) == 0.0          # no cross-graph leakage
+    for (k, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()), msg=k)
+
+
+def test_cfg2_backward_is_linear_in_the_incoming_gradient():
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, _ = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    torch.manual_seed(4)
+    T = 136
+    obs = torch.rand(T, B2, F2, device=DEV, requires_grad=True)
+    g1, g2 = torch.randn(T, B2, H2, device=DEV), torch.randn(T, B2, H2, device=DEV)
+    params = list(g.parameters())
+
+    def grads(gm):
+        out, _ = mem.rollout(obs)
+        return torch.autograd.grad(out, [obs] + params, gm)
+
+    ga, gb, gc = grads(g1), grads(g2), grads(2.0 * g1 - 0.5 * g2)
+    for a, b_, c in zip(ga, gb, gc):
+        want = 2.0 * a - 0.5 * b_
+        torch.testing.assert_close(c, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7)
+
+
+def test_cfg3_euclid_full_batch_matches_oracle():
+    """cfg3: EuclideanEdge's cross-batch mean couples all 256 graphs, so the oracle runs the full
+    batch - for a few steps (clustered observations)."""
+    from gcm.edge_selectors.distance import EuclideanEdge
+    B, N, F, H, T = 256, 128, 64, 32, 6
+    mem, g, ref = _dense_pair(F, H, N, EuclideanEdge(2.0), seed=5)
+    gen = torch.Generator().manual_seed(6)
+    centres = 4.0 * torch.randn(3, F, generator=gen)
+    obs = centres[torch.arange(T) % 3][:, None, :] + 0.05 * torch.randn(T, B, F, generator=gen)
+    obs_d = obs.to(DEV).requires_grad_(True)
+    out, hid = _loop(mem, obs_d)
+    out.mean().backward()
+    obs_c = obs.clone().requires_grad_(True)
+    out_c, hid_c = od.dense_rollout(obs_c, None, ref, graph_size=N, edge_selectors=od.EuclideanEdge(2.0))
+    out_c.mean().backward()
+    assert torch.equal(hid[1].cpu(), hid_c[1])                    # edge decisions: bit exact
+    assert float(hid_c[1].sum()) > 0
+    torch.testing.assert_close(out.detach().cpu(), out_c.detach(), rtol=1e-5, atol=1e-6)
+    gs = float(obs_c.grad.abs().max())
+    torch.testing.assert_close(obs_d.grad.cpu(), obs_c.grad, rtol=1e-4, atol=1e-5 * gs)
+
+
+def test_cfg4_sparse_full_size_one_shot():
+    """cfg4: SparseGCM + TemporalEdge([1]), B = 512 graphs of 512 nodes in one call.
+    Closed forms (COO = the chain i -> i-1 per graph, T = taus), oracle on a slice of graphs,
+    one-shot == two half calls."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    B, N, F, H = 512, 512, 32, 32
+    torch.manual_seed(7)
+    ref = osp.canonical_gnn(F, H)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(H, H), "x, edges, weights -> x"), torch.nn.Tanh()])
+    g.load_state_dict(ref.state_dict())
+    g = g.to(DEV)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1]), graph_size=N)
+    x = torch.rand(B, N, F)
+    taus = torch.full((B,), N, dtype=torch.long)
+    x_d = x.to(DEV).requires_grad_(True)
+    out, hid = mem(x_d, taus.to(DEV), None)
+    pick = [0, 300, 511]
+    w = torch.linspace(0.5, 1.5, len(pick) * N * H).view(len(pick), N, H)
+    (out[pick] * w.to(DEV)).sum().backward()
+    # closed forms
+    idx = hid[1].coalesce().indices().cpu()
+    assert idx.shape[1] == B * (N - 1)
+    want_b = torch.arange(B).repeat_interleave(N - 1)
+    want_sink = torch.arange(1, N).repeat(B)
+    assert torch.equal(idx[0], want_b) and torch.equal(idx[1], want_sink) and torch.equal(idx[2], want_sink - 1)
+    assert torch.equal(hid[2].cpu(), taus) and torch.equal(hid[0], x_d.detach())
+    # oracle on the slice
+    x_c = x[pick].clone().requires_grad_(True)
+    out_c, _ = osp.sparse_step(x_c, taus[pick], None, ref, graph_size=N, edge_selectors=osp.TemporalEdge([1]))
+    (out_c * w).sum().backward()
+    torch.testing.assert_close(out[pick].detach().cpu(), out_c.detach(), rtol=1e-5, atol=1e-5)
+    gs = float(x_c.grad.abs().max())
+    torch.testing.assert_close(x_d.grad[pick].cpu(), x_c.grad, rtol=1e-4, atol=1e-5 * gs)
+    for (k, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
+    # one call == two half calls
+    with torch.no_grad():
+        half = torch.full((B,), N // 2, dtype=torch.long, device=DEV)
+        o1, h1 = mem(x_d[:, : N // 2].detach(), half, None)
+        o2, h2 = mem(x_d[:, N // 2:].detach(), half, h1)
+    torch.testing.assert_close(torch.cat([o1, o2], 1), out.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(h2[1].coalesce().indices(), hid[1].coalesce().indices())
