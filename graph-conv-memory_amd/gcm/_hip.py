@@ -69,6 +69,8 @@ PROTOTYPES = {
     "gcm_dense_gnn2_param_count": (_Z, [_I, _I, _I]),
     "gcm_dense_gnn2_row_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 5 + [_I] * 5 + [_P]),
     "gcm_dense_gnn2_row_bwd": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] + [_P] * 7 + [_I] * 6 + [_P]),
+    "gcm_skinny_wgrad_workspace_bytes": (_Z, [_I] * 3),
+    "gcm_skinny_wgrad": (_I, [_P] * 4 + [_Z] + [_I] * 3 + [_P]),
     "gcm_sum_slabs": (_I, [_P, _I, _I, _P, _P]),
     "gcm_sum_slabs_acc": (_I, [_P, _I, _I, _P, _P, _P]),
     "gcm_dense_step_fused_fwd": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] + [_P] * 3 + [_I] + [_P] * 5

@@ -837,6 +837,43 @@ def fused_rollout(obs, nodes0, packed, adj0, num_nodes0, flags, cfg):
     return _FusedRollout.apply(obs, nodes0, packed, adj0, num_nodes0, flags, cfg)
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    """y = x W^T + b for many rows and narrow layers (the LearnedEdge edge network): forward and
+    dX are library GEMMs, the weight gradient - a [O x M] x [M x I] product with M = B*N rows, which
+    a library GEMM runs on one or two workgroups - is gcm_skinny_wgrad (rows split over the grid)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad
+        gx = g.matmul(weight) if need_x else None
+        gw = gb = None
+        if need_w or need_b:
+            O, I = weight.shape
+            g2 = g.reshape(-1, O).contiguous()
+            x2 = x.reshape(-1, I).contiguous()
+            M = g2.shape[0]
+            lib = _hip.lib()
+            ws_bytes = lib.gcm_skinny_wgrad_workspace_bytes(M, O, I)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            out = torch.empty(O * I + O, device=g.device, dtype=_f32)
+            _call("gcm_skinny_wgrad", _hip.ptr(g2), _hip.ptr(x2), _hip.ptr(out), _hip.ptr(ws), ws_bytes,
+                  M, O, I, _hip.stream())
+            gw = out[:O * I].view(O, I) if need_w else None
+            gb = out[O * I:] if (need_b and ctx.has_bias) else None
+        return gx, gw, gb
+
+
+def skinny_linear(x, weight, bias):
+    return _SkinnyLinear.apply(x, weight, bias)
+
+
 # ===========================================================================
 # SURVEY 8(f) "next" rows: positional encoding, packed sparse hidden state
 # ===========================================================================

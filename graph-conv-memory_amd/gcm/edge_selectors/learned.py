@@ -29,15 +29,18 @@ class LearnedEdge(torch.nn.Module):
         self.noise_fn = None
 
     def build_edge_network(self, input_size: int) -> torch.nn.Sequential:
-        """learned.py:38-51: (i || j) -> logit(edge(i, j))."""
+        """learned.py:38-51: (i || j) -> logit(edge(i, j)).  The linears are nn.Linear subclasses
+        (same parameters and state_dict) whose weight gradient over the B*N candidate rows is a
+        row-split kernel instead of a one-workgroup library GEMM."""
+        from ..nn import SkinnyLinear
         return torch.nn.Sequential(
-            torch.nn.Linear(2 * input_size, input_size),
+            SkinnyLinear(2 * input_size, input_size),
             torch.nn.ReLU(),
             torch.nn.LayerNorm(input_size),
-            torch.nn.Linear(input_size, input_size),
+            SkinnyLinear(input_size, input_size),
             torch.nn.ReLU(),
             torch.nn.LayerNorm(input_size),
-            torch.nn.Linear(input_size, 1),
+            SkinnyLinear(input_size, 1),
         )
 
     def compute_new_adj(self, nodes, num_nodes, adj, B):

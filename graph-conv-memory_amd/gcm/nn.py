@@ -11,6 +11,23 @@ from . import _hip, _ops
 _FUSABLE = {torch.nn.Tanh: _hip.ACT_TANH, torch.nn.ReLU: _hip.ACT_RELU}
 
 
+class SkinnyLinear(torch.nn.Linear):
+    """torch.nn.Linear (same parameters, same state_dict keys) for inputs with very many rows and
+    <= 64 features in and out - the layers of LearnedEdge's default edge network (learned.py:38-51).
+    Forward and input gradient are the library GEMMs; the weight gradient runs as the row-split
+    kernel gcm_skinny_wgrad.  Anything else (CPU tensors, wide layers, few rows, other dtypes)
+    behaves exactly like nn.Linear."""
+
+    MIN_ROWS = 2048
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and self.in_features <= 64 and self.out_features <= 64
+                and x.numel() // self.in_features >= self.MIN_ROWS and torch.is_grad_enabled()
+                and (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad))):
+            return _ops.skinny_linear(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class DenseGraphConv(torch.nn.Module):
     """out = lin_rel(adj @ x) + lin_root(x), adj [B,N,N] float, x [B,N,F].
     Runs as one fused fp32-MFMA kernel (csrc/graphconv.hip)."""

@@ -48,15 +48,17 @@ class LearnedEdge(torch.nn.Module):
         self.stats[f"gnorm_{p_name}"] = grad.norm().detach().item()
 
     def build_edge_network(self, input_size: int) -> torch.nn.Sequential:
-        """learned.py:69-88: (i || j) -> logit(edge(i, j)), orthogonal init."""
+        """learned.py:69-88: (i || j) -> logit(edge(i, j)), orthogonal init.  nn.Linear subclasses
+        with a row-split weight-gradient kernel (the candidate list has O(sum T^2) rows)."""
+        from ..nn import SkinnyLinear
         m = torch.nn.Sequential(
-            torch.nn.Linear(2 * input_size, input_size),
+            SkinnyLinear(2 * input_size, input_size),
             torch.nn.ReLU(),
             torch.nn.LayerNorm(input_size),
-            torch.nn.Linear(input_size, input_size),
+            SkinnyLinear(input_size, input_size),
             torch.nn.ReLU(),
             torch.nn.LayerNorm(input_size),
-            torch.nn.Linear(input_size, 1),
+            SkinnyLinear(input_size, 1),
         )
         m.apply(self.init_weights)
         if self.store_grads:

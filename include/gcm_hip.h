@@ -227,6 +227,14 @@ int gcm_learned_pairs_fwd(const float* nodes, const int64_t* cur_idx, float* pai
 int gcm_learned_pairs_bwd(const float* g_pairs, const int64_t* cur_idx, float* g_nodes, int B,
                           int N, int F, gcm_stream_t stream);
 
+/* Weight gradient of a skinny Linear (the LearnedEdge edge network, learned.py:38-51, scores B*N
+ * candidate rows with <= 64-wide linears): dw_db = dW [O,I] | db [O] with dW = dY^T X, db = column
+ * sums of dY; dY [M,O], X [M,I], O, I <= 64 (GCM_EUNSUPPORTED otherwise).  Rows are split over the
+ * grid, partial slabs are summed in a fixed order. */
+size_t gcm_skinny_wgrad_workspace_bytes(int M, int O, int I);
+int gcm_skinny_wgrad(const float* dy, const float* x, float* dw_db, void* workspace,
+                     size_t workspace_bytes, int M, int O, int I, gcm_stream_t stream);
+
 /* learned.py:76-111 (non-deterministic branch), fused: per graph soft = softmax_j<cur(logits +
  * noise) (gumbel_softmax tau=1 with caller-supplied gumbel noise), edge_j = soft_j > cutoff
  * (STE forward, util.py:9-18), adj[b, cur, j] = (edge_j + adj[b, cur, j] > 0) for j < cur.

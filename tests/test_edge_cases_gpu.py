@@ -252,3 +252,29 @@ def test_parameter_gradient_chain_survives_detach_and_restarts():
     out2, _ = _loop(mem, obs[5:9], hid)
     ref2, _ = mem.rollout(obs[5:9], tuple(h.detach() for h in hid))
     torch.testing.assert_close(out2, ref2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,I,O,bias", [(32768, 64, 32, True), (5000, 32, 32, True), (2049, 32, 1, True),
+                                        (4097, 33, 17, False), (100, 64, 32, True)])
+def test_skinny_linear_matches_nn_linear(M, I, O, bias):
+    """gcm.nn.SkinnyLinear == nn.Linear: forward bit exact (same library GEMM), input gradient
+    bit exact, weight / bias gradients to fp32 summation order (rows split over the grid).
+    M = 100 takes nn.Linear's own path."""
+    from gcm import nn as G
+    torch.manual_seed(M)
+    ref = torch.nn.Linear(I, O, bias=bias).to(DEV)
+    lin = G.SkinnyLinear(I, O, bias=bias).to(DEV)
+    lin.load_state_dict(ref.state_dict())
+    x = torch.randn(M, I, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = lin(xa.view(M // 1, I)), ref(xb)
+    assert torch.equal(ya, yb)
+    gy = torch.randn(M, O, device=DEV)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.equal(xa.grad, xb.grad)
+    scale = float(ref.weight.grad.abs().max())
+    torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5 * scale)
+    if bias:
+        torch.testing.assert_close(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
+    assert set(lin.state_dict()) == set(ref.state_dict())
