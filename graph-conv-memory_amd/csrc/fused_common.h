@@ -190,47 +190,64 @@ struct AdjRows {
         buf[t * 4 + q] = v;
       }
   }
-  // selector writes on the freshly advanced adjacency, in registers (cur = new node's row)
-  __device__ __forceinline__ void apply_edits(const Edits& E, int cur, int r_base, int lane) {
+  // selector writes on the freshly advanced adjacency, in registers (cur = new node's row).
+  // lane_hop / lane_dir: lane i < E.n_hops holds hops[i] / dir[i] (read ONCE from the kernel
+  // arguments by the caller): indexing E.hops[i] inside the tile loops made hipcc re-load it from
+  // the kernarg segment for every (tile, row group, hop) - ~100 scalar loads with their waits,
+  // 6.5 us of a 15 us kernel.
+  __device__ __forceinline__ void apply_edits(const Edits& E, int lane_hop, int lane_dir, int cur,
+                                              int r_base, int lane) {
+    const int n_hops = E.n_hops;
     // wave-uniform early out: does any edit touch this wave's 32 rows?
     bool touched = (cur >> 5) == (r_base >> 5);
-    for (int i = 0; i < E.n_hops; ++i)
-      touched |= (E.dir[i] & GCM_DIR_BACKWARD) && cur >= E.hops[i] &&
-                 ((cur - E.hops[i]) >> 5) == (r_base >> 5);
+    for (int i = 0; i < n_hops; ++i) {
+      const int h = __builtin_amdgcn_readlane(lane_hop, i), d = __builtin_amdgcn_readlane(lane_dir, i);
+      touched |= (d & GCM_DIR_BACKWARD) && cur >= h && ((cur - h) >> 5) == (r_base >> 5);
+    }
     touched |= E.dense && (r_base < cur);
     if (!touched) return;
+    for (int i = 0; i < n_hops; ++i) {
+      const int h = __builtin_amdgcn_readlane(lane_hop, i), d = __builtin_amdgcn_readlane(lane_dir, i);
+      if (h < 0 || cur < h) continue;   // uniform
+      const int past = cur - h;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = r_base + (lane >> 3) + 8 * q, c = t * 32 + (lane & 7) * 4;
-        float4 v = buf[t * 4 + q];
-        // component k of v <- 1 (selects, no runtime-indexed register access)
-        auto set1 = [&v](int k) {
+        for (int q = 0; q < 4; ++q) {
+          const int r = r_base + (lane >> 3) + 8 * q, c = t * 32 + (lane & 7) * 4;
+          float4 v = buf[t * 4 + q];
+          int k = -1;   // component of v that becomes 1 (selects, no runtime-indexed registers)
+          if ((d & GCM_DIR_FORWARD) && r == cur) k = past - c;
+          if ((d & GCM_DIR_BACKWARD) && r == past) k = cur - c;
           v.x = k == 0 ? 1.f : v.x;
           v.y = k == 1 ? 1.f : v.y;
           v.z = k == 2 ? 1.f : v.z;
           v.w = k == 3 ? 1.f : v.w;
-        };
-        for (int i = 0; i < E.n_hops; ++i) {
-          const int h = E.hops[i];
-          if (h < 0 || cur < h) continue;   // uniform
-          const int past = cur - h;
-          if ((E.dir[i] & GCM_DIR_FORWARD) && r == cur) set1(past - c);
-          if ((E.dir[i] & GCM_DIR_BACKWARD) && r == past) set1(cur - c);
+          buf[t * 4 + q] = v;
         }
-        if (E.dense) {
+    }
+    if (E.dense) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = r_base + (lane >> 3) + 8 * q, c = t * 32 + (lane & 7) * 4;
+          float4 v = buf[t * 4 + q];
           if (r == cur) {   // row cur: columns 0..cur (self edge included)
             v.x = c <= cur ? 1.f : v.x;
             v.y = c + 1 <= cur ? 1.f : v.y;
             v.z = c + 2 <= cur ? 1.f : v.z;
             v.w = c + 3 <= cur ? 1.f : v.w;
           } else if (r < cur) {   // column cur: rows 0..cur-1
-            set1(cur - c);
+            const int k = cur - c;
+            v.x = k == 0 ? 1.f : v.x;
+            v.y = k == 1 ? 1.f : v.y;
+            v.z = k == 2 ? 1.f : v.z;
+            v.w = k == 3 ? 1.f : v.w;
           }
+          buf[t * 4 + q] = v;
         }
-        buf[t * 4 + q] = v;
-      }
+    }
   }
   // write this wave's rows to the new adjacency in HBM (16-byte stores)
   __device__ __forceinline__ void store_global(float* __restrict__ ag, int N, int r_base,

@@ -72,6 +72,11 @@ __device__ __forceinline__ void gnn2_row_fwd_body(
   STAMP(0);
   // ---- issue every load: x, layer-1 weights, this wave's adjacency rows, layer-2 weights ----
   const int r_base = wave * 32;
+  int lane_hop = -1, lane_dir = 0;   // lane i < n_hops: the i-th folded temporal edit
+  if (ADV && lane < A.edits.n_hops) {
+    lane_hop = A.edits.hops[lane & 15];
+    lane_dir = A.edits.dir[lane & 15];
+  }
   const bool wave_live = wave < NT;
   Stage<NP, FP, false, EXACT> st_x;
   Stage<HP, FP, true, EXACT> st_wr, st_wo;
@@ -118,7 +123,7 @@ __device__ __forceinline__ void gnn2_row_fwd_body(
 
   if (wave_live) {
     if (ADV) {
-      rows.apply_edits(A.edits, cur, r_base, lane);
+      rows.apply_edits(A.edits, lane_hop, lane_dir, cur, r_base, lane);
       rows.store_global(A.adj_out + (size_t)b * N * N, N, r_base, lane);
     }
     // ---- layer 1, aggregation: agg = adj[rows,:] @ x, K tile by K tile ------------------
@@ -298,8 +303,14 @@ __global__ __launch_bounds__(256) void k_step_fwd_live(
   float* sVv = sV + 256;
   unsigned* sMask = reinterpret_cast<unsigned*>(sV);   // word R: non-zero col tiles of row tile R
 
+  STAMP(0);
   // ---- every load, then the state copy ------------------------------------------------------
   const int r_base = wave * 32;
+  int lane_hop = -1, lane_dir = 0;   // lane i < n_hops: the i-th folded temporal edit
+  if (lane < A.edits.n_hops) {
+    lane_hop = A.edits.hops[lane & 15];
+    lane_dir = A.edits.dir[lane & 15];
+  }
   const bool wave_rows = wave < NT;
   Stage<NP, FP, false, true> st_x;
   Stage<HP, FP, true, true> st_wr, st_wo;
@@ -325,20 +336,23 @@ __global__ __launch_bounds__(256) void k_step_fwd_live(
   LiveGnn<NT, NCT, NHT, N2T> G;
   G.sAdj = sAdj; G.sX = sX; G.sAH = sAH; G.sW1 = sW1; G.sW2 = sW2; G.sVv = sVv; G.sMask = sMask;
   G.init_lane(P, tid);
+  STAMP(1);
   {
     float* no = A.nodes_out + (size_t)b * N * F;
 #pragma unroll
     for (int i = 0; i < st_x.PER; ++i) no[tid + 256 * i] = st_x.v[i];
   }
+  STAMP(2);
   st_x.store(sX, FS, tid);
   st_wr.store(sW1, HS, tid);
   st_wo.store(sW1 + FP * HS, HS, tid);
   st_w2r.store(sW2, W2S, tid);
   st_w2o.store(sW2 + HP, W2S, tid);
+  STAMP(3);
   {
     unsigned bits = 0;
     if (wave_rows) {
-      rows.apply_edits(A.edits, cur, r_base, lane);
+      rows.apply_edits(A.edits, lane_hop, lane_dir, cur, r_base, lane);
       rows.store_global(A.adj_out + (size_t)b * N * N, N, r_base, lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -348,15 +362,19 @@ __global__ __launch_bounds__(256) void k_step_fwd_live(
     }
     if (lane == 0) sMask[wave] = bits;
   }
+  STAMP(4);
   __syncthreads();
 
+  STAMP(5);
   // ---- the live tiles (live_gnn.h) ------------------------------------------------------------
   unsigned nzmask;
   bool lvt[NT];
   G.flags(cur, nzmask, lvt);
+  STAMP(6);
   G.run(cur, nzmask, lvt, agg1_out ? agg1_out + (size_t)b * N * F : nullptr,
         h1_out ? h1_out + (size_t)b * N * H1 : nullptr,
         agg2_out ? agg2_out + (size_t)b * H1 : nullptr, mx_out + (size_t)b * H2, flags);
+  STAMP(7);
 }
 
 template <int NT, int NCT, int NHT, int N2T>
