@@ -67,8 +67,9 @@ void check(int rc, const char* what) {
 }
 
 // float offsets inside the forward buffer: nodes | adj | mx | h1 | agg1 | agg2 (64-float aligned)
+// ... then cur | count_out as 2*B int64 (same allocation: one caching-allocator round trip per step)
 struct Layout {
-  int64_t total, o_adj, o_mx, o_h1, o_agg1, o_agg2;
+  int64_t total, o_adj, o_mx, o_h1, o_agg1, o_agg2, o_idx;
   Layout(int64_t B, int64_t N, int64_t F, int64_t H1, int64_t H2, bool need_bwd) {
     const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * N * N), n_mx = pad64(B * H2);
     const int64_t n_h1 = pad64(B * N * H1), n_agg2 = pad64(B * H1);
@@ -77,7 +78,8 @@ struct Layout {
     o_h1 = o_mx + n_mx;
     o_agg1 = o_h1 + n_h1;
     o_agg2 = o_agg1 + n_nodes;
-    total = need_bwd ? o_agg2 + n_agg2 : o_h1;
+    o_idx = need_bwd ? o_agg2 + n_agg2 : o_h1;   // 64-float aligned => 8-byte aligned
+    total = o_idx + pad64(4 * B);
   }
 };
 
@@ -95,7 +97,7 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
     const bool need_bwd = need_bwd_ != 0;   // decided by the caller: grad mode is off in here
     const Layout L(B, N, F, H1, H2, need_bwd);
     at::Tensor buf = at::empty({L.total}, obs.options());
-    at::Tensor ibuf = at::empty({2, B}, count_in.options());
+    at::Tensor ibuf = buf.narrow(0, L.o_idx, 4 * B).view(at::kLong).view({2, B});
     float* base = buf.data_ptr<float>();
     int64_t* ib = ibuf.data_ptr<int64_t>();
     size_t ws_bytes = 0;
@@ -114,7 +116,7 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
     at::Tensor mx = buf.narrow(0, L.o_mx, B * H2).view({B, H2});
     at::Tensor cur = ibuf.select(0, 0), count_out = ibuf.select(0, 1);
     if (need_bwd) {
-      ctx->save_for_backward({buf, ibuf, count_in, packed});
+      ctx->save_for_backward({buf, count_in, packed});
       auto& sd = ctx->saved_data;
       sd["dims"] = std::vector<int64_t>{B, N, F, H1, H2, cfg->P, cfg->has_bias, cfg->act1,
                                         cfg->act2, stream};
@@ -130,7 +132,7 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
-    const at::Tensor &buf = saved[0], &ibuf = saved[1], &count_in = saved[2], &packed = saved[3];
+    const at::Tensor &buf = saved[0], &count_in = saved[1], &packed = saved[2];
     const auto d = ctx->saved_data["dims"].toIntVector();
     const int64_t B = d[0], N = d[1], F = d[2], H1 = d[3], H2 = d[4], P = d[5];
     const int has_bias = (int)d[6], act1 = (int)d[7], act2 = (int)d[8];
@@ -149,7 +151,7 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
     const float* base = buf.data_ptr<float>();
     const int rc = gcm_dense_step_bwd_acc(
         g_mx.data_ptr<float>(), g_no.defined() ? g_no.data_ptr<float>() : nullptr, base,
-        base + L.o_adj, ibuf.data_ptr<int64_t>(), count_in.data_ptr<int64_t>(),
+        base + L.o_adj, reinterpret_cast<const int64_t*>(base + L.o_idx), count_in.data_ptr<int64_t>(),
         packed.data_ptr<float>(), has_bias, act1, act2, base + L.o_mx, base + L.o_h1,
         base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes,
         g_par.defined() ? g_par.data_ptr<float>() : nullptr, ob + n_nodes + n_obs,

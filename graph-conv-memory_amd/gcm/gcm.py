@@ -106,6 +106,7 @@ class DenseGCM(torch.nn.Module):
         # kernels + ONE fused GNN kernel under ONE autograd node (csrc/fused.hip)
         self.fused = fused
         self._plan_cache = None
+        self._token = object()   # identifies hidden states produced by this module (_gcm_link)
         self._cfg_cache = {}
         self._cfg_last = None
         self._packed_cache = None
@@ -291,18 +292,21 @@ class DenseGCM(torch.nn.Module):
                               [(t, t._version if t is not None else 0) for t in tensors])
         return packed
 
-    def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags):
+    def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags, link=None):
         root = self._packed_params(cfg)
         # Steps of one rollout share the parameter vector through a chain (each step hands it to
         # the next as an alias), so the backward adds the T parameter gradients inside the step
         # kernels instead of T tiny engine-side sums.  The link travels on the hidden state the
-        # caller passes back; a detached / foreign hidden state simply starts a new chain.
-        chain = getattr(nodes, "_gcm_chain", None)
-        packed = chain[0] if chain is not None and chain[1] is root else root
+        # caller passes back (`_gcm_link`, which also lets the next call skip re-validating a
+        # hidden state this module produced itself); a detached / foreign hidden state simply
+        # starts a new chain.
+        packed = link[4] if link is not None and link[4] is not None and link[5] is root else root
         mx, nodes_out, adj_out, cur, num_nodes_next, packed_out = _ops.fused_step(
             x, nodes, packed, adj, num_nodes, flags, cfg)
-        if packed_out is not None and packed_out.requires_grad:
-            nodes_out._gcm_chain = (packed_out, root)
+        if packed_out is not None and not packed_out.requires_grad:
+            packed_out = None
+        nodes_out._gcm_link = (self._token, adj_out, cfg, flags, packed_out, root, x.shape, weights,
+                               num_nodes_next)
         if self.mutate_num_nodes_on_overflow:
             num_nodes.copy_(cur)
         if self.finite_check != "off":
@@ -343,6 +347,13 @@ class DenseGCM(torch.nn.Module):
         if hidden is None:
             hidden = self.get_initial_hidden_state(x)
         nodes, adj, weights, num_nodes = hidden
+
+        # A hidden state this module returned itself (same node / adjacency tensors, same input
+        # shape): everything checked below held for it by construction.
+        link = getattr(nodes, "_gcm_link", None)
+        if (link is not None and link[0] is self._token and link[1] is adj and link[7] is weights
+                and link[8] is num_nodes and x.shape == link[6] and x.dtype is torch.float32):
+            return self._forward_fused(x, nodes, adj, weights, num_nodes, link[2], link[3], link)
 
         # gcm.py:246-260, as one comparison
         if (x.dtype, nodes.dtype, adj.dtype, weights.dtype, num_nodes.dtype, num_nodes.dim()) != _DTYPES:
