@@ -6,6 +6,15 @@
 //                       dW_root2 [H2*H1] | db2 [H2]
 #include "fused_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps4)
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+// stand-alone diagnostic library: the shape check lives in fused_fwd.hip
+extern "C" int gcm_dense_gnn2_row_supported(int, int, int, int) { return 1; }
+#endif
+
 namespace gcm_fused {
 
 template <int NT, int NCT, int NHT, int N2T, bool EXACT>
@@ -52,6 +61,7 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
   float* sU = sD2 + H2P;                // u = dagg2 | dh1cur            [2*HP]
   int* sFlag = reinterpret_cast<int*>(sU + 2 * HP);   // adj tile (row tile, col tile) non-zero [16]
 
+  STAMP(0);
   // ---- issue every load ----------------------------------------------------------------
   const int r_base = wave * 32;
   const bool wave_live = wave < NT;
@@ -76,11 +86,13 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
   st_wo.load(P.w_root1, H1, F, F, tid);
   if (wave_live) rows.load(ag, N, r_base, lane);
 
+  STAMP(1);
   st_w2r.store(sW2, W2S, tid);
   st_w2o.store(sW2 + HP, W2S, tid);
   if (tid < H2P) sD2[tid] = tid < H2 ? gm * gcm_act_grad(mv, P.act2) : 0.f;
   if (tid < 2 * HP) sVv[tid] = v_in;
   __syncthreads();
+  STAMP(2);
   // ---- u[m] = sum_o W2c[o][m] * d2[o]  (m < HP: dagg2, m >= HP: dh1cur) -------------------
   {
     constexpr int G = 256 / (2 * HP), OC = H2P / G;
@@ -113,6 +125,7 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
     }
     if (tid < H2) sl_b2[tid] = (accumulate ? sl_b2[tid] : 0.f) + sD2[tid];
   }
+  STAMP(3);
   st_h1.store(sG, HS, tid);
   st_wr.store(sW1, FS, tid);
   st_wo.store(sW1 + HP * FS, FS, tid);
@@ -132,6 +145,7 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
     for (int q = 0; q < G; ++q) t += sV[q * 2 * HP + tid];
     sU[tid] = t;
   }
+  STAMP(4);
   // which 32-row tiles can hold a non-zero G1 row: rows j with adj[cur][j] != 0, and row cur
   bool g_live[NT];
 #pragma unroll
@@ -140,20 +154,58 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
     g_live[t] = __any(a != 0.f) || (cur >> 5) == t;
   }
   __syncthreads();
+  STAMP(5);
+  bool my_rows_live = false;   // g_live[wave] without a runtime-indexed register array
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t == wave) my_rows_live = g_live[t];
+  // B(k=row, j=f) operands straight from HBM/L2 (every element is used exactly once); the loads of
+  // job j+1 are issued before job j's cross-wave reduction, job 0's before the G1 phase above
+  auto load_bq = [&](float (&bq)[16], int job) {
+    const int which = job & 1, ct = (job >> 1) % NCT;
+    const float* src = which ? xg : a1g;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = r_base + 2 * s + lh, f = ct * 32 + li;
+      if (EXACT) {
+        bq[s] = src[row * F + f];
+      } else {
+        const float t = src[(row < N ? row : N - 1) * F + (f < F ? f : F - 1)];
+        bq[s] = (row < N && f < F) ? t : 0.f;
+      }
+    }
+  };
+  float bq[16];
+  if (my_rows_live) load_bq(bq, 0);
   // ---- G1[j][h] = (adj[cur][j] * dagg2[h] + [j==cur] dh1cur[h]) * act1'(h1[j][h]), in place --
   {
-    constexpr int PER = NP * HP / 256;
+    // only the live row tiles: the others hold no gradient and nobody reads their sG rows
+    constexpr int PT = 32 * HP / 256;   // elements per thread and row tile
+    const int act1_v = gcm_vgpr(P.act1);
     float part = 0.f;  // column sums of G1 (db1): a thread always handles the same h
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, j = e / HP, h = e % HP;
-      const float a = sAdj[adj_at<NP>(cur, j)];
-      const float d = a * sU[h] + (j == cur ? sU[HP + h] : 0.f);
-      float v = d * gcm_act_grad(sG[j * HS + h], P.act1);
-      if (d == 0.f || !(EXACT || (j < N && h < H1))) v = 0.f;   // also keeps 0 * garbage out
-      sG[j * HS + h] = v;
-      part += v;
-    }
+    for (int t = 0; t < NT; ++t)
+      if (g_live[t]) {   // uniform
+        float av[PT], hv[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {   // every LDS read in flight before the arithmetic
+          const int e = tid + 256 * (t * PT + i), j = e / HP, h = e % HP;
+          av[i] = sAdj[adj_at<NP>(cur, j)];
+          hv[i] = sG[j * HS + h];
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+          const int e = tid + 256 * (t * PT + i), j = e / HP, h = e % HP;
+          const float d = av[i] * sU[h] + (j == cur ? sU[HP + h] : 0.f);
+          const float y = hv[i];
+          const float ga = act1_v == GCM_ACT_TANH ? 1.f - y * y
+                                                  : (act1_v == GCM_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : 1.f);
+          float v = d * ga;
+          if (d == 0.f || !(EXACT || (j < N && h < H1))) v = 0.f;   // also keeps 0 * garbage out
+          sG[j * HS + h] = v;
+          part += v;
+        }
+      }
     sV[tid] = part;  // 256/HP partial sums per h
   }
   __syncthreads();
@@ -165,37 +217,26 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
     sl_b1[tid] = t;
   }
 
+  STAMP(6);
   // ---- layer-1 parameter gradients: [H1 x F] = G1^T (H1 x N) @ {agg1, x} (N x F) ---------
   // every wave contracts over its own 32 rows (skipped when its G1 rows are all zero); the
   // partial tiles meet in LDS.
-  bool my_rows_live = false;   // g_live[wave] without a runtime-indexed register array
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if (t == wave) my_rows_live = g_live[t];
 #pragma unroll 1
   for (int job = 0; job < 2 * NHT * NCT; ++job) {
     const int which = job & 1, ct = (job >> 1) % NCT, ht = (job >> 1) / NCT;
-    const float* src = which ? xg : a1g;
     f32x16 a;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
     if (my_rows_live) {
-      // B(k=row, j=f) straight from HBM/L2: every element is used exactly once
-      float bq[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int row = r_base + 2 * s + lh, f = ct * 32 + li;
-        if (EXACT) {
-          bq[s] = src[row * F + f];
-        } else {
-          const float t = src[(row < N ? row : N - 1) * F + (f < F ? f : F - 1)];
-          bq[s] = (row < N && f < F) ? t : 0.f;
-        }
-      }
       const float* ap = sG + (r_base + lh) * HS + ht * 32 + li;   // A(i=h, k=row)
+      float aq[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) aq[s] = ap[2 * s * HS];
+      __builtin_amdgcn_sched_barrier(0);   // one LDS round trip in front of the MFMA chain
 #pragma unroll
       for (int s = 0; s < 16; ++s)
-        a = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * HS], bq[s], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], bq[s], a, 0, 0, 0);
+      if (job + 1 < 2 * NHT * NCT) load_bq(bq, job + 1);
     }
     float* dst = which ? sl_root1 : sl_rel1;
     float old[4];
@@ -217,6 +258,7 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
     __syncthreads();
   }
 
+  STAMP(7);
   // ---- dAgg1 = G1 @ W_rel1 -> LDS ;  acc = G1 @ W_root1 (root part of dX) -----------------
   f32x16 acc[NCT];
   float gno[NCT][16];
@@ -239,14 +281,15 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
         f32x16 d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[r] = 0.f;
-        mma32(d, sG + r_base * HS, HS, 1, sW1 + c * 32, FS, 1, HP, li, lh);
-        mma32(acc[c], sG + r_base * HS, HS, 1, sW1 + HP * FS + c * 32, FS, 1, HP, li, lh);
+        mma32b<HP>(d, sG + r_base * HS, HS, 1, sW1 + c * 32, FS, 1, li, lh);
+        mma32b<HP>(acc[c], sG + r_base * HS, HS, 1, sW1 + HP * FS + c * 32, FS, 1, li, lh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sD[(r_base + acc_row(r, lh)) * FS + c * 32 + li] = d[r];
       }
     }
   }
   __syncthreads();
+  STAMP(8);
   // ---- dX[i] += sum_k adj[k][i] * dAgg1[k]   (A read down the columns of the adj image) ----
   // K tile kt contributes only when its dAgg rows can be non-zero and adj tile (kt, wave) is
   if (wave_live) {
@@ -255,11 +298,14 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
       if (g_live[kt] && sFlag[kt * 4 + wave]) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
-          mma32(acc[c], sAdj + (wave * NP + kt * 32) * 33, 1, 33, sD + (kt * 32) * FS + c * 32, FS,
-                1, 32, li, lh);
+          mma32b<32>(acc[c], sAdj + (wave * NP + kt * 32) * 33, 1, 33, sD + (kt * 32) * FS + c * 32,
+                     FS, 1, li, lh);
       }
     }
-    // ---- epilogue: add the gradient from later steps, undo insert + roll (gcm.py:262-278) ----
+    STAMP(9);
+    // ---- epilogue: add the gradient from later steps, undo insert + roll (gcm.py:262-278);
+    // selects instead of a three-way branch per element ------------------------------------------
+    const int sh = wrap ? 1 : 0;
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -267,17 +313,14 @@ __global__ __launch_bounds__(256) void k_gnn2_row_bwd(
         const int row = r_base + acc_row(r, lh), col = c * 32 + li;
         if (EXACT || (row < N && col < F)) {
           const float v = acc[c][r] + gno[c][r];
-          if (row == cur) {
-            g_obs[(size_t)b * F + col] = v;     // the inserted row belongs to the observation
-            if (!wrap) gin[row * F + col] = 0.f;
-          } else if (!wrap) {
-            gin[row * F + col] = v;
-          } else {
-            gin[(row + 1) * F + col] = v;       // out[r] = in[r+1]
-          }
+          const bool is_cur = row == cur;
+          if (is_cur) g_obs[(size_t)b * F + col] = v;   // the inserted row belongs to the observation
+          const int dst = row + sh;                      // out[r] = in[r+1] on overflow
+          if (dst < N) gin[dst * F + col] = is_cur ? 0.f : v;
         }
       }
   }
+  STAMP(10);
   if (wrap)  // in[0] was cleared before the roll: no gradient
     for (int c = tid; c < F; c += 256) gin[c] = 0.f;
 }

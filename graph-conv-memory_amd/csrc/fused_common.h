@@ -87,6 +87,24 @@ __device__ __forceinline__ void mma16g(f32x4& acc, const float* a, int ais, int 
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
 }
 
+// mma32 with every LDS operand read in flight before the first MFMA (K compile-time, <= 64)
+template <int K>
+__device__ __forceinline__ void mma32b(f32x16& acc, const float* a, int ais, int aks, const float* b,
+                                       int bks, int bjs, int li, int lh) {
+  const float* ap = a + li * ais + lh * aks;
+  const float* bp = b + lh * bks + li * bjs;
+  float av[K / 2], bv[K / 2];
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s) {
+    av[s] = ap[2 * s * aks];
+    bv[s] = bp[2 * s * bks];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+}
+
 struct Gnn2 {
   const float *w_rel1, *b_rel1, *w_root1;  // [H1,F], [H1], [H1,F]
   const float *w_rel2, *b_rel2, *w_root2;  // [H2,H1], [H2], [H2,H1]
