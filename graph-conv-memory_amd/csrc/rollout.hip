@@ -110,6 +110,22 @@ extern "C" int gcm_dense_step_bwd_acc(const float* g_mx, const float* g_nodes_ou
   return gcm_sum_slabs_acc(slabs, n_slabs, (int)P, g_params_prev, g_params, stream);
 }
 
+extern "C" int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out,
+                                        const float* nodes_out, const float* adj_out,
+                                        const int64_t* cur, const int64_t* count_in,
+                                        const float* params, int has_bias, int act1, int act2,
+                                        const float* mx, const float* h1, const float* agg1,
+                                        const float* agg2, float* g_nodes_in, float* g_obs,
+                                        float* slabs, int accumulate, int B, int N, int F, int H1,
+                                        int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(params && slabs);
+  const Unpacked u = unpack(params, has_bias, F, H1, H2);
+  return gcm_dense_gnn2_row_bwd(g_mx, g_nodes_out, nodes_out, adj_out, cur, count_in, u.w_rel1,
+                                u.b1, u.w_root1, act1, u.w_rel2, u.b2, u.w_root2, act2, mx, h1,
+                                agg1, agg2, g_nodes_in, g_obs, slabs, accumulate, B, N, F, H1, H2,
+                                stream);
+}
+
 extern "C" int gcm_dense_rollout_fwd(const float* obs, float* nodes_all, float* adj_all,
                                      int64_t* count_all, int64_t* cur_all,
                                      const gcm_selector_desc* selectors, int n_selectors,

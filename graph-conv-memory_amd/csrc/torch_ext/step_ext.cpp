@@ -7,10 +7,12 @@
 // gcm_dense_step_fwd / gcm_dense_step_bwd), without the interpreter on the path - in particular the
 // backward runs on the autograd engine thread without taking the GIL.
 //
-// The parameter gradient is threaded through the chain of step nodes: a node hands the packed
-// parameter vector on as a sixth output (an alias), the next step consumes that one, and in the
-// backward each node adds its own gradient to the running total inside gcm_sum_slabs_acc.  The
-// autograd engine would otherwise sum T separate [param_count] tensors with one tiny kernel each.
+// The parameter gradient of the T steps of a rollout is not summed step by step: every step node
+// accumulates its per-graph slabs into ONE slab array owned by the module (slab_acc, read-modify-
+// write inside the backward kernel) and returns no gradient for the parameter vector; a gate node
+// between the parameter vector and the steps (gcm/_ops.py:_ParamGate) runs after all of them and
+// adds the single slab sum.  The autograd engine would otherwise sum T separate [param_count]
+// tensors with one tiny kernel each, after T slab-sum launches.
 //
 // No device code here: PyTorch is plumbing (allocation, autograd graph, stream); the product is the
 // C-ABI library this file links against.
@@ -87,7 +89,7 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
   static variable_list forward(AutogradContext* ctx, at::Tensor obs, at::Tensor nodes_in,
                                at::Tensor packed, at::Tensor adj_in, at::Tensor count_in,
                                at::Tensor flags, int64_t cfg_handle, int64_t stream,
-                               int64_t need_bwd_) {
+                               int64_t need_bwd_, at::Tensor slab_acc, int64_t is_head) {
     StepCfg* cfg = reinterpret_cast<StepCfg*>(cfg_handle);
     obs = obs.contiguous();
     nodes_in = nodes_in.contiguous();
@@ -119,15 +121,14 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
       ctx->save_for_backward({buf, count_in, packed});
       auto& sd = ctx->saved_data;
       sd["dims"] = std::vector<int64_t>{B, N, F, H1, H2, cfg->P, cfg->has_bias, cfg->act1,
-                                        cfg->act2, stream};
+                                        cfg->act2, stream, is_head};
+      if (slab_acc.defined() && slab_acc.numel() == B * cfg->P) sd["slab_acc"] = slab_acc;
     }
     ctx->mark_non_differentiable({adj_out, cur, count_out});
     // undefined output gradients stay undefined (backward handles them): the engine would
     // otherwise launch one zero-fill per output and step
     ctx->set_materialize_grads(false);
-    // the parameter vector, handed on to the next step (same storage; nobody writes to it)
-    at::Tensor packed_out = packed.alias();
-    return {mx, nodes_out, adj_out, cur, count_out, packed_out};
+    return {mx, nodes_out, adj_out, cur, count_out};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -138,40 +139,59 @@ struct FusedStepFn : public torch::autograd::Function<FusedStepFn> {
     const int has_bias = (int)d[6], act1 = (int)d[7], act2 = (int)d[8];
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(d[9]);
     const Layout L(B, N, F, H1, H2, true);
-    at::Tensor g_par = grads.size() > 5 && grads[5].defined() ? grads[5].contiguous() : at::Tensor();
-    if (!grads[0].defined() && !grads[1].defined())   // this step feeds nothing: pass the total on
-      return {at::Tensor(), at::Tensor(), g_par, at::Tensor(), at::Tensor(), at::Tensor(),
-              at::Tensor(), at::Tensor(), at::Tensor()};
+    const bool is_head = d.size() > 10 && d[10] != 0;
+    at::Tensor slab_acc;
+    if (ctx->saved_data.count("slab_acc")) slab_acc = ctx->saved_data["slab_acc"].toTensor();
+    const bool want_par = ctx->needs_input_grad(2);
+    const bool deferred = want_par && slab_acc.defined();   // slabs go to the module's array
+    if (!grads[0].defined() && !grads[1].defined())   // this step feeds nothing
+      return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+              at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     at::Tensor g_mx = grads[0].defined() ? grads[0].contiguous() : at::zeros({B, H2}, buf.options());
     at::Tensor g_no = grads[1].defined() ? grads[1].contiguous() : at::Tensor();
-    // outputs + slab scratch in one allocation: g_nodes_in | g_obs | g_params | slabs
+    // outputs (+ slab scratch when the sum happens here) in one allocation:
+    // g_nodes_in | g_obs | g_params | slabs
     const int64_t n_nodes = pad64(B * N * F), n_obs = pad64(B * F), n_p = pad64(P);
-    at::Tensor out = at::empty({n_nodes + n_obs + n_p + B * P}, buf.options());
+    at::Tensor out = at::empty({n_nodes + n_obs + (deferred ? 0 : n_p + B * P)}, buf.options());
     float* ob = out.data_ptr<float>();
     const float* base = buf.data_ptr<float>();
-    const int rc = gcm_dense_step_bwd_acc(
-        g_mx.data_ptr<float>(), g_no.defined() ? g_no.data_ptr<float>() : nullptr, base,
-        base + L.o_adj, reinterpret_cast<const int64_t*>(base + L.o_idx), count_in.data_ptr<int64_t>(),
-        packed.data_ptr<float>(), has_bias, act1, act2, base + L.o_mx, base + L.o_h1,
-        base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes,
-        g_par.defined() ? g_par.data_ptr<float>() : nullptr, ob + n_nodes + n_obs,
-        ob + n_nodes + n_obs + n_p, sizeof(float) * (size_t)(B * P), (int)B, (int)N, (int)F,
-        (int)H1, (int)H2, stream);
-    check(rc, "gcm_dense_step_bwd_acc");
+    const int64_t* ib = reinterpret_cast<const int64_t*>(base + L.o_idx);
+    if (deferred) {
+      const int rc = gcm_dense_step_bwd_slabs(
+          g_mx.data_ptr<float>(), g_no.defined() ? g_no.data_ptr<float>() : nullptr, base,
+          base + L.o_adj, ib, count_in.data_ptr<int64_t>(), packed.data_ptr<float>(), has_bias, act1,
+          act2, base + L.o_mx, base + L.o_h1, base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes,
+          slab_acc.data_ptr<float>(), /*accumulate=*/1, (int)B, (int)N, (int)F, (int)H1, (int)H2,
+          stream);
+      check(rc, "gcm_dense_step_bwd_slabs");
+    } else {
+      const int rc = gcm_dense_step_bwd(
+          g_mx.data_ptr<float>(), g_no.defined() ? g_no.data_ptr<float>() : nullptr, base,
+          base + L.o_adj, ib, count_in.data_ptr<int64_t>(), packed.data_ptr<float>(), has_bias, act1,
+          act2, base + L.o_mx, base + L.o_h1, base + L.o_agg1, base + L.o_agg2, ob, ob + n_nodes,
+          ob + n_nodes + n_obs, ob + n_nodes + n_obs + n_p, sizeof(float) * (size_t)(B * P), (int)B,
+          (int)N, (int)F, (int)H1, (int)H2, stream);
+      check(rc, "gcm_dense_step_bwd");
+    }
     at::Tensor g_obs, g_nodes_in, g_params;
     if (ctx->needs_input_grad(0)) g_obs = out.narrow(0, n_nodes, B * F).view({B, F});
     if (ctx->needs_input_grad(1)) g_nodes_in = out.narrow(0, 0, B * N * F).view({B, N, F});
-    if (ctx->needs_input_grad(2)) g_params = out.narrow(0, n_nodes + n_obs, P);
-    else if (g_par.defined()) g_params = g_par;
+    if (want_par) {
+      // deferred: the gate adds the slab sum; the first step of a chain hands it a defined (zero)
+      // gradient so that the gate is certain to run
+      if (!deferred) g_params = out.narrow(0, n_nodes + n_obs, P);
+      else if (is_head) g_params = at::zeros({P}, buf.options());
+    }
     return {g_obs, g_nodes_in, g_params, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor(), at::Tensor()};
+            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
 std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& nodes_in,
                                    const at::Tensor& packed, const at::Tensor& adj_in,
                                    const at::Tensor& count_in, const at::Tensor& flags,
-                                   int64_t cfg_handle, int64_t stream) {
+                                   int64_t cfg_handle, int64_t stream,
+                                   const c10::optional<at::Tensor>& slab_acc, bool is_head) {
   TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && packed.is_cuda() && adj_in.is_cuda() &&
                   count_in.is_cuda() && flags.is_cuda(),
               "fused_step: every tensor must live on a HIP device (no CPU fallback)");
@@ -182,7 +202,9 @@ std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& node
   const bool need_bwd = at::GradMode::is_enabled() &&
                         (obs.requires_grad() || nodes_in.requires_grad() || packed.requires_grad());
   return FusedStepFn::apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg_handle, stream,
-                            (int64_t)need_bwd);
+                            (int64_t)need_bwd,
+                            slab_acc.has_value() ? *slab_acc : at::empty({0}, obs.options()),
+                            (int64_t)is_head);
 }
 
 }  // namespace

@@ -77,6 +77,7 @@ PROTOTYPES = {
                                  + [_I] * 5 + [_P]),
     "gcm_dense_step_fwd": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 6 + [_Z] + [_I] * 5 + [_P]),
     "gcm_dense_step_bwd": (_I, [_P] * 7 + [_I] * 3 + [_P] * 8 + [_Z] + [_I] * 5 + [_P]),
+    "gcm_dense_step_bwd_slabs": (_I, [_P] * 7 + [_I] * 3 + [_P] * 7 + [_I] * 6 + [_P]),
     "gcm_dense_step_bwd_acc": (_I, [_P] * 7 + [_I] * 3 + [_P] * 9 + [_Z] + [_I] * 5 + [_P]),
     "gcm_dense_rollout_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 3 + [_I] + [_P] * 6
                               + [_Z] + [_I] * 6 + [_P]),

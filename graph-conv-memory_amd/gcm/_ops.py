@@ -724,18 +724,64 @@ class _FusedStep(torch.autograd.Function):
         return g_obs, g_nodes_in, g_params, None, None, None, None
 
 
-def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg):
+class SlabHolder:
+    """The parameter-gradient slab arrays [B, P] of one packed parameter vector (one per batch size
+    seen): every step's backward kernel accumulates into them, _ParamGate sums them once."""
+
+    def __init__(self, P, device):
+        self.P, self.device = P, device
+        self.slabs = {}
+
+    def get(self, B):
+        t = self.slabs.get(B)
+        if t is None:
+            t = torch.zeros(B, self.P, device=self.device, dtype=_f32)
+            self.slabs[B] = t
+        return t
+
+
+class _ParamGate(torch.autograd.Function):
+    """Identity on the packed parameter vector, placed between it and the step nodes: its backward
+    runs after every step node of the pass (they are its consumers) and adds the ONE sum of the
+    slab arrays the steps accumulated into - instead of T slab sums and T engine-side adds."""
+
+    @staticmethod
+    def forward(ctx, packed, holder):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return packed.view_as(packed)
+
+    @staticmethod
+    def backward(ctx, g):
+        holder = ctx.holder
+        total = g
+        for B, slabs in holder.slabs.items():
+            out = torch.empty(holder.P, device=slabs.device, dtype=_f32)
+            _call("gcm_sum_slabs_acc", _hip.ptr(slabs), B, holder.P, _hip.ptr(total), _hip.ptr(out),
+                  _hip.stream())
+            slabs.zero_()
+            total = out
+        return total, None
+
+
+def param_gate(packed, holder):
+    return _ParamGate.apply(packed, holder)
+
+
+def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg, slab_acc=None, is_head=True):
     """The per-step node: the C++ autograd node when gcm/_lib/ext is built (same C-ABI calls,
     no interpreter on the path), else the Python Function above.  Kernel timing (TIMER) goes
     through the Python one, whose launches it can bracket.
-    -> (mx, nodes_out, adj_out, cur, count_out, packed_out); packed_out (C++ node, grad mode) is
-    the parameter vector to feed the NEXT step of the same chain, or None."""
+    slab_acc [B, P]: where the C++ node's backward accumulates the parameter-gradient slabs (summed
+    once by _ParamGate); is_head: first step of a chain of hidden states.
+    -> (mx, nodes_out, adj_out, cur, count_out)"""
     if TIMER is None:
         handle = cfg.cpp_handle()
         if handle:
             return _ext.module().fused_step(obs, nodes_in, packed, adj_in, count_in, flags, handle,
-                                            torch._C._cuda_getCurrentRawStream(obs.device.index))
-    return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg) + (None,)
+                                            torch._C._cuda_getCurrentRawStream(obs.device.index),
+                                            slab_acc, is_head)
+    return _FusedStep.apply(obs, nodes_in, packed, adj_in, count_in, flags, cfg)
 
 
 # Time-parallel BPTT keeps T*B*(N*F + F + P) floats of scratch; above this many bytes the

@@ -286,26 +286,31 @@ class DenseGCM(torch.nn.Module):
                  for t, n in zip(tensors, sizes)]
         packed = torch.cat(parts)
         used = [False]
+        gated = holder = None
         if packed.requires_grad:
             packed.register_hook(lambda g: used.__setitem__(0, True))
+            holder = _ops.SlabHolder(cfg.P, dev)
+            gated = _ops.param_gate(packed, holder)
         self._packed_cache = (key, packed, used,
-                              [(t, t._version if t is not None else 0) for t in tensors])
+                              [(t, t._version if t is not None else 0) for t in tensors], gated, holder)
         return packed
 
     def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags, link=None):
         root = self._packed_params(cfg)
-        # Steps of one rollout share the parameter vector through a chain (each step hands it to
-        # the next as an alias), so the backward adds the T parameter gradients inside the step
-        # kernels instead of T tiny engine-side sums.  The link travels on the hidden state the
-        # caller passes back (`_gcm_link`, which also lets the next call skip re-validating a
-        # hidden state this module produced itself); a detached / foreign hidden state simply
-        # starts a new chain.
-        packed = link[4] if link is not None and link[4] is not None and link[5] is root else root
-        mx, nodes_out, adj_out, cur, num_nodes_next, packed_out = _ops.fused_step(
-            x, nodes, packed, adj, num_nodes, flags, cfg)
-        if packed_out is not None and not packed_out.requires_grad:
-            packed_out = None
-        nodes_out._gcm_link = (self._token, adj_out, cfg, flags, packed_out, root, x.shape, weights,
+        gated, holder = self._packed_cache[4], self._packed_cache[5]
+        # In grad mode the steps consume the parameter vector through a gate node and accumulate
+        # their parameter-gradient slabs into ONE array of the module (summed once by the gate,
+        # _ops._ParamGate) instead of returning T gradients for the engine to add.
+        # `_gcm_link` on the returned node matrix lets the next call skip re-validating a hidden
+        # state this module produced itself, and tells whether it continues the same chain.
+        if gated is not None:
+            is_head = link is None or link[5] is not root
+            mx, nodes_out, adj_out, cur, num_nodes_next = _ops.fused_step(
+                x, nodes, gated, adj, num_nodes, flags, cfg, holder.get(x.shape[0]), is_head)
+        else:
+            mx, nodes_out, adj_out, cur, num_nodes_next = _ops.fused_step(
+                x, nodes, root, adj, num_nodes, flags, cfg)
+        nodes_out._gcm_link = (self._token, adj_out, cfg, flags, None, root, x.shape, weights,
                                num_nodes_next)
         if self.mutate_num_nodes_on_overflow:
             num_nodes.copy_(cur)

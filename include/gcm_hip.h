@@ -349,6 +349,17 @@ int gcm_dense_step_bwd_acc(const float* g_mx, const float* g_nodes_out, const fl
                            float* g_params, void* workspace, size_t workspace_bytes, int B, int N,
                            int F, int H1, int H2, gcm_stream_t stream);
 
+/* The step adjoint without the slab sum: slabs [B, param_count] receive (accumulate = 0) or
+ * accumulate (accumulate != 0, read-modify-write) the per-graph parameter-gradient slabs of this
+ * step.  A caller that owns a time loop keeps one slab array for all T steps and sums it once
+ * (gcm_sum_slabs) instead of once per step. */
+int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const float* nodes_out,
+                             const float* adj_out, const int64_t* cur, const int64_t* count_in,
+                             const float* params, int has_bias, int act1, int act2, const float* mx,
+                             const float* h1, const float* agg1, const float* agg2,
+                             float* g_nodes_in, float* g_obs, float* slabs, int accumulate, int B,
+                             int N, int F, int H1, int H2, gcm_stream_t stream);
+
 /* ---- time-batched rollout (caller loop ray_gcm.py:200-202) --------- */
 
 

@@ -209,9 +209,9 @@ def test_cpp_node_matches_python_node(monkeypatch):
         assert torch.equal(a, b)
     assert torch.equal(res[0][2], res[1][2])
     for a, b in zip(res[0][3], res[1][3]):
-        # the chain adds the per-step parameter gradients in reverse-time order inside k_sum_slabs;
-        # the engine adds them in the same order for the Python node, but as separate roundings
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+        # C++ node: per-graph slabs accumulate over the steps, one sum at the gate; Python node:
+        # one slab sum per step, the engine adds the T results - same terms, different order
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
 
 
 def test_parameter_gradient_chain_survives_detach_and_restarts():
@@ -278,3 +278,25 @@ def test_skinny_linear_matches_nn_linear(M, I, O, bias):
     if bias:
         torch.testing.assert_close(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
     assert set(lin.state_dict()) == set(ref.state_dict())
+
+
+def test_parameter_gate_under_partial_and_repeated_backward():
+    """The slab array the step nodes accumulate into is flushed by the gate on every pass:
+    autograd.grad for the observations only (parameters not requested) leaves nothing behind,
+    retain_graph + a second backward gives the same parameter gradients again, and a step whose
+    outputs do not reach the loss contributes nothing."""
+    mem, g = _cfg2_like(seed=5)
+    obs = torch.rand(12, 3, 32, device=DEV, requires_grad=True)
+    params = list(g.parameters())
+    out, _ = _loop(mem, obs)
+    loss = (out[:9] ** 2).sum()                      # the last three steps do not reach the loss
+    (g_obs,) = torch.autograd.grad(loss, [obs], retain_graph=True)
+    assert float(g_obs[9:].abs().max()) == 0.0
+    first = torch.autograd.grad(loss, params, retain_graph=True)
+    second = torch.autograd.grad(loss, params)
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    ref_out, _ = mem.rollout(obs[:9])
+    ref = torch.autograd.grad((ref_out ** 2).sum(), params)
+    for a, b in zip(first, ref):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
