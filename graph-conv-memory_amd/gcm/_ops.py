@@ -582,7 +582,7 @@ class StepConfig:
         self.fn_fwd = lib.gcm_dense_step_fwd
         self.fn_bwd = lib.gcm_dense_step_bwd
         self.has_distance = any(d.kind == _hip.SEL_DISTANCE for d in descs)
-        self._cpp, self._cpp_handle = None, None
+        self._cpp, self._cpp_handle, self._cpp_call = None, None, None
 
     def cpp_handle(self):
         """address of the C++ twin of this config (0 when the torch extension is not built)"""
@@ -597,6 +597,15 @@ class StepConfig:
                 h = self._cpp.handle()
             self._cpp_handle = h
         return h
+
+    def cpp_call(self):
+        """(ext.fused_step, config handle, device index) or None when the extension is not built"""
+        c = self._cpp_call
+        if c is None:
+            h = self.cpp_handle()
+            c = (_ext.module().fused_step, h, self.device.index) if h else False
+            self._cpp_call = c
+        return c or None
 
     def workspace(self, B):
         if not self.has_distance:

@@ -161,6 +161,8 @@ class DenseGCM(torch.nn.Module):
 
     def _poll(self, flags):
         self._steps += 1
+        if self.finite_check == "deferred" and self._steps % self.poll_interval:
+            return                        # the common step: nothing to look at
         if self.finite_check == "sync":
             bits = int(flags.item())
             if bits:
@@ -305,11 +307,17 @@ class DenseGCM(torch.nn.Module):
         # state this module produced itself, and tells whether it continues the same chain.
         if gated is not None:
             is_head = link is None or link[5] is not root
-            mx, nodes_out, adj_out, cur, num_nodes_next = _ops.fused_step(
-                x, nodes, gated, adj, num_nodes, flags, cfg, holder.get(x.shape[0]), is_head)
+            packed, slab_acc = gated, holder.get(x.shape[0])
+        else:
+            is_head, packed, slab_acc = True, root, None
+        fast = cfg.cpp_call() if _ops.TIMER is None else None
+        if fast is not None:      # (function, handle, device index) of the C++ node: no wrapper layers
+            mx, nodes_out, adj_out, cur, num_nodes_next = fast[0](
+                x, nodes, packed, adj, num_nodes, flags, fast[1],
+                torch._C._cuda_getCurrentRawStream(fast[2]), slab_acc, is_head)
         else:
             mx, nodes_out, adj_out, cur, num_nodes_next = _ops.fused_step(
-                x, nodes, root, adj, num_nodes, flags, cfg)
+                x, nodes, packed, adj, num_nodes, flags, cfg, slab_acc, is_head)
         nodes_out._gcm_link = (self._token, adj_out, cfg, flags, None, root, x.shape, weights,
                                num_nodes_next)
         if self.mutate_num_nodes_on_overflow:
