@@ -143,6 +143,14 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
 #pragma unroll
     for (int t = 0; t < NT; ++t) live |= (__any(sRow[t * 32 + li] != 0.f) ? 1u : 0u) << t;
     live = __builtin_amdgcn_readfirstlane(live);
+    // this wave's column strip of the FIRST live adjacency row tile (the A operands of dX; usually
+    // the only one): in flight from here on, further live tiles are fetched when they are used
+    const int t0 = __builtin_ctz(live);
+    float av0[16];
+    if (wave_rows) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) av0[s] = ag[(t0 * 32 + lh + 2 * s) * N + r_base + li];
+    }
     // h1 of the live row tiles: loads in flight under the layer-2 arithmetic
     constexpr int PERG = 32 * HP / 256;
     float hv[NT][PERG];
@@ -257,8 +265,13 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
         if ((live >> t) & 1u) {
           // this wave's column strip of adjacency row tile t: the A operands, HBM -> registers
           float av[16];
+          if (t == t0) {
 #pragma unroll
-          for (int s = 0; s < 16; ++s) av[s] = ag[(t * 32 + lh + 2 * s) * N + r_base + li];
+            for (int s = 0; s < 16; ++s) av[s] = av0[s];
+          } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) av[s] = ag[(t * 32 + lh + 2 * s) * N + r_base + li];
+          }
           bool nz = false;
 #pragma unroll
           for (int s = 0; s < 16; ++s) nz |= av[s] != 0.f;
@@ -277,22 +290,29 @@ __global__ __launch_bounds__(256, (LdsBptt<NT, NCT, NHT, N2T>::WAVES)) void k_bp
           }
         }
       }
-      // epilogue: root part, incoming gradient, undo insert + roll (gcm.py:262-278); no branches
+      // epilogue: root part, incoming gradient, undo insert + roll (gcm.py:262-278).  One base
+      // pointer per array and compile-time row offsets (acc_row(r, lh) = 4*lh + const(r)): the
+      // per-element 64-bit addresses of the first version spilled, and every scratch reload waits
+      // on vmcnt(0), i.e. for the item's own stores.
       const bool mine = (live >> wave) & 1u;
-      const float* gg = g_nodes_out ? g_nodes_out + (size_t)item * N * F : nullptr;
       const int sh = wrap ? 1 : 0;
+      const int row0 = r_base + 4 * lh;
+      float* gq = gin + (row0 + sh) * F + li;                       // out[r] = in[r+1] on overflow
+      float* po = pobs + (size_t)item * F + li;
+      const float* gg = g_nodes_out ? g_nodes_out + (size_t)item * N * F + row0 * F + li : nullptr;
+      const float* rt = sRt + row0 * FS + li;
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = r_base + acc_row(r, lh), col = c * 32 + li;
+          const int ro = (r & 3) + 8 * (r >> 2);                    // row - row0, compile time
+          const int row = row0 + ro;
           float v = acc[c][r];
-          if (gg) v += gg[row * F + col];   // gradient from later steps (per-step use only)
-          if (mine) v += sRt[row * FS + col];
+          if (gg) v += gg[ro * F + c * 32];   // gradient from later steps (per-step use only)
+          if (mine) v += rt[ro * FS + c * 32];
           const bool is_cur = row == cur;
-          if (is_cur) pobs[(size_t)item * F + col] = v;   // the inserted row belongs to the observation
-          const int dst = row + sh;                        // out[r] = in[r+1] on overflow
-          if (dst < N) gin[dst * F + col] = is_cur ? 0.f : v;
+          if (is_cur) po[c * 32] = v;         // the inserted row belongs to the observation
+          if (row + sh < N) gq[ro * F + c * 32] = is_cur ? 0.f : v;
         }
     }
     if (wrap && tid < F) gin[tid] = 0.f;   // in[0] was dropped by the roll: no gradient
