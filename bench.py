@@ -240,6 +240,14 @@ def main():
         obs.grad = None
     torch.cuda.synchronize()
     kern = _ops.TIMER.summary()
+    # ... and around the two C-ABI calls of the rollout entry (persistent forward; backward =
+    # time-parallel BPTT + reverse scan + one slab sum)
+    _ops.TIMER = _ops.KernelTimer()
+    for _ in range(min(args.steps, 3)):
+        rollout_api(mem, obs, bucket, weight)
+        gnn.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    kern_roll = _ops.TIMER.summary()
     _ops.TIMER = None
     # (b) the two dominant kernels alone: R back-to-back launches through the C ABI on the live
     #     state of this workload (graph after T steps), one event pair around the batch
@@ -318,6 +326,11 @@ def main():
             "kernel_ms": {k: round(v[1], 5) for k, v in kern.items()},
             "rollout_api": {"value": states / dt_roll, "unit": "belief-states/s",
                             "ms_per_step": dt_roll / args.steps * 1e3,
+                            "kernel_ms": {k: round(v[1], 5) for k, v in kern_roll.items()},
+                            # SURVEY 8(d) bytes of T steps over the persistent forward kernel's time: an
+                            # EFFECTIVE rate - the kernel keeps the state in LDS and does not move them
+                            "forward_effective_GBps": (T * alg_bytes / (kern_roll["gcm_dense_rollout_fwd"][1] * 1e-3) / 1e9
+                                                       if "gcm_dense_rollout_fwd" in kern_roll else None),
                             "note": "same workload and results through the additive DenseGCM.rollout(obs[T,B,F]) "
                                     "entry, one autograd node: persistent forward kernel (graph state resident "
                                     "in LDS for all T steps), time-parallel BPTT (one launch over T*B graph-steps "
