@@ -230,6 +230,22 @@ def main():
     timed(rollout_api, 2)
     dt_roll = timed(rollout_api, args.steps)
 
+    # forward only (inference, no autograd graph): SURVEY 8(d) asks for it beside fwd+bwd
+    def fwd_step(mem, obs, bucket, weight):
+        with torch.no_grad():
+            hidden = None
+            for t in range(obs.shape[0]):
+                _, hidden = mem(obs[t], hidden)
+
+    def fwd_roll(mem, obs, bucket, weight):
+        with torch.no_grad():
+            mem.rollout(obs, None)
+
+    timed(fwd_step, 1)
+    dt_fwd = timed(fwd_step, args.steps)
+    timed(fwd_roll, 1)
+    dt_fwd_roll = timed(fwd_roll, args.steps)
+
     # ---- kernel durations with HIP events on the launch stream -------------------------------
     # (a) in situ: event pairs around every C-ABI call of a repeated timed region (a step call
     #     enqueues state-advance + selector + fused GNN kernels, so these are per-call sums)
@@ -320,6 +336,8 @@ def main():
                                    "through the per-step drop-in API `for t: mx, m = gcm(obs[t], m)` + backward" % T,
                        "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": T,
                        "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
+            "forward_only": {"per_step_api": states / dt_fwd, "rollout_api": states / dt_fwd_roll,
+                             "unit": "belief-states/s", "note": "torch.no_grad(): no history kept"},
             "host_path": "c++ autograd node (gcm/_lib/ext)" if _ext.module() is not None
                          else "python autograd function",
             "roofline": dominant, "roofline_mfma_view": other,
