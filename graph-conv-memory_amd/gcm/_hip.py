@@ -69,6 +69,9 @@ PROTOTYPES = {
     "gcm_dense_gnn2_param_count": (_Z, [_I, _I, _I]),
     "gcm_dense_gnn2_row_fwd": (_I, [_P] * 6 + [_I] + [_P] * 3 + [_I] + [_P] * 5 + [_I] * 5 + [_P]),
     "gcm_dense_gnn2_row_bwd": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] + [_P] * 7 + [_I] * 6 + [_P]),
+    "gcm_relu_layernorm_fwd": (_I, [_P] * 4 + [_L, _I, ctypes.c_float, _P]),
+    "gcm_relu_layernorm_bwd_workspace_bytes": (_Z, [_L, _I]),
+    "gcm_relu_layernorm_bwd": (_I, [_P] * 6 + [_Z, _L, _I, ctypes.c_float, _P]),
     "gcm_skinny_wgrad_workspace_bytes": (_Z, [_I] * 3),
     "gcm_skinny_wgrad": (_I, [_P] * 4 + [_Z] + [_I] * 3 + [_P]),
     "gcm_sum_slabs": (_I, [_P, _I, _I, _P, _P]),

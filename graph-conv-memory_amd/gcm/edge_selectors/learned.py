@@ -47,7 +47,7 @@ class LearnedEdge(torch.nn.Module):
         """learned.py:53-113.  `adj` is rewritten in place (the caller hands over its own
         buffer, as DenseGCM does) and returned."""
         pairs = _ops.learned_pairs(nodes, num_nodes)                  # [B, N, 2F]
-        logits = self.edge_network(pairs).squeeze(-1)                 # [B, N]
+        logits = _ops.edge_network_forward(self.edge_network, pairs).squeeze(-1)   # [B, N]
         if self.noise_fn is not None:
             noise = self.noise_fn(logits)
         else:

@@ -78,7 +78,7 @@ class LearnedEdge(torch.nn.Module):
                 indices=torch.zeros(3, 0, dtype=torch.long, device=nodes.device),
                 values=torch.zeros(0, device=nodes.device), size=(B, N, N))
         pairs = _ops.causal_pairs(nodes, edges)                 # [E, 2F]  learned.py:121-124
-        logits = self.edge_network(pairs).squeeze(-1)
+        logits = _ops.edge_network_forward(self.edge_network, pairs).squeeze(-1)
         cutoff = 1 / (1 + self.num_edge_samples)
         self.tau_param.data.clamp_(*self.temp_bounds)
         if self.deterministic:   # util.sparse_tempered_softmax: the same softmax without noise

@@ -235,6 +235,17 @@ size_t gcm_skinny_wgrad_workspace_bytes(int M, int O, int I);
 int gcm_skinny_wgrad(const float* dy, const float* x, float* dw_db, void* workspace,
                      size_t workspace_bytes, int M, int O, int I, gcm_stream_t stream);
 
+/* y = LayerNorm(relu(x)) over the last dimension (F <= 64, biased variance, eps as torch.nn.LayerNorm):
+ * the ReLU - LayerNorm pairs of the LearnedEdge edge network (learned.py:38-51) on M = B*N rows.
+ * Backward: dx [M,F] and dgamma_dbeta = dgamma [F] | dbeta [F] (per-workgroup slabs, fixed-order
+ * sum); x is the pre-activation saved by the caller. */
+int gcm_relu_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                           int64_t M, int F, float eps, gcm_stream_t stream);
+size_t gcm_relu_layernorm_bwd_workspace_bytes(int64_t M, int F);
+int gcm_relu_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx,
+                           float* dgamma_dbeta, void* workspace, size_t workspace_bytes, int64_t M,
+                           int F, float eps, gcm_stream_t stream);
+
 /* learned.py:76-111 (non-deterministic branch), fused: per graph soft = softmax_j<cur(logits +
  * noise) (gumbel_softmax tau=1 with caller-supplied gumbel noise), edge_j = soft_j > cutoff
  * (STE forward, util.py:9-18), adj[b, cur, j] = (edge_j + adj[b, cur, j] > 0) for j < cur.

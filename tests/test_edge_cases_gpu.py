@@ -300,3 +300,52 @@ def test_parameter_gate_under_partial_and_repeated_backward():
     ref = torch.autograd.grad((ref_out ** 2).sum(), params)
     for a, b in zip(first, ref):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("M,F", [(32768, 32), (5000, 17), (2500, 64), (1, 32), (300, 33)])
+def test_relu_layernorm_matches_torch(M, F):
+    """gcm_relu_layernorm_fwd/bwd == LayerNorm(relu(x)) of torch (outputs 1e-5, gradients 1e-4)."""
+    from gcm import _ops
+    torch.manual_seed(M + F)
+    ln = torch.nn.LayerNorm(F).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(M, F, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ga, ba = ln.weight.detach().clone().requires_grad_(True), ln.bias.detach().clone().requires_grad_(True)
+    ya = _ops.relu_layernorm(xa, ga, ba, ln.eps)
+    yb = ln(torch.relu(xb))
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
+    gy = torch.randn(M, F, device=DEV)
+    ya.backward(gy)
+    yb.backward(gy)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ga.grad, ln.weight.grad, rtol=1e-4, atol=1e-5 * float(ln.weight.grad.abs().max()) + 1e-6)
+    torch.testing.assert_close(ba.grad, ln.bias.grad, rtol=1e-4, atol=1e-5 * float(ln.bias.grad.abs().max()) + 1e-6)
+
+
+def test_default_edge_network_path_matches_module():
+    """LearnedEdge's default edge network through skinny_linear / relu_layernorm == the nn.Sequential
+    called as a module (outputs and every parameter gradient); a user-supplied network is left alone."""
+    from gcm import _ops
+    from gcm.edge_selectors.learned import LearnedEdge
+    torch.manual_seed(0)
+    sel = LearnedEdge(32).to(DEV)
+    net = sel.edge_network
+    assert _ops.default_edge_network(net) is not None
+    x = torch.randn(64, 128, 64, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = _ops.edge_network_forward(net, xa)
+    ya.square().sum().backward()
+    got = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    yb = net(xb)
+    yb.square().sum().backward()
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5 * float(xb.grad.abs().max()))
+    for a, p in zip(got, net.parameters()):
+        torch.testing.assert_close(a, p.grad, rtol=1e-4, atol=1e-5 * float(p.grad.abs().max()))
+    custom = torch.nn.Sequential(torch.nn.Linear(64, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).to(DEV)
+    assert _ops.default_edge_network(custom) is None
+    assert _ops.edge_network_forward(custom, x).shape == (64, 128, 1)
