@@ -990,18 +990,83 @@ def default_edge_network(net):
     return mods
 
 
+class _EdgeMLP(torch.autograd.Function):
+    """The default edge network (learned.py:38-51) as ONE autograd node: Linear - ReLU - LayerNorm -
+    Linear - ReLU - LayerNorm - Linear on M = B*N candidate rows.  Same kernels and library GEMMs
+    as the module-by-module path (skinny_linear / relu_layernorm), chained by hand in both
+    directions: five Python-level autograd nodes per step become one."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1):
+        lin = torch.nn.functional.linear
+        x2 = x.reshape(-1, x.shape[-1])
+        M = x2.shape[0]
+        p0 = lin(x2, w0, b0)                                   # pre-activations are saved,
+        h0 = torch.empty_like(p0)                              # the normalised rows recomputed
+        st = _hip.stream()
+        _call("gcm_relu_layernorm_fwd", _hip.ptr(p0), _hip.ptr(g0), _hip.ptr(be0), _hip.ptr(h0), M,
+              p0.shape[1], eps0, st)
+        p1 = lin(h0, w1, b1)
+        h1 = torch.empty_like(p1)
+        _call("gcm_relu_layernorm_fwd", _hip.ptr(p1), _hip.ptr(g1), _hip.ptr(be1), _hip.ptr(h1), M,
+              p1.shape[1], eps1, st)
+        out = lin(h1, w2, b2)
+        ctx.save_for_backward(x2, p0, h0, p1, h1, w0, g0, w1, g1, w2)
+        ctx.eps = (eps0, eps1)
+        ctx.has_bias = (b0 is not None, b1 is not None, b2 is not None)
+        ctx.xshape = x.shape
+        return out.view(*x.shape[:-1], out.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, p0, h0, p1, h1, w0, g0, w1, g1, w2 = ctx.saved_tensors
+        lib = _hip.lib()
+        st = _hip.stream()
+        dev = x2.device
+        M = x2.shape[0]
+        need = ctx.needs_input_grad
+
+        def wgrad(gy, xin, O, I):
+            ws_bytes = lib.gcm_skinny_wgrad_workspace_bytes(M, O, I)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            out = torch.empty(O * I + O, device=dev, dtype=_f32)
+            _call("gcm_skinny_wgrad", _hip.ptr(gy), _hip.ptr(xin), _hip.ptr(out), _hip.ptr(ws), ws_bytes,
+                  M, O, I, st)
+            return out[:O * I].view(O, I), out[O * I:]
+
+        def ln_bwd(gy, pre, gamma, eps):
+            F = pre.shape[1]
+            dx = torch.empty_like(pre)
+            dgb = torch.empty(2 * F, device=dev, dtype=_f32)
+            ws_bytes = lib.gcm_relu_layernorm_bwd_workspace_bytes(M, F)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _call("gcm_relu_layernorm_bwd", _hip.ptr(gy), _hip.ptr(pre), _hip.ptr(gamma), _hip.ptr(dx),
+                  _hip.ptr(dgb), _hip.ptr(ws), ws_bytes, M, F, eps, st)
+            return dx, dgb[:F], dgb[F:]
+
+        g2 = g.reshape(M, -1).contiguous()
+        dw2, db2 = wgrad(g2, h1, w2.shape[0], w2.shape[1])
+        gh1 = g2.matmul(w2)
+        gp1, dg1, dbe1 = ln_bwd(gh1, p1, g1, ctx.eps[1])
+        dw1, db1 = wgrad(gp1, h0, w1.shape[0], w1.shape[1])
+        gh0 = gp1.matmul(w1)
+        gp0, dg0, dbe0 = ln_bwd(gh0, p0, g0, ctx.eps[0])
+        dw0, db0 = wgrad(gp0, x2, w0.shape[0], w0.shape[1])
+        gx = gp0.matmul(w0).view(ctx.xshape) if need[0] else None
+        hb = ctx.has_bias
+        return (gx, dw0, db0 if hb[0] else None, dg0, dbe0, dw1, db1 if hb[1] else None, dg1, dbe1,
+                dw2, db2 if hb[2] else None, None, None)
+
+
 def edge_network_forward(net, x):
-    """net(x) for the default architecture on device rows, through the row-split kernels."""
+    """net(x) for the default architecture on device rows: one autograd node over the row-split
+    kernels; anything else is called as the torch module it is."""
     mods = default_edge_network(net)
     if mods is None or not x.is_cuda or x.dtype != _f32 or x.numel() // x.shape[-1] < 2048:
         return net(x)
     l0, _, n0, l1, _, n1, l2 = mods
-    lin = skinny_linear if torch.is_grad_enabled() else torch.nn.functional.linear
-    h = lin(x, l0.weight, l0.bias)
-    h = relu_layernorm(h, n0.weight, n0.bias, n0.eps)
-    h = lin(h, l1.weight, l1.bias)
-    h = relu_layernorm(h, n1.weight, n1.bias, n1.eps)
-    return lin(h, l2.weight, l2.bias)
+    return _EdgeMLP.apply(x, l0.weight, l0.bias, n0.weight, n0.bias, l1.weight, l1.bias, n1.weight, n1.bias,
+                          l2.weight, l2.bias, n0.eps, n1.eps)
 
 
 # ===========================================================================
