@@ -990,28 +990,71 @@ def default_edge_network(net):
     return mods
 
 
+def _mlp_fwd(x2, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1):
+    """Linear - ReLU - LayerNorm - Linear - ReLU - LayerNorm - Linear on rows x2 [M, I];
+    -> (out [M, O], tensors the backward needs)."""
+    lin = torch.nn.functional.linear
+    M = x2.shape[0]
+    st = _hip.stream()
+    p0 = lin(x2, w0, b0)                                   # pre-activations are saved,
+    h0 = torch.empty_like(p0)                              # the row statistics recomputed
+    _call("gcm_relu_layernorm_fwd", _hip.ptr(p0), _hip.ptr(g0), _hip.ptr(be0), _hip.ptr(h0), M,
+          p0.shape[1], eps0, st)
+    p1 = lin(h0, w1, b1)
+    h1 = torch.empty_like(p1)
+    _call("gcm_relu_layernorm_fwd", _hip.ptr(p1), _hip.ptr(g1), _hip.ptr(be1), _hip.ptr(h1), M,
+          p1.shape[1], eps1, st)
+    return lin(h1, w2, b2), (x2, p0, h0, p1, h1, w0, g0, w1, g1, w2)
+
+
+def _mlp_bwd(g2, saved, eps, has_bias, need_x):
+    """adjoint of _mlp_fwd for g2 [M, O] -> (g_x2 | None, [dw0, db0, dg0, dbe0, dw1, db1, dg1, dbe1, dw2, db2])"""
+    x2, p0, h0, p1, h1, w0, g0, w1, g1, w2 = saved
+    lib = _hip.lib()
+    st = _hip.stream()
+    dev = x2.device
+    M = x2.shape[0]
+
+    def wgrad(gy, xin, O, I):
+        ws_bytes = lib.gcm_skinny_wgrad_workspace_bytes(M, O, I)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty(O * I + O, device=dev, dtype=_f32)
+        _call("gcm_skinny_wgrad", _hip.ptr(gy), _hip.ptr(xin), _hip.ptr(out), _hip.ptr(ws), ws_bytes,
+              M, O, I, st)
+        return out[:O * I].view(O, I), out[O * I:]
+
+    def ln_bwd(gy, pre, gamma, e):
+        F = pre.shape[1]
+        dx = torch.empty_like(pre)
+        dgb = torch.empty(2 * F, device=dev, dtype=_f32)
+        ws_bytes = lib.gcm_relu_layernorm_bwd_workspace_bytes(M, F)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _call("gcm_relu_layernorm_bwd", _hip.ptr(gy), _hip.ptr(pre), _hip.ptr(gamma), _hip.ptr(dx),
+              _hip.ptr(dgb), _hip.ptr(ws), ws_bytes, M, F, e, st)
+        return dx, dgb[:F], dgb[F:]
+
+    dw2, db2 = wgrad(g2, h1, w2.shape[0], w2.shape[1])
+    gp1, dg1, dbe1 = ln_bwd(g2.matmul(w2), p1, g1, eps[1])
+    dw1, db1 = wgrad(gp1, h0, w1.shape[0], w1.shape[1])
+    gp0, dg0, dbe0 = ln_bwd(gp1.matmul(w1), p0, g0, eps[0])
+    dw0, db0 = wgrad(gp0, x2, w0.shape[0], w0.shape[1])
+    gx = gp0.matmul(w0) if need_x else None
+    hb = has_bias
+    return gx, [dw0, db0 if hb[0] else None, dg0, dbe0, dw1, db1 if hb[1] else None, dg1, dbe1, dw2,
+                db2 if hb[2] else None]
+
+
 class _EdgeMLP(torch.autograd.Function):
     """The default edge network (learned.py:38-51) as ONE autograd node: Linear - ReLU - LayerNorm -
-    Linear - ReLU - LayerNorm - Linear on M = B*N candidate rows.  Same kernels and library GEMMs
-    as the module-by-module path (skinny_linear / relu_layernorm), chained by hand in both
-    directions: five Python-level autograd nodes per step become one."""
+    Linear - ReLU - LayerNorm - Linear on M candidate rows.  Same kernels and library GEMMs as the
+    module-by-module path (skinny_linear / relu_layernorm), chained by hand in both directions:
+    five Python-level autograd nodes per step become one."""
 
     @staticmethod
     def forward(ctx, x, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1):
-        lin = torch.nn.functional.linear
         x2 = x.reshape(-1, x.shape[-1])
-        M = x2.shape[0]
-        p0 = lin(x2, w0, b0)                                   # pre-activations are saved,
-        h0 = torch.empty_like(p0)                              # the normalised rows recomputed
-        st = _hip.stream()
-        _call("gcm_relu_layernorm_fwd", _hip.ptr(p0), _hip.ptr(g0), _hip.ptr(be0), _hip.ptr(h0), M,
-              p0.shape[1], eps0, st)
-        p1 = lin(h0, w1, b1)
-        h1 = torch.empty_like(p1)
-        _call("gcm_relu_layernorm_fwd", _hip.ptr(p1), _hip.ptr(g1), _hip.ptr(be1), _hip.ptr(h1), M,
-              p1.shape[1], eps1, st)
-        out = lin(h1, w2, b2)
-        ctx.save_for_backward(x2, p0, h0, p1, h1, w0, g0, w1, g1, w2)
+        out, saved = _mlp_fwd(x2, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1)
+        ctx.save_for_backward(*saved)
         ctx.eps = (eps0, eps1)
         ctx.has_bias = (b0 is not None, b1 is not None, b2 is not None)
         ctx.xshape = x.shape
@@ -1019,43 +1062,70 @@ class _EdgeMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        x2, p0, h0, p1, h1, w0, g0, w1, g1, w2 = ctx.saved_tensors
-        lib = _hip.lib()
+        saved = ctx.saved_tensors
+        g2 = g.reshape(saved[0].shape[0], -1).contiguous()
+        gx, pg = _mlp_bwd(g2, saved, ctx.eps, ctx.has_bias, ctx.needs_input_grad[0])
+        return (gx.view(ctx.xshape) if gx is not None else None, *pg, None, None)
+
+
+class _LearnedEdgeDefault(torch.autograd.Function):
+    """Dense LearnedEdge with the default edge network as ONE autograd node (learned.py:53-113):
+    candidate pairs, edge network, gumbel noise, gumbel-softmax + STE + adjacency-row write (in
+    place on `adj`, which the caller owns).  `noise` None = draw it here with the device RNG the
+    way torch.nn.functional.gumbel_softmax does."""
+
+    @staticmethod
+    def forward(ctx, nodes, adj, cur, noise, cutoff, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1):
+        nodes = nodes.contiguous()
+        _hip.on_device(nodes, adj, cur)
+        B, N, F = nodes.shape
         st = _hip.stream()
-        dev = x2.device
-        M = x2.shape[0]
-        need = ctx.needs_input_grad
+        pairs = torch.empty(B * N, 2 * F, device=nodes.device, dtype=_f32)
+        _call("gcm_learned_pairs_fwd", _hip.ptr(nodes), _hip.ptr(cur), _hip.ptr(pairs), B, N, F, st)
+        logits, saved = _mlp_fwd(pairs, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1)
+        logits = logits.view(B, N)
+        if noise is None:
+            noise = -torch.empty_like(logits).exponential_().log()
+        noise = noise.contiguous()
+        soft = torch.empty(B, N, device=adj.device, dtype=_f32)
+        _call("gcm_learned_select_fwd", _hip.ptr(logits), _hip.ptr(noise), _hip.ptr(cur), float(cutoff),
+              _hip.ptr(adj), _hip.ptr(soft), B, N, st)
+        ctx.mark_dirty(adj)
+        ctx.save_for_backward(soft, cur, *saved)
+        ctx.eps = (eps0, eps1)
+        ctx.has_bias = (b0 is not None, b1 is not None, b2 is not None)
+        ctx.dims = (B, N, F)
+        return adj
 
-        def wgrad(gy, xin, O, I):
-            ws_bytes = lib.gcm_skinny_wgrad_workspace_bytes(M, O, I)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            out = torch.empty(O * I + O, device=dev, dtype=_f32)
-            _call("gcm_skinny_wgrad", _hip.ptr(gy), _hip.ptr(xin), _hip.ptr(out), _hip.ptr(ws), ws_bytes,
-                  M, O, I, st)
-            return out[:O * I].view(O, I), out[O * I:]
+    @staticmethod
+    def backward(ctx, g_adj):
+        soft, cur, *saved = ctx.saved_tensors
+        B, N, F = ctx.dims
+        st = _hip.stream()
+        g_adj = g_adj.contiguous()
+        g_logits = torch.empty(B * N, 1, device=g_adj.device, dtype=_f32)
+        _call("gcm_learned_select_bwd", _hip.ptr(g_adj), _hip.ptr(soft), _hip.ptr(cur), _hip.ptr(g_logits),
+              B, N, st)
+        g_pairs, pg = _mlp_bwd(g_logits, saved, ctx.eps, ctx.has_bias, ctx.needs_input_grad[0])
+        g_nodes = None
+        if g_pairs is not None:
+            g_nodes = torch.empty(B, N, F, device=g_adj.device, dtype=_f32)
+            _call("gcm_learned_pairs_bwd", _hip.ptr(g_pairs), _hip.ptr(cur), _hip.ptr(g_nodes), B, N, F, st)
+        # both straight-through estimators are identities: the incoming adjacency receives g_adj
+        # unchanged, also at the rewritten entries (learned.py:108-110 adds adj inside the STE)
+        return (g_nodes, g_adj, None, None, None, *pg, None, None)
 
-        def ln_bwd(gy, pre, gamma, eps):
-            F = pre.shape[1]
-            dx = torch.empty_like(pre)
-            dgb = torch.empty(2 * F, device=dev, dtype=_f32)
-            ws_bytes = lib.gcm_relu_layernorm_bwd_workspace_bytes(M, F)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _call("gcm_relu_layernorm_bwd", _hip.ptr(gy), _hip.ptr(pre), _hip.ptr(gamma), _hip.ptr(dx),
-                  _hip.ptr(dgb), _hip.ptr(ws), ws_bytes, M, F, eps, st)
-            return dx, dgb[:F], dgb[F:]
 
-        g2 = g.reshape(M, -1).contiguous()
-        dw2, db2 = wgrad(g2, h1, w2.shape[0], w2.shape[1])
-        gh1 = g2.matmul(w2)
-        gp1, dg1, dbe1 = ln_bwd(gh1, p1, g1, ctx.eps[1])
-        dw1, db1 = wgrad(gp1, h0, w1.shape[0], w1.shape[1])
-        gh0 = gp1.matmul(w1)
-        gp0, dg0, dbe0 = ln_bwd(gh0, p0, g0, ctx.eps[0])
-        dw0, db0 = wgrad(gp0, x2, w0.shape[0], w0.shape[1])
-        gx = gp0.matmul(w0).view(ctx.xshape) if need[0] else None
-        hb = ctx.has_bias
-        return (gx, dw0, db0 if hb[0] else None, dg0, dbe0, dw1, db1 if hb[1] else None, dg1, dbe1,
-                dw2, db2 if hb[2] else None, None, None)
+def learned_edge_default(net, nodes, adj, cur, noise, cutoff):
+    """The fused dense LearnedEdge when `net` is the default edge network on device tensors, else None."""
+    mods = default_edge_network(net)
+    if mods is None or not nodes.is_cuda or nodes.dtype != _f32 or nodes.shape[0] * nodes.shape[1] < 2048:
+        return None
+    l0, _, n0, l1, _, n1, l2 = mods
+    if l2.out_features != 1 or l0.in_features != 2 * nodes.shape[2]:
+        return None
+    return _LearnedEdgeDefault.apply(nodes, adj, cur, noise, cutoff, l0.weight, l0.bias, n0.weight, n0.bias,
+                                     l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n0.eps, n1.eps)
 
 
 def edge_network_forward(net, x):

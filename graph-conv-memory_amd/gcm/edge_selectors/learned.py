@@ -46,13 +46,18 @@ class LearnedEdge(torch.nn.Module):
     def compute_new_adj(self, nodes, num_nodes, adj, B):
         """learned.py:53-113.  `adj` is rewritten in place (the caller hands over its own
         buffer, as DenseGCM does) and returned."""
+        cutoff = 1 / (1 + self.num_edge_samples)
+        if self.noise_fn is None:
+            # default edge network + device RNG: the whole selector is one autograd node
+            out = _ops.learned_edge_default(self.edge_network, nodes, adj, num_nodes, None, cutoff)
+            if out is not None:
+                return out
         pairs = _ops.learned_pairs(nodes, num_nodes)                  # [B, N, 2F]
         logits = _ops.edge_network_forward(self.edge_network, pairs).squeeze(-1)   # [B, N]
         if self.noise_fn is not None:
             noise = self.noise_fn(logits)
         else:
             noise = -torch.empty_like(logits).exponential_().log()
-        cutoff = 1 / (1 + self.num_edge_samples)
         return _ops.learned_select_(adj, logits, noise, num_nodes, cutoff)
 
     def forward(self, nodes, adj, weights, num_nodes, B):

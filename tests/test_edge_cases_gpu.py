@@ -349,3 +349,41 @@ def test_default_edge_network_path_matches_module():
     custom = torch.nn.Sequential(torch.nn.Linear(64, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).to(DEV)
     assert _ops.default_edge_network(custom) is None
     assert _ops.edge_network_forward(custom, x).shape == (64, 128, 1)
+
+
+def test_learned_edge_single_node_path_equals_stepwise_path():
+    """LearnedEdge with the default edge network and the device RNG runs as one autograd node;
+    with the same RNG state it must equal the op-by-op path (which the golden vectors pin) bit for
+    bit: adjacency, beliefs and every gradient."""
+    from gcm.gcm import DenseGCM
+    from gcm import nn as G
+    from gcm.edge_selectors.learned import LearnedEdge
+    B, N, F, H, T = 32, 64, 32, 32, 12          # B * N = 2048 rows: the fused selector applies
+
+    def build():
+        torch.manual_seed(11)
+        g = G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+                                                   (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+        sel = LearnedEdge(F).to(DEV)
+        return DenseGCM(g, edge_selectors=sel, graph_size=N), g, sel
+
+    obs = torch.rand(T, B, F, device=DEV)
+    res = []
+    for stepwise in (False, True):
+        mem, g, sel = build()
+        if stepwise:   # an explicit noise function takes the op-by-op path; same draws from the same RNG state
+            sel.noise_fn = lambda logits: -torch.empty_like(logits).exponential_().log()
+        torch.manual_seed(99)
+        o = obs.clone().requires_grad_(True)
+        hid, outs = None, []
+        for t in range(T):
+            mx, hid = mem(o[t], hid)
+            outs.append(mx)
+        torch.stack(outs).square().sum().backward()
+        res.append((torch.stack(outs).detach(), hid[1].detach(), o.grad,
+                    [p.grad.clone() for p in list(g.parameters()) + list(sel.parameters())]))
+    assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].sum()) > 0
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b)
