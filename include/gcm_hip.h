@@ -13,7 +13,8 @@
  *   - nothing is allocated inside; kernels that need scratch take
  *     `workspace` + `workspace_bytes`, sized by the matching *_workspace_bytes;
  *   - `stream` is a hipStream_t; calls are asynchronous and HIP-graph capturable; the
- *     only process state is a one-time "dynamic LDS size allowed" attribute per kernel;
+ *     only process state is a one-time "dynamic LDS size allowed" attribute per kernel and
+ *     the cached compute-unit count of the device (gcm_dense_bptt_batched_slabs);
  *   - return 0 on success, GCM_E* (<0) for an argument error detected on the
  *     host, or a positive hipError_t from the launch.
  */
