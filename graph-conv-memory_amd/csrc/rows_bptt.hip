@@ -1,0 +1,283 @@
+// Time-parallel backward of the live-row DenseGCM step (rows_step.hip) for the parameters of the
+// canonical 2-layer GNN.
+//
+// When neither the observations nor the incoming node matrix need a gradient (the reference's own
+// speed test and RL training loops feed plain observations: tests/test_speed.py:44-63,
+// ray_gcm.py:200-202), the backward of step t depends on g_mx[t] and on what step t saved - on no
+// other step.  So the per-step autograd nodes only RECORD (saved record, g_mx) and the parameter
+// gate, which runs after all of them, hands every recorded graph-step ("item") to ONE launch of
+// this kernel.  The gradient is as sparse as the forward: G1 = dL/dh1 is non-zero on the live rows
+// only, so an item is a few hundred floats:
+//
+//     d2   = g_mx * act2'(mx)                                  [H2]
+//     u    = W2c^T d2          (dagg2 | dh1cur)                [2*H1]
+//     dW2c += d2 (x) v,  db2 += d2                             v = agg2 | h1[cur]
+//     G1_l = (coef_l * dagg2 + [l == l_cur] dh1cur) * act1'(h1_l)          for the L live rows
+//     dW1c += G1_l (x) [agg1_l | x_l],  db1 += G1_l
+//
+// One WAVE owns one item at a time: lane m holds column m of the outer products (d2 / G1 values are
+// broadcast with v_readlane), so an item is ~100 + 64 L VALU instructions and no LDS traffic; the
+// gradient accumulates in registers across the items of a wave, the four waves of a workgroup
+// meet in LDS at the end, one slab per workgroup, summed in fixed order (deterministic).
+#include "gcm_common.h"
+#include "rows_common.h"
+
+#define GCM_ROWS_MAX_STEPS 64   /* steps per launch: two pointer tables in the kernel arguments */
+
+namespace gcm_rows {
+
+struct StepTable {
+  const float* saved[GCM_ROWS_MAX_STEPS];
+  const float* gmx[GCM_ROWS_MAX_STEPS];
+};
+
+__device__ __forceinline__ float act_grad_sel(float y, int act_v) {
+  float g = 1.f;
+  g = act_v == GCM_ACT_TANH ? 1.f - y * y : g;
+  g = act_v == GCM_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : g;
+  return g;
+}
+
+// FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
+// C2 = columns of v per lane (column m = lane + 64 c).
+template <int FP, int HP, int H2P>
+__global__ __launch_bounds__(256) void k_bptt_rows(
+    StepTable tab, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
+    const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
+    int B, int N, int F, int H1, int H2) {
+  constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  const int items = n_steps * B;
+  const int n_waves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+
+  // layer-2 weights, column m of W2c = [w_rel2 | w_root2] per lane: w2c[c][o]
+  float w2c[C2][H2P];
+#pragma unroll
+  for (int c = 0; c < C2; ++c) {
+    const int m = lane + 64 * c;
+    const bool ok = m < 2 * H1;
+    const int mc = ok ? m : 2 * H1 - 1;
+    const float* src = mc < H1 ? w_rel2 + mc : w_root2 + (mc - H1);
+#pragma unroll
+    for (int o = 0; o < H2P; ++o) {
+      const float t = src[(size_t)(o < H2 ? o : H2 - 1) * H1];
+      w2c[c][o] = (ok && o < H2) ? t : 0.f;
+    }
+  }
+  float acc1[C1][HP], acc2[C2][H2P];
+#pragma unroll
+  for (int c = 0; c < C1; ++c)
+#pragma unroll
+    for (int h = 0; h < HP; ++h) acc1[c][h] = 0.f;
+#pragma unroll
+  for (int c = 0; c < C2; ++c)
+#pragma unroll
+    for (int o = 0; o < H2P; ++o) acc2[c][o] = 0.f;
+  float db1 = 0.f, db2 = 0.f;
+
+#pragma unroll 1
+  for (int item = wid; item < items; item += n_waves) {
+    const int s = item / B, b = item - s * B;
+    const float* sv = tab.saved[s];
+    const float* gm = tab.gmx[s];
+    const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+    const int L = __builtin_amdgcn_readfirstlane(hdr[0]);
+    const int l_cur = __builtin_amdgcn_readfirstlane(hdr[1]);
+    const float* rows = sv + lay.o_rows + (size_t)b * N * lay.rw;
+    const float* coef = sv + lay.o_coef + (size_t)b * N;
+    // d2 in lane o < H2
+    const int oc = lane < H2 ? lane : H2 - 1;
+    const float g = gm[(long)b * gmx_sb + (long)oc * gmx_sh];
+    const float y = sv[(size_t)b * H2 + oc];
+    const float d2 = lane < H2 ? g * act_grad_sel(y, act2_v) : 0.f;
+    db2 += d2;
+    float vv[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {
+      const int m = lane + 64 * c;
+      const float t = sv[lay.o_v + (size_t)b * 2 * H1 + (m < 2 * H1 ? m : 2 * H1 - 1)];
+      vv[c] = m < 2 * H1 ? t : 0.f;
+    }
+    // first live row's loads in flight under the layer-2 arithmetic
+    float u[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) u[c] = 0.f;
+#pragma unroll
+    for (int o = 0; o < H2P; ++o) {
+      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o));
+#pragma unroll
+      for (int c = 0; c < C2; ++c) {
+        u[c] = fmaf(w2c[c][o], d, u[c]);
+        acc2[c][o] = fmaf(d, vv[c], acc2[c][o]);
+      }
+    }
+    // dagg2[h] = u at column h, dh1cur[h] = u at column H1 + h: bring both to lane h
+    float dagg2, dh1c;
+    {
+      const int hh = lane < H1 ? lane : 0;
+      const int m1 = H1 + hh;
+      float t0 = __shfl(u[0], hh & 63), t1 = __shfl(u[0], m1 & 63);
+      if (C2 == 2) {
+        const float a1 = __shfl(u[C2 - 1], hh & 63), b1 = __shfl(u[C2 - 1], m1 & 63);
+        t0 = hh >= 64 ? a1 : t0;
+        t1 = m1 >= 64 ? b1 : t1;
+      }
+      dagg2 = t0;
+      dh1c = t1;
+    }
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+      const float* row = rows + (size_t)l * lay.rw;
+      const float cf = coef[l];
+      const float hv = row[lane < H1 ? lane : H1 - 1];
+      float ax[C1];
+#pragma unroll
+      for (int c = 0; c < C1; ++c) {
+        const int m = lane + 64 * c;
+        const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
+        ax[c] = m < 2 * F ? t : 0.f;
+      }
+      float g1 = (cf * dagg2 + (l == l_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
+      g1 = lane < H1 ? g1 : 0.f;
+      db1 += g1;
+#pragma unroll
+      for (int h = 0; h < HP; ++h) {
+        const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
+#pragma unroll
+        for (int c = 0; c < C1; ++c) acc1[c][h] = fmaf(gh, ax[c], acc1[c][h]);
+      }
+    }
+  }
+
+  // ---- one slab per workgroup: the waves add their registers into LDS one after another ----------
+  // slab: dW_rel1 [H1*F] | dW_root1 [H1*F] | db1 [H1] | dW_rel2 [H2*H1] | dW_root2 [H2*H1] | db2 [H2]
+  extern __shared__ float sSlab[];
+  const int P = 2 * H1 * F + H1 + 2 * H2 * H1 + H2;
+  const int o_root1 = H1 * F, o_b1 = 2 * H1 * F, o_rel2 = o_b1 + H1, o_root2 = o_rel2 + H2 * H1;
+  const int o_b2 = o_root2 + H2 * H1;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int c = 0; c < C1; ++c) {
+        const int m = lane + 64 * c;
+        if (m < 2 * F) {
+          const int base = m < F ? m : o_root1 + (m - F);
+#pragma unroll
+          for (int h = 0; h < HP; ++h)
+            if (h < H1) {
+              float* d = sSlab + base + h * F;
+              *d = (w ? *d : 0.f) + acc1[c][h];
+            }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C2; ++c) {
+        const int m = lane + 64 * c;
+        if (m < 2 * H1) {
+          const int base = m < H1 ? o_rel2 + m : o_root2 + (m - H1);
+#pragma unroll
+          for (int o = 0; o < H2P; ++o)
+            if (o < H2) {
+              float* d = sSlab + base + o * H1;
+              *d = (w ? *d : 0.f) + acc2[c][o];
+            }
+        }
+      }
+      if (lane < H1) sSlab[o_b1 + lane] = (w ? sSlab[o_b1 + lane] : 0.f) + db1;
+      if (lane < H2) sSlab[o_b2 + lane] = (w ? sSlab[o_b2 + lane] : 0.f) + db2;
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (size_t)blockIdx.x * P;
+  for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
+}
+
+template <int FP, int HP, int H2P>
+int launch_bptt(hipStream_t s, int grid, const StepTable& tab, int n_steps, long sb, long sh,
+                const float* w_rel2, const float* w_root2, int act1, int act2,
+                const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2) {
+  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  const size_t lds = sizeof(float) * P;
+  auto kern = k_bptt_rows<FP, HP, H2P>;
+  if (lds > 64 * 1024) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static size_t attr_set[64] = {};
+    size_t& cur = attr_set[dev & 63];
+    if (lds > cur) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      cur = lds;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, n_steps, sb, sh, w_rel2, w_root2, act1,
+                     act2, lay, slabs, B, N, F, H1, H2);
+  return gcm_launch_status();
+}
+
+}  // namespace gcm_rows
+
+extern "C" int gcm_dense_rows_bptt_slabs(int n_steps, int B) {
+  if (n_steps <= 0 || B <= 0) return 0;
+  const long items = (long)n_steps * B;
+  const long chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
+  // per launch: up to 512 workgroups of 4 waves (two per CU), at least one item per wave
+  long per = (items / chunks + 3) / 4;
+  if (per > 512) per = 512;
+  if (per < 1) per = 1;
+  return (int)(per * chunks);
+}
+
+extern "C" size_t gcm_dense_rows_bptt_workspace_bytes(int n_steps, int B, int F, int H1, int H2) {
+  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  return sizeof(float) * P * (size_t)gcm_dense_rows_bptt_slabs(n_steps, B);
+}
+
+/* saved_host / gmx_host: HOST arrays of n_steps device pointers (the record each step's forward
+ * wrote, and that step's g_mx [B, H2] with element strides gmx_stride_b / gmx_stride_h - an expanded
+ * gradient has stride 0).  g_params = g_params_prev (NULL = 0) + the parameter gradient. */
+extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_host,
+                                   int n_steps, long gmx_stride_b, long gmx_stride_h,
+                                   const float* params, int has_bias, int act1, int act2,
+                                   const float* g_params_prev, float* g_params, void* workspace,
+                                   size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                                   gcm_stream_t stream) {
+  GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace);
+  GCM_REQUIRE(n_steps > 0 && B > 0);
+  if (!gcm_dense_rows_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  if (workspace_bytes < gcm_dense_rows_bptt_workspace_bytes(n_steps, B, F, H1, H2))
+    return GCM_EWORKSPACE;
+  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
+  hipStream_t s = (hipStream_t)stream;
+  const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64, h2p = H2 <= 32 ? 32 : 64;
+  const int chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
+  const int total_slabs = gcm_dense_rows_bptt_slabs(n_steps, B);
+  const int per = total_slabs / chunks;
+  float* slabs = (float*)workspace;
+  for (int c = 0; c < chunks; ++c) {
+    const int s0 = c * GCM_ROWS_MAX_STEPS;
+    const int ns = n_steps - s0 < GCM_ROWS_MAX_STEPS ? n_steps - s0 : GCM_ROWS_MAX_STEPS;
+    gcm_rows::StepTable tab{};
+    for (int i = 0; i < ns; ++i) {
+      GCM_REQUIRE(saved_host[s0 + i] && gmx_host[s0 + i]);
+      tab.saved[i] = saved_host[s0 + i];
+      tab.gmx[i] = gmx_host[s0 + i];
+    }
+    float* sl = slabs + (size_t)c * per * P;
+    int rc = GCM_EUNSUPPORTED;
+#define GCM_RB(a, b_, cc)                                                                          \
+  if (fp == a && hp == b_ && h2p == cc)                                                            \
+    rc = gcm_rows::launch_bptt<a, b_, cc>(s, per, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,     \
+                                          w_root2, act1, act2, lay, sl, B, N, F, H1, H2);
+    GCM_RB(32, 32, 32) GCM_RB(32, 32, 64) GCM_RB(32, 64, 32) GCM_RB(32, 64, 64)
+    GCM_RB(64, 32, 32) GCM_RB(64, 32, 64) GCM_RB(64, 64, 32) GCM_RB(64, 64, 64)
+#undef GCM_RB
+    if (rc) return rc;
+  }
+  (void)has_bias;
+  return gcm_sum_slabs_acc(slabs, total_slabs, (int)P, g_params_prev, g_params, stream);
+}

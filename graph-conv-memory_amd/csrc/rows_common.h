@@ -1,0 +1,35 @@
+// The per-step record the live-row forward (rows_step.hip) saves for the time-parallel backward
+// (rows_bptt.hip).  One allocation per step, float offsets, 64-float aligned sections:
+//
+//   mx   [B, H2]          belief states (also the step's output tensor)
+//   v    [B, 2*H1]        agg2 | h1[cur]               (the input of layer 2)
+//   hdr  [B, 4] int32     L = number of live rows, l_cur = position of row cur in the list,
+//                         cur, wrapped
+//   coef [B, N]           adj[cur, j_l] for l < L      (compact, ascending j)
+//   rows [B, N, rw]       per live row l < L: h1[j_l] [H1] | agg1[j_l] [F] | x[j_l] [F]; rw = H1 + 2F
+//
+// Capacity is N rows per graph (DenseEdge makes every row <= cur live); only L rows are touched.
+#pragma once
+#include <stddef.h>
+
+namespace gcm_rows {
+
+struct SavedLayout {
+  size_t total, o_v, o_hdr, o_coef, o_rows;
+  int rw;
+};
+
+static inline size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+static inline SavedLayout make_layout(int B, int N, int F, int H1, int H2) {
+  SavedLayout l;
+  l.rw = H1 + 2 * F;
+  l.o_v = pad64((size_t)B * H2);
+  l.o_hdr = l.o_v + pad64((size_t)B * 2 * H1);
+  l.o_coef = l.o_hdr + pad64((size_t)B * 4);
+  l.o_rows = l.o_coef + pad64((size_t)B * N);
+  l.total = l.o_rows + pad64((size_t)B * N * l.rw);
+  return l;
+}
+
+}  // namespace gcm_rows

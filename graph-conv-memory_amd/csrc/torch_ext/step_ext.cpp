@@ -48,6 +48,12 @@ struct StepCfg {
     P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2);
   }
 
+  void update_descs(int64_t desc_ptr, int n_desc) {   // re-read device pointers (dist_param)
+    if (n_desc == (int)descs.size() && n_desc)
+      std::memcpy(descs.data(), reinterpret_cast<const void*>(desc_ptr),
+                  sizeof(gcm_selector_desc) * n_desc);
+  }
+
   void* workspace(int B, const at::Tensor& like, size_t* bytes) {
     *bytes = 0;
     if (!has_distance) return nullptr;
@@ -207,12 +213,166 @@ std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& node
                             (int64_t)is_head);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The live-row step (rows_step.hip / rows_bptt.hip): one kernel per forward step, donated or
+// functional state, and NO kernel per backward step - the step nodes record (saved record, g_mx)
+// in a holder owned by the parameter gate (gcm/_ops.py:_ParamGate), whose backward runs after all
+// of them and hands every recorded graph-step to one time-parallel launch (RowsHolder::flush).
+// Used when neither the observation nor the incoming node matrix needs a gradient.
+// ---------------------------------------------------------------------------------------------
+struct RowsHolder {
+  struct Rec {
+    at::Tensor buf, gmx;
+    int64_t B, sb, sh;
+  };
+  std::vector<Rec> recs;
+  int N, F, H1, H2, has_bias, act1, act2;
+  int64_t P;
+  at::Tensor zero_p;   // the defined (zero) gradient the head step of a chain returns
+
+  RowsHolder(int N_, int F_, int H1_, int H2_, int has_bias_, int act1_, int act2_)
+      : N(N_), F(F_), H1(H1_), H2(H2_), has_bias(has_bias_), act1(act1_), act2(act2_) {
+    P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2);
+  }
+
+  int64_t pending() const { return (int64_t)recs.size(); }
+  void clear() { recs.clear(); }
+
+  // g_params = g_prev (may be undefined) + the parameter gradient of every recorded step
+  at::Tensor flush(const at::Tensor& packed, const at::Tensor& g_prev, int64_t stream) {
+    if (recs.empty()) return g_prev;
+    at::Tensor prev = g_prev;
+    if (prev.defined() && (prev.scalar_type() != at::kFloat || !prev.is_contiguous()))
+      prev = prev.to(at::kFloat).contiguous();
+    size_t i = 0;
+    std::vector<const float*> sv, gm;
+    while (i < recs.size()) {   // runs of steps with the same batch size and gradient strides
+      size_t j = i;
+      sv.clear();
+      gm.clear();
+      while (j < recs.size() && recs[j].B == recs[i].B && recs[j].sb == recs[i].sb &&
+             recs[j].sh == recs[i].sh) {
+        sv.push_back(recs[j].buf.data_ptr<float>());
+        gm.push_back(recs[j].gmx.data_ptr<float>());
+        ++j;
+      }
+      const int n = (int)(j - i), B = (int)recs[i].B;
+      const size_t ws_bytes = gcm_dense_rows_bptt_workspace_bytes(n, B, F, H1, H2);
+      at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
+      at::Tensor out = at::empty({P}, packed.options());
+      const int rc = gcm_dense_rows_bptt(
+          sv.data(), gm.data(), n, (long)recs[i].sb, (long)recs[i].sh, packed.data_ptr<float>(),
+          has_bias, act1, act2, prev.defined() ? prev.data_ptr<float>() : nullptr,
+          out.data_ptr<float>(), ws.data_ptr(), ws_bytes, B, N, F, H1, H2,
+          reinterpret_cast<gcm_stream_t>(stream));
+      check(rc, "gcm_dense_rows_bptt");
+      prev = out;
+      i = j;
+    }
+    recs.clear();
+    return prev;
+  }
+};
+
+struct RowsStepFn : public torch::autograd::Function<RowsStepFn> {
+  // the only differentiable input is the (gated) packed parameter vector; mx the only output
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor packed, at::Tensor buf, int64_t B,
+                            int64_t H2, int64_t holder_handle, int64_t is_head) {
+    ctx->saved_data["buf"] = buf;
+    ctx->saved_data["holder"] = holder_handle;
+    ctx->saved_data["head"] = is_head;
+    ctx->set_materialize_grads(false);
+    return buf.narrow(0, 0, B * H2).view({B, H2});   // the record starts with the belief states
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    RowsHolder* holder = reinterpret_cast<RowsHolder*>(ctx->saved_data["holder"].toInt());
+    const bool is_head = ctx->saved_data["head"].toInt() != 0;
+    at::Tensor g_params;
+    if (grads[0].defined()) {
+      at::Tensor buf = ctx->saved_data["buf"].toTensor();
+      at::Tensor g = grads[0];
+      if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+      holder->recs.push_back({buf, g, g.size(0), g.stride(0), g.stride(1)});
+    }
+    if (is_head) {   // a defined gradient so that the gate is certain to run
+      if (!holder->zero_p.defined()) holder->zero_p = at::zeros({holder->P}, grads[0].defined()
+                                                                   ? grads[0].options().dtype(at::kFloat)
+                                                                   : ctx->saved_data["buf"].toTensor().options());
+      g_params = holder->zero_p;
+    }
+    return {g_params, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// -> {mx, nodes_out, adj_out, count_out}; donate: the three state tensors are the inputs themselves
+std::vector<at::Tensor> rows_step(const at::Tensor& obs, const at::Tensor& nodes_in,
+                                  const at::Tensor& adj_in, const at::Tensor& count_in,
+                                  const at::Tensor& packed, const at::Tensor& flags,
+                                  int64_t cfg_handle, int64_t stream, int64_t holder_handle,
+                                  bool donate, bool is_head) {
+  StepCfg* cfg = reinterpret_cast<StepCfg*>(cfg_handle);
+  TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() &&
+                  packed.is_cuda() && flags.is_cuda(),
+              "rows_step: every tensor must live on a HIP device (no CPU fallback)");
+  TORCH_CHECK(obs.scalar_type() == at::kFloat && nodes_in.scalar_type() == at::kFloat &&
+              adj_in.scalar_type() == at::kFloat && packed.scalar_type() == at::kFloat &&
+              count_in.scalar_type() == at::kLong && obs.is_contiguous() && nodes_in.is_contiguous() &&
+              adj_in.is_contiguous() && packed.is_contiguous() && count_in.is_contiguous());
+  const int64_t B = obs.size(0);
+  const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+  TORCH_CHECK(nodes_in.size(0) == B && nodes_in.size(1) == N && nodes_in.size(2) == F &&
+                  adj_in.size(0) == B && adj_in.size(1) == N && adj_in.size(2) == N &&
+                  count_in.size(0) == B && obs.size(1) == F,
+              "rows_step: hidden state and observation shapes disagree");
+  const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad() && holder_handle != 0;
+  size_t lay[6];
+  check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
+  at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+  at::Tensor nodes_out, adj_out, count_out;
+  if (donate) {
+    nodes_out = nodes_in;
+    adj_out = adj_in;
+    count_out = count_in;
+  } else {
+    const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * (int64_t)N * N);
+    at::Tensor st = at::empty({n_nodes + n_adj + pad64(2 * B)}, obs.options());
+    nodes_out = st.narrow(0, 0, B * N * F).view({B, N, F});
+    adj_out = st.narrow(0, n_nodes, B * (int64_t)N * N).view({B, N, N});
+    count_out = st.narrow(0, n_nodes + n_adj, 2 * B).view(at::kLong);
+  }
+  const int rc = gcm_dense_rows_step_fwd(
+      obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+      count_in.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), adj_out.data_ptr<float>(),
+      count_out.data_ptr<int64_t>(), nullptr, cfg->descs.empty() ? nullptr : cfg->descs.data(),
+      (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
+      buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
+      reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2,
+      reinterpret_cast<gcm_stream_t>(stream));
+  check(rc, "gcm_dense_rows_step_fwd");
+  at::Tensor mx = need_bwd ? RowsStepFn::apply(packed, buf, B, (int64_t)H2, holder_handle, (int64_t)is_head)
+                           : buf.narrow(0, 0, B * H2).view({B, H2});
+  return {mx, nodes_out, adj_out, count_out};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the fused DenseGCM step (host side of libgcm_hip.so)";
   pybind11::class_<StepCfg>(m, "StepCfg")
       .def(pybind11::init<int64_t, int, int, int, int, int, int, int, int>())
-      .def("handle", [](StepCfg& c) { return reinterpret_cast<int64_t>(&c); });
+      .def("handle", [](StepCfg& c) { return reinterpret_cast<int64_t>(&c); })
+      .def("update_descs", &StepCfg::update_descs);
   m.def("fused_step", &fused_step);
+  pybind11::class_<RowsHolder>(m, "RowsHolder")
+      .def(pybind11::init<int, int, int, int, int, int, int>())
+      .def("handle", [](RowsHolder& h) { return reinterpret_cast<int64_t>(&h); })
+      .def("pending", &RowsHolder::pending)
+      .def("clear", &RowsHolder::clear)
+      .def("flush", [](RowsHolder& h, const at::Tensor& packed, const c10::optional<at::Tensor>& g,
+                       int64_t stream) {
+        return h.flush(packed, g.has_value() ? *g : at::Tensor(), stream);
+      });
+  m.def("rows_step", &rows_step);
 }

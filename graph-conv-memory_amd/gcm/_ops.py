@@ -583,6 +583,17 @@ class StepConfig:
         self.fn_bwd = lib.gcm_dense_step_bwd
         self.has_distance = any(d.kind == _hip.SEL_DISTANCE for d in descs)
         self._cpp, self._cpp_handle, self._cpp_call = None, None, None
+        # the live-row step (rows_step.hip): index-writing selectors only, <= 16 hops in all
+        self.rows_ok = bool(
+            all(d.kind in (_hip.SEL_TEMPORAL, _hip.SEL_DENSE) for d in descs)
+            and sum(d.n_hops for d in descs if d.kind == _hip.SEL_TEMPORAL) <= 16
+            and lib.gcm_dense_rows_supported(N, F, H1, H2)
+            and _ext.module() is not None and hasattr(_ext.module(), "rows_step"))
+
+    def rows_holder(self):
+        """a fresh record holder for one packed parameter vector (C++: RowsHolder)"""
+        return _ext.module().RowsHolder(self.N, self.F, self.H1, self.H2, self.has_bias,
+                                        self.acts[0], self.acts[1])
 
     def cpp_handle(self):
         """address of the C++ twin of this config (0 when the torch extension is not built)"""
@@ -606,6 +617,21 @@ class StepConfig:
             c = (_ext.module().fused_step, h, self.device.index) if h else False
             self._cpp_call = c
         return c or None
+
+    @property
+    def rows_call(self):
+        return _ext.module().rows_step
+
+    def refresh_pointers(self):
+        """re-read the device pointers baked into the selector descriptors (a re-assigned
+        Distance.dist_param) into this config and its C++ twin"""
+        for i, (d, src) in enumerate(zip(self.descs, getattr(self, "desc_sources", ()))):
+            if d.kind == _hip.SEL_DISTANCE and src is not None:
+                p = src()
+                d.dist_param = p
+                self.arr[i].dist_param = p
+        if self._cpp is not None:
+            self._cpp.update_descs(self.arr_ptr, self.n_desc)
 
     def workspace(self, B):
         if not self.has_distance:
@@ -751,18 +777,23 @@ class SlabHolder:
 
 class _ParamGate(torch.autograd.Function):
     """Identity on the packed parameter vector, placed between it and the step nodes: its backward
-    runs after every step node of the pass (they are its consumers) and adds the ONE sum of the
-    slab arrays the steps accumulated into - instead of T slab sums and T engine-side adds."""
+    runs after every step node of the pass (they are its consumers) and produces the parameter
+    gradient of ALL of them at once -
+      * fused-step nodes (gcm_dense_step_bwd_slabs) accumulated per-graph slabs into `holder`:
+        one slab sum instead of T slab sums and T engine-side adds;
+      * live-row step nodes (rows_step.hip) only recorded (saved record, g_mx) in `rows`: one
+        time-parallel launch over every recorded graph-step (gcm_dense_rows_bptt)."""
 
     @staticmethod
-    def forward(ctx, packed, holder):
-        ctx.holder = holder
+    def forward(ctx, packed, holder, rows):
+        ctx.holder, ctx.rows = holder, rows
+        ctx.packed = packed.detach()
         ctx.set_materialize_grads(False)
         return packed.view_as(packed)
 
     @staticmethod
     def backward(ctx, g):
-        holder = ctx.holder
+        holder, rows = ctx.holder, ctx.rows
         total = g
         for B, slabs in holder.slabs.items():
             out = torch.empty(holder.P, device=slabs.device, dtype=_f32)
@@ -770,11 +801,14 @@ class _ParamGate(torch.autograd.Function):
                   _hip.stream())
             slabs.zero_()
             total = out
-        return total, None
+        if rows is not None and rows.pending():
+            total = rows.flush(ctx.packed, total,
+                               torch._C._cuda_getCurrentRawStream(ctx.packed.device.index))
+        return total, None, None
 
 
-def param_gate(packed, holder):
-    return _ParamGate.apply(packed, holder)
+def param_gate(packed, holder, rows=None):
+    return _ParamGate.apply(packed, holder, rows)
 
 
 def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg, slab_acc=None, is_head=True):

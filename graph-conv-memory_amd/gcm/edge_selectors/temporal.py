@@ -26,11 +26,13 @@ class TemporalBackedge(torch.nn.Module):
     def native_desc(self):
         """Descriptor for the fused / rollout paths (struct gcm_selector_desc)."""
         from .. import _hip
+        if len(self.hops) > 16:       # the descriptor holds 16 hops: the layered path takes over
+            return None
         d = _hip.SelectorDesc(kind=_hip.SEL_TEMPORAL, n_hops=len(self.hops),
                               direction=_hip.DIR[self.direction])
         for i, h in enumerate(self.hops):
             d.hops[i] = h
-        return d if len(self.hops) <= 16 else None
+        return d
 
     def forward(self, nodes, adj_mats, edge_weights, num_nodes, B):
         """temporal.py:72-88: for every hop and every graph with num_nodes >= hop set

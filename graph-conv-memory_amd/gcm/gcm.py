@@ -85,6 +85,7 @@ class DenseGCM(torch.nn.Module):
         poll_interval: int = 16,
         mutate_num_nodes_on_overflow: bool = False,
         fused: bool = True,
+        donate_state: bool = False,
     ):
         super().__init__()
         assert finite_check in ("deferred", "sync", "off")
@@ -105,6 +106,13 @@ class DenseGCM(torch.nn.Module):
         # selectors are native non-differentiable ones, a step runs as state-advance + selector
         # kernels + ONE fused GNN kernel under ONE autograd node (csrc/fused.hip)
         self.fused = fused
+        # donate_state=True: the caller hands over the hidden state it passes in; the step advances
+        # `nodes`, `adj` and `num_nodes` IN PLACE and returns the same tensors (no per-step clone of
+        # the state, gcm.py:262,278,286).  Results are identical; a caller that keeps older hidden
+        # states around (they would all alias the newest one) must leave this off.  Takes effect on
+        # the live-row path (index-writing selectors, canonical GNN, no gradient w.r.t. obs / nodes);
+        # every other case falls back to functional semantics.
+        self.donate_state = donate_state
         self._plan_cache = None
         self._token = object()   # identifies hidden states produced by this module (_gcm_link)
         self._cfg_cache = {}
@@ -112,6 +120,7 @@ class DenseGCM(torch.nn.Module):
         self._packed_cache = None
         self._flags = {}      # device -> uint32[1] flag word written by the kernels
         self._pending = []    # [(pinned host copy, event)] of flag words in flight
+        self._pinned_pool = []
         self._steps = 0
 
     # -- state ---------------------------------------------------------------
@@ -149,20 +158,30 @@ class DenseGCM(torch.nn.Module):
         """Surface anything the kernels flagged so far.  block=False only looks at
         flag copies that have already landed on the host."""
         if block:
+            bits = 0
+            for host, ev in self._pending:     # copies in flight carry bits the device word
+                ev.synchronize()               # no longer has (it was zeroed behind each copy)
+                bits |= int(host.item())
+            self._pending.clear()
             for dev, f in self._flags.items():
-                bits = int(f.item())
-                f.zero_()
-                self._pending.clear()
-                self._raise_for(bits)
+                b = int(f.item())
+                if b:
+                    f.zero_()
+                bits |= b
+            self._raise_for(bits)
             return
         while self._pending and self._pending[0][1].query():
-            host, _ = self._pending.pop(0)
-            self._raise_for(int(host.item()))
+            host, ev = self._pending.pop(0)
+            bits = int(host.item())
+            self._pinned_pool.append((host, ev))
+            self._raise_for(bits)
 
     def _poll(self, flags):
         self._steps += 1
         if self.finite_check == "deferred" and self._steps % self.poll_interval:
             return                        # the common step: nothing to look at
+        if torch.cuda.is_current_stream_capturing():
+            return                        # inside a HIP-graph capture: the flag word is read later
         if self.finite_check == "sync":
             bits = int(flags.item())
             if bits:
@@ -170,14 +189,21 @@ class DenseGCM(torch.nn.Module):
             self._raise_for(bits)
         elif self.finite_check == "deferred":
             self.check_flags(block=False)
-            if self._steps % self.poll_interval == 0:
-                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                host.copy_(flags, non_blocking=True)
-                flags.zero_()
-                ev = torch.cuda.Event()
-                ev.record()
-                self._pending.append((host, ev))
+            self._enqueue_flag_copy(flags)
 
+    def _enqueue_flag_copy(self, flags):
+        """async copy of the flag word to a pinned host word (recycled), zeroing it behind"""
+        pool = self._pinned_pool
+        host, ev = pool.pop() if pool else (torch.empty(1, dtype=torch.int32, pin_memory=True),
+                                            torch.cuda.Event())
+        host.copy_(flags, non_blocking=True)
+        flags.zero_()
+        ev.record()
+        self._pending.append((host, ev))
+        if len(self._pending) > 64:       # nobody is polling: fold the oldest back
+            h, e = self._pending.pop(0)
+            e.synchronize()
+            self._raise_for(int(h.item()))
 
     # -- fused fast path -----------------------------------------------------------
     def _structure(self):
@@ -238,7 +264,7 @@ class DenseGCM(torch.nn.Module):
         if st is None or weights.numel() != 0 or adj.requires_grad or not nodes.is_cuda:
             return None
         last = self._cfg_last
-        if last is not None and last[0] == nodes.shape[1] and last[1] == F and last[2] is nodes.device:
+        if last is not None and last[0] == nodes.shape[1] and last[1] == F and last[2] == nodes.device:
             return last[3]
         key = (nodes.shape[1], F, nodes.device)
         cached = self._cfg_cache.get(key)
@@ -255,23 +281,29 @@ class DenseGCM(torch.nn.Module):
                            (2 if convs[1].lin_rel.bias is not None else 0)
                 cfg = _ops.StepConfig(descs, acts, has_bias, N, F, H1, H2, nodes.device)
                 cfg.convs = convs
+                cfg.desc_sources = [
+                    (lambda m=m: m.dist_param.data_ptr() if m.learned else None)
+                    if isinstance(m, Distance) else None for m in mods]
                 cfg.lins = (convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel, convs[1].lin_root)
         self._cfg_cache[key] = cfg
         if cfg is not False:
             self._cfg_last = (nodes.shape[1], F, nodes.device, cfg)
         return cfg if cfg is not False else None
 
-    def _packed_params(self, cfg):
+    def _packed_params(self, cfg, head=False):
         """The six GNN tensors as one flat vector (layout of include/gcm_hip.h "packed parameter
-        vector"), so that a step returns ONE gradient tensor.  Rebuilt when a parameter changed
-        or after the previous vector took part in a backward pass."""
+        vector"), so that a step returns ONE gradient tensor.  Rebuilt at the head of every chain
+        of hidden states (`head`: hidden is None or not produced by this module - the reference
+        reads live parameters, and writes through `.data` / `module.float()` bump no version
+        counter), when a parameter changed, or after the previous vector took part in a backward
+        pass; reused only inside a linked chain."""
         # current parameter tensors through the modules' own dicts (nn.Module.__getattr__ chains
         # cost ~0.5 us each and this runs every step)
         (rel0, root0, rel1, root1) = cfg.lins
         tensors = (rel0._parameters["weight"], root0._parameters["weight"], rel0._parameters["bias"],
                    rel1._parameters["weight"], root1._parameters["weight"], rel1._parameters["bias"])
         cache = self._packed_cache
-        if cache is not None and not cache[2][0] and cache[0] == torch.is_grad_enabled():
+        if cache is not None and not head and not cache[2][0] and cache[0] == torch.is_grad_enabled():
             # valid while the very same tensor objects have not been written to (optimizer steps
             # bump _version; re-assigned Parameters are new objects)
             live = True
@@ -288,17 +320,62 @@ class DenseGCM(torch.nn.Module):
                  for t, n in zip(tensors, sizes)]
         packed = torch.cat(parts)
         used = [False]
-        gated = holder = None
+        gated = holder = rows = None
         if packed.requires_grad:
             packed.register_hook(lambda g: used.__setitem__(0, True))
             holder = _ops.SlabHolder(cfg.P, dev)
-            gated = _ops.param_gate(packed, holder)
+            rows = cfg.rows_holder() if cfg.rows_ok else None
+            gated = _ops.param_gate(packed, holder, rows)
+        for d in cfg.descs:               # a re-assigned dist_param must not leave a stale pointer
+            if d.kind == _hip.SEL_DISTANCE:
+                cfg.refresh_pointers()
+                break
         self._packed_cache = (key, packed, used,
-                              [(t, t._version if t is not None else 0) for t in tensors], gated, holder)
+                              [(t, t._version if t is not None else 0) for t in tensors], gated, holder,
+                              rows)
         return packed
 
+    def _forward_rows(self, x, hidden, cfg, flags, link):
+        """The live-row step (csrc/rows_step.hip): one kernel forward, no kernel backward (the
+        parameter gate launches one time-parallel pass over every recorded step).  Taken when
+        neither x nor the incoming node matrix needs a gradient."""
+        nodes, adj, weights, num_nodes = hidden
+        root = self._packed_params(cfg, head=link is None)
+        pc = self._packed_cache
+        gated, rows = pc[4], pc[6]
+        if gated is not None:
+            packed, hh = gated, rows.handle()
+            is_head = link is None or link[5] is not root
+        else:
+            packed, hh, is_head = root, 0, True
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if link is None and not (nodes.is_contiguous() and adj.is_contiguous()
+                                 and num_nodes.is_contiguous()):
+            if self.donate_state:
+                raise ValueError("donate_state=True needs contiguous hidden-state tensors")
+            nodes, adj, num_nodes = nodes.contiguous(), adj.contiguous(), num_nodes.contiguous()
+        donate = self.donate_state
+        fn, handle, dev_index = cfg.cpp_call()
+        mx, n2, a2, c2 = cfg.rows_call(
+            x, nodes, adj, num_nodes, packed, flags, handle,
+            torch._C._cuda_getCurrentRawStream(dev_index), hh, donate, is_head)
+        if donate:
+            if link is None or link[5] is not root:
+                nodes._gcm_link = (self._token, adj, cfg, flags, None, root, x.shape, weights,
+                                   num_nodes)
+            out = hidden
+        else:
+            n2._gcm_link = (self._token, a2, cfg, flags, None, root, x.shape, weights, c2)
+            if self.mutate_num_nodes_on_overflow:
+                num_nodes.copy_(c2 - 1)
+            out = (n2, a2, weights, c2)
+        if self.finite_check != "off":
+            self._poll(flags)
+        return mx, out
+
     def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags, link=None):
-        root = self._packed_params(cfg)
+        root = self._packed_params(cfg, head=link is None)
         gated, holder = self._packed_cache[4], self._packed_cache[5]
         # In grad mode the steps consume the parameter vector through a gate node and accumulate
         # their parameter-gradient slabs into ONE array of the module (summed once by the gate,
@@ -342,11 +419,17 @@ class DenseGCM(torch.nn.Module):
                 mx, hidden = self(obs[t], hidden)
                 outs.append(mx)
             return torch.stack(outs), hidden
+        B, N = obs.shape[1], nodes.shape[1]
+        assert (nodes.shape[0], adj.shape, num_nodes.shape[0], nodes.shape[2]) == \
+            (B, (B, N, N), B, obs.shape[2]), "hidden state and observation shapes disagree"
         flags = self._flag_word(obs.device)
         mx_all, nodes_T, adj_T, count_T = _ops.fused_rollout(
-            obs, nodes, self._packed_params(cfg), adj, num_nodes, flags, cfg)
+            obs, nodes, self._packed_params(cfg, head=True), adj, num_nodes, flags, cfg)
         if self.finite_check == "sync":
             self.check_flags()
+        elif self.finite_check == "deferred" and not torch.cuda.is_current_stream_capturing():
+            self.check_flags(block=False)      # gcm.py:316-318 for rollout-only loops
+            self._enqueue_flag_copy(flags)
         return mx_all, (nodes_T, adj_T, weights, count_T)
 
     # -- the step --------------------------------------------------------------
@@ -366,7 +449,10 @@ class DenseGCM(torch.nn.Module):
         link = getattr(nodes, "_gcm_link", None)
         if (link is not None and link[0] is self._token and link[1] is adj and link[7] is weights
                 and link[8] is num_nodes and x.shape == link[6] and x.dtype is torch.float32):
-            return self._forward_fused(x, nodes, adj, weights, num_nodes, link[2], link[3], link)
+            cfg = link[2]
+            if cfg.rows_ok and not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad)):
+                return self._forward_rows(x, hidden, cfg, link[3], link)
+            return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, link[3], link)
 
         # gcm.py:246-260, as one comparison
         if (x.dtype, nodes.dtype, adj.dtype, weights.dtype, num_nodes.dtype, num_nodes.dim()) != _DTYPES:
@@ -383,6 +469,12 @@ class DenseGCM(torch.nn.Module):
         flags = self._flag_word(x.device)
         plan = self._fused_plan(nodes, adj, weights, x.shape[-1])
         if plan is not None:
+            # raw pointers from here on: the shapes must agree (the reference raises an indexing
+            # error on a mismatched hidden state)
+            assert (nodes.shape[0], adj.shape[0], num_nodes.shape[0], nodes.shape[2]) == \
+                (B, B, B, x.shape[1]), "hidden state and observation shapes disagree"
+            if plan.rows_ok and not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad)):
+                return self._forward_rows(x, hidden, plan, flags, None)
             return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
         # insert x at row num_nodes (after the overflow roll); fresh nodes/adj/weights buffers
         nodes, adj, weights, cur, num_nodes_next = _ops.state_advance(

@@ -372,6 +372,49 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
                              float* g_nodes_in, float* g_obs, float* slabs, int accumulate, int B,
                              int N, int F, int H1, int H2, gcm_stream_t stream);
 
+/* ---- the DenseGCM step on the LIVE ROWS, donated or functional state (gcm.py:213-321) ---------
+ *
+ * DenseGCM keeps row cur of the last GNN layer (gcm.py:314), so layer 1 is needed only on the rows
+ * j with adj[cur, j] != 0 and on row cur.  gcm_dense_rows_step_fwd evaluates exactly those rows
+ * (exact: the rest is multiplied by zero in the reference) and does the whole step in one kernel:
+ * overflow roll (gcm.py:323-355), node insert (:274), the index-writing selectors
+ * (GCM_SEL_TEMPORAL / GCM_SEL_DENSE; others: GCM_EUNSUPPORTED), both DenseGraphConv layers, the
+ * belief row and the finite flag.
+ *
+ * State ownership.  nodes_out == nodes_in AND adj_out == adj_in (count_out may equal count_in):
+ * the caller DONATES the state; it is advanced in place and only the inserted node, the
+ * selector's entries and the count are written - the reference's per-step clones
+ * (gcm.py:262,278,286) are not materialised.  Distinct output buffers: functional semantics, the
+ * kernel also streams the copy.  Results are identical either way.
+ *
+ * saved (may be NULL: inference): receives the record the time-parallel backward reads, laid out
+ * by gcm_dense_rows_layout (float offsets {total, v, hdr, coef, rows} and the row width); mx must
+ * then point at saved (the record starts with the [B,H2] belief states).
+ * Shapes: N <= 128, N % 4 == 0, F % 4 == 0, F, H1, H2 <= 64 (gcm_dense_rows_supported). */
+int gcm_dense_rows_supported(int N, int F, int H1, int H2);
+int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t* out6);
+int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, const float* adj_in,
+                            const int64_t* count_in, float* nodes_out, float* adj_out,
+                            int64_t* count_out, int64_t* cur_out /* may be NULL */,
+                            const gcm_selector_desc* selectors, int n_selectors,
+                            const float* params, int has_bias, int act1, int act2, float* mx,
+                            float* saved, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                            gcm_stream_t stream);
+
+/* Parameter gradient of n_steps recorded steps in one pass (time-parallel BPTT; valid when neither
+ * the observations nor the incoming node matrix need a gradient, so step t's adjoint depends on
+ * g_mx[t] and its own record only).  saved_host / gmx_host: HOST arrays of n_steps DEVICE pointers
+ * (each step's record and its g_mx [B,H2], element strides gmx_stride_b / gmx_stride_h; 0 for an
+ * expanded gradient).  g_params [param_count] = g_params_prev (NULL = 0) + gradient, laid out like
+ * the packed parameter vector.  workspace: gcm_dense_rows_bptt_workspace_bytes. */
+int gcm_dense_rows_bptt_slabs(int n_steps, int B);
+size_t gcm_dense_rows_bptt_workspace_bytes(int n_steps, int B, int F, int H1, int H2);
+int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                        long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias,
+                        int act1, int act2, const float* g_params_prev, float* g_params,
+                        void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
+                        int H2, gcm_stream_t stream);
+
 /* ---- time-batched rollout (caller loop ray_gcm.py:200-202) --------- */
 
 

@@ -1,0 +1,329 @@
+"""The live-row DenseGCM step (csrc/rows_step.hip, rows_bptt.hip): one kernel per forward step on
+the rows that reach the belief, donated or functional state, time-parallel parameter backward run by
+the gate.  Parity against the reference's golden vectors and the CPU oracle.  Needs an MI355X."""
+import ctypes
+
+import pytest
+import torch
+
+from _golden import Fixture, oracle_selector
+from oracle import dense as od
+from test_dense_gpu import dev_gnn_from, product_selector, DEV, RTOL, ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_taken(mem):
+    """True when the last rollout recorded live-row steps / has a rows holder."""
+    pc = mem._packed_cache
+    return pc is not None and pc[6] is not None
+
+
+GOLD = ["g1_temporal_h1", "g2_temporal_h124_both", "g1b_cfg1", "g5_dense_edge", "g13_exact_temporal",
+        "g13_exact_dense"]
+
+
+@pytest.mark.parametrize("donate", [False, True])
+@pytest.mark.parametrize("name", GOLD)
+def test_rows_path_matches_reference(name, donate):
+    """obs without gradient => the live-row kernels run (forward state bit exact, beliefs 1e-5,
+    parameter gradients from the time-parallel backward) - against the reference's own vectors."""
+    from gcm.gcm import DenseGCM
+    fx = Fixture(name)
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    mem = DenseGCM(g, edge_selectors=product_selector(m, fx.group("sel_param:")), graph_size=m["N"],
+                   donate_state=donate)
+    obs = fx["obs"].to(DEV)
+    h0 = fx.h0()
+    hidden = None if h0 is None else tuple(t.to(DEV).clone() for t in h0)
+    mxs, sums = [], []
+    for t in range(m["T"]):
+        mx, hidden = mem(obs[t], hidden)
+        mxs.append(mx)
+        sums.append(hidden[1].sum(dim=(1, 2)))
+    if m["N"] % 4 == 0 and m["F"] % 4 == 0:      # else: the fused kernels (same results)
+        assert _rows_taken(mem) and mem._packed_cache[6].pending() == 0
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    mem.check_flags()
+    assert torch.equal(hidden[1].cpu(), fx["hT_adj"])            # adjacency: bit exact
+    assert torch.equal(torch.stack(sums).cpu(), fx["adj_sums"])
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])
+    assert torch.equal(hidden[3].cpu(), fx["hT_num_nodes"])
+    atol = 5e-6 if m["selector"] == "dense" else ATOL
+    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=atol)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+
+
+CASES = [
+    # B, N, F, H1, H2, T, selector
+    (3, 8, 4, 16, 16, 13, ("temporal", [1, 2], "forward")),
+    (5, 12, 8, 8, 24, 30, ("temporal", [1, 3], "both")),
+    (4, 32, 32, 32, 32, 40, ("temporal", [1, 2, 4], "backward")),
+    (2, 128, 32, 32, 32, 140, ("temporal", [1, 2, 4], "forward")),
+    (3, 20, 12, 40, 8, 26, ("dense", None, None)),
+    (2, 64, 64, 64, 64, 70, ("dense", None, None)),
+    (2, 36, 36, 20, 44, 40, ("temporal", [2, 5], "both")),
+    (300, 16, 8, 16, 16, 20, ("temporal", [1], "forward")),
+]
+
+
+def _mk(B, N, F, H1, H2, sel, donate):
+    from gcm import nn as G
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.dense import DenseEdge
+    from oracle import pyg
+    ref = pyg.Sequential("x, adj, weights, B, N", [
+        (pyg.DenseGraphConv(F, H1), "x, adj -> x"), torch.nn.Tanh(),
+        (pyg.DenseGraphConv(H1, H2), "x, adj -> x"), torch.nn.Tanh()])
+    g = G.Sequential("x, adj, weights, B, N", [
+        (G.DenseGraphConv(F, H1), "x, adj -> x"), torch.nn.Tanh(),
+        (G.DenseGraphConv(H1, H2), "x, adj -> x"), torch.nn.Tanh()])
+    g.load_state_dict(ref.state_dict())
+    g = g.to(DEV)
+    if sel[0] == "temporal":
+        ps, osel = TemporalBackedge(sel[1], direction=sel[2]), od.TemporalBackedge(sel[1], sel[2])
+    else:
+        ps, osel = DenseEdge(), od.DenseEdge()
+    mem = DenseGCM(g, edge_selectors=ps, graph_size=N, donate_state=donate)
+    return ref, g, mem, osel
+
+
+@pytest.mark.parametrize("donate", [False, True])
+@pytest.mark.parametrize("case", CASES)
+def test_rows_path_vs_oracle(case, donate):
+    """Ragged and tile-exact shapes, staggered starts, overflow crossings, vs the CPU oracle."""
+    B, N, F, H1, H2, T, sel = case
+    torch.manual_seed(B * 31 + N)
+    ref, g, mem, osel = _mk(B, N, F, H1, H2, sel, donate)
+    obs = torch.rand(T, B, F)
+    # staggered starts: graph b already holds count0[b] nodes (and the matching temporal adjacency
+    # would be there too - the oracle and the product both start from this very state)
+    count0 = torch.randint(0, N + 1, (B,))
+    nodes0 = torch.rand(B, N, F) * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    adj0 = torch.zeros(B, N, N)
+    for b in range(B):
+        for i in range(1, int(count0[b])):
+            adj0[b, i, i - 1] = 1.0
+    h_o = (nodes0.clone(), adj0.clone(), torch.zeros(0), count0.clone())
+    h_d = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
+    out_c, hid_c = od.dense_rollout(obs, h_o, ref, graph_size=N, edge_selectors=osel)
+    wgt = torch.rand(T, B, H2)
+    (out_c * wgt).sum().backward()
+    obs_d = obs.to(DEV)
+    outs, hidden = [], h_d
+    for t in range(T):
+        mx, hidden = mem(obs_d[t], hidden)
+        outs.append(mx)
+    out_d = torch.stack(outs)
+    (out_d * wgt.to(DEV)).sum().backward()
+    mem.check_flags()
+    assert _rows_taken(mem)
+    if donate:   # the state was advanced in place: same tensor objects all the way
+        assert hidden[0] is h_d[0] and hidden[1] is h_d[1] and hidden[3] is h_d[3]
+    else:
+        assert torch.equal(h_d[0].cpu(), nodes0) and torch.equal(h_d[1].cpu(), adj0)
+        assert torch.equal(h_d[3].cpu(), count0)
+    assert torch.equal(hidden[1].cpu(), hid_c[1]) and torch.equal(hidden[0].cpu(), hid_c[0])
+    assert torch.equal(hidden[3].cpu(), hid_c[3])
+    atol = 2e-5 if sel[0] == "dense" else 2e-6
+    torch.testing.assert_close(out_d.cpu(), out_c, rtol=RTOL, atol=atol)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        scale = float(pc.grad.abs().max()) + 1e-12
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=2e-5 * scale, msg=k)
+
+
+def test_rows_foreign_adjacency():
+    """A caller's own state may hold anything: entries in row cur and beyond (the reference keeps
+    and uses them).  The live-row list is built from the real row, not from the selector."""
+    B, N, F, H = 4, 16, 8, 16
+    torch.manual_seed(3)
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("temporal", [1], "forward"), False)
+    count0 = torch.tensor([3, 5, 0, 9])
+    nodes0 = torch.rand(B, N, F)
+    adj0 = (torch.rand(B, N, N) < 0.3).float() * torch.rand(B, N, N).round(decimals=2)
+    obs = torch.rand(3, B, F)
+    out_c, hid_c = od.dense_rollout(obs, (nodes0.clone(), adj0.clone(), torch.zeros(0), count0.clone()),
+                                    ref, graph_size=N, edge_selectors=osel)
+    hidden = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
+    outs = []
+    with torch.no_grad():
+        for t in range(3):
+            mx, hidden = mem(obs[t].to(DEV), hidden)
+            outs.append(mx)
+    torch.testing.assert_close(torch.stack(outs).cpu(), out_c.detach(), rtol=RTOL, atol=5e-6)
+    assert torch.equal(hidden[1].cpu(), hid_c[1]) and torch.equal(hidden[0].cpu(), hid_c[0])
+
+
+def test_rows_step_c_abi_against_functional_kernel():
+    """gcm_dense_rows_step_fwd (donated and functional) against gcm_dense_step_fwd, raw C ABI."""
+    from gcm import _hip
+    lib = _hip.lib()
+    B, N, F, H = 7, 64, 32, 32
+    torch.manual_seed(0)
+    P = lib.gcm_dense_gnn2_param_count(F, H, H)
+    params = (torch.randn(P) * 0.2).to(DEV)
+    count = torch.tensor([0, 1, 5, 31, 63, 64, 40]).to(DEV)
+    nodes = torch.rand(B, N, F) * (torch.arange(N)[None, :, None] < count.cpu()[:, None, None])
+    nodes = nodes.to(DEV)
+    adj = torch.zeros(B, N, N)
+    for b in range(B):
+        for i in range(2, int(count[b])):
+            adj[b, i, i - 1] = adj[b, i, i - 2] = 1.0
+            adj[b, i - 2, i] = 1.0
+    adj = adj.to(DEV)
+    obs = torch.rand(B, F, device=DEV)
+    d = _hip.SelectorDesc(kind=_hip.SEL_TEMPORAL, n_hops=2, direction=_hip.DIR["both"])
+    d.hops[0], d.hops[1] = 1, 2
+    arr = (_hip.SelectorDesc * 1)(d)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st = _hip.stream()
+    p = _hip.ptr
+    # functional reference kernels
+    n_ref, a_ref = torch.empty_like(nodes), torch.empty_like(adj)
+    ib = torch.empty(2, B, dtype=torch.int64, device=DEV)
+    mx_ref = torch.empty(B, H, device=DEV)
+    rc = lib.gcm_dense_step_fwd(p(obs), p(nodes), p(adj), p(count), p(n_ref), p(a_ref), ib.data_ptr(),
+                                ib.data_ptr() + 8 * B, ctypes.addressof(arr), 1, p(params), 3, 1, 1,
+                                p(mx_ref), None, None, None, p(flags), None, 0, B, N, F, H, H, st)
+    assert rc == 0
+    lay = (ctypes.c_size_t * 6)()
+    assert lib.gcm_dense_rows_layout(B, N, F, H, H, ctypes.addressof(lay)) == 0
+    for donate in (False, True):
+        n_in, a_in, c_in = nodes.clone(), adj.clone(), count.clone()
+        n_out = n_in if donate else torch.empty_like(nodes)
+        a_out = a_in if donate else torch.empty_like(adj)
+        c_out = c_in if donate else torch.empty_like(count)
+        saved = torch.zeros(lay[0], device=DEV)
+        rc = lib.gcm_dense_rows_step_fwd(p(obs), p(n_in), p(a_in), p(c_in), p(n_out), p(a_out), p(c_out),
+                                         None, ctypes.addressof(arr), 1, p(params), 3, 1, 1, p(saved),
+                                         p(saved), p(flags), B, N, F, H, H, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(n_out, n_ref) and torch.equal(a_out, a_ref)
+        assert torch.equal(c_out, ib[1])
+        torch.testing.assert_close(saved[:B * H].view(B, H), mx_ref, rtol=RTOL, atol=ATOL)
+        if not donate:
+            assert torch.equal(n_in, nodes) and torch.equal(a_in, adj) and torch.equal(c_in, count)
+        hdr = saved[lay[2]:lay[2] + 4 * B].view(torch.int32).view(B, 4).cpu()
+        cur = (ib[0]).cpu()
+        assert torch.equal(hdr[:, 2].long(), cur)
+        want_L = torch.tensor([int((a_ref[b, int(cur[b])] != 0).sum()) + (0 if a_ref[b, int(cur[b]), int(cur[b])] != 0 else 1)
+                               for b in range(B)])
+        assert torch.equal(hdr[:, 0].long(), want_L)
+
+
+def test_rows_mixed_with_obs_gradient_steps():
+    """A chain whose observations need a gradient takes the fused kernels; switching between the
+    two kinds of step inside one chain keeps results and gradients right."""
+    B, N, F, H, T = 3, 32, 32, 32, 12
+    torch.manual_seed(5)
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("temporal", [1, 2], "forward"), False)
+    obs = torch.rand(T, B, F)
+    need = [t % 3 == 1 for t in range(T)]
+    oc = [obs[t].clone().requires_grad_(need[t]) for t in range(T)]
+    odv = [obs[t].to(DEV).requires_grad_(need[t]) for t in range(T)]
+    hid_c, outs_c = None, []
+    for t in range(T):
+        mx, hid_c = od.dense_step(oc[t], hid_c, ref, graph_size=N, edge_selectors=osel)
+        outs_c.append(mx)
+    torch.stack(outs_c).mean().backward()
+    hid, outs = None, []
+    for t in range(T):
+        mx, hid = mem(odv[t], hid)
+        outs.append(mx)
+    torch.stack(outs).mean().backward()
+    torch.testing.assert_close(torch.stack(outs).cpu(), torch.stack(outs_c).detach(), rtol=RTOL, atol=ATOL)
+    for t in range(T):
+        if need[t]:
+            torch.testing.assert_close(odv[t].grad.cpu(), oc[t].grad, rtol=1e-4, atol=1e-8)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+
+def test_rows_two_backward_passes_and_partial_loss():
+    """retain_graph, a loss on part of the steps, two sequences through one module."""
+    B, N, F, H, T = 4, 16, 8, 16, 9
+    torch.manual_seed(7)
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("temporal", [1], "both"), True)
+    obs = torch.rand(2, T, B, F)
+    def run_ref():
+        tot = 0
+        for s in range(2):
+            out, _ = od.dense_rollout(obs[s], None, ref, graph_size=N, edge_selectors=osel)
+            tot = tot + out[T // 2:].sum() * (s + 1)
+        return tot
+    run_ref().backward()
+    tot = 0
+    for s in range(2):
+        hid, outs = None, []
+        for t in range(T):
+            mx, hid = mem(obs[s, t].to(DEV), hid)
+            outs.append(mx)
+        tot = tot + torch.stack(outs[T // 2:]).sum() * (s + 1)
+    tot.backward(retain_graph=True)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+    g.zero_grad()
+    tot.backward()
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+
+def test_rows_graph_capture_replay():
+    """The per-step loop + backward captured in a HIP graph (in process) and replayed: state bit
+    exact against the reference's g13 vectors after every replay, parameter gradients equal."""
+    from gcm.gcm import DenseGCM
+    fx = Fixture("g13_exact_temporal")
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    mem = DenseGCM(g, edge_selectors=product_selector(m, fx.group("sel_param:")), graph_size=m["N"],
+                   donate_state=True)
+    obs = fx["obs"].to(DEV)
+    T, B = m["T"], obs.shape[1]
+    h0 = tuple(t.to(DEV) for t in fx.h0())
+
+    def rollout():
+        hidden = tuple(t.clone() for t in h0)      # (re-created inside the graph on every replay)
+        outs = []
+        for t in range(T):
+            mx, hidden = mem(obs[t], hidden)
+            outs.append(mx)
+        out = torch.stack(outs)
+        out.mean().backward()
+        return out, hidden
+
+    for _ in range(3):                       # warm-up on a side stream, as torch.cuda.graphs asks
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g.zero_grad(set_to_none=True)
+            rollout()
+        torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, hidden = rollout()
+    for rep in range(3):
+        for p in g.parameters():
+            p.grad.zero_()
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(hidden[1].cpu(), fx["hT_adj"])
+        assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])
+        assert torch.equal(hidden[3].cpu(), fx["hT_num_nodes"])
+        torch.testing.assert_close(out.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+        for k, p in g.named_parameters():
+            want = fx["grad:" + k]
+            torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+    mem.check_flags()
