@@ -25,6 +25,13 @@
 #include "fused_common.h"
 #include "rows_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps5, tools/kstamp_rows.py)
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 namespace gcm_rows {
 
 using gcm_fused::Edits;
@@ -32,419 +39,518 @@ using gcm_fused::Gnn2;
 
 template <int FP, int HP, int H2P>
 struct Lds {
-  static constexpr int XS = FP + 16;       // x image [128][XS]: B operand, stride = 16 mod 32
-  static constexpr int RS = 130;           // live adjacency rows [16][RS]: A operand, 2 mod 32
-  static constexpr int AS = 2 * FP + 2;    // [agg1 | x[j]] rows [16][AS]: A operand, 2 mod 32
-  static constexpr int W1S = 2 * FP + 2;   // W1 [h][rel f | root f]: B operand read as B[k][n=h]
-  static constexpr int HS = HP + 1;        // h1 rows [16][HS]
-  static constexpr int W2S = 2 * HP + 1;   // W2 [o][rel k | root k]
-  static constexpr int X = 128 * XS, ROWS = 16 * RS, AGG = 16 * AS, W1 = HP * W1S, H1R = 16 * HS;
-  static constexpr int W2 = H2P * W2S;
-  // rowcur[128] | coef[128] | live j [128] | v [2*HP] | partials [256] | ints [16]
-  static constexpr int MISC = 128 + 128 + 128 + 2 * HP + 256 + 16;
-  static constexpr int TOTAL = X + ROWS + AGG + W1 + H1R + W2 + MISC;
+  static constexpr int XS = FP + 16;   // x image [128][XS]: B operand of the aggregation (stride = 16 mod 32)
+  static constexpr int RS = 130;       // live adjacency rows [16][RS]: A operand (stride = 2 mod 32)
+  static constexpr int AS = FP + 4;    // agg1 rows [16][AS], read 16 bytes at a time
+  static constexpr int HS = HP + 1;    // h1 rows [16][HS]
+  static constexpr int X = 128 * XS, ROWS = 16 * RS, AGG = 16 * AS, H1R = 16 * HS;
+  // rowcur [128] | coef [128] | live j [128] | v [2 HP] | candidates [4][32] |
+  // agg2 partials (double) [4 waves][4][16] | ints [16]
+  static constexpr int MISC = 3 * 128 + 2 * HP + 128 + 512 + 16;
+  static constexpr int TOTAL = X + ROWS + AGG + H1R + MISC;
 };
 
+// the state copy's stores; the overflow fix-ups (last column shifted in registers, last row zero)
+// are applied here so that nothing depends on the loaded values while the loads are being issued
 template <int ADJ_PER, int NODE_PER>
 __device__ __forceinline__ void store_copy(const float4 (&ca)[ADJ_PER], const float4 (&cn)[NODE_PER],
-                                           float* ag, float* ng, int tid, int N, int N4, int F4) {
+                                           float* ag, float* ng, int tid, int N, int N4, int F4,
+                                           bool wrap) {
+  const int lim_a = N * N4, lim_n = N * F4, sh = wrap ? 1 : 0;
 #pragma unroll
   for (int i = 0; i < ADJ_PER; ++i) {
     const int e4 = tid + 256 * i;
-    if (e4 < N * N4) *reinterpret_cast<float4*>(ag + e4 * 4) = ca[i];
+    const int r = e4 / N4, c = (e4 - r * N4) * 4;
+    float4 v = ca[i];
+    if (wrap && c + 4 >= N) v = make_float4(v.y, v.z, v.w, 0.f);
+    if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 < lim_a) *reinterpret_cast<float4*>(ag + e4 * 4) = v;
   }
 #pragma unroll
   for (int i = 0; i < NODE_PER; ++i) {
     const int e4 = tid + 256 * i;
-    if (e4 < N * F4) *reinterpret_cast<float4*>(ng + e4 * 4) = cn[i];
+    const int r = e4 / F4;
+    float4 v = cn[i];
+    if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 < lim_n) *reinterpret_cast<float4*>(ng + e4 * 4) = v;
   }
 }
 
-template <int FP, int HP, int H2P>
+// out[r][c] = in[r + sh][c + sh]: the loads of the roll (sh = 1, dword-aligned 16-byte loads) or of
+// the plain copy (sh = 0), from clamped addresses
+template <int ADJ_PER, int NODE_PER, bool WRAP>
+__device__ __forceinline__ void load_copy(float4 (&ca)[ADJ_PER], float4 (&cn)[NODE_PER],
+                                          const float* ag_in, const float* ng_in, int tid, int N,
+                                          int N4, int F, int F4) {
+  const int lim_a = N * N4, lim_n = N * F4;
+#pragma unroll
+  for (int i = 0; i < ADJ_PER; ++i) {
+    const int e4 = min(tid + 256 * i, lim_a - 1);
+    if (!WRAP) {
+      ca[i] = *reinterpret_cast<const float4*>(ag_in + 4 * e4);
+    } else {
+      const int r = e4 / N4, c = (e4 - r * N4) * 4;
+      const int rs = r + 1 < N ? r + 1 : N - 1;
+      const bool tail = c + 4 >= N;   // in[.][N] does not exist: shifted at store time
+      __builtin_memcpy(&ca[i], ag_in + rs * N + c + (tail ? 0 : 1), sizeof(float4));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NODE_PER; ++i) {
+    const int e4 = min(tid + 256 * i, lim_n - 1);
+    if (!WRAP) {
+      cn[i] = *reinterpret_cast<const float4*>(ng_in + 4 * e4);
+    } else {
+      const int r = e4 / F4, c = (e4 - r * F4) * 4;
+      cn[i] = *reinterpret_cast<const float4*>(ng_in + (r + 1 < N ? r + 1 : N - 1) * F + c);
+    }
+  }
+}
+
+__device__ __forceinline__ float f4_at(const float4& v, int i) {   // i: compile time after unrolling
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+// The live-row list.  Slot 0 is row cur; then the rows the folded temporal selectors connect it to
+// (cur - hop for forward / both hops, in hop order, duplicates dropped): these CANDIDATES depend on
+// cur alone, so their adjacency rows are fetched before row cur of the adjacency has even arrived.
+// Rows that are live for any other reason (DenseEdge; entries a caller's own state holds in row
+// cur) are appended in ascending order once the row is known, and fetched then.  The order of the
+// list is the summation order of layer 2 and of the backward.
+//
+// The kernel runs at one wave per SIMD, so it is bound by instruction issue and by the chain of
+// dependent latencies, not by bytes:
+//   * everything that does not depend on the count (x rows, the weights - straight into the
+//     registers that feed the MFMAs, no LDS staging -, biases, the functional copy's loads) is in
+//     flight before the count has arrived; then row cur and the candidate rows;
+//   * the linears use a K order in which every lane group owns CONTIGUOUS k (16-byte LDS reads of
+//     the A operand, 16-byte global loads of the B operand);
+//   * four workgroup barriers on the common path; the selector's HBM entries, the inserted node
+//     and (functional state) the copy's stores go last, off the critical path.
+// NX: graph size as a compile-time constant (0: run time); EXACT: F, H1, H2 are the padded sizes.
+// The specialisations fold the clamps, masks and most of the address arithmetic away - a third of
+// the instructions of a kernel that is bound by instruction issue.
+template <int FP, int HP, int H2P, bool FUNC, int NX, bool EXACT>
 __global__ __launch_bounds__(256) void k_step_rows(
     const float* __restrict__ obs, const float* nodes_in, const float* adj_in,
     const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
     int64_t* __restrict__ cur_out, Edits E, Gnn2 P, float* __restrict__ mx_out,
-    float* __restrict__ saved, SavedLayout lay, uint32_t* __restrict__ flags, int N, int F, int H1,
-    int H2) {
+    float* __restrict__ saved, SavedLayout lay, uint32_t* __restrict__ flags, int N_, int F_,
+    int H1_, int H2_) {
   using L = Lds<FP, HP, H2P>;
-  constexpr int XS = L::XS, RS = L::RS, AS = L::AS, W1S = L::W1S, HS = L::HS, W2S = L::W2S;
+  const int N = NX ? NX : N_, F = EXACT ? FP : F_, H1 = EXACT ? HP : H1_, H2 = EXACT ? H2P : H2_;
+  constexpr int XS = L::XS, RS = L::RS, AS = L::AS, HS = L::HS;
+  constexpr int HB = HP / 16, FB = FP / 16;
+  constexpr int KL = FP / 2;                          // k values per lane group in the linears
+  constexpr int KG = 256 / H2P, KC = 2 * HP / KG;     // layer 2: KG adjacent lanes share an output
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m16 = lane & 15, kq = lane >> 4;
-  const bool inplace = adj_out == adj_in;
   const int N4 = N >> 2, F4 = F >> 2;
-
-  const int64_t n_in = count_in[b];
-  const bool wrap = n_in + 1 > N;
-  const int64_t c64 = wrap ? n_in - 1 : n_in;
-  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  const int o2 = tid / KG, kg = tid % KG;
 
   extern __shared__ float smem[];
   float* sX = smem;
   float* sRows = sX + L::X;
   float* sAgg = sRows + L::ROWS;
-  float* sW1 = sAgg + L::AGG;
-  float* sH1 = sW1 + L::W1;
-  float* sW2 = sH1 + L::H1R;
-  float* sRowCur = sW2 + L::W2;
+  float* sH1 = sAgg + L::AGG;
+  float* sRowCur = sH1 + L::H1R;
   float* sCoef = sRowCur + 128;
   int* sLive = reinterpret_cast<int*>(sCoef + 128);
   float* sV = reinterpret_cast<float*>(sLive + 128);
-  float* sPart = sV + 2 * HP;
-  int* sInt = reinterpret_cast<int*>(sPart + 256);   // [0..1] live count of wave 0 / 1, [2] l_cur,
-                                                     // [3] K-chunk mask of the current row group
+  int* sCand = reinterpret_cast<int*>(sV + 2 * HP);   // [4 waves][32]: each wave's own copy
+  double* sA2 = reinterpret_cast<double*>(sCand + 128);   // [4 waves][4 kq][16]
+  int* sInt = reinterpret_cast<int*>(sA2 + 256);   // [0..1] extra live rows of wave 0 / 1, [3] K-chunk mask
 
   const float* ng_in = nodes_in + (size_t)b * N * F;
   const float* ag_in = adj_in + (size_t)b * N * N;
   float* ng = nodes_out + (size_t)b * N * F;
   float* ag = adj_out + (size_t)b * N * N;
 
-  int lane_hop = -1, lane_dir = 0;   // lane i < n_hops: the i-th folded temporal edit
-  if (lane < E.n_hops) {
-    lane_hop = E.hops[lane & 15];
-    lane_dir = E.dir[lane & 15];
-  }
+  STAMP(0);
+  // ---- loads that do not depend on the count ----------------------------------------------------
+  // first in the queue (loads return in order): the folded hops of this lane, then the count
   const int n_hops = E.n_hops;
-  const bool dense = E.dense != 0;
-
-  // ---- the state copy / overflow roll ---------------------------------------------------------
-  // out[r][c] = wrap ? in[r+1][c+1] (last row / column zero) : in[r][c]; nodes alike by rows.
-  // Needed when the state is not donated (functional copy) or the graph overflows.  The loads are
-  // issued here, the stores after the pipeline's own first loads (below) - except for a donated
-  // overflow, where source and destination alias and everything must land first.
-  constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
-  float4 ca[ADJ_PER], cn[NODE_PER];
-  const bool need_copy = !inplace || wrap;   // uniform per workgroup
-  if (need_copy) {
-    const int sh = wrap ? 1 : 0;
+  int lane_h = -1, cdir = 0;
+  if (lane >= 1 && lane <= n_hops) {
+    lane_h = E.hops[(lane - 1) & 15];
+    cdir = E.dir[(lane - 1) & 15];
+  }
+  const int64_t n_in = count_in[b];
+  // x rows (unshifted; the overflow shift and the observation are applied when the image is written)
+  constexpr int XROWS = 256 / (FP / 4), PER = 128 / XROWS;   // rows per pass, float4 per thread
+  const int xc = (tid % (FP / 4)) * 4, xr0 = tid / (FP / 4);
+  const int xcc = xc < F ? xc : F - 4;
+  float4 xv[PER];
 #pragma unroll
-    for (int i = 0; i < ADJ_PER; ++i) {
-      const int e4 = tid + 256 * i;
-      const int r = e4 / N4, c = (e4 - r * N4) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < N * N4) {   // uniform per i for N = 128
-        const int rs = r + sh < N ? r + sh : N - 1;
-        const bool tail = wrap && c + 4 >= N;   // in[.][N] does not exist: shift in registers
-        const float* p = ag_in + rs * N + c + (tail ? 0 : sh);
-        __builtin_memcpy(&v, p, sizeof(float4));   // dword-aligned 16-byte load
-        if (tail) v = make_float4(v.y, v.z, v.w, 0.f);
-        if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      ca[i] = v;
-    }
+  for (int i = 0; i < PER; ++i) {
+    const int r = xr0 + i * XROWS;
+    xv[i] = *reinterpret_cast<const float4*>(ng_in + (r < N ? r : N - 1) * F + xcc);
+  }
+  const float4 obv = *reinterpret_cast<const float4*>(obs + (size_t)b * F + xcc);
+  // layer-1 weights, B operand of the linears: lane (h = 16 (wave % HB) + m16, kq) owns k in
+  // [kq KL, (kq + 1) KL) of [W_rel1 | W_root1][h] - contiguous in memory
+  const int hcol = 16 * (wave % HB) + m16;
+  float4 w1r[KL / 4];
+  {
+    const float* src = (kq < 2 ? P.w_rel1 : P.w_root1) + (hcol < H1 ? hcol : H1 - 1) * F;
 #pragma unroll
-    for (int i = 0; i < NODE_PER; ++i) {
-      const int e4 = tid + 256 * i;
-      const int r = e4 / F4, c = (e4 - r * F4) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < N * F4) {
-        const int rs = r + sh < N ? r + sh : N - 1;
-        v = *reinterpret_cast<const float4*>(ng_in + rs * F + c);
-        if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      cn[i] = v;
+    for (int q = 0; q < KL / 4; ++q) {
+      const int c = (kq & 1) * KL + 4 * q;
+      w1r[q] = *reinterpret_cast<const float4*>(src + (c < F ? c : F - 4));
     }
   }
-  // where the pipeline reads the (advanced, pre-selector) state from
-  const float* ag_rd = ag_in;
-  const float* ng_rd = ng_in;
+  // layer-2 weights: thread (o2, kg) owns k in [kg KC, (kg + 1) KC) of [W_rel2 | W_root2][o2]
+  float w2r[KC];
+  {
+    const bool root = kg * KC >= HP;
+    const int kk0 = root ? kg * KC - HP : kg * KC;
+    const float* src = (root ? P.w_root2 : P.w_rel2) + (o2 < H2 ? o2 : H2 - 1) * H1;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) w2r[k] = src[kk0 + k < H1 ? kk0 + k : H1 - 1];
+  }
+  // biases (the packed vector always holds the slots; zeros when a layer has no bias)
+  const float bias1 = P.b_rel1[hcol < H1 ? hcol : H1 - 1];
+  const float bias2 = P.b_rel2[o2 < H2 ? o2 : H2 - 1];
+  // functional state, no overflow (the common case, assumed here): the copy's loads
+  constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
+  float4 ca[FUNC ? ADJ_PER : 1], cn[FUNC ? NODE_PER : 1];
+  if (FUNC) load_copy<FUNC ? ADJ_PER : 1, FUNC ? NODE_PER : 1, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
+  // kernel arguments used late: in registers now (a scalar load at its point of use is a round trip)
+  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  const size_t lay_v = lay.o_v, lay_hdr = lay.o_hdr, lay_coef = lay.o_coef, lay_rows = lay.o_rows;
+  const int rw = lay.rw;
+  const int dense_i = E.dense;
+  asm volatile("" ::"s"(lay_v), "s"(lay_rows), "s"(saved), "s"(mx_out), "s"(dense_i), "s"(N), "s"(count_out),
+               "s"(flags));
+  asm volatile("" ::: "memory");   // compiler barrier: the loads above stay above, unpredicated
+
+  const bool wrap = n_in + 1 > N;
+  const int64_t c64 = wrap ? n_in - 1 : n_in;
+  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  const int sh = wrap ? 1 : 0;
+  STAMP(1);
+  // ---- overflow (gcm.py:323-355): roll the state, in place when it is donated (every load lands
+  // before the first store).  Rare; its own loads, stores and barriers. ----------------------------
   if (wrap) {
-    if (inplace) {   // every load of the roll lands before the first store
+    float4 ra[ADJ_PER], rn[NODE_PER];
+    load_copy<ADJ_PER, NODE_PER, true>(ra, rn, ag_in, ng_in, tid, N, N4, F, F4);
+    if (!FUNC) {   // source and destination alias
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    store_copy<ADJ_PER, NODE_PER>(ca, cn, ag, ng, tid, N, N4, F4);
+    store_copy<ADJ_PER, NODE_PER>(ra, rn, ag, ng, tid, N, N4, F4, true);
     __syncthreads();   // the rolled state is visible to the whole workgroup
-    ag_rd = ag;
-    ng_rd = ng;
   }
+  const float* ag_rd = wrap ? ag : ag_in;   // the advanced, pre-selector adjacency
 
-  // ---- phase A: every load that depends on cur only ----------------------------------------------
-  // x image = node matrix with the observation in row cur (gcm.py:274); rows >= N and columns >= F
-  // are zero (K / N padding of the MFMAs)
-  {
-    constexpr int PER = 128 * FP / 4 / 256;   // float4 per thread of the padded image
-    float4 xv[PER];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- row cur of the advanced adjacency, before the selectors (all zero for a state this code
+  // produced; a caller's own state may hold anything): heads the longest dependent chain ------------
+  float rc_val = ag_rd[cur * N + min(tid & 127, N - 1)];
+  // ---- candidates (every wave computes them for itself: no barrier) ------------------------------
+  // lane 0: row cur; lane i in [1, n_hops]: cur - hop[i-1] when that hop writes into row cur
+  const bool dense = dense_i != 0;
+  int cj = cur;
+  bool cvalid = lane == 0;
+  if (lane >= 1 && lane <= n_hops) {
+    cj = cur - lane_h;
+    cvalid = ((cdir & GCM_DIR_FORWARD) || lane_h == 0) && lane_h >= 0 && lane_h <= cur;
+  }
+  // row that gets a column-cur entry from a backward / both hop, per hop lane
+  const int lane_colrow = (lane >= 1 && lane <= n_hops && (cdir & GCM_DIR_BACKWARD) && cj >= 0 && cj <= cur)
+                              ? cj : -1;
+  // duplicates dropped (a later lane that names the row of an earlier valid one), and for row
+  // j = tid & 127 of the phase below: is it a candidate?  One pass over the hop lanes, vector ops only.
+  const int jrow = tid & 127;
+  bool is_cand = jrow == cur, hop0 = false, dup = false;
+  for (int k = 1; k <= n_hops; ++k) {
+    const int jk = __builtin_amdgcn_readlane(cj, k);
+    const bool vk = __builtin_amdgcn_readlane((int)cvalid, k) != 0;   // (before any removal: a
+    hop0 |= __builtin_amdgcn_readlane(lane_h, k) == 0;                //  duplicate of a duplicate
+    is_cand |= vk && jk == jrow;                                      //  is a duplicate as well)
+    dup |= vk && jk == cj && k < lane;
+  }
+  dup |= lane >= 1 && cj == cur;   // hop 0 names row cur itself (lane 0)
+  cvalid = cvalid && !dup;
+  const unsigned long long cbal = __ballot(cvalid);
+  const int C = __popcll(cbal);                       // 1 .. 17
+  const int cpos = __popcll(cbal & ((1ull << lane) - 1ull));
+  if (cvalid) sCand[wave * 32 + cpos] = cj;
+  const int Cs = C < 16 ? C : 16;                     // rows fetched ahead (group 0)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // candidate rows: thread (l = tid / 16, c4 = tid % 16) holds columns 4 c4 .. and 4 (c4 + 16) ..
+  const int sl = tid >> 4, c4 = tid & 15;
+  const int sj = sl < Cs ? sCand[wave * 32 + sl] : cur;
+  float4 sp[2];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e4 = tid + 256 * i, r = e4 / (FP / 4), c = (e4 % (FP / 4)) * 4;
-      const bool ok = r < N && c < F;
-      const int rc = r < N ? r : N - 1, cc = c < F ? c : F - 4;
-      const float* src = r == cur ? obs + (size_t)b * F + cc : ng_rd + rc * F + cc;
-      const float4 t = *reinterpret_cast<const float4*>(src);
-      xv[i] = ok ? t : zero4;
-    }
-    // layer-1 weights as [h][rel f | root f] (padding zero), layer-2 as [o][rel k | root k]
-    constexpr int PW1 = HP * 2 * FP / 256;
-    float w1v[PW1];
+  for (int q = 0; q < 2; ++q) {
+    const int c = (c4 + 16 * q) * 4;
+    sp[q] = *reinterpret_cast<const float4*>(ag_rd + sj * N + (c < N ? c : N - 4));
+  }
+  asm volatile("" ::: "memory");
+  STAMP(2);
+  // ---- x image: node matrix after the roll, the observation in row cur (gcm.py:274), zero padding
 #pragma unroll
-    for (int i = 0; i < PW1; ++i) {
-      const int e = tid + 256 * i, h = e / (2 * FP), k = e % (2 * FP);
-      const int f = k < FP ? k : k - FP;
-      const float* src = k < FP ? P.w_rel1 : P.w_root1;
-      const float t = src[(h < H1 ? h : H1 - 1) * F + (f < F ? f : F - 1)];
-      w1v[i] = (h < H1 && f < F) ? t : 0.f;
+  for (int i = 0; i < PER; ++i) {
+    const int r = xr0 + i * XROWS;
+    // image row of loaded row r: r - sh; the row dropped by the roll (r = 0) writes row cur instead
+    const bool is_obs = wrap ? r == 0 : r == cur;
+    const int ir = is_obs ? cur : r - sh;
+    const bool ok = r < N && xc < F;
+    const float4 t = xv[i];
+    float4 v = make_float4(is_obs ? obv.x : t.x, is_obs ? obv.y : t.y, is_obs ? obv.z : t.z,
+                           is_obs ? obv.w : t.w);
+    v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    *reinterpret_cast<float4*>(sX + (r < N ? ir : r) * XS + xc) = v;
+  }
+  // ---- row cur after the selectors (temporal.py:72-88, dense.py:16-21), extra live rows ----------
+  rc_val = (tid < 128 && tid < N) ? rc_val : 0.f;
+  float r_new = rc_val;
+  bool xpred = false;
+  unsigned long long xbal = 0;
+  if (tid < 128) {
+    const int j = tid;
+    if (is_cand && j != cur) r_new = 1.f;            // a forward / both hop writes (cur, j)
+    if (dense && j <= cur) r_new = 1.f;
+    if (j == cur && hop0) r_new = 1.f;
+    sRowCur[j] = r_new;
+    sCoef[j] = 0.f;                                  // entries beyond the live list stay zero
+    xpred = j < N && r_new != 0.f && !is_cand;       // live, and not fetched ahead
+    xbal = __ballot(xpred);
+    if (lane == 0) sInt[wave] = __popcll(xbal);
+  }
+  if (tid == 128) sInt[3] = 0;
+  STAMP(3);
+  __syncthreads();   // #1: x image, row cur, counts
+  STAMP(4);
+  const int n_extra = sInt[0] + sInt[1];
+  const int Ltot = C + n_extra;
+  const bool slow = Ltot > Cs;   // rows that were not fetched ahead (uniform)
+  if (tid < 128) {
+    if (wave == 0 && cvalid) {             // the candidates, in hop order
+      sLive[cpos] = cj;
+      sCoef[cpos] = sRowCur[cj];
     }
-    constexpr int PW2 = H2P * 2 * HP / 256;
-    float w2v[PW2];
-#pragma unroll
-    for (int i = 0; i < PW2; ++i) {
-      const int e = tid + 256 * i, o = e / (2 * HP), k = e % (2 * HP);
-      const int kk = k < HP ? k : k - HP;
-      const float* src = k < HP ? P.w_rel2 : P.w_root2;
-      const float t = src[(o < H2 ? o : H2 - 1) * H1 + (kk < H1 ? kk : H1 - 1)];
-      w2v[i] = (o < H2 && kk < H1) ? t : 0.f;
-    }
-    // row cur of the advanced adjacency, before the selectors (all zero for a state this code
-    // produced; a caller's own state may hold anything)
-    float rc_val = 0.f;
-    if (tid < 128) {
-      const float t = ag_rd[cur * N + (tid < N ? tid : N - 1)];
-      rc_val = tid < N ? t : 0.f;
-    }
-    if (need_copy && !wrap) store_copy<ADJ_PER, NODE_PER>(ca, cn, ag, ng, tid, N, N4, F4);   // functional copy: stores behind the pipeline's loads
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e4 = tid + 256 * i, r = e4 / (FP / 4), c = (e4 % (FP / 4)) * 4;
-      float* d = sX + r * XS + c;
-      d[0] = xv[i].x; d[1] = xv[i].y; d[2] = xv[i].z; d[3] = xv[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < PW1; ++i) {
-      const int e = tid + 256 * i, h = e / (2 * FP), k = e % (2 * FP);
-      sW1[h * W1S + k] = w1v[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PW2; ++i) {
-      const int e = tid + 256 * i, o = e / (2 * HP), k = e % (2 * HP);
-      sW2[o * W2S + k] = w2v[i];
-    }
-    // ---- phase B: selector writes on row cur (temporal.py:72-88, dense.py:16-21), live list ------
-    float r_new = rc_val;
-    bool pred = false;
-    unsigned long long bal = 0;
-    if (tid < 128) {
-      const int j = tid;
-      for (int i = 0; i < n_hops; ++i) {
-        const int h = __builtin_amdgcn_readlane(lane_hop, i), d = __builtin_amdgcn_readlane(lane_dir, i);
-        if (((d & GCM_DIR_FORWARD) || h == 0) && h >= 0 && cur >= h && j == cur - h) r_new = 1.f;
-      }
-      if (dense && j <= cur) r_new = 1.f;
-      sRowCur[j] = r_new;
-      pred = j < N && (r_new != 0.f || j == cur);
-      bal = __ballot(pred);
-      if (lane == 0) sInt[wave] = __popcll(bal);
-    }
-    if (tid == 0) sInt[3] = 0;
-    __syncthreads();   // x image, weights, counts; the copy's stores are ordered before what follows
-    if (tid < 128) {
-      const int j = tid;
-      const int pos = (wave ? sInt[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
-      if (pred) {
-        sLive[pos] = j;
-        sCoef[pos] = r_new;
-        if (j == cur) sInt[2] = pos;
-      }
-      // the selector's entries go back to HBM behind the copy's stores
-      if (j < N && r_new != rc_val) ag[cur * N + j] = r_new;
-    } else {
-      const int t2 = tid - 128;   // column cur: backward hops (temporal) / rows < cur (dense)
-      if (wave == 2 && (lane_dir & GCM_DIR_BACKWARD) && lane_hop >= 0 && cur >= lane_hop)
-        ag[(cur - lane_hop) * N + cur] = 1.f;   // lane i < n_hops holds hop i (lane_hop = -1 beyond)
-      if (dense) {
-        for (int r = t2; r < cur; r += 128) ag[r * N + cur] = 1.f;
-      }
-      if (t2 < F4) {   // the inserted node (gcm.py:274)
-        *reinterpret_cast<float4*>(ng + cur * F + t2 * 4) =
-            *reinterpret_cast<const float4*>(obs + (size_t)b * F + t2 * 4);
-      }
+    if (xpred) {                           // the others, ascending
+      const int pos = C + (wave ? sInt[0] : 0) + __popcll(xbal & ((1ull << lane) - 1ull));
+      sLive[pos] = tid;
+      sCoef[pos] = r_new;
     }
   }
-  __syncthreads();   // live list
-  const int Ltot = sInt[0] + sInt[1];
-  const int l_cur = sInt[2];
-  float* sv_rows = nullptr;
-  if (saved) {
-    sv_rows = saved + lay.o_rows + (size_t)b * N * lay.rw;
-    if (tid == 0) {
-      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * b;
-      hdr[0] = Ltot; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = wrap ? 1 : 0;
-    }
-    float* cf = saved + lay.o_coef + (size_t)b * N;
-    for (int l = tid; l < Ltot; l += 256) cf[l] = sCoef[l];
-  }
+  if (slow) __syncthreads();   // #2 (rare): the appended rows are fetched through the list
 
   // ---- the live rows, 16 at a time ---------------------------------------------------------------
-  float a2 = 0.f, h1c = 0.f;   // tid < HP: agg2[tid], h1[cur][tid]
-  const float bias1 = (P.b_rel1 && wave < HP / 16 && 16 * wave + m16 < H1) ? P.b_rel1[16 * wave + m16] : 0.f;
-  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  double a2p = 0.0;   // waves < HB: this lane's part of agg2[hcol] (fp64: up to N terms)
+  float h1c = 0.f;    // waves < HB, kq == 0: h1[cur][hcol]
   const int n_groups = (Ltot + 15) >> 4;
+  float* sv_rows = saved ? saved + lay_rows + (size_t)b * N * rw : nullptr;
 #pragma unroll 1
   for (int g = 0; g < n_groups; ++g) {
-    // -- C: adjacency rows of this group -> LDS (with the selector's column-cur entries applied in
-    //       registers: the stores above may or may not have landed, both give the same row)
+    STAMP(5);
+    // -- C: adjacency rows of this group -> LDS, the selector's column-cur entries applied in
+    //       registers (the selector's stores go to HBM at the end: the rows read here are older)
     {
-      const int l = tid >> 4, c4 = tid & 15;
-      const int lg = 16 * g + l;
+      const int l = sl, lg = 16 * g + l;
       const bool valid = lg < Ltot;
-      const int j = valid ? sLive[lg] : 0;
+      const bool ahead = g == 0 && l < Cs;
+      const int j = ahead ? sj : (valid ? sLive[lg] : 0);
       bool colcur = dense && j < cur;   // does (j, cur) get an entry from the selectors?
-      for (int i = 0; i < n_hops; ++i) {
-        const int h = __builtin_amdgcn_readlane(lane_hop, i), d = __builtin_amdgcn_readlane(lane_dir, i);
-        colcur |= (d & GCM_DIR_BACKWARD) && h >= 0 && cur >= h && j == cur - h;
-      }
+      for (int k = 1; k <= n_hops; ++k) colcur |= __builtin_amdgcn_readlane(lane_colrow, k) == j;
       unsigned nzbits = 0;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int c = (c4 + 16 * q) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < N) {
-          v = *reinterpret_cast<const float4*>(ag_rd + j * N + c);
-          if (j == cur) v = make_float4(sRowCur[c], sRowCur[c + 1], sRowCur[c + 2], sRowCur[c + 3]);
-          else if (colcur) {
-            const int k = cur - c;
-            v.x = k == 0 ? 1.f : v.x;
-            v.y = k == 1 ? 1.f : v.y;
-            v.z = k == 2 ? 1.f : v.z;
-            v.w = k == 3 ? 1.f : v.w;
-          }
+        float4 v = sp[q];
+        if (!ahead && valid) v = *reinterpret_cast<const float4*>(ag_rd + j * N + (c < N ? c : N - 4));
+        if (j == cur) v = make_float4(sRowCur[c], sRowCur[c + 1], sRowCur[c + 2], sRowCur[c + 3]);
+        else if (colcur) {
+          const int k = cur - c;
+          v.x = k == 0 ? 1.f : v.x;
+          v.y = k == 1 ? 1.f : v.y;
+          v.z = k == 2 ? 1.f : v.z;
+          v.w = k == 3 ? 1.f : v.w;
         }
-        if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float* d = sRows + l * RS + c;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (!valid || c >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2* d = reinterpret_cast<float2*>(sRows + l * RS + c);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
         const bool nz = (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
-        const unsigned long long bal = __ballot(nz);   // lane = 16*l' + c4: fold the 4 rows
+        const unsigned long long bal = __ballot(nz);   // lane = 16 l' + c4: fold the wave's 4 rows
         const unsigned m = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);
         nzbits |= m << (16 * q);
       }
-      // x[j] beside agg1 in the A image of the linears
-#pragma unroll
-      for (int i = 0; i < FP / 16; ++i) {
-        const int f = c4 + 16 * i;
-        sAgg[l * AS + FP + f] = valid ? sX[j * XS + f] : 0.f;
-      }
       if (lane == 0 && nzbits) atomicOr(reinterpret_cast<unsigned*>(&sInt[3]), nzbits);
     }
-    __syncthreads();
+    STAMP(6);
+    __syncthreads();   // #3
+    STAMP(7);
     // -- D: agg1 = rows @ x over the non-zero 4-column chunks (exact: zero chunks add nothing)
-    if (wave < FP / 16) {
+    if (wave < FB) {
       unsigned km = __builtin_amdgcn_readfirstlane((unsigned)sInt[3]);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* ap = sRows + m16 * RS + kq;
       const float* bp = sX + kq * XS + 16 * wave + m16;
-      while (km) {
-        const int c = __builtin_ctz(km);
-        km &= km - 1;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * c], bp[4 * c * XS], acc, 0, 0, 0);
+      while (km) {   // four chunks per trip: the LDS reads of a trip are in flight together
+        float av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool has = km != 0;
+          const int c = has ? __builtin_ctz(km) : 0;
+          km &= km - 1;
+          const float a = ap[4 * c], bb = bp[4 * c * XS];
+          av[q] = has ? a : 0.f;
+          bv[q] = has ? bb : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int l = 4 * kq + r, f = 16 * wave + m16;
-        sAgg[l * AS + f] = acc[r];
-      }
+      for (int r = 0; r < 4; ++r) sAgg[(4 * kq + r) * AS + 16 * wave + m16] = acc[r];
     }
-    __syncthreads();
-    // -- E: h1 = act1([agg1 | x[j]] @ [W_rel1 | W_root1]^T + b1)
-    if (tid == 255) sInt[3] = 0;   // D has read the chunk mask (barrier above); C of the next group ORs after two more
-    if (wave < HP / 16) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* ap = sAgg + m16 * AS + kq;
-      const float* bp = sW1 + (16 * wave + m16) * W1S + kq;
-      float av[2 * FP / 4], bv[2 * FP / 4];
+    STAMP(8);
+    __syncthreads();   // #4
+    STAMP(9);
+    // -- E: h1 = act1([agg1 | x[j]] @ [W_rel1 | W_root1]^T + b1); this lane's part of agg2
+    if (tid == 255) sInt[3] = 0;   // D has read the chunk mask; the next group's C ORs after #5
+    if (wave < HB) {
+      // A operand: lane (l = m16, kq) reads its KL contiguous k - agg1[l] (kq < 2) or x[j_l] (kq >= 2)
+      const int lg = 16 * g + m16;
+      const int jl = lg < Ltot ? sLive[lg] : cur;
+      const float* abase = (kq < 2 ? sAgg + m16 * AS : sX + jl * XS) + (kq & 1) * KL;
+      float4 a4[KL / 4];
 #pragma unroll
-      for (int s = 0; s < 2 * FP / 4; ++s) {
-        av[s] = ap[4 * s];
-        bv[s] = bp[4 * s];
-      }
+      for (int q = 0; q < KL / 4; ++q) a4[q] = *reinterpret_cast<const float4*>(abase + 4 * q);
+      float cf[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cf[r] = sCoef[16 * g + 4 * kq + r];
       __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 2 * FP / 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+      for (int q = 0; q < KL / 4; ++q) {   // two chains: the 16x16x4 MFMA has 40 cycles of latency
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].x, w1r[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].y, w1r[q].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].z, w1r[q].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].w, w1r[q].w, acc1, 0, 0, 0);
+      }
+      float hv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int l = 4 * kq + r, h = 16 * wave + m16;
-        sH1[l * HS + h] = gcm_act_sel(acc[r] + bias1, act1_v);
+        const float t = gcm_act_sel(acc0[r] + acc1[r] + bias1, act1_v);
+        hv[r] = hcol < H1 ? t : 0.f;                 // padding columns stay out of layer 2
+        sH1[(4 * kq + r) * HS + hcol] = hv[r];
+        a2p = fma((double)cf[r], (double)hv[r], a2p);   // coef is zero beyond the live list
       }
-    }
-    __syncthreads();
-    // -- F: layer-2 aggregation over this group; rows saved for BPTT
-    if (tid < HP) {
-      const int lmax = Ltot - 16 * g < 16 ? Ltot - 16 * g : 16;
-      for (int l = 0; l < lmax; ++l) a2 = fmaf(sCoef[16 * g + l], sH1[l * HS + tid], a2);
-      if (l_cur >= 16 * g && l_cur < 16 * g + 16) h1c = sH1[(l_cur - 16 * g) * HS + tid];
-    }
-    if (sv_rows) {
-      const int rw = lay.rw;   // h1 [H1] | agg1 [F] | x[j] [F]
-      for (int e = tid; e < 16 * rw; e += 256) {
-        const int l = e / rw, k = e - l * rw;
-        if (16 * g + l < Ltot) {
-          const float v = k < H1 ? sH1[l * HS + k]
-                                 : (k < H1 + F ? sAgg[l * AS + (k - H1)] : sAgg[l * AS + FP + (k - H1 - F)]);
-          sv_rows[(size_t)(16 * g + l) * rw + k] = v;
+      if (g == 0 && kq == 0) h1c = hv[0];            // row cur is slot 0 of the list
+      if (g == n_groups - 1) {                       // the four lane groups of a column meet in LDS
+        sA2[(wave * 4 + kq) * 16 + m16] = a2p;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (kq == 0) {
+          const double t = (sA2[(wave * 4 + 0) * 16 + m16] + sA2[(wave * 4 + 1) * 16 + m16]) +
+                           (sA2[(wave * 4 + 2) * 16 + m16] + sA2[(wave * 4 + 3) * 16 + m16]);
+          sV[hcol] = (float)t;
+          sV[HP + hcol] = h1c;
         }
       }
     }
-    __syncthreads();   // sRows / sAgg / sH1 are rewritten by the next group
+    STAMP(10);
+    __syncthreads();   // #5
+    STAMP(11);
+    if (sv_rows) {   // thread -> (row l, columns k = c4 + 16 i): h1 [H1] | agg1 [F] | x[j] [F]
+      const int l = sl;
+      if (16 * g + l < Ltot) {
+        const int j = sLive[16 * g + l];
+        float* dst = sv_rows + (size_t)(16 * g + l) * rw;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+          const int k = c4 + 16 * i;
+          if (k < H1) dst[k] = sH1[l * HS + k];
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+          const int k = c4 + 16 * i;
+          if (k < F) {
+            dst[H1 + k] = sAgg[l * AS + k];
+            dst[H1 + F + k] = sX[j * XS + k];
+          }
+        }
+      }
+    }
+    if (g + 1 < n_groups) __syncthreads();   // the images are rewritten by the next group
   }
 
-  // ---- layer 2 on row cur: mx = act2(W2c v + b2), v = agg2 | h1[cur] -------------------------------
-  if (tid < HP) {
-    sV[tid] = a2;
-    sV[HP + tid] = h1c;
-    if (saved && tid < H1) {
-      float* v = saved + lay.o_v + (size_t)b * 2 * H1;
-      v[tid] = a2;
-      v[H1 + tid] = h1c;
-    }
-  }
-  __syncthreads();
+  // ---- layer 2 on row cur: mx = act2(W2c v + b2), v = agg2 | h1[cur]; KG adjacent lanes per output --
   {
-    constexpr int G2 = 256 / H2P, KC = (2 * HP) / G2;
-    const int gq = tid / H2P, o = tid - gq * H2P;
-    float s = 0.f;
-    const float* wrow = sW2 + o * W2S + gq * KC;
-    const float* vv = sV + gq * KC;
+    const float* vv = sV + kg * KC;
+    float xq[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) s = fmaf(wrow[k], vv[k], s);
-    sPart[tid] = s;
-    __syncthreads();
-    bool nonfinite = false;
-    if (tid < H2) {
-      float t = P.b_rel2 ? P.b_rel2[tid] : 0.f;
+    for (int k = 0; k < KC; ++k) xq[k] = vv[k];
+    float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < G2; ++q) t += sPart[q * H2P + tid];
-      const float v = gcm_act_sel(t, act2_v);
-      mx_out[(size_t)b * H2 + tid] = v;
-      nonfinite = !isfinite(v);
+    for (int k = 0; k < KC; ++k) t = fmaf(w2r[k], xq[k], t);
+#pragma unroll
+    for (int d = 1; d < KG; d <<= 1) t += __shfl_xor(t, d);
+    const float v = gcm_act_sel(t + bias2, act2_v);
+    const bool mine = kg == 0 && o2 < H2;
+    if (mine) mx_out[(size_t)b * H2 + o2] = v;
+    const bool any_bad = __any(mine && !isfinite(v));
+    if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+  }
+  if (saved) {
+    if (tid == 0) {
+      int* hdr = reinterpret_cast<int*>(saved + lay_hdr) + 4 * b;
+      hdr[0] = Ltot; hdr[1] = 0; hdr[2] = cur; hdr[3] = wrap ? 1 : 0;
     }
-    if (wave == 0) {   // H2 <= 64: every output lives in wave 0
-      const bool any_bad = __any(nonfinite);
-      if (any_bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+    float* cf = saved + lay_coef + (size_t)b * N;
+    for (int l = tid; l < Ltot; l += 256) cf[l] = sCoef[l];
+    if (tid < 2 * H1) {
+      const int k = tid < H1 ? tid : HP + (tid - H1);
+      saved[lay_v + (size_t)b * 2 * H1 + tid] = sV[k];
     }
   }
-  if (tid == 0) {   // last: count_out may alias count_in, which every wave has read by now
-    count_out[b] = cur + 1;
-    if (cur_out) cur_out[b] = cur;
-    const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
-    if (f) atomicOr(flags, f);
+  STAMP(12);
+  // ---- the state, off the critical path: (functional) the copy's stores, then the selector's
+  // entries, the inserted node and the count behind them ------------------------------------------
+  if (FUNC && !wrap) {
+    store_copy<FUNC ? ADJ_PER : 1, FUNC ? NODE_PER : 1>(ca, cn, ag, ng, tid, N, N4, F4, false);
+    __syncthreads();   // ordered: the entries below overwrite copied values
+  }
+  if (tid < 128) {
+    if (tid < N && r_new != rc_val) ag[cur * N + tid] = r_new;
+  } else {
+    const int t2 = tid - 128;   // column cur: backward hops (temporal) / rows < cur (dense)
+    if (wave == 2 && lane_colrow >= 0) ag[lane_colrow * N + cur] = 1.f;
+    if (dense) {
+      for (int r = t2; r < cur; r += 128) ag[r * N + cur] = 1.f;
+    }
+    if (t2 < F4) {   // the inserted node (gcm.py:274)
+      *reinterpret_cast<float4*>(ng + cur * F + t2 * 4) =
+          *reinterpret_cast<const float4*>(obs + (size_t)b * F + t2 * 4);
+    }
+    if (t2 == 127) {   // count_out may alias count_in: every wave read it long ago
+      count_out[b] = cur + 1;
+      if (cur_out) cur_out[b] = cur;
+      const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
+      if (f) atomicOr(flags, f);
+    }
   }
 }
 
-template <int FP, int HP, int H2P>
+template <int FP, int HP, int H2P, int NX, bool EXACT>
 int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* adj_in,
            const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
            int64_t* cur_out, const Edits& E, const Gnn2& P, float* mx, float* saved,
            const SavedLayout& lay, uint32_t* flags, int B, int N, int F, int H1, int H2) {
   constexpr size_t lds = sizeof(float) * (size_t)Lds<FP, HP, H2P>::TOTAL;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = k_step_rows<FP, HP, H2P>;
+  const bool func = adj_out != adj_in;
+  auto kern = func ? k_step_rows<FP, HP, H2P, true, NX, EXACT> : k_step_rows<FP, HP, H2P, false, NX, EXACT>;
   if (lds > 64 * 1024) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    static bool attr_set[64] = {};   // per device (index clamped): the attribute is per context
-    bool& done = attr_set[dev & 63];
+    static bool attr_set[2][64] = {};   // per device (index clamped): the attribute is per context
+    bool& done = attr_set[func][dev & 63];
     if (!done) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       done = true;
@@ -509,11 +615,19 @@ extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, 
   const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
   hipStream_t s = (hipStream_t)stream;
   const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64, h2p = H2 <= 32 ? 32 : 64;
+  // tile-exact specialisations of the common shapes
+#define GCM_RX(a, n)                                                                               \
+  if (F == a && H1 == a && H2 == a && N == n)                                                      \
+    return gcm_rows::launch<a, a, a, n, true>(s, obs, nodes_in, adj_in, count_in, nodes_out,       \
+                                              adj_out, count_out, cur_out, E, P, mx, saved, lay,   \
+                                              flags, B, N, F, H1, H2);
+  GCM_RX(32, 128) GCM_RX(32, 64) GCM_RX(32, 32) GCM_RX(64, 128)
+#undef GCM_RX
 #define GCM_R(a, b_, c)                                                                          \
   if (fp == a && hp == b_ && h2p == c)                                                           \
-    return gcm_rows::launch<a, b_, c>(s, obs, nodes_in, adj_in, count_in, nodes_out, adj_out,    \
-                                      count_out, cur_out, E, P, mx, saved, lay, flags, B, N, F,  \
-                                      H1, H2);
+    return gcm_rows::launch<a, b_, c, 0, false>(s, obs, nodes_in, adj_in, count_in, nodes_out,   \
+                                                adj_out, count_out, cur_out, E, P, mx, saved,    \
+                                                lay, flags, B, N, F, H1, H2);
   GCM_R(32, 32, 32) GCM_R(32, 32, 64) GCM_R(32, 64, 32) GCM_R(32, 64, 64)
   GCM_R(64, 32, 32) GCM_R(64, 32, 64) GCM_R(64, 64, 32) GCM_R(64, 64, 64)
 #undef GCM_R

@@ -15,9 +15,10 @@ import torch
 def initial_hidden(x, graph_size, edge_weights=False):
     """gcm.py:194-211 - all-zero (nodes, adj, weights, num_nodes)."""
     B, F = x.shape
-    nodes = torch.zeros(B, graph_size, F)
-    adj = torch.zeros(B, graph_size, graph_size)
-    weights = torch.zeros(B, graph_size, graph_size) if edge_weights else torch.zeros(0)
+    dt = x.dtype                      # float32 like the reference; float64 for error bounds in tests
+    nodes = torch.zeros(B, graph_size, F, dtype=dt)
+    adj = torch.zeros(B, graph_size, graph_size, dtype=dt)
+    weights = torch.zeros(B, graph_size, graph_size, dtype=dt) if edge_weights else torch.zeros(0, dtype=dt)
     return nodes, adj, weights, torch.zeros(B, dtype=torch.long)
 
 
@@ -248,7 +249,7 @@ def dense_step(x, hidden, gnn, graph_size=128, edge_selectors=None, preprocessor
     if hidden is None:
         hidden = initial_hidden(x, graph_size, edge_weights)
     nodes, adj, weights, num_nodes = hidden
-    assert x.dtype == nodes.dtype == weights.dtype == torch.float32
+    assert x.dtype == nodes.dtype == weights.dtype and x.dtype in (torch.float32, torch.float64)
     assert num_nodes.dtype == torch.long and num_nodes.dim() == 1
     B, N = x.shape[0], nodes.shape[1]
     assert N == adj.shape[1] == adj.shape[2]

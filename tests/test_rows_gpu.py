@@ -13,6 +13,21 @@ from test_dense_gpu import dev_gnn_from, product_selector, DEV, RTOL, ATOL
 pytestmark = pytest.mark.gpu
 
 
+def _fp64_bound(ref, obs, hidden, out32, **kw):
+    """Summation-order noise: for DenseEdge every aggregate adds up to N terms of magnitude ~1, and
+    two fp32 evaluations in different orders differ by more than 1e-5 relative.  The bound used
+    instead: distance to the SAME computation in float64 (the oracle run in double), which must
+    not exceed 3x the distance of the reference's own fp32 evaluation from it (floor 2e-6).
+    Returns (out64, atol)."""
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    h64 = None if hidden is None else tuple(t.double() if t.is_floating_point() else t.clone() for t in hidden)
+    with torch.no_grad():
+        out64, _ = od.dense_rollout(obs.double(), h64, ref64, **kw)
+    err32 = float((out32.detach().double() - out64).abs().max())
+    return out64, max(2e-6, 3.0 * err32)
+
+
 def _rows_taken(mem):
     """True when the last rollout recorded live-row steps / has a rows holder."""
     pc = mem._packed_cache
@@ -53,8 +68,12 @@ def test_rows_path_matches_reference(name, donate):
     assert torch.equal(torch.stack(sums).cpu(), fx["adj_sums"])
     assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])
     assert torch.equal(hidden[3].cpu(), fx["hT_num_nodes"])
-    atol = 5e-6 if m["selector"] == "dense" else ATOL
-    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=atol)
+    if m["selector"] == "dense":       # up to N terms per aggregate: bound through float64
+        out64, atol = _fp64_bound(ref, fx["obs"], fx.h0(), fx["mx"], graph_size=m["N"],
+                                  edge_selectors=oracle_selector(m))
+        assert float((mxs.detach().cpu().double() - out64).abs().max()) <= atol
+    else:
+        torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
         torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
@@ -132,8 +151,11 @@ def test_rows_path_vs_oracle(case, donate):
         assert torch.equal(h_d[3].cpu(), count0)
     assert torch.equal(hidden[1].cpu(), hid_c[1]) and torch.equal(hidden[0].cpu(), hid_c[0])
     assert torch.equal(hidden[3].cpu(), hid_c[3])
-    atol = 2e-5 if sel[0] == "dense" else 2e-6
-    torch.testing.assert_close(out_d.cpu(), out_c, rtol=RTOL, atol=atol)
+    if sel[0] == "dense":              # up to N terms per aggregate: bound through float64
+        out64, atol = _fp64_bound(ref, obs, h_o, out_c, graph_size=N, edge_selectors=osel)
+        assert float((out_d.detach().cpu().double() - out64).abs().max()) <= atol
+    else:
+        torch.testing.assert_close(out_d.cpu(), out_c, rtol=RTOL, atol=2e-6)
     for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
         scale = float(pc.grad.abs().max()) + 1e-12
         torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=2e-5 * scale, msg=k)
