@@ -5,16 +5,22 @@ Metric (BASELINE.json): belief-states/sec = B*T / wall time of
     reset state; for t in range(T): mx_t, m = gcm(obs[t], m); loss = stack(mx).mean();
     loss.backward(); all-reduce grads (N>1); synchronize
 on cfg2: DenseGCM + TemporalBackedge([1,2,4]), B=256 per GPU, graph_size=128, obs=hidden=32,
-2 x DenseGraphConv + tanh.  One "step" of this bench = one such rollout (B*T belief states).
-Batch-sharded over ranks (weak scaling: every rank owns B graphs), one RCCL all-reduce of the
-flat gradient bucket per backward.
+2 x DenseGraphConv + tanh.  One "step" of this bench = one such rollout (B*T belief states)
+through the per-step drop-in call surface.  Batch-sharded over ranks (weak scaling: every rank
+owns B graphs), one RCCL all-reduce of the flat gradient bucket per backward.
 
-  python bench.py --gpus N --steps K --warmup W
+`value` is measured with the module's donated-state mode (`DenseGCM(..., donate_state=True)`:
+the step advances the hidden state in place instead of cloning it, same results) and with the
+loop + backward captured once in a HIP graph and replayed (torch.cuda.CUDAGraph, in process);
+the same loop run eagerly, with and without donation, is reported beside it (`variants`).
+
+  python bench.py --gpus N --steps K --warmup W        # N > 1 without WORLD_SIZE: spawns N ranks
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,16 +29,37 @@ for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak; no TF32 on gfx950
 B, N, F, H = 256, 128, 32, 32
 HOPS = [1, 2, 4]
 
 
-def build_memory(device):
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes BEFORE
+    anything in this process touches the GPU (never re-exec a process that has), relay rank 0's
+    JSON line and the worst exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def build_memory(device, donate=False, selector="temporal"):
+    import torch
     from gcm import nn as G
     from gcm.gcm import DenseGCM
     from gcm.edge_selectors.temporal import TemporalBackedge
@@ -41,101 +68,134 @@ def build_memory(device):
     gnn = G.Sequential("x, adj, weights, B, N", [
         (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
         (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(device)
-    return DenseGCM(gnn, edge_selectors=TemporalBackedge(HOPS), graph_size=N), gnn
+    if selector == "learned":
+        from gcm.edge_selectors.learned import LearnedEdge
+        sel = LearnedEdge(F).to(device)
+    else:
+        sel = TemporalBackedge(HOPS)
+    return DenseGCM(gnn, edge_selectors=sel, graph_size=N, donate_state=donate), gnn
 
 
-def rollout(mem, obs, bucket, weight):
+def rollout(mem, obs, bucket=None, weight=1.0):
+    import torch
     hidden, outs = None, []
     for t in range(obs.shape[0]):
         mx, hidden = mem(obs[t], hidden)
         outs.append(mx)
     loss = torch.stack(outs).mean()
     loss.backward()
-    bucket.all_reduce_mean(weight)
+    if bucket is not None:
+        bucket.all_reduce_mean(weight)
     return loss
 
 
-def rollout_api(mem, obs, bucket, weight):
+def rollout_api(mem, obs, bucket=None, weight=1.0):
     """Same work through the additive time-batched entry DenseGCM.rollout."""
     out, _ = mem.rollout(obs, None)
     loss = out.mean()
     loss.backward()
-    bucket.all_reduce_mean(weight)
+    if bucket is not None:
+        bucket.all_reduce_mean(weight)
     return loss
 
 
-def time_dominant_kernels(mem, obs, reps=200):
-    """Mean launch duration of the one-kernel forward step (k_step_fwd_live) and of the GNN-only
-    kernels k_gnn2_row_fwd / k_gnn2_row_bwd on the real end-of-rollout state."""
-    from gcm import _hip, _ops
+def capture(mem, gnn, obs):
+    """The per-step loop + backward as one HIP graph (captured in this process; the usual
+    side-stream warm-up first).  Returns the graph; parameter .grad tensors are graph outputs."""
+    import torch
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            gnn.zero_grad(set_to_none=True)
+            rollout(mem, obs)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gnn.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rollout(mem, obs)
+    return g
+
+
+def time_step_kernel(mem, obs, reps=3):
+    """Duration of the dominant kernel (k_step_rows, one launch per forward step) IN SITU: the T
+    launches of a rollout through the C ABI on the evolving donated state, a HIP event pair on the
+    launch stream around every launch; mean over T x reps launches.  Also the time-parallel
+    backward kernel on the records of one rollout."""
+    import ctypes
+    import torch
+    from gcm import _hip
 
     lib = _hip.lib()
-    with torch.no_grad():
-        hidden = None
-        for t in range(obs.shape[0]):
-            _, hidden = mem(obs[t], hidden)
-    nodes, adj, _, count = hidden
-    dev = nodes.device
-    cur = (count - 1).contiguous()
-    cfg = mem._fused_plan(nodes, adj, torch.zeros(0, device=dev), F)
-    w = cfg.unpack_ptrs(mem._packed_params(cfg).detach())
-    P = cfg.P
-    mx = torch.empty(B, H, device=dev)
-    h1 = torch.empty(B, N, H, device=dev)
-    agg1 = torch.empty(B, N, F, device=dev)
-    agg2 = torch.empty(B, H, device=dev)
+    dev = obs.device
+    T = obs.shape[0]
+    cfg = mem._fused_plan(*mem.get_initial_hidden_state(obs[0])[:3], F)
+    params = mem._packed_params(cfg, head=True).detach()
+    lay = (ctypes.c_size_t * 6)()
+    lib.gcm_dense_rows_layout(B, N, F, H, H, ctypes.addressof(lay))
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
-    g_mx, g_no = torch.randn(B, H, device=dev), torch.randn(B, N, F, device=dev)
-    g_ni, g_obs = torch.empty(B, N, F, device=dev), torch.empty(B, F, device=dev)
-    slabs = torch.empty(B, P, device=dev)
-    p, st = _hip.ptr, _hip.stream()
+    st, p = _hip.stream(), _hip.ptr
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
 
-    def fwd():
-        return lib.gcm_dense_gnn2_row_fwd(p(nodes), p(adj), p(cur), w[0], w[1], w[2], 1, w[3], w[4], w[5], 1,
-                                          p(mx), p(h1), p(agg1), p(agg2), p(flags), B, N, F, H, H, st)
+    def new_event():
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        return e
 
-    def bwd():
-        return lib.gcm_dense_gnn2_row_bwd(p(g_mx), p(g_no), p(nodes), p(adj), p(cur), p(cur), w[0], w[1], w[2], 1,
-                                          w[3], w[4], w[5], 1, p(mx), p(h1), p(agg1), p(agg2), p(g_ni),
-                                          p(g_obs), p(slabs), 0, B, N, F, H, H, st)
-
-    # the one-kernel forward step (advance + selector + GNN) on the state one step earlier
-    with torch.no_grad():
-        hid = None
-        for t in range(obs.shape[0] - 1):
-            _, hid = mem(obs[t], hid)
-    n_in, a_in, _, c_in = hid
-    n_out, a_out = torch.empty_like(n_in), torch.empty_like(a_in)
-    ibuf = torch.empty(2, B, dtype=torch.int64, device=dev)
-    x_last = obs[-1].contiguous()
-
-    def step():
-        return lib.gcm_dense_step_fused_fwd(p(x_last), p(n_in), p(a_in), p(c_in), p(n_out), p(a_out),
-                                            ibuf.data_ptr(), ibuf.data_ptr() + 8 * B, cfg.arr_ptr, cfg.n_desc,
-                                            w[0], w[1], w[2], 1, w[3], w[4], w[5], 1, p(mx), p(h1), p(agg1),
-                                            p(agg2), p(flags), B, N, F, H, H, st)
-
-    out = {}
-    for name, fn in (("k_step_fwd_live", step), ("k_gnn2_row_fwd", fwd), ("k_gnn2_row_bwd", bwd)):
-        for _ in range(10):
-            assert fn() == 0
+    evs = [(new_event(), new_event()) for _ in range(T)]
+    spans = []
+    saved_all = [torch.empty(lay[0], device=dev) for _ in range(T)]
+    for _ in range(reps + 1):
+        nodes, adj, _, count = mem.get_initial_hidden_state(obs[0])
+        for t in range(T):
+            sv = saved_all[t]
+            # events recorded by the dispatch itself (kernel begin / end timestamps)
+            lib.gcm_debug_time_next_launch(evs[t][0], evs[t][1])
+            rc = lib.gcm_dense_rows_step_fwd(p(obs[t]), p(nodes), p(adj), p(count), p(nodes), p(adj), p(count), None,
+                                             cfg.arr_ptr, cfg.n_desc, p(params), cfg.has_bias, cfg.acts[0],
+                                             cfg.acts[1], p(sv), p(sv), p(flags), B, N, F, H, H, st)
+            assert rc == 0
         torch.cuda.synchronize()
+        ms = ctypes.c_float()
+        row = []
+        for a, b in evs:
+            assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            row.append(ms.value)
+        spans.append(row)
+    for a, b in evs:
+        hip.hipEventDestroy(a)
+        hip.hipEventDestroy(b)
+    step_ms = sum(sum(s) for s in spans[1:]) / (reps * T)
+    # the backward kernel over the T records
+    g_mx = torch.full((T, B, H), 1.0 / (T * B * H), device=dev)
+    arr_s = (ctypes.c_void_p * T)(*[s.data_ptr() for s in saved_all])
+    arr_g = (ctypes.c_void_p * T)(*[g_mx[t].data_ptr() for t in range(T)])
+    ws_bytes = lib.gcm_dense_rows_bptt_workspace_bytes(T, B, F, H, H)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    gp = torch.empty(cfg.P, device=dev)
+    times = []
+    for _ in range(reps + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(reps):
-            fn()
+        rc = lib.gcm_dense_rows_bptt(arr_s, arr_g, T, H, 1, p(params), cfg.has_bias, cfg.acts[0], cfg.acts[1], None,
+                                     p(gp), p(ws), ws_bytes, B, N, F, H, H, st)
         b.record()
+        assert rc == 0
         torch.cuda.synchronize()
-        out[name] = (reps, a.elapsed_time(b) / reps)
-    return out
+        times.append(a.elapsed_time(b))
+    return step_ms, sum(times[1:]) / reps
 
 
 def cpu_baseline(T, budget_s=20.0):
     """The oracle (op-for-op eager-PyTorch restatement of the reference, kind "port") timed on
     this box's host cores on a BOUNDED sample of the same workload: the same B/N/F/H/selector,
     a rollout of T_s <= T steps fwd+bwd (T_s sized so the sample stays within ~budget_s).
-    The thread count is calibrated first (8..64): eager torch on 256 threads is far slower
-    than on 16-32 for these op sizes, so the CPU gets its best configuration."""
+    Thread policy: torch's own default is one thread per host CPU, which on a
+    256-CPU host is several times SLOWER than 16-32 threads for these op sizes; the CPU gets its
+    best configuration of {8, 16, 32, 64, os.cpu_count()} and the choice is recorded."""
+    import torch
     from oracle import dense as od
 
     torch.manual_seed(0)
@@ -150,44 +210,52 @@ def cpu_baseline(T, budget_s=20.0):
         gnn.zero_grad(set_to_none=True)
         return time.perf_counter() - t0
 
-    best = None
-    for th in [t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 8)] or [os.cpu_count() or 1]:
+    ncpu = os.cpu_count() or 1
+    tried = {}
+    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
         torch.set_num_threads(th)
         run(2)
-        dt = run(4)
-        if best is None or dt < best[1]:
-            best = (th, dt)
-    torch.set_num_threads(best[0])
-    per_step = best[1] / 4
+        tried[th] = run(4)
+    best = min(tried, key=tried.get)
+    torch.set_num_threads(best)
+    per_step = tried[best] / 4
     # per-step cost grows with t (autograd state), so size the sample conservatively
     T_s = int(max(8, min(T, budget_s / (2.5 * per_step))))
     dt = run(T_s)
-    return {"value": B * T_s / dt, "unit": "belief-states/s", "cores": best[0], "kind": "port",
-            "seconds": dt, "host_cpus": os.cpu_count(),
+    return {"value": B * T_s / dt, "unit": "belief-states/s", "cores": best, "kind": "port",
+            "seconds": dt, "host_cpus": ncpu,
+            "threads_tried_s_per_4_steps": {str(k): round(v, 3) for k, v in tried.items()},
             "sample": f"1 rollout fwd+bwd, same workload (B={B}, N={N}, F={F}, H={H}, hops={HOPS}) "
-                      f"truncated to T={T_s} steps, oracle/dense.py on {best[0]} torch threads "
-                      f"(best of 8/16/32/64)"}
+                      f"truncated to T={T_s} steps, oracle/dense.py on {best} torch threads "
+                      f"(best of {sorted(tried)})"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--T", type=int, default=128, help="rollout length (128 fills the graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager loop instead of the graph replay")
     args = ap.parse_args()
 
-    from gcm import _ops, parallel
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+
+    import torch
+    import torch.distributed as dist
+    from gcm import parallel
 
     rank, local_rank, world = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local_rank)
     T = args.T
-    mem, gnn = build_memory(device)
+    mem, gnn = build_memory(device, donate=True)
     bucket = parallel.GradBucket(gnn)
     gen = torch.Generator().manual_seed(1000 + rank)
-    obs = torch.rand(T, B, F, generator=gen).to(device)   # resident in HBM; like the reference's speed test and the CPU baseline, obs carries no grad
+    # resident in HBM; like the reference's speed test and the CPU baseline, obs carries no grad
+    obs = torch.rand(T, B, F, generator=gen).to(device)
     weight = 1.0 / world
 
     def sync():
@@ -195,136 +263,101 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        rollout(mem, obs, bucket, weight)
-        gnn.zero_grad(set_to_none=True)
-        obs.grad = None
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rollout(mem, obs, bucket, weight)
-        gnn.zero_grad(set_to_none=True)
-        obs.grad = None
-    sync()
-    dt = time.perf_counter() - t0
-    mem.check_flags()
-    t = torch.tensor([dt], device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    graph = None if args.no_graph else capture(mem, gnn, obs)
 
-    # ---- the same work through the time-batched entry (reported beside `value`) ---------------
-    def timed(fn, steps):
+    def step():
+        if graph is not None:
+            graph.replay()
+            bucket.all_reduce_mean(weight)
+        else:
+            rollout(mem, obs, bucket, weight)
+            gnn.zero_grad(set_to_none=True)
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            fn(mem, obs, bucket, weight)
-            gnn.zero_grad(set_to_none=True)
-            obs.grad = None
+            fn()
         sync()
         t = torch.tensor([time.perf_counter() - t0], device=device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    timed(rollout_api, 2)
-    dt_roll = timed(rollout_api, args.steps)
+    dt = timed(step, args.steps, args.warmup)
+    # the flag word the kernels OR into (finite check, overflow, bad counts), read once
+    flags = mem._flag_word(device)
+    bits = int(flags.item())
+    assert not (bits & 6), f"kernels flagged {bits}"
 
-    # forward only (inference, no autograd graph): SURVEY 8(d) asks for it beside fwd+bwd
-    def fwd_step(mem, obs, bucket, weight):
+    # ---- the same work along the other paths (reported beside `value`) ---------------------------
+    side = max(3, min(20, args.steps // 10))
+    variants = {}
+    mem_e, gnn_e = build_memory(device, donate=True)
+    bucket_e = parallel.GradBucket(gnn_e)
+
+    def eager(m, g, bk):
+        def f():
+            rollout(m, obs, bk, weight)
+            g.zero_grad(set_to_none=True)
+        return f
+
+    variants["eager_donated"] = world * B * T * side / timed(eager(mem_e, gnn_e, bucket_e), side, 2)
+    mem_f, gnn_f = build_memory(device, donate=False)
+    bucket_f = parallel.GradBucket(gnn_f)
+    variants["eager_functional"] = world * B * T * side / timed(eager(mem_f, gnn_f, bucket_f), side, 2)
+
+    def roll():
+        rollout_api(mem_f, obs, bucket_f, weight)
+        gnn_f.zero_grad(set_to_none=True)
+
+    variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
+
+    def fwd_only():
         with torch.no_grad():
             hidden = None
-            for t in range(obs.shape[0]):
-                _, hidden = mem(obs[t], hidden)
+            for t in range(T):
+                _, hidden = mem_e(obs[t], hidden)
 
-    def fwd_roll(mem, obs, bucket, weight):
-        with torch.no_grad():
-            mem.rollout(obs, None)
+    variants["forward_only_eager_donated"] = world * B * T * side / timed(fwd_only, side, 1)
+    mem_e.check_flags()
+    mem_f.check_flags()
 
-    timed(fwd_step, 1)
-    dt_fwd = timed(fwd_step, args.steps)
-    timed(fwd_roll, 1)
-    dt_fwd_roll = timed(fwd_roll, args.steps)
-
-    # ---- kernel durations with HIP events on the launch stream -------------------------------
-    # (a) in situ: event pairs around every C-ABI call of a repeated timed region (a step call
-    #     enqueues state-advance + selector + fused GNN kernels, so these are per-call sums)
-    _ops.TIMER = _ops.KernelTimer()
-    for _ in range(min(args.steps, 3)):
-        rollout(mem, obs, bucket, weight)
-        gnn.zero_grad(set_to_none=True)
-        obs.grad = None
-    torch.cuda.synchronize()
-    kern = _ops.TIMER.summary()
-    # ... and around the two C-ABI calls of the rollout entry (persistent forward; backward =
-    # time-parallel BPTT + reverse scan + one slab sum)
-    _ops.TIMER = _ops.KernelTimer()
-    for _ in range(min(args.steps, 3)):
-        rollout_api(mem, obs, bucket, weight)
-        gnn.zero_grad(set_to_none=True)
-    torch.cuda.synchronize()
-    kern_roll = _ops.TIMER.summary()
-    _ops.TIMER = None
-    # (b) the two dominant kernels alone: R back-to-back launches through the C ABI on the live
-    #     state of this workload (graph after T steps), one event pair around the batch
-    kern.update(time_dominant_kernels(mem, obs))
+    step_ms, bptt_ms = time_step_kernel(mem_e, obs) if rank == 0 else (None, None)
 
     if rank == 0:
         states = world * B * T * args.steps
-        # full-dense algorithmic FLOPs per belief state (both layers on all N rows)
-        fwd_full = 2 * N * N * (F + H) + 4 * N * (F * H + H * H)
-        # what the fused kernels execute: layer 1 on all rows, layer 2 only on the kept row
-        fwd_exec = 2 * N * N * F + 4 * N * F * H + 2 * N * H + 4 * H * H
-        bwd_exec = 2 * N * N * F + 8 * N * F * H + 2 * N * H + 8 * H * H
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath))
-
-        def mfma_view(kernel, full, execd):
-            n_launch, ms = kern[kernel]
-            sec = ms * 1e-3
-            return {"bound": "mfma", "kernel": kernel, "achieved": B * full / sec / 1e12,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": B * full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": traffic.get(kernel), "flops_per_launch": B * full,
-                    "avg_launch_ms": ms, "launches_timed": n_launch,
-                    "achieved_executed": B * execd / sec / 1e12,
-                    "frac_executed": B * execd / sec / 1e12 / PEAK_F32_MFMA_TFLOPS}
-
-        # Dominant kernel = k_step_fwd_live (one kernel per forward step).  It is HBM-bound
-        # (AI 8-17 FLOP/B < ridge 20-25): SURVEY 8(d)'s compulsory bytes per belief state
-        # (adj once, x once, obs in, belief out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2)
-        # over its mean launch time; `functional` adds what the reference's functional state
-        # semantics force through HBM (adj + nodes copied out every step, gcm.py:262-286) and the
-        # activations saved for BPTT - only the live 32-row tiles of h1 / agg1 (1 of 4 on the timed
-        # state: node 127 links to 126, 125, 123).
+        # Dominant kernel = k_step_rows: one launch per forward step, > 90 % of the GPU time of the
+        # metric (the backward of the whole rollout is ONE launch of k_bptt_rows).  Bounding
+        # roofline: HBM.  `achieved` = SURVEY 8(d)'s compulsory bytes per belief state (adj once, x
+        # once, obs in, belief out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2) x B
+        # over the mean launch time.  The kernel exploits "only row n_b is kept" (gcm.py:314): it
+        # reads the node matrix, row cur and the live rows, not the [N,N] adjacency - `traffic` (PMC)
+        # is what it actually moves, `achieved_moved` the rate of that.
         alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
-        live_rows = 32
-        func_bytes = B * (2 * 4 * N * N + 2 * 4 * N * F + 4 * F + 4 * H + 16
-                          + 4 * live_rows * H + 4 * live_rows * F + 4 * H)
-        n_launch, ms = kern["k_step_fwd_live"]
-        sec = ms * 1e-3
-        dominant = {"bound": "hbm", "kernel": "k_step_fwd_live", "achieved": alg_bytes / sec / 1e9,
+        sec = step_ms * 1e-3
+        moved = traffic.get("k_step_rows")
+        dominant = {"bound": "hbm", "kernel": "k_step_rows", "achieved": alg_bytes / sec / 1e9,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS,
-                    "traffic": traffic.get("k_step_fwd_live"), "bytes_per_launch": alg_bytes,
-                    "avg_launch_ms": ms, "launches_timed": n_launch,
-                    "achieved_functional": func_bytes / sec / 1e9,
-                    "frac_functional": func_bytes / sec / 1e9 / PEAK_HBM_GBS,
-                    "functional_bytes_per_launch": func_bytes,
-                    "note": "bytes_per_launch = SURVEY 8(d) compulsory bytes (in-place state); the kernel "
-                            "also copies adj+nodes out (functional hidden state, gcm.py:262-286) and saves "
-                            "the live tiles of h1/agg1 for BPTT = functional_bytes_per_launch, which is what "
-                            "`traffic` (PMC: 2*FETCH_SIZE+WRITE_SIZE) measures. avg_launch_ms: 200 "
-                            "back-to-back launches on the end-of-rollout state, one HIP event pair"}
-        note = ("flops: SURVEY 8(d) full-dense (2 layers x all N rows); *_executed: what the kernel can "
-                "execute at most - layer 1 on all rows (GNN-only kernels) or on the live 32-row tile "
-                "(k_step_fwd_live), row-only layer 2 (gcm.py:314); all-zero 32x32 adjacency tiles are skipped")
-        fwd_live = 2 * live_rows * N * F + 4 * live_rows * F * H + 2 * N * H + 4 * H * H
-        other = [dict(mfma_view("k_gnn2_row_bwd", 2 * fwd_full, bwd_exec), note=note),
-                 dict(mfma_view("k_step_fwd_live", fwd_full, fwd_live), note=note),
-                 dict(mfma_view("k_gnn2_row_fwd", fwd_full, fwd_exec), note=note)]
-        from gcm import _ext
+                    "traffic": moved, "bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms,
+                    "launches_timed": 3 * T,
+                    "achieved_moved": (moved / sec / 1e9) if moved else None,
+                    "note": "bytes_per_launch = SURVEY 8(d) full-dense compulsory bytes (what the reference's "
+                            "formulation must move); the live-row kernel moves `traffic` bytes (PMC: "
+                            "2*FETCH_SIZE + WRITE_SIZE per launch, profiles/r02_traffic_detail.json) because only "
+                            "the rows that reach the kept belief row are evaluated and the state is advanced "
+                            "in place: the kernel is bound by its chain of dependent latencies (one wave per "
+                            "SIMD at B = 256 graphs on 256 CUs), not by bytes. avg_launch_ms: the T launches "
+                            "of a rollout in situ on the evolving state, each bracketed by HIP events recorded by "
+                            "the dispatch itself (hipExtLaunchKernelGGL start/stop events = the kernel begin/end "
+                            "timestamps rocprofv3 --kernel-trace reports)"}
+        fwd_full = 2 * N * N * (F + H) + 4 * N * (F * H + H * H)
         line = {
             "metric": "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 F=32",
             "value": states / dt, "unit": "belief-states/s", "n_gpus": world,
@@ -333,26 +366,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": "cfg2: DenseGCM + TemporalBackedge([1,2,4]), B=256/GPU, graph_size=128, "
                                    "obs=32, hidden=32, 2x DenseGraphConv+tanh, T=%d; one bench step = one rollout "
-                                   "through the per-step drop-in API `for t: mx, m = gcm(obs[t], m)` + backward" % T,
+                                   "through the per-step drop-in call surface `for t: mx, m = gcm(obs[t], m)` + "
+                                   "backward" % T,
                        "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": T,
+                       "state": "donated (DenseGCM(donate_state=True): hidden state advanced in place)",
+                       "launch": "eager" if graph is None else "HIP graph of the loop + backward, captured once "
+                                                               "in process, replayed per bench step",
                        "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
-            "forward_only": {"per_step_api": states / dt_fwd, "rollout_api": states / dt_fwd_roll,
-                             "unit": "belief-states/s", "note": "torch.no_grad(): no history kept"},
-            "host_path": "c++ autograd node (gcm/_lib/ext)" if _ext.module() is not None
-                         else "python autograd function",
-            "roofline": dominant, "roofline_mfma_view": other,
-            "kernel_ms": {k: round(v[1], 5) for k, v in kern.items()},
-            "rollout_api": {"value": states / dt_roll, "unit": "belief-states/s",
-                            "ms_per_step": dt_roll / args.steps * 1e3,
-                            "kernel_ms": {k: round(v[1], 5) for k, v in kern_roll.items()},
-                            # SURVEY 8(d) bytes of T steps over the persistent forward kernel's time: an
-                            # EFFECTIVE rate - the kernel keeps the state in LDS and does not move them
-                            "forward_effective_GBps": (T * alg_bytes / (kern_roll["gcm_dense_rollout_fwd"][1] * 1e-3) / 1e9
-                                                       if "gcm_dense_rollout_fwd" in kern_roll else None),
-                            "note": "same workload and results through the additive DenseGCM.rollout(obs[T,B,F]) "
-                                    "entry, one autograd node: persistent forward kernel (graph state resident "
-                                    "in LDS for all T steps), time-parallel BPTT (one launch over T*B graph-steps "
-                                    "+ reverse scan of the node gradient)"},
+            "variants": {k: round(v, 1) for k, v in variants.items()},
+            "variants_note": "belief-states/s of the same workload: eager per-step loop with donated / "
+                             "functional (reference-default) state, the additive DenseGCM.rollout entry, and the "
+                             "forward loop alone under no_grad",
+            "roofline": dominant,
+            "roofline_mfma_view": {"kernel": "k_step_rows", "flops_per_launch_full_dense": B * fwd_full,
+                                   "achieved_full_dense_TFLOPs": B * fwd_full / sec / 1e12,
+                                   "frac_of_fp32_mfma_peak": B * fwd_full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "note": "SURVEY 8(d) full-dense FLOPs (2 layers x all N rows) over the same "
+                                           "launch time; the kernel executes layer 1 on the live rows only"},
+            "kernel_ms": {"k_step_rows": round(step_ms, 5), "k_bptt_rows(T=%d)" % T: round(bptt_ms, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T)

@@ -22,6 +22,8 @@
 // what makes donation compatible with BPTT.
 //
 // One workgroup (4 waves) per graph.  N <= 128, N % 4 == 0, F % 4 == 0, F, H1, H2 <= 64.
+#include <hip/hip_ext.h>
+
 #include "fused_common.h"
 #include "rows_common.h"
 
@@ -537,6 +539,8 @@ __global__ __launch_bounds__(256) void k_step_rows(
   }
 }
 
+static thread_local hipEvent_t t_start = nullptr, t_stop = nullptr;   // gcm_debug_time_next_launch
+
 template <int FP, int HP, int H2P, int NX, bool EXACT>
 int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* adj_in,
            const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
@@ -556,12 +560,25 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
       done = true;
     }
   }
+  if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
+    hipExtLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in, adj_in,
+                          count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
+                          N, F, H1, H2);
+    t_start = t_stop = nullptr;
+    return gcm_launch_status();
+  }
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in, nodes_out,
                      adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2);
   return gcm_launch_status();
 }
 
 }  // namespace gcm_rows
+
+extern "C" int gcm_debug_time_next_launch(void* start_event, void* stop_event) {
+  gcm_rows::t_start = (hipEvent_t)start_event;
+  gcm_rows::t_stop = (hipEvent_t)stop_event;
+  return GCM_OK;
+}
 
 extern "C" int gcm_dense_rows_supported(int N, int F, int H1, int H2) {
   if (N <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;

@@ -401,6 +401,12 @@ int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, const float
                             float* saved, uint32_t* flags, int B, int N, int F, int H1, int H2,
                             gcm_stream_t stream);
 
+/* Measurement aid (bench.py): the NEXT gcm_dense_rows_step_fwd launch of the calling thread is
+ * bracketed by the two hipEvent_t given here, recorded by the dispatch itself
+ * (hipExtLaunchKernelGGL start / stop events: the kernel's own begin / end timestamps, what
+ * rocprofv3 --kernel-trace reports) instead of by marker packets around it.  One-shot. */
+int gcm_debug_time_next_launch(void* start_event, void* stop_event);
+
 /* Parameter gradient of n_steps recorded steps in one pass (time-parallel BPTT; valid when neither
  * the observations nor the incoming node matrix need a gradient, so step t's adjoint depends on
  * g_mx[t] and its own record only).  saved_host / gmx_host: HOST arrays of n_steps DEVICE pointers

@@ -22,7 +22,12 @@ def per_kernel(d, counter):
         for row in csv.DictReader(open(f)):
             m = re.search(r"\b(k_[A-Za-z0-9_]+)", row["Kernel_Name"])
             if m and row.get("Counter_Name") == counter:
-                acc[m.group(1)].append(float(row["Counter_Value"]))
+                name = m.group(1)
+                if name == "k_step_rows":       # template <FP, HP, H2P, FUNC, ...>: functional state copy?
+                    t = re.search(r"k_step_rows<\d+, \d+, \d+, (true|false)", row["Kernel_Name"])
+                    if t and t.group(1) == "true":
+                        name = "k_step_rows_functional"
+                acc[name].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
