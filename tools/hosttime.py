@@ -1,65 +1,80 @@
-#!/usr/bin/env python3
-"""Where does the per-step host time go?  Dev tool."""
+"""Host-side timing of the per-step loop on cfg2: eager with functional / donated state (fwd+bwd, forward only
+under no_grad and in grad mode) and the HIP-graph replay.  Dev tool: `T=128 python tools/hosttime.py`."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "graph-conv-memory_amd"))
+for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
+    sys.path.insert(0, p)
 import torch
 import bench
-from gcm import parallel, _ops
 
+B, N, F, H, T = 256, 128, 32, 32, int(os.environ.get("T", 128))
 dev = torch.device("cuda", 0)
-mem, gnn = bench.build_memory(dev)
-obs = torch.rand(128, bench.B, bench.F).to(dev)
-T = 128
 
-def fwd(grad):
-    ctx = torch.enable_grad() if grad else torch.no_grad()
-    with ctx:
-        hid, outs = None, []
-        for t in range(T):
-            mx, hid = mem(obs[t], hid)
-            outs.append(mx)
-    return outs
 
-for _ in range(3):
-    torch.stack(fwd(True)).mean().backward(); gnn.zero_grad(set_to_none=True)
-torch.cuda.synchronize()
+def build(donate):
+    mem, gnn = bench.build_memory(dev)
+    mem.donate_state = donate
+    return mem, gnn
 
-def timed(label, fn, n=5):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n):
-        r = fn()
-    t_host = (time.perf_counter() - t0) / n
-    torch.cuda.synchronize(); t_all = (time.perf_counter() - t0) / n
-    print(f"{label:38s} host {t_host*1e3:7.2f} ms  ({t_host/T*1e6:6.1f} us/step)   host+gpu {t_all*1e3:7.2f} ms")
-    return r
 
-timed("forward loop, no_grad", lambda: fwd(False))
-outs = timed("forward loop, grad", lambda: fwd(True))
-FW = []
-def fb():
+def rollout(mem, obs):
+    hidden, outs = None, []
+    for t in range(obs.shape[0]):
+        mx, hidden = mem(obs[t], hidden)
+        outs.append(mx)
+    loss = torch.stack(outs).mean()
+    loss.backward()
+    return loss
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
-    tf = time.perf_counter()
-    o = fwd(True)
-    tf1 = time.perf_counter() - tf
-    torch.cuda.synchronize()
-    FW.append((tf1, time.perf_counter() - tf))
     t0 = time.perf_counter()
-    torch.stack(o).mean().backward()
-    t1 = time.perf_counter() - t0
+    for _ in range(n):
+        fn()
     torch.cuda.synchronize()
-    t2 = time.perf_counter() - t0
-    gnn.zero_grad(set_to_none=True)
-    return t1, t2
-rs = [fb() for _ in range(5)]
-print(f"{'forward (memory recycled by backward)':38s} host {sum(r[0] for r in FW)/5*1e3:7.2f} ms  ({sum(r[0] for r in FW)/5/T*1e6:6.1f} us/step)   host+gpu {sum(r[1] for r in FW)/5*1e3:7.2f} ms")
-print(f"{'backward only':38s} host {sum(r[0] for r in rs)/5*1e3:7.2f} ms  ({sum(r[0] for r in rs)/5/T*1e6:6.1f} us/step)   host+gpu {sum(r[1] for r in rs)/5*1e3:7.2f} ms")
-# raw C call cost
-cfg = mem._fused_plan(*mem.get_initial_hidden_state(obs[0])[:3], bench.F)
-packed = mem._packed_params(cfg).detach()
-h = mem.get_initial_hidden_state(obs[0])
-flags = torch.zeros(1, dtype=torch.int32, device=dev)
-def raw():
-    for t in range(T):
-        _ops._FusedStep.apply(obs[t], h[0], packed, h[1], h[3], flags, cfg)
-timed("128 x _FusedStep.apply (no module)", raw)
+    return (time.perf_counter() - t0) / n
+
+
+obs = torch.rand(T, B, F).to(dev)
+for donate in (False, True):
+    mem, gnn = build(donate)
+    dt = timeit(lambda: (rollout(mem, obs), gnn.zero_grad(set_to_none=True)))
+    print(f"eager donate={donate}: {dt*1e3:.3f} ms/rollout  {B*T/dt/1e6:.2f} M states/s")
+    # forward only timing (no_grad)
+    def fwd():
+        with torch.no_grad():
+            h = None
+            for t in range(T):
+                _, h = mem(obs[t], h)
+    dt = timeit(fwd)
+    print(f"   fwd-only no_grad: {dt*1e3:.3f} ms  {B*T/dt/1e6:.2f} M states/s")
+    # fwd with grad, without backward
+    def fwd_g():
+        h, outs = None, []
+        for t in range(T):
+            mx, h = mem(obs[t], h)
+            outs.append(mx)
+        return outs
+    dt = timeit(fwd_g)
+    print(f"   fwd-only grad mode: {dt*1e3:.3f} ms")
+
+# graph replay
+mem, gnn = build(True)
+mem.finite_check = "off"
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(3):
+        gnn.zero_grad(set_to_none=True)
+        rollout(mem, obs)
+torch.cuda.current_stream().wait_stream(s)
+torch.cuda.synchronize()
+gnn.zero_grad(set_to_none=True)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    loss = rollout(mem, obs)
+dt = timeit(lambda: g.replay(), n=20)
+print(f"graph replay donated: {dt*1e3:.3f} ms/rollout  {B*T/dt/1e6:.2f} M states/s")
