@@ -363,12 +363,7 @@ int launch_bptt(hipStream_t s, int grid, const float* g_mx, const float* g_no, c
   constexpr size_t lds = sizeof(float) * (size_t)LdsBptt<NT, NCT, NHT, N2T>::TOTAL;
   if (lds > 160 * 1024) return GCM_EUNSUPPORTED;
   auto kern = k_bptt_batched<NT, NCT, NHT, N2T>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g_mx, g_no, x, adj, cur, nn_in, P, mx, h1,
                      agg1, agg2, Q, pobs, slabs, items);
   return gcm_launch_status();

@@ -278,12 +278,7 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
 #define GCM_EUCLID_MFMA(FTv)                                                                     \
   {                                                                                              \
     auto kern = k_euclid_mfma<FTv>;                                                              \
-    static bool attr_set = false;                                                                \
-    if (!attr_set && lds > 64 * 1024) {                                                          \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)lds);                                                       \
-      attr_set = true;                                                                           \
-    }                                                                                            \
+    gcm_allow_dynamic_lds((const void*)kern, lds);                                                                                            \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, nodes, ws_cur, ws_cnorm, cur_idx,          \
                        dist_param, adj, dist_out, max_distance, bidirectional, B, N, F);         \
   }

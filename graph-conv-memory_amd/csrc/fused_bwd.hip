@@ -366,12 +366,7 @@ int launch_bwd(hipStream_t s, const float* g_mx, const float* g_nodes_out, const
   constexpr size_t lds = sizeof(float) * (size_t)L::BWD;
   const bool exact = N == L::NP && F == L::FP && H1 == L::HP && H2 == L::H2P;
   auto kern = exact ? k_gnn2_row_bwd<NT, NCT, NHT, N2T, true> : k_gnn2_row_bwd<NT, NCT, NHT, N2T, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[exact] && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set[exact] = true;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, g_mx, g_nodes_out, x, adj, cur, nn_in, P,
                      mx, h1, agg1, agg2, g_nodes_in, g_obs, slabs, accumulate, N, F, H1, H2);
   return gcm_launch_status();

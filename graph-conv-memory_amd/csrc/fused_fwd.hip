@@ -387,23 +387,13 @@ int launch_step(hipStream_t s, const float* nodes_in, const float* adj_in, Advan
   constexpr size_t lds_live = sizeof(float) * (size_t)LdsLive<NT, NCT, NHT, N2T>::TOTAL;
   if (exact && lds_live <= 160 * 1024) {   // live-tile kernel
     auto kl = k_step_fwd_live<NT, NCT, NHT, N2T>;
-    static bool live_attr = false;
-    if (!live_attr && lds_live > 64 * 1024) {
-      (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_live);
-      live_attr = true;
-    }
+    gcm_allow_dynamic_lds((const void*)kl, lds_live);
     hipLaunchKernelGGL(kl, dim3(B), dim3(256), lds_live, s, nodes_in, adj_in, A, P, mx, h1, agg1,
                        agg2, flags);
     return gcm_launch_status();
   }
   auto kern = exact ? k_step_fwd<NT, NCT, NHT, N2T, true> : k_step_fwd<NT, NCT, NHT, N2T, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[exact] && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set[exact] = true;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, nodes_in, adj_in, A, P, mx, h1, agg1, agg2,
                      flags, N, F, H1, H2);
   return gcm_launch_status();
@@ -417,12 +407,7 @@ int launch_fwd(hipStream_t s, const float* x, const float* adj, const int64_t* c
   constexpr size_t lds = sizeof(float) * (size_t)L::FWD;
   const bool exact = N == L::NP && F == L::FP && H1 == L::HP && H2 == L::H2P;
   auto kern = exact ? k_gnn2_row_fwd<NT, NCT, NHT, N2T, true> : k_gnn2_row_fwd<NT, NCT, NHT, N2T, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[exact] && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set[exact] = true;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, x, adj, cur, P, mx, h1, agg1, agg2, flags,
                      N, F, H1, H2);
   return gcm_launch_status();

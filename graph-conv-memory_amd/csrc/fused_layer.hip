@@ -305,12 +305,7 @@ int launch_layer_fwd(hipStream_t s, const float* x, const float* adj, const floa
   constexpr size_t lds = sizeof(float) * (size_t)L::FWD;
   const bool exact = N == L::NP && F == L::FP && H == L::HP;
   auto kern = exact ? k_layer_fwd<NT, NCT, NHT, true> : k_layer_fwd<NT, NCT, NHT, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[exact] && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set[exact] = true;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, x, adj, w_rel, b_rel, w_root, out, agg, N,
                      F, H, act);
   return gcm_launch_status();
@@ -325,12 +320,7 @@ int launch_layer_bwd(hipStream_t s, const float* g_out, const float* out, const 
   const size_t lds = sizeof(float) * ((size_t)L::BWD + (g_adj ? L::BWD_X : 0));
   const bool exact = N == L::NP && F == L::FP && H == L::HP;
   auto kern = exact ? k_layer_bwd<NT, NCT, NHT, true> : k_layer_bwd<NT, NCT, NHT, false>;
-  static size_t attr_set[2] = {0, 0};   // largest dynamic-LDS size already allowed
-  if (lds > 64 * 1024 && lds > attr_set[exact]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set[exact] = lds;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, g_out, out, x, adj, agg, w_rel, w_root, g_x,
                      g_adj, slabs, want_w, N, F, H, act);
   return gcm_launch_status();

@@ -15,6 +15,11 @@ static inline int gcm_launch_status() {
   return e == hipSuccess ? GCM_OK : (int)e;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize (needed above 64 KB of dynamic LDS) is a property of a
+// kernel ON A DEVICE: the largest size granted so far is remembered per (kernel, device), behind a
+// mutex - one process may drive several devices from several threads.  Defined in state.hip.
+void gcm_allow_dynamic_lds(const void* kernel, size_t bytes);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -151,9 +151,7 @@ int launch_fwd(int nct, dim3 grid, size_t lds, hipStream_t s, const float* x, co
 #define GCM_FWD_CASE(NCT)                                                                      \
   case NCT: {                                                                                  \
     auto kern = k_graphconv_fwd<WAVES, NCT>;                                                   \
-    if (lds > 64 * 1024)                                                                       \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                     \
+    gcm_allow_dynamic_lds((const void*)kern, lds); \
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, s, x, adj, w_rel, b_rel, w_root, out, \
                        agg, N, Fi, Fo, act);                                                   \
     break;                                                                                     \
@@ -842,9 +840,7 @@ extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, con
 #define GCM_BWD_LAUNCH(W, C)                                                                      \
   {                                                                                               \
     auto k1 = k_graphconv_bwd_rows<W, C>;                                                         \
-    if (lds1 > 64 * 1024)                                                                         \
-      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                (int)lds1);                                                       \
+    gcm_allow_dynamic_lds((const void*)k1, lds1); \
     hipLaunchKernelGGL(k1, grid, dim3(64 * W), lds1, s, g_out, out, x, agg, w_rel, w_root, g_x,   \
                        g_adj, ws_dagg, slabs, N, Fi, Fo, act, want_w);                            \
     if (g_x) {                                                                                    \
@@ -899,12 +895,7 @@ extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, con
 #define GCM_CSR2(a, b_)                                                                         \
   if (NCT == a && NHT == b_) {                                                                  \
     auto kern = k_csr_fwd2<a, b_>;                                                              \
-    static bool attr_set = false;                                                               \
-    if (!attr_set && lds2 > 64 * 1024) {                                                        \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds2);                                                     \
-      attr_set = true;                                                                          \
-    }                                                                                           \
+    gcm_allow_dynamic_lds((const void*)kern, lds2);                                                                                           \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds2, s, x, row_ptr, col, w, mask, w_rel, b_rel,  \
                        w_root, out, agg, M, Fi, Fo, act);                                       \
     return gcm_launch_status();                                                                 \
@@ -916,9 +907,7 @@ extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, con
 #define GCM_CSR_FWD(NCT)                                                                        \
   {                                                                                             \
     auto kern = k_csr_graphconv_fwd<NCT>;                                                       \
-    if (lds > 64 * 1024)                                                                        \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds);                                                      \
+    gcm_allow_dynamic_lds((const void*)kern, lds); \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, row_ptr, col, w, mask, w_rel, b_rel,   \
                        w_root, out, agg, M, Fi, Fo, act);                                       \
   }
@@ -972,12 +961,7 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
 #define GCM_ROWS2(a, b_)                                                                        \
   if (NCT == a && NHT == b_) {                                                                  \
     auto kern = k_rows_bwd2<a, b_>;                                                             \
-    static bool attr_set = false;                                                               \
-    if (!attr_set && lds2 > 64 * 1024) {                                                        \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds2);                                                     \
-      attr_set = true;                                                                          \
-    }                                                                                           \
+    gcm_allow_dynamic_lds((const void*)kern, lds2);                                                                                           \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds2, s, g_out, out, x, agg, w_rel, w_root, g_x,  \
                        ws_dagg, slabs, M, Fi, Fo, act, want_w);                                 \
     rows_done = true;                                                                           \
@@ -989,9 +973,7 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
 #define GCM_CSR_BWD(W, C)                                                                       \
   {                                                                                             \
     auto k1 = k_graphconv_bwd_rows<W, C>;                                                       \
-    if (lds1 > 64 * 1024)                                                                       \
-      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                (int)lds1);                                                     \
+    gcm_allow_dynamic_lds((const void*)k1, lds1); \
     hipLaunchKernelGGL(k1, grid, dim3(64 * W), lds1, s, g_out, out, x, agg, w_rel, w_root, g_x, \
                        no_adj, ws_dagg, slabs, N, Fi, Fo, act, want_w);                         \
   }

@@ -1,0 +1,717 @@
+// DenseGCM + LearnedEdge as fused per-graph kernels (edge_selectors/learned.py:38-113 with the
+// default edge network, DenseGraphConv x 2 as the GNN; observations without gradient).
+//
+// The default edge network scores a candidate pair (cur, j) from cat(x[cur], x[j]):
+//     Linear(2F, F) - ReLU - LayerNorm - Linear(F, F) - ReLU - LayerNorm - Linear(F, 1)
+// Its first layer splits into a per-graph bias and ONE [N x F] x [F x F] product,
+//     P0[j] = W0b x[j] + (W0a x[cur] + b0),
+// so the whole network is two 128 x 32 x 32 products on the fp32 MFMA plus row-wise ReLU-LayerNorms:
+// one workgroup per graph keeps the node matrix and both hidden layers in LDS.
+//
+//   k_learned_select   forward: edge network on all N candidate rows, gumbel-softmax over j < cur,
+//                      straight-through threshold, adjacency row cur written in place.
+//   k_learned_step_bwd backward of one step, everything in one launch:
+//     * GNN adjoint on the live rows (rows j with adj[cur, j] != 0, and cur: gcm.py:314 keeps one
+//       row of the last layer) -> parameter-gradient slab;
+//     * the gradient w.r.t. the ADJACENCY, which is what trains the edge network.  Its chain through
+//       time is dense in the reference (a [B,N,N] tensor per step); here it is carried in compact
+//       time is a dense [B,N,N] tensor PER STEP in the reference (every step's node receives and
+//       returns one); here ONE chain buffer GA [B,N,N] lives across the steps and is updated
+//       sparsely: a step adds dAgg1[l] . x[k] to the rows layer 1 aggregated into (the live rows),
+//       reads row cur - the only entries differentiated at this step,
+//           g_sel_t[j] = dagg2_t . h1_t[j] + GA[cur_t][j]      (j < cur_t),
+//       and undoes the state advance (zero row cur; on overflow, gcm.py:323-355, one shift of the
+//       buffer) for the step before;
+//     * selection adjoint (softmax; both straight-through estimators are identities);
+//     * edge-network adjoint with the forward recomputed in LDS (nothing but `soft` is saved).
+//
+// Shapes: N <= 128, F <= 32, H1 <= 32, H2 <= 32 (BASELINE cfg5: 128 / 32 / 32 / 32).
+#include "fused_common.h"
+
+namespace gcm_learned {
+
+using gcm_fused::mma32;
+
+constexpr int NP = 128, FP = 32, FS = 33;
+
+struct Mlp {   // pointers into the packed edge-network parameter vector (gcm_learned_mlp_layout)
+  const float *w0, *b0, *g0, *be0, *w1, *b1, *g1, *be1, *w2, *b2;
+};
+__host__ __device__ inline Mlp unpack_mlp(const float* p, int F) {
+  Mlp m;
+  m.w0 = p; m.b0 = m.w0 + 2 * F * F; m.g0 = m.b0 + F; m.be0 = m.g0 + F;
+  m.w1 = m.be0 + F; m.b1 = m.w1 + F * F; m.g1 = m.b1 + F; m.be1 = m.g1 + F;
+  m.w2 = m.be1 + F; m.b2 = m.w2 + F;
+  return m;
+}
+
+// [rows x F] matrix with leading dimension ld -> LDS image [RP][FS], zero padded; 256 threads
+template <int RP>
+__device__ __forceinline__ void stage(const float* __restrict__ src, float* dst, int R, int C, int ld, int tid) {
+  constexpr int PER = RP * FP / 256;
+  float v[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 256 * i, r = e / FP, c = e % FP;
+    v[i] = src[(r < R ? r : R - 1) * ld + (c < C ? c : C - 1)];
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 256 * i, r = e / FP, c = e % FP;
+    dst[r * FS + c] = (r < R && c < C) ? v[i] : 0.f;
+  }
+}
+
+// out rows [32 wave, 32 wave + 32) = A[rows, :] (K = 32) @ Bt^T, Bt stored [n][k] (stride FS);
+// acc(r) -> row 32 wave + acc_row(r, lh), column li
+__device__ __forceinline__ f32x16 gemm_rows(const float* sA, const float* sBt, int wave, int li, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  mma32(acc, sA + 32 * wave * FS, FS, 1, sBt, 1, FS, 32, li, lh);
+  return acc;
+}
+
+// ReLU + LayerNorm of row `row` of sP (in place -> gamma * xhat + beta), one thread per row.
+// Returns nothing; stats (mean, rstd) optionally stored.
+__device__ __forceinline__ void relu_ln_row(float* sP, int row, int F, const float* sg, const float* sb,
+                                            float eps, float* mu_out, float* rs_out) {
+  float a[FP];
+  float s = 0.f;
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const float v = sP[row * FS + f];
+    a[f] = (f < F && v > 0.f) ? v : 0.f;
+    s += a[f];
+  }
+  const float mean = s / (float)F;
+  float q = 0.f;
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const float d = f < F ? a[f] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = rsqrtf(q / (float)F + eps);
+#pragma unroll
+  for (int f = 0; f < FP; ++f) sP[row * FS + f] = f < F ? fmaf((a[f] - mean) * rstd, sg[f], sb[f]) : 0.f;
+  if (mu_out) { mu_out[row] = mean; rs_out[row] = rstd; }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: logits of all candidate rows, gumbel-softmax, threshold, adjacency row (learned.py:53-113)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_learned_select(
+    const float* __restrict__ nodes, float* __restrict__ adj, const int64_t* __restrict__ cur_idx,
+    const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp, float eps0,
+    float eps1, float cutoff, float* __restrict__ soft, int N, int F) {
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  int64_t c64 = cur_idx[b];
+  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  const Mlp M = unpack_mlp(mlp, F);
+  const float* xg = nodes + (size_t)b * N * F;
+  extern __shared__ float smem[];
+  float* sX = smem;                 // [NP][FS]
+  float* sA = sX + NP * FS;         // P0 -> H0
+  float* sB = sA + NP * FS;         // P1 -> H1
+  float* sW0b = sB + NP * FS;       // [o][f] = W0[o][F + f]
+  float* sW1 = sW0b + FP * FS;      // [o][f]
+  float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
+  float* sLogit = sVec + 7 * FP;    // [NP]
+
+  stage<NP>(xg, sX, N, F, F, tid);
+  stage<FP>(M.w0 + F, sW0b, F, F, 2 * F, tid);
+  stage<FP>(M.w1, sW1, F, F, F, tid);
+  if (tid < FP) {
+    const int o = tid < F ? tid : F - 1;
+    float c0 = M.b0[o];
+    for (int f = 0; f < F; ++f) c0 = fmaf(M.w0[o * 2 * F + f], xg[cur * F + f], c0);
+    const bool ok = tid < F;
+    sVec[tid] = ok ? c0 : 0.f;
+    sVec[FP + tid] = ok ? M.b1[o] : 0.f;
+    sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
+    sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
+    sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
+    sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
+    sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
+  }
+  __syncthreads();
+  {
+    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
+  }
+  __syncthreads();
+  if (tid < NP) relu_ln_row(sA, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
+  __syncthreads();
+  {
+    const f32x16 acc = gemm_rows(sA, sW1, wave, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sB[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
+  }
+  __syncthreads();
+  if (tid < NP) {
+    relu_ln_row(sB, tid, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
+    float lg = M.b2[0];
+#pragma unroll
+    for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sB[tid * FS + f], lg);
+    sLogit[tid] = lg;
+  }
+  __syncthreads();
+  if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
+    float z[2], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      float nz = 0.f;
+      if (j < cur) {
+        const float t = noise[(size_t)b * N + j];
+        nz = noise_is_exp ? -logf(t) : t;
+      }
+      z[c] = j < cur ? sLogit[j] + nz : -INFINITY;
+      m = fmaxf(m, z[c]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      z[c] = (lane + 64 * c < cur) ? expf(z[c] - m) : 0.f;
+      s += z[c];
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    float* row = adj + ((size_t)b * N + cur) * N;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      if (j < N) {
+        const float p = z[c] * inv;
+        soft[(size_t)b * N + j] = p;
+        if (j < cur) {
+          const float edge = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12)
+          row[j] = (edge + row[j] > 0.f) ? 1.f : 0.f;            // learned.py:108-110
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of one step (see the header comment)
+// ---------------------------------------------------------------------------------------------
+// slab per graph (floats): GNN part as the packed GNN vector (dW_rel1 | dW_root1 | db1 | dW_rel2 |
+// dW_root2 | db2), then the edge network as its packed vector.
+__global__ __launch_bounds__(256) void k_learned_step_bwd(
+    const float* __restrict__ g_mx, const float* __restrict__ nodes, const float* __restrict__ adj,
+    const int64_t* __restrict__ cur_idx, const int64_t* __restrict__ count_in,
+    const float* __restrict__ gnn, int act1, int act2, const float* __restrict__ mx,
+    const float* __restrict__ h1, const float* __restrict__ agg1, const float* __restrict__ agg2,
+    const float* __restrict__ soft, const float* __restrict__ mlp, float eps0, float eps1,
+    float* __restrict__ GA, float* __restrict__ slabs, int accumulate, int N, int F,
+    int H1, int H2) {
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  int64_t c64 = cur_idx[b];
+  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  const bool wrapped = count_in[b] + 1 > N;
+  const Mlp M = unpack_mlp(mlp, F);
+  const int Pg = 2 * H1 * F + H1 + 2 * H2 * H1 + H2, Pm = 3 * F * F + 7 * F + 1;
+  const float* w_rel1 = gnn;
+  const float* w_rel2 = gnn + 2 * H1 * F + H1;
+  const float* w_root2 = w_rel2 + H2 * H1;
+  const float* xg = nodes + (size_t)b * N * F;
+  const float* ag = adj + (size_t)b * N * N;
+  const float* h1g = h1 + (size_t)b * N * H1;
+  const float* a1g = agg1 + (size_t)b * N * F;
+  float* GAg = GA + (size_t)b * N * N;   // this graph's chain buffer (see the header comment)
+  float* slab = slabs + (size_t)b * (Pg + Pm);
+  float* sl_m = slab + Pg;
+
+  extern __shared__ float smem[];
+  float* sX = smem;                    // [NP][FS]
+  float* sP0 = sX + NP * FS;           // P0 -> gP0
+  float* sH0 = sP0 + NP * FS;          // H0
+  float* sP1 = sH0 + NP * FS;          // P1 -> gP1
+  float* sG = sP1 + NP * FS;           // h1 image (phase A), then gH0
+  float* sW0b = sG + NP * FS;          // [o][f]
+  float* sW1 = sW0b + FP * FS;         // [o][f]
+  float* sWr1 = sW1 + FP * FS;         // w_rel1 [h][f]
+  float* sR = sWr1 + FP * FS;          // [4][1024] cross-wave reduction of the dW tiles
+  float* sVec = sR + 4096;             // c0 | b1 | g0 | be0 | g1 | be1 | w2
+  float* sMu0 = sVec + 7 * FP;         // per-row LayerNorm statistics [NP] x 4
+  float* sRs0 = sMu0 + NP;
+  float* sMu1 = sRs0 + NP;
+  float* sRs1 = sMu1 + NP;
+  float* sGl = sRs1 + NP;              // g_logit [NP]
+  float* sSel = sGl + NP;              // g_sel [NP]
+  float* sCoef = sSel + NP;            // adj[cur, :] [NP]
+  float* sD2 = sCoef + NP;             // d2 [32] | u [64] | v [64] | (32 spare) | colsum scratch [256]
+  float* sU = sD2 + 32;
+  float* sVv = sU + 64;
+  float* sCs = sVv + 64 + 32;
+  int* sLive = reinterpret_cast<int*>(sCs + 256);   // [NP] + count
+
+  // ---- loads: node matrix, h1, weights, row cur of the adjacency, the kept row's vectors ---------
+  stage<NP>(xg, sX, N, F, F, tid);
+  stage<NP>(h1g, sG, N, H1, H1, tid);
+  stage<FP>(M.w0 + F, sW0b, F, F, 2 * F, tid);
+  stage<FP>(M.w1, sW1, F, F, F, tid);
+  stage<FP>(w_rel1, sWr1, H1, F, F, tid);
+  if (tid < NP) sCoef[tid] = tid < N ? ag[cur * N + tid] : 0.f;
+  if (tid < FP) {
+    const int o = tid < F ? tid : F - 1;
+    float c0 = M.b0[o];
+    for (int f = 0; f < F; ++f) c0 = fmaf(M.w0[o * 2 * F + f], xg[cur * F + f], c0);
+    const bool ok = tid < F;
+    sVec[tid] = ok ? c0 : 0.f;
+    sVec[FP + tid] = ok ? M.b1[o] : 0.f;
+    sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
+    sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
+    sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
+    sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
+    sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
+    const int oc = tid < H2 ? tid : H2 - 1;
+    const float gm = g_mx[(size_t)b * H2 + oc], y = mx[(size_t)b * H2 + oc];
+    sD2[tid] = tid < H2 ? gm * gcm_act_grad(y, act2) : 0.f;
+  }
+  if (tid < 64) {   // v = agg2 | h1[cur]
+    const int k = tid < 32 ? tid : tid - 32;
+    const int kc = k < H1 ? k : H1 - 1;
+    const float t = tid < 32 ? agg2[(size_t)b * H1 + kc] : h1g[cur * H1 + kc];
+    sVv[tid] = k < H1 ? t : 0.f;
+  }
+  __syncthreads();
+  // ---- phase A: layer-2 adjoint ----------------------------------------------------------------------
+  if (tid < 64) {   // u[m] = sum_o W2c[o][m] d2[o]   (m < 32: dagg2, else dh1cur)
+    const int k = tid < 32 ? tid : tid - 32;
+    const float* wc = (tid < 32 ? w_rel2 : w_root2) + (k < H1 ? k : H1 - 1);
+    float s = 0.f;
+    for (int o = 0; o < H2; ++o) s = fmaf(wc[o * H1], sD2[o], s);
+    sU[tid] = k < H1 ? s : 0.f;
+  }
+  {   // dW2c[o][k] (+)= d2[o] v[k]; db2
+    float* sl_rel2 = slab + 2 * H1 * F + H1;
+    float* sl_root2 = sl_rel2 + H2 * H1;
+    float* sl_b2 = sl_root2 + H2 * H1;
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int o = e >> 6, k = e & 63, kk = k & 31;
+      if (o < H2 && kk < H1) {
+        float* d = (k < 32 ? sl_rel2 : sl_root2) + o * H1 + kk;
+        *d = (accumulate ? *d : 0.f) + sD2[o] * sVv[k];
+      }
+    }
+    if (tid < H2) sl_b2[tid] = (accumulate ? sl_b2[tid] : 0.f) + sD2[tid];
+  }
+  // live rows: ballot over row cur (entries of the sampled row), list in LDS
+  {
+    const bool pred = tid < N && tid < NP && (sCoef[tid & (NP - 1)] != 0.f || tid == cur);
+    const unsigned long long bal = __ballot(pred);
+    if (lane == 0 && wave < 2) sLive[NP + wave] = __popcll(bal);
+    __syncthreads();
+    const int pos = (wave ? sLive[NP] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pred) sLive[pos] = tid;
+  }
+  __syncthreads();
+  const int L = sLive[NP] + sLive[NP + 1];
+  // G1[l][h] = (coef dagg2[h] + [j == cur] dh1cur[h]) act1'(h1[j][h]) -> sR[l][h]  (L <= 128 rows x 32)
+  for (int e = tid; e < L * 32; e += 256) {
+    const int l = e >> 5, h = e & 31, j = sLive[l];
+    const float y = sG[j * FS + h];
+    const float d = sCoef[j] * sU[h] + (j == cur ? sU[32 + h] : 0.f);
+    sR[l * 32 + h] = h < H1 ? d * gcm_act_grad(y, act1) : 0.f;
+  }
+  __syncthreads();
+  {   // layer-1 parameter gradients on the live rows: dW1c[h][m] (+)= sum_l G1[l][h] [agg1 | x][j_l][m]
+    const int h = tid >> 3, m0 = (tid & 7) * 8;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    float bsum = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int j = sLive[l];
+      const float g = sR[l * 32 + h];
+      bsum += g;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int m = m0 + q, f = m & 31;
+        const float a = f < F ? (m < 32 ? a1g[j * F + f] : sX[j * FS + f]) : 0.f;
+        acc[q] = fmaf(g, a, acc[q]);
+      }
+    }
+    if (h < H1) {
+      float* sl_rel1 = slab;
+      float* sl_root1 = slab + H1 * F;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int m = m0 + q, f = m & 31;
+        if (f < F) {
+          float* d = (m < 32 ? sl_rel1 : sl_root1) + h * F + f;
+          *d = (accumulate ? *d : 0.f) + acc[q];
+        }
+      }
+      if ((tid & 7) == 0) {
+        float* d = slab + 2 * H1 * F + h;
+        *d = (accumulate ? *d : 0.f) + bsum;
+      }
+    }
+  }
+  // dAgg1[l][f] = G1[l] . w_rel1[:, f] -> sP0 [l][FS] (free until the edge network is recomputed)
+  for (int e = tid; e < L * 32; e += 256) {
+    const int l = e >> 5, f = e & 31;
+    float s = 0.f;
+    if (f < F) {
+#pragma unroll
+      for (int h = 0; h < 32; ++h) s = fmaf(sR[l * 32 + h], sWr1[h * FS + f], s);
+    }
+    sP0[l * FS + f] = s;
+  }
+  __syncthreads();
+  // the adjacency gradient of the rows layer 1 aggregated into: GA[j_l][k] += dAgg1[l] . x[k] for every
+  // column k (entry (j_l, k) exists from the step that wrote row j_l until node k is dropped: the
+  // chain buffer is rolled with the state below, so later contributions land on the right entries).
+  // Row cur is consumed right here (g_sel) and is not written back.
+  int l_cur = -1;
+  for (int l = 0; l < L; ++l) l_cur = sLive[l] == cur ? l : l_cur;   // (row cur is always in the list)
+  for (int e = tid; e < L * N; e += 256) {
+    const int l = e / N, k = e - l * N, j = sLive[l];
+    if (j != cur) {
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < 32; ++f) s = fmaf(sP0[l * FS + f], sX[k * FS + f], s);
+      GAg[j * N + k] += s;
+    }
+  }
+  // ---- g_sel[j] = dagg2 . h1[j] + GA[cur][j] + dAgg1[cur] . x[j]  (j < cur); selection adjoint ------
+  if (tid < NP) {
+    float s = 0.f;
+    if (tid < cur) {
+      s = GAg[cur * N + tid];
+#pragma unroll
+      for (int h = 0; h < 32; ++h) s = fmaf(sU[h], sG[tid * FS + h], s);
+#pragma unroll
+      for (int f = 0; f < 32; ++f) s = fmaf(sP0[l_cur * FS + f], sX[tid * FS + f], s);
+    }
+    sSel[tid] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float p[2], g[2], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      const bool live = j < cur;
+      p[c] = live ? soft[(size_t)b * N + j] : 0.f;
+      g[c] = live ? sSel[j] : 0.f;
+      dot = fmaf(p[c], g[c], dot);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) sGl[lane + 64 * c] = p[c] * (g[c] - dot);
+  }
+  // ---- the chain buffer for the previous step: undo the state advance (gcm.py:262-278, 323-355).
+  // No overflow: row cur did not exist before (zero).  Overflow: every entry moves back by one row
+  // and one column, the dropped node's row / column and the new node's row carry nothing.
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every GA read / write above is done
+    if (wrapped) {
+      constexpr int PERG = NP * NP / 256;
+      float gv[PERG];
+#pragma unroll
+      for (int i = 0; i < PERG; ++i) {
+        const int e = tid + 256 * i, r = e / NP, c = e % NP;      // destination entry (r, c) <- (r-1, c-1)
+        const int rs = r - 1, cs = c - 1;
+        const bool ok = r < N && c < N && rs >= 0 && cs >= 0 && rs != cur;
+        const float t = GAg[(rs >= 0 && rs < N ? rs : 0) * N + (cs >= 0 && cs < N ? cs : 0)];
+        gv[i] = ok ? t : 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PERG; ++i) {
+        const int e = tid + 256 * i, r = e / NP, c = e % NP;
+        if (r < N && c < N) GAg[r * N + c] = gv[i];
+      }
+    } else if (tid < N) {
+      GAg[cur * N + tid] = 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- edge network: forward recomputed, then its adjoint -------------------------------------------
+  {
+    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wave + gcm_fused::acc_row(r, lh);
+      const float v = acc[r] + sVec[li];
+      sP0[row * FS + li] = v;
+      sH0[row * FS + li] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < NP) relu_ln_row(sH0, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);
+  __syncthreads();
+  {
+    const f32x16 acc = gemm_rows(sH0, sW1, wave, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
+  }
+  __syncthreads();
+  if (tid < NP) {   // statistics of layer 1 (the normalised values are rebuilt where needed)
+    float s = 0.f, a[FP];
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float v = sP1[tid * FS + f];
+      a[f] = (f < F && v > 0.f) ? v : 0.f;
+      s += a[f];
+    }
+    const float mean = s / (float)F;
+    float q = 0.f;
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float d = f < F ? a[f] - mean : 0.f;
+      q = fmaf(d, d, q);
+    }
+    sMu1[tid] = mean;
+    sRs1[tid] = rsqrtf(q / (float)F + eps1);
+  }
+  __syncthreads();
+  // column sums over the rows (8 row groups x 32 columns): dw2, dgamma1, dbeta1, db2
+  {
+    const int f = tid & 31, grp = tid >> 5;
+    float s_w2 = 0.f, s_g1 = 0.f, s_b1 = 0.f, s_bb = 0.f;
+    const float w2f = sVec[6 * FP + f], g1f = sVec[4 * FP + f], be1f = sVec[5 * FP + f];
+    for (int j = grp; j < N; j += 8) {
+      const float gl = sGl[j];
+      const float v = sP1[j * FS + f];
+      const float xh = ((v > 0.f ? v : 0.f) - sMu1[j]) * sRs1[j];
+      s_w2 = fmaf(gl, fmaf(xh, g1f, be1f), s_w2);   // dw2[f] += gl * H1m[j][f]
+      s_g1 = fmaf(gl * w2f, xh, s_g1);
+      s_b1 = fmaf(gl, w2f, s_b1);
+      s_bb += gl;
+    }
+    auto colsum = [&](float v) {
+      sCs[tid] = v;
+      __syncthreads();
+      float t = 0.f;
+      if (tid < 32) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+      }
+      __syncthreads();
+      return t;
+    };
+    const int o_w1 = 2 * F * F + 3 * F, o_b1 = o_w1 + F * F, o_g1 = o_b1 + F, o_be1 = o_g1 + F;
+    const int o_w2 = o_be1 + F, o_b2 = o_w2 + F;
+    const float t_w2 = colsum(s_w2), t_g1 = colsum(s_g1), t_b1 = colsum(s_b1), t_bb = colsum(s_bb);
+    if (tid < F) {
+      sl_m[o_w2 + tid] = (accumulate ? sl_m[o_w2 + tid] : 0.f) + t_w2;
+      sl_m[o_g1 + tid] = (accumulate ? sl_m[o_g1 + tid] : 0.f) + t_g1;
+      sl_m[o_be1 + tid] = (accumulate ? sl_m[o_be1 + tid] : 0.f) + t_b1;
+    }
+    if (tid == 0) sl_m[o_b2] = (accumulate ? sl_m[o_b2] : 0.f) + t_bb;
+  }
+  // LayerNorm-1 + ReLU adjoint, row by row: gP1 in place of P1
+  if (tid < NP) {
+    const int j = tid;
+    const float gl = sGl[j], mean = sMu1[j], rstd = sRs1[j];
+    float xh[FP], gx[FP], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float v = sP1[j * FS + f];
+      xh[f] = f < F ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
+      gx[f] = f < F ? gl * sVec[6 * FP + f] * sVec[4 * FP + f] : 0.f;
+      m1 += gx[f];
+      m2 = fmaf(gx[f], xh[f], m2);
+    }
+    m1 /= (float)F;
+    m2 /= (float)F;
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float v = sP1[j * FS + f];
+      const float da = rstd * (gx[f] - m1 - xh[f] * m2);
+      sP1[j * FS + f] = (f < F && v > 0.f) ? da : 0.f;
+    }
+  }
+  __syncthreads();
+  // db1' = column sums of gP1; dW1 = gP1^T H0 (K = rows, split over the waves); gH0 = gP1 W1
+  const int o_b0 = 2 * F * F, o_g0 = o_b0 + F, o_be0 = o_g0 + F, o_w1 = o_be0 + F, o_b1 = o_w1 + F * F;
+  {
+    const int f = tid & 31, grp = tid >> 5;
+    float s = 0.f;
+    for (int j = grp; j < N; j += 8) s += sP1[j * FS + f];
+    sCs[tid] = s;
+  }
+  {
+    f32x16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    // A(i = o, k = row) = gP1[row][o];  B(k = row, j = f) = H0[row][f]
+    mma32(a, sP1 + 32 * wave * FS, 1, FS, sH0 + 32 * wave * FS, FS, 1, 32, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = a[r];
+  }
+  __syncthreads();
+  if (tid < F) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+    sl_m[o_b1 + tid] = (accumulate ? sl_m[o_b1 + tid] : 0.f) + t;
+  }
+  for (int e = tid; e < 1024; e += 256) {
+    const int o = e >> 5, f = e & 31;
+    if (o < F && f < F) {
+      float* d = sl_m + o_w1 + o * F + f;
+      *d = (accumulate ? *d : 0.f) + ((sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]));
+    }
+  }
+  {   // gH0[rows] = gP1[rows] @ W1  (B(k = o, j = f) = W1[o][f]) -> sG
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    mma32(acc, sP1 + 32 * wave * FS, FS, 1, sW1, FS, 1, 32, li, lh);
+    __syncthreads();   // sR / sCs reads above are done before they are reused; sG (h1) is free
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sG[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r];
+  }
+  __syncthreads();
+  // dgamma0 / dbeta0 (column sums of gH0 * xhat0, gH0), then LayerNorm-0 + ReLU adjoint: gP0 in place
+  {
+    const int f = tid & 31, grp = tid >> 5;
+    float s_g = 0.f, s_b = 0.f;
+    for (int j = grp; j < N; j += 8) {
+      const float v = sP0[j * FS + f];
+      const float xh = ((v > 0.f ? v : 0.f) - sMu0[j]) * sRs0[j];
+      const float gh = sG[j * FS + f];
+      s_g = fmaf(gh, xh, s_g);
+      s_b += gh;
+    }
+    sCs[tid] = s_g;
+    __syncthreads();
+    if (tid < F) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+      sl_m[o_g0 + tid] = (accumulate ? sl_m[o_g0 + tid] : 0.f) + t;
+    }
+    __syncthreads();
+    sCs[tid] = s_b;
+    __syncthreads();
+    if (tid < F) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+      sl_m[o_be0 + tid] = (accumulate ? sl_m[o_be0 + tid] : 0.f) + t;
+    }
+  }
+  if (tid < NP) {
+    const int j = tid;
+    const float mean = sMu0[j], rstd = sRs0[j];
+    float xh[FP], gx[FP], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float v = sP0[j * FS + f];
+      xh[f] = f < F ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
+      gx[f] = f < F ? sG[j * FS + f] * sVec[2 * FP + f] : 0.f;
+      m1 += gx[f];
+      m2 = fmaf(gx[f], xh[f], m2);
+    }
+    m1 /= (float)F;
+    m2 /= (float)F;
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float v = sP0[j * FS + f];
+      const float da = rstd * (gx[f] - m1 - xh[f] * m2);
+      sP0[j * FS + f] = (f < F && v > 0.f) ? da : 0.f;
+    }
+  }
+  __syncthreads();
+  // db0 = column sums of gP0; dW0a = db0 (x) x[cur]; dW0b = gP0^T X
+  {
+    const int f = tid & 31, grp = tid >> 5;
+    float s = 0.f;
+    for (int j = grp; j < N; j += 8) s += sP0[j * FS + f];
+    sCs[tid] = s;
+  }
+  {
+    f32x16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    mma32(a, sP0 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, 32, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = a[r];
+  }
+  __syncthreads();
+  if (tid < FP) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+    sVec[tid] = t;   // db0 (c0 is no longer needed)
+    if (tid < F) sl_m[o_b0 + tid] = (accumulate ? sl_m[o_b0 + tid] : 0.f) + t;
+  }
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) {
+    const int o = e >> 5, f = e & 31;
+    if (o < F && f < F) {
+      float* da = sl_m + o * 2 * F + f;          // W0a half
+      float* db = sl_m + o * 2 * F + F + f;      // W0b half
+      *da = (accumulate ? *da : 0.f) + sVec[o] * sX[cur * FS + f];
+      *db = (accumulate ? *db : 0.f) + ((sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]));
+    }
+  }
+}
+
+constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
+constexpr size_t lds_bwd() {
+  return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8);
+}
+
+}  // namespace gcm_learned
+
+extern "C" int gcm_learned_step_supported(int N, int F, int H1, int H2) {
+  return (N > 0 && N <= 128 && F > 0 && F <= 32 && H1 > 0 && H1 <= 32 && H2 > 0 && H2 <= 32) ? 1 : 0;
+}
+
+extern "C" size_t gcm_learned_mlp_param_count(int F) { return 3 * (size_t)F * F + 7 * (size_t)F + 1; }
+
+extern "C" int gcm_learned_select_fused(const float* nodes, float* adj, const int64_t* cur_idx,
+                                        const float* noise, int noise_is_exp, const float* mlp_params,
+                                        float eps0, float eps1, float cutoff, float* soft, int B, int N,
+                                        int F, gcm_stream_t stream) {
+  GCM_REQUIRE(nodes && adj && cur_idx && noise && mlp_params && soft && B > 0);
+  if (!gcm_learned_step_supported(N, F, 1, 1)) return GCM_EUNSUPPORTED;
+  constexpr size_t lds = gcm_learned::lds_select();
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_select, lds);
+  hipLaunchKernelGGL(gcm_learned::k_learned_select, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, adj,
+                     cur_idx, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_learned_step_bwd(const float* g_mx, const float* nodes, const float* adj,
+                                    const int64_t* cur_idx, const int64_t* count_in,
+                                    const float* gnn_params, int act1, int act2, const float* mx,
+                                    const float* h1, const float* agg1, const float* agg2,
+                                    const float* soft, const float* mlp_params, float eps0, float eps1,
+                                    float* GA, float* slabs, int accumulate, int B, int N, int F, int H1,
+                                    int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(g_mx && nodes && adj && cur_idx && count_in && gnn_params && mx && h1 && agg1 && agg2 && soft &&
+              mlp_params && GA && slabs && B > 0);
+  if (!gcm_learned_step_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  constexpr size_t lds = gcm_learned::lds_bwd();
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_step_bwd, lds);
+  hipLaunchKernelGGL(gcm_learned::k_learned_step_bwd, dim3(B), dim3(256), lds, (hipStream_t)stream, g_mx,
+                     nodes, adj, cur_idx, count_in, gnn_params, act1, act2, mx, h1, agg1, agg2, soft,
+                     mlp_params, eps0, eps1, GA, slabs, accumulate, N, F, H1, H2);
+  return gcm_launch_status();
+}

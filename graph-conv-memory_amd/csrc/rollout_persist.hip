@@ -274,12 +274,7 @@ int launch_rollout(hipStream_t s, const float* obs, float* nodes_all, float* adj
   constexpr size_t lds = sizeof(float) * (size_t)LdsRoll<NT, NCT, NHT, N2T>::TOTAL;
   if (lds > 160 * 1024) return GCM_EUNSUPPORTED;
   auto kern = k_rollout_fwd<NT, NCT, NHT, N2T>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, obs, nodes_all, adj_all, count_all, cur_all,
                      E, P, mx_all, h1_all, agg1_all, agg2_all, flags, T, B, hist);
   return gcm_launch_status();
@@ -443,12 +438,7 @@ extern "C" int gcm_dense_gnodes_scan(const float* Q_all, const float* pobs_all,
   const int nper = (N * F + 255) / 256;
 #define GCM_SCAN(P)                                                                              \
   {                                                                                              \
-    static size_t lds_attr = 64 * 1024;                                                          \
-    if (lds > lds_attr) {                                                                        \
-      (void)hipFuncSetAttribute((const void*)gcm_fused::k_gnodes_scan<P>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      lds_attr = lds;                                                                            \
-    }                                                                                            \
+    gcm_allow_dynamic_lds((const void*)gcm_fused::k_gnodes_scan<P>, lds); \
     hipLaunchKernelGGL(gcm_fused::k_gnodes_scan<P>, dim3(B), dim3(256), lds, s, Q_all, pobs_all, \
                        g_nodes_T, cur_all, count_all, g_obs_all, g_nodes_0, T, B, N, F);         \
     return gcm_launch_status();                                                                  \

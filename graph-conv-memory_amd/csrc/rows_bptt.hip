@@ -201,16 +201,7 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, int n_steps, long
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   const size_t lds = sizeof(float) * P;
   auto kern = k_bptt_rows<FP, HP, H2P>;
-  if (lds > 64 * 1024) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static size_t attr_set[64] = {};
-    size_t& cur = attr_set[dev & 63];
-    if (lds > cur) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      cur = lds;
-    }
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, n_steps, sb, sh, w_rel2, w_root2, act1,
                      act2, lay, slabs, B, N, F, H1, H2);
   return gcm_launch_status();

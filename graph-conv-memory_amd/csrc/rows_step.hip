@@ -550,16 +550,7 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
   static_assert(lds <= 160 * 1024, "LDS budget");
   const bool func = adj_out != adj_in;
   auto kern = func ? k_step_rows<FP, HP, H2P, true, NX, EXACT> : k_step_rows<FP, HP, H2P, false, NX, EXACT>;
-  if (lds > 64 * 1024) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_set[2][64] = {};   // per device (index clamped): the attribute is per context
-    bool& done = attr_set[func][dev & 63];
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done = true;
-    }
-  }
+  gcm_allow_dynamic_lds((const void*)kern, lds);
   if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
     hipExtLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in, adj_in,
                           count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,

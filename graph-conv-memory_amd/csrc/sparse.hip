@@ -423,6 +423,53 @@ extern "C" int gcm_sparse_flatten_bwd(const float* g_flat, const int64_t* T, con
   return gcm_launch_status();
 }
 
+__global__ void k_coo_merge(const int64_t* __restrict__ old_idx, const int64_t* __restrict__ new_idx,
+                            const float* __restrict__ old_val, const float* __restrict__ new_val,
+                            const int64_t* __restrict__ old_bptr, const int64_t* __restrict__ new_bptr,
+                            int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+                            int64_t* __restrict__ perm, uint32_t* __restrict__ flags, int64_t Ea,
+                            int64_t Eb) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t E = Ea + Eb;
+  if (e >= E) return;
+  int64_t b, snk, src, pos;
+  float v = 1.f;
+  if (e < Ea) {   // a stored entry: shifted by the new entries of the graphs before its own
+    b = old_idx[e]; snk = old_idx[Ea + e]; src = old_idx[2 * Ea + e];
+    pos = e + new_bptr[b];
+    if (old_val) v = old_val[e];
+  } else {        // a new entry: behind every stored entry of its own graph
+    const int64_t j = e - Ea;
+    b = new_idx[j]; snk = new_idx[Eb + j]; src = new_idx[2 * Eb + j];
+    pos = j + old_bptr[b + 1];
+    if (new_val) v = new_val[j];
+    const int64_t last = old_bptr[b + 1] - 1;
+    if (last >= old_bptr[b]) {
+      const int64_t ls = old_idx[Ea + last], lc = old_idx[2 * Ea + last];
+      if (snk < ls || (snk == ls && src <= lc)) atomicOr(flags, GCM_FLAG_MERGE_ORDER);
+    }
+  }
+  out_idx[pos] = b; out_idx[E + pos] = snk; out_idx[2 * E + pos] = src;
+  if (out_val) out_val[pos] = v;
+  if (perm) perm[pos] = e;
+}
+
+extern "C" int gcm_coo_merge_segments(const int64_t* old_idx, const int64_t* new_idx,
+                                      const float* old_val, const float* new_val,
+                                      const int64_t* old_bptr, const int64_t* new_bptr,
+                                      int64_t* out_idx, float* out_val, int64_t* perm,
+                                      uint32_t* flags, int64_t Ea, int64_t Eb, int B,
+                                      gcm_stream_t stream) {
+  GCM_REQUIRE(old_bptr && new_bptr && out_idx && flags && (old_idx || Ea == 0) && (new_idx || Eb == 0));
+  GCM_REQUIRE(Ea >= 0 && Eb >= 0 && B > 0);
+  const int64_t E = Ea + Eb;
+  if (E == 0) return GCM_OK;
+  hipLaunchKernelGGL(k_coo_merge, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     old_idx, new_idx, old_val, new_val, old_bptr, new_bptr, out_idx, out_val, perm, flags,
+                     Ea, Eb);
+  return gcm_launch_status();
+}
+
 extern "C" int gcm_ptr_from_sorted(const int64_t* keys, int64_t* ptr, int64_t E, int64_t M,
                                    gcm_stream_t stream) {
   GCM_REQUIRE(ptr && E >= 0 && M >= 0 && (keys || E == 0));

@@ -301,7 +301,25 @@ extern "C" int gcm_posenc_add(float* x, const float* pe, const int64_t* num_node
   return gcm_launch_status();
 }
 
-extern "C" int gcm_version(void) { return 100; }
+#include <map>
+#include <mutex>
+#include <utility>
+
+void gcm_allow_dynamic_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& g = granted[{kernel, dev}];
+  if (bytes > g) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    g = bytes;
+  }
+}
+
+extern "C" int gcm_version(void) { return 101; }
 
 extern "C" const char* gcm_status_string(int code) {
   switch (code) {

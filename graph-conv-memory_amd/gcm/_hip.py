@@ -17,7 +17,7 @@ ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 DIR = {"forward": 1, "backward": 2, "both": 3}
 DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
 FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
-FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW = 8, 16, 32
+FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER = 8, 16, 32, 64
 
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                      ctypes.c_int64)
@@ -47,6 +47,7 @@ PROTOTYPES = {
     "gcm_sparse_flatten_bwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
     "gcm_sparse_edges_to_csr": (_I, [_P] * 5 + [_L, _L, _I, _P]),
     "gcm_ptr_from_sorted": (_I, [_P, _P, _L, _L, _P]),
+    "gcm_coo_merge_segments": (_I, [_P] * 10 + [_L, _L, _I, _P]),
     "gcm_khop_mask": (_I, [_P] * 5 + [_I, _P, _P, _L, _I, _I, _P]),
     "gcm_sparse_extract_fwd": (_I, [_P] * 6 + [_I, _I, _I, _L, _P]),
     "gcm_sparse_extract_bwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
@@ -86,6 +87,10 @@ PROTOTYPES = {
     "gcm_dense_rows_layout": (_I, [_I] * 5 + [_P]),
     "gcm_dense_rows_step_fwd": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_I] * 5 + [_P]),
     "gcm_debug_time_next_launch": (_I, [_P, _P]),
+    "gcm_learned_step_supported": (_I, [_I] * 4),
+    "gcm_learned_mlp_param_count": (_Z, [_I]),
+    "gcm_learned_select_fused": (_I, [_P, _P, _P, _P, _I, _P, _F, _F, _F, _P, _I, _I, _I, _P]),
+    "gcm_learned_step_bwd": (_I, [_P] * 6 + [_I, _I] + [_P] * 6 + [_F, _F, _P, _P, _I] + [_I] * 5 + [_P]),
     "gcm_dense_rows_bptt_slabs": (_I, [_I, _I]),
     "gcm_dense_rows_bptt_workspace_bytes": (_Z, [_I] * 5),
     "gcm_dense_rows_bptt": (_I, [_P, _P, _I, ctypes.c_long, ctypes.c_long, _P, _I, _I, _I, _P, _P, _P, _Z]
@@ -168,3 +173,7 @@ def on_device(*tensors):
             )
         if not t.is_contiguous():
             raise ValueError("gcm kernels need contiguous tensors")
+        if t.device.index != torch.cuda.current_device():
+            raise HipLibraryError(
+                f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: the "
+                "kernels launch on the current device's stream - wrap the call in torch.cuda.device(...)")

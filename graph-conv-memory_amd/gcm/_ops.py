@@ -298,16 +298,53 @@ def sparse_insert(nodes, x, T, taus, flags):
     return _SparseInsert.apply(nodes, x, T, taus, flags)
 
 
-def sparse_temporal_edges(T, taus, hops_desc):
-    """COO indices [3, E] (batch, sink, source) of the TemporalEdge selector, already in
-    coalesced order.  One host sync (E)."""
+def sparse_temporal_count(T, taus, hops_desc):
+    """edge_off [B+1] of the TemporalEdge selector (closed form per graph); no host sync."""
     _hip.on_device(T, taus)
     B = T.numel()
     edge_off = torch.empty(B + 1, dtype=_i64, device=T.device)
     arr = _hops_arg(hops_desc)
     _call("gcm_sparse_temporal_count", _hip.ptr(T), _hip.ptr(taus), ctypes.addressof(arr),
           len(hops_desc), _hip.ptr(edge_off), B, _hip.stream())
-    E = int(edge_off[B].item())
+    return edge_off
+
+
+def coo_merge_segments(old_idx, old_val, new_idx, new_val, new_bptr, B, flags):
+    """sparse_gcm.py:132-139 without a sort, for new entries that sort behind the stored ones of
+    their graph (gcm_coo_merge_segments).  -> (idx [3, Ea+Eb], values)."""
+    old_idx, new_idx = old_idx.contiguous(), new_idx.contiguous()
+    Ea, Eb = old_idx.shape[1], new_idx.shape[1]
+    dev = new_idx.device
+    if Eb == 0:
+        return old_idx, old_val
+    if Ea == 0:
+        return new_idx, new_val
+    old_bptr = ptr_from_sorted(old_idx[0], B) if Ea else torch.zeros(B + 1, dtype=_i64, device=dev)
+    if new_bptr is None:
+        new_bptr = ptr_from_sorted(new_idx[0], B)
+    out_idx = torch.empty(3, Ea + Eb, dtype=_i64, device=dev)
+    grad = old_val.requires_grad or new_val.requires_grad
+    out_val = None if grad else torch.empty(Ea + Eb, dtype=_f32, device=dev)
+    perm = torch.empty(Ea + Eb, dtype=_i64, device=dev) if grad else None
+    _call("gcm_coo_merge_segments", _hip.ptr(old_idx) if Ea else None, _hip.ptr(new_idx) if Eb else None,
+          None if grad else _hip.ptr(old_val.contiguous()), None if grad else _hip.ptr(new_val.contiguous()),
+          _hip.ptr(old_bptr), _hip.ptr(new_bptr), _hip.ptr(out_idx), _hip.ptr(out_val), _hip.ptr(perm),
+          _hip.ptr(flags), Ea, Eb, B, _hip.stream())
+    if grad:
+        out_val = torch.cat([old_val, new_val])[perm]
+    return out_idx, out_val
+
+
+def sparse_temporal_edges(T, taus, hops_desc, edge_off=None, E=None):
+    """COO indices [3, E] (batch, sink, source) of the TemporalEdge selector, already in
+    coalesced order.  One host sync (E) unless the caller already knows E."""
+    _hip.on_device(T, taus)
+    B = T.numel()
+    arr = _hops_arg(hops_desc)
+    if edge_off is None:
+        edge_off = sparse_temporal_count(T, taus, hops_desc)
+    if E is None:
+        E = int(edge_off[B].item())
     idx = torch.empty(3, E, dtype=_i64, device=T.device)
     _call("gcm_sparse_temporal_fill", _hip.ptr(T), _hip.ptr(taus), ctypes.addressof(arr),
           len(hops_desc), _hip.ptr(edge_off), _hip.ptr(idx), E, B, _hip.stream())
@@ -589,6 +626,36 @@ class StepConfig:
             and sum(d.n_hops for d in descs if d.kind == _hip.SEL_TEMPORAL) <= 16
             and lib.gcm_dense_rows_supported(N, F, H1, H2)
             and _ext.module() is not None and hasattr(_ext.module(), "rows_step"))
+
+    # -- DenseGCM + LearnedEdge (csrc/learned_step.hip) ----------------------------------------
+    learned_sel = None          # the LearnedEdge module when this config is the fused learned step
+
+    def set_learned(self, sel, mods):
+        """sel: LearnedEdge with the default edge network `mods` (default_edge_network)."""
+        lib = _hip.lib()
+        self.learned_sel, self.mlp_mods = sel, mods
+        self.Pm = lib.gcm_learned_mlp_param_count(self.F)
+        self.P_total = self.P + self.Pm
+        self.eps = (float(mods[2].eps), float(mods[5].eps))
+        self.cutoff = 1.0 / (1 + sel.num_edge_samples)
+        self._zero_chain, self._zero_params = {}, {}
+        self.rows_ok = False
+
+    def zero_chain(self, B, dev):
+        """the proxy whose GRADIENT is the adjacency-gradient chain buffer: a [B,N,N] view of one
+        zero (no memory)"""
+        z = self._zero_chain.get(dev)
+        if z is None:
+            z = torch.zeros(1, 1, 1, device=dev)
+            self._zero_chain[dev] = z
+        return z.expand(B, self.N, self.N)       # a fresh view object per call (it gets a grad_fn)
+
+    def zero_params(self, dev):
+        z = self._zero_params.get(dev)
+        if z is None:
+            z = torch.zeros(self.P_total, device=dev)
+            self._zero_params[dev] = z
+        return z
 
     def rows_holder(self):
         """a fresh record holder for one packed parameter vector (C++: RowsHolder)"""
@@ -920,6 +987,79 @@ class _FusedRollout(torch.autograd.Function):
         need = ctx.needs_input_grad
         return (g_obs if need[0] else None, g_nodes0 if need[1] else None,
                 flat if need[2] else None, None, None, None, None)
+
+
+class _LearnedStep(torch.autograd.Function):
+    """One DenseGCM + LearnedEdge step (default edge network, observations without gradient) as ONE
+    autograd node: state advance, fused edge network + gumbel selection, dense 2-layer GNN forward;
+    ONE kernel backward (gcm_learned_step_bwd).  The adjacency's gradient chain through time travels
+    as the gradient of the `dchain` proxy (ONE [B,N,N] buffer, updated sparsely: csrc/learned_step.hip), the
+    parameter gradients accumulate into the gate's slab array.
+    inputs: packed = GNN vector | edge-network vector (gated), dchain_in; the rest is data."""
+
+    @staticmethod
+    def forward(ctx, packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags, cfg,
+                slab_acc, is_head):
+        lib = _hip.lib()
+        B, N, F, H1, H2, P = obs.shape[0], cfg.N, cfg.F, cfg.H1, cfg.H2, cfg.P
+        dev = obs.device
+        st = _hip.stream()
+        obs, nodes_in, adj_in = obs.contiguous(), nodes_in.contiguous(), adj_in.contiguous()
+        noise = noise.contiguous()
+        _hip.on_device(obs, nodes_in, adj_in, count_in, noise, packed, flags)
+        need_bwd = ctx.needs_input_grad[0]
+        nodes_out, adj_out = torch.empty_like(nodes_in), torch.empty_like(adj_in)
+        ibuf = torch.empty(2, B, dtype=torch.int64, device=dev)
+        cur, count_out = ibuf[0], ibuf[1]
+        p = _hip.ptr
+        _call("gcm_state_advance_fwd", p(nodes_in), p(adj_in), None, p(count_in), p(obs), p(nodes_out),
+              p(adj_out), None, p(cur), p(count_out), p(flags), B, N, F, st)
+        soft = torch.empty(B, N, device=dev, dtype=_f32)
+        base = packed.data_ptr()
+        _call("gcm_learned_select_fused", p(nodes_out), p(adj_out), p(cur), p(noise), int(noise_is_exp),
+              base + 4 * P, cfg.eps[0], cfg.eps[1], cfg.cutoff, p(soft), B, N, F, st)
+        mx = torch.empty(B, H2, device=dev, dtype=_f32)
+        h1 = torch.empty(B, N, H1, device=dev, dtype=_f32) if need_bwd else None
+        agg1 = torch.empty(B, N, F, device=dev, dtype=_f32) if need_bwd else None
+        agg2 = torch.empty(B, H1, device=dev, dtype=_f32) if need_bwd else None
+        w = cfg.unpack_ptrs(packed)
+        _call("gcm_dense_gnn2_row_fwd", p(nodes_out), p(adj_out), p(cur), w[0], w[1], w[2], cfg.acts[0],
+              w[3], w[4], w[5], cfg.acts[1], p(mx), p(h1), p(agg1), p(agg2), p(flags), B, N, F, H1, H2, st)
+        if need_bwd:
+            ctx.save_for_backward(packed, nodes_out, adj_out, ibuf, count_in, mx, h1, agg1, agg2, soft)
+            ctx.cfg, ctx.slab_acc, ctx.is_head = cfg, slab_acc, is_head
+        dchain_out = cfg.zero_chain(B, dev)
+        ctx.mark_non_differentiable(nodes_out, adj_out, cur, count_out)
+        ctx.set_materialize_grads(False)
+        return mx, dchain_out, nodes_out, adj_out, cur, count_out
+
+    @staticmethod
+    def backward(ctx, g_mx, g_chain, _gn, _ga, _gc, _gk):
+        packed, nodes_out, adj_out, ibuf, count_in, mx, h1, agg1, agg2, soft = ctx.saved_tensors
+        cfg = ctx.cfg
+        B, N, F, H1, H2, P = mx.shape[0], cfg.N, cfg.F, cfg.H1, cfg.H2, cfg.P
+        dev = mx.device
+        if g_mx is None and g_chain is None:
+            return (None,) * 12
+        if g_mx is None:
+            g_mx = torch.zeros(B, H2, device=dev, dtype=_f32)
+        g_mx = g_mx.contiguous()
+        # the chain buffer: handed down from the step after this one (mutated in place), or new
+        D = g_chain if (g_chain is not None and g_chain.is_contiguous()) else \
+            (torch.zeros(B, N, N, device=dev, dtype=_f32) if g_chain is None else g_chain.contiguous())
+        p = _hip.ptr
+        base = packed.data_ptr()
+        _call("gcm_learned_step_bwd", p(g_mx), p(nodes_out), p(adj_out), ibuf.data_ptr(), p(count_in), base,
+              cfg.acts[0], cfg.acts[1], p(mx), p(h1), p(agg1), p(agg2), p(soft), base + 4 * P, cfg.eps[0],
+              cfg.eps[1], p(D), p(ctx.slab_acc), 1, B, N, F, H1, H2, _hip.stream())
+        g_packed = cfg.zero_params(dev) if ctx.is_head else None     # a defined gradient: the gate runs
+        return (g_packed, D if ctx.needs_input_grad[1] else None) + (None,) * 10
+
+
+def learned_step(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags, cfg,
+                 slab_acc, is_head):
+    return _LearnedStep.apply(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags,
+                              cfg, slab_acc, is_head)
 
 
 def fused_rollout(obs, nodes0, packed, adj0, num_nodes0, flags, cfg):

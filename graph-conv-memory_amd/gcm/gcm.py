@@ -240,6 +240,12 @@ class DenseGCM(torch.nn.Module):
                 return None
             native = (TemporalBackedge, DenseEdge, Distance)
             sel = self.edge_selectors
+            from .edge_selectors.learned import LearnedEdge
+            if isinstance(sel, LearnedEdge):
+                # the fused learned step (csrc/learned_step.hip): default edge network only
+                if sel.deterministic or _ops.default_edge_network(sel.edge_network) is None:
+                    return None
+                return convs, tuple(acts), [sel]
             if sel is None:
                 mods = []
             elif isinstance(sel, native):
@@ -271,10 +277,23 @@ class DenseGCM(torch.nn.Module):
         if cached is not None:
             return cached if cached is not False else None
         from .edge_selectors.distance import Distance
+        from .edge_selectors.learned import LearnedEdge
         convs, acts, mods = st
         N, H1, H2 = nodes.shape[1], convs[0].out_channels, convs[1].out_channels
         cfg = False
-        if convs[0].in_channels == F and _ops.gnn2_supported(N, F, H1, H2):
+        if mods and isinstance(mods[0], LearnedEdge):
+            sel = mods[0]
+            net = _ops.default_edge_network(sel.edge_network)
+            if (convs[0].in_channels == F and net is not None and net[0].in_features == 2 * F
+                    and net[0].out_features == F and net[6].out_features == 1
+                    and _hip.lib().gcm_learned_step_supported(N, F, H1, H2)):
+                has_bias = (1 if convs[0].lin_rel.bias is not None else 0) | \
+                           (2 if convs[1].lin_rel.bias is not None else 0)
+                cfg = _ops.StepConfig([], acts, has_bias, N, F, H1, H2, nodes.device)
+                cfg.convs = convs
+                cfg.lins = (convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel, convs[1].lin_root)
+                cfg.set_learned(sel, net)
+        elif convs[0].in_channels == F and _ops.gnn2_supported(N, F, H1, H2):
             descs = [m.native_desc(F) if isinstance(m, Distance) else m.native_desc() for m in mods]
             if all(d is not None for d in descs):
                 has_bias = (1 if convs[0].lin_rel.bias is not None else 0) | \
@@ -302,6 +321,10 @@ class DenseGCM(torch.nn.Module):
         (rel0, root0, rel1, root1) = cfg.lins
         tensors = (rel0._parameters["weight"], root0._parameters["weight"], rel0._parameters["bias"],
                    rel1._parameters["weight"], root1._parameters["weight"], rel1._parameters["bias"])
+        if cfg.learned_sel is not None:     # ... | edge network (layout of gcm_learned_* in gcm_hip.h)
+            l0, _, n0, l1, _, n1, l2 = cfg.mlp_mods
+            tensors = tensors + (l0.weight, l0.bias, n0.weight, n0.bias, l1.weight, l1.bias, n1.weight,
+                                 n1.bias, l2.weight, l2.bias)
         cache = self._packed_cache
         if cache is not None and not head and not cache[2][0] and cache[0] == torch.is_grad_enabled():
             # valid while the very same tensor objects have not been written to (optimizer steps
@@ -315,6 +338,9 @@ class DenseGCM(torch.nn.Module):
                 return cache[1]
         key = torch.is_grad_enabled()
         sizes = (cfg.H1 * cfg.F, cfg.H1 * cfg.F, cfg.H1, cfg.H2 * cfg.H1, cfg.H2 * cfg.H1, cfg.H2)
+        if cfg.learned_sel is not None:
+            Fe = cfg.F
+            sizes = sizes + (2 * Fe * Fe, Fe, Fe, Fe, Fe * Fe, Fe, Fe, Fe, Fe, 1)
         dev = tensors[0].device
         parts = [t.reshape(-1) if t is not None else torch.zeros(n, device=dev)
                  for t, n in zip(tensors, sizes)]
@@ -323,7 +349,7 @@ class DenseGCM(torch.nn.Module):
         gated = holder = rows = None
         if packed.requires_grad:
             packed.register_hook(lambda g: used.__setitem__(0, True))
-            holder = _ops.SlabHolder(cfg.P, dev)
+            holder = _ops.SlabHolder(cfg.P_total if cfg.learned_sel is not None else cfg.P, dev)
             rows = cfg.rows_holder() if cfg.rows_ok else None
             gated = _ops.param_gate(packed, holder, rows)
         for d in cfg.descs:               # a re-assigned dist_param must not leave a stale pointer
@@ -374,6 +400,40 @@ class DenseGCM(torch.nn.Module):
             self._poll(flags)
         return mx, out
 
+    def _forward_learned(self, x, hidden, cfg, flags, link):
+        """DenseGCM + LearnedEdge as fused kernels (csrc/learned_step.hip): 4 launches forward, one
+        backward.  The returned adjacency carries no autograd history of its own: its gradient chain
+        travels with the hidden state in compact form (`_gcm_dchain` on the adjacency tensor)."""
+        nodes, adj, weights, num_nodes = hidden
+        root = self._packed_params(cfg, head=link is None)
+        pc = self._packed_cache
+        gated, holder = pc[4], pc[5]
+        B = x.shape[0]
+        sel = cfg.learned_sel
+        if sel.noise_fn is not None:      # injected gumbel draws (parity tests); values of the argument unspecified
+            noise, is_exp = sel.noise_fn(torch.empty(B, cfg.N, device=x.device)), 0
+        else:                             # torch.nn.functional.gumbel_softmax draws -log(Exp(1)) the same way
+            noise, is_exp = torch.empty(B, cfg.N, device=x.device).exponential_(), 1
+        if gated is not None:
+            is_head = link is None or link[5] is not root
+            dchain = getattr(adj, "_gcm_dchain", None) if not is_head else None
+            if dchain is None:
+                dchain = cfg.zero_chain(B, x.device)
+            mx, dchain_out, n2, a2, cur, c2 = _ops.learned_step(
+                gated, dchain, x, nodes, adj, num_nodes, noise, is_exp, flags, cfg, holder.get(B), is_head)
+            a2._gcm_dchain = dchain_out
+        else:
+            with torch.no_grad():
+                mx, _, n2, a2, cur, c2 = _ops.learned_step(
+                    root, cfg.zero_chain(B, x.device), x, nodes, adj, num_nodes, noise, is_exp, flags, cfg,
+                    None, True)
+        n2._gcm_link = (self._token, a2, cfg, flags, None, root, x.shape, weights, c2)
+        if self.mutate_num_nodes_on_overflow:
+            num_nodes.copy_(cur)
+        if self.finite_check != "off":
+            self._poll(flags)
+        return mx, (n2, a2, weights, c2)
+
     def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags, link=None):
         root = self._packed_params(cfg, head=link is None)
         gated, holder = self._packed_cache[4], self._packed_cache[5]
@@ -409,10 +469,15 @@ class DenseGCM(torch.nn.Module):
         module tree qualifies for the fused kernels the whole rollout is enqueued by one C call
         and is one autograd node, otherwise it is the plain Python loop."""
         assert obs.dim() == 3 and obs.dtype == torch.float32
+        if obs.is_cuda and obs.device.index != torch.cuda.current_device():
+            with torch.cuda.device(obs.device):
+                return self.rollout(obs, hidden)
         if hidden is None:
             hidden = self.get_initial_hidden_state(obs[0])
         nodes, adj, weights, num_nodes = hidden
         cfg = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
+        if cfg is not None and cfg.learned_sel is not None:
+            cfg = None                    # LearnedEdge: the per-step kernels, in a loop
         if cfg is None:
             outs = []
             for t in range(obs.shape[0]):
@@ -450,9 +515,20 @@ class DenseGCM(torch.nn.Module):
         if (link is not None and link[0] is self._token and link[1] is adj and link[7] is weights
                 and link[8] is num_nodes and x.shape == link[6] and x.dtype is torch.float32):
             cfg = link[2]
-            if cfg.rows_ok and not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad)):
+            no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
+            if cfg.rows_ok and no_dx:
                 return self._forward_rows(x, hidden, cfg, link[3], link)
-            return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, link[3], link)
+            if cfg.learned_sel is None:
+                return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, link[3], link)
+            if no_dx:
+                return self._forward_learned(x, hidden, cfg, link[3], link)
+            # (observations with gradient: the layered path below)
+
+        # the kernels are launched on the CURRENT device's stream: tensors on another GPU get a
+        # device guard for the call (PyTorch ops in the reference guard implicitly)
+        if x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return self.forward(x, hidden)
 
         # gcm.py:246-260, as one comparison
         if (x.dtype, nodes.dtype, adj.dtype, weights.dtype, num_nodes.dtype, num_nodes.dim()) != _DTYPES:
@@ -473,9 +549,13 @@ class DenseGCM(torch.nn.Module):
             # error on a mismatched hidden state)
             assert (nodes.shape[0], adj.shape[0], num_nodes.shape[0], nodes.shape[2]) == \
                 (B, B, B, x.shape[1]), "hidden state and observation shapes disagree"
-            if plan.rows_ok and not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad)):
+            no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
+            if plan.rows_ok and no_dx:
                 return self._forward_rows(x, hidden, plan, flags, None)
-            return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
+            if plan.learned_sel is None:
+                return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
+            if no_dx:
+                return self._forward_learned(x, hidden, plan, flags, None)
         # insert x at row num_nodes (after the overflow roll); fresh nodes/adj/weights buffers
         nodes, adj, weights, cur, num_nodes_next = _ops.state_advance(
             nodes, adj, weights, num_nodes, x, flags)

@@ -66,6 +66,8 @@ class LearnedEdge(torch.nn.Module):
                 p.register_hook(functools.partial(self.grad_hook, n))
         return m
 
+    new_sinks_only = True   # every sampled edge ends in a NEW node: SparseGCM merges without a sort
+
     def forward(self, nodes, T, taus, B):
         N = nodes.shape[1]
         if list(self.parameters())[0].device != nodes.device:
@@ -90,8 +92,9 @@ class LearnedEdge(torch.nn.Module):
         soft = _ops.segment_softmax(logits, self.tau_param, noise, edges)
         mask = soft > cutoff                                    # learned.py:143-151
         kept = soft[mask]
+        # (a subset of the closed-form candidate list: still in coalesced order, duplicate free)
         adj = torch.sparse_coo_tensor(indices=edges.indices[:, mask], values=kept / kept.detach(),
-                                      size=(B, N, N))
+                                      size=(B, N, N), is_coalesced=True)
         if self.log_stats:                                      # learned.py:153-159
             self.stats["edges_per_node"] = (kept.numel() / taus.sum().detach()).item()
             self.stats["edge_density"] = kept.numel() / edges.E

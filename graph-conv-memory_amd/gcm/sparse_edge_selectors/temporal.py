@@ -21,8 +21,17 @@ class TemporalEdge(torch.nn.Module):
         # a repeated hop only makes a duplicate edge that coalesce()/normalisation removes
         self._hops_desc = sorted({int(h) for h in hops}, reverse=True)
 
-    def forward(self, nodes, T, taus, B):
-        idx = _ops.sparse_temporal_edges(T, taus, self._hops_desc)
+    new_sinks_only = True   # every edge ends in a NEW node: SparseGCM merges without a sort
+
+    def plan(self, T, taus):
+        """per-graph edge offsets [B+1] (device; no sync): SparseGCM reads the total back together
+        with its own sizes and hands both to forward()"""
+        return _ops.sparse_temporal_count(T, taus, self._hops_desc)
+
+    def forward(self, nodes, T, taus, B, plan=None):
+        edge_off, E = plan if plan is not None else (None, None)
+        idx = _ops.sparse_temporal_edges(T, taus, self._hops_desc, edge_off, E)
         vals = torch.ones(idx.shape[1], device=idx.device)
-        return torch.sparse_coo_tensor(idx, vals, size=(B, int(1e5), int(1e5)),
-                                       is_coalesced=True)
+        out = torch.sparse_coo_tensor(idx, vals, size=(B, int(1e5), int(1e5)), is_coalesced=True)
+        out.gcm_bptr = edge_off      # rows of each graph (None: computed on demand)
+        return out

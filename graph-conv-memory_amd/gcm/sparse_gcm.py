@@ -64,9 +64,14 @@ class SparseGCM(torch.nn.Module):
             self._flags[device] = f
         return f
 
-    @staticmethod
-    def _merge(adj, new_adj):
-        """sparse_gcm.py:132-139: concatenate the COO lists and coalesce."""
+    def _merge(self, adj, new_adj, selector, B, flags):
+        """sparse_gcm.py:132-139: concatenate the COO lists and coalesce.  Selectors whose edges
+        all end in new nodes (every shipped one) merge as a segmented concatenation - no sort;
+        a violated order is flagged on the device and surfaces at the call's flag check."""
+        if getattr(selector, "new_sinks_only", False) and new_adj.is_coalesced() and adj.is_coalesced():
+            idx, val = _ops.coo_merge_segments(adj.indices(), adj.values(), new_adj.indices(),
+                                               new_adj.values(), getattr(new_adj, "gcm_bptr", None), B, flags)
+            return torch.sparse_coo_tensor(idx, val, size=adj.shape, is_coalesced=True)
         new_adj = new_adj.coalesce()
         if adj._nnz() == 0 and new_adj.is_coalesced():
             return torch.sparse_coo_tensor(new_adj.indices(), new_adj.values(), size=adj.shape,
@@ -102,7 +107,14 @@ class SparseGCM(torch.nn.Module):
         flags = self._flag_word(x.device)
 
         node_off, _new_off, totals = _ops.sparse_plan(T, taus)
-        M, _n_new, max_total, _max_tau = (int(v) for v in totals.tolist())   # the one readback
+        sel, sel_plan = self.edge_selectors, None
+        if hasattr(sel, "plan"):        # a selector that sizes itself on the device: one readback for both
+            edge_off = sel.plan(T, taus)
+            sizes = torch.cat([totals, edge_off[B:]]).tolist()
+            sel_plan = (edge_off, int(sizes[4]))
+        else:
+            sizes = totals.tolist()
+        M, _n_new, max_total, _max_tau = (int(v) for v in sizes[:4])         # the one readback
         if max_total > N:                                   # sparse_gcm.py:120-121
             raise Exception("Overflow")
 
@@ -111,13 +123,16 @@ class SparseGCM(torch.nn.Module):
         dirty_nodes = nodes.clone() if user_code else nodes
 
         if self.edge_selectors:
-            adj = self._merge(adj, self.edge_selectors(dirty_nodes, T, taus, B))
+            new_adj = sel(dirty_nodes, T, taus, B, plan=sel_plan) if sel_plan is not None \
+                else sel(dirty_nodes, T, taus, B)
+            adj = self._merge(adj, new_adj, sel, B, flags)
         if self.preprocessor:
             dirty_nodes = self.preprocessor(dirty_nodes)
         if self.positional_encoder:
             dirty_nodes = self.positional_encoder(dirty_nodes, T + taus)
         if self.aux_edge_selectors:
-            adj = self._merge(adj, self.aux_edge_selectors(dirty_nodes, T, taus, B))
+            adj = self._merge(adj, self.aux_edge_selectors(dirty_nodes, T, taus, B), self.aux_edge_selectors,
+                              B, flags)
 
         # sparse_gcm.py:160-164: all weights become 1 while keeping the path to the logits
         v = adj.values()
@@ -146,6 +161,8 @@ class SparseGCM(torch.nn.Module):
             bits = int(flags.item())
             if bits:
                 flags.zero_()
+            assert not bits & _hip.FLAG_MERGE_ORDER, \
+                "the stored adjacency has entries at or behind the new nodes (not a state this module produced)"
             assert not bits & _hip.FLAG_ACAUSAL, "Causality violated"
             assert not bits & _hip.FLAG_NONFINITE, \
                 "Got NaN in returned memory, try using tanh activation"

@@ -173,6 +173,20 @@ int gcm_sparse_flatten_bwd(const float* g_flat, const int64_t* T, const int64_t*
 int gcm_sparse_edges_to_csr(const int64_t* coo, const int64_t* node_off, int64_t* edge_index,
                             int64_t* row_ptr, uint32_t* flags, int64_t E, int64_t M, int B,
                             gcm_stream_t stream);
+/* sparse_gcm.py:132-139 (concatenate the stored and the new COO lists, coalesce) for the case every
+ * shipped selector produces: the new entries of a graph sort BEHIND its stored ones (their sinks are
+ * the new nodes).  Then the coalesced result is, per graph, the old entries followed by the new
+ * ones - a segmented concatenation, no sort.  old_idx [3,Ea] / new_idx [3,Eb] coalesced (batch,
+ * sink, source); old_bptr / new_bptr [B+1] = gcm_ptr_from_sorted over their batch rows; out_idx
+ * [3,Ea+Eb]; out_val (may be NULL) gets the values, perm (may be NULL) the position of every
+ * output entry in cat(old, new) (for values that carry gradients).  ORs GCM_FLAG_MERGE_ORDER when
+ * a new entry does not sort behind the stored ones (the caller then falls back to a sort). */
+#define GCM_FLAG_MERGE_ORDER 64u
+int gcm_coo_merge_segments(const int64_t* old_idx, const int64_t* new_idx, const float* old_val,
+                           const float* new_val, const int64_t* old_bptr, const int64_t* new_bptr,
+                           int64_t* out_idx, float* out_val, int64_t* perm, uint32_t* flags,
+                           int64_t Ea, int64_t Eb, int B, gcm_stream_t stream);
+
 /* generic: ptr[r] = first position in sorted keys[0..E) with key >= r, r in [0, M]. */
 int gcm_ptr_from_sorted(const int64_t* keys, int64_t* ptr, int64_t E, int64_t M,
                         gcm_stream_t stream);
@@ -420,6 +434,41 @@ int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_
                         int act1, int act2, const float* g_params_prev, float* g_params,
                         void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
                         int H2, gcm_stream_t stream);
+
+/* ---- DenseGCM + LearnedEdge, fused per graph (edge_selectors/learned.py:38-113) --------------
+ *
+ * The default edge network (learned.py:38-51: Linear(2F,F)-ReLU-LayerNorm-Linear(F,F)-ReLU-LayerNorm-
+ * Linear(F,1)) as ONE kernel per direction.  Packed edge-network parameter vector (and gradient
+ * slab) layout: W0 [F,2F] | b0 [F] | ln0.weight [F] | ln0.bias [F] | W1 [F,F] | b1 [F] | ln1.weight
+ * [F] | ln1.bias [F] | w2 [F] | b2 [1]  (gcm_learned_mlp_param_count floats).
+ * Shapes: N <= 128, F, H1, H2 <= 32 (gcm_learned_step_supported). */
+int gcm_learned_step_supported(int N, int F, int H1, int H2);
+size_t gcm_learned_mlp_param_count(int F);
+
+/* learned.py:53-113 on an already advanced state: logits of all candidate pairs (cur, j), gumbel
+ * softmax over j < cur with the given noise (gumbel draws, or exponential draws e with
+ * noise_is_exp: g = -log e), straight-through threshold at `cutoff`, adjacency row cur rewritten IN
+ * PLACE; soft [B,N] receives the softmax (what the backward needs). */
+int gcm_learned_select_fused(const float* nodes, float* adj, const int64_t* cur_idx,
+                             const float* noise, int noise_is_exp, const float* mlp_params,
+                             float eps0, float eps1, float cutoff, float* soft, int B, int N, int F,
+                             gcm_stream_t stream);
+
+/* Backward of one DenseGCM + LearnedEdge step when the observations carry no gradient: GNN adjoint on
+ * the live rows, the adjacency gradient in compact form, selection adjoint, edge-network adjoint
+ * (forward recomputed).  nodes / adj: the step's OUTPUT state; h1 / agg1 [B,N,.], agg2, mx as saved
+ * by gcm_dense_gnn2_row_fwd; soft from gcm_learned_select_fused; count_in = num_nodes before the
+ * step.  GA [B,N,N] is the chain buffer of the adjacency gradient: in, as left by the step after this
+ * one (zeros for the last step of a chain); out, for the step before (this step's live rows added,
+ * row cur consumed, the state advance undone).  slabs
+ * [B, gnn2_param_count + mlp_param_count]: per-graph parameter gradients, overwritten or
+ * (accumulate != 0) added to; the caller sums them once (gcm_sum_slabs). */
+int gcm_learned_step_bwd(const float* g_mx, const float* nodes, const float* adj,
+                         const int64_t* cur_idx, const int64_t* count_in, const float* gnn_params,
+                         int act1, int act2, const float* mx, const float* h1, const float* agg1,
+                         const float* agg2, const float* soft, const float* mlp_params, float eps0,
+                         float eps1, float* GA, float* slabs, int accumulate, int B, int N, int F,
+                         int H1, int H2, gcm_stream_t stream);
 
 /* ---- time-batched rollout (caller loop ray_gcm.py:200-202) --------- */
 

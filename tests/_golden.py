@@ -51,3 +51,18 @@ def oracle_selector(meta, sel_params=None, noise=None):
         return od.SpatialEdge(meta["max_distance"], slice(*meta["a"]), slice(*meta["b"]),
                               dist_param=dist_param)
     raise KeyError(kind)
+
+
+def fp64_bound(ref, obs, hidden, out32, **kw):
+    """Summation-order noise: when an aggregate adds up to N terms of magnitude ~1, two fp32
+    evaluations in different orders differ by more than 1e-5 relative.  The bound used instead:
+    distance to the SAME computation in float64 (the oracle run in double), which must not exceed 3x
+    the distance of the reference's own fp32 evaluation from it (floor 2e-6).  -> (out64, atol)."""
+    import copy
+    from oracle import dense as od
+    ref64 = copy.deepcopy(ref).double()
+    h64 = None if hidden is None else tuple(t.double() if t.is_floating_point() else t.clone() for t in hidden)
+    with torch.no_grad():
+        out64, _ = od.dense_rollout(obs.double(), h64, ref64, **kw)
+    err32 = float((out32.detach().double() - out64).abs().max())
+    return out64, max(2e-6, 3.0 * err32)

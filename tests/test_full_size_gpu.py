@@ -163,6 +163,45 @@ def test_cfg3_euclid_full_batch_matches_oracle():
     torch.testing.assert_close(obs_d.grad.cpu(), obs_c.grad, rtol=1e-4, atol=1e-5 * gs)
 
 
+def test_cfg3_euclid_full_batch_prefilled_state():
+    """cfg3 at full size with FULL graphs: every graph starts with n_b in [96, 124] stored nodes
+    (clustered like the observations, a temporal chain as adjacency), so every step thresholds ~100
+    candidate distances per graph against the cross-batch mean and the last steps cross the
+    overflow (gcm.py:323-355).  Full-batch oracle, edge decisions bit exact."""
+    from gcm.edge_selectors.distance import EuclideanEdge
+    B, N, F, H, T = 256, 128, 64, 32, 8
+    mem, g, ref = _dense_pair(F, H, N, EuclideanEdge(2.0), seed=9)
+    gen = torch.Generator().manual_seed(10)
+    centres = 4.0 * torch.randn(4, F, generator=gen)
+    count0 = torch.randint(96, 125, (B,), generator=gen)
+    nodes0 = centres[torch.arange(N) % 4][None, :, :] + 0.05 * torch.randn(B, N, F, generator=gen)
+    nodes0 = nodes0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    adj0 = torch.zeros(B, N, N)
+    i = torch.arange(1, N)
+    adj0[:, i, i - 1] = 1.0
+    adj0 = adj0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    obs = centres[torch.arange(T) % 4][:, None, :] + 0.05 * torch.randn(T, B, F, generator=gen)
+    h_c = (nodes0.clone(), adj0.clone(), torch.zeros(0), count0.clone())
+    with torch.no_grad():
+        out_c, hid_c = od.dense_rollout(obs, h_c, ref, graph_size=N, edge_selectors=od.EuclideanEdge(2.0))
+        hid = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
+        outs = []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+    mem.check_flags()
+    assert torch.equal(hid[1].cpu(), hid_c[1])                    # ~25 new edges per graph and step
+    assert float((hid_c[1] - adj0).clamp(min=0).sum()) > 20 * B * T
+    assert torch.equal(hid[0].cpu(), hid_c[0]) and torch.equal(hid[3].cpu(), hid_c[3])
+    assert int(hid_c[3].max()) == N                               # some graphs overflowed and rolled
+    # ~100 live rows per graph: every layer-2 aggregate adds ~25-100 terms (summation-order noise
+    # above 1e-5 relative between any two fp32 evaluations) -> bound through the float64 oracle
+    from _golden import fp64_bound
+    sel64 = od.EuclideanEdge(2.0)
+    out64, atol = fp64_bound(ref, obs, h_c, out_c, graph_size=N, edge_selectors=sel64)
+    assert float((torch.stack(outs).cpu().double() - out64).abs().max()) <= atol
+
+
 def test_cfg4_sparse_full_size_one_shot():
     """cfg4: SparseGCM + TemporalEdge([1]), B = 512 graphs of 512 nodes in one call.
     Closed forms (COO = the chain i -> i-1 per graph, T = taus), oracle on a slice of graphs,

@@ -1,0 +1,145 @@
+"""DenseGCM + LearnedEdge on the fused kernels (csrc/learned_step.hip): edge network, gumbel
+selection and the compact adjacency-gradient chain, against the reference's recorded-noise vectors
+and the CPU oracle with injected noise - up to BASELINE cfg5's per-GPU size.  Needs an MI355X."""
+import pytest
+import torch
+
+from _golden import Fixture
+from oracle import dense as od
+from test_dense_gpu import dev_gnn_from, DEV, RTOL, ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _taken(mem):
+    cfg = mem._cfg_last[3] if mem._cfg_last else None
+    return cfg is not None and cfg.learned_sel is not None
+
+
+def test_learned_fused_matches_reference_vectors():
+    """g6 (the reference run with its gumbel draws recorded), observations WITHOUT gradient: the
+    fused path.  Sampled adjacency bit exact, beliefs 1e-5, GNN and edge-network gradients."""
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.learned import LearnedEdge
+    fx = Fixture("g6_learned")
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    sel = LearnedEdge(m["F"], num_edge_samples=m["num_edge_samples"])
+    sel.load_state_dict(fx.group("sel_param:"))
+    sel = sel.to(DEV)
+    step = {"t": 0}
+
+    def noise(like):   # the reference drew nothing at t = 0 (learned.py:120-121)
+        key = f"noise_{step['t']}"
+        return fx[key].to(DEV) if key in fx else torch.zeros_like(like)
+
+    sel.noise_fn = noise
+    mem = DenseGCM(g, edge_selectors=sel, graph_size=m["N"])
+    obs = fx["obs"].to(DEV)
+    hidden, mxs = None, []
+    for t in range(m["T"]):
+        step["t"] = t
+        mx, hidden = mem(obs[t], hidden)
+        mxs.append(mx)
+    assert _taken(mem)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    mem.check_flags()
+    assert torch.equal(hidden[1].cpu(), fx["hT_adj"])       # sampled edges: bit exact
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"])
+    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+    for k, p in sel.named_parameters():
+        want = fx["sel_grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
+
+
+def _pair(F, H, N, k, seed):
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.learned import LearnedEdge
+    torch.manual_seed(seed)
+    ref = od.canonical_gnn(F, H)
+    net = od.build_edge_network(F)
+    with torch.no_grad():          # livelier than the default init: the sampled rows change over time
+        for p in net.parameters():
+            p.mul_(2.0)
+    g = dev_gnn_from(ref, [(F, H, torch.nn.Tanh), (H, H, torch.nn.Tanh)])
+    sel = LearnedEdge(F, num_edge_samples=k)
+    sel.edge_network.load_state_dict(net.state_dict())
+    sel = sel.to(DEV)
+    return ref, net, g, sel, DenseGCM(g, edge_selectors=sel, graph_size=N)
+
+
+def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3):
+    """product on the whole batch, oracle on the graphs `pick`, same injected gumbel noise; the loss
+    weights only the picked graphs."""
+    ref, net, g, sel, mem = _pair(F, H, N, k, seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    obs = torch.rand(T, B, F, generator=gen)
+    noise = -torch.empty(T, B, N).exponential_(generator=gen).log()
+    nodes0 = torch.rand(B, N, F, generator=gen) * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    adj0 = torch.zeros(B, N, N)
+    i = torch.arange(1, N)
+    adj0[:, i, i - 1] = 1.0
+    adj0 = adj0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    wgt = torch.rand(T, len(pick), H, generator=gen)
+    # oracle on the slice
+    step = {"t": 0}
+    osel = od.LearnedEdge(net, num_edge_samples=k,
+                          noise_fn=lambda shape: noise[step["t"]][pick][:, : shape[1]])
+    hid = (nodes0[pick].clone(), adj0[pick].clone(), torch.zeros(0), count0[pick].clone())
+    outs = []
+    for t in range(T):
+        step["t"] = t
+        mx, hid = od.dense_step(obs[t][pick], hid, ref, graph_size=N, edge_selectors=osel)
+        outs.append(mx)
+    out_c = torch.stack(outs)
+    (out_c * wgt).sum().backward()
+    # product on everything
+    pstep = {"t": 0}
+    sel.noise_fn = lambda like: noise[pstep["t"]].to(DEV)
+    hidden = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
+    outs = []
+    for t in range(T):
+        pstep["t"] = t
+        mx, hidden = mem(obs[t].to(DEV), hidden)
+        outs.append(mx)
+    assert _taken(mem)
+    out_d = torch.stack(outs)
+    (out_d[:, pick] * wgt.to(DEV)).sum().backward()
+    mem.check_flags()
+    assert torch.equal(hidden[1][pick].cpu(), hid[1].detach())          # sampled adjacency: bit exact
+    assert torch.equal(hidden[0][pick].cpu(), hid[0]) and torch.equal(hidden[3][pick].cpu(), hid[3])
+    torch.testing.assert_close(out_d[:, pick].cpu(), out_c.detach(), rtol=RTOL, atol=2e-6)
+    for (kk, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=2e-5 * float(pc.grad.abs().max()), msg=kk)
+    # (the last LayerNorm's bias and the output bias get sum_j g_logit[j] = 0 analytically - softmax
+    #  gradients sum to zero -: rounding noise on both sides, hence the floor from the common scale)
+    scale = max(float(p.grad.abs().max()) for p in net.parameters())
+    assert scale > 0
+    for (kk, pc), (_, pd) in zip(net.named_parameters(), sel.edge_network.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=rtol_sel,
+                                   atol=2e-5 * float(pc.grad.abs().max()) + 2e-6 * scale, msg=kk)
+    return hidden
+
+
+@pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2)])
+def test_learned_fused_vs_oracle(B, N, F, H, T, k):
+    """ragged shapes, staggered starts, overflow crossings (the chain buffer rolls with the state)"""
+    torch.manual_seed(B + N)
+    count0 = torch.randint(0, N + 1, (B,))
+    _run_both(B, N, F, H, T, k, seed=B * 7 + N, count0=count0, pick=list(range(B)))
+
+
+def test_learned_fused_cfg5_size_slice():
+    """BASELINE cfg5's per-GPU share: B = 256, N = 128, F = H = 32, graphs almost full (so every
+    step scores ~100+ candidates per graph and the last steps overflow); oracle on a slice."""
+    B, N, F, H, T = 256, 128, 32, 32, 6
+    gen = torch.Generator().manual_seed(3)
+    count0 = torch.randint(100, 127, (B,), generator=gen)
+    hidden = _run_both(B, N, F, H, T, 5, seed=11, count0=count0, pick=[0, 97, 255])
+    assert int(hidden[3].max()) == N
