@@ -336,6 +336,10 @@ class DenseGCM(torch.nn.Module):
                     break
             if live:
                 return cache[1]
+        # drop the previous vector FIRST: its graph keeps the parameters' AccumulateGrad nodes alive,
+        # bound to the stream they were created on - a later HIP-graph capture of this module would
+        # then be made to synchronise with that (possibly the default) stream and fail
+        self._packed_cache = cache = None
         key = torch.is_grad_enabled()
         sizes = (cfg.H1 * cfg.F, cfg.H1 * cfg.F, cfg.H1, cfg.H2 * cfg.H1, cfg.H2 * cfg.H1, cfg.H2)
         if cfg.learned_sel is not None:

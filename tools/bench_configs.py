@@ -64,9 +64,29 @@ def run_dense(name, B, N, F, H, T, sel, obs, iters=5):
             p.grad = None
 
     dt, dr = timeit(loop, iters), timeit(roll, iters)
+    # the same per-step loop + backward captured once in a HIP graph and replayed
+    dg = None
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            loop()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loop()
+        dg = timeit(graph.replay, 4 * iters)
+        mem.check_flags()
+    except Exception as e:     # a path with host syncs cannot be captured
+        dg = None
+        print("graph capture failed:", type(e).__name__, str(e)[:200], file=sys.stderr)
+        torch.cuda.synchronize()
     print(json.dumps({"config": name, "B": B, "N": N, "F": F, "H": H, "T": T,
                       "per_step_api_states_per_s": B * T / dt, "rollout_api_states_per_s": B * T / dr,
+                      "per_step_api_graph_replay_states_per_s": (B * T / dg) if dg else None,
                       "ms_per_rollout": dt * 1e3, "ms_per_rollout_rollout_api": dr * 1e3,
+                      "ms_per_rollout_graph_replay": dg * 1e3 if dg else None,
                       "fused": mem._structure() is not None}))
 
 
