@@ -31,6 +31,16 @@ struct StepTable {
   const float* gmx[GCM_ROWS_MAX_STEPS];
 };
 
+// History of DenseGCM.rollout's persistent forward kernel (rollout_persist.hip) as the record source:
+// per-step arrays [T, B, ...]; adj / nodes point at slot 1 of the [T+1, ...] state arrays (the state
+// AFTER step t).  Only the live 32-row tiles of h1 / agg1 / adj / nodes were written - the live ROWS
+// read here lie inside them.
+struct Hist {
+  const float *adj, *nodes, *h1, *agg1, *agg2, *mx, *gmx;
+  const int64_t* cur;
+  long gmx_st;   // element stride of g_mx along t
+};
+
 __device__ __forceinline__ float act_grad_sel(float y, int act_v) {
   float g = 1.f;
   g = act_v == GCM_ACT_TANH ? 1.f - y * y : g;
@@ -40,9 +50,9 @@ __device__ __forceinline__ float act_grad_sel(float y, int act_v) {
 
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
 // C2 = columns of v per lane (column m = lane + 64 c).
-template <int FP, int HP, int H2P>
+template <int FP, int HP, int H2P, bool HIST>
 __global__ __launch_bounds__(256) void k_bptt_rows(
-    StepTable tab, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
+    StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
     int B, int N, int F, int H1, int H2) {
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
@@ -79,27 +89,47 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
 #pragma unroll 1
   for (int item = wid; item < items; item += n_waves) {
     const int s = item / B, b = item - s * B;
-    const float* sv = tab.saved[s];
-    const float* gm = tab.gmx[s];
-    const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
-    const int L = __builtin_amdgcn_readfirstlane(hdr[0]);
-    const int l_cur = __builtin_amdgcn_readfirstlane(hdr[1]);
-    const float* rows = sv + lay.o_rows + (size_t)b * N * lay.rw;
-    const float* coef = sv + lay.o_coef + (size_t)b * N;
-    // d2 in lane o < H2
     const int oc = lane < H2 ? lane : H2 - 1;
-    const float g = gm[(long)b * gmx_sb + (long)oc * gmx_sh];
-    const float y = sv[(size_t)b * H2 + oc];
-    const float d2 = lane < H2 ? g * act_grad_sel(y, act2_v) : 0.f;
-    db2 += d2;
+    // what differs between the two record sources: where the numbers of the item live
+    const float* sv = nullptr;
+    int L = 0, l_cur = 0, cur = 0;
+    unsigned long long m0 = 0, m1 = 0;   // HIST: live rows as two 64-bit masks
+    float a0 = 0.f, a1 = 0.f, g, y;
     float vv[C2];
+    if (!HIST) {
+      sv = tab.saved[s];
+      const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+      L = __builtin_amdgcn_readfirstlane(hdr[0]);
+      l_cur = __builtin_amdgcn_readfirstlane(hdr[1]);
+      g = tab.gmx[s][(long)b * gmx_sb + (long)oc * gmx_sh];
+      y = sv[(size_t)b * H2 + oc];
 #pragma unroll
-    for (int c = 0; c < C2; ++c) {
-      const int m = lane + 64 * c;
-      const float t = sv[lay.o_v + (size_t)b * 2 * H1 + (m < 2 * H1 ? m : 2 * H1 - 1)];
-      vv[c] = m < 2 * H1 ? t : 0.f;
+      for (int c = 0; c < C2; ++c) {
+        const int m = lane + 64 * c;
+        const float t = sv[lay.o_v + (size_t)b * 2 * H1 + (m < 2 * H1 ? m : 2 * H1 - 1)];
+        vv[c] = m < 2 * H1 ? t : 0.f;
+      }
+    } else {
+      const size_t gi = (size_t)item;   // = s * B + b
+      const int64_t c64 = hs.cur[gi];
+      cur = __builtin_amdgcn_readfirstlane(c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64));
+      g = hs.gmx[(long)s * hs.gmx_st + (long)b * gmx_sb + (long)oc * gmx_sh];
+      y = hs.mx[gi * H2 + oc];
+      const float* arow = hs.adj + (gi * N + cur) * N;
+      a0 = arow[lane < N ? lane : N - 1];
+      a1 = arow[lane + 64 < N ? lane + 64 : N - 1];
+      m0 = __ballot(lane < N && (a0 != 0.f || lane == cur));
+      m1 = __ballot(lane + 64 < N && (a1 != 0.f || lane + 64 == cur));
+#pragma unroll
+      for (int c = 0; c < C2; ++c) {
+        const int m = lane + 64 * c;
+        const int k = m < H1 ? m : (m - H1 < H1 ? m - H1 : H1 - 1);
+        const float t = m < H1 ? hs.agg2[gi * H1 + k] : hs.h1[(gi * N + cur) * H1 + k];
+        vv[c] = m < 2 * H1 ? t : 0.f;
+      }
     }
-    // first live row's loads in flight under the layer-2 arithmetic
+    const float d2 = lane < H2 ? g * act_grad_sel(y, act2_v) : 0.f;   // d2 in lane o < H2
+    db2 += d2;
     float u[C2];
 #pragma unroll
     for (int c = 0; c < C2; ++c) u[c] = 0.f;
@@ -116,29 +146,49 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     float dagg2, dh1c;
     {
       const int hh = lane < H1 ? lane : 0;
-      const int m1 = H1 + hh;
-      float t0 = __shfl(u[0], hh & 63), t1 = __shfl(u[0], m1 & 63);
+      const int m1c = H1 + hh;
+      float t0 = __shfl(u[0], hh & 63), t1 = __shfl(u[0], m1c & 63);
       if (C2 == 2) {
-        const float a1 = __shfl(u[C2 - 1], hh & 63), b1 = __shfl(u[C2 - 1], m1 & 63);
-        t0 = hh >= 64 ? a1 : t0;
-        t1 = m1 >= 64 ? b1 : t1;
+        const float b1 = __shfl(u[C2 - 1], m1c & 63);
+        t1 = m1c >= 64 ? b1 : t1;
       }
       dagg2 = t0;
       dh1c = t1;
     }
+    // the live rows
 #pragma unroll 1
-    for (int l = 0; l < L; ++l) {
-      const float* row = rows + (size_t)l * lay.rw;
-      const float cf = coef[l];
-      const float hv = row[lane < H1 ? lane : H1 - 1];
-      float ax[C1];
+    for (int l = 0;; ++l) {
+      float cf, hv, ax[C1];
+      bool is_cur;
+      if (!HIST) {
+        if (l >= L) break;
+        const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
+        cf = sv[lay.o_coef + (size_t)b * N + l];
+        is_cur = l == l_cur;
+        hv = row[lane < H1 ? lane : H1 - 1];
 #pragma unroll
-      for (int c = 0; c < C1; ++c) {
-        const int m = lane + 64 * c;
-        const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
-        ax[c] = m < 2 * F ? t : 0.f;
+        for (int c = 0; c < C1; ++c) {
+          const int m = lane + 64 * c;
+          const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
+          ax[c] = m < 2 * F ? t : 0.f;
+        }
+      } else {
+        if (!(m0 | m1)) break;
+        const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+        if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+        cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? a0 : a1), j & 63));
+        is_cur = j == cur;
+        const size_t rj = (size_t)item * N + j;
+        hv = hs.h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+          const int m = lane + 64 * c;
+          const int f = m < F ? m : (m - F < F ? m - F : F - 1);
+          const float t = m < F ? hs.agg1[rj * F + f] : hs.nodes[rj * F + f];
+          ax[c] = m < 2 * F ? t : 0.f;
+        }
       }
-      float g1 = (cf * dagg2 + (l == l_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
+      float g1 = (cf * dagg2 + (is_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
       g1 = lane < H1 ? g1 : 0.f;
       db1 += g1;
 #pragma unroll
@@ -194,15 +244,15 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
 }
 
-template <int FP, int HP, int H2P>
-int launch_bptt(hipStream_t s, int grid, const StepTable& tab, int n_steps, long sb, long sh,
+template <int FP, int HP, int H2P, bool HIST>
+int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, int n_steps, long sb, long sh,
                 const float* w_rel2, const float* w_root2, int act1, int act2,
                 const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2) {
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   const size_t lds = sizeof(float) * P;
-  auto kern = k_bptt_rows<FP, HP, H2P>;
+  auto kern = k_bptt_rows<FP, HP, H2P, HIST>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, n_steps, sb, sh, w_rel2, w_root2, act1,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,
                      act2, lay, slabs, B, N, F, H1, H2);
   return gcm_launch_status();
 }
@@ -262,8 +312,9 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
     int rc = GCM_EUNSUPPORTED;
 #define GCM_RB(a, b_, cc)                                                                          \
   if (fp == a && hp == b_ && h2p == cc)                                                            \
-    rc = gcm_rows::launch_bptt<a, b_, cc>(s, per, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,     \
-                                          w_root2, act1, act2, lay, sl, B, N, F, H1, H2);
+    rc = gcm_rows::launch_bptt<a, b_, cc, false>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,  \
+                                                 gmx_stride_h, w_rel2, w_root2, act1, act2, lay, sl, B, \
+                                                 N, F, H1, H2);
     GCM_RB(32, 32, 32) GCM_RB(32, 32, 64) GCM_RB(32, 64, 32) GCM_RB(32, 64, 64)
     GCM_RB(64, 32, 32) GCM_RB(64, 32, 64) GCM_RB(64, 64, 32) GCM_RB(64, 64, 64)
 #undef GCM_RB
@@ -271,4 +322,54 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
   }
   (void)has_bias;
   return gcm_sum_slabs_acc(slabs, total_slabs, (int)P, g_params_prev, g_params, stream);
+}
+
+/* Parameter gradient of a DenseGCM.rollout from the history its forward kept (gcm_dense_rollout_fwd /
+ * gcm_dense_rollout_persistent_fwd), for the case that neither the observations nor the initial node
+ * matrix need a gradient: every graph-step is independent, ONE launch over all T*B of them reading
+ * only the live ROWS (no reverse scan of the node gradient, no per-step Q array).
+ * adj_all [T+1,B,N,N], nodes_all [T+1,B,N,F] (slot t+1 = state after step t), cur_all [T,B],
+ * mx_all / h1_all / agg1_all / agg2_all as written by the forward; g_mx_all with element strides. */
+extern "C" size_t gcm_dense_rollout_bwd_params_workspace_bytes(int T, int B, int F, int H1, int H2) {
+  return gcm_dense_rows_bptt_workspace_bytes(T < GCM_ROWS_MAX_STEPS ? T : GCM_ROWS_MAX_STEPS, B, F, H1, H2);
+}
+
+extern "C" int gcm_dense_rollout_bwd_params(const float* g_mx_all, long gmx_stride_t, long gmx_stride_b,
+                                            long gmx_stride_h, const float* nodes_all,
+                                            const float* adj_all, const int64_t* cur_all,
+                                            const float* params, int act1, int act2,
+                                            const float* mx_all, const float* h1_all,
+                                            const float* agg1_all, const float* agg2_all,
+                                            float* g_params, void* workspace, size_t workspace_bytes,
+                                            int T, int B, int N, int F, int H1, int H2,
+                                            gcm_stream_t stream) {
+  GCM_REQUIRE(g_mx_all && nodes_all && adj_all && cur_all && params && mx_all && h1_all && agg1_all &&
+              agg2_all && g_params && workspace);
+  GCM_REQUIRE(T > 0 && B > 0 && (long)T * B < (1l << 31));
+  if (!gcm_dense_rows_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  if (workspace_bytes < gcm_dense_rollout_bwd_params_workspace_bytes(T, B, F, H1, H2)) return GCM_EWORKSPACE;
+  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
+  gcm_rows::Hist hs{adj_all + (size_t)B * N * N, nodes_all + (size_t)B * N * F, h1_all, agg1_all, agg2_all,
+                    mx_all, g_mx_all, cur_all, gmx_stride_t};
+  // one launch over all T*B items (the step index is item / B): grid as for 64 steps
+  const int grid = gcm_dense_rows_bptt_slabs(T < GCM_ROWS_MAX_STEPS ? T : GCM_ROWS_MAX_STEPS, B);
+  hipStream_t s = (hipStream_t)stream;
+  const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64, h2p = H2 <= 32 ? 32 : 64;
+  float* slabs = (float*)workspace;
+  int rc = GCM_EUNSUPPORTED;
+  const gcm_rows::StepTable none{};
+#define GCM_RH(a, b_, cc)                                                                          \
+  if (fp == a && hp == b_ && h2p == cc)                                                            \
+    rc = gcm_rows::launch_bptt<a, b_, cc, true>(s, grid, none, hs, T, gmx_stride_b, gmx_stride_h,  \
+                                                w_rel2, w_root2, act1, act2, lay, slabs, B, N, F,  \
+                                                H1, H2);
+  GCM_RH(32, 32, 32) GCM_RH(32, 32, 64) GCM_RH(32, 64, 32) GCM_RH(32, 64, 64)
+  GCM_RH(64, 32, 32) GCM_RH(64, 32, 64) GCM_RH(64, 64, 32) GCM_RH(64, 64, 64)
+#undef GCM_RH
+  if (rc) return rc;
+  (void)P;
+  return gcm_sum_slabs(slabs, grid, (int)P, g_params, stream);
 }

@@ -969,6 +969,21 @@ class _FusedRollout(torch.autograd.Function):
         lib = _hip.lib()
         if g_mx_all is None:
             g_mx_all = torch.zeros(T, B, H2, device=dev)
+        need = ctx.needs_input_grad
+        if (not need[0] and not need[1] and g_mx_all.dtype == _f32
+                and lib.gcm_dense_rows_supported(N, F, H1, H2)):
+            # only the parameters need a gradient: every graph-step is independent - one launch over
+            # the live rows of all T*B of them (csrc/rows_bptt.hip), no reverse scan, no Q array; an
+            # expanded gradient (mean()) is read through its strides
+            flat = torch.empty(P, device=dev, dtype=_f32)
+            ws_bytes = lib.gcm_dense_rollout_bwd_params_workspace_bytes(T, B, F, H1, H2)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            st_t, st_b, st_h = g_mx_all.stride()
+            _call("gcm_dense_rollout_bwd_params", _hip.ptr(g_mx_all), st_t, st_b, st_h, _hip.ptr(nodes_all),
+                  _hip.ptr(adj_all), _hip.ptr(cur_all), packed.data_ptr(), cfg.acts[0], cfg.acts[1],
+                  _hip.ptr(mx_all), _hip.ptr(h1_all), _hip.ptr(agg1_all), _hip.ptr(agg2_all), _hip.ptr(flat),
+                  _hip.ptr(ws), ws_bytes, T, B, N, F, H1, H2, _hip.stream())
+            return None, None, flat if need[2] else None, None, None, None, None
         g_mx_all = g_mx_all.contiguous()
         g_nodes_T = None if g_nodes_T is None else g_nodes_T.contiguous()
         g_obs = torch.empty(T, B, F, device=dev, dtype=_f32)

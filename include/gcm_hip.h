@@ -435,6 +435,19 @@ int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_
                         void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
                         int H2, gcm_stream_t stream);
 
+/* Parameter gradient of a rollout from the history gcm_dense_rollout_fwd /
+ * gcm_dense_rollout_persistent_fwd kept, when neither the observations nor the initial node matrix
+ * need a gradient: all T*B graph-steps in ONE launch over the live rows (no reverse scan, no Q array).
+ * g_mx_all: [T,B,H2] with element strides (0 for an expanded gradient). */
+size_t gcm_dense_rollout_bwd_params_workspace_bytes(int T, int B, int F, int H1, int H2);
+int gcm_dense_rollout_bwd_params(const float* g_mx_all, long gmx_stride_t, long gmx_stride_b,
+                                 long gmx_stride_h, const float* nodes_all, const float* adj_all,
+                                 const int64_t* cur_all, const float* params, int act1, int act2,
+                                 const float* mx_all, const float* h1_all, const float* agg1_all,
+                                 const float* agg2_all, float* g_params, void* workspace,
+                                 size_t workspace_bytes, int T, int B, int N, int F, int H1, int H2,
+                                 gcm_stream_t stream);
+
 /* ---- DenseGCM + LearnedEdge, fused per graph (edge_selectors/learned.py:38-113) --------------
  *
  * The default edge network (learned.py:38-51: Linear(2F,F)-ReLU-LayerNorm-Linear(F,F)-ReLU-LayerNorm-

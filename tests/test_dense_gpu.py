@@ -521,6 +521,34 @@ def test_fused_matches_layered_and_rollout(B, N, F, H1, H2, T, sel_kind):
             torch.testing.assert_close(got[3][k], want[3][k], rtol=1e-4, atol=1e-5 * scale, msg=k)
 
 
+@pytest.mark.parametrize("N,F,H1,H2,T,sel_kind", [(32, 32, 32, 32, 50, "temporal"), (64, 64, 64, 64, 70, "dense"),
+                                                  (128, 32, 32, 32, 140, "temporal"), (96, 32, 64, 32, 30, "none")])
+def test_rollout_params_only_backward(N, F, H1, H2, T, sel_kind):
+    """Observations without a gradient: the rollout's backward is the one live-row parameter kernel
+    over the kept history (no dX chain).  Same parameter gradients as the full backward."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.dense import DenseEdge
+    sel = {"temporal": lambda: TemporalBackedge([1, 2, 4]), "dense": lambda: DenseEdge(), "none": lambda: None}[sel_kind]
+    torch.manual_seed(N + T)
+    B = 5
+    obs = torch.rand(T, B, F, device=DEV)
+    starts = torch.randint(0, N // 2, (B,), device=DEV)
+    nodes0 = torch.rand(B, N, F, device=DEV) * (torch.arange(N, device=DEV)[None, :, None] < starts[:, None, None])
+    adj0 = ((torch.rand(B, N, N, device=DEV) < 0.1) & (torch.arange(N, device=DEV)[None, :, None] < starts[:, None, None])
+            & (torch.arange(N, device=DEV)[None, None, :] < starts[:, None, None])).float()
+    h0 = (nodes0, adj0, torch.zeros(0, device=DEV), starts)
+    mem, g = _mk(F, H1, H2, torch.nn.Tanh, torch.nn.Tanh, sel(), N, fused=True)
+    want = _run(mem, g, obs, h0, rollout=True)
+    g.zero_grad(set_to_none=True)
+    out, hid = mem.rollout(obs, h0)
+    (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
+    mem.check_flags()
+    torch.testing.assert_close(out.detach(), want[0], rtol=0, atol=0)
+    for k, p in g.named_parameters():
+        scale = float(want[3][k].abs().max()) + 1e-12
+        torch.testing.assert_close(p.grad, want[3][k], rtol=1e-4, atol=1e-5 * scale, msg=k)
+
+
 def test_rollout_bptt_schedules_agree(monkeypatch):
     """time-parallel BPTT (one batched adjoint launch + reverse scan) == step-by-step BPTT."""
     from gcm.edge_selectors.temporal import TemporalBackedge
