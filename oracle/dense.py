@@ -46,14 +46,63 @@ def wrap_overflow(nodes, adj, weights, num_nodes):
 # --------------------------------------------------------------------------
 # edge selectors: f(nodes, adj, weights, num_nodes, B) -> (adj, weights)
 # --------------------------------------------------------------------------
-class TemporalBackedge:
-    """edge_selectors/temporal.py:72-88 (deterministic_forward)."""
+def sparsemax(z):
+    """Sparsemax of a 1-D tensor (Martins & Astudillo 2016, Algorithm 1) - what the third-party
+    `sparsemax` package (absent from /root/reference; imported at util.py:5) computes for
+    util.Spardmax (util.py:29-42).  Parity unpinned: published algorithm only."""
+    zs, _ = torch.sort(z, descending=True)
+    k = torch.arange(1, z.numel() + 1, dtype=z.dtype)
+    csum = zs.cumsum(0)
+    kz = int((1 + k * zs > csum).sum())
+    tau = (csum[kz - 1] - 1) / kz
+    return torch.clamp(z - tau, min=0)
 
-    def __init__(self, hops=(1,), direction="forward"):
+
+class TemporalBackedge:
+    """edge_selectors/temporal.py:72-88 (deterministic_forward) and :51-70 (learned_forward).
+
+    learned=True: `window` is the learnable logit vector; `noise_fn(n)` returns the standard
+    gumbel noise of one torch.nn.functional.gumbel_softmax call over n logits (calls come in the
+    reference's order: graphs ascending, samples ascending) - default: drawn like torch does."""
+
+    def __init__(self, hops=(1,), direction="forward", learned=False, learning_window=10,
+                 deterministic=False, num_samples=3, noise_fn=None):
         assert direction in ("forward", "backward", "both")
         self.hops, self.direction = list(hops), direction
+        self.learned = learned
+        if learned:
+            self.window = torch.ones(learning_window, requires_grad=True)
+            self.num_samples, self.deterministic = num_samples, deterministic
+            self.noise_fn = noise_fn or (lambda n: -torch.empty(n).exponential_().log())
+
+    def _gumbel_hard(self, logits):
+        # torch.nn.functional.gumbel_softmax(logits, tau=1, hard=True)
+        soft = torch.softmax(logits + self.noise_fn(logits.numel()), dim=-1)
+        hard = torch.zeros_like(soft)
+        hard[int(soft.argmax())] = 1.0
+        return hard - soft.detach() + soft
+
+    def _learned(self, nodes, adj, weights, num_nodes, B):
+        adj = adj.clone()
+        for b in range(B):
+            n = int(num_nodes[b])
+            if n == 0:
+                continue
+            rel = self.window[:n]
+            if self.deterministic:
+                soft = sparsemax(rel)
+                mask = (soft > 0).float() - soft.detach() + soft          # util.py:38-42
+            else:
+                mask = torch.zeros_like(rel)
+                for _ in range(self.num_samples):                         # util.diff_or, util.py:456-465
+                    y = self._gumbel_hard(rel)
+                    mask = mask + y - mask * y
+            adj[b, n, :n] = adj[b, n, :n] + mask          # (shape error when n > learning_window)
+        return adj, weights
 
     def __call__(self, nodes, adj, weights, num_nodes, B):
+        if self.learned:
+            return self._learned(nodes, adj, weights, num_nodes, B)
         adj = adj.clone()
         for hop in self.hops:
             ok = torch.nonzero(num_nodes >= hop).flatten()

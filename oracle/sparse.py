@@ -163,12 +163,26 @@ def get_causal_edges(T, taus, window=None):
     return torch.cat(out, dim=-1)
 
 
-def sparse_gumbel_softmax(logits, dim, tau=1.0, noise=None):
-    """util.py:89-113 (hard=False)."""
+def sparse_gumbel_softmax(logits, dim, tau=1.0, noise=None, hard=False):
+    """util.py:89-130.  hard=True: util.py:110-130 calls torch_scatter.scatter_max (third-party,
+    absent from /root/reference and this image; its documented semantics: per group the maximum and
+    the index of the FIRST entry attaining it) - restated as a loop over rows; pinned by the
+    reference's own known-answer test (tests/test_sparse_gcm.py:795-823)."""
     logits = logits.coalesce()
     g = noise if noise is not None else -torch.empty_like(logits.values()).exponential_().log()
     z = torch.sparse_coo_tensor(logits.indices(), (logits.values() + g) / tau, size=logits.shape)
-    return torch.sparse.softmax(z, dim=dim).coalesce()
+    soft = torch.sparse.softmax(z, dim=dim).coalesce()
+    if not hard:
+        return soft
+    idx, vals = soft.indices(), soft.values()
+    dim = dim % idx.shape[0]
+    rows = {}
+    for e in range(vals.numel()):
+        k = tuple(int(idx[d, e]) for d in range(idx.shape[0]) if d != dim)
+        if k not in rows or float(vals[e].detach()) > float(vals[rows[k]].detach()):
+            rows[k] = e
+    keep = torch.tensor([rows[k] for k in sorted(rows)], dtype=torch.long)
+    return torch.sparse_coo_tensor(idx[:, keep], vals[keep], size=logits.shape)
 
 
 class LearnedEdge:

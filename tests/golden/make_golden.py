@@ -253,7 +253,11 @@ def main():
         out = ((logits + g) / tau).softmax(dim)
         torch.set_rng_state(state)
         ref = real_gs(logits, tau=tau, hard=hard, dim=dim)   # the real thing, same draws
-        assert torch.equal(ref, out)
+        if hard:     # one-hot of the same soft sample (straight-through value)
+            one_hot = torch.zeros_like(out).scatter_(dim, out.argmax(dim, keepdim=True), 1.0)
+            assert torch.equal(ref.detach(), (one_hot - out.detach()) + out.detach())
+        else:
+            assert torch.equal(ref, out)
         noises.append(g.detach().clone())
         return ref
 
@@ -274,6 +278,43 @@ def main():
         run_dense("g6_learned", m, obs, None, gnn, sel_module=sel,
                   meta=dict(B=B, N=N, F=F, H=H, T=T, selector="learned", num_edge_samples=3),
                   extra=noise_arrays)
+    finally:
+        torch.nn.functional.gumbel_softmax = real_gs
+
+    # ---- G14: TemporalBackedge(learned=True): gumbel windows with captured noise --------------
+    torch.manual_seed(14)
+    gen = torch.Generator().manual_seed(15)
+    B, N, F, H, T, W, S = 3, 12, 6, 8, 6, 10, 3
+    starts = [0, 2, 4]
+    gnn = od.canonical_gnn(F, H)
+    sel = TemporalBackedge(learned=True, learning_window=W, num_samples=S)
+    with torch.no_grad():
+        sel.window.copy_(torch.randn(W, generator=gen))
+    noises.clear()
+    torch.nn.functional.gumbel_softmax = recording_gumbel_softmax
+    m = DenseGCM(gnn, edge_selectors=sel, graph_size=N)
+    h0 = staggered_state(B, N, F, starts, gen)
+
+    def window_noise():
+        # calls come graph by graph (empty graphs skipped), sample by sample; one [n_b] draw each
+        out, it = torch.zeros(T, B, S, W), iter(noises)
+        for t in range(T):
+            for b in range(B):
+                n = starts[b] + t
+                for i in range(S if n > 0 else 0):
+                    g = next(it)
+                    assert g.shape == (n,)
+                    out[t, b, i, :n] = g
+        assert next(it, None) is None
+        return {"noise": out}
+
+    try:
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):      # util.diff_or prints on every call
+            run_dense("g14_temporal_learned", m, torch.rand(T, B, F, generator=gen), h0, gnn, sel_module=sel,
+                      meta=dict(B=B, N=N, F=F, H=H, T=T, selector="temporal_learned", learning_window=W,
+                                num_samples=S, starts=starts),
+                      extra=window_noise)
     finally:
         torch.nn.functional.gumbel_softmax = real_gs
 

@@ -415,6 +415,95 @@ def test_learned_edge_matches_reference():
         torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
 
 
+def test_temporal_backedge_learned_matches_reference():
+    """TemporalBackedge(learned=True) (temporal.py:51-70) against the reference run with
+    recorded gumbel draws: sampled edges bit exact, window-logit gradient included."""
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    fx = Fixture("g14_temporal_learned")
+    m = fx.meta
+    ref = od.canonical_gnn(m["F"], m["H"])
+    ref.load_state_dict(fx.group("param:"))
+    g = dev_gnn_from(ref, [(m["F"], m["H"], torch.nn.Tanh), (m["H"], m["H"], torch.nn.Tanh)])
+    sel = TemporalBackedge(learned=True, learning_window=m["learning_window"], num_samples=m["num_samples"])
+    sel.load_state_dict(fx.group("sel_param:"))
+    sel = sel.to(DEV)
+    step = {"t": 0}
+    sel.noise_fn = lambda shape, dev: fx["noise"][step["t"]].permute(1, 0, 2).contiguous().to(dev)
+    mem = DenseGCM(g, edge_selectors=sel, graph_size=m["N"])
+    obs = fx["obs"].to(DEV).requires_grad_(True)
+    hidden, mxs = tuple(t.to(DEV) for t in fx.h0()), []
+    for t in range(m["T"]):
+        step["t"] = t
+        mx, hidden = mem(obs[t], hidden)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    mem.check_flags()
+    assert torch.equal(hidden[1].detach().cpu(), fx["hT_adj"])
+    assert torch.equal(hidden[0].cpu(), fx["hT_nodes"]) and torch.equal(hidden[3].cpu(), fx["hT_num_nodes"])
+    torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
+    gs = float(fx["grad_obs"].abs().max())
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    want = fx["sel_grad:window"]
+    torch.testing.assert_close(sel.window.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+    for k, p in g.named_parameters():
+        want = fx["grad:" + k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+
+
+def test_temporal_backedge_learned_variants():
+    """Device-RNG draws, the deterministic (hard sparsemax) variant against the oracle restatement,
+    and the reference's failure beyond the learning window."""
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm import nn as G
+    torch.manual_seed(0)
+    B, N, F, W = 4, 16, 8, 6
+
+    def gnn():
+        torch.manual_seed(1)
+        return G.Sequential("x, adj, weights, B, N", [(G.DenseGraphConv(F, F), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+
+    sel = TemporalBackedge(learned=True, learning_window=W, num_samples=2).to(DEV)
+    mem = DenseGCM(gnn(), edge_selectors=sel, graph_size=N)
+    hidden, outs = None, []
+    for t in range(W + 1):
+        mx, hidden = mem(torch.randn(B, F, device=DEV), hidden)
+        outs.append(mx)
+        adj = hidden[1].detach()
+        assert bool(((adj == 0) | (adj == 1)).all())
+        assert int(adj.sum()) <= 2 * B * t and (t == 0 or int(adj[:, t].sum()) >= B)
+    torch.stack(outs).sum().backward()
+    assert sel.window.grad is not None and bool(torch.isfinite(sel.window.grad).all())
+    with pytest.raises(RuntimeError):                     # n_b = W + 1 nodes: window too short
+        mem(torch.randn(B, F, device=DEV), hidden)
+
+    # deterministic: hard sparsemax over window[:n_b] vs the oracle's per-graph loop
+    torch.manual_seed(2)
+    win = torch.randn(W)
+    obs = torch.randn(W, B, F)
+    sel = TemporalBackedge(learned=True, learning_window=W, deterministic=True)
+    with torch.no_grad():
+        sel.window.copy_(win)
+    mem = DenseGCM(gnn(), edge_selectors=sel.to(DEV), graph_size=N)
+    osel = od.TemporalBackedge(learned=True, learning_window=W, deterministic=True)
+    osel.window = win.clone().requires_grad_(True)
+    torch.manual_seed(1)
+    ognn = pyg.Sequential("x, adj, weights, B, N", [(pyg.DenseGraphConv(F, F), "x, adj -> x"), torch.nn.Tanh()])
+    hidden, ohid, got, want = None, None, [], []
+    for t in range(W):
+        mx, hidden = mem(obs[t].to(DEV), hidden)
+        omx, ohid = od.dense_step(obs[t], ohid, ognn, graph_size=N, edge_selectors=osel)
+        got.append(mx); want.append(omx)
+    assert torch.equal(hidden[1].detach().cpu(), ohid[1].detach())
+    torch.testing.assert_close(torch.stack(got).cpu(), torch.stack(want), rtol=RTOL, atol=ATOL)
+    torch.stack(got).sum().backward()
+    torch.stack(want).sum().backward()
+    scale = float(osel.window.grad.abs().max())
+    torch.testing.assert_close(sel.window.grad.cpu(), osel.window.grad, rtol=1e-4, atol=1e-5 * scale + 1e-8)
+
+
 def test_learned_edge_default_noise_runs():
     """Device-RNG gumbel draws: adjacency stays binary, new edges only in row cur, grads flow."""
     from gcm.gcm import DenseGCM

@@ -78,3 +78,24 @@ def test_selector_constructors():
     assert CosineEdge(0.5).max_distance == 0.5
     s = SpatialEdge(1.0, slice(0, 3))
     assert s._slices(8) == ((0, 3), (0, 3))
+
+
+def test_util_straight_through_helpers():
+    """util.Spardmax / Hardmax / diff_or (util.py:29-56, 456-465): host-side torch ops, checked
+    against the oracle's per-row sparsemax restatement."""
+    from gcm import util
+    from oracle import dense as od
+    torch.manual_seed(0)
+    z = torch.randn(5, 9, requires_grad=True)
+    p = util.sparsemax(z)
+    for r in range(5):
+        torch.testing.assert_close(p[r], od.sparsemax(z[r].detach()), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(util.sparsemax(z.t(), 0).t(), p)
+    hard = util.Spardmax()(z)
+    assert torch.equal(hard.detach(), (p > 0).float())
+    hard.sum().backward()                      # straight through: the sparsemax gradient (rows sum to 1 -> 0)
+    assert float(z.grad.abs().max()) < 1e-6
+    hm = util.Hardmax(cutoff=0.2)(z.detach())
+    assert torch.equal(hm, (torch.softmax(z.detach(), -1) > 0.2).float())
+    a, b, c = (torch.tensor(v) for v in ([0., 1., 0., 1.], [0., 0., 1., 1.], [0., 0., 0., 1.]))
+    assert torch.equal(util.diff_or([a, b, c]), torch.tensor([0., 1., 1., 1.]))

@@ -70,6 +70,56 @@ def test_learned_edge_oracle_matches_reference():
         torch.testing.assert_close(p.grad, fx["sel_grad:edge_network." + k], rtol=1e-4, atol=1e-7)
 
 
+def test_temporal_learned_oracle_matches_reference():
+    """TemporalBackedge(learned=True) (temporal.py:51-70) with the reference's recorded gumbel draws."""
+    fx = Fixture("g14_temporal_learned")
+    m = fx.meta
+    gnn = od.canonical_gnn(m["F"], m["H"])
+    gnn.load_state_dict(fx.group("param:"))
+    calls = {"t": 0, "k": 0}
+
+    def noise(n):                       # graphs ascending (empty ones skipped), samples ascending
+        order = [(b, i) for b in range(m["B"]) if m["starts"][b] + calls["t"] > 0 for i in range(m["num_samples"])]
+        b, i = order[calls["k"]]
+        calls["k"] += 1
+        return fx["noise"][calls["t"], b, i, :n]
+
+    sel = od.TemporalBackedge(learned=True, learning_window=m["learning_window"],
+                              num_samples=m["num_samples"], noise_fn=noise)
+    sel.window = fx["sel_param:window"].clone().requires_grad_(True)
+    obs = fx["obs"].clone().requires_grad_(True)
+    hidden, mxs = fx.h0(), []
+    for t in range(m["T"]):
+        calls["t"], calls["k"] = t, 0
+        mx, hidden = od.dense_step(obs[t], hidden, gnn, graph_size=m["N"], edge_selectors=sel)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    assert torch.equal(hidden[1].detach(), fx["hT_adj"])
+    torch.testing.assert_close(mxs, fx["mx"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(sel.window.grad, fx["sel_grad:window"], rtol=1e-4, atol=1e-7)
+    for k, p in gnn.named_parameters():
+        torch.testing.assert_close(p.grad, fx["grad:" + k], rtol=1e-5, atol=1e-7)
+
+
+def test_sparsemax_restatement_properties():
+    """Spardmax's sparsemax (third-party package, absent: parity unpinned) - simplex projection
+    properties and the closed form for two logits."""
+    torch.manual_seed(0)
+    for n in (1, 2, 5, 17):
+        z = 2 * torch.randn(n)
+        p = od.sparsemax(z)
+        assert abs(float(p.sum()) - 1) < 1e-6 and bool((p >= 0).all())
+        # support = the largest entries; inside it p - z is constant (= -tau)
+        sup = p > 0
+        assert float(z[sup].min()) >= float(z[~sup].max()) if (~sup).any() else True
+        d = (p - z)[sup]
+        assert float(d.max() - d.min()) < 1e-6
+    torch.testing.assert_close(od.sparsemax(torch.tensor([0.3, 0.1])), torch.tensor([0.6, 0.4]))
+    torch.testing.assert_close(od.sparsemax(torch.tensor([3.0, 0.1])), torch.tensor([1.0, 0.0]))
+
+
 @pytest.mark.parametrize("name", ["g7_wrap_weights", "g7_wrap_noweights"])
 def test_wrap_overflow_oracle(name):
     fx = Fixture(name)
@@ -212,3 +262,16 @@ def test_sparse_learned_oracle_matches_reference(name):
     torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-4, atol=1e-7)
     for k, p in net.named_parameters():
         torch.testing.assert_close(p.grad, fx["sel_grad:edge_network." + k], rtol=1e-4, atol=1e-7)
+
+
+def test_sparse_gumbel_softmax_hard_oracle_known_answer():
+    """hard=True against the reference's own known-answer vector (tests/test_sparse_gcm.py:795-823)."""
+    idx = torch.tensor([[0, 0, 0, 0, 0, 0, 1, 1], [0, 0, 0, 0, 1, 1, 1, 1],
+                        [0, 1, 2, 2, 0, 5, 4, 4], [0, 0, 1, 0, 0, 3, 0, 3]])
+    values = torch.ones(8) * 1e15
+    values[3] = 0
+    values[-1] = 0
+    res = osp.sparse_gumbel_softmax(torch.sparse_coo_tensor(idx, values, size=(2, 2, 100, 100)), 3,
+                                    hard=True).coalesce()
+    want = torch.tensor([[0, 0, 0, 0, 0, 1], [0, 0, 0, 1, 1, 1], [0, 1, 2, 0, 5, 4], [0, 0, 1, 0, 3, 0]])
+    assert torch.equal(res.indices(), want) and torch.equal(res.values(), torch.ones(6))

@@ -284,6 +284,50 @@ def test_sparse_gumbel_softmax_matches_torch_sparse_softmax():
     torch.testing.assert_close(got.values().cpu(), want.values(), rtol=1e-5, atol=1e-7)
 
 
+def _known_answer_logits():
+    """The reference's own vector for hard=True (tests/test_sparse_gcm.py:795-823)."""
+    idx = torch.tensor([[0, 0, 0, 0, 0, 0, 1, 1], [0, 0, 0, 0, 1, 1, 1, 1],
+                        [0, 1, 2, 2, 0, 5, 4, 4], [0, 0, 1, 0, 0, 3, 0, 3]])
+    values = torch.ones(8) * 1e15
+    values[3] = 0
+    values[-1] = 0
+    want = torch.tensor([[0, 0, 0, 0, 0, 1], [0, 0, 0, 1, 1, 1], [0, 1, 2, 0, 5, 4], [0, 0, 1, 0, 3, 0]])
+    return torch.sparse_coo_tensor(idx, values, size=(2, 2, 100, 100)), want
+
+
+def test_sparse_gumbel_softmax_hard_known_answer():
+    from gcm import util
+    a, want = _known_answer_logits()
+    res = util.sparse_gumbel_softmax(a.to(DEV), 3, hard=True).coalesce()
+    assert torch.equal(res.indices().cpu(), want)
+    assert torch.equal(res.values().cpu(), torch.ones(6))
+
+
+@pytest.mark.parametrize("dim", [2, 1])
+@pytest.mark.parametrize("hard", [False, True])
+def test_sparse_gumbel_softmax_dims_and_hard_vs_oracle(dim, hard):
+    """Rows along the last dim (contiguous in COO order) and along a middle dim (sorted by row key);
+    hard: same surviving entries and values as the oracle's scatter_max loop, gradient included."""
+    from gcm import util
+    torch.manual_seed(3)
+    dense = torch.rand(4, 9, 9) < 0.35
+    idx = dense.nonzero().t().contiguous()
+    vals = torch.randn(idx.shape[1])
+    noise = -torch.empty(idx.shape[1]).exponential_().log()
+    vc = vals.clone().requires_grad_(True)
+    vd = vals.to(DEV).requires_grad_(True)
+    want = osp.sparse_gumbel_softmax(torch.sparse_coo_tensor(idx, vc, size=(4, 9, 9)), dim, tau=0.8,
+                                     noise=noise, hard=hard).coalesce()
+    got = util.sparse_gumbel_softmax(torch.sparse_coo_tensor(idx.to(DEV), vd, size=(4, 9, 9)), dim, tau=0.8,
+                                     noise=noise.to(DEV), hard=hard).coalesce()
+    assert torch.equal(got.indices().cpu(), want.indices())
+    torch.testing.assert_close(got.values().cpu(), want.values(), rtol=1e-5, atol=1e-7)
+    w = torch.randn(want.values().numel())
+    (want.values() * w).sum().backward()
+    (got.values() * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(vd.grad.cpu(), vc.grad, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["g12_sparse_learned", "g12_sparse_learned_win3"])
 def test_sparse_learned_edge_matches_reference(name):
     from gcm.sparse_gcm import SparseGCM
