@@ -54,7 +54,7 @@ template <int FP, int HP, int H2P, bool HIST>
 __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
-    int B, int N, int F, int H1, int H2) {
+    int B, int N, int F, int H1, int H2, int deg_term) {
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
 #pragma unroll
     for (int o = 0; o < H2P; ++o) acc2[c][o] = 0.f;
   float db1 = 0.f, db2 = 0.f;
+  float dc1 = 0.f;   // deg_term: gradient of the folded preprocessor-bias vector (sum_l deg_l G1_l)
 
 #pragma unroll 1
   for (int item = wid; item < items; item += n_waves) {
@@ -158,12 +159,13 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     // the live rows
 #pragma unroll 1
     for (int l = 0;; ++l) {
-      float cf, hv, ax[C1];
+      float cf, hv, ax[C1], dg = 0.f;
       bool is_cur;
       if (!HIST) {
         if (l >= L) break;
         const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
         cf = sv[lay.o_coef + (size_t)b * N + l];
+        if (deg_term) dg = sv[lay.o_deg + (size_t)b * N + l];
         is_cur = l == l_cur;
         hv = row[lane < H1 ? lane : H1 - 1];
 #pragma unroll
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       float g1 = (cf * dagg2 + (is_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
       g1 = lane < H1 ? g1 : 0.f;
       db1 += g1;
+      dc1 = fmaf(dg, g1, dc1);
 #pragma unroll
       for (int h = 0; h < HP; ++h) {
         const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
 
   // ---- one slab per workgroup: the waves add their registers into LDS one after another ----------
   // slab: dW_rel1 [H1*F] | dW_root1 [H1*F] | db1 [H1] | dW_rel2 [H2*H1] | dW_root2 [H2*H1] | db2 [H2]
+  //       (| dc1 [H1] with deg_term)
   extern __shared__ float sSlab[];
-  const int P = 2 * H1 * F + H1 + 2 * H2 * H1 + H2;
+  const int P0 = 2 * H1 * F + H1 + 2 * H2 * H1 + H2;
+  const int P = P0 + (deg_term ? H1 : 0);
   const int o_root1 = H1 * F, o_b1 = 2 * H1 * F, o_rel2 = o_b1 + H1, o_root2 = o_rel2 + H2 * H1;
   const int o_b2 = o_root2 + H2 * H1;
 #pragma unroll 1
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       }
       if (lane < H1) sSlab[o_b1 + lane] = (w ? sSlab[o_b1 + lane] : 0.f) + db1;
       if (lane < H2) sSlab[o_b2 + lane] = (w ? sSlab[o_b2 + lane] : 0.f) + db2;
+      if (deg_term && lane < H1) sSlab[P0 + lane] = (w ? sSlab[P0 + lane] : 0.f) + dc1;
     }
     __syncthreads();
   }
@@ -247,13 +253,14 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
 template <int FP, int HP, int H2P, bool HIST>
 int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, int n_steps, long sb, long sh,
                 const float* w_rel2, const float* w_root2, int act1, int act2,
-                const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2) {
-  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+                const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2,
+                int deg_term = 0) {
+  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   const size_t lds = sizeof(float) * P;
   auto kern = k_bptt_rows<FP, HP, H2P, HIST>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,
-                     act2, lay, slabs, B, N, F, H1, H2);
+                     act2, lay, slabs, B, N, F, H1, H2, deg_term);
   return gcm_launch_status();
 }
 
@@ -271,7 +278,7 @@ extern "C" int gcm_dense_rows_bptt_slabs(int n_steps, int B) {
 }
 
 extern "C" size_t gcm_dense_rows_bptt_workspace_bytes(int n_steps, int B, int F, int H1, int H2) {
-  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  const size_t P = 2 * (size_t)H1 * F + 2 * H1 + 2 * (size_t)H2 * H1 + H2;   // with the dc1 section
   return sizeof(float) * P * (size_t)gcm_dense_rows_bptt_slabs(n_steps, B);
 }
 
@@ -289,7 +296,8 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
   if (!gcm_dense_rows_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
   if (workspace_bytes < gcm_dense_rows_bptt_workspace_bytes(n_steps, B, F, H1, H2))
     return GCM_EWORKSPACE;
-  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  const int deg_term = (has_bias & GCM_GNN_HAS_DEG_TERM) ? 1 : 0;
+  const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
@@ -314,13 +322,12 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
   if (fp == a && hp == b_ && h2p == cc)                                                            \
     rc = gcm_rows::launch_bptt<a, b_, cc, false>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,  \
                                                  gmx_stride_h, w_rel2, w_root2, act1, act2, lay, sl, B, \
-                                                 N, F, H1, H2);
+                                                 N, F, H1, H2, deg_term);
     GCM_RB(32, 32, 32) GCM_RB(32, 32, 64) GCM_RB(32, 64, 32) GCM_RB(32, 64, 64)
     GCM_RB(64, 32, 32) GCM_RB(64, 32, 64) GCM_RB(64, 64, 32) GCM_RB(64, 64, 64)
 #undef GCM_RB
     if (rc) return rc;
   }
-  (void)has_bias;
   return gcm_sum_slabs_acc(slabs, total_slabs, (int)P, g_params_prev, g_params, stream);
 }
 

@@ -7,6 +7,8 @@
 //                         cur, wrapped
 //   coef [B, N]           adj[cur, j_l] for l < L      (compact, ascending j)
 //   rows [B, N, rw]       per live row l < L: h1[j_l] [H1] | agg1[j_l] [F] | x[j_l] [F]; rw = H1 + 2F
+//   deg  [B, N]           row sums of the live adjacency rows, l < L (written only when a Linear
+//                         preprocessor's bias is folded into the step: GCM_GNN_HAS_DEG_TERM)
 //
 // Capacity is N rows per graph (DenseEdge makes every row <= cur live); only L rows are touched.
 #pragma once
@@ -15,7 +17,7 @@
 namespace gcm_rows {
 
 struct SavedLayout {
-  size_t total, o_v, o_hdr, o_coef, o_rows;
+  size_t total, o_v, o_hdr, o_coef, o_rows, o_deg;
   int rw;
 };
 
@@ -28,7 +30,8 @@ static inline SavedLayout make_layout(int B, int N, int F, int H1, int H2) {
   l.o_hdr = l.o_v + pad64((size_t)B * 2 * H1);
   l.o_coef = l.o_hdr + pad64((size_t)B * 4);
   l.o_rows = l.o_coef + pad64((size_t)B * N);
-  l.total = l.o_rows + pad64((size_t)B * N * l.rw);
+  l.o_deg = l.o_rows + pad64((size_t)B * N * l.rw);
+  l.total = l.o_deg + pad64((size_t)B * N);
   return l;
 }
 

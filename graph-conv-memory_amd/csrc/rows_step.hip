@@ -47,8 +47,8 @@ struct Lds {
   static constexpr int HS = HP + 1;    // h1 rows [16][HS]
   static constexpr int X = 128 * XS, ROWS = 16 * RS, AGG = 16 * AS, H1R = 16 * HS;
   // rowcur [128] | coef [128] | live j [128] | v [2 HP] | candidates [4][32] |
-  // agg2 partials (double) [4 waves][4][16] | ints [16]
-  static constexpr int MISC = 3 * 128 + 2 * HP + 128 + 512 + 16;
+  // agg2 partials (double) [4 waves][4][16] | ints [16] | row sums of the group's live rows [16]
+  static constexpr int MISC = 3 * 128 + 2 * HP + 128 + 512 + 16 + 16;
   static constexpr int TOTAL = X + ROWS + AGG + H1R + MISC;
 };
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
     const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
     int64_t* __restrict__ cur_out, Edits E, Gnn2 P, float* __restrict__ mx_out,
     float* __restrict__ saved, SavedLayout lay, uint32_t* __restrict__ flags, int N_, int F_,
-    int H1_, int H2_) {
+    int H1_, int H2_, const float* __restrict__ c1, const float* __restrict__ pe) {
   using L = Lds<FP, HP, H2P>;
   const int N = NX ? NX : N_, F = EXACT ? FP : F_, H1 = EXACT ? HP : H1_, H2 = EXACT ? H2P : H2_;
   constexpr int XS = L::XS, RS = L::RS, AS = L::AS, HS = L::HS;
@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256) void k_step_rows(
   int* sCand = reinterpret_cast<int*>(sV + 2 * HP);   // [4 waves][32]: each wave's own copy
   double* sA2 = reinterpret_cast<double*>(sCand + 128);   // [4 waves][4 kq][16]
   int* sInt = reinterpret_cast<int*>(sA2 + 256);   // [0..1] extra live rows of wave 0 / 1, [3] K-chunk mask
+  float* sDeg = reinterpret_cast<float*>(sInt + 16);
+  // a folded preprocessor / positional encoding (generic shapes only): see gcm_dense_rows_step_fwd
+  const bool fold_deg = !EXACT && c1 != nullptr, fold_pe = !EXACT && pe != nullptr;
 
   const float* ng_in = nodes_in + (size_t)b * N * F;
   const float* ag_in = adj_in + (size_t)b * N * N;
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
   // biases (the packed vector always holds the slots; zeros when a layer has no bias)
   const float bias1 = P.b_rel1[hcol < H1 ? hcol : H1 - 1];
   const float bias2 = P.b_rel2[o2 < H2 ? o2 : H2 - 1];
+  const float c1v = fold_deg ? c1[hcol < H1 ? hcol : H1 - 1] : 0.f;
   // functional state, no overflow (the common case, assumed here): the copy's loads
   constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
   float4 ca[FUNC ? ADJ_PER : 1], cn[FUNC ? NODE_PER : 1];
@@ -304,6 +308,10 @@ __global__ __launch_bounds__(256) void k_step_rows(
     float4 v = make_float4(is_obs ? obv.x : t.x, is_obs ? obv.y : t.y, is_obs ? obv.z : t.z,
                            is_obs ? obv.w : t.w);
     v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    if (fold_pe && ok && ir <= cur) {   // gcm.py:120-131, mode "add": rows up to and including cur
+      const float4 e = *reinterpret_cast<const float4*>(pe + ir * F + xc);
+      v = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
+    }
     *reinterpret_cast<float4*>(sX + (r < N ? ir : r) * XS + xc) = v;
   }
   // ---- row cur after the selectors (temporal.py:72-88, dense.py:16-21), extra live rows ----------
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
       bool colcur = dense && j < cur;   // does (j, cur) get an entry from the selectors?
       for (int k = 1; k <= n_hops; ++k) colcur |= __builtin_amdgcn_readlane(lane_colrow, k) == j;
       unsigned nzbits = 0;
+      float dsum = 0.f;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int c = (c4 + 16 * q) * 4;
@@ -377,12 +386,18 @@ __global__ __launch_bounds__(256) void k_step_rows(
         float2* d = reinterpret_cast<float2*>(sRows + l * RS + c);
         d[0] = make_float2(v.x, v.y);
         d[1] = make_float2(v.z, v.w);
+        dsum += (v.x + v.y) + (v.z + v.w);
         const bool nz = (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
         const unsigned long long bal = __ballot(nz);   // lane = 16 l' + c4: fold the wave's 4 rows
         const unsigned m = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);
         nzbits |= m << (16 * q);
       }
       if (lane == 0 && nzbits) atomicOr(reinterpret_cast<unsigned*>(&sInt[3]), nzbits);
+      if (fold_deg) {   // row sum of live row l: the 16 lanes that hold it
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) dsum += __shfl_xor(dsum, d);
+        if (c4 == 0) sDeg[l] = dsum;
+      }
     }
     STAMP(6);
     __syncthreads();   // #3
@@ -438,7 +453,9 @@ __global__ __launch_bounds__(256) void k_step_rows(
       float hv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t = gcm_act_sel(acc0[r] + acc1[r] + bias1, act1_v);
+        float pre = acc0[r] + acc1[r] + bias1;
+        if (fold_deg) pre = fmaf(sDeg[4 * kq + r], c1v, pre);
+        const float t = gcm_act_sel(pre, act1_v);
         hv[r] = hcol < H1 ? t : 0.f;                 // padding columns stay out of layer 2
         sH1[(4 * kq + r) * HS + hcol] = hv[r];
         a2p = fma((double)cf[r], (double)hv[r], a2p);   // coef is zero beyond the live list
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
             dst[H1 + F + k] = sX[j * XS + k];
           }
         }
+        if (fold_deg && c4 == 0) saved[lay.o_deg + (size_t)b * N + 16 * g + l] = sDeg[l];
       }
     }
     if (g + 1 < n_groups) __syncthreads();   // the images are rewritten by the next group
@@ -545,7 +563,8 @@ template <int FP, int HP, int H2P, int NX, bool EXACT>
 int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* adj_in,
            const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
            int64_t* cur_out, const Edits& E, const Gnn2& P, float* mx, float* saved,
-           const SavedLayout& lay, uint32_t* flags, int B, int N, int F, int H1, int H2) {
+           const SavedLayout& lay, uint32_t* flags, int B, int N, int F, int H1, int H2,
+           const float* c1 = nullptr, const float* pe = nullptr) {
   constexpr size_t lds = sizeof(float) * (size_t)Lds<FP, HP, H2P>::TOTAL;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const bool func = adj_out != adj_in;
@@ -554,12 +573,12 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
   if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
     hipExtLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in, adj_in,
                           count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
-                          N, F, H1, H2);
+                          N, F, H1, H2, c1, pe);
     t_start = t_stop = nullptr;
     return gcm_launch_status();
   }
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in, nodes_out,
-                     adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2);
+                     adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe);
   return gcm_launch_status();
 }
 
@@ -618,14 +637,18 @@ extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, 
   const float* w_rel2 = b1 + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   const float* b2 = w_root2 + (size_t)H2 * H1;
-  gcm_fused::Gnn2 P{w_rel1, (has_bias & 1) ? b1 : nullptr, w_root1, w_rel2,
-                    (has_bias & 2) ? b2 : nullptr, w_root2, act1, act2};
+  // folded preprocessor bias / positional encoding: extra sections behind the GNN parameters
+  const float* c1 = (has_bias & GCM_GNN_HAS_DEG_TERM) ? b2 + H2 : nullptr;
+  const float* pe = (has_bias & GCM_GNN_HAS_PE_TABLE) ? b2 + H2 + (c1 ? H1 : 0) : nullptr;
+  const bool folded = c1 || pe;
+  // the bias slots are always there (zeros when a layer has none): read unconditionally
+  gcm_fused::Gnn2 P{w_rel1, b1, w_root1, w_rel2, b2, w_root2, act1, act2};
   const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
   hipStream_t s = (hipStream_t)stream;
   const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64, h2p = H2 <= 32 ? 32 : 64;
   // tile-exact specialisations of the common shapes
 #define GCM_RX(a, n)                                                                               \
-  if (F == a && H1 == a && H2 == a && N == n)                                                      \
+  if (!folded && F == a && H1 == a && H2 == a && N == n)                                                      \
     return gcm_rows::launch<a, a, a, n, true>(s, obs, nodes_in, adj_in, count_in, nodes_out,       \
                                               adj_out, count_out, cur_out, E, P, mx, saved, lay,   \
                                               flags, B, N, F, H1, H2);
@@ -635,7 +658,7 @@ extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, 
   if (fp == a && hp == b_ && h2p == c)                                                           \
     return gcm_rows::launch<a, b_, c, 0, false>(s, obs, nodes_in, adj_in, count_in, nodes_out,   \
                                                 adj_out, count_out, cur_out, E, P, mx, saved,    \
-                                                lay, flags, B, N, F, H1, H2);
+                                                lay, flags, B, N, F, H1, H2, c1, pe);
   GCM_R(32, 32, 32) GCM_R(32, 32, 64) GCM_R(32, 64, 32) GCM_R(32, 64, 64)
   GCM_R(64, 32, 32) GCM_R(64, 32, 64) GCM_R(64, 64, 32) GCM_R(64, 64, 64)
 #undef GCM_R

@@ -228,12 +228,14 @@ struct RowsHolder {
   };
   std::vector<Rec> recs;
   int N, F, H1, H2, has_bias, act1, act2;
-  int64_t P;
+  int64_t P;           // floats the backward kernel writes: GNN gradient (| d c1 with the deg term)
+  int64_t total = 0;   // length of the packed vector (>= P: constant sections may follow)
   at::Tensor zero_p;   // the defined (zero) gradient the head step of a chain returns
 
   RowsHolder(int N_, int F_, int H1_, int H2_, int has_bias_, int act1_, int act2_)
       : N(N_), F(F_), H1(H1_), H2(H2_), has_bias(has_bias_), act1(act1_), act2(act2_) {
-    P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2);
+    P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2) + ((has_bias & GCM_GNN_HAS_DEG_TERM) ? H1 : 0);
+    total = P;
   }
 
   int64_t pending() const { return (int64_t)recs.size(); }
@@ -260,7 +262,9 @@ struct RowsHolder {
       const int n = (int)(j - i), B = (int)recs[i].B;
       const size_t ws_bytes = gcm_dense_rows_bptt_workspace_bytes(n, B, F, H1, H2);
       at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
-      at::Tensor out = at::empty({P}, packed.options());
+      // the kernel writes the first P floats; constant sections behind them get a zero gradient
+      at::Tensor out = packed.numel() > P ? at::zeros({packed.numel()}, packed.options())
+                                          : at::empty({P}, packed.options());
       const int rc = gcm_dense_rows_bptt(
           sv.data(), gm.data(), n, (long)recs[i].sb, (long)recs[i].sh, packed.data_ptr<float>(),
           has_bias, act1, act2, prev.defined() ? prev.data_ptr<float>() : nullptr,
@@ -297,7 +301,7 @@ struct RowsStepFn : public torch::autograd::Function<RowsStepFn> {
       holder->recs.push_back({buf, g, g.size(0), g.stride(0), g.stride(1)});
     }
     if (is_head) {   // a defined gradient so that the gate is certain to run
-      if (!holder->zero_p.defined()) holder->zero_p = at::zeros({holder->P}, grads[0].defined()
+      if (!holder->zero_p.defined()) holder->zero_p = at::zeros({holder->total}, grads[0].defined()
                                                                    ? grads[0].options().dtype(at::kFloat)
                                                                    : ctx->saved_data["buf"].toTensor().options());
       g_params = holder->zero_p;
@@ -327,6 +331,14 @@ std::vector<at::Tensor> rows_step(const at::Tensor& obs, const at::Tensor& nodes
                   count_in.size(0) == B && obs.size(1) == F,
               "rows_step: hidden state and observation shapes disagree");
   const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad() && holder_handle != 0;
+  if (need_bwd) {
+    RowsHolder* holder = reinterpret_cast<RowsHolder*>(holder_handle);
+    TORCH_CHECK(packed.numel() >= holder->P, "rows_step: packed parameter vector too short");
+    if (holder->total != packed.numel()) {
+      holder->total = packed.numel();
+      holder->zero_p = at::Tensor();
+    }
+  }
   size_t lay[6];
   check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
   at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());

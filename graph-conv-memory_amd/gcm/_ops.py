@@ -627,6 +627,10 @@ class StepConfig:
             and lib.gcm_dense_rows_supported(N, F, H1, H2)
             and _ext.module() is not None and hasattr(_ext.module(), "rows_step"))
 
+    # (Linear preprocessor | None, PositionalEncoding in "add" mode | None) folded into the live-row
+    # step, or None (gcm.py:_fold_config)
+    fold = None
+
     # -- DenseGCM + LearnedEdge (csrc/learned_step.hip) ----------------------------------------
     learned_sel = None          # the LearnedEdge module when this config is the fused learned step
 

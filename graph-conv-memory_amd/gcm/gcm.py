@@ -114,6 +114,7 @@ class DenseGCM(torch.nn.Module):
         # every other case falls back to functional semantics.
         self.donate_state = donate_state
         self._plan_cache = None
+        self._fold = None     # set by _structure(): what the live-row step absorbs besides the GNN
         self._token = object()   # identifies hidden states produced by this module (_gcm_link)
         self._cfg_cache = {}
         self._cfg_last = None
@@ -216,10 +217,37 @@ class DenseGCM(torch.nn.Module):
         from .edge_selectors.dense import DenseEdge
         from .edge_selectors.distance import Distance
 
-        def analyse():
-            if (not self.fused or self.pooled or self.preprocessor is not None
-                    or self.positional_encoder is not None or self.aux_edge_selectors is not None):
+        def foldable():
+            """What sits between the selectors and the GNN (gcm.py:290-306), when the live-row step
+            can absorb it: a Linear preprocessor (folded into the layer-1 weights, its bias through
+            the row sums of the adjacency), index-writing aux selectors, and - as in the reference only
+            when aux selectors exist - the PositionalEncoding ("add": a table added to the rows <= cur
+            of the GNN's input; "cat": seen by the aux selectors only, which do not read it)."""
+            pre = self.preprocessor
+            if isinstance(pre, torch.nn.Sequential) and len(pre) == 1:
+                pre = pre[0]
+            if pre is not None and type(pre) is not torch.nn.Linear:
                 return None
+            aux = self.aux_edge_selectors
+            if aux is not None and not (isinstance(aux, DenseEdge) or
+                                        (isinstance(aux, TemporalBackedge) and not aux.learned)):
+                return None
+            pe = self.positional_encoder if aux is not None else None   # gcm.py:294-301
+            if pe is not None and type(pe) is not PositionalEncoding:
+                return None
+            if pe is not None and pe.mode == "add" and pre is not None:
+                return None
+            return {"pre": pre, "aux": aux, "pe": pe}
+
+        def analyse():
+            if not self.fused or self.pooled:
+                return None
+            self._fold = None
+            if (self.preprocessor is not None or self.positional_encoder is not None
+                    or self.aux_edge_selectors is not None):
+                self._fold = foldable()
+                if self._fold is None:
+                    return None
             g = self.gnn
             if not isinstance(g, G.Sequential) or len(g.arg_names) < 2:
                 return None
@@ -243,7 +271,8 @@ class DenseGCM(torch.nn.Module):
             from .edge_selectors.learned import LearnedEdge
             if isinstance(sel, LearnedEdge):
                 # the fused learned step (csrc/learned_step.hip): default edge network only
-                if sel.deterministic or _ops.default_edge_network(sel.edge_network) is None:
+                if (sel.deterministic or _ops.default_edge_network(sel.edge_network) is None
+                        or self._fold is not None):
                     return None
                 return convs, tuple(acts), [sel]
             if sel is None:
@@ -259,6 +288,11 @@ class DenseGCM(torch.nn.Module):
                     mods.append(mod)
             else:
                 return None
+            if self._fold is not None:
+                if any(isinstance(m, Distance) for m in mods):    # (they would need the dX path)
+                    return None
+                if self._fold["aux"] is not None:
+                    mods = mods + [self._fold["aux"]]
             return convs, tuple(acts), mods
 
         self._plan_cache = (analyse(),)
@@ -293,6 +327,8 @@ class DenseGCM(torch.nn.Module):
                 cfg.convs = convs
                 cfg.lins = (convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel, convs[1].lin_root)
                 cfg.set_learned(sel, net)
+        elif self._fold is not None:
+            cfg = self._fold_config(convs, acts, mods, N, F, H1, H2, nodes.device)
         elif convs[0].in_channels == F and _ops.gnn2_supported(N, F, H1, H2):
             descs = [m.native_desc(F) if isinstance(m, Distance) else m.native_desc() for m in mods]
             if all(d is not None for d in descs):
@@ -308,6 +344,37 @@ class DenseGCM(torch.nn.Module):
         if cfg is not False:
             self._cfg_last = (nodes.shape[1], F, nodes.device, cfg)
         return cfg if cfg is not False else None
+
+    def _fold_config(self, convs, acts, mods, N, F, H1, H2, device):
+        """StepConfig of a module with a folded preprocessor / positional encoding / aux selectors
+        (live-row step only), or False."""
+        fold = self._fold
+        pre, pe = fold["pre"], fold["pe"]
+        Fg = pre.out_features if pre is not None else F
+        if (pre is not None and pre.in_features != F) or convs[0].in_channels != Fg:
+            return False
+        if pe is not None and not hasattr(pe, "pe"):      # the lazily built table / reproject layer
+            pe.run_once(torch.empty(0, Fg, device=device))
+        pe_add = pe is not None and pe.mode == "add"
+        if pe_add and (pe.pe.shape[0] < N or pe.pe.shape[1] < F):
+            return False
+        descs = [m.native_desc() for m in mods]
+        if any(d is None for d in descs):
+            return False
+        has_bias = (1 if convs[0].lin_rel.bias is not None else 0) | \
+                   (2 if convs[1].lin_rel.bias is not None else 0)
+        if pre is not None and pre.bias is not None:
+            has_bias |= _hip.GNN_HAS_DEG_TERM
+        if pe_add:
+            has_bias |= _hip.GNN_HAS_PE_TABLE
+        cfg = _ops.StepConfig(descs, acts, has_bias, N, F, H1, H2, device)
+        if not cfg.rows_ok:
+            return False
+        cfg.convs = convs
+        cfg.desc_sources = [None] * len(descs)
+        cfg.lins = (convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel, convs[1].lin_root)
+        cfg.fold = (pre, pe if pe_add else None)
+        return cfg
 
     def _packed_params(self, cfg, head=False):
         """The six GNN tensors as one flat vector (layout of include/gcm_hip.h "packed parameter
@@ -325,6 +392,9 @@ class DenseGCM(torch.nn.Module):
             l0, _, n0, l1, _, n1, l2 = cfg.mlp_mods
             tensors = tensors + (l0.weight, l0.bias, n0.weight, n0.bias, l1.weight, l1.bias, n1.weight,
                                  n1.bias, l2.weight, l2.bias)
+        fold = cfg.fold
+        if fold is not None and fold[0] is not None:
+            tensors = tensors + (fold[0]._parameters["weight"], fold[0]._parameters["bias"])
         cache = self._packed_cache
         if cache is not None and not head and not cache[2][0] and cache[0] == torch.is_grad_enabled():
             # valid while the very same tensor objects have not been written to (optimizer steps
@@ -348,6 +418,8 @@ class DenseGCM(torch.nn.Module):
         dev = tensors[0].device
         parts = [t.reshape(-1) if t is not None else torch.zeros(n, device=dev)
                  for t, n in zip(tensors, sizes)]
+        if fold is not None:
+            parts = self._folded_parts(cfg, tensors, parts)
         packed = torch.cat(parts)
         used = [False]
         gated = holder = rows = None
@@ -364,6 +436,26 @@ class DenseGCM(torch.nn.Module):
                               [(t, t._version if t is not None else 0) for t in tensors], gated, holder,
                               rows)
         return packed
+
+    @staticmethod
+    def _folded_parts(cfg, tensors, parts):
+        """Packed vector of a folded configuration (include/gcm_hip.h, "Folded node transforms"):
+        layer 1 composed with the Linear preprocessor x' = W_p x + b_p -
+            W_rel1 W_p | W_root1 W_p | b1 + W_root1 b_p | layer 2 | c1 = W_rel1 b_p | pe table
+        built with torch ops, so autograd carries the kernel's gradient back to W_p, b_p and the
+        original layer-1 tensors."""
+        pre, pe = cfg.fold
+        if pre is not None:
+            w_rel, w_root, b1 = tensors[0], tensors[1], tensors[2]
+            w_p, b_p = tensors[-2], tensors[-1]
+            parts[0] = (w_rel @ w_p).reshape(-1)
+            parts[1] = (w_root @ w_p).reshape(-1)
+            if b_p is not None:
+                parts[2] = parts[2] + w_root @ b_p
+                parts.append(w_rel @ b_p)
+        if pe is not None:
+            parts.append(pe.pe[: cfg.N, : cfg.F].reshape(-1))
+        return parts
 
     def _forward_rows(self, x, hidden, cfg, flags, link):
         """The live-row step (csrc/rows_step.hip): one kernel forward, no kernel backward (the
@@ -480,8 +572,8 @@ class DenseGCM(torch.nn.Module):
             hidden = self.get_initial_hidden_state(obs[0])
         nodes, adj, weights, num_nodes = hidden
         cfg = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
-        if cfg is not None and cfg.learned_sel is not None:
-            cfg = None                    # LearnedEdge: the per-step kernels, in a loop
+        if cfg is not None and (cfg.learned_sel is not None or cfg.fold is not None):
+            cfg = None                    # LearnedEdge / folded transforms: the per-step kernels, in a loop
         if cfg is None:
             outs = []
             for t in range(obs.shape[0]):
@@ -522,7 +614,7 @@ class DenseGCM(torch.nn.Module):
             no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
             if cfg.rows_ok and no_dx:
                 return self._forward_rows(x, hidden, cfg, link[3], link)
-            if cfg.learned_sel is None:
+            if cfg.learned_sel is None and cfg.fold is None:
                 return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, link[3], link)
             if no_dx:
                 return self._forward_learned(x, hidden, cfg, link[3], link)
@@ -556,7 +648,7 @@ class DenseGCM(torch.nn.Module):
             no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
             if plan.rows_ok and no_dx:
                 return self._forward_rows(x, hidden, plan, flags, None)
-            if plan.learned_sel is None:
+            if plan.learned_sel is None and plan.fold is None:
                 return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
             if no_dx:
                 return self._forward_learned(x, hidden, plan, flags, None)

@@ -404,7 +404,20 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
  * saved (may be NULL: inference): receives the record the time-parallel backward reads, laid out
  * by gcm_dense_rows_layout (float offsets {total, v, hdr, coef, rows} and the row width); mx must
  * then point at saved (the record starts with the [B,H2] belief states).
- * Shapes: N <= 128, N % 4 == 0, F % 4 == 0, F, H1, H2 <= 64 (gcm_dense_rows_supported). */
+ * Shapes: N <= 128, N % 4 == 0, F % 4 == 0, F, H1, H2 <= 64 (gcm_dense_rows_supported).
+ *
+ * Folded node transforms (gcm.py:290-306: what sits between the selectors and the GNN).  A Linear
+ * preprocessor x' = W_p x + b_p, applied by the reference to all N rows every step, commutes with
+ * the aggregation: lin_rel1(adj @ x') = (W_rel1 W_p)(adj @ x) + rowsum(adj) * (W_rel1 b_p).  The caller
+ * passes W_rel1 W_p / W_root1 W_p / b1 + W_root1 b_p in the layer-1 slots (F = the raw observation width)
+ * and, with GCM_GNN_HAS_DEG_TERM set in has_bias, the vector c1 = W_rel1 b_p [H1] directly behind
+ * the packed GNN parameters; the kernel adds rowsum(adj[j,:]) * c1 on every live row and records the
+ * row sums, and gcm_dense_rows_bptt returns d c1 behind the GNN gradient (param_count + H1 floats).
+ * GCM_GNN_HAS_PE_TABLE: a positional-encoding table pe [N, F] follows (behind c1 when both are
+ * set); rows <= cur of the node image get pe[row] added before the GNN (PositionalEncoding mode
+ * "add", gcm.py:120-131); the stored nodes stay raw. */
+#define GCM_GNN_HAS_DEG_TERM 4
+#define GCM_GNN_HAS_PE_TABLE 8
 int gcm_dense_rows_supported(int N, int F, int H1, int H2);
 int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t* out6);
 int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, const float* adj_in,

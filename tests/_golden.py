@@ -66,3 +66,24 @@ def fp64_bound(ref, obs, hidden, out32, **kw):
         out64, _ = od.dense_rollout(obs.double(), h64, ref64, **kw)
     err32 = float((out32.detach().double() - out64).abs().max())
     return out64, max(2e-6, 3.0 * err32)
+
+
+# ---- G15 (folded preprocessor / aux selectors / positional encoding): how each fixture's module
+# was put together in tests/golden/make_golden.py -----------------------------------------------
+FOLD_SPECS = {
+    # name: (selector, aux selector): ("temporal", hops, direction) | ("dense",) | None
+    "g15_fold_pre": (("temporal", [1, 2], "forward"), None),
+    "g15_fold_pre_nobias": (("dense",), None),
+    "g15_fold_pre_aux_cat": (("temporal", [1], "forward"), ("temporal", [3], "both")),
+    "g15_fold_pe_add": (("temporal", [1], "forward"), ("temporal", [2], "forward")),
+    "g15_fold_pre_exact": (("temporal", [1, 2, 4], "forward"), None),
+    "g15_fold_pe_add_exact": (("temporal", [1, 2, 4], "forward"), ("dense",)),
+}
+
+
+def fold_selector(spec, temporal_cls, dense_cls):
+    if spec is None:
+        return None
+    if spec[0] == "dense":
+        return dense_cls()
+    return temporal_cls(spec[1], direction=spec[2])

@@ -357,6 +357,34 @@ def main():
     enc1 = pe(torch.zeros(2, 7, 5), torch.tensor([1, 8]))
     save("g10_posenc_table", dict(N=7, F=5), enc0=enc0, enc1=enc1, pe=pe.pe)
 
+    # ---- G15: what the live-row step folds in at shapes its kernels take:
+    # a Linear preprocessor (ray_gcm.py:117,131-135), index-writing aux selectors, PositionalEncoding
+    # ("add" reaches the GNN through the reference's in-place write, gcm.py:131,294-301; "cat" is seen
+    # by the aux selectors only).  Every run crosses the overflow. ---------------------------------
+    specs15 = [
+        # name, B, N, F_obs, F_gnn, H, T, selector, aux, pe mode, preprocessor bias
+        ("g15_fold_pre", 3, 16, 8, 12, 8, 20, lambda: TemporalBackedge([1, 2]), None, None, True),
+        ("g15_fold_pre_nobias", 2, 16, 8, 8, 12, 18, lambda: DenseEdge(), None, None, False),
+        ("g15_fold_pre_aux_cat", 3, 16, 8, 12, 8, 20, lambda: TemporalBackedge([1]),
+         lambda: TemporalBackedge([3], direction="both"), "cat", True),
+        ("g15_fold_pe_add", 3, 16, 8, 8, 8, 20, lambda: TemporalBackedge([1]), lambda: TemporalBackedge([2]), "add", None),
+        ("g15_fold_pre_exact", 2, 32, 32, 32, 32, 40, lambda: TemporalBackedge([1, 2, 4]), None, None, True),
+        ("g15_fold_pe_add_exact", 2, 32, 32, 32, 32, 40, lambda: TemporalBackedge([1, 2, 4]), lambda: DenseEdge(), "add", None),
+    ]
+    for name, B, N, F, Fg, H, T, mk_sel, mk_aux, mode, pre_bias in specs15:
+        torch.manual_seed(15)
+        gen = torch.Generator().manual_seed(16)
+        gnn = od.canonical_gnn(Fg, H)
+        pre = torch.nn.Linear(F, Fg, bias=pre_bias) if pre_bias is not None else None
+        pe = PositionalEncoding(max_len=N, mode=mode, cat_dim=2) if mode else None
+        holder = torch.nn.ModuleDict({k: v for k, v in (("pre", pre), ("pe", pe)) if v is not None})
+        m = DenseGCM(gnn, preprocessor=pre, edge_selectors=mk_sel(), aux_edge_selectors=mk_aux() if mk_aux else None,
+                     positional_encoder=pe, graph_size=N)
+        obs = torch.rand(T, B, F, generator=gen)
+        torch.manual_seed(17)           # the lazily created reproject layer (mode="cat")
+        run_dense(name, m, obs, None, gnn, sel_module=holder,
+                  meta=dict(B=B, N=N, F=F, Fg=Fg, H=H, T=T, mode=mode, cat_dim=2, pre_bias=pre_bias))
+
     # ---- G11: pack_hidden / unpack_hidden --------------------
     gen = torch.Generator().manual_seed(11)
     B, N, F, max_edges = 4, 9, 3, 12

@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from _golden import Fixture, oracle_selector
+from _golden import Fixture, oracle_selector, FOLD_SPECS, fold_selector
 from oracle import dense as od, pyg, sparse as osp
 
 DENSE = ["g1_temporal_h1", "g2_temporal_h124_both", "g1b_cfg1", "g3_euclid", "g3_euclid_mixed",
@@ -196,6 +196,45 @@ def test_posenc_oracle_matches_reference(mode):
     assert torch.equal(hidden[0], fx["hT_nodes"]) and torch.equal(hidden[1], fx["hT_adj"])
     torch.testing.assert_close(mxs, fx["mx"], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", sorted(FOLD_SPECS))
+def test_fold_fixtures_oracle_matches_reference(name):
+    """G15: Linear preprocessor / aux selectors / PositionalEncoding between selectors and GNN."""
+    fx = Fixture(name)
+    m = fx.meta
+    gnn = od.canonical_gnn(m["Fg"], m["H"])
+    gnn.load_state_dict(fx.group("param:"))
+    sp = fx.group("sel_param:")
+    pre = None
+    if m["pre_bias"] is not None:
+        pre = torch.nn.Linear(m["F"], m["Fg"], bias=m["pre_bias"])
+        pre.load_state_dict({k[len("pre."):]: v for k, v in sp.items() if k.startswith("pre.")})
+    pe = None
+    if m["mode"]:
+        reproject = None
+        if m["mode"] == "cat":
+            reproject = torch.nn.Linear(m["Fg"], m["Fg"] - m["cat_dim"])
+            reproject.load_state_dict({k[len("pe.reproject."):]: v for k, v in sp.items()
+                                       if k.startswith("pe.reproject.")})
+        pe = od.PositionalEncoding(max_len=m["N"], mode=m["mode"], cat_dim=m["cat_dim"], reproject=reproject)
+    sel, aux = (fold_selector(s, od.TemporalBackedge, od.DenseEdge) for s in FOLD_SPECS[name])
+    obs = fx["obs"].clone().requires_grad_(True)
+    hidden, mxs = None, []
+    for t in range(m["T"]):
+        mx, hidden = od.dense_step(obs[t], hidden, gnn, graph_size=m["N"], edge_selectors=sel,
+                                   preprocessor=pre, aux_edge_selectors=aux, positional_encoder=pe)
+        mxs.append(mx)
+    mxs = torch.stack(mxs)
+    mxs.mean().backward()
+    assert torch.equal(hidden[0], fx["hT_nodes"]) and torch.equal(hidden[1], fx["hT_adj"])
+    torch.testing.assert_close(mxs, fx["mx"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(obs.grad, fx["grad_obs"], rtol=1e-5, atol=1e-7)
+    for k, p in gnn.named_parameters():
+        torch.testing.assert_close(p.grad, fx["grad:" + k], rtol=1e-5, atol=1e-7)
+    if pre is not None:
+        for k, p in pre.named_parameters():
+            torch.testing.assert_close(p.grad, fx["sel_grad:pre." + k], rtol=1e-5, atol=1e-7)
 
 
 def test_posenc_table_oracle():
