@@ -470,6 +470,86 @@ extern "C" int gcm_coo_merge_segments(const int64_t* old_idx, const int64_t* new
   return gcm_launch_status();
 }
 
+// ---------------------------------------------------------------------------
+// CSC view of a batched CSR edge list without a sort (the backward's transpose gather).
+// The flat edge list of SparseGCM is grouped by graph and an edge never leaves its graph, so the
+// CSC entries of graph b's sources occupy exactly graph b's own slice [row_ptr[n0], row_ptr[n1]) of
+// the edge array: a counting sort per graph, no global scan.  ONE WAVE owns a graph - counters of its
+// (local) sources in LDS, edges visited in CSR order 64 at a time - so the result does not depend on
+// the timing of other waves; entries of a column keep ascending sink order except among the edges of
+// one 64-edge chunk that share a source, where the LDS unit's fixed lane order decides.
+// ---------------------------------------------------------------------------
+#define GCM_CSC_WAVES 4
+__global__ __launch_bounds__(64 * GCM_CSC_WAVES) void k_csc_batched(
+    const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ col,
+    const int64_t* __restrict__ dst, const int64_t* __restrict__ node_off,
+    int64_t* __restrict__ col_ptr, int64_t* __restrict__ rows, int64_t* __restrict__ perm, int B,
+    int64_t M, int n_cap) {
+  extern __shared__ int s_cnt[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * GCM_CSC_WAVES + wave;
+  if (b >= B) return;   // (no workgroup barrier below: waves are independent)
+  int* cnt = s_cnt + (size_t)wave * n_cap;
+  const int64_t n0 = node_off[b], n1 = node_off[b + 1];
+  const int n = min((int)(n1 - n0), n_cap);
+  const int64_t e0 = row_ptr[n0], e1 = n > 0 ? row_ptr[n1] : e0;
+  // (a source outside the graph's node range cannot come from SparseGCM; clamped, never out of bounds)
+  auto local = [&](int64_t e) { const int64_t j = col[e] - n0; return (int)(j < 0 ? 0 : (j >= n ? n - 1 : j)); };
+  for (int j = lane; j < n; j += 64) cnt[j] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[local(e)], 1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // exclusive scan of the counters -> column starts (global positions), 64 at a time
+  int carry = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const int c = j < n ? cnt[j] : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    const int start = carry + incl - c;
+    if (j < n) {
+      cnt[j] = start;
+      col_ptr[n0 + j] = e0 + start;
+    }
+    carry += __shfl(incl, 63);
+  }
+  if (b == B - 1 && lane == 0) col_ptr[M] = e1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // fill, in CSR order
+  for (int64_t base = e0; base < e1; base += 64) {
+    const int64_t e = base + lane;
+    if (e < e1) {
+      const int pos = atomicAdd(&cnt[local(e)], 1);
+      rows[e0 + pos] = dst[e];
+      perm[e0 + pos] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int gcm_csc_from_csr_batched(const int64_t* row_ptr, const int64_t* col,
+                                        const int64_t* dst, const int64_t* node_off,
+                                        int64_t* col_ptr, int64_t* rows, int64_t* perm, int B,
+                                        int64_t M, int64_t E, int max_nodes_per_graph,
+                                        gcm_stream_t stream) {
+  GCM_REQUIRE(row_ptr && node_off && col_ptr && B > 0 && M >= 0 && E >= 0 && max_nodes_per_graph > 0);
+  GCM_REQUIRE((col && dst && rows && perm) || E == 0);
+  if (max_nodes_per_graph > 8192) return GCM_EUNSUPPORTED;
+  const size_t lds = sizeof(int) * (size_t)max_nodes_per_graph * GCM_CSC_WAVES;
+  gcm_allow_dynamic_lds((const void*)k_csc_batched, lds);
+  hipLaunchKernelGGL(k_csc_batched, dim3((unsigned)((B + GCM_CSC_WAVES - 1) / GCM_CSC_WAVES)),
+                     dim3(64 * GCM_CSC_WAVES), lds, (hipStream_t)stream, row_ptr, col, dst, node_off, col_ptr,
+                     rows, perm, B, M, max_nodes_per_graph);
+  return gcm_launch_status();
+}
+
 extern "C" int gcm_ptr_from_sorted(const int64_t* keys, int64_t* ptr, int64_t E, int64_t M,
                                    gcm_stream_t stream) {
   GCM_REQUIRE(ptr && E >= 0 && M >= 0 && (keys || E == 0));

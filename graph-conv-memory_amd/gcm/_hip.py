@@ -48,6 +48,7 @@ PROTOTYPES = {
     "gcm_sparse_flatten_bwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
     "gcm_sparse_edges_to_csr": (_I, [_P] * 5 + [_L, _L, _I, _P]),
     "gcm_ptr_from_sorted": (_I, [_P, _P, _L, _L, _P]),
+    "gcm_csc_from_csr_batched": (_I, [_P] * 7 + [_I, _L, _L, _I, _P]),
     "gcm_coo_merge_segments": (_I, [_P] * 10 + [_L, _L, _I, _P]),
     "gcm_khop_mask": (_I, [_P] * 5 + [_I, _P, _P, _L, _I, _I, _P]),
     "gcm_sparse_extract_fwd": (_I, [_P] * 6 + [_I, _I, _I, _L, _P]),

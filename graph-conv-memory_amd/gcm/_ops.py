@@ -391,10 +391,13 @@ class GraphIndex:
     built lazily, CSC by source (backward gather).  Attached to the edge_index tensor handed
     to the GNN (attribute `gcm_graph`) so GraphConv layers share it."""
 
-    def __init__(self, edge_index, row_ptr, M, csr_perm=None, mask=None):
+    def __init__(self, edge_index, row_ptr, M, csr_perm=None, mask=None, batches=None):
         self.edge_index = edge_index            # [2, E] (source, sink); CSR order unless csr_perm
         self.csr_perm = csr_perm                # positions of the CSR entries in edge_index
         self.row_ptr, self.M, self.mask = row_ptr, M, mask
+        # (node_off [B+1], B, max nodes per graph) when the list is grouped by graph and no edge
+        # leaves its graph (SparseGCM's flat list): the CSC view is then built without a sort
+        self.batches = batches
         src = edge_index[0] if csr_perm is None else edge_index[0][csr_perm]
         self.col = src.contiguous()
         self._csc = None
@@ -410,9 +413,20 @@ class GraphIndex:
     def csc(self):
         """(col_ptr [M+1], rows [E], perm [E]): entry k of the CSC is CSR entry perm[k]."""
         if self._csc is None:
-            src_sorted, perm = torch.sort(self.col, stable=True)
-            rows = self.dst_csr()[perm].contiguous()
-            self._csc = (ptr_from_sorted(src_sorted, self.M), rows, perm.contiguous())
+            bt = self.batches
+            if bt is not None and self.csr_perm is None and bt[2] <= 8192:
+                E, dev = self.E, self.col.device
+                col_ptr = torch.empty(self.M + 1, dtype=_i64, device=dev)
+                rows = torch.empty(E, dtype=_i64, device=dev)
+                perm = torch.empty(E, dtype=_i64, device=dev)
+                _call("gcm_csc_from_csr_batched", _hip.ptr(self.row_ptr), _hip.ptr(self.col),
+                      _hip.ptr(self.dst_csr()), _hip.ptr(bt[0]), _hip.ptr(col_ptr), _hip.ptr(rows),
+                      _hip.ptr(perm), bt[1], self.M, E, bt[2], _hip.stream())
+                self._csc = (col_ptr, rows, perm)
+            else:
+                src_sorted, perm = torch.sort(self.col, stable=True)
+                rows = self.dst_csr()[perm].contiguous()
+                self._csc = (ptr_from_sorted(src_sorted, self.M), rows, perm.contiguous())
         return self._csc
 
     @staticmethod
@@ -422,8 +436,9 @@ class GraphIndex:
         return GraphIndex(edge_index, ptr_from_sorted(dst_sorted, M), M, csr_perm=perm)
 
 
-def sparse_edges_to_csr(coo, node_off, M, B, flags):
-    """coo [3,E] sorted (batch, sink, source) -> (edge_index [2,E] (source, sink), GraphIndex)."""
+def sparse_edges_to_csr(coo, node_off, M, B, flags, n_cap=None):
+    """coo [3,E] sorted (batch, sink, source) -> (edge_index [2,E] (source, sink), GraphIndex).
+    n_cap: the graph size (bound on the nodes of one graph), when known."""
     coo = coo.contiguous()
     _hip.on_device(coo, node_off, flags)
     E = coo.shape[1]
@@ -431,7 +446,8 @@ def sparse_edges_to_csr(coo, node_off, M, B, flags):
     row_ptr = torch.empty(M + 1, dtype=_i64, device=coo.device)
     _call("gcm_sparse_edges_to_csr", _hip.ptr(coo), _hip.ptr(node_off), _hip.ptr(edge_index),
           _hip.ptr(row_ptr), _hip.ptr(flags), E, M, B, _hip.stream())
-    return edge_index, GraphIndex(edge_index, row_ptr, M)
+    return edge_index, GraphIndex(edge_index, row_ptr, M,
+                                  batches=None if n_cap is None else (node_off, B, int(n_cap)))
 
 
 def khop_mask(graph, node_off, T, taus, hops, B, t_pad):

@@ -140,7 +140,7 @@ class SparseGCM(torch.nn.Module):
         adj = torch.sparse_coo_tensor(adj.indices(), v, size=adj.shape, is_coalesced=True)
 
         flat_nodes = _ops.sparse_flatten(dirty_nodes, T, taus, node_off, M)
-        edges, graph = _ops.sparse_edges_to_csr(adj.indices(), node_off, M, B, flags)
+        edges, graph = _ops.sparse_edges_to_csr(adj.indices(), node_off, M, B, flags, n_cap=N)
         weights = v
         # (torch_geometric.utils.coalesce(reduce="mean") at sparse_gcm.py:172-175 only
         #  reorders here: the COO list is already duplicate free)
@@ -149,7 +149,7 @@ class SparseGCM(torch.nn.Module):
             node_feats = self.gnn(flat_nodes, edges, weights)
         elif self._native_gnn():
             mask = _ops.khop_mask(graph, node_off, T, taus, self.max_hops, B, t_pad)
-            sub = _ops.GraphIndex(edges, graph.row_ptr, M, mask=mask)
+            sub = _ops.GraphIndex(edges, graph.row_ptr, M, mask=mask, batches=graph.batches)
             edges.gcm_graph = sub
             node_feats = self.gnn(flat_nodes, edges, weights)
         else:

@@ -428,6 +428,18 @@ int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, const float
                             float* saved, uint32_t* flags, int B, int N, int F, int H1, int H2,
                             gcm_stream_t stream);
 
+/* CSC (by source) view of a CSR (by sink) edge list that is grouped by graph - what the backward's
+ * transpose gather reads - without a sort (replaces the sort-based coalesce of the reference's
+ * autograd path, torch_geometric GraphConv's scatter).  node_off [B+1]: the graphs' node ranges;
+ * every edge stays inside its graph (SparseGCM's flat list, sparse_gcm.py:165-170); dst [E]: sink
+ * of each CSR entry.  Out: col_ptr [M+1], rows [E] (sink of each CSC entry), perm [E] (its CSR
+ * position).  One wave per graph with its source counters in LDS: GCM_EUNSUPPORTED when
+ * max_nodes_per_graph > 8192 (the caller sorts instead). */
+int gcm_csc_from_csr_batched(const int64_t* row_ptr, const int64_t* col, const int64_t* dst,
+                             const int64_t* node_off, int64_t* col_ptr, int64_t* rows,
+                             int64_t* perm, int B, int64_t M, int64_t E, int max_nodes_per_graph,
+                             gcm_stream_t stream);
+
 /* Measurement aid (bench.py): the NEXT gcm_dense_rows_step_fwd launch of the calling thread is
  * bracketed by the two hipEvent_t given here, recorded by the dispatch itself
  * (hipExtLaunchKernelGGL start / stop events: the kernel's own begin / end timestamps, what

@@ -71,6 +71,32 @@ def test_temporal_edge_matches_oracle():
         assert tuple(got.shape) == tuple(want.shape)
 
 
+@pytest.mark.parametrize("B,N,p", [(5, 16, 0.5), (3, 200, 0.05), (7, 64, 1.0), (4, 33, 0.0), (2, 700, 0.02)])
+def test_csc_view_without_sort(B, N, p):
+    """The backward's CSC view (one wave per graph, LDS counters) against a stable sort by source."""
+    from gcm import _ops
+    torch.manual_seed(B * N)
+    counts = torch.randint(0, N + 1, (B,))
+    counts[0] = N
+    coo = []
+    for b in range(B):
+        n = int(counts[b])
+        m = torch.tril(torch.rand(n, n) < p, diagonal=-1)
+        snk, src = m.nonzero(as_tuple=True)
+        coo.append(torch.stack([torch.full_like(snk, b), snk, src]))
+    coo = torch.cat(coo, dim=1).to(DEV)
+    node_off = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).to(DEV)
+    M = int(node_off[-1])
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    edges, graph = _ops.sparse_edges_to_csr(coo, node_off, M, B, flags, n_cap=N)
+    col_ptr, rows, perm = graph.csc()
+    plain = _ops.GraphIndex(edges, graph.row_ptr, M)            # the sort-based construction
+    want_ptr, want_rows, want_perm = plain.csc()
+    assert torch.equal(col_ptr, want_ptr)
+    assert torch.equal(rows, want_rows) and torch.equal(perm, want_perm)
+    assert int(flags.item()) == 0
+
+
 def test_khop_mask_matches_k_hop_subgraph():
     from gcm import _ops
     torch.manual_seed(1)
