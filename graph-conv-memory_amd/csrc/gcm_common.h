@@ -19,6 +19,8 @@ static inline int gcm_launch_status() {
 // kernel ON A DEVICE: the largest size granted so far is remembered per (kernel, device), behind a
 // mutex - one process may drive several devices from several threads.  Defined in state.hip.
 void gcm_allow_dynamic_lds(const void* kernel, size_t bytes);
+// compute units of the current device (cached per device; persistent kernels size their grids by it)
+int gcm_cu_count();
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -650,6 +650,199 @@ __global__ __launch_bounds__(256) void k_csr_fwd2(
   }
 }
 
+// CSR GraphConv forward, third generation, for Fi, Fo in {32, 64} exactly: the kernel is bound by
+// HBM (x, agg and out once each; the neighbour rows mostly hit in cache), so everything is shaped
+// for bytes in flight - ONE WAVE owns 32 destination rows end to end (no workgroup barrier
+// anywhere), every global access of the node rows is 16 bytes per lane, the weights live in
+// registers for the whole life of the (persistent) wave, and the two linears run on the 32x32x2 fp32
+// MFMA with a K order in which every lane reads CONTIGUOUS k (lane half kk owns k in
+// [kk FI/2, (kk+1) FI/2): 16-byte LDS reads of the A operand, 16-byte global loads of the weights).
+// HAS_W / HAS_MASK: edge weights / k-hop row mask present (compile time: a data-dependent choice
+// inside the gather loop would serialise its loads).
+template <int FI, int FO, bool HAS_W, bool HAS_MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_csr_fwd3(
+    const float* __restrict__ x, const int64_t* __restrict__ row_ptr,
+    const int64_t* __restrict__ col, const float* __restrict__ w,
+    const uint8_t* __restrict__ mask, const float* __restrict__ w_rel,
+    const float* __restrict__ b_rel, const float* __restrict__ w_root, float* __restrict__ out,
+    float* __restrict__ agg_out, int64_t M, int64_t E, int act, int n_tiles) {
+  constexpr int CPR = FI / 4;     // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;   // rows per pass of the wave
+  constexpr int NP = 32 / RPP;    // passes per 32-row tile
+  constexpr int KH = FI / 2;      // k values per lane half
+  constexpr int NT = FO / 32;     // 32-column output tiles
+  constexpr int AS = FI + 4;      // LDS row stride (16-byte aligned rows)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int act_v = gcm_vgpr(act);
+  extern __shared__ float smem[];
+  float* sA = smem + (size_t)wave * 2 * 32 * AS;   // this wave's agg tile, then its x tile
+  float* sX = sA + 32 * AS;
+
+  // weights -> LDS once per (persistent) workgroup, in operand order: sW[(m, nt, kk, n)][KH (+4)] with
+  // m = 0 W_rel, 1 W_root - lane (n = li, kk = lh) reads its KH contiguous k, 16 bytes at a time
+  constexpr int WS = KH + 4;
+  float* sW = smem + (size_t)4 * 2 * 32 * AS;
+  for (int e = tid; e < 2 * FO * CPR; e += 256) {
+    const int m = e / (FO * CPR), rem = e - m * FO * CPR, n = rem / CPR, q = rem % CPR;
+    const float4 v = *reinterpret_cast<const float4*>((m ? w_root : w_rel) + (size_t)n * FI + 4 * q);
+    const int kk = (4 * q) / KH, k0 = 4 * q - kk * KH;
+    *reinterpret_cast<float4*>(sW + (size_t)(((m * NT + n / 32) * 2 + kk) * 32 + (n & 31)) * WS + k0) = v;
+  }
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = b_rel ? b_rel[nt * 32 + li] : 0.f;
+  __syncthreads();
+  const int lr = lane / CPR, c4 = (lane % CPR) * 4;
+  const int n_waves = gridDim.x * 4;
+  // A tile's own rows and row_ptr entries are fetched one trip ahead (while the previous tile is in
+  // its MFMA / store phase): a trip then consists of two dependent round trips (column indices,
+  // neighbour rows) instead of three, and the wave has loads in flight in every phase.
+  float4 xv[NP];
+  int64_t q0[NP], q1[NP];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int64_t r = r0 + i * RPP + lr;
+      const int64_t rc = r < M ? r : M - 1;   // (past the end: loaded, never used)
+      xv[i] = *reinterpret_cast<const float4*>(x + (size_t)rc * FI + c4);
+      q0[i] = row_ptr[rc];
+      q1[i] = row_ptr[rc + 1];
+    }
+  };
+  fetch((int64_t)(blockIdx.x * 4 + wave) * 32);
+#pragma unroll 1
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+    const int64_t r0 = (int64_t)tile * 32;
+    float4 ag[NP];
+    int64_t p0[NP];
+    int deg[NP], dmax = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int rl = i * RPP + lr;
+      const int64_t r = r0 + rl;
+      bool live = r < M;
+      if (HAS_MASK) live = live && mask[r < M ? r : M - 1] != 0;
+      p0[i] = q0[i];
+      deg[i] = live ? (int)(q1[i] - q0[i]) : 0;
+      const float4 xz = live ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(sX + rl * AS + c4) = xz;   // the x tile goes to LDS right away
+      ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dmax = max(dmax, deg[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+    // neighbour gather: the wave's rows advance together, one edge each per trip
+#pragma unroll 1
+    for (int d = 0; d < dmax; ++d) {
+      float4 m[NP];
+      float we[NP];
+      bool on[NP];
+      int64_t cc[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {   // every load of a round trip is issued before the first use
+        on[i] = d < deg[i];
+        const int64_t e = on[i] ? p0[i] + d : 0;   // (dmax > 0 implies E > 0)
+        cc[i] = col[e];
+        we[i] = HAS_W ? w[e] : 1.f;
+      }
+      asm volatile("" ::: "memory");
+      uint8_t mk[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        m[i] = *reinterpret_cast<const float4*>(x + (size_t)cc[i] * FI + c4);
+        mk[i] = HAS_MASK ? mask[cc[i]] : (uint8_t)1;
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {   // mul then add, separately rounded (msg = x_j * w; index_add)
+        float4 t = m[i];
+        if (HAS_W) t = make_float4(__fmul_rn(we[i], t.x), __fmul_rn(we[i], t.y), __fmul_rn(we[i], t.z),
+                                   __fmul_rn(we[i], t.w));
+        const bool take = on[i] && mk[i] != 0;
+        ag[i] = make_float4(take ? __fadd_rn(ag[i].x, t.x) : ag[i].x, take ? __fadd_rn(ag[i].y, t.y) : ag[i].y,
+                            take ? __fadd_rn(ag[i].z, t.z) : ag[i].z, take ? __fadd_rn(ag[i].w, t.w) : ag[i].w);
+      }
+    }
+    fetch(r0 + (int64_t)n_waves * 32);   // the next tile of this wave
+    const bool full = r0 + 32 <= M;   // (uniform) every row of the tile exists: unpredicated stores
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int rl = i * RPP + lr;
+      *reinterpret_cast<float4*>(sA + rl * AS + c4) = ag[i];
+    }
+    if (agg_out) {
+      float* ab = agg_out + (size_t)(r0 + lr) * FI + c4;
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) *reinterpret_cast<float4*>(ab + (size_t)i * RPP * FI) = ag[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+          if (r0 + i * RPP + lr < M) *reinterpret_cast<float4*>(ab + (size_t)i * RPP * FI) = ag[i];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // out = act(agg @ W_rel^T + x @ W_root^T + b)
+    float4 a4[KH / 4], x4[KH / 4];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      a4[q] = *reinterpret_cast<const float4*>(sA + li * AS + lh * KH + 4 * q);
+      x4[q] = *reinterpret_cast<const float4*>(sX + li * AS + lh * KH + 4 * q);
+    }
+    uint8_t mrow[16];
+    if (HAS_MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = r0 + acc_row(r, lh);
+        mrow[r] = mask[row < M ? row : M - 1];
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* pr = sW + (size_t)(((0 * NT + nt) * 2 + lh) * 32 + li) * WS;
+      const float* po = sW + (size_t)(((1 * NT + nt) * 2 + lh) * 32 + li) * WS;
+#pragma unroll
+      for (int q = 0; q < KH / 4; ++q) {
+        const float4 wv = *reinterpret_cast<const float4*>(pr + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, wv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, wv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, wv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, wv.w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < KH / 4; ++q) {
+        const float4 wv = *reinterpret_cast<const float4*>(po + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[q].x, wv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[q].y, wv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[q].z, wv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[q].w, wv.w, acc, 0, 0, 0);
+      }
+      // acc[r] is row acc_row(r, lh) = (r & 3) + 8 (r >> 2) + 4 lh: one base pointer, constant offsets
+      float* ob = out + (size_t)(r0 + 4 * lh) * FO + nt * 32 + li;
+      float ov[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = gcm_act_sel(acc[r] + bias[nt], act_v);
+        ov[r] = (!HAS_MASK || mrow[r]) ? t : 0.f;
+      }
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[((r & 3) + 8 * (r >> 2)) * FO] = ov[r];
+      } else {
+        const int left = (int)(M - r0) - 4 * lh;   // rows of this lane half inside M
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((r & 3) + 8 * (r >> 2) < left) ob[((r & 3) + 8 * (r >> 2)) * FO] = ov[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the tiles are rewritten by the next trip
+  }
+}
+
 // Row-local part of the backward for flat rows:  G = g_out * act'(out);
 //   ws_dagg = G @ W_rel ; g_x = G @ W_root (the transpose aggregation is added later) ;
 //   slab[block] = { G^T agg , G^T x , colsum G }.
@@ -888,6 +1081,27 @@ extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, con
   const int FiP = round32(Fi);
   dim3 grid((unsigned)((M + 127) / 128));
   hipStream_t s = (hipStream_t)stream;
+  if (Fi == 32 && (Fo == 32 || Fo == 64) && M >= 32) {   // third generation: exact tiles
+    const int n_tiles = (int)((M + 31) / 32);
+    const size_t lds3 = sizeof(float) * (4 * 2 * 32 * ((size_t)Fi + 4) + 2 * (size_t)Fo * 2 * (Fi / 2 + 4));
+#define GCM_CSR3(a, b_, hw, hm)                                                                 \
+  if (Fi == a && Fo == b_ && (w != nullptr) == hw && (mask != nullptr) == hm) {                 \
+    auto kern = k_csr_fwd3<a, b_, hw, hm>;                                                            \
+    gcm_allow_dynamic_lds((const void*)kern, lds3);                                             \
+    /* resident workgroups per CU (persistent waves): 3 waves per SIMD by registers, 160 KB of LDS */ \
+    const int by_lds = (int)((160 * 1024) / lds3);                                              \
+    const int per_cu = by_lds < 1 ? 1 : (by_lds > 3 ? 3 : by_lds);                              \
+    const int cap = per_cu * gcm_cu_count();                                                    \
+    const int blocks = (n_tiles + 3) / 4 < cap ? (n_tiles + 3) / 4 : cap;                       \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds3, s, x, row_ptr, col, w, mask, w_rel, \
+                       b_rel, w_root, out, agg, M, (int64_t)0, act, n_tiles);                   \
+    return gcm_launch_status();                                                                 \
+  }
+    GCM_CSR3(32, 32, false, false) GCM_CSR3(32, 32, true, false) GCM_CSR3(32, 32, false, true)
+    GCM_CSR3(32, 32, true, true) GCM_CSR3(32, 64, false, false) GCM_CSR3(32, 64, true, false)
+    GCM_CSR3(32, 64, false, true) GCM_CSR3(32, 64, true, true)
+#undef GCM_CSR3
+  }
   if (Fi <= 64 && Fo <= 64) {   // second-generation kernel
     const int NCT = FiP / 32, NHT = round32(Fo) / 32;
     const size_t lds2 = sizeof(float) * ((size_t)128 * (FiP + 1) + 2 * FiP * (32 * NHT + 1) + 1) + 8 +

@@ -319,7 +319,22 @@ void gcm_allow_dynamic_lds(const void* kernel, size_t bytes) {
   }
 }
 
-extern "C" int gcm_version(void) { return 101; }
+int gcm_cu_count() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  int& c = cus[dev];
+  if (!c) {
+    hipDeviceProp_t prop;
+    c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ? prop.multiProcessorCount : 256;
+  }
+  return c;
+}
+
+extern "C" int gcm_version(void) { return 102; }
 
 extern "C" const char* gcm_status_string(int code) {
   switch (code) {
