@@ -12,16 +12,53 @@
 
 namespace {
 
+// Where a kernel finds the graph.  Either the ADVANCED state (count == nullptr): cur_idx[b] is the row
+// that holds the current node.  Or the state BEFORE the step (count = num_nodes going in, obs = the
+// new nodes): the current node is obs[b], it will land in row cur = min(count, N-1), and after the
+// overflow roll (count + 1 > N) image row j is stored row j + 1.  Same arithmetic either way: the
+// second form lets the live-row step (rows_step.hip) run the distance selectors ahead of its own
+// state advance, with the decisions handed over as a row [B, N] instead of adjacency writes.
+struct View {
+  const float* nodes;
+  const int64_t* cur_idx;
+  const int64_t* count;
+  const float* obs;
+};
+__device__ __forceinline__ int view_cur(const View& v, int b, int N, int& sh) {
+  sh = 0;
+  int64_t c;
+  if (v.count) {
+    const int64_t n = v.count[b];
+    sh = n + 1 > N ? 1 : 0;
+    c = sh ? n - 1 : n;
+  } else {
+    c = v.cur_idx[b];
+  }
+  return (int)(c < 0 ? 0 : (c > N - 1 ? N - 1 : c));
+}
+__device__ __forceinline__ const float* view_cur_row(const View& v, int b, int cur, int N, int F) {
+  return v.count ? v.obs + (size_t)b * F : v.nodes + ((size_t)b * N + cur) * F;
+}
+// decision for image row j: adjacency entry (advanced state) or the row handed to the step kernel
+__device__ __forceinline__ void view_emit(float* adj, float* sel_row, int b, int cur, int j, int N,
+                                          bool hit, int bidirectional) {
+  if (sel_row) {
+    sel_row[(size_t)b * N + j] = hit ? 1.f : 0.f;
+  } else if (hit) {
+    adj[((size_t)b * N + cur) * N + j] = 1.f;
+    if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
+  }
+}
+
 // gather cur rows (scaled) into workspace: ws_cur [B, F]
-__global__ void k_gather_cur(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
-                             const float* __restrict__ dist_param, float* __restrict__ ws_cur,
-                             int B, int N, int F) {
+__global__ void k_gather_cur(View vw, const float* __restrict__ dist_param,
+                             float* __restrict__ ws_cur, int B, int N, int F) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * F) return;
   const int b = i / F, f = i - b * F;
-  int64_t c = cur_idx[b];
-  c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
-  const float v = nodes[((size_t)b * N + c) * F + f];
+  int sh;
+  const int c = view_cur(vw, b, N, sh);
+  const float v = view_cur_row(vw, b, c, N, F)[f];
   ws_cur[i] = dist_param ? v / dist_param[0] : v;
 }
 
@@ -30,25 +67,26 @@ __global__ void k_gather_cur(const float* __restrict__ nodes, const int64_t* __r
 // and are read as broadcast 16-byte vectors.
 template <int FP>
 __global__ __launch_bounds__(128) void k_euclid_crossbatch(
-    const float* __restrict__ nodes, const float* __restrict__ ws_cur,
-    const int64_t* __restrict__ cur_idx, const float* __restrict__ dist_param,
-    float* __restrict__ adj, float* __restrict__ dist_out, float max_distance, int bidirectional,
-    int B, int N, int F) {
+    View vw, const float* __restrict__ ws_cur, const float* __restrict__ dist_param,
+    float* __restrict__ adj, float* __restrict__ sel_row, float* __restrict__ dist_out,
+    float max_distance, int bidirectional, int B, int N, int F) {
+  const float* __restrict__ nodes = vw.nodes;
   constexpr int CH = 32;  // cur rows per LDS chunk
   __shared__ __attribute__((aligned(16))) float sC[CH * FP];
   const int b = blockIdx.y;
   const int j = blockIdx.x * 128 + threadIdx.x;
-  int64_t cur = cur_idx[b];
-  cur = cur < 0 ? 0 : (cur > N - 1 ? N - 1 : cur);
+  int sh;
+  const int cur = view_cur(vw, b, N, sh);
   // rows >= cur can never become edges (distance.py:31-33); skip whole blocks of them
   const bool block_live = (int64_t)blockIdx.x * 128 < cur || dist_out != nullptr;
   if (!block_live) return;
   const bool live = j < N && (j < cur || dist_out != nullptr);
+  const int js = j + sh < N ? j + sh : N - 1;   // stored row of image row j
 
   float n[FP];
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
-    float v = (live && f < F) ? nodes[((size_t)b * N + j) * F + f] : 0.f;
+    float v = (live && f < F) ? nodes[((size_t)b * N + js) * F + f] : 0.f;
     n[f] = dist_param ? v / dist_param[0] : v;
   }
   float total = 0.f;
@@ -79,10 +117,7 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
   if (!live) return;
   const float d = total / (float)B;
   if (dist_out) dist_out[(size_t)b * N + j] = d;
-  if (j < cur && d < max_distance) {
-    adj[((size_t)b * N + cur) * N + j] = 1.f;
-    if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
-  }
+  if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
 }
 
 
@@ -96,16 +131,17 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
 // ---------------------------------------------------------------------------
 template <int FT>   // F padded to 32*FT
 __global__ __launch_bounds__(256) void k_euclid_mfma(
-    const float* __restrict__ nodes, const float* __restrict__ ws_curT /* [F][B] */,
-    const float* __restrict__ ws_cnorm /* [B] */, const int64_t* __restrict__ cur_idx,
-    const float* __restrict__ dist_param, float* __restrict__ adj, float* __restrict__ dist_out,
+    View vw, const float* __restrict__ ws_curT /* [F][B] */,
+    const float* __restrict__ ws_cnorm /* [B] */, const float* __restrict__ dist_param,
+    float* __restrict__ adj, float* __restrict__ sel_row, float* __restrict__ dist_out,
     float max_distance, int bidirectional, int B, int N, int F) {
+  const float* __restrict__ nodes = vw.nodes;
   constexpr int FP = 32 * FT, NS = FP + 1;
   constexpr int CB = FT >= 4 ? 128 : 256;   // graphs per LDS chunk of current rows (fits 160 KB)
   const int b = blockIdx.y, j0 = blockIdx.x * 128;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  int64_t cur64 = cur_idx[b];
-  const int cur = cur64 < 0 ? 0 : (cur64 > N - 1 ? N - 1 : (int)cur64);
+  int sh;
+  const int cur = view_cur(vw, b, N, sh);
   if (j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows
 
   extern __shared__ float smem[];
@@ -115,12 +151,24 @@ __global__ __launch_bounds__(256) void k_euclid_mfma(
   float* sCn = sNn + 128;           // [CB]  |c|^2
 
   const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
-  // node rows of this block
-  for (int e = tid; e < 128 * FP; e += 256) {
-    const int r = e / FP, f = e % FP;
-    const int j = j0 + r;
-    const float t = nodes[((size_t)b * N + (j < N ? j : N - 1)) * F + (f < F ? f : F - 1)];
-    sN[r * NS + f] = (j < N && f < F) ? (dist_param ? t / inv_scale_den : t) : 0.f;
+  // node rows of this block: every load in flight before the first LDS store (a load -> store loop
+  // exposes one memory round trip per element at one wave per SIMD)
+  {
+    constexpr int PER = 128 * FP / 256;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, f = e % FP;
+      const int j = j0 + r + sh;   // stored row of image row j0 + r
+      v[i] = nodes[((size_t)b * N + (j < N ? j : N - 1)) * F + (f < F ? f : F - 1)];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, f = e % FP;
+      const float t = v[i];
+      sN[r * NS + f] = (j0 + r < N && f < F) ? (dist_param ? t / inv_scale_den : t) : 0.f;
+    }
   }
   __syncthreads();
   if (tid < 128) {
@@ -136,10 +184,24 @@ __global__ __launch_bounds__(256) void k_euclid_mfma(
 
   for (int c0 = 0; c0 < B; c0 += CB) {
     __syncthreads();
-    for (int e = tid; e < FP * CB; e += 256) {
-      const int f = e / CB, c = e % CB;
-      const float t = ws_curT[(size_t)(f < F ? f : F - 1) * B + (c0 + c < B ? c0 + c : B - 1)];
-      sC[e] = (f < F && c0 + c < B) ? t : 0.f;
+    {   // current rows of this chunk of graphs, [F][CB]: 32 loads in flight at a time
+      constexpr int PER = FP * CB / 256, STEP = 32;
+      static_assert(PER % STEP == 0, "chunking");
+#pragma unroll 1
+      for (int i0 = 0; i0 < PER; i0 += STEP) {
+        float v[STEP];
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+          const int e = tid + 256 * (i0 + i), f = e / CB, c = e % CB;
+          v[i] = ws_curT[(size_t)(f < F ? f : F - 1) * B + (c0 + c < B ? c0 + c : B - 1)];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+          const int e = tid + 256 * (i0 + i), f = e / CB, c = e % CB;
+          sC[e] = (f < F && c0 + c < B) ? v[i] : 0.f;
+        }
+      }
     }
     for (int c = tid; c < CB; c += 256) sCn[c] = c0 + c < B ? ws_cnorm[c0 + c] : 0.f;
     __syncthreads();
@@ -180,25 +242,23 @@ __global__ __launch_bounds__(256) void k_euclid_mfma(
       if (j >= N) continue;
       const float d = rowsum[r] / (float)B;
       if (dist_out) dist_out[(size_t)b * N + j] = d;
-      if (j < cur && d < max_distance) {
-        adj[((size_t)b * N + cur) * N + j] = 1.f;
-        if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
-      }
+      if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
     }
   }
 }
 
 // current rows (scaled) transposed to [F][B] + their squared norms
-__global__ void k_gather_curT(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
-                              const float* __restrict__ dist_param, float* __restrict__ ws_curT,
-                              float* __restrict__ ws_cnorm, int B, int N, int F) {
+__global__ void k_gather_curT(View vw, const float* __restrict__ dist_param,
+                              float* __restrict__ ws_curT, float* __restrict__ ws_cnorm, int B, int N,
+                              int F) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  int64_t c = cur_idx[b];
-  c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+  int sh;
+  const int c = view_cur(vw, b, N, sh);
+  const float* row = view_cur_row(vw, b, c, N, F);
   float s = 0.f;
   for (int f = 0; f < F; ++f) {
-    float v = nodes[((size_t)b * N + c) * F + f];
+    float v = row[f];
     if (dist_param) v = v / dist_param[0];
     ws_curT[(size_t)f * B + b] = v;
     s = fmaf(v, v, s);
@@ -207,18 +267,18 @@ __global__ void k_gather_curT(const float* __restrict__ nodes, const int64_t* __
 }
 
 // per-graph modes: one thread per (b, j)
-__global__ void k_pergraph(const float* __restrict__ nodes, const int64_t* __restrict__ cur_idx,
-                           const float* __restrict__ dist_param, float* __restrict__ adj,
-                           float* __restrict__ dist_out, int mode, float max_distance, int a0,
-                           int a1, int b0, int bidirectional, int B, int N, int F) {
+__global__ void k_pergraph(View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
+                           float* __restrict__ sel_row, float* __restrict__ dist_out, int mode,
+                           float max_distance, int a0, int a1, int b0, int bidirectional, int B, int N,
+                           int F) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * N) return;
   const int b = i / N, j = i - b * N;
-  int64_t cur = cur_idx[b];
-  cur = cur < 0 ? 0 : (cur > N - 1 ? N - 1 : cur);
+  int sh;
+  const int cur = view_cur(vw, b, N, sh);
   if (j >= cur && dist_out == nullptr) return;
-  const float* c = nodes + ((size_t)b * N + cur) * F;
-  const float* n = nodes + ((size_t)b * N + j) * F;
+  const float* c = view_cur_row(vw, b, cur, N, F);
+  const float* n = vw.nodes + ((size_t)b * N + (j + sh < N ? j + sh : N - 1)) * F;
   const float sc = dist_param ? dist_param[0] : 1.f;
   float d;
   if (mode == GCM_DIST_L2_PERGRAPH) {
@@ -241,10 +301,7 @@ __global__ void k_pergraph(const float* __restrict__ nodes, const int64_t* __res
     d = s;
   }
   if (dist_out) dist_out[i] = d;
-  if (j < cur && d < max_distance) {
-    adj[((size_t)b * N + cur) * N + j] = 1.f;
-    if (bidirectional) adj[((size_t)b * N + j) * N + cur] = 1.f;
-  }
+  if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
 }
 
 }  // namespace
@@ -255,12 +312,10 @@ extern "C" size_t gcm_edge_distance_workspace_bytes(int mode, int B, int N, int 
   return ((size_t)B * F + B) * sizeof(float);
 }
 
-extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* cur_idx, int mode,
-                                 float max_distance, const float* dist_param, int a0, int a1,
-                                 int b0, int b1, int bidirectional, float* dist_out,
-                                 void* workspace, size_t workspace_bytes, int B, int N, int F,
-                                 gcm_stream_t stream) {
-  GCM_REQUIRE(nodes && adj && cur_idx && B > 0 && N > 0 && F > 0);
+static int run_distance(const View& vw, float* adj, float* sel_row, int mode, float max_distance,
+                        const float* dist_param, int a0, int a1, int b0, int b1, int bidirectional,
+                        float* dist_out, void* workspace, size_t workspace_bytes, int B, int N, int F,
+                        gcm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (mode == GCM_DIST_EUCLID_CROSSBATCH) {
     if (F > 128 || B > 65535) return GCM_EUNSUPPORTED;
@@ -269,8 +324,8 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
     float* ws_cur = (float*)workspace;
     if (B >= 32) {   // matrix-core path (torch.cdist's own switch to the mm formulation is at 25)
       float* ws_cnorm = ws_cur + (size_t)B * F;
-      hipLaunchKernelGGL(k_gather_curT, dim3((B + 127) / 128), dim3(128), 0, s, nodes, cur_idx,
-                         dist_param, ws_cur, ws_cnorm, B, N, F);
+      hipLaunchKernelGGL(k_gather_curT, dim3((B + 127) / 128), dim3(128), 0, s, vw, dist_param, ws_cur,
+                         ws_cnorm, B, N, F);
       dim3 grid((N + 127) / 128, B);
       const int FT = (F + 31) / 32;
       const int CBv = FT >= 4 ? 128 : 256;
@@ -278,9 +333,9 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
 #define GCM_EUCLID_MFMA(FTv)                                                                     \
   {                                                                                              \
     auto kern = k_euclid_mfma<FTv>;                                                              \
-    gcm_allow_dynamic_lds((const void*)kern, lds);                                                                                            \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, nodes, ws_cur, ws_cnorm, cur_idx,          \
-                       dist_param, adj, dist_out, max_distance, bidirectional, B, N, F);         \
+    gcm_allow_dynamic_lds((const void*)kern, lds);                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, vw, ws_cur, ws_cnorm, dist_param, adj,     \
+                       sel_row, dist_out, max_distance, bidirectional, B, N, F);                 \
   }
       switch (FT) {
         case 1: GCM_EUCLID_MFMA(1) break;
@@ -291,12 +346,12 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
 #undef GCM_EUCLID_MFMA
       return gcm_launch_status();
     }
-    hipLaunchKernelGGL(k_gather_cur, dim3((B * F + 255) / 256), dim3(256), 0, s, nodes, cur_idx,
-                       dist_param, ws_cur, B, N, F);
+    hipLaunchKernelGGL(k_gather_cur, dim3((B * F + 255) / 256), dim3(256), 0, s, vw, dist_param, ws_cur,
+                       B, N, F);
     dim3 grid((N + 127) / 128, B);
-#define GCM_EUCLID(FP)                                                                       \
-  hipLaunchKernelGGL(k_euclid_crossbatch<FP>, grid, dim3(128), 0, s, nodes, ws_cur, cur_idx, \
-                     dist_param, adj, dist_out, max_distance, bidirectional, B, N, F)
+#define GCM_EUCLID(FP)                                                                        \
+  hipLaunchKernelGGL(k_euclid_crossbatch<FP>, grid, dim3(128), 0, s, vw, ws_cur, dist_param, adj, \
+                     sel_row, dist_out, max_distance, bidirectional, B, N, F)
     if (F <= 16) GCM_EUCLID(16);
     else if (F <= 32) GCM_EUCLID(32);
     else if (F <= 64) GCM_EUCLID(64);
@@ -310,8 +365,33 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
     return GCM_EINVAL;
   }
   const int total = B * N;
-  hipLaunchKernelGGL(k_pergraph, dim3((total + 255) / 256), dim3(256), 0, s, nodes, cur_idx,
-                     dist_param, adj, dist_out, mode, max_distance, a0, a1, b0, bidirectional, B,
-                     N, F);
+  hipLaunchKernelGGL(k_pergraph, dim3((total + 255) / 256), dim3(256), 0, s, vw, dist_param, adj, sel_row,
+                     dist_out, mode, max_distance, a0, a1, b0, bidirectional, B, N, F);
   return gcm_launch_status();
+}
+
+extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* cur_idx, int mode,
+                                 float max_distance, const float* dist_param, int a0, int a1,
+                                 int b0, int b1, int bidirectional, float* dist_out,
+                                 void* workspace, size_t workspace_bytes, int B, int N, int F,
+                                 gcm_stream_t stream) {
+  GCM_REQUIRE(nodes && adj && cur_idx && B > 0 && N > 0 && F > 0);
+  const View vw{nodes, cur_idx, nullptr, nullptr};
+  return run_distance(vw, adj, nullptr, mode, max_distance, dist_param, a0, a1, b0, b1, bidirectional,
+                      dist_out, workspace, workspace_bytes, B, N, F, stream);
+}
+
+/* The same selectors on the state BEFORE the step (nodes_in, count_in = num_nodes going in, obs =
+ * the nodes about to be inserted): sel_row [B, N] receives 1 / 0 for every image row j < cur_b (the
+ * row the node lands in, after the overflow roll); entries j >= cur_b are left untouched.  This is
+ * what gcm_dense_rows_step_fwd merges into row cur of the adjacency. */
+extern "C" int gcm_edge_distance_pre(const float* nodes_in, const int64_t* count_in, const float* obs,
+                                     float* sel_row, int mode, float max_distance,
+                                     const float* dist_param, int a0, int a1, int b0, int b1,
+                                     void* workspace, size_t workspace_bytes, int B, int N, int F,
+                                     gcm_stream_t stream) {
+  GCM_REQUIRE(nodes_in && count_in && obs && sel_row && B > 0 && N > 0 && F > 0);
+  const View vw{nodes_in, nullptr, count_in, obs};
+  return run_distance(vw, nullptr, sel_row, mode, max_distance, dist_param, a0, a1, b0, b1, 0, nullptr,
+                      workspace, workspace_bytes, B, N, F, stream);
 }

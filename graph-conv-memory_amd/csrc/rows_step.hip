@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_step_rows(
     const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
     int64_t* __restrict__ cur_out, Edits E, Gnn2 P, float* __restrict__ mx_out,
     float* __restrict__ saved, SavedLayout lay, uint32_t* __restrict__ flags, int N_, int F_,
-    int H1_, int H2_, const float* __restrict__ c1, const float* __restrict__ pe) {
+    int H1_, int H2_, const float* __restrict__ c1, const float* __restrict__ pe,
+    const float* __restrict__ sel_row) {
   using L = Lds<FP, HP, H2P>;
   const int N = NX ? NX : N_, F = EXACT ? FP : F_, H1 = EXACT ? HP : H1_, H2 = EXACT ? H2P : H2_;
   constexpr int XS = L::XS, RS = L::RS, AS = L::AS, HS = L::HS;
@@ -166,6 +167,9 @@ __global__ __launch_bounds__(256) void k_step_rows(
   float* sDeg = reinterpret_cast<float*>(sInt + 16);
   // a folded preprocessor / positional encoding (generic shapes only): see gcm_dense_rows_step_fwd
   const bool fold_deg = !EXACT && c1 != nullptr, fold_pe = !EXACT && pe != nullptr;
+  // decisions of a distance selector that ran ahead of this kernel (gcm_edge_distance_pre): 1 / 0 per
+  // image row j < cur (entries beyond are unspecified)
+  const bool has_sel = !EXACT && sel_row != nullptr;
 
   const float* ng_in = nodes_in + (size_t)b * N * F;
   const float* ag_in = adj_in + (size_t)b * N * N;
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
   const float bias1 = P.b_rel1[hcol < H1 ? hcol : H1 - 1];
   const float bias2 = P.b_rel2[o2 < H2 ? o2 : H2 - 1];
   const float c1v = fold_deg ? c1[hcol < H1 ? hcol : H1 - 1] : 0.f;
+  const float srv = has_sel ? sel_row[(size_t)b * N + min(tid & 127, N - 1)] : 0.f;
   // functional state, no overflow (the common case, assumed here): the copy's loads
   constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
   float4 ca[FUNC ? ADJ_PER : 1], cn[FUNC ? NODE_PER : 1];
@@ -324,6 +329,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
     if (is_cand && j != cur) r_new = 1.f;            // a forward / both hop writes (cur, j)
     if (dense && j <= cur) r_new = 1.f;
     if (j == cur && hop0) r_new = 1.f;
+    if (has_sel && j < cur && srv != 0.f) r_new = 1.f;   // distance.py:31-37
     sRowCur[j] = r_new;
     sCoef[j] = 0.f;                                  // entries beyond the live list stay zero
     xpred = j < N && r_new != 0.f && !is_cand;       // live, and not fetched ahead
@@ -564,7 +570,7 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
            const int64_t* count_in, float* nodes_out, float* adj_out, int64_t* count_out,
            int64_t* cur_out, const Edits& E, const Gnn2& P, float* mx, float* saved,
            const SavedLayout& lay, uint32_t* flags, int B, int N, int F, int H1, int H2,
-           const float* c1 = nullptr, const float* pe = nullptr) {
+           const float* c1 = nullptr, const float* pe = nullptr, const float* sel_row = nullptr) {
   constexpr size_t lds = sizeof(float) * (size_t)Lds<FP, HP, H2P>::TOTAL;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const bool func = adj_out != adj_in;
@@ -573,12 +579,13 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
   if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
     hipExtLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in, adj_in,
                           count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
-                          N, F, H1, H2, c1, pe);
+                          N, F, H1, H2, c1, pe, sel_row);
     t_start = t_stop = nullptr;
     return gcm_launch_status();
   }
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in, nodes_out,
-                     adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe);
+                     adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe,
+                     sel_row);
   return gcm_launch_status();
 }
 
@@ -604,6 +611,15 @@ extern "C" int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t
   return GCM_OK;
 }
 
+extern "C" size_t gcm_dense_rows_step_workspace_bytes(const gcm_selector_desc* selectors,
+                                                      int n_selectors, int B, int N, int F) {
+  size_t need = 0;
+  for (int i = 0; selectors && i < n_selectors; ++i)
+    if (selectors[i].kind == GCM_SEL_DISTANCE)
+      need = sizeof(float) * (size_t)B * N + gcm_edge_distance_workspace_bytes(selectors[i].mode, B, N, F);
+  return need;
+}
+
 extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, const float* adj_in,
                                        const int64_t* count_in, float* nodes_out, float* adj_out,
                                        int64_t* count_out, int64_t* cur_out,
@@ -611,14 +627,43 @@ extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, 
                                        const float* params, int has_bias, int act1, int act2,
                                        float* mx, float* saved, uint32_t* flags, int B, int N,
                                        int F, int H1, int H2, gcm_stream_t stream) {
+  return gcm_dense_rows_step_fwd_ws(obs, nodes_in, adj_in, count_in, nodes_out, adj_out, count_out,
+                                    cur_out, selectors, n_selectors, params, has_bias, act1, act2, mx,
+                                    saved, flags, nullptr, 0, B, N, F, H1, H2, stream);
+}
+
+extern "C" int gcm_dense_rows_step_fwd_ws(const float* obs, const float* nodes_in, const float* adj_in,
+                                          const int64_t* count_in, float* nodes_out, float* adj_out,
+                                          int64_t* count_out, int64_t* cur_out,
+                                          const gcm_selector_desc* selectors, int n_selectors,
+                                          const float* params, int has_bias, int act1, int act2,
+                                          float* mx, float* saved, uint32_t* flags, void* workspace,
+                                          size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                                          gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes_in && adj_in && count_in && nodes_out && adj_out && count_out && params &&
               mx && flags);
   GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0));
   GCM_REQUIRE((nodes_out == nodes_in) == (adj_out == adj_in));   // donate both or neither
   if (!gcm_dense_rows_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
   gcm_fused::Edits E{};
+  const float* sel_row = nullptr;
   for (int i = 0; i < n_selectors; ++i) {
     const gcm_selector_desc& d = selectors[i];
+    if (d.kind == GCM_SEL_DISTANCE) {
+      // the distance selector runs first, on the state as it comes in, and hands its row over
+      if (sel_row || d.bidirectional) return GCM_EUNSUPPORTED;
+      GCM_REQUIRE(workspace);
+      if (workspace_bytes < gcm_dense_rows_step_workspace_bytes(selectors, n_selectors, B, N, F))
+        return GCM_EWORKSPACE;
+      float* row = (float*)workspace;
+      const int rc = gcm_edge_distance_pre(nodes_in, count_in, obs, row, d.mode, d.max_distance,
+                                           d.dist_param, d.a0, d.a1, d.b0, d.b1, row + (size_t)B * N,
+                                           workspace_bytes - sizeof(float) * (size_t)B * N, B, N, F,
+                                           stream);
+      if (rc) return rc;
+      sel_row = row;
+      continue;
+    }
     if (d.kind == GCM_SEL_TEMPORAL) {
       for (int k = 0; k < d.n_hops; ++k) {
         if (E.n_hops >= 16) return GCM_EUNSUPPORTED;
@@ -640,7 +685,7 @@ extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, 
   // folded preprocessor bias / positional encoding: extra sections behind the GNN parameters
   const float* c1 = (has_bias & GCM_GNN_HAS_DEG_TERM) ? b2 + H2 : nullptr;
   const float* pe = (has_bias & GCM_GNN_HAS_PE_TABLE) ? b2 + H2 + (c1 ? H1 : 0) : nullptr;
-  const bool folded = c1 || pe;
+  const bool folded = c1 || pe || sel_row;
   // the bias slots are always there (zeros when a layer has none): read unconditionally
   gcm_fused::Gnn2 P{w_rel1, b1, w_root1, w_rel2, b2, w_root2, act1, act2};
   const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
@@ -658,7 +703,7 @@ extern "C" int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, 
   if (fp == a && hp == b_ && h2p == c)                                                           \
     return gcm_rows::launch<a, b_, c, 0, false>(s, obs, nodes_in, adj_in, count_in, nodes_out,   \
                                                 adj_out, count_out, cur_out, E, P, mx, saved,    \
-                                                lay, flags, B, N, F, H1, H2, c1, pe);
+                                                lay, flags, B, N, F, H1, H2, c1, pe, sel_row);
   GCM_R(32, 32, 32) GCM_R(32, 32, 64) GCM_R(32, 64, 32) GCM_R(32, 64, 64)
   GCM_R(64, 32, 32) GCM_R(64, 32, 64) GCM_R(64, 64, 32) GCM_R(64, 64, 64)
 #undef GCM_R

@@ -61,6 +61,8 @@ struct StepCfg {
     for (const auto& d : descs)
       if (d.kind == GCM_SEL_DISTANCE)
         need = std::max(need, gcm_edge_distance_workspace_bytes(d.mode, B, N, F));
+    // (the live-row step also keeps the selector's decision row there)
+    need = std::max(need, gcm_dense_rows_step_workspace_bytes(descs.data(), (int)descs.size(), B, N, F));
     if (need > ws_bytes) {
       ws = at::empty({(int64_t)need}, like.options().dtype(at::kByte));
       ws_bytes = need;
@@ -354,15 +356,17 @@ std::vector<at::Tensor> rows_step(const at::Tensor& obs, const at::Tensor& nodes
     adj_out = st.narrow(0, n_nodes, B * (int64_t)N * N).view({B, N, N});
     count_out = st.narrow(0, n_nodes + n_adj, 2 * B).view(at::kLong);
   }
-  const int rc = gcm_dense_rows_step_fwd(
+  size_t ws_bytes = 0;
+  void* ws = cfg->workspace((int)B, obs, &ws_bytes);
+  const int rc = gcm_dense_rows_step_fwd_ws(
       obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
       count_in.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), adj_out.data_ptr<float>(),
       count_out.data_ptr<int64_t>(), nullptr, cfg->descs.empty() ? nullptr : cfg->descs.data(),
       (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
       buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
-      reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2,
+      reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2,
       reinterpret_cast<gcm_stream_t>(stream));
-  check(rc, "gcm_dense_rows_step_fwd");
+  check(rc, "gcm_dense_rows_step_fwd_ws");
   at::Tensor mx = need_bwd ? RowsStepFn::apply(packed, buf, B, (int64_t)H2, holder_handle, (int64_t)is_head)
                            : buf.narrow(0, 0, B * H2).view({B, H2});
   return {mx, nodes_out, adj_out, count_out};

@@ -88,6 +88,9 @@ PROTOTYPES = {
     "gcm_dense_rows_supported": (_I, [_I] * 4),
     "gcm_dense_rows_layout": (_I, [_I] * 5 + [_P]),
     "gcm_dense_rows_step_fwd": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_I] * 5 + [_P]),
+    "gcm_dense_rows_step_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
+    "gcm_dense_rows_step_fwd_ws": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_P, _Z] + [_I] * 5 + [_P]),
+    "gcm_edge_distance_pre": (_I, [_P] * 4 + [_I, _F, _P] + [_I] * 4 + [_P, _Z] + [_I] * 3 + [_P]),
     "gcm_debug_time_next_launch": (_I, [_P, _P]),
     "gcm_learned_step_supported": (_I, [_I] * 4),
     "gcm_learned_mlp_param_count": (_Z, [_I]),

@@ -636,9 +636,12 @@ class StepConfig:
         self.fn_bwd = lib.gcm_dense_step_bwd
         self.has_distance = any(d.kind == _hip.SEL_DISTANCE for d in descs)
         self._cpp, self._cpp_handle, self._cpp_call = None, None, None
-        # the live-row step (rows_step.hip): index-writing selectors only, <= 16 hops in all
+        # the live-row step (rows_step.hip): index-writing selectors (<= 16 hops in all) and at most
+        # one distance selector, which then runs ahead of the step on the incoming state
+        n_dist = sum(1 for d in descs if d.kind == _hip.SEL_DISTANCE)
         self.rows_ok = bool(
-            all(d.kind in (_hip.SEL_TEMPORAL, _hip.SEL_DENSE) for d in descs)
+            all(d.kind in (_hip.SEL_TEMPORAL, _hip.SEL_DENSE, _hip.SEL_DISTANCE) for d in descs)
+            and n_dist <= 1 and not any(d.kind == _hip.SEL_DISTANCE and d.bidirectional for d in descs)
             and sum(d.n_hops for d in descs if d.kind == _hip.SEL_TEMPORAL) <= 16
             and lib.gcm_dense_rows_supported(N, F, H1, H2)
             and _ext.module() is not None and hasattr(_ext.module(), "rows_step"))

@@ -440,6 +440,26 @@ int gcm_csc_from_csr_batched(const int64_t* row_ptr, const int64_t* col, const i
                              int64_t* perm, int B, int64_t M, int64_t E, int max_nodes_per_graph,
                              gcm_stream_t stream);
 
+/* gcm_dense_rows_step_fwd for selector chains that contain ONE distance selector
+ * (GCM_SEL_DISTANCE, not bidirectional; distance.py:18-39): the selector runs first, on the state
+ * as it comes in (gcm_edge_distance_pre: the current node is obs[b], stored row j + 1 stands for
+ * image row j when the graph is about to roll), and its decisions travel to the step kernel as a
+ * row [B, N] inside `workspace` (gcm_dense_rows_step_workspace_bytes) - the adjacency is then written
+ * once, by the step kernel.  Without a distance selector workspace may be NULL. */
+size_t gcm_dense_rows_step_workspace_bytes(const gcm_selector_desc* selectors, int n_selectors, int B,
+                                           int N, int F);
+int gcm_dense_rows_step_fwd_ws(const float* obs, const float* nodes_in, const float* adj_in,
+                               const int64_t* count_in, float* nodes_out, float* adj_out,
+                               int64_t* count_out, int64_t* cur_out /* may be NULL */,
+                               const gcm_selector_desc* selectors, int n_selectors,
+                               const float* params, int has_bias, int act1, int act2, float* mx,
+                               float* saved, uint32_t* flags, void* workspace, size_t workspace_bytes,
+                               int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+int gcm_edge_distance_pre(const float* nodes_in, const int64_t* count_in, const float* obs,
+                          float* sel_row, int mode, float max_distance, const float* dist_param,
+                          int a0, int a1, int b0, int b1, void* workspace, size_t workspace_bytes,
+                          int B, int N, int F, gcm_stream_t stream);
+
 /* Measurement aid (bench.py): the NEXT gcm_dense_rows_step_fwd launch of the calling thread is
  * bracketed by the two hipEvent_t given here, recorded by the dispatch itself
  * (hipExtLaunchKernelGGL start / stop events: the kernel's own begin / end timestamps, what

@@ -23,7 +23,9 @@ def _rows_taken(mem):
 
 
 GOLD = ["g1_temporal_h1", "g2_temporal_h124_both", "g1b_cfg1", "g5_dense_edge", "g13_exact_temporal",
-        "g13_exact_dense"]
+        "g13_exact_dense",
+        # distance selectors: they run ahead of the step kernel, on the incoming state
+        "g3_euclid", "g3_euclid_mixed", "g3_euclid_learned", "g4_spatial", "g4_spatial_ab", "g4_cosine"]
 
 
 @pytest.mark.parametrize("donate", [False, True])
@@ -337,3 +339,50 @@ def test_rows_graph_capture_replay():
             want = fx["grad:" + k]
             torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
     mem.check_flags()
+
+
+@pytest.mark.parametrize("kind,B,N,F,T", [("euclid", 40, 128, 64, 140), ("euclid", 33, 32, 20, 40),
+                                          ("cosine", 6, 64, 32, 70), ("spatial", 5, 36, 12, 40)])
+def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
+    """Distance selectors ahead of the live-row step (matrix-core Euclidean kernel for B >= 32) ==
+    the fused path that runs them on the advanced state: same adjacency bit for bit through the
+    overflow, same beliefs and parameter gradients."""
+    from gcm import nn as G
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.distance import EuclideanEdge, CosineEdge, SpatialEdge
+    torch.manual_seed(B + N)
+    H = 32
+    centres = 3 * torch.randn(6, F)
+    # all graphs visit the same cluster at time t: the cross-batch mean distance separates the clusters
+    obs = (centres[torch.arange(T) % 6][:, None, :] + 0.05 * torch.randn(T, B, F)).to(DEV)
+
+    def build(donate):
+        torch.manual_seed(1)
+        g = G.Sequential("x, adj, weights, B, N", [
+            (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+            (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+        sel = {"euclid": lambda: EuclideanEdge(3.0), "cosine": lambda: CosineEdge(0.5),
+               "spatial": lambda: SpatialEdge(1.0, slice(0, 3))}[kind]()
+        return DenseGCM(g, edge_selectors=sel, graph_size=N, donate_state=donate), g
+
+    res = []
+    for mode in ("fused", "rows", "rows_donated"):
+        mem, g = build(mode == "rows_donated")
+        x = obs.clone().requires_grad_(mode == "fused")     # a gradient w.r.t. obs => the fused path
+        hidden, outs, sums = None, [], []
+        for t in range(T):
+            mx, hidden = mem(x[t], hidden)
+            outs.append(mx)
+            sums.append(hidden[1].sum(dim=(1, 2)).clone())
+        assert _rows_taken(mem)                              # (the holder exists; no_dx steps record into it)
+        out = torch.stack(outs)
+        (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
+        mem.check_flags()
+        res.append((out.detach(), hidden[1].clone(), torch.stack(sums), {k_: p.grad.clone() for k_, p in g.named_parameters()}))
+    assert float(res[0][2].max()) > 0                        # the thresholds do connect nodes
+    for r in res[1:]:
+        assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+        torch.testing.assert_close(r[0], res[0][0], rtol=1e-5, atol=5e-6)
+        for k_ in r[3]:
+            scale = float(res[0][3][k_].abs().max()) + 1e-12
+            torch.testing.assert_close(r[3][k_], res[0][3][k_], rtol=1e-4, atol=2e-5 * scale, msg=k_)

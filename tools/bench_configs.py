@@ -40,13 +40,14 @@ def timeit(fn, iters, warm=2):
     return (time.perf_counter() - t0) / iters
 
 
-def run_dense(name, B, N, F, H, T, sel, obs, iters=5):
+def run_dense(name, B, N, F, H, T, sel, obs, iters=5, pre=None, **kw):
     if ONLY not in name:
         return
     torch.manual_seed(0)
-    gnn = dense_gnn(F, H)
-    mem = DenseGCM(gnn, edge_selectors=sel, graph_size=N)
-    params = list(gnn.parameters()) + (list(sel.parameters()) if sel is not None else [])
+    gnn = dense_gnn(pre.out_features if pre is not None else F, H)
+    mem = DenseGCM(gnn, edge_selectors=sel, graph_size=N, preprocessor=pre, **kw)
+    params = list(gnn.parameters()) + (list(sel.parameters()) if sel is not None else []) + \
+        (list(pre.parameters()) if pre is not None else [])
 
     def loop():
         hid, outs = None, []
@@ -98,6 +99,10 @@ B, N, F, H, T = 256, 128, 64, 32, 128
 c = 4 * torch.randn(8, F)
 obs3 = (c[torch.arange(T) % 8][:, None, :] + 0.05 * torch.randn(T, B, F)).to(dev)
 run_dense("cfg3 EuclideanEdge(2.0) cross-batch", B, N, F, H, T, EuclideanEdge(2.0), obs3, iters=3)
+# cfg2's shape behind the RLlib model's default preprocessor (ray_gcm.py:117): folded into the step
+B, N, F, H, T = 256, 128, 32, 32, 128
+run_dense("cfg2 + Linear(32,32) preprocessor (folded), donated", B, N, F, H, T, TemporalBackedge([1, 2, 4]),
+          torch.rand(T, B, F, device=dev), pre=torch.nn.Linear(F, 32).to(dev), donate_state=True)
 # cfg5 per-GPU share
 B, N, F, H, T = 256, 128, 32, 32, 64
 run_dense("cfg5/GPU LearnedEdge(32)", B, N, F, H, T, LearnedEdge(32).to(dev), torch.rand(T, B, F, device=dev), iters=3)
