@@ -8,7 +8,17 @@
 //
 // then adj[b, cur_b, j] = 1 for every j < cur_b with d[b,j] < max_distance.
 // The distance matrix never leaves the chip unless dist_out is given.
-#include "gcm_common.h"
+#include "fused_common.h"
+
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps6, tools/kstamp_euclid.py)
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#define DSTAMP(i) do { if (blockIdx.y == (gridDim.y >> 1)) STAMP(i); } while (0)
+#else
+#define DSTAMP(i)
+#endif
 
 namespace {
 
@@ -125,58 +135,67 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
 // EUCLID_CROSSBATCH on the matrix cores (B >= 32): the [N x B] block of squared distances of
 // one graph's nodes against ALL current rows is |n|^2 + |c|^2 - 2 n.c^T, i.e. a [N x F] x [F x B]
 // product (v_mfma_f32_32x32x2_f32) - the formulation torch.cdist itself switches to above 25
-// rows.  One workgroup = one graph x 128 node rows; the (scaled) current rows of all graphs sit
-// transposed in LDS ([F][B], shared by the four waves), each wave owns 32 node rows.  sqrt and
-// the mean over b' run on the accumulators; rows >= cur are skipped (distance.py:31-33).
+// rows.  One workgroup (8 waves) = one graph x 128 node rows.  The (scaled) current rows of a chunk
+// of CB graphs are gathered straight from the state into LDS, transposed ([F][CB+1]: coalesced
+// global reads along F, conflict-free LDS writes and MFMA operand reads), their squared norms
+// computed in place - no separate gather kernel.  Wave w owns node rows 32 (w & 3) and the column
+// half (w >> 2) of every chunk; sqrt and the mean over b' run on the accumulators, the two halves
+// meet in LDS in fixed order.  Rows >= cur are skipped (distance.py:31-33).
 // ---------------------------------------------------------------------------
 template <int FT>   // F padded to 32*FT
-__global__ __launch_bounds__(256) void k_euclid_mfma(
-    View vw, const float* __restrict__ ws_curT /* [F][B] */,
-    const float* __restrict__ ws_cnorm /* [B] */, const float* __restrict__ dist_param,
-    float* __restrict__ adj, float* __restrict__ sel_row, float* __restrict__ dist_out,
-    float max_distance, int bidirectional, int B, int N, int F) {
+__global__ __launch_bounds__(512) void k_euclid_mfma(
+    View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
+    float* __restrict__ sel_row, float* __restrict__ dist_out, float max_distance, int bidirectional,
+    int B, int N, int F) {
   const float* __restrict__ nodes = vw.nodes;
   constexpr int FP = 32 * FT, NS = FP + 1;
   constexpr int CB = FT >= 4 ? 128 : 256;   // graphs per LDS chunk of current rows (fits 160 KB)
+  constexpr int CS = CB + 1;
+  constexpr int HT = CB / 64;               // 32-column tiles per wave and chunk
   const int b = blockIdx.y, j0 = blockIdx.x * 128;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int rw = wave & 3, ch = wave >> 2;
   int sh;
   const int cur = view_cur(vw, b, N, sh);
   if (j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows
 
   extern __shared__ float smem[];
   float* sN = smem;                 // [128][NS]  node rows (scaled)
-  float* sC = sN + 128 * NS;        // [FP][CB]   current rows, transposed, one chunk of CB graphs
-  float* sNn = sC + FP * CB;        // [128] |n|^2
+  float* sC = sN + 128 * NS;        // [FP][CS]   current rows, transposed, one chunk of CB graphs
+  float* sNn = sC + FP * CS;        // [128] |n|^2
   float* sCn = sNn + 128;           // [CB]  |c|^2
+  float* sHalf = sCn + CB;          // [128] row sums of column half 1
 
   const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
+  DSTAMP(0);
   // node rows of this block: every load in flight before the first LDS store (a load -> store loop
   // exposes one memory round trip per element at one wave per SIMD)
   {
-    constexpr int PER = 128 * FP / 256;
+    constexpr int PER = 128 * FP / 512;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, r = e / FP, f = e % FP;
+      const int e = tid + 512 * i, r = e / FP, f = e % FP;
       const int j = j0 + r + sh;   // stored row of image row j0 + r
       v[i] = nodes[((size_t)b * N + (j < N ? j : N - 1)) * F + (f < F ? f : F - 1)];
     }
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, r = e / FP, f = e % FP;
+      const int e = tid + 512 * i, r = e / FP, f = e % FP;
       const float t = v[i];
       sN[r * NS + f] = (j0 + r < N && f < F) ? (dist_param ? t / inv_scale_den : t) : 0.f;
     }
   }
   __syncthreads();
+  DSTAMP(1);
   if (tid < 128) {
     float s = 0.f;
     for (int f = 0; f < FP; ++f) s = fmaf(sN[tid * NS + f], sN[tid * NS + f], s);
     sNn[tid] = s;
   }
-  const int r_base = wave * 32;
+  DSTAMP(2);
+  const int r_base = rw * 32;
   const bool wave_live = (j0 + r_base < cur) || dist_out != nullptr;
   float rowsum[16];
 #pragma unroll
@@ -184,86 +203,126 @@ __global__ __launch_bounds__(256) void k_euclid_mfma(
 
   for (int c0 = 0; c0 < B; c0 += CB) {
     __syncthreads();
-    {   // current rows of this chunk of graphs, [F][CB]: 32 loads in flight at a time
-      constexpr int PER = FP * CB / 256, STEP = 32;
-      static_assert(PER % STEP == 0, "chunking");
-#pragma unroll 1
-      for (int i0 = 0; i0 < PER; i0 += STEP) {
-        float v[STEP];
+    {   // current rows of this chunk of graphs -> [F][CS], every load in flight before the first store
+      constexpr int PER = FP * CB / 512;
+      float v[PER];
+      if (vw.count) {   // (uniform) the current nodes are the observations: no index to chase
 #pragma unroll
-        for (int i = 0; i < STEP; ++i) {
-          const int e = tid + 256 * (i0 + i), f = e / CB, c = e % CB;
-          v[i] = ws_curT[(size_t)(f < F ? f : F - 1) * B + (c0 + c < B ? c0 + c : B - 1)];
+        for (int i = 0; i < PER; ++i) {
+          const int e = tid + 512 * i, c = e / FP, f = e % FP;
+          const int g = c0 + c < B ? c0 + c : B - 1;
+          v[i] = vw.obs[(size_t)g * F + (f < F ? f : F - 1)];
         }
-        asm volatile("" ::: "memory");
+      } else {
 #pragma unroll
-        for (int i = 0; i < STEP; ++i) {
-          const int e = tid + 256 * (i0 + i), f = e / CB, c = e % CB;
-          sC[e] = (f < F && c0 + c < B) ? v[i] : 0.f;
+        for (int i = 0; i < PER; ++i) {
+          const int e = tid + 512 * i, c = e / FP, f = e % FP;
+          const int g = c0 + c < B ? c0 + c : B - 1;
+          int64_t cg = vw.cur_idx[g];
+          cg = cg < 0 ? 0 : (cg > N - 1 ? N - 1 : cg);
+          v[i] = nodes[((size_t)g * N + cg) * F + (f < F ? f : F - 1)];
         }
       }
-    }
-    for (int c = tid; c < CB; c += 256) sCn[c] = c0 + c < B ? ws_cnorm[c0 + c] : 0.f;
-    __syncthreads();
-    if (wave_live) {
-      const int tiles = (min(CB, B - c0) + 31) / 32;
-      for (int ct = 0; ct < tiles; ++ct) {
-        f32x16 acc;
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int i = 0; i < PER; ++i) {
+        const int e = tid + 512 * i, c = e / FP, f = e % FP;
+        const float t = dist_param ? v[i] / inv_scale_den : v[i];
+        sC[f * CS + c] = (f < F && c0 + c < B) ? t : 0.f;
+      }
+    }
+    __syncthreads();
+    DSTAMP(3);
+    if (tid < CB) {   // |c|^2, features in ascending order
+      float s = 0.f;
+      for (int f = 0; f < FP; ++f) s = fmaf(sC[f * CS + tid], sC[f * CS + tid], s);
+      sCn[tid] = s;
+    }
+    __syncthreads();
+    DSTAMP(4);
+    if (wave_live) {
+      float nn[16];   // |n|^2 of this lane's 16 accumulator rows
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nn[r] = sNn[r_base + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      // A operand (this wave's 32 node rows): the same for every column tile - read once
+      float av[FP / 2];
+      {
         const float* ap = sN + (r_base + li) * NS + lh;        // A(i=row, k=f)
-        const float* bp = sC + lh * CB + ct * 32 + li;         // B(k=f, j=b')
-#pragma unroll 8
-        for (int k = 0; k < FP; k += 2)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * CB], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < FP / 2; ++q) av[q] = ap[2 * q];
+      }
+      // Two column tiles at a time, their MFMA chains interleaved (a dependent 32x32x2 chain alone
+      // leaves the matrix pipe idle between issues); B operands in registers before the chains start
+      const int n_t = min(HT, (B - c0 - ch * HT * 32 + 31) / 32);   // column tiles of this wave in this chunk
+      auto load_b = [&](int t, float (&dst)[FP / 2]) {
+        const float* bp = sC + lh * CS + (ch * HT + t) * 32 + li;   // B(k=f, j=b')
+#pragma unroll
+        for (int q = 0; q < FP / 2; ++q) dst[q] = bp[2 * q * CS];
+      };
+      auto finish = [&](const f32x16& acc, int t) {
+        const int ct = ch * HT + t;
         const int col = c0 + ct * 32 + li;
         const float cn = sCn[ct * 32 + li];
+        const float keep = col < B ? 1.f : 0.f;
+        // v_sqrt_f32 (1 ulp) instead of the correctly rounded library routine (a dozen instructions):
+        // the epilogue is otherwise as long as the MFMA chain
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = r_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const float d2 = sNn[row] + cn - 2.f * acc[r];
-          rowsum[r] += col < B ? sqrtf(fmaxf(d2, 0.f)) : 0.f;
+          const float d2 = fmaf(-2.f, acc[r], nn[r] + cn);
+          rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(d2, 0.f)), rowsum[r]);
+        }
+      };
+#pragma unroll
+      for (int t = 0; t < HT; t += 2) {
+        if (t < n_t) {
+          float b0[FP / 2], b1[FP / 2];
+          const bool two = t + 1 < n_t;
+          load_b(t, b0);
+          load_b(two ? t + 1 : t, b1);
+          f32x16 acc0, acc1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+          for (int q = 0; q < FP / 2; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc1, 0, 0, 0);
+          }
+#ifdef GCM_EUCLID_NO_EPILOGUE   // (diagnostic: the MFMA chains alone)
+          rowsum[0] += acc0[0] + acc1[0];
+#else
+          finish(acc0, t);
+          if (two) finish(acc1, t + 1);
+#endif
         }
       }
     }
   }
-  if (!wave_live) return;
-  // sum over the 32 columns held by the lanes of each half-wave
+  DSTAMP(5);
+  // sum over the 32 columns held by the lanes of each half-wave, then the two column halves
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float v = rowsum[r];
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     rowsum[r] = v;
   }
+  if (ch == 1 && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sHalf[r_base + (r & 3) + 8 * (r >> 2) + 4 * lh] = rowsum[r];
+  }
+  __syncthreads();
+  if (!wave_live || ch == 1) return;
   if (li == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = j0 + r_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int rl = r_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int j = j0 + rl;
       if (j >= N) continue;
-      const float d = rowsum[r] / (float)B;
+      const float d = (rowsum[r] + sHalf[rl]) / (float)B;
       if (dist_out) dist_out[(size_t)b * N + j] = d;
       if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
     }
   }
-}
-
-// current rows (scaled) transposed to [F][B] + their squared norms
-__global__ void k_gather_curT(View vw, const float* __restrict__ dist_param,
-                              float* __restrict__ ws_curT, float* __restrict__ ws_cnorm, int B, int N,
-                              int F) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int sh;
-  const int c = view_cur(vw, b, N, sh);
-  const float* row = view_cur_row(vw, b, c, N, F);
-  float s = 0.f;
-  for (int f = 0; f < F; ++f) {
-    float v = row[f];
-    if (dist_param) v = v / dist_param[0];
-    ws_curT[(size_t)f * B + b] = v;
-    s = fmaf(v, v, s);
-  }
-  ws_cnorm[b] = s;
+  DSTAMP(6);
 }
 
 // per-graph modes: one thread per (b, j)
@@ -319,23 +378,17 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
   hipStream_t s = (hipStream_t)stream;
   if (mode == GCM_DIST_EUCLID_CROSSBATCH) {
     if (F > 128 || B > 65535) return GCM_EUNSUPPORTED;
-    GCM_REQUIRE(workspace);
-    if (workspace_bytes < ((size_t)B * F + B) * sizeof(float)) return GCM_EWORKSPACE;
-    float* ws_cur = (float*)workspace;
     if (B >= 32) {   // matrix-core path (torch.cdist's own switch to the mm formulation is at 25)
-      float* ws_cnorm = ws_cur + (size_t)B * F;
-      hipLaunchKernelGGL(k_gather_curT, dim3((B + 127) / 128), dim3(128), 0, s, vw, dist_param, ws_cur,
-                         ws_cnorm, B, N, F);
       dim3 grid((N + 127) / 128, B);
       const int FT = (F + 31) / 32;
       const int CBv = FT >= 4 ? 128 : 256;
-      const size_t lds = sizeof(float) * ((size_t)128 * (32 * FT + 1) + (size_t)32 * FT * CBv + 128 + CBv);
+      const size_t lds = sizeof(float) * ((size_t)128 * (32 * FT + 1) + (size_t)32 * FT * (CBv + 1) + 256 + CBv);
 #define GCM_EUCLID_MFMA(FTv)                                                                     \
   {                                                                                              \
     auto kern = k_euclid_mfma<FTv>;                                                              \
     gcm_allow_dynamic_lds((const void*)kern, lds);                                               \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, vw, ws_cur, ws_cnorm, dist_param, adj,     \
-                       sel_row, dist_out, max_distance, bidirectional, B, N, F);                 \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, vw, dist_param, adj, sel_row, dist_out,    \
+                       max_distance, bidirectional, B, N, F);                                    \
   }
       switch (FT) {
         case 1: GCM_EUCLID_MFMA(1) break;
@@ -346,6 +399,9 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
 #undef GCM_EUCLID_MFMA
       return gcm_launch_status();
     }
+    GCM_REQUIRE(workspace);
+    if (workspace_bytes < ((size_t)B * F + B) * sizeof(float)) return GCM_EWORKSPACE;
+    float* ws_cur = (float*)workspace;
     hipLaunchKernelGGL(k_gather_cur, dim3((B * F + 255) / 256), dim3(256), 0, s, vw, dist_param, ws_cur,
                        B, N, F);
     dim3 grid((N + 127) / 128, B);
