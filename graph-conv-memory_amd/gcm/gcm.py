@@ -574,6 +574,9 @@ class DenseGCM(torch.nn.Module):
         cfg = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
         if cfg is not None and (cfg.learned_sel is not None or cfg.fold is not None):
             cfg = None                    # LearnedEdge / folded transforms: the per-step kernels, in a loop
+        elif (cfg is not None and cfg.has_distance and cfg.rows_ok
+              and not (torch.is_grad_enabled() and (obs.requires_grad or nodes.requires_grad))):
+            cfg = None                    # distance selectors: selector kernel + live-row step per step
         if cfg is None:
             outs = []
             for t in range(obs.shape[0]):

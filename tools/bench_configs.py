@@ -99,6 +99,8 @@ B, N, F, H, T = 256, 128, 64, 32, 128
 c = 4 * torch.randn(8, F)
 obs3 = (c[torch.arange(T) % 8][:, None, :] + 0.05 * torch.randn(T, B, F)).to(dev)
 run_dense("cfg3 EuclideanEdge(2.0) cross-batch", B, N, F, H, T, EuclideanEdge(2.0), obs3, iters=3)
+run_dense("cfg3 EuclideanEdge(2.0) cross-batch, donated state", B, N, F, H, T, EuclideanEdge(2.0), obs3, iters=3,
+          donate_state=True)
 # cfg2's shape behind the RLlib model's default preprocessor (ray_gcm.py:117): folded into the step
 B, N, F, H, T = 256, 128, 32, 32, 128
 run_dense("cfg2 + Linear(32,32) preprocessor (folded), donated", B, N, F, H, T, TemporalBackedge([1, 2, 4]),

@@ -45,8 +45,9 @@ for k in sorted(fetch):
         "note": "corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 counts 128-B read requests as 64 B)"})
 path = os.path.join(ROOT, "profiles", f"{tag}_traffic_detail.json")
 json.dump(out, open(path, "w"), indent=1)
-flat = {k: v["bytes_corrected"] for k, v in out.items()}
-json.dump(flat, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+if "--keep-traffic-json" not in sys.argv:      # (a side profile: profiles/traffic.json stays the bench's)
+    flat = {k: v["bytes_corrected"] for k, v in out.items()}
+    json.dump(flat, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for k, v in out.items():
     print(f"{k:24s} launches={v['launches']:5d} fetch={v['FETCH_SIZE_KiB'] / 1024:8.2f} MiB "
           f"write={v['WRITE_SIZE_KiB'] / 1024:8.2f} MiB corrected={v['bytes_corrected'] / 1e6:8.2f} MB")
