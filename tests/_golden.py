@@ -68,6 +68,32 @@ def fp64_bound(ref, obs, hidden, out32, **kw):
     return out64, max(2e-6, 3.0 * err32)
 
 
+def fp64_grad_bound(ref, fx, sel, loss="mean", floor=5e-7, factor=3.0):
+    """Gradient tolerances from the same rollout evaluated in float64 by the oracle: for every GNN
+    parameter (and the observations) -> (g64, atol) with atol = max(factor x the error of the REFERENCE's
+    own fp32 gradient against float64, floor x the gradient's scale).  In practice ~1e-6 of the
+    gradient scale - two orders tighter than a 1e-4 rtol - and it scales with what fp32 can deliver for
+    the case at hand (long sums: DenseEdge) instead of a fixed number."""
+    import copy
+    from oracle import dense as od
+    m = fx.meta
+    ref64 = copy.deepcopy(ref).double()
+    h0 = fx.h0()
+    h64 = None if h0 is None else tuple(t.double() if t.is_floating_point() else t.clone() for t in h0)
+    obs64 = fx["obs"].double().requires_grad_(True)
+    out64, _ = od.dense_rollout(obs64, h64, ref64, graph_size=m["N"], edge_selectors=sel)
+    assert loss == "mean"
+    out64.mean().backward()
+    res = {}
+    for k, p in list(ref64.named_parameters()) + [("obs", obs64)]:
+        g64 = p.grad
+        want32 = fx["grad_obs"] if k == "obs" else fx["grad:" + k]
+        scale = float(g64.abs().max())
+        err_ref = float((want32.double() - g64).abs().max())
+        res[k] = (g64, max(factor * err_ref, floor * scale))
+    return res
+
+
 # ---- G15 (folded preprocessor / aux selectors / positional encoding): how each fixture's module
 # was put together in tests/golden/make_golden.py -----------------------------------------------
 FOLD_SPECS = {
