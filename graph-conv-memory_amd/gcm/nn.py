@@ -88,8 +88,11 @@ class GraphConv(torch.nn.Module):
         if graph is None or graph.M != x.shape[0]:
             graph = _ops.GraphIndex.from_edge_index(edge_index, x.shape[0])
         w = edge_weight
-        if w is not None and w.numel() != graph.E:
-            w = None                      # PyG: a weight vector of the wrong length is ignored
+        if w is not None and (w.numel() != graph.E or getattr(w, "gcm_unit_weights", False)):
+            # PyG: a weight vector of the wrong length is ignored.  Unit weights without a gradient
+            # (what SparseGCM passes unless a learned selector is in play: sparse_gcm.py:160-164) multiply
+            # by exactly 1: the kernel then skips the weight loads altogether
+            w = None
         if w is not None and graph.csr_perm is not None:
             w = w[graph.csr_perm]
         return _ops.csr_graphconv(x, w, self.lin_rel.weight, self.lin_rel.bias,

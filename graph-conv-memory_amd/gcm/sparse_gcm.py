@@ -136,7 +136,10 @@ class SparseGCM(torch.nn.Module):
 
         # sparse_gcm.py:160-164: all weights become 1 while keeping the path to the logits
         v = adj.values()
+        unit = not v.requires_grad
         v = v / v.detach() if v.requires_grad else torch.ones_like(v)
+        if unit:
+            v.gcm_unit_weights = True      # lets gcm.nn.GraphConv skip the multiplication by 1
         adj = torch.sparse_coo_tensor(adj.indices(), v, size=adj.shape, is_coalesced=True)
 
         flat_nodes = _ops.sparse_flatten(dirty_nodes, T, taus, node_off, M)
