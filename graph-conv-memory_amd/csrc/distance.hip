@@ -203,32 +203,36 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
 
   for (int c0 = 0; c0 < B; c0 += CB) {
     __syncthreads();
-    {   // current rows of this chunk of graphs -> [F][CS], every load in flight before the first store
-      constexpr int PER = FP * CB / 512;
-      float v[PER];
-      if (vw.count) {   // (uniform) the current nodes are the observations: no index to chase
+    {   // current rows of this chunk of graphs -> [F][CS]; a batch of loads in flight before its stores
+      constexpr int PER = FP * CB / 512, STEP = PER <= 32 ? PER : 16;
+      static_assert(PER % STEP == 0, "chunking");
+#pragma unroll 1
+      for (int i0 = 0; i0 < PER; i0 += STEP) {
+        float v[STEP];
+        if (vw.count) {   // (uniform) the current nodes are the observations: no index to chase
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-          const int e = tid + 512 * i, c = e / FP, f = e % FP;
-          const int g = c0 + c < B ? c0 + c : B - 1;
-          v[i] = vw.obs[(size_t)g * F + (f < F ? f : F - 1)];
+          for (int i = 0; i < STEP; ++i) {
+            const int e = tid + 512 * (i0 + i), c = e / FP, f = e % FP;
+            const int g = c0 + c < B ? c0 + c : B - 1;
+            v[i] = vw.obs[(size_t)g * F + (f < F ? f : F - 1)];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < STEP; ++i) {
+            const int e = tid + 512 * (i0 + i), c = e / FP, f = e % FP;
+            const int g = c0 + c < B ? c0 + c : B - 1;
+            int64_t cg = vw.cur_idx[g];
+            cg = cg < 0 ? 0 : (cg > N - 1 ? N - 1 : cg);
+            v[i] = nodes[((size_t)g * N + cg) * F + (f < F ? f : F - 1)];
+          }
         }
-      } else {
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-          const int e = tid + 512 * i, c = e / FP, f = e % FP;
-          const int g = c0 + c < B ? c0 + c : B - 1;
-          int64_t cg = vw.cur_idx[g];
-          cg = cg < 0 ? 0 : (cg > N - 1 ? N - 1 : cg);
-          v[i] = nodes[((size_t)g * N + cg) * F + (f < F ? f : F - 1)];
+        for (int i = 0; i < STEP; ++i) {
+          const int e = tid + 512 * (i0 + i), c = e / FP, f = e % FP;
+          const float t = dist_param ? v[i] / inv_scale_den : v[i];
+          sC[f * CS + c] = (f < F && c0 + c < B) ? t : 0.f;
         }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int e = tid + 512 * i, c = e / FP, f = e % FP;
-        const float t = dist_param ? v[i] / inv_scale_den : v[i];
-        sC[f * CS + c] = (f < F && c0 + c < B) ? t : 0.f;
       }
     }
     __syncthreads();
@@ -244,21 +248,7 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
       float nn[16];   // |n|^2 of this lane's 16 accumulator rows
 #pragma unroll
       for (int r = 0; r < 16; ++r) nn[r] = sNn[r_base + (r & 3) + 8 * (r >> 2) + 4 * lh];
-      // A operand (this wave's 32 node rows): the same for every column tile - read once
-      float av[FP / 2];
-      {
-        const float* ap = sN + (r_base + li) * NS + lh;        // A(i=row, k=f)
-#pragma unroll
-        for (int q = 0; q < FP / 2; ++q) av[q] = ap[2 * q];
-      }
-      // Two column tiles at a time, their MFMA chains interleaved (a dependent 32x32x2 chain alone
-      // leaves the matrix pipe idle between issues); B operands in registers before the chains start
       const int n_t = min(HT, (B - c0 - ch * HT * 32 + 31) / 32);   // column tiles of this wave in this chunk
-      auto load_b = [&](int t, float (&dst)[FP / 2]) {
-        const float* bp = sC + lh * CS + (ch * HT + t) * 32 + li;   // B(k=f, j=b')
-#pragma unroll
-        for (int q = 0; q < FP / 2; ++q) dst[q] = bp[2 * q * CS];
-      };
       auto finish = [&](const f32x16& acc, int t) {
         const int ct = ch * HT + t;
         const int col = c0 + ct * 32 + li;
@@ -272,27 +262,51 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
           rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(d2, 0.f)), rowsum[r]);
         }
       };
+      if constexpr (FT <= 2) {
+        // A operand (this wave's 32 node rows): the same for every column tile - read once; two column
+        // tiles at a time, their MFMA chains interleaved, B operands in registers before the chains start
+        float av[FP / 2];
+        {
+          const float* ap = sN + (r_base + li) * NS + lh;        // A(i=row, k=f)
 #pragma unroll
-      for (int t = 0; t < HT; t += 2) {
-        if (t < n_t) {
-          float b0[FP / 2], b1[FP / 2];
-          const bool two = t + 1 < n_t;
-          load_b(t, b0);
-          load_b(two ? t + 1 : t, b1);
-          f32x16 acc0, acc1;
+          for (int q = 0; q < FP / 2; ++q) av[q] = ap[2 * q];
+        }
+        auto load_b = [&](int t, float (&dst)[FP / 2]) {
+          const float* bp = sC + lh * CS + (ch * HT + t) * 32 + li;   // B(k=f, j=b')
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+          for (int q = 0; q < FP / 2; ++q) dst[q] = bp[2 * q * CS];
+        };
 #pragma unroll
-          for (int q = 0; q < FP / 2; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc1, 0, 0, 0);
+        for (int t = 0; t < HT; t += 2) {
+          if (t < n_t) {
+            float b0[FP / 2], b1[FP / 2];
+            const bool two = t + 1 < n_t;
+            load_b(t, b0);
+            load_b(two ? t + 1 : t, b1);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < FP / 2; ++q) {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc1, 0, 0, 0);
+            }
+            finish(acc0, t);
+            if (two) finish(acc1, t + 1);
           }
-#ifdef GCM_EUCLID_NO_EPILOGUE   // (diagnostic: the MFMA chains alone)
-          rowsum[0] += acc0[0] + acc1[0];
-#else
-          finish(acc0, t);
-          if (two) finish(acc1, t + 1);
-#endif
+        }
+      } else {
+        // wide features: operands stay in LDS (the register-resident form would spill)
+        for (int t = 0; t < n_t; ++t) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const float* ap = sN + (r_base + li) * NS + lh;
+          const float* bp = sC + lh * CS + (ch * HT + t) * 32 + li;
+#pragma unroll 8
+          for (int k = 0; k < FP; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * CS], acc, 0, 0, 0);
+          finish(acc, t);
         }
       }
     }

@@ -252,7 +252,7 @@ def test_distance_matrix_matches_oracle():
         torch.testing.assert_close(d[self_entry], want[self_entry], rtol=1e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("B,N,F,learned", [(40, 50, 24, False), (64, 128, 64, True), (33, 20, 100, False),
+@pytest.mark.parametrize("B,N,F,learned", [(40, 50, 24, False), (64, 128, 64, True), (33, 20, 100, False), (48, 40, 80, True),
                                             (300, 16, 128, False)])
 def test_euclid_matrix_core_path(B, N, F, learned):
     """B >= 32 runs the MFMA formulation (|n|^2+|c|^2-2nc, like torch.cdist above 25 rows)."""
