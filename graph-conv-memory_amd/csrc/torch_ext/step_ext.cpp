@@ -19,6 +19,7 @@
 #include <torch/extension.h>
 
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "gcm_hip.h"
@@ -372,6 +373,155 @@ std::vector<at::Tensor> rows_step(const at::Tensor& obs, const at::Tensor& nodes
   return {mx, nodes_out, adj_out, count_out};
 }
 
+// ---------------------------------------------------------------------------------------------
+// DenseGCM + LearnedEdge (default edge network, observations without gradient) as ONE node per step:
+// the host twin of gcm/_ops.py:_LearnedStep (same C-ABI calls: gcm_state_advance_fwd,
+// gcm_learned_select_fused, gcm_dense_gnn2_row_fwd forward; gcm_learned_step_bwd backward).  The Python
+// Function cost ~80 us of interpreter / trampoline time per step against ~80 us of kernels.
+// Differentiable inputs: the gated packed vector (GNN | edge network) and the chain proxy whose
+// GRADIENT is the adjacency-gradient chain buffer GA [B,N,N] (handed down the steps, mutated in place).
+// ---------------------------------------------------------------------------------------------
+struct LearnedCfg {
+  int N, F, H1, H2, act1, act2, has_bias;
+  double eps0, eps1, cutoff;
+  int64_t P, P_total;
+  std::unordered_map<int, at::Tensor> zero_chain, zero_params;   // per device
+  LearnedCfg(int N_, int F_, int H1_, int H2_, int act1_, int act2_, int has_bias_, double e0, double e1,
+             double cutoff_)
+      : N(N_), F(F_), H1(H1_), H2(H2_), act1(act1_), act2(act2_), has_bias(has_bias_), eps0(e0), eps1(e1),
+        cutoff(cutoff_) {
+    P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2);
+    P_total = P + (int64_t)gcm_learned_mlp_param_count(F);
+  }
+};
+
+struct LearnedStepFn : public torch::autograd::Function<LearnedStepFn> {
+  static variable_list forward(AutogradContext* ctx, at::Tensor packed, at::Tensor dchain_in, at::Tensor obs,
+                               at::Tensor nodes_in, at::Tensor adj_in, at::Tensor count_in, at::Tensor noise,
+                               int64_t noise_is_exp, at::Tensor flags, int64_t cfg_handle, int64_t stream,
+                               int64_t need_bwd_, at::Tensor slab_acc, int64_t is_head) {
+    LearnedCfg* cfg = reinterpret_cast<LearnedCfg*>(cfg_handle);
+    obs = obs.contiguous();
+    nodes_in = nodes_in.contiguous();
+    adj_in = adj_in.contiguous();
+    noise = noise.contiguous();
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = need_bwd_ != 0;
+    const Layout L(B, N, F, H1, H2, need_bwd);          // nodes | adj | mx | h1 | agg1 | agg2 | cur, count
+    const int64_t o_soft = L.total;
+    at::Tensor buf = at::empty({L.total + pad64(B * (int64_t)N)}, obs.options());
+    at::Tensor ibuf = buf.narrow(0, L.o_idx, 4 * B).view(at::kLong).view({2, B});
+    float* base = buf.data_ptr<float>();
+    int64_t* ib = ibuf.data_ptr<int64_t>();
+    uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
+    gcm_stream_t st = reinterpret_cast<gcm_stream_t>(stream);
+    const float* pk = packed.data_ptr<float>();
+    check(gcm_state_advance_fwd(nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(), nullptr,
+                                count_in.data_ptr<int64_t>(), obs.data_ptr<float>(), base, base + L.o_adj,
+                                nullptr, ib, ib + B, fl, (int)B, N, F, st),
+          "gcm_state_advance_fwd");
+    check(gcm_learned_select_fused(base, base + L.o_adj, ib, noise.data_ptr<float>(), (int)noise_is_exp,
+                                   pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff,
+                                   base + o_soft, (int)B, N, F, st),
+          "gcm_learned_select_fused");
+    const float* w_rel1 = pk;
+    const float* w_root1 = w_rel1 + (size_t)H1 * F;
+    const float* b1 = w_root1 + (size_t)H1 * F;
+    const float* w_rel2 = b1 + H1;
+    const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+    const float* b2 = w_root2 + (size_t)H2 * H1;
+    check(gcm_dense_gnn2_row_fwd(base, base + L.o_adj, ib, w_rel1, (cfg->has_bias & 1) ? b1 : nullptr, w_root1,
+                                 cfg->act1, w_rel2, (cfg->has_bias & 2) ? b2 : nullptr, w_root2, cfg->act2,
+                                 base + L.o_mx, need_bwd ? base + L.o_h1 : nullptr,
+                                 need_bwd ? base + L.o_agg1 : nullptr, need_bwd ? base + L.o_agg2 : nullptr, fl,
+                                 (int)B, N, F, H1, H2, st),
+          "gcm_dense_gnn2_row_fwd");
+    at::Tensor nodes_out = buf.narrow(0, 0, B * N * F).view({B, N, F});
+    at::Tensor adj_out = buf.narrow(0, L.o_adj, B * (int64_t)N * N).view({B, N, N});
+    at::Tensor mx = buf.narrow(0, L.o_mx, B * H2).view({B, H2});
+    at::Tensor cur = ibuf.select(0, 0), count_out = ibuf.select(0, 1);
+    const int dev = obs.get_device();
+    at::Tensor& z = cfg->zero_chain[dev];
+    if (!z.defined()) z = at::zeros({1, 1, 1}, obs.options());
+    at::Tensor dchain_out = z.expand({B, N, N});   // a fresh view per call: it gets this node as grad_fn
+    if (need_bwd) {
+      ctx->save_for_backward({packed, count_in});
+      ctx->saved_data["buf"] = buf;
+      ctx->saved_data["cfg"] = cfg_handle;
+      ctx->saved_data["slab"] = slab_acc;
+      ctx->saved_data["head"] = is_head;
+      ctx->saved_data["o_soft"] = o_soft;
+      ctx->saved_data["stream"] = stream;   // the engine runs the backward on the forward's stream
+      ctx->saved_data["need_chain"] = (int64_t)(dchain_in.requires_grad() ? 1 : 0);
+    }
+    ctx->mark_non_differentiable({nodes_out, adj_out, cur, count_out});
+    ctx->set_materialize_grads(false);
+    return {mx, dchain_out, nodes_out, adj_out, cur, count_out};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list out(14);
+    if (!grads[0].defined() && !grads[1].defined()) return out;
+    LearnedCfg* cfg = reinterpret_cast<LearnedCfg*>(ctx->saved_data["cfg"].toInt());
+    auto saved = ctx->get_saved_variables();
+    const at::Tensor& packed = saved[0];
+    const at::Tensor& count_in = saved[1];
+    at::Tensor buf = ctx->saved_data["buf"].toTensor();
+    at::Tensor slab = ctx->saved_data["slab"].toTensor();
+    const int64_t o_soft = ctx->saved_data["o_soft"].toInt();
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const int64_t B = count_in.size(0);
+    const Layout L(B, N, F, H1, H2, true);
+    at::Tensor g_mx = grads[0].defined() ? grads[0] : at::zeros({B, H2}, buf.options());
+    if (g_mx.scalar_type() != at::kFloat || !g_mx.is_contiguous()) g_mx = g_mx.to(at::kFloat).contiguous();
+    // the chain buffer: handed down from the step after this one (mutated in place), or new
+    at::Tensor D;
+    if (grads[1].defined())
+      D = grads[1].is_contiguous() ? grads[1] : grads[1].contiguous();
+    else
+      D = at::zeros({B, N, N}, buf.options());
+    float* base = buf.data_ptr<float>();
+    const float* pk = packed.data_ptr<float>();
+    const int64_t* ib = reinterpret_cast<const int64_t*>(base + L.o_idx);
+    check(gcm_learned_step_bwd(g_mx.data_ptr<float>(), base, base + L.o_adj, ib, count_in.data_ptr<int64_t>(), pk,
+                               cfg->act1, cfg->act2, base + L.o_mx, base + L.o_h1, base + L.o_agg1,
+                               base + L.o_agg2, base + o_soft, pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1,
+                               D.data_ptr<float>(), slab.data_ptr<float>(), 1, (int)B, N, F, H1, H2,
+                               reinterpret_cast<gcm_stream_t>(ctx->saved_data["stream"].toInt())),
+          "gcm_learned_step_bwd");
+    if (ctx->saved_data["head"].toInt() != 0) {   // a defined gradient: the gate runs
+      at::Tensor& zp = cfg->zero_params[(int)buf.get_device()];
+      if (!zp.defined()) zp = at::zeros({cfg->P_total}, buf.options());
+      out[0] = zp;
+    }
+    if (ctx->saved_data["need_chain"].toInt() != 0) out[1] = D;
+    return out;
+  }
+};
+
+std::vector<at::Tensor> learned_step(const at::Tensor& packed, const at::Tensor& dchain_in, const at::Tensor& obs,
+                                     const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                                     const at::Tensor& count_in, const at::Tensor& noise, int64_t noise_is_exp,
+                                     const at::Tensor& flags, int64_t cfg_handle, int64_t stream,
+                                     const c10::optional<at::Tensor>& slab_acc, bool is_head) {
+  TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() && packed.is_cuda() &&
+                  noise.is_cuda() && flags.is_cuda(),
+              "learned_step: every tensor must live on a HIP device (no CPU fallback)");
+  LearnedCfg* cfg = reinterpret_cast<LearnedCfg*>(cfg_handle);
+  TORCH_CHECK(packed.is_contiguous() && packed.numel() >= cfg->P_total && count_in.is_contiguous() &&
+              obs.scalar_type() == at::kFloat && count_in.scalar_type() == at::kLong);
+  const int64_t B = obs.size(0);
+  TORCH_CHECK(nodes_in.size(0) == B && nodes_in.size(1) == cfg->N && nodes_in.size(2) == cfg->F &&
+                  adj_in.size(0) == B && adj_in.size(1) == cfg->N && adj_in.size(2) == cfg->N &&
+                  count_in.size(0) == B && obs.size(1) == cfg->F && noise.numel() == B * cfg->N,
+              "learned_step: hidden state, observation and noise shapes disagree");
+  const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad() && slab_acc.has_value();
+  return LearnedStepFn::apply(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags,
+                              cfg_handle, stream, (int64_t)need_bwd, need_bwd ? *slab_acc : at::Tensor(),
+                              (int64_t)is_head);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -391,4 +541,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return h.flush(packed, g.has_value() ? *g : at::Tensor(), stream);
       });
   m.def("rows_step", &rows_step);
+  pybind11::class_<LearnedCfg>(m, "LearnedCfg")
+      .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())
+      .def("handle", [](LearnedCfg& c) { return reinterpret_cast<int64_t>(&c); });
+  m.def("learned_step", &learned_step);
 }

@@ -664,6 +664,20 @@ class StepConfig:
         self._zero_chain, self._zero_params = {}, {}
         self.rows_ok = False
 
+    def learned_cpp_handle(self):
+        """address of the C++ twin of the learned-step config (0 when the extension lacks it)"""
+        h = getattr(self, "_learned_cpp_h", None)
+        if h is None:
+            ext = _ext.module()
+            if ext is None or not hasattr(ext, "LearnedCfg") or TIMER is not None:
+                h = 0
+            else:
+                self._learned_cpp = ext.LearnedCfg(self.N, self.F, self.H1, self.H2, self.acts[0], self.acts[1],
+                                                   self.has_bias, self.eps[0], self.eps[1], self.cutoff)
+                h = self._learned_cpp.handle()
+            self._learned_cpp_h = h
+        return h
+
     def zero_chain(self, B, dev):
         """the proxy whose GRADIENT is the adjacency-gradient chain buffer: a [B,N,N] view of one
         zero (no memory)"""
@@ -1096,6 +1110,13 @@ class _LearnedStep(torch.autograd.Function):
 
 def learned_step(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags, cfg,
                  slab_acc, is_head):
+    """The per-step node of DenseGCM + LearnedEdge: the C++ autograd node when gcm/_lib/ext is built (same
+    C-ABI calls, no interpreter on the path), else the Python Function above."""
+    h = cfg.learned_cpp_handle()
+    if h:
+        return _ext.module().learned_step(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise,
+                                          int(noise_is_exp), flags, h,
+                                          torch._C._cuda_getCurrentRawStream(obs.device.index), slab_acc, is_head)
     return _LearnedStep.apply(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags,
                               cfg, slab_acc, is_head)
 

@@ -115,6 +115,7 @@ class DenseGCM(torch.nn.Module):
         self.donate_state = donate_state
         self._plan_cache = None
         self._fold = None     # set by _structure(): what the live-row step absorbs besides the GNN
+        self._noise_pool = None   # [exponential draws [16, B, N], next index] of the fused LearnedEdge step
         self._token = object()   # identifies hidden states produced by this module (_gcm_link)
         self._cfg_cache = {}
         self._cfg_last = None
@@ -509,7 +510,15 @@ class DenseGCM(torch.nn.Module):
         if sel.noise_fn is not None:      # injected gumbel draws (parity tests); values of the argument unspecified
             noise, is_exp = sel.noise_fn(torch.empty(B, cfg.N, device=x.device)), 0
         else:                             # torch.nn.functional.gumbel_softmax draws -log(Exp(1)) the same way
-            noise, is_exp = torch.empty(B, cfg.N, device=x.device).exponential_(), 1
+            # (16 steps' worth per draw: one RNG launch instead of sixteen)
+            # A pool drawn outside a HIP-graph capture is not used inside one (and vice versa): the
+            # captured kernels would keep reading its address after it has been replaced.
+            pool, cap = self._noise_pool, torch.cuda.is_current_stream_capturing()
+            if (pool is None or pool[1] >= 16 or pool[2] != cap or pool[0].shape[1] != B
+                    or pool[0].device != x.device):
+                pool = self._noise_pool = [torch.empty(16, B, cfg.N, device=x.device).exponential_(), 0, cap]
+            noise, is_exp = pool[0][pool[1]], 1
+            pool[1] += 1
         if gated is not None:
             is_head = link is None or link[5] is not root
             dchain = getattr(adj, "_gcm_dchain", None) if not is_head else None
