@@ -142,36 +142,37 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
 // half (w >> 2) of every chunk; sqrt and the mean over b' run on the accumulators, the two halves
 // meet in LDS in fixed order.  Rows >= cur are skipped (distance.py:31-33).
 // ---------------------------------------------------------------------------
-template <int FT>   // F padded to 32*FT
+template <int FT, int RB, int CB>   // F padded to 32 FT; RB node rows per workgroup; CB graphs per LDS chunk
 __global__ __launch_bounds__(512) void k_euclid_mfma(
     View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
     float* __restrict__ sel_row, float* __restrict__ dist_out, float max_distance, int bidirectional,
     int B, int N, int F) {
   const float* __restrict__ nodes = vw.nodes;
-  constexpr int FP = 32 * FT, NS = FP + 1;
-  constexpr int CB = FT >= 4 ? 128 : 256;   // graphs per LDS chunk of current rows (fits 160 KB)
-  constexpr int CS = CB + 1;
-  constexpr int HT = CB / 64;               // 32-column tiles per wave and chunk
-  const int b = blockIdx.y, j0 = blockIdx.x * 128;
+  constexpr int FP = 32 * FT, NS = FP + 1, CS = CB + 1;
+  constexpr int RWN = RB / 32;              // 32-row blocks of the workgroup
+  constexpr int CG = 8 / RWN;               // column groups: wave = (row block, column group)
+  constexpr int HT = CB / (32 * CG);        // 32-column tiles per wave and chunk
+  static_assert(RB % 32 == 0 && 8 % RWN == 0 && HT >= 1 && CB % (32 * CG) == 0, "tiling");
+  const int b = blockIdx.y, j0 = blockIdx.x * RB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int rw = wave & 3, ch = wave >> 2;
+  const int rw = wave % RWN, ch = wave / RWN;
   int sh;
   const int cur = view_cur(vw, b, N, sh);
   if (j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows
 
   extern __shared__ float smem[];
-  float* sN = smem;                 // [128][NS]  node rows (scaled)
-  float* sC = sN + 128 * NS;        // [FP][CS]   current rows, transposed, one chunk of CB graphs
-  float* sNn = sC + FP * CS;        // [128] |n|^2
-  float* sCn = sNn + 128;           // [CB]  |c|^2
-  float* sHalf = sCn + CB;          // [128] row sums of column half 1
+  float* sN = smem;                 // [RB][NS]   node rows (scaled)
+  float* sC = sN + RB * NS;         // [FP][CS]   current rows, transposed, one chunk of CB graphs
+  float* sNn = sC + FP * CS;        // [RB] |n|^2
+  float* sCn = sNn + RB;            // [CB] |c|^2
+  float* sPart = sCn + CB;          // [CG - 1][RB] row sums of column groups 1 ..
 
   const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
   DSTAMP(0);
   // node rows of this block: every load in flight before the first LDS store (a load -> store loop
-  // exposes one memory round trip per element at one wave per SIMD)
+  // exposes one memory round trip per element)
   {
-    constexpr int PER = 128 * FP / 512;
+    constexpr int PER = RB * FP / 512;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
   }
   __syncthreads();
   DSTAMP(1);
-  if (tid < 128) {
+  if (tid < RB) {
     float s = 0.f;
     for (int f = 0; f < FP; ++f) s = fmaf(sN[tid * NS + f], sN[tid * NS + f], s);
     sNn[tid] = s;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
   for (int c0 = 0; c0 < B; c0 += CB) {
     __syncthreads();
     {   // current rows of this chunk of graphs -> [F][CS]; a batch of loads in flight before its stores
-      constexpr int PER = FP * CB / 512, STEP = PER <= 32 ? PER : 16;
+      constexpr int PER = FP * CB / 512, STEP = PER <= 16 ? PER : (PER % 16 == 0 ? 16 : 8);
       static_assert(PER % STEP == 0, "chunking");
 #pragma unroll 1
       for (int i0 = 0; i0 < PER; i0 += STEP) {
@@ -263,8 +264,8 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
         }
       };
       if constexpr (FT <= 2) {
-        // A operand (this wave's 32 node rows): the same for every column tile - read once; two column
-        // tiles at a time, their MFMA chains interleaved, B operands in registers before the chains start
+        // operands in registers before the MFMA chain starts: A (this wave's 32 node rows) once per
+        // chunk, B per column tile; with two tiles per chunk their chains are interleaved
         float av[FP / 2];
         {
           const float* ap = sN + (r_base + li) * NS + lh;        // A(i=row, k=f)
@@ -276,24 +277,35 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
 #pragma unroll
           for (int q = 0; q < FP / 2; ++q) dst[q] = bp[2 * q * CS];
         };
+        if constexpr (HT >= 2) {
 #pragma unroll
-        for (int t = 0; t < HT; t += 2) {
-          if (t < n_t) {
-            float b0[FP / 2], b1[FP / 2];
-            const bool two = t + 1 < n_t;
-            load_b(t, b0);
-            load_b(two ? t + 1 : t, b1);
-            f32x16 acc0, acc1;
+          for (int t = 0; t < HT; t += 2) {
+            if (t < n_t) {
+              float b0[FP / 2], b1[FP / 2];
+              const bool two = t + 1 < n_t;
+              load_b(t, b0);
+              load_b(two ? t + 1 : t, b1);
+              f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+              for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-            for (int q = 0; q < FP / 2; ++q) {
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc1, 0, 0, 0);
+              for (int q = 0; q < FP / 2; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b1[q], acc1, 0, 0, 0);
+              }
+              finish(acc0, t);
+              if (two) finish(acc1, t + 1);
             }
-            finish(acc0, t);
-            if (two) finish(acc1, t + 1);
           }
+        } else if (n_t > 0) {
+          float b0[FP / 2];
+          load_b(0, b0);
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int q = 0; q < FP / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], b0[q], acc, 0, 0, 0);
+          finish(acc, 0);
         }
       } else {
         // wide features: operands stay in LDS (the register-resident form would spill)
@@ -312,26 +324,29 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
     }
   }
   DSTAMP(5);
-  // sum over the 32 columns held by the lanes of each half-wave, then the two column halves
+  // sum over the 32 columns held by the lanes of each half-wave, then the column groups in fixed order
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float v = rowsum[r];
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     rowsum[r] = v;
   }
-  if (ch == 1 && li == 0) {
+  if (ch > 0 && li == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sHalf[r_base + (r & 3) + 8 * (r >> 2) + 4 * lh] = rowsum[r];
+    for (int r = 0; r < 16; ++r) sPart[(ch - 1) * RB + r_base + (r & 3) + 8 * (r >> 2) + 4 * lh] = rowsum[r];
   }
   __syncthreads();
-  if (!wave_live || ch == 1) return;
+  if (!wave_live || ch > 0) return;
   if (li == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = r_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int j = j0 + rl;
       if (j >= N) continue;
-      const float d = (rowsum[r] + sHalf[rl]) / (float)B;
+      float tot = rowsum[r];
+#pragma unroll
+      for (int g = 0; g < CG - 1; ++g) tot += sPart[g * RB + rl];
+      const float d = tot / (float)B;
       if (dist_out) dist_out[(size_t)b * N + j] = d;
       if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
     }
@@ -393,13 +408,19 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
   if (mode == GCM_DIST_EUCLID_CROSSBATCH) {
     if (F > 128 || B > 65535) return GCM_EUNSUPPORTED;
     if (B >= 32) {   // matrix-core path (torch.cdist's own switch to the mm formulation is at 25)
-      dim3 grid((N + 127) / 128, B);
+      // 128 node rows x 256-graph chunks per workgroup (one workgroup per CU at cfg3: B = 256 graphs of
+      // 128 nodes).  Measured against 64 rows x 128-graph chunks (two to three workgroups per CU, one's
+      // staging under another's MFMA phase): 21.3 us vs 23.7 us - the extra staging traffic and the
+      // single MFMA chain per wave cost more than the overlap returns.
+      constexpr int RB = 128;
+      dim3 grid((N + RB - 1) / RB, B);
       const int FT = (F + 31) / 32;
-      const int CBv = FT >= 4 ? 128 : 256;
-      const size_t lds = sizeof(float) * ((size_t)128 * (32 * FT + 1) + (size_t)32 * FT * (CBv + 1) + 256 + CBv);
+      const int CBv = FT >= 4 ? 128 : 256;   // (fits 160 KB of LDS)
+      const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)32 * FT * (CBv + 1) + RB + CBv +
+                                          (size_t)(8 / (RB / 32) - 1) * RB);
 #define GCM_EUCLID_MFMA(FTv)                                                                     \
   {                                                                                              \
-    auto kern = k_euclid_mfma<FTv>;                                                              \
+    auto kern = k_euclid_mfma<FTv, RB, (FTv >= 4 ? 128 : 256)>;                                  \
     gcm_allow_dynamic_lds((const void*)kern, lds);                                               \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, vw, dist_param, adj, sel_row, dist_out,    \
                        max_distance, bidirectional, B, N, F);                                    \
