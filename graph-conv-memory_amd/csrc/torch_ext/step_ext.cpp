@@ -282,35 +282,31 @@ struct RowsHolder {
   }
 };
 
-struct RowsStepFn : public torch::autograd::Function<RowsStepFn> {
-  // the only differentiable input is the (gated) packed parameter vector; mx the only output
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor packed, at::Tensor buf, int64_t B,
-                            int64_t H2, int64_t holder_handle, int64_t is_head) {
-    ctx->saved_data["buf"] = buf;
-    ctx->saved_data["holder"] = holder_handle;
-    ctx->saved_data["head"] = is_head;
-    ctx->set_materialize_grads(false);
-    return buf.narrow(0, 0, B * H2).view({B, H2});   // the record starts with the belief states
-  }
+// The step's autograd node, written against torch::autograd::Node directly: it has ONE differentiable
+// input (the gated packed parameter vector), ONE output (mx) and a backward that only records
+// (record, g_mx) - the Function<> wrapper (AutogradContext, saved-data dictionary, variable-list
+// marshalling, materialised gradients) cost more host time per step than the kernel takes.
+struct RowsNode : public torch::autograd::Node {
+  at::Tensor buf;
+  RowsHolder* holder = nullptr;
+  bool is_head = false;
 
-  static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    RowsHolder* holder = reinterpret_cast<RowsHolder*>(ctx->saved_data["holder"].toInt());
-    const bool is_head = ctx->saved_data["head"].toInt() != 0;
-    at::Tensor g_params;
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(1);
+    if (!buf.defined()) throw std::runtime_error("rows_step: backward through a released step record");
     if (grads[0].defined()) {
-      at::Tensor buf = ctx->saved_data["buf"].toTensor();
       at::Tensor g = grads[0];
       if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
       holder->recs.push_back({buf, g, g.size(0), g.stride(0), g.stride(1)});
     }
     if (is_head) {   // a defined gradient so that the gate is certain to run
-      if (!holder->zero_p.defined()) holder->zero_p = at::zeros({holder->total}, grads[0].defined()
-                                                                   ? grads[0].options().dtype(at::kFloat)
-                                                                   : ctx->saved_data["buf"].toTensor().options());
-      g_params = holder->zero_p;
+      if (!holder->zero_p.defined()) holder->zero_p = at::zeros({holder->total}, buf.options());
+      out[0] = holder->zero_p;
     }
-    return {g_params, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    return out;
   }
+  void release_variables() override { buf.reset(); }
+  std::string name() const override { return "GcmRowsStep"; }
 };
 
 // -> {mx, nodes_out, adj_out, count_out}; donate: the three state tensors are the inputs themselves
@@ -368,8 +364,15 @@ std::vector<at::Tensor> rows_step(const at::Tensor& obs, const at::Tensor& nodes
       reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2,
       reinterpret_cast<gcm_stream_t>(stream));
   check(rc, "gcm_dense_rows_step_fwd_ws");
-  at::Tensor mx = need_bwd ? RowsStepFn::apply(packed, buf, B, (int64_t)H2, holder_handle, (int64_t)is_head)
-                           : buf.narrow(0, 0, B * H2).view({B, H2});
+  at::Tensor mx = buf.narrow(0, 0, B * H2).view({B, H2});   // the record starts with the belief states
+  if (need_bwd) {
+    auto node = std::make_shared<RowsNode>();
+    node->buf = buf;
+    node->holder = reinterpret_cast<RowsHolder*>(holder_handle);
+    node->is_head = is_head;
+    node->set_next_edges(torch::autograd::collect_next_edges(packed));
+    torch::autograd::create_gradient_edge(mx, std::move(node));
+  }
   return {mx, nodes_out, adj_out, count_out};
 }
 
