@@ -389,3 +389,85 @@ def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
         for k_ in r[3]:
             scale = float(res[0][3][k_].abs().max()) + 1e-12
             torch.testing.assert_close(r[3][k_], res[0][3][k_], rtol=1e-4, atol=2e-5 * scale, msg=k_)
+
+
+@pytest.mark.parametrize("kind", ["fold_pre", "euclid", "learned"])
+def test_graph_capture_replay_other_step_kinds(kind):
+    """The folded step, a distance selector ahead of the step and the fused LearnedEdge step are free of
+    host syncs too: loop + backward captured once and replayed == the same loop run eagerly (state bit
+    exact; LearnedEdge with injected draws so that both runs sample the same edges)."""
+    from gcm import nn as G
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.distance import EuclideanEdge
+    from gcm.edge_selectors.learned import LearnedEdge
+    torch.manual_seed(3)
+    B, N, F, H, T = 40, 32, 32, 32, 40
+    centres = 3 * torch.randn(5, F)
+    obs = (centres[torch.arange(T) % 5][:, None, :] + 0.05 * torch.randn(T, B, F)).to(DEV)
+    noise = -torch.empty(T, B, N, device=DEV).exponential_().log()
+    step = {"t": 0}
+
+    def build():
+        torch.manual_seed(4)
+        g = G.Sequential("x, adj, weights, B, N", [
+            (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+            (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+        kw, mods = {}, [g]
+        if kind == "fold_pre":
+            kw = dict(preprocessor=torch.nn.Linear(F, F).to(DEV), edge_selectors=TemporalBackedge([1, 2]))
+            mods.append(kw["preprocessor"])
+        elif kind == "euclid":
+            kw = dict(edge_selectors=EuclideanEdge(3.0))
+        else:
+            sel = LearnedEdge(F, num_edge_samples=3).to(DEV)
+            sel.noise_fn = lambda logits: noise[step["t"]]
+            kw = dict(edge_selectors=sel)
+            mods.append(sel)
+        return DenseGCM(g, graph_size=N, **kw), mods
+
+    def rollout(mem):
+        hidden, outs = None, []
+        for t in range(T):
+            step["t"] = t
+            mx, hidden = mem(obs[t], hidden)
+            outs.append(mx)
+        out = torch.stack(outs)
+        (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
+        return out, hidden
+
+    mem_e, mods_e = build()
+    out_e, hid_e = rollout(mem_e)
+    mem_e.check_flags()
+    grads_e = [p.grad.clone() for m_ in mods_e for p in m_.parameters() if p.grad is not None]
+    assert float(hid_e[1].sum()) > 0
+
+    mem_g, mods_g = build()
+    params = [p for m_ in mods_g for p in m_.parameters()]
+    for _ in range(2):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for p in params:
+                p.grad = None
+            rollout(mem_g)
+        torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g, hid_g = rollout(mem_g)
+    for _ in range(2):
+        for p in params:
+            if p.grad is not None:
+                p.grad.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(hid_g[1].detach(), hid_e[1].detach()) and torch.equal(hid_g[0], hid_e[0])
+        torch.testing.assert_close(out_g.detach(), out_e.detach(), rtol=0, atol=0)
+        grads_g = [p.grad for p in params if p.grad is not None]
+        assert len(grads_g) == len(grads_e)
+        for a, b_ in zip(grads_g, grads_e):
+            torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6 * float(b_.abs().max()) + 1e-9)
+    mem_g.check_flags()
