@@ -59,6 +59,13 @@ __device__ __forceinline__ float gcm_act_sel(float v, int act_v) {
   out = act_v == GCM_ACT_RELU ? r : out;
   return out;
 }
+// d act / d pre, expressed through the activation OUTPUT y (activation code in a VGPR: selects)
+__device__ __forceinline__ float gcm_act_grad_sel(float y, int act_v) {
+  float g = 1.f;
+  g = act_v == GCM_ACT_TANH ? 1.f - y * y : g;
+  g = act_v == GCM_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : g;
+  return g;
+}
 // d act / d pre, expressed through the activation OUTPUT y
 __device__ __forceinline__ float gcm_act_grad(float y, int act) {
   if (act == GCM_ACT_TANH) return 1.f - y * y;

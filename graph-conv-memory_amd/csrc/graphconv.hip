@@ -945,6 +945,205 @@ __global__ __launch_bounds__(256) void k_rows_bwd2(
   }
 }
 
+// CSR GraphConv backward, third generation (Fi = Fo = 32, no k-hop mask, no edge-weight gradient):
+// the row-local adjoint AND the transpose aggregation in one pass, shaped like k_csr_fwd3 (one wave
+// per 32 rows, persistent, 16-byte accesses, no workgroup barrier in the loop).
+//   G   = g_out * act'(out)
+//   g_x[j] = G[j] W_root + (sum_{k in CSC column j} w_k G[sink_k]) W_rel        (NEED_X)
+//   dW_rel += G^T agg,  dW_root += G^T x,  db += colsum G                       (accumulated in the
+//   wave's registers over all its tiles; one slab per workgroup at the end, fixed order)
+// The second generation wrote G W_rel for every row (33.5 MB at cfg4), read it back through the CSC
+// gather and read-modify-wrote g_x: 325 MB per layer in two kernels; this one moves the four inputs and
+// g_x once (168 MB) - the gathered rows are the neighbours' g_out / out rows, which mostly hit in cache.
+template <bool HAS_W, bool NEED_X>
+__global__ __launch_bounds__(256) void k_csr_bwd3(
+    const float* __restrict__ g_out, const float* __restrict__ out, const float* __restrict__ x,
+    const float* __restrict__ agg, const int64_t* __restrict__ col_ptr,
+    const int64_t* __restrict__ rows_csc, const int64_t* __restrict__ perm,
+    const float* __restrict__ w, const float* __restrict__ w_rel, const float* __restrict__ w_root,
+    float* __restrict__ g_x, float* __restrict__ slabs, int64_t M, int act, int n_tiles) {
+  constexpr int FI = 32, FO = 32, AS = 36, WS = 20;
+  constexpr int NP = 4, RPP = 8;      // lane (lr = lane / 8, c4 = 4 (lane % 8)) owns rows lr + 8 i
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int act_v = gcm_vgpr(act);
+  extern __shared__ float smem[];
+  float* sG = smem + (size_t)wave * 3 * 32 * AS;   // G tile | agg tile (then the gathered G) | x tile
+  float* sA = sG + 32 * AS;
+  float* sX = sA + 32 * AS;
+  // weights for g_x = [GT | G] @ [W_rel | W_root] (K = o): sW[(m, kk, f)][16 o (+4)] = W_m[kk 16 + s][f]
+  float* sW = smem + (size_t)4 * 3 * 32 * AS;
+  for (int e = tid; e < 2 * FO * FI; e += 256) {
+    const int m = e / (FO * FI), rem = e - m * FO * FI, o = rem / FI, f = rem % FI;
+    sW[(size_t)((m * 2 + o / 16) * 32 + f) * WS + (o & 15)] = (m ? w_root : w_rel)[(size_t)o * FI + f];
+  }
+  __syncthreads();
+  const int lr = lane >> 3, c4 = (lane & 7) * 4;
+  const int n_waves = gridDim.x * 4;
+  f32x16 dwr, dwo;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dwr[r] = 0.f; dwo[r] = 0.f; }
+  float4 db4 = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of G over this lane's rows
+  auto act_grad4 = [&](const float4& g, const float4& y) {
+    return make_float4(g.x * gcm_act_grad_sel(y.x, act_v), g.y * gcm_act_grad_sel(y.y, act_v),
+                       g.z * gcm_act_grad_sel(y.z, act_v), g.w * gcm_act_grad_sel(y.w, act_v));
+  };
+#pragma unroll 1
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+    const int64_t r0 = (int64_t)tile * 32;
+    float4 gv[NP], yv[NP], xv[NP], av[NP];
+    int64_t p0[NP];
+    int deg[NP], dmax = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int64_t r = r0 + i * RPP + lr;
+      const int64_t rc = r < M ? r : M - 1;
+      gv[i] = *reinterpret_cast<const float4*>(g_out + (size_t)rc * FO + c4);
+      yv[i] = *reinterpret_cast<const float4*>(out + (size_t)rc * FO + c4);
+      xv[i] = *reinterpret_cast<const float4*>(x + (size_t)rc * FI + c4);
+      av[i] = *reinterpret_cast<const float4*>(agg + (size_t)rc * FI + c4);
+      if (NEED_X) {
+        p0[i] = 0;
+        deg[i] = 0;
+        if (col_ptr) {   // (uniform; null: no edges at all)
+          p0[i] = col_ptr[rc];
+          deg[i] = r < M ? (int)(col_ptr[rc + 1] - p0[i]) : 0;
+        }
+        dmax = max(dmax, deg[i]);
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int rl = i * RPP + lr;
+      const bool live = r0 + rl < M;
+      float4 G = act_grad4(gv[i], yv[i]);
+      if (!live) G = make_float4(0.f, 0.f, 0.f, 0.f);
+      db4 = make_float4(db4.x + G.x, db4.y + G.y, db4.z + G.z, db4.w + G.w);
+      *reinterpret_cast<float4*>(sG + rl * AS + c4) = G;
+      *reinterpret_cast<float4*>(sA + rl * AS + c4) = live ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(sX + rl * AS + c4) = live ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // transpose aggregation of G over the CSC column of each row (the sinks this node feeds)
+    float4 gt[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) gt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NEED_X) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+#pragma unroll 1
+      for (int d = 0; d < dmax; ++d) {
+        int64_t sk[NP];
+        float we[NP];
+        bool on[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          on[i] = d < deg[i];
+          const int64_t k = on[i] ? p0[i] + d : 0;   // (dmax > 0 implies E > 0)
+          sk[i] = rows_csc[k];
+          we[i] = HAS_W ? w[perm[k]] : 1.f;
+        }
+        asm volatile("" ::: "memory");
+        float4 ng[NP], ny[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          ng[i] = *reinterpret_cast<const float4*>(g_out + (size_t)sk[i] * FO + c4);
+          ny[i] = *reinterpret_cast<const float4*>(out + (size_t)sk[i] * FO + c4);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          float4 t = act_grad4(ng[i], ny[i]);
+          const float ww = on[i] ? we[i] : 0.f;
+          gt[i] = make_float4(fmaf(ww, t.x, gt[i].x), fmaf(ww, t.y, gt[i].y), fmaf(ww, t.z, gt[i].z),
+                              fmaf(ww, t.w, gt[i].w));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // dW_rel += G^T agg, dW_root += G^T x: M = o, N = f, K = the 32 rows (lane half kk owns rows kk 16 + s)
+    {
+      float ga[16], ba[16], bx[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = lh * 16 + q;
+        ga[q] = sG[row * AS + li];
+        ba[q] = sA[row * AS + li];
+        bx[q] = sX[row * AS + li];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        dwr = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[q], ba[q], dwr, 0, 0, 0);
+        dwo = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[q], bx[q], dwo, 0, 0, 0);
+      }
+    }
+    if (NEED_X) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NP; ++i)   // the agg tile has been read: it now holds the gathered G
+        *reinterpret_cast<float4*>(sA + (i * RPP + lr) * AS + c4) = gt[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // g_x = GT @ W_rel + G @ W_root: lane (row = li, kk) reads its 16 contiguous o
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* pt = sA + li * AS + lh * 16;
+      const float* pg = sG + li * AS + lh * 16;
+      const float* wr_ = sW + (size_t)((0 * 2 + lh) * 32 + li) * WS;
+      const float* wo_ = sW + (size_t)((1 * 2 + lh) * 32 + li) * WS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(pt + 4 * q);
+        const float4 wv = *reinterpret_cast<const float4*>(wr_ + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv.w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(pg + 4 * q);
+        const float4 wv = *reinterpret_cast<const float4*>(wo_ + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv.w, acc, 0, 0, 0);
+      }
+      float* ob = g_x + (size_t)(r0 + 4 * lh) * FI + li;
+      if (r0 + 32 <= M) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[((r & 3) + 8 * (r >> 2)) * FI] = acc[r];
+      } else {
+        const int left = (int)(M - r0) - 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((r & 3) + 8 * (r >> 2) < left) ob[((r & 3) + 8 * (r >> 2)) * FI] = acc[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the tiles are rewritten by the next trip
+  }
+  // ---- one slab per workgroup: { G^T agg [FO][FI] | G^T x [FO][FI] | colsum G [FO] }, the four waves
+  // summed in fixed order.  acc[r] of dwr / dwo is entry (o = acc_row(r, lh), f = li).
+  db4.x += __shfl_xor(db4.x, 8); db4.y += __shfl_xor(db4.y, 8); db4.z += __shfl_xor(db4.z, 8); db4.w += __shfl_xor(db4.w, 8);
+  db4.x += __shfl_xor(db4.x, 16); db4.y += __shfl_xor(db4.y, 16); db4.z += __shfl_xor(db4.z, 16); db4.w += __shfl_xor(db4.w, 16);
+  db4.x += __shfl_xor(db4.x, 32); db4.y += __shfl_xor(db4.y, 32); db4.z += __shfl_xor(db4.z, 32); db4.w += __shfl_xor(db4.w, 32);
+  __syncthreads();                       // every wave is done with its tiles: LDS becomes the reduction buffer
+  constexpr int SL = 2 * FO * FI + FO;
+  float* red = smem + (size_t)wave * (SL + 32);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = acc_row(r, lh);
+    red[o * FI + li] = dwr[r];
+    red[FO * FI + o * FI + li] = dwo[r];
+  }
+  if (lane < 8) *reinterpret_cast<float4*>(red + 2 * FO * FI + 4 * lane) = db4;
+  __syncthreads();
+  float* slab = slabs + (size_t)blockIdx.x * SL;
+  for (int e = tid; e < SL; e += 256)
+    slab[e] = (smem[e] + smem[(SL + 32) + e]) + (smem[2 * (SL + 32) + e] + smem[3 * (SL + 32) + e]);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1169,6 +1368,33 @@ extern "C" int gcm_csr_graphconv_bwd(const float* g_out, const float* out, const
   const int N = (int)M;
   float* no_adj = nullptr;
   bool rows_done = false;
+  if (Fi == 32 && Fo == 32 && !mask && !g_w && M >= 32 && (!g_x || E == 0 || (col_ptr && rows && perm))) {
+    // third generation: row-local adjoint and transpose aggregation in one pass
+    const int n_tiles = (int)((M + 31) / 32);
+    const size_t lds3 = sizeof(float) * (4 * 3 * 32 * 36 + 2 * 2 * 32 * 20);
+    const int cap = 2 * gcm_cu_count();   // two resident workgroups per CU (LDS)
+    const int blocks = (n_tiles + 3) / 4 < cap ? (n_tiles + 3) / 4 : cap;
+    const bool need_x = g_x != nullptr, gather = need_x && E > 0;
+    // (no edges: the CSC view may be absent - the gather loop never runs, col_ptr is not read)
+#define GCM_BWD3(hw, nx)                                                                        \
+  if ((w != nullptr) == hw && need_x == nx) {                                                   \
+    auto kern = k_csr_bwd3<hw, nx>;                                                             \
+    gcm_allow_dynamic_lds((const void*)kern, lds3);                                             \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds3, s, g_out, out, x, agg,              \
+                       gather ? col_ptr : nullptr, rows, perm, w, w_rel, w_root, g_x, slabs, M, act, \
+                       n_tiles);                                                                \
+  }
+    GCM_BWD3(false, false) GCM_BWD3(true, false) GCM_BWD3(false, true) GCM_BWD3(true, true)
+#undef GCM_BWD3
+    int rc3 = gcm_launch_status();
+    if (rc3 != GCM_OK) return rc3;
+    if (want_w) {
+      const int slab_len = (int)p.slab_len;
+      hipLaunchKernelGGL(k_reduce_slabs, dim3((slab_len + 15) / 16), dim3(256), 0, s, slabs, blocks,
+                         slab_len, g_w_rel, g_w_root, g_b_rel, Fo * Fi, Fo);
+    }
+    return gcm_launch_status();
+  }
   if (Fi <= 64 && Fo <= 64 && p.waves == 4) {   // second-generation row-local kernel
     const int NCT = FiP / 32, NHT = FoP / 32;
     const size_t lds2 = sizeof(float) * ((size_t)128 * (FoP + 1) + 2 * FoP * (FiP + 1) + 4 * 1024 + 256);

@@ -26,6 +26,10 @@ def dev_sparse_gnn(ref, F, H, act, layers=2):
 @pytest.mark.parametrize("M,E,Fi,Fo,act,weighted", [
     (5, 0, 3, 3, None, False), (40, 90, 8, 16, "tanh", True), (300, 1500, 32, 32, "tanh", False),
     (1000, 4000, 33, 70, "relu", True), (129, 700, 128, 128, "tanh", True),
+    # Fi = Fo = 32: the third-generation kernels (one wave per 32 rows; forward, and the backward with the
+    # transpose aggregation folded in) - ragged last tile, heavy fan-in / fan-out, no edges at all
+    (5000, 30000, 32, 32, "tanh", True), (1000, 2500, 32, 32, "relu", False), (65, 4000, 32, 32, None, True),
+    (4096, 0, 32, 32, "tanh", False), (3333, 9000, 32, 64, "tanh", True),
 ])
 def test_csr_graphconv_kernel(M, E, Fi, Fo, act, weighted):
     """Generic edge_index (unsorted, duplicates allowed) through gcm.nn.GraphConv."""
@@ -53,6 +57,30 @@ def test_csr_graphconv_kernel(M, E, Fi, Fo, act, weighted):
     torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
     if weighted and E:
         torch.testing.assert_close(wd.grad.cpu(), wc.grad, rtol=1e-4, atol=1e-4)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
+        scale = float(pc.grad.abs().max()) + 1e-6
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
+
+
+def test_csr_graphconv_constant_edge_weights():
+    """Edge weights that carry no gradient: the fused backward (transpose aggregation inside the row
+    kernel) reads them through the CSC permutation."""
+    from gcm import nn as G
+    torch.manual_seed(11)
+    M, E, F = 2000, 7000, 32
+    ref = pyg.GraphConv(F, F)
+    dev = G.GraphConv(F, F)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.to(DEV)
+    x, ei, w = torch.randn(M, F), torch.randint(0, M, (2, E)), torch.rand(E)
+    xc, xd = x.clone().requires_grad_(True), x.to(DEV).requires_grad_(True)
+    yc = torch.tanh(ref(xc, ei, w))
+    yd = dev(xd, ei.to(DEV), w.to(DEV), _act=1)
+    torch.testing.assert_close(yd.cpu(), yc, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(yc)
+    yc.backward(g)
+    yd.backward(g.to(DEV))
+    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
     for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
         scale = float(pc.grad.abs().max()) + 1e-6
         torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
