@@ -49,13 +49,25 @@ __global__ __launch_bounds__(256) void k_sparse_plan(const int64_t* __restrict__
   }
 }
 
+// The packing kernels below move whole feature rows: VT = float4 (rows of F / 4 vectors, every
+// pointer 16-byte aligned) moves them 16 bytes per lane, VT = float is the general form.  F counts VTs.
+__device__ __forceinline__ float vt_zero(float) { return 0.f; }
+__device__ __forceinline__ float4 vt_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ bool vt_nonfinite(float v) { return !isfinite(v); }
+__device__ __forceinline__ bool vt_nonfinite(const float4& v) {
+  return !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+}
+static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+
 // ---------------------------------------------------------------------------
 // insert new observations into the node matrix (sparse_gcm.py:116-128) + adjoint
 // ---------------------------------------------------------------------------
-template <bool BWD>
+template <bool BWD, typename VT>
 __global__ __launch_bounds__(256) void k_sparse_insert(
-    const float* __restrict__ src, const float* __restrict__ x, const int64_t* __restrict__ T,
-    const int64_t* __restrict__ taus, float* __restrict__ dst, float* __restrict__ g_x,
+    const VT* __restrict__ src, const VT* __restrict__ x, const int64_t* __restrict__ T,
+    const int64_t* __restrict__ taus, VT* __restrict__ dst, VT* __restrict__ g_x,
     uint32_t* __restrict__ flags, int N, int F, int t_pad, int rows_per_block) {
   const int b = blockIdx.y;
   const int64_t t0 = T[b];
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256) void k_sparse_insert(
     if (!BWD) {
       dst[at] = fresh ? x[((size_t)b * t_pad + k) * F + f] : src[at];
     } else {
-      dst[at] = fresh ? 0.f : src[at];
+      dst[at] = fresh ? vt_zero(VT()) : src[at];
     }
   }
   if (BWD && g_x) {  // g_x[b, k] = g_nodes_out[b, T+k] for k < tau, else 0 (only for rows in range)
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) void k_sparse_insert(
       const int k = k0 + e / F, f = e % F;
       const int64_t r = t0 + k;
       const bool ok = k < tau && r >= 0 && r < N;
-      g_x[((size_t)b * t_pad + k) * F + f] = ok ? src[((size_t)b * N + r) * F + f] : 0.f;
+      g_x[((size_t)b * t_pad + k) * F + f] = ok ? src[((size_t)b * N + r) * F + f] : vt_zero(VT());
     }
   }
 }
@@ -184,12 +196,12 @@ __global__ __launch_bounds__(256) void k_temporal_fill(const int64_t* __restrict
 // ---------------------------------------------------------------------------
 // flatten nodes (util.py:426-452) + adjoint
 // ---------------------------------------------------------------------------
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_flatten(const float* __restrict__ src,
+template <bool BWD, typename VT>
+__global__ __launch_bounds__(256) void k_flatten(const VT* __restrict__ src,
                                                  const int64_t* __restrict__ T,
                                                  const int64_t* __restrict__ taus,
                                                  const int64_t* __restrict__ node_off,
-                                                 float* __restrict__ dst, int N, int F, int64_t M,
+                                                 VT* __restrict__ dst, int N, int F, int64_t M,
                                                  int rows_per_block) {
   const int b = blockIdx.y;
   int64_t live = T[b] + taus[b];
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void k_flatten(const float* __restrict__ src,
     if (!BWD) {
       if (ok) dst[(size_t)(off + r) * F + f] = src[((size_t)b * N + r) * F + f];
     } else {
-      dst[((size_t)b * N + r) * F + f] = ok ? src[(size_t)(off + r) * F + f] : 0.f;
+      dst[((size_t)b * N + r) * F + f] = ok ? src[(size_t)(off + r) * F + f] : vt_zero(VT());
     }
   }
 }
@@ -274,9 +286,10 @@ __global__ void k_khop_round(const int64_t* __restrict__ row_ptr, const int64_t*
 // ---------------------------------------------------------------------------
 // output rows (sparse_gcm.py:176-208) + adjoint
 // ---------------------------------------------------------------------------
-__global__ void k_extract_fwd(const float* __restrict__ feats, const int64_t* __restrict__ T,
+template <typename VT>
+__global__ void k_extract_fwd(const VT* __restrict__ feats, const int64_t* __restrict__ T,
                               const int64_t* __restrict__ taus,
-                              const int64_t* __restrict__ node_off, float* __restrict__ out,
+                              const int64_t* __restrict__ node_off, VT* __restrict__ out,
                               uint32_t* __restrict__ flags, int B, int t_pad, int H, int64_t M) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool nonfinite = false;
@@ -284,20 +297,21 @@ __global__ void k_extract_fwd(const float* __restrict__ feats, const int64_t* __
     const int f = i % H;
     const int k = (i / H) % t_pad;
     const int b = i / ((int64_t)H * t_pad);
-    float v = 0.f;
+    VT v = vt_zero(VT());
     const int64_t row = node_off[b] + T[b] + k;
     if (k < taus[b] && row >= 0 && row < M) {
       v = feats[(size_t)row * H + f];
-      nonfinite = !isfinite(v);
+      nonfinite = vt_nonfinite(v);
     }
     out[i] = v;
   }
   if (__any(nonfinite) && (threadIdx.x & 63) == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
 }
 
-__global__ void k_extract_bwd(const float* __restrict__ g_out, const int64_t* __restrict__ T,
+template <typename VT>
+__global__ void k_extract_bwd(const VT* __restrict__ g_out, const int64_t* __restrict__ T,
                               const int64_t* __restrict__ taus,
-                              const int64_t* __restrict__ node_off, float* __restrict__ g_feats,
+                              const int64_t* __restrict__ node_off, VT* __restrict__ g_feats,
                               int B, int t_pad, int H, int64_t M) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * t_pad * H) return;
@@ -353,9 +367,14 @@ extern "C" int gcm_sparse_insert_fwd(const float* nodes_in, const float* x, cons
   GCM_REQUIRE(B > 0 && N > 0 && F > 0 && t_pad > 0);
   if (B > 65535) return GCM_EUNSUPPORTED;
   const int rpb = 32;
-  hipLaunchKernelGGL(k_sparse_insert<false>, dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
-                     (hipStream_t)stream, nodes_in, x, T, taus, nodes_out, (float*)nullptr, flags,
-                     N, F, t_pad, rpb);
+  if (F % 4 == 0 && aligned16(nodes_in, x, nodes_out))
+    hipLaunchKernelGGL((k_sparse_insert<false, float4>), dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)nodes_in, (const float4*)x, T, taus,
+                       (float4*)nodes_out, (float4*)nullptr, flags, N, F / 4, t_pad, rpb);
+  else
+    hipLaunchKernelGGL((k_sparse_insert<false, float>), dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                       (hipStream_t)stream, nodes_in, x, T, taus, nodes_out, (float*)nullptr, flags,
+                       N, F, t_pad, rpb);
   return gcm_launch_status();
 }
 
@@ -367,9 +386,14 @@ extern "C" int gcm_sparse_insert_bwd(const float* g_nodes_out, const int64_t* T,
   if (B > 65535) return GCM_EUNSUPPORTED;
   const int rpb = 32;
   const int blocks = (max(N, t_pad) + rpb - 1) / rpb;
-  hipLaunchKernelGGL(k_sparse_insert<true>, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream,
-                     g_nodes_out, (const float*)nullptr, T, taus, g_nodes_in, g_x,
-                     (uint32_t*)nullptr, N, F, t_pad, rpb);
+  if (F % 4 == 0 && aligned16(g_nodes_out, g_nodes_in, g_x))
+    hipLaunchKernelGGL((k_sparse_insert<true, float4>), dim3(blocks, B), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_nodes_out, (const float4*)nullptr, T, taus, (float4*)g_nodes_in,
+                       (float4*)g_x, (uint32_t*)nullptr, N, F / 4, t_pad, rpb);
+  else
+    hipLaunchKernelGGL((k_sparse_insert<true, float>), dim3(blocks, B), dim3(256), 0, (hipStream_t)stream,
+                       g_nodes_out, (const float*)nullptr, T, taus, g_nodes_in, g_x,
+                       (uint32_t*)nullptr, N, F, t_pad, rpb);
   return gcm_launch_status();
 }
 
@@ -406,8 +430,13 @@ extern "C" int gcm_sparse_flatten_fwd(const float* nodes, const int64_t* T, cons
   if (M == 0) return GCM_OK;
   GCM_REQUIRE(flat);
   const int rpb = 32;
-  hipLaunchKernelGGL(k_flatten<false>, dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
-                     (hipStream_t)stream, nodes, T, taus, node_off, flat, N, F, M, rpb);
+  if (F % 4 == 0 && aligned16(nodes, flat))
+    hipLaunchKernelGGL((k_flatten<false, float4>), dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)nodes, T, taus, node_off, (float4*)flat, N, F / 4,
+                       M, rpb);
+  else
+    hipLaunchKernelGGL((k_flatten<false, float>), dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                       (hipStream_t)stream, nodes, T, taus, node_off, flat, N, F, M, rpb);
   return gcm_launch_status();
 }
 
@@ -418,8 +447,13 @@ extern "C" int gcm_sparse_flatten_bwd(const float* g_flat, const int64_t* T, con
   GCM_REQUIRE(g_flat || M == 0);
   if (B > 65535) return GCM_EUNSUPPORTED;
   const int rpb = 32;
-  hipLaunchKernelGGL(k_flatten<true>, dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
-                     (hipStream_t)stream, g_flat, T, taus, node_off, g_nodes, N, F, M, rpb);
+  if (F % 4 == 0 && aligned16(g_flat, g_nodes))
+    hipLaunchKernelGGL((k_flatten<true, float4>), dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)g_flat, T, taus, node_off, (float4*)g_nodes, N,
+                       F / 4, M, rpb);
+  else
+    hipLaunchKernelGGL((k_flatten<true, float>), dim3((N + rpb - 1) / rpb, B), dim3(256), 0,
+                       (hipStream_t)stream, g_flat, T, taus, node_off, g_nodes, N, F, M, rpb);
   return gcm_launch_status();
 }
 
@@ -602,9 +636,16 @@ extern "C" int gcm_sparse_extract_fwd(const float* feats, const int64_t* T, cons
                                       int t_pad, int H, int64_t M, gcm_stream_t stream) {
   GCM_REQUIRE(T && taus && node_off && out && flags && B > 0 && t_pad > 0 && H > 0 && M >= 0);
   GCM_REQUIRE(feats || M == 0);
-  const int64_t total = (int64_t)B * t_pad * H;
-  hipLaunchKernelGGL(k_extract_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, feats, T, taus, node_off, out, flags, B, t_pad, H, M);
+  if (H % 4 == 0 && aligned16(feats, out)) {
+    const int64_t total = (int64_t)B * t_pad * (H / 4);
+    hipLaunchKernelGGL(k_extract_fwd<float4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feats, T, taus, node_off, (float4*)out, flags, B,
+                       t_pad, H / 4, M);
+  } else {
+    const int64_t total = (int64_t)B * t_pad * H;
+    hipLaunchKernelGGL(k_extract_fwd<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, feats, T, taus, node_off, out, flags, B, t_pad, H, M);
+  }
   return gcm_launch_status();
 }
 
@@ -617,9 +658,15 @@ extern "C" int gcm_sparse_extract_bwd(const float* g_out, const int64_t* T, cons
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(g_feats, 0, (size_t)M * H * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
-  const int64_t total = (int64_t)B * t_pad * H;
-  hipLaunchKernelGGL(k_extract_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_out,
-                     T, taus, node_off, g_feats, B, t_pad, H, M);
+  if (H % 4 == 0 && aligned16(g_out, g_feats)) {
+    const int64_t total = (int64_t)B * t_pad * (H / 4);
+    hipLaunchKernelGGL(k_extract_bwd<float4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const float4*)g_out, T, taus, node_off, (float4*)g_feats, B, t_pad, H / 4, M);
+  } else {
+    const int64_t total = (int64_t)B * t_pad * H;
+    hipLaunchKernelGGL(k_extract_bwd<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_out,
+                       T, taus, node_off, g_feats, B, t_pad, H, M);
+  }
   return gcm_launch_status();
 }
 
