@@ -28,6 +28,16 @@
 // Shapes: N <= 128, F <= 32, H1 <= 32, H2 <= 32 (BASELINE cfg5: 128 / 32 / 32 / 32).
 #include "fused_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps7, tools/kstamp_learned.py)
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#define LSTAMP(i) STAMP(i)
+#else
+#define LSTAMP(i)
+#endif
+
 namespace gcm_learned {
 
 using gcm_fused::mma32;
@@ -234,8 +244,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
   const float* h1g = h1 + (size_t)b * N * H1;
   const float* a1g = agg1 + (size_t)b * N * F;
   float* GAg = GA + (size_t)b * N * N;   // this graph's chain buffer (see the header comment)
-  float* slab = slabs + (size_t)b * (Pg + Pm);
-  float* sl_m = slab + Pg;
+  float* slab_g = slabs + (size_t)b * (Pg + Pm);
 
   extern __shared__ float smem[];
   float* sX = smem;                    // [NP][FS]
@@ -260,13 +269,44 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
   float* sVv = sU + 64;
   float* sCs = sVv + 64 + 32;
   int* sLive = reinterpret_cast<int*>(sCs + 256);   // [NP] + count
+  // The parameter-gradient slab of this graph is built in LDS and written once: every update below is
+  // a read-modify-write, and against HBM each of the dozen update sites exposed a memory round trip.
+  float* slab = reinterpret_cast<float*>(sLive + NP + 8);   // [Pg + Pm]
+  float* sl_m = slab + Pg;
 
-  // ---- loads: node matrix, h1, weights, row cur of the adjacency, the kept row's vectors ---------
-  stage<NP>(xg, sX, N, F, F, tid);
-  stage<NP>(h1g, sG, N, H1, H1, tid);
-  stage<FP>(M.w0 + F, sW0b, F, F, 2 * F, tid);
-  stage<FP>(M.w1, sW1, F, F, F, tid);
-  stage<FP>(w_rel1, sWr1, H1, F, F, tid);
+  LSTAMP(0);
+  // ---- loads: node matrix, h1, weights, row cur of the adjacency, the kept row's vectors, the slab so
+  // far - every global load in flight before the first LDS store (one round trip, not one per matrix) ---
+  {
+    using gcm_fused::Stage;
+    Stage<NP, FP, false, false> st_x, st_h;
+    Stage<FP, FP, false, false> st_w0, st_w1, st_wr;
+    st_x.load(xg, N, F, F, tid);
+    st_h.load(h1g, N, H1, H1, tid);
+    st_w0.load(M.w0 + F, F, F, 2 * F, tid);
+    st_w1.load(M.w1, F, F, F, tid);
+    st_wr.load(w_rel1, H1, F, F, tid);
+    constexpr int SLAB_PER = (2 * FP * FP + FP + 2 * FP * FP + FP + 3 * FP * FP + 7 * FP + 1 + 255) / 256;
+    float sv[SLAB_PER];
+    if (accumulate) {   // (uniform)
+#pragma unroll
+      for (int i = 0; i < SLAB_PER; ++i) {
+        const int e = tid + 256 * i;
+        sv[i] = slab_g[e < Pg + Pm ? e : Pg + Pm - 1];
+      }
+    }
+    asm volatile("" ::: "memory");
+    st_x.store(sX, FS, tid);
+    st_h.store(sG, FS, tid);
+    st_w0.store(sW0b, FS, tid);
+    st_w1.store(sW1, FS, tid);
+    st_wr.store(sWr1, FS, tid);
+#pragma unroll
+    for (int i = 0; i < SLAB_PER; ++i) {
+      const int e = tid + 256 * i;
+      if (e < Pg + Pm) slab[e] = accumulate ? sv[i] : 0.f;
+    }
+  }
   if (tid < NP) sCoef[tid] = tid < N ? ag[cur * N + tid] : 0.f;
   if (tid < FP) {
     const int o = tid < F ? tid : F - 1;
@@ -290,6 +330,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     const float t = tid < 32 ? agg2[(size_t)b * H1 + kc] : h1g[cur * H1 + kc];
     sVv[tid] = k < H1 ? t : 0.f;
   }
+  LSTAMP(1);
   __syncthreads();
   // ---- phase A: layer-2 adjoint ----------------------------------------------------------------------
   if (tid < 64) {   // u[m] = sum_o W2c[o][m] d2[o]   (m < 32: dagg2, else dh1cur)
@@ -312,6 +353,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     }
     if (tid < H2) sl_b2[tid] = (accumulate ? sl_b2[tid] : 0.f) + sD2[tid];
   }
+  LSTAMP(2);
   // live rows: ballot over row cur (entries of the sampled row), list in LDS
   {
     const bool pred = tid < N && tid < NP && (sCoef[tid & (NP - 1)] != 0.f || tid == cur);
@@ -331,6 +373,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     sR[l * 32 + h] = h < H1 ? d * gcm_act_grad(y, act1) : 0.f;
   }
   __syncthreads();
+  LSTAMP(3);
   {   // layer-1 parameter gradients on the live rows: dW1c[h][m] (+)= sum_l G1[l][h] [agg1 | x][j_l][m]
     const int h = tid >> 3, m0 = (tid & 7) * 8;
     float acc[8];
@@ -365,6 +408,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
       }
     }
   }
+  LSTAMP(4);
   // dAgg1[l][f] = G1[l] . w_rel1[:, f] -> sP0 [l][FS] (free until the edge network is recomputed)
   for (int e = tid; e < L * 32; e += 256) {
     const int l = e >> 5, f = e & 31;
@@ -391,6 +435,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
       GAg[j * N + k] += s;
     }
   }
+  LSTAMP(5);
   // ---- g_sel[j] = dagg2 . h1[j] + GA[cur][j] + dAgg1[cur] . x[j]  (j < cur); selection adjoint ------
   if (tid < NP) {
     float s = 0.f;
@@ -418,6 +463,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
 #pragma unroll
     for (int c = 0; c < 2; ++c) sGl[lane + 64 * c] = p[c] * (g[c] - dot);
   }
+  LSTAMP(6);
   // ---- the chain buffer for the previous step: undo the state advance (gcm.py:262-278, 323-355).
   // No overflow: row cur did not exist before (zero).  Overflow: every entry moves back by one row
   // and one column, the dropped node's row / column and the new node's row carry nothing.
@@ -447,6 +493,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     }
   }
   __syncthreads();
+  LSTAMP(7);
   // ---- edge network: forward recomputed, then its adjoint -------------------------------------------
   {
     const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
@@ -486,6 +533,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     sRs1[tid] = rsqrtf(q / (float)F + eps1);
   }
   __syncthreads();
+  LSTAMP(8);
   // column sums over the rows (8 row groups x 32 columns): dw2, dgamma1, dbeta1, db2
   {
     const int f = tid & 31, grp = tid >> 5;
@@ -521,6 +569,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     }
     if (tid == 0) sl_m[o_b2] = (accumulate ? sl_m[o_b2] : 0.f) + t_bb;
   }
+  LSTAMP(9);
   // LayerNorm-1 + ReLU adjoint, row by row: gP1 in place of P1
   if (tid < NP) {
     const int j = tid;
@@ -544,6 +593,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     }
   }
   __syncthreads();
+  LSTAMP(10);
   // db1' = column sums of gP1; dW1 = gP1^T H0 (K = rows, split over the waves); gH0 = gP1 W1
   const int o_b0 = 2 * F * F, o_g0 = o_b0 + F, o_be0 = o_g0 + F, o_w1 = o_be0 + F, o_b1 = o_w1 + F * F;
   {
@@ -585,6 +635,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     for (int r = 0; r < 16; ++r) sG[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r];
   }
   __syncthreads();
+  LSTAMP(11);
   // dgamma0 / dbeta0 (column sums of gH0 * xhat0, gH0), then LayerNorm-0 + ReLU adjoint: gP0 in place
   {
     const int f = tid & 31, grp = tid >> 5;
@@ -636,6 +687,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     }
   }
   __syncthreads();
+  LSTAMP(12);
   // db0 = column sums of gP0; dW0a = db0 (x) x[cur]; dW0b = gP0^T X
   {
     const int f = tid & 31, grp = tid >> 5;
@@ -669,11 +721,15 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
       *db = (accumulate ? *db : 0.f) + ((sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]));
     }
   }
+  __syncthreads();
+  for (int e = tid; e < Pg + Pm; e += 256) slab_g[e] = slab[e];
+  LSTAMP(13);
 }
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
 constexpr size_t lds_bwd() {
-  return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8);
+  return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
+                          (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);
 }
 
 }  // namespace gcm_learned
