@@ -83,29 +83,70 @@ __device__ __forceinline__ f32x16 gemm_rows(const float* sA, const float* sBt, i
   return acc;
 }
 
-// ReLU + LayerNorm of row `row` of sP (in place -> gamma * xhat + beta), one thread per row.
-// Returns nothing; stats (mean, rstd) optionally stored.
-__device__ __forceinline__ void relu_ln_row(float* sP, int row, int F, const float* sg, const float* sb,
-                                            float eps, float* mu_out, float* rs_out) {
-  float a[FP];
+// ReLU + LayerNorm of the rows of sP (in place -> gamma * xhat + beta), TWO adjacent threads per row
+// (row = tid / 2, each owns 16 of the 32 columns; the row statistics meet through one lane shuffle):
+// all 256 threads work on the 128 rows.  Statistics (mean, rstd) optionally stored.  write = false
+// leaves sP untouched (statistics only).
+__device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const float* sg, const float* sb,
+                                             float eps, float* mu_out, float* rs_out, bool write = true) {
+  const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
+  float a[FP / 2];
   float s = 0.f;
 #pragma unroll
-  for (int f = 0; f < FP; ++f) {
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
     const float v = sP[row * FS + f];
-    a[f] = (f < F && v > 0.f) ? v : 0.f;
-    s += a[f];
+    a[k] = (f < F && v > 0.f) ? v : 0.f;
+    s += a[k];
   }
+  s += __shfl_xor(s, 1);
   const float mean = s / (float)F;
   float q = 0.f;
 #pragma unroll
-  for (int f = 0; f < FP; ++f) {
-    const float d = f < F ? a[f] - mean : 0.f;
+  for (int k = 0; k < FP / 2; ++k) {
+    const float d = f0 + k < F ? a[k] - mean : 0.f;
     q = fmaf(d, d, q);
   }
+  q += __shfl_xor(q, 1);
   const float rstd = rsqrtf(q / (float)F + eps);
+  if (write) {
 #pragma unroll
-  for (int f = 0; f < FP; ++f) sP[row * FS + f] = f < F ? fmaf((a[f] - mean) * rstd, sg[f], sb[f]) : 0.f;
-  if (mu_out) { mu_out[row] = mean; rs_out[row] = rstd; }
+    for (int k = 0; k < FP / 2; ++k) {
+      const int f = f0 + k;
+      sP[row * FS + f] = f < F ? fmaf((a[k] - mean) * rstd, sg[f], sb[f]) : 0.f;
+    }
+  }
+  if (mu_out && (tid & 1) == 0) { mu_out[row] = mean; rs_out[row] = rstd; }
+}
+
+// LayerNorm + ReLU adjoint of the rows of sP (pre-activation values, overwritten by the gradient w.r.t.
+// them): gx[f] = the gradient w.r.t. the normalised value times gamma; two threads per row as above.
+template <typename GX>
+__device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, const float* sMu, const float* sRs,
+                                                 GX gx_of) {
+  const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
+  const float mean = sMu[row], rstd = sRs[row];
+  float xh[FP / 2], gx[FP / 2], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
+    const float v = sP[row * FS + f];
+    xh[k] = f < F ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
+    gx[k] = f < F ? gx_of(row, f) : 0.f;
+    m1 += gx[k];
+    m2 = fmaf(gx[k], xh[k], m2);
+  }
+  m1 += __shfl_xor(m1, 1);
+  m2 += __shfl_xor(m2, 1);
+  m1 /= (float)F;
+  m2 /= (float)F;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
+    const float v = sP[row * FS + f];
+    const float da = rstd * (gx[k] - m1 - xh[k] * m2);
+    sP[row * FS + f] = (f < F && v > 0.f) ? da : 0.f;
+  }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -162,7 +203,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
   }
   __syncthreads();
-  if (tid < NP) relu_ln_row(sA, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
+  relu_ln_rows(sA, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
   __syncthreads();
   {
     const f32x16 acc = gemm_rows(sA, sW1, wave, li, lh);
@@ -170,8 +211,9 @@ __global__ __launch_bounds__(256) void k_learned_select(
     for (int r = 0; r < 16; ++r) sB[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
   }
   __syncthreads();
+  relu_ln_rows(sB, tid, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
+  __syncthreads();
   if (tid < NP) {
-    relu_ln_row(sB, tid, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
     float lg = M.b2[0];
 #pragma unroll
     for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sB[tid * FS + f], lg);
@@ -506,7 +548,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     }
   }
   __syncthreads();
-  if (tid < NP) relu_ln_row(sH0, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);
+  relu_ln_rows(sH0, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);
   __syncthreads();
   {
     const f32x16 acc = gemm_rows(sH0, sW1, wave, li, lh);
@@ -514,24 +556,8 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
     for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
   }
   __syncthreads();
-  if (tid < NP) {   // statistics of layer 1 (the normalised values are rebuilt where needed)
-    float s = 0.f, a[FP];
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float v = sP1[tid * FS + f];
-      a[f] = (f < F && v > 0.f) ? v : 0.f;
-      s += a[f];
-    }
-    const float mean = s / (float)F;
-    float q = 0.f;
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float d = f < F ? a[f] - mean : 0.f;
-      q = fmaf(d, d, q);
-    }
-    sMu1[tid] = mean;
-    sRs1[tid] = rsqrtf(q / (float)F + eps1);
-  }
+  // statistics of layer 1 (the normalised values are rebuilt where needed)
+  relu_ln_rows(sP1, tid, F, nullptr, nullptr, eps1, sMu1, sRs1, /*write=*/false);
   __syncthreads();
   LSTAMP(8);
   // column sums over the rows (8 row groups x 32 columns): dw2, dgamma1, dbeta1, db2
@@ -571,27 +597,8 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
   }
   LSTAMP(9);
   // LayerNorm-1 + ReLU adjoint, row by row: gP1 in place of P1
-  if (tid < NP) {
-    const int j = tid;
-    const float gl = sGl[j], mean = sMu1[j], rstd = sRs1[j];
-    float xh[FP], gx[FP], m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float v = sP1[j * FS + f];
-      xh[f] = f < F ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
-      gx[f] = f < F ? gl * sVec[6 * FP + f] * sVec[4 * FP + f] : 0.f;
-      m1 += gx[f];
-      m2 = fmaf(gx[f], xh[f], m2);
-    }
-    m1 /= (float)F;
-    m2 /= (float)F;
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float v = sP1[j * FS + f];
-      const float da = rstd * (gx[f] - m1 - xh[f] * m2);
-      sP1[j * FS + f] = (f < F && v > 0.f) ? da : 0.f;
-    }
-  }
+  relu_ln_rows_bwd(sP1, tid, F, sMu1, sRs1,
+                   [&](int j, int f) { return sGl[j] * sVec[6 * FP + f] * sVec[4 * FP + f]; });
   __syncthreads();
   LSTAMP(10);
   // db1' = column sums of gP1; dW1 = gP1^T H0 (K = rows, split over the waves); gH0 = gP1 W1
@@ -665,27 +672,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
       sl_m[o_be0 + tid] = (accumulate ? sl_m[o_be0 + tid] : 0.f) + t;
     }
   }
-  if (tid < NP) {
-    const int j = tid;
-    const float mean = sMu0[j], rstd = sRs0[j];
-    float xh[FP], gx[FP], m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float v = sP0[j * FS + f];
-      xh[f] = f < F ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
-      gx[f] = f < F ? sG[j * FS + f] * sVec[2 * FP + f] : 0.f;
-      m1 += gx[f];
-      m2 = fmaf(gx[f], xh[f], m2);
-    }
-    m1 /= (float)F;
-    m2 /= (float)F;
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float v = sP0[j * FS + f];
-      const float da = rstd * (gx[f] - m1 - xh[f] * m2);
-      sP0[j * FS + f] = (f < F && v > 0.f) ? da : 0.f;
-    }
-  }
+  relu_ln_rows_bwd(sP0, tid, F, sMu0, sRs0, [&](int j, int f) { return sG[j * FS + f] * sVec[2 * FP + f]; });
   __syncthreads();
   LSTAMP(12);
   // db0 = column sums of gP0; dW0a = db0 (x) x[cur]; dW0b = gP0^T X
