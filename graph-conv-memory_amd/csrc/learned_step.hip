@@ -27,6 +27,7 @@
 //
 // Shapes: N <= 128, F <= 32, H1 <= 32, H2 <= 32 (BASELINE cfg5: 128 / 32 / 32 / 32).
 #include "fused_common.h"
+#include "state_copy.h"
 
 #ifdef GCM_STAMPS   // diagnostic build only (make stamps7, tools/kstamp_learned.py)
 __device__ unsigned long long g_stamps[32];
@@ -161,16 +162,41 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // forward: logits of all candidate rows, gumbel-softmax, threshold, adjacency row (learned.py:53-113)
 // ---------------------------------------------------------------------------------------------
+// ADVANCE: the state advance (gcm.py:262-278, overflow roll :323-355) is done by this kernel too -
+// `nodes` / `adj` are then the OUTPUT state, read from nodes_in / adj_in through registers (the copy's
+// loads ride with the edge network's, its stores drain under the two GEMMs), the observation goes into
+// row cur, cur / count come out; N % 4 == 0 and F % 4 == 0.  Otherwise nodes / adj hold the advanced
+// state already (gcm_state_advance_fwd ran) and cur_idx is read.
+template <bool ADVANCE>
 __global__ __launch_bounds__(256) void k_learned_select(
-    const float* __restrict__ nodes, float* __restrict__ adj, const int64_t* __restrict__ cur_idx,
+    const float* __restrict__ nodes_c, float* __restrict__ adj, const int64_t* __restrict__ cur_idx_c,
     const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp, float eps0,
-    float eps1, float cutoff, float* __restrict__ soft, int N, int F) {
+    float eps1, float cutoff, float* __restrict__ soft, int N, int F, const float* __restrict__ obs,
+    const float* __restrict__ nodes_in, const float* __restrict__ adj_in,
+    const int64_t* __restrict__ count_in, float* __restrict__ nodes_out, int64_t* __restrict__ cur_out,
+    int64_t* __restrict__ count_out, uint32_t* __restrict__ flags) {
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  int64_t c64 = cur_idx[b];
-  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  int cur;
+  bool wrap = false;
+  if (ADVANCE) {
+    const int64_t n_in = count_in[b];
+    wrap = n_in + 1 > N;
+    const int64_t c64 = wrap ? n_in - 1 : n_in;
+    cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+    if (tid == 0) {
+      cur_out[b] = cur;
+      count_out[b] = cur + 1;
+      const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
+      if (f) atomicOr(flags, f);
+    }
+  } else {
+    const int64_t c64 = cur_idx_c[b];
+    cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  }
   const Mlp M = unpack_mlp(mlp, F);
-  const float* xg = nodes + (size_t)b * N * F;
+  const float* xg = ADVANCE ? nullptr : nodes_c + (size_t)b * N * F;
+  const float* xcur = ADVANCE ? obs + (size_t)b * F : xg + (size_t)cur * F;   // the current node
   extern __shared__ float smem[];
   float* sX = smem;                 // [NP][FS]
   float* sA = sX + NP * FS;         // P0 -> H0
@@ -180,13 +206,52 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
 
-  stage<NP>(xg, sX, N, F, F, tid);
+  if (ADVANCE) {
+    // the state copy through registers (roll folded in), the node image for the edge network from the
+    // same registers, the observation patched into row cur
+    constexpr int ADJ_PER = 16, NODE_PER = (NP * FP / 4 + 255) / 256;
+    const int N4 = N >> 2, F4 = F >> 2;
+    const float* ag_in = adj_in + (size_t)b * N * N;
+    const float* ng_in = nodes_in + (size_t)b * N * F;
+    float4 ca[ADJ_PER], cn[NODE_PER];
+    if (wrap) gcm_state::load_copy<ADJ_PER, NODE_PER, true>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
+    else gcm_state::load_copy<ADJ_PER, NODE_PER, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
+    asm volatile("" ::: "memory");
+    const int lim_n = N * F4;
+#pragma unroll
+    for (int i = 0; i < NODE_PER; ++i) {
+      const int e4 = tid + 256 * i, r = e4 / F4, c = (e4 - r * F4) * 4;
+      if (e4 < lim_n) {
+        float4 v = cn[i];
+        if (wrap && r + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r == cur) v = *reinterpret_cast<const float4*>(obs + (size_t)b * F + c);
+        cn[i] = v;
+        sX[r * FS + c] = v.x; sX[r * FS + c + 1] = v.y; sX[r * FS + c + 2] = v.z; sX[r * FS + c + 3] = v.w;
+      }
+    }
+    // zero padding of the image (rows >= N, columns >= F)
+    for (int e = tid; e < NP * FP; e += 256) {
+      const int r = e / FP, c = e % FP;
+      if (r >= N || c >= F) sX[r * FS + c] = 0.f;
+    }
+    float* ng_out = nodes_out + (size_t)b * N * F;
+    gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, wrap);
+    // the inserted node: store_copy's roll fix-up zeroes the last row - the thread that owns a piece of
+    // row cur writes the observation behind its own copy store (same thread, same address: ordered)
+#pragma unroll
+    for (int i = 0; i < NODE_PER; ++i) {
+      const int e4 = tid + 256 * i, r = e4 / F4;
+      if (e4 < lim_n && r == cur) *reinterpret_cast<float4*>(ng_out + e4 * 4) = cn[i];
+    }
+  } else {
+    stage<NP>(xg, sX, N, F, F, tid);
+  }
   stage<FP>(M.w0 + F, sW0b, F, F, 2 * F, tid);
   stage<FP>(M.w1, sW1, F, F, F, tid);
   if (tid < FP) {
     const int o = tid < F ? tid : F - 1;
     float c0 = M.b0[o];
-    for (int f = 0; f < F; ++f) c0 = fmaf(M.w0[o * 2 * F + f], xg[cur * F + f], c0);
+    for (int f = 0; f < F; ++f) c0 = fmaf(M.w0[o * 2 * F + f], xcur[f], c0);
     const bool ok = tid < F;
     sVec[tid] = ok ? c0 : 0.f;
     sVec[FP + tid] = ok ? M.b1[o] : 0.f;
@@ -219,6 +284,9 @@ __global__ __launch_bounds__(256) void k_learned_select(
     for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sB[tid * FS + f], lg);
     sLogit[tid] = lg;
   }
+  // (ADVANCE) the copy's stores of row cur - other threads', issued long ago - must have landed before
+  // wave 0 writes the sampled entries of that row below: released here, ahead of the barrier
+  if (ADVANCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (waits for this wave's stores: cheap - they were issued two GEMMs ago; an agent-scope release would write the L2 back)
   __syncthreads();
   if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
     float z[2], m = -INFINITY;
@@ -251,7 +319,10 @@ __global__ __launch_bounds__(256) void k_learned_select(
         soft[(size_t)b * N + j] = p;
         if (j < cur) {
           const float edge = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12)
-          row[j] = (edge + row[j] > 0.f) ? 1.f : 0.f;            // learned.py:108-110
+          float old;
+          if (ADVANCE) old = wrap ? 0.f : adj_in[((size_t)b * N + cur) * N + j];
+          else old = row[j];
+          row[j] = (edge + old > 0.f) ? 1.f : 0.f;               // learned.py:108-110
         }
       }
     }
@@ -734,9 +805,34 @@ extern "C" int gcm_learned_select_fused(const float* nodes, float* adj, const in
   GCM_REQUIRE(nodes && adj && cur_idx && noise && mlp_params && soft && B > 0);
   if (!gcm_learned_step_supported(N, F, 1, 1)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_select, lds);
-  hipLaunchKernelGGL(gcm_learned::k_learned_select, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, adj,
-                     cur_idx, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F);
+  auto kern = gcm_learned::k_learned_select<false>;
+  gcm_allow_dynamic_lds((const void*)kern, lds);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, adj, cur_idx, noise,
+                     noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr,
+                     (int64_t*)nullptr, (int64_t*)nullptr, (uint32_t*)nullptr);
+  return gcm_launch_status();
+}
+
+/* gcm_state_advance_fwd + gcm_learned_select_fused in ONE kernel: the state copy (overflow roll folded in)
+ * travels through the registers of the workgroup that runs the edge network on the same node rows.
+ * Needs N % 4 == 0 and F % 4 == 0 (GCM_EUNSUPPORTED otherwise: call the two entry points instead). */
+extern "C" int gcm_learned_advance_select_fused(const float* obs, const float* nodes_in, const float* adj_in,
+                                                const int64_t* count_in, const float* noise,
+                                                int noise_is_exp, const float* mlp_params, float eps0,
+                                                float eps1, float cutoff, float* nodes_out, float* adj_out,
+                                                int64_t* cur_out, int64_t* count_out, float* soft,
+                                                uint32_t* flags, int B, int N, int F, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_in && adj_in && count_in && noise && mlp_params && nodes_out && adj_out && cur_out &&
+              count_out && soft && flags && B > 0);
+  GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
+  if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
+  constexpr size_t lds = gcm_learned::lds_select();
+  auto kern = gcm_learned::k_learned_select<true>;
+  gcm_allow_dynamic_lds((const void*)kern, lds);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
+                     (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F,
+                     obs, nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags);
   return gcm_launch_status();
 }
 

@@ -420,14 +420,23 @@ struct LearnedStepFn : public torch::autograd::Function<LearnedStepFn> {
     uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
     gcm_stream_t st = reinterpret_cast<gcm_stream_t>(stream);
     const float* pk = packed.data_ptr<float>();
-    check(gcm_state_advance_fwd(nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(), nullptr,
-                                count_in.data_ptr<int64_t>(), obs.data_ptr<float>(), base, base + L.o_adj,
-                                nullptr, ib, ib + B, fl, (int)B, N, F, st),
-          "gcm_state_advance_fwd");
-    check(gcm_learned_select_fused(base, base + L.o_adj, ib, noise.data_ptr<float>(), (int)noise_is_exp,
-                                   pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff,
-                                   base + o_soft, (int)B, N, F, st),
-          "gcm_learned_select_fused");
+    if ((N & 3) == 0 && (F & 3) == 0) {   // state advance and selection in one kernel
+      check(gcm_learned_advance_select_fused(obs.data_ptr<float>(), nodes_in.data_ptr<float>(),
+                                             adj_in.data_ptr<float>(), count_in.data_ptr<int64_t>(),
+                                             noise.data_ptr<float>(), (int)noise_is_exp, pk + cfg->P,
+                                             (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base,
+                                             base + L.o_adj, ib, ib + B, base + o_soft, fl, (int)B, N, F, st),
+            "gcm_learned_advance_select_fused");
+    } else {
+      check(gcm_state_advance_fwd(nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(), nullptr,
+                                  count_in.data_ptr<int64_t>(), obs.data_ptr<float>(), base, base + L.o_adj,
+                                  nullptr, ib, ib + B, fl, (int)B, N, F, st),
+            "gcm_state_advance_fwd");
+      check(gcm_learned_select_fused(base, base + L.o_adj, ib, noise.data_ptr<float>(), (int)noise_is_exp,
+                                     pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff,
+                                     base + o_soft, (int)B, N, F, st),
+            "gcm_learned_select_fused");
+    }
     const float* w_rel1 = pk;
     const float* w_root1 = w_rel1 + (size_t)H1 * F;
     const float* b1 = w_root1 + (size_t)H1 * F;

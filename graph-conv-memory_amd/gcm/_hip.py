@@ -95,6 +95,7 @@ PROTOTYPES = {
     "gcm_learned_step_supported": (_I, [_I] * 4),
     "gcm_learned_mlp_param_count": (_Z, [_I]),
     "gcm_learned_select_fused": (_I, [_P, _P, _P, _P, _I, _P, _F, _F, _F, _P, _I, _I, _I, _P]),
+    "gcm_learned_advance_select_fused": (_I, [_P] * 5 + [_I, _P, _F, _F, _F] + [_P] * 6 + [_I, _I, _I, _P]),
     "gcm_learned_step_bwd": (_I, [_P] * 6 + [_I, _I] + [_P] * 6 + [_F, _F, _P, _P, _I] + [_I] * 5 + [_P]),
     "gcm_dense_rows_bptt_slabs": (_I, [_I, _I]),
     "gcm_dense_rollout_bwd_params_workspace_bytes": (_Z, [_I] * 5),

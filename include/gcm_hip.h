@@ -512,6 +512,17 @@ int gcm_learned_select_fused(const float* nodes, float* adj, const int64_t* cur_
                              float eps0, float eps1, float cutoff, float* soft, int B, int N, int F,
                              gcm_stream_t stream);
 
+/* gcm_state_advance_fwd + gcm_learned_select_fused in ONE kernel (gcm.py:262-278 + learned.py:53-113):
+ * the state copy, with the overflow roll folded in, travels through the registers of the workgroup that
+ * runs the edge network on the same node rows; the observation lands in row cur, cur / count come out.
+ * N % 4 == 0 and F % 4 == 0 (GCM_EUNSUPPORTED otherwise: call the two entry points one after the other). */
+int gcm_learned_advance_select_fused(const float* obs, const float* nodes_in, const float* adj_in,
+                                     const int64_t* count_in, const float* noise, int noise_is_exp,
+                                     const float* mlp_params, float eps0, float eps1, float cutoff,
+                                     float* nodes_out, float* adj_out, int64_t* cur_out,
+                                     int64_t* count_out, float* soft, uint32_t* flags, int B, int N, int F,
+                                     gcm_stream_t stream);
+
 /* Backward of one DenseGCM + LearnedEdge step when the observations carry no gradient: GNN adjoint on
  * the live rows, the adjacency gradient in compact form, selection adjoint, edge-network adjoint
  * (forward recomputed).  nodes / adj: the step's OUTPUT state; h1 / agg1 [B,N,.], agg2, mx as saved

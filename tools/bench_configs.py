@@ -29,7 +29,7 @@ def dense_gnn(F, H):
         (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(dev)
 
 
-def timeit(fn, iters, warm=2):
+def timeit(fn, iters, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -107,7 +107,7 @@ run_dense("cfg2 + Linear(32,32) preprocessor (folded), donated", B, N, F, H, T, 
           torch.rand(T, B, F, device=dev), pre=torch.nn.Linear(F, 32).to(dev), donate_state=True)
 # cfg5 per-GPU share
 B, N, F, H, T = 256, 128, 32, 32, 64
-run_dense("cfg5/GPU LearnedEdge(32)", B, N, F, H, T, LearnedEdge(32).to(dev), torch.rand(T, B, F, device=dev), iters=3)
+run_dense("cfg5/GPU LearnedEdge(32)", B, N, F, H, T, LearnedEdge(32).to(dev), torch.rand(T, B, F, device=dev), iters=10)
 
 # cfg4 sparse
 if not ('cfg4'.startswith(ONLY) or ONLY.startswith('cfg4')):
