@@ -118,7 +118,7 @@ def capture(mem, gnn, obs):
     return g
 
 
-def time_step_kernel(mem, obs, reps=3):
+def time_step_kernel(mem, obs, reps=10):
     """Duration of the dominant kernel (k_step_rows, one launch per forward step) IN SITU: the T
     launches of a rollout through the C ABI on the evolving donated state, a HIP event pair on the
     launch stream around every launch; mean over T x reps launches.  Also the time-parallel

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
   const bool fold_deg = !EXACT && c1 != nullptr, fold_pe = !EXACT && pe != nullptr;
   // decisions of a distance selector that ran ahead of this kernel (gcm_edge_distance_pre): 1 / 0 per
   // image row j < cur (entries beyond are unspecified)
-  const bool has_sel = !EXACT && sel_row != nullptr;
+  const bool has_sel = sel_row != nullptr;
 
   const float* ng_in = nodes_in + (size_t)b * N * F;
   const float* ag_in = adj_in + (size_t)b * N * N;
@@ -645,6 +645,11 @@ extern "C" int gcm_dense_rows_step_fwd_ws(const float* obs, const float* nodes_i
                                               flags, B, N, F, H1, H2);
   GCM_RX(32, 128) GCM_RX(32, 64) GCM_RX(32, 32) GCM_RX(64, 128)
 #undef GCM_RX
+  // cfg3's shape (observations of 64, hidden 32, 128 nodes), with or without a distance selector's row
+  if (!c1 && !pe && F == 64 && H1 == 32 && H2 == 32 && N == 128)
+    return gcm_rows::launch<64, 32, 32, 128, true>(s, obs, nodes_in, adj_in, count_in, nodes_out, adj_out,
+                                                   count_out, cur_out, E, P, mx, saved, lay, flags, B, N, F,
+                                                   H1, H2, nullptr, nullptr, sel_row);
 #define GCM_R(a, b_, c)                                                                          \
   if (fp == a && hp == b_ && h2p == c)                                                           \
     return gcm_rows::launch<a, b_, c, 0, false>(s, obs, nodes_in, adj_in, count_in, nodes_out,   \
