@@ -120,9 +120,9 @@ def capture(mem, gnn, obs):
 
 def time_step_kernel(mem, obs, reps=10):
     """Duration of the dominant kernel (k_step_rows, one launch per forward step) IN SITU: the T
-    launches of a rollout through the C ABI on the evolving donated state, a HIP event pair on the
-    launch stream around every launch; mean over T x reps launches.  Also the time-parallel
-    backward kernel on the records of one rollout."""
+    launches of a rollout through the C ABI on the evolving donated state, enqueued back to back (as the
+    replayed graph does), a HIP event pair on the launch stream around every launch; mean over
+    T x reps launches.  Also the time-parallel backward kernel on the records of one rollout."""
     import ctypes
     import torch
     from gcm import _hip
@@ -147,16 +147,18 @@ def time_step_kernel(mem, obs, reps=10):
     evs = [(new_event(), new_event()) for _ in range(T)]
     spans = []
     saved_all = [torch.empty(lay[0], device=dev) for _ in range(T)]
+    ev_a = (ctypes.c_void_p * T)(*[a for a, _ in evs])
+    ev_b = (ctypes.c_void_p * T)(*[b for _, b in evs])
+    sv_p = (ctypes.c_void_p * T)(*[t_.data_ptr() for t_ in saved_all])
+    obs_c = obs.contiguous()
     for _ in range(reps + 1):
         nodes, adj, _, count = mem.get_initial_hidden_state(obs[0])
-        for t in range(T):
-            sv = saved_all[t]
-            # events recorded by the dispatch itself (kernel begin / end timestamps)
-            lib.gcm_debug_time_next_launch(evs[t][0], evs[t][1])
-            rc = lib.gcm_dense_rows_step_fwd(p(obs[t]), p(nodes), p(adj), p(count), p(nodes), p(adj), p(count), None,
-                                             cfg.arr_ptr, cfg.n_desc, p(params), cfg.has_bias, cfg.acts[0],
-                                             cfg.acts[1], p(sv), p(sv), p(flags), B, N, F, H, H, st)
-            assert rc == 0
+        # the T launches enqueued back to back from C (the cadence of the replayed graph that `value`
+        # times), each bracketed by events recorded by the dispatch itself (kernel begin / end timestamps)
+        rc = lib.gcm_debug_time_rows_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
+                                             p(params), cfg.has_bias, cfg.acts[0], cfg.acts[1], sv_p, p(flags),
+                                             ev_a, ev_b, T, B, N, F, H, H, st)
+        assert rc == 0
         torch.cuda.synchronize()
         ms = ctypes.c_float()
         row = []
@@ -354,7 +356,8 @@ def main():
                             "the rows that reach the kept belief row are evaluated and the state is advanced "
                             "in place: the kernel is bound by its chain of dependent latencies (one wave per "
                             "SIMD at B = 256 graphs on 256 CUs), not by bytes. avg_launch_ms: the T launches "
-                            "of a rollout in situ on the evolving state, each bracketed by HIP events recorded by "
+                            "of a rollout in situ on the evolving state, enqueued back to back from C (the cadence of the "
+                            "replayed graph the timed region runs), each bracketed by HIP events recorded by "
                             "the dispatch itself (hipExtLaunchKernelGGL start/stop events = the kernel begin/end "
                             "timestamps rocprofv3 --kernel-trace reports)"}
         fwd_full = 2 * N * N * (F + H) + 4 * N * (F * H + H * H)

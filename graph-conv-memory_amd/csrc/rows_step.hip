@@ -543,6 +543,27 @@ extern "C" int gcm_debug_time_next_launch(void* start_event, void* stop_event) {
   return GCM_OK;
 }
 
+/* Measurement aid (bench.py): T steps of gcm_dense_rows_step_fwd enqueued back to back from C on the
+ * evolving donated state - the launch cadence of a replayed HIP graph, which an interpreter loop does
+ * not reach (the gaps it leaves let the clocks sag and the caches cool) - every launch bracketed by the
+ * caller's HIP events, recorded by the dispatch itself (gcm_debug_time_next_launch). */
+extern "C" int gcm_debug_time_rows_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,
+                                           const gcm_selector_desc* selectors, int n_selectors,
+                                           const float* params, int has_bias, int act1, int act2,
+                                           float* const* saved_per_step, uint32_t* flags,
+                                           void* const* start_events, void* const* stop_events, int T,
+                                           int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs_all && saved_per_step && start_events && stop_events && T > 0);
+  for (int t = 0; t < T; ++t) {
+    gcm_debug_time_next_launch(start_events[t], stop_events[t]);
+    const int rc = gcm_dense_rows_step_fwd(obs_all + (size_t)t * B * F, nodes, adj, count, nodes, adj, count,
+                                           nullptr, selectors, n_selectors, params, has_bias, act1, act2,
+                                           saved_per_step[t], saved_per_step[t], flags, B, N, F, H1, H2, stream);
+    if (rc) return rc;
+  }
+  return GCM_OK;
+}
+
 extern "C" int gcm_dense_rows_supported(int N, int F, int H1, int H2) {
   if (N <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;
   if (N > 128 || F > 64 || H1 > 64 || H2 > 64) return 0;

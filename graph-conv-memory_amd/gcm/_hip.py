@@ -92,6 +92,7 @@ PROTOTYPES = {
     "gcm_dense_rows_step_fwd_ws": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_P, _Z] + [_I] * 5 + [_P]),
     "gcm_edge_distance_pre": (_I, [_P] * 4 + [_I, _F, _P] + [_I] * 4 + [_P, _Z] + [_I] * 3 + [_P]),
     "gcm_debug_time_next_launch": (_I, [_P, _P]),
+    "gcm_debug_time_rows_rollout": (_I, [_P] * 5 + [_I, _P, _I, _I, _I] + [_P] * 4 + [_I] * 6 + [_P]),
     "gcm_learned_step_supported": (_I, [_I] * 4),
     "gcm_learned_mlp_param_count": (_Z, [_I]),
     "gcm_learned_select_fused": (_I, [_P, _P, _P, _P, _I, _P, _F, _F, _F, _P, _I, _I, _I, _P]),

@@ -466,6 +466,16 @@ int gcm_edge_distance_pre(const float* nodes_in, const int64_t* count_in, const 
  * rocprofv3 --kernel-trace reports) instead of by marker packets around it.  One-shot. */
 int gcm_debug_time_next_launch(void* start_event, void* stop_event);
 
+/* Measurement aid (bench.py): T steps of gcm_dense_rows_step_fwd on the evolving donated state,
+ * enqueued back to back from C (the launch cadence of a replayed HIP graph), launch t bracketed by
+ * start_events[t] / stop_events[t] (hipEvent_t, recorded by the dispatch itself).  obs_all [T,B,F];
+ * saved_per_step: host array of T record pointers (gcm_dense_rows_layout). */
+int gcm_debug_time_rows_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,
+                                const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                int has_bias, int act1, int act2, float* const* saved_per_step,
+                                uint32_t* flags, void* const* start_events, void* const* stop_events, int T,
+                                int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+
 /* Parameter gradient of n_steps recorded steps in one pass (time-parallel BPTT; valid when neither
  * the observations nor the incoming node matrix need a gradient, so step t's adjoint depends on
  * g_mx[t] and its own record only).  saved_host / gmx_host: HOST arrays of n_steps DEVICE pointers
