@@ -51,9 +51,8 @@ class GradBucket:
     def all_reduce_mean(self, local_weight=1.0):
         """grad <- sum_r local_weight_r * grad_r  (pass local_weight = B_local / B_global to
         get the gradient of the global-batch mean loss from per-rank local-mean losses).
-        Three launches per call: gather into the flat buffer, the collective (RCCL: averaged in
-        flight when every rank passes 1 / world), one multi-tensor copy back; nothing at all in a
-        one-rank job with weight 1."""
+        Four launches per call: gather into the flat buffer, the weight, the collective, one
+        multi-tensor copy back; nothing at all in a one-rank job with weight 1."""
         if not self.params:
             return
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -68,13 +67,10 @@ class GradBucket:
                 off += p.numel()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         torch.cat([g.reshape(-1) for g in grads], out=self.flat)
-        if world > 1 and dist.get_backend() == "nccl" and abs(local_weight * world - 1.0) < 1e-12:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-        else:
-            if local_weight != 1.0:
-                self.flat.mul_(local_weight)
-            if world > 1:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if local_weight != 1.0:
+            self.flat.mul_(local_weight)
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
