@@ -150,6 +150,24 @@ __device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, cons
   }
 }
 
+// c0[o] = b0[o] + W0a[o, :] . x_cur: both vectors in registers before the first use (a load -> fma loop
+// exposed up to F memory round trips on the 32 threads that run it), summed in ascending f
+__device__ __forceinline__ float c0_dot(const float* __restrict__ w_row, const float* __restrict__ xcur,
+                                        float b0, int F) {
+  float wv[FP], xv[FP];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    wv[f] = w_row[f < F ? f : F - 1];
+    xv[f] = xcur[f < F ? f : F - 1];
+  }
+  asm volatile("" ::: "memory");
+  float c0 = b0;
+#pragma unroll
+  for (int f = 0; f < FP; ++f)
+    if (f < F) c0 = fmaf(wv[f], xv[f], c0);
+  return c0;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
@@ -206,6 +224,9 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
 
+  gcm_fused::Stage<FP, FP, false, false> st_w0, st_w1;   // in flight together with the loads below
+  st_w0.load(M.w0 + F, F, F, 2 * F, tid);
+  st_w1.load(M.w1, F, F, F, tid);
   if (ADVANCE) {
     // the state copy through registers (roll folded in), the node image for the edge network from the
     // same registers, the observation patched into row cur
@@ -246,12 +267,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
   } else {
     stage<NP>(xg, sX, N, F, F, tid);
   }
-  stage<FP>(M.w0 + F, sW0b, F, F, 2 * F, tid);
-  stage<FP>(M.w1, sW1, F, F, F, tid);
+  st_w0.store(sW0b, FS, tid);
+  st_w1.store(sW1, FS, tid);
   if (tid < FP) {
     const int o = tid < F ? tid : F - 1;
-    float c0 = M.b0[o];
-    for (int f = 0; f < F; ++f) c0 = fmaf(M.w0[o * 2 * F + f], xcur[f], c0);
+    const float c0 = c0_dot(M.w0 + (size_t)o * 2 * F, xcur, M.b0[o], F);
     const bool ok = tid < F;
     sVec[tid] = ok ? c0 : 0.f;
     sVec[FP + tid] = ok ? M.b1[o] : 0.f;
@@ -423,8 +443,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
   if (tid < NP) sCoef[tid] = tid < N ? ag[cur * N + tid] : 0.f;
   if (tid < FP) {
     const int o = tid < F ? tid : F - 1;
-    float c0 = M.b0[o];
-    for (int f = 0; f < F; ++f) c0 = fmaf(M.w0[o * 2 * F + f], xg[cur * F + f], c0);
+    const float c0 = c0_dot(M.w0 + (size_t)o * 2 * F, xg + (size_t)cur * F, M.b0[o], F);
     const bool ok = tid < F;
     sVec[tid] = ok ? c0 : 0.f;
     sVec[FP + tid] = ok ? M.b1[o] : 0.f;
