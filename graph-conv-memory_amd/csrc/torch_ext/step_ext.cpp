@@ -17,6 +17,9 @@
 // No device code here: PyTorch is plumbing (allocation, autograd graph, stream); the product is the
 // C-ABI library this file links against.
 #include <torch/extension.h>
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/python_variable.h>
 
 #include <cstring>
 #include <unordered_map>
@@ -219,162 +222,277 @@ std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& node
 
 // ---------------------------------------------------------------------------------------------
 // The live-row step (rows_step.hip / rows_bptt.hip): one kernel per forward step, donated or
-// functional state, and NO kernel per backward step - the step nodes record (saved record, g_mx)
-// in a holder owned by the parameter gate (gcm/_ops.py:_ParamGate), whose backward runs after all
-// of them and hands every recorded graph-step to one time-parallel launch (RowsHolder::flush).
-// Used when neither the observation nor the incoming node matrix needs a gradient.
+// functional state, and NO kernel and NO autograd node per backward step.  With no gradient flowing
+// into observations or nodes, step t's adjoint depends on g_mx[t] and step t's own record only, so
+// every step of a chain of hidden states hangs its belief tensor on ONE node (RowsChainNode: forward
+// output k = step k's mx).  The engine delivers all g_mx at once and the node hands every recorded
+// graph-step to one time-parallel launch (gcm_dense_rows_bptt).  Round 2 had one node per step plus a
+// gate node: ~8 us of engine time per step, more than the kernel takes.
 // ---------------------------------------------------------------------------------------------
-struct RowsHolder {
+struct RowsChainNode : public torch::autograd::Node {
   struct Rec {
-    at::Tensor buf, gmx;
-    int64_t B, sb, sh;
+    at::Tensor buf;      // the step's record (gcm_dense_rows_layout); starts with mx
+    uint32_t version;    // of buf (= of mx, its view) when recorded
   };
-  std::vector<Rec> recs;
-  int N, F, H1, H2, has_bias, act1, act2;
-  int64_t P;           // floats the backward kernel writes: GNN gradient (| d c1 with the deg term)
-  int64_t total = 0;   // length of the packed vector (>= P: constant sections may follow)
-  at::Tensor zero_p;   // the defined (zero) gradient the head step of a chain returns
-
-  RowsHolder(int N_, int F_, int H1_, int H2_, int has_bias_, int act1_, int act2_)
-      : N(N_), F(F_), H1(H1_), H2(H2_), has_bias(has_bias_), act1(act1_), act2(act2_) {
-    P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2) + ((has_bias & GCM_GNN_HAS_DEG_TERM) ? H1 : 0);
-    total = P;
-  }
-
-  int64_t pending() const { return (int64_t)recs.size(); }
-  void clear() { recs.clear(); }
-
-  // g_params = g_prev (may be undefined) + the parameter gradient of every recorded step
-  at::Tensor flush(const at::Tensor& packed, const at::Tensor& g_prev, int64_t stream) {
-    if (recs.empty()) return g_prev;
-    at::Tensor prev = g_prev;
-    if (prev.defined() && (prev.scalar_type() != at::kFloat || !prev.is_contiguous()))
-      prev = prev.to(at::kFloat).contiguous();
-    size_t i = 0;
-    std::vector<const float*> sv, gm;
-    while (i < recs.size()) {   // runs of steps with the same batch size and gradient strides
-      size_t j = i;
-      sv.clear();
-      gm.clear();
-      while (j < recs.size() && recs[j].B == recs[i].B && recs[j].sb == recs[i].sb &&
-             recs[j].sh == recs[i].sh) {
-        sv.push_back(recs[j].buf.data_ptr<float>());
-        gm.push_back(recs[j].gmx.data_ptr<float>());
-        ++j;
-      }
-      const int n = (int)(j - i), B = (int)recs[i].B;
-      const size_t ws_bytes = gcm_dense_rows_bptt_workspace_bytes(n, B, F, H1, H2);
-      at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
-      // the kernel writes the first P floats; constant sections behind them get a zero gradient
-      at::Tensor out = packed.numel() > P ? at::zeros({packed.numel()}, packed.options())
-                                          : at::empty({P}, packed.options());
-      const int rc = gcm_dense_rows_bptt(
-          sv.data(), gm.data(), n, (long)recs[i].sb, (long)recs[i].sh, packed.data_ptr<float>(),
-          has_bias, act1, act2, prev.defined() ? prev.data_ptr<float>() : nullptr,
-          out.data_ptr<float>(), ws.data_ptr(), ws_bytes, B, N, F, H1, H2,
-          reinterpret_cast<gcm_stream_t>(stream));
-      check(rc, "gcm_dense_rows_bptt");
-      prev = out;
-      i = j;
-    }
-    recs.clear();
-    return prev;
-  }
-};
-
-// The step's autograd node, written against torch::autograd::Node directly: it has ONE differentiable
-// input (the gated packed parameter vector), ONE output (mx) and a backward that only records
-// (record, g_mx) - the Function<> wrapper (AutogradContext, saved-data dictionary, variable-list
-// marshalling, materialised gradients) cost more host time per step than the kernel takes.
-struct RowsNode : public torch::autograd::Node {
-  at::Tensor buf;
-  RowsHolder* holder = nullptr;
-  bool is_head = false;
+  std::vector<Rec> recs;   // recs[k] <-> forward output k
+  at::Tensor packed;       // the packed parameter vector, detached (the kernel re-reads the weights)
+  int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
+  int64_t P = 0;           // floats the backward kernel writes (GNN gradient | d c1 with the deg term)
+  bool executed = false, released = false;
 
   variable_list apply(variable_list&& grads) override {
+    executed = true;
     variable_list out(1);
-    if (!buf.defined()) throw std::runtime_error("rows_step: backward through a released step record");
-    if (grads[0].defined()) {
-      at::Tensor g = grads[0];
-      if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
-      holder->recs.push_back({buf, g, g.size(0), g.stride(0), g.stride(1)});
+    TORCH_CHECK(!released, "Trying to backward through the live-row steps of a DenseGCM chain a second "
+                           "time (their records were freed); pass retain_graph=True to the first call");
+    TORCH_CHECK(grads.size() == recs.size(), "rows chain: ", grads.size(), " gradients for ", recs.size(),
+                " recorded steps");
+    // groups of steps with equal batch size and gradient strides (an expanded gradient, as mean()
+    // produces, is read with stride 0 - no .contiguous() copies), in first-seen order
+    struct Group {
+      int64_t B, sb, sh;
+      std::vector<const float*> sv, gm;
+    };
+    std::vector<Group> groups;
+    std::vector<at::Tensor> keep;
+    for (size_t k = 0; k < grads.size(); ++k) {
+      if (!grads[k].defined()) continue;
+      const Rec& r = recs[k];
+      TORCH_CHECK(r.buf._version() == r.version,
+                  "one of the variables needed for gradient computation has been modified by an inplace "
+                  "operation: the belief states returned by DenseGCM step ", k, " of this chain (version ",
+                  r.buf._version(), ", expected ", r.version, ") are part of the record its backward reads");
+      at::Tensor g = grads[k];
+      if (g.scalar_type() != at::kFloat) {
+        g = g.to(at::kFloat);
+        keep.push_back(g);
+      }
+      const int64_t B = g.size(0), sb = g.stride(0), sh = g.stride(1);
+      Group* grp = nullptr;
+      for (auto& c : groups)
+        if (c.B == B && c.sb == sb && c.sh == sh) grp = &c;
+      if (!grp) {
+        groups.push_back({B, sb, sh, {}, {}});
+        grp = &groups.back();
+      }
+      grp->sv.push_back(r.buf.data_ptr<float>());
+      grp->gm.push_back(g.data_ptr<float>());
     }
-    if (is_head) {   // a defined gradient so that the gate is certain to run
-      if (!holder->zero_p.defined()) holder->zero_p = at::zeros({holder->total}, buf.options());
-      out[0] = holder->zero_p;
+    if (groups.empty()) return out;
+    const gcm_stream_t stream =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(packed.get_device()).stream());
+    at::Tensor prev;
+    for (auto& c : groups) {
+      const int n = (int)c.sv.size();
+      const size_t ws_bytes = gcm_dense_rows_bptt_workspace_bytes(n, (int)c.B, F, H1, H2);
+      at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
+      // the kernel writes the first P floats; constant sections behind them get a zero gradient
+      at::Tensor res = packed.numel() > P ? at::zeros({packed.numel()}, packed.options())
+                                          : at::empty({P}, packed.options());
+      check(gcm_dense_rows_bptt(c.sv.data(), c.gm.data(), n, (long)c.sb, (long)c.sh,
+                                packed.data_ptr<float>(), has_bias, act1, act2,
+                                prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
+                                ws.data_ptr(), ws_bytes, (int)c.B, N, F, H1, H2, stream),
+            "gcm_dense_rows_bptt");
+      prev = res;
     }
+    out[0] = prev;
     return out;
   }
-  void release_variables() override { buf.reset(); }
-  std::string name() const override { return "GcmRowsStep"; }
+  void release_variables() override {
+    recs.clear();
+    released = true;
+  }
+  std::string name() const override { return "GcmRowsChain"; }
 };
 
-// -> {mx, nodes_out, adj_out, count_out}; donate: the three state tensors are the inputs themselves
-std::vector<at::Tensor> rows_step(const at::Tensor& obs, const at::Tensor& nodes_in,
-                                  const at::Tensor& adj_in, const at::Tensor& count_in,
-                                  const at::Tensor& packed, const at::Tensor& flags,
-                                  int64_t cfg_handle, int64_t stream, int64_t holder_handle,
-                                  bool donate, bool is_head) {
-  StepCfg* cfg = reinterpret_cast<StepCfg*>(cfg_handle);
-  TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() &&
-                  packed.is_cuda() && flags.is_cuda(),
-              "rows_step: every tensor must live on a HIP device (no CPU fallback)");
-  TORCH_CHECK(obs.scalar_type() == at::kFloat && nodes_in.scalar_type() == at::kFloat &&
-              adj_in.scalar_type() == at::kFloat && packed.scalar_type() == at::kFloat &&
-              count_in.scalar_type() == at::kLong && obs.is_contiguous() && nodes_in.is_contiguous() &&
-              adj_in.is_contiguous() && packed.is_contiguous() && count_in.is_contiguous());
-  const int64_t B = obs.size(0);
-  const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
-  TORCH_CHECK(nodes_in.size(0) == B && nodes_in.size(1) == N && nodes_in.size(2) == F &&
-                  adj_in.size(0) == B && adj_in.size(1) == N && adj_in.size(2) == N &&
-                  count_in.size(0) == B && obs.size(1) == F,
-              "rows_step: hidden state and observation shapes disagree");
-  const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad() && holder_handle != 0;
-  if (need_bwd) {
-    RowsHolder* holder = reinterpret_cast<RowsHolder*>(holder_handle);
-    TORCH_CHECK(packed.numel() >= holder->P, "rows_step: packed parameter vector too short");
-    if (holder->total != packed.numel()) {
-      holder->total = packed.numel();
-      holder->zero_p = at::Tensor();
+// The per-step host path of `belief, m = gcm(obs, m)` on the live-row kernels.  One instance per
+// (DenseGCM module, step configuration).  `run` is the checked entry (Python validated the hidden
+// state and built the packed parameter vector); `step` is what DenseGCM.__call__ tries first: when
+// the hidden state is the very tuple of tensors the previous call returned, the observation has the
+// same shape, the parameters are the same objects at the same versions and grad mode has not
+// changed, everything `run` needs is known to hold and the step is ONE call from Python: two
+// allocations, one launch, one output registered on the chain node.  Anything else returns None and
+// Python takes the checked path.
+struct RowsFast {
+  StepCfg* cfg = nullptr;
+  at::Tensor packed, flags;
+  bool donate = false, grad_mode = false, armed = false;
+  std::shared_ptr<RowsChainNode> node;
+  std::vector<pybind11::object> dicts, keys;   // module._parameters dicts and the names read from them
+  std::vector<pybind11::object> objs;          // the Parameter objects (or None) the packed vector was built from
+  std::vector<uint32_t> vers;
+  at::Tensor l_nodes, l_adj, l_weights, l_count;   // the hidden state returned last
+  int64_t xB = -1, xF = -1, n_steps = 0;
+  int dev = -1;
+
+  explicit RowsFast(const std::vector<std::pair<pybind11::object, pybind11::object>>& specs) {
+    for (const auto& s : specs) {
+      dicts.push_back(s.first);
+      keys.push_back(s.second);
     }
   }
-  size_t lay[6];
-  check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
-  at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
-  at::Tensor nodes_out, adj_out, count_out;
-  if (donate) {
-    nodes_out = nodes_in;
-    adj_out = adj_in;
-    count_out = count_in;
-  } else {
-    const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * (int64_t)N * N);
-    at::Tensor st = at::empty({n_nodes + n_adj + pad64(2 * B)}, obs.options());
-    nodes_out = st.narrow(0, 0, B * N * F).view({B, N, F});
-    adj_out = st.narrow(0, n_nodes, B * (int64_t)N * N).view({B, N, N});
-    count_out = st.narrow(0, n_nodes + n_adj, 2 * B).view(at::kLong);
+
+  bool params_current() const {
+    for (size_t i = 0; i < dicts.size(); ++i) {
+      PyObject* o = PyDict_GetItem(dicts[i].ptr(), keys[i].ptr());   // borrowed
+      if (o != objs[i].ptr()) return false;
+      if (o && THPVariable_Check(o) && THPVariable_Unpack(o)._version() != vers[i]) return false;
+    }
+    return true;
   }
-  size_t ws_bytes = 0;
-  void* ws = cfg->workspace((int)B, obs, &ws_bytes);
-  const int rc = gcm_dense_rows_step_fwd_ws(
-      obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
-      count_in.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), adj_out.data_ptr<float>(),
-      count_out.data_ptr<int64_t>(), nullptr, cfg->descs.empty() ? nullptr : cfg->descs.data(),
-      (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
-      buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
-      reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2,
-      reinterpret_cast<gcm_stream_t>(stream));
-  check(rc, "gcm_dense_rows_step_fwd_ws");
-  at::Tensor mx = buf.narrow(0, 0, B * H2).view({B, H2});   // the record starts with the belief states
-  if (need_bwd) {
-    auto node = std::make_shared<RowsNode>();
-    node->buf = buf;
-    node->holder = reinterpret_cast<RowsHolder*>(holder_handle);
-    node->is_head = is_head;
-    node->set_next_edges(torch::autograd::collect_next_edges(packed));
-    torch::autograd::create_gradient_edge(mx, std::move(node));
+
+  void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_) {
+    cfg = reinterpret_cast<StepCfg*>(cfg_handle);
+    packed = packed_;
+    flags = flags_;
+    donate = donate_;
+    grad_mode = at::GradMode::is_enabled();
+    dev = packed.get_device();
+    objs.clear();
+    vers.clear();
+    for (size_t i = 0; i < dicts.size(); ++i) {
+      PyObject* o = PyDict_GetItem(dicts[i].ptr(), keys[i].ptr());
+      objs.push_back(o ? pybind11::reinterpret_borrow<pybind11::object>(o) : pybind11::object());
+      vers.push_back(o && THPVariable_Check(o) ? THPVariable_Unpack(o)._version() : 0);
+    }
+    node.reset();
+    if (grad_mode && packed.requires_grad()) {
+      node = std::shared_ptr<RowsChainNode>(new RowsChainNode(), torch::autograd::deleteNode);
+      node->packed = packed.detach();
+      node->N = cfg->N; node->F = cfg->F; node->H1 = cfg->H1; node->H2 = cfg->H2;
+      node->has_bias = cfg->has_bias; node->act1 = cfg->act1; node->act2 = cfg->act2;
+      node->P = (int64_t)gcm_dense_gnn2_param_count(cfg->F, cfg->H1, cfg->H2) +
+                ((cfg->has_bias & GCM_GNN_HAS_DEG_TERM) ? cfg->H1 : 0);
+      TORCH_CHECK(packed.numel() >= node->P, "rows step: packed parameter vector too short");
+      node->set_next_edges(torch::autograd::collect_next_edges(packed));
+    }
+    armed = true;
   }
-  return {mx, nodes_out, adj_out, count_out};
-}
+
+  // one step; inputs validated by the caller.  -> mx; the new state lands in l_*
+  at::Tensor launch(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                    const at::Tensor& weights, const at::Tensor& count_in) {
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = node != nullptr;
+    size_t lay[6];
+    check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
+    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    at::Tensor nodes_out, adj_out, count_out;
+    if (donate) {
+      nodes_out = nodes_in;
+      adj_out = adj_in;
+      count_out = count_in;
+    } else {
+      const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * (int64_t)N * N);
+      at::Tensor st = at::empty({n_nodes + n_adj + pad64(2 * B)}, obs.options());
+      nodes_out = st.narrow(0, 0, B * N * F).view({B, N, F});
+      adj_out = st.narrow(0, n_nodes, B * (int64_t)N * N).view({B, N, N});
+      count_out = st.narrow(0, n_nodes + n_adj, 2 * B).view(at::kLong);
+    }
+    size_t ws_bytes = 0;
+    void* ws = cfg->workspace((int)B, obs, &ws_bytes);
+    const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
+    check(gcm_dense_rows_step_fwd_ws(
+              obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+              count_in.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), adj_out.data_ptr<float>(),
+              count_out.data_ptr<int64_t>(), nullptr, cfg->descs.empty() ? nullptr : cfg->descs.data(),
+              (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
+              buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
+              reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2, stream),
+          "gcm_dense_rows_step_fwd_ws");
+    at::Tensor mx = buf.narrow(0, 0, B * H2).view({B, H2});   // the record starts with the belief states
+    if (need_bwd) {
+      node->recs.push_back({buf, buf._version()});
+      torch::autograd::create_gradient_edge(mx, node);
+    }
+    l_nodes = nodes_out;
+    l_adj = adj_out;
+    l_weights = weights;
+    l_count = count_out;
+    xB = B;
+    xF = obs.size(1);
+    ++n_steps;
+    return mx;
+  }
+
+  bool continues(const at::Tensor& nodes, const at::Tensor& adj, const at::Tensor& weights,
+                 const at::Tensor& count) const {
+    return armed && nodes.unsafeGetTensorImpl() == l_nodes.unsafeGetTensorImpl() &&
+           adj.unsafeGetTensorImpl() == l_adj.unsafeGetTensorImpl() &&
+           weights.unsafeGetTensorImpl() == l_weights.unsafeGetTensorImpl() &&
+           count.unsafeGetTensorImpl() == l_count.unsafeGetTensorImpl();
+  }
+
+  // the checked entry -> (mx, nodes, adj, num_nodes)
+  pybind11::tuple run(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                      const at::Tensor& weights, const at::Tensor& count_in, const at::Tensor& packed_,
+                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_) {
+    StepCfg* c = reinterpret_cast<StepCfg*>(cfg_handle);
+    TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() &&
+                    packed_.is_cuda() && flags_.is_cuda(),
+                "rows_step: every tensor must live on a HIP device (no CPU fallback)");
+    TORCH_CHECK(obs.scalar_type() == at::kFloat && nodes_in.scalar_type() == at::kFloat &&
+                adj_in.scalar_type() == at::kFloat && packed_.scalar_type() == at::kFloat &&
+                count_in.scalar_type() == at::kLong && obs.is_contiguous() && nodes_in.is_contiguous() &&
+                adj_in.is_contiguous() && packed_.is_contiguous() && count_in.is_contiguous());
+    const int64_t B = obs.size(0);
+    TORCH_CHECK(obs.dim() == 2 && nodes_in.dim() == 3 && adj_in.dim() == 3 && nodes_in.size(0) == B &&
+                    nodes_in.size(1) == c->N && nodes_in.size(2) == c->F && adj_in.size(0) == B &&
+                    adj_in.size(1) == c->N && adj_in.size(2) == c->N && count_in.dim() == 1 &&
+                    count_in.size(0) == B && obs.size(1) == c->F,
+                "rows_step: hidden state and observation shapes disagree");
+    TORCH_CHECK(obs.get_device() == c10::hip::current_device() && nodes_in.get_device() == obs.get_device() &&
+                    packed_.get_device() == obs.get_device(),
+                "rows_step: tensors must live on the current device");
+    if (!armed || c != cfg || packed_.unsafeGetTensorImpl() != packed.unsafeGetTensorImpl() ||
+        flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || donate_ != donate ||
+        grad_mode != at::GradMode::is_enabled() || (node && node->executed))
+      arm(packed_, flags_, cfg_handle, donate_);
+    at::Tensor mx = launch(obs, nodes_in, adj_in, weights, count_in);
+    return pybind11::make_tuple(mx, l_nodes, l_adj, l_count);
+  }
+
+  // the unchecked entry: (mx, hidden) or None
+  pybind11::object step(pybind11::handle x, pybind11::handle hidden) {
+    if (!armed || !PyTuple_Check(hidden.ptr()) || PyTuple_GET_SIZE(hidden.ptr()) != 4 ||
+        !THPVariable_Check(x.ptr()))
+      return pybind11::none();
+    PyObject* h = hidden.ptr();
+    PyObject *pn = PyTuple_GET_ITEM(h, 0), *pa = PyTuple_GET_ITEM(h, 1), *pw = PyTuple_GET_ITEM(h, 2),
+             *pc = PyTuple_GET_ITEM(h, 3);
+    if (!THPVariable_Check(pn) || !THPVariable_Check(pa) || !THPVariable_Check(pw) || !THPVariable_Check(pc))
+      return pybind11::none();
+    if (!continues(THPVariable_Unpack(pn), THPVariable_Unpack(pa), THPVariable_Unpack(pw),
+                   THPVariable_Unpack(pc)))
+      return pybind11::none();
+    const at::Tensor& xt = THPVariable_Unpack(x.ptr());
+    const bool grad = at::GradMode::is_enabled();
+    if (grad != grad_mode || (node && node->executed) || xt.dim() != 2 || xt.size(0) != xB ||
+        xt.size(1) != xF || xt.scalar_type() != at::kFloat || !xt.is_cuda() || xt.get_device() != dev ||
+        c10::hip::current_device() != dev || (grad && xt.requires_grad()) || !params_current())
+      return pybind11::none();
+    at::Tensor obs = xt.is_contiguous() ? xt : xt.contiguous();
+    at::Tensor mx = launch(obs, l_nodes, l_adj, l_weights, l_count);
+    pybind11::object pmx = pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(mx));
+    if (donate) return pybind11::make_tuple(pmx, pybind11::reinterpret_borrow<pybind11::object>(h));
+    pybind11::object hn = pybind11::reinterpret_steal<pybind11::object>(PyTuple_New(4));
+    PyTuple_SET_ITEM(hn.ptr(), 0, THPVariable_Wrap(l_nodes));
+    PyTuple_SET_ITEM(hn.ptr(), 1, THPVariable_Wrap(l_adj));
+    Py_INCREF(pw);
+    PyTuple_SET_ITEM(hn.ptr(), 2, pw);
+    PyTuple_SET_ITEM(hn.ptr(), 3, THPVariable_Wrap(l_count));
+    return pybind11::make_tuple(pmx, hn);
+  }
+
+  int64_t pending() const { return node && !node->executed ? (int64_t)node->recs.size() : 0; }
+  void forget() {   // drop the packed vector (and with it the references into its autograd graph)
+    armed = false;
+    node.reset();
+    packed = at::Tensor();
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // DenseGCM + LearnedEdge (default edge network, observations without gradient) as ONE node per step:
@@ -543,16 +661,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("handle", [](StepCfg& c) { return reinterpret_cast<int64_t>(&c); })
       .def("update_descs", &StepCfg::update_descs);
   m.def("fused_step", &fused_step);
-  pybind11::class_<RowsHolder>(m, "RowsHolder")
-      .def(pybind11::init<int, int, int, int, int, int, int>())
-      .def("handle", [](RowsHolder& h) { return reinterpret_cast<int64_t>(&h); })
-      .def("pending", &RowsHolder::pending)
-      .def("clear", &RowsHolder::clear)
-      .def("flush", [](RowsHolder& h, const at::Tensor& packed, const c10::optional<at::Tensor>& g,
-                       int64_t stream) {
-        return h.flush(packed, g.has_value() ? *g : at::Tensor(), stream);
-      });
-  m.def("rows_step", &rows_step);
+  pybind11::class_<RowsFast>(m, "RowsFast")
+      .def(pybind11::init<const std::vector<std::pair<pybind11::object, pybind11::object>>&>())
+      .def("run", &RowsFast::run)
+      .def("step", &RowsFast::step)
+      .def("continues", &RowsFast::continues)
+      .def("pending", &RowsFast::pending)
+      .def("forget", &RowsFast::forget)
+      .def("steps", [](RowsFast& f) { return f.n_steps; })
+      .def("has_chain", [](RowsFast& f) { return f.node != nullptr; });
   pybind11::class_<LearnedCfg>(m, "LearnedCfg")
       .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())
       .def("handle", [](LearnedCfg& c) { return reinterpret_cast<int64_t>(&c); });

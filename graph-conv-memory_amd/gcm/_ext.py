@@ -22,15 +22,21 @@ _tried = False
 
 def build(verbose=False):
     """Compile the extension into gcm/_lib/ext/ (host C++ only; links libgcm_hip.so)."""
+    import torch
     from torch.utils import cpp_extension
     from . import _hip
     _hip.lib()   # libgcm_hip.so must exist (and is then already mapped when the module loads)
     os.makedirs(_EXT_DIR, exist_ok=True)
     global _mod, _tried
     _mod = cpp_extension.load(
-        name=_NAME, sources=[_SRC], extra_include_paths=[_INCLUDE],
-        extra_cflags=["-O2", "-std=c++17"],
-        extra_ldflags=[f"-L{_LIB_DIR}", "-lgcm_hip", "-Wl,-rpath,'$$ORIGIN/..'"],
+        name=_NAME, sources=[_SRC],
+        # host C++ only; the ROCm include path is for c10/hip (current stream / device of the
+        # process), whose library torch has loaded already
+        extra_include_paths=[_INCLUDE, os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")],
+        extra_cflags=["-O2", "-std=c++17", "-Wno-deprecated-declarations"],
+        extra_ldflags=[f"-L{_LIB_DIR}", "-lgcm_hip", "-Wl,-rpath,'$$ORIGIN/..'",
+                       f"-L{os.path.join(os.path.dirname(torch.__file__), 'lib')}", "-lc10_hip",
+                       "-ltorch_python"],
         build_directory=_EXT_DIR, verbose=verbose)
     _tried = True
     return _mod

@@ -644,7 +644,8 @@ class StepConfig:
             and n_dist <= 1 and not any(d.kind == _hip.SEL_DISTANCE and d.bidirectional for d in descs)
             and sum(d.n_hops for d in descs if d.kind == _hip.SEL_TEMPORAL) <= 16
             and lib.gcm_dense_rows_supported(N, F, H1, H2)
-            and _ext.module() is not None and hasattr(_ext.module(), "rows_step"))
+            and _ext.module() is not None and hasattr(_ext.module(), "RowsFast"))
+        self._rows_fast = None
 
     # (Linear preprocessor | None, PositionalEncoding in "add" mode | None) folded into the live-row
     # step, or None (gcm.py:_fold_config)
@@ -694,10 +695,20 @@ class StepConfig:
             self._zero_params[dev] = z
         return z
 
-    def rows_holder(self):
-        """a fresh record holder for one packed parameter vector (C++: RowsHolder)"""
-        return _ext.module().RowsHolder(self.N, self.F, self.H1, self.H2, self.has_bias,
-                                        self.acts[0], self.acts[1])
+    def rows_fast(self):
+        """The host path of the live-row step (C++: RowsFast in csrc/torch_ext/step_ext.cpp), one per
+        configuration: it validates a continuing chain by itself - hidden state returned by the
+        previous call, same parameter objects at the same versions (read through the modules' own
+        `_parameters` dicts) - and runs the step without the interpreter."""
+        f = self._rows_fast
+        if f is None:
+            rel0, root0, rel1, root1 = self.lins
+            specs = [(rel0._parameters, "weight"), (root0._parameters, "weight"), (rel0._parameters, "bias"),
+                     (rel1._parameters, "weight"), (root1._parameters, "weight"), (rel1._parameters, "bias")]
+            if self.fold is not None and self.fold[0] is not None:
+                specs += [(self.fold[0]._parameters, "weight"), (self.fold[0]._parameters, "bias")]
+            f = self._rows_fast = _ext.module().RowsFast(specs)
+        return f
 
     def cpp_handle(self):
         """address of the C++ twin of this config (0 when the torch extension is not built)"""
@@ -721,10 +732,6 @@ class StepConfig:
             c = (_ext.module().fused_step, h, self.device.index) if h else False
             self._cpp_call = c
         return c or None
-
-    @property
-    def rows_call(self):
-        return _ext.module().rows_step
 
     def refresh_pointers(self):
         """re-read the device pointers baked into the selector descriptors (a re-assigned
@@ -885,19 +892,18 @@ class _ParamGate(torch.autograd.Function):
     gradient of ALL of them at once -
       * fused-step nodes (gcm_dense_step_bwd_slabs) accumulated per-graph slabs into `holder`:
         one slab sum instead of T slab sums and T engine-side adds;
-      * live-row step nodes (rows_step.hip) only recorded (saved record, g_mx) in `rows`: one
-        time-parallel launch over every recorded graph-step (gcm_dense_rows_bptt)."""
+    (The live-row steps do not pass through the gate: all of a chain's steps share one autograd node
+    - RowsChainNode in csrc/torch_ext/step_ext.cpp - that consumes the packed vector directly.)"""
 
     @staticmethod
-    def forward(ctx, packed, holder, rows):
-        ctx.holder, ctx.rows = holder, rows
-        ctx.packed = packed.detach()
+    def forward(ctx, packed, holder):
+        ctx.holder = holder
         ctx.set_materialize_grads(False)
         return packed.view_as(packed)
 
     @staticmethod
     def backward(ctx, g):
-        holder, rows = ctx.holder, ctx.rows
+        holder = ctx.holder
         total = g
         for B, slabs in holder.slabs.items():
             out = torch.empty(holder.P, device=slabs.device, dtype=_f32)
@@ -905,14 +911,11 @@ class _ParamGate(torch.autograd.Function):
                   _hip.stream())
             slabs.zero_()
             total = out
-        if rows is not None and rows.pending():
-            total = rows.flush(ctx.packed, total,
-                               torch._C._cuda_getCurrentRawStream(ctx.packed.device.index))
-        return total, None, None
+        return total, None
 
 
-def param_gate(packed, holder, rows=None):
-    return _ParamGate.apply(packed, holder, rows)
+def param_gate(packed, holder):
+    return _ParamGate.apply(packed, holder)
 
 
 def fused_step(obs, nodes_in, packed, adj_in, count_in, flags, cfg, slab_acc=None, is_head=True):

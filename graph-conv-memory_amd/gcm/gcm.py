@@ -17,6 +17,7 @@ import math
 from typing import Tuple, Union
 
 import torch
+from torch.nn.modules.module import _has_any_global_hook
 
 from . import _hip, _ops
 
@@ -123,7 +124,8 @@ class DenseGCM(torch.nn.Module):
         self._flags = {}      # device -> uint32[1] flag word written by the kernels
         self._pending = []    # [(pinned host copy, event)] of flag words in flight
         self._pinned_pool = []
-        self._steps = 0
+        self._ctr = [0]       # steps since the last poll (a list: nn.Module.__setattr__ is slow)
+        self._fast = None     # (RowsFast, flag word) of the last live-row step: what __call__ tries first
 
     # -- state ---------------------------------------------------------------
     def get_initial_hidden_state(self, x):
@@ -138,6 +140,14 @@ class DenseGCM(torch.nn.Module):
             weights = torch.zeros(0, device=x.device)
         num_nodes = torch.zeros(B, dtype=torch.long, device=x.device)
         return nodes, edges, weights, num_nodes
+
+    def rows_steps(self):
+        """Number of steps this module has run on the live-row kernels (csrc/rows_step.hip) so far."""
+        n = 0
+        for cfg in self._cfg_cache.values():
+            if cfg is not False and cfg._rows_fast is not None:
+                n += cfg._rows_fast.steps()
+        return n
 
     # -- device flag word ------------------------------------------------------
     def _flag_word(self, device):
@@ -179,9 +189,11 @@ class DenseGCM(torch.nn.Module):
             self._raise_for(bits)
 
     def _poll(self, flags):
-        self._steps += 1
-        if self.finite_check == "deferred" and self._steps % self.poll_interval:
+        c = self._ctr
+        c[0] += 1
+        if self.finite_check == "deferred" and c[0] < self.poll_interval:
             return                        # the common step: nothing to look at
+        c[0] = 0
         if torch.cuda.is_current_stream_capturing():
             return                        # inside a HIP-graph capture: the flag word is read later
         if self.finite_check == "sync":
@@ -319,8 +331,14 @@ class DenseGCM(torch.nn.Module):
         if mods and isinstance(mods[0], LearnedEdge):
             sel = mods[0]
             net = _ops.default_edge_network(sel.edge_network)
+            # the kernels index the edge network with the fixed F-wide layout of learned.py:38-51
+            # (2F -> F -> F -> 1, LayerNorms over F, every bias present): anything else - e.g. a hidden
+            # width G != F, which default_edge_network accepts - takes the layered path
             if (convs[0].in_channels == F and net is not None and net[0].in_features == 2 * F
-                    and net[0].out_features == F and net[6].out_features == 1
+                    and net[0].out_features == F and net[3].in_features == F and net[3].out_features == F
+                    and net[6].in_features == F and net[6].out_features == 1
+                    and tuple(net[2].normalized_shape) == (F,) and tuple(net[5].normalized_shape) == (F,)
+                    and all(net[i].bias is not None for i in (0, 3, 6))
                     and _hip.lib().gcm_learned_step_supported(N, F, H1, H2)):
                 has_bias = (1 if convs[0].lin_rel.bias is not None else 0) | \
                            (2 if convs[1].lin_rel.bias is not None else 0)
@@ -411,6 +429,8 @@ class DenseGCM(torch.nn.Module):
         # bound to the stream they were created on - a later HIP-graph capture of this module would
         # then be made to synchronise with that (possibly the default) stream and fail
         self._packed_cache = cache = None
+        if cfg._rows_fast is not None:
+            cfg._rows_fast.forget()
         key = torch.is_grad_enabled()
         sizes = (cfg.H1 * cfg.F, cfg.H1 * cfg.F, cfg.H1, cfg.H2 * cfg.H1, cfg.H2 * cfg.H1, cfg.H2)
         if cfg.learned_sel is not None:
@@ -422,20 +442,20 @@ class DenseGCM(torch.nn.Module):
         if fold is not None:
             parts = self._folded_parts(cfg, tensors, parts)
         packed = torch.cat(parts)
+        if cfg.learned_sel is not None:
+            assert packed.numel() == cfg.P_total, "edge network does not have the fused kernels' layout"
         used = [False]
-        gated = holder = rows = None
+        gated = holder = None
         if packed.requires_grad:
             packed.register_hook(lambda g: used.__setitem__(0, True))
             holder = _ops.SlabHolder(cfg.P_total if cfg.learned_sel is not None else cfg.P, dev)
-            rows = cfg.rows_holder() if cfg.rows_ok else None
-            gated = _ops.param_gate(packed, holder, rows)
+            gated = _ops.param_gate(packed, holder)
         for d in cfg.descs:               # a re-assigned dist_param must not leave a stale pointer
             if d.kind == _hip.SEL_DISTANCE:
                 cfg.refresh_pointers()
                 break
         self._packed_cache = (key, packed, used,
-                              [(t, t._version if t is not None else 0) for t in tensors], gated, holder,
-                              rows)
+                              [(t, t._version if t is not None else 0) for t in tensors], gated, holder)
         return packed
 
     @staticmethod
@@ -459,40 +479,32 @@ class DenseGCM(torch.nn.Module):
         return parts
 
     def _forward_rows(self, x, hidden, cfg, flags, link):
-        """The live-row step (csrc/rows_step.hip): one kernel forward, no kernel backward (the
-        parameter gate launches one time-parallel pass over every recorded step).  Taken when
-        neither x nor the incoming node matrix needs a gradient."""
+        """The live-row step (csrc/rows_step.hip), checked entry: one kernel forward, no kernel and no
+        autograd node per step backward (every step of a chain hangs its belief tensor on one node,
+        whose backward is one time-parallel launch over every recorded step).  Taken when neither x
+        nor the incoming node matrix needs a gradient.  A continuing chain does not come through
+        here at all: DenseGCM.__call__ hands it to the C++ host path (RowsFast.step) directly."""
         nodes, adj, weights, num_nodes = hidden
-        root = self._packed_params(cfg, head=link is None)
-        pc = self._packed_cache
-        gated, rows = pc[4], pc[6]
-        if gated is not None:
-            packed, hh = gated, rows.handle()
-            is_head = link is None or link[5] is not root
-        else:
-            packed, hh, is_head = root, 0, True
+        fast = cfg.rows_fast()
+        cont = fast.continues(nodes, adj, weights, num_nodes)
+        root = self._packed_params(cfg, head=link is None and not cont)
         if not x.is_contiguous():
             x = x.contiguous()
-        if link is None and not (nodes.is_contiguous() and adj.is_contiguous()
-                                 and num_nodes.is_contiguous()):
+        if not (nodes.is_contiguous() and adj.is_contiguous() and num_nodes.is_contiguous()):
             if self.donate_state:
                 raise ValueError("donate_state=True needs contiguous hidden-state tensors")
             nodes, adj, num_nodes = nodes.contiguous(), adj.contiguous(), num_nodes.contiguous()
         donate = self.donate_state
-        fn, handle, dev_index = cfg.cpp_call()
-        mx, n2, a2, c2 = cfg.rows_call(
-            x, nodes, adj, num_nodes, packed, flags, handle,
-            torch._C._cuda_getCurrentRawStream(dev_index), hh, donate, is_head)
+        mx, n2, a2, c2 = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(), donate)
         if donate:
-            if link is None or link[5] is not root:
-                nodes._gcm_link = (self._token, adj, cfg, flags, None, root, x.shape, weights,
-                                   num_nodes)
             out = hidden
         else:
-            n2._gcm_link = (self._token, a2, cfg, flags, None, root, x.shape, weights, c2)
             if self.mutate_num_nodes_on_overflow:
                 num_nodes.copy_(c2 - 1)
             out = (n2, a2, weights, c2)
+        # the next call of this module tries the unchecked entry first (not with the compat flag that
+        # writes into the caller's num_nodes: that needs the checked path every step)
+        self._fast = None if self.mutate_num_nodes_on_overflow else (fast, flags)
         if self.finite_check != "off":
             self._poll(flags)
         return mx, out
@@ -606,6 +618,23 @@ class DenseGCM(torch.nn.Module):
         return mx_all, (nodes_T, adj_T, weights, count_T)
 
     # -- the step --------------------------------------------------------------
+    def __call__(self, *args, **kwargs):
+        """`belief, m = gcm(obs, m)`.  A step that continues the chain of the previous call on the
+        live-row kernels is ONE call into the C++ host path (RowsFast.step validates exactly that:
+        same hidden-state tensors as returned last, same observation shape, parameters untouched, grad
+        mode unchanged); everything else - and any module with hooks - goes through
+        torch.nn.Module.__call__ and forward() below."""
+        fast = self._fast
+        if (fast is not None and len(args) == 2 and not kwargs and not self._forward_hooks
+                and not self._forward_pre_hooks and not self._backward_hooks
+                and not self._backward_pre_hooks and not _has_any_global_hook()):
+            r = fast[0].step(args[0], args[1])
+            if r is not None:
+                if self.finite_check != "off":
+                    self._poll(fast[1])
+                return r
+        return torch.nn.Module.__call__(self, *args, **kwargs)
+
     def forward(
         self,
         x,
@@ -616,6 +645,12 @@ class DenseGCM(torch.nn.Module):
         if hidden is None:
             hidden = self.get_initial_hidden_state(x)
         nodes, adj, weights, num_nodes = hidden
+
+        # the kernels are launched on the CURRENT device's stream: tensors on another GPU get a
+        # device guard for the call (PyTorch ops in the reference guard implicitly)
+        if x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return self.forward(x, hidden)
 
         # A hidden state this module returned itself (same node / adjacency tensors, same input
         # shape): everything checked below held for it by construction.
@@ -631,12 +666,6 @@ class DenseGCM(torch.nn.Module):
             if no_dx:
                 return self._forward_learned(x, hidden, cfg, link[3], link)
             # (observations with gradient: the layered path below)
-
-        # the kernels are launched on the CURRENT device's stream: tensors on another GPU get a
-        # device guard for the call (PyTorch ops in the reference guard implicitly)
-        if x.is_cuda and x.device.index != torch.cuda.current_device():
-            with torch.cuda.device(x.device):
-                return self.forward(x, hidden)
 
         # gcm.py:246-260, as one comparison
         if (x.dtype, nodes.dtype, adj.dtype, weights.dtype, num_nodes.dtype, num_nodes.dim()) != _DTYPES:

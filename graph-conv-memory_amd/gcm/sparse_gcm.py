@@ -64,11 +64,16 @@ class SparseGCM(torch.nn.Module):
             self._flags[device] = f
         return f
 
-    def _merge(self, adj, new_adj, selector, B, flags):
+    def _merge(self, adj, new_adj, selector, B, flags, first=True):
         """sparse_gcm.py:132-139: concatenate the COO lists and coalesce.  Selectors whose edges
         all end in new nodes (every shipped one) merge as a segmented concatenation - no sort;
-        a violated order is flagged on the device and surfaces at the call's flag check."""
-        if getattr(selector, "new_sinks_only", False) and new_adj.is_coalesced() and adj.is_coalesced():
+        a violated order is flagged on the device and surfaces at the call's flag check.
+        `first`: the merge into the STORED state.  Only there does "stored entries, then the new
+        ones" hold per graph: after it the list already has entries ending in the new nodes, so
+        the aux selector's edges (sparse_gcm.py:146-152) interleave with them and may duplicate
+        them - that merge is the reference's cat + coalesce (duplicates summed)."""
+        if (first and getattr(selector, "new_sinks_only", False) and new_adj.is_coalesced()
+                and adj.is_coalesced()):
             idx, val = _ops.coo_merge_segments(adj.indices(), adj.values(), new_adj.indices(),
                                                new_adj.values(), getattr(new_adj, "gcm_bptr", None), B, flags)
             return torch.sparse_coo_tensor(idx, val, size=adj.shape, is_coalesced=True)
@@ -132,7 +137,7 @@ class SparseGCM(torch.nn.Module):
             dirty_nodes = self.positional_encoder(dirty_nodes, T + taus)
         if self.aux_edge_selectors:
             adj = self._merge(adj, self.aux_edge_selectors(dirty_nodes, T, taus, B), self.aux_edge_selectors,
-                              B, flags)
+                              B, flags, first=False)
 
         # sparse_gcm.py:160-164: all weights become 1 while keeping the path to the logits
         v = adj.values()

@@ -113,3 +113,28 @@ def fold_selector(spec, temporal_cls, dense_cls):
     if spec[0] == "dense":
         return dense_cls()
     return temporal_cls(spec[1], direction=spec[2])
+
+
+def fp64_rollout_bounds(ref, obs, hidden, weight, sel_factory, graph_size, factor=3.0, floor=5e-7):
+    """The oracle on (obs, hidden) in fp32 and in float64, loss = sum(out * weight): ->
+    (out32, final hidden32, {param name: (g64, atol)}, (out64, out_atol)) with
+    atol = max(factor x |reference-fp32 - fp64|, floor x scale) - what fp32 can deliver for the case,
+    instead of a fixed rtol.  sel_factory() -> a fresh oracle selector (stateless ones may be shared)."""
+    import copy
+    from oracle import dense as od
+    ref.zero_grad(set_to_none=True)
+    h32 = None if hidden is None else tuple(t.clone() for t in hidden)
+    out32, hid32 = od.dense_rollout(obs, h32, ref, graph_size=graph_size, edge_selectors=sel_factory())
+    (out32 * weight).sum().backward()
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad(set_to_none=True)
+    h64 = None if hidden is None else tuple(t.double() if t.is_floating_point() else t.clone() for t in hidden)
+    out64, _ = od.dense_rollout(obs.double(), h64, ref64, graph_size=graph_size, edge_selectors=sel_factory())
+    (out64 * weight.double()).sum().backward()
+    bounds = {}
+    for (k, p32), (_, p64) in zip(ref.named_parameters(), ref64.named_parameters()):
+        scale = float(p64.grad.abs().max())
+        err = float((p32.grad.double() - p64.grad).abs().max())
+        bounds[k] = (p64.grad, max(factor * err, floor * scale))
+    err_o = float((out32.detach().double() - out64.detach()).abs().max())
+    return out32.detach(), hid32, bounds, (out64.detach(), max(2e-6, factor * err_o))

@@ -461,10 +461,11 @@ def main():
          win2=gcm.util.get_causal_edges(Tq, tq, window=2), win0=gcm.util.get_causal_edges(Tq, tq, window=0))
 
     # ---- G8: SparseGCM + TemporalEdge ----------------------------------------
-    def run_sparse(name, B, N, F, H, hops, obs, tau_plan, max_hops=None, act=None):
+    def run_sparse(name, B, N, F, H, hops, obs, tau_plan, max_hops=None, act=None, aux_hops=None):
         torch.manual_seed(0)
         gnn = osp.canonical_gnn(F, H, act=act)
-        m = SparseGCM(gnn, edge_selectors=TemporalEdge(hops), graph_size=N, max_hops=max_hops)
+        m = SparseGCM(gnn, edge_selectors=TemporalEdge(hops), graph_size=N, max_hops=max_hops,
+                      aux_edge_selectors=TemporalEdge(aux_hops) if aux_hops else None)
         obs = obs.clone().requires_grad_(True)
         hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
         for taus in tau_plan:
@@ -485,7 +486,8 @@ def main():
         arrays.update(params_of(gnn))
         for k, p in gnn.named_parameters():
             arrays["grad:" + k] = p.grad.clone()
-        save(name, dict(B=B, N=N, F=F, H=H, hops=hops, max_hops=max_hops, act=bool(act)), **arrays)
+        save(name, dict(B=B, N=N, F=F, H=H, hops=hops, max_hops=max_hops, act=bool(act),
+                        aux_hops=aux_hops), **arrays)
 
     B, N, F, ts = 3, 8, 3, 8
     ar = torch.arange(B * ts * F, dtype=torch.float32).reshape(B, ts, F)
@@ -499,6 +501,10 @@ def main():
             torch.tensor([1, 1, 1, 1])]
     run_sparse("g8_sparse_ragged", B, N, F, H, [1, 3], robs, plan, act=torch.nn.Tanh)
     run_sparse("g8_sparse_ragged_2hop", B, N, F, H, [1, 3], robs, plan, max_hops=2, act=torch.nn.Tanh)
+    # main + aux selectors (sparse_gcm.py:146-152): the aux edges end in the same new nodes as the
+    # main selector's, interleave with them and (second case) duplicate some of them
+    run_sparse("g16_sparse_aux", B, N, F, H, [1], robs, plan, act=torch.nn.Tanh, aux_hops=[2])
+    run_sparse("g16_sparse_aux_overlap", B, N, F, H, [1, 3], robs, plan, act=torch.nn.Tanh, aux_hops=[3, 2, 1])
 
 
 if __name__ == "__main__":

@@ -247,3 +247,159 @@ def test_cfg4_sparse_full_size_one_shot():
         o2, h2 = mem(x_d[:, N // 2:].detach(), half, h1)
     torch.testing.assert_close(torch.cat([o1, o2], 1), out.detach(), rtol=1e-5, atol=1e-5)
     assert torch.equal(h2[1].coalesce().indices(), hid[1].coalesce().indices())
+
+
+# --------------------------------------------------------------------------------------------------
+# The path bench.py times: the per-step loop on the LIVE-ROW kernels (k_step_rows + k_bptt_rows; obs
+# without gradient, as in the reference's tests/test_speed.py:44-63), functional and donated state,
+# eager and captured in a HIP graph - at cfg2's full size against the oracle.
+# --------------------------------------------------------------------------------------------------
+def _cfg2_rows_case(T, pick, seed):
+    torch.manual_seed(seed)
+    obs = torch.rand(T, B2, F2)
+    w = torch.linspace(0.5, 1.5, T * len(pick) * H2).view(T, len(pick), H2)
+    return obs, w
+
+
+def _check_against_slice_oracle(out, hid, g, ref, obs, w, pick, N, sel_factory, h0=None):
+    from _golden import fp64_rollout_bounds
+    h0s = None if h0 is None else tuple(t[pick] if t.numel() else t for t in h0)
+    out32, hid_c, bounds, (out64, out_atol) = fp64_rollout_bounds(ref, obs[:, pick], h0s, w, sel_factory, N)
+    got = out[:, pick].detach().cpu()
+    torch.testing.assert_close(got, out32, rtol=1e-5, atol=1e-6)
+    assert float((got.double() - out64).abs().max()) <= out_atol
+    assert torch.equal(hid[1][pick].cpu(), hid_c[1]) and torch.equal(hid[0][pick].cpu(), hid_c[0])
+    assert torch.equal(hid[3][pick].cpu(), hid_c[3])
+    for k, p in g.named_parameters():
+        g64, atol = bounds[k]
+        err = float((p.grad.cpu().double() - g64).abs().max())
+        assert err <= atol, (k, err, atol, float(g64.abs().max()))
+
+
+@pytest.mark.parametrize("donate", [False, True])
+def test_cfg2_rows_path_slice_matches_oracle(donate):
+    """cfg2 at full size (B = 256, N = 128, T = 150: 22 steps of steady-state overflow), obs WITHOUT
+    gradient => k_step_rows forward, one k_bptt_rows launch per 64 recorded steps backward; the loss
+    weights 3 of the 256 graphs.  Beliefs, final state and parameter gradients against the oracle on
+    that slice, gradients bounded through the float64 evaluation."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, ref = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    mem.donate_state = donate
+    T, pick = 150, [0, 117, 255]
+    obs, w = _cfg2_rows_case(T, pick, seed=3)
+    out, hid = _loop(mem, obs.to(DEV))
+    assert mem.rows_steps() == T
+    (out[:, pick] * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    _check_against_slice_oracle(out, hid, g, ref, obs, w, pick, N2, lambda: od.TemporalBackedge(HOPS))
+    # ... and with every graph in the loss (the fixed-order slab reduction over all workgroups):
+    # equal to the sum over disjoint slices by linearity, checked against the full-mean run below
+    g.zero_grad(set_to_none=True)
+    out2, _ = _loop(mem, obs.to(DEV))
+    assert torch.equal(out2, out)                                   # deterministic
+    gm = torch.rand(T, B2, H2, device=DEV)
+    (out2 * gm).sum().backward()
+    full = {k: p.grad.clone() for k, p in g.named_parameters()}
+    parts = None
+    for lo in range(0, B2, 64):                                     # four disjoint quarter-batch losses
+        g.zero_grad(set_to_none=True)
+        out3, _ = _loop(mem, obs.to(DEV))
+        (out3[:, lo:lo + 64] * gm[:, lo:lo + 64]).sum().backward()
+        cur = {k: p.grad.double() for k, p in g.named_parameters()}
+        parts = cur if parts is None else {k: parts[k] + cur[k] for k in cur}
+    for k in full:
+        scale = float(parts[k].abs().max())
+        assert float((full[k].double() - parts[k]).abs().max()) <= 2e-6 * scale, k
+
+
+@pytest.mark.parametrize("donate", [False, True])
+def test_cfg2_rows_path_graph_replay_matches_eager(donate):
+    """The loop + backward captured once in a HIP graph (torch.cuda.CUDAGraph, in process) and
+    replayed three times: what bench.py's `value` times.  Every replay equals the eager run bit for
+    bit (beliefs, final state, parameter gradients), and the eager run matches the oracle slice."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, ref = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    mem.donate_state = donate
+    T, pick = 150, [3, 128, 254]
+    obs, w = _cfg2_rows_case(T, pick, seed=4)
+    obs_d = obs.to(DEV)
+    w_d = torch.zeros(T, B2, H2)          # (a dense weight: list indexing's backward does not capture)
+    w_d[:, pick] = w
+    w_d = w_d.to(DEV)
+
+    def run():
+        out, hid = _loop(mem, obs_d)
+        (out * w_d).sum().backward()
+        return out, hid
+
+    out_e, hid_e = run()
+    mem.check_flags()
+    _check_against_slice_oracle(out_e, hid_e, g, ref, obs, w, pick, N2, lambda: od.TemporalBackedge(HOPS))
+    eager = {k: p.grad.clone() for k, p in g.named_parameters()}
+    out_e = out_e.detach().clone()
+    hid_e = tuple(t.clone() for t in hid_e)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            g.zero_grad(set_to_none=True)
+            run()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g, hid_g = run()
+    assert mem.rows_steps() == 4 * T
+    for rep in range(3):
+        for p in g.parameters():                                    # static .grad tensors of the capture
+            p.grad.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g, out_e), rep
+        assert torch.equal(hid_g[0], hid_e[0]) and torch.equal(hid_g[1], hid_e[1]) and torch.equal(hid_g[3], hid_e[3])
+        for k, p in g.named_parameters():
+            assert torch.equal(p.grad, eager[k]), (rep, k)
+    mem.check_flags()
+
+
+def test_cfg3_rows_path_param_gradients_full_batch():
+    """cfg3 at full size on the live-row path (obs without gradient): EuclideanEdge ahead of
+    k_step_rows, 8 steps from graphs that already hold 96-124 nodes (~25 new edges per graph and
+    step, the last steps overflow); parameter gradients against the full-batch oracle (the cross-batch
+    mean couples all 256 graphs), bounded through float64."""
+    from gcm.edge_selectors.distance import EuclideanEdge
+    B, N, F, H, T = 256, 128, 64, 32, 8
+    for donate in (False, True):
+        mem, g, ref = _dense_pair(F, H, N, EuclideanEdge(2.0), seed=9)
+        mem.donate_state = donate
+        gen = torch.Generator().manual_seed(10)
+        centres = 4.0 * torch.randn(4, F, generator=gen)
+        count0 = torch.randint(96, 125, (B,), generator=gen)
+        nodes0 = centres[torch.arange(N) % 4][None, :, :] + 0.05 * torch.randn(B, N, F, generator=gen)
+        nodes0 = nodes0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+        adj0 = torch.zeros(B, N, N)
+        i = torch.arange(1, N)
+        adj0[:, i, i - 1] = 1.0
+        adj0 = adj0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+        obs = centres[torch.arange(T) % 4][:, None, :] + 0.05 * torch.randn(T, B, F, generator=gen)
+        w = torch.rand(T, B, H, generator=gen)
+        h0 = (nodes0, adj0, torch.zeros(0), count0)
+        hid = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
+        outs = []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+        assert mem.rows_steps() == T
+        out = torch.stack(outs)
+        (out * w.to(DEV)).sum().backward()
+        mem.check_flags()
+        from _golden import fp64_rollout_bounds
+        out32, hid_c, bounds, (out64, out_atol) = fp64_rollout_bounds(
+            ref, obs, h0, w, lambda: od.EuclideanEdge(2.0), N)
+        assert torch.equal(hid[1].cpu(), hid_c[1])                  # edge decisions: bit exact
+        assert float((out.detach().cpu().double() - out64).abs().max()) <= out_atol
+        for k, p in g.named_parameters():
+            g64, atol = bounds[k]
+            err = float((p.grad.cpu().double() - g64).abs().max())
+            assert err <= atol, (donate, k, err, atol)

@@ -143,3 +143,61 @@ def test_learned_fused_cfg5_size_slice():
     count0 = torch.randint(100, 127, (B,), generator=gen)
     hidden = _run_both(B, N, F, H, T, 5, seed=11, count0=count0, pick=[0, 97, 255])
     assert int(hidden[3].max()) == N
+
+
+def test_learned_fused_cfg5_size_long_rollout():
+    """cfg5's per-GPU share for T = 44 steps from almost-full graphs: ~110+ candidates scored per
+    graph and step, every graph overflows and then rolls at every step (the chain buffer rolls with the
+    state); oracle on a slice of 3 graphs with the same injected gumbel draws."""
+    B, N, F, H, T = 256, 128, 32, 32, 44
+    gen = torch.Generator().manual_seed(5)
+    count0 = torch.randint(108, 127, (B,), generator=gen)
+    hidden = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254])
+    assert int(hidden[3].min()) == N          # every graph is in steady-state overflow by the end
+
+
+def test_learned_noise_pool_statistics_and_equivalence():
+    """The default noise path of the fused LearnedEdge step: Exp(1) draws from the device RNG, 16
+    steps' worth per launch (`DenseGCM._noise_pool`), turned into gumbel noise inside the kernel
+    (torch.nn.functional.gumbel_softmax draws -log(Exp(1)) the same way, learned.py:89).
+    (1) the draws are Exp(1) (mean, variance, independence of consecutive pools and of a pool's
+    slices); (2) a run on the pool equals a run that gets the very same draws injected per step
+    through `noise_fn` (the parity tests' path)."""
+    B, N, F, H, T = 64, 32, 32, 32, 40
+    ref, net, g, sel, mem = _pair(F, H, N, 5, seed=21)
+    obs = torch.rand(T, B, F, device=DEV)
+    pools, used = [], []
+    hidden, outs = None, []
+    with torch.no_grad():
+        for t in range(T):
+            mx, hidden = mem(obs[t], hidden)
+            pool = mem._noise_pool
+            if not pools or pools[-1] is not pool[0]:
+                pools.append(pool[0])
+            used.append(pool[0][pool[1] - 1])
+            outs.append(mx)
+    assert _taken(mem)
+    assert len(pools) == 3 and all(p.shape == (16, B, N) for p in pools)      # 40 steps = 16 + 16 + 8
+    draws = torch.stack(pools).double()
+    n = draws.numel()
+    assert float(draws.min()) > 0
+    assert abs(float(draws.mean()) - 1.0) < 5.0 / n ** 0.5                     # sd of the mean = 1/sqrt(n)
+    assert abs(float(draws.var()) - 1.0) < 5.0 * (8.0 / n) ** 0.5              # var of the sample variance = 8/n
+    assert abs(float((draws < 0.6931471805599453).double().mean()) - 0.5) < 5.0 * 0.5 / n ** 0.5   # median
+    flat = draws.reshape(3 * 16, -1)
+    c = torch.corrcoef(flat)                                                   # slices / pools are independent
+    assert float((c - torch.eye(48, dtype=c.dtype, device=c.device)).abs().max()) < 6.0 / flat.shape[1] ** 0.5
+    # (2) the same draws injected step by step
+    ref2, net2, g2, sel2, mem2 = _pair(F, H, N, 5, seed=21)
+    step = {"t": 0}
+    sel2.noise_fn = lambda like: -used[step["t"]].log()
+    hidden2, outs2 = None, []
+    with torch.no_grad():
+        for t in range(T):
+            step["t"] = t
+            mx, hidden2 = mem2(obs[t], hidden2)
+            outs2.append(mx)
+    same = (hidden[1] == hidden2[1]).flatten(1).all(dim=1)
+    assert float(same.double().mean()) >= 0.98      # (-log(x) is evaluated by the kernel in one run, by torch in the other)
+    assert float(hidden[1].sum()) > float(B * 8)    # and edges were sampled at all
+    torch.testing.assert_close(torch.stack(outs)[:, same], torch.stack(outs2)[:, same], rtol=1e-5, atol=2e-6)

@@ -135,7 +135,7 @@ def test_wrap_overflow_oracle(name):
 
 
 SPARSE = ["g8_sparse_oneshot", "g8_sparse_oneshot_2hop", "g8_sparse_stepwise",
-          "g8_sparse_ragged", "g8_sparse_ragged_2hop"]
+          "g8_sparse_ragged", "g8_sparse_ragged_2hop", "g16_sparse_aux", "g16_sparse_aux_overlap"]
 
 
 @pytest.mark.parametrize("name", SPARSE)
@@ -145,6 +145,7 @@ def test_sparse_oracle_matches_reference(name):
     gnn = osp.canonical_gnn(m["F"], m["H"], act=torch.nn.Tanh if m["act"] else None)
     gnn.load_state_dict(fx.group("param:"))
     sel = osp.TemporalEdge(m["hops"])
+    aux = osp.TemporalEdge(m["aux_hops"]) if m.get("aux_hops") else None
     obs = fx["obs"].clone().requires_grad_(True)
     B = m["B"]
     hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
@@ -154,7 +155,7 @@ def test_sparse_oracle_matches_reference(name):
         for b in range(B):
             x[b, : taus[b]] = obs[b, pos[b]: pos[b] + taus[b]]
         out, hidden = osp.sparse_step(x, taus, hidden, gnn, graph_size=m["N"], edge_selectors=sel,
-                                      max_hops=m["max_hops"])
+                                      max_hops=m["max_hops"], aux_edge_selectors=aux)
         outs.append(out)
         pos = pos + taus
     loss = sum(o.sum() for o in outs) / sum(o.numel() for o in outs)

@@ -150,7 +150,10 @@ def test_khop_mask_matches_k_hop_subgraph():
 
 
 SPARSE = ["g8_sparse_oneshot", "g8_sparse_oneshot_2hop", "g8_sparse_stepwise",
-          "g8_sparse_ragged", "g8_sparse_ragged_2hop"]
+          "g8_sparse_ragged", "g8_sparse_ragged_2hop",
+          # main + aux selectors (the aux merge must coalesce - its edges interleave with / duplicate
+          # the main selector's)
+          "g16_sparse_aux", "g16_sparse_aux_overlap"]
 
 
 @pytest.mark.parametrize("name", SPARSE)
@@ -163,7 +166,8 @@ def test_sparse_rollout_matches_reference(name):
     ref = osp.canonical_gnn(m["F"], m["H"], act=act)
     ref.load_state_dict(fx.group("param:"))
     g = dev_sparse_gnn(ref, m["F"], m["H"], act)
-    mem = SparseGCM(g, edge_selectors=TemporalEdge(m["hops"]), graph_size=m["N"], max_hops=m["max_hops"])
+    mem = SparseGCM(g, edge_selectors=TemporalEdge(m["hops"]), graph_size=m["N"], max_hops=m["max_hops"],
+                    aux_edge_selectors=TemporalEdge(m["aux_hops"]) if m.get("aux_hops") else None)
     obs = fx["obs"].to(DEV).requires_grad_(True)
     B = m["B"]
     hidden, outs, pos = None, [], torch.zeros(B, dtype=torch.long)
