@@ -59,6 +59,142 @@ __device__ __forceinline__ float f4_at(const float4& v, int i) {   // i: compile
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// Functional state (distinct output buffers): the state advance of gcm.py:262-287 - copy, overflow
+// roll, the selectors' entries, the inserted node, the count - is a pure function of the incoming
+// state, independent of the GNN.  It runs in a SECOND WORKGROUP per graph of the same launch (blocks
+// B..2B-1), which streams the graph's 80 KB HBM -> registers -> HBM with the edits applied in registers;
+// the graph's compute workgroup (block b) only reads the old state - through shifted addresses when
+// the graph rolls - so the two never wait for each other.  (Round 2 moved the copy through the compute
+// waves' registers: its stores had to wait for the end of the kernel - loads and stores share one
+// in-order counter per wave - 11.8 us against 6.2 us donated.  Extra waves in the SAME workgroup do
+// not work either: s_barrier counts every wave that has not terminated, so the compute waves' first
+// barrier waited for the whole copy - measured: copy alone 8.4 us, compute alone 5.9 us, both 12.2 us.)
+#ifndef GCM_STATE_CH
+#define GCM_STATE_CH 4
+#endif
+template <int FP>
+__device__ __forceinline__ void advance_state_waves(
+    const float* __restrict__ obs, const float* ng_in, const float* ag_in, const int64_t* count_in,
+    float* ng, float* ag, int64_t* count_out, int64_t* cur_out, const Edits& E,
+    uint32_t* __restrict__ flags, const float* __restrict__ sel_row, int b, int t, int N, int F) {
+  // items: 16 float4 of the adjacency and NODE_PER of the node matrix per thread, moved in chunks of
+  // CH with two chunks of loads in flight while a chunk is edited and stored - every workgroup of the
+  // launch starts at the same time, so without this the whole chip reads, then the whole chip writes
+  constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
+  constexpr int NITEM = ADJ_PER + NODE_PER, CH = GCM_STATE_CH, NCH = (NITEM + CH - 1) / CH;
+  const int lane = t & 63;
+  const int N4 = N >> 2, F4 = F >> 2;
+  const int lim_a = N * N4, lim_n = N * F4;
+  const int n_hops = E.n_hops;
+  int lane_h = -1, cdir = 0;
+  if (lane >= 1 && lane <= n_hops) {
+    lane_h = E.hops[(lane - 1) & 15];
+    cdir = E.dir[(lane - 1) & 15];
+  }
+  const int64_t n_in = count_in[b];
+  const bool dense = E.dense != 0;
+  float4 buf[NITEM];
+  // out[r][c] = in[r + sh][c + sh] (sh = 1: the overflow roll, gcm.py:323-355; dword-aligned 16-byte
+  // loads, the last column shifted in registers at store time), from clamped addresses
+  auto issue = [&](int i, int sh) {
+    if (i < ADJ_PER) {
+      const int e4 = min(t + 256 * i, lim_a - 1);
+      const int r = e4 / N4, c = (e4 - r * N4) * 4;
+      const int rs = r + sh < N ? r + sh : N - 1;
+      const bool tail = c + 4 >= N;
+      __builtin_memcpy(&buf[i], ag_in + rs * N + c + ((sh && !tail) ? 1 : 0), sizeof(float4));
+    } else {
+      const int e4 = min(t + 256 * (i - ADJ_PER), lim_n - 1);
+      const int r = e4 / F4, c = (e4 - r * F4) * 4;
+      buf[i] = *reinterpret_cast<const float4*>(ng_in + (r + sh < N ? r + sh : N - 1) * F + c);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 2 * CH && i < NITEM; ++i) issue(i, 0);   // (no overflow: assumed)
+  asm volatile("" ::: "memory");
+  const bool wrap = n_in + 1 > N;
+  const int64_t c64 = wrap ? n_in - 1 : n_in;
+  const int cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
+  const int sh = wrap ? 1 : 0;
+  if (wrap) {
+#pragma unroll
+    for (int i = 0; i < 2 * CH && i < NITEM; ++i) issue(i, 1);
+  }
+  // the folded temporal hops as two bit sets over the node index (scalar code): entries (cur, j) of
+  // forward / both hops, rows j that get a (j, cur) entry from backward / both hops
+  unsigned long long cand0 = 0, cand1 = 0, col0 = 0, col1 = 0;
+  bool hop0 = false;
+  for (int k = 1; k <= n_hops; ++k) {
+    const int h = __builtin_amdgcn_readlane(lane_h, k), d = __builtin_amdgcn_readlane(cdir, k);
+    if (h < 0 || h > cur) continue;
+    if (h == 0) {
+      hop0 = true;
+      continue;
+    }
+    const int j = cur - h;
+    const unsigned long long bit = 1ull << (j & 63);
+    if (d & GCM_DIR_FORWARD) (j < 64 ? cand0 : cand1) |= bit;
+    if (d & GCM_DIR_BACKWARD) (j < 64 ? col0 : col1) |= bit;
+  }
+  auto finish = [&](int i) {   // edits in registers, then the store
+    float4 v = buf[i];
+    if (i < ADJ_PER) {
+      const int e4 = t + 256 * i;
+      const int r = e4 / N4, c = (e4 - r * N4) * 4;
+      if (wrap && c + 4 >= N) v = make_float4(v.y, v.z, v.w, 0.f);
+      if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r == cur) {   // temporal.py:72-88 (forward), dense.py:16-21, distance.py:31-37
+        float4 sr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sel_row) sr = *reinterpret_cast<const float4*>(sel_row + (size_t)b * N + (c < N ? c : N - 4));
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        const float ss[4] = {sr.x, sr.y, sr.z, sr.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = c + k;
+          const bool in_cand = (((j < 64 ? cand0 : cand1) >> (j & 63)) & 1ull) != 0;
+          // (bitwise on purpose: hipcc 7.2 lowered the short-circuit form of this condition to a branch
+          //  tree that dropped its last term - tools/_dbg/dbg_sel.py, the g3 fixtures)
+          const bool set = in_cand | (dense & (j <= cur)) | ((j == cur) & hop0) | ((j < cur) & (ss[k] != 0.f));
+          vv[k] = set ? 1.f : vv[k];
+        }
+        v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      } else {          // column cur: backward hops, DenseEdge's rows < cur
+        const int k = cur - c;
+        if (k >= 0 && k < 4) {
+          const bool in_col = (((r < 64 ? col0 : col1) >> (r & 63)) & 1ull) != 0;
+          const bool set = in_col | (dense & (r < cur));
+          v.x = (set & (k == 0)) ? 1.f : v.x;
+          v.y = (set & (k == 1)) ? 1.f : v.y;
+          v.z = (set & (k == 2)) ? 1.f : v.z;
+          v.w = (set & (k == 3)) ? 1.f : v.w;
+        }
+      }
+      if (e4 < lim_a) *reinterpret_cast<float4*>(ag + e4 * 4) = v;
+    } else {
+      const int e4 = t + 256 * (i - ADJ_PER);
+      const int r = e4 / F4, c = (e4 - r * F4) * 4;
+      if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r == cur) v = *reinterpret_cast<const float4*>(obs + (size_t)b * F + c);   // gcm.py:274
+      if (e4 < lim_n) *reinterpret_cast<float4*>(ng + e4 * 4) = v;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+    for (int i = (k + 2) * CH; i < (k + 3) * CH && i < NITEM; ++i) issue(i, sh);
+    asm volatile("" ::: "memory");   // the next chunk's loads are in the queue before this chunk's stores
+#pragma unroll
+    for (int i = k * CH; i < (k + 1) * CH && i < NITEM; ++i) finish(i);
+    asm volatile("" ::: "memory");
+  }
+  if (t == 0) {
+    count_out[b] = cur + 1;
+    if (cur_out) cur_out[b] = cur;
+    const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
+    if (f) atomicOr(flags, f);
+  }
+}
+
 // The live-row list.  Slot 0 is row cur; then the rows the folded temporal selectors connect it to
 // (cur - hop for forward / both hops, in hop order, duplicates dropped): these CANDIDATES depend on
 // cur alone, so their adjacency rows are fetched before row cur of the adjacency has even arrived.
@@ -85,7 +221,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
     int64_t* __restrict__ cur_out, Edits E, Gnn2 P, float* __restrict__ mx_out,
     float* __restrict__ saved, SavedLayout lay, uint32_t* __restrict__ flags, int N_, int F_,
     int H1_, int H2_, const float* __restrict__ c1, const float* __restrict__ pe,
-    const float* __restrict__ sel_row) {
+    const float* __restrict__ sel_row, int Bn) {
   using L = Lds<FP, HP, H2P>;
   const int N = NX ? NX : N_, F = EXACT ? FP : F_, H1 = EXACT ? HP : H1_, H2 = EXACT ? H2P : H2_;
   constexpr int XS = L::XS, RS = L::RS, AS = L::AS, HS = L::HS;
@@ -121,6 +257,20 @@ __global__ __launch_bounds__(256) void k_step_rows(
   const float* ag_in = adj_in + (size_t)b * N * N;
   float* ng = nodes_out + (size_t)b * N * F;
   float* ag = adj_out + (size_t)b * N * N;
+
+  if (FUNC && blockIdx.x >= Bn) {   // blocks B..2B-1: the functional state advance of graph blockIdx.x - B
+#if defined(GCM_EXP) && GCM_EXP == 1
+    return;
+#endif
+    const int bs = blockIdx.x - Bn;
+    advance_state_waves<FP>(obs, nodes_in + (size_t)bs * N * F, adj_in + (size_t)bs * N * N, count_in,
+                            nodes_out + (size_t)bs * N * F, adj_out + (size_t)bs * N * N, count_out, cur_out, E,
+                            flags, sel_row, bs, tid, N, F);
+    return;
+  }
+#if defined(GCM_EXP) && GCM_EXP == 2
+  if (FUNC) return;
+#endif
 
   STAMP(0);
   // ---- loads that do not depend on the count ----------------------------------------------------
@@ -169,10 +319,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
   const float bias2 = P.b_rel2[o2 < H2 ? o2 : H2 - 1];
   const float c1v = fold_deg ? c1[hcol < H1 ? hcol : H1 - 1] : 0.f;
   const float srv = has_sel ? sel_row[(size_t)b * N + min(tid & 127, N - 1)] : 0.f;
-  // functional state, no overflow (the common case, assumed here): the copy's loads
-  constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
-  float4 ca[FUNC ? ADJ_PER : 1], cn[FUNC ? NODE_PER : 1];
-  if (FUNC) load_copy<FUNC ? ADJ_PER : 1, FUNC ? NODE_PER : 1, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
+  constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;   // (the in-place roll below)
   // kernel arguments used late: in registers now (a scalar load at its point of use is a round trip)
   const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
   const size_t lay_v = lay.o_v, lay_hdr = lay.o_hdr, lay_coef = lay.o_coef, lay_rows = lay.o_rows;
@@ -189,21 +336,34 @@ __global__ __launch_bounds__(256) void k_step_rows(
   STAMP(1);
   // ---- overflow (gcm.py:323-355): roll the state, in place when it is donated (every load lands
   // before the first store).  Rare; its own loads, stores and barriers. ----------------------------
-  if (wrap) {
+  if (wrap && !FUNC) {
     float4 ra[ADJ_PER], rn[NODE_PER];
     load_copy<ADJ_PER, NODE_PER, true>(ra, rn, ag_in, ng_in, tid, N, N4, F, F4);
-    if (!FUNC) {   // source and destination alias
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // source and destination alias
+    __syncthreads();
     store_copy<ADJ_PER, NODE_PER>(ra, rn, ag, ng, tid, N, N4, F4, true);
     __syncthreads();   // the rolled state is visible to the whole workgroup
   }
-  const float* ag_rd = wrap ? ag : ag_in;   // the advanced, pre-selector adjacency
+  // Functional state and the graph rolls: the rolled adjacency is never materialised for this
+  // workgroup - rolled[j][c] = in[j + 1][c + 1], last row and column zero - it reads the old state
+  // through shifted (dword-aligned 16-byte) addresses; same instructions either way, the shift is data.
+  const bool shifted = FUNC && wrap;
+  const int rsh = shifted ? 1 : 0;
+  const float* ag_rd = (wrap && !FUNC) ? ag : ag_in;   // the advanced adjacency, before the selectors
+  auto adj_row4 = [&](int j, int c) -> float4 {   // columns c .. c+3 of row j (c clamped by the caller)
+    const bool tail = shifted && c + 4 >= N;      // in[.][N] does not exist: shifted in registers
+    const int jr = j + rsh < N ? j + rsh : N - 1;
+    float4 v;
+    __builtin_memcpy(&v, ag_rd + jr * N + c + ((shifted && !tail) ? 1 : 0), sizeof(float4));
+    if (tail) v = make_float4(v.y, v.z, v.w, 0.f);
+    if (shifted && j + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+  };
 
   // ---- row cur of the advanced adjacency, before the selectors (all zero for a state this code
   // produced; a caller's own state may hold anything): heads the longest dependent chain ------------
   float rc_val = ag_rd[cur * N + min(tid & 127, N - 1)];
+  if (shifted) rc_val = 0.f;   // (row N - 1 of a rolled adjacency)
   // ---- candidates (every wave computes them for itself: no barrier) ------------------------------
   // lane 0: row cur; lane i in [1, n_hops]: cur - hop[i-1] when that hop writes into row cur
   const bool dense = dense_i != 0;
@@ -243,7 +403,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int c = (c4 + 16 * q) * 4;
-    sp[q] = *reinterpret_cast<const float4*>(ag_rd + sj * N + (c < N ? c : N - 4));
+    sp[q] = adj_row4(sj, c < N ? c : N - 4);
   }
   asm volatile("" ::: "memory");
   STAMP(2);
@@ -325,7 +485,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
       for (int q = 0; q < 2; ++q) {
         const int c = (c4 + 16 * q) * 4;
         float4 v = sp[q];
-        if (!ahead && valid) v = *reinterpret_cast<const float4*>(ag_rd + j * N + (c < N ? c : N - 4));
+        if (!ahead && valid) v = adj_row4(j, c < N ? c : N - 4);
         if (j == cur) v = make_float4(sRowCur[c], sRowCur[c + 1], sRowCur[c + 2], sRowCur[c + 3]);
         else if (colcur) {
           const int k = cur - c;
@@ -482,12 +642,9 @@ __global__ __launch_bounds__(256) void k_step_rows(
     }
   }
   STAMP(12);
-  // ---- the state, off the critical path: (functional) the copy's stores, then the selector's
-  // entries, the inserted node and the count behind them ------------------------------------------
-  if (FUNC && !wrap) {
-    store_copy<FUNC ? ADJ_PER : 1, FUNC ? NODE_PER : 1>(ca, cn, ag, ng, tid, N, N4, F4, false);
-    __syncthreads();   // ordered: the entries below overwrite copied values
-  }
+  // ---- the donated state, off the critical path: the selector's entries, the inserted node and the
+  // count ------------------------------------------------------------------------------------------
+  if (FUNC) return;   // (functional state: written by the state waves)
   if (tid < 128) {
     if (tid < N && r_new != rc_val) ag[cur * N + tid] = r_new;
   } else {
@@ -523,15 +680,15 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
   auto kern = func ? k_step_rows<FP, HP, H2P, true, NX, EXACT> : k_step_rows<FP, HP, H2P, false, NX, EXACT>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
-    hipExtLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in, adj_in,
-                          count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
-                          N, F, H1, H2, c1, pe, sel_row);
+    hipExtLaunchKernelGGL(kern, dim3(func ? 2 * B : B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in,
+                          adj_in, count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
+                          N, F, H1, H2, c1, pe, sel_row, B);
     t_start = t_stop = nullptr;
     return gcm_launch_status();
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in, nodes_out,
-                     adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe,
-                     sel_row);
+  hipLaunchKernelGGL(kern, dim3(func ? 2 * B : B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in,
+                     nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe,
+                     sel_row, B);
   return gcm_launch_status();
 }
 

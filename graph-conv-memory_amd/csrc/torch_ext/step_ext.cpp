@@ -648,8 +648,8 @@ std::vector<at::Tensor> learned_step(const at::Tensor& packed, const at::Tensor&
               "learned_step: hidden state, observation and noise shapes disagree");
   const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad() && slab_acc.has_value();
   return LearnedStepFn::apply(packed, dchain_in, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags,
-                              cfg_handle, stream, (int64_t)need_bwd, need_bwd ? *slab_acc : at::Tensor(),
-                              (int64_t)is_head);
+                              cfg_handle, stream, (int64_t)need_bwd,
+                              need_bwd ? *slab_acc : at::empty({0}, obs.options()), (int64_t)is_head);
 }
 
 }  // namespace

@@ -146,7 +146,9 @@ def lib():
                 "`make -C graph-conv-memory_amd/csrc` (hipcc, --offload-arch=gfx950). "
                 "This package has no CPU fallback."
             )
-        handle = ctypes.CDLL(_LIB_PATH)
+        # (GCM_HIP_LIB: a diagnostic build of the same library - csrc/Makefile `stamps*`, `exp` - for the
+        #  dev tools under tools/; never set by the product)
+        handle = ctypes.CDLL(os.environ.get("GCM_HIP_LIB") or _LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
