@@ -61,8 +61,8 @@ __device__ __forceinline__ float f4_at(const float4& v, int i) {   // i: compile
 
 // Functional state (distinct output buffers): the state advance of gcm.py:262-287 - copy, overflow
 // roll, the selectors' entries, the inserted node, the count - is a pure function of the incoming
-// state, independent of the GNN.  It runs in a SECOND WORKGROUP per graph of the same launch (blocks
-// B..2B-1), which streams the graph's 80 KB HBM -> registers -> HBM with the edits applied in registers;
+// state, independent of the GNN.  It runs in EXTRA WORKGROUPS of the same launch (blocks >= B,
+// GCM_STATE_WGS per graph), which stream the graph's 80 KB HBM -> registers -> HBM with the edits applied in registers;
 // the graph's compute workgroup (block b) only reads the old state - through shifted addresses when
 // the graph rolls - so the two never wait for each other.  (Round 2 moved the copy through the compute
 // waves' registers: its stores had to wait for the end of the kernel - loads and stores share one
@@ -70,17 +70,24 @@ __device__ __forceinline__ float f4_at(const float4& v, int i) {   // i: compile
 // not work either: s_barrier counts every wave that has not terminated, so the compute waves' first
 // barrier waited for the whole copy - measured: copy alone 8.4 us, compute alone 5.9 us, both 12.2 us.)
 #ifndef GCM_STATE_CH
-#define GCM_STATE_CH 4
+#define GCM_STATE_CH 2
+#endif
+#ifndef GCM_STATE_WGS
+#define GCM_STATE_WGS 2   // state workgroups per graph (each moves every GCM_STATE_WGS-th 4 KB slice)
 #endif
 template <int FP>
 __device__ __forceinline__ void advance_state_waves(
     const float* __restrict__ obs, const float* ng_in, const float* ag_in, const int64_t* count_in,
     float* ng, float* ag, int64_t* count_out, int64_t* cur_out, const Edits& E,
-    uint32_t* __restrict__ flags, const float* __restrict__ sel_row, int b, int t, int N, int F) {
-  // items: 16 float4 of the adjacency and NODE_PER of the node matrix per thread, moved in chunks of
-  // CH with two chunks of loads in flight while a chunk is edited and stored - every workgroup of the
-  // launch starts at the same time, so without this the whole chip reads, then the whole chip writes
-  constexpr int ADJ_PER = 16, NODE_PER = (128 * FP / 4 + 255) / 256;
+    uint32_t* __restrict__ flags, const float* __restrict__ sel_row, int b, int ks, int t, int N, int F) {
+  // items: float4 number t + 256 q of the adjacency (q < 16) and of the node matrix (q < NODE_ALL),
+  // workgroup ks of the graph takes q = ks, ks + KS, ...; moved in chunks of CH with two chunks of loads
+  // in flight while a chunk is edited and stored - every workgroup of the launch starts at the same
+  // time, so without this the whole chip reads, then the whole chip writes
+  constexpr int KS = GCM_STATE_WGS;
+  constexpr int ADJ_ALL = 16, NODE_ALL = (128 * FP / 4 + 255) / 256;
+  constexpr int ADJ_PER = ADJ_ALL / KS, NODE_PER = (NODE_ALL + KS - 1) / KS;
+  static_assert(ADJ_ALL % KS == 0, "state workgroups per graph");
   constexpr int NITEM = ADJ_PER + NODE_PER, CH = GCM_STATE_CH, NCH = (NITEM + CH - 1) / CH;
   const int lane = t & 63;
   const int N4 = N >> 2, F4 = F >> 2;
@@ -94,23 +101,28 @@ __device__ __forceinline__ void advance_state_waves(
   const int64_t n_in = count_in[b];
   const bool dense = E.dense != 0;
   float4 buf[NITEM];
-  // out[r][c] = in[r + sh][c + sh] (sh = 1: the overflow roll, gcm.py:323-355; dword-aligned 16-byte
-  // loads, the last column shifted in registers at store time), from clamped addresses
-  auto issue = [&](int i, int sh) {
+  auto e4_of = [&](int i) { return t + 256 * ((i < ADJ_PER ? i : i - ADJ_PER) * KS + ks); };
+  // the plain copy's loads (16-byte aligned), from clamped addresses
+  auto issue0 = [&](int i) {
+    if (i < ADJ_PER) buf[i] = *reinterpret_cast<const float4*>(ag_in + 4 * min(e4_of(i), lim_a - 1));
+    else buf[i] = *reinterpret_cast<const float4*>(ng_in + 4 * min(e4_of(i), lim_n - 1));
+  };
+  // the overflow roll's (gcm.py:323-355): out[r][c] = in[r + 1][c + 1], dword-aligned 16-byte loads,
+  // the last column shifted in registers at store time
+  auto issue1 = [&](int i) {
     if (i < ADJ_PER) {
-      const int e4 = min(t + 256 * i, lim_a - 1);
+      const int e4 = min(e4_of(i), lim_a - 1);
       const int r = e4 / N4, c = (e4 - r * N4) * 4;
-      const int rs = r + sh < N ? r + sh : N - 1;
       const bool tail = c + 4 >= N;
-      __builtin_memcpy(&buf[i], ag_in + rs * N + c + ((sh && !tail) ? 1 : 0), sizeof(float4));
+      __builtin_memcpy(&buf[i], ag_in + (r + 1 < N ? r + 1 : N - 1) * N + c + (tail ? 0 : 1), sizeof(float4));
     } else {
-      const int e4 = min(t + 256 * (i - ADJ_PER), lim_n - 1);
+      const int e4 = min(e4_of(i), lim_n - 1);
       const int r = e4 / F4, c = (e4 - r * F4) * 4;
-      buf[i] = *reinterpret_cast<const float4*>(ng_in + (r + sh < N ? r + sh : N - 1) * F + c);
+      buf[i] = *reinterpret_cast<const float4*>(ng_in + (r + 1 < N ? r + 1 : N - 1) * F + c);
     }
   };
 #pragma unroll
-  for (int i = 0; i < 2 * CH && i < NITEM; ++i) issue(i, 0);   // (no overflow: assumed)
+  for (int i = 0; i < 2 * CH && i < NITEM; ++i) issue0(i);   // (no overflow: assumed)
   asm volatile("" ::: "memory");
   const bool wrap = n_in + 1 > N;
   const int64_t c64 = wrap ? n_in - 1 : n_in;
@@ -118,7 +130,7 @@ __device__ __forceinline__ void advance_state_waves(
   const int sh = wrap ? 1 : 0;
   if (wrap) {
 #pragma unroll
-    for (int i = 0; i < 2 * CH && i < NITEM; ++i) issue(i, 1);
+    for (int i = 0; i < 2 * CH && i < NITEM; ++i) issue1(i);
   }
   // the folded temporal hops as two bit sets over the node index (scalar code): entries (cur, j) of
   // forward / both hops, rows j that get a (j, cur) entry from backward / both hops
@@ -138,8 +150,8 @@ __device__ __forceinline__ void advance_state_waves(
   }
   auto finish = [&](int i) {   // edits in registers, then the store
     float4 v = buf[i];
+    const int e4 = e4_of(i);
     if (i < ADJ_PER) {
-      const int e4 = t + 256 * i;
       const int r = e4 / N4, c = (e4 - r * N4) * 4;
       if (wrap && c + 4 >= N) v = make_float4(v.y, v.z, v.w, 0.f);
       if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -171,23 +183,34 @@ __device__ __forceinline__ void advance_state_waves(
       }
       if (e4 < lim_a) *reinterpret_cast<float4*>(ag + e4 * 4) = v;
     } else {
-      const int e4 = t + 256 * (i - ADJ_PER);
       const int r = e4 / F4, c = (e4 - r * F4) * 4;
       if (r + sh >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r == cur) v = *reinterpret_cast<const float4*>(obs + (size_t)b * F + c);   // gcm.py:274
       if (e4 < lim_n) *reinterpret_cast<float4*>(ng + e4 * 4) = v;
     }
   };
+  if (!wrap) {
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
 #pragma unroll
-    for (int i = (k + 2) * CH; i < (k + 3) * CH && i < NITEM; ++i) issue(i, sh);
-    asm volatile("" ::: "memory");   // the next chunk's loads are in the queue before this chunk's stores
+      for (int i = (k + 2) * CH; i < (k + 3) * CH && i < NITEM; ++i) issue0(i);
+      asm volatile("" ::: "memory");   // the next chunk's loads are in the queue before this chunk's stores
 #pragma unroll
-    for (int i = k * CH; i < (k + 1) * CH && i < NITEM; ++i) finish(i);
-    asm volatile("" ::: "memory");
+      for (int i = k * CH; i < (k + 1) * CH && i < NITEM; ++i) finish(i);
+      asm volatile("" ::: "memory");
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+      for (int i = (k + 2) * CH; i < (k + 3) * CH && i < NITEM; ++i) issue1(i);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = k * CH; i < (k + 1) * CH && i < NITEM; ++i) finish(i);
+      asm volatile("" ::: "memory");
+    }
   }
-  if (t == 0) {
+  if (t == 0 && ks == 0) {
     count_out[b] = cur + 1;
     if (cur_out) cur_out[b] = cur;
     const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
@@ -258,14 +281,14 @@ __global__ __launch_bounds__(256) void k_step_rows(
   float* ng = nodes_out + (size_t)b * N * F;
   float* ag = adj_out + (size_t)b * N * N;
 
-  if (FUNC && blockIdx.x >= Bn) {   // blocks B..2B-1: the functional state advance of graph blockIdx.x - B
+  if (FUNC && blockIdx.x >= Bn) {   // blocks B ..: the functional state advance (GCM_STATE_WGS workgroups per graph)
 #if defined(GCM_EXP) && GCM_EXP == 1
     return;
 #endif
-    const int bs = blockIdx.x - Bn;
+    const int q = blockIdx.x - Bn, bs = q % Bn, ks = q / Bn;
     advance_state_waves<FP>(obs, nodes_in + (size_t)bs * N * F, adj_in + (size_t)bs * N * N, count_in,
                             nodes_out + (size_t)bs * N * F, adj_out + (size_t)bs * N * N, count_out, cur_out, E,
-                            flags, sel_row, bs, tid, N, F);
+                            flags, sel_row, bs, ks, tid, N, F);
     return;
   }
 #if defined(GCM_EXP) && GCM_EXP == 2
@@ -680,13 +703,13 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
   auto kern = func ? k_step_rows<FP, HP, H2P, true, NX, EXACT> : k_step_rows<FP, HP, H2P, false, NX, EXACT>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
-    hipExtLaunchKernelGGL(kern, dim3(func ? 2 * B : B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in,
+    hipExtLaunchKernelGGL(kern, dim3(func ? (1 + GCM_STATE_WGS) * B : B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in,
                           adj_in, count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
                           N, F, H1, H2, c1, pe, sel_row, B);
     t_start = t_stop = nullptr;
     return gcm_launch_status();
   }
-  hipLaunchKernelGGL(kern, dim3(func ? 2 * B : B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in,
+  hipLaunchKernelGGL(kern, dim3(func ? (1 + GCM_STATE_WGS) * B : B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in,
                      nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe,
                      sel_row, B);
   return gcm_launch_status();
