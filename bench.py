@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py - belief-states/sec of the DenseGCM hot path on MI355X.
+"""bench.py - belief-states/sec of the DenseGCM / SparseGCM hot path on MI355X.
 
 Metric (BASELINE.json): belief-states/sec = B*T / wall time of
     reset state; for t in range(T): mx_t, m = gcm(obs[t], m); loss = stack(mx).mean();
     loss.backward(); all-reduce grads (N>1); synchronize
-on cfg2: DenseGCM + TemporalBackedge([1,2,4]), B=256 per GPU, graph_size=128, obs=hidden=32,
-2 x DenseGraphConv + tanh.  One "step" of this bench = one such rollout (B*T belief states)
-through the per-step drop-in call surface.  Batch-sharded over ranks (weak scaling: every rank
-owns B graphs), one RCCL all-reduce of the flat gradient bucket per backward.
+Default workload = cfg2 (the configuration the metric is quoted on): DenseGCM + TemporalBackedge([1,2,4]),
+B=256 per GPU, graph_size=128, obs=hidden=32, 2 x DenseGraphConv + tanh, T=128.  One "step" of this
+bench = one such rollout (B*T belief states) through the per-step drop-in call surface.  Batch-sharded
+over ranks (weak scaling: every rank owns B graphs), one RCCL all-reduce of the flat gradient bucket
+per backward.
 
-`value` is measured with the module's donated-state mode (`DenseGCM(..., donate_state=True)`:
-the step advances the hidden state in place instead of cloning it, same results) and with the
-loop + backward captured once in a HIP graph and replayed (torch.cuda.CUDAGraph, in process);
-the same loop run eagerly, with and without donation, is reported beside it (`variants`).
+`value` (cfg2 / cfg3) is measured with the module's donated-state mode (`DenseGCM(..., donate_state=True)`:
+the step advances the hidden state in place instead of cloning it, same results) and with the loop +
+backward captured once in a HIP graph and replayed (torch.cuda.CUDAGraph, in process); the same loop run
+eagerly, with donated and with functional (reference-default) state, is reported beside it (`variants`).
 
   python bench.py --gpus N --steps K --warmup W        # N > 1 without WORLD_SIZE: spawns N ranks
+  python bench.py --config cfg3|cfg4|cfg5 ...          # the other BASELINE configs, same JSON contract
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import ctypes
 import json
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -31,8 +35,23 @@ for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
 
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak; no TF32 on gfx950
-B, N, F, H = 256, 128, 32, 32
 HOPS = [1, 2, 4]
+
+# BASELINE.json configs[1..4]; B is per GPU
+CONFIGS = {
+    "cfg2": dict(kind="dense", B=256, N=128, F=32, H=32, T=128, selector="temporal",
+                 text="cfg2: DenseGCM + TemporalBackedge([1,2,4]), B=256/GPU, graph_size=128, obs=32, hidden=32, "
+                      "2x DenseGraphConv+tanh"),
+    "cfg3": dict(kind="dense", B=256, N=128, F=64, H=32, T=128, selector="euclid",
+                 text="cfg3: DenseGCM + EuclideanEdge(2.0) (cross-batch mean, reference-exact), B=256, "
+                      "graph_size=128, obs=64, hidden=32, clustered observations (SURVEY 8d)"),
+    "cfg5": dict(kind="dense", B=256, N=128, F=32, H=32, T=64, selector="learned",
+                 text="cfg5: DenseGCM + LearnedEdge(32), B=256/GPU (B=2048 over 8 ranks), graph_size=128, "
+                      "obs=hidden=32, gumbel noise from the per-rank device generator"),
+    "cfg4": dict(kind="sparse", B=512, N=512, F=32, H=32, T=512, selector="temporal_sparse",
+                 text="cfg4: SparseGCM + TemporalEdge([1]), B=512/GPU, graph_size=512, obs=hidden=32, 2x GraphConv+tanh, "
+                      "one call per episode (taus=512)"),
+}
 
 
 def spawn_ranks(args):
@@ -45,6 +64,9 @@ def spawn_ranks(args):
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool only support dmabuf IPC; without it RCCL's
+        # intra-node transport setup fails with `hipIpcGetMemHandle: invalid argument` (it is exported
+        # in the image already - kept explicit for ranks started from a scrubbed environment)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -58,22 +80,50 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def build_memory(device, donate=False, selector="temporal"):
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def dense_gnn(F, H, device):
     import torch
     from gcm import nn as G
+    return G.Sequential("x, adj, weights, B, N", [
+        (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+        (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(device)
+
+
+def build_memory(device, donate=False, selector="temporal", cfg=None):
+    """(DenseGCM, gnn, selector module) of a dense config (default: cfg2)."""
+    import torch
     from gcm.gcm import DenseGCM
     from gcm.edge_selectors.temporal import TemporalBackedge
 
+    c = cfg or CONFIGS["cfg2"]
     torch.manual_seed(0)
-    gnn = G.Sequential("x, adj, weights, B, N", [
-        (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
-        (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(device)
+    gnn = dense_gnn(c["F"], c["H"], device)
     if selector == "learned":
         from gcm.edge_selectors.learned import LearnedEdge
-        sel = LearnedEdge(F).to(device)
+        sel = LearnedEdge(c["F"]).to(device)
+    elif selector == "euclid":
+        from gcm.edge_selectors.distance import EuclideanEdge
+        sel = EuclideanEdge(2.0)
     else:
         sel = TemporalBackedge(HOPS)
-    return DenseGCM(gnn, edge_selectors=sel, graph_size=N, donate_state=donate), gnn
+    mem = DenseGCM(gnn, edge_selectors=sel, graph_size=c["N"], donate_state=donate)
+    return mem, gnn, sel
+
+
+def make_obs(c, rank, device):
+    """Synthetic observations resident in HBM; like the reference's speed test and the CPU
+    baseline, obs carries no gradient."""
+    import torch
+    gen = torch.Generator().manual_seed(1000 + rank)
+    T, B, F = c["T"], c["B"], c["F"]
+    if c["selector"] == "euclid":      # 8 cluster centres shared across the batch, k_t = t mod 8
+        centres = 4.0 * torch.randn(8, F, generator=torch.Generator().manual_seed(7))
+        obs = centres[torch.arange(T) % 8][:, None, :] + 0.05 * torch.randn(T, B, F, generator=gen)
+    else:
+        obs = torch.rand(T, B, F, generator=gen)
+    return obs.to(device)
 
 
 def rollout(mem, obs, bucket=None, weight=1.0):
@@ -99,37 +149,60 @@ def rollout_api(mem, obs, bucket=None, weight=1.0):
     return loss
 
 
-def capture(mem, gnn, obs):
-    """The per-step loop + backward as one HIP graph (captured in this process; the usual
-    side-stream warm-up first).  Returns the graph; parameter .grad tensors are graph outputs."""
+def capture(fn, zero):
+    """`fn` as one HIP graph (captured in this process; the usual side-stream warm-up first)."""
     import torch
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(3):
-            gnn.zero_grad(set_to_none=True)
-            rollout(mem, obs)
+            zero()
+            fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
-    gnn.zero_grad(set_to_none=True)
+    zero()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        rollout(mem, obs)
+        fn()
     return g
 
 
-def time_step_kernel(mem, obs, reps=10):
-    """Duration of the dominant kernel (k_step_rows, one launch per forward step) IN SITU: the T
-    launches of a rollout through the C ABI on the evolving donated state, enqueued back to back (as the
-    replayed graph does), a HIP event pair on the launch stream around every launch; mean over
-    T x reps launches.  Also the time-parallel backward kernel on the records of one rollout."""
-    import ctypes
+def event_time(fn, iters, warm=3):
+    """ms per call of `fn` (launches on torch's current stream), HIP events around `iters` calls."""
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+# ------------------------------------------------------------------------------------------------
+# in-situ duration of the dominant kernels
+# ------------------------------------------------------------------------------------------------
+def time_step_kernel(mem, obs, c, reps=10):
+    """k_step_rows (one launch per forward step) IN SITU, two ways:
+    (events) the T launches of a rollout through the C ABI on the evolving donated state, enqueued back
+    to back from C, a HIP event pair recorded by the dispatch itself around every launch
+    (hipExtLaunchKernelGGL start/stop events = the begin/end timestamps rocprofv3 --kernel-trace
+    reports); mean over reps x T launches.  Sensitive to the host: when the box's CPUs are busy the
+    launches are not back to back and the clocks sag (8.3 us against 5.7 us across two leases in round 2);
+    (graph) the T-step forward loop alone captured in a HIP graph (training mode: records written),
+    replay time / T - the cadence inside the graph `value` times, launch gaps included, so an UPPER bound
+    on the kernel's own duration, independent of the host.
+    Also the time-parallel backward kernel on the records of one rollout.
+    -> (events ms, graph ms, bptt ms, launches timed by events)"""
     import torch
     from gcm import _hip
 
     lib = _hip.lib()
     dev = obs.device
-    T = obs.shape[0]
+    T, B, N, F, H = obs.shape[0], c["B"], c["N"], c["F"], c["H"]
     cfg = mem._fused_plan(*mem.get_initial_hidden_state(obs[0])[:3], F)
     params = mem._packed_params(cfg, head=True).detach()
     lay = (ctypes.c_size_t * 6)()
@@ -144,75 +217,187 @@ def time_step_kernel(mem, obs, reps=10):
         assert hip.hipEventCreate(ctypes.byref(e)) == 0
         return e
 
-    evs = [(new_event(), new_event()) for _ in range(T)]
-    spans = []
     saved_all = [torch.empty(lay[0], device=dev) for _ in range(T)]
-    ev_a = (ctypes.c_void_p * T)(*[a for a, _ in evs])
-    ev_b = (ctypes.c_void_p * T)(*[b for _, b in evs])
-    sv_p = (ctypes.c_void_p * T)(*[t_.data_ptr() for t_ in saved_all])
-    obs_c = obs.contiguous()
-    for _ in range(reps + 1):
-        nodes, adj, _, count = mem.get_initial_hidden_state(obs[0])
-        # the T launches enqueued back to back from C (the cadence of the replayed graph that `value`
-        # times), each bracketed by events recorded by the dispatch itself (kernel begin / end timestamps)
-        rc = lib.gcm_debug_time_rows_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
-                                             p(params), cfg.has_bias, cfg.acts[0], cfg.acts[1], sv_p, p(flags),
-                                             ev_a, ev_b, T, B, N, F, H, H, st)
-        assert rc == 0
-        torch.cuda.synchronize()
-        ms = ctypes.c_float()
-        row = []
+    step_ev = None
+    if not cfg.has_distance:     # (the C helper drives the plain step; a distance selector needs its workspace)
+        evs = [(new_event(), new_event()) for _ in range(T)]
+        spans = []
+        ev_a = (ctypes.c_void_p * T)(*[a for a, _ in evs])
+        ev_b = (ctypes.c_void_p * T)(*[b for _, b in evs])
+        sv_p = (ctypes.c_void_p * T)(*[t_.data_ptr() for t_ in saved_all])
+        obs_c = obs.contiguous()
+        for _ in range(reps + 1):
+            nodes, adj, _, count = mem.get_initial_hidden_state(obs[0])
+            rc = lib.gcm_debug_time_rows_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
+                                                 p(params), cfg.has_bias, cfg.acts[0], cfg.acts[1], sv_p, p(flags),
+                                                 ev_a, ev_b, T, B, N, F, H, H, st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            ms = ctypes.c_float()
+            row = []
+            for a, b in evs:
+                assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+                row.append(ms.value)
+            spans.append(row)
         for a, b in evs:
-            assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
-            row.append(ms.value)
-        spans.append(row)
-    for a, b in evs:
-        hip.hipEventDestroy(a)
-        hip.hipEventDestroy(b)
-    step_ms = sum(sum(s) for s in spans[1:]) / (reps * T)
+            hip.hipEventDestroy(a)
+            hip.hipEventDestroy(b)
+        step_ev = sum(sum(s) for s in spans[1:]) / (reps * T)
+
+    # the forward loop alone as a HIP graph (grad mode: the records are written, as in the timed region)
+    def fwd_only():
+        hidden = None
+        for t in range(T):
+            _, hidden = mem(obs[t], hidden)
+
+    g = capture(fwd_only, lambda: None)
+    step_graph = event_time(g.replay, 30, warm=5) / T
+    del g
+
     # the backward kernel over the T records
+    if cfg.has_distance:         # (records of a real rollout: the live-row counts matter)
+        hidden = None
+        recs = []
+        for t in range(T):
+            mx, hidden = mem(obs[t], hidden)
+            recs.append(mx)
+        saved_ptrs = [m_.data_ptr() for m_ in recs]
+    else:
+        saved_ptrs = [s.data_ptr() for s in saved_all]
     g_mx = torch.full((T, B, H), 1.0 / (T * B * H), device=dev)
-    arr_s = (ctypes.c_void_p * T)(*[s.data_ptr() for s in saved_all])
+    arr_s = (ctypes.c_void_p * T)(*saved_ptrs)
     arr_g = (ctypes.c_void_p * T)(*[g_mx[t].data_ptr() for t in range(T)])
     ws_bytes = lib.gcm_dense_rows_bptt_workspace_bytes(T, B, F, H, H)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     gp = torch.empty(cfg.P, device=dev)
-    times = []
-    for _ in range(reps + 1):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+
+    def bptt():
         rc = lib.gcm_dense_rows_bptt(arr_s, arr_g, T, H, 1, p(params), cfg.has_bias, cfg.acts[0], cfg.acts[1], None,
                                      p(gp), p(ws), ws_bytes, B, N, F, H, H, st)
-        b.record()
         assert rc == 0
-        torch.cuda.synchronize()
-        times.append(a.elapsed_time(b))
-    return step_ms, sum(times[1:]) / reps
+
+    bptt_ms = event_time(bptt, reps, warm=1)
+    return step_ev, step_graph, bptt_ms, reps * T
 
 
-def cpu_baseline(T, budget_s=20.0):
-    """The oracle (op-for-op eager-PyTorch restatement of the reference, kind "port") timed on
-    this box's host cores on a BOUNDED sample of the same workload: the same B/N/F/H/selector,
-    a rollout of T_s <= T steps fwd+bwd (T_s sized so the sample stays within ~budget_s).
-    Thread policy: torch's own default is one thread per host CPU, which on a
+def time_euclid_kernel(c, iters=50):
+    """k_euclid_mfma alone (gcm_edge_distance_pre through the C ABI) on FULL graphs (every row a
+    candidate: 2*B*B*N*F flops per launch), HIP events around back-to-back launches."""
+    import torch
+    from gcm import _hip
+    lib, p, st = _hip.lib(), _hip.ptr, _hip.stream()
+    B, N, F = c["B"], c["N"], c["F"]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator().manual_seed(3)
+    nodes = torch.randn(B, N, F, generator=gen).to(dev)
+    count = torch.full((B,), N - 1, dtype=torch.long, device=dev)
+    obs = torch.randn(B, F, generator=gen).to(dev)
+    ws_bytes = lib.gcm_edge_distance_workspace_bytes(_hip.DIST_EUCLID_CROSSBATCH, B, N, F)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    row = torch.empty(B, N, device=dev)
+
+    def launch():
+        rc = lib.gcm_edge_distance_pre(p(nodes), p(count), p(obs), p(row), _hip.DIST_EUCLID_CROSSBATCH, 2.0, None,
+                                       0, 0, 0, 0, p(ws), ws_bytes, B, N, F, st)
+        assert rc == 0
+
+    return event_time(launch, iters, warm=5)
+
+
+def time_csr_kernels(c, iters=50):
+    """The CSR GraphConv forward kernel alone at the one-shot shape (B chains of N nodes: E = B*(N-1)
+    edges, sum N = B*N rows), through the C ABI, HIP events around back-to-back launches."""
+    import torch
+    from gcm import _hip
+    lib, p, st = _hip.lib(), _hip.ptr, _hip.stream()
+    B, N, F, H = c["B"], c["N"], c["F"], c["H"]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    M = B * N
+    x = torch.rand(M, F, device=dev)
+    deg = torch.ones(M, dtype=torch.long, device=dev)
+    deg[::N] = 0
+    row_ptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), deg.cumsum(0)])
+    col = (torch.arange(M, device=dev) - 1)[deg.bool()].contiguous()
+    w_rel, w_root = torch.randn(H, F, device=dev) * .1, torch.randn(H, F, device=dev) * .1
+    b = torch.randn(H, device=dev)
+    out, agg = torch.empty(M, H, device=dev), torch.empty(M, F, device=dev)
+
+    def fwd():
+        rc = lib.gcm_csr_graphconv_fwd(p(x), p(row_ptr), p(col), None, None, p(w_rel), p(b), p(w_root), p(out),
+                                       p(agg), M, F, H, 1, st)
+        assert rc == 0
+
+    return event_time(fwd, iters, warm=5), int(col.numel()), M
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (op-for-op eager-PyTorch restatement of the reference, kind "port")
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(c, budget_s=20.0):
+    """The oracle timed on this box's host cores on a BOUNDED sample of the same workload: the same
+    B/N/F/H/selector, a rollout of T_s <= T steps fwd+bwd (T_s sized so the sample stays within
+    ~budget_s).  Thread policy: torch's own default is one thread per host CPU, which on a
     256-CPU host is several times SLOWER than 16-32 threads for these op sizes; the CPU gets its
     best configuration of {8, 16, 32, 64, os.cpu_count()} and the choice is recorded."""
     import torch
     from oracle import dense as od
 
+    B, N, F, H, T = c["B"], c["N"], c["F"], c["H"], c["T"]
     torch.manual_seed(0)
+    ncpu = os.cpu_count() or 1
+    if c["kind"] == "sparse":
+        from oracle import sparse as osp
+        gnn = osp.canonical_gnn(F, H)
+        x = torch.rand(B, N, F)
+        taus = torch.full((B,), N, dtype=torch.long)
+
+        def run(graphs):
+            t0 = time.perf_counter()
+            out, _ = osp.sparse_step(x[:graphs], taus[:graphs], None, gnn, graph_size=N,
+                                     edge_selectors=osp.TemporalEdge([1]))
+            out.mean().backward()
+            gnn.zero_grad(set_to_none=True)
+            return time.perf_counter() - t0
+
+        tried = {}
+        for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+            torch.set_num_threads(th)
+            run(16)
+            tried[th] = run(64)
+        best = min(tried, key=tried.get)
+        torch.set_num_threads(best)
+        graphs = int(max(16, min(B, 64 * budget_s / (2.0 * tried[best]))))
+        dt = run(graphs)
+        return {"value": graphs * N / dt, "unit": "belief-states/s", "cores": best, "kind": "port",
+                "seconds": dt, "host_cpus": ncpu,
+                "threads_tried_s_per_64_graphs": {str(k): round(v, 3) for k, v in tried.items()},
+                "sample": f"one SparseGCM call fwd+bwd on {graphs} of the {B} graphs (N={N} nodes each, F={F}, "
+                          f"H={H}, TemporalEdge([1]), taus={N}), oracle/sparse.py on {best} torch threads "
+                          f"(best of {sorted(tried)})"}
     gnn = od.canonical_gnn(F, H)
-    sel = od.TemporalBackedge(HOPS)
-    obs = torch.rand(T, B, F)
+    if c["selector"] == "euclid":
+        sel = od.EuclideanEdge(2.0)
+        centres = 4.0 * torch.randn(8, F)
+        obs = centres[torch.arange(T) % 8][:, None, :] + 0.05 * torch.randn(T, B, F)
+        extra = []
+    elif c["selector"] == "learned":
+        net = od.build_edge_network(F)
+        sel = od.LearnedEdge(net, num_edge_samples=5)
+        obs = torch.rand(T, B, F)
+        extra = [net]
+    else:
+        sel = od.TemporalBackedge(HOPS)
+        obs = torch.rand(T, B, F)
+        extra = []
 
     def run(steps):
         t0 = time.perf_counter()
         out, _ = od.dense_rollout(obs[:steps], None, gnn, graph_size=N, edge_selectors=sel)
         out.mean().backward()
-        gnn.zero_grad(set_to_none=True)
+        for m in [gnn] + extra:
+            m.zero_grad(set_to_none=True)
         return time.perf_counter() - t0
 
-    ncpu = os.cpu_count() or 1
     tried = {}
     for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
         torch.set_num_threads(th)
@@ -227,17 +412,20 @@ def cpu_baseline(T, budget_s=20.0):
     return {"value": B * T_s / dt, "unit": "belief-states/s", "cores": best, "kind": "port",
             "seconds": dt, "host_cpus": ncpu,
             "threads_tried_s_per_4_steps": {str(k): round(v, 3) for k, v in tried.items()},
-            "sample": f"1 rollout fwd+bwd, same workload (B={B}, N={N}, F={F}, H={H}, hops={HOPS}) "
+            "sample": f"1 rollout fwd+bwd, same workload (B={B}, N={N}, F={F}, H={H}, selector={c['selector']}) "
                       f"truncated to T={T_s} steps, oracle/dense.py on {best} torch threads "
                       f"(best of {sorted(tried)})"}
 
 
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None, help="default: 1000 (cfg2), 200 (cfg3/cfg5), 50 (cfg4)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--T", type=int, default=128, help="rollout length (128 fills the graph)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--T", type=int, default=None, help="rollout length (cfg2: 128 fills the graph)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra timed blocks of K steps for value_spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager loop instead of the graph replay")
     args = ap.parse_args()
@@ -249,31 +437,21 @@ def main():
     import torch.distributed as dist
     from gcm import parallel
 
+    c = dict(CONFIGS[args.config])
+    if args.T:
+        c["T"] = args.T
+    if args.steps is None:
+        args.steps = {"cfg2": 1000, "cfg3": 200, "cfg5": 200, "cfg4": 50}[args.config]
     rank, local_rank, world = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local_rank)
-    T = args.T
-    mem, gnn = build_memory(device, donate=True)
-    bucket = parallel.GradBucket(gnn)
-    gen = torch.Generator().manual_seed(1000 + rank)
-    # resident in HBM; like the reference's speed test and the CPU baseline, obs carries no grad
-    obs = torch.rand(T, B, F, generator=gen).to(device)
+    B, N, F, H, T = c["B"], c["N"], c["F"], c["H"], c["T"]
     weight = 1.0 / world
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    graph = None if args.no_graph else capture(mem, gnn, obs)
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            bucket.all_reduce_mean(weight)
-        else:
-            rollout(mem, obs, bucket, weight)
-            gnn.zero_grad(set_to_none=True)
 
     def timed(fn, steps, warm):
         for _ in range(warm):
@@ -288,8 +466,61 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    line = {"metric": "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 F=32", "unit": "belief-states/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+
+    if c["kind"] == "sparse":
+        bench_sparse(args, c, line, rank, world, device, timed, weight, traffic)
+    else:
+        bench_dense(args, c, line, rank, world, device, timed, weight, traffic)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def spread_of(times, states_per_block):
+    vals = sorted(states_per_block / t for t in times)
+    return {"min": vals[0], "median": statistics.median(vals), "max": vals[-1], "blocks": len(vals),
+            "note": "belief-states/s of each timed block of `steps` bench steps (the first block is `value`)"}
+
+
+def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
+    import torch
+    from gcm import parallel
+    B, N, F, H, T = c["B"], c["N"], c["F"], c["H"], c["T"]
+    name = args.config
+    if c["selector"] == "euclid" and world > 1:
+        raise SystemExit("cfg3: EuclideanEdge averages over the whole batch (distance.py:48-49); a sharded run "
+                         "needs EuclideanEdge(shard_group=...) - run it on one GPU")
+    can_donate = c["selector"] != "learned"
+    mem, gnn, sel = build_memory(device, donate=can_donate, selector=c["selector"], cfg=c)
+    mods = [gnn] + ([sel] if c["selector"] == "learned" else [])
+    bucket = parallel.GradBucket(*mods)
+    if c["selector"] == "learned":       # per-rank gumbel draws (seeds 0 + rank)
+        torch.cuda.manual_seed(rank)
+    obs = make_obs(c, rank, device)
+
+    def zero():
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+
+    graph = None if args.no_graph else capture(lambda: rollout(mem, obs), zero)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            bucket.all_reduce_mean(weight)
+        else:
+            rollout(mem, obs, bucket, weight)
+            zero()
+
     dt = timed(step, args.steps, args.warmup)
-    # the flag word the kernels OR into (finite check, overflow, bad counts), read once
+    blocks = [dt] + [timed(step, args.steps, 0) for _ in range(max(0, args.repeats))]
     flags = mem._flag_word(device)
     bits = int(flags.item())
     assert not (bits & 6), f"kernels flagged {bits}"
@@ -297,103 +528,212 @@ def main():
     # ---- the same work along the other paths (reported beside `value`) ---------------------------
     side = max(3, min(20, args.steps // 10))
     variants = {}
-    mem_e, gnn_e = build_memory(device, donate=True)
-    bucket_e = parallel.GradBucket(gnn_e)
 
-    def eager(m, g, bk):
+    def eager(m, mods_, bk):
         def f():
             rollout(m, obs, bk, weight)
-            g.zero_grad(set_to_none=True)
+            for q in mods_:
+                q.zero_grad(set_to_none=True)
         return f
 
-    variants["eager_donated"] = world * B * T * side / timed(eager(mem_e, gnn_e, bucket_e), side, 2)
-    mem_f, gnn_f = build_memory(device, donate=False)
-    bucket_f = parallel.GradBucket(gnn_f)
-    variants["eager_functional"] = world * B * T * side / timed(eager(mem_f, gnn_f, bucket_f), side, 2)
+    def variant(donate, reps=3):
+        m, g_, s_ = build_memory(device, donate=donate, selector=c["selector"], cfg=c)
+        mods_ = [g_] + ([s_] if c["selector"] == "learned" else [])
+        bk = parallel.GradBucket(*mods_)
+        f = eager(m, mods_, bk)
+        ts = [timed(f, side, 2 if i == 0 else 0) for i in range(reps)]
+        m.check_flags()
+        return m, g_, bk, [world * B * T * side / t for t in ts]
 
-    def roll():
-        rollout_api(mem_f, obs, bucket_f, weight)
-        gnn_f.zero_grad(set_to_none=True)
+    if can_donate:
+        mem_e, gnn_e, bucket_e, v = variant(True)
+        variants["eager_donated"] = statistics.median(v)
+        variants["eager_donated_min_max"] = [min(v), max(v)]
+    mem_f, gnn_f, bucket_f, v = variant(False)
+    variants["eager_functional"] = statistics.median(v)
+    variants["eager_functional_min_max"] = [min(v), max(v)]
+    if c["selector"] == "temporal":
+        def roll():
+            rollout_api(mem_f, obs, bucket_f, weight)
+            gnn_f.zero_grad(set_to_none=True)
+        variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
 
-    variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
+        def fwd_only():
+            with torch.no_grad():
+                hidden = None
+                for t in range(T):
+                    _, hidden = mem_e(obs[t], hidden)
+        variants["forward_only_eager_donated"] = world * B * T * side / timed(fwd_only, side, 1)
+        mem_e.check_flags()
 
-    def fwd_only():
-        with torch.no_grad():
-            hidden = None
-            for t in range(T):
-                _, hidden = mem_e(obs[t], hidden)
-
-    variants["forward_only_eager_donated"] = world * B * T * side / timed(fwd_only, side, 1)
-    mem_e.check_flags()
-    mem_f.check_flags()
-
-    step_ms, bptt_ms = time_step_kernel(mem_e, obs) if rank == 0 else (None, None)
-
-    if rank == 0:
-        states = world * B * T * args.steps
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))
-        # Dominant kernel = k_step_rows: one launch per forward step, > 90 % of the GPU time of the
-        # metric (the backward of the whole rollout is ONE launch of k_bptt_rows).  Bounding
-        # roofline: HBM.  `achieved` = SURVEY 8(d)'s compulsory bytes per belief state (adj once, x
-        # once, obs in, belief out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2) x B
-        # over the mean launch time.  The kernel exploits "only row n_b is kept" (gcm.py:314): it
-        # reads the node matrix, row cur and the live rows, not the [N,N] adjacency - `traffic` (PMC)
-        # is what it actually moves, `achieved_moved` the rate of that.
+    if rank != 0:
+        return
+    states = world * B * T * args.steps
+    ms_per_step = dt / args.steps * 1e3
+    fwd_full = 2 * N * N * (F + H) + 4 * N * (F * H + H * H)       # SURVEY 8(d), per belief state
+    kernel_ms = {}
+    if c["selector"] in ("temporal", "euclid"):
+        step_ev, step_graph, bptt_ms, n_ev = time_step_kernel(mem_e, obs, c)
+        bound = (ms_per_step - bptt_ms) / T if graph is not None else None
+        cands = [v for v in (step_ev, step_graph) if v is not None]
+        step_ms = min(cands)
+        kernel_ms = {"k_step_rows": round(step_ms, 5), "k_step_rows_events": step_ev and round(step_ev, 5),
+                     "k_step_rows_graph_fwd_loop_over_T": round(step_graph, 5),
+                     "k_bptt_rows(T=%d)" % T: round(bptt_ms, 5)}
+    if c["selector"] == "temporal":
+        # Dominant kernel = k_step_rows: one launch per forward step, ~80 % of the GPU time of the metric
+        # (the backward of the whole rollout is two launches of k_bptt_rows).  Bounding roofline: HBM.
+        # `achieved` = SURVEY 8(d)'s compulsory bytes per belief state (adj once, x once, obs in, belief
+        # out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2) x B over the mean launch time.  The
+        # kernel exploits "only row n_b is kept" (gcm.py:314): it reads the node matrix, row cur and the
+        # live rows, not the [N,N] adjacency - `traffic` (PMC) is what it actually moves.
         alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
         sec = step_ms * 1e-3
         moved = traffic.get("k_step_rows")
-        dominant = {"bound": "hbm", "kernel": "k_step_rows", "achieved": alg_bytes / sec / 1e9,
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS,
-                    "traffic": moved, "bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms,
-                    "launches_timed": 3 * T,
-                    "achieved_moved": (moved / sec / 1e9) if moved else None,
-                    "note": "bytes_per_launch = SURVEY 8(d) full-dense compulsory bytes (what the reference's "
-                            "formulation must move); the live-row kernel moves `traffic` bytes (PMC: "
-                            "2*FETCH_SIZE + WRITE_SIZE per launch, profiles/r02_traffic_detail.json) because only "
-                            "the rows that reach the kept belief row are evaluated and the state is advanced "
-                            "in place: the kernel is bound by its chain of dependent latencies (one wave per "
-                            "SIMD at B = 256 graphs on 256 CUs), not by bytes. avg_launch_ms: the T launches "
-                            "of a rollout in situ on the evolving state, enqueued back to back from C (the cadence of the "
-                            "replayed graph the timed region runs), each bracketed by HIP events recorded by "
-                            "the dispatch itself (hipExtLaunchKernelGGL start/stop events = the kernel begin/end "
-                            "timestamps rocprofv3 --kernel-trace reports)"}
-        fwd_full = 2 * N * N * (F + H) + 4 * N * (F * H + H * H)
-        line = {
-            "metric": "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 F=32",
-            "value": states / dt, "unit": "belief-states/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "cfg2: DenseGCM + TemporalBackedge([1,2,4]), B=256/GPU, graph_size=128, "
-                                   "obs=32, hidden=32, 2x DenseGraphConv+tanh, T=%d; one bench step = one rollout "
-                                   "through the per-step drop-in call surface `for t: mx, m = gcm(obs[t], m)` + "
-                                   "backward" % T,
-                       "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": T,
-                       "state": "donated (DenseGCM(donate_state=True): hidden state advanced in place)",
-                       "launch": "eager" if graph is None else "HIP graph of the loop + backward, captured once "
-                                                               "in process, replayed per bench step",
-                       "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
-            "variants": {k: round(v, 1) for k, v in variants.items()},
-            "variants_note": "belief-states/s of the same workload: eager per-step loop with donated / "
-                             "functional (reference-default) state, the additive DenseGCM.rollout entry, and the "
-                             "forward loop alone under no_grad",
-            "roofline": dominant,
-            "roofline_mfma_view": {"kernel": "k_step_rows", "flops_per_launch_full_dense": B * fwd_full,
-                                   "achieved_full_dense_TFLOPs": B * fwd_full / sec / 1e12,
-                                   "frac_of_fp32_mfma_peak": B * fwd_full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   "note": "SURVEY 8(d) full-dense FLOPs (2 layers x all N rows) over the same "
-                                           "launch time; the kernel executes layer 1 on the live rows only"},
-            "kernel_ms": {"k_step_rows": round(step_ms, 5), "k_bptt_rows(T=%d)" % T: round(bptt_ms, 5)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(T)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        inconsistent = bound is not None and step_ms > bound * 1.02
+        line["roofline"] = {
+            "bound": "hbm", "kernel": "k_step_rows", "achieved": alg_bytes / sec / 1e9, "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS, "traffic": moved,
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms,
+            "avg_launch_ms_events": step_ev, "launches_timed_events": n_ev,
+            "avg_launch_ms_graph_fwd_loop": step_graph,
+            "avg_launch_ms_upper_bound_from_value": bound, "timing_inconsistent": bool(inconsistent),
+            "achieved_moved": (moved / sec / 1e9) if moved else None,
+            "note": "bytes_per_launch = SURVEY 8(d) full-dense compulsory bytes (what the reference's formulation "
+                    "must move): an EFFECTIVE rate; the live-row kernel moves `traffic` bytes (PMC: 2*FETCH_SIZE + "
+                    "WRITE_SIZE per launch, profiles/) - `achieved_moved` is the rate of those - because only the rows "
+                    "that reach the kept belief row are evaluated and the state is advanced in place: the kernel is "
+                    "bound by its chain of dependent latencies (one wave per SIMD at B = 256 graphs on 256 CUs), not "
+                    "by bytes.  avg_launch_ms = min(events, graph): `events` = the T launches of a rollout in situ "
+                    "enqueued back to back from C, each bracketed by HIP events recorded by the dispatch itself "
+                    "(sensitive to a busy host); `graph` = replay time of the captured forward loop / T (launch gaps "
+                    "included: an upper bound, host independent); both must not exceed (ms_per_step - bptt) / T, "
+                    "else timing_inconsistent"}
+        line["roofline_mfma_view"] = {
+            "kernel": "k_step_rows", "flops_per_launch_full_dense": B * fwd_full,
+            "achieved_full_dense_TFLOPs": B * fwd_full / sec / 1e12,
+            "frac_of_fp32_mfma_peak": B * fwd_full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "note": "SURVEY 8(d) full-dense FLOPs (2 layers x all N rows) over the same launch time; the kernel "
+                    "executes layer 1 on the live rows only"}
+    elif c["selector"] == "euclid":
+        # Dominant kernel = k_euclid_mfma (the cross-batch distance contraction [N x F].[F x B] per graph on
+        # the fp32 MFMA): 2*B*B*N*F flops per launch.  Timed alone on full graphs.
+        eu_ms = time_euclid_kernel(c)
+        flops = 2.0 * B * B * N * F
+        kernel_ms["k_euclid_mfma(full graphs)"] = round(eu_ms, 5)
+        line["roofline"] = {
+            "bound": "mfma", "kernel": "k_euclid_mfma", "achieved": flops / (eu_ms * 1e-3) / 1e12,
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / (eu_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic.get("k_euclid_mfma"),
+            "flops_per_launch": flops, "avg_launch_ms": eu_ms,
+            "note": "fp32 MFMA (no TF32 on gfx950); the kernel alone through the C ABI (gcm_edge_distance_pre) on "
+                    "graphs that hold N-1 nodes - every stored row is a candidate -, HIP events around 50 "
+                    "back-to-back launches on the launch stream; in a rollout that starts from empty graphs the "
+                    "kernel skips rows >= cur, so its in-situ average is shorter"}
+    else:
+        # cfg5: no single dominant kernel (selection, GNN forward, one fused backward per step): the WHOLE
+        # step against the fp32 MFMA peak on SURVEY 8(d)'s flops - GNN fwd+bwd (3x forward), the adjacency
+        # gradient (2N^2 F + 2N^2 H), the edge network on N candidate pairs fwd+bwd (3 x 2(3F^2+F) each)
+        per_state = 3 * fwd_full + 2 * N * N * (F + H) + 3 * N * 2 * (3 * F * F + F)
+        step_s = dt / args.steps / T
+        line["roofline"] = {
+            "bound": "mfma", "kernel": "k_learned_select + k_gnn2_row_fwd + k_learned_step_bwd (whole step)",
+            "achieved": B * per_state / step_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": B * per_state / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "flops_per_step": B * per_state, "avg_step_ms": step_s * 1e3,
+            "note": "EFFECTIVE: SURVEY 8(d) full-dense flops of one fwd+bwd memory step of B graphs over the wall "
+                    "time per step of the timed region (ms_per_step / T); the kernels evaluate layer 1 on the live "
+                    "rows only"}
+    line.update({
+        "value": states / dt, "ms_per_step": ms_per_step,
+        "value_spread": spread_of(blocks, world * B * T * args.steps),
+        "config": {"workload": c["text"] + ", T=%d; one bench step = one rollout through the per-step drop-in call "
+                                           "surface `for t: mx, m = gcm(obs[t], m)` + backward" % T,
+                   "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": T,
+                   "state": "donated (DenseGCM(donate_state=True): hidden state advanced in place)" if can_donate
+                            else "functional",
+                   "launch": "eager" if graph is None else "HIP graph of the loop + backward, captured once "
+                                                           "in process, replayed per bench step",
+                   "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
+        "variants": {k: (round(v, 1) if not isinstance(v, list) else [round(x, 1) for x in v])
+                     for k, v in variants.items()},
+        "variants_note": "belief-states/s of the same workload: the eager per-step loop with donated / functional "
+                         "(reference-default: what an unchanged caller of the reference gets) state, median [min, max] "
+                         "of 3 blocks; the additive DenseGCM.rollout entry; the forward loop alone under no_grad",
+        "kernel_ms": kernel_ms,
+    })
+    if name != "cfg2":
+        line["metric"] = "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 (%s)" % name
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(c)
+    print(json.dumps(line))
+
+
+def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
+    """cfg4: SparseGCM + TemporalEdge([1]).  One bench step = one call over whole episodes
+    (x [B, N, F], taus = N: B*N belief states) + backward."""
+    import torch
+    from gcm import nn as G
+    from gcm import parallel
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    B, N, F, H = c["B"], c["N"], c["F"], c["H"]
+    torch.manual_seed(0)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(H, H), "x, edges, weights -> x"), torch.nn.Tanh()]).to(device)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1]), graph_size=N)
+    bucket = parallel.GradBucket(g)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    x = torch.rand(B, N, F, generator=gen).to(device)
+    taus = torch.full((B,), N, dtype=torch.long, device=device)
+
+    def oneshot():
+        out, _ = mem(x, taus, None)
+        out.mean().backward()
+        bucket.all_reduce_mean(weight)
+        g.zero_grad(set_to_none=True)
+
+    dt = timed(oneshot, args.steps, args.warmup)
+    blocks = [dt] + [timed(oneshot, args.steps, 0) for _ in range(max(0, args.repeats))]
+    one = torch.ones(B, dtype=torch.long, device=device)
+    n_sw = N      # SURVEY 8(d): stepwise taus=1 x 512
+
+    def stepwise():
+        hid, outs = None, []
+        for t in range(n_sw):
+            o, hid = mem(x[:, t:t + 1], one, hid)
+            outs.append(o)
+        torch.cat(outs, 1).mean().backward()
+        bucket.all_reduce_mean(weight)
+        g.zero_grad(set_to_none=True)
+
+    variants = {"stepwise_taus1_x%d" % n_sw: world * B * n_sw / timed(stepwise, 2, 1)}
+    if rank != 0:
+        return
+    fwd_ms, E, M = time_csr_kernels(c)
+    alg = E * (F * 4 + 16) + 2 * M * F * 4          # SURVEY 8(d): per layer, one-shot
+    states = world * B * N * args.steps
+    line.update({
+        "metric": "belief-states/sec (BxT) SparseGCM fwd+bwd, graph_size=512 F=32 (cfg4)",
+        "value": states / dt, "ms_per_step": dt / args.steps * 1e3,
+        "value_spread": spread_of(blocks, world * B * N * args.steps),
+        "config": {"workload": c["text"] + "; one bench step = one SparseGCM call on [B, 512, F] + backward, eager",
+                   "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": N,
+                   "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
+        "variants": {k: round(v, 1) for k, v in variants.items()},
+        "variants_note": "stepwise: the same episodes one node per call (taus = 1, %d calls) + one backward" % n_sw,
+        "roofline": {"bound": "hbm", "kernel": "k_csr_fwd3", "achieved": alg / (fwd_ms * 1e-3) / 1e9,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     "traffic": traffic.get("k_csr_fwd3"), "bytes_per_launch": alg, "avg_launch_ms": fwd_ms,
+                     "note": "SURVEY 8(d): E*(4F+16) + 2*sumN*4F bytes per GraphConv layer (E = %d edges, sumN = %d "
+                             "rows); the forward kernel of one layer alone through the C ABI (gcm_csr_graphconv_fwd, "
+                             "training mode: agg saved), HIP events around 50 back-to-back launches on the launch "
+                             "stream" % (E, M)},
+        "kernel_ms": {"k_csr_fwd3": round(fwd_ms, 5)},
+    })
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(c)
+    print(json.dumps(line))
 
 
 if __name__ == "__main__":

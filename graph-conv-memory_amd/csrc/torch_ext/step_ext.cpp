@@ -229,10 +229,21 @@ std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& node
 // graph-step to one time-parallel launch (gcm_dense_rows_bptt).  Round 2 had one node per step plus a
 // gate node: ~8 us of engine time per step, more than the kernel takes.
 // ---------------------------------------------------------------------------------------------
+// A contiguous tensor over part of `base`'s storage WITHOUT a view relation (no narrow/view dispatches,
+// no view bookkeeping: ~0.1 us instead of ~1.5 us per pair on the per-step host path).  It has its own
+// version counter.  offset in elements of `dtype`.
+static at::Tensor alias_of(const at::Tensor& base, int64_t offset, at::IntArrayRef sizes, caffe2::TypeMeta dtype) {
+  auto impl = c10::make_intrusive<c10::TensorImpl>(c10::Storage(base.storage()), base.key_set(), dtype);
+  impl->set_storage_offset(offset);
+  impl->set_sizes_contiguous(sizes);
+  return at::Tensor(std::move(impl));
+}
+
 struct RowsChainNode : public torch::autograd::Node {
   struct Rec {
-    at::Tensor buf;      // the step's record (gcm_dense_rows_layout); starts with mx
-    uint32_t version;    // of buf (= of mx, its view) when recorded
+    at::Tensor buf;             // the step's record (gcm_dense_rows_layout); starts with mx
+    c10::VariableVersion vc;    // version counter of the belief tensor handed to the caller (it aliases
+    uint32_t version;           // the head of the record) and its value when recorded
   };
   std::vector<Rec> recs;   // recs[k] <-> forward output k
   at::Tensor packed;       // the packed parameter vector, detached (the kernel re-reads the weights)
@@ -258,10 +269,11 @@ struct RowsChainNode : public torch::autograd::Node {
     for (size_t k = 0; k < grads.size(); ++k) {
       if (!grads[k].defined()) continue;
       const Rec& r = recs[k];
-      TORCH_CHECK(r.buf._version() == r.version,
+      TORCH_CHECK(r.vc.current_version() == r.version,
                   "one of the variables needed for gradient computation has been modified by an inplace "
                   "operation: the belief states returned by DenseGCM step ", k, " of this chain (version ",
-                  r.buf._version(), ", expected ", r.version, ") are part of the record its backward reads");
+                  r.vc.current_version(), ", expected ", r.version,
+                  ") are part of the record its backward reads");
       at::Tensor g = grads[k];
       if (g.scalar_type() != at::kFloat) {
         g = g.to(at::kFloat);
@@ -319,6 +331,7 @@ struct RowsFast {
   at::Tensor packed, flags;
   bool donate = false, grad_mode = false, armed = false;
   std::shared_ptr<RowsChainNode> node;
+  std::vector<pybind11::object> hook_dicts;    // the module's and torch's global hook dicts: all must be empty
   std::vector<pybind11::object> dicts, keys;   // module._parameters dicts and the names read from them
   std::vector<pybind11::object> objs;          // the Parameter objects (or None) the packed vector was built from
   std::vector<uint32_t> vers;
@@ -326,11 +339,19 @@ struct RowsFast {
   int64_t xB = -1, xF = -1, n_steps = 0;
   int dev = -1;
 
-  explicit RowsFast(const std::vector<std::pair<pybind11::object, pybind11::object>>& specs) {
+  RowsFast(const std::vector<std::pair<pybind11::object, pybind11::object>>& specs,
+           const std::vector<pybind11::object>& hooks)
+      : hook_dicts(hooks) {
     for (const auto& s : specs) {
       dicts.push_back(s.first);
       keys.push_back(s.second);
     }
+  }
+
+  bool hooks_registered() const {   // torch.nn.Module.__call__ has work to do: take the long way
+    for (const auto& d : hook_dicts)
+      if (PyObject_Size(d.ptr()) != 0) return true;
+    return false;
   }
 
   bool params_current() const {
@@ -387,9 +408,9 @@ struct RowsFast {
     } else {
       const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * (int64_t)N * N);
       at::Tensor st = at::empty({n_nodes + n_adj + pad64(2 * B)}, obs.options());
-      nodes_out = st.narrow(0, 0, B * N * F).view({B, N, F});
-      adj_out = st.narrow(0, n_nodes, B * (int64_t)N * N).view({B, N, N});
-      count_out = st.narrow(0, n_nodes + n_adj, 2 * B).view(at::kLong);
+      nodes_out = alias_of(st, 0, {B, N, F}, st.dtype());
+      adj_out = alias_of(st, n_nodes, {B, N, N}, st.dtype());
+      count_out = alias_of(st, (n_nodes + n_adj) / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
     }
     size_t ws_bytes = 0;
     void* ws = cfg->workspace((int)B, obs, &ws_bytes);
@@ -402,9 +423,10 @@ struct RowsFast {
               buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
               reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2, stream),
           "gcm_dense_rows_step_fwd_ws");
-    at::Tensor mx = buf.narrow(0, 0, B * H2).view({B, H2});   // the record starts with the belief states
+    at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());   // the record starts with the belief states
     if (need_bwd) {
-      node->recs.push_back({buf, buf._version()});
+      const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
+      node->recs.push_back({buf, vc, vc.current_version()});
       torch::autograd::create_gradient_edge(mx, node);
     }
     l_nodes = nodes_out;
@@ -471,7 +493,8 @@ struct RowsFast {
     const bool grad = at::GradMode::is_enabled();
     if (grad != grad_mode || (node && node->executed) || xt.dim() != 2 || xt.size(0) != xB ||
         xt.size(1) != xF || xt.scalar_type() != at::kFloat || !xt.is_cuda() || xt.get_device() != dev ||
-        c10::hip::current_device() != dev || (grad && xt.requires_grad()) || !params_current())
+        c10::hip::current_device() != dev || (grad && xt.requires_grad()) || !params_current() ||
+        hooks_registered())
       return pybind11::none();
     at::Tensor obs = xt.is_contiguous() ? xt : xt.contiguous();
     at::Tensor mx = launch(obs, l_nodes, l_adj, l_weights, l_count);
@@ -662,7 +685,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("update_descs", &StepCfg::update_descs);
   m.def("fused_step", &fused_step);
   pybind11::class_<RowsFast>(m, "RowsFast")
-      .def(pybind11::init<const std::vector<std::pair<pybind11::object, pybind11::object>>&>())
+      .def(pybind11::init<const std::vector<std::pair<pybind11::object, pybind11::object>>&,
+                          const std::vector<pybind11::object>&>())
       .def("run", &RowsFast::run)
       .def("step", &RowsFast::step)
       .def("continues", &RowsFast::continues)

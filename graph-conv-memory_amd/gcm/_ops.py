@@ -695,7 +695,7 @@ class StepConfig:
             self._zero_params[dev] = z
         return z
 
-    def rows_fast(self):
+    def rows_fast(self, module):
         """The host path of the live-row step (C++: RowsFast in csrc/torch_ext/step_ext.cpp), one per
         configuration: it validates a continuing chain by itself - hidden state returned by the
         previous call, same parameter objects at the same versions (read through the modules' own
@@ -707,7 +707,14 @@ class StepConfig:
                      (rel1._parameters, "weight"), (root1._parameters, "weight"), (rel1._parameters, "bias")]
             if self.fold is not None and self.fold[0] is not None:
                 specs += [(self.fold[0]._parameters, "weight"), (self.fold[0]._parameters, "bias")]
-            f = self._rows_fast = _ext.module().RowsFast(specs)
+            # the dicts torch.nn.Module.__call__ would consult: with any of them non-empty the unchecked
+            # entry declines and the call goes through nn.Module.__call__
+            from torch.nn.modules import module as M
+            hooks = [module._forward_hooks, module._forward_pre_hooks, module._backward_hooks,
+                     module._backward_pre_hooks, M._global_backward_pre_hooks, M._global_backward_hooks,
+                     M._global_forward_pre_hooks, M._global_forward_hooks,
+                     M._global_forward_hooks_always_called, M._global_forward_hooks_with_kwargs]
+            f = self._rows_fast = _ext.module().RowsFast(specs, hooks)
         return f
 
     def cpp_handle(self):

@@ -17,7 +17,6 @@ import math
 from typing import Tuple, Union
 
 import torch
-from torch.nn.modules.module import _has_any_global_hook
 
 from . import _hip, _ops
 
@@ -193,7 +192,10 @@ class DenseGCM(torch.nn.Module):
         c[0] += 1
         if self.finite_check == "deferred" and c[0] < self.poll_interval:
             return                        # the common step: nothing to look at
-        c[0] = 0
+        self._poll_due(flags)
+
+    def _poll_due(self, flags):
+        self._ctr[0] = 0
         if torch.cuda.is_current_stream_capturing():
             return                        # inside a HIP-graph capture: the flag word is read later
         if self.finite_check == "sync":
@@ -485,7 +487,7 @@ class DenseGCM(torch.nn.Module):
         nor the incoming node matrix needs a gradient.  A continuing chain does not come through
         here at all: DenseGCM.__call__ hands it to the C++ host path (RowsFast.step) directly."""
         nodes, adj, weights, num_nodes = hidden
-        fast = cfg.rows_fast()
+        fast = cfg.rows_fast(self)
         cont = fast.continues(nodes, adj, weights, num_nodes)
         root = self._packed_params(cfg, head=link is None and not cont)
         if not x.is_contiguous():
@@ -504,7 +506,11 @@ class DenseGCM(torch.nn.Module):
             out = (n2, a2, weights, c2)
         # the next call of this module tries the unchecked entry first (not with the compat flag that
         # writes into the caller's num_nodes: that needs the checked path every step)
-        self._fast = None if self.mutate_num_nodes_on_overflow else (fast, flags)
+        if self.mutate_num_nodes_on_overflow:
+            self._fast = None
+        else:    # (bound C++ entry, flag word, steps between looks at it)
+            every = {"deferred": self.poll_interval, "sync": 1, "off": float("inf")}[self.finite_check]
+            self._fast = (fast.step, flags, every)
         if self.finite_check != "off":
             self._poll(flags)
         return mx, out
@@ -622,18 +628,26 @@ class DenseGCM(torch.nn.Module):
         """`belief, m = gcm(obs, m)`.  A step that continues the chain of the previous call on the
         live-row kernels is ONE call into the C++ host path (RowsFast.step validates exactly that:
         same hidden-state tensors as returned last, same observation shape, parameters untouched, grad
-        mode unchanged); everything else - and any module with hooks - goes through
+        mode unchanged, no module / global hooks registered); everything else goes through
         torch.nn.Module.__call__ and forward() below."""
         fast = self._fast
-        if (fast is not None and len(args) == 2 and not kwargs and not self._forward_hooks
-                and not self._forward_pre_hooks and not self._backward_hooks
-                and not self._backward_pre_hooks and not _has_any_global_hook()):
-            r = fast[0].step(args[0], args[1])
+        if fast is not None and not kwargs and len(args) == 2:
+            r = fast[0](args[0], args[1])
             if r is not None:
-                if self.finite_check != "off":
-                    self._poll(fast[1])
+                c = self._ctr           # gcm.py:316-318, deferred: look at the flag word now and then
+                c[0] += 1
+                if c[0] >= fast[2]:
+                    self._poll_due(fast[1])
                 return r
         return torch.nn.Module.__call__(self, *args, **kwargs)
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle of a module that has already run: the per-shape plans, the packed
+        parameter vector and the C++ host path are runtime caches (rebuilt on the first call)."""
+        d = dict(self.__dict__)
+        d.update(_plan_cache=None, _fold=None, _noise_pool=None, _token=object(), _cfg_cache={}, _cfg_last=None,
+                 _packed_cache=None, _flags={}, _pending=[], _pinned_pool=[], _ctr=[0], _fast=None)
+        return d
 
     def forward(
         self,

@@ -470,3 +470,49 @@ def test_graph_capture_replay_other_step_kinds(kind):
         for a, b_ in zip(grads_g, grads_e):
             torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6 * float(b_.abs().max()) + 1e-9)
     mem_g.check_flags()
+
+
+def test_rows_inplace_on_returned_belief_is_detected():
+    """the belief tensor aliases the head of the record the time-parallel backward reads; a
+    legal in-place op on it must make backward raise (as stock autograd does for a saved tensor), not
+    produce silently wrong parameter gradients."""
+    ref, g, mem, _ = _mk(4, 16, 8, 16, 16, ("temporal", [1, 2], "forward"), False)
+    obs = torch.rand(6, 4, 8, device=DEV)
+    hidden, outs = None, []
+    for t in range(6):
+        mx, hidden = mem(obs[t], hidden)
+        outs.append(mx)
+    assert _rows_taken(mem)
+    with torch.no_grad():
+        outs[3].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        torch.stack(outs).sum().backward()
+
+
+def test_rows_module_with_hooks_and_deepcopy():
+    """Hooks registered on the module (or globally) are honoured: the unchecked C++ entry declines and the
+    call goes through torch.nn.Module.__call__.  A module that has already run can be deep-copied (its
+    runtime caches are rebuilt) and the copy computes the same thing."""
+    import copy
+    ref, g, mem, _ = _mk(3, 16, 8, 16, 16, ("temporal", [1, 2], "forward"), True)
+    obs = torch.rand(8, 3, 8, device=DEV)
+    seen = []
+    hidden = None
+    for t in range(4):
+        mx, hidden = mem(obs[t], hidden)
+    h = mem.register_forward_hook(lambda m, a, out: seen.append(a[0].shape))
+    for t in range(4, 8):
+        mx, hidden = mem(obs[t], hidden)
+    h.remove()
+    assert len(seen) == 4
+    mem2 = copy.deepcopy(mem)
+    assert mem2._fast is None and mem2.rows_steps() == 0
+    outs = []
+    for m in (mem, mem2):
+        hid, o = None, []
+        with torch.no_grad():
+            for t in range(8):
+                mx, hid = m(obs[t], hid)
+                o.append(mx)
+        outs.append(torch.stack(o))
+    assert torch.equal(outs[0], outs[1])

@@ -1,5 +1,6 @@
-"""Host-side timing of the per-step loop on cfg2: eager with functional / donated state (fwd+bwd, forward only
-under no_grad and in grad mode) and the HIP-graph replay.  Dev tool: `T=128 python tools/hosttime.py`."""
+"""Host-side cost of the per-step loop on cfg2: for each mode the time the interpreter needs to ISSUE a T-step
+forward loop (no device sync inside), the time until the device has finished it, and the same for
+loop + backward.  issue ~ done: host-bound; issue << done: GPU-bound.  Dev tool: `T=128 python tools/hosttime.py`."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
@@ -7,74 +8,37 @@ for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
 import torch
 import bench
 
-B, N, F, H, T = 256, 128, 32, 32, int(os.environ.get("T", 128))
+T = int(os.environ.get("T", 128))
 dev = torch.device("cuda", 0)
-
-
-def build(donate):
-    mem, gnn = bench.build_memory(dev)
-    mem.donate_state = donate
-    return mem, gnn
-
-
-def rollout(mem, obs):
-    hidden, outs = None, []
-    for t in range(obs.shape[0]):
-        mx, hidden = mem(obs[t], hidden)
-        outs.append(mx)
-    loss = torch.stack(outs).mean()
-    loss.backward()
-    return loss
-
-
-def timeit(fn, n=10, warm=3):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
-
-
-obs = torch.rand(T, B, F).to(dev)
-for donate in (False, True):
-    mem, gnn = build(donate)
-    dt = timeit(lambda: (rollout(mem, obs), gnn.zero_grad(set_to_none=True)))
-    print(f"eager donate={donate}: {dt*1e3:.3f} ms/rollout  {B*T/dt/1e6:.2f} M states/s")
-    # forward only timing (no_grad)
-    def fwd():
-        with torch.no_grad():
-            h = None
-            for t in range(T):
-                _, h = mem(obs[t], h)
-    dt = timeit(fwd)
-    print(f"   fwd-only no_grad: {dt*1e3:.3f} ms  {B*T/dt/1e6:.2f} M states/s")
-    # fwd with grad, without backward
-    def fwd_g():
-        h, outs = None, []
-        for t in range(T):
-            mx, h = mem(obs[t], h)
-            outs.append(mx)
-        return outs
-    dt = timeit(fwd_g)
-    print(f"   fwd-only grad mode: {dt*1e3:.3f} ms")
-
-# graph replay
-mem, gnn = build(True)
-mem.finite_check = "off"
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3):
-        gnn.zero_grad(set_to_none=True)
-        rollout(mem, obs)
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
-gnn.zero_grad(set_to_none=True)
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    loss = rollout(mem, obs)
-dt = timeit(lambda: g.replay(), n=20)
-print(f"graph replay donated: {dt*1e3:.3f} ms/rollout  {B*T/dt/1e6:.2f} M states/s")
+c = bench.CONFIGS["cfg2"]
+obs = torch.rand(T, c["B"], c["F"], device=dev)
+rows = []
+for donate in (True, False):
+    mem, gnn, _ = bench.build_memory(dev, donate=donate)
+    for grad in (False, True):
+        res = []
+        for it in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.set_grad_enabled(grad):
+                hidden, outs = None, []
+                for t in range(T):
+                    mx, hidden = mem(obs[t], hidden)
+                    outs.append(mx)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            tb0 = tb1 = tb2 = t2
+            if grad:
+                loss = torch.stack(outs).mean()
+                tb0 = time.perf_counter()
+                loss.backward()
+                tb1 = time.perf_counter()
+                torch.cuda.synchronize()
+                tb2 = time.perf_counter()
+                gnn.zero_grad(set_to_none=True)
+            res.append((t1 - t0, t2 - t0, tb0 - t2, tb1 - tb0, tb2 - tb0))
+        res = res[3:]
+        m = [sum(r[i] for r in res) / len(res) for i in range(5)]
+        print(f"donate={donate!s:5} grad={grad!s:5}  fwd issue {m[0] / T * 1e6:6.2f} us/step, done {m[1] / T * 1e6:6.2f} us/step"
+              + (f" | stack+mean {m[2] * 1e6:6.0f} us, backward issue {m[3] * 1e6:6.0f} us, done {m[4] * 1e6:6.0f} us" if grad else ""))

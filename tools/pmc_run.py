@@ -15,9 +15,9 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
-obs = torch.rand(128, bench.B, bench.F).to(dev)
+obs = torch.rand(128, bench.CONFIGS['cfg2']['B'], bench.CONFIGS['cfg2']['F']).to(dev)
 for donate in (True, False):
-    mem, gnn = bench.build_memory(dev, donate=donate)
+    mem, gnn, _ = bench.build_memory(dev, donate=donate)
     for _ in range(2):
         bench.rollout(mem, obs)
         gnn.zero_grad(set_to_none=True)
