@@ -28,11 +28,17 @@ namespace {
 // overflow roll (count + 1 > N) image row j is stored row j + 1.  Same arithmetic either way: the
 // second form lets the live-row step (rows_step.hip) run the distance selectors ahead of its own
 // state advance, with the decisions handed over as a row [B, N] instead of adjacency writes.
+//
+// cur_rows != nullptr: the "current nodes" the distances are taken against come from outside - n_cur rows
+// [n_cur, F], the all-gathered current nodes of EVERY rank of a batch-sharded run (EuclideanEdge's
+// mean runs over all graphs b' of the GLOBAL batch, distance.py:48-49) - instead of the B local ones.
 struct View {
   const float* nodes;
   const int64_t* cur_idx;
   const int64_t* count;
   const float* obs;
+  const float* cur_rows;
+  int n_cur;
 };
 __device__ __forceinline__ int view_cur(const View& v, int b, int N, int& sh) {
   sh = 0;
@@ -62,13 +68,18 @@ __device__ __forceinline__ void view_emit(float* adj, float* sel_row, int b, int
 
 // gather cur rows (scaled) into workspace: ws_cur [B, F]
 __global__ void k_gather_cur(View vw, const float* __restrict__ dist_param,
-                             float* __restrict__ ws_cur, int B, int N, int F) {
+                             float* __restrict__ ws_cur, int Bc, int N, int F) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * F) return;
+  if (i >= Bc * F) return;
   const int b = i / F, f = i - b * F;
-  int sh;
-  const int c = view_cur(vw, b, N, sh);
-  const float v = view_cur_row(vw, b, c, N, F)[f];
+  float v;
+  if (vw.cur_rows) {
+    v = vw.cur_rows[i];
+  } else {
+    int sh;
+    const int c = view_cur(vw, b, N, sh);
+    v = view_cur_row(vw, b, c, N, F)[f];
+  }
   ws_cur[i] = dist_param ? v / dist_param[0] : v;
 }
 
@@ -79,7 +90,7 @@ template <int FP>
 __global__ __launch_bounds__(128) void k_euclid_crossbatch(
     View vw, const float* __restrict__ ws_cur, const float* __restrict__ dist_param,
     float* __restrict__ adj, float* __restrict__ sel_row, float* __restrict__ dist_out,
-    float max_distance, int bidirectional, int B, int N, int F) {
+    float max_distance, int bidirectional, int Bc, int N, int F) {
   const float* __restrict__ nodes = vw.nodes;
   constexpr int CH = 32;  // cur rows per LDS chunk
   __shared__ __attribute__((aligned(16))) float sC[CH * FP];
@@ -100,14 +111,14 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
     n[f] = dist_param ? v / dist_param[0] : v;
   }
   float total = 0.f;
-  for (int c0 = 0; c0 < B; c0 += CH) {
+  for (int c0 = 0; c0 < Bc; c0 += CH) {   // Bc current rows: the local batch, or every rank's (sharded)
     __syncthreads();
     for (int e = threadIdx.x; e < CH * FP; e += 128) {
       const int r = e / FP, f = e - r * FP;
-      sC[e] = (c0 + r < B && f < F) ? ws_cur[(size_t)(c0 + r) * F + f] : 0.f;
+      sC[e] = (c0 + r < Bc && f < F) ? ws_cur[(size_t)(c0 + r) * F + f] : 0.f;
     }
     __syncthreads();
-    const int rows = min(CH, B - c0);
+    const int rows = min(CH, Bc - c0);
     for (int r = 0; r < rows; ++r) {
       const f32x4* cp = reinterpret_cast<const f32x4*>(sC + r * FP);
       float s = 0.f;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(128) void k_euclid_crossbatch(
     }
   }
   if (!live) return;
-  const float d = total / (float)B;
+  const float d = total / (float)Bc;
   if (dist_out) dist_out[(size_t)b * N + j] = d;
   if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
 }
@@ -146,7 +157,7 @@ template <int FT, int RB, int CB>   // F padded to 32 FT; RB node rows per workg
 __global__ __launch_bounds__(512) void k_euclid_mfma(
     View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
     float* __restrict__ sel_row, float* __restrict__ dist_out, float max_distance, int bidirectional,
-    int B, int N, int F) {
+    int Bc, int N, int F) {
   const float* __restrict__ nodes = vw.nodes;
   constexpr int FP = 32 * FT, NS = FP + 1, CS = CB + 1;
   constexpr int RWN = RB / 32;              // 32-row blocks of the workgroup
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
 #pragma unroll
   for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
 
-  for (int c0 = 0; c0 < B; c0 += CB) {
+  for (int c0 = 0; c0 < Bc; c0 += CB) {   // Bc current rows: the local batch, or every rank's (sharded)
     __syncthreads();
     {   // current rows of this chunk of graphs -> [F][CS]; a batch of loads in flight before its stores
       constexpr int PER = FP * CB / 512, STEP = PER <= 16 ? PER : (PER % 16 == 0 ? 16 : 8);
@@ -210,18 +221,19 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
 #pragma unroll 1
       for (int i0 = 0; i0 < PER; i0 += STEP) {
         float v[STEP];
-        if (vw.count) {   // (uniform) the current nodes are the observations: no index to chase
+        if (vw.count || vw.cur_rows) {   // (uniform) the current nodes are the observations / the gathered rows
+          const float* rows = vw.cur_rows ? vw.cur_rows : vw.obs;
 #pragma unroll
           for (int i = 0; i < STEP; ++i) {
             const int e = tid + 512 * (i0 + i), c = e / FP, f = e % FP;
-            const int g = c0 + c < B ? c0 + c : B - 1;
-            v[i] = vw.obs[(size_t)g * F + (f < F ? f : F - 1)];
+            const int g = c0 + c < Bc ? c0 + c : Bc - 1;
+            v[i] = rows[(size_t)g * F + (f < F ? f : F - 1)];
           }
         } else {
 #pragma unroll
           for (int i = 0; i < STEP; ++i) {
             const int e = tid + 512 * (i0 + i), c = e / FP, f = e % FP;
-            const int g = c0 + c < B ? c0 + c : B - 1;
+            const int g = c0 + c < Bc ? c0 + c : Bc - 1;
             int64_t cg = vw.cur_idx[g];
             cg = cg < 0 ? 0 : (cg > N - 1 ? N - 1 : cg);
             v[i] = nodes[((size_t)g * N + cg) * F + (f < F ? f : F - 1)];
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
         for (int i = 0; i < STEP; ++i) {
           const int e = tid + 512 * (i0 + i), c = e / FP, f = e % FP;
           const float t = dist_param ? v[i] / inv_scale_den : v[i];
-          sC[f * CS + c] = (f < F && c0 + c < B) ? t : 0.f;
+          sC[f * CS + c] = (f < F && c0 + c < Bc) ? t : 0.f;
         }
       }
     }
@@ -249,12 +261,12 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
       float nn[16];   // |n|^2 of this lane's 16 accumulator rows
 #pragma unroll
       for (int r = 0; r < 16; ++r) nn[r] = sNn[r_base + (r & 3) + 8 * (r >> 2) + 4 * lh];
-      const int n_t = min(HT, (B - c0 - ch * HT * 32 + 31) / 32);   // column tiles of this wave in this chunk
+      const int n_t = min(HT, (Bc - c0 - ch * HT * 32 + 31) / 32);   // column tiles of this wave in this chunk
       auto finish = [&](const f32x16& acc, int t) {
         const int ct = ch * HT + t;
         const int col = c0 + ct * 32 + li;
         const float cn = sCn[ct * 32 + li];
-        const float keep = col < B ? 1.f : 0.f;
+        const float keep = col < Bc ? 1.f : 0.f;
         // v_sqrt_f32 (1 ulp) instead of the correctly rounded library routine (a dozen instructions):
         // the epilogue is otherwise as long as the MFMA chain
 #pragma unroll
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
       float tot = rowsum[r];
 #pragma unroll
       for (int g = 0; g < CG - 1; ++g) tot += sPart[g * RB + rl];
-      const float d = tot / (float)B;
+      const float d = tot / (float)Bc;
       if (dist_out) dist_out[(size_t)b * N + j] = d;
       if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
     }
@@ -395,7 +407,7 @@ __global__ void k_pergraph(View vw, const float* __restrict__ dist_param, float*
 }  // namespace
 
 extern "C" size_t gcm_edge_distance_workspace_bytes(int mode, int B, int N, int F) {
-  (void)N;
+  (void)N;   // B: the number of current rows (the local batch, or n_cur_rows of a sharded selector)
   if (mode != GCM_DIST_EUCLID_CROSSBATCH || B <= 0 || F <= 0) return 0;
   return ((size_t)B * F + B) * sizeof(float);
 }
@@ -405,9 +417,12 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
                         float* dist_out, void* workspace, size_t workspace_bytes, int B, int N, int F,
                         gcm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (vw.cur_rows && mode != GCM_DIST_EUCLID_CROSSBATCH) return GCM_EINVAL;   // only the cross-batch mean couples graphs
   if (mode == GCM_DIST_EUCLID_CROSSBATCH) {
     if (F > 128 || B > 65535) return GCM_EUNSUPPORTED;
-    if (B >= 32) {   // matrix-core path (torch.cdist's own switch to the mm formulation is at 25)
+    const int Bc = vw.cur_rows ? vw.n_cur : B;   // rows the mean runs over
+    if (Bc <= 0) return GCM_EINVAL;
+    if (Bc >= 32) {   // matrix-core path (torch.cdist's own switch to the mm formulation is at 25)
       // 128 node rows x 256-graph chunks per workgroup (one workgroup per CU at cfg3: B = 256 graphs of
       // 128 nodes).  Measured against 64 rows x 128-graph chunks (two to three workgroups per CU, one's
       // staging under another's MFMA phase): 21.3 us vs 23.7 us - the extra staging traffic and the
@@ -423,7 +438,7 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
     auto kern = k_euclid_mfma<FTv, RB, (FTv >= 4 ? 128 : 256)>;                                  \
     gcm_allow_dynamic_lds((const void*)kern, lds);                                               \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, vw, dist_param, adj, sel_row, dist_out,    \
-                       max_distance, bidirectional, B, N, F);                                    \
+                       max_distance, bidirectional, Bc, N, F);                                   \
   }
       switch (FT) {
         case 1: GCM_EUCLID_MFMA(1) break;
@@ -435,14 +450,14 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
       return gcm_launch_status();
     }
     GCM_REQUIRE(workspace);
-    if (workspace_bytes < ((size_t)B * F + B) * sizeof(float)) return GCM_EWORKSPACE;
+    if (workspace_bytes < ((size_t)Bc * F + Bc) * sizeof(float)) return GCM_EWORKSPACE;
     float* ws_cur = (float*)workspace;
-    hipLaunchKernelGGL(k_gather_cur, dim3((B * F + 255) / 256), dim3(256), 0, s, vw, dist_param, ws_cur,
-                       B, N, F);
+    hipLaunchKernelGGL(k_gather_cur, dim3((Bc * F + 255) / 256), dim3(256), 0, s, vw, dist_param, ws_cur,
+                       Bc, N, F);
     dim3 grid((N + 127) / 128, B);
 #define GCM_EUCLID(FP)                                                                        \
   hipLaunchKernelGGL(k_euclid_crossbatch<FP>, grid, dim3(128), 0, s, vw, ws_cur, dist_param, adj, \
-                     sel_row, dist_out, max_distance, bidirectional, B, N, F)
+                     sel_row, dist_out, max_distance, bidirectional, Bc, N, F)
     if (F <= 16) GCM_EUCLID(16);
     else if (F <= 32) GCM_EUCLID(32);
     else if (F <= 64) GCM_EUCLID(64);
@@ -466,8 +481,17 @@ extern "C" int gcm_edge_distance(const float* nodes, float* adj, const int64_t* 
                                  int b0, int b1, int bidirectional, float* dist_out,
                                  void* workspace, size_t workspace_bytes, int B, int N, int F,
                                  gcm_stream_t stream) {
-  GCM_REQUIRE(nodes && adj && cur_idx && B > 0 && N > 0 && F > 0);
-  const View vw{nodes, cur_idx, nullptr, nullptr};
+  return gcm_edge_distance_ex(nodes, adj, cur_idx, mode, max_distance, dist_param, a0, a1, b0, b1,
+                              bidirectional, dist_out, nullptr, 0, workspace, workspace_bytes, B, N, F, stream);
+}
+
+extern "C" int gcm_edge_distance_ex(const float* nodes, float* adj, const int64_t* cur_idx, int mode,
+                                    float max_distance, const float* dist_param, int a0, int a1,
+                                    int b0, int b1, int bidirectional, float* dist_out,
+                                    const float* cur_rows, int n_cur_rows, void* workspace,
+                                    size_t workspace_bytes, int B, int N, int F, gcm_stream_t stream) {
+  GCM_REQUIRE(nodes && adj && cur_idx && B > 0 && N > 0 && F > 0 && (!cur_rows || n_cur_rows > 0));
+  const View vw{nodes, cur_idx, nullptr, nullptr, cur_rows, n_cur_rows};
   return run_distance(vw, adj, nullptr, mode, max_distance, dist_param, a0, a1, b0, b1, bidirectional,
                       dist_out, workspace, workspace_bytes, B, N, F, stream);
 }
@@ -481,8 +505,17 @@ extern "C" int gcm_edge_distance_pre(const float* nodes_in, const int64_t* count
                                      const float* dist_param, int a0, int a1, int b0, int b1,
                                      void* workspace, size_t workspace_bytes, int B, int N, int F,
                                      gcm_stream_t stream) {
-  GCM_REQUIRE(nodes_in && count_in && obs && sel_row && B > 0 && N > 0 && F > 0);
-  const View vw{nodes_in, nullptr, count_in, obs};
+  return gcm_edge_distance_pre_ex(nodes_in, count_in, obs, sel_row, mode, max_distance, dist_param, a0, a1, b0,
+                                  b1, nullptr, 0, workspace, workspace_bytes, B, N, F, stream);
+}
+
+extern "C" int gcm_edge_distance_pre_ex(const float* nodes_in, const int64_t* count_in, const float* obs,
+                                        float* sel_row, int mode, float max_distance,
+                                        const float* dist_param, int a0, int a1, int b0, int b1,
+                                        const float* cur_rows, int n_cur_rows, void* workspace,
+                                        size_t workspace_bytes, int B, int N, int F, gcm_stream_t stream) {
+  GCM_REQUIRE(nodes_in && count_in && obs && sel_row && B > 0 && N > 0 && F > 0 && (!cur_rows || n_cur_rows > 0));
+  const View vw{nodes_in, nullptr, count_in, obs, cur_rows, n_cur_rows};
   return run_distance(vw, nullptr, sel_row, mode, max_distance, dist_param, a0, a1, b0, b1, 0, nullptr,
                       workspace, workspace_bytes, B, N, F, stream);
 }

@@ -32,9 +32,9 @@ int run_selectors(const gcm_selector_desc* selectors, int n_selectors, const flo
     else if (d.kind == GCM_SEL_DENSE)
       rc = gcm_edge_dense(adj_out, cur, B, N, stream);
     else if (d.kind == GCM_SEL_DISTANCE)
-      rc = gcm_edge_distance(nodes_out, adj_out, cur, d.mode, d.max_distance, d.dist_param, d.a0,
-                             d.a1, d.b0, d.b1, d.bidirectional, nullptr, workspace,
-                             workspace_bytes, B, N, F, stream);
+      rc = gcm_edge_distance_ex(nodes_out, adj_out, cur, d.mode, d.max_distance, d.dist_param, d.a0,
+                                d.a1, d.b0, d.b1, d.bidirectional, nullptr, d.cur_rows, d.n_cur_rows,
+                                workspace, workspace_bytes, B, N, F, stream);
     else
       rc = GCM_EINVAL;
     if (rc) return rc;

@@ -24,6 +24,8 @@
 // One workgroup (4 waves) per graph.  N <= 128, N % 4 == 0, F % 4 == 0, F, H1, H2 <= 64.
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+
 #include "fused_common.h"
 #include "rows_common.h"
 #include "state_copy.h"
@@ -763,7 +765,8 @@ extern "C" size_t gcm_dense_rows_step_workspace_bytes(const gcm_selector_desc* s
   size_t need = 0;
   for (int i = 0; selectors && i < n_selectors; ++i)
     if (selectors[i].kind == GCM_SEL_DISTANCE)
-      need = sizeof(float) * (size_t)B * N + gcm_edge_distance_workspace_bytes(selectors[i].mode, B, N, F);
+      need = sizeof(float) * (size_t)B * N +
+             gcm_edge_distance_workspace_bytes(selectors[i].mode, std::max(B, selectors[i].n_cur_rows), N, F);
   return need;
 }
 
@@ -803,10 +806,10 @@ extern "C" int gcm_dense_rows_step_fwd_ws(const float* obs, const float* nodes_i
       if (workspace_bytes < gcm_dense_rows_step_workspace_bytes(selectors, n_selectors, B, N, F))
         return GCM_EWORKSPACE;
       float* row = (float*)workspace;
-      const int rc = gcm_edge_distance_pre(nodes_in, count_in, obs, row, d.mode, d.max_distance,
-                                           d.dist_param, d.a0, d.a1, d.b0, d.b1, row + (size_t)B * N,
-                                           workspace_bytes - sizeof(float) * (size_t)B * N, B, N, F,
-                                           stream);
+      const int rc = gcm_edge_distance_pre_ex(nodes_in, count_in, obs, row, d.mode, d.max_distance,
+                                              d.dist_param, d.a0, d.a1, d.b0, d.b1, d.cur_rows, d.n_cur_rows,
+                                              row + (size_t)B * N,
+                                              workspace_bytes - sizeof(float) * (size_t)B * N, B, N, F, stream);
       if (rc) return rc;
       sel_row = row;
       continue;

@@ -64,7 +64,7 @@ struct StepCfg {
     size_t need = 0;
     for (const auto& d : descs)
       if (d.kind == GCM_SEL_DISTANCE)
-        need = std::max(need, gcm_edge_distance_workspace_bytes(d.mode, B, N, F));
+        need = std::max(need, gcm_edge_distance_workspace_bytes(d.mode, std::max(B, d.n_cur_rows), N, F));
     // (the live-row step also keeps the selector's decision row there)
     need = std::max(need, gcm_dense_rows_step_workspace_bytes(descs.data(), (int)descs.size(), B, N, F));
     if (need > ws_bytes) {

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "gcm_edge_dense": (_I, [_P, _P, _I, _I, _P]),
     "gcm_edge_distance_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "gcm_edge_distance": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _I, _I, _I, _P]),
+    "gcm_edge_distance_ex": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
     "gcm_dense_graphconv_fwd": (_I, [_P] * 7 + [_I] * 5 + [_P]),
     "gcm_dense_graphconv_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "gcm_dense_graphconv_bwd": (_I, [_P] * 13 + [_Z] + [_I] * 5 + [_P]),
@@ -91,6 +92,7 @@ PROTOTYPES = {
     "gcm_dense_rows_step_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
     "gcm_dense_rows_step_fwd_ws": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_P, _Z] + [_I] * 5 + [_P]),
     "gcm_edge_distance_pre": (_I, [_P] * 4 + [_I, _F, _P] + [_I] * 4 + [_P, _Z] + [_I] * 3 + [_P]),
+    "gcm_edge_distance_pre_ex": (_I, [_P] * 4 + [_I, _F, _P] + [_I] * 4 + [_P, _I, _P, _Z] + [_I] * 3 + [_P]),
     "gcm_debug_time_next_launch": (_I, [_P, _P]),
     "gcm_debug_time_rows_rollout": (_I, [_P] * 5 + [_I, _P, _I, _I, _I] + [_P] * 4 + [_I] * 6 + [_P]),
     "gcm_learned_step_supported": (_I, [_I] * 4),
@@ -123,7 +125,7 @@ class SelectorDesc(ctypes.Structure):
     """struct gcm_selector_desc (include/gcm_hip.h)."""
     _fields_ = [("kind", _I), ("n_hops", _I), ("hops", ctypes.c_int32 * 16), ("direction", _I),
                 ("mode", _I), ("max_distance", _F), ("dist_param", _P), ("a0", _I), ("a1", _I),
-                ("b0", _I), ("b1", _I), ("bidirectional", _I)]
+                ("b0", _I), ("b1", _I), ("bidirectional", _I), ("cur_rows", _P), ("n_cur_rows", _I)]
 
 
 SEL_TEMPORAL, SEL_DENSE, SEL_DISTANCE = 1, 2, 3

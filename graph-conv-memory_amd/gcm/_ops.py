@@ -230,18 +230,21 @@ def edge_dense_(adj, cur):
 
 
 def edge_distance_(nodes, adj, cur, mode, max_distance, dist_param=None, a=(0, 0), b=(0, 0),
-                   bidirectional=False, want_dist=False):
+                   bidirectional=False, want_dist=False, cur_rows=None):
+    """cur_rows [n, F]: the current nodes of every rank (all-gathered) when a batch-sharded
+    EuclideanEdge takes its mean over the global batch; None: the local graphs' own."""
     nodes = nodes.contiguous()
-    _hip.on_device(nodes, adj, cur, dist_param)
+    _hip.on_device(nodes, adj, cur, dist_param, cur_rows)
     B, N, F = nodes.shape
     lib = _hip.lib()
-    ws_bytes = lib.gcm_edge_distance_workspace_bytes(mode, B, N, F)
+    n_cur = 0 if cur_rows is None else cur_rows.shape[0]
+    ws_bytes = lib.gcm_edge_distance_workspace_bytes(mode, max(B, n_cur), N, F)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=nodes.device)
     dist = torch.empty(B, N, device=nodes.device, dtype=_f32) if want_dist else None
-    rc = lib.gcm_edge_distance(_hip.ptr(nodes), _hip.ptr(adj), _hip.ptr(cur), mode,
-                               float(max_distance), _hip.ptr(dist_param), a[0], a[1], b[0], b[1],
-                               int(bidirectional), _hip.ptr(dist), _hip.ptr(ws), ws_bytes, B, N, F,
-                               _hip.stream())
+    rc = lib.gcm_edge_distance_ex(_hip.ptr(nodes), _hip.ptr(adj), _hip.ptr(cur), mode,
+                                  float(max_distance), _hip.ptr(dist_param), a[0], a[1], b[0], b[1],
+                                  int(bidirectional), _hip.ptr(dist), _hip.ptr(cur_rows), n_cur, _hip.ptr(ws),
+                                  ws_bytes, B, N, F, _hip.stream())
     _hip.check(rc, "gcm_edge_distance")
     return adj, dist
 
@@ -650,6 +653,9 @@ class StepConfig:
     # (Linear preprocessor | None, PositionalEncoding in "add" mode | None) folded into the live-row
     # step, or None (gcm.py:_fold_config)
     fold = None
+    # Distance selectors of a batch-sharded run (EuclideanEdge(shard_group=...)): their current rows are
+    # all-gathered ahead of every step (DenseGCM._gather_sharded)
+    sharded = ()
 
     # -- DenseGCM + LearnedEdge (csrc/learned_step.hip) ----------------------------------------
     learned_sel = None          # the LearnedEdge module when this config is the fused learned step
@@ -742,12 +748,15 @@ class StepConfig:
 
     def refresh_pointers(self):
         """re-read the device pointers baked into the selector descriptors (a re-assigned
-        Distance.dist_param) into this config and its C++ twin"""
+        Distance.dist_param, the gathered current rows of a sharded EuclideanEdge) into this config and
+        its C++ twin"""
         for i, (d, src) in enumerate(zip(self.descs, getattr(self, "desc_sources", ()))):
             if d.kind == _hip.SEL_DISTANCE and src is not None:
-                p = src()
+                p, rows, n_rows = src()
                 d.dist_param = p
                 self.arr[i].dist_param = p
+                d.cur_rows, d.n_cur_rows = rows, n_rows
+                self.arr[i].cur_rows, self.arr[i].n_cur_rows = rows, n_rows
         if self._cpp is not None:
             self._cpp.update_descs(self.arr_ptr, self.n_desc)
 
@@ -757,7 +766,8 @@ class StepConfig:
         need = 0
         for d in self.descs:
             if d.kind == _hip.SEL_DISTANCE:
-                need = max(need, _hip.lib().gcm_edge_distance_workspace_bytes(d.mode, B, self.N, self.F))
+                need = max(need, _hip.lib().gcm_edge_distance_workspace_bytes(d.mode, max(B, d.n_cur_rows),
+                                                                               self.N, self.F))
         if need > self.ws_bytes:
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self.ws_bytes = need

@@ -357,9 +357,8 @@ class DenseGCM(torch.nn.Module):
                            (2 if convs[1].lin_rel.bias is not None else 0)
                 cfg = _ops.StepConfig(descs, acts, has_bias, N, F, H1, H2, nodes.device)
                 cfg.convs = convs
-                cfg.desc_sources = [
-                    (lambda m=m: m.dist_param.data_ptr() if m.learned else None)
-                    if isinstance(m, Distance) else None for m in mods]
+                cfg.desc_sources = [m.pointer_source if isinstance(m, Distance) else None for m in mods]
+                cfg.sharded = [m for m in mods if isinstance(m, Distance) and m.shard_group is not None]
                 cfg.lins = (convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel, convs[1].lin_root)
         self._cfg_cache[key] = cfg
         if cfg is not False:
@@ -480,6 +479,14 @@ class DenseGCM(torch.nn.Module):
             parts.append(pe.pe[: cfg.N, : cfg.F].reshape(-1))
         return parts
 
+    @staticmethod
+    def _gather_sharded(cfg, x):
+        """EuclideanEdge(shard_group=...): every rank's current nodes (= the observations going in) into
+        the selector's persistent buffer, ahead of the kernels that read it (SURVEY 8e "Exception")."""
+        for m in cfg.sharded:
+            if m.gather_current(x):
+                cfg.refresh_pointers()
+
     def _forward_rows(self, x, hidden, cfg, flags, link):
         """The live-row step (csrc/rows_step.hip), checked entry: one kernel forward, no kernel and no
         autograd node per step backward (every step of a chain hangs its belief tensor on one node,
@@ -506,7 +513,7 @@ class DenseGCM(torch.nn.Module):
             out = (n2, a2, weights, c2)
         # the next call of this module tries the unchecked entry first (not with the compat flag that
         # writes into the caller's num_nodes: that needs the checked path every step)
-        if self.mutate_num_nodes_on_overflow:
+        if self.mutate_num_nodes_on_overflow or cfg.sharded:   # (a collective ahead of every step)
             self._fast = None
         else:    # (bound C++ entry, flag word, steps between looks at it)
             every = {"deferred": self.poll_interval, "sync": 1, "off": float("inf")}[self.finite_check]
@@ -673,6 +680,8 @@ class DenseGCM(torch.nn.Module):
                 and link[8] is num_nodes and x.shape == link[6] and x.dtype is torch.float32):
             cfg = link[2]
             no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
+            if cfg.sharded:
+                self._gather_sharded(cfg, x)
             if cfg.rows_ok and no_dx:
                 return self._forward_rows(x, hidden, cfg, link[3], link)
             if cfg.learned_sel is None and cfg.fold is None:
@@ -701,6 +710,8 @@ class DenseGCM(torch.nn.Module):
             assert (nodes.shape[0], adj.shape[0], num_nodes.shape[0], nodes.shape[2]) == \
                 (B, B, B, x.shape[1]), "hidden state and observation shapes disagree"
             no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
+            if plan.sharded:
+                self._gather_sharded(plan, x)
             if plan.rows_ok and no_dx:
                 return self._forward_rows(x, hidden, plan, flags, None)
             if plan.learned_sel is None and plan.fold is None:

@@ -41,18 +41,39 @@ def shard_bounds(total, rank, world):
 class GradBucket:
     """All parameter gradients of one or more modules as ONE flat fp32 buffer, so that a
     backward pass costs exactly one collective.  At F=H=32 the bucket is ~30 KB: the
-    all-reduce is latency bound, link bandwidth is irrelevant."""
+    all-reduce is latency bound, link bandwidth is irrelevant.
 
-    def __init__(self, *modules):
+    alias_grads=True: after the first call every `p.grad` IS its slice of the flat buffer (a view; the
+    bucket keeps no reference of its own, so autograd accumulates into it in place): later backward
+    passes write straight into the bucket and all_reduce_mean is the collective alone.  Needs
+    `zero()` / `zero_grad(set_to_none=False)` between steps (set_to_none=True drops the views - still
+    correct, the gather then runs again) and must stay off when the backward pass is replayed from a
+    HIP graph (the graph writes the gradient tensors it was captured with)."""
+
+    def __init__(self, *modules, alias_grads=False):
         self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
+        self.alias_grads = alias_grads
         self.flat = None
+        self.launches = 0      # device launches of the last all_reduce_mean besides the collective (tests)
+
+    def _view(self, i):
+        off, p = self.offsets[i], self.params[i]
+        return self.flat[off:off + p.numel()].view_as(p)
+
+    def zero(self):
+        """zero the bucket (and with it every aliased gradient) in one launch"""
+        if self.flat is not None:
+            self.flat.zero_()
 
     def all_reduce_mean(self, local_weight=1.0):
         """grad <- sum_r local_weight_r * grad_r  (pass local_weight = B_local / B_global to
         get the gradient of the global-batch mean loss from per-rank local-mean losses).
-        Four launches per call: gather into the flat buffer, the weight, the collective, one
-        multi-tensor copy back; nothing at all in a one-rank job with weight 1."""
+        Launches per call: one multi-tensor gather into the flat buffer (none when the gradients
+        alias it), the weight (folded into the collective as an average on RCCL when the shards are
+        equal), the collective, one multi-tensor copy back (none with alias_grads); nothing at all in
+        a one-rank job with weight 1."""
+        self.launches = 0
         if not self.params:
             return
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -61,17 +82,30 @@ class GradBucket:
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(self.numel, device=dev)
-            self.views, off = [], 0
+            self.offsets, off = [], 0
             for p in self.params:
-                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                self.offsets.append(off)
                 off += p.numel()
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
-        if local_weight != 1.0:
+        base = self.flat.data_ptr()
+        aliased = all(p.grad is not None and p.grad.is_contiguous() and p.grad.data_ptr() == base + 4 * o
+                      for p, o in zip(self.params, self.offsets))
+        if not aliased:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+            torch._foreach_copy_([self._view(i) for i in range(len(self.params))], grads)
+            self.launches += 1
+        avg = (world > 1 and abs(local_weight * world - 1.0) < 1e-12 and dist.get_backend() == "nccl")
+        if local_weight != 1.0 and not avg:
             self.flat.mul_(local_weight)
+            self.launches += 1
         if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+        if self.alias_grads:
+            if not aliased:
+                for i, p in enumerate(self.params):
+                    p.grad = self._view(i)
+            return
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-        torch._foreach_copy_([p.grad for p in self.params], self.views)
+        torch._foreach_copy_([p.grad for p in self.params], [self._view(i) for i in range(len(self.params))])
+        self.launches += 1

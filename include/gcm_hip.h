@@ -106,6 +106,16 @@ int gcm_edge_distance(const float* nodes, float* adj, const int64_t* cur_idx, in
                       float max_distance, const float* dist_param, int a0, int a1, int b0, int b1,
                       int bidirectional, float* dist_out, void* workspace, size_t workspace_bytes,
                       int B, int N, int F, gcm_stream_t stream);
+/* The same with the "current nodes" of GCM_DIST_EUCLID_CROSSBATCH supplied by the caller: cur_rows
+ * [n_cur_rows, F] = the current nodes of every rank of a batch-sharded run, all-gathered (SURVEY 8e:
+ * EuclideanEdge's mean couples all graphs of the GLOBAL batch, distance.py:48-49).  NULL / 0 = the
+ * local graphs' own current nodes (gcm_edge_distance).  Workspace: gcm_edge_distance_workspace_bytes
+ * with B = max(B, n_cur_rows). */
+int gcm_edge_distance_ex(const float* nodes, float* adj, const int64_t* cur_idx, int mode,
+                         float max_distance, const float* dist_param, int a0, int a1, int b0, int b1,
+                         int bidirectional, float* dist_out, const float* cur_rows, int n_cur_rows,
+                         void* workspace, size_t workspace_bytes, int B, int N, int F,
+                         gcm_stream_t stream);
 
 /* ---- DenseGraphConv (PyG; call sites README.md:56-62) ---------------------- */
 
@@ -323,6 +333,11 @@ typedef struct gcm_selector_desc {
   const float* dist_param;/* distance: device pointer or NULL                        */
   int a0, a1, b0, b1;     /* distance: pose slices                                   */
   int bidirectional;      /* distance                                                */
+  /* distance, GCM_DIST_EUCLID_CROSSBATCH in a batch-sharded run: the current nodes of EVERY rank,
+   * all-gathered by the caller [n_cur_rows, F] (device pointer), so that the mean of distance.py:48-49
+   * runs over the global batch; NULL / 0: the local batch's own current nodes                */
+  const float* cur_rows;
+  int n_cur_rows;
 } gcm_selector_desc;
 
 /* ---- one DenseGCM step per call (the per-step drop-in API, gcm.py:213-321) ------------ */
@@ -459,6 +474,11 @@ int gcm_edge_distance_pre(const float* nodes_in, const int64_t* count_in, const 
                           float* sel_row, int mode, float max_distance, const float* dist_param,
                           int a0, int a1, int b0, int b1, void* workspace, size_t workspace_bytes,
                           int B, int N, int F, gcm_stream_t stream);
+int gcm_edge_distance_pre_ex(const float* nodes_in, const int64_t* count_in, const float* obs,
+                             float* sel_row, int mode, float max_distance, const float* dist_param,
+                             int a0, int a1, int b0, int b1, const float* cur_rows, int n_cur_rows,
+                             void* workspace, size_t workspace_bytes, int B, int N, int F,
+                             gcm_stream_t stream);
 
 /* Measurement aid (bench.py): the NEXT gcm_dense_rows_step_fwd launch of the calling thread is
  * bracketed by the two hipEvent_t given here, recorded by the dispatch itself

@@ -22,13 +22,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(selector, world, path):
+def _launch(selector, world, path, mode=""):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GCM_SINGLE_DEVICE="1", GCM_DIST_BACKEND="gloo")
-        procs.append(subprocess.Popen([sys.executable, WORKER, selector, path], env=env))
+        procs.append(subprocess.Popen([sys.executable, WORKER, selector, path, mode], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
     return [torch.load(f"{path}.{r}") for r in range(world)]
@@ -44,6 +44,17 @@ def test_sharded_product_rollout_equals_global_batch(tmp_path):
             torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6 * float(w.abs().max()))
 
 
+def test_bucket_aliased_gradients(tmp_path):
+    """GradBucket(alias_grads=True): after the first call the parameters' .grad tensors are slices of
+    the flat bucket, the next backward accumulates into it in place and all_reduce_mean is the
+    collective (+ the weight) alone; same gradients as the copying form."""
+    got = _launch("temporal", 2, str(tmp_path / "al"), "alias")
+    ref = _launch("temporal", 2, str(tmp_path / "cp"))
+    for r in range(2):
+        for g, w in zip(got[r]["grads"], ref[r]["grads"]):
+            torch.testing.assert_close(g, w, rtol=1e-6, atol=1e-8)
+
+
 def test_bucket_covers_selector_parameters(tmp_path):
     """cfg5's shape of job: LearnedEdge's edge network is part of the all-reduced bucket and both
     ranks end with identical gradients (the sampled edges differ per rank: no comparison with a
@@ -54,6 +65,36 @@ def test_bucket_covers_selector_parameters(tmp_path):
         assert torch.equal(a, b)
         assert torch.isfinite(a).all()
     assert any(float(g.abs().max()) > 0 for g in got[0]["grads"][6:])
+
+
+@pytest.mark.parametrize("mode", ["", "obs_grad", "big"])
+def test_sharded_euclidean_edge_equals_global_batch(tmp_path, mode):
+    """SURVEY 8e "Exception": EuclideanEdge's mean runs over every graph of the batch (distance.py:48-49).
+    EuclideanEdge(shard_group=...) all-gathers the ranks' current nodes ahead of the distance kernel:
+    two ranks with 4 graphs each == one process with the 8 graphs (edge decisions bit exact, beliefs,
+    gradients) - on the live-row path and (obs with gradient) on the fused one."""
+    got = _launch("euclid", 2, str(tmp_path / "eu"), mode)
+    one = _launch("euclid", 1, str(tmp_path / "one"), mode)[0]
+    assert float(one["adj"].sum()) > one["adj"].shape[0] * 4     # the selector did connect nodes
+    assert torch.equal(torch.cat([g["adj"] for g in got], dim=0), one["adj"])
+    torch.testing.assert_close(torch.cat([g["out"] for g in got], dim=1), one["out"], rtol=1e-6, atol=1e-7)
+    for r in range(2):
+        for g, w in zip(got[r]["grads"], one["grads"]):
+            torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6 * float(w.abs().max()))
+
+
+def test_bench_cfg5_two_ranks():
+    """bench.py --config cfg5 --gpus 2 (LearnedEdge, GradBucket over GNN + edge network, per-rank device
+    RNG seeds) through the launcherless spawn, two ranks sharing one GPU over gloo."""
+    env = dict(os.environ, GCM_SINGLE_DEVICE="1", GCM_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg5", "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--T", "12", "--repeats", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "cfg5" in line["config"]["workload"]
+    assert line["roofline"]["frac"] > 0 and line["value_spread"]["blocks"] == 2
 
 
 def test_bench_spawns_its_own_ranks():
