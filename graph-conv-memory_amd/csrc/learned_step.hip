@@ -27,6 +27,7 @@
 //
 // Shapes: N <= 128, F <= 32, H1 <= 32, H2 <= 32 (BASELINE cfg5: 128 / 32 / 32 / 32).
 #include "fused_common.h"
+#include "rows_common.h"
 #include "state_copy.h"
 
 #ifdef GCM_STAMPS   // diagnostic build only (make stamps7, tools/kstamp_learned.py)
@@ -803,6 +804,351 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
   LSTAMP(13);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TIME-PARALLEL backward of a whole chain of steps (round 3; k_learned_step_bwd above is one step at a
+// time, one workgroup per CU, ~20 barrier phases behind a sequential [B,N,N] chain buffer).
+//
+// With observations that carry no gradient the only path between steps is the adjacency: the entries
+// (j, k) written when node j was inserted are read by layer 1 of every later step in which row j is
+// live.  The gradient w.r.t. them is dAgg1_{t'}[j] . x[k] - a rank-one term per (later step, live row) -
+// so the whole "chain buffer" of a node collapses to ONE vector
+//     D_t = sum over steps t' >= t in which the node inserted at step t is a live row of dAgg1_{t'}[that row]
+// and the selection adjoint of step t is   g_sel_t[j] = dagg2_t . h1_t[j] + D_t^(j) . x[j]  (j < cur_t),
+// where D_t^(j) stops at the last step that still holds node j (the overflow roll, gcm.py:323-355, drops the
+// oldest node and with it the entries that pointed at it): a prefix of the time-ordered sum - row j of the
+// running sums over t', picked by the number of rolls since step t.
+// dAgg1 / dagg2 depend on g_mx[t'] and step t' alone, so:
+//   pass A (rows_bptt.hip, MODE 2): every graph-step independently - GNN parameter gradient, and per item
+//          cur, the live rows, dagg2 and dAgg1 per live row, into arrays indexed [path step, b];
+//   pass B (here): every graph-step independently - D_t by scanning the <= N later items of its graph (the
+//          node inserted at step t sits in row cur_{t'} - (t' - t) of step t'; fixed order, no atomics),
+//          selection adjoint, edge network recomputed and differentiated.
+// Pass B is persistent: 2 workgroups per CU (69 KB of LDS each: the node image doubles as H0's, h1's as
+// P1's), the weight-gradient tiles of the three products stay in each wave's MFMA accumulators and the
+// column sums in registers across ALL items of the workgroup; one slab per workgroup at the end.
+// ---------------------------------------------------------------------------------------------
+struct BpttB {
+  gcm_rows::StepTable tab;            // tab.saved[s]: the buffer of step s0 + s (nodes at offset 0)
+  size_t o_h1, o_soft;                // float offsets of h1 [B,N,H1] and soft [B,N] inside it
+  const int* hdr;                     // pass A: [T, B, 2] cur, L
+  const int* live;                    //         [T, B, N]
+  const float* da;                    //         [T, B, N, F]
+  const float* dagg2;                 //         [T, B, H1]
+  int s0, n_steps, T;
+};
+
+// ReLU + LayerNorm of the rows of src -> dst (two threads per row), statistics stored
+__device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, int tid, int F, const float* sg,
+                                                const float* sb, float eps, float* mu_out, float* rs_out) {
+  const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
+  float a[FP / 2];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
+    const float v = src[row * FS + f];
+    a[k] = (f < F && v > 0.f) ? v : 0.f;
+    s += a[k];
+  }
+  s += __shfl_xor(s, 1);
+  const float mean = s / (float)F;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const float d = f0 + k < F ? a[k] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  q += __shfl_xor(q, 1);
+  const float rstd = rsqrtf(q / (float)F + eps);
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
+    dst[row * FS + f] = f < F ? fmaf((a[k] - mean) * rstd, sg[f], sb[f]) : 0.f;
+  }
+  if ((tid & 1) == 0) { mu_out[row] = mean; rs_out[row] = rstd; }
+}
+
+__global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float* __restrict__ mlp, float eps0,
+                                                        float eps1, float* __restrict__ slabs, int B, int N,
+                                                        int F, int H1) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cf = tid & 31, cg = tid >> 5;   // column-sum mapping: column cf, row group cg (rows cg, cg + 8, ...)
+  const Mlp M = unpack_mlp(mlp, F);
+  extern __shared__ float smem[];
+  float* sX = smem;                    // node image [NP][FS]; H0 in the middle of an item
+  float* sP0 = sX + NP * FS;           // scan scratch, then P0 -> gP0
+  float* sP1 = sP0 + NP * FS;          // h1 image, then P1 -> gP1 -> gH0
+  float* sW0b = sP1 + NP * FS;         // [o][f] = W0[o][F + f]
+  float* sW0a = sW0b + FP * FS;        // [o][f] = W0[o][f]
+  float* sW1 = sW0a + FP * FS;         // [o][f]
+  float* sVec = sW1 + FP * FS;         // b0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
+  float* sMu0 = sVec + 7 * FP;
+  float* sRs0 = sMu0 + NP;
+  float* sMu1 = sRs0 + NP;
+  float* sRs1 = sMu1 + NP;
+  float* sSel = sRs1 + NP;             // g_sel [NP]
+  float* sGl = sSel + NP;              // g_logit [NP]
+  float* sD = sGl + NP;                // D_t [32] | dagg2_t [32]
+  float* sCs = sD + 64;                // [8][32] partial sums
+  int* sSlot = reinterpret_cast<int*>(sCs + 256);   // [NP] slot of this node in the live list of step t + i
+  int* sWc = sSlot + NP;               // [NP] rolls between step t and step t + i (non-decreasing)
+  int* sFirst = sWc + NP;              // [NP + 2] first i with sWc[i] >= w;  [NP + 1]: last step of the chain
+
+  {   // weights: once per workgroup
+    gcm_fused::Stage<FP, FP, false, false> st_a, st_b, st_1;
+    st_a.load(M.w0, F, F, 2 * F, tid);
+    st_b.load(M.w0 + F, F, F, 2 * F, tid);
+    st_1.load(M.w1, F, F, F, tid);
+    st_a.store(sW0a, FS, tid);
+    st_b.store(sW0b, FS, tid);
+    st_1.store(sW1, FS, tid);
+    if (tid < FP) {
+      const int o = tid < F ? tid : F - 1;
+      const bool ok = tid < F;
+      sVec[tid] = ok ? M.b0[o] : 0.f;
+      sVec[FP + tid] = ok ? M.b1[o] : 0.f;
+      sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
+      sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
+      sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
+      sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
+      sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
+    }
+  }
+  f32x16 aW1, aW0b, aW0a;   // weight-gradient tiles [o = acc_row][f = li], this wave's share of the rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aW1[r] = 0.f; aW0b[r] = 0.f; aW0a[r] = 0.f; }
+  float c_w2 = 0.f, c_g1 = 0.f, c_be1 = 0.f, c_b2 = 0.f, c_b1 = 0.f, c_g0 = 0.f, c_be0 = 0.f, c_b0 = 0.f;
+  __syncthreads();
+
+  const int items = a.n_steps * B;
+#pragma unroll 1
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int s = item / B, b = item - s * B;
+    const int sg = a.s0 + s;
+    const float* base = a.tab.saved[s];
+    const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * ((size_t)sg * B + b)]);
+    if (cur <= 0) continue;   // no candidate rows: nothing was selected, nothing to differentiate (uniform)
+    const float* xg = base + (size_t)b * N * F;
+    const float* hg = base + a.o_h1 + (size_t)b * N * H1;
+    gcm_fused::Stage<NP, FP, false, false> st_x, st_h;
+    st_x.load(xg, N, F, F, tid);
+    st_h.load(hg, N, H1, H1, tid);
+    // ---- D_t: where does the node inserted at this step sit in the live lists of the next <= N steps? ---
+    constexpr int NONE = 1 << 30;
+    if (tid < NP) {
+      const int t2 = sg + tid;
+      int slot = -1, w = NONE;
+      if (t2 < a.T) {
+        const size_t it2 = (size_t)t2 * B + b;
+        const int cur2 = a.hdr[2 * it2], L2 = a.hdr[2 * it2 + 1];
+        const int r = cur2 - tid;            // its row at step t2 (one roll per step once the graph is full)
+        w = cur + tid - cur2;                // rolls since this step
+        if (r >= 0)
+          for (int l = 0; l < L2; ++l)
+            if (a.live[it2 * N + l] == r) slot = l;
+      }
+      sSlot[tid] = slot;
+      sWc[tid] = w;
+    } else {
+      sFirst[tid - NP] = NONE;               // (tid - NP < 128; entries 128 / 129 below)
+      if (tid == NP) sFirst[NP] = NONE;
+    }
+    if (tid < 32) sD[32 + tid] = tid < H1 ? a.dagg2[((size_t)sg * B + b) * H1 + tid] : 0.f;
+    __syncthreads();
+    if (tid < NP) {
+      const int w = sWc[tid];
+      if (w != NONE) {
+        if (tid == 0 || sWc[tid - 1] < w) sFirst[w < NP ? w : NP] = tid;   // (w grows by at most one per step)
+        if (tid == NP - 1 || sWc[tid + 1] == NONE) sFirst[NP + 1] = tid;   // the last step in range
+      }
+    }
+    {
+      constexpr int PER = NP * FP / 256;
+      float v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int e = tid + 256 * i, r = e / FP, f = e % FP;
+        const int slot = sSlot[r];
+        const int t2 = sg + r < a.T ? sg + r : a.T - 1;
+        const float t = a.da[(((size_t)t2 * B + b) * N + (slot >= 0 ? slot : 0)) * F + (f < F ? f : F - 1)];
+        v[i] = (slot >= 0 && f < F) ? t : 0.f;
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int e = tid + 256 * i, r = e / FP, f = e % FP;
+        sP0[r * FS + f] = v[i];
+      }
+    }
+    st_x.store(sX, FS, tid);
+    st_h.store(sP1, FS, tid);
+    __syncthreads();
+    // running sums over the later steps, in time order (fixed order: 8 segments of 16 steps, then the
+    // segments): row i of sP0 becomes the sum of the contributions of steps t .. t + i
+    {
+      float run = 0.f;
+      for (int r = 16 * cg; r < 16 * cg + 16; ++r) {
+        run += sP0[r * FS + cf];
+        sP0[r * FS + cf] = run;
+      }
+      sCs[cg * 32 + cf] = run;
+    }
+    __syncthreads();
+    {
+      float off = 0.f;
+      for (int q = 0; q < cg; ++q) off += sCs[q * 32 + cf];
+      if (cg > 0)
+        for (int r = 16 * cg; r < 16 * cg + 16; ++r) sP0[r * FS + cf] += off;
+    }
+    __syncthreads();
+    // ---- g_sel[j] = dagg2 . h1[j] + D^(j) . x[j]   (j < cur): two threads per row ----------------------
+    {
+      const int row = tid >> 1, half = tid & 1;
+      // node j is still there at step t + i as long as fewer than j + 1 rolls happened since
+      const int fj = sFirst[row + 1 < NP ? row + 1 : NP];
+      const int istar = fj != NONE ? fj - 1 : sFirst[NP + 1];
+      const float* vec = half ? sP0 + istar * FS : sD + 32;
+      const float* img = (half ? sX : sP1) + row * FS;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t = fmaf(vec[k], img[k], t);
+      t += __shfl_xor(t, 1);
+      if (half == 0) sSel[row] = row < cur ? t : 0.f;
+    }
+    __syncthreads();
+    if (wave == 0) {   // softmax adjoint (tau = 1); both straight-through estimators are identities
+      const float* soft = base + a.o_soft + (size_t)b * N;
+      float p[2], g[2], dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = lane + 64 * c;
+        const bool live = j < cur;
+        p[c] = live ? soft[j < N ? j : N - 1] : 0.f;
+        g[c] = live ? sSel[j] : 0.f;
+        dot = fmaf(p[c], g[c], dot);
+      }
+      dot = wave_sum(dot);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) sGl[lane + 64 * c] = p[c] * (g[c] - dot);
+    }
+    // ---- edge network recomputed: P0 = X W0b^T + (W0a x_cur + b0) ---------------------------------------
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      mma32(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, 32, li, lh);
+      mma32(acc, sX + cur * FS, 0, 1, sW0a, 1, FS, 32, li, lh);     // every row gets W0a x_cur
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sP0[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
+    }
+    __syncthreads();   // (sP0's scan scratch was consumed two barriers ago)
+    relu_ln_rows_to(sP0, sX, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);   // H0 over the node image
+    __syncthreads();
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      mma32(acc, sX + 32 * wave * FS, FS, 1, sW1, 1, FS, 32, li, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
+    }
+    __syncthreads();
+    relu_ln_rows(sP1, tid, F, nullptr, nullptr, eps1, sMu1, sRs1, /*write=*/false);
+    __syncthreads();
+    {   // dw2, dgamma1, dbeta1, db2: this thread's rows of its column
+      const float w2f = sVec[6 * FP + cf], g1f = sVec[4 * FP + cf], be1f = sVec[5 * FP + cf];
+      for (int j = cg; j < N; j += 8) {
+        const float gl = sGl[j];
+        const float v = sP1[j * FS + cf];
+        const float xh = ((v > 0.f ? v : 0.f) - sMu1[j]) * sRs1[j];
+        c_w2 = fmaf(gl, fmaf(xh, g1f, be1f), c_w2);
+        c_g1 = fmaf(gl * w2f, xh, c_g1);
+        c_be1 = fmaf(gl, w2f, c_be1);
+        if (cf == 0) c_b2 += gl;
+      }
+    }
+    __syncthreads();
+    relu_ln_rows_bwd(sP1, tid, F, sMu1, sRs1,
+                     [&](int j, int f) { return sGl[j] * sVec[6 * FP + f] * sVec[4 * FP + f]; });   // gP1
+    __syncthreads();
+    for (int j = cg; j < N; j += 8) c_b1 += sP1[j * FS + cf];
+    // dW1 += gP1^T H0 (K = this wave's rows);  gH0 = gP1 W1
+    mma32(aW1, sP1 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, 32, li, lh);
+    f32x16 gh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gh[r] = 0.f;
+    mma32(gh, sP1 + 32 * wave * FS, FS, 1, sW1, FS, 1, 32, li, lh);
+    st_x.load(xg, N, F, F, tid);   // the node image again (H0 is done with after this phase)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = gh[r];   // gH0
+    st_x.store(sX, FS, tid);
+    __syncthreads();
+    {   // dgamma0, dbeta0
+      for (int j = cg; j < N; j += 8) {
+        const float v = sP0[j * FS + cf];
+        const float xh = ((v > 0.f ? v : 0.f) - sMu0[j]) * sRs0[j];
+        const float ghv = sP1[j * FS + cf];
+        c_g0 = fmaf(ghv, xh, c_g0);
+        c_be0 += ghv;
+      }
+    }
+    __syncthreads();
+    relu_ln_rows_bwd(sP0, tid, F, sMu0, sRs0, [&](int j, int f) { return sP1[j * FS + f] * sVec[2 * FP + f]; });   // gP0
+    __syncthreads();
+    for (int j = cg; j < N; j += 8) c_b0 += sP0[j * FS + cf];
+    // dW0b += gP0^T X;  dW0a += gP0^T (x_cur in every row)
+    mma32(aW0b, sP0 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, 32, li, lh);
+    mma32(aW0a, sP0 + 32 * wave * FS, 1, FS, sX + cur * FS, 0, 1, 32, li, lh);
+    __syncthreads();   // the images are rewritten by the next item
+  }
+
+  // ---- one slab per workgroup (packed edge-network layout), waves and row groups summed in fixed order ---
+  const int Pm = 3 * F * F + 7 * F + 1;
+  float* slab = slabs + (size_t)blockIdx.x * Pm;
+  const int o_b0 = 2 * F * F, o_g0 = o_b0 + F, o_be0 = o_g0 + F, o_w1 = o_be0 + F, o_b1 = o_w1 + F * F;
+  const int o_g1 = o_b1 + F, o_be1 = o_g1 + F, o_w2 = o_be1 + F, o_b2 = o_w2 + F;
+  float* sR = sP0;   // [4][1024]
+  auto tile_out = [&](const f32x16& acc, int row_stride, int col0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      const int o = e >> 5, f = e & 31;
+      if (o < F && f < F) slab[col0 + o * row_stride + f] = (sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]);
+    }
+    __syncthreads();
+  };
+  __syncthreads();
+  tile_out(aW0a, 2 * F, 0);
+  tile_out(aW0b, 2 * F, F);
+  tile_out(aW1, F, o_w1);
+  auto col_out = [&](float v, int off, int n) {
+    sCs[cg * 32 + cf] = v;
+    __syncthreads();
+    if (tid < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+      slab[off + tid] = t;
+    }
+    __syncthreads();
+  };
+  col_out(c_b0, o_b0, F);
+  col_out(c_g0, o_g0, F);
+  col_out(c_be0, o_be0, F);
+  col_out(c_b1, o_b1, F);
+  col_out(c_g1, o_g1, F);
+  col_out(c_be1, o_be1, F);
+  col_out(c_w2, o_w2, F);
+  col_out(c_b2, o_b2, 1);
+}
+
+constexpr size_t lds_bptt_b() {
+  return sizeof(float) * (3 * NP * FS + 3 * FP * FS + 7 * FP + 6 * NP + 64 + 256 + 3 * NP + 2);
+}
+
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
@@ -872,4 +1218,108 @@ extern "C" int gcm_learned_step_bwd(const float* g_mx, const float* nodes, const
                      nodes, adj, cur_idx, count_in, gnn_params, act1, act2, mx, h1, agg1, agg2, soft,
                      mlp_params, eps0, eps1, GA, slabs, accumulate, N, F, H1, H2);
   return gcm_launch_status();
+}
+
+/* ---- time-parallel backward of a chain of fused LearnedEdge steps (see k_learned_bptt_b) -------------- */
+static inline size_t lrn_pad64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, size_t* out8) {
+  GCM_REQUIRE(out8 && B > 0 && N > 0 && F > 0 && H1 > 0 && H2 > 0);
+  // nodes | adj | mx | h1 | agg1 | agg2 | cur, count_out (2 B int64) | soft      (64-float aligned sections)
+  const size_t n_nodes = lrn_pad64((size_t)B * N * F), n_adj = lrn_pad64((size_t)B * N * N);
+  const size_t n_mx = lrn_pad64((size_t)B * H2), n_h1 = lrn_pad64((size_t)B * N * H1), n_agg2 = lrn_pad64((size_t)B * H1);
+  out8[1] = n_nodes;                 // o_adj
+  out8[2] = out8[1] + n_adj;         // o_mx
+  out8[3] = out8[2] + n_mx;          // o_h1
+  out8[4] = out8[3] + n_h1;          // o_agg1
+  out8[5] = out8[4] + n_nodes;       // o_agg2
+  out8[6] = out8[5] + n_agg2;        // o_idx
+  out8[7] = out8[6] + lrn_pad64(4 * (size_t)B);   // o_soft
+  out8[0] = out8[7] + lrn_pad64((size_t)B * N);   // total floats
+  return GCM_OK;
+}
+
+static int lrn_grid_b(int n_steps_launch, int B) {   // persistent: two workgroups per CU
+  const long items = (long)n_steps_launch * B;
+  return (int)(items < 512 ? items : 512);
+}
+
+extern "C" size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, int F, int H1, int H2) {
+  if (n_steps <= 0 || B <= 0) return 0;
+  const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2, Pm = 3 * (size_t)F * F + 7 * F + 1;
+  const size_t chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
+  const size_t TB = (size_t)n_steps * B;
+  size_t fl = lrn_pad64(Pg * (size_t)gcm_dense_rows_bptt_slabs(n_steps, B)) + lrn_pad64(Pm * 512 * chunks) +
+              lrn_pad64(TB * 2) + lrn_pad64(TB * N) + lrn_pad64(TB * N * F) + lrn_pad64(TB * H1);
+  return sizeof(float) * fl;
+}
+
+/* saved_host: HOST array of the n_steps step buffers of ONE chain of hidden states, in step order
+ * (gcm_learned_step_layout); gmx_host[t]: that step's g_mx [B, H2] (element strides as given) or NULL
+ * (zero gradient: a step whose own gradient another call accounts for).  params: GNN | edge network,
+ * packed.  g_params [Pg + Pm] = g_params_prev (NULL = 0) + the gradient. */
+extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                                long gmx_stride_b, long gmx_stride_h, const float* params, int act1, int act2,
+                                float eps0, float eps1, const float* g_params_prev, float* g_params,
+                                void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                                gcm_stream_t stream) {
+  GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace && n_steps > 0 && B > 0);
+  if (!gcm_learned_step_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  if (workspace_bytes < gcm_learned_bptt_workspace_bytes(n_steps, B, N, F, H1, H2)) return GCM_EWORKSPACE;
+  const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2, Pm = 3 * (size_t)F * F + 7 * F + 1;
+  const int chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
+  const int total_a = gcm_dense_rows_bptt_slabs(n_steps, B), per_a = total_a / chunks;
+  const size_t TB = (size_t)n_steps * B;
+  float* ws = (float*)workspace;
+  float* slabs_a = ws;
+  float* slabs_b = slabs_a + lrn_pad64(Pg * (size_t)total_a);
+  int* hdr = (int*)(slabs_b + lrn_pad64(Pm * 512 * (size_t)chunks));
+  int* live = hdr + lrn_pad64(TB * 2);
+  float* da = (float*)(live + lrn_pad64(TB * N));
+  float* dagg2 = da + lrn_pad64(TB * N * F);
+  size_t lay[8];
+  gcm_learned_step_layout(B, N, F, H1, H2, lay);
+  const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  // pass A: every step, every graph (the arrays pass B scans must be complete before it starts)
+  for (int c = 0; c < chunks; ++c) {
+    const int s0 = c * GCM_ROWS_MAX_STEPS;
+    const int ns = n_steps - s0 < GCM_ROWS_MAX_STEPS ? n_steps - s0 : GCM_ROWS_MAX_STEPS;
+    gcm_rows::StepTable tab{};
+    for (int i = 0; i < ns; ++i) {
+      GCM_REQUIRE(saved_host[s0 + i]);
+      tab.saved[i] = saved_host[s0 + i];
+      tab.gmx[i] = gmx_host[s0 + i];
+    }
+    gcm_rows::LearnedSrc src{lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], params, hdr, live, da, dagg2, s0};
+    const int rc = gcm_rows::launch_bptt_learned(stream, per_a, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,
+                                                 w_root2, act1, act2, slabs_a + (size_t)c * per_a * Pg, src, B, N,
+                                                 F, H1, H2);
+    if (rc) return rc;
+  }
+  // pass B
+  constexpr size_t lds = gcm_learned::lds_bptt_b();
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_b, lds);
+  int total_b = 0;
+  for (int c = 0; c < chunks; ++c) {
+    const int s0 = c * GCM_ROWS_MAX_STEPS;
+    const int ns = n_steps - s0 < GCM_ROWS_MAX_STEPS ? n_steps - s0 : GCM_ROWS_MAX_STEPS;
+    gcm_learned::BpttB a{};
+    for (int i = 0; i < ns; ++i) a.tab.saved[i] = saved_host[s0 + i];
+    a.o_h1 = lay[3];
+    a.o_soft = lay[7];
+    a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
+    a.s0 = s0; a.n_steps = ns; a.T = n_steps;
+    const int grid = lrn_grid_b(ns, B);
+    hipLaunchKernelGGL(gcm_learned::k_learned_bptt_b, dim3(grid), dim3(256), lds, (hipStream_t)stream, a,
+                       params + Pg, eps0, eps1, slabs_b + (size_t)total_b * Pm, B, N, F, H1);
+    const int rc = gcm_launch_status();
+    if (rc) return rc;
+    total_b += grid;
+  }
+  int rc = gcm_sum_slabs_acc(slabs_a, total_a, (int)Pg, g_params_prev, g_params, stream);
+  if (rc) return rc;
+  return gcm_sum_slabs_acc(slabs_b, total_b, (int)Pm, g_params_prev ? g_params_prev + Pg : nullptr, g_params + Pg,
+                           stream);
 }

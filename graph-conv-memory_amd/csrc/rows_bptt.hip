@@ -22,14 +22,7 @@
 #include "gcm_common.h"
 #include "rows_common.h"
 
-#define GCM_ROWS_MAX_STEPS 64   /* steps per launch: two pointer tables in the kernel arguments */
-
 namespace gcm_rows {
-
-struct StepTable {
-  const float* saved[GCM_ROWS_MAX_STEPS];
-  const float* gmx[GCM_ROWS_MAX_STEPS];
-};
 
 // History of DenseGCM.rollout's persistent forward kernel (rollout_persist.hip) as the record source:
 // per-step arrays [T, B, ...]; adj / nodes point at slot 1 of the [T+1, ...] state arrays (the state
@@ -48,13 +41,33 @@ __device__ __forceinline__ float act_grad_sel(float y, int act_v) {
   return g;
 }
 
+// MODE 2 - the fused DenseGCM + LearnedEdge step (learned_step.hip) as the record source: every step kept
+// its FULL layers in one buffer (tab.saved[s] + the float offsets in LrnSrc; per-graph indexing).  The
+// GNN parameter gradient is the same sum over the live rows; on top of it this pass hands the
+// selection's backward (learned_bptt.hip) what it needs from the GNN: per item (s0 + s, b) the row cur
+// and the live-row list, dagg2, and per live row l
+//     dAgg1_l = G1_l W_rel1                                       [F]
+// - the gradient w.r.t. row j_l of the aggregate adj @ x, i.e. w.r.t. the adjacency entries (j_l, k)
+// through dAgg1_l . x[k].  A step whose tab.gmx entry is NULL takes g_mx = 0 (a record another pass owns).
+struct LrnSrc {
+  size_t o_adj, o_mx, o_h1, o_agg1, o_agg2, o_idx;   // float offsets inside a step's buffer
+  const float* w_rel1;                                // [H1, F]
+  int* hdr;          // [T, B, 2]  cur, L
+  int* live;         // [T, B, N]  rows j_l
+  float* da;         // [T, B, N, F]
+  float* dagg2;      // [T, B, H1]
+  int s0;            // path index of this launch's first step
+};
+
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
-// C2 = columns of v per lane (column m = lane + 64 c).
-template <int FP, int HP, int H2P, bool HIST>
+// C2 = columns of v per lane (column m = lane + 64 c).  MODE: 0 live-row records, 1 rollout history,
+// 2 learned-step buffers.
+template <int FP, int HP, int H2P, int MODE>
 __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
-    int B, int N, int F, int H1, int H2, int deg_term) {
+    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn) {
+  constexpr bool HIST = MODE != 0;
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
@@ -73,6 +86,14 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     for (int o = 0; o < H2P; ++o) {
       const float t = src[(size_t)(o < H2 ? o : H2 - 1) * H1];
       w2c[c][o] = (ok && o < H2) ? t : 0.f;
+    }
+  }
+  float wr1c[MODE == 2 ? HP : 1];   // MODE 2: column `lane` of W_rel1
+  if (MODE == 2) {
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      const float t = lrn.w_rel1[(size_t)(h < H1 ? h : H1 - 1) * F + (lane < F ? lane : F - 1)];
+      wr1c[MODE == 2 ? h : 0] = (h < H1 && lane < F) ? t : 0.f;
     }
   }
   float acc1[C1][HP], acc2[C2][H2P];
@@ -96,6 +117,9 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     int L = 0, l_cur = 0, cur = 0;
     unsigned long long m0 = 0, m1 = 0;   // HIST: live rows as two 64-bit masks
     float a0 = 0.f, a1 = 0.f, g, y;
+    Hist src{};        // HIST: where the full layers of this item live
+    size_t gi = 0;     //       and the index of its graph in them
+    int n_live = 0;    // MODE 2: live rows handed on so far
     float vv[C2];
     if (!HIST) {
       sv = tab.saved[s];
@@ -111,12 +135,23 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         vv[c] = m < 2 * H1 ? t : 0.f;
       }
     } else {
-      const size_t gi = (size_t)item;   // = s * B + b
-      const int64_t c64 = hs.cur[gi];
+      if (MODE == 2) {   // this step's own buffer, per-graph indexing
+        const float* base = tab.saved[s];
+        src.adj = base + lrn.o_adj; src.nodes = base; src.h1 = base + lrn.o_h1; src.agg1 = base + lrn.o_agg1;
+        src.agg2 = base + lrn.o_agg2; src.mx = base + lrn.o_mx;
+        src.cur = reinterpret_cast<const int64_t*>(base + lrn.o_idx);
+        gi = (size_t)b;
+        const float* gp = tab.gmx[s];
+        g = gp ? gp[(long)b * gmx_sb + (long)oc * gmx_sh] : 0.f;
+      } else {
+        src = hs;
+        gi = (size_t)item;   // = s * B + b
+        g = hs.gmx[(long)s * hs.gmx_st + (long)b * gmx_sb + (long)oc * gmx_sh];
+      }
+      const int64_t c64 = src.cur[gi];
       cur = __builtin_amdgcn_readfirstlane(c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64));
-      g = hs.gmx[(long)s * hs.gmx_st + (long)b * gmx_sb + (long)oc * gmx_sh];
-      y = hs.mx[gi * H2 + oc];
-      const float* arow = hs.adj + (gi * N + cur) * N;
+      y = src.mx[gi * H2 + oc];
+      const float* arow = src.adj + (gi * N + cur) * N;
       a0 = arow[lane < N ? lane : N - 1];
       a1 = arow[lane + 64 < N ? lane + 64 : N - 1];
       m0 = __ballot(lane < N && (a0 != 0.f || lane == cur));
@@ -125,7 +160,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       for (int c = 0; c < C2; ++c) {
         const int m = lane + 64 * c;
         const int k = m < H1 ? m : (m - H1 < H1 ? m - H1 : H1 - 1);
-        const float t = m < H1 ? hs.agg2[gi * H1 + k] : hs.h1[(gi * N + cur) * H1 + k];
+        const float t = m < H1 ? src.agg2[gi * H1 + k] : src.h1[(gi * N + cur) * H1 + k];
         vv[c] = m < 2 * H1 ? t : 0.f;
       }
     }
@@ -180,26 +215,41 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
         cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? a0 : a1), j & 63));
         is_cur = j == cur;
-        const size_t rj = (size_t)item * N + j;
-        hv = hs.h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
+        const size_t rj = gi * N + j;
+        hv = src.h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
           const int m = lane + 64 * c;
           const int f = m < F ? m : (m - F < F ? m - F : F - 1);
-          const float t = m < F ? hs.agg1[rj * F + f] : hs.nodes[rj * F + f];
+          const float t = m < F ? src.agg1[rj * F + f] : src.nodes[rj * F + f];
           ax[c] = m < 2 * F ? t : 0.f;
         }
+        if (MODE == 2 && lane == 0) lrn.live[((size_t)(lrn.s0 + s) * B + b) * N + n_live] = j;
       }
       float g1 = (cf * dagg2 + (is_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
       g1 = lane < H1 ? g1 : 0.f;
       db1 += g1;
       dc1 = fmaf(dg, g1, dc1);
+      float da = 0.f;
 #pragma unroll
       for (int h = 0; h < HP; ++h) {
         const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
 #pragma unroll
         for (int c = 0; c < C1; ++c) acc1[c][h] = fmaf(gh, ax[c], acc1[c][h]);
+        if (MODE == 2) da = fmaf(gh, wr1c[MODE == 2 ? h : 0], da);
       }
+      if (MODE == 2) {   // dAgg1_l, column `lane`
+        if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;
+        ++n_live;
+      }
+    }
+    if (MODE == 2) {
+      const size_t it = (size_t)(lrn.s0 + s) * B + b;
+      if (lane == 0) {
+        lrn.hdr[2 * it] = cur;
+        lrn.hdr[2 * it + 1] = n_live;
+      }
+      if (lane < H1) lrn.dagg2[it * H1 + lane] = dagg2;
     }
   }
 
@@ -250,18 +300,27 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
 }
 
-template <int FP, int HP, int H2P, bool HIST>
+template <int FP, int HP, int H2P, int MODE>
 int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, int n_steps, long sb, long sh,
                 const float* w_rel2, const float* w_root2, int act1, int act2,
                 const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2,
-                int deg_term = 0) {
+                int deg_term = 0, const LrnSrc& lrn = LrnSrc{}) {
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   const size_t lds = sizeof(float) * P;
-  auto kern = k_bptt_rows<FP, HP, H2P, HIST>;
+  auto kern = k_bptt_rows<FP, HP, H2P, MODE>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,
-                     act2, lay, slabs, B, N, F, H1, H2, deg_term);
+                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn);
   return gcm_launch_status();
+}
+
+int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh,
+                        const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,
+                        const LearnedSrc& src, int B, int N, int F, int H1, int H2) {
+  LrnSrc l{src.o_adj, src.o_mx, src.o_h1, src.o_agg1, src.o_agg2, src.o_idx, src.w_rel1,
+           src.hdr,   src.live, src.da,   src.dagg2,  src.s0};
+  return launch_bptt<32, 32, 32, 2>((hipStream_t)stream, grid, tab, Hist{}, n_steps, gmx_sb, gmx_sh, w_rel2,
+                                    w_root2, act1, act2, SavedLayout{}, slabs, B, N, F, H1, H2, 0, l);
 }
 
 }  // namespace gcm_rows
@@ -320,7 +379,7 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
     int rc = GCM_EUNSUPPORTED;
 #define GCM_RB(a, b_, cc)                                                                          \
   if (fp == a && hp == b_ && h2p == cc)                                                            \
-    rc = gcm_rows::launch_bptt<a, b_, cc, false>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,  \
+    rc = gcm_rows::launch_bptt<a, b_, cc, 0>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,  \
                                                  gmx_stride_h, w_rel2, w_root2, act1, act2, lay, sl, B, \
                                                  N, F, H1, H2, deg_term);
     GCM_RB(32, 32, 32) GCM_RB(32, 32, 64) GCM_RB(32, 64, 32) GCM_RB(32, 64, 64)
@@ -370,7 +429,7 @@ extern "C" int gcm_dense_rollout_bwd_params(const float* g_mx_all, long gmx_stri
   const gcm_rows::StepTable none{};
 #define GCM_RH(a, b_, cc)                                                                          \
   if (fp == a && hp == b_ && h2p == cc)                                                            \
-    rc = gcm_rows::launch_bptt<a, b_, cc, true>(s, grid, none, hs, T, gmx_stride_b, gmx_stride_h,  \
+    rc = gcm_rows::launch_bptt<a, b_, cc, 1>(s, grid, none, hs, T, gmx_stride_b, gmx_stride_h,  \
                                                 w_rel2, w_root2, act1, act2, lay, slabs, B, N, F,  \
                                                 H1, H2);
   GCM_RH(32, 32, 32) GCM_RH(32, 32, 64) GCM_RH(32, 64, 32) GCM_RH(32, 64, 64)

@@ -14,7 +14,30 @@
 #pragma once
 #include <stddef.h>
 
+#define GCM_ROWS_MAX_STEPS 64   /* steps per launch: two pointer tables in the kernel arguments */
+
 namespace gcm_rows {
+
+// device pointers of up to 64 recorded steps, by value in the kernel arguments
+struct StepTable {
+  const float* saved[GCM_ROWS_MAX_STEPS];
+  const float* gmx[GCM_ROWS_MAX_STEPS];
+};
+
+// Pass A of the learned-step backward (learned_step.hip: gcm_learned_bptt), defined in rows_bptt.hip:
+// k_bptt_rows over the full-layer buffers of up to GCM_ROWS_MAX_STEPS steps.  Offsets in floats.
+struct LearnedSrc {
+  size_t o_adj, o_mx, o_h1, o_agg1, o_agg2, o_idx;
+  const float* w_rel1;
+  int* hdr;
+  int* live;
+  float* da;
+  float* dagg2;
+  int s0;
+};
+int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh,
+                        const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,
+                        const LearnedSrc& src, int B, int N, int F, int H1, int H2);
 
 struct SavedLayout {
   size_t total, o_v, o_hdr, o_coef, o_rows, o_deg;

@@ -21,6 +21,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/python_variable.h>
 
+#include <algorithm>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -653,6 +654,198 @@ struct LearnedStepFn : public torch::autograd::Function<LearnedStepFn> {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the same forward kernels, but every step of a chain of hidden states hangs its belief
+// tensor on ONE node (as the live-row steps do) and the backward is time-parallel
+// (gcm_learned_bptt: two passes over all recorded graph-steps, no [B,N,N] gradient chain buffer, no
+// kernel and no autograd node per step).  Steps form a tree through their `parent` (the step that
+// produced the hidden state they continued); every root-to-leaf path is one gcm_learned_bptt call,
+// with g_mx = 0 for the steps an earlier path already accounted for (everything downstream of g_mx and
+// of the adjacency gradient is linear, so shared ancestors simply receive each branch's share).
+// ---------------------------------------------------------------------------------------------
+struct LearnedChainNode : public torch::autograd::Node {
+  struct Rec {
+    at::Tensor buf;             // gcm_learned_step_layout
+    c10::VariableVersion vc;    // of the belief tensor (aliases buf)
+    uint32_t version;
+    int parent;                 // index of the step whose hidden state this one continued, or -1
+    int64_t B;
+  };
+  std::vector<Rec> recs;
+  at::Tensor packed;            // detached
+  LearnedCfg* cfg = nullptr;
+  bool executed = false, released = false;
+
+  variable_list apply(variable_list&& grads) override {
+    executed = true;
+    variable_list out(1);
+    TORCH_CHECK(!released, "Trying to backward through the LearnedEdge steps of a DenseGCM chain a second time "
+                           "(their records were freed); pass retain_graph=True to the first call");
+    TORCH_CHECK(grads.size() == recs.size(), "learned chain: ", grads.size(), " gradients for ", recs.size(),
+                " recorded steps");
+    const int n = (int)recs.size();
+    std::vector<char> has_child(n, 0), done(n, 0);
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+      if (recs[i].parent >= 0) has_child[recs[i].parent] = 1;
+      any |= grads[i].defined();
+    }
+    if (!any) return out;
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const gcm_stream_t stream =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(packed.get_device()).stream());
+    at::Tensor prev;
+    std::vector<at::Tensor> keep;
+    for (int leaf = 0; leaf < n; ++leaf) {
+      if (has_child[leaf]) continue;
+      std::vector<int> path;
+      for (int i = leaf; i >= 0; i = recs[i].parent) path.push_back(i);
+      std::reverse(path.begin(), path.end());
+      // gradients of the steps this path owns, with common strides
+      std::vector<at::Tensor> g(path.size());
+      bool same = true, first = true, owned_any = false;
+      int64_t sb = 0, sh = 0;
+      for (size_t t = 0; t < path.size(); ++t) {
+        const int i = path[t];
+        if (done[i] || !grads[i].defined()) continue;
+        const Rec& r = recs[i];
+        TORCH_CHECK(r.vc.current_version() == r.version,
+                    "one of the variables needed for gradient computation has been modified by an inplace "
+                    "operation: the belief states returned by DenseGCM (LearnedEdge) step ", i);
+        g[t] = grads[i].scalar_type() == at::kFloat ? grads[i] : grads[i].to(at::kFloat);
+        if (first) { sb = g[t].stride(0); sh = g[t].stride(1); first = false; }
+        same &= g[t].stride(0) == sb && g[t].stride(1) == sh;
+        owned_any = true;
+      }
+      for (int i : path) done[i] = 1;
+      if (!owned_any) continue;
+      if (!same) {
+        for (auto& t : g)
+          if (t.defined()) t = t.contiguous();
+        sb = H2; sh = 1;
+      }
+      std::vector<const float*> sv(path.size()), gm(path.size());
+      for (size_t t = 0; t < path.size(); ++t) {
+        sv[t] = recs[path[t]].buf.data_ptr<float>();
+        gm[t] = g[t].defined() ? g[t].data_ptr<float>() : nullptr;
+        if (g[t].defined()) keep.push_back(g[t]);
+      }
+      const int T = (int)path.size(), B = (int)recs[path[0]].B;
+      const size_t ws_bytes = gcm_learned_bptt_workspace_bytes(T, B, N, F, H1, H2);
+      at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
+      at::Tensor res = at::empty({cfg->P_total}, packed.options());
+      check(gcm_learned_bptt(sv.data(), gm.data(), T, (long)sb, (long)sh, packed.data_ptr<float>(), cfg->act1,
+                             cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
+                             prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
+                             ws.data_ptr(), ws_bytes, B, N, F, H1, H2, stream),
+            "gcm_learned_bptt");
+      prev = res;
+    }
+    out[0] = prev;
+    return out;
+  }
+  void release_variables() override {
+    recs.clear();
+    released = true;
+  }
+  std::string name() const override { return "GcmLearnedChain"; }
+};
+
+struct LearnedChain {   // one per packed parameter vector
+  std::shared_ptr<LearnedChainNode> node;
+  LearnedCfg* cfg;
+  at::Tensor packed;
+  LearnedChain(int64_t cfg_handle, const at::Tensor& packed_) : cfg(reinterpret_cast<LearnedCfg*>(cfg_handle)), packed(packed_) {
+    TORCH_CHECK(packed.is_cuda() && packed.is_contiguous() && packed.numel() >= cfg->P_total);
+    if (at::GradMode::is_enabled() && packed.requires_grad()) {
+      node = std::shared_ptr<LearnedChainNode>(new LearnedChainNode(), torch::autograd::deleteNode);
+      node->packed = packed.detach();
+      node->cfg = cfg;
+      node->set_next_edges(torch::autograd::collect_next_edges(packed));
+    }
+  }
+  bool executed() const { return node && node->executed; }
+  bool recording() const { return node != nullptr; }
+  int64_t steps() const { return node ? (int64_t)node->recs.size() : 0; }
+};
+
+// -> (mx, nodes_out, adj_out, cur, count_out, index of this step in the chain (or -1))
+pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const at::Tensor& nodes_in_,
+                              const at::Tensor& adj_in_, const at::Tensor& count_in, const at::Tensor& noise_,
+                              int64_t noise_is_exp, const at::Tensor& flags, int64_t parent) {
+  LearnedCfg* cfg = chain.cfg;
+  TORCH_CHECK(obs_.is_cuda() && nodes_in_.is_cuda() && adj_in_.is_cuda() && count_in.is_cuda() && noise_.is_cuda() &&
+                  flags.is_cuda(),
+              "learned_step: every tensor must live on a HIP device (no CPU fallback)");
+  TORCH_CHECK(count_in.is_contiguous() && obs_.scalar_type() == at::kFloat && count_in.scalar_type() == at::kLong);
+  at::Tensor obs = obs_.contiguous(), nodes_in = nodes_in_.contiguous(), adj_in = adj_in_.contiguous(),
+             noise = noise_.contiguous();
+  const int64_t B = obs.size(0);
+  const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+  TORCH_CHECK(nodes_in.size(0) == B && nodes_in.size(1) == N && nodes_in.size(2) == F && adj_in.size(0) == B &&
+                  adj_in.size(1) == N && adj_in.size(2) == N && count_in.size(0) == B && obs.size(1) == F &&
+                  noise.numel() == B * N,
+              "learned_step: hidden state, observation and noise shapes disagree");
+  const bool need_bwd = chain.node != nullptr && at::GradMode::is_enabled();
+  const Layout L(B, N, F, H1, H2, need_bwd);
+  const int64_t o_soft = L.total;
+  if (need_bwd) {
+    size_t lay[8];
+    check(gcm_learned_step_layout((int)B, N, F, H1, H2, lay), "gcm_learned_step_layout");
+    TORCH_CHECK((int64_t)lay[1] == L.o_adj && (int64_t)lay[2] == L.o_mx && (int64_t)lay[3] == L.o_h1 &&
+                    (int64_t)lay[4] == L.o_agg1 && (int64_t)lay[5] == L.o_agg2 && (int64_t)lay[6] == L.o_idx &&
+                    (int64_t)lay[7] == o_soft,
+                "learned_step: buffer layouts of the host node and the library disagree");
+    TORCH_CHECK(parent < (int64_t)chain.node->recs.size());
+  }
+  at::Tensor buf = at::empty({L.total + pad64(B * (int64_t)N)}, obs.options());
+  float* base = buf.data_ptr<float>();
+  int64_t* ib = reinterpret_cast<int64_t*>(base + L.o_idx);
+  uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
+  const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(obs.get_device()).stream());
+  const float* pk = chain.packed.data_ptr<float>();
+  if ((N & 3) == 0 && (F & 3) == 0) {
+    check(gcm_learned_advance_select_fused(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                           count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp,
+                                           pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base,
+                                           base + L.o_adj, ib, ib + B, base + o_soft, fl, (int)B, N, F, st),
+          "gcm_learned_advance_select_fused");
+  } else {
+    check(gcm_state_advance_fwd(nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(), nullptr,
+                                count_in.data_ptr<int64_t>(), obs.data_ptr<float>(), base, base + L.o_adj, nullptr, ib,
+                                ib + B, fl, (int)B, N, F, st),
+          "gcm_state_advance_fwd");
+    check(gcm_learned_select_fused(base, base + L.o_adj, ib, noise.data_ptr<float>(), (int)noise_is_exp, pk + cfg->P,
+                                   (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base + o_soft, (int)B, N, F,
+                                   st),
+          "gcm_learned_select_fused");
+  }
+  const float* w_rel1 = pk;
+  const float* w_root1 = w_rel1 + (size_t)H1 * F;
+  const float* b1 = w_root1 + (size_t)H1 * F;
+  const float* w_rel2 = b1 + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  const float* b2 = w_root2 + (size_t)H2 * H1;
+  check(gcm_dense_gnn2_row_fwd(base, base + L.o_adj, ib, w_rel1, (cfg->has_bias & 1) ? b1 : nullptr, w_root1, cfg->act1,
+                               w_rel2, (cfg->has_bias & 2) ? b2 : nullptr, w_root2, cfg->act2, base + L.o_mx,
+                               need_bwd ? base + L.o_h1 : nullptr, need_bwd ? base + L.o_agg1 : nullptr,
+                               need_bwd ? base + L.o_agg2 : nullptr, fl, (int)B, N, F, H1, H2, st),
+        "gcm_dense_gnn2_row_fwd");
+  at::Tensor nodes_out = alias_of(buf, 0, {B, N, F}, buf.dtype());
+  at::Tensor adj_out = alias_of(buf, L.o_adj, {B, N, N}, buf.dtype());
+  at::Tensor mx = alias_of(buf, L.o_mx, {B, H2}, buf.dtype());
+  at::Tensor cur = alias_of(buf, L.o_idx / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
+  at::Tensor count_out = alias_of(buf, L.o_idx / 2 + B, {B}, caffe2::TypeMeta::Make<int64_t>());
+  int64_t index = -1;
+  if (need_bwd) {
+    const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
+    chain.node->recs.push_back({buf, vc, vc.current_version(), (int)parent, B});
+    index = (int64_t)chain.node->recs.size() - 1;
+    torch::autograd::create_gradient_edge(mx, chain.node);
+  }
+  return pybind11::make_tuple(mx, nodes_out, adj_out, cur, count_out, index);
+}
+
 std::vector<at::Tensor> learned_step(const at::Tensor& packed, const at::Tensor& dchain_in, const at::Tensor& obs,
                                      const at::Tensor& nodes_in, const at::Tensor& adj_in,
                                      const at::Tensor& count_in, const at::Tensor& noise, int64_t noise_is_exp,
@@ -698,4 +891,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())
       .def("handle", [](LearnedCfg& c) { return reinterpret_cast<int64_t>(&c); });
   m.def("learned_step", &learned_step);
+  pybind11::class_<LearnedChain>(m, "LearnedChain")
+      .def(pybind11::init<int64_t, const at::Tensor&>())
+      .def("executed", &LearnedChain::executed)
+      .def("recording", &LearnedChain::recording)
+      .def("steps", &LearnedChain::steps);
+  m.def("learned_step2", &learned_step2);
 }

@@ -125,6 +125,10 @@ class DenseGCM(torch.nn.Module):
         self._pinned_pool = []
         self._ctr = [0]       # steps since the last poll (a list: nn.Module.__setattr__ is slow)
         self._fast = None     # (RowsFast, flag word) of the last live-row step: what __call__ tries first
+        self._learned_chain = None   # (packed vector, LearnedChain, grad mode): the fused LearnedEdge steps' one autograd node
+        # False: the round-2 backward of the fused LearnedEdge step (one kernel per step behind a [B,N,N]
+        # gradient chain buffer) instead of the time-parallel one - kept for A/B tests
+        self.learned_time_parallel = True
 
     # -- state ---------------------------------------------------------------
     def get_initial_hidden_state(self, x):
@@ -430,6 +434,7 @@ class DenseGCM(torch.nn.Module):
         # bound to the stream they were created on - a later HIP-graph capture of this module would
         # then be made to synchronise with that (possibly the default) stream and fail
         self._packed_cache = cache = None
+        self._learned_chain = None
         if cfg._rows_fast is not None:
             cfg._rows_fast.forget()
         key = torch.is_grad_enabled()
@@ -544,7 +549,21 @@ class DenseGCM(torch.nn.Module):
                 pool = self._noise_pool = [torch.empty(16, B, cfg.N, device=x.device).exponential_(), 0, cap]
             noise, is_exp = pool[0][pool[1]], 1
             pool[1] += 1
-        if gated is not None:
+        ext = _ops._ext.module()
+        if self.learned_time_parallel and ext is not None and hasattr(ext, "learned_step2") and _ops.TIMER is None:
+            # every step of a chain of hidden states hangs its belief tensor on ONE autograd node
+            # (LearnedChainNode in csrc/torch_ext/step_ext.cpp); the adjacency carries the index of the step
+            # that wrote it, so that the time-parallel backward can follow the chain (or tree) of states
+            lc = self._learned_chain
+            if lc is None or lc[0] is not root or lc[1].executed() or lc[2] != torch.is_grad_enabled():
+                lc = self._learned_chain = (root, ext.LearnedChain(cfg.learned_cpp_handle(), root),
+                                            torch.is_grad_enabled())
+            lin = getattr(adj, "_gcm_lin", None)
+            parent = lin[1] if (lin is not None and lin[0] is lc[1]) else -1
+            mx, n2, a2, cur, c2, idx = ext.learned_step2(lc[1], x, nodes, adj, num_nodes, noise, is_exp, flags, parent)
+            if idx >= 0:
+                a2._gcm_lin = (lc[1], idx)
+        elif gated is not None:
             is_head = link is None or link[5] is not root
             dchain = getattr(adj, "_gcm_dchain", None) if not is_head else None
             if dchain is None:
@@ -653,7 +672,8 @@ class DenseGCM(torch.nn.Module):
         parameter vector and the C++ host path are runtime caches (rebuilt on the first call)."""
         d = dict(self.__dict__)
         d.update(_plan_cache=None, _fold=None, _noise_pool=None, _token=object(), _cfg_cache={}, _cfg_last=None,
-                 _packed_cache=None, _flags={}, _pending=[], _pinned_pool=[], _ctr=[0], _fast=None)
+                 _packed_cache=None, _flags={}, _pending=[], _pinned_pool=[], _ctr=[0], _fast=None,
+                 _learned_chain=None)
         return d
 
     def forward(

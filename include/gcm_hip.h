@@ -650,6 +650,28 @@ int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const f
                           float* g_params, void* workspace, size_t workspace_bytes, int T, int B,
                           int N, int F, int H1, int H2, gcm_stream_t stream);
 
+/* ---- DenseGCM + LearnedEdge: the backward of a whole chain of steps, time-parallel ----------------------
+ *
+ * With observations that carry no gradient the steps are coupled only through the adjacency, and the
+ * gradient w.r.t. the entries a step wrote collapses to one vector per inserted node,
+ *     D_t = sum over later steps t' in which that node is a live row of dAgg1_t'[its row],
+ *     g_sel_t[j] = dagg2_t . h1_t[j] + D_t . x[j]          (learned.py:96-110, both STEs identities)
+ * so every graph-step is independent given two passes: A) GNN adjoint on the live rows (parameter
+ * gradient, dagg2, dAgg1 per live row), B) D_t by a fixed-order scan of the <= N later steps of the graph,
+ * selection adjoint, edge network recomputed and differentiated.  No [B,N,N] gradient tensor exists.
+ * gcm_learned_step_layout: float offsets {total, adj, mx, h1, agg1, agg2, idx (cur | count_out, int64), soft} of
+ * the buffer one forward step keeps (nodes at 0; what gcm_learned_advance_select_fused +
+ * gcm_dense_gnn2_row_fwd write).  saved_host / gmx_host: HOST arrays of n_steps device pointers, the steps
+ * of ONE chain of hidden states in order; gmx_host[t] == NULL: zero gradient.  params / g_params: GNN
+ * (gcm_dense_gnn2_param_count) | edge network (gcm_learned_mlp_param_count), g_params = g_params_prev
+ * (NULL = 0) + gradient. */
+int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, size_t* out8);
+size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, int F, int H1, int H2);
+int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                     long gmx_stride_b, long gmx_stride_h, const float* params, int act1, int act2,
+                     float eps0, float eps1, const float* g_params_prev, float* g_params, void* workspace,
+                     size_t workspace_bytes, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+
 /* ---- SURVEY 8(f) "next" rows ---------------------------------------------------------- */
 
 /* PositionalEncoding mode="add" (src/gcm/gcm.py:120-131, util.idxs_up_to_including_num_nodes
