@@ -876,10 +876,10 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
   const int cf = tid & 31, cg = tid >> 5;   // column-sum mapping: column cf, row group cg (rows cg, cg + 8, ...)
   const Mlp M = unpack_mlp(mlp, F);
   extern __shared__ float smem[];
-  float* sX = smem;                    // node image [NP][FS]; H0 in the middle of an item
-  float* sP0 = sX + NP * FS;           // scan scratch, then P0 -> gP0
-  float* sP1 = sP0 + NP * FS;          // h1 image, then P1 -> gP1 -> gH0
-  float* sW0b = sP1 + NP * FS;         // [o][f] = W0[o][F + f]
+  float* sX_ = smem;                   // node image [NP][FS]; H0 in the middle of an item
+  float* sP0_ = sX_ + NP * FS;         // scan scratch, then P0 -> gP0
+  float* sP1_ = sP0_ + NP * FS;        // h1 image, then P1 -> gP1 -> gH0
+  float* sW0b = sP1_ + NP * FS;         // [o][f] = W0[o][F + f]
   float* sW0a = sW0b + FP * FS;        // [o][f] = W0[o][f]
   float* sW1 = sW0a + FP * FS;         // [o][f]
   float* sVec = sW1 + FP * FS;         // b0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
@@ -919,6 +919,9 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
 #pragma unroll
   for (int r = 0; r < 16; ++r) { aW1[r] = 0.f; aW0b[r] = 0.f; aW0a[r] = 0.f; }
   float c_w2 = 0.f, c_g1 = 0.f, c_be1 = 0.f, c_b2 = 0.f, c_b1 = 0.f, c_g0 = 0.f, c_be0 = 0.f, c_b0 = 0.f;
+  // Rows >= cur of an item carry a zero gradient: waves whose 32 rows all lie beyond skip their products
+  // and leave whatever the images held - which must be finite (0 x NaN), hence zeroed once.
+  for (int e = tid; e < 3 * NP * FS; e += 256) sX_[e] = 0.f;
   __syncthreads();
 
   const int items = a.n_steps * B;
@@ -927,10 +930,20 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
     const int s = item / B, b = item - s * B;
     const int sg = a.s0 + s;
     const float* base = a.tab.saved[s];
+    int zv = 0, tl = threadIdx.x;
+    // loop-variant copies of the thread index and of the LDS bases: hipcc's LICM otherwise parks the address
+    // arithmetic and predicates of every staging / product phase below (~250 registers) in front of the item
+    // loop, which cost the second workgroup per CU (391 -> 240 registers)
+    asm volatile("" : "+v"(zv), "+v"(tl));
+    const int tid = tl, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5, cf = tid & 31, cg = tid >> 5;
+    float* const sX = sX_ + zv; float* const sP0 = sP0_ + zv; float* const sP1 = sP1_ + zv;
     const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * ((size_t)sg * B + b)]);
     if (cur <= 0) continue;   // no candidate rows: nothing was selected, nothing to differentiate (uniform)
     const float* xg = base + (size_t)b * N * F;
     const float* hg = base + a.o_h1 + (size_t)b * N * H1;
+    const bool wave_on = 32 * wave < cur;      // this wave's rows hold candidates
+    const int jn = cur < N ? cur : N;          // rows with a gradient
+    LSTAMP(14);
     gcm_fused::Stage<NP, FP, false, false> st_x, st_h;
     st_x.load(xg, N, F, F, tid);
     st_h.load(hg, N, H1, H1, tid);
@@ -944,9 +957,14 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
         const int cur2 = a.hdr[2 * it2], L2 = a.hdr[2 * it2 + 1];
         const int r = cur2 - tid;            // its row at step t2 (one roll per step once the graph is full)
         w = cur + tid - cur2;                // rolls since this step
-        if (r >= 0)
-          for (int l = 0; l < L2; ++l)
+        if (r >= 0) {   // the first 8 entries in one round trip (a LearnedEdge row has <= 1/cutoff of them)
+          int e[8];   // (dword-aligned: N need not be a multiple of 4)
+          __builtin_memcpy(e, a.live + it2 * N, sizeof(e));
+#pragma unroll
+          for (int l = 0; l < 8; ++l) slot = (l < L2 && e[l] == r) ? l : slot;
+          for (int l = 8; l < L2; ++l)
             if (a.live[it2 * N + l] == r) slot = l;
+        }
       }
       sSlot[tid] = slot;
       sWc[tid] = w;
@@ -956,6 +974,7 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
     }
     if (tid < 32) sD[32 + tid] = tid < H1 ? a.dagg2[((size_t)sg * B + b) * H1 + tid] : 0.f;
     __syncthreads();
+    LSTAMP(15);
     if (tid < NP) {
       const int w = sWc[tid];
       if (w != NONE) {
@@ -984,6 +1003,7 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
     st_x.store(sX, FS, tid);
     st_h.store(sP1, FS, tid);
     __syncthreads();
+    LSTAMP(16);
     // running sums over the later steps, in time order (fixed order: 8 segments of 16 steps, then the
     // segments): row i of sP0 becomes the sum of the contributions of steps t .. t + i
     {
@@ -1002,6 +1022,7 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
         for (int r = 16 * cg; r < 16 * cg + 16; ++r) sP0[r * FS + cf] += off;
     }
     __syncthreads();
+    LSTAMP(17);
     // ---- g_sel[j] = dagg2 . h1[j] + D^(j) . x[j]   (j < cur): two threads per row ----------------------
     {
       const int row = tid >> 1, half = tid & 1;
@@ -1017,6 +1038,7 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       if (half == 0) sSel[row] = row < cur ? t : 0.f;
     }
     __syncthreads();
+    LSTAMP(18);
     if (wave == 0) {   // softmax adjoint (tau = 1); both straight-through estimators are identities
       const float* soft = base + a.o_soft + (size_t)b * N;
       float p[2], g[2], dot = 0.f;
@@ -1033,32 +1055,36 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       for (int c = 0; c < 2; ++c) sGl[lane + 64 * c] = p[c] * (g[c] - dot);
     }
     // ---- edge network recomputed: P0 = X W0b^T + (W0a x_cur + b0) ---------------------------------------
-    {
+    if (wave_on) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      mma32(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, 32, li, lh);
-      mma32(acc, sX + cur * FS, 0, 1, sW0a, 1, FS, 32, li, lh);     // every row gets W0a x_cur
+      gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, li, lh);
+      gcm_fused::mma32b<32>(acc, sX + cur * FS, 0, 1, sW0a, 1, FS, li, lh);     // every row gets W0a x_cur
 #pragma unroll
       for (int r = 0; r < 16; ++r) sP0[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
     }
     __syncthreads();   // (sP0's scan scratch was consumed two barriers ago)
+    LSTAMP(19);
     relu_ln_rows_to(sP0, sX, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);   // H0 over the node image
     __syncthreads();
-    {
+    LSTAMP(20);
+    if (wave_on) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      mma32(acc, sX + 32 * wave * FS, FS, 1, sW1, 1, FS, 32, li, lh);
+      gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW1, 1, FS, li, lh);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
     }
     __syncthreads();
+    LSTAMP(21);
     relu_ln_rows(sP1, tid, F, nullptr, nullptr, eps1, sMu1, sRs1, /*write=*/false);
     __syncthreads();
+    LSTAMP(22);
     {   // dw2, dgamma1, dbeta1, db2: this thread's rows of its column
       const float w2f = sVec[6 * FP + cf], g1f = sVec[4 * FP + cf], be1f = sVec[5 * FP + cf];
-      for (int j = cg; j < N; j += 8) {
+      for (int j = cg; j < jn; j += 8) {
         const float gl = sGl[j];
         const float v = sP1[j * FS + cf];
         const float xh = ((v > 0.f ? v : 0.f) - sMu1[j]) * sRs1[j];
@@ -1069,24 +1095,29 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       }
     }
     __syncthreads();
+    LSTAMP(23);
     relu_ln_rows_bwd(sP1, tid, F, sMu1, sRs1,
                      [&](int j, int f) { return sGl[j] * sVec[6 * FP + f] * sVec[4 * FP + f]; });   // gP1
     __syncthreads();
-    for (int j = cg; j < N; j += 8) c_b1 += sP1[j * FS + cf];
+    LSTAMP(24);
+    for (int j = cg; j < jn; j += 8) c_b1 += sP1[j * FS + cf];
     // dW1 += gP1^T H0 (K = this wave's rows);  gH0 = gP1 W1
-    mma32(aW1, sP1 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, 32, li, lh);
     f32x16 gh;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gh[r] = 0.f;
-    mma32(gh, sP1 + 32 * wave * FS, FS, 1, sW1, FS, 1, 32, li, lh);
+    if (wave_on) {
+      gcm_fused::mma32b<32>(aW1, sP1 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, li, lh);
+      gcm_fused::mma32b<32>(gh, sP1 + 32 * wave * FS, FS, 1, sW1, FS, 1, li, lh);
+    }
     st_x.load(xg, N, F, F, tid);   // the node image again (H0 is done with after this phase)
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = gh[r];   // gH0
     st_x.store(sX, FS, tid);
     __syncthreads();
+    LSTAMP(25);
     {   // dgamma0, dbeta0
-      for (int j = cg; j < N; j += 8) {
+      for (int j = cg; j < jn; j += 8) {
         const float v = sP0[j * FS + cf];
         const float xh = ((v > 0.f ? v : 0.f) - sMu0[j]) * sRs0[j];
         const float ghv = sP1[j * FS + cf];
@@ -1095,13 +1126,18 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       }
     }
     __syncthreads();
+    LSTAMP(26);
     relu_ln_rows_bwd(sP0, tid, F, sMu0, sRs0, [&](int j, int f) { return sP1[j * FS + f] * sVec[2 * FP + f]; });   // gP0
     __syncthreads();
-    for (int j = cg; j < N; j += 8) c_b0 += sP0[j * FS + cf];
+    LSTAMP(27);
+    for (int j = cg; j < jn; j += 8) c_b0 += sP0[j * FS + cf];
     // dW0b += gP0^T X;  dW0a += gP0^T (x_cur in every row)
-    mma32(aW0b, sP0 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, 32, li, lh);
-    mma32(aW0a, sP0 + 32 * wave * FS, 1, FS, sX + cur * FS, 0, 1, 32, li, lh);
+    if (wave_on) {
+      gcm_fused::mma32b<32>(aW0b, sP0 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, li, lh);
+      gcm_fused::mma32b<32>(aW0a, sP0 + 32 * wave * FS, 1, FS, sX + cur * FS, 0, 1, li, lh);
+    }
     __syncthreads();   // the images are rewritten by the next item
+    LSTAMP(28);
   }
 
   // ---- one slab per workgroup (packed edge-network layout), waves and row groups summed in fixed order ---
@@ -1109,7 +1145,7 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
   float* slab = slabs + (size_t)blockIdx.x * Pm;
   const int o_b0 = 2 * F * F, o_g0 = o_b0 + F, o_be0 = o_g0 + F, o_w1 = o_be0 + F, o_b1 = o_w1 + F * F;
   const int o_g1 = o_b1 + F, o_be1 = o_g1 + F, o_w2 = o_be1 + F, o_b2 = o_w2 + F;
-  float* sR = sP0;   // [4][1024]
+  float* sR = sP0_;   // [4][1024]
   auto tile_out = [&](const f32x16& acc, int row_stride, int col0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
