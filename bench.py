@@ -497,7 +497,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     if c["selector"] == "euclid" and world > 1:
         raise SystemExit("cfg3: EuclideanEdge averages over the whole batch (distance.py:48-49); a sharded run "
                          "needs EuclideanEdge(shard_group=...) - run it on one GPU")
-    can_donate = c["selector"] != "learned"
+    can_donate = True
     mem, gnn, sel = build_memory(device, donate=can_donate, selector=c["selector"], cfg=c)
     mods = [gnn] + ([sel] if c["selector"] == "learned" else [])
     bucket = parallel.GradBucket(*mods)

@@ -186,14 +186,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 // loads ride with the edge network's, its stores drain under the two GEMMs), the observation goes into
 // row cur, cur / count come out; N % 4 == 0 and F % 4 == 0.  Otherwise nodes / adj hold the advanced
 // state already (gcm_state_advance_fwd ran) and cur_idx is read.
-template <bool ADVANCE>
+// MODE 2 (round 3, donated state): as ADVANCE, but `nodes_out` / `adj` ARE `nodes_in` / `adj_in` - the state is
+// advanced in place.  Without overflow nothing is copied: the node rows are read once for the edge
+// network's image, the observation lands in row cur, the sampled entries in row cur of the adjacency; on
+// overflow the roll happens in place (every load lands before the first store).  What the time-parallel
+// backward needs of the state goes into the step's record: the node matrix after the insert (`snap`, 4 MB
+// at cfg5 instead of the 21 MB state copy) and row cur of the adjacency (`row_out`).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_learned_select(
-    const float* __restrict__ nodes_c, float* __restrict__ adj, const int64_t* __restrict__ cur_idx_c,
+    const float* __restrict__ nodes_c, float* adj, const int64_t* __restrict__ cur_idx_c,
     const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp, float eps0,
     float eps1, float cutoff, float* __restrict__ soft, int N, int F, const float* __restrict__ obs,
-    const float* __restrict__ nodes_in, const float* __restrict__ adj_in,
-    const int64_t* __restrict__ count_in, float* __restrict__ nodes_out, int64_t* __restrict__ cur_out,
-    int64_t* __restrict__ count_out, uint32_t* __restrict__ flags) {
+    const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes_out,
+    int64_t* __restrict__ cur_out, int64_t* count_out, uint32_t* __restrict__ flags,
+    float* __restrict__ snap, float* __restrict__ row_out) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
+  constexpr bool ADVANCE = MODE != 0, DONATE = MODE == 2;
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   int cur;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     cur = c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64);
     if (tid == 0) {
       cur_out[b] = cur;
-      count_out[b] = cur + 1;
+      if (!DONATE) count_out[b] = cur + 1;   // (donated: count_out IS count_in, which every wave is reading - below)
       const uint32_t f = (wrap ? GCM_FLAG_WRAPPED : 0u) | ((n_in < 0 || n_in > N) ? GCM_FLAG_BAD_COUNT : 0u);
       if (f) atomicOr(flags, f);
     }
@@ -236,10 +243,19 @@ __global__ __launch_bounds__(256) void k_learned_select(
     const float* ag_in = adj_in + (size_t)b * N * N;
     const float* ng_in = nodes_in + (size_t)b * N * F;
     float4 ca[ADJ_PER], cn[NODE_PER];
-    if (wrap) gcm_state::load_copy<ADJ_PER, NODE_PER, true>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
-    else gcm_state::load_copy<ADJ_PER, NODE_PER, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
-    asm volatile("" ::: "memory");
     const int lim_n = N * F4;
+    if (wrap) {
+      gcm_state::load_copy<ADJ_PER, NODE_PER, true>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
+    } else if (DONATE) {   // in place, no overflow: only the node rows are read (for the image)
+#pragma unroll
+      for (int i = 0; i < NODE_PER; ++i) {
+        const int e4 = min(tid + 256 * i, lim_n - 1);
+        cn[i] = *reinterpret_cast<const float4*>(ng_in + 4 * e4);
+      }
+    } else {
+      gcm_state::load_copy<ADJ_PER, NODE_PER, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NODE_PER; ++i) {
       const int e4 = tid + 256 * i, r = e4 / F4, c = (e4 - r * F4) * 4;
@@ -257,7 +273,21 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (r >= N || c >= F) sX[r * FS + c] = 0.f;
     }
     float* ng_out = nodes_out + (size_t)b * N * F;
-    gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, wrap);
+    if (DONATE) {
+      float* sn = snap + (size_t)b * N * F;   // the node matrix after the insert, for the record
+#pragma unroll
+      for (int i = 0; i < NODE_PER; ++i) {
+        const int e4 = tid + 256 * i;
+        if (e4 < lim_n) *reinterpret_cast<float4*>(sn + e4 * 4) = cn[i];
+      }
+      if (wrap) {   // source and destination alias: every load lands before the first store
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, true);
+      }
+    } else {
+      gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, wrap);
+    }
     // the inserted node: store_copy's roll fix-up zeroes the last row - the thread that owns a piece of
     // row cur writes the observation behind its own copy store (same thread, same address: ordered)
 #pragma unroll
@@ -309,6 +339,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   // wave 0 writes the sampled entries of that row below: released here, ahead of the barrier
   if (ADVANCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (waits for this wave's stores: cheap - they were issued two GEMMs ago; an agent-scope release would write the L2 back)
   __syncthreads();
+  if (DONATE && tid == 255) count_out[b] = cur + 1;   // every wave read count_in long ago
   if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
     float z[2], m = -INFINITY;
 #pragma unroll
@@ -343,7 +374,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
           float old;
           if (ADVANCE) old = wrap ? 0.f : adj_in[((size_t)b * N + cur) * N + j];
           else old = row[j];
-          row[j] = (edge + old > 0.f) ? 1.f : 0.f;               // learned.py:108-110
+          const float nv = (edge + old > 0.f) ? 1.f : 0.f;       // learned.py:108-110
+          row[j] = nv;
+          if (DONATE) row_out[(size_t)b * N + j] = nv;
+        } else if (DONATE) {
+          row_out[(size_t)b * N + j] = 0.f;
         }
       }
     }
@@ -1206,12 +1241,12 @@ extern "C" int gcm_learned_select_fused(const float* nodes, float* adj, const in
   GCM_REQUIRE(nodes && adj && cur_idx && noise && mlp_params && soft && B > 0);
   if (!gcm_learned_step_supported(N, F, 1, 1)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<false>;
+  auto kern = gcm_learned::k_learned_select<0>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, adj, cur_idx, noise,
                      noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr,
-                     (int64_t*)nullptr, (int64_t*)nullptr, (uint32_t*)nullptr);
+                     (int64_t*)nullptr, (int64_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr);
   return gcm_launch_status();
 }
 
@@ -1229,11 +1264,34 @@ extern "C" int gcm_learned_advance_select_fused(const float* obs, const float* n
   GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
   if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<true>;
+  auto kern = gcm_learned::k_learned_select<1>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F,
-                     obs, nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags);
+                     obs, nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,
+                     (float*)nullptr);
+  return gcm_launch_status();
+}
+
+/* gcm_learned_advance_select_fused on a DONATED state: nodes / adj / count are advanced in place (count_out may
+ * alias count_in); nodes_snap [B,N,F] receives the node matrix after the insert and adj_row [B,N] row cur of the
+ * adjacency after the selection - what gcm_learned_bptt reads of the state (gcm_learned_step_layout, compact). */
+extern "C" int gcm_learned_advance_select_inplace(const float* obs, float* nodes, float* adj, const int64_t* count_in,
+                                                  const float* noise, int noise_is_exp, const float* mlp_params,
+                                                  float eps0, float eps1, float cutoff, int64_t* cur_out,
+                                                  int64_t* count_out, float* soft, float* nodes_snap,
+                                                  float* adj_row, uint32_t* flags, int B, int N, int F,
+                                                  gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && adj && count_in && noise && mlp_params && cur_out && count_out && soft && nodes_snap &&
+              adj_row && flags && B > 0);
+  if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
+  constexpr size_t lds = gcm_learned::lds_select();
+  auto kern = gcm_learned::k_learned_select<2>;
+  gcm_allow_dynamic_lds((const void*)kern, lds);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
+                     (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, obs,
+                     (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags, nodes_snap,
+                     adj_row);
   return gcm_launch_status();
 }
 
@@ -1259,10 +1317,11 @@ extern "C" int gcm_learned_step_bwd(const float* g_mx, const float* nodes, const
 /* ---- time-parallel backward of a chain of fused LearnedEdge steps (see k_learned_bptt_b) -------------- */
 static inline size_t lrn_pad64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, size_t* out8) {
+extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int compact, size_t* out8) {
   GCM_REQUIRE(out8 && B > 0 && N > 0 && F > 0 && H1 > 0 && H2 > 0);
   // nodes | adj | mx | h1 | agg1 | agg2 | cur, count_out (2 B int64) | soft      (64-float aligned sections)
-  const size_t n_nodes = lrn_pad64((size_t)B * N * F), n_adj = lrn_pad64((size_t)B * N * N);
+  // compact (donated state): `adj` holds row cur only, [B, N]
+  const size_t n_nodes = lrn_pad64((size_t)B * N * F), n_adj = lrn_pad64((size_t)B * N * (compact ? 1 : N));
   const size_t n_mx = lrn_pad64((size_t)B * H2), n_h1 = lrn_pad64((size_t)B * N * H1), n_agg2 = lrn_pad64((size_t)B * H1);
   out8[1] = n_nodes;                 // o_adj
   out8[2] = out8[1] + n_adj;         // o_mx
@@ -1296,7 +1355,7 @@ extern "C" size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, in
  * packed.  g_params [Pg + Pm] = g_params_prev (NULL = 0) + the gradient. */
 extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                                 long gmx_stride_b, long gmx_stride_h, const float* params, int act1, int act2,
-                                float eps0, float eps1, const float* g_params_prev, float* g_params,
+                                float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
                                 void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                                 gcm_stream_t stream) {
   GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace && n_steps > 0 && B > 0);
@@ -1314,7 +1373,7 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
   float* da = (float*)(live + lrn_pad64(TB * N));
   float* dagg2 = da + lrn_pad64(TB * N * F);
   size_t lay[8];
-  gcm_learned_step_layout(B, N, F, H1, H2, lay);
+  gcm_learned_step_layout(B, N, F, H1, H2, compact, lay);
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   // pass A: every step, every graph (the arrays pass B scans must be complete before it starts)
@@ -1327,7 +1386,7 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
       tab.saved[i] = saved_host[s0 + i];
       tab.gmx[i] = gmx_host[s0 + i];
     }
-    gcm_rows::LearnedSrc src{lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], params, hdr, live, da, dagg2, s0};
+    gcm_rows::LearnedSrc src{lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], params, hdr, live, da, dagg2, s0, compact};
     const int rc = gcm_rows::launch_bptt_learned(stream, per_a, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,
                                                  w_root2, act1, act2, slabs_a + (size_t)c * per_a * Pg, src, B, N,
                                                  F, H1, H2);

@@ -57,6 +57,7 @@ struct LrnSrc {
   float* da;         // [T, B, N, F]
   float* dagg2;      // [T, B, H1]
   int s0;            // path index of this launch's first step
+  int adj_compact;   // the buffers hold row cur of the adjacency only ([B, N])
 };
 
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       const int64_t c64 = src.cur[gi];
       cur = __builtin_amdgcn_readfirstlane(c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64));
       y = src.mx[gi * H2 + oc];
-      const float* arow = src.adj + (gi * N + cur) * N;
+      const float* arow = (MODE == 2 && lrn.adj_compact) ? src.adj + gi * N : src.adj + (gi * N + cur) * N;
       a0 = arow[lane < N ? lane : N - 1];
       a1 = arow[lane + 64 < N ? lane + 64 : N - 1];
       m0 = __ballot(lane < N && (a0 != 0.f || lane == cur));
@@ -318,7 +319,7 @@ int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_step
                         const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,
                         const LearnedSrc& src, int B, int N, int F, int H1, int H2) {
   LrnSrc l{src.o_adj, src.o_mx, src.o_h1, src.o_agg1, src.o_agg2, src.o_idx, src.w_rel1,
-           src.hdr,   src.live, src.da,   src.dagg2,  src.s0};
+           src.hdr,   src.live, src.da,   src.dagg2,  src.s0, src.adj_compact};
   return launch_bptt<32, 32, 32, 2>((hipStream_t)stream, grid, tab, Hist{}, n_steps, gmx_sb, gmx_sh, w_rel2,
                                     w_root2, act1, act2, SavedLayout{}, slabs, B, N, F, H1, H2, 0, l);
 }

@@ -34,6 +34,7 @@ struct LearnedSrc {
   float* da;
   float* dagg2;
   int s0;
+  int adj_compact;   // the step buffers hold row cur of the adjacency only ([B, N] at o_adj)
 };
 int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh,
                         const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,

@@ -675,6 +675,7 @@ struct LearnedChainNode : public torch::autograd::Node {
   at::Tensor packed;            // detached
   LearnedCfg* cfg = nullptr;
   bool executed = false, released = false;
+  bool compact = false;         // the steps ran on a donated state: their buffers hold row cur of the adjacency only
 
   variable_list apply(variable_list&& grads) override {
     executed = true;
@@ -735,7 +736,7 @@ struct LearnedChainNode : public torch::autograd::Node {
       at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
       at::Tensor res = at::empty({cfg->P_total}, packed.options());
       check(gcm_learned_bptt(sv.data(), gm.data(), T, (long)sb, (long)sh, packed.data_ptr<float>(), cfg->act1,
-                             cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
+                             cfg->act2, (float)cfg->eps0, (float)cfg->eps1, compact ? 1 : 0,
                              prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
                              ws.data_ptr(), ws_bytes, B, N, F, H1, H2, stream),
             "gcm_learned_bptt");
@@ -755,12 +756,16 @@ struct LearnedChain {   // one per packed parameter vector
   std::shared_ptr<LearnedChainNode> node;
   LearnedCfg* cfg;
   at::Tensor packed;
-  LearnedChain(int64_t cfg_handle, const at::Tensor& packed_) : cfg(reinterpret_cast<LearnedCfg*>(cfg_handle)), packed(packed_) {
+  bool donate;
+  LearnedChain(int64_t cfg_handle, const at::Tensor& packed_, bool donate_)
+      : cfg(reinterpret_cast<LearnedCfg*>(cfg_handle)), packed(packed_), donate(donate_) {
     TORCH_CHECK(packed.is_cuda() && packed.is_contiguous() && packed.numel() >= cfg->P_total);
+    if ((cfg->N & 3) || (cfg->F & 3)) donate = false;   // (the in-place kernel moves 16-byte pieces)
     if (at::GradMode::is_enabled() && packed.requires_grad()) {
       node = std::shared_ptr<LearnedChainNode>(new LearnedChainNode(), torch::autograd::deleteNode);
       node->packed = packed.detach();
       node->cfg = cfg;
+      node->compact = donate;
       node->set_next_edges(torch::autograd::collect_next_edges(packed));
     }
   }
@@ -787,55 +792,88 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
                   noise.numel() == B * N,
               "learned_step: hidden state, observation and noise shapes disagree");
   const bool need_bwd = chain.node != nullptr && at::GradMode::is_enabled();
-  const Layout L(B, N, F, H1, H2, need_bwd);
-  const int64_t o_soft = L.total;
-  if (need_bwd) {
-    size_t lay[8];
-    check(gcm_learned_step_layout((int)B, N, F, H1, H2, lay), "gcm_learned_step_layout");
-    TORCH_CHECK((int64_t)lay[1] == L.o_adj && (int64_t)lay[2] == L.o_mx && (int64_t)lay[3] == L.o_h1 &&
-                    (int64_t)lay[4] == L.o_agg1 && (int64_t)lay[5] == L.o_agg2 && (int64_t)lay[6] == L.o_idx &&
-                    (int64_t)lay[7] == o_soft,
-                "learned_step: buffer layouts of the host node and the library disagree");
-    TORCH_CHECK(parent < (int64_t)chain.node->recs.size());
-  }
-  at::Tensor buf = at::empty({L.total + pad64(B * (int64_t)N)}, obs.options());
-  float* base = buf.data_ptr<float>();
-  int64_t* ib = reinterpret_cast<int64_t*>(base + L.o_idx);
+  const bool donate = chain.donate;
   uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
   const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(obs.get_device()).stream());
   const float* pk = chain.packed.data_ptr<float>();
-  if ((N & 3) == 0 && (F & 3) == 0) {
-    check(gcm_learned_advance_select_fused(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
-                                           count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp,
-                                           pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base,
-                                           base + L.o_adj, ib, ib + B, base + o_soft, fl, (int)B, N, F, st),
-          "gcm_learned_advance_select_fused");
-  } else {
-    check(gcm_state_advance_fwd(nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(), nullptr,
-                                count_in.data_ptr<int64_t>(), obs.data_ptr<float>(), base, base + L.o_adj, nullptr, ib,
-                                ib + B, fl, (int)B, N, F, st),
-          "gcm_state_advance_fwd");
-    check(gcm_learned_select_fused(base, base + L.o_adj, ib, noise.data_ptr<float>(), (int)noise_is_exp, pk + cfg->P,
-                                   (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base + o_soft, (int)B, N, F,
-                                   st),
-          "gcm_learned_select_fused");
-  }
   const float* w_rel1 = pk;
   const float* w_root1 = w_rel1 + (size_t)H1 * F;
   const float* b1 = w_root1 + (size_t)H1 * F;
   const float* w_rel2 = b1 + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   const float* b2 = w_root2 + (size_t)H2 * H1;
-  check(gcm_dense_gnn2_row_fwd(base, base + L.o_adj, ib, w_rel1, (cfg->has_bias & 1) ? b1 : nullptr, w_root1, cfg->act1,
-                               w_rel2, (cfg->has_bias & 2) ? b2 : nullptr, w_root2, cfg->act2, base + L.o_mx,
-                               need_bwd ? base + L.o_h1 : nullptr, need_bwd ? base + L.o_agg1 : nullptr,
-                               need_bwd ? base + L.o_agg2 : nullptr, fl, (int)B, N, F, H1, H2, st),
-        "gcm_dense_gnn2_row_fwd");
-  at::Tensor nodes_out = alias_of(buf, 0, {B, N, F}, buf.dtype());
-  at::Tensor adj_out = alias_of(buf, L.o_adj, {B, N, N}, buf.dtype());
-  at::Tensor mx = alias_of(buf, L.o_mx, {B, H2}, buf.dtype());
-  at::Tensor cur = alias_of(buf, L.o_idx / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
-  at::Tensor count_out = alias_of(buf, L.o_idx / 2 + B, {B}, caffe2::TypeMeta::Make<int64_t>());
+  if (need_bwd) TORCH_CHECK(parent < (int64_t)chain.node->recs.size());
+  at::Tensor buf, nodes_out, adj_out, mx, cur, count_out;
+  if (donate) {
+    // the state is advanced in place; the step's buffer keeps the node matrix after the insert, row cur of
+    // the adjacency, the GNN's layers and the softmax row (gcm_learned_step_layout, compact)
+    TORCH_CHECK(nodes_in_.is_contiguous() && adj_in_.is_contiguous(),
+                "donate_state=True needs contiguous hidden-state tensors");
+    size_t lay[8];
+    check(gcm_learned_step_layout((int)B, N, F, H1, H2, 1, lay), "gcm_learned_step_layout");
+    buf = at::empty({(int64_t)lay[0]}, obs.options());
+    float* base = buf.data_ptr<float>();
+    int64_t* ib = reinterpret_cast<int64_t*>(base + lay[6]);
+    float* nodes = nodes_in.data_ptr<float>();
+    float* adj = adj_in.data_ptr<float>();
+    check(gcm_learned_advance_select_inplace(obs.data_ptr<float>(), nodes, adj, count_in.data_ptr<int64_t>(),
+                                             noise.data_ptr<float>(), (int)noise_is_exp, pk + cfg->P,
+                                             (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, ib,
+                                             count_in.data_ptr<int64_t>(), base + lay[7], base, base + lay[1], fl,
+                                             (int)B, N, F, st),
+          "gcm_learned_advance_select_inplace");
+    check(gcm_dense_gnn2_row_fwd(nodes, adj, ib, w_rel1, (cfg->has_bias & 1) ? b1 : nullptr, w_root1, cfg->act1,
+                                 w_rel2, (cfg->has_bias & 2) ? b2 : nullptr, w_root2, cfg->act2, base + lay[2],
+                                 base + lay[3], base + lay[4], base + lay[5], fl, (int)B, N, F, H1, H2, st),
+          "gcm_dense_gnn2_row_fwd");
+    nodes_out = nodes_in_;
+    adj_out = adj_in_;
+    count_out = count_in;
+    mx = alias_of(buf, (int64_t)lay[2], {B, H2}, buf.dtype());
+    cur = alias_of(buf, (int64_t)lay[6] / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
+  } else {
+    const Layout L(B, N, F, H1, H2, need_bwd);
+    const int64_t o_soft = L.total;
+    if (need_bwd) {
+      size_t lay[8];
+      check(gcm_learned_step_layout((int)B, N, F, H1, H2, 0, lay), "gcm_learned_step_layout");
+      TORCH_CHECK((int64_t)lay[1] == L.o_adj && (int64_t)lay[2] == L.o_mx && (int64_t)lay[3] == L.o_h1 &&
+                      (int64_t)lay[4] == L.o_agg1 && (int64_t)lay[5] == L.o_agg2 && (int64_t)lay[6] == L.o_idx &&
+                      (int64_t)lay[7] == o_soft,
+                  "learned_step: buffer layouts of the host node and the library disagree");
+    }
+    buf = at::empty({L.total + pad64(B * (int64_t)N)}, obs.options());
+    float* base = buf.data_ptr<float>();
+    int64_t* ib = reinterpret_cast<int64_t*>(base + L.o_idx);
+    if ((N & 3) == 0 && (F & 3) == 0) {
+      check(gcm_learned_advance_select_fused(obs.data_ptr<float>(), nodes_in.data_ptr<float>(),
+                                             adj_in.data_ptr<float>(), count_in.data_ptr<int64_t>(),
+                                             noise.data_ptr<float>(), (int)noise_is_exp, pk + cfg->P,
+                                             (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base,
+                                             base + L.o_adj, ib, ib + B, base + o_soft, fl, (int)B, N, F, st),
+            "gcm_learned_advance_select_fused");
+    } else {
+      check(gcm_state_advance_fwd(nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(), nullptr,
+                                  count_in.data_ptr<int64_t>(), obs.data_ptr<float>(), base, base + L.o_adj, nullptr,
+                                  ib, ib + B, fl, (int)B, N, F, st),
+            "gcm_state_advance_fwd");
+      check(gcm_learned_select_fused(base, base + L.o_adj, ib, noise.data_ptr<float>(), (int)noise_is_exp,
+                                     pk + cfg->P, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff,
+                                     base + o_soft, (int)B, N, F, st),
+            "gcm_learned_select_fused");
+    }
+    check(gcm_dense_gnn2_row_fwd(base, base + L.o_adj, ib, w_rel1, (cfg->has_bias & 1) ? b1 : nullptr, w_root1,
+                                 cfg->act1, w_rel2, (cfg->has_bias & 2) ? b2 : nullptr, w_root2, cfg->act2,
+                                 base + L.o_mx, need_bwd ? base + L.o_h1 : nullptr,
+                                 need_bwd ? base + L.o_agg1 : nullptr, need_bwd ? base + L.o_agg2 : nullptr, fl,
+                                 (int)B, N, F, H1, H2, st),
+          "gcm_dense_gnn2_row_fwd");
+    nodes_out = alias_of(buf, 0, {B, N, F}, buf.dtype());
+    adj_out = alias_of(buf, L.o_adj, {B, N, N}, buf.dtype());
+    mx = alias_of(buf, L.o_mx, {B, H2}, buf.dtype());
+    cur = alias_of(buf, L.o_idx / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
+    count_out = alias_of(buf, L.o_idx / 2 + B, {B}, caffe2::TypeMeta::Make<int64_t>());
+  }
   int64_t index = -1;
   if (need_bwd) {
     const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
@@ -892,7 +930,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("handle", [](LearnedCfg& c) { return reinterpret_cast<int64_t>(&c); });
   m.def("learned_step", &learned_step);
   pybind11::class_<LearnedChain>(m, "LearnedChain")
-      .def(pybind11::init<int64_t, const at::Tensor&>())
+      .def(pybind11::init<int64_t, const at::Tensor&, bool>())
+      .def("donates", [](LearnedChain& c) { return c.donate; })
       .def("executed", &LearnedChain::executed)
       .def("recording", &LearnedChain::recording)
       .def("steps", &LearnedChain::steps);

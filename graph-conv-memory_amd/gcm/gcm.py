@@ -556,13 +556,21 @@ class DenseGCM(torch.nn.Module):
             # that wrote it, so that the time-parallel backward can follow the chain (or tree) of states
             lc = self._learned_chain
             if lc is None or lc[0] is not root or lc[1].executed() or lc[2] != torch.is_grad_enabled():
-                lc = self._learned_chain = (root, ext.LearnedChain(cfg.learned_cpp_handle(), root),
+                lc = self._learned_chain = (root, ext.LearnedChain(cfg.learned_cpp_handle(), root,
+                                                                   bool(self.donate_state)),
                                             torch.is_grad_enabled())
             lin = getattr(adj, "_gcm_lin", None)
             parent = lin[1] if (lin is not None and lin[0] is lc[1]) else -1
             mx, n2, a2, cur, c2, idx = ext.learned_step2(lc[1], x, nodes, adj, num_nodes, noise, is_exp, flags, parent)
             if idx >= 0:
                 a2._gcm_lin = (lc[1], idx)
+            if lc[1].donates():      # the state was advanced in place: the caller's own tuple
+                n2._gcm_link = (self._token, a2, cfg, flags, None, root, x.shape, weights, c2)
+                if self.mutate_num_nodes_on_overflow:
+                    raise NotImplementedError("mutate_num_nodes_on_overflow with donate_state")
+                if self.finite_check != "off":
+                    self._poll(flags)
+                return mx, hidden
         elif gated is not None:
             is_head = link is None or link[5] is not root
             dchain = getattr(adj, "_gcm_dchain", None) if not is_head else None

@@ -661,16 +661,26 @@ int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const f
  * selection adjoint, edge network recomputed and differentiated.  No [B,N,N] gradient tensor exists.
  * gcm_learned_step_layout: float offsets {total, adj, mx, h1, agg1, agg2, idx (cur | count_out, int64), soft} of
  * the buffer one forward step keeps (nodes at 0; what gcm_learned_advance_select_fused +
- * gcm_dense_gnn2_row_fwd write).  saved_host / gmx_host: HOST arrays of n_steps device pointers, the steps
+ * gcm_dense_gnn2_row_fwd write); compact: the `adj` section is row cur only, [B, N].  saved_host / gmx_host: HOST arrays of n_steps device pointers, the steps
  * of ONE chain of hidden states in order; gmx_host[t] == NULL: zero gradient.  params / g_params: GNN
  * (gcm_dense_gnn2_param_count) | edge network (gcm_learned_mlp_param_count), g_params = g_params_prev
  * (NULL = 0) + gradient. */
-int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, size_t* out8);
+int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int compact, size_t* out8);
 size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, int F, int H1, int H2);
 int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                      long gmx_stride_b, long gmx_stride_h, const float* params, int act1, int act2,
-                     float eps0, float eps1, const float* g_params_prev, float* g_params, void* workspace,
-                     size_t workspace_bytes, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+                     float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
+                     void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                     gcm_stream_t stream);
+/* The forward's first kernel on a DONATED state (advanced in place, nothing copied without overflow):
+ * nodes_snap [B,N,F] and adj_row [B,N] are the sections `nodes` / `adj` of the COMPACT step buffer
+ * (gcm_learned_step_layout(..., compact = 1): row cur of the adjacency only).  gcm_dense_gnn2_row_fwd
+ * then runs on the state itself. */
+int gcm_learned_advance_select_inplace(const float* obs, float* nodes, float* adj, const int64_t* count_in,
+                                       const float* noise, int noise_is_exp, const float* mlp_params,
+                                       float eps0, float eps1, float cutoff, int64_t* cur_out,
+                                       int64_t* count_out, float* soft, float* nodes_snap, float* adj_row,
+                                       uint32_t* flags, int B, int N, int F, gcm_stream_t stream);
 
 /* ---- SURVEY 8(f) "next" rows ---------------------------------------------------------- */
 

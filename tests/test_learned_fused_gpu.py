@@ -58,7 +58,7 @@ def test_learned_fused_matches_reference_vectors():
         torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
 
 
-def _pair(F, H, N, k, seed):
+def _pair(F, H, N, k, seed, donate=False):
     from gcm.gcm import DenseGCM
     from gcm.edge_selectors.learned import LearnedEdge
     torch.manual_seed(seed)
@@ -71,13 +71,13 @@ def _pair(F, H, N, k, seed):
     sel = LearnedEdge(F, num_edge_samples=k)
     sel.edge_network.load_state_dict(net.state_dict())
     sel = sel.to(DEV)
-    return ref, net, g, sel, DenseGCM(g, edge_selectors=sel, graph_size=N)
+    return ref, net, g, sel, DenseGCM(g, edge_selectors=sel, graph_size=N, donate_state=donate)
 
 
-def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3):
+def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False):
     """product on the whole batch, oracle on the graphs `pick`, same injected gumbel noise; the loss
     weights only the picked graphs."""
-    ref, net, g, sel, mem = _pair(F, H, N, k, seed)
+    ref, net, g, sel, mem = _pair(F, H, N, k, seed, donate)
     gen = torch.Generator().manual_seed(seed + 1)
     obs = torch.rand(T, B, F, generator=gen)
     noise = -torch.empty(T, B, N).exponential_(generator=gen).log()
@@ -103,12 +103,15 @@ def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3):
     pstep = {"t": 0}
     sel.noise_fn = lambda like: noise[pstep["t"]].to(DEV)
     hidden = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
+    h_first = (hidden[0].data_ptr(), hidden[1].data_ptr())
     outs = []
     for t in range(T):
         pstep["t"] = t
         mx, hidden = mem(obs[t].to(DEV), hidden)
         outs.append(mx)
     assert _taken(mem)
+    if donate and N % 4 == 0 and F % 4 == 0:       # advanced in place: the caller's own tensors all the way
+        assert hidden[0].data_ptr() == h_first[0] and hidden[1].data_ptr() == h_first[1]
     out_d = torch.stack(outs)
     (out_d[:, pick] * wgt.to(DEV)).sum().backward()
     mem.check_flags()
@@ -127,12 +130,14 @@ def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3):
     return hidden
 
 
+@pytest.mark.parametrize("donate", [False, True])
 @pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2)])
-def test_learned_fused_vs_oracle(B, N, F, H, T, k):
-    """ragged shapes, staggered starts, overflow crossings (the chain buffer rolls with the state)"""
+def test_learned_fused_vs_oracle(B, N, F, H, T, k, donate):
+    """ragged shapes, staggered starts, overflow crossings; functional and donated state (the state advanced
+    in place, the step's record keeps the node matrix and row cur of the adjacency)"""
     torch.manual_seed(B + N)
     count0 = torch.randint(0, N + 1, (B,))
-    _run_both(B, N, F, H, T, k, seed=B * 7 + N, count0=count0, pick=list(range(B)))
+    _run_both(B, N, F, H, T, k, seed=B * 7 + N, count0=count0, pick=list(range(B)), donate=donate)
 
 
 def test_learned_fused_cfg5_size_slice():
@@ -154,6 +159,8 @@ def test_learned_fused_cfg5_size_long_rollout():
     count0 = torch.randint(108, 127, (B,), generator=gen)
     hidden = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254])
     assert int(hidden[3].min()) == N          # every graph is in steady-state overflow by the end
+    hidden = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254], donate=True)
+    assert int(hidden[3].min()) == N
 
 
 def test_learned_noise_pool_statistics_and_equivalence():
