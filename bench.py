@@ -565,6 +565,27 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                     _, hidden = mem_e(obs[t], hidden)
         variants["forward_only_eager_donated"] = world * B * T * side / timed(fwd_only, side, 1)
         mem_e.check_flags()
+        # observations that need a gradient (an encoder in front of the memory): the live-row kernels with
+        # one light autograd node per step; eager and graph-replayed
+        obs_g = obs.clone().requires_grad_(True)
+
+        def with_obs_grad():
+            rollout(mem_f, obs_g, bucket_f, weight)
+            gnn_f.zero_grad(set_to_none=True)
+            obs_g.grad = None
+        variants["eager_functional_obs_grad"] = world * B * T * side / timed(with_obs_grad, side, 2)
+        try:
+            def zero_g():
+                gnn_f.zero_grad(set_to_none=True)
+                obs_g.grad = None
+            gg = capture(lambda: rollout(mem_f, obs_g), zero_g)
+            variants["graph_functional_obs_grad"] = world * B * T * side / timed(gg.replay, side, 2)
+            del gg
+        except Exception as e:      # (reported, not fatal: the headline does not depend on it)
+            variants["graph_functional_obs_grad"] = 0.0
+            print("obs-grad graph capture failed:", type(e).__name__, str(e)[:200], file=sys.stderr)
+            torch.cuda.synchronize()
+        mem_f.check_flags()
 
     if rank != 0:
         return

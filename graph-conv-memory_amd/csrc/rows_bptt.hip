@@ -60,15 +60,40 @@ struct LrnSrc {
   int adj_compact;   // the buffers hold row cur of the adjacency only ([B, N])
 };
 
+// DXO (MODE 0, records written with GCM_GNN_RECORD_DX): the observations / incoming nodes need a gradient too.
+// The node matrix x enters a step through layer 1 only - as the root term of the live rows and through
+// the aggregate of their adjacency rows - so per step the gradient w.r.t. x is sparse in rows:
+//     dx[j_l] += G1_l W_root1 ;   dx[k] += adj'[j_l, k] * (G1_l W_rel1)   for the non-zero k of live row l
+// (a dozen rows of F floats for TemporalBackedge([1,2,4])).  Row k of step s holds the node that was inserted
+// at step s - (cur - k) of the chain (one roll per step once the graph is full) - or, when that is negative,
+// an initial node of the state the chain started from.  The backward of a chain runs its steps LAST TO FIRST
+// (autograd has one node per step here: an observation's producer is younger than the chain's head, so no
+// single node could reach them all), one launch per step, one wave per graph: the rows are added straight
+// into the accumulators of the nodes they belong to - gx [T, B, F], one slot per step's observation, complete
+// when that step's own launch has run - and gn0 [B, N, F] for the initial nodes.  No [B,N,F] gradient tensor
+// per step, no reverse scan kernel.  The parameter gradient goes into the slab array of the chain
+// (accumulated in place launch after launch, summed once at the end).
+struct DxOut {
+  float* gx;                 // [T, B, F]
+  float* gn0;                // [B, N, F] or NULL
+  const int64_t* count0;     // [B] num_nodes entering the chain's first step
+  const float* w_rel1;       // [H1, F]
+  const float* w_root1;      // [H1, F]
+  const float* gnodes;       // gradient handed to the node matrix this step RETURNED, [B,N,F], or NULL
+  int s_lin;                 // index of this launch's (single) step in the chain
+  int accumulate;            // slabs: add to what is there
+};
+
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
 // C2 = columns of v per lane (column m = lane + 64 c).  MODE: 0 live-row records, 1 rollout history,
 // 2 learned-step buffers.
-template <int FP, int HP, int H2P, int MODE>
+template <int FP, int HP, int H2P, int MODE, bool DXO = false>
 __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
-    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn) {
+    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn, DxOut dxo) {
   constexpr bool HIST = MODE != 0;
+  static_assert(!DXO || MODE == 0, "dx output: live-row records only");
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
@@ -97,6 +122,16 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       wr1c[MODE == 2 ? h : 0] = (h < H1 && lane < F) ? t : 0.f;
     }
   }
+  float wdx[DXO ? 2 * HP : 1];   // DXO: column `lane` of W_rel1 | W_root1
+  if (DXO) {
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      const size_t o = (size_t)(h < H1 ? h : H1 - 1) * F + (lane < F ? lane : F - 1);
+      const float a = dxo.w_rel1[o], r = dxo.w_root1[o];
+      wdx[DXO ? h : 0] = (h < H1 && lane < F) ? a : 0.f;
+      wdx[DXO ? HP + h : 0] = (h < H1 && lane < F) ? r : 0.f;
+    }
+  }
   float acc1[C1][HP], acc2[C2][H2P];
 #pragma unroll
   for (int c = 0; c < C1; ++c)
@@ -121,13 +156,30 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     Hist src{};        // HIST: where the full layers of this item live
     size_t gi = 0;     //       and the index of its graph in them
     int n_live = 0;    // MODE 2: live rows handed on so far
+    // DXO: row k of this step's node matrix gets `val` (column `lane`): straight into the accumulator of the
+    // node that sits there (this wave owns graph b; the launches of a chain are serialised on the stream)
+    int dx_cur = 0, dx_n0 = 0;
+    auto dx_add = [&](int k, float val) {
+      const int kk = dxo.s_lin - (dx_cur - k);          // the chain step that inserted that node
+      float* p = kk >= 0 ? dxo.gx + ((size_t)kk * B + b) * F + lane
+                         : (dxo.gn0 && kk + dx_n0 >= 0 ? dxo.gn0 + ((size_t)b * N + (kk + dx_n0)) * F + lane : nullptr);
+      if (p && lane < F) *p += val;
+    };
     float vv[C2];
     if (!HIST) {
       sv = tab.saved[s];
       const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
       L = __builtin_amdgcn_readfirstlane(hdr[0]);
       l_cur = __builtin_amdgcn_readfirstlane(hdr[1]);
-      g = tab.gmx[s][(long)b * gmx_sb + (long)oc * gmx_sh];
+      if (DXO) {
+        dx_cur = __builtin_amdgcn_readfirstlane(hdr[2]);
+        const int64_t c0 = dxo.count0[b];
+        dx_n0 = __builtin_amdgcn_readfirstlane((int)(c0 < 0 ? 0 : (c0 > N ? N : c0)));
+      }
+      {
+        const float* gp = tab.gmx[s];
+        g = gp ? gp[(long)b * gmx_sb + (long)oc * gmx_sh] : 0.f;   // NULL: no gradient reached this step's belief
+      }
       y = sv[(size_t)b * H2 + oc];
 #pragma unroll
       for (int c = 0; c < C2; ++c) {
@@ -231,18 +283,39 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       g1 = lane < H1 ? g1 : 0.f;
       db1 += g1;
       dc1 = fmaf(dg, g1, dc1);
-      float da = 0.f;
+      float da = 0.f, dxa = 0.f, dxr = 0.f;
 #pragma unroll
       for (int h = 0; h < HP; ++h) {
         const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
 #pragma unroll
         for (int c = 0; c < C1; ++c) acc1[c][h] = fmaf(gh, ax[c], acc1[c][h]);
         if (MODE == 2) da = fmaf(gh, wr1c[MODE == 2 ? h : 0], da);
+        if (DXO) {
+          dxa = fmaf(gh, wdx[DXO ? h : 0], dxa);
+          dxr = fmaf(gh, wdx[DXO ? HP + h : 0], dxr);
+        }
+      }
+      if (DXO) {
+        // root term into the live row itself, aggregate term into the non-zero columns of its adjacency row
+        const int jl = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(sv + lay.o_live)[(size_t)b * N + l]);
+        dx_add(jl, dxr);
+        const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
+        const float r0 = ar[lane < N ? lane : N - 1], r1 = ar[lane + 64 < N ? lane + 64 : N - 1];
+        unsigned long long z0 = __ballot(lane < N && r0 != 0.f), z1 = __ballot(lane + 64 < N && r1 != 0.f);
+        while (z0 | z1) {
+          const int k = z0 ? __builtin_ctzll(z0) : 64 + __builtin_ctzll(z1);
+          if (z0) z0 &= z0 - 1; else z1 &= z1 - 1;
+          const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k < 64 ? r0 : r1), k & 63));
+          dx_add(k, a * dxa);
+        }
       }
       if (MODE == 2) {   // dAgg1_l, column `lane`
         if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;
         ++n_live;
       }
+    }
+    if (DXO && dxo.gnodes) {   // a gradient handed to the node matrix this step returned: every row up to cur
+      for (int k = 0; k <= dx_cur; ++k) dx_add(k, lane < F ? dxo.gnodes[((size_t)b * N + k) * F + lane] : 0.f);
     }
     if (MODE == 2) {
       const size_t it = (size_t)(lrn.s0 + s) * B + b;
@@ -298,20 +371,24 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     __syncthreads();
   }
   float* slab = slabs + (size_t)blockIdx.x * P;
-  for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
+  if (DXO && dxo.accumulate) {
+    for (int e = tid; e < P; e += 256) slab[e] += sSlab[e];
+  } else {
+    for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
+  }
 }
 
-template <int FP, int HP, int H2P, int MODE>
+template <int FP, int HP, int H2P, int MODE, bool DXO = false>
 int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, int n_steps, long sb, long sh,
                 const float* w_rel2, const float* w_root2, int act1, int act2,
                 const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2,
-                int deg_term = 0, const LrnSrc& lrn = LrnSrc{}) {
+                int deg_term = 0, const LrnSrc& lrn = LrnSrc{}, const DxOut& dxo = DxOut{}) {
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   const size_t lds = sizeof(float) * P;
-  auto kern = k_bptt_rows<FP, HP, H2P, MODE>;
+  auto kern = k_bptt_rows<FP, HP, H2P, MODE, DXO>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,
-                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn);
+                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn, dxo);
   return gcm_launch_status();
 }
 
@@ -439,4 +516,45 @@ extern "C" int gcm_dense_rollout_bwd_params(const float* g_mx_all, long gmx_stri
   if (rc) return rc;
   (void)P;
   return gcm_sum_slabs(slabs, grid, (int)P, g_params, stream);
+}
+
+/* ---- gradient w.r.t. the observations / the incoming node matrix of a chain of live-row steps ----------- */
+extern "C" int gcm_dense_rows_dx_supported(int N, int F, int H1, int H2) {
+  return gcm_dense_rows_supported(N, F, H1, H2) && F <= 64 && H1 <= 32 && H2 <= 32;
+}
+
+extern "C" int gcm_dense_rows_dx_slabs(int B) { return gcm_dense_rows_bptt_slabs(1, B); }
+
+/* The backward of ONE step of a chain (record written with GCM_GNN_RECORD_DX); the steps of a chain are
+ * handed over last to first.  g_mx [B, H2] with element strides, or NULL; g_nodes_out: the gradient handed
+ * to the node matrix this step returned ([B,N,F] contiguous) or NULL.  slabs [gcm_dense_rows_dx_slabs(B),
+ * param_count]: the chain's parameter-gradient slabs, added to when accumulate != 0 (sum them with
+ * gcm_sum_slabs once every step has run).  gx [T, B, F] (zeroed by the caller before the first launch of the
+ * chain's backward): slot t is the gradient w.r.t. the observation of step t, complete once step t itself has
+ * been handed over.  gn0 [B, N, F] (zeroed) or NULL: the node matrix the chain started from; count0 [B]:
+ * num_nodes entering its first step.  s_lin: index of this step in the chain. */
+extern "C" int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx, long gmx_stride_b,
+                                           long gmx_stride_h, const float* g_nodes_out, const float* params,
+                                           int has_bias, int act1, int act2, const int64_t* count0,
+                                           float* slabs, int accumulate, float* gx, float* gn0, int s_lin, int B,
+                                           int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(saved && params && count0 && slabs && gx && B > 0 && s_lin >= 0);
+  if (!gcm_dense_rows_dx_supported(N, F, H1, H2) || (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)))
+    return GCM_EUNSUPPORTED;
+  const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, true);
+  gcm_rows::StepTable tab{};
+  tab.saved[0] = saved;
+  tab.gmx[0] = g_mx;
+  gcm_rows::DxOut dxo{gx, gn0, count0, params, params + (size_t)H1 * F, g_nodes_out, s_lin, accumulate};
+  const int grid = gcm_dense_rows_dx_slabs(B);
+  hipStream_t s = (hipStream_t)stream;
+  if (F <= 32)
+    return gcm_rows::launch_bptt<32, 32, 32, 0, true>(s, grid, tab, gcm_rows::Hist{}, 1, gmx_stride_b, gmx_stride_h,
+                                                      w_rel2, w_root2, act1, act2, lay, slabs, B, N, F, H1, H2, 0,
+                                                      gcm_rows::LrnSrc{}, dxo);
+  return gcm_rows::launch_bptt<64, 32, 32, 0, true>(s, grid, tab, gcm_rows::Hist{}, 1, gmx_stride_b, gmx_stride_h,
+                                                    w_rel2, w_root2, act1, act2, lay, slabs, B, N, F, H1, H2, 0,
+                                                    gcm_rows::LrnSrc{}, dxo);
 }

@@ -9,6 +9,8 @@
 //   rows [B, N, rw]       per live row l < L: h1[j_l] [H1] | agg1[j_l] [F] | x[j_l] [F]; rw = H1 + 2F
 //   deg  [B, N]           row sums of the live adjacency rows, l < L (written only when a Linear
 //                         preprocessor's bias is folded into the step: GCM_GNN_HAS_DEG_TERM)
+//   live [B, N] int32     (GCM_GNN_RECORD_DX only) the row j_l of live slot l
+//   arows [B, N, N]       (GCM_GNN_RECORD_DX only) the adjacency row of live slot l as layer 1 aggregated it
 //
 // Capacity is N rows per graph (DenseEdge makes every row <= cur live); only L rows are touched.
 #pragma once
@@ -43,11 +45,15 @@ int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_step
 struct SavedLayout {
   size_t total, o_v, o_hdr, o_coef, o_rows, o_deg;
   int rw;
+  // records that also serve the gradient w.r.t. the observations / nodes (GCM_GNN_RECORD_DX): the row
+  // index of every live row, and its adjacency row as layer 1 aggregated it (0: absent)
+  size_t o_live;    // [B, N] int32   j_l
+  size_t o_arows;   // [B, N, N]      adj'[j_l, :]  (capacity N rows per graph; L written)
 };
 
 static inline size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-static inline SavedLayout make_layout(int B, int N, int F, int H1, int H2) {
+static inline SavedLayout make_layout(int B, int N, int F, int H1, int H2, bool dx = false) {
   SavedLayout l;
   l.rw = H1 + 2 * F;
   l.o_v = pad64((size_t)B * H2);
@@ -56,6 +62,12 @@ static inline SavedLayout make_layout(int B, int N, int F, int H1, int H2) {
   l.o_rows = l.o_coef + pad64((size_t)B * N);
   l.o_deg = l.o_rows + pad64((size_t)B * N * l.rw);
   l.total = l.o_deg + pad64((size_t)B * N);
+  l.o_live = l.o_arows = 0;
+  if (dx) {
+    l.o_live = l.total;
+    l.o_arows = l.o_live + pad64((size_t)B * N);
+    l.total = l.o_arows + pad64((size_t)B * N * N);
+  }
   return l;
 }
 

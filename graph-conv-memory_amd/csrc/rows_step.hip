@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
   // kernel arguments used late: in registers now (a scalar load at its point of use is a round trip)
   const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
   const size_t lay_v = lay.o_v, lay_hdr = lay.o_hdr, lay_coef = lay.o_coef, lay_rows = lay.o_rows;
+  const size_t lay_ar = saved ? lay.o_arows : 0, lay_lv = lay.o_live;
   const int rw = lay.rw;
   const int dense_i = E.dense;
   asm volatile("" ::"s"(lay_v), "s"(lay_rows), "s"(saved), "s"(mx_out), "s"(dense_i), "s"(N), "s"(count_out),
@@ -523,6 +524,8 @@ __global__ __launch_bounds__(256) void k_step_rows(
         float2* d = reinterpret_cast<float2*>(sRows + l * RS + c);
         d[0] = make_float2(v.x, v.y);
         d[1] = make_float2(v.z, v.w);
+        if (lay_ar && valid && c < N)   // GCM_GNN_RECORD_DX: the row as layer 1 aggregates it
+          *reinterpret_cast<float4*>(saved + lay_ar + ((size_t)b * N + lg) * N + c) = v;
         dsum += (v.x + v.y) + (v.z + v.w);
         const bool nz = (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
         const unsigned long long bal = __ballot(nz);   // lane = 16 l' + c4: fold the wave's 4 rows
@@ -530,6 +533,7 @@ __global__ __launch_bounds__(256) void k_step_rows(
         nzbits |= m << (16 * q);
       }
       if (lane == 0 && nzbits) atomicOr(reinterpret_cast<unsigned*>(&sInt[3]), nzbits);
+      if (lay_ar && valid && c4 == 0) reinterpret_cast<int*>(saved + lay_lv)[(size_t)b * N + lg] = j;
       if (fold_deg) {   // row sum of live row l: the 16 lanes that hold it
 #pragma unroll
         for (int d = 1; d < 16; d <<= 1) dsum += __shfl_xor(dsum, d);
@@ -760,6 +764,14 @@ extern "C" int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t
   return GCM_OK;
 }
 
+extern "C" int gcm_dense_rows_layout_dx(int B, int N, int F, int H1, int H2, size_t* out8) {
+  GCM_REQUIRE(out8 && B > 0 && N > 0 && F > 0 && H1 > 0 && H2 > 0);
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, true);
+  out8[0] = lay.total; out8[1] = lay.o_v; out8[2] = lay.o_hdr; out8[3] = lay.o_coef;
+  out8[4] = lay.o_rows; out8[5] = (size_t)lay.rw; out8[6] = lay.o_live; out8[7] = lay.o_arows;
+  return GCM_OK;
+}
+
 extern "C" size_t gcm_dense_rows_step_workspace_bytes(const gcm_selector_desc* selectors,
                                                       int n_selectors, int B, int N, int F) {
   size_t need = 0;
@@ -838,7 +850,7 @@ extern "C" int gcm_dense_rows_step_fwd_ws(const float* obs, const float* nodes_i
   const bool folded = c1 || pe || sel_row;
   // the bias slots are always there (zeros when a layer has none): read unconditionally
   gcm_fused::Gnn2 P{w_rel1, b1, w_root1, w_rel2, b2, w_root2, act1, act2};
-  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, (has_bias & GCM_GNN_RECORD_DX) != 0);
   hipStream_t s = (hipStream_t)stream;
   const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64, h2p = H2 <= 32 ? 32 : 64;
   // tile-exact specialisations of the common shapes

@@ -251,12 +251,11 @@ struct RowsChainNode : public torch::autograd::Node {
   int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
   int64_t P = 0;           // floats the backward kernel writes (GNN gradient | d c1 with the deg term)
   bool executed = false, released = false;
-
   variable_list apply(variable_list&& grads) override {
     executed = true;
-    variable_list out(1);
     TORCH_CHECK(!released, "Trying to backward through the live-row steps of a DenseGCM chain a second "
                            "time (their records were freed); pass retain_graph=True to the first call");
+    variable_list out(1);
     TORCH_CHECK(grads.size() == recs.size(), "rows chain: ", grads.size(), " gradients for ", recs.size(),
                 " recorded steps");
     // groups of steps with equal batch size and gradient strides (an expanded gradient, as mean()
@@ -319,6 +318,107 @@ struct RowsChainNode : public torch::autograd::Node {
   std::string name() const override { return "GcmRowsChain"; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Live-row steps whose observations (or the node matrix the chain started from) need a gradient.
+// An observation's producer is younger than the head of the chain, and autograd edges only reach older
+// nodes - so no single node can return all of them: here every step IS a node (DxStepNode: inputs its
+// observation, the previous step, the gate), but a light one.  The engine runs them last step first (each
+// depends on its successor); a step's launch (gcm_dense_rows_bptt_dx_step, one wave per graph) adds its few
+// rows of dL/dx into the accumulators of the nodes they belong to (gx: one [B,F] slot per step), so by the
+// time step k runs, slot k is complete and is what it returns.  The parameter gradient accumulates in the
+// chain's slab array; the gate (created at the head: inputs the packed vector and the head's node matrix)
+// runs after every step and sums it once.
+// ---------------------------------------------------------------------------------------------
+struct DxChain {
+  at::Tensor packed;    // detached
+  at::Tensor count0;    // num_nodes entering the first step
+  at::Tensor slabs;     // [n_slabs, P], zero between passes
+  at::Tensor gx, gn0;   // accumulators of the running backward pass
+  at::Tensor zero_p;
+  int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0, n_slabs = 0;
+  int64_t P = 0, T = 0, B = 0;
+  int pass = -2;        // graph task the accumulators belong to
+  bool want_gn0 = false, gave_defined = false, slabs_dirty = false, executed = false;
+
+  void begin_pass_if_new() {
+    const int id = torch::autograd::get_current_graph_task_id();
+    if (id == pass && gx.defined() && gx.size(0) == T) return;
+    pass = id;
+    gx = at::zeros({T, B, F}, packed.options());
+    gn0 = want_gn0 ? at::zeros({B, N, F}, packed.options()) : at::Tensor();
+    if (slabs_dirty) slabs.zero_();   // (a pass whose gate never ran, e.g. autograd.grad w.r.t. the observations only)
+    slabs_dirty = false;
+    gave_defined = false;
+  }
+};
+
+struct DxGateNode : public torch::autograd::Node {
+  std::shared_ptr<DxChain> ch;
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(2);
+    ch->executed = true;
+    if (ch->pass != torch::autograd::get_current_graph_task_id() || !ch->slabs_dirty) return out;   // no step ran
+    const gcm_stream_t stream =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(ch->packed.get_device()).stream());
+    at::Tensor res = at::empty({ch->P}, ch->packed.options());
+    check(gcm_sum_slabs(ch->slabs.data_ptr<float>(), ch->n_slabs, (int)ch->P, res.data_ptr<float>(), stream),
+          "gcm_sum_slabs");
+    ch->slabs.zero_();
+    ch->slabs_dirty = false;
+    out[0] = res;
+    if (ch->gn0.defined() && task_should_compute_output(1)) out[1] = ch->gn0;
+    ch->gx = at::Tensor();
+    ch->gn0 = at::Tensor();
+    ch->pass = -2;
+    return out;
+  }
+  std::string name() const override { return "GcmRowsDxGate"; }
+};
+
+struct DxStepNode : public torch::autograd::Node {
+  std::shared_ptr<DxChain> ch;
+  at::Tensor buf;
+  c10::VariableVersion vc;
+  uint32_t version = 0;
+  int64_t k = 0;
+
+  variable_list apply(variable_list&& grads) override {   // grads: belief, (successor), returned node matrix
+    variable_list out(3);
+    TORCH_CHECK(buf.defined(), "Trying to backward through a live-row step of a DenseGCM chain a second time (its "
+                               "record was freed); pass retain_graph=True to the first call");
+    ch->executed = true;
+    ch->begin_pass_if_new();
+    at::Tensor g = grads[0], gn = grads[2];
+    if (g.defined()) {
+      TORCH_CHECK(vc.current_version() == version,
+                  "one of the variables needed for gradient computation has been modified by an inplace "
+                  "operation: the belief states returned by DenseGCM step ", k, " of this chain");
+      if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+    }
+    if (gn.defined()) gn = gn.to(at::kFloat).contiguous();
+    const gcm_stream_t stream =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(ch->packed.get_device()).stream());
+    check(gcm_dense_rows_bptt_dx_step(
+              buf.data_ptr<float>(), g.defined() ? g.data_ptr<float>() : nullptr, g.defined() ? (long)g.stride(0) : 0,
+              g.defined() ? (long)g.stride(1) : 0, gn.defined() ? gn.data_ptr<float>() : nullptr,
+              ch->packed.data_ptr<float>(), ch->has_bias, ch->act1, ch->act2, ch->count0.data_ptr<int64_t>(),
+              ch->slabs.data_ptr<float>(), 1, ch->gx.data_ptr<float>(),
+              ch->gn0.defined() ? ch->gn0.data_ptr<float>() : nullptr, (int)k, (int)ch->B, ch->N, ch->F, ch->H1,
+              ch->H2, stream),
+          "gcm_dense_rows_bptt_dx_step");
+    ch->slabs_dirty = true;
+    if (task_should_compute_output(0)) out[0] = ch->gx.select(0, k);
+    if (!ch->gave_defined) {   // one defined gradient per pass, so that the gate is certain to run
+      if (!ch->zero_p.defined()) ch->zero_p = at::zeros({ch->packed.numel()}, ch->packed.options());
+      out[2] = ch->zero_p;
+      ch->gave_defined = true;
+    }
+    return out;
+  }
+  void release_variables() override { buf.reset(); }
+  std::string name() const override { return "GcmRowsDxStep"; }
+};
+
 // The per-step host path of `belief, m = gcm(obs, m)` on the live-row kernels.  One instance per
 // (DenseGCM module, step configuration).  `run` is the checked entry (Python validated the hidden
 // state and built the packed parameter vector); `step` is what DenseGCM.__call__ tries first: when
@@ -331,6 +431,10 @@ struct RowsFast {
   StepCfg* cfg = nullptr;
   at::Tensor packed, flags;
   bool donate = false, grad_mode = false, armed = false;
+  bool dx_mode = false;   // the armed chain differentiates w.r.t. observations / nodes: one node per step (DxStepNode)
+  std::shared_ptr<DxChain> dxc;
+  std::shared_ptr<DxGateNode> dx_gate;
+  std::shared_ptr<DxStepNode> dx_last;
   std::shared_ptr<RowsChainNode> node;
   std::vector<pybind11::object> hook_dicts;    // the module's and torch's global hook dicts: all must be empty
   std::vector<pybind11::object> dicts, keys;   // module._parameters dicts and the names read from them
@@ -364,11 +468,13 @@ struct RowsFast {
     return true;
   }
 
-  void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_) {
+  void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_, bool dx_ = false,
+           const at::Tensor& head_nodes = at::Tensor(), const at::Tensor& head_count = at::Tensor()) {
     cfg = reinterpret_cast<StepCfg*>(cfg_handle);
     packed = packed_;
     flags = flags_;
-    donate = donate_;
+    donate = donate_ && !dx_;
+    dx_mode = false;
     grad_mode = at::GradMode::is_enabled();
     dev = packed.get_device();
     objs.clear();
@@ -379,7 +485,31 @@ struct RowsFast {
       vers.push_back(o && THPVariable_Check(o) ? THPVariable_Unpack(o)._version() : 0);
     }
     node.reset();
-    if (grad_mode && packed.requires_grad()) {
+    dxc.reset();
+    dx_gate.reset();
+    dx_last.reset();
+    if (grad_mode && packed.requires_grad() && dx_) {
+      TORCH_CHECK(gcm_dense_rows_dx_supported(cfg->N, cfg->F, cfg->H1, cfg->H2) &&
+                      !(cfg->has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)),
+                  "rows step: this configuration has no observation-gradient form");
+      dx_mode = true;
+      dxc = std::make_shared<DxChain>();
+      dxc->packed = packed.detach();
+      dxc->count0 = head_count;
+      dxc->N = cfg->N; dxc->F = cfg->F; dxc->H1 = cfg->H1; dxc->H2 = cfg->H2;
+      dxc->has_bias = cfg->has_bias; dxc->act1 = cfg->act1; dxc->act2 = cfg->act2;
+      dxc->P = (int64_t)gcm_dense_gnn2_param_count(cfg->F, cfg->H1, cfg->H2);
+      dxc->B = head_count.size(0);
+      dxc->n_slabs = gcm_dense_rows_dx_slabs((int)dxc->B);
+      dxc->slabs = at::zeros({dxc->n_slabs, dxc->P}, packed.options());
+      dxc->want_gn0 = head_nodes.defined() && head_nodes.requires_grad();
+      dx_gate = std::shared_ptr<DxGateNode>(new DxGateNode(), torch::autograd::deleteNode);
+      dx_gate->ch = dxc;
+      dx_gate->set_next_edges(torch::autograd::collect_next_edges(packed));
+      dx_gate->add_next_edge(dxc->want_gn0 ? torch::autograd::impl::gradient_edge(head_nodes)
+                                           : torch::autograd::Edge());
+      dx_gate->add_input_metadata(packed);
+    } else if (grad_mode && packed.requires_grad()) {
       node = std::shared_ptr<RowsChainNode>(new RowsChainNode(), torch::autograd::deleteNode);
       node->packed = packed.detach();
       node->N = cfg->N; node->F = cfg->F; node->H1 = cfg->H1; node->H2 = cfg->H2;
@@ -397,9 +527,10 @@ struct RowsFast {
                     const at::Tensor& weights, const at::Tensor& count_in) {
     const int64_t B = obs.size(0);
     const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
-    const bool need_bwd = node != nullptr;
-    size_t lay[6];
-    check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
+    const bool need_bwd = node != nullptr || dxc != nullptr;
+    size_t lay[8];
+    if (dx_mode) check(gcm_dense_rows_layout_dx((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout_dx");
+    else check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
     at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
     at::Tensor nodes_out, adj_out, count_out;
     if (donate) {
@@ -420,12 +551,26 @@ struct RowsFast {
               obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
               count_in.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), adj_out.data_ptr<float>(),
               count_out.data_ptr<int64_t>(), nullptr, cfg->descs.empty() ? nullptr : cfg->descs.data(),
-              (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
-              buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
+              (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias | (dx_mode ? GCM_GNN_RECORD_DX : 0),
+              cfg->act1, cfg->act2, buf.data_ptr<float>(), need_bwd ? buf.data_ptr<float>() : nullptr,
               reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2, stream),
           "gcm_dense_rows_step_fwd_ws");
     at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());   // the record starts with the belief states
-    if (need_bwd) {
+    if (dxc) {   // one light node per step: inputs its observation, its predecessor, the gate
+      auto sn = std::shared_ptr<DxStepNode>(new DxStepNode(), torch::autograd::deleteNode);
+      sn->ch = dxc;
+      sn->buf = buf;
+      sn->vc = mx.unsafeGetTensorImpl()->version_counter();
+      sn->version = sn->vc.current_version();
+      sn->k = dxc->T++;
+      sn->add_next_edge(obs.requires_grad() ? torch::autograd::impl::gradient_edge(obs) : torch::autograd::Edge());
+      sn->add_next_edge(dx_last ? torch::autograd::Edge(dx_last, 1) : torch::autograd::Edge());
+      sn->add_next_edge(torch::autograd::Edge(dx_gate, 0));
+      torch::autograd::create_gradient_edge(mx, sn);                      // output 0
+      sn->add_input_metadata(torch::autograd::Node::undefined_input{});   // output 1: what the successor hangs on
+      torch::autograd::create_gradient_edge(nodes_out, sn);               // output 2
+      dx_last = sn;
+    } else if (need_bwd) {
       const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
       node->recs.push_back({buf, vc, vc.current_version()});
       torch::autograd::create_gradient_edge(mx, node);
@@ -451,8 +596,9 @@ struct RowsFast {
   // the checked entry -> (mx, nodes, adj, num_nodes)
   pybind11::tuple run(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
                       const at::Tensor& weights, const at::Tensor& count_in, const at::Tensor& packed_,
-                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_) {
+                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_, bool need_dx) {
     StepCfg* c = reinterpret_cast<StepCfg*>(cfg_handle);
+    TORCH_CHECK(c != nullptr, "rows_step: no step configuration");
     TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() &&
                     packed_.is_cuda() && flags_.is_cuda(),
                 "rows_step: every tensor must live on a HIP device (no CPU fallback)");
@@ -469,10 +615,14 @@ struct RowsFast {
     TORCH_CHECK(obs.get_device() == c10::hip::current_device() && nodes_in.get_device() == obs.get_device() &&
                     packed_.get_device() == obs.get_device(),
                 "rows_step: tensors must live on the current device");
+    need_dx = need_dx && at::GradMode::is_enabled() && packed_.requires_grad();
+    // a chain that differentiates w.r.t. its inputs holds ONE chain of hidden states: a state that is not
+    // the one returned last starts a new node (whose input 1 is that state's node matrix)
+    const bool new_chain = (need_dx || dx_mode) && !(dx_mode && continues(nodes_in, adj_in, weights, count_in));
     if (!armed || c != cfg || packed_.unsafeGetTensorImpl() != packed.unsafeGetTensorImpl() ||
-        flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || donate_ != donate ||
-        grad_mode != at::GradMode::is_enabled() || (node && node->executed))
-      arm(packed_, flags_, cfg_handle, donate_);
+        flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || (donate_ && !need_dx) != donate ||
+        grad_mode != at::GradMode::is_enabled() || (node && node->executed) || (dxc && dxc->executed) || new_chain)
+      arm(packed_, flags_, cfg_handle, donate_, need_dx, nodes_in, count_in);
     at::Tensor mx = launch(obs, nodes_in, adj_in, weights, count_in);
     return pybind11::make_tuple(mx, l_nodes, l_adj, l_count);
   }
@@ -492,9 +642,9 @@ struct RowsFast {
       return pybind11::none();
     const at::Tensor& xt = THPVariable_Unpack(x.ptr());
     const bool grad = at::GradMode::is_enabled();
-    if (grad != grad_mode || (node && node->executed) || xt.dim() != 2 || xt.size(0) != xB ||
+    if (grad != grad_mode || (node && node->executed) || (dxc && dxc->executed) || xt.dim() != 2 || xt.size(0) != xB ||
         xt.size(1) != xF || xt.scalar_type() != at::kFloat || !xt.is_cuda() || xt.get_device() != dev ||
-        c10::hip::current_device() != dev || (grad && xt.requires_grad()) || !params_current() ||
+        c10::hip::current_device() != dev || (grad && xt.requires_grad() && !dx_mode) || !params_current() ||
         hooks_registered())
       return pybind11::none();
     at::Tensor obs = xt.is_contiguous() ? xt : xt.contiguous();
@@ -514,6 +664,9 @@ struct RowsFast {
   void forget() {   // drop the packed vector (and with it the references into its autograd graph)
     armed = false;
     node.reset();
+    dxc.reset();
+    dx_gate.reset();
+    dx_last.reset();
     packed = at::Tensor();
   }
 };
@@ -924,7 +1077,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("pending", &RowsFast::pending)
       .def("forget", &RowsFast::forget)
       .def("steps", [](RowsFast& f) { return f.n_steps; })
-      .def("has_chain", [](RowsFast& f) { return f.node != nullptr; });
+      .def("has_chain", [](RowsFast& f) { return f.node != nullptr || f.dxc != nullptr; });
   pybind11::class_<LearnedCfg>(m, "LearnedCfg")
       .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())
       .def("handle", [](LearnedCfg& c) { return reinterpret_cast<int64_t>(&c); });

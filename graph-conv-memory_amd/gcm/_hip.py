@@ -18,7 +18,7 @@ DIR = {"forward": 1, "backward": 2, "both": 3}
 DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
 FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
 FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER = 8, 16, 32, 64
-GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE = 4, 8      # has_bias bits of the live-row step (gcm_hip.h)
+GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bits of the live-row step (gcm_hip.h)
 
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                      ctypes.c_int64)
@@ -88,6 +88,11 @@ PROTOTYPES = {
     "gcm_dense_step_bwd_acc": (_I, [_P] * 7 + [_I] * 3 + [_P] * 9 + [_Z] + [_I] * 5 + [_P]),
     "gcm_dense_rows_supported": (_I, [_I] * 4),
     "gcm_dense_rows_layout": (_I, [_I] * 5 + [_P]),
+    "gcm_dense_rows_layout_dx": (_I, [_I] * 5 + [_P]),
+    "gcm_dense_rows_dx_supported": (_I, [_I] * 4),
+    "gcm_dense_rows_dx_slabs": (_I, [_I]),
+    "gcm_dense_rows_bptt_dx_step": (_I, [_P, _P, ctypes.c_long, ctypes.c_long, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]
+                                    + [_I] * 6 + [_P]),
     "gcm_dense_rows_step_fwd": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_I] * 5 + [_P]),
     "gcm_dense_rows_step_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
     "gcm_dense_rows_step_fwd_ws": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_P, _Z] + [_I] * 5 + [_P]),

@@ -649,6 +649,8 @@ class StepConfig:
             and lib.gcm_dense_rows_supported(N, F, H1, H2)
             and _ext.module() is not None and hasattr(_ext.module(), "RowsFast"))
         self._rows_fast = None
+        # ... and its form that also differentiates w.r.t. the observations / the incoming nodes
+        self.dx_ok = bool(self.rows_ok and lib.gcm_dense_rows_dx_supported(N, F, H1, H2))
 
     # (Linear preprocessor | None, PositionalEncoding in "add" mode | None) folded into the live-row
     # step, or None (gcm.py:_fold_config)

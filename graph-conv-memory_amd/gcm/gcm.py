@@ -129,6 +129,9 @@ class DenseGCM(torch.nn.Module):
         # False: the round-2 backward of the fused LearnedEdge step (one kernel per step behind a [B,N,N]
         # gradient chain buffer) instead of the time-parallel one - kept for A/B tests
         self.learned_time_parallel = True
+        # False: steps whose observations / nodes need a gradient take the round-1 fused kernels (one kernel per
+        # step and direction, full state saved) instead of the live-row kernels + time-parallel backward - A/B tests
+        self.rows_dx = True
 
     # -- state ---------------------------------------------------------------
     def get_initial_hidden_state(self, x):
@@ -398,6 +401,7 @@ class DenseGCM(torch.nn.Module):
         cfg.desc_sources = [None] * len(descs)
         cfg.lins = (convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel, convs[1].lin_root)
         cfg.fold = (pre, pe if pe_add else None)
+        cfg.dx_ok = False      # (a gradient w.r.t. the observations through a folded transform: the layered path)
         return cfg
 
     def _packed_params(self, cfg, head=False):
@@ -492,7 +496,7 @@ class DenseGCM(torch.nn.Module):
             if m.gather_current(x):
                 cfg.refresh_pointers()
 
-    def _forward_rows(self, x, hidden, cfg, flags, link):
+    def _forward_rows(self, x, hidden, cfg, flags, link, need_dx=False):
         """The live-row step (csrc/rows_step.hip), checked entry: one kernel forward, no kernel and no
         autograd node per step backward (every step of a chain hangs its belief tensor on one node,
         whose backward is one time-parallel launch over every recorded step).  Taken when neither x
@@ -508,8 +512,10 @@ class DenseGCM(torch.nn.Module):
             if self.donate_state:
                 raise ValueError("donate_state=True needs contiguous hidden-state tensors")
             nodes, adj, num_nodes = nodes.contiguous(), adj.contiguous(), num_nodes.contiguous()
-        donate = self.donate_state
-        mx, n2, a2, c2 = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(), donate)
+        # (a gradient w.r.t. the observations / nodes: functional state - autograd does not allow the caller's
+        #  node matrix to be advanced in place)
+        donate = self.donate_state and not need_dx
+        mx, n2, a2, c2 = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(), donate, need_dx)
         if donate:
             out = hidden
         else:
@@ -710,8 +716,8 @@ class DenseGCM(torch.nn.Module):
             no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
             if cfg.sharded:
                 self._gather_sharded(cfg, x)
-            if cfg.rows_ok and no_dx:
-                return self._forward_rows(x, hidden, cfg, link[3], link)
+            if cfg.rows_ok and (no_dx or (cfg.dx_ok and self.rows_dx)):
+                return self._forward_rows(x, hidden, cfg, link[3], link, not no_dx)
             if cfg.learned_sel is None and cfg.fold is None:
                 return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, link[3], link)
             if no_dx:
@@ -740,8 +746,8 @@ class DenseGCM(torch.nn.Module):
             no_dx = not (torch.is_grad_enabled() and (x.requires_grad or nodes.requires_grad))
             if plan.sharded:
                 self._gather_sharded(plan, x)
-            if plan.rows_ok and no_dx:
-                return self._forward_rows(x, hidden, plan, flags, None)
+            if plan.rows_ok and (no_dx or (plan.dx_ok and self.rows_dx)):
+                return self._forward_rows(x, hidden, plan, flags, None, not no_dx)
             if plan.learned_sel is None and plan.fold is None:
                 return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
             if no_dx:

@@ -433,8 +433,13 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
  * "add", gcm.py:120-131); the stored nodes stay raw. */
 #define GCM_GNN_HAS_DEG_TERM 4
 #define GCM_GNN_HAS_PE_TABLE 8
+/* has_bias bit: the record also keeps what the gradient w.r.t. the observations / incoming nodes needs
+ * (gcm_dense_rows_bptt_dx): the live rows' indices and adjacency rows (gcm_dense_rows_layout_dx). */
+#define GCM_GNN_RECORD_DX 16
 int gcm_dense_rows_supported(int N, int F, int H1, int H2);
 int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t* out6);
+/* with GCM_GNN_RECORD_DX: float offsets {total, v, hdr, coef, rows, row width, live, arows} */
+int gcm_dense_rows_layout_dx(int B, int N, int F, int H1, int H2, size_t* out8);
 int gcm_dense_rows_step_fwd(const float* obs, const float* nodes_in, const float* adj_in,
                             const int64_t* count_in, float* nodes_out, float* adj_out,
                             int64_t* count_out, int64_t* cur_out /* may be NULL */,
@@ -509,6 +514,23 @@ int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_
                         int act1, int act2, const float* g_params_prev, float* g_params,
                         void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
                         int H2, gcm_stream_t stream);
+
+/* Records written with GCM_GNN_RECORD_DX, when the observations (and / or the node matrix the chain started
+ * from) need a gradient too - the reference's own tests require gradients to reach the inputs
+ * (tests/test_gcm.py:355-365).  x enters a step through layer 1 only, so per step the gradient w.r.t. the node
+ * matrix is a handful of rows; row k of step s belongs to the node inserted at step s - (cur - k) of the chain.
+ * The steps of a chain are handed over LAST TO FIRST, one launch each (one wave per graph), which adds those
+ * rows straight into gx [T, B, F] (slot t: gradient w.r.t. the observation of step t, complete once step t
+ * itself has run) and gn0 [B, N, F] (the initial nodes; may be NULL) - both zeroed by the caller before the
+ * chain's first launch - and its parameter gradient into `slabs` [gcm_dense_rows_dx_slabs(B), param_count]
+ * (accumulate != 0: added; sum with gcm_sum_slabs at the end).  g_mx (strided) / g_nodes_out ([B,N,F], the
+ * gradient handed to the node matrix this step returned) may be NULL.  F <= 64, H1, H2 <= 32. */
+int gcm_dense_rows_dx_supported(int N, int F, int H1, int H2);
+int gcm_dense_rows_dx_slabs(int B);
+int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx, long gmx_stride_b, long gmx_stride_h,
+                                const float* g_nodes_out, const float* params, int has_bias, int act1, int act2,
+                                const int64_t* count0, float* slabs, int accumulate, float* gx, float* gn0,
+                                int s_lin, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 
 /* Parameter gradient of a rollout from the history gcm_dense_rollout_fwd /
  * gcm_dense_rollout_persistent_fwd kept, when neither the observations nor the initial node matrix

@@ -198,6 +198,7 @@ def test_cpp_node_matches_python_node(monkeypatch):
     res = []
     for use_cpp in (True, False):
         mem, g = _cfg2_like()
+        mem.rows_dx = False          # the round-1 fused step (one kernel per step and direction), both hosts
         if not use_cpp:
             monkeypatch.setattr(_ops.StepConfig, "cpp_handle", lambda self: 0)
         o = obs.clone().requires_grad_(True)

@@ -107,6 +107,8 @@ def test_cfg2_slice_matches_oracle(entry):
     obs = torch.rand(T, B2, F2)
     obs_d = obs.to(DEV).requires_grad_(True)
     out, hid = _loop(mem, obs_d) if entry == "step" else mem.rollout(obs_d)
+    if entry == "step":      # observations WITH gradient: the live-row kernels too (one light node per step)
+        assert mem.rows_steps() == T
     w = torch.linspace(0.5, 1.5, T * len(pick) * H2).view(T, len(pick), H2)
     (out[:, pick] * w.to(DEV)).sum().backward()
     obs_c = obs[:, pick].clone().requires_grad_(True)

@@ -370,6 +370,7 @@ def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
     res = []
     for mode in ("fused", "rows", "rows_donated"):
         mem, g = build(mode == "rows_donated")
+        mem.rows_dx = mode != "fused"                        # the round-1 fused kernels for the obs-gradient steps
         x = obs.clone().requires_grad_(mode == "fused")     # a gradient w.r.t. obs => the fused path
         hidden, outs, sums = None, [], []
         for t in range(T):
