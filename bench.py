@@ -567,18 +567,31 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         mem_e.check_flags()
         # observations that need a gradient (an encoder in front of the memory): the live-row kernels with
         # one light autograd node per step; eager and graph-replayed
-        obs_g = obs.clone().requires_grad_(True)
+        def rollout_xs(m, xs):      # per-step leaves (an encoder's outputs), not slices of one [T,B,F] leaf
+            hidden, outs = None, []
+            for x in xs:
+                mx, hidden = m(x, hidden)
+                outs.append(mx)
+            torch.stack(outs).mean().backward()
+
+        xs = [obs[t].clone().requires_grad_(True) for t in range(T)]
 
         def with_obs_grad():
-            rollout(mem_f, obs_g, bucket_f, weight)
+            rollout_xs(mem_f, xs)
             gnn_f.zero_grad(set_to_none=True)
-            obs_g.grad = None
+            for x in xs:
+                x.grad = None
         variants["eager_functional_obs_grad"] = world * B * T * side / timed(with_obs_grad, side, 2)
         try:
+            # (a fresh module and leaves: an AccumulateGrad node made on another stream breaks the capture)
+            mem_g, gnn_g, _ = build_memory(device, donate=False, selector=c["selector"], cfg=c)
+            xs2 = [obs[t].clone().requires_grad_(True) for t in range(T)]
+
             def zero_g():
-                gnn_f.zero_grad(set_to_none=True)
-                obs_g.grad = None
-            gg = capture(lambda: rollout(mem_f, obs_g), zero_g)
+                gnn_g.zero_grad(set_to_none=True)
+                for x in xs2:
+                    x.grad = None
+            gg = capture(lambda: rollout_xs(mem_g, xs2), zero_g)
             variants["graph_functional_obs_grad"] = world * B * T * side / timed(gg.replay, side, 2)
             del gg
         except Exception as e:      # (reported, not fatal: the headline does not depend on it)

@@ -60,40 +60,15 @@ struct LrnSrc {
   int adj_compact;   // the buffers hold row cur of the adjacency only ([B, N])
 };
 
-// DXO (MODE 0, records written with GCM_GNN_RECORD_DX): the observations / incoming nodes need a gradient too.
-// The node matrix x enters a step through layer 1 only - as the root term of the live rows and through
-// the aggregate of their adjacency rows - so per step the gradient w.r.t. x is sparse in rows:
-//     dx[j_l] += G1_l W_root1 ;   dx[k] += adj'[j_l, k] * (G1_l W_rel1)   for the non-zero k of live row l
-// (a dozen rows of F floats for TemporalBackedge([1,2,4])).  Row k of step s holds the node that was inserted
-// at step s - (cur - k) of the chain (one roll per step once the graph is full) - or, when that is negative,
-// an initial node of the state the chain started from.  The backward of a chain runs its steps LAST TO FIRST
-// (autograd has one node per step here: an observation's producer is younger than the chain's head, so no
-// single node could reach them all), one launch per step, one wave per graph: the rows are added straight
-// into the accumulators of the nodes they belong to - gx [T, B, F], one slot per step's observation, complete
-// when that step's own launch has run - and gn0 [B, N, F] for the initial nodes.  No [B,N,F] gradient tensor
-// per step, no reverse scan kernel.  The parameter gradient goes into the slab array of the chain
-// (accumulated in place launch after launch, summed once at the end).
-struct DxOut {
-  float* gx;                 // [T, B, F]
-  float* gn0;                // [B, N, F] or NULL
-  const int64_t* count0;     // [B] num_nodes entering the chain's first step
-  const float* w_rel1;       // [H1, F]
-  const float* w_root1;      // [H1, F]
-  const float* gnodes;       // gradient handed to the node matrix this step RETURNED, [B,N,F], or NULL
-  int s_lin;                 // index of this launch's (single) step in the chain
-  int accumulate;            // slabs: add to what is there
-};
-
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
 // C2 = columns of v per lane (column m = lane + 64 c).  MODE: 0 live-row records, 1 rollout history,
 // 2 learned-step buffers.
-template <int FP, int HP, int H2P, int MODE, bool DXO = false>
+template <int FP, int HP, int H2P, int MODE>
 __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
-    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn, DxOut dxo) {
+    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn) {
   constexpr bool HIST = MODE != 0;
-  static_assert(!DXO || MODE == 0, "dx output: live-row records only");
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
@@ -122,16 +97,6 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       wr1c[MODE == 2 ? h : 0] = (h < H1 && lane < F) ? t : 0.f;
     }
   }
-  float wdx[DXO ? 2 * HP : 1];   // DXO: column `lane` of W_rel1 | W_root1
-  if (DXO) {
-#pragma unroll
-    for (int h = 0; h < HP; ++h) {
-      const size_t o = (size_t)(h < H1 ? h : H1 - 1) * F + (lane < F ? lane : F - 1);
-      const float a = dxo.w_rel1[o], r = dxo.w_root1[o];
-      wdx[DXO ? h : 0] = (h < H1 && lane < F) ? a : 0.f;
-      wdx[DXO ? HP + h : 0] = (h < H1 && lane < F) ? r : 0.f;
-    }
-  }
   float acc1[C1][HP], acc2[C2][H2P];
 #pragma unroll
   for (int c = 0; c < C1; ++c)
@@ -156,30 +121,13 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     Hist src{};        // HIST: where the full layers of this item live
     size_t gi = 0;     //       and the index of its graph in them
     int n_live = 0;    // MODE 2: live rows handed on so far
-    // DXO: row k of this step's node matrix gets `val` (column `lane`): straight into the accumulator of the
-    // node that sits there (this wave owns graph b; the launches of a chain are serialised on the stream)
-    int dx_cur = 0, dx_n0 = 0;
-    auto dx_add = [&](int k, float val) {
-      const int kk = dxo.s_lin - (dx_cur - k);          // the chain step that inserted that node
-      float* p = kk >= 0 ? dxo.gx + ((size_t)kk * B + b) * F + lane
-                         : (dxo.gn0 && kk + dx_n0 >= 0 ? dxo.gn0 + ((size_t)b * N + (kk + dx_n0)) * F + lane : nullptr);
-      if (p && lane < F) *p += val;
-    };
     float vv[C2];
     if (!HIST) {
       sv = tab.saved[s];
       const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
       L = __builtin_amdgcn_readfirstlane(hdr[0]);
       l_cur = __builtin_amdgcn_readfirstlane(hdr[1]);
-      if (DXO) {
-        dx_cur = __builtin_amdgcn_readfirstlane(hdr[2]);
-        const int64_t c0 = dxo.count0[b];
-        dx_n0 = __builtin_amdgcn_readfirstlane((int)(c0 < 0 ? 0 : (c0 > N ? N : c0)));
-      }
-      {
-        const float* gp = tab.gmx[s];
-        g = gp ? gp[(long)b * gmx_sb + (long)oc * gmx_sh] : 0.f;   // NULL: no gradient reached this step's belief
-      }
+      g = tab.gmx[s][(long)b * gmx_sb + (long)oc * gmx_sh];
       y = sv[(size_t)b * H2 + oc];
 #pragma unroll
       for (int c = 0; c < C2; ++c) {
@@ -283,39 +231,18 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       g1 = lane < H1 ? g1 : 0.f;
       db1 += g1;
       dc1 = fmaf(dg, g1, dc1);
-      float da = 0.f, dxa = 0.f, dxr = 0.f;
+      float da = 0.f;
 #pragma unroll
       for (int h = 0; h < HP; ++h) {
         const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
 #pragma unroll
         for (int c = 0; c < C1; ++c) acc1[c][h] = fmaf(gh, ax[c], acc1[c][h]);
         if (MODE == 2) da = fmaf(gh, wr1c[MODE == 2 ? h : 0], da);
-        if (DXO) {
-          dxa = fmaf(gh, wdx[DXO ? h : 0], dxa);
-          dxr = fmaf(gh, wdx[DXO ? HP + h : 0], dxr);
-        }
-      }
-      if (DXO) {
-        // root term into the live row itself, aggregate term into the non-zero columns of its adjacency row
-        const int jl = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(sv + lay.o_live)[(size_t)b * N + l]);
-        dx_add(jl, dxr);
-        const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
-        const float r0 = ar[lane < N ? lane : N - 1], r1 = ar[lane + 64 < N ? lane + 64 : N - 1];
-        unsigned long long z0 = __ballot(lane < N && r0 != 0.f), z1 = __ballot(lane + 64 < N && r1 != 0.f);
-        while (z0 | z1) {
-          const int k = z0 ? __builtin_ctzll(z0) : 64 + __builtin_ctzll(z1);
-          if (z0) z0 &= z0 - 1; else z1 &= z1 - 1;
-          const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k < 64 ? r0 : r1), k & 63));
-          dx_add(k, a * dxa);
-        }
       }
       if (MODE == 2) {   // dAgg1_l, column `lane`
         if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;
         ++n_live;
       }
-    }
-    if (DXO && dxo.gnodes) {   // a gradient handed to the node matrix this step returned: every row up to cur
-      for (int k = 0; k <= dx_cur; ++k) dx_add(k, lane < F ? dxo.gnodes[((size_t)b * N + k) * F + lane] : 0.f);
     }
     if (MODE == 2) {
       const size_t it = (size_t)(lrn.s0 + s) * B + b;
@@ -371,24 +298,20 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     __syncthreads();
   }
   float* slab = slabs + (size_t)blockIdx.x * P;
-  if (DXO && dxo.accumulate) {
-    for (int e = tid; e < P; e += 256) slab[e] += sSlab[e];
-  } else {
-    for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
-  }
+  for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
 }
 
-template <int FP, int HP, int H2P, int MODE, bool DXO = false>
+template <int FP, int HP, int H2P, int MODE>
 int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, int n_steps, long sb, long sh,
                 const float* w_rel2, const float* w_root2, int act1, int act2,
                 const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2,
-                int deg_term = 0, const LrnSrc& lrn = LrnSrc{}, const DxOut& dxo = DxOut{}) {
+                int deg_term = 0, const LrnSrc& lrn = LrnSrc{}) {
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   const size_t lds = sizeof(float) * P;
-  auto kern = k_bptt_rows<FP, HP, H2P, MODE, DXO>;
+  auto kern = k_bptt_rows<FP, HP, H2P, MODE>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,
-                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn, dxo);
+                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn);
   return gcm_launch_status();
 }
 
@@ -523,38 +446,170 @@ extern "C" int gcm_dense_rows_dx_supported(int N, int F, int H1, int H2) {
   return gcm_dense_rows_supported(N, F, H1, H2) && F <= 64 && H1 <= 32 && H2 <= 32;
 }
 
-extern "C" int gcm_dense_rows_dx_slabs(int B) { return gcm_dense_rows_bptt_slabs(1, B); }
+namespace gcm_rows {
 
-/* The backward of ONE step of a chain (record written with GCM_GNN_RECORD_DX); the steps of a chain are
- * handed over last to first.  g_mx [B, H2] with element strides, or NULL; g_nodes_out: the gradient handed
- * to the node matrix this step returned ([B,N,F] contiguous) or NULL.  slabs [gcm_dense_rows_dx_slabs(B),
- * param_count]: the chain's parameter-gradient slabs, added to when accumulate != 0 (sum them with
- * gcm_sum_slabs once every step has run).  gx [T, B, F] (zeroed by the caller before the first launch of the
- * chain's backward): slot t is the gradient w.r.t. the observation of step t, complete once step t itself has
- * been handed over.  gn0 [B, N, F] (zeroed) or NULL: the node matrix the chain started from; count0 [B]:
- * num_nodes entering its first step.  s_lin: index of this step in the chain. */
+// The observations / incoming nodes of a chain of live-row steps need a gradient too (records written with
+// GCM_GNN_RECORD_DX).  The node matrix x enters a step through layer 1 only - as the root term of the live rows
+// and through the aggregate of their adjacency rows - so per step the gradient w.r.t. x is sparse in rows:
+//     dx[j_l] += G1_l W_root1 ;   dx[k] += adj'[j_l, k] * (G1_l W_rel1)   for the non-zero k of live row l
+// (a dozen rows of F floats for TemporalBackedge([1,2,4])).  Row k of step s holds the node that was inserted
+// at step s - (cur - k) of the chain (one roll per step once the graph is full) - or, when that is negative,
+// an initial node of the state the chain started from.  The backward of a chain runs its steps LAST TO FIRST
+// (autograd has one node per step here: an observation's producer is younger than the chain's head, so no
+// single node could reach them all), one launch per step: the rows are added straight into the accumulators
+// of the nodes they belong to - gx [T, B, F], one slot per step's observation, complete when that step's own
+// launch has run - and gn0 [B, N, F] for the initial nodes.  No [B,N,F] gradient tensor per step, no reverse
+// scan kernel.  (The parameter gradient of those steps: one time-parallel k_bptt_rows launch at the end.)
+// The dx part of the backward of ONE step, as its own small kernel: one wave per graph, every
+// load that does not depend on another one issued before the first use (weights, the step's vectors, the first
+// eight live rows with their adjacency rows), the rows summed in the wave's LDS tile, one batch of
+// read-modify-writes on the accumulators at the end.  H1, H2 <= 32, F <= 64.
+__global__ __launch_bounds__(256) void k_rows_dx_step(
+    const float* __restrict__ sv, const float* __restrict__ gmx, long gmx_sb, long gmx_sh,
+    const float* __restrict__ gnodes, const float* __restrict__ w_rel1, const float* __restrict__ w_root1,
+    const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay,
+    const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int B, int N, int F, int H1, int H2) {
+  extern __shared__ float dxs[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  float* tile = dxs + (size_t)wave * N * F;
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  constexpr int LB = 8;   // live rows fetched ahead
+  // ---- loads ---------------------------------------------------------------------------------------
+  const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+  const int h_l = hdr[0], h_lc = hdr[1], h_cur = hdr[2];
+  const int oc = lane < H2 ? lane : H2 - 1, hc = lane < H1 ? lane : H1 - 1, fc = lane < F ? lane : F - 1;
+  const float g = gmx ? gmx[(long)b * gmx_sb + (long)oc * gmx_sh] : 0.f;
+  const float y = sv[(size_t)b * H2 + oc];
+  const int64_t c0 = count0[b];
+  float w2a[32], w2r[32], wa[32], wr[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) {
+    const size_t i2 = (size_t)(o < H2 ? o : H2 - 1) * H1 + hc, i1 = (size_t)(o < H1 ? o : H1 - 1) * F + fc;
+    w2a[o] = w_rel2[i2];
+    w2r[o] = w_root2[i2];
+    wa[o] = w_rel1[i1];
+    wr[o] = w_root1[i1];
+  }
+  const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
+  const float* coef = sv + lay.o_coef + (size_t)b * N;
+  float cf8[LB], hv8[LB], r0[LB], r1[LB];
+  int jl8[LB];
+#pragma unroll
+  for (int l = 0; l < LB; ++l) {
+    const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
+    const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
+    cf8[l] = coef[l];
+    jl8[l] = live[l];
+    hv8[l] = row[hc];
+    r0[l] = ar[lane < N ? lane : N - 1];
+    r1[l] = ar[lane + 64 < N ? lane + 64 : N - 1];
+  }
+  asm volatile("" ::: "memory");
+  const int L = __builtin_amdgcn_readfirstlane(h_l), l_cur = __builtin_amdgcn_readfirstlane(h_lc);
+  const int cur = __builtin_amdgcn_readfirstlane(h_cur);
+  const int n0 = __builtin_amdgcn_readfirstlane((int)(c0 < 0 ? 0 : (c0 > N ? N : c0)));
+  // ---- layer-2 adjoint: d2 in lane o, dagg2 / dh1cur in lane h ---------------------------------------
+  const float d2 = lane < H2 ? g * act_grad_sel(y, act2_v) : 0.f;
+  float dagg2 = 0.f, dh1c = 0.f;
+#pragma unroll
+  for (int o = 0; o < 32; ++o) {
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o));
+    dagg2 = fmaf(o < H2 ? w2a[o] : 0.f, d, dagg2);
+    dh1c = fmaf(o < H2 ? w2r[o] : 0.f, d, dh1c);
+  }
+  // ---- the live rows -----------------------------------------------------------------------------------
+  unsigned long long tm0 = 0, tm1 = 0;
+  auto add_row = [&](int k, float val) {
+    const bool seen = k < 64 ? ((tm0 >> k) & 1ull) != 0 : ((tm1 >> (k - 64)) & 1ull) != 0;
+    if (lane < F) {
+      float* q = tile + k * F + lane;
+      *q = (seen ? *q : 0.f) + val;
+    }
+    if (k < 64) tm0 |= 1ull << k; else tm1 |= 1ull << (k - 64);
+  };
+  auto live_row = [&](int l, float cf, float hv, int jl, float a0, float a1) {
+    float g1 = (cf * dagg2 + (l == l_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
+    g1 = lane < H1 ? g1 : 0.f;
+    float dxa = 0.f, dxr = 0.f;
+#pragma unroll
+    for (int h = 0; h < 32; ++h) {
+      const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
+      dxa = fmaf(gh, (h < H1 && lane < F) ? wa[h] : 0.f, dxa);
+      dxr = fmaf(gh, (h < H1 && lane < F) ? wr[h] : 0.f, dxr);
+    }
+    add_row(__builtin_amdgcn_readfirstlane(jl), dxr);
+    unsigned long long z0 = __ballot(lane < N && a0 != 0.f), z1 = __ballot(lane + 64 < N && a1 != 0.f);
+    while (z0 | z1) {
+      const int k = z0 ? __builtin_ctzll(z0) : 64 + __builtin_ctzll(z1);
+      if (z0) z0 &= z0 - 1; else z1 &= z1 - 1;
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k < 64 ? a0 : a1), k & 63));
+      add_row(k, a * dxa);
+    }
+  };
+#pragma unroll
+  for (int l = 0; l < LB; ++l)
+    if (l < L) live_row(l, cf8[l], hv8[l], jl8[l], r0[l], r1[l]);
+#pragma unroll 1
+  for (int l = LB; l < L; ++l) {
+    const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
+    const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
+    live_row(l, coef[l], row[hc], live[l], ar[lane < N ? lane : N - 1], ar[lane + 64 < N ? lane + 64 : N - 1]);
+  }
+  if (gnodes) {   // a gradient handed to the node matrix this step returned: every row up to cur
+    for (int k = 0; k <= cur; ++k) add_row(k, lane < F ? gnodes[((size_t)b * N + k) * F + lane] : 0.f);
+  }
+  // ---- row k holds the node inserted at chain step s_lin - (cur - k) (negative: an initial node) -------
+  while (tm0 | tm1) {
+    float* pp[8];
+    float v8[8], old8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      pp[i] = nullptr;
+      v8[i] = 0.f;
+      if (tm0 | tm1) {
+        const int k = tm0 ? __builtin_ctzll(tm0) : 64 + __builtin_ctzll(tm1);
+        if (tm0) tm0 &= tm0 - 1; else tm1 &= tm1 - 1;
+        const int kk = s_lin - (cur - k);
+        if (kk >= 0) pp[i] = gx + ((size_t)kk * B + b) * F + lane;
+        else if (gn0 && kk + n0 >= 0) pp[i] = gn0 + ((size_t)b * N + (kk + n0)) * F + lane;
+        if (lane < F) v8[i] = tile[k * F + lane];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) old8[i] = (pp[i] && lane < F) ? *pp[i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (pp[i] && lane < F) *pp[i] = old8[i] + v8[i];
+  }
+}
+
+}  // namespace gcm_rows
+
+/* The dx part of the backward of ONE step of a chain (record written with GCM_GNN_RECORD_DX); the steps of a
+ * chain are handed over last to first.  g_mx [B, H2] with element strides, or NULL; g_nodes_out: the gradient
+ * handed to the node matrix this step returned ([B,N,F] contiguous) or NULL.  gx [T, B, F] (zeroed by the
+ * caller before the first launch of the chain's backward): slot t is the gradient w.r.t. the observation of
+ * step t, complete once step t itself has been handed over.  gn0 [B, N, F] (zeroed) or NULL: the node matrix
+ * the chain started from; count0 [B]: num_nodes entering its first step.  s_lin: index of this step in the
+ * chain.  (The parameter gradient of the chain's steps: gcm_dense_rows_bptt over their records - the dx
+ * sections sit behind the others.) */
 extern "C" int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx, long gmx_stride_b,
                                            long gmx_stride_h, const float* g_nodes_out, const float* params,
-                                           int has_bias, int act1, int act2, const int64_t* count0,
-                                           float* slabs, int accumulate, float* gx, float* gn0, int s_lin, int B,
-                                           int N, int F, int H1, int H2, gcm_stream_t stream) {
-  GCM_REQUIRE(saved && params && count0 && slabs && gx && B > 0 && s_lin >= 0);
+                                           int has_bias, int act1, int act2, const int64_t* count0, float* gx,
+                                           float* gn0, int s_lin, int B, int N, int F, int H1, int H2,
+                                           gcm_stream_t stream) {
+  GCM_REQUIRE(saved && params && count0 && gx && B > 0 && s_lin >= 0);
   if (!gcm_dense_rows_dx_supported(N, F, H1, H2) || (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)))
     return GCM_EUNSUPPORTED;
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, true);
-  gcm_rows::StepTable tab{};
-  tab.saved[0] = saved;
-  tab.gmx[0] = g_mx;
-  gcm_rows::DxOut dxo{gx, gn0, count0, params, params + (size_t)H1 * F, g_nodes_out, s_lin, accumulate};
-  const int grid = gcm_dense_rows_dx_slabs(B);
-  hipStream_t s = (hipStream_t)stream;
-  if (F <= 32)
-    return gcm_rows::launch_bptt<32, 32, 32, 0, true>(s, grid, tab, gcm_rows::Hist{}, 1, gmx_stride_b, gmx_stride_h,
-                                                      w_rel2, w_root2, act1, act2, lay, slabs, B, N, F, H1, H2, 0,
-                                                      gcm_rows::LrnSrc{}, dxo);
-  return gcm_rows::launch_bptt<64, 32, 32, 0, true>(s, grid, tab, gcm_rows::Hist{}, 1, gmx_stride_b, gmx_stride_h,
-                                                    w_rel2, w_root2, act1, act2, lay, slabs, B, N, F, H1, H2, 0,
-                                                    gcm_rows::LrnSrc{}, dxo);
+  const size_t lds = sizeof(float) * 4 * (size_t)N * F;
+  gcm_allow_dynamic_lds((const void*)gcm_rows::k_rows_dx_step, lds);
+  hipLaunchKernelGGL(gcm_rows::k_rows_dx_step, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, saved, g_mx,
+                     gmx_stride_b, gmx_stride_h, g_nodes_out, params, params + (size_t)H1 * F, w_rel2, w_root2, act1,
+                     act2, lay, count0, gx, gn0, s_lin, B, N, F, H1, H2);
+  return gcm_launch_status();
 }

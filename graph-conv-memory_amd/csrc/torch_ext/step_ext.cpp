@@ -332,13 +332,15 @@ struct RowsChainNode : public torch::autograd::Node {
 struct DxChain {
   at::Tensor packed;    // detached
   at::Tensor count0;    // num_nodes entering the first step
-  at::Tensor slabs;     // [n_slabs, P], zero between passes
   at::Tensor gx, gn0;   // accumulators of the running backward pass
   at::Tensor zero_p;
-  int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0, n_slabs = 0;
+  // (record, g_mx) of the steps of the running pass: their parameter gradient is ONE time-parallel launch
+  // by the gate (gcm_dense_rows_bptt; the dx sections of a record sit behind the ones it reads)
+  std::vector<at::Tensor> p_bufs, p_gmx;
+  int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
   int64_t P = 0, T = 0, B = 0;
   int pass = -2;        // graph task the accumulators belong to
-  bool want_gn0 = false, gave_defined = false, slabs_dirty = false, executed = false;
+  bool want_gn0 = false, gave_defined = false, executed = false;
 
   void begin_pass_if_new() {
     const int id = torch::autograd::get_current_graph_task_id();
@@ -346,8 +348,8 @@ struct DxChain {
     pass = id;
     gx = at::zeros({T, B, F}, packed.options());
     gn0 = want_gn0 ? at::zeros({B, N, F}, packed.options()) : at::Tensor();
-    if (slabs_dirty) slabs.zero_();   // (a pass whose gate never ran, e.g. autograd.grad w.r.t. the observations only)
-    slabs_dirty = false;
+    p_bufs.clear();      // (a pass whose gate never ran, e.g. autograd.grad w.r.t. the observations only)
+    p_gmx.clear();
     gave_defined = false;
   }
 };
@@ -357,16 +359,37 @@ struct DxGateNode : public torch::autograd::Node {
   variable_list apply(variable_list&& grads) override {
     variable_list out(2);
     ch->executed = true;
-    if (ch->pass != torch::autograd::get_current_graph_task_id() || !ch->slabs_dirty) return out;   // no step ran
+    if (ch->pass != torch::autograd::get_current_graph_task_id()) return out;   // no step ran
     const gcm_stream_t stream =
         reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(ch->packed.get_device()).stream());
-    at::Tensor res = at::empty({ch->P}, ch->packed.options());
-    check(gcm_sum_slabs(ch->slabs.data_ptr<float>(), ch->n_slabs, (int)ch->P, res.data_ptr<float>(), stream),
-          "gcm_sum_slabs");
-    ch->slabs.zero_();
-    ch->slabs_dirty = false;
-    out[0] = res;
+    // groups of steps with equal gradient strides (an expanded gradient is read with stride 0)
+    at::Tensor prev;
+    std::vector<char> done(ch->p_bufs.size(), 0);
+    for (size_t i = 0; i < ch->p_bufs.size(); ++i) {
+      if (done[i]) continue;
+      const int64_t sb = ch->p_gmx[i].stride(0), sh = ch->p_gmx[i].stride(1);
+      std::vector<const float*> sv, gm;
+      for (size_t j = i; j < ch->p_bufs.size(); ++j)
+        if (!done[j] && ch->p_gmx[j].stride(0) == sb && ch->p_gmx[j].stride(1) == sh) {
+          sv.push_back(ch->p_bufs[j].data_ptr<float>());
+          gm.push_back(ch->p_gmx[j].data_ptr<float>());
+          done[j] = 1;
+        }
+      const int n = (int)sv.size();
+      const size_t ws_bytes = gcm_dense_rows_bptt_workspace_bytes(n, (int)ch->B, ch->F, ch->H1, ch->H2);
+      at::Tensor ws = at::empty({(int64_t)ws_bytes}, ch->packed.options().dtype(at::kByte));
+      at::Tensor res = at::empty({ch->P}, ch->packed.options());
+      check(gcm_dense_rows_bptt(sv.data(), gm.data(), n, (long)sb, (long)sh, ch->packed.data_ptr<float>(),
+                                ch->has_bias, ch->act1, ch->act2, prev.defined() ? prev.data_ptr<float>() : nullptr,
+                                res.data_ptr<float>(), ws.data_ptr(), ws_bytes, (int)ch->B, ch->N, ch->F, ch->H1,
+                                ch->H2, stream),
+            "gcm_dense_rows_bptt");
+      prev = res;
+    }
+    out[0] = prev;
     if (ch->gn0.defined() && task_should_compute_output(1)) out[1] = ch->gn0;
+    ch->p_bufs.clear();
+    ch->p_gmx.clear();
     ch->gx = at::Tensor();
     ch->gn0 = at::Tensor();
     ch->pass = -2;
@@ -402,11 +425,13 @@ struct DxStepNode : public torch::autograd::Node {
               buf.data_ptr<float>(), g.defined() ? g.data_ptr<float>() : nullptr, g.defined() ? (long)g.stride(0) : 0,
               g.defined() ? (long)g.stride(1) : 0, gn.defined() ? gn.data_ptr<float>() : nullptr,
               ch->packed.data_ptr<float>(), ch->has_bias, ch->act1, ch->act2, ch->count0.data_ptr<int64_t>(),
-              ch->slabs.data_ptr<float>(), 1, ch->gx.data_ptr<float>(),
-              ch->gn0.defined() ? ch->gn0.data_ptr<float>() : nullptr, (int)k, (int)ch->B, ch->N, ch->F, ch->H1,
-              ch->H2, stream),
+              ch->gx.data_ptr<float>(), ch->gn0.defined() ? ch->gn0.data_ptr<float>() : nullptr, (int)k, (int)ch->B,
+              ch->N, ch->F, ch->H1, ch->H2, stream),
           "gcm_dense_rows_bptt_dx_step");
-    ch->slabs_dirty = true;
+    if (g.defined()) {
+      ch->p_bufs.push_back(buf);
+      ch->p_gmx.push_back(g);
+    }
     if (task_should_compute_output(0)) out[0] = ch->gx.select(0, k);
     if (!ch->gave_defined) {   // one defined gradient per pass, so that the gate is certain to run
       if (!ch->zero_p.defined()) ch->zero_p = at::zeros({ch->packed.numel()}, ch->packed.options());
@@ -500,8 +525,6 @@ struct RowsFast {
       dxc->has_bias = cfg->has_bias; dxc->act1 = cfg->act1; dxc->act2 = cfg->act2;
       dxc->P = (int64_t)gcm_dense_gnn2_param_count(cfg->F, cfg->H1, cfg->H2);
       dxc->B = head_count.size(0);
-      dxc->n_slabs = gcm_dense_rows_dx_slabs((int)dxc->B);
-      dxc->slabs = at::zeros({dxc->n_slabs, dxc->P}, packed.options());
       dxc->want_gn0 = head_nodes.defined() && head_nodes.requires_grad();
       dx_gate = std::shared_ptr<DxGateNode>(new DxGateNode(), torch::autograd::deleteNode);
       dx_gate->ch = dxc;

@@ -522,15 +522,14 @@ int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_
  * The steps of a chain are handed over LAST TO FIRST, one launch each (one wave per graph), which adds those
  * rows straight into gx [T, B, F] (slot t: gradient w.r.t. the observation of step t, complete once step t
  * itself has run) and gn0 [B, N, F] (the initial nodes; may be NULL) - both zeroed by the caller before the
- * chain's first launch - and its parameter gradient into `slabs` [gcm_dense_rows_dx_slabs(B), param_count]
- * (accumulate != 0: added; sum with gcm_sum_slabs at the end).  g_mx (strided) / g_nodes_out ([B,N,F], the
- * gradient handed to the node matrix this step returned) may be NULL.  F <= 64, H1, H2 <= 32. */
+ * chain's first launch.  g_mx (strided) / g_nodes_out ([B,N,F], the gradient handed to the node matrix this
+ * step returned) may be NULL.  The PARAMETER gradient of those steps is gcm_dense_rows_bptt over the same
+ * records (their dx sections sit behind the others).  F <= 64, H1, H2 <= 32. */
 int gcm_dense_rows_dx_supported(int N, int F, int H1, int H2);
-int gcm_dense_rows_dx_slabs(int B);
 int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx, long gmx_stride_b, long gmx_stride_h,
                                 const float* g_nodes_out, const float* params, int has_bias, int act1, int act2,
-                                const int64_t* count0, float* slabs, int accumulate, float* gx, float* gn0,
-                                int s_lin, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+                                const int64_t* count0, float* gx, float* gn0, int s_lin, int B, int N, int F,
+                                int H1, int H2, gcm_stream_t stream);
 
 /* Parameter gradient of a rollout from the history gcm_dense_rollout_fwd /
  * gcm_dense_rollout_persistent_fwd kept, when neither the observations nor the initial node matrix
