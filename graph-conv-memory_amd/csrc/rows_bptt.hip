@@ -487,10 +487,12 @@ __global__ __launch_bounds__(256) void k_rows_dx_step(
 #pragma unroll
   for (int o = 0; o < 32; ++o) {
     const size_t i2 = (size_t)(o < H2 ? o : H2 - 1) * H1 + hc, i1 = (size_t)(o < H1 ? o : H1 - 1) * F + fc;
-    w2a[o] = w_rel2[i2];
-    w2r[o] = w_root2[i2];
-    wa[o] = w_rel1[i1];
-    wr[o] = w_root1[i1];
+    const float t0 = w_rel2[i2], t1 = w_root2[i2], t2 = w_rel1[i1], t3 = w_root1[i1];
+    const bool k2 = o < H2 && lane < H1, k1 = o < H1 && lane < F;   // (masked once, here)
+    w2a[o] = k2 ? t0 : 0.f;
+    w2r[o] = k2 ? t1 : 0.f;
+    wa[o] = k1 ? t2 : 0.f;
+    wr[o] = k1 ? t3 : 0.f;
   }
   const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
   const float* coef = sv + lay.o_coef + (size_t)b * N;
@@ -516,8 +518,8 @@ __global__ __launch_bounds__(256) void k_rows_dx_step(
 #pragma unroll
   for (int o = 0; o < 32; ++o) {
     const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o));
-    dagg2 = fmaf(o < H2 ? w2a[o] : 0.f, d, dagg2);
-    dh1c = fmaf(o < H2 ? w2r[o] : 0.f, d, dh1c);
+    dagg2 = fmaf(w2a[o], d, dagg2);
+    dh1c = fmaf(w2r[o], d, dh1c);
   }
   // ---- the live rows -----------------------------------------------------------------------------------
   unsigned long long tm0 = 0, tm1 = 0;
@@ -536,8 +538,8 @@ __global__ __launch_bounds__(256) void k_rows_dx_step(
 #pragma unroll
     for (int h = 0; h < 32; ++h) {
       const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
-      dxa = fmaf(gh, (h < H1 && lane < F) ? wa[h] : 0.f, dxa);
-      dxr = fmaf(gh, (h < H1 && lane < F) ? wr[h] : 0.f, dxr);
+      dxa = fmaf(gh, wa[h], dxa);
+      dxr = fmaf(gh, wr[h], dxr);
     }
     add_row(__builtin_amdgcn_readfirstlane(jl), dxr);
     unsigned long long z0 = __ballot(lane < N && a0 != 0.f), z1 = __ballot(lane + 64 < N && a1 != 0.f);

@@ -1082,6 +1082,288 @@ std::vector<at::Tensor> learned_step(const at::Tensor& packed, const at::Tensor&
                               need_bwd ? *slab_acc : at::empty({0}, obs.options()), (int64_t)is_head);
 }
 
+// ---------------------------------------------------------------------------------------------
+// SparseGCM.forward (sparse_gcm.py:72-212) for the canonical configuration - edge_selectors = TemporalEdge,
+// gnn = 2 x GraphConv (+ fused activation), no preprocessor / positional encoder / aux selectors / max_hops -
+// as ONE host call and ONE autograd node: plan -> (the one readback: flat sizes) -> insert -> temporal edges
+// -> segmented merge with the stored COO list -> flatten -> CSR -> two GraphConv layers -> extract.
+// Round 2 ran this from Python: ~35 launches and ~30 small torch ops per call, 0.21 ms of kernels inside
+// 0.6 ms of wall time at cfg4, and 1.3 M states/s stepwise.
+// ---------------------------------------------------------------------------------------------
+// The GNN parameter gradients of the SparseGCM calls of one backward pass are summed here (one multi-tensor add
+// per call) and handed to the parameters once, by a gate that is older than every call's node and therefore
+// runs after all of them - not as one gradient tensor per call and parameter for the engine to add up (six
+// small add kernels per call: 10 % of the GPU time of a stepwise run).
+struct SparseGate : public torch::autograd::Node {
+  std::vector<at::Tensor> acc = std::vector<at::Tensor>(6);
+  std::vector<c10::TensorImpl*> keys = std::vector<c10::TensorImpl*>(6, nullptr);
+  at::Tensor kick;      // a defined gradient for the gate's only input, so that it is certain to run
+  int pass = -2;
+  bool executed = false, gave = false;
+
+  void begin_pass_if_new() {
+    const int id = torch::autograd::get_current_graph_task_id();
+    if (id == pass) return;
+    pass = id;
+    for (auto& a : acc) a = at::Tensor();
+    gave = false;
+  }
+  void add(std::vector<at::Tensor>& g) {   // g[i] undefined: no gradient for that parameter
+    std::vector<at::Tensor> dst, src;
+    for (int i = 0; i < 6; ++i) {
+      if (!g[i].defined()) continue;
+      if (!acc[i].defined()) acc[i] = g[i];
+      else { dst.push_back(acc[i]); src.push_back(g[i]); }
+    }
+    if (!dst.empty()) at::_foreach_add_(dst, src);
+  }
+  variable_list apply(variable_list&& grads) override {
+    executed = true;
+    variable_list out(6);
+    if (pass == torch::autograd::get_current_graph_task_id())
+      for (int i = 0; i < 6; ++i) out[i] = acc[i];
+    for (auto& a : acc) a = at::Tensor();
+    pass = -2;
+    return out;
+  }
+  std::string name() const override { return "GcmSparseGate"; }
+};
+
+static std::shared_ptr<SparseGate>& sparse_gate_slot() {
+  static std::shared_ptr<SparseGate> g;
+  return g;
+}
+
+struct SparseStepNode : public torch::autograd::Node {
+  std::shared_ptr<SparseGate> gate;
+  at::Tensor T, taus, node_off, flat, edge_index, row_ptr, out1, agg1, out2, agg2;
+  at::Tensor w_rel1, w_root1, w_rel2, w_root2;
+  int64_t B = 0, N = 0, F = 0, H1 = 0, H2 = 0, t_pad = 0, M = 0, E = 0;
+  int act1 = 0, act2 = 0;
+  bool has_b1 = false, has_b2 = false;
+
+  // inputs: x, nodes_in, the gate; outputs: mx_dense, nodes_out
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(3);
+    std::vector<at::Tensor> pg(6);   // w_rel1, b1, w_root1, w_rel2, b2, w_root2
+    TORCH_CHECK(flat.defined(), "Trying to backward through a SparseGCM step a second time (its saved tensors "
+                                "were freed); pass retain_graph=True to the first call");
+    if (!grads[0].defined() && !grads[1].defined()) return out;
+    const auto opt = flat.options();
+    const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(flat.get_device()).stream());
+    const bool need_x = task_should_compute_output(0), need_nodes = task_should_compute_output(1);
+    const bool need_in = need_x || need_nodes;
+    at::Tensor g_dirty;   // gradient w.r.t. the node matrix after the insert
+    if (grads[1].defined()) g_dirty = grads[1].to(at::kFloat).contiguous();
+    if (grads[0].defined()) {
+      at::Tensor g_mx = grads[0].to(at::kFloat).contiguous();
+      at::Tensor g_f2 = at::empty({M, H2}, opt);
+      check(gcm_sparse_extract_bwd(g_mx.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
+                                   node_off.data_ptr<int64_t>(), g_f2.data_ptr<float>(), (int)B, (int)t_pad,
+                                   (int)H2, M, st),
+            "gcm_sparse_extract_bwd");
+      // CSC view for the transpose gathers (grouped by graph: no sort)
+      at::Tensor col_ptr, rows, perm;
+      const int64_t* col = edge_index.data_ptr<int64_t>();
+      if (E > 0) {
+        col_ptr = at::empty({M + 1}, edge_index.options());
+        rows = at::empty({E}, edge_index.options());
+        perm = at::empty({E}, edge_index.options());
+        check(gcm_csc_from_csr_batched(row_ptr.data_ptr<int64_t>(), col, col + E, node_off.data_ptr<int64_t>(),
+                                       col_ptr.data_ptr<int64_t>(), rows.data_ptr<int64_t>(),
+                                       perm.data_ptr<int64_t>(), (int)B, M, E, (int)N, st),
+              "gcm_csc_from_csr_batched");
+      }
+      auto layer_bwd = [&](const at::Tensor& g_out, const at::Tensor& o, const at::Tensor& xin, const at::Tensor& ag,
+                           const at::Tensor& w_rel, const at::Tensor& w_root, int Fi, int Fo, int act, bool want_x,
+                           int i_rel, bool has_b) -> at::Tensor {
+        at::Tensor g_xin = want_x ? at::empty({M, Fi}, opt) : at::Tensor();
+        at::Tensor g_wr = at::empty_like(w_rel), g_wt = at::empty_like(w_root);
+        at::Tensor g_b = has_b ? at::empty({Fo}, opt) : at::Tensor();
+        const size_t wsb = gcm_csr_graphconv_bwd_workspace_bytes(M, Fi, Fo);
+        at::Tensor ws = at::empty({(int64_t)wsb}, opt.dtype(at::kByte));
+        check(gcm_csr_graphconv_bwd(g_out.data_ptr<float>(), o.data_ptr<float>(), xin.data_ptr<float>(),
+                                    ag.data_ptr<float>(), row_ptr.data_ptr<int64_t>(), col,
+                                    E > 0 ? col_ptr.data_ptr<int64_t>() : nullptr,
+                                    E > 0 ? rows.data_ptr<int64_t>() : nullptr,
+                                    E > 0 ? perm.data_ptr<int64_t>() : nullptr, nullptr, nullptr,
+                                    w_rel.data_ptr<float>(), w_root.data_ptr<float>(),
+                                    want_x ? g_xin.data_ptr<float>() : nullptr, nullptr, g_wr.data_ptr<float>(),
+                                    has_b ? g_b.data_ptr<float>() : nullptr, g_wt.data_ptr<float>(), ws.data_ptr(),
+                                    wsb, M, E, Fi, Fo, act, st),
+              "gcm_csr_graphconv_bwd");
+        pg[i_rel] = g_wr;
+        if (has_b) pg[i_rel + 1] = g_b;
+        pg[i_rel + 2] = g_wt;
+        return g_xin;
+      };
+      at::Tensor g_f1 = layer_bwd(g_f2, out2, out1, agg2, w_rel2, w_root2, (int)H1, (int)H2, act2, true, 3, has_b2);
+      at::Tensor g_flat = layer_bwd(g_f1, out1, flat, agg1, w_rel1, w_root1, (int)F, (int)H1, act1, need_in, 0, has_b1);
+      gate->begin_pass_if_new();
+      gate->add(pg);
+      if (!gate->gave) {
+        out[2] = gate->kick;
+        gate->gave = true;
+      }
+      if (need_in) {
+        at::Tensor g_nodes = at::empty({B, N, F}, opt);
+        check(gcm_sparse_flatten_bwd(g_flat.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
+                                     node_off.data_ptr<int64_t>(), g_nodes.data_ptr<float>(), (int)B, (int)N, (int)F,
+                                     M, st),
+              "gcm_sparse_flatten_bwd");
+        g_dirty = g_dirty.defined() ? g_dirty + g_nodes : g_nodes;
+      }
+    }
+    if (need_in && g_dirty.defined()) {
+      at::Tensor g_nodes_in = at::empty({B, N, F}, opt), g_x = at::empty({B, t_pad, F}, opt);
+      check(gcm_sparse_insert_bwd(g_dirty.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
+                                  g_nodes_in.data_ptr<float>(), g_x.data_ptr<float>(), (int)B, (int)N, (int)F,
+                                  (int)t_pad, st),
+            "gcm_sparse_insert_bwd");
+      if (need_x) out[0] = g_x;
+      if (need_nodes) out[1] = g_nodes_in;
+    }
+    return out;
+  }
+  void release_variables() override {
+    flat.reset(); out1.reset(); agg1.reset(); out2.reset(); agg2.reset(); edge_index.reset(); row_ptr.reset();
+  }
+  std::string name() const override { return "GcmSparseStep"; }
+};
+
+// -> (mx_dense [B,t,H2], nodes_out, indices [3,E] (batch, sink, source), values [E], T + taus), or an int status:
+// 1 = overflow (sparse_gcm.py:120-121)
+pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& taus, const at::Tensor& nodes_,
+                                      const at::Tensor& adj_idx_, const at::Tensor& T, const std::vector<int>& hops_desc,
+                                      const at::Tensor& w_rel1, const c10::optional<at::Tensor>& b1,
+                                      const at::Tensor& w_root1, int act1, const at::Tensor& w_rel2,
+                                      const c10::optional<at::Tensor>& b2, const at::Tensor& w_root2, int act2,
+                                      const at::Tensor& flags) {
+  TORCH_CHECK(x_.is_cuda() && taus.is_cuda() && nodes_.is_cuda() && T.is_cuda() && flags.is_cuda(),
+              "sparse step: every tensor must live on a HIP device (no CPU fallback)");
+  at::Tensor x = x_.contiguous(), nodes = nodes_.contiguous(), adj_idx = adj_idx_.contiguous();
+  const int64_t B = x.size(0), t_pad = x.size(1), F = x.size(2), N = nodes.size(1);
+  const int64_t H1 = w_rel1.size(0), H2 = w_rel2.size(0), Ea = adj_idx.size(1);
+  TORCH_CHECK(nodes.size(0) == B && nodes.size(2) == F && taus.numel() == B && T.numel() == B &&
+                  w_rel1.size(1) == F && w_rel2.size(1) == H1,
+              "sparse step: shapes disagree");
+  const auto iopt = T.options();
+  const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(x.get_device()).stream());
+  uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
+  // ---- plan: node offsets, edge offsets; the one readback
+  at::Tensor plan = at::empty({3 * (B + 1) + 4}, iopt);
+  int64_t* node_off = plan.data_ptr<int64_t>();
+  int64_t* new_off = node_off + (B + 1);
+  int64_t* edge_off = new_off + (B + 1);
+  int64_t* totals = edge_off + (B + 1);   // follows edge_off[B]: the five numbers read back are contiguous
+  check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
+        "gcm_sparse_plan");
+  std::vector<int32_t> hops(hops_desc.begin(), hops_desc.end());
+  check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                  edge_off, (int)B, st),
+        "gcm_sparse_temporal_count");
+  at::Tensor host = plan.narrow(0, 3 * (B + 1) - 1, 5).cpu();   // edge_off[B] | M | n_new | max_total | max_tau
+  const int64_t* hv = host.data_ptr<int64_t>();
+  const int64_t Eb = hv[0], M = hv[1], max_total = hv[3];
+  if (max_total > N) return pybind11::int_(1);
+  at::Tensor node_off_t = plan.narrow(0, 0, B + 1);
+  // ---- insert, edges, merge
+  at::Tensor nodes_out = at::empty_like(nodes);
+  check(gcm_sparse_insert_fwd(nodes.data_ptr<float>(), x.data_ptr<float>(), T.data_ptr<int64_t>(),
+                              taus.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), fl, (int)B, (int)N, (int)F,
+                              (int)t_pad, st),
+        "gcm_sparse_insert_fwd");
+  at::Tensor idx_new = at::empty({3, Eb}, iopt);
+  check(gcm_sparse_temporal_fill(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                 edge_off, idx_new.data_ptr<int64_t>(), Eb, (int)B, st),
+        "gcm_sparse_temporal_fill");
+  at::Tensor idx;
+  if (Ea == 0) {
+    idx = idx_new;
+  } else if (Eb == 0) {
+    idx = adj_idx;
+  } else {
+    at::Tensor old_bptr = at::empty({B + 1}, iopt);
+    check(gcm_ptr_from_sorted(adj_idx.data_ptr<int64_t>(), old_bptr.data_ptr<int64_t>(), Ea, B, st),
+          "gcm_ptr_from_sorted");
+    idx = at::empty({3, Ea + Eb}, iopt);
+    check(gcm_coo_merge_segments(adj_idx.data_ptr<int64_t>(), idx_new.data_ptr<int64_t>(), nullptr, nullptr,
+                                 old_bptr.data_ptr<int64_t>(), edge_off, idx.data_ptr<int64_t>(), nullptr, nullptr,
+                                 fl, Ea, Eb, (int)B, st),
+          "gcm_coo_merge_segments");
+  }
+  const int64_t E = idx.size(1);
+  at::Tensor vals = at::ones({E}, x.options());
+  // ---- flat node matrix, CSR, the two layers, the new rows
+  at::Tensor flat = at::empty({M, F}, x.options());
+  check(gcm_sparse_flatten_fwd(nodes_out.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
+                               flat.data_ptr<float>(), (int)B, (int)N, (int)F, M, st),
+        "gcm_sparse_flatten_fwd");
+  at::Tensor edge_index = at::empty({2, E}, iopt), row_ptr = at::empty({M + 1}, iopt);
+  check(gcm_sparse_edges_to_csr(idx.data_ptr<int64_t>(), node_off, edge_index.data_ptr<int64_t>(),
+                                row_ptr.data_ptr<int64_t>(), fl, E, M, (int)B, st),
+        "gcm_sparse_edges_to_csr");
+  const bool need_bwd = at::GradMode::is_enabled() &&
+                        (x_.requires_grad() || nodes_.requires_grad() || w_rel1.requires_grad() ||
+                         w_root1.requires_grad() || w_rel2.requires_grad() || w_root2.requires_grad() ||
+                         (b1.has_value() && b1->requires_grad()) || (b2.has_value() && b2->requires_grad()));
+  at::Tensor out1 = at::empty({M, H1}, x.options()), out2 = at::empty({M, H2}, x.options());
+  at::Tensor agg1 = need_bwd ? at::empty({M, F}, x.options()) : at::Tensor();
+  at::Tensor agg2 = need_bwd ? at::empty({M, H1}, x.options()) : at::Tensor();
+  at::Tensor wr1 = w_rel1.contiguous(), wt1 = w_root1.contiguous(), wr2 = w_rel2.contiguous(), wt2 = w_root2.contiguous();
+  const int64_t* col = edge_index.data_ptr<int64_t>();
+  check(gcm_csr_graphconv_fwd(flat.data_ptr<float>(), row_ptr.data_ptr<int64_t>(), col, nullptr, nullptr,
+                              wr1.data_ptr<float>(), b1.has_value() ? b1->data_ptr<float>() : nullptr,
+                              wt1.data_ptr<float>(), out1.data_ptr<float>(), need_bwd ? agg1.data_ptr<float>() : nullptr,
+                              M, (int)F, (int)H1, act1, st),
+        "gcm_csr_graphconv_fwd");
+  check(gcm_csr_graphconv_fwd(out1.data_ptr<float>(), row_ptr.data_ptr<int64_t>(), col, nullptr, nullptr,
+                              wr2.data_ptr<float>(), b2.has_value() ? b2->data_ptr<float>() : nullptr,
+                              wt2.data_ptr<float>(), out2.data_ptr<float>(), need_bwd ? agg2.data_ptr<float>() : nullptr,
+                              M, (int)H1, (int)H2, act2, st),
+        "gcm_csr_graphconv_fwd");
+  at::Tensor mx = at::empty({B, t_pad, H2}, x.options());
+  check(gcm_sparse_extract_fwd(out2.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
+                               mx.data_ptr<float>(), fl, (int)B, (int)t_pad, (int)H2, M, st),
+        "gcm_sparse_extract_fwd");
+  if (need_bwd) {
+    auto node = std::shared_ptr<SparseStepNode>(new SparseStepNode(), torch::autograd::deleteNode);
+    node->T = T; node->taus = taus; node->node_off = node_off_t; node->flat = flat;
+    node->edge_index = edge_index; node->row_ptr = row_ptr; node->out1 = out1; node->agg1 = agg1;
+    node->out2 = out2; node->agg2 = agg2;
+    node->w_rel1 = wr1.detach(); node->w_root1 = wt1.detach(); node->w_rel2 = wr2.detach(); node->w_root2 = wt2.detach();
+    node->B = B; node->N = N; node->F = F; node->H1 = H1; node->H2 = H2; node->t_pad = t_pad; node->M = M; node->E = E;
+    node->act1 = act1; node->act2 = act2; node->has_b1 = b1.has_value(); node->has_b2 = b2.has_value();
+    auto edge = [](const at::Tensor& t) {
+      return t.requires_grad() ? torch::autograd::impl::gradient_edge(t) : torch::autograd::Edge();
+    };
+    // the gate of these six parameter tensors (a new one once the previous has run)
+    const at::Tensor* ps[6] = {&w_rel1, b1.has_value() ? &*b1 : nullptr, &w_root1,
+                               &w_rel2, b2.has_value() ? &*b2 : nullptr, &w_root2};
+    std::shared_ptr<SparseGate>& slot = sparse_gate_slot();
+    bool same = slot && !slot->executed;
+    for (int i = 0; same && i < 6; ++i) same = slot->keys[i] == (ps[i] ? ps[i]->unsafeGetTensorImpl() : nullptr);
+    if (!same) {
+      slot = std::shared_ptr<SparseGate>(new SparseGate(), torch::autograd::deleteNode);
+      for (int i = 0; i < 6; ++i) {
+        slot->keys[i] = ps[i] ? ps[i]->unsafeGetTensorImpl() : nullptr;
+        slot->add_next_edge(ps[i] ? edge(*ps[i]) : torch::autograd::Edge());
+      }
+      slot->kick = at::zeros({1}, w_rel1.options());
+      slot->add_input_metadata(slot->kick);
+    }
+    node->gate = slot;
+    node->add_next_edge(edge(x_));
+    node->add_next_edge(edge(nodes_));
+    node->add_next_edge(torch::autograd::Edge(slot, 0));
+    torch::autograd::create_gradient_edge(mx, node);
+    if (x_.requires_grad() || nodes_.requires_grad()) torch::autograd::create_gradient_edge(nodes_out, node);
+    else node->add_input_metadata(torch::autograd::Node::undefined_input{});
+  }
+  at::Tensor T_out = T + taus;
+  return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -1112,4 +1394,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("recording", &LearnedChain::recording)
       .def("steps", &LearnedChain::steps);
   m.def("learned_step2", &learned_step2);
+  m.def("sparse_temporal_step", &sparse_temporal_step);
 }

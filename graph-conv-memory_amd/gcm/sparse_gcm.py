@@ -46,6 +46,8 @@ class SparseGCM(torch.nn.Module):
         self.max_hops = max_hops
         self.finite_check = finite_check
         self._flags = {}
+        self._fast_plan = None    # (structure analysed once): the canonical configuration's C++ host path
+        self.fast_host = True     # False: the layered Python path always (A/B tests)
 
     def get_initial_hidden_state(self, x):
         """sparse_gcm.py:55-70."""
@@ -98,6 +100,40 @@ class SparseGCM(torch.nn.Module):
                 return False
         return has
 
+    def _canonical(self):
+        """(hops, conv1, act1, conv2, act2) when this module is the canonical configuration - TemporalEdge
+        selector, two GraphConv layers (each optionally followed by Tanh / ReLU), nothing else - whose whole
+        forward runs as ONE call into the C++ host path (csrc/torch_ext/step_ext.cpp: sparse_temporal_step):
+        plan, the one readback, insert, edges, merge, flatten, CSR, both layers, extract, one autograd node.
+        None: the layered path below (any other selector / GNN / option)."""
+        if self._fast_plan is None:
+            from . import _ext
+            from .sparse_edge_selectors.temporal import TemporalEdge
+            plan = False
+            ext = _ext.module()
+            g, sel = self.gnn, self.edge_selectors
+            if (ext is not None and hasattr(ext, "sparse_temporal_step") and type(sel) is TemporalEdge
+                    and self.aux_edge_selectors is None and self.preprocessor is None
+                    and self.positional_encoder is None and self.max_hops is None
+                    and isinstance(g, _nn.Sequential) and len(g.arg_names) == 3):
+                xn = g.arg_names[0]
+                convs, acts = [], []
+                ok = True
+                for mod, ins, outs in g.stages():
+                    if isinstance(mod, _nn.GraphConv) and ins == g.arg_names and outs == [xn]:
+                        convs.append(mod)
+                        acts.append(_hip.ACT_NONE)
+                    elif (type(mod) in _nn._FUSABLE and convs and ins == [xn] and outs == [xn]
+                          and acts[-1] == _hip.ACT_NONE):
+                        acts[-1] = _nn._FUSABLE[type(mod)]
+                    else:
+                        ok = False
+                        break
+                if ok and len(convs) == 2 and convs[0].out_channels == convs[1].in_channels:
+                    plan = (ext.sparse_temporal_step, sel._hops_desc, convs[0], acts[0], convs[1], acts[1])
+            self._fast_plan = plan
+        return self._fast_plan or None
+
     def forward(self, x, taus, hidden):
         """x [B, t, feat] zero padded in t; taus [B] valid lengths; hidden (nodes, adj, T) or
         None.  Returns (mx [B, t, H] zero padded, (nodes, adj, T + taus))."""
@@ -110,6 +146,20 @@ class SparseGCM(torch.nn.Module):
         N = nodes.shape[1]
         B, t_pad, _ = x.shape
         flags = self._flag_word(x.device)
+
+        fast = self._canonical() if self.fast_host else None
+        if (fast is not None and x.is_cuda and not adj.values().requires_grad
+                and fast[2].in_channels == x.shape[-1] and x.device.index == torch.cuda.current_device()):
+            fn, hops, c1, a1, c2, a2 = fast
+            r = fn(x, taus, nodes, adj.indices(), T, hops, c1.lin_rel.weight, c1.lin_rel.bias, c1.lin_root.weight,
+                   a1, c2.lin_rel.weight, c2.lin_rel.bias, c2.lin_root.weight, a2, flags)
+            if r == 1:                                         # sparse_gcm.py:120-121
+                raise Exception("Overflow")
+            mx_dense, nodes_out, idx, vals, T_out = r
+            vals.gcm_unit_weights = True
+            adj_out = torch.sparse_coo_tensor(idx, vals, size=adj.shape, is_coalesced=True)
+            self._check_flags(flags)
+            return mx_dense, (nodes_out, adj_out, T_out)
 
         node_off, _new_off, totals = _ops.sparse_plan(T, taus)
         sel, sel_plan = self.edge_selectors, None
@@ -165,6 +215,10 @@ class SparseGCM(torch.nn.Module):
                                             B, t_pad, M)
         mx_dense = _ops.sparse_extract(node_feats, T, taus, node_off, B, t_pad, flags)
 
+        self._check_flags(flags)
+        return mx_dense, (nodes, adj, T + taus)
+
+    def _check_flags(self, flags):
         if self.finite_check == "sync":
             bits = int(flags.item())
             if bits:
@@ -174,7 +228,6 @@ class SparseGCM(torch.nn.Module):
             assert not bits & _hip.FLAG_ACAUSAL, "Causality violated"
             assert not bits & _hip.FLAG_NONFINITE, \
                 "Got NaN in returned memory, try using tanh activation"
-        return mx_dense, (nodes, adj, T + taus)
 
     def _khop_generic(self, flat_nodes, edges, weights, graph, node_off, T, taus, B, t_pad, M):
         """sparse_gcm.py:182-199 for a GNN that is not built from gcm.nn.GraphConv: hand it the
