@@ -17,7 +17,7 @@ ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 DIR = {"forward": 1, "backward": 2, "both": 3}
 DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
 FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
-FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER = 8, 16, 32, 64
+FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER, FLAG_WINDOW = 8, 16, 32, 64, 128
 GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bits of the live-row step (gcm_hip.h)
 
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
@@ -34,6 +34,11 @@ PROTOTYPES = {
     "gcm_gather_rows_bwd": (_I, [_P] * 3 + [_I, _I, _I, _P]),
     "gcm_edge_temporal": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "gcm_edge_dense": (_I, [_P, _P, _I, _I, _P]),
+    "gcm_rows_linear": (_I, [_P] * 4 + [ctypes.c_int64, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
+    "gcm_posenc_cat_finish": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "gcm_posenc_cat_bwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "gcm_temporal_window_fwd": (_I, [_P] * 6 + [_I] * 5 + [_P, _P]),
+    "gcm_temporal_window_bwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "gcm_edge_distance_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "gcm_edge_distance": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _I, _I, _I, _P]),
     "gcm_edge_distance_ex": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),

@@ -221,6 +221,48 @@ def edge_temporal_(adj, cur, hops, direction):
     return adj
 
 
+class _TemporalWindow(torch.autograd.Function):
+    """TemporalBackedge(learned=True) (temporal.py:51-70): adj[b, n_b, :n_b] += the OR of the sampled
+    one-hots, in place on `adj` like the reference's slice assignment."""
+
+    @staticmethod
+    def forward(ctx, adj, window, cur, noise, S, deterministic, flags):
+        window = window.contiguous()
+        _hip.on_device(adj, window, cur, noise, flags)
+        B, N, _ = adj.shape
+        W = window.numel()
+        Wn = min(W, N)
+        soft = torch.empty(1 if deterministic else S, B, Wn, device=adj.device, dtype=_f32)
+        scratch = torch.empty(B, Wn, device=adj.device, dtype=_f32)
+        _call("gcm_temporal_window_fwd", _hip.ptr(window), _hip.ptr(noise), _hip.ptr(cur), _hip.ptr(adj),
+              _hip.ptr(soft), _hip.ptr(scratch), B, N, W, S, int(deterministic), _hip.ptr(flags), _hip.stream())
+        ctx.mark_dirty(adj)
+        ctx.save_for_backward(soft, cur)
+        ctx.cfg = (W, S, int(deterministic))
+        return adj
+
+    @staticmethod
+    def backward(ctx, g_adj):
+        soft, cur = ctx.saved_tensors
+        W, S, det = ctx.cfg
+        _, B, Wn = soft.shape
+        g_adj = g_adj.contiguous()
+        part = torch.empty(B, Wn, device=g_adj.device, dtype=_f32)
+        _call("gcm_temporal_window_bwd", _hip.ptr(g_adj), _hip.ptr(soft), _hip.ptr(cur), _hip.ptr(part),
+              B, g_adj.shape[-1], W, S, det, _hip.stream())
+        g_window = part.sum(0)
+        if Wn < W:
+            g_window = torch.cat([g_window, g_window.new_zeros(W - Wn)])
+        return g_adj, g_window, None, None, None, None, None
+
+
+def temporal_window_(adj, window, cur, noise, num_samples, deterministic, flags):
+    """noise: [S, B, min(W, N)] standard gumbel draws (None when deterministic)"""
+    if noise is not None:
+        noise = noise.contiguous()
+    return _TemporalWindow.apply(adj, window, cur, noise, num_samples, deterministic, flags)
+
+
 def edge_dense_(adj, cur):
     _hip.on_device(adj, cur)
     B, N, _ = adj.shape
@@ -1147,22 +1189,43 @@ def fused_rollout(obs, nodes0, packed, adj0, num_nodes0, flags, cfg):
     return _FusedRollout.apply(obs, nodes0, packed, adj0, num_nodes0, flags, cfg)
 
 
+def rows_linear(x2, weight, bias=None, transpose=False, ln=None, out=None, ldy=0):
+    """csrc/rows_linear.hip on rows x2 [M, *]: x2 W^T + bias (transpose: x2 W).  ln = (gamma, beta, eps):
+    -> (pre-activation, LayerNorm(relu(pre-activation))).  out/ldy: write into a wider matrix."""
+    x2 = x2.contiguous()
+    weight = weight.contiguous()
+    _hip.on_device(x2, weight, bias)
+    M = x2.shape[0]
+    O, I = weight.shape
+    n_out = I if transpose else O
+    y = out if out is not None else torch.empty(M, n_out, device=x2.device, dtype=_f32)
+    h = torch.empty(M, n_out, device=x2.device, dtype=_f32) if ln is not None else None
+    _call("gcm_rows_linear", _hip.ptr(x2), _hip.ptr(weight), _hip.ptr(bias), _hip.ptr(y), M, I, O,
+          int(transpose), ldy, _hip.ptr(ln[0]) if ln else None, _hip.ptr(ln[1]) if ln else None,
+          float(ln[2]) if ln else 0.0, _hip.ptr(h), _hip.stream())
+    return (y, h) if ln is not None else y
+
+
 class _SkinnyLinear(torch.autograd.Function):
-    """y = x W^T + b for many rows and narrow layers (the LearnedEdge edge network): forward and
-    dX are library GEMMs, the weight gradient - a [O x M] x [M x I] product with M = B*N rows, which
-    a library GEMM runs on one or two workgroups - is gcm_skinny_wgrad (rows split over the grid)."""
+    """y = x W^T + b for many rows and narrow layers (<= 64 features: the LearnedEdge edge network, the
+    PositionalEncoding re-projection): forward and dX are gcm_rows_linear (a row stream through the matrix
+    cores), the weight gradient - a [O x M] x [M x I] product with M = B*N rows, which a library GEMM runs
+    on one or two workgroups - is gcm_skinny_wgrad (rows split over the grid)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        y = rows_linear(x.reshape(-1, x.shape[-1]), weight, bias)
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad
-        gx = g.matmul(weight) if need_x else None
+        gx = None
+        if need_x:
+            gx = rows_linear(g.reshape(-1, weight.shape[0]), weight, transpose=True).view(x.shape)
         gw = gb = None
         if need_w or need_b:
             O, I = weight.shape
@@ -1248,18 +1311,11 @@ def default_edge_network(net):
 def _mlp_fwd(x2, w0, b0, g0, be0, w1, b1, g1, be1, w2, b2, eps0, eps1):
     """Linear - ReLU - LayerNorm - Linear - ReLU - LayerNorm - Linear on rows x2 [M, I];
     -> (out [M, O], tensors the backward needs)."""
-    lin = torch.nn.functional.linear
-    M = x2.shape[0]
-    st = _hip.stream()
-    p0 = lin(x2, w0, b0)                                   # pre-activations are saved,
-    h0 = torch.empty_like(p0)                              # the row statistics recomputed
-    _call("gcm_relu_layernorm_fwd", _hip.ptr(p0), _hip.ptr(g0), _hip.ptr(be0), _hip.ptr(h0), M,
-          p0.shape[1], eps0, st)
-    p1 = lin(h0, w1, b1)
-    h1 = torch.empty_like(p1)
-    _call("gcm_relu_layernorm_fwd", _hip.ptr(p1), _hip.ptr(g1), _hip.ptr(be1), _hip.ptr(h1), M,
-          p1.shape[1], eps1, st)
-    return lin(h1, w2, b2), (x2, p0, h0, p1, h1, w0, g0, w1, g1, w2)
+    # three launches of gcm_rows_linear, the first two with the ReLU + LayerNorm epilogue; the
+    # pre-activations are saved, the row statistics recomputed in the backward
+    p0, h0 = rows_linear(x2, w0, b0, ln=(g0, be0, eps0))
+    p1, h1 = rows_linear(h0, w1, b1, ln=(g1, be1, eps1))
+    return rows_linear(h1, w2, b2), (x2, p0, h0, p1, h1, w0, g0, w1, g1, w2)
 
 
 def _mlp_bwd(g2, saved, eps, has_bias, need_x):
@@ -1289,11 +1345,11 @@ def _mlp_bwd(g2, saved, eps, has_bias, need_x):
         return dx, dgb[:F], dgb[F:]
 
     dw2, db2 = wgrad(g2, h1, w2.shape[0], w2.shape[1])
-    gp1, dg1, dbe1 = ln_bwd(g2.matmul(w2), p1, g1, eps[1])
+    gp1, dg1, dbe1 = ln_bwd(rows_linear(g2, w2, transpose=True), p1, g1, eps[1])
     dw1, db1 = wgrad(gp1, h0, w1.shape[0], w1.shape[1])
-    gp0, dg0, dbe0 = ln_bwd(gp1.matmul(w1), p0, g0, eps[0])
+    gp0, dg0, dbe0 = ln_bwd(rows_linear(gp1, w1, transpose=True), p0, g0, eps[0])
     dw0, db0 = wgrad(gp0, x2, w0.shape[0], w0.shape[1])
-    gx = gp0.matmul(w0) if need_x else None
+    gx = rows_linear(gp0, w0, transpose=True) if need_x else None
     hb = has_bias
     return gx, [dw0, db0 if hb[0] else None, dg0, dbe0, dw1, db1 if hb[1] else None, dg1, dbe1, dw2,
                 db2 if hb[2] else None]
@@ -1374,7 +1430,7 @@ class _LearnedEdgeDefault(torch.autograd.Function):
 def learned_edge_default(net, nodes, adj, cur, noise, cutoff):
     """The fused dense LearnedEdge when `net` is the default edge network on device tensors, else None."""
     mods = default_edge_network(net)
-    if mods is None or not nodes.is_cuda or nodes.dtype != _f32 or nodes.shape[0] * nodes.shape[1] < 2048:
+    if mods is None or not nodes.is_cuda or nodes.dtype != _f32:
         return None
     l0, _, n0, l1, _, n1, l2 = mods
     if l2.out_features != 1 or l0.in_features != 2 * nodes.shape[2]:
@@ -1387,7 +1443,7 @@ def edge_network_forward(net, x):
     """net(x) for the default architecture on device rows: one autograd node over the row-split
     kernels; anything else is called as the torch module it is."""
     mods = default_edge_network(net)
-    if mods is None or not x.is_cuda or x.dtype != _f32 or x.numel() // x.shape[-1] < 2048:
+    if mods is None or not x.is_cuda or x.dtype != _f32 or x.numel() == 0:
         return net(x)
     l0, _, n0, l1, _, n1, l2 = mods
     return _EdgeMLP.apply(x, l0.weight, l0.bias, n0.weight, n0.bias, l1.weight, l1.bias, n1.weight, n1.bias,
@@ -1412,6 +1468,57 @@ class _PosEncAdd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, None, None
+
+
+class _PosEncCat(torch.autograd.Function):
+    """PositionalEncoding(mode="cat") (gcm.py:133-140): rows i <= num_nodes[b] become
+    [pe[i, :cat_dim] | reproject(x[b, i])], the rows beyond stay x - gcm_rows_linear writes the
+    re-projection straight into the output's columns cat_dim.., one element-wise pass finishes it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pe, num_nodes, cat_dim):
+        x = x.contiguous()
+        _hip.on_device(x, weight, bias, pe, num_nodes)
+        B, N, F = x.shape
+        out = torch.empty_like(x)
+        rows_linear(x.view(B * N, F), weight, bias, out=out.view(B * N, F)[:, cat_dim:], ldy=F)
+        _call("gcm_posenc_cat_finish", _hip.ptr(x), _hip.ptr(pe), pe.stride(0), _hip.ptr(num_nodes), _hip.ptr(out),
+              B, N, F, cat_dim, _hip.stream())
+        ctx.save_for_backward(x, weight, num_nodes)
+        ctx.cat_dim = cat_dim
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, num_nodes = ctx.saved_tensors
+        B, N, F = x.shape
+        cat = ctx.cat_dim
+        g = g.contiguous()
+        g_x = torch.empty_like(x)
+        g_proj = torch.empty(B * N, F - cat, device=x.device, dtype=_f32)
+        _call("gcm_posenc_cat_bwd", _hip.ptr(g), _hip.ptr(num_nodes), _hip.ptr(g_x), _hip.ptr(g_proj), B, N, F, cat,
+              _hip.stream())
+        if ctx.needs_input_grad[0]:
+            g_x = g_x + rows_linear(g_proj, weight, transpose=True).view(B, N, F)
+        else:
+            g_x = None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            O, I = weight.shape
+            lib = _hip.lib()
+            ws_bytes = lib.gcm_skinny_wgrad_workspace_bytes(B * N, O, I)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            out = torch.empty(O * I + O, device=g.device, dtype=_f32)
+            _call("gcm_skinny_wgrad", _hip.ptr(g_proj), _hip.ptr(x), _hip.ptr(out), _hip.ptr(ws), ws_bytes,
+                  B * N, O, I, _hip.stream())
+            gw = out[:O * I].view(O, I)
+            gb = out[O * I:] if ctx.has_bias else None
+        return g_x, gw, gb, None, None, None
+
+
+def posenc_cat(x, weight, bias, pe, num_nodes, cat_dim):
+    return _PosEncCat.apply(x, weight, bias, pe, num_nodes, cat_dim)
 
 
 def posenc_add_(x, pe, num_nodes):

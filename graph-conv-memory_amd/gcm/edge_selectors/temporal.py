@@ -6,7 +6,9 @@ from typing import List
 import torch
 
 from .. import _ops
-from ..util import sparsemax as _sparsemax
+
+
+WINDOW_ERROR = "TemporalBackedge(learned=True): a graph holds more nodes than the learning window ({})"
 
 
 class TemporalBackedge(torch.nn.Module):
@@ -25,6 +27,8 @@ class TemporalBackedge(torch.nn.Module):
             self.deterministic = deterministic
         # test hook: callable(shape, device) -> standard gumbel noise (default: device RNG)
         self.noise_fn = None
+        # the flag word of the DenseGCM that drives this selector (it lends it before each call)
+        self._gcm_flags = None
 
     def native_desc(self):
         """Descriptor for the fused / rollout paths (struct gcm_selector_desc)."""
@@ -38,44 +42,31 @@ class TemporalBackedge(torch.nn.Module):
         return d
 
     def learned_forward(self, nodes, adj_mats, edge_weights, num_nodes, B):
-        """temporal.py:51-70, all graphs at once: every graph with n_b > 0 nodes draws `num_samples`
-        straight-through gumbel one-hots over window[:n_b] (or one hard sparsemax when
-        deterministic), ORs them (util.diff_or: res + t - res*t) and adds the result to
-        adj[b, n_b, :n_b].  Like the reference this needs n_b <= learning_window (its slice
-        assignment raises a shape RuntimeError beyond it)."""
+        """temporal.py:51-70, all graphs in one launch (csrc/temporal_window.hip): every graph with
+        n_b > 0 nodes draws `num_samples` straight-through gumbel one-hots over window[:n_b] (or one hard
+        sparsemax when deterministic), ORs them (util.diff_or: res + t - res*t) and adds the result to
+        adj[b, n_b, :n_b], in place like the reference.  Like the reference this needs
+        n_b <= learning_window (its slice assignment raises a shape RuntimeError beyond it): the kernel
+        raises a flag instead, which DenseGCM surfaces with its other flags (finite_check) - a selector
+        called on its own checks it on the spot."""
         W = self.window.numel()
         N = adj_mats.shape[-1]
-        if int(num_nodes.max()) > W:
-            raise RuntimeError(f"TemporalBackedge(learned=True): a graph holds {int(num_nodes.max())} nodes, "
-                               f"the learning window only {W}")
         Wn = min(W, N)
-        cols = torch.arange(Wn, device=nodes.device)
-        valid = cols[None, :] < num_nodes[:, None]                                   # [B, Wn]
-        # an empty graph takes part with one dummy column so that its softmax stays finite; its
-        # mask is zeroed below
-        keep = valid | ((num_nodes == 0)[:, None] & (cols == 0)[None, :])
-        logits = self.window[:Wn].to(nodes.device)[None, :].expand(B, Wn)
-        if self.deterministic:
-            soft = _sparsemax(logits.masked_fill(~keep, float("-inf")))
-            mask = (soft > 0).float() - soft.detach() + soft                         # util.py:38-42
-        else:
+        noise = None
+        if not self.deterministic:
             S = self.num_samples
             if self.noise_fn is not None:
-                g = self.noise_fn((S, B, Wn), nodes.device)
+                noise = self.noise_fn((S, B, Wn), nodes.device)
             else:                                                                    # F.gumbel_softmax's draw
-                g = -torch.empty(S, B, Wn, device=nodes.device).exponential_().log()
-            soft = torch.softmax((logits[None] + g).masked_fill(~keep[None], float("-inf")), dim=-1)
-            hard = torch.zeros_like(soft).scatter_(-1, soft.argmax(-1, keepdim=True), 1.0)
-            y = hard - soft.detach() + soft
-            mask = torch.zeros_like(y[0])
-            for s in range(S):                                                       # util.py:456-465
-                mask = mask + y[s] - mask * y[s]
-        mask = mask * valid
-        b_idx = torch.arange(B, device=nodes.device)
+                noise = -torch.empty(S, B, Wn, device=nodes.device).exponential_().log()
+        flags, own = self._gcm_flags, False
+        if flags is None or flags.device != adj_mats.device:
+            flags, own = torch.zeros(1, dtype=torch.int32, device=adj_mats.device), True
+        window = self.window if self.window.device == adj_mats.device else self.window.to(adj_mats.device)
         cur = num_nodes.clamp(max=N - 1)
-        row = adj_mats[b_idx, cur]
-        row = torch.cat([row[:, :Wn] + mask, row[:, Wn:]], dim=-1)
-        adj_mats = adj_mats.index_put((b_idx, cur), row)
+        adj_mats = _ops.temporal_window_(adj_mats, window, cur, noise, self.num_samples, self.deterministic, flags)
+        if own and int(flags.item()):
+            raise RuntimeError(WINDOW_ERROR.format(W))
         return adj_mats, edge_weights
 
     def forward(self, nodes, adj_mats, edge_weights, num_nodes, B):

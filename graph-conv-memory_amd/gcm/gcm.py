@@ -28,8 +28,8 @@ class PositionalEncoding(torch.nn.Module):
     """Embed a sin/cos positional encoding into the graph without touching future nodes
     (node index > num_nodes).  Reference: src/gcm/gcm.py:92-143 (same constructor, same lazily
     built `pe` buffer and `reproject` layer).  mode="add" is one in-place kernel
-    (gcm_posenc_add); mode="cat" re-projects the features with a library GEMM and writes the
-    first cat_dim columns from the table."""
+    (gcm_posenc_add); mode="cat" re-projects the features with gcm_rows_linear straight into the
+    output's last columns and writes the first cat_dim columns from the table (gcm_posenc_cat_finish)."""
 
     def __init__(self, max_len: int = 5000, mode="add", cat_dim: int = 8):
         super().__init__()
@@ -60,6 +60,10 @@ class PositionalEncoding(torch.nn.Module):
             return _ops.posenc_add_(x.contiguous() if not x.is_contiguous() else x, self.pe,
                                     num_nodes)
         N, F = x.shape[1], x.shape[2]
+        if x.is_cuda and x.dtype == torch.float32 and F <= 64 and 0 < self.cat_dim < F and x.dim() == 3 \
+                and self.pe.shape[0] >= N:
+            return _ops.posenc_cat(x, self.reproject.weight, self.reproject.bias, self.pe, num_nodes, self.cat_dim)
+        # (wider features than the row kernel takes: torch ops)
         live = (torch.arange(N, device=x.device)[None, :] <= num_nodes[:, None]).unsqueeze(-1)
         pe = self.pe[:N, : self.cat_dim].unsqueeze(0).expand(x.shape[0], -1, -1)
         enc = torch.cat((pe, self.reproject(x)), dim=-1)
@@ -155,6 +159,14 @@ class DenseGCM(torch.nn.Module):
                 n += cfg._rows_fast.steps()
         return n
 
+    def _flag_users(self):
+        users = self.__dict__.get("_flag_user_list")
+        if users is None:
+            users = [m for sel in (self.edge_selectors, self.aux_edge_selectors) if sel is not None
+                     for m in sel.modules() if hasattr(m, "_gcm_flags")]
+            self.__dict__["_flag_user_list"] = users
+        return users
+
     # -- device flag word ------------------------------------------------------
     def _flag_word(self, device):
         f = self._flags.get(device)
@@ -169,6 +181,9 @@ class DenseGCM(torch.nn.Module):
         if bits & _hip.FLAG_WRAPPED and not DenseGCM.did_warn:
             print("Overflow detected, wrapping around. Will not warn again")
             DenseGCM.did_warn = True
+        if bits & _hip.FLAG_WINDOW:
+            from .edge_selectors.temporal import WINDOW_ERROR
+            raise RuntimeError(WINDOW_ERROR.format("see TemporalBackedge.learning_window"))
         if bits & _hip.FLAG_NONFINITE:
             raise AssertionError("Got NaN in returned memory, try using tanh activation")
 
@@ -687,7 +702,7 @@ class DenseGCM(torch.nn.Module):
         d = dict(self.__dict__)
         d.update(_plan_cache=None, _fold=None, _noise_pool=None, _token=object(), _cfg_cache={}, _cfg_last=None,
                  _packed_cache=None, _flags={}, _pending=[], _pinned_pool=[], _ctr=[0], _fast=None,
-                 _learned_chain=None)
+                 _learned_chain=None, _flag_user_list=None)
         return d
 
     def forward(
@@ -763,6 +778,8 @@ class DenseGCM(torch.nn.Module):
         user_code = self.preprocessor is not None or self.positional_encoder is not None
         dirty_nodes = nodes.clone() if user_code else nodes
 
+        for m in self._flag_users():      # selectors whose kernels raise flags write this module's word
+            m._gcm_flags = flags
         if self.edge_selectors:
             adj, weights = self.edge_selectors(dirty_nodes, adj, weights, cur, B)
         if self.preprocessor:

@@ -14,8 +14,8 @@ _FUSABLE = {torch.nn.Tanh: _hip.ACT_TANH, torch.nn.ReLU: _hip.ACT_RELU}
 class SkinnyLinear(torch.nn.Linear):
     """torch.nn.Linear (same parameters, same state_dict keys) for inputs with very many rows and
     <= 64 features in and out - the layers of LearnedEdge's default edge network (learned.py:38-51).
-    Forward and input gradient are the library GEMMs; the weight gradient runs as the row-split
-    kernel gcm_skinny_wgrad.  Anything else (CPU tensors, wide layers, few rows, other dtypes)
+    Forward and input gradient are gcm_rows_linear (csrc/rows_linear.hip); the weight gradient runs as
+    the row-split kernel gcm_skinny_wgrad.  Anything else (CPU tensors, wide layers, few rows, other dtypes)
     behaves exactly like nn.Linear."""
 
     MIN_ROWS = 2048

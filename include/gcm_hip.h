@@ -93,6 +93,42 @@ int gcm_gather_rows_bwd(const float* g_out, const int64_t* cur_idx, float* g_fea
 int gcm_edge_temporal(float* adj, const int64_t* cur_idx, const int32_t* hops_host, int n_hops,
                       int direction, int B, int N, gcm_stream_t stream);
 
+/* edge_selectors/temporal.py:51-70 (TemporalBackedge(learned=True)): every graph with 0 < n_b = cur_idx[b]
+ * stored nodes draws S straight-through gumbel one-hots over window[:n_b] (noise [S, B, Wn], Wn = min(W, N),
+ * standard gumbel draws) - or, deterministic, one hard sparsemax (util.py:29-42) - ORs them (util.py:456-465)
+ * and ADDS the mask to adj[b, n_b, :n_b].  soft [S or 1, B, Wn] (the soft samples) is what the backward
+ * needs; mask_ws [B, Wn] scratch.  n_b > W raises GCM_FLAG_WINDOW (the reference's slice assignment fails
+ * there) and leaves the graph untouched.  S <= 32. */
+#define GCM_FLAG_WINDOW 128u
+int gcm_temporal_window_fwd(const float* window, const float* noise, const int64_t* cur_idx, float* adj,
+                            float* soft, float* mask_ws, int B, int N, int W, int S, int deterministic,
+                            uint32_t* flags, gcm_stream_t stream);
+/* its adjoint w.r.t. the window logits: g_window_part [B, Wn], one row per graph (the caller sums over b);
+ * g_adj [B, N, N] is the gradient of the adjacency the forward wrote (it passes through to adj unchanged). */
+int gcm_temporal_window_bwd(const float* g_adj, const float* soft, const int64_t* cur_idx,
+                            float* g_window_part, int B, int N, int W, int S, int deterministic,
+                            gcm_stream_t stream);
+
+/* ---- narrow Linear layers on many rows (edge_selectors/learned.py:38-51 edge network; gcm.py:133-140) ----
+ * W is [O, I] row major (torch.nn.Linear.weight), I, O <= 64.
+ *   transpose = 0:  y[M, O] = x[M, I] W^T + bias      (bias may be NULL)
+ *   transpose = 1:  y[M, I] = x[M, O] W               (the input gradient; bias NULL)
+ * ldy: leading dimension of y (0: dense).  gamma/beta/h non-NULL (transpose = 0 only): additionally
+ * h[M, O] = LayerNorm(relu(y)) * gamma + beta over the O columns (biased variance, eps) - the
+ * Linear-ReLU-LayerNorm stage of the default edge network in one pass over the rows. */
+int gcm_rows_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int I, int O,
+                    int transpose, int ldy, const float* gamma, const float* beta, float eps, float* h,
+                    gcm_stream_t stream);
+/* PositionalEncoding(mode="cat") (gcm.py:133-140): out [B,N,F] already holds the re-projected features in
+ * its columns cat_dim.. (gcm_rows_linear with ldy = F); this writes the table columns pe[i, :cat_dim] of the
+ * rows i <= num_nodes[b] and restores the rows beyond from x. */
+int gcm_posenc_cat_finish(const float* x, const float* pe, int pe_ld, const int64_t* num_nodes, float* out,
+                          int B, int N, int F, int cat_dim, gcm_stream_t stream);
+/* adjoint: g_x [B,N,F] = the rows beyond num_nodes of g_out (zero elsewhere), g_proj [B*N, F - cat_dim] =
+ * the encoded rows' columns cat_dim.. (zero elsewhere). */
+int gcm_posenc_cat_bwd(const float* g_out, const int64_t* num_nodes, float* g_x, float* g_proj, int B, int N,
+                       int F, int cat_dim, gcm_stream_t stream);
+
 /* edge_selectors/dense.py:11-23. */
 int gcm_edge_dense(float* adj, const int64_t* cur_idx, int B, int N, gcm_stream_t stream);
 

@@ -481,8 +481,12 @@ def test_temporal_backedge_learned_variants():
         assert int(adj.sum()) <= 2 * B * t and (t == 0 or int(adj[:, t].sum()) >= B)
     torch.stack(outs).sum().backward()
     assert sel.window.grad is not None and bool(torch.isfinite(sel.window.grad).all())
-    with pytest.raises(RuntimeError):                     # n_b = W + 1 nodes: window too short
-        mem(torch.randn(B, F, device=DEV), hidden)
+    with pytest.raises(RuntimeError):                     # n_b = W + 1 nodes: window too short (the kernel
+        mem(torch.randn(B, F, device=DEV), hidden)        # raises a flag, surfaced with the module's others)
+        mem.check_flags()
+    with pytest.raises(RuntimeError):                     # ... and on the spot for a selector used on its own
+        sel._gcm_flags = None
+        sel(hidden[0], hidden[1].detach().clone(), hidden[2], hidden[3], B)
 
     # deterministic: hard sparsemax over window[:n_b] vs the oracle's per-graph loop
     torch.manual_seed(2)
@@ -749,3 +753,60 @@ def test_posenc_in_step_matches_reference(mode):
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
         torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+
+
+@pytest.mark.parametrize("B,N,F,cat", [(5, 12, 10, 4), (3, 130, 64, 8), (2, 7, 3, 1)])
+def test_posenc_cat_kernel_matches_oracle(B, N, F, cat):
+    """PositionalEncoding(mode="cat") (gcm.py:133-140) as gcm_rows_linear + gcm_posenc_cat_finish against the
+    oracle: output, and the gradients w.r.t. the nodes and the re-projection layer."""
+    from gcm.gcm import PositionalEncoding
+    torch.manual_seed(B * 100 + N)
+    x = torch.randn(B, N, F)
+    num_nodes = torch.randint(0, N, (B,))
+    num_nodes[0] = 0
+    num_nodes[-1] = N - 1
+    weight = torch.randn(B, N, F)
+    pe = PositionalEncoding(max_len=N + 3, mode="cat", cat_dim=cat)
+    xd = x.to(DEV).requires_grad_(True)
+    pe.run_once(xd)
+    rp = torch.nn.Linear(F, F - cat)
+    rp.load_state_dict({k: v.cpu() for k, v in pe.reproject.state_dict().items()})
+    ope = od.PositionalEncoding(max_len=N + 3, mode="cat", cat_dim=cat, reproject=rp)
+    xo = x.clone().requires_grad_(True)
+    want = ope(xo, num_nodes)
+    got = pe(xd, num_nodes.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6)
+    live = torch.arange(N)[None, :] <= num_nodes[:, None]
+    assert torch.equal(got.detach().cpu()[~live], x[~live])                      # rows beyond stay bit exact
+    assert torch.equal(got.detach().cpu()[live][:, :cat], want.detach()[live][:, :cat])   # table columns too
+    (got * weight.to(DEV)).sum().backward()
+    (want * weight).sum().backward()
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-5, atol=1e-6)
+    for (k, p), (_, q) in zip(pe.reproject.named_parameters(), rp.named_parameters()):
+        scale = float(q.grad.abs().max())
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-5, atol=2e-6 * scale, msg=k)
+
+
+@pytest.mark.parametrize("M,I,O", [(1, 5, 7), (300, 64, 64), (4097, 32, 1), (129, 1, 33), (2048, 48, 17)])
+def test_rows_linear_matches_torch(M, I, O):
+    """gcm_rows_linear (the edge network's Linear layers, learned.py:38-51): y = x W^T + b, the input
+    gradient x W, and the ReLU + LayerNorm epilogue, against torch in float64."""
+    from gcm import _ops
+    torch.manual_seed(M + I + O)
+    x, w, b = torch.randn(M, I), torch.randn(O, I) / I ** 0.5, torch.randn(O)
+    g, gamma, beta = torch.randn(M, O), torch.rand(O) + 0.5, torch.randn(O)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = _ops.rows_linear(xd, wd, bd)
+    want = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    torch.testing.assert_close(y.cpu().double(), want, rtol=1e-5, atol=1e-5)
+    gx = _ops.rows_linear(g.to(DEV), wd, transpose=True)
+    torch.testing.assert_close(gx.cpu().double(), g.double() @ w.double(), rtol=1e-5, atol=1e-5)
+    p, h = _ops.rows_linear(xd, wd, bd, ln=(gamma.to(DEV), beta.to(DEV), 1e-5))
+    assert torch.equal(p, y)
+    if O > 1:
+        want_h = torch.nn.functional.layer_norm(torch.relu(want), (O,), gamma.double(), beta.double(), 1e-5)
+        torch.testing.assert_close(h.cpu().double(), want_h, rtol=1e-4, atol=1e-4)
+    # into a wider matrix (the PositionalEncoding re-projection)
+    wide = torch.full((M, O + 3), 7.0, device=DEV)
+    _ops.rows_linear(xd, wd, bd, out=wide[:, 3:], ldy=O + 3)
+    assert torch.equal(wide[:, 3:], y) and bool((wide[:, :3] == 7.0).all())

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from _golden import Fixture
-from oracle import pyg, sparse as osp
+from oracle import dense as od, pyg, sparse as osp
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -454,3 +454,57 @@ def test_sparse_learned_edge_default_noise_runs():
     assert bool((idx[2] < idx[1]).all())                      # causal
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sel.edge_network.parameters())
     assert any(k.startswith("gnorm_") for k in sel.stats)     # grad hooks (store_grads)
+
+
+def test_sparse_learned_edge_smoke_size_matches_oracle():
+    """The reference's smoke size (tests/test_sparse_gcm.py:822-852: B=8, N=256, F=32) with injected
+    gumbel draws against the oracle: outputs, sampled edges (bit exact) and every gradient.  At this
+    size the edge network runs on ~20 k candidate rows per call - gcm_rows_linear / gcm_skinny_wgrad /
+    gcm_relu_layernorm_bwd, no library GEMM."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.learned import LearnedEdge
+    torch.manual_seed(5)
+    B, N, F, tau_len, calls, window = 8, 256, 32, 24, 3, 40
+    ref = osp.canonical_gnn(F, F, act=torch.nn.Tanh)
+    g = dev_sparse_gnn(ref, F, F, torch.nn.Tanh)
+    sel = LearnedEdge(F, num_edge_samples=3, window=window, store_grads=False)
+    net = od.build_edge_network(F)
+    net.load_state_dict({k[len("edge_network."):]: v for k, v in sel.state_dict().items()
+                         if k.startswith("edge_network.")})
+    sel = sel.to(DEV)
+    draws = []
+
+    def dev_noise(logits):
+        gz = -torch.empty(logits.numel()).exponential_().log()
+        draws.append(gz)
+        return gz.to(DEV)
+
+    sel.noise_fn = dev_noise
+    mem = SparseGCM(g, edge_selectors=sel, graph_size=N)
+    obs = torch.randn(calls, B, tau_len, F)
+    od_ = obs.to(DEV).requires_grad_(True)
+    taus = torch.full((B,), tau_len, dtype=torch.long)
+    hidden, outs = None, []
+    for c in range(calls):
+        out, hidden = mem(od_[c], taus.to(DEV), hidden)
+        outs.append(out)
+    torch.stack(outs).mean().backward()
+
+    it = iter(draws)
+    osel = osp.LearnedEdge(net, 3, window=window, tau=sel.state_dict()["tau_param"].cpu(),
+                           noise_fn=lambda n: next(it))
+    oo = obs.clone().requires_grad_(True)
+    ohid, oouts = None, []
+    for c in range(calls):
+        out, ohid = osp.sparse_step(oo[c], taus, ohid, ref, graph_size=N, edge_selectors=osel)
+        oouts.append(out)
+    torch.stack(oouts).mean().backward()
+    assert torch.equal(hidden[1].coalesce().indices().cpu(), ohid[1].coalesce().indices())
+    for a, b in zip(outs, oouts):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-5, atol=1e-5)
+    gs = float(oo.grad.abs().max())
+    torch.testing.assert_close(od_.grad.cpu(), oo.grad, rtol=1e-4, atol=1e-5 * gs)
+    for (k, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
+    for (k, p), (_, q) in zip(sel.edge_network.named_parameters(), net.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-5 * float(q.grad.abs().max()) + 1e-8, msg=k)
