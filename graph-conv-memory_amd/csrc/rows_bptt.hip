@@ -464,16 +464,14 @@ namespace gcm_rows {
 // load that does not depend on another one issued before the first use (weights, the step's vectors, the first
 // eight live rows with their adjacency rows), the rows summed in the wave's LDS tile, one batch of
 // read-modify-writes on the accumulators at the end.  H1, H2 <= 32, F <= 64.
-__global__ __launch_bounds__(256) void k_rows_dx_step(
+// ATOMIC: many steps of a chain run concurrently (k_rows_dx_all) - the accumulators take hardware float adds
+template <bool ATOMIC>
+__device__ __forceinline__ void rows_dx_body(
     const float* __restrict__ sv, const float* __restrict__ gmx, long gmx_sb, long gmx_sh,
     const float* __restrict__ gnodes, const float* __restrict__ w_rel1, const float* __restrict__ w_root1,
-    const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay,
-    const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int B, int N, int F, int H1, int H2) {
-  extern __shared__ float dxs[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
-  float* tile = dxs + (size_t)wave * N * F;
+    const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1, int act2, const SavedLayout& lay,
+    const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int b, int lane, float* tile, int B, int N,
+    int F, int H1, int H2) {
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
   constexpr int LB = 8;   // live rows fetched ahead
   // ---- loads ---------------------------------------------------------------------------------------
@@ -561,6 +559,14 @@ __global__ __launch_bounds__(256) void k_rows_dx_step(
   }
   if (gnodes) {   // a gradient handed to the node matrix this step returned: every row up to cur
     for (int k = 0; k <= cur; ++k) add_row(k, lane < F ? gnodes[((size_t)b * N + k) * F + lane] : 0.f);
+    // ... and the rows beyond, which no step has touched yet: still the rows of the state the chain started from
+    if (gn0 && lane < F)
+      for (int k = cur + 1; k < N; ++k) {
+        float* q = gn0 + ((size_t)b * N + k) * F + lane;
+        const float v = gnodes[((size_t)b * N + k) * F + lane];
+        if (ATOMIC) unsafeAtomicAdd(q, v);
+        else *q += v;
+      }
   }
   // ---- row k holds the node inserted at chain step s_lin - (cur - k) (negative: an initial node) -------
   while (tm0 | tm1) {
@@ -579,12 +585,56 @@ __global__ __launch_bounds__(256) void k_rows_dx_step(
         if (lane < F) v8[i] = tile[k * F + lane];
       }
     }
+    if (ATOMIC) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) old8[i] = (pp[i] && lane < F) ? *pp[i] : 0.f;
+      for (int i = 0; i < 8; ++i)
+        if (pp[i] && lane < F) unsafeAtomicAdd(pp[i], v8[i]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (pp[i] && lane < F) *pp[i] = old8[i] + v8[i];
+      for (int i = 0; i < 8; ++i) old8[i] = (pp[i] && lane < F) ? *pp[i] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (pp[i] && lane < F) *pp[i] = old8[i] + v8[i];
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void k_rows_dx_step(
+    const float* __restrict__ sv, const float* __restrict__ gmx, long gmx_sb, long gmx_sh,
+    const float* __restrict__ gnodes, const float* __restrict__ w_rel1, const float* __restrict__ w_root1,
+    const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay,
+    const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int B, int N, int F, int H1, int H2) {
+  extern __shared__ float dxs[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  rows_dx_body<false>(sv, gmx, gmx_sb, gmx_sh, gnodes, w_rel1, w_root1, w_rel2, w_root2, act1, act2, lay, count0, gx,
+                      gn0, s_lin, b, lane, dxs + (size_t)wave * N * F, B, N, F, H1, H2);
+}
+
+// device pointers of up to GCM_ROWS_MAX_STEPS consecutive steps of a chain (NULL: that step has none)
+struct DxTable {
+  const float* saved[GCM_ROWS_MAX_STEPS];
+  const float* gmx[GCM_ROWS_MAX_STEPS];
+  const float* gn[GCM_ROWS_MAX_STEPS];
+};
+
+// every (step, graph) of the table at once, one wave each; steps with neither gradient are skipped
+__global__ __launch_bounds__(256) void k_rows_dx_all(
+    DxTable tab, int n_steps, int s0, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel1,
+    const float* __restrict__ w_root1, const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1,
+    int act2, SavedLayout lay, const int64_t* __restrict__ count0, float* gx, float* gn0, int B, int N, int F, int H1,
+    int H2) {
+  extern __shared__ float dxs[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_steps * B) return;
+  const int s = item / B, b = item - s * B;
+  const float* gm = tab.gmx[s];
+  const float* gn = tab.gn[s];
+  if (!gm && !gn) return;
+  rows_dx_body<true>(tab.saved[s], gm, gmx_sb, gmx_sh, gn, w_rel1, w_root1, w_rel2, w_root2, act1, act2, lay, count0,
+                     gx, gn0, s0 + s, b, lane, dxs + (size_t)wave * N * F, B, N, F, H1, H2);
 }
 
 }  // namespace gcm_rows
@@ -613,5 +663,39 @@ extern "C" int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx
   hipLaunchKernelGGL(gcm_rows::k_rows_dx_step, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, saved, g_mx,
                      gmx_stride_b, gmx_stride_h, g_nodes_out, params, params + (size_t)H1 * F, w_rel2, w_root2, act1,
                      act2, lay, count0, gx, gn0, s_lin, B, N, F, H1, H2);
+  return gcm_launch_status();
+}
+
+/* The same for up to GCM_ROWS_MAX_STEPS consecutive steps of a chain in ONE launch (one wave per step and
+ * graph): saved / g_mx / g_nodes_out are HOST arrays of n_steps device pointers (g_mx[s], g_nodes_out[s] NULL:
+ * none; every g_mx with the same element strides), s0 the chain index of the first.  The steps run
+ * concurrently, so gx / gn0 (zeroed by the caller) take hardware float atomic adds: the order of summation -
+ * and with it the last bits of the result - is not fixed; gcm_dense_rows_bptt_dx_step, handed the steps last
+ * to first, is the ordered form. */
+extern "C" int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_mx, long gmx_stride_b,
+                                          long gmx_stride_h, const float* const* g_nodes_out, int n_steps, int s0,
+                                          const float* params, int has_bias, int act1, int act2,
+                                          const int64_t* count0, float* gx, float* gn0, int B, int N, int F, int H1,
+                                          int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(saved && g_mx && g_nodes_out && params && count0 && gx && B > 0 && s0 >= 0);
+  GCM_REQUIRE(n_steps > 0 && n_steps <= GCM_ROWS_MAX_STEPS);
+  if (!gcm_dense_rows_dx_supported(N, F, H1, H2) || (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)))
+    return GCM_EUNSUPPORTED;
+  gcm_rows::DxTable tab;
+  for (int s = 0; s < GCM_ROWS_MAX_STEPS; ++s) {
+    tab.saved[s] = s < n_steps ? saved[s] : nullptr;
+    tab.gmx[s] = s < n_steps ? g_mx[s] : nullptr;
+    tab.gn[s] = s < n_steps ? g_nodes_out[s] : nullptr;
+    if (s < n_steps) GCM_REQUIRE(saved[s] != nullptr);
+  }
+  const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, true);
+  const size_t lds = sizeof(float) * 4 * (size_t)N * F;
+  gcm_allow_dynamic_lds((const void*)gcm_rows::k_rows_dx_all, lds);
+  const long items = (long)n_steps * B;
+  hipLaunchKernelGGL(gcm_rows::k_rows_dx_all, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream,
+                     tab, n_steps, s0, gmx_stride_b, gmx_stride_h, params, params + (size_t)H1 * F, w_rel2, w_root2,
+                     act1, act2, lay, count0, gx, gn0, B, N, F, H1, H2);
   return gcm_launch_status();
 }

@@ -245,19 +245,105 @@ struct RowsChainNode : public torch::autograd::Node {
     at::Tensor buf;             // the step's record (gcm_dense_rows_layout); starts with mx
     c10::VariableVersion vc;    // version counter of the belief tensor handed to the caller (it aliases
     uint32_t version;           // the head of the record) and its value when recorded
+    int out_mx = -1;            // which of this node's outputs the belief tensor is
+    int out_nodes = -1;         // dx: ... and the returned node matrix
+    int edge_x = -1;            // dx: the next edge that leads to this step's observation (-1: no gradient)
   };
-  std::vector<Rec> recs;   // recs[k] <-> forward output k
+  std::vector<Rec> recs;   // the recorded steps, in chain order
   at::Tensor packed;       // the packed parameter vector, detached (the kernel re-reads the weights)
   int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
   int64_t P = 0;           // floats the backward kernel writes (GNN gradient | d c1 with the deg term)
   bool executed = false, released = false;
+  // dx: the chain also differentiates w.r.t. its observations (and the node matrix it started from) - all of
+  // it in this ONE node, time-parallel (gcm_dense_rows_bptt_dx_all).  An observation's producer is younger
+  // than this node, and Node::add_next_edge refuses new edges once a node has parents (it could no longer
+  // keep parent.topological_nr > child.topological_nr for them).  The invariant is what matters, not the
+  // bookkeeping: this node starts with a topological number far above any ordinary graph's (2^40), appends
+  // an observation's edge directly when the producer's number is below its own - which also proves the
+  // producer does not depend on this chain's outputs (an ancestor's number would be larger) - and reports
+  // failure otherwise (a policy that feeds belief t-1 into observation t: one node per step, DxStepNode).
+  bool dx = false, want_gn0 = false;
+  int edge_gn0 = -1;
+  int64_t B = 0;
+  at::Tensor count0;       // num_nodes entering the first step
+  void start_dx() {
+    dx = true;
+    if (topological_nr_ < (1ull << 40)) topological_nr_ = 1ull << 40;
+  }
+  bool can_take(const at::Tensor& obs) const {
+    if (!obs.requires_grad()) return true;
+    const auto e = torch::autograd::impl::gradient_edge(obs);
+    if (!e.function) return true;
+    return e.function->topological_nr() < topological_nr_ || recs.empty();
+  }
+  int take_x_edge(const at::Tensor& obs) {   // -> index of the new next edge, -1: none needed
+    if (!obs.requires_grad()) return -1;
+    auto e = torch::autograd::impl::gradient_edge(obs);
+    if (!e.function) return -1;
+    const uint64_t p = e.function->topological_nr();
+    if (p >= topological_nr_) {
+      TORCH_CHECK(recs.empty(), "rows chain: observation depends on this chain's outputs");
+      topological_nr_ = p + (1ull << 32);   // first step, no parents yet: sit above the producer (stacked memories)
+    }
+    next_edges().push_back(std::move(e));
+    return (int)next_edges().size() - 1;
+  }
+  void apply_dx(variable_list& grads, variable_list& out, gcm_stream_t stream) {
+    const int K = (int)recs.size();
+    at::Tensor gx = at::zeros({K, B, F}, packed.options());
+    at::Tensor gn0 = want_gn0 ? at::zeros({B, N, F}, packed.options()) : at::Tensor();
+    // belief gradients with common element strides (an expanded one is read with stride 0; mixed strides:
+    // contiguous copies); node-matrix gradients contiguous
+    std::vector<at::Tensor> gms(K), gns(K);
+    int64_t sb = 0, sh = 0;
+    bool have = false, mixed = false;
+    for (int k = 0; k < K; ++k) {
+      const Rec& r = recs[k];
+      at::Tensor g = r.out_mx >= 0 ? grads[r.out_mx] : at::Tensor();
+      if (g.defined()) {
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        if (!have) { sb = g.stride(0); sh = g.stride(1); have = true; }
+        mixed = mixed || g.stride(0) != sb || g.stride(1) != sh;
+        gms[k] = g;
+      }
+      at::Tensor n = r.out_nodes >= 0 ? grads[r.out_nodes] : at::Tensor();
+      if (n.defined()) gns[k] = n.to(at::kFloat).contiguous();
+    }
+    if (mixed) {
+      for (auto& g : gms)
+        if (g.defined()) g = g.contiguous();
+      sb = H2;
+      sh = 1;
+    }
+    std::vector<const float*> sv(K, nullptr), gm(K, nullptr), gn(K, nullptr);
+    for (int k = 0; k < K; ++k) {
+      sv[k] = recs[k].buf.data_ptr<float>();
+      if (gms[k].defined()) gm[k] = gms[k].data_ptr<float>();
+      if (gns[k].defined()) gn[k] = gns[k].data_ptr<float>();
+    }
+    constexpr int CHUNK = 64;   // steps per launch (gcm_dense_rows_bptt_dx_all)
+    for (int k0 = 0; k0 < K; k0 += CHUNK) {
+      const int n = std::min(K - k0, CHUNK);
+      bool any = false;
+      for (int k = k0; k < k0 + n; ++k) any = any || gm[k] || gn[k];
+      if (!any) continue;
+      check(gcm_dense_rows_bptt_dx_all(sv.data() + k0, gm.data() + k0, (long)sb, (long)sh, gn.data() + k0, n, k0,
+                                       packed.data_ptr<float>(), has_bias, act1, act2, count0.data_ptr<int64_t>(),
+                                       gx.data_ptr<float>(), gn0.defined() ? gn0.data_ptr<float>() : nullptr, (int)B,
+                                       N, F, H1, H2, stream),
+            "gcm_dense_rows_bptt_dx_all");
+    }
+    for (int k = 0; k < K; ++k)
+      if (recs[k].edge_x >= 0 && task_should_compute_output(recs[k].edge_x)) out[recs[k].edge_x] = gx.select(0, k);
+    if (edge_gn0 >= 0 && gn0.defined() && task_should_compute_output(edge_gn0)) out[edge_gn0] = gn0;
+  }
   variable_list apply(variable_list&& grads) override {
     executed = true;
     TORCH_CHECK(!released, "Trying to backward through the live-row steps of a DenseGCM chain a second "
                            "time (their records were freed); pass retain_graph=True to the first call");
-    variable_list out(1);
-    TORCH_CHECK(grads.size() == recs.size(), "rows chain: ", grads.size(), " gradients for ", recs.size(),
-                " recorded steps");
+    variable_list out(num_outputs());
+    TORCH_CHECK(grads.size() == (dx ? 2 : 1) * recs.size(), "rows chain: ", grads.size(), " gradients for ",
+                recs.size(), " recorded steps");
     // groups of steps with equal batch size and gradient strides (an expanded gradient, as mean()
     // produces, is read with stride 0 - no .contiguous() copies), in first-seen order
     struct Group {
@@ -266,15 +352,15 @@ struct RowsChainNode : public torch::autograd::Node {
     };
     std::vector<Group> groups;
     std::vector<at::Tensor> keep;
-    for (size_t k = 0; k < grads.size(); ++k) {
-      if (!grads[k].defined()) continue;
+    for (size_t k = 0; k < recs.size(); ++k) {
       const Rec& r = recs[k];
+      if (!grads[r.out_mx].defined()) continue;
       TORCH_CHECK(r.vc.current_version() == r.version,
                   "one of the variables needed for gradient computation has been modified by an inplace "
                   "operation: the belief states returned by DenseGCM step ", k, " of this chain (version ",
                   r.vc.current_version(), ", expected ", r.version,
                   ") are part of the record its backward reads");
-      at::Tensor g = grads[k];
+      at::Tensor g = grads[r.out_mx];
       if (g.scalar_type() != at::kFloat) {
         g = g.to(at::kFloat);
         keep.push_back(g);
@@ -290,9 +376,10 @@ struct RowsChainNode : public torch::autograd::Node {
       grp->sv.push_back(r.buf.data_ptr<float>());
       grp->gm.push_back(g.data_ptr<float>());
     }
-    if (groups.empty()) return out;
     const gcm_stream_t stream =
         reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(packed.get_device()).stream());
+    if (dx) apply_dx(grads, out, stream);
+    if (groups.empty()) return out;
     at::Tensor prev;
     for (auto& c : groups) {
       const int n = (int)c.sv.size();
@@ -456,7 +543,9 @@ struct RowsFast {
   StepCfg* cfg = nullptr;
   at::Tensor packed, flags;
   bool donate = false, grad_mode = false, armed = false;
-  bool dx_mode = false;   // the armed chain differentiates w.r.t. observations / nodes: one node per step (DxStepNode)
+  bool dx_mode = false;   // the armed chain differentiates w.r.t. observations / nodes:
+  int dx_kind = 0;        //   1 in its one chain node, time-parallel (RowsChainNode::dx); 2 one node per step (DxStepNode)
+  bool dx_steps_only = false;   // an observation depended on this module's own outputs once: kind 2 from then on
   std::shared_ptr<DxChain> dxc;
   std::shared_ptr<DxGateNode> dx_gate;
   std::shared_ptr<DxStepNode> dx_last;
@@ -493,13 +582,14 @@ struct RowsFast {
     return true;
   }
 
-  void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_, bool dx_ = false,
+  void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_, int dx_ = 0,
            const at::Tensor& head_nodes = at::Tensor(), const at::Tensor& head_count = at::Tensor()) {
     cfg = reinterpret_cast<StepCfg*>(cfg_handle);
     packed = packed_;
     flags = flags_;
     donate = donate_ && !dx_;
     dx_mode = false;
+    dx_kind = 0;
     grad_mode = at::GradMode::is_enabled();
     dev = packed.get_device();
     objs.clear();
@@ -513,11 +603,13 @@ struct RowsFast {
     dxc.reset();
     dx_gate.reset();
     dx_last.reset();
-    if (grad_mode && packed.requires_grad() && dx_) {
+    if (grad_mode && packed.requires_grad() && dx_)
       TORCH_CHECK(gcm_dense_rows_dx_supported(cfg->N, cfg->F, cfg->H1, cfg->H2) &&
                       !(cfg->has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)),
                   "rows step: this configuration has no observation-gradient form");
+    if (grad_mode && packed.requires_grad() && dx_ == 2) {
       dx_mode = true;
+      dx_kind = 2;
       dxc = std::make_shared<DxChain>();
       dxc->packed = packed.detach();
       dxc->count0 = head_count;
@@ -541,6 +633,18 @@ struct RowsFast {
                 ((cfg->has_bias & GCM_GNN_HAS_DEG_TERM) ? cfg->H1 : 0);
       TORCH_CHECK(packed.numel() >= node->P, "rows step: packed parameter vector too short");
       node->set_next_edges(torch::autograd::collect_next_edges(packed));
+      if (dx_ == 1) {
+        dx_mode = true;
+        dx_kind = 1;
+        node->count0 = head_count;
+        node->B = head_count.size(0);
+        node->want_gn0 = head_nodes.defined() && head_nodes.requires_grad();
+        if (node->want_gn0) {
+          node->add_next_edge(torch::autograd::impl::gradient_edge(head_nodes));
+          node->edge_gn0 = (int)node->num_outputs() - 1;
+        }
+        node->start_dx();
+      }
     }
     armed = true;
   }
@@ -595,8 +699,15 @@ struct RowsFast {
       dx_last = sn;
     } else if (need_bwd) {
       const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
-      node->recs.push_back({buf, vc, vc.current_version()});
+      RowsChainNode::Rec r{buf, vc, vc.current_version()};
+      if (dx_kind == 1) r.edge_x = node->take_x_edge(obs);   // (before the record joins: the first step may re-seat the node)
+      r.out_mx = (int)node->num_inputs();
       torch::autograd::create_gradient_edge(mx, node);
+      if (dx_kind == 1) {
+        r.out_nodes = (int)node->num_inputs();
+        torch::autograd::create_gradient_edge(nodes_out, node);
+      }
+      node->recs.push_back(std::move(r));
     }
     l_nodes = nodes_out;
     l_adj = adj_out;
@@ -619,7 +730,7 @@ struct RowsFast {
   // the checked entry -> (mx, nodes, adj, num_nodes)
   pybind11::tuple run(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
                       const at::Tensor& weights, const at::Tensor& count_in, const at::Tensor& packed_,
-                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_, bool need_dx) {
+                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_, int need_dx) {
     StepCfg* c = reinterpret_cast<StepCfg*>(cfg_handle);
     TORCH_CHECK(c != nullptr, "rows_step: no step configuration");
     TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() &&
@@ -638,10 +749,17 @@ struct RowsFast {
     TORCH_CHECK(obs.get_device() == c10::hip::current_device() && nodes_in.get_device() == obs.get_device() &&
                     packed_.get_device() == obs.get_device(),
                 "rows_step: tensors must live on the current device");
-    need_dx = need_dx && at::GradMode::is_enabled() && packed_.requires_grad();
+    if (!(at::GradMode::is_enabled() && packed_.requires_grad())) need_dx = 0;
+    if (need_dx == 1 && dx_steps_only) need_dx = 2;
     // a chain that differentiates w.r.t. its inputs holds ONE chain of hidden states: a state that is not
     // the one returned last starts a new node (whose input 1 is that state's node matrix)
-    const bool new_chain = (need_dx || dx_mode) && !(dx_mode && continues(nodes_in, adj_in, weights, count_in));
+    bool new_chain = (need_dx || dx_mode) && !(dx_mode && dx_kind == need_dx && continues(nodes_in, adj_in, weights, count_in));
+    if (!new_chain && dx_kind == 1 && node && !node->can_take(obs)) {
+      // this observation was computed from the chain's own outputs: a single node would sit on a cycle
+      dx_steps_only = true;
+      need_dx = 2;
+      new_chain = true;
+    }
     if (!armed || c != cfg || packed_.unsafeGetTensorImpl() != packed.unsafeGetTensorImpl() ||
         flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || (donate_ && !need_dx) != donate ||
         grad_mode != at::GradMode::is_enabled() || (node && node->executed) || (dxc && dxc->executed) || new_chain)
@@ -668,7 +786,7 @@ struct RowsFast {
     if (grad != grad_mode || (node && node->executed) || (dxc && dxc->executed) || xt.dim() != 2 || xt.size(0) != xB ||
         xt.size(1) != xF || xt.scalar_type() != at::kFloat || !xt.is_cuda() || xt.get_device() != dev ||
         c10::hip::current_device() != dev || (grad && xt.requires_grad() && !dx_mode) || !params_current() ||
-        hooks_registered())
+        hooks_registered() || (dx_kind == 1 && !node->can_take(xt)))
       return pybind11::none();
     at::Tensor obs = xt.is_contiguous() ? xt : xt.contiguous();
     at::Tensor mx = launch(obs, l_nodes, l_adj, l_weights, l_count);

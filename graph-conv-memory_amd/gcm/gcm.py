@@ -133,8 +133,11 @@ class DenseGCM(torch.nn.Module):
         # False: the round-2 backward of the fused LearnedEdge step (one kernel per step behind a [B,N,N]
         # gradient chain buffer) instead of the time-parallel one - kept for A/B tests
         self.learned_time_parallel = True
-        # False: steps whose observations / nodes need a gradient take the round-1 fused kernels (one kernel per
-        # step and direction, full state saved) instead of the live-row kernels + time-parallel backward - A/B tests
+        # Steps whose observations / nodes need a gradient run on the live-row kernels too.  True: the whole
+        # chain's dL/dx in ONE launch by the chain's single autograd node (hardware float atomics: the order of
+        # summation, i.e. the last bits, is not fixed; a policy that feeds belief t-1 into observation t switches
+        # to "steps" by itself); "steps": one light node and launch per step, ordered sums (bit-reproducible);
+        # False: the round-1 fused kernels (one kernel per step and direction, full state saved) - A/B tests
         self.rows_dx = True
 
     # -- state ---------------------------------------------------------------
@@ -511,7 +514,7 @@ class DenseGCM(torch.nn.Module):
             if m.gather_current(x):
                 cfg.refresh_pointers()
 
-    def _forward_rows(self, x, hidden, cfg, flags, link, need_dx=False):
+    def _forward_rows(self, x, hidden, cfg, flags, link, need_dx=0):
         """The live-row step (csrc/rows_step.hip), checked entry: one kernel forward, no kernel and no
         autograd node per step backward (every step of a chain hangs its belief tensor on one node,
         whose backward is one time-parallel launch over every recorded step).  Taken when neither x
@@ -732,7 +735,7 @@ class DenseGCM(torch.nn.Module):
             if cfg.sharded:
                 self._gather_sharded(cfg, x)
             if cfg.rows_ok and (no_dx or (cfg.dx_ok and self.rows_dx)):
-                return self._forward_rows(x, hidden, cfg, link[3], link, not no_dx)
+                return self._forward_rows(x, hidden, cfg, link[3], link, 0 if no_dx else (2 if self.rows_dx == "steps" else 1))
             if cfg.learned_sel is None and cfg.fold is None:
                 return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, link[3], link)
             if no_dx:
@@ -762,7 +765,7 @@ class DenseGCM(torch.nn.Module):
             if plan.sharded:
                 self._gather_sharded(plan, x)
             if plan.rows_ok and (no_dx or (plan.dx_ok and self.rows_dx)):
-                return self._forward_rows(x, hidden, plan, flags, None, not no_dx)
+                return self._forward_rows(x, hidden, plan, flags, None, 0 if no_dx else (2 if self.rows_dx == "steps" else 1))
             if plan.learned_sel is None and plan.fold is None:
                 return self._forward_fused(x, nodes, adj, weights, num_nodes, plan, flags)
             if no_dx:

@@ -517,3 +517,119 @@ def test_rows_module_with_hooks_and_deepcopy():
                 o.append(mx)
         outs.append(torch.stack(o))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("mode", [True, "steps"])
+@pytest.mark.parametrize("sel,N,T", [(("temporal", [1, 2, 4], "forward"), 16, 40), (("dense",), 12, 20),
+                                     (("temporal", [1, 3], "both"), 128, 24)])
+def test_rows_obs_gradient_chain_vs_oracle(mode, sel, N, T):
+    """Observations (and the initial node matrix) with gradient on the live-row kernels, both backward forms:
+    the chain's one node with the time-parallel launch (rows_dx=True) and one node per step ("steps") - through
+    the overflow, staggered starts, a loss on part of the steps, a gradient handed to a returned node matrix,
+    and torch.autograd.grad w.r.t. the observations only."""
+    B, F, H = 5, 8, 16
+    torch.manual_seed(N * 7 + T)
+    ref, g, mem, osel = _mk(B, N, F, H, H, sel, False)
+    mem.rows_dx = mode
+    obs = torch.rand(T, B, F)
+    count0 = torch.randint(0, N + 1, (B,))
+    nodes0 = torch.rand(B, N, F) * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    adj0 = torch.zeros(B, N, N)
+    for b in range(B):
+        for i in range(1, int(count0[b])):
+            adj0[b, i, i - 1] = 1.0
+    w = torch.rand(T, B, H)
+    w[T // 3] = 0                                            # a step without a gradient
+    wn = torch.rand(B, N, F)
+
+    def loss_of(step, x, n0, dev):
+        hid, outs, mid = (n0, adj0.to(dev), torch.zeros(0, device=dev), count0.to(dev)), [], None
+        for t in range(T):
+            mx, hid = step(x[t], hid)
+            outs.append(mx)
+            if t == T // 2:
+                mid = hid[0]
+        keep = [t for t in range(T) if t != T // 3]
+        loss = sum((outs[t] * w[t].to(dev)).sum() for t in keep) + (mid * wn.to(dev)).sum()
+        return loss, torch.stack(outs)
+
+    xo, no = obs.clone().requires_grad_(True), nodes0.clone().requires_grad_(True)
+    lo, out_o = loss_of(lambda x, h: od.dense_step(x, h, ref, graph_size=N, edge_selectors=osel), xo, no, "cpu")
+    lo.backward()
+    xd, nd = obs.to(DEV).requires_grad_(True), nodes0.to(DEV).requires_grad_(True)
+    ld, out_d = loss_of(mem, xd, nd, DEV)
+    assert _rows_taken(mem) and mem.rows_steps() == T
+    (gx_only,) = torch.autograd.grad(ld, [xd], retain_graph=True)
+    assert all(p.grad is None for p in g.parameters())
+    ld.backward()
+    mem.check_flags()
+    # (the forward is pinned with the float64 bound in test_rows_path_vs_oracle; DenseEdge sums up to N terms)
+    torch.testing.assert_close(out_d.detach().cpu(), out_o.detach(), rtol=1e-5, atol=5e-6)
+    scale = float(xo.grad.abs().max())
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(gx_only.cpu(), xo.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(nd.grad.cpu(), no.grad, rtol=1e-4, atol=1e-5 * float(no.grad.abs().max()))
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+
+def test_rows_obs_gradient_feedback_and_stacked_memories():
+    """(a) A policy that feeds belief t-1 into observation t: a single chain node would sit on a cycle - the
+    module notices (the producer's topological number is above the chain's) and continues with one node per
+    step.  (b) Two memories stacked (the second reads the first's beliefs): both keep the one-node form."""
+    B, N, F, H, T = 4, 16, 8, 8, 14
+    torch.manual_seed(3)
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("temporal", [1, 2], "forward"), False)
+    lin_o = torch.nn.Linear(H, F)
+    lin_d = torch.nn.Linear(H, F).to(DEV)
+    lin_d.load_state_dict(lin_o.state_dict())
+    obs = torch.rand(T, B, F)
+
+    def feedback(step, lin, x, dev):
+        hid, outs, prev = None, [], torch.zeros(B, H, device=dev)
+        for t in range(T):
+            mx, hid = step(x[t] + torch.tanh(lin(prev)), hid)
+            outs.append(mx)
+            prev = mx
+        return torch.stack(outs)
+
+    xo = obs.clone().requires_grad_(True)
+    out_o = feedback(lambda x, h: od.dense_step(x, h, ref, graph_size=N, edge_selectors=osel), lin_o, xo, "cpu")
+    out_o.sum().backward()
+    xd = obs.to(DEV).requires_grad_(True)
+    out_d = feedback(mem, lin_d, xd, DEV)
+    assert mem.rows_steps() == T
+    out_d.sum().backward()
+    torch.testing.assert_close(out_d.detach().cpu(), out_o.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-5 * float(xo.grad.abs().max()))
+    for (k, pc), (_, pd) in list(zip(ref.named_parameters(), g.named_parameters())) + \
+            list(zip(lin_o.named_parameters(), lin_d.named_parameters())):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+    # (b) stacked
+    torch.manual_seed(4)
+    ref1, g1, mem1, osel1 = _mk(B, N, F, H, F, ("temporal", [1], "forward"), False)
+    ref2, g2, mem2, osel2 = _mk(B, N, F, H, H, ("dense",), False)
+
+    def stacked(s1, s2, x):
+        h1 = h2 = None
+        outs = []
+        for t in range(T):
+            m1, h1 = s1(x[t], h1)
+            m2, h2 = s2(m1, h2)
+            outs.append(m2)
+        return torch.stack(outs)
+
+    xo = obs.clone().requires_grad_(True)
+    out_o = stacked(lambda x, h: od.dense_step(x, h, ref1, graph_size=N, edge_selectors=osel1),
+                    lambda x, h: od.dense_step(x, h, ref2, graph_size=N, edge_selectors=osel2), xo)
+    (out_o ** 2).sum().backward()
+    xd = obs.to(DEV).requires_grad_(True)
+    out_d = stacked(mem1, mem2, xd)
+    (out_d ** 2).sum().backward()
+    assert mem1.rows_steps() == T and mem2.rows_steps() == T
+    torch.testing.assert_close(out_d.detach().cpu(), out_o.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-5 * float(xo.grad.abs().max()))
+    for (k, pc), (_, pd) in list(zip(ref1.named_parameters(), g1.named_parameters())) + \
+            list(zip(ref2.named_parameters(), g2.named_parameters())):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
