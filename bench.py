@@ -565,8 +565,9 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                     _, hidden = mem_e(obs[t], hidden)
         variants["forward_only_eager_donated"] = world * B * T * side / timed(fwd_only, side, 1)
         mem_e.check_flags()
-        # observations that need a gradient (an encoder in front of the memory): the live-row kernels with
-        # one light autograd node per step; eager and graph-replayed
+        # observations that need a gradient (an encoder in front of the memory): the live-row kernels, dL/dx of
+        # the whole chain in one time-parallel launch by the chain's node; eager and graph-replayed, functional
+        # and donated state
         def rollout_xs(m, xs):      # per-step leaves (an encoder's outputs), not slices of one [T,B,F] leaf
             hidden, outs = None, []
             for x in xs:
@@ -582,22 +583,23 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             for x in xs:
                 x.grad = None
         variants["eager_functional_obs_grad"] = world * B * T * side / timed(with_obs_grad, side, 2)
-        try:
-            # (a fresh module and leaves: an AccumulateGrad node made on another stream breaks the capture)
-            mem_g, gnn_g, _ = build_memory(device, donate=False, selector=c["selector"], cfg=c)
-            xs2 = [obs[t].clone().requires_grad_(True) for t in range(T)]
+        for state, don in (("functional", False), ("donated", True)):
+            try:
+                # (a fresh module and leaves: an AccumulateGrad node made on another stream breaks the capture)
+                mem_g, gnn_g, _ = build_memory(device, donate=don, selector=c["selector"], cfg=c)
+                xs2 = [obs[t].clone().requires_grad_(True) for t in range(T)]
 
-            def zero_g():
-                gnn_g.zero_grad(set_to_none=True)
-                for x in xs2:
-                    x.grad = None
-            gg = capture(lambda: rollout_xs(mem_g, xs2), zero_g)
-            variants["graph_functional_obs_grad"] = world * B * T * side / timed(gg.replay, side, 2)
-            del gg
-        except Exception as e:      # (reported, not fatal: the headline does not depend on it)
-            variants["graph_functional_obs_grad"] = 0.0
-            print("obs-grad graph capture failed:", type(e).__name__, str(e)[:200], file=sys.stderr)
-            torch.cuda.synchronize()
+                def zero_g():
+                    gnn_g.zero_grad(set_to_none=True)
+                    for x in xs2:
+                        x.grad = None
+                gg = capture(lambda: rollout_xs(mem_g, xs2), zero_g)
+                variants[f"graph_{state}_obs_grad"] = world * B * T * side / timed(gg.replay, side, 2)
+                del gg
+            except Exception as e:      # (reported, not fatal: the headline does not depend on it)
+                variants[f"graph_{state}_obs_grad"] = 0.0
+                print("obs-grad graph capture failed:", type(e).__name__, str(e)[:200], file=sys.stderr)
+                torch.cuda.synchronize()
         mem_f.check_flags()
 
     if rank != 0:

@@ -342,8 +342,8 @@ struct RowsChainNode : public torch::autograd::Node {
     TORCH_CHECK(!released, "Trying to backward through the live-row steps of a DenseGCM chain a second "
                            "time (their records were freed); pass retain_graph=True to the first call");
     variable_list out(num_outputs());
-    TORCH_CHECK(grads.size() == (dx ? 2 : 1) * recs.size(), "rows chain: ", grads.size(), " gradients for ",
-                recs.size(), " recorded steps");
+    TORCH_CHECK(grads.size() == num_inputs(), "rows chain: ", grads.size(), " gradients for ", num_inputs(),
+                " outputs of ", recs.size(), " recorded steps");
     // groups of steps with equal batch size and gradient strides (an expanded gradient, as mean()
     // produces, is read with stride 0 - no .contiguous() copies), in first-seen order
     struct Group {
@@ -582,12 +582,19 @@ struct RowsFast {
     return true;
   }
 
+  // A donated state is advanced in place, which autograd does not allow for a tensor that carries a gradient:
+  // with the one-node form of the observation gradient (kind 1) the records alone serve the backward, so the
+  // state may still be donated - the returned node matrix is then a plain tensor (no gradient through it);
+  // not when the chain starts from a node matrix that itself needs a gradient, nor with one node per step.
+  static bool want_donate(bool donate_, int dx_, const at::Tensor& head_nodes) {
+    return donate_ && (dx_ == 0 || (dx_ == 1 && !(head_nodes.defined() && head_nodes.requires_grad())));
+  }
   void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_, int dx_ = 0,
            const at::Tensor& head_nodes = at::Tensor(), const at::Tensor& head_count = at::Tensor()) {
     cfg = reinterpret_cast<StepCfg*>(cfg_handle);
     packed = packed_;
     flags = flags_;
-    donate = donate_ && !dx_;
+    donate = want_donate(donate_, dx_, head_nodes);
     dx_mode = false;
     dx_kind = 0;
     grad_mode = at::GradMode::is_enabled();
@@ -703,7 +710,7 @@ struct RowsFast {
       if (dx_kind == 1) r.edge_x = node->take_x_edge(obs);   // (before the record joins: the first step may re-seat the node)
       r.out_mx = (int)node->num_inputs();
       torch::autograd::create_gradient_edge(mx, node);
-      if (dx_kind == 1) {
+      if (dx_kind == 1 && !donate) {
         r.out_nodes = (int)node->num_inputs();
         torch::autograd::create_gradient_edge(nodes_out, node);
       }
@@ -761,11 +768,11 @@ struct RowsFast {
       new_chain = true;
     }
     if (!armed || c != cfg || packed_.unsafeGetTensorImpl() != packed.unsafeGetTensorImpl() ||
-        flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || (donate_ && !need_dx) != donate ||
+        flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || want_donate(donate_, need_dx, nodes_in) != donate ||
         grad_mode != at::GradMode::is_enabled() || (node && node->executed) || (dxc && dxc->executed) || new_chain)
       arm(packed_, flags_, cfg_handle, donate_, need_dx, nodes_in, count_in);
     at::Tensor mx = launch(obs, nodes_in, adj_in, weights, count_in);
-    return pybind11::make_tuple(mx, l_nodes, l_adj, l_count);
+    return pybind11::make_tuple(mx, l_nodes, l_adj, l_count, donate);
   }
 
   // the unchecked entry: (mx, hidden) or None

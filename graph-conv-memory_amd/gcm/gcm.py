@@ -530,10 +530,10 @@ class DenseGCM(torch.nn.Module):
             if self.donate_state:
                 raise ValueError("donate_state=True needs contiguous hidden-state tensors")
             nodes, adj, num_nodes = nodes.contiguous(), adj.contiguous(), num_nodes.contiguous()
-        # (a gradient w.r.t. the observations / nodes: functional state - autograd does not allow the caller's
-        #  node matrix to be advanced in place)
-        donate = self.donate_state and not need_dx
-        mx, n2, a2, c2 = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(), donate, need_dx)
+        # (a donated state with a gradient w.r.t. the observations: only in the one-node form, and the returned
+        #  node matrix is then a plain tensor - RowsFast::want_donate decides and reports)
+        mx, n2, a2, c2, donate = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(),
+                                          self.donate_state, need_dx)
         if donate:
             out = hidden
         else:

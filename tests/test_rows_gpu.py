@@ -633,3 +633,32 @@ def test_rows_obs_gradient_feedback_and_stacked_memories():
     for (k, pc), (_, pd) in list(zip(ref1.named_parameters(), g1.named_parameters())) + \
             list(zip(ref2.named_parameters(), g2.named_parameters())):
         torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+
+def test_rows_obs_gradient_with_donated_state():
+    """donate_state=True and observations with gradient: the one-node form needs the records only, so the
+    state is still advanced in place (the returned node matrix is then a plain tensor); same beliefs,
+    observation and parameter gradients as the oracle, through the overflow."""
+    B, N, F, H, T = 6, 16, 8, 16, 30
+    torch.manual_seed(11)
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("temporal", [1, 2, 4], "forward"), True)
+    obs = torch.rand(T, B, F)
+    w = torch.rand(T, B, H)
+    xo = obs.clone().requires_grad_(True)
+    out_o, _ = od.dense_rollout(xo, None, ref, graph_size=N, edge_selectors=osel)
+    (out_o * w).sum().backward()
+    xd = obs.to(DEV).requires_grad_(True)
+    hid, outs, ptrs = None, [], set()
+    for t in range(T):
+        mx, hid = mem(xd[t], hid)
+        outs.append(mx)
+        ptrs.add(hid[0].data_ptr())
+        assert not hid[0].requires_grad
+    assert len(ptrs) == 1 and mem.rows_steps() == T          # advanced in place, on the live-row kernels
+    out_d = torch.stack(outs)
+    (out_d * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    torch.testing.assert_close(out_d.detach().cpu(), out_o.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-5 * float(xo.grad.abs().max()))
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
