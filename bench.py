@@ -428,6 +428,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="extra timed blocks of K steps for value_spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager loop instead of the graph replay")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the variants (cfg4: the stepwise leg) - for profiles of the headline leg alone")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -743,7 +745,9 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
         bucket.all_reduce_mean(weight)
         g.zero_grad(set_to_none=True)
 
-    variants = {"stepwise_taus1_x%d" % n_sw: world * B * n_sw / timed(stepwise, 2, 1)}
+    variants = {}
+    if not args.headline_only:
+        variants["stepwise_taus1_x%d" % n_sw] = world * B * n_sw / timed(stepwise, 2, 1)
     if rank != 0:
         return
     fwd_ms, E, M = time_csr_kernels(c)

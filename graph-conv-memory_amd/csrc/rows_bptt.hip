@@ -465,33 +465,48 @@ namespace gcm_rows {
 // eight live rows with their adjacency rows), the rows summed in the wave's LDS tile, one batch of
 // read-modify-writes on the accumulators at the end.  H1, H2 <= 32, F <= 64.
 // ATOMIC: many steps of a chain run concurrently (k_rows_dx_all) - the accumulators take hardware float adds
+// the four weight matrices as the lanes hold them: lane h the columns h of W_rel2 / W_root2 (rows o), lane f the
+// columns f of W_rel1 / W_root1 (rows h)
+struct DxWeights {
+  float w2a[32], w2r[32], wa[32], wr[32];
+  __device__ __forceinline__ void load(const float* __restrict__ w_rel1, const float* __restrict__ w_root1,
+                                       const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int lane,
+                                       int F, int H1, int H2) {
+    const int hc = lane < H1 ? lane : H1 - 1, fc = lane < F ? lane : F - 1;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+      const size_t i2 = (size_t)(o < H2 ? o : H2 - 1) * H1 + hc, i1 = (size_t)(o < H1 ? o : H1 - 1) * F + fc;
+      const float t0 = w_rel2[i2], t1 = w_root2[i2], t2 = w_rel1[i1], t3 = w_root1[i1];
+      const bool k2 = o < H2 && lane < H1, k1 = o < H1 && lane < F;   // (masked once, here)
+      w2a[o] = k2 ? t0 : 0.f;
+      w2r[o] = k2 ? t1 : 0.f;
+      wa[o] = k1 ? t2 : 0.f;
+      wr[o] = k1 ? t3 : 0.f;
+    }
+  }
+};
+
 template <bool ATOMIC>
 __device__ __forceinline__ void rows_dx_body(
     const float* __restrict__ sv, const float* __restrict__ gmx, long gmx_sb, long gmx_sh,
-    const float* __restrict__ gnodes, const float* __restrict__ w_rel1, const float* __restrict__ w_root1,
-    const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1, int act2, const SavedLayout& lay,
-    const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int b, int lane, float* tile, int B, int N,
+    const float* __restrict__ gnodes, const DxWeights& W, int act1, int act2, const SavedLayout& lay,
+    const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int b, int lane, float* tile_, int B, int N,
     int F, int H1, int H2) {
+  typedef __attribute__((address_space(3))) float lds_float;
+  lds_float* const tile = (lds_float*)tile_;   // (the wave's accumulator tile: ds_ instructions, not flat ones)
+  const float (&w2a)[32] = W.w2a;
+  const float (&w2r)[32] = W.w2r;
+  const float (&wa)[32] = W.wa;
+  const float (&wr)[32] = W.wr;
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
   constexpr int LB = 8;   // live rows fetched ahead
   // ---- loads ---------------------------------------------------------------------------------------
   const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
   const int h_l = hdr[0], h_lc = hdr[1], h_cur = hdr[2];
-  const int oc = lane < H2 ? lane : H2 - 1, hc = lane < H1 ? lane : H1 - 1, fc = lane < F ? lane : F - 1;
+  const int oc = lane < H2 ? lane : H2 - 1, hc = lane < H1 ? lane : H1 - 1;
   const float g = gmx ? gmx[(long)b * gmx_sb + (long)oc * gmx_sh] : 0.f;
   const float y = sv[(size_t)b * H2 + oc];
   const int64_t c0 = count0[b];
-  float w2a[32], w2r[32], wa[32], wr[32];
-#pragma unroll
-  for (int o = 0; o < 32; ++o) {
-    const size_t i2 = (size_t)(o < H2 ? o : H2 - 1) * H1 + hc, i1 = (size_t)(o < H1 ? o : H1 - 1) * F + fc;
-    const float t0 = w_rel2[i2], t1 = w_root2[i2], t2 = w_rel1[i1], t3 = w_root1[i1];
-    const bool k2 = o < H2 && lane < H1, k1 = o < H1 && lane < F;   // (masked once, here)
-    w2a[o] = k2 ? t0 : 0.f;
-    w2r[o] = k2 ? t1 : 0.f;
-    wa[o] = k1 ? t2 : 0.f;
-    wr[o] = k1 ? t3 : 0.f;
-  }
   const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
   const float* coef = sv + lay.o_coef + (size_t)b * N;
   float cf8[LB], hv8[LB], r0[LB], r1[LB];
@@ -521,15 +536,20 @@ __device__ __forceinline__ void rows_dx_body(
   }
   // ---- the live rows -----------------------------------------------------------------------------------
   unsigned long long tm0 = 0, tm1 = 0;
-  auto add_row = [&](int k, float val) {
-    const bool seen = k < 64 ? ((tm0 >> k) & 1ull) != 0 : ((tm1 >> (k - 64)) & 1ull) != 0;
+  auto add_row = [&](int k, float val) __attribute__((always_inline)) {
+    // (value selects throughout: with `k < 64 ? tm0 : tm1` written as branches the compiler keeps both masks
+    //  in scratch memory and selects an address)
+    const unsigned long long bit = 1ull << (k & 63);
+    const unsigned long long m = k < 64 ? tm0 : tm1;
+    const bool seen = (m & bit) != 0;
     if (lane < F) {
-      float* q = tile + k * F + lane;
+      lds_float* q = tile + k * F + lane;
       *q = (seen ? *q : 0.f) + val;
     }
-    if (k < 64) tm0 |= 1ull << k; else tm1 |= 1ull << (k - 64);
+    tm0 |= k < 64 ? bit : 0ull;
+    tm1 |= k < 64 ? 0ull : bit;
   };
-  auto live_row = [&](int l, float cf, float hv, int jl, float a0, float a1) {
+  auto live_row = [&](int l, float cf, float hv, int jl, float a0, float a1) __attribute__((always_inline)) {
     float g1 = (cf * dagg2 + (l == l_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
     g1 = lane < H1 ? g1 : 0.f;
     float dxa = 0.f, dxr = 0.f;
@@ -569,32 +589,45 @@ __device__ __forceinline__ void rows_dx_body(
       }
   }
   // ---- row k holds the node inserted at chain step s_lin - (cur - k) (negative: an initial node) -------
+  constexpr int NONE = -(1 << 30);
+  auto target = [&](int kk) __attribute__((always_inline)) -> float* {
+    if (kk >= 0) return gx + ((size_t)kk * B + b) * F + lane;
+    if (kk != NONE && gn0 && kk + n0 >= 0) return gn0 + ((size_t)b * N + (kk + n0)) * F + lane;
+    return nullptr;
+  };
   while (tm0 | tm1) {
-    float* pp[8];
+    int kk8[8];
     float v8[8], old8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      pp[i] = nullptr;
+      kk8[i] = NONE;
       v8[i] = 0.f;
       if (tm0 | tm1) {
-        const int k = tm0 ? __builtin_ctzll(tm0) : 64 + __builtin_ctzll(tm1);
-        if (tm0) tm0 &= tm0 - 1; else tm1 &= tm1 - 1;
-        const int kk = s_lin - (cur - k);
-        if (kk >= 0) pp[i] = gx + ((size_t)kk * B + b) * F + lane;
-        else if (gn0 && kk + n0 >= 0) pp[i] = gn0 + ((size_t)b * N + (kk + n0)) * F + lane;
+        const int k = tm0 ? __builtin_ctzll(tm0) : 64 + __builtin_ctzll(tm1 | (1ull << 63));
+        const bool low = tm0 != 0;
+        tm0 &= low ? tm0 - 1 : tm0;
+        tm1 &= low ? tm1 : tm1 - 1;
+        kk8[i] = s_lin - (cur - k);
         if (lane < F) v8[i] = tile[k * F + lane];
       }
     }
     if (ATOMIC) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (pp[i] && lane < F) unsafeAtomicAdd(pp[i], v8[i]);
+      for (int i = 0; i < 8; ++i) {
+        float* q = target(kk8[i]);
+        if (q && lane < F) unsafeAtomicAdd(q, v8[i]);
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) old8[i] = (pp[i] && lane < F) ? *pp[i] : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        const float* q = target(kk8[i]);
+        old8[i] = (q && lane < F) ? *q : 0.f;
+      }
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (pp[i] && lane < F) *pp[i] = old8[i] + v8[i];
+      for (int i = 0; i < 8; ++i) {
+        float* q = target(kk8[i]);
+        if (q && lane < F) *q = old8[i] + v8[i];
+      }
     }
   }
 }
@@ -608,8 +641,10 @@ __global__ __launch_bounds__(256) void k_rows_dx_step(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
   if (b >= B) return;
-  rows_dx_body<false>(sv, gmx, gmx_sb, gmx_sh, gnodes, w_rel1, w_root1, w_rel2, w_root2, act1, act2, lay, count0, gx,
-                      gn0, s_lin, b, lane, dxs + (size_t)wave * N * F, B, N, F, H1, H2);
+  DxWeights W;
+  W.load(w_rel1, w_root1, w_rel2, w_root2, lane, F, H1, H2);
+  rows_dx_body<false>(sv, gmx, gmx_sb, gmx_sh, gnodes, W, act1, act2, lay, count0, gx, gn0, s_lin, b, lane,
+                      dxs + (size_t)wave * N * F, B, N, F, H1, H2);
 }
 
 // device pointers of up to GCM_ROWS_MAX_STEPS consecutive steps of a chain (NULL: that step has none)
@@ -619,7 +654,8 @@ struct DxTable {
   const float* gn[GCM_ROWS_MAX_STEPS];
 };
 
-// every (step, graph) of the table at once, one wave each; steps with neither gradient are skipped
+// every (step, graph) of the table, one wave per item, the waves of a grid sized to the machine striding over
+// the items with the weights in their registers; steps with neither gradient are skipped
 __global__ __launch_bounds__(256) void k_rows_dx_all(
     DxTable tab, int n_steps, int s0, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel1,
     const float* __restrict__ w_root1, const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1,
@@ -627,14 +663,18 @@ __global__ __launch_bounds__(256) void k_rows_dx_all(
     int H2) {
   extern __shared__ float dxs[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= n_steps * B) return;
-  const int s = item / B, b = item - s * B;
-  const float* gm = tab.gmx[s];
-  const float* gn = tab.gn[s];
-  if (!gm && !gn) return;
-  rows_dx_body<true>(tab.saved[s], gm, gmx_sb, gmx_sh, gn, w_rel1, w_root1, w_rel2, w_root2, act1, act2, lay, count0,
-                     gx, gn0, s0 + s, b, lane, dxs + (size_t)wave * N * F, B, N, F, H1, H2);
+  DxWeights W;
+  W.load(w_rel1, w_root1, w_rel2, w_root2, lane, F, H1, H2);
+  const int items = n_steps * B;
+#pragma unroll 1
+  for (int item = blockIdx.x * 4 + wave; item < items; item += gridDim.x * 4) {
+    const int s = item / B, b = item - s * B;
+    const float* gm = tab.gmx[s];
+    const float* gn = tab.gn[s];
+    if (!gm && !gn) continue;
+    rows_dx_body<true>(tab.saved[s], gm, gmx_sb, gmx_sh, gn, W, act1, act2, lay, count0, gx, gn0, s0 + s, b, lane,
+                       dxs + (size_t)wave * N * F, B, N, F, H1, H2);
+  }
 }
 
 }  // namespace gcm_rows
@@ -694,7 +734,8 @@ extern "C" int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float
   const size_t lds = sizeof(float) * 4 * (size_t)N * F;
   gcm_allow_dynamic_lds((const void*)gcm_rows::k_rows_dx_all, lds);
   const long items = (long)n_steps * B;
-  hipLaunchKernelGGL(gcm_rows::k_rows_dx_all, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream,
+  const long wgs = (items + 3) / 4, resident = 2L * gcm_cu_count();   // (64 KB of LDS per workgroup: two per CU)
+  hipLaunchKernelGGL(gcm_rows::k_rows_dx_all, dim3((unsigned)(wgs < resident ? wgs : resident)), dim3(256), lds, (hipStream_t)stream,
                      tab, n_steps, s0, gmx_stride_b, gmx_stride_h, params, params + (size_t)H1 * F, w_rel2, w_root2,
                      act1, act2, lay, count0, gx, gn0, B, N, F, H1, H2);
   return gcm_launch_status();

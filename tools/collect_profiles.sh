@@ -1,10 +1,12 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the MI355X box (run from the repo root through gpurun):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03 [part ...]      parts: bench stats pmc   (default: all)
 # Kernel-trace statistics and PMC passes are separate runs (a --pmc pass never carries other trace
 # domains); everything lands under gpurun_out/<tag>/ and is copied into profiles/ afterwards.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
+shift || true
+PARTS=${*:-bench stats pmc}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -12,28 +14,35 @@ stats() {   # name, script args...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$@" > "$OUT/$name.log" 2>&1 < /dev/null
   cp "$(ls -t "$OUT/$name"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_${name}_kernel_stats.csv"
+  grep '^{' "$OUT/$name.log" | tail -1 > "$OUT/${TAG}_${name}_profiled.json" || true
   rm -rf "$OUT/$name"          # (the raw traces are large; gpurun_out/ travels back)
   echo "stats $name done"
 }
-pmc() {     # counter, name, script args...
-  local ctr=$1 name=$2; shift 2
-  rocprofv3 --pmc "$ctr" --kernel-trace --output-format csv -d "$OUT/${name}_$ctr" -- python3 "$@" > "$OUT/${name}_$ctr.log" 2>&1 < /dev/null
-  echo "pmc $ctr $name done"
+pmc() {     # counter, script args...
+  local ctr=$1; shift
+  rocprofv3 --pmc "$ctr" --kernel-trace --output-format csv -d "$OUT/pmc_$ctr" -- python3 "$@" > "$OUT/pmc_$ctr.log" 2>&1 < /dev/null
+  echo "pmc $ctr done"
 }
-python3 bench.py > "$OUT/bench.log" 2>&1 && tail -1 "$OUT/bench.log" > "$OUT/${TAG}_bench.json"
-echo "bench done"
-stats bench bench.py --no-cpu-baseline
-grep '^{' "$OUT/bench.log" | tail -1 > "$OUT/${TAG}_bench_profiled.json"
-stats cfg4 tools/bench_configs.py cfg4
-stats cfg3 tools/bench_configs.py "cfg3 EuclideanEdge(2.0) cross-batch"
-stats cfg5 tools/bench_configs.py cfg5
-pmc FETCH_SIZE dense tools/pmc_run.py
-pmc WRITE_SIZE dense tools/pmc_run.py
-pmc FETCH_SIZE cfg4 tools/bench_configs.py cfg4-oneshot
-pmc WRITE_SIZE cfg4 tools/bench_configs.py cfg4-oneshot
-python3 tools/pmc_summarise.py "$OUT/dense_FETCH_SIZE" "$OUT/dense_WRITE_SIZE" "$TAG" > "$OUT/${TAG}_traffic.txt"
-python3 tools/pmc_summarise.py "$OUT/cfg4_FETCH_SIZE" "$OUT/cfg4_WRITE_SIZE" "${TAG}_cfg4_oneshot" --keep-traffic-json > "$OUT/${TAG}_cfg4_traffic.txt"
-cp profiles/${TAG}_traffic_detail.json profiles/${TAG}_cfg4_oneshot_traffic_detail.json profiles/traffic.json "$OUT/"
-rm -rf "$OUT"/dense_FETCH_SIZE "$OUT"/dense_WRITE_SIZE "$OUT"/cfg4_FETCH_SIZE "$OUT"/cfg4_WRITE_SIZE
-python3 tools/bench_configs.py > "$OUT/${TAG}_configs.jsonl.log" 2>&1 && grep '^{' "$OUT/${TAG}_configs.jsonl.log" > "$OUT/${TAG}_configs.jsonl"
+for part in $PARTS; do
+  case $part in
+    bench)   # the JSON line of every config, unprofiled
+      for cfg in cfg2 cfg3 cfg4 cfg5; do
+        python3 bench.py --config $cfg > "$OUT/bench_$cfg.log" 2>&1 && tail -1 "$OUT/bench_$cfg.log" > "$OUT/${TAG}_bench_$cfg.json"
+        echo "bench $cfg done"
+      done ;;
+    stats)   # --kernel-trace --stats of the same command (cfg4: the one-shot headline leg alone, and both legs)
+      stats bench_cfg2 bench.py --config cfg2 --no-cpu-baseline
+      stats bench_cfg3 bench.py --config cfg3 --no-cpu-baseline
+      stats bench_cfg4_oneshot bench.py --config cfg4 --no-cpu-baseline --headline-only
+      stats bench_cfg4 bench.py --config cfg4 --no-cpu-baseline
+      stats bench_cfg5 bench.py --config cfg5 --no-cpu-baseline
+      stats sparse_learned tools/prof_sparse_learned.py ;;
+    pmc)
+      pmc FETCH_SIZE tools/pmc_run.py
+      pmc WRITE_SIZE tools/pmc_run.py
+      python3 tools/pmc_summarise.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$TAG" > "$OUT/${TAG}_traffic.txt"
+      cp profiles/${TAG}_traffic_detail.json profiles/traffic.json "$OUT/"
+      rm -rf "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE ;;
+  esac
+done
 echo "all done"

@@ -24,9 +24,17 @@ def per_kernel(d, counter):
             if m and row.get("Counter_Name") == counter:
                 name = m.group(1)
                 if name == "k_step_rows":       # template <FP, HP, H2P, FUNC, ...>: functional state copy?
-                    t = re.search(r"k_step_rows<\d+, \d+, \d+, (true|false)", row["Kernel_Name"])
-                    if t and t.group(1) == "true":
+                    t = re.search(r"k_step_rows<(\d+), \d+, \d+, (true|false)", row["Kernel_Name"])
+                    if t and t.group(2) == "true":
                         name = "k_step_rows_functional"
+                    if t and t.group(1) != "32":      # cfg3 (F = 64)
+                        name += "_f" + t.group(1)
+                if name == "k_bptt_rows":        # template <FP, HP, H2P, MODE>: 2 = pass A of the LearnedEdge backward
+                    t = re.search(r"k_bptt_rows<(\d+), \d+, \d+, (\d+)", row["Kernel_Name"])
+                    if t and t.group(2) == "2":
+                        name = "k_bptt_rows_learned"
+                    elif t and t.group(1) != "32":
+                        name += "_f" + t.group(1)
                 acc[name].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
