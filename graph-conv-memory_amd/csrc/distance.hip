@@ -366,6 +366,189 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
   DSTAMP(6);
 }
 
+// ---------------------------------------------------------------------------
+// The same product for F <= 64 (FT <= 2), laid out for a graph that is only partly filled: the work of a
+// step is (live 32-row blocks) x (column tiles), and the block rows >= cur are skipped - so the tiles must be
+// dealt so that every SIMD gets its share of the LIVE ones.  Wave w owns column tile (w & 3) of every
+// 128-graph chunk (its B operand is read from LDS once per chunk) and the row blocks of parity (w >> 2);
+// waves w and w + 4 share a SIMD, so each SIMD multiplies exactly `nb` tiles per chunk whatever nb is (the
+// wave = (row block, column half) layout above keeps two SIMDs idle while a graph holds < 64 nodes and runs
+// at the full graph's time from the first node on).  The chunks of current rows are double-buffered: the
+// loads of chunk c + 1 are in flight during the products of chunk c.  Row sums meet in LDS in fixed order
+// (chunks in sequence inside a wave, then the four column tiles): same decisions on every run.
+// ---------------------------------------------------------------------------
+template <int FT>
+__global__ __launch_bounds__(1024) void k_euclid_mfma2(
+    View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
+    float* __restrict__ sel_row, float* __restrict__ dist_out, float max_distance, int bidirectional,
+    int Bc, int N, int F) {
+  const float* __restrict__ nodes = vw.nodes;
+  constexpr int FP = 32 * FT, NS = FP + 1, RB = 128, CB = 128, CS = CB + 1;
+  constexpr int NT = 1024;
+  const int b = blockIdx.y, j0 = blockIdx.x * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int ct = wave & 3, rb = wave >> 2;   // 16 waves: SIMD = column tile, its four waves = the row blocks
+  int sh;
+  const int cur = view_cur(vw, b, N, sh);
+  const int nb = dist_out ? RB / 32 : max(0, min(RB / 32, (cur - j0 + 31) / 32));   // live 32-row blocks
+  extern __shared__ float smem[];
+  float* sN = smem;                   // [RB][NS]      node rows (scaled)
+  float* sC = sN + RB * NS;           // [2][FP][CS]   current rows, transposed, two chunks of CB graphs
+  float* sNn = sC + 2 * FP * CS;      // [RB]   |n|^2
+  float* sCn = sNn + RB;              // [2][CB] |c|^2
+  float* sPart = sCn + 2 * CB;        // [4][RB] row sums per column tile
+
+  const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
+  const float* crows = vw.cur_rows ? vw.cur_rows : vw.obs;
+  const bool from_rows = vw.count || vw.cur_rows;   // (uniform) the current nodes are the observations / gathered rows
+  // Staging: thread t holds SEG = FP / 8 consecutive features (segment t & 7) of row t >> 3 of a 128-row tile -
+  // 16-byte loads when F allows, conflict-free LDS stores in both layouts, and the row's squared norm is the
+  // sum over the eight lanes of a row (two quad permutes and a half-row mirror on the DPP path - no LDS pass,
+  // no second barrier).
+  constexpr int SEG = FP / 8;
+  static_assert(RB * FP == NT * SEG && CB * FP == NT * SEG, "one segment per thread");
+  const int srow = tid >> 3, sf0 = (tid & 7) * SEG;
+  const bool vec4 = (F & 3) == 0;
+  auto load_seg = [&](const float* __restrict__ row, float (&v)[SEG]) __attribute__((always_inline)) {
+    if (vec4) {
+#pragma unroll
+      for (int k = 0; k < SEG; k += 4) {
+        const int f = sf0 + k < F ? sf0 + k : F - 4;
+        const float4 t = *reinterpret_cast<const float4*>(row + f);
+        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) v[k] = row[sf0 + k < F ? sf0 + k : F - 1];
+    }
+  };
+  auto seg_norm = [&](const float (&v)[SEG]) __attribute__((always_inline)) {
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) q = fmaf(v[k], v[k], q);
+    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return q;
+  };
+  auto load_chunk = [&](int c0, float (&v)[SEG]) __attribute__((always_inline)) {
+    const int g = c0 + srow < Bc ? c0 + srow : Bc - 1;
+    if (from_rows) {
+      load_seg(crows + (size_t)g * F, v);
+    } else {
+      int64_t cg = vw.cur_idx[g];
+      cg = cg < 0 ? 0 : (cg > N - 1 ? N - 1 : cg);
+      load_seg(nodes + ((size_t)g * N + cg) * F, v);
+    }
+  };
+  auto store_chunk = [&](float* dst, float* dst_n, int c0, float (&v)[SEG]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+      const float t = dist_param ? v[k] / inv_scale_den : v[k];
+      v[k] = (sf0 + k < F && c0 + srow < Bc) ? t : 0.f;
+      dst[(sf0 + k) * CS + srow] = v[k];
+    }
+    const float q = seg_norm(v);
+    if ((tid & 7) == 0) dst_n[srow] = q;
+  };
+  DSTAMP(0);
+  {
+    // the first chunk of current rows (its addresses do not depend on this graph's fill level: in flight while
+    // `cur` arrives) and the node rows of the live blocks: every load in flight before the first LDS store
+    float vn[SEG], vc[SEG];
+    load_chunk(0, vc);
+    if (j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows (uniform)
+    const int j = j0 + srow + sh;   // stored row of image row j0 + srow
+    const bool row_live = srow < 32 * nb && j0 + srow < N;
+    if (row_live) {
+      load_seg(nodes + ((size_t)b * N + (j < N ? j : N - 1)) * F, vn);
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) vn[k] = 0.f;
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+      const float t = dist_param ? vn[k] / inv_scale_den : vn[k];
+      vn[k] = (row_live && sf0 + k < F) ? t : 0.f;
+      sN[srow * NS + sf0 + k] = vn[k];
+    }
+    const float q = seg_norm(vn);
+    if ((tid & 7) == 0) sNn[srow] = q;
+    store_chunk(sC, sCn, 0, vc);
+  }
+  __syncthreads();
+  DSTAMP(1);
+  DSTAMP(2);
+
+  float rowsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
+  float av[FP / 2];   // A(i = row, k = f): this wave's 32 node rows, in registers for every chunk
+  if (rb < nb) {
+    const float* ap = sN + (rb * 32 + li) * NS + lh;
+#pragma unroll
+    for (int q = 0; q < FP / 2; ++q) av[q] = ap[2 * q];
+  }
+
+  int buf = 0;
+  for (int c0 = 0; c0 < Bc; c0 += CB, buf ^= 1) {
+    const bool has_next = c0 + CB < Bc;
+    float vnext[SEG];
+    if (has_next) load_chunk(c0 + CB, vnext);
+    const float* sCb = sC + buf * FP * CS;
+    if (c0 + ct * 32 < Bc && rb < nb) {   // this wave's column tile holds graphs, and its row block is live
+      float bq[FP / 2];
+      {
+        const float* bp = sCb + lh * CS + ct * 32 + li;   // B(k = f, j = b')
+#pragma unroll
+        for (int q = 0; q < FP / 2; ++q) bq[q] = bp[2 * q * CS];
+      }
+      const float cn = sCn[buf * CB + ct * 32 + li];
+      const float keep = c0 + ct * 32 + li < Bc ? 1.f : 0.f;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < FP / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[q], acc, 0, 0, 0);
+      // v_sqrt_f32 (1 ulp) instead of the correctly rounded library routine (a dozen instructions)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float nn = sNn[rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];   // (16 more registers would spill)
+        const float d2 = fmaf(-2.f, acc[r], nn + cn);
+        rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(d2, 0.f)), rowsum[r]);
+      }
+    }
+    if (c0 == 0) DSTAMP(3);
+    if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c0 + CB, vnext);
+    __syncthreads();   // chunk c0 is consumed, chunk c0 + CB (rows and norms) is in LDS
+    if (c0 == 0) DSTAMP(4);
+  }
+  DSTAMP(5);
+  // sum over the 32 columns held by the lanes of each half-wave, then the four column tiles in fixed order
+  if (rb < nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = rowsum[r];
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (li == 0) sPart[ct * RB + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < RB && tid < 32 * nb) {
+    const int j = j0 + tid;
+    if (j < N) {
+      const int tiles = min(4, (Bc + 31) / 32);   // (column tiles that ever held graphs)
+      float tot = sPart[tid];
+      for (int t = 1; t < tiles; ++t) tot += sPart[t * RB + tid];
+      const float d = tot / (float)Bc;
+      if (dist_out) dist_out[(size_t)b * N + j] = d;
+      if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
+    }
+  }
+  DSTAMP(6);
+}
+
 // per-graph modes: one thread per (b, j)
 __global__ void k_pergraph(View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
                            float* __restrict__ sel_row, float* __restrict__ dist_out, int mode,
@@ -440,12 +623,23 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, vw, dist_param, adj, sel_row, dist_out,    \
                        max_distance, bidirectional, Bc, N, F);                                   \
   }
+      // F <= 64: tiles dealt by liveness, double-buffered chunks of 128 graphs (k_euclid_mfma2)
+      const size_t lds2 = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
+                                           (size_t)4 * RB);
+#define GCM_EUCLID_MFMA2(FTv)                                                                    \
+  {                                                                                              \
+    auto kern = k_euclid_mfma2<FTv>;                                                             \
+    gcm_allow_dynamic_lds((const void*)kern, lds2);                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds2, s, vw, dist_param, adj, sel_row, dist_out,  \
+                       max_distance, bidirectional, Bc, N, F);                                   \
+  }
       switch (FT) {
-        case 1: GCM_EUCLID_MFMA(1) break;
-        case 2: GCM_EUCLID_MFMA(2) break;
+        case 1: GCM_EUCLID_MFMA2(1) break;
+        case 2: GCM_EUCLID_MFMA2(2) break;
         case 3: GCM_EUCLID_MFMA(3) break;
         default: GCM_EUCLID_MFMA(4) break;
       }
+#undef GCM_EUCLID_MFMA2
 #undef GCM_EUCLID_MFMA
       return gcm_launch_status();
     }
