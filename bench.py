@@ -654,28 +654,29 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             "note": "SURVEY 8(d) full-dense FLOPs (2 layers x all N rows) over the same launch time; the kernel "
                     "executes layer 1 on the live rows only"}
     elif c["selector"] == "euclid":
-        # Dominant kernel = k_euclid_mfma (the cross-batch distance contraction [N x F].[F x B] per graph on
+        # Dominant kernel = k_euclid_mfma2 (the cross-batch distance contraction [N x F].[F x B] per graph on
         # the fp32 MFMA): 2*B*B*N*F flops per launch.  Timed alone on full graphs.
         eu_ms = time_euclid_kernel(c)
         flops = 2.0 * B * B * N * F
-        kernel_ms["k_euclid_mfma(full graphs)"] = round(eu_ms, 5)
+        kernel_ms["k_euclid_mfma2(full graphs)"] = round(eu_ms, 5)
         line["roofline"] = {
-            "bound": "mfma", "kernel": "k_euclid_mfma", "achieved": flops / (eu_ms * 1e-3) / 1e12,
+            "bound": "mfma", "kernel": "k_euclid_mfma2", "achieved": flops / (eu_ms * 1e-3) / 1e12,
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / (eu_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic.get("k_euclid_mfma"),
+            "frac": flops / (eu_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic.get("k_euclid_mfma2"),
             "flops_per_launch": flops, "avg_launch_ms": eu_ms,
             "note": "fp32 MFMA (no TF32 on gfx950); the kernel alone through the C ABI (gcm_edge_distance_pre) on "
                     "graphs that hold N-1 nodes - every stored row is a candidate -, HIP events around 50 "
                     "back-to-back launches on the launch stream; in a rollout that starts from empty graphs the "
-                    "kernel skips rows >= cur, so its in-situ average is shorter"}
+                    "kernel skips the 32-row blocks >= cur, so its in-situ average is shorter (rocprofv3 average "
+                    "over the bench run: profiles/); `traffic` (PMC) is that in-situ average"}
     else:
-        # cfg5: no single dominant kernel (selection, GNN forward, one fused backward per step): the WHOLE
+        # cfg5: no single dominant kernel (selection, GNN forward, the two time-parallel backward passes): the WHOLE
         # step against the fp32 MFMA peak on SURVEY 8(d)'s flops - GNN fwd+bwd (3x forward), the adjacency
         # gradient (2N^2 F + 2N^2 H), the edge network on N candidate pairs fwd+bwd (3 x 2(3F^2+F) each)
         per_state = 3 * fwd_full + 2 * N * N * (F + H) + 3 * N * 2 * (3 * F * F + F)
         step_s = dt / args.steps / T
         line["roofline"] = {
-            "bound": "mfma", "kernel": "k_learned_select + k_gnn2_row_fwd + k_learned_step_bwd (whole step)",
+            "bound": "mfma", "kernel": "k_learned_select + k_gnn2_row_fwd + k_bptt_rows<2> (pass A) + k_learned_bptt_b (pass B): whole step",
             "achieved": B * per_state / step_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": B * per_state / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
             "flops_per_step": B * per_state, "avg_step_ms": step_s * 1e3,

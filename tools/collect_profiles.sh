@@ -36,6 +36,7 @@ for part in $PARTS; do
       stats bench_cfg4_oneshot bench.py --config cfg4 --no-cpu-baseline --headline-only
       stats bench_cfg4 bench.py --config cfg4 --no-cpu-baseline
       stats bench_cfg5 bench.py --config cfg5 --no-cpu-baseline
+      stats euclid_full tools/prof_euclid_full.py
       stats sparse_learned tools/prof_sparse_learned.py ;;
     pmc)
       pmc FETCH_SIZE tools/pmc_run.py
