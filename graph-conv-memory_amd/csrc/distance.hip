@@ -527,12 +527,20 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   DSTAMP(5);
   // sum over the 32 columns held by the lanes of each half-wave, then the four column tiles in fixed order
   if (rb < nb) {
+    // (on the DPP path: sixteen waves' butterflies through ds_bpermute are 300 KB of LDS crossbar traffic)
+#define GCM_DPP_ADD(v, ctrl, rmask) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = rowsum[r];
-      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (li == 0) sPart[ct * RB + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = v;
+      GCM_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+      GCM_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+      GCM_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror: the other quad of the 8
+      GCM_DPP_ADD(v, 0x140, 0xF);   // row_mirror: the other 8 of the row of 16
+      GCM_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 into rows 1 and 3: lanes 16..31 / 48..63 hold the 32-lane sums
+      if (li == 16) sPart[ct * RB + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = v;
     }
+#undef GCM_DPP_ADD
   }
   __syncthreads();
   if (tid < RB && tid < 32 * nb) {
