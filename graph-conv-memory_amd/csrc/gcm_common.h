@@ -39,6 +39,32 @@ __device__ __forceinline__ float gcm_tanh(float x) {
   return copysignf(ax < 0.25f ? small : big, x);
 }
 
+// Cross-lane sums / maxima on the DPP path (full-rate VALU) instead of __shfl_xor (ds_bpermute: every step of
+// a butterfly is an LDS round trip of ~100 cycles on the critical path of the single-wave kernels here).
+#define GCM_DPP_F(v, ctrl, rmask, old) \
+  __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), ctrl, rmask, 0xF, false))
+// value of the lane's xor-1 neighbour (quad_perm [1,0,3,2])
+__device__ __forceinline__ float gcm_lane_xor1(float v) { return GCM_DPP_F(v, 0xB1, 0xF, 0.f); }
+// sum / max over the 64 lanes, the same value returned to every lane
+__device__ __forceinline__ float gcm_wave_sum(float v) {
+  v += GCM_DPP_F(v, 0xB1, 0xF, 0.f);    // quad_perm [1,0,3,2]
+  v += GCM_DPP_F(v, 0x4E, 0xF, 0.f);    // quad_perm [2,3,0,1]
+  v += GCM_DPP_F(v, 0x141, 0xF, 0.f);   // row_half_mirror
+  v += GCM_DPP_F(v, 0x140, 0xF, 0.f);   // row_mirror: every lane holds its row's (16 lanes) sum
+  v += GCM_DPP_F(v, 0x142, 0xA, 0.f);   // row_bcast15 -> rows 1, 3
+  v += GCM_DPP_F(v, 0x143, 0xC, 0.f);   // row_bcast31 -> rows 2, 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float gcm_wave_max(float v) {
+  v = fmaxf(v, GCM_DPP_F(v, 0xB1, 0xF, v));
+  v = fmaxf(v, GCM_DPP_F(v, 0x4E, 0xF, v));
+  v = fmaxf(v, GCM_DPP_F(v, 0x141, 0xF, v));
+  v = fmaxf(v, GCM_DPP_F(v, 0x140, 0xF, v));
+  v = fmaxf(v, GCM_DPP_F(v, 0x142, 0xA, v));
+  v = fmaxf(v, GCM_DPP_F(v, 0x143, 0xC, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ float gcm_act(float v, int act) {
   if (act == GCM_ACT_TANH) return gcm_tanh(v);
   if (act == GCM_ACT_RELU) return v > 0.f ? v : 0.f;

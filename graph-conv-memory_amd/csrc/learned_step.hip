@@ -101,7 +101,7 @@ __device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const fl
     a[k] = (f < F && v > 0.f) ? v : 0.f;
     s += a[k];
   }
-  s += __shfl_xor(s, 1);
+  s += gcm_lane_xor1(s);
   const float mean = s / (float)F;
   float q = 0.f;
 #pragma unroll
@@ -109,7 +109,7 @@ __device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const fl
     const float d = f0 + k < F ? a[k] - mean : 0.f;
     q = fmaf(d, d, q);
   }
-  q += __shfl_xor(q, 1);
+  q += gcm_lane_xor1(q);
   const float rstd = rsqrtf(q / (float)F + eps);
   if (write) {
 #pragma unroll
@@ -138,8 +138,8 @@ __device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, cons
     m1 += gx[k];
     m2 = fmaf(gx[k], xh[k], m2);
   }
-  m1 += __shfl_xor(m1, 1);
-  m2 += __shfl_xor(m2, 1);
+  m1 += gcm_lane_xor1(m1);
+  m2 += gcm_lane_xor1(m2);
   m1 /= (float)F;
   m2 /= (float)F;
 #pragma unroll
@@ -169,14 +169,8 @@ __device__ __forceinline__ float c0_dot(const float* __restrict__ w_row, const f
   return c0;
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return gcm_wave_max(v); }
+__device__ __forceinline__ float wave_sum(float v) { return gcm_wave_sum(v); }
 
 // ---------------------------------------------------------------------------------------------
 // forward: logits of all candidate rows, gumbel-softmax, threshold, adjacency row (learned.py:53-113)
@@ -885,7 +879,7 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
     a[k] = (f < F && v > 0.f) ? v : 0.f;
     s += a[k];
   }
-  s += __shfl_xor(s, 1);
+  s += gcm_lane_xor1(s);
   const float mean = s / (float)F;
   float q = 0.f;
 #pragma unroll
@@ -893,7 +887,7 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
     const float d = f0 + k < F ? a[k] - mean : 0.f;
     q = fmaf(d, d, q);
   }
-  q += __shfl_xor(q, 1);
+  q += gcm_lane_xor1(q);
   const float rstd = rsqrtf(q / (float)F + eps);
 #pragma unroll
   for (int k = 0; k < FP / 2; ++k) {
@@ -1069,7 +1063,7 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < 32; ++k) t = fmaf(vec[k], img[k], t);
-      t += __shfl_xor(t, 1);
+      t += gcm_lane_xor1(t);
       if (half == 0) sSel[row] = row < cur ? t : 0.f;
     }
     __syncthreads();

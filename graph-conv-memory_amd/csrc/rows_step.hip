@@ -650,8 +650,14 @@ __global__ __launch_bounds__(256) void k_step_rows(
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < KC; ++k) t = fmaf(w2r[k], xq[k], t);
-#pragma unroll
-    for (int d = 1; d < KG; d <<= 1) t += __shfl_xor(t, d);
+    // sum over the KG (4 or 8) adjacent lanes of an output on the DPP path (ds_bpermute butterflies: three
+    // dependent LDS round trips on the step's critical path)
+    static_assert(KG == 4 || KG == 8, "layer-2 lane groups");
+#define GCM_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
+    GCM_DPP_ADD(t, 0xB1);                 // quad_perm [1,0,3,2]
+    GCM_DPP_ADD(t, 0x4E);                 // quad_perm [2,3,0,1]
+    if (KG == 8) GCM_DPP_ADD(t, 0x141);   // row_half_mirror: the other quad of the 8
+#undef GCM_DPP_ADD
     const float v = gcm_act_sel(t + bias2, act2_v);
     const bool mine = kg == 0 && o2 < H2;
     if (mine) mx_out[(size_t)b * H2 + o2] = v;
