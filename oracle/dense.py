@@ -192,7 +192,7 @@ class _STE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        return (x > 0).float()
+        return (x > 0).to(x.dtype)   # (`.float()` in the reference; dtype-generic for the float64 bound of the tests)
 
     @staticmethod
     def backward(ctx, g):
@@ -229,7 +229,7 @@ class LearnedEdge:
         pair = torch.cat((nodes[b_idx, i_idx], nodes[b_idx, j_idx]), dim=-1)
         logits = self.net(pair).squeeze()
         width = int(num_nodes.max())
-        shaped = torch.full((B, width), -1e10)
+        shaped = torch.full((B, width), -1e10, dtype=logits.dtype)   # (dtype-generic: the float64 bound of the tests)
         shaped = shaped.index_put((b_idx, j_idx), logits)
         soft = torch.softmax(shaped + self.noise_fn(shaped.shape), dim=-1)
         edges = _STE.apply(soft - 1.0 / (1 + self.k))
