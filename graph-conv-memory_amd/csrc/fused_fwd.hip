@@ -77,7 +77,16 @@ __device__ __forceinline__ void gnn2_row_fwd_body(
     lane_hop = A.edits.hops[lane & 15];
     lane_dir = A.edits.dir[lane & 15];
   }
-  const bool wave_live = wave < NT;
+  bool wave_live = wave < NT;
+  if (!ADV && wave_live && r_base > cur) {
+    // A 32-row block beyond row cur is needed only if row cur aggregates from it (layer 2 reads h1[j] where
+    // adj[cur, j] != 0; the backward passes read the rows j < cur and the live rows): look at row cur's entries
+    // in this block first - one more round trip for the waves that most probably have nothing to do, and a
+    // partly filled graph (LearnedEdge rollouts from empty graphs) no longer streams its empty rows.
+    const int j = r_base + (lane & 31);
+    const float a = ag[(size_t)cur * N + (j < N ? j : N - 1)];
+    wave_live = __ballot(j < N && a != 0.f) != 0ull;
+  }
   Stage<NP, FP, false, EXACT> st_x;
   Stage<HP, FP, true, EXACT> st_wr, st_wo;
   Stage<H2P, HP, false, EXACT> st_w2r, st_w2o;
@@ -194,7 +203,10 @@ __device__ __forceinline__ void gnn2_row_fwd_body(
     const int g = tid / HP, h = tid - g * HP;
     float s = 0.f;
 #pragma unroll 4
-    for (int j = g; j < N; j += G) s = fmaf(sAdj[adj_at<NP>(cur, j)], sAH[j * AS + h], s);
+    for (int j = g; j < N; j += G) {   // (h1 rows of skipped blocks are not in LDS: their coefficient is zero)
+      const float a = sAdj[adj_at<NP>(cur, j)];
+      s = a != 0.f ? fmaf(a, sAH[j * AS + h], s) : s;
+    }
     sV[tid] = s;
     __syncthreads();
     if (tid < HP) {
