@@ -737,10 +737,12 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
     one = torch.ones(B, dtype=torch.long, device=device)
     n_sw = N      # stepwise taus=1 x 512
 
+    xs = [x[:, t:t + 1].contiguous() for t in range(n_sw)]   # a stepwise caller's observations: one [B, 1, F] per call
+
     def stepwise():
         hid, outs = None, []
         for t in range(n_sw):
-            o, hid = mem(x[:, t:t + 1], one, hid)
+            o, hid = mem(xs[t], one, hid)
             outs.append(o)
         torch.cat(outs, 1).mean().backward()
         bucket.all_reduce_mean(weight)
