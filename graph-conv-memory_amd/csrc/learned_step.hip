@@ -27,6 +27,9 @@
 //
 // Shapes: N <= 128, F <= 32, H1 <= 32, H2 <= 32 (BASELINE cfg5: 128 / 32 / 32 / 32).
 #include "fused_common.h"
+#include <utility>
+#include <vector>
+
 #include "rows_common.h"
 #include "state_copy.h"
 
@@ -186,15 +189,30 @@ __device__ __forceinline__ float wave_sum(float v) { return gcm_wave_sum(v); }
 // overflow the roll happens in place (every load lands before the first store).  What the time-parallel
 // backward needs of the state goes into the step's record: the node matrix after the insert (`snap`, 4 MB
 // at cfg5 instead of the 21 MB state copy) and row cur of the adjacency (`row_out`).
-template <int MODE>
+// TAIL (round 3, "cached" steps): the GNN of the step rides on the selection.  Rows of h1 never change once
+// written while a graph has not overflowed (row j's adjacency entries and the rows it aggregates are final
+// after step j), so a chain that starts from EMPTY graphs keeps h1 / agg1 / x of every node in per-chain caches
+// [B,N,.] and a step only computes row cur: agg1[cur] from the selected rows of the node image (already in LDS),
+// h1[cur], agg2 from the selected rows of the h1 cache (preloaded to LDS next to the node image), the belief -
+// four 32 x 32 matrix-vector products on wave 0 behind the selection instead of a second kernel over the
+// whole graph (k_gnn2_row_fwd).  The backward passes read the caches (gcm_learned_bptt_cached).
+struct GnnTail {
+  const float* gnn;                  // packed GNN parameters (gcm_dense_gnn2_param_count layout)
+  int act1, act2, has_bias, H1, H2;
+  float *cH, *cA, *cX;               // caches: h1 [B,N,H1], agg1 [B,N,F], nodes [B,N,F]
+  float *mx_out, *agg2_out;          // this step: [B,H2], [B,H1]
+};
+
+template <int MODE, bool TAIL>
 __global__ __launch_bounds__(256) void k_learned_select(
     const float* __restrict__ nodes_c, float* adj, const int64_t* __restrict__ cur_idx_c,
     const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp, float eps0,
     float eps1, float cutoff, float* __restrict__ soft, int N, int F, const float* __restrict__ obs,
     const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes_out,
     int64_t* __restrict__ cur_out, int64_t* count_out, uint32_t* __restrict__ flags,
-    float* __restrict__ snap, float* __restrict__ row_out) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
+    float* __restrict__ snap, float* __restrict__ row_out, GnnTail gt) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
   constexpr bool ADVANCE = MODE != 0, DONATE = MODE == 2;
+  static_assert(!TAIL || DONATE, "the cached step runs on a donated state");
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   int cur;
@@ -225,10 +243,22 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sW1 = sW0b + FP * FS;      // [o][f]
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
+  float* sHc = sLogit + NP;         // TAIL: [NP][FS] the h1 cache of this graph
+  float* sWg = sHc + NP * FS;       // TAIL: [4][FP][FS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride FS
 
   gcm_fused::Stage<FP, FP, false, false> st_w0, st_w1;   // in flight together with the loads below
   st_w0.load(M.w0 + F, F, F, 2 * F, tid);
   st_w1.load(M.w1, F, F, F, tid);
+  gcm_fused::Stage<NP, FP, false, false> st_hc;
+  gcm_fused::Stage<FP, FP, false, false> st_g[4];
+  if (TAIL) {
+    const int H1 = gt.H1, H2 = gt.H2;
+    st_hc.load(gt.cH + (size_t)b * N * H1, N, H1, H1, tid);
+    st_g[0].load(gt.gnn, H1, F, F, tid);
+    st_g[1].load(gt.gnn + (size_t)H1 * F, H1, F, F, tid);
+    st_g[2].load(gt.gnn + 2 * (size_t)H1 * F + H1, H2, H1, H1, tid);
+    st_g[3].load(gt.gnn + 2 * (size_t)H1 * F + H1 + (size_t)H2 * H1, H2, H1, H1, tid);
+  }
   if (ADVANCE) {
     // the state copy through registers (roll folded in), the node image for the edge network from the
     // same registers, the observation patched into row cur
@@ -268,11 +298,13 @@ __global__ __launch_bounds__(256) void k_learned_select(
     }
     float* ng_out = nodes_out + (size_t)b * N * F;
     if (DONATE) {
-      float* sn = snap + (size_t)b * N * F;   // the node matrix after the insert, for the record
+      if (!TAIL) {
+        float* sn = snap + (size_t)b * N * F;   // the node matrix after the insert, for the record
 #pragma unroll
-      for (int i = 0; i < NODE_PER; ++i) {
-        const int e4 = tid + 256 * i;
-        if (e4 < lim_n) *reinterpret_cast<float4*>(sn + e4 * 4) = cn[i];
+        for (int i = 0; i < NODE_PER; ++i) {
+          const int e4 = tid + 256 * i;
+          if (e4 < lim_n) *reinterpret_cast<float4*>(sn + e4 * 4) = cn[i];
+        }
       }
       if (wrap) {   // source and destination alias: every load lands before the first store
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -294,6 +326,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
   }
   st_w0.store(sW0b, FS, tid);
   st_w1.store(sW1, FS, tid);
+  if (TAIL) {
+    st_hc.store(sHc, FS, tid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st_g[q].store(sWg + q * FP * FS, FS, tid);
+  }
   if (tid < FP) {
     const int o = tid < F ? tid : F - 1;
     const float c0 = c0_dot(M.w0 + (size_t)o * 2 * F, xcur, M.b0[o], F);
@@ -371,10 +408,68 @@ __global__ __launch_bounds__(256) void k_learned_select(
           const float nv = (edge + old > 0.f) ? 1.f : 0.f;       // learned.py:108-110
           row[j] = nv;
           if (DONATE) row_out[(size_t)b * N + j] = nv;
-        } else if (DONATE) {
-          row_out[(size_t)b * N + j] = 0.f;
+          if (TAIL) z[c] = nv;
+        } else {
+          if (DONATE) row_out[(size_t)b * N + j] = 0.f;
+          if (TAIL) z[c] = 0.f;
         }
+      } else if (TAIL) {
+        z[c] = 0.f;
       }
+    }
+    if (TAIL) {
+      // ---- the GNN on row cur (see GnnTail): the selected rows S = { j < cur : row[j] = 1 }, ascending -------
+      const int H1 = gt.H1, H2 = gt.H2;
+      unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
+      const int fl_ = lane < FP ? lane : FP - 1;
+      float agg1 = 0.f, agg2 = 0.f;          // lane f: agg1[f]; lane h: agg2[h]
+      while (m0 | m1) {
+        const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+        if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+        agg1 += sX[j * FS + fl_];
+        agg2 += sHc[j * FS + fl_];
+      }
+      const float xc = sX[cur * FS + fl_];    // lane f: x[cur][f]
+      agg1 = lane < F ? agg1 : 0.f;
+      agg2 = lane < H1 ? agg2 : 0.f;
+      // h1[cur][h] = act1(b1[h] + sum_f W_rel1[h][f] agg1[f] + W_root1[h][f] x[cur][f]), lane h
+      const float* wr1 = sWg + fl_ * FS;
+      const float* wt1 = sWg + FP * FS + fl_ * FS;
+      float p1 = (gt.has_bias & 1) && lane < H1 ? gt.gnn[2 * (size_t)H1 * F + lane] : 0.f;
+#pragma unroll
+      for (int f = 0; f < FP; ++f) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg1), f));
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), f));
+        p1 = fmaf(wr1[f], a, p1);
+        p1 = fmaf(wt1[f], x, p1);
+      }
+      float h1c = gcm_act(p1, gt.act1);
+      h1c = lane < H1 ? h1c : 0.f;
+      // mx[o] = act2(b2[o] + sum_h W_rel2[o][h] agg2[h] + W_root2[o][h] h1[cur][h]), lane o
+      const float* wr2 = sWg + 2 * FP * FS + fl_ * FS;
+      const float* wt2 = sWg + 3 * FP * FS + fl_ * FS;
+      float p2 = (gt.has_bias & 2) && lane < H2
+                     ? gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + lane] : 0.f;
+#pragma unroll
+      for (int h = 0; h < FP; ++h) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg2), h));
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h1c), h));
+        p2 = fmaf(wr2[h], a, p2);
+        p2 = fmaf(wt2[h], x, p2);
+      }
+      const float v = gcm_act(p2, gt.act2);
+      const size_t rc = (size_t)b * N + cur;
+      if (lane < H1) {
+        gt.cH[rc * H1 + lane] = h1c;
+        gt.agg2_out[(size_t)b * H1 + lane] = agg2;
+      }
+      if (lane < F) {
+        gt.cA[rc * F + lane] = agg1;
+        gt.cX[rc * F + lane] = xc;
+      }
+      if (lane < H2) gt.mx_out[(size_t)b * H2 + lane] = v;
+      const bool bad = __any(lane < H2 && !isfinite(v));
+      if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
     }
   }
 }
@@ -859,6 +954,7 @@ __global__ __launch_bounds__(256) void k_learned_step_bwd(
 struct BpttB {
   gcm_rows::StepTable tab;            // tab.saved[s]: the buffer of step s0 + s (nodes at offset 0)
   size_t o_h1, o_soft;                // float offsets of h1 [B,N,H1] and soft [B,N] inside it
+  const float *c_nodes, *c_h1;        // cached steps: the chain's caches instead (NULL: the step's own buffer)
   const int* hdr;                     // pass A: [T, B, 2] cur, L
   const int* live;                    //         [T, B, N]
   const float* da;                    //         [T, B, N, F]
@@ -968,8 +1064,8 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
     float* const sX = sX_ + zv; float* const sP0 = sP0_ + zv; float* const sP1 = sP1_ + zv;
     const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * ((size_t)sg * B + b)]);
     if (cur <= 0) continue;   // no candidate rows: nothing was selected, nothing to differentiate (uniform)
-    const float* xg = base + (size_t)b * N * F;
-    const float* hg = base + a.o_h1 + (size_t)b * N * H1;
+    const float* xg = (a.c_nodes ? a.c_nodes : base) + (size_t)b * N * F;
+    const float* hg = (a.c_h1 ? a.c_h1 : base + a.o_h1) + (size_t)b * N * H1;
     const bool wave_on = 32 * wave < cur;      // this wave's rows hold candidates
     const int jn = cur < N ? cur : N;          // rows with a gradient
     LSTAMP(14);
@@ -1215,6 +1311,7 @@ constexpr size_t lds_bptt_b() {
 }
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
+constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * FS); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
                           (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);
@@ -1235,12 +1332,13 @@ extern "C" int gcm_learned_select_fused(const float* nodes, float* adj, const in
   GCM_REQUIRE(nodes && adj && cur_idx && noise && mlp_params && soft && B > 0);
   if (!gcm_learned_step_supported(N, F, 1, 1)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<0>;
+  auto kern = gcm_learned::k_learned_select<0, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, adj, cur_idx, noise,
                      noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr,
-                     (int64_t*)nullptr, (int64_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (int64_t*)nullptr, (int64_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr,
+                     gcm_learned::GnnTail{});
   return gcm_launch_status();
 }
 
@@ -1258,12 +1356,12 @@ extern "C" int gcm_learned_advance_select_fused(const float* obs, const float* n
   GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
   if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<1>;
+  auto kern = gcm_learned::k_learned_select<1, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F,
                      obs, nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,
-                     (float*)nullptr);
+                     (float*)nullptr, gcm_learned::GnnTail{});
   return gcm_launch_status();
 }
 
@@ -1280,12 +1378,39 @@ extern "C" int gcm_learned_advance_select_inplace(const float* obs, float* nodes
               adj_row && flags && B > 0);
   if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<2>;
+  auto kern = gcm_learned::k_learned_select<2, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags, nodes_snap,
-                     adj_row);
+                     adj_row, gcm_learned::GnnTail{});
+  return gcm_launch_status();
+}
+
+/* One whole forward step of a chain that started from EMPTY graphs and has not overflowed (fewer than N steps so
+ * far), on a DONATED state: gcm_learned_advance_select_inplace with the step's GNN behind the selection (see
+ * GnnTail) - one launch.  cache_h1 [B,N,H1], cache_agg1 [B,N,F], cache_nodes [B,N,F]: the chain's caches (row cur is
+ * written; rows < cur were written by the earlier steps of the chain; zero-filled by the caller at the chain's
+ * head).  The step's record (gcm_learned_step_layout, compact = 2): adj_row [B,N], mx [B,H2], agg2 [B,H1], cur /
+ * count, soft [B,N]. */
+extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
+                                       const float* noise, int noise_is_exp, const float* params, int has_bias,
+                                       int act1, int act2, float eps0, float eps1, float cutoff, int64_t* cur_out,
+                                       int64_t* count_out, float* soft, float* adj_row, float* mx, float* agg2,
+                                       float* cache_h1, float* cache_agg1, float* cache_nodes, uint32_t* flags, int B,
+                                       int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && adj && count_in && noise && params && cur_out && count_out && soft && adj_row && mx &&
+              agg2 && cache_h1 && cache_agg1 && cache_nodes && flags && B > 0);
+  if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
+  const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  constexpr size_t lds = gcm_learned::lds_select_tail();
+  auto kern = gcm_learned::k_learned_select<2, true>;
+  gcm_allow_dynamic_lds((const void*)kern, lds);
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
+                     (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
+                     (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags,
+                     (float*)nullptr, adj_row, gt);
   return gcm_launch_status();
 }
 
@@ -1315,8 +1440,12 @@ extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int 
   GCM_REQUIRE(out8 && B > 0 && N > 0 && F > 0 && H1 > 0 && H2 > 0);
   // nodes | adj | mx | h1 | agg1 | agg2 | cur, count_out (2 B int64) | soft      (64-float aligned sections)
   // compact (donated state): `adj` holds row cur only, [B, N]
-  const size_t n_nodes = lrn_pad64((size_t)B * N * F), n_adj = lrn_pad64((size_t)B * N * (compact ? 1 : N));
-  const size_t n_mx = lrn_pad64((size_t)B * H2), n_h1 = lrn_pad64((size_t)B * N * H1), n_agg2 = lrn_pad64((size_t)B * H1);
+  // compact = 2 (cached step, gcm_learned_step_cached): no nodes / h1 / agg1 sections at all - they live in the
+  // chain's caches
+  const bool cached = compact == 2;
+  const size_t n_nodes = cached ? 0 : lrn_pad64((size_t)B * N * F), n_adj = lrn_pad64((size_t)B * N * (compact ? 1 : N));
+  const size_t n_mx = lrn_pad64((size_t)B * H2), n_h1 = cached ? 0 : lrn_pad64((size_t)B * N * H1),
+               n_agg2 = lrn_pad64((size_t)B * H1);
   out8[1] = n_nodes;                 // o_adj
   out8[2] = out8[1] + n_adj;         // o_mx
   out8[3] = out8[2] + n_mx;          // o_h1
@@ -1333,12 +1462,18 @@ static int lrn_grid_b(int n_steps_launch, int B) {   // persistent: two workgrou
   return (int)(items < 512 ? items : 512);
 }
 
+// pass-A workgroups (= slabs) per launch: what gcm_dense_rows_bptt_slabs gives a full chunk
+static inline int lrn_per_a(int n_steps, int B) {
+  return gcm_dense_rows_bptt_slabs(GCM_ROWS_MAX_STEPS < n_steps ? GCM_ROWS_MAX_STEPS : n_steps, B);
+}
+
 extern "C" size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, int F, int H1, int H2) {
   if (n_steps <= 0 || B <= 0) return 0;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2, Pm = 3 * (size_t)F * F + 7 * F + 1;
-  const size_t chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
+  // (one launch more than the step count needs: a chain's cached prefix and the steps behind it do not share one)
+  const size_t chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS + 1;
   const size_t TB = (size_t)n_steps * B;
-  size_t fl = lrn_pad64(Pg * (size_t)gcm_dense_rows_bptt_slabs(n_steps, B)) + lrn_pad64(Pm * 512 * chunks) +
+  size_t fl = lrn_pad64(Pg * (size_t)lrn_per_a(n_steps, B) * chunks) + lrn_pad64(Pm * 512 * chunks) +
               lrn_pad64(TB * 2) + lrn_pad64(TB * N) + lrn_pad64(TB * N * F) + lrn_pad64(TB * H1);
   return sizeof(float) * fl;
 }
@@ -1352,12 +1487,34 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
                                 float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
                                 void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                                 gcm_stream_t stream) {
+  return gcm_learned_bptt_cached(saved_host, gmx_host, n_steps, 0, nullptr, nullptr, nullptr, gmx_stride_b,
+                                 gmx_stride_h, params, act1, act2, eps0, eps1, compact, g_params_prev, g_params,
+                                 workspace, workspace_bytes, B, N, F, H1, H2, stream);
+}
+
+/* gcm_learned_bptt for a chain whose first n_cached steps are cached ones (gcm_learned_step_cached: records in the
+ * compact = 2 layout, node matrix / h1 / agg1 of every node in the chain's caches); the steps behind them have
+ * the `compact` layout. */
+extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                                       int n_cached, const float* cache_nodes, const float* cache_h1,
+                                       const float* cache_agg1, long gmx_stride_b, long gmx_stride_h,
+                                       const float* params, int act1, int act2, float eps0, float eps1, int compact,
+                                       const float* g_params_prev, float* g_params, void* workspace,
+                                       size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                                       gcm_stream_t stream) {
   GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace && n_steps > 0 && B > 0);
+  GCM_REQUIRE(n_cached >= 0 && n_cached <= n_steps && (n_cached == 0 || (cache_nodes && cache_h1 && cache_agg1)));
   if (!gcm_learned_step_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
   if (workspace_bytes < gcm_learned_bptt_workspace_bytes(n_steps, B, N, F, H1, H2)) return GCM_EWORKSPACE;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2, Pm = 3 * (size_t)F * F + 7 * F + 1;
-  const int chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
-  const int total_a = gcm_dense_rows_bptt_slabs(n_steps, B), per_a = total_a / chunks;
+  // chunks of <= GCM_ROWS_MAX_STEPS steps of ONE kind (cached | not): {first step, count}
+  std::vector<std::pair<int, int>> chunk_list;
+  for (int lo = 0, hi = n_cached; lo < n_steps; lo = hi, hi = n_steps)
+    for (int s0 = lo; s0 < hi; s0 += GCM_ROWS_MAX_STEPS)
+      chunk_list.push_back({s0, hi - s0 < GCM_ROWS_MAX_STEPS ? hi - s0 : GCM_ROWS_MAX_STEPS});
+  const int chunks = (int)chunk_list.size();
+  const int per_a = lrn_per_a(n_steps, B);
+  const int total_a = per_a * chunks;
   const size_t TB = (size_t)n_steps * B;
   float* ws = (float*)workspace;
   float* slabs_a = ws;
@@ -1366,21 +1523,25 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
   int* live = hdr + lrn_pad64(TB * 2);
   float* da = (float*)(live + lrn_pad64(TB * N));
   float* dagg2 = da + lrn_pad64(TB * N * F);
-  size_t lay[8];
-  gcm_learned_step_layout(B, N, F, H1, H2, compact, lay);
+  size_t lay_full[8], lay_c[8];
+  gcm_learned_step_layout(B, N, F, H1, H2, compact, lay_full);
+  gcm_learned_step_layout(B, N, F, H1, H2, 2, lay_c);
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   // pass A: every step, every graph (the arrays pass B scans must be complete before it starts)
   for (int c = 0; c < chunks; ++c) {
-    const int s0 = c * GCM_ROWS_MAX_STEPS;
-    const int ns = n_steps - s0 < GCM_ROWS_MAX_STEPS ? n_steps - s0 : GCM_ROWS_MAX_STEPS;
+    const int s0 = chunk_list[c].first, ns = chunk_list[c].second;
+    const bool cached = s0 < n_cached;
+    const size_t* lay = cached ? lay_c : lay_full;
     gcm_rows::StepTable tab{};
     for (int i = 0; i < ns; ++i) {
       GCM_REQUIRE(saved_host[s0 + i]);
       tab.saved[i] = saved_host[s0 + i];
       tab.gmx[i] = gmx_host[s0 + i];
     }
-    gcm_rows::LearnedSrc src{lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], params, hdr, live, da, dagg2, s0, compact};
+    gcm_rows::LearnedSrc src{lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], params, hdr, live, da, dagg2, s0,
+                             cached ? 1 : compact, cached ? cache_nodes : nullptr, cached ? cache_h1 : nullptr,
+                             cached ? cache_agg1 : nullptr};
     const int rc = gcm_rows::launch_bptt_learned(stream, per_a, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,
                                                  w_root2, act1, act2, slabs_a + (size_t)c * per_a * Pg, src, B, N,
                                                  F, H1, H2);
@@ -1392,12 +1553,15 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
   gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_b, lds);
   int total_b = 0;
   for (int c = 0; c < chunks; ++c) {
-    const int s0 = c * GCM_ROWS_MAX_STEPS;
-    const int ns = n_steps - s0 < GCM_ROWS_MAX_STEPS ? n_steps - s0 : GCM_ROWS_MAX_STEPS;
+    const int s0 = chunk_list[c].first, ns = chunk_list[c].second;
+    const bool cached = s0 < n_cached;
+    const size_t* lay = cached ? lay_c : lay_full;
     gcm_learned::BpttB a{};
     for (int i = 0; i < ns; ++i) a.tab.saved[i] = saved_host[s0 + i];
     a.o_h1 = lay[3];
     a.o_soft = lay[7];
+    a.c_nodes = cached ? cache_nodes : nullptr;
+    a.c_h1 = cached ? cache_h1 : nullptr;
     a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
     a.s0 = s0; a.n_steps = ns; a.T = n_steps;
     const int grid = lrn_grid_b(ns, B);

@@ -58,6 +58,7 @@ struct LrnSrc {
   float* dagg2;      // [T, B, H1]
   int s0;            // path index of this launch's first step
   int adj_compact;   // the buffers hold row cur of the adjacency only ([B, N])
+  const float *c_nodes, *c_h1, *c_agg1;   // cached steps: the chain's caches instead of the step's own sections
 };
 
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
@@ -138,7 +139,10 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     } else {
       if (MODE == 2) {   // this step's own buffer, per-graph indexing
         const float* base = tab.saved[s];
-        src.adj = base + lrn.o_adj; src.nodes = base; src.h1 = base + lrn.o_h1; src.agg1 = base + lrn.o_agg1;
+        src.adj = base + lrn.o_adj;
+        src.nodes = lrn.c_nodes ? lrn.c_nodes : base;
+        src.h1 = lrn.c_h1 ? lrn.c_h1 : base + lrn.o_h1;
+        src.agg1 = lrn.c_agg1 ? lrn.c_agg1 : base + lrn.o_agg1;
         src.agg2 = base + lrn.o_agg2; src.mx = base + lrn.o_mx;
         src.cur = reinterpret_cast<const int64_t*>(base + lrn.o_idx);
         gi = (size_t)b;
@@ -319,7 +323,8 @@ int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_step
                         const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,
                         const LearnedSrc& src, int B, int N, int F, int H1, int H2) {
   LrnSrc l{src.o_adj, src.o_mx, src.o_h1, src.o_agg1, src.o_agg2, src.o_idx, src.w_rel1,
-           src.hdr,   src.live, src.da,   src.dagg2,  src.s0, src.adj_compact};
+           src.hdr,   src.live, src.da,   src.dagg2,  src.s0, src.adj_compact,
+           src.c_nodes, src.c_h1, src.c_agg1};
   return launch_bptt<32, 32, 32, 2>((hipStream_t)stream, grid, tab, Hist{}, n_steps, gmx_sb, gmx_sh, w_rel2,
                                     w_root2, act1, act2, SavedLayout{}, slabs, B, N, F, H1, H2, 0, l);
 }

@@ -37,6 +37,8 @@ struct LearnedSrc {
   float* dagg2;
   int s0;
   int adj_compact;   // the step buffers hold row cur of the adjacency only ([B, N] at o_adj)
+  // cached steps (learned_step.hip: gcm_learned_step_cached): node matrix / h1 / agg1 in the chain's caches
+  const float *c_nodes, *c_h1, *c_agg1;
 };
 int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh,
                         const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,

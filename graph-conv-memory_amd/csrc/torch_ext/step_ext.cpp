@@ -971,12 +971,14 @@ struct LearnedChainNode : public torch::autograd::Node {
     uint32_t version;
     int parent;                 // index of the step whose hidden state this one continued, or -1
     int64_t B;
+    bool cached = false;        // a cached step (gcm_learned_step_cached): buf in the compact = 2 layout
   };
   std::vector<Rec> recs;
   at::Tensor packed;            // detached
   LearnedCfg* cfg = nullptr;
   bool executed = false, released = false;
   bool compact = false;         // the steps ran on a donated state: their buffers hold row cur of the adjacency only
+  at::Tensor cH, cA, cX;        // the caches of the chain's cached steps (h1, agg1, node matrix of every node)
 
   variable_list apply(variable_list&& grads) override {
     executed = true;
@@ -1033,14 +1035,20 @@ struct LearnedChainNode : public torch::autograd::Node {
         if (g[t].defined()) keep.push_back(g[t]);
       }
       const int T = (int)path.size(), B = (int)recs[path[0]].B;
+      int n_cached = 0;   // (cached steps are a prefix of every path: they end at the first fork / overflow risk)
+      while (n_cached < T && recs[path[n_cached]].cached) ++n_cached;
+      for (int t = n_cached; t < T; ++t) TORCH_CHECK(!recs[path[t]].cached, "learned chain: cached step behind a full one");
       const size_t ws_bytes = gcm_learned_bptt_workspace_bytes(T, B, N, F, H1, H2);
       at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
       at::Tensor res = at::empty({cfg->P_total}, packed.options());
-      check(gcm_learned_bptt(sv.data(), gm.data(), T, (long)sb, (long)sh, packed.data_ptr<float>(), cfg->act1,
-                             cfg->act2, (float)cfg->eps0, (float)cfg->eps1, compact ? 1 : 0,
-                             prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
-                             ws.data_ptr(), ws_bytes, B, N, F, H1, H2, stream),
-            "gcm_learned_bptt");
+      check(gcm_learned_bptt_cached(sv.data(), gm.data(), T, n_cached, n_cached ? cX.data_ptr<float>() : nullptr,
+                                    n_cached ? cH.data_ptr<float>() : nullptr,
+                                    n_cached ? cA.data_ptr<float>() : nullptr, (long)sb, (long)sh,
+                                    packed.data_ptr<float>(), cfg->act1, cfg->act2, (float)cfg->eps0,
+                                    (float)cfg->eps1, compact ? 1 : 0,
+                                    prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
+                                    ws.data_ptr(), ws_bytes, B, N, F, H1, H2, stream),
+            "gcm_learned_bptt_cached");
       prev = res;
     }
     out[0] = prev;
@@ -1073,12 +1081,19 @@ struct LearnedChain {   // one per packed parameter vector
   bool executed() const { return node && node->executed; }
   bool recording() const { return node != nullptr; }
   int64_t steps() const { return node ? (int64_t)node->recs.size() : 0; }
+  // cached steps (gcm_learned_step_cached): while the chain is linear, started from empty graphs, runs on a
+  // donated state and has made fewer than N steps (no graph can have overflowed)
+  bool cache_ok = false;
+  int64_t cached_steps = 0, all_steps = 0;
+  at::Tensor cH, cA, cX;
+  const void* last_nodes = nullptr;   // the node matrix the previous step returned: a linear chain continues it
+  int64_t n_cached() const { return cached_steps; }
 };
 
 // -> (mx, nodes_out, adj_out, cur, count_out, index of this step in the chain (or -1))
 pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const at::Tensor& nodes_in_,
                               const at::Tensor& adj_in_, const at::Tensor& count_in, const at::Tensor& noise_,
-                              int64_t noise_is_exp, const at::Tensor& flags, int64_t parent) {
+                              int64_t noise_is_exp, const at::Tensor& flags, int64_t parent, bool fresh) {
   LearnedCfg* cfg = chain.cfg;
   TORCH_CHECK(obs_.is_cuda() && nodes_in_.is_cuda() && adj_in_.is_cuda() && count_in.is_cuda() && noise_.is_cuda() &&
                   flags.is_cuda(),
@@ -1105,7 +1120,38 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
   const float* b2 = w_root2 + (size_t)H2 * H1;
   if (need_bwd) TORCH_CHECK(parent < (int64_t)chain.node->recs.size());
   at::Tensor buf, nodes_out, adj_out, mx, cur, count_out;
-  if (donate) {
+  // cached step?  (see LearnedChain)
+  if (chain.all_steps == 0) chain.cache_ok = fresh && donate && nodes_in_.is_contiguous() && adj_in_.is_contiguous();
+  else if (chain.cache_ok)
+    chain.cache_ok = chain.last_nodes == nodes_in_.data_ptr() && chain.cached_steps == chain.all_steps &&
+                     chain.cached_steps < N && (!need_bwd || parent == (int64_t)chain.node->recs.size() - 1);
+  const bool cached = chain.cache_ok;
+  if (cached) {
+    if (chain.all_steps == 0) {
+      chain.cH = at::zeros({B, N, H1}, obs.options());
+      chain.cA = at::zeros({B, N, F}, obs.options());
+      chain.cX = at::zeros({B, N, F}, obs.options());
+      if (chain.node) { chain.node->cH = chain.cH; chain.node->cA = chain.cA; chain.node->cX = chain.cX; }
+    }
+    size_t lay[8];
+    check(gcm_learned_step_layout((int)B, N, F, H1, H2, 2, lay), "gcm_learned_step_layout");
+    buf = at::empty({(int64_t)lay[0]}, obs.options());
+    float* base = buf.data_ptr<float>();
+    int64_t* ib = reinterpret_cast<int64_t*>(base + lay[6]);
+    check(gcm_learned_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                  count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp, pk,
+                                  cfg->has_bias, cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
+                                  (float)cfg->cutoff, ib, count_in.data_ptr<int64_t>(), base + lay[7], base + lay[1],
+                                  base + lay[2], base + lay[5], chain.cH.data_ptr<float>(),
+                                  chain.cA.data_ptr<float>(), chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2, st),
+          "gcm_learned_step_cached");
+    nodes_out = nodes_in_;
+    adj_out = adj_in_;
+    count_out = count_in;
+    mx = alias_of(buf, (int64_t)lay[2], {B, H2}, buf.dtype());
+    cur = alias_of(buf, (int64_t)lay[6] / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
+    ++chain.cached_steps;
+  } else if (donate) {
     // the state is advanced in place; the step's buffer keeps the node matrix after the insert, row cur of
     // the adjacency, the GNN's layers and the softmax row (gcm_learned_step_layout, compact)
     TORCH_CHECK(nodes_in_.is_contiguous() && adj_in_.is_contiguous(),
@@ -1175,10 +1221,12 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
     cur = alias_of(buf, L.o_idx / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
     count_out = alias_of(buf, L.o_idx / 2 + B, {B}, caffe2::TypeMeta::Make<int64_t>());
   }
+  ++chain.all_steps;
+  chain.last_nodes = nodes_out.data_ptr();
   int64_t index = -1;
   if (need_bwd) {
     const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
-    chain.node->recs.push_back({buf, vc, vc.current_version(), (int)parent, B});
+    chain.node->recs.push_back({buf, vc, vc.current_version(), (int)parent, B, cached});
     index = (int64_t)chain.node->recs.size() - 1;
     torch::autograd::create_gradient_edge(mx, chain.node);
   }
@@ -1514,6 +1562,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("learned_step", &learned_step);
   pybind11::class_<LearnedChain>(m, "LearnedChain")
       .def(pybind11::init<int64_t, const at::Tensor&, bool>())
+      .def("cached_steps", &LearnedChain::n_cached)
+      .def("total_steps", [](LearnedChain& c) { return c.all_steps; })
       .def("donates", [](LearnedChain& c) { return c.donate; })
       .def("executed", &LearnedChain::executed)
       .def("recording", &LearnedChain::recording)

@@ -133,6 +133,9 @@ class DenseGCM(torch.nn.Module):
         # False: the round-2 backward of the fused LearnedEdge step (one kernel per step behind a [B,N,N]
         # gradient chain buffer) instead of the time-parallel one - kept for A/B tests
         self.learned_time_parallel = True
+        # False: no cached steps (the first N steps of a LearnedEdge rollout from empty graphs on a donated state as
+        # ONE launch each, the GNN behind the selection on per-chain caches) - A/B tests
+        self.learned_cached_steps = True
         # Steps whose observations / nodes need a gradient run on the live-row kernels too.  True: the whole
         # chain's dL/dx in ONE launch by the chain's single autograd node (hardware float atomics: the order of
         # summation, i.e. the last bits, is not fixed; a policy that feeds belief t-1 into observation t switches
@@ -579,13 +582,21 @@ class DenseGCM(torch.nn.Module):
             # (LearnedChainNode in csrc/torch_ext/step_ext.cpp); the adjacency carries the index of the step
             # that wrote it, so that the time-parallel backward can follow the chain (or tree) of states
             lc = self._learned_chain
-            if lc is None or lc[0] is not root or lc[1].executed() or lc[2] != torch.is_grad_enabled():
+            # (a chain that starts from the empty graphs of hidden = None runs its first N steps as cached steps,
+            #  LearnedChain in step_ext.cpp: its caches belong to ONE such rollout)
+            fresh = getattr(nodes, "_gcm_fresh", False)
+            if fresh:
+                nodes._gcm_fresh = False      # (a donated state is this very tensor at every later step)
+            fresh = fresh and self.learned_cached_steps
+            if (lc is None or lc[0] is not root or lc[1].executed() or lc[2] != torch.is_grad_enabled()
+                    or (fresh and lc[1].total_steps() > 0)):
                 lc = self._learned_chain = (root, ext.LearnedChain(cfg.learned_cpp_handle(), root,
                                                                    bool(self.donate_state)),
                                             torch.is_grad_enabled())
             lin = getattr(adj, "_gcm_lin", None)
             parent = lin[1] if (lin is not None and lin[0] is lc[1]) else -1
-            mx, n2, a2, cur, c2, idx = ext.learned_step2(lc[1], x, nodes, adj, num_nodes, noise, is_exp, flags, parent)
+            mx, n2, a2, cur, c2, idx = ext.learned_step2(lc[1], x, nodes, adj, num_nodes, noise, is_exp, flags, parent,
+                                                         bool(fresh))
             if idx >= 0:
                 a2._gcm_lin = (lc[1], idx)
             if lc[1].donates():      # the state was advanced in place: the caller's own tuple
@@ -717,6 +728,7 @@ class DenseGCM(torch.nn.Module):
         num_nodes [B]) or None.  Returns (belief [B, H], new hidden)."""
         if hidden is None:
             hidden = self.get_initial_hidden_state(x)
+            hidden[0]._gcm_fresh = True     # empty graphs: what the cached LearnedEdge steps may rely on
         nodes, adj, weights, num_nodes = hidden
 
         # the kernels are launched on the CURRENT device's stream: tensors on another GPU get a

@@ -738,6 +738,27 @@ int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_hos
                      float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
                      void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                      gcm_stream_t stream);
+/* Cached steps.  Rows of h1 never change once written while a graph has not overflowed (row j's adjacency
+ * entries and the rows it aggregates are final after step j), so a chain that starts from EMPTY graphs keeps
+ * h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every node in per-chain caches (zero-filled by the
+ * caller at the chain's head) and a step computes row cur only - the whole forward step (gcm.py:262-321 with
+ * learned.py:53-113) in ONE launch on a donated state, for the first N steps of such a chain.  The step's record
+ * (gcm_learned_step_layout, compact = 2: no nodes / h1 / agg1 sections): adj_row [B,N], mx [B,H2], agg2 [B,H1],
+ * cur | count, soft [B,N].  params: GNN | edge network, packed.  gcm_learned_bptt_cached: gcm_learned_bptt for
+ * a chain whose first n_cached steps are such steps (the steps behind them: `compact` layout). */
+int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
+                            const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
+                            int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
+                            float* soft, float* adj_row, float* mx, float* agg2, float* cache_h1,
+                            float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1,
+                            int H2, gcm_stream_t stream);
+int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                            int n_cached, const float* cache_nodes, const float* cache_h1,
+                            const float* cache_agg1, long gmx_stride_b, long gmx_stride_h, const float* params,
+                            int act1, int act2, float eps0, float eps1, int compact, const float* g_params_prev,
+                            float* g_params, void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
+                            int H2, gcm_stream_t stream);
+
 /* The forward's first kernel on a DONATED state (advanced in place, nothing copied without overflow):
  * nodes_snap [B,N,F] and adj_row [B,N] are the sections `nodes` / `adj` of the COMPACT step buffer
  * (gcm_learned_step_layout(..., compact = 1): row cur of the adjacency only).  gcm_dense_gnn2_row_fwd

@@ -236,3 +236,60 @@ def test_learned_noise_pool_statistics_and_equivalence():
     assert float(same.double().mean()) >= 0.98      # (-log(x) is evaluated by the kernel in one run, by torch in the other)
     assert float(hidden[1].sum()) > float(B * 8)    # and edges were sampled at all
     torch.testing.assert_close(torch.stack(outs)[:, same], torch.stack(outs2)[:, same], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2),
+                                         (6, 128, 32, 32, 20, 5)])
+def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k):
+    """A rollout from hidden = None on a donated state: its first N steps are cached steps (ONE launch each: the
+    GNN behind the selection on the chain's h1 / agg1 / node caches, gcm_learned_step_cached), the steps behind
+    them - the graphs overflow - the usual ones; the backward mixes both kinds.  Against the oracle with the same
+    injected gumbel draws, and against the same rollout without cached steps."""
+    res = []
+    for cached in (True, False):
+        ref, net, g, sel, mem = _pair(F, H, N, k, seed=7, donate=True)
+        mem.learned_cached_steps = cached
+        gen = torch.Generator().manual_seed(11)
+        obs = torch.rand(T, B, F, generator=gen)
+        noise = -torch.empty(T, B, N).exponential_(generator=gen).log()
+        wgt = torch.rand(T, B, H, generator=gen)
+        pstep = {"t": 0}
+        sel.noise_fn = lambda like: noise[pstep["t"]].to(DEV)
+        hidden, outs = None, []
+        for t in range(T):
+            pstep["t"] = t
+            mx, hidden = mem(obs[t].to(DEV), hidden)
+            outs.append(mx)
+        assert _taken(mem)
+        n_c = mem._learned_chain[1].cached_steps()
+        assert n_c == (min(T, N) if cached else 0), n_c
+        out_d = torch.stack(outs)
+        (out_d * wgt.to(DEV)).sum().backward()
+        mem.check_flags()
+        res.append((out_d.detach().cpu(), [t.detach().cpu() for t in (hidden[0], hidden[1], hidden[3])],
+                    {k_: p.grad.cpu().clone() for k_, p in list(g.named_parameters()) +
+                     [("net." + n_, p_) for n_, p_ in sel.edge_network.named_parameters()]}))
+    # oracle
+    step = {"t": 0}
+    osel = od.LearnedEdge(net, num_edge_samples=k, noise_fn=lambda shape: noise[step["t"]][:, : shape[1]])
+    hid, outs = None, []
+    for t in range(T):
+        step["t"] = t
+        mx, hid = od.dense_step(obs[t], hid, ref, graph_size=N, edge_selectors=osel)
+        outs.append(mx)
+    out_c = torch.stack(outs)
+    (out_c * wgt).sum().backward()
+    want = dict(list(ref.named_parameters()) + [("net." + n_, p_) for n_, p_ in net.named_parameters()])
+    scale = max(float(p.grad.abs().max()) for p in net.parameters())
+    for out_d, state, grads in res:
+        assert torch.equal(state[1], hid[1].detach()) and torch.equal(state[0], hid[0]) and torch.equal(state[2], hid[3])
+        torch.testing.assert_close(out_d, out_c.detach(), rtol=RTOL, atol=2e-6)
+        for k_, gd in grads.items():
+            gc = want[k_].grad
+            torch.testing.assert_close(gd, gc, rtol=2e-3 if k_.startswith("net.") else 1e-4,
+                                       atol=2e-5 * float(gc.abs().max()) + 2e-6 * (scale if k_.startswith("net.") else 0.0),
+                                       msg=k_)
+    for k_ in res[0][2]:       # cached against not cached: the same arithmetic up to summation order
+        a, b = res[0][2][k_], res[1][2][k_]   # (gradients that are zero analytically: the floor from the common scale)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) +
+                                   (2e-6 * scale if k_.startswith("net.") else 0.0), msg=k_)
