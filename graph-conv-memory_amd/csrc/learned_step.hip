@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     int64_t* __restrict__ cur_out, int64_t* count_out, uint32_t* __restrict__ flags,
     float* __restrict__ snap, float* __restrict__ row_out, GnnTail gt) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
   constexpr bool ADVANCE = MODE != 0, DONATE = MODE == 2;
-  static_assert(!TAIL || DONATE, "the cached step runs on a donated state");
+  static_assert(!TAIL || ADVANCE, "the cached step advances the state itself");
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   int cur;
@@ -1414,6 +1414,30 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   return gcm_launch_status();
 }
 
+/* gcm_learned_step_cached on a FUNCTIONAL state: the new state goes to nodes_out / adj_out (the `nodes` / `adj`
+ * sections of the record, gcm_learned_step_layout compact = 3), the inputs are left alone. */
+extern "C" int gcm_learned_step_cached_functional(
+    const float* obs, const float* nodes_in, const float* adj_in, const int64_t* count_in, const float* noise,
+    int noise_is_exp, const float* params, int has_bias, int act1, int act2, float eps0, float eps1, float cutoff,
+    float* nodes_out, float* adj_out, int64_t* cur_out, int64_t* count_out, float* soft, float* mx, float* agg2,
+    float* cache_h1, float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1, int H2,
+    gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_in && adj_in && count_in && noise && params && nodes_out && adj_out && cur_out &&
+              count_out && soft && mx && agg2 && cache_h1 && cache_agg1 && cache_nodes && flags && B > 0);
+  GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
+  if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
+  const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  constexpr size_t lds = gcm_learned::lds_select_tail();
+  auto kern = gcm_learned::k_learned_select<1, true>;
+  gcm_allow_dynamic_lds((const void*)kern, lds);
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
+                     (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
+                     nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,
+                     (float*)nullptr, gt);
+  return gcm_launch_status();
+}
+
 extern "C" int gcm_learned_step_bwd(const float* g_mx, const float* nodes, const float* adj,
                                     const int64_t* cur_idx, const int64_t* count_in,
                                     const float* gnn_params, int act1, int act2, const float* mx,
@@ -1440,17 +1464,19 @@ extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int 
   GCM_REQUIRE(out8 && B > 0 && N > 0 && F > 0 && H1 > 0 && H2 > 0);
   // nodes | adj | mx | h1 | agg1 | agg2 | cur, count_out (2 B int64) | soft      (64-float aligned sections)
   // compact (donated state): `adj` holds row cur only, [B, N]
-  // compact = 2 (cached step, gcm_learned_step_cached): no nodes / h1 / agg1 sections at all - they live in the
-  // chain's caches
-  const bool cached = compact == 2;
-  const size_t n_nodes = cached ? 0 : lrn_pad64((size_t)B * N * F), n_adj = lrn_pad64((size_t)B * N * (compact ? 1 : N));
+  // compact = 2 (cached step on a donated state, gcm_learned_step_cached): no nodes / h1 / agg1 sections at all -
+  // they live in the chain's caches
+  // compact = 3: a cached step on a FUNCTIONAL state (the record holds the new state: nodes | full adj)
+  const bool cached = compact >= 2, row_only = compact == 1 || compact == 2;
+  const size_t n_nodes = compact == 2 ? 0 : lrn_pad64((size_t)B * N * F),
+               n_adj = lrn_pad64((size_t)B * N * (row_only ? 1 : N));
   const size_t n_mx = lrn_pad64((size_t)B * H2), n_h1 = cached ? 0 : lrn_pad64((size_t)B * N * H1),
-               n_agg2 = lrn_pad64((size_t)B * H1);
+               n_agg1 = cached ? 0 : lrn_pad64((size_t)B * N * F), n_agg2 = lrn_pad64((size_t)B * H1);
   out8[1] = n_nodes;                 // o_adj
   out8[2] = out8[1] + n_adj;         // o_mx
   out8[3] = out8[2] + n_mx;          // o_h1
   out8[4] = out8[3] + n_h1;          // o_agg1
-  out8[5] = out8[4] + n_nodes;       // o_agg2
+  out8[5] = out8[4] + n_agg1;        // o_agg2
   out8[6] = out8[5] + n_agg2;        // o_idx
   out8[7] = out8[6] + lrn_pad64(4 * (size_t)B);   // o_soft
   out8[0] = out8[7] + lrn_pad64((size_t)B * N);   // total floats
@@ -1487,7 +1513,7 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
                                 float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
                                 void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                                 gcm_stream_t stream) {
-  return gcm_learned_bptt_cached(saved_host, gmx_host, n_steps, 0, nullptr, nullptr, nullptr, gmx_stride_b,
+  return gcm_learned_bptt_cached(saved_host, gmx_host, n_steps, 0, 2, nullptr, nullptr, nullptr, gmx_stride_b,
                                  gmx_stride_h, params, act1, act2, eps0, eps1, compact, g_params_prev, g_params,
                                  workspace, workspace_bytes, B, N, F, H1, H2, stream);
 }
@@ -1496,7 +1522,7 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
  * compact = 2 layout, node matrix / h1 / agg1 of every node in the chain's caches); the steps behind them have
  * the `compact` layout. */
 extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
-                                       int n_cached, const float* cache_nodes, const float* cache_h1,
+                                       int n_cached, int cached_layout, const float* cache_nodes, const float* cache_h1,
                                        const float* cache_agg1, long gmx_stride_b, long gmx_stride_h,
                                        const float* params, int act1, int act2, float eps0, float eps1, int compact,
                                        const float* g_params_prev, float* g_params, void* workspace,
@@ -1504,6 +1530,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
                                        gcm_stream_t stream) {
   GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace && n_steps > 0 && B > 0);
   GCM_REQUIRE(n_cached >= 0 && n_cached <= n_steps && (n_cached == 0 || (cache_nodes && cache_h1 && cache_agg1)));
+  GCM_REQUIRE(cached_layout == 2 || cached_layout == 3);
   if (!gcm_learned_step_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
   if (workspace_bytes < gcm_learned_bptt_workspace_bytes(n_steps, B, N, F, H1, H2)) return GCM_EWORKSPACE;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2, Pm = 3 * (size_t)F * F + 7 * F + 1;
@@ -1525,7 +1552,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
   float* dagg2 = da + lrn_pad64(TB * N * F);
   size_t lay_full[8], lay_c[8];
   gcm_learned_step_layout(B, N, F, H1, H2, compact, lay_full);
-  gcm_learned_step_layout(B, N, F, H1, H2, 2, lay_c);
+  gcm_learned_step_layout(B, N, F, H1, H2, cached_layout, lay_c);
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   // pass A: every step, every graph (the arrays pass B scans must be complete before it starts)
@@ -1540,7 +1567,8 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       tab.gmx[i] = gmx_host[s0 + i];
     }
     gcm_rows::LearnedSrc src{lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], params, hdr, live, da, dagg2, s0,
-                             cached ? 1 : compact, cached ? cache_nodes : nullptr, cached ? cache_h1 : nullptr,
+                             cached ? (cached_layout == 2 ? 1 : 0) : compact, cached ? cache_nodes : nullptr,
+                             cached ? cache_h1 : nullptr,
                              cached ? cache_agg1 : nullptr};
     const int rc = gcm_rows::launch_bptt_learned(stream, per_a, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,
                                                  w_root2, act1, act2, slabs_a + (size_t)c * per_a * Pg, src, B, N,

@@ -1041,7 +1041,8 @@ struct LearnedChainNode : public torch::autograd::Node {
       const size_t ws_bytes = gcm_learned_bptt_workspace_bytes(T, B, N, F, H1, H2);
       at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
       at::Tensor res = at::empty({cfg->P_total}, packed.options());
-      check(gcm_learned_bptt_cached(sv.data(), gm.data(), T, n_cached, n_cached ? cX.data_ptr<float>() : nullptr,
+      check(gcm_learned_bptt_cached(sv.data(), gm.data(), T, n_cached, compact ? 2 : 3,
+                                    n_cached ? cX.data_ptr<float>() : nullptr,
                                     n_cached ? cH.data_ptr<float>() : nullptr,
                                     n_cached ? cA.data_ptr<float>() : nullptr, (long)sb, (long)sh,
                                     packed.data_ptr<float>(), cfg->act1, cfg->act2, (float)cfg->eps0,
@@ -1121,7 +1122,8 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
   if (need_bwd) TORCH_CHECK(parent < (int64_t)chain.node->recs.size());
   at::Tensor buf, nodes_out, adj_out, mx, cur, count_out;
   // cached step?  (see LearnedChain)
-  if (chain.all_steps == 0) chain.cache_ok = fresh && donate && nodes_in_.is_contiguous() && adj_in_.is_contiguous();
+  if (chain.all_steps == 0)
+    chain.cache_ok = fresh && (N & 3) == 0 && (F & 3) == 0 && nodes_in_.is_contiguous() && adj_in_.is_contiguous();
   else if (chain.cache_ok)
     chain.cache_ok = chain.last_nodes == nodes_in_.data_ptr() && chain.cached_steps == chain.all_steps &&
                      chain.cached_steps < N && (!need_bwd || parent == (int64_t)chain.node->recs.size() - 1);
@@ -1134,10 +1136,22 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
       if (chain.node) { chain.node->cH = chain.cH; chain.node->cA = chain.cA; chain.node->cX = chain.cX; }
     }
     size_t lay[8];
-    check(gcm_learned_step_layout((int)B, N, F, H1, H2, 2, lay), "gcm_learned_step_layout");
+    check(gcm_learned_step_layout((int)B, N, F, H1, H2, donate ? 2 : 3, lay), "gcm_learned_step_layout");
     buf = at::empty({(int64_t)lay[0]}, obs.options());
     float* base = buf.data_ptr<float>();
     int64_t* ib = reinterpret_cast<int64_t*>(base + lay[6]);
+    if (!donate) {
+      check(gcm_learned_step_cached_functional(
+                obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp, pk, cfg->has_bias, cfg->act1,
+                cfg->act2, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base, base + lay[1], ib, ib + B,
+                base + lay[7], base + lay[2], base + lay[5], chain.cH.data_ptr<float>(), chain.cA.data_ptr<float>(),
+                chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2, st),
+            "gcm_learned_step_cached_functional");
+      nodes_out = alias_of(buf, 0, {B, N, F}, buf.dtype());
+      adj_out = alias_of(buf, (int64_t)lay[1], {B, N, N}, buf.dtype());
+      count_out = alias_of(buf, (int64_t)lay[6] / 2 + B, {B}, caffe2::TypeMeta::Make<int64_t>());
+    } else {
     check(gcm_learned_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
                                   count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp, pk,
                                   cfg->has_bias, cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
@@ -1148,6 +1162,7 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
     nodes_out = nodes_in_;
     adj_out = adj_in_;
     count_out = count_in;
+    }
     mx = alias_of(buf, (int64_t)lay[2], {B, H2}, buf.dtype());
     cur = alias_of(buf, (int64_t)lay[6] / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
     ++chain.cached_steps;

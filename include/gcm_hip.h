@@ -744,16 +744,25 @@ int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_hos
  * caller at the chain's head) and a step computes row cur only - the whole forward step (gcm.py:262-321 with
  * learned.py:53-113) in ONE launch on a donated state, for the first N steps of such a chain.  The step's record
  * (gcm_learned_step_layout, compact = 2: no nodes / h1 / agg1 sections): adj_row [B,N], mx [B,H2], agg2 [B,H1],
- * cur | count, soft [B,N].  params: GNN | edge network, packed.  gcm_learned_bptt_cached: gcm_learned_bptt for
- * a chain whose first n_cached steps are such steps (the steps behind them: `compact` layout). */
+ * cur | count, soft [B,N].  params: GNN | edge network, packed.  gcm_learned_step_cached_functional: the same on a
+ * functional state (record layout compact = 3: nodes_out | adj_out | mx | agg2 | cur, count | soft).
+ * gcm_learned_bptt_cached: gcm_learned_bptt for a chain whose first n_cached steps are such steps (records in
+ * layout `cached_layout` = 2 | 3; the steps behind them: `compact` layout). */
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                             const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
                             int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
                             float* soft, float* adj_row, float* mx, float* agg2, float* cache_h1,
                             float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1,
                             int H2, gcm_stream_t stream);
+int gcm_learned_step_cached_functional(const float* obs, const float* nodes_in, const float* adj_in,
+                                       const int64_t* count_in, const float* noise, int noise_is_exp,
+                                       const float* params, int has_bias, int act1, int act2, float eps0,
+                                       float eps1, float cutoff, float* nodes_out, float* adj_out, int64_t* cur_out,
+                                       int64_t* count_out, float* soft, float* mx, float* agg2, float* cache_h1,
+                                       float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F,
+                                       int H1, int H2, gcm_stream_t stream);
 int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
-                            int n_cached, const float* cache_nodes, const float* cache_h1,
+                            int n_cached, int cached_layout, const float* cache_nodes, const float* cache_h1,
                             const float* cache_agg1, long gmx_stride_b, long gmx_stride_h, const float* params,
                             int act1, int act2, float eps0, float eps1, int compact, const float* g_params_prev,
                             float* g_params, void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,

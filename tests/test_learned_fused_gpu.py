@@ -238,16 +238,17 @@ def test_learned_noise_pool_statistics_and_equivalence():
     torch.testing.assert_close(torch.stack(outs)[:, same], torch.stack(outs2)[:, same], rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("donate", [True, False])
 @pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2),
                                          (6, 128, 32, 32, 20, 5)])
-def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k):
-    """A rollout from hidden = None on a donated state: its first N steps are cached steps (ONE launch each: the
+def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k, donate):
+    """A rollout from hidden = None (donated or functional state): its first N steps are cached steps (ONE launch each: the
     GNN behind the selection on the chain's h1 / agg1 / node caches, gcm_learned_step_cached), the steps behind
     them - the graphs overflow - the usual ones; the backward mixes both kinds.  Against the oracle with the same
     injected gumbel draws, and against the same rollout without cached steps."""
     res = []
     for cached in (True, False):
-        ref, net, g, sel, mem = _pair(F, H, N, k, seed=7, donate=True)
+        ref, net, g, sel, mem = _pair(F, H, N, k, seed=7, donate=donate)
         mem.learned_cached_steps = cached
         gen = torch.Generator().manual_seed(11)
         obs = torch.rand(T, B, F, generator=gen)
