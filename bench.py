@@ -670,13 +670,14 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                     "kernel skips the 32-row blocks >= cur, so its in-situ average is shorter (rocprofv3 average "
                     "over the bench run: profiles/); `traffic` (PMC) is that in-situ average"}
     else:
-        # cfg5: no single dominant kernel (selection, GNN forward, the two time-parallel backward passes): the WHOLE
+        # cfg5: no single dominant kernel (the cached forward step, the two time-parallel backward passes): the WHOLE
         # step against the fp32 MFMA peak on SURVEY 8(d)'s flops - GNN fwd+bwd (3x forward), the adjacency
         # gradient (2N^2 F + 2N^2 H), the edge network on N candidate pairs fwd+bwd (3 x 2(3F^2+F) each)
         per_state = 3 * fwd_full + 2 * N * N * (F + H) + 3 * N * 2 * (3 * F * F + F)
         step_s = dt / args.steps / T
         line["roofline"] = {
-            "bound": "mfma", "kernel": "k_learned_select + k_gnn2_row_fwd + k_bptt_rows<2> (pass A) + k_learned_bptt_b (pass B): whole step",
+            "bound": "mfma", "kernel": "k_learned_select<2,tail> (cached step: selection + the GNN on row cur) + k_bptt_rows<2> (pass A) + "
+                              "k_learned_bptt_b (pass B): whole step",
             "achieved": B * per_state / step_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": B * per_state / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
             "flops_per_step": B * per_state, "avg_step_ms": step_s * 1e3,
