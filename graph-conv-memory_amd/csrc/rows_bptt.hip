@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
     int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn) {
-  constexpr bool HIST = MODE != 0;
+  constexpr bool HIST = MODE == 1 || MODE == 2;   // (3: records of cached steps, rows in the chain's caches)
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
@@ -203,16 +203,29 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       bool is_cur;
       if (!HIST) {
         if (l >= L) break;
-        const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
         cf = sv[lay.o_coef + (size_t)b * N + l];
-        if (deg_term) dg = sv[lay.o_deg + (size_t)b * N + l];
         is_cur = l == l_cur;
-        hv = row[lane < H1 ? lane : H1 - 1];
+        if (MODE == 3) {   // cached step: the row's h1 | agg1 | x from the chain's caches
+          const int j = reinterpret_cast<const int*>(sv + lay.o_live)[(size_t)b * N + l];
+          const size_t rj = (size_t)b * N + j;
+          hv = lrn.c_h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
 #pragma unroll
-        for (int c = 0; c < C1; ++c) {
-          const int m = lane + 64 * c;
-          const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
-          ax[c] = m < 2 * F ? t : 0.f;
+          for (int c = 0; c < C1; ++c) {
+            const int m = lane + 64 * c;
+            const int f = m < F ? m : (m - F < F ? m - F : F - 1);
+            const float t = m < F ? lrn.c_agg1[rj * F + f] : lrn.c_nodes[rj * F + f];
+            ax[c] = m < 2 * F ? t : 0.f;
+          }
+        } else {
+          const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
+          if (deg_term) dg = sv[lay.o_deg + (size_t)b * N + l];
+          hv = row[lane < H1 ? lane : H1 - 1];
+#pragma unroll
+          for (int c = 0; c < C1; ++c) {
+            const int m = lane + 64 * c;
+            const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
+            ax[c] = m < 2 * F ? t : 0.f;
+          }
         }
       } else {
         if (!(m0 | m1)) break;
@@ -350,12 +363,43 @@ extern "C" size_t gcm_dense_rows_bptt_workspace_bytes(int n_steps, int B, int F,
 /* saved_host / gmx_host: HOST arrays of n_steps device pointers (the record each step's forward
  * wrote, and that step's g_mx [B, H2] with element strides gmx_stride_b / gmx_stride_h - an expanded
  * gradient has stride 0).  g_params = g_params_prev (NULL = 0) + the parameter gradient. */
+static int rows_bptt_impl(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                          long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias, int act1, int act2,
+                          const float* cache_nodes, const float* cache_h1, const float* cache_agg1,
+                          const float* g_params_prev, float* g_params, void* workspace, size_t workspace_bytes, int B,
+                          int N, int F, int H1, int H2, gcm_stream_t stream);
+
 extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* const* gmx_host,
                                    int n_steps, long gmx_stride_b, long gmx_stride_h,
                                    const float* params, int has_bias, int act1, int act2,
                                    const float* g_params_prev, float* g_params, void* workspace,
                                    size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                                    gcm_stream_t stream) {
+  return rows_bptt_impl(saved_host, gmx_host, n_steps, gmx_stride_b, gmx_stride_h, params, has_bias, act1, act2,
+                        nullptr, nullptr, nullptr, g_params_prev, g_params, workspace, workspace_bytes, B, N, F, H1,
+                        H2, stream);
+}
+
+/* The same for the records of CACHED steps (rows_cached.hip: gcm_dense_rows_step_cached): the live rows'
+ * h1 | agg1 | x come from the chain's caches. */
+extern "C" int gcm_dense_rows_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                                          long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias,
+                                          int act1, int act2, const float* cache_nodes, const float* cache_h1,
+                                          const float* cache_agg1, const float* g_params_prev, float* g_params,
+                                          void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
+                                          int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(cache_nodes && cache_h1 && cache_agg1);
+  if (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)) return GCM_EUNSUPPORTED;
+  return rows_bptt_impl(saved_host, gmx_host, n_steps, gmx_stride_b, gmx_stride_h, params, has_bias, act1, act2,
+                        cache_nodes, cache_h1, cache_agg1, g_params_prev, g_params, workspace, workspace_bytes, B, N,
+                        F, H1, H2, stream);
+}
+
+static int rows_bptt_impl(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                          long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias, int act1, int act2,
+                          const float* cache_nodes, const float* cache_h1, const float* cache_agg1,
+                          const float* g_params_prev, float* g_params, void* workspace, size_t workspace_bytes, int B,
+                          int N, int F, int H1, int H2, gcm_stream_t stream) {
   GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace);
   GCM_REQUIRE(n_steps > 0 && B > 0);
   if (!gcm_dense_rows_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
@@ -365,7 +409,14 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
-  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
+  gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
+  gcm_rows::LrnSrc caches{};
+  if (cache_h1) {   // cached records: v / hdr / coef at the same offsets, the live list behind coef, no rows section
+    lay.o_live = gcm_rows::make_cached_layout(B, N, H1, H2).o_live;
+    caches.c_nodes = cache_nodes;
+    caches.c_h1 = cache_h1;
+    caches.c_agg1 = cache_agg1;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64, h2p = H2 <= 32 ? 32 : 64;
   const int chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS;
@@ -385,9 +436,12 @@ extern "C" int gcm_dense_rows_bptt(const float* const* saved_host, const float* 
     int rc = GCM_EUNSUPPORTED;
 #define GCM_RB(a, b_, cc)                                                                          \
   if (fp == a && hp == b_ && h2p == cc)                                                            \
-    rc = gcm_rows::launch_bptt<a, b_, cc, 0>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,  \
-                                                 gmx_stride_h, w_rel2, w_root2, act1, act2, lay, sl, B, \
-                                                 N, F, H1, H2, deg_term);
+    rc = cache_h1 ? gcm_rows::launch_bptt<a, b_, cc, 3>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,   \
+                                                        gmx_stride_h, w_rel2, w_root2, act1, act2, lay, sl, B, \
+                                                        N, F, H1, H2, 0, caches)                               \
+                  : gcm_rows::launch_bptt<a, b_, cc, 0>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,   \
+                                                        gmx_stride_h, w_rel2, w_root2, act1, act2, lay, sl, B, \
+                                                        N, F, H1, H2, deg_term);
     GCM_RB(32, 32, 32) GCM_RB(32, 32, 64) GCM_RB(32, 64, 32) GCM_RB(32, 64, 64)
     GCM_RB(64, 32, 32) GCM_RB(64, 32, 64) GCM_RB(64, 64, 32) GCM_RB(64, 64, 64)
 #undef GCM_RB

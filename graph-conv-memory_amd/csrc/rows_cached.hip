@@ -1,0 +1,299 @@
+// Cached live-row step (round 3): the DenseGCM step (gcm.py:262-321) for a chain of hidden states that started
+// from EMPTY graphs, has not overflowed (fewer than N steps) and whose selectors only ever write row cur of the
+// adjacency (TemporalBackedge with direction "forward", temporal.py:72-88; DenseEdge, dense.py:16-21, also writes
+// COLUMN cur, "backward" / "both" hops write into older rows: their layer-1 rows change at every step).
+//
+// In such a chain the rows of layer 1 are FINAL once written: row j's adjacency entries are written at step j
+// and never again, and they point at older nodes, whose features do not change.  k_step_rows re-evaluates the
+// live rows (cur - hop) at every step, which costs it two dependent round trips (row cur of the adjacency, then
+// the live rows' adjacency rows) before their inputs can even be fetched.  Here the chain keeps
+//     cH [B,N,H1] = h1 of every node,  cA [B,N,F] = agg1,  cX [B,N,F] = the node itself
+// and a step computes row cur alone: its selected set S follows from `cur` and the selectors' parameters, so
+// every input (the |S| node rows, the |S| cached h1 rows, the observation) is fetched in ONE round trip behind
+// the count; then agg1[cur], h1[cur], agg2 = sum_S h1[j], the belief - four small matrix-vector products.
+// One wave per graph, four graphs per workgroup (the weights staged once per workgroup in LDS, rows at an
+// odd stride: lane o reads row o conflict-free).  The state is advanced in place (donated): the observation
+// into row cur of the node matrix, the selected entries into row cur of the adjacency, count + 1.
+//
+// The record of such a step (gcm_dense_rows_cached_layout) holds what the time-parallel backward cannot find in
+// the caches: mx | v = agg2, h1[cur] | hdr (L, l_cur, cur, 0) | coef [B,N] | live [B,N] (the rows of S and row cur,
+// ascending; coef = adj[cur, j], 0 for row cur without a self loop).  k_bptt_rows<.., 3> gathers the rows'
+// (h1 | agg1 | x) from the caches.
+#include "fused_common.h"
+#include "gcm_common.h"
+#include "rows_common.h"
+
+#ifdef GCM_STAMPS
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
+namespace gcm_rows {
+
+// FP = F, HP = H1 (32 or 64: compile-time, so that the piece arithmetic is shifts and the matrix-vector loops are
+// branch-free - a bounds check per element kept each LDS read behind its own branch, one round trip per element:
+// 5 us of the first version).  H2 <= 64.
+template <int FP, int HP>
+__global__ __launch_bounds__(256) void k_step_rows_cached(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    gcm_fused::Edits E, const float* __restrict__ params, int act1, int act2, float* __restrict__ cH,
+    float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved, CachedLayout lay,
+    uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
+  constexpr int F = FP, H1 = HP, FS = FP + 1, HS = HP + 1;
+  extern __shared__ float sW[];
+  float* sR1 = sW;                 // W_rel1  [H1][FS]   (row o at an odd stride: lane o reads row o conflict-free)
+  float* sT1 = sR1 + H1 * FS;      // W_root1 [H1][FS]
+  float* sR2 = sT1 + H1 * FS;      // W_rel2  [64][HS]   (rows >= H2 never written: lanes >= H2 are masked)
+  float* sT2 = sR2 + 64 * HS;      // W_root2 [64][HS]
+  float* sVec = sT2 + 64 * HS;     // per wave: agg1 | x [2 FP], then agg2 | h1cur [2 HP]  (128-float slots)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x * 4 + wave;
+  const float* w_rel1 = params;
+  const float* w_root1 = w_rel1 + H1 * F;
+  const float* b1 = w_root1 + H1 * F;
+  const float* w_rel2 = b1 + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  const float* b2 = w_root2 + (size_t)H2 * H1;
+  STAMP(0);
+  // cur_host >= 0: the host knows the row (a chain from empty graphs: every graph holds as many nodes as the chain
+  // has made steps) - no load of the count in front of everything else
+  const bool on = b < B;
+  const size_t gb = (size_t)(on ? b : 0);
+  const int64_t n64 = cur_host >= 0 ? (int64_t)cur_host : count[gb];
+  // the weights in 16-byte pieces, every load in flight before the first LDS store: piece p = tid + 256 q of a
+  // [R x C] matrix is (row p / (C / 4), columns 4 (p % (C / 4)) ..)
+  constexpr int Q1 = H1 * F / 4 / 256, Q2 = 64 * H1 / 4 / 256;
+  float4 w1r[Q1], w1t[Q1], w2r[Q2], w2t[Q2];
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) {
+    const int pce = tid + 256 * q;
+    w1r[q] = *reinterpret_cast<const float4*>(w_rel1 + 4 * pce);
+    w1t[q] = *reinterpret_cast<const float4*>(w_root1 + 4 * pce);
+  }
+#pragma unroll
+  for (int q = 0; q < Q2; ++q) {
+    const int pce = tid + 256 * q, o = pce / (H1 / 4);
+    const int pc = o < H2 ? pce : 0;
+    w2r[q] = *reinterpret_cast<const float4*>(w_rel2 + 4 * pc);
+    w2t[q] = *reinterpret_cast<const float4*>(w_root2 + 4 * pc);
+  }
+  const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
+  const float bias1 = b1[hl], bias2 = b2[ol];
+  const float xc = obs[gb * F + fl];
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  asm volatile("" ::: "memory");
+  // ---- row cur and its selected set S (wave-uniform) -----------------------------------------------------
+  const bool bad = n64 < 0 || n64 >= N;   // (>= N: the graph would roll - the host never sends such a chain here)
+  const int cur = __builtin_amdgcn_readfirstlane(bad ? 0 : (int)n64);
+  unsigned long long m0 = 0, m1 = 0;      // S without row cur
+  bool self = false;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {           // (constant indices: the hop table arrives in one scalar load)
+    const int h = E.hops[i], j = cur - h;
+    const bool use = i < E.n_hops && h >= 0 && j >= 0;   // temporal.py:74: graphs with num_nodes >= hop
+    self = self || (use && h == 0);
+    const bool edge = use && h > 0;
+    m0 |= (edge && j < 64) ? 1ull << (j & 63) : 0ull;
+    m1 |= (edge && j >= 64) ? 1ull << ((j - 64) & 63) : 0ull;
+  }
+  STAMP(1);
+  // ---- one round trip: the rows of S from the node matrix and from the h1 cache (the first four issued
+  // together, more in further batches) ------------------------------------------------------------------------
+  float xa[4], ha[4];
+  unsigned long long a0 = m0, a1 = m1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool any = (a0 | a1) != 0;
+    const int j = !any ? 0 : (a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1));
+    const bool low = a0 != 0;
+    a0 &= low ? a0 - 1 : a0;
+    a1 &= (low || !any) ? a1 : a1 - 1;
+    const float tx = nodes[(gb * N + j) * F + fl], th = cH[(gb * N + j) * H1 + hl];
+    xa[q] = any ? tx : 0.f;
+    ha[q] = any ? th : 0.f;
+  }
+  asm volatile("" ::: "memory");
+  STAMP(2);
+  // the weights into LDS (their loads are older than the input loads: no wait for those)
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) {
+    const int pce = tid + 256 * q, o = pce / (F / 4), c = 4 * (pce % (F / 4));
+    float* d0 = sR1 + o * FS + c;
+    float* d1 = sT1 + o * FS + c;
+    d0[0] = w1r[q].x; d0[1] = w1r[q].y; d0[2] = w1r[q].z; d0[3] = w1r[q].w;
+    d1[0] = w1t[q].x; d1[1] = w1t[q].y; d1[2] = w1t[q].z; d1[3] = w1t[q].w;
+  }
+#pragma unroll
+  for (int q = 0; q < Q2; ++q) {
+    const int pce = tid + 256 * q, o = pce / (H1 / 4), c = 4 * (pce % (H1 / 4));
+    float* d0 = sR2 + o * HS + c;
+    float* d1 = sT2 + o * HS + c;
+    d0[0] = w2r[q].x; d0[1] = w2r[q].y; d0[2] = w2r[q].z; d0[3] = w2r[q].w;
+    d1[0] = w2t[q].x; d1[1] = w2t[q].y; d1[2] = w2t[q].z; d1[3] = w2t[q].w;
+  }
+  float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
+  while (a0 | a1) {   // more than four selected rows
+    const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
+    if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
+    agg1 += nodes[(gb * N + j) * F + fl];
+    agg2 += cH[(gb * N + j) * H1 + hl];
+  }
+  agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
+  float* sv = sVec + wave * 128;
+  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
+  __syncthreads();   // the weights (and this wave's vector) are in LDS
+  STAMP(3);
+  if (!on) return;
+  // ---- h1[cur][h] = act1(b1[h] + W_rel1[h,:] agg1 + W_root1[h,:] x), lane h: the row from LDS (one read per
+  // element, all in flight), the vector as 16-byte broadcast reads - no cross-lane traffic --------------------------
+  float p1 = bias1;
+  {
+    const float* wr = sR1 + hl * FS;
+    const float* wt = sT1 + hl * FS;
+    float rw[F], tw[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { rw[f] = wr[f]; tw[f] = wt[f]; }
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < F / 4; ++f4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
+      pa = fmaf(rw[4 * f4], a.x, pa); pb = fmaf(tw[4 * f4], x.x, pb);
+      pa = fmaf(rw[4 * f4 + 1], a.y, pa); pb = fmaf(tw[4 * f4 + 1], x.y, pb);
+      pa = fmaf(rw[4 * f4 + 2], a.z, pa); pb = fmaf(tw[4 * f4 + 2], x.z, pb);
+      pa = fmaf(rw[4 * f4 + 3], a.w, pa); pb = fmaf(tw[4 * f4 + 3], x.w, pb);
+    }
+    p1 += pa + pb;
+  }
+  STAMP(4);
+  const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
+  agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
+  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }   // (same wave wrote and read the slot: program order)
+  // ---- mx[o] = act2(b2[o] + W_rel2[o,:] agg2 + W_root2[o,:] h1[cur]), lane o ---------------------------------------
+  float p2 = bias2;
+  {
+    const float* wr = sR2 + ol * HS;
+    const float* wt = sT2 + ol * HS;
+    float rw[H1], tw[H1];
+#pragma unroll
+    for (int h = 0; h < H1; ++h) { rw[h] = wr[h]; tw[h] = wt[h]; }
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int h4 = 0; h4 < H1 / 4; ++h4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
+      pa = fmaf(rw[4 * h4], a.x, pa); pb = fmaf(tw[4 * h4], x.x, pb);
+      pa = fmaf(rw[4 * h4 + 1], a.y, pa); pb = fmaf(tw[4 * h4 + 1], x.y, pb);
+      pa = fmaf(rw[4 * h4 + 2], a.z, pa); pb = fmaf(tw[4 * h4 + 2], x.z, pb);
+      pa = fmaf(rw[4 * h4 + 3], a.w, pa); pb = fmaf(tw[4 * h4 + 3], x.w, pb);
+    }
+    p2 += pa + pb;
+  }
+  const float v = gcm_act_sel(p2, act2_v);
+  STAMP(5);
+  // ---- the state, the caches, the record ---------------------------------------------------------------------------
+  const size_t rc = gb * N + cur;
+  if (!bad) {
+    if (lane < F) {
+      nodes[rc * F + lane] = xc;
+      cX[rc * F + lane] = xc;
+      cA[rc * F + lane] = agg1;
+    }
+    if (lane < H1) cH[rc * H1 + lane] = h1c;
+    // row cur of the adjacency: the entries of S (and the self loop) become 1, what else is there stays
+    float* arow = adj + rc * N;
+    const unsigned long long s0 = m0 | ((self && cur < 64) ? 1ull << cur : 0ull);
+    const unsigned long long s1 = m1 | ((self && cur >= 64) ? 1ull << (cur - 64) : 0ull);
+    if (lane < N && ((s0 >> lane) & 1ull)) arow[lane] = 1.f;
+    if (lane + 64 < N && ((s1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
+    if (lane == 0) count[b] = cur + 1;
+  }
+  if (lane < H2) saved[gb * H2 + lane] = v;                         // mx: the head of the record
+  if (lay.total) {
+    if (lane < H1) {
+      saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
+      saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
+    }
+    // live list: the rows of S and row cur, ascending; coef = adj[cur, j] (0 for row cur without a self loop)
+    const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
+    int* live = reinterpret_cast<int*>(saved + lay.o_live) + gb * N;
+    float* coef = saved + lay.o_coef + gb * N;
+    const int j0 = lane, j1 = lane + 64;
+    const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
+    const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
+    const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
+    if (in0) { live[pos0] = j0; coef[pos0] = (j0 == cur && !self) ? 0.f : 1.f; }
+    if (in1) { live[pos1] = j1; coef[pos1] = (j1 == cur && !self) ? 0.f : 1.f; }
+    if (lane == 0) {
+      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
+      const int L = __popcll(l0) + __popcll(l1);
+      const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull)) : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
+      hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
+    }
+  }
+  STAMP(6);
+  const bool nonfinite = __any(lane < H2 && !isfinite(v));
+  if ((nonfinite || bad) && lane == 0)
+    atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
+}
+
+}  // namespace gcm_rows
+
+extern "C" int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
+                                               int N, int F, int H1, int H2) {
+  if (!gcm_dense_rows_supported(N, F, H1, H2) || F > 64 || H1 > 64 || H2 > 64 || N > 128) return 0;
+  if ((F != 32 && F != 64) || (H1 != 32 && H1 != 64)) return 0;   // (the kernel is specialised on them)
+  if (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE | GCM_GNN_RECORD_DX)) return 0;
+  int hops = 0;
+  for (int i = 0; i < n_selectors; ++i) {
+    const gcm_selector_desc& d = selectors[i];
+    // only row cur may be written: DenseEdge (dense.py:16-21) also writes column cur, "backward" / "both" hops
+    // write into older rows - their layer-1 rows change at every step
+    if (d.kind != GCM_SEL_TEMPORAL || d.direction != GCM_DIR_FORWARD) return 0;
+    hops += d.n_hops;
+  }
+  return hops <= 16;
+}
+
+extern "C" int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2, size_t* out5) {
+  GCM_REQUIRE(out5 && B > 0 && N > 0);
+  const gcm_rows::CachedLayout l = gcm_rows::make_cached_layout(B, N, H1, H2);
+  out5[0] = l.total; out5[1] = l.o_v; out5[2] = l.o_hdr; out5[3] = l.o_coef; out5[4] = l.o_live;
+  (void)F;
+  return GCM_OK;
+}
+
+extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
+                                          const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                          int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
+                                          float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags,
+                                          int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && adj && count && params && cache_h1 && cache_agg1 && cache_nodes && saved && flags);
+  GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0));
+  if (!gcm_dense_rows_cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  gcm_fused::Edits E{};
+  for (int i = 0; i < n_selectors; ++i) {
+    const gcm_selector_desc& d = selectors[i];
+    for (int k = 0; k < d.n_hops; ++k) {
+      E.hops[E.n_hops] = d.hops[k];
+      E.dir[E.n_hops++] = d.direction;
+    }
+  }
+  gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, N, H1, H2);
+  if (!record) lay.total = 0;
+  const size_t lds = sizeof(float) * (2 * (size_t)H1 * (F + 1) + 2 * (size_t)64 * (H1 + 1) + 4 * 128);
+#define GCM_RC(a, b_)                                                                                           \
+  if (F == a && H1 == b_) {                                                                                     \
+    auto kern = gcm_rows::k_step_rows_cached<a, b_>;                                                            \
+    gcm_allow_dynamic_lds((const void*)kern, lds);                                                              \
+    hipLaunchKernelGGL(kern, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, obs, nodes, adj, count, E, \
+                       params, act1, act2, cache_h1, cache_agg1, cache_nodes, saved, lay, flags, B, N, H2,      \
+                       cur_host);                                                                              \
+    return gcm_launch_status();                                                                                 \
+  }
+  GCM_RC(32, 32) GCM_RC(64, 32) GCM_RC(32, 64) GCM_RC(64, 64)
+#undef GCM_RC
+  return GCM_EUNSUPPORTED;
+}

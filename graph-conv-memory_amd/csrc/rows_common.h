@@ -73,4 +73,19 @@ static inline SavedLayout make_layout(int B, int N, int F, int H1, int H2, bool 
   return l;
 }
 
+// record of a cached step (rows_cached.hip): mx | v | hdr | coef | live - the first four at the offsets of
+// SavedLayout (k_bptt_rows reads them alike), no rows section: the rows are in the chain's caches
+struct CachedLayout {
+  size_t total, o_v, o_hdr, o_coef, o_live;
+};
+static inline CachedLayout make_cached_layout(int B, int N, int H1, int H2) {
+  CachedLayout l;
+  l.o_v = pad64((size_t)B * H2);
+  l.o_hdr = l.o_v + pad64((size_t)B * 2 * H1);
+  l.o_coef = l.o_hdr + pad64((size_t)B * 4);
+  l.o_live = l.o_coef + pad64((size_t)B * N);
+  l.total = l.o_live + pad64((size_t)B * N);
+  return l;
+}
+
 }  // namespace gcm_rows

@@ -248,7 +248,9 @@ struct RowsChainNode : public torch::autograd::Node {
     int out_mx = -1;            // which of this node's outputs the belief tensor is
     int out_nodes = -1;         // dx: ... and the returned node matrix
     int edge_x = -1;            // dx: the next edge that leads to this step's observation (-1: no gradient)
+    bool cached = false;        // a cached step (rows_cached.hip): the live rows are in the chain's caches
   };
+  at::Tensor cH, cA, cX;        // the caches of the chain's cached steps
   std::vector<Rec> recs;   // the recorded steps, in chain order
   at::Tensor packed;       // the packed parameter vector, detached (the kernel re-reads the weights)
   int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
@@ -348,6 +350,7 @@ struct RowsChainNode : public torch::autograd::Node {
     // produces, is read with stride 0 - no .contiguous() copies), in first-seen order
     struct Group {
       int64_t B, sb, sh;
+      bool cached;
       std::vector<const float*> sv, gm;
     };
     std::vector<Group> groups;
@@ -368,9 +371,9 @@ struct RowsChainNode : public torch::autograd::Node {
       const int64_t B = g.size(0), sb = g.stride(0), sh = g.stride(1);
       Group* grp = nullptr;
       for (auto& c : groups)
-        if (c.B == B && c.sb == sb && c.sh == sh) grp = &c;
+        if (c.B == B && c.sb == sb && c.sh == sh && c.cached == r.cached) grp = &c;
       if (!grp) {
-        groups.push_back({B, sb, sh, {}, {}});
+        groups.push_back({B, sb, sh, r.cached, {}, {}});
         grp = &groups.back();
       }
       grp->sv.push_back(r.buf.data_ptr<float>());
@@ -388,6 +391,13 @@ struct RowsChainNode : public torch::autograd::Node {
       // the kernel writes the first P floats; constant sections behind them get a zero gradient
       at::Tensor res = packed.numel() > P ? at::zeros({packed.numel()}, packed.options())
                                           : at::empty({P}, packed.options());
+      if (c.cached)
+        check(gcm_dense_rows_bptt_cached(c.sv.data(), c.gm.data(), n, (long)c.sb, (long)c.sh, packed.data_ptr<float>(),
+                                         has_bias, act1, act2, cX.data_ptr<float>(), cH.data_ptr<float>(),
+                                         cA.data_ptr<float>(), prev.defined() ? prev.data_ptr<float>() : nullptr,
+                                         res.data_ptr<float>(), ws.data_ptr(), ws_bytes, (int)c.B, N, F, H1, H2, stream),
+              "gcm_dense_rows_bptt_cached");
+      else
       check(gcm_dense_rows_bptt(c.sv.data(), c.gm.data(), n, (long)c.sb, (long)c.sh,
                                 packed.data_ptr<float>(), has_bias, act1, act2,
                                 prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
@@ -546,6 +556,11 @@ struct RowsFast {
   bool dx_mode = false;   // the armed chain differentiates w.r.t. observations / nodes:
   int dx_kind = 0;        //   1 in its one chain node, time-parallel (RowsChainNode::dx); 2 one node per step (DxStepNode)
   bool dx_steps_only = false;   // an observation depended on this module's own outputs once: kind 2 from then on
+  // cached steps (rows_cached.hip): the armed chain started from the empty graphs of hidden = None on a donated
+  // state, its selectors only write row cur, it is linear and has made fewer than N steps
+  bool cache_ok = false;
+  int64_t cached_steps = 0, chain_steps = 0;
+  at::Tensor cH, cA, cX;
   std::shared_ptr<DxChain> dxc;
   std::shared_ptr<DxGateNode> dx_gate;
   std::shared_ptr<DxStepNode> dx_last;
@@ -590,7 +605,8 @@ struct RowsFast {
     return donate_ && (dx_ == 0 || (dx_ == 1 && !(head_nodes.defined() && head_nodes.requires_grad())));
   }
   void arm(const at::Tensor& packed_, const at::Tensor& flags_, int64_t cfg_handle, bool donate_, int dx_ = 0,
-           const at::Tensor& head_nodes = at::Tensor(), const at::Tensor& head_count = at::Tensor()) {
+           const at::Tensor& head_nodes = at::Tensor(), const at::Tensor& head_count = at::Tensor(),
+           bool fresh = false) {
     cfg = reinterpret_cast<StepCfg*>(cfg_handle);
     packed = packed_;
     flags = flags_;
@@ -653,7 +669,56 @@ struct RowsFast {
         node->start_dx();
       }
     }
+    chain_steps = cached_steps = 0;
+    cH = cA = cX = at::Tensor();
+    cache_ok = fresh && donate && dx_kind == 0 &&
+               gcm_dense_rows_cached_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
+                                               cfg->has_bias, cfg->N, cfg->F, cfg->H1, cfg->H2) != 0;
     armed = true;
+  }
+
+  // a cached step (see cache_ok): one small launch, the record without a rows section
+  at::Tensor launch_cached(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                           const at::Tensor& weights, const at::Tensor& count_in) {
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = node != nullptr;
+    if (cached_steps == 0) {
+      cH = at::zeros({B, N, H1}, obs.options());
+      cA = at::zeros({B, N, F}, obs.options());
+      cX = at::zeros({B, N, F}, obs.options());
+      if (node) { node->cH = cH; node->cA = cA; node->cX = cX; }
+    }
+    size_t lay[5];
+    check(gcm_dense_rows_cached_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_cached_layout");
+    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
+    check(gcm_dense_rows_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                     count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                     (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1,
+                                     cfg->act2, cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
+                                     buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
+                                     reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
+          "gcm_dense_rows_step_cached");
+    at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
+    if (need_bwd) {
+      const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
+      RowsChainNode::Rec r{buf, vc, vc.current_version()};
+      r.cached = true;
+      r.out_mx = (int)node->num_inputs();
+      torch::autograd::create_gradient_edge(mx, node);
+      node->recs.push_back(std::move(r));
+    }
+    l_nodes = nodes_in;
+    l_adj = adj_in;
+    l_weights = weights;
+    l_count = count_in;
+    xB = B;
+    xF = obs.size(1);
+    ++n_steps;
+    ++chain_steps;
+    ++cached_steps;
+    return mx;
   }
 
   // one step; inputs validated by the caller.  -> mx; the new state lands in l_*
@@ -661,6 +726,10 @@ struct RowsFast {
                     const at::Tensor& weights, const at::Tensor& count_in) {
     const int64_t B = obs.size(0);
     const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    if (cache_ok && cached_steps == chain_steps && cached_steps < N && (cached_steps == 0 || cH.size(0) == B))
+      return launch_cached(obs, nodes_in, adj_in, weights, count_in);
+    cache_ok = false;
+    ++chain_steps;
     const bool need_bwd = node != nullptr || dxc != nullptr;
     size_t lay[8];
     if (dx_mode) check(gcm_dense_rows_layout_dx((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout_dx");
@@ -737,7 +806,7 @@ struct RowsFast {
   // the checked entry -> (mx, nodes, adj, num_nodes)
   pybind11::tuple run(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
                       const at::Tensor& weights, const at::Tensor& count_in, const at::Tensor& packed_,
-                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_, int need_dx) {
+                      const at::Tensor& flags_, int64_t cfg_handle, bool donate_, int need_dx, bool fresh) {
     StepCfg* c = reinterpret_cast<StepCfg*>(cfg_handle);
     TORCH_CHECK(c != nullptr, "rows_step: no step configuration");
     TORCH_CHECK(obs.is_cuda() && nodes_in.is_cuda() && adj_in.is_cuda() && count_in.is_cuda() &&
@@ -769,8 +838,11 @@ struct RowsFast {
     }
     if (!armed || c != cfg || packed_.unsafeGetTensorImpl() != packed.unsafeGetTensorImpl() ||
         flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || want_donate(donate_, need_dx, nodes_in) != donate ||
-        grad_mode != at::GradMode::is_enabled() || (node && node->executed) || (dxc && dxc->executed) || new_chain)
-      arm(packed_, flags_, cfg_handle, donate_, need_dx, nodes_in, count_in);
+        grad_mode != at::GradMode::is_enabled() || (node && node->executed) || (dxc && dxc->executed) || new_chain ||
+        (fresh && donate_ && need_dx == 0))   // (a rollout from empty graphs: its own chain node - it may own caches)
+      arm(packed_, flags_, cfg_handle, donate_, need_dx, nodes_in, count_in, fresh);
+    else if (cache_ok && !continues(nodes_in, adj_in, weights, count_in))
+      cache_ok = false;
     at::Tensor mx = launch(obs, nodes_in, adj_in, weights, count_in);
     return pybind11::make_tuple(mx, l_nodes, l_adj, l_count, donate);
   }
@@ -1570,6 +1642,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("pending", &RowsFast::pending)
       .def("forget", &RowsFast::forget)
       .def("steps", [](RowsFast& f) { return f.n_steps; })
+      .def("cached_steps", [](RowsFast& f) { return f.cached_steps; })
       .def("has_chain", [](RowsFast& f) { return f.node != nullptr || f.dxc != nullptr; });
   pybind11::class_<LearnedCfg>(m, "LearnedCfg")
       .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())

@@ -136,6 +136,9 @@ class DenseGCM(torch.nn.Module):
         # False: no cached steps (the first N steps of a LearnedEdge rollout from empty graphs on a donated state as
         # ONE launch each, the GNN behind the selection on per-chain caches) - A/B tests
         self.learned_cached_steps = True
+        # False: no cached live-row steps (csrc/rows_cached.hip: the first N steps of a rollout from empty graphs on a
+        # donated state, forward-only TemporalBackedge selectors: row cur alone over per-chain caches) - A/B
+        self.rows_cached_steps = True
         # Steps whose observations / nodes need a gradient run on the live-row kernels too.  True: the whole
         # chain's dL/dx in ONE launch by the chain's single autograd node (hardware float atomics: the order of
         # summation, i.e. the last bits, is not fixed; a policy that feeds belief t-1 into observation t switches
@@ -163,6 +166,14 @@ class DenseGCM(torch.nn.Module):
         for cfg in self._cfg_cache.values():
             if cfg is not False and cfg._rows_fast is not None:
                 n += cfg._rows_fast.steps()
+        return n
+
+    def rows_cached_steps_taken(self):
+        """... of which cached steps (csrc/rows_cached.hip) in the chains armed last."""
+        n = 0
+        for cfg in self._cfg_cache.values():
+            if cfg is not False and cfg._rows_fast is not None:
+                n += cfg._rows_fast.cached_steps()
         return n
 
     def _flag_users(self):
@@ -535,8 +546,11 @@ class DenseGCM(torch.nn.Module):
             nodes, adj, num_nodes = nodes.contiguous(), adj.contiguous(), num_nodes.contiguous()
         # (a donated state with a gradient w.r.t. the observations: only in the one-node form, and the returned
         #  node matrix is then a plain tensor - RowsFast::want_donate decides and reports)
+        fresh = getattr(nodes, "_gcm_fresh", False)
+        if fresh:
+            nodes._gcm_fresh = False          # (a donated state is this very tensor at every later step)
         mx, n2, a2, c2, donate = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(),
-                                          self.donate_state, need_dx)
+                                          self.donate_state, need_dx, bool(fresh and self.rows_cached_steps))
         if donate:
             out = hidden
         else:

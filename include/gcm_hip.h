@@ -576,6 +576,32 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
                                const float* params, int has_bias, int act1, int act2, const int64_t* count0,
                                float* gx, float* gn0, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 
+/* ---- cached live-row steps (round 3) --------------------------------------------------------------------
+ * The DenseGCM step (gcm.py:262-321) for a chain of hidden states that started from EMPTY graphs, has made
+ * fewer than N steps (nothing can have overflowed) and whose selectors only write row cur of the adjacency
+ * (TemporalBackedge direction "forward", temporal.py:72-88; not DenseEdge, which also writes column cur).  There the rows of layer 1
+ * are final once written, so the chain keeps h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every
+ * node in caches (zero-filled by the caller at the chain's head) and a step evaluates row cur alone, every input
+ * fetched in one round trip behind the count.  The state (nodes, adj, count) is advanced IN PLACE.
+ * saved: the step's record, gcm_dense_rows_cached_layout floats {total, v, hdr, coef, live} (mx [B,H2] at 0 - always
+ * written; the rest only with record != 0).  cur_host >= 0: the row every graph's new node lands in, when the host
+ * knows it (a chain from empty graphs: the number of steps made so far) - the kernel then does not wait for the
+ * count; -1: read it.  gcm_dense_rows_bptt_cached: gcm_dense_rows_bptt over such records. */
+int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
+                                    int F, int H1, int H2);
+int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2, size_t* out5);
+int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
+                               const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                               int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
+                               float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags, int B,
+                               int N, int F, int H1, int H2, gcm_stream_t stream);
+int gcm_dense_rows_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
+                               long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias, int act1,
+                               int act2, const float* cache_nodes, const float* cache_h1,
+                               const float* cache_agg1, const float* g_params_prev, float* g_params,
+                               void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                               gcm_stream_t stream);
+
 /* Parameter gradient of a rollout from the history gcm_dense_rollout_fwd /
  * gcm_dense_rollout_persistent_fwd kept, when neither the observations nor the initial node matrix
  * need a gradient: all T*B graph-steps in ONE launch over the live rows (no reverse scan, no Q array).

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 from _golden import fp64_bound as _fp64_bound, fp64_grad_bound as _fp64_grad_bound  # noqa: E402
+from _golden import fp64_rollout_bounds as _fp64_rollout_bounds  # noqa: E402
 
 
 def _rows_taken(mem):
@@ -662,3 +663,47 @@ def test_rows_obs_gradient_with_donated_state():
     torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-5 * float(xo.grad.abs().max()))
     for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
         torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+
+@pytest.mark.parametrize("sel,B,N,F,H,T", [(("temporal", [1, 2, 4], "forward"), 5, 16, 32, 32, 40),
+                                           (("temporal", [2, 5], "forward"), 4, 12, 32, 64, 20),
+                                           (("temporal", [0, 1, 3], "forward"), 3, 128, 32, 32, 131),
+                                           (("temporal", [1], "forward"), 6, 32, 64, 32, 30),
+                                           (("temporal", [1, 2, 3, 4, 5, 6], "forward"), 2, 20, 64, 64, 26),
+                                           (("temporal", [1, 2], "forward"), 3, 16, 8, 16, 20)])   # (sizes the kernel does not take)
+def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
+    """A donated rollout from hidden = None whose selectors only write row cur: its first N steps are cached steps
+    (rows_cached.hip: row cur alone over the chain's h1 / agg1 / node caches), the steps behind them - the graphs
+    overflow - the usual live-row ones, one backward over both kinds.  Against the oracle (state bit exact) and
+    against the same rollout with the cached steps switched off."""
+    res = []
+    obs = None
+    for cached in (True, False):
+        torch.manual_seed(N + T)
+        ref, g, mem, osel = _mk(B, N, F, H, H, sel, True)
+        mem.rows_cached_steps = cached
+        obs = torch.rand(T, B, F)
+        w = torch.rand(T, B, H)
+        hid, outs = None, []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+        takes = F in (32, 64) and H in (32, 64)      # (the cached kernel is specialised on these)
+        assert mem.rows_steps() == T and mem.rows_cached_steps_taken() == (min(T, N) if cached and takes else 0)
+        if cached:   # selectors that write older rows keep the usual step
+            _, _, mem_b, _ = _mk(B, N, F, H, H, ("temporal", [1], "both"), True)
+            mem_b(obs[0].to(DEV), None)
+            assert mem_b.rows_cached_steps_taken() == 0
+        out = torch.stack(outs)
+        (out * w.to(DEV)).sum().backward()
+        mem.check_flags()
+        res.append((out.detach().cpu(), [t.cpu() for t in (hid[0], hid[1], hid[3])],
+                    {k: p.grad.cpu().clone() for k, p in g.named_parameters()}, ref, osel, w))
+    ref, osel, w = res[0][3], res[0][4], res[0][5]
+    out32, hid32, bounds, (out64, out_atol) = _fp64_rollout_bounds(ref, obs, None, w, lambda: osel, N)
+    for out, state, grads, *_ in res:
+        assert torch.equal(state[0], hid32[0]) and torch.equal(state[1], hid32[1]) and torch.equal(state[2], hid32[3])
+        assert float((out.double() - out64).abs().max()) <= out_atol
+        for k, gd in grads.items():
+            g64, atol = bounds[k]
+            assert float((gd.double() - g64).abs().max()) <= atol, k
