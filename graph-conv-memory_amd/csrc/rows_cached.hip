@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   // cur_host >= 0: the host knows the row (a chain from empty graphs: every graph holds as many nodes as the chain
   // has made steps) - no load of the count in front of everything else
   const bool on = b < B;
-  const size_t gb = (size_t)(on ? b : 0);
+  const unsigned gb = (unsigned)(on ? b : 0);   // (32-bit offsets throughout: B N max(F, N) < 2^31 is checked by the host)
   const int64_t n64 = cur_host >= 0 ? (int64_t)cur_host : count[gb];
   // the weights in 16-byte pieces, every load in flight before the first LDS store: piece p = tid + 256 q of a
   // [R x C] matrix is (row p / (C / 4), columns 4 (p % (C / 4)) ..)
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
     w2r[q] = *reinterpret_cast<const float4*>(w_rel2 + 4 * pc);
     w2t[q] = *reinterpret_cast<const float4*>(w_root2 + 4 * pc);
   }
+  STAMP(8);
   const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
   const float bias1 = b1[hl], bias2 = b2[ol];
   const float xc = obs[gb * F + fl];
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
     const bool low = a0 != 0;
     a0 &= low ? a0 - 1 : a0;
     a1 &= (low || !any) ? a1 : a1 - 1;
-    const float tx = nodes[(gb * N + j) * F + fl], th = cH[(gb * N + j) * H1 + hl];
+    const unsigned rj = gb * (unsigned)N + (unsigned)j;
+    const float tx = nodes[rj * F + fl], th = cH[rj * H1 + hl];
     xa[q] = any ? tx : 0.f;
     ha[q] = any ? th : 0.f;
   }
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   while (a0 | a1) {   // more than four selected rows
     const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
     if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
-    agg1 += nodes[(gb * N + j) * F + fl];
-    agg2 += cH[(gb * N + j) * H1 + hl];
+    const unsigned rj = gb * (unsigned)N + (unsigned)j;
+    agg1 += nodes[rj * F + fl];
+    agg2 += cH[rj * H1 + hl];
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   float* sv = sVec + wave * 128;
@@ -148,6 +151,13 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   if (!on) return;
   // ---- h1[cur][h] = act1(b1[h] + W_rel1[h,:] agg1 + W_root1[h,:] x), lane h: the row from LDS (one read per
   // element, all in flight), the vector as 16-byte broadcast reads - no cross-lane traffic --------------------------
+  float rw2[H1], tw2[H1];   // layer 2's rows too: in flight under layer 1's arithmetic
+  {
+    const float* wr = sR2 + ol * HS;
+    const float* wt = sT2 + ol * HS;
+#pragma unroll
+    for (int h = 0; h < H1; ++h) { rw2[h] = wr[h]; tw2[h] = wt[h]; }
+  }
   float p1 = bias1;
   {
     const float* wr = sR1 + hl * FS;
@@ -174,11 +184,8 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   // ---- mx[o] = act2(b2[o] + W_rel2[o,:] agg2 + W_root2[o,:] h1[cur]), lane o ---------------------------------------
   float p2 = bias2;
   {
-    const float* wr = sR2 + ol * HS;
-    const float* wt = sT2 + ol * HS;
-    float rw[H1], tw[H1];
-#pragma unroll
-    for (int h = 0; h < H1; ++h) { rw[h] = wr[h]; tw[h] = wt[h]; }
+    const float (&rw)[H1] = rw2;
+    const float (&tw)[H1] = tw2;
     float pa = 0.f, pb = 0.f;
 #pragma unroll
     for (int h4 = 0; h4 < H1 / 4; ++h4) {
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   const float v = gcm_act_sel(p2, act2_v);
   STAMP(5);
   // ---- the state, the caches, the record ---------------------------------------------------------------------------
-  const size_t rc = gb * N + cur;
+  const unsigned rc = gb * (unsigned)N + (unsigned)cur;
   if (!bad) {
     if (lane < F) {
       nodes[rc * F + lane] = xc;
@@ -210,12 +217,14 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
     if (lane + 64 < N && ((s1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
     if (lane == 0) count[b] = cur + 1;
   }
+  STAMP(9);
   if (lane < H2) saved[gb * H2 + lane] = v;                         // mx: the head of the record
   if (lay.total) {
     if (lane < H1) {
       saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
       saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
     }
+    STAMP(10);
     // live list: the rows of S and row cur, ascending; coef = adj[cur, j] (0 for row cur without a self loop)
     const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
     int* live = reinterpret_cast<int*>(saved + lay.o_live) + gb * N;
@@ -273,6 +282,7 @@ extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float*
   GCM_REQUIRE(obs && nodes && adj && count && params && cache_h1 && cache_agg1 && cache_nodes && saved && flags);
   GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0));
   if (!gcm_dense_rows_cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  if ((size_t)B * N * (size_t)(F > N ? F : N) >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;   // 32-bit offsets inside
   gcm_fused::Edits E{};
   for (int i = 0; i < n_selectors; ++i) {
     const gcm_selector_desc& d = selectors[i];

@@ -60,6 +60,8 @@ for host_cur in (-1, CUR):
     for i in range(6):
         print(f"  {i} -> {i + 1}  {names[i]:46s} {acc[i]:9.1f}")
     print(f"  total {sum(acc):9.1f}")
+    print(f"  inside 0 -> 1: weight loads issued after {out[8] - out[0]} cycles; inside 5 -> 6: state + cache stores "
+          f"{out[9] - out[5]}, mx + v {out[10] - out[9]}, live list + header {out[6] - out[10]}")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for it in range(50):

@@ -4,7 +4,8 @@ T shortened where the kernel's traffic does not depend on it.  Run once per coun
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py
 then tools/pmc_summarise.py writes profiles/<tag>_traffic_detail.json and profiles/traffic.json.
-  cfg2: 2 eager per-step rollouts fwd+bwd donated (k_step_rows<32,..,false>, k_bptt_rows), 2 functional
+  cfg2: 2 eager per-step rollouts fwd+bwd donated with cached steps (k_step_rows_cached, k_bptt_rows<..,3>), 2 without
+        (k_step_rows<32,..,false>, k_bptt_rows), 2 functional
         (k_step_rows<32,..,true>), 2 rollout-API calls, 2 with observation gradients donated (k_rows_dx_all), T=128
   cfg3: 1 rollout donated, T=128 (k_euclid_mfma, k_step_rows<64,...>)
   cfg5: 1 rollout donated, T=64 (k_learned_select, k_gnn2_row_fwd, k_learned_bptt_b, k_bptt_rows mode 2)
@@ -23,8 +24,9 @@ dev = torch.device("cuda", 0)
 if "cfg2" in which:
     c = bench.CONFIGS["cfg2"]
     obs = torch.rand(128, c["B"], c["F"]).to(dev)
-    for donate in (True, False):
+    for donate, cached in ((True, True), (True, False), (False, False)):
         mem, gnn, _ = bench.build_memory(dev, donate=donate)
+        mem.rows_cached_steps = cached      # (True: k_step_rows_cached, what the bench's timed region runs)
         for _ in range(2):
             bench.rollout(mem, obs)
             gnn.zero_grad(set_to_none=True)
