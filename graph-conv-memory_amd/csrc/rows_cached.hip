@@ -248,6 +248,164 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
     atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same step with the weights read from a LANE-MAJOR image (k_cached_weight_image, made once per chain:
+// image[m][k][lane] = W_m[lane][k], m = W_rel1, W_root1 (k < F), W_rel2, W_root2 (k < H1)): lane h's row of
+// every matrix arrives as coalesced loads issued at kernel start together with the inputs - ONE memory round
+// trip for everything, no LDS staging and no barrier.  One wave = one workgroup = one graph (256 workgroups
+// spread the 64 KB of weight loads over all CUs' texture paths).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_cached_weight_image(const float* __restrict__ params, float* __restrict__ image, int F, int H1,
+                                      int H2) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // over [4][64][64]
+  if (e >= 4 * 64 * 64) return;
+  const int m = e >> 12, k = (e >> 6) & 63, lane = e & 63;
+  const float* w_rel1 = params;
+  const float* w_root1 = w_rel1 + (size_t)H1 * F;
+  const float* w_rel2 = w_root1 + (size_t)H1 * F + H1;
+  const float* w_root2 = w_rel2 + (size_t)H2 * H1;
+  float v = 0.f;
+  if (m < 2) { if (lane < H1 && k < F) v = (m == 0 ? w_rel1 : w_root1)[(size_t)lane * F + k]; }
+  else { if (lane < H2 && k < H1) v = (m == 2 ? w_rel2 : w_root2)[(size_t)lane * H1 + k]; }
+  image[e] = v;
+}
+
+template <int FP, int HP>
+__global__ __launch_bounds__(64) void k_step_rows_cached_img(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
+  constexpr int F = FP, H1 = HP;
+  __shared__ __attribute__((aligned(16))) float sv[128];
+  const int lane = threadIdx.x;
+  const unsigned gb = blockIdx.x;
+  const float* b1 = params + 2 * H1 * F;
+  const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
+  const int64_t n64 = cur_host >= 0 ? (int64_t)cur_host : count[gb];
+  // every weight load in flight at once (coalesced: lane h reads element h of row k of the image)
+  float r1[F], t1[F], r2[H1], t2[H1];
+#pragma unroll
+  for (int k = 0; k < F; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
+#pragma unroll
+  for (int k = 0; k < H1; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
+  const float bias1 = b1[hl], bias2 = b2[ol];
+  const float xc = obs[gb * F + fl];
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  asm volatile("" ::: "memory");
+  const bool bad = n64 < 0 || n64 >= N;
+  const int cur = __builtin_amdgcn_readfirstlane(bad ? 0 : (int)n64);
+  unsigned long long m0 = 0, m1 = 0;
+  bool self = false;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int h = E.hops[i], j = cur - h;
+    const bool use = i < E.n_hops && h >= 0 && j >= 0;
+    self = self || (use && h == 0);
+    const bool edge = use && h > 0;
+    m0 |= (edge && j < 64) ? 1ull << (j & 63) : 0ull;
+    m1 |= (edge && j >= 64) ? 1ull << ((j - 64) & 63) : 0ull;
+  }
+  float xa[4], ha[4];
+  unsigned long long a0 = m0, a1 = m1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool any = (a0 | a1) != 0;
+    const int j = !any ? 0 : (a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1));
+    const bool low = a0 != 0;
+    a0 &= low ? a0 - 1 : a0;
+    a1 &= (low || !any) ? a1 : a1 - 1;
+    const unsigned rj = gb * (unsigned)N + (unsigned)j;
+    const float tx = nodes[rj * F + fl], th = cH[rj * H1 + hl];
+    xa[q] = any ? tx : 0.f;
+    ha[q] = any ? th : 0.f;
+  }
+  float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
+  while (a0 | a1) {
+    const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
+    if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
+    const unsigned rj = gb * (unsigned)N + (unsigned)j;
+    agg1 += nodes[rj * F + fl];
+    agg2 += cH[rj * H1 + hl];
+  }
+  agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
+  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
+  // (one wave: its LDS operations execute in order - the broadcast reads below see these writes)
+  float p1 = bias1;
+  {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < F / 4; ++f4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
+      pa = fmaf(r1[4 * f4], a.x, pa); pb = fmaf(t1[4 * f4], x.x, pb);
+      pa = fmaf(r1[4 * f4 + 1], a.y, pa); pb = fmaf(t1[4 * f4 + 1], x.y, pb);
+      pa = fmaf(r1[4 * f4 + 2], a.z, pa); pb = fmaf(t1[4 * f4 + 2], x.z, pb);
+      pa = fmaf(r1[4 * f4 + 3], a.w, pa); pb = fmaf(t1[4 * f4 + 3], x.w, pb);
+    }
+    p1 += pa + pb;
+  }
+  const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
+  agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
+  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }
+  float p2 = bias2;
+  {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int h4 = 0; h4 < H1 / 4; ++h4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
+      pa = fmaf(r2[4 * h4], a.x, pa); pb = fmaf(t2[4 * h4], x.x, pb);
+      pa = fmaf(r2[4 * h4 + 1], a.y, pa); pb = fmaf(t2[4 * h4 + 1], x.y, pb);
+      pa = fmaf(r2[4 * h4 + 2], a.z, pa); pb = fmaf(t2[4 * h4 + 2], x.z, pb);
+      pa = fmaf(r2[4 * h4 + 3], a.w, pa); pb = fmaf(t2[4 * h4 + 3], x.w, pb);
+    }
+    p2 += pa + pb;
+  }
+  const float v = gcm_act_sel(p2, act2_v);
+  const unsigned rc = gb * (unsigned)N + (unsigned)cur;
+  if (!bad) {
+    if (lane < F) {
+      nodes[rc * F + lane] = xc;
+      cX[rc * F + lane] = xc;
+      cA[rc * F + lane] = agg1;
+    }
+    if (lane < H1) cH[rc * H1 + lane] = h1c;
+    float* arow = adj + (size_t)rc * N;
+    const unsigned long long s0 = m0 | ((self && cur < 64) ? 1ull << cur : 0ull);
+    const unsigned long long s1 = m1 | ((self && cur >= 64) ? 1ull << (cur - 64) : 0ull);
+    if (lane < N && ((s0 >> lane) & 1ull)) arow[lane] = 1.f;
+    if (lane + 64 < N && ((s1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
+    if (lane == 0) count[gb] = cur + 1;
+  }
+  if (lane < H2) saved[gb * H2 + lane] = v;
+  if (lay.total) {
+    if (lane < H1) {
+      saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
+      saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
+    }
+    const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
+    int* live = reinterpret_cast<int*>(saved + lay.o_live) + gb * N;
+    float* coef = saved + lay.o_coef + gb * N;
+    const int j0 = lane, j1 = lane + 64;
+    const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
+    const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
+    const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
+    if (in0) { live[pos0] = j0; coef[pos0] = (j0 == cur && !self) ? 0.f : 1.f; }
+    if (in1) { live[pos1] = j1; coef[pos1] = (j1 == cur && !self) ? 0.f : 1.f; }
+    if (lane == 0) {
+      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
+      const int L = __popcll(l0) + __popcll(l1);
+      const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull)) : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
+      hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
+    }
+  }
+  const bool nonfinite = __any(lane < H2 && !isfinite(v));
+  if ((nonfinite || bad) && lane == 0)
+    atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
+}
+
 }  // namespace gcm_rows
 
 extern "C" int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
@@ -274,8 +432,17 @@ extern "C" int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2,
   return GCM_OK;
 }
 
+extern "C" int gcm_dense_rows_cached_weight_image(const float* params, float* image, int F, int H1, int H2,
+                                                  gcm_stream_t stream) {
+  GCM_REQUIRE(params && image && F > 0 && F <= 64 && H1 > 0 && H1 <= 64 && H2 > 0 && H2 <= 64);
+  hipLaunchKernelGGL(gcm_rows::k_cached_weight_image, dim3(4 * 64 * 64 / 256), dim3(256), 0, (hipStream_t)stream, params,
+                     image, F, H1, H2);
+  return gcm_launch_status();
+}
+
 extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
                                           const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                          const float* weight_image,
                                           int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
                                           float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags,
                                           int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
@@ -293,6 +460,18 @@ extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float*
   }
   gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, N, H1, H2);
   if (!record) lay.total = 0;
+  if (weight_image) {
+#define GCM_RI(a, b_)                                                                                            \
+  if (F == a && H1 == b_) {                                                                                      \
+    hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream, obs,  \
+                       nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes,    \
+                       saved, lay, flags, B, N, H2, cur_host);                                                       \
+    return gcm_launch_status();                                                                                  \
+  }
+    GCM_RI(32, 32) GCM_RI(64, 32) GCM_RI(32, 64) GCM_RI(64, 64)
+#undef GCM_RI
+    return GCM_EUNSUPPORTED;
+  }
   const size_t lds = sizeof(float) * (2 * (size_t)H1 * (F + 1) + 2 * (size_t)64 * (H1 + 1) + 4 * 128);
 #define GCM_RC(a, b_)                                                                                           \
   if (F == a && H1 == b_) {                                                                                     \

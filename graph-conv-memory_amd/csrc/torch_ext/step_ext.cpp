@@ -560,7 +560,7 @@ struct RowsFast {
   // state, its selectors only write row cur, it is linear and has made fewer than N steps
   bool cache_ok = false;
   int64_t cached_steps = 0, chain_steps = 0;
-  at::Tensor cH, cA, cX;
+  at::Tensor cH, cA, cX, wimg;
   std::shared_ptr<DxChain> dxc;
   std::shared_ptr<DxGateNode> dx_gate;
   std::shared_ptr<DxStepNode> dx_last;
@@ -688,6 +688,11 @@ struct RowsFast {
       cA = at::zeros({B, N, F}, obs.options());
       cX = at::zeros({B, N, F}, obs.options());
       if (node) { node->cH = cH; node->cA = cA; node->cX = cX; }
+      // the weights lane-major, once per chain (the parameters are fixed inside one)
+      wimg = at::empty({4 * 64 * 64}, obs.options());
+      check(gcm_dense_rows_cached_weight_image(packed.data_ptr<float>(), wimg.data_ptr<float>(), F, H1, H2,
+                                               reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream())),
+            "gcm_dense_rows_cached_weight_image");
     }
     size_t lay[5];
     check(gcm_dense_rows_cached_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_cached_layout");
@@ -695,8 +700,8 @@ struct RowsFast {
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
     check(gcm_dense_rows_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
                                      count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
-                                     (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1,
-                                     cfg->act2, cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
+                                     (int)cfg->descs.size(), packed.data_ptr<float>(), wimg.data_ptr<float>(), cfg->has_bias,
+                                     cfg->act1, cfg->act2, cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
                                      buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
                                      reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
           "gcm_dense_rows_step_cached");

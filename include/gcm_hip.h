@@ -586,13 +586,17 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
  * saved: the step's record, gcm_dense_rows_cached_layout floats {total, v, hdr, coef, live} (mx [B,H2] at 0 - always
  * written; the rest only with record != 0).  cur_host >= 0: the row every graph's new node lands in, when the host
  * knows it (a chain from empty graphs: the number of steps made so far) - the kernel then does not wait for the
- * count; -1: read it.  gcm_dense_rows_bptt_cached: gcm_dense_rows_bptt over such records. */
+ * count; -1: read it.  weight_image (may be NULL): [4][64][64] floats from gcm_dense_rows_cached_weight_image, the
+ * four weight matrices lane-major (made once per chain: the parameters are fixed inside one) - with it a step is one
+ * wave per graph whose every load, weights included, is issued at kernel start (no LDS staging, no barrier).  gcm_dense_rows_bptt_cached: gcm_dense_rows_bptt over such records. */
 int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
                                     int F, int H1, int H2);
 int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2, size_t* out5);
+int gcm_dense_rows_cached_weight_image(const float* params, float* image, int F, int H1, int H2,
+                                       gcm_stream_t stream);
 int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
                                const gcm_selector_desc* selectors, int n_selectors, const float* params,
-                               int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
+                               const float* weight_image, int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
                                float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags, int B,
                                int N, int F, int H1, int H2, gcm_stream_t stream);
 int gcm_dense_rows_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,

@@ -47,7 +47,7 @@ for host_cur in (-1, CUR):
     for it in range(R + 3):
         count.fill_(CUR)
         torch.cuda.synchronize()
-        rc = lib.gcm_dense_rows_step_cached(p(obs), p(nodes), p(adj), p(count), ctypes.byref(sel), 1, p(params), 3, 1, 1,
+        rc = lib.gcm_dense_rows_step_cached(p(obs), p(nodes), p(adj), p(count), ctypes.byref(sel), 1, p(params), None, 3, 1, 1,
                                             p(cH), p(cA), p(cX), p(saved), 1, host_cur, p(flags), B, N, F, H, H, st)
         assert rc == 0, rc
         torch.cuda.synchronize()
@@ -66,7 +66,7 @@ for host_cur in (-1, CUR):
     e0.record()
     for it in range(50):
         count.fill_(CUR)
-        lib.gcm_dense_rows_step_cached(p(obs), p(nodes), p(adj), p(count), ctypes.byref(sel), 1, p(params), 3, 1, 1,
+        lib.gcm_dense_rows_step_cached(p(obs), p(nodes), p(adj), p(count), ctypes.byref(sel), 1, p(params), None, 3, 1, 1,
                                        p(cH), p(cA), p(cX), p(saved), 1, host_cur, p(flags), B, N, F, H, H, st)
     e1.record()
     torch.cuda.synchronize()
