@@ -19,6 +19,8 @@
 // the caches: mx | v = agg2, h1[cur] | hdr (L, l_cur, cur, 0) | coef [B,N] | live [B,N] (the rows of S and row cur,
 // ascending; coef = adj[cur, j], 0 for row cur without a self loop).  k_bptt_rows<.., 3> gathers the rows'
 // (h1 | agg1 | x) from the caches.
+#include <hip/hip_ext.h>
+
 #include "fused_common.h"
 #include "gcm_common.h"
 #include "rows_common.h"
@@ -485,4 +487,40 @@ extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float*
   GCM_RC(32, 32) GCM_RC(64, 32) GCM_RC(32, 64) GCM_RC(64, 64)
 #undef GCM_RC
   return GCM_EUNSUPPORTED;
+}
+
+/* Measurement aid (bench.py), the cached twin of gcm_debug_time_rows_rollout: T cached steps (T <= N) of a rollout
+ * from empty graphs enqueued back to back from C, each launch bracketed by the caller's HIP events recorded by the
+ * dispatch itself (hipExtLaunchKernelGGL start / stop events = the kernel begin / end timestamps rocprofv3
+ * --kernel-trace reports).  Temporal selectors with forward hops only; F, H1 in {32, 64}; weight_image as above. */
+extern "C" int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,
+                                             const gcm_selector_desc* selectors, int n_selectors,
+                                             const float* params, const float* weight_image, int has_bias, int act1,
+                                             int act2, float* cache_h1, float* cache_agg1, float* cache_nodes,
+                                             float* const* saved_per_step, uint32_t* flags, void* const* start_events,
+                                             void* const* stop_events, int T, int B, int N, int F, int H1, int H2,
+                                             gcm_stream_t stream) {
+  GCM_REQUIRE(obs_all && nodes && adj && count && params && weight_image && cache_h1 && cache_agg1 && cache_nodes &&
+              saved_per_step && start_events && stop_events && flags && T > 0 && T <= N);
+  if (!gcm_dense_rows_cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  gcm_fused::Edits E{};
+  for (int i = 0; i < n_selectors; ++i)
+    for (int k = 0; k < selectors[i].n_hops; ++k) {
+      E.hops[E.n_hops] = selectors[i].hops[k];
+      E.dir[E.n_hops++] = selectors[i].direction;
+    }
+  const gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, N, H1, H2);
+  for (int t = 0; t < T; ++t) {
+#define GCM_RT(a, b_)                                                                                           \
+  if (F == a && H1 == b_)                                                                                       \
+    hipExtLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,  \
+                          (hipEvent_t)start_events[t], (hipEvent_t)stop_events[t], 0,                            \
+                          obs_all + (size_t)t * B * F, nodes, adj, count, E, params, weight_image, act1, act2,   \
+                          cache_h1, cache_agg1, cache_nodes, saved_per_step[t], lay, flags, B, N, H2, t);
+    GCM_RT(32, 32) GCM_RT(64, 32) GCM_RT(32, 64) GCM_RT(64, 64)
+#undef GCM_RT
+    const int rc = gcm_launch_status();
+    if (rc) return rc;
+  }
+  return GCM_OK;
 }

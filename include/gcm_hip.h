@@ -599,6 +599,14 @@ int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64
                                const float* weight_image, int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
                                float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags, int B,
                                int N, int F, int H1, int H2, gcm_stream_t stream);
+/* measurement aid (bench.py): T <= N cached steps of a rollout from empty graphs enqueued back to back from C, each
+ * launch bracketed by the caller's HIP events recorded by the dispatch itself (cf. gcm_debug_time_rows_rollout) */
+int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,
+                                  const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                  const float* weight_image, int has_bias, int act1, int act2, float* cache_h1,
+                                  float* cache_agg1, float* cache_nodes, float* const* saved_per_step,
+                                  uint32_t* flags, void* const* start_events, void* const* stop_events, int T, int B,
+                                  int N, int F, int H1, int H2, gcm_stream_t stream);
 int gcm_dense_rows_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                                long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias, int act1,
                                int act2, const float* cache_nodes, const float* cache_h1,
