@@ -20,6 +20,7 @@
 // gradient accumulates in registers across the items of a wave, the four waves of a workgroup
 // meet in LDS at the end, one slab per workgroup, summed in fixed order (deterministic).
 #include "gcm_common.h"
+#include "fused_common.h"
 #include "rows_common.h"
 
 namespace gcm_rows {
@@ -545,12 +546,15 @@ struct DxWeights {
   }
 };
 
-template <bool ATOMIC>
+// CACHED: the record of a cached step (rows_cached.hip) - no rows / arows sections: the chain started from empty
+// graphs, so row cur IS the chain index s_lin, the live rows are cur - hop (E: forward hops only), their h1 rows
+// sit in the chain's cache and their adjacency rows follow from the hop table.
+template <bool ATOMIC, bool CACHED = false>
 __device__ __forceinline__ void rows_dx_body(
     const float* __restrict__ sv, const float* __restrict__ gmx, long gmx_sb, long gmx_sh,
     const float* __restrict__ gnodes, const DxWeights& W, int act1, int act2, const SavedLayout& lay,
     const int64_t* __restrict__ count0, float* gx, float* gn0, int s_lin, int b, int lane, float* tile_, int B, int N,
-    int F, int H1, int H2) {
+    int F, int H1, int H2, const gcm_fused::Edits* Ep = nullptr, const float* __restrict__ cH = nullptr) {
   typedef __attribute__((address_space(3))) float lds_float;
   lds_float* const tile = (lds_float*)tile_;   // (the wave's accumulator tile: ds_ instructions, not flat ones)
   const float (&w2a)[32] = W.w2a;
@@ -560,30 +564,76 @@ __device__ __forceinline__ void rows_dx_body(
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
   constexpr int LB = 8;   // live rows fetched ahead
   // ---- loads ---------------------------------------------------------------------------------------
-  const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
-  const int h_l = hdr[0], h_lc = hdr[1], h_cur = hdr[2];
   const int oc = lane < H2 ? lane : H2 - 1, hc = lane < H1 ? lane : H1 - 1;
   const float g = gmx ? gmx[(long)b * gmx_sb + (long)oc * gmx_sh] : 0.f;
   const float y = sv[(size_t)b * H2 + oc];
-  const int64_t c0 = count0[b];
   const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
   const float* coef = sv + lay.o_coef + (size_t)b * N;
   float cf8[LB], hv8[LB], r0[LB], r1[LB];
   int jl8[LB];
+  int L, l_cur, cur, n0;
+  unsigned long long lm0 = 0, lm1 = 0;   // CACHED: the live rows beyond the first LB
+  bool self = false;
+  // adjacency entry (j, k) of a chain whose selectors are the forward hops of E: k = j - hop (hop 0: the self loop)
+  auto hop_edge = [&](int j, int k) __attribute__((always_inline)) {
+    bool e = false;
 #pragma unroll
-  for (int l = 0; l < LB; ++l) {
-    const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
-    const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
-    cf8[l] = coef[l];
-    jl8[l] = live[l];
-    hv8[l] = row[hc];
-    r0[l] = ar[lane < N ? lane : N - 1];
-    r1[l] = ar[lane + 64 < N ? lane + 64 : N - 1];
+    for (int i = 0; i < 16; ++i) e = e || (i < Ep->n_hops && Ep->hops[i] >= 0 && k >= 0 && j - Ep->hops[i] == k);
+    return e;
+  };
+  if (CACHED) {
+    cur = s_lin;
+    n0 = 0;
+    unsigned long long m0 = 0, m1 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int h = Ep->hops[i], j = cur - h;
+      const bool use = i < Ep->n_hops && h >= 0 && j >= 0;
+      self = self || (use && h == 0);
+      const bool edge = use && h > 0;
+      m0 |= (edge && j < 64) ? 1ull << (j & 63) : 0ull;
+      m1 |= (edge && j >= 64) ? 1ull << ((j - 64) & 63) : 0ull;
+    }
+    m0 |= cur < 64 ? 1ull << cur : 0ull;
+    m1 |= cur >= 64 ? 1ull << (cur - 64) : 0ull;
+    L = __popcll(m0) + __popcll(m1);
+    l_cur = L - 1;                          // row cur is the largest index of the list
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const bool any = (m0 | m1) != 0;
+      const int j = !any ? 0 : (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
+      const bool low = m0 != 0;
+      m0 &= low ? m0 - 1 : m0;
+      m1 &= (low || !any) ? m1 : m1 - 1;
+      jl8[l] = j;
+      cf8[l] = (j == cur && !self) ? 0.f : 1.f;
+      hv8[l] = cH[((size_t)b * N + j) * H1 + hc];
+      r0[l] = hop_edge(j, lane) ? 1.f : 0.f;
+      r1[l] = hop_edge(j, lane + 64) ? 1.f : 0.f;
+    }
+    lm0 = m0;
+    lm1 = m1;
+    asm volatile("" ::: "memory");
+  } else {
+    const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+    const int h_l = hdr[0], h_lc = hdr[1], h_cur = hdr[2];
+    const int64_t c0 = count0[b];
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
+      const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
+      cf8[l] = coef[l];
+      jl8[l] = live[l];
+      hv8[l] = row[hc];
+      r0[l] = ar[lane < N ? lane : N - 1];
+      r1[l] = ar[lane + 64 < N ? lane + 64 : N - 1];
+    }
+    asm volatile("" ::: "memory");
+    L = __builtin_amdgcn_readfirstlane(h_l);
+    l_cur = __builtin_amdgcn_readfirstlane(h_lc);
+    cur = __builtin_amdgcn_readfirstlane(h_cur);
+    n0 = __builtin_amdgcn_readfirstlane((int)(c0 < 0 ? 0 : (c0 > N ? N : c0)));
   }
-  asm volatile("" ::: "memory");
-  const int L = __builtin_amdgcn_readfirstlane(h_l), l_cur = __builtin_amdgcn_readfirstlane(h_lc);
-  const int cur = __builtin_amdgcn_readfirstlane(h_cur);
-  const int n0 = __builtin_amdgcn_readfirstlane((int)(c0 < 0 ? 0 : (c0 > N ? N : c0)));
   // ---- layer-2 adjoint: d2 in lane o, dagg2 / dh1cur in lane h ---------------------------------------
   const float d2 = lane < H2 ? g * act_grad_sel(y, act2_v) : 0.f;
   float dagg2 = 0.f, dh1c = 0.f;
@@ -630,11 +680,21 @@ __device__ __forceinline__ void rows_dx_body(
 #pragma unroll
   for (int l = 0; l < LB; ++l)
     if (l < L) live_row(l, cf8[l], hv8[l], jl8[l], r0[l], r1[l]);
+  if (CACHED) {
 #pragma unroll 1
-  for (int l = LB; l < L; ++l) {
-    const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
-    const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
-    live_row(l, coef[l], row[hc], live[l], ar[lane < N ? lane : N - 1], ar[lane + 64 < N ? lane + 64 : N - 1]);
+    for (int l = LB; l < L; ++l) {
+      const int j = lm0 ? __builtin_ctzll(lm0) : 64 + __builtin_ctzll(lm1);
+      if (lm0) lm0 &= lm0 - 1; else lm1 &= lm1 - 1;
+      live_row(l, (j == cur && !self) ? 0.f : 1.f, cH[((size_t)b * N + j) * H1 + hc], j, hop_edge(j, lane) ? 1.f : 0.f,
+               hop_edge(j, lane + 64) ? 1.f : 0.f);
+    }
+  } else {
+#pragma unroll 1
+    for (int l = LB; l < L; ++l) {
+      const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
+      const float* ar = sv + lay.o_arows + ((size_t)b * N + l) * N;
+      live_row(l, coef[l], row[hc], live[l], ar[lane < N ? lane : N - 1], ar[lane + 64 < N ? lane + 64 : N - 1]);
+    }
   }
   if (gnodes) {   // a gradient handed to the node matrix this step returned: every row up to cur
     for (int k = 0; k <= cur; ++k) add_row(k, lane < F ? gnodes[((size_t)b * N + k) * F + lane] : 0.f);
@@ -715,11 +775,12 @@ struct DxTable {
 
 // every (step, graph) of the table, one wave per item, the waves of a grid sized to the machine striding over
 // the items with the weights in their registers; steps with neither gradient are skipped
+template <bool CACHED>
 __global__ __launch_bounds__(256) void k_rows_dx_all(
     DxTable tab, int n_steps, int s0, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel1,
     const float* __restrict__ w_root1, const float* __restrict__ w_rel2, const float* __restrict__ w_root2, int act1,
     int act2, SavedLayout lay, const int64_t* __restrict__ count0, float* gx, float* gn0, int B, int N, int F, int H1,
-    int H2) {
+    int H2, gcm_fused::Edits E, const float* __restrict__ cH) {
   extern __shared__ float dxs[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   DxWeights W;
@@ -731,8 +792,8 @@ __global__ __launch_bounds__(256) void k_rows_dx_all(
     const float* gm = tab.gmx[s];
     const float* gn = tab.gn[s];
     if (!gm && !gn) continue;
-    rows_dx_body<true>(tab.saved[s], gm, gmx_sb, gmx_sh, gn, W, act1, act2, lay, count0, gx, gn0, s0 + s, b, lane,
-                       dxs + (size_t)wave * N * F, B, N, F, H1, H2);
+    rows_dx_body<true, CACHED>(tab.saved[s], gm, gmx_sb, gmx_sh, gn, W, act1, act2, lay, count0, gx, gn0, s0 + s, b,
+                               lane, dxs + (size_t)wave * N * F, B, N, F, H1, H2, &E, cH);
   }
 }
 
@@ -771,12 +832,43 @@ extern "C" int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx
  * concurrently, so gx / gn0 (zeroed by the caller) take hardware float atomic adds: the order of summation -
  * and with it the last bits of the result - is not fixed; gcm_dense_rows_bptt_dx_step, handed the steps last
  * to first, is the ordered form. */
+static int rows_dx_all_impl(const float* const* saved, const float* const* g_mx, long gmx_stride_b,
+                            long gmx_stride_h, const float* const* g_nodes_out, int n_steps, int s0,
+                            const float* params, int has_bias, int act1, int act2, const int64_t* count0, float* gx,
+                            float* gn0, const gcm_selector_desc* selectors, int n_selectors, const float* cache_h1,
+                            int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+
 extern "C" int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_mx, long gmx_stride_b,
                                           long gmx_stride_h, const float* const* g_nodes_out, int n_steps, int s0,
                                           const float* params, int has_bias, int act1, int act2,
                                           const int64_t* count0, float* gx, float* gn0, int B, int N, int F, int H1,
                                           int H2, gcm_stream_t stream) {
-  GCM_REQUIRE(saved && g_mx && g_nodes_out && params && count0 && gx && B > 0 && s0 >= 0);
+  return rows_dx_all_impl(saved, g_mx, gmx_stride_b, gmx_stride_h, g_nodes_out, n_steps, s0, params, has_bias, act1,
+                          act2, count0, gx, gn0, nullptr, 0, nullptr, B, N, F, H1, H2, stream);
+}
+
+/* The same over the records of CACHED steps (rows_cached.hip) of a chain that started from empty graphs: s0 is then
+ * also the row the first step's node landed in; the live rows and their adjacency rows follow from the selectors'
+ * forward hops, their h1 rows come from the chain's cache. */
+extern "C" int gcm_dense_rows_bptt_dx_all_cached(const float* const* saved, const float* const* g_mx,
+                                                 long gmx_stride_b, long gmx_stride_h, int n_steps, int s0,
+                                                 const float* params, int has_bias, int act1, int act2,
+                                                 const gcm_selector_desc* selectors, int n_selectors,
+                                                 const float* cache_h1, float* gx, int B, int N, int F, int H1, int H2,
+                                                 gcm_stream_t stream) {
+  GCM_REQUIRE(cache_h1 && (selectors || n_selectors == 0));
+  if (!gcm_dense_rows_cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  static const float* const kNone[GCM_ROWS_MAX_STEPS] = {};
+  return rows_dx_all_impl(saved, g_mx, gmx_stride_b, gmx_stride_h, kNone, n_steps, s0, params, has_bias, act1, act2,
+                          nullptr, gx, nullptr, selectors, n_selectors, cache_h1, B, N, F, H1, H2, stream);
+}
+
+static int rows_dx_all_impl(const float* const* saved, const float* const* g_mx, long gmx_stride_b,
+                            long gmx_stride_h, const float* const* g_nodes_out, int n_steps, int s0,
+                            const float* params, int has_bias, int act1, int act2, const int64_t* count0, float* gx,
+                            float* gn0, const gcm_selector_desc* selectors, int n_selectors, const float* cache_h1,
+                            int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(saved && g_mx && g_nodes_out && params && (count0 || cache_h1) && gx && B > 0 && s0 >= 0);
   GCM_REQUIRE(n_steps > 0 && n_steps <= GCM_ROWS_MAX_STEPS);
   if (!gcm_dense_rows_dx_supported(N, F, H1, H2) || (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE)))
     return GCM_EUNSUPPORTED;
@@ -789,13 +881,30 @@ extern "C" int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float
   }
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
-  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, true);
+  gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, true);
+  gcm_fused::Edits E{};
+  if (cache_h1) {
+    lay.o_live = gcm_rows::make_cached_layout(B, N, H1, H2).o_live;   // (v / hdr / coef sit where the full record has them)
+    for (int i = 0; i < n_selectors; ++i)
+      for (int k = 0; k < selectors[i].n_hops; ++k) {
+        E.hops[E.n_hops] = selectors[i].hops[k];
+        E.dir[E.n_hops++] = selectors[i].direction;
+      }
+  }
   const size_t lds = sizeof(float) * 4 * (size_t)N * F;
-  gcm_allow_dynamic_lds((const void*)gcm_rows::k_rows_dx_all, lds);
   const long items = (long)n_steps * B;
   const long wgs = (items + 3) / 4, resident = 2L * gcm_cu_count();   // (64 KB of LDS per workgroup: two per CU)
-  hipLaunchKernelGGL(gcm_rows::k_rows_dx_all, dim3((unsigned)(wgs < resident ? wgs : resident)), dim3(256), lds, (hipStream_t)stream,
-                     tab, n_steps, s0, gmx_stride_b, gmx_stride_h, params, params + (size_t)H1 * F, w_rel2, w_root2,
-                     act1, act2, lay, count0, gx, gn0, B, N, F, H1, H2);
+  const dim3 grid((unsigned)(wgs < resident ? wgs : resident));
+  if (cache_h1) {
+    gcm_allow_dynamic_lds((const void*)gcm_rows::k_rows_dx_all<true>, lds);
+    hipLaunchKernelGGL(gcm_rows::k_rows_dx_all<true>, grid, dim3(256), lds, (hipStream_t)stream, tab, n_steps, s0,
+                       gmx_stride_b, gmx_stride_h, params, params + (size_t)H1 * F, w_rel2, w_root2, act1, act2, lay,
+                       count0, gx, gn0, B, N, F, H1, H2, E, cache_h1);
+  } else {
+    gcm_allow_dynamic_lds((const void*)gcm_rows::k_rows_dx_all<false>, lds);
+    hipLaunchKernelGGL(gcm_rows::k_rows_dx_all<false>, grid, dim3(256), lds, (hipStream_t)stream, tab, n_steps, s0,
+                       gmx_stride_b, gmx_stride_h, params, params + (size_t)H1 * F, w_rel2, w_root2, act1, act2, lay,
+                       count0, gx, gn0, B, N, F, H1, H2, E, cache_h1);
+  }
   return gcm_launch_status();
 }

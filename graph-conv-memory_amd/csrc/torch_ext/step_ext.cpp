@@ -251,6 +251,7 @@ struct RowsChainNode : public torch::autograd::Node {
     bool cached = false;        // a cached step (rows_cached.hip): the live rows are in the chain's caches
   };
   at::Tensor cH, cA, cX;        // the caches of the chain's cached steps
+  std::vector<gcm_selector_desc> descs;   // ... and the selectors their live rows follow from (dx of cached steps)
   std::vector<Rec> recs;   // the recorded steps, in chain order
   at::Tensor packed;       // the packed parameter vector, detached (the kernel re-reads the weights)
   int N = 0, F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
@@ -323,12 +324,22 @@ struct RowsChainNode : public torch::autograd::Node {
       if (gms[k].defined()) gm[k] = gms[k].data_ptr<float>();
       if (gns[k].defined()) gn[k] = gns[k].data_ptr<float>();
     }
-    constexpr int CHUNK = 64;   // steps per launch (gcm_dense_rows_bptt_dx_all)
-    for (int k0 = 0; k0 < K; k0 += CHUNK) {
-      const int n = std::min(K - k0, CHUNK);
+    constexpr int CHUNK = 64;   // steps per launch (gcm_dense_rows_bptt_dx_all), of one kind (cached | not)
+    for (int k0 = 0, n = 0; k0 < K; k0 += n) {
+      const bool kind = recs[k0].cached;
+      n = 1;
+      while (n < CHUNK && k0 + n < K && recs[k0 + n].cached == kind) ++n;
       bool any = false;
       for (int k = k0; k < k0 + n; ++k) any = any || gm[k] || gn[k];
       if (!any) continue;
+      if (kind) {
+        check(gcm_dense_rows_bptt_dx_all_cached(sv.data() + k0, gm.data() + k0, (long)sb, (long)sh, n, k0,
+                                                packed.data_ptr<float>(), has_bias, act1, act2,
+                                                descs.empty() ? nullptr : descs.data(), (int)descs.size(),
+                                                cH.data_ptr<float>(), gx.data_ptr<float>(), (int)B, N, F, H1, H2, stream),
+              "gcm_dense_rows_bptt_dx_all_cached");
+        continue;
+      }
       check(gcm_dense_rows_bptt_dx_all(sv.data() + k0, gm.data() + k0, (long)sb, (long)sh, gn.data() + k0, n, k0,
                                        packed.data_ptr<float>(), has_bias, act1, act2, count0.data_ptr<int64_t>(),
                                        gx.data_ptr<float>(), gn0.defined() ? gn0.data_ptr<float>() : nullptr, (int)B,
@@ -671,7 +682,7 @@ struct RowsFast {
     }
     chain_steps = cached_steps = 0;
     cH = cA = cX = at::Tensor();
-    cache_ok = fresh && donate && dx_kind == 0 &&
+    cache_ok = fresh && donate && dx_kind != 2 &&
                gcm_dense_rows_cached_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
                                                cfg->has_bias, cfg->N, cfg->F, cfg->H1, cfg->H2) != 0;
     armed = true;
@@ -687,7 +698,7 @@ struct RowsFast {
       cH = at::zeros({B, N, H1}, obs.options());
       cA = at::zeros({B, N, F}, obs.options());
       cX = at::zeros({B, N, F}, obs.options());
-      if (node) { node->cH = cH; node->cA = cA; node->cX = cX; }
+      if (node) { node->cH = cH; node->cA = cA; node->cX = cX; node->descs = cfg->descs; }
       // the weights lane-major, once per chain (the parameters are fixed inside one)
       wimg = at::empty({4 * 64 * 64}, obs.options());
       check(gcm_dense_rows_cached_weight_image(packed.data_ptr<float>(), wimg.data_ptr<float>(), F, H1, H2,
@@ -710,6 +721,7 @@ struct RowsFast {
       const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
       RowsChainNode::Rec r{buf, vc, vc.current_version()};
       r.cached = true;
+      if (dx_kind == 1) r.edge_x = node->take_x_edge(obs);
       r.out_mx = (int)node->num_inputs();
       torch::autograd::create_gradient_edge(mx, node);
       node->recs.push_back(std::move(r));

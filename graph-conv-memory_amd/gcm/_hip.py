@@ -104,6 +104,8 @@ PROTOTYPES = {
     "gcm_dense_rows_step_cached": (_I, [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_bptt_cached": (_I, [_P, _P, _I, ctypes.c_long, ctypes.c_long, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z]
                                    + [_I] * 5 + [_P]),
+    "gcm_dense_rows_bptt_dx_all_cached": (_I, [_P, _P, ctypes.c_long, ctypes.c_long, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P]
+                                          + [_I] * 5 + [_P]),
     "gcm_dense_rows_bptt_dx_all": (_I, [_P, _P, ctypes.c_long, ctypes.c_long, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P]
                                    + [_I] * 5 + [_P]),
     "gcm_dense_rows_step_fwd": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_I] * 5 + [_P]),

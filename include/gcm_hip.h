@@ -607,6 +607,14 @@ int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes, float* adj
                                   float* cache_agg1, float* cache_nodes, float* const* saved_per_step,
                                   uint32_t* flags, void* const* start_events, void* const* stop_events, int T, int B,
                                   int N, int F, int H1, int H2, gcm_stream_t stream);
+/* gcm_dense_rows_bptt_dx_all over the records of cached steps (a chain from empty graphs: s0 is also the row the
+ * first of these steps' nodes landed in; live rows and their adjacency rows from the selectors' forward hops, their
+ * h1 rows from the chain's cache). */
+int gcm_dense_rows_bptt_dx_all_cached(const float* const* saved, const float* const* g_mx, long gmx_stride_b,
+                                      long gmx_stride_h, int n_steps, int s0, const float* params, int has_bias,
+                                      int act1, int act2, const gcm_selector_desc* selectors, int n_selectors,
+                                      const float* cache_h1, float* gx, int B, int N, int F, int H1, int H2,
+                                      gcm_stream_t stream);
 int gcm_dense_rows_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                                long gmx_stride_b, long gmx_stride_h, const float* params, int has_bias, int act1,
                                int act2, const float* cache_nodes, const float* cache_h1,

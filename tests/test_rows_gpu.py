@@ -707,3 +707,34 @@ def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
         for k, gd in grads.items():
             g64, atol = bounds[k]
             assert float((gd.double() - g64).abs().max()) <= atol, k
+
+
+@pytest.mark.parametrize("hops,B,N,F,H,T", [([1, 2, 4], 6, 16, 32, 32, 30), ([0, 1, 3], 3, 128, 32, 32, 130),
+                                            ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10], 2, 24, 64, 32, 24)])
+def test_rows_cached_steps_with_obs_gradient(hops, B, N, F, H, T):
+    """Observations with gradient on a donated state from hidden = None: the cached steps' part of dL/dx comes from
+    the caches and the hop table (gcm_dense_rows_bptt_dx_all_cached), the steps behind them - the graphs overflow -
+    from their own records; beliefs, state, observation and parameter gradients against the oracle."""
+    torch.manual_seed(N + T)
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("temporal", hops, "forward"), True)
+    obs = torch.rand(T, B, F)
+    w = torch.rand(T, B, H)
+    w[T // 3] = 0
+    xo = obs.clone().requires_grad_(True)
+    out_o, hid_o = od.dense_rollout(xo, None, ref, graph_size=N, edge_selectors=osel)
+    (out_o * w).sum().backward()
+    xs = [obs[t].to(DEV).requires_grad_(True) for t in range(T)]       # per-step leaves (an encoder's outputs)
+    hid, outs = None, []
+    for t in range(T):
+        mx, hid = mem(xs[t], hid)
+        outs.append(mx)
+    assert mem.rows_steps() == T and mem.rows_cached_steps_taken() == min(T, N)
+    out_d = torch.stack(outs)
+    (out_d * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    torch.testing.assert_close(out_d.detach().cpu(), out_o.detach(), rtol=RTOL, atol=ATOL)
+    assert torch.equal(hid[1].cpu(), hid_o[1]) and torch.equal(hid[0].cpu(), hid_o[0])
+    gx = torch.stack([x.grad.cpu() for x in xs])
+    torch.testing.assert_close(gx, xo.grad, rtol=1e-4, atol=1e-5 * float(xo.grad.abs().max()))
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
