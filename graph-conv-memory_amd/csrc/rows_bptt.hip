@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         vv[c] = m < 2 * H1 ? t : 0.f;
       }
     }
-    const float d2 = lane < H2 ? g * act_grad_sel(y, act2_v) : 0.f;   // d2 in lane o < H2
+    // (MODE 3, L = 0: the empty record of a graph that got no node this step - SparseGCM with taus[b] = 0 - whose
+    //  zero padded output row takes no gradient)
+    const float d2 = (lane < H2 && !(MODE == 3 && L == 0)) ? g * act_grad_sel(y, act2_v) : 0.f;   // d2 in lane o < H2
     db2 += d2;
     float u[C2];
 #pragma unroll
@@ -403,7 +405,10 @@ static int rows_bptt_impl(const float* const* saved_host, const float* const* gm
                           int N, int F, int H1, int H2, gcm_stream_t stream) {
   GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace);
   GCM_REQUIRE(n_steps > 0 && B > 0);
-  if (!gcm_dense_rows_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  // (records of cached steps: the kernel only indexes the caches by row - any graph size; SparseGCM's stepwise use)
+  if (cache_h1 ? (N <= 0 || F <= 0 || F > 64 || H1 <= 0 || H1 > 64 || H2 <= 0 || H2 > 64)
+               : !gcm_dense_rows_supported(N, F, H1, H2))
+    return GCM_EUNSUPPORTED;
   if (workspace_bytes < gcm_dense_rows_bptt_workspace_bytes(n_steps, B, F, H1, H2))
     return GCM_EWORKSPACE;
   const int deg_term = (has_bias & GCM_GNN_HAS_DEG_TERM) ? 1 : 0;

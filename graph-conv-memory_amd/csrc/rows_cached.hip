@@ -408,6 +408,130 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// SparseGCM, stepwise use (sparse_gcm.py:72-212 called with one new node per graph: x [B, 1, F], taus in {0, 1}) with a
+// TemporalEdge selector (sparse_edge_selectors/temporal.py:18-63), in a chain that started from empty graphs: the
+// same argument - edges only ever point from a new node to older ones, so the layer-1 row of a node is final once
+// written - and the same step: the new node's rows of both layers from the chain's caches, instead of flattening
+// the whole batch, building CSR / CSC views of it and running both GraphConv layers over every stored node.
+// The node's row index is T[b] (read: the graphs of a SparseGCM batch need not move in lockstep); taus[b] = 0:
+// no node this step (zero output row, empty record).
+// ---------------------------------------------------------------------------------------------------------
+template <int FP, int HP>
+__global__ __launch_bounds__(64) void k_sparse_step_cached(
+    const float* __restrict__ x, const int64_t* __restrict__ T, const int64_t* __restrict__ taus, gcm_fused::Edits E,
+    const float* __restrict__ params, const float* __restrict__ image, int act1, int act2, float* __restrict__ cH,
+    float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ mx, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2) {
+  constexpr int F = FP, H1 = HP;
+  __shared__ __attribute__((aligned(16))) float sv[128];
+  const int lane = threadIdx.x;
+  const unsigned gb = blockIdx.x;
+  const float* b1 = params + 2 * H1 * F;
+  const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
+  const int64_t n64 = T[gb], tau = taus[gb];
+  float r1[F], t1[F], r2[H1], t2[H1];
+#pragma unroll
+  for (int k = 0; k < F; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
+#pragma unroll
+  for (int k = 0; k < H1; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
+  const float bias1 = b1[hl], bias2 = b2[ol];
+  const float xc = x[gb * F + fl];
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  asm volatile("" ::: "memory");
+  const bool on = tau > 0;
+  const bool bad = on && (n64 < 0 || n64 >= N);
+  const bool rec = on && !bad;
+  const int cur = __builtin_amdgcn_readfirstlane(rec ? (int)n64 : 0);
+  // the selected rows: cur - hop for every (distinct, host-sorted descending) hop with a source (temporal.py:
+  // t - h >= 0) - straight from the hop table (any graph size; no row masks), every load issued together
+  float xa[16], ha[16];
+  unsigned valid = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int h = E.hops[i], j = cur - h;
+    const bool ok = rec && i < E.n_hops && h > 0 && j >= 0;
+    valid |= ok ? 1u << i : 0u;
+    const unsigned rj = gb * (unsigned)N + (unsigned)(ok ? j : 0);
+    const float tx = cX[rj * F + fl], th = cH[rj * H1 + hl];
+    xa[i] = ok ? tx : 0.f;
+    ha[i] = ok ? th : 0.f;
+  }
+  float agg1 = 0.f, agg2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { agg1 += xa[i]; agg2 += ha[i]; }   // (hops descending: sources ascending)
+  agg1 = lane < F ? agg1 : 0.f;
+  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
+  float p1 = bias1;
+  {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < F / 4; ++f4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
+      const float4 xx = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
+      pa = fmaf(r1[4 * f4], a.x, pa); pb = fmaf(t1[4 * f4], xx.x, pb);
+      pa = fmaf(r1[4 * f4 + 1], a.y, pa); pb = fmaf(t1[4 * f4 + 1], xx.y, pb);
+      pa = fmaf(r1[4 * f4 + 2], a.z, pa); pb = fmaf(t1[4 * f4 + 2], xx.z, pb);
+      pa = fmaf(r1[4 * f4 + 3], a.w, pa); pb = fmaf(t1[4 * f4 + 3], xx.w, pb);
+    }
+    p1 += pa + pb;
+  }
+  const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
+  agg2 = lane < H1 ? agg2 : 0.f;
+  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }
+  float p2 = bias2;
+  {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int h4 = 0; h4 < H1 / 4; ++h4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
+      const float4 xx = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
+      pa = fmaf(r2[4 * h4], a.x, pa); pb = fmaf(t2[4 * h4], xx.x, pb);
+      pa = fmaf(r2[4 * h4 + 1], a.y, pa); pb = fmaf(t2[4 * h4 + 1], xx.y, pb);
+      pa = fmaf(r2[4 * h4 + 2], a.z, pa); pb = fmaf(t2[4 * h4 + 2], xx.z, pb);
+      pa = fmaf(r2[4 * h4 + 3], a.w, pa); pb = fmaf(t2[4 * h4 + 3], xx.w, pb);
+    }
+    p2 += pa + pb;
+  }
+  const float v = rec ? gcm_act_sel(p2, act2_v) : 0.f;   // (no node: the padded output row is zero)
+  const unsigned rc = gb * (unsigned)N + (unsigned)cur;
+  if (rec) {
+    if (lane < F) { cX[rc * F + lane] = xc; cA[rc * F + lane] = agg1; }
+    if (lane < H1) cH[rc * H1 + lane] = h1c;
+  }
+  if (lane < H2) {
+    mx[gb * H2 + lane] = v;
+    saved[gb * H2 + lane] = v;
+  }
+  if (lay.total) {
+    if (lane < H1) {
+      saved[lay.o_v + gb * 2 * H1 + lane] = rec ? agg2 : 0.f;
+      saved[lay.o_v + gb * 2 * H1 + H1 + lane] = rec ? h1c : 0.f;
+    }
+    // live list: the selected rows (ascending) and row cur behind them; coef = 1 for an edge, 0 for row cur
+    int* live = reinterpret_cast<int*>(saved + lay.o_live) + (size_t)gb * N;
+    float* coef = saved + lay.o_coef + (size_t)gb * N;
+    const int Ls = __popc(valid);
+    int myh = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) myh = lane == i ? E.hops[i] : myh;
+    if (lane < 16 && ((valid >> lane) & 1u)) {
+      const int pos = __popc(valid & ((1u << lane) - 1u));
+      live[pos] = cur - myh;
+      coef[pos] = 1.f;
+    }
+    if (lane == 16 && rec) { live[Ls] = cur; coef[Ls] = 0.f; }
+    if (lane == 0) {
+      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
+      hdr[0] = rec ? Ls + 1 : 0; hdr[1] = Ls; hdr[2] = cur; hdr[3] = 0;
+    }
+  }
+  const bool nonfinite = __any(lane < H2 && !isfinite(v));
+  if ((nonfinite || bad) && lane == 0)
+    atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_SPARSE_OVERFLOW : 0u));
+}
+
 }  // namespace gcm_rows
 
 extern "C" int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
@@ -523,4 +647,38 @@ extern "C" int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes,
     if (rc) return rc;
   }
   return GCM_OK;
+}
+
+/* SparseGCM stepwise (x [B, 1, F], taus in {0, 1}) in a chain from empty graphs, TemporalEdge selector with hops >= 1
+ * (HOST array): the new node's belief from the chain's caches (see k_sparse_step_cached).  T: node counts BEFORE the
+ * step.  mx [B, H2]; saved: the record (gcm_dense_rows_cached_layout; written in full with record != 0, else mx only).
+ * The state itself (node matrix, COO adjacency, T) is advanced by the caller with the usual entry points. */
+extern "C" int gcm_sparse_step_cached(const float* x, const int64_t* T, const int64_t* taus, const int32_t* hops_host,
+                                      int n_hops, const float* params, const float* weight_image, int act1, int act2,
+                                      float* cache_h1, float* cache_agg1, float* cache_nodes, float* mx, float* saved,
+                                      int record, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                      gcm_stream_t stream) {
+  GCM_REQUIRE(x && T && taus && hops_host && params && weight_image && cache_h1 && cache_agg1 && cache_nodes && mx &&
+              saved && flags && B > 0 && N > 0 && n_hops >= 0);
+  if (n_hops > 16 || H2 > 64 || H2 <= 0 || (F != 32 && F != 64) || (H1 != 32 && H1 != 64))
+    return GCM_EUNSUPPORTED;
+  if ((size_t)B * N * 64 >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;
+  gcm_fused::Edits E{};
+  for (int i = 0; i < n_hops; ++i) {
+    if (hops_host[i] < 1) return GCM_EUNSUPPORTED;   // (a hop of 0 would be a self loop: "Causality violated")
+    E.hops[E.n_hops] = hops_host[i];
+    E.dir[E.n_hops++] = GCM_DIR_FORWARD;
+  }
+  gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, N, H1, H2);
+  if (!record) lay.total = 0;
+#define GCM_SC(a, b_)                                                                                         \
+  if (F == a && H1 == b_) {                                                                                   \
+    hipLaunchKernelGGL((gcm_rows::k_sparse_step_cached<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream, x, T, \
+                       taus, E, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes, mx, saved,   \
+                       lay, flags, B, N, H2);                                                                     \
+    return gcm_launch_status();                                                                               \
+  }
+  GCM_SC(32, 32) GCM_SC(64, 32) GCM_SC(32, 64) GCM_SC(64, 64)
+#undef GCM_SC
+  return GCM_EUNSUPPORTED;
 }

@@ -1508,6 +1508,121 @@ struct SparseStepNode : public torch::autograd::Node {
   std::string name() const override { return "GcmSparseStep"; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// SparseGCM called one node at a time (x [B, 1, F], taus in {0, 1}: ray_sparse_gcm.py's rollout loop), canonical
+// configuration, in a chain of hidden states that started from EMPTY graphs.  TemporalEdge only ever points from a
+// new node at older ones, so the layer-1 row of a node is final once written: the chain keeps h1 / agg1 / x of every
+// node in caches and a call evaluates the new node's rows alone (gcm_sparse_step_cached: one launch) instead of
+// flattening the batch, building CSR / CSC views and running both GraphConv layers over every stored node.  The
+// state the caller sees (node matrix, COO adjacency, T) is advanced as before.  Backward: every cached call leaves
+// a record; ONE gate per chain collects the records a backward pass reaches and runs one time-parallel launch over
+// them (gcm_dense_rows_bptt_cached), handing each of the six parameter tensors its gradient once.
+// ---------------------------------------------------------------------------------------------
+struct SparseChainGate : public torch::autograd::Node {
+  at::Tensor packed, cH, cA, cX, kick;
+  std::vector<at::Tensor> recs, gms;   // what the current backward pass has reached
+  int pass = -2;
+  bool gave = false, executed = false, has_b1 = false, has_b2 = false;
+  int B = 0, N = 0, F = 0, H1 = 0, H2 = 0, act1 = 0, act2 = 0;
+
+  void begin_pass_if_new() {
+    const int id = torch::autograd::get_current_graph_task_id();
+    if (id == pass) return;
+    pass = id;
+    recs.clear();
+    gms.clear();
+    gave = false;
+  }
+  // inputs: the kick; outputs: w_rel1, b1, w_root1, w_rel2, b2, w_root2
+  variable_list apply(variable_list&& grads) override {
+    executed = true;
+    variable_list out(6);
+    const bool mine = pass == torch::autograd::get_current_graph_task_id();
+    std::vector<at::Tensor> rs, gs;
+    rs.swap(recs);
+    gs.swap(gms);
+    pass = -2;
+    if (!mine || rs.empty()) return out;
+    const int n = (int)rs.size();
+    std::vector<const float*> sv(n), gm(n);
+    for (int i = 0; i < n; ++i) { sv[i] = rs[i].data_ptr<float>(); gm[i] = gs[i].data_ptr<float>(); }
+    const gcm_stream_t st =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(packed.get_device()).stream());
+    const size_t wsb = gcm_dense_rows_bptt_workspace_bytes(n, B, F, H1, H2);
+    at::Tensor ws = at::empty({(int64_t)wsb}, packed.options().dtype(at::kByte));
+    at::Tensor res = at::empty({packed.numel()}, packed.options());
+    check(gcm_dense_rows_bptt_cached(sv.data(), gm.data(), n, (long)H2, 1L, packed.data_ptr<float>(),
+                                     (has_b1 ? 1 : 0) | (has_b2 ? 2 : 0), act1, act2, cX.data_ptr<float>(),
+                                     cH.data_ptr<float>(), cA.data_ptr<float>(), nullptr, res.data_ptr<float>(),
+                                     ws.data_ptr(), wsb, B, N, F, H1, H2, st),
+          "gcm_dense_rows_bptt_cached");
+    // packed: W_rel1 | W_root1 | b1 | W_rel2 | W_root2 | b2
+    int64_t o = 0;
+    out[0] = res.narrow(0, o, (int64_t)H1 * F).view({H1, F}); o += (int64_t)H1 * F;
+    out[2] = res.narrow(0, o, (int64_t)H1 * F).view({H1, F}); o += (int64_t)H1 * F;
+    if (has_b1) out[1] = res.narrow(0, o, H1);
+    o += H1;
+    out[3] = res.narrow(0, o, (int64_t)H2 * H1).view({H2, H1}); o += (int64_t)H2 * H1;
+    out[5] = res.narrow(0, o, (int64_t)H2 * H1).view({H2, H1}); o += (int64_t)H2 * H1;
+    if (has_b2) out[4] = res.narrow(0, o, H2);
+    return out;
+  }
+  std::string name() const override { return "GcmSparseChainGate"; }
+};
+
+struct SparseCachedStepNode : public torch::autograd::Node {
+  std::shared_ptr<SparseChainGate> gate;
+  at::Tensor rec;
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(1);
+    TORCH_CHECK(rec.defined(), "Trying to backward through a SparseGCM step a second time (its saved tensors "
+                               "were freed); pass retain_graph=True to the first call");
+    if (!grads[0].defined()) return out;
+    gate->begin_pass_if_new();
+    gate->recs.push_back(rec);
+    gate->gms.push_back(grads[0].to(at::kFloat).contiguous());
+    if (!gate->gave) {
+      out[0] = gate->kick;
+      gate->gave = true;
+    }
+    return out;
+  }
+  void release_variables() override { rec.reset(); }
+  std::string name() const override { return "GcmSparseCachedStep"; }
+};
+
+struct SparseChain {
+  std::shared_ptr<SparseChainGate> gate;
+  at::Tensor packed, wimg, cH, cA, cX;
+  at::Tensor last_nodes, last_idx, last_T;   // the state the previous call returned (kept alive: its addresses
+                                             // cannot be handed out again while the chain is armed)
+  c10::TensorImpl* pkeys[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t pvers[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t vers_nodes = 0, vers_T = 0;
+  bool live = false;
+  int64_t steps = 0, B = 0;
+
+  void drop() {
+    live = false;
+    gate.reset();
+    packed = wimg = cH = cA = cX = last_nodes = last_idx = last_T = at::Tensor();
+  }
+  bool same_params(const at::Tensor* const* ps) const {
+    for (int i = 0; i < 6; ++i) {
+      if ((ps[i] ? ps[i]->unsafeGetTensorImpl() : nullptr) != pkeys[i]) return false;
+      if (ps[i] && ps[i]->_version() != pvers[i]) return false;
+    }
+    return true;
+  }
+  bool continues(const at::Tensor& nodes, const at::Tensor& idx, const at::Tensor& T,
+                 const at::Tensor* const* ps) const {
+    return live && last_nodes.defined() && nodes.data_ptr() == last_nodes.data_ptr() &&
+           nodes._version() == vers_nodes && T.data_ptr() == last_T.data_ptr() && T._version() == vers_T &&
+           idx.size(1) == last_idx.size(1) && (idx.size(1) == 0 || idx.data_ptr() == last_idx.data_ptr()) &&
+           nodes.size(0) == B && same_params(ps);
+  }
+};
+
 // -> (mx_dense [B,t,H2], nodes_out, indices [3,E] (batch, sink, source), values [E], T + taus), or an int status:
 // 1 = overflow (sparse_gcm.py:120-121)
 pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& taus, const at::Tensor& nodes_,
@@ -1515,7 +1630,7 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
                                       const at::Tensor& w_rel1, const c10::optional<at::Tensor>& b1,
                                       const at::Tensor& w_root1, int act1, const at::Tensor& w_rel2,
                                       const c10::optional<at::Tensor>& b2, const at::Tensor& w_root2, int act2,
-                                      const at::Tensor& flags) {
+                                      const at::Tensor& flags, pybind11::object chain_obj, bool fresh) {
   TORCH_CHECK(x_.is_cuda() && taus.is_cuda() && nodes_.is_cuda() && T.is_cuda() && flags.is_cuda(),
               "sparse step: every tensor must live on a HIP device (no CPU fallback)");
   at::Tensor x = x_.contiguous(), nodes = nodes_.contiguous(), adj_idx = adj_idx_.contiguous();
@@ -1527,6 +1642,51 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   const auto iopt = T.options();
   const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(x.get_device()).stream());
   uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
+  const at::Tensor* ps[6] = {&w_rel1, b1.has_value() ? &*b1 : nullptr, &w_root1,
+                             &w_rel2, b2.has_value() ? &*b2 : nullptr, &w_root2};
+  const bool need_bwd = at::GradMode::is_enabled() &&
+                        (x_.requires_grad() || nodes_.requires_grad() || w_rel1.requires_grad() ||
+                         w_root1.requires_grad() || w_rel2.requires_grad() || w_root2.requires_grad() ||
+                         (b1.has_value() && b1->requires_grad()) || (b2.has_value() && b2->requires_grad()));
+  // ---- a call on the chain's caches?  (see SparseChain: one node per graph, no gradient w.r.t. x / the node matrix,
+  //      a chain from empty graphs - `fresh`: the caller vouches that T == 0 everywhere - whose previous call
+  //      returned exactly this state, parameters untouched since its head)
+  SparseChain* ch = chain_obj.is_none() ? nullptr : chain_obj.cast<SparseChain*>();
+  bool cached = false;
+  if (ch) {
+    bool ok = t_pad == 1 && !x_.requires_grad() && !nodes_.requires_grad() && (F == 32 || F == 64) &&
+              (H1 == 32 || H1 == 64) && H2 > 0 && H2 <= 64 && hops_desc.size() <= 16 &&
+              (size_t)B * N * 64 < ((size_t)1 << 31) && w_rel1.scalar_type() == at::kFloat;
+    for (int h : hops_desc) ok = ok && h >= 1;
+    if (ok && fresh && Ea == 0) {
+      ch->drop();
+      at::NoGradGuard ng;
+      std::vector<at::Tensor> parts = {
+          w_rel1.detach().reshape({-1}), w_root1.detach().reshape({-1}),
+          b1.has_value() ? b1->detach().reshape({-1}) : at::zeros({H1}, x.options()),
+          w_rel2.detach().reshape({-1}), w_root2.detach().reshape({-1}),
+          b2.has_value() ? b2->detach().reshape({-1}) : at::zeros({H2}, x.options())};
+      ch->packed = at::cat(parts);
+      ch->wimg = at::empty({4 * 64 * 64}, x.options());
+      check(gcm_dense_rows_cached_weight_image(ch->packed.data_ptr<float>(), ch->wimg.data_ptr<float>(), (int)F,
+                                               (int)H1, (int)H2, st),
+            "gcm_dense_rows_cached_weight_image");
+      // (rows are read only behind a select on "written before": no zero fill)
+      ch->cH = at::empty({B, N, H1}, x.options());
+      ch->cA = at::empty({B, N, F}, x.options());
+      ch->cX = at::empty({B, N, F}, x.options());
+      for (int i = 0; i < 6; ++i) {
+        ch->pkeys[i] = ps[i] ? ps[i]->unsafeGetTensorImpl() : nullptr;
+        ch->pvers[i] = ps[i] ? ps[i]->_version() : 0;
+      }
+      ch->B = B;
+      ch->steps = 0;
+      ch->live = cached = true;
+    } else if (ok && ch->continues(nodes, adj_idx, T, ps)) {
+      cached = true;
+    }
+    if (!cached && ch->live) ch->drop();
+  }
   // ---- plan: node offsets, edge offsets; the one readback
   at::Tensor plan = at::empty({3 * (B + 1) + 4}, iopt);
   int64_t* node_off = plan.data_ptr<int64_t>();
@@ -1571,6 +1731,44 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   }
   const int64_t E = idx.size(1);
   at::Tensor vals = at::ones({E}, x.options());
+  if (cached) {
+    // ---- the new node's belief from the caches; the record; the chain's gate
+    size_t lay[5];
+    check(gcm_dense_rows_cached_layout((int)B, (int)N, (int)F, (int)H1, (int)H2, lay), "gcm_dense_rows_cached_layout");
+    at::Tensor rec = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, x.options());
+    at::Tensor mx = at::empty({B, t_pad, H2}, x.options());
+    std::vector<int32_t> hp(hops_desc.begin(), hops_desc.end());
+    check(gcm_sparse_step_cached(x.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hp.data(),
+                                 (int)hp.size(), ch->packed.data_ptr<float>(), ch->wimg.data_ptr<float>(), act1, act2,
+                                 ch->cH.data_ptr<float>(), ch->cA.data_ptr<float>(), ch->cX.data_ptr<float>(),
+                                 mx.data_ptr<float>(), rec.data_ptr<float>(), need_bwd ? 1 : 0, fl, (int)B, (int)N,
+                                 (int)F, (int)H1, (int)H2, st),
+          "gcm_sparse_step_cached");
+    if (need_bwd) {
+      if (!ch->gate) {
+        auto g = std::shared_ptr<SparseChainGate>(new SparseChainGate(), torch::autograd::deleteNode);
+        g->packed = ch->packed; g->cH = ch->cH; g->cA = ch->cA; g->cX = ch->cX;
+        g->B = (int)B; g->N = (int)N; g->F = (int)F; g->H1 = (int)H1; g->H2 = (int)H2;
+        g->act1 = act1; g->act2 = act2; g->has_b1 = b1.has_value(); g->has_b2 = b2.has_value();
+        for (int i = 0; i < 6; ++i)
+          g->add_next_edge(ps[i] && ps[i]->requires_grad() ? torch::autograd::impl::gradient_edge(*ps[i])
+                                                           : torch::autograd::Edge());
+        g->kick = at::zeros({1}, x.options());
+        g->add_input_metadata(g->kick);
+        ch->gate = g;
+      }
+      auto node = std::shared_ptr<SparseCachedStepNode>(new SparseCachedStepNode(), torch::autograd::deleteNode);
+      node->gate = ch->gate;
+      node->rec = rec;
+      node->add_next_edge(torch::autograd::Edge(ch->gate, 0));
+      torch::autograd::create_gradient_edge(mx, node);
+    }
+    at::Tensor T_out = T + taus;
+    ch->last_nodes = nodes_out; ch->last_idx = idx; ch->last_T = T_out;
+    ch->vers_nodes = nodes_out._version(); ch->vers_T = T_out._version();
+    ++ch->steps;
+    return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out);
+  }
   // ---- flat node matrix, CSR, the two layers, the new rows
   at::Tensor flat = at::empty({M, F}, x.options());
   check(gcm_sparse_flatten_fwd(nodes_out.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
@@ -1580,10 +1778,6 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   check(gcm_sparse_edges_to_csr(idx.data_ptr<int64_t>(), node_off, edge_index.data_ptr<int64_t>(),
                                 row_ptr.data_ptr<int64_t>(), fl, E, M, (int)B, st),
         "gcm_sparse_edges_to_csr");
-  const bool need_bwd = at::GradMode::is_enabled() &&
-                        (x_.requires_grad() || nodes_.requires_grad() || w_rel1.requires_grad() ||
-                         w_root1.requires_grad() || w_rel2.requires_grad() || w_root2.requires_grad() ||
-                         (b1.has_value() && b1->requires_grad()) || (b2.has_value() && b2->requires_grad()));
   at::Tensor out1 = at::empty({M, H1}, x.options()), out2 = at::empty({M, H2}, x.options());
   at::Tensor agg1 = need_bwd ? at::empty({M, F}, x.options()) : at::Tensor();
   at::Tensor agg2 = need_bwd ? at::empty({M, H1}, x.options()) : at::Tensor();
@@ -1615,8 +1809,6 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
       return t.requires_grad() ? torch::autograd::impl::gradient_edge(t) : torch::autograd::Edge();
     };
     // the gate of these six parameter tensors (a new one once the previous has run)
-    const at::Tensor* ps[6] = {&w_rel1, b1.has_value() ? &*b1 : nullptr, &w_root1,
-                               &w_rel2, b2.has_value() ? &*b2 : nullptr, &w_root2};
     std::shared_ptr<SparseGate>& slot = sparse_gate_slot();
     bool same = slot && !slot->executed;
     for (int i = 0; same && i < 6; ++i) same = slot->keys[i] == (ps[i] ? ps[i]->unsafeGetTensorImpl() : nullptr);
@@ -1674,5 +1866,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("recording", &LearnedChain::recording)
       .def("steps", &LearnedChain::steps);
   m.def("learned_step2", &learned_step2);
+  pybind11::class_<SparseChain>(m, "SparseChain")
+      .def(pybind11::init<>())
+      .def("steps", [](SparseChain& c) { return c.steps; })
+      .def("live", [](SparseChain& c) { return c.live; })
+      .def("drop", &SparseChain::drop);
   m.def("sparse_temporal_step", &sparse_temporal_step);
 }

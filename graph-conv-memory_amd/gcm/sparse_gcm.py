@@ -48,6 +48,18 @@ class SparseGCM(torch.nn.Module):
         self._flags = {}
         self._fast_plan = None    # (structure analysed once): the canonical configuration's C++ host path
         self.fast_host = True     # False: the layered Python path always (A/B tests)
+        # One node per call (x [B, 1, F]) in a chain from empty graphs: the new node's belief from the chain's
+        # h1 / agg1 / x caches in ONE launch, one time-parallel backward launch per chain (step_ext.cpp:
+        # SparseChain).  False: every call runs both GraphConv layers over every stored node.
+        self.stepwise_cache = True
+        self._chain = None
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle of a module that has already run: the analysed structure, the flag words and
+        the stepwise chain are runtime caches (rebuilt on the first call)."""
+        d = dict(self.__dict__)
+        d.update(_fast_plan=None, _flags={}, _chain=None)
+        return d
 
     def get_initial_hidden_state(self, x):
         """sparse_gcm.py:55-70."""
@@ -57,6 +69,7 @@ class SparseGCM(torch.nn.Module):
         adj = torch.zeros((B, self.graph_size, self.graph_size), device=x.device,
                           layout=torch.sparse_coo)
         T = torch.zeros(B, dtype=torch.long, device=x.device)
+        T._gcm_fresh = T._version      # (all zero by construction: lets a stepwise chain start on the caches)
         return nodes, adj, T
 
     def _flag_word(self, device):
@@ -140,6 +153,7 @@ class SparseGCM(torch.nn.Module):
         if hidden is None:
             hidden = self.get_initial_hidden_state(x)
         nodes, adj, T = hidden
+        fresh = getattr(T, "_gcm_fresh", None) == T._version
         assert x.dim() == 3 and x.dtype == torch.float32
         assert taus.dtype == torch.long and T.dtype == torch.long
         adj = adj.coalesce()
@@ -151,8 +165,14 @@ class SparseGCM(torch.nn.Module):
         if (fast is not None and x.is_cuda and not adj.values().requires_grad
                 and fast[2].in_channels == x.shape[-1] and x.device.index == torch.cuda.current_device()):
             fn, hops, c1, a1, c2, a2 = fast
+            chain = None
+            if self.stepwise_cache and t_pad == 1:
+                chain = self._chain
+                if chain is None:
+                    from . import _ext
+                    chain = self._chain = _ext.module().SparseChain()
             r = fn(x, taus, nodes, adj.indices(), T, hops, c1.lin_rel.weight, c1.lin_rel.bias, c1.lin_root.weight,
-                   a1, c2.lin_rel.weight, c2.lin_rel.bias, c2.lin_root.weight, a2, flags)
+                   a1, c2.lin_rel.weight, c2.lin_rel.bias, c2.lin_root.weight, a2, flags, chain, fresh)
             if r == 1:                                         # sparse_gcm.py:120-121
                 raise Exception("Overflow")
             mx_dense, nodes_out, idx, vals, T_out = r

@@ -599,6 +599,17 @@ int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64
                                const float* weight_image, int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
                                float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags, int B,
                                int N, int F, int H1, int H2, gcm_stream_t stream);
+/* SparseGCM in stepwise use (sparse_gcm.py:72-212 called with x [B, 1, F], taus in {0, 1}) with a TemporalEdge selector
+ * (sparse_edge_selectors/temporal.py:18-63; hops_host: HOST array, every hop >= 1), in a chain from empty graphs: the
+ * new node's belief from the chain's caches (the layer-1 row of a node is final once written: its edges point at
+ * older nodes only) - instead of flattening the batch, building CSR / CSC views and running both GraphConv layers
+ * over every stored node.  T: node counts BEFORE the step; taus[b] = 0: no node (zero output row).  mx [B, H2]; saved:
+ * the record (gcm_dense_rows_cached_layout; in full with record != 0), read by gcm_dense_rows_bptt_cached.  The state
+ * itself (node matrix, COO adjacency, T) is advanced by the caller with the usual entry points. */
+int gcm_sparse_step_cached(const float* x, const int64_t* T, const int64_t* taus, const int32_t* hops_host, int n_hops,
+                           const float* params, const float* weight_image, int act1, int act2, float* cache_h1,
+                           float* cache_agg1, float* cache_nodes, float* mx, float* saved, int record,
+                           uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 /* measurement aid (bench.py): T <= N cached steps of a rollout from empty graphs enqueued back to back from C, each
  * launch bracketed by the caller's HIP events recorded by the dispatch itself (cf. gcm_debug_time_rows_rollout) */
 int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,

@@ -107,7 +107,7 @@ def sparse_step(x, taus, hidden, gnn, graph_size=128, edge_selectors=None,
             out_idx, max_hops, edges, relabel_nodes=True, num_nodes=int((T + taus).sum()))
         mx = gnn(flat_nodes[sub], sub_edges, weights[emask])[node_map]
     assert torch.all(torch.isfinite(mx)), "Got NaN in returned memory, try using tanh activation"
-    mx_dense = torch.zeros((*x.shape[:-1], mx.shape[-1]))
+    mx_dense = torch.zeros((*x.shape[:-1], mx.shape[-1]), dtype=mx.dtype)   # (dtype-generic: float64 runs bound the tests)
     mx_dense = mx_dense.index_put((pad_b, pad_t), mx)
     return mx_dense, (nodes, adj, T + taus)
 

@@ -508,3 +508,144 @@ def test_sparse_learned_edge_smoke_size_matches_oracle():
         torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
     for (k, p), (_, q) in zip(sel.edge_network.named_parameters(), net.named_parameters()):
         torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-5 * float(q.grad.abs().max()) + 1e-8, msg=k)
+
+
+# --------------------------------------------------------------------------
+# SparseGCM one node per call on the chain's caches (step_ext.cpp: SparseChain; gcm_sparse_step_cached)
+# --------------------------------------------------------------------------
+def _stepwise_case(hops, B, N, F, H, T, act, p_skip, seed):
+    gen = torch.Generator().manual_seed(seed)
+    obs = torch.rand(T, B, 1, F, generator=gen)
+    taus = (torch.rand(T, B, generator=gen) >= p_skip).long()      # some graphs get no node in some calls
+    weight = torch.rand(T, B, 1, H, generator=gen) - 0.3
+    ref = osp.canonical_gnn(F, H, act=act)
+    return obs, taus, weight, ref
+
+
+def _oracle_stepwise(ref, obs, taus, weight, hops, N, dtype):
+    import copy
+    r = copy.deepcopy(ref).to(dtype)
+    n0, a0, T0 = osp.initial_hidden(obs[0], N)
+    hid, loss, outs = (n0.to(dtype), a0.to(dtype), T0), 0.0, []
+    for t in range(obs.shape[0]):
+        o, hid = osp.sparse_step(obs[t].to(dtype), taus[t], hid, lambda a, b, c: r(a, b, c), graph_size=N,
+                                 edge_selectors=osp.TemporalEdge(hops))
+        outs.append(o)
+        loss = loss + (o * weight[t].to(dtype)).sum()
+    loss.backward()
+    return torch.stack(outs).detach(), hid, {k: p.grad for k, p in r.named_parameters()}
+
+
+@pytest.mark.parametrize("hops,B,N,F,H,T,act,p_skip", [
+    ([1], 6, 16, 32, 32, 16, torch.nn.Tanh, 0.0),
+    ([1, 2, 4], 5, 32, 32, 32, 30, torch.nn.Tanh, 0.25),
+    ([3, 1], 4, 12, 64, 32, 12, torch.nn.ReLU, 0.1),
+    ([2], 3, 700, 32, 64, 40, None, 0.3),            # (graph_size beyond the dense kernels' 128)
+])
+def test_sparse_stepwise_cached_chain_vs_oracle(hops, B, N, F, H, T, act, p_skip):
+    """x [B, 1, F] per call from hidden = None: every call on the caches (one launch + the state advance), the
+    backward as one launch at the chain's gate.  Against the oracle called the same way: state bit exact, beliefs
+    and parameter gradients inside the float64 bound (3x the reference formulation's own fp32 error); and against
+    this module's general path (both GraphConv layers over every stored node)."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    obs, taus, weight, ref = _stepwise_case(hops, B, N, F, H, T, act, p_skip, seed=len(hops) * 100 + B)
+    out32, hid32, g32 = _oracle_stepwise(ref, obs, taus, weight, hops, N, torch.float32)
+    out64, _, g64 = _oracle_stepwise(ref, obs, taus, weight, hops, N, torch.float64)
+    g = dev_sparse_gnn(ref, F, H, act)
+    results = {}
+    for cache in (True, False):
+        mem = SparseGCM(g, edge_selectors=TemporalEdge(hops), graph_size=N)
+        mem.stepwise_cache = cache
+        g.zero_grad(set_to_none=True)
+        hid, outs = None, []
+        for t in range(T):
+            o, hid = mem(obs[t].to(DEV), taus[t].to(DEV), hid)
+            outs.append(o)
+        if cache:
+            assert mem._chain.steps() == T and mem._chain.live()
+        else:
+            assert mem._chain is None
+        (torch.stack(outs) * weight.to(DEV)).sum().backward()
+        results[cache] = (torch.stack(outs).detach().cpu(), hid, {k: p.grad.cpu() for k, p in g.named_parameters()})
+    got, hid, grads = results[True]
+    atol_o = max(2e-6, 3.0 * float((out32.double() - out64).abs().max()))
+    assert float((got.double() - out64).abs().max()) <= atol_o
+    assert torch.equal(hid[0].cpu(), hid32[0])
+    assert torch.equal(hid[1].coalesce().indices().cpu(), hid32[1].coalesce().indices())
+    assert torch.equal(hid[1].coalesce().values().cpu(), hid32[1].coalesce().values())
+    assert torch.equal(hid[2].cpu(), hid32[2])
+    for k, want in g64.items():
+        err_ref = float((g32[k].double() - want).abs().max())
+        atol = max(3.0 * err_ref, 5e-7 * float(want.abs().max()))
+        assert float((grads[k].double() - want).abs().max()) <= atol, k
+    # the general path of this module: same beliefs to 1e-5, same state bit for bit
+    base, hid_b, _ = results[False]
+    torch.testing.assert_close(got, base, rtol=1e-5, atol=1e-5)
+    assert torch.equal(hid[0], hid_b[0]) and torch.equal(hid[2], hid_b[2])
+    assert torch.equal(hid[1].coalesce().indices(), hid_b[1].coalesce().indices())
+
+
+def test_sparse_stepwise_cached_chain_ends_and_restarts():
+    """What ends a chain on the caches: a fork (the previous state handed in again), a parameter written in place,
+    a call with more than one node; the calls behind it run the general path and stay correct; hidden = None or
+    get_initial_hidden_state() starts a new one.  Two backward passes over one chain (retain_graph)."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    hops, B, N, F, H, T = [1, 2], 4, 16, 32, 32, 10
+    obs, taus, weight, ref = _stepwise_case(hops, B, N, F, H, T, torch.nn.Tanh, 0.0, seed=7)
+    out32, _, g32 = _oracle_stepwise(ref, obs, taus, weight, hops, N, torch.float32)
+    g = dev_sparse_gnn(ref, F, H, torch.nn.Tanh)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge(hops), graph_size=N)
+    one = torch.ones(B, dtype=torch.long, device=DEV)
+
+    def run(hid, t0, t1, outs):
+        for t in range(t0, t1):
+            o, hid = mem(obs[t].to(DEV), one, hid)
+            outs.append(o)
+        return hid
+
+    # fork: step 4 evaluated twice from the same state; the second evaluation and everything behind it is general
+    outs = []
+    hid = run(mem.get_initial_hidden_state(obs[0].to(DEV)), 0, 4, outs)
+    assert mem._chain.steps() == 4
+    o_a, hid_a = mem(obs[4].to(DEV), one, hid)
+    assert mem._chain.steps() == 5
+    o_b, hid_b = mem(obs[4].to(DEV), one, hid)
+    assert not mem._chain.live()
+    torch.testing.assert_close(o_a, o_b, rtol=1e-5, atol=1e-6)
+    outs.append(o_b)
+    hid = run(hid_b, 5, T, outs)
+    assert not mem._chain.live()
+    loss = (torch.stack(outs) * weight.to(DEV)).sum()
+    loss.backward(retain_graph=True)
+    first = {k: p.grad.clone() for k, p in g.named_parameters()}
+    torch.testing.assert_close(torch.stack(outs).detach().cpu(), out32, rtol=1e-5, atol=1e-5)
+    for k, p in g.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), g32[k], rtol=1e-4, atol=1e-5 * float(g32[k].abs().max()), msg=k)
+    loss.backward()                                     # a second pass over the same records: gradients add up
+    for k, p in g.named_parameters():
+        torch.testing.assert_close(p.grad, 2 * first[k], rtol=1e-5, atol=1e-6, msg=k)
+    g.zero_grad(set_to_none=True)
+
+    # a parameter written in place mid-chain: the cached rows of h1 are stale - the chain ends there
+    outs = []
+    hid = run(None, 0, 3, outs)
+    assert mem._chain.live() and mem._chain.steps() == 3
+    with torch.no_grad():
+        next(g.parameters()).mul_(1.0)
+    hid = run(hid, 3, 5, outs)
+    assert not mem._chain.live()
+    torch.testing.assert_close(torch.stack(outs).detach().cpu(), out32[:5], rtol=1e-5, atol=1e-5)
+    # several nodes in one call: general path; a new chain from None afterwards
+    x2 = torch.cat([obs[5], obs[6]], 1).to(DEV)
+    o2, hid = mem(x2, 2 * one, hid)
+    torch.testing.assert_close(o2.detach().cpu(), torch.cat([out32[5], out32[6]], 1), rtol=1e-5, atol=1e-5)
+    run(None, 0, 2, [])
+    assert mem._chain.live() and mem._chain.steps() == 2
+    # no_grad calls ride on the caches too (no records)
+    with torch.no_grad():
+        outs = []
+        run(None, 0, T, outs)
+    assert mem._chain.steps() == T
+    torch.testing.assert_close(torch.stack(outs).cpu(), out32, rtol=1e-5, atol=1e-5)
