@@ -202,6 +202,83 @@ __global__ __launch_bounds__(256) void k_temporal_count(const int64_t* __restric
   for (int b = lo; b < hi; ++b) edge_off[b] = cnt[b] + chunk_sum[threadIdx.x];
 }
 
+// SparseGCM called one node at a time (x [B, 1, F]): everything a call plans, in ONE launch instead of three and a
+// pointer rebuild - k_sparse_plan's offsets / totals, k_temporal_count's edge offsets, T + taus, and the per-graph
+// pointer of the merged COO list (old_bptr + edge offsets: the list only ever grows behind each graph's stored
+// entries, so the pointer of the state a chain hands on needs no k_ptr_from_sorted over the entries).
+// out: node_off [B+1] | new_off [B+1] | edge_off [B+1] | totals [4]  (the layout sparse_temporal_step reads back)
+__device__ __forceinline__ int64_t temporal_count_of(int64_t t0, int64_t tau, const Hops16& hops, int n_hops) {
+  int64_t c = 0;
+  for (int i = 0; i < n_hops; ++i) {
+    const int64_t h = hops.h[i];
+    if (h < 0) continue;
+    const int64_t first = (h > 1 ? h : 1) > t0 ? (h > 1 ? h : 1) : t0;
+    const int64_t n = t0 + tau - first;
+    c += n > 0 ? n : 0;
+  }
+  return c;
+}
+__global__ __launch_bounds__(256) void k_sparse_step_plan(const int64_t* __restrict__ T,
+                                                          const int64_t* __restrict__ taus, Hops16 hops,
+                                                          int n_hops, const int64_t* __restrict__ old_bptr,
+                                                          int64_t* __restrict__ out, int64_t* __restrict__ T_out,
+                                                          int64_t* __restrict__ merged_bptr, int B) {
+  __shared__ int64_t sW[4][5];   // per wave: sum n, sum tau, sum edges, max n, max tau
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int per = (B + 255) / 256;
+  const int lo = min(B, tid * per), hi = min(B, lo + per);
+  int64_t* node_off = out;
+  int64_t* new_off = out + (B + 1);
+  int64_t* edge_off = new_off + (B + 1);
+  int64_t* totals = edge_off + (B + 1);
+  int64_t a = 0, c = 0, e = 0, ma = 0, mc = 0;
+  for (int b = lo; b < hi; ++b) {
+    const int64_t t0 = T[b], tau = taus[b] > 0 ? taus[b] : 0;
+    a += t0 + taus[b];
+    c += taus[b];
+    e += temporal_count_of(t0, tau, hops, n_hops);
+    ma = t0 + taus[b] > ma ? t0 + taus[b] : ma;
+    mc = taus[b] > mc ? taus[b] : mc;
+  }
+  int64_t ia = a, ic = c, ie = e;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    ia += shfl_up_i64(ia, d, lane);
+    ic += shfl_up_i64(ic, d, lane);
+    ie += shfl_up_i64(ie, d, lane);
+    const int64_t oa = shfl_xor_i64(ma, d), oc = shfl_xor_i64(mc, d);
+    ma = oa > ma ? oa : ma;
+    mc = oc > mc ? oc : mc;
+  }
+  if (lane == 63) { sW[wave][0] = ia; sW[wave][1] = ic; sW[wave][2] = ie; sW[wave][3] = ma; sW[wave][4] = mc; }
+  __syncthreads();
+  int64_t ba = 0, bc = 0, be = 0, ta = 0, tc = 0, te = 0, xa = 0, xc = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) { ba += sW[w][0]; bc += sW[w][1]; be += sW[w][2]; }
+    ta += sW[w][0]; tc += sW[w][1]; te += sW[w][2];
+    xa = sW[w][3] > xa ? sW[w][3] : xa;
+    xc = sW[w][4] > xc ? sW[w][4] : xc;
+  }
+  if (tid == 0) {
+    node_off[B] = ta; new_off[B] = tc; edge_off[B] = te;
+    totals[0] = ta; totals[1] = tc; totals[2] = xa; totals[3] = xc;
+    if (merged_bptr) merged_bptr[B] = (old_bptr ? old_bptr[B] : 0) + te;
+  }
+  a = ba + ia - a;   // exclusive prefixes of this thread's first graph
+  c = bc + ic - c;
+  e = be + ie - e;
+  for (int b = lo; b < hi; ++b) {
+    const int64_t t0 = T[b], tau = taus[b] > 0 ? taus[b] : 0;
+    node_off[b] = a; new_off[b] = c; edge_off[b] = e;
+    if (merged_bptr) merged_bptr[b] = (old_bptr ? old_bptr[b] : 0) + e;
+    if (T_out) T_out[b] = t0 + taus[b];
+    a += t0 + taus[b];
+    c += taus[b];
+    e += temporal_count_of(t0, tau, hops, n_hops);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_temporal_fill(const int64_t* __restrict__ T,
                                                        const int64_t* __restrict__ taus,
                                                        Hops16 hops, int n_hops,
@@ -453,6 +530,17 @@ extern "C" int gcm_sparse_temporal_count(const int64_t* T, const int64_t* taus,
   hipLaunchKernelGGL(k_temporal_count, dim3(1), dim3(256), (size_t)B * sizeof(int64_t),
                      (hipStream_t)stream, T, taus, pack_hops(hops_host, n_hops), n_hops, edge_off,
                      B);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_step_plan(const int64_t* T, const int64_t* taus, const int32_t* hops_host, int n_hops,
+                                    const int64_t* old_bptr, int64_t* plan, int64_t* T_out, int64_t* merged_bptr,
+                                    int B, gcm_stream_t stream) {
+  GCM_REQUIRE(T && taus && hops_host && plan && B > 0 && n_hops > 0);
+  if (n_hops > 16) return GCM_EUNSUPPORTED;
+  for (int i = 1; i < n_hops; ++i) GCM_REQUIRE(hops_host[i] < hops_host[i - 1]);
+  hipLaunchKernelGGL(k_sparse_step_plan, dim3(1), dim3(256), 0, (hipStream_t)stream, T, taus,
+                     pack_hops(hops_host, n_hops), n_hops, old_bptr, plan, T_out, merged_bptr, B);
   return gcm_launch_status();
 }
 

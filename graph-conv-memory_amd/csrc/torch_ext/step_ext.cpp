@@ -1594,6 +1594,7 @@ struct SparseCachedStepNode : public torch::autograd::Node {
 struct SparseChain {
   std::shared_ptr<SparseChainGate> gate;
   at::Tensor packed, wimg, cH, cA, cX;
+  at::Tensor bptr;                           // per-graph pointer [B+1] of the COO list the previous call returned
   at::Tensor last_nodes, last_idx, last_T;   // the state the previous call returned (kept alive: its addresses
                                              // cannot be handed out again while the chain is armed)
   c10::TensorImpl* pkeys[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1605,7 +1606,7 @@ struct SparseChain {
   void drop() {
     live = false;
     gate.reset();
-    packed = wimg = cH = cA = cX = last_nodes = last_idx = last_T = at::Tensor();
+    packed = wimg = cH = cA = cX = bptr = last_nodes = last_idx = last_T = at::Tensor();
   }
   bool same_params(const at::Tensor* const* ps) const {
     for (int i = 0; i < 6; ++i) {
@@ -1693,13 +1694,28 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   int64_t* new_off = node_off + (B + 1);
   int64_t* edge_off = new_off + (B + 1);
   int64_t* totals = edge_off + (B + 1);   // follows edge_off[B]: the five numbers read back are contiguous
-  check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
-        "gcm_sparse_plan");
   std::vector<int32_t> hops(hops_desc.begin(), hops_desc.end());
-  check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
-                                  edge_off, (int)B, st),
-        "gcm_sparse_temporal_count");
-  at::Tensor host = plan.narrow(0, 3 * (B + 1) - 1, 5).cpu();   // edge_off[B] | M | n_new | max_total | max_tau
+  at::Tensor T_out, bptr_out;
+  if (cached) {   // one launch: offsets, edge offsets, T + taus, the merged list's per-graph pointer
+    T_out = at::empty_like(T);
+    bptr_out = at::empty({B + 1}, iopt);
+    check(gcm_sparse_step_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                               ch->bptr.defined() ? ch->bptr.data_ptr<int64_t>() : nullptr, node_off,
+                               T_out.data_ptr<int64_t>(), bptr_out.data_ptr<int64_t>(), (int)B, st),
+          "gcm_sparse_step_plan");
+  } else {
+    check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
+          "gcm_sparse_plan");
+    check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                    edge_off, (int)B, st),
+          "gcm_sparse_temporal_count");
+  }
+  // edge_off[B] | M | n_new | max_total | max_tau  -> a pinned host buffer (no pageable staging copy)
+  static at::Tensor pinned;
+  if (!pinned.defined()) pinned = at::empty({8}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+  at::Tensor host = pinned.narrow(0, 0, 5);
+  host.copy_(plan.narrow(0, 3 * (B + 1) - 1, 5), /*non_blocking=*/true);
+  c10::hip::getCurrentHIPStream(x.get_device()).synchronize();
   const int64_t* hv = host.data_ptr<int64_t>();
   const int64_t Eb = hv[0], M = hv[1], max_total = hv[3];
   if (max_total > N) return pybind11::int_(1);
@@ -1714,23 +1730,29 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   check(gcm_sparse_temporal_fill(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
                                  edge_off, idx_new.data_ptr<int64_t>(), Eb, (int)B, st),
         "gcm_sparse_temporal_fill");
-  at::Tensor idx;
+  at::Tensor idx, vals;
   if (Ea == 0) {
     idx = idx_new;
   } else if (Eb == 0) {
     idx = adj_idx;
   } else {
-    at::Tensor old_bptr = at::empty({B + 1}, iopt);
-    check(gcm_ptr_from_sorted(adj_idx.data_ptr<int64_t>(), old_bptr.data_ptr<int64_t>(), Ea, B, st),
-          "gcm_ptr_from_sorted");
+    at::Tensor old_bptr;
+    if (cached && ch->bptr.defined()) {
+      old_bptr = ch->bptr;   // (kept by the chain: gcm_sparse_step_plan)
+    } else {
+      old_bptr = at::empty({B + 1}, iopt);
+      check(gcm_ptr_from_sorted(adj_idx.data_ptr<int64_t>(), old_bptr.data_ptr<int64_t>(), Ea, B, st),
+            "gcm_ptr_from_sorted");
+    }
     idx = at::empty({3, Ea + Eb}, iopt);
+    vals = at::empty({Ea + Eb}, x.options());   // (unit weights: the merge writes them as it goes)
     check(gcm_coo_merge_segments(adj_idx.data_ptr<int64_t>(), idx_new.data_ptr<int64_t>(), nullptr, nullptr,
-                                 old_bptr.data_ptr<int64_t>(), edge_off, idx.data_ptr<int64_t>(), nullptr, nullptr,
-                                 fl, Ea, Eb, (int)B, st),
+                                 old_bptr.data_ptr<int64_t>(), edge_off, idx.data_ptr<int64_t>(),
+                                 vals.data_ptr<float>(), nullptr, fl, Ea, Eb, (int)B, st),
           "gcm_coo_merge_segments");
   }
   const int64_t E = idx.size(1);
-  at::Tensor vals = at::ones({E}, x.options());
+  if (!vals.defined()) vals = at::ones({E}, x.options());
   if (cached) {
     // ---- the new node's belief from the caches; the record; the chain's gate
     size_t lay[5];
@@ -1763,7 +1785,7 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
       node->add_next_edge(torch::autograd::Edge(ch->gate, 0));
       torch::autograd::create_gradient_edge(mx, node);
     }
-    at::Tensor T_out = T + taus;
+    ch->bptr = bptr_out;
     ch->last_nodes = nodes_out; ch->last_idx = idx; ch->last_T = T_out;
     ch->vers_nodes = nodes_out._version(); ch->vers_T = T_out._version();
     ++ch->steps;
@@ -1829,8 +1851,19 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     if (x_.requires_grad() || nodes_.requires_grad()) torch::autograd::create_gradient_edge(nodes_out, node);
     else node->add_input_metadata(torch::autograd::Node::undefined_input{});
   }
-  at::Tensor T_out = T + taus;
+  T_out = T + taus;
   return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out);
+}
+
+// The device flag word through a pinned host buffer (Tensor.item() stages through pageable memory: about twice
+// the latency, and this is on the path of every SparseGCM call with finite_check = "sync").
+int64_t read_flag_word(const at::Tensor& flags) {
+  TORCH_CHECK(flags.is_cuda() && flags.numel() == 1 && flags.scalar_type() == at::kInt);
+  static at::Tensor pinned;
+  if (!pinned.defined()) pinned = at::empty({1}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+  pinned.copy_(flags, /*non_blocking=*/true);
+  c10::hip::getCurrentHIPStream(flags.get_device()).synchronize();
+  return (int64_t)(uint32_t)pinned.data_ptr<int32_t>()[0];
 }
 
 }  // namespace
@@ -1872,4 +1905,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("live", [](SparseChain& c) { return c.live; })
       .def("drop", &SparseChain::drop);
   m.def("sparse_temporal_step", &sparse_temporal_step);
+  m.def("read_flag_word", &read_flag_word);
 }

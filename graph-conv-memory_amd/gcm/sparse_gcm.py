@@ -240,7 +240,12 @@ class SparseGCM(torch.nn.Module):
 
     def _check_flags(self, flags):
         if self.finite_check == "sync":
-            bits = int(flags.item())
+            fast = self._fast_plan
+            if fast and flags.is_cuda and flags.device.index == torch.cuda.current_device():
+                from . import _ext
+                bits = _ext.module().read_flag_word(flags)
+            else:
+                bits = int(flags.item())
             if bits:
                 flags.zero_()
             assert not bits & _hip.FLAG_MERGE_ORDER, \

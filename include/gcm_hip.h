@@ -195,6 +195,15 @@ int gcm_sparse_insert_bwd(const float* g_nodes_out, const int64_t* T, const int6
                           float* g_nodes_in, float* g_x, int B, int N, int F, int t_pad,
                           gcm_stream_t stream);
 
+/* SparseGCM called one node at a time (sparse_gcm.py:72-212 with x [B, 1, F]; ray_sparse_gcm.py's rollout loop):
+ * everything such a call plans, in ONE launch - gcm_sparse_plan (util.py:176-208), gcm_sparse_temporal_count
+ * (sparse_edge_selectors/temporal.py:18-63), T + taus (sparse_gcm.py:211), and the per-graph pointer of the merged
+ * COO list.  plan: node_off [B+1] | new_off [B+1] | edge_off [B+1] | totals [4] {M, n_new, max_total, max_tau}.
+ * old_bptr [B+1] (NULL: an empty list): per-graph pointer of the stored list; merged_bptr [B+1] (may be NULL) =
+ * old_bptr + edge_off.  T_out [B] (may be NULL) = T + taus.  hops_host: HOST array, strictly descending. */
+int gcm_sparse_step_plan(const int64_t* T, const int64_t* taus, const int32_t* hops_host, int n_hops,
+                         const int64_t* old_bptr, int64_t* plan, int64_t* T_out, int64_t* merged_bptr, int B,
+                         gcm_stream_t stream);
 /* sparse_edge_selectors/temporal.py:18-63, closed form.  hops_host: HOST array, must be
  * sorted DESCENDING and unique (so that sources ascend inside a sink: coalesced order).
  * count: edge_off[b] = number of edges of graphs < b, [B+1].

@@ -251,6 +251,57 @@ def test_cfg4_sparse_full_size_one_shot():
     assert torch.equal(h2[1].coalesce().indices(), hid[1].coalesce().indices())
 
 
+def test_cfg4_sparse_full_size_stepwise_on_the_caches():
+    """cfg4 called one node at a time (bench.py's stepwise leg: x [B, 1, F] x 512 calls from hidden = None, every
+    call on the chain's caches - gcm_sparse_step_cached - and ONE backward launch at the chain's gate): closed
+    forms of the state, and beliefs + parameter gradients of a slice of graphs against the oracle called the same
+    way (float64-bounded: 3x the reference formulation's own fp32 error)."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    from test_sparse_gpu import _oracle_stepwise
+    B, N, F, H, T = 512, 512, 32, 32, 512
+    torch.manual_seed(11)
+    ref = osp.canonical_gnn(F, H)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(H, H), "x, edges, weights -> x"), torch.nn.Tanh()])
+    g.load_state_dict(ref.state_dict())
+    g = g.to(DEV)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1]), graph_size=N)
+    x = torch.rand(T, B, 1, F)
+    x_d = x.to(DEV)
+    one = torch.ones(B, dtype=torch.long, device=DEV)
+    pick = [0, 300, 511]
+    w = torch.linspace(0.5, 1.5, T * len(pick) * H).view(T, len(pick), 1, H)
+    hid, outs = None, []
+    for t in range(T):
+        o, hid = mem(x_d[t], one, hid)
+        outs.append(o)
+    assert mem._chain.steps() == T and mem._chain.live()
+    out = torch.stack(outs)
+    (out[:, pick] * w.to(DEV)).sum().backward()
+    # closed forms
+    idx = hid[1].coalesce().indices().cpu()
+    assert idx.shape[1] == B * (N - 1)
+    want_sink = torch.arange(1, N).repeat(B)
+    assert torch.equal(idx[0], torch.arange(B).repeat_interleave(N - 1))
+    assert torch.equal(idx[1], want_sink) and torch.equal(idx[2], want_sink - 1)
+    assert torch.equal(hid[2].cpu(), torch.full((B,), T)) and torch.equal(hid[0].cpu(), x[:, :, 0].transpose(0, 1))
+    assert bool((hid[1].coalesce().values() == 1).all())
+    # the slice against the oracle
+    taus = torch.ones(T, len(pick), dtype=torch.long)
+    out32, _, g32 = _oracle_stepwise(ref, x[:, pick], taus, w, [1], N, torch.float32)
+    out64, _, g64 = _oracle_stepwise(ref, x[:, pick], taus, w, [1], N, torch.float64)
+    got = out[:, pick].detach().cpu()
+    torch.testing.assert_close(got, out32, rtol=1e-5, atol=1e-6)
+    assert float((got.double() - out64).abs().max()) <= max(2e-6, 3.0 * float((out32.double() - out64).abs().max()))
+    for k, p in g.named_parameters():
+        want = g64[k]
+        atol = max(3.0 * float((g32[k].double() - want).abs().max()), 5e-7 * float(want.abs().max()))
+        err = float((p.grad.cpu().double() - want).abs().max())
+        assert err <= atol, (k, err, atol)
+
+
 # --------------------------------------------------------------------------------------------------
 # The path bench.py times: the per-step loop on the LIVE-ROW kernels (k_step_rows + k_bptt_rows; obs
 # without gradient, as in the reference's tests/test_speed.py:44-63), functional and donated state,
