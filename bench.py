@@ -802,6 +802,9 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
     if not args.headline_only:
         # (two warm-up rollouts: the caching allocator sees the 512 growing sizes of a rollout once before the clock starts)
         variants["stepwise_taus1_x%d" % n_sw] = world * B * n_sw * 3 / timed(stepwise, 3, 2)
+        mem.stepwise_cache = False     # (A/B: every call runs both GraphConv layers over every stored node)
+        variants["stepwise_taus1_x%d_general_path" % n_sw] = world * B * n_sw * 2 / timed(stepwise, 2, 1)
+        mem.stepwise_cache = True
     if rank != 0:
         return
     fwd_ms, E, M = time_csr_kernels(c)
@@ -815,7 +818,10 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
                    "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": N,
                    "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
         "variants": {k: round(v, 1) for k, v in variants.items()},
-        "variants_note": "stepwise: the same episodes one node per call (taus = 1, %d calls) + one backward" % n_sw,
+        "variants_note": "stepwise: the same episodes one node per call (taus = 1, %d calls from hidden = None) + one "
+                         "backward, default settings (finite_check = 'sync'): every call on the chain's caches "
+                         "(gcm_sparse_step_cached: the new node's rows alone; one time-parallel backward launch per "
+                         "chain); _general_path: the same with stepwise_cache = False" % n_sw,
         "roofline": {"bound": "hbm", "kernel": "k_csr_fwd3", "achieved": alg / (fwd_ms * 1e-3) / 1e9,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      "traffic": traffic.get("k_csr_fwd3"), "bytes_per_launch": alg, "avg_launch_ms": fwd_ms,

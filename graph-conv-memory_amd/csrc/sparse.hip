@@ -623,6 +623,60 @@ __global__ void k_coo_merge(const int64_t* __restrict__ old_idx, const int64_t* 
   if (perm) perm[pos] = e;
 }
 
+// A call of a one-node-per-call chain (gcm_sparse_step_plan): TemporalEdge's new entries (sparse_edge_selectors/
+// temporal.py:18-63: sink T[b], sources T[b] - h ascending) generated straight into their places of the merged
+// list (sparse_gcm.py:132-139: stored entries of graph b, then its new ones) - k_temporal_fill + k_coo_merge as one
+// launch, with the number of new entries read on the DEVICE (plan: edge_off[B]) so that the host can enqueue the
+// whole call before it reads any size back.  One thread per slot of the upper bound Ea + max_new; rows of the
+// output are E = Ea + edge_off[B] apart.  Unit weights written alongside.
+__global__ void k_chain_edges(const int64_t* __restrict__ old_idx, const int64_t* __restrict__ old_bptr,
+                              const int64_t* __restrict__ edge_off, const int64_t* __restrict__ T,
+                              const int64_t* __restrict__ taus, Hops16 hops, int n_hops,
+                              int64_t* __restrict__ out_idx, float* __restrict__ out_val, int64_t Ea, int B) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t Eb = edge_off[B], E = Ea + Eb;
+  if (e >= E) return;
+  int64_t b, snk, src, pos;
+  if (e < Ea) {
+    b = old_idx[e]; snk = old_idx[Ea + e]; src = old_idx[2 * Ea + e];
+    pos = e + edge_off[b];
+  } else {
+    const int64_t j = e - Ea;
+    int lo = 0, hi = B;                 // the graph with edge_off[b] <= j < edge_off[b + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (edge_off[mid] <= j) lo = mid; else hi = mid;
+    }
+    b = lo;
+    int64_t k = j - edge_off[b];        // its k-th new entry: one new node (taus in {0, 1}), hops descending
+    const int64_t t = T[b];
+    snk = t; src = -1;
+    for (int i = 0; i < n_hops; ++i) {
+      const int64_t h = hops.h[i];
+      if (h < 0 || t - h < 0 || t <= 0) continue;
+      if (k == 0) { src = t - h; break; }
+      --k;
+    }
+    pos = j + (old_bptr ? old_bptr[b + 1] : 0);
+  }
+  out_idx[pos] = b; out_idx[E + pos] = snk; out_idx[2 * E + pos] = src;
+  out_val[pos] = 1.f;
+}
+
+extern "C" int gcm_sparse_chain_edges(const int64_t* old_idx, const int64_t* old_bptr, const int64_t* plan,
+                                      const int64_t* T, const int64_t* taus, const int32_t* hops_host, int n_hops,
+                                      int64_t* out_idx, float* out_val, int64_t Ea, int64_t max_new, int B,
+                                      gcm_stream_t stream) {
+  GCM_REQUIRE(plan && T && taus && hops_host && out_idx && out_val && (old_idx || Ea == 0) && (old_bptr || Ea == 0));
+  GCM_REQUIRE(Ea >= 0 && max_new >= 0 && B > 0 && n_hops > 0);
+  if (n_hops > 16) return GCM_EUNSUPPORTED;
+  if (Ea + max_new == 0) return GCM_OK;
+  hipLaunchKernelGGL(k_chain_edges, dim3((unsigned)((Ea + max_new + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     old_idx, old_bptr, plan + 2 * (size_t)(B + 1), T, taus, pack_hops(hops_host, n_hops), n_hops,
+                     out_idx, out_val, Ea, B);
+  return gcm_launch_status();
+}
+
 extern "C" int gcm_coo_merge_segments(const int64_t* old_idx, const int64_t* new_idx,
                                       const float* old_val, const float* new_val,
                                       const int64_t* old_bptr, const int64_t* new_bptr,

@@ -1544,6 +1544,15 @@ struct SparseChainGate : public torch::autograd::Node {
     pass = -2;
     if (!mine || rs.empty()) return out;
     const int n = (int)rs.size();
+    // incoming gradients [B, 1, H2]: by their own strides when every step's agree (slices of one stacked tensor,
+    // expanded scalars), else as contiguous copies
+    bool same = true;
+    for (int i = 0; i < n; ++i)
+      same = same && gs[i].scalar_type() == at::kFloat && gs[i].dim() == 3 && gs[i].stride(0) == gs[0].stride(0) &&
+             gs[i].stride(2) == gs[0].stride(2);
+    if (!same)
+      for (int i = 0; i < n; ++i) gs[i] = gs[i].to(at::kFloat).contiguous();
+    const long sb = (long)gs[0].stride(0), sh = (long)gs[0].stride(2);
     std::vector<const float*> sv(n), gm(n);
     for (int i = 0; i < n; ++i) { sv[i] = rs[i].data_ptr<float>(); gm[i] = gs[i].data_ptr<float>(); }
     const gcm_stream_t st =
@@ -1551,7 +1560,7 @@ struct SparseChainGate : public torch::autograd::Node {
     const size_t wsb = gcm_dense_rows_bptt_workspace_bytes(n, B, F, H1, H2);
     at::Tensor ws = at::empty({(int64_t)wsb}, packed.options().dtype(at::kByte));
     at::Tensor res = at::empty({packed.numel()}, packed.options());
-    check(gcm_dense_rows_bptt_cached(sv.data(), gm.data(), n, (long)H2, 1L, packed.data_ptr<float>(),
+    check(gcm_dense_rows_bptt_cached(sv.data(), gm.data(), n, sb, sh, packed.data_ptr<float>(),
                                      (has_b1 ? 1 : 0) | (has_b2 ? 2 : 0), act1, act2, cX.data_ptr<float>(),
                                      cH.data_ptr<float>(), cA.data_ptr<float>(), nullptr, res.data_ptr<float>(),
                                      ws.data_ptr(), wsb, B, N, F, H1, H2, st),
@@ -1580,7 +1589,7 @@ struct SparseCachedStepNode : public torch::autograd::Node {
     if (!grads[0].defined()) return out;
     gate->begin_pass_if_new();
     gate->recs.push_back(rec);
-    gate->gms.push_back(grads[0].to(at::kFloat).contiguous());
+    gate->gms.push_back(grads[0]);   // (as it comes - usually a slice of the caller's stacked beliefs: read by strides)
     if (!gate->gave) {
       out[0] = gate->kick;
       gate->gave = true;
@@ -1631,7 +1640,8 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
                                       const at::Tensor& w_rel1, const c10::optional<at::Tensor>& b1,
                                       const at::Tensor& w_root1, int act1, const at::Tensor& w_rel2,
                                       const c10::optional<at::Tensor>& b2, const at::Tensor& w_root2, int act2,
-                                      const at::Tensor& flags, pybind11::object chain_obj, bool fresh) {
+                                      const at::Tensor& flags, pybind11::object chain_obj, bool fresh,
+                                      bool want_flags) {
   TORCH_CHECK(x_.is_cuda() && taus.is_cuda() && nodes_.is_cuda() && T.is_cuda() && flags.is_cuda(),
               "sparse step: every tensor must live on a HIP device (no CPU fallback)");
   at::Tensor x = x_.contiguous(), nodes = nodes_.contiguous(), adj_idx = adj_idx_.contiguous();
@@ -1688,84 +1698,68 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     }
     if (!cached && ch->live) ch->drop();
   }
-  // ---- plan: node offsets, edge offsets; the one readback
+  std::vector<int32_t> hops(hops_desc.begin(), hops_desc.end());
+  // (sizes and the flag word come back through a pinned host buffer: no pageable staging copy)
+  static at::Tensor pinned, pinned_fl;
+  if (!pinned.defined()) {
+    pinned = at::empty({8}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    pinned_fl = at::empty({1}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+  }
+  at::Tensor host = pinned.narrow(0, 0, 5);   // edge_off[B] | M | n_new | max_total | max_tau
+  const int64_t* hv = host.data_ptr<int64_t>();
   at::Tensor plan = at::empty({3 * (B + 1) + 4}, iopt);
   int64_t* node_off = plan.data_ptr<int64_t>();
-  int64_t* new_off = node_off + (B + 1);
-  int64_t* edge_off = new_off + (B + 1);
-  int64_t* totals = edge_off + (B + 1);   // follows edge_off[B]: the five numbers read back are contiguous
-  std::vector<int32_t> hops(hops_desc.begin(), hops_desc.end());
-  at::Tensor T_out, bptr_out;
-  if (cached) {   // one launch: offsets, edge offsets, T + taus, the merged list's per-graph pointer
-    T_out = at::empty_like(T);
-    bptr_out = at::empty({B + 1}, iopt);
-    check(gcm_sparse_step_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
-                               ch->bptr.defined() ? ch->bptr.data_ptr<int64_t>() : nullptr, node_off,
-                               T_out.data_ptr<int64_t>(), bptr_out.data_ptr<int64_t>(), (int)B, st),
-          "gcm_sparse_step_plan");
-  } else {
-    check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
-          "gcm_sparse_plan");
-    check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
-                                    edge_off, (int)B, st),
-          "gcm_sparse_temporal_count");
-  }
-  // edge_off[B] | M | n_new | max_total | max_tau  -> a pinned host buffer (no pageable staging copy)
-  static at::Tensor pinned;
-  if (!pinned.defined()) pinned = at::empty({8}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-  at::Tensor host = pinned.narrow(0, 0, 5);
-  host.copy_(plan.narrow(0, 3 * (B + 1) - 1, 5), /*non_blocking=*/true);
-  c10::hip::getCurrentHIPStream(x.get_device()).synchronize();
-  const int64_t* hv = host.data_ptr<int64_t>();
-  const int64_t Eb = hv[0], M = hv[1], max_total = hv[3];
-  if (max_total > N) return pybind11::int_(1);
-  at::Tensor node_off_t = plan.narrow(0, 0, B + 1);
-  // ---- insert, edges, merge
-  at::Tensor nodes_out = at::empty_like(nodes);
-  check(gcm_sparse_insert_fwd(nodes.data_ptr<float>(), x.data_ptr<float>(), T.data_ptr<int64_t>(),
-                              taus.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), fl, (int)B, (int)N, (int)F,
-                              (int)t_pad, st),
-        "gcm_sparse_insert_fwd");
-  at::Tensor idx_new = at::empty({3, Eb}, iopt);
-  check(gcm_sparse_temporal_fill(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
-                                 edge_off, idx_new.data_ptr<int64_t>(), Eb, (int)B, st),
-        "gcm_sparse_temporal_fill");
-  at::Tensor idx, vals;
-  if (Ea == 0) {
-    idx = idx_new;
-  } else if (Eb == 0) {
-    idx = adj_idx;
-  } else {
-    at::Tensor old_bptr;
-    if (cached && ch->bptr.defined()) {
-      old_bptr = ch->bptr;   // (kept by the chain: gcm_sparse_step_plan)
-    } else {
-      old_bptr = at::empty({B + 1}, iopt);
-      check(gcm_ptr_from_sorted(adj_idx.data_ptr<int64_t>(), old_bptr.data_ptr<int64_t>(), Ea, B, st),
-            "gcm_ptr_from_sorted");
-    }
-    idx = at::empty({3, Ea + Eb}, iopt);
-    vals = at::empty({Ea + Eb}, x.options());   // (unit weights: the merge writes them as it goes)
-    check(gcm_coo_merge_segments(adj_idx.data_ptr<int64_t>(), idx_new.data_ptr<int64_t>(), nullptr, nullptr,
-                                 old_bptr.data_ptr<int64_t>(), edge_off, idx.data_ptr<int64_t>(),
-                                 vals.data_ptr<float>(), nullptr, fl, Ea, Eb, (int)B, st),
-          "gcm_coo_merge_segments");
-  }
-  const int64_t E = idx.size(1);
-  if (!vals.defined()) vals = at::ones({E}, x.options());
+
   if (cached) {
-    // ---- the new node's belief from the caches; the record; the chain's gate
+    // ---- a call of the chain: five launches enqueued back to back, ONE readback at the end (sizes + flag word).
+    //      The COO list is written into a buffer sized by the bound B * |hops| on the new entries (its rows E
+    //      apart, E read on the device) and narrowed to the exact size afterwards.
+    const int64_t max_new = B * (int64_t)hops.size();
+    at::Tensor T_out = at::empty_like(T), bptr_out = at::empty({B + 1}, iopt);
+    const int64_t* old_bptr = ch->bptr.defined() ? ch->bptr.data_ptr<int64_t>() : nullptr;
+    TORCH_CHECK(Ea == 0 || old_bptr, "sparse chain: the stored list has no pointer");
+    check(gcm_sparse_step_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                               old_bptr, node_off, T_out.data_ptr<int64_t>(), bptr_out.data_ptr<int64_t>(), (int)B, st),
+          "gcm_sparse_step_plan");
+    // (the new node's rows first: they need the plan's inputs only - so that the sizes AND the flag word are on their
+    //  way back while the state's copy and the COO list are still being written)
     size_t lay[5];
     check(gcm_dense_rows_cached_layout((int)B, (int)N, (int)F, (int)H1, (int)H2, lay), "gcm_dense_rows_cached_layout");
     at::Tensor rec = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, x.options());
     at::Tensor mx = at::empty({B, t_pad, H2}, x.options());
-    std::vector<int32_t> hp(hops_desc.begin(), hops_desc.end());
-    check(gcm_sparse_step_cached(x.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hp.data(),
-                                 (int)hp.size(), ch->packed.data_ptr<float>(), ch->wimg.data_ptr<float>(), act1, act2,
+    check(gcm_sparse_step_cached(x.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(),
+                                 (int)hops.size(), ch->packed.data_ptr<float>(), ch->wimg.data_ptr<float>(), act1, act2,
                                  ch->cH.data_ptr<float>(), ch->cA.data_ptr<float>(), ch->cX.data_ptr<float>(),
                                  mx.data_ptr<float>(), rec.data_ptr<float>(), need_bwd ? 1 : 0, fl, (int)B, (int)N,
                                  (int)F, (int)H1, (int)H2, st),
           "gcm_sparse_step_cached");
+    host.copy_(plan.narrow(0, 3 * (B + 1) - 1, 5), /*non_blocking=*/true);
+    if (want_flags) pinned_fl.copy_(flags, /*non_blocking=*/true);
+    static hipEvent_t sizes_ready = nullptr;
+    if (!sizes_ready)
+      TORCH_CHECK(hipEventCreateWithFlags(&sizes_ready, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    TORCH_CHECK(hipEventRecord(sizes_ready, (hipStream_t)st) == hipSuccess, "hipEventRecord failed");
+    at::Tensor nodes_out = at::empty_like(nodes);
+    check(gcm_sparse_insert_fwd(nodes.data_ptr<float>(), x.data_ptr<float>(), T.data_ptr<int64_t>(),
+                                taus.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), fl, (int)B, (int)N, (int)F,
+                                (int)t_pad, st),
+          "gcm_sparse_insert_fwd");
+    at::Tensor idx_buf = at::empty({3 * (Ea + max_new)}, iopt), val_buf = at::empty({Ea + max_new}, x.options());
+    check(gcm_sparse_chain_edges(Ea ? adj_idx.data_ptr<int64_t>() : nullptr, old_bptr, node_off,
+                                 T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                 idx_buf.data_ptr<int64_t>(), val_buf.data_ptr<float>(), Ea, max_new, (int)B, st),
+          "gcm_sparse_chain_edges");
+    // the sizes and the flag word: as soon as the first two launches have retired - the others run on while the
+    // host builds the outputs, returns and prepares the next call
+    TORCH_CHECK(hipEventSynchronize(sizes_ready) == hipSuccess, "hipEventSynchronize failed");
+    const int64_t Eb = hv[0], max_total = hv[3], E = Ea + Eb;
+    if (max_total > N || Eb > max_new) {   // sparse_gcm.py:120-121 (every kernel above is bounds-checked)
+      c10::hip::getCurrentHIPStream(x.get_device()).synchronize();
+      ch->drop();
+      flags.zero_();
+      return pybind11::int_(1);
+    }
+    at::Tensor idx = idx_buf.narrow(0, 0, 3 * E).view({3, E}), vals = val_buf.narrow(0, 0, E);
     if (need_bwd) {
       if (!ch->gate) {
         auto g = std::shared_ptr<SparseChainGate>(new SparseChainGate(), torch::autograd::deleteNode);
@@ -1789,8 +1783,52 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     ch->last_nodes = nodes_out; ch->last_idx = idx; ch->last_T = T_out;
     ch->vers_nodes = nodes_out._version(); ch->vers_T = T_out._version();
     ++ch->steps;
-    return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out);
+    const int64_t bits = want_flags ? (int64_t)(uint32_t)pinned_fl.data_ptr<int32_t>()[0] : -1;
+    return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out, bits);
   }
+
+  // ---- plan: node offsets, edge offsets; the one readback
+  int64_t* new_off = node_off + (B + 1);
+  int64_t* edge_off = new_off + (B + 1);
+  int64_t* totals = edge_off + (B + 1);   // follows edge_off[B]: the five numbers read back are contiguous
+  check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
+        "gcm_sparse_plan");
+  check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                  edge_off, (int)B, st),
+        "gcm_sparse_temporal_count");
+  host.copy_(plan.narrow(0, 3 * (B + 1) - 1, 5), /*non_blocking=*/true);
+  c10::hip::getCurrentHIPStream(x.get_device()).synchronize();
+  const int64_t Eb = hv[0], M = hv[1], max_total = hv[3];
+  if (max_total > N) return pybind11::int_(1);
+  at::Tensor node_off_t = plan.narrow(0, 0, B + 1);
+  // ---- insert, edges, merge
+  at::Tensor nodes_out = at::empty_like(nodes);
+  check(gcm_sparse_insert_fwd(nodes.data_ptr<float>(), x.data_ptr<float>(), T.data_ptr<int64_t>(),
+                              taus.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), fl, (int)B, (int)N, (int)F,
+                              (int)t_pad, st),
+        "gcm_sparse_insert_fwd");
+  at::Tensor idx_new = at::empty({3, Eb}, iopt);
+  check(gcm_sparse_temporal_fill(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                 edge_off, idx_new.data_ptr<int64_t>(), Eb, (int)B, st),
+        "gcm_sparse_temporal_fill");
+  at::Tensor idx, vals;
+  if (Ea == 0) {
+    idx = idx_new;
+  } else if (Eb == 0) {
+    idx = adj_idx;
+  } else {
+    at::Tensor old_bptr = at::empty({B + 1}, iopt);
+    check(gcm_ptr_from_sorted(adj_idx.data_ptr<int64_t>(), old_bptr.data_ptr<int64_t>(), Ea, B, st),
+          "gcm_ptr_from_sorted");
+    idx = at::empty({3, Ea + Eb}, iopt);
+    vals = at::empty({Ea + Eb}, x.options());   // (unit weights: the merge writes them as it goes)
+    check(gcm_coo_merge_segments(adj_idx.data_ptr<int64_t>(), idx_new.data_ptr<int64_t>(), nullptr, nullptr,
+                                 old_bptr.data_ptr<int64_t>(), edge_off, idx.data_ptr<int64_t>(),
+                                 vals.data_ptr<float>(), nullptr, fl, Ea, Eb, (int)B, st),
+          "gcm_coo_merge_segments");
+  }
+  const int64_t E = idx.size(1);
+  if (!vals.defined()) vals = at::ones({E}, x.options());
   // ---- flat node matrix, CSR, the two layers, the new rows
   at::Tensor flat = at::empty({M, F}, x.options());
   check(gcm_sparse_flatten_fwd(nodes_out.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
@@ -1851,8 +1889,8 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     if (x_.requires_grad() || nodes_.requires_grad()) torch::autograd::create_gradient_edge(nodes_out, node);
     else node->add_input_metadata(torch::autograd::Node::undefined_input{});
   }
-  T_out = T + taus;
-  return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out);
+  at::Tensor T_out = T + taus;
+  return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out, (int64_t)-1);   // (-1: flag word not read)
 }
 
 // The device flag word through a pinned host buffer (Tensor.item() stages through pageable memory: about twice

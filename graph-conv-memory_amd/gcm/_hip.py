@@ -100,6 +100,7 @@ PROTOTYPES = {
     "gcm_dense_rows_cached_supported": (_I, [_P, _I, _I, _I, _I, _I, _I]),
     "gcm_dense_rows_cached_layout": (_I, [_I] * 5 + [_P]),
     "gcm_sparse_step_plan": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "gcm_sparse_chain_edges": (_I, [_P] * 6 + [_I, _P, _P, _L, _L, _I, _P]),
     "gcm_sparse_step_cached": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _P] + [_I] * 5 + [_P]),
     "gcm_debug_time_cached_rollout": (_I, [_P] * 5 + [_I, _P, _P, _I, _I, _I] + [_P] * 7 + [_I] * 6 + [_P]),
     "gcm_dense_rows_cached_weight_image": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -171,14 +171,23 @@ class SparseGCM(torch.nn.Module):
                 if chain is None:
                     from . import _ext
                     chain = self._chain = _ext.module().SparseChain()
-            r = fn(x, taus, nodes, adj.indices(), T, hops, c1.lin_rel.weight, c1.lin_rel.bias, c1.lin_root.weight,
-                   a1, c2.lin_rel.weight, c2.lin_rel.bias, c2.lin_root.weight, a2, flags, chain, fresh)
+            # (current parameter tensors through the modules' own dicts: nn.Module.__getattr__ chains cost
+            #  ~0.5 us each and this runs every call)
+            try:
+                r1, t1, r2, t2 = (c1._modules["lin_rel"]._parameters, c1._modules["lin_root"]._parameters,
+                                  c2._modules["lin_rel"]._parameters, c2._modules["lin_root"]._parameters)
+                ws = (r1["weight"], r1["bias"], t1["weight"], r2["weight"], r2["bias"], t2["weight"])
+            except KeyError:       # (parametrized / re-registered weights: the attribute protocol)
+                ws = (c1.lin_rel.weight, c1.lin_rel.bias, c1.lin_root.weight,
+                      c2.lin_rel.weight, c2.lin_rel.bias, c2.lin_root.weight)
+            r = fn(x, taus, nodes, adj.indices(), T, hops, ws[0], ws[1], ws[2], a1, ws[3], ws[4], ws[5], a2,
+                   flags, chain, fresh, self.finite_check == "sync")
             if r == 1:                                         # sparse_gcm.py:120-121
                 raise Exception("Overflow")
-            mx_dense, nodes_out, idx, vals, T_out = r
+            mx_dense, nodes_out, idx, vals, T_out, bits = r
             vals.gcm_unit_weights = True
             adj_out = torch.sparse_coo_tensor(idx, vals, size=adj.shape, is_coalesced=True)
-            self._check_flags(flags)
+            self._check_flags(flags, bits)      # (bits >= 0: the flag word came back with the call's sizes)
             return mx_dense, (nodes_out, adj_out, T_out)
 
         node_off, _new_off, totals = _ops.sparse_plan(T, taus)
@@ -238,10 +247,12 @@ class SparseGCM(torch.nn.Module):
         self._check_flags(flags)
         return mx_dense, (nodes, adj, T + taus)
 
-    def _check_flags(self, flags):
+    def _check_flags(self, flags, bits=-1):
         if self.finite_check == "sync":
             fast = self._fast_plan
-            if fast and flags.is_cuda and flags.device.index == torch.cuda.current_device():
+            if bits >= 0:
+                pass
+            elif fast and flags.is_cuda and flags.device.index == torch.cuda.current_device():
                 from . import _ext
                 bits = _ext.module().read_flag_word(flags)
             else:

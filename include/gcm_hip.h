@@ -204,6 +204,16 @@ int gcm_sparse_insert_bwd(const float* g_nodes_out, const int64_t* T, const int6
 int gcm_sparse_step_plan(const int64_t* T, const int64_t* taus, const int32_t* hops_host, int n_hops,
                          const int64_t* old_bptr, int64_t* plan, int64_t* T_out, int64_t* merged_bptr, int B,
                          gcm_stream_t stream);
+/* A call of such a chain: TemporalEdge's new entries (sparse_edge_selectors/temporal.py:18-63; one new node per
+ * graph, taus in {0, 1}, every hop >= 1) generated straight into their places of the merged COO list
+ * (sparse_gcm.py:132-139) - gcm_sparse_temporal_fill + gcm_coo_merge_segments as one launch, the number of new
+ * entries read on the device (plan from gcm_sparse_step_plan), so that the host can enqueue the whole call before
+ * it reads any size back.  out_idx: 3 rows (batch, sink, source), E = Ea + plan.edge_off[B] apart, in a buffer of at
+ * least 3 * (Ea + max_new) elements; out_val [>= Ea + max_new]: unit weights.  max_new >= the new entries
+ * (B * n_hops bounds them). */
+int gcm_sparse_chain_edges(const int64_t* old_idx, const int64_t* old_bptr, const int64_t* plan, const int64_t* T,
+                           const int64_t* taus, const int32_t* hops_host, int n_hops, int64_t* out_idx,
+                           float* out_val, int64_t Ea, int64_t max_new, int B, gcm_stream_t stream);
 /* sparse_edge_selectors/temporal.py:18-63, closed form.  hops_host: HOST array, must be
  * sorted DESCENDING and unique (so that sources ascend inside a sink: coalesced order).
  * count: edge_off[b] = number of edges of graphs < b, [B+1].
