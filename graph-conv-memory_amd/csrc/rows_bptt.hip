@@ -69,7 +69,7 @@ template <int FP, int HP, int H2P, int MODE>
 __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
-    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn) {
+    int B, int N, int F, int H1, int H2, int deg_term, LrnSrc lrn, int wave_regions) {
   constexpr bool HIST = MODE == 1 || MODE == 2;   // (3: records of cached steps, rows in the chain's caches)
   constexpr int C1 = 2 * FP / 64, C2 = 2 * HP / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -78,26 +78,32 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   const int n_waves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
 
   // layer-2 weights, column m of W2c = [w_rel2 | w_root2] per lane: w2c[c][o]
+  // (every load issued before the first select: written as "load, then mask" in one loop the compiler sank each
+  //  load under its mask's branch and waited for it alone - 32 to 64 dependent round trips, ~20 us of a 50 us launch)
   float w2c[C2][H2P];
 #pragma unroll
   for (int c = 0; c < C2; ++c) {
     const int m = lane + 64 * c;
-    const bool ok = m < 2 * H1;
-    const int mc = ok ? m : 2 * H1 - 1;
+    const int mc = m < 2 * H1 ? m : 2 * H1 - 1;
     const float* src = mc < H1 ? w_rel2 + mc : w_root2 + (mc - H1);
 #pragma unroll
-    for (int o = 0; o < H2P; ++o) {
-      const float t = src[(size_t)(o < H2 ? o : H2 - 1) * H1];
-      w2c[c][o] = (ok && o < H2) ? t : 0.f;
-    }
+    for (int o = 0; o < H2P; ++o) w2c[c][o] = src[(size_t)(o < H2 ? o : H2 - 1) * H1];
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < C2; ++c) {
+    const bool ok = lane + 64 * c < 2 * H1;
+#pragma unroll
+    for (int o = 0; o < H2P; ++o) w2c[c][o] = (ok && o < H2) ? w2c[c][o] : 0.f;
   }
   float wr1c[MODE == 2 ? HP : 1];   // MODE 2: column `lane` of W_rel1
   if (MODE == 2) {
 #pragma unroll
-    for (int h = 0; h < HP; ++h) {
-      const float t = lrn.w_rel1[(size_t)(h < H1 ? h : H1 - 1) * F + (lane < F ? lane : F - 1)];
-      wr1c[MODE == 2 ? h : 0] = (h < H1 && lane < F) ? t : 0.f;
-    }
+    for (int h = 0; h < HP; ++h)
+      wr1c[MODE == 2 ? h : 0] = lrn.w_rel1[(size_t)(h < H1 ? h : H1 - 1) * F + (lane < F ? lane : F - 1)];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < HP; ++h) wr1c[MODE == 2 ? h : 0] = (h < H1 && lane < F) ? wr1c[MODE == 2 ? h : 0] : 0.f;
   }
   float acc1[C1][HP], acc2[C2][H2P];
 #pragma unroll
@@ -111,33 +117,177 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   float db1 = 0.f, db2 = 0.f;
   float dc1 = 0.f;   // deg_term: gradient of the folded preprocessor-bias vector (sum_l deg_l G1_l)
 
-#pragma unroll 1
-  for (int item = wid; item < items; item += n_waves) {
-    const int s = item / B, b = item - s * B;
-    const int oc = lane < H2 ? lane : H2 - 1;
-    // what differs between the two record sources: where the numbers of the item live
-    const float* sv = nullptr;
-    int L = 0, l_cur = 0, cur = 0;
-    unsigned long long m0 = 0, m1 = 0;   // HIST: live rows as two 64-bit masks
-    float a0 = 0.f, a1 = 0.f, g, y;
-    Hist src{};        // HIST: where the full layers of this item live
-    size_t gi = 0;     //       and the index of its graph in them
-    int n_live = 0;    // MODE 2: live rows handed on so far
-    float vv[C2];
-    if (!HIST) {
-      sv = tab.saved[s];
+  const int oc = lane < H2 ? lane : H2 - 1;
+  // layer 2 of an item: d2 = g act2'(y); dW2 += d2 (x) [agg2 | h1cur]; -> dagg2, dh1cur in lane h
+  auto layer2 = [&](float g, float y, const float (&vv)[C2], bool empty, float& dagg2, float& dh1c)
+      __attribute__((always_inline)) {
+    // (empty: the record of a graph that got no node this step - SparseGCM with taus[b] = 0 - whose zero padded
+    //  output row takes no gradient)
+    const float d2 = (lane < H2 && !empty) ? g * act_grad_sel(y, act2_v) : 0.f;   // d2 in lane o < H2
+    db2 += d2;
+    float u[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) u[c] = 0.f;
+#pragma unroll
+    for (int o = 0; o < H2P; ++o) {
+      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o));
+#pragma unroll
+      for (int c = 0; c < C2; ++c) {
+        u[c] = fmaf(w2c[c][o], d, u[c]);
+        acc2[c][o] = fmaf(d, vv[c], acc2[c][o]);
+      }
+    }
+    // dagg2[h] = u at column h, dh1cur[h] = u at column H1 + h: bring both to lane h
+    const int hh = lane < H1 ? lane : 0;
+    const int m1c = H1 + hh;
+    float t0 = __shfl(u[0], hh & 63), t1 = __shfl(u[0], m1c & 63);
+    if (C2 == 2) {
+      const float b1 = __shfl(u[C2 - 1], m1c & 63);
+      t1 = m1c >= 64 ? b1 : t1;
+    }
+    dagg2 = t0;
+    dh1c = t1;
+  };
+  // what a live row adds: G1_l = (coef_l dagg2 + [l = cur] dh1cur) * act1'(h1_l);  dW1 += G1_l (x) [agg1_l | x_l]
+  auto consume = [&](float cf, bool is_cur, float dagg2, float dh1c, float hv, const float (&ax)[C1], float dg,
+                     float& da_out) __attribute__((always_inline)) {
+    float g1 = (cf * dagg2 + (is_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
+    g1 = lane < H1 ? g1 : 0.f;
+    db1 += g1;
+    dc1 = fmaf(dg, g1, dc1);
+    float da = 0.f;
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
+#pragma unroll
+      for (int c = 0; c < C1; ++c) acc1[c][h] = fmaf(gh, ax[c], acc1[c][h]);
+      if (MODE == 2) da = fmaf(gh, wr1c[MODE == 2 ? h : 0], da);
+    }
+    da_out = da;
+  };
+
+  if (!HIST) {
+    // Records (MODE 0 / 3), software-pipelined ACROSS items and across the rows of an item.  An item's data hang on
+    // a chain of dependent loads - the record pointer, its header / row list, then the rows the list names - which
+    // a wave with eight items to do used to pay in full for every item and every row (~7 us per item at four live
+    // rows, two waves per SIMD to hide it).  Now: the "front" of item i + 1 (header, incoming gradient, y, v, the row
+    // list: coefficients, and for cached steps the row indices, lane l holding entries l and l + 64) is requested
+    // before item i is worked on; row l + 1 is requested before row l is consumed; and the first row of item
+    // i + 1 before the last row of item i.  Same items, same rows, same order of every sum.
+    struct Front {
+      const float* sv;
+      int b, hdr0, hdr1, ja, jb;
+      float g, y, vv[C2], cfa, cfb;
+    };
+    auto front = [&](int item, Front& f) __attribute__((always_inline)) {
+      const int s = item / B, b = item - s * B;
+      const float* sv = tab.saved[s];
+      f.sv = sv;
+      f.b = b;
       const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
-      L = __builtin_amdgcn_readfirstlane(hdr[0]);
-      l_cur = __builtin_amdgcn_readfirstlane(hdr[1]);
-      g = tab.gmx[s][(long)b * gmx_sb + (long)oc * gmx_sh];
-      y = sv[(size_t)b * H2 + oc];
+      f.hdr0 = hdr[0];
+      f.hdr1 = hdr[1];
+      f.g = tab.gmx[s][(long)b * gmx_sb + (long)oc * gmx_sh];
+      f.y = sv[(size_t)b * H2 + oc];
 #pragma unroll
       for (int c = 0; c < C2; ++c) {
         const int m = lane + 64 * c;
         const float t = sv[lay.o_v + (size_t)b * 2 * H1 + (m < 2 * H1 ? m : 2 * H1 - 1)];
-        vv[c] = m < 2 * H1 ? t : 0.f;
+        f.vv[c] = m < 2 * H1 ? t : 0.f;
       }
-    } else {
+      const int e0 = lane < N ? lane : N - 1, e1 = lane + 64 < N ? lane + 64 : N - 1;   // (entries >= L: unused)
+      f.cfa = sv[lay.o_coef + (size_t)b * N + e0];
+      f.cfb = sv[lay.o_coef + (size_t)b * N + e1];
+      f.ja = f.jb = 0;
+      if (MODE == 3) {
+        const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
+        f.ja = live[e0];
+        f.jb = live[e1];
+      }
+    };
+    auto fetch = [&](const Front& f, int l, float& hv, float (&ax)[C1], float& dg) __attribute__((always_inline)) {
+      dg = 0.f;
+      if (MODE == 3) {   // cached step: the row's h1 | agg1 | x from the chain's caches
+        const int j = l < 64 ? __builtin_amdgcn_readlane(f.ja, l & 63) : __builtin_amdgcn_readlane(f.jb, l & 63);
+        const size_t rj = (size_t)f.b * N + j;
+        hv = lrn.c_h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+          const int m = lane + 64 * c;
+          const int k = m < F ? m : (m - F < F ? m - F : F - 1);
+          const float t = m < F ? lrn.c_agg1[rj * F + k] : lrn.c_nodes[rj * F + k];
+          ax[c] = m < 2 * F ? t : 0.f;
+        }
+      } else {
+        const float* row = f.sv + lay.o_rows + ((size_t)f.b * N + l) * lay.rw;
+        if (deg_term) dg = f.sv[lay.o_deg + (size_t)f.b * N + l];
+        hv = row[lane < H1 ? lane : H1 - 1];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+          const int m = lane + 64 * c;
+          const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
+          ax[c] = m < 2 * F ? t : 0.f;
+        }
+      }
+    };
+    // (the row lists hold at most 128 entries: N <= 128 on the dense path, <= 17 selected rows on the sparse one)
+    auto coef_of = [&](const Front& f, int l) __attribute__((always_inline)) {
+      return __int_as_float(l < 64 ? __builtin_amdgcn_readlane(__float_as_int(f.cfa), l & 63)
+                                   : __builtin_amdgcn_readlane(__float_as_int(f.cfb), l & 63));
+    };
+    // one item: `cur` and its first row (hv0 / ax0 / dg0) are in registers; leaves `nxt` and ITS first row there.
+    // (Two fronts used in turn - the item loop below is unrolled by two with the roles swapped - so that nothing
+    //  is copied between them: a copy would wait for the loads it copies.)
+    auto step = [&](int item, Front& cur, float& hv0, float (&ax0)[C1], float& dg0, Front& nxt, float& hvN,
+                    float (&axN)[C1], float& dgN) __attribute__((always_inline)) {
+      const bool has_next = item + n_waves < items;
+      if (has_next) front(item + n_waves, nxt);
+      const int L = min(__builtin_amdgcn_readfirstlane(cur.hdr0), 128);
+      const int l_cur = __builtin_amdgcn_readfirstlane(cur.hdr1);
+      float dagg2, dh1c, unused;
+      layer2(cur.g, cur.y, cur.vv, MODE == 3 && L == 0, dagg2, dh1c);
+      float hvB = 0.f, axB[C1], dgB = 0.f;
+#pragma unroll
+      for (int c = 0; c < C1; ++c) axB[c] = 0.f;
+      // (the next item's first row: requested before this item's last row is consumed)
+      auto fetch_next0 = [&]() __attribute__((always_inline)) {
+        if (has_next && __builtin_amdgcn_readfirstlane(nxt.hdr0) > 0) fetch(nxt, 0, hvN, axN, dgN);
+      };
+      if (L == 0) fetch_next0();
+#pragma unroll 1
+      for (int l = 0; l < L; l += 2) {
+        const bool two = l + 1 < L;
+        if (two) fetch(cur, l + 1, hvB, axB, dgB);
+        else fetch_next0();
+        consume(coef_of(cur, l), l == l_cur, dagg2, dh1c, hv0, ax0, dg0, unused);
+        if (two) {
+          if (l + 2 < L) fetch(cur, l + 2, hv0, ax0, dg0);
+          else fetch_next0();
+          consume(coef_of(cur, l + 1), l + 1 == l_cur, dagg2, dh1c, hvB, axB, dgB, unused);
+        }
+      }
+    };
+    Front f0{}, f1{};
+    float hv0 = 0.f, ax0[C1], dg0 = 0.f, hv1 = 0.f, ax1[C1], dg1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) ax0[c] = ax1[c] = 0.f;
+    if (wid < items) {
+      front(wid, f0);
+      if (__builtin_amdgcn_readfirstlane(f0.hdr0) > 0) fetch(f0, 0, hv0, ax0, dg0);
+    }
+#pragma unroll 1
+    for (int item = wid; item < items; item += 2 * n_waves) {
+      step(item, f0, hv0, ax0, dg0, f1, hv1, ax1, dg1);
+      if (item + n_waves < items) step(item + n_waves, f1, hv1, ax1, dg1, f0, hv0, ax0, dg0);
+    }
+  } else {
+#pragma unroll 1
+    for (int item = wid; item < items; item += n_waves) {
+      const int s = item / B, b = item - s * B;
+      Hist src{};        // where the full layers of this item live
+      size_t gi = 0;     // and the index of its graph in them
+      int n_live = 0;    // MODE 2: live rows handed on so far
+      float g, vv[C2];
       if (MODE == 2) {   // this step's own buffer, per-graph indexing
         const float* base = tab.saved[s];
         src.adj = base + lrn.o_adj;
@@ -155,13 +305,13 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         g = hs.gmx[(long)s * hs.gmx_st + (long)b * gmx_sb + (long)oc * gmx_sh];
       }
       const int64_t c64 = src.cur[gi];
-      cur = __builtin_amdgcn_readfirstlane(c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64));
-      y = src.mx[gi * H2 + oc];
+      const int cur = __builtin_amdgcn_readfirstlane(c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : (int)c64));
+      const float y = src.mx[gi * H2 + oc];
       const float* arow = (MODE == 2 && lrn.adj_compact) ? src.adj + gi * N : src.adj + (gi * N + cur) * N;
-      a0 = arow[lane < N ? lane : N - 1];
-      a1 = arow[lane + 64 < N ? lane + 64 : N - 1];
-      m0 = __ballot(lane < N && (a0 != 0.f || lane == cur));
-      m1 = __ballot(lane + 64 < N && (a1 != 0.f || lane + 64 == cur));
+      const float a0 = arow[lane < N ? lane : N - 1];
+      const float a1 = arow[lane + 64 < N ? lane + 64 : N - 1];
+      unsigned long long m0 = __ballot(lane < N && (a0 != 0.f || lane == cur));       // live rows as two 64-bit masks
+      unsigned long long m1 = __ballot(lane + 64 < N && (a1 != 0.f || lane + 64 == cur));
 #pragma unroll
       for (int c = 0; c < C2; ++c) {
         const int m = lane + 64 * c;
@@ -169,75 +319,17 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         const float t = m < H1 ? src.agg2[gi * H1 + k] : src.h1[(gi * N + cur) * H1 + k];
         vv[c] = m < 2 * H1 ? t : 0.f;
       }
-    }
-    // (MODE 3, L = 0: the empty record of a graph that got no node this step - SparseGCM with taus[b] = 0 - whose
-    //  zero padded output row takes no gradient)
-    const float d2 = (lane < H2 && !(MODE == 3 && L == 0)) ? g * act_grad_sel(y, act2_v) : 0.f;   // d2 in lane o < H2
-    db2 += d2;
-    float u[C2];
-#pragma unroll
-    for (int c = 0; c < C2; ++c) u[c] = 0.f;
-#pragma unroll
-    for (int o = 0; o < H2P; ++o) {
-      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o));
-#pragma unroll
-      for (int c = 0; c < C2; ++c) {
-        u[c] = fmaf(w2c[c][o], d, u[c]);
-        acc2[c][o] = fmaf(d, vv[c], acc2[c][o]);
-      }
-    }
-    // dagg2[h] = u at column h, dh1cur[h] = u at column H1 + h: bring both to lane h
-    float dagg2, dh1c;
-    {
-      const int hh = lane < H1 ? lane : 0;
-      const int m1c = H1 + hh;
-      float t0 = __shfl(u[0], hh & 63), t1 = __shfl(u[0], m1c & 63);
-      if (C2 == 2) {
-        const float b1 = __shfl(u[C2 - 1], m1c & 63);
-        t1 = m1c >= 64 ? b1 : t1;
-      }
-      dagg2 = t0;
-      dh1c = t1;
-    }
-    // the live rows
+      float dagg2, dh1c;
+      layer2(g, y, vv, false, dagg2, dh1c);
 #pragma unroll 1
-    for (int l = 0;; ++l) {
-      float cf, hv, ax[C1], dg = 0.f;
-      bool is_cur;
-      if (!HIST) {
-        if (l >= L) break;
-        cf = sv[lay.o_coef + (size_t)b * N + l];
-        is_cur = l == l_cur;
-        if (MODE == 3) {   // cached step: the row's h1 | agg1 | x from the chain's caches
-          const int j = reinterpret_cast<const int*>(sv + lay.o_live)[(size_t)b * N + l];
-          const size_t rj = (size_t)b * N + j;
-          hv = lrn.c_h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
-#pragma unroll
-          for (int c = 0; c < C1; ++c) {
-            const int m = lane + 64 * c;
-            const int f = m < F ? m : (m - F < F ? m - F : F - 1);
-            const float t = m < F ? lrn.c_agg1[rj * F + f] : lrn.c_nodes[rj * F + f];
-            ax[c] = m < 2 * F ? t : 0.f;
-          }
-        } else {
-          const float* row = sv + lay.o_rows + ((size_t)b * N + l) * lay.rw;
-          if (deg_term) dg = sv[lay.o_deg + (size_t)b * N + l];
-          hv = row[lane < H1 ? lane : H1 - 1];
-#pragma unroll
-          for (int c = 0; c < C1; ++c) {
-            const int m = lane + 64 * c;
-            const float t = row[H1 + (m < 2 * F ? m : 2 * F - 1)];
-            ax[c] = m < 2 * F ? t : 0.f;
-          }
-        }
-      } else {
+      for (;;) {
         if (!(m0 | m1)) break;
         const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
         if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
-        cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? a0 : a1), j & 63));
-        is_cur = j == cur;
+        const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? a0 : a1), j & 63));
         const size_t rj = gi * N + j;
-        hv = src.h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
+        float ax[C1], da;
+        const float hv = src.h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
 #pragma unroll
         for (int c = 0; c < C1; ++c) {
           const int m = lane + 64 * c;
@@ -246,31 +338,20 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
           ax[c] = m < 2 * F ? t : 0.f;
         }
         if (MODE == 2 && lane == 0) lrn.live[((size_t)(lrn.s0 + s) * B + b) * N + n_live] = j;
+        consume(cf, j == cur, dagg2, dh1c, hv, ax, 0.f, da);
+        if (MODE == 2) {   // dAgg1_l, column `lane`
+          if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;
+          ++n_live;
+        }
       }
-      float g1 = (cf * dagg2 + (is_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
-      g1 = lane < H1 ? g1 : 0.f;
-      db1 += g1;
-      dc1 = fmaf(dg, g1, dc1);
-      float da = 0.f;
-#pragma unroll
-      for (int h = 0; h < HP; ++h) {
-        const float gh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), h));
-#pragma unroll
-        for (int c = 0; c < C1; ++c) acc1[c][h] = fmaf(gh, ax[c], acc1[c][h]);
-        if (MODE == 2) da = fmaf(gh, wr1c[MODE == 2 ? h : 0], da);
+      if (MODE == 2) {
+        const size_t it = (size_t)(lrn.s0 + s) * B + b;
+        if (lane == 0) {
+          lrn.hdr[2 * it] = cur;
+          lrn.hdr[2 * it + 1] = n_live;
+        }
+        if (lane < H1) lrn.dagg2[it * H1 + lane] = dagg2;
       }
-      if (MODE == 2) {   // dAgg1_l, column `lane`
-        if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;
-        ++n_live;
-      }
-    }
-    if (MODE == 2) {
-      const size_t it = (size_t)(lrn.s0 + s) * B + b;
-      if (lane == 0) {
-        lrn.hdr[2 * it] = cur;
-        lrn.hdr[2 * it + 1] = n_live;
-      }
-      if (lane < H1) lrn.dagg2[it * H1 + lane] = dagg2;
     }
   }
 
@@ -282,6 +363,41 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   const int P = P0 + (deg_term ? H1 : 0);
   const int o_root1 = H1 * F, o_b1 = 2 * H1 * F, o_rel2 = o_b1 + H1, o_root2 = o_rel2 + H2 * H1;
   const int o_b2 = o_root2 + H2 * H1;
+  // wave_regions: each wave lays its registers down in a region of its own (plain stores, nothing to wait for), one
+  // barrier, then every thread adds the four regions of its elements in the order the waves used to add themselves,
+  // ((w0 + w1) + w2) + w3 - the same sums bit for bit.  Otherwise (shapes whose four regions would not leave room
+  // for two workgroups per CU) the waves take turns on one region: 64+ read-modify-writes per lane, four times over.
+  float* slab = slabs + (size_t)blockIdx.x * P;
+  if (wave_regions) {
+    float* mine = sSlab + (size_t)wave * P;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+      const int m = lane + 64 * c;
+      if (m < 2 * F) {
+        const int base = m < F ? m : o_root1 + (m - F);
+#pragma unroll
+        for (int h = 0; h < HP; ++h)
+          if (h < H1) mine[base + h * F] = acc1[c][h];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {
+      const int m = lane + 64 * c;
+      if (m < 2 * H1) {
+        const int base = m < H1 ? o_rel2 + m : o_root2 + (m - H1);
+#pragma unroll
+        for (int o = 0; o < H2P; ++o)
+          if (o < H2) mine[base + o * H1] = acc2[c][o];
+      }
+    }
+    if (lane < H1) mine[o_b1 + lane] = db1;
+    if (lane < H2) mine[o_b2 + lane] = db2;
+    if (deg_term && lane < H1) mine[P0 + lane] = dc1;
+    __syncthreads();
+    for (int e = tid; e < P; e += 256)
+      slab[e] = ((sSlab[e] + sSlab[P + e]) + sSlab[2 * P + e]) + sSlab[3 * (size_t)P + e];
+    return;
+  }
 #pragma unroll 1
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
@@ -317,9 +433,9 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     }
     __syncthreads();
   }
-  float* slab = slabs + (size_t)blockIdx.x * P;
   for (int e = tid; e < P; e += 256) slab[e] = sSlab[e];
 }
+
 
 template <int FP, int HP, int H2P, int MODE>
 int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, int n_steps, long sb, long sh,
@@ -327,11 +443,13 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
                 const SavedLayout& lay, float* slabs, int B, int N, int F, int H1, int H2,
                 int deg_term = 0, const LrnSrc& lrn = LrnSrc{}) {
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
-  const size_t lds = sizeof(float) * P;
+  // (one LDS region per wave while four of them leave room for two workgroups per CU: see the kernel's tail)
+  const int wave_regions = sizeof(float) * P * 4 <= 80 * 1024 ? 1 : 0;
+  const size_t lds = sizeof(float) * P * (wave_regions ? 4 : 1);
   auto kern = k_bptt_rows<FP, HP, H2P, MODE>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,
-                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn);
+                     act2, lay, slabs, B, N, F, H1, H2, deg_term, lrn, wave_regions);
   return gcm_launch_status();
 }
 

@@ -1735,7 +1735,10 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
           "gcm_sparse_step_cached");
     host.copy_(plan.narrow(0, 3 * (B + 1) - 1, 5), /*non_blocking=*/true);
     if (want_flags) pinned_fl.copy_(flags, /*non_blocking=*/true);
-    static hipEvent_t sizes_ready = nullptr;
+    static hipEvent_t events[64] = {};   // one per device (an event belongs to the device it was created on)
+    const int dev_i = (int)x.get_device();
+    TORCH_CHECK(dev_i >= 0 && dev_i < 64, "sparse chain: device index out of range");
+    hipEvent_t& sizes_ready = events[dev_i];
     if (!sizes_ready)
       TORCH_CHECK(hipEventCreateWithFlags(&sizes_ready, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
     TORCH_CHECK(hipEventRecord(sizes_ready, (hipStream_t)st) == hipSuccess, "hipEventRecord failed");

@@ -42,3 +42,29 @@ for donate in (True, False):
         m = [sum(r[i] for r in res) / len(res) for i in range(5)]
         print(f"donate={donate!s:5} grad={grad!s:5}  fwd issue {m[0] / T * 1e6:6.2f} us/step, done {m[1] / T * 1e6:6.2f} us/step"
               + (f" | stack+mean {m[2] * 1e6:6.0f} us, backward issue {m[3] * 1e6:6.0f} us, done {m[4] * 1e6:6.0f} us" if grad else ""))
+
+# what the caller's own loop costs (no module call): obs[t] + list append
+res = []
+for it in range(6):
+    t0 = time.perf_counter()
+    outs = []
+    for t in range(T):
+        outs.append(obs[t])
+    res.append(time.perf_counter() - t0)
+print(f"caller's loop alone (obs[t] + append): {min(res) / T * 1e6:.2f} us/step")
+xs = [obs[t] for t in range(T)]
+for donate in (True, False):
+    mem, gnn, _ = bench.build_memory(dev, donate=donate)
+    res = []
+    for it in range(8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hidden, outs = None, []
+        for x in xs:
+            mx, hidden = mem(x, hidden)
+            outs.append(mx)
+        res.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        torch.stack(outs).mean().backward()
+        gnn.zero_grad(set_to_none=True)
+    print(f"donate={donate!s:5} pre-indexed observations: fwd issue {min(res[3:]) / T * 1e6:.2f} us/step")
