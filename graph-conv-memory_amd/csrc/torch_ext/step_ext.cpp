@@ -695,9 +695,11 @@ struct RowsFast {
     const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
     const bool need_bwd = node != nullptr;
     if (cached_steps == 0) {
-      cH = at::zeros({B, N, H1}, obs.options());
-      cA = at::zeros({B, N, F}, obs.options());
-      cX = at::zeros({B, N, F}, obs.options());
+      // (no zero fill: forward and backward read a row only behind a select on "written before" - three 4 MB fill
+      //  launches per chain were 2 % of a graph-replayed cfg2 rollout)
+      cH = at::empty({B, N, H1}, obs.options());
+      cA = at::empty({B, N, F}, obs.options());
+      cX = at::empty({B, N, F}, obs.options());
       if (node) { node->cH = cH; node->cA = cA; node->cX = cX; node->descs = cfg->descs; }
       // the weights lane-major, once per chain (the parameters are fixed inside one)
       wimg = at::empty({4 * 64 * 64}, obs.options());
