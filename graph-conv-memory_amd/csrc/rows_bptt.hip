@@ -166,6 +166,154 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     da_out = da;
   };
 
+  // ---- records at F = H1 = 32 (cfg2 / cfg4 / cfg5's GNN): the rank-1 updates on the matrix cores ----------------
+  // dW1 += G1_l (x) [agg1_l | x_l] over the live rows is a [32 x rows] . [rows x 64] product: rows are taken in
+  // PAIRS - lanes 0-31 hold row l, lanes 32-63 row l + 1 (k = 0 / 1 of v_mfma_f32_32x32x2_f32) - as two MFMAs per
+  // pair (the agg1 block, the x block) instead of 2 x 64 v_readlane + v_fma; layer 2's d2 (x) [agg2 | h1cur] as two
+  // MFMAs per item with d2 masked to one half each.  The VALU form executes ~875 instructions per item and was
+  // issue-bound at two waves per SIMD.  Same pipelining as below (front of item i + 1 ahead of item i, pair p + 1
+  // ahead of pair p, the next item's first pair ahead of this item's last).
+  if (!HIST && FP == 32 && HP == 32 && H2P == 32 && F == 32 && H1 == 32 && wave_regions) {
+    const int q = lane & 31, half = lane >> 5;
+    const int ocq = q < H2 ? q : H2 - 1;
+    struct FrontM {
+      const float* sv;
+      int b, hdr0, hdr1, ja, jb;
+      float g, y, vv, cfa, cfb;
+    };
+    auto front = [&](int item, FrontM& f) __attribute__((always_inline)) {
+      const int s = item / B, b = item - s * B;
+      const float* sv = tab.saved[s];
+      f.sv = sv;
+      f.b = b;
+      const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+      f.hdr0 = hdr[0];
+      f.hdr1 = hdr[1];
+      f.g = tab.gmx[s][(long)b * gmx_sb + (long)ocq * gmx_sh];   // (both halves: d2 replicated)
+      f.y = sv[(size_t)b * H2 + ocq];
+      f.vv = sv[lay.o_v + (size_t)b * 64 + lane];                // agg2 [32] | h1cur [32]
+      const int e0 = lane < N ? lane : N - 1, e1 = lane + 64 < N ? lane + 64 : N - 1;   // (entries >= L: unused)
+      f.cfa = sv[lay.o_coef + (size_t)b * N + e0];
+      f.cfb = sv[lay.o_coef + (size_t)b * N + e1];
+      f.ja = f.jb = 0;
+      if (MODE == 3) {
+        const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
+        f.ja = live[e0];
+        f.jb = live[e1];
+      }
+    };
+    auto rl = [&](int v, int l) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(v, l & 63); };
+    // the pair (l, l + 1): h1 | agg1 | x of row l + half, element q (an absent second row: the first one's, masked)
+    auto fetch = [&](const FrontM& f, int l, int L, float& hv, float& ag, float& xx, float& dg)
+        __attribute__((always_inline)) {
+      const int l1 = l + 1 < L ? l + 1 : l;
+      dg = 0.f;
+      if (MODE == 3) {
+        const int j0 = l < 64 ? rl(f.ja, l) : rl(f.jb, l), j1 = l1 < 64 ? rl(f.ja, l1) : rl(f.jb, l1);
+        const size_t rj = ((size_t)f.b * N + (half ? j1 : j0)) * 32 + q;
+        hv = lrn.c_h1[rj];
+        ag = lrn.c_agg1[rj];
+        xx = lrn.c_nodes[rj];
+      } else {
+        const float* row = f.sv + lay.o_rows + ((size_t)f.b * N + (half ? l1 : l)) * lay.rw;
+        if (deg_term) dg = f.sv[lay.o_deg + (size_t)f.b * N + (half ? l1 : l)];
+        hv = row[q];
+        ag = row[32 + q];
+        xx = row[64 + q];
+      }
+    };
+    f32x16 aR, aT, a2r, a2t;   // dW_rel1 | dW_root1 | dW_rel2 | dW_root2 tiles: [out = acc row][in = q]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aR[r] = 0.f; aT[r] = 0.f; a2r[r] = 0.f; a2t[r] = 0.f; }
+    float db1p = 0.f, dc1p = 0.f, db2p = 0.f;   // per lane: halves (and for db2 the replica) met at the end
+    auto step = [&](int item, FrontM& cur, float& hv0, float& ag0, float& xx0, float& dg0, FrontM& nxt, float& hvN,
+                    float& agN, float& xxN, float& dgN) __attribute__((always_inline)) {
+      const bool has_next = item + n_waves < items;
+      if (has_next) front(item + n_waves, nxt);
+      const int L = min(__builtin_amdgcn_readfirstlane(cur.hdr0), 128);
+      const int l_cur = __builtin_amdgcn_readfirstlane(cur.hdr1);
+      // layer 2: d2 in BOTH halves; u = [w_rel2 | w_root2]^T d2 on the VALU (a matrix-vector product)
+      const float d2 = (q < H2 && !(MODE == 3 && L == 0)) ? cur.g * act_grad_sel(cur.y, act2_v) : 0.f;
+      db2p += d2;
+      float u = 0.f;
+#pragma unroll
+      for (int o = 0; o < 32; ++o)
+        u = fmaf(w2c[0][o], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o)), u);
+      a2r = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : d2, cur.vv, a2r, 0, 0, 0);   // d2 (x) agg2
+      a2t = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? d2 : 0.f, cur.vv, a2t, 0, 0, 0);   // d2 (x) h1cur
+      const float dagg2 = __shfl(u, q), dh1c = __shfl(u, 32 + q);   // (in both halves)
+      auto fetch_next0 = [&]() __attribute__((always_inline)) {
+        if (has_next) {
+          const int Ln = min(__builtin_amdgcn_readfirstlane(nxt.hdr0), 128);
+          if (Ln > 0) fetch(nxt, 0, Ln, hvN, agN, xxN, dgN);
+        }
+      };
+      auto consume = [&](int l, float hv, float ag, float xx, float dg) __attribute__((always_inline)) {
+        const int l1 = l + 1;
+        const float c0 = __int_as_float(l < 64 ? rl(__float_as_int(cur.cfa), l) : rl(__float_as_int(cur.cfb), l));
+        const float c1 = __int_as_float(l1 < 64 ? rl(__float_as_int(cur.cfa), l1) : rl(__float_as_int(cur.cfb), l1));
+        const int lm = l + half;
+        float g1 = ((half ? c1 : c0) * dagg2 + (lm == l_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
+        g1 = lm < L ? g1 : 0.f;
+        db1p += g1;
+        dc1p = fmaf(dg, g1, dc1p);
+        aR = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, ag, aR, 0, 0, 0);
+        aT = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xx, aT, 0, 0, 0);
+      };
+      float hvB = 0.f, agB = 0.f, xxB = 0.f, dgB = 0.f;
+      if (L == 0) fetch_next0();
+#pragma unroll 1
+      for (int l = 0; l < L; l += 4) {
+        const bool two = l + 2 < L;
+        if (two) fetch(cur, l + 2, L, hvB, agB, xxB, dgB);
+        else fetch_next0();
+        consume(l, hv0, ag0, xx0, dg0);
+        if (two) {
+          if (l + 4 < L) fetch(cur, l + 4, L, hv0, ag0, xx0, dg0);
+          else fetch_next0();
+          consume(l + 2, hvB, agB, xxB, dgB);
+        }
+      }
+    };
+    FrontM f0{}, f1{};
+    float hv0 = 0.f, ag0 = 0.f, xx0 = 0.f, dg0 = 0.f, hv1 = 0.f, ag1 = 0.f, xx1 = 0.f, dg1 = 0.f;
+    if (wid < items) {
+      front(wid, f0);
+      const int L0 = min(__builtin_amdgcn_readfirstlane(f0.hdr0), 128);
+      if (L0 > 0) fetch(f0, 0, L0, hv0, ag0, xx0, dg0);
+    }
+#pragma unroll 1
+    for (int item = wid; item < items; item += 2 * n_waves) {
+      step(item, f0, hv0, ag0, xx0, dg0, f1, hv1, ag1, xx1, dg1);
+      if (item + n_waves < items) step(item + n_waves, f1, hv1, ag1, xx1, dg1, f0, hv0, ag0, xx0, dg0);
+    }
+    // ---- the wave's tiles into its LDS region, the four regions summed in fixed order (as below) -------------
+    extern __shared__ float sSlabM[];
+    const int P0m = 2 * 32 * 32 + 32 + 2 * H2 * 32 + H2;
+    const int Pm = P0m + (deg_term ? 32 : 0);
+    const int m_root1 = 32 * 32, m_b1 = 2 * 32 * 32, m_rel2 = m_b1 + 32, m_root2 = m_rel2 + H2 * 32, m_b2 = m_root2 + H2 * 32;
+    float* mine = sSlabM + (size_t)wave * Pm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row of a 32x32 tile
+      mine[i * 32 + q] = aR[r];
+      mine[m_root1 + i * 32 + q] = aT[r];
+      if (i < H2) {
+        mine[m_rel2 + i * 32 + q] = a2r[r];
+        mine[m_root2 + i * 32 + q] = a2t[r];
+      }
+    }
+    const float db1m = db1p + __shfl_xor(db1p, 32), dc1m = dc1p + __shfl_xor(dc1p, 32);
+    if (lane < 32) mine[m_b1 + lane] = db1m;
+    if (lane < H2) mine[m_b2 + lane] = db2p;
+    if (deg_term && lane < 32) mine[P0m + lane] = dc1m;
+    __syncthreads();
+    float* slabm = slabs + (size_t)blockIdx.x * Pm;
+    for (int e = tid; e < Pm; e += 256)
+      slabm[e] = ((sSlabM[e] + sSlabM[Pm + e]) + sSlabM[2 * Pm + e]) + sSlabM[3 * (size_t)Pm + e];
+    return;
+  }
+
   if (!HIST) {
     // Records (MODE 0 / 3), software-pipelined ACROSS items and across the rows of an item.  An item's data hang on
     // a chain of dependent loads - the record pointer, its header / row list, then the rows the list names - which
