@@ -259,6 +259,24 @@ __global__ __launch_bounds__(256) void k_learned_select(
     st_g[2].load(gt.gnn + 2 * (size_t)H1 * F + H1, H2, H1, H1, tid);
     st_g[3].load(gt.gnn + 2 * (size_t)H1 * F + H1 + (size_t)H2 * H1, H2, H1, H1, tid);
   }
+  // What the single wave of the sampling / GNN tail reads from memory, requested NOW (lane-indexed, clamped
+  // addresses, every thread): the gumbel draws, the incoming row cur of the adjacency, the two GNN biases.  Read at
+  // their points of use they were six dependent round trips on the kernel's one-wave critical path.
+  float pf_noise[2], pf_old[2], pf_b1 = 0.f, pf_b2 = 0.f;
+  {
+    const int pl = tid & 63;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = pl + 64 * c < N ? pl + 64 * c : N - 1;
+      pf_noise[c] = noise[(size_t)b * N + j];
+      pf_old[c] = ADVANCE ? adj_in[((size_t)b * N + cur) * N + j] : 0.f;
+    }
+    if (TAIL) {
+      const int H1 = gt.H1, H2 = gt.H2;
+      pf_b1 = gt.gnn[2 * (size_t)H1 * F + (pl < H1 ? pl : H1 - 1)];
+      pf_b2 = gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + (pl < H2 ? pl : H2 - 1)];
+    }
+  }
   if (ADVANCE) {
     // the state copy through registers (roll folded in), the node image for the edge network from the
     // same registers, the observation patched into row cur
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
       const int j = lane + 64 * c;
       float nz = 0.f;
       if (j < cur) {
-        const float t = noise[(size_t)b * N + j];
+        const float t = pf_noise[c];
         nz = noise_is_exp ? -logf(t) : t;
       }
       z[c] = j < cur ? sLogit[j] + nz : -INFINITY;
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
         if (j < cur) {
           const float edge = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12)
           float old;
-          if (ADVANCE) old = wrap ? 0.f : adj_in[((size_t)b * N + cur) * N + j];
+          if (ADVANCE) old = wrap ? 0.f : pf_old[c];
           else old = row[j];
           const float nv = (edge + old > 0.f) ? 1.f : 0.f;       // learned.py:108-110
           row[j] = nv;
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
       // h1[cur][h] = act1(b1[h] + sum_f W_rel1[h][f] agg1[f] + W_root1[h][f] x[cur][f]), lane h
       const float* wr1 = sWg + fl_ * FS;
       const float* wt1 = sWg + FP * FS + fl_ * FS;
-      float p1 = (gt.has_bias & 1) && lane < H1 ? gt.gnn[2 * (size_t)H1 * F + lane] : 0.f;
+      float p1 = (gt.has_bias & 1) && lane < H1 ? pf_b1 : 0.f;
 #pragma unroll
       for (int f = 0; f < FP; ++f) {
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg1), f));
@@ -448,8 +466,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
       // mx[o] = act2(b2[o] + sum_h W_rel2[o][h] agg2[h] + W_root2[o][h] h1[cur][h]), lane o
       const float* wr2 = sWg + 2 * FP * FS + fl_ * FS;
       const float* wt2 = sWg + 3 * FP * FS + fl_ * FS;
-      float p2 = (gt.has_bias & 2) && lane < H2
-                     ? gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + lane] : 0.f;
+      float p2 = (gt.has_bias & 2) && lane < H2 ? pf_b2 : 0.f;
 #pragma unroll
       for (int h = 0; h < FP; ++h) {
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg2), h));
@@ -1079,12 +1096,15 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       int slot = -1, w = NONE;
       if (t2 < a.T) {
         const size_t it2 = (size_t)t2 * B + b;
+        // the header and the first 8 entries of the live list in ONE round trip (the list's address does not depend
+        // on the header; a LearnedEdge row has <= 1/cutoff entries)
+        int e[8];   // (dword-aligned: N need not be a multiple of 4)
+        __builtin_memcpy(e, a.live + it2 * N, sizeof(e));
         const int cur2 = a.hdr[2 * it2], L2 = a.hdr[2 * it2 + 1];
+        asm volatile("" ::: "memory");
         const int r = cur2 - tid;            // its row at step t2 (one roll per step once the graph is full)
         w = cur + tid - cur2;                // rolls since this step
-        if (r >= 0) {   // the first 8 entries in one round trip (a LearnedEdge row has <= 1/cutoff of them)
-          int e[8];   // (dword-aligned: N need not be a multiple of 4)
-          __builtin_memcpy(e, a.live + it2 * N, sizeof(e));
+        if (r >= 0) {
 #pragma unroll
           for (int l = 0; l < 8; ++l) slot = (l < L2 && e[l] == r) ? l : slot;
           for (int l = 8; l < L2; ++l)
@@ -1115,14 +1135,15 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
         const int e = tid + 256 * i, r = e / FP, f = e % FP;
         const int slot = sSlot[r];
         const int t2 = sg + r < a.T ? sg + r : a.T - 1;
-        const float t = a.da[(((size_t)t2 * B + b) * N + (slot >= 0 ? slot : 0)) * F + (f < F ? f : F - 1)];
-        v[i] = (slot >= 0 && f < F) ? t : 0.f;
+        // (load first, mask in the loop below: written as one select the compiler sank every load under its mask's
+        //  branch and waited for it alone - PER = 16 dependent round trips per item)
+        v[i] = a.da[(((size_t)t2 * B + b) * N + (slot >= 0 ? slot : 0)) * F + (f < F ? f : F - 1)];
       }
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int e = tid + 256 * i, r = e / FP, f = e % FP;
-        sP0[r * FS + f] = v[i];
+        sP0[r * FS + f] = (sSlot[r] >= 0 && f < F) ? v[i] : 0.f;
       }
     }
     st_x.store(sX, FS, tid);
