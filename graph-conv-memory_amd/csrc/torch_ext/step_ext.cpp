@@ -28,6 +28,18 @@
 
 #include "gcm_hip.h"
 
+#ifdef GCM_HOST_PROF
+#include <chrono>
+static double g_prof[8];
+static long g_prof_n;
+static inline double prof_now() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define PROF_T(i) { const double t_ = prof_now(); g_prof[i] += t_ - prof_t; prof_t = t_; }
+#else
+#define PROF_T(i)
+#endif
+
 namespace {
 
 using torch::autograd::AutogradContext;
@@ -707,9 +719,13 @@ struct RowsFast {
                                                reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream())),
             "gcm_dense_rows_cached_weight_image");
     }
+#ifdef GCM_HOST_PROF
+    double prof_t = prof_now();
+#endif
     size_t lay[5];
     check(gcm_dense_rows_cached_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_cached_layout");
     at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    PROF_T(1)
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
     check(gcm_dense_rows_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
                                      count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
@@ -718,7 +734,9 @@ struct RowsFast {
                                      buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
                                      reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
           "gcm_dense_rows_step_cached");
+    PROF_T(2)
     at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
+    PROF_T(3)
     if (need_bwd) {
       const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
       RowsChainNode::Rec r{buf, vc, vc.current_version()};
@@ -728,6 +746,7 @@ struct RowsFast {
       torch::autograd::create_gradient_edge(mx, node);
       node->recs.push_back(std::move(r));
     }
+    PROF_T(4)
     l_nodes = nodes_in;
     l_adj = adj_in;
     l_weights = weights;
@@ -868,6 +887,10 @@ struct RowsFast {
 
   // the unchecked entry: (mx, hidden) or None
   pybind11::object step(pybind11::handle x, pybind11::handle hidden) {
+#ifdef GCM_HOST_PROF
+    double prof_t = prof_now();
+    ++g_prof_n;
+#endif
     if (!armed || !PyTuple_Check(hidden.ptr()) || PyTuple_GET_SIZE(hidden.ptr()) != 4 ||
         !THPVariable_Check(x.ptr()))
       return pybind11::none();
@@ -887,9 +910,17 @@ struct RowsFast {
         hooks_registered() || (dx_kind == 1 && !node->can_take(xt)))
       return pybind11::none();
     at::Tensor obs = xt.is_contiguous() ? xt : xt.contiguous();
+    PROF_T(0)
     at::Tensor mx = launch(obs, l_nodes, l_adj, l_weights, l_count);
+#ifdef GCM_HOST_PROF
+    prof_t = prof_now();
+#endif
     pybind11::object pmx = pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(mx));
-    if (donate) return pybind11::make_tuple(pmx, pybind11::reinterpret_borrow<pybind11::object>(h));
+    if (donate) {
+      pybind11::tuple r_ = pybind11::make_tuple(pmx, pybind11::reinterpret_borrow<pybind11::object>(h));
+      PROF_T(5)
+      return r_;
+    }
     pybind11::object hn = pybind11::reinterpret_steal<pybind11::object>(PyTuple_New(4));
     PyTuple_SET_ITEM(hn.ptr(), 0, THPVariable_Wrap(l_nodes));
     PyTuple_SET_ITEM(hn.ptr(), 1, THPVariable_Wrap(l_adj));
@@ -1949,4 +1980,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("drop", &SparseChain::drop);
   m.def("sparse_temporal_step", &sparse_temporal_step);
   m.def("read_flag_word", &read_flag_word);
+#ifdef GCM_HOST_PROF
+  m.def("host_prof", []() {
+    std::vector<double> v(g_prof, g_prof + 8);
+    v.push_back((double)g_prof_n);
+    for (auto& x : g_prof) x = 0;
+    g_prof_n = 0;
+    return v;
+  });
+#endif
 }

@@ -33,7 +33,8 @@ def build(verbose=False):
         # host C++ only; the ROCm include path is for c10/hip (current stream / device of the
         # process), whose library torch has loaded already
         extra_include_paths=[_INCLUDE, os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")],
-        extra_cflags=["-O2", "-std=c++17", "-Wno-deprecated-declarations"],
+        extra_cflags=["-O2", "-std=c++17", "-Wno-deprecated-declarations"]
+        + (["-DGCM_HOST_PROF"] if os.environ.get("GCM_HOST_PROF") == "1" else []),   # (tools/hosttime.py: segments of RowsFast.step)
         extra_ldflags=[f"-L{_LIB_DIR}", "-lgcm_hip", "-Wl,-rpath,'$$ORIGIN/..'",
                        f"-L{os.path.join(os.path.dirname(torch.__file__), 'lib')}", "-lc10_hip",
                        "-ltorch_python"],

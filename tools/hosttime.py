@@ -68,3 +68,25 @@ for donate in (True, False):
         torch.stack(outs).mean().backward()
         gnn.zero_grad(set_to_none=True)
     print(f"donate={donate!s:5} pre-indexed observations: fwd issue {min(res[3:]) / T * 1e6:.2f} us/step")
+
+# segments of RowsFast.step (extension built with GCM_HOST_PROF=1): us per step
+from gcm import _ext
+ext = _ext.module()
+if hasattr(ext, "host_prof"):
+    mem, gnn, _ = bench.build_memory(dev, donate=True)
+    for it in range(4):
+        ext.host_prof()
+        t0 = time.perf_counter()
+        hidden, outs = None, []
+        for x in xs:
+            mx, hidden = mem(x, hidden)
+            outs.append(mx)
+        dt = time.perf_counter() - t0
+        v = ext.host_prof()
+        torch.cuda.synchronize()
+        torch.stack(outs).mean().backward()
+        gnn.zero_grad(set_to_none=True)
+    n = max(v[8], 1)
+    names = ["checks", "record alloc", "launch", "mx alias", "autograd edge + rec", "wrap + tuple"]
+    print("RowsFast.step segments (us/step, %d fast steps of %d): " % (n, T) + ", ".join("%s %.2f" % (nm, v[i] / n) for i, nm in enumerate(names))
+          + "; sum %.2f of %.2f per loop iteration" % (sum(v[:6]) / n, dt / T * 1e6))
