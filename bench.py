@@ -292,9 +292,14 @@ def time_step_kernel(mem, obs, c, reps=10):
     if cfg.has_distance:         # (records of a real rollout: the live-row counts matter)
         hidden = None
         recs = []
-        for t in range(T):
-            mx, hidden = mem(obs[t], hidden)
-            recs.append(mx)
+        keep = mem.rows_cached_steps
+        mem.rows_cached_steps = False     # (live-row records: what gcm_dense_rows_bptt below reads; cached steps
+        try:                              #  leave another layout, read through the chain's caches)
+            for t in range(T):
+                mx, hidden = mem(obs[t], hidden)
+                recs.append(mx)
+        finally:
+            mem.rows_cached_steps = keep
         saved_ptrs = [m_.data_ptr() for m_ in recs]
     else:
         saved_ptrs = [s.data_ptr() for s in saved_all]

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
-    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
+    const float* __restrict__ sel_row) {
   constexpr int F = FP, H1 = HP;
   __shared__ __attribute__((aligned(16))) float sv[128];
   const int lane = threadIdx.x;
@@ -285,6 +286,13 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
   const float* b1 = params + 2 * H1 * F;
   const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
   const int64_t n64 = cur_host >= 0 ? (int64_t)cur_host : count[gb];
+  // decisions of a distance selector that ran ahead of this kernel (gcm_edge_distance_pre: 1 / 0 per row j < cur,
+  // entries beyond unspecified; distance.py:31-37 writes row cur alone - the cached argument holds)
+  float sel0 = 0.f, sel1 = 0.f;
+  if (sel_row) {
+    sel0 = sel_row[gb * (unsigned)N + (unsigned)(lane < N ? lane : N - 1)];
+    sel1 = sel_row[gb * (unsigned)N + (unsigned)(lane + 64 < N ? lane + 64 : N - 1)];
+  }
   // every weight load in flight at once (coalesced: lane h reads element h of row k of the image)
   float r1[F], t1[F], r2[H1], t2[H1];
 #pragma unroll
@@ -309,6 +317,10 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     m0 |= (edge && j < 64) ? 1ull << (j & 63) : 0ull;
     m1 |= (edge && j >= 64) ? 1ull << ((j - 64) & 63) : 0ull;
   }
+  if (sel_row) {
+    m0 |= __ballot(lane < cur && lane < N && sel0 != 0.f);
+    m1 |= __ballot(lane + 64 < cur && lane + 64 < N && sel1 != 0.f);
+  }
   float xa[4], ha[4];
   unsigned long long a0 = m0, a1 = m1;
 #pragma unroll
@@ -324,12 +336,24 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     ha[q] = any ? th : 0.f;
   }
   float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
+  // further rows (a distance selector's clusters; more than four hops): eight per round trip, added in ascending
+  // order - the sums a row-at-a-time loop makes
   while (a0 | a1) {
-    const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
-    if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
-    const unsigned rj = gb * (unsigned)N + (unsigned)j;
-    agg1 += nodes[rj * F + fl];
-    agg2 += cH[rj * H1 + hl];
+    float bx[8], bh[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool any = (a0 | a1) != 0;
+      const int j = !any ? 0 : (a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1));
+      const bool low = a0 != 0;
+      a0 &= low ? a0 - 1 : a0;
+      a1 &= (low || !any) ? a1 : a1 - 1;
+      const unsigned rj = gb * (unsigned)N + (unsigned)j;
+      const float tx = nodes[rj * F + fl], th = cH[rj * H1 + hl];
+      bx[q] = any ? tx : 0.f;
+      bh[q] = any ? th : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { agg1 += bx[q]; agg2 += bh[q]; }
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
@@ -534,20 +558,32 @@ __global__ __launch_bounds__(64) void k_sparse_step_cached(
 
 }  // namespace gcm_rows
 
-extern "C" int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
-                                               int N, int F, int H1, int H2) {
+static int cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N, int F, int H1,
+                            int H2, bool allow_distance) {
   if (!gcm_dense_rows_supported(N, F, H1, H2) || F > 64 || H1 > 64 || H2 > 64 || N > 128) return 0;
   if ((F != 32 && F != 64) || (H1 != 32 && H1 != 64)) return 0;   // (the kernel is specialised on them)
   if (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE | GCM_GNN_RECORD_DX)) return 0;
-  int hops = 0;
+  int hops = 0, dist = 0;
   for (int i = 0; i < n_selectors; ++i) {
     const gcm_selector_desc& d = selectors[i];
     // only row cur may be written: DenseEdge (dense.py:16-21) also writes column cur, "backward" / "both" hops
-    // write into older rows - their layer-1 rows change at every step
+    // write into older rows - their layer-1 rows change at every step.  A distance selector (distance.py:31-37)
+    // that is not bidirectional writes row cur alone: its decisions arrive as a row (gcm_edge_distance_pre).
+    if (d.kind == GCM_SEL_DISTANCE && allow_distance && !d.bidirectional && dist == 0) { ++dist; continue; }
     if (d.kind != GCM_SEL_TEMPORAL || d.direction != GCM_DIR_FORWARD) return 0;
     hops += d.n_hops;
   }
   return hops <= 16;
+}
+
+extern "C" int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
+                                               int N, int F, int H1, int H2) {
+  return cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2, false);
+}
+
+extern "C" int gcm_dense_rows_cached_supported_ws(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
+                                                  int N, int F, int H1, int H2) {
+  return cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2, true);
 }
 
 extern "C" int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2, size_t* out5) {
@@ -572,13 +608,40 @@ extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float*
                                           int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
                                           float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags,
                                           int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
+  if (!gcm_dense_rows_cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  return gcm_dense_rows_step_cached_ws(obs, nodes, adj, count, selectors, n_selectors, params, weight_image, has_bias,
+                                       act1, act2, cache_h1, cache_agg1, cache_nodes, saved, record, cur_host, flags,
+                                       nullptr, 0, B, N, F, H1, H2, stream);
+}
+
+extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, float* adj, int64_t* count,
+                                             const gcm_selector_desc* selectors, int n_selectors,
+                                             const float* params, const float* weight_image, int has_bias, int act1,
+                                             int act2, float* cache_h1, float* cache_agg1, float* cache_nodes,
+                                             float* saved, int record, int cur_host, uint32_t* flags, void* workspace,
+                                             size_t workspace_bytes, int B, int N, int F, int H1, int H2,
+                                             gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes && adj && count && params && cache_h1 && cache_agg1 && cache_nodes && saved && flags);
   GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0));
-  if (!gcm_dense_rows_cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  if (!gcm_dense_rows_cached_supported_ws(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
   if ((size_t)B * N * (size_t)(F > N ? F : N) >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;   // 32-bit offsets inside
   gcm_fused::Edits E{};
+  const float* sel_row = nullptr;
   for (int i = 0; i < n_selectors; ++i) {
     const gcm_selector_desc& d = selectors[i];
+    if (d.kind == GCM_SEL_DISTANCE) {
+      // the distance selector runs first, on the state as it comes in, and hands its row over (as for
+      // gcm_dense_rows_step_fwd_ws); the decision row is the head of the workspace
+      GCM_REQUIRE(workspace && weight_image);
+      if (workspace_bytes < gcm_dense_rows_step_workspace_bytes(selectors, n_selectors, B, N, F)) return GCM_EWORKSPACE;
+      float* row = (float*)workspace;
+      const int rc = gcm_edge_distance_pre_ex(nodes, count, obs, row, d.mode, d.max_distance, d.dist_param, d.a0, d.a1,
+                                              d.b0, d.b1, d.cur_rows, d.n_cur_rows, row + (size_t)B * N,
+                                              workspace_bytes - sizeof(float) * (size_t)B * N, B, N, F, stream);
+      if (rc) return rc;
+      sel_row = row;
+      continue;
+    }
     for (int k = 0; k < d.n_hops; ++k) {
       E.hops[E.n_hops] = d.hops[k];
       E.dir[E.n_hops++] = d.direction;
@@ -591,7 +654,7 @@ extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float*
   if (F == a && H1 == b_) {                                                                                      \
     hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream, obs,  \
                        nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes,    \
-                       saved, lay, flags, B, N, H2, cur_host);                                                       \
+                       saved, lay, flags, B, N, H2, cur_host, sel_row);                                              \
     return gcm_launch_status();                                                                                  \
   }
     GCM_RI(32, 32) GCM_RI(64, 32) GCM_RI(32, 64) GCM_RI(64, 64)
@@ -640,7 +703,8 @@ extern "C" int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes,
     hipExtLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,  \
                           (hipEvent_t)start_events[t], (hipEvent_t)stop_events[t], 0,                            \
                           obs_all + (size_t)t * B * F, nodes, adj, count, E, params, weight_image, act1, act2,   \
-                          cache_h1, cache_agg1, cache_nodes, saved_per_step[t], lay, flags, B, N, H2, t);
+                          cache_h1, cache_agg1, cache_nodes, saved_per_step[t], lay, flags, B, N, H2, t,          \
+                          (const float*)nullptr);
     GCM_RT(32, 32) GCM_RT(64, 32) GCM_RT(32, 64) GCM_RT(64, 64)
 #undef GCM_RT
     const int rc = gcm_launch_status();

@@ -694,9 +694,12 @@ struct RowsFast {
     }
     chain_steps = cached_steps = 0;
     cH = cA = cX = at::Tensor();
-    cache_ok = fresh && donate && dx_kind != 2 &&
-               gcm_dense_rows_cached_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
-                                               cfg->has_bias, cfg->N, cfg->F, cfg->H1, cfg->H2) != 0;
+    // (a distance selector's decisions reach the cached step as a row: no hop table to rebuild the live rows from
+    //  in the observation-gradient launch - those chains stay on the general kernel)
+    cache_ok = fresh && donate && dx_kind != 2 && !(cfg->has_distance && dx_kind != 0) &&
+               gcm_dense_rows_cached_supported_ws(cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                                  (int)cfg->descs.size(), cfg->has_bias, cfg->N, cfg->F, cfg->H1,
+                                                  cfg->H2) != 0;
     armed = true;
   }
 
@@ -727,13 +730,16 @@ struct RowsFast {
     at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
     PROF_T(1)
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
-    check(gcm_dense_rows_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
-                                     count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
-                                     (int)cfg->descs.size(), packed.data_ptr<float>(), wimg.data_ptr<float>(), cfg->has_bias,
-                                     cfg->act1, cfg->act2, cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
-                                     buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
-                                     reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
-          "gcm_dense_rows_step_cached");
+    size_t ws_bytes = 0;
+    void* ws = cfg->workspace((int)B, obs, &ws_bytes);   // (a distance selector's scratch and decision row)
+    check(gcm_dense_rows_step_cached_ws(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                        count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                        (int)cfg->descs.size(), packed.data_ptr<float>(), wimg.data_ptr<float>(), cfg->has_bias,
+                                        cfg->act1, cfg->act2, cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
+                                        buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
+                                        reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2,
+                                        stream),
+          "gcm_dense_rows_step_cached_ws");
     PROF_T(2)
     at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
     PROF_T(3)

@@ -618,6 +618,19 @@ int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64
                                const float* weight_image, int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
                                float* cache_nodes, float* saved, int record, int cur_host, uint32_t* flags, int B,
                                int N, int F, int H1, int H2, gcm_stream_t stream);
+/* The cached step for selector chains that also hold ONE distance selector (GCM_SEL_DISTANCE, not bidirectional;
+ * distance.py:18-39 - it writes row cur alone, so the rows of layer 1 stay final): the selector runs first, on the
+ * state as it comes in (gcm_edge_distance_pre), its decisions reach the step as a row [B, N] at the head of
+ * `workspace` (gcm_dense_rows_step_workspace_bytes), the selected rows are gathered eight per round trip.
+ * weight_image is required on this path.  Without a distance selector workspace may be NULL. */
+int gcm_dense_rows_cached_supported_ws(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
+                                       int F, int H1, int H2);
+int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, float* adj, int64_t* count,
+                                  const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                  const float* weight_image, int has_bias, int act1, int act2, float* cache_h1,
+                                  float* cache_agg1, float* cache_nodes, float* saved, int record, int cur_host,
+                                  uint32_t* flags, void* workspace, size_t workspace_bytes, int B, int N, int F,
+                                  int H1, int H2, gcm_stream_t stream);
 /* SparseGCM in stepwise use (sparse_gcm.py:72-212 called with x [B, 1, F], taus in {0, 1}) with a TemporalEdge selector
  * (sparse_edge_selectors/temporal.py:18-63; hops_host: HOST array, every hop >= 1), in a chain from empty graphs: the
  * new node's belief from the chain's caches (the layer-1 row of a node is final once written: its edges point at

@@ -379,6 +379,11 @@ def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
             outs.append(mx)
             sums.append(hidden[1].sum(dim=(1, 2)).clone())
         assert _rows_taken(mem) == (mode != "fused")
+        # a donated chain from empty graphs at a size the cached step is specialised on: its first N steps run on
+        # the chain's caches (the selector's decision row handed to k_step_rows_cached_img), the rest - the graphs
+        # roll - on the general kernel
+        if mode == "rows_donated":
+            assert mem.rows_cached_steps_taken() == (min(T, N) if F in (32, 64) else 0)
         out = torch.stack(outs)
         (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
         mem.check_flags()
@@ -386,7 +391,9 @@ def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
     assert float(res[0][2].max()) > 0                        # the thresholds do connect nodes
     for r in res[1:]:
         assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
-        torch.testing.assert_close(r[0], res[0][0], rtol=1e-5, atol=5e-6)
+        # (two fp32 evaluations with different orders of the row sums - dozens of rows per aggregate here -: 1e-5,
+        #  north_star's tolerance, on each)
+        torch.testing.assert_close(r[0], res[0][0], rtol=1e-5, atol=1e-5)
         for k_ in r[3]:
             scale = float(res[0][3][k_].abs().max()) + 1e-12
             torch.testing.assert_close(r[3][k_], res[0][3][k_], rtol=1e-4, atol=2e-5 * scale, msg=k_)

@@ -90,3 +90,23 @@ if hasattr(ext, "host_prof"):
     names = ["checks", "record alloc", "launch", "mx alias", "autograd edge + rec", "wrap + tuple"]
     print("RowsFast.step segments (us/step, %d fast steps of %d): " % (n, T) + ", ".join("%s %.2f" % (nm, v[i] / n) for i, nm in enumerate(names))
           + "; sum %.2f of %.2f per loop iteration" % (sum(v[:6]) / n, dt / T * 1e6))
+
+# the same loop on a non-default stream (the null stream's launches carry the legacy synchronisation bookkeeping)
+side = torch.cuda.Stream()
+for donate in (True, False):
+    mem, gnn, _ = bench.build_memory(dev, donate=donate)
+    res = []
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for it in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hidden, outs = None, []
+            for x in xs:
+                mx, hidden = mem(x, hidden)
+                outs.append(mx)
+            res.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            torch.stack(outs).mean().backward()
+            gnn.zero_grad(set_to_none=True)
+    print(f"donate={donate!s:5} pre-indexed observations, side stream: fwd issue {min(res[3:]) / T * 1e6:.2f} us/step")
