@@ -366,6 +366,23 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
   DSTAMP(6);
 }
 
+// The cached live-row step (rows_cached.hip: k_step_rows_cached_img's arithmetic, H1, H2 <= 32) riding on the distance
+// kernel as the work of wave 0 behind the decisions - like the GNN tail of the LearnedEdge selection kernel: a
+// chain from empty graphs whose selector is EuclideanEdge runs ONE launch per step instead of two (the second
+// one's launch, ramp-up, weight loads and decision-row round trip: ~3 us of 21 at cfg3).  The four weight matrices
+// are staged into LDS, k-major, with the kernel's other staging loads; the state is advanced in place.
+struct StepTail {
+  const float* params;      // packed GNN parameters (the biases)
+  const float* image;       // gcm_dense_rows_cached_weight_image: [4][64][64], image[m][k][out]
+  float *nodes, *adj;       // the donated state
+  int64_t* count;
+  float *cH, *cA, *cX;      // the chain's caches
+  float* saved;             // the step's record (gcm_dense_rows_cached_layout), mx at its head
+  size_t o_v, o_hdr, o_coef, o_live, total;   // total = 0: mx only
+  uint32_t* flags;
+  int act1, act2, H1, H2;
+};
+
 // ---------------------------------------------------------------------------
 // The same product for F <= 64 (FT <= 2), laid out for a graph that is only partly filled: the work of a
 // step is (live 32-row blocks) x (column tiles), and the block rows >= cur are skipped - so the tiles must be
@@ -377,11 +394,11 @@ __global__ __launch_bounds__(512) void k_euclid_mfma(
 // loads of chunk c + 1 are in flight during the products of chunk c.  Row sums meet in LDS in fixed order
 // (chunks in sequence inside a wave, then the four column tiles): same decisions on every run.
 // ---------------------------------------------------------------------------
-template <int FT>
+template <int FT, bool TAIL>
 __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
     float* __restrict__ sel_row, float* __restrict__ dist_out, float max_distance, int bidirectional,
-    int Bc, int N, int F) {
+    int Bc, int N, int F, StepTail tl) {
   const float* __restrict__ nodes = vw.nodes;
   constexpr int FP = 32 * FT, NS = FP + 1, RB = 128, CB = 128, CS = CB + 1;
   constexpr int NT = 1024;
@@ -397,6 +414,8 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float* sNn = sC + 2 * FP * CS;      // [RB]   |n|^2
   float* sCn = sNn + RB;              // [2][CB] |c|^2
   float* sPart = sCn + 2 * CB;        // [4][RB] row sums per column tile
+  float* sW = sPart + 4 * RB;         // TAIL: [2 FP + 64][32] W_rel1 | W_root1 (k < FP each) | W_rel2 | W_root2 (k < 32 each), k-major
+  float* sDec = sW + (2 * FP + 64) * 32;   // TAIL: [RB] this step's decisions
 
   const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
   const float* crows = vw.cur_rows ? vw.cur_rows : vw.obs;
@@ -457,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     // `cur` arrives) and the node rows of the live blocks: every load in flight before the first LDS store
     float vn[SEG], vc[SEG];
     load_chunk(0, vc);
-    if (j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows (uniform)
+    if (!TAIL && j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows (uniform)
     const int j = j0 + srow + sh;   // stored row of image row j0 + srow
     const bool row_live = srow < 32 * nb && j0 + srow < N;
     if (row_live) {
@@ -551,10 +570,149 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       for (int t = 1; t < tiles; ++t) tot += sPart[t * RB + tid];
       const float d = tot / (float)Bc;
       if (dist_out) dist_out[(size_t)b * N + j] = d;
-      if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
+      if (TAIL) sDec[tid] = (j < cur && d < max_distance) ? 1.f : 0.f;
+      else if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
     }
   }
   DSTAMP(6);
+  if (TAIL) {
+    if (tid < RB && !(tid < 32 * nb && j0 + tid < N)) sDec[tid] = 0.f;   // rows beyond the live blocks
+    __syncthreads();
+    // ---- the cached live-row step on row cur (rows_cached.hip).  Wave 0 gathers the selected rows while the other
+    //      fifteen waves, done with their tiles, bring the four weight matrices into LDS (k-major: one round trip,
+    //      under the gather's); then wave 0 alone: two matrix-vector products, the state, the caches, the record.
+    const int H1 = tl.H1, H2 = tl.H2;
+    const unsigned gb = (unsigned)b;
+    const int fl = lane < F ? lane : F - 1, hl = lane & 31, kh = lane >> 5;
+    const int64_t n64 = vw.count[b];
+    const bool bad = n64 < 0 || n64 >= N;                     // (a chain from empty graphs never rolls)
+    unsigned long long m0 = 0, m1 = 0;
+    float agg1 = 0.f, agg2 = 0.f, xc = 0.f;
+    float* sv = sPart;                                        // (free: every row sum has been read)
+    if (wave != 0) {
+      constexpr int WN = (2 * FP + 64) * 32;
+      for (int e = tid - 64; e < WN; e += NT - 64) {
+        const int k = e >> 5, h = e & 31;                     // row k of the k-major image, output h
+        const int m = k < FP ? 0 : (k < 2 * FP ? 1 : (k < 2 * FP + 32 ? 2 : 3));
+        const int kk = m == 0 ? k : (m == 1 ? k - FP : (m == 2 ? k - 2 * FP : k - 2 * FP - 32));
+        sW[e] = tl.image[m * 4096 + kk * 64 + h];
+      }
+    } else {
+      xc = vw.obs[gb * (unsigned)F + fl];
+      m0 = __ballot(!bad && lane < cur && sDec[lane] != 0.f);
+      m1 = __ballot(!bad && lane + 64 < cur && lane + 64 < RB && sDec[(lane + 64) & (RB - 1)] != 0.f);
+      unsigned long long a0 = m0, a1 = m1;
+      while (a0 | a1) {          // eight rows per round trip, added in ascending order
+        float bx[8], bh[8];
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+          const bool any = (a0 | a1) != 0;
+          const int j = !any ? 0 : (a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1));
+          const bool low = a0 != 0;
+          a0 &= low ? a0 - 1 : a0;
+          a1 &= (low || !any) ? a1 : a1 - 1;
+          const unsigned rj = gb * (unsigned)N + (unsigned)j;
+          const float tx = tl.nodes[rj * F + fl], th = tl.cH[rj * H1 + (hl < H1 ? hl : H1 - 1)];
+          bx[qq] = any ? tx : 0.f;
+          bh[qq] = any ? th : 0.f;
+        }
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) { agg1 += bx[qq]; agg2 += bh[qq]; }
+      }
+      agg1 = lane < F ? agg1 : 0.f;
+      agg2 = lane < H1 ? agg2 : 0.f;
+      if (lane < FP) { sv[lane] = lane < F ? agg1 : 0.f; sv[FP + lane] = lane < F ? xc : 0.f; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float* b1p = tl.params + 2 * (size_t)H1 * F;
+    const float* b2p = b1p + H1 + 2 * (size_t)H2 * H1;
+    const float bias1 = b1p[hl < H1 ? hl : H1 - 1], bias2 = b2p[hl < H2 ? hl : H2 - 1];
+    const int act1_v = gcm_vgpr(tl.act1), act2_v = gcm_vgpr(tl.act2);
+    // layer 1: the half-waves split k (lanes 0-31: k < FP / 2, lanes 32-63: the rest), met by one cross-half add
+    constexpr int KH = FP / 2;
+    float p1;
+    {
+      float wr[KH], wt[KH];
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        wr[k] = sW[(kh * KH + k) * 32 + hl];
+        wt[k] = sW[(FP + kh * KH + k) * 32 + hl];
+      }
+      float pa = 0.f, pb = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < KH / 4; ++k4) {
+        const float4 a = *reinterpret_cast<const float4*>(sv + kh * KH + 4 * k4);
+        const float4 x = *reinterpret_cast<const float4*>(sv + FP + kh * KH + 4 * k4);
+        pa = fmaf(wr[4 * k4], a.x, pa); pb = fmaf(wt[4 * k4], x.x, pb);
+        pa = fmaf(wr[4 * k4 + 1], a.y, pa); pb = fmaf(wt[4 * k4 + 1], x.y, pb);
+        pa = fmaf(wr[4 * k4 + 2], a.z, pa); pb = fmaf(wt[4 * k4 + 2], x.z, pb);
+        pa = fmaf(wr[4 * k4 + 3], a.w, pa); pb = fmaf(wt[4 * k4 + 3], x.w, pb);
+      }
+      p1 = pa + pb;
+      p1 += __shfl_xor(p1, 32);
+      p1 += bias1;
+    }
+    const float h1c = hl < H1 ? gcm_act_sel(p1, act1_v) : 0.f;   // (both halves hold h1c[lane & 31])
+    // (one wave: its LDS operations execute in order - the reads above are done before these writes land)
+    if (lane < 32) { sv[lane] = agg2; sv[32 + lane] = h1c; }
+    // layer 2: lanes 0-31 W_rel2 . agg2, lanes 32-63 W_root2 . h1cur
+    float p2;
+    {
+      float w2[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) w2[k] = sW[(2 * FP + kh * 32 + k) * 32 + hl];
+      float pa = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const float4 a = *reinterpret_cast<const float4*>(sv + kh * 32 + 4 * k4);
+        pa = fmaf(w2[4 * k4], a.x, pa);
+        pa = fmaf(w2[4 * k4 + 1], a.y, pa);
+        pa = fmaf(w2[4 * k4 + 2], a.z, pa);
+        pa = fmaf(w2[4 * k4 + 3], a.w, pa);
+      }
+      p2 = pa + __shfl_xor(pa, 32) + bias2;
+    }
+    const float v = gcm_act_sel(p2, act2_v);
+    const unsigned rc = gb * (unsigned)N + (unsigned)cur;
+    if (!bad) {
+      if (lane < F) {
+        tl.nodes[rc * F + lane] = xc;
+        tl.cX[rc * F + lane] = xc;
+        tl.cA[rc * F + lane] = agg1;
+      }
+      if (lane < H1) tl.cH[rc * H1 + lane] = h1c;
+      float* arow = tl.adj + (size_t)rc * N;
+      if (lane < N && ((m0 >> lane) & 1ull)) arow[lane] = 1.f;
+      if (lane + 64 < N && ((m1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
+      if (lane == 0) tl.count[gb] = cur + 1;
+    }
+    if (lane < H2) tl.saved[gb * H2 + lane] = v;
+    if (tl.total) {
+      if (lane < H1) {
+        tl.saved[tl.o_v + gb * 2 * H1 + lane] = agg2;
+        tl.saved[tl.o_v + gb * 2 * H1 + H1 + lane] = h1c;
+      }
+      const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
+      int* live = reinterpret_cast<int*>(tl.saved + tl.o_live) + gb * N;
+      float* coef = tl.saved + tl.o_coef + gb * N;
+      const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
+      const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
+      const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
+      if (in0) { live[pos0] = lane; coef[pos0] = lane == cur ? 0.f : 1.f; }
+      if (in1) { live[pos1] = lane + 64; coef[pos1] = lane + 64 == cur ? 0.f : 1.f; }
+      if (lane == 0) {
+        int* hdr = reinterpret_cast<int*>(tl.saved + tl.o_hdr) + 4 * gb;
+        const int L = __popcll(l0) + __popcll(l1);
+        const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull))
+                                   : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
+        hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
+      }
+    }
+    const bool nonfinite = __any(lane < H2 && !isfinite(v));
+    if ((nonfinite || bad) && lane == 0)
+      atomicOr(tl.flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
+  }
 }
 
 // per-graph modes: one thread per (b, j)
@@ -636,10 +794,10 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
                                            (size_t)4 * RB);
 #define GCM_EUCLID_MFMA2(FTv)                                                                    \
   {                                                                                              \
-    auto kern = k_euclid_mfma2<FTv>;                                                             \
+    auto kern = k_euclid_mfma2<FTv, false>;                                                      \
     gcm_allow_dynamic_lds((const void*)kern, lds2);                                              \
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds2, s, vw, dist_param, adj, sel_row, dist_out,  \
-                       max_distance, bidirectional, Bc, N, F);                                   \
+                       max_distance, bidirectional, Bc, N, F, StepTail{});                       \
   }
       switch (FT) {
         case 1: GCM_EUCLID_MFMA2(1) break;
@@ -675,6 +833,43 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
   const int total = B * N;
   hipLaunchKernelGGL(k_pergraph, dim3((total + 255) / 256), dim3(256), 0, s, vw, dist_param, adj, sel_row,
                      dist_out, mode, max_distance, a0, a1, b0, bidirectional, B, N, F);
+  return gcm_launch_status();
+}
+
+/* EuclideanEdge (cross-batch mean, distance.py:41-49) on the state as it comes in + the cached live-row step on row
+ * cur (gcm_dense_rows_step_cached_ws's arithmetic) as ONE launch: k_euclid_mfma2 with the step as wave 0's tail.
+ * For: Bc >= 32 current rows, F in {32, 64}, N <= 128, H1, H2 <= 32, no other selector.  GCM_EUNSUPPORTED otherwise
+ * (the caller then runs the two launches).  lay5: gcm_dense_rows_cached_layout. */
+extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
+                                             float max_distance, const float* dist_param, const float* cur_rows,
+                                             int n_cur_rows, const float* params, const float* weight_image, int act1,
+                                             int act2, float* cache_h1, float* cache_agg1, float* cache_nodes,
+                                             float* saved, const size_t* lay5, int record, uint32_t* flags, int B,
+                                             int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && adj && count && params && weight_image && cache_h1 && cache_agg1 && cache_nodes &&
+              saved && lay5 && flags && B > 0);
+  const int Bc = cur_rows ? n_cur_rows : B;
+  if (Bc < 32 || (F != 32 && F != 64) || N > 128 || N < 1 || H1 > 32 || H1 < 1 || H2 > 32 || H2 < 1 || B > 65535)
+    return GCM_EUNSUPPORTED;
+  View vw{nodes, nullptr, count, obs, cur_rows, n_cur_rows};
+  StepTail tl{params, weight_image, nodes, adj, count, cache_h1, cache_agg1, cache_nodes, saved,
+              lay5[1], lay5[2], lay5[3], lay5[4], record ? lay5[0] : 0, flags, act1, act2, H1, H2};
+  constexpr int RB = 128;
+  const int FT = F / 32;
+  const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
+                                      (size_t)4 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB);
+  hipStream_t s = (hipStream_t)stream;
+  if (FT == 1) {
+    auto kern = k_euclid_mfma2<1, true>;
+    gcm_allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3(1, B), dim3(1024), lds, s, vw, dist_param, adj, (float*)nullptr, (float*)nullptr,
+                       max_distance, 0, Bc, N, F, tl);
+  } else {
+    auto kern = k_euclid_mfma2<2, true>;
+    gcm_allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3(1, B), dim3(1024), lds, s, vw, dist_param, adj, (float*)nullptr, (float*)nullptr,
+                       max_distance, 0, Bc, N, F, tl);
+  }
   return gcm_launch_status();
 }
 

@@ -602,6 +602,10 @@ extern "C" int gcm_dense_rows_cached_weight_image(const float* params, float* im
   return gcm_launch_status();
 }
 
+// (A/B switch of the tests and of tools: the two-launch form of a EuclideanEdge chain)
+static bool g_no_fused_euclid = false;
+extern "C" void gcm_debug_set_fused_euclid(int on) { g_no_fused_euclid = !on; }
+
 extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
                                           const gcm_selector_desc* selectors, int n_selectors, const float* params,
                                           const float* weight_image,
@@ -627,6 +631,17 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   if ((size_t)B * N * (size_t)(F > N ? F : N) >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;   // 32-bit offsets inside
   gcm_fused::Edits E{};
   const float* sel_row = nullptr;
+  // EuclideanEdge alone: the distance kernel and the step as ONE launch when the shapes allow
+  if (n_selectors == 1 && selectors[0].kind == GCM_SEL_DISTANCE && selectors[0].mode == GCM_DIST_EUCLID_CROSSBATCH &&
+      weight_image && !g_no_fused_euclid) {
+    const gcm_selector_desc& d = selectors[0];
+    const gcm_rows::CachedLayout l = gcm_rows::make_cached_layout(B, N, H1, H2);
+    const size_t lay5[5] = {l.total, l.o_v, l.o_hdr, l.o_coef, l.o_live};
+    const int rc = gcm_edge_distance_step_cached(obs, nodes, adj, count, d.max_distance, d.dist_param, d.cur_rows,
+                                                 d.n_cur_rows, params, weight_image, act1, act2, cache_h1, cache_agg1,
+                                                 cache_nodes, saved, lay5, record, flags, B, N, F, H1, H2, stream);
+    if (rc != GCM_EUNSUPPORTED) return rc;
+  }
   for (int i = 0; i < n_selectors; ++i) {
     const gcm_selector_desc& d = selectors[i];
     if (d.kind == GCM_SEL_DISTANCE) {

@@ -631,6 +631,16 @@ int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, float* adj, in
                                   float* cache_agg1, float* cache_nodes, float* saved, int record, int cur_host,
                                   uint32_t* flags, void* workspace, size_t workspace_bytes, int B, int N, int F,
                                   int H1, int H2, gcm_stream_t stream);
+/* EuclideanEdge (distance.py:41-49, not bidirectional) as the ONLY selector of such a chain: the distance kernel and
+ * the cached step as one launch (the step is the tail of the matrix-core distance kernel's first wave) -
+ * gcm_dense_rows_step_cached_ws takes this path by itself when the shapes allow (>= 32 current rows, F in {32, 64},
+ * N <= 128, H1, H2 <= 32); GCM_EUNSUPPORTED otherwise.  lay5: gcm_dense_rows_cached_layout. */
+void gcm_debug_set_fused_euclid(int on);   /* 0: the two-launch form (A/B in tests and tools); default on */
+int gcm_edge_distance_step_cached(const float* obs, float* nodes, float* adj, int64_t* count, float max_distance,
+                                  const float* dist_param, const float* cur_rows, int n_cur_rows, const float* params,
+                                  const float* weight_image, int act1, int act2, float* cache_h1, float* cache_agg1,
+                                  float* cache_nodes, float* saved, const size_t* lay5, int record, uint32_t* flags,
+                                  int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 /* SparseGCM in stepwise use (sparse_gcm.py:72-212 called with x [B, 1, F], taus in {0, 1}) with a TemporalEdge selector
  * (sparse_edge_selectors/temporal.py:18-63; hops_host: HOST array, every hop >= 1), in a chain from empty graphs: the
  * new node's belief from the chain's caches (the layer-1 row of a node is final once written: its edges point at

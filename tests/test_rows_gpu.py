@@ -745,3 +745,46 @@ def test_rows_cached_steps_with_obs_gradient(hops, B, N, F, H, T):
     torch.testing.assert_close(gx, xo.grad, rtol=1e-4, atol=1e-5 * float(xo.grad.abs().max()))
     for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
         torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * float(pc.grad.abs().max()), msg=k)
+
+
+def test_euclid_chain_one_launch_per_step_equals_two():
+    """A donated chain from empty graphs whose only selector is EuclideanEdge: the distance kernel and the cached
+    step as ONE launch (the step is the tail of k_euclid_mfma2's first wave) against the same chain as two launches
+    (gcm_edge_distance_pre, then k_step_rows_cached_img with the decision row): the same state bit for bit, the same
+    beliefs and parameter gradients to fp32 summation order."""
+    from gcm import nn as G, _hip
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.distance import EuclideanEdge
+    B, N, F, H, T = 40, 128, 64, 32, 100
+    torch.manual_seed(5)
+    centres = 3 * torch.randn(6, F)
+    obs = (centres[torch.arange(T) % 6][:, None, :] + 0.05 * torch.randn(T, B, F)).to(DEV)
+    w = torch.linspace(0.5, 1.5, T * B * H, device=DEV).view(T, B, H)
+    res = []
+    try:
+        for fused in (1, 0):
+            _hip.lib().gcm_debug_set_fused_euclid(fused)
+            torch.manual_seed(1)
+            g = G.Sequential("x, adj, weights, B, N", [
+                (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+                (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+            mem = DenseGCM(g, edge_selectors=EuclideanEdge(3.0), graph_size=N, donate_state=True)
+            hidden, outs = None, []
+            for t in range(T):
+                mx, hidden = mem(obs[t], hidden)
+                outs.append(mx)
+            assert mem.rows_cached_steps_taken() == T
+            out = torch.stack(outs)
+            (out * w).sum().backward()
+            mem.check_flags()
+            res.append((out.detach(), [h.clone() for h in hidden], {k: p.grad.clone() for k, p in g.named_parameters()}))
+    finally:
+        _hip.lib().gcm_debug_set_fused_euclid(1)
+    a, b = res
+    assert float(a[1][1].sum()) > 0
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-5)
+    for k in a[2]:
+        scale = float(b[2][k].abs().max()) + 1e-12
+        torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-4, atol=2e-5 * scale, msg=k)
