@@ -657,6 +657,10 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # is of the kernel that did NOT run in the timed region, and only the graph-derived figure applies
         cached = mem_e.rows_cached_steps_taken() > 0
         step_kernel = "k_step_rows_cached" if cached else "k_step_rows"
+        if cached and c["selector"] == "euclid":
+            # one launch per step: the cached step is the tail of the distance kernel's first wave;
+            # the only in-situ figure is the captured forward loop's cadence
+            step_kernel = "k_euclid_mfma2<TAIL>(distance + cached step)"
         # the kernel's own launch duration (dispatch-recorded events: what rocprofv3 reports too) where it was
         # measured; the graph-derived cadence - launch gaps included, but consecutive launches of so short a
         # kernel also overlap their ramp-up and drain - beside it
