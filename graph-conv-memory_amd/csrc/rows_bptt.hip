@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   // MFMAs per item with d2 masked to one half each.  The VALU form executes ~875 instructions per item and was
   // issue-bound at two waves per SIMD.  Same pipelining as below (front of item i + 1 ahead of item i, pair p + 1
   // ahead of pair p, the next item's first pair ahead of this item's last).
-  if (!HIST && FP == 32 && HP == 32 && H2P == 32 && F == 32 && H1 == 32 && wave_regions) {
+  if (!HIST && FP == 32 && HP == 32 && H2P == 32 && F == 32 && H1 == 32 && wave_regions == 3) {
     const int q = lane & 31, half = lane >> 5;
     const int ocq = q < H2 ? q : H2 - 1;
     struct FrontM {
@@ -311,6 +311,182 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     float* slabm = slabs + (size_t)blockIdx.x * Pm;
     for (int e = tid; e < Pm; e += 256)
       slabm[e] = ((sSlabM[e] + sSlabM[Pm + e]) + sSlabM[2 * Pm + e]) + sSlabM[3 * (size_t)Pm + e];
+    return;
+  }
+
+  // ---- the same at F = 64 (cfg3): two 32-column blocks per node row (four MFMAs per row pair), the tiles met in LDS
+  //      in two rounds - layer 1, then layer 2: four regions of the larger round fit beside a second workgroup ----
+  if (!HIST && FP == 64 && HP == 32 && H2P == 32 && F == FP && H1 == 32 && wave_regions == 2) {
+    constexpr int FB = FP / 32;   // 32-column blocks of a node row (F = 32: 1, F = 64: 2)
+    const int q = lane & 31, half = lane >> 5;
+    const int ocq = q < H2 ? q : H2 - 1;
+    struct FrontM {
+      const float* sv;
+      int b, hdr0, hdr1, ja, jb;
+      float g, y, vv, cfa, cfb;
+    };
+    auto front = [&](int item, FrontM& f) __attribute__((always_inline)) {
+      const int s = item / B, b = item - s * B;
+      const float* sv = tab.saved[s];
+      f.sv = sv;
+      f.b = b;
+      const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+      f.hdr0 = hdr[0];
+      f.hdr1 = hdr[1];
+      f.g = tab.gmx[s][(long)b * gmx_sb + (long)ocq * gmx_sh];   // (both halves: d2 replicated)
+      f.y = sv[(size_t)b * H2 + ocq];
+      f.vv = sv[lay.o_v + (size_t)b * 64 + lane];                // agg2 [32] | h1cur [32]
+      const int e0 = lane < N ? lane : N - 1, e1 = lane + 64 < N ? lane + 64 : N - 1;   // (entries >= L: unused)
+      f.cfa = sv[lay.o_coef + (size_t)b * N + e0];
+      f.cfb = sv[lay.o_coef + (size_t)b * N + e1];
+      f.ja = f.jb = 0;
+      if (MODE == 3) {
+        const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
+        f.ja = live[e0];
+        f.jb = live[e1];
+      }
+    };
+    auto rl = [&](int v, int l) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(v, l & 63); };
+    // the pair (l, l + 1): h1 | agg1 | x of row l + half, element q (an absent second row: the first one's, masked)
+    auto fetch = [&](const FrontM& f, int l, int L, float& hv, float (&ag)[FB], float (&xx)[FB], float& dg)
+        __attribute__((always_inline)) {
+      const int l1 = l + 1 < L ? l + 1 : l;
+      dg = 0.f;
+      if (MODE == 3) {
+        const int j0 = l < 64 ? rl(f.ja, l) : rl(f.jb, l), j1 = l1 < 64 ? rl(f.ja, l1) : rl(f.jb, l1);
+        const size_t rr = (size_t)f.b * N + (half ? j1 : j0);
+        hv = lrn.c_h1[rr * 32 + q];
+#pragma unroll
+        for (int c = 0; c < FB; ++c) {
+          ag[c] = lrn.c_agg1[rr * FP + 32 * c + q];
+          xx[c] = lrn.c_nodes[rr * FP + 32 * c + q];
+        }
+      } else {
+        const float* row = f.sv + lay.o_rows + ((size_t)f.b * N + (half ? l1 : l)) * lay.rw;
+        if (deg_term) dg = f.sv[lay.o_deg + (size_t)f.b * N + (half ? l1 : l)];
+        hv = row[q];
+#pragma unroll
+        for (int c = 0; c < FB; ++c) {
+          ag[c] = row[32 + 32 * c + q];
+          xx[c] = row[32 + FP + 32 * c + q];
+        }
+      }
+    };
+    f32x16 aR[FB], aT[FB], a2r, a2t;   // dW_rel1 | dW_root1 (per 32-column block) | dW_rel2 | dW_root2 tiles: [out = acc row][in = q]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a2r[r] = 0.f; a2t[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < FB; ++c) { aR[c][r] = 0.f; aT[c][r] = 0.f; }
+    }
+    float db1p = 0.f, dc1p = 0.f, db2p = 0.f;   // per lane: halves (and for db2 the replica) met at the end
+    auto step = [&](int item, FrontM& cur, float& hv0, float (&ag0)[FB], float (&xx0)[FB], float& dg0, FrontM& nxt,
+                    float& hvN, float (&agN)[FB], float (&xxN)[FB], float& dgN) __attribute__((always_inline)) {
+      const bool has_next = item + n_waves < items;
+      if (has_next) front(item + n_waves, nxt);
+      const int L = min(__builtin_amdgcn_readfirstlane(cur.hdr0), 128);
+      const int l_cur = __builtin_amdgcn_readfirstlane(cur.hdr1);
+      // layer 2: d2 in BOTH halves; u = [w_rel2 | w_root2]^T d2 on the VALU (a matrix-vector product)
+      const float d2 = (q < H2 && !(MODE == 3 && L == 0)) ? cur.g * act_grad_sel(cur.y, act2_v) : 0.f;
+      db2p += d2;
+      float u = 0.f;
+#pragma unroll
+      for (int o = 0; o < 32; ++o)
+        u = fmaf(w2c[0][o], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o)), u);
+      a2r = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : d2, cur.vv, a2r, 0, 0, 0);   // d2 (x) agg2
+      a2t = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? d2 : 0.f, cur.vv, a2t, 0, 0, 0);   // d2 (x) h1cur
+      const float dagg2 = __shfl(u, q), dh1c = __shfl(u, 32 + q);   // (in both halves)
+      auto fetch_next0 = [&]() __attribute__((always_inline)) {
+        if (has_next) {
+          const int Ln = min(__builtin_amdgcn_readfirstlane(nxt.hdr0), 128);
+          if (Ln > 0) fetch(nxt, 0, Ln, hvN, agN, xxN, dgN);
+        }
+      };
+      auto consume = [&](int l, float hv, const float (&ag)[FB], const float (&xx)[FB], float dg)
+          __attribute__((always_inline)) {
+        const int l1 = l + 1;
+        const float c0 = __int_as_float(l < 64 ? rl(__float_as_int(cur.cfa), l) : rl(__float_as_int(cur.cfb), l));
+        const float c1 = __int_as_float(l1 < 64 ? rl(__float_as_int(cur.cfa), l1) : rl(__float_as_int(cur.cfb), l1));
+        const int lm = l + half;
+        float g1 = ((half ? c1 : c0) * dagg2 + (lm == l_cur ? dh1c : 0.f)) * act_grad_sel(hv, act1_v);
+        g1 = lm < L ? g1 : 0.f;
+        db1p += g1;
+        dc1p = fmaf(dg, g1, dc1p);
+#pragma unroll
+        for (int c = 0; c < FB; ++c) {
+          aR[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, ag[c], aR[c], 0, 0, 0);
+          aT[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xx[c], aT[c], 0, 0, 0);
+        }
+      };
+      float hvB = 0.f, agB[FB], xxB[FB], dgB = 0.f;
+#pragma unroll
+      for (int c = 0; c < FB; ++c) { agB[c] = 0.f; xxB[c] = 0.f; }
+      if (L == 0) fetch_next0();
+#pragma unroll 1
+      for (int l = 0; l < L; l += 4) {
+        const bool two = l + 2 < L;
+        if (two) fetch(cur, l + 2, L, hvB, agB, xxB, dgB);
+        else fetch_next0();
+        consume(l, hv0, ag0, xx0, dg0);
+        if (two) {
+          if (l + 4 < L) fetch(cur, l + 4, L, hv0, ag0, xx0, dg0);
+          else fetch_next0();
+          consume(l + 2, hvB, agB, xxB, dgB);
+        }
+      }
+    };
+    FrontM f0{}, f1{};
+    float hv0 = 0.f, ag0[FB], xx0[FB], dg0 = 0.f, hv1 = 0.f, ag1[FB], xx1[FB], dg1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < FB; ++c) { ag0[c] = xx0[c] = ag1[c] = xx1[c] = 0.f; }
+    if (wid < items) {
+      front(wid, f0);
+      const int L0 = min(__builtin_amdgcn_readfirstlane(f0.hdr0), 128);
+      if (L0 > 0) fetch(f0, 0, L0, hv0, ag0, xx0, dg0);
+    }
+#pragma unroll 1
+    for (int item = wid; item < items; item += 2 * n_waves) {
+      step(item, f0, hv0, ag0, xx0, dg0, f1, hv1, ag1, xx1, dg1);
+      if (item + n_waves < items) step(item + n_waves, f1, hv1, ag1, xx1, dg1, f0, hv0, ag0, xx0, dg0);
+    }
+    // ---- the waves' tiles meet in LDS in two rounds (layer 1, then layer 2: four regions of the larger of the two fit
+    //      beside a second workgroup at F = 64 too), every element summed ((w0 + w1) + w2) + w3 ----------------------
+    extern __shared__ float sSlabM[];
+    const int P0m = 2 * 32 * FP + 32 + 2 * H2 * 32 + H2;
+    const int Pm = P0m + (deg_term ? 32 : 0);
+    const int m_root1 = 32 * FP, m_b1 = 2 * 32 * FP, m_rel2 = m_b1 + 32, m_root2 = m_rel2 + H2 * 32, m_b2 = m_root2 + H2 * 32;
+    const int R1 = m_rel2, R2 = Pm - m_rel2;            // floats of a region in round 1 / 2
+    const int RS = R1 > R2 ? R1 : R2;
+    float* mine = sSlabM + (size_t)wave * RS;
+    float* slabm = slabs + (size_t)blockIdx.x * Pm;
+    const float db1m = db1p + __shfl_xor(db1p, 32), dc1m = dc1p + __shfl_xor(dc1p, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row of a 32x32 tile
+#pragma unroll
+      for (int c = 0; c < FB; ++c) {
+        mine[i * FP + 32 * c + q] = aR[c][r];
+        mine[m_root1 + i * FP + 32 * c + q] = aT[c][r];
+      }
+    }
+    if (lane < 32) mine[m_b1 + lane] = db1m;
+    __syncthreads();
+    for (int e = tid; e < R1; e += 256)
+      slabm[e] = ((sSlabM[e] + sSlabM[RS + e]) + sSlabM[2 * RS + e]) + sSlabM[3 * (size_t)RS + e];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < H2) {
+        mine[i * 32 + q] = a2r[r];
+        mine[(m_root2 - m_rel2) + i * 32 + q] = a2t[r];
+      }
+    }
+    if (lane < H2) mine[(m_b2 - m_rel2) + lane] = db2p;
+    if (deg_term && lane < 32) mine[(P0m - m_rel2) + lane] = dc1m;
+    __syncthreads();
+    for (int e = tid; e < R2; e += 256)
+      slabm[m_rel2 + e] = ((sSlabM[e] + sSlabM[RS + e]) + sSlabM[2 * RS + e]) + sSlabM[3 * (size_t)RS + e];
     return;
   }
 
@@ -592,8 +768,20 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
                 int deg_term = 0, const LrnSrc& lrn = LrnSrc{}) {
   const size_t P = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2 + (deg_term ? H1 : 0);
   // (one LDS region per wave while four of them leave room for two workgroups per CU: see the kernel's tail)
-  const int wave_regions = sizeof(float) * P * 4 <= 80 * 1024 ? 1 : 0;
-  const size_t lds = sizeof(float) * P * (wave_regions ? 4 : 1);
+  int wave_regions = sizeof(float) * P * 4 <= 80 * 1024 ? 1 : 0;
+  size_t lds = sizeof(float) * P * (wave_regions ? 4 : 1);
+  if ((MODE == 0 || MODE == 3) && HP == 32 && H2P == 32 && H1 == 32 && F == FP) {
+    // the matrix-core forms (see the kernel).  F = 32: one region of P floats per wave (wave_regions = 3);
+    // F = 64: the tiles meet in two rounds, four regions of the larger round (wave_regions = 2)
+    if (FP == 32) {
+      wave_regions = 3;
+      lds = sizeof(float) * P * 4;
+    } else {
+      const size_t r1 = 2 * (size_t)32 * F + 32, r2 = P - r1;
+      wave_regions = 2;
+      lds = sizeof(float) * 4 * (r1 > r2 ? r1 : r2);
+    }
+  }
   auto kern = k_bptt_rows<FP, HP, H2P, MODE>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1,

@@ -272,12 +272,14 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
   image[e] = v;
 }
 
-template <int FP, int HP>
-__global__ __launch_bounds__(64) void k_step_rows_cached_img(
+// SEL: the decisions of a distance selector arrive as a row (sel_row) and the selected rows beyond the first four
+// are gathered eight per round trip; without it the kernel is the temporal-hops form exactly (cfg2's timed kernel).
+template <int FP, int HP, bool SEL>
+__device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    const gcm_fused::Edits& E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
-    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
+    const CachedLayout& lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
     const float* __restrict__ sel_row) {
   constexpr int F = FP, H1 = HP;
   __shared__ __attribute__((aligned(16))) float sv[128];
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
   // decisions of a distance selector that ran ahead of this kernel (gcm_edge_distance_pre: 1 / 0 per row j < cur,
   // entries beyond unspecified; distance.py:31-37 writes row cur alone - the cached argument holds)
   float sel0 = 0.f, sel1 = 0.f;
-  if (sel_row) {
+  if (SEL) {
     sel0 = sel_row[gb * (unsigned)N + (unsigned)(lane < N ? lane : N - 1)];
     sel1 = sel_row[gb * (unsigned)N + (unsigned)(lane + 64 < N ? lane + 64 : N - 1)];
   }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     m0 |= (edge && j < 64) ? 1ull << (j & 63) : 0ull;
     m1 |= (edge && j >= 64) ? 1ull << ((j - 64) & 63) : 0ull;
   }
-  if (sel_row) {
+  if (SEL) {
     m0 |= __ballot(lane < cur && lane < N && sel0 != 0.f);
     m1 |= __ballot(lane + 64 < cur && lane + 64 < N && sel1 != 0.f);
   }
@@ -338,7 +340,14 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
   float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
   // further rows (a distance selector's clusters; more than four hops): eight per round trip, added in ascending
   // order - the sums a row-at-a-time loop makes
-  while (a0 | a1) {
+  while (!SEL && (a0 | a1)) {
+    const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
+    if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
+    const unsigned rj = gb * (unsigned)N + (unsigned)j;
+    agg1 += nodes[rj * F + fl];
+    agg2 += cH[rj * H1 + hl];
+  }
+  while (SEL && (a0 | a1)) {
     float bx[8], bh[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -430,6 +439,29 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
   const bool nonfinite = __any(lane < H2 && !isfinite(v));
   if ((nonfinite || bad) && lane == 0)
     atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
+}
+
+// The two kernels over that body.  (Separate signatures on purpose: with the decision row's pointer as a ninth
+// pointer argument of the temporal form too, the same instructions ran 170 ns per launch slower - the kernel-argument
+// segment is fetched differently - which was 3 % of cfg2's timed region.)
+template <int FP, int HP>
+__global__ __launch_bounds__(64) void k_step_rows_cached_img(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
+  step_rows_cached_img_body<FP, HP, false>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
+                                           flags, B, N, H2, cur_host, nullptr);
+}
+template <int FP, int HP>
+__global__ __launch_bounds__(64) void k_step_rows_cached_sel(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
+    const float* __restrict__ sel_row) {
+  step_rows_cached_img_body<FP, HP, true>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
+                                          flags, B, N, H2, cur_host, sel_row);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -667,9 +699,14 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   if (weight_image) {
 #define GCM_RI(a, b_)                                                                                            \
   if (F == a && H1 == b_) {                                                                                      \
-    hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream, obs,  \
-                       nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes,    \
-                       saved, lay, flags, B, N, H2, cur_host, sel_row);                                              \
+    if (sel_row)                                                                                                 \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_sel<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
+                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row);                               \
+    else                                                                                                         \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
+                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         cache_nodes, saved, lay, flags, B, N, H2, cur_host);                                        \
     return gcm_launch_status();                                                                                  \
   }
     GCM_RI(32, 32) GCM_RI(64, 32) GCM_RI(32, 64) GCM_RI(64, 64)
@@ -718,8 +755,7 @@ extern "C" int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes,
     hipExtLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,  \
                           (hipEvent_t)start_events[t], (hipEvent_t)stop_events[t], 0,                            \
                           obs_all + (size_t)t * B * F, nodes, adj, count, E, params, weight_image, act1, act2,   \
-                          cache_h1, cache_agg1, cache_nodes, saved_per_step[t], lay, flags, B, N, H2, t,          \
-                          (const float*)nullptr);
+                          cache_h1, cache_agg1, cache_nodes, saved_per_step[t], lay, flags, B, N, H2, t);
     GCM_RT(32, 32) GCM_RT(64, 32) GCM_RT(32, 64) GCM_RT(64, 64)
 #undef GCM_RT
     const int rc = gcm_launch_status();
