@@ -201,6 +201,9 @@ def time_step_kernel(mem, obs, c, reps=10):
     from gcm import _hip
 
     lib = _hip.lib()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gcm_debuglib          # libgcm_hip_debug.so: the same kernels with dispatch-recorded events around them
+    dbg = gcm_debuglib.lib()
     dev = obs.device
     T, B, N, F, H = obs.shape[0], c["B"], c["N"], c["F"], c["H"]
     cfg = mem._fused_plan(*mem.get_initial_hidden_state(obs[0])[:3], F)
@@ -228,7 +231,7 @@ def time_step_kernel(mem, obs, c, reps=10):
         obs_c = obs.contiguous()
         for _ in range(reps + 1):
             nodes, adj, _, count = mem.get_initial_hidden_state(obs[0])
-            rc = lib.gcm_debug_time_rows_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
+            rc = dbg.gcm_debug_time_rows_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
                                                  p(params), cfg.has_bias, cfg.acts[0], cfg.acts[1], sv_p, p(flags),
                                                  ev_a, ev_b, T, B, N, F, H, H, st)
             assert rc == 0
@@ -253,7 +256,7 @@ def time_step_kernel(mem, obs, c, reps=10):
         saved_c = [torch.empty(layc[0], device=dev) for _ in range(T)]
         sv_c = (ctypes.c_void_p * T)(*[t_.data_ptr() for t_ in saved_c])
         image = torch.empty(4 * 64 * 64, device=dev)
-        assert lib.gcm_dense_rows_cached_weight_image(p(params), p(image), F, H, H, st) == 0
+        assert dbg.gcm_dense_rows_cached_weight_image(p(params), p(image), F, H, H, st) == 0
         evs = [(new_event(), new_event()) for _ in range(T)]
         ev_a = (ctypes.c_void_p * T)(*[a for a, _ in evs])
         ev_b = (ctypes.c_void_p * T)(*[b for _, b in evs])
@@ -262,7 +265,7 @@ def time_step_kernel(mem, obs, c, reps=10):
         for _ in range(reps + 1):
             nodes, adj, _, count = mem.get_initial_hidden_state(obs[0])
             cH, cA, cX = (torch.zeros(B, N, d, device=dev) for d in (H, F, F))
-            rc = lib.gcm_debug_time_cached_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
+            rc = dbg.gcm_debug_time_cached_rollout(p(obs_c), p(nodes), p(adj), p(count), cfg.arr_ptr, cfg.n_desc,
                                                    p(params), p(image), cfg.has_bias, cfg.acts[0], cfg.acts[1], p(cH),
                                                    p(cA), p(cX), sv_c, p(flags), ev_a, ev_b, T, B, N, F, H, H, st)
             assert rc == 0, rc

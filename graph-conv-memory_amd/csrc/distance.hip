@@ -840,6 +840,11 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
  * cur (gcm_dense_rows_step_cached_ws's arithmetic) as ONE launch: k_euclid_mfma2 with the step as wave 0's tail.
  * For: Bc >= 32 current rows, F in {32, 64}, N <= 128, H1, H2 <= 32, no other selector.  GCM_EUNSUPPORTED otherwise
  * (the caller then runs the two launches).  lay5: gcm_dense_rows_cached_layout. */
+extern "C" int gcm_edge_distance_step_cached_supported(int n_cur_rows, int B, int N, int F, int H1, int H2) {
+  return !(n_cur_rows < 32 || (F != 32 && F != 64) || N > 128 || N < 1 || H1 > 32 || H1 < 1 || H2 > 32 || H2 < 1 ||
+           B > 65535 || B < 1);
+}
+
 extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
                                              float max_distance, const float* dist_param, const float* cur_rows,
                                              int n_cur_rows, const float* params, const float* weight_image, int act1,
@@ -849,8 +854,7 @@ extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, flo
   GCM_REQUIRE(obs && nodes && adj && count && params && weight_image && cache_h1 && cache_agg1 && cache_nodes &&
               saved && lay5 && flags && B > 0);
   const int Bc = cur_rows ? n_cur_rows : B;
-  if (Bc < 32 || (F != 32 && F != 64) || N > 128 || N < 1 || H1 > 32 || H1 < 1 || H2 > 32 || H2 < 1 || B > 65535)
-    return GCM_EUNSUPPORTED;
+  if (!gcm_edge_distance_step_cached_supported(Bc, B, N, F, H1, H2)) return GCM_EUNSUPPORTED;
   View vw{nodes, nullptr, count, obs, cur_rows, n_cur_rows};
   StepTail tl{params, weight_image, nodes, adj, count, cache_h1, cache_agg1, cache_nodes, saved,
               lay5[1], lay5[2], lay5[3], lay5[4], record ? lay5[0] : 0, flags, act1, act2, H1, H2};

@@ -634,9 +634,26 @@ extern "C" int gcm_dense_rows_cached_weight_image(const float* params, float* im
   return gcm_launch_status();
 }
 
-// (A/B switch of the tests and of tools: the two-launch form of a EuclideanEdge chain)
-static bool g_no_fused_euclid = false;
-extern "C" void gcm_debug_set_fused_euclid(int on) { g_no_fused_euclid = !on; }
+// EuclideanEdge alone: the distance kernel and the cached step are ONE launch when the shapes allow
+// (gcm_edge_distance_step_cached), unless the caller asks for the two-launch form (GCM_STEP_TWO_LAUNCH in has_bias:
+// the A/B of tests and tools - a per-call argument, the library keeps no switch)
+static bool one_launch_distance(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int B, int N, int F,
+                                int H1, int H2) {
+  if (n_selectors != 1 || selectors[0].kind != GCM_SEL_DISTANCE || selectors[0].mode != GCM_DIST_EUCLID_CROSSBATCH ||
+      (has_bias & GCM_STEP_TWO_LAUNCH))
+    return false;
+  return gcm_edge_distance_step_cached_supported(selectors[0].cur_rows ? selectors[0].n_cur_rows : B, B, N, F, H1, H2) != 0;
+}
+
+extern "C" int gcm_dense_rows_cached_launches(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int B,
+                                              int N, int F, int H1, int H2) {
+  if (B <= 0 || !gcm_dense_rows_cached_supported_ws(selectors, n_selectors, has_bias, N, F, H1, H2)) return 0;
+  if (one_launch_distance(selectors, n_selectors, has_bias, B, N, F, H1, H2)) return 1;
+  int n = 1;
+  for (int i = 0; i < n_selectors; ++i)
+    if (selectors[i].kind == GCM_SEL_DISTANCE) ++n;
+  return n;
+}
 
 extern "C" int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,
                                           const gcm_selector_desc* selectors, int n_selectors, const float* params,
@@ -664,8 +681,7 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   gcm_fused::Edits E{};
   const float* sel_row = nullptr;
   // EuclideanEdge alone: the distance kernel and the step as ONE launch when the shapes allow
-  if (n_selectors == 1 && selectors[0].kind == GCM_SEL_DISTANCE && selectors[0].mode == GCM_DIST_EUCLID_CROSSBATCH &&
-      weight_image && !g_no_fused_euclid) {
+  if (weight_image && one_launch_distance(selectors, n_selectors, has_bias, B, N, F, H1, H2)) {
     const gcm_selector_desc& d = selectors[0];
     const gcm_rows::CachedLayout l = gcm_rows::make_cached_layout(B, N, H1, H2);
     const size_t lay5[5] = {l.total, l.o_v, l.o_hdr, l.o_coef, l.o_live};
@@ -728,6 +744,7 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   return GCM_EUNSUPPORTED;
 }
 
+#ifdef GCM_DEBUG_ABI   // libgcm_hip_debug.so only (include/gcm_hip_debug.h)
 /* Measurement aid (bench.py), the cached twin of gcm_debug_time_rows_rollout: T cached steps (T <= N) of a rollout
  * from empty graphs enqueued back to back from C, each launch bracketed by the caller's HIP events recorded by the
  * dispatch itself (hipExtLaunchKernelGGL start / stop events = the kernel begin / end timestamps rocprofv3
@@ -763,6 +780,7 @@ extern "C" int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes,
   }
   return GCM_OK;
 }
+#endif   // GCM_DEBUG_ABI
 
 /* SparseGCM stepwise (x [B, 1, F], taus in {0, 1}) in a chain from empty graphs, TemporalEdge selector with hops >= 1
  * (HOST array): the new node's belief from the chain's caches (see k_sparse_step_cached).  T: node counts BEFORE the

@@ -701,7 +701,9 @@ __global__ __launch_bounds__(256) void k_step_rows(
   }
 }
 
+#ifdef GCM_DEBUG_ABI   // libgcm_hip_debug.so only (include/gcm_hip_debug.h): the product library keeps no state
 static thread_local hipEvent_t t_start = nullptr, t_stop = nullptr;   // gcm_debug_time_next_launch
+#endif
 
 template <int FP, int HP, int H2P, int NX, bool EXACT>
 int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* adj_in,
@@ -714,6 +716,7 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
   const bool func = adj_out != adj_in;
   auto kern = func ? k_step_rows<FP, HP, H2P, true, NX, EXACT> : k_step_rows<FP, HP, H2P, false, NX, EXACT>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
+#ifdef GCM_DEBUG_ABI
   if (t_start && t_stop) {   // one-shot: events recorded by the dispatch itself
     hipExtLaunchKernelGGL(kern, dim3(func ? (1 + GCM_STATE_WGS) * B : B), dim3(256), lds, s, t_start, t_stop, 0, obs, nodes_in,
                           adj_in, count_in, nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags,
@@ -721,6 +724,7 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
     t_start = t_stop = nullptr;
     return gcm_launch_status();
   }
+#endif
   hipLaunchKernelGGL(kern, dim3(func ? (1 + GCM_STATE_WGS) * B : B), dim3(256), lds, s, obs, nodes_in, adj_in, count_in,
                      nodes_out, adj_out, count_out, cur_out, E, P, mx, saved, lay, flags, N, F, H1, H2, c1, pe,
                      sel_row, B);
@@ -729,6 +733,7 @@ int launch(hipStream_t s, const float* obs, const float* nodes_in, const float* 
 
 }  // namespace gcm_rows
 
+#ifdef GCM_DEBUG_ABI
 extern "C" int gcm_debug_time_next_launch(void* start_event, void* stop_event) {
   gcm_rows::t_start = (hipEvent_t)start_event;
   gcm_rows::t_stop = (hipEvent_t)stop_event;
@@ -755,6 +760,7 @@ extern "C" int gcm_debug_time_rows_rollout(const float* obs_all, float* nodes, f
   }
   return GCM_OK;
 }
+#endif   // GCM_DEBUG_ABI
 
 extern "C" int gcm_dense_rows_supported(int N, int F, int H1, int H2) {
   if (N <= 0 || F <= 0 || H1 <= 0 || H2 <= 0) return 0;

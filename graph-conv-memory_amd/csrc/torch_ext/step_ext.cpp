@@ -50,6 +50,7 @@ inline int64_t pad64(int64_t n) { return (n + 63) & ~int64_t(63); }
 struct StepCfg {
   std::vector<gcm_selector_desc> descs;
   int act1, act2, has_bias, N, F, H1, H2;
+  int cached_flags = 0;   // extra has_bias bits of the cached step only (GCM_STEP_TWO_LAUNCH: the A/B of tests / tools)
   int64_t P;
   bool has_distance = false;
   at::Tensor ws;   // scratch of the distance selectors
@@ -593,7 +594,21 @@ struct RowsFast {
   std::vector<pybind11::object> objs;          // the Parameter objects (or None) the packed vector was built from
   std::vector<uint32_t> vers;
   at::Tensor l_nodes, l_adj, l_weights, l_count;   // the hidden state returned last
+  // ... and its version counters right after the launch: the kernels write through raw pointers, so only a caller's
+  // in-place edit (e.g. zeroing the graphs of finished episodes in a donated state) moves them - a cached step, which
+  // reads its per-chain caches and the host's step count instead of the state, must then not run
+  uint32_t lv_nodes = 0, lv_adj = 0, lv_count = 0;
   int64_t xB = -1, xF = -1, n_steps = 0;
+
+  void note_versions() {
+    lv_nodes = l_nodes._version();
+    lv_adj = l_adj._version();
+    lv_count = l_count._version();
+  }
+  bool state_untouched() const {
+    return l_nodes.defined() && l_nodes._version() == lv_nodes && l_adj._version() == lv_adj &&
+           l_count._version() == lv_count;
+  }
   int dev = -1;
 
   RowsFast(const std::vector<std::pair<pybind11::object, pybind11::object>>& specs,
@@ -734,7 +749,8 @@ struct RowsFast {
     void* ws = cfg->workspace((int)B, obs, &ws_bytes);   // (a distance selector's scratch and decision row)
     check(gcm_dense_rows_step_cached_ws(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
                                         count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
-                                        (int)cfg->descs.size(), packed.data_ptr<float>(), wimg.data_ptr<float>(), cfg->has_bias,
+                                        (int)cfg->descs.size(), packed.data_ptr<float>(), wimg.data_ptr<float>(),
+                                        cfg->has_bias | cfg->cached_flags,
                                         cfg->act1, cfg->act2, cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
                                         buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
                                         reinterpret_cast<uint32_t*>(flags.data_ptr()), ws, ws_bytes, (int)B, N, F, H1, H2,
@@ -759,6 +775,7 @@ struct RowsFast {
     l_count = count_in;
     xB = B;
     xF = obs.size(1);
+    note_versions();
     ++n_steps;
     ++chain_steps;
     ++cached_steps;
@@ -770,7 +787,8 @@ struct RowsFast {
                     const at::Tensor& weights, const at::Tensor& count_in) {
     const int64_t B = obs.size(0);
     const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
-    if (cache_ok && cached_steps == chain_steps && cached_steps < N && (cached_steps == 0 || cH.size(0) == B))
+    if (cache_ok && cached_steps == chain_steps && cached_steps < N &&
+        (cached_steps == 0 || (cH.size(0) == B && state_untouched())))
       return launch_cached(obs, nodes_in, adj_in, weights, count_in);
     cache_ok = false;
     ++chain_steps;
@@ -833,6 +851,7 @@ struct RowsFast {
     l_adj = adj_out;
     l_weights = weights;
     l_count = count_out;
+    note_versions();
     xB = B;
     xF = obs.size(1);
     ++n_steps;
@@ -913,7 +932,7 @@ struct RowsFast {
     if (grad != grad_mode || (node && node->executed) || (dxc && dxc->executed) || xt.dim() != 2 || xt.size(0) != xB ||
         xt.size(1) != xF || xt.scalar_type() != at::kFloat || !xt.is_cuda() || xt.get_device() != dev ||
         c10::hip::current_device() != dev || (grad && xt.requires_grad() && !dx_mode) || !params_current() ||
-        hooks_registered() || (dx_kind == 1 && !node->can_take(xt)))
+        hooks_registered() || (dx_kind == 1 && !node->can_take(xt)) || (dx_mode && !state_untouched()))
       return pybind11::none();
     at::Tensor obs = xt.is_contiguous() ? xt : xt.contiguous();
     PROF_T(0)
@@ -936,6 +955,12 @@ struct RowsFast {
     return pybind11::make_tuple(pmx, hn);
   }
 
+  // the chain differentiates w.r.t. its observations (their gradient follows the rows of the node matrix back to the
+  // steps that inserted them, by position) and the caller has written into the state this chain returned last
+  bool edited_dx_state(const at::Tensor& nodes, const at::Tensor& adj, const at::Tensor& weights,
+                       const at::Tensor& count) const {
+    return dx_mode && continues(nodes, adj, weights, count) && !state_untouched();
+  }
   int64_t pending() const { return node && !node->executed ? (int64_t)node->recs.size() : 0; }
   void forget() {   // drop the packed vector (and with it the references into its autograd graph)
     armed = false;
@@ -1216,6 +1241,16 @@ struct LearnedChain {   // one per packed parameter vector
   int64_t cached_steps = 0, all_steps = 0;
   at::Tensor cH, cA, cX;
   const void* last_nodes = nullptr;   // the node matrix the previous step returned: a linear chain continues it
+  // the state the previous step returned and its version counters right after the launch (the kernels write through
+  // raw pointers: only a caller's in-place edit moves them, and the caches no longer describe such a state)
+  at::Tensor l_nodes, l_adj, l_count;
+  uint32_t lv_nodes = 0, lv_adj = 0, lv_count = 0;
+  bool state_untouched(const at::Tensor& n, const at::Tensor& a, const at::Tensor& c) const {
+    return l_nodes.defined() && n.unsafeGetTensorImpl() == l_nodes.unsafeGetTensorImpl() &&
+           a.unsafeGetTensorImpl() == l_adj.unsafeGetTensorImpl() &&
+           c.unsafeGetTensorImpl() == l_count.unsafeGetTensorImpl() && n._version() == lv_nodes &&
+           a._version() == lv_adj && c._version() == lv_count;
+  }
   int64_t n_cached() const { return cached_steps; }
 };
 
@@ -1254,7 +1289,8 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
     chain.cache_ok = fresh && (N & 3) == 0 && (F & 3) == 0 && nodes_in_.is_contiguous() && adj_in_.is_contiguous();
   else if (chain.cache_ok)
     chain.cache_ok = chain.last_nodes == nodes_in_.data_ptr() && chain.cached_steps == chain.all_steps &&
-                     chain.cached_steps < N && (!need_bwd || parent == (int64_t)chain.node->recs.size() - 1);
+                     chain.cached_steps < N && (!need_bwd || parent == (int64_t)chain.node->recs.size() - 1) &&
+                     chain.state_untouched(nodes_in_, adj_in_, count_in);
   const bool cached = chain.cache_ok;
   if (cached) {
     if (chain.all_steps == 0) {
@@ -1366,6 +1402,12 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
   }
   ++chain.all_steps;
   chain.last_nodes = nodes_out.data_ptr();
+  chain.l_nodes = nodes_out;
+  chain.l_adj = adj_out;
+  chain.l_count = count_out;
+  chain.lv_nodes = nodes_out._version();
+  chain.lv_adj = adj_out._version();
+  chain.lv_count = count_out._version();
   int64_t index = -1;
   if (need_bwd) {
     const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
@@ -1953,7 +1995,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   pybind11::class_<StepCfg>(m, "StepCfg")
       .def(pybind11::init<int64_t, int, int, int, int, int, int, int, int>())
       .def("handle", [](StepCfg& c) { return reinterpret_cast<int64_t>(&c); })
-      .def("update_descs", &StepCfg::update_descs);
+      .def("update_descs", &StepCfg::update_descs)
+      .def("set_cached_flags", [](StepCfg& c, int f) { c.cached_flags = f; })
+      .def("cached_launches", [](StepCfg& c, int B) {   // launches per cached step (0: no cached form)
+        return gcm_dense_rows_cached_launches(c.descs.empty() ? nullptr : c.descs.data(), (int)c.descs.size(),
+                                              c.has_bias | c.cached_flags, B, c.N, c.F, c.H1, c.H2);
+      });
   m.def("fused_step", &fused_step);
   pybind11::class_<RowsFast>(m, "RowsFast")
       .def(pybind11::init<const std::vector<std::pair<pybind11::object, pybind11::object>>&,
@@ -1961,6 +2008,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("run", &RowsFast::run)
       .def("step", &RowsFast::step)
       .def("continues", &RowsFast::continues)
+      .def("edited_dx_state", &RowsFast::edited_dx_state)
+      .def("donates", [](RowsFast& f) { return f.donate; })
       .def("pending", &RowsFast::pending)
       .def("forget", &RowsFast::forget)
       .def("steps", [](RowsFast& f) { return f.n_steps; })

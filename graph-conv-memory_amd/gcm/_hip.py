@@ -19,6 +19,7 @@ DIST_EUCLID_CROSSBATCH, DIST_L2_PERGRAPH, DIST_COSINE_SIM = 0, 1, 2
 FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
 FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER, FLAG_WINDOW = 8, 16, 32, 64, 128
 GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bits of the live-row step (gcm_hip.h)
+STEP_TWO_LAUNCH = 32      # ... of the cached step: a distance selector and the step as two launches (A/B)
 
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                      ctypes.c_int64)
@@ -101,14 +102,14 @@ PROTOTYPES = {
     "gcm_dense_rows_cached_supported_ws": (_I, [_P, _I, _I, _I, _I, _I, _I]),
     "gcm_dense_rows_step_cached_ws": (_I, [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _Z]
                                       + [_I] * 5 + [_P]),
-    "gcm_debug_set_fused_euclid": (None, [_I]),
+    "gcm_edge_distance_step_cached_supported": (_I, [_I] * 6),
+    "gcm_dense_rows_cached_launches": (_I, [_P, _I, _I, _I, _I, _I, _I, _I]),
     "gcm_edge_distance_step_cached": (_I, [_P] * 4 + [_F, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _P]
                                       + [_I] * 5 + [_P]),
     "gcm_dense_rows_cached_layout": (_I, [_I] * 5 + [_P]),
     "gcm_sparse_step_plan": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "gcm_sparse_chain_edges": (_I, [_P] * 6 + [_I, _P, _P, _L, _L, _I, _P]),
     "gcm_sparse_step_cached": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _P] + [_I] * 5 + [_P]),
-    "gcm_debug_time_cached_rollout": (_I, [_P] * 5 + [_I, _P, _P, _I, _I, _I] + [_P] * 7 + [_I] * 6 + [_P]),
     "gcm_dense_rows_cached_weight_image": (_I, [_P, _P, _I, _I, _I, _P]),
     "gcm_dense_rows_step_cached": (_I, [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_bptt_cached": (_I, [_P, _P, _I, ctypes.c_long, ctypes.c_long, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z]
@@ -122,8 +123,6 @@ PROTOTYPES = {
     "gcm_dense_rows_step_fwd_ws": (_I, [_P] * 9 + [_I] + [_P] + [_I] * 3 + [_P] * 3 + [_P, _Z] + [_I] * 5 + [_P]),
     "gcm_edge_distance_pre": (_I, [_P] * 4 + [_I, _F, _P] + [_I] * 4 + [_P, _Z] + [_I] * 3 + [_P]),
     "gcm_edge_distance_pre_ex": (_I, [_P] * 4 + [_I, _F, _P] + [_I] * 4 + [_P, _I, _P, _Z] + [_I] * 3 + [_P]),
-    "gcm_debug_time_next_launch": (_I, [_P, _P]),
-    "gcm_debug_time_rows_rollout": (_I, [_P] * 5 + [_I, _P, _I, _I, _I] + [_P] * 4 + [_I] * 6 + [_P]),
     "gcm_learned_step_supported": (_I, [_I] * 4),
     "gcm_learned_mlp_param_count": (_Z, [_I]),
     "gcm_learned_select_fused": (_I, [_P, _P, _P, _P, _I, _P, _F, _F, _F, _P, _I, _I, _I, _P]),

@@ -139,6 +139,9 @@ class DenseGCM(torch.nn.Module):
         # False: no cached live-row steps (csrc/rows_cached.hip: the first N steps of a rollout from empty graphs on a
         # donated state, forward-only TemporalBackedge selectors: row cur alone over per-chain caches) - A/B
         self.rows_cached_steps = True
+        # False: a cached EuclideanEdge chain as TWO launches per step (distance kernel, then the cached step) instead
+        # of one (csrc/distance.hip: k_euclid_mfma2<.., TAIL>) - A/B tests; read when a chain is armed
+        self.rows_one_launch_distance = True
         # Steps whose observations / nodes need a gradient run on the live-row kernels too.  True: the whole
         # chain's dL/dx in ONE launch by the chain's single autograd node (hardware float atomics: the order of
         # summation, i.e. the last bits, is not fixed; a policy that feeds belief t-1 into observation t switches
@@ -175,6 +178,15 @@ class DenseGCM(torch.nn.Module):
             if cfg is not False and cfg._rows_fast is not None:
                 n += cfg._rows_fast.cached_steps()
         return n
+
+    def rows_cached_launches_per_step(self, B):
+        """Kernel launches one cached step of this module's last configuration makes at batch size B (0: no cached
+        form; 1: forward temporal hops, or EuclideanEdge alone as the one-launch form; 2: distance kernel + step) -
+        gcm_dense_rows_cached_launches, a pure function of the configuration."""
+        cfg = self._cfg_last[3] if self._cfg_last else None
+        if cfg is None or not cfg.cpp_handle():
+            return 0
+        return cfg._cpp.cached_launches(B)
 
     def _flag_users(self):
         users = self.__dict__.get("_flag_user_list")
@@ -536,6 +548,15 @@ class DenseGCM(torch.nn.Module):
         here at all: DenseGCM.__call__ hands it to the C++ host path (RowsFast.step) directly."""
         nodes, adj, weights, num_nodes = hidden
         fast = cfg.rows_fast(self)
+        if need_dx and fast.edited_dx_state(nodes, adj, weights, num_nodes):
+            # The chain's dL/dx follows the rows of the node matrix back to the steps that inserted them BY POSITION;
+            # a state the caller has edited in place (zeroed graphs of finished episodes ...) no longer has that form.
+            if fast.donates():
+                raise RuntimeError("donate_state=True with observation gradients: the hidden state was modified in "
+                                   "place between two steps of a chain - use functional state (donate_state=False), "
+                                   "or detach the chain (start it again from the edited state under a new call)")
+            self._fast = None
+            return self._forward_fused(x, nodes, adj, weights, num_nodes, cfg, flags, link)   # (full state saved)
         cont = fast.continues(nodes, adj, weights, num_nodes)
         root = self._packed_params(cfg, head=link is None and not cont)
         if not x.is_contiguous():
@@ -549,6 +570,8 @@ class DenseGCM(torch.nn.Module):
         fresh = getattr(nodes, "_gcm_fresh", False)
         if fresh:
             nodes._gcm_fresh = False          # (a donated state is this very tensor at every later step)
+            if cfg.has_distance and cfg.cpp_handle():
+                cfg._cpp.set_cached_flags(0 if self.rows_one_launch_distance else _hip.STEP_TWO_LAUNCH)
         mx, n2, a2, c2, donate = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(),
                                           self.donate_state, need_dx, bool(fresh and self.rows_cached_steps))
         if donate:

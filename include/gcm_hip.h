@@ -491,6 +491,9 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
 /* has_bias bit: the record also keeps what the gradient w.r.t. the observations / incoming nodes needs
  * (gcm_dense_rows_bptt_dx): the live rows' indices and adjacency rows (gcm_dense_rows_layout_dx). */
 #define GCM_GNN_RECORD_DX 16
+/* gcm_dense_rows_step_cached_ws only: a distance selector and the cached step as two launches (see
+ * gcm_dense_rows_cached_launches) */
+#define GCM_STEP_TWO_LAUNCH 32
 int gcm_dense_rows_supported(int N, int F, int H1, int H2);
 int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t* out6);
 /* with GCM_GNN_RECORD_DX: float offsets {total, v, hdr, coef, rows, row width, live, arows} */
@@ -539,22 +542,6 @@ int gcm_edge_distance_pre_ex(const float* nodes_in, const int64_t* count_in, con
                              int a0, int a1, int b0, int b1, const float* cur_rows, int n_cur_rows,
                              void* workspace, size_t workspace_bytes, int B, int N, int F,
                              gcm_stream_t stream);
-
-/* Measurement aid (bench.py): the NEXT gcm_dense_rows_step_fwd launch of the calling thread is
- * bracketed by the two hipEvent_t given here, recorded by the dispatch itself
- * (hipExtLaunchKernelGGL start / stop events: the kernel's own begin / end timestamps, what
- * rocprofv3 --kernel-trace reports) instead of by marker packets around it.  One-shot. */
-int gcm_debug_time_next_launch(void* start_event, void* stop_event);
-
-/* Measurement aid (bench.py): T steps of gcm_dense_rows_step_fwd on the evolving donated state,
- * enqueued back to back from C (the launch cadence of a replayed HIP graph), launch t bracketed by
- * start_events[t] / stop_events[t] (hipEvent_t, recorded by the dispatch itself).  obs_all [T,B,F];
- * saved_per_step: host array of T record pointers (gcm_dense_rows_layout). */
-int gcm_debug_time_rows_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,
-                                const gcm_selector_desc* selectors, int n_selectors, const float* params,
-                                int has_bias, int act1, int act2, float* const* saved_per_step,
-                                uint32_t* flags, void* const* start_events, void* const* stop_events, int T,
-                                int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 
 /* Parameter gradient of n_steps recorded steps in one pass (time-parallel BPTT; valid when neither
  * the observations nor the incoming node matrix need a gradient, so step t's adjoint depends on
@@ -635,7 +622,13 @@ int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, float* adj, in
  * the cached step as one launch (the step is the tail of the matrix-core distance kernel's first wave) -
  * gcm_dense_rows_step_cached_ws takes this path by itself when the shapes allow (>= 32 current rows, F in {32, 64},
  * N <= 128, H1, H2 <= 32); GCM_EUNSUPPORTED otherwise.  lay5: gcm_dense_rows_cached_layout. */
-void gcm_debug_set_fused_euclid(int on);   /* 0: the two-launch form (A/B in tests and tools); default on */
+int gcm_edge_distance_step_cached_supported(int n_cur_rows, int B, int N, int F, int H1, int H2);
+/* -> the number of kernel launches ONE call of gcm_dense_rows_step_cached_ws makes for these arguments (0: not
+ * supported; 1: forward temporal hops, or EuclideanEdge alone in the one-launch form; 2: a distance selector's kernel,
+ * then the step).  GCM_STEP_TWO_LAUNCH in has_bias asks for the two-launch form where the one-launch form exists
+ * (the A/B of tests and tools; a per-call argument - the library holds no switch). */
+int gcm_dense_rows_cached_launches(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int B, int N,
+                                   int F, int H1, int H2);
 int gcm_edge_distance_step_cached(const float* obs, float* nodes, float* adj, int64_t* count, float max_distance,
                                   const float* dist_param, const float* cur_rows, int n_cur_rows, const float* params,
                                   const float* weight_image, int act1, int act2, float* cache_h1, float* cache_agg1,
@@ -652,14 +645,6 @@ int gcm_sparse_step_cached(const float* x, const int64_t* T, const int64_t* taus
                            const float* params, const float* weight_image, int act1, int act2, float* cache_h1,
                            float* cache_agg1, float* cache_nodes, float* mx, float* saved, int record,
                            uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
-/* measurement aid (bench.py): T <= N cached steps of a rollout from empty graphs enqueued back to back from C, each
- * launch bracketed by the caller's HIP events recorded by the dispatch itself (cf. gcm_debug_time_rows_rollout) */
-int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes, float* adj, int64_t* count,
-                                  const gcm_selector_desc* selectors, int n_selectors, const float* params,
-                                  const float* weight_image, int has_bias, int act1, int act2, float* cache_h1,
-                                  float* cache_agg1, float* cache_nodes, float* const* saved_per_step,
-                                  uint32_t* flags, void* const* start_events, void* const* stop_events, int T, int B,
-                                  int N, int F, int H1, int H2, gcm_stream_t stream);
 /* gcm_dense_rows_bptt_dx_all over the records of cached steps (a chain from empty graphs: s0 is also the row the
  * first of these steps' nodes landed in; live rows and their adjacency rows from the selectors' forward hops, their
  * h1 rows from the chain's cache). */

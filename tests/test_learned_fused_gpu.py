@@ -74,88 +74,94 @@ def _pair(F, H, N, k, seed, donate=False):
     return ref, net, g, sel, DenseGCM(g, edge_selectors=sel, graph_size=N, donate_state=donate)
 
 
-def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False):
+def _oracle_learned(ref, net, obs, noise, wgt, k, N, hid0, dtype=torch.float32):
+    """The oracle's per-step loop (learned.py:53-113 restated) with injected gumbel draws, loss = sum(out * wgt), in
+    float32 or float64 (on deep copies) -> (out, final hidden, {name: gradient}; edge network under "net.")."""
+    import copy
+    ref_, net_ = copy.deepcopy(ref).to(dtype), copy.deepcopy(net).to(dtype)
+    for m_ in (ref_, net_):
+        m_.zero_grad(set_to_none=True)
+    step = {"t": 0}
+    osel = od.LearnedEdge(net_, num_edge_samples=k,
+                          noise_fn=lambda shape: noise[step["t"]][:, : shape[1]].to(dtype))
+    hid = None if hid0 is None else tuple(t.to(dtype) if t.is_floating_point() else t.clone() for t in hid0)
+    outs = []
+    for t in range(obs.shape[0]):
+        step["t"] = t
+        mx, hid = od.dense_step(obs[t].to(dtype), hid, ref_, graph_size=N, edge_selectors=osel)
+        outs.append(mx)
+    out = torch.stack(outs)
+    (out * wgt.to(dtype)).sum().backward()
+    grads = {kk: p.grad for kk, p in ref_.named_parameters()}
+    grads.update({"net." + kk: p.grad for kk, p in net_.named_parameters()})
+    return out.detach(), tuple(t.detach() for t in hid), grads
+
+
+def _check_learned_grads(got, g32, g64, same_edges, rtol_sel=2e-3, must_bound=False):
+    """Parameter gradients (GNN + edge network "net.*") against the oracle.  With the same sampled edges in the
+    oracle's float32 and float64 runs: the float64 bound of tests/_golden.py - no further from the float64 gradient
+    than 3x the oracle's own fp32 evaluation is, floor 1e-6 of the gradient scale (the last LayerNorm's bias and
+    the output bias get sum_j g_logit[j] = 0 analytically - softmax gradients sum to zero -: the floor there comes
+    from the edge network's common scale).  Otherwise (a softmax value within rounding of the threshold flipped an
+    edge between the two precisions, so float64 describes another graph): rtol against the float32 oracle."""
+    scale = max(float(v.abs().max()) for kk, v in g64.items() if kk.startswith("net."))
+    assert scale > 0
+    assert same_edges or not must_bound, "the float32 and float64 oracle runs sampled different edges: pick another seed"
+    for kk, gd in got.items():
+        sc = scale if kk.startswith("net.") else float(g64[kk].abs().max())
+        if same_edges:
+            err_ref = float((g32[kk].double() - g64[kk]).abs().max())
+            err = float((gd.double() - g64[kk]).abs().max())
+            assert err <= max(3.0 * err_ref, 1e-6 * sc), (kk, err, err_ref, sc)
+        else:
+            torch.testing.assert_close(gd, g32[kk], rtol=rtol_sel,
+                                       atol=2e-5 * float(g32[kk].abs().max()) + 2e-6 * sc, msg=kk)
+
+
+def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False, must_bound=False):
     """product on the whole batch, oracle on the graphs `pick`, same injected gumbel noise; the loss
-    weights only the picked graphs."""
+    weights only the picked graphs.  count0 = None: from hidden = None (empty graphs: the cached steps)."""
     ref, net, g, sel, mem = _pair(F, H, N, k, seed, donate)
     gen = torch.Generator().manual_seed(seed + 1)
     obs = torch.rand(T, B, F, generator=gen)
     noise = -torch.empty(T, B, N).exponential_(generator=gen).log()
-    nodes0 = torch.rand(B, N, F, generator=gen) * (torch.arange(N)[None, :, None] < count0[:, None, None])
-    adj0 = torch.zeros(B, N, N)
-    i = torch.arange(1, N)
-    adj0[:, i, i - 1] = 1.0
-    adj0 = adj0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+    h0 = hidden = None
+    if count0 is not None:
+        nodes0 = torch.rand(B, N, F, generator=gen) * (torch.arange(N)[None, :, None] < count0[:, None, None])
+        adj0 = torch.zeros(B, N, N)
+        i = torch.arange(1, N)
+        adj0[:, i, i - 1] = 1.0
+        adj0 = adj0 * (torch.arange(N)[None, :, None] < count0[:, None, None])
+        h0 = (nodes0[pick].clone(), adj0[pick].clone(), torch.zeros(0), count0[pick].clone())
+        hidden = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
     wgt = torch.rand(T, len(pick), H, generator=gen)
-    # oracle on the slice
-    step = {"t": 0}
-    osel = od.LearnedEdge(net, num_edge_samples=k,
-                          noise_fn=lambda shape: noise[step["t"]][pick][:, : shape[1]])
-    hid = (nodes0[pick].clone(), adj0[pick].clone(), torch.zeros(0), count0[pick].clone())
-    outs = []
-    for t in range(T):
-        step["t"] = t
-        mx, hid = od.dense_step(obs[t][pick], hid, ref, graph_size=N, edge_selectors=osel)
-        outs.append(mx)
-    out_c = torch.stack(outs)
-    (out_c * wgt).sum().backward()
-    # the same run in float64 (same draws; the same edges unless a softmax value sits within rounding of the
-    # threshold): what bounds the gradient comparison below
-    import copy
-    ref64, net64 = copy.deepcopy(ref).double(), copy.deepcopy(net).double()
-    for m_ in (ref64, net64):
-        m_.zero_grad(set_to_none=True)
-    step64 = {"t": 0}
-    osel64 = od.LearnedEdge(net64, num_edge_samples=k,
-                            noise_fn=lambda shape: noise[step64["t"]][pick][:, : shape[1]].double())
-    hid64 = (nodes0[pick].double(), adj0[pick].double(), torch.zeros(0, dtype=torch.float64), count0[pick].clone())
-    outs64 = []
-    for t in range(T):
-        step64["t"] = t
-        mx, hid64 = od.dense_step(obs[t][pick].double(), hid64, ref64, graph_size=N, edge_selectors=osel64)
-        outs64.append(mx)
-    (torch.stack(outs64) * wgt.double()).sum().backward()
-    same_edges = torch.equal(hid64[1].detach().float(), hid[1].detach())
+    # oracle on the slice, in float32 and in float64 (same draws; the same edges unless a softmax value sits within
+    # rounding of the threshold): the latter bounds the gradient comparison below
+    out_c, hid, g32 = _oracle_learned(ref, net, obs[:, pick], noise[:, pick], wgt, k, N, h0)
+    _, hid64, g64 = _oracle_learned(ref, net, obs[:, pick], noise[:, pick], wgt, k, N, h0, torch.float64)
+    same_edges = torch.equal(hid64[1].float(), hid[1])
     # product on everything
     pstep = {"t": 0}
     sel.noise_fn = lambda like: noise[pstep["t"]].to(DEV)
-    hidden = (nodes0.to(DEV), adj0.to(DEV), torch.zeros(0, device=DEV), count0.to(DEV))
-    h_first = (hidden[0].data_ptr(), hidden[1].data_ptr())
+    h_first = None if hidden is None else (hidden[0].data_ptr(), hidden[1].data_ptr())
     outs = []
     for t in range(T):
         pstep["t"] = t
         mx, hidden = mem(obs[t].to(DEV), hidden)
         outs.append(mx)
     assert _taken(mem)
-    if donate and N % 4 == 0 and F % 4 == 0:       # advanced in place: the caller's own tensors all the way
+    if donate and N % 4 == 0 and F % 4 == 0 and h_first:   # advanced in place: the caller's own tensors all the way
         assert hidden[0].data_ptr() == h_first[0] and hidden[1].data_ptr() == h_first[1]
     out_d = torch.stack(outs)
     (out_d[:, pick] * wgt.to(DEV)).sum().backward()
     mem.check_flags()
-    assert torch.equal(hidden[1][pick].cpu(), hid[1].detach())          # sampled adjacency: bit exact
+    assert torch.equal(hidden[1][pick].cpu(), hid[1])          # sampled adjacency: bit exact
     assert torch.equal(hidden[0][pick].cpu(), hid[0]) and torch.equal(hidden[3][pick].cpu(), hid[3])
-    torch.testing.assert_close(out_d[:, pick].cpu(), out_c.detach(), rtol=RTOL, atol=2e-6)
-    # (the last LayerNorm's bias and the output bias get sum_j g_logit[j] = 0 analytically - softmax
-    #  gradients sum to zero -: rounding noise on both sides, hence the floor from the common scale)
-    scale = max(float(p.grad.abs().max()) for p in net.parameters())
-    assert scale > 0
-    triples = [(kk, pc, pd, p64, float(p64.grad.abs().max()))
-               for ((kk, pc), (_, pd), (_, p64)) in zip(ref.named_parameters(), g.named_parameters(), ref64.named_parameters())]
-    triples += [(kk, pc, pd, p64, scale)
-                for ((kk, pc), (_, pd), (_, p64)) in zip(net.named_parameters(), sel.edge_network.named_parameters(),
-                                                         net64.named_parameters())]
-    if same_edges:
-        # float64 bound (tests/_golden.py): no further from the float64 gradient than 3x the oracle's own fp32
-        # evaluation is, floor 1e-6 of the gradient scale - what fp32 can deliver for the case, not a fixed rtol
-        for kk, pc, pd, p64, sc in triples:
-            err_ref = float((pc.grad.double() - p64.grad).abs().max())
-            err = float((pd.grad.cpu().double() - p64.grad).abs().max())
-            assert err <= max(3.0 * err_ref, 1e-6 * sc), (kk, err, err_ref, sc)
-    else:
-        for kk, pc, pd, p64, sc in triples:
-            torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=rtol_sel,
-                                       atol=2e-5 * float(pc.grad.abs().max()) + 2e-6 * sc, msg=kk)
-    return hidden
+    torch.testing.assert_close(out_d[:, pick].detach().cpu(), out_c, rtol=RTOL, atol=2e-6)
+    got = {kk: p.grad.cpu() for kk, p in g.named_parameters()}
+    got.update({"net." + kk: p.grad.cpu() for kk, p in sel.edge_network.named_parameters()})
+    _check_learned_grads(got, g32, g64, same_edges, rtol_sel, must_bound)
+    return hidden, mem
 
 
 @pytest.mark.parametrize("donate", [False, True])
@@ -174,7 +180,7 @@ def test_learned_fused_cfg5_size_slice():
     B, N, F, H, T = 256, 128, 32, 32, 6
     gen = torch.Generator().manual_seed(3)
     count0 = torch.randint(100, 127, (B,), generator=gen)
-    hidden = _run_both(B, N, F, H, T, 5, seed=11, count0=count0, pick=[0, 97, 255])
+    hidden, _ = _run_both(B, N, F, H, T, 5, seed=11, count0=count0, pick=[0, 97, 255])
     assert int(hidden[3].max()) == N
 
 
@@ -185,10 +191,25 @@ def test_learned_fused_cfg5_size_long_rollout():
     B, N, F, H, T = 256, 128, 32, 32, 44
     gen = torch.Generator().manual_seed(5)
     count0 = torch.randint(108, 127, (B,), generator=gen)
-    hidden = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254])
+    hidden, _ = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254])
     assert int(hidden[3].min()) == N          # every graph is in steady-state overflow by the end
-    hidden = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254], donate=True)
+    hidden, _ = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254], donate=True)
     assert int(hidden[3].min()) == N
+
+
+@pytest.mark.parametrize("donate", [True, False])
+def test_learned_cfg5_timed_path_from_empty_graphs_full_size(donate):
+    """The kernels bench.py --config cfg5 is timed on, at its per-GPU size, directly against the oracle (VERDICT r3
+    #1b): B = 256, N = 128, F = H = 32, a chain from hidden = None - every step a cached step, ONE launch
+    (k_learned_select<MODE, TAIL>: selection + the GNN on row cur over the chain's caches), the backward the two
+    time-parallel passes (k_bptt_rows<.., 2>, k_learned_bptt_b) over the caches - T = 32 steps, injected gumbel
+    draws, oracle on a 3-graph slice in float32 and float64.  Sampled adjacency bit exact, beliefs 1e-5, EVERY
+    gradient (GNN and edge network) inside the float64 bound - no rtol."""
+    B, N, F, H, T = 256, 128, 32, 32, 32
+    hidden, mem = _run_both(B, N, F, H, T, 5, seed=17, count0=None, pick=[2, 101, 255], donate=donate, must_bound=True)
+    assert mem._learned_chain[1].cached_steps() == T        # all of them on the cached step
+    assert int(hidden[3].min()) == T and int(hidden[3].max()) == T
+    assert float(hidden[1].sum()) > B * T                    # (edges were sampled at all)
 
 
 def test_learned_noise_pool_statistics_and_equivalence():
@@ -270,26 +291,15 @@ def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k, donate):
         res.append((out_d.detach().cpu(), [t.detach().cpu() for t in (hidden[0], hidden[1], hidden[3])],
                     {k_: p.grad.cpu().clone() for k_, p in list(g.named_parameters()) +
                      [("net." + n_, p_) for n_, p_ in sel.edge_network.named_parameters()]}))
-    # oracle
-    step = {"t": 0}
-    osel = od.LearnedEdge(net, num_edge_samples=k, noise_fn=lambda shape: noise[step["t"]][:, : shape[1]])
-    hid, outs = None, []
-    for t in range(T):
-        step["t"] = t
-        mx, hid = od.dense_step(obs[t], hid, ref, graph_size=N, edge_selectors=osel)
-        outs.append(mx)
-    out_c = torch.stack(outs)
-    (out_c * wgt).sum().backward()
-    want = dict(list(ref.named_parameters()) + [("net." + n_, p_) for n_, p_ in net.named_parameters()])
-    scale = max(float(p.grad.abs().max()) for p in net.parameters())
+    # oracle, float32 and float64
+    out_c, hid, g32 = _oracle_learned(ref, net, obs, noise, wgt, k, N, None)
+    _, hid64, g64 = _oracle_learned(ref, net, obs, noise, wgt, k, N, None, torch.float64)
+    same_edges = torch.equal(hid64[1].float(), hid[1])
+    scale = max(float(v.abs().max()) for kk, v in g32.items() if kk.startswith("net."))
     for out_d, state, grads in res:
-        assert torch.equal(state[1], hid[1].detach()) and torch.equal(state[0], hid[0]) and torch.equal(state[2], hid[3])
-        torch.testing.assert_close(out_d, out_c.detach(), rtol=RTOL, atol=2e-6)
-        for k_, gd in grads.items():
-            gc = want[k_].grad
-            torch.testing.assert_close(gd, gc, rtol=2e-3 if k_.startswith("net.") else 1e-4,
-                                       atol=2e-5 * float(gc.abs().max()) + 2e-6 * (scale if k_.startswith("net.") else 0.0),
-                                       msg=k_)
+        assert torch.equal(state[1], hid[1]) and torch.equal(state[0], hid[0]) and torch.equal(state[2], hid[3])
+        torch.testing.assert_close(out_d, out_c, rtol=RTOL, atol=2e-6)
+        _check_learned_grads(grads, g32, g64, same_edges)
     for k_ in res[0][2]:       # cached against not cached: the same arithmetic up to summation order
         a, b = res[0][2][k_], res[1][2][k_]   # (gradients that are zero analytically: the floor from the common scale)
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) +

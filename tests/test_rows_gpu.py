@@ -752,7 +752,7 @@ def test_euclid_chain_one_launch_per_step_equals_two():
     step as ONE launch (the step is the tail of k_euclid_mfma2's first wave) against the same chain as two launches
     (gcm_edge_distance_pre, then k_step_rows_cached_img with the decision row): the same state bit for bit, the same
     beliefs and parameter gradients to fp32 summation order."""
-    from gcm import nn as G, _hip
+    from gcm import nn as G
     from gcm.gcm import DenseGCM
     from gcm.edge_selectors.distance import EuclideanEdge
     B, N, F, H, T = 40, 128, 64, 32, 100
@@ -761,25 +761,23 @@ def test_euclid_chain_one_launch_per_step_equals_two():
     obs = (centres[torch.arange(T) % 6][:, None, :] + 0.05 * torch.randn(T, B, F)).to(DEV)
     w = torch.linspace(0.5, 1.5, T * B * H, device=DEV).view(T, B, H)
     res = []
-    try:
-        for fused in (1, 0):
-            _hip.lib().gcm_debug_set_fused_euclid(fused)
-            torch.manual_seed(1)
-            g = G.Sequential("x, adj, weights, B, N", [
-                (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
-                (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
-            mem = DenseGCM(g, edge_selectors=EuclideanEdge(3.0), graph_size=N, donate_state=True)
-            hidden, outs = None, []
-            for t in range(T):
-                mx, hidden = mem(obs[t], hidden)
-                outs.append(mx)
-            assert mem.rows_cached_steps_taken() == T
-            out = torch.stack(outs)
-            (out * w).sum().backward()
-            mem.check_flags()
-            res.append((out.detach(), [h.clone() for h in hidden], {k: p.grad.clone() for k, p in g.named_parameters()}))
-    finally:
-        _hip.lib().gcm_debug_set_fused_euclid(1)
+    for fused in (True, False):
+        torch.manual_seed(1)
+        g = G.Sequential("x, adj, weights, B, N", [
+            (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+            (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+        mem = DenseGCM(g, edge_selectors=EuclideanEdge(3.0), graph_size=N, donate_state=True)
+        mem.rows_one_launch_distance = fused      # (a per-call flag of the C ABI: GCM_STEP_TWO_LAUNCH)
+        hidden, outs = None, []
+        for t in range(T):
+            mx, hidden = mem(obs[t], hidden)
+            outs.append(mx)
+        assert mem.rows_cached_steps_taken() == T
+        assert mem.rows_cached_launches_per_step(B) == (1 if fused else 2)
+        out = torch.stack(outs)
+        (out * w).sum().backward()
+        mem.check_flags()
+        res.append((out.detach(), [h.clone() for h in hidden], {k: p.grad.clone() for k, p in g.named_parameters()}))
     a, b = res
     assert float(a[1][1].sum()) > 0
     for x, y in zip(a[1], b[1]):
@@ -788,3 +786,46 @@ def test_euclid_chain_one_launch_per_step_equals_two():
     for k in a[2]:
         scale = float(b[2][k].abs().max()) + 1e-12
         torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-4, atol=2e-5 * scale, msg=k)
+
+
+@pytest.mark.parametrize("sel,F", [(("temporal", [1, 2, 4], "forward"), 32), (("temporal", [1, 3], "both"), 32)])
+def test_rows_donated_state_reset_in_place_mid_chain(sel, F):
+    """A caller that owns a donated state may edit it between two steps - the usual RL idiom at an episode's end:
+    `num_nodes[done] = 0; nodes[done] = 0; adj[done] = 0`.  A cached step reads its per-chain caches and the host's
+    step count, not the state (rows_cached.hip): the host path watches the state's version counters and hands the
+    rest of such a chain to the kernel that reads the state.  Against the oracle with the same edit."""
+    B, N, H, T, t_reset, done = 6, 16, 32, 30, 9, [1, 4]
+    torch.manual_seed(77)
+    ref, g, mem, osel = _mk(B, N, F, H, H, sel, True)
+    obs = torch.rand(T, B, F)
+    w = torch.rand(T, B, H)
+    # oracle: two segments around the edit
+    out_a, hid_o = od.dense_rollout(obs[:t_reset], None, ref, graph_size=N, edge_selectors=osel)
+    nodes_o, adj_o, w_o, count_o = (t.clone() for t in hid_o)
+    count_o[done] = 0
+    nodes_o[done] = 0
+    adj_o[done] = 0
+    out_b, hid_o = od.dense_rollout(obs[t_reset:], (nodes_o, adj_o, w_o, count_o), ref, graph_size=N,
+                                    edge_selectors=osel)
+    out_o = torch.cat([out_a, out_b])
+    (out_o * w).sum().backward()
+    hid, outs = None, []
+    for t in range(T):
+        if t == t_reset:
+            hid[3][done] = 0
+            hid[0][done] = 0
+            hid[1][done] = 0
+        mx, hid = mem(obs[t].to(DEV), hid)
+        outs.append(mx)
+    assert mem.rows_steps() == T
+    if sel[2] == "forward":      # cached steps up to the edit, the state-reading kernel behind it
+        assert mem.rows_cached_steps_taken() == t_reset
+    out_d = torch.stack(outs)
+    (out_d * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    assert torch.equal(hid[0].cpu(), hid_o[0]) and torch.equal(hid[1].cpu(), hid_o[1])
+    assert torch.equal(hid[3].cpu(), hid_o[3])
+    torch.testing.assert_close(out_d.detach().cpu(), out_o.detach(), rtol=RTOL, atol=2e-6)
+    for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
+        scale = float(pc.grad.abs().max()) + 1e-12
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=2e-5 * scale, msg=k)
