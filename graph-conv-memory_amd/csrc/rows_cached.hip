@@ -21,6 +21,8 @@
 // (h1 | agg1 | x) from the caches.
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+
 #include "fused_common.h"
 #include "gcm_common.h"
 #include "rows_common.h"
@@ -465,6 +467,178 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The cached step in the STEADY STATE of such a chain (round 4): t_abs >= N steps made, every graph is full and
+// every step drops the oldest node (gcm.py:263-271, 323-355: zero row / column 0, roll nodes by -1 and the
+// adjacency by (-1, -1), insert at row N - 1).  For a chain whose selectors are forward temporal hops only
+// (temporal.py:72-88) and that started from empty graphs:
+//   * the adjacency is the band adj[i, i - h] = 1 (i >= h) on every full graph, and the roll maps that band onto
+//     itself (new[i, i - h] = old[i + 1, i + 1 - h]; the entries of column 0 fall off, row N - 1 is zeroed and
+//     gets the same hops back from the selector): the step leaves the adjacency and the count UNTOUCHED - the
+//     reference rewrites all N^2 entries per graph and step to arrive at the same values;
+//   * the caches become rings: node t lives in slot t mod N, the rows the new node aggregates from are the nodes
+//     t_abs - h, whose layer-1 rows are still final when N > 2 max(hop): a node's own sources are at most
+//     max(hop) older, and only nodes older than t_abs - N have been dropped;
+//   * the node matrix does roll (nodes[i] <- nodes[i + 1], the observation into row N - 1): a second wave of the
+//     graph's workgroup moves it in place - every load of the graph before its first store, one wave, in order.
+// Wave 0 is the step proper (the body of k_step_rows_cached_img in ring coordinates, its node rows from the cX
+// ring instead of the matrix the other wave is moving).  A ring slot is overwritten N steps later, so the
+// record of such a step is the GENERAL live-row record (rows_common.h: SavedLayout - the rows h1 | agg1 | x of the
+// live rows travel in the record, ascending, row cur last), which gcm_dense_rows_bptt reads like any other.
+// hops: sorted descending, distinct, 0 < h < N (host: gcm_dense_rows_step_cached_roll); self: a hop of 0.
+// ---------------------------------------------------------------------------------------------------------
+template <int FP, int HP>
+__global__ __launch_bounds__(128) void k_step_rows_cached_roll(
+    const float* __restrict__ obs, float* __restrict__ nodes, gcm_fused::Edits E, int self_i,
+    const float* __restrict__ params, const float* __restrict__ image, int act1, int act2, float* __restrict__ cH,
+    float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved, SavedLayout lay, int record,
+    uint32_t* __restrict__ flags, int B, int N, int H2, int slot_new) {
+  // slot_new = t_abs mod N (host): the ring slot of the new node; node t_abs - h sits h slots behind it
+  constexpr int F = FP, H1 = HP;
+  __shared__ __attribute__((aligned(16))) float sv[128];
+  const int lane = threadIdx.x & 63;
+  const unsigned gb = blockIdx.x;
+  if (threadIdx.x >= 64) {
+    // ---- wave 1: the node matrix, in place: row r <- row r + 1, row N - 1 <- the observation -------------------
+    constexpr int PER = 128 * FP / 4 / 64;                 // float4 per lane at N = 128
+    const int F4 = F / 4, total = N * F4, moved = total - F4;
+    // (an array of HIP's float4 STRUCT of this length is not promoted to registers by hipcc 7.2 - it went through
+    //  scratch memory; the compiler's own vector type is)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f* g4 = reinterpret_cast<v4f*>(nodes + (size_t)gb * N * F);
+    const v4f* o4 = reinterpret_cast<const v4f*>(obs + (size_t)gb * F);
+    v4f v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lane + 64 * i;
+      const int src = idx < moved ? idx + F4 : total - 1;   // (clamped: an unconditional load)
+      v[i] = g4[src];
+    }
+    const v4f ov = o4[lane < F4 ? lane : F4 - 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // source and destination alias: every load has landed
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < moved) g4[idx] = v[i];
+    }
+    if (lane < F4) g4[moved + lane] = ov;
+    if (gb == 0 && lane == 0) atomicOr(flags, GCM_FLAG_WRAPPED);   // gcm.py:264-266: the caller's one-time notice
+    return;
+  }
+  // ---- wave 0: the step on row cur = N - 1, ring coordinates -----------------------------------------------------
+  const float* b1 = params + 2 * H1 * F;
+  const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
+  float r1[F], t1[F], r2[H1], t2[H1];
+#pragma unroll
+  for (int k = 0; k < F; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
+#pragma unroll
+  for (int k = 0; k < H1; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
+  const float bias1 = b1[hl], bias2 = b2[ol];
+  const float xc = obs[gb * F + fl];
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  const int n_h = E.n_hops;
+  const bool self = self_i != 0;
+  // the selected rows, ascending in node age (hops descending): the first four in one round trip with everything
+  // above, further ones four at a time
+  float xa[4], ha[4], ca[4];
+  int slot[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool on = q < n_h;
+    const int h = on ? E.hops[q] : 0;
+    slot[q] = slot_new - h + (slot_new < h ? N : 0);        // (0 < h < N)
+    const unsigned rj = gb * (unsigned)N + (unsigned)slot[q];
+    const float tx = cX[rj * F + fl], th = cH[rj * H1 + hl], ta = cA[rj * F + fl];
+    xa[q] = on ? tx : 0.f;
+    ha[q] = on ? th : 0.f;
+    ca[q] = ta;
+  }
+  asm volatile("" ::: "memory");
+  float* rows = saved + lay.o_rows + (size_t)gb * N * lay.rw;
+  const bool rec = record != 0;
+  float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
+  if (rec) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < n_h) {
+        float* row = rows + (size_t)q * lay.rw;
+        if (lane < H1) row[lane] = ha[q];
+        if (lane < F) { row[H1 + lane] = ca[q]; row[H1 + F + lane] = xa[q]; }
+      }
+  }
+  for (int q = 4; q < n_h; ++q) {
+    int hq = 0;   // (a run-time index into the kernel-argument array would move it to scratch)
+#pragma unroll
+    for (int i = 4; i < 16; ++i) hq = q == i ? E.hops[i] : hq;
+    const int sl = slot_new - hq + (slot_new < hq ? N : 0);
+    const unsigned rj = gb * (unsigned)N + (unsigned)sl;
+    const float tx = cX[rj * F + fl], th = cH[rj * H1 + hl], ta = cA[rj * F + fl];
+    agg1 += tx;
+    agg2 += th;
+    if (rec) {
+      float* row = rows + (size_t)q * lay.rw;
+      if (lane < H1) row[lane] = th;
+      if (lane < F) { row[H1 + lane] = ta; row[H1 + F + lane] = tx; }
+    }
+  }
+  agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
+  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
+  float p1 = bias1;
+  {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < F / 4; ++f4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
+      pa = fmaf(r1[4 * f4], a.x, pa); pb = fmaf(t1[4 * f4], x.x, pb);
+      pa = fmaf(r1[4 * f4 + 1], a.y, pa); pb = fmaf(t1[4 * f4 + 1], x.y, pb);
+      pa = fmaf(r1[4 * f4 + 2], a.z, pa); pb = fmaf(t1[4 * f4 + 2], x.z, pb);
+      pa = fmaf(r1[4 * f4 + 3], a.w, pa); pb = fmaf(t1[4 * f4 + 3], x.w, pb);
+    }
+    p1 += pa + pb;
+  }
+  const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
+  agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
+  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }
+  float p2 = bias2;
+  {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int h4 = 0; h4 < H1 / 4; ++h4) {
+      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
+      pa = fmaf(r2[4 * h4], a.x, pa); pb = fmaf(t2[4 * h4], x.x, pb);
+      pa = fmaf(r2[4 * h4 + 1], a.y, pa); pb = fmaf(t2[4 * h4 + 1], x.y, pb);
+      pa = fmaf(r2[4 * h4 + 2], a.z, pa); pb = fmaf(t2[4 * h4 + 2], x.z, pb);
+      pa = fmaf(r2[4 * h4 + 3], a.w, pa); pb = fmaf(t2[4 * h4 + 3], x.w, pb);
+    }
+    p2 += pa + pb;
+  }
+  const float v = gcm_act_sel(p2, act2_v);
+  const unsigned rc = gb * (unsigned)N + (unsigned)slot_new;      // the new node's ring slot (node t_abs - N leaves)
+  if (lane < F) { cX[rc * F + lane] = xc; cA[rc * F + lane] = agg1; }
+  if (lane < H1) cH[rc * H1 + lane] = h1c;
+  if (lane < H2) saved[gb * H2 + lane] = v;                         // mx: the head of the record
+  if (rec) {
+    if (lane < H1) {
+      saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
+      saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
+    }
+    float* row = rows + (size_t)n_h * lay.rw;                       // row cur: last in the list
+    if (lane < H1) row[lane] = h1c;
+    if (lane < F) { row[H1 + lane] = agg1; row[H1 + F + lane] = xc; }
+    float* coef = saved + lay.o_coef + (size_t)gb * N;
+    if (lane <= n_h) coef[lane] = (lane < n_h || self) ? 1.f : 0.f;
+    if (lane == 0) {
+      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
+      hdr[0] = n_h + 1; hdr[1] = n_h; hdr[2] = N - 1; hdr[3] = 1;
+    }
+  }
+  const bool nonfinite = __any(lane < H2 && !isfinite(v));
+  if (nonfinite && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // SparseGCM, stepwise use (sparse_gcm.py:72-212 called with one new node per graph: x [B, 1, F], taus in {0, 1}) with a
 // TemporalEdge selector (sparse_edge_selectors/temporal.py:18-63), in a chain that started from empty graphs: the
 // same argument - edges only ever point from a new node to older ones, so the layer-1 row of a node is final once
@@ -741,6 +915,64 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   }
   GCM_RC(32, 32) GCM_RC(64, 32) GCM_RC(32, 64) GCM_RC(64, 64)
 #undef GCM_RC
+  return GCM_EUNSUPPORTED;
+}
+
+// hops of forward temporal selectors as the steady-state step wants them: distinct, descending, 0 < h < N; -> count,
+// -1 when the configuration has no steady-state cached form
+static int roll_hops(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N, int F, int H1, int H2,
+                     int* hops16, int* self) {
+  if (!cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2, false)) return -1;
+  int n = 0, mx = 0;
+  *self = 0;
+  for (int i = 0; i < n_selectors; ++i)
+    for (int k = 0; k < selectors[i].n_hops; ++k) {
+      const int h = selectors[i].hops[k];
+      if (h < 0 || h > N - 1) continue;   // (temporal.py:74: no source for this hop in a graph of N nodes)
+      if (h == 0) { *self = 1; continue; }
+      bool seen = false;
+      for (int q = 0; q < n; ++q) seen = seen || hops16[q] == h;
+      if (!seen) hops16[n++] = h;
+      mx = h > mx ? h : mx;
+    }
+  if (N <= 2 * mx) return -1;             // the rows the new node aggregates from must not have lost a source
+  std::sort(hops16, hops16 + n, [](int a, int b) { return a > b; });
+  return n;
+}
+
+extern "C" int gcm_dense_rows_cached_roll_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
+                                                    int N, int F, int H1, int H2) {
+  int hops[16], self;
+  return roll_hops(selectors, n_selectors, has_bias, N, F, H1, H2, hops, &self) >= 0 ? 1 : 0;
+}
+
+extern "C" int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, const gcm_selector_desc* selectors,
+                                               int n_selectors, const float* params, const float* weight_image,
+                                               int has_bias, int act1, int act2, float* cache_h1, float* cache_agg1,
+                                               float* cache_nodes, float* saved, int record, int t_abs, uint32_t* flags,
+                                               int B, int N, int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && params && weight_image && cache_h1 && cache_agg1 && cache_nodes && saved && flags);
+  GCM_REQUIRE(B > 0 && (selectors || n_selectors == 0) && t_abs >= N);
+  if ((size_t)B * N * (size_t)(F > N ? F : N) >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;   // 32-bit offsets inside
+  gcm_fused::Edits E{};
+  int hops[16], self = 0;
+  const int n = roll_hops(selectors, n_selectors, has_bias, N, F, H1, H2, hops, &self);
+  if (n < 0) return GCM_EUNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    E.hops[i] = hops[i];
+    E.dir[i] = GCM_DIR_FORWARD;
+  }
+  E.n_hops = n;
+  const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
+#define GCM_RR(a, b_)                                                                                             \
+  if (F == a && H1 == b_) {                                                                                       \
+    hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_>), dim3(B), dim3(128), 0, (hipStream_t)stream, obs,   \
+                       nodes, E, self, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes, saved,    \
+                       lay, record, flags, B, N, H2, t_abs % N);                                                      \
+    return gcm_launch_status();                                                                                   \
+  }
+  GCM_RR(32, 32) GCM_RR(64, 32) GCM_RR(32, 64) GCM_RR(64, 64)
+#undef GCM_RR
   return GCM_EUNSUPPORTED;
 }
 

@@ -583,8 +583,13 @@ struct RowsFast {
   // cached steps (rows_cached.hip): the armed chain started from the empty graphs of hidden = None on a donated
   // state, its selectors only write row cur, it is linear and has made fewer than N steps
   bool cache_ok = false;
-  int64_t cached_steps = 0, chain_steps = 0;
+  // ... and past N steps, in the steady state (every graph full, every step drops its oldest node), while the
+  // selectors are forward temporal hops with N > 2 max(hop): gcm_dense_rows_step_cached_roll - the caches as rings,
+  // the band adjacency untouched, the node matrix rolled in place
+  bool roll_ok = false;
+  int64_t cached_steps = 0, chain_steps = 0, rolled_steps = 0;
   at::Tensor cH, cA, cX, wimg;
+  at::Tensor rH, rA, rX;   // the ring caches of the steady-state steps (copies: the first N records keep reading cH / cA / cX)
   std::shared_ptr<DxChain> dxc;
   std::shared_ptr<DxGateNode> dx_gate;
   std::shared_ptr<DxStepNode> dx_last;
@@ -707,15 +712,67 @@ struct RowsFast {
         node->start_dx();
       }
     }
-    chain_steps = cached_steps = 0;
-    cH = cA = cX = at::Tensor();
+    chain_steps = cached_steps = rolled_steps = 0;
+    cH = cA = cX = rH = rA = rX = at::Tensor();
     // (a distance selector's decisions reach the cached step as a row: no hop table to rebuild the live rows from
     //  in the observation-gradient launch - those chains stay on the general kernel)
     cache_ok = fresh && donate && dx_kind != 2 && !(cfg->has_distance && dx_kind != 0) &&
                gcm_dense_rows_cached_supported_ws(cfg->descs.empty() ? nullptr : cfg->descs.data(),
                                                   (int)cfg->descs.size(), cfg->has_bias, cfg->N, cfg->F, cfg->H1,
                                                   cfg->H2) != 0;
+    // (observation gradients follow the rows of the node matrix back to their steps by position: such chains hand
+    //  the rolling regime to the kernel that records the rows' positions)
+    roll_ok = cache_ok && dx_kind == 0 &&
+              gcm_dense_rows_cached_roll_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                                   (int)cfg->descs.size(), cfg->has_bias, cfg->N, cfg->F, cfg->H1,
+                                                   cfg->H2) != 0;
     armed = true;
+  }
+
+  // a cached step in the steady state (see roll_ok): the general live-row record, the state's node matrix rolled in
+  // place by the same launch, adjacency and count as they are
+  at::Tensor launch_cached_roll(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                                const at::Tensor& weights, const at::Tensor& count_in) {
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = node != nullptr;
+    if (rolled_steps == 0) {
+      // A ring slot is overwritten N steps later, but the records of the first N steps read their rows from the
+      // caches when the backward runs: the rings start as copies (once per chain; no backward, no copy)
+      if (need_bwd) { rH = cH.clone(); rA = cA.clone(); rX = cX.clone(); }
+      else { rH = cH; rA = cA; rX = cX; }
+    }
+    size_t lay[8];
+    check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
+    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
+    check(gcm_dense_rows_step_cached_roll(obs.data_ptr<float>(), nodes_in.data_ptr<float>(),
+                                          cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
+                                          packed.data_ptr<float>(), wimg.data_ptr<float>(), cfg->has_bias, cfg->act1,
+                                          cfg->act2, rH.data_ptr<float>(), rA.data_ptr<float>(), rX.data_ptr<float>(),
+                                          buf.data_ptr<float>(), need_bwd ? 1 : 0, (int)cached_steps,
+                                          reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
+          "gcm_dense_rows_step_cached_roll");
+    at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
+    if (need_bwd) {
+      const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
+      RowsChainNode::Rec r{buf, vc, vc.current_version()};   // (cached = false: its rows travel in the record)
+      r.out_mx = (int)node->num_inputs();
+      torch::autograd::create_gradient_edge(mx, node);
+      node->recs.push_back(std::move(r));
+    }
+    l_nodes = nodes_in;
+    l_adj = adj_in;
+    l_weights = weights;
+    l_count = count_in;
+    note_versions();
+    xB = B;
+    xF = obs.size(1);
+    ++n_steps;
+    ++chain_steps;
+    ++cached_steps;
+    ++rolled_steps;
+    return mx;
   }
 
   // a cached step (see cache_ok): one small launch, the record without a rows section
@@ -787,9 +844,11 @@ struct RowsFast {
                     const at::Tensor& weights, const at::Tensor& count_in) {
     const int64_t B = obs.size(0);
     const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
-    if (cache_ok && cached_steps == chain_steps && cached_steps < N &&
-        (cached_steps == 0 || (cH.size(0) == B && state_untouched())))
-      return launch_cached(obs, nodes_in, adj_in, weights, count_in);
+    if (cache_ok && cached_steps == chain_steps && (cached_steps == 0 || (cH.size(0) == B && state_untouched()))) {
+      if (cached_steps < N) return launch_cached(obs, nodes_in, adj_in, weights, count_in);
+      // (t_abs as an int, ring slots from it: a chain of 2^31 steps ends the cached run)
+      if (roll_ok && cached_steps < (int64_t)0x7fffffff) return launch_cached_roll(obs, nodes_in, adj_in, weights, count_in);
+    }
     cache_ok = false;
     ++chain_steps;
     const bool need_bwd = node != nullptr || dxc != nullptr;
@@ -2014,6 +2073,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("forget", &RowsFast::forget)
       .def("steps", [](RowsFast& f) { return f.n_steps; })
       .def("cached_steps", [](RowsFast& f) { return f.cached_steps; })
+      .def("rolled_steps", [](RowsFast& f) { return f.rolled_steps; })
       .def("has_chain", [](RowsFast& f) { return f.node != nullptr || f.dxc != nullptr; });
   pybind11::class_<LearnedCfg>(m, "LearnedCfg")
       .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())

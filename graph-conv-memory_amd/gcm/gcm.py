@@ -179,6 +179,14 @@ class DenseGCM(torch.nn.Module):
                 n += cfg._rows_fast.cached_steps()
         return n
 
+    def rows_rolled_steps_taken(self):
+        """... of which steady-state ones (gcm_dense_rows_step_cached_roll: past N steps, every step drops the oldest node)."""
+        n = 0
+        for cfg in self._cfg_cache.values():
+            if cfg is not False and cfg._rows_fast is not None:
+                n += cfg._rows_fast.rolled_steps()
+        return n
+
     def rows_cached_launches_per_step(self, B):
         """Kernel launches one cached step of this module's last configuration makes at batch size B (0: no cached
         form; 1: forward temporal hops, or EuclideanEdge alone as the one-launch form; 2: distance kernel + step) -

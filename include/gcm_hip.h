@@ -622,6 +622,21 @@ int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, float* adj, in
  * the cached step as one launch (the step is the tail of the matrix-core distance kernel's first wave) -
  * gcm_dense_rows_step_cached_ws takes this path by itself when the shapes allow (>= 32 current rows, F in {32, 64},
  * N <= 128, H1, H2 <= 32); GCM_EUNSUPPORTED otherwise.  lay5: gcm_dense_rows_cached_layout. */
+/* The cached step in the STEADY STATE of such a chain (t_abs >= N steps made: every graph is full and every step
+ * drops the oldest node, gcm.py:263-271, 323-355), selectors = forward temporal hops only, N > 2 max(hop).  There
+ * the band adjacency is a fixed point of the overflow roll (the step leaves adj and count untouched - the values
+ * the reference arrives at by rewriting all of it), the caches are rings (node t in slot t mod N), and the node
+ * matrix is rolled in place by a second wave of the graph's workgroup.  saved: the GENERAL live-row record
+ * (gcm_dense_rows_layout; written in full with record != 0, else mx [B,H2] only) - gcm_dense_rows_bptt reads it.
+ * weight_image: gcm_dense_rows_cached_weight_image.  GCM_EUNSUPPORTED when the configuration has no such form
+ * (gcm_dense_rows_cached_roll_supported). */
+int gcm_dense_rows_cached_roll_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
+                                         int F, int H1, int H2);
+int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, const gcm_selector_desc* selectors, int n_selectors,
+                                    const float* params, const float* weight_image, int has_bias, int act1, int act2,
+                                    float* cache_h1, float* cache_agg1, float* cache_nodes, float* saved, int record,
+                                    int t_abs, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                    gcm_stream_t stream);
 int gcm_edge_distance_step_cached_supported(int n_cur_rows, int B, int N, int F, int H1, int H2);
 /* -> the number of kernel launches ONE call of gcm_dense_rows_step_cached_ws makes for these arguments (0: not
  * supported; 1: forward temporal hops, or EuclideanEdge alone in the one-launch form; 2: a distance selector's kernel,

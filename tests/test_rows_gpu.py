@@ -674,15 +674,20 @@ def test_rows_obs_gradient_with_donated_state():
 
 @pytest.mark.parametrize("sel,B,N,F,H,T", [(("temporal", [1, 2, 4], "forward"), 5, 16, 32, 32, 40),
                                            (("temporal", [2, 5], "forward"), 4, 12, 32, 64, 20),
-                                           (("temporal", [0, 1, 3], "forward"), 3, 128, 32, 32, 131),
+                                           (("temporal", [0, 1, 3], "forward"), 3, 128, 32, 32, 300),   # (T > 2N)
+                                           (("temporal", [1, 2, 4], "forward"), 7, 128, 32, 32, 270),
+                                           (("temporal", [3, 7], "forward"), 4, 12, 32, 32, 40),      # (N <= 2 max hop: no steady-state form)
                                            (("temporal", [1], "forward"), 6, 32, 64, 32, 30),
                                            (("temporal", [1, 2, 3, 4, 5, 6], "forward"), 2, 20, 64, 64, 26),
                                            (("temporal", [1, 2], "forward"), 3, 16, 8, 16, 20)])   # (sizes the kernel does not take)
 def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
     """A donated rollout from hidden = None whose selectors only write row cur: its first N steps are cached steps
-    (rows_cached.hip: row cur alone over the chain's h1 / agg1 / node caches), the steps behind them - the graphs
-    overflow - the usual live-row ones, one backward over both kinds.  Against the oracle (state bit exact) and
-    against the same rollout with the cached steps switched off."""
+    (rows_cached.hip: row cur alone over the chain's h1 / agg1 / node caches), and the steps behind them - every
+    graph full, every step drops its oldest node (gcm.py:323-355) - the steady-state cached steps (round 4:
+    k_step_rows_cached_roll - the caches as rings, the band adjacency a fixed point of the roll and left untouched,
+    the node matrix rolled in place) when N > 2 max(hop), else the usual live-row ones; one backward over both
+    kinds of record.  Against the oracle (state bit exact, T up to 300 > 2N) and against the same rollout with the
+    cached steps switched off."""
     res = []
     obs = None
     for cached in (True, False):
@@ -696,7 +701,10 @@ def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
             mx, hid = mem(obs[t].to(DEV), hid)
             outs.append(mx)
         takes = F in (32, 64) and H in (32, 64)      # (the cached kernel is specialised on these)
-        assert mem.rows_steps() == T and mem.rows_cached_steps_taken() == (min(T, N) if cached and takes else 0)
+        steady = N > 2 * max(sel[1])                 # (the steady-state form: see above)
+        assert mem.rows_steps() == T
+        assert mem.rows_cached_steps_taken() == ((T if steady else min(T, N)) if cached and takes else 0)
+        assert mem.rows_rolled_steps_taken() == (max(0, T - N) if cached and takes and steady else 0)
         if cached:   # selectors that write older rows keep the usual step
             _, _, mem_b, _ = _mk(B, N, F, H, H, ("temporal", [1], "both"), True)
             mem_b(obs[0].to(DEV), None)
