@@ -182,6 +182,81 @@ def event_time(fn, iters, warm=3):
     return a.elapsed_time(b) / iters
 
 
+def short_kernel_name(name):
+    """'void ns::k<32, 32>(float const*, ...)' -> 'ns::k<32, 32>' (argument list and return type dropped)"""
+    name = name.strip()
+    if name.endswith(")"):
+        depth = 0
+        for i in range(len(name) - 1, -1, -1):
+            depth += name[i] == ")"
+            depth -= name[i] == "("
+            if depth == 0:
+                name = name[:i]
+                break
+    return name[5:] if name.startswith("void ") else name
+
+
+def profile_kernels(fn, reps=3):
+    """Per-kernel durations of `reps` calls of `fn`, measured LIVE in this process by torch.profiler's device
+    activity tracing (kineto over roctracer: each kernel's begin / end timestamps on the stream it was launched on -
+    what `rocprofv3 --kernel-trace --stats` reports; the committed profiles/ summaries of the same command must
+    agree).  Works for kernels launched eagerly and for kernel nodes of a replayed HIP graph alike.  Independent of
+    the wall-clock `value`.  -> {short kernel name: {"launches_per_call", "avg_us", "us_per_call"}}"""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    out = {}
+    for e in prof.key_averages():
+        if e.device_time_total <= 0 or e.count <= 0:
+            continue
+        k = short_kernel_name(e.key)
+        d = out.setdefault(k, {"launches_per_call": 0.0, "us_per_call": 0.0})
+        d["launches_per_call"] += e.count / reps
+        d["us_per_call"] += e.device_time_total / reps
+    for d in out.values():
+        d["avg_us"] = d["us_per_call"] / max(d["launches_per_call"], 1e-9)
+    return out
+
+
+def kernel_table(prof, top=10):
+    """the `top` kernels of a profile_kernels() result by time, with their share of the GPU time of a call"""
+    total = sum(d["us_per_call"] for d in prof.values()) or 1.0
+    rows = sorted(prof.items(), key=lambda kv: -kv[1]["us_per_call"])[:top]
+    return [{"kernel": k, "launches_per_step": round(d["launches_per_call"], 2), "avg_us": round(d["avg_us"], 3),
+             "us_per_step": round(d["us_per_call"], 2), "share_of_gpu_time": round(d["us_per_call"] / total, 4)}
+            for k, d in rows], total
+
+
+def find_kernel(prof, *prefixes):
+    """the entry whose short name contains one of the given pieces (the longest-running one when several do)"""
+    best = None
+    for k, d in prof.items():
+        if any(pf in k for pf in prefixes) and (best is None or d["us_per_call"] > best[1]["us_per_call"]):
+            best = (k, d)
+    return best
+
+
+def launch_floor(grid, block, nodes=128):
+    """What a chain of dependent launches costs on this box when the kernels do nothing (libgcm_hip_debug.so):
+    us per node of a replayed HIP graph of `nodes` empty kernels of the step kernel's launch shape, the begin -> end
+    duration of one empty dispatch and the begin-to-begin cadence of back-to-back empty launches outside a graph."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gcm_debuglib
+    g_us, d_us, c_us = gcm_debuglib.launch_floor(grid=grid, block=block, nodes=nodes)
+    return {"graph_of_%d_empty_kernels_us_per_node" % nodes: round(g_us, 3),
+            "empty_dispatch_begin_to_end_us": round(d_us, 3), "empty_back_to_back_cadence_us": round(c_us, 3),
+            "grid": grid, "block": block,
+            "note": "cadence of a replayed HIP graph of empty kernels (same grid x block as the step kernel), one "
+                    "after the other on one stream like the captured per-step loop: the launch floor the step "
+                    "kernel's duration is to be read against; begin -> end of an empty kernel bracketed by "
+                    "dispatch-recorded events (hipExtLaunchKernelGGL) beside it"}
+
+
 # ------------------------------------------------------------------------------------------------
 # in-situ duration of the dominant kernels
 # ------------------------------------------------------------------------------------------------
@@ -324,7 +399,8 @@ def time_step_kernel(mem, obs, c, reps=10):
 
 def time_euclid_kernel(c, iters=50):
     """k_euclid_mfma alone (gcm_edge_distance_pre through the C ABI) on FULL graphs (every row a
-    candidate: 2*B*B*N*F flops per launch), HIP events around back-to-back launches."""
+    candidate: 2*B*B*N*F flops per launch): `iters` back-to-back launches under the
+    in-process kernel profiler -> profile_kernels() result."""
     import torch
     from gcm import _hip
     lib, p, st = _hip.lib(), _hip.ptr, _hip.stream()
@@ -343,7 +419,13 @@ def time_euclid_kernel(c, iters=50):
                                        0, 0, 0, 0, p(ws), ws_bytes, B, N, F, st)
         assert rc == 0
 
-    return event_time(launch, iters, warm=5)
+    def burst():
+        for _ in range(iters):
+            launch()
+
+    for _ in range(5):
+        launch()
+    return profile_kernels(burst, reps=1)
 
 
 def time_csr_kernels(c, iters=50):
@@ -646,112 +728,215 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                 torch.cuda.synchronize()
         mem_f.check_flags()
 
+    # ---- the steady-state regime ("also T=256"): after t >= graph_size every step drops every graph's
+    # oldest node (gcm.py:263-271, 323-355) - the normal regime of a long RL rollout --------------------------------
+    if c["selector"] == "temporal" and T <= N and not args.headline_only:
+        from gcm.gcm import DenseGCM
+        DenseGCM.did_warn = True     # (the reference's one-time overflow notice is a print: stdout stays ONE JSON line)
+        T2 = 2 * N
+        obs2 = make_obs(dict(c, T=T2), rank, device)
+        mem_2, gnn_2, _ = build_memory(device, donate=True, selector=c["selector"], cfg=c)
+        g2 = capture(lambda: rollout(mem_2, obs2), lambda: gnn_2.zero_grad(set_to_none=True))
+        variants["T%d_graph_donated" % T2] = world * B * T2 * side / timed(g2.replay, side, 2)
+        variants["T%d_steady_state_step_us" % T2] = None     # (filled from the kernel profile below)
+        if rank == 0:
+            p2 = profile_kernels(g2.replay, reps=2)
+            kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_rows<")
+            if kr is not None:
+                variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
+                variants["T%d_steady_state_kernel" % T2] = kr[0]
+        del g2
+
+        def eager2(m, gn, bk):
+            def f():
+                rollout(m, obs2, bk, weight)
+                gn.zero_grad(set_to_none=True)
+            return f
+        variants["T%d_eager_donated" % T2] = world * B * T2 * side / timed(eager2(mem_e, gnn_e, bucket_e), side, 1)
+        variants["T%d_eager_functional" % T2] = world * B * T2 * side / timed(eager2(mem_f, gnn_f, bucket_f), side, 1)
+        mem_e.check_flags()
+        mem_f.check_flags()
+
     if rank != 0:
         return
     states = world * B * T * args.steps
     ms_per_step = dt / args.steps * 1e3
     fwd_full = 2 * N * N * (F + H) + 4 * N * (F * H + H * H)       # SURVEY 8(d), per belief state
+    # ---- every kernel of the timed region, measured live (the replayed graph itself; the eager rollout with
+    # --no-graph): the independent source of every kernel duration below ------------------------------------------
+    prof_reps = 5
+    if graph is not None:
+        prof = profile_kernels(graph.replay, reps=prof_reps)
+    else:
+        def one():
+            rollout(mem, obs)
+            zero()
+        prof = profile_kernels(one, reps=prof_reps)
+    table, gpu_us = kernel_table(prof)
     kernel_ms = {}
-    if c["selector"] in ("temporal", "euclid"):
-        step_ev, step_graph, bptt_ms, n_ev, step_ev_cached = time_step_kernel(mem_e, obs, c)
-        bound = (ms_per_step - bptt_ms) / T if graph is not None else None
-        # cached steps (csrc/rows_cached.hip): what a rollout from empty graphs with forward-only temporal selectors
-        # runs on a donated state - then the in-situ event timing above, which drives k_step_rows through the C ABI,
-        # is of the kernel that did NOT run in the timed region, and only the graph-derived figure applies
-        cached = mem_e.rows_cached_steps_taken() > 0
-        step_kernel = "k_step_rows_cached" if cached else "k_step_rows"
-        if cached and c["selector"] == "euclid":
-            # one launch per step: the cached step is the tail of the distance kernel's first wave;
-            # the only in-situ figure is the captured forward loop's cadence
-            step_kernel = "k_euclid_mfma2<TAIL>(distance + cached step)"
-        # the kernel's own launch duration (dispatch-recorded events: what rocprofv3 reports too) where it was
-        # measured; the graph-derived cadence - launch gaps included, but consecutive launches of so short a
-        # kernel also overlap their ramp-up and drain - beside it
-        ev = step_ev_cached if cached else step_ev
-        step_ms = ev if ev is not None else step_graph
-        step_src = "events" if ev is not None else "graph_fwd_loop"
-        if bound is not None:
-            # `roofline` is priced on the figure the timed region itself proves: (ms_per_step - bptt) / T - launch gaps
-            # and the loss's kernels included, so the kernel cannot take longer; host independent, and the one the
-            # rocprofv3 average of a profiled run lands next to.  The event figure (the kernel's own begin -> end, 10 %
-            # shorter on a quiet host, longer than the bound on a busy one) and the graph cadence (consecutive launches
-            # of so short a kernel overlap their ramp-up and drain: it can be SHORTER than the kernel's duration) are
-            # reported beside it.
-            step_ms, step_src = bound, "upper_bound_from_value"
-        kernel_ms = {step_kernel: round(step_ms, 5), "k_step_rows_events": step_ev and round(step_ev, 5),
-                     "k_step_rows_cached_events": step_ev_cached and round(step_ev_cached, 5),
-                     step_kernel + "_graph_fwd_loop_over_T": round(step_graph, 5),
-                     "k_bptt_rows(T=%d)" % T: round(bptt_ms, 5)}
+    src = ("torch.profiler device activity (kineto over roctracer: kernel begin / end timestamps, as rocprofv3 "
+           "--kernel-trace reports them) over %d %s of the timed region, in this process"
+           % (prof_reps, "replays of the captured HIP graph" if graph is not None else "eager rollouts"))
+
+    def hbm_view(nbytes, sec):
+        return None if not nbytes else {"bytes_per_launch": nbytes, "GB/s": nbytes / sec / 1e9,
+                                        "frac_of_hbm_peak": nbytes / sec / 1e9 / PEAK_HBM_GBS}
+
     if c["selector"] == "temporal":
-        # Dominant kernel = k_step_rows: one launch per forward step, ~80 % of the GPU time of the metric
-        # (the backward of the whole rollout is two launches of k_bptt_rows).  Bounding roofline: HBM.
-        # `achieved` = SURVEY 8(d)'s compulsory bytes per belief state (adj once, x once, obs in, belief
-        # out, adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2) x B over the mean launch time.  The
-        # kernel exploits "only row n_b is kept" (gcm.py:314): it reads the node matrix, row cur and the
-        # live rows, not the [N,N] adjacency - `traffic` (PMC) is what it actually moves.
+        # Dominant kernel = the step kernel: one launch per forward step, ~85 % of the GPU time of the metric
+        # (the backward of the whole rollout is two launches of k_bptt_rows).
+        # `achieved` = SURVEY 8(d)'s compulsory bytes per belief state (adj once, x once, obs in, belief out,
+        # adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2) x B over the mean launch duration - an
+        # EFFECTIVE rate: the kernel exploits "only row n_b is kept" (gcm.py:314) and, in a chain from empty
+        # graphs, caches layer 1; `executed` is what it really moves and computes.
+        k = find_kernel(prof, "k_step_rows_cached_img<", "k_step_rows_cached<", "k_step_rows<")
+        kb = find_kernel(prof, "k_bptt_rows<")
+        step_kernel, kd = k
+        sec = kd["avg_us"] * 1e-6
         alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
-        sec = step_ms * 1e-3
-        moved = traffic.get(step_kernel, traffic.get(step_kernel + "_img"))
-        inconsistent = bound is not None and ev is not None and ev > bound * 1.02   # (a busy host stretched the C loop)
+        cached = "cached" in step_kernel
+        tkey = "k_step_rows_cached_img" if cached else "k_step_rows"
+        moved = traffic.get(tkey)
+        # executed flops per launch of the cached step: |S| row adds for both aggregates + four H x F matrix-vector
+        # products per graph; the general kernel: layer 1 on its live rows (|S| + 1) over their non-zero chunks
+        n_sel = len(HOPS)
+        exec_flops = B * (n_sel * (F + H) + 2 * (2 * F * H) + 2 * (2 * H * H)) if cached else \
+            B * ((n_sel + 1) * (n_sel * F + 2 * (2 * F * H)) + n_sel * H + 2 * (2 * H * H))
+        cross = {}
+        try:        # cross-checks (NOT the source of avg_launch_ms): dispatch-recorded events, graph cadence, value
+            step_ev, step_graph, bptt_ev, n_ev, step_ev_cached = time_step_kernel(mem_e, obs, c)
+            cross = {"events_back_to_back_from_C_ms": step_ev_cached if cached else step_ev,
+                     "events_k_step_rows_general_ms": step_ev,
+                     "captured_forward_loop_over_T_ms": step_graph,
+                     "from_value_ms": (ms_per_step - (kb[1]["us_per_call"] * 1e-3 if kb else 0.0)) / T
+                     if graph is not None else None,
+                     "note": "events: the T launches of a rollout enqueued back to back from C (libgcm_hip_debug.so), "
+                             "each bracketed by HIP events the dispatch itself records - an empty kernel reads "
+                             "`launch_floor_us.empty_dispatch_begin_to_end_us` there; graph: replay time of the "
+                             "captured forward loop / T (launch gaps included); from_value: (ms_per_step - "
+                             "k_bptt_rows) / T, what the timed region itself leaves per step"}
+        except Exception as e:      # (the cross-checks need libgcm_hip_debug.so; the line does not)
+            cross = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+        try:
+            floor = launch_floor(B, 64 if cached else 256, nodes=T)
+        except Exception as e:
+            floor = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+        ex = hbm_view(moved, sec) or {}
+        ex.update({"flops_per_launch": exec_flops, "TFLOP/s": exec_flops / sec / 1e12,
+                   "frac_of_fp32_mfma_peak": exec_flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                   "note": "what the kernel really does per launch: bytes = PMC (2*FETCH_SIZE + WRITE_SIZE, "
+                           "profiles/traffic.json), flops = its own formulation (row cur over the chain's caches); "
+                           "at neither limit - a launch-to-retire latency chain, see launch_floor_us"})
         line["roofline"] = {
             "bound": "hbm", "kernel": step_kernel, "achieved": alg_bytes / sec / 1e9, "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS, "traffic": moved,
-            "bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms, "avg_launch_ms_source": step_src,
-            "avg_launch_ms_events": step_ev_cached if cached else step_ev, "launches_timed_events": n_ev,
-            "avg_launch_ms_events_k_step_rows": step_ev,
-            "avg_launch_ms_graph_fwd_loop": step_graph,
-            "avg_launch_ms_upper_bound_from_value": bound, "timing_inconsistent": bool(inconsistent),
-            "achieved_moved": (moved / sec / 1e9) if moved else None,
-            "note": "bytes_per_launch = SURVEY 8(d) full-dense compulsory bytes (what the reference's formulation "
-                    "must move): an EFFECTIVE rate; the live-row kernel moves `traffic` bytes (PMC: 2*FETCH_SIZE + "
-                    "WRITE_SIZE per launch, profiles/) - `achieved_moved` is the rate of those - because only the rows "
-                    "that reach the kept belief row are evaluated and the state is advanced in place: the kernel is "
-                    "bound by its chain of dependent latencies (one wave per SIMD at B = 256 graphs on 256 CUs), not "
-                    "by bytes.  avg_launch_ms = the bound (ms_per_step - bptt) / T that the timed region itself sets (avg_launch_ms_source; conservative); beside it `events` = the T launches of a rollout in situ "
-                    "enqueued back to back from C, each bracketed by HIP events recorded by the dispatch itself "
-                    "(sensitive to a busy host); `graph` = replay time of the captured forward loop / T (launch gaps "
-                    "included: an upper bound, host independent); both must not exceed (ms_per_step - bptt) / T, "
-                    "else timing_inconsistent.  With cached steps the kernel that runs in the timed region is "
-                    "k_step_rows_cached (row cur alone over the chain's caches, csrc/rows_cached.hip): both figures "
-                    "are of that kernel (its own in-situ C loop: gcm_debug_time_cached_rollout); the event figure of "
-                    "the general kernel k_step_rows is kept beside them (avg_launch_ms_events_k_step_rows)"}
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": kd["avg_us"] * 1e-3, "avg_launch_ms_source": src,
+            "launches_timed": int(round(kd["launches_per_call"] * prof_reps)),
+            "executed": ex, "launch_floor_us": floor, "cross_checks": cross,
+            "note": "EFFECTIVE rate: bytes_per_launch = SURVEY 8(d)'s full-dense compulsory bytes (what the "
+                    "reference's formulation must move per step) over the kernel's measured mean duration; the kernel "
+                    "itself moves `traffic` bytes (`executed`): only the rows that reach the kept belief row are "
+                    "evaluated, layer 1 of older rows comes from the chain's caches, the state is advanced in place"}
         line["roofline_mfma_view"] = {
             "kernel": step_kernel, "flops_per_launch_full_dense": B * fwd_full,
             "achieved_full_dense_TFLOPs": B * fwd_full / sec / 1e12,
             "frac_of_fp32_mfma_peak": B * fwd_full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "note": "SURVEY 8(d) full-dense FLOPs (2 layers x all N rows) over the same launch time; the kernel "
-                    "executes layer 1 on the live rows only"}
+            "note": "SURVEY 8(d) full-dense FLOPs (2 layers x all N rows) over the same duration: EFFECTIVE (> 1 means "
+                    "the dense work is not performed, by design); executed flops: roofline.executed"}
+        kernel_ms = {step_kernel: round(kd["avg_us"] * 1e-3, 6)}
+        if kb:
+            kernel_ms[kb[0]] = round(kb[1]["avg_us"] * 1e-3, 6)
     elif c["selector"] == "euclid":
-        # Dominant kernel = k_euclid_mfma2 (the cross-batch distance contraction [N x F].[F x B] per graph on
-        # the fp32 MFMA): 2*B*B*N*F flops per launch.  Timed alone on full graphs.
-        eu_ms = time_euclid_kernel(c)
+        # Dominant kernel = k_euclid_mfma2 (the cross-batch distance contraction [N x F].[F x B] per graph on the
+        # fp32 MFMA, in a donated chain from empty graphs with the cached step as its tail): 2*B*B*N*F flops per
+        # launch on FULL graphs.  The roofline line is the kernel alone on full graphs; the
+        # in-situ mean of the timed rollout (graphs fill up: blocks of 32 rows >= cur are skipped) beside it.
+        eu_prof = time_euclid_kernel(c)
+        ke = find_kernel(eu_prof, "k_euclid_mfma")
+        eu_ms = ke[1]["avg_us"] * 1e-3
         flops = 2.0 * B * B * N * F
-        kernel_ms["k_euclid_mfma2(full graphs)"] = round(eu_ms, 5)
+        ki = find_kernel(prof, "k_euclid_mfma")
+        kb = find_kernel(prof, "k_bptt_rows<")
+        in_situ = None
+        if ki is not None:
+            rows_live = sum(min(N, 32 * (t // 32 + 1)) for t in range(T)) / T      # rows < cur, in 32-row blocks
+            f_in = 2.0 * B * B * rows_live * F
+            sec_i = ki[1]["avg_us"] * 1e-6
+            in_situ = {"kernel": ki[0], "avg_launch_ms": ki[1]["avg_us"] * 1e-3,
+                       "launches_timed": int(round(ki[1]["launches_per_call"] * prof_reps)),
+                       "flops_per_launch_mean": f_in, "TFLOP/s": f_in / sec_i / 1e12,
+                       "frac_of_fp32_mfma_peak": f_in / sec_i / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                       "traffic": traffic.get("k_euclid_mfma2"),
+                       "note": "the timed rollout from empty graphs: mean over its T launches (the cached step runs as "
+                               "the tail of the same launch); flops = the live 32-row blocks' share of 2*B*B*N*F"}
+            kernel_ms[ki[0] + " (in situ)"] = round(ki[1]["avg_us"] * 1e-3, 6)
+        kernel_ms[ke[0] + " (full graphs, alone)"] = round(eu_ms, 6)
+        if kb:
+            kernel_ms[kb[0]] = round(kb[1]["avg_us"] * 1e-3, 6)
         line["roofline"] = {
-            "bound": "mfma", "kernel": "k_euclid_mfma2", "achieved": flops / (eu_ms * 1e-3) / 1e12,
+            "bound": "mfma", "kernel": ke[0], "achieved": flops / (eu_ms * 1e-3) / 1e12,
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / (eu_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic.get("k_euclid_mfma2"),
             "flops_per_launch": flops, "avg_launch_ms": eu_ms,
-            "note": "fp32 MFMA (no TF32 on gfx950); the kernel alone through the C ABI (gcm_edge_distance_pre) on "
-                    "graphs that hold N-1 nodes - every stored row is a candidate -, HIP events around 50 "
-                    "back-to-back launches on the launch stream; in a rollout that starts from empty graphs the "
-                    "kernel skips the 32-row blocks >= cur, so its in-situ average is shorter (rocprofv3 average "
-                    "over the bench run: profiles/); `traffic` (PMC) is that in-situ average"}
+            "avg_launch_ms_source": "torch.profiler device activity over 50 back-to-back launches of the kernel alone "
+                                    "(gcm_edge_distance_pre through the C ABI) on graphs that hold N-1 nodes",
+            "in_situ": in_situ,
+            "note": "fp32 MFMA (no TF32 on gfx950); executed flops = algorithmic flops here (every stored row is a "
+                    "candidate)"}
     else:
-        # cfg5: no single dominant kernel (the cached forward step, the two time-parallel backward passes): the WHOLE
-        # step against the fp32 MFMA peak on SURVEY 8(d)'s flops - GNN fwd+bwd (3x forward), the adjacency
-        # gradient (2N^2 F + 2N^2 H), the edge network on N candidate pairs fwd+bwd (3 x 2(3F^2+F) each)
+        # cfg5: three kernels carry the step - the cached forward step (selection: the edge network on N candidate
+        # rows + gumbel-softmax + the GNN on row cur), pass B of the backward (edge network recomputed and
+        # differentiated per graph-step, persistent) and pass A (k_bptt_rows<..,2>: GNN parameter gradient).  Each
+        # priced on the flops it EXECUTES (its own formulation) and on its PMC bytes; the dominant one is `roofline`.
+        Fe = F
+        sel_exec = B * (2 * (2 * N * Fe * Fe) + 2 * Fe * Fe + 2 * N * Fe + 2 * (2 * F * H) + 2 * (2 * H * H))
+        sel_ref = B * (2 * N * (3 * Fe * Fe + Fe))           # learned.py:38-51 on N candidate pairs, forward
+        bpb_exec = B * T * (8 * (2 * N * Fe * Fe))           # per chain launch: eight N x F x F products per graph-step
+        kinds = [("k_learned_select", ("k_learned_select<",), sel_exec, sel_ref,
+                  "selection + GNN tail (cached step); flops: two N x F x F products, the W0a x[cur] and F -> 1 "
+                  "layers, four matrix-vector products of the GNN tail; LayerNorm / softmax VALU work not counted; "
+                  "flops_reference_formulation = 2 N (3F^2 + F) per graph (the reference's 2F-wide first layer on "
+                  "every candidate pair)"),
+                 ("k_learned_bptt_b", ("k_learned_bptt_b",), bpb_exec, None,
+                  "pass B: per graph-step the edge network recomputed and differentiated - eight N x F x F "
+                  "products on the fp32 MFMA (LayerNorm passes not counted); one persistent launch per chain"),
+                 ("k_bptt_rows_learned", ("k_bptt_rows<",), None, None,
+                  "pass A: GNN parameter gradient over the live rows of every graph-step")]
+        rows = []
+        for tkey, prefixes, fl_exec, fl_ref, note in kinds:
+            kk = find_kernel(prof, *prefixes)
+            if kk is None:
+                continue
+            sec = kk[1]["avg_us"] * 1e-6
+            ent = {"kernel": kk[0], "launches_per_step": round(kk[1]["launches_per_call"], 2),
+                   "avg_launch_ms": kk[1]["avg_us"] * 1e-3,
+                   "share_of_gpu_time": round(kk[1]["us_per_call"] / gpu_us, 4), "note": note}
+            if fl_exec:
+                ent.update({"flops_per_launch": fl_exec, "TFLOP/s": fl_exec / sec / 1e12,
+                            "frac_of_fp32_mfma_peak": fl_exec / sec / 1e12 / PEAK_F32_MFMA_TFLOPS})
+            if fl_ref:
+                ent["flops_reference_formulation"] = fl_ref
+            hv = hbm_view(traffic.get(tkey), sec)
+            if hv:
+                ent["hbm"] = hv
+            rows.append(ent)
+            kernel_ms[kk[0]] = round(kk[1]["avg_us"] * 1e-3, 6)
+        dom = max((r for r in rows if "flops_per_launch" in r), key=lambda r: r["share_of_gpu_time"])
         per_state = 3 * fwd_full + 2 * N * N * (F + H) + 3 * N * 2 * (3 * F * F + F)
         step_s = dt / args.steps / T
         line["roofline"] = {
-            "bound": "mfma", "kernel": "k_learned_select<2,tail> (cached step: selection + the GNN on row cur) + k_bptt_rows<2> (pass A) + "
-                              "k_learned_bptt_b (pass B): whole step",
-            "achieved": B * per_state / step_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": B * per_state / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-            "flops_per_step": B * per_state, "avg_step_ms": step_s * 1e3,
-            "note": "EFFECTIVE: SURVEY 8(d) full-dense flops of one fwd+bwd memory step of B graphs over the wall "
-                    "time per step of the timed region (ms_per_step / T); the kernels evaluate layer 1 on the live "
-                    "rows only"}
+            "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["TFLOP/s"], "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": dom["frac_of_fp32_mfma_peak"],
+            "traffic": dom.get("hbm", {}).get("bytes_per_launch"), "flops_per_launch": dom["flops_per_launch"],
+            "avg_launch_ms": dom["avg_launch_ms"], "avg_launch_ms_source": src, "kernels": rows,
+            "effective_whole_step": {"flops_per_step": B * per_state, "avg_step_ms": step_s * 1e3,
+                                     "TFLOP/s": B * per_state / step_s / 1e12,
+                                     "frac_of_fp32_mfma_peak": B * per_state / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                     "note": "SURVEY 8(d)'s full-dense flops of one fwd+bwd memory step (GNN 3x forward, "
+                                             "dAdj, the edge network on N pairs fwd+bwd) over the wall time per step: "
+                                             "EFFECTIVE, not executed - kept for continuity with round 3"},
+            "note": "EXECUTED flops of the dominant kernel over its measured mean duration; every kernel of the step "
+                    "in `kernels` (flops executed, PMC bytes where collected: profiles/traffic.json)"}
     line.update({
         "value": states / dt, "ms_per_step": ms_per_step,
         "value_spread": spread_of(blocks, world * B * T * args.steps),
@@ -763,15 +948,24 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                    "launch": "eager" if graph is None else "HIP graph of the loop + backward, captured once "
                                                            "in process, replayed per bench step",
                    "parallelism": f"dp{world} (batch-sharded, 1 flat-bucket all-reduce per backward)"},
-        "variants": {k: (round(v, 1) if not isinstance(v, list) else [round(x, 1) for x in v])
+        "variants": {k: (round(v, 1) if isinstance(v, float) else ([round(x, 1) for x in v] if isinstance(v, list) else v))
                      for k, v in variants.items()},
         "variants_note": "belief-states/s of the same workload: the eager per-step loop with donated / functional "
                          "(reference-default: what an unchanged caller of the reference gets) state, median [min, max] "
-                         "of 3 blocks; the additive DenseGCM.rollout entry; the forward loop alone under no_grad",
+                         "of 3 blocks; the additive DenseGCM.rollout entry; the forward loop alone under no_grad; "
+                         "T<2N>_*: rollouts of 2 x graph_size steps - the second half in the steady state, every step "
+                         "dropping every graph's oldest node (gcm.py:323-355)",
         "kernel_ms": kernel_ms,
+        "kernel_table": {"rows": table, "gpu_us_per_step": round(gpu_us, 2), "source": src},
     })
     if name != "cfg2":
         line["metric"] = "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 (%s)" % name
+    info = {"world_size_seen": world, "device": torch.cuda.get_device_name(device), "torch": torch.__version__}
+    try:
+        info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        info["rccl_version"] = None
+    line["runtime"] = info
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(c)
     print(json.dumps(line))
@@ -826,12 +1020,39 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
         mem.stepwise_cache = True
     if rank != 0:
         return
-    fwd_ms, E, M = time_csr_kernels(c)
+    fwd_ms_alone, E, M = time_csr_kernels(c)
     alg = E * (F * 4 + 16) + 2 * M * F * 4          # per layer, one-shot
+    # every kernel of one call (forward + backward), measured live in this process
+    prof_reps = 5
+
+    def one_call():
+        out, _ = mem(x, taus, None)
+        out.mean().backward()
+        g.zero_grad(set_to_none=True)
+
+    prof = profile_kernels(one_call, reps=prof_reps)
+    table, gpu_us = kernel_table(prof, top=16)
+    n_launch = sum(d["launches_per_call"] for d in prof.values())
+    src = ("torch.profiler device activity (kineto over roctracer: kernel begin / end timestamps, as rocprofv3 "
+           "--kernel-trace reports them) over %d eager calls (forward + backward), in this process" % prof_reps)
+    kf = find_kernel(prof, "k_csr_fwd3<", "k_csr_fwd2<", "k_csr_graphconv_fwd")
+    fwd_ms = kf[1]["avg_us"] * 1e-3
     states = world * B * N * args.steps
+    ms_per_step = dt / args.steps * 1e3
+    # the whole call against the same roofline: 2 GraphConv layers x (forward + backward), each direction at least the
+    # layer's forward bytes (x / agg / out once each, the edge list once) - what an ideal fused implementation moves
+    whole_alg = 4 * alg
+    pmc_sum = 0.0
+    pmc_missing = []
+    for k, d in prof.items():
+        keys = [t for t in traffic if t in k]
+        if keys:
+            pmc_sum += traffic[max(keys, key=len)] * d["launches_per_call"]
+        elif d["us_per_call"] > 0.02 * gpu_us:
+            pmc_missing.append(k)
     line.update({
         "metric": "belief-states/sec (BxT) SparseGCM fwd+bwd, graph_size=512 F=32 (cfg4)",
-        "value": states / dt, "ms_per_step": dt / args.steps * 1e3,
+        "value": states / dt, "ms_per_step": ms_per_step,
         "value_spread": spread_of(blocks, world * B * N * args.steps),
         "config": {"workload": c["text"] + "; one bench step = one SparseGCM call on [B, 512, F] + backward, eager",
                    "B_per_gpu": B, "graph_size": N, "obs": F, "hidden": H, "T": N,
@@ -841,15 +1062,39 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
                          "backward, default settings (finite_check = 'sync'): every call on the chain's caches "
                          "(gcm_sparse_step_cached: the new node's rows alone; one time-parallel backward launch per "
                          "chain); _general_path: the same with stepwise_cache = False" % n_sw,
-        "roofline": {"bound": "hbm", "kernel": "k_csr_fwd3", "achieved": alg / (fwd_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": kf[0], "achieved": alg / (fwd_ms * 1e-3) / 1e9,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      "traffic": traffic.get("k_csr_fwd3"), "bytes_per_launch": alg, "avg_launch_ms": fwd_ms,
+                     "avg_launch_ms_source": src,
+                     "launches_timed": int(round(kf[1]["launches_per_call"] * prof_reps)),
+                     "avg_launch_ms_alone_back_to_back": fwd_ms_alone,
+                     "executed": {"bytes_per_launch": traffic.get("k_csr_fwd3"),
+                                  "GB/s": (traffic.get("k_csr_fwd3") or 0) / (fwd_ms * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": (traffic.get("k_csr_fwd3") or 0) / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                     "whole_call": {"algorithmic_bytes": whole_alg, "wall_ms": ms_per_step,
+                                    "GB/s_over_wall": whole_alg / (ms_per_step * 1e-3) / 1e9,
+                                    "frac_over_wall": whole_alg / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                    "gpu_ms": gpu_us * 1e-3,
+                                    "GB/s_over_gpu_time": whole_alg / (gpu_us * 1e-6) / 1e9,
+                                    "frac_over_gpu_time": whole_alg / (gpu_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                                    "kernel_launches_per_call": round(n_launch, 1),
+                                    "pmc_bytes_per_call": pmc_sum or None,
+                                    "pmc_over_algorithmic": (pmc_sum / whole_alg) if pmc_sum else None,
+                                    "kernels_without_pmc_above_2pct": pmc_missing,
+                                    "note": "the WHOLE call (forward + backward of both GraphConv layers, packing, loss) "
+                                            "against 4 x the per-layer algorithmic bytes; pmc_bytes_per_call = sum over "
+                                            "the call's kernels of their PMC bytes per launch (profiles/traffic.json)"},
                      "note": "SURVEY 8(d): E*(4F+16) + 2*sumN*4F bytes per GraphConv layer (E = %d edges, sumN = %d "
-                             "rows); the forward kernel of one layer alone through the C ABI (gcm_csr_graphconv_fwd, "
-                             "training mode: agg saved), HIP events around 50 back-to-back launches on the launch "
-                             "stream" % (E, M)},
-        "kernel_ms": {"k_csr_fwd3": round(fwd_ms, 5)},
+                             "rows); the forward kernel of one layer IN SITU (mean over the call's two layers)" % (E, M)},
+        "kernel_ms": {kf[0]: round(fwd_ms, 5)},
+        "kernel_table": {"rows": table, "gpu_us_per_step": round(gpu_us, 2), "source": src},
     })
+    info = {"world_size_seen": world, "device": torch.cuda.get_device_name(device), "torch": torch.__version__}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        info["rccl_version"] = None
+    line["runtime"] = info
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(c)
     print(json.dumps(line))
