@@ -54,6 +54,16 @@ class Distance(torch.nn.Module):
         fresh = False
         if (self._rows is None or self._rows.shape != (world * cur.shape[0], cur.shape[1])
                 or self._rows.device != cur.device):
+            # the flat all-gather (and the kernels' [world * B, F] view of its result) need equal shards: checked
+            # once per (re)allocation - unequal ones (parallel.shard_bounds when total % world != 0) would hang or
+            # truncate the collective and skew the cross-batch mean
+            mine = torch.tensor([cur.shape[0]], dtype=torch.int64, device=cur.device)
+            sizes = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(sizes, mine, group=group)
+            sizes = [int(s_) for s_ in sizes]
+            if any(s_ != cur.shape[0] for s_ in sizes):
+                raise ValueError(f"EuclideanEdge(shard_group=...): every rank must hold the same number of graphs, "
+                                 f"got {sizes} - pad the batch or shard it evenly")
             self._rows = torch.empty(world * cur.shape[0], cur.shape[1], device=cur.device)
             fresh = True
         cur = cur.detach().contiguous()

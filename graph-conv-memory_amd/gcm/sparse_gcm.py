@@ -143,9 +143,28 @@ class SparseGCM(torch.nn.Module):
                         ok = False
                         break
                 if ok and len(convs) == 2 and convs[0].out_channels == convs[1].in_channels:
-                    plan = (ext.sparse_temporal_step, sel._hops_desc, convs[0], acts[0], convs[1], acts[1])
-            self._fast_plan = plan
-        return self._fast_plan or None
+                    # the modules the one C++ call stands in for: a hook on any of them must still fire, so the
+                    # call then takes the layered path (their hook dicts are consulted at every call)
+                    mods = [g, sel, convs[0], convs[1], convs[0].lin_rel, convs[0].lin_root, convs[1].lin_rel,
+                            convs[1].lin_root] + [m for m, _, _ in g.stages()]
+                    hooks = [d for m in mods for d in (m._forward_hooks, m._forward_pre_hooks, m._backward_hooks,
+                                                       m._backward_pre_hooks)]
+                    plan = (ext.sparse_temporal_step, sel._hops_desc, convs[0], acts[0], convs[1], acts[1], hooks)
+            self.__dict__["_fast_plan"] = plan
+        plan = self._fast_plan
+        if plan and any(plan[6]):      # (a hook was registered since)
+            return None
+        return plan or None
+
+    # what _canonical() looked at: re-assigning any of it re-runs the analysis
+    _PLAN_ATTRS = frozenset(("gnn", "edge_selectors", "aux_edge_selectors", "preprocessor", "positional_encoder",
+                             "max_hops"))
+
+    def __setattr__(self, name, value):
+        if name in SparseGCM._PLAN_ATTRS and "_fast_plan" in self.__dict__:
+            self.__dict__["_fast_plan"] = None
+            self.__dict__["_chain"] = None
+        super().__setattr__(name, value)
 
     def forward(self, x, taus, hidden):
         """x [B, t, feat] zero padded in t; taus [B] valid lengths; hidden (nodes, adj, T) or
@@ -164,7 +183,7 @@ class SparseGCM(torch.nn.Module):
         fast = self._canonical() if self.fast_host else None
         if (fast is not None and x.is_cuda and not adj.values().requires_grad
                 and fast[2].in_channels == x.shape[-1] and x.device.index == torch.cuda.current_device()):
-            fn, hops, c1, a1, c2, a2 = fast
+            fn, hops, c1, a1, c2, a2 = fast[:6]
             chain = None
             if self.stepwise_cache and t_pad == 1:
                 chain = self._chain

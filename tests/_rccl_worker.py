@@ -1,0 +1,57 @@
+"""One rank of the RCCL test (tests/test_parallel_gpu.py): backend "nccl" (= RCCL on ROCm), one rank per GPU.  What
+the data-parallel path asks of the collective library, each against its closed form: communicator set-up (with the
+dmabuf IPC mode this pool needs), all-reduce SUM and AVG of the flat gradient bucket (gcm/parallel.py), the
+all-gather of current rows EuclideanEdge(shard_group=...) makes ahead of its kernel (gcm/edge_selectors/distance.py)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "graph-conv-memory_amd")):
+    sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    from gcm import parallel
+    from gcm.edge_selectors.distance import EuclideanEdge
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert dist.get_backend() == "nccl"
+    t = (torch.arange(1000, device=dev, dtype=torch.float32) + 1.0) * (rank + 1)
+    a = t.clone()
+    dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    want = (torch.arange(1000, device=dev, dtype=torch.float32) + 1.0) * (world * (world + 1) / 2)
+    torch.testing.assert_close(a, want)
+    a = t.clone()
+    dist.all_reduce(a, op=dist.ReduceOp.AVG)
+    torch.testing.assert_close(a, want / world)
+    # the flat gradient bucket: p.grad = rank + 1 everywhere, weight 1 / world -> the mean (the AVG fold when world > 1)
+    lin = torch.nn.Linear(32, 32).to(dev)
+    for p in lin.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    bucket = parallel.GradBucket(lin)
+    bucket.all_reduce_mean(1.0 / world)
+    for p in lin.parameters():
+        torch.testing.assert_close(p.grad, torch.full_like(p, (world + 1) / 2.0))
+    # EuclideanEdge(shard_group=...): every rank's current rows, in rank order
+    sel = EuclideanEdge(2.0, shard_group=True)
+    x = torch.full((4, 8), float(rank), device=dev)
+    sel.gather_current(x)
+    got = sel._rows
+    want_rows = torch.arange(world, device=dev, dtype=torch.float32).repeat_interleave(4)[:, None].expand(-1, 8)
+    torch.testing.assert_close(got.view(world * 4, 8), want_rows)
+    dist.barrier()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps({"world": world, "rccl": list(torch.cuda.nccl.version()),                           "device": torch.cuda.get_device_name(dev)}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,3 +106,67 @@ def test_bench_spawns_its_own_ranks():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+# --------------------------------------------------------------------------------------------------
+# RCCL itself (backend "nccl"): one rank per GPU.  On a one-GPU box: a one-rank communicator (set-up, the
+# collectives' code paths, the bucket, the gathered rows); with >= 2 GPUs visible also the product kernels under
+# the real collective and bench.py's sharded configuration - the first thing an 8-GPU driver run would hit.
+# --------------------------------------------------------------------------------------------------
+def _launch_rccl(world, argv, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GCM_SINGLE_DEVICE", None)
+        env.pop("GCM_DIST_BACKEND", None)
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate(timeout=timeout)
+    assert procs[0].returncode == 0
+    for p in procs[1:]:
+        assert p.wait(timeout=timeout) == 0
+    return out.decode()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_rccl_collectives(world):
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    out = _launch_rccl(world, [os.path.join(ROOT, "tests", "_rccl_worker.py")])
+    info = json.loads(out.strip().splitlines()[-1])
+    assert info["world"] == world and len(info["rccl"]) >= 2
+
+
+def test_sharded_product_rollout_over_rccl(tmp_path):
+    """two ranks, two GPUs, backend nccl: the product kernels under the real all-reduce == the global batch"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    path = str(tmp_path / "rccl")
+    _launch_rccl(2, [WORKER, "temporal", path, ""])
+    got = [torch.load(f"{path}.{r}") for r in range(2)]
+    one = _launch("temporal", 1, str(tmp_path / "one"))[0]
+    torch.testing.assert_close(torch.cat([g["out"] for g in got], dim=1), one["out"], rtol=1e-6, atol=1e-7)
+    for r in range(2):
+        for g, w in zip(got[r]["grads"], one["grads"]):
+            torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6 * float(w.abs().max()))
+    path = str(tmp_path / "rccl_eu")
+    _launch_rccl(2, [WORKER, "euclid", path, "big"])          # all_gather_into_tensor ahead of the distance kernel
+    got = [torch.load(f"{path}.{r}") for r in range(2)]
+    one = _launch("euclid", 1, str(tmp_path / "one_eu"), "big")[0]
+    assert torch.equal(torch.cat([g["adj"] for g in got], dim=0), one["adj"])
+
+
+def test_bench_cfg5_two_gpus_over_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "GCM_SINGLE_DEVICE", "GCM_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg5", "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--T", "12", "--repeats", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["runtime"]["world_size_seen"] == 2 and line["runtime"]["rccl_version"]
