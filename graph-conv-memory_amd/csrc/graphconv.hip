@@ -659,13 +659,16 @@ __global__ __launch_bounds__(256) void k_csr_fwd2(
 // [kk FI/2, (kk+1) FI/2): 16-byte LDS reads of the A operand, 16-byte global loads of the weights).
 // HAS_W / HAS_MASK: edge weights / k-hop row mask present (compile time: a data-dependent choice
 // inside the gather loop would serialise its loads).
-template <int FI, int FO, bool HAS_W, bool HAS_MASK>
+template <int FI, int FO, bool HAS_W, bool HAS_MASK, bool CHK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_csr_fwd3(
     const float* __restrict__ x, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ col, const float* __restrict__ w,
     const uint8_t* __restrict__ mask, const float* __restrict__ w_rel,
     const float* __restrict__ b_rel, const float* __restrict__ w_root, float* __restrict__ out,
-    float* __restrict__ agg_out, int64_t M, int64_t E, int act, int n_tiles) {
+    float* __restrict__ agg_out, int64_t M, uint32_t* __restrict__ flags, int act, int n_tiles) {
+  // CHK: GCM_FLAG_NONFINITE is raised in *flags when an output value is not finite - the check SparseGCM makes
+  // on the rows it returns (sparse_gcm.py:201-203), for callers that hand `out` back as it is (compile time: the
+  // sixteen class tests per lane and tile cost the HBM-bound kernel 4 % when they sat behind a run-time pointer)
   constexpr int CPR = FI / 4;     // 16-byte chunks per row
   constexpr int RPP = 64 / CPR;   // rows per pass of the wave
   constexpr int NP = 32 / RPP;    // passes per 32-row tile
@@ -824,11 +827,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       // acc[r] is row acc_row(r, lh) = (r & 3) + 8 (r >> 2) + 4 lh: one base pointer, constant offsets
       float* ob = out + (size_t)(r0 + 4 * lh) * FO + nt * 32 + li;
       float ov[16];
+      bool bad = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float t = gcm_act_sel(acc[r] + bias[nt], act_v);
         ov[r] = (!HAS_MASK || mrow[r]) ? t : 0.f;
+        if (CHK) bad = bad || !isfinite(ov[r]);
       }
+      // (rows past M in a partial tile are computed from clamped loads of real rows: finite iff those are)
+      if (CHK && __any(bad) && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
       if (full) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ob[((r & 3) + 8 * (r >> 2)) * FO] = ov[r];
@@ -1268,11 +1275,37 @@ extern "C" int gcm_dense_graphconv_bwd(const float* g_out, const float* out, con
 // ---------------------------------------------------------------------------
 // C ABI: GraphConv over CSR
 // ---------------------------------------------------------------------------
+static int csr_fwd_impl(const float* x, const int64_t* row_ptr, const int64_t* col, const float* w,
+                        const uint8_t* mask, const float* w_rel, const float* b_rel, const float* w_root,
+                        float* out, float* agg, int64_t M, int Fi, int Fo, int act, uint32_t* flags,
+                        gcm_stream_t stream);
+
 extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, const int64_t* col,
                                      const float* w, const uint8_t* mask, const float* w_rel,
                                      const float* b_rel, const float* w_root, float* out,
                                      float* agg, int64_t M, int Fi, int Fo, int act,
                                      gcm_stream_t stream) {
+  return csr_fwd_impl(x, row_ptr, col, w, mask, w_rel, b_rel, w_root, out, agg, M, Fi, Fo, act, nullptr, stream);
+}
+
+extern "C" int gcm_csr_graphconv_fwd_checked_supported(int64_t M, int Fi, int Fo) {
+  return (Fi == 32 && (Fo == 32 || Fo == 64) && M >= 32 && M <= (int64_t)2147483647 - 256) ? 1 : 0;
+}
+
+extern "C" int gcm_csr_graphconv_fwd_checked(const float* x, const int64_t* row_ptr, const int64_t* col,
+                                             const float* w, const uint8_t* mask, const float* w_rel,
+                                             const float* b_rel, const float* w_root, float* out, float* agg,
+                                             int64_t M, int Fi, int Fo, int act, uint32_t* flags,
+                                             gcm_stream_t stream) {
+  GCM_REQUIRE(flags);
+  if (!gcm_csr_graphconv_fwd_checked_supported(M, Fi, Fo)) return GCM_EUNSUPPORTED;
+  return csr_fwd_impl(x, row_ptr, col, w, mask, w_rel, b_rel, w_root, out, agg, M, Fi, Fo, act, flags, stream);
+}
+
+static int csr_fwd_impl(const float* x, const int64_t* row_ptr, const int64_t* col, const float* w,
+                        const uint8_t* mask, const float* w_rel, const float* b_rel, const float* w_root,
+                        float* out, float* agg, int64_t M, int Fi, int Fo, int act, uint32_t* flags,
+                        gcm_stream_t stream) {
   GCM_REQUIRE(row_ptr && w_rel && w_root && M >= 0 && Fi > 0 && Fo > 0);
   if (M == 0) return GCM_OK;
   GCM_REQUIRE(x && out);
@@ -1293,9 +1326,26 @@ extern "C" int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, con
     const int cap = per_cu * gcm_cu_count();                                                    \
     const int blocks = (n_tiles + 3) / 4 < cap ? (n_tiles + 3) / 4 : cap;                       \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds3, s, x, row_ptr, col, w, mask, w_rel, \
-                       b_rel, w_root, out, agg, M, (int64_t)0, act, n_tiles);                   \
+                       b_rel, w_root, out, agg, M, flags, act, n_tiles);                        \
     return gcm_launch_status();                                                                 \
   }
+    if (flags && !w && !mask) {   // the checked form (gcm_csr_graphconv_fwd_checked)
+#define GCM_CSR3C(a, b_)                                                                        \
+  if (Fi == a && Fo == b_) {                                                                    \
+    auto kern = k_csr_fwd3<a, b_, false, false, true>;                                          \
+    gcm_allow_dynamic_lds((const void*)kern, lds3);                                             \
+    const int by_lds = (int)((160 * 1024) / lds3);                                              \
+    const int per_cu = by_lds < 1 ? 1 : (by_lds > 3 ? 3 : by_lds);                              \
+    const int cap = per_cu * gcm_cu_count();                                                    \
+    const int blocks = (n_tiles + 3) / 4 < cap ? (n_tiles + 3) / 4 : cap;                       \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds3, s, x, row_ptr, col, w, mask, w_rel, \
+                       b_rel, w_root, out, agg, M, flags, act, n_tiles);                        \
+    return gcm_launch_status();                                                                 \
+  }
+      GCM_CSR3C(32, 32) GCM_CSR3C(32, 64)
+#undef GCM_CSR3C
+    }
+    if (flags) return GCM_EUNSUPPORTED;   // (edge weights / k-hop mask: no checked form)
     GCM_CSR3(32, 32, false, false) GCM_CSR3(32, 32, true, false) GCM_CSR3(32, 32, false, true)
     GCM_CSR3(32, 32, true, true) GCM_CSR3(32, 64, false, false) GCM_CSR3(32, 64, true, false)
     GCM_CSR3(32, 64, false, true) GCM_CSR3(32, 64, true, true)

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_sparse_insert(
     const bool fresh = k >= 0 && k < tau;
     const size_t at = ((size_t)b * N + r) * F + f;
     if (!BWD) {
-      dst[at] = fresh ? x[((size_t)b * t_pad + k) * F + f] : src[at];
+      dst[at] = fresh ? x[((size_t)b * t_pad + k) * F + f] : (src ? src[at] : vt_zero(VT()));   // (src NULL: empty graphs)
     } else {
       dst[at] = fresh ? vt_zero(VT()) : src[at];
     }
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void k_temporal_fill(const int64_t* __restrict
                                                        const int64_t* __restrict__ taus,
                                                        Hops16 hops, int n_hops,
                                                        const int64_t* __restrict__ edge_off,
-                                                       int64_t* __restrict__ indices, int64_t E) {
+                                                       int64_t* __restrict__ indices, int64_t E,
+                                                       float* __restrict__ vals) {
   // one workgroup per graph; thread k walks new node T+k.  Position inside the graph =
   // sum of degrees of earlier new nodes; degrees are < n_hops only for the first max(hops)
   // nodes of an episode, so the prefix is closed form after a short serial head.
@@ -311,8 +312,80 @@ __global__ __launch_bounds__(256) void k_temporal_fill(const int64_t* __restrict
         indices[w] = b;
         indices[E + w] = t;
         indices[2 * E + w] = t - h;
+        if (vals) vals[w] = 1.f;   // (the unit weights of the list, sparse_gcm.py:160-164)
       }
       ++w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Whole episodes from EMPTY graphs (T = 0 everywhere: the one-shot use of SparseGCM, cfg4): every index structure of
+// the call in closed form, in ONE launch - the COO entries TemporalEdge adds (sparse_edge_selectors/temporal.py:18-63)
+// with their unit weights, the flat (source, sink) list with CSR row pointers (util.py:287-304 + the sort inside
+// coalesce), and the CSC view the backward's transpose gather reads.  Replaces k_temporal_fill, the fill of the
+// values, k_edges_flat, k_ptr_from_sorted and k_csc_batched (33 us of launches at cfg4) - nothing here depends on
+// data, only on taus and the hop set H (distinct, descending, h >= 1):
+//   node t of graph b (offset o = node_off[b], edge base e0 = edge_off[b], tau = taus[b]) has the sources t - h, h <= t:
+//     CSR   row_ptr[o + t] = e0 + P(t),  P(t) = sum_h max(0, t - h);  its entries in hop order (sources ascending)
+//     CSC   col_ptr[o + s] = e0 + Q(s),  Q(s) = sum_h min(s, max(0, tau - h));  the entries of source s are the
+//           sinks s + h < tau, h ascending;  perm = the CSR position of (s + h, s) = e0 + P(s + h) + #{h' > h, h' <= s + h}
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_temporal_structure(
+    const int64_t* __restrict__ taus, Hops16 hops, int n_hops, const int64_t* __restrict__ node_off,
+    const int64_t* __restrict__ edge_off, int64_t* __restrict__ coo, float* __restrict__ vals,
+    int64_t* __restrict__ edge_index, int64_t* __restrict__ row_ptr, int64_t* __restrict__ col_ptr,
+    int64_t* __restrict__ rows, int64_t* __restrict__ perm, int64_t E, int64_t M, int B) {
+  const int b = blockIdx.x;
+  const int64_t tau = taus[b] > 0 ? taus[b] : 0;
+  const int64_t o = node_off[b], e0 = edge_off[b];
+  if (b == 0 && threadIdx.x == 0) {
+    row_ptr[M] = E;
+    if (col_ptr) col_ptr[M] = E;
+  }
+  for (int64_t t = threadIdx.x; t < tau; t += blockDim.x) {
+    if (o + t >= M) break;
+    int64_t P = 0, Q = 0;
+    for (int i = 0; i < n_hops; ++i) {
+      const int64_t h = hops.h[i];
+      P += t > h ? t - h : 0;
+      const int64_t lim = tau > h ? tau - h : 0;
+      Q += t < lim ? t : lim;
+    }
+    row_ptr[o + t] = e0 + P;
+    int64_t w = e0 + P;
+    for (int i = 0; i < n_hops; ++i) {   // hops descending -> sources ascending
+      const int64_t h = hops.h[i];
+      if (h > t) continue;
+      if (w < E) {
+        coo[w] = b;
+        coo[E + w] = t;
+        coo[2 * E + w] = t - h;
+        if (vals) vals[w] = 1.f;
+        edge_index[w] = o + t - h;
+        edge_index[E + w] = o + t;
+      }
+      ++w;
+    }
+    if (col_ptr) {
+      col_ptr[o + t] = e0 + Q;
+      int64_t k = e0 + Q;
+      for (int i = n_hops - 1; i >= 0; --i) {   // hops ascending -> sinks ascending
+        const int64_t h = hops.h[i], sink = t + h;
+        if (sink >= tau) continue;
+        int64_t Ps = 0;
+        int above = 0;
+        for (int j = 0; j < n_hops; ++j) {
+          const int64_t hj = hops.h[j];
+          Ps += sink > hj ? sink - hj : 0;
+          above += (hj > h && hj <= sink) ? 1 : 0;
+        }
+        if (k < E) {
+          rows[k] = o + sink;
+          perm[k] = e0 + Ps + above;
+        }
+        ++k;
+      }
     }
   }
 }
@@ -487,7 +560,7 @@ extern "C" int gcm_sparse_plan(const int64_t* T, const int64_t* taus, int64_t* n
 extern "C" int gcm_sparse_insert_fwd(const float* nodes_in, const float* x, const int64_t* T,
                                      const int64_t* taus, float* nodes_out, uint32_t* flags, int B,
                                      int N, int F, int t_pad, gcm_stream_t stream) {
-  GCM_REQUIRE(nodes_in && x && T && taus && nodes_out && flags);
+  GCM_REQUIRE(x && T && taus && nodes_out && flags);   // (nodes_in may be NULL: all zeros, not read)
   GCM_REQUIRE(B > 0 && N > 0 && F > 0 && t_pad > 0);
   if (B > 65535) return GCM_EUNSUPPORTED;
   const int rpb = 32;
@@ -548,12 +621,35 @@ extern "C" int gcm_sparse_temporal_fill(const int64_t* T, const int64_t* taus,
                                         const int32_t* hops_host, int n_hops,
                                         const int64_t* edge_off, int64_t* indices, int64_t E,
                                         int B, gcm_stream_t stream) {
+  return gcm_sparse_temporal_fill_vals(T, taus, hops_host, n_hops, edge_off, indices, nullptr, E, B, stream);
+}
+
+extern "C" int gcm_sparse_temporal_fill_vals(const int64_t* T, const int64_t* taus, const int32_t* hops_host,
+                                             int n_hops, const int64_t* edge_off, int64_t* indices, float* vals,
+                                             int64_t E, int B, gcm_stream_t stream) {
   GCM_REQUIRE(T && taus && hops_host && edge_off && B > 0 && n_hops > 0 && E >= 0);
   if (n_hops > 16) return GCM_EUNSUPPORTED;
   if (E == 0) return GCM_OK;
   GCM_REQUIRE(indices);
   hipLaunchKernelGGL(k_temporal_fill, dim3(B), dim3(256), 0, (hipStream_t)stream, T, taus,
-                     pack_hops(hops_host, n_hops), n_hops, edge_off, indices, E);
+                     pack_hops(hops_host, n_hops), n_hops, edge_off, indices, E, vals);
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_sparse_temporal_structure(const int64_t* taus, const int32_t* hops_host, int n_hops,
+                                             const int64_t* node_off, const int64_t* edge_off, int64_t* coo,
+                                             float* vals, int64_t* edge_index, int64_t* row_ptr, int64_t* col_ptr,
+                                             int64_t* rows, int64_t* perm, int64_t E, int64_t M, int B,
+                                             gcm_stream_t stream) {
+  GCM_REQUIRE(taus && hops_host && node_off && edge_off && row_ptr && B > 0 && n_hops > 0 && E >= 0 && M >= 0);
+  GCM_REQUIRE((coo && edge_index) || E == 0);
+  GCM_REQUIRE(!col_ptr || E == 0 || (rows && perm));
+  if (n_hops > 16) return GCM_EUNSUPPORTED;
+  for (int i = 0; i < n_hops; ++i)   // distinct, descending, no self loops
+    if (hops_host[i] < 1 || (i > 0 && hops_host[i] >= hops_host[i - 1])) return GCM_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_temporal_structure, dim3(B), dim3(256), 0, (hipStream_t)stream, taus,
+                     pack_hops(hops_host, n_hops), n_hops, node_off, edge_off, coo, vals, edge_index, row_ptr, col_ptr,
+                     rows, perm, E, M, B);
   return gcm_launch_status();
 }
 

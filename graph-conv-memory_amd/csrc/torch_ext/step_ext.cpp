@@ -1554,10 +1554,15 @@ static std::shared_ptr<SparseGate>& sparse_gate_slot() {
 struct SparseStepNode : public torch::autograd::Node {
   std::shared_ptr<SparseGate> gate;
   at::Tensor T, taus, node_off, flat, edge_index, row_ptr, out1, agg1, out2, agg2;
+  at::Tensor col_ptr, csc_rows, csc_perm;   // the CSC view when the forward already made it (whole episodes from empty graphs)
   at::Tensor w_rel1, w_root1, w_rel2, w_root2;
   int64_t B = 0, N = 0, F = 0, H1 = 0, H2 = 0, t_pad = 0, M = 0, E = 0;
   int act1 = 0, act2 = 0;
   bool has_b1 = false, has_b2 = false;
+  // whole-episode calls (see sparse_temporal_step): the returned rows are out2 itself / the flat matrix is the state
+  bool all_new = false, flat_is_state = false;
+  c10::VariableVersion mx_vc;      // version counter of the returned rows when they alias out2, and its value then
+  uint32_t mx_version = 0;
 
   // inputs: x, nodes_in, the gate; outputs: mx_dense, nodes_out
   variable_list apply(variable_list&& grads) override {
@@ -1574,15 +1579,23 @@ struct SparseStepNode : public torch::autograd::Node {
     if (grads[1].defined()) g_dirty = grads[1].to(at::kFloat).contiguous();
     if (grads[0].defined()) {
       at::Tensor g_mx = grads[0].to(at::kFloat).contiguous();
-      at::Tensor g_f2 = at::empty({M, H2}, opt);
-      check(gcm_sparse_extract_bwd(g_mx.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
-                                   node_off.data_ptr<int64_t>(), g_f2.data_ptr<float>(), (int)B, (int)t_pad,
-                                   (int)H2, M, st),
-            "gcm_sparse_extract_bwd");
+      at::Tensor g_f2;
+      if (all_new) {   // mx is out2 seen as [B, t_pad, H2]: its gradient is g_f2 as it is
+        TORCH_CHECK(mx_vc.current_version() == mx_version,
+                    "one of the variables needed for gradient computation has been modified by an inplace operation: "
+                    "the rows returned by this SparseGCM call are the last layer's output its backward reads");
+        g_f2 = g_mx.view({M, H2});
+      } else {
+        g_f2 = at::empty({M, H2}, opt);
+        check(gcm_sparse_extract_bwd(g_mx.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
+                                     node_off.data_ptr<int64_t>(), g_f2.data_ptr<float>(), (int)B, (int)t_pad,
+                                     (int)H2, M, st),
+              "gcm_sparse_extract_bwd");
+      }
       // CSC view for the transpose gathers (grouped by graph: no sort)
-      at::Tensor col_ptr, rows, perm;
+      at::Tensor col_ptr = this->col_ptr, rows = csc_rows, perm = csc_perm;
       const int64_t* col = edge_index.data_ptr<int64_t>();
-      if (E > 0) {
+      if (E > 0 && !col_ptr.defined()) {
         col_ptr = at::empty({M + 1}, edge_index.options());
         rows = at::empty({E}, edge_index.options());
         perm = at::empty({E}, edge_index.options());
@@ -1623,11 +1636,16 @@ struct SparseStepNode : public torch::autograd::Node {
         gate->gave = true;
       }
       if (need_in) {
-        at::Tensor g_nodes = at::empty({B, N, F}, opt);
-        check(gcm_sparse_flatten_bwd(g_flat.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
-                                     node_off.data_ptr<int64_t>(), g_nodes.data_ptr<float>(), (int)B, (int)N, (int)F,
-                                     M, st),
-              "gcm_sparse_flatten_bwd");
+        at::Tensor g_nodes;
+        if (flat_is_state) {
+          g_nodes = g_flat.view({B, N, F});
+        } else {
+          g_nodes = at::empty({B, N, F}, opt);
+          check(gcm_sparse_flatten_bwd(g_flat.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(),
+                                       node_off.data_ptr<int64_t>(), g_nodes.data_ptr<float>(), (int)B, (int)N, (int)F,
+                                       M, st),
+                "gcm_sparse_flatten_bwd");
+        }
         g_dirty = g_dirty.defined() ? g_dirty + g_nodes : g_nodes;
       }
     }
@@ -1775,28 +1793,36 @@ struct SparseChain {
 
 // -> (mx_dense [B,t,H2], nodes_out, indices [3,E] (batch, sink, source), values [E], T + taus), or an int status:
 // 1 = overflow (sparse_gcm.py:120-121)
-pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& taus, const at::Tensor& nodes_,
+pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& taus,
+                                      const c10::optional<at::Tensor>& nodes_opt, int64_t N_arg,
                                       const at::Tensor& adj_idx_, const at::Tensor& T, const std::vector<int>& hops_desc,
                                       const at::Tensor& w_rel1, const c10::optional<at::Tensor>& b1,
                                       const at::Tensor& w_root1, int act1, const at::Tensor& w_rel2,
                                       const c10::optional<at::Tensor>& b2, const at::Tensor& w_root2, int act2,
                                       const at::Tensor& flags, pybind11::object chain_obj, bool fresh,
                                       bool want_flags) {
-  TORCH_CHECK(x_.is_cuda() && taus.is_cuda() && nodes_.is_cuda() && T.is_cuda() && flags.is_cuda(),
+  // nodes_opt empty: the call starts from hidden = None - empty graphs - and the all-zero node matrix [B, N_arg, F] is
+  // neither materialised nor read (`fresh` is then true by construction)
+  const bool no_nodes = !nodes_opt.has_value();
+  TORCH_CHECK(x_.is_cuda() && taus.is_cuda() && (no_nodes || nodes_opt->is_cuda()) && T.is_cuda() && flags.is_cuda(),
               "sparse step: every tensor must live on a HIP device (no CPU fallback)");
-  at::Tensor x = x_.contiguous(), nodes = nodes_.contiguous(), adj_idx = adj_idx_.contiguous();
-  const int64_t B = x.size(0), t_pad = x.size(1), F = x.size(2), N = nodes.size(1);
+  TORCH_CHECK(!no_nodes || (fresh && adj_idx_.size(1) == 0 && N_arg > 0), "sparse step: no node matrix, but not a fresh state");
+  at::Tensor x = x_.contiguous(), nodes = no_nodes ? at::Tensor() : nodes_opt->contiguous(), adj_idx = adj_idx_.contiguous();
+  const at::Tensor nodes_ = no_nodes ? at::Tensor() : *nodes_opt;
+  const bool nodes_grad = !no_nodes && nodes_.requires_grad();
+  const int64_t B = x.size(0), t_pad = x.size(1), F = x.size(2), N = no_nodes ? N_arg : nodes.size(1);
   const int64_t H1 = w_rel1.size(0), H2 = w_rel2.size(0), Ea = adj_idx.size(1);
-  TORCH_CHECK(nodes.size(0) == B && nodes.size(2) == F && taus.numel() == B && T.numel() == B &&
+  TORCH_CHECK((no_nodes || (nodes.size(0) == B && nodes.size(2) == F)) && taus.numel() == B && T.numel() == B &&
                   w_rel1.size(1) == F && w_rel2.size(1) == H1,
               "sparse step: shapes disagree");
+  const float* nodes_ptr = no_nodes ? nullptr : nodes.data_ptr<float>();
   const auto iopt = T.options();
   const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(x.get_device()).stream());
   uint32_t* fl = reinterpret_cast<uint32_t*>(flags.data_ptr());
   const at::Tensor* ps[6] = {&w_rel1, b1.has_value() ? &*b1 : nullptr, &w_root1,
                              &w_rel2, b2.has_value() ? &*b2 : nullptr, &w_root2};
   const bool need_bwd = at::GradMode::is_enabled() &&
-                        (x_.requires_grad() || nodes_.requires_grad() || w_rel1.requires_grad() ||
+                        (x_.requires_grad() || nodes_grad || w_rel1.requires_grad() ||
                          w_root1.requires_grad() || w_rel2.requires_grad() || w_root2.requires_grad() ||
                          (b1.has_value() && b1->requires_grad()) || (b2.has_value() && b2->requires_grad()));
   // ---- a call on the chain's caches?  (see SparseChain: one node per graph, no gradient w.r.t. x / the node matrix,
@@ -1805,7 +1831,7 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   SparseChain* ch = chain_obj.is_none() ? nullptr : chain_obj.cast<SparseChain*>();
   bool cached = false;
   if (ch) {
-    bool ok = t_pad == 1 && !x_.requires_grad() && !nodes_.requires_grad() && (F == 32 || F == 64) &&
+    bool ok = t_pad == 1 && !x_.requires_grad() && !nodes_grad && (F == 32 || F == 64) &&
               (H1 == 32 || H1 == 64) && H2 > 0 && H2 <= 64 && hops_desc.size() <= 16 &&
               (size_t)B * N * 64 < ((size_t)1 << 31) && w_rel1.scalar_type() == at::kFloat;
     for (int h : hops_desc) ok = ok && h >= 1;
@@ -1833,7 +1859,7 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
       ch->B = B;
       ch->steps = 0;
       ch->live = cached = true;
-    } else if (ok && ch->continues(nodes, adj_idx, T, ps)) {
+    } else if (ok && !no_nodes && ch->continues(nodes, adj_idx, T, ps)) {
       cached = true;
     }
     if (!cached && ch->live) ch->drop();
@@ -1882,8 +1908,8 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     if (!sizes_ready)
       TORCH_CHECK(hipEventCreateWithFlags(&sizes_ready, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
     TORCH_CHECK(hipEventRecord(sizes_ready, (hipStream_t)st) == hipSuccess, "hipEventRecord failed");
-    at::Tensor nodes_out = at::empty_like(nodes);
-    check(gcm_sparse_insert_fwd(nodes.data_ptr<float>(), x.data_ptr<float>(), T.data_ptr<int64_t>(),
+    at::Tensor nodes_out = at::empty({B, N, F}, x.options());
+    check(gcm_sparse_insert_fwd(nodes_ptr, x.data_ptr<float>(), T.data_ptr<int64_t>(),
                                 taus.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), fl, (int)B, (int)N, (int)F,
                                 (int)t_pad, st),
           "gcm_sparse_insert_fwd");
@@ -1934,29 +1960,76 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   int64_t* new_off = node_off + (B + 1);
   int64_t* edge_off = new_off + (B + 1);
   int64_t* totals = edge_off + (B + 1);   // follows edge_off[B]: the five numbers read back are contiguous
-  check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
-        "gcm_sparse_plan");
-  check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
-                                  edge_off, (int)B, st),
-        "gcm_sparse_temporal_count");
+  at::Tensor T_out;
+  bool desc = !hops.empty() && hops.size() <= 16;
+  for (size_t i = 1; i < hops.size(); ++i) desc = desc && hops[i] < hops[i - 1];
+  if (desc) {   // offsets, totals, edge offsets and T + taus in one launch
+    T_out = at::empty_like(T);
+    check(gcm_sparse_step_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(), nullptr,
+                               node_off, T_out.data_ptr<int64_t>(), nullptr, (int)B, st),
+          "gcm_sparse_step_plan");
+  } else {
+    check(gcm_sparse_plan(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off, new_off, totals, (int)B, st),
+          "gcm_sparse_plan");
+    check(gcm_sparse_temporal_count(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                    edge_off, (int)B, st),
+          "gcm_sparse_temporal_count");
+  }
   host.copy_(plan.narrow(0, 3 * (B + 1) - 1, 5), /*non_blocking=*/true);
   c10::hip::getCurrentHIPStream(x.get_device()).synchronize();
   const int64_t Eb = hv[0], M = hv[1], max_total = hv[3];
   if (max_total > N) return pybind11::int_(1);
   at::Tensor node_off_t = plan.narrow(0, 0, B + 1);
+  // What the packing kernels reduce to on whole episodes (the one-shot use, cfg4):
+  //   from_empty    every graph starts empty (the caller vouches: `fresh`, no stored entries): the incoming node
+  //                 matrix is all zeros and is not read;
+  //   all_new       ... and every graph receives t_pad nodes: flat row i IS new node i, so the returned rows are the
+  //                 last layer's output as it is (no extract copy forward, none backward);
+  //   flat_is_state every graph is full after the call: the flat node matrix [M, F] IS the returned node matrix
+  //                 [B, N, F] (no flatten copy).
+  const bool from_empty = fresh && Ea == 0;
+  const bool all_new = from_empty && M == B * t_pad && gcm_csr_graphconv_fwd_checked_supported(M, (int)H1, (int)H2) != 0;
+  const bool flat_is_state = M == B * N;
   // ---- insert, edges, merge
-  at::Tensor nodes_out = at::empty_like(nodes);
-  check(gcm_sparse_insert_fwd(nodes.data_ptr<float>(), x.data_ptr<float>(), T.data_ptr<int64_t>(),
+  at::Tensor nodes_out = at::empty({B, N, F}, x.options());
+  check(gcm_sparse_insert_fwd(from_empty ? nullptr : nodes_ptr, x.data_ptr<float>(), T.data_ptr<int64_t>(),
                               taus.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), fl, (int)B, (int)N, (int)F,
                               (int)t_pad, st),
         "gcm_sparse_insert_fwd");
-  at::Tensor idx_new = at::empty({3, Eb}, iopt);
-  check(gcm_sparse_temporal_fill(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
-                                 edge_off, idx_new.data_ptr<int64_t>(), Eb, (int)B, st),
-        "gcm_sparse_temporal_fill");
+  at::Tensor idx_new = at::empty({3, Eb}, iopt), vals_new = at::empty({Eb}, x.options());
+  // from empty graphs every index structure of the call is closed form: COO entries, unit weights, the flat list,
+  // CSR pointers and (for the backward) the CSC view in ONE launch
+  at::Tensor edge_index, row_ptr, col_ptr, csc_rows, csc_perm;
+  bool structured = false;
+  if (from_empty && Eb > 0) {
+    bool ok = hops.size() <= 16;
+    for (size_t i = 0; i < hops.size(); ++i) ok = ok && hops[i] >= 1 && (i == 0 || hops[i] < hops[i - 1]);
+    if (ok) {
+      edge_index = at::empty({2, Eb}, iopt);
+      row_ptr = at::empty({M + 1}, iopt);
+      if (need_bwd) {
+        col_ptr = at::empty({M + 1}, iopt);
+        csc_rows = at::empty({Eb}, iopt);
+        csc_perm = at::empty({Eb}, iopt);
+      }
+      check(gcm_sparse_temporal_structure(taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(), node_off, edge_off,
+                                          idx_new.data_ptr<int64_t>(), vals_new.data_ptr<float>(),
+                                          edge_index.data_ptr<int64_t>(), row_ptr.data_ptr<int64_t>(),
+                                          need_bwd ? col_ptr.data_ptr<int64_t>() : nullptr,
+                                          need_bwd ? csc_rows.data_ptr<int64_t>() : nullptr,
+                                          need_bwd ? csc_perm.data_ptr<int64_t>() : nullptr, Eb, M, (int)B, st),
+            "gcm_sparse_temporal_structure");
+      structured = true;
+    }
+  }
+  if (!structured)
+    check(gcm_sparse_temporal_fill_vals(T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), hops.data(), (int)hops.size(),
+                                        edge_off, idx_new.data_ptr<int64_t>(), vals_new.data_ptr<float>(), Eb, (int)B, st),
+          "gcm_sparse_temporal_fill");
   at::Tensor idx, vals;
   if (Ea == 0) {
     idx = idx_new;
+    vals = vals_new;
   } else if (Eb == 0) {
     idx = adj_idx;
   } else {
@@ -1973,14 +2046,22 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
   const int64_t E = idx.size(1);
   if (!vals.defined()) vals = at::ones({E}, x.options());
   // ---- flat node matrix, CSR, the two layers, the new rows
-  at::Tensor flat = at::empty({M, F}, x.options());
-  check(gcm_sparse_flatten_fwd(nodes_out.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
-                               flat.data_ptr<float>(), (int)B, (int)N, (int)F, M, st),
-        "gcm_sparse_flatten_fwd");
-  at::Tensor edge_index = at::empty({2, E}, iopt), row_ptr = at::empty({M + 1}, iopt);
-  check(gcm_sparse_edges_to_csr(idx.data_ptr<int64_t>(), node_off, edge_index.data_ptr<int64_t>(),
-                                row_ptr.data_ptr<int64_t>(), fl, E, M, (int)B, st),
-        "gcm_sparse_edges_to_csr");
+  at::Tensor flat;
+  if (flat_is_state) {
+    flat = nodes_out.view({M, F});
+  } else {
+    flat = at::empty({M, F}, x.options());
+    check(gcm_sparse_flatten_fwd(nodes_out.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
+                                 flat.data_ptr<float>(), (int)B, (int)N, (int)F, M, st),
+          "gcm_sparse_flatten_fwd");
+  }
+  if (!structured) {
+    edge_index = at::empty({2, E}, iopt);
+    row_ptr = at::empty({M + 1}, iopt);
+    check(gcm_sparse_edges_to_csr(idx.data_ptr<int64_t>(), node_off, edge_index.data_ptr<int64_t>(),
+                                  row_ptr.data_ptr<int64_t>(), fl, E, M, (int)B, st),
+          "gcm_sparse_edges_to_csr");
+  }
   at::Tensor out1 = at::empty({M, H1}, x.options()), out2 = at::empty({M, H2}, x.options());
   at::Tensor agg1 = need_bwd ? at::empty({M, F}, x.options()) : at::Tensor();
   at::Tensor agg2 = need_bwd ? at::empty({M, H1}, x.options()) : at::Tensor();
@@ -1991,15 +2072,25 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
                               wt1.data_ptr<float>(), out1.data_ptr<float>(), need_bwd ? agg1.data_ptr<float>() : nullptr,
                               M, (int)F, (int)H1, act1, st),
         "gcm_csr_graphconv_fwd");
-  check(gcm_csr_graphconv_fwd(out1.data_ptr<float>(), row_ptr.data_ptr<int64_t>(), col, nullptr, nullptr,
-                              wr2.data_ptr<float>(), b2.has_value() ? b2->data_ptr<float>() : nullptr,
-                              wt2.data_ptr<float>(), out2.data_ptr<float>(), need_bwd ? agg2.data_ptr<float>() : nullptr,
-                              M, (int)H1, (int)H2, act2, st),
-        "gcm_csr_graphconv_fwd");
-  at::Tensor mx = at::empty({B, t_pad, H2}, x.options());
-  check(gcm_sparse_extract_fwd(out2.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
-                               mx.data_ptr<float>(), fl, (int)B, (int)t_pad, (int)H2, M, st),
-        "gcm_sparse_extract_fwd");
+  at::Tensor mx;
+  if (all_new) {   // the returned rows ARE the layer's output: its epilogue makes the finite check (sparse_gcm.py:201-203)
+    check(gcm_csr_graphconv_fwd_checked(out1.data_ptr<float>(), row_ptr.data_ptr<int64_t>(), col, nullptr, nullptr,
+                                        wr2.data_ptr<float>(), b2.has_value() ? b2->data_ptr<float>() : nullptr,
+                                        wt2.data_ptr<float>(), out2.data_ptr<float>(),
+                                        need_bwd ? agg2.data_ptr<float>() : nullptr, M, (int)H1, (int)H2, act2, fl, st),
+          "gcm_csr_graphconv_fwd_checked");
+    mx = alias_of(out2, 0, {B, t_pad, H2}, out2.dtype());   // (no view relation: it gets this call's node below)
+  } else {
+    check(gcm_csr_graphconv_fwd(out1.data_ptr<float>(), row_ptr.data_ptr<int64_t>(), col, nullptr, nullptr,
+                                wr2.data_ptr<float>(), b2.has_value() ? b2->data_ptr<float>() : nullptr,
+                                wt2.data_ptr<float>(), out2.data_ptr<float>(), need_bwd ? agg2.data_ptr<float>() : nullptr,
+                                M, (int)H1, (int)H2, act2, st),
+          "gcm_csr_graphconv_fwd");
+    mx = at::empty({B, t_pad, H2}, x.options());
+    check(gcm_sparse_extract_fwd(out2.data_ptr<float>(), T.data_ptr<int64_t>(), taus.data_ptr<int64_t>(), node_off,
+                                 mx.data_ptr<float>(), fl, (int)B, (int)t_pad, (int)H2, M, st),
+          "gcm_sparse_extract_fwd");
+  }
   if (need_bwd) {
     auto node = std::shared_ptr<SparseStepNode>(new SparseStepNode(), torch::autograd::deleteNode);
     node->T = T; node->taus = taus; node->node_off = node_off_t; node->flat = flat;
@@ -2008,6 +2099,11 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     node->w_rel1 = wr1.detach(); node->w_root1 = wt1.detach(); node->w_rel2 = wr2.detach(); node->w_root2 = wt2.detach();
     node->B = B; node->N = N; node->F = F; node->H1 = H1; node->H2 = H2; node->t_pad = t_pad; node->M = M; node->E = E;
     node->act1 = act1; node->act2 = act2; node->has_b1 = b1.has_value(); node->has_b2 = b2.has_value();
+    node->all_new = all_new; node->flat_is_state = flat_is_state;
+    node->col_ptr = col_ptr; node->csc_rows = csc_rows; node->csc_perm = csc_perm;   // (defined: made with the CSR view)
+    // (the returned rows alias out2, which the backward reads: an in-place write by the caller must be noticed)
+    node->mx_vc = mx.unsafeGetTensorImpl()->version_counter();
+    node->mx_version = node->mx_vc.current_version();
     auto edge = [](const at::Tensor& t) {
       return t.requires_grad() ? torch::autograd::impl::gradient_edge(t) : torch::autograd::Edge();
     };
@@ -2026,13 +2122,13 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     }
     node->gate = slot;
     node->add_next_edge(edge(x_));
-    node->add_next_edge(edge(nodes_));
+    node->add_next_edge(no_nodes ? torch::autograd::Edge() : edge(nodes_));
     node->add_next_edge(torch::autograd::Edge(slot, 0));
     torch::autograd::create_gradient_edge(mx, node);
-    if (x_.requires_grad() || nodes_.requires_grad()) torch::autograd::create_gradient_edge(nodes_out, node);
+    if (x_.requires_grad() || nodes_grad) torch::autograd::create_gradient_edge(nodes_out, node);
     else node->add_input_metadata(torch::autograd::Node::undefined_input{});
   }
-  at::Tensor T_out = T + taus;
+  if (!T_out.defined()) T_out = T + taus;
   return pybind11::make_tuple(mx, nodes_out, idx, vals, T_out, (int64_t)-1);   // (-1: flag word not read)
 }
 

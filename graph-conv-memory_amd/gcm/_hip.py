@@ -51,6 +51,10 @@ PROTOTYPES = {
     "gcm_sparse_insert_bwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "gcm_sparse_temporal_count": (_I, [_P, _P, _P, _I, _P, _I, _P]),
     "gcm_sparse_temporal_fill": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _P]),
+    "gcm_sparse_temporal_fill_vals": (_I, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _P]),
+    "gcm_sparse_temporal_structure": (_I, [_P, _P, _I] + [_P] * 9 + [_L, _L, _I, _P]),
+    "gcm_csr_graphconv_fwd_checked_supported": (_I, [_L, _I, _I]),
+    "gcm_csr_graphconv_fwd_checked": (_I, [_P] * 10 + [_L, _I, _I, _I, _P, _P]),
     "gcm_sparse_flatten_fwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
     "gcm_sparse_flatten_bwd": (_I, [_P] * 5 + [_I, _I, _I, _L, _P]),
     "gcm_sparse_edges_to_csr": (_I, [_P] * 5 + [_L, _L, _I, _P]),

@@ -69,8 +69,12 @@ class SparseGCM(torch.nn.Module):
         adj = torch.zeros((B, self.graph_size, self.graph_size), device=x.device,
                           layout=torch.sparse_coo)
         T = torch.zeros(B, dtype=torch.long, device=x.device)
-        T._gcm_fresh = T._version      # (all zero by construction: lets a stepwise chain start on the caches)
+        T._gcm_fresh = T._version      # (all zero by construction: lets a stepwise chain start on the caches,
+        nodes._gcm_fresh = nodes._version   # and the insert kernel skip reading the zero node matrix)
         return nodes, adj, T
+
+    def _empty_adj(self, x):
+        return torch.zeros((x.shape[0], self.graph_size, self.graph_size), device=x.device, layout=torch.sparse_coo)
 
     def _flag_word(self, device):
         f = self._flags.get(device)
@@ -169,18 +173,27 @@ class SparseGCM(torch.nn.Module):
     def forward(self, x, taus, hidden):
         """x [B, t, feat] zero padded in t; taus [B] valid lengths; hidden (nodes, adj, T) or
         None.  Returns (mx [B, t, H] zero padded, (nodes, adj, T + taus))."""
+        fast = self._canonical() if self.fast_host else None
+        lazy = False
         if hidden is None:
-            hidden = self.get_initial_hidden_state(x)
+            if (fast is not None and x.is_cuda and x.dim() == 3 and fast[2].in_channels == x.shape[-1]
+                    and x.device.index == torch.cuda.current_device()):
+                # empty graphs on the one-call host path: the all-zero node matrix [B, N, F] (33 MB at cfg4) is
+                # neither filled nor read - the insert kernel knows it is zero
+                lazy = True
+                hidden = (None, self._empty_adj(x), torch.zeros(x.shape[0], dtype=torch.long, device=x.device))
+            else:
+                hidden = self.get_initial_hidden_state(x)
         nodes, adj, T = hidden
-        fresh = getattr(T, "_gcm_fresh", None) == T._version
+        fresh = lazy or (getattr(T, "_gcm_fresh", None) == T._version
+                         and getattr(nodes, "_gcm_fresh", None) == nodes._version)
         assert x.dim() == 3 and x.dtype == torch.float32
         assert taus.dtype == torch.long and T.dtype == torch.long
         adj = adj.coalesce()
-        N = nodes.shape[1]
+        N = self.graph_size if lazy else nodes.shape[1]
         B, t_pad, _ = x.shape
         flags = self._flag_word(x.device)
 
-        fast = self._canonical() if self.fast_host else None
         if (fast is not None and x.is_cuda and not adj.values().requires_grad
                 and fast[2].in_channels == x.shape[-1] and x.device.index == torch.cuda.current_device()):
             fn, hops, c1, a1, c2, a2 = fast[:6]
@@ -199,7 +212,7 @@ class SparseGCM(torch.nn.Module):
             except KeyError:       # (parametrized / re-registered weights: the attribute protocol)
                 ws = (c1.lin_rel.weight, c1.lin_rel.bias, c1.lin_root.weight,
                       c2.lin_rel.weight, c2.lin_rel.bias, c2.lin_root.weight)
-            r = fn(x, taus, nodes, adj.indices(), T, hops, ws[0], ws[1], ws[2], a1, ws[3], ws[4], ws[5], a2,
+            r = fn(x, taus, nodes, N, adj.indices(), T, hops, ws[0], ws[1], ws[2], a1, ws[3], ws[4], ws[5], a2,
                    flags, chain, fresh, self.finite_check == "sync")
             if r == 1:                                         # sparse_gcm.py:120-121
                 raise Exception("Overflow")

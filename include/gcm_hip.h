@@ -188,6 +188,7 @@ int gcm_sparse_plan(const int64_t* T, const int64_t* taus, int64_t* node_off, in
 
 /* sparse_gcm.py:116-128: nodes_out = nodes_in with x[b, k, :] written to row T[b]+k for
  * k < taus[b] (x is [B, t_pad, F], zero padded).  ORs GCM_FLAG_SPARSE_OVERFLOW. */
+/* (nodes_in == NULL: the incoming node matrix is all zeros - empty graphs - and is not read) */
 int gcm_sparse_insert_fwd(const float* nodes_in, const float* x, const int64_t* T,
                           const int64_t* taus, float* nodes_out, uint32_t* flags, int B, int N,
                           int F, int t_pad, gcm_stream_t stream);
@@ -223,6 +224,19 @@ int gcm_sparse_temporal_count(const int64_t* T, const int64_t* taus, const int32
 int gcm_sparse_temporal_fill(const int64_t* T, const int64_t* taus, const int32_t* hops_host,
                              int n_hops, const int64_t* edge_off, int64_t* indices, int64_t E,
                              int B, gcm_stream_t stream);
+/* Whole episodes from EMPTY graphs (T = 0 for every graph): every index structure of the call in closed form, one
+ * launch - the COO entries TemporalEdge adds (coo [3, E], vals [E] or NULL), the flat (source, sink) list edge_index
+ * [2, E] with its CSR row pointers row_ptr [M + 1], and (col_ptr non-NULL) the CSC view col_ptr [M + 1] / rows [E] /
+ * perm [E] of gcm_csc_from_csr_batched.  node_off / edge_off [B + 1]: gcm_sparse_plan / gcm_sparse_temporal_count (or
+ * gcm_sparse_step_plan) on T = 0.  hops: distinct, descending, >= 1 (GCM_EUNSUPPORTED otherwise: the general kernels). */
+int gcm_sparse_temporal_structure(const int64_t* taus, const int32_t* hops_host, int n_hops, const int64_t* node_off,
+                                  const int64_t* edge_off, int64_t* coo, float* vals, int64_t* edge_index,
+                                  int64_t* row_ptr, int64_t* col_ptr, int64_t* rows, int64_t* perm, int64_t E,
+                                  int64_t M, int B, gcm_stream_t stream);
+/* ... also writing the entries' unit weights vals [E] (NULL: indices only) */
+int gcm_sparse_temporal_fill_vals(const int64_t* T, const int64_t* taus, const int32_t* hops_host, int n_hops,
+                                  const int64_t* edge_off, int64_t* indices, float* vals, int64_t E, int B,
+                                  gcm_stream_t stream);
 
 /* util.flatten_nodes util.py:426-452: flat[node_off[b] + i] = nodes[b, i] for i < (T+taus)[b]. */
 int gcm_sparse_flatten_fwd(const float* nodes, const int64_t* T, const int64_t* taus,
@@ -284,6 +298,15 @@ int gcm_csr_graphconv_fwd(const float* x, const int64_t* row_ptr, const int64_t*
                           const float* w, const uint8_t* mask, const float* w_rel,
                           const float* b_rel, const float* w_root, float* out, float* agg,
                           int64_t M, int Fi, int Fo, int act, gcm_stream_t stream);
+/* The same with the finite check SparseGCM makes on the rows it returns (sparse_gcm.py:201-203) folded into the
+ * layer's epilogue: GCM_FLAG_NONFINITE is raised in *flags when an output value is not finite - for callers that hand
+ * `out` back as it is (every row a new node).  Fi = 32, Fo in {32, 64}, M >= 32 (the persistent-wave kernel);
+ * GCM_EUNSUPPORTED otherwise (..._supported tells beforehand). */
+int gcm_csr_graphconv_fwd_checked_supported(int64_t M, int Fi, int Fo);
+int gcm_csr_graphconv_fwd_checked(const float* x, const int64_t* row_ptr, const int64_t* col, const float* w,
+                                  const uint8_t* mask, const float* w_rel, const float* b_rel, const float* w_root,
+                                  float* out, float* agg, int64_t M, int Fi, int Fo, int act, uint32_t* flags,
+                                  gcm_stream_t stream);
 
 /* Backward.  col_ptr/rows/perm: the same edges as CSC by source (perm[k] = position of CSC
  * entry k in the CSR edge order, for w and g_w).  Outputs may be NULL to skip. */

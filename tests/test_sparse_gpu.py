@@ -649,3 +649,78 @@ def test_sparse_stepwise_cached_chain_ends_and_restarts():
         run(None, 0, T, outs)
     assert mem._chain.steps() == T
     torch.testing.assert_close(torch.stack(outs).cpu(), out32, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("hops,B,N", [([1], 5, 40), ([4, 2, 1], 7, 33), ([9, 5, 3], 4, 16), ([2], 3, 2),
+                                      ([16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1], 3, 50)])
+def test_temporal_structure_closed_form_equals_the_general_kernels(hops, B, N):
+    """Whole episodes from empty graphs: gcm_sparse_temporal_structure writes the COO entries, the flat list, the CSR
+    pointers and the CSC view in one launch, in closed form - against the oracle's TemporalEdge (temporal.py:18-63) and
+    the kernels it stands in for (k_temporal_fill, k_edges_flat, k_ptr_from_sorted, k_csc_batched), ragged taus
+    including empty and one-node graphs.  Bit exact (indices)."""
+    import ctypes
+    from gcm import _hip, _ops
+    lib, p, st = _hip.lib(), _hip.ptr, _hip.stream()
+    torch.manual_seed(N + len(hops))
+    taus = torch.randint(0, N + 1, (B,))
+    taus[0], taus[1 % B] = N, 0
+    if B > 2:
+        taus[2] = 1
+    T0 = torch.zeros(B, dtype=torch.long)
+    want_coo = osp.TemporalEdge(hops)(None, T0, taus, B).coalesce().indices()
+    E = want_coo.shape[1]
+    off = torch.cat([torch.zeros(1, dtype=torch.long), taus.cumsum(0)])
+    M = int(off[-1])
+    d = lambda t: t.to(DEV)
+    taus_d, off_d, T0_d = d(taus), d(off), d(T0)      # (kept alive: the calls below take raw pointers)
+    edge_off = _ops.sparse_temporal_count(T0_d, taus_d, hops)
+    assert int(edge_off[-1]) == E
+    coo = torch.full((3, E), -1, dtype=torch.long, device=DEV)
+    vals = torch.zeros(E, device=DEV)
+    edge_index = torch.full((2, E), -1, dtype=torch.long, device=DEV)
+    row_ptr = torch.full((M + 1,), -1, dtype=torch.long, device=DEV)
+    col_ptr = torch.full((M + 1,), -1, dtype=torch.long, device=DEV)
+    rows = torch.full((E,), -1, dtype=torch.long, device=DEV)
+    perm = torch.full((E,), -1, dtype=torch.long, device=DEV)
+    h = (ctypes.c_int32 * len(hops))(*hops)
+    rc = lib.gcm_sparse_temporal_structure(p(taus_d), ctypes.addressof(h), len(hops), p(off_d), p(edge_off), p(coo),
+                                           p(vals), p(edge_index), p(row_ptr), p(col_ptr), p(rows), p(perm), E, M, B, st)
+    assert rc == 0
+    assert torch.equal(coo.cpu(), want_coo) and bool((vals == 1).all())
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    want_d = d(want_coo)
+    edges, graph = _ops.sparse_edges_to_csr(want_d, off_d, M, B, flags, n_cap=N)
+    assert torch.equal(edge_index, edges) and torch.equal(row_ptr, graph.row_ptr)
+    w_ptr, w_rows, w_perm = graph.csc()
+    assert torch.equal(col_ptr, w_ptr) and torch.equal(rows, w_rows) and torch.equal(perm, w_perm)
+    # hops the closed form does not take: the general kernels
+    bad = (ctypes.c_int32 * 2)(1, 2)
+    assert lib.gcm_sparse_temporal_structure(p(taus_d), ctypes.addressof(bad), 2, p(off_d), p(edge_off), p(coo),
+                                             p(vals), p(edge_index), p(row_ptr), p(col_ptr), p(rows), p(perm), E, M, B,
+                                             st) == _hip.GCM_EUNSUPPORTED
+
+
+def test_one_shot_from_none_returns_aliases_that_are_watched():
+    """hidden = None, whole episodes: the returned rows are the last layer's output itself (no extract copy) - an
+    in-place write by the caller before backward() is reported like any saved tensor's; the returned node matrix is
+    a fresh tensor (not the caller's x)."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    B, N, F, H = 6, 64, 32, 32
+    torch.manual_seed(0)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(H, H), "x, edges, weights -> x"), torch.nn.Tanh()]).to(DEV)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1, 2]), graph_size=N)
+    x = torch.rand(B, N, F, device=DEV)
+    taus = torch.full((B,), N, dtype=torch.long, device=DEV)
+    out, hid = mem(x, taus, None)
+    assert hid[0].data_ptr() != x.data_ptr() and torch.equal(hid[0], x)
+    out.mul_(2.0)
+    with pytest.raises(RuntimeError, match="inplace"):
+        out.sum().backward()
+    # and the NaN check still fires on this path (sparse_gcm.py:201-203)
+    xb = x.clone()
+    xb[3, 10, 5] = float("nan")
+    with pytest.raises(AssertionError):
+        mem(xb, taus, None)
