@@ -700,30 +700,38 @@ class DenseGCM(torch.nn.Module):
             self._poll(flags)
         return mx, (nodes_out, adj_out, weights, num_nodes_next)
 
-    def rollout(self, obs, hidden=None):
-        """T memory steps at once: obs [T, B, feat] -> (beliefs [T, B, H],
-        hidden after the last step).  Identical in result to T calls of forward(); when the
-        module tree qualifies for the fused kernels the whole rollout is enqueued by one C call
-        and is one autograd node, otherwise it is the plain Python loop."""
+    def rollout(self, obs, hidden=None, batch_first=False):
+        """T memory steps at once: obs [T, B, feat] -> (beliefs [T, B, H], hidden after the
+        last step); batch_first=True: obs [B, T, feat] -> beliefs [B, T, H] - the shape RLlib's wrapper holds
+        (ray_gcm.py:186-209: `flat` [B, T, F] in, the stacked beliefs [B*T, H] out).  Identical in result to T calls
+        of forward().  Index-writing selectors on the canonical GNN: the whole rollout is enqueued by one C call and
+        is one autograd node; every other configuration (LearnedEdge, distance selectors, folded transforms, user
+        modules) runs the per-step kernels in a loop - on a state this call owns, so the steps advance it IN PLACE
+        whatever `donate_state` says (the caller never sees the intermediate states; the incoming state is copied
+        once)."""
         assert obs.dim() == 3 and obs.dtype == torch.float32
+        if batch_first:
+            out, hidden = self.rollout(obs.transpose(0, 1), hidden)
+            return out.transpose(0, 1), hidden
         if obs.is_cuda and obs.device.index != torch.cuda.current_device():
             with torch.cuda.device(obs.device):
                 return self.rollout(obs, hidden)
-        if hidden is None:
+        if obs.shape[0] == 0:
+            if hidden is None:
+                hidden = self.get_initial_hidden_state(obs[0] if obs.shape[0] else obs.new_zeros(obs.shape[1:]))
+            return obs.new_zeros(0, obs.shape[1], 0), hidden
+        fresh = hidden is None
+        if fresh:
             hidden = self.get_initial_hidden_state(obs[0])
         nodes, adj, weights, num_nodes = hidden
-        cfg = self._fused_plan(nodes, adj, weights, obs.shape[-1]) if obs.shape[0] else None
+        cfg = self._fused_plan(nodes, adj, weights, obs.shape[-1])
         if cfg is not None and (cfg.learned_sel is not None or cfg.fold is not None):
             cfg = None                    # LearnedEdge / folded transforms: the per-step kernels, in a loop
         elif (cfg is not None and cfg.has_distance and cfg.rows_ok
               and not (torch.is_grad_enabled() and (obs.requires_grad or nodes.requires_grad))):
             cfg = None                    # distance selectors: selector kernel + live-row step per step
         if cfg is None:
-            outs = []
-            for t in range(obs.shape[0]):
-                mx, hidden = self(obs[t], hidden)
-                outs.append(mx)
-            return torch.stack(outs), hidden
+            return self._rollout_loop(obs, hidden, fresh)
         B, N = obs.shape[1], nodes.shape[1]
         assert (nodes.shape[0], adj.shape, num_nodes.shape[0], nodes.shape[2]) == \
             (B, (B, N, N), B, obs.shape[2]), "hidden state and observation shapes disagree"
@@ -736,6 +744,32 @@ class DenseGCM(torch.nn.Module):
             self.check_flags(block=False)      # gcm.py:316-318 for rollout-only loops
             self._enqueue_flag_copy(flags)
         return mx_all, (nodes_T, adj_T, weights, count_T)
+
+    def _rollout_loop(self, obs, hidden, fresh):
+        """rollout() as the loop of per-step calls.  The intermediate hidden states never leave this function, so -
+        when no gradient flows through the state itself - the steps run on a state this call owns and advance it in
+        place (the live-row / LearnedEdge kernels' donated form: no per-step copy of the 21 MB state), whatever the
+        module's `donate_state`; a chain from hidden = None also gets the cached steps."""
+        nodes = hidden[0]
+        own = (not self.donate_state and self.fused and nodes.is_cuda and hidden[2].numel() == 0
+               and not (torch.is_grad_enabled() and (obs.requires_grad or nodes.requires_grad or hidden[1].requires_grad)))
+        if own:
+            if fresh:
+                hidden = None             # (the module's own empty graphs: the cached steps' precondition)
+            else:
+                hidden = (nodes.clone(), hidden[1].clone(), hidden[2], hidden[3].clone())
+            self.donate_state = True
+        try:
+            outs = []
+            for t in range(obs.shape[0]):
+                mx, hidden = self(obs[t], hidden)
+                outs.append(mx)
+        finally:
+            if own:
+                self.donate_state = False
+                self._fast = None         # (the C++ entry and the LearnedEdge chain were armed for a donated state)
+                self._learned_chain = None
+        return torch.stack(outs), hidden
 
     # -- the step --------------------------------------------------------------
     def __call__(self, *args, **kwargs):

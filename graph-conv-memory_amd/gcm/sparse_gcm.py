@@ -170,6 +170,16 @@ class SparseGCM(torch.nn.Module):
             self.__dict__["_chain"] = None
         super().__setattr__(name, value)
 
+    def rollout(self, x, hidden=None, taus=None):
+        """The time-batched entry (the shape RLlib's wrapper holds: x [B, T, feat], batch first):
+        T memory steps of every graph in ONE call - which is what forward() already is for SparseGCM (the reference's
+        own tests pin one call == T single-node calls, tests/test_sparse_gcm.py:395-540): forward(x, taus = T for every
+        graph, hidden).  A stepwise caller (x [B, 1, F] per call, ray_sparse_gcm.py:198-213) pays ~50 us of host and
+        launch cost per call; whole episodes through here run at the one-shot rate (bench.py --config cfg4)."""
+        if taus is None:
+            taus = torch.full((x.shape[0],), x.shape[1], dtype=torch.long, device=x.device)
+        return self(x, taus, hidden)
+
     def forward(self, x, taus, hidden):
         """x [B, t, feat] zero padded in t; taus [B] valid lengths; hidden (nodes, adj, T) or
         None.  Returns (mx [B, t, H] zero padded, (nodes, adj, T + taus))."""

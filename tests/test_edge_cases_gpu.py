@@ -392,3 +392,118 @@ def test_learned_edge_single_node_path_equals_stepwise_path():
     assert torch.equal(res[0][2], res[1][2])
     for a, b in zip(res[0][3], res[1][3]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["euclid", "learned", "fold_pre", "temporal"])
+@pytest.mark.parametrize("start", ["none", "state"])
+def test_rollout_entry_equals_single_steps_every_selector(kind, start):
+    """DenseGCM.rollout for the configurations that run it as the loop of per-step kernels on a
+    state the call owns (advanced in place whatever donate_state says): == T single functional steps - state bit
+    exact, beliefs / parameter gradients to summation order - from hidden = None and from a caller's state, which
+    must come back untouched; batch_first=True ([B, T, F] in, [B, T, H] out: ray_gcm.py:186-209) is the same run."""
+    from gcm import nn as G
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    from gcm.edge_selectors.distance import EuclideanEdge
+    from gcm.edge_selectors.learned import LearnedEdge
+    B, N, F, H, T = 40, 32, 32, 32, 45          # (T > N: the graphs overflow inside the rollout)
+    torch.manual_seed(3)
+    centres = 3 * torch.randn(5, F)
+    obs = (centres[torch.arange(T) % 5][:, None, :] + 0.05 * torch.randn(T, B, F)).to(DEV)
+    noise = -torch.empty(T, B, N).exponential_().log().to(DEV)
+    w = torch.rand(T, B, H, device=DEV)
+
+    def make():
+        torch.manual_seed(11)
+        g = G.Sequential("x, adj, weights, B, N", [
+            (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+            (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+        pre, step = None, {"t": 0}
+        if kind == "euclid":
+            sel = EuclideanEdge(3.0)
+        elif kind == "learned":
+            sel = LearnedEdge(F, num_edge_samples=4).to(DEV)
+            sel.noise_fn = lambda like: noise[step["t"]]
+        elif kind == "fold_pre":
+            sel, pre = TemporalBackedge([1, 3]), torch.nn.Linear(F, F).to(DEV)
+        else:
+            sel = TemporalBackedge([1, 2, 4])
+        mem = DenseGCM(g, preprocessor=pre, edge_selectors=sel, graph_size=N)
+        return mem, g, sel, pre, step
+
+    def state0():
+        if start == "none":
+            return None
+        torch.manual_seed(5)
+        c0 = torch.randint(0, N // 2, (B,))
+        n0 = torch.rand(B, N, F) * (torch.arange(N)[None, :, None] < c0[:, None, None])
+        a0 = torch.zeros(B, N, N)
+        i = torch.arange(1, N)
+        a0[:, i, i - 1] = 1.0
+        a0 = a0 * (torch.arange(N)[None, :, None] < c0[:, None, None])
+        return (n0.to(DEV), a0.to(DEV), torch.zeros(0, device=DEV), c0.to(DEV))
+
+    # T single steps, functional state
+    mem, g, sel, pre, step = make()
+    hid, outs = state0(), []
+    for t in range(T):
+        step["t"] = t
+        mx, hid = mem(obs[t], hid)
+        outs.append(mx)
+    want = torch.stack(outs)
+    (want * w).sum().backward()
+    mem.check_flags()
+    mods = [g] + ([sel] if kind == "learned" else []) + ([pre] if pre is not None else [])
+    want_g = [p.grad.clone() for m in mods for p in m.parameters()]
+    for bf in (False, True):
+        mem2, g2, sel2, pre2, step2 = make()
+        if kind == "learned":       # rollout() makes its own steps: the draws by call count
+            cnt = {"t": 0}
+
+            def nf(like, cnt=cnt):
+                cnt["t"] += 1
+                return noise[cnt["t"] - 1]
+            sel2.noise_fn = nf
+        h0 = state0()
+        keep = None if h0 is None else tuple(t.clone() for t in h0)
+        o = obs.transpose(0, 1).contiguous() if bf else obs
+        got, hid2 = mem2.rollout(o, h0, batch_first=bf)
+        if bf:
+            assert got.shape == (B, T, H)
+            got = got.transpose(0, 1)
+        (got * w).sum().backward()
+        mem2.check_flags()
+        assert not mem2.donate_state
+        if keep is not None:        # the caller's state is untouched
+            assert all(torch.equal(a, b_) for a, b_ in zip(h0, keep))
+            assert hid2[0].data_ptr() != h0[0].data_ptr()
+        assert torch.equal(hid2[0], hid[0]) and torch.equal(hid2[1], hid[1]) and torch.equal(hid2[3], hid[3])
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
+        mods2 = [g2] + ([sel2] if kind == "learned" else []) + ([pre2] if pre2 is not None else [])
+        got_g = [p.grad for m in mods2 for p in m.parameters()]
+        scale = max(float(x.abs().max()) for x in want_g)
+        for a, b_ in zip(got_g, want_g):
+            torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-6 * scale)
+
+
+def test_sparse_rollout_entry_is_one_call():
+    """SparseGCM.rollout(x [B, T, F]) == T single-node calls (tests/test_sparse_gcm.py:469-540 of the reference pin
+    exactly that for forward())."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    B, N, F, H, T = 5, 24, 32, 32, 24
+    torch.manual_seed(0)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(H, H), "x, edges, weights -> x"), torch.nn.Tanh()]).to(DEV)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1, 2]), graph_size=N)
+    x = torch.rand(B, T, F, device=DEV)
+    out, hid = mem.rollout(x)
+    one = torch.ones(B, dtype=torch.long, device=DEV)
+    h, outs = None, []
+    for t in range(T):
+        o, h = mem(x[:, t:t + 1].contiguous(), one, h)
+        outs.append(o)
+    torch.testing.assert_close(out, torch.cat(outs, 1), rtol=1e-5, atol=2e-6)
+    assert torch.equal(hid[1].coalesce().indices(), h[1].coalesce().indices()) and torch.equal(hid[0], h[0])
+    assert torch.equal(hid[2], h[2])
