@@ -678,11 +678,17 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     mem_f, gnn_f, bucket_f, v = variant(False)
     variants["eager_functional"] = statistics.median(v)
     variants["eager_functional_min_max"] = [min(v), max(v)]
+    # the additive time-batched entry DenseGCM.rollout on the FUNCTIONAL module: temporal / dense
+    # selectors as one C call, LearnedEdge from empty graphs as the two-launch time-parallel forward, everything else
+    # as the per-step loop on a state the call owns
+    mods_f = [gnn_f] + ([s_ for s_ in [getattr(mem_f, "edge_selectors", None)] if c["selector"] == "learned"])
+
+    def roll():
+        rollout_api(mem_f, obs, bucket_f, weight)
+        for q in mods_f:
+            q.zero_grad(set_to_none=True)
+    variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
     if c["selector"] == "temporal":
-        def roll():
-            rollout_api(mem_f, obs, bucket_f, weight)
-            gnn_f.zero_grad(set_to_none=True)
-        variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
 
         def fwd_only():
             with torch.no_grad():

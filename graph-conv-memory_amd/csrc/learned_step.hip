@@ -492,6 +492,249 @@ __global__ __launch_bounds__(256) void k_learned_select(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Time-parallel forward of a whole rollout (round 4; DenseGCM.rollout with LearnedEdge from EMPTY graphs, T <= N
+// steps, observations without gradient).  Nothing in the selection of step t depends on another step's RESULT: the
+// edge network scores pairs of raw observations (learned.py:53-87), the gumbel draws are given, and with empty
+// graphs to start from node j is observation j.  So every (graph, step) is one workgroup of ONE launch
+// (k_learned_roll_select: what k_learned_select<2, true> does for its step, with cur = t, the node image from the
+// observation tensor [T, B, F], and layer 1 of the GNN on row cur - h1 / agg1 / x into the chain's caches), and the
+// belief states follow in a second launch once every h1 row exists (k_learned_roll_l2: layer 2 on row cur, one wave
+// per (graph, step)) - two launches instead of T latency-bound ones.  Same arithmetic in the same order as the
+// cached per-step kernel: same sampled edges, same beliefs.  The records (gcm_learned_step_layout, compact = 2: row
+// cur of the adjacency, soft, cur, agg2, mx), one per step at a fixed stride, and the caches are what
+// gcm_learned_bptt_cached reads.
+// ---------------------------------------------------------------------------------------------
+struct RollRec {          // the T step records: record t at rec0 + t * stride (floats)
+  float* rec0;
+  size_t stride, o_row, o_mx, o_agg2, o_idx, o_soft;
+};
+
+__global__ __launch_bounds__(256) void k_learned_roll_select(
+    const float* __restrict__ obs, const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp,
+    float eps0, float eps1, float cutoff, const float* __restrict__ gnn, int act1, int has_bias, int H1,
+    float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count, RollRec R,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, int B, int T, int N, int F) {
+  const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cur = t;                                   // empty graphs at the start: node j is observation j
+  const Mlp M = unpack_mlp(mlp, F);
+  const float* xcur = obs + ((size_t)t * B + b) * F;
+  float* rec = R.rec0 + (size_t)t * R.stride;
+  extern __shared__ float smem[];
+  float* sX = smem;                 // [NP][FS]
+  float* sA = sX + NP * FS;
+  float* sB = sA + NP * FS;
+  float* sW0b = sB + NP * FS;
+  float* sW1 = sW0b + FP * FS;
+  float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2
+  float* sLogit = sVec + 7 * FP;    // [NP]
+  float* sWg = sLogit + NP;         // [2][FP][FS] W_rel1 | W_root1
+
+  gcm_fused::Stage<FP, FP, false, false> st_w0, st_w1, st_g0, st_g1;
+  st_w0.load(M.w0 + F, F, F, 2 * F, tid);
+  st_w1.load(M.w1, F, F, F, tid);
+  st_g0.load(gnn, H1, F, F, tid);
+  st_g1.load(gnn + (size_t)H1 * F, H1, F, F, tid);
+  float pf_noise[2], pf_b1;
+  {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c < N ? lane + 64 * c : N - 1;
+      pf_noise[c] = noise[((size_t)t * B + b) * N + j];
+    }
+    pf_b1 = gnn[2 * (size_t)H1 * F + (lane < H1 ? lane : H1 - 1)];
+  }
+  {   // the node image: rows j <= cur are observations j of this graph, the rest zero (empty graphs)
+    constexpr int PER = NP * FP / 256;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, c = e % FP;
+      v[i] = obs[((size_t)(r <= cur ? r : cur) * B + b) * F + (c < F ? c : F - 1)];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, r = e / FP, c = e % FP;
+      sX[r * FS + c] = (r <= cur && c < F) ? v[i] : 0.f;
+    }
+  }
+  st_w0.store(sW0b, FS, tid);
+  st_w1.store(sW1, FS, tid);
+  st_g0.store(sWg, FS, tid);
+  st_g1.store(sWg + FP * FS, FS, tid);
+  if (tid < FP) {
+    const int o = tid < F ? tid : F - 1;
+    const float c0 = c0_dot(M.w0 + (size_t)o * 2 * F, xcur, M.b0[o], F);
+    const bool ok = tid < F;
+    sVec[tid] = ok ? c0 : 0.f;
+    sVec[FP + tid] = ok ? M.b1[o] : 0.f;
+    sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
+    sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
+    sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
+    sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
+    sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
+  }
+  __syncthreads();
+  // (a 32-row block with no candidate row - rows >= cur - is skipped: its logits are never read)
+  const bool live_blk = 32 * wave < cur;
+  if (live_blk) {
+    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
+  }
+  __syncthreads();
+  if (32 * (tid >> 6) < cur) relu_ln_rows(sA, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
+  __syncthreads();
+  if (live_blk) {
+    const f32x16 acc = gemm_rows(sA, sW1, wave, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sB[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
+  }
+  __syncthreads();
+  if (32 * (tid >> 6) < cur) relu_ln_rows(sB, tid, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
+  __syncthreads();
+  if (tid < NP && tid < cur) {
+    float lg = M.b2[0];
+#pragma unroll
+    for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sB[tid * FS + f], lg);
+    sLogit[tid] = lg;
+  }
+  __syncthreads();
+  if (wave == 1) {   // the state: the inserted node, the count behind the last step
+    if (lane < F) nodes[((size_t)b * N + cur) * F + lane] = sX[cur * FS + lane];
+    if (lane == 0) {
+      reinterpret_cast<int64_t*>(rec + R.o_idx)[b] = cur;
+      if (t == T - 1) count[b] = T;
+    }
+  }
+  if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
+    float z[2], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      float nz = 0.f;
+      if (j < cur) {
+        const float tt = pf_noise[c];
+        nz = noise_is_exp ? -logf(tt) : tt;
+      }
+      z[c] = j < cur ? sLogit[j] + nz : -INFINITY;
+      m = fmaxf(m, z[c]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      z[c] = (lane + 64 * c < cur) ? expf(z[c] - m) : 0.f;
+      s += z[c];
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    float* row = adj + ((size_t)b * N + cur) * N;
+    float* soft = rec + R.o_soft;
+    float* row_out = rec + R.o_row;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      if (j < N) {
+        const float p = z[c] * inv;
+        soft[(size_t)b * N + j] = p;
+        float nv = 0.f;
+        if (j < cur) nv = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12); the incoming row is empty
+        if (j < cur) row[j] = nv;                              // (the rest of the row stays zero)
+        row_out[(size_t)b * N + j] = nv;
+        z[c] = nv;
+      } else {
+        z[c] = 0.f;
+      }
+    }
+    // ---- layer 1 of the GNN on row cur: the selected rows S = { j < cur : row[j] = 1 }, ascending -------------
+    unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
+    const int fl_ = lane < FP ? lane : FP - 1;
+    float agg1 = 0.f;
+    while (m0 | m1) {
+      const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+      if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+      agg1 += sX[j * FS + fl_];
+    }
+    const float xc = sX[cur * FS + fl_];
+    agg1 = lane < F ? agg1 : 0.f;
+    const float* wr1 = sWg + fl_ * FS;
+    const float* wt1 = sWg + FP * FS + fl_ * FS;
+    float p1 = (has_bias & 1) && lane < H1 ? pf_b1 : 0.f;
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg1), f));
+      const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), f));
+      p1 = fmaf(wr1[f], a, p1);
+      p1 = fmaf(wt1[f], x, p1);
+    }
+    float h1c = gcm_act(p1, act1);
+    h1c = lane < H1 ? h1c : 0.f;
+    const size_t rc = (size_t)b * N + cur;
+    if (lane < H1) cH[rc * H1 + lane] = h1c;
+    if (lane < F) {
+      cA[rc * F + lane] = agg1;
+      cX[rc * F + lane] = xc;
+    }
+  }
+}
+
+// layer 2 on row cur of every (graph, step): one wave each, four per workgroup
+__global__ __launch_bounds__(256) void k_learned_roll_l2(const float* __restrict__ gnn, int act2, int has_bias,
+                                                         int H1, int H2, RollRec R, const float* __restrict__ cH,
+                                                         float* __restrict__ mx_all, uint32_t* __restrict__ flags,
+                                                         int B, int T, int N, int F) {
+  __shared__ float sW[2 * FP * FS];   // W_rel2 | W_root2, row o at stride FS
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  {
+    gcm_fused::Stage<FP, FP, false, false> a, c;
+    a.load(gnn + 2 * (size_t)H1 * F + H1, H2, H1, H1, tid);
+    c.load(gnn + 2 * (size_t)H1 * F + H1 + (size_t)H2 * H1, H2, H1, H1, tid);
+    a.store(sW, FS, tid);
+    c.store(sW + FP * FS, FS, tid);
+  }
+  __syncthreads();
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= (long)T * B) return;
+  const int t = (int)(item / B), b = (int)(item - (long)t * B);
+  float* rec = R.rec0 + (size_t)t * R.stride;
+  const float* row = rec + R.o_row + (size_t)b * N;
+  const float z0 = row[lane < N ? lane : N - 1], z1 = row[lane + 64 < N ? lane + 64 : N - 1];
+  const float pf_b2 = gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + (lane < H2 ? lane : H2 - 1)];
+  unsigned long long m0 = __ballot(lane < N && z0 != 0.f), m1 = __ballot(lane + 64 < N && z1 != 0.f);
+  const int hl = lane < H1 ? lane : H1 - 1;
+  float agg2 = 0.f;
+  while (m0 | m1) {
+    const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+    if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+    agg2 += cH[((size_t)b * N + j) * H1 + hl];
+  }
+  float h1c = cH[((size_t)b * N + t) * H1 + hl];
+  agg2 = lane < H1 ? agg2 : 0.f;
+  h1c = lane < H1 ? h1c : 0.f;
+  const int fl_ = lane < FP ? lane : FP - 1;
+  const float* wr2 = sW + fl_ * FS;
+  const float* wt2 = sW + FP * FS + fl_ * FS;
+  float p2 = (has_bias & 2) && lane < H2 ? pf_b2 : 0.f;
+#pragma unroll
+  for (int h = 0; h < FP; ++h) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg2), h));
+    const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h1c), h));
+    p2 = fmaf(wr2[h], a, p2);
+    p2 = fmaf(wt2[h], x, p2);
+  }
+  const float v = gcm_act(p2, act2);
+  if (lane < H1) rec[R.o_agg2 + (size_t)b * H1 + lane] = agg2;
+  if (lane < H2) {
+    rec[R.o_mx + (size_t)b * H2 + lane] = v;
+    mx_all[((size_t)t * B + b) * H2 + lane] = v;
+  }
+  const bool bad = __any(lane < H2 && !isfinite(v));
+  if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward of one step (see the header comment)
 // ---------------------------------------------------------------------------------------------
 // slab per graph (floats): GNN part as the packed GNN vector (dW_rel1 | dW_root1 | db1 | dW_rel2 |
@@ -1333,6 +1576,7 @@ constexpr size_t lds_bptt_b() {
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
 constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * FS); }
+constexpr size_t lds_roll_select() { return lds_select() + sizeof(float) * (2 * FP * FS); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
                           (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);
@@ -1456,6 +1700,38 @@ extern "C" int gcm_learned_step_cached_functional(
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,
                      (float*)nullptr, gt);
+  return gcm_launch_status();
+}
+
+/* DenseGCM.rollout with LearnedEdge, the whole forward of T <= N steps from EMPTY graphs in two launches (see
+ * k_learned_roll_select).  obs [T,B,F], noise [T,B,N]; nodes [B,N,F] / adj [B,N,N]: the state AFTER the rollout, both
+ * ZERO on entry (rows >= T stay zero), count [B] <- T; records: T step records of gcm_learned_step_layout(compact = 2)
+ * at `rec_stride` floats from each other (>= that layout's total); caches [B,N,.] (rows < T written); mx_all [T,B,H2].
+ * What gcm_learned_bptt_cached (n_cached = T, cached_layout = 2) reads. */
+extern "C" int gcm_learned_rollout_fwd(const float* obs, const float* noise, int noise_is_exp, const float* params,
+                                       int has_bias, int act1, int act2, float eps0, float eps1, float cutoff,
+                                       float* nodes, float* adj, int64_t* count, float* records, size_t rec_stride,
+                                       float* cache_h1, float* cache_agg1, float* cache_nodes, float* mx_all,
+                                       uint32_t* flags, int T, int B, int N, int F, int H1, int H2,
+                                       gcm_stream_t stream) {
+  GCM_REQUIRE(obs && noise && params && nodes && adj && count && records && cache_h1 && cache_agg1 && cache_nodes &&
+              mx_all && flags && T > 0 && B > 0);
+  if (!gcm_learned_step_supported(N, F, H1, H2) || T > N || B > 65535 || T > 65535) return GCM_EUNSUPPORTED;
+  size_t lay[8];
+  gcm_learned_step_layout(B, N, F, H1, H2, 2, lay);
+  GCM_REQUIRE(rec_stride >= lay[0]);
+  const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  gcm_learned::RollRec R{records, rec_stride, lay[1], lay[2], lay[5], lay[6], lay[7]};
+  constexpr size_t lds = gcm_learned::lds_roll_select();
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_roll_select, lds);
+  hipLaunchKernelGGL(gcm_learned::k_learned_roll_select, dim3(B, T), dim3(256), lds, (hipStream_t)stream, obs, noise,
+                     noise_is_exp, params + Pg, eps0, eps1, cutoff, params, act1, has_bias, H1, nodes, adj, count, R,
+                     cache_h1, cache_agg1, cache_nodes, B, T, N, F);
+  int rc = gcm_launch_status();
+  if (rc) return rc;
+  const long items = (long)T * B;
+  hipLaunchKernelGGL(gcm_learned::k_learned_roll_l2, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, params, act2, has_bias, H1, H2, R, cache_h1, mx_all, flags, B, T, N, F);
   return gcm_launch_status();
 }
 

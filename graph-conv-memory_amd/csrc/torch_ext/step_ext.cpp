@@ -1477,6 +1477,98 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
   return pybind11::make_tuple(mx, nodes_out, adj_out, cur, count_out, index);
 }
 
+// ---------------------------------------------------------------------------------------------
+// DenseGCM.rollout with LearnedEdge from EMPTY graphs, T <= N steps, observations without gradient: the whole
+// forward in two launches (gcm_learned_rollout_fwd: every (graph, step) a workgroup - the selection depends on raw
+// observations and the given gumbel draws only), ONE autograd node whose backward is the chain's time-parallel one
+// (gcm_learned_bptt_cached over the T records and the caches).  The returned state (nodes, adj, count) is new.
+// ---------------------------------------------------------------------------------------------
+struct LearnedRolloutNode : public torch::autograd::Node {
+  at::Tensor packed, records, cH, cA, cX;
+  c10::VariableVersion vc;
+  uint32_t version = 0;
+  LearnedCfg* cfg = nullptr;
+  int64_t T = 0, B = 0, stride = 0;
+  bool released = false;
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(1);
+    TORCH_CHECK(!released, "Trying to backward through a DenseGCM.rollout (LearnedEdge) a second time (its records "
+                           "were freed); pass retain_graph=True to the first call");
+    if (!grads[0].defined()) return out;
+    TORCH_CHECK(vc.current_version() == version,
+                "one of the variables needed for gradient computation has been modified by an inplace operation: "
+                "the belief states returned by DenseGCM.rollout (LearnedEdge)");
+    at::Tensor g = grads[0].scalar_type() == at::kFloat ? grads[0] : grads[0].to(at::kFloat);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    std::vector<const float*> sv(T), gm(T);
+    for (int64_t t = 0; t < T; ++t) {
+      sv[t] = records.data_ptr<float>() + t * stride;
+      gm[t] = g.data_ptr<float>() + t * g.stride(0);
+    }
+    const gcm_stream_t stream =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(packed.get_device()).stream());
+    const size_t ws_bytes = gcm_learned_bptt_workspace_bytes((int)T, (int)B, N, F, H1, H2);
+    at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
+    at::Tensor res = at::empty({cfg->P_total}, packed.options());
+    check(gcm_learned_bptt_cached(sv.data(), gm.data(), (int)T, (int)T, 2, cX.data_ptr<float>(), cH.data_ptr<float>(),
+                                  cA.data_ptr<float>(), (long)g.stride(1), (long)g.stride(2), packed.data_ptr<float>(),
+                                  cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1, 1, nullptr,
+                                  res.data_ptr<float>(), ws.data_ptr(), ws_bytes, (int)B, N, F, H1, H2, stream),
+          "gcm_learned_bptt_cached");
+    out[0] = res;
+    return out;
+  }
+  void release_variables() override {
+    records.reset(); cH.reset(); cA.reset(); cX.reset();
+    released = true;
+  }
+  std::string name() const override { return "GcmLearnedRollout"; }
+};
+
+// -> (mx_all [T,B,H2], nodes [B,N,F], adj [B,N,N], count [B])
+pybind11::tuple learned_rollout(int64_t cfg_handle, const at::Tensor& packed, const at::Tensor& obs_,
+                                const at::Tensor& noise_, int64_t noise_is_exp, const at::Tensor& flags) {
+  LearnedCfg* cfg = reinterpret_cast<LearnedCfg*>(cfg_handle);
+  TORCH_CHECK(cfg != nullptr && obs_.is_cuda() && noise_.is_cuda() && packed.is_cuda() && flags.is_cuda(),
+              "learned_rollout: every tensor must live on a HIP device (no CPU fallback)");
+  at::Tensor obs = obs_.contiguous(), noise = noise_.contiguous();
+  const int64_t T = obs.size(0), B = obs.size(1);
+  const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+  TORCH_CHECK(obs.dim() == 3 && obs.size(2) == F && noise.numel() == T * B * N && T >= 1 && T <= N &&
+                  packed.is_contiguous() && packed.numel() >= cfg->P_total && obs.scalar_type() == at::kFloat,
+              "learned_rollout: shapes disagree (T <= graph_size steps from empty graphs)");
+  const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad();
+  size_t lay[8];
+  check(gcm_learned_step_layout((int)B, N, F, H1, H2, 2, lay), "gcm_learned_step_layout");
+  const int64_t stride = (int64_t)lay[0];
+  at::Tensor records = at::empty({T * stride}, obs.options());
+  at::Tensor nodes = at::zeros({B, N, F}, obs.options()), adj = at::zeros({B, N, N}, obs.options());
+  at::Tensor count = at::empty({B}, obs.options().dtype(at::kLong));
+  at::Tensor cH = at::empty({B, N, H1}, obs.options()), cA = at::empty({B, N, F}, obs.options()),
+             cX = at::empty({B, N, F}, obs.options());
+  at::Tensor mx_all = at::empty({T, B, H2}, obs.options());
+  const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(obs.get_device()).stream());
+  check(gcm_learned_rollout_fwd(obs.data_ptr<float>(), noise.data_ptr<float>(), (int)noise_is_exp,
+                                packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2, (float)cfg->eps0,
+                                (float)cfg->eps1, (float)cfg->cutoff, nodes.data_ptr<float>(), adj.data_ptr<float>(),
+                                count.data_ptr<int64_t>(), records.data_ptr<float>(), (size_t)stride,
+                                cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
+                                mx_all.data_ptr<float>(), reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)T, (int)B,
+                                N, F, H1, H2, st),
+        "gcm_learned_rollout_fwd");
+  if (need_bwd) {
+    auto node = std::shared_ptr<LearnedRolloutNode>(new LearnedRolloutNode(), torch::autograd::deleteNode);
+    node->packed = packed.detach();
+    node->records = records; node->cH = cH; node->cA = cA; node->cX = cX;
+    node->cfg = cfg; node->T = T; node->B = B; node->stride = stride;
+    node->vc = mx_all.unsafeGetTensorImpl()->version_counter();
+    node->version = node->vc.current_version();
+    node->set_next_edges(torch::autograd::collect_next_edges(packed));
+    torch::autograd::create_gradient_edge(mx_all, node);
+  }
+  return pybind11::make_tuple(mx_all, nodes, adj, count);
+}
+
 std::vector<at::Tensor> learned_step(const at::Tensor& packed, const at::Tensor& dchain_in, const at::Tensor& obs,
                                      const at::Tensor& nodes_in, const at::Tensor& adj_in,
                                      const at::Tensor& count_in, const at::Tensor& noise, int64_t noise_is_exp,
@@ -2184,6 +2276,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("recording", &LearnedChain::recording)
       .def("steps", &LearnedChain::steps);
   m.def("learned_step2", &learned_step2);
+  m.def("learned_rollout", &learned_rollout);
   pybind11::class_<SparseChain>(m, "SparseChain")
       .def(pybind11::init<>())
       .def("steps", [](SparseChain& c) { return c.steps; })

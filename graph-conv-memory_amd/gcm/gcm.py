@@ -721,6 +721,16 @@ class DenseGCM(torch.nn.Module):
                 hidden = self.get_initial_hidden_state(obs[0] if obs.shape[0] else obs.new_zeros(obs.shape[1:]))
             return obs.new_zeros(0, obs.shape[1], 0), hidden
         fresh = hidden is None
+        if fresh and not self.edge_weights:
+            # (the plan looks at shapes and devices only: the 21 MB empty state is materialised by whoever needs it)
+            z = obs.new_empty(0, self.graph_size, obs.shape[-1])
+            cfg = self._fused_plan(z, obs.new_empty(0, self.graph_size, self.graph_size), obs.new_zeros(0), obs.shape[-1])
+            # (T <= N: the adjacency entries a step writes are read by later steps' layer 1 - their gradient reaches
+            #  the selection through ONE chain's records, so a rollout is not split at the overflow)
+            if (cfg is not None and cfg.learned_sel is not None and self.learned_time_parallel
+                    and self.learned_cached_steps and obs.shape[0] <= self.graph_size
+                    and not (torch.is_grad_enabled() and obs.requires_grad)):
+                return self._rollout_learned(obs, cfg)
         if fresh:
             hidden = self.get_initial_hidden_state(obs[0])
         nodes, adj, weights, num_nodes = hidden
@@ -744,6 +754,34 @@ class DenseGCM(torch.nn.Module):
             self.check_flags(block=False)      # gcm.py:316-318 for rollout-only loops
             self._enqueue_flag_copy(flags)
         return mx_all, (nodes_T, adj_T, weights, count_T)
+
+    def _rollout_learned(self, obs, cfg):
+        """rollout() with LearnedEdge from hidden = None, T <= graph_size steps, observations without gradient: TWO
+        launches (gcm_learned_rollout_fwd: the selection of a step depends on raw observations and its gumbel draws
+        only, so every (graph, step) is a workgroup of one launch; the beliefs follow in a second one) and one
+        autograd node whose backward is the chain's time-parallel one.  The hidden state it returns is a plain
+        tensor tuple: like every rollout() it ends its gradient chain (a later call's gradient does not reach this
+        rollout's selections - truncated BPTT at the call boundary, which is what RLlib's state passing does)."""
+        ext = _ops._ext.module()
+        T, B = obs.shape[0], obs.shape[1]
+        N = cfg.N
+        if ext is None or not hasattr(ext, "learned_rollout") or not cfg.learned_cpp_handle() or (N & 3) or (cfg.F & 3):
+            return self._rollout_loop(obs, self.get_initial_hidden_state(obs[0]), True)
+        root = self._packed_params(cfg, head=True)
+        sel = cfg.learned_sel
+        if sel.noise_fn is not None:      # injected gumbel draws (parity tests): one call per step, in step order
+            noise = torch.stack([sel.noise_fn(torch.empty(B, N, device=obs.device)) for _ in range(T)])
+            is_exp = 0
+        else:                             # torch.nn.functional.gumbel_softmax draws -log(Exp(1)) the same way
+            noise, is_exp = torch.empty(T, B, N, device=obs.device).exponential_(), 1
+        flags = self._flag_word(obs.device)
+        mx, nodes, adj, count = ext.learned_rollout(cfg.learned_cpp_handle(), root, obs, noise, is_exp, flags)
+        if self.finite_check == "sync":
+            self.check_flags()
+        elif self.finite_check == "deferred" and not torch.cuda.is_current_stream_capturing():
+            self.check_flags(block=False)
+            self._enqueue_flag_copy(flags)
+        return mx, (nodes, adj, torch.zeros(0, device=obs.device), count)
 
     def _rollout_loop(self, obs, hidden, fresh):
         """rollout() as the loop of per-step calls.  The intermediate hidden states never leave this function, so -

@@ -853,6 +853,18 @@ int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const f
  * of ONE chain of hidden states in order; gmx_host[t] == NULL: zero gradient.  params / g_params: GNN
  * (gcm_dense_gnn2_param_count) | edge network (gcm_learned_mlp_param_count), g_params = g_params_prev
  * (NULL = 0) + gradient. */
+/* DenseGCM.rollout with LearnedEdge: the whole forward of T <= N steps from EMPTY graphs, observations without
+ * gradient, in TWO launches - the selection of step t (learned.py:53-113) depends on raw observations and the given
+ * gumbel draws only, so every (graph, step) is a workgroup of one launch (edge network, gumbel-softmax, threshold,
+ * adjacency row, layer 1 of the GNN on row cur into the caches), and the belief states follow in a second one.
+ * obs [T,B,F], noise [T,B,N]; nodes [B,N,F] / adj [B,N,N]: the state AFTER the rollout, ZERO on entry; count [B] <- T;
+ * records: T step records (gcm_learned_step_layout, compact = 2) rec_stride floats apart; caches [B,N,.]; mx_all
+ * [T,B,H2].  Backward: gcm_learned_bptt_cached over those records (n_cached = T, cached_layout = 2). */
+int gcm_learned_rollout_fwd(const float* obs, const float* noise, int noise_is_exp, const float* params, int has_bias,
+                            int act1, int act2, float eps0, float eps1, float cutoff, float* nodes, float* adj,
+                            int64_t* count, float* records, size_t rec_stride, float* cache_h1, float* cache_agg1,
+                            float* cache_nodes, float* mx_all, uint32_t* flags, int T, int B, int N, int F, int H1,
+                            int H2, gcm_stream_t stream);
 int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int compact, size_t* out8);
 size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, int F, int H1, int H2);
 int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_host, int n_steps,

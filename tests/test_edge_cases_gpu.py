@@ -394,7 +394,7 @@ def test_learned_edge_single_node_path_equals_stepwise_path():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("kind", ["euclid", "learned", "fold_pre", "temporal"])
+@pytest.mark.parametrize("kind", ["euclid", "learned", "learned_short", "fold_pre", "temporal"])
 @pytest.mark.parametrize("start", ["none", "state"])
 def test_rollout_entry_equals_single_steps_every_selector(kind, start):
     """DenseGCM.rollout for the configurations that run it as the loop of per-step kernels on a
@@ -407,6 +407,8 @@ def test_rollout_entry_equals_single_steps_every_selector(kind, start):
     from gcm.edge_selectors.distance import EuclideanEdge
     from gcm.edge_selectors.learned import LearnedEdge
     B, N, F, H, T = 40, 32, 32, 32, 45          # (T > N: the graphs overflow inside the rollout)
+    if kind == "learned_short":                 # T <= N from hidden = None: the two-launch time-parallel forward
+        kind, T = "learned", 29
     torch.manual_seed(3)
     centres = 3 * torch.randn(5, F)
     obs = (centres[torch.arange(T) % 5][:, None, :] + 0.05 * torch.randn(T, B, F)).to(DEV)

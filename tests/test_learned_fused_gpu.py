@@ -118,7 +118,7 @@ def _check_learned_grads(got, g32, g64, same_edges, rtol_sel=2e-3, must_bound=Fa
                                        atol=2e-5 * float(g32[kk].abs().max()) + 2e-6 * sc, msg=kk)
 
 
-def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False, must_bound=False):
+def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False, must_bound=False, rollout=False):
     """product on the whole batch, oracle on the graphs `pick`, same injected gumbel noise; the loss
     weights only the picked graphs.  count0 = None: from hidden = None (empty graphs: the cached steps)."""
     ref, net, g, sel, mem = _pair(F, H, N, k, seed, donate)
@@ -144,15 +144,26 @@ def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False,
     pstep = {"t": 0}
     sel.noise_fn = lambda like: noise[pstep["t"]].to(DEV)
     h_first = None if hidden is None else (hidden[0].data_ptr(), hidden[1].data_ptr())
-    outs = []
-    for t in range(T):
-        pstep["t"] = t
-        mx, hidden = mem(obs[t].to(DEV), hidden)
-        outs.append(mx)
+    if rollout:      # the time-batched entry: from hidden = None and T <= N, two launches for the whole forward
+        assert hidden is None
+        cnt = {"t": 0}
+
+        def by_count(like):
+            cnt["t"] += 1
+            return noise[cnt["t"] - 1].to(DEV)
+        sel.noise_fn = by_count
+        out_d, hidden = mem.rollout(obs.to(DEV))
+        assert cnt["t"] == T
+    else:
+        outs = []
+        for t in range(T):
+            pstep["t"] = t
+            mx, hidden = mem(obs[t].to(DEV), hidden)
+            outs.append(mx)
+        out_d = torch.stack(outs)
     assert _taken(mem)
     if donate and N % 4 == 0 and F % 4 == 0 and h_first:   # advanced in place: the caller's own tensors all the way
         assert hidden[0].data_ptr() == h_first[0] and hidden[1].data_ptr() == h_first[1]
-    out_d = torch.stack(outs)
     (out_d[:, pick] * wgt.to(DEV)).sum().backward()
     mem.check_flags()
     assert torch.equal(hidden[1][pick].cpu(), hid[1])          # sampled adjacency: bit exact
@@ -195,6 +206,17 @@ def test_learned_fused_cfg5_size_long_rollout():
     assert int(hidden[3].min()) == N          # every graph is in steady-state overflow by the end
     hidden, _ = _run_both(B, N, F, H, T, 5, seed=13, count0=count0, pick=[1, 130, 254], donate=True)
     assert int(hidden[3].min()) == N
+
+
+def test_learned_rollout_entry_time_parallel_full_size():
+    """DenseGCM.rollout with LearnedEdge at cfg5's per-GPU size (B = 256, N = 128, F = H = 32, T = 64 from
+    hidden = None): the two-launch time-parallel forward (k_learned_roll_select, k_learned_roll_l2) and the chain's
+    time-parallel backward over its records - against the oracle's per-step loop on a 3-graph slice with the same
+    injected gumbel draws: sampled adjacency bit exact, beliefs 1e-5, every gradient inside the float64 bound."""
+    B, N, F, H, T = 256, 128, 32, 32, 64
+    hidden, mem = _run_both(B, N, F, H, T, 5, seed=17, count0=None, pick=[2, 101, 255], must_bound=True, rollout=True)
+    assert int(hidden[3].min()) == T and int(hidden[3].max()) == T
+    assert float(hidden[1].sum()) > B * T
 
 
 @pytest.mark.parametrize("donate", [True, False])
