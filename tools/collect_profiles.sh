@@ -4,7 +4,7 @@
 # Kernel-trace statistics and PMC passes are separate runs (a --pmc pass never carries other trace
 # domains); everything lands under gpurun_out/<tag>/ and is copied into profiles/ afterwards.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift || true
 PARTS=${*:-bench stats pmc}
 OUT=$PWD/gpurun_out/$TAG
@@ -37,7 +37,8 @@ for part in $PARTS; do
       stats bench_cfg4 bench.py --config cfg4 --no-cpu-baseline
       stats bench_cfg5 bench.py --config cfg5 --no-cpu-baseline
       stats euclid_full tools/prof_euclid_full.py
-      stats sparse_learned tools/prof_sparse_learned.py ;;
+      stats sparse_learned tools/prof_sparse_learned.py
+      stats layered tools/prof_layered.py ;;
     pmc)
       pmc FETCH_SIZE tools/pmc_run.py
       pmc WRITE_SIZE tools/pmc_run.py

@@ -4,7 +4,8 @@ T shortened where the kernel's traffic does not depend on it.  Run once per coun
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py
 then tools/pmc_summarise.py writes profiles/<tag>_traffic_detail.json and profiles/traffic.json.
-  cfg2: 2 eager per-step rollouts fwd+bwd donated with cached steps (k_step_rows_cached, k_bptt_rows<..,3>), 2 without
+  cfg2: 2 eager per-step rollouts fwd+bwd donated with cached steps (k_step_rows_cached, k_bptt_rows<..,3>) + one of
+        T = 256 (k_step_rows_cached_roll), 2 without
         (k_step_rows<32,..,false>, k_bptt_rows), 2 functional
         (k_step_rows<32,..,true>), 2 rollout-API calls, 2 with observation gradients donated (k_rows_dx_all), T=128
   cfg3: 1 rollout donated, T=128 (k_euclid_mfma, k_step_rows<64,...>)
@@ -24,11 +25,17 @@ dev = torch.device("cuda", 0)
 if "cfg2" in which:
     c = bench.CONFIGS["cfg2"]
     obs = torch.rand(128, c["B"], c["F"]).to(dev)
+    obs256 = torch.rand(256, c["B"], c["F"]).to(dev)
+    from gcm.gcm import DenseGCM
+    DenseGCM.did_warn = True
     for donate, cached in ((True, True), (True, False), (False, False)):
         mem, gnn, _ = bench.build_memory(dev, donate=donate)
         mem.rows_cached_steps = cached      # (True: k_step_rows_cached, what the bench's timed region runs)
         for _ in range(2):
             bench.rollout(mem, obs)
+            gnn.zero_grad(set_to_none=True)
+        if donate and cached:               # T = 2N: the steady-state cached step (k_step_rows_cached_roll)
+            bench.rollout(mem, obs256)
             gnn.zero_grad(set_to_none=True)
         if not donate:
             for _ in range(2):
@@ -49,6 +56,8 @@ for name, T in (("cfg3", 128), ("cfg5", 64)):
         obs = torch.rand(T, c["B"], c["F"]).to(dev)
         mem, gnn, sel = bench.build_memory(dev, donate=True, selector=c["selector"], cfg=c)
         bench.rollout(mem, obs)
+        if name == "cfg5":                  # the time-batched entry: k_learned_roll_select / k_learned_roll_l2
+            bench.rollout_api(mem, obs)
         torch.cuda.synchronize()
 if "cfg4" in which:
     from gcm import nn as G
