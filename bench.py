@@ -196,6 +196,13 @@ def short_kernel_name(name):
     return name[5:] if name.startswith("void ") else name
 
 
+def external_profiler_attached():
+    """rocprofv3 preloads its tool library into the process; kineto's own roctracer session then reports garbage
+    durations (both trace the same dispatches) - the in-process profile is skipped and the line says so."""
+    return ("rocprofiler-sdk-tool" in os.environ.get("LD_PRELOAD", "")
+            or bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or bool(os.environ.get("ROCPROFILER_LIBRARY_CTOR")))
+
+
 def profile_kernels(fn, reps=3):
     """Per-kernel durations of `reps` calls of `fn`, measured LIVE in this process by torch.profiler's device
     activity tracing (kineto over roctracer: each kernel's begin / end timestamps on the stream it was launched on -
@@ -397,10 +404,9 @@ def time_step_kernel(mem, obs, c, reps=10):
     return step_ev, step_graph, bptt_ms, reps * T, step_ev_cached
 
 
-def time_euclid_kernel(c, iters=50):
-    """k_euclid_mfma alone (gcm_edge_distance_pre through the C ABI) on FULL graphs (every row a
-    candidate: 2*B*B*N*F flops per launch): `iters` back-to-back launches under the
-    in-process kernel profiler -> profile_kernels() result."""
+def euclid_launcher(c):
+    """-> a closure launching k_euclid_mfma alone (gcm_edge_distance_pre through the C ABI) on FULL graphs (every row a
+    candidate: 2*B*B*N*F flops per launch)"""
     import torch
     from gcm import _hip
     lib, p, st = _hip.lib(), _hip.ptr, _hip.stream()
@@ -418,6 +424,14 @@ def time_euclid_kernel(c, iters=50):
         rc = lib.gcm_edge_distance_pre(p(nodes), p(count), p(obs), p(row), _hip.DIST_EUCLID_CROSSBATCH, 2.0, None,
                                        0, 0, 0, 0, p(ws), ws_bytes, B, N, F, st)
         assert rc == 0
+    launch.keep = (nodes, count, obs, ws, row)
+    return launch
+
+
+def time_euclid_kernel(c, iters=50):
+    """`iters` back-to-back launches of the kernel alone on full graphs under the in-process kernel profiler
+    -> profile_kernels() result."""
+    launch = euclid_launcher(c)
 
     def burst():
         for _ in range(iters):
@@ -650,6 +664,16 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     flags = mem._flag_word(device)
     bits = int(flags.item())
     assert not (bits & 6), f"kernels flagged {bits}"
+    if external_profiler_attached():
+        # under rocprofv3 the run is the timed region alone: its kernel-trace statistics are then those of the
+        # headline's kernels (profiles/<tag>_bench_<cfg>_kernel_stats.csv), to be read against the unprofiled line
+        if rank == 0:
+            line.update({"value": world * B * T * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                         "config": {"workload": c["text"] + ", T=%d" % T},
+                         "profiled_by": "an external profiler (rocprofv3): the timed region only; kernel durations are "
+                                        "in its own kernel-trace statistics, not measured in process"})
+            print(json.dumps(line))
+        return
 
     # ---- the same work along the other paths (reported beside `value`) ---------------------------
     side = max(3, min(20, args.steps // 10))
@@ -1003,6 +1027,15 @@ def bench_sparse(args, c, line, rank, world, device, timed, weight, traffic):
 
     dt = timed(oneshot, args.steps, args.warmup)
     blocks = [dt] + [timed(oneshot, args.steps, 0) for _ in range(max(0, args.repeats))]
+    if external_profiler_attached():      # (see bench_dense)
+        if rank == 0:
+            line.update({"metric": "belief-states/sec (BxT) SparseGCM fwd+bwd, graph_size=512 F=32 (cfg4)",
+                         "value": world * B * N * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                         "config": {"workload": c["text"]},
+                         "profiled_by": "an external profiler (rocprofv3): the timed region only; kernel durations are "
+                                        "in its own kernel-trace statistics, not measured in process"})
+            print(json.dumps(line))
+        return
     one = torch.ones(B, dtype=torch.long, device=device)
     n_sw = N      # stepwise taus=1 x 512
 

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the MI355X box (run from the repo root through gpurun):
-#   bash tools/collect_profiles.sh r03 [part ...]      parts: bench stats pmc   (default: all)
+#   bash tools/collect_profiles.sh r04 [part ...]      parts: bench stats stats_tools pmc   (default: all)
 # Kernel-trace statistics and PMC passes are separate runs (a --pmc pass never carries other trace
 # domains); everything lands under gpurun_out/<tag>/ and is copied into profiles/ afterwards.
 set -e -o pipefail
 TAG=${1:-r04}
 shift || true
-PARTS=${*:-bench stats pmc}
+PARTS=${*:-bench stats stats_tools pmc}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -31,11 +31,12 @@ for part in $PARTS; do
         echo "bench $cfg done"
       done ;;
     stats)   # --kernel-trace --stats of the same command (cfg4: the one-shot headline leg alone, and both legs)
+      # (under rocprofv3 bench.py runs its timed region alone - the profiler's kernel statistics are the headline's)
       stats bench_cfg2 bench.py --config cfg2 --no-cpu-baseline
       stats bench_cfg3 bench.py --config cfg3 --no-cpu-baseline
-      stats bench_cfg4_oneshot bench.py --config cfg4 --no-cpu-baseline --headline-only
       stats bench_cfg4 bench.py --config cfg4 --no-cpu-baseline
-      stats bench_cfg5 bench.py --config cfg5 --no-cpu-baseline
+      stats bench_cfg5 bench.py --config cfg5 --no-cpu-baseline ;;
+    stats_tools)
       stats euclid_full tools/prof_euclid_full.py
       stats sparse_learned tools/prof_sparse_learned.py
       stats layered tools/prof_layered.py ;;

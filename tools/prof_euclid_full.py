@@ -10,6 +10,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "graph-conv-memory_amd"))
 import bench  # noqa: E402
 
-for _ in range(4):
-    ms = bench.time_euclid_kernel(bench.CONFIGS["cfg3"])
-print("k_euclid_mfma2 on full graphs: %.2f us per launch (HIP events, 50 back to back)" % (ms * 1e3))
+import torch  # noqa: E402
+
+launch = bench.euclid_launcher(bench.CONFIGS["cfg3"])
+for _ in range(200):
+    launch()
+torch.cuda.synchronize()
+print("k_euclid_mfma2 on full graphs: 200 back-to-back launches done")
