@@ -758,6 +758,31 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                 torch.cuda.synchronize()
         mem_f.check_flags()
 
+    # ---- the layered path (a user GNN the fused step does not cover: three DenseGraphConv layers; pooled=True):
+    # the general DenseGraphConv kernels, one launch per layer and direction -------------------------
+    layered = None
+    if c["selector"] == "temporal" and not args.headline_only and rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import prof_layered
+            layered = {}
+            for kind in ("three_layer", "pooled"):
+                lp, lT, _ = prof_layered.run(kind, T=16, reps=2, device=device)
+                fw, bw = find_kernel(lp, "k_layer_fwd<", "k_graphconv_fwd<"), find_kernel(lp, "k_layer_bwd<", "k_graphconv_bwd")
+                tot = sum(d_["us_per_call"] for d_ in lp.values())
+                # per layer, training mode: adj once, x / agg / out once each
+                lbytes = B * 4 * (N * N + N * F + N * F + N * H)
+                ent = {"gpu_us_per_step": round(tot / lT, 2), "belief_states_per_s_gpu_time": B / (tot / lT * 1e-6)}
+                if fw:
+                    ent["layer_fwd"] = {"kernel": fw[0], "avg_us": round(fw[1]["avg_us"], 3), "bytes_per_launch": lbytes,
+                                        "GB/s": lbytes / (fw[1]["avg_us"] * 1e-6) / 1e9,
+                                        "frac_of_hbm_peak": lbytes / (fw[1]["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS}
+                if bw:
+                    ent["layer_bwd"] = {"kernel": bw[0], "avg_us": round(bw[1]["avg_us"], 3)}
+                layered[kind] = ent
+        except Exception as e:      # (reported, not fatal)
+            layered = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+
     # ---- the steady-state regime ("also T=256"): after t >= graph_size every step drops every graph's
     # oldest node (gcm.py:263-271, 323-355) - the normal regime of a long RL rollout --------------------------------
     if c["selector"] == "temporal" and T <= N and not args.headline_only:
@@ -988,6 +1013,12 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         "kernel_ms": kernel_ms,
         "kernel_table": {"rows": table, "gpu_us_per_step": round(gpu_us, 2), "source": src},
     })
+    if layered is not None:
+        line["layered_path"] = dict(layered, note="the same shapes through GNNs the fused step does not cover (three "
+                                                  "DenseGraphConv layers; the canonical two with pooled=True): one "
+                                                  "DenseGraphConv kernel per layer and direction (csrc/fused_layer.hip), "
+                                                  "per-step loop fwd + bwd, T = 16; layer_fwd priced on adj + x + agg + out "
+                                                  "once each per layer (unfused AI = 16 FLOP/B: HBM-bound)")
     if name != "cfg2":
         line["metric"] = "belief-states/sec (BxT) DenseGCM fwd+bwd, graph_size=128 (%s)" % name
     info = {"world_size_seen": world, "device": torch.cuda.get_device_name(device), "torch": torch.__version__}

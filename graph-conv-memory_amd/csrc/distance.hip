@@ -381,6 +381,8 @@ struct StepTail {
   size_t o_v, o_hdr, o_coef, o_live, total;   // total = 0: mx only
   uint32_t* flags;
   int act1, act2, H1, H2;
+  int cur_host;             // >= 0: the row every graph's new node lands in, known to the host (a chain from empty
+                            // graphs: the number of steps made so far) - nothing waits for the count; -1: read it
 };
 
 // ---------------------------------------------------------------------------
@@ -405,8 +407,10 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   const int b = blockIdx.y, j0 = blockIdx.x * RB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int ct = wave & 3, rb = wave >> 2;   // 16 waves: SIMD = column tile, its four waves = the row blocks
-  int sh;
-  const int cur = view_cur(vw, b, N, sh);
+  int sh = 0;
+  int cur;
+  if (TAIL && tl.cur_host >= 0) cur = tl.cur_host < N ? tl.cur_host : N - 1;   // (uniform; no load behind it)
+  else cur = view_cur(vw, b, N, sh);
   const int nb = dist_out ? RB / 32 : max(0, min(RB / 32, (cur - j0 + 31) / 32));   // live 32-row blocks
   extern __shared__ float smem[];
   float* sN = smem;                   // [RB][NS]      node rows (scaled)
@@ -470,6 +474,9 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const float q = seg_norm(v);
     if ((tid & 7) == 0) dst_n[srow] = q;
   };
+  // (Tried in round 4: both chunks of current rows staged before the one barrier - they fit the two LDS buffers at
+  //  Bc <= 256 - and no barrier per chunk, hoping the four waves of a SIMD would drift apart and overlap one's sqrt
+  //  epilogue with another's MFMA chain: they start in lockstep and stay there, and the longer staging cost 1 us.)
   DSTAMP(0);
   {
     // the first chunk of current rows (its addresses do not depend on this graph's fill level: in flight while
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const int H1 = tl.H1, H2 = tl.H2;
     const unsigned gb = (unsigned)b;
     const int fl = lane < F ? lane : F - 1, hl = lane & 31, kh = lane >> 5;
-    const int64_t n64 = vw.count[b];
+    const int64_t n64 = tl.cur_host >= 0 ? (int64_t)tl.cur_host : vw.count[b];
     const bool bad = n64 < 0 || n64 >= N;                     // (a chain from empty graphs never rolls)
     unsigned long long m0 = 0, m1 = 0;
     float agg1 = 0.f, agg2 = 0.f, xc = 0.f;
@@ -849,15 +856,17 @@ extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, flo
                                              float max_distance, const float* dist_param, const float* cur_rows,
                                              int n_cur_rows, const float* params, const float* weight_image, int act1,
                                              int act2, float* cache_h1, float* cache_agg1, float* cache_nodes,
-                                             float* saved, const size_t* lay5, int record, uint32_t* flags, int B,
-                                             int N, int F, int H1, int H2, gcm_stream_t stream) {
+                                             float* saved, const size_t* lay5, int record, int cur_host,
+                                             uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                             gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes && adj && count && params && weight_image && cache_h1 && cache_agg1 && cache_nodes &&
               saved && lay5 && flags && B > 0);
   const int Bc = cur_rows ? n_cur_rows : B;
   if (!gcm_edge_distance_step_cached_supported(Bc, B, N, F, H1, H2)) return GCM_EUNSUPPORTED;
   View vw{nodes, nullptr, count, obs, cur_rows, n_cur_rows};
   StepTail tl{params, weight_image, nodes, adj, count, cache_h1, cache_agg1, cache_nodes, saved,
-              lay5[1], lay5[2], lay5[3], lay5[4], record ? lay5[0] : 0, flags, act1, act2, H1, H2};
+              lay5[1], lay5[2], lay5[3], lay5[4], record ? lay5[0] : 0, flags, act1, act2, H1, H2,
+              cur_host >= 0 ? cur_host : -1};
   constexpr int RB = 128;
   const int FT = F / 32;
   const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +

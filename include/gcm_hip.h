@@ -644,7 +644,9 @@ int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, float* adj, in
 /* EuclideanEdge (distance.py:41-49, not bidirectional) as the ONLY selector of such a chain: the distance kernel and
  * the cached step as one launch (the step is the tail of the matrix-core distance kernel's first wave) -
  * gcm_dense_rows_step_cached_ws takes this path by itself when the shapes allow (>= 32 current rows, F in {32, 64},
- * N <= 128, H1, H2 <= 32); GCM_EUNSUPPORTED otherwise.  lay5: gcm_dense_rows_cached_layout. */
+ * N <= 128, H1, H2 <= 32); GCM_EUNSUPPORTED otherwise.  lay5: gcm_dense_rows_cached_layout.  cur_host >= 0: the row
+ * every graph's new node lands in, when the host knows it (a chain from empty graphs: its step count) - the node rows
+ * are then fetched without waiting for the count; -1: read it. */
 /* The cached step in the STEADY STATE of such a chain (t_abs >= N steps made: every graph is full and every step
  * drops the oldest node, gcm.py:263-271, 323-355), selectors = forward temporal hops only, N > 2 max(hop).  There
  * the band adjacency is a fixed point of the overflow roll (the step leaves adj and count untouched - the values
@@ -670,8 +672,8 @@ int gcm_dense_rows_cached_launches(const gcm_selector_desc* selectors, int n_sel
 int gcm_edge_distance_step_cached(const float* obs, float* nodes, float* adj, int64_t* count, float max_distance,
                                   const float* dist_param, const float* cur_rows, int n_cur_rows, const float* params,
                                   const float* weight_image, int act1, int act2, float* cache_h1, float* cache_agg1,
-                                  float* cache_nodes, float* saved, const size_t* lay5, int record, uint32_t* flags,
-                                  int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+                                  float* cache_nodes, float* saved, const size_t* lay5, int record, int cur_host,
+                                  uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 /* SparseGCM in stepwise use (sparse_gcm.py:72-212 called with x [B, 1, F], taus in {0, 1}) with a TemporalEdge selector
  * (sparse_edge_selectors/temporal.py:18-63; hops_host: HOST array, every hop >= 1), in a chain from empty graphs: the
  * new node's belief from the chain's caches (the layer-1 row of a node is final once written: its edges point at
