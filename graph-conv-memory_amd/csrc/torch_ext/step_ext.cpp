@@ -1478,6 +1478,100 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// DenseGCM.rollout from EMPTY graphs with forward temporal hops as the only selectors, observations without gradient:
+// the time-parallel forward (csrc/rollout_tp.hip: two launches for all T steps) and ONE autograd node whose backward
+// is gcm_dense_rows_bptt_cached over the T records and the caches [B, Tc, .] (N := Tc).
+// ---------------------------------------------------------------------------------------------
+struct RowsRolloutNode : public torch::autograd::Node {
+  at::Tensor packed, records, cH, cA, cX;
+  c10::VariableVersion vc;
+  uint32_t version = 0;
+  int64_t T = 0, B = 0, Tc = 0, stride = 0;
+  int F = 0, H1 = 0, H2 = 0, has_bias = 0, act1 = 0, act2 = 0;
+  bool released = false;
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(1);
+    TORCH_CHECK(!released, "Trying to backward through a DenseGCM.rollout a second time (its records were freed); "
+                           "pass retain_graph=True to the first call");
+    if (!grads[0].defined()) return out;
+    TORCH_CHECK(vc.current_version() == version,
+                "one of the variables needed for gradient computation has been modified by an inplace operation: "
+                "the belief states returned by DenseGCM.rollout");
+    at::Tensor g = grads[0].scalar_type() == at::kFloat ? grads[0] : grads[0].to(at::kFloat);
+    std::vector<const float*> sv(T), gm(T);
+    for (int64_t t = 0; t < T; ++t) {
+      sv[t] = records.data_ptr<float>() + t * stride;
+      gm[t] = g.data_ptr<float>() + t * g.stride(0);
+    }
+    const gcm_stream_t stream =
+        reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(packed.get_device()).stream());
+    const size_t ws_bytes = gcm_dense_rows_bptt_workspace_bytes((int)T, (int)B, F, H1, H2);
+    at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
+    const int64_t P = (int64_t)gcm_dense_gnn2_param_count(F, H1, H2);
+    at::Tensor res = packed.numel() > P ? at::zeros({packed.numel()}, packed.options()) : at::empty({P}, packed.options());
+    check(gcm_dense_rows_bptt_cached(sv.data(), gm.data(), (int)T, (long)g.stride(1), (long)g.stride(2),
+                                     packed.data_ptr<float>(), has_bias, act1, act2, cX.data_ptr<float>(),
+                                     cH.data_ptr<float>(), cA.data_ptr<float>(), nullptr, res.data_ptr<float>(),
+                                     ws.data_ptr(), ws_bytes, (int)B, (int)Tc, F, H1, H2, stream),
+          "gcm_dense_rows_bptt_cached");
+    out[0] = res;
+    return out;
+  }
+  void release_variables() override {
+    records.reset(); cH.reset(); cA.reset(); cX.reset();
+    released = true;
+  }
+  std::string name() const override { return "GcmRowsRollout"; }
+};
+
+// -> (mx_all [T,B,H2], nodes [B,N,F], adj [B,N,N], count [B]) or None when the configuration has no such form
+pybind11::object rows_rollout_tp(int64_t cfg_handle, const at::Tensor& packed, const at::Tensor& obs_,
+                                 const at::Tensor& flags) {
+  StepCfg* cfg = reinterpret_cast<StepCfg*>(cfg_handle);
+  TORCH_CHECK(cfg != nullptr && obs_.is_cuda() && packed.is_cuda() && flags.is_cuda(),
+              "rows_rollout_tp: every tensor must live on a HIP device (no CPU fallback)");
+  at::Tensor obs = obs_.contiguous();
+  const int64_t T = obs.size(0), B = obs.size(1);
+  const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+  TORCH_CHECK(obs.dim() == 3 && obs.size(2) == F && obs.scalar_type() == at::kFloat && packed.is_contiguous() && T >= 1);
+  if (T > 65535 || !gcm_dense_rollout_tp_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                                   (int)cfg->descs.size(), cfg->has_bias, (int)T, N, F, H1, H2))
+    return pybind11::none();
+  const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad();
+  const int64_t Tc = T;
+  size_t lay[5];
+  check(gcm_dense_rows_cached_layout((int)B, (int)Tc, F, H1, H2, lay), "gcm_dense_rows_cached_layout");
+  const int64_t stride = need_bwd ? (int64_t)lay[0] : pad64(B * H2);
+  at::Tensor records = at::empty({T * stride}, obs.options());
+  at::Tensor nodes = T < N ? at::zeros({B, N, F}, obs.options()) : at::empty({B, N, F}, obs.options());
+  at::Tensor adj = at::zeros({B, N, N}, obs.options());
+  at::Tensor count = at::empty({B}, obs.options().dtype(at::kLong));
+  at::Tensor cH = at::empty({B, Tc, H1}, obs.options()), cA = at::empty({B, Tc, F}, obs.options()),
+             cX = at::empty({B, Tc, F}, obs.options());
+  at::Tensor mx_all = at::empty({T, B, H2}, obs.options());
+  const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(obs.get_device()).stream());
+  check(gcm_dense_rollout_tp_fwd(obs.data_ptr<float>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                 (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
+                                 nodes.data_ptr<float>(), adj.data_ptr<float>(), count.data_ptr<int64_t>(),
+                                 cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
+                                 records.data_ptr<float>(), (size_t)stride, need_bwd ? 1 : 0, mx_all.data_ptr<float>(),
+                                 reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)T, (int)B, N, (int)Tc, F, H1, H2, st),
+        "gcm_dense_rollout_tp_fwd");
+  if (need_bwd) {
+    auto node = std::shared_ptr<RowsRolloutNode>(new RowsRolloutNode(), torch::autograd::deleteNode);
+    node->packed = packed.detach();
+    node->records = records; node->cH = cH; node->cA = cA; node->cX = cX;
+    node->T = T; node->B = B; node->Tc = Tc; node->stride = stride;
+    node->F = F; node->H1 = H1; node->H2 = H2; node->has_bias = cfg->has_bias; node->act1 = cfg->act1; node->act2 = cfg->act2;
+    node->vc = mx_all.unsafeGetTensorImpl()->version_counter();
+    node->version = node->vc.current_version();
+    node->set_next_edges(torch::autograd::collect_next_edges(packed));
+    torch::autograd::create_gradient_edge(mx_all, node);
+  }
+  return pybind11::make_tuple(mx_all, nodes, adj, count);
+}
+
+// ---------------------------------------------------------------------------------------------
 // DenseGCM.rollout with LearnedEdge from EMPTY graphs, T <= N steps, observations without gradient: the whole
 // forward in two launches (gcm_learned_rollout_fwd: every (graph, step) a workgroup - the selection depends on raw
 // observations and the given gumbel draws only), ONE autograd node whose backward is the chain's time-parallel one
@@ -2277,6 +2371,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("steps", &LearnedChain::steps);
   m.def("learned_step2", &learned_step2);
   m.def("learned_rollout", &learned_rollout);
+  m.def("rows_rollout_tp", &rows_rollout_tp);
   pybind11::class_<SparseChain>(m, "SparseChain")
       .def(pybind11::init<>())
       .def("steps", [](SparseChain& c) { return c.steps; })

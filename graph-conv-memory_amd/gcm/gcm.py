@@ -142,6 +142,9 @@ class DenseGCM(torch.nn.Module):
         # False: a cached EuclideanEdge chain as TWO launches per step (distance kernel, then the cached step) instead
         # of one (csrc/distance.hip: k_euclid_mfma2<.., TAIL>) - A/B tests; read when a chain is armed
         self.rows_one_launch_distance = True
+        # False: rollout() from empty graphs with forward temporal hops runs the persistent per-graph kernel of round 1
+        # instead of the two-launch time-parallel forward (csrc/rollout_tp.hip) - A/B tests
+        self.rollout_time_parallel = True
         # Steps whose observations / nodes need a gradient run on the live-row kernels too.  True: the whole
         # chain's dL/dx in ONE launch by the chain's single autograd node (hardware float atomics: the order of
         # summation, i.e. the last bits, is not fixed; a policy that feeds belief t-1 into observation t switches
@@ -731,6 +734,25 @@ class DenseGCM(torch.nn.Module):
                     and self.learned_cached_steps and obs.shape[0] <= self.graph_size
                     and not (torch.is_grad_enabled() and obs.requires_grad)):
                 return self._rollout_learned(obs, cfg)
+            # forward temporal hops only, from empty graphs, observations without gradient: no recurrence at all - the
+            # whole forward as two launches over every (step, graph) (csrc/rollout_tp.hip), one autograd node
+            if (cfg is not None and cfg.learned_sel is None and cfg.fold is None and cfg.rows_ok
+                    and self.rollout_time_parallel
+                    and not (torch.is_grad_enabled() and obs.requires_grad)):
+                ext = _ops._ext.module()
+                if ext is not None and hasattr(ext, "rows_rollout_tp") and cfg.cpp_handle():
+                    flags = self._flag_word(obs.device)
+                    r = ext.rows_rollout_tp(cfg.cpp_handle(), self._packed_params(cfg, head=True), obs, flags)
+                    if r is not None:
+                        mx, nodes, adj, count = r
+                        if self.finite_check == "sync":
+                            self.check_flags()
+                        elif self.finite_check == "deferred" and not torch.cuda.is_current_stream_capturing():
+                            self.check_flags(block=False)
+                            self._enqueue_flag_copy(flags)
+                        if obs.shape[0] > self.graph_size and self.finite_check != "off":
+                            flags.bitwise_or_(_hip.FLAG_WRAPPED)     # gcm.py:264-266: the one-time overflow notice
+                        return mx, (nodes, adj, torch.zeros(0, device=obs.device), count)
         if fresh:
             hidden = self.get_initial_hidden_state(obs[0])
         nodes, adj, weights, num_nodes = hidden

@@ -855,6 +855,23 @@ int gcm_dense_rollout_bwd(const float* g_mx_all, const float* g_nodes_T, const f
  * of ONE chain of hidden states in order; gmx_host[t] == NULL: zero gradient.  params / g_params: GNN
  * (gcm_dense_gnn2_param_count) | edge network (gcm_learned_mlp_param_count), g_params = g_params_prev
  * (NULL = 0) + gradient. */
+/* ---- time-parallel DenseGCM rollout (round 4) -------------------------------------------------------------
+ * DenseGCM.rollout(obs [T,B,F]) from EMPTY graphs, selectors = forward temporal hops only (temporal.py:72-88),
+ * observations without gradient, canonical two-layer GNN: no recurrence at all (node t is observation t, the band
+ * adjacency is closed form and a fixed point of the overflow roll), so the whole forward is TWO launches - layer 1 of
+ * every (step, graph) on the matrix cores into the caches [B, Tc, .] (Tc >= T rows per graph: cache_h1 [B,Tc,H1],
+ * cache_agg1 / cache_nodes [B,Tc,F]) plus the final state (nodes [B,N,F]: zero on entry when T < N; adj [B,N,N]: ZERO on
+ * entry; count [B]), then layer 2 -> mx_all [T,B,H2] and the T step records (gcm_dense_rows_cached_layout(B, Tc, ...)
+ * - N := Tc -, rec_stride floats apart; record = 0: mx only) that gcm_dense_rows_bptt_cached(..., N := Tc) reads.
+ * T > N needs N > 2 max(hop) (a live row must not have lost a source to the roll); F, H1 in {32, 64}, H2 <= 64. */
+int gcm_dense_rollout_tp_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int T, int N,
+                                   int F, int H1, int H2);
+int gcm_dense_rollout_tp_fwd(const float* obs, const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                             int has_bias, int act1, int act2, float* nodes, float* adj, int64_t* count,
+                             float* cache_h1, float* cache_agg1, float* cache_nodes, float* records, size_t rec_stride,
+                             int record, float* mx_all, uint32_t* flags, int T, int B, int N, int Tc, int F, int H1,
+                             int H2, gcm_stream_t stream);
+
 /* DenseGCM.rollout with LearnedEdge: the whole forward of T <= N steps from EMPTY graphs, observations without
  * gradient, in TWO launches - the selection of step t (learned.py:53-113) depends on raw observations and the given
  * gumbel draws only, so every (graph, step) is a workgroup of one launch (edge network, gumbel-softmax, threshold,

@@ -499,3 +499,32 @@ def test_cfg3_timed_path_one_launch_from_empty_graphs_full_batch_oracle():
         g64, atol = bounds[k]
         err = float((p.grad.cpu().double() - g64).abs().max())
         assert err <= atol, (k, err, atol, float(g64.abs().max()))
+
+
+@pytest.mark.parametrize("T", [128, 200])
+def test_cfg2_rollout_time_parallel_slice_matches_oracle(T):
+    """DenseGCM.rollout at cfg2's full size from hidden = None, observations WITHOUT gradient: the two-launch
+    time-parallel forward (csrc/rollout_tp.hip: forward temporal hops have no recurrence) and the time-parallel backward
+    over its records; T = 200 spends 72 steps in the steady state (every step drops every graph's oldest node).
+    Beliefs, final state and parameter gradients against the oracle's per-step loop on a 3-graph slice (float64
+    bound); closed forms of the state; and equality with the per-step loop of this library."""
+    from gcm.edge_selectors.temporal import TemporalBackedge
+    mem, g, ref = _dense_pair(F2, H2, N2, TemporalBackedge(HOPS))
+    pick = [0, 117, 255]
+    obs, w = _cfg2_rows_case(T, pick, seed=8)
+    obs_d = obs.to(DEV)
+    out, hid = mem.rollout(obs_d)
+    assert out.grad_fn is not None and out.grad_fn.name() == "GcmRowsRollout"     # the new path ran
+    (out[:, pick] * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    _check_against_slice_oracle(out, hid, g, ref, obs, w, pick, N2, lambda: od.TemporalBackedge(HOPS))
+    nodes, adj, _, count = hid
+    assert torch.equal(count.cpu(), torch.full((B2,), min(T, N2)))
+    assert torch.equal(nodes, obs_d[T - min(T, N2):].transpose(0, 1))
+    assert torch.equal(adj, _band(N2, HOPS, min(T, N2)).to(DEV).expand(B2, N2, N2))
+    with torch.no_grad():
+        out_s, hid_s = _loop(mem, obs_d)
+        out_i, _ = mem.rollout(obs_d)               # inference: no records
+    torch.testing.assert_close(out.detach(), out_s, rtol=1e-5, atol=1e-6)
+    assert torch.equal(out_i, out.detach())
+    assert torch.equal(hid_s[0], nodes) and torch.equal(hid_s[1], adj) and torch.equal(hid_s[3], count)

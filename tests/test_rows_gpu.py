@@ -837,3 +837,31 @@ def test_rows_donated_state_reset_in_place_mid_chain(sel, F):
     for (k, pc), (_, pd) in zip(ref.named_parameters(), g.named_parameters()):
         scale = float(pc.grad.abs().max()) + 1e-12
         torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=2e-5 * scale, msg=k)
+
+
+@pytest.mark.parametrize("hops,B,N,F,H1,H2,T", [([1, 2, 4], 37, 16, 32, 32, 32, 40), ([0, 1, 3], 5, 64, 64, 64, 16, 131),
+                                                ([2, 5], 64, 12, 32, 64, 64, 11), ([1], 33, 32, 64, 32, 8, 70),
+                                                ([3, 7], 4, 12, 32, 32, 32, 40)])
+def test_rollout_time_parallel_vs_oracle(hops, B, N, F, H1, H2, T):
+    """rollout() from hidden = None with forward temporal hops (csrc/rollout_tp.hip) against the oracle's per-step loop:
+    ragged batch sizes (partial 32-graph tiles), F / H1 in {32, 64}, narrow H2, a self loop (hop 0), T below and beyond
+    the graph size; state bit exact, beliefs and parameter gradients inside the float64 bound.  N <= 2 max(hop) with
+    T > N has no time-parallel form (a live row loses a source to the roll): the persistent kernel runs."""
+    torch.manual_seed(N + T)
+    ref, g, mem, osel = _mk(B, N, F, H1, H2, ("temporal", hops, "forward"), False)
+    obs = torch.rand(T, B, F)
+    w = torch.rand(T, B, H2)
+    out, hid = mem.rollout(obs.to(DEV))
+    cfg = mem._cfg_last[3] if mem._cfg_last else None      # (shapes the fused plan does not take: the layered loop)
+    tp = cfg is not None and cfg.rows_ok and not (T > N and N <= 2 * max(hops))
+    assert (out.grad_fn.name() == "GcmRowsRollout") == tp
+    assert tp or hops == [3, 7]
+    (out * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    out32, hid32, bounds, (out64, out_atol) = _fp64_rollout_bounds(ref, obs, None, w, lambda: osel, N)
+    assert torch.equal(hid[0].cpu(), hid32[0]) and torch.equal(hid[1].cpu(), hid32[1])
+    assert torch.equal(hid[3].cpu(), hid32[3])
+    assert float((out.detach().cpu().double() - out64).abs().max()) <= out_atol
+    for k, p in g.named_parameters():
+        g64, atol = bounds[k]
+        assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
