@@ -74,11 +74,11 @@ def test_graphconv_kernel(B, N, Fi, Fo, act):
     g = torch.randn_like(yc)
     yc.backward(g)
     yd.backward(g.to(DEV))
-    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(ad.grad.cpu(), ac.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-5, atol=1e-5 * float(xc.grad.abs().max()) + 1e-9)
+    torch.testing.assert_close(ad.grad.cpu(), ac.grad, rtol=1e-5, atol=1e-5 * float(ac.grad.abs().max()) + 1e-9)
     for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
         scale = float(pc.grad.abs().max()) + 1e-6
-        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-5, atol=1e-5 * scale + 1e-5, msg=k)
 
 
 def test_graphconv_identity_known_answer():
@@ -265,7 +265,7 @@ def test_euclid_matrix_core_path(B, N, F, learned):
     ref_sel = od.EuclideanEdge(thr, dist_param=torch.tensor([thr]) if learned else None)
     d = dev_sel.distances(nodes.to(DEV), nn_.to(DEV)).cpu()
     want = ref_sel.distances(nodes, nn_)
-    torch.testing.assert_close(d, want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(d, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-9)
     # thresholded result, away from the threshold
     adj = torch.zeros(B, N, N, device=DEV)
     got, _ = dev_sel(nodes.to(DEV), adj, torch.zeros(0, device=DEV), nn_.to(DEV), B)
@@ -411,13 +411,13 @@ def test_learned_edge_matches_reference():
     assert torch.equal(hidden[1].detach().cpu(), fx["hT_adj"])       # sampled edges: bit exact
     torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
     gs = float(fx["grad_obs"].abs().max())
-    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-5, atol=1e-5 * gs)
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()), msg=k)
     for k, p in sel.named_parameters():
         want = fx["sel_grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
 
 
 def test_temporal_backedge_learned_matches_reference():
@@ -449,12 +449,12 @@ def test_temporal_backedge_learned_matches_reference():
     assert torch.equal(hidden[0].cpu(), fx["hT_nodes"]) and torch.equal(hidden[3].cpu(), fx["hT_num_nodes"])
     torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
     gs = float(fx["grad_obs"].abs().max())
-    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-5, atol=1e-5 * gs)
     want = fx["sel_grad:window"]
-    torch.testing.assert_close(sel.window.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+    torch.testing.assert_close(sel.window.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()), msg=k)
 
 
 def test_temporal_backedge_learned_variants():
@@ -510,7 +510,7 @@ def test_temporal_backedge_learned_variants():
     torch.stack(got).sum().backward()
     torch.stack(want).sum().backward()
     scale = float(osel.window.grad.abs().max())
-    torch.testing.assert_close(sel.window.grad.cpu(), osel.window.grad, rtol=1e-4, atol=1e-5 * scale + 1e-8)
+    torch.testing.assert_close(sel.window.grad.cpu(), osel.window.grad, rtol=1e-5, atol=1e-5 * scale + 1e-8)
 
 
 def test_learned_edge_default_noise_runs():
@@ -612,11 +612,11 @@ def test_fused_matches_layered_and_rollout(B, N, F, H1, H2, T, sel_kind):
         # dense rows sum ~N terms in a different order; the test GNN ends in a ReLU, whose mask can
         # flip for a pre-activation within that noise of zero
         g_atol = 2e-5 if sel_kind == "dense" else 5e-6
-        torch.testing.assert_close(got[2], want[2], rtol=1e-4, atol=g_atol)
-        torch.testing.assert_close(got_g0, want_g0, rtol=1e-4, atol=g_atol)
+        torch.testing.assert_close(got[2], want[2], rtol=1e-5, atol=g_atol)
+        torch.testing.assert_close(got_g0, want_g0, rtol=1e-5, atol=g_atol)
         for k in want[3]:
             scale = float(want[3][k].abs().max()) + 1e-12
-            torch.testing.assert_close(got[3][k], want[3][k], rtol=1e-4, atol=1e-5 * scale, msg=k)
+            torch.testing.assert_close(got[3][k], want[3][k], rtol=1e-5, atol=1e-5 * scale, msg=k)
 
 
 @pytest.mark.parametrize("N,F,H1,H2,T,sel_kind", [(32, 32, 32, 32, 50, "temporal"), (64, 64, 64, 64, 70, "dense"),
@@ -644,7 +644,7 @@ def test_rollout_params_only_backward(N, F, H1, H2, T, sel_kind):
     torch.testing.assert_close(out.detach(), want[0], rtol=0, atol=0)
     for k, p in g.named_parameters():
         scale = float(want[3][k].abs().max()) + 1e-12
-        torch.testing.assert_close(p.grad, want[3][k], rtol=1e-4, atol=1e-5 * scale, msg=k)
+        torch.testing.assert_close(p.grad, want[3][k], rtol=1e-5, atol=1e-5 * scale, msg=k)
 
 
 def test_rollout_bptt_schedules_agree(monkeypatch):
@@ -749,10 +749,10 @@ def test_posenc_in_step_matches_reference(mode):
     assert torch.equal(hidden[1].cpu(), fx["hT_adj"])
     torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
     gs = float(fx["grad_obs"].abs().max())
-    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-5, atol=1e-5 * gs)
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()), msg=k)
 
 
 @pytest.mark.parametrize("B,N,F,cat", [(5, 12, 10, 4), (3, 130, 64, 8), (2, 7, 3, 1)])
@@ -805,7 +805,7 @@ def test_rows_linear_matches_torch(M, I, O):
     assert torch.equal(p, y)
     if O > 1:
         want_h = torch.nn.functional.layer_norm(torch.relu(want), (O,), gamma.double(), beta.double(), 1e-5)
-        torch.testing.assert_close(h.cpu().double(), want_h, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(h.cpu().double(), want_h, rtol=1e-5, atol=1e-5 * float(want_h.abs().max()) + 1e-9)
     # into a wider matrix (the PositionalEncoding re-projection)
     wide = torch.full((M, O + 3), 7.0, device=DEV)
     _ops.rows_linear(xd, wd, bd, out=wide[:, 3:], ldy=O + 3)

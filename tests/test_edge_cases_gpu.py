@@ -40,7 +40,7 @@ def _compare_rollouts(ref_kw, dev_mem, ref_gnn, obs, h0=None, rtol=1e-5, atol=1e
     torch.testing.assert_close(odv.cpu(), oc, rtol=rtol, atol=atol)
     for a, b in zip(hid_d, hid_c):
         assert torch.equal(a.cpu(), b)
-    torch.testing.assert_close(obs_d.grad.cpu(), obs_c.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(obs_d.grad.cpu(), obs_c.grad, rtol=1e-5, atol=1e-5 * float(obs_c.grad.abs().max()) + 1e-9)
 
 
 @pytest.mark.parametrize("B,N,F,H,T", [(1, 1, 1, 1, 3), (1, 2, 3, 2, 5), (2, 129, 8, 8, 4), (3, 200, 70, 40, 3),
@@ -212,7 +212,7 @@ def test_cpp_node_matches_python_node(monkeypatch):
     for a, b in zip(res[0][3], res[1][3]):
         # C++ node: per-graph slabs accumulate over the steps, one sum at the gate; Python node:
         # one slab sum per step, the engine adds the T results - same terms, different order
-        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
 
 
 def test_parameter_gradient_chain_survives_detach_and_restarts():
@@ -230,7 +230,7 @@ def test_parameter_gradient_chain_survives_detach_and_restarts():
     o2, _ = mem.rollout(obs[10:], tuple(h.detach() for h in h1))
     (o1.sum() + o2.sum()).backward()
     for a, p in zip(got, g.parameters()):
-        torch.testing.assert_close(a, p.grad, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-5 * float(p.grad.abs().max()) + 1e-9)
     # (b) two independent sequences, one backward
     g.zero_grad(set_to_none=True)
     oa, _ = _loop(mem, obs[:8])
@@ -242,7 +242,7 @@ def test_parameter_gradient_chain_survives_detach_and_restarts():
     rb, _ = mem.rollout(obs[8:20])
     (ra.sum() + rb.sum()).backward()
     for a, p in zip(got, g.parameters()):
-        torch.testing.assert_close(a, p.grad, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-5 * float(p.grad.abs().max()) + 1e-9)
     # (c) a parameter update in the middle of a kept hidden state: the next step must see the new
     # parameters (the chain restarts from the re-packed vector)
     g.zero_grad(set_to_none=True)
@@ -279,9 +279,9 @@ def test_skinny_linear_matches_nn_linear(M, I, O, bias):
         err_lib = float((lib.detach().double() - want).abs().max())
         assert float((got.detach().double() - want).abs().max()) <= max(3 * err_lib, 2e-6 * float(want.abs().max()))
     scale = float(ref.weight.grad.abs().max())
-    torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-5 * scale)
     if bias:
-        torch.testing.assert_close(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
+        torch.testing.assert_close(lin.bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-5 * float(ref.bias.grad.abs().max()))
     assert set(lin.state_dict()) == set(ref.state_dict())
 
 
@@ -304,7 +304,7 @@ def test_parameter_gate_under_partial_and_repeated_backward():
     ref_out, _ = mem.rollout(obs[:9])
     ref = torch.autograd.grad((ref_out ** 2).sum(), params)
     for a, b in zip(first, ref):
-        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()))
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize("M,F", [(32768, 32), (5000, 17), (2500, 64), (1, 32), (300, 33)])
@@ -325,9 +325,9 @@ def test_relu_layernorm_matches_torch(M, F):
     gy = torch.randn(M, F, device=DEV)
     ya.backward(gy)
     yb.backward(gy)
-    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(ga.grad, ln.weight.grad, rtol=1e-4, atol=1e-5 * float(ln.weight.grad.abs().max()) + 1e-6)
-    torch.testing.assert_close(ba.grad, ln.bias.grad, rtol=1e-4, atol=1e-5 * float(ln.bias.grad.abs().max()) + 1e-6)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5 * float(xb.grad.abs().max()) + 1e-9)
+    torch.testing.assert_close(ga.grad, ln.weight.grad, rtol=1e-5, atol=1e-5 * float(ln.weight.grad.abs().max()) + 1e-6)
+    torch.testing.assert_close(ba.grad, ln.bias.grad, rtol=1e-5, atol=1e-5 * float(ln.bias.grad.abs().max()) + 1e-6)
 
 
 def test_default_edge_network_path_matches_module():
@@ -348,9 +348,9 @@ def test_default_edge_network_path_matches_module():
     yb = net(xb)
     yb.square().sum().backward()
     torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5 * float(xb.grad.abs().max()))
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5 * float(xb.grad.abs().max()))
     for a, p in zip(got, net.parameters()):
-        torch.testing.assert_close(a, p.grad, rtol=1e-4, atol=1e-5 * float(p.grad.abs().max()))
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-5 * float(p.grad.abs().max()))
     custom = torch.nn.Sequential(torch.nn.Linear(64, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).to(DEV)
     assert _ops.default_edge_network(custom) is None
     assert _ops.edge_network_forward(custom, x).shape == (64, 128, 1)
@@ -485,7 +485,7 @@ def test_rollout_entry_equals_single_steps_every_selector(kind, start):
         got_g = [p.grad for m in mods2 for p in m.parameters()]
         scale = max(float(x.abs().max()) for x in want_g)
         for a, b_ in zip(got_g, want_g):
-            torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-6 * scale)
+            torch.testing.assert_close(a, b_, rtol=1e-5, atol=2e-6 * scale)
 
 
 def test_sparse_rollout_entry_is_one_call():

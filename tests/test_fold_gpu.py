@@ -77,12 +77,12 @@ def _check(fx, mxs, hidden, g, pre, tag):
         torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL, msg=lambda s: f"{tag}: {s}")
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()),
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()),
                                    msg=lambda s, k=k: f"{tag} {k}: {s}")
     if pre is not None:
         for k, p in pre.named_parameters():
             want = fx["sel_grad:pre." + k]
-            torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()),
+            torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()),
                                        msg=lambda s, k=k: f"{tag} pre.{k}: {s}")
 
 
@@ -127,7 +127,7 @@ def test_folded_rollout_and_dx_dispatch(name):
     mxs.mean().backward()
     _check(fx, mxs.detach(), hidden, g, pre, f"{name} layered")
     gs = float(fx["grad_obs"].abs().max())
-    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-5, atol=1e-5 * gs)
 
 
 @pytest.mark.parametrize("kind", ["pre", "pe_add"])
@@ -171,4 +171,4 @@ def test_folded_step_full_size_vs_layered(kind):
     assert torch.equal(res[0][1][0], res[1][1][0]) and torch.equal(res[0][1][1], res[1][1][1])
     for k in res[1][2]:
         scale = float(res[1][2][k].abs().max()) + 1e-12
-        torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-4, atol=2e-5 * scale, msg=k)
+        torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-5, atol=2e-5 * scale, msg=k)

@@ -117,11 +117,11 @@ def test_cfg2_slice_matches_oracle(entry):
     torch.testing.assert_close(out[:, pick].detach().cpu(), out_c.detach(), rtol=1e-5, atol=1e-6)
     assert torch.equal(hid[1][pick].cpu(), hid_c[1]) and torch.equal(hid[0][pick].cpu(), hid_c[0])
     gs = float(obs_c.grad.abs().max())
-    torch.testing.assert_close(obs_d.grad[:, pick].cpu(), obs_c.grad, rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs_d.grad[:, pick].cpu(), obs_c.grad, rtol=1e-5, atol=1e-5 * gs)
     rest = [b for b in range(B2) if b not in pick]
     assert float(obs_d.grad[:, rest].abs().max()) == 0.0          # no cross-graph leakage
     for (k, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
-        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()), msg=k)
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-5, atol=1e-5 * float(q.grad.abs().max()), msg=k)
 
 
 def test_cfg2_backward_is_linear_in_the_incoming_gradient():
@@ -140,7 +140,7 @@ def test_cfg2_backward_is_linear_in_the_incoming_gradient():
     ga, gb, gc = grads(g1), grads(g2), grads(2.0 * g1 - 0.5 * g2)
     for a, b_, c in zip(ga, gb, gc):
         want = 2.0 * a - 0.5 * b_
-        torch.testing.assert_close(c, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7)
+        torch.testing.assert_close(c, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-7)
 
 
 def test_cfg3_euclid_full_batch_matches_oracle():
@@ -162,7 +162,7 @@ def test_cfg3_euclid_full_batch_matches_oracle():
     assert float(hid_c[1].sum()) > 0
     torch.testing.assert_close(out.detach().cpu(), out_c.detach(), rtol=1e-5, atol=1e-6)
     gs = float(obs_c.grad.abs().max())
-    torch.testing.assert_close(obs_d.grad.cpu(), obs_c.grad, rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs_d.grad.cpu(), obs_c.grad, rtol=1e-5, atol=1e-5 * gs)
 
 
 def test_cfg3_euclid_full_batch_prefilled_state():
@@ -239,9 +239,9 @@ def test_cfg4_sparse_full_size_one_shot():
     (out_c * w).sum().backward()
     torch.testing.assert_close(out[pick].detach().cpu(), out_c.detach(), rtol=1e-5, atol=1e-5)
     gs = float(x_c.grad.abs().max())
-    torch.testing.assert_close(x_d.grad[pick].cpu(), x_c.grad, rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(x_d.grad[pick].cpu(), x_c.grad, rtol=1e-5, atol=1e-5 * gs)
     for (k, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
-        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-5, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
     # one call == two half calls
     with torch.no_grad():
         half = torch.full((B,), N // 2, dtype=torch.long, device=DEV)

@@ -52,10 +52,10 @@ def test_learned_fused_matches_reference_vectors():
     torch.testing.assert_close(mxs.cpu(), fx["mx"], rtol=RTOL, atol=ATOL)
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()), msg=k)
     for k, p in sel.named_parameters():
         want = fx["sel_grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
 
 
 def _pair(F, H, N, k, seed, donate=False):
@@ -324,5 +324,5 @@ def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k, donate):
         _check_learned_grads(grads, g32, g64, same_edges)
     for k_ in res[0][2]:       # cached against not cached: the same arithmetic up to summation order
         a, b = res[0][2][k_], res[1][2][k_]   # (gradients that are zero analytically: the floor from the common scale)
-        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) +
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()) +
                                    (2e-6 * scale if k_.startswith("net.") else 0.0), msg=k_)

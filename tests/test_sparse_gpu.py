@@ -54,12 +54,12 @@ def test_csr_graphconv_kernel(M, E, Fi, Fo, act, weighted):
     g = torch.randn_like(yc)
     yc.backward(g)
     yd.backward(g.to(DEV))
-    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-5, atol=1e-5 * float(xc.grad.abs().max()) + 1e-9)
     if weighted and E:
-        torch.testing.assert_close(wd.grad.cpu(), wc.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(wd.grad.cpu(), wc.grad, rtol=1e-5, atol=1e-5 * float(wc.grad.abs().max()) + 1e-9)
     for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
         scale = float(pc.grad.abs().max()) + 1e-6
-        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-5, atol=1e-5 * scale + 1e-5, msg=k)
 
 
 def test_csr_graphconv_constant_edge_weights():
@@ -80,10 +80,10 @@ def test_csr_graphconv_constant_edge_weights():
     g = torch.randn_like(yc)
     yc.backward(g)
     yd.backward(g.to(DEV))
-    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-5, atol=1e-5 * float(xc.grad.abs().max()) + 1e-9)
     for (k, pc), (_, pd) in zip(ref.named_parameters(), dev.named_parameters()):
         scale = float(pc.grad.abs().max()) + 1e-6
-        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5, msg=k)
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-5, atol=1e-5 * scale + 1e-5, msg=k)
 
 
 def test_temporal_edge_matches_oracle():
@@ -188,10 +188,10 @@ def test_sparse_rollout_matches_reference(name):
     assert torch.equal(hidden[1].coalesce().values().cpu(), fx["hT_adj_values"])
     assert torch.equal(hidden[2].cpu(), fx["hT_T"])
     gs = float(fx["grad_obs"].abs().max())
-    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-5, atol=1e-5 * gs)
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=k)
 
 
 def test_dense_equals_sparse():
@@ -383,7 +383,7 @@ def test_sparse_gumbel_softmax_dims_and_hard_vs_oracle(dim, hard):
     w = torch.randn(want.values().numel())
     (want.values() * w).sum().backward()
     (got.values() * w.to(DEV)).sum().backward()
-    torch.testing.assert_close(vd.grad.cpu(), vc.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(vd.grad.cpu(), vc.grad, rtol=1e-5, atol=1e-5 * float(vc.grad.abs().max()) + 1e-9)
 
 
 @pytest.mark.parametrize("name", ["g12_sparse_learned", "g12_sparse_learned_win3"])
@@ -424,13 +424,13 @@ def test_sparse_learned_edge_matches_reference(name):
     assert torch.equal(hidden[1].coalesce().indices().cpu(), fx["hT_adj_indices"])   # sampled edges: bit exact
     assert torch.equal(hidden[0].cpu(), fx["hT_nodes"]) and torch.equal(hidden[2].cpu(), fx["hT_T"])
     gs = float(fx["grad_obs"].abs().max())
-    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(obs.grad.cpu(), fx["grad_obs"], rtol=1e-5, atol=1e-5 * gs)
     for k, p in g.named_parameters():
         want = fx["grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=k)
     for k, p in sel.named_parameters():
         want = fx["sel_grad:" + k]
-        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-3, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-8, msg=k)
     assert {"edges_per_node", "edge_density", "logits_mean", "logits_var", "temperature"} <= set(sel.stats)
 
 
@@ -503,11 +503,11 @@ def test_sparse_learned_edge_smoke_size_matches_oracle():
     for a, b in zip(outs, oouts):
         torch.testing.assert_close(a.cpu(), b, rtol=1e-5, atol=1e-5)
     gs = float(oo.grad.abs().max())
-    torch.testing.assert_close(od_.grad.cpu(), oo.grad, rtol=1e-4, atol=1e-5 * gs)
+    torch.testing.assert_close(od_.grad.cpu(), oo.grad, rtol=1e-5, atol=1e-5 * gs)
     for (k, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
-        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-4, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-5, atol=1e-5 * float(q.grad.abs().max()) + 1e-7, msg=k)
     for (k, p), (_, q) in zip(sel.edge_network.named_parameters(), net.named_parameters()):
-        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-5 * float(q.grad.abs().max()) + 1e-8, msg=k)
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-5, atol=1e-5 * float(q.grad.abs().max()) + 1e-8, msg=k)
 
 
 # --------------------------------------------------------------------------
@@ -622,7 +622,7 @@ def test_sparse_stepwise_cached_chain_ends_and_restarts():
     first = {k: p.grad.clone() for k, p in g.named_parameters()}
     torch.testing.assert_close(torch.stack(outs).detach().cpu(), out32, rtol=1e-5, atol=1e-5)
     for k, p in g.named_parameters():
-        torch.testing.assert_close(p.grad.cpu(), g32[k], rtol=1e-4, atol=1e-5 * float(g32[k].abs().max()), msg=k)
+        torch.testing.assert_close(p.grad.cpu(), g32[k], rtol=1e-5, atol=1e-5 * float(g32[k].abs().max()), msg=k)
     loss.backward()                                     # a second pass over the same records: gradients add up
     for k, p in g.named_parameters():
         torch.testing.assert_close(p.grad, 2 * first[k], rtol=1e-5, atol=1e-6, msg=k)
