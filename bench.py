@@ -946,15 +946,21 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         Fe = F
         sel_exec = B * (2 * (2 * N * Fe * Fe) + 2 * Fe * Fe + 2 * N * Fe + 2 * (2 * F * H) + 2 * (2 * H * H))
         sel_ref = B * (2 * N * (3 * Fe * Fe + Fe))           # learned.py:38-51 on N candidate pairs, forward
-        bpb_exec = B * T * (8 * (2 * N * Fe * Fe))           # per chain launch: eight N x F x F products per graph-step
+        # pass B2 works per 32-row block with a candidate row: step t of a rollout from empty graphs has t candidates
+        live_blocks = sum((min(t, N - 1) + 31) // 32 for t in range(T))
+        bpb_exec = B * live_blocks * (8 * (2 * 32 * Fe * Fe))   # eight 32 x F x F products per live block
         kinds = [("k_learned_select", ("k_learned_select<",), sel_exec, sel_ref,
                   "selection + GNN tail (cached step); flops: two N x F x F products, the W0a x[cur] and F -> 1 "
                   "layers, four matrix-vector products of the GNN tail; LayerNorm / softmax VALU work not counted; "
                   "flops_reference_formulation = 2 N (3F^2 + F) per graph (the reference's 2F-wide first layer on "
                   "every candidate pair)"),
-                 ("k_learned_bptt_b", ("k_learned_bptt_b",), bpb_exec, None,
-                  "pass B: per graph-step the edge network recomputed and differentiated - eight N x F x F "
-                  "products on the fp32 MFMA (LayerNorm passes not counted); one persistent launch per chain"),
+                 ("k_learned_bptt_mlp", ("k_learned_bptt_mlp",), bpb_exec, None,
+                  "pass B2: the edge network recomputed and differentiated per 32-row block that holds a candidate row "
+                  "(one block per wave, eight 32 x F x F products on the fp32 MFMA each; LayerNorm passes not "
+                  "counted); one persistent launch per chain"),
+                 ("k_learned_bptt_sel", ("k_learned_bptt_sel",), None, None,
+                  "pass B1: per graph-step the gradient collected over the later steps that hold the node, selection "
+                  "and softmax adjoint -> g_logit [T,B,N]"),
                  ("k_bptt_rows_learned", ("k_bptt_rows<",), None, None,
                   "pass A: GNN parameter gradient over the live rows of every graph-step")]
         rows = []

@@ -1253,34 +1253,193 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
   if ((tid & 1) == 0) { mu_out[row] = mean; rs_out[row] = rstd; }
 }
 
-__global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float* __restrict__ mlp, float eps0,
-                                                        float eps1, float* __restrict__ slabs, int B, int N,
-                                                        int F, int H1) {
+// ---------------------------------------------------------------------------------------------
+// Pass B in TWO kernels (round 4).  Round 3's single kernel (one 256-thread workgroup per item, two per CU, all
+// 128 rows of the item's images through every phase) was bound by VALU issue, not by latency - in-kernel stamps:
+// ~46 k cycles per item, the two workgroups of a CU filling each other's gaps, 3 - 5 k cycles per LayerNorm /
+// column-sum / staging phase - and three quarters of that went to rows >= cur (a rollout of T <= N steps from
+// empty graphs has cur < 64 on every item).  Measured at cfg5: 712 us -> 238 + 54 us per 64-step chain.
+//   B1 (k_learned_bptt_sel): one 128-thread workgroup per item - D_t from the <= min(N, T - t) later items only,
+//      selection adjoint, softmax adjoint -> g_logit [T, B, N];
+//   B2 (k_learned_bptt_mlp): the edge network recomputed and differentiated per 32-ROW BLOCK, one block per WAVE
+//      (no workgroup barrier inside the loop; each wave owns four 32 x 32 images), blocks with no candidate row
+//      skipped: the work is proportional to the candidate rows.  One 8-wave workgroup per CU, weight-gradient
+//      tiles in the MFMA accumulators across all blocks of a wave, one slab per workgroup.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// row p[0 .. n) -> out[32], zero padded (16-byte loads when the row is a whole number of them)
+__device__ __forceinline__ void load_row32(const float* __restrict__ p, int n, float* out) {
+  if ((n & 3) == 0 && (reinterpret_cast<size_t>(p) & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = 4 * q < n ? reinterpret_cast<const float4*>(p)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+      const float v = p[f < n ? f : n - 1];
+      out[f] = f < n ? v : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __restrict__ g_logit, int B, int N,
+                                                          int F, int H1) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int s = blockIdx.x / B, b = blockIdx.x - s * B, sg = a.s0 + s;
+  const size_t it = (size_t)sg * B + b;
+  const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * it]);
+  if (cur <= 0) return;   // no candidate rows (pass B2 skips the item too)
+  __shared__ float sP[NP * FS];        // dAgg1 contributions of the later steps, then their running sums
+  __shared__ float sD2[32], sCs[4 * 32], sSel[NP];
+  __shared__ int sSlot[NP], sWc[NP], sFirst[NP + 2];
+  const float* base = a.tab.saved[s];
+  const float* xg = (a.c_nodes ? a.c_nodes : base) + (size_t)b * N * F;
+  const float* hg = (a.c_h1 ? a.c_h1 : base + a.o_h1) + (size_t)b * N * H1;
+  const int n_fut = a.T - sg < NP ? a.T - sg : NP;   // later steps (this one included) that can hold the node
+  float xr[32], hr[32];                // this thread's candidate row
+  {
+    const int j = tid < cur ? tid : cur - 1;
+    load_row32(xg + (size_t)j * F, F, xr);
+    load_row32(hg + (size_t)j * H1, H1, hr);
+  }
+  constexpr int NONE = 1 << 30;
+  {   // where does the node inserted at this step sit in the live list of step t + tid?
+    int slot = -1, w = NONE;
+    if (tid < n_fut) {
+      const size_t it2 = it + (size_t)tid * B;
+      int e[8];
+      __builtin_memcpy(e, a.live + it2 * N, sizeof(e));
+      const int cur2 = a.hdr[2 * it2], L2 = a.hdr[2 * it2 + 1];
+      asm volatile("" ::: "memory");
+      const int r = cur2 - tid;
+      w = cur + tid - cur2;
+      if (r >= 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) slot = (l < L2 && e[l] == r) ? l : slot;
+        for (int l = 8; l < L2; ++l)
+          if (a.live[it2 * N + l] == r) slot = l;
+      }
+    }
+    sSlot[tid] = slot;
+    sWc[tid] = w;
+    sFirst[tid] = NONE;
+    if (tid < 2) sFirst[NP + tid] = NONE;
+  }
+  if (tid < 32) sD2[tid] = tid < H1 ? a.dagg2[it * H1 + tid] : 0.f;
+  __syncthreads();
+  {
+    const int w = sWc[tid];
+    if (w != NONE) {
+      if (tid == 0 || sWc[tid - 1] < w) sFirst[w < NP ? w : NP] = tid;
+      if (tid == NP - 1 || sWc[tid + 1] == NONE) sFirst[NP + 1] = tid;
+    }
+  }
+  {   // gather: thread (column f, row group q) takes rows q, q + 4, ... of the steps in range, 8 loads in flight
+    const int f = tid & 31, q = tid >> 5;
+#pragma unroll 1
+    for (int r0 = 0; r0 < n_fut; r0 += 32) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r0 + q + 4 * i, rc = r < n_fut ? r : n_fut - 1;
+        const int slot = sSlot[rc];
+        v[i] = a.da[((it + (size_t)rc * B) * N + (slot >= 0 ? slot : 0)) * F + (f < F ? f : F - 1)];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r0 + q + 4 * i;
+        sP[r * FS + f] = (r < n_fut && sSlot[r] >= 0 && f < F) ? v[i] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  {   // running sums over the later steps in time order: 4 segments of 32 steps, then the segments
+    const int cf = tid & 31, cg = tid >> 5;
+    const bool on = 32 * cg < n_fut;
+    float v[32], run = 0.f;
+    if (on) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) v[r] = sP[(32 * cg + r) * FS + cf];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) { run += v[r]; v[r] = run; }
+    }
+    sCs[cg * 32 + cf] = run;
+    __syncthreads();
+    float off = 0.f;
+    for (int q = 0; q < cg; ++q) off += sCs[q * 32 + cf];
+    if (on) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) sP[(32 * cg + r) * FS + cf] = v[r] + off;
+    }
+  }
+  __syncthreads();
+  {   // g_sel[j] = dagg2 . h1[j] + D^(j) . x[j]
+    float t = 0.f;
+    if (tid < cur) {
+      const int fj = sFirst[tid + 1 < NP ? tid + 1 : NP];
+      const int istar = fj != NONE ? fj - 1 : sFirst[NP + 1];
+      const float* dv = sP + istar * FS;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        t1 = fmaf(sD2[k], hr[k], t1);
+        t2 = fmaf(dv[k], xr[k], t2);
+      }
+      t = t1 + t2;
+    }
+    sSel[tid] = t;
+  }
+  __syncthreads();
+  if (tid < 64) {   // softmax adjoint (tau = 1); both straight-through estimators are identities
+    const float* soft = base + a.o_soft + (size_t)b * N;
+    float p[2], g[2], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      const bool live = j < cur;
+      p[c] = live ? soft[j < N ? j : N - 1] : 0.f;
+      g[c] = live ? sSel[j] : 0.f;
+      dot = fmaf(p[c], g[c], dot);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      if (j < N) g_logit[it * N + j] = p[c] * (g[c] - dot);
+    }
+  }
+}
+
+constexpr int MLP_WAVES = 8;
+constexpr int MLP_WSZ = 33 * FS + 3 * 32 * FS + 5 * 32 + 3;   // floats per wave: X (+ x_cur row) | P0 | H0 | P1 | 5 vectors
+constexpr size_t lds_bptt_mlp() {
+  return sizeof(float) * (3 * FP * FS + 7 * FP + 2 * MLP_WAVES * 32 + MLP_WAVES * MLP_WSZ);
+}
+
+__global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, const float* __restrict__ g_logit,
+                                                                     const float* __restrict__ mlp, float eps0,
+                                                                     float eps1, float* __restrict__ slabs, int B,
+                                                                     int N, int F) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int cf = tid & 31, cg = tid >> 5;   // column-sum mapping: column cf, row group cg (rows cg, cg + 8, ...)
+  const int cf = lane & 31, cg = lane >> 5;   // column sums: column cf, rows cg, cg + 2, ... of the block
   const Mlp M = unpack_mlp(mlp, F);
   extern __shared__ float smem[];
-  float* sX_ = smem;                   // node image [NP][FS]; H0 in the middle of an item
-  float* sP0_ = sX_ + NP * FS;         // scan scratch, then P0 -> gP0
-  float* sP1_ = sP0_ + NP * FS;        // h1 image, then P1 -> gP1 -> gH0
-  float* sW0b = sP1_ + NP * FS;         // [o][f] = W0[o][F + f]
+  float* sW0b = smem;                  // [o][f] = W0[o][F + f]
   float* sW0a = sW0b + FP * FS;        // [o][f] = W0[o][f]
-  float* sW1 = sW0a + FP * FS;         // [o][f]
-  float* sVec = sW1 + FP * FS;         // b0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
-  float* sMu0 = sVec + 7 * FP;
-  float* sRs0 = sMu0 + NP;
-  float* sMu1 = sRs0 + NP;
-  float* sRs1 = sMu1 + NP;
-  float* sSel = sRs1 + NP;             // g_sel [NP]
-  float* sGl = sSel + NP;              // g_logit [NP]
-  float* sD = sGl + NP;                // D_t [32] | dagg2_t [32]
-  float* sCs = sD + 64;                // [8][32] partial sums
-  int* sSlot = reinterpret_cast<int*>(sCs + 256);   // [NP] slot of this node in the live list of step t + i
-  int* sWc = sSlot + NP;               // [NP] rolls between step t and step t + i (non-decreasing)
-  int* sFirst = sWc + NP;              // [NP + 2] first i with sWc[i] >= w;  [NP + 1]: last step of the chain
-
-  {   // weights: once per workgroup
+  float* sW1 = sW0a + FP * FS;
+  float* sVec = sW1 + FP * FS;         // b0 | b1 | g0 | be0 | g1 | be1 | w2
+  float* sCs = sVec + 7 * FP;          // [2 MLP_WAVES][32] partial column sums (epilogue)
+  float* sWave = sCs + 2 * MLP_WAVES * 32;
+  float* sX_ = sWave + wave * MLP_WSZ;  // [33][FS]: the block's node rows, row 32 = x_cur
+  if (tid < 256) {
     gcm_fused::Stage<FP, FP, false, false> st_a, st_b, st_1;
     st_a.load(M.w0, F, F, 2 * F, tid);
     st_b.load(M.w0 + F, F, F, 2 * F, tid);
@@ -1300,180 +1459,86 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
       sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
     }
   }
-  f32x16 aW1, aW0b, aW0a;   // weight-gradient tiles [o = acc_row][f = li], this wave's share of the rows
+  for (int e = lane; e < MLP_WSZ; e += 64) sX_[e] = 0.f;
+  f32x16 aW1, aW0b, aW0a;   // weight-gradient tiles [o = acc_row][f = li], summed over this wave's blocks
 #pragma unroll
   for (int r = 0; r < 16; ++r) { aW1[r] = 0.f; aW0b[r] = 0.f; aW0a[r] = 0.f; }
   float c_w2 = 0.f, c_g1 = 0.f, c_be1 = 0.f, c_b2 = 0.f, c_b1 = 0.f, c_g0 = 0.f, c_be0 = 0.f, c_b0 = 0.f;
-  // Rows >= cur of an item carry a zero gradient: waves whose 32 rows all lie beyond skip their products
-  // and leave whatever the images held - which must be finite (0 x NaN), hence zeroed once.
-  for (int e = tid; e < 3 * NP * FS; e += 256) sX_[e] = 0.f;
   __syncthreads();
 
-  const int items = a.n_steps * B;
+  const long items = (long)a.n_steps * B;
+  const long units = items * ((N + 31) / 32);   // block-major: the always-live first blocks of all items come first
 #pragma unroll 1
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int s = item / B, b = item - s * B;
-    const int sg = a.s0 + s;
-    const float* base = a.tab.saved[s];
-    int zv = 0, tl = threadIdx.x;
-    // loop-variant copies of the thread index and of the LDS bases: hipcc's LICM otherwise parks the address
-    // arithmetic and predicates of every staging / product phase below (~250 registers) in front of the item
-    // loop, which cost the second workgroup per CU (391 -> 240 registers)
-    asm volatile("" : "+v"(zv), "+v"(tl));
-    const int tid = tl, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5, cf = tid & 31, cg = tid >> 5;
-    float* const sX = sX_ + zv; float* const sP0 = sP0_ + zv; float* const sP1 = sP1_ + zv;
-    const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * ((size_t)sg * B + b)]);
-    if (cur <= 0) continue;   // no candidate rows: nothing was selected, nothing to differentiate (uniform)
-    const float* xg = (a.c_nodes ? a.c_nodes : base) + (size_t)b * N * F;
-    const float* hg = (a.c_h1 ? a.c_h1 : base + a.o_h1) + (size_t)b * N * H1;
-    const bool wave_on = 32 * wave < cur;      // this wave's rows hold candidates
-    const int jn = cur < N ? cur : N;          // rows with a gradient
-    LSTAMP(14);
-    gcm_fused::Stage<NP, FP, false, false> st_x, st_h;
-    st_x.load(xg, N, F, F, tid);
-    st_h.load(hg, N, H1, H1, tid);
-    // ---- D_t: where does the node inserted at this step sit in the live lists of the next <= N steps? ---
-    constexpr int NONE = 1 << 30;
-    if (tid < NP) {
-      const int t2 = sg + tid;
-      int slot = -1, w = NONE;
-      if (t2 < a.T) {
-        const size_t it2 = (size_t)t2 * B + b;
-        // the header and the first 8 entries of the live list in ONE round trip (the list's address does not depend
-        // on the header; a LearnedEdge row has <= 1/cutoff entries)
-        int e[8];   // (dword-aligned: N need not be a multiple of 4)
-        __builtin_memcpy(e, a.live + it2 * N, sizeof(e));
-        const int cur2 = a.hdr[2 * it2], L2 = a.hdr[2 * it2 + 1];
-        asm volatile("" ::: "memory");
-        const int r = cur2 - tid;            // its row at step t2 (one roll per step once the graph is full)
-        w = cur + tid - cur2;                // rolls since this step
-        if (r >= 0) {
-#pragma unroll
-          for (int l = 0; l < 8; ++l) slot = (l < L2 && e[l] == r) ? l : slot;
-          for (int l = 8; l < L2; ++l)
-            if (a.live[it2 * N + l] == r) slot = l;
-        }
-      }
-      sSlot[tid] = slot;
-      sWc[tid] = w;
-    } else {
-      sFirst[tid - NP] = NONE;               // (tid - NP < 128; entries 128 / 129 below)
-      if (tid == NP) sFirst[NP] = NONE;
-    }
-    if (tid < 32) sD[32 + tid] = tid < H1 ? a.dagg2[((size_t)sg * B + b) * H1 + tid] : 0.f;
-    __syncthreads();
-    LSTAMP(15);
-    if (tid < NP) {
-      const int w = sWc[tid];
-      if (w != NONE) {
-        if (tid == 0 || sWc[tid - 1] < w) sFirst[w < NP ? w : NP] = tid;   // (w grows by at most one per step)
-        if (tid == NP - 1 || sWc[tid + 1] == NONE) sFirst[NP + 1] = tid;   // the last step in range
-      }
-    }
+  for (long u = (long)blockIdx.x * MLP_WAVES + wave; u < units; u += (long)gridDim.x * MLP_WAVES) {
+    const int k = (int)(u / items);
+    const long item = u - (long)k * items;
+    const int s = (int)(item / B), b = (int)(item - (long)s * B), sg = a.s0 + s;
+    const size_t it = (size_t)sg * B + b;
+    const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * it]);
+    if (32 * k >= cur) continue;       // no candidate row in this block (wave-uniform)
+    int zv = 0;
+    asm volatile("" : "+v"(zv));        // loop-variant LDS bases: keeps hipcc's LICM from parking every phase's
+                                         // address arithmetic in registers in front of the loop
+    float* const sX = sX_ + zv;
+    float* const sP0 = sX + 33 * FS;
+    float* const sH = sP0 + 32 * FS;
+    float* const sP1 = sH + 32 * FS;
+    float* const sGl = sP1 + 32 * FS;
+    float* const sMu0 = sGl + 32;
+    float* const sRs0 = sMu0 + 32;
+    float* const sMu1 = sRs0 + 32;
+    float* const sRs1 = sMu1 + 32;
+    const float* xg = (a.c_nodes ? a.c_nodes : a.tab.saved[s]) + (size_t)b * N * F;
+    const int j0 = 32 * k;
+    const int jn = cur - j0 < 32 ? cur - j0 : 32;   // candidate rows of the block
     {
-      constexpr int PER = NP * FP / 256;
-      float v[PER];
+      float v[16];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int e = tid + 256 * i, r = e / FP, f = e % FP;
-        const int slot = sSlot[r];
-        const int t2 = sg + r < a.T ? sg + r : a.T - 1;
-        // (load first, mask in the loop below: written as one select the compiler sank every load under its mask's
-        //  branch and waited for it alone - PER = 16 dependent round trips per item)
-        v[i] = a.da[(((size_t)t2 * B + b) * N + (slot >= 0 ? slot : 0)) * F + (f < F ? f : F - 1)];
+      for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, r = e >> 5, c = e & 31;
+        const int j = j0 + r < N ? j0 + r : N - 1;
+        v[i] = xg[(size_t)j * F + (c < F ? c : F - 1)];
       }
+      const float xc = xg[(size_t)cur * F + (li < F ? li : F - 1)];
+      const float glv = g_logit[it * N + (j0 + li < N ? j0 + li : N - 1)];
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int e = tid + 256 * i, r = e / FP, f = e % FP;
-        sP0[r * FS + f] = (sSlot[r] >= 0 && f < F) ? v[i] : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, r = e >> 5, c = e & 31;
+        sX[r * FS + c] = (j0 + r < N && c < F) ? v[i] : 0.f;
+      }
+      if (lh == 0) {
+        sX[32 * FS + li] = li < F ? xc : 0.f;
+        sGl[li] = li < jn ? glv : 0.f;
       }
     }
-    st_x.store(sX, FS, tid);
-    st_h.store(sP1, FS, tid);
-    __syncthreads();
-    LSTAMP(16);
-    // running sums over the later steps, in time order (fixed order: 8 segments of 16 steps, then the
-    // segments): row i of sP0 becomes the sum of the contributions of steps t .. t + i
-    {
-      float run = 0.f;
-      for (int r = 16 * cg; r < 16 * cg + 16; ++r) {
-        run += sP0[r * FS + cf];
-        sP0[r * FS + cf] = run;
-      }
-      sCs[cg * 32 + cf] = run;
-    }
-    __syncthreads();
-    {
-      float off = 0.f;
-      for (int q = 0; q < cg; ++q) off += sCs[q * 32 + cf];
-      if (cg > 0)
-        for (int r = 16 * cg; r < 16 * cg + 16; ++r) sP0[r * FS + cf] += off;
-    }
-    __syncthreads();
-    LSTAMP(17);
-    // ---- g_sel[j] = dagg2 . h1[j] + D^(j) . x[j]   (j < cur): two threads per row ----------------------
-    {
-      const int row = tid >> 1, half = tid & 1;
-      // node j is still there at step t + i as long as fewer than j + 1 rolls happened since
-      const int fj = sFirst[row + 1 < NP ? row + 1 : NP];
-      const int istar = fj != NONE ? fj - 1 : sFirst[NP + 1];
-      const float* vec = half ? sP0 + istar * FS : sD + 32;
-      const float* img = (half ? sX : sP1) + row * FS;
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) t = fmaf(vec[k], img[k], t);
-      t += gcm_lane_xor1(t);
-      if (half == 0) sSel[row] = row < cur ? t : 0.f;
-    }
-    __syncthreads();
-    LSTAMP(18);
-    if (wave == 0) {   // softmax adjoint (tau = 1); both straight-through estimators are identities
-      const float* soft = base + a.o_soft + (size_t)b * N;
-      float p[2], g[2], dot = 0.f;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int j = lane + 64 * c;
-        const bool live = j < cur;
-        p[c] = live ? soft[j < N ? j : N - 1] : 0.f;
-        g[c] = live ? sSel[j] : 0.f;
-        dot = fmaf(p[c], g[c], dot);
-      }
-      dot = wave_sum(dot);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) sGl[lane + 64 * c] = p[c] * (g[c] - dot);
-    }
-    // ---- edge network recomputed: P0 = X W0b^T + (W0a x_cur + b0) ---------------------------------------
-    if (wave_on) {
+    wsync();
+    {   // P0 = X W0b^T + (W0a x_cur + b0)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, li, lh);
-      gcm_fused::mma32b<32>(acc, sX + cur * FS, 0, 1, sW0a, 1, FS, li, lh);     // every row gets W0a x_cur
+      gcm_fused::mma32b<32>(acc, sX, FS, 1, sW0b, 1, FS, li, lh);
+      gcm_fused::mma32b<32>(acc, sX + 32 * FS, 0, 1, sW0a, 1, FS, li, lh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sP0[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
+      for (int r = 0; r < 16; ++r) sP0[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[li];
     }
-    __syncthreads();   // (sP0's scan scratch was consumed two barriers ago)
-    LSTAMP(19);
-    relu_ln_rows_to(sP0, sX, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);   // H0 over the node image
-    __syncthreads();
-    LSTAMP(20);
-    if (wave_on) {
+    wsync();
+    relu_ln_rows_to(sP0, sH, lane, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);
+    wsync();
+    {   // P1 = H0 W1^T + b1
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW1, 1, FS, li, lh);
+      gcm_fused::mma32b<32>(acc, sH, FS, 1, sW1, 1, FS, li, lh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
+      for (int r = 0; r < 16; ++r) sP1[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[FP + li];
     }
-    __syncthreads();
-    LSTAMP(21);
-    relu_ln_rows(sP1, tid, F, nullptr, nullptr, eps1, sMu1, sRs1, /*write=*/false);
-    __syncthreads();
-    LSTAMP(22);
-    {   // dw2, dgamma1, dbeta1, db2: this thread's rows of its column
+    wsync();
+    relu_ln_rows(sP1, lane, F, nullptr, nullptr, eps1, sMu1, sRs1, /*write=*/false);
+    wsync();
+    {   // dw2, dgamma1, dbeta1, db2
       const float w2f = sVec[6 * FP + cf], g1f = sVec[4 * FP + cf], be1f = sVec[5 * FP + cf];
-      for (int j = cg; j < jn; j += 8) {
+      for (int j = cg; j < jn; j += 2) {
         const float gl = sGl[j];
         const float v = sP1[j * FS + cf];
         const float xh = ((v > 0.f ? v : 0.f) - sMu1[j]) * sRs1[j];
@@ -1483,50 +1548,36 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
         if (cf == 0) c_b2 += gl;
       }
     }
-    __syncthreads();
-    LSTAMP(23);
-    relu_ln_rows_bwd(sP1, tid, F, sMu1, sRs1,
+    wsync();
+    relu_ln_rows_bwd(sP1, lane, F, sMu1, sRs1,
                      [&](int j, int f) { return sGl[j] * sVec[6 * FP + f] * sVec[4 * FP + f]; });   // gP1
-    __syncthreads();
-    LSTAMP(24);
-    for (int j = cg; j < jn; j += 8) c_b1 += sP1[j * FS + cf];
-    // dW1 += gP1^T H0 (K = this wave's rows);  gH0 = gP1 W1
-    f32x16 gh;
+    wsync();
+    for (int j = cg; j < jn; j += 2) c_b1 += sP1[j * FS + cf];
+    {   // dW1 += gP1^T H0;  gH0 = gP1 W1 (over P1's place)
+      f32x16 gh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gh[r] = 0.f;
-    if (wave_on) {
-      gcm_fused::mma32b<32>(aW1, sP1 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, li, lh);
-      gcm_fused::mma32b<32>(gh, sP1 + 32 * wave * FS, FS, 1, sW1, FS, 1, li, lh);
-    }
-    st_x.load(xg, N, F, F, tid);   // the node image again (H0 is done with after this phase)
-    __syncthreads();
+      for (int r = 0; r < 16; ++r) gh[r] = 0.f;
+      gcm_fused::mma32b<32>(aW1, sP1, 1, FS, sH, FS, 1, li, lh);
+      gcm_fused::mma32b<32>(gh, sP1, FS, 1, sW1, FS, 1, li, lh);
+      wsync();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sP1[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = gh[r];   // gH0
-    st_x.store(sX, FS, tid);
-    __syncthreads();
-    LSTAMP(25);
-    {   // dgamma0, dbeta0
-      for (int j = cg; j < jn; j += 8) {
-        const float v = sP0[j * FS + cf];
-        const float xh = ((v > 0.f ? v : 0.f) - sMu0[j]) * sRs0[j];
-        const float ghv = sP1[j * FS + cf];
-        c_g0 = fmaf(ghv, xh, c_g0);
-        c_be0 += ghv;
-      }
+      for (int r = 0; r < 16; ++r) sP1[gcm_fused::acc_row(r, lh) * FS + li] = gh[r];
     }
-    __syncthreads();
-    LSTAMP(26);
-    relu_ln_rows_bwd(sP0, tid, F, sMu0, sRs0, [&](int j, int f) { return sP1[j * FS + f] * sVec[2 * FP + f]; });   // gP0
-    __syncthreads();
-    LSTAMP(27);
-    for (int j = cg; j < jn; j += 8) c_b0 += sP0[j * FS + cf];
-    // dW0b += gP0^T X;  dW0a += gP0^T (x_cur in every row)
-    if (wave_on) {
-      gcm_fused::mma32b<32>(aW0b, sP0 + 32 * wave * FS, 1, FS, sX + 32 * wave * FS, FS, 1, li, lh);
-      gcm_fused::mma32b<32>(aW0a, sP0 + 32 * wave * FS, 1, FS, sX + cur * FS, 0, 1, li, lh);
+    wsync();
+    for (int j = cg; j < jn; j += 2) {   // dgamma0, dbeta0
+      const float v = sP0[j * FS + cf];
+      const float xh = ((v > 0.f ? v : 0.f) - sMu0[j]) * sRs0[j];
+      const float ghv = sP1[j * FS + cf];
+      c_g0 = fmaf(ghv, xh, c_g0);
+      c_be0 += ghv;
     }
-    __syncthreads();   // the images are rewritten by the next item
-    LSTAMP(28);
+    wsync();
+    relu_ln_rows_bwd(sP0, lane, F, sMu0, sRs0, [&](int j, int f) { return sP1[j * FS + f] * sVec[2 * FP + f]; });   // gP0
+    wsync();
+    for (int j = cg; j < jn; j += 2) c_b0 += sP0[j * FS + cf];
+    gcm_fused::mma32b<32>(aW0b, sP0, 1, FS, sX, FS, 1, li, lh);
+    gcm_fused::mma32b<32>(aW0a, sP0, 1, FS, sX + 32 * FS, 0, 1, li, lh);
+    wsync();   // the images are rewritten by the wave's next block
   }
 
   // ---- one slab per workgroup (packed edge-network layout), waves and row groups summed in fixed order ---
@@ -1534,14 +1585,20 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
   float* slab = slabs + (size_t)blockIdx.x * Pm;
   const int o_b0 = 2 * F * F, o_g0 = o_b0 + F, o_be0 = o_g0 + F, o_w1 = o_be0 + F, o_b1 = o_w1 + F * F;
   const int o_g1 = o_b1 + F, o_be1 = o_g1 + F, o_w2 = o_be1 + F, o_b2 = o_w2 + F;
-  float* sR = sP0_;   // [4][1024]
+  float* sR = sWave;   // [MLP_WAVES][1024]
+  static_assert(MLP_WSZ >= 1024, "the epilogue's tiles live in the waves' images");
   auto tile_out = [&](const f32x16& acc, int row_stride, int col0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
+    for (int r = 0; r < 16; ++r) sR[wave * MLP_WSZ + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
     __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
+    for (int e = tid; e < 1024; e += 64 * MLP_WAVES) {
       const int o = e >> 5, f = e & 31;
-      if (o < F && f < F) slab[col0 + o * row_stride + f] = (sR[e] + sR[1024 + e]) + (sR[2048 + e] + sR[3072 + e]);
+      if (o < F && f < F) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < MLP_WAVES; ++w) t += sR[w * MLP_WSZ + e];
+        slab[col0 + o * row_stride + f] = t;
+      }
     }
     __syncthreads();
   };
@@ -1550,12 +1607,12 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
   tile_out(aW0b, 2 * F, F);
   tile_out(aW1, F, o_w1);
   auto col_out = [&](float v, int off, int n) {
-    sCs[cg * 32 + cf] = v;
+    sCs[(2 * wave + cg) * 32 + cf] = v;
     __syncthreads();
     if (tid < n) {
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t += sCs[q * 32 + tid];
+      for (int q = 0; q < 2 * MLP_WAVES; ++q) t += sCs[q * 32 + tid];
       slab[off + tid] = t;
     }
     __syncthreads();
@@ -1568,10 +1625,6 @@ __global__ __launch_bounds__(256, 2) void k_learned_bptt_b(BpttB a, const float*
   col_out(c_be1, o_be1, F);
   col_out(c_w2, o_w2, F);
   col_out(c_b2, o_b2, 1);
-}
-
-constexpr size_t lds_bptt_b() {
-  return sizeof(float) * (3 * NP * FS + 3 * FP * FS + 7 * FP + 6 * NP + 64 + 256 + 3 * NP + 2);
 }
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
@@ -1754,7 +1807,7 @@ extern "C" int gcm_learned_step_bwd(const float* g_mx, const float* nodes, const
   return gcm_launch_status();
 }
 
-/* ---- time-parallel backward of a chain of fused LearnedEdge steps (see k_learned_bptt_b) -------------- */
+/* ---- time-parallel backward of a chain of fused LearnedEdge steps (see k_learned_bptt_sel / _mlp) ------ */
 static inline size_t lrn_pad64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int compact, size_t* out8) {
@@ -1780,11 +1833,6 @@ extern "C" int gcm_learned_step_layout(int B, int N, int F, int H1, int H2, int 
   return GCM_OK;
 }
 
-static int lrn_grid_b(int n_steps_launch, int B) {   // persistent: two workgroups per CU
-  const long items = (long)n_steps_launch * B;
-  return (int)(items < 512 ? items : 512);
-}
-
 // pass-A workgroups (= slabs) per launch: what gcm_dense_rows_bptt_slabs gives a full chunk
 static inline int lrn_per_a(int n_steps, int B) {
   return gcm_dense_rows_bptt_slabs(GCM_ROWS_MAX_STEPS < n_steps ? GCM_ROWS_MAX_STEPS : n_steps, B);
@@ -1796,8 +1844,9 @@ extern "C" size_t gcm_learned_bptt_workspace_bytes(int n_steps, int B, int N, in
   // (one launch more than the step count needs: a chain's cached prefix and the steps behind it do not share one)
   const size_t chunks = (n_steps + GCM_ROWS_MAX_STEPS - 1) / GCM_ROWS_MAX_STEPS + 1;
   const size_t TB = (size_t)n_steps * B;
-  size_t fl = lrn_pad64(Pg * (size_t)lrn_per_a(n_steps, B) * chunks) + lrn_pad64(Pm * 512 * chunks) +
-              lrn_pad64(TB * 2) + lrn_pad64(TB * N) + lrn_pad64(TB * N * F) + lrn_pad64(TB * H1);
+  size_t fl = lrn_pad64(Pg * (size_t)lrn_per_a(n_steps, B) * chunks) + lrn_pad64(Pm * 256 * chunks) +
+              lrn_pad64(TB * 2) + lrn_pad64(TB * N) + lrn_pad64(TB * N * F) + lrn_pad64(TB * H1) +
+              lrn_pad64(TB * N);   // ... | g_logit
   return sizeof(float) * fl;
 }
 
@@ -1843,7 +1892,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
   float* ws = (float*)workspace;
   float* slabs_a = ws;
   float* slabs_b = slabs_a + lrn_pad64(Pg * (size_t)total_a);
-  int* hdr = (int*)(slabs_b + lrn_pad64(Pm * 512 * (size_t)chunks));
+  int* hdr = (int*)(slabs_b + lrn_pad64(Pm * 256 * (size_t)chunks));
   int* live = hdr + lrn_pad64(TB * 2);
   float* da = (float*)(live + lrn_pad64(TB * N));
   float* dagg2 = da + lrn_pad64(TB * N * F);
@@ -1872,30 +1921,39 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
                                                  F, H1, H2);
     if (rc) return rc;
   }
-  // pass B
-  constexpr size_t lds = gcm_learned::lds_bptt_b();
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_b, lds);
+  // pass B: B1 (selection + softmax adjoint of every item -> g_logit), then B2 (edge network, per 32-row block)
+  float* g_logit = dagg2 + lrn_pad64(TB * H1);
+  constexpr size_t lds = gcm_learned::lds_bptt_mlp();
+  static_assert(lds <= 160 * 1024, "one 8-wave workgroup per CU");
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp, lds);
   int total_b = 0;
-  for (int c = 0; c < chunks; ++c) {
-    const int s0 = chunk_list[c].first, ns = chunk_list[c].second;
-    const bool cached = s0 < n_cached;
-    const size_t* lay = cached ? lay_c : lay_full;
-    gcm_learned::BpttB a{};
-    for (int i = 0; i < ns; ++i) a.tab.saved[i] = saved_host[s0 + i];
-    a.o_h1 = lay[3];
-    a.o_soft = lay[7];
-    a.c_nodes = cached ? cache_nodes : nullptr;
-    a.c_h1 = cached ? cache_h1 : nullptr;
-    a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
-    a.s0 = s0; a.n_steps = ns; a.T = n_steps;
-    const int grid = lrn_grid_b(ns, B);
-    hipLaunchKernelGGL(gcm_learned::k_learned_bptt_b, dim3(grid), dim3(256), lds, (hipStream_t)stream, a,
-                       params + Pg, eps0, eps1, slabs_b + (size_t)total_b * Pm, B, N, F, H1);
-    const int rc = gcm_launch_status();
-    if (rc) return rc;
-    total_b += grid;
-  }
+  for (int pass = 0; pass < 2; ++pass)
+    for (int c = 0; c < chunks; ++c) {
+      const int s0 = chunk_list[c].first, ns = chunk_list[c].second;
+      const bool cached = s0 < n_cached;
+      const size_t* lay = cached ? lay_c : lay_full;
+      gcm_learned::BpttB a{};
+      for (int i = 0; i < ns; ++i) a.tab.saved[i] = saved_host[s0 + i];
+      a.o_h1 = lay[3];
+      a.o_soft = lay[7];
+      a.c_nodes = cached ? cache_nodes : nullptr;
+      a.c_h1 = cached ? cache_h1 : nullptr;
+      a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
+      a.s0 = s0; a.n_steps = ns; a.T = n_steps;
+      if (pass == 0) {
+        hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel, dim3(ns * B), dim3(128), 0, (hipStream_t)stream, a,
+                           g_logit, B, N, F, H1);
+      } else {
+        const long units8 = ((long)ns * B + gcm_learned::MLP_WAVES - 1) / gcm_learned::MLP_WAVES;
+        const int grid = (int)(units8 < 256 ? units8 : 256);
+        hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp, dim3(grid), dim3(64 * gcm_learned::MLP_WAVES), lds,
+                           (hipStream_t)stream, a, (const float*)g_logit, params + Pg, eps0, eps1,
+                           slabs_b + (size_t)total_b * Pm, B, N, F);
+        total_b += grid;
+      }
+      const int rc = gcm_launch_status();
+      if (rc) return rc;
+    }
   int rc = gcm_sum_slabs_acc(slabs_a, total_a, (int)Pg, g_params_prev, g_params, stream);
   if (rc) return rc;
   return gcm_sum_slabs_acc(slabs_b, total_b, (int)Pm, g_params_prev ? g_params_prev + Pg : nullptr, g_params + Pg,

@@ -224,7 +224,7 @@ def test_learned_cfg5_timed_path_from_empty_graphs_full_size(donate):
     """The kernels bench.py --config cfg5 is timed on, at its per-GPU size, directly against the oracle (VERDICT r3
     #1b): B = 256, N = 128, F = H = 32, a chain from hidden = None - every step a cached step, ONE launch
     (k_learned_select<MODE, TAIL>: selection + the GNN on row cur over the chain's caches), the backward the two
-    time-parallel passes (k_bptt_rows<.., 2>, k_learned_bptt_b) over the caches - T = 32 steps, injected gumbel
+    time-parallel passes (k_bptt_rows<.., 2>, k_learned_bptt_sel, k_learned_bptt_mlp) over the caches - T = 32 steps, injected gumbel
     draws, oracle on a 3-graph slice in float32 and float64.  Sampled adjacency bit exact, beliefs 1e-5, EVERY
     gradient (GNN and edge network) inside the float64 bound - no rtol."""
     B, N, F, H, T = 256, 128, 32, 32, 32

@@ -9,7 +9,7 @@ then tools/pmc_summarise.py writes profiles/<tag>_traffic_detail.json and profil
         (k_step_rows<32,..,false>, k_bptt_rows), 2 functional
         (k_step_rows<32,..,true>), 2 rollout-API calls, 2 with observation gradients donated (k_rows_dx_all), T=128
   cfg3: 1 rollout donated, T=128 (k_euclid_mfma, k_step_rows<64,...>)
-  cfg5: 1 rollout donated, T=64 (k_learned_select, k_gnn2_row_fwd, k_learned_bptt_b, k_bptt_rows mode 2)
+  cfg5: 1 rollout donated, T=64 (k_learned_select, k_gnn2_row_fwd, k_learned_bptt_sel, k_learned_bptt_mlp, k_bptt_rows mode 2)
   cfg4: 1 one-shot call fwd+bwd (k_csr_fwd3, k_csr_bwd3, packing kernels)"""
 import os
 import sys
