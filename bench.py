@@ -703,7 +703,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     variants["eager_functional"] = statistics.median(v)
     variants["eager_functional_min_max"] = [min(v), max(v)]
     # the additive time-batched entry DenseGCM.rollout on the FUNCTIONAL module: temporal / dense
-    # selectors as one C call, LearnedEdge from empty graphs as the two-launch time-parallel forward, everything else
+    # selectors as one C call, LearnedEdge from empty graphs as the three-launch time-parallel forward, everything else
     # as the per-step loop on a state the call owns
     mods_f = [gnn_f] + ([s_ for s_ in [getattr(mem_f, "edge_selectors", None)] if c["selector"] == "learned"])
 

@@ -495,11 +495,13 @@ __global__ __launch_bounds__(256) void k_learned_select(
 // Time-parallel forward of a whole rollout (round 4; DenseGCM.rollout with LearnedEdge from EMPTY graphs, T <= N
 // steps, observations without gradient).  Nothing in the selection of step t depends on another step's RESULT: the
 // edge network scores pairs of raw observations (learned.py:53-87), the gumbel draws are given, and with empty
-// graphs to start from node j is observation j.  So every (graph, step) is one workgroup of ONE launch
-// (k_learned_roll_select: what k_learned_select<2, true> does for its step, with cur = t, the node image from the
-// observation tensor [T, B, F], and layer 1 of the GNN on row cur - h1 / agg1 / x into the chain's caches), and the
-// belief states follow in a second launch once every h1 row exists (k_learned_roll_l2: layer 2 on row cur, one wave
-// per (graph, step)) - two launches instead of T latency-bound ones.  Same arithmetic in the same order as the
+// graphs to start from node j is observation j.  So every (graph, step) is independent work of THREE launches
+// instead of T latency-bound ones: k_learned_roll_logits (the edge network of k_learned_select<2, true> with
+// cur = t and the node image from the observation tensor [T, B, F], per 32-row block with a candidate row),
+// k_learned_roll_pick (softmax, threshold, adjacency / node row, layer 1 of the GNN on row cur - h1 / agg1 / x into
+// the chain's caches), and, once every h1 row exists, k_learned_roll_l2 (layer 2 on row cur -> the belief states),
+// the last two one wave per (graph, step).  (The first version ran launches 1 + 2 as one workgroup per (graph,
+// step) with all 128 rows staged and the weights loaded per item: 303 us at cfg5.)  Same arithmetic in the same order as the
 // cached per-step kernel: same sampled edges, same beliefs.  The records (gcm_learned_step_layout, compact = 2: row
 // cur of the adjacency, soft, cur, agg2, mx), one per step at a fixed stride, and the caches are what
 // gcm_learned_bptt_cached reads.
@@ -509,174 +511,240 @@ struct RollRec {          // the T step records: record t at rec0 + t * stride (
   size_t stride, o_row, o_mx, o_agg2, o_idx, o_soft;
 };
 
-__global__ __launch_bounds__(256) void k_learned_roll_select(
-    const float* __restrict__ obs, const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp,
-    float eps0, float eps1, float cutoff, const float* __restrict__ gnn, int act1, int has_bias, int H1,
-    float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count, RollRec R,
-    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, int B, int T, int N, int F) {
-  const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 31, lh = lane >> 5;
-  const int cur = t;                                   // empty graphs at the start: node j is observation j
-  const Mlp M = unpack_mlp(mlp, F);
-  const float* xcur = obs + ((size_t)t * B + b) * F;
-  float* rec = R.rec0 + (size_t)t * R.stride;
-  extern __shared__ float smem[];
-  float* sX = smem;                 // [NP][FS]
-  float* sA = sX + NP * FS;
-  float* sB = sA + NP * FS;
-  float* sW0b = sB + NP * FS;
-  float* sW1 = sW0b + FP * FS;
-  float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2
-  float* sLogit = sVec + 7 * FP;    // [NP]
-  float* sWg = sLogit + NP;         // [2][FP][FS] W_rel1 | W_root1
+// one wave of work on a 32 x 32 block of an LDS image shared with nobody: LDS writes -> reads of other lanes
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
-  gcm_fused::Stage<FP, FP, false, false> st_w0, st_w1, st_g0, st_g1;
-  st_w0.load(M.w0 + F, F, F, 2 * F, tid);
-  st_w1.load(M.w1, F, F, F, tid);
-  st_g0.load(gnn, H1, F, F, tid);
-  st_g1.load(gnn + (size_t)H1 * F, H1, F, F, tid);
-  float pf_noise[2], pf_b1;
+// Launch 1 of 3: the logits of every candidate row of every (graph, step).  The unit of work is a 32-ROW BLOCK of
+// one item that holds a candidate row (32 k < cur = t), one block per WAVE of a persistent 16-wave workgroup per CU
+// (weights staged once; no workgroup barrier in the loop; blocks without candidates are never touched - a 64-step
+// rollout has 1.5 live blocks per item, not 4).  Per block what k_learned_select does for its rows, in its order:
+// c0 = b0 + W0a x_cur (ascending f), P0 = X W0b^T + c0, ReLU + LayerNorm, P1, ReLU + LayerNorm, the F -> 1 layer.
+// The logits land in the `soft` section of the step's record; k_learned_roll_pick turns them into probabilities.
+constexpr int RL_WAVES = 16;
+constexpr int RL_WSZ = 33 * FS + 32 * FS + 32 + 3;   // floats per wave: X (row 32 = x_cur; later P1) | P0 | c0
+constexpr size_t lds_roll_logits() { return sizeof(float) * (3 * FP * FS + 7 * FP + RL_WAVES * RL_WSZ); }
+
+__global__ __launch_bounds__(64 * RL_WAVES) void k_learned_roll_logits(const float* __restrict__ obs,
+                                                                       const float* __restrict__ mlp, float eps0,
+                                                                       float eps1, RollRec R, int B, int T, int N,
+                                                                       int F) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const Mlp M = unpack_mlp(mlp, F);
+  extern __shared__ float smem[];
+  float* sW0b = smem;                  // [o][f] = W0[o][F + f]
+  float* sW0a = sW0b + FP * FS;        // [o][f] = W0[o][f]
+  float* sW1 = sW0a + FP * FS;
+  float* sVec = sW1 + FP * FS;         // b0 | b1 | g0 | be0 | g1 | be1 | w2
+  float* sX_ = sVec + 7 * FP + wave * RL_WSZ;
+  if (tid < 256) {
+    gcm_fused::Stage<FP, FP, false, false> st_a, st_b, st_1;
+    st_a.load(M.w0, F, F, 2 * F, tid);
+    st_b.load(M.w0 + F, F, F, 2 * F, tid);
+    st_1.load(M.w1, F, F, F, tid);
+    st_a.store(sW0a, FS, tid);
+    st_b.store(sW0b, FS, tid);
+    st_1.store(sW1, FS, tid);
+    if (tid < FP) {
+      const int o = tid < F ? tid : F - 1;
+      const bool ok = tid < F;
+      sVec[tid] = ok ? M.b0[o] : 0.f;
+      sVec[FP + tid] = ok ? M.b1[o] : 0.f;
+      sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
+      sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
+      sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
+      sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
+      sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
+    }
+  }
+  for (int e = lane; e < RL_WSZ; e += 64) sX_[e] = 0.f;
+  const float b2 = M.b2[0];
+  __syncthreads();
+  const long items = (long)T * B;
+  const long units = items * ((N + 31) / 32);   // block-major
+#pragma unroll 1
+  for (long u = (long)blockIdx.x * RL_WAVES + wave; u < units; u += (long)gridDim.x * RL_WAVES) {
+    const int k = (int)(u / items);
+    const long item = u - (long)k * items;
+    const int t = (int)(item / B), b = (int)(item - (long)t * B);
+    const int cur = t;                                   // empty graphs at the start: node j is observation j
+    const int j0 = 32 * k;
+    if (j0 >= cur) continue;                             // no candidate row in this block (wave-uniform)
+    int zv = 0;
+    asm volatile("" : "+v"(zv));
+    float* const sX = sX_ + zv;
+    float* const sA = sX + 33 * FS;
+    float* const sC0 = sA + 32 * FS;
+    {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, r = e >> 5, c = e & 31;
+        const int j = j0 + r <= cur ? j0 + r : cur;
+        v[i] = obs[((size_t)j * B + b) * F + (c < F ? c : F - 1)];
+      }
+      const float xc = obs[((size_t)t * B + b) * F + (li < F ? li : F - 1)];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, r = e >> 5, c = e & 31;
+        sX[r * FS + c] = (j0 + r <= cur && c < F) ? v[i] : 0.f;
+      }
+      if (lh == 0) sX[32 * FS + li] = li < F ? xc : 0.f;
+    }
+    wsync();
+    if (lh == 0) {   // c0[o] = b0[o] + W0a[o, :] . x_cur, ascending f (c0_dot's order)
+      float c0 = sVec[li];
+      const float* w = sW0a + li * FS;
+      const float* x = sX + 32 * FS;
+#pragma unroll
+      for (int f = 0; f < FP; ++f)
+        if (f < F) c0 = fmaf(w[f], x[f], c0);
+      sC0[li] = li < F ? c0 : 0.f;
+    }
+    wsync();
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      gcm_fused::mma32b<32>(acc, sX, FS, 1, sW0b, 1, FS, li, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sC0[li];
+    }
+    wsync();
+    relu_ln_rows(sA, lane, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
+    wsync();
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      gcm_fused::mma32b<32>(acc, sA, FS, 1, sW1, 1, FS, li, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sX[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[FP + li];
+    }
+    wsync();
+    relu_ln_rows(sX, lane, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
+    wsync();
+    if (lh == 0 && j0 + li < cur) {
+      float lg = b2;
+#pragma unroll
+      for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sX[li * FS + f], lg);
+      (R.rec0 + (size_t)t * R.stride + R.o_soft)[(size_t)b * N + j0 + li] = lg;
+    }
+    wsync();   // the images are rewritten by the wave's next block
+  }
+}
+
+// Launch 2 of 3: one wave per (graph, step) - gumbel-softmax over the candidates' logits, threshold, row cur of the
+// adjacency and of the node matrix, and layer 1 of the GNN on row cur (h1 / agg1 / x into the chain's caches).
+__global__ __launch_bounds__(256) void k_learned_roll_pick(
+    const float* __restrict__ obs, const float* __restrict__ noise, int noise_is_exp, float cutoff,
+    const float* __restrict__ gnn, int act1, int has_bias, int H1, float* __restrict__ nodes,
+    float* __restrict__ adj, int64_t* __restrict__ count, RollRec R, float* __restrict__ cH, float* __restrict__ cA,
+    float* __restrict__ cX, int B, int T, int N, int F) {
+  __shared__ float sWg[2 * FP * FS];   // W_rel1 | W_root1, row o at stride FS
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int j = lane + 64 * c < N ? lane + 64 * c : N - 1;
-      pf_noise[c] = noise[((size_t)t * B + b) * N + j];
-    }
-    pf_b1 = gnn[2 * (size_t)H1 * F + (lane < H1 ? lane : H1 - 1)];
-  }
-  {   // the node image: rows j <= cur are observations j of this graph, the rest zero (empty graphs)
-    constexpr int PER = NP * FP / 256;
-    float v[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, r = e / FP, c = e % FP;
-      v[i] = obs[((size_t)(r <= cur ? r : cur) * B + b) * F + (c < F ? c : F - 1)];
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, r = e / FP, c = e % FP;
-      sX[r * FS + c] = (r <= cur && c < F) ? v[i] : 0.f;
-    }
-  }
-  st_w0.store(sW0b, FS, tid);
-  st_w1.store(sW1, FS, tid);
-  st_g0.store(sWg, FS, tid);
-  st_g1.store(sWg + FP * FS, FS, tid);
-  if (tid < FP) {
-    const int o = tid < F ? tid : F - 1;
-    const float c0 = c0_dot(M.w0 + (size_t)o * 2 * F, xcur, M.b0[o], F);
-    const bool ok = tid < F;
-    sVec[tid] = ok ? c0 : 0.f;
-    sVec[FP + tid] = ok ? M.b1[o] : 0.f;
-    sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
-    sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
-    sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
-    sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
-    sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
+    gcm_fused::Stage<FP, FP, false, false> st_g0, st_g1;
+    st_g0.load(gnn, H1, F, F, tid);
+    st_g1.load(gnn + (size_t)H1 * F, H1, F, F, tid);
+    st_g0.store(sWg, FS, tid);
+    st_g1.store(sWg + FP * FS, FS, tid);
   }
   __syncthreads();
-  // (a 32-row block with no candidate row - rows >= cur - is skipped: its logits are never read)
-  const bool live_blk = 32 * wave < cur;
-  if (live_blk) {
-    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= (long)T * B) return;
+  const int t = (int)(item / B), b = (int)(item - (long)t * B);
+  const int cur = t;
+  float* rec = R.rec0 + (size_t)t * R.stride;
+  float* soft = rec + R.o_soft;
+  float* row_out = rec + R.o_row;
+  float pf_noise[2], pf_lg[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
+  for (int c = 0; c < 2; ++c) {
+    const int j = lane + 64 * c < N ? lane + 64 * c : N - 1;
+    pf_noise[c] = noise[((size_t)t * B + b) * N + j];
+    pf_lg[c] = soft[(size_t)b * N + j];   // (written by k_learned_roll_logits for j < cur; masked below)
   }
-  __syncthreads();
-  if (32 * (tid >> 6) < cur) relu_ln_rows(sA, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
-  __syncthreads();
-  if (live_blk) {
-    const f32x16 acc = gemm_rows(sA, sW1, wave, li, lh);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sB[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
+  const float pf_b1 = gnn[2 * (size_t)H1 * F + (lane < H1 ? lane : H1 - 1)];
+  const int fo = lane < F ? lane : F - 1;
+  const float xc_raw = obs[((size_t)t * B + b) * F + fo];
+  asm volatile("" ::: "memory");
+  // the state: the inserted node, the count behind the last step
+  if (lane < F) nodes[((size_t)b * N + cur) * F + lane] = xc_raw;
+  if (lane == 0) {
+    reinterpret_cast<int64_t*>(rec + R.o_idx)[b] = cur;
+    if (t == T - 1) count[b] = T;
   }
-  __syncthreads();
-  if (32 * (tid >> 6) < cur) relu_ln_rows(sB, tid, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
-  __syncthreads();
-  if (tid < NP && tid < cur) {
-    float lg = M.b2[0];
+  // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
+  float z[2], m = -INFINITY;
 #pragma unroll
-    for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sB[tid * FS + f], lg);
-    sLogit[tid] = lg;
+  for (int c = 0; c < 2; ++c) {
+    const int j = lane + 64 * c;
+    float nz = 0.f;
+    if (j < cur) {
+      const float tt = pf_noise[c];
+      nz = noise_is_exp ? -logf(tt) : tt;
+    }
+    z[c] = j < cur ? pf_lg[c] + nz : -INFINITY;
+    m = fmaxf(m, z[c]);
   }
-  __syncthreads();
-  if (wave == 1) {   // the state: the inserted node, the count behind the last step
-    if (lane < F) nodes[((size_t)b * N + cur) * F + lane] = sX[cur * FS + lane];
-    if (lane == 0) {
-      reinterpret_cast<int64_t*>(rec + R.o_idx)[b] = cur;
-      if (t == T - 1) count[b] = T;
+  m = wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    z[c] = (lane + 64 * c < cur) ? expf(z[c] - m) : 0.f;
+    s += z[c];
+  }
+  s = wave_sum(s);
+  const float inv = s > 0.f ? 1.f / s : 0.f;
+  float* row = adj + ((size_t)b * N + cur) * N;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int j = lane + 64 * c;
+    if (j < N) {
+      const float p = z[c] * inv;
+      soft[(size_t)b * N + j] = p;
+      float nv = 0.f;
+      if (j < cur) nv = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12); the incoming row is empty
+      if (j < cur) row[j] = nv;                              // (the rest of the row stays zero)
+      row_out[(size_t)b * N + j] = nv;
+      z[c] = nv;
+    } else {
+      z[c] = 0.f;
     }
   }
-  if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
-    float z[2], m = -INFINITY;
+  // ---- layer 1 of the GNN on row cur: the selected rows S = { j < cur : row[j] = 1 }, ascending -------------
+  unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
+  const int fl_ = lane < FP ? lane : FP - 1;
+  float agg1 = 0.f;
+  while (m0 | m1) {
+    const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+    if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+    agg1 += obs[((size_t)j * B + b) * F + fo];
+  }
+  const float xc = lane < F ? xc_raw : 0.f;
+  agg1 = lane < F ? agg1 : 0.f;
+  const float* wr1 = sWg + fl_ * FS;
+  const float* wt1 = sWg + FP * FS + fl_ * FS;
+  float p1 = (has_bias & 1) && lane < H1 ? pf_b1 : 0.f;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int j = lane + 64 * c;
-      float nz = 0.f;
-      if (j < cur) {
-        const float tt = pf_noise[c];
-        nz = noise_is_exp ? -logf(tt) : tt;
-      }
-      z[c] = j < cur ? sLogit[j] + nz : -INFINITY;
-      m = fmaxf(m, z[c]);
-    }
-    m = wave_max(m);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      z[c] = (lane + 64 * c < cur) ? expf(z[c] - m) : 0.f;
-      s += z[c];
-    }
-    s = wave_sum(s);
-    const float inv = s > 0.f ? 1.f / s : 0.f;
-    float* row = adj + ((size_t)b * N + cur) * N;
-    float* soft = rec + R.o_soft;
-    float* row_out = rec + R.o_row;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int j = lane + 64 * c;
-      if (j < N) {
-        const float p = z[c] * inv;
-        soft[(size_t)b * N + j] = p;
-        float nv = 0.f;
-        if (j < cur) nv = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12); the incoming row is empty
-        if (j < cur) row[j] = nv;                              // (the rest of the row stays zero)
-        row_out[(size_t)b * N + j] = nv;
-        z[c] = nv;
-      } else {
-        z[c] = 0.f;
-      }
-    }
-    // ---- layer 1 of the GNN on row cur: the selected rows S = { j < cur : row[j] = 1 }, ascending -------------
-    unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
-    const int fl_ = lane < FP ? lane : FP - 1;
-    float agg1 = 0.f;
-    while (m0 | m1) {
-      const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
-      if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
-      agg1 += sX[j * FS + fl_];
-    }
-    const float xc = sX[cur * FS + fl_];
-    agg1 = lane < F ? agg1 : 0.f;
-    const float* wr1 = sWg + fl_ * FS;
-    const float* wt1 = sWg + FP * FS + fl_ * FS;
-    float p1 = (has_bias & 1) && lane < H1 ? pf_b1 : 0.f;
-#pragma unroll
-    for (int f = 0; f < FP; ++f) {
-      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg1), f));
-      const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), f));
-      p1 = fmaf(wr1[f], a, p1);
-      p1 = fmaf(wt1[f], x, p1);
-    }
-    float h1c = gcm_act(p1, act1);
-    h1c = lane < H1 ? h1c : 0.f;
-    const size_t rc = (size_t)b * N + cur;
-    if (lane < H1) cH[rc * H1 + lane] = h1c;
-    if (lane < F) {
-      cA[rc * F + lane] = agg1;
-      cX[rc * F + lane] = xc;
-    }
+  for (int f = 0; f < FP; ++f) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg1), f));
+    const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), f));
+    p1 = fmaf(wr1[f], a, p1);
+    p1 = fmaf(wt1[f], x, p1);
+  }
+  float h1c = gcm_act(p1, act1);
+  h1c = lane < H1 ? h1c : 0.f;
+  const size_t rc = (size_t)b * N + cur;
+  if (lane < H1) cH[rc * H1 + lane] = h1c;
+  if (lane < F) {
+    cA[rc * F + lane] = agg1;
+    cX[rc * F + lane] = xc;
   }
 }
 
@@ -1266,11 +1334,6 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
 //      skipped: the work is proportional to the candidate rows.  One 8-wave workgroup per CU, weight-gradient
 //      tiles in the MFMA accumulators across all blocks of a wave, one slab per workgroup.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // row p[0 .. n) -> out[32], zero padded (16-byte loads when the row is a whole number of them)
 __device__ __forceinline__ void load_row32(const float* __restrict__ p, int n, float* out) {
   if ((n & 3) == 0 && (reinterpret_cast<size_t>(p) & 15) == 0) {
@@ -1629,7 +1692,6 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
 constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * FS); }
-constexpr size_t lds_roll_select() { return lds_select() + sizeof(float) * (2 * FP * FS); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
                           (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);
@@ -1756,8 +1818,8 @@ extern "C" int gcm_learned_step_cached_functional(
   return gcm_launch_status();
 }
 
-/* DenseGCM.rollout with LearnedEdge, the whole forward of T <= N steps from EMPTY graphs in two launches (see
- * k_learned_roll_select).  obs [T,B,F], noise [T,B,N]; nodes [B,N,F] / adj [B,N,N]: the state AFTER the rollout, both
+/* DenseGCM.rollout with LearnedEdge, the whole forward of T <= N steps from EMPTY graphs in three launches (see
+ * k_learned_roll_logits).  obs [T,B,F], noise [T,B,N]; nodes [B,N,F] / adj [B,N,N]: the state AFTER the rollout, both
  * ZERO on entry (rows >= T stay zero), count [B] <- T; records: T step records of gcm_learned_step_layout(compact = 2)
  * at `rec_stride` floats from each other (>= that layout's total); caches [B,N,.] (rows < T written); mx_all [T,B,H2].
  * What gcm_learned_bptt_cached (n_cached = T, cached_layout = 2) reads. */
@@ -1775,14 +1837,23 @@ extern "C" int gcm_learned_rollout_fwd(const float* obs, const float* noise, int
   GCM_REQUIRE(rec_stride >= lay[0]);
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   gcm_learned::RollRec R{records, rec_stride, lay[1], lay[2], lay[5], lay[6], lay[7]};
-  constexpr size_t lds = gcm_learned::lds_roll_select();
-  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_roll_select, lds);
-  hipLaunchKernelGGL(gcm_learned::k_learned_roll_select, dim3(B, T), dim3(256), lds, (hipStream_t)stream, obs, noise,
-                     noise_is_exp, params + Pg, eps0, eps1, cutoff, params, act1, has_bias, H1, nodes, adj, count, R,
-                     cache_h1, cache_agg1, cache_nodes, B, T, N, F);
+  constexpr size_t lds = gcm_learned::lds_roll_logits();
+  static_assert(lds <= 160 * 1024, "one 16-wave workgroup per CU");
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_roll_logits, lds);
+  const long items = (long)T * B;
+  {
+    const long wgs = (items + gcm_learned::RL_WAVES - 1) / gcm_learned::RL_WAVES;
+    hipLaunchKernelGGL(gcm_learned::k_learned_roll_logits, dim3((unsigned)(wgs < 256 ? wgs : 256)),
+                       dim3(64 * gcm_learned::RL_WAVES), lds, (hipStream_t)stream, obs, params + Pg, eps0, eps1, R, B, T,
+                       N, F);
+  }
   int rc = gcm_launch_status();
   if (rc) return rc;
-  const long items = (long)T * B;
+  hipLaunchKernelGGL(gcm_learned::k_learned_roll_pick, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, obs, noise, noise_is_exp, cutoff, params, act1, has_bias, H1, nodes, adj,
+                     count, R, cache_h1, cache_agg1, cache_nodes, B, T, N, F);
+  rc = gcm_launch_status();
+  if (rc) return rc;
   hipLaunchKernelGGL(gcm_learned::k_learned_roll_l2, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, params, act2, has_bias, H1, H2, R, cache_h1, mx_all, flags, B, T, N, F);
   return gcm_launch_status();

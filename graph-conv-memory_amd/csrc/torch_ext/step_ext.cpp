@@ -1573,7 +1573,7 @@ pybind11::object rows_rollout_tp(int64_t cfg_handle, const at::Tensor& packed, c
 
 // ---------------------------------------------------------------------------------------------
 // DenseGCM.rollout with LearnedEdge from EMPTY graphs, T <= N steps, observations without gradient: the whole
-// forward in two launches (gcm_learned_rollout_fwd: every (graph, step) a workgroup - the selection depends on raw
+// forward in three launches (gcm_learned_rollout_fwd: every (graph, step) independent work - the selection depends on raw
 // observations and the given gumbel draws only), ONE autograd node whose backward is the chain's time-parallel one
 // (gcm_learned_bptt_cached over the T records and the caches).  The returned state (nodes, adj, count) is new.
 // ---------------------------------------------------------------------------------------------

@@ -873,9 +873,10 @@ int gcm_dense_rollout_tp_fwd(const float* obs, const gcm_selector_desc* selector
                              int H2, gcm_stream_t stream);
 
 /* DenseGCM.rollout with LearnedEdge: the whole forward of T <= N steps from EMPTY graphs, observations without
- * gradient, in TWO launches - the selection of step t (learned.py:53-113) depends on raw observations and the given
- * gumbel draws only, so every (graph, step) is a workgroup of one launch (edge network, gumbel-softmax, threshold,
- * adjacency row, layer 1 of the GNN on row cur into the caches), and the belief states follow in a second one.
+ * gradient, in THREE launches - the selection of step t (learned.py:53-113) depends on raw observations and the given
+ * gumbel draws only, so every (graph, step) is independent work: the edge network's logits per 32-row block that
+ * holds a candidate row (one block per wave), then one wave per (graph, step) for gumbel-softmax, threshold, adjacency
+ * row and layer 1 of the GNN on row cur into the caches, and the belief states in a third launch.
  * obs [T,B,F], noise [T,B,N]; nodes [B,N,F] / adj [B,N,N]: the state AFTER the rollout, ZERO on entry; count [B] <- T;
  * records: T step records (gcm_learned_step_layout, compact = 2) rec_stride floats apart; caches [B,N,.]; mx_all
  * [T,B,H2].  Backward: gcm_learned_bptt_cached over those records (n_cached = T, cached_layout = 2). */

@@ -407,7 +407,7 @@ def test_rollout_entry_equals_single_steps_every_selector(kind, start):
     from gcm.edge_selectors.distance import EuclideanEdge
     from gcm.edge_selectors.learned import LearnedEdge
     B, N, F, H, T = 40, 32, 32, 32, 45          # (T > N: the graphs overflow inside the rollout)
-    if kind == "learned_short":                 # T <= N from hidden = None: the two-launch time-parallel forward
+    if kind == "learned_short":                 # T <= N from hidden = None: the three-launch time-parallel forward
         kind, T = "learned", 29
     torch.manual_seed(3)
     centres = 3 * torch.randn(5, F)

@@ -144,7 +144,7 @@ def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False,
     pstep = {"t": 0}
     sel.noise_fn = lambda like: noise[pstep["t"]].to(DEV)
     h_first = None if hidden is None else (hidden[0].data_ptr(), hidden[1].data_ptr())
-    if rollout:      # the time-batched entry: from hidden = None and T <= N, two launches for the whole forward
+    if rollout:      # the time-batched entry: from hidden = None and T <= N, three launches for the whole forward
         assert hidden is None
         cnt = {"t": 0}
 
@@ -210,7 +210,7 @@ def test_learned_fused_cfg5_size_long_rollout():
 
 def test_learned_rollout_entry_time_parallel_full_size():
     """DenseGCM.rollout with LearnedEdge at cfg5's per-GPU size (B = 256, N = 128, F = H = 32, T = 64 from
-    hidden = None): the two-launch time-parallel forward (k_learned_roll_select, k_learned_roll_l2) and the chain's
+    hidden = None): the three-launch time-parallel forward (k_learned_roll_logits, k_learned_roll_pick, k_learned_roll_l2) and the chain's
     time-parallel backward over its records - against the oracle's per-step loop on a 3-graph slice with the same
     injected gumbel draws: sampled adjacency bit exact, beliefs 1e-5, every gradient inside the float64 bound."""
     B, N, F, H, T = 256, 128, 32, 32, 64

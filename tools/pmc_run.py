@@ -56,7 +56,7 @@ for name, T in (("cfg3", 128), ("cfg5", 64)):
         obs = torch.rand(T, c["B"], c["F"]).to(dev)
         mem, gnn, sel = bench.build_memory(dev, donate=True, selector=c["selector"], cfg=c)
         bench.rollout(mem, obs)
-        if name == "cfg5":                  # the time-batched entry: k_learned_roll_select / k_learned_roll_l2
+        if name == "cfg5":                  # the time-batched entry: k_learned_roll_logits / _pick / _l2
             bench.rollout_api(mem, obs)
         torch.cuda.synchronize()
 if "cfg4" in which:
