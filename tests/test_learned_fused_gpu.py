@@ -176,10 +176,13 @@ def _run_both(B, N, F, H, T, k, seed, count0, pick, rtol_sel=2e-3, donate=False,
 
 
 @pytest.mark.parametrize("donate", [False, True])
-@pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2)])
+@pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2),
+                                         (4, 72, 20, 24, 90, 4), (3, 50, 10, 12, 60, 3)])
 def test_learned_fused_vs_oracle(B, N, F, H, T, k, donate):
     """ragged shapes, staggered starts, overflow crossings; functional and donated state (the state advanced
-    in place, the step's record keeps the node matrix and row cur of the adjacency)"""
+    in place, the step's record keeps the node matrix and row cur of the adjacency).  N = 72 / 50: a last 32-row
+    block that is partly beyond the graph (the backward works per block, k_learned_bptt_mlp); F = 10: rows that are
+    no whole number of 16-byte loads."""
     torch.manual_seed(B + N)
     count0 = torch.randint(0, N + 1, (B,))
     _run_both(B, N, F, H, T, k, seed=B * 7 + N, count0=count0, pick=list(range(B)), donate=donate)
@@ -217,6 +220,15 @@ def test_learned_rollout_entry_time_parallel_full_size():
     hidden, mem = _run_both(B, N, F, H, T, 5, seed=17, count0=None, pick=[2, 101, 255], must_bound=True, rollout=True)
     assert int(hidden[3].min()) == T and int(hidden[3].max()) == T
     assert float(hidden[1].sum()) > B * T
+
+
+@pytest.mark.parametrize("B,N,F,H,T,k", [(5, 72, 20, 24, 60, 4), (3, 50, 10, 12, 50, 3), (6, 128, 32, 16, 100, 5)])
+def test_learned_rollout_entry_ragged_blocks(B, N, F, H, T, k):
+    """The time-parallel rollout (forward per 32-row block with a candidate row: k_learned_roll_logits) at graph
+    sizes that are no multiple of 32, narrow / odd feature widths and a hidden width different from the observation's:
+    against the oracle's per-step loop, sampled adjacency bit exact."""
+    hidden, mem = _run_both(B, N, F, H, T, k, seed=23 + N, count0=None, pick=list(range(B)), rollout=True)
+    assert int(hidden[3].min()) == T
 
 
 @pytest.mark.parametrize("donate", [True, False])
