@@ -48,6 +48,7 @@ namespace gcm_learned {
 using gcm_fused::mma32;
 
 constexpr int NP = 128, FP = 32, FS = 33;
+constexpr int GS = 36;   // row stride of the GNN weights in the cached step's tail: 16-byte aligned rows
 
 struct Mlp {   // pointers into the packed edge-network parameter vector (gcm_learned_mlp_layout)
   const float *w0, *b0, *g0, *be0, *w1, *b1, *g1, *be1, *w2, *b2;
@@ -92,8 +93,12 @@ __device__ __forceinline__ f32x16 gemm_rows(const float* sA, const float* sBt, i
 // (row = tid / 2, each owns 16 of the 32 columns; the row statistics meet through one lane shuffle):
 // all 256 threads work on the 128 rows.  Statistics (mean, rstd) optionally stored.  write = false
 // leaves sP untouched (statistics only).
-__device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const float* sg, const float* sb,
-                                             float eps, float* mu_out, float* rs_out, bool write = true) {
+// FULL (F == FP, uniform): the same arithmetic without the column guards - a third of the instructions of a pass
+// that the block-granular kernels are bound by (they issue ~2 k VALU / LDS instructions per 32-row block).
+// REG: sg / sb are this thread's 16 entries (registers, index k) instead of the LDS vectors (index f).
+template <bool FULL, bool REG = false>
+__device__ __forceinline__ void relu_ln_rows_t(float* sP, int tid, int F, const float* sg, const float* sb,
+                                               float eps, float* mu_out, float* rs_out, bool write) {
   const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
   float a[FP / 2];
   float s = 0.f;
@@ -101,7 +106,7 @@ __device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const fl
   for (int k = 0; k < FP / 2; ++k) {
     const int f = f0 + k;
     const float v = sP[row * FS + f];
-    a[k] = (f < F && v > 0.f) ? v : 0.f;
+    a[k] = ((FULL || f < F) && v > 0.f) ? v : 0.f;
     s += a[k];
   }
   s += gcm_lane_xor1(s);
@@ -109,7 +114,7 @@ __device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const fl
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < FP / 2; ++k) {
-    const float d = f0 + k < F ? a[k] - mean : 0.f;
+    const float d = (FULL || f0 + k < F) ? a[k] - mean : 0.f;
     q = fmaf(d, d, q);
   }
   q += gcm_lane_xor1(q);
@@ -118,17 +123,32 @@ __device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const fl
 #pragma unroll
     for (int k = 0; k < FP / 2; ++k) {
       const int f = f0 + k;
-      sP[row * FS + f] = f < F ? fmaf((a[k] - mean) * rstd, sg[f], sb[f]) : 0.f;
+      sP[row * FS + f] = (FULL || f < F) ? fmaf((a[k] - mean) * rstd, sg[REG ? k : f], sb[REG ? k : f]) : 0.f;
     }
   }
   if (mu_out && (tid & 1) == 0) { mu_out[row] = mean; rs_out[row] = rstd; }
 }
+// the F -> 1 layer on the rows of an [.][FS] image: two adjacent lanes per row, each half of the dot product in
+// ascending f, the halves added, + b2 - ONE function for the per-step and the time-parallel kernel (same logits,
+// bit for bit: the sampled edges of the two paths agree)
+__device__ __forceinline__ float logit_row2(const float* row, const float* w2, int half, float b2) {
+  float p = 0.f;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) p = fmaf(w2[(FP / 2) * half + k], row[(FP / 2) * half + k], p);
+  p += gcm_lane_xor1(p);
+  return p + b2;
+}
+__device__ __forceinline__ void relu_ln_rows(float* sP, int tid, int F, const float* sg, const float* sb,
+                                             float eps, float* mu_out, float* rs_out, bool write = true) {
+  if (F == FP) relu_ln_rows_t<true>(sP, tid, F, sg, sb, eps, mu_out, rs_out, write);
+  else relu_ln_rows_t<false>(sP, tid, F, sg, sb, eps, mu_out, rs_out, write);
+}
 
 // LayerNorm + ReLU adjoint of the rows of sP (pre-activation values, overwritten by the gradient w.r.t.
 // them): gx[f] = the gradient w.r.t. the normalised value times gamma; two threads per row as above.
-template <typename GX>
-__device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, const float* sMu, const float* sRs,
-                                                 GX gx_of) {
+template <bool FULL, typename GX>
+__device__ __forceinline__ void relu_ln_rows_bwd_t(float* sP, int tid, int F, const float* sMu, const float* sRs,
+                                                   GX gx_of) {
   const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
   const float mean = sMu[row], rstd = sRs[row];
   float xh[FP / 2], gx[FP / 2], m1 = 0.f, m2 = 0.f;
@@ -136,8 +156,8 @@ __device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, cons
   for (int k = 0; k < FP / 2; ++k) {
     const int f = f0 + k;
     const float v = sP[row * FS + f];
-    xh[k] = f < F ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
-    gx[k] = f < F ? gx_of(row, f) : 0.f;
+    xh[k] = (FULL || f < F) ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
+    gx[k] = (FULL || f < F) ? gx_of(row, f) : 0.f;
     m1 += gx[k];
     m2 = fmaf(gx[k], xh[k], m2);
   }
@@ -150,8 +170,14 @@ __device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, cons
     const int f = f0 + k;
     const float v = sP[row * FS + f];
     const float da = rstd * (gx[k] - m1 - xh[k] * m2);
-    sP[row * FS + f] = (f < F && v > 0.f) ? da : 0.f;
+    sP[row * FS + f] = ((FULL || f < F) && v > 0.f) ? da : 0.f;
   }
+}
+template <typename GX>
+__device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, const float* sMu, const float* sRs,
+                                                 GX gx_of) {
+  if (F == FP) relu_ln_rows_bwd_t<true>(sP, tid, F, sMu, sRs, gx_of);
+  else relu_ln_rows_bwd_t<false>(sP, tid, F, sMu, sRs, gx_of);
 }
 
 // c0[o] = b0[o] + W0a[o, :] . x_cur: both vectors in registers before the first use (a load -> fma loop
@@ -203,6 +229,39 @@ struct GnnTail {
   float *mx_out, *agg2_out;          // this step: [B,H2], [B,H1]
 };
 
+// one wave of work on a 32 x 32 block of an LDS image shared with nobody: LDS writes -> reads of other lanes
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// gcm_fused::Stage<RP, CP, false, false> with an unguarded form for exact shapes (any leading dimension); 256 threads
+template <int RP, int CP>
+struct StageL {
+  static constexpr int PER = RP * CP / 256;
+  float v[PER];
+  template <bool EX>
+  __device__ __forceinline__ void load(const float* __restrict__ src, int R, int C, int ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, r = e / CP, c = e % CP;
+      if (EX) {
+        v[i] = src[r * ld + c];
+      } else {
+        const float t = src[(r < R ? r : R - 1) * ld + (c < C ? c : C - 1)];
+        v[i] = (r < R && c < C) ? t : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, r = e / CP, c = e % CP;
+      dst[r * S + c] = v[i];
+    }
+  }
+};
+
 template <int MODE, bool TAIL>
 __global__ __launch_bounds__(256) void k_learned_select(
     const float* __restrict__ nodes_c, float* adj, const int64_t* __restrict__ cur_idx_c,
@@ -210,14 +269,25 @@ __global__ __launch_bounds__(256) void k_learned_select(
     float eps1, float cutoff, float* __restrict__ soft, int N, int F, const float* __restrict__ obs,
     const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes_out,
     int64_t* __restrict__ cur_out, int64_t* count_out, uint32_t* __restrict__ flags,
-    float* __restrict__ snap, float* __restrict__ row_out, GnnTail gt) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
+    float* __restrict__ snap, float* __restrict__ row_out, GnnTail gt, int cur_host) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
   constexpr bool ADVANCE = MODE != 0, DONATE = MODE == 2;
   static_assert(!TAIL || ADVANCE, "the cached step advances the state itself");
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
+  LSTAMP(14);
   int cur;
   bool wrap = false;
-  if (ADVANCE) {
+  int64_t n_chk = 0;   // cur_host: the count as stored, compared at the END of the kernel (nothing waits for it)
+  if (ADVANCE && cur_host >= 0) {
+    // the host knows the row (a chain from empty graphs that has not overflowed: every graph holds as many nodes as
+    // the chain has made steps): no load in front of every address below
+    cur = cur_host < N ? cur_host : N - 1;
+    if (tid == 0) {
+      n_chk = count_in[b];
+      cur_out[b] = cur;
+      if (!DONATE) count_out[b] = cur + 1;
+    }
+  } else if (ADVANCE) {
     const int64_t n_in = count_in[b];
     wrap = n_in + 1 > N;
     const int64_t c64 = wrap ? n_in - 1 : n_in;
@@ -234,8 +304,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   }
   const Mlp M = unpack_mlp(mlp, F);
   const float* xg = ADVANCE ? nullptr : nodes_c + (size_t)b * N * F;
-  const float* xcur = ADVANCE ? obs + (size_t)b * F : xg + (size_t)cur * F;   // the current node
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem;                 // [NP][FS]
   float* sA = sX + NP * FS;         // P0 -> H0
   float* sB = sA + NP * FS;         // P1 -> H1
@@ -243,25 +312,17 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sW1 = sW0b + FP * FS;      // [o][f]
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
-  float* sHc = sLogit + NP;         // TAIL: [NP][FS] the h1 cache of this graph
-  float* sWg = sHc + NP * FS;       // TAIL: [4][FP][FS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride FS
+  float* sW0a = sLogit + NP;        // [o][f] = W0[o][f]
+  float* sHc = sW0a + FP * FS;      // TAIL: [NP][FS] the h1 cache of this graph
+  float* sWg = sHc + NP * FS;       // TAIL: [4][FP][GS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride GS (16-byte aligned rows)
 
-  gcm_fused::Stage<FP, FP, false, false> st_w0, st_w1;   // in flight together with the loads below
-  st_w0.load(M.w0 + F, F, F, 2 * F, tid);
-  st_w1.load(M.w1, F, F, F, tid);
-  gcm_fused::Stage<NP, FP, false, false> st_hc;
-  gcm_fused::Stage<FP, FP, false, false> st_g[4];
-  if (TAIL) {
-    const int H1 = gt.H1, H2 = gt.H2;
-    st_hc.load(gt.cH + (size_t)b * N * H1, N, H1, H1, tid);
-    st_g[0].load(gt.gnn, H1, F, F, tid);
-    st_g[1].load(gt.gnn + (size_t)H1 * F, H1, F, F, tid);
-    st_g[2].load(gt.gnn + 2 * (size_t)H1 * F + H1, H2, H1, H1, tid);
-    st_g[3].load(gt.gnn + 2 * (size_t)H1 * F + H1 + (size_t)H2 * H1, H2, H1, H1, tid);
-  }
-  // What the single wave of the sampling / GNN tail reads from memory, requested NOW (lane-indexed, clamped
-  // addresses, every thread): the gumbel draws, the incoming row cur of the adjacency, the two GNN biases.  Read at
-  // their points of use they were six dependent round trips on the kernel's one-wave critical path.
+  // EVERY load of the kernel is requested here, in one round trip (in-kernel stamps of round 3 / 4: a load issued
+  // at its point of use - the observation patched into row cur, W0a and x_cur for c0, the seven vectors - is a
+  // whole memory round trip on the critical path of a kernel that runs one wave per SIMD), the farthest first: what
+  // the caller or the previous step's kernel wrote (observation, gumbel draws, node rows, adjacency row, h1 cache),
+  // then the parameters (L2 resident).  `ex`: exact shapes (uniform) - the same loads without clamps and masks, a
+  // few hundred VALU instructions less in front of the first wait.
+  const bool ex = F == FP && N == NP && (!TAIL || (gt.H1 == FP && gt.H2 == FP));
   float pf_noise[2], pf_old[2], pf_b1 = 0.f, pf_b2 = 0.f;
   {
     const int pl = tid & 63;
@@ -271,21 +332,19 @@ __global__ __launch_bounds__(256) void k_learned_select(
       pf_noise[c] = noise[(size_t)b * N + j];
       pf_old[c] = ADVANCE ? adj_in[((size_t)b * N + cur) * N + j] : 0.f;
     }
-    if (TAIL) {
-      const int H1 = gt.H1, H2 = gt.H2;
-      pf_b1 = gt.gnn[2 * (size_t)H1 * F + (pl < H1 ? pl : H1 - 1)];
-      pf_b2 = gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + (pl < H2 ? pl : H2 - 1)];
-    }
   }
+  constexpr int ADJ_PER = 16, NODE_PER = (NP * FP / 4 + 255) / 256;
+  const int N4 = N >> 2, F4 = F >> 2;
+  const int lim_n = N * F4;
+  float4 ca[ADJ_PER], cn[NODE_PER], ob[NODE_PER];
   if (ADVANCE) {
-    // the state copy through registers (roll folded in), the node image for the edge network from the
-    // same registers, the observation patched into row cur
-    constexpr int ADJ_PER = 16, NODE_PER = (NP * FP / 4 + 255) / 256;
-    const int N4 = N >> 2, F4 = F >> 2;
     const float* ag_in = adj_in + (size_t)b * N * N;
     const float* ng_in = nodes_in + (size_t)b * N * F;
-    float4 ca[ADJ_PER], cn[NODE_PER];
-    const int lim_n = N * F4;
+#pragma unroll
+    for (int i = 0; i < NODE_PER; ++i) {   // this thread's pieces of the observation, whichever row turns out to be cur
+      const int e4 = min(tid + 256 * i, lim_n - 1);
+      ob[i] = *reinterpret_cast<const float4*>(obs + (size_t)b * F + (e4 % F4) * 4);
+    }
     if (wrap) {
       gcm_state::load_copy<ADJ_PER, NODE_PER, true>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
     } else if (DONATE) {   // in place, no overflow: only the node rows are read (for the image)
@@ -297,6 +356,48 @@ __global__ __launch_bounds__(256) void k_learned_select(
     } else {
       gcm_state::load_copy<ADJ_PER, NODE_PER, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
     }
+  }
+  StageL<NP, FP> st_hc;
+  StageL<FP, FP> st_w0, st_w0a, st_w1, st_g[4];
+  if (ex) {
+    if (TAIL) st_hc.load<true>(gt.cH + (size_t)b * N * FP, N, FP, FP, tid);
+    st_w0.load<true>(M.w0 + F, F, F, 2 * F, tid);
+    st_w0a.load<true>(M.w0, F, F, 2 * F, tid);
+    st_w1.load<true>(M.w1, F, F, F, tid);
+    if (TAIL) {
+      st_g[0].load<true>(gt.gnn, FP, FP, FP, tid);
+      st_g[1].load<true>(gt.gnn + FP * FP, FP, FP, FP, tid);
+      st_g[2].load<true>(gt.gnn + 2 * FP * FP + FP, FP, FP, FP, tid);
+      st_g[3].load<true>(gt.gnn + 3 * FP * FP + FP, FP, FP, FP, tid);
+    }
+  } else {
+    const int H1 = gt.H1, H2 = gt.H2;
+    if (TAIL) st_hc.load<false>(gt.cH + (size_t)b * N * H1, N, H1, H1, tid);
+    st_w0.load<false>(M.w0 + F, F, F, 2 * F, tid);
+    st_w0a.load<false>(M.w0, F, F, 2 * F, tid);
+    st_w1.load<false>(M.w1, F, F, F, tid);
+    if (TAIL) {
+      st_g[0].load<false>(gt.gnn, H1, F, F, tid);
+      st_g[1].load<false>(gt.gnn + (size_t)H1 * F, H1, F, F, tid);
+      st_g[2].load<false>(gt.gnn + 2 * (size_t)H1 * F + H1, H2, H1, H1, tid);
+      st_g[3].load<false>(gt.gnn + 2 * (size_t)H1 * F + H1 + (size_t)H2 * H1, H2, H1, H1, tid);
+    }
+  }
+  float pf_vec[7];                  // b0 | b1 | g0 | be0 | g1 | be1 | w2, entry lane & 31
+  {
+    const int o = (tid & 31) < F ? (tid & 31) : F - 1;
+    pf_vec[0] = M.b0[o]; pf_vec[1] = M.b1[o]; pf_vec[2] = M.g0[o]; pf_vec[3] = M.be0[o];
+    pf_vec[4] = M.g1[o]; pf_vec[5] = M.be1[o]; pf_vec[6] = M.w2[o];
+  }
+  const float pf_b2e = M.b2[0];
+  if (TAIL) {
+    const int pl = tid & 31, H1 = gt.H1, H2 = gt.H2;   // (both halves of a wave: lane & 31)
+    pf_b1 = gt.gnn[2 * (size_t)H1 * F + (pl < H1 ? pl : H1 - 1)];
+    pf_b2 = gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + (pl < H2 ? pl : H2 - 1)];
+  }
+  if (ADVANCE) {
+    // the state copy through registers (roll folded in), the node image for the edge network from the
+    // same registers, the observation patched into row cur
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NODE_PER; ++i) {
@@ -304,16 +405,17 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (e4 < lim_n) {
         float4 v = cn[i];
         if (wrap && r + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r == cur) v = *reinterpret_cast<const float4*>(obs + (size_t)b * F + c);
+        if (r == cur) v = ob[i];
         cn[i] = v;
         sX[r * FS + c] = v.x; sX[r * FS + c + 1] = v.y; sX[r * FS + c + 2] = v.z; sX[r * FS + c + 3] = v.w;
       }
     }
     // zero padding of the image (rows >= N, columns >= F)
-    for (int e = tid; e < NP * FP; e += 256) {
-      const int r = e / FP, c = e % FP;
-      if (r >= N || c >= F) sX[r * FS + c] = 0.f;
-    }
+    if (!ex)
+      for (int e = tid; e < NP * FP; e += 256) {
+        const int r = e / FP, c = e % FP;
+        if (r >= N || c >= F) sX[r * FS + c] = 0.f;
+      }
     float* ng_out = nodes_out + (size_t)b * N * F;
     if (DONATE) {
       if (!TAIL) {
@@ -342,52 +444,80 @@ __global__ __launch_bounds__(256) void k_learned_select(
   } else {
     stage<NP>(xg, sX, N, F, F, tid);
   }
+  LSTAMP(15);
   st_w0.store(sW0b, FS, tid);
+  st_w0a.store(sW0a, FS, tid);
   st_w1.store(sW1, FS, tid);
   if (TAIL) {
     st_hc.store(sHc, FS, tid);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st_g[q].store(sWg + q * FP * FS, FS, tid);
+    for (int q = 0; q < 4; ++q) st_g[q].store(sWg + q * FP * GS, GS, tid);
   }
   if (tid < FP) {
-    const int o = tid < F ? tid : F - 1;
-    const float c0 = c0_dot(M.w0 + (size_t)o * 2 * F, xcur, M.b0[o], F);
     const bool ok = tid < F;
-    sVec[tid] = ok ? c0 : 0.f;
-    sVec[FP + tid] = ok ? M.b1[o] : 0.f;
-    sVec[2 * FP + tid] = ok ? M.g0[o] : 0.f;
-    sVec[3 * FP + tid] = ok ? M.be0[o] : 0.f;
-    sVec[4 * FP + tid] = ok ? M.g1[o] : 0.f;
-    sVec[5 * FP + tid] = ok ? M.be1[o] : 0.f;
-    sVec[6 * FP + tid] = ok ? M.w2[o] : 0.f;
-  }
-  __syncthreads();
-  {
-    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[li];
+    for (int q = 1; q < 7; ++q) sVec[q * FP + tid] = ok ? pf_vec[q] : 0.f;
   }
   __syncthreads();
-  relu_ln_rows(sA, tid, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
+  LSTAMP(16);
+  float gr0[FP / 2], br0[FP / 2], gr1[FP / 2], br1[FP / 2];   // LayerNorm scale / shift of this thread's 16 columns
+  {
+    const int f0 = (tid & 1) * (FP / 2);
+#pragma unroll
+    for (int k = 0; k < FP / 2; ++k) {
+      gr0[k] = sVec[2 * FP + f0 + k]; br0[k] = sVec[3 * FP + f0 + k];
+      gr1[k] = sVec[4 * FP + f0 + k]; br1[k] = sVec[5 * FP + f0 + k];
+    }
+  }
+  {
+    // c0[o] = b0[o] + W0a[o, :] . x_cur (ascending f), every lane its column's - from the images, not from memory
+    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
+    float c0 = pf_vec[0];
+    {
+      const float* w = sW0a + li * FS;
+      const float* x = sX + cur * FS;
+      float wv[FP], xv[FP];
+#pragma unroll
+      for (int f = 0; f < FP; ++f) { wv[f] = w[f]; xv[f] = x[f]; }
+      if (F == FP) {
+#pragma unroll
+        for (int f = 0; f < FP; ++f) c0 = fmaf(wv[f], xv[f], c0);
+      } else {
+#pragma unroll
+        for (int f = 0; f < FP; ++f)
+          if (f < F) c0 = fmaf(wv[f], xv[f], c0);
+        c0 = li < F ? c0 : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + c0;
+  }
   __syncthreads();
+  LSTAMP(17);
+  if (F == FP) relu_ln_rows_t<true, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
+  else relu_ln_rows_t<false, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
+  __syncthreads();
+  LSTAMP(18);
   {
     const f32x16 acc = gemm_rows(sA, sW1, wave, li, lh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) sB[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + sVec[FP + li];
   }
   __syncthreads();
-  relu_ln_rows(sB, tid, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
+  LSTAMP(19);
+  if (F == FP) relu_ln_rows_t<true, true>(sB, tid, F, gr1, br1, eps1, nullptr, nullptr, true);
+  else relu_ln_rows_t<false, true>(sB, tid, F, gr1, br1, eps1, nullptr, nullptr, true);
   __syncthreads();
-  if (tid < NP) {
-    float lg = M.b2[0];
-#pragma unroll
-    for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sB[tid * FS + f], lg);
-    sLogit[tid] = lg;
+  LSTAMP(20);
+  {
+    const float lg = logit_row2(sB + (tid >> 1) * FS, sVec + 6 * FP, tid & 1, pf_b2e);
+    if ((tid & 1) == 0) sLogit[tid >> 1] = lg;
   }
   // (ADVANCE) the copy's stores of row cur - other threads', issued long ago - must have landed before
   // wave 0 writes the sampled entries of that row below: released here, ahead of the barrier
   if (ADVANCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (waits for this wave's stores: cheap - they were issued two GEMMs ago; an agent-scope release would write the L2 back)
   __syncthreads();
+  LSTAMP(21);
   if (DONATE && tid == 255) count_out[b] = cur + 1;   // every wave read count_in long ago
   if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
     float z[2], m = -INFINITY;
@@ -435,45 +565,71 @@ __global__ __launch_bounds__(256) void k_learned_select(
         z[c] = 0.f;
       }
     }
+    LSTAMP(22);
     if (TAIL) {
       // ---- the GNN on row cur (see GnnTail): the selected rows S = { j < cur : row[j] = 1 }, ascending -------
       const int H1 = gt.H1, H2 = gt.H2;
       unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
       const int fl_ = lane < FP ? lane : FP - 1;
       float agg1 = 0.f, agg2 = 0.f;          // lane f: agg1[f]; lane h: agg2[h]
-      while (m0 | m1) {
-        const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
-        if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
-        agg1 += sX[j * FS + fl_];
-        agg2 += sHc[j * FS + fl_];
+      while (m0 | m1) {                      // eight selected rows per trip: their LDS reads in flight together
+        int js[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool has = (m0 | m1) != 0;
+          js[q] = !has ? -1 : (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
+          if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+        }
+        float xa[8], ha[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = js[q] >= 0 ? js[q] : 0;
+          xa[q] = sX[j * FS + fl_];
+          ha[q] = sHc[j * FS + fl_];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (js[q] >= 0) { agg1 += xa[q]; agg2 += ha[q]; }
       }
       const float xc = sX[cur * FS + fl_];    // lane f: x[cur][f]
       agg1 = lane < F ? agg1 : 0.f;
       agg2 = lane < H1 ? agg2 : 0.f;
-      // h1[cur][h] = act1(b1[h] + sum_f W_rel1[h][f] agg1[f] + W_root1[h][f] x[cur][f]), lane h
-      const float* wr1 = sWg + fl_ * FS;
-      const float* wt1 = sWg + FP * FS + fl_ * FS;
-      float p1 = (gt.has_bias & 1) && lane < H1 ? pf_b1 : 0.f;
+      // h1[cur][h] = act1(b1[h] + sum_f W_rel1[h][f] agg1[f] + W_root1[h][f] x[cur][f]): lane h takes the W_rel
+      // half, lane 32 + h the W_root half; the operand vectors go through LDS (16-byte broadcast reads) and the
+      // weight rows sit at a 16-byte aligned stride (GS), so a half is 8 + 8 LDS reads and 32 products in two
+      // chains.  (The first form - 64 + 64 v_readlane broadcasts and dependent fmas on one lane - was a fifth of
+      // the kernel.)
+      const int o = lane & 31;
+      float* sU = sLogit;                    // [agg1 | x_cur | agg2 | h1_cur], 32 each (the logits are consumed)
+      if (lh == 0) { sU[o] = agg1; sU[32 + o] = xc; sU[64 + o] = agg2; }
+      wsync();
+      auto half_dot = [&](const float* wrow, const float* u) {
+        float4 wv[8], uv[8];
 #pragma unroll
-      for (int f = 0; f < FP; ++f) {
-        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg1), f));
-        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), f));
-        p1 = fmaf(wr1[f], a, p1);
-        p1 = fmaf(wt1[f], x, p1);
-      }
+        for (int q = 0; q < 8; ++q) {
+          wv[q] = reinterpret_cast<const float4*>(wrow)[q];
+          uv[q] = reinterpret_cast<const float4*>(u)[q];
+        }
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          pa = fmaf(wv[q].x, uv[q].x, pa);
+          pb = fmaf(wv[q].y, uv[q].y, pb);
+          pa = fmaf(wv[q].z, uv[q].z, pa);
+          pb = fmaf(wv[q].w, uv[q].w, pb);
+        }
+        const float p = pa + pb;
+        return p + __shfl_xor(p, 32);
+      };
+      float p1 = half_dot(sWg + (lh ? FP * GS : 0) + o * GS, sU + 32 * lh);
+      p1 += (gt.has_bias & 1) && o < H1 ? pf_b1 : 0.f;
       float h1c = gcm_act(p1, gt.act1);
-      h1c = lane < H1 ? h1c : 0.f;
-      // mx[o] = act2(b2[o] + sum_h W_rel2[o][h] agg2[h] + W_root2[o][h] h1[cur][h]), lane o
-      const float* wr2 = sWg + 2 * FP * FS + fl_ * FS;
-      const float* wt2 = sWg + 3 * FP * FS + fl_ * FS;
-      float p2 = (gt.has_bias & 2) && lane < H2 ? pf_b2 : 0.f;
-#pragma unroll
-      for (int h = 0; h < FP; ++h) {
-        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(agg2), h));
-        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h1c), h));
-        p2 = fmaf(wr2[h], a, p2);
-        p2 = fmaf(wt2[h], x, p2);
-      }
+      h1c = o < H1 ? h1c : 0.f;              // (both halves hold h1[cur][o])
+      if (lh == 0) sU[96 + o] = h1c;
+      wsync();
+      // mx[o] = act2(b2[o] + sum_h W_rel2[o][h] agg2[h] + W_root2[o][h] h1[cur][h]), the same way
+      float p2 = half_dot(sWg + (lh ? 3 * FP * GS : 2 * FP * GS) + o * GS, sU + 64 + 32 * lh);
+      p2 += (gt.has_bias & 2) && o < H2 ? pf_b2 : 0.f;
       const float v = gcm_act(p2, gt.act2);
       const size_t rc = (size_t)b * N + cur;
       if (lane < H1) {
@@ -489,6 +645,8 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
     }
   }
+  if (ADVANCE && cur_host >= 0 && tid == 0 && n_chk != (int64_t)cur_host) atomicOr(flags, GCM_FLAG_BAD_COUNT);
+  LSTAMP(23);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -510,12 +668,6 @@ struct RollRec {          // the T step records: record t at rec0 + t * stride (
   float* rec0;
   size_t stride, o_row, o_mx, o_agg2, o_idx, o_soft;
 };
-
-// one wave of work on a 32 x 32 block of an LDS image shared with nobody: LDS writes -> reads of other lanes
-__device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // Launch 1 of 3: the logits of every candidate row of every (graph, step).  The unit of work is a 32-ROW BLOCK of
 // one item that holds a candidate row (32 k < cur = t), one block per WAVE of a persistent 16-wave workgroup per CU
@@ -628,11 +780,10 @@ __global__ __launch_bounds__(64 * RL_WAVES) void k_learned_roll_logits(const flo
     wsync();
     relu_ln_rows(sX, lane, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
     wsync();
-    if (lh == 0 && j0 + li < cur) {
-      float lg = b2;
-#pragma unroll
-      for (int f = 0; f < FP; ++f) lg = fmaf(sVec[6 * FP + f], sX[li * FS + f], lg);
-      (R.rec0 + (size_t)t * R.stride + R.o_soft)[(size_t)b * N + j0 + li] = lg;
+    {
+      const float lg = logit_row2(sX + (lane >> 1) * FS, sVec + 6 * FP, lane & 1, b2);
+      const int j = j0 + (lane >> 1);
+      if ((lane & 1) == 0 && j < cur) (R.rec0 + (size_t)t * R.stride + R.o_soft)[(size_t)b * N + j] = lg;
     }
     wsync();   // the images are rewritten by the wave's next block
   }
@@ -1291,8 +1442,9 @@ struct BpttB {
 };
 
 // ReLU + LayerNorm of the rows of src -> dst (two threads per row), statistics stored
-__device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, int tid, int F, const float* sg,
-                                                const float* sb, float eps, float* mu_out, float* rs_out) {
+template <bool FULL>
+__device__ __forceinline__ void relu_ln_rows_to_t(const float* src, float* dst, int tid, int F, const float* sg,
+                                                  const float* sb, float eps, float* mu_out, float* rs_out) {
   const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
   float a[FP / 2];
   float s = 0.f;
@@ -1300,7 +1452,7 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
   for (int k = 0; k < FP / 2; ++k) {
     const int f = f0 + k;
     const float v = src[row * FS + f];
-    a[k] = (f < F && v > 0.f) ? v : 0.f;
+    a[k] = ((FULL || f < F) && v > 0.f) ? v : 0.f;
     s += a[k];
   }
   s += gcm_lane_xor1(s);
@@ -1308,7 +1460,7 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < FP / 2; ++k) {
-    const float d = f0 + k < F ? a[k] - mean : 0.f;
+    const float d = (FULL || f0 + k < F) ? a[k] - mean : 0.f;
     q = fmaf(d, d, q);
   }
   q += gcm_lane_xor1(q);
@@ -1316,9 +1468,14 @@ __device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, in
 #pragma unroll
   for (int k = 0; k < FP / 2; ++k) {
     const int f = f0 + k;
-    dst[row * FS + f] = f < F ? fmaf((a[k] - mean) * rstd, sg[f], sb[f]) : 0.f;
+    dst[row * FS + f] = (FULL || f < F) ? fmaf((a[k] - mean) * rstd, sg[f], sb[f]) : 0.f;
   }
   if ((tid & 1) == 0) { mu_out[row] = mean; rs_out[row] = rstd; }
+}
+__device__ __forceinline__ void relu_ln_rows_to(const float* src, float* dst, int tid, int F, const float* sg,
+                                                const float* sb, float eps, float* mu_out, float* rs_out) {
+  if (F == FP) relu_ln_rows_to_t<true>(src, dst, tid, F, sg, sb, eps, mu_out, rs_out);
+  else relu_ln_rows_to_t<false>(src, dst, tid, F, sg, sb, eps, mu_out, rs_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1690,8 +1847,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
   col_out(c_b2, o_b2, 1);
 }
 
-constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + 7 * FP + NP); }
-constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * FS); }
+constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 3 * FP * FS + 7 * FP + NP); }
+constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * GS); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
                           (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);
@@ -1718,7 +1875,7 @@ extern "C" int gcm_learned_select_fused(const float* nodes, float* adj, const in
                      noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr,
                      (int64_t*)nullptr, (int64_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr,
-                     gcm_learned::GnnTail{});
+                     gcm_learned::GnnTail{}, -1);
   return gcm_launch_status();
 }
 
@@ -1741,7 +1898,7 @@ extern "C" int gcm_learned_advance_select_fused(const float* obs, const float* n
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F,
                      obs, nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,
-                     (float*)nullptr, gcm_learned::GnnTail{});
+                     (float*)nullptr, gcm_learned::GnnTail{}, -1);
   return gcm_launch_status();
 }
 
@@ -1763,7 +1920,7 @@ extern "C" int gcm_learned_advance_select_inplace(const float* obs, float* nodes
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags, nodes_snap,
-                     adj_row, gcm_learned::GnnTail{});
+                     adj_row, gcm_learned::GnnTail{}, -1);
   return gcm_launch_status();
 }
 
@@ -1771,14 +1928,15 @@ extern "C" int gcm_learned_advance_select_inplace(const float* obs, float* nodes
  * far), on a DONATED state: gcm_learned_advance_select_inplace with the step's GNN behind the selection (see
  * GnnTail) - one launch.  cache_h1 [B,N,H1], cache_agg1 [B,N,F], cache_nodes [B,N,F]: the chain's caches (row cur is
  * written; rows < cur were written by the earlier steps of the chain; zero-filled by the caller at the chain's
- * head).  The step's record (gcm_learned_step_layout, compact = 2): adj_row [B,N], mx [B,H2], agg2 [B,H1], cur /
+ * head).  cur_host >= 0: the row every graph's new node lands in, when the host knows it (the chain's step count: no
+ * load in front of the kernel's addresses; count_in is compared at the end - GCM_FLAG_BAD_COUNT); -1: read count_in.  The step's record (gcm_learned_step_layout, compact = 2): adj_row [B,N], mx [B,H2], agg2 [B,H1], cur /
  * count, soft [B,N]. */
 extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                                        const float* noise, int noise_is_exp, const float* params, int has_bias,
                                        int act1, int act2, float eps0, float eps1, float cutoff, int64_t* cur_out,
                                        int64_t* count_out, float* soft, float* adj_row, float* mx, float* agg2,
                                        float* cache_h1, float* cache_agg1, float* cache_nodes, uint32_t* flags, int B,
-                                       int N, int F, int H1, int H2, gcm_stream_t stream) {
+                                       int N, int F, int H1, int H2, int cur_host, gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes && adj && count_in && noise && params && cur_out && count_out && soft && adj_row && mx &&
               agg2 && cache_h1 && cache_agg1 && cache_nodes && flags && B > 0);
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
@@ -1790,7 +1948,7 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags,
-                     (float*)nullptr, adj_row, gt);
+                     (float*)nullptr, adj_row, gt, cur_host >= 0 ? cur_host : -1);
   return gcm_launch_status();
 }
 
@@ -1801,7 +1959,7 @@ extern "C" int gcm_learned_step_cached_functional(
     int noise_is_exp, const float* params, int has_bias, int act1, int act2, float eps0, float eps1, float cutoff,
     float* nodes_out, float* adj_out, int64_t* cur_out, int64_t* count_out, float* soft, float* mx, float* agg2,
     float* cache_h1, float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1, int H2,
-    gcm_stream_t stream) {
+    int cur_host, gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes_in && adj_in && count_in && noise && params && nodes_out && adj_out && cur_out &&
               count_out && soft && mx && agg2 && cache_h1 && cache_agg1 && cache_nodes && flags && B > 0);
   GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
@@ -1814,7 +1972,7 @@ extern "C" int gcm_learned_step_cached_functional(
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,
-                     (float*)nullptr, gt);
+                     (float*)nullptr, gt, cur_host >= 0 ? cur_host : -1);
   return gcm_launch_status();
 }
 

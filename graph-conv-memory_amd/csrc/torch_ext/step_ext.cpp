@@ -1369,7 +1369,7 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
                 count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp, pk, cfg->has_bias, cfg->act1,
                 cfg->act2, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base, base + lay[1], ib, ib + B,
                 base + lay[7], base + lay[2], base + lay[5], chain.cH.data_ptr<float>(), chain.cA.data_ptr<float>(),
-                chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2, st),
+                chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2, (int)chain.cached_steps, st),
             "gcm_learned_step_cached_functional");
       nodes_out = alias_of(buf, 0, {B, N, F}, buf.dtype());
       adj_out = alias_of(buf, (int64_t)lay[1], {B, N, N}, buf.dtype());
@@ -1380,7 +1380,8 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
                                   cfg->has_bias, cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
                                   (float)cfg->cutoff, ib, count_in.data_ptr<int64_t>(), base + lay[7], base + lay[1],
                                   base + lay[2], base + lay[5], chain.cH.data_ptr<float>(),
-                                  chain.cA.data_ptr<float>(), chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2, st),
+                                  chain.cA.data_ptr<float>(), chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2,
+                                  (int)chain.cached_steps, st),
           "gcm_learned_step_cached");
     nodes_out = nodes_in_;
     adj_out = adj_in_;

@@ -900,6 +900,8 @@ int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_hos
  * (gcm_learned_step_layout, compact = 2: no nodes / h1 / agg1 sections): adj_row [B,N], mx [B,H2], agg2 [B,H1],
  * cur | count, soft [B,N].  params: GNN | edge network, packed.  gcm_learned_step_cached_functional: the same on a
  * functional state (record layout compact = 3: nodes_out | adj_out | mx | agg2 | cur, count | soft).
+ * cur_host >= 0: the row every graph's new node lands in, when the host knows it (the chain's step count - no count
+ * load in front of the kernel's addresses; count_in is then only compared, GCM_FLAG_BAD_COUNT); -1: read count_in.
  * gcm_learned_bptt_cached: gcm_learned_bptt for a chain whose first n_cached steps are such steps (records in
  * layout `cached_layout` = 2 | 3; the steps behind them: `compact` layout). */
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
@@ -907,14 +909,14 @@ int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const in
                             int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
                             float* soft, float* adj_row, float* mx, float* agg2, float* cache_h1,
                             float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1,
-                            int H2, gcm_stream_t stream);
+                            int H2, int cur_host, gcm_stream_t stream);
 int gcm_learned_step_cached_functional(const float* obs, const float* nodes_in, const float* adj_in,
                                        const int64_t* count_in, const float* noise, int noise_is_exp,
                                        const float* params, int has_bias, int act1, int act2, float eps0,
                                        float eps1, float cutoff, float* nodes_out, float* adj_out, int64_t* cur_out,
                                        int64_t* count_out, float* soft, float* mx, float* agg2, float* cache_h1,
                                        float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F,
-                                       int H1, int H2, gcm_stream_t stream);
+                                       int H1, int H2, int cur_host, gcm_stream_t stream);
 int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                             int n_cached, int cached_layout, const float* cache_nodes, const float* cache_h1,
                             const float* cache_agg1, long gmx_stride_b, long gmx_stride_h, const float* params,
