@@ -9,8 +9,14 @@
 // one workgroup per graph keeps the node matrix and both hidden layers in LDS.
 //
 //   k_learned_select   forward: edge network on all N candidate rows, gumbel-softmax over j < cur,
-//                      straight-through threshold, adjacency row cur written in place.
-//   k_learned_step_bwd backward of one step, everything in one launch:
+//                      straight-through threshold, adjacency row cur written in place; <MODE> folds the state
+//                      advance in (functional / donated), <TAIL> the GNN on row cur over the chain's caches.
+//   k_learned_roll_logits / _pick / _l2   the forward of a whole rollout from empty graphs in three launches
+//                      (DenseGCM.rollout), the edge network per 32-row block with a candidate row.
+//   k_bptt_rows<.., 2> (rows_bptt.hip) + k_learned_bptt_sel + k_learned_bptt_mlp   the time-parallel backward of
+//                      a chain of steps (see "TIME-PARALLEL backward" below): what every fused chain runs.
+//   k_learned_step_bwd backward of ONE step (round 2's sequential form, kept behind gcm_learned_step_bwd for the
+//                      C ABI's single-step callers), everything in one launch:
 //     * GNN adjoint on the live rows (rows j with adj[cur, j] != 0, and cur: gcm.py:314 keeps one
 //       row of the last layer) -> parameter-gradient slab;
 //     * the gradient w.r.t. the ADJACENCY, which is what trains the edge network.  Its chain through

@@ -276,14 +276,17 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
 
 // SEL: the decisions of a distance selector arrive as a row (sel_row) and the selected rows beyond the first four
 // are gathered eight per round trip; without it the kernel is the temporal-hops form exactly (cfg2's timed kernel).
-template <int FP, int HP, bool SEL>
+// EX: F == FP and H1 == HP (compile-time widths: cfg2's / cfg3's timed kernels); otherwise the widths are the runtime
+// Fr <= FP, H1r <= HP - the weight image is zero beyond them (k_cached_weight_image) and the operand vectors are
+// written zero-padded, so the products run over FP / HP all the same.
+template <int FP, int HP, bool SEL, bool EX = true>
 __device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     const gcm_fused::Edits& E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     const CachedLayout& lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
-    const float* __restrict__ sel_row) {
-  constexpr int F = FP, H1 = HP;
+    const float* __restrict__ sel_row, int Fr = FP, int H1r = HP) {
+  const int F = EX ? FP : Fr, H1 = EX ? HP : H1r;
   __shared__ __attribute__((aligned(16))) float sv[128];
   const int lane = threadIdx.x;
   const unsigned gb = blockIdx.x;
@@ -298,11 +301,11 @@ __device__ __forceinline__ void step_rows_cached_img_body(
     sel1 = sel_row[gb * (unsigned)N + (unsigned)(lane + 64 < N ? lane + 64 : N - 1)];
   }
   // every weight load in flight at once (coalesced: lane h reads element h of row k of the image)
-  float r1[F], t1[F], r2[H1], t2[H1];
+  float r1[FP], t1[FP], r2[HP], t2[HP];
 #pragma unroll
-  for (int k = 0; k < F; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
+  for (int k = 0; k < FP; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
 #pragma unroll
-  for (int k = 0; k < H1; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  for (int k = 0; k < HP; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
   const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
   const float bias1 = b1[hl], bias2 = b2[ol];
   const float xc = obs[gb * F + fl];
@@ -367,15 +370,15 @@ __device__ __forceinline__ void step_rows_cached_img_body(
     for (int q = 0; q < 8; ++q) { agg1 += bx[q]; agg2 += bh[q]; }
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
-  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
+  if (lane < FP) { sv[lane] = agg1; sv[FP + lane] = (EX || lane < F) ? xc : 0.f; }
   // (one wave: its LDS operations execute in order - the broadcast reads below see these writes)
   float p1 = bias1;
   {
     float pa = 0.f, pb = 0.f;
 #pragma unroll
-    for (int f4 = 0; f4 < F / 4; ++f4) {
+    for (int f4 = 0; f4 < FP / 4; ++f4) {
       const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
-      const float4 x = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + FP + 4 * f4);
       pa = fmaf(r1[4 * f4], a.x, pa); pb = fmaf(t1[4 * f4], x.x, pb);
       pa = fmaf(r1[4 * f4 + 1], a.y, pa); pb = fmaf(t1[4 * f4 + 1], x.y, pb);
       pa = fmaf(r1[4 * f4 + 2], a.z, pa); pb = fmaf(t1[4 * f4 + 2], x.z, pb);
@@ -385,14 +388,14 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   }
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
-  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }
+  if (lane < HP) { sv[lane] = agg2; sv[HP + lane] = h1c; }
   float p2 = bias2;
   {
     float pa = 0.f, pb = 0.f;
 #pragma unroll
-    for (int h4 = 0; h4 < H1 / 4; ++h4) {
+    for (int h4 = 0; h4 < HP / 4; ++h4) {
       const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
-      const float4 x = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
+      const float4 x = *reinterpret_cast<const float4*>(sv + HP + 4 * h4);
       pa = fmaf(r2[4 * h4], a.x, pa); pb = fmaf(t2[4 * h4], x.x, pb);
       pa = fmaf(r2[4 * h4 + 1], a.y, pa); pb = fmaf(t2[4 * h4 + 1], x.y, pb);
       pa = fmaf(r2[4 * h4 + 2], a.z, pa); pb = fmaf(t2[4 * h4 + 2], x.z, pb);
@@ -464,6 +467,18 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
     const float* __restrict__ sel_row) {
   step_rows_cached_img_body<FP, HP, true>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
                                           flags, B, N, H2, cur_host, sel_row);
+}
+// any widths F <= FP, H1 <= HP (round 4: the observation / hidden sizes that are not 32 or 64 - BASELINE cfg1's
+// F = 8 among them - took the general live-row kernel before)
+template <int FP, int HP, bool SEL>
+__global__ __launch_bounds__(64) void k_step_rows_cached_gen(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
+    const float* __restrict__ sel_row, int F, int H1) {
+  step_rows_cached_img_body<FP, HP, SEL, false>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX,
+                                                saved, lay, flags, B, N, H2, cur_host, sel_row, F, H1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -767,7 +782,6 @@ __global__ __launch_bounds__(64) void k_sparse_step_cached(
 static int cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N, int F, int H1,
                             int H2, bool allow_distance) {
   if (!gcm_dense_rows_supported(N, F, H1, H2) || F > 64 || H1 > 64 || H2 > 64 || N > 128) return 0;
-  if ((F != 32 && F != 64) || (H1 != 32 && H1 != 64)) return 0;   // (the kernel is specialised on them)
   if (has_bias & (GCM_GNN_HAS_DEG_TERM | GCM_GNN_HAS_PE_TABLE | GCM_GNN_RECORD_DX)) return 0;
   int hops = 0, dist = 0;
   for (int i = 0; i < n_selectors; ++i) {
@@ -902,6 +916,23 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   }
     GCM_RI(32, 32) GCM_RI(64, 32) GCM_RI(32, 64) GCM_RI(64, 64)
 #undef GCM_RI
+    // other widths: the padded form
+    const int fp = F <= 32 ? 32 : 64, hp = H1 <= 32 ? 32 : 64;
+#define GCM_RG(a, b_)                                                                                            \
+  if (fp == a && hp == b_) {                                                                                     \
+    if (sel_row)                                                                                                 \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_gen<a, b_, true>), dim3(B), dim3(64), 0, (hipStream_t)stream, \
+                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row, F, H1);                        \
+    else                                                                                                         \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_gen<a, b_, false>), dim3(B), dim3(64), 0,                    \
+                         (hipStream_t)stream, obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, \
+                         cache_agg1, cache_nodes, saved, lay, flags, B, N, H2, cur_host, (const float*)nullptr, F,   \
+                         H1);                                                                                        \
+    return gcm_launch_status();                                                                                  \
+  }
+    GCM_RG(32, 32) GCM_RG(64, 32) GCM_RG(32, 64) GCM_RG(64, 64)
+#undef GCM_RG
     return GCM_EUNSUPPORTED;
   }
   const size_t lds = sizeof(float) * (2 * (size_t)H1 * (F + 1) + 2 * (size_t)64 * (H1 + 1) + 4 * 128);
@@ -924,6 +955,7 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
 static int roll_hops(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N, int F, int H1, int H2,
                      int* hops16, int* self) {
   if (!cached_supported(selectors, n_selectors, has_bias, N, F, H1, H2, false)) return -1;
+  if ((F != 32 && F != 64) || (H1 != 32 && H1 != 64)) return -1;   // (k_step_rows_cached_roll is specialised on them)
   int n = 0, mx = 0;
   *self = 0;
   for (int i = 0; i < n_selectors; ++i)

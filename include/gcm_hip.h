@@ -617,7 +617,9 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
  * knows it (a chain from empty graphs: the number of steps made so far) - the kernel then does not wait for the
  * count; -1: read it.  weight_image (may be NULL): [4][64][64] floats from gcm_dense_rows_cached_weight_image, the
  * four weight matrices lane-major (made once per chain: the parameters are fixed inside one) - with it a step is one
- * wave per graph whose every load, weights included, is issued at kernel start (no LDS staging, no barrier).  gcm_dense_rows_bptt_cached: gcm_dense_rows_bptt over such records. */
+ * wave per graph whose every load, weights included, is issued at kernel start (no LDS staging, no barrier).
+ * Widths: F, H1, H2 <= 64, N <= 128; 32 and 64 are compile-time widths, anything else runs padded to them and needs
+ * the weight image (GCM_EUNSUPPORTED without it).  gcm_dense_rows_bptt_cached: gcm_dense_rows_bptt over such records. */
 int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
                                     int F, int H1, int H2);
 int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2, size_t* out5);

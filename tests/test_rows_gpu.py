@@ -379,11 +379,11 @@ def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
             outs.append(mx)
             sums.append(hidden[1].sum(dim=(1, 2)).clone())
         assert _rows_taken(mem) == (mode != "fused")
-        # a donated chain from empty graphs at a size the cached step is specialised on: its first N steps run on
-        # the chain's caches (the selector's decision row handed to k_step_rows_cached_img), the rest - the graphs
-        # roll - on the general kernel
+        # a donated chain from empty graphs: its first N steps run on the chain's caches (the selector's decision row
+        # handed to k_step_rows_cached_sel; widths that are not 32 / 64 - F = 20, 12 here - in the padded form), the
+        # rest - the graphs roll - on the general kernel
         if mode == "rows_donated":
-            assert mem.rows_cached_steps_taken() == (min(T, N) if F in (32, 64) else 0)
+            assert mem.rows_cached_steps_taken() == min(T, N)
         out = torch.stack(outs)
         (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
         mem.check_flags()
@@ -679,7 +679,9 @@ def test_rows_obs_gradient_with_donated_state():
                                            (("temporal", [3, 7], "forward"), 4, 12, 32, 32, 40),      # (N <= 2 max hop: no steady-state form)
                                            (("temporal", [1], "forward"), 6, 32, 64, 32, 30),
                                            (("temporal", [1, 2, 3, 4, 5, 6], "forward"), 2, 20, 64, 64, 26),
-                                           (("temporal", [1, 2], "forward"), 3, 16, 8, 16, 20)])   # (sizes the kernel does not take)
+                                           (("temporal", [1, 2], "forward"), 3, 16, 8, 16, 20),    # (widths below 32: the padded form)
+                                           (("temporal", [1, 2], "forward"), 3, 16, 8, 16, 40),    # (... and T > N: the usual steps behind)
+                                           (("temporal", [1, 3], "forward"), 4, 24, 20, 48, 30)])  # (F -> 32, H -> 64 padded)
 def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
     """A donated rollout from hidden = None whose selectors only write row cur: its first N steps are cached steps
     (rows_cached.hip: row cur alone over the chain's h1 / agg1 / node caches), and the steps behind them - every
@@ -700,8 +702,8 @@ def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
         for t in range(T):
             mx, hid = mem(obs[t].to(DEV), hid)
             outs.append(mx)
-        takes = F in (32, 64) and H in (32, 64)      # (the cached kernel is specialised on these)
-        steady = N > 2 * max(sel[1])                 # (the steady-state form: see above)
+        takes = F <= 64 and H <= 64                  # (any widths up to 64: padded to 32 / 64 inside)
+        steady = N > 2 * max(sel[1]) and F in (32, 64) and H in (32, 64)   # (the steady-state form: see above)
         assert mem.rows_steps() == T
         assert mem.rows_cached_steps_taken() == ((T if steady else min(T, N)) if cached and takes else 0)
         assert mem.rows_rolled_steps_taken() == (max(0, T - N) if cached and takes and steady else 0)
