@@ -19,6 +19,7 @@
 #include <torch/extension.h>
 #include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <torch/csrc/autograd/python_variable.h>
 
 #include <algorithm>
@@ -1479,6 +1480,135 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// The host path of a CONTINUING LearnedEdge chain (round 4; RowsFast's twin for gcm.py:_forward_learned): DenseGCM.__call__
+// hands (obs, hidden) to step() directly, which validates what _forward_learned / _packed_params check in the
+// interpreter every step - the hidden state is the one this chain returned last and no caller has written into it,
+// same parameter objects at the same versions (read through the modules' own _parameters dicts), no hooks on the
+// module, no injected noise function, grad mode unchanged, chain not yet run backward - draws the step's gumbel
+// noise from the module's pool (the SAME list object _forward_learned uses: one RNG stream whichever path runs) and
+// calls learned_step2.  Anything else returns None: the call then goes through nn.Module.__call__ and re-arms.
+// ---------------------------------------------------------------------------------------------
+struct LearnedFast {
+  std::vector<pybind11::object> hook_dicts, dicts, keys, objs;
+  std::vector<uint32_t> vers;
+  pybind11::object sel_dict, key_noise;     // the selector module's __dict__ and the string "noise_fn"
+  pybind11::object chain_obj, pool, link, root, weights;   // LearnedChain, gcm._noise_pool (list), the state's link items
+  pybind11::object token, cfg_obj, flags_obj, key_link, key_lin;
+  LearnedChain* chain = nullptr;
+  at::Tensor flags;
+  bool armed = false, grad_mode = false;
+  int dev = -1;
+  int64_t xB = -1, xF = -1, parent = -1, N = 0, n_steps = 0;
+
+  LearnedFast(const std::vector<std::pair<pybind11::object, pybind11::object>>& specs,
+              const std::vector<pybind11::object>& hooks, pybind11::object sel_dict_)
+      : hook_dicts(hooks), sel_dict(std::move(sel_dict_)) {
+    for (const auto& sp : specs) {
+      dicts.push_back(sp.first);
+      keys.push_back(sp.second);
+    }
+    key_noise = pybind11::str("noise_fn");
+    key_link = pybind11::str("_gcm_link");
+    key_lin = pybind11::str("_gcm_lin");
+  }
+  bool hooks_registered() const {
+    for (const auto& d : hook_dicts)
+      if (PyObject_Size(d.ptr()) != 0) return true;
+    return false;
+  }
+  bool params_current() const {
+    for (size_t i = 0; i < dicts.size(); ++i) {
+      PyObject* o = PyDict_GetItem(dicts[i].ptr(), keys[i].ptr());   // borrowed
+      if (o != objs[i].ptr()) return false;
+      if (o && THPVariable_Check(o) && THPVariable_Unpack(o)._version() != vers[i]) return false;
+    }
+    return true;
+  }
+  // after a step of _forward_learned on `chain_obj_`: the next call may come straight here
+  void arm(pybind11::object chain_obj_, pybind11::object pool_, pybind11::object token_, pybind11::object cfg_,
+           pybind11::object flags_, pybind11::object root_, pybind11::object weights_, int64_t parent_, int64_t xB_,
+           int64_t xF_, int64_t N_) {
+    chain_obj = std::move(chain_obj_);
+    chain = &chain_obj.cast<LearnedChain&>();
+    pool = std::move(pool_);
+    token = std::move(token_);
+    cfg_obj = std::move(cfg_);
+    flags_obj = std::move(flags_);
+    flags = THPVariable_Unpack(flags_obj.ptr());
+    root = std::move(root_);
+    weights = std::move(weights_);
+    parent = parent_;
+    xB = xB_; xF = xF_; N = N_;
+    grad_mode = at::GradMode::is_enabled();
+    dev = chain->packed.get_device();
+    objs.clear();
+    vers.clear();
+    for (size_t i = 0; i < dicts.size(); ++i) {
+      PyObject* o = PyDict_GetItem(dicts[i].ptr(), keys[i].ptr());
+      objs.push_back(o ? pybind11::reinterpret_borrow<pybind11::object>(o) : pybind11::object());
+      vers.push_back(o && THPVariable_Check(o) ? THPVariable_Unpack(o)._version() : 0);
+    }
+    armed = true;
+  }
+  void forget() {
+    armed = false;
+    chain = nullptr;
+    chain_obj = pybind11::object();
+    root = pybind11::object();
+  }
+  pybind11::object step(pybind11::handle x, pybind11::handle hidden) {
+    if (!armed || !PyTuple_Check(hidden.ptr()) || PyTuple_GET_SIZE(hidden.ptr()) != 4 || !THPVariable_Check(x.ptr()))
+      return pybind11::none();
+    PyObject* h = hidden.ptr();
+    PyObject *pn = PyTuple_GET_ITEM(h, 0), *pa = PyTuple_GET_ITEM(h, 1), *pw = PyTuple_GET_ITEM(h, 2),
+             *pc = PyTuple_GET_ITEM(h, 3);
+    if (!THPVariable_Check(pn) || !THPVariable_Check(pa) || !THPVariable_Check(pc) || pw != weights.ptr())
+      return pybind11::none();
+    const at::Tensor &tn = THPVariable_Unpack(pn), &ta = THPVariable_Unpack(pa), &tc = THPVariable_Unpack(pc);
+    if (!chain->state_untouched(tn, ta, tc)) return pybind11::none();
+    const at::Tensor& xt = THPVariable_Unpack(x.ptr());
+    const bool grad = at::GradMode::is_enabled();
+    if (grad != grad_mode || chain->executed() || xt.dim() != 2 || xt.size(0) != xB || xt.size(1) != xF ||
+        xt.scalar_type() != at::kFloat || !xt.is_cuda() || xt.get_device() != dev || c10::hip::current_device() != dev ||
+        (grad && xt.requires_grad()) || !params_current() || hooks_registered())
+      return pybind11::none();
+    PyObject* nf = PyDict_GetItem(sel_dict.ptr(), key_noise.ptr());
+    if (nf != Py_None) return pybind11::none();   // (absent or injected: the interpreter's path decides)
+    // the gumbel draws: 16 steps' worth per RNG launch, from the module's pool [tensor, next, capturing]
+    if (!PyList_Check(pool.ptr()) || PyList_GET_SIZE(pool.ptr()) != 3) return pybind11::none();
+    PyObject* pt = PyList_GET_ITEM(pool.ptr(), 0);
+    const long next = PyLong_AsLong(PyList_GET_ITEM(pool.ptr(), 1));
+    const bool cap_now = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
+    if (!THPVariable_Check(pt) || next < 0 || next >= 16 || (PyList_GET_ITEM(pool.ptr(), 2) == Py_True) != cap_now)
+      return pybind11::none();                     // (exhausted or drawn under another capture state: refilled there)
+    const at::Tensor& pool_t = THPVariable_Unpack(pt);
+    if (pool_t.dim() != 3 || pool_t.size(1) != xB || pool_t.size(2) != N || pool_t.get_device() != dev)
+      return pybind11::none();
+    at::Tensor noise = pool_t.select(0, next);
+    PyObject* nx = PyLong_FromLong(next + 1);
+    PyList_SetItem(pool.ptr(), 1, nx);            // (steals nx)
+    pybind11::tuple r = learned_step2(*chain, xt, tn, ta, tc, noise, 1, flags, parent, false);
+    ++n_steps;
+    const int64_t idx = r[5].cast<int64_t>();
+    parent = idx;
+    pybind11::object a2 = r[2], n2 = r[1], c2 = r[4];
+    if (idx >= 0) {
+      pybind11::tuple lin = pybind11::make_tuple(chain_obj, idx);
+      if (PyObject_SetAttr(a2.ptr(), key_lin.ptr(), lin.ptr()) != 0) throw pybind11::error_already_set();
+    }
+    if (chain->donate) return pybind11::make_tuple(r[0], pybind11::reinterpret_borrow<pybind11::object>(h));
+    // functional state: what _forward_learned leaves on the new node matrix (gcm.py: `_gcm_link`)
+    pybind11::object xshape = pybind11::reinterpret_steal<pybind11::object>(
+        PyObject_GetAttrString(x.ptr(), "shape"));
+    if (!xshape) throw pybind11::error_already_set();
+    pybind11::tuple lk = pybind11::make_tuple(token, a2, cfg_obj, flags_obj, pybind11::none(), root, xshape,
+                                              weights, c2);
+    if (PyObject_SetAttr(n2.ptr(), key_link.ptr(), lk.ptr()) != 0) throw pybind11::error_already_set();
+    return pybind11::make_tuple(r[0], pybind11::make_tuple(n2, a2, weights, c2));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // DenseGCM.rollout from EMPTY graphs with forward temporal hops as the only selectors, observations without gradient:
 // the time-parallel forward (csrc/rollout_tp.hip: two launches for all T steps) and ONE autograd node whose backward
 // is gcm_dense_rows_bptt_cached over the T records and the caches [B, Tc, .] (N := Tc).
@@ -2371,6 +2501,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("recording", &LearnedChain::recording)
       .def("steps", &LearnedChain::steps);
   m.def("learned_step2", &learned_step2);
+  pybind11::class_<LearnedFast>(m, "LearnedFast")
+      .def(pybind11::init<const std::vector<std::pair<pybind11::object, pybind11::object>>&,
+                          const std::vector<pybind11::object>&, pybind11::object>())
+      .def("arm", &LearnedFast::arm)
+      .def("step", &LearnedFast::step)
+      .def("forget", &LearnedFast::forget)
+      .def("steps", [](LearnedFast& f) { return f.n_steps; });
   m.def("learned_rollout", &learned_rollout);
   m.def("rows_rollout_tp", &rows_rollout_tp);
   pybind11::class_<SparseChain>(m, "SparseChain")

@@ -745,6 +745,28 @@ class StepConfig:
             self._zero_params[dev] = z
         return z
 
+    _learned_fast = None
+
+    def learned_fast(self, module):
+        """The host path of a continuing LearnedEdge chain (C++: LearnedFast in csrc/torch_ext/step_ext.cpp), one per
+        configuration - RowsFast's twin: parameters read through the modules' own `_parameters` dicts, the hook dicts
+        torch.nn.Module.__call__ would consult, the selector's `__dict__` (an injected `noise_fn` declines)."""
+        f = self._learned_fast
+        if f is None:
+            rel0, root0, rel1, root1 = self.lins
+            specs = [(rel0._parameters, "weight"), (root0._parameters, "weight"), (rel0._parameters, "bias"),
+                     (rel1._parameters, "weight"), (root1._parameters, "weight"), (rel1._parameters, "bias")]
+            l0, _, n0, l1, _, n1, l2 = self.mlp_mods
+            for m in (l0, n0, l1, n1, l2):
+                specs += [(m._parameters, "weight"), (m._parameters, "bias")]
+            from torch.nn.modules import module as M
+            hooks = [module._forward_hooks, module._forward_pre_hooks, module._backward_hooks,
+                     module._backward_pre_hooks, M._global_backward_pre_hooks, M._global_backward_hooks,
+                     M._global_forward_pre_hooks, M._global_forward_hooks,
+                     M._global_forward_hooks_always_called, M._global_forward_hooks_with_kwargs]
+            f = self._learned_fast = _ext.module().LearnedFast(specs, hooks, self.learned_sel.__dict__)
+        return f
+
     def rows_fast(self, module):
         """The host path of the live-row step (C++: RowsFast in csrc/torch_ext/step_ext.cpp), one per
         configuration: it validates a continuing chain by itself - hidden state returned by the

@@ -136,6 +136,9 @@ class DenseGCM(torch.nn.Module):
         # False: no cached steps (the first N steps of a LearnedEdge rollout from empty graphs on a donated state as
         # ONE launch each, the GNN behind the selection on per-chain caches) - A/B tests
         self.learned_cached_steps = True
+        # ... a continuing LearnedEdge chain's steps run from DenseGCM.__call__ straight into the C++ host path
+        # (LearnedFast in csrc/torch_ext/step_ext.cpp); False: every step through forward() - A/B tests
+        self.learned_fast_path = True
         # False: no cached live-row steps (csrc/rows_cached.hip: the first N steps of a rollout from empty graphs on a
         # donated state, forward-only TemporalBackedge selectors: row cur alone over per-chain caches) - A/B
         self.rows_cached_steps = True
@@ -172,6 +175,14 @@ class DenseGCM(torch.nn.Module):
         for cfg in self._cfg_cache.values():
             if cfg is not False and cfg._rows_fast is not None:
                 n += cfg._rows_fast.steps()
+        return n
+
+    def learned_fast_steps(self):
+        """Number of LearnedEdge steps that went from __call__ straight into the C++ host path (LearnedFast)."""
+        n = 0
+        for cfg in self._cfg_cache.values():
+            if cfg is not False and cfg._learned_fast is not None:
+                n += cfg._learned_fast.steps()
         return n
 
     def rows_cached_steps_taken(self):
@@ -496,6 +507,8 @@ class DenseGCM(torch.nn.Module):
         self._learned_chain = None
         if cfg._rows_fast is not None:
             cfg._rows_fast.forget()
+        if cfg._learned_fast is not None:
+            cfg._learned_fast.forget()
         key = torch.is_grad_enabled()
         sizes = (cfg.H1 * cfg.F, cfg.H1 * cfg.F, cfg.H1, cfg.H2 * cfg.H1, cfg.H2 * cfg.H1, cfg.H2)
         if cfg.learned_sel is not None:
@@ -647,6 +660,13 @@ class DenseGCM(torch.nn.Module):
                                                          bool(fresh))
             if idx >= 0:
                 a2._gcm_lin = (lc[1], idx)
+            # the next call of this chain may skip the interpreter: DenseGCM.__call__ -> LearnedFast.step (C++)
+            if (sel.noise_fn is None and not self.mutate_num_nodes_on_overflow and hasattr(ext, "LearnedFast")
+                    and self.learned_fast_path):
+                lf = cfg.learned_fast(self)
+                lf.arm(lc[1], self._noise_pool, self._token, cfg, flags, root, weights, idx, B, x.shape[1], cfg.N)
+                every = {"deferred": self.poll_interval, "sync": 1, "off": float("inf")}[self.finite_check]
+                self._fast = (lf.step, flags, every)
             if lc[1].donates():      # the state was advanced in place: the caller's own tuple
                 n2._gcm_link = (self._token, a2, cfg, flags, None, root, x.shape, weights, c2)
                 if self.mutate_num_nodes_on_overflow:

@@ -340,3 +340,58 @@ def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k, donate):
         a, b = res[0][2][k_], res[1][2][k_]   # (gradients that are zero analytically: the floor from the common scale)
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()) +
                                    (2e-6 * scale if k_.startswith("net.") else 0.0), msg=k_)
+
+
+@pytest.mark.parametrize("donate", [True, False])
+@pytest.mark.parametrize("B,N,F,H,T", [(7, 32, 32, 32, 34), (5, 24, 12, 16, 20)])   # (T + 7 short of a pool refill)
+def test_learned_fast_host_path_equals_interpreter_path(B, N, F, H, T, donate):
+    """A continuing LearnedEdge chain goes from DenseGCM.__call__ straight into the C++ host path (LearnedFast:
+    the checks of forward() / _forward_learned / _packed_params done natively, the gumbel draws from the module's
+    own pool): every step but the chain's first, the same kernels on the same draws - beliefs, state and every
+    parameter gradient bit for bit those of the interpreter's path; it declines (and the interpreter's path runs)
+    once a parameter is written to, a hook is registered or a noise function injected."""
+    res = []
+    for fast in (True, False):
+        ref, net, g, sel, mem = _pair(F, H, N, 4, seed=5, donate=donate)
+        mem.learned_fast_path = fast
+        torch.manual_seed(99)
+        obs = torch.rand(T, B, F, device=DEV)
+        hidden, outs = None, []
+        for t in range(T):
+            mx, hidden = mem(obs[t], hidden)
+            outs.append(mx)
+        assert _taken(mem)
+        assert mem.learned_fast_steps() == (T - 1 - (T - 1) // 16 if fast else 0)   # (a pool refill per 16 steps goes the long way)
+        out = torch.stack(outs)
+        (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
+        mem.check_flags()
+        grads = [p.grad.clone() for p in list(g.parameters()) + list(sel.edge_network.parameters())]
+        res.append((out.detach().clone(), [hidden[0].clone(), hidden[1].clone(), hidden[3].clone()], grads))
+        if fast:       # declines: a written parameter, a forward hook, an injected noise function
+            n0 = mem.learned_fast_steps()
+            mx, hidden = mem(obs[0], hidden)
+            assert mem.learned_fast_steps() == n0          # (the chain ran backward: a new chain starts the long way)
+            mx, hidden = mem(obs[1], hidden)
+            assert mem.learned_fast_steps() == n0 + 1
+            with torch.no_grad():
+                next(g.parameters()).mul_(1.0)
+            mx, hidden = mem(obs[2], hidden)
+            assert mem.learned_fast_steps() == n0 + 1
+            mx, hidden = mem(obs[3], hidden)
+            assert mem.learned_fast_steps() == n0 + 2
+            hk = mem.register_forward_hook(lambda m, i, o: None)
+            mx, hidden = mem(obs[4], hidden)
+            assert mem.learned_fast_steps() == n0 + 2
+            hk.remove()
+            mx, hidden = mem(obs[5], hidden)
+            sel.noise_fn = lambda like: torch.zeros_like(like)
+            n1 = mem.learned_fast_steps()
+            mx, hidden = mem(obs[6], hidden)
+            assert mem.learned_fast_steps() == n1
+            sel.noise_fn = None
+            mem.check_flags()
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
