@@ -1493,7 +1493,7 @@ struct LearnedFast {
   std::vector<uint32_t> vers;
   pybind11::object sel_dict, key_noise;     // the selector module's __dict__ and the string "noise_fn"
   pybind11::object chain_obj, pool, link, root, weights;   // LearnedChain, gcm._noise_pool (list), the state's link items
-  pybind11::object token, cfg_obj, flags_obj, key_link, key_lin;
+  pybind11::object token, cfg_ref, flags_obj, key_link, key_lin;   // cfg_ref: weakref.ref(config) - the config owns this object
   LearnedChain* chain = nullptr;
   at::Tensor flags;
   bool armed = false, grad_mode = false;
@@ -1532,7 +1532,7 @@ struct LearnedFast {
     chain = &chain_obj.cast<LearnedChain&>();
     pool = std::move(pool_);
     token = std::move(token_);
-    cfg_obj = std::move(cfg_);
+    cfg_ref = std::move(cfg_);
     flags_obj = std::move(flags_);
     flags = THPVariable_Unpack(flags_obj.ptr());
     root = std::move(root_);
@@ -1577,6 +1577,7 @@ struct LearnedFast {
     // the gumbel draws: 16 steps' worth per RNG launch, from the module's pool [tensor, next, capturing]
     if (!PyList_Check(pool.ptr()) || PyList_GET_SIZE(pool.ptr()) != 3) return pybind11::none();
     PyObject* pt = PyList_GET_ITEM(pool.ptr(), 0);
+    if (!PyLong_Check(PyList_GET_ITEM(pool.ptr(), 1))) return pybind11::none();
     const long next = PyLong_AsLong(PyList_GET_ITEM(pool.ptr(), 1));
     const bool cap_now = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
     if (!THPVariable_Check(pt) || next < 0 || next >= 16 || (PyList_GET_ITEM(pool.ptr(), 2) == Py_True) != cap_now)
@@ -1584,6 +1585,9 @@ struct LearnedFast {
     const at::Tensor& pool_t = THPVariable_Unpack(pt);
     if (pool_t.dim() != 3 || pool_t.size(1) != xB || pool_t.size(2) != N || pool_t.get_device() != dev)
       return pybind11::none();
+    PyObject* cfg_live = PyWeakref_GetObject(cfg_ref.ptr());   // borrowed (the config owns this object: alive)
+    if (!cfg_live || cfg_live == Py_None) return pybind11::none();
+    // ---- nothing below declines: the step runs here ----
     at::Tensor noise = pool_t.select(0, next);
     PyObject* nx = PyLong_FromLong(next + 1);
     PyList_SetItem(pool.ptr(), 1, nx);            // (steals nx)
@@ -1601,8 +1605,8 @@ struct LearnedFast {
     pybind11::object xshape = pybind11::reinterpret_steal<pybind11::object>(
         PyObject_GetAttrString(x.ptr(), "shape"));
     if (!xshape) throw pybind11::error_already_set();
-    pybind11::tuple lk = pybind11::make_tuple(token, a2, cfg_obj, flags_obj, pybind11::none(), root, xshape,
-                                              weights, c2);
+    pybind11::tuple lk = pybind11::make_tuple(token, a2, pybind11::reinterpret_borrow<pybind11::object>(cfg_live),
+                                              flags_obj, pybind11::none(), root, xshape, weights, c2);
     if (PyObject_SetAttr(n2.ptr(), key_link.ptr(), lk.ptr()) != 0) throw pybind11::error_already_set();
     return pybind11::make_tuple(r[0], pybind11::make_tuple(n2, a2, weights, c2));
   }

@@ -16,6 +16,8 @@ reference's exact raise point) or not at all (`"off"`).
 import math
 from typing import Tuple, Union
 
+import weakref
+
 import torch
 
 from . import _hip, _ops
@@ -664,7 +666,8 @@ class DenseGCM(torch.nn.Module):
             if (sel.noise_fn is None and not self.mutate_num_nodes_on_overflow and hasattr(ext, "LearnedFast")
                     and self.learned_fast_path):
                 lf = cfg.learned_fast(self)
-                lf.arm(lc[1], self._noise_pool, self._token, cfg, flags, root, weights, idx, B, x.shape[1], cfg.N)
+                lf.arm(lc[1], self._noise_pool, self._token, weakref.ref(cfg), flags, root, weights, idx, B, x.shape[1],
+                       cfg.N)
                 every = {"deferred": self.poll_interval, "sync": 1, "off": float("inf")}[self.finite_check]
                 self._fast = (lf.step, flags, every)
             if lc[1].donates():      # the state was advanced in place: the caller's own tuple

@@ -395,3 +395,15 @@ def test_learned_fast_host_path_equals_interpreter_path(B, N, F, H, T, donate):
         assert torch.equal(a, b)
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+    # the C++ host path keeps no reference cycle through the module alive (it holds its config weakly)
+    import gc
+    import weakref
+    mem_f = _pair(F, H, N, 4, seed=5, donate=donate)[4]
+    hidden = None
+    for t in range(3):
+        mx, hidden = mem_f(obs[t], hidden)
+    assert mem_f.learned_fast_steps() == 2
+    wr = weakref.ref(mem_f)
+    del mem_f, mx, hidden
+    gc.collect()
+    assert wr() is None
