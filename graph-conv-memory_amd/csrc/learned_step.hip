@@ -241,29 +241,51 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// gcm_fused::Stage<RP, CP, false, false> with an unguarded form for exact shapes (any leading dimension); 256 threads
+// gcm_fused::Stage<RP, CP, false, false> with a form for exact shapes (EX: no clamps, no masks, 16-byte global loads -
+// a thread then holds four consecutive columns per piece - and 16-byte LDS stores where the row stride S allows);
+// any leading dimension that is a multiple of 4 floats when EX.  256 threads.
 template <int RP, int CP>
 struct StageL {
   static constexpr int PER = RP * CP / 256;
+  static_assert(PER % 4 == 0 && CP % 4 == 0, "whole 16-byte pieces per thread");
   float v[PER];
   template <bool EX>
   __device__ __forceinline__ void load(const float* __restrict__ src, int R, int C, int ld, int tid) {
+    if (EX) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, r = e / CP, c = e % CP;
-      if (EX) {
-        v[i] = src[r * ld + c];
-      } else {
+      for (int i = 0; i < PER / 4; ++i) {
+        const int e4 = tid + 256 * i, r = e4 / (CP / 4), c = (e4 % (CP / 4)) * 4;
+        const float4 t = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int e = tid + 256 * i, r = e / CP, c = e % CP;
         const float t = src[(r < R ? r : R - 1) * ld + (c < C ? c : C - 1)];
         v[i] = (r < R && c < C) ? t : 0.f;
       }
     }
   }
-  __device__ __forceinline__ void store(float* dst, int S, int tid) const {
+  template <bool EX, int S>
+  __device__ __forceinline__ void store(float* dst, int tid) const {
+    if (EX) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i, r = e / CP, c = e % CP;
-      dst[r * S + c] = v[i];
+      for (int i = 0; i < PER / 4; ++i) {
+        const int e4 = tid + 256 * i, r = e4 / (CP / 4), c = (e4 % (CP / 4)) * 4;
+        if (S % 4 == 0) {
+          *reinterpret_cast<float4*>(dst + r * S + c) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[r * S + c + k] = v[4 * i + k];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int e = tid + 256 * i, r = e / CP, c = e % CP;
+        dst[r * S + c] = v[i];
+      }
     }
   }
 };
@@ -318,8 +340,8 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sW1 = sW0b + FP * FS;      // [o][f]
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
-  float* sW0a = sLogit + NP;        // [o][f] = W0[o][f]
-  float* sHc = sW0a + FP * FS;      // TAIL: [NP][FS] the h1 cache of this graph
+  float* sW0a = sLogit + NP;        // [o][f] = W0[o][f], rows at stride GS (16-byte aligned)
+  float* sHc = sW0a + FP * GS;      // TAIL: [NP][FS] the h1 cache of this graph
   float* sWg = sHc + NP * FS;       // TAIL: [4][FP][GS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride GS (16-byte aligned rows)
 
   // EVERY load of the kernel is requested here, in one round trip (in-kernel stamps of round 3 / 4: a load issued
@@ -411,7 +433,10 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (e4 < lim_n) {
         float4 v = cn[i];
         if (wrap && r + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r == cur) v = ob[i];
+        if (r == cur) {
+          v = ob[i];
+          *reinterpret_cast<float4*>(sVec + c) = v;   // x_cur, 16-byte aligned (c0 reads it in pieces)
+        }
         cn[i] = v;
         sX[r * FS + c] = v.x; sX[r * FS + c + 1] = v.y; sX[r * FS + c + 2] = v.z; sX[r * FS + c + 3] = v.w;
       }
@@ -451,13 +476,24 @@ __global__ __launch_bounds__(256) void k_learned_select(
     stage<NP>(xg, sX, N, F, F, tid);
   }
   LSTAMP(15);
-  st_w0.store(sW0b, FS, tid);
-  st_w0a.store(sW0a, FS, tid);
-  st_w1.store(sW1, FS, tid);
-  if (TAIL) {
-    st_hc.store(sHc, FS, tid);
+  if (ex) {
+    st_w0.store<true, FS>(sW0b, tid);
+    st_w0a.store<true, GS>(sW0a, tid);
+    st_w1.store<true, FS>(sW1, tid);
+    if (TAIL) {
+      st_hc.store<true, FS>(sHc, tid);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st_g[q].store(sWg + q * FP * GS, GS, tid);
+      for (int q = 0; q < 4; ++q) st_g[q].store<true, GS>(sWg + q * FP * GS, tid);
+    }
+  } else {
+    st_w0.store<false, FS>(sW0b, tid);
+    st_w0a.store<false, GS>(sW0a, tid);
+    st_w1.store<false, FS>(sW1, tid);
+    if (TAIL) {
+      st_hc.store<false, FS>(sHc, tid);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) st_g[q].store<false, GS>(sWg + q * FP * GS, tid);
+    }
   }
   if (tid < FP) {
     const bool ok = tid < F;
@@ -469,25 +505,49 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float gr0[FP / 2], br0[FP / 2], gr1[FP / 2], br1[FP / 2];   // LayerNorm scale / shift of this thread's 16 columns
   {
     const int f0 = (tid & 1) * (FP / 2);
+    auto take16 = [&](const float* src, float* dst) {   // (16-byte pieces: sVec and f0 are 16-byte aligned)
 #pragma unroll
-    for (int k = 0; k < FP / 2; ++k) {
-      gr0[k] = sVec[2 * FP + f0 + k]; br0[k] = sVec[3 * FP + f0 + k];
-      gr1[k] = sVec[4 * FP + f0 + k]; br1[k] = sVec[5 * FP + f0 + k];
-    }
+      for (int q = 0; q < FP / 8; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(src + f0)[q];
+        dst[4 * q] = t.x; dst[4 * q + 1] = t.y; dst[4 * q + 2] = t.z; dst[4 * q + 3] = t.w;
+      }
+    };
+    take16(sVec + 2 * FP, gr0); take16(sVec + 3 * FP, br0);
+    take16(sVec + 4 * FP, gr1); take16(sVec + 5 * FP, br1);
   }
   {
     // c0[o] = b0[o] + W0a[o, :] . x_cur (ascending f), every lane its column's - from the images, not from memory
-    const f32x16 acc = gemm_rows(sX, sW0b, wave, li, lh);
+    // (the product's 16 dependent MFMAs leave the VALU idle for ~1 k cycles: c0's LDS reads and its chain of products
+    //  are scheduled into them - one MFMA, four reads, two products per group)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, li, lh);   // (= gemm_rows: same order)
     float c0 = pf_vec[0];
     {
-      const float* w = sW0a + li * FS;
+      const float* w = sW0a + li * GS;
       const float* x = sX + cur * FS;
       float wv[FP], xv[FP];
+      if (ADVANCE && ex) {   // 16-byte pieces: the weight row (aligned stride) and x_cur's aligned copy in sVec
 #pragma unroll
-      for (int f = 0; f < FP; ++f) { wv[f] = w[f]; xv[f] = x[f]; }
+        for (int q = 0; q < FP / 4; ++q) {
+          const float4 tw = reinterpret_cast<const float4*>(w)[q], tx = reinterpret_cast<const float4*>(sVec)[q];
+          wv[4 * q] = tw.x; wv[4 * q + 1] = tw.y; wv[4 * q + 2] = tw.z; wv[4 * q + 3] = tw.w;
+          xv[4 * q] = tx.x; xv[4 * q + 1] = tx.y; xv[4 * q + 2] = tx.z; xv[4 * q + 3] = tx.w;
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < FP; ++f) { wv[f] = w[f]; xv[f] = x[f]; }
+      }
       if (F == FP) {
 #pragma unroll
         for (int f = 0; f < FP; ++f) c0 = fmaf(wv[f], xv[f], c0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
       } else {
 #pragma unroll
         for (int f = 0; f < FP; ++f)
@@ -575,28 +635,36 @@ __global__ __launch_bounds__(256) void k_learned_select(
     if (TAIL) {
       // ---- the GNN on row cur (see GnnTail): the selected rows S = { j < cur : row[j] = 1 }, ascending -------
       const int H1 = gt.H1, H2 = gt.H2;
-      unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
+      const unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
       const int fl_ = lane < FP ? lane : FP - 1;
       float agg1 = 0.f, agg2 = 0.f;          // lane f: agg1[f]; lane h: agg2[h]
-      while (m0 | m1) {                      // eight selected rows per trip: their LDS reads in flight together
-        int js[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const bool has = (m0 | m1) != 0;
-          js[q] = !has ? -1 : (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
-          if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
-        }
+      // the selected rows as a compact ascending list: every selected lane writes its row at its rank (a scalar
+      // find-first-bit chain over the two masks cost 1.8 k cycles here), then eight rows per trip, their LDS reads
+      // in flight together, added in ascending order
+      const int n0 = __popcll(m0), n_sel = n0 + __popcll(m1);
+      int* sIdx = reinterpret_cast<int*>(sLogit);   // (the logits are consumed; sU takes this place below)
+      {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (z[0] != 0.f) sIdx[__popcll(m0 & below)] = lane;
+        if (z[1] != 0.f) sIdx[n0 + __popcll(m1 & below)] = lane + 64;
+      }
+      wsync();
+#pragma unroll 1
+      for (int q0 = 0; q0 < n_sel; q0 += 8) {
+        const int4 ia = *reinterpret_cast<const int4*>(sIdx + q0), ib = *reinterpret_cast<const int4*>(sIdx + q0 + 4);
+        const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
         float xa[8], ha[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const int j = js[q] >= 0 ? js[q] : 0;
+          const int j = q0 + q < n_sel ? js[q] : 0;
           xa[q] = sX[j * FS + fl_];
           ha[q] = sHc[j * FS + fl_];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (js[q] >= 0) { agg1 += xa[q]; agg2 += ha[q]; }
+          if (q0 + q < n_sel) { agg1 += xa[q]; agg2 += ha[q]; }
       }
+      wsync();
       const float xc = sX[cur * FS + fl_];    // lane f: x[cur][f]
       agg1 = lane < F ? agg1 : 0.f;
       agg2 = lane < H1 ? agg2 : 0.f;
@@ -627,6 +695,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
         const float p = pa + pb;
         return p + __shfl_xor(p, 32);
       };
+      LSTAMP(24);
       float p1 = half_dot(sWg + (lh ? FP * GS : 0) + o * GS, sU + 32 * lh);
       p1 += (gt.has_bias & 1) && o < H1 ? pf_b1 : 0.f;
       float h1c = gcm_act(p1, gt.act1);
@@ -634,9 +703,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (lh == 0) sU[96 + o] = h1c;
       wsync();
       // mx[o] = act2(b2[o] + sum_h W_rel2[o][h] agg2[h] + W_root2[o][h] h1[cur][h]), the same way
+      LSTAMP(25);
       float p2 = half_dot(sWg + (lh ? 3 * FP * GS : 2 * FP * GS) + o * GS, sU + 64 + 32 * lh);
       p2 += (gt.has_bias & 2) && o < H2 ? pf_b2 : 0.f;
       const float v = gcm_act(p2, gt.act2);
+      LSTAMP(26);
       const size_t rc = (size_t)b * N + cur;
       if (lane < H1) {
         gt.cH[rc * H1 + lane] = h1c;
@@ -1853,7 +1924,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
   col_out(c_b2, o_b2, 1);
 }
 
-constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 3 * FP * FS + 7 * FP + NP); }
+constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + FP * GS + 7 * FP + NP); }
 constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * GS); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +

@@ -39,3 +39,5 @@ print("k_learned_select<2, true>, step 63 of a rollout, workgroup 0 / thread 0  
 for i, n in enumerate(names):
     print(f"  {14 + i:2d} -> {15 + i:2d}  {n:44s} {acc[i]:9.1f}")
 print(f"  total {sum(acc):9.1f}")
+print("  inside the tail: 22 -> 24 gather of the selected rows %.0f, 24 -> 25 layer 1 on row cur %.0f, 25 -> 26 layer 2 %.0f, "
+      "26 -> 23 stores %.0f" % (out[24] - out[22], out[25] - out[24], out[26] - out[25], out[23] - out[26]))
