@@ -45,8 +45,14 @@ extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
 }
 #define LSTAMP(i) STAMP(i)
+#ifdef GCM_STAMPS_B2
+#define BSTAMP(i) STAMP(i)
+#else
+#define BSTAMP(i)
+#endif
 #else
 #define LSTAMP(i)
+#define BSTAMP(i)
 #endif
 
 namespace gcm_learned {
@@ -184,6 +190,45 @@ __device__ __forceinline__ void relu_ln_rows_bwd(float* sP, int tid, int F, cons
                                                  GX gx_of) {
   if (F == FP) relu_ln_rows_bwd_t<true>(sP, tid, F, sMu, sRs, gx_of);
   else relu_ln_rows_bwd_t<false>(sP, tid, F, sMu, sRs, gx_of);
+}
+// the same adjoint with the incoming gradient of this thread's 16 columns handed over in registers (gx[k]: the
+// gradient w.r.t. the normalised value times gamma, column f0 + k) and the pre-activations read ONCE: a third of
+// the LDS reads of the form above (the block-granular backward is bound by the instructions it issues)
+template <bool FULL>
+__device__ __forceinline__ void relu_ln_rows_bwd_v(float* sP, int tid, int F, const float* sMu, const float* sRs,
+                                                   const float (&gxv)[FP / 2]) {
+  const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
+  const float mean = sMu[row], rstd = sRs[row];
+  float xh[FP / 2], gx[FP / 2], m1 = 0.f, m2 = 0.f;
+  unsigned pos = 0;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
+    const float v = sP[row * FS + f];
+    pos |= (v > 0.f ? 1u : 0u) << k;
+    xh[k] = (FULL || f < F) ? ((v > 0.f ? v : 0.f) - mean) * rstd : 0.f;
+    gx[k] = (FULL || f < F) ? gxv[k] : 0.f;
+    m1 += gx[k];
+    m2 = fmaf(gx[k], xh[k], m2);
+  }
+  m1 += gcm_lane_xor1(m1);
+  m2 += gcm_lane_xor1(m2);
+  m1 /= (float)F;
+  m2 /= (float)F;
+#pragma unroll
+  for (int k = 0; k < FP / 2; ++k) {
+    const int f = f0 + k;
+    const float da = rstd * (gx[k] - m1 - xh[k] * m2);
+    sP[row * FS + f] = ((FULL || f < F) && ((pos >> k) & 1u)) ? da : 0.f;
+  }
+}
+// 16 consecutive floats of a 16-byte aligned LDS vector -> registers (four 16-byte reads)
+__device__ __forceinline__ void lds_take16(const float* src, float (&dst)[FP / 2]) {
+#pragma unroll
+  for (int q = 0; q < FP / 8; ++q) {
+    const float4 t = reinterpret_cast<const float4*>(src)[q];
+    dst[4 * q] = t.x; dst[4 * q + 1] = t.y; dst[4 * q + 2] = t.z; dst[4 * q + 3] = t.w;
+  }
 }
 
 // c0[o] = b0[o] + W0a[o, :] . x_cur: both vectors in registers before the first use (a load -> fma loop
@@ -1519,6 +1564,7 @@ struct BpttB {
 };
 
 // ReLU + LayerNorm of the rows of src -> dst (two threads per row), statistics stored
+// (sg / sb: 16-byte aligned LDS vectors - this thread's 16 entries come as four 16-byte reads each)
 template <bool FULL>
 __device__ __forceinline__ void relu_ln_rows_to_t(const float* src, float* dst, int tid, int F, const float* sg,
                                                   const float* sb, float eps, float* mu_out, float* rs_out) {
@@ -1543,9 +1589,14 @@ __device__ __forceinline__ void relu_ln_rows_to_t(const float* src, float* dst, 
   q += gcm_lane_xor1(q);
   const float rstd = rsqrtf(q / (float)F + eps);
 #pragma unroll
-  for (int k = 0; k < FP / 2; ++k) {
-    const int f = f0 + k;
-    dst[row * FS + f] = (FULL || f < F) ? fmaf((a[k] - mean) * rstd, sg[f], sb[f]) : 0.f;
+  for (int q4 = 0; q4 < FP / 8; ++q4) {   // scale / shift in 16-byte pieces, right where they are used
+    const float4 tg = reinterpret_cast<const float4*>(sg + f0)[q4], tb = reinterpret_cast<const float4*>(sb + f0)[q4];
+    const float gv[4] = {tg.x, tg.y, tg.z, tg.w}, bv[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * q4 + kk, f = f0 + k;
+      dst[row * FS + f] = (FULL || f < F) ? fmaf((a[k] - mean) * rstd, gv[kk], bv[kk]) : 0.f;
+    }
   }
   if ((tid & 1) == 0) { mu_out[row] = mean; rs_out[row] = rstd; }
 }
@@ -1728,7 +1779,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
   const int li = lane & 31, lh = lane >> 5;
   const int cf = lane & 31, cg = lane >> 5;   // column sums: column cf, rows cg, cg + 2, ... of the block
   const Mlp M = unpack_mlp(mlp, F);
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW0b = smem;                  // [o][f] = W0[o][F + f]
   float* sW0a = sW0b + FP * FS;        // [o][f] = W0[o][f]
   float* sW1 = sW0a + FP * FS;
@@ -1773,6 +1824,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
     const size_t it = (size_t)sg * B + b;
     const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * it]);
     if (32 * k >= cur) continue;       // no candidate row in this block (wave-uniform)
+    BSTAMP(0);
     int zv = 0;
     asm volatile("" : "+v"(zv));        // loop-variant LDS bases: keeps hipcc's LICM from parking every phase's
                                          // address arithmetic in registers in front of the loop
@@ -1810,6 +1862,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       }
     }
     wsync();
+    BSTAMP(1);
     {   // P0 = X W0b^T + (W0a x_cur + b0)
       f32x16 acc;
 #pragma unroll
@@ -1820,8 +1873,10 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       for (int r = 0; r < 16; ++r) sP0[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[li];
     }
     wsync();
+    BSTAMP(2);
     relu_ln_rows_to(sP0, sH, lane, F, sVec + 2 * FP, sVec + 3 * FP, eps0, sMu0, sRs0);
     wsync();
+    BSTAMP(3);
     {   // P1 = H0 W1^T + b1
       f32x16 acc;
 #pragma unroll
@@ -1831,11 +1886,17 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       for (int r = 0; r < 16; ++r) sP1[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[FP + li];
     }
     wsync();
+    BSTAMP(4);
     relu_ln_rows(sP1, lane, F, nullptr, nullptr, eps1, sMu1, sRs1, /*write=*/false);
     wsync();
+    BSTAMP(5);
     {   // dw2, dgamma1, dbeta1, db2
+      // (all 16 rows of this lane's group, no trip count: rows beyond the candidates carry g_logit = 0 and exact
+      //  zeros behind it - a loop over `jn` rows waited for its four LDS reads at every trip)
       const float w2f = sVec[6 * FP + cf], g1f = sVec[4 * FP + cf], be1f = sVec[5 * FP + cf];
-      for (int j = cg; j < jn; j += 2) {
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int j = cg + 2 * i;
         const float gl = sGl[j];
         const float v = sP1[j * FS + cf];
         const float xh = ((v > 0.f ? v : 0.f) - sMu1[j]) * sRs1[j];
@@ -1846,10 +1907,25 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       }
     }
     wsync();
-    relu_ln_rows_bwd(sP1, lane, F, sMu1, sRs1,
-                     [&](int j, int f) { return sGl[j] * sVec[6 * FP + f] * sVec[4 * FP + f]; });   // gP1
+    BSTAMP(6);
+    {   // gP1: the LayerNorm-1 adjoint of gx[f] = g_logit[j] w2[f] gamma1[f]
+      const int f0 = (lane & 1) * (FP / 2);
+      float gx[FP / 2];
+      const float gl = sGl[lane >> 1];
+#pragma unroll
+      for (int q = 0; q < FP / 8; ++q) {
+        const float4 w2 = reinterpret_cast<const float4*>(sVec + 6 * FP + f0)[q];
+        const float4 g1 = reinterpret_cast<const float4*>(sVec + 4 * FP + f0)[q];
+        gx[4 * q] = gl * w2.x * g1.x; gx[4 * q + 1] = gl * w2.y * g1.y;
+        gx[4 * q + 2] = gl * w2.z * g1.z; gx[4 * q + 3] = gl * w2.w * g1.w;
+      }
+      if (F == FP) relu_ln_rows_bwd_v<true>(sP1, lane, F, sMu1, sRs1, gx);
+      else relu_ln_rows_bwd_v<false>(sP1, lane, F, sMu1, sRs1, gx);
+    }
     wsync();
-    for (int j = cg; j < jn; j += 2) c_b1 += sP1[j * FS + cf];
+    BSTAMP(7);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) c_b1 += sP1[(cg + 2 * i) * FS + cf];
     {   // dW1 += gP1^T H0;  gH0 = gP1 W1 (over P1's place)
       f32x16 gh;
 #pragma unroll
@@ -1861,7 +1937,10 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       for (int r = 0; r < 16; ++r) sP1[gcm_fused::acc_row(r, lh) * FS + li] = gh[r];
     }
     wsync();
-    for (int j = cg; j < jn; j += 2) {   // dgamma0, dbeta0
+    BSTAMP(8);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {   // dgamma0, dbeta0
+      const int j = cg + 2 * i;
       const float v = sP0[j * FS + cf];
       const float xh = ((v > 0.f ? v : 0.f) - sMu0[j]) * sRs0[j];
       const float ghv = sP1[j * FS + cf];
@@ -1869,12 +1948,28 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       c_be0 += ghv;
     }
     wsync();
-    relu_ln_rows_bwd(sP0, lane, F, sMu0, sRs0, [&](int j, int f) { return sP1[j * FS + f] * sVec[2 * FP + f]; });   // gP0
+    BSTAMP(9);
+    {   // gP0: the LayerNorm-0 adjoint of gx[f] = gH0[j][f] gamma0[f]
+      const int f0 = (lane & 1) * (FP / 2);
+      float gx[FP / 2];
+      const float* gh = sP1 + (lane >> 1) * FS + f0;
+#pragma unroll
+      for (int q = 0; q < FP / 8; ++q) {
+        const float4 g0 = reinterpret_cast<const float4*>(sVec + 2 * FP + f0)[q];
+        gx[4 * q] = gh[4 * q] * g0.x; gx[4 * q + 1] = gh[4 * q + 1] * g0.y;
+        gx[4 * q + 2] = gh[4 * q + 2] * g0.z; gx[4 * q + 3] = gh[4 * q + 3] * g0.w;
+      }
+      if (F == FP) relu_ln_rows_bwd_v<true>(sP0, lane, F, sMu0, sRs0, gx);
+      else relu_ln_rows_bwd_v<false>(sP0, lane, F, sMu0, sRs0, gx);
+    }
     wsync();
-    for (int j = cg; j < jn; j += 2) c_b0 += sP0[j * FS + cf];
+    BSTAMP(10);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) c_b0 += sP0[(cg + 2 * i) * FS + cf];
     gcm_fused::mma32b<32>(aW0b, sP0, 1, FS, sX, FS, 1, li, lh);
     gcm_fused::mma32b<32>(aW0a, sP0, 1, FS, sX + 32 * FS, 0, 1, li, lh);
     wsync();   // the images are rewritten by the wave's next block
+    BSTAMP(11);
   }
 
   // ---- one slab per workgroup (packed edge-network layout), waves and row groups summed in fixed order ---
