@@ -108,7 +108,8 @@ __device__ __forceinline__ f32x16 gemm_rows(const float* sA, const float* sBt, i
 // FULL (F == FP, uniform): the same arithmetic without the column guards - a third of the instructions of a pass
 // that the block-granular kernels are bound by (they issue ~2 k VALU / LDS instructions per 32-row block).
 // REG: sg / sb are this thread's 16 entries (registers, index k) instead of the LDS vectors (index f).
-template <bool FULL, bool REG = false>
+// VEC: sg / sb are 16-byte aligned LDS vectors, read in 16-byte pieces.
+template <bool FULL, bool REG = false, bool VEC = false>
 __device__ __forceinline__ void relu_ln_rows_t(float* sP, int tid, int F, const float* sg, const float* sb,
                                                float eps, float* mu_out, float* rs_out, bool write) {
   const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
@@ -131,7 +132,18 @@ __device__ __forceinline__ void relu_ln_rows_t(float* sP, int tid, int F, const 
   }
   q += gcm_lane_xor1(q);
   const float rstd = rsqrtf(q / (float)F + eps);
-  if (write) {
+  if (write && VEC) {
+#pragma unroll
+    for (int q4 = 0; q4 < FP / 8; ++q4) {
+      const float4 tg = reinterpret_cast<const float4*>(sg + f0)[q4], tb = reinterpret_cast<const float4*>(sb + f0)[q4];
+      const float gv[4] = {tg.x, tg.y, tg.z, tg.w}, bv[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * q4 + kk, f = f0 + k;
+        sP[row * FS + f] = (FULL || f < F) ? fmaf((a[k] - mean) * rstd, gv[kk], bv[kk]) : 0.f;
+      }
+    }
+  } else if (write) {
 #pragma unroll
     for (int k = 0; k < FP / 2; ++k) {
       const int f = f0 + k;
@@ -808,7 +820,7 @@ __global__ __launch_bounds__(64 * RL_WAVES) void k_learned_roll_logits(const flo
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const Mlp M = unpack_mlp(mlp, F);
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sW0b = smem;                  // [o][f] = W0[o][F + f]
   float* sW0a = sW0b + FP * FS;        // [o][f] = W0[o][f]
   float* sW1 = sW0a + FP * FS;
@@ -889,7 +901,8 @@ __global__ __launch_bounds__(64 * RL_WAVES) void k_learned_roll_logits(const flo
       for (int r = 0; r < 16; ++r) sA[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sC0[li];
     }
     wsync();
-    relu_ln_rows(sA, lane, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr);
+    if (F == FP) relu_ln_rows_t<true, false, true>(sA, lane, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr, true);
+    else relu_ln_rows_t<false, false, true>(sA, lane, F, sVec + 2 * FP, sVec + 3 * FP, eps0, nullptr, nullptr, true);
     wsync();
     {
       f32x16 acc;
@@ -900,7 +913,8 @@ __global__ __launch_bounds__(64 * RL_WAVES) void k_learned_roll_logits(const flo
       for (int r = 0; r < 16; ++r) sX[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[FP + li];
     }
     wsync();
-    relu_ln_rows(sX, lane, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr);
+    if (F == FP) relu_ln_rows_t<true, false, true>(sX, lane, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr, true);
+    else relu_ln_rows_t<false, false, true>(sX, lane, F, sVec + 4 * FP, sVec + 5 * FP, eps1, nullptr, nullptr, true);
     wsync();
     {
       const float lg = logit_row2(sX + (lane >> 1) * FS, sVec + 6 * FP, lane & 1, b2);
