@@ -234,14 +234,6 @@ __device__ __forceinline__ void relu_ln_rows_bwd_v(float* sP, int tid, int F, co
     sP[row * FS + f] = ((FULL || f < F) && ((pos >> k) & 1u)) ? da : 0.f;
   }
 }
-// 16 consecutive floats of a 16-byte aligned LDS vector -> registers (four 16-byte reads)
-__device__ __forceinline__ void lds_take16(const float* src, float (&dst)[FP / 2]) {
-#pragma unroll
-  for (int q = 0; q < FP / 8; ++q) {
-    const float4 t = reinterpret_cast<const float4*>(src)[q];
-    dst[4 * q] = t.x; dst[4 * q + 1] = t.y; dst[4 * q + 2] = t.z; dst[4 * q + 3] = t.w;
-  }
-}
 
 // c0[o] = b0[o] + W0a[o, :] . x_cur: both vectors in registers before the first use (a load -> fma loop
 // exposed up to F memory round trips on the 32 threads that run it), summed in ascending f
