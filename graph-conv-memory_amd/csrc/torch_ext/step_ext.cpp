@@ -1314,10 +1314,13 @@ struct LearnedChain {   // one per packed parameter vector
   int64_t n_cached() const { return cached_steps; }
 };
 
-// -> (mx, nodes_out, adj_out, cur, count_out, index of this step in the chain (or -1))
-pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const at::Tensor& nodes_in_,
-                              const at::Tensor& adj_in_, const at::Tensor& count_in, const at::Tensor& noise_,
-                              int64_t noise_is_exp, const at::Tensor& flags, int64_t parent, bool fresh) {
+struct LearnedStepOut {
+  at::Tensor mx, nodes, adj, cur, count;
+  int64_t index;   // of this step in the chain (or -1)
+};
+LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, const at::Tensor& nodes_in_,
+                                  const at::Tensor& adj_in_, const at::Tensor& count_in, const at::Tensor& noise_,
+                                  int64_t noise_is_exp, const at::Tensor& flags, int64_t parent, bool fresh) {
   LearnedCfg* cfg = chain.cfg;
   TORCH_CHECK(obs_.is_cuda() && nodes_in_.is_cuda() && adj_in_.is_cuda() && count_in.is_cuda() && noise_.is_cuda() &&
                   flags.is_cuda(),
@@ -1476,7 +1479,15 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs_, const
     index = (int64_t)chain.node->recs.size() - 1;
     torch::autograd::create_gradient_edge(mx, chain.node);
   }
-  return pybind11::make_tuple(mx, nodes_out, adj_out, cur, count_out, index);
+  return {mx, nodes_out, adj_out, cur, count_out, index};
+}
+// -> (mx, nodes_out, adj_out, cur, count_out, index of this step in the chain (or -1))
+pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs, const at::Tensor& nodes_in,
+                              const at::Tensor& adj_in, const at::Tensor& count_in, const at::Tensor& noise,
+                              int64_t noise_is_exp, const at::Tensor& flags, int64_t parent, bool fresh) {
+  LearnedStepOut r = learned_step2_impl(chain, obs, nodes_in, adj_in, count_in, noise, noise_is_exp, flags, parent,
+                                        fresh);
+  return pybind11::make_tuple(r.mx, r.nodes, r.adj, r.cur, r.count, r.index);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1591,16 +1602,25 @@ struct LearnedFast {
     at::Tensor noise = pool_t.select(0, next);
     PyObject* nx = PyLong_FromLong(next + 1);
     PyList_SetItem(pool.ptr(), 1, nx);            // (steals nx)
-    pybind11::tuple r = learned_step2(*chain, xt, tn, ta, tc, noise, 1, flags, parent, false);
+    LearnedStepOut r = learned_step2_impl(*chain, xt, tn, ta, tc, noise, 1, flags, parent, false);
     ++n_steps;
-    const int64_t idx = r[5].cast<int64_t>();
+    const int64_t idx = r.index;
     parent = idx;
-    pybind11::object a2 = r[2], n2 = r[1], c2 = r[4];
+    pybind11::object pmx = pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(r.mx));
+    if (chain->donate) {   // the state was advanced in place: the caller's own tensors and tuple
+      if (idx >= 0) {
+        pybind11::tuple lin = pybind11::make_tuple(chain_obj, idx);
+        if (PyObject_SetAttr(pa, key_lin.ptr(), lin.ptr()) != 0) throw pybind11::error_already_set();
+      }
+      return pybind11::make_tuple(pmx, pybind11::reinterpret_borrow<pybind11::object>(h));
+    }
+    pybind11::object a2 = pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(r.adj)),
+                     n2 = pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(r.nodes)),
+                     c2 = pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(r.count));
     if (idx >= 0) {
       pybind11::tuple lin = pybind11::make_tuple(chain_obj, idx);
       if (PyObject_SetAttr(a2.ptr(), key_lin.ptr(), lin.ptr()) != 0) throw pybind11::error_already_set();
     }
-    if (chain->donate) return pybind11::make_tuple(r[0], pybind11::reinterpret_borrow<pybind11::object>(h));
     // functional state: what _forward_learned leaves on the new node matrix (gcm.py: `_gcm_link`)
     pybind11::object xshape = pybind11::reinterpret_steal<pybind11::object>(
         PyObject_GetAttrString(x.ptr(), "shape"));
@@ -1608,7 +1628,7 @@ struct LearnedFast {
     pybind11::tuple lk = pybind11::make_tuple(token, a2, pybind11::reinterpret_borrow<pybind11::object>(cfg_live),
                                               flags_obj, pybind11::none(), root, xshape, weights, c2);
     if (PyObject_SetAttr(n2.ptr(), key_link.ptr(), lk.ptr()) != 0) throw pybind11::error_already_set();
-    return pybind11::make_tuple(r[0], pybind11::make_tuple(n2, a2, weights, c2));
+    return pybind11::make_tuple(pmx, pybind11::make_tuple(n2, a2, weights, c2));
   }
 };
 
