@@ -1662,6 +1662,12 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
     load_row32(xg + (size_t)j * F, F, xr);
     load_row32(hg + (size_t)j * H1, H1, hr);
   }
+  float pf_soft[2];                    // the softmax row, for the adjoint at the end: requested with everything else
+  {
+    const float* soft = base + a.o_soft + (size_t)b * N;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) pf_soft[c] = soft[lane + 64 * c < N ? lane + 64 * c : N - 1];
+  }
   constexpr int NONE = 1 << 30;
   {   // where does the node inserted at this step sit in the live list of step t + tid?
     int slot = -1, w = NONE;
@@ -1752,13 +1758,12 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
   }
   __syncthreads();
   if (tid < 64) {   // softmax adjoint (tau = 1); both straight-through estimators are identities
-    const float* soft = base + a.o_soft + (size_t)b * N;
     float p[2], g[2], dot = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int j = lane + 64 * c;
       const bool live = j < cur;
-      p[c] = live ? soft[j < N ? j : N - 1] : 0.f;
+      p[c] = live ? pf_soft[c] : 0.f;
       g[c] = live ? sSel[j] : 0.f;
       dot = fmaf(p[c], g[c], dot);
     }
