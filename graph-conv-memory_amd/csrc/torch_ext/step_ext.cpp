@@ -1491,6 +1491,52 @@ pybind11::tuple learned_step2(LearnedChain& chain, const at::Tensor& obs, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The packed parameter vector (gcm.py:_packed_params) as ONE autograd node: torch.cat of the flattened parameters
+// with a backward that hands every parameter its slice of the flat gradient as a view - instead of CatBackward and a
+// view node per parameter (six of them for the GNN, sixteen with the edge network: a third of a rollout's backward
+// on the host).
+// ---------------------------------------------------------------------------------------------
+struct PackNode : public torch::autograd::Node {
+  std::vector<std::vector<int64_t>> shapes;
+  std::vector<int64_t> offs, ns;
+  variable_list apply(variable_list&& grads) override {
+    variable_list out(shapes.size());
+    if (!grads[0].defined()) return out;
+    const at::Tensor g = grads[0].contiguous();
+    for (size_t i = 0; i < shapes.size(); ++i)
+      if (task_should_compute_output(i)) out[i] = g.narrow(0, offs[i], ns[i]).view(shapes[i]);
+    return out;
+  }
+};
+
+at::Tensor pack_params(const std::vector<at::Tensor>& ts) {
+  TORCH_CHECK(!ts.empty());
+  at::Tensor packed;
+  {
+    at::NoGradGuard ng;
+    std::vector<at::Tensor> flat;
+    flat.reserve(ts.size());
+    for (const auto& t : ts) flat.push_back(t.reshape({-1}));
+    packed = at::cat(flat);
+  }
+  bool any = false;
+  for (const auto& t : ts) any = any || t.requires_grad();
+  if (at::GradMode::is_enabled() && any) {
+    auto node = std::shared_ptr<PackNode>(new PackNode(), torch::autograd::deleteNode);
+    int64_t off = 0;
+    for (const auto& t : ts) {
+      node->shapes.push_back(t.sizes().vec());
+      node->offs.push_back(off);
+      node->ns.push_back(t.numel());
+      off += t.numel();
+    }
+    node->set_next_edges(torch::autograd::collect_next_edges(ts));
+    torch::autograd::create_gradient_edge(packed, node);   // (adds the input metadata itself)
+  }
+  return packed;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The host path of a CONTINUING LearnedEdge chain (round 4; RowsFast's twin for gcm.py:_forward_learned): DenseGCM.__call__
 // hands (obs, hidden) to step() directly, which validates what _forward_learned / _packed_params check in the
 // interpreter every step - the hidden state is the one this chain returned last and no caller has written into it,
@@ -2525,6 +2571,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("recording", &LearnedChain::recording)
       .def("steps", &LearnedChain::steps);
   m.def("learned_step2", &learned_step2);
+  m.def("pack_params", &pack_params);
   pybind11::class_<LearnedFast>(m, "LearnedFast")
       .def(pybind11::init<const std::vector<std::pair<pybind11::object, pybind11::object>>&,
                           const std::vector<pybind11::object>&, pybind11::object>())

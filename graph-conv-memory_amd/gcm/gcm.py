@@ -517,26 +517,40 @@ class DenseGCM(torch.nn.Module):
             Fe = cfg.F
             sizes = sizes + (2 * Fe * Fe, Fe, Fe, Fe, Fe * Fe, Fe, Fe, Fe, Fe, 1)
         dev = tensors[0].device
-        parts = [t.reshape(-1) if t is not None else torch.zeros(n, device=dev)
-                 for t, n in zip(tensors, sizes)]
-        if fold is not None:
-            parts = self._folded_parts(cfg, tensors, parts)
-        packed = torch.cat(parts)
+        ext = _ops._ext.module()
+        if fold is None and ext is not None and hasattr(ext, "pack_params") and all(t is not None for t in tensors):
+            packed = ext.pack_params(list(tensors))     # (one autograd node: every parameter's gradient a view)
+        else:
+            parts = [t.reshape(-1) if t is not None else torch.zeros(n, device=dev)
+                     for t, n in zip(tensors, sizes)]
+            if fold is not None:
+                parts = self._folded_parts(cfg, tensors, parts)
+            packed = torch.cat(parts)
         if cfg.learned_sel is not None:
             assert packed.numel() == cfg.P_total, "edge network does not have the fused kernels' layout"
         used = [False]
-        gated = holder = None
         if packed.requires_grad:
             packed.register_hook(lambda g: used.__setitem__(0, True))
-            holder = _ops.SlabHolder(cfg.P_total if cfg.learned_sel is not None else cfg.P, dev)
-            gated = _ops.param_gate(packed, holder)
+        # (the gate of the per-step fused nodes - _gate() - is made when one of them first asks for it)
+        gate = [None, None, cfg.P_total if cfg.learned_sel is not None else cfg.P, dev]
         for d in cfg.descs:               # a re-assigned dist_param must not leave a stale pointer
             if d.kind == _hip.SEL_DISTANCE:
                 cfg.refresh_pointers()
                 break
         self._packed_cache = (key, packed, used,
-                              [(t, t._version if t is not None else 0) for t in tensors], gated, holder)
+                              [(t, t._version if t is not None else 0) for t in tensors], gate)
         return packed
+
+    def _gate(self):
+        """(gated packed vector, slab holder) of the current packed vector - what the per-step fused nodes consume
+        the parameters through in grad mode (_ops._ParamGate: their parameter-gradient slabs summed once) - or
+        (None, None) without gradients.  Made on first use: the live-row and rollout paths never ask."""
+        pc = self._packed_cache
+        g = pc[4]
+        if g[0] is None and pc[1].requires_grad:
+            g[1] = _ops.SlabHolder(g[2], g[3])
+            g[0] = _ops.param_gate(pc[1], g[1])
+        return g[0], g[1]
 
     @staticmethod
     def _folded_parts(cfg, tensors, parts):
@@ -623,8 +637,6 @@ class DenseGCM(torch.nn.Module):
         travels with the hidden state in compact form (`_gcm_dchain` on the adjacency tensor)."""
         nodes, adj, weights, num_nodes = hidden
         root = self._packed_params(cfg, head=link is None)
-        pc = self._packed_cache
-        gated, holder = pc[4], pc[5]
         B = x.shape[0]
         sel = cfg.learned_sel
         if sel.noise_fn is not None:      # injected gumbel draws (parity tests); values of the argument unspecified
@@ -677,7 +689,8 @@ class DenseGCM(torch.nn.Module):
                 if self.finite_check != "off":
                     self._poll(flags)
                 return mx, hidden
-        elif gated is not None:
+        elif self._gate()[0] is not None:
+            gated, holder = self._gate()
             is_head = link is None or link[5] is not root
             dchain = getattr(adj, "_gcm_dchain", None) if not is_head else None
             if dchain is None:
@@ -699,7 +712,7 @@ class DenseGCM(torch.nn.Module):
 
     def _forward_fused(self, x, nodes, adj, weights, num_nodes, cfg, flags, link=None):
         root = self._packed_params(cfg, head=link is None)
-        gated, holder = self._packed_cache[4], self._packed_cache[5]
+        gated, holder = self._gate()
         # In grad mode the steps consume the parameter vector through a gate node and accumulate
         # their parameter-gradient slabs into ONE array of the module (summed once by the gate,
         # _ops._ParamGate) instead of returning T gradients for the engine to add.
