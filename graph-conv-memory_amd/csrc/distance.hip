@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   if (TAIL && tl.cur_host >= 0) cur = tl.cur_host < N ? tl.cur_host : N - 1;   // (uniform; no load behind it)
   else cur = view_cur(vw, b, N, sh);
   const int nb = dist_out ? RB / 32 : max(0, min(RB / 32, (cur - j0 + 31) / 32));   // live 32-row blocks
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sN = smem;                   // [RB][NS]      node rows (scaled)
   float* sC = sN + RB * NS;           // [2][FP][CS]   current rows, transposed, two chunks of CB graphs
   float* sNn = sC + 2 * FP * CS;      // [RB]   |n|^2
@@ -420,6 +420,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float* sPart = sCn + 2 * CB;        // [4][RB] row sums per column tile
   float* sW = sPart + 4 * RB;         // TAIL: [2 FP + 64][32] W_rel1 | W_root1 (k < FP each) | W_rel2 | W_root2 (k < 32 each), k-major
   float* sDec = sW + (2 * FP + 64) * 32;   // TAIL: [RB] this step's decisions
+  float* sHc = sDec + RB;                  // TAIL: [N][H1] the h1 cache of this graph (flat copy; H1 % 4 == 0)
 
   const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
   const float* crows = vw.cur_rows ? vw.cur_rows : vw.obs;
@@ -477,6 +478,9 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   // (Tried in round 4: both chunks of current rows staged before the one barrier - they fit the two LDS buffers at
   //  Bc <= 256 - and no barrier per chunk, hoping the four waves of a SIMD would drift apart and overlap one's sqrt
   //  epilogue with another's MFMA chain: they start in lockstep and stay there, and the longer staging cost 1 us.)
+  // TAIL: the observation of this graph, for the cached step behind the decisions (requested now: one register)
+  float pf_xc = 0.f;
+  if (TAIL && wave == 0) pf_xc = vw.obs[(unsigned)b * (unsigned)F + (unsigned)(lane < F ? lane : F - 1)];
   DSTAMP(0);
   {
     // the first chunk of current rows (its addresses do not depend on this graph's fill level: in flight while
@@ -551,6 +555,29 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     if (c0 == 0) DSTAMP(4);
   }
   DSTAMP(5);
+  // TAIL: what the cached step behind the decisions reads that does not depend on them - the four weight matrices
+  // (lane-major image) and the h1 cache of this graph - is requested HERE by all sixteen waves (the MFMA operands'
+  // registers are free; the round trip runs under the reductions below) and stored to LDS behind the next barrier:
+  // the tail used to start with these round trips, wave 0 with one more per eight selected rows.
+  constexpr int WN = (2 * FP + 64) * 32, NIW = WN / NT;
+  static_assert(WN % NT == 0, "whole rounds of the workgroup over the weight image");
+  float pfw[NIW];
+  float4 pfh;
+  const bool hc_lds = TAIL && (tl.H1 & 3) == 0 && N * tl.H1 <= 4 * NT;   // h1 cache staged in LDS
+  if (TAIL) {
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int e = tid + i * NT;
+      const int k = e >> 5, h = e & 31;                     // row k of the k-major image, output h
+      const int m = k < FP ? 0 : (k < 2 * FP ? 1 : (k < 2 * FP + 32 ? 2 : 3));
+      const int kk = m == 0 ? k : (m == 1 ? k - FP : (m == 2 ? k - 2 * FP : k - 2 * FP - 32));
+      pfw[i] = tl.image[m * 4096 + kk * 64 + h];
+    }
+    if (hc_lds) {
+      const int n4 = N * tl.H1 / 4;
+      pfh = reinterpret_cast<const float4*>(tl.cH + (size_t)b * N * tl.H1)[tid < n4 ? tid : n4 - 1];
+    }
+  }
   // sum over the 32 columns held by the lanes of each half-wave, then the four column tiles in fixed order
   if (rb < nb) {
     // (on the DPP path: sixteen waves' butterflies through ds_bpermute are 300 KB of LDS crossbar traffic)
@@ -569,6 +596,11 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
 #undef GCM_DPP_ADD
   }
   __syncthreads();
+  if (TAIL) {
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) sW[tid + i * NT] = pfw[i];
+    if (hc_lds && tid < N * tl.H1 / 4) reinterpret_cast<float4*>(sHc)[tid] = pfh;
+  }
   if (tid < RB && tid < 32 * nb) {
     const int j = j0 + tid;
     if (j < N) {
@@ -593,21 +625,43 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const int fl = lane < F ? lane : F - 1, hl = lane & 31, kh = lane >> 5;
     const int64_t n64 = tl.cur_host >= 0 ? (int64_t)tl.cur_host : vw.count[b];
     const bool bad = n64 < 0 || n64 >= N;                     // (a chain from empty graphs never rolls)
+    if (wave != 0) return;                                    // (their share was done at kernel start)
     unsigned long long m0 = 0, m1 = 0;
-    float agg1 = 0.f, agg2 = 0.f, xc = 0.f;
+    float agg1 = 0.f, agg2 = 0.f;
+    const float xc = pf_xc;
     float* sv = sPart;                                        // (free: every row sum has been read)
-    if (wave != 0) {
-      constexpr int WN = (2 * FP + 64) * 32;
-      for (int e = tid - 64; e < WN; e += NT - 64) {
-        const int k = e >> 5, h = e & 31;                     // row k of the k-major image, output h
-        const int m = k < FP ? 0 : (k < 2 * FP ? 1 : (k < 2 * FP + 32 ? 2 : 3));
-        const int kk = m == 0 ? k : (m == 1 ? k - FP : (m == 2 ? k - 2 * FP : k - 2 * FP - 32));
-        sW[e] = tl.image[m * 4096 + kk * 64 + h];
+    m0 = __ballot(!bad && lane < cur && sDec[lane] != 0.f);
+    m1 = __ballot(!bad && lane + 64 < cur && lane + 64 < RB && sDec[(lane + 64) & (RB - 1)] != 0.f);
+    const int hc = hl < H1 ? hl : H1 - 1;
+    if (hc_lds && !dist_param && sh == 0) {
+      // the selected rows as a compact ascending list (every selected lane writes its row at its rank), gathered
+      // from the LDS images - the node rows staged for the distances, the h1 cache staged at kernel start - eight
+      // per trip, added in ascending order.  (Was: a find-first-bit chain over the masks and a GLOBAL round trip
+      // per eight rows - a cluster of dozens of near neighbours cost the tail several of them.)
+      const int n0 = __popcll(m0), n_sel = n0 + __popcll(m1);
+      int* sIdx = reinterpret_cast<int*>(sPart + 2 * RB);     // [RB]
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if ((m0 >> lane) & 1ull) sIdx[__popcll(m0 & below)] = lane;
+      if ((m1 >> lane) & 1ull) sIdx[n0 + __popcll(m1 & below)] = lane + 64;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int q0 = 0; q0 < n_sel; q0 += 8) {
+        const int4 ia = *reinterpret_cast<const int4*>(sIdx + q0), ib = *reinterpret_cast<const int4*>(sIdx + q0 + 4);
+        const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        float bx[8], bh[8];
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+          const bool any = q0 + qq < n_sel;
+          const int j = any ? js[qq] : 0;
+          const float tx = sN[j * NS + fl], th = sHc[j * H1 + hc];
+          bx[qq] = any ? tx : 0.f;
+          bh[qq] = any ? th : 0.f;
+        }
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) { agg1 += bx[qq]; agg2 += bh[qq]; }
       }
     } else {
-      xc = vw.obs[gb * (unsigned)F + fl];
-      m0 = __ballot(!bad && lane < cur && sDec[lane] != 0.f);
-      m1 = __ballot(!bad && lane + 64 < cur && lane + 64 < RB && sDec[(lane + 64) & (RB - 1)] != 0.f);
       unsigned long long a0 = m0, a1 = m1;
       while (a0 | a1) {          // eight rows per round trip, added in ascending order
         float bx[8], bh[8];
@@ -619,19 +673,19 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
           a0 &= low ? a0 - 1 : a0;
           a1 &= (low || !any) ? a1 : a1 - 1;
           const unsigned rj = gb * (unsigned)N + (unsigned)j;
-          const float tx = tl.nodes[rj * F + fl], th = tl.cH[rj * H1 + (hl < H1 ? hl : H1 - 1)];
+          const float tx = tl.nodes[rj * F + fl], th = tl.cH[rj * H1 + hc];
           bx[qq] = any ? tx : 0.f;
           bh[qq] = any ? th : 0.f;
         }
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) { agg1 += bx[qq]; agg2 += bh[qq]; }
       }
-      agg1 = lane < F ? agg1 : 0.f;
-      agg2 = lane < H1 ? agg2 : 0.f;
-      if (lane < FP) { sv[lane] = lane < F ? agg1 : 0.f; sv[FP + lane] = lane < F ? xc : 0.f; }
     }
-    __syncthreads();
-    if (wave != 0) return;
+    agg1 = lane < F ? agg1 : 0.f;
+    agg2 = lane < H1 ? agg2 : 0.f;
+    if (lane < FP) { sv[lane] = lane < F ? agg1 : 0.f; sv[FP + lane] = lane < F ? xc : 0.f; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const float* b1p = tl.params + 2 * (size_t)H1 * F;
     const float* b2p = b1p + H1 + 2 * (size_t)H2 * H1;
     const float bias1 = b1p[hl < H1 ? hl : H1 - 1], bias2 = b2p[hl < H2 ? hl : H2 - 1];
@@ -870,7 +924,7 @@ extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, flo
   constexpr int RB = 128;
   const int FT = F / 32;
   const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
-                                      (size_t)4 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB);
+                                      (size_t)4 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32);
   hipStream_t s = (hipStream_t)stream;
   if (FT == 1) {
     auto kern = k_euclid_mfma2<1, true>;
