@@ -625,7 +625,8 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const int fl = lane < F ? lane : F - 1, hl = lane & 31, kh = lane >> 5;
     const int64_t n64 = tl.cur_host >= 0 ? (int64_t)tl.cur_host : vw.count[b];
     const bool bad = n64 < 0 || n64 >= N;                     // (a chain from empty graphs never rolls)
-    if (wave != 0) return;                                    // (their share was done at kernel start)
+    if (wave != 0) return;                                    // (their share was done behind the MFMA loop)
+    DSTAMP(7);
     unsigned long long m0 = 0, m1 = 0;
     float agg1 = 0.f, agg2 = 0.f;
     const float xc = pf_xc;
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     if (lane < FP) { sv[lane] = lane < F ? agg1 : 0.f; sv[FP + lane] = lane < F ? xc : 0.f; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    DSTAMP(8);
     const float* b1p = tl.params + 2 * (size_t)H1 * F;
     const float* b2p = b1p + H1 + 2 * (size_t)H2 * H1;
     const float bias1 = b1p[hl < H1 ? hl : H1 - 1], bias2 = b2p[hl < H2 ? hl : H2 - 1];
@@ -715,6 +717,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       p1 += bias1;
     }
     const float h1c = hl < H1 ? gcm_act_sel(p1, act1_v) : 0.f;   // (both halves hold h1c[lane & 31])
+    DSTAMP(9);
     // (one wave: its LDS operations execute in order - the reads above are done before these writes land)
     if (lane < 32) { sv[lane] = agg2; sv[32 + lane] = h1c; }
     // layer 2: lanes 0-31 W_rel2 . agg2, lanes 32-63 W_root2 . h1cur
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       p2 = pa + __shfl_xor(pa, 32) + bias2;
     }
     const float v = gcm_act_sel(p2, act2_v);
+    DSTAMP(10);
     const unsigned rc = gb * (unsigned)N + (unsigned)cur;
     if (!bad) {
       if (lane < F) {
@@ -773,6 +777,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const bool nonfinite = __any(lane < H2 && !isfinite(v));
     if ((nonfinite || bad) && lane == 0)
       atomicOr(tl.flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
+    DSTAMP(11);
   }
 }
 
