@@ -785,30 +785,54 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
 
     # ---- the steady-state regime ("also T=256"): after t >= graph_size every step drops every graph's
     # oldest node (gcm.py:263-271, 323-355) - the normal regime of a long RL rollout --------------------------------
-    if c["selector"] == "temporal" and T <= N and not args.headline_only:
+    t256_table = None
+    if T <= N and not args.headline_only:
         from gcm.gcm import DenseGCM
         DenseGCM.did_warn = True     # (the reference's one-time overflow notice is a print: stdout stays ONE JSON line)
         T2 = 2 * N
         obs2 = make_obs(dict(c, T=T2), rank, device)
-        mem_2, gnn_2, _ = build_memory(device, donate=True, selector=c["selector"], cfg=c)
-        g2 = capture(lambda: rollout(mem_2, obs2), lambda: gnn_2.zero_grad(set_to_none=True))
+        mem_2, gnn_2, sel_2 = build_memory(device, donate=True, selector=c["selector"], cfg=c)
+        mods_2 = [gnn_2] + ([sel_2] if c["selector"] == "learned" else [])
+
+        def zero_2():
+            for q in mods_2:
+                q.zero_grad(set_to_none=True)
+        g2 = capture(lambda: rollout(mem_2, obs2), zero_2)
         variants["T%d_graph_donated" % T2] = world * B * T2 * side / timed(g2.replay, side, 2)
         variants["T%d_steady_state_step_us" % T2] = None     # (filled from the kernel profile below)
         if rank == 0:
             p2 = profile_kernels(g2.replay, reps=2)
-            kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_rows<")
-            if kr is not None:
-                variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
-                variants["T%d_steady_state_kernel" % T2] = kr[0]
+            if c["selector"] == "temporal":
+                kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_rows<")
+                if kr is not None:
+                    variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
+                    variants["T%d_steady_state_kernel" % T2] = kr[0]
+            else:
+                # the kernels that run T2 - N times per rollout are the steady-state step's (the first N steps run the
+                # cached kernels of the headline): their mean durations add up to the steady-state step
+                ss = {k: d for k, d in p2.items() if abs(d["launches_per_call"] - (T2 - N)) < 0.5}
+                variants["T%d_steady_state_step_us" % T2] = round(sum(d["avg_us"] for d in ss.values()), 3) if ss else None
+                variants["T%d_steady_state_kernels" % T2] = {k: round(d["avg_us"], 3) for k, d in ss.items()}
+                t256_table = kernel_table(p2, top=8)[0]
         del g2
 
         def eager2(m, gn, bk):
+            sels = [m.edge_selectors] if c["selector"] == "learned" else []
+
             def f():
                 rollout(m, obs2, bk, weight)
                 gn.zero_grad(set_to_none=True)
+                for q in sels:
+                    q.zero_grad(set_to_none=True)
             return f
         variants["T%d_eager_donated" % T2] = world * B * T2 * side / timed(eager2(mem_e, gnn_e, bucket_e), side, 1)
         variants["T%d_eager_functional" % T2] = world * B * T2 * side / timed(eager2(mem_f, gnn_f, bucket_f), side, 1)
+        if c["selector"] != "temporal":
+            def roll2():
+                rollout_api(mem_f, obs2, bucket_f, weight)
+                for q in mods_f:
+                    q.zero_grad(set_to_none=True)
+            variants["T%d_rollout_api" % T2] = world * B * T2 * side / timed(roll2, side, 1)
         mem_e.check_flags()
         mem_f.check_flags()
 
@@ -1019,6 +1043,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         "kernel_ms": kernel_ms,
         "kernel_table": {"rows": table, "gpu_us_per_step": round(gpu_us, 2), "source": src},
     })
+    if t256_table is not None:
+        line["T%d_kernel_table" % (2 * N)] = t256_table
     if layered is not None:
         line["layered_path"] = dict(layered, note="the same shapes through GNNs the fused step does not cover (three "
                                                   "DenseGraphConv layers; the canonical two with pooled=True): one "

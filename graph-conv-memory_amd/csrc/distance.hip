@@ -514,11 +514,16 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float rowsum[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
-  float av[FP / 2];   // A(i = row, k = f): this wave's 32 node rows, in registers for every chunk
+  // The squared norms ride in the product as one more k step: A'(i, .) = [-2 n_i | |n_i|^2, 1], B'(., j) = [c_j | 1, |c_j|^2],
+  // so the accumulator IS |n|^2 + |c|^2 - 2 n.c (the epilogue is max / sqrt / add per element: it had been as long as
+  // the MFMA chain).  Same arithmetic, value for value, as the time-parallel form (euclid_tp.hip: k_euclid_tp).
+  constexpr int KQ = FP / 2;
+  float av[KQ + 1];   // A'(i = row, k): this wave's 32 node rows, in registers for every chunk
   if (rb < nb) {
     const float* ap = sN + (rb * 32 + li) * NS + lh;
 #pragma unroll
-    for (int q = 0; q < FP / 2; ++q) av[q] = ap[2 * q];
+    for (int q = 0; q < KQ; ++q) av[q] = -2.f * ap[2 * q];
+    av[KQ] = lh ? 1.f : sNn[rb * 32 + li];
   }
 
   int buf = 0;
@@ -528,26 +533,23 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     if (has_next) load_chunk(c0 + CB, vnext);
     const float* sCb = sC + buf * FP * CS;
     if (c0 + ct * 32 < Bc && rb < nb) {   // this wave's column tile holds graphs, and its row block is live
-      float bq[FP / 2];
+      float bq[KQ + 1];
       {
-        const float* bp = sCb + lh * CS + ct * 32 + li;   // B(k = f, j = b')
+        const float* bp = sCb + lh * CS + ct * 32 + li;   // B'(k, j = b')
 #pragma unroll
-        for (int q = 0; q < FP / 2; ++q) bq[q] = bp[2 * q * CS];
+        for (int q = 0; q < KQ; ++q) bq[q] = bp[2 * q * CS];
+        bq[KQ] = lh ? sCn[buf * CB + ct * 32 + li] : 1.f;
       }
-      const float cn = sCn[buf * CB + ct * 32 + li];
       const float keep = c0 + ct * 32 + li < Bc ? 1.f : 0.f;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int q = 0; q < FP / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[q], acc, 0, 0, 0);
+      for (int q = 0; q <= KQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[q], acc, 0, 0, 0);
       // v_sqrt_f32 (1 ulp) instead of the correctly rounded library routine (a dozen instructions)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float nn = sNn[rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];   // (16 more registers would spill)
-        const float d2 = fmaf(-2.f, acc[r], nn + cn);
-        rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(d2, 0.f)), rowsum[r]);
-      }
+      for (int r = 0; r < 16; ++r)
+        rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(acc[r], 0.f)), rowsum[r]);
     }
     if (c0 == 0) DSTAMP(3);
     if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c0 + CB, vnext);

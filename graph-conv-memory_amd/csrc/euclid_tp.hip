@@ -1,0 +1,479 @@
+// Time-parallel DenseGCM rollout with EuclideanEdge (round 5): DenseGCM.rollout(obs[T,B,F]) from EMPTY graphs with
+// EuclideanEdge (edge_selectors/distance.py:18-49, cross-batch mean, not bidirectional) as the only selector and
+// observations that carry no gradient (ray_gcm.py:186-209 hands the whole [B, T, F] block over).
+//
+// The reference walks the T steps one after the other: step t inserts observation t as node t, takes the distances
+// of the current nodes of ALL graphs against every stored node of each graph (cdist + mean over b'), thresholds, and
+// runs the GNN.  The per-step kernel (distance.hip: k_euclid_mfma2) follows that chain - one [N x F].[F x B]
+// contraction per graph and step behind a launch, a staging round trip and a serial tail: 19 us x T.  But nothing
+// in the selection of step t depends on another step's RESULT: node j is observation j, the current rows of step
+// t are obs[t, :, :].  So all T selections of a graph are ONE causal contraction
+//
+//     S[b, t, j] = sum_{b'} || obs[t, b'] - obs[j, b] ||            j < t (and j > t - N once the graph rolls)
+//
+// i.e. [N x F] . [F x (T B)] per graph, GEMM-shaped and MFMA-bound with no latency chain:
+//
+//   k_euclid_tp      one workgroup (16 waves) per graph, persistent over the T steps.  The graph's nodes sit in an
+//                    LDS RING (node n in slot n mod N - the overflow roll of gcm.py:323-355 becomes "the slot of
+//                    node t - N is dead at step t and is overwritten by node t"), wave w = (column tile w & 3,
+//                    slot block w >> 2) keeps its 32 slots as the MFMA A operand in registers (re-read when a node
+//                    is inserted into its block), the current rows of (step, 128-graph chunk) stream through two LDS
+//                    buffers shared by all slot blocks; v_mfma_f32_32x32x2_f32 with the squared norms folded in as
+//                    one more k step (A' = [-2a | |a|^2 | 1], B' = [c | 1 | |c|^2]: the accumulator IS d^2), sqrt
+//                    and the sum over b' on the accumulators, the four column tiles of a step met in LDS in fixed
+//                    order - the arithmetic of k_euclid_mfma2, value for value: the same distances bit for bit, hence
+//                    the same decisions as T single steps.  Output: decision BITS [T, B, 4] (ring slot s of step t).
+//   k_euclid_tp_gnn  (T <= N) one workgroup per graph: with the adjacency known the GNN is time-parallel too (rows
+//                    of layer 1 are final once written: a distance selector that is not bidirectional writes row cur
+//                    only) - agg1 = Dec X, h1 = act1([agg1 | x] W1^T + b1), agg2 = Dec h1, mx = act2([agg2 | h1] W2^T
+//                    + b2) as four products on the matrix cores with the 0 / 1 operand expanded from the bits; the
+//                    chain's caches [B, Tc, .], the step records gcm_dense_rows_bptt_cached reads (N := Tc), the
+//                    beliefs [T, B, H2] and the final state (nodes, adj, count) written whole.
+#include "fused_common.h"
+#include "gcm_common.h"
+#include "rows_common.h"
+
+namespace gcm_etp {
+
+using gcm_fused::acc_row;
+using gcm_fused::mma32;
+
+// ---------------------------------------------------------------------------------------------------------
+template <int FT>
+__global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ obs, const float* __restrict__ dist_param,
+                                                    float max_distance, uint32_t* __restrict__ decbits, int T, int B, int N,
+                                                    int F) {
+  constexpr int FP = 32 * FT, NS = FP + 1, RB = 128, CB = 128, CS = CB + 1, NT = 1024, KQ = FP / 2;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int ct = wave & 3, rb = wave >> 2;   // SIMD = column tile, its four waves = the slot blocks
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sN = smem;                    // [RB][NS]      ring image of the graph's nodes, scaled, times -2
+  float* sC = sN + RB * NS;            // [2][FP][CS]   current rows, transposed, two chunks of CB graphs
+  float* sNn = sC + 2 * FP * CS;       // [RB]     |n|^2
+  float* sCn = sNn + RB;               // [2][CB]  |c|^2
+  float* sPart = sCn + 2 * CB;         // [2][4][RB] row sums per column tile, two steps
+
+  const float den = dist_param ? dist_param[0] : 1.f;
+  // staging: thread = SEG consecutive features (segment tid & 7) of row tid >> 3 of a 128-row tile (distance.hip)
+  constexpr int SEG = FP / 8;
+  static_assert(CB * FP == NT * SEG, "one segment per thread");
+  const int srow = tid >> 3, sf0 = (tid & 7) * SEG;
+  const bool vec4 = (F & 3) == 0;
+  auto load_seg = [&](const float* __restrict__ row, float (&v)[SEG]) __attribute__((always_inline)) {
+    if (vec4) {
+#pragma unroll
+      for (int k = 0; k < SEG; k += 4) {
+        const int f = sf0 + k < F ? sf0 + k : F - 4;
+        const float4 t = *reinterpret_cast<const float4*>(row + f);
+        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG; ++k) v[k] = row[sf0 + k < F ? sf0 + k : F - 1];
+    }
+  };
+  auto seg_norm = [&](const float (&v)[SEG]) __attribute__((always_inline)) {
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) q = fmaf(v[k], v[k], q);
+    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return q;
+  };
+  auto load_chunk = [&](int t, int c0, float (&v)[SEG]) __attribute__((always_inline)) {
+    const int g = c0 + srow < B ? c0 + srow : B - 1;
+    load_seg(obs + ((size_t)t * B + g) * F, v);
+  };
+  auto store_chunk = [&](float* dst, float* dst_n, int c0, float (&v)[SEG]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+      const float t = dist_param ? v[k] / den : v[k];
+      v[k] = (sf0 + k < F && c0 + srow < B) ? t : 0.f;
+      dst[(sf0 + k) * CS + srow] = v[k];
+    }
+    const float q = seg_norm(v);
+    if ((tid & 7) == 0) dst_n[srow] = q;
+  };
+  // node n of this graph (= observation n) into ring slot n mod N: the threads of staging row 0 (tid < 8)
+  auto insert_node = [&](int slot, float (&v)[SEG]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+      const float t = dist_param ? v[k] / den : v[k];
+      v[k] = sf0 + k < F ? t : 0.f;
+    }
+    const float q = seg_norm(v);
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) sN[slot * NS + sf0 + k] = -2.f * v[k];
+    if (tid == 0) sNn[slot] = q;
+  };
+
+  const int nch = (B + CB - 1) / CB;                 // chunks of current rows per step
+  const int tiles = (B + 31) / 32 < 4 ? (B + 31) / 32 : 4;   // column tiles that ever hold graphs
+  const int R = (T - 1) * nch;                        // rounds: (t = 1 .. T - 1) x chunks
+  const int b_chunk = b / CB, b_row = b % CB;         // where this graph's own current row sits in a step's chunks
+  if (tid < 4) decbits[((size_t)0 * B + b) * 4 + tid] = 0u;   // step 0: no candidates
+  for (int e = tid; e < RB * NS; e += NT) sN[e] = 0.f;
+  if (tid < RB) sNn[tid] = 0.f;
+  __syncthreads();
+  if (R > 0) {
+    float vc[SEG], vn[SEG];
+    load_chunk(1, 0, vc);
+    if (tid < 8) load_seg(obs + (size_t)b * F, vn);
+    asm volatile("" ::: "memory");
+    store_chunk(sC, sCn, 0, vc);
+    if (tid < 8) insert_node(0, vn);
+  }
+  __syncthreads();
+
+  // decisions of step t from the four tiles' row sums: threads 0 .. 127 = ring slots
+  auto finalize = [&](int t) __attribute__((always_inline)) {
+    const float* p = sPart + (t & 1) * 4 * RB;
+    float tot = p[tid];
+    for (int q = 1; q < tiles; ++q) tot += p[q * RB + tid];
+    const float d = tot / (float)B;
+    const bool valid = tid < N && (t < N ? tid < t : tid != t % N);
+    const unsigned long long m = __ballot(valid && d < max_distance);
+    if (lane == 0) {
+      uint32_t* o = decbits + ((size_t)t * B + b) * 4 + 2 * wave;
+      o[0] = (uint32_t)m;
+      o[1] = (uint32_t)(m >> 32);
+    }
+  };
+
+  float rowsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
+  float av[KQ + 1];   // A'(i = slot, k): -2 x the wave's 32 slots' rows | (|n|^2, 1)
+#pragma unroll
+  for (int q = 0; q <= KQ; ++q) av[q] = 0.f;
+
+  int t = 1, c = 0, buf = 0;
+#pragma unroll 1
+  for (int g = 0; g < R; ++g, buf ^= 1) {
+    const bool first = c == 0, last = c == nch - 1, has_next = g + 1 < R;
+    const int t2 = last ? t + 1 : t, c2 = last ? 0 : c + 1;
+    float vnext[SEG];
+    if (has_next) load_chunk(t2, c2 * CB, vnext);
+    if (first && t >= 2 && tid < RB) finalize(t - 1);
+    if (first && (t == 1 || rb == (((t - 1) % N) >> 5))) {   // (wave-uniform) node t - 1 went into this wave's block
+      const float* ap = sN + (rb * 32 + li) * NS + lh;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) av[q] = ap[2 * q];
+      av[KQ] = lh ? 1.f : sNn[rb * 32 + li];
+    }
+    const int lim = t < N ? t : N;
+    const bool live = rb * 32 < lim;                        // the block holds a candidate slot
+    const int col0 = c * CB + ct * 32;
+    if (live && col0 < B) {
+      const float* sCb = sC + buf * FP * CS;
+      float bq[KQ + 1];
+      {
+        const float* bp = sCb + lh * CS + ct * 32 + li;     // B'(k, j = b')
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) bq[q] = bp[2 * q * CS];
+        bq[KQ] = lh ? sCn[buf * CB + ct * 32 + li] : 1.f;
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q <= KQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[q], acc, 0, 0, 0);
+      // acc = |n|^2 + |c|^2 - 2 n.c; v_sqrt_f32 (1 ulp), summed over b' per lane (columns), chunks in sequence
+      const float keep = col0 + li < B ? 1.f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(acc[r], 0.f)), rowsum[r]);
+    }
+    if (last && live) {
+      // sum over the 32 columns held by the lanes of each half-wave (DPP path), then the tiles in fixed order
+      float* p = sPart + (t & 1) * 4 * RB + ct * RB + rb * 32;
+#define GCM_DPP_ADD(v, ctrl, rmask) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = rowsum[r];
+        GCM_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+        GCM_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+        GCM_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+        GCM_DPP_ADD(v, 0x140, 0xF);   // row_mirror
+        GCM_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 into rows 1 and 3: lanes 16..31 / 48..63 hold the 32-lane sums
+        if (li == 16) p[(r & 3) + 8 * (r >> 2) + 4 * lh] = v;
+        rowsum[r] = 0.f;
+      }
+#undef GCM_DPP_ADD
+    }
+    // node t (a candidate from step t + 1 on) IS current row b of step t: copied from the chunk that holds it into
+    // ring slot t mod N - dead at step t (it held node t - N), so whoever still reads it masks it
+    if (c == b_chunk && wave == 15 && lane < FP) {
+      const float* sCb = sC + buf * FP * CS;
+      sN[(t % N) * NS + lane] = -2.f * sCb[lane * CS + b_row];
+      if (lane == 0) sNn[t % N] = sCn[buf * CB + b_row];
+    }
+    if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c2 * CB, vnext);
+    __syncthreads();   // round g is consumed; the next chunk, the inserted node and the row sums are in LDS
+    t = t2;
+    c = c2;
+  }
+  if (T >= 2 && tid < RB) finalize(T - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The GNN over all T <= N steps of one graph, adjacency given as decision bits (ring slot = node index here).
+template <int FP, int HP>
+__global__ __launch_bounds__(256) void k_euclid_tp_gnn(
+    const float* __restrict__ obs, const uint32_t* __restrict__ decbits, const float* __restrict__ params, int act1,
+    int act2, float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ nodes_out,
+    float* __restrict__ adj_out, int64_t* __restrict__ count_out, float* __restrict__ mx_all, float* __restrict__ rec0,
+    size_t rec_stride, gcm_rows::CachedLayout lay, int record, uint32_t* __restrict__ flags, int T, int B, int N, int Tc,
+    int F, int H1, int H2) {
+  constexpr int XS = FP + 1, HS = HP + 1, W2S = 65, AS = (FP > HP ? FP : HP) + 1;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;                       // [128][XS]   x rows (node t = observation t)
+  float* sA = sX + 128 * XS;              // [128][AS]   agg1, later agg2 (first HP columns)
+  float* sH = sA + 128 * AS;              // [128][HS]   h1
+  float* sW1 = sH + 128 * HS;             // [2 FP][HS]  k < FP: W_rel1[n][k], else W_root1[n][k - FP]
+  float* sW2 = sW1;                       // [2 HP][W2S] k < HP: W_rel2[n][k], else W_root2[n][k - HP] - staged behind layer 1
+  constexpr int WSZ = 2 * FP * HS > 2 * HP * W2S ? 2 * FP * HS : 2 * HP * W2S;
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(sW1 + WSZ);   // [128][4]
+
+  const int F4 = F >> 2;
+  // ---- stage: x rows (zero-padded), the weights, the bits ----
+  for (int e = tid; e < 128 * XS; e += 256) sX[e] = 0.f;
+  for (int e = tid; e < 128 * AS; e += 256) sA[e] = 0.f;
+  for (int e = tid; e < 128 * HS; e += 256) sH[e] = 0.f;
+  for (int e = tid; e < 128 * 4; e += 256) {
+    const int t = e >> 2;
+    sBits[e] = t < T ? decbits[((size_t)t * B + b) * 4 + (e & 3)] : 0u;
+  }
+  __syncthreads();
+  for (int e = tid; e < T * F4; e += 256) {
+    const int t = e / F4, c4 = e - t * F4;
+    const float4 v = *reinterpret_cast<const float4*>(obs + ((size_t)t * B + b) * F + 4 * c4);
+    float* d = sX + t * XS + 4 * c4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    *reinterpret_cast<float4*>(cX + ((size_t)b * Tc + t) * F + 4 * c4) = v;
+    *reinterpret_cast<float4*>(nodes_out + ((size_t)b * N + t) * F + 4 * c4) = v;
+  }
+  for (int e = tid; e < (N - T) * F4; e += 256)      // rows the rollout did not reach stay empty
+    *reinterpret_cast<float4*>(nodes_out + ((size_t)b * N + T) * F + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = tid; e < 2 * FP * HP; e += 256) {
+    const int m = e / (FP * HP), rem = e - m * FP * HP, n = rem / FP, k = rem % FP;
+    sW1[(m * FP + k) * HS + n] = (n < H1 && k < F) ? params[(size_t)m * H1 * F + (size_t)n * F + k] : 0.f;
+  }
+  const float* w2 = params + 2 * (size_t)H1 * F + H1;
+  const float* b1 = params + 2 * (size_t)H1 * F;
+  const float* b2 = w2 + 2 * (size_t)H2 * H1;
+  if (tid == 0) count_out[b] = T;
+  // the final adjacency: row t = the decisions of step t, rows >= T empty
+  for (int e = tid; e < N * (N >> 2); e += 256) {
+    const int t = e / (N >> 2), j0 = (e - t * (N >> 2)) * 4;
+    const uint32_t w = t < T ? sBits[t * 4 + (j0 >> 5)] >> (j0 & 31) : 0u;
+    *reinterpret_cast<float4*>(adj_out + ((size_t)b * N + t) * N + j0) =
+        make_float4((w & 1u) ? 1.f : 0.f, (w & 2u) ? 1.f : 0.f, (w & 4u) ? 1.f : 0.f, (w & 8u) ? 1.f : 0.f);
+  }
+  if (N & 3) {                                        // (not taken by the host today: N % 4 == 0)
+    for (int e = tid; e < N * N; e += 256) {
+      const int t = e / N, j = e - t * N;
+      adj_out[((size_t)b * N + t) * N + j] = (t < T && ((sBits[t * 4 + (j >> 5)] >> (j & 31)) & 1u)) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int mt = wave;                       // this wave's 32 steps
+  const bool tile_live = mt * 32 < T;
+  const int trow = mt * 32 + li;             // A-operand row of this lane
+  uint32_t wl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wl[q] = sBits[trow * 4 + q] >> lh;   // bit (2 q' + lh) of word q -> bit 2 q' here
+  // acc += Dec[32 mt .., :] . S[:, col0 + li]   (S row stride ss): the 0 / 1 operand from the bits, causal blocks only
+  auto dec_mma = [&](f32x16& acc, const float* s, int ss, int col0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt <= mt) {
+        const float* bp = s + (kt * 32 + lh) * ss + col0 + li;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float a = (float)((wl[kt] >> (2 * q)) & 1u);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * q * ss], acc, 0, 0, 0);
+        }
+      }
+    }
+  };
+  // ---- agg1 = Dec X ----
+  if (tile_live) {
+#pragma unroll
+    for (int nt = 0; nt < FP / 32; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      dec_mma(acc, sX, XS, nt * 32);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = mt * 32 + acc_row(r, lh), f = nt * 32 + li;
+        sA[t * AS + f] = acc[r];
+        if (t < T && f < F) cA[((size_t)b * Tc + t) * F + f] = acc[r];
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- h1 = act1([agg1 | x] [W_rel1 | W_root1]^T + b1)   (this wave's own rows of sA / sX) ----
+  if (tile_live) {
+#pragma unroll
+    for (int nt = 0; nt < HP / 32; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      mma32(acc, sA + mt * 32 * AS, AS, 1, sW1 + nt * 32, HS, 1, FP, li, lh);
+      mma32(acc, sX + mt * 32 * XS, XS, 1, sW1 + FP * HS + nt * 32, HS, 1, FP, li, lh);
+      const int h = nt * 32 + li;
+      const float bias = h < H1 ? b1[h] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = mt * 32 + acc_row(r, lh);
+        const float v = (t < T && h < H1) ? gcm_act(acc[r] + bias, act1) : 0.f;
+        sH[t * HS + h] = v;
+        if (t < T && h < H1) cH[((size_t)b * Tc + t) * H1 + h] = v;
+      }
+    }
+  }
+  __syncthreads();   // agg2 reads the h1 rows of every earlier tile; layer 1's weights are done with
+  for (int e = tid; e < 2 * HP * 64; e += 256) {
+    const int m = e / (HP * 64), rem = e - m * HP * 64, n = rem / HP, k = rem % HP;
+    sW2[(m * HP + k) * W2S + n] = (n < H2 && k < H1) ? w2[(size_t)m * H2 * H1 + (size_t)n * H1 + k] : 0.f;
+  }
+  // ---- agg2 = Dec h1 ----
+  if (tile_live) {
+#pragma unroll
+    for (int nt = 0; nt < HP / 32; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      dec_mma(acc, sH, HS, nt * 32);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[(mt * 32 + acc_row(r, lh)) * AS + nt * 32 + li] = acc[r];
+    }
+  }
+  __syncthreads();   // layer 2's weights are staged
+  // ---- mx = act2([agg2 | h1] [W_rel2 | W_root2]^T + b2), the records ----
+  bool bad = false;
+  if (tile_live) {
+    const int n_out = (H2 + 31) / 32;
+    for (int nt = 0; nt < n_out; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      mma32(acc, sA + mt * 32 * AS, AS, 1, sW2 + nt * 32, W2S, 1, HP, li, lh);
+      mma32(acc, sH + mt * 32 * HS, HS, 1, sW2 + HP * W2S + nt * 32, W2S, 1, HP, li, lh);
+      const int col = nt * 32 + li;
+      const float bias = col < H2 ? b2[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = mt * 32 + acc_row(r, lh);
+        const float v = gcm_act(acc[r] + bias, act2);
+        if (t < T && col < H2) {
+          mx_all[((size_t)t * B + b) * H2 + col] = v;
+          rec0[(size_t)t * rec_stride + (size_t)b * H2 + col] = v;      // mx: the head of the record
+          bad = bad || !isfinite(v);
+        }
+      }
+    }
+    if (record) {
+      // v = agg2 | h1[cur]; the live list: the selected rows (ascending), row cur behind them
+      for (int e = lane; e < 32 * HP; e += 64) {
+        const int t = mt * 32 + e / HP, h = e % HP;
+        if (t < T && h < H1) {
+          float* v = rec0 + (size_t)t * rec_stride + lay.o_v + (size_t)b * 2 * H1;
+          v[h] = sA[t * AS + h];
+          v[H1 + h] = sH[t * HS + h];
+        }
+      }
+      if (lh == 0 && trow < T) {
+        float* rec = rec0 + (size_t)trow * rec_stride;
+        int* live = reinterpret_cast<int*>(rec + lay.o_live) + (size_t)b * Tc;
+        float* coef = rec + lay.o_coef + (size_t)b * Tc;
+        int l = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t w = sBits[trow * 4 + q];
+          while (w) {
+            const int j = q * 32 + __builtin_ctz(w);
+            w &= w - 1;
+            live[l] = j;
+            coef[l] = 1.f;
+            ++l;
+          }
+        }
+        live[l] = trow;
+        coef[l] = 0.f;
+        int* hdr = reinterpret_cast<int*>(rec + lay.o_hdr) + 4 * b;
+        hdr[0] = l + 1; hdr[1] = l; hdr[2] = trow; hdr[3] = 0;
+      }
+    }
+  }
+  if (__any(bad) && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+}
+
+}  // namespace gcm_etp
+
+/* EuclideanEdge alone (cross-batch mean over the B local graphs, not bidirectional), canonical two-layer GNN, from
+ * empty graphs: the time-parallel forms.  _decide: every step's decisions for any T (ring slots: node n in slot
+ * n mod N; at step t >= N the slot t mod N is dead).  _fwd: T <= N - the whole forward, two launches. */
+extern "C" int gcm_euclid_rollout_tp_supported(int T, int B, int N, int F, int H1, int H2) {
+  return !(T < 1 || B < 32 || B > 65535 || N < 1 || N > 128 || (N & 3) || F < 4 || F > 64 || (F & 3) || H1 < 1 ||
+           H1 > 64 || H2 < 1 || H2 > 64 || T > 65535);
+}
+
+extern "C" int gcm_euclid_rollout_tp_decide(const float* obs, float max_distance, const float* dist_param,
+                                            uint32_t* decbits, int T, int B, int N, int F, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && decbits);
+  if (!gcm_euclid_rollout_tp_supported(T, B, N, F, 32, 32)) return GCM_EUNSUPPORTED;
+  const int FT = (F + 31) / 32, FP = 32 * FT;
+  const size_t lds = sizeof(float) * ((size_t)128 * (FP + 1) + (size_t)2 * FP * 129 + 128 + 2 * 128 + (size_t)2 * 4 * 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (FT == 1) {
+    auto kern = gcm_etp::k_euclid_tp<1>;
+    gcm_allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, s, obs, dist_param, max_distance, decbits, T, B, N, F);
+  } else {
+    auto kern = gcm_etp::k_euclid_tp<2>;
+    gcm_allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, s, obs, dist_param, max_distance, decbits, T, B, N, F);
+  }
+  return gcm_launch_status();
+}
+
+extern "C" int gcm_euclid_rollout_tp_fwd(const float* obs, float max_distance, const float* dist_param,
+                                         const float* params, int act1, int act2, float* nodes, float* adj,
+                                         int64_t* count, float* cache_h1, float* cache_agg1, float* cache_nodes,
+                                         float* records, size_t rec_stride, int record, float* mx_all,
+                                         uint32_t* decbits, uint32_t* flags, int T, int B, int N, int Tc, int F, int H1,
+                                         int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && params && nodes && adj && count && cache_h1 && cache_agg1 && cache_nodes && records && mx_all &&
+              decbits && flags && Tc >= T);
+  if (!gcm_euclid_rollout_tp_supported(T, B, N, F, H1, H2) || T > N) return GCM_EUNSUPPORTED;
+  const gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, Tc, H1, H2);
+  GCM_REQUIRE(rec_stride >= (record ? lay.total : gcm_rows::pad64((size_t)B * H2)));
+  int rc = gcm_euclid_rollout_tp_decide(obs, max_distance, dist_param, decbits, T, B, N, F, stream);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int FP = F <= 32 ? 32 : 64, HP = H1 <= 32 ? 32 : 64;
+#define GCM_ETP_GNN(a, b_)                                                                                          \
+  if (FP == a && HP == b_) {                                                                                        \
+    auto k2 = gcm_etp::k_euclid_tp_gnn<a, b_>;                                                                      \
+    const size_t lds2 = sizeof(float) * ((size_t)128 * (a + 1) + (size_t)128 * ((a > b_ ? a : b_) + 1) +              \
+                                         (size_t)128 * (b_ + 1) +                                                   \
+                                         (2 * a * (b_ + 1) > 2 * b_ * 65 ? (size_t)2 * a * (b_ + 1) : (size_t)2 * b_ * 65) + 128 * 4);                                          \
+    gcm_allow_dynamic_lds((const void*)k2, lds2);                                                                   \
+    hipLaunchKernelGGL(k2, dim3(B), dim3(256), lds2, s, obs, decbits, params, act1, act2, cache_h1, cache_agg1,     \
+                       cache_nodes, nodes, adj, count, mx_all, records, rec_stride, lay, record, flags, T, B, N, Tc, \
+                       F, H1, H2);                                                                                  \
+  }
+  GCM_ETP_GNN(32, 32) GCM_ETP_GNN(64, 32) GCM_ETP_GNN(32, 64) GCM_ETP_GNN(64, 64)
+#undef GCM_ETP_GNN
+  return gcm_launch_status();
+}

@@ -1735,8 +1735,14 @@ pybind11::object rows_rollout_tp(int64_t cfg_handle, const at::Tensor& packed, c
   const int64_t T = obs.size(0), B = obs.size(1);
   const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
   TORCH_CHECK(obs.dim() == 3 && obs.size(2) == F && obs.scalar_type() == at::kFloat && packed.is_contiguous() && T >= 1);
-  if (T > 65535 || !gcm_dense_rollout_tp_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(),
-                                                   (int)cfg->descs.size(), cfg->has_bias, (int)T, N, F, H1, H2))
+  // EuclideanEdge alone (csrc/euclid_tp.hip): every step's decisions as one causal contraction per graph, then the GNN of
+  // all T <= N steps in one launch per graph; same records, same node
+  const bool euclid = cfg->descs.size() == 1 && cfg->descs[0].kind == GCM_SEL_DISTANCE &&
+                      cfg->descs[0].mode == GCM_DIST_EUCLID_CROSSBATCH && !cfg->descs[0].bidirectional &&
+                      cfg->descs[0].cur_rows == nullptr && !(cfg->has_bias & ~3) && T <= N && B <= 65535 &&
+                      gcm_euclid_rollout_tp_supported((int)T, (int)B, N, F, H1, H2);
+  if (T > 65535 || (!euclid && !gcm_dense_rollout_tp_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(),
+                                                               (int)cfg->descs.size(), cfg->has_bias, (int)T, N, F, H1, H2)))
     return pybind11::none();
   const bool need_bwd = at::GradMode::is_enabled() && packed.requires_grad();
   const int64_t Tc = T;
@@ -1744,13 +1750,23 @@ pybind11::object rows_rollout_tp(int64_t cfg_handle, const at::Tensor& packed, c
   check(gcm_dense_rows_cached_layout((int)B, (int)Tc, F, H1, H2, lay), "gcm_dense_rows_cached_layout");
   const int64_t stride = need_bwd ? (int64_t)lay[0] : pad64(B * H2);
   at::Tensor records = at::empty({T * stride}, obs.options());
-  at::Tensor nodes = T < N ? at::zeros({B, N, F}, obs.options()) : at::empty({B, N, F}, obs.options());
-  at::Tensor adj = at::zeros({B, N, N}, obs.options());
+  at::Tensor nodes = (T < N && !euclid) ? at::zeros({B, N, F}, obs.options()) : at::empty({B, N, F}, obs.options());
+  at::Tensor adj = euclid ? at::empty({B, N, N}, obs.options()) : at::zeros({B, N, N}, obs.options());
   at::Tensor count = at::empty({B}, obs.options().dtype(at::kLong));
   at::Tensor cH = at::empty({B, Tc, H1}, obs.options()), cA = at::empty({B, Tc, F}, obs.options()),
              cX = at::empty({B, Tc, F}, obs.options());
   at::Tensor mx_all = at::empty({T, B, H2}, obs.options());
   const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(obs.get_device()).stream());
+  if (euclid) {
+    at::Tensor bits = at::empty({T, B, 4}, obs.options().dtype(at::kInt));
+    check(gcm_euclid_rollout_tp_fwd(obs.data_ptr<float>(), cfg->descs[0].max_distance, cfg->descs[0].dist_param,
+                                    packed.data_ptr<float>(), cfg->act1, cfg->act2, nodes.data_ptr<float>(),
+                                    adj.data_ptr<float>(), count.data_ptr<int64_t>(), cH.data_ptr<float>(),
+                                    cA.data_ptr<float>(), cX.data_ptr<float>(), records.data_ptr<float>(), (size_t)stride,
+                                    need_bwd ? 1 : 0, mx_all.data_ptr<float>(), reinterpret_cast<uint32_t*>(bits.data_ptr()),
+                                    reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)T, (int)B, N, (int)Tc, F, H1, H2, st),
+          "gcm_euclid_rollout_tp_fwd");
+  } else
   check(gcm_dense_rollout_tp_fwd(obs.data_ptr<float>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
                                  (int)cfg->descs.size(), packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
                                  nodes.data_ptr<float>(), adj.data_ptr<float>(), count.data_ptr<int64_t>(),

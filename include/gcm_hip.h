@@ -874,6 +874,30 @@ int gcm_dense_rollout_tp_fwd(const float* obs, const gcm_selector_desc* selector
                              int record, float* mx_all, uint32_t* flags, int T, int B, int N, int Tc, int F, int H1,
                              int H2, gcm_stream_t stream);
 
+/* ---- time-parallel DenseGCM rollout with EuclideanEdge (round 5; csrc/euclid_tp.hip) ----------------------------
+ * DenseGCM.rollout(obs [T,B,F]) from EMPTY graphs with EuclideanEdge (edge_selectors/distance.py:18-49: the mean over
+ * the B graphs' current nodes of the distance to a stored node, threshold max_distance; dist_param: the `learned`
+ * divisor or NULL; not bidirectional) as the ONLY selector, observations without gradient: node j is observation j
+ * and the current rows of step t are obs[t], so the T selections of a graph are one causal [N x F].[F x (T B)]
+ * contraction on the fp32 MFMA instead of T dependent launches (replaces the loop of gcm.py:262-321 that
+ * ray_gcm.py:186-209 drives).  Same arithmetic, value for value, as the per-step kernel behind gcm_edge_distance_pre /
+ * gcm_edge_distance_step_cached: the same distances, hence the same decisions as T single steps.
+ * _decide: decbits [T, B, 4] uint32 - bit s of step t = ring slot s selected, node n sitting in slot n mod N (for
+ *   t < N: slot = node = adjacency column; at t >= N the slot t mod N is the node the roll of gcm.py:323-355 drops, never
+ *   selected).  Any T >= 1.  B >= 32 (below: the per-step VALU form), N <= 128, N % 4 == 0, F <= 64, F % 4 == 0.
+ * _fwd: T <= N.  Decisions, then the GNN of all T steps in one launch per graph (rows of layer 1 are final once
+ *   written): caches [B, Tc, .] (Tc >= T), the T step records (gcm_dense_rows_cached_layout(B, Tc, ...), rec_stride
+ *   floats apart; record = 0: mx only) for gcm_dense_rows_bptt_cached(..., N := Tc), mx_all [T,B,H2], and the state after
+ *   the rollout written whole (nodes [B,N,F], adj [B,N,N], count [B] <- T; no zero-fill needed).  H1, H2 <= 64. */
+int gcm_euclid_rollout_tp_supported(int T, int B, int N, int F, int H1, int H2);
+int gcm_euclid_rollout_tp_decide(const float* obs, float max_distance, const float* dist_param, uint32_t* decbits,
+                                 int T, int B, int N, int F, gcm_stream_t stream);
+int gcm_euclid_rollout_tp_fwd(const float* obs, float max_distance, const float* dist_param, const float* params,
+                              int act1, int act2, float* nodes, float* adj, int64_t* count, float* cache_h1,
+                              float* cache_agg1, float* cache_nodes, float* records, size_t rec_stride, int record,
+                              float* mx_all, uint32_t* decbits, uint32_t* flags, int T, int B, int N, int Tc, int F,
+                              int H1, int H2, gcm_stream_t stream);
+
 /* DenseGCM.rollout with LearnedEdge: the whole forward of T <= N steps from EMPTY graphs, observations without
  * gradient, in THREE launches - the selection of step t (learned.py:53-113) depends on raw observations and the given
  * gumbel draws only, so every (graph, step) is independent work: the edge network's logits per 32-row block that

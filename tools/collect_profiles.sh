@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the MI355X box (run from the repo root through gpurun):
-#   bash tools/collect_profiles.sh r04 [part ...]      parts: bench stats stats_tools pmc   (default: all)
+#   bash tools/collect_profiles.sh r05 [part ...]      parts: bench stats stats_tools pmc sq   (default: all)
 # Kernel-trace statistics and PMC passes are separate runs (a --pmc pass never carries other trace
 # domains); everything lands under gpurun_out/<tag>/ and is copied into profiles/ afterwards.
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 shift || true
-PARTS=${*:-bench stats stats_tools pmc}
+PARTS=${*:-bench stats stats_tools pmc sq}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -46,6 +46,24 @@ for part in $PARTS; do
       python3 tools/pmc_summarise.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$TAG" > "$OUT/${TAG}_traffic.txt"
       cp profiles/${TAG}_traffic_detail.json profiles/traffic.json "$OUT/"
       rm -rf "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE ;;
+    sq)      # MFMA utilisation, LDS conflicts, issue stalls of the MFMA kernels (north_star: "MFMA utilisation (dense
+             # path)"); SQ has 8 counter slots per pass; names the installed rocprofv3 does not list are dropped
+      rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
+      pick() { local out=""; for c in "$@"; do grep -qw "$c" "$OUT/counters_available.txt" && out="$out $c"; done; echo $out; }
+      P1=$(pick SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA GRBM_GUI_ACTIVE)
+      P2=$(pick SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES)
+      P3=$(pick SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES)
+      i=0
+      for P in "$P1" "$P2" "$P3"; do
+        i=$((i+1))
+        [ -z "$P" ] && continue
+        echo "sq pass $i: $P"
+        rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/sq_$i" -- python3 tools/pmc_mfma_run.py > "$OUT/sq_$i.log" 2>&1 < /dev/null \
+          || echo "sq pass $i failed (see sq_$i.log)"
+      done
+      python3 tools/pmc_sq_summarise.py "$TAG" "$OUT"/sq_1 "$OUT"/sq_2 "$OUT"/sq_3 > "$OUT/${TAG}_mfma_util.txt" || true
+      cp profiles/${TAG}_mfma_util.json "$OUT/" || true
+      rm -rf "$OUT"/sq_1 "$OUT"/sq_2 "$OUT"/sq_3 ;;
   esac
 done
 echo "all done"
