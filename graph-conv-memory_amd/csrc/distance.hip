@@ -9,6 +9,7 @@
 // then adj[b, cur_b, j] = 1 for every j < cur_b with d[b,j] < max_distance.
 // The distance matrix never leaves the chip unless dist_out is given.
 #include "fused_common.h"
+#include "euclid_chain.h"
 
 #ifdef GCM_STAMPS   // diagnostic build only (make stamps6, tools/kstamp_euclid.py)
 __device__ unsigned long long g_stamps[32];
@@ -417,8 +418,8 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float* sC = sN + RB * NS;           // [2][FP][CS]   current rows, transposed, two chunks of CB graphs
   float* sNn = sC + 2 * FP * CS;      // [RB]   |n|^2
   float* sCn = sNn + RB;              // [2][CB] |c|^2
-  float* sPart = sCn + 2 * CB;        // [4][RB] row sums per column tile
-  float* sW = sPart + 4 * RB;         // TAIL: [2 FP + 64][32] W_rel1 | W_root1 (k < FP each) | W_rel2 | W_root2 (k < 32 each), k-major
+  float* sPart = sCn + 2 * CB;        // [4][2][RB] sums over b' per (column tile, lane half)
+  float* sW = sPart + 8 * RB;         // TAIL: [2 FP + 64][32] W_rel1 | W_root1 (k < FP each) | W_rel2 | W_root2 (k < 32 each), k-major
   float* sDec = sW + (2 * FP + 64) * 32;   // TAIL: [RB] this step's decisions
   float* sHc = sDec + RB;                  // TAIL: [N][H1] the h1 cache of this graph (flat copy; H1 % 4 == 0)
 
@@ -438,8 +439,10 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
 #pragma unroll
       for (int k = 0; k < SEG; k += 4) {
         const int f = sf0 + k < F ? sf0 + k : F - 4;
-        const float4 t = *reinterpret_cast<const float4*>(row + f);
-        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        // (the compiler's own 4-vector: ONE global_load_dwordx4 - HIP's float4 struct is split into scalars and
+        //  re-merged only sometimes, and the staging phase is bound by the number of load instructions)
+        const f32x4 t = *reinterpret_cast<const f32x4*>(row + f);
+        v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3];
       }
     } else {
 #pragma unroll
@@ -511,19 +514,18 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   DSTAMP(1);
   DSTAMP(2);
 
-  float rowsum[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
-  // The squared norms ride in the product as one more k step: A'(i, .) = [-2 n_i | |n_i|^2, 1], B'(., j) = [c_j | 1, |c_j|^2],
-  // so the accumulator IS |n|^2 + |c|^2 - 2 n.c (the epilogue is max / sqrt / add per element: it had been as long as
-  // the MFMA chain).  Same arithmetic, value for value, as the time-parallel form (euclid_tp.hip: k_euclid_tp).
+  // euclid_chain.h: acc(i = current row, j = node) = C' N' with the squared norms as one more k step - the accumulator
+  // IS |c|^2 + |n|^2 - 2 c.n, a lane holds one node and sixteen current rows: sqrt and the sum over b' stay in the lane
+  // (no epilogue as long as the MFMA chain, no butterfly over the columns).  Same arithmetic, value for value, as the
+  // time-parallel form (euclid_tp.hip: k_euclid_tp).
   constexpr int KQ = FP / 2;
-  float av[KQ + 1];   // A'(i = row, k): this wave's 32 node rows, in registers for every chunk
+  float part = 0.f;
+  float nv[KQ + 1];   // N'(k, j = node): this wave's 32 node rows (times -2) | (1, |n|^2), in registers for every chunk
   if (rb < nb) {
-    const float* ap = sN + (rb * 32 + li) * NS + lh;
+    const float* np = sN + (rb * 32 + li) * NS + lh;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) av[q] = -2.f * ap[2 * q];
-    av[KQ] = lh ? 1.f : sNn[rb * 32 + li];
+    for (int q = 0; q < KQ; ++q) nv[q] = -2.f * np[2 * q];
+    nv[KQ] = lh ? sNn[rb * 32 + li] : 1.f;
   }
 
   int buf = 0;
@@ -533,23 +535,13 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     if (has_next) load_chunk(c0 + CB, vnext);
     const float* sCb = sC + buf * FP * CS;
     if (c0 + ct * 32 < Bc && rb < nb) {   // this wave's column tile holds graphs, and its row block is live
-      float bq[KQ + 1];
-      {
-        const float* bp = sCb + lh * CS + ct * 32 + li;   // B'(k, j = b')
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) bq[q] = bp[2 * q * CS];
-        bq[KQ] = lh ? sCn[buf * CB + ct * 32 + li] : 1.f;
-      }
-      const float keep = c0 + ct * 32 + li < Bc ? 1.f : 0.f;
+      const float c_last = lh ? 1.f : sCn[buf * CB + ct * 32 + li];
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int q = 0; q <= KQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[q], acc, 0, 0, 0);
-      // v_sqrt_f32 (1 ulp) instead of the correctly rounded library routine (a dozen instructions)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(acc[r], 0.f)), rowsum[r]);
+      float unused;
+      gcm_dist_chain<KQ, (GCM_CHAIN_W < KQ ? GCM_CHAIN_W : KQ), false>(acc, nv, sCb + lh * CS + ct * 32 + li, CS, c_last, acc, unused);   // C'(i = b', k)
+      part += gcm_dist_tile_sum(acc, lh, Bc - (c0 + ct * 32));
     }
     if (c0 == 0) DSTAMP(3);
     if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c0 + CB, vnext);
@@ -580,23 +572,8 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       pfh = reinterpret_cast<const float4*>(tl.cH + (size_t)b * N * tl.H1)[tid < n4 ? tid : n4 - 1];
     }
   }
-  // sum over the 32 columns held by the lanes of each half-wave, then the four column tiles in fixed order
-  if (rb < nb) {
-    // (on the DPP path: sixteen waves' butterflies through ds_bpermute are 300 KB of LDS crossbar traffic)
-#define GCM_DPP_ADD(v, ctrl, rmask) \
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = rowsum[r];
-      GCM_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-      GCM_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-      GCM_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror: the other quad of the 8
-      GCM_DPP_ADD(v, 0x140, 0xF);   // row_mirror: the other 8 of the row of 16
-      GCM_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 into rows 1 and 3: lanes 16..31 / 48..63 hold the 32-lane sums
-      if (li == 16) sPart[ct * RB + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = v;
-    }
-#undef GCM_DPP_ADD
-  }
+  // the lane's sum over b' of its node, per (column tile, lane half); met in fixed order below
+  if (rb < nb) sPart[(2 * ct + lh) * RB + rb * 32 + li] = part;
   __syncthreads();
   if (TAIL) {
 #pragma unroll
@@ -607,9 +584,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const int j = j0 + tid;
     if (j < N) {
       const int tiles = min(4, (Bc + 31) / 32);   // (column tiles that ever held graphs)
-      float tot = sPart[tid];
-      for (int t = 1; t < tiles; ++t) tot += sPart[t * RB + tid];
-      const float d = tot / (float)Bc;
+      const float d = gcm_dist_total(sPart, RB, tid, tiles) / (float)Bc;
       if (dist_out) dist_out[(size_t)b * N + j] = d;
       if (TAIL) sDec[tid] = (j < cur && d < max_distance) ? 1.f : 0.f;
       else if (j < cur) view_emit(adj, sel_row, b, cur, j, N, d < max_distance, bidirectional);
@@ -859,7 +834,7 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
   }
       // F <= 64: tiles dealt by liveness, double-buffered chunks of 128 graphs (k_euclid_mfma2)
       const size_t lds2 = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
-                                           (size_t)4 * RB);
+                                           (size_t)8 * RB);
 #define GCM_EUCLID_MFMA2(FTv)                                                                    \
   {                                                                                              \
     auto kern = k_euclid_mfma2<FTv, false>;                                                      \
@@ -931,7 +906,7 @@ extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, flo
   constexpr int RB = 128;
   const int FT = F / 32;
   const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
-                                      (size_t)4 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32);
+                                      (size_t)8 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32);
   hipStream_t s = (hipStream_t)stream;
   if (FT == 1) {
     auto kern = k_euclid_mfma2<1, true>;

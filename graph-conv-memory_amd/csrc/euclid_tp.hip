@@ -30,6 +30,7 @@
 //                    chain's caches [B, Tc, .], the step records gcm_dense_rows_bptt_cached reads (N := Tc), the
 //                    beliefs [T, B, H2] and the final state (nodes, adj, count) written whole.
 #include "fused_common.h"
+#include "euclid_chain.h"
 #include "gcm_common.h"
 #include "rows_common.h"
 
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
   float* sC = sN + RB * NS;            // [2][FP][CS]   current rows, transposed, two chunks of CB graphs
   float* sNn = sC + 2 * FP * CS;       // [RB]     |n|^2
   float* sCn = sNn + RB;               // [2][CB]  |c|^2
-  float* sPart = sCn + 2 * CB;         // [2][4][RB] row sums per column tile, two steps
+  float* sPart = sCn + 2 * CB;         // [4][4][2][RB] sums over b' per (column tile, lane half), four steps in flight
 
   const float den = dist_param ? dist_param[0] : 1.f;
   // staging: thread = SEG consecutive features (segment tid & 7) of row tid >> 3 of a 128-row tile (distance.hip)
@@ -65,8 +66,10 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
 #pragma unroll
       for (int k = 0; k < SEG; k += 4) {
         const int f = sf0 + k < F ? sf0 + k : F - 4;
-        const float4 t = *reinterpret_cast<const float4*>(row + f);
-        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        // (the compiler's own 4-vector: ONE global_load_dwordx4 - HIP's float4 struct is split into scalars and
+        //  re-merged only sometimes, and the staging phase is bound by the number of load instructions)
+        const f32x4 t = *reinterpret_cast<const f32x4*>(row + f);
+        v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3];
       }
     } else {
 #pragma unroll
@@ -127,82 +130,79 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
   }
   __syncthreads();
 
-  // decisions of step t from the four tiles' row sums: threads 0 .. 127 = ring slots
-  auto finalize = [&](int t) __attribute__((always_inline)) {
-    const float* p = sPart + (t & 1) * 4 * RB;
-    float tot = p[tid];
-    for (int q = 1; q < tiles; ++q) tot += p[q * RB + tid];
-    const float d = tot / (float)B;
-    const bool valid = tid < N && (t < N ? tid < t : tid != t % N);
+  // decisions of step u from the partial sums: threads 0 .. 127 = ring slots
+  auto finalize = [&](int u) __attribute__((always_inline)) {
+    const float d = gcm_dist_total(sPart + (u & 3) * 8 * RB, RB, tid, tiles) / (float)B;
+    const bool valid = tid < N && (u < N ? tid < u : tid != u % N);
     const unsigned long long m = __ballot(valid && d < max_distance);
     if (lane == 0) {
-      uint32_t* o = decbits + ((size_t)t * B + b) * 4 + 2 * wave;
+      uint32_t* o = decbits + ((size_t)u * B + b) * 4 + 2 * wave;
       o[0] = (uint32_t)m;
       o[1] = (uint32_t)(m >> 32);
     }
   };
 
-  float rowsum[16];
+  // Software pipeline: the sqrt / sum epilogue of a wave's tile runs UNDER the MFMA chain of its next tile (the
+  // scheduler places its instructions behind the chain's MFMAs: gcm_dist_chain<.., PIPE>) - with the epilogue in
+  // program order behind its own chain the four waves of a SIMD finish their chains together and then queue for the
+  // one VALU.  So a tile's sum is settled one round late, a step's partial sums reach LDS in the first round of the
+  // NEXT step and are met one round after that (four steps' buffers: no reader meets a writer).
+  float part = 0.f;     // this lane's node: sum over b' of the step's settled tiles
+  float nv[KQ + 1];     // N'(k, j = slot): -2 x the wave's 32 slots' rows | (1, |n|^2)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) rowsum[r] = 0.f;
-  float av[KQ + 1];   // A'(i = slot, k): -2 x the wave's 32 slots' rows | (|n|^2, 1)
+  for (int q = 0; q <= KQ; ++q) nv[q] = 0.f;
+  f32x16 accp;          // the tile whose epilogue is pending
 #pragma unroll
-  for (int q = 0; q <= KQ; ++q) av[q] = 0.f;
+  for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+  bool pend = false;    // (wave-uniform)
+  int pend_rows = 32;
+  // the sums of step u are complete (its last tile settled): to LDS, if this wave's block was live in step u
+  auto publish = [&](int u) __attribute__((always_inline)) {
+    if (rb * 32 < (u < N ? u : N)) sPart[(u & 3) * 8 * RB + (2 * ct + lh) * RB + rb * 32 + li] = part;
+    part = 0.f;
+  };
 
   int t = 1, c = 0, buf = 0;
+  float touch = 0.f;
 #pragma unroll 1
   for (int g = 0; g < R; ++g, buf ^= 1) {
     const bool first = c == 0, last = c == nch - 1, has_next = g + 1 < R;
     const int t2 = last ? t + 1 : t, c2 = last ? 0 : c + 1;
     float vnext[SEG];
+    asm volatile("" ::"v"(touch));   // (the touch of two rounds ago has landed: consumed here, before the next one)
     if (has_next) load_chunk(t2, c2 * CB, vnext);
-    if (first && t >= 2 && tid < RB) finalize(t - 1);
+    if (g >= 1 && (g - 1) % nch == 0 && g - 1 >= nch && tid < RB) finalize((g - 1) / nch);
     if (first && (t == 1 || rb == (((t - 1) % N) >> 5))) {   // (wave-uniform) node t - 1 went into this wave's block
-      const float* ap = sN + (rb * 32 + li) * NS + lh;
+      const float* np = sN + (rb * 32 + li) * NS + lh;
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) av[q] = ap[2 * q];
-      av[KQ] = lh ? 1.f : sNn[rb * 32 + li];
+      for (int q = 0; q < KQ; ++q) nv[q] = np[2 * q];
+      nv[KQ] = lh ? sNn[rb * 32 + li] : 1.f;
     }
     const int lim = t < N ? t : N;
     const bool live = rb * 32 < lim;                        // the block holds a candidate slot
     const int col0 = c * CB + ct * 32;
     if (live && col0 < B) {
-      const float* sCb = sC + buf * FP * CS;
-      float bq[KQ + 1];
-      {
-        const float* bp = sCb + lh * CS + ct * 32 + li;     // B'(k, j = b')
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) bq[q] = bp[2 * q * CS];
-        bq[KQ] = lh ? sCn[buf * CB + ct * 32 + li] : 1.f;
-      }
+      const float* cp = sC + buf * FP * CS + lh * CS + ct * 32 + li;     // C'(i = b', k)
+      const float c_last = lh ? 1.f : sCn[buf * CB + ct * 32 + li];
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int q = 0; q <= KQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[q], acc, 0, 0, 0);
-      // acc = |n|^2 + |c|^2 - 2 n.c; v_sqrt_f32 (1 ulp), summed over b' per lane (columns), chunks in sequence
-      const float keep = col0 + li < B ? 1.f : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        rowsum[r] = fmaf(keep, __builtin_amdgcn_sqrtf(fmaxf(acc[r], 0.f)), rowsum[r]);
-    }
-    if (last && live) {
-      // sum over the 32 columns held by the lanes of each half-wave (DPP path), then the tiles in fixed order
-      float* p = sPart + (t & 1) * 4 * RB + ct * RB + rb * 32;
-#define GCM_DPP_ADD(v, ctrl, rmask) \
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = rowsum[r];
-        GCM_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-        GCM_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-        GCM_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
-        GCM_DPP_ADD(v, 0x140, 0xF);   // row_mirror
-        GCM_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 into rows 1 and 3: lanes 16..31 / 48..63 hold the 32-lane sums
-        if (li == 16) p[(r & 3) + 8 * (r >> 2) + 4 * lh] = v;
-        rowsum[r] = 0.f;
+      if (pend && pend_rows < 32) {                         // (the batch's last, partial tile: not pipelined)
+        part += gcm_dist_tile_sum_masked(accp, lh, pend_rows);
+        pend = false;
       }
-#undef GCM_DPP_ADD
+      float psum = 0.f;
+      if (!pend) gcm_dist_chain<KQ, 8, false>(acc, nv, cp, CS, c_last, accp, psum);
+      else gcm_dist_chain<KQ, 8, true>(acc, nv, cp, CS, c_last, accp, psum);
+      part += psum;
+      if (first && t >= 2) publish(t - 1);                  // (the pending tile was step t - 1's last)
+      accp = acc;
+      pend = true;
+      pend_rows = B - col0;
+    } else {
+      if (pend) part += gcm_dist_tile_sum(accp, lh, pend_rows);
+      pend = false;
+      if (first && t >= 2) publish(t - 1);
     }
     // node t (a candidate from step t + 1 on) IS current row b of step t: copied from the chunk that holds it into
     // ring slot t mod N - dead at step t (it held node t - N), so whoever still reads it masks it
@@ -212,11 +212,25 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
       if (lane == 0) sNn[t % N] = sCn[buf * CB + b_row];
     }
     if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c2 * CB, vnext);
-    __syncthreads();   // round g is consumed; the next chunk, the inserted node and the row sums are in LDS
+    if (g + 2 < R) {   // warm the L2 for the chunk after next (every WG of an XCD reads the same 32 KB per round)
+      const int t3 = c2 == nch - 1 ? t2 + 1 : t2, c3 = c2 == nch - 1 ? 0 : c2 + 1;
+      const int gr = c3 * CB + srow < B ? c3 * CB + srow : B - 1;
+      touch = obs[((size_t)t3 * B + gr) * F + (sf0 < F ? sf0 : 0)];
+    }
+    __syncthreads();   // round g is consumed; the next chunk, the inserted node and the published sums are in LDS
     t = t2;
     c = c2;
   }
-  if (T >= 2 && tid < RB) finalize(T - 1);
+  asm volatile("" ::"v"(touch));
+  if (T >= 2) {
+    if (pend) part += gcm_dist_tile_sum(accp, lh, pend_rows);
+    publish(T - 1);
+    __syncthreads();
+    if (tid < RB) {
+      if (nch == 1 && T >= 3) finalize(T - 2);
+      finalize(T - 1);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -433,7 +447,7 @@ extern "C" int gcm_euclid_rollout_tp_decide(const float* obs, float max_distance
   GCM_REQUIRE(obs && decbits);
   if (!gcm_euclid_rollout_tp_supported(T, B, N, F, 32, 32)) return GCM_EUNSUPPORTED;
   const int FT = (F + 31) / 32, FP = 32 * FT;
-  const size_t lds = sizeof(float) * ((size_t)128 * (FP + 1) + (size_t)2 * FP * 129 + 128 + 2 * 128 + (size_t)2 * 4 * 128);
+  const size_t lds = sizeof(float) * ((size_t)128 * (FP + 1) + (size_t)2 * FP * 129 + 128 + 2 * 128 + (size_t)4 * 8 * 128);
   hipStream_t s = (hipStream_t)stream;
   if (FT == 1) {
     auto kern = gcm_etp::k_euclid_tp<1>;

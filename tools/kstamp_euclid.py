@@ -7,7 +7,7 @@ import os
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "graph-conv-memory_amd", "gcm", "_lib", "libgcm_hip_stamps6.so"))
+lib = ctypes.CDLL(os.environ.get("STAMPLIB") or os.path.join(ROOT, "graph-conv-memory_amd", "gcm", "_lib", "libgcm_hip_stamps6.so"))
 B, N, F = 256, 128, 64
 CUR = int(os.environ.get("CUR", 100))
 dev = "cuda:0"
