@@ -384,6 +384,10 @@ struct StepTail {
   int act1, act2, H1, H2;
   int cur_host;             // >= 0: the row every graph's new node lands in, known to the host (a chain from empty
                             // graphs: the number of steps made so far) - nothing waits for the count; -1: read it
+  uint32_t* abits;          // the chain's adjacency as bits, [B][N][4] (row i: bit j = adj[i, j]), or NULL: kept by the
+                            // cached steps for the steady-state step below, which reads its live rows' adjacency from it
+  size_t o_rows;            // TAIL = 2: the general record's rows section (rows_common.h: SavedLayout), rw floats a row
+  int rw;
 };
 
 // ---------------------------------------------------------------------------
@@ -397,7 +401,8 @@ struct StepTail {
 // loads of chunk c + 1 are in flight during the products of chunk c.  Row sums meet in LDS in fixed order
 // (chunks in sequence inside a wave, then the four column tiles): same decisions on every run.
 // ---------------------------------------------------------------------------
-template <int FT, bool TAIL>
+template <int FT, int TAIL>   // TAIL: 0 the selector alone; 1 + the cached step (a chain that has not rolled yet); 2 + the
+                               // steady-state step (every graph full: roll, live rows re-evaluated) - see behind the decisions
 __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     View vw, const float* __restrict__ dist_param, float* __restrict__ adj,
     float* __restrict__ sel_row, float* __restrict__ dist_out, float max_distance, int bidirectional,
@@ -406,11 +411,12 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   constexpr int FP = 32 * FT, NS = FP + 1, RB = 128, CB = 128, CS = CB + 1;
   constexpr int NT = 1024;
   const int b = blockIdx.y, j0 = blockIdx.x * RB;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int ct = wave & 3, rb = wave >> 2;   // 16 waves: SIMD = column tile, its four waves = the row blocks
   int sh = 0;
   int cur;
-  if (TAIL && tl.cur_host >= 0) cur = tl.cur_host < N ? tl.cur_host : N - 1;   // (uniform; no load behind it)
+  if (TAIL == 2) { cur = N - 1; sh = 1; }   // every graph is full: image row j is stored row j + 1 (gcm.py:323-355)
+  else if (TAIL && tl.cur_host >= 0) cur = tl.cur_host < N ? tl.cur_host : N - 1;   // (uniform; no load behind it)
   else cur = view_cur(vw, b, N, sh);
   const int nb = dist_out ? RB / 32 : max(0, min(RB / 32, (cur - j0 + 31) / 32));   // live 32-row blocks
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -421,7 +427,8 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float* sPart = sCn + 2 * CB;        // [4][2][RB] sums over b' per (column tile, lane half)
   float* sW = sPart + 8 * RB;         // TAIL: [2 FP + 64][32] W_rel1 | W_root1 (k < FP each) | W_rel2 | W_root2 (k < 32 each), k-major
   float* sDec = sW + (2 * FP + 64) * 32;   // TAIL: [RB] this step's decisions
-  float* sHc = sDec + RB;                  // TAIL: [N][H1] the h1 cache of this graph (flat copy; H1 % 4 == 0)
+  float* sHc = sDec + RB;                  // TAIL: [N][H1] the h1 cache of this graph (flat copy; H1 % 4 == 0); TAIL = 2: the live rows' h1
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(sHc + 128 * 32);   // TAIL = 2: [RB][4] the adjacency bits of this graph
 
   const float inv_scale_den = dist_param ? dist_param[0] : 1.f;
   const float* crows = vw.cur_rows ? vw.cur_rows : vw.obs;
@@ -557,7 +564,36 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   static_assert(WN % NT == 0, "whole rounds of the workgroup over the weight image");
   float pfw[NIW];
   float4 pfh;
-  const bool hc_lds = TAIL && (tl.H1 & 3) == 0 && N * tl.H1 <= 4 * NT;   // h1 cache staged in LDS
+  const bool hc_lds = TAIL == 1 && (tl.H1 & 3) == 0 && N * tl.H1 <= 4 * NT;   // h1 cache staged in LDS
+  // TAIL = 2: the overflow roll of this graph's state (gcm.py:323-355: nodes[i] <- nodes[i + 1], adj[i, j] <- adj[i + 1,
+  // j + 1], last column empty) rides in the same registers: every load is requested here, under the reductions, and
+  // has landed at the barrier behind the decisions; the stores follow it (source and destination alias: a thread's
+  // stores hit what another thread loads).  As flat arrays the roll is a shift by N + 1 (adjacency) and F (nodes).
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int RA = 128 * 128 / 4 / NT, RN = 128 * FP / 4 / NT;   // 16-byte pieces per thread at N = 128
+  f32x4 roll_a[RA], roll_n[RN];
+  uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;
+  if (TAIL == 2) {
+    const float* ga = tl.adj + (size_t)b * N * N;
+    const float* gn = tl.nodes + (size_t)b * N * F;
+    const int a_end = (N - 1) * N, n_end = (N - 1) * F;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int e = 4 * (tid + NT * i);
+      // (the last piece of row N - 2 would read one float past the graph: it takes the aligned piece and shifts below)
+      const int src = e >= a_end ? 0 : (e == a_end - 4 ? e + N : e + N + 1);
+      roll_a[i] = *reinterpret_cast<const f32x4u*>(ga + src);
+    }
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+      const int e = 4 * (tid + NT * i);
+      roll_n[i] = *reinterpret_cast<const f32x4*>(gn + (e >= n_end ? 0 : e + F));
+    }
+    if (tid < N - 1) {   // old row tid + 1 of the adjacency bits -> (shifted below) image row tid
+      const uint4 t = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + tid + 1) * 4)[0];
+      ob0 = t.x; ob1 = t.y; ob2 = t.z; ob3 = t.w;
+    }
+  }
   if (TAIL) {
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
@@ -591,7 +627,174 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     }
   }
   DSTAMP(6);
-  if (TAIL) {
+  if (TAIL == 2) {
+    // ---- the steady-state step: every graph is full, the step drops the oldest node (gcm.py:263-271, 323-355).  The
+    //      layer-1 rows of older nodes are no longer final (a row loses the sources the roll drops), so the live rows -
+    //      the selected ones - are re-evaluated here: their adjacency from the chain's bit image (one 16-byte row each,
+    //      fetched at kernel start: no round trip behind the decisions), their sources from the node image staged for
+    //      the distances, one live row per wave at a time; wave 0 then row cur.  The record is the GENERAL live-row
+    //      record (rows_common.h: the rows h1 | agg1 | x travel in it).  dist_param == NULL (the image is unscaled).
+    if (tid < RB && !(tid < 32 * nb && j0 + tid < N)) sDec[tid] = 0.f;   // rows beyond the live blocks
+    if (tid < RB) {   // the adjacency bits after the roll: row i <- (old row i + 1) >> 1 (column 0 falls off)
+      uint32_t* o = sBits + tid * 4;
+      o[0] = (ob0 >> 1) | (ob1 << 31); o[1] = (ob1 >> 1) | (ob2 << 31); o[2] = (ob2 >> 1) | (ob3 << 31); o[3] = ob3 >> 1;
+    }
+    __syncthreads();   // decisions, weights and bits are in LDS; every roll load has landed
+    const int H1 = tl.H1, H2 = tl.H2;
+    const unsigned gb = (unsigned)b;
+    // the selected rows (image rows j < N - 1): every wave takes the same two ballots
+    const unsigned long long m0 = __ballot(lane < N - 1 && sDec[lane] != 0.f);
+    const unsigned long long m1 = __ballot(lane + 64 < N - 1 && sDec[(lane + 64) & (RB - 1)] != 0.f);
+    const int n0 = __popcll(m0), n_sel = n0 + __popcll(m1);
+    {   // the state, in place: the rolled rows, then row N - 1 (the new node, its decisions); the bit image likewise
+      float* ga = tl.adj + (size_t)b * N * N;
+      float* gn = tl.nodes + (size_t)b * N * F;
+      const int a_end = (N - 1) * N, n_end = (N - 1) * F;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int e = 4 * (tid + NT * i);
+        if (e < a_end) {
+          f32x4 v = roll_a[i];
+          if (e == a_end - 4) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; }
+          if ((e + 3) % N == N - 1) v[3] = 0.f;            // (N % 4 == 0: only a piece's last element can be column N - 1)
+          *reinterpret_cast<f32x4*>(ga + e) = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        const int e = 4 * (tid + NT * i);
+        if (e < n_end) *reinterpret_cast<f32x4*>(gn + e) = roll_n[i];
+      }
+      if (tid < N) ga[a_end + tid] = tid < N - 1 ? sDec[tid] : 0.f;
+      if (wave == 1 && lane < F) gn[n_end + lane] = vw.obs[gb * (unsigned)F + (unsigned)lane];
+      if (tid < N) {
+        uint4 t;
+        if (tid < N - 1) { const uint32_t* q = sBits + tid * 4; t = make_uint4(q[0], q[1], q[2], q[3]); }
+        else t = make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32));
+        reinterpret_cast<uint4*>(tl.abits + ((size_t)b * N + tid) * 4)[0] = t;
+      }
+    }
+    // this wave's weights of layer 1, once: lanes 0-31 k < FP / 2, lanes 32-63 the rest (met by one cross-half add)
+    constexpr int KH = FP / 2;
+    const int hl = lane & 31, kh = lane >> 5, fl = lane < FP ? lane : FP - 1;
+    float wr[KH], wt[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      wr[k] = sW[(kh * KH + k) * 32 + hl];
+      wt[k] = sW[(FP + kh * KH + k) * 32 + hl];
+    }
+    const float* b1p = tl.params + 2 * (size_t)H1 * F;
+    const float* b2p = b1p + H1 + 2 * (size_t)H2 * H1;
+    const float bias1 = b1p[hl < H1 ? hl : H1 - 1], bias2 = b2p[hl < H2 ? hl : H2 - 1];
+    const int act1_v = gcm_vgpr(tl.act1), act2_v = gcm_vgpr(tl.act2);
+    float* svw = sC + wave * 2 * FP;                          // (the chunk buffers are free) this wave's agg1 | x
+    float* sH1 = sHc;                                         // [n_sel][32] the live rows' h1, list order
+    const bool rec = tl.total != 0;
+    float* rows = tl.saved + tl.o_rows + (size_t)gb * N * tl.rw;
+    auto layer1 = [&](float agg, float x) __attribute__((always_inline)) {   // lane f holds agg1[f], x[f] -> h1[lane & 31]
+      if (lane < FP) { svw[lane] = agg; svw[FP + lane] = x; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float pa = 0.f, pb = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < KH / 4; ++k4) {
+        const float4 a = *reinterpret_cast<const float4*>(svw + kh * KH + 4 * k4);
+        const float4 xx = *reinterpret_cast<const float4*>(svw + FP + kh * KH + 4 * k4);
+        pa = fmaf(wr[4 * k4], a.x, pa); pb = fmaf(wt[4 * k4], xx.x, pb);
+        pa = fmaf(wr[4 * k4 + 1], a.y, pa); pb = fmaf(wt[4 * k4 + 1], xx.y, pb);
+        pa = fmaf(wr[4 * k4 + 2], a.z, pa); pb = fmaf(wt[4 * k4 + 2], xx.z, pb);
+        pa = fmaf(wr[4 * k4 + 3], a.w, pa); pb = fmaf(wt[4 * k4 + 3], xx.w, pb);
+      }
+      float p1 = pa + pb;
+      p1 += __shfl_xor(p1, 32);
+      p1 += bias1;
+      __builtin_amdgcn_wave_barrier();                        // (the next row overwrites svw)
+      return hl < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
+    };
+    // live rows: list position l (ascending j) -> wave l mod 16
+    {
+      unsigned long long a0 = m0, a1 = m1;
+      for (int l = 0; l < n_sel; ++l) {
+        const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
+        if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
+        if ((l & 15) != wave) continue;
+        float agg = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                          // sources in ascending order (adj[j, k] = 1, k < j)
+          uint32_t w = __builtin_amdgcn_readfirstlane(sBits[j * 4 + q]);
+          while (w) {
+            const int k = q * 32 + __builtin_ctz(w);
+            w &= w - 1;
+            agg += sN[k * NS + fl];
+          }
+        }
+        const float x = sN[j * NS + fl];
+        const float h = layer1(lane < F ? agg : 0.f, lane < F ? x : 0.f);
+        if (lane < 32) sH1[l * 32 + lane] = h;
+        if (rec) {
+          float* row = rows + (size_t)l * tl.rw;
+          if (lane < H1) row[lane] = h;
+          if (lane < F) { row[H1 + lane] = agg; row[H1 + F + lane] = x; }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- row cur = N - 1 on wave 0: agg1 over the selected rows, layer 1, agg2 over their h1, layer 2
+    const float xc = pf_xc;
+    float agg1 = 0.f, agg2 = 0.f;
+    {
+      unsigned long long a0 = m0, a1 = m1;
+      for (int l = 0; l < n_sel; ++l) {
+        const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
+        if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
+        agg1 += sN[j * NS + fl];
+        agg2 += sH1[l * 32 + hl];
+      }
+    }
+    agg1 = lane < F ? agg1 : 0.f;
+    agg2 = hl < H1 ? agg2 : 0.f;
+    const float h1c = layer1(agg1, lane < F ? xc : 0.f);
+    if (lane < 32) { svw[lane] = agg2; svw[32 + lane] = h1c; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float p2;
+    {   // layer 2: lanes 0-31 W_rel2 . agg2, lanes 32-63 W_root2 . h1cur
+      float pa = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const float4 a = *reinterpret_cast<const float4*>(svw + kh * 32 + 4 * k4);
+        const float* w2 = sW + (2 * FP + kh * 32 + 4 * k4) * 32 + hl;
+        pa = fmaf(w2[0], a.x, pa);
+        pa = fmaf(w2[32], a.y, pa);
+        pa = fmaf(w2[64], a.z, pa);
+        pa = fmaf(w2[96], a.w, pa);
+      }
+      p2 = pa + __shfl_xor(pa, 32) + bias2;
+    }
+    const float v = gcm_act_sel(p2, act2_v);
+    if (lane < H2) tl.saved[gb * H2 + lane] = v;
+    if (rec) {
+      if (lane < H1) {
+        tl.saved[tl.o_v + gb * 2 * H1 + lane] = agg2;
+        tl.saved[tl.o_v + gb * 2 * H1 + H1 + lane] = h1c;
+      }
+      float* row = rows + (size_t)n_sel * tl.rw;              // row cur: last in the list
+      if (lane < H1) row[lane] = h1c;
+      if (lane < F) { row[H1 + lane] = agg1; row[H1 + F + lane] = xc; }
+      float* coef = tl.saved + tl.o_coef + (size_t)gb * N;
+      for (int l = lane; l <= n_sel; l += 64) coef[l] = l < n_sel ? 1.f : 0.f;
+      if (lane == 0) {
+        int* hdr = reinterpret_cast<int*>(tl.saved + tl.o_hdr) + 4 * gb;
+        hdr[0] = n_sel + 1; hdr[1] = n_sel; hdr[2] = N - 1; hdr[3] = 1;
+      }
+    }
+    const bool nonfinite = __any(lane < H2 && !isfinite(v));
+    if (lane == 0 && (nonfinite || gb == 0))
+      atomicOr(tl.flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (gb == 0 ? GCM_FLAG_WRAPPED : 0u));   // gcm.py:264-266
+    return;
+  }
+  if (TAIL == 1) {
     if (tid < RB && !(tid < 32 * nb && j0 + tid < N)) sDec[tid] = 0.f;   // rows beyond the live blocks
     __syncthreads();
     // ---- the cached live-row step on row cur (rows_cached.hip).  Wave 0 gathers the selected rows while the other
@@ -727,6 +930,9 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       float* arow = tl.adj + (size_t)rc * N;
       if (lane < N && ((m0 >> lane) & 1ull)) arow[lane] = 1.f;
       if (lane + 64 < N && ((m1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
+      if (tl.abits && lane == 0)      // (the bit image the steady-state step reads its live rows' adjacency from)
+        reinterpret_cast<uint4*>(tl.abits + (size_t)rc * 4)[0] =
+            make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32));
       if (lane == 0) tl.count[gb] = cur + 1;
     }
     if (lane < H2) tl.saved[gb * H2 + lane] = v;
@@ -837,7 +1043,7 @@ static int run_distance(const View& vw, float* adj, float* sel_row, int mode, fl
                                            (size_t)8 * RB);
 #define GCM_EUCLID_MFMA2(FTv)                                                                    \
   {                                                                                              \
-    auto kern = k_euclid_mfma2<FTv, false>;                                                      \
+    auto kern = k_euclid_mfma2<FTv, 0>;                                                          \
     gcm_allow_dynamic_lds((const void*)kern, lds2);                                              \
     hipLaunchKernelGGL(kern, grid, dim3(1024), lds2, s, vw, dist_param, adj, sel_row, dist_out,  \
                        max_distance, bidirectional, Bc, N, F, StepTail{});                       \
@@ -893,7 +1099,7 @@ extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, flo
                                              int n_cur_rows, const float* params, const float* weight_image, int act1,
                                              int act2, float* cache_h1, float* cache_agg1, float* cache_nodes,
                                              float* saved, const size_t* lay5, int record, int cur_host,
-                                             uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                             uint32_t* adj_bits, uint32_t* flags, int B, int N, int F, int H1, int H2,
                                              gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes && adj && count && params && weight_image && cache_h1 && cache_agg1 && cache_nodes &&
               saved && lay5 && flags && B > 0);
@@ -902,22 +1108,63 @@ extern "C" int gcm_edge_distance_step_cached(const float* obs, float* nodes, flo
   View vw{nodes, nullptr, count, obs, cur_rows, n_cur_rows};
   StepTail tl{params, weight_image, nodes, adj, count, cache_h1, cache_agg1, cache_nodes, saved,
               lay5[1], lay5[2], lay5[3], lay5[4], record ? lay5[0] : 0, flags, act1, act2, H1, H2,
-              cur_host >= 0 ? cur_host : -1};
+              cur_host >= 0 ? cur_host : -1, adj_bits, 0, 0};
   constexpr int RB = 128;
   const int FT = F / 32;
   const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
                                       (size_t)8 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32);
   hipStream_t s = (hipStream_t)stream;
   if (FT == 1) {
-    auto kern = k_euclid_mfma2<1, true>;
+    auto kern = k_euclid_mfma2<1, 1>;
     gcm_allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3(1, B), dim3(1024), lds, s, vw, dist_param, adj, (float*)nullptr, (float*)nullptr,
                        max_distance, 0, Bc, N, F, tl);
   } else {
-    auto kern = k_euclid_mfma2<2, true>;
+    auto kern = k_euclid_mfma2<2, 1>;
     gcm_allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3(1, B), dim3(1024), lds, s, vw, dist_param, adj, (float*)nullptr, (float*)nullptr,
                        max_distance, 0, Bc, N, F, tl);
+  }
+  return gcm_launch_status();
+}
+
+/* The same chain in the STEADY STATE (every graph holds N nodes: count[b] == N, which the caller guarantees - a chain
+ * from empty graphs that has made >= N steps): the step drops each graph's oldest node (gcm.py:263-271, 323-355), so the
+ * layer-1 rows of older nodes are no longer final and the live rows are re-evaluated - ONE launch still: distances on
+ * the matrix cores, then the roll of the donated state IN PLACE (nodes, adj; count stays N), the live rows' layer 1
+ * from the bit image of the adjacency the cached steps kept (adj_bits [B][N][4], rolled here too), row cur, the belief.
+ * saved: the GENERAL live-row record (gcm_dense_rows_layout: lay6 = {total, v, hdr, coef, rows, rw}; mx at 0; in full
+ * with record != 0), read by gcm_dense_rows_bptt.  No `learned` divisor, local batch only. */
+extern "C" int gcm_edge_distance_step_ring_supported(int B, int N, int F, int H1, int H2) {
+  return gcm_edge_distance_step_cached_supported(B, B, N, F, H1, H2) && N >= 8 && (N & 3) == 0;
+}
+
+extern "C" int gcm_edge_distance_step_ring(const float* obs, float* nodes, float* adj, int64_t* count,
+                                           float max_distance, const float* params, const float* weight_image,
+                                           int act1, int act2, uint32_t* adj_bits, float* saved, const size_t* lay6,
+                                           int record, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                           gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && adj && count && params && weight_image && adj_bits && saved && lay6 && flags && B > 0);
+  if (!gcm_edge_distance_step_ring_supported(B, N, F, H1, H2)) return GCM_EUNSUPPORTED;
+  View vw{nodes, nullptr, count, obs, nullptr, 0};
+  StepTail tl{params, weight_image, nodes, adj, count, nullptr, nullptr, nullptr, saved,
+              lay6[1], lay6[2], lay6[3], 0, record ? lay6[0] : 0, flags, act1, act2, H1, H2, -1, adj_bits, lay6[4],
+              (int)lay6[5]};
+  constexpr int RB = 128;
+  const int FT = F / 32;
+  const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
+                                      (size_t)8 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32 + 4 * RB);
+  hipStream_t s = (hipStream_t)stream;
+  if (FT == 1) {
+    auto kern = k_euclid_mfma2<1, 2>;
+    gcm_allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3(1, B), dim3(1024), lds, s, vw, (const float*)nullptr, adj, (float*)nullptr,
+                       (float*)nullptr, max_distance, 0, B, N, F, tl);
+  } else {
+    auto kern = k_euclid_mfma2<2, 2>;
+    gcm_allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3(1, B), dim3(1024), lds, s, vw, (const float*)nullptr, adj, (float*)nullptr,
+                       (float*)nullptr, max_distance, 0, B, N, F, tl);
   }
   return gcm_launch_status();
 }

@@ -875,8 +875,8 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
     const size_t lay5[5] = {l.total, l.o_v, l.o_hdr, l.o_coef, l.o_live};
     const int rc = gcm_edge_distance_step_cached(obs, nodes, adj, count, d.max_distance, d.dist_param, d.cur_rows,
                                                  d.n_cur_rows, params, weight_image, act1, act2, cache_h1, cache_agg1,
-                                                 cache_nodes, saved, lay5, record, cur_host, flags, B, N, F, H1, H2,
-                                                 stream);
+                                                 cache_nodes, saved, lay5, record, cur_host, nullptr, flags, B, N, F, H1,
+                                                 H2, stream);
     if (rc != GCM_EUNSUPPORTED) return rc;
   }
   for (int i = 0; i < n_selectors; ++i) {

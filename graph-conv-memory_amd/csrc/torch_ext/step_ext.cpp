@@ -588,8 +588,12 @@ struct RowsFast {
   // selectors are forward temporal hops with N > 2 max(hop): gcm_dense_rows_step_cached_roll - the caches as rings,
   // the band adjacency untouched, the node matrix rolled in place
   bool roll_ok = false;
+  // ... or while the only selector is EuclideanEdge in its one-launch form (no `learned` divisor, local batch):
+  // gcm_edge_distance_step_ring - the roll in the same launch, the live rows re-evaluated from the chain's bit image of
+  // the adjacency (abits, kept by the cached steps)
+  bool ring_ok = false;
   int64_t cached_steps = 0, chain_steps = 0, rolled_steps = 0;
-  at::Tensor cH, cA, cX, wimg;
+  at::Tensor cH, cA, cX, wimg, abits;
   at::Tensor rH, rA, rX;   // the ring caches of the steady-state steps (copies: the first N records keep reading cH / cA / cX)
   std::shared_ptr<DxChain> dxc;
   std::shared_ptr<DxGateNode> dx_gate;
@@ -714,7 +718,7 @@ struct RowsFast {
       }
     }
     chain_steps = cached_steps = rolled_steps = 0;
-    cH = cA = cX = rH = rA = rX = at::Tensor();
+    cH = cA = cX = rH = rA = rX = abits = at::Tensor();
     // (a distance selector's decisions reach the cached step as a row: no hop table to rebuild the live rows from
     //  in the observation-gradient launch - those chains stay on the general kernel)
     cache_ok = fresh && donate && dx_kind != 2 && !(cfg->has_distance && dx_kind != 0) &&
@@ -727,7 +731,50 @@ struct RowsFast {
               gcm_dense_rows_cached_roll_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(),
                                                    (int)cfg->descs.size(), cfg->has_bias, cfg->N, cfg->F, cfg->H1,
                                                    cfg->H2) != 0;
+    ring_ok = cache_ok && dx_kind == 0 && cfg->descs.size() == 1 && cfg->descs[0].kind == GCM_SEL_DISTANCE &&
+              cfg->descs[0].mode == GCM_DIST_EUCLID_CROSSBATCH && !cfg->descs[0].bidirectional &&
+              cfg->descs[0].dist_param == nullptr && cfg->descs[0].cur_rows == nullptr && !(cfg->has_bias & ~3) &&
+              !(cfg->cached_flags & GCM_STEP_TWO_LAUNCH);
     armed = true;
+  }
+
+  // the steady-state step of an EuclideanEdge chain (see ring_ok): one launch, the general live-row record
+  at::Tensor launch_ring(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                         const at::Tensor& weights, const at::Tensor& count_in) {
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = node != nullptr;
+    size_t lay[8];
+    check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
+    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
+    check(gcm_edge_distance_step_ring(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                      count_in.data_ptr<int64_t>(), cfg->descs[0].max_distance, packed.data_ptr<float>(),
+                                      wimg.data_ptr<float>(), cfg->act1, cfg->act2,
+                                      reinterpret_cast<uint32_t*>(abits.data_ptr()), buf.data_ptr<float>(), lay,
+                                      need_bwd ? 1 : 0, reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2,
+                                      stream),
+          "gcm_edge_distance_step_ring");
+    at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
+    if (need_bwd) {
+      const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
+      RowsChainNode::Rec r{buf, vc, vc.current_version()};   // (cached = false: its rows travel in the record)
+      r.out_mx = (int)node->num_inputs();
+      torch::autograd::create_gradient_edge(mx, node);
+      node->recs.push_back(std::move(r));
+    }
+    l_nodes = nodes_in;
+    l_adj = adj_in;
+    l_weights = weights;
+    l_count = count_in;
+    note_versions();
+    xB = B;
+    xF = obs.size(1);
+    ++n_steps;
+    ++chain_steps;
+    ++cached_steps;
+    ++rolled_steps;
+    return mx;
   }
 
   // a cached step in the steady state (see roll_ok): the general live-row record, the state's node matrix rolled in
@@ -805,6 +852,21 @@ struct RowsFast {
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
     size_t ws_bytes = 0;
     void* ws = cfg->workspace((int)B, obs, &ws_bytes);   // (a distance selector's scratch and decision row)
+    if (ring_ok && cached_steps == 0) {
+      ring_ok = gcm_edge_distance_step_cached_supported((int)B, (int)B, N, F, H1, H2) &&
+                gcm_edge_distance_step_ring_supported((int)B, N, F, H1, H2);
+      if (ring_ok) abits = at::zeros({B, (int64_t)N, 4}, obs.options().dtype(at::kInt));
+    }
+    if (ring_ok) {   // EuclideanEdge alone, one launch: called directly, so that it also keeps the chain's bit image
+      check(gcm_edge_distance_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                          count_in.data_ptr<int64_t>(), cfg->descs[0].max_distance, nullptr, nullptr, 0,
+                                          packed.data_ptr<float>(), wimg.data_ptr<float>(), cfg->act1, cfg->act2,
+                                          cH.data_ptr<float>(), cA.data_ptr<float>(), cX.data_ptr<float>(),
+                                          buf.data_ptr<float>(), lay, need_bwd ? 1 : 0, (int)cached_steps,
+                                          reinterpret_cast<uint32_t*>(abits.data_ptr()),
+                                          reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
+            "gcm_edge_distance_step_cached");
+    } else
     check(gcm_dense_rows_step_cached_ws(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
                                         count_in.data_ptr<int64_t>(), cfg->descs.empty() ? nullptr : cfg->descs.data(),
                                         (int)cfg->descs.size(), packed.data_ptr<float>(), wimg.data_ptr<float>(),
@@ -849,6 +911,7 @@ struct RowsFast {
       if (cached_steps < N) return launch_cached(obs, nodes_in, adj_in, weights, count_in);
       // (t_abs as an int, ring slots from it: a chain of 2^31 steps ends the cached run)
       if (roll_ok && cached_steps < (int64_t)0x7fffffff) return launch_cached_roll(obs, nodes_in, adj_in, weights, count_in);
+      if (ring_ok && abits.defined()) return launch_ring(obs, nodes_in, adj_in, weights, count_in);
     }
     cache_ok = false;
     ++chain_steps;

@@ -111,8 +111,10 @@ PROTOTYPES = {
     "gcm_dense_rows_step_cached_roll": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]
                                         + [_I] * 5 + [_P]),
     "gcm_dense_rows_cached_launches": (_I, [_P, _I, _I, _I, _I, _I, _I, _I]),
-    "gcm_edge_distance_step_cached": (_I, [_P] * 4 + [_F, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _I, _P]
+    "gcm_edge_distance_step_cached": (_I, [_P] * 4 + [_F, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _I, _P, _P]
                                       + [_I] * 5 + [_P]),
+    "gcm_edge_distance_step_ring_supported": (_I, [_I] * 5),
+    "gcm_edge_distance_step_ring": (_I, [_P] * 4 + [_F, _P, _P, _I, _I, _P, _P, _P, _I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_cached_layout": (_I, [_I] * 5 + [_P]),
     "gcm_sparse_step_plan": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "gcm_sparse_chain_edges": (_I, [_P] * 6 + [_I, _P, _P, _L, _L, _I, _P]),

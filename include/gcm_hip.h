@@ -675,7 +675,23 @@ int gcm_edge_distance_step_cached(const float* obs, float* nodes, float* adj, in
                                   const float* dist_param, const float* cur_rows, int n_cur_rows, const float* params,
                                   const float* weight_image, int act1, int act2, float* cache_h1, float* cache_agg1,
                                   float* cache_nodes, float* saved, const size_t* lay5, int record, int cur_host,
-                                  uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+                                  uint32_t* adj_bits, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                  gcm_stream_t stream);
+/* ... and the same chain past graph_size steps (round 5) - the STEADY STATE of a long rollout: every graph holds N nodes
+ * (the caller guarantees count[b] == N: a chain from empty graphs that has made >= N steps) and every step drops the
+ * oldest one (gcm.py:263-271, 323-355), so the layer-1 rows of older nodes are no longer final.  Still ONE launch: the
+ * distances on the matrix cores, the overflow roll of the donated state IN PLACE (nodes, adj; count stays N), the live
+ * rows' layer 1 re-evaluated from the node image staged for the distances and from adj_bits - the chain's adjacency
+ * as bits, [B][N][4] uint32 (row i: bit j = adj[i, j]), zero at the chain's head, kept current by
+ * gcm_edge_distance_step_cached(adj_bits != NULL) and rolled here -, row cur, the belief.  saved: the GENERAL live-row
+ * record (gcm_dense_rows_layout: lay6 = {total, v, hdr, coef, rows, rw}; mx [B,H2] at 0; in full with record != 0) that
+ * gcm_dense_rows_bptt reads.  No `learned` divisor, the local batch's own current rows, B >= 32, F in {32, 64},
+ * N <= 128, N % 4 == 0, H1, H2 <= 32. */
+int gcm_edge_distance_step_ring_supported(int B, int N, int F, int H1, int H2);
+int gcm_edge_distance_step_ring(const float* obs, float* nodes, float* adj, int64_t* count, float max_distance,
+                                const float* params, const float* weight_image, int act1, int act2, uint32_t* adj_bits,
+                                float* saved, const size_t* lay6, int record, uint32_t* flags, int B, int N, int F,
+                                int H1, int H2, gcm_stream_t stream);
 /* SparseGCM in stepwise use (sparse_gcm.py:72-212 called with x [B, 1, F], taus in {0, 1}) with a TemporalEdge selector
  * (sparse_edge_selectors/temporal.py:18-63; hops_host: HOST array, every hop >= 1), in a chain from empty graphs: the
  * new node's belief from the chain's caches (the layer-1 row of a node is final once written: its edges point at

@@ -148,3 +148,76 @@ def test_euclid_tp_decisions_beyond_graph_size(B, N, F, T, learned):
             assert torch.equal(row, want), t
             n_set += int(want.sum())
     assert n_set > B * T        # (the threshold sits inside the distribution)
+
+
+@pytest.mark.parametrize("B,N,F,H,T", [(40, 32, 64, 32, 85), (33, 16, 32, 32, 50), (96, 64, 64, 32, 150)])
+def test_euclid_chain_steady_state_one_launch_vs_oracle(B, N, F, H, T):
+    """A donated EuclideanEdge chain from empty graphs carried past graph_size steps: from step N on every step drops
+    every graph's oldest node (gcm.py:263-271, 323-355) and runs gcm_edge_distance_step_ring - distances, the roll of the
+    state in place, the live rows re-evaluated from the chain's bit image of the adjacency, ONE launch.  Against the
+    oracle's per-step loop: state bit exact, beliefs and parameter gradients inside the float64 bound."""
+    from gcm.gcm import DenseGCM
+    DenseGCM.did_warn = True
+    torch.manual_seed(B + T)
+    maxd = 3.0
+    ref, g, mem = _mk(F, H, H, N, maxd, donate=True)
+    obs = _clustered(T, B, F, n_c=5, seed=T)
+    w = torch.rand(T, B, H)
+    obs_d = obs.to(DEV)
+    hid, outs = None, []
+    for t in range(T):
+        mx, hid = mem(obs_d[t], hid)
+        outs.append(mx)
+    assert mem.rows_cached_steps_taken() == T and mem.rows_rolled_steps_taken() == T - N
+    out = torch.stack(outs)
+    (out * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    out32, hid32, bounds, (out64, out_atol) = fp64_rollout_bounds(ref, obs, None, w, lambda: od.EuclideanEdge(maxd), N)
+    assert float(hid32[1].sum()) > B * N
+    assert torch.equal(hid[1].cpu(), hid32[1]) and torch.equal(hid[0].cpu(), hid32[0]) and torch.equal(hid[3].cpu(), hid32[3])
+    assert float((out.detach().cpu().double() - out64).abs().max()) <= out_atol
+    for k, p in g.named_parameters():
+        g64, atol = bounds[k]
+        assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
+
+
+def test_euclid_chain_steady_state_full_size_equals_general_kernels():
+    """cfg3's shape (B = 256, N = 128, F = 64) for 2 N + 8 steps, thresholds inside the distance distribution: the
+    one-launch chain (cached steps, then the steady-state step) against the same chain on the general kernels (distance
+    kernel + k_step_rows per step): the state after every 16th step bit for bit, beliefs / gradients to summation order."""
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.distance import EuclideanEdge
+    DenseGCM.did_warn = True
+    B, N, F, T = 256, 128, 64, 264
+    torch.manual_seed(5)
+    obs = torch.rand(T, B, F, device=DEV)
+    probe = EuclideanEdge(1e9)
+    nodes = obs[:N].transpose(0, 1).contiguous()
+    d = probe.distances(nodes, torch.full((B,), N - 1, dtype=torch.long, device=DEV))
+    maxd = float(d[:, : N - 1].quantile(0.15))
+    res = []
+    for one_launch in (True, False):
+        torch.manual_seed(9)
+        ref, g, mem = _mk(F, 32, 32, N, maxd, donate=True)
+        mem.rows_cached_steps = one_launch
+        hid, outs, snaps = None, [], []
+        for t in range(T):
+            mx, hid = mem(obs[t], hid)
+            outs.append(mx)
+            if t % 16 == 15 or t == T - 1:
+                snaps.append((hid[0].clone(), hid[1].clone(), hid[3].clone()))
+        assert mem.rows_rolled_steps_taken() == (T - N if one_launch else 0)
+        out = torch.stack(outs)
+        out.sum().backward()
+        mem.check_flags()
+        res.append((out.detach(), snaps, {k: p.grad.clone() for k, p in g.named_parameters()}))
+    a, b = res
+    for sa, sb in zip(a[1], b[1]):
+        for x, y in zip(sa, sb):
+            assert torch.equal(x, y)
+    deg = float(a[1][-1][1].sum()) / (B * N)
+    assert 5 < deg < 60, deg
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=5e-5)
+    for k in a[2]:
+        scale = float(b[2][k].abs().max()) + 1e-12
+        torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-5, atol=5e-5 * scale, msg=k)
