@@ -492,10 +492,20 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float pf_xc = 0.f;
   if (TAIL && wave == 0) pf_xc = vw.obs[(unsigned)b * (unsigned)F + (unsigned)(lane < F ? lane : F - 1)];
   DSTAMP(0);
+  // TAIL = 2 - the overflow roll (gcm.py:323-355) without reading the state back.  The adjacency of such a chain is
+  // 0 / 1 and the chain keeps it as bits: the rolled rows 0 .. N - 2 (new[i, j] = old[i + 1, j + 1], last column empty)
+  // do not depend on this step's decisions, so they are WRITTEN from the bit image behind the staging barrier - 16.8 MB
+  // of stores per step at cfg3 that drain under the distance phase, no loads of the old matrix - instead of moving
+  // 2 x 16.8 MB in place behind it.  The node rows are in this kernel's registers anyway (staged for the distances):
+  // stored one row up at the same point.
+  constexpr int RA = 128 * 128 / 4 / NT;
+  uint4 wb[RA];
+  const unsigned n_magic = 0xFFFFFFFFu / (unsigned)N + 1u;   // e / N = umulhi(e, n_magic) for e < 2^16
+  float vn[SEG];
   {
     // the first chunk of current rows (its addresses do not depend on this graph's fill level: in flight while
     // `cur` arrives) and the node rows of the live blocks: every load in flight before the first LDS store
-    float vn[SEG], vc[SEG];
+    float vc[SEG];
     load_chunk(0, vc);
     if (!TAIL && j0 >= cur && dist_out == nullptr) return;   // whole block beyond the live rows (uniform)
     const int j = j0 + srow + sh;   // stored row of image row j0 + srow
@@ -505,6 +515,13 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     } else {
 #pragma unroll
       for (int k = 0; k < SEG; ++k) vn[k] = 0.f;
+    }
+    if (TAIL == 2) {   // (requested behind the staging loads: one round trip for all)
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int row = (int)__umulhi((unsigned)(4 * (tid + NT * i)), n_magic);
+        wb[i] = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + (row + 1 < N ? row + 1 : N - 1)) * 4)[0];
+      }
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -518,6 +535,33 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     store_chunk(sC, sCn, 0, vc);
   }
   __syncthreads();
+  if (TAIL == 2) {
+    if (srow < N - 1) {   // stored row srow + 1 -> row srow (every thread's load of its row has landed)
+      float* dst = tl.nodes + ((size_t)b * N + srow) * F + sf0;
+#pragma unroll
+      for (int k = 0; k < SEG; k += 4)
+        if (sf0 + k < F) *reinterpret_cast<f32x4*>(dst + k) = f32x4{vn[k], vn[k + 1], vn[k + 2], vn[k + 3]};
+    }
+    float* ga = tl.adj + (size_t)b * N * N;
+    const int a_end = (N - 1) * N;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int e = 4 * (tid + NT * i);
+      if (e < a_end) {
+        const int row = (int)__umulhi((unsigned)e, n_magic), c1 = e - row * N + 1;   // new row, columns c .. c + 3 <- old row + 1, columns c + 1 .. c + 4
+        const uint4 w = wb[i];
+        const int wi = c1 >> 5;
+        const uint32_t lo = wi == 0 ? w.x : (wi == 1 ? w.y : (wi == 2 ? w.z : w.w));
+        const uint32_t hi = wi == 0 ? w.y : (wi == 1 ? w.z : (wi == 2 ? w.w : 0u));
+        const uint32_t b4 = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (c1 & 31));
+        const int n_ok = N - c1;                               // columns c1 .. N - 1 exist (the last column stays empty)
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (q < n_ok && ((b4 >> q) & 1u)) ? 1.f : 0.f;
+        *reinterpret_cast<f32x4*>(ga + e) = v;
+      }
+    }
+  }
   DSTAMP(1);
   DSTAMP(2);
 
@@ -565,34 +609,10 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   float pfw[NIW];
   float4 pfh;
   const bool hc_lds = TAIL == 1 && (tl.H1 & 3) == 0 && N * tl.H1 <= 4 * NT;   // h1 cache staged in LDS
-  // TAIL = 2: the overflow roll of this graph's state (gcm.py:323-355: nodes[i] <- nodes[i + 1], adj[i, j] <- adj[i + 1,
-  // j + 1], last column empty) rides in the same registers: every load is requested here, under the reductions, and
-  // has landed at the barrier behind the decisions; the stores follow it (source and destination alias: a thread's
-  // stores hit what another thread loads).  As flat arrays the roll is a shift by N + 1 (adjacency) and F (nodes).
-  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-  constexpr int RA = 128 * 128 / 4 / NT, RN = 128 * FP / 4 / NT;   // 16-byte pieces per thread at N = 128
-  f32x4 roll_a[RA], roll_n[RN];
-  uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;
-  if (TAIL == 2) {
-    const float* ga = tl.adj + (size_t)b * N * N;
-    const float* gn = tl.nodes + (size_t)b * N * F;
-    const int a_end = (N - 1) * N, n_end = (N - 1) * F;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int e = 4 * (tid + NT * i);
-      // (the last piece of row N - 2 would read one float past the graph: it takes the aligned piece and shifts below)
-      const int src = e >= a_end ? 0 : (e == a_end - 4 ? e + N : e + N + 1);
-      roll_a[i] = *reinterpret_cast<const f32x4u*>(ga + src);
-    }
-#pragma unroll
-    for (int i = 0; i < RN; ++i) {
-      const int e = 4 * (tid + NT * i);
-      roll_n[i] = *reinterpret_cast<const f32x4*>(gn + (e >= n_end ? 0 : e + F));
-    }
-    if (tid < N - 1) {   // old row tid + 1 of the adjacency bits -> (shifted below) image row tid
-      const uint4 t = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + tid + 1) * 4)[0];
-      ob0 = t.x; ob1 = t.y; ob2 = t.z; ob3 = t.w;
-    }
+  uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;   // TAIL = 2: old row tid + 1 of the bits -> (shifted below) image row tid
+  if (TAIL == 2 && tid < N - 1) {
+    const uint4 t = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + tid + 1) * 4)[0];
+    ob0 = t.x; ob1 = t.y; ob2 = t.z; ob3 = t.w;
   }
   if (TAIL) {
 #pragma unroll
@@ -635,36 +655,24 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     //      the distances, one live row per wave at a time; wave 0 then row cur.  The record is the GENERAL live-row
     //      record (rows_common.h: the rows h1 | agg1 | x travel in it).  dist_param == NULL (the image is unscaled).
     if (tid < RB && !(tid < 32 * nb && j0 + tid < N)) sDec[tid] = 0.f;   // rows beyond the live blocks
+    float* sXc = reinterpret_cast<float*>(sBits + RB * 4);    // [64] the observation of this graph
+    if (wave == 0 && lane < FP) sXc[lane] = lane < F ? pf_xc : 0.f;
     if (tid < RB) {   // the adjacency bits after the roll: row i <- (old row i + 1) >> 1 (column 0 falls off)
       uint32_t* o = sBits + tid * 4;
       o[0] = (ob0 >> 1) | (ob1 << 31); o[1] = (ob1 >> 1) | (ob2 << 31); o[2] = (ob2 >> 1) | (ob3 << 31); o[3] = ob3 >> 1;
     }
-    __syncthreads();   // decisions, weights and bits are in LDS; every roll load has landed
+    __syncthreads();   // decisions, weights and bits are in LDS
+    DSTAMP(12);
     const int H1 = tl.H1, H2 = tl.H2;
     const unsigned gb = (unsigned)b;
     // the selected rows (image rows j < N - 1): every wave takes the same two ballots
     const unsigned long long m0 = __ballot(lane < N - 1 && sDec[lane] != 0.f);
     const unsigned long long m1 = __ballot(lane + 64 < N - 1 && sDec[(lane + 64) & (RB - 1)] != 0.f);
     const int n0 = __popcll(m0), n_sel = n0 + __popcll(m1);
-    {   // the state, in place: the rolled rows, then row N - 1 (the new node, its decisions); the bit image likewise
+    {   // the state: row N - 1 (the new node, its decisions); the bit image (the rolled rows went out behind the staging)
       float* ga = tl.adj + (size_t)b * N * N;
       float* gn = tl.nodes + (size_t)b * N * F;
       const int a_end = (N - 1) * N, n_end = (N - 1) * F;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const int e = 4 * (tid + NT * i);
-        if (e < a_end) {
-          f32x4 v = roll_a[i];
-          if (e == a_end - 4) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; }
-          if ((e + 3) % N == N - 1) v[3] = 0.f;            // (N % 4 == 0: only a piece's last element can be column N - 1)
-          *reinterpret_cast<f32x4*>(ga + e) = v;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < RN; ++i) {
-        const int e = 4 * (tid + NT * i);
-        if (e < n_end) *reinterpret_cast<f32x4*>(gn + e) = roll_n[i];
-      }
       if (tid < N) ga[a_end + tid] = tid < N - 1 ? sDec[tid] : 0.f;
       if (wave == 1 && lane < F) gn[n_end + lane] = vw.obs[gb * (unsigned)F + (unsigned)lane];
       if (tid < N) {
@@ -674,6 +682,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         reinterpret_cast<uint4*>(tl.abits + ((size_t)b * N + tid) * 4)[0] = t;
       }
     }
+    DSTAMP(13);
     // this wave's weights of layer 1, once: lanes 0-31 k < FP / 2, lanes 32-63 the rest (met by one cross-half add)
     constexpr int KH = FP / 2;
     const int hl = lane & 31, kh = lane >> 5, fl = lane < FP ? lane : FP - 1;
@@ -711,24 +720,46 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       __builtin_amdgcn_wave_barrier();                        // (the next row overwrites svw)
       return hl < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
     };
-    // live rows: list position l (ascending j) -> wave l mod 16
+    DSTAMP(14);
+    // live rows: list position l (ascending j) -> wave l mod 16.  No scalar bit loops (each find-first-bit step
+    // compiled to a branch tree with a VALU round trip): a selected row's position is its rank among the mask bits
+    // below it, its sources become a compact ascending list in this wave's LDS scratch, gathered eight per trip.
     {
-      unsigned long long a0 = m0, a1 = m1;
-      for (int l = 0; l < n_sel; ++l) {
-        const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
-        if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
-        if ((l & 15) != wave) continue;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int rank0 = __popcll(m0 & below), rank1 = n0 + __popcll(m1 & below);
+      int* widx = reinterpret_cast<int*>(sC + 16 * 2 * FP) + wave * 128;     // [128] this wave's source list
+      // (list position n_sel is row cur itself: its sources are the selected rows, its features the observation - its
+      //  layer 1 runs beside the others instead of behind the barrier on wave 0)
+      for (int l = wave; l <= n_sel; l += 16) {
+        const bool is_cur = l == n_sel;
+        const unsigned long long h0 = __ballot(((m0 >> lane) & 1ull) && rank0 == l);
+        const unsigned long long h1 = __ballot(((m1 >> lane) & 1ull) && rank1 == l);
+        const int j = is_cur ? N - 1 : (h0 ? __builtin_ctzll(h0) : 64 + __builtin_ctzll(h1));     // (uniform)
+        const uint4 wq = *reinterpret_cast<const uint4*>(sBits + (is_cur ? 0 : j) * 4);
+        const unsigned long long s0 = is_cur ? m0 : (((unsigned long long)wq.y << 32) | wq.x);
+        const unsigned long long s1 = is_cur ? m1 : (((unsigned long long)wq.w << 32) | wq.z);
+        const int c0 = __popcll(s0), n_src = __builtin_amdgcn_readfirstlane(c0 + __popcll(s1));
+        if ((s0 >> lane) & 1ull) widx[__popcll(s0 & below)] = lane;
+        if ((s1 >> lane) & 1ull) widx[c0 + __popcll(s1 & below)] = lane + 64;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float x = is_cur ? sXc[fl] : sN[j * NS + fl];
         float agg = 0.f;
+#pragma unroll 1
+        for (int q0 = 0; q0 < n_src; q0 += 8) {                  // sources ascending (adj[j, k] = 1, k < j), eight per trip
+          const int4 ia = *reinterpret_cast<const int4*>(widx + q0), ib = *reinterpret_cast<const int4*>(widx + q0 + 4);
+          const int ks[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+          float bx[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                          // sources in ascending order (adj[j, k] = 1, k < j)
-          uint32_t w = __builtin_amdgcn_readfirstlane(sBits[j * 4 + q]);
-          while (w) {
-            const int k = q * 32 + __builtin_ctz(w);
-            w &= w - 1;
-            agg += sN[k * NS + fl];
+          for (int qq = 0; qq < 8; ++qq) {
+            const bool any = q0 + qq < n_src;
+            const float tx = sN[(any ? ks[qq] : 0) * NS + fl];
+            bx[qq] = any ? tx : 0.f;
           }
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) agg += bx[qq];
         }
-        const float x = sN[j * NS + fl];
+        __builtin_amdgcn_wave_barrier();                          // (the next row rewrites widx)
         const float h = layer1(lane < F ? agg : 0.f, lane < F ? x : 0.f);
         if (lane < 32) sH1[l * 32 + lane] = h;
         if (rec) {
@@ -738,37 +769,43 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         }
       }
     }
+    DSTAMP(15);
     __syncthreads();
     if (wave != 0) return;
-    // ---- row cur = N - 1 on wave 0: agg1 over the selected rows, layer 1, agg2 over their h1, layer 2
-    const float xc = pf_xc;
-    float agg1 = 0.f, agg2 = 0.f;
-    {
-      unsigned long long a0 = m0, a1 = m1;
-      for (int l = 0; l < n_sel; ++l) {
-        const int j = a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1);
-        if (a0) a0 &= a0 - 1; else a1 &= a1 - 1;
-        agg1 += sN[j * NS + fl];
-        agg2 += sH1[l * 32 + hl];
+    DSTAMP(16);
+    // ---- row cur = N - 1 on wave 0: agg2 over the live rows' h1 (ascending), layer 2
+    float agg2 = 0.f;
+#pragma unroll 1
+    for (int l0 = 0; l0 < n_sel; l0 += 8) {
+      float bh[8];
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        const float th = sH1[((l0 + qq) & 127) * 32 + hl];
+        bh[qq] = l0 + qq < n_sel ? th : 0.f;
       }
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) agg2 += bh[qq];
     }
-    agg1 = lane < F ? agg1 : 0.f;
     agg2 = hl < H1 ? agg2 : 0.f;
-    const float h1c = layer1(agg1, lane < F ? xc : 0.f);
+    DSTAMP(17);
+    const float h1c = sH1[(n_sel & 127) * 32 + hl];
+    DSTAMP(18);
     if (lane < 32) { svw[lane] = agg2; svw[32 + lane] = h1c; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float p2;
     {   // layer 2: lanes 0-31 W_rel2 . agg2, lanes 32-63 W_root2 . h1cur
+      float w2r[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) w2r[k] = sW[(2 * FP + kh * 32 + k) * 32 + hl];
       float pa = 0.f;
 #pragma unroll
       for (int k4 = 0; k4 < 8; ++k4) {
         const float4 a = *reinterpret_cast<const float4*>(svw + kh * 32 + 4 * k4);
-        const float* w2 = sW + (2 * FP + kh * 32 + 4 * k4) * 32 + hl;
-        pa = fmaf(w2[0], a.x, pa);
-        pa = fmaf(w2[32], a.y, pa);
-        pa = fmaf(w2[64], a.z, pa);
-        pa = fmaf(w2[96], a.w, pa);
+        pa = fmaf(w2r[4 * k4], a.x, pa);
+        pa = fmaf(w2r[4 * k4 + 1], a.y, pa);
+        pa = fmaf(w2r[4 * k4 + 2], a.z, pa);
+        pa = fmaf(w2r[4 * k4 + 3], a.w, pa);
       }
       p2 = pa + __shfl_xor(pa, 32) + bias2;
     }
@@ -779,10 +816,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         tl.saved[tl.o_v + gb * 2 * H1 + lane] = agg2;
         tl.saved[tl.o_v + gb * 2 * H1 + H1 + lane] = h1c;
       }
-      float* row = rows + (size_t)n_sel * tl.rw;              // row cur: last in the list
-      if (lane < H1) row[lane] = h1c;
-      if (lane < F) { row[H1 + lane] = agg1; row[H1 + F + lane] = xc; }
-      float* coef = tl.saved + tl.o_coef + (size_t)gb * N;
+      float* coef = tl.saved + tl.o_coef + (size_t)gb * N;    // (row cur - last in the list - was written with the live rows)
       for (int l = lane; l <= n_sel; l += 64) coef[l] = l < n_sel ? 1.f : 0.f;
       if (lane == 0) {
         int* hdr = reinterpret_cast<int*>(tl.saved + tl.o_hdr) + 4 * gb;
@@ -792,6 +826,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const bool nonfinite = __any(lane < H2 && !isfinite(v));
     if (lane == 0 && (nonfinite || gb == 0))
       atomicOr(tl.flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (gb == 0 ? GCM_FLAG_WRAPPED : 0u));   // gcm.py:264-266
+    DSTAMP(19);
     return;
   }
   if (TAIL == 1) {
@@ -1153,7 +1188,7 @@ extern "C" int gcm_edge_distance_step_ring(const float* obs, float* nodes, float
   constexpr int RB = 128;
   const int FT = F / 32;
   const size_t lds = sizeof(float) * ((size_t)RB * (32 * FT + 1) + (size_t)2 * 32 * FT * 129 + RB + 2 * 128 +
-                                      (size_t)8 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32 + 4 * RB);
+                                      (size_t)8 * RB + (size_t)(2 * 32 * FT + 64) * 32 + RB + (size_t)128 * 32 + 4 * RB + 64);
   hipStream_t s = (hipStream_t)stream;
   if (FT == 1) {
     auto kern = k_euclid_mfma2<1, 2>;

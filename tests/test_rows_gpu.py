@@ -382,8 +382,12 @@ def test_rows_path_distance_selectors_vs_fused_path(kind, B, N, F, T):
         # a donated chain from empty graphs: its first N steps run on the chain's caches (the selector's decision row
         # handed to k_step_rows_cached_sel; widths that are not 32 / 64 - F = 20, 12 here - in the padded form), the
         # rest - the graphs roll - on the general kernel
+        # (round 5: EuclideanEdge alone in its one-launch form stays on the chain past N steps - the steady-state step,
+        #  gcm_edge_distance_step_ring, counted with the cached ones)
         if mode == "rows_donated":
-            assert mem.rows_cached_steps_taken() == min(T, N)
+            ring = kind == "euclid" and B >= 32 and F in (32, 64)
+            assert mem.rows_cached_steps_taken() == (T if ring else min(T, N))
+            assert mem.rows_rolled_steps_taken() == (max(0, T - N) if ring else 0)
         out = torch.stack(outs)
         (out * torch.linspace(0.5, 1.5, out.numel(), device=DEV).view_as(out)).sum().backward()
         mem.check_flags()
