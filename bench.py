@@ -149,6 +149,11 @@ def rollout_api(mem, obs, bucket=None, weight=1.0):
     return loss
 
 
+def dist_backend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_initialized() else None
+
+
 def capture(fn, zero):
     """`fn` as one HIP graph (captured in this process; the usual side-stream warm-up first)."""
     import torch
@@ -649,12 +654,37 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         for m in mods:
             m.zero_grad(set_to_none=True)
 
-    graph = None if args.no_graph else capture(lambda: rollout(mem, obs), zero)
+    # N > 1: the gradients alias the flat bucket BEFORE the capture (GradBucket.attach: the backward accumulates into it
+    # in place - no gather / copy-back launch per step), the bucket's zero fill is a node of the graph, and so is the
+    # all-reduce when the backend can be captured (RCCL); else the collective follows each replay eagerly.
+    comm = {"captured": False, "launches_outside_graph": 0, "bucket_floats": bucket.numel}
+    graph = None
+    if not args.no_graph and world > 1:
+        bucket.attach()
+
+        def body(with_comm):
+            bucket.zero()
+            rollout(mem, obs)
+            if with_comm:
+                bucket.all_reduce_mean(weight)
+        if os.environ.get("GCM_BENCH_CAPTURE_COMM", "1") == "1" and dist_backend() == "nccl":
+            try:
+                graph = capture(lambda: body(True), bucket.zero)
+                comm["captured"] = True
+            except Exception as e:      # (reported; the eager collective is the fallback)
+                comm["capture_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+                torch.cuda.synchronize()
+                graph = None
+        if graph is None:
+            graph = capture(lambda: body(False), bucket.zero)
+    elif not args.no_graph:
+        graph = capture(lambda: rollout(mem, obs), zero)
 
     def step():
         if graph is not None:
             graph.replay()
-            bucket.all_reduce_mean(weight)
+            if world > 1 and not comm["captured"]:
+                bucket.all_reduce_mean(weight)
         else:
             rollout(mem, obs, bucket, weight)
             zero()
@@ -664,6 +694,14 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     flags = mem._flag_word(device)
     bits = int(flags.item())
     assert not (bits & 6), f"kernels flagged {bits}"
+    if world > 1:
+        # the collective alone (the flat bucket, ~30 KB: latency-bound), events around 20 calls on the launch stream
+        comm["comm_us_per_step"] = round(event_time(lambda: bucket.all_reduce_mean(weight), 20, warm=3) * 1e3, 2)
+        comm["launches_outside_graph"] = 0 if (graph is not None and comm["captured"]) else 1 + bucket.launches
+        comm["note"] = ("per bench step besides the replayed graph: the all-reduce of the flat gradient bucket (and what "
+                        "GradBucket.all_reduce_mean launches around it: nothing once the gradients alias the bucket and "
+                        "the weight folds into ReduceOp.AVG); captured = the collective is a node of the HIP graph")
+        line["comm"] = comm
     if external_profiler_attached():
         # under rocprofv3 the run is the timed region alone: its kernel-trace statistics are then those of the
         # headline's kernels (profiles/<tag>_bench_<cfg>_kernel_stats.csv), to be read against the unprofiled line
@@ -712,6 +750,25 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         for q in mods_f:
             q.zero_grad(set_to_none=True)
     variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
+    rollout_kernels = None
+    if rank == 0 and c["selector"] == "euclid":
+        # the time-parallel entry's own kernels (csrc/euclid_tp.hip): every step's decisions as one causal contraction
+        pr = profile_kernels(roll, reps=2)
+        kt = find_kernel(pr, "k_euclid_tp<")
+        if kt is not None:
+            pairs = sum(min(t, N - 1) for t in range(T))
+            blocks = sum(32 * ((min(t, N) + 31) // 32) for t in range(1, T))
+            alg, exe = 2.0 * B * B * F * pairs, 2.0 * B * B * (F + 2) * blocks
+            sec = kt[1]["avg_us"] * 1e-6
+            rollout_kernels = {
+                "kernel": kt[0], "avg_launch_ms": kt[1]["avg_us"] * 1e-3, "launches_per_call": kt[1]["launches_per_call"],
+                "flops_algorithmic": alg, "TFLOP/s": alg / sec / 1e12,
+                "frac_of_fp32_mfma_peak": alg / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "flops_executed": exe, "frac_executed": exe / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "table": kernel_table(pr, top=6)[0],
+                "note": "DenseGCM.rollout(obs[T,B,F]) with EuclideanEdge: k_euclid_tp = the decisions of all T steps (2 B^2 F "
+                        "flops per candidate (step, node) pair: algorithmic; executed: whole 32-slot blocks and the norm "
+                        "k step), then the GNN of all steps in one launch per graph, the backward over the T records"}
     if c["selector"] == "temporal":
 
         def fwd_only():
@@ -808,9 +865,15 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                     variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
                     variants["T%d_steady_state_kernel" % T2] = kr[0]
             else:
-                # the kernels that run T2 - N times per rollout are the steady-state step's (the first N steps run the
-                # cached kernels of the headline): their mean durations add up to the steady-state step
-                ss = {k: d for k, d in p2.items() if abs(d["launches_per_call"] - (T2 - N)) < 0.5}
+                # the kernels of the steady-state step (the first N steps run the cached kernels of the headline): the
+                # one-launch EuclideanEdge step k_euclid_mfma2<.., 2>; for LearnedEdge every kernel that runs once per
+                # steady-state step; their mean durations add up to the steady-state step
+                if c["selector"] == "euclid":
+                    ss = {k: d for k, d in p2.items() if "k_euclid_mfma2<" in k and k.rstrip().endswith(", 2>")}
+                    if not ss:
+                        ss = {k: d for k, d in p2.items() if "k_step_rows<" in k or "k_euclid_mfma2<2, 0>" in k}
+                else:
+                    ss = {k: d for k, d in p2.items() if abs(d["launches_per_call"] - (T2 - N)) < 0.5}
                 variants["T%d_steady_state_step_us" % T2] = round(sum(d["avg_us"] for d in ss.values()), 3) if ss else None
                 variants["T%d_steady_state_kernels" % T2] = {k: round(d["avg_us"], 3) for k, d in ss.items()}
                 t256_table = kernel_table(p2, top=8)[0]
@@ -1043,6 +1106,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         "kernel_ms": kernel_ms,
         "kernel_table": {"rows": table, "gpu_us_per_step": round(gpu_us, 2), "source": src},
     })
+    if rollout_kernels is not None:
+        line["rollout_api_kernels"] = rollout_kernels
     if t256_table is not None:
         line["T%d_kernel_table" % (2 * N)] = t256_table
     if layered is not None:

@@ -2029,6 +2029,8 @@ struct SparseStepNode : public torch::autograd::Node {
   bool all_new = false, flat_is_state = false;
   c10::VariableVersion mx_vc;      // version counter of the returned rows when they alias out2, and its value then
   uint32_t mx_version = 0;
+  c10::VariableVersion flat_vc;    // ... of the returned node matrix when the flat matrix aliases it (flat_is_state)
+  uint32_t flat_version = 0;
 
   // inputs: x, nodes_in, the gate; outputs: mx_dense, nodes_out
   variable_list apply(variable_list&& grads) override {
@@ -2037,6 +2039,11 @@ struct SparseStepNode : public torch::autograd::Node {
     TORCH_CHECK(flat.defined(), "Trying to backward through a SparseGCM step a second time (its saved tensors "
                                 "were freed); pass retain_graph=True to the first call");
     if (!grads[0].defined() && !grads[1].defined()) return out;
+    // (the flat matrix layer 1's weight gradient reads IS the node matrix handed back to the caller)
+    TORCH_CHECK(!flat_is_state || flat_vc.current_version() == flat_version,
+                "one of the variables needed for gradient computation has been modified by an inplace operation: the node "
+                "matrix returned by this SparseGCM call (every graph full: it is the flat matrix its backward reads) - "
+                "edit a clone, or edit it after backward()");
     const auto opt = flat.options();
     const gcm_stream_t st = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(flat.get_device()).stream());
     const bool need_x = task_should_compute_output(0), need_nodes = task_should_compute_output(1);
@@ -2570,6 +2577,10 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
     // (the returned rows alias out2, which the backward reads: an in-place write by the caller must be noticed)
     node->mx_vc = mx.unsafeGetTensorImpl()->version_counter();
     node->mx_version = node->mx_vc.current_version();
+    if (flat_is_state) {
+      node->flat_vc = nodes_out.unsafeGetTensorImpl()->version_counter();
+      node->flat_version = node->flat_vc.current_version();
+    }
     auto edge = [](const at::Tensor& t) {
       return t.requires_grad() ? torch::autograd::impl::gradient_edge(t) : torch::autograd::Edge();
     };

@@ -47,7 +47,11 @@ class Distance(torch.nn.Module):
     def gather_current(self, cur):
         """Batch-sharded run (shard_group set): all-gather this rank's current nodes [B, F] into the
         persistent [world * B, F] buffer the kernels read.  -> True when the buffer was (re)allocated
-        (the configurations that baked its address must re-read it)."""
+        (the configurations that baked its address must re-read it).
+        The equal-shard check (a size all_gather) runs when a rank (re)allocates its buffer, i.e. on the first
+        call and when ITS batch size or feature width changes - a rank-local condition: a change of the batch
+        size must therefore happen on every rank at the same step (as a sharded batch does by construction);
+        otherwise the ranks would enter different collectives."""
         import torch.distributed as dist
         group = None if self.shard_group is True else self.shard_group
         world = dist.get_world_size(group)

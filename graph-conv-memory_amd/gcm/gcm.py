@@ -739,22 +739,41 @@ class DenseGCM(torch.nn.Module):
             self._poll(flags)
         return mx, (nodes_out, adj_out, weights, num_nodes_next)
 
-    def rollout(self, obs, hidden=None, batch_first=False):
+    def rollout(self, obs, hidden=None, batch_first=False, truncate=True):
         """T memory steps at once: obs [T, B, feat] -> (beliefs [T, B, H], hidden after the
         last step); batch_first=True: obs [B, T, feat] -> beliefs [B, T, H] - the shape RLlib's wrapper holds
-        (ray_gcm.py:186-209: `flat` [B, T, F] in, the stacked beliefs [B*T, H] out).  Identical in result to T calls
-        of forward().  Index-writing selectors on the canonical GNN: the whole rollout is enqueued by one C call and
-        is one autograd node; every other configuration (LearnedEdge, distance selectors, folded transforms, user
-        modules) runs the per-step kernels in a loop - on a state this call owns, so the steps advance it IN PLACE
-        whatever `donate_state` says (the caller never sees the intermediate states; the incoming state is copied
-        once)."""
+        (ray_gcm.py:186-209: `flat` [B, T, F] in, the stacked beliefs [B*T, H] out).  The VALUES (beliefs, hidden
+        state) are those of T calls of forward(), and so is every gradient that flows inside the call.  Index-writing
+        selectors on the canonical GNN: the whole rollout is enqueued by one C call and is one autograd node;
+        EuclideanEdge alone and LearnedEdge from empty graphs: time-parallel forwards (csrc/euclid_tp.hip,
+        gcm_learned_rollout_fwd); every other configuration runs the per-step kernels in a loop - on a state this
+        call owns, so the steps advance it IN PLACE whatever `donate_state` says (the caller never sees the
+        intermediate states; the incoming state is copied once).
+
+        truncate (LearnedEdge only - the one selector whose ADJACENCY carries a gradient, learned.py:89-113): True
+        (default) - the hidden state going in and the one coming out are plain tensors: truncated BPTT at the call
+        boundary, which is what RLlib's state passing does (ray_gcm.py:186-209 hands states over as detached
+        batches).  A later call's loss then does not reach this call's edge selections through the returned
+        adjacency, as it would across T forward() calls.  False: the chain of hidden states is kept across the call
+        boundary exactly as T forward() calls keep it (functional state, per-step kernels; slower)."""
         assert obs.dim() == 3 and obs.dtype == torch.float32
         if batch_first:
-            out, hidden = self.rollout(obs.transpose(0, 1), hidden)
+            out, hidden = self.rollout(obs.transpose(0, 1), hidden, truncate=truncate)
             return out.transpose(0, 1), hidden
         if obs.is_cuda and obs.device.index != torch.cuda.current_device():
             with torch.cuda.device(obs.device):
-                return self.rollout(obs, hidden)
+                return self.rollout(obs, hidden, truncate=truncate)
+        if not truncate and torch.is_grad_enabled():
+            from .edge_selectors.learned import LearnedEdge
+            if any(isinstance(m, LearnedEdge) for sel in (self.edge_selectors, self.aux_edge_selectors)
+                   if sel is not None for m in sel.modules()):
+                outs = []
+                for t in range(obs.shape[0]):        # T forward() calls: the chain (_gcm_lin / adj.grad_fn) survives
+                    mx, hidden = self(obs[t], hidden)
+                    outs.append(mx)
+                if not outs:
+                    return self.rollout(obs, hidden)
+                return torch.stack(outs), hidden
         if obs.shape[0] == 0:
             if hidden is None:
                 hidden = self.get_initial_hidden_state(obs[0] if obs.shape[0] else obs.new_zeros(obs.shape[1:]))
@@ -823,7 +842,8 @@ class DenseGCM(torch.nn.Module):
         ext = _ops._ext.module()
         T, B = obs.shape[0], obs.shape[1]
         N = cfg.N
-        if ext is None or not hasattr(ext, "learned_rollout") or not cfg.learned_cpp_handle() or (N & 3) or (cfg.F & 3):
+        if (ext is None or not hasattr(ext, "learned_rollout") or not cfg.learned_cpp_handle() or (N & 3) or (cfg.F & 3)
+                or B > 65535):            # (gcm_learned_rollout_fwd: GCM_EUNSUPPORTED above 65535 graphs - ADVICE r4)
             return self._rollout_loop(obs, self.get_initial_hidden_state(obs[0]), True)
         root = self._packed_params(cfg, head=True)
         sel = cfg.learned_sel

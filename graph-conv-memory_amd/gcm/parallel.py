@@ -61,12 +61,43 @@ class GradBucket:
         off, p = self.offsets[i], self.params[i]
         return self.flat[off:off + p.numel()].view_as(p)
 
+    def _ensure_flat(self):
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, device=dev)
+            self.offsets, off = [], 0
+            for p in self.params:
+                self.offsets.append(off)
+                off += p.numel()
+
+    def attach(self):
+        """Make every `p.grad` its (zeroed) slice of the flat buffer NOW - before the first backward, e.g. ahead of a
+        HIP-graph capture of `bucket.zero(); loss.backward(); bucket.all_reduce_mean(w)`: autograd then accumulates
+        into the bucket in place (AccumulateGrad adds into an existing .grad), the captured graph needs no gather /
+        copy-back launch, and the collective itself can sit inside the graph (all_reduce_mean is capture-safe once
+        the gradients alias the bucket: a scale and the collective, no allocation)."""
+        if not self.params:
+            return self
+        self._ensure_flat()
+        self.flat.zero_()
+        for i, p in enumerate(self.params):
+            p.grad = self._view(i)
+        self.alias_grads = True
+        return self
+
+    def aliased(self):
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        return all(p.grad is not None and p.grad.is_contiguous() and p.grad.data_ptr() == base + 4 * o
+                   for p, o in zip(self.params, self.offsets))
+
     def zero(self):
         """zero the bucket (and with it every aliased gradient) in one launch"""
         if self.flat is not None:
             self.flat.zero_()
 
-    def all_reduce_mean(self, local_weight=1.0):
+    def all_reduce_mean(self, local_weight=1.0, force_collective=False):
         """grad <- sum_r local_weight_r * grad_r  (pass local_weight = B_local / B_global to
         get the gradient of the global-batch mean loss from per-rank local-mean losses).
         Launches per call: one multi-tensor gather into the flat buffer (none when the gradients
@@ -77,18 +108,10 @@ class GradBucket:
         if not self.params:
             return
         world = dist.get_world_size() if dist.is_initialized() else 1
-        if world == 1 and local_weight == 1.0:
+        if world == 1 and local_weight == 1.0 and not (force_collective and dist.is_initialized()):
             return
-        dev = self.params[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, device=dev)
-            self.offsets, off = [], 0
-            for p in self.params:
-                self.offsets.append(off)
-                off += p.numel()
-        base = self.flat.data_ptr()
-        aliased = all(p.grad is not None and p.grad.is_contiguous() and p.grad.data_ptr() == base + 4 * o
-                      for p, o in zip(self.params, self.offsets))
+        self._ensure_flat()
+        aliased = self.aliased()
         if not aliased:
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
             torch._foreach_copy_([self._view(i) for i in range(len(self.params))], grads)
@@ -97,7 +120,7 @@ class GradBucket:
         if local_weight != 1.0 and not avg:
             self.flat.mul_(local_weight)
             self.launches += 1
-        if world > 1:
+        if world > 1 or (force_collective and dist.is_initialized()):   # (force_collective: a one-rank communicator - tests)
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
         if self.alias_grads:
             if not aliased:

@@ -407,3 +407,59 @@ def test_learned_fast_host_path_equals_interpreter_path(B, N, F, H, T, donate):
     del mem_f, mx, hidden
     gc.collect()
     assert wr() is None
+
+
+def test_learned_rollout_call_boundary_truncate():
+    """what DenseGCM.rollout does with the adjacency's gradient chain at the call boundary, pinned.  Two
+    consecutive chunks of one sequence, the loss on the SECOND chunk only: with truncate=False the edge network still
+    receives the gradient that reaches the first chunk's selections through the hidden state (exactly what 2 T
+    forward() calls give: learned.py:89-113, the returned adjacency carries its gumbel-softmax history); with
+    truncate=True (default; RLlib-style detached states, ray_gcm.py:186-209) the first chunk's selections get none."""
+    from gcm import nn as G
+    from gcm.gcm import DenseGCM
+    from gcm.edge_selectors.learned import LearnedEdge
+    B, N, F, H, T = 6, 32, 32, 32, 10
+    torch.manual_seed(3)
+    obs = torch.rand(2 * T, B, F, device=DEV)
+    noise = torch.rand(2 * T, B, N, device=DEV).clamp_(1e-6, 1 - 1e-6)
+    noise = -torch.log(-torch.log(noise))
+
+    def run(mode):
+        torch.manual_seed(11)
+        g = G.Sequential("x, adj, weights, B, N", [
+            (G.DenseGraphConv(F, H), "x, adj -> x"), torch.nn.Tanh(),
+            (G.DenseGraphConv(H, H), "x, adj -> x"), torch.nn.Tanh()]).to(DEV)
+        sel = LearnedEdge(F).to(DEV)
+        step = {"t": 0}
+
+        def nf(like):
+            t = step["t"]
+            step["t"] += 1
+            return noise[t]
+        sel.noise_fn = nf
+        mem = DenseGCM(g, edge_selectors=sel, graph_size=N)
+        if mode == "steps":
+            hid, outs = None, []
+            for t in range(2 * T):
+                mx, hid = mem(obs[t], hid)
+                outs.append(mx)
+            out2 = torch.stack(outs[T:])
+        else:
+            _, hid = mem.rollout(obs[:T], None, truncate=mode == "truncate")
+            out2, hid = mem.rollout(obs[T:], hid, truncate=mode == "truncate")
+        out2.sum().backward()
+        mem.check_flags()
+        return out2.detach(), hid[1].detach(), {k: p.grad.clone() for k, p in sel.named_parameters()}
+
+    ref = run("steps")
+    keep = run("keep")
+    cut = run("truncate")
+    assert torch.equal(keep[1], ref[1]) and torch.equal(cut[1], ref[1])          # the same sampled edges
+    torch.testing.assert_close(keep[0], ref[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cut[0], ref[0], rtol=1e-5, atol=1e-6)
+    differs = False
+    for k in ref[2]:
+        scale = float(ref[2][k].abs().max()) + 1e-12
+        torch.testing.assert_close(keep[2][k], ref[2][k], rtol=1e-4, atol=2e-5 * scale, msg=k)
+        differs = differs or float((cut[2][k] - ref[2][k]).abs().max()) > 1e-3 * scale
+    assert differs, "truncate=True must cut the gradient that crosses the call boundary"
