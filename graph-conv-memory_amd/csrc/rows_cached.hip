@@ -272,6 +272,9 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
   if (m < 2) { if (lane < H1 && k < F) v = (m == 0 ? w_rel1 : w_root1)[(size_t)lane * F + k]; }
   else { if (lane < H2 && k < H1) v = (m == 2 ? w_rel2 : w_root2)[(size_t)lane * H1 + k]; }
   image[e] = v;
+  // ... and once more four k per lane, image4[m][k / 4][lane][k % 4] behind it: lane h's row of a matrix as 16-byte
+  // loads (k_step_rows_cached_img: 32 load instructions per step instead of 128)
+  image[4 * 64 * 64 + (((m * 16 + (k >> 2)) * 64 + lane) << 2) + (k & 3)] = v;
 }
 
 // SEL: the decisions of a distance selector arrive as a row (sel_row) and the selected rows beyond the first four
@@ -279,7 +282,7 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
 // EX: F == FP and H1 == HP (compile-time widths: cfg2's / cfg3's timed kernels); otherwise the widths are the runtime
 // Fr <= FP, H1r <= HP - the weight image is zero beyond them (k_cached_weight_image) and the operand vectors are
 // written zero-padded, so the products run over FP / HP all the same.
-template <int FP, int HP, bool SEL, bool EX = true>
+template <int FP, int HP, bool SEL, bool EX = true, bool V4 = false>
 __device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     const gcm_fused::Edits& E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
@@ -302,10 +305,26 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   }
   // every weight load in flight at once (coalesced: lane h reads element h of row k of the image)
   float r1[FP], t1[FP], r2[HP], t2[HP];
+  if (V4) {   // image4[m][k / 4][lane][4] (the second half of the image): 16 bytes per lane and load
+    const f32x4* i4 = reinterpret_cast<const f32x4*>(image + 4 * 64 * 64);
 #pragma unroll
-  for (int k = 0; k < FP; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
+    for (int k4 = 0; k4 < FP / 4; ++k4) {
+      const f32x4 a = i4[(0 * 16 + k4) * 64 + lane], c = i4[(1 * 16 + k4) * 64 + lane];
 #pragma unroll
-  for (int k = 0; k < HP; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+      for (int q = 0; q < 4; ++q) { r1[4 * k4 + q] = a[q]; t1[4 * k4 + q] = c[q]; }
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < HP / 4; ++k4) {
+      const f32x4 a = i4[(2 * 16 + k4) * 64 + lane], c = i4[(3 * 16 + k4) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { r2[4 * k4 + q] = a[q]; t2[4 * k4 + q] = c[q]; }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < FP; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
+#pragma unroll
+    for (int k = 0; k < HP; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  }
   const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
   const float bias1 = b1[hl], bias2 = b2[ol];
   const float xc = obs[gb * F + fl];
@@ -457,6 +476,15 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
   step_rows_cached_img_body<FP, HP, false>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
                                            flags, B, N, H2, cur_host, nullptr);
+}
+template <int FP, int HP>   // ... the weights as 16-byte loads (image4)
+__global__ __launch_bounds__(64) void k_step_rows_cached_img4(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
+  step_rows_cached_img_body<FP, HP, false, true, true>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX,
+                                                       saved, lay, flags, B, N, H2, cur_host, nullptr);
 }
 template <int FP, int HP>
 __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
@@ -908,6 +936,10 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_sel<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
                          obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row);                               \
+    else if (has_bias & GCM_STEP_IMG_V4)                                                                          \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img4<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,      \
+                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         cache_nodes, saved, lay, flags, B, N, H2, cur_host);                                        \
     else                                                                                                         \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
                          obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \

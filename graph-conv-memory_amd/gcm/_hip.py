@@ -20,6 +20,7 @@ FLAG_WRAPPED, FLAG_BAD_COUNT, FLAG_NONFINITE = 1, 2, 4
 FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER, FLAG_WINDOW = 8, 16, 32, 64, 128
 GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bits of the live-row step (gcm_hip.h)
 STEP_TWO_LAUNCH = 32      # ... of the cached step: a distance selector and the step as two launches (A/B)
+STEP_IMG_V4 = 64          # ... its weights as 16-byte loads (the image's second layout)
 
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                      ctypes.c_int64)

@@ -14,6 +14,7 @@ are replaced by a device-side flag word that is polled without blocking
 reference's exact raise point) or not at all (`"off"`).
 """
 import math
+import os
 from typing import Tuple, Union
 
 import weakref
@@ -147,6 +148,11 @@ class DenseGCM(torch.nn.Module):
         # False: a cached EuclideanEdge chain as TWO launches per step (distance kernel, then the cached step) instead
         # of one (csrc/distance.hip: k_euclid_mfma2<.., TAIL>) - A/B tests; read when a chain is armed
         self.rows_one_launch_distance = True
+        # True: the cached temporal step reads its weights as 32 16-byte loads per lane (image4) instead of 128 4-byte
+        # ones (round 3's lane-major image).  Measured in round 5 on cfg2 (same box, graph replay): 4.85 us per step
+        # against 4.63 us - SLOWER (the kernel is a launch-to-retire latency chain, not bound by load instructions), so
+        # it stays off; kept as the A/B (env GCM_IMG_V4=1)
+        self.rows_weight_image_v4 = os.environ.get("GCM_IMG_V4", "0") == "1"
         # False: rollout() from empty graphs with forward temporal hops runs the persistent per-graph kernel of round 1
         # instead of the two-launch time-parallel forward (csrc/rollout_tp.hip) - A/B tests
         self.rollout_time_parallel = True
@@ -610,8 +616,10 @@ class DenseGCM(torch.nn.Module):
         fresh = getattr(nodes, "_gcm_fresh", False)
         if fresh:
             nodes._gcm_fresh = False          # (a donated state is this very tensor at every later step)
-            if cfg.has_distance and cfg.cpp_handle():
-                cfg._cpp.set_cached_flags(0 if self.rows_one_launch_distance else _hip.STEP_TWO_LAUNCH)
+            if cfg.cpp_handle():
+                cfg._cpp.set_cached_flags(
+                    (0 if (self.rows_one_launch_distance or not cfg.has_distance) else _hip.STEP_TWO_LAUNCH)
+                    | (_hip.STEP_IMG_V4 if self.rows_weight_image_v4 else 0))
         mx, n2, a2, c2, donate = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(),
                                           self.donate_state, need_dx, bool(fresh and self.rows_cached_steps))
         if donate:
