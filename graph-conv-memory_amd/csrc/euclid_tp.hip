@@ -34,6 +34,23 @@
 #include "gcm_common.h"
 #include "rows_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (tools/kstamp_euclid_tp.py): two rounds of workgroup 0, thread 0
+__device__ unsigned long long g_stamps_tp[32];
+extern "C" int gcm_debug_read_stamps_tp(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_tp), sizeof(unsigned long long) * n);
+}
+#define TSTAMP(i)                                                                   \
+  do {                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (g == 38 || g == 238)) {             \
+      unsigned long long t_;                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+      g_stamps_tp[(g == 38 ? 0 : 8) + (i)] = t_;                                    \
+    }                                                                               \
+  } while (0)
+#else
+#define TSTAMP(i)
+#endif
+
 namespace gcm_etp {
 
 using gcm_fused::acc_row;
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
     const bool first = c == 0, last = c == nch - 1, has_next = g + 1 < R;
     const int t2 = last ? t + 1 : t, c2 = last ? 0 : c + 1;
     float vnext[SEG];
-    asm volatile("" ::"v"(touch));   // (the touch of two rounds ago has landed: consumed here, before the next one)
+    TSTAMP(0);
     if (has_next) load_chunk(t2, c2 * CB, vnext);
     if (g >= 1 && (g - 1) % nch == 0 && g - 1 >= nch && tid < RB) finalize((g - 1) / nch);
     if (first && (t == 1 || rb == (((t - 1) % N) >> 5))) {   // (wave-uniform) node t - 1 went into this wave's block
@@ -178,6 +195,7 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
       for (int q = 0; q < KQ; ++q) nv[q] = np[2 * q];
       nv[KQ] = lh ? sNn[rb * 32 + li] : 1.f;
     }
+    TSTAMP(1);
     const int lim = t < N ? t : N;
     const bool live = rb * 32 < lim;                        // the block holds a candidate slot
     const int col0 = c * CB + ct * 32;
@@ -192,6 +210,9 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
         pend = false;
       }
       float psum = 0.f;
+#ifdef GCM_ETP_NOPIPE
+      if (pend) { part += gcm_dist_tile_sum_full(accp); pend = false; }
+#endif
       if (!pend) gcm_dist_chain<KQ, 8, false>(acc, nv, cp, CS, c_last, accp, psum);
       else gcm_dist_chain<KQ, 8, true>(acc, nv, cp, CS, c_last, accp, psum);
       part += psum;
@@ -204,6 +225,7 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
       pend = false;
       if (first && t >= 2) publish(t - 1);
     }
+    TSTAMP(2);
     // node t (a candidate from step t + 1 on) IS current row b of step t: copied from the chunk that holds it into
     // ring slot t mod N - dead at step t (it held node t - N), so whoever still reads it masks it
     if (c == b_chunk && wave == 15 && lane < FP) {
@@ -211,13 +233,26 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
       sN[(t % N) * NS + lane] = -2.f * sCb[lane * CS + b_row];
       if (lane == 0) sNn[t % N] = sCn[buf * CB + b_row];
     }
+    TSTAMP(3);
     if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c2 * CB, vnext);
-    if (g + 2 < R) {   // warm the L2 for the chunk after next (every WG of an XCD reads the same 32 KB per round)
+    TSTAMP(4);
+#ifndef GCM_ETP_NOTOUCH
+    // warm the L2 for the chunk after next (every WG of an XCD reads the same 32 KB per round).  The previous touch is
+    // consumed HERE, a full round after its issue (the wait for `vnext` above already covered it: loads return in
+    // order) - consumed at the top of the round it stalled every round for an HBM round trip.
+    asm volatile("" ::"v"(touch));
+    if (g + 2 < R) {
       const int t3 = c2 == nch - 1 ? t2 + 1 : t2, c3 = c2 == nch - 1 ? 0 : c2 + 1;
       const int gr = c3 * CB + srow < B ? c3 * CB + srow : B - 1;
       touch = obs[((size_t)t3 * B + gr) * F + (sf0 < F ? sf0 : 0)];
     }
-    __syncthreads();   // round g is consumed; the next chunk, the inserted node and the published sums are in LDS
+#endif
+    // round g is consumed; the next chunk, the inserted node and the published sums are in LDS.  A raw barrier behind
+    // the LDS counter only: __syncthreads() also drains vmcnt, i.e. waits for the L2 touch issued just above (an HBM
+    // miss: ~2 us per round - measured as the round's fixed cost)
+    TSTAMP(5);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TSTAMP(6);
     t = t2;
     c = c2;
   }
