@@ -38,6 +38,7 @@ for part in $PARTS; do
       stats bench_cfg5 bench.py --config cfg5 --no-cpu-baseline ;;
     stats_tools)
       stats euclid_full tools/prof_euclid_full.py
+      stats euclid_tp tools/prof_euclid_tp.py
       stats sparse_learned tools/prof_sparse_learned.py
       stats layered tools/prof_layered.py ;;
     pmc)

@@ -53,11 +53,15 @@ if "cfg2" in which:
 for name, T in (("cfg3", 128), ("cfg5", 64)):
     if name in which:
         c = bench.CONFIGS[name]
-        obs = torch.rand(T, c["B"], c["F"]).to(dev)
+        obs = bench.make_obs(dict(c, T=T), 0, dev)
         mem, gnn, sel = bench.build_memory(dev, donate=True, selector=c["selector"], cfg=c)
         bench.rollout(mem, obs)
-        if name == "cfg5":                  # the time-batched entry: k_learned_roll_logits / _pick / _l2
-            bench.rollout_api(mem, obs)
+        # the time-batched entry: cfg5 k_learned_roll_logits / _pick / _l2; cfg3 k_euclid_tp / k_euclid_tp_gnn (round 5)
+        bench.rollout_api(mem, obs)
+        if name == "cfg3":                  # ... and 32 steps past graph_size: the steady-state step k_euclid_mfma2<.., 2>
+            from gcm.gcm import DenseGCM
+            DenseGCM.did_warn = True
+            bench.rollout(mem, bench.make_obs(dict(c, T=T + 32), 0, dev))
         torch.cuda.synchronize()
 if "cfg4" in which:
     from gcm import nn as G

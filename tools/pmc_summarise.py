@@ -29,6 +29,11 @@ def per_kernel(d, counter):
                         name = "k_step_rows_functional"
                     if t and t.group(1) != "32":      # cfg3 (F = 64)
                         name += "_f" + t.group(1)
+                if name == "k_euclid_mfma2":     # template <FT, TAIL>: 0 selector alone, 1 + cached step, 2 + steady-state step
+                    t = re.search(r"k_euclid_mfma2<\d+, (\d+|true|false)>", row["Kernel_Name"])
+                    tail = {"false": "0", "true": "1"}.get(t.group(1), t.group(1)) if t else "0"
+                    if tail != "0":
+                        name += "_tail" + tail
                 if name == "k_bptt_rows":        # template <FP, HP, H2P, MODE>: 2 = pass A of the LearnedEdge backward
                     t = re.search(r"k_bptt_rows<(\d+), \d+, \d+, (\d+)", row["Kernel_Name"])
                     if t and t.group(2) == "2":
