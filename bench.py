@@ -757,8 +757,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         kt = find_kernel(pr, "k_euclid_tp<")
         if kt is not None:
             pairs = sum(min(t, N - 1) for t in range(T))
-            blocks = sum(32 * ((min(t, N) + 31) // 32) for t in range(1, T))
-            alg, exe = 2.0 * B * B * F * pairs, 2.0 * B * B * (F + 2) * blocks
+            slot_rows = sum(32 * ((min(t, N) + 31) // 32) for t in range(1, T))
+            alg, exe = 2.0 * B * B * F * pairs, 2.0 * B * B * (F + 2) * slot_rows
             sec = kt[1]["avg_us"] * 1e-6
             rollout_kernels = {
                 "kernel": kt[0], "avg_launch_ms": kt[1]["avg_us"] * 1e-3, "launches_per_call": kt[1]["launches_per_call"],
