@@ -1008,7 +1008,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                        "launches_timed": int(round(ki[1]["launches_per_call"] * prof_reps)),
                        "flops_per_launch_mean": f_in, "TFLOP/s": f_in / sec_i / 1e12,
                        "frac_of_fp32_mfma_peak": f_in / sec_i / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                       "traffic": traffic.get("k_euclid_mfma2"),
+                       "traffic": traffic.get("k_euclid_mfma2_tail1", traffic.get("k_euclid_mfma2")),
                        "note": "the timed rollout from empty graphs: mean over its T launches (the cached step runs as "
                                "the tail of the same launch); flops = the live 32-row blocks' share of 2*B*B*N*F"}
             kernel_ms[ki[0] + " (in situ)"] = round(ki[1]["avg_us"] * 1e-3, 6)
@@ -1106,6 +1106,36 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         "kernel_ms": kernel_ms,
         "kernel_table": {"rows": table, "gpu_us_per_step": round(gpu_us, 2), "source": src},
     })
+    # MFMA-pipe utilisation, LDS conflicts and LDS issue stalls from the committed SQ counter passes
+    # (tools/collect_profiles.sh sq -> profiles/mfma_util.json): per kernel of this line that has an entry there
+    upath = os.path.join(ROOT, "profiles", "mfma_util.json")
+    if os.path.exists(upath):
+        util = json.load(open(upath))
+
+        def counters_of(kname):
+            for key, ent in util.items():
+                if key in kname and "mfma_busy_frac" in ent:
+                    return {k: ent[k] for k in ("mfma_busy_frac", "lds_conflict_frac", "wait_inst_lds_frac",
+                                                "wait_inst_any_frac", "wait_any_frac", "avg_us_under_pmc") if k in ent}
+            return None
+        rf = line.get("roofline", {})
+        cn = counters_of(rf.get("kernel", ""))
+        if cn:
+            rf["sq_counters"] = dict(cn, source="rocprofv3 --pmc SQ_* passes over tools/pmc_mfma_run.py, summarised by "
+                                                "tools/pmc_sq_summarise.py: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
+                                                "(4 x SQ_BUSY_CU_CYCLES)")
+        if isinstance(rf.get("in_situ"), dict):
+            cn = counters_of(rf["in_situ"].get("kernel", ""))
+            if cn:
+                rf["in_situ"]["sq_counters"] = cn
+        for ent in rf.get("kernels", []) or []:
+            cn = counters_of(ent.get("kernel", ""))
+            if cn:
+                ent["sq_counters"] = cn
+        if rollout_kernels is not None:
+            cn = counters_of(rollout_kernels.get("kernel", ""))
+            if cn:
+                rollout_kernels["sq_counters"] = cn
     if rollout_kernels is not None:
         line["rollout_api_kernels"] = rollout_kernels
     if t256_table is not None:

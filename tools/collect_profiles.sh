@@ -64,6 +64,7 @@ for part in $PARTS; do
       done
       python3 tools/pmc_sq_summarise.py "$TAG" "$OUT"/sq_1 "$OUT"/sq_2 "$OUT"/sq_3 > "$OUT/${TAG}_mfma_util.txt" || true
       cp profiles/${TAG}_mfma_util.json "$OUT/" || true
+      cp profiles/${TAG}_mfma_util.json "$OUT/mfma_util.json" || true    # (-> profiles/mfma_util.json: what bench.py reads)
       rm -rf "$OUT"/sq_1 "$OUT"/sq_2 "$OUT"/sq_3 ;;
   esac
 done

@@ -58,6 +58,10 @@ for name, T in (("cfg3", 128), ("cfg5", 64)):
         bench.rollout(mem, obs)
         # the time-batched entry: cfg5 k_learned_roll_logits / _pick / _l2; cfg3 k_euclid_tp / k_euclid_tp_gnn (round 5)
         bench.rollout_api(mem, obs)
+        if name == "cfg3":                  # the selector alone on full graphs (bench.py's roofline kernel: k_euclid_mfma2<.., 0>)
+            launch = bench.euclid_launcher(c)
+            for _ in range(8):
+                launch()
         if name == "cfg3":                  # ... and 32 steps past graph_size: the steady-state step k_euclid_mfma2<.., 2>
             from gcm.gcm import DenseGCM
             DenseGCM.did_warn = True
