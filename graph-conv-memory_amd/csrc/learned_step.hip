@@ -282,6 +282,7 @@ struct GnnTail {
   int act1, act2, has_bias, H1, H2;
   float *cH, *cA, *cX;               // caches: h1 [B,N,H1], agg1 [B,N,F], nodes [B,N,F]
   float *mx_out, *agg2_out;          // this step: [B,H2], [B,H1]
+  float *h1_out, *agg1_out;          // TAIL = 2: layer 1 of every row of the graph, [B,N,H1] / [B,N,F] (the step's record)
 };
 
 // one wave of work on a 32 x 32 block of an LDS image shared with nobody: LDS writes -> reads of other lanes
@@ -339,7 +340,15 @@ struct StageL {
   }
 };
 
-template <int MODE, bool TAIL>
+// TAIL: 0 - selection only; 1 - the cached step (row cur over the chain's caches, above); 2 - the STEADY-STATE step
+// (round 5): every graph is full, the step rolls the donated state in place and the rows of layer 1 are no longer final
+// (a row loses the sources the roll drops), so layer 1 is re-evaluated for ALL rows right here - the adjacency as a bit
+// image in LDS (built from the rolled rows that pass through this workgroup's registers anyway + the new row), agg1 =
+// Adj X and h1 on the matrix cores from the node image already staged for the edge network, then row cur's layer 2 on
+// wave 0.  It writes what k_gnn2_row_fwd wrote into the step's record (h1, agg1, agg2, mx: gcm_learned_step_layout,
+// compact = 1), so the chain's backward reads it unchanged - ONE launch instead of two, and no second pass over the
+// 16.8 MB adjacency.
+template <int MODE, int TAIL>
 __global__ __launch_bounds__(256) void k_learned_select(
     const float* __restrict__ nodes_c, float* adj, const int64_t* __restrict__ cur_idx_c,
     const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp, float eps0,
@@ -390,7 +399,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
   float* sW0a = sLogit + NP;        // [o][f] = W0[o][f], rows at stride GS (16-byte aligned)
-  float* sHc = sW0a + FP * GS;      // TAIL: [NP][FS] the h1 cache of this graph
+  float* sHc = sW0a + FP * GS;      // TAIL = 1: [NP][FS] the h1 cache of this graph; TAIL = 2: [NP][4] the adjacency as bits
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(sHc);
+  if (TAIL == 2) {
+    sBits[tid] = 0u; sBits[tid + 256] = 0u;   // (before the barrier that precedes the in-place stores below)
+  }
   float* sWg = sHc + NP * FS;       // TAIL: [4][FP][GS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride GS (16-byte aligned rows)
 
   // EVERY load of the kernel is requested here, in one round trip (in-kernel stamps of round 3 / 4: a load issued
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   StageL<NP, FP> st_hc;
   StageL<FP, FP> st_w0, st_w0a, st_w1, st_g[4];
   if (ex) {
-    if (TAIL) st_hc.load<true>(gt.cH + (size_t)b * N * FP, N, FP, FP, tid);
+    if (TAIL == 1) st_hc.load<true>(gt.cH + (size_t)b * N * FP, N, FP, FP, tid);
     st_w0.load<true>(M.w0 + F, F, F, 2 * F, tid);
     st_w0a.load<true>(M.w0, F, F, 2 * F, tid);
     st_w1.load<true>(M.w1, F, F, F, tid);
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     }
   } else {
     const int H1 = gt.H1, H2 = gt.H2;
-    if (TAIL) st_hc.load<false>(gt.cH + (size_t)b * N * H1, N, H1, H1, tid);
+    if (TAIL == 1) st_hc.load<false>(gt.cH + (size_t)b * N * H1, N, H1, H1, tid);
     st_w0.load<false>(M.w0 + F, F, F, 2 * F, tid);
     st_w0a.load<false>(M.w0, F, F, 2 * F, tid);
     st_w1.load<false>(M.w1, F, F, F, tid);
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
       }
     float* ng_out = nodes_out + (size_t)b * N * F;
     if (DONATE) {
-      if (!TAIL) {
+      if (TAIL != 1) {
         float* sn = snap + (size_t)b * N * F;   // the node matrix after the insert, for the record
 #pragma unroll
         for (int i = 0; i < NODE_PER; ++i) {
@@ -510,6 +523,18 @@ __global__ __launch_bounds__(256) void k_learned_select(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, true);
+        if (TAIL == 2) {   // the rolled rows as bits (store_copy's fix-ups: last column shifted in, last row empty)
+          const int lim_a = N * N4;
+#pragma unroll
+          for (int i = 0; i < ADJ_PER; ++i) {
+            const int e4 = tid + 256 * i, r = e4 / N4, c = (e4 - r * N4) * 4;
+            float4 v = ca[i];
+            if (c + 4 >= N) v = make_float4(v.y, v.z, v.w, 0.f);
+            if (r + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t bits = (v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 2u : 0u) | (v.z != 0.f ? 4u : 0u) | (v.w != 0.f ? 8u : 0u);
+            if (e4 < lim_a && bits) atomicOr(&sBits[r * 4 + (c >> 5)], bits << (c & 31));
+          }
+        }
       }
     } else {
       gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, wrap);
@@ -530,7 +555,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     st_w0a.store<true, GS>(sW0a, tid);
     st_w1.store<true, FS>(sW1, tid);
     if (TAIL) {
-      st_hc.store<true, FS>(sHc, tid);
+      if (TAIL == 1) st_hc.store<true, FS>(sHc, tid);
 #pragma unroll
       for (int q = 0; q < 4; ++q) st_g[q].store<true, GS>(sWg + q * FP * GS, tid);
     }
@@ -539,7 +564,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     st_w0a.store<false, GS>(sW0a, tid);
     st_w1.store<false, FS>(sW1, tid);
     if (TAIL) {
-      st_hc.store<false, FS>(sHc, tid);
+      if (TAIL == 1) st_hc.store<false, FS>(sHc, tid);
 #pragma unroll
       for (int q = 0; q < 4; ++q) st_g[q].store<false, GS>(sWg + q * FP * GS, tid);
     }
@@ -681,7 +706,14 @@ __global__ __launch_bounds__(256) void k_learned_select(
       }
     }
     LSTAMP(22);
-    if (TAIL) {
+    if (TAIL == 2) {   // row cur of the bit image: this step's entries (the rolled image's last row is empty)
+      const unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
+      if (lane == 0) {
+        sBits[cur * 4] = (uint32_t)m0; sBits[cur * 4 + 1] = (uint32_t)(m0 >> 32);
+        sBits[cur * 4 + 2] = (uint32_t)m1; sBits[cur * 4 + 3] = (uint32_t)(m1 >> 32);
+      }
+    }
+    if (TAIL == 1) {
       // ---- the GNN on row cur (see GnnTail): the selected rows S = { j < cur : row[j] = 1 }, ascending -------
       const int H1 = gt.H1, H2 = gt.H2;
       const unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
@@ -771,6 +803,112 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
     }
   }
+  if (TAIL == 2) {
+    // ---- layer 1 of EVERY row on the advanced state, then row cur's layer 2 (see the TAIL note above) -----------
+    const int H1 = gt.H1, H2 = gt.H2;
+    if (!wrap && tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);   // (the caller guarantees full graphs)
+    __syncthreads();                           // row cur's bits (wave 0) and every wave's rolled rows are in LDS
+    const int trow = 32 * wave + li;           // A-operand row of this lane
+    uint32_t wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wl[q] = sBits[trow * 4 + q] >> lh;   // bit (2 q' + lh) of word q -> bit 2 q' here
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {           // agg1 = Adj X: sources are older rows - blocks kt <= this tile only
+      if (kt <= wave) {
+        const float* bp = sX + (kt * 32 + lh) * FS + li;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float a = (float)((wl[kt] >> (2 * q)) & 1u);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * q * FS], acc, 0, 0, 0);
+        }
+      }
+    }
+    float* a1g = gt.agg1_out + (size_t)b * N * F;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = 32 * wave + gcm_fused::acc_row(r, lh);
+      sA[t * FS + li] = acc[r];
+      if (t < N && li < F) a1g[t * F + li] = acc[r];
+    }
+    wsync();
+    // h1 = act1([agg1 | x] [W_rel1 | W_root1]^T + b1): this wave's 32 rows; B(k, o) = W[o][k] (rows at stride GS)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    gcm_fused::mma32(acc, sA + 32 * wave * FS, FS, 1, sWg, 1, GS, FP, li, lh);
+    gcm_fused::mma32(acc, sX + 32 * wave * FS, FS, 1, sWg + FP * GS, 1, GS, FP, li, lh);
+    const float bias1 = (gt.has_bias & 1) && li < H1 ? pf_b1 : 0.f;
+    float* h1g = gt.h1_out + (size_t)b * N * H1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = 32 * wave + gcm_fused::acc_row(r, lh);
+      const float h = (t < N && li < H1) ? gcm_act(acc[r] + bias1, gt.act1) : 0.f;
+      sB[t * FS + li] = h;
+      if (t < N && li < H1) h1g[t * H1 + li] = h;
+    }
+    __syncthreads();                           // row cur aggregates h1 rows of every tile
+    if (wave == 0) {
+      const uint32_t c0 = sBits[cur * 4], c1 = sBits[cur * 4 + 1], c2 = sBits[cur * 4 + 2], c3 = sBits[cur * 4 + 3];
+      const unsigned long long m0 = ((unsigned long long)c1 << 32) | c0, m1 = ((unsigned long long)c3 << 32) | c2;
+      const int n0 = __popcll(m0), n_sel = __builtin_amdgcn_readfirstlane(n0 + __popcll(m1));
+      int* sIdx = reinterpret_cast<int*>(sLogit);   // (the logits are consumed)
+      {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if ((m0 >> lane) & 1ull) sIdx[__popcll(m0 & below)] = lane;
+        if ((m1 >> lane) & 1ull) sIdx[n0 + __popcll(m1 & below)] = lane + 64;
+      }
+      wsync();
+      const int fl_ = lane < FP ? lane : FP - 1;
+      float agg2 = 0.f;
+#pragma unroll 1
+      for (int q0 = 0; q0 < n_sel; q0 += 8) {       // the selected rows' h1, ascending, eight per trip
+        const int4 ia = *reinterpret_cast<const int4*>(sIdx + q0), ib = *reinterpret_cast<const int4*>(sIdx + q0 + 4);
+        const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        float ha[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ha[q] = sB[(q0 + q < n_sel ? js[q] : 0) * FS + fl_];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q0 + q < n_sel) agg2 += ha[q];
+      }
+      wsync();
+      agg2 = lane < H1 ? agg2 : 0.f;
+      const int o = lane & 31;
+      const float h1c = sB[cur * FS + o];
+      float* sU = sLogit;                           // [agg2 | h1_cur], 32 each
+      if (lh == 0) { sU[o] = agg2; sU[32 + o] = h1c; }
+      wsync();
+      float p2;
+      {
+        const float* wrow = sWg + (lh ? 3 * FP * GS : 2 * FP * GS) + o * GS;
+        const float* u = sU + 32 * lh;
+        float4 wv[8], uv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          wv[q] = reinterpret_cast<const float4*>(wrow)[q];
+          uv[q] = reinterpret_cast<const float4*>(u)[q];
+        }
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          pa = fmaf(wv[q].x, uv[q].x, pa);
+          pb = fmaf(wv[q].y, uv[q].y, pb);
+          pa = fmaf(wv[q].z, uv[q].z, pa);
+          pb = fmaf(wv[q].w, uv[q].w, pb);
+        }
+        const float pp = pa + pb;
+        p2 = pp + __shfl_xor(pp, 32);
+      }
+      p2 += (gt.has_bias & 2) && o < H2 ? pf_b2 : 0.f;
+      const float v = gcm_act(p2, gt.act2);
+      if (lane < H1) gt.agg2_out[(size_t)b * H1 + lane] = agg2;
+      if (lane < H2) gt.mx_out[(size_t)b * H2 + lane] = v;
+      const bool bad = __any(lane < H2 && !isfinite(v));
+      if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+    }
+  }
   if (ADVANCE && cur_host >= 0 && tid == 0 && n_chk != (int64_t)cur_host) atomicOr(flags, GCM_FLAG_BAD_COUNT);
   LSTAMP(23);
 }
@@ -780,7 +918,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
 // steps, observations without gradient).  Nothing in the selection of step t depends on another step's RESULT: the
 // edge network scores pairs of raw observations (learned.py:53-87), the gumbel draws are given, and with empty
 // graphs to start from node j is observation j.  So every (graph, step) is independent work of THREE launches
-// instead of T latency-bound ones: k_learned_roll_logits (the edge network of k_learned_select<2, true> with
+// instead of T latency-bound ones: k_learned_roll_logits (the edge network of k_learned_select<2, 1> with
 // cur = t and the node image from the observation tensor [T, B, F], per 32-row block with a candidate row),
 // k_learned_roll_pick (softmax, threshold, adjacency / node row, layer 1 of the GNN on row cur - h1 / agg1 / x into
 // the chain's caches), and, once every h1 row exists, k_learned_roll_l2 (layer 2 on row cur -> the belief states),
@@ -2052,7 +2190,7 @@ extern "C" int gcm_learned_select_fused(const float* nodes, float* adj, const in
   GCM_REQUIRE(nodes && adj && cur_idx && noise && mlp_params && soft && B > 0);
   if (!gcm_learned_step_supported(N, F, 1, 1)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<0, false>;
+  auto kern = gcm_learned::k_learned_select<0, 0>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, adj, cur_idx, noise,
                      noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, (const float*)nullptr,
@@ -2076,7 +2214,7 @@ extern "C" int gcm_learned_advance_select_fused(const float* obs, const float* n
   GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
   if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<1, false>;
+  auto kern = gcm_learned::k_learned_select<1, 0>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F,
@@ -2098,7 +2236,7 @@ extern "C" int gcm_learned_advance_select_inplace(const float* obs, float* nodes
               adj_row && flags && B > 0);
   if (!gcm_learned_step_supported(N, F, 1, 1) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   constexpr size_t lds = gcm_learned::lds_select();
-  auto kern = gcm_learned::k_learned_select<2, false>;
+  auto kern = gcm_learned::k_learned_select<2, 0>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, mlp_params, eps0, eps1, cutoff, soft, N, F, obs,
@@ -2125,13 +2263,42 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_tail();
-  auto kern = gcm_learned::k_learned_select<2, true>;
+  auto kern = gcm_learned::k_learned_select<2, 1>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags,
                      (float*)nullptr, adj_row, gt, cur_host >= 0 ? cur_host : -1);
+  return gcm_launch_status();
+}
+
+/* The whole forward step of such a chain PAST graph_size steps (round 5) - the steady state: every graph holds N nodes
+ * (count_in[b] == N: the caller's guarantee - a chain from empty graphs that has made >= N steps; GCM_FLAG_BAD_COUNT
+ * otherwise), each step drops the oldest one (gcm.py:263-271, 323-355).  gcm_learned_advance_select_inplace with the
+ * GNN behind the selection in the same launch (k_learned_select<2, 2>): layer 1 of every row re-evaluated from the
+ * node image staged for the edge network and a bit image of the advanced adjacency, row cur's layer 2.  Writes what
+ * gcm_learned_advance_select_inplace + gcm_dense_gnn2_row_fwd write into the step's record
+ * (gcm_learned_step_layout, compact = 1: nodes_snap, adj_row, mx, h1, agg1, agg2, cur, soft), which gcm_learned_bptt
+ * reads unchanged.  N % 4 == 0, F % 4 == 0, F, H1, H2 <= 32. */
+extern "C" int gcm_learned_step_steady(const float* obs, float* nodes, float* adj, const int64_t* count_in,
+                                       const float* noise, int noise_is_exp, const float* params, int has_bias,
+                                       int act1, int act2, float eps0, float eps1, float cutoff, int64_t* cur_out,
+                                       int64_t* count_out, float* soft, float* nodes_snap, float* adj_row, float* mx,
+                                       float* h1, float* agg1, float* agg2, uint32_t* flags, int B, int N, int F, int H1,
+                                       int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes && adj && count_in && noise && params && cur_out && count_out && soft && nodes_snap &&
+              adj_row && mx && h1 && agg1 && agg2 && flags && B > 0);
+  if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
+  const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
+  constexpr size_t lds = gcm_learned::lds_select_tail();
+  auto kern = gcm_learned::k_learned_select<2, 2>;
+  gcm_allow_dynamic_lds((const void*)kern, lds);
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, nullptr, nullptr, nullptr, mx, agg2, h1, agg1};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
+                     (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
+                     (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags, nodes_snap,
+                     adj_row, gt, -1);
   return gcm_launch_status();
 }
 
@@ -2149,9 +2316,9 @@ extern "C" int gcm_learned_step_cached_functional(
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_tail();
-  auto kern = gcm_learned::k_learned_select<1, true>;
+  auto kern = gcm_learned::k_learned_select<1, 1>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,

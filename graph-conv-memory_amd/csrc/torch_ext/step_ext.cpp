@@ -1361,7 +1361,10 @@ struct LearnedChain {   // one per packed parameter vector
   // cached steps (gcm_learned_step_cached): while the chain is linear, started from empty graphs, runs on a
   // donated state and has made fewer than N steps (no graph can have overflowed)
   bool cache_ok = false;
-  int64_t cached_steps = 0, all_steps = 0;
+  // ... and past N steps, while the chain stays linear on its untouched donated state: every graph is full, the
+  // steady-state step (gcm_learned_step_steady: one launch, the record of the two-launch form)
+  bool steady_ok = false;
+  int64_t cached_steps = 0, all_steps = 0, steady_steps = 0;
   at::Tensor cH, cA, cX;
   const void* last_nodes = nullptr;   // the node matrix the previous step returned: a linear chain continues it
   // the state the previous step returned and its version counters right after the launch (the kernels write through
@@ -1418,6 +1421,13 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
                      chain.cached_steps < N && (!need_bwd || parent == (int64_t)chain.node->recs.size() - 1) &&
                      chain.state_untouched(nodes_in_, adj_in_, count_in);
   const bool cached = chain.cache_ok;
+  if (chain.all_steps == 0) chain.steady_ok = cached && donate;
+  else if (chain.steady_ok && !cached)
+    chain.steady_ok = chain.cached_steps == N && chain.all_steps == chain.cached_steps + chain.steady_steps &&
+                      chain.last_nodes == nodes_in_.data_ptr() &&
+                      (!need_bwd || parent == (int64_t)chain.node->recs.size() - 1) &&
+                      chain.state_untouched(nodes_in_, adj_in_, count_in);
+  const bool steady = !cached && donate && chain.steady_ok;
   if (cached) {
     if (chain.all_steps == 0) {
       chain.cH = at::zeros({B, N, H1}, obs.options());
@@ -1469,6 +1479,15 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
     int64_t* ib = reinterpret_cast<int64_t*>(base + lay[6]);
     float* nodes = nodes_in.data_ptr<float>();
     float* adj = adj_in.data_ptr<float>();
+    if (steady) {   // every graph is full: selection, in-place roll and the GNN of every row as ONE launch
+      check(gcm_learned_step_steady(obs.data_ptr<float>(), nodes, adj, count_in.data_ptr<int64_t>(),
+                                    noise.data_ptr<float>(), (int)noise_is_exp, pk, cfg->has_bias, cfg->act1, cfg->act2,
+                                    (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, ib,
+                                    count_in.data_ptr<int64_t>(), base + lay[7], base, base + lay[1], base + lay[2],
+                                    base + lay[3], base + lay[4], base + lay[5], fl, (int)B, N, F, H1, H2, st),
+            "gcm_learned_step_steady");
+      ++chain.steady_steps;
+    } else {
     check(gcm_learned_advance_select_inplace(obs.data_ptr<float>(), nodes, adj, count_in.data_ptr<int64_t>(),
                                              noise.data_ptr<float>(), (int)noise_is_exp, pk + cfg->P,
                                              (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, ib,
@@ -1479,6 +1498,7 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
                                  w_rel2, (cfg->has_bias & 2) ? b2 : nullptr, w_root2, cfg->act2, base + lay[2],
                                  base + lay[3], base + lay[4], base + lay[5], fl, (int)B, N, F, H1, H2, st),
           "gcm_dense_gnn2_row_fwd");
+    }
     nodes_out = nodes_in_;
     adj_out = adj_in_;
     count_out = count_in;
@@ -2656,6 +2676,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(pybind11::init<int64_t, const at::Tensor&, bool>())
       .def("cached_steps", &LearnedChain::n_cached)
       .def("total_steps", [](LearnedChain& c) { return c.all_steps; })
+      .def("steady_steps", [](LearnedChain& c) { return c.steady_steps; })
       .def("donates", [](LearnedChain& c) { return c.donate; })
       .def("executed", &LearnedChain::executed)
       .def("recording", &LearnedChain::recording)

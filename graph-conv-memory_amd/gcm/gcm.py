@@ -193,6 +193,12 @@ class DenseGCM(torch.nn.Module):
                 n += cfg._learned_fast.steps()
         return n
 
+    def learned_steady_steps_taken(self):
+        """Steps of the current LearnedEdge chain that ran as the one-launch steady-state step (gcm_learned_step_steady:
+        past graph_size steps of a chain from empty graphs on a donated state)."""
+        lc = self._learned_chain
+        return int(lc[1].steady_steps()) if lc is not None else 0
+
     def rows_cached_steps_taken(self):
         """... of which cached steps (csrc/rows_cached.hip) in the chains armed last."""
         n = 0

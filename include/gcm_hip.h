@@ -936,6 +936,19 @@ int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_hos
                      float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
                      void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                      gcm_stream_t stream);
+/* The whole forward step of such a chain PAST graph_size steps (round 5): the steady state - every graph holds N nodes
+ * (count_in[b] == N, the caller's guarantee: a chain from empty graphs that has made >= N steps; GCM_FLAG_BAD_COUNT
+ * otherwise) and each step drops the oldest one (gcm.py:263-271, 323-355).  gcm_learned_advance_select_inplace with the
+ * GNN behind the selection in the SAME launch: layer 1 of every row re-evaluated on the matrix cores from the node image
+ * staged for the edge network and a bit image of the advanced adjacency (the rolled rows pass through the workgroup's
+ * registers anyway), row cur's layer 2.  Writes what gcm_learned_advance_select_inplace + gcm_dense_gnn2_row_fwd write
+ * into the step's record (gcm_learned_step_layout, compact = 1), which gcm_learned_bptt reads unchanged.
+ * params: GNN | edge network.  N % 4 == 0, F % 4 == 0, F, H1, H2 <= 32. */
+int gcm_learned_step_steady(const float* obs, float* nodes, float* adj, const int64_t* count_in, const float* noise,
+                            int noise_is_exp, const float* params, int has_bias, int act1, int act2, float eps0,
+                            float eps1, float cutoff, int64_t* cur_out, int64_t* count_out, float* soft,
+                            float* nodes_snap, float* adj_row, float* mx, float* h1, float* agg1, float* agg2,
+                            uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 /* Cached steps.  Rows of h1 never change once written while a graph has not overflowed (row j's adjacency
  * entries and the rows it aggregates are final after step j), so a chain that starts from EMPTY graphs keeps
  * h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every node in per-chain caches (zero-filled by the

@@ -463,3 +463,17 @@ def test_learned_rollout_call_boundary_truncate():
         torch.testing.assert_close(keep[2][k], ref[2][k], rtol=1e-4, atol=2e-5 * scale, msg=k)
         differs = differs or float((cut[2][k] - ref[2][k]).abs().max()) > 1e-3 * scale
     assert differs, "truncate=True must cut the gradient that crosses the call boundary"
+
+
+@pytest.mark.parametrize("B,N,F,H,T,k", [(6, 32, 32, 32, 80, 5), (5, 16, 8, 16, 40, 3), (4, 72, 20, 24, 100, 4)])
+def test_learned_chain_steady_state_one_launch_vs_oracle(B, N, F, H, T, k):
+    """A donated LearnedEdge chain from empty graphs carried past graph_size steps: the first N steps are cached steps,
+    from step N on every step drops every graph's oldest node (gcm.py:263-271, 323-355) and runs
+    gcm_learned_step_steady - selection, in-place roll and layer 1 of every row re-evaluated in ONE launch, the record
+    of the two-launch form.  Against the oracle's per-step loop with the same injected gumbel draws: sampled adjacency
+    bit exact, beliefs 1e-5, every gradient (GNN and edge network)."""
+    from gcm.gcm import DenseGCM
+    DenseGCM.did_warn = True
+    hidden, mem = _run_both(B, N, F, H, T, k, seed=31 + N, count0=None, pick=list(range(B)), donate=True)
+    assert int(hidden[3].min()) == N
+    assert mem.learned_steady_steps_taken() == (T - N if (N % 4 == 0 and F % 4 == 0) else 0)
