@@ -283,12 +283,37 @@ struct GnnTail {
   float *cH, *cA, *cX;               // caches: h1 [B,N,H1], agg1 [B,N,F], nodes [B,N,F]
   float *mx_out, *agg2_out;          // this step: [B,H2], [B,H1]
   float *h1_out, *agg1_out;          // TAIL = 2: layer 1 of every row of the graph, [B,N,H1] / [B,N,F] (the step's record)
+  const float *h1_prev, *agg1_prev;  // TAIL = 2: layer 1 of the state BEFORE the step, [B,N,H1] / [B,N,F] (the previous step's record, or
+                                     // the caches of the cached steps before the first steady one)
+  uint32_t* abits;                   // TAIL = 2: the adjacency as bits [B][N][4] (bit j & 31 of word j >> 5 of row r: adj[r][j] != 0),
+                                     // the state BEFORE the step on entry, after it on exit (gcm_adj_bits builds the first one)
 };
 
 // one wave of work on a 32 x 32 block of an LDS image shared with nobody: LDS writes -> reads of other lanes
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+// half of a 32-wide matrix-vector product on a half wave: the 32 products of a weight row (16-byte aligned, LDS) with
+// a vector (LDS, 16-byte broadcast reads) in two chains; the other half wave's sum added (lanes l and l + 32 form a row)
+__device__ __forceinline__ float half_dot(const float* wrow, const float* u) {
+  float4 wv[8], uv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    wv[q] = reinterpret_cast<const float4*>(wrow)[q];
+    uv[q] = reinterpret_cast<const float4*>(u)[q];
+  }
+  float pa = 0.f, pb = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    pa = fmaf(wv[q].x, uv[q].x, pa);
+    pb = fmaf(wv[q].y, uv[q].y, pb);
+    pa = fmaf(wv[q].z, uv[q].z, pa);
+    pb = fmaf(wv[q].w, uv[q].w, pb);
+  }
+  const float p = pa + pb;
+  return p + __shfl_xor(p, 32);
 }
 
 // gcm_fused::Stage<RP, CP, false, false> with a form for exact shapes (EX: no clamps, no masks, 16-byte global loads -
@@ -299,12 +324,13 @@ struct StageL {
   static constexpr int PER = RP * CP / 256;
   static_assert(PER % 4 == 0 && CP % 4 == 0, "whole 16-byte pieces per thread");
   float v[PER];
+  // rsh: image row r <- source row r + rsh (clamped to the last one)
   template <bool EX>
-  __device__ __forceinline__ void load(const float* __restrict__ src, int R, int C, int ld, int tid) {
+  __device__ __forceinline__ void load(const float* __restrict__ src, int R, int C, int ld, int tid, int rsh = 0) {
     if (EX) {
 #pragma unroll
       for (int i = 0; i < PER / 4; ++i) {
-        const int e4 = tid + 256 * i, r = e4 / (CP / 4), c = (e4 % (CP / 4)) * 4;
+        const int e4 = tid + 256 * i, r = min(e4 / (CP / 4) + rsh, RP - 1), c = (e4 % (CP / 4)) * 4;
         const float4 t = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
         v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
       }
@@ -312,7 +338,7 @@ struct StageL {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int e = tid + 256 * i, r = e / CP, c = e % CP;
-        const float t = src[(r < R ? r : R - 1) * ld + (c < C ? c : C - 1)];
+        const float t = src[(r + rsh < R ? r + rsh : R - 1) * ld + (c < C ? c : C - 1)];
         v[i] = (r < R && c < C) ? t : 0.f;
       }
     }
@@ -343,9 +369,14 @@ struct StageL {
 // TAIL: 0 - selection only; 1 - the cached step (row cur over the chain's caches, above); 2 - the STEADY-STATE step
 // (round 5): every graph is full, the step rolls the donated state in place and the rows of layer 1 are no longer final
 // (a row loses the sources the roll drops), so layer 1 is re-evaluated for ALL rows right here - the adjacency as a bit
-// image in LDS (built from the rolled rows that pass through this workgroup's registers anyway + the new row), agg1 =
-// Adj X and h1 on the matrix cores from the node image already staged for the edge network, then row cur's layer 2 on
-// wave 0.  It writes what k_gnn2_row_fwd wrote into the step's record (h1, agg1, agg2, mx: gcm_learned_step_layout,
+// image in LDS, agg1 = Adj X and h1 on the matrix cores from the node image already staged for the edge network, then
+// row cur's layer 2 on wave 0.  The adjacency's roll does not READ the fp32 matrix: the chain keeps its bit image
+// (GnnTail::abits, 2 KB a graph), the step shifts that by one row and one column, writes from it the 16-byte pieces of
+// the fp32 rows whose bits CHANGE (no load -> barrier -> store of the whole matrix through 64 registers a thread; the
+// sampled adjacency is sparse, most pieces of the shifted matrix equal what is already there) and leaves the image of
+// the new state behind.  (Stamps of the first form, which rolled through registers: the roll's loads were 40 % of the
+// launch; of the second, which wrote every piece: 25 MB of stores leaving 256 CUs in the same phase, 5 us of stalls
+// wherever the stores were put.)  It writes what k_gnn2_row_fwd wrote into the step's record (h1, agg1, agg2, mx: gcm_learned_step_layout,
 // compact = 1), so the chain's backward reads it unchanged - ONE launch instead of two, and no second pass over the
 // 16.8 MB adjacency.
 template <int MODE, int TAIL>
@@ -399,12 +430,10 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sVec = sW1 + FP * FS;      // c0 | b1 | g0 | be0 | g1 | be1 | w2   (7 x 32)
   float* sLogit = sVec + 7 * FP;    // [NP]
   float* sW0a = sLogit + NP;        // [o][f] = W0[o][f], rows at stride GS (16-byte aligned)
-  float* sHc = sW0a + FP * GS;      // TAIL = 1: [NP][FS] the h1 cache of this graph; TAIL = 2: [NP][4] the adjacency as bits
-  uint32_t* sBits = reinterpret_cast<uint32_t*>(sHc);
-  if (TAIL == 2) {
-    sBits[tid] = 0u; sBits[tid + 256] = 0u;   // (before the barrier that precedes the in-place stores below)
-  }
+  float* sHc = sW0a + FP * GS;      // TAIL: [NP][FS] h1 of this graph's rows (TAIL = 1: the chain's cache; 2: the previous step's, one row up)
   float* sWg = sHc + NP * FS;       // TAIL: [4][FP][GS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride GS (16-byte aligned rows)
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(sWg + 4 * FP * GS);   // TAIL = 2: [NP][4] the advanced adjacency as bits | [NP][4] its
+  uint32_t* sAff = sBits + 2 * NP * 4;                                // difference to the one in place | [4] tile flags (below)
 
   // EVERY load of the kernel is requested here, in one round trip (in-kernel stamps of round 3 / 4: a load issued
   // at its point of use - the observation patched into row cur, W0a and x_cur for c0, the seven vectors - is a
@@ -420,22 +449,43 @@ __global__ __launch_bounds__(256) void k_learned_select(
     for (int c = 0; c < 2; ++c) {
       const int j = pl + 64 * c < N ? pl + 64 * c : N - 1;
       pf_noise[c] = noise[(size_t)b * N + j];
-      pf_old[c] = ADVANCE ? adj_in[((size_t)b * N + cur) * N + j] : 0.f;
+      pf_old[c] = ADVANCE && TAIL != 2 ? adj_in[((size_t)b * N + cur) * N + j] : 0.f;   // (steady state: the row is new)
     }
   }
   constexpr int ADJ_PER = 16, NODE_PER = (NP * FP / 4 + 255) / 256;
   const int N4 = N >> 2, F4 = F >> 2;
+  // piece index -> row: a shift at the exact shapes (a division by a run-time value is ~40 instructions, and a thread
+  // does one per piece of the state it moves; the asm keeps the compiler from evaluating both sides)
+  auto div_f4 = [&](const int e4) {
+    int r;
+    if (ex) { r = e4 / (FP / 4); } else { r = e4 / F4; asm volatile("" : "+v"(r)); }
+    return r;
+  };
+  auto div_n4 = [&](const int e4) {
+    int r;
+    if (ex) { r = e4 / (NP / 4); } else { r = e4 / N4; asm volatile("" : "+v"(r)); }
+    return r;
+  };
   const int lim_n = N * F4;
   float4 ca[ADJ_PER], cn[NODE_PER], ob[NODE_PER];
+  uint4 wbits = make_uint4(0u, 0u, 0u, 0u), obits = make_uint4(0u, 0u, 0u, 0u);
   if (ADVANCE) {
     const float* ag_in = adj_in + (size_t)b * N * N;
     const float* ng_in = nodes_in + (size_t)b * N * F;
 #pragma unroll
     for (int i = 0; i < NODE_PER; ++i) {   // this thread's pieces of the observation, whichever row turns out to be cur
       const int e4 = min(tid + 256 * i, lim_n - 1);
-      ob[i] = *reinterpret_cast<const float4*>(obs + (size_t)b * F + (e4 % F4) * 4);
+      ob[i] = *reinterpret_cast<const float4*>(obs + (size_t)b * F + (e4 - div_f4(e4) * F4) * 4);
     }
-    if (wrap) {
+    if (TAIL == 2) {   // bit row tid + 1 (-> row tid), node rows one down; the fp32 adjacency is not read
+      if (wrap && tid + 1 < N) wbits = *reinterpret_cast<const uint4*>(gt.abits + ((size_t)b * N + tid + 1) * 4);
+      if (wrap && tid < N) obits = *reinterpret_cast<const uint4*>(gt.abits + ((size_t)b * N + tid) * 4);
+#pragma unroll
+      for (int i = 0; i < NODE_PER; ++i) {
+        const int e4 = min(tid + 256 * i, lim_n - 1), r = div_f4(e4), c = (e4 - r * F4) * 4;
+        cn[i] = *reinterpret_cast<const float4*>(ng_in + (wrap ? min(r + 1, N - 1) : r) * F + c);
+      }
+    } else if (wrap) {
       gcm_state::load_copy<ADJ_PER, NODE_PER, true>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
     } else if (DONATE) {   // in place, no overflow: only the node rows are read (for the image)
 #pragma unroll
@@ -447,10 +497,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
       gcm_state::load_copy<ADJ_PER, NODE_PER, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
     }
   }
-  StageL<NP, FP> st_hc;
+  StageL<NP, FP> st_hc, st_ha;
   StageL<FP, FP> st_w0, st_w0a, st_w1, st_g[4];
   if (ex) {
     if (TAIL == 1) st_hc.load<true>(gt.cH + (size_t)b * N * FP, N, FP, FP, tid);
+
     st_w0.load<true>(M.w0 + F, F, F, 2 * F, tid);
     st_w0a.load<true>(M.w0, F, F, 2 * F, tid);
     st_w1.load<true>(M.w1, F, F, F, tid);
@@ -463,6 +514,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   } else {
     const int H1 = gt.H1, H2 = gt.H2;
     if (TAIL == 1) st_hc.load<false>(gt.cH + (size_t)b * N * H1, N, H1, H1, tid);
+
     st_w0.load<false>(M.w0 + F, F, F, 2 * F, tid);
     st_w0a.load<false>(M.w0, F, F, 2 * F, tid);
     st_w1.load<false>(M.w1, F, F, F, tid);
@@ -485,13 +537,90 @@ __global__ __launch_bounds__(256) void k_learned_select(
     pf_b1 = gt.gnn[2 * (size_t)H1 * F + (pl < H1 ? pl : H1 - 1)];
     pf_b2 = gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + (pl < H2 ? pl : H2 - 1)];
   }
+  // TAIL 2: the roll's stores - the 16-byte pieces of the fp32 adjacency whose bits change (dmask: which of this thread's
+  // ADJ_PER pieces), the node rows and their copy for the record (row cur = N - 1 holds the observation by then), and
+  // layer 1 of the rows that keep their sources, one row up (parts 3 and 4) - in parts, one behind the barrier that
+  // follows the loads and one in front of each of the next phases of the edge network (every workgroup is in the same
+  // phase: issued in one piece the stores of 256 CUs meet in the same microsecond)
+  uint32_t dmask = 0u;
+  // rows re-evaluated by this step (below) rather than copied: the rows that lost a source, one at a time - or, when they
+  // are many, every row of a 32-row tile that holds one, on the matrix cores
+  bool by_tile = false;
+  auto re_evaluated = [&](const int r) {
+    const uint32_t w = sAff[r >> 5];
+    return by_tile ? w != 0u : ((w >> (r & 31)) & 1u) != 0u;
+  };
+  auto steady_stores = [&](const int k) {
+    if (TAIL == 2 && wrap) {
+      float* ag = adj + (size_t)b * N * N;
+      float* ngo = nodes_out + (size_t)b * N * F;
+      float* sn = snap + (size_t)b * N * F;
+      float* h1g = gt.h1_out + (size_t)b * N * gt.H1;
+      float* a1g = gt.agg1_out + (size_t)b * N * F;
+#if !(defined(GCM_LS_EXP) && (GCM_LS_EXP & 1))
+      if ((dmask >> (k * (ADJ_PER / 4))) & ((1u << (ADJ_PER / 4)) - 1u)) {
+#pragma unroll
+        for (int i = 0; i < ADJ_PER; ++i) {
+          if (i / (ADJ_PER / 4) != k) continue;
+          const int e4 = tid + 256 * i, r = div_n4(e4), c = (e4 - r * N4) * 4;
+          if ((dmask >> i) & 1u) {
+            const uint32_t u = sBits[r * 4 + (c >> 5)] >> (c & 31);
+            *reinterpret_cast<float4*>(ag + e4 * 4) = make_float4((float)(u & 1u), (float)((u >> 1) & 1u),
+                                                                  (float)((u >> 2) & 1u), (float)((u >> 3) & 1u));
+          }
+        }
+      }
+#endif
+#pragma unroll
+      for (int i = 0; i < NODE_PER; ++i) {
+        if (i * 4 / NODE_PER != k) continue;
+        const int e4 = tid + 256 * i;
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 2)
+        if (e4 < lim_n && cn[i].x == 12345.f) {
+#else
+        if (e4 < lim_n) {
+#endif
+          *reinterpret_cast<float4*>(ngo + e4 * 4) = cn[i];
+          *reinterpret_cast<float4*>(sn + e4 * 4) = cn[i];
+        }
+      }
+      // layer 1 of row r: that of row r + 1 of the previous state (in st_hc / st_ha) unless the row is re-evaluated
+      // below; row cur is this step's
+      if (k == 3) {   // the h1 image row cur's layer 2 gathers from (the re-evaluated rows are overwritten below)
+        if (ex) st_hc.store<true, FS>(sHc, tid);
+        else st_hc.store<false, FS>(sHc, tid);
+      }
+      if (ex) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i / 2 != k - 3) continue;
+          const int e4 = tid + 256 * i, r = e4 / (FP / 4), c = (e4 % (FP / 4)) * 4;
+          if (r < cur && !re_evaluated(r)) {
+            *reinterpret_cast<float4*>(h1g + r * FP + c) = make_float4(st_hc.v[4 * i], st_hc.v[4 * i + 1], st_hc.v[4 * i + 2], st_hc.v[4 * i + 3]);
+            *reinterpret_cast<float4*>(a1g + r * FP + c) = make_float4(st_ha.v[4 * i], st_ha.v[4 * i + 1], st_ha.v[4 * i + 2], st_ha.v[4 * i + 3]);
+
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i / 8 != k - 3) continue;
+          const int e = tid + 256 * i, r = e / FP, c = e % FP;
+          if (r < cur && !re_evaluated(r)) {
+            if (c < gt.H1) h1g[r * gt.H1 + c] = st_hc.v[i];
+            if (c < F) a1g[r * F + c] = st_ha.v[i];
+          }
+        }
+      }
+    }
+  };
   if (ADVANCE) {
     // the state copy through registers (roll folded in), the node image for the edge network from the
     // same registers, the observation patched into row cur
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NODE_PER; ++i) {
-      const int e4 = tid + 256 * i, r = e4 / F4, c = (e4 - r * F4) * 4;
+      const int e4 = tid + 256 * i, r = div_f4(e4), c = (e4 - r * F4) * 4;
       if (e4 < lim_n) {
         float4 v = cn[i];
         if (wrap && r + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -511,7 +640,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
       }
     float* ng_out = nodes_out + (size_t)b * N * F;
     if (DONATE) {
-      if (TAIL != 1) {
+      if (TAIL == 0) {
         float* sn = snap + (size_t)b * N * F;   // the node matrix after the insert, for the record
 #pragma unroll
         for (int i = 0; i < NODE_PER; ++i) {
@@ -519,22 +648,53 @@ __global__ __launch_bounds__(256) void k_learned_select(
           if (e4 < lim_n) *reinterpret_cast<float4*>(sn + e4 * 4) = cn[i];
         }
       }
-      if (wrap) {   // source and destination alias: every load lands before the first store
+      if (TAIL == 2) {
+        // the rolled bit image: row r <- row r + 1 one column down (out[r][j] = in[r + 1][j + 1]); row N - 1 empty
+        // until this step's selection fills it (below)
+        if (tid < NP) {
+          uint4 o;
+          o.x = (wbits.x >> 1) | (wbits.y << 31); o.y = (wbits.y >> 1) | (wbits.z << 31);
+          o.z = (wbits.z >> 1) | (wbits.w << 31); o.w = wbits.w >> 1;
+          *reinterpret_cast<uint4*>(sBits + tid * 4) = o;
+          // ... and where it differs from the image in place: only those 16-byte pieces of the fp32 matrix are written
+          *reinterpret_cast<uint4*>(sBits + NP * 4 + tid * 4) = make_uint4(o.x ^ obits.x, o.y ^ obits.y, o.z ^ obits.z, o.w ^ obits.w);
+          // a row whose sources included the dropped node (column 0 of its old row) is re-evaluated (sAff: those rows)
+          const unsigned long long ma = __ballot(tid + 1 < N && (wbits.x & 1u));
+          if (lane == 0) { sAff[2 * wave] = (uint32_t)ma; sAff[2 * wave + 1] = (uint32_t)(ma >> 32); }
+        }
+        LSTAMP(28);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the node rows' source and destination alias: every load
+        LSTAMP(29);
+        __syncthreads();                                   // lands before the first store
+        LSTAMP(30);
+        // rows r + 1 of the previous state's layer 1 - what row r of the advanced graph holds unless it lost a source:
+        // requested here, behind the wait every other load of the step had to pass (nothing needs them before the
+        // edge network's second product: 8.4 MB that arrive under its first)
+        if (ex) {
+          st_hc.load<true>(gt.h1_prev + (size_t)b * N * FP, N, FP, FP, tid, 1);
+          st_ha.load<true>(gt.agg1_prev + (size_t)b * N * FP, N, FP, FP, tid, 1);
+        } else {
+          st_hc.load<false>(gt.h1_prev + (size_t)b * N * gt.H1, N, gt.H1, gt.H1, tid, 1);
+          st_ha.load<false>(gt.agg1_prev + (size_t)b * N * F, N, F, F, tid, 1);
+        }
+        by_tile = __popc(sAff[0]) + __popc(sAff[1]) + __popc(sAff[2]) + __popc(sAff[3]) > 12;
+        {
+          const int lim_a = N * N4;
+          uint32_t dv[ADJ_PER];
+#pragma unroll
+          for (int i = 0; i < ADJ_PER; ++i) {              // (the reads of all pieces in flight together)
+            const int e4 = min(tid + 256 * i, lim_a - 1), r = div_n4(e4), c = (e4 - r * N4) * 4;
+            dv[i] = sBits[NP * 4 + r * 4 + (c >> 5)] >> (c & 31);
+          }
+#pragma unroll
+          for (int i = 0; i < ADJ_PER; ++i) dmask |= (tid + 256 * i < lim_a && (dv[i] & 15u)) ? 1u << i : 0u;
+        }
+        LSTAMP(31);
+        steady_stores(0);
+      } else if (wrap) {   // source and destination alias: every load lands before the first store
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, true);
-        if (TAIL == 2) {   // the rolled rows as bits (store_copy's fix-ups: last column shifted in, last row empty)
-          const int lim_a = N * N4;
-#pragma unroll
-          for (int i = 0; i < ADJ_PER; ++i) {
-            const int e4 = tid + 256 * i, r = e4 / N4, c = (e4 - r * N4) * 4;
-            float4 v = ca[i];
-            if (c + 4 >= N) v = make_float4(v.y, v.z, v.w, 0.f);
-            if (r + 1 >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const uint32_t bits = (v.x != 0.f ? 1u : 0u) | (v.y != 0.f ? 2u : 0u) | (v.z != 0.f ? 4u : 0u) | (v.w != 0.f ? 8u : 0u);
-            if (e4 < lim_a && bits) atomicOr(&sBits[r * 4 + (c >> 5)], bits << (c & 31));
-          }
-        }
       }
     } else {
       gcm_state::store_copy<ADJ_PER, NODE_PER>(ca, cn, adj + (size_t)b * N * N, ng_out, tid, N, N4, F4, wrap);
@@ -543,7 +703,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     // row cur writes the observation behind its own copy store (same thread, same address: ordered)
 #pragma unroll
     for (int i = 0; i < NODE_PER; ++i) {
-      const int e4 = tid + 256 * i, r = e4 / F4;
+      const int e4 = tid + 256 * i, r = div_f4(e4);
       if (e4 < lim_n && r == cur) *reinterpret_cast<float4*>(ng_out + e4 * 4) = cn[i];
     }
   } else {
@@ -576,6 +736,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   }
   __syncthreads();
   LSTAMP(16);
+  steady_stores(1);
   float gr0[FP / 2], br0[FP / 2], gr1[FP / 2], br1[FP / 2];   // LayerNorm scale / shift of this thread's 16 columns
   {
     const int f0 = (tid & 1) * (FP / 2);
@@ -634,10 +795,12 @@ __global__ __launch_bounds__(256) void k_learned_select(
   }
   __syncthreads();
   LSTAMP(17);
+  steady_stores(2);
   if (F == FP) relu_ln_rows_t<true, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
   else relu_ln_rows_t<false, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
   __syncthreads();
   LSTAMP(18);
+  steady_stores(3);
   {
     const f32x16 acc = gemm_rows(sA, sW1, wave, li, lh);
 #pragma unroll
@@ -645,6 +808,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   }
   __syncthreads();
   LSTAMP(19);
+  steady_stores(4);
   if (F == FP) relu_ln_rows_t<true, true>(sB, tid, F, gr1, br1, eps1, nullptr, nullptr, true);
   else relu_ln_rows_t<false, true>(sB, tid, F, gr1, br1, eps1, nullptr, nullptr, true);
   __syncthreads();
@@ -659,8 +823,9 @@ __global__ __launch_bounds__(256) void k_learned_select(
   __syncthreads();
   LSTAMP(21);
   if (DONATE && tid == 255) count_out[b] = cur + 1;   // every wave read count_in long ago
+  float z[2] = {0.f, 0.f};   // wave 0: the softmax terms, then this step's entries of row cur
   if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
-    float z[2], m = -INFINITY;
+    float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int j = lane + 64 * c;
@@ -713,7 +878,132 @@ __global__ __launch_bounds__(256) void k_learned_select(
         sBits[cur * 4 + 2] = (uint32_t)m1; sBits[cur * 4 + 3] = (uint32_t)(m1 >> 32);
       }
     }
-    if (TAIL == 1) {
+  }
+  if (TAIL == 2) {
+    // ---- layer 1 of the rows that LOST a source (sAff, per 32-row tile; rare: the sampled adjacency is sparse), while
+    // wave 0 is in the softmax: waves 1 - 3, tile by tile - agg1 = Adj X from the rolled bit image and the node image on
+    // the matrix cores, h1 = act1([agg1 | x] W^T + b1); the rows go into the h1 image (row cur's agg2 reads it below)
+    // and into the record.  Row cur itself is wave 0's, below (its bits are being written: whatever this computes for
+    // it is dropped).
+    const int H1 = gt.H1;
+    if (!wrap && tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);   // (the caller guarantees full graphs)
+    if (wave != 0 && !by_tile) {
+      // one row at a time, round robin over waves 1 - 3, as wave 0 does row cur below: the row's sources from the bit
+      // image as a rank-compacted list, agg1 gathered from the node image, h1 as two half products (scratch: this
+      // wave's corner of sA, which the edge network is done with)
+      int* sIdxW = reinterpret_cast<int*>(sA + wave * 256);
+      float* sUW = sA + wave * 256 + 128;        // [agg1 | x_t], 32 each
+      float* a1g = gt.agg1_out + (size_t)b * N * F;
+      float* h1g = gt.h1_out + (size_t)b * N * H1;
+      const int fl_ = lane < FP ? lane : FP - 1, o = lane & 31;
+      int idx = 0;
+#pragma unroll 1
+      for (int wq = 0; wq < 4; ++wq) {
+        uint32_t mw = __builtin_amdgcn_readfirstlane(sAff[wq]);
+#pragma unroll 1
+        while (mw) {
+          const int t = 32 * wq + __builtin_ctz(mw);
+          mw &= mw - 1u;
+          const bool mine = idx % 3 == wave - 1;
+          ++idx;
+          if (!mine) continue;
+          const uint32_t c0 = sBits[t * 4], c1 = sBits[t * 4 + 1], c2 = sBits[t * 4 + 2], c3 = sBits[t * 4 + 3];
+          const unsigned long long m0 = ((unsigned long long)c1 << 32) | c0, m1 = ((unsigned long long)c3 << 32) | c2;
+          const int n0 = __popcll(m0), n_sel = __builtin_amdgcn_readfirstlane(n0 + __popcll(m1));
+          {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((m0 >> lane) & 1ull) sIdxW[__popcll(m0 & below)] = lane;
+            if ((m1 >> lane) & 1ull) sIdxW[n0 + __popcll(m1 & below)] = lane + 64;
+          }
+          wsync();
+          float agg1 = 0.f;
+#pragma unroll 1
+          for (int q0 = 0; q0 < n_sel; q0 += 8) {
+            const int4 ia = *reinterpret_cast<const int4*>(sIdxW + q0), ib = *reinterpret_cast<const int4*>(sIdxW + q0 + 4);
+            const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+            float xa[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xa[q] = sX[(q0 + q < n_sel ? js[q] : 0) * FS + fl_];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (q0 + q < n_sel) agg1 += xa[q];
+          }
+          agg1 = lane < F ? agg1 : 0.f;
+          const float xt = sX[t * FS + fl_];
+          if (lh == 0) { sUW[o] = agg1; sUW[32 + o] = xt; }
+          wsync();
+          float p1 = half_dot(sWg + (lh ? FP * GS : 0) + o * GS, sUW + 32 * lh);
+          p1 += (gt.has_bias & 1) && o < H1 ? pf_b1 : 0.f;
+          float h = gcm_act(p1, gt.act1);
+          h = o < H1 ? h : 0.f;
+          if (lh == 0) sHc[t * FS + o] = h;
+          if (lane < H1) h1g[t * H1 + lane] = h;
+          if (lane < F) a1g[t * F + lane] = agg1;
+          wsync();
+        }
+      }
+    }
+    if (wave != 0 && by_tile) {
+#pragma unroll 1
+      for (int T = (wave == 1 ? 0 : wave); T < (wave == 1 ? 2 : wave + 1); ++T) {
+        if (!sAff[T]) continue;
+        const int trow = 32 * T + li;            // A-operand row of this lane
+        uint32_t wl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wl[q] = sBits[trow * 4 + q] >> lh;   // bit (2 q' + lh) of word q -> bit 2 q' here
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt <= T; ++kt) {        // sources are older rows: blocks kt <= T only
+          const float* bp = sX + (kt * 32 + lh) * FS + li;
+          const uint32_t wk = wl[0];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float a = (float)((wk >> (2 * q)) & 1u);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * q * FS], acc, 0, 0, 0);
+          }
+          wl[0] = wl[1]; wl[1] = wl[2]; wl[2] = wl[3];
+        }
+        float* a1g = gt.agg1_out + (size_t)b * N * F;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = 32 * T + gcm_fused::acc_row(r, lh);
+          sA[t * FS + li] = acc[r];
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 4)
+          if (t < cur && li < F && acc[r] == 12345.f) a1g[t * F + li] = acc[r];
+#else
+          if (t < cur && li < F) a1g[t * F + li] = acc[r];
+#endif
+        }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        gcm_fused::mma32b<FP>(acc, sA + 32 * T * FS, FS, 1, sWg, 1, GS, li, lh);            // B(k, o) = W[o][k] (rows at stride GS)
+        gcm_fused::mma32b<FP>(acc, sX + 32 * T * FS, FS, 1, sWg + FP * GS, 1, GS, li, lh);
+        const float bias1 = (gt.has_bias & 1) && li < H1 ? pf_b1 : 0.f;
+        float* h1g = gt.h1_out + (size_t)b * N * H1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = 32 * T + gcm_fused::acc_row(r, lh);
+          const float h = (t < N && li < H1) ? gcm_act(acc[r] + bias1, gt.act1) : 0.f;
+          if (t < cur) {
+            sHc[t * FS + li] = h;
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 4)
+            if (li < H1 && h == 12345.f) h1g[t * H1 + li] = h;
+#else
+            if (li < H1) h1g[t * H1 + li] = h;
+#endif
+          }
+        }
+      }
+    }
+    __syncthreads();   // row cur's bits (wave 0) and the re-evaluated rows of the h1 image are in LDS
+    LSTAMP(27);
+    if (tid < N) *reinterpret_cast<uint4*>(gt.abits + ((size_t)b * N + tid) * 4) = *reinterpret_cast<const uint4*>(sBits + tid * 4);
+  }
+  if (wave == 0) {
+    if (TAIL) {
       // ---- the GNN on row cur (see GnnTail): the selected rows S = { j < cur : row[j] = 1 }, ascending -------
       const int H1 = gt.H1, H2 = gt.H2;
       const unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
@@ -758,24 +1048,6 @@ __global__ __launch_bounds__(256) void k_learned_select(
       float* sU = sLogit;                    // [agg1 | x_cur | agg2 | h1_cur], 32 each (the logits are consumed)
       if (lh == 0) { sU[o] = agg1; sU[32 + o] = xc; sU[64 + o] = agg2; }
       wsync();
-      auto half_dot = [&](const float* wrow, const float* u) {
-        float4 wv[8], uv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          wv[q] = reinterpret_cast<const float4*>(wrow)[q];
-          uv[q] = reinterpret_cast<const float4*>(u)[q];
-        }
-        float pa = 0.f, pb = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          pa = fmaf(wv[q].x, uv[q].x, pa);
-          pb = fmaf(wv[q].y, uv[q].y, pb);
-          pa = fmaf(wv[q].z, uv[q].z, pa);
-          pb = fmaf(wv[q].w, uv[q].w, pb);
-        }
-        const float p = pa + pb;
-        return p + __shfl_xor(p, 32);
-      };
       LSTAMP(24);
       float p1 = half_dot(sWg + (lh ? FP * GS : 0) + o * GS, sU + 32 * lh);
       p1 += (gt.has_bias & 1) && o < H1 ? pf_b1 : 0.f;
@@ -791,119 +1063,13 @@ __global__ __launch_bounds__(256) void k_learned_select(
       LSTAMP(26);
       const size_t rc = (size_t)b * N + cur;
       if (lane < H1) {
-        gt.cH[rc * H1 + lane] = h1c;
+        (TAIL == 1 ? gt.cH : gt.h1_out)[rc * H1 + lane] = h1c;
         gt.agg2_out[(size_t)b * H1 + lane] = agg2;
       }
       if (lane < F) {
-        gt.cA[rc * F + lane] = agg1;
-        gt.cX[rc * F + lane] = xc;
+        (TAIL == 1 ? gt.cA : gt.agg1_out)[rc * F + lane] = agg1;
+        if (TAIL == 1) gt.cX[rc * F + lane] = xc;
       }
-      if (lane < H2) gt.mx_out[(size_t)b * H2 + lane] = v;
-      const bool bad = __any(lane < H2 && !isfinite(v));
-      if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
-    }
-  }
-  if (TAIL == 2) {
-    // ---- layer 1 of EVERY row on the advanced state, then row cur's layer 2 (see the TAIL note above) -----------
-    const int H1 = gt.H1, H2 = gt.H2;
-    if (!wrap && tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);   // (the caller guarantees full graphs)
-    __syncthreads();                           // row cur's bits (wave 0) and every wave's rolled rows are in LDS
-    const int trow = 32 * wave + li;           // A-operand row of this lane
-    uint32_t wl[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wl[q] = sBits[trow * 4 + q] >> lh;   // bit (2 q' + lh) of word q -> bit 2 q' here
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {           // agg1 = Adj X: sources are older rows - blocks kt <= this tile only
-      if (kt <= wave) {
-        const float* bp = sX + (kt * 32 + lh) * FS + li;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float a = (float)((wl[kt] >> (2 * q)) & 1u);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * q * FS], acc, 0, 0, 0);
-        }
-      }
-    }
-    float* a1g = gt.agg1_out + (size_t)b * N * F;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = 32 * wave + gcm_fused::acc_row(r, lh);
-      sA[t * FS + li] = acc[r];
-      if (t < N && li < F) a1g[t * F + li] = acc[r];
-    }
-    wsync();
-    // h1 = act1([agg1 | x] [W_rel1 | W_root1]^T + b1): this wave's 32 rows; B(k, o) = W[o][k] (rows at stride GS)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    gcm_fused::mma32(acc, sA + 32 * wave * FS, FS, 1, sWg, 1, GS, FP, li, lh);
-    gcm_fused::mma32(acc, sX + 32 * wave * FS, FS, 1, sWg + FP * GS, 1, GS, FP, li, lh);
-    const float bias1 = (gt.has_bias & 1) && li < H1 ? pf_b1 : 0.f;
-    float* h1g = gt.h1_out + (size_t)b * N * H1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = 32 * wave + gcm_fused::acc_row(r, lh);
-      const float h = (t < N && li < H1) ? gcm_act(acc[r] + bias1, gt.act1) : 0.f;
-      sB[t * FS + li] = h;
-      if (t < N && li < H1) h1g[t * H1 + li] = h;
-    }
-    __syncthreads();                           // row cur aggregates h1 rows of every tile
-    if (wave == 0) {
-      const uint32_t c0 = sBits[cur * 4], c1 = sBits[cur * 4 + 1], c2 = sBits[cur * 4 + 2], c3 = sBits[cur * 4 + 3];
-      const unsigned long long m0 = ((unsigned long long)c1 << 32) | c0, m1 = ((unsigned long long)c3 << 32) | c2;
-      const int n0 = __popcll(m0), n_sel = __builtin_amdgcn_readfirstlane(n0 + __popcll(m1));
-      int* sIdx = reinterpret_cast<int*>(sLogit);   // (the logits are consumed)
-      {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if ((m0 >> lane) & 1ull) sIdx[__popcll(m0 & below)] = lane;
-        if ((m1 >> lane) & 1ull) sIdx[n0 + __popcll(m1 & below)] = lane + 64;
-      }
-      wsync();
-      const int fl_ = lane < FP ? lane : FP - 1;
-      float agg2 = 0.f;
-#pragma unroll 1
-      for (int q0 = 0; q0 < n_sel; q0 += 8) {       // the selected rows' h1, ascending, eight per trip
-        const int4 ia = *reinterpret_cast<const int4*>(sIdx + q0), ib = *reinterpret_cast<const int4*>(sIdx + q0 + 4);
-        const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-        float ha[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ha[q] = sB[(q0 + q < n_sel ? js[q] : 0) * FS + fl_];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (q0 + q < n_sel) agg2 += ha[q];
-      }
-      wsync();
-      agg2 = lane < H1 ? agg2 : 0.f;
-      const int o = lane & 31;
-      const float h1c = sB[cur * FS + o];
-      float* sU = sLogit;                           // [agg2 | h1_cur], 32 each
-      if (lh == 0) { sU[o] = agg2; sU[32 + o] = h1c; }
-      wsync();
-      float p2;
-      {
-        const float* wrow = sWg + (lh ? 3 * FP * GS : 2 * FP * GS) + o * GS;
-        const float* u = sU + 32 * lh;
-        float4 wv[8], uv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          wv[q] = reinterpret_cast<const float4*>(wrow)[q];
-          uv[q] = reinterpret_cast<const float4*>(u)[q];
-        }
-        float pa = 0.f, pb = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          pa = fmaf(wv[q].x, uv[q].x, pa);
-          pb = fmaf(wv[q].y, uv[q].y, pb);
-          pa = fmaf(wv[q].z, uv[q].z, pa);
-          pb = fmaf(wv[q].w, uv[q].w, pb);
-        }
-        const float pp = pa + pb;
-        p2 = pp + __shfl_xor(pp, 32);
-      }
-      p2 += (gt.has_bias & 2) && o < H2 ? pf_b2 : 0.f;
-      const float v = gcm_act(p2, gt.act2);
-      if (lane < H1) gt.agg2_out[(size_t)b * H1 + lane] = agg2;
       if (lane < H2) gt.mx_out[(size_t)b * H2 + lane] = v;
       const bool bad = __any(lane < H2 && !isfinite(v));
       if (bad && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
@@ -2170,6 +2336,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + FP * GS + 7 * FP + NP); }
 constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * GS); }
+constexpr size_t lds_select_steady() { return lds_select_tail() + sizeof(uint32_t) * (2 * NP * 4 + 4); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
                           (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);
@@ -2265,11 +2432,48 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   constexpr size_t lds = gcm_learned::lds_select_tail();
   auto kern = gcm_learned::k_learned_select<2, 1>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags,
                      (float*)nullptr, adj_row, gt, cur_host >= 0 ? cur_host : -1);
+  return gcm_launch_status();
+}
+
+namespace gcm_learned {
+// the adjacency [B,N,N] as bits [B][N][4]: bit j & 31 of word j >> 5 of row r = (adj[r][j] != 0); a thread a word
+__global__ __launch_bounds__(256) void k_adj_bits(const float* __restrict__ adj, uint32_t* __restrict__ bits, int N,
+                                                  size_t n_words) {
+  const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  const size_t row = w >> 2;
+  const int c0 = (int)(w & 3) * 32;
+  const float* src = adj + row * N + c0;
+  uint32_t u = 0u;
+  if (c0 + 32 <= N) {
+    f32x4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = reinterpret_cast<const f32x4*>(src)[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u |= (v[q][k] != 0.f ? 1u : 0u) << (4 * q + k);
+  } else {
+    for (int k = 0; c0 + k < N; ++k) u |= (src[k] != 0.f ? 1u : 0u) << k;
+  }
+  bits[w] = u;
+}
+}  // namespace gcm_learned
+
+/* The bit image a steady-state chain keeps of its adjacency (gcm_learned_step_steady): adj [B,N,N] -> bits [B][N][4]
+ * u32, bit (j & 31) of word (j >> 5) of row r set where adj[b][r][j] != 0.  N <= 128, N % 4 == 0.  Run once when a
+ * chain enters the steady state; every steady step then carries the image along. */
+extern "C" int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t stream) {
+  GCM_REQUIRE(adj && bits && B > 0);
+  if (N <= 0 || N > 128 || (N & 3)) return GCM_EUNSUPPORTED;
+  const size_t n_words = (size_t)B * N * 4;
+  hipLaunchKernelGGL(gcm_learned::k_adj_bits, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     adj, bits, N, n_words);
   return gcm_launch_status();
 }
 
@@ -2285,16 +2489,17 @@ extern "C" int gcm_learned_step_steady(const float* obs, float* nodes, float* ad
                                        const float* noise, int noise_is_exp, const float* params, int has_bias,
                                        int act1, int act2, float eps0, float eps1, float cutoff, int64_t* cur_out,
                                        int64_t* count_out, float* soft, float* nodes_snap, float* adj_row, float* mx,
-                                       float* h1, float* agg1, float* agg2, uint32_t* flags, int B, int N, int F, int H1,
-                                       int H2, gcm_stream_t stream) {
+                                       float* h1, float* agg1, float* agg2, const float* h1_prev,
+                                       const float* agg1_prev, uint32_t* adj_bits, uint32_t* flags, int B, int N, int F,
+                                       int H1, int H2, gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes && adj && count_in && noise && params && cur_out && count_out && soft && nodes_snap &&
-              adj_row && mx && h1 && agg1 && agg2 && flags && B > 0);
+              adj_row && mx && h1 && agg1 && agg2 && h1_prev && agg1_prev && adj_bits && flags && B > 0);
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
-  constexpr size_t lds = gcm_learned::lds_select_tail();
+  constexpr size_t lds = gcm_learned::lds_select_steady();
   auto kern = gcm_learned::k_learned_select<2, 2>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, nullptr, nullptr, nullptr, mx, agg2, h1, agg1};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, nullptr, nullptr, nullptr, mx, agg2, h1, agg1, h1_prev, agg1_prev, adj_bits};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags, nodes_snap,
@@ -2318,7 +2523,7 @@ extern "C" int gcm_learned_step_cached_functional(
   constexpr size_t lds = gcm_learned::lds_select_tail();
   auto kern = gcm_learned::k_learned_select<1, 1>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,

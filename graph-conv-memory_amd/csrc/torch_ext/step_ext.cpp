@@ -1366,6 +1366,8 @@ struct LearnedChain {   // one per packed parameter vector
   bool steady_ok = false;
   int64_t cached_steps = 0, all_steps = 0, steady_steps = 0;
   at::Tensor cH, cA, cX;
+  at::Tensor abits;                   // [B,N,4] the adjacency as bits, kept by the steady-state steps
+  at::Tensor prev_rec;                // the previous steady step's record (its h1 / agg1 feed the next one)
   const void* last_nodes = nullptr;   // the node matrix the previous step returned: a linear chain continues it
   // the state the previous step returned and its version counters right after the launch (the kernels write through
   // raw pointers: only a caller's in-place edit moves them, and the caches no longer describe such a state)
@@ -1480,12 +1482,22 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
     float* nodes = nodes_in.data_ptr<float>();
     float* adj = adj_in.data_ptr<float>();
     if (steady) {   // every graph is full: selection, in-place roll and the GNN of every row as ONE launch
+      if (chain.steady_steps == 0) {   // the adjacency's bit image, carried along by the steady steps from here on
+        chain.abits = at::empty({B, N, 4}, obs.options().dtype(at::kInt));
+        check(gcm_adj_bits(adj, reinterpret_cast<uint32_t*>(chain.abits.data_ptr<int32_t>()), (int)B, N, st),
+              "gcm_adj_bits");
+      }
+      // layer 1 of the rows as the previous step left it: its record, or the caches of the N cached steps
+      const float* h1_prev = chain.steady_steps ? chain.prev_rec.data_ptr<float>() + lay[3] : chain.cH.data_ptr<float>();
+      const float* agg1_prev = chain.steady_steps ? chain.prev_rec.data_ptr<float>() + lay[4] : chain.cA.data_ptr<float>();
       check(gcm_learned_step_steady(obs.data_ptr<float>(), nodes, adj, count_in.data_ptr<int64_t>(),
                                     noise.data_ptr<float>(), (int)noise_is_exp, pk, cfg->has_bias, cfg->act1, cfg->act2,
                                     (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, ib,
                                     count_in.data_ptr<int64_t>(), base + lay[7], base, base + lay[1], base + lay[2],
-                                    base + lay[3], base + lay[4], base + lay[5], fl, (int)B, N, F, H1, H2, st),
+                                    base + lay[3], base + lay[4], base + lay[5], h1_prev, agg1_prev,
+                                    reinterpret_cast<uint32_t*>(chain.abits.data_ptr<int32_t>()), fl, (int)B, N, F, H1, H2, st),
             "gcm_learned_step_steady");
+      chain.prev_rec = buf;
       ++chain.steady_steps;
     } else {
     check(gcm_learned_advance_select_inplace(obs.data_ptr<float>(), nodes, adj, count_in.data_ptr<int64_t>(),

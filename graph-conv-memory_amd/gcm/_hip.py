@@ -146,7 +146,8 @@ PROTOTYPES = {
     "gcm_euclid_rollout_tp_supported": (_I, [_I] * 6),
     "gcm_euclid_rollout_tp_decide": (_I, [_P, _F, _P, _P, _I, _I, _I, _I, _P]),
     "gcm_euclid_rollout_tp_fwd": (_I, [_P, _F, _P, _P, _I, _I] + [_P] * 7 + [_Z, _I, _P, _P, _P] + [_I] * 7 + [_P]),
-    "gcm_learned_step_steady": (_I, [_P] * 5 + [_I, _P, _I, _I, _I, _F, _F, _F] + [_P] * 10 + [_I] * 5 + [_P]),
+    "gcm_learned_step_steady": (_I, [_P] * 5 + [_I, _P, _I, _I, _I, _F, _F, _F] + [_P] * 13 + [_I] * 5 + [_P]),
+    "gcm_adj_bits": (_I, [_P, _P, _I, _I, _P]),
     "gcm_learned_rollout_fwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P]
                                 + [_I] * 6 + [_P]),
     "gcm_learned_advance_select_inplace": (_I, [_P] * 5 + [_I, _P, _F, _F, _F] + [_P] * 6 + [_I, _I, _I, _P]),

@@ -940,15 +940,27 @@ int gcm_learned_bptt(const float* const* saved_host, const float* const* gmx_hos
  * (count_in[b] == N, the caller's guarantee: a chain from empty graphs that has made >= N steps; GCM_FLAG_BAD_COUNT
  * otherwise) and each step drops the oldest one (gcm.py:263-271, 323-355).  gcm_learned_advance_select_inplace with the
  * GNN behind the selection in the SAME launch: layer 1 of every row re-evaluated on the matrix cores from the node image
- * staged for the edge network and a bit image of the advanced adjacency (the rolled rows pass through the workgroup's
- * registers anyway), row cur's layer 2.  Writes what gcm_learned_advance_select_inplace + gcm_dense_gnn2_row_fwd write
- * into the step's record (gcm_learned_step_layout, compact = 1), which gcm_learned_bptt reads unchanged.
+ * staged for the edge network and a bit image of the advanced adjacency, row cur's layer 2.  Writes what
+ * gcm_learned_advance_select_inplace + gcm_dense_gnn2_row_fwd write into the step's record (gcm_learned_step_layout,
+ * compact = 1), which gcm_learned_bptt reads unchanged.
+ * adj_bits [B][N][4] u32: the adjacency of the state as bits (gcm_adj_bits), that of the INPUT state on entry and of the
+ * advanced state on exit - the roll shifts the image and writes the 16-byte pieces of the fp32 rows whose bits change;
+ * the fp32 matrix is not read.
+ * h1_prev [B,N,H1], agg1_prev [B,N,F]: layer 1 of the INPUT state's rows (the previous steady step's h1 / agg1, or the
+ * caches of gcm_learned_step_cached in front of the first one); may be this step's h1 / agg1 (every load of a graph
+ * lands before its first store).  Row r of the advanced graph is row r + 1 of the input graph: its layer 1 is copied
+ * unless the row had the dropped node as a source - 32-row tiles with such a row are re-evaluated on the matrix cores
+ * (agg1 = Adj X from the bit image).  The cost of a step therefore follows the adjacency: about the cached step's when
+ * it is sparse, the full re-evaluation's when most rows point at the oldest node.
  * params: GNN | edge network.  N % 4 == 0, F % 4 == 0, F, H1, H2 <= 32. */
 int gcm_learned_step_steady(const float* obs, float* nodes, float* adj, const int64_t* count_in, const float* noise,
                             int noise_is_exp, const float* params, int has_bias, int act1, int act2, float eps0,
                             float eps1, float cutoff, int64_t* cur_out, int64_t* count_out, float* soft,
                             float* nodes_snap, float* adj_row, float* mx, float* h1, float* agg1, float* agg2,
-                            uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+                            const float* h1_prev, const float* agg1_prev, uint32_t* adj_bits, uint32_t* flags, int B, int N, int F, int H1, int H2, gcm_stream_t stream);
+/* adj [B,N,N] -> bits [B][N][4] u32: bit (j & 31) of word (j >> 5) of row r set where adj[b][r][j] != 0 (N <= 128,
+ * N % 4 == 0).  Run once when a chain enters the steady state; gcm_learned_step_steady carries the image along. */
+int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t stream);
 /* Cached steps.  Rows of h1 never change once written while a graph has not overflowed (row j's adjacency
  * entries and the rows it aggregates are final after step j), so a chain that starts from EMPTY graphs keeps
  * h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every node in per-chain caches (zero-filled by the

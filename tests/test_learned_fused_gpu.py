@@ -465,7 +465,8 @@ def test_learned_rollout_call_boundary_truncate():
     assert differs, "truncate=True must cut the gradient that crosses the call boundary"
 
 
-@pytest.mark.parametrize("B,N,F,H,T,k", [(6, 32, 32, 32, 80, 5), (5, 16, 8, 16, 40, 3), (4, 72, 20, 24, 100, 4)])
+@pytest.mark.parametrize("B,N,F,H,T,k", [(6, 32, 32, 32, 80, 5), (5, 16, 8, 16, 40, 3), (4, 72, 20, 24, 100, 4),
+                                         (3, 128, 32, 32, 200, 5), (4, 32, 32, 32, 70, 20), (3, 72, 20, 24, 100, 30)])
 def test_learned_chain_steady_state_one_launch_vs_oracle(B, N, F, H, T, k):
     """A donated LearnedEdge chain from empty graphs carried past graph_size steps: the first N steps are cached steps,
     from step N on every step drops every graph's oldest node (gcm.py:263-271, 323-355) and runs
