@@ -45,6 +45,19 @@ extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
 }
 #define LSTAMP(i) STAMP(i)
+// first / last s_memrealtime (100 MHz, one counter for the device) of EVERY workgroup of the last k_learned_select launch
+__device__ unsigned long long g_span[2048][2];
+extern "C" int gcm_debug_read_spans(unsigned long long* out, int n_wg) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * n_wg);
+}
+#define LSPAN(i)                                                                   \
+  do {                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {                                   \
+      unsigned long long t_;                                                       \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+      g_span[blockIdx.x][i] = t_;                                                  \
+    }                                                                              \
+  } while (0)
 #ifdef GCM_STAMPS_B2
 #define BSTAMP(i) STAMP(i)
 #else
@@ -53,6 +66,7 @@ extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
 #else
 #define LSTAMP(i)
 #define BSTAMP(i)
+#define LSPAN(i)
 #endif
 
 namespace gcm_learned {
@@ -295,6 +309,16 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// 16-byte WRITE-THROUGH store (sc1) of data this launch does not read again: the bytes leave for memory while the
+// kernel computes instead of sitting dirty in the XCD's L2 until the write-back at the end of the launch, which nothing
+// overlaps (16.8 MB a steady-state step: ~4 us behind the last workgroup).  rsrc: a buffer descriptor of the graph's
+// matrix (wave-uniform), off: byte offset.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wt_store4(__amdgpu_buffer_rsrc_t rsrc, int off, float x, float y, float z, float w) {
+  const u32x4 v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);
+}
+
 // half of a 32-wide matrix-vector product on a half wave: the 32 products of a weight row (16-byte aligned, LDS) with
 // a vector (LDS, 16-byte broadcast reads) in two chains; the other half wave's sum added (lanes l and l + 32 form a row)
 __device__ __forceinline__ float half_dot(const float* wrow, const float* u) {
@@ -392,6 +416,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   LSTAMP(14);
+  LSPAN(0);
   int cur;
   bool wrap = false;
   int64_t n_chk = 0;   // cur_host: the count as stored, compared at the END of the kernel (nothing waits for it)
@@ -403,6 +428,18 @@ __global__ __launch_bounds__(256) void k_learned_select(
       n_chk = count_in[b];
       cur_out[b] = cur;
       if (!DONATE) count_out[b] = cur + 1;
+    }
+  } else if (TAIL == 2) {
+    // steady state: every graph is full (the chain's guarantee - checked at the END of the kernel, like cur_host):
+    // no load in front of every address below
+    cur = N - 1;
+    wrap = true;
+    if (tid == 0) {
+      n_chk = count_in[b];
+      cur_out[b] = cur;
+      // every graph drops a node: ONE workgroup says so, at the start (256 atomics on one word at the END of the launch
+      // were ~2 us between the last workgroup and the launch's completion)
+      if (b == 0) atomicOr(flags, GCM_FLAG_WRAPPED);
     }
   } else if (ADVANCE) {
     const int64_t n_in = count_in[b];
@@ -432,8 +469,8 @@ __global__ __launch_bounds__(256) void k_learned_select(
   float* sW0a = sLogit + NP;        // [o][f] = W0[o][f], rows at stride GS (16-byte aligned)
   float* sHc = sW0a + FP * GS;      // TAIL: [NP][FS] h1 of this graph's rows (TAIL = 1: the chain's cache; 2: the previous step's, one row up)
   float* sWg = sHc + NP * FS;       // TAIL: [4][FP][GS] W_rel1 | W_root1 | W_rel2 | W_root2, row o at stride GS (16-byte aligned rows)
-  uint32_t* sBits = reinterpret_cast<uint32_t*>(sWg + 4 * FP * GS);   // TAIL = 2: [NP][4] the advanced adjacency as bits | [NP][4] its
-  uint32_t* sAff = sBits + 2 * NP * 4;                                // difference to the one in place | [4] tile flags (below)
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(sWg + 4 * FP * GS);   // TAIL = 2: [NP][4] the advanced adjacency as bits
+  uint32_t* sAff = sBits + NP * 4;                                    // | [4] the rows that lost a source, as bits (below)
 
   // EVERY load of the kernel is requested here, in one round trip (in-kernel stamps of round 3 / 4: a load issued
   // at its point of use - the observation patched into row cur, W0a and x_cur for c0, the seven vectors - is a
@@ -459,11 +496,6 @@ __global__ __launch_bounds__(256) void k_learned_select(
   auto div_f4 = [&](const int e4) {
     int r;
     if (ex) { r = e4 / (FP / 4); } else { r = e4 / F4; asm volatile("" : "+v"(r)); }
-    return r;
-  };
-  auto div_n4 = [&](const int e4) {
-    int r;
-    if (ex) { r = e4 / (NP / 4); } else { r = e4 / N4; asm volatile("" : "+v"(r)); }
     return r;
   };
   const int lim_n = N * F4;
@@ -537,12 +569,10 @@ __global__ __launch_bounds__(256) void k_learned_select(
     pf_b1 = gt.gnn[2 * (size_t)H1 * F + (pl < H1 ? pl : H1 - 1)];
     pf_b2 = gt.gnn[2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + (pl < H2 ? pl : H2 - 1)];
   }
-  // TAIL 2: the roll's stores - the 16-byte pieces of the fp32 adjacency whose bits change (dmask: which of this thread's
-  // ADJ_PER pieces), the node rows and their copy for the record (row cur = N - 1 holds the observation by then), and
+  // TAIL 2: the roll's stores - the node rows and their copy for the record (row cur = N - 1 holds the observation by then), and
   // layer 1 of the rows that keep their sources, one row up (parts 3 and 4) - in parts, one behind the barrier that
   // follows the loads and one in front of each of the next phases of the edge network (every workgroup is in the same
   // phase: issued in one piece the stores of 256 CUs meet in the same microsecond)
-  uint32_t dmask = 0u;
   // rows re-evaluated by this step (below) rather than copied: the rows that lost a source, one at a time - or, when they
   // are many, every row of a 32-row tile that holds one, on the matrix cores
   bool by_tile = false;
@@ -552,24 +582,15 @@ __global__ __launch_bounds__(256) void k_learned_select(
   };
   auto steady_stores = [&](const int k) {
     if (TAIL == 2 && wrap) {
-      float* ag = adj + (size_t)b * N * N;
       float* ngo = nodes_out + (size_t)b * N * F;
       float* sn = snap + (size_t)b * N * F;
       float* h1g = gt.h1_out + (size_t)b * N * gt.H1;
       float* a1g = gt.agg1_out + (size_t)b * N * F;
-#if !(defined(GCM_LS_EXP) && (GCM_LS_EXP & 1))
-      if ((dmask >> (k * (ADJ_PER / 4))) & ((1u << (ADJ_PER / 4)) - 1u)) {
-#pragma unroll
-        for (int i = 0; i < ADJ_PER; ++i) {
-          if (i / (ADJ_PER / 4) != k) continue;
-          const int e4 = tid + 256 * i, r = div_n4(e4), c = (e4 - r * N4) * 4;
-          if ((dmask >> i) & 1u) {
-            const uint32_t u = sBits[r * 4 + (c >> 5)] >> (c & 31);
-            *reinterpret_cast<float4*>(ag + e4 * 4) = make_float4((float)(u & 1u), (float)((u >> 1) & 1u),
-                                                                  (float)((u >> 2) & 1u), (float)((u >> 3) & 1u));
-          }
-        }
-      }
+#ifndef GCM_LS_PLAIN
+      const __amdgpu_buffer_rsrc_t r_ng = __builtin_amdgcn_make_buffer_rsrc(ngo, 0, N * F * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_sn = __builtin_amdgcn_make_buffer_rsrc(sn, 0, N * F * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc(h1g, 0, N * gt.H1 * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc(a1g, 0, N * F * 4, 0x00020000);
 #endif
 #pragma unroll
       for (int i = 0; i < NODE_PER; ++i) {
@@ -580,8 +601,13 @@ __global__ __launch_bounds__(256) void k_learned_select(
 #else
         if (e4 < lim_n) {
 #endif
+#ifndef GCM_LS_PLAIN
+          wt_store4(r_ng, e4 * 16, cn[i].x, cn[i].y, cn[i].z, cn[i].w);
+          wt_store4(r_sn, e4 * 16, cn[i].x, cn[i].y, cn[i].z, cn[i].w);
+#else
           *reinterpret_cast<float4*>(ngo + e4 * 4) = cn[i];
           *reinterpret_cast<float4*>(sn + e4 * 4) = cn[i];
+#endif
         }
       }
       // layer 1 of row r: that of row r + 1 of the previous state (in st_hc / st_ha) unless the row is re-evaluated
@@ -595,9 +621,18 @@ __global__ __launch_bounds__(256) void k_learned_select(
         for (int i = 0; i < 4; ++i) {
           if (i / 2 != k - 3) continue;
           const int e4 = tid + 256 * i, r = e4 / (FP / 4), c = (e4 % (FP / 4)) * 4;
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 8)
+          if (r < cur && !re_evaluated(r) && st_hc.v[4 * i] == 12345.f) {
+#else
           if (r < cur && !re_evaluated(r)) {
+#endif
+#ifndef GCM_LS_PLAIN
+            wt_store4(r_h1, (r * FP + c) * 4, st_hc.v[4 * i], st_hc.v[4 * i + 1], st_hc.v[4 * i + 2], st_hc.v[4 * i + 3]);
+            wt_store4(r_a1, (r * FP + c) * 4, st_ha.v[4 * i], st_ha.v[4 * i + 1], st_ha.v[4 * i + 2], st_ha.v[4 * i + 3]);
+#else
             *reinterpret_cast<float4*>(h1g + r * FP + c) = make_float4(st_hc.v[4 * i], st_hc.v[4 * i + 1], st_hc.v[4 * i + 2], st_hc.v[4 * i + 3]);
             *reinterpret_cast<float4*>(a1g + r * FP + c) = make_float4(st_ha.v[4 * i], st_ha.v[4 * i + 1], st_ha.v[4 * i + 2], st_ha.v[4 * i + 3]);
+#endif
 
           }
         }
@@ -656,8 +691,28 @@ __global__ __launch_bounds__(256) void k_learned_select(
           o.x = (wbits.x >> 1) | (wbits.y << 31); o.y = (wbits.y >> 1) | (wbits.z << 31);
           o.z = (wbits.z >> 1) | (wbits.w << 31); o.w = wbits.w >> 1;
           *reinterpret_cast<uint4*>(sBits + tid * 4) = o;
-          // ... and where it differs from the image in place: only those 16-byte pieces of the fp32 matrix are written
-          *reinterpret_cast<uint4*>(sBits + NP * 4 + tid * 4) = make_uint4(o.x ^ obits.x, o.y ^ obits.y, o.z ^ obits.z, o.w ^ obits.w);
+          // ... and where it differs from the image in place: only those 16-byte pieces of the fp32 matrix are written,
+          // by the row's thread (nothing in this kernel reads the fp32 matrix: no need to wait for the barrier; a
+          // sparse adjacency changes a piece or two a row)
+          if (wrap && tid < N) {
+            const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+            const uint32_t dw[4] = {o.x ^ obits.x, o.y ^ obits.y, o.z ^ obits.z, o.w ^ obits.w};
+            float* arow = adj + ((size_t)b * N + tid) * N;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              uint32_t m = (dw[w] | (dw[w] >> 1) | (dw[w] >> 2) | (dw[w] >> 3)) & 0x11111111u;   // pieces that change
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 65)
+              m = 0u;
+#endif
+              while (m) {
+                const int sh = __builtin_ctz(m);
+                m &= m - 1u;
+                const uint32_t u = ow[w] >> sh;
+                *reinterpret_cast<float4*>(arow + 32 * w + sh) = make_float4((float)(u & 1u), (float)((u >> 1) & 1u),
+                                                                             (float)((u >> 2) & 1u), (float)((u >> 3) & 1u));
+              }
+            }
+          }
           // a row whose sources included the dropped node (column 0 of its old row) is re-evaluated (sAff: those rows)
           const unsigned long long ma = __ballot(tid + 1 < N && (wbits.x & 1u));
           if (lane == 0) { sAff[2 * wave] = (uint32_t)ma; sAff[2 * wave + 1] = (uint32_t)(ma >> 32); }
@@ -670,7 +725,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
         // rows r + 1 of the previous state's layer 1 - what row r of the advanced graph holds unless it lost a source:
         // requested here, behind the wait every other load of the step had to pass (nothing needs them before the
         // edge network's second product: 8.4 MB that arrive under its first)
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 32)
+        if (false) {
+#else
         if (ex) {
+#endif
           st_hc.load<true>(gt.h1_prev + (size_t)b * N * FP, N, FP, FP, tid, 1);
           st_ha.load<true>(gt.agg1_prev + (size_t)b * N * FP, N, FP, FP, tid, 1);
         } else {
@@ -678,17 +737,6 @@ __global__ __launch_bounds__(256) void k_learned_select(
           st_ha.load<false>(gt.agg1_prev + (size_t)b * N * F, N, F, F, tid, 1);
         }
         by_tile = __popc(sAff[0]) + __popc(sAff[1]) + __popc(sAff[2]) + __popc(sAff[3]) > 12;
-        {
-          const int lim_a = N * N4;
-          uint32_t dv[ADJ_PER];
-#pragma unroll
-          for (int i = 0; i < ADJ_PER; ++i) {              // (the reads of all pieces in flight together)
-            const int e4 = min(tid + 256 * i, lim_a - 1), r = div_n4(e4), c = (e4 - r * N4) * 4;
-            dv[i] = sBits[NP * 4 + r * 4 + (c >> 5)] >> (c & 31);
-          }
-#pragma unroll
-          for (int i = 0; i < ADJ_PER; ++i) dmask |= (tid + 256 * i < lim_a && (dv[i] & 15u)) ? 1u << i : 0u;
-        }
         LSTAMP(31);
         steady_stores(0);
       } else if (wrap) {   // source and destination alias: every load lands before the first store
@@ -886,7 +934,6 @@ __global__ __launch_bounds__(256) void k_learned_select(
     // and into the record.  Row cur itself is wave 0's, below (its bits are being written: whatever this computes for
     // it is dropped).
     const int H1 = gt.H1;
-    if (!wrap && tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);   // (the caller guarantees full graphs)
     if (wave != 0 && !by_tile) {
       // one row at a time, round robin over waves 1 - 3, as wave 0 does row cur below: the row's sources from the bit
       // image as a rank-compacted list, agg1 gathered from the node image, h1 as two half products (scratch: this
@@ -1000,7 +1047,12 @@ __global__ __launch_bounds__(256) void k_learned_select(
     }
     __syncthreads();   // row cur's bits (wave 0) and the re-evaluated rows of the h1 image are in LDS
     LSTAMP(27);
-    if (tid < N) *reinterpret_cast<uint4*>(gt.abits + ((size_t)b * N + tid) * 4) = *reinterpret_cast<const uint4*>(sBits + tid * 4);
+#if defined(GCM_LS_EXP) && (GCM_LS_EXP & 16)
+    if (tid < N && sBits[tid * 4] == 0x12345u)
+#else
+    if (tid < N)
+#endif
+      *reinterpret_cast<uint4*>(gt.abits + ((size_t)b * N + tid) * 4) = *reinterpret_cast<const uint4*>(sBits + tid * 4);
   }
   if (wave == 0) {
     if (TAIL) {
@@ -1076,7 +1128,9 @@ __global__ __launch_bounds__(256) void k_learned_select(
     }
   }
   if (ADVANCE && cur_host >= 0 && tid == 0 && n_chk != (int64_t)cur_host) atomicOr(flags, GCM_FLAG_BAD_COUNT);
+  if (TAIL == 2 && tid == 0 && n_chk != (int64_t)N) atomicOr(flags, GCM_FLAG_BAD_COUNT);
   LSTAMP(23);
+  LSPAN(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2336,7 +2390,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
 
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + FP * GS + 7 * FP + NP); }
 constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * GS); }
-constexpr size_t lds_select_steady() { return lds_select_tail() + sizeof(uint32_t) * (2 * NP * 4 + 4); }
+constexpr size_t lds_select_steady() { return lds_select_tail() + sizeof(uint32_t) * (NP * 4 + 4); }
 constexpr size_t lds_bwd() {
   return sizeof(float) * (5 * NP * FS + 3 * FP * FS + 4096 + 7 * FP + 7 * NP + 32 + 64 + 64 + 32 + 256 + NP + 8 +
                           (2 * FP * FP + FP + 2 * FP * FP + FP) + (3 * FP * FP + 7 * FP + 1) + 3);

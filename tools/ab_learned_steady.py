@@ -33,6 +33,16 @@ for it in range(6):
     torch.cuda.synchronize()
     if it:
         best = min(best, e0.elapsed_time(e1) * 1e3 / N)
+def chain():
+    with torch.no_grad():
+        h = None
+        for t in range(2 * N):
+            _, h = mem(obs[t], h)
+
+
+prof = bench.profile_kernels(chain, reps=2)
+kern = {k: round(d["avg_us"], 2) for k, d in prof.items() if "k_learned_select" in k or "k_adj_bits" in k}
+print("kernel durations (device activity trace), us:", kern)
 adj = hidden[1]
 print(f"{sys.argv[1] if len(sys.argv) > 1 else 'product'}: steady step {best:7.2f} us (best of 5 chains), "
       f"steady steps {mem.learned_steady_steps_taken()}, adjacency density {float((adj != 0).float().mean()):.4f}")

@@ -21,8 +21,8 @@ c = dict(bench.CONFIGS["cfg5"])
 c["T"] = 2 * c["N"]
 mem, gnn, sel = bench.build_memory(dev, donate=True, selector="learned", cfg=c)
 obs = bench.make_obs(c, 0, dev)
-seq = [(14, 28, "count / addresses, every load issued, node image -> LDS, bit images"), (28, 29, "every load landed"),
-       (29, 30, "barrier"), (30, 31, "previous layer 1 requested; which 16-byte pieces of the adjacency change"),
+seq = [(14, 28, "addresses, every load issued, node image -> LDS, bit images, changed adjacency pieces stored"), (28, 29, "every load landed"),
+       (29, 30, "barrier"), (30, 31, "previous layer 1 requested"),
        (31, 15, "stores part 0"), (15, 16, "LDS images (+ barrier)"),
        (16, 17, "stores part 1; c0, P0 (product)"), (17, 18, "stores part 2; LayerNorm 0"), (18, 19, "stores part 3; P1 (product)"),
        (19, 20, "LayerNorm 1"), (20, 21, "logits (+ fence, barrier)"), (21, 22, "gumbel-softmax, adjacency row"),
@@ -46,3 +46,15 @@ print("k_learned_select<2, 2>, last step of a 2 N chain, workgroup 0 / thread 0 
 for (a, b, n), v in zip(seq, acc):
     print(f"  {a:2d} -> {b:2d}  {n:58s} {v:9.1f}")
 print(f"  total {sum(acc):9.1f}")
+B = c["B"]
+sp = (ctypes.c_ulonglong * (2 * B))()
+lib.gcm_debug_read_spans.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.gcm_debug_read_spans(sp, B)
+st = [sp[2 * i] for i in range(B)]
+en = [sp[2 * i + 1] for i in range(B)]
+t0 = min(st)
+dur = sorted((e - s_) / 100.0 for s_, e in zip(st, en))
+off = sorted((s_ - t0) / 100.0 for s_ in st)
+print(f"every workgroup of the last launch (s_memrealtime, us): first start -> last end {(max(en) - t0) / 100.0:.2f}; own duration min "
+      f"{dur[0]:.2f} median {dur[B // 2]:.2f} p90 {dur[int(B * 0.9)]:.2f} max {dur[-1]:.2f}; start offsets median {off[B // 2]:.2f} "
+      f"p90 {off[int(B * 0.9)]:.2f} max {off[-1]:.2f}")
