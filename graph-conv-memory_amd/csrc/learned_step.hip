@@ -309,16 +309,6 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// 16-byte WRITE-THROUGH store (sc1) of data this launch does not read again: the bytes leave for memory while the
-// kernel computes instead of sitting dirty in the XCD's L2 until the write-back at the end of the launch, which nothing
-// overlaps (16.8 MB a steady-state step: ~4 us behind the last workgroup).  rsrc: a buffer descriptor of the graph's
-// matrix (wave-uniform), off: byte offset.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void wt_store4(__amdgpu_buffer_rsrc_t rsrc, int off, float x, float y, float z, float w) {
-  const u32x4 v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);
-}
-
 // half of a 32-wide matrix-vector product on a half wave: the 32 products of a weight row (16-byte aligned, LDS) with
 // a vector (LDS, 16-byte broadcast reads) in two chains; the other half wave's sum added (lanes l and l + 32 form a row)
 __device__ __forceinline__ float half_dot(const float* wrow, const float* u) {
