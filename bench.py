@@ -875,9 +875,9 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                 else:
                     # (the one-launch steady-state step k_learned_select<2, 2>, or - a chain that fell back - every
                     #  kernel that runs once per steady-state step: the profiler drops events, hence the slack)
-                    ss = {k: d for k, d in p2.items() if "k_learned_select<2, 2>" in k}
+                    ss = {k: d for k, d in p2.items() if "k_learned_select<2, 2" in k}
                     if not ss:
-                        ss = {k: d for k, d in p2.items() if "k_learned_select<2, 1>" not in k
+                        ss = {k: d for k, d in p2.items() if "k_learned_select<2, 1" not in k
                               and abs(d["launches_per_call"] - (T2 - N)) < 0.25 * (T2 - N)}
                 variants["T%d_steady_state_step_us" % T2] = round(sum(d["avg_us"] for d in ss.values()), 3) if ss else None
                 variants["T%d_steady_state_kernels" % T2] = {k: round(d["avg_us"], 3) for k, d in ss.items()}

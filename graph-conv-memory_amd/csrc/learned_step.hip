@@ -303,6 +303,14 @@ struct GnnTail {
                                      // the state BEFORE the step on entry, after it on exit (gcm_adj_bits builds the first one)
 };
 
+// 16 bytes from global memory as ONE global_load_dwordx4: through the compiler's own 4-vector (a load of HIP's float4
+// struct is split by field use - dwordx3 + dword, dwordx2 pairs - and the first phase of the step kernels is bound by
+// the number of instructions in front of the first wait)
+__device__ __forceinline__ float4 ld4(const float* p) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
 // one wave of work on a 32 x 32 block of an LDS image shared with nobody: LDS writes -> reads of other lanes
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -345,7 +353,7 @@ struct StageL {
 #pragma unroll
       for (int i = 0; i < PER / 4; ++i) {
         const int e4 = tid + 256 * i, r = min(e4 / (CP / 4) + rsh, RP - 1), c = (e4 % (CP / 4)) * 4;
-        const float4 t = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+        const float4 t = ld4(src + (size_t)r * ld + c);
         v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
       }
     } else {
@@ -393,15 +401,21 @@ struct StageL {
 // wherever the stores were put.)  It writes what k_gnn2_row_fwd wrote into the step's record (h1, agg1, agg2, mx: gcm_learned_step_layout,
 // compact = 1), so the chain's backward reads it unchanged - ONE launch instead of two, and no second pass over the
 // 16.8 MB adjacency.
-template <int MODE, int TAIL>
+// EX: the exact shapes N = NP, F = H1 = H2 = FP as compile-time constants (cfg5; the launchers check): every bound,
+// clamp and row / column index of the staging code folds - the first phase of the kernel was ~1000 VALU instructions of
+// address arithmetic and forty conditional blocks around its fifty loads, a quarter of the cached step.
+template <int MODE, int TAIL, bool EX = false>
 __global__ __launch_bounds__(256) void k_learned_select(
     const float* __restrict__ nodes_c, float* adj, const int64_t* __restrict__ cur_idx_c,
     const float* __restrict__ noise, int noise_is_exp, const float* __restrict__ mlp, float eps0,
-    float eps1, float cutoff, float* __restrict__ soft, int N, int F, const float* __restrict__ obs,
+    float eps1, float cutoff, float* __restrict__ soft, int N_, int F_, const float* __restrict__ obs,
     const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes_out,
     int64_t* __restrict__ cur_out, int64_t* count_out, uint32_t* __restrict__ flags,
-    float* __restrict__ snap, float* __restrict__ row_out, GnnTail gt, int cur_host) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
+    float* __restrict__ snap, float* __restrict__ row_out, GnnTail gt_, int cur_host) {   // (MODE 2: adj == adj_in, nodes_out == nodes_in)
   constexpr bool ADVANCE = MODE != 0, DONATE = MODE == 2;
+  const int N = EX ? NP : N_, F = EX ? FP : F_;
+  GnnTail gt = gt_;
+  if (EX) { gt.H1 = FP; gt.H2 = FP; }
   static_assert(!TAIL || ADVANCE, "the cached step advances the state itself");
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   // the caller or the previous step's kernel wrote (observation, gumbel draws, node rows, adjacency row, h1 cache),
   // then the parameters (L2 resident).  `ex`: exact shapes (uniform) - the same loads without clamps and masks, a
   // few hundred VALU instructions less in front of the first wait.
-  const bool ex = F == FP && N == NP && (!TAIL || (gt.H1 == FP && gt.H2 == FP));
+  const bool ex = EX || (F == FP && N == NP && (!TAIL || (gt.H1 == FP && gt.H2 == FP)));
   float pf_noise[2], pf_old[2], pf_b1 = 0.f, pf_b2 = 0.f;
   {
     const int pl = tid & 63;
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
 #pragma unroll
     for (int i = 0; i < NODE_PER; ++i) {   // this thread's pieces of the observation, whichever row turns out to be cur
       const int e4 = min(tid + 256 * i, lim_n - 1);
-      ob[i] = *reinterpret_cast<const float4*>(obs + (size_t)b * F + (e4 - div_f4(e4) * F4) * 4);
+      ob[i] = ld4(obs + (size_t)b * F + (e4 - div_f4(e4) * F4) * 4);
     }
     if (TAIL == 2) {   // bit row tid + 1 (-> row tid), node rows one down; the fp32 adjacency is not read
       if (wrap && tid + 1 < N) wbits = *reinterpret_cast<const uint4*>(gt.abits + ((size_t)b * N + tid + 1) * 4);
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
 #pragma unroll
       for (int i = 0; i < NODE_PER; ++i) {
         const int e4 = min(tid + 256 * i, lim_n - 1), r = div_f4(e4), c = (e4 - r * F4) * 4;
-        cn[i] = *reinterpret_cast<const float4*>(ng_in + (wrap ? min(r + 1, N - 1) : r) * F + c);
+        cn[i] = ld4(ng_in + (wrap ? min(r + 1, N - 1) : r) * F + c);
       }
     } else if (wrap) {
       gcm_state::load_copy<ADJ_PER, NODE_PER, true>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
 #pragma unroll
       for (int i = 0; i < NODE_PER; ++i) {
         const int e4 = min(tid + 256 * i, lim_n - 1);
-        cn[i] = *reinterpret_cast<const float4*>(ng_in + 4 * e4);
+        cn[i] = ld4(ng_in + 4 * e4);
       }
     } else {
       gcm_state::load_copy<ADJ_PER, NODE_PER, false>(ca, cn, ag_in, ng_in, tid, N, N4, F, F4);
@@ -2474,7 +2488,8 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_tail();
-  auto kern = gcm_learned::k_learned_select<2, 1>;
+  const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
+  auto kern = exact ? gcm_learned::k_learned_select<2, 1, true> : gcm_learned::k_learned_select<2, 1, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
@@ -2541,7 +2556,8 @@ extern "C" int gcm_learned_step_steady(const float* obs, float* nodes, float* ad
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_steady();
-  auto kern = gcm_learned::k_learned_select<2, 2>;
+  const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
+  auto kern = exact ? gcm_learned::k_learned_select<2, 2, true> : gcm_learned::k_learned_select<2, 2, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, nullptr, nullptr, nullptr, mx, agg2, h1, agg1, h1_prev, agg1_prev, adj_bits};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
@@ -2565,7 +2581,8 @@ extern "C" int gcm_learned_step_cached_functional(
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_tail();
-  auto kern = gcm_learned::k_learned_select<1, 1>;
+  const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
+  auto kern = exact ? gcm_learned::k_learned_select<1, 1, true> : gcm_learned::k_learned_select<1, 1, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
