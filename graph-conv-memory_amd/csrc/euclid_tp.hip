@@ -67,10 +67,10 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
   const int ct = wave & 3, rb = wave >> 2;   // SIMD = column tile, its four waves = the slot blocks
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sN = smem;                    // [RB][NS]      ring image of the graph's nodes, scaled, times -2
-  float* sC = sN + RB * NS;            // [2][FP][CS]   current rows, transposed, two chunks of CB graphs
-  float* sNn = sC + 2 * FP * CS;       // [RB]     |n|^2
-  float* sCn = sNn + RB;               // [2][CB]  |c|^2
-  float* sPart = sCn + 2 * CB;         // [4][4][2][RB] sums over b' per (column tile, lane half), four steps in flight
+  float* sC = sN + RB * NS;            // [3][FP][CS]   current rows, transposed, three chunks of CB graphs (below)
+  float* sNn = sC + 3 * FP * CS;       // [RB]     |n|^2
+  float* sCn = sNn + RB;               // [3][CB]  |c|^2
+  float* sPart = sCn + 3 * CB;         // [4][4][2][RB] sums over b' per (column tile, lane half), four steps in flight
 
   const float den = dist_param ? dist_param[0] : 1.f;
   // staging: thread = SEG consecutive features (segment tid & 7) of row tid >> 3 of a 128-row tile (distance.hip)
@@ -137,10 +137,16 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
   for (int e = tid; e < RB * NS; e += NT) sN[e] = 0.f;
   if (tid < RB) sNn[tid] = 0.f;
   __syncthreads();
+  // The chunks of current rows run THREE deep: round g reads chunk g from LDS, chunk g + 1 goes from registers to LDS
+  // at the top of round g (its loads were requested at the top of round g - 1: landed long ago - no wait, and no store
+  // phase between the MFMA chain and the round's barrier, where it was 1.5 k of a round's 13 k cycles), chunk g + 2 is
+  // requested into the same registers right behind.  Three buffers: the one being written was last read two rounds ago.
+  float vq[SEG];   // chunk g + 1
   if (R > 0) {
     float vc[SEG], vn[SEG];
     load_chunk(1, 0, vc);
     if (tid < 8) load_seg(obs + (size_t)b * F, vn);
+    if (R > 1) load_chunk(nch == 1 ? 2 : 1, nch == 1 ? 0 : CB, vq);
     asm volatile("" ::: "memory");
     store_chunk(sC, sCn, 0, vc);
     if (tid < 8) insert_node(0, vn);
@@ -180,14 +186,24 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
   };
 
   int t = 1, c = 0, buf = 0;
-  float touch = 0.f;
 #pragma unroll 1
-  for (int g = 0; g < R; ++g, buf ^= 1) {
-    const bool first = c == 0, last = c == nch - 1, has_next = g + 1 < R;
+  for (int g = 0; g < R; ++g, buf = buf == 2 ? 0 : buf + 1) {
+    const bool first = c == 0, last = c == nch - 1;
     const int t2 = last ? t + 1 : t, c2 = last ? 0 : c + 1;
-    float vnext[SEG];
+    const int bufn = buf == 2 ? 0 : buf + 1;
     TSTAMP(0);
-    if (has_next) load_chunk(t2, c2 * CB, vnext);
+    // the round's staging (chunk g + 1 registers -> LDS, chunk g + 2 requested): in FRONT of the MFMA chain on the even
+    // slot blocks, BEHIND it on the odd ones - the four waves of a SIMD are the four slot blocks of a column tile, so one
+    // pair's staging runs under the other pair's matrix work instead of all sixteen waves staging while the pipe idles
+    auto stage_io = [&]() __attribute__((always_inline)) {
+      if (g + 1 < R) store_chunk(sC + bufn * FP * CS, sCn + bufn * CB, c2 * CB, vq);
+      if (g + 2 < R) {
+        const bool last2 = c2 == nch - 1;
+        load_chunk(last2 ? t2 + 1 : t2, (last2 ? 0 : c2 + 1) * CB, vq);
+      }
+    };
+    const bool io_first = (rb & 1) == 0;   // (wave-uniform)
+    if (io_first) stage_io();
     if (g >= 1 && (g - 1) % nch == 0 && g - 1 >= nch && tid < RB) finalize((g - 1) / nch);
     if (first && (t == 1 || rb == (((t - 1) % N) >> 5))) {   // (wave-uniform) node t - 1 went into this wave's block
       const float* np = sN + (rb * 32 + li) * NS + lh;
@@ -210,7 +226,10 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
         pend = false;
       }
       float psum = 0.f;
-#ifdef GCM_ETP_NOPIPE
+#ifndef GCM_ETP_PIPE
+      // (the epilogue of the previous tile in front of this chain, not under it: the pipelined form - GCM_ETP_PIPE -
+      //  keeps sixteen more registers live across the chain, which with the loop-carried chunk registers no longer fit
+      //  the 128 a wave of a 16-wave workgroup has; it measured the same when it did)
       if (pend) { part += gcm_dist_tile_sum_full(accp); pend = false; }
 #endif
       if (!pend) gcm_dist_chain<KQ, 8, false>(acc, nv, cp, CS, c_last, accp, psum);
@@ -234,29 +253,17 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
       if (lane == 0) sNn[t % N] = sCn[buf * CB + b_row];
     }
     TSTAMP(3);
-    if (has_next) store_chunk(sC + (buf ^ 1) * FP * CS, sCn + (buf ^ 1) * CB, c2 * CB, vnext);
+    if (!io_first) stage_io();
     TSTAMP(4);
-#ifndef GCM_ETP_NOTOUCH
-    // warm the L2 for the chunk after next (every WG of an XCD reads the same 32 KB per round).  The previous touch is
-    // consumed HERE, a full round after its issue (the wait for `vnext` above already covered it: loads return in
-    // order) - consumed at the top of the round it stalled every round for an HBM round trip.
-    asm volatile("" ::"v"(touch));
-    if (g + 2 < R) {
-      const int t3 = c2 == nch - 1 ? t2 + 1 : t2, c3 = c2 == nch - 1 ? 0 : c2 + 1;
-      const int gr = c3 * CB + srow < B ? c3 * CB + srow : B - 1;
-      touch = obs[((size_t)t3 * B + gr) * F + (sf0 < F ? sf0 : 0)];
-    }
-#endif
     // round g is consumed; the next chunk, the inserted node and the published sums are in LDS.  A raw barrier behind
-    // the LDS counter only: __syncthreads() also drains vmcnt, i.e. waits for the L2 touch issued just above (an HBM
-    // miss: ~2 us per round - measured as the round's fixed cost)
+    // the LDS counter only: __syncthreads() also drains vmcnt, i.e. waits for the loads of the chunk after next issued
+    // at the top of the round (an HBM miss: ~2 us per round - measured as the round's fixed cost)
     TSTAMP(5);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TSTAMP(6);
     t = t2;
     c = c2;
   }
-  asm volatile("" ::"v"(touch));
   if (T >= 2) {
     if (pend) part += gcm_dist_tile_sum(accp, lh, pend_rows);
     publish(T - 1);
@@ -482,7 +489,7 @@ extern "C" int gcm_euclid_rollout_tp_decide(const float* obs, float max_distance
   GCM_REQUIRE(obs && decbits);
   if (!gcm_euclid_rollout_tp_supported(T, B, N, F, 32, 32)) return GCM_EUNSUPPORTED;
   const int FT = (F + 31) / 32, FP = 32 * FT;
-  const size_t lds = sizeof(float) * ((size_t)128 * (FP + 1) + (size_t)2 * FP * 129 + 128 + 2 * 128 + (size_t)4 * 8 * 128);
+  const size_t lds = sizeof(float) * ((size_t)128 * (FP + 1) + (size_t)3 * FP * 129 + 128 + 3 * 128 + (size_t)4 * 8 * 128);
   hipStream_t s = (hipStream_t)stream;
   if (FT == 1) {
     auto kern = gcm_etp::k_euclid_tp<1>;
