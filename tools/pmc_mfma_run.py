@@ -30,8 +30,8 @@ for name in ("cfg3", "cfg5"):
         bench.rollout(mem, obs)
         mem_f, _, _ = bench.build_memory(dev, donate=False, selector=c["selector"], cfg=c)
         bench.rollout_api(mem_f, obs)
-        if name == "cfg3":          # 16 steps past graph_size: the steady-state step k_euclid_mfma2<.., 2>
-            bench.rollout(mem, bench.make_obs(dict(c, T=c["N"] + 16), 0, dev))
+        # 16 steps past graph_size: the steady-state steps k_euclid_mfma2<.., 2> / k_learned_select<2, 2, ..>
+        bench.rollout(mem, bench.make_obs(dict(c, T=c["N"] + 16), 0, dev))
         torch.cuda.synchronize()
 if "cfg2" in which:
     c = bench.CONFIGS["cfg2"]

@@ -66,6 +66,10 @@ for name, T in (("cfg3", 128), ("cfg5", 64)):
             from gcm.gcm import DenseGCM
             DenseGCM.did_warn = True
             bench.rollout(mem, bench.make_obs(dict(c, T=T + 32), 0, dev))
+        if name == "cfg5":                  # ... the LearnedEdge chain 32 steps past graph_size: k_learned_select<2, 2, ..>
+            from gcm.gcm import DenseGCM
+            DenseGCM.did_warn = True
+            bench.rollout(mem, bench.make_obs(dict(c, T=c["N"] + 32), 0, dev))
         torch.cuda.synchronize()
 if "cfg4" in which:
     from gcm import nn as G

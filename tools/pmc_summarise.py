@@ -34,6 +34,10 @@ def per_kernel(d, counter):
                     tail = {"false": "0", "true": "1"}.get(t.group(1), t.group(1)) if t else "0"
                     if tail != "0":
                         name += "_tail" + tail
+                if name == "k_learned_select":   # template <MODE, TAIL, EX>: TAIL 2 = the steady-state step
+                    t = re.search(r"k_learned_select<\d+, (\d+|true|false)", row["Kernel_Name"])
+                    if t and t.group(1) == "2":
+                        name += "_steady"
                 if name == "k_bptt_rows":        # template <FP, HP, H2P, MODE>: 2 = pass A of the LearnedEdge backward
                     t = re.search(r"k_bptt_rows<(\d+), \d+, \d+, (\d+)", row["Kernel_Name"])
                     if t and t.group(2) == "2":
