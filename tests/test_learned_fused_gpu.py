@@ -478,3 +478,25 @@ def test_learned_chain_steady_state_one_launch_vs_oracle(B, N, F, H, T, k):
     hidden, mem = _run_both(B, N, F, H, T, k, seed=31 + N, count0=None, pick=list(range(B)), donate=True)
     assert int(hidden[3].min()) == N
     assert mem.learned_steady_steps_taken() == (T - N if (N % 4 == 0 and F % 4 == 0) else 0)
+
+
+@pytest.mark.parametrize("B,N", [(7, 128), (5, 72), (3, 4), (64, 100)])
+def test_adj_bits_through_the_c_abi(B, N):
+    """gcm_adj_bits (the image a steady-state LearnedEdge chain keeps of its adjacency): bit (j & 31) of word (j >> 5)
+    of row r = (adj[b, r, j] != 0), every other bit zero - against numpy, ragged N."""
+    import numpy as np
+    from gcm import _hip
+    lib = _hip.lib()
+    torch.manual_seed(B + N)
+    adj = (torch.rand(B, N, N) < 0.2).float() * torch.randint(1, 3, (B, N, N)).float()   # non-zero, not only 1.0
+    a_dev = adj.to(DEV)
+    bits = torch.full((B, N, 4), -1, dtype=torch.int32, device=DEV)
+    _hip.check(lib.gcm_adj_bits(a_dev.data_ptr(), bits.data_ptr(), B, N, _hip.stream()), "gcm_adj_bits")
+    torch.cuda.synchronize()
+    got = bits.cpu().numpy().astype(np.uint32)
+    want = np.zeros((B, N, 4), dtype=np.uint32)
+    nz = (adj != 0).numpy()
+    for j in range(N):
+        want[:, :, j >> 5] |= nz[:, :, j].astype(np.uint32) << np.uint32(j & 31)
+    assert np.array_equal(got, want)
+    assert lib.gcm_adj_bits(a_dev.data_ptr(), bits.data_ptr(), B, 130, _hip.stream()) != 0     # N > 128: refused
