@@ -36,17 +36,35 @@
 
 #ifdef GCM_STAMPS   // diagnostic build only (tools/kstamp_euclid_tp.py): two rounds of workgroup 0, thread 0
 __device__ unsigned long long g_stamps_tp[32];
+__device__ unsigned long long g_stamps_all[128];
+extern "C" int gcm_debug_read_stamps_tp_all(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_all), sizeof(unsigned long long) * 128);
+}
 extern "C" int gcm_debug_read_stamps_tp(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_tp), sizeof(unsigned long long) * n);
 }
+#ifdef GCM_STAMP_ALLWAVES   // every wave of workgroup 0 in round 238: [wave][phase]
 #define TSTAMP(i)                                                                   \
   do {                                                                              \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (g == 38 || g == 238)) {             \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && g == 238) {                   \
+      unsigned long long t_;                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+      g_stamps_all[(threadIdx.x >> 6) * 8 + (i)] = t_;                              \
+    }                                                                               \
+  } while (0)
+#else
+#ifndef GCM_STAMP_TID   // (which thread stamps: 0 = the oldest wave; 768 / 832 ... = a wave of the last slot block)
+#define GCM_STAMP_TID 0
+#endif
+#define TSTAMP(i)                                                                   \
+  do {                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == GCM_STAMP_TID && (g == 38 || g == 238)) { \
       unsigned long long t_;                                                        \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
       g_stamps_tp[(g == 38 ? 0 : 8) + (i)] = t_;                                    \
     }                                                                               \
   } while (0)
+#endif
 #else
 #define TSTAMP(i)
 #endif
@@ -165,20 +183,16 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
     }
   };
 
-  // Software pipeline: the sqrt / sum epilogue of a wave's tile runs UNDER the MFMA chain of its next tile (the
-  // scheduler places its instructions behind the chain's MFMAs: gcm_dist_chain<.., PIPE>) - with the epilogue in
-  // program order behind its own chain the four waves of a SIMD finish their chains together and then queue for the
-  // one VALU.  So a tile's sum is settled one round late, a step's partial sums reach LDS in the first round of the
-  // NEXT step and are met one round after that (four steps' buffers: no reader meets a writer).
-  float part = 0.f;     // this lane's node: sum over b' of the step's settled tiles
+  // A tile's sqrt / sum epilogue follows its own chain.  The waves of a SIMD do not run in lockstep (the staging above is
+  // in front of the chain on two of them and behind it on the other two) and the matrix pipe serves their chains one
+  // after the other - one dependent chain alone keeps it busy - so a wave's epilogue (VALU) runs under the NEXT wave's
+  // chain.  (Per-wave stamps of the form that ran the previous tile's epilogue in FRONT of the chain: the four chains
+  // of a SIMD took 2.6 - 3.1 k cycles each, one after the other - 2.1 k of matrix work + the 0.55 k epilogue exposed
+  // each time.)  A step's partial sums reach LDS in its last round and are met one round later (four steps' buffers).
+  float part = 0.f;     // this lane's node: sum over b' of the step's tiles
   float nv[KQ + 1];     // N'(k, j = slot): -2 x the wave's 32 slots' rows | (1, |n|^2)
 #pragma unroll
   for (int q = 0; q <= KQ; ++q) nv[q] = 0.f;
-  f32x16 accp;          // the tile whose epilogue is pending
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accp[r] = 0.f;
-  bool pend = false;    // (wave-uniform)
-  int pend_rows = 32;
   // the sums of step u are complete (its last tile settled): to LDS, if this wave's block was live in step u
   auto publish = [&](int u) __attribute__((always_inline)) {
     if (rb * 32 < (u < N ? u : N)) sPart[(u & 3) * 8 * RB + (2 * ct + lh) * RB + rb * 32 + li] = part;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
     };
     const bool io_first = (rb & 1) == 0;   // (wave-uniform)
     if (io_first) stage_io();
-    if (g >= 1 && (g - 1) % nch == 0 && g - 1 >= nch && tid < RB) finalize((g - 1) / nch);
+    if (first && t >= 2 && tid < RB) finalize(t - 1);   // (published in the previous round, the last of step t - 1)
     if (first && (t == 1 || rb == (((t - 1) % N) >> 5))) {   // (wave-uniform) node t - 1 went into this wave's block
       const float* np = sN + (rb * 32 + li) * NS + lh;
 #pragma unroll
@@ -221,29 +235,11 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      if (pend && pend_rows < 32) {                         // (the batch's last, partial tile: not pipelined)
-        part += gcm_dist_tile_sum_masked(accp, lh, pend_rows);
-        pend = false;
-      }
-      float psum = 0.f;
-#ifndef GCM_ETP_PIPE
-      // (the epilogue of the previous tile in front of this chain, not under it: the pipelined form - GCM_ETP_PIPE -
-      //  keeps sixteen more registers live across the chain, which with the loop-carried chunk registers no longer fit
-      //  the 128 a wave of a 16-wave workgroup has; it measured the same when it did)
-      if (pend) { part += gcm_dist_tile_sum_full(accp); pend = false; }
-#endif
-      if (!pend) gcm_dist_chain<KQ, 8, false>(acc, nv, cp, CS, c_last, accp, psum);
-      else gcm_dist_chain<KQ, 8, true>(acc, nv, cp, CS, c_last, accp, psum);
-      part += psum;
-      if (first && t >= 2) publish(t - 1);                  // (the pending tile was step t - 1's last)
-      accp = acc;
-      pend = true;
-      pend_rows = B - col0;
-    } else {
-      if (pend) part += gcm_dist_tile_sum(accp, lh, pend_rows);
-      pend = false;
-      if (first && t >= 2) publish(t - 1);
+      float unused;
+      gcm_dist_chain<KQ, 8, false>(acc, nv, cp, CS, c_last, acc, unused);
+      part += gcm_dist_tile_sum(acc, lh, B - col0);
     }
+    if (last) publish(t);                                   // every tile of step t is in `part`
     TSTAMP(2);
     // node t (a candidate from step t + 1 on) IS current row b of step t: copied from the chunk that holds it into
     // ring slot t mod N - dead at step t (it held node t - N), so whoever still reads it masks it
@@ -264,15 +260,7 @@ __global__ __launch_bounds__(1024) void k_euclid_tp(const float* __restrict__ ob
     t = t2;
     c = c2;
   }
-  if (T >= 2) {
-    if (pend) part += gcm_dist_tile_sum(accp, lh, pend_rows);
-    publish(T - 1);
-    __syncthreads();
-    if (tid < RB) {
-      if (nch == 1 && T >= 3) finalize(T - 2);
-      finalize(T - 1);
-    }
-  }
+  if (T >= 2 && tid < RB) finalize(T - 1);   // (published in the last round, behind its barrier)
 }
 
 // ---------------------------------------------------------------------------------------------------------
