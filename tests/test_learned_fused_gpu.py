@@ -500,3 +500,43 @@ def test_adj_bits_through_the_c_abi(B, N):
         want[:, :, j >> 5] |= nz[:, :, j].astype(np.uint32) << np.uint32(j & 31)
     assert np.array_equal(got, want)
     assert lib.gcm_adj_bits(a_dev.data_ptr(), bits.data_ptr(), B, 130, _hip.stream()) != 0     # N > 128: refused
+
+
+def test_learned_steady_chain_falls_back_when_the_caller_edits_the_state():
+    """The steady-state step rolls the adjacency through the chain's own bit image - valid only while the donated state
+    is the chain's.  A caller that edits the adjacency in place between two steps (torch sees it: the version counter)
+    must get the general kernels from then on, working on the edited matrix: against the oracle given the same edit."""
+    from gcm.gcm import DenseGCM
+    DenseGCM.did_warn = True
+    B, N, F, H, k = 4, 32, 32, 32, 4
+    T1, T2 = N + 6, 5
+    ref, net, g, sel, mem = _pair(F, H, N, k, seed=91, donate=True)
+    gen = torch.Generator().manual_seed(92)
+    obs = torch.rand(T1 + T2, B, F, generator=gen)
+    noise = -torch.empty(T1 + T2, B, N).exponential_(generator=gen).log()
+    step = {"t": 0}
+    osel = od.LearnedEdge(net, num_edge_samples=k, noise_fn=lambda shape: noise[step["t"]][:, : shape[1]])
+    sel.noise_fn = lambda like: noise[step["t"]].to(DEV)
+
+    def edit(adj):           # a few edges the selector never sampled: rows 9 and 20 point at nodes 3 and 0
+        adj[:, 9, 3] = 1.0
+        adj[:, 20, 0] = 1.0
+        adj[:, 20, 7] = 0.0
+
+    hid_o, hid_p, outs_o, outs_p = None, None, [], []
+    with torch.no_grad():
+        for t in range(T1 + T2):
+            step["t"] = t
+            if t == T1:
+                a = hid_o[1].clone()
+                edit(a)
+                hid_o = (hid_o[0], a, hid_o[2], hid_o[3])
+                edit(hid_p[1])                     # in place, on the donated tensor
+            mo, hid_o = od.dense_step(obs[t], hid_o, ref, graph_size=N, edge_selectors=osel)
+            mp, hid_p = mem(obs[t].to(DEV), hid_p)
+            outs_o.append(mo)
+            outs_p.append(mp.cpu())
+    mem.check_flags()
+    assert mem.learned_steady_steps_taken() == T1 - N      # steady until the edit, the general kernels after it
+    assert torch.equal(hid_p[1].cpu(), hid_o[1]) and torch.equal(hid_p[0].cpu(), hid_o[0])
+    torch.testing.assert_close(torch.stack(outs_p), torch.stack(outs_o), rtol=RTOL, atol=2e-6)

@@ -27,7 +27,7 @@ acc, R = [0.0] * len(names), 5
 for it in range(R + 1):
     with torch.no_grad():
         hidden = None
-        for t in range(c["T"]):
+        for t in range(int(os.environ.get("T_STOP", c["T"]))):     # (T_STOP: the step whose launch is read, e.g. 20)
             mx, hidden = mem(obs[t], hidden)
     torch.cuda.synchronize()
     out = (ctypes.c_ulonglong * 32)()
