@@ -221,3 +221,40 @@ def test_euclid_chain_steady_state_full_size_equals_general_kernels():
     for k in a[2]:
         scale = float(b[2][k].abs().max()) + 1e-12
         torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-5, atol=5e-5 * scale, msg=k)
+
+
+def test_euclid_steady_chain_falls_back_when_the_caller_edits_the_state():
+    """The steady-state step writes the rolled adjacency from the chain's own bit image - valid only while the donated
+    state is the chain's.  After an in-place edit of the adjacency by the caller (torch's version counter shows it) the
+    chain runs the general kernels on the edited matrix: against the oracle given the same edit."""
+    from gcm.gcm import DenseGCM
+    DenseGCM.did_warn = True
+    B, N, F, H = 40, 32, 64, 32
+    T1, T2 = N + 7, 6
+    torch.manual_seed(3)
+    maxd = 3.0
+    ref, g, mem = _mk(F, H, H, N, maxd, donate=True)
+    obs = _clustered(T1 + T2, B, F, n_c=5, seed=17)
+    osel = od.EuclideanEdge(maxd)
+
+    def edit(adj):
+        adj[:, 11, 2] = 1.0
+        adj[:, 25, 0] = 1.0
+        adj[:, 25, 9] = 0.0
+
+    hid_o, hid_p, outs_o, outs_p = None, None, [], []
+    with torch.no_grad():
+        for t in range(T1 + T2):
+            if t == T1:
+                a = hid_o[1].clone()
+                edit(a)
+                hid_o = (hid_o[0], a, hid_o[2], hid_o[3])
+                edit(hid_p[1])
+            mo, hid_o = od.dense_step(obs[t], hid_o, ref, graph_size=N, edge_selectors=osel)
+            mp, hid_p = mem(obs[t].to(DEV), hid_p)
+            outs_o.append(mo)
+            outs_p.append(mp.cpu())
+    mem.check_flags()
+    assert mem.rows_rolled_steps_taken() == T1 - N
+    assert torch.equal(hid_p[1].cpu(), hid_o[1]) and torch.equal(hid_p[0].cpu(), hid_o[0])
+    torch.testing.assert_close(torch.stack(outs_p), torch.stack(outs_o), rtol=1e-5, atol=2e-6)
