@@ -123,16 +123,18 @@ __device__ __forceinline__ f32x16 gemm_rows(const float* sA, const float* sBt, i
 // that the block-granular kernels are bound by (they issue ~2 k VALU / LDS instructions per 32-row block).
 // REG: sg / sb are this thread's 16 entries (registers, index k) instead of the LDS vectors (index f).
 // VEC: sg / sb are 16-byte aligned LDS vectors, read in 16-byte pieces.
+// ofs (optional): this thread's 16 entries of a per-column offset added to the row before the ReLU.
 template <bool FULL, bool REG = false, bool VEC = false>
 __device__ __forceinline__ void relu_ln_rows_t(float* sP, int tid, int F, const float* sg, const float* sb,
-                                               float eps, float* mu_out, float* rs_out, bool write) {
+                                               float eps, float* mu_out, float* rs_out, bool write,
+                                               const float* ofs = nullptr) {
   const int row = tid >> 1, f0 = (tid & 1) * (FP / 2);
   float a[FP / 2];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < FP / 2; ++k) {
     const int f = f0 + k;
-    const float v = sP[row * FS + f];
+    const float v = ofs ? sP[row * FS + f] + ofs[k] : sP[row * FS + f];
     a[k] = ((FULL || f < F) && v > 0.f) ? v : 0.f;
     s += a[k];
   }
@@ -295,6 +297,8 @@ struct GnnTail {
   const float* gnn;                  // packed GNN parameters (gcm_dense_gnn2_param_count layout)
   int act1, act2, has_bias, H1, H2;
   float *cH, *cA, *cX;               // caches: h1 [B,N,H1], agg1 [B,N,F], nodes [B,N,F]
+  float* cU;                         // TAIL = 1 at the exact shapes: [B,N,F] the edge network's first product of every stored row,
+                                     // U[j] = W0[:, F:] x_j (below)
   float *mx_out, *agg2_out;          // this step: [B,H2], [B,H1]
   float *h1_out, *agg1_out;          // TAIL = 2: layer 1 of every row of the graph, [B,N,H1] / [B,N,F] (the step's record)
   const float *h1_prev, *agg1_prev;  // TAIL = 2: layer 1 of the state BEFORE the step, [B,N,H1] / [B,N,F] (the previous step's record, or
@@ -483,6 +487,11 @@ __global__ __launch_bounds__(256) void k_learned_select(
   // then the parameters (L2 resident).  `ex`: exact shapes (uniform) - the same loads without clamps and masks, a
   // few hundred VALU instructions less in front of the first wait.
   const bool ex = EX || (F == FP && N == NP && (!TAIL || (gt.H1 == FP && gt.H2 == FP)));
+  // UC (cached steps at the exact shapes): the first layer of the edge network on candidate row j is W0b x_j + (W0a x_cur
+  // + b0), and x_j never changes once stored - the chain keeps U[j] = W0b x_j [B,N,F] and a step stages it as the image
+  // the product P0 = X W0b^T used to fill (16 MFMAs a wave and their operand reads: 2.4 k of the step's 15 k cycles),
+  // adds c0 on the way into the LayerNorm, and leaves U[cur] behind for the steps to come (wave 1, under wave 0's tail).
+  constexpr bool UC = TAIL == 1 && EX;
   float pf_noise[2], pf_old[2], pf_b1 = 0.f, pf_b2 = 0.f;
   {
     const int pl = tid & 63;
@@ -537,6 +546,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
   StageL<FP, FP> st_w0, st_w0a, st_w1, st_g[4];
   if (ex) {
     if (TAIL == 1) st_hc.load<true>(gt.cH + (size_t)b * N * FP, N, FP, FP, tid);
+    if (UC) st_ha.load<true>(gt.cU + (size_t)b * N * FP, N, FP, FP, tid);
 
     st_w0.load<true>(M.w0 + F, F, F, 2 * F, tid);
     st_w0a.load<true>(M.w0, F, F, 2 * F, tid);
@@ -768,6 +778,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     st_w1.store<true, FS>(sW1, tid);
     if (TAIL) {
       if (TAIL == 1) st_hc.store<true, FS>(sHc, tid);
+      if (UC) st_ha.store<true, FS>(sA, tid);
 #pragma unroll
       for (int q = 0; q < 4; ++q) st_g[q].store<true, GS>(sWg + q * FP * GS, tid);
     }
@@ -809,7 +820,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, li, lh);   // (= gemm_rows: same order)
+    if (!UC) gcm_fused::mma32b<32>(acc, sX + 32 * wave * FS, FS, 1, sW0b, 1, FS, li, lh);   // (= gemm_rows: same order)
     float c0 = pf_vec[0];
     {
       const float* w = sW0a + li * GS;
@@ -829,11 +840,13 @@ __global__ __launch_bounds__(256) void k_learned_select(
       if (F == FP) {
 #pragma unroll
         for (int f = 0; f < FP; ++f) c0 = fmaf(wv[f], xv[f], c0);
+        if (!UC) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
         }
       } else {
 #pragma unroll
@@ -842,13 +855,26 @@ __global__ __launch_bounds__(256) void k_learned_select(
         c0 = li < F ? c0 : 0.f;
       }
     }
+    if (UC) {   // the image holds U already: c0 goes to the LayerNorm's threads (this wave's rows are its own: a wave-local exchange)
+      if (lh == 0) sLogit[32 * wave + li] = c0;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + c0;
+      for (int r = 0; r < 16; ++r) sA[(32 * wave + gcm_fused::acc_row(r, lh)) * FS + li] = acc[r] + c0;
+    }
   }
   __syncthreads();
   LSTAMP(17);
   steady_stores(2);
-  if (F == FP) relu_ln_rows_t<true, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
+  if (UC) {
+    float c0v[FP / 2];
+    const float* src = sLogit + 32 * wave + (tid & 1) * (FP / 2);
+#pragma unroll
+    for (int q = 0; q < FP / 8; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(src)[q];
+      c0v[4 * q] = t.x; c0v[4 * q + 1] = t.y; c0v[4 * q + 2] = t.z; c0v[4 * q + 3] = t.w;
+    }
+    relu_ln_rows_t<true, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true, c0v);
+  } else if (F == FP) relu_ln_rows_t<true, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
   else relu_ln_rows_t<false, true>(sA, tid, F, gr0, br0, eps0, nullptr, nullptr, true);
   __syncthreads();
   LSTAMP(18);
@@ -875,6 +901,16 @@ __global__ __launch_bounds__(256) void k_learned_select(
   __syncthreads();
   LSTAMP(21);
   if (DONATE && tid == 255) count_out[b] = cur + 1;   // every wave read count_in long ago
+  if (UC && wave == 1) {   // U[cur] = W0b x_cur for the steps to come: lanes o and o + 32 take half of the row each
+    const int o = lane & 31;
+    const float* w = sW0b + o * FS + 16 * lh;
+    const float* x = sVec + 16 * lh;           // (x_cur's copy)
+    float p = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p = fmaf(w[k], x[k], p);
+    p += __shfl_xor(p, 32);
+    if (lane < FP) gt.cU[((size_t)b * N + cur) * FP + lane] = p;
+  }
   float z[2] = {0.f, 0.f};   // wave 0: the softmax terms, then this step's entries of row cur
   if (wave == 0) {   // gumbel-softmax over j < cur (learned.py:88-95), N <= 128: two entries per lane
     float m = -INFINITY;
@@ -2481,17 +2517,18 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
                                        const float* noise, int noise_is_exp, const float* params, int has_bias,
                                        int act1, int act2, float eps0, float eps1, float cutoff, int64_t* cur_out,
                                        int64_t* count_out, float* soft, float* adj_row, float* mx, float* agg2,
-                                       float* cache_h1, float* cache_agg1, float* cache_nodes, uint32_t* flags, int B,
-                                       int N, int F, int H1, int H2, int cur_host, gcm_stream_t stream) {
+                                       float* cache_h1, float* cache_agg1, float* cache_nodes, float* cache_u,
+                                       uint32_t* flags, int B, int N, int F, int H1, int H2, int cur_host,
+                                       gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes && adj && count_in && noise && params && cur_out && count_out && soft && adj_row && mx &&
-              agg2 && cache_h1 && cache_agg1 && cache_nodes && flags && B > 0);
+              agg2 && cache_h1 && cache_agg1 && cache_nodes && cache_u && flags && B > 0);
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_tail();
   const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
   auto kern = exact ? gcm_learned::k_learned_select<2, 1, true> : gcm_learned::k_learned_select<2, 1, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, cache_u, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags,
@@ -2559,7 +2596,7 @@ extern "C" int gcm_learned_step_steady(const float* obs, float* nodes, float* ad
   const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
   auto kern = exact ? gcm_learned::k_learned_select<2, 2, true> : gcm_learned::k_learned_select<2, 2, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, nullptr, nullptr, nullptr, mx, agg2, h1, agg1, h1_prev, agg1_prev, adj_bits};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, nullptr, nullptr, nullptr, nullptr, mx, agg2, h1, agg1, h1_prev, agg1_prev, adj_bits};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      (const float*)nodes, (const float*)adj, count_in, nodes, cur_out, count_out, flags, nodes_snap,
@@ -2573,10 +2610,10 @@ extern "C" int gcm_learned_step_cached_functional(
     const float* obs, const float* nodes_in, const float* adj_in, const int64_t* count_in, const float* noise,
     int noise_is_exp, const float* params, int has_bias, int act1, int act2, float eps0, float eps1, float cutoff,
     float* nodes_out, float* adj_out, int64_t* cur_out, int64_t* count_out, float* soft, float* mx, float* agg2,
-    float* cache_h1, float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1, int H2,
-    int cur_host, gcm_stream_t stream) {
+    float* cache_h1, float* cache_agg1, float* cache_nodes, float* cache_u, uint32_t* flags, int B, int N, int F,
+    int H1, int H2, int cur_host, gcm_stream_t stream) {
   GCM_REQUIRE(obs && nodes_in && adj_in && count_in && noise && params && nodes_out && adj_out && cur_out &&
-              count_out && soft && mx && agg2 && cache_h1 && cache_agg1 && cache_nodes && flags && B > 0);
+              count_out && soft && mx && agg2 && cache_h1 && cache_agg1 && cache_nodes && cache_u && flags && B > 0);
   GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in);
   if (!gcm_learned_step_supported(N, F, H1, H2) || (N & 3) || (F & 3)) return GCM_EUNSUPPORTED;
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
@@ -2584,7 +2621,7 @@ extern "C" int gcm_learned_step_cached_functional(
   const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
   auto kern = exact ? gcm_learned::k_learned_select<1, 1, true> : gcm_learned::k_learned_select<1, 1, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
-  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
+  gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, cache_u, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)nullptr, adj_out,
                      (const int64_t*)nullptr, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, N, F, obs,
                      nodes_in, adj_in, count_in, nodes_out, cur_out, count_out, flags, (float*)nullptr,

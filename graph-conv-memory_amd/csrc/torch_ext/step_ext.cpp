@@ -1366,6 +1366,7 @@ struct LearnedChain {   // one per packed parameter vector
   bool steady_ok = false;
   int64_t cached_steps = 0, all_steps = 0, steady_steps = 0;
   at::Tensor cH, cA, cX;
+  at::Tensor cU;                      // [B,N,F] W0b x_j of every stored row (gcm_learned_step_cached: cache_u)
   at::Tensor abits;                   // [B,N,4] the adjacency as bits, kept by the steady-state steps
   at::Tensor prev_rec;                // the previous steady step's record (its h1 / agg1 feed the next one)
   const void* last_nodes = nullptr;   // the node matrix the previous step returned: a linear chain continues it
@@ -1435,6 +1436,7 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
       chain.cH = at::zeros({B, N, H1}, obs.options());
       chain.cA = at::zeros({B, N, F}, obs.options());
       chain.cX = at::zeros({B, N, F}, obs.options());
+      chain.cU = at::empty({B, N, F}, obs.options());   // (rows < cur are written before they are read as candidates)
       if (chain.node) { chain.node->cH = chain.cH; chain.node->cA = chain.cA; chain.node->cX = chain.cX; }
     }
     size_t lay[8];
@@ -1448,7 +1450,8 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
                 count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp, pk, cfg->has_bias, cfg->act1,
                 cfg->act2, (float)cfg->eps0, (float)cfg->eps1, (float)cfg->cutoff, base, base + lay[1], ib, ib + B,
                 base + lay[7], base + lay[2], base + lay[5], chain.cH.data_ptr<float>(), chain.cA.data_ptr<float>(),
-                chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2, (int)chain.cached_steps, st),
+                chain.cX.data_ptr<float>(), chain.cU.data_ptr<float>(), fl, (int)B, N, F, H1, H2,
+                (int)chain.cached_steps, st),
             "gcm_learned_step_cached_functional");
       nodes_out = alias_of(buf, 0, {B, N, F}, buf.dtype());
       adj_out = alias_of(buf, (int64_t)lay[1], {B, N, N}, buf.dtype());
@@ -1459,8 +1462,8 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
                                   cfg->has_bias, cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
                                   (float)cfg->cutoff, ib, count_in.data_ptr<int64_t>(), base + lay[7], base + lay[1],
                                   base + lay[2], base + lay[5], chain.cH.data_ptr<float>(),
-                                  chain.cA.data_ptr<float>(), chain.cX.data_ptr<float>(), fl, (int)B, N, F, H1, H2,
-                                  (int)chain.cached_steps, st),
+                                  chain.cA.data_ptr<float>(), chain.cX.data_ptr<float>(), chain.cU.data_ptr<float>(), fl,
+                                  (int)B, N, F, H1, H2, (int)chain.cached_steps, st),
           "gcm_learned_step_cached");
     nodes_out = nodes_in_;
     adj_out = adj_in_;

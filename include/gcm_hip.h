@@ -971,21 +971,25 @@ int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t st
  * functional state (record layout compact = 3: nodes_out | adj_out | mx | agg2 | cur, count | soft).
  * cur_host >= 0: the row every graph's new node lands in, when the host knows it (the chain's step count - no count
  * load in front of the kernel's addresses; count_in is then only compared, GCM_FLAG_BAD_COUNT); -1: read count_in.
+ * cache_u [B,N,F] (a fourth per-chain cache, any contents at the chain's head): the edge network's first-layer
+ * product of every stored row, U[j] = W0[:, F:] x_j - x_j never changes once stored, so at the exact shapes N = 128,
+ * F = H1 = H2 = 32 a step stages U instead of multiplying the node image by W0b again, adds W0a x_cur + b0 on the way
+ * into the LayerNorm and writes U[cur]; other shapes leave it untouched.
  * gcm_learned_bptt_cached: gcm_learned_bptt for a chain whose first n_cached steps are such steps (records in
  * layout `cached_layout` = 2 | 3; the steps behind them: `compact` layout). */
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                             const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
                             int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
                             float* soft, float* adj_row, float* mx, float* agg2, float* cache_h1,
-                            float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F, int H1,
-                            int H2, int cur_host, gcm_stream_t stream);
+                            float* cache_agg1, float* cache_nodes, float* cache_u, uint32_t* flags, int B, int N,
+                            int F, int H1, int H2, int cur_host, gcm_stream_t stream);
 int gcm_learned_step_cached_functional(const float* obs, const float* nodes_in, const float* adj_in,
                                        const int64_t* count_in, const float* noise, int noise_is_exp,
                                        const float* params, int has_bias, int act1, int act2, float eps0,
                                        float eps1, float cutoff, float* nodes_out, float* adj_out, int64_t* cur_out,
                                        int64_t* count_out, float* soft, float* mx, float* agg2, float* cache_h1,
-                                       float* cache_agg1, float* cache_nodes, uint32_t* flags, int B, int N, int F,
-                                       int H1, int H2, int cur_host, gcm_stream_t stream);
+                                       float* cache_agg1, float* cache_nodes, float* cache_u, uint32_t* flags, int B,
+                                       int N, int F, int H1, int H2, int cur_host, gcm_stream_t stream);
 int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                             int n_cached, int cached_layout, const float* cache_nodes, const float* cache_h1,
                             const float* cache_agg1, long gmx_stride_b, long gmx_stride_h, const float* params,
