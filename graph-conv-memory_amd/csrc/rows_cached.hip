@@ -282,10 +282,33 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
 // EX: F == FP and H1 == HP (compile-time widths: cfg2's / cfg3's timed kernels); otherwise the widths are the runtime
 // Fr <= FP, H1r <= HP - the weight image is zero beyond them (k_cached_weight_image) and the operand vectors are
 // written zero-padded, so the products run over FP / HP all the same.
+// The forward temporal hops of the step as ONE 128-bit mask, built on the host: bit (128 - h) of (rev_hi : rev_lo) for
+// every hop 0 < h < 128, so that the source rows of row cur - bit j for j = cur - h >= 0 - are that mask shifted right
+// by 128 - cur: half a dozen scalar instructions in the kernel.  (The first form walked the sixteen hop slots of the
+// Edits argument with compares and 64-bit selects: 864 of the kernel's 1481 instructions were that loop's scalar code,
+// in a kernel that is one wave issuing an instruction every four cycles - and 136 bytes of kernel arguments.)
+struct HopMask {
+  unsigned long long rev_lo, rev_hi;
+  int self;   // a hop of 0 (the row aggregates itself)
+  int pad;
+};
+inline HopMask make_hop_mask(const gcm_fused::Edits& E) {
+  HopMask m{0ull, 0ull, 0, 0};
+  for (int i = 0; i < E.n_hops; ++i) {
+    const int h = E.hops[i];
+    if (h == 0) m.self = 1;
+    if (h <= 0 || h >= 128) continue;
+    const int bit = 128 - h;
+    if (bit >= 64) m.rev_hi |= 1ull << (bit - 64);
+    else m.rev_lo |= 1ull << bit;
+  }
+  return m;
+}
+
 template <int FP, int HP, bool SEL, bool EX = true, bool V4 = false>
 __device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    const gcm_fused::Edits& E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    const HopMask& hm, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     const CachedLayout& lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
     const float* __restrict__ sel_row, int Fr = FP, int H1r = HP) {
@@ -332,16 +355,17 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   asm volatile("" ::: "memory");
   const bool bad = n64 < 0 || n64 >= N;
   const int cur = __builtin_amdgcn_readfirstlane(bad ? 0 : (int)n64);
-  unsigned long long m0 = 0, m1 = 0;
-  bool self = false;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int h = E.hops[i], j = cur - h;
-    const bool use = i < E.n_hops && h >= 0 && j >= 0;
-    self = self || (use && h == 0);
-    const bool edge = use && h > 0;
-    m0 |= (edge && j < 64) ? 1ull << (j & 63) : 0ull;
-    m1 |= (edge && j >= 64) ? 1ull << ((j - 64) & 63) : 0ull;
+  unsigned long long m0, m1;
+  const bool self = hm.self != 0;
+  {
+    const int sft = 128 - cur;   // (cur in 0 .. 127: 1 .. 128)
+    if (sft >= 64) {
+      m1 = 0ull;
+      m0 = sft >= 128 ? 0ull : hm.rev_hi >> (sft - 64);
+    } else {
+      m0 = (hm.rev_lo >> sft) | (hm.rev_hi << (64 - sft));
+      m1 = hm.rev_hi >> sft;
+    }
   }
   if (SEL) {
     m0 |= __ballot(lane < cur && lane < N && sel0 != 0.f);
@@ -471,7 +495,7 @@ __device__ __forceinline__ void step_rows_cached_img_body(
 template <int FP, int HP>
 __global__ __launch_bounds__(64) void k_step_rows_cached_img(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
   step_rows_cached_img_body<FP, HP, false>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
 template <int FP, int HP>   // ... the weights as 16-byte loads (image4)
 __global__ __launch_bounds__(64) void k_step_rows_cached_img4(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
   step_rows_cached_img_body<FP, HP, false, true, true>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX,
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img4(
 template <int FP, int HP>
 __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
     const float* __restrict__ sel_row) {
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
 template <int FP, int HP, bool SEL>
 __global__ __launch_bounds__(64) void k_step_rows_cached_gen(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    gcm_fused::Edits E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host,
     const float* __restrict__ sel_row, int F, int H1) {
@@ -929,20 +953,21 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   }
   gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, N, H1, H2);
   if (!record) lay.total = 0;
+  const gcm_rows::HopMask HM = gcm_rows::make_hop_mask(E);
   if (weight_image) {
 #define GCM_RI(a, b_)                                                                                            \
   if (F == a && H1 == b_) {                                                                                      \
     if (sel_row)                                                                                                 \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_sel<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
-                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row);                               \
     else if (has_bias & GCM_STEP_IMG_V4)                                                                          \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img4<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,      \
-                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host);                                        \
     else                                                                                                         \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
-                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host);                                        \
     return gcm_launch_status();                                                                                  \
   }
@@ -954,11 +979,11 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
   if (fp == a && hp == b_) {                                                                                     \
     if (sel_row)                                                                                                 \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_gen<a, b_, true>), dim3(B), dim3(64), 0, (hipStream_t)stream, \
-                         obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
+                         obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row, F, H1);                        \
     else                                                                                                         \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_gen<a, b_, false>), dim3(B), dim3(64), 0,                    \
-                         (hipStream_t)stream, obs, nodes, adj, count, E, params, weight_image, act1, act2, cache_h1, \
+                         (hipStream_t)stream, obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, \
                          cache_agg1, cache_nodes, saved, lay, flags, B, N, H2, cur_host, (const float*)nullptr, F,   \
                          H1);                                                                                        \
     return gcm_launch_status();                                                                                  \
@@ -1063,12 +1088,13 @@ extern "C" int gcm_debug_time_cached_rollout(const float* obs_all, float* nodes,
       E.dir[E.n_hops++] = selectors[i].direction;
     }
   const gcm_rows::CachedLayout lay = gcm_rows::make_cached_layout(B, N, H1, H2);
+  const gcm_rows::HopMask HM = gcm_rows::make_hop_mask(E);
   for (int t = 0; t < T; ++t) {
 #define GCM_RT(a, b_)                                                                                           \
   if (F == a && H1 == b_)                                                                                       \
     hipExtLaunchKernelGGL((gcm_rows::k_step_rows_cached_img<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,  \
                           (hipEvent_t)start_events[t], (hipEvent_t)stop_events[t], 0,                            \
-                          obs_all + (size_t)t * B * F, nodes, adj, count, E, params, weight_image, act1, act2,   \
+                          obs_all + (size_t)t * B * F, nodes, adj, count, HM, params, weight_image, act1, act2,  \
                           cache_h1, cache_agg1, cache_nodes, saved_per_step[t], lay, flags, B, N, H2, t);
     GCM_RT(32, 32) GCM_RT(64, 32) GCM_RT(32, 64) GCM_RT(64, 64)
 #undef GCM_RT
