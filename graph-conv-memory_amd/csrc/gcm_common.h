@@ -24,6 +24,7 @@ int gcm_cu_count();
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 16-byte WRITE-THROUGH store (sc1) of data this launch does not read again: the bytes leave for memory while the
 // kernel computes instead of sitting dirty in the XCD's L2 until the write-back at the end of the launch, which nothing

@@ -272,9 +272,11 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
   if (m < 2) { if (lane < H1 && k < F) v = (m == 0 ? w_rel1 : w_root1)[(size_t)lane * F + k]; }
   else { if (lane < H2 && k < H1) v = (m == 2 ? w_rel2 : w_root2)[(size_t)lane * H1 + k]; }
   image[e] = v;
-  // ... and once more four k per lane, image4[m][k / 4][lane][k % 4] behind it: lane h's row of a matrix as 16-byte
-  // loads (k_step_rows_cached_img: 32 load instructions per step instead of 128)
-  image[4 * 64 * 64 + (((m * 16 + (k >> 2)) * 64 + lane) << 2) + (k & 3)] = v;
+  // ... and once more behind it with the two matrices of a layer interleaved, image2[layer][k][lane][rel | root]: a lane's
+  // (W_rel[h][k], W_root[h][k]) as ONE 8-byte load into an adjacent register pair - what v_pk_fma_f32 wants
+  // (k_step_rows_cached_img: 64 load instructions per step instead of 128, and none of the 128 register moves that
+  // paired the operands of the packed products)
+  image[4 * 64 * 64 + ((((m >> 1) * 64 + k) * 64 + lane) << 1) + (m & 1)] = v;
 }
 
 // SEL: the decisions of a distance selector arrive as a row (sel_row) and the selected rows beyond the first four
@@ -328,20 +330,13 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   }
   // every weight load in flight at once (coalesced: lane h reads element h of row k of the image)
   float r1[FP], t1[FP], r2[HP], t2[HP];
-  if (V4) {   // image4[m][k / 4][lane][4] (the second half of the image): 16 bytes per lane and load
-    const f32x4* i4 = reinterpret_cast<const f32x4*>(image + 4 * 64 * 64);
+  f32x2 w1[V4 ? FP : 1], w2[V4 ? HP : 1];   // V4 (the interleaved image): (rel, root) pairs of layer 1 / 2
+  if (V4) {
+    const f32x2* i2 = reinterpret_cast<const f32x2*>(image + 4 * 64 * 64);
 #pragma unroll
-    for (int k4 = 0; k4 < FP / 4; ++k4) {
-      const f32x4 a = i4[(0 * 16 + k4) * 64 + lane], c = i4[(1 * 16 + k4) * 64 + lane];
+    for (int k = 0; k < FP; ++k) w1[k] = i2[k * 64 + lane];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { r1[4 * k4 + q] = a[q]; t1[4 * k4 + q] = c[q]; }
-    }
-#pragma unroll
-    for (int k4 = 0; k4 < HP / 4; ++k4) {
-      const f32x4 a = i4[(2 * 16 + k4) * 64 + lane], c = i4[(3 * 16 + k4) * 64 + lane];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { r2[4 * k4 + q] = a[q]; t2[4 * k4 + q] = c[q]; }
-    }
+    for (int k = 0; k < HP; ++k) w2[k] = i2[(64 + k) * 64 + lane];
   } else {
 #pragma unroll
     for (int k = 0; k < FP; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
@@ -413,10 +408,21 @@ __device__ __forceinline__ void step_rows_cached_img_body(
     for (int q = 0; q < 8; ++q) { agg1 += bx[q]; agg2 += bh[q]; }
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
-  if (lane < FP) { sv[lane] = agg1; sv[FP + lane] = (EX || lane < F) ? xc : 0.f; }
+  if (V4) {
+    if (lane < FP) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, (EX || lane < F) ? xc : 0.f};
+  } else if (lane < FP) { sv[lane] = agg1; sv[FP + lane] = (EX || lane < F) ? xc : 0.f; }
   // (one wave: its LDS operations execute in order - the broadcast reads below see these writes)
   float p1 = bias1;
-  {
+  if (V4) {   // (pa, pb) as one packed accumulator: the same two chains, value for value
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FP / 2; ++j) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(sv + 4 * j);   // (agg1, x)[2 j], (agg1, x)[2 j + 1]
+      acc = w1[2 * j] * f32x2{u[0], u[1]} + acc;
+      acc = w1[2 * j + 1] * f32x2{u[2], u[3]} + acc;
+    }
+    p1 += acc[0] + acc[1];
+  } else {
     float pa = 0.f, pb = 0.f;
 #pragma unroll
     for (int f4 = 0; f4 < FP / 4; ++f4) {
@@ -431,9 +437,20 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   }
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
-  if (lane < HP) { sv[lane] = agg2; sv[HP + lane] = h1c; }
+  if (V4) {
+    if (lane < HP) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
+  } else if (lane < HP) { sv[lane] = agg2; sv[HP + lane] = h1c; }
   float p2 = bias2;
-  {
+  if (V4) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HP / 2; ++j) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(sv + 4 * j);
+      acc = w2[2 * j] * f32x2{u[0], u[1]} + acc;
+      acc = w2[2 * j + 1] * f32x2{u[2], u[3]} + acc;
+    }
+    p2 += acc[0] + acc[1];
+  } else {
     float pa = 0.f, pb = 0.f;
 #pragma unroll
     for (int h4 = 0; h4 < HP / 4; ++h4) {
@@ -501,7 +518,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
   step_rows_cached_img_body<FP, HP, false>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
                                            flags, B, N, H2, cur_host, nullptr);
 }
-template <int FP, int HP>   // ... the weights as 16-byte loads (image4)
+template <int FP, int HP>   // ... the weights from the layer-interleaved image (image2), packed products
 __global__ __launch_bounds__(64) void k_step_rows_cached_img4(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,

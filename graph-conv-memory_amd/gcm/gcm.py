@@ -148,11 +148,13 @@ class DenseGCM(torch.nn.Module):
         # False: a cached EuclideanEdge chain as TWO launches per step (distance kernel, then the cached step) instead
         # of one (csrc/distance.hip: k_euclid_mfma2<.., TAIL>) - A/B tests; read when a chain is armed
         self.rows_one_launch_distance = True
-        # True: the cached temporal step reads its weights as 32 16-byte loads per lane (image4) instead of 128 4-byte
-        # ones (round 3's lane-major image).  Measured in round 5 on cfg2 (same box, graph replay): 4.85 us per step
-        # against 4.63 us - SLOWER (the kernel is a launch-to-retire latency chain, not bound by load instructions), so
-        # it stays off; kept as the A/B (env GCM_IMG_V4=1)
-        self.rows_weight_image_v4 = os.environ.get("GCM_IMG_V4", "0") == "1"
+        # True: the cached temporal-hops step (k_step_rows_cached_img4) reads the weight image in its interleaved form -
+        # image2[layer][k][lane][rel | root], one 8-byte load per (W_rel[h][k], W_root[h][k]) pair straight into the
+        # adjacent registers v_pk_fma_f32 wants: 64 load instructions instead of 128 and none of the 128 register moves
+        # that paired the operands.  cfg2 on the same box, graph replay: 58.2 M against 55.2 M for the plain lane-major
+        # image (False; env GCM_IMG_V4=0 for the A/B).  (Round 5's first use of this slot - four k per lane as 16-byte
+        # loads - had measured slower: 4.85 against 4.63 us.)
+        self.rows_weight_image_v4 = os.environ.get("GCM_IMG_V4", "1") == "1"
         # False: rollout() from empty graphs with forward temporal hops runs the persistent per-graph kernel of round 1
         # instead of the two-launch time-parallel forward (csrc/rollout_tp.hip) - A/B tests
         self.rollout_time_parallel = True

@@ -517,7 +517,9 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
 /* gcm_dense_rows_step_cached_ws only: a distance selector and the cached step as two launches (see
  * gcm_dense_rows_cached_launches) */
 #define GCM_STEP_TWO_LAUNCH 32
-/* ... the cached step's weights as 16-byte loads from the second layout of the weight image (A/B; tools) */
+/* ... the cached temporal-hops step reads the SECOND layout of the weight image: the two matrices of a layer interleaved,
+ * image2[layer][k][lane][rel | root] - one 8-byte load per pair, packed products without register moves (the module's
+ * default since round 5: cfg2 58.2 M against 55.2 M; clear the bit for the A/B) */
 #define GCM_STEP_IMG_V4 64
 int gcm_dense_rows_supported(int N, int F, int H1, int H2);
 int gcm_dense_rows_layout(int B, int N, int F, int H1, int H2, size_t* out6);
@@ -618,7 +620,8 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
  * written; the rest only with record != 0).  cur_host >= 0: the row every graph's new node lands in, when the host
  * knows it (a chain from empty graphs: the number of steps made so far) - the kernel then does not wait for the
  * count; -1: read it.  weight_image (may be NULL): 2 x [4][64][64] floats from gcm_dense_rows_cached_weight_image, the
- * four weight matrices lane-major (made once per chain: the parameters are fixed inside one) - with it a step is one
+ * four weight matrices lane-major [m][k][lane] and, behind them, layer-interleaved [layer][k][lane][2] (GCM_STEP_IMG_V4)
+ * (made once per chain: the parameters are fixed inside one) - with it a step is one
  * wave per graph whose every load, weights included, is issued at kernel start (no LDS staging, no barrier).
  * Widths: F, H1, H2 <= 64, N <= 128; 32 and 64 are compile-time widths, anything else runs padded to them and needs
  * the weight image (GCM_EUNSUPPORTED without it).  gcm_dense_rows_bptt_cached: gcm_dense_rows_bptt over such records. */
