@@ -284,6 +284,28 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
 // EX: F == FP and H1 == HP (compile-time widths: cfg2's / cfg3's timed kernels); otherwise the widths are the runtime
 // Fr <= FP, H1r <= HP - the weight image is zero beyond them (k_cached_weight_image) and the operand vectors are
 // written zero-padded, so the products run over FP / HP all the same.
+// The layer-interleaved weight image (k_cached_weight_image: image2[layer][k][lane][rel | root], behind the lane-major one):
+// lane h's (W_rel[h][k], W_root[h][k]) as one 8-byte load into an adjacent register pair, the operand vectors interleaved
+// in LDS the same way ((agg, x)[k] pairs), the two products of a layer as ONE chain of packed fmas - the arithmetic of the
+// two scalar chains pa += W_rel[h][k] agg[k], pb += W_root[h][k] x[k] (k ascending) and pa + pb, value for value.
+template <int K>
+__device__ __forceinline__ void load_pair_weights(f32x2 (&w)[K], const float* __restrict__ image, int layer, int lane) {
+  const f32x2* i2 = reinterpret_cast<const f32x2*>(image + 4 * 64 * 64) + (size_t)layer * 64 * 64;
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = i2[k * 64 + lane];
+}
+template <int K>
+__device__ __forceinline__ float pair_matvec(const f32x2 (&w)[K], const float* sv) {   // sv: (agg, x)[k], 16-byte aligned
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < K / 2; ++j) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(sv + 4 * j);
+    acc = w[2 * j] * f32x2{u[0], u[1]} + acc;
+    acc = w[2 * j + 1] * f32x2{u[2], u[3]} + acc;
+  }
+  return acc[0] + acc[1];
+}
+
 // The forward temporal hops of the step as ONE 128-bit mask, built on the host: bit (128 - h) of (rev_hi : rev_lo) for
 // every hop 0 < h < 128, so that the source rows of row cur - bit j for j = cur - h >= 0 - are that mask shifted right
 // by 128 - cur: half a dozen scalar instructions in the kernel.  (The first form walked the sixteen hop slots of the
@@ -611,11 +633,9 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   // ---- wave 0: the step on row cur = N - 1, ring coordinates -----------------------------------------------------
   const float* b1 = params + 2 * H1 * F;
   const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
-  float r1[F], t1[F], r2[H1], t2[H1];
-#pragma unroll
-  for (int k = 0; k < F; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
-#pragma unroll
-  for (int k = 0; k < H1; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  f32x2 w1[F], w2[H1];   // (rel, root) pairs of layer 1 / 2: the interleaved image
+  load_pair_weights(w1, image, 0, lane);
+  load_pair_weights(w2, image, 1, lane);
   const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
   const float bias1 = b1[hl], bias2 = b2[ol];
   const float xc = obs[gb * F + fl];
@@ -666,38 +686,12 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
     }
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
-  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
-  float p1 = bias1;
-  {
-    float pa = 0.f, pb = 0.f;
-#pragma unroll
-    for (int f4 = 0; f4 < F / 4; ++f4) {
-      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
-      const float4 x = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
-      pa = fmaf(r1[4 * f4], a.x, pa); pb = fmaf(t1[4 * f4], x.x, pb);
-      pa = fmaf(r1[4 * f4 + 1], a.y, pa); pb = fmaf(t1[4 * f4 + 1], x.y, pb);
-      pa = fmaf(r1[4 * f4 + 2], a.z, pa); pb = fmaf(t1[4 * f4 + 2], x.z, pb);
-      pa = fmaf(r1[4 * f4 + 3], a.w, pa); pb = fmaf(t1[4 * f4 + 3], x.w, pb);
-    }
-    p1 += pa + pb;
-  }
+  if (lane < F) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, xc};
+  const float p1 = bias1 + pair_matvec(w1, sv);
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
-  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }
-  float p2 = bias2;
-  {
-    float pa = 0.f, pb = 0.f;
-#pragma unroll
-    for (int h4 = 0; h4 < H1 / 4; ++h4) {
-      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
-      const float4 x = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
-      pa = fmaf(r2[4 * h4], a.x, pa); pb = fmaf(t2[4 * h4], x.x, pb);
-      pa = fmaf(r2[4 * h4 + 1], a.y, pa); pb = fmaf(t2[4 * h4 + 1], x.y, pb);
-      pa = fmaf(r2[4 * h4 + 2], a.z, pa); pb = fmaf(t2[4 * h4 + 2], x.z, pb);
-      pa = fmaf(r2[4 * h4 + 3], a.w, pa); pb = fmaf(t2[4 * h4 + 3], x.w, pb);
-    }
-    p2 += pa + pb;
-  }
+  if (lane < H1) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
+  const float p2 = bias2 + pair_matvec(w2, sv);
   const float v = gcm_act_sel(p2, act2_v);
   const unsigned rc = gb * (unsigned)N + (unsigned)slot_new;      // the new node's ring slot (node t_abs - N leaves)
   if (lane < F) { cX[rc * F + lane] = xc; cA[rc * F + lane] = agg1; }
@@ -744,11 +738,9 @@ __global__ __launch_bounds__(64) void k_sparse_step_cached(
   const float* b1 = params + 2 * H1 * F;
   const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
   const int64_t n64 = T[gb], tau = taus[gb];
-  float r1[F], t1[F], r2[H1], t2[H1];
-#pragma unroll
-  for (int k = 0; k < F; ++k) { r1[k] = image[k * 64 + lane]; t1[k] = image[4096 + k * 64 + lane]; }
-#pragma unroll
-  for (int k = 0; k < H1; ++k) { r2[k] = image[2 * 4096 + k * 64 + lane]; t2[k] = image[3 * 4096 + k * 64 + lane]; }
+  f32x2 w1[F], w2[H1];   // (rel, root) pairs of layer 1 / 2: the interleaved image
+  load_pair_weights(w1, image, 0, lane);
+  load_pair_weights(w2, image, 1, lane);
   const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
   const float bias1 = b1[hl], bias2 = b2[ol];
   const float xc = x[gb * F + fl];
@@ -776,38 +768,12 @@ __global__ __launch_bounds__(64) void k_sparse_step_cached(
 #pragma unroll
   for (int i = 0; i < 16; ++i) { agg1 += xa[i]; agg2 += ha[i]; }   // (hops descending: sources ascending)
   agg1 = lane < F ? agg1 : 0.f;
-  if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
-  float p1 = bias1;
-  {
-    float pa = 0.f, pb = 0.f;
-#pragma unroll
-    for (int f4 = 0; f4 < F / 4; ++f4) {
-      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * f4);
-      const float4 xx = *reinterpret_cast<const float4*>(sv + F + 4 * f4);
-      pa = fmaf(r1[4 * f4], a.x, pa); pb = fmaf(t1[4 * f4], xx.x, pb);
-      pa = fmaf(r1[4 * f4 + 1], a.y, pa); pb = fmaf(t1[4 * f4 + 1], xx.y, pb);
-      pa = fmaf(r1[4 * f4 + 2], a.z, pa); pb = fmaf(t1[4 * f4 + 2], xx.z, pb);
-      pa = fmaf(r1[4 * f4 + 3], a.w, pa); pb = fmaf(t1[4 * f4 + 3], xx.w, pb);
-    }
-    p1 += pa + pb;
-  }
+  if (lane < F) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, xc};
+  const float p1 = bias1 + pair_matvec(w1, sv);
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 : 0.f;
-  if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }
-  float p2 = bias2;
-  {
-    float pa = 0.f, pb = 0.f;
-#pragma unroll
-    for (int h4 = 0; h4 < H1 / 4; ++h4) {
-      const float4 a = *reinterpret_cast<const float4*>(sv + 4 * h4);
-      const float4 xx = *reinterpret_cast<const float4*>(sv + H1 + 4 * h4);
-      pa = fmaf(r2[4 * h4], a.x, pa); pb = fmaf(t2[4 * h4], xx.x, pb);
-      pa = fmaf(r2[4 * h4 + 1], a.y, pa); pb = fmaf(t2[4 * h4 + 1], xx.y, pb);
-      pa = fmaf(r2[4 * h4 + 2], a.z, pa); pb = fmaf(t2[4 * h4 + 2], xx.z, pb);
-      pa = fmaf(r2[4 * h4 + 3], a.w, pa); pb = fmaf(t2[4 * h4 + 3], xx.w, pb);
-    }
-    p2 += pa + pb;
-  }
+  if (lane < H1) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
+  const float p2 = bias2 + pair_matvec(w2, sv);
   const float v = rec ? gcm_act_sel(p2, act2_v) : 0.f;   // (no node: the padded output row is zero)
   const unsigned rc = gb * (unsigned)N + (unsigned)cur;
   if (rec) {
