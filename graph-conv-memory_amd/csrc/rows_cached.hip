@@ -313,18 +313,31 @@ __device__ __forceinline__ float pair_matvec(const f32x2 (&w)[K], const float* s
 // in a kernel that is one wave issuing an instruction every four cycles - and 136 bytes of kernel arguments.)
 struct HopMask {
   unsigned long long rev_lo, rev_hi;
-  int self;   // a hop of 0 (the row aggregates itself)
-  int pad;
+  int hop4[4];   // n4 >= 0: the distinct hops 0 < h < 128, DESCENDING (sources ascending), 0 in the unused slots
+  int n4;        // their number when there are at most four, else -1 (the kernel then walks the mask)
+  int self;      // a hop of 0 (the row aggregates itself)
 };
 inline HopMask make_hop_mask(const gcm_fused::Edits& E) {
-  HopMask m{0ull, 0ull, 0, 0};
+  HopMask m{0ull, 0ull, {0, 0, 0, 0}, 0, 0};
+  int distinct[128], nd = 0;
   for (int i = 0; i < E.n_hops; ++i) {
     const int h = E.hops[i];
     if (h == 0) m.self = 1;
     if (h <= 0 || h >= 128) continue;
     const int bit = 128 - h;
+    const bool seen = bit >= 64 ? ((m.rev_hi >> (bit - 64)) & 1ull) != 0 : ((m.rev_lo >> bit) & 1ull) != 0;
     if (bit >= 64) m.rev_hi |= 1ull << (bit - 64);
     else m.rev_lo |= 1ull << bit;
+    if (!seen) distinct[nd++] = h;
+  }
+  if (nd <= 4) {
+    for (int a = 0; a < nd; ++a)               // descending
+      for (int c = a + 1; c < nd; ++c)
+        if (distinct[c] > distinct[a]) { const int t = distinct[a]; distinct[a] = distinct[c]; distinct[c] = t; }
+    for (int a = 0; a < nd; ++a) m.hop4[a] = distinct[a];
+    m.n4 = nd;
+  } else {
+    m.n4 = -1;
   }
   return m;
 }
@@ -390,19 +403,45 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   }
   float xa[4], ha[4];
   unsigned long long a0 = m0, a1 = m1;
+  float agg1, agg2;
+  if (V4 && !SEL && hm.n4 >= 0) {
+    // at most four hops (the temporal form's usual case): the source rows are cur - hop, straight from the hop slots -
+    // no bit scans.  Hops descending = sources ascending; the slots WITH a source are a contiguous run (a larger hop
+    // runs out of rows first, unused slots are at the end), so the sum below is the mask walk's (v0 + v1) + (v2 + v3)
+    // over the compacted list in every case but one: the first slot without a source and the other three with one.
+    bool lead = false;   // slot 0 is a hop without a source (cur < hop)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool any = (a0 | a1) != 0;
-    const int j = !any ? 0 : (a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1));
-    const bool low = a0 != 0;
-    a0 &= low ? a0 - 1 : a0;
-    a1 &= (low || !any) ? a1 : a1 - 1;
-    const unsigned rj = gb * (unsigned)N + (unsigned)j;
-    const float tx = nodes[rj * F + fl], th = cH[rj * H1 + hl];
-    xa[q] = any ? tx : 0.f;
-    ha[q] = any ? th : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int h = hm.hop4[q], j = cur - h;
+      const bool any = h > 0 && j >= 0;
+      if (q == 0) lead = h > 0 && j < 0;
+      const unsigned rj = gb * (unsigned)N + (unsigned)(any ? j : 0);
+      const float tx = nodes[rj * F + fl], th = cH[rj * H1 + hl];
+      xa[q] = any ? tx : 0.f;
+      ha[q] = any ? th : 0.f;
+    }
+    const float n1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), n2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
+    const float c1 = (xa[1] + xa[2]) + xa[3], c2 = (ha[1] + ha[2]) + ha[3];
+    agg1 = lead ? c1 : n1;
+    agg2 = lead ? c2 : n2;
+    a0 = 0ull;
+    a1 = 0ull;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool any = (a0 | a1) != 0;
+      const int j = !any ? 0 : (a0 ? __builtin_ctzll(a0) : 64 + __builtin_ctzll(a1));
+      const bool low = a0 != 0;
+      a0 &= low ? a0 - 1 : a0;
+      a1 &= (low || !any) ? a1 : a1 - 1;
+      const unsigned rj = gb * (unsigned)N + (unsigned)j;
+      const float tx = nodes[rj * F + fl], th = cH[rj * H1 + hl];
+      xa[q] = any ? tx : 0.f;
+      ha[q] = any ? th : 0.f;
+    }
+    agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]);
+    agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
   }
-  float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
   // further rows (a distance selector's clusters; more than four hops): eight per round trip, added in ascending
   // order - the sums a row-at-a-time loop makes
   while (!SEL && (a0 | a1)) {
