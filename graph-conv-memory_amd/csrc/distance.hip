@@ -935,6 +935,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     DSTAMP(9);
     // (one wave: its LDS operations execute in order - the reads above are done before these writes land)
     if (lane < 32) { sv[lane] = agg2; sv[32 + lane] = h1c; }
+    asm volatile("" ::: "memory");   // (lanes exchange through LDS: keep the loads below behind these stores)
     // layer 2: lanes 0-31 W_rel2 . agg2, lanes 32-63 W_root2 . h1cur
     float p2;
     {

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   float* sv = sVec + wave * 128;
   if (lane < F) { sv[lane] = agg1; sv[F + lane] = xc; }
+  asm volatile("" ::: "memory");   // (lanes exchange through LDS: the loads below are not this thread's stores - keep them apart)
   __syncthreads();   // the weights (and this wave's vector) are in LDS
   STAMP(3);
   if (!on) return;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void k_step_rows_cached(
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
   if (lane < H1) { sv[lane] = agg2; sv[H1 + lane] = h1c; }   // (same wave wrote and read the slot: program order)
+  asm volatile("" ::: "memory");
   // ---- mx[o] = act2(b2[o] + W_rel2[o,:] agg2 + W_root2[o,:] h1[cur]), lane o ---------------------------------------
   float p2 = bias2;
   {
@@ -277,6 +279,11 @@ __global__ void k_cached_weight_image(const float* __restrict__ params, float* _
   // (k_step_rows_cached_img: 64 load instructions per step instead of 128, and none of the 128 register moves that
   // paired the operands of the packed products)
   image[4 * 64 * 64 + ((((m >> 1) * 64 + k) * 64 + lane) << 1) + (m & 1)] = v;
+  // ... and, for widths <= 32 (where lanes 32 - 63 of the one-wave step hold no output), a third one that splits k over
+  // the half-waves: image3[layer][k % 16][(k / 16) * 32 + h][rel | root] - lane h + 32 kh multiplies k = 16 kh .. 16 kh + 15
+  // of output h: half the weight loads and half the dependent products per lane, one cross-half add per layer
+  if (lane < 32 && k < 32)
+    image[2 * 4 * 64 * 64 + ((((m >> 1) * 16 + (k & 15)) * 64 + (k >> 4) * 32 + lane) << 1) + (m & 1)] = v;
 }
 
 // SEL: the decisions of a distance selector arrive as a row (sel_row) and the selected rows beyond the first four
@@ -342,7 +349,7 @@ inline HopMask make_hop_mask(const gcm_fused::Edits& E) {
   return m;
 }
 
-template <int FP, int HP, bool SEL, bool EX = true, bool V4 = false>
+template <int FP, int HP, bool SEL, bool EX = true, bool V4 = false, bool HS = false>   // HS: H2 <= 32 too (host)
 __device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     const HopMask& hm, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
@@ -366,7 +373,13 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   // every weight load in flight at once (coalesced: lane h reads element h of row k of the image)
   float r1[FP], t1[FP], r2[HP], t2[HP];
   f32x2 w1[V4 ? FP : 1], w2[V4 ? HP : 1];   // V4 (the interleaved image): (rel, root) pairs of layer 1 / 2
-  if (V4) {
+  constexpr bool HALF = V4 && EX && FP == 32 && HP == 32 && HS;   // k split over the half-waves (image3): 16 pairs a lane and layer
+  const int kh = lane >> 5;
+  if (HALF) {
+    const f32x2* i3 = reinterpret_cast<const f32x2*>(image + 2 * 4 * 64 * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { w1[k] = i3[k * 64 + lane]; w2[k] = i3[(16 + k) * 64 + lane]; }
+  } else if (V4) {
     const f32x2* i2 = reinterpret_cast<const f32x2*>(image + 4 * 64 * 64);
 #pragma unroll
     for (int k = 0; k < FP; ++k) w1[k] = i2[k * 64 + lane];
@@ -471,10 +484,24 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   if (V4) {
     if (lane < FP) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, (EX || lane < F) ? xc : 0.f};
+    // (the stores are 2-vectors, the loads below 4-vectors: to the compiler's type-based alias analysis they do not
+    //  alias, and the half-wave form's loads of layer 2 came out of layer 1's registers - a compiler barrier per store)
+    asm volatile("" ::: "memory");
   } else if (lane < FP) { sv[lane] = agg1; sv[FP + lane] = (EX || lane < F) ? xc : 0.f; }
+  asm volatile("" ::: "memory");   // (lanes exchange through LDS: a compiler barrier per exchange)
   // (one wave: its LDS operations execute in order - the broadcast reads below see these writes)
   float p1 = bias1;
-  if (V4) {   // (pa, pb) as one packed accumulator: the same two chains, value for value
+  if (HALF) {   // this half-wave's sixteen k of both chains, then the other half's
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(sv + 32 * kh + 4 * j);
+      acc = w1[2 * j] * f32x2{u[0], u[1]} + acc;
+      acc = w1[2 * j + 1] * f32x2{u[2], u[3]} + acc;
+    }
+    const float ph = acc[0] + acc[1];
+    p1 += ph + __shfl_xor(ph, 32);
+  } else if (V4) {   // (pa, pb) as one packed accumulator: the same two chains, value for value
     f32x2 acc = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < FP / 2; ++j) {
@@ -500,9 +527,21 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
   if (V4) {
     if (lane < HP) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
+    asm volatile("" ::: "memory");
   } else if (lane < HP) { sv[lane] = agg2; sv[HP + lane] = h1c; }
+  asm volatile("" ::: "memory");
   float p2 = bias2;
-  if (V4) {
+  if (HALF) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(sv + 32 * kh + 4 * j);
+      acc = w2[2 * j] * f32x2{u[0], u[1]} + acc;
+      acc = w2[2 * j + 1] * f32x2{u[2], u[3]} + acc;
+    }
+    const float ph = acc[0] + acc[1];
+    p2 += ph + __shfl_xor(ph, 32);
+  } else if (V4) {
     f32x2 acc = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < HP / 2; ++j) {
@@ -579,14 +618,14 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img(
   step_rows_cached_img_body<FP, HP, false>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX, saved, lay,
                                            flags, B, N, H2, cur_host, nullptr);
 }
-template <int FP, int HP>   // ... the weights from the layer-interleaved image (image2), packed products
+template <int FP, int HP, bool HS = false>   // ... the weights from the layer-interleaved image (image2 / image3), packed products
 __global__ __launch_bounds__(64) void k_step_rows_cached_img4(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
     float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
-  step_rows_cached_img_body<FP, HP, false, true, true>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA, cX,
-                                                       saved, lay, flags, B, N, H2, cur_host, nullptr);
+  step_rows_cached_img_body<FP, HP, false, true, true, HS>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA,
+                                                           cX, saved, lay, flags, B, N, H2, cur_host, nullptr);
 }
 template <int FP, int HP>
 __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
@@ -726,10 +765,12 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   if (lane < F) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, xc};
+  asm volatile("" ::: "memory");   // (2-vector stores, 4-vector loads: no alias to the compiler's type-based analysis)
   const float p1 = bias1 + pair_matvec(w1, sv);
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
   if (lane < H1) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
+  asm volatile("" ::: "memory");
   const float p2 = bias2 + pair_matvec(w2, sv);
   const float v = gcm_act_sel(p2, act2_v);
   const unsigned rc = gb * (unsigned)N + (unsigned)slot_new;      // the new node's ring slot (node t_abs - N leaves)
@@ -808,10 +849,12 @@ __global__ __launch_bounds__(64) void k_sparse_step_cached(
   for (int i = 0; i < 16; ++i) { agg1 += xa[i]; agg2 += ha[i]; }   // (hops descending: sources ascending)
   agg1 = lane < F ? agg1 : 0.f;
   if (lane < F) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, xc};
+  asm volatile("" ::: "memory");   // (2-vector stores, 4-vector loads: no alias to the compiler's type-based analysis)
   const float p1 = bias1 + pair_matvec(w1, sv);
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 : 0.f;
   if (lane < H1) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
+  asm volatile("" ::: "memory");
   const float p2 = bias2 + pair_matvec(w2, sv);
   const float v = rec ? gcm_act_sel(p2, act2_v) : 0.f;   // (no node: the padded output row is zero)
   const unsigned rc = gb * (unsigned)N + (unsigned)cur;
@@ -983,6 +1026,10 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_sel<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
                          obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row);                               \
+    else if ((has_bias & GCM_STEP_IMG_V4) && a == 32 && b_ == 32 && H2 <= 32)                                     \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img4<a, b_, true>), dim3(B), dim3(64), 0,                     \
+                         (hipStream_t)stream, obs, nodes, adj, count, HM, params, weight_image, act1, act2,           \
+                         cache_h1, cache_agg1, cache_nodes, saved, lay, flags, B, N, H2, cur_host);                   \
     else if (has_bias & GCM_STEP_IMG_V4)                                                                          \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img4<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,      \
                          obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \

@@ -619,8 +619,9 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
  * saved: the step's record, gcm_dense_rows_cached_layout floats {total, v, hdr, coef, live} (mx [B,H2] at 0 - always
  * written; the rest only with record != 0).  cur_host >= 0: the row every graph's new node lands in, when the host
  * knows it (a chain from empty graphs: the number of steps made so far) - the kernel then does not wait for the
- * count; -1: read it.  weight_image (may be NULL): 2 x [4][64][64] floats from gcm_dense_rows_cached_weight_image, the
- * four weight matrices lane-major [m][k][lane] and, behind them, layer-interleaved [layer][k][lane][2] (GCM_STEP_IMG_V4)
+ * count; -1: read it.  weight_image (may be NULL): 2 x [4][64][64] + 4096 floats from gcm_dense_rows_cached_weight_image,
+ * the four weight matrices lane-major [m][k][lane], behind them layer-interleaved [layer][k][lane][2] (GCM_STEP_IMG_V4)
+ * and - used at F = H1 = 32, H2 <= 32 - the same split over the half-waves [layer][k % 16][(k / 16) * 32 + h][2]
  * (made once per chain: the parameters are fixed inside one) - with it a step is one
  * wave per graph whose every load, weights included, is issued at kernel start (no LDS staging, no barrier).
  * Widths: F, H1, H2 <= 64, N <= 128; 32 and 64 are compile-time widths, anything else runs padded to them and needs
