@@ -313,6 +313,25 @@ __device__ __forceinline__ float pair_matvec(const f32x2 (&w)[K], const float* s
   return acc[0] + acc[1];
 }
 
+// ... and with k split over the half-waves (image3; widths <= 32: lanes 32 - 63 hold no output): lane h + 32 kh takes
+// k = 16 kh .. 16 kh + 15 of output h, the halves meet by one cross-half add
+__device__ __forceinline__ void load_pair_weights_half(f32x2 (&w)[16], const float* __restrict__ image, int layer, int lane) {
+  const f32x2* i3 = reinterpret_cast<const f32x2*>(image + 2 * 4 * 64 * 64) + layer * 16 * 64;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w[k] = i3[k * 64 + lane];
+}
+__device__ __forceinline__ float pair_matvec_half(const f32x2 (&w)[16], const float* sv, int kh) {
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(sv + 32 * kh + 4 * j);
+    acc = w[2 * j] * f32x2{u[0], u[1]} + acc;
+    acc = w[2 * j + 1] * f32x2{u[2], u[3]} + acc;
+  }
+  const float ph = acc[0] + acc[1];
+  return ph + __shfl_xor(ph, 32);
+}
+
 // The forward temporal hops of the step as ONE 128-bit mask, built on the host: bit (128 - h) of (rev_hi : rev_lo) for
 // every hop 0 < h < 128, so that the source rows of row cur - bit j for j = cur - h >= 0 - are that mask shifted right
 // by 128 - cur: half a dozen scalar instructions in the kernel.  (The first form walked the sixteen hop slots of the
@@ -670,7 +689,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_gen(
 // live rows travel in the record, ascending, row cur last), which gcm_dense_rows_bptt reads like any other.
 // hops: sorted descending, distinct, 0 < h < N (host: gcm_dense_rows_step_cached_roll); self: a hop of 0.
 // ---------------------------------------------------------------------------------------------------------
-template <int FP, int HP>
+template <int FP, int HP, bool HS = false>   // HS: F = H1 = 32 and H2 <= 32 (host): the half-wave form of the products
 __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
     const float* __restrict__ obs, float* __restrict__ nodes, gcm_fused::Edits E, int self_i,
     const float* __restrict__ params, const float* __restrict__ image, int act1, int act2, float* __restrict__ cH,
@@ -711,9 +730,16 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   // ---- wave 0: the step on row cur = N - 1, ring coordinates -----------------------------------------------------
   const float* b1 = params + 2 * H1 * F;
   const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
-  f32x2 w1[F], w2[H1];   // (rel, root) pairs of layer 1 / 2: the interleaved image
-  load_pair_weights(w1, image, 0, lane);
-  load_pair_weights(w2, image, 1, lane);
+  constexpr bool HALF = HS && FP == 32 && HP == 32;
+  const int kh = lane >> 5;
+  f32x2 w1[HALF ? 16 : F], w2[HALF ? 16 : H1];   // (rel, root) pairs of layer 1 / 2: the interleaved image
+  if constexpr (HALF) {
+    load_pair_weights_half(w1, image, 0, lane);
+    load_pair_weights_half(w2, image, 1, lane);
+  } else {
+    load_pair_weights(w1, image, 0, lane);
+    load_pair_weights(w2, image, 1, lane);
+  }
   const int fl = lane < F ? lane : F - 1, hl = lane < H1 ? lane : H1 - 1, ol = lane < H2 ? lane : H2 - 1;
   const float bias1 = b1[hl], bias2 = b2[ol];
   const float xc = obs[gb * F + fl];
@@ -766,12 +792,16 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   if (lane < F) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, xc};
   asm volatile("" ::: "memory");   // (2-vector stores, 4-vector loads: no alias to the compiler's type-based analysis)
-  const float p1 = bias1 + pair_matvec(w1, sv);
+  float p1 = bias1;
+  if constexpr (HALF) p1 += pair_matvec_half(w1, sv, kh);
+  else p1 += pair_matvec(w1, sv);
   const float h1c = lane < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
   agg2 = lane < H1 ? agg2 + (self ? h1c : 0.f) : 0.f;
   if (lane < H1) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg2, h1c};
   asm volatile("" ::: "memory");
-  const float p2 = bias2 + pair_matvec(w2, sv);
+  float p2 = bias2;
+  if constexpr (HALF) p2 += pair_matvec_half(w2, sv, kh);
+  else p2 += pair_matvec(w2, sv);
   const float v = gcm_act_sel(p2, act2_v);
   const unsigned rc = gb * (unsigned)N + (unsigned)slot_new;      // the new node's ring slot (node t_abs - N leaves)
   if (lane < F) { cX[rc * F + lane] = xc; cA[rc * F + lane] = agg1; }
@@ -1125,9 +1155,14 @@ extern "C" int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, c
   const gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2);
 #define GCM_RR(a, b_)                                                                                             \
   if (F == a && H1 == b_) {                                                                                       \
-    hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_>), dim3(B), dim3(128), 0, (hipStream_t)stream, obs,   \
-                       nodes, E, self, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes, saved,    \
-                       lay, record, flags, B, N, H2, t_abs % N);                                                      \
+    if (a == 32 && b_ == 32 && H2 <= 32)                                                                          \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_, true>), dim3(B), dim3(128), 0,                     \
+                         (hipStream_t)stream, obs, nodes, E, self, params, weight_image, act1, act2, cache_h1,        \
+                         cache_agg1, cache_nodes, saved, lay, record, flags, B, N, H2, t_abs % N);                    \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_>), dim3(B), dim3(128), 0, (hipStream_t)stream,      \
+                         obs, nodes, E, self, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes,    \
+                         saved, lay, record, flags, B, N, H2, t_abs % N);                                             \
     return gcm_launch_status();                                                                                   \
   }
   GCM_RR(32, 32) GCM_RR(64, 32) GCM_RR(32, 64) GCM_RR(64, 64)
