@@ -980,6 +980,15 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             "bytes_per_launch": alg_bytes, "avg_launch_ms": kd["avg_us"] * 1e-3, "avg_launch_ms_source": src,
             "launches_timed": int(round(kd["launches_per_call"] * prof_reps)),
             "executed": ex, "launch_floor_us": floor, "cross_checks": cross,
+            "cadence": ({"per_step_ms": cross["captured_forward_loop_over_T_ms"],
+                         "frac_at_cadence": alg_bytes / (cross["captured_forward_loop_over_T_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "sum_of_durations_over_wall": kd["avg_us"] * 1e-3 / cross["captured_forward_loop_over_T_ms"],
+                         "note": "replay time of the captured forward loop / T: the step kernels of a replayed graph "
+                                 "overlap - launch N + 1 is dispatched (its begin timestamp taken) while launch N "
+                                 "drains - so the begin-to-end durations `frac` is computed from add up to more than "
+                                 "the loop's wall time (sum_of_durations_over_wall > 1); this is the rate the loop "
+                                 "itself sustains"}
+                        if cross.get("captured_forward_loop_over_T_ms") else None),
             "note": "EFFECTIVE rate: bytes_per_launch = SURVEY 8(d)'s full-dense compulsory bytes (what the "
                     "reference's formulation must move per step) over the kernel's measured mean duration; the kernel "
                     "itself moves `traffic` bytes (`executed`): only the rows that reach the kept belief row are "
