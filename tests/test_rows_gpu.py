@@ -871,3 +871,32 @@ def test_rollout_time_parallel_vs_oracle(hops, B, N, F, H1, H2, T):
     for k, p in g.named_parameters():
         g64, atol = bounds[k]
         assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
+
+
+@pytest.mark.parametrize("H2,hops", [(64, [1, 2, 4]), (32, [1, 2, 4, 8]), (16, [3]), (48, [1, 2, 3, 5, 9])])
+def test_rows_cached_step_variants_of_the_exact_widths(H2, hops):
+    """F = H1 = 32 with the output width around 32 and the hop count around four: the cached temporal step has a form
+    per case - k split over the half-waves (H2 <= 32: lanes 32 - 63 hold no output) or the full-wave products
+    (H2 > 32); the source rows straight from four hop slots or, with more hops, from the mask walk - and so has the
+    steady-state step behind it.  T > N so both kernels run; against the oracle (state bit exact, beliefs and gradients
+    inside the float64 bound)."""
+    B, N, F, H1, T = 5, 40, 32, 32, 70
+    torch.manual_seed(H2 + len(hops))
+    ref, g, mem, osel = _mk(B, N, F, H1, H2, ("temporal", hops, "forward"), True)
+    obs = torch.rand(T, B, F)
+    w = torch.rand(T, B, H2)
+    hid, outs = None, []
+    for t in range(T):
+        mx, hid = mem(obs[t].to(DEV), hid)
+        outs.append(mx)
+    steady = N > 2 * max(hops)
+    assert mem.rows_cached_steps_taken() == (T if steady else N)
+    out = torch.stack(outs)
+    (out * w.to(DEV)).sum().backward()
+    mem.check_flags()
+    out32, hid32, bounds, (out64, out_atol) = _fp64_rollout_bounds(ref, obs, None, w, lambda: osel, N)
+    assert torch.equal(hid[0].cpu(), hid32[0]) and torch.equal(hid[1].cpu(), hid32[1]) and torch.equal(hid[3].cpu(), hid32[3])
+    assert float((out.detach().cpu().double() - out64).abs().max()) <= out_atol
+    for k, p in g.named_parameters():
+        g64, atol = bounds[k]
+        assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
