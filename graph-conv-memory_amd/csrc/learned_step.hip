@@ -1960,6 +1960,7 @@ struct BpttB {
   gcm_rows::StepTable tab;            // tab.saved[s]: the buffer of step s0 + s (nodes at offset 0)
   size_t o_h1, o_soft;                // float offsets of h1 [B,N,H1] and soft [B,N] inside it
   const float *c_nodes, *c_h1;        // cached steps: the chain's caches instead (NULL: the step's own buffer)
+  const float* c_u;                   // ... and, where the chain keeps it, U[j] = W0[:, F:] x_j [B,N,F] (pass B2; NULL: recomputed)
   const int* hdr;                     // pass A: [T, B, 2] cur, L
   const int* live;                    //         [T, B, N]
   const float* da;                    //         [T, B, N, F]
@@ -2249,6 +2250,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
     const float* xg = (a.c_nodes ? a.c_nodes : a.tab.saved[s]) + (size_t)b * N * F;
     const int j0 = 32 * k;
     const int jn = cur - j0 < 32 ? cur - j0 : 32;   // candidate rows of the block
+    const bool have_u = a.c_u != nullptr;   // (uniform)
+    float uv[16];                           // this lane's sixteen entries of the block's U rows: column li of rows r
     {
       float v[16];
 #pragma unroll
@@ -2256,6 +2259,16 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
         const int e = lane + 64 * i, r = e >> 5, c = e & 31;
         const int j = j0 + r < N ? j0 + r : N - 1;
         v[i] = xg[(size_t)j * F + (c < F ? c : F - 1)];
+        uv[i] = 0.f;
+      }
+      if (have_u) {
+        const float* ug = a.c_u + (size_t)b * N * F;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = lane + 64 * i, r = e >> 5, c = e & 31;
+          const int j = j0 + r < N ? j0 + r : N - 1;
+          uv[i] = ug[(size_t)j * F + (c < F ? c : F - 1)];
+        }
       }
       const float xc = xg[(size_t)cur * F + (li < F ? li : F - 1)];
       const float glv = g_logit[it * N + (j0 + li < N ? j0 + li : N - 1)];
@@ -2272,7 +2285,22 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
     }
     wsync();
     BSTAMP(1);
-    {   // P0 = X W0b^T + (W0a x_cur + b0)
+    if (have_u) {
+      // P0[j] = U[j] + c0 from the chain's cache of the first-layer product (the forward kept U[j] = W0b x_j of every
+      // stored row: gcm_learned_step_cached, cache_u): no matrix product here - 32 of the block's 112 MFMAs - and the
+      // same P0 the forward normalised.  c0[o] = b0[o] + W0a[o, :] . x_cur: the half-waves split f, one cross-half add.
+      const float* w = sW0a + li * FS + 16 * lh;
+      const float* x = sX + 32 * FS + 16 * lh;
+      float p = 0.f;
+#pragma unroll
+      for (int f = 0; f < 16; ++f) p = fmaf(w[f], x[f], p);
+      const float c0 = p + __shfl_xor(p, 32) + sVec[li];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (lane + 64 * i) >> 5;
+        sP0[r * FS + li] = (r < jn ? uv[i] : 0.f) + c0;   // (rows behind the candidates: U is not written there)
+      }
+    } else {   // P0 = X W0b^T + (W0a x_cur + b0)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -2373,10 +2401,20 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
     }
     wsync();
     BSTAMP(10);
+    float cb = 0.f;
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) c_b0 += sP0[(cg + 2 * i) * FS + cf];
+    for (int i = 0; i < 16; ++i) cb += sP0[(cg + 2 * i) * FS + cf];
+    c_b0 += cb;
     gcm_fused::mma32b<32>(aW0b, sP0, 1, FS, sX, FS, 1, li, lh);
-    gcm_fused::mma32b<32>(aW0a, sP0, 1, FS, sX + 32 * FS, 0, 1, li, lh);
+    {
+      // dW0a += gP0^T (x_cur for every row) = (column sums of gP0) x_cur^T: an outer product of two vectors the wave
+      // holds already - sixteen fmas a lane instead of sixteen MFMAs a block
+      sGl[cf] = cb + __shfl_xor(cb, 32);       // (g_logit is consumed; both half-waves write the same value)
+      wsync();
+      const float xcf = sX[32 * FS + li];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) aW0a[r] = fmaf(sGl[gcm_fused::acc_row(r, lh)], xcf, aW0a[r]);
+    }
     wsync();   // the images are rewritten by the wave's next block
     BSTAMP(11);
   }
@@ -2741,7 +2779,7 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
                                 float eps0, float eps1, int compact, const float* g_params_prev, float* g_params,
                                 void* workspace, size_t workspace_bytes, int B, int N, int F, int H1, int H2,
                                 gcm_stream_t stream) {
-  return gcm_learned_bptt_cached(saved_host, gmx_host, n_steps, 0, 2, nullptr, nullptr, nullptr, gmx_stride_b,
+  return gcm_learned_bptt_cached(saved_host, gmx_host, n_steps, 0, 2, nullptr, nullptr, nullptr, nullptr, gmx_stride_b,
                                  gmx_stride_h, params, act1, act2, eps0, eps1, compact, g_params_prev, g_params,
                                  workspace, workspace_bytes, B, N, F, H1, H2, stream);
 }
@@ -2751,7 +2789,8 @@ extern "C" int gcm_learned_bptt(const float* const* saved_host, const float* con
  * the `compact` layout. */
 extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                                        int n_cached, int cached_layout, const float* cache_nodes, const float* cache_h1,
-                                       const float* cache_agg1, long gmx_stride_b, long gmx_stride_h,
+                                       const float* cache_agg1, const float* cache_u, long gmx_stride_b,
+                                       long gmx_stride_h,
                                        const float* params, int act1, int act2, float eps0, float eps1, int compact,
                                        const float* g_params_prev, float* g_params, void* workspace,
                                        size_t workspace_bytes, int B, int N, int F, int H1, int H2,
@@ -2820,6 +2859,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       a.o_soft = lay[7];
       a.c_nodes = cached ? cache_nodes : nullptr;
       a.c_h1 = cached ? cache_h1 : nullptr;
+      a.c_u = cached && F == gcm_learned::FP ? cache_u : nullptr;
       a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
       a.s0 = s0; a.n_steps = ns; a.T = n_steps;
       if (pass == 0) {

@@ -1255,6 +1255,7 @@ struct LearnedChainNode : public torch::autograd::Node {
   bool executed = false, released = false;
   bool compact = false;         // the steps ran on a donated state: their buffers hold row cur of the adjacency only
   at::Tensor cH, cA, cX;        // the caches of the chain's cached steps (h1, agg1, node matrix of every node)
+  at::Tensor cU;                // ... and the first-layer product of the edge network on every node (exact shapes only)
 
   variable_list apply(variable_list&& grads) override {
     executed = true;
@@ -1320,7 +1321,8 @@ struct LearnedChainNode : public torch::autograd::Node {
       check(gcm_learned_bptt_cached(sv.data(), gm.data(), T, n_cached, compact ? 2 : 3,
                                     n_cached ? cX.data_ptr<float>() : nullptr,
                                     n_cached ? cH.data_ptr<float>() : nullptr,
-                                    n_cached ? cA.data_ptr<float>() : nullptr, (long)sb, (long)sh,
+                                    n_cached ? cA.data_ptr<float>() : nullptr,
+                                    n_cached && cU.defined() ? cU.data_ptr<float>() : nullptr, (long)sb, (long)sh,
                                     packed.data_ptr<float>(), cfg->act1, cfg->act2, (float)cfg->eps0,
                                     (float)cfg->eps1, compact ? 1 : 0,
                                     prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
@@ -1437,7 +1439,11 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
       chain.cA = at::zeros({B, N, F}, obs.options());
       chain.cX = at::zeros({B, N, F}, obs.options());
       chain.cU = at::empty({B, N, F}, obs.options());   // (rows < cur are written before they are read as candidates)
-      if (chain.node) { chain.node->cH = chain.cH; chain.node->cA = chain.cA; chain.node->cX = chain.cX; }
+      if (chain.node) {
+        chain.node->cH = chain.cH; chain.node->cA = chain.cA; chain.node->cX = chain.cX;
+        // (the cached steps write U at the exact shapes only: gcm_learned_step_cached)
+        if (N == 128 && F == 32 && H1 == 32 && H2 == 32) chain.node->cU = chain.cU;
+      }
     }
     size_t lay[8];
     check(gcm_learned_step_layout((int)B, N, F, H1, H2, donate ? 2 : 3, lay), "gcm_learned_step_layout");
@@ -1920,7 +1926,8 @@ struct LearnedRolloutNode : public torch::autograd::Node {
     at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
     at::Tensor res = at::empty({cfg->P_total}, packed.options());
     check(gcm_learned_bptt_cached(sv.data(), gm.data(), (int)T, (int)T, 2, cX.data_ptr<float>(), cH.data_ptr<float>(),
-                                  cA.data_ptr<float>(), (long)g.stride(1), (long)g.stride(2), packed.data_ptr<float>(),
+                                  cA.data_ptr<float>(), nullptr, (long)g.stride(1), (long)g.stride(2),
+                                  packed.data_ptr<float>(),
                                   cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1, 1, nullptr,
                                   res.data_ptr<float>(), ws.data_ptr(), ws_bytes, (int)B, N, F, H1, H2, stream),
           "gcm_learned_bptt_cached");

@@ -155,7 +155,7 @@ PROTOTYPES = {
     "gcm_learned_bptt": (_I, [_P, _P, _I, ctypes.c_long, ctypes.c_long, _P, _I, _I, _F, _F, _I, _P, _P, _P, _Z]
                          + [_I] * 5 + [_P]),
     "gcm_learned_step_cached_functional": (_I, [_P] * 5 + [_I, _P, _I, _I, _I, _F, _F, _F] + [_P] * 12 + [_I] * 6 + [_P]),
-    "gcm_learned_bptt_cached": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P, _I, _I, _F, _F, _I,
+    "gcm_learned_bptt_cached": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P, _I, _I, _F, _F, _I,
                                      _P, _P, _P, _Z] + [_I] * 5 + [_P]),
     "gcm_learned_step_cached": (_I, [_P] * 5 + [_I, _P, _I, _I, _I, _F, _F, _F] + [_P] * 11 + [_I] * 6 + [_P]),
     "gcm_dense_rollout_bwd_params_workspace_bytes": (_Z, [_I] * 5),

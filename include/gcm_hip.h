@@ -980,7 +980,9 @@ int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t st
  * F = H1 = H2 = 32 a step stages U instead of multiplying the node image by W0b again, adds W0a x_cur + b0 on the way
  * into the LayerNorm and writes U[cur]; other shapes leave it untouched.
  * gcm_learned_bptt_cached: gcm_learned_bptt for a chain whose first n_cached steps are such steps (records in
- * layout `cached_layout` = 2 | 3; the steps behind them: `compact` layout). */
+ * layout `cached_layout` = 2 | 3; the steps behind them: `compact` layout).  cache_u (may be NULL): the chain's U cache -
+ * with it (F = 32) the edge network's backward takes P0 = U + c0 from it instead of multiplying the node rows by W0
+ * again (32 of its 112 matrix instructions per 32-row block). */
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                             const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
                             int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
@@ -996,7 +998,8 @@ int gcm_learned_step_cached_functional(const float* obs, const float* nodes_in, 
                                        int N, int F, int H1, int H2, int cur_host, gcm_stream_t stream);
 int gcm_learned_bptt_cached(const float* const* saved_host, const float* const* gmx_host, int n_steps,
                             int n_cached, int cached_layout, const float* cache_nodes, const float* cache_h1,
-                            const float* cache_agg1, long gmx_stride_b, long gmx_stride_h, const float* params,
+                            const float* cache_agg1, const float* cache_u, long gmx_stride_b, long gmx_stride_h,
+                            const float* params,
                             int act1, int act2, float eps0, float eps1, int compact, const float* g_params_prev,
                             float* g_params, void* workspace, size_t workspace_bytes, int B, int N, int F, int H1,
                             int H2, gcm_stream_t stream);
