@@ -2285,29 +2285,31 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
     }
     wsync();
     BSTAMP(1);
-    if (have_u) {
-      // P0[j] = U[j] + c0 from the chain's cache of the first-layer product (the forward kept U[j] = W0b x_j of every
-      // stored row: gcm_learned_step_cached, cache_u): no matrix product here - 32 of the block's 112 MFMAs - and the
-      // same P0 the forward normalised.  c0[o] = b0[o] + W0a[o, :] . x_cur: the half-waves split f, one cross-half add.
+    {
+      // c0[o] = b0[o] + W0a[o, :] . x_cur, the same for every row of the block: a vector, not a 32 x 32 x 32 product with
+      // x_cur repeated in every row (which it was: 16 of the block's MFMAs) - the half-waves split f, one cross-half add
       const float* w = sW0a + li * FS + 16 * lh;
       const float* x = sX + 32 * FS + 16 * lh;
       float p = 0.f;
 #pragma unroll
       for (int f = 0; f < 16; ++f) p = fmaf(w[f], x[f], p);
       const float c0 = p + __shfl_xor(p, 32) + sVec[li];
+      if (have_u) {
+        // P0[j] = U[j] + c0 from the chain's cache of the first-layer product (the forward kept U[j] = W0b x_j of
+        // every stored row: gcm_learned_step_cached, cache_u): no matrix product at all, and the P0 the forward normalised
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = (lane + 64 * i) >> 5;
-        sP0[r * FS + li] = (r < jn ? uv[i] : 0.f) + c0;   // (rows behind the candidates: U is not written there)
+        for (int i = 0; i < 16; ++i) {
+          const int r = (lane + 64 * i) >> 5;
+          sP0[r * FS + li] = (r < jn ? uv[i] : 0.f) + c0;   // (rows behind the candidates: U is not written there)
+        }
+      } else {   // P0 = X W0b^T + c0
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        gcm_fused::mma32b<32>(acc, sX, FS, 1, sW0b, 1, FS, li, lh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sP0[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + c0;
       }
-    } else {   // P0 = X W0b^T + (W0a x_cur + b0)
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      gcm_fused::mma32b<32>(acc, sX, FS, 1, sW0b, 1, FS, li, lh);
-      gcm_fused::mma32b<32>(acc, sX + 32 * FS, 0, 1, sW0a, 1, FS, li, lh);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sP0[gcm_fused::acc_row(r, lh) * FS + li] = acc[r] + sVec[li];
     }
     wsync();
     BSTAMP(2);
