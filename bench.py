@@ -1045,19 +1045,24 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # differentiated per graph-step, persistent) and pass A (k_bptt_rows<..,2>: GNN parameter gradient).  Each
         # priced on the flops it EXECUTES (its own formulation) and on its PMC bytes; the dominant one is `roofline`.
         Fe = F
-        sel_exec = B * (2 * (2 * N * Fe * Fe) + 2 * Fe * Fe + 2 * N * Fe + 2 * (2 * F * H) + 2 * (2 * H * H))
+        # (the exact-shape cached step takes the first product from the chain's U cache: ONE N x F x F product)
+        exact_u = N == 128 and F == 32 and H == 32
+        sel_exec = B * ((1 if exact_u else 2) * (2 * N * Fe * Fe) + 2 * 2 * Fe * Fe + 2 * N * Fe + 2 * (2 * F * H) + 2 * (2 * H * H))
         sel_ref = B * (2 * N * (3 * Fe * Fe + Fe))           # learned.py:38-51 on N candidate pairs, forward
         # pass B2 works per 32-row block with a candidate row: step t of a rollout from empty graphs has t candidates
         live_blocks = sum((min(t, N - 1) + 31) // 32 for t in range(T))
-        bpb_exec = B * live_blocks * (8 * (2 * 32 * Fe * Fe))   # eight 32 x F x F products per live block
+        n_prod = 4 if exact_u else 5   # P1, dW1, gH0, dW0b (+ P0 without the U cache); c0 / dW0a are vector work
+        bpb_exec = B * live_blocks * (n_prod * (2 * 32 * Fe * Fe))
         kinds = [("k_learned_select", ("k_learned_select<",), sel_exec, sel_ref,
-                  "selection + GNN tail (cached step); flops: two N x F x F products, the W0a x[cur] and F -> 1 "
+                  "selection + GNN tail (cached step); flops: the N x F x F products it executes (one with the U "
+                  "cache of the exact shapes, else two), the W0b / W0a x[cur] and F -> 1 "
                   "layers, four matrix-vector products of the GNN tail; LayerNorm / softmax VALU work not counted; "
                   "flops_reference_formulation = 2 N (3F^2 + F) per graph (the reference's 2F-wide first layer on "
                   "every candidate pair)"),
                  ("k_learned_bptt_mlp", ("k_learned_bptt_mlp",), bpb_exec, None,
                   "pass B2: the edge network recomputed and differentiated per 32-row block that holds a candidate row "
-                  "(one block per wave, eight 32 x F x F products on the fp32 MFMA each; LayerNorm passes not "
+                  "(one block per wave; 32 x F x F products on the fp32 MFMA: P1, dW1, gH0, dW0b - and P0 where the "
+                  "chain keeps no U cache; c0 and dW0a are vector work since round 5 - LayerNorm passes not "
                   "counted); one persistent launch per chain"),
                  ("k_learned_bptt_sel", ("k_learned_bptt_sel",), None, None,
                   "pass B1: per graph-step the gradient collected over the later steps that hold the node, selection "
