@@ -490,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   //  epilogue with another's MFMA chain: they start in lockstep and stay there, and the longer staging cost 1 us.)
   // TAIL: the observation of this graph, for the cached step behind the decisions (requested now: one register)
   float pf_xc = 0.f;
-  if (TAIL && wave == 0) pf_xc = vw.obs[(unsigned)b * (unsigned)F + (unsigned)(lane < F ? lane : F - 1)];
+  if (TAIL && wave <= 1) pf_xc = vw.obs[(unsigned)b * (unsigned)F + (unsigned)(lane < F ? lane : F - 1)];
   DSTAMP(0);
   // TAIL = 2 - the overflow roll (gcm.py:323-355) without reading the state back.  The adjacency of such a chain is
   // 0 / 1 and the chain keeps it as bits: the rolled rows 0 .. N - 2 (new[i, j] = old[i + 1, j + 1], last column empty)
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const int fl = lane < F ? lane : F - 1, hl = lane & 31, kh = lane >> 5;
     const int64_t n64 = tl.cur_host >= 0 ? (int64_t)tl.cur_host : vw.count[b];
     const bool bad = n64 < 0 || n64 >= N;                     // (a chain from empty graphs never rolls)
-    if (wave != 0) return;                                    // (their share was done behind the MFMA loop)
+    if (wave > 1) return;                                     // (their share was done behind the MFMA loop)
     DSTAMP(7);
     unsigned long long m0 = 0, m1 = 0;
     float agg1 = 0.f, agg2 = 0.f;
@@ -848,6 +848,43 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     float* sv = sPart;                                        // (free: every row sum has been read)
     m0 = __ballot(!bad && lane < cur && sDec[lane] != 0.f);
     m1 = __ballot(!bad && lane + 64 < cur && lane + 64 < RB && sDec[(lane + 64) & (RB - 1)] != 0.f);
+    if (wave == 1) {
+      // ---- wave 1: what of the step depends on the decisions alone - the state's row cur (observation, adjacency
+      //      row, bit image, count) and the record's live list - beside wave 0's gather and products, not behind them
+      //      (it was a quarter of the tail)
+      const unsigned rc = gb * (unsigned)N + (unsigned)cur;
+      if (!bad) {
+        if (lane < F) {
+          tl.nodes[rc * F + lane] = xc;
+          tl.cX[rc * F + lane] = xc;
+        }
+        float* arow = tl.adj + (size_t)rc * N;
+        if (lane < N && ((m0 >> lane) & 1ull)) arow[lane] = 1.f;
+        if (lane + 64 < N && ((m1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
+        if (tl.abits && lane == 0)      // (the bit image the steady-state step reads its live rows' adjacency from)
+          reinterpret_cast<uint4*>(tl.abits + (size_t)rc * 4)[0] =
+              make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32));
+        if (lane == 0) tl.count[gb] = cur + 1;
+      }
+      if (tl.total) {
+        const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
+        int* live = reinterpret_cast<int*>(tl.saved + tl.o_live) + gb * N;
+        float* coef = tl.saved + tl.o_coef + gb * N;
+        const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
+        const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
+        const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
+        if (in0) { live[pos0] = lane; coef[pos0] = lane == cur ? 0.f : 1.f; }
+        if (in1) { live[pos1] = lane + 64; coef[pos1] = lane + 64 == cur ? 0.f : 1.f; }
+        if (lane == 0) {
+          int* hdr = reinterpret_cast<int*>(tl.saved + tl.o_hdr) + 4 * gb;
+          const int L = __popcll(l0) + __popcll(l1);
+          const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull))
+                                     : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
+          hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
+        }
+      }
+      return;
+    }
     const int hc = hl < H1 ? hl : H1 - 1;
     if (hc_lds && !dist_param && sh == 0) {
       // the selected rows as a compact ascending list (every selected lane writes its row at its rank), gathered
@@ -956,42 +993,14 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const float v = gcm_act_sel(p2, act2_v);
     DSTAMP(10);
     const unsigned rc = gb * (unsigned)N + (unsigned)cur;
-    if (!bad) {
-      if (lane < F) {
-        tl.nodes[rc * F + lane] = xc;
-        tl.cX[rc * F + lane] = xc;
-        tl.cA[rc * F + lane] = agg1;
-      }
+    if (!bad) {   // (the rest of row cur and the record's lists: wave 1, above)
+      if (lane < F) tl.cA[rc * F + lane] = agg1;
       if (lane < H1) tl.cH[rc * H1 + lane] = h1c;
-      float* arow = tl.adj + (size_t)rc * N;
-      if (lane < N && ((m0 >> lane) & 1ull)) arow[lane] = 1.f;
-      if (lane + 64 < N && ((m1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
-      if (tl.abits && lane == 0)      // (the bit image the steady-state step reads its live rows' adjacency from)
-        reinterpret_cast<uint4*>(tl.abits + (size_t)rc * 4)[0] =
-            make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32));
-      if (lane == 0) tl.count[gb] = cur + 1;
     }
     if (lane < H2) tl.saved[gb * H2 + lane] = v;
-    if (tl.total) {
-      if (lane < H1) {
-        tl.saved[tl.o_v + gb * 2 * H1 + lane] = agg2;
-        tl.saved[tl.o_v + gb * 2 * H1 + H1 + lane] = h1c;
-      }
-      const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
-      int* live = reinterpret_cast<int*>(tl.saved + tl.o_live) + gb * N;
-      float* coef = tl.saved + tl.o_coef + gb * N;
-      const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
-      const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
-      const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
-      if (in0) { live[pos0] = lane; coef[pos0] = lane == cur ? 0.f : 1.f; }
-      if (in1) { live[pos1] = lane + 64; coef[pos1] = lane + 64 == cur ? 0.f : 1.f; }
-      if (lane == 0) {
-        int* hdr = reinterpret_cast<int*>(tl.saved + tl.o_hdr) + 4 * gb;
-        const int L = __popcll(l0) + __popcll(l1);
-        const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull))
-                                   : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
-        hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
-      }
+    if (tl.total && lane < H1) {
+      tl.saved[tl.o_v + gb * 2 * H1 + lane] = agg2;
+      tl.saved[tl.o_v + gb * 2 * H1 + H1 + lane] = h1c;
     }
     const bool nonfinite = __any(lane < H2 && !isfinite(v));
     if ((nonfinite || bad) && lane == 0)
