@@ -2276,7 +2276,9 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int e = lane + 64 * i, r = e >> 5, c = e & 31;
-        sX[r * FS + c] = (j0 + r < N && c < F) ? v[i] : 0.f;
+        // (rows behind the candidates carry exact-zero gradients below, but 0 x whatever a cache row that was never
+        //  written holds is not 0 when that is a NaN: they enter the products as zeros)
+        sX[r * FS + c] = (r < jn && c < F) ? v[i] : 0.f;
       }
       if (lh == 0) {
         sX[32 * FS + li] = li < F ? xc : 0.f;

@@ -1435,9 +1435,11 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
   const bool steady = !cached && donate && chain.steady_ok;
   if (cached) {
     if (chain.all_steps == 0) {
-      chain.cH = at::zeros({B, N, H1}, obs.options());
-      chain.cA = at::zeros({B, N, F}, obs.options());
-      chain.cX = at::zeros({B, N, F}, obs.options());
+      // (no zero fill: a cached step reads rows < cur of the caches only, and the backward takes rows of a block that
+      //  lie behind the candidates as zeros - three 4 MB fills less per chain)
+      chain.cH = at::empty({B, N, H1}, obs.options());
+      chain.cA = at::empty({B, N, F}, obs.options());
+      chain.cX = at::empty({B, N, F}, obs.options());
       chain.cU = at::empty({B, N, F}, obs.options());   // (rows < cur are written before they are read as candidates)
       if (chain.node) {
         chain.node->cH = chain.cH; chain.node->cA = chain.cA; chain.node->cX = chain.cX;

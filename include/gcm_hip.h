@@ -967,8 +967,9 @@ int gcm_learned_step_steady(const float* obs, float* nodes, float* adj, const in
 int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t stream);
 /* Cached steps.  Rows of h1 never change once written while a graph has not overflowed (row j's adjacency
  * entries and the rows it aggregates are final after step j), so a chain that starts from EMPTY graphs keeps
- * h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every node in per-chain caches (zero-filled by the
- * caller at the chain's head) and a step computes row cur only - the whole forward step (gcm.py:262-321 with
+ * h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every node in per-chain caches (any contents at the
+ * chain's head: rows < cur are written before they are read, and the backward takes block rows behind the candidates
+ * as zeros) and a step computes row cur only - the whole forward step (gcm.py:262-321 with
  * learned.py:53-113) in ONE launch on a donated state, for the first N steps of such a chain.  The step's record
  * (gcm_learned_step_layout, compact = 2: no nodes / h1 / agg1 sections): adj_row [B,N], mx [B,H2], agg2 [B,H1],
  * cur | count, soft [B,N].  params: GNN | edge network, packed.  gcm_learned_step_cached_functional: the same on a

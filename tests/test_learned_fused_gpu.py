@@ -540,3 +540,23 @@ def test_learned_steady_chain_falls_back_when_the_caller_edits_the_state():
     assert mem.learned_steady_steps_taken() == T1 - N      # steady until the edit, the general kernels after it
     assert torch.equal(hid_p[1].cpu(), hid_o[1]) and torch.equal(hid_p[0].cpu(), hid_o[0])
     torch.testing.assert_close(torch.stack(outs_p), torch.stack(outs_o), rtol=RTOL, atol=2e-6)
+
+
+@pytest.mark.parametrize("rollout", [False, True])
+def test_learned_chain_does_not_depend_on_uninitialised_cache_rows(rollout):
+    """The chain's caches (h1, agg1, nodes, U) are allocated without a zero fill: a cached step reads rows < cur only and
+    the backward takes the rows of a 32-row block that lie behind the candidates as zeros.  With torch filling every
+    uninitialised allocation with NaN (deterministic mode's fill_uninitialized_memory) the per-step chain and the
+    time-parallel rollout must still match the oracle - T = 29 leaves three rows of the first block unwritten."""
+    from gcm.gcm import DenseGCM
+    DenseGCM.did_warn = True
+    prev_det = torch.are_deterministic_algorithms_enabled()
+    prev_fill = torch.utils.deterministic.fill_uninitialized_memory
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        _run_both(5, 128, 32, 32, 29, 4, seed=77, count0=None, pick=[0, 2, 4], donate=True, rollout=rollout)
+        _run_both(4, 40, 20, 24, 29, 3, seed=78, count0=None, pick=[0, 1], donate=not rollout, rollout=rollout)
+    finally:
+        torch.utils.deterministic.fill_uninitialized_memory = prev_fill
+        torch.use_deterministic_algorithms(prev_det)
