@@ -258,3 +258,20 @@ def test_euclid_steady_chain_falls_back_when_the_caller_edits_the_state():
     assert mem.rows_rolled_steps_taken() == T1 - N
     assert torch.equal(hid_p[1].cpu(), hid_o[1]) and torch.equal(hid_p[0].cpu(), hid_o[0])
     torch.testing.assert_close(torch.stack(outs_p), torch.stack(outs_o), rtol=1e-5, atol=2e-6)
+
+
+def test_euclid_paths_do_not_depend_on_uninitialised_memory():
+    """The time-parallel rollout writes its caches, records and final state whole (no zero fill) and the per-step chain
+    allocates its caches and records empty.  With torch filling every uninitialised allocation with NaN (deterministic
+    mode's fill_uninitialized_memory) both must still match the oracle - T = 37 leaves the last 32-row blocks partly
+    unwritten; the chain runs past graph_size into the steady-state step."""
+    prev_det = torch.are_deterministic_algorithms_enabled()
+    prev_fill = torch.utils.deterministic.fill_uninitialized_memory
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        test_euclid_rollout_time_parallel_vs_oracle(160, 128, 32, 32, 32, 37, False)
+        test_euclid_chain_steady_state_one_launch_vs_oracle(33, 16, 32, 32, 50)
+    finally:
+        torch.utils.deterministic.fill_uninitialized_memory = prev_fill
+        torch.use_deterministic_algorithms(prev_det)

@@ -900,3 +900,36 @@ def test_rows_cached_step_variants_of_the_exact_widths(H2, hops):
     for k, p in g.named_parameters():
         g64, atol = bounds[k]
         assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
+
+
+@pytest.mark.parametrize("sel,F,H", [(("temporal", [1, 2, 4], "forward"), 32, 32), (("temporal", [2, 5], "forward"), 20, 48)])
+def test_rows_chain_does_not_depend_on_uninitialised_memory(sel, F, H):
+    """The cached-step chain allocates its caches and records without a zero fill.  With torch filling every
+    uninitialised allocation with NaN (deterministic mode's fill_uninitialized_memory) a donated rollout past graph_size
+    - cached steps, then the steady-state / live-row steps - and its backward must still match the oracle."""
+    B, N, T = 4, 24, 40
+    prev_det = torch.are_deterministic_algorithms_enabled()
+    prev_fill = torch.utils.deterministic.fill_uninitialized_memory
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        torch.manual_seed(5)
+        ref, g, mem, osel = _mk(B, N, F, H, H, sel, True)
+        obs = torch.rand(T, B, F)
+        w = torch.rand(T, B, H)
+        hid, outs = None, []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+        out = torch.stack(outs)
+        (out * w.to(DEV)).sum().backward()
+        mem.check_flags()
+    finally:
+        torch.utils.deterministic.fill_uninitialized_memory = prev_fill
+        torch.use_deterministic_algorithms(prev_det)
+    out32, hid32, bounds, (out64, out_atol) = _fp64_rollout_bounds(ref, obs, None, w, lambda: osel, N)
+    assert torch.equal(hid[0].cpu(), hid32[0]) and torch.equal(hid[1].cpu(), hid32[1])
+    assert float((out.detach().cpu().double() - out64).abs().max()) <= out_atol
+    for k, p in g.named_parameters():
+        g64, atol = bounds[k]
+        assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
