@@ -724,3 +724,20 @@ def test_one_shot_from_none_returns_aliases_that_are_watched():
     xb[3, 10, 5] = float("nan")
     with pytest.raises(AssertionError):
         mem(xb, taus, None)
+
+
+def test_sparse_paths_do_not_depend_on_uninitialised_memory():
+    """SparseGCM's whole-episode call and its stepwise cached chain allocate their flat buffers, index structures,
+    caches and records without a zero fill where a kernel writes them whole.  With torch filling every uninitialised
+    allocation with NaN (deterministic mode's fill_uninitialized_memory) they must still match the reference vectors /
+    the oracle."""
+    prev_det = torch.are_deterministic_algorithms_enabled()
+    prev_fill = torch.utils.deterministic.fill_uninitialized_memory
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        test_sparse_rollout_matches_reference(SPARSE[0])
+        test_sparse_stepwise_cached_chain_vs_oracle([1, 2, 4], 6, 24, 32, 32, 20, torch.nn.Tanh, 0.0)
+    finally:
+        torch.utils.deterministic.fill_uninitialized_memory = prev_fill
+        torch.use_deterministic_algorithms(prev_det)
