@@ -342,7 +342,7 @@ def time_step_kernel(mem, obs, c, reps=10):
         lib.gcm_dense_rows_cached_layout(B, N, F, H, H, ctypes.addressof(layc))
         saved_c = [torch.empty(layc[0], device=dev) for _ in range(T)]
         sv_c = (ctypes.c_void_p * T)(*[t_.data_ptr() for t_ in saved_c])
-        image = torch.empty(2 * 4 * 64 * 64 + 4096, device=dev)
+        image = torch.empty(_hip.lib().gcm_dense_rows_cached_weight_image_floats(), device=dev)
         assert dbg.gcm_dense_rows_cached_weight_image(p(params), p(image), F, H, H, st) == 0
         evs = [(new_event(), new_event()) for _ in range(T)]
         ev_a = (ctypes.c_void_p * T)(*[a for a, _ in evs])

@@ -961,6 +961,10 @@ extern "C" int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2,
   return GCM_OK;
 }
 
+/* floats a weight image takes (gcm_dense_rows_cached_weight_image writes all of it): the lane-major layout, the
+ * layer-interleaved one and the half-wave split of the widths <= 32 */
+extern "C" size_t gcm_dense_rows_cached_weight_image_floats(void) { return 2 * 4 * 64 * 64 + 2 * 16 * 64 * 2; }
+
 extern "C" int gcm_dense_rows_cached_weight_image(const float* params, float* image, int F, int H1, int H2,
                                                   gcm_stream_t stream) {
   GCM_REQUIRE(params && image && F > 0 && F <= 64 && H1 > 0 && H1 <= 64 && H2 > 0 && H2 <= 64);

@@ -837,7 +837,7 @@ struct RowsFast {
       cX = at::empty({B, N, F}, obs.options());
       if (node) { node->cH = cH; node->cA = cA; node->cX = cX; node->descs = cfg->descs; }
       // the weights lane-major, once per chain (the parameters are fixed inside one)
-      wimg = at::empty({2 * 4 * 64 * 64 + 4096}, obs.options());
+      wimg = at::empty({(int64_t)gcm_dense_rows_cached_weight_image_floats()}, obs.options());
       check(gcm_dense_rows_cached_weight_image(packed.data_ptr<float>(), wimg.data_ptr<float>(), F, H1, H2,
                                                reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream())),
             "gcm_dense_rows_cached_weight_image");
@@ -2361,7 +2361,7 @@ pybind11::object sparse_temporal_step(const at::Tensor& x_, const at::Tensor& ta
           w_rel2.detach().reshape({-1}), w_root2.detach().reshape({-1}),
           b2.has_value() ? b2->detach().reshape({-1}) : at::zeros({H2}, x.options())};
       ch->packed = at::cat(parts);
-      ch->wimg = at::empty({2 * 4 * 64 * 64 + 4096}, x.options());
+      ch->wimg = at::empty({(int64_t)gcm_dense_rows_cached_weight_image_floats()}, x.options());
       check(gcm_dense_rows_cached_weight_image(ch->packed.data_ptr<float>(), ch->wimg.data_ptr<float>(), (int)F,
                                                (int)H1, (int)H2, st),
             "gcm_dense_rows_cached_weight_image");

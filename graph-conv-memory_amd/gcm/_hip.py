@@ -121,6 +121,7 @@ PROTOTYPES = {
     "gcm_sparse_chain_edges": (_I, [_P] * 6 + [_I, _P, _P, _L, _L, _I, _P]),
     "gcm_sparse_step_cached": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_cached_weight_image": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gcm_dense_rows_cached_weight_image_floats": (_Z, []),
     "gcm_dense_rows_step_cached": (_I, [_P] * 5 + [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_bptt_cached": (_I, [_P, _P, _I, ctypes.c_long, ctypes.c_long, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z]
                                    + [_I] * 5 + [_P]),

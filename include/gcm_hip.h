@@ -629,6 +629,7 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
 int gcm_dense_rows_cached_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
                                     int F, int H1, int H2);
 int gcm_dense_rows_cached_layout(int B, int N, int F, int H1, int H2, size_t* out5);
+size_t gcm_dense_rows_cached_weight_image_floats(void);   /* the floats `image` must hold (36864) */
 int gcm_dense_rows_cached_weight_image(const float* params, float* image, int F, int H1, int H2,
                                        gcm_stream_t stream);
 int gcm_dense_rows_step_cached(const float* obs, float* nodes, float* adj, int64_t* count,

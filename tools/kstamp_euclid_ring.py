@@ -32,7 +32,7 @@ nodes, adj, _, count = hid
 w = (adj.view(B, N, 4, 32) > 0).to(torch.int64) << torch.arange(32, device=dev)
 abits = w.sum(-1).to(torch.int32).contiguous()            # [B, N, 4]: bit j of row i = adj[i, j]  (bit 31 wraps into the sign)
 params = mem._packed_cache[1].detach().contiguous()
-wimg = torch.empty(2 * 4 * 64 * 64 + 4096, device=dev)
+wimg = torch.empty(lib.gcm_dense_rows_cached_weight_image_floats(), device=dev)
 st = _hip.stream()
 assert lib.gcm_dense_rows_cached_weight_image(params.data_ptr(), wimg.data_ptr(), F, H, H, st) == 0
 lay = (ctypes.c_size_t * 8)()
