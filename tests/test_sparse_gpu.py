@@ -737,7 +737,9 @@ def test_sparse_paths_do_not_depend_on_uninitialised_memory():
     torch.utils.deterministic.fill_uninitialized_memory = True
     try:
         test_sparse_rollout_matches_reference(SPARSE[0])
-        test_sparse_stepwise_cached_chain_vs_oracle([1, 2, 4], 6, 24, 32, 32, 20, torch.nn.Tanh, 0.0)
+        import os
+        if os.environ.get("GCM_NO_TORCH_EXT") != "1":     # (the cached chain lives in the C++ host path)
+            test_sparse_stepwise_cached_chain_vs_oracle([1, 2, 4], 6, 24, 32, 32, 20, torch.nn.Tanh, 0.0)
     finally:
         torch.utils.deterministic.fill_uninitialized_memory = prev_fill
         torch.use_deterministic_algorithms(prev_det)
