@@ -679,6 +679,11 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             graph = capture(lambda: body(False), bucket.zero)
     elif not args.no_graph:
         graph = capture(lambda: rollout(mem, obs), zero)
+    # what rank 0 profiles ALONE further down must hold no collective (the other ranks have left by then: a replayed
+    # all-reduce would wait for them forever): with the collective captured, a twin of the graph without it
+    graph_prof = graph
+    if graph is not None and comm["captured"]:
+        graph_prof = capture(lambda: body(False), bucket.zero)
 
     def step():
         if graph is not None:
@@ -751,7 +756,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             q.zero_grad(set_to_none=True)
     variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
     rollout_kernels = None
-    if rank == 0 and c["selector"] == "euclid":
+    if rank == 0 and world == 1 and c["selector"] == "euclid":   # (world == 1: `roll` reduces its gradients)
         # the time-parallel entry's own kernels (csrc/euclid_tp.hip): every step's decisions as one causal contraction
         pr = profile_kernels(roll, reps=2)
         kt = find_kernel(pr, "k_euclid_tp<")
@@ -857,8 +862,13 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         g2 = capture(lambda: rollout(mem_2, obs2), zero_2)
         variants["T%d_graph_donated" % T2] = world * B * T2 * side / timed(g2.replay, side, 2)
         variants["T%d_steady_state_step_us" % T2] = None     # (filled from the kernel profile below)
+        p2 = None
         if rank == 0:
-            p2 = profile_kernels(g2.replay, reps=2)
+            try:        # (rank 0 alone: no collective in here - g2 holds none - and no exception may leave it)
+                p2 = profile_kernels(g2.replay, reps=2)
+            except Exception as e:
+                variants["T%d_profile_error" % T2] = "%s: %s" % (type(e).__name__, str(e)[:120])
+        if p2 is not None:
             if c["selector"] == "temporal":
                 kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_rows<")
                 if kr is not None:
@@ -913,7 +923,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     # --no-graph): the independent source of every kernel duration below ------------------------------------------
     prof_reps = 5
     if graph is not None:
-        prof = profile_kernels(graph.replay, reps=prof_reps)
+        prof = profile_kernels(graph_prof.replay, reps=prof_reps)
     else:
         def one():
             rollout(mem, obs)
