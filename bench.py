@@ -48,6 +48,12 @@ CONFIGS = {
     "cfg5": dict(kind="dense", B=256, N=128, F=32, H=32, T=64, selector="learned",
                  text="cfg5: DenseGCM + LearnedEdge(32), B=256/GPU (B=2048 over 8 ranks), graph_size=128, "
                       "obs=hidden=32, gumbel noise from the per-rank device generator"),
+    # the dense-materialised regime: the reference's own speed script runs DenseGCM + DenseEdge
+    # (tests/test_speed.py:21-27, edge_selectors/dense.py:11-23) - every row <= cur is live, the step kernel does
+    # the real cur^2 F aggregation on the fp32 MFMA
+    "dense_edge": dict(kind="dense", B=256, N=128, F=32, H=32, T=128, selector="dense",
+                       text="dense_edge: DenseGCM + DenseEdge (every earlier node both ways + self edge: the adjacency "
+                            "is materialised dense), B=256, graph_size=128, obs=hidden=32, 2x DenseGraphConv+tanh"),
     "cfg4": dict(kind="sparse", B=512, N=512, F=32, H=32, T=512, selector="temporal_sparse",
                  text="cfg4: SparseGCM + TemporalEdge([1]), B=512/GPU, graph_size=512, obs=hidden=32, 2x GraphConv+tanh, "
                       "one call per episode (taus=512)"),
@@ -106,6 +112,9 @@ def build_memory(device, donate=False, selector="temporal", cfg=None):
     elif selector == "euclid":
         from gcm.edge_selectors.distance import EuclideanEdge
         sel = EuclideanEdge(2.0)
+    elif selector == "dense":
+        from gcm.edge_selectors.dense import DenseEdge
+        sel = DenseEdge()
     else:
         sel = TemporalBackedge(HOPS)
     mem = DenseGCM(gnn, edge_selectors=sel, graph_size=c["N"], donate_state=donate)
@@ -251,6 +260,42 @@ def find_kernel(prof, *prefixes):
         if any(pf in k for pf in prefixes) and (best is None or d["us_per_call"] > best[1]["us_per_call"]):
             best = (k, d)
     return best
+
+
+def forward_loop_cadence(mem, obs, iters=30):
+    """Wall time per step-kernel launch: the T-step forward loop alone (grad mode: the records are written, as in the
+    timed region) captured once as a HIP graph, HIP events on the launch stream around `iters` replays, / T.  An
+    EXCLUSIVE time per launch (gaps between launches included): T x this <= ms_per_step by construction, unlike the
+    begin-to-end durations a kernel tracer reports for consecutive nodes of a replayed graph, which overlap."""
+    T = obs.shape[0]
+
+    def fwd_only():
+        hidden = None
+        for t in range(T):
+            _, hidden = mem(obs[t], hidden)
+
+    g = capture(fwd_only, lambda: None)
+    ms = event_time(g.replay, iters, warm=5) / T
+    del g
+    return ms
+
+
+def committed_csv_avg(cfg_name, kernel_short):
+    """The newest committed `rocprofv3 --kernel-trace --stats` summary of this bench command
+    (profiles/rNN_bench_<cfg>_kernel_stats.csv) -> (file, calls, average ns) of the kernel whose name holds
+    `kernel_short`; None when there is none.  A LOOKUP of a committed file, labelled as such in the line."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_%s_kernel_stats.csv" % cfg_name)))
+    for path in reversed(files):
+        try:
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    if kernel_short in short_kernel_name(row["Name"]):
+                        return os.path.relpath(path, ROOT), int(row["Calls"]), float(row["AverageNs"])
+        except Exception:
+            continue
+    return None
 
 
 def launch_floor(grid, block, nodes=128):
@@ -528,6 +573,10 @@ def cpu_baseline(c, budget_s=20.0):
         sel = od.LearnedEdge(net, num_edge_samples=5)
         obs = torch.rand(T, B, F)
         extra = [net]
+    elif c["selector"] == "dense":
+        sel = od.DenseEdge()
+        obs = torch.rand(T, B, F)
+        extra = []
     else:
         sel = od.TemporalBackedge(HOPS)
         obs = torch.rand(T, B, F)
@@ -586,7 +635,7 @@ def main():
     if args.T:
         c["T"] = args.T
     if args.steps is None:
-        args.steps = {"cfg2": 1000, "cfg3": 200, "cfg5": 200, "cfg4": 50}[args.config]
+        args.steps = {"cfg2": 1000, "cfg3": 200, "cfg5": 200, "cfg4": 50, "dense_edge": 100}[args.config]
     rank, local_rank, world = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local_rank)
@@ -869,8 +918,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             except Exception as e:
                 variants["T%d_profile_error" % T2] = "%s: %s" % (type(e).__name__, str(e)[:120])
         if p2 is not None:
-            if c["selector"] == "temporal":
-                kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_rows<")
+            if c["selector"] in ("temporal", "dense"):
+                kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_colcache<", "k_step_rows<")
                 if kr is not None:
                     variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
                     variants["T%d_steady_state_kernel" % T2] = kr[0]
@@ -905,7 +954,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             return f
         variants["T%d_eager_donated" % T2] = world * B * T2 * side / timed(eager2(mem_e, gnn_e, bucket_e), side, 1)
         variants["T%d_eager_functional" % T2] = world * B * T2 * side / timed(eager2(mem_f, gnn_f, bucket_f), side, 1)
-        if c["selector"] != "temporal":
+        if c["selector"] not in ("temporal", "dense"):
             def roll2():
                 rollout_api(mem_f, obs2, bucket_f, weight)
                 for q in mods_f:
@@ -984,25 +1033,53 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                    "note": "what the kernel really does per launch: bytes = PMC (2*FETCH_SIZE + WRITE_SIZE, "
                            "profiles/traffic.json), flops = its own formulation (row cur over the chain's caches); "
                            "at neither limit - a launch-to-retire latency chain, see launch_floor_us"})
+        # The duration `frac` is computed from: the wall time the timed region spends per launch of the step kernel =
+        # replay time of the captured forward loop / T, HIP events on the launch stream (the
+        # begin-to-end durations of consecutive graph nodes overlap - their sum exceeded ms_per_step - so they stay a
+        # side field, with the committed rocprofv3 CSV's figure of the same command next to them).
+        try:
+            cad_ms = forward_loop_cadence(mem_e, obs)
+            cad_src = ("HIP events (torch.cuda.Event on the launch stream) around 30 replays of the T-step forward loop "
+                       "captured as a HIP graph, / T: wall time per launch of the step kernel inside the loop the metric "
+                       "times (launch gaps included; T x avg_launch_ms <= ms_per_step)")
+        except Exception as e:      # (capture unavailable: fall back to what the timed region leaves per step)
+            cad_ms = (ms_per_step - (kb[1]["us_per_call"] * 1e-3 if kb else 0.0)) / T
+            cad_src = "(ms_per_step - k_bptt_rows) / T [forward-loop capture failed: %s]" % type(e).__name__
+        csv_row = committed_csv_avg(name, step_kernel.split("::")[-1])
+        b2e = {"avg_launch_ms": kd["avg_us"] * 1e-3, "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS, "source": src,
+               "sum_over_T_launches_ms": kd["avg_us"] * 1e-3 * T,
+               "note": "begin -> end timestamps of each kernel node (what a kernel tracer reports); consecutive nodes "
+                       "of a replayed graph overlap (node t + 1's begin stamp is taken while node t drains), so these "
+                       "durations add up to more than the loop's wall time - NOT the duration `frac` uses"}
+        if csv_row is not None:
+            csv_frac = alg_bytes / (csv_row[2] * 1e-9) / 1e9 / PEAK_HBM_GBS
+            b2e["rocprofv3_csv"] = {"file": csv_row[0], "calls": csv_row[1], "avg_ns": csv_row[2], "frac": csv_frac,
+                                    "differs_from_in_process_pct": round(100.0 * (csv_row[2] * 1e-6 / (kd["avg_us"] * 1e-3) - 1.0), 2),
+                                    "source": "committed file (rocprofv3 --kernel-trace --stats of `bench.py --config %s`), "
+                                              "not measured in this run; frac = bytes_per_launch / avg_ns / 8 TB/s" % name}
+        cad_sec = cad_ms * 1e-3
+        ex_c = dict(ex)
+        if moved:
+            ex_c.update({"GB/s": moved / cad_sec / 1e9, "frac_of_hbm_peak": moved / cad_sec / 1e9 / PEAK_HBM_GBS})
+        ex_c.update({"TFLOP/s": exec_flops / cad_sec / 1e12,
+                     "frac_of_fp32_mfma_peak": exec_flops / cad_sec / 1e12 / PEAK_F32_MFMA_TFLOPS})
         line["roofline"] = {
-            "bound": "hbm", "kernel": step_kernel, "achieved": alg_bytes / sec / 1e9, "peak": PEAK_HBM_GBS,
-            "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / PEAK_HBM_GBS, "traffic": moved,
-            "bytes_per_launch": alg_bytes, "avg_launch_ms": kd["avg_us"] * 1e-3, "avg_launch_ms_source": src,
-            "launches_timed": int(round(kd["launches_per_call"] * prof_reps)),
-            "executed": ex, "launch_floor_us": floor, "cross_checks": cross,
-            "cadence": ({"per_step_ms": cross["captured_forward_loop_over_T_ms"],
-                         "frac_at_cadence": alg_bytes / (cross["captured_forward_loop_over_T_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "sum_of_durations_over_wall": kd["avg_us"] * 1e-3 / cross["captured_forward_loop_over_T_ms"],
-                         "note": "replay time of the captured forward loop / T: the step kernels of a replayed graph "
-                                 "overlap - launch N + 1 is dispatched (its begin timestamp taken) while launch N "
-                                 "drains - so the begin-to-end durations `frac` is computed from add up to more than "
-                                 "the loop's wall time (sum_of_durations_over_wall > 1); this is the rate the loop "
-                                 "itself sustains"}
-                        if cross.get("captured_forward_loop_over_T_ms") else None),
+            "bound": "hbm", "kernel": step_kernel, "achieved": alg_bytes / cad_sec / 1e9, "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": alg_bytes / cad_sec / 1e9 / PEAK_HBM_GBS, "traffic": moved,
+            "traffic_source": "committed file profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                              "tools/pmc_run.py, summarised by tools/pmc_summarise.py); not measured in this run",
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": cad_ms, "avg_launch_ms_source": cad_src,
+            "launches_timed": 30 * T,
+            "consistency": {"launches_per_step": T, "launches_x_avg_launch_ms": cad_ms * T, "ms_per_step": ms_per_step,
+                            "holds": bool(cad_ms * T <= ms_per_step * 1.02) if graph is not None else None,
+                            "whole_step_GB/s_upper_check": alg_bytes * T / (ms_per_step * 1e-3) / 1e9},
+            "begin_to_end": b2e,
+            "executed": ex_c, "launch_floor_us": floor, "cross_checks": cross,
             "note": "EFFECTIVE rate: bytes_per_launch = SURVEY 8(d)'s full-dense compulsory bytes (what the "
-                    "reference's formulation must move per step) over the kernel's measured mean duration; the kernel "
+                    "reference's formulation must move per step) over the wall time per launch; the kernel "
                     "itself moves `traffic` bytes (`executed`): only the rows that reach the kept belief row are "
                     "evaluated, layer 1 of older rows comes from the chain's caches, the state is advanced in place"}
+        sec = cad_sec      # (the MFMA view below is priced on the same duration)
         line["roofline_mfma_view"] = {
             "kernel": step_kernel, "flops_per_launch_full_dense": B * fwd_full,
             "achieved_full_dense_TFLOPs": B * fwd_full / sec / 1e12,
@@ -1049,6 +1126,46 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             "in_situ": in_situ,
             "note": "fp32 MFMA (no TF32 on gfx950); executed flops = algorithmic flops here (every stored row is a "
                     "candidate)"}
+    elif c["selector"] == "dense":
+        # The dense-materialised regime (the reference's own speed script: tests/test_speed.py:21-27):
+        # DenseEdge makes every row <= cur live and every live row's adjacency row full, so the step really does
+        # the cur^2 F aggregation.  Priced on the fp32 MFMA peak, twice: EXECUTED flops of the kernel's own formulation
+        # (per graph-step with L = cur + 1 live rows: 2 L^2 F aggregation + 4 L F H layer-1 linears + 2 L H + 4 H^2 for
+        # row cur of layer 2), and SURVEY 8(d)'s full-dense flops (2 layers x all N rows) as the EFFECTIVE figure.
+        k = find_kernel(prof, "k_step_colcache<", "k_step_rows<")
+        kb = find_kernel(prof, "k_bptt_dense<", "k_bptt_rows<")
+        step_kernel, kd = k
+        sec = kd["avg_us"] * 1e-6
+        Ls = [min(t, N - 1) + 1 for t in range(T)]
+        recompute = "k_step_rows<" in step_kernel
+        if recompute:
+            per_graph = [2.0 * L * L * F + 4.0 * L * F * H + 2.0 * L * H + 4.0 * H * H for L in Ls]
+        else:   # the cached dense step: rank-1 update of the layer-1 pre-activations (L H adds), tanh on L rows, row cur
+            per_graph = [2.0 * L * H + 2.0 * L * H + 2.0 * (2 * F * H) + 2.0 * (2 * F * H) + 4.0 * H * H for L in Ls]
+        exec_flops = B * sum(per_graph) / T
+        exec_full = B * (2.0 * N * N * F + 4.0 * N * F * H + 2.0 * N * H + 4.0 * H * H)
+        line["roofline"] = {
+            "bound": "mfma", "kernel": step_kernel, "achieved": B * fwd_full / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": B * fwd_full / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "traffic": traffic.get("k_step_colcache" if not recompute else "k_step_rows_dense"),
+            "flops_per_launch": B * fwd_full, "avg_launch_ms": kd["avg_us"] * 1e-3, "avg_launch_ms_source": src,
+            "launches_timed": int(round(kd["launches_per_call"] * prof_reps)),
+            "executed": {"flops_per_launch_mean": exec_flops, "TFLOP/s": exec_flops / sec / 1e12,
+                         "frac_of_fp32_mfma_peak": exec_flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "flops_per_launch_full_graphs": exec_full,
+                         "note": "what the kernel's own formulation computes, mean over the T launches of a rollout from "
+                                 "empty graphs (L = cur + 1 live rows at step cur)"},
+            "note": "EFFECTIVE: SURVEY 8(d)'s full-dense forward flops per belief state (2 N^2 (F+H) + 4 N (FH + H^2): "
+                    "both DenseGraphConv layers on all N rows, what the reference computes every step) x B over the "
+                    "step kernel's measured mean duration; `executed` = the flops of the kernel's own formulation"}
+        kernel_ms = {step_kernel: round(kd["avg_us"] * 1e-3, 6)}
+        if kb:
+            Lsum = sum(Ls)
+            bw_flops = B * (sum(2.0 * L * H * 2 * F + 2.0 * L * H * H + 2.0 * L * L * F for L in Ls))
+            kernel_ms[kb[0]] = round(kb[1]["avg_us"] * 1e-3, 6)
+            line["roofline"]["backward"] = {"kernel": kb[0], "launches_per_step": round(kb[1]["launches_per_call"], 2),
+                                            "avg_launch_ms": kb[1]["avg_us"] * 1e-3, "us_per_step": round(kb[1]["us_per_call"], 1),
+                                            "live_rows_per_rollout": B * Lsum}
     else:
         # cfg5: three kernels carry the step - the cached forward step (selection: the edge network on N candidate
         # rows + gumbel-softmax + the GNN on row cur), pass B of the backward (edge network recomputed and
@@ -1144,13 +1261,14 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         def counters_of(kname):
             for key, ent in util.items():
                 if key in kname and "mfma_busy_frac" in ent:
-                    return {k: ent[k] for k in ("mfma_busy_frac", "lds_conflict_frac", "wait_inst_lds_frac",
-                                                "wait_inst_any_frac", "wait_any_frac", "avg_us_under_pmc") if k in ent}
+                    return dict({k: ent[k] for k in ("mfma_busy_frac", "lds_conflict_frac", "wait_inst_lds_frac",
+                                                     "wait_inst_any_frac", "wait_any_frac", "avg_us_under_pmc") if k in ent},
+                                source="committed file profiles/mfma_util.json (not measured in this run)")
             return None
         rf = line.get("roofline", {})
         cn = counters_of(rf.get("kernel", ""))
         if cn:
-            rf["sq_counters"] = dict(cn, source="rocprofv3 --pmc SQ_* passes over tools/pmc_mfma_run.py, summarised by "
+            rf["sq_counters"] = dict(cn, source="committed file profiles/mfma_util.json, not measured in this run: rocprofv3 --pmc SQ_* passes over tools/pmc_mfma_run.py, summarised by "
                                                 "tools/pmc_sq_summarise.py: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
                                                 "(4 x SQ_BUSY_CU_CYCLES)")
         if isinstance(rf.get("in_situ"), dict):

@@ -52,6 +52,7 @@ struct StepCfg {
   std::vector<gcm_selector_desc> descs;
   int act1, act2, has_bias, N, F, H1, H2;
   int cached_flags = 0;   // extra has_bias bits of the cached step only (GCM_STEP_TWO_LAUNCH: the A/B of tests / tools)
+  bool col_cache = true;  // chains whose selectors write column cur take gcm_dense_rows_step_colcache (A/B switch)
   int64_t P;
   bool has_distance = false;
   at::Tensor ws;   // scratch of the distance selectors
@@ -592,8 +593,13 @@ struct RowsFast {
   // gcm_edge_distance_step_ring - the roll in the same launch, the live rows re-evaluated from the chain's bit image of
   // the adjacency (abits, kept by the cached steps)
   bool ring_ok = false;
-  int64_t cached_steps = 0, chain_steps = 0, rolled_steps = 0;
+  // ... or (round 6) the chain's selectors also write COLUMN cur - DenseEdge, "backward" / "both" hops - on a donated
+  // state from empty graphs: gcm_dense_rows_step_colcache (rank-1 updates of the chain's agg1 cache, one MFMA product of
+  // the live rows), the general live-row record; past N steps the general kernel
+  bool col_ok = false;
+  int64_t cached_steps = 0, chain_steps = 0, rolled_steps = 0, col_steps = 0;
   at::Tensor cH, cA, cX, wimg, abits;
+  at::Tensor kA, kR;   // the column-write chain's caches: agg1 [B,N,F], root [B,N,H1]
   at::Tensor rH, rA, rX;   // the ring caches of the steady-state steps (copies: the first N records keep reading cH / cA / cX)
   std::shared_ptr<DxChain> dxc;
   std::shared_ptr<DxGateNode> dx_gate;
@@ -717,8 +723,8 @@ struct RowsFast {
         node->start_dx();
       }
     }
-    chain_steps = cached_steps = rolled_steps = 0;
-    cH = cA = cX = rH = rA = rX = abits = at::Tensor();
+    chain_steps = cached_steps = rolled_steps = col_steps = 0;
+    cH = cA = cX = rH = rA = rX = abits = kA = kR = at::Tensor();
     // (a distance selector's decisions reach the cached step as a row: no hop table to rebuild the live rows from
     //  in the observation-gradient launch - those chains stay on the general kernel)
     cache_ok = fresh && donate && dx_kind != 2 && !(cfg->has_distance && dx_kind != 0) &&
@@ -735,7 +741,53 @@ struct RowsFast {
               cfg->descs[0].mode == GCM_DIST_EUCLID_CROSSBATCH && !cfg->descs[0].bidirectional &&
               cfg->descs[0].dist_param == nullptr && cfg->descs[0].cur_rows == nullptr && !(cfg->has_bias & ~3) &&
               !(cfg->cached_flags & GCM_STEP_TWO_LAUNCH);
+    col_ok = !cache_ok && fresh && donate && dx_kind == 0 && !cfg->has_distance && cfg->col_cache &&
+             gcm_dense_rows_colcache_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
+                                               cfg->has_bias, cfg->N, cfg->F, cfg->H1, cfg->H2) != 0;
     armed = true;
+  }
+
+  // a step of a chain whose selectors write column cur too (see col_ok): one launch, the general live-row record
+  at::Tensor launch_colcache(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
+                             const at::Tensor& weights, const at::Tensor& count_in) {
+    const int64_t B = obs.size(0);
+    const int N = cfg->N, F = cfg->F, H1 = cfg->H1, H2 = cfg->H2;
+    const bool need_bwd = node != nullptr;
+    if (cached_steps == 0) {   // (uninitialised: a row is read only after the step that wrote it)
+      kA = at::empty({B, N, F}, obs.options());
+      kR = at::empty({B, N, H1}, obs.options());
+    }
+    size_t lay[8];
+    check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
+    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
+    check(gcm_dense_rows_step_colcache(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                       count_in.data_ptr<int64_t>(), cfg->descs.data(), (int)cfg->descs.size(),
+                                       packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
+                                       kA.data_ptr<float>(), kR.data_ptr<float>(), buf.data_ptr<float>(),
+                                       need_bwd ? 1 : 0, (int)cached_steps,
+                                       reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
+          "gcm_dense_rows_step_colcache");
+    at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
+    if (need_bwd) {
+      const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
+      RowsChainNode::Rec r{buf, vc, vc.current_version()};   // (cached = false: its rows travel in the record)
+      r.out_mx = (int)node->num_inputs();
+      torch::autograd::create_gradient_edge(mx, node);
+      node->recs.push_back(std::move(r));
+    }
+    l_nodes = nodes_in;
+    l_adj = adj_in;
+    l_weights = weights;
+    l_count = count_in;
+    note_versions();
+    xB = B;
+    xF = obs.size(1);
+    ++n_steps;
+    ++chain_steps;
+    ++cached_steps;
+    ++col_steps;
+    return mx;
   }
 
   // the steady-state step of an EuclideanEdge chain (see ring_ok): one launch, the general live-row record
@@ -913,7 +965,10 @@ struct RowsFast {
       if (roll_ok && cached_steps < (int64_t)0x7fffffff) return launch_cached_roll(obs, nodes_in, adj_in, weights, count_in);
       if (ring_ok && abits.defined()) return launch_ring(obs, nodes_in, adj_in, weights, count_in);
     }
-    cache_ok = false;
+    if (col_ok && cached_steps == chain_steps && cached_steps < N &&
+        (cached_steps == 0 || (kA.size(0) == B && state_untouched())))
+      return launch_colcache(obs, nodes_in, adj_in, weights, count_in);
+    cache_ok = col_ok = false;
     ++chain_steps;
     const bool need_bwd = node != nullptr || dxc != nullptr;
     size_t lay[8];
@@ -2673,6 +2728,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("handle", [](StepCfg& c) { return reinterpret_cast<int64_t>(&c); })
       .def("update_descs", &StepCfg::update_descs)
       .def("set_cached_flags", [](StepCfg& c, int f) { c.cached_flags = f; })
+      .def("set_col_cache", [](StepCfg& c, bool on) { c.col_cache = on; })
       .def("cached_launches", [](StepCfg& c, int B) {   // launches per cached step (0: no cached form)
         return gcm_dense_rows_cached_launches(c.descs.empty() ? nullptr : c.descs.data(), (int)c.descs.size(),
                                               c.has_bias | c.cached_flags, B, c.N, c.F, c.H1, c.H2);
@@ -2689,8 +2745,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("pending", &RowsFast::pending)
       .def("forget", &RowsFast::forget)
       .def("steps", [](RowsFast& f) { return f.n_steps; })
-      .def("cached_steps", [](RowsFast& f) { return f.cached_steps; })
+      .def("cached_steps", [](RowsFast& f) { return f.cached_steps - f.col_steps; })
       .def("rolled_steps", [](RowsFast& f) { return f.rolled_steps; })
+      .def("col_steps", [](RowsFast& f) { return f.col_steps; })
       .def("has_chain", [](RowsFast& f) { return f.node != nullptr || f.dxc != nullptr; });
   pybind11::class_<LearnedCfg>(m, "LearnedCfg")
       .def(pybind11::init<int, int, int, int, int, int, int, double, double, double>())

@@ -145,6 +145,10 @@ class DenseGCM(torch.nn.Module):
         # False: no cached live-row steps (csrc/rows_cached.hip: the first N steps of a rollout from empty graphs on a
         # donated state, forward-only TemporalBackedge selectors: row cur alone over per-chain caches) - A/B
         self.rows_cached_steps = True
+        # False: chains whose selectors also write COLUMN cur of the adjacency (DenseEdge; "backward" / "both" hops) stay
+        # on the general live-row kernel instead of the column-write cached step (csrc/rows_colcache.hip: rank-1
+        # updates of the chain's layer-1 aggregate, one matrix-core product of the live rows) - A/B tests
+        self.rows_col_cache = True
         # False: a cached EuclideanEdge chain as TWO launches per step (distance kernel, then the cached step) instead
         # of one (csrc/distance.hip: k_euclid_mfma2<.., TAIL>) - A/B tests; read when a chain is armed
         self.rows_one_launch_distance = True
@@ -207,6 +211,14 @@ class DenseGCM(torch.nn.Module):
         for cfg in self._cfg_cache.values():
             if cfg is not False and cfg._rows_fast is not None:
                 n += cfg._rows_fast.cached_steps()
+        return n
+
+    def rows_col_steps_taken(self):
+        """... of which column-write cached steps (gcm_dense_rows_step_colcache: DenseEdge / backward hops)."""
+        n = 0
+        for cfg in self._cfg_cache.values():
+            if cfg is not False and cfg._rows_fast is not None:
+                n += cfg._rows_fast.col_steps()
         return n
 
     def rows_rolled_steps_taken(self):
@@ -628,6 +640,7 @@ class DenseGCM(torch.nn.Module):
                 cfg._cpp.set_cached_flags(
                     (0 if (self.rows_one_launch_distance or not cfg.has_distance) else _hip.STEP_TWO_LAUNCH)
                     | (_hip.STEP_IMG_V4 if self.rows_weight_image_v4 else 0))
+                cfg._cpp.set_col_cache(bool(self.rows_col_cache))
         mx, n2, a2, c2, donate = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(),
                                           self.donate_state, need_dx, bool(fresh and self.rows_cached_steps))
         if donate:

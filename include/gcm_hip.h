@@ -671,6 +671,27 @@ int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, const gcm_se
                                     float* cache_h1, float* cache_agg1, float* cache_nodes, float* saved, int record,
                                     int t_abs, uint32_t* flags, int B, int N, int F, int H1, int H2,
                                     gcm_stream_t stream);
+/* The cached step for selector chains that also write COLUMN cur of the adjacency (round 6): DenseEdge
+ * (edge_selectors/dense.py:16-21) and TemporalBackedge with direction "backward" / "both"
+ * (edge_selectors/temporal.py:82-87) - alone or chained with forward hops.  Same preconditions as
+ * gcm_dense_rows_step_cached (a chain from EMPTY graphs on a donated state, fewer than N steps made), plus cur_host >= 0
+ * is required (every graph of such a chain holds cur_host nodes).  A column write is a rank-1 correction of the older
+ * rows' layer-1 aggregate (agg1[j] += x[cur]), so the chain keeps cache_agg1 [B,N,F] (agg1 of every node) and
+ * cache_root [B,N,H1] (W_root1 x[j] + b1, final once written) - both uninitialised at the chain's head - and a step is
+ * the masked column sum for the new row, the rank-1 update, ONE [rows x F] . [F x H1] product of the live rows on the
+ * fp32 matrix cores and layer 2 on row cur: cur F + 2 cur F H1 flops per graph where the general live-row kernel
+ * re-aggregates cur^2 F.  The state (nodes, adj, count) is advanced IN PLACE; a graph whose count differs from cur_host
+ * is left untouched and raises GCM_FLAG_BAD_COUNT.  saved: the GENERAL live-row record (gcm_dense_rows_layout; mx [B,H2]
+ * at 0 - always written; the rest with record != 0), read by gcm_dense_rows_bptt.  F, H1 in {32, 64}, H2 <= 64,
+ * N <= 128, has_bias without fold bits; _supported also returns 0 for chains that never write a column (they have
+ * gcm_dense_rows_step_cached). */
+int gcm_dense_rows_colcache_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
+                                      int F, int H1, int H2);
+int gcm_dense_rows_step_colcache(const float* obs, float* nodes, float* adj, int64_t* count,
+                                 const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                 int has_bias, int act1, int act2, float* cache_agg1, float* cache_root, float* saved,
+                                 int record, int cur_host, uint32_t* flags, int B, int N, int F, int H1, int H2,
+                                 gcm_stream_t stream);
 int gcm_edge_distance_step_cached_supported(int n_cur_rows, int B, int N, int F, int H1, int H2);
 /* -> the number of kernel launches ONE call of gcm_dense_rows_step_cached_ws makes for these arguments (0: not
  * supported; 1: forward temporal hops, or EuclideanEdge alone in the one-launch form; 2: a distance selector's kernel,

@@ -730,6 +730,97 @@ def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
             assert float((gd.double() - g64).abs().max()) <= atol, k
 
 
+@pytest.mark.parametrize("sel,B,N,F,H1,H2,T", [(("dense", None, None), 5, 16, 32, 32, 32, 40),
+                                               (("dense", None, None), 3, 128, 32, 32, 32, 140),
+                                               (("temporal", [1, 2, 4], "both"), 4, 32, 32, 32, 32, 50),
+                                               (("temporal", [1, 3], "backward"), 4, 24, 64, 32, 48, 30),
+                                               (("temporal", [0, 2], "both"), 3, 20, 32, 64, 16, 26),
+                                               (("dense", None, None), 2, 64, 64, 64, 64, 70),
+                                               (("temporal", [1, 2, 4], "both"), 300, 128, 32, 32, 32, 20),
+                                               (("dense", None, None), 3, 16, 8, 16, 16, 20)])   # (widths without the form)
+def test_rows_colcache_steps_vs_oracle(sel, B, N, F, H1, H2, T):
+    """A donated rollout from hidden = None whose selectors also write COLUMN cur of the adjacency - DenseEdge
+    (dense.py:16-21), TemporalBackedge "backward" / "both" (temporal.py:82-87): its first N steps are column-write
+    cached steps (rows_colcache.hip: rank-1 updates of the chain's layer-1 aggregate, one matrix-core product of the
+    live rows), the steps behind them the usual live-row ones; one backward over both kinds of record.  Against the
+    oracle (state bit exact, beliefs and gradients inside the float64 bound) and against the same rollout with the
+    form switched off."""
+    res = []
+    obs = None
+    takes = F in (32, 64) and H1 in (32, 64)
+    for on in (True, False):
+        torch.manual_seed(N + T)
+        ref, g, mem, osel = _mk(B, N, F, H1, H2, sel, True)
+        mem.rows_col_cache = on
+        obs = torch.rand(T, B, F) - 0.5
+        w = torch.rand(T, B, H2)
+        hid, outs = None, []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+        assert mem.rows_steps() == T
+        assert mem.rows_col_steps_taken() == (min(T, N) if on and takes else 0)
+        assert mem.rows_cached_steps_taken() == 0
+        out = torch.stack(outs)
+        (out * w.to(DEV)).sum().backward()
+        mem.check_flags()
+        res.append((out.detach().cpu(), [t.cpu() for t in (hid[0], hid[1], hid[3])],
+                    {k: p.grad.cpu().clone() for k, p in g.named_parameters()}, ref, osel, w))
+    ref, osel, w = res[0][3], res[0][4], res[0][5]
+    if B > 16:      # (the oracle on a slice of the batch: graphs are independent)
+        pick = [0, B // 2, B - 1]
+        wz = torch.zeros_like(w)
+        wz[:, pick] = w[:, pick]
+        res2 = []
+        for on in (True, False):
+            torch.manual_seed(N + T)
+            _, g, mem, _ = _mk(B, N, F, H1, H2, sel, True)
+            mem.rows_col_cache = on
+            hid, outs = None, []
+            for t in range(T):
+                mx, hid = mem(obs[t].to(DEV), hid)
+                outs.append(mx)
+            (torch.stack(outs) * wz.to(DEV)).sum().backward()
+            res2.append((torch.stack(outs).detach().cpu()[:, pick], [t.cpu()[pick] for t in (hid[0], hid[1], hid[3])],
+                         {k: p.grad.cpu().clone() for k, p in g.named_parameters()}))
+        res, obs, w = res2, obs[:, pick], w[:, pick]
+    out32, hid32, bounds, (out64, out_atol) = _fp64_rollout_bounds(ref, obs, None, w, lambda: osel, N)
+    for out, state, grads, *_ in res:
+        assert torch.equal(state[0], hid32[0]) and torch.equal(state[1], hid32[1]) and torch.equal(state[2], hid32[3])
+        assert float((out.double() - out64).abs().max()) <= out_atol
+        for k, gd in grads.items():
+            g64, atol = bounds[k]
+            assert float((gd.double() - g64).abs().max()) <= atol, k
+
+
+def test_rows_colcache_leaves_an_edited_chain():
+    """A caller that edits the donated state in place between two steps (zeroing the graphs of finished episodes) ends
+    the column-write cached run: the next step is the general live-row kernel on the state as it is."""
+    torch.manual_seed(5)
+    B, N, F, H = 4, 32, 32, 32
+    ref, g, mem, osel = _mk(B, N, F, H, H, ("dense", None, None), True)
+    obs = torch.rand(12, B, F)
+    hid = None
+    with torch.no_grad():
+        for t in range(6):
+            _, hid = mem(obs[t].to(DEV), hid)
+        assert mem.rows_col_steps_taken() == 6
+        hid[0][1].zero_(); hid[1][1].zero_(); hid[3][1] = 0          # graph 1 starts a new episode
+        outs = []
+        for t in range(6, 12):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+        assert mem.rows_col_steps_taken() == 6 and mem.rows_steps() == 12
+    mem.check_flags()
+    h_o = None
+    out_a, h_o = od.dense_rollout(obs[:6], None, ref, graph_size=N, edge_selectors=osel)
+    h_o = tuple(t.clone() for t in h_o)
+    h_o[0][1].zero_(); h_o[1][1].zero_(); h_o[3][1] = 0
+    out_b, h_o = od.dense_rollout(obs[6:], h_o, ref, graph_size=N, edge_selectors=osel)
+    torch.testing.assert_close(torch.stack(outs).cpu(), out_b.detach(), rtol=1e-5, atol=5e-6)
+    assert torch.equal(hid[1].cpu(), h_o[1]) and torch.equal(hid[0].cpu(), h_o[0]) and torch.equal(hid[3].cpu(), h_o[3])
+
+
 @pytest.mark.parametrize("hops,B,N,F,H,T", [([1, 2, 4], 6, 16, 32, 32, 30), ([0, 1, 3], 3, 128, 32, 32, 130),
                                             ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10], 2, 24, 64, 32, 24)])
 def test_rows_cached_steps_with_obs_gradient(hops, B, N, F, H, T):
