@@ -30,6 +30,13 @@
 #include "fused_common.h"
 #include "rows_common.h"
 
+#ifdef GCM_STAMPS   // diagnostic build only (make stamps11, tools/kstamp_colcache.py)
+__device__ unsigned long long g_stamps[32];
+extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 namespace gcm_rows {
 
 using gcm_fused::acc_row;
@@ -38,6 +45,10 @@ using gcm_fused::Gnn2;
 struct RowMask {
   unsigned long long lo, hi;
 };
+// bits [32 w, 32 w + 32) of the mask (w compile-time or wave-uniform: scalar code)
+__device__ __forceinline__ unsigned mword(const RowMask& m, int w) {
+  return (unsigned)((w & 2 ? m.hi : m.lo) >> ((w & 1) * 32));
+}
 __device__ __forceinline__ bool mbit(const RowMask& m, int j) {
   return ((j < 64 ? m.lo >> j : m.hi >> (j - 64)) & 1ull) != 0;
 }
@@ -46,6 +57,9 @@ __device__ __forceinline__ int mrank(const RowMask& m, int j) {
   if (j < 64) return __popcll(m.lo & ((1ull << j) - 1ull));
   return __popcll(m.lo) + __popcll(m.hi & ((1ull << (j - 64)) - 1ull));
 }
+// LDS exchange between the waves of the workgroup: waits for this wave's LDS operations only - __syncthreads() also
+// drains the wave's global loads and STORES (vmcnt(0)), which here would put every barrier behind the record's stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int FK, int HK, int O2T>
 __global__ __launch_bounds__(256) void k_step_colcache(
@@ -54,20 +68,23 @@ __global__ __launch_bounds__(256) void k_step_colcache(
     float* __restrict__ cR, float* __restrict__ saved, const SavedLayout lay, uint32_t* __restrict__ flags,
     const int N, const int H2) {
   constexpr int C4 = FK / 4;       // 16-byte pieces of a node row
-  constexpr int RG = 256 / C4;     // node rows per pass of the workgroup
+  constexpr int RG = 256 / C4;     // node rows per pass of the workgroup (32 or 16)
   constexpr int XP = 128 / RG;     // node rows per thread
   constexpr int KH = FK / 2;       // k per half-wave
   constexpr int KQ = KH / 4;
   constexpr int CT = HK / 32;      // 32-column tiles of layer 1
   constexpr int PS = FK + 4;       // stride of the partial-sum image
-  __shared__ float sPart[RG * PS];
+  constexpr int SPLIT = 64 / FK;   // lanes per feature in the row-group sum (2 or 1)
+  constexpr int GP = RG / SPLIT;   // row groups per lane there (16)
+  __shared__ __attribute__((aligned(16))) float sPart[RG * PS];
   __shared__ __attribute__((aligned(16))) float sAggc[FK];
   __shared__ float sRcur[HK];
   __shared__ __attribute__((aligned(16))) float sV[2 * HK];
-  __shared__ double sA2[4 * HK];
+  __shared__ float sA2[4 * HK];
 
   const int b = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t gb = (size_t)b;
   float* ng = nodes + gb * N * FK;
   float* ag = adj + gb * N * N;
@@ -76,8 +93,10 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   const bool rec = lay.total != 0;
   const int rw = lay.rw;
   float* sv_rows = saved + lay.o_rows + gb * N * rw;
+  const bool tile_on = 32 * wave <= cur;          // wave-uniform: this wave's 32 rows hold a row <= cur
 
-  // ---- every load of the step, before anything waits -----------------------------------------------------------
+  STAMP(0);
+  // ---- every load of the step, in the order of use, before anything waits ------------------------------------------
   const int64_t n_in = count[b];
   // node rows, one 16-byte piece per (row group, piece) thread: the new row's aggregate and the record's x section
   const int c4 = tid % C4, rg = tid / C4;
@@ -85,45 +104,52 @@ __global__ __launch_bounds__(256) void k_step_colcache(
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
     const int row = rg + RG * i;
-    xr[i] = *reinterpret_cast<const f32x4*>(ng + (row < N ? row : N - 1) * FK + 4 * c4);
+    if (RG * i <= cur)   // (uniform: passes beyond the stored rows are skipped)
+      xr[i] = *reinterpret_cast<const f32x4*>(ng + (row < N ? row : N - 1) * FK + 4 * c4);
+    else
+      xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const f32x4 obq = *reinterpret_cast<const f32x4*>(obs + gb * FK + 4 * c4);
-  // the A operand: row r = 32 wave + li, k in [lh KH, (lh + 1) KH) - agg1 of the stored rows from the chain's cache
-  const int r = 32 * wave + li;
-  const int rc = r < N ? r : N - 1;
-  const bool tile_on = 32 * wave <= cur;          // wave-uniform: this wave's 32 rows hold a row <= cur
-  f32x4 ca[KQ], xa[KQ];
+  // the observation as the A-operand lanes hold a row: k in [lh KH, (lh + 1) KH)
+  f32x4 xa[KQ];
 #pragma unroll
-  for (int q = 0; q < KQ; ++q) {
-    ca[q] = *reinterpret_cast<const f32x4*>(cAg + rc * FK + lh * KH + 4 * q);
-    xa[q] = *reinterpret_cast<const f32x4*>(obs + gb * FK + lh * KH + 4 * q);
-  }
-  // the B operand: W_rel1[col][k], col = 32 ct + li, the same k
-  f32x4 wb[CT][KQ];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int q = 0; q < KQ; ++q)
-      wb[ct][q] = *reinterpret_cast<const f32x4*>(P.w_rel1 + (32 * ct + li) * FK + lh * KH + 4 * q);
-  // root[j][col] of the rows this lane's accumulators hold
-  float crv[CT][16];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = 32 * wave + acc_row(i, lh);
-      crv[ct][i] = cRg[(row < N ? row : N - 1) * HK + 32 * ct + li];
-    }
-  // wave 3: W_root1 (the new node's root row);  wave 0: layer 2
+  for (int q = 0; q < KQ; ++q) xa[q] = *reinterpret_cast<const f32x4*>(obs + gb * FK + lh * KH + 4 * q);
+  // wave 3: W_root1 (the new node's root row)
   f32x4 wr[CT][KQ];
   float b1v[CT];
+  if (wave == 3) {
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q)
-      wr[ct][q] = *reinterpret_cast<const f32x4*>(P.w_root1 + (32 * ct + li) * FK + lh * KH + 4 * q);
-    b1v[ct] = P.b_rel1[32 * ct + li];
+      for (int q = 0; q < KQ; ++q)
+        wr[ct][q] = *reinterpret_cast<const f32x4*>(P.w_root1 + (32 * ct + li) * FK + lh * KH + 4 * q);
+      b1v[ct] = P.b_rel1[32 * ct + li];
+    }
   }
+  // the A operand: row r = 32 wave + li, k in [lh KH, (lh + 1) KH) - agg1 of the stored rows from the chain's cache;
+  // the B operand: W_rel1[col][k], col = 32 ct + li, the same k; root[j][col] of the rows the accumulators hold
+  const int r = 32 * wave + li;
+  const int rc = r < N ? r : N - 1;
+  f32x4 ca[KQ], wb[CT][KQ], crq[CT][4];
+  const int NQ = N >> 2;   // the root cache is kept in quads of rows: cR[b][row / 4][col][row % 4] (one 16-byte load
+                           // per four accumulator rows of a lane)
+  if (tile_on) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) ca[q] = *reinterpret_cast<const f32x4*>(cAg + rc * FK + lh * KH + 4 * q);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        wb[ct][q] = *reinterpret_cast<const f32x4*>(P.w_rel1 + (32 * ct + li) * FK + lh * KH + 4 * q);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {   // rows 8 q4 + 4 lh + (0 .. 3) of the tile: one quad of the root cache
+        const int quad = 8 * wave + 2 * q4 + lh;
+        crq[ct][q4] = *reinterpret_cast<const f32x4*>(cRg + ((quad < NQ ? quad : NQ - 1) * HK + 32 * ct + li) * 4);
+      }
+  }
+  // wave 0: layer 2
   f32x4 w2[O2T][HK / 4];
   float b2v[O2T];
   if (wave == 0) {
@@ -136,8 +162,9 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       b2v[ot] = P.b_rel2[o];
     }
   }
-  const int act1_v = gcm_vgpr(P.act1), act2_v = gcm_vgpr(P.act2);
+  const int act1 = P.act1, act2 = P.act2;
   asm volatile("" ::: "memory");
+  STAMP(1);
 
   // A chain from empty graphs holds `cur` nodes in every graph; anything else (a caller edited the count) leaves the
   // graph untouched and raises the flag (uniform per workgroup: nothing has been stored yet)
@@ -145,22 +172,33 @@ __global__ __launch_bounds__(256) void k_step_colcache(
     if (tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);
     return;
   }
-  const bool self = mbit(srow, cur);
-  // position of stored row j (< cur) in the record's live list: slot 0 is row cur, the others ascending
-  auto slot_of = [&](int j) { return 1 + mrank(srow, j); };
+  STAMP(2);
+  // the masks as four 32-row words (scalars) and the live-list position of each word's first row: slot 0 is row cur,
+  // the stored live rows follow in ascending order
+  const unsigned sw0 = mword(srow, 0), sw1 = mword(srow, 1), sw2 = mword(srow, 2), sw3 = mword(srow, 3);
+  const unsigned selfbit = mbit(srow, cur) ? 1u : 0u;
+  const int pc1 = 1 + __popc(sw0), pc2 = pc1 + __popc(sw1), pc3 = pc2 + __popc(sw2);
+  const int L = pc3 + __popc(sw3) - (int)selfbit;   // row cur + the stored sources
+  auto sword = [&](int w) { return w == 0 ? sw0 : (w == 1 ? sw1 : (w == 2 ? sw2 : sw3)); };
+  auto sbase = [&](int w) { return w == 0 ? 1 : (w == 1 ? pc1 : (w == 2 ? pc2 : pc3)); };
 
   // ---- the new row's aggregate: sum of the selected node rows, ascending inside a thread, then over the row groups
   {
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
+      if (RG * i > cur) continue;   // uniform
       const int row = rg + RG * i;
+      const int w = (RG * i) >> 5, bit = row & 31;     // w: compile time
+      const unsigned word = sword(w);
       const bool is_cur = row == cur;
       const f32x4 v = is_cur ? obq : xr[i];
-      const bool src = row <= cur && mbit(srow, row);
+      const bool src = ((word >> bit) & 1u) != 0;      // (bits beyond cur are never set)
       if (src) part += v;
-      if (rec && (is_cur || (row < cur && src)))
-        *reinterpret_cast<f32x4*>(sv_rows + (size_t)(is_cur ? 0 : slot_of(row)) * rw + HK + FK + 4 * c4) = v;
+      if (rec && (is_cur || src)) {
+        const unsigned slot = is_cur ? 0u : (unsigned)sbase(w) + (unsigned)__popc(word & ((1u << bit) - 1u));
+        *reinterpret_cast<f32x4*>(sv_rows + slot * (unsigned)rw + HK + FK + 4 * c4) = v;
+      }
     }
     *reinterpret_cast<f32x4*>(sPart + rg * PS + 4 * c4) = part;
   }
@@ -180,71 +218,127 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       const float v = t + b1v[ct];
       if (lh == 0) {
         sRcur[32 * ct + li] = v;
-        cRg[cur * HK + 32 * ct + li] = v;
+        cRg[((cur >> 2) * HK + 32 * ct + li) * 4 + (cur & 3)] = v;
       }
     }
   }
-  __syncthreads();   // #1
-  if (tid < FK) {
+  STAMP(3);
+  lds_barrier();   // #1
+  STAMP(4);
+  if (wave == 2) {   // the row groups' partial sums -> agg1[cur]: lane (feature, part) takes GP groups
+    const int f = lane % FK, part = lane / FK;
+    float v[GP];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) v[g] = sPart[(part * GP + g) * PS + f];
     float s = 0.f;
-#pragma unroll 8
-    for (int g = 0; g < RG; ++g) s += sPart[g * PS + tid];
-    sAggc[tid] = s;
-    cAg[cur * FK + tid] = s;
-    if (rec) sv_rows[HK + tid] = s;
+#pragma unroll
+    for (int g = 0; g < GP; ++g) s += v[g];
+    if (SPLIT == 2) s += __shfl_xor(s, 32);
+    if (part == 0) {
+      sAggc[f] = s;
+      cAg[cur * FK + f] = s;
+      if (rec) sv_rows[HK + f] = s;
+    }
   }
-  __syncthreads();   // #2
+  lds_barrier();   // #2
+  STAMP(5);
 
   // ---- layer 1 of the live rows: [32 rows x F] . [F x H1] per wave ------------------------------------------------
   if (tile_on) {
-    const bool stored = r < cur;
-    const bool upd = stored && mbit(scol, r);        // the row gains the source cur
-    const bool lrow = stored && mbit(srow, r);       // a stored live row
-    float a[KH];
+    const unsigned sr_t = sword(wave), sc_t = mword(scol, wave);   // scalars
+    const int rb = sbase(wave);
+    const int cur_bit = cur - 32 * wave;                            // row cur inside this tile: 0 .. 31
+    {
+      const bool upd = ((sc_t >> li) & 1u) != 0;        // the row gains the source cur (stored rows only)
+      const bool lrow = ((sr_t >> li) & 1u) != 0 && li != cur_bit;   // a stored live row
+      const int slot = rb + __popc(sr_t & ((1u << li) - 1u));
+      float* rdst = sv_rows + (unsigned)slot * (unsigned)rw + HK + lh * KH;
+      float a[KH];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      f32x4 v = ca[q];
-      if (upd) {
-        v += xa[q];
-        *reinterpret_cast<f32x4*>(cAg + r * FK + lh * KH + 4 * q) = v;
+      for (int q = 0; q < KQ; ++q) {
+        f32x4 v = ca[q];
+        if (upd) {
+          v += xa[q];
+          *reinterpret_cast<f32x4*>(cAg + r * FK + lh * KH + 4 * q) = v;
+        }
+        if (li == cur_bit) v = *reinterpret_cast<const f32x4*>(sAggc + lh * KH + 4 * q);
+        if (rec && lrow) *reinterpret_cast<f32x4*>(rdst + 4 * q) = v;
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
       }
-      if (r == cur) v = *reinterpret_cast<const f32x4*>(sAggc + lh * KH + 4 * q);
-      if (rec && lrow) *reinterpret_cast<f32x4*>(sv_rows + (size_t)slot_of(r) * rw + HK + lh * KH + 4 * q) = v;
-      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-    }
-    f32x16 acc[CT];
+      STAMP(6);
+      f32x16 acc[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < KH; ++s)
+      for (int s = 0; s < KH; ++s)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const f32x4 w = wb[ct][s >> 2];
-        const float wv = (s & 3) == 0 ? w.x : ((s & 3) == 1 ? w.y : ((s & 3) == 2 ? w.z : w.w));
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wv, acc[ct], 0, 0, 0);
-      }
+        for (int ct = 0; ct < CT; ++ct) {
+          const f32x4 w = wb[ct][s >> 2];
+          const float wv = (s & 3) == 0 ? w.x : ((s & 3) == 1 ? w.y : ((s & 3) == 2 ? w.z : w.w));
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wv, acc[ct], 0, 0, 0);
+        }
+      STAMP(7);
+      // the activation, this lane's part of agg2, h1[cur], the record's h1 rows.  One wave = one instruction stream:
+      // the activation is a uniform branch around the loop (not selects inside it), positions come from the tile's
+      // mask word
+      auto epilogue = [&](auto actf) {
+        const unsigned live_t = sr_t | (cur_bit < 32 ? 1u << cur_bit : 0u);   // (scalar) rows of the tile with a record row
+        const unsigned srl = lh ? sr_t >> 4 : sr_t;   // bit c: the source bit of this lane's row c + 4 lh
+        const bool cur_lane = cur_bit < 32 && ((cur_bit >> 2) & 1) == lh;   // row cur sits in this lane's accumulators
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      double a2 = 0.0;   // agg2[col] over this lane's rows (fp64: up to N terms, as in k_step_rows)
+        for (int ct = 0; ct < CT; ++ct) {
+          const float rcur = sRcur[32 * ct + li];
+          float a2 = 0.f, hc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 32 * wave + acc_row(i, lh);
-        const bool is_cur = row == cur;
-        const float pre = acc[ct][i] + (is_cur ? sRcur[32 * ct + li] : crv[ct][i]);
-        const float h = gcm_act_sel(pre, act1_v);
-        const bool src = row <= cur && mbit(srow, row);
-        a2 += src ? (double)h : 0.0;
-        if (is_cur) sV[HK + 32 * ct + li] = h;
-        if (rec && (is_cur || (row < cur && src)))
-          sv_rows[(size_t)(is_cur ? 0 : slot_of(row)) * rw + 32 * ct + li] = h;
-      }
-      a2 += __shfl_xor(a2, 32);
-      if (lh == 0) sA2[wave * HK + 32 * ct + li] = a2;
+          for (int q4 = 0; q4 < 4; ++q4) {
+            if (((live_t >> (8 * q4)) & 0xffu) == 0u) continue;   // uniform: no live row among rows 8 q4 .. 8 q4 + 7
+            // record position (in floats) of this lane's first stored live row of the block; the next ones follow
+            const unsigned below = lh ? (1u << (8 * q4 + 4)) - 1u : (1u << (8 * q4)) - 1u;
+            unsigned off = ((unsigned)rb + (unsigned)__popc(sr_t & below)) * (unsigned)rw + 32u * ct + (unsigned)li;
+            const f32x4 rq = crq[ct][q4];
+            if ((cur_bit >> 3) == q4) {   // uniform: the block that holds row cur (its root row from LDS, no record row here)
+#pragma unroll
+              for (int ii = 0; ii < 4; ++ii) {
+                const bool is_cur = 8 * q4 + ii + 4 * lh == cur_bit;
+                const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
+                const float h = actf(acc[ct][4 * q4 + ii] + (is_cur ? rcur : rr));
+                const bool src = ((srl >> (8 * q4 + ii)) & 1u) != 0;
+                a2 += src ? h : 0.f;
+                hc = is_cur ? h : hc;
+                const bool stored = src && !is_cur;
+                if (rec && stored) sv_rows[off] = h;
+                off += stored ? (unsigned)rw : 0u;
+              }
+            } else {
+#pragma unroll
+              for (int ii = 0; ii < 4; ++ii) {
+                const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
+                const float h = actf(acc[ct][4 * q4 + ii] + rr);
+                const bool src = ((srl >> (8 * q4 + ii)) & 1u) != 0;
+                a2 += src ? h : 0.f;
+                if (rec && src) sv_rows[off] = h;
+                off += src ? (unsigned)rw : 0u;
+              }
+            }
+          }
+          a2 += __shfl_xor(a2, 32);
+          if (lh == 0) sA2[wave * HK + 32 * ct + li] = a2;
+          if (cur_lane) {
+            sV[HK + 32 * ct + li] = hc;
+            if (rec) sv_rows[32 * ct + li] = hc;   // slot 0: row cur
+          }
+        }
+      };
+      if (act1 == GCM_ACT_TANH) epilogue([](float v) { return gcm_tanh(v); });
+      else if (act1 == GCM_ACT_RELU) epilogue([](float v) { return v > 0.f ? v : 0.f; });
+      else epilogue([](float v) { return v; });
     }
   }
-  __syncthreads();   // #3
+  STAMP(8);
+  lds_barrier();   // #3
+  STAMP(9);
 
   // ---- layer 2 on row cur (wave 0); the donated state (the other waves) ---------------------------------------------
   if (wave == 0) {
@@ -252,8 +346,8 @@ __global__ __launch_bounds__(256) void k_step_colcache(
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       if (lh == 0) {
-        double t = sA2[32 * ct + li];
-        for (int w = 1; w <= wmax; ++w) t += sA2[w * HK + 32 * ct + li];
+        double t = (double)sA2[32 * ct + li];
+        for (int w = 1; w <= wmax; ++w) t += (double)sA2[w * HK + 32 * ct + li];
         sV[32 * ct + li] = (float)t;
       }
     }
@@ -274,27 +368,27 @@ __global__ __launch_bounds__(256) void k_step_colcache(
         t = fmaf(w2[ot][q].w, x4.w, t);
       }
       t += __shfl_xor(t, 32);
-      const float y = gcm_act_sel(t + b2v[ot], act2_v);
+      const float y = gcm_act(t + b2v[ot], act2);
       const int o = 32 * ot + li;
       const bool mine = lh == 0 && o < H2;
       if (mine) saved[gb * H2 + o] = y;   // (the record starts with the belief states: mx IS saved[0 .. B H2))
       bad |= mine && !isfinite(y);
     }
     if (__any(bad) && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+    STAMP(10);
     if (rec) {
       for (int k = lane; k < 2 * HK; k += 64) saved[lay.o_v + gb * 2 * HK + k] = sV[k];
       if (lane == 0) {
         int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * b;
-        const int L = 1 + mrank(srow, cur);
         hdr[0] = L; hdr[1] = 0; hdr[2] = cur; hdr[3] = 0;
       }
     }
+    STAMP(11);
   } else {
     const int t2 = tid - 64;   // 0 .. 191
     if (rec) {   // coef: adj[cur, j_l] - the self edge for slot 0, one for every other live row
-      const int L = 1 + mrank(srow, cur);
       float* cf = saved + lay.o_coef + gb * N;
-      for (int l = t2; l < L; l += 192) cf[l] = l == 0 ? (self ? 1.f : 0.f) : 1.f;
+      for (int l = t2; l < L; l += 192) cf[l] = l == 0 ? (selfbit ? 1.f : 0.f) : 1.f;
     }
     for (int j = t2; j <= cur; j += 192) {
       if (mbit(srow, j)) ag[cur * N + j] = 1.f;              // row cur (temporal.py:76-81, dense.py:18,20)
@@ -345,7 +439,7 @@ static bool colcache_masks(const gcm_selector_desc* selectors, int n_selectors, 
 
 extern "C" int gcm_dense_rows_colcache_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
                                                  int N, int F, int H1, int H2) {
-  if (N <= 0 || N > 128 || !(F == 32 || F == 64) || !(H1 == 32 || H1 == 64) || H2 <= 0 || H2 > 64) return 0;
+  if (N <= 0 || N > 128 || (N & 3) || !(F == 32 || F == 64) || !(H1 == 32 || H1 == 64) || H2 <= 0 || H2 > 64) return 0;
   if (has_bias & ~3) return 0;   // (no folded preprocessor / positional encoding, no observation-gradient record)
   if (n_selectors <= 0 || !selectors) return 0;
   gcm_rows::RowMask a, c;

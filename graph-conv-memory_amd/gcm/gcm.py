@@ -148,7 +148,7 @@ class DenseGCM(torch.nn.Module):
         # False: chains whose selectors also write COLUMN cur of the adjacency (DenseEdge; "backward" / "both" hops) stay
         # on the general live-row kernel instead of the column-write cached step (csrc/rows_colcache.hip: rank-1
         # updates of the chain's layer-1 aggregate, one matrix-core product of the live rows) - A/B tests
-        self.rows_col_cache = True
+        self.rows_col_cache = os.environ.get("GCM_COL_CACHE", "1") == "1"
         # False: a cached EuclideanEdge chain as TWO launches per step (distance kernel, then the cached step) instead
         # of one (csrc/distance.hip: k_euclid_mfma2<.., TAIL>) - A/B tests; read when a chain is armed
         self.rows_one_launch_distance = True

@@ -677,7 +677,8 @@ int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, const gcm_se
  * gcm_dense_rows_step_cached (a chain from EMPTY graphs on a donated state, fewer than N steps made), plus cur_host >= 0
  * is required (every graph of such a chain holds cur_host nodes).  A column write is a rank-1 correction of the older
  * rows' layer-1 aggregate (agg1[j] += x[cur]), so the chain keeps cache_agg1 [B,N,F] (agg1 of every node) and
- * cache_root [B,N,H1] (W_root1 x[j] + b1, final once written) - both uninitialised at the chain's head - and a step is
+ * cache_root [B,N/4,H1,4] (W_root1 x[j] + b1 in quads of rows, final once written; chain-internal layout) - both
+ * uninitialised at the chain's head - and a step is
  * the masked column sum for the new row, the rank-1 update, ONE [rows x F] . [F x H1] product of the live rows on the
  * fp32 matrix cores and layer 2 on row cur: cur F + 2 cur F H1 flops per graph where the general live-row kernel
  * re-aggregates cur^2 F.  The state (nodes, adj, count) is advanced IN PLACE; a graph whose count differs from cur_host
