@@ -27,6 +27,8 @@
 // (slot 0 = row cur, then the other live rows ascending), read by k_bptt_rows<.., 0> unchanged.
 //
 // One workgroup (4 waves) per graph.  F, H1 in {32, 64}, H2 <= 64, N <= 128.
+#include <type_traits>
+
 #include "fused_common.h"
 #include "rows_common.h"
 
@@ -257,10 +259,9 @@ __global__ __launch_bounds__(256) void k_step_colcache(
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         f32x4 v = ca[q];
-        if (upd) {
-          v += xa[q];
-          *reinterpret_cast<f32x4*>(cAg + r * FK + lh * KH + 4 * q) = v;
-        }
+        const f32x4 xq = xa[q];
+        v += f32x4{upd ? xq.x : 0.f, upd ? xq.y : 0.f, upd ? xq.z : 0.f, upd ? xq.w : 0.f};
+        if (upd) *reinterpret_cast<f32x4*>(cAg + r * FK + lh * KH + 4 * q) = v;
         if (li == cur_bit) v = *reinterpret_cast<const f32x4*>(sAggc + lh * KH + 4 * q);
         if (rec && lrow) *reinterpret_cast<f32x4*>(rdst + 4 * q) = v;
         a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
@@ -283,10 +284,17 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       // the activation, this lane's part of agg2, h1[cur], the record's h1 rows.  One wave = one instruction stream:
       // the activation is a uniform branch around the loop (not selects inside it), positions come from the tile's
       // mask word
-      auto epilogue = [&](auto actf) {
+      // (One wave = one instruction stream, and a dependent VALU chain runs at about half its issue rate: the four
+      //  rows of a block are evaluated side by side and nothing in the loop branches - a row without a record row
+      //  stores into the record's unused `deg` section instead of being masked off.)
+      auto epilogue = [&](auto actf, auto recc) {
+        constexpr bool REC = decltype(recc)::value;
         const unsigned live_t = sr_t | (cur_bit < 32 ? 1u << cur_bit : 0u);   // (scalar) rows of the tile with a record row
         const unsigned srl = lh ? sr_t >> 4 : sr_t;   // bit c: the source bit of this lane's row c + 4 lh
         const bool cur_lane = cur_bit < 32 && ((cur_bit >> 2) & 1) == lh;   // row cur sits in this lane's accumulators
+        const unsigned dump = (unsigned)(lay.o_deg - lay.o_rows) + (unsigned)(b * N + (li < N ? li : N - 1));   // from sv_rows0
+        float* sv_rows0 = saved + lay.o_rows;   // (uniform base, 32-bit offsets: B N rw < 2^31 is checked by the host)
+        const unsigned gofs = (unsigned)b * (unsigned)N * (unsigned)rw;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const float rcur = sRcur[32 * ct + li];
@@ -296,30 +304,26 @@ __global__ __launch_bounds__(256) void k_step_colcache(
             if (((live_t >> (8 * q4)) & 0xffu) == 0u) continue;   // uniform: no live row among rows 8 q4 .. 8 q4 + 7
             // record position (in floats) of this lane's first stored live row of the block; the next ones follow
             const unsigned below = lh ? (1u << (8 * q4 + 4)) - 1u : (1u << (8 * q4)) - 1u;
-            unsigned off = ((unsigned)rb + (unsigned)__popc(sr_t & below)) * (unsigned)rw + 32u * ct + (unsigned)li;
+            unsigned off = gofs + ((unsigned)rb + (unsigned)__popc(sr_t & below)) * (unsigned)rw + 32u * ct + (unsigned)li;
             const f32x4 rq = crq[ct][q4];
-            if ((cur_bit >> 3) == q4) {   // uniform: the block that holds row cur (its root row from LDS, no record row here)
+            const bool cur_blk = (cur_bit >> 3) == q4;   // uniform: the block that holds row cur
+            float h[4];
+            bool st[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+              const bool is_cur = cur_blk && 8 * q4 + ii + 4 * lh == cur_bit;
+              const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
+              h[ii] = actf(acc[ct][4 * q4 + ii] + (is_cur ? rcur : rr));
+              const bool src = ((srl >> (8 * q4 + ii)) & 1u) != 0;
+              a2 += src ? h[ii] : 0.f;
+              hc = is_cur ? h[ii] : hc;
+              st[ii] = src && !is_cur;   // a stored live row: it has a record row (row cur's is slot 0, below)
+            }
+            if (REC) {
 #pragma unroll
               for (int ii = 0; ii < 4; ++ii) {
-                const bool is_cur = 8 * q4 + ii + 4 * lh == cur_bit;
-                const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
-                const float h = actf(acc[ct][4 * q4 + ii] + (is_cur ? rcur : rr));
-                const bool src = ((srl >> (8 * q4 + ii)) & 1u) != 0;
-                a2 += src ? h : 0.f;
-                hc = is_cur ? h : hc;
-                const bool stored = src && !is_cur;
-                if (rec && stored) sv_rows[off] = h;
-                off += stored ? (unsigned)rw : 0u;
-              }
-            } else {
-#pragma unroll
-              for (int ii = 0; ii < 4; ++ii) {
-                const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
-                const float h = actf(acc[ct][4 * q4 + ii] + rr);
-                const bool src = ((srl >> (8 * q4 + ii)) & 1u) != 0;
-                a2 += src ? h : 0.f;
-                if (rec && src) sv_rows[off] = h;
-                off += src ? (unsigned)rw : 0u;
+                sv_rows0[st[ii] ? off : dump] = h[ii];
+                off += st[ii] ? (unsigned)rw : 0u;
               }
             }
           }
@@ -327,13 +331,17 @@ __global__ __launch_bounds__(256) void k_step_colcache(
           if (lh == 0) sA2[wave * HK + 32 * ct + li] = a2;
           if (cur_lane) {
             sV[HK + 32 * ct + li] = hc;
-            if (rec) sv_rows[32 * ct + li] = hc;   // slot 0: row cur
+            if (REC) sv_rows[32 * ct + li] = hc;   // slot 0: row cur
           }
         }
       };
-      if (act1 == GCM_ACT_TANH) epilogue([](float v) { return gcm_tanh(v); });
-      else if (act1 == GCM_ACT_RELU) epilogue([](float v) { return v > 0.f ? v : 0.f; });
-      else epilogue([](float v) { return v; });
+      auto with_act = [&](auto recc) {
+        if (act1 == GCM_ACT_TANH) epilogue([](float v) { return gcm_tanh(v); }, recc);
+        else if (act1 == GCM_ACT_RELU) epilogue([](float v) { return v > 0.f ? v : 0.f; }, recc);
+        else epilogue([](float v) { return v; }, recc);
+      };
+      if (rec) with_act(std::true_type{});
+      else with_act(std::false_type{});
     }
   }
   STAMP(8);
@@ -468,6 +476,7 @@ extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, floa
   const float* b2 = w_root2 + (size_t)H2 * H1;
   const gcm_fused::Gnn2 P{w_rel1, b1, w_root1, w_rel2, b2, w_root2, act1, act2};
   gcm_rows::SavedLayout lay = gcm_rows::make_layout(B, N, F, H1, H2, false);
+  if (lay.total >= ((size_t)1 << 32)) return GCM_EUNSUPPORTED;   // (32-bit float offsets into the record)
   if (!record) lay.total = 0;
   hipStream_t s = (hipStream_t)stream;
 #define GCM_CC(a, b_, c)                                                                                          \
