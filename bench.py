@@ -724,6 +724,14 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                 comm["capture_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
                 torch.cuda.synchronize()
                 graph = None
+            # every rank takes the same path: if the capture failed anywhere, nobody replays a captured collective
+            import torch.distributed as dist
+            ok = torch.tensor([1 if comm["captured"] else 0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm["captured"]:
+                comm["captured"] = False
+                comm["capture_error"] = "another rank failed to capture the collective"
+                graph = None
         if graph is None:
             graph = capture(lambda: body(False), bucket.zero)
     elif not args.no_graph:
@@ -751,7 +759,10 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
     if world > 1:
         # the collective alone (the flat bucket, ~30 KB: latency-bound), events around 20 calls on the launch stream
         comm["comm_us_per_step"] = round(event_time(lambda: bucket.all_reduce_mean(weight), 20, warm=3) * 1e3, 2)
+        # (bucket.launches is reset by every all_reduce_mean call: what it holds is the LAST call's launches besides
+        #  the collective - a per-step figure, measured on the call just timed)
         comm["launches_outside_graph"] = 0 if (graph is not None and comm["captured"]) else 1 + bucket.launches
+        comm["gradients_aliased"] = bool(bucket.aliased())
         comm["note"] = ("per bench step besides the replayed graph: the all-reduce of the flat gradient bucket (and what "
                         "GradBucket.all_reduce_mean launches around it: nothing once the gradients alias the bucket and "
                         "the weight folds into ReduceOp.AVG); captured = the collective is a node of the HIP graph")

@@ -468,7 +468,10 @@ __global__ __launch_bounds__(256) void k_euclid_tp_gnn(
  * empty graphs: the time-parallel forms.  _decide: every step's decisions for any T (ring slots: node n in slot
  * n mod N; at step t >= N the slot t mod N is dead).  _fwd: T <= N - the whole forward, two launches. */
 extern "C" int gcm_euclid_rollout_tp_supported(int T, int B, int N, int F, int H1, int H2) {
-  return !(T < 1 || B < 32 || B > 65535 || N < 1 || N > 128 || (N & 3) || F < 4 || F > 64 || (F & 3) || H1 < 1 ||
+  // F in {32, 64}: the widths at which the decisions are pinned bit for bit against the per-step kernels
+  // (tests/test_euclid_tp_gpu.py; other multiples of four would run the zero-padded staging against the per-step
+  // path's two-launch form - an equality nobody has checked, so rollout() keeps the per-step loop there)
+  return !(T < 1 || B < 32 || B > 65535 || N < 1 || N > 128 || (N & 3) || !(F == 32 || F == 64) || H1 < 1 ||
            H1 > 64 || H2 < 1 || H2 > 64 || T > 65535);
 }
 

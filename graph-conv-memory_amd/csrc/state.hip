@@ -334,7 +334,10 @@ int gcm_cu_count() {
   return c;
 }
 
-extern "C" int gcm_version(void) { return 102; }
+extern "C" int gcm_version(void) { return 103; }
+// bumped whenever an existing entry point's SIGNATURE or a caller-allocated buffer's size changes (new entry points
+// alone do not bump it): a binding built against another value must not call into this library
+extern "C" int gcm_abi_version(void) { return GCM_ABI_VERSION; }
 
 extern "C" const char* gcm_status_string(int code) {
   switch (code) {

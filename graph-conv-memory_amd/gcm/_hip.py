@@ -22,6 +22,8 @@ GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bit
 STEP_TWO_LAUNCH = 32      # ... of the cached step: a distance selector and the step as two launches (A/B)
 STEP_IMG_V4 = 64          # ... its weights as 16-byte loads (the image's second layout)
 
+ABI_VERSION = 6           # include/gcm_hip.h: GCM_ABI_VERSION
+
 _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                      ctypes.c_int64)
 
@@ -29,6 +31,7 @@ _P, _I, _F, _Z, _L = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_si
 # symbol declared in include/gcm_hip.h is exported and bound.
 PROTOTYPES = {
     "gcm_version": (_I, []),
+    "gcm_abi_version": (_I, []),
     "gcm_status_string": (ctypes.c_char_p, [_I]),
     "gcm_state_advance_fwd": (_I, [_P] * 11 + [_I, _I, _I, _P]),
     "gcm_state_advance_bwd": (_I, [_P] * 6 + [_I, _I, _I, _P]),
@@ -214,6 +217,10 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        got = handle.gcm_abi_version()
+        if got != ABI_VERSION:     # (the prototype table below was written against include/gcm_hip.h's GCM_ABI_VERSION)
+            raise HipLibraryError(f"{_LIB_PATH} has ABI revision {got}, this binding expects {ABI_VERSION}: "
+                                  "rebuild the library (`python __graft_entry__.py`)")
         _lib = handle
     return _lib
 

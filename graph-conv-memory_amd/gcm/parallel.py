@@ -75,7 +75,13 @@ class GradBucket:
         HIP-graph capture of `bucket.zero(); loss.backward(); bucket.all_reduce_mean(w)`: autograd then accumulates
         into the bucket in place (AccumulateGrad adds into an existing .grad), the captured graph needs no gather /
         copy-back launch, and the collective itself can sit inside the graph (all_reduce_mean is capture-safe once
-        the gradients alias the bucket: a scale and the collective, no allocation)."""
+        the gradients alias the bucket: a scale and the collective, no allocation).
+
+        The aliasing lives in `p.grad`: `Module.zero_grad()` / `Optimizer.zero_grad()` with torch's default
+        `set_to_none=True` DROP it, and a replayed graph then keeps accumulating into the bucket while `p.grad` is
+        None - the optimizer would silently skip every parameter.  Between steps use `bucket.zero()` (one launch) or
+        `zero_grad(set_to_none=False)`, and call `ensure_attached()` before each replay / optimizer step (cheap: pointer
+        compares on the host; it re-attaches when a caller dropped the views)."""
         if not self.params:
             return self
         self._ensure_flat()
@@ -84,6 +90,20 @@ class GradBucket:
             p.grad = self._view(i)
         self.alias_grads = True
         return self
+
+    def ensure_attached(self):
+        """Re-establish `p.grad` = slice of the flat bucket if a caller dropped it (zero_grad(set_to_none=True));
+        -> True when the gradients were still aliased.  Host-side pointer compares only; the bucket's contents are
+        kept (a replayed graph may already have written this step's gradient into it)."""
+        if not self.params:
+            return True
+        self._ensure_flat()
+        if self.aliased():
+            return True
+        for i, p in enumerate(self.params):
+            p.grad = self._view(i)
+        self.alias_grads = True
+        return False
 
     def aliased(self):
         if self.flat is None:

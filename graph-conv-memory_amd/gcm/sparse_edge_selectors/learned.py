@@ -16,7 +16,9 @@ class LearnedEdge(torch.nn.Module):
     Same constructor and return value as the reference (a torch.sparse_coo [B,N,N] with indices
     (batch, sink, source)).  Candidates are enumerated in closed form on the device, the pair
     matrix and its adjoint are gather kernels, the softmax over sink rows is one wave per row;
-    the (user replaceable) edge network runs as library GEMMs.  `noise_fn(logits) -> gumbel
+    the reference's default edge network (recognised by its structure) runs on the hand-written row kernels
+    (gcm_rows_linear / gcm_skinny_wgrad / gcm_relu_layernorm_*: no library GEMM in the trace since round 3), any
+    other user-supplied network is called as the torch module it is.  `noise_fn(logits) -> gumbel
     noise [E]` may be set to inject the random draws (parity tests)."""
 
     def __init__(self, input_size: int = 0, model: Union[None, torch.nn.Module] = None,

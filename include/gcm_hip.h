@@ -56,6 +56,14 @@ typedef void* gcm_stream_t; /* hipStream_t */
 #define GCM_FLAG_NONFINITE 4u  /* belief state has NaN/Inf (gcm.py:316-318)            */
 
 int gcm_version(void);
+/* ABI revision of this header: bumped whenever an EXISTING entry point's signature or the size of a caller-allocated
+ * buffer changes (round 5 did both: the weight image of gcm_dense_rows_cached_weight_image grew from 16 384 to
+ * gcm_dense_rows_cached_weight_image_floats() = 36 864 floats, and gcm_edge_distance_step_cached /
+ * gcm_learned_step_cached(_functional) / gcm_learned_bptt_cached gained pointer arguments mid-signature).  A binding
+ * compares gcm_abi_version() with the GCM_ABI_VERSION it was written against before any other call (gcm/_hip.py
+ * does; INTEGRATION.md shows the stub) - stale ctypes prototypes would otherwise shift pointers silently. */
+#define GCM_ABI_VERSION 6
+int gcm_abi_version(void);
 const char* gcm_status_string(int code);
 
 /* ---- DenseGCM state ------------------------------------------------------ */

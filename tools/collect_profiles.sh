@@ -14,7 +14,7 @@ stats() {   # name, script args...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$@" > "$OUT/$name.log" 2>&1 < /dev/null
   cp "$(ls -t "$OUT/$name"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_${name}_kernel_stats.csv"
-  grep '^{' "$OUT/$name.log" | tail -1 > "$OUT/${TAG}_${name}_profiled.json" || true
+  if grep -q '^{' "$OUT/$name.log"; then grep '^{' "$OUT/$name.log" | tail -1 > "$OUT/${TAG}_${name}_profiled.json"; fi   # (tools that print no JSON line leave no file)
   rm -rf "$OUT/$name"          # (the raw traces are large; gpurun_out/ travels back)
   echo "stats $name done"
 }
