@@ -166,6 +166,135 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     da_out = da;
   };
 
+  // ---- MODE 4 (round 6): general records at F = H1 = 32 whose graphs hold MANY live rows (DenseEdge: every row <= cur,
+  // dense.py:16-21) ------------------------------------------------------------------------------------------------
+  // The pair form below keeps two row pairs of a wave in flight - enough for the handful of live rows temporal hops
+  // leave, but a dense_edge rollout reads 0.8 GB of rows and that depth left the launch latency-bound (233 us per 64
+  // steps at B = 256: 1.7 TB/s).  Here a wave fetches SIXTEEN rows (eight pairs: 24 dword loads a lane) ahead of the
+  // sixteen it is consuming - the next item's first batch behind an item's last - so ~6 KB per wave are always on
+  // their way.  Same arithmetic, same order of the sums per wave as the pair form.
+  if (MODE == 4) {
+    constexpr int PB = 8;   // row pairs per batch
+    const int q = lane & 31, half = lane >> 5;
+    const int ocq = q < H2 ? q : H2 - 1;
+    struct FrontD {
+      const float* sv;
+      int b, hdr0, hdr1;
+      float g, y, vv, cfa, cfb;
+    };
+    struct Rows {
+      float hv[PB], ag[PB], xx[PB];
+    };
+    auto front = [&](int item, FrontD& f) __attribute__((always_inline)) {
+      const int s = item / B, b = item - s * B;
+      const float* sv = tab.saved[s];
+      f.sv = sv;
+      f.b = b;
+      const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+      f.hdr0 = hdr[0];
+      f.hdr1 = hdr[1];
+      f.g = tab.gmx[s][(long)b * gmx_sb + (long)ocq * gmx_sh];   // (both halves: d2 replicated)
+      f.y = sv[(size_t)b * H2 + ocq];
+      f.vv = sv[lay.o_v + (size_t)b * 64 + lane];                // agg2 [32] | h1cur [32]
+      const int e0 = lane < N ? lane : N - 1, e1 = lane + 64 < N ? lane + 64 : N - 1;   // (entries >= L: unused)
+      f.cfa = sv[lay.o_coef + (size_t)b * N + e0];
+      f.cfb = sv[lay.o_coef + (size_t)b * N + e1];
+    };
+    auto rl = [&](int v, int l) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(v, l & 63); };
+    // rows l0 .. l0 + 15 (L > 0): pair p = rows l0 + 2 p (lanes 0-31) and l0 + 2 p + 1 (lanes 32-63), element q;
+    // rows beyond the list are read from its last row and masked when consumed
+    auto fetch = [&](const FrontD& f, int l0, int L, Rows& R) __attribute__((always_inline)) {
+      const float* base = f.sv + lay.o_rows + (size_t)f.b * N * lay.rw + q;
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        const int l = l0 + 2 * p + half;
+        const float* row = base + (size_t)(l < L ? l : L - 1) * lay.rw;
+        R.hv[p] = row[0];
+        R.ag[p] = row[32];
+        R.xx[p] = row[64];
+      }
+    };
+    f32x16 aR, aT, a2r, a2t;   // dW_rel1 | dW_root1 | dW_rel2 | dW_root2 tiles: [out = acc row][in = q]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aR[r] = 0.f; aT[r] = 0.f; a2r[r] = 0.f; a2t[r] = 0.f; }
+    float db1p = 0.f, db2p = 0.f;
+    FrontD f0{}, f1{};
+    Rows RC, RN;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) { RC.hv[p] = RC.ag[p] = RC.xx[p] = 0.f; RN.hv[p] = RN.ag[p] = RN.xx[p] = 0.f; }
+    if (wid < items) {
+      front(wid, f0);
+      const int L0 = min(__builtin_amdgcn_readfirstlane(f0.hdr0), 128);
+      if (L0 > 0) fetch(f0, 0, L0, RC);
+    }
+#pragma unroll 1
+    for (int item = wid; item < items; item += n_waves) {
+      const bool has_next = item + n_waves < items;
+      if (has_next) front(item + n_waves, f1);
+      const int L = min(__builtin_amdgcn_readfirstlane(f0.hdr0), 128);
+      const int l_cur = __builtin_amdgcn_readfirstlane(f0.hdr1);
+      const float d2 = q < H2 ? f0.g * act_grad_sel(f0.y, act2_v) : 0.f;
+      db2p += d2;
+      float u = 0.f;
+#pragma unroll
+      for (int o = 0; o < 32; ++o)
+        u = fmaf(w2c[0][o], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o)), u);
+      a2r = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : d2, f0.vv, a2r, 0, 0, 0);   // d2 (x) agg2
+      a2t = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? d2 : 0.f, f0.vv, a2t, 0, 0, 0);   // d2 (x) h1cur
+      const float dagg2 = __shfl(u, q), dh1c = __shfl(u, 32 + q);   // (in both halves)
+      auto fetch_next0 = [&](Rows& R) __attribute__((always_inline)) {
+        if (has_next) {
+          const int Ln = min(__builtin_amdgcn_readfirstlane(f1.hdr0), 128);
+          if (Ln > 0) fetch(f1, 0, Ln, R);
+        }
+      };
+      if (L == 0) fetch_next0(RC);
+#pragma unroll 1
+      for (int l0 = 0; l0 < L; l0 += 2 * PB) {
+        if (l0 + 2 * PB < L) fetch(f0, l0 + 2 * PB, L, RN);
+        else fetch_next0(RN);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+          const int l = l0 + 2 * p;
+          if (l >= L) break;   // uniform
+          const int l1 = l + 1;
+          const float c0 = __int_as_float(l < 64 ? rl(__float_as_int(f0.cfa), l) : rl(__float_as_int(f0.cfb), l));
+          const float c1 = __int_as_float(l1 < 64 ? rl(__float_as_int(f0.cfa), l1) : rl(__float_as_int(f0.cfb), l1));
+          const int lm = l + half;
+          float g1 = ((half ? c1 : c0) * dagg2 + (lm == l_cur ? dh1c : 0.f)) * act_grad_sel(RC.hv[p], act1_v);
+          g1 = lm < L ? g1 : 0.f;
+          db1p += g1;
+          aR = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, RC.ag[p], aR, 0, 0, 0);
+          aT = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, RC.xx[p], aT, 0, 0, 0);
+        }
+        RC = RN;
+      }
+      f0 = f1;
+    }
+    extern __shared__ float sSlabD[];
+    const int Pm = 2 * 32 * 32 + 32 + 2 * H2 * 32 + H2;
+    const int m_root1 = 32 * 32, m_b1 = 2 * 32 * 32, m_rel2 = m_b1 + 32, m_root2 = m_rel2 + H2 * 32, m_b2 = m_root2 + H2 * 32;
+    float* mine = sSlabD + (size_t)wave * Pm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row of a 32x32 tile
+      mine[i * 32 + q] = aR[r];
+      mine[m_root1 + i * 32 + q] = aT[r];
+      if (i < H2) {
+        mine[m_rel2 + i * 32 + q] = a2r[r];
+        mine[m_root2 + i * 32 + q] = a2t[r];
+      }
+    }
+    const float db1m = db1p + __shfl_xor(db1p, 32);
+    if (lane < 32) mine[m_b1 + lane] = db1m;
+    if (lane < H2) mine[m_b2 + lane] = db2p;
+    __syncthreads();
+    float* slabm = slabs + (size_t)blockIdx.x * Pm;
+    for (int e = tid; e < Pm; e += 256)
+      slabm[e] = ((sSlabD[e] + sSlabD[Pm + e]) + sSlabD[2 * Pm + e]) + sSlabD[3 * (size_t)Pm + e];
+    return;
+  }
+
   // ---- records at F = H1 = 32 (cfg2 / cfg4 / cfg5's GNN): the rank-1 updates on the matrix cores ----------------
   // dW1 += G1_l (x) [agg1_l | x_l] over the live rows is a [32 x rows] . [rows x 64] product: rows are taken in
   // PAIRS - lanes 0-31 hold row l, lanes 32-63 row l + 1 (k = 0 / 1 of v_mfma_f32_32x32x2_f32) - as two MFMAs per
@@ -770,7 +899,10 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
   // (one LDS region per wave while four of them leave room for two workgroups per CU: see the kernel's tail)
   int wave_regions = sizeof(float) * P * 4 <= 80 * 1024 ? 1 : 0;
   size_t lds = sizeof(float) * P * (wave_regions ? 4 : 1);
-  if ((MODE == 0 || MODE == 3) && HP == 32 && H2P == 32 && H1 == 32 && F == FP) {
+  if (MODE == 4) {   // (the launcher's caller checked F == H1 == 32, H2 <= 32, no folded terms)
+    wave_regions = 3;
+    lds = sizeof(float) * P * 4;
+  } else if ((MODE == 0 || MODE == 3) && HP == 32 && H2P == 32 && H1 == 32 && F == FP) {
     // the matrix-core forms (see the kernel).  F = 32: one region of P floats per wave (wave_regions = 3);
     // F = 64: the tiles meet in two rounds, four regions of the larger round (wave_regions = 2)
     if (FP == 32) {
@@ -894,6 +1026,14 @@ static int rows_bptt_impl(const float* const* saved_host, const float* const* gm
     }
     float* sl = slabs + (size_t)c * per * P;
     int rc = GCM_EUNSUPPORTED;
+    // GCM_BPTT_MANY_ROWS: the caller knows the records hold many live rows per graph (DenseEdge): the deep-prefetch
+    // form of the matrix-core pass, where it exists
+    if ((has_bias & GCM_BPTT_MANY_ROWS) && !cache_h1 && !deg_term && F == 32 && H1 == 32 && H2 <= 32) {
+      rc = gcm_rows::launch_bptt<32, 32, 32, 4>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b, gmx_stride_h, w_rel2,
+                                                w_root2, act1, act2, lay, sl, B, N, F, H1, H2, 0);
+      if (rc) return rc;
+      continue;
+    }
 #define GCM_RB(a, b_, cc)                                                                          \
   if (fp == a && hp == b_ && h2p == cc)                                                            \
     rc = cache_h1 ? gcm_rows::launch_bptt<a, b_, cc, 3>(s, per, tab, gcm_rows::Hist{}, ns, gmx_stride_b,   \

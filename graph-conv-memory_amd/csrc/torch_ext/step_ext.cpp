@@ -266,6 +266,7 @@ struct RowsChainNode : public torch::autograd::Node {
     bool cached = false;        // a cached step (rows_cached.hip): the live rows are in the chain's caches
   };
   at::Tensor cH, cA, cX;        // the caches of the chain's cached steps
+  bool many_rows = false;       // a DenseEdge selector: every row <= cur is live (GCM_BPTT_MANY_ROWS)
   std::vector<gcm_selector_desc> descs;   // ... and the selectors their live rows follow from (dx of cached steps)
   std::vector<Rec> recs;   // the recorded steps, in chain order
   at::Tensor packed;       // the packed parameter vector, detached (the kernel re-reads the weights)
@@ -425,7 +426,7 @@ struct RowsChainNode : public torch::autograd::Node {
               "gcm_dense_rows_bptt_cached");
       else
       check(gcm_dense_rows_bptt(c.sv.data(), c.gm.data(), n, (long)c.sb, (long)c.sh,
-                                packed.data_ptr<float>(), has_bias, act1, act2,
+                                packed.data_ptr<float>(), has_bias | (many_rows ? GCM_BPTT_MANY_ROWS : 0), act1, act2,
                                 prev.defined() ? prev.data_ptr<float>() : nullptr, res.data_ptr<float>(),
                                 ws.data_ptr(), ws_bytes, (int)c.B, N, F, H1, H2, stream),
             "gcm_dense_rows_bptt");
@@ -709,6 +710,7 @@ struct RowsFast {
       node->P = (int64_t)gcm_dense_gnn2_param_count(cfg->F, cfg->H1, cfg->H2) +
                 ((cfg->has_bias & GCM_GNN_HAS_DEG_TERM) ? cfg->H1 : 0);
       TORCH_CHECK(packed.numel() >= node->P, "rows step: packed parameter vector too short");
+      for (const auto& d : cfg->descs) node->many_rows = node->many_rows || d.kind == GCM_SEL_DENSE;
       node->set_next_edges(torch::autograd::collect_next_edges(packed));
       if (dx_ == 1) {
         dx_mode = true;

@@ -522,6 +522,10 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
 /* has_bias bit: the record also keeps what the gradient w.r.t. the observations / incoming nodes needs
  * (gcm_dense_rows_bptt_dx): the live rows' indices and adjacency rows (gcm_dense_rows_layout_dx). */
 #define GCM_GNN_RECORD_DX 16
+/* gcm_dense_rows_bptt only (a hint, never changes the result's meaning): the records hold MANY live rows per graph
+ * (DenseEdge: every row <= cur) - the pass then fetches sixteen rows ahead instead of two (F = H1 = 32, H2 <= 32, no
+ * folded terms; ignored elsewhere). */
+#define GCM_BPTT_MANY_ROWS 128
 /* gcm_dense_rows_step_cached_ws only: a distance selector and the cached step as two launches (see
  * gcm_dense_rows_cached_launches) */
 #define GCM_STEP_TWO_LAUNCH 32
