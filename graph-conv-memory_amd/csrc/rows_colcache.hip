@@ -63,12 +63,16 @@ __device__ __forceinline__ int mrank(const RowMask& m, int j) {
 // drains the wave's global loads and STORES (vmcnt(0)), which here would put every barrier behind the record's stores
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ssrc: the STORED rows the new row aggregates from;  self: the new row's own self edge;  scol: the stored rows that gain
+// the new node as a source;  sdrop (steady state): the stored rows that lose the dropped node as a source - all in RING
+// coordinates (slot of a node = its chain index mod N; below N steps slot = graph row).  cur: the new node's slot;
+// rot: the slot of graph row 0 as the state comes in (0 below N steps);  n_slots: slots in use after the step.
 template <int FK, int HK, int O2T>
 __global__ __launch_bounds__(256) void k_step_colcache(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    const RowMask srow, const RowMask scol, const int cur, const Gnn2 P, float* __restrict__ cA,
-    float* __restrict__ cR, float* __restrict__ saved, const SavedLayout lay, uint32_t* __restrict__ flags,
-    const int N, const int H2) {
+    const RowMask ssrc, const int self, const RowMask scol, const RowMask sdrop, const int cur, const int rot,
+    const int steady, const Gnn2 P, float* __restrict__ cA, float* __restrict__ cR, float* __restrict__ saved,
+    const SavedLayout lay, uint32_t* __restrict__ flags, const int N, const int H2) {
   constexpr int C4 = FK / 4;       // 16-byte pieces of a node row
   constexpr int RG = 256 / C4;     // node rows per pass of the workgroup (32 or 16)
   constexpr int XP = 128 / RG;     // node rows per thread
@@ -95,18 +99,31 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   const bool rec = lay.total != 0;
   const int rw = lay.rw;
   float* sv_rows = saved + lay.o_rows + gb * N * rw;
-  const bool tile_on = 32 * wave <= cur;          // wave-uniform: this wave's 32 rows hold a row <= cur
+  const int n_slots = steady ? N : cur + 1;       // slots in use after the step = graph rows read below
+  const bool tile_on = 32 * wave < n_slots;       // wave-uniform: this wave's 32 slots hold a node
 
   STAMP(0);
   // ---- every load of the step, in the order of use, before anything waits ------------------------------------------
   const int64_t n_in = count[b];
-  // node rows, one 16-byte piece per (row group, piece) thread: the new row's aggregate and the record's x section
+  // steady state: the dropped node - graph row 0 - as the A-operand lanes hold a row.  FIRST in the queue: loads return
+  // in order, so a wave that has its node rows (barrier #1) has this one too - the roll overwrites row 0 behind that
+  // barrier.
+  f32x4 xo[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) xo[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (steady) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) xo[q] = *reinterpret_cast<const f32x4*>(ng + lh * KH + 4 * q);
+  }
+  asm volatile("" ::: "memory");   // (the compiler keeps them in front of the node rows' loads)
+  // node rows (graph coordinates, the state as it comes in), one 16-byte piece per (row group, piece) thread: the new
+  // row's aggregate, the record's x section and - in the steady state - the roll of the node matrix
   const int c4 = tid % C4, rg = tid / C4;
   f32x4 xr[XP];
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
     const int row = rg + RG * i;
-    if (RG * i <= cur)   // (uniform: passes beyond the stored rows are skipped)
+    if (RG * i < n_slots)   // (uniform: passes beyond the stored rows are skipped)
       xr[i] = *reinterpret_cast<const f32x4*>(ng + (row < N ? row : N - 1) * FK + 4 * c4);
     else
       xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -128,12 +145,12 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       b1v[ct] = P.b_rel1[32 * ct + li];
     }
   }
-  // the A operand: row r = 32 wave + li, k in [lh KH, (lh + 1) KH) - agg1 of the stored rows from the chain's cache;
-  // the B operand: W_rel1[col][k], col = 32 ct + li, the same k; root[j][col] of the rows the accumulators hold
+  // the A operand: slot r = 32 wave + li, k in [lh KH, (lh + 1) KH) - agg1 of the stored rows from the chain's cache;
+  // the B operand: W_rel1[col][k], col = 32 ct + li, the same k; root[slot][col] of the rows the accumulators hold
   const int r = 32 * wave + li;
   const int rc = r < N ? r : N - 1;
   f32x4 ca[KQ], wb[CT][KQ], crq[CT][4];
-  const int NQ = N >> 2;   // the root cache is kept in quads of rows: cR[b][row / 4][col][row % 4] (one 16-byte load
+  const int NQ = N >> 2;   // the root cache is kept in quads of rows: cR[b][slot / 4][col][slot % 4] (one 16-byte load
                            // per four accumulator rows of a lane)
   if (tile_on) {
 #pragma unroll
@@ -168,43 +185,56 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   asm volatile("" ::: "memory");
   STAMP(1);
 
-  // A chain from empty graphs holds `cur` nodes in every graph; anything else (a caller edited the count) leaves the
-  // graph untouched and raises the flag (uniform per workgroup: nothing has been stored yet)
-  if (n_in != (int64_t)cur) {
+  // A chain from empty graphs holds min(steps made, N) nodes in every graph; anything else (a caller edited the count)
+  // leaves the graph untouched and raises the flag (uniform per workgroup: nothing has been stored yet)
+  if (n_in != (int64_t)(steady ? N : cur)) {
     if (tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);
     return;
   }
   STAMP(2);
-  // the masks as four 32-row words (scalars) and the live-list position of each word's first row: slot 0 is row cur,
-  // the stored live rows follow in ascending order
-  const unsigned sw0 = mword(srow, 0), sw1 = mword(srow, 1), sw2 = mword(srow, 2), sw3 = mword(srow, 3);
-  const unsigned selfbit = mbit(srow, cur) ? 1u : 0u;
+  // the stored sources as four 32-slot words (scalars) and the record position of each word's first slot: slot 0 of
+  // the record is the new row, the stored live rows follow in ascending SLOT order
+  const unsigned sw0 = mword(ssrc, 0), sw1 = mword(ssrc, 1), sw2 = mword(ssrc, 2), sw3 = mword(ssrc, 3);
   const int pc1 = 1 + __popc(sw0), pc2 = pc1 + __popc(sw1), pc3 = pc2 + __popc(sw2);
-  const int L = pc3 + __popc(sw3) - (int)selfbit;   // row cur + the stored sources
+  const int L = pc3 + __popc(sw3);   // the new row + its stored sources
   auto sword = [&](int w) { return w == 0 ? sw0 : (w == 1 ? sw1 : (w == 2 ? sw2 : sw3)); };
   auto sbase = [&](int w) { return w == 0 ? 1 : (w == 1 ? pc1 : (w == 2 ? pc2 : pc3)); };
 
-  // ---- the new row's aggregate: sum of the selected node rows, ascending inside a thread, then over the row groups
-  {
+  // ---- the new row's aggregate: sum of the selected node rows, ascending inside a thread, then over the row groups.
+  // Graph row i of the incoming state sits in slot i + rot (mod N); the new node takes the place of graph row `cur`
+  // (below N steps) / of the dropped graph row 0 (steady state: that thread carries the observation instead).
+  auto new_row_sum = [&](auto ringc) {
+    constexpr bool RING = decltype(ringc)::value;   // rot != 0: slot = (row + rot) mod N; else slot = row and the
+                                                    // mask word of a pass is a compile-time choice of a scalar
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-      if (RG * i > cur) continue;   // uniform
+      if (RG * i >= n_slots) continue;   // uniform
       const int row = rg + RG * i;
-      const int w = (RG * i) >> 5, bit = row & 31;     // w: compile time
-      const unsigned word = sword(w);
-      const bool is_cur = row == cur;
-      const f32x4 v = is_cur ? obq : xr[i];
-      const bool src = ((word >> bit) & 1u) != 0;      // (bits beyond cur are never set)
-      if (src) part += v;
-      if (rec && (is_cur || src)) {
-        const unsigned slot = is_cur ? 0u : (unsigned)sbase(w) + (unsigned)__popc(word & ((1u << bit) - 1u));
-        *reinterpret_cast<f32x4*>(sv_rows + slot * (unsigned)rw + HK + FK + 4 * c4) = v;
+      const bool is_cur = steady ? row == 0 : row == cur;
+      bool stored;     // a stored source of the new row
+      unsigned pos;    // its record row
+      if (RING) {
+        int slot = row + rot;
+        slot -= slot >= N ? N : 0;
+        stored = row < n_slots && !is_cur && mbit(ssrc, slot);
+        pos = 1u + (unsigned)mrank(ssrc, slot);
+      } else {
+        const int w = (RG * i) >> 5, bit = row & 31;     // w: compile time
+        const unsigned word = sword(w);
+        stored = !is_cur && ((word >> bit) & 1u) != 0;   // (bits beyond the slots in use are never set)
+        pos = (unsigned)sbase(w) + (unsigned)__popc(word & ((1u << bit) - 1u));
       }
+      const f32x4 v = is_cur ? obq : xr[i];
+      if (stored || (is_cur && self != 0)) part += v;
+      if (rec && (stored || is_cur))
+        *reinterpret_cast<f32x4*>(sv_rows + (is_cur ? 0u : pos) * (unsigned)rw + HK + FK + 4 * c4) = v;
     }
     *reinterpret_cast<f32x4*>(sPart + rg * PS + 4 * c4) = part;
-  }
-  // the new node's root row (wave 3 holds no stored row until cur >= 96)
+  };
+  if (rot) new_row_sum(std::true_type{});
+  else new_row_sum(std::false_type{});
+  // the new node's root row (wave 3 holds no stored row until 96 slots are in use)
   if (wave == 3) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -225,8 +255,20 @@ __global__ __launch_bounds__(256) void k_step_colcache(
     }
   }
   STAMP(3);
-  lds_barrier();   // #1
+  lds_barrier();   // #1: every wave has its node rows in registers
   STAMP(4);
+  // the node matrix of the donated state: the observation into row cur (gcm.py:274) - in the steady state behind the
+  // overflow roll (gcm.py:323-355: row i <- row i + 1), in place: every wave's loads of it landed before barrier #1
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    if (RG * i >= n_slots) continue;
+    const int row = rg + RG * i;
+    if (steady) {
+      if (row < N) *reinterpret_cast<f32x4*>(ng + (row == 0 ? N - 1 : row - 1) * FK + 4 * c4) = row == 0 ? obq : xr[i];
+    } else if (row == cur) {
+      *reinterpret_cast<f32x4*>(ng + cur * FK + 4 * c4) = obq;
+    }
+  }
   if (wave == 2) {   // the row groups' partial sums -> agg1[cur]: lane (feature, part) takes GP groups
     const int f = lane % FK, part = lane / FK;
     float v[GP];
@@ -245,23 +287,26 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   lds_barrier();   // #2
   STAMP(5);
 
-  // ---- layer 1 of the live rows: [32 rows x F] . [F x H1] per wave ------------------------------------------------
+  // ---- layer 1 of the live rows: [32 slots x F] . [F x H1] per wave ------------------------------------------------
   if (tile_on) {
-    const unsigned sr_t = sword(wave), sc_t = mword(scol, wave);   // scalars
+    const unsigned sr_t = sword(wave), sc_t = mword(scol, wave), sd_t = mword(sdrop, wave);   // scalars
     const int rb = sbase(wave);
-    const int cur_bit = cur - 32 * wave;                            // row cur inside this tile: 0 .. 31
+    const bool cur_in = (cur >> 5) == wave;          // the new row's slot lies in this tile
+    const int cur_bit = cur_in ? cur & 31 : 99;
     {
-      const bool upd = ((sc_t >> li) & 1u) != 0;        // the row gains the source cur (stored rows only)
-      const bool lrow = ((sr_t >> li) & 1u) != 0 && li != cur_bit;   // a stored live row
-      const int slot = rb + __popc(sr_t & ((1u << li) - 1u));
-      float* rdst = sv_rows + (unsigned)slot * (unsigned)rw + HK + lh * KH;
+      const bool upd = ((sc_t >> li) & 1u) != 0;     // the row gains the source cur
+      const bool drp = ((sd_t >> li) & 1u) != 0;     // steady state: the row loses the dropped node
+      const bool lrow = ((sr_t >> li) & 1u) != 0;    // a stored live row
+      const unsigned pos = (unsigned)rb + (unsigned)__popc(sr_t & ((1u << li) - 1u));
+      float* rdst = sv_rows + pos * (unsigned)rw + HK + lh * KH;
       float a[KH];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         f32x4 v = ca[q];
-        const f32x4 xq = xa[q];
+        const f32x4 xq = xa[q], xd = xo[q];
+        if (steady) v -= f32x4{drp ? xd.x : 0.f, drp ? xd.y : 0.f, drp ? xd.z : 0.f, drp ? xd.w : 0.f};   // (uniform)
         v += f32x4{upd ? xq.x : 0.f, upd ? xq.y : 0.f, upd ? xq.z : 0.f, upd ? xq.w : 0.f};
-        if (upd) *reinterpret_cast<f32x4*>(cAg + r * FK + lh * KH + 4 * q) = v;
+        if (upd || drp) *reinterpret_cast<f32x4*>(cAg + r * FK + lh * KH + 4 * q) = v;
         if (li == cur_bit) v = *reinterpret_cast<const f32x4*>(sAggc + lh * KH + 4 * q);
         if (rec && lrow) *reinterpret_cast<f32x4*>(rdst + 4 * q) = v;
         a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
@@ -281,19 +326,17 @@ __global__ __launch_bounds__(256) void k_step_colcache(
           acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wv, acc[ct], 0, 0, 0);
         }
       STAMP(7);
-      // the activation, this lane's part of agg2, h1[cur], the record's h1 rows.  One wave = one instruction stream:
-      // the activation is a uniform branch around the loop (not selects inside it), positions come from the tile's
-      // mask word
+      // the activation, this lane's part of agg2, h1[cur], the record's h1 rows.
       // (One wave = one instruction stream, and a dependent VALU chain runs at about half its issue rate: the four
       //  rows of a block are evaluated side by side and nothing in the loop branches - a row without a record row
       //  stores into the record's unused `deg` section instead of being masked off.)
       auto epilogue = [&](auto actf, auto recc) {
         constexpr bool REC = decltype(recc)::value;
-        const unsigned live_t = sr_t | (cur_bit < 32 ? 1u << cur_bit : 0u);   // (scalar) rows of the tile with a record row
+        const unsigned live_t = sr_t | (cur_in ? 1u << cur_bit : 0u);   // (scalar) slots of the tile with a record row
         const unsigned srl = lh ? sr_t >> 4 : sr_t;   // bit c: the source bit of this lane's row c + 4 lh
-        const bool cur_lane = cur_bit < 32 && ((cur_bit >> 2) & 1) == lh;   // row cur sits in this lane's accumulators
+        const bool cur_lane = cur_in && ((cur_bit >> 2) & 1) == lh;   // the new row sits in this lane's accumulators
         const unsigned dump = (unsigned)(lay.o_deg - lay.o_rows) + (unsigned)(b * N + (li < N ? li : N - 1));   // from sv_rows0
-        float* sv_rows0 = saved + lay.o_rows;   // (uniform base, 32-bit offsets: B N rw < 2^31 is checked by the host)
+        float* sv_rows0 = saved + lay.o_rows;   // (uniform base, 32-bit offsets: the host checked the record's size)
         const unsigned gofs = (unsigned)b * (unsigned)N * (unsigned)rw;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -301,12 +344,12 @@ __global__ __launch_bounds__(256) void k_step_colcache(
           float a2 = 0.f, hc = 0.f;
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
-            if (((live_t >> (8 * q4)) & 0xffu) == 0u) continue;   // uniform: no live row among rows 8 q4 .. 8 q4 + 7
+            if (((live_t >> (8 * q4)) & 0xffu) == 0u) continue;   // uniform: no live row among slots 8 q4 .. 8 q4 + 7
             // record position (in floats) of this lane's first stored live row of the block; the next ones follow
             const unsigned below = lh ? (1u << (8 * q4 + 4)) - 1u : (1u << (8 * q4)) - 1u;
             unsigned off = gofs + ((unsigned)rb + (unsigned)__popc(sr_t & below)) * (unsigned)rw + 32u * ct + (unsigned)li;
             const f32x4 rq = crq[ct][q4];
-            const bool cur_blk = (cur_bit >> 3) == q4;   // uniform: the block that holds row cur
+            const bool cur_blk = (cur_bit >> 3) == q4;   // uniform: the block that holds the new row
             float h[4];
             bool st[4];
 #pragma unroll
@@ -314,10 +357,9 @@ __global__ __launch_bounds__(256) void k_step_colcache(
               const bool is_cur = cur_blk && 8 * q4 + ii + 4 * lh == cur_bit;
               const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
               h[ii] = actf(acc[ct][4 * q4 + ii] + (is_cur ? rcur : rr));
-              const bool src = ((srl >> (8 * q4 + ii)) & 1u) != 0;
-              a2 += src ? h[ii] : 0.f;
+              st[ii] = ((srl >> (8 * q4 + ii)) & 1u) != 0;   // a stored source: in agg2, and it has a record row
+              a2 += (st[ii] || (is_cur && self != 0)) ? h[ii] : 0.f;
               hc = is_cur ? h[ii] : hc;
-              st[ii] = src && !is_cur;   // a stored live row: it has a record row (row cur's is slot 0, below)
             }
             if (REC) {
 #pragma unroll
@@ -331,7 +373,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
           if (lh == 0) sA2[wave * HK + 32 * ct + li] = a2;
           if (cur_lane) {
             sV[HK + 32 * ct + li] = hc;
-            if (REC) sv_rows[32 * ct + li] = hc;   // slot 0: row cur
+            if (REC) sv_rows[32 * ct + li] = hc;   // record row 0: the new row
           }
         }
       };
@@ -348,14 +390,14 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   lds_barrier();   // #3
   STAMP(9);
 
-  // ---- layer 2 on row cur (wave 0); the donated state (the other waves) ---------------------------------------------
+  // ---- layer 2 on the new row (wave 0); the rest of the donated state (the other waves) ---------------------------
   if (wave == 0) {
-    const int wmax = cur >> 5;
+    const int n_tiles = (n_slots + 31) >> 5;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       if (lh == 0) {
         double t = (double)sA2[32 * ct + li];
-        for (int w = 1; w <= wmax; ++w) t += (double)sA2[w * HK + 32 * ct + li];
+        for (int w = 1; w < n_tiles; ++w) t += (double)sA2[w * HK + 32 * ct + li];
         sV[32 * ct + li] = (float)t;
       }
     }
@@ -388,37 +430,54 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       for (int k = lane; k < 2 * HK; k += 64) saved[lay.o_v + gb * 2 * HK + k] = sV[k];
       if (lane == 0) {
         int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * b;
-        hdr[0] = L; hdr[1] = 0; hdr[2] = cur; hdr[3] = 0;
+        hdr[0] = L; hdr[1] = 0; hdr[2] = steady ? N - 1 : cur; hdr[3] = steady;
       }
     }
     STAMP(11);
   } else {
     const int t2 = tid - 64;   // 0 .. 191
-    if (rec) {   // coef: adj[cur, j_l] - the self edge for slot 0, one for every other live row
+    if (rec) {   // coef: adj[cur, j_l] - the self edge for record row 0, one for every other live row
       float* cf = saved + lay.o_coef + gb * N;
-      for (int l = t2; l < L; l += 192) cf[l] = l == 0 ? (selfbit ? 1.f : 0.f) : 1.f;
+      for (int l = t2; l < L; l += 192) cf[l] = l == 0 ? (self ? 1.f : 0.f) : 1.f;
     }
-    for (int j = t2; j <= cur; j += 192) {
-      if (mbit(srow, j)) ag[cur * N + j] = 1.f;              // row cur (temporal.py:76-81, dense.py:18,20)
-      if (j < cur && mbit(scol, j)) ag[j * N + cur] = 1.f;   // column cur (temporal.py:82-87, dense.py:19)
+    if (!steady) {
+      // the selectors' entries (below N steps slot = graph row); in the steady state the adjacency is a fixed point
+      // of roll + selectors - a Toeplitz pattern built by the same hops at every step - and stays as it is
+      for (int j = t2; j <= cur; j += 192) {
+        if (j == cur ? self != 0 : mbit(ssrc, j)) ag[cur * N + j] = 1.f;   // row cur (temporal.py:76-81, dense.py:18,20)
+        if (j < cur && mbit(scol, j)) ag[j * N + cur] = 1.f;              // column cur (temporal.py:82-87, dense.py:19)
+      }
+      if (t2 == 191) count[b] = cur + 1;
+    } else if (b == 0 && t2 == 191) {
+      atomicOr(flags, GCM_FLAG_WRAPPED);   // every graph drops its oldest node (gcm.py:263-271); the count stays N
     }
-    if (t2 < C4) *reinterpret_cast<f32x4*>(ng + cur * FK + 4 * t2) =
-        *reinterpret_cast<const f32x4*>(obs + gb * FK + 4 * t2);   // gcm.py:274
-    if (t2 == 191) count[b] = cur + 1;
   }
 }
 
 }  // namespace gcm_rows
 
-// the selector chain and the row the new node lands in -> the sources of row cur / the rows that gain the source cur
-static bool colcache_masks(const gcm_selector_desc* selectors, int n_selectors, int cur, gcm_rows::RowMask* srow,
-                           gcm_rows::RowMask* scol, bool* writes_column) {
-  gcm_rows::RowMask r{0, 0}, c{0, 0};
-  auto set = [](gcm_rows::RowMask& m, int j) {
-    if (j < 64) m.lo |= 1ull << j;
-    else m.hi |= 1ull << (j - 64);
+// The selector chain and the number of steps the chain has made -> the masks of k_step_colcache in ring coordinates.
+// Graph coordinates first: c = the graph row the new node lands in (t below N steps, N - 1 after), sources / column
+// rows among the rows < c, the rows that lose the dropped node among the incoming rows >= 1; then graph row i of the
+// state AFTER the step sits in slot (rot + 1 + i) mod N in the steady state (rot = t mod N: the slot the dropped node
+// vacates), in slot i before it.
+struct ColMasks {
+  gcm_rows::RowMask ssrc, scol, sdrop;
+  int self, cur, rot, steady;
+  bool writes_column;
+};
+static bool colcache_masks(const gcm_selector_desc* selectors, int n_selectors, int N, int t, ColMasks* out) {
+  ColMasks m{};
+  auto set = [](gcm_rows::RowMask& k, int j) {
+    if (j < 64) k.lo |= 1ull << j;
+    else k.hi |= 1ull << (j - 64);
   };
-  bool col = false;
+  m.steady = t >= N ? 1 : 0;
+  m.rot = m.steady ? t % N : 0;
+  const int c = m.steady ? N - 1 : t;
+  m.cur = m.steady ? m.rot : t;
+  auto post = [&](int i) { return m.steady ? (m.rot + 1 + i) % N : i; };   // slot of graph row i after the step
+  auto pre = [&](int i) { return (m.rot + i) % N; };                       // ... of graph row i as the state comes in
   for (int i = 0; i < n_selectors; ++i) {
     const gcm_selector_desc& d = selectors[i];
     if (d.kind == GCM_SEL_TEMPORAL) {
@@ -426,22 +485,23 @@ static bool colcache_masks(const gcm_selector_desc* selectors, int n_selectors, 
       for (int k = 0; k < d.n_hops; ++k) {
         const int h = d.hops[k];
         if (h < 0) return false;
-        if (d.direction & GCM_DIR_BACKWARD) col = col || h > 0;
-        if (h > cur) continue;                                     // temporal.py:74: num_nodes >= hop
-        if ((d.direction & GCM_DIR_FORWARD) || h == 0) set(r, cur - h);
-        if ((d.direction & GCM_DIR_BACKWARD) && h > 0) set(c, cur - h);
+        if (d.direction & GCM_DIR_BACKWARD) m.writes_column = m.writes_column || h > 0;
+        if (h > c) continue;                                       // temporal.py:74: num_nodes >= hop
+        if (h == 0) { m.self = 1; continue; }
+        if (d.direction & GCM_DIR_FORWARD) set(m.ssrc, post(c - h));
+        if (d.direction & GCM_DIR_BACKWARD) set(m.scol, post(c - h));
+        if (m.steady && (d.direction & GCM_DIR_FORWARD) && h <= N - 1) set(m.sdrop, pre(h));   // entry (h, 0)
       }
     } else if (d.kind == GCM_SEL_DENSE) {
-      col = true;
-      for (int j = 0; j <= cur; ++j) set(r, j);
-      for (int j = 0; j < cur; ++j) set(c, j);
+      m.writes_column = true;
+      m.self = 1;
+      for (int j = 0; j < c; ++j) { set(m.ssrc, post(j)); set(m.scol, post(j)); }
+      if (m.steady) for (int j = 1; j < N; ++j) set(m.sdrop, pre(j));
     } else {
       return false;
     }
   }
-  *srow = r;
-  *scol = c;
-  if (writes_column) *writes_column = col;
+  *out = m;
   return true;
 }
 
@@ -450,10 +510,9 @@ extern "C" int gcm_dense_rows_colcache_supported(const gcm_selector_desc* select
   if (N <= 0 || N > 128 || (N & 3) || !(F == 32 || F == 64) || !(H1 == 32 || H1 == 64) || H2 <= 0 || H2 > 64) return 0;
   if (has_bias & ~3) return 0;   // (no folded preprocessor / positional encoding, no observation-gradient record)
   if (n_selectors <= 0 || !selectors) return 0;
-  gcm_rows::RowMask a, c;
-  bool col = false;
-  if (!colcache_masks(selectors, n_selectors, 0, &a, &c, &col)) return 0;
-  return col ? 1 : 0;   // (chains that only ever write row cur have the one-wave cached step of rows_cached.hip)
+  ColMasks m;
+  if (!colcache_masks(selectors, n_selectors, N, 0, &m)) return 0;
+  return m.writes_column ? 1 : 0;   // (chains that only ever write row cur have the one-wave cached step of rows_cached.hip)
 }
 
 extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, float* adj, int64_t* count,
@@ -464,10 +523,9 @@ extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, floa
   GCM_REQUIRE(obs && nodes && adj && count && params && cache_agg1 && cache_root && saved && flags);
   GCM_REQUIRE(B > 0 && cur_host >= 0);
   if (!gcm_dense_rows_colcache_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
-  if (cur_host >= N) return GCM_EUNSUPPORTED;   // (a full graph rolls: the caches stop being valid)
   if ((size_t)B * N * (size_t)(F > N ? F : N) >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;
-  gcm_rows::RowMask srow, scol;
-  if (!colcache_masks(selectors, n_selectors, cur_host, &srow, &scol, nullptr)) return GCM_EUNSUPPORTED;
+  ColMasks m;
+  if (!colcache_masks(selectors, n_selectors, N, cur_host, &m)) return GCM_EUNSUPPORTED;
   const float* w_rel1 = params;
   const float* w_root1 = w_rel1 + (size_t)H1 * F;
   const float* b1 = w_root1 + (size_t)H1 * F;
@@ -482,7 +540,8 @@ extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, floa
 #define GCM_CC(a, b_, c)                                                                                          \
   if (F == a && H1 == b_ && (H2 <= 32 ? 1 : 2) == c) {                                                           \
     hipLaunchKernelGGL((gcm_rows::k_step_colcache<a, b_, c>), dim3(B), dim3(256), 0, s, obs, nodes, adj, count,     \
-                       srow, scol, cur_host, P, cache_agg1, cache_root, saved, lay, flags, N, H2);                  \
+                       m.ssrc, m.self, m.scol, m.sdrop, m.cur, m.rot, m.steady, P, cache_agg1, cache_root, saved,   \
+                       lay, flags, N, H2);                                                                          \
     return gcm_launch_status();                                                                                   \
   }
   GCM_CC(32, 32, 1) GCM_CC(32, 32, 2) GCM_CC(64, 32, 1) GCM_CC(64, 32, 2)

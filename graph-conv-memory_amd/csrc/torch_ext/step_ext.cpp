@@ -967,7 +967,8 @@ struct RowsFast {
       if (roll_ok && cached_steps < (int64_t)0x7fffffff) return launch_cached_roll(obs, nodes_in, adj_in, weights, count_in);
       if (ring_ok && abits.defined()) return launch_ring(obs, nodes_in, adj_in, weights, count_in);
     }
-    if (col_ok && cached_steps == chain_steps && cached_steps < N &&
+    // (below N steps and - the ring form - past them: every step then drops the oldest node)
+    if (col_ok && cached_steps == chain_steps && cached_steps < (int64_t)0x7fffffff &&
         (cached_steps == 0 || (kA.size(0) == B && state_untouched())))
       return launch_colcache(obs, nodes_in, adj_in, weights, count_in);
     cache_ok = col_ok = false;

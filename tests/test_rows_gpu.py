@@ -737,12 +737,16 @@ def test_rows_cached_steps_vs_oracle(sel, B, N, F, H, T):
                                                (("temporal", [0, 2], "both"), 3, 20, 32, 64, 16, 26),
                                                (("dense", None, None), 2, 64, 64, 64, 64, 70),
                                                (("temporal", [1, 2, 4], "both"), 300, 128, 32, 32, 32, 20),
+                                               (("dense", None, None), 3, 32, 32, 32, 32, 150),      # (> 4 N steps)
+                                               (("temporal", [0, 3, 5], "both"), 4, 20, 32, 32, 32, 75),
+                                               (("temporal", [2, 7], "backward"), 2, 8, 64, 64, 40, 30),
                                                (("dense", None, None), 3, 16, 8, 16, 16, 20)])   # (widths without the form)
 def test_rows_colcache_steps_vs_oracle(sel, B, N, F, H1, H2, T):
     """A donated rollout from hidden = None whose selectors also write COLUMN cur of the adjacency - DenseEdge
     (dense.py:16-21), TemporalBackedge "backward" / "both" (temporal.py:82-87): its first N steps are column-write
     cached steps (rows_colcache.hip: rank-1 updates of the chain's layer-1 aggregate, one matrix-core product of the
-    live rows), the steps behind them the usual live-row ones; one backward over both kinds of record.  Against the
+    live rows), and so are the steps behind them (the caches as rings: a full graph drops its oldest node every step,
+    the rows that held it as a source get the opposite rank-1 correction); one backward over the records.  Against the
     oracle (state bit exact, beliefs and gradients inside the float64 bound) and against the same rollout with the
     form switched off."""
     res = []
@@ -759,7 +763,7 @@ def test_rows_colcache_steps_vs_oracle(sel, B, N, F, H1, H2, T):
             mx, hid = mem(obs[t].to(DEV), hid)
             outs.append(mx)
         assert mem.rows_steps() == T
-        assert mem.rows_col_steps_taken() == (min(T, N) if on and takes else 0)
+        assert mem.rows_col_steps_taken() == (T if on and takes else 0)      # (past N steps: the ring form)
         assert mem.rows_cached_steps_taken() == 0
         out = torch.stack(outs)
         (out * w.to(DEV)).sum().backward()
