@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   const int rw = lay.rw;
   float* sv_rows = saved + lay.o_rows + gb * N * rw;
   const int n_slots = steady ? N : cur + 1;       // slots in use after the step = graph rows read below
-  const bool tile_on = 32 * wave < n_slots;       // wave-uniform: this wave's 32 slots hold a node
+  // wave-uniform: this wave's 32 slots hold a row the step touches (a live row, a row whose aggregate changes, the new
+  // row) - with a handful of temporal hops most tiles hold none and skip their loads, product and activation
+  const bool tile_on = 32 * wave < n_slots && ((mword(ssrc, wave) | mword(scol, wave) | mword(sdrop, wave)) != 0u ||
+                                               (cur >> 5) == wave);
 
   STAMP(0);
   // ---- every load of the step, in the order of use, before anything waits ------------------------------------------
@@ -385,6 +388,10 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       if (rec) with_act(std::true_type{});
       else with_act(std::false_type{});
     }
+  }
+  else if (lh == 0) {   // (a tile without work: its part of agg2 is zero)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) sA2[wave * HK + 32 * ct + li] = 0.f;
   }
   STAMP(8);
   lds_barrier();   // #3
