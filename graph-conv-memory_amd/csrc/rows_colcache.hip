@@ -31,6 +31,7 @@
 
 #include "fused_common.h"
 #include "rows_common.h"
+#include "rows_state_waves.h"
 
 #ifdef GCM_STAMPS   // diagnostic build only (make stamps11, tools/kstamp_colcache.py)
 __device__ unsigned long long g_stamps[32];
@@ -67,12 +68,24 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the new node as a source;  sdrop (steady state): the stored rows that lose the dropped node as a source - all in RING
 // coordinates (slot of a node = its chain index mod N; below N steps slot = graph row).  cur: the new node's slot;
 // rot: the slot of graph row 0 as the state comes in (0 below N steps);  n_slots: slots in use after the step.
-template <int FK, int HK, int O2T>
+// FUNC: functional state (the reference's default: gcm.py:262,278,286 clone it every step) - the state advance (copy,
+// roll, the selectors' entries, the observation, the count) runs in GCM_STATE_WGS extra workgroups per graph of the same
+// launch (rows_state_waves.h: blocks >= Bn; `E` = the selector chain as they want it), the compute workgroups read the
+// incoming state and write the chain's caches and the record only.
+template <int FK, int HK, int O2T, bool FUNC>
 __global__ __launch_bounds__(256) void k_step_colcache(
-    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
-    const RowMask ssrc, const int self, const RowMask scol, const RowMask sdrop, const int cur, const int rot,
-    const int steady, const Gnn2 P, float* __restrict__ cA, float* __restrict__ cR, float* __restrict__ saved,
-    const SavedLayout lay, uint32_t* __restrict__ flags, const int N, const int H2) {
+    const float* __restrict__ obs, const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes,
+    float* adj, int64_t* count, const RowMask ssrc, const int self, const RowMask scol, const RowMask sdrop,
+    const int cur, const int rot, const int steady, const Gnn2 P, float* __restrict__ cA, float* __restrict__ cR,
+    float* __restrict__ saved, const SavedLayout lay, uint32_t* __restrict__ flags, const int N, const int H2,
+    const Edits E, const int Bn) {
+  if (FUNC && (int)blockIdx.x >= Bn) {
+    const int q = blockIdx.x - Bn, bs = q % Bn, ks = q / Bn;
+    advance_state_waves<FK>(obs, nodes_in + (size_t)bs * N * FK, adj_in + (size_t)bs * N * N, count_in,
+                            nodes + (size_t)bs * N * FK, adj + (size_t)bs * N * N, count, nullptr, E, flags, nullptr, bs,
+                            ks, threadIdx.x, N, FK);
+    return;
+  }
   constexpr int C4 = FK / 4;       // 16-byte pieces of a node row
   constexpr int RG = 256 / C4;     // node rows per pass of the workgroup (32 or 16)
   constexpr int XP = 128 / RG;     // node rows per thread
@@ -92,7 +105,8 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t gb = (size_t)b;
-  float* ng = nodes + gb * N * FK;
+  const float* ng_in = nodes_in + gb * N * FK;   // the state as it comes in (FUNC: never written)
+  float* ng = nodes + gb * N * FK;               // donated: the same matrix, advanced in place
   float* ag = adj + gb * N * N;
   float* cAg = cA + gb * N * FK;
   float* cRg = cR + gb * N * HK;
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
 
   STAMP(0);
   // ---- every load of the step, in the order of use, before anything waits ------------------------------------------
-  const int64_t n_in = count[b];
+  const int64_t n_in = count_in[b];
   // steady state: the dropped node - graph row 0 - as the A-operand lanes hold a row.  FIRST in the queue: loads return
   // in order, so a wave that has its node rows (barrier #1) has this one too - the roll overwrites row 0 behind that
   // barrier.
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   for (int q = 0; q < KQ; ++q) xo[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (steady) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) xo[q] = *reinterpret_cast<const f32x4*>(ng + lh * KH + 4 * q);
+    for (int q = 0; q < KQ; ++q) xo[q] = *reinterpret_cast<const f32x4*>(ng_in + lh * KH + 4 * q);
   }
   asm volatile("" ::: "memory");   // (the compiler keeps them in front of the node rows' loads)
   // node rows (graph coordinates, the state as it comes in), one 16-byte piece per (row group, piece) thread: the new
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   for (int i = 0; i < XP; ++i) {
     const int row = rg + RG * i;
     if (RG * i < n_slots)   // (uniform: passes beyond the stored rows are skipped)
-      xr[i] = *reinterpret_cast<const f32x4*>(ng + (row < N ? row : N - 1) * FK + 4 * c4);
+      xr[i] = *reinterpret_cast<const f32x4*>(ng_in + (row < N ? row : N - 1) * FK + 4 * c4);
     else
       xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   // overflow roll (gcm.py:323-355: row i <- row i + 1), in place: every wave's loads of it landed before barrier #1
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
-    if (RG * i >= n_slots) continue;
+    if (FUNC || RG * i >= n_slots) continue;   // (functional state: the state workgroups write the new matrix)
     const int row = rg + RG * i;
     if (steady) {
       if (row < N) *reinterpret_cast<f32x4*>(ng + (row == 0 ? N - 1 : row - 1) * FK + 4 * c4) = row == 0 ? obq : xr[i];
@@ -447,7 +461,9 @@ __global__ __launch_bounds__(256) void k_step_colcache(
       float* cf = saved + lay.o_coef + gb * N;
       for (int l = t2; l < L; l += 192) cf[l] = l == 0 ? (self ? 1.f : 0.f) : 1.f;
     }
-    if (!steady) {
+    if (FUNC) {
+      // (the state workgroups write the whole new state, flags included)
+    } else if (!steady) {
       // the selectors' entries (below N steps slot = graph row); in the steady state the adjacency is a fixed point
       // of roll + selectors - a Toeplitz pattern built by the same hops at every step - and stays as it is
       for (int j = t2; j <= cur; j += 192) {
@@ -522,17 +538,29 @@ extern "C" int gcm_dense_rows_colcache_supported(const gcm_selector_desc* select
   return m.writes_column ? 1 : 0;   // (chains that only ever write row cur have the one-wave cached step of rows_cached.hip)
 }
 
-extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, float* adj, int64_t* count,
-                                            const gcm_selector_desc* selectors, int n_selectors, const float* params,
-                                            int has_bias, int act1, int act2, float* cache_agg1, float* cache_root,
-                                            float* saved, int record, int cur_host, uint32_t* flags, int B, int N,
-                                            int F, int H1, int H2, gcm_stream_t stream) {
-  GCM_REQUIRE(obs && nodes && adj && count && params && cache_agg1 && cache_root && saved && flags);
+static int colcache_launch(const float* obs, const float* nodes_in, const float* adj_in, const int64_t* count_in,
+                           float* nodes_out, float* adj_out, int64_t* count_out, const gcm_selector_desc* selectors,
+                           int n_selectors, const float* params, int has_bias, int act1, int act2, float* cache_agg1,
+                           float* cache_root, float* saved, int record, int cur_host, uint32_t* flags, int B, int N,
+                           int F, int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(obs && nodes_in && adj_in && count_in && nodes_out && adj_out && count_out && params && cache_agg1 &&
+              cache_root && saved && flags);
   GCM_REQUIRE(B > 0 && cur_host >= 0);
+  GCM_REQUIRE((nodes_out == nodes_in) == (adj_out == adj_in) && (nodes_out == nodes_in) == (count_out == count_in));
   if (!gcm_dense_rows_colcache_supported(selectors, n_selectors, has_bias, N, F, H1, H2)) return GCM_EUNSUPPORTED;
   if ((size_t)B * N * (size_t)(F > N ? F : N) >= ((size_t)1 << 31)) return GCM_EUNSUPPORTED;
   ColMasks m;
   if (!colcache_masks(selectors, n_selectors, N, cur_host, &m)) return GCM_EUNSUPPORTED;
+  gcm_fused::Edits E{};
+  for (int i = 0; i < n_selectors; ++i) {   // (the state workgroups of the functional form take the chain as hops)
+    const gcm_selector_desc& d = selectors[i];
+    if (d.kind == GCM_SEL_DENSE) E.dense = 1;
+    for (int k = 0; d.kind == GCM_SEL_TEMPORAL && k < d.n_hops; ++k) {
+      if (E.n_hops >= 16) return GCM_EUNSUPPORTED;
+      E.hops[E.n_hops] = d.hops[k];
+      E.dir[E.n_hops++] = d.direction;
+    }
+  }
   const float* w_rel1 = params;
   const float* w_root1 = w_rel1 + (size_t)H1 * F;
   const float* b1 = w_root1 + (size_t)H1 * F;
@@ -544,15 +572,43 @@ extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, floa
   if (lay.total >= ((size_t)1 << 32)) return GCM_EUNSUPPORTED;   // (32-bit float offsets into the record)
   if (!record) lay.total = 0;
   hipStream_t s = (hipStream_t)stream;
+  const bool func = nodes_out != nodes_in;
 #define GCM_CC(a, b_, c)                                                                                          \
   if (F == a && H1 == b_ && (H2 <= 32 ? 1 : 2) == c) {                                                           \
-    hipLaunchKernelGGL((gcm_rows::k_step_colcache<a, b_, c>), dim3(B), dim3(256), 0, s, obs, nodes, adj, count,     \
-                       m.ssrc, m.self, m.scol, m.sdrop, m.cur, m.rot, m.steady, P, cache_agg1, cache_root, saved,   \
-                       lay, flags, N, H2);                                                                          \
+    if (func)                                                                                                     \
+      hipLaunchKernelGGL((gcm_rows::k_step_colcache<a, b_, c, true>), dim3((1 + GCM_STATE_WGS) * B), dim3(256), 0, s, \
+                         obs, nodes_in, adj_in, count_in, nodes_out, adj_out, count_out, m.ssrc, m.self, m.scol,      \
+                         m.sdrop, m.cur, m.rot, m.steady, P, cache_agg1, cache_root, saved, lay, flags, N, H2, E, B); \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gcm_rows::k_step_colcache<a, b_, c, false>), dim3(B), dim3(256), 0, s, obs, nodes_in,       \
+                         adj_in, count_in, nodes_out, adj_out, count_out, m.ssrc, m.self, m.scol, m.sdrop, m.cur,     \
+                         m.rot, m.steady, P, cache_agg1, cache_root, saved, lay, flags, N, H2, E, B);                 \
     return gcm_launch_status();                                                                                   \
   }
   GCM_CC(32, 32, 1) GCM_CC(32, 32, 2) GCM_CC(64, 32, 1) GCM_CC(64, 32, 2)
   GCM_CC(32, 64, 1) GCM_CC(32, 64, 2) GCM_CC(64, 64, 1) GCM_CC(64, 64, 2)
 #undef GCM_CC
   return GCM_EUNSUPPORTED;
+}
+
+extern "C" int gcm_dense_rows_step_colcache(const float* obs, float* nodes, float* adj, int64_t* count,
+                                            const gcm_selector_desc* selectors, int n_selectors, const float* params,
+                                            int has_bias, int act1, int act2, float* cache_agg1, float* cache_root,
+                                            float* saved, int record, int cur_host, uint32_t* flags, int B, int N,
+                                            int F, int H1, int H2, gcm_stream_t stream) {
+  return colcache_launch(obs, nodes, adj, count, nodes, adj, count, selectors, n_selectors, params, has_bias, act1, act2,
+                         cache_agg1, cache_root, saved, record, cur_host, flags, B, N, F, H1, H2, stream);
+}
+
+extern "C" int gcm_dense_rows_step_colcache_functional(const float* obs, const float* nodes_in, const float* adj_in,
+                                                       const int64_t* count_in, float* nodes_out, float* adj_out,
+                                                       int64_t* count_out, const gcm_selector_desc* selectors,
+                                                       int n_selectors, const float* params, int has_bias, int act1,
+                                                       int act2, float* cache_agg1, float* cache_root, float* saved,
+                                                       int record, int cur_host, uint32_t* flags, int B, int N, int F,
+                                                       int H1, int H2, gcm_stream_t stream) {
+  GCM_REQUIRE(nodes_out != nodes_in && adj_out != adj_in && count_out != count_in);
+  return colcache_launch(obs, nodes_in, adj_in, count_in, nodes_out, adj_out, count_out, selectors, n_selectors, params,
+                         has_bias, act1, act2, cache_agg1, cache_root, saved, record, cur_host, flags, B, N, F, H1, H2,
+                         stream);
 }

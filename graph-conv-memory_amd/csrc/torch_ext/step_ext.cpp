@@ -743,7 +743,8 @@ struct RowsFast {
               cfg->descs[0].mode == GCM_DIST_EUCLID_CROSSBATCH && !cfg->descs[0].bidirectional &&
               cfg->descs[0].dist_param == nullptr && cfg->descs[0].cur_rows == nullptr && !(cfg->has_bias & ~3) &&
               !(cfg->cached_flags & GCM_STEP_TWO_LAUNCH);
-    col_ok = !cache_ok && fresh && donate && dx_kind == 0 && !cfg->has_distance && cfg->col_cache &&
+    // (donated or functional state: the functional form writes the new state from extra workgroups of its launch)
+    col_ok = !cache_ok && fresh && dx_kind == 0 && !cfg->has_distance && cfg->col_cache &&
              gcm_dense_rows_colcache_supported(cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
                                                cfg->has_bias, cfg->N, cfg->F, cfg->H1, cfg->H2) != 0;
     armed = true;
@@ -763,13 +764,30 @@ struct RowsFast {
     check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
     at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
-    check(gcm_dense_rows_step_colcache(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
-                                       count_in.data_ptr<int64_t>(), cfg->descs.data(), (int)cfg->descs.size(),
-                                       packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
-                                       kA.data_ptr<float>(), kR.data_ptr<float>(), buf.data_ptr<float>(),
-                                       need_bwd ? 1 : 0, (int)cached_steps,
-                                       reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
-          "gcm_dense_rows_step_colcache");
+    at::Tensor nodes_out = nodes_in, adj_out = adj_in, count_out = count_in;
+    if (donate) {
+      check(gcm_dense_rows_step_colcache(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                                         count_in.data_ptr<int64_t>(), cfg->descs.data(), (int)cfg->descs.size(),
+                                         packed.data_ptr<float>(), cfg->has_bias, cfg->act1, cfg->act2,
+                                         kA.data_ptr<float>(), kR.data_ptr<float>(), buf.data_ptr<float>(),
+                                         need_bwd ? 1 : 0, (int)cached_steps,
+                                         reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1, H2, stream),
+            "gcm_dense_rows_step_colcache");
+    } else {   // functional state: one allocation for the new nodes | adj | count, as the general step makes it
+      const int64_t n_nodes = pad64(B * N * F), n_adj = pad64(B * (int64_t)N * N);
+      at::Tensor st = at::empty({n_nodes + n_adj + pad64(2 * B)}, obs.options());
+      nodes_out = alias_of(st, 0, {B, N, F}, st.dtype());
+      adj_out = alias_of(st, n_nodes, {B, N, N}, st.dtype());
+      count_out = alias_of(st, (n_nodes + n_adj) / 2, {B}, caffe2::TypeMeta::Make<int64_t>());
+      check(gcm_dense_rows_step_colcache_functional(
+                obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
+                count_in.data_ptr<int64_t>(), nodes_out.data_ptr<float>(), adj_out.data_ptr<float>(),
+                count_out.data_ptr<int64_t>(), cfg->descs.data(), (int)cfg->descs.size(), packed.data_ptr<float>(),
+                cfg->has_bias, cfg->act1, cfg->act2, kA.data_ptr<float>(), kR.data_ptr<float>(), buf.data_ptr<float>(),
+                need_bwd ? 1 : 0, (int)cached_steps, reinterpret_cast<uint32_t*>(flags.data_ptr()), (int)B, N, F, H1,
+                H2, stream),
+            "gcm_dense_rows_step_colcache_functional");
+    }
     at::Tensor mx = alias_of(buf, 0, {B, H2}, buf.dtype());
     if (need_bwd) {
       const c10::VariableVersion& vc = mx.unsafeGetTensorImpl()->version_counter();
@@ -778,10 +796,10 @@ struct RowsFast {
       torch::autograd::create_gradient_edge(mx, node);
       node->recs.push_back(std::move(r));
     }
-    l_nodes = nodes_in;
-    l_adj = adj_in;
+    l_nodes = nodes_out;
+    l_adj = adj_out;
     l_weights = weights;
-    l_count = count_in;
+    l_count = count_out;
     note_versions();
     xB = B;
     xF = obs.size(1);
@@ -1083,10 +1101,11 @@ struct RowsFast {
     if (!armed || c != cfg || packed_.unsafeGetTensorImpl() != packed.unsafeGetTensorImpl() ||
         flags_.unsafeGetTensorImpl() != flags.unsafeGetTensorImpl() || want_donate(donate_, need_dx, nodes_in) != donate ||
         grad_mode != at::GradMode::is_enabled() || (node && node->executed) || (dxc && dxc->executed) || new_chain ||
-        (fresh && donate_ && need_dx == 0))   // (a rollout from empty graphs: its own chain node - it may own caches)
+        (fresh && need_dx == 0))   // (a rollout from empty graphs: its own chain node - it may own caches; donated or -
+                                   //  the column-write cached steps - functional state)
       arm(packed_, flags_, cfg_handle, donate_, need_dx, nodes_in, count_in, fresh);
-    else if (cache_ok && !continues(nodes_in, adj_in, weights, count_in))
-      cache_ok = false;
+    else if ((cache_ok || col_ok) && !continues(nodes_in, adj_in, weights, count_in))
+      cache_ok = col_ok = false;
     at::Tensor mx = launch(obs, nodes_in, adj_in, weights, count_in);
     return pybind11::make_tuple(mx, l_nodes, l_adj, l_count, donate);
   }

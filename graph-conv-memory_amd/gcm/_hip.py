@@ -115,6 +115,7 @@ PROTOTYPES = {
     "gcm_dense_rows_step_cached_roll": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]
                                         + [_I] * 5 + [_P]),
     "gcm_dense_rows_colcache_supported": (_I, [_P, _I, _I, _I, _I, _I, _I]),
+    "gcm_dense_rows_step_colcache_functional": (_I, [_P] * 8 + [_I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_step_colcache": (_I, [_P] * 5 + [_I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P] + [_I] * 5 + [_P]),
     "gcm_dense_rows_cached_launches": (_I, [_P, _I, _I, _I, _I, _I, _I, _I]),
     "gcm_edge_distance_step_cached": (_I, [_P] * 4 + [_F, _P, _P, _I, _P, _P, _I, _I] + [_P] * 5 + [_I, _I, _P, _P]

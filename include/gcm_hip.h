@@ -700,6 +700,16 @@ int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, const gcm_se
  * gcm_dense_rows_step_cached). */
 int gcm_dense_rows_colcache_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias, int N,
                                       int F, int H1, int H2);
+/* ... with FUNCTIONAL state (the reference's default, gcm.py:262,278,286: the inputs are never modified): the new state
+ * (copy, overflow roll, the selectors' entries, the observation, the count) is written to the *_out buffers by extra
+ * workgroups of the same launch, the chain's caches stay valid as long as the caller hands the state returned last back
+ * in (a linear chain - the host checks it by tensor identity). */
+int gcm_dense_rows_step_colcache_functional(const float* obs, const float* nodes_in, const float* adj_in,
+                                            const int64_t* count_in, float* nodes_out, float* adj_out,
+                                            int64_t* count_out, const gcm_selector_desc* selectors, int n_selectors,
+                                            const float* params, int has_bias, int act1, int act2, float* cache_agg1,
+                                            float* cache_root, float* saved, int record, int cur_host, uint32_t* flags,
+                                            int B, int N, int F, int H1, int H2, gcm_stream_t stream);
 int gcm_dense_rows_step_colcache(const float* obs, float* nodes, float* adj, int64_t* count,
                                  const gcm_selector_desc* selectors, int n_selectors, const float* params,
                                  int has_bias, int act1, int act2, float* cache_agg1, float* cache_root, float* saved,

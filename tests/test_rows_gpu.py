@@ -797,6 +797,62 @@ def test_rows_colcache_steps_vs_oracle(sel, B, N, F, H1, H2, T):
             assert float((gd.double() - g64).abs().max()) <= atol, k
 
 
+@pytest.mark.parametrize("sel,B,N,F,H,T", [(("dense", None, None), 4, 16, 32, 32, 40),
+                                           (("temporal", [1, 3], "both"), 3, 32, 64, 32, 50),
+                                           (("dense", None, None), 260, 128, 32, 32, 12)])
+def test_rows_colcache_functional_state(sel, B, N, F, H, T):
+    """The reference's default - functional state: every step returns fresh nodes / adj / num_nodes and leaves its
+    inputs untouched (gcm.py:262,278,286) - on the column-write cached steps: the new state comes from extra workgroups of
+    the same launch.  Every intermediate state is kept and compared with the oracle's (bit exact), beliefs and
+    gradients inside the float64 bound; a second rollout of the same module starts a new chain; a call that branches
+    off an OLDER state leaves the cached run."""
+    torch.manual_seed(N + T)
+    ref, g, mem, osel = _mk(B, N, F, H, H, sel, False)
+    obs = torch.rand(T, B, F) - 0.5
+    w = torch.rand(T, B, H)
+    for rep in range(2):
+        g.zero_grad(set_to_none=True)
+        hid, outs, states = None, [], []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+            states.append(hid)
+        assert mem.rows_col_steps_taken() == T
+        out = torch.stack(outs)
+        (out * w.to(DEV)).sum().backward()
+        mem.check_flags()
+    assert len({h[0].data_ptr() for h in states}) == T       # fresh tensors every step
+    pick = list(range(B)) if B <= 16 else [0, B // 2, B - 1]
+    if B > 16:
+        g.zero_grad(set_to_none=True)
+        wz = torch.zeros_like(w)
+        wz[:, pick] = w[:, pick]
+        hid, outs = None, []
+        for t in range(T):
+            mx, hid = mem(obs[t].to(DEV), hid)
+            outs.append(mx)
+        (torch.stack(outs) * wz.to(DEV)).sum().backward()
+    out32, hid32, bounds, (out64, out_atol) = _fp64_rollout_bounds(ref, obs[:, pick], None, w[:, pick], lambda: osel, N)
+    assert float((out.detach().cpu()[:, pick].double() - out64).abs().max()) <= out_atol
+    for k, p in g.named_parameters():
+        g64, atol = bounds[k]
+        assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
+    # the state after every step against the oracle's, step by step
+    h_o = None
+    for t in range(T):
+        _, h_o = od.dense_rollout(obs[t:t + 1, pick], h_o, ref, graph_size=N, edge_selectors=osel)
+        h_o = tuple(x.detach() for x in h_o)
+        n_d, a_d, _, c_d = states[t]
+        assert torch.equal(n_d.cpu()[pick], h_o[0]) and torch.equal(a_d.cpu()[pick], h_o[1]), t
+        assert torch.equal(c_d.cpu()[pick], h_o[3]), t
+    # branching off an older state: the general kernel, the same values as the chain had at that point
+    if T > 5:
+        with torch.no_grad():
+            mx_b, _ = mem(obs[4].to(DEV), states[3])
+        assert mem.rows_col_steps_taken() == 0      # (a new chain, armed on a caller's state: no cached form)
+        torch.testing.assert_close(mx_b.cpu(), out.detach().cpu()[4], rtol=1e-5, atol=5e-6)
+
+
 def test_rows_colcache_leaves_an_edited_chain():
     """A caller that edits the donated state in place between two steps (zeroing the graphs of finished episodes) ends
     the column-write cached run: the next step is the general live-row kernel on the state as it is."""
