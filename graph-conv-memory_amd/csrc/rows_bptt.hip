@@ -23,6 +23,10 @@
 #include "fused_common.h"
 #include "rows_common.h"
 
+#ifndef GCM_BPTT_PB
+#define GCM_BPTT_PB 8   // MODE 4: row pairs a wave fetches ahead (A/B: make ... CXXFLAGS+=-DGCM_BPTT_PB=12)
+#endif
+
 namespace gcm_rows {
 
 // History of DenseGCM.rollout's persistent forward kernel (rollout_persist.hip) as the record source:
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   // sixteen it is consuming - the next item's first batch behind an item's last - so ~6 KB per wave are always on
   // their way.  Same arithmetic, same order of the sums per wave as the pair form.
   if (MODE == 4) {
-    constexpr int PB = 8;   // row pairs per batch
+    constexpr int PB = GCM_BPTT_PB;   // row pairs per batch
     const int q = lane & 31, half = lane >> 5;
     const int ocq = q < H2 ? q : H2 - 1;
     struct FrontD {

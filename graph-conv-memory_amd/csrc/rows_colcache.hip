@@ -72,6 +72,37 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // roll, the selectors' entries, the observation, the count) runs in GCM_STATE_WGS extra workgroups per graph of the same
 // launch (rows_state_waves.h: blocks >= Bn; `E` = the selector chain as they want it), the compute workgroups read the
 // incoming state and write the chain's caches and the record only.
+// FUNC: functional state (the reference's default: gcm.py:262,278,286 clone it every step) - the state advance (copy,
+// roll, the selectors' entries, the observation, the count) runs in GCM_STATE_WGS extra workgroups per graph of the same
+// launch (rows_state_waves.h: blocks >= Bn; `E` = the selector chain as they want it), the compute workgroups read the
+// incoming state and write the chain's caches and the record only.
+// gcm_tanh (gcm_common.h) on four independent values: the same two forms and the same select, value for value - but the
+// polynomial form (|x| < 0.25, where 1 - e would cancel) is evaluated only when some lane of the wave holds such a value:
+// behind sums over many nodes most pre-activations are large, and the epilogue of these kernels is one wave's
+// instruction stream (a uniform branch, so the results do not depend on it).
+__device__ __forceinline__ void tanh4(float (&x)[4]) {
+  float big[4];
+  bool any_small = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float ax = fabsf(x[i]);
+    const float e = __expf(-2.f * ax);
+    big[i] = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+    any_small |= ax < 0.25f;
+  }
+  if (__any(any_small)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ax = fabsf(x[i]), x2 = x[i] * x[i];
+      const float small =
+          ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+      big[i] = ax < 0.25f ? small : big[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = copysignf(big[i], x[i]);
+}
+
 template <int FK, int HK, int O2T, bool FUNC>
 __global__ __launch_bounds__(256) void k_step_colcache(
     const float* __restrict__ obs, const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes,
@@ -138,12 +169,14 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   const int c4 = tid % C4, rg = tid / C4;
   f32x4 xr[XP];
 #pragma unroll
+  for (int i = 0; i < XP; ++i) xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int i = 0; i < XP; ++i) {
+    // (uniform: passes beyond the stored rows are skipped.  The zero fill sits BEFORE the loads: as the other arm of
+    //  the branch it made hipcc wait for every load in flight - vmcnt(0) - right behind the first pass)
     const int row = rg + RG * i;
-    if (RG * i < n_slots)   // (uniform: passes beyond the stored rows are skipped)
+    if (i == 0 || RG * i < n_slots)   // (pass 0 always holds a row: no branch - hipcc waited behind its conditional form)
       xr[i] = *reinterpret_cast<const f32x4*>(ng_in + (row < N ? row : N - 1) * FK + 4 * c4);
-    else
-      xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const f32x4 obq = *reinterpret_cast<const f32x4*>(obs + gb * FK + 4 * c4);
   // the observation as the A-operand lanes hold a row: k in [lh KH, (lh + 1) KH)
@@ -373,7 +406,12 @@ __global__ __launch_bounds__(256) void k_step_colcache(
             for (int ii = 0; ii < 4; ++ii) {
               const bool is_cur = cur_blk && 8 * q4 + ii + 4 * lh == cur_bit;
               const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
-              h[ii] = actf(acc[ct][4 * q4 + ii] + (is_cur ? rcur : rr));
+              h[ii] = acc[ct][4 * q4 + ii] + (is_cur ? rcur : rr);
+            }
+            actf(h);   // the four rows side by side
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+              const bool is_cur = cur_blk && 8 * q4 + ii + 4 * lh == cur_bit;
               st[ii] = ((srl >> (8 * q4 + ii)) & 1u) != 0;   // a stored source: in agg2, and it has a record row
               a2 += (st[ii] || (is_cur && self != 0)) ? h[ii] : 0.f;
               hc = is_cur ? h[ii] : hc;
@@ -395,9 +433,17 @@ __global__ __launch_bounds__(256) void k_step_colcache(
         }
       };
       auto with_act = [&](auto recc) {
-        if (act1 == GCM_ACT_TANH) epilogue([](float v) { return gcm_tanh(v); }, recc);
-        else if (act1 == GCM_ACT_RELU) epilogue([](float v) { return v > 0.f ? v : 0.f; }, recc);
-        else epilogue([](float v) { return v; }, recc);
+        // (a wave-uniform "no lane holds a small value: skip gcm_tanh's polynomial arm" was tried: with 256 values a
+        //  wave some lane almost always does - 0.13 us slower)
+        if (act1 == GCM_ACT_TANH) epilogue([](float (&v)[4]) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gcm_tanh(v[i]);
+        }, recc);
+        else if (act1 == GCM_ACT_RELU) epilogue([](float (&v)[4]) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        }, recc);
+        else epilogue([](float (&)[4]) {}, recc);
       };
       if (rec) with_act(std::true_type{});
       else with_act(std::false_type{});
