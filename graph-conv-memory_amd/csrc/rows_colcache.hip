@@ -72,37 +72,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // roll, the selectors' entries, the observation, the count) runs in GCM_STATE_WGS extra workgroups per graph of the same
 // launch (rows_state_waves.h: blocks >= Bn; `E` = the selector chain as they want it), the compute workgroups read the
 // incoming state and write the chain's caches and the record only.
-// FUNC: functional state (the reference's default: gcm.py:262,278,286 clone it every step) - the state advance (copy,
-// roll, the selectors' entries, the observation, the count) runs in GCM_STATE_WGS extra workgroups per graph of the same
-// launch (rows_state_waves.h: blocks >= Bn; `E` = the selector chain as they want it), the compute workgroups read the
-// incoming state and write the chain's caches and the record only.
-// gcm_tanh (gcm_common.h) on four independent values: the same two forms and the same select, value for value - but the
-// polynomial form (|x| < 0.25, where 1 - e would cancel) is evaluated only when some lane of the wave holds such a value:
-// behind sums over many nodes most pre-activations are large, and the epilogue of these kernels is one wave's
-// instruction stream (a uniform branch, so the results do not depend on it).
-__device__ __forceinline__ void tanh4(float (&x)[4]) {
-  float big[4];
-  bool any_small = false;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float ax = fabsf(x[i]);
-    const float e = __expf(-2.f * ax);
-    big[i] = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
-    any_small |= ax < 0.25f;
-  }
-  if (__any(any_small)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float ax = fabsf(x[i]), x2 = x[i] * x[i];
-      const float small =
-          ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
-      big[i] = ax < 0.25f ? small : big[i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = copysignf(big[i], x[i]);
-}
-
 template <int FK, int HK, int O2T, bool FUNC>
 __global__ __launch_bounds__(256) void k_step_colcache(
     const float* __restrict__ obs, const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes,
