@@ -940,7 +940,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                 variants["T%d_profile_error" % T2] = "%s: %s" % (type(e).__name__, str(e)[:120])
         if p2 is not None:
             if c["selector"] in ("temporal", "dense"):
-                kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_colcache<", "k_step_rows<")
+                kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_colcache", "k_step_rows<")
                 if kr is not None:
                     variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
                     variants["T%d_steady_state_kernel" % T2] = kr[0]
@@ -1153,7 +1153,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # the cur^2 F aggregation.  Priced on the fp32 MFMA peak, twice: EXECUTED flops of the kernel's own formulation
         # (per graph-step with L = cur + 1 live rows: 2 L^2 F aggregation + 4 L F H layer-1 linears + 2 L H + 4 H^2 for
         # row cur of layer 2), and SURVEY 8(d)'s full-dense flops (2 layers x all N rows) as the EFFECTIVE figure.
-        k = find_kernel(prof, "k_step_colcache<", "k_step_rows<")
+        k = find_kernel(prof, "k_step_colcache", "k_step_rows<")
         kb = find_kernel(prof, "k_bptt_dense<", "k_bptt_rows<")
         step_kernel, kd = k
         sec = kd["avg_us"] * 1e-6

@@ -492,6 +492,375 @@ __global__ __launch_bounds__(256) void k_step_colcache(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same step with EIGHT waves per graph at F = H1 = 32 (the bench shape): 16-slot tiles on v_mfma_f32_16x16x4_f32.
+// k_step_colcache's phases are one wave's dependent instruction stream each (in-kernel stamps: ~8 cycles an instruction
+// at one wave per SIMD - nothing fills the bubbles of a dependent chain); with two waves per SIMD the other wave does,
+// and every per-lane loop halves (8 activations a lane instead of 16, two node rows a thread instead of four).
+// Lane (m = lane & 15, g = lane >> 4) of wave w: slot 16 w + m as the A operand's row, k in [8 g, 8 g + 8) of it and of
+// W_rel1[col] (col = 16 ct + m) - the matrix instruction's k index is g, so instruction s pairs A[m][8 g + s] with
+// B[8 g + s][col]; its accumulators hold slots 16 w + 4 g + (0 .. 3) at column col = one quad of the root cache.
+// Same arguments, caches, record and results as k_step_colcache<32, 32, O2T, FUNC> (the sums of a row's 32 products are
+// associated differently: eight per lane group instead of sixteen per half).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int O2T, bool FUNC>
+__global__ __launch_bounds__(512) void k_step_colcache8(
+    const float* __restrict__ obs, const float* nodes_in, const float* adj_in, const int64_t* count_in, float* nodes,
+    float* adj, int64_t* count, const RowMask ssrc, const int self, const RowMask scol, const RowMask sdrop,
+    const int cur, const int rot, const int steady, const Gnn2 P, float* __restrict__ cA, float* __restrict__ cR,
+    float* __restrict__ saved, const SavedLayout lay, uint32_t* __restrict__ flags, const int N, const int H2,
+    const Edits E, const int Bn) {
+  constexpr int FK = 32, HK = 32;
+  if (FUNC && (int)blockIdx.x >= Bn) {
+    // (the state advance is written for GCM_STATE_WGS workgroups of 256 threads per graph: here the two halves of ONE
+    //  512-thread workgroup - it has no workgroup barrier and its cross-lane traffic stays inside a wave)
+    static_assert(GCM_STATE_WGS == 2, "two 256-thread halves per state workgroup");
+    const int bs = blockIdx.x - Bn, ks = threadIdx.x >> 8;
+    advance_state_waves<FK>(obs, nodes_in + (size_t)bs * N * FK, adj_in + (size_t)bs * N * N, count_in,
+                            nodes + (size_t)bs * N * FK, adj + (size_t)bs * N * N, count, nullptr, E, flags, nullptr,
+                            bs, ks, threadIdx.x & 255, N, FK);
+    return;
+  }
+  constexpr int C4 = 8, RG = 64, XP = 2, PS = FK + 4;
+  __shared__ __attribute__((aligned(16))) float sPart[RG * PS];
+  __shared__ __attribute__((aligned(16))) float sAggc[FK];
+  __shared__ float sRcur[HK];
+  __shared__ __attribute__((aligned(16))) float sV[2 * HK];
+  __shared__ float sA2[8 * HK];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t gb = (size_t)b;
+  const float* ng_in = nodes_in + gb * N * FK;
+  float* ng = nodes + gb * N * FK;
+  float* ag = adj + gb * N * N;
+  float* cAg = cA + gb * N * FK;
+  float* cRg = cR + gb * N * HK;
+  const bool rec = lay.total != 0;
+  const int rw = lay.rw;
+  float* sv_rows = saved + lay.o_rows + gb * N * rw;
+  const int n_slots = steady ? N : cur + 1;
+  // this wave's 16 slots as mask bits (scalars)
+  auto half16 = [&](const RowMask& k) { return (mword(k, wave >> 1) >> (16 * (wave & 1))) & 0xffffu; };
+  const unsigned sr_t = half16(ssrc), sc_t = half16(scol), sd_t = half16(sdrop);
+  const bool cur_in = (cur >> 4) == wave;
+  const bool tile_on = 16 * wave < n_slots && ((sr_t | sc_t | sd_t) != 0u || cur_in);
+
+  // ---- every load of the step, in the order of use ------------------------------------------------------------------
+  const int64_t n_in = count_in[b];
+  f32x4 xo[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) xo[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (steady) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) xo[q] = *reinterpret_cast<const f32x4*>(ng_in + 8 * g + 4 * q);
+  }
+  asm volatile("" ::: "memory");
+  const int c4 = tid % C4, rg = tid / C4;   // node rows rg and rg + 64, piece c4
+  f32x4 xr[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int row = rg + RG * i;
+    if (i == 0 || RG * i < n_slots)
+      xr[i] = *reinterpret_cast<const f32x4*>(ng_in + (row < N ? row : N - 1) * FK + 4 * c4);
+  }
+  const f32x4 obq = *reinterpret_cast<const f32x4*>(obs + gb * FK + 4 * c4);
+  f32x4 xa[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) xa[q] = *reinterpret_cast<const f32x4*>(obs + gb * FK + 8 * g + 4 * q);
+  // wave 7: W_root1 (the new node's root row)
+  f32x4 wr[2][2];
+  float b1v[2];
+  if (wave == 7) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        wr[ct][q] = *reinterpret_cast<const f32x4*>(P.w_root1 + (16 * ct + m) * FK + 8 * g + 4 * q);
+      b1v[ct] = P.b_rel1[16 * ct + m];
+    }
+  }
+  const int r = 16 * wave + m;
+  const int rc = r < N ? r : N - 1;
+  const int NQ = N >> 2;
+  f32x4 ca[2], wb[2][2], crq[2];
+  if (tile_on) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ca[q] = *reinterpret_cast<const f32x4*>(cAg + rc * FK + 8 * g + 4 * q);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        wb[ct][q] = *reinterpret_cast<const f32x4*>(P.w_rel1 + (16 * ct + m) * FK + 8 * g + 4 * q);
+    const int quad = 4 * wave + g;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+      crq[ct] = *reinterpret_cast<const f32x4*>(cRg + ((quad < NQ ? quad : NQ - 1) * HK + 16 * ct + m) * 4);
+  }
+  // wave 0: layer 2 (lane & 31 = output, lane >> 5 = W_rel2 . agg2 / W_root2 . h1[cur])
+  const int li = lane & 31, lh = lane >> 5;
+  f32x4 w2[O2T][HK / 4];
+  float b2v[O2T];
+  if (wave == 0) {
+#pragma unroll
+    for (int ot = 0; ot < O2T; ++ot) {
+      const int o = 32 * ot + li < H2 ? 32 * ot + li : H2 - 1;
+      const float* src = (lh ? P.w_root2 : P.w_rel2) + o * HK;
+#pragma unroll
+      for (int q = 0; q < HK / 4; ++q) w2[ot][q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+      b2v[ot] = P.b_rel2[o];
+    }
+  }
+  const int act1 = P.act1, act2 = P.act2;
+  asm volatile("" ::: "memory");
+
+  if (n_in != (int64_t)(steady ? N : cur)) {
+    if (tid == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);
+    return;
+  }
+  const unsigned sw0 = mword(ssrc, 0), sw1 = mword(ssrc, 1), sw2 = mword(ssrc, 2), sw3 = mword(ssrc, 3);
+  const int pc1 = 1 + __popc(sw0), pc2 = pc1 + __popc(sw1), pc3 = pc2 + __popc(sw2);
+  const int L = pc3 + __popc(sw3);
+  auto sword = [&](int w) { return w == 0 ? sw0 : (w == 1 ? sw1 : (w == 2 ? sw2 : sw3)); };
+  auto sbase = [&](int w) { return w == 0 ? 1 : (w == 1 ? pc1 : (w == 2 ? pc2 : pc3)); };
+
+  // ---- the new row's aggregate ----------------------------------------------------------------------------------------
+  auto new_row_sum = [&](auto ringc) {
+    constexpr bool RING = decltype(ringc)::value;
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      if (RG * i >= n_slots) continue;   // uniform
+      const int row = rg + RG * i;
+      const bool is_cur = steady ? row == 0 : row == cur;
+      bool stored;
+      unsigned pos;
+      if (RING) {
+        int slot = row + rot;
+        slot -= slot >= N ? N : 0;
+        stored = row < n_slots && !is_cur && mbit(ssrc, slot);
+        pos = 1u + (unsigned)mrank(ssrc, slot);
+      } else {
+        const int w = 2 * i + (rg >> 5), bit = row & 31;   // (row = rg + 64 i: word 2 i or 2 i + 1)
+        const unsigned word = sword(w);
+        stored = !is_cur && ((word >> bit) & 1u) != 0;
+        pos = (unsigned)sbase(w) + (unsigned)__popc(word & ((1u << bit) - 1u));
+      }
+      const f32x4 v = is_cur ? obq : xr[i];
+      if (stored || (is_cur && self != 0)) part += v;
+      if (rec && (stored || is_cur))
+        *reinterpret_cast<f32x4*>(sv_rows + (is_cur ? 0u : pos) * (unsigned)rw + HK + FK + 4 * c4) = v;
+    }
+    *reinterpret_cast<f32x4*>(sPart + rg * PS + 4 * c4) = part;
+  };
+  if (rot) new_row_sum(std::true_type{});
+  else new_row_sum(std::false_type{});
+  if (wave == 7) {   // the new node's root row: lane (col m, group g) takes eight k
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        t = fmaf(wr[ct][q].x, xa[q].x, t);
+        t = fmaf(wr[ct][q].y, xa[q].y, t);
+        t = fmaf(wr[ct][q].z, xa[q].z, t);
+        t = fmaf(wr[ct][q].w, xa[q].w, t);
+      }
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      const float v = t + b1v[ct];
+      if (g == 0) {
+        sRcur[16 * ct + m] = v;
+        cRg[((cur >> 2) * HK + 16 * ct + m) * 4 + (cur & 3)] = v;
+      }
+    }
+  }
+  lds_barrier();   // #1
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    if (FUNC || RG * i >= n_slots) continue;
+    const int row = rg + RG * i;
+    if (steady) {
+      if (row < N) *reinterpret_cast<f32x4*>(ng + (row == 0 ? N - 1 : row - 1) * FK + 4 * c4) = row == 0 ? obq : xr[i];
+    } else if (row == cur) {
+      *reinterpret_cast<f32x4*>(ng + cur * FK + 4 * c4) = obq;
+    }
+  }
+  if (wave == 6) {   // 64 row groups -> agg1[cur]: lane (feature, half) takes 32 groups
+    const int f = lane & 31, part = lane >> 5;
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = sPart[(part * 32 + k) * PS + f];
+    float s0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s0 += v[k];
+    s0 += __shfl_xor(s0, 32);
+    if (part == 0) {
+      sAggc[f] = s0;
+      cAg[cur * FK + f] = s0;
+      if (rec) sv_rows[HK + f] = s0;
+    }
+  }
+  lds_barrier();   // #2
+
+  // ---- layer 1 of the live rows: [16 slots x 32] . [32 x 32] per wave ----------------------------------------------
+  if (tile_on) {
+    const int rb = sbase(wave >> 1) + ((wave & 1) ? __popc(sword(wave >> 1) & 0xffffu) : 0);
+    const int cur_bit = cur_in ? cur & 15 : 99;
+    const bool upd = ((sc_t >> m) & 1u) != 0, drp = ((sd_t >> m) & 1u) != 0, lrow = ((sr_t >> m) & 1u) != 0;
+    const unsigned pos = (unsigned)rb + (unsigned)__popc(sr_t & ((1u << m) - 1u));
+    float* rdst = sv_rows + pos * (unsigned)rw + HK + 8 * g;
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 v = ca[q];
+      const f32x4 xq = xa[q], xd = xo[q];
+      if (steady) v -= f32x4{drp ? xd.x : 0.f, drp ? xd.y : 0.f, drp ? xd.z : 0.f, drp ? xd.w : 0.f};
+      v += f32x4{upd ? xq.x : 0.f, upd ? xq.y : 0.f, upd ? xq.z : 0.f, upd ? xq.w : 0.f};
+      if (upd || drp) *reinterpret_cast<f32x4*>(cAg + r * FK + 8 * g + 4 * q) = v;
+      if (m == cur_bit) v = *reinterpret_cast<const f32x4*>(sAggc + 8 * g + 4 * q);
+      if (rec && lrow) *reinterpret_cast<f32x4*>(rdst + 4 * q) = v;
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    f32x4 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 w = wb[ct][s >> 2];
+        const float wv = (s & 3) == 0 ? w.x : ((s & 3) == 1 ? w.y : ((s & 3) == 2 ? w.z : w.w));
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wv, acc[ct], 0, 0, 0);
+      }
+    // the activation of this lane's four slots (4 g + 0 .. 3) at columns m and 16 + m, side by side, no branch inside
+    auto epilogue = [&](auto actf, auto recc) {
+      constexpr bool REC = decltype(recc)::value;
+      const unsigned dump = (unsigned)(lay.o_deg - lay.o_rows) + (unsigned)(b * N + (m < N ? m : N - 1));
+      float* sv_rows0 = saved + lay.o_rows;
+      const unsigned gofs = (unsigned)b * (unsigned)N * (unsigned)rw;
+      const unsigned off0 = gofs + ((unsigned)rb + (unsigned)__popc(sr_t & ((1u << (4 * g)) - 1u))) * (unsigned)rw + (unsigned)m;
+      const bool cur_grp = cur_in && (cur_bit >> 2) == g;   // the new row sits in this lane's accumulators
+      float h[2][4];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const float rcur = sRcur[16 * ct + m];
+        const f32x4 rq = crq[ct];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const bool is_cur = cur_grp && (cur_bit & 3) == ii;
+          const float rr = ii == 0 ? rq.x : (ii == 1 ? rq.y : (ii == 2 ? rq.z : rq.w));
+          h[ct][ii] = acc[ct][ii] + (is_cur ? rcur : rr);
+        }
+      }
+      actf(h);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float a2 = 0.f, hc = 0.f;
+        unsigned off = off0 + 16u * ct;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const bool is_cur = cur_grp && (cur_bit & 3) == ii;
+          const bool st = ((sr_t >> (4 * g + ii)) & 1u) != 0;
+          a2 += (st || (is_cur && self != 0)) ? h[ct][ii] : 0.f;
+          hc = is_cur ? h[ct][ii] : hc;
+          if (REC) {
+            sv_rows0[st ? off : dump] = h[ct][ii];
+            off += st ? (unsigned)rw : 0u;
+          }
+        }
+        a2 += __shfl_xor(a2, 16);
+        a2 += __shfl_xor(a2, 32);
+        if (g == 0) sA2[wave * HK + 16 * ct + m] = a2;
+        if (cur_grp) {
+          sV[HK + 16 * ct + m] = hc;
+          if (REC) sv_rows[16 * ct + m] = hc;   // record row 0: the new row
+        }
+      }
+    };
+    auto with_act = [&](auto recc) {
+      if (act1 == GCM_ACT_TANH) epilogue([](float (&v)[2][4]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[c][i] = gcm_tanh(v[c][i]);
+      }, recc);
+      else if (act1 == GCM_ACT_RELU) epilogue([](float (&v)[2][4]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[c][i] = v[c][i] > 0.f ? v[c][i] : 0.f;
+      }, recc);
+      else epilogue([](float (&)[2][4]) {}, recc);
+    };
+    if (rec) with_act(std::true_type{});
+    else with_act(std::false_type{});
+  } else if (g == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) sA2[wave * HK + 16 * ct + m] = 0.f;
+  }
+  lds_barrier();   // #3
+
+  if (wave == 0) {
+    const int n_tiles = (n_slots + 15) >> 4;
+    if (lh == 0) {
+      double t = (double)sA2[li];
+      for (int w = 1; w < n_tiles; ++w) t += (double)sA2[w * HK + li];
+      sV[li] = (float)t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const float* vv = sV + lh * HK;
+    bool bad = false;
+#pragma unroll
+    for (int ot = 0; ot < O2T; ++ot) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < HK / 4; ++q) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(vv + 4 * q);
+        t = fmaf(w2[ot][q].x, x4.x, t);
+        t = fmaf(w2[ot][q].y, x4.y, t);
+        t = fmaf(w2[ot][q].z, x4.z, t);
+        t = fmaf(w2[ot][q].w, x4.w, t);
+      }
+      t += __shfl_xor(t, 32);
+      const float y = gcm_act(t + b2v[ot], act2);
+      const int o = 32 * ot + li;
+      const bool mine = lh == 0 && o < H2;
+      if (mine) saved[gb * H2 + o] = y;
+      bad |= mine && !isfinite(y);
+    }
+    if (__any(bad) && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
+    if (rec) {
+      for (int k = lane; k < 2 * HK; k += 64) saved[lay.o_v + gb * 2 * HK + k] = sV[k];
+      if (lane == 0) {
+        int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * b;
+        hdr[0] = L; hdr[1] = 0; hdr[2] = steady ? N - 1 : cur; hdr[3] = steady;
+      }
+    }
+  } else {
+    const int t2 = tid - 64;   // 0 .. 447
+    if (rec) {
+      float* cf = saved + lay.o_coef + gb * N;
+      for (int l = t2; l < L; l += 448) cf[l] = l == 0 ? (self ? 1.f : 0.f) : 1.f;
+    }
+    if (FUNC) {
+    } else if (!steady) {
+      for (int j = t2; j <= cur; j += 448) {
+        if (j == cur ? self != 0 : mbit(ssrc, j)) ag[cur * N + j] = 1.f;
+        if (j < cur && mbit(scol, j)) ag[j * N + cur] = 1.f;
+      }
+      if (t2 == 447) count[b] = cur + 1;
+    } else if (b == 0 && t2 == 447) {
+      atomicOr(flags, GCM_FLAG_WRAPPED);
+    }
+  }
+}
+
 }  // namespace gcm_rows
 
 // The selector chain and the number of steps the chain has made -> the masks of k_step_colcache in ring coordinates.
@@ -546,7 +915,7 @@ static bool colcache_masks(const gcm_selector_desc* selectors, int n_selectors, 
 extern "C" int gcm_dense_rows_colcache_supported(const gcm_selector_desc* selectors, int n_selectors, int has_bias,
                                                  int N, int F, int H1, int H2) {
   if (N <= 0 || N > 128 || (N & 3) || !(F == 32 || F == 64) || !(H1 == 32 || H1 == 64) || H2 <= 0 || H2 > 64) return 0;
-  if (has_bias & ~3) return 0;   // (no folded preprocessor / positional encoding, no observation-gradient record)
+  if (has_bias & ~(3 | GCM_STEP_FOUR_WAVES)) return 0;   // (no folded preprocessor / positional encoding, no dx record)
   if (n_selectors <= 0 || !selectors) return 0;
   ColMasks m;
   if (!colcache_masks(selectors, n_selectors, N, 0, &m)) return 0;
@@ -588,6 +957,22 @@ static int colcache_launch(const float* obs, const float* nodes_in, const float*
   if (!record) lay.total = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool func = nodes_out != nodes_in;
+  if (F == 32 && H1 == 32 && !(has_bias & GCM_STEP_FOUR_WAVES)) {   // eight waves per graph (16-slot tiles)
+#define GCM_C8(c)                                                                                                   \
+  if ((H2 <= 32 ? 1 : 2) == c) {                                                                                    \
+    if (func)                                                                                                       \
+      hipLaunchKernelGGL((gcm_rows::k_step_colcache8<c, true>), dim3(2 * B), dim3(512), 0, s, obs,                      \
+                         nodes_in, adj_in, count_in, nodes_out, adj_out, count_out, m.ssrc, m.self, m.scol, m.sdrop,    \
+                         m.cur, m.rot, m.steady, P, cache_agg1, cache_root, saved, lay, flags, N, H2, E, B);            \
+    else                                                                                                            \
+      hipLaunchKernelGGL((gcm_rows::k_step_colcache8<c, false>), dim3(B), dim3(512), 0, s, obs, nodes_in, adj_in,       \
+                         count_in, nodes_out, adj_out, count_out, m.ssrc, m.self, m.scol, m.sdrop, m.cur, m.rot,        \
+                         m.steady, P, cache_agg1, cache_root, saved, lay, flags, N, H2, E, B);                          \
+    return gcm_launch_status();                                                                                     \
+  }
+    GCM_C8(1) GCM_C8(2)
+#undef GCM_C8
+  }
 #define GCM_CC(a, b_, c)                                                                                          \
   if (F == a && H1 == b_ && (H2 <= 32 ? 1 : 2) == c) {                                                           \
     if (func)                                                                                                     \

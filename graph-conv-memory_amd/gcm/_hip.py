@@ -21,6 +21,8 @@ FLAG_SPARSE_OVERFLOW, FLAG_ACAUSAL, FLAG_PACK_OVERFLOW, FLAG_MERGE_ORDER, FLAG_W
 GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bits of the live-row step (gcm_hip.h)
 STEP_TWO_LAUNCH = 32      # ... of the cached step: a distance selector and the step as two launches (A/B)
 STEP_IMG_V4 = 64          # ... its weights as 16-byte loads (the image's second layout)
+BPTT_MANY_ROWS = 128      # gcm_dense_rows_bptt: records with many live rows per graph (DenseEdge)
+STEP_FOUR_WAVES = 256     # gcm_dense_rows_step_colcache: the four-wave kernel where the eight-wave form exists (A/B)
 
 ABI_VERSION = 6           # include/gcm_hip.h: GCM_ABI_VERSION
 

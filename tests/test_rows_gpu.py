@@ -853,6 +853,79 @@ def test_rows_colcache_functional_state(sel, B, N, F, H, T):
         torch.testing.assert_close(mx_b.cpu(), out.detach().cpu()[4], rtol=1e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize("kind", ["dense", "both"])
+def test_rows_colcache_c_abi_four_and_eight_waves(kind):
+    """gcm_dense_rows_step_colcache through the raw C ABI at F = H = 32, where two kernels exist - eight waves per
+    graph on 16-slot tiles (the default) and four waves on 32-slot tiles (GCM_STEP_FOUR_WAVES in has_bias: what the
+    wider shapes run) - on the same chain from empty graphs, 2.2 N steps (the ring form behind step N), against the
+    general live-row kernel gcm_dense_rows_step_fwd: states bit for bit, beliefs 1e-5, the records' header and live rows
+    (as sets: the general kernel lists them in another order); and the functional entry against the donated one."""
+    from gcm import _hip
+    lib = _hip.lib()
+    B, N, F, H, T = 5, 32, 32, 32, 70
+    torch.manual_seed(3)
+    P = lib.gcm_dense_gnn2_param_count(F, H, H)
+    params = (torch.randn(P) * 0.2).to(DEV)
+    obs = (torch.rand(T, B, F) - 0.5).to(DEV)
+    if kind == "dense":
+        d = _hip.SelectorDesc(kind=_hip.SEL_DENSE)
+    else:
+        d = _hip.SelectorDesc(kind=_hip.SEL_TEMPORAL, n_hops=3, direction=_hip.DIR["both"])
+        d.hops[0], d.hops[1], d.hops[2] = 0, 1, 3
+    arr = (_hip.SelectorDesc * 1)(d)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st, p = _hip.stream(), _hip.ptr
+    lay = (ctypes.c_size_t * 6)()
+    assert lib.gcm_dense_rows_layout(B, N, F, H, H, ctypes.addressof(lay)) == 0
+    FOUR = 256   # GCM_STEP_FOUR_WAVES
+
+    def chain(form):
+        nodes, adj = torch.zeros(B, N, F, device=DEV), torch.zeros(B, N, N, device=DEV)
+        count = torch.zeros(B, dtype=torch.int64, device=DEV)
+        cA, cR = torch.full((B, N, F), float("nan"), device=DEV), torch.full((B, N, H), float("nan"), device=DEV)
+        out = []
+        for t in range(T):
+            saved = torch.zeros(lay[0], device=DEV)
+            if form == "general":
+                rc = lib.gcm_dense_rows_step_fwd(p(obs[t]), p(nodes), p(adj), p(count), p(nodes), p(adj), p(count), None,
+                                                 ctypes.addressof(arr), 1, p(params), 3, 1, 1, p(saved), p(saved),
+                                                 p(flags), B, N, F, H, H, st)
+            elif form == "functional":
+                n2, a2, c2 = torch.empty_like(nodes), torch.empty_like(adj), torch.empty_like(count)
+                rc = lib.gcm_dense_rows_step_colcache_functional(p(obs[t]), p(nodes), p(adj), p(count), p(n2), p(a2), p(c2),
+                                                                 ctypes.addressof(arr), 1, p(params), 3, 1, 1, p(cA), p(cR),
+                                                                 p(saved), 1, t, p(flags), B, N, F, H, H, st)
+                nodes, adj, count = n2, a2, c2
+            else:
+                rc = lib.gcm_dense_rows_step_colcache(p(obs[t]), p(nodes), p(adj), p(count), ctypes.addressof(arr), 1,
+                                                      p(params), 3 | (FOUR if form == "four" else 0), 1, 1, p(cA), p(cR),
+                                                      p(saved), 1, t, p(flags), B, N, F, H, H, st)
+            assert rc == 0, (form, t, rc)
+            out.append((saved, nodes.clone(), adj.clone(), count.clone()))
+        torch.cuda.synchronize()
+        return out
+
+    ref = chain("general")
+    for form in ("eight", "four", "functional"):
+        got = chain(form)
+        for t in range(T):
+            (sv, n, a, c), (sv0, n0, a0, c0) = got[t], ref[t]
+            assert torch.equal(n, n0) and torch.equal(a, a0) and torch.equal(c, c0), (form, t)
+            # (beliefs: up to N-term sums in another order than the general kernel's - 1e-5 of the pre-activation's
+            #  scale, an absolute tolerance on tanh's output; the oracle tests bound the same through float64)
+            err = float((sv[:B * H] - sv0[:B * H]).abs().max())
+            assert err <= (4e-5 if kind == "dense" else 5e-6), (form, t, err)
+            hdr = sv[lay[2]:lay[2] + 4 * B].view(torch.int32).view(B, 4).cpu()
+            hdr0 = sv0[lay[2]:lay[2] + 4 * B].view(torch.int32).view(B, 4).cpu()
+            assert torch.equal(hdr[:, 0], hdr0[:, 0]) and torch.equal(hdr[:, 2], hdr0[:, 2]), (form, t)
+            # the live rows' x sections as multisets of row sums (their order differs between the kernels)
+            rw, L = int(lay[5]), int(hdr[0, 0])
+            rows = sv[lay[4]:lay[4] + B * N * rw].view(B, N, rw)[:, :L, H + F:].sum(-1).sort(dim=1).values
+            rows0 = sv0[lay[4]:lay[4] + B * N * rw].view(B, N, rw)[:, :L, H + F:].sum(-1).sort(dim=1).values
+            torch.testing.assert_close(rows, rows0, rtol=0, atol=0)
+    assert int(flags.item()) & ~1 == 0      # (GCM_FLAG_WRAPPED past N steps, nothing else)
+
+
 def test_rows_colcache_leaves_an_edited_chain():
     """A caller that edits the donated state in place between two steps (zeroing the graphs of finished episodes) ends
     the column-write cached run: the next step is the general live-row kernel on the state as it is."""

@@ -33,26 +33,31 @@ saved = torch.empty(lay[0], device=dev)
 flags = torch.zeros(1, dtype=torch.int32, device=dev)
 
 
-def run(lib, cur, record):
+FOUR = 256   # GCM_STEP_FOUR_WAVES: the four-wave kernel (the one the stamps are in) where the eight-wave form exists
+
+
+def run(lib, cur, record, four=False):
     count.fill_(cur)
-    rc = lib.gcm_dense_rows_step_colcache(p(obs), p(nodes), p(adj), p(count), ctypes.byref(sel), 1, p(params), 3, 1, 1,
-                                          p(cA), p(cR), p(saved), record, cur, p(flags), B, N, F, H, H, st)
+    rc = lib.gcm_dense_rows_step_colcache(p(obs), p(nodes), p(adj), p(count), ctypes.byref(sel), 1, p(params),
+                                          3 | (FOUR if four else 0), 1, 1, p(cA), p(cR), p(saved), record, cur, p(flags),
+                                          B, N, F, H, H, st)
     assert rc == 0, rc
 
 
 lib = _hip.lib()
-for record in (1, 0):
-    for cur in (0, 31, 63, 95, 127):
-        for _ in range(3):
-            run(lib, cur, record)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            run(lib, cur, record)
-        e1.record()
-        torch.cuda.synchronize()
-        print(f"record={record} cur={cur:3d}: {e0.elapsed_time(e1) / 50 * 1e3:6.2f} us per (fill + launch)")
+for four in (False, True):
+    for record in (1, 0):
+        for cur in (0, 31, 63, 95, 127):
+            for _ in range(3):
+                run(lib, cur, record, four)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                run(lib, cur, record, four)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"{'four' if four else 'eight'} waves record={record} cur={cur:3d}: {e0.elapsed_time(e1) / 50 * 1e3:6.2f} us per (fill + launch)")
 assert int(flags.item()) == 0, int(flags.item())
 sp = os.path.join(ROOT, "graph-conv-memory_amd", "gcm", "_lib", "libgcm_hip_stamps11.so")
 if os.path.exists(sp):
@@ -63,7 +68,7 @@ if os.path.exists(sp):
     for cur in (31, 63, 127):
         acc, R = [0.0] * 11, 10
         for it in range(R + 3):
-            run(ls, cur, 1)
+            run(ls, cur, 1, True)
             torch.cuda.synchronize()
             out = (ctypes.c_ulonglong * 32)()
             ls.gcm_debug_read_stamps(out, 32)
