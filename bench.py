@@ -1016,7 +1016,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # adj-row write-back: 4N^2+4NF+4F+4H+4N = 82.7 KB at cfg2) x B over the mean launch duration - an
         # EFFECTIVE rate: the kernel exploits "only row n_b is kept" (gcm.py:314) and, in a chain from empty
         # graphs, caches layer 1; `executed` is what it really moves and computes.
-        k = find_kernel(prof, "k_step_rows_cached_img4<", "k_step_rows_cached_img<", "k_step_rows_cached<", "k_step_rows<")
+        k = find_kernel(prof, "k_step_rows_cached_img4", "k_step_rows_cached_img<", "k_step_rows_cached<", "k_step_rows<")
         kb = find_kernel(prof, "k_bptt_rows<")
         step_kernel, kd = k
         sec = kd["avg_us"] * 1e-6

@@ -368,7 +368,13 @@ inline HopMask make_hop_mask(const gcm_fused::Edits& E) {
   return m;
 }
 
-template <int FP, int HP, bool SEL, bool EX = true, bool V4 = false, bool HS = false>   // HS: H2 <= 32 too (host)
+// BK2 (round 6): a SECOND wave of the graph's workgroup does everything that does not depend on the arithmetic - the
+// observation into row cur of the node matrix and of the node cache, the selector's entries in row cur of the adjacency,
+// the count, the record's live list / coefficients / header - while wave 0 computes.  They never meet (no barrier, no
+// LDS between them): all of it follows from `cur` (the host's: cur_host >= 0 is required) and the hop mask.  ~120 of the
+// one-wave kernel's ~600 instructions leave its instruction stream - a stream that runs at about eight cycles an
+// instruction when it is alone on its SIMD.
+template <int FP, int HP, bool SEL, bool EX = true, bool V4 = false, bool HS = false, bool BK2 = false>   // HS: H2 <= 32 too (host)
 __device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
     const HopMask& hm, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
@@ -377,8 +383,64 @@ __device__ __forceinline__ void step_rows_cached_img_body(
     const float* __restrict__ sel_row, int Fr = FP, int H1r = HP) {
   const int F = EX ? FP : Fr, H1 = EX ? HP : H1r;
   __shared__ __attribute__((aligned(16))) float sv[128];
-  const int lane = threadIdx.x;
+  const int lane = BK2 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   const unsigned gb = blockIdx.x;
+  // the sources of row cur from the hop mask (see HopMask)
+  auto hop_sources = [&](const int cur, unsigned long long& m0, unsigned long long& m1) {
+    const int sft = 128 - cur;   // (cur in 0 .. 127: 1 .. 128)
+    if (sft >= 64) {
+      m1 = 0ull;
+      m0 = sft >= 128 ? 0ull : hm.rev_hi >> (sft - 64);
+    } else {
+      m0 = (hm.rev_lo >> sft) | (hm.rev_hi << (64 - sft));
+      m1 = hm.rev_hi >> sft;
+    }
+  };
+  // what follows from cur and the masks alone: the donated state's entries and the record's live list
+  auto bookkeeping = [&](const int cur, const bool bad, const unsigned long long m0, const unsigned long long m1,
+                         const float xc) {
+    const bool self = hm.self != 0;
+    const unsigned rc = gb * (unsigned)N + (unsigned)cur;
+    if (!bad) {
+      if (lane < F) {
+        nodes[rc * F + lane] = xc;
+        cX[rc * F + lane] = xc;
+      }
+      float* arow = adj + (size_t)rc * N;
+      const unsigned long long s0 = m0 | ((self && cur < 64) ? 1ull << cur : 0ull);
+      const unsigned long long s1 = m1 | ((self && cur >= 64) ? 1ull << (cur - 64) : 0ull);
+      if (lane < N && ((s0 >> lane) & 1ull)) arow[lane] = 1.f;
+      if (lane + 64 < N && ((s1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
+      if (lane == 0) count[gb] = cur + 1;
+    }
+    if (lay.total) {
+      const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
+      int* live = reinterpret_cast<int*>(saved + lay.o_live) + gb * N;
+      float* coef = saved + lay.o_coef + gb * N;
+      const int j0 = lane, j1 = lane + 64;
+      const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
+      const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
+      const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
+      if (in0) { live[pos0] = j0; coef[pos0] = (j0 == cur && !self) ? 0.f : 1.f; }
+      if (in1) { live[pos1] = j1; coef[pos1] = (j1 == cur && !self) ? 0.f : 1.f; }
+      if (lane == 0) {
+        int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
+        const int L = __popcll(l0) + __popcll(l1);
+        const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull)) : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
+        hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
+      }
+    }
+  };
+  if (BK2 && threadIdx.x >= 64) {   // the bookkeeping wave (cur_host >= 0: the launcher's condition; no SEL form)
+    const float xo_ = obs[gb * F + (lane < F ? lane : F - 1)];
+    const bool bad_ = cur_host < 0 || cur_host >= N;
+    const int cur_ = bad_ ? 0 : cur_host;
+    unsigned long long b0, b1_;
+    hop_sources(cur_, b0, b1_);
+    bookkeeping(cur_, bad_, b0, b1_, xo_);
+    if (bad_ && lane == 0) atomicOr(flags, GCM_FLAG_BAD_COUNT);
+    return;
+  }
   const float* b1 = params + 2 * H1 * F;
   const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
   const int64_t n64 = cur_host >= 0 ? (int64_t)cur_host : count[gb];
@@ -419,16 +481,7 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   const int cur = __builtin_amdgcn_readfirstlane(bad ? 0 : (int)n64);
   unsigned long long m0, m1;
   const bool self = hm.self != 0;
-  {
-    const int sft = 128 - cur;   // (cur in 0 .. 127: 1 .. 128)
-    if (sft >= 64) {
-      m1 = 0ull;
-      m0 = sft >= 128 ? 0ull : hm.rev_hi >> (sft - 64);
-    } else {
-      m0 = (hm.rev_lo >> sft) | (hm.rev_hi << (64 - sft));
-      m1 = hm.rev_hi >> sft;
-    }
-  }
+  hop_sources(cur, m0, m1);
   if (SEL) {
     m0 |= __ballot(lane < cur && lane < N && sel0 != 0.f);
     m1 |= __ballot(lane + 64 < cur && lane + 64 < N && sel1 != 0.f);
@@ -585,44 +638,18 @@ __device__ __forceinline__ void step_rows_cached_img_body(
   const float v = gcm_act_sel(p2, act2_v);
   const unsigned rc = gb * (unsigned)N + (unsigned)cur;
   if (!bad) {
-    if (lane < F) {
-      nodes[rc * F + lane] = xc;
-      cX[rc * F + lane] = xc;
-      cA[rc * F + lane] = agg1;
-    }
+    if (lane < F) cA[rc * F + lane] = agg1;
     if (lane < H1) cH[rc * H1 + lane] = h1c;
-    float* arow = adj + (size_t)rc * N;
-    const unsigned long long s0 = m0 | ((self && cur < 64) ? 1ull << cur : 0ull);
-    const unsigned long long s1 = m1 | ((self && cur >= 64) ? 1ull << (cur - 64) : 0ull);
-    if (lane < N && ((s0 >> lane) & 1ull)) arow[lane] = 1.f;
-    if (lane + 64 < N && ((s1 >> lane) & 1ull)) arow[lane + 64] = 1.f;
-    if (lane == 0) count[gb] = cur + 1;
   }
   if (lane < H2) saved[gb * H2 + lane] = v;
-  if (lay.total) {
-    if (lane < H1) {
-      saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
-      saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
-    }
-    const unsigned long long l0 = m0 | (cur < 64 ? 1ull << cur : 0ull), l1 = m1 | (cur >= 64 ? 1ull << (cur - 64) : 0ull);
-    int* live = reinterpret_cast<int*>(saved + lay.o_live) + gb * N;
-    float* coef = saved + lay.o_coef + gb * N;
-    const int j0 = lane, j1 = lane + 64;
-    const bool in0 = (l0 >> lane) & 1ull, in1 = (l1 >> lane) & 1ull;
-    const int pos0 = __popcll(l0 & ((1ull << lane) - 1ull));
-    const int pos1 = __popcll(l0) + __popcll(l1 & ((1ull << lane) - 1ull));
-    if (in0) { live[pos0] = j0; coef[pos0] = (j0 == cur && !self) ? 0.f : 1.f; }
-    if (in1) { live[pos1] = j1; coef[pos1] = (j1 == cur && !self) ? 0.f : 1.f; }
-    if (lane == 0) {
-      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
-      const int L = __popcll(l0) + __popcll(l1);
-      const int l_cur = cur < 64 ? __popcll(l0 & ((1ull << cur) - 1ull)) : __popcll(l0) + __popcll(l1 & ((1ull << (cur - 64)) - 1ull));
-      hdr[0] = L; hdr[1] = l_cur; hdr[2] = cur; hdr[3] = 0;
-    }
+  if (lay.total && lane < H1) {
+    saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
+    saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
   }
+  if (!BK2) bookkeeping(cur, bad, m0, m1, xc);   // (BK2: the second wave's)
   const bool nonfinite = __any(lane < H2 && !isfinite(v));
-  if ((nonfinite || bad) && lane == 0)
-    atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | (bad ? GCM_FLAG_BAD_COUNT : 0u));
+  if ((nonfinite || (bad && !BK2)) && lane == 0)
+    atomicOr(flags, (nonfinite ? GCM_FLAG_NONFINITE : 0u) | ((bad && !BK2) ? GCM_FLAG_BAD_COUNT : 0u));
 }
 
 // The two kernels over that body.  (Separate signatures on purpose: with the decision row's pointer as a ninth
@@ -645,6 +672,16 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_img4(
     CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
   step_rows_cached_img_body<FP, HP, false, true, true, HS>(obs, nodes, adj, count, E, params, image, act1, act2, cH, cA,
                                                            cX, saved, lay, flags, B, N, H2, cur_host, nullptr);
+}
+// ... with the bookkeeping on a second wave (BK2 above): F = H1 = 32, H2 <= 32, cur_host >= 0
+__global__ __launch_bounds__(128) void k_step_rows_cached_img4b(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, int64_t* __restrict__ count,
+    HopMask E, const float* __restrict__ params, const float* __restrict__ image, int act1, int act2,
+    float* __restrict__ cH, float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved,
+    CachedLayout lay, uint32_t* __restrict__ flags, int B, int N, int H2, int cur_host) {
+  step_rows_cached_img_body<32, 32, false, true, true, true, true>(obs, nodes, adj, count, E, params, image, act1, act2,
+                                                                   cH, cA, cX, saved, lay, flags, B, N, H2, cur_host,
+                                                                   nullptr);
 }
 template <int FP, int HP>
 __global__ __launch_bounds__(64) void k_step_rows_cached_sel(
@@ -1060,6 +1097,11 @@ extern "C" int gcm_dense_rows_step_cached_ws(const float* obs, float* nodes, flo
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_sel<a, b_>), dim3(B), dim3(64), 0, (hipStream_t)stream,       \
                          obs, nodes, adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1,          \
                          cache_nodes, saved, lay, flags, B, N, H2, cur_host, sel_row);                               \
+    else if ((has_bias & GCM_STEP_IMG_V4) && a == 32 && b_ == 32 && H2 <= 32 && cur_host >= 0 &&                  \
+             !(has_bias & GCM_STEP_ONE_WAVE))                                                                     \
+      hipLaunchKernelGGL(gcm_rows::k_step_rows_cached_img4b, dim3(B), dim3(128), 0, (hipStream_t)stream, obs, nodes,  \
+                         adj, count, HM, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes, saved,  \
+                         lay, flags, B, N, H2, cur_host);                                                             \
     else if ((has_bias & GCM_STEP_IMG_V4) && a == 32 && b_ == 32 && H2 <= 32)                                     \
       hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_img4<a, b_, true>), dim3(B), dim3(64), 0,                     \
                          (hipStream_t)stream, obs, nodes, adj, count, HM, params, weight_image, act1, act2,           \

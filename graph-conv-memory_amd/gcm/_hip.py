@@ -22,6 +22,7 @@ GNN_HAS_DEG_TERM, GNN_HAS_PE_TABLE, GNN_RECORD_DX = 4, 8, 16      # has_bias bit
 STEP_TWO_LAUNCH = 32      # ... of the cached step: a distance selector and the step as two launches (A/B)
 STEP_IMG_V4 = 64          # ... its weights as 16-byte loads (the image's second layout)
 BPTT_MANY_ROWS = 128      # gcm_dense_rows_bptt: records with many live rows per graph (DenseEdge)
+STEP_ONE_WAVE = 512       # gcm_dense_rows_step_cached: the one-wave kernel where the two-wave form exists (A/B)
 STEP_FOUR_WAVES = 256     # gcm_dense_rows_step_colcache: the four-wave kernel where the eight-wave form exists (A/B)
 
 ABI_VERSION = 6           # include/gcm_hip.h: GCM_ABI_VERSION

@@ -159,6 +159,11 @@ class DenseGCM(torch.nn.Module):
         # image (False; env GCM_IMG_V4=0 for the A/B).  (Round 5's first use of this slot - four k per lane as 16-byte
         # loads - had measured slower: 4.85 against 4.63 us.)
         self.rows_weight_image_v4 = os.environ.get("GCM_IMG_V4", "1") == "1"
+        # True (round 6): the cached temporal-hops step at F = H1 = 32 runs with a SECOND wave per graph that writes what
+        # follows from `cur` alone (the observation into the node matrix / cache, the adjacency row, the count, the record's
+        # live list) while wave 0 computes - ~120 instructions off a one-wave instruction stream.  False (env
+        # GCM_ONE_WAVE=1): the one-wave kernel (A/B)
+        self.rows_bookkeeping_wave = os.environ.get("GCM_ONE_WAVE", "0") != "1"
         # False: rollout() from empty graphs with forward temporal hops runs the persistent per-graph kernel of round 1
         # instead of the two-launch time-parallel forward (csrc/rollout_tp.hip) - A/B tests
         self.rollout_time_parallel = True
@@ -639,7 +644,8 @@ class DenseGCM(torch.nn.Module):
             if cfg.cpp_handle():
                 cfg._cpp.set_cached_flags(
                     (0 if (self.rows_one_launch_distance or not cfg.has_distance) else _hip.STEP_TWO_LAUNCH)
-                    | (_hip.STEP_IMG_V4 if self.rows_weight_image_v4 else 0))
+                    | (_hip.STEP_IMG_V4 if self.rows_weight_image_v4 else 0)
+                    | (0 if self.rows_bookkeeping_wave else _hip.STEP_ONE_WAVE))
                 cfg._cpp.set_col_cache(bool(self.rows_col_cache))
         mx, n2, a2, c2, donate = fast.run(x, nodes, adj, weights, num_nodes, root, flags, cfg.cpp_handle(),
                                           self.donate_state, need_dx, bool(fresh and self.rows_cached_steps))

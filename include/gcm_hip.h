@@ -529,6 +529,9 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
 /* gcm_dense_rows_step_colcache[_functional] only: the four-wave kernel where the eight-wave form exists (F = H1 = 32) -
  * the A/B of tests and tools; a per-call argument, the library keeps no switch */
 #define GCM_STEP_FOUR_WAVES 256
+/* gcm_dense_rows_step_cached[_ws] only: the one-wave kernel where the two-wave form exists (F = H1 = 32, H2 <= 32,
+ * cur_host >= 0, GCM_STEP_IMG_V4: a second wave does the state's entries and the record's live list) - A/B */
+#define GCM_STEP_ONE_WAVE 512
 /* gcm_dense_rows_step_cached_ws only: a distance selector and the cached step as two launches (see
  * gcm_dense_rows_cached_launches) */
 #define GCM_STEP_TWO_LAUNCH 32
