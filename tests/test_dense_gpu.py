@@ -683,8 +683,11 @@ def test_rollout_inference_keeps_no_history(N, F, H, T, sel_kind):
             mx, h = mem(obs[t], h)
             outs.append(mx)
     mem.check_flags()
-    # two fp32 summation orders; dense rows add up to N terms before the tanh
-    torch.testing.assert_close(out, torch.stack(outs), rtol=1e-5, atol=1e-6 if sel_kind == "temporal" else 3e-5)
+    # two fp32 summation orders; dense rows add up to N terms before the tanh - and past N steps the per-step loop's
+    # column-write cached steps keep each row's aggregate by rank-1 corrections (+ the new node, - the dropped one:
+    # csrc/rows_colcache.hip) where rollout() sums afresh: both sit inside the float64 bound of the oracle tests
+    # (tests/test_rows_gpu.py::test_rows_colcache_steps_vs_oracle), 6e-5 apart from each other here
+    torch.testing.assert_close(out, torch.stack(outs), rtol=1e-5, atol=1e-6 if sel_kind == "temporal" else 1.5e-4)
     for a, b in zip(hid, h):
         assert torch.equal(a, b)
 
