@@ -69,7 +69,10 @@ struct LrnSrc {
 // FP / HP / H2P: F, H1, H2 rounded up to 32 or 64.  C1 = columns of [agg1 | x] per lane,
 // C2 = columns of v per lane (column m = lane + 64 c).  MODE: 0 live-row records, 1 rollout history,
 // 2 learned-step buffers.
-template <int FP, int HP, int H2P, int MODE>
+// X32: F = H1 = 32 exactly and H2 <= 32 as a COMPILE-TIME fact (the launcher checks): the kernel is then the matrix-core
+// form alone - as a run-time branch beside the general form the compiler sized the registers for both (236 VGPRs:
+// two waves per SIMD on a pass that is bound by the latency of its row gathers)
+template <int FP, int HP, int H2P, int MODE, bool X32 = false>
 __global__ __launch_bounds__(256) void k_bptt_rows(
     StepTable tab, Hist hs, int n_steps, long gmx_sb, long gmx_sh, const float* __restrict__ w_rel2,
     const float* __restrict__ w_root2, int act1, int act2, SavedLayout lay, float* __restrict__ slabs,
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
   // MFMAs per item with d2 masked to one half each.  The VALU form executes ~875 instructions per item and was
   // issue-bound at two waves per SIMD.  Same pipelining as below (front of item i + 1 ahead of item i, pair p + 1
   // ahead of pair p, the next item's first pair ahead of this item's last).
-  if (!HIST && FP == 32 && HP == 32 && H2P == 32 && F == 32 && H1 == 32 && wave_regions == 3) {
+  if (X32 || (!HIST && FP == 32 && HP == 32 && H2P == 32 && F == 32 && H1 == 32 && wave_regions == 3)) {
     const int q = lane & 31, half = lane >> 5;
     const int ocq = q < H2 ? q : H2 - 1;
     struct FrontM {
@@ -916,6 +919,15 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
       const size_t r1 = 2 * (size_t)32 * F + 32, r2 = P - r1;
       wave_regions = 2;
       lds = sizeof(float) * 4 * (r1 > r2 ? r1 : r2);
+    }
+  }
+  if constexpr ((MODE == 0 || MODE == 3) && FP == 32 && HP == 32 && H2P == 32) {
+    if (F == 32 && H1 == 32 && wave_regions == 3) {   // the matrix-core form alone (see X32)
+      auto kx = k_bptt_rows<FP, HP, H2P, MODE, true>;
+      gcm_allow_dynamic_lds((const void*)kx, lds);
+      hipLaunchKernelGGL(kx, dim3(grid), dim3(256), lds, s, tab, hs, n_steps, sb, sh, w_rel2, w_root2, act1, act2, lay,
+                         slabs, B, N, F, H1, H2, deg_term, lrn, wave_regions);
+      return gcm_launch_status();
     }
   }
   auto kern = k_bptt_rows<FP, HP, H2P, MODE>;

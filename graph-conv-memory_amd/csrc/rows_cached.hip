@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64) void k_step_rows_cached_gen(
 // hops: sorted descending, distinct, 0 < h < N (host: gcm_dense_rows_step_cached_roll); self: a hop of 0.
 // ---------------------------------------------------------------------------------------------------------
 template <int FP, int HP, bool HS = false>   // HS: F = H1 = 32 and H2 <= 32 (host): the half-wave form of the products
-__global__ __launch_bounds__(128) void k_step_rows_cached_roll(
+__global__ __launch_bounds__(192) void k_step_rows_cached_roll(
     const float* __restrict__ obs, float* __restrict__ nodes, gcm_fused::Edits E, int self_i,
     const float* __restrict__ params, const float* __restrict__ image, int act1, int act2, float* __restrict__ cH,
     float* __restrict__ cA, float* __restrict__ cX, float* __restrict__ saved, SavedLayout lay, int record,
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   __shared__ __attribute__((aligned(16))) float sv[128];
   const int lane = threadIdx.x & 63;
   const unsigned gb = blockIdx.x;
-  if (threadIdx.x >= 64) {
+  if (threadIdx.x >= 64 && threadIdx.x < 128) {
     // ---- wave 1: the node matrix, in place: row r <- row r + 1, row N - 1 <- the observation -------------------
     constexpr int PER = 128 * FP / 4 / 64;                 // float4 per lane at N = 128
     const int F4 = F / 4, total = N * F4, moved = total - F4;
@@ -764,6 +764,38 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
     if (gb == 0 && lane == 0) atomicOr(flags, GCM_FLAG_WRAPPED);   // gcm.py:264-266: the caller's one-time notice
     return;
   }
+  if (threadIdx.x >= 128) {
+    // ---- wave 2 (round 6): what does not depend on the step's arithmetic - the selected rows' h1 | agg1 | x from the
+    // rings into the record (they travel in it: a ring slot is overwritten N steps later), its coefficients and header,
+    // the observation into the node ring.  ~60 instructions and a third of the loads off wave 0's stream.
+    const int F_ = FP, H1_ = HP;
+    const int fl2 = lane < F_ ? lane : F_ - 1, hl2 = lane < H1_ ? lane : H1_ - 1;
+    const float xo = obs[gb * F_ + fl2];
+    const unsigned rc2 = gb * (unsigned)N + (unsigned)slot_new;
+    if (lane < F_) cX[rc2 * F_ + lane] = xo;
+    if (record) {
+      const int nh = E.n_hops;
+      float* rows2 = saved + lay.o_rows + (size_t)gb * N * lay.rw;
+      for (int q = 0; q < nh; ++q) {
+        int hq = 0;   // (a run-time index into the kernel-argument array would move it to scratch)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hq = q == i ? E.hops[i] : hq;
+        const int sl = slot_new - hq + (slot_new < hq ? N : 0);
+        const unsigned rj = gb * (unsigned)N + (unsigned)sl;
+        const float tx = cX[rj * F_ + fl2], th = cH[rj * H1_ + hl2], ta = cA[rj * F_ + fl2];
+        float* row = rows2 + (size_t)q * lay.rw;
+        if (lane < H1_) row[lane] = th;
+        if (lane < F_) { row[H1_ + lane] = ta; row[H1_ + F_ + lane] = tx; }
+      }
+      float* coef = saved + lay.o_coef + (size_t)gb * N;
+      if (lane <= nh) coef[lane] = (lane < nh || self_i != 0) ? 1.f : 0.f;
+      if (lane == 0) {
+        int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
+        hdr[0] = nh + 1; hdr[1] = nh; hdr[2] = N - 1; hdr[3] = 1;
+      }
+    }
+    return;
+  }
   // ---- wave 0: the step on row cur = N - 1, ring coordinates -----------------------------------------------------
   const float* b1 = params + 2 * H1 * F;
   const float* b2 = b1 + H1 + 2 * (size_t)H2 * H1;
@@ -785,7 +817,7 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   const bool self = self_i != 0;
   // the selected rows, ascending in node age (hops descending): the first four in one round trip with everything
   // above, further ones four at a time
-  float xa[4], ha[4], ca[4];
+  float xa[4], ha[4];
   int slot[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -793,38 +825,22 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
     const int h = on ? E.hops[q] : 0;
     slot[q] = slot_new - h + (slot_new < h ? N : 0);        // (0 < h < N)
     const unsigned rj = gb * (unsigned)N + (unsigned)slot[q];
-    const float tx = cX[rj * F + fl], th = cH[rj * H1 + hl], ta = cA[rj * F + fl];
+    const float tx = cX[rj * F + fl], th = cH[rj * H1 + hl];
     xa[q] = on ? tx : 0.f;
     ha[q] = on ? th : 0.f;
-    ca[q] = ta;
   }
   asm volatile("" ::: "memory");
   float* rows = saved + lay.o_rows + (size_t)gb * N * lay.rw;
   const bool rec = record != 0;
   float agg1 = (xa[0] + xa[1]) + (xa[2] + xa[3]), agg2 = (ha[0] + ha[1]) + (ha[2] + ha[3]);
-  if (rec) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < n_h) {
-        float* row = rows + (size_t)q * lay.rw;
-        if (lane < H1) row[lane] = ha[q];
-        if (lane < F) { row[H1 + lane] = ca[q]; row[H1 + F + lane] = xa[q]; }
-      }
-  }
-  for (int q = 4; q < n_h; ++q) {
+  for (int q = 4; q < n_h; ++q) {   // (their record rows: wave 2)
     int hq = 0;   // (a run-time index into the kernel-argument array would move it to scratch)
 #pragma unroll
     for (int i = 4; i < 16; ++i) hq = q == i ? E.hops[i] : hq;
     const int sl = slot_new - hq + (slot_new < hq ? N : 0);
     const unsigned rj = gb * (unsigned)N + (unsigned)sl;
-    const float tx = cX[rj * F + fl], th = cH[rj * H1 + hl], ta = cA[rj * F + fl];
-    agg1 += tx;
-    agg2 += th;
-    if (rec) {
-      float* row = rows + (size_t)q * lay.rw;
-      if (lane < H1) row[lane] = th;
-      if (lane < F) { row[H1 + lane] = ta; row[H1 + F + lane] = tx; }
-    }
+    agg1 += cX[rj * F + fl];
+    agg2 += cH[rj * H1 + hl];
   }
   agg1 = lane < F ? agg1 + (self ? xc : 0.f) : 0.f;
   if (lane < F) *reinterpret_cast<f32x2*>(sv + 2 * lane) = f32x2{agg1, xc};
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
   else p2 += pair_matvec(w2, sv);
   const float v = gcm_act_sel(p2, act2_v);
   const unsigned rc = gb * (unsigned)N + (unsigned)slot_new;      // the new node's ring slot (node t_abs - N leaves)
-  if (lane < F) { cX[rc * F + lane] = xc; cA[rc * F + lane] = agg1; }
+  if (lane < F) cA[rc * F + lane] = agg1;                           // (cX[rc]: wave 2)
   if (lane < H1) cH[rc * H1 + lane] = h1c;
   if (lane < H2) saved[gb * H2 + lane] = v;                         // mx: the head of the record
   if (rec) {
@@ -849,15 +865,9 @@ __global__ __launch_bounds__(128) void k_step_rows_cached_roll(
       saved[lay.o_v + gb * 2 * H1 + lane] = agg2;
       saved[lay.o_v + gb * 2 * H1 + H1 + lane] = h1c;
     }
-    float* row = rows + (size_t)n_h * lay.rw;                       // row cur: last in the list
+    float* row = rows + (size_t)n_h * lay.rw;                       // row cur: last in the list (the others: wave 2)
     if (lane < H1) row[lane] = h1c;
     if (lane < F) { row[H1 + lane] = agg1; row[H1 + F + lane] = xc; }
-    float* coef = saved + lay.o_coef + (size_t)gb * N;
-    if (lane <= n_h) coef[lane] = (lane < n_h || self) ? 1.f : 0.f;
-    if (lane == 0) {
-      int* hdr = reinterpret_cast<int*>(saved + lay.o_hdr) + 4 * gb;
-      hdr[0] = n_h + 1; hdr[1] = n_h; hdr[2] = N - 1; hdr[3] = 1;
-    }
   }
   const bool nonfinite = __any(lane < H2 && !isfinite(v));
   if (nonfinite && lane == 0) atomicOr(flags, GCM_FLAG_NONFINITE);
@@ -1202,11 +1212,11 @@ extern "C" int gcm_dense_rows_step_cached_roll(const float* obs, float* nodes, c
 #define GCM_RR(a, b_)                                                                                             \
   if (F == a && H1 == b_) {                                                                                       \
     if (a == 32 && b_ == 32 && H2 <= 32)                                                                          \
-      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_, true>), dim3(B), dim3(128), 0,                     \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_, true>), dim3(B), dim3(192), 0,                     \
                          (hipStream_t)stream, obs, nodes, E, self, params, weight_image, act1, act2, cache_h1,        \
                          cache_agg1, cache_nodes, saved, lay, record, flags, B, N, H2, t_abs % N);                    \
     else                                                                                                          \
-      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_>), dim3(B), dim3(128), 0, (hipStream_t)stream,      \
+      hipLaunchKernelGGL((gcm_rows::k_step_rows_cached_roll<a, b_>), dim3(B), dim3(192), 0, (hipStream_t)stream,      \
                          obs, nodes, E, self, params, weight_image, act1, act2, cache_h1, cache_agg1, cache_nodes,    \
                          saved, lay, record, flags, B, N, H2, t_abs % N);                                             \
     return gcm_launch_status();                                                                                   \
