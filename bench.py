@@ -1022,8 +1022,9 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         sec = kd["avg_us"] * 1e-6
         alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
         cached = "cached" in step_kernel
-        tkey = ("k_step_rows_cached_img4" if "img4" in step_kernel else "k_step_rows_cached_img") if cached else "k_step_rows"
-        moved = traffic.get(tkey, traffic.get("k_step_rows_cached_img") if cached else None)
+        tkey = (("k_step_rows_cached_img4b" if "img4b" in step_kernel else "k_step_rows_cached_img4")
+                if "img4" in step_kernel else "k_step_rows_cached_img") if cached else "k_step_rows"
+        moved = traffic.get(tkey, traffic.get("k_step_rows_cached_img4", traffic.get("k_step_rows_cached_img")) if cached else None)
         # executed flops per launch of the cached step: |S| row adds for both aggregates + four H x F matrix-vector
         # products per graph; the general kernel: layer 1 on its live rows (|S| + 1) over their non-zero chunks
         n_sel = len(HOPS)
