@@ -12,7 +12,8 @@ tag = sys.argv[1]
 P = lambda n: os.path.join(ROOT, "profiles", n)
 tr = json.load(open(P("traffic.json")))
 det = json.load(open(P(f"{tag}_dense_traffic_detail.json")))
-for src, dst in (("k_step_colcache", "k_step_colcache"), ("k_step_rows", "k_step_rows_dense"), ("k_bptt_rows", "k_bptt_rows_dense")):
+for src, dst in (("k_step_colcache", "k_step_colcache"), ("k_step_colcache8", "k_step_colcache"),
+                 ("k_step_rows", "k_step_rows_dense"), ("k_bptt_rows", "k_bptt_rows_dense")):
     if src in det:
         tr[dst] = det[src]["bytes_corrected"]
 json.dump(dict(sorted(tr.items())), open(P("traffic.json"), "w"), indent=1)
