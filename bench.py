@@ -798,9 +798,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         m.check_flags()
         return m, g_, bk, [world * B * T * side / t for t in ts]
 
-    _dbg = os.environ.get("GCM_BENCH_DBG", "")
     if can_donate:
-        mem_e, gnn_e, bucket_e, v = variant(True, reps=1 if "novar" in _dbg else 3)
+        mem_e, gnn_e, bucket_e, v = variant(True)
         variants["eager_donated"] = statistics.median(v)
         variants["eager_donated_min_max"] = [min(v), max(v)]
     mem_f, gnn_f, bucket_f, v = variant(False)
@@ -815,8 +814,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         rollout_api(mem_f, obs, bucket_f, weight)
         for q in mods_f:
             q.zero_grad(set_to_none=True)
-    if "noroll" not in _dbg:
-        variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
+    variants["rollout_api"] = world * B * T * side / timed(roll, side, 2)
     rollout_kernels = None
     if rank == 0 and world == 1 and c["selector"] == "euclid":   # (world == 1: `roll` reduces its gradients)
         # the time-parallel entry's own kernels (csrc/euclid_tp.hip): every step's decisions as one causal contraction
@@ -1183,7 +1181,6 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         kernel_ms = {step_kernel: round(kd["avg_us"] * 1e-3, 6)}
         if kb:
             Lsum = sum(Ls)
-            bw_flops = B * (sum(2.0 * L * H * 2 * F + 2.0 * L * H * H + 2.0 * L * L * F for L in Ls))
             kernel_ms[kb[0]] = round(kb[1]["avg_us"] * 1e-3, 6)
             line["roofline"]["backward"] = {"kernel": kb[0], "launches_per_step": round(kb[1]["launches_per_call"], 2),
                                             "avg_launch_ms": kb[1]["avg_us"] * 1e-3, "us_per_step": round(kb[1]["us_per_call"], 1),
