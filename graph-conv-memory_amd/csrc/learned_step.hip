@@ -2551,8 +2551,8 @@ extern "C" int gcm_learned_advance_select_inplace(const float* obs, float* nodes
 /* One whole forward step of a chain that started from EMPTY graphs and has not overflowed (fewer than N steps so
  * far), on a DONATED state: gcm_learned_advance_select_inplace with the step's GNN behind the selection (see
  * GnnTail) - one launch.  cache_h1 [B,N,H1], cache_agg1 [B,N,F], cache_nodes [B,N,F]: the chain's caches (row cur is
- * written; rows < cur were written by the earlier steps of the chain; zero-filled by the caller at the chain's
- * head).  cur_host >= 0: the row every graph's new node lands in, when the host knows it (the chain's step count: no
+ * written; rows < cur were written by the earlier steps of the chain; any contents at the chain's head - a row is
+ * read only behind the step that wrote it).  cur_host >= 0: the row every graph's new node lands in, when the host knows it (the chain's step count: no
  * load in front of the kernel's addresses; count_in is compared at the end - GCM_FLAG_BAD_COUNT); -1: read count_in.  The step's record (gcm_learned_step_layout, compact = 2): adj_row [B,N], mx [B,H2], agg2 [B,H1], cur /
  * count, soft [B,N]. */
 extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,

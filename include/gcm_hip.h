@@ -632,7 +632,7 @@ int gcm_dense_rows_bptt_dx_all(const float* const* saved, const float* const* g_
  * fewer than N steps (nothing can have overflowed) and whose selectors only write row cur of the adjacency
  * (TemporalBackedge direction "forward", temporal.py:72-88; not DenseEdge, which also writes column cur).  There the rows of layer 1
  * are final once written, so the chain keeps h1 [B,N,H1], agg1 [B,N,F] and the node matrix [B,N,F] of every
- * node in caches (zero-filled by the caller at the chain's head) and a step evaluates row cur alone, every input
+ * node in caches (any contents at the chain's head: a row is read only behind the step that wrote it) and a step evaluates row cur alone, every input
  * fetched in one round trip behind the count.  The state (nodes, adj, count) is advanced IN PLACE.
  * saved: the step's record, gcm_dense_rows_cached_layout floats {total, v, hdr, coef, live} (mx [B,H2] at 0 - always
  * written; the rest only with record != 0).  cur_host >= 0: the row every graph's new node lands in, when the host
