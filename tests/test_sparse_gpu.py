@@ -726,6 +726,55 @@ def test_one_shot_from_none_returns_aliases_that_are_watched():
         mem(xb, taus, None)
 
 
+def test_one_shot_sizes_are_reused_for_the_same_taus_tensor():
+    """Whole-episode calls from hidden = None with the SAME taus tensor (object and version counter) reuse the flat sizes
+    the first call read back - no host round trip in front of the call's launches; ragged taus; a taus tensor edited in
+    place (its version counter moves) is read back again and gives the new sizes; one edited behind the counter's back
+    (.data) is caught by the device's own figures at the call's closing flag read."""
+    from gcm.sparse_gcm import SparseGCM
+    from gcm import nn as G, _ext
+    from gcm.sparse_edge_selectors.temporal import TemporalEdge
+    ext = _ext.module()
+    B, N, F, H = 5, 32, 32, 32
+    torch.manual_seed(1)
+    ref = osp.canonical_gnn(F, H)
+    g = G.Sequential("x, edges, weights", [(G.GraphConv(F, H), "x, edges, weights -> x"), torch.nn.Tanh(),
+                                           (G.GraphConv(H, H), "x, edges, weights -> x"), torch.nn.Tanh()])
+    g.load_state_dict(ref.state_dict())
+    g = g.to(DEV)
+    mem = SparseGCM(g, edge_selectors=TemporalEdge([1, 3]), graph_size=N)
+    x = torch.rand(B, N, F)
+    taus = torch.tensor([32, 7, 0, 19, 32])
+
+    def check(taus_cpu, taus_dev):
+        out, hid = mem(x.to(DEV), taus_dev, None)
+        out_o, hid_o = osp.sparse_step(x, taus_cpu, None, ref, graph_size=N, edge_selectors=osp.TemporalEdge([1, 3]))
+        torch.testing.assert_close(out.cpu(), out_o.detach(), rtol=1e-5, atol=2e-6)
+        assert torch.equal(hid[1].coalesce().indices().cpu(), hid_o[1].coalesce().indices())
+        assert torch.equal(hid[2].cpu(), hid_o[2])
+
+    td = taus.to(DEV)
+    h0 = ext.sparse_sizes_memo_hits()
+    check(taus, td)
+    assert ext.sparse_sizes_memo_hits() == h0            # first sight of this tensor: read back
+    check(taus, td)
+    check(taus, td)
+    assert ext.sparse_sizes_memo_hits() == h0 + 2        # ... then reused
+    td[1] = 12                                           # in place: the version counter moves
+    taus2 = taus.clone()
+    taus2[1] = 12
+    check(taus2, td)
+    assert ext.sparse_sizes_memo_hits() == h0 + 2
+    check(taus2, td)
+    assert ext.sparse_sizes_memo_hits() == h0 + 3
+    td.data[3] = 2                                       # behind the counter's back: caught at the closing flag read
+    with pytest.raises(RuntimeError, match="version counter"):
+        mem(x.to(DEV), td, None)
+    taus3 = taus2.clone()
+    taus3[3] = 2
+    check(taus3, td)                                     # (the memo was dropped: read back, correct again)
+
+
 def test_sparse_paths_do_not_depend_on_uninitialised_memory():
     """SparseGCM's whole-episode call and its stepwise cached chain allocate their flat buffers, index structures,
     caches and records without a zero fill where a kernel writes them whole.  With torch filling every uninitialised
