@@ -20,7 +20,7 @@ def test_golden_and_kernel_suites_without_the_torch_extension():
     p = subprocess.run(
         [sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
          os.path.join(ROOT, "tests", "test_dense_gpu.py"), os.path.join(ROOT, "tests", "test_sparse_gpu.py"),
-         "-k", "not stepwise_cached_chain and not returns_aliases_that_are_watched"],
+         "-k", "not stepwise_cached_chain and not returns_aliases_that_are_watched and not sizes_are_reused"],
         env=env, capture_output=True, timeout=1500, cwd=ROOT)
     tail = p.stdout.decode()[-1500:]
     assert p.returncode == 0, tail
