@@ -1199,7 +1199,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         live_blocks = sum((min(t, N - 1) + 31) // 32 for t in range(T))
         n_prod = 4 if exact_u else 5   # P1, dW1, gH0, dW0b (+ P0 without the U cache); c0 / dW0a are vector work
         bpb_exec = B * live_blocks * (n_prod * (2 * 32 * Fe * Fe))
-        kinds = [("k_learned_select", ("k_learned_select<",), sel_exec, sel_ref,
+        kinds = [("k_learned_select", ("k_learned_select<", "k_learned_select8"), sel_exec, sel_ref,
                   "selection + GNN tail (cached step); flops: the N x F x F products it executes (one with the U "
                   "cache of the exact shapes, else two), the W0b / W0a x[cur] and F -> 1 "
                   "layers, four matrix-vector products of the GNN tail; LayerNorm / softmax VALU work not counted; "

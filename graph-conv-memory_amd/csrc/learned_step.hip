@@ -1174,6 +1174,349 @@ __global__ __launch_bounds__(256) void k_learned_select(
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_learned_select<2, 1, true> re-cut for EIGHT waves per graph (round 6): the cached step of a chain from empty graphs on a
+// donated state at the exact shapes N = 128, F = H1 = H2 = 32, the host's cur (cur_host >= 0).
+//
+// Why: the four-wave kernel is one wave per SIMD walking nine phases through ~100 KB of LDS images (node rows and h1 rows
+// staged only so that the tail can gather a handful of them, the edge network's two 32-column images written and read
+// back between every pair of phases, five workgroup barriers) - a wave alone on its SIMD issues a dependent instruction
+// about every eight cycles (§3.12 of DESIGN.md), so its 5.2 k-cycle edge network and 4 k-cycle softmax + tail are mostly
+// issue bubbles.  Here:
+//   * the edge network lives in REGISTERS, 16 candidate rows per wave, two waves per SIMD: lane (m, g) holds features
+//     [8 g, 8 g + 8) of row 16 w + m - its piece of U[j] = W0b x_j straight from the chain's cache (two 16-byte loads),
+//     + c0, ReLU, LayerNorm (row statistics: two cross-group shuffles), and those eight values ARE the A operand of
+//     v_mfma_f32_16x16x4_f32 (k index = g: instruction s pairs H0[m][8 g + s] with W1[col][8 g + s], the B operand
+//     straight from global memory); the product's accumulators hold rows 4 g + (0 .. 3) at columns m and 16 + m, so the
+//     second LayerNorm's row statistics and the F -> 1 layer are 16-lane DPP reductions - no LDS image, no barrier between
+//     the phases;
+//   * nothing is staged for the tail: the selected rows (at most a handful: entries above 1 / (1 + num_edge_samples)) are
+//     gathered from the node matrix and the h1 cache behind the selection, the GNN's weight rows sit in wave 0's
+//     registers from the start;
+//   * c0 = b0 + W0a x_cur, U[cur] = W0b x_cur and the state's stores run on the waves whose rows are not candidates yet.
+// Same record, caches and state as k_learned_select<2, 1, true> (gcm_learned_bptt_cached reads them unchanged); the
+// sums of a row are associated differently (eight per lane group), so logits agree to rounding, not bit for bit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, in every lane of it
+  v += GCM_DPP_F(v, 0xB1, 0xF, 0.f);    // quad_perm [1,0,3,2]
+  v += GCM_DPP_F(v, 0x4E, 0xF, 0.f);    // quad_perm [2,3,0,1]
+  v += GCM_DPP_F(v, 0x141, 0xF, 0.f);   // row_half_mirror
+  v += GCM_DPP_F(v, 0x140, 0xF, 0.f);   // row_mirror
+  return v;
+}
+
+__global__ __launch_bounds__(512) void k_learned_select8(
+    const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, const int64_t* count_in,
+    int64_t* count_out, int64_t* __restrict__ cur_out, const float* __restrict__ noise, int noise_is_exp,
+    const float* __restrict__ mlp, float eps0, float eps1, float cutoff, float* __restrict__ soft,
+    float* __restrict__ row_out, uint32_t* __restrict__ flags, GnnTail gt, int cur) {
+  constexpr int N = NP, F = FP;
+  __shared__ __attribute__((aligned(16))) float sC0[FP];
+  __shared__ __attribute__((aligned(16))) float sLogit8[NP];
+  __shared__ __attribute__((aligned(16))) float sU8[4 * FP];
+  __shared__ int sIdx8[NP];
+  // the candidate rows' x and h1 for the tail's gather (a handful of them, known only behind the softmax: fetched from
+  // global memory there the gather was a 2 k-cycle round trip on wave 0's critical path; every wave brings its 16 rows
+  // along with its other loads instead)
+  // W1 and the edge network's six vectors, once per graph (waves 6 / 7 bring them along with c0 / U[cur]): as eight
+  // waves' own global loads they were a third of the bytes the CU's address path had to process before anything ran
+  constexpr int WS8 = FP + 4;
+  __shared__ __attribute__((aligned(16))) float sW18[FP * WS8];
+  __shared__ __attribute__((aligned(16))) float sVec8[6 * FP];   // g0 | be0 | b1 | g1 | be1 | w2
+  constexpr int XS8 = FP + 4;
+  __shared__ __attribute__((aligned(16))) float sX8[NP * XS8];
+  __shared__ __attribute__((aligned(16))) float sH8[NP * XS8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const Mlp M = unpack_mlp(mlp, F);
+  const size_t gb = (size_t)b;
+  const bool tile_on = 16 * wave < cur;   // (uniform) this wave's rows hold a candidate (j < cur)
+
+  LSTAMP(0);
+  // ---- loads, everything up front -----------------------------------------------------------------------------------
+  int64_t n_chk = 0;
+  if (tid == 0) n_chk = count_in[b];
+  // the edge network's operands of this wave's 16 rows
+  const int r = 16 * wave + m;
+  f32x4 u4[2], w1[2][2], xg4[2], hg4[2];
+  float g0v[8], be0v[8], b1c[2], g1c[2], be1c[2], w2c[2];
+  if (tile_on) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) u4[q] = *reinterpret_cast<const f32x4*>(gt.cU + (gb * N + r) * FP + 8 * g + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      xg4[q] = *reinterpret_cast<const f32x4*>(nodes + (gb * N + r) * FP + 8 * g + 4 * q);
+      hg4[q] = *reinterpret_cast<const f32x4*>(gt.cH + (gb * N + r) * FP + 8 * g + 4 * q);
+    }
+  }
+  const float b2e = M.b2[0];
+  // wave 7: c0 = b0 + W0a x_cur;  wave 6: U[cur] = W0b x_cur;  lane (o, half): sixteen k of row o
+  f32x4 wq[4], xq[4];
+  float b0o = 0.f;
+  if (wave >= 6) {
+    const float* wrow = M.w0 + li * 2 * FP + (wave == 6 ? FP : 0) + 16 * lh;   // w0 [F][2F]: W0a | W0b
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wq[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+      xq[q] = *reinterpret_cast<const f32x4*>(obs + gb * FP + 16 * lh + 4 * q);
+    }
+    b0o = M.b0[li];
+  }
+  f32x4 stg[4];   // wave 6: W1 (row lane >> 1, sixteen floats);  wave 7: the six vectors (lanes 0 - 47, four floats each)
+  if (wave == 6) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stg[q] = *reinterpret_cast<const f32x4*>(M.w1 + (lane >> 1) * FP + 16 * (lane & 1) + 4 * q);
+  } else if (wave == 7 && lane < 48) {
+    const float* vsrc = lane < 8 ? M.g0 + 4 * lane : (lane < 16 ? M.be0 + 4 * (lane - 8) : (lane < 24 ? M.b1 + 4 * (lane - 16) :
+                        (lane < 32 ? M.g1 + 4 * (lane - 24) : (lane < 40 ? M.be1 + 4 * (lane - 32) : M.w2 + 4 * (lane - 40)))));
+    stg[0] = *reinterpret_cast<const f32x4*>(vsrc);
+  }
+  // wave 0: the gumbel draws and the old row (softmax / selection), the GNN's weight rows (the tail)
+  float pf_noise[2] = {0.f, 0.f}, pf_old[2] = {0.f, 0.f}, xc = 0.f, gb1 = 0.f, gb2 = 0.f;
+  f32x4 wg1[8], wg2[8];
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      pf_noise[c] = noise[gb * N + lane + 64 * c];
+      pf_old[c] = adj[(gb * N + cur) * N + lane + 64 * c];
+    }
+    xc = obs[gb * FP + li];
+    const float* r1 = gt.gnn + (lh ? FP * FP : 0) + li * FP;                       // W_rel1 / W_root1 row o
+    const float* r2 = gt.gnn + 2 * FP * FP + FP + (lh ? FP * FP : 0) + li * FP;    // W_rel2 / W_root2 row o
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      wg1[q] = *reinterpret_cast<const f32x4*>(r1 + 4 * q);
+      wg2[q] = *reinterpret_cast<const f32x4*>(r2 + 4 * q);
+    }
+    gb1 = gt.gnn[2 * FP * FP + li];
+    gb2 = gt.gnn[2 * FP * FP + FP + 2 * FP * FP + li];
+  }
+  asm volatile("" ::: "memory");
+  LSTAMP(1);
+
+  // ---- c0, U[cur]; the observation into the state and the node cache (wave 5) ---------------------------------------
+  if (wave >= 6) {
+    float p = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      p = fmaf(wq[q].x, xq[q].x, p); p = fmaf(wq[q].y, xq[q].y, p);
+      p = fmaf(wq[q].z, xq[q].z, p); p = fmaf(wq[q].w, xq[q].w, p);
+    }
+    p += __shfl_xor(p, 32);
+    if (lh == 0) {
+      if (wave == 7) sC0[li] = p + b0o;
+      else gt.cU[(gb * N + cur) * FP + li] = p;
+    }
+  }
+  if (wave == 6) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(sW18 + (lane >> 1) * WS8 + 16 * (lane & 1) + 4 * q) = stg[q];
+  } else if (wave == 7 && lane < 48) {
+    *reinterpret_cast<f32x4*>(sVec8 + 4 * lane) = stg[0];
+  }
+  if (wave == 5 && lane < FP) {
+    const float xo = obs[gb * FP + lane];
+    nodes[(gb * N + cur) * FP + lane] = xo;     // gcm.py:274
+    gt.cX[(gb * N + cur) * FP + lane] = xo;
+  }
+  LSTAMP(2);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #1: c0
+  LSTAMP(3);
+
+  // ---- the edge network on this wave's 16 rows, in registers (learned.py:38-51) -----------------------------------
+  if (tile_on) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) w1[ct][q] = *reinterpret_cast<const f32x4*>(sW18 + (16 * ct + m) * WS8 + 8 * g + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 tg = *reinterpret_cast<const f32x4*>(sVec8 + 8 * g + 4 * q);
+      const f32x4 tb = *reinterpret_cast<const f32x4*>(sVec8 + FP + 8 * g + 4 * q);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { g0v[4 * q + kk] = tg[kk]; be0v[4 * q + kk] = tb[kk]; }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      b1c[ct] = sVec8[2 * FP + 16 * ct + m]; g1c[ct] = sVec8[3 * FP + 16 * ct + m];
+      be1c[ct] = sVec8[4 * FP + 16 * ct + m]; w2c[ct] = sVec8[5 * FP + 16 * ct + m];
+    }
+    float a[8];
+    {
+      const f32x4 c0a = *reinterpret_cast<const f32x4*>(sC0 + 8 * g), c0b = *reinterpret_cast<const f32x4*>(sC0 + 8 * g + 4);
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = (k < 4 ? u4[0][k] : u4[1][k - 4]) + (k < 4 ? c0a[k] : c0b[k - 4]);
+        a[k] = v > 0.f ? v : 0.f;
+        s += a[k];
+      }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s / (float)FP;
+      float qv = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = a[k] - mean; qv = fmaf(d, d, qv); }
+      qv += __shfl_xor(qv, 16);
+      qv += __shfl_xor(qv, 32);
+      const float rstd = rsqrtf(qv / (float)FP + eps0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = fmaf((a[k] - mean) * rstd, g0v[k], be0v[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // this wave's rows of the tail's gather images
+      *reinterpret_cast<f32x4*>(sX8 + r * XS8 + 8 * g + 4 * q) = xg4[q];
+      *reinterpret_cast<f32x4*>(sH8 + r * XS8 + 8 * g + 4 * q) = hg4[q];
+    }
+    LSTAMP(4);
+    f32x4 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 w = w1[ct][s >> 2];
+        const float wv = (s & 3) == 0 ? w.x : ((s & 3) == 1 ? w.y : ((s & 3) == 2 ? w.z : w.w));
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wv, acc[ct], 0, 0, 0);
+      }
+    // rows 4 g + i at columns m (ct 0) and 16 + m (ct 1): + b1, ReLU, LayerNorm over the 32 columns of a row = the 16
+    // lanes of this DPP row x 2, the F -> 1 layer the same way
+    LSTAMP(5);
+    float lg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v0 = acc[0][i] + b1c[0], v1 = acc[1][i] + b1c[1];
+      v0 = v0 > 0.f ? v0 : 0.f;
+      v1 = v1 > 0.f ? v1 : 0.f;
+      const float mean = row16_sum(v0 + v1) / (float)FP;
+      const float d0 = v0 - mean, d1 = v1 - mean;
+      const float rstd = rsqrtf(row16_sum(fmaf(d0, d0, d1 * d1)) / (float)FP + eps1);
+      const float h0 = fmaf(d0 * rstd, g1c[0], be1c[0]), h1 = fmaf(d1 * rstd, g1c[1], be1c[1]);
+      lg[i] = row16_sum(fmaf(w2c[0], h0, w2c[1] * h1)) + b2e;
+    }
+    if (m < 4) sLogit8[16 * wave + 4 * g + m] = m == 0 ? lg[0] : (m == 1 ? lg[1] : (m == 2 ? lg[2] : lg[3]));
+  }
+  LSTAMP(6);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the logits
+  if (wave != 0) return;
+  LSTAMP(7);
+
+  // ---- wave 0: gumbel-softmax over j < cur (learned.py:88-95), threshold, row cur of the adjacency -------------------
+  float z[2];
+  {
+    float mx_ = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      float nz = 0.f;
+      if (j < cur) {
+        const float t = pf_noise[c];
+        nz = noise_is_exp ? -logf(t) : t;
+      }
+      z[c] = j < cur ? sLogit8[j] + nz : -INFINITY;
+      mx_ = fmaxf(mx_, z[c]);
+    }
+    mx_ = wave_max(mx_);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      z[c] = (lane + 64 * c < cur) ? expf(z[c] - mx_) : 0.f;
+      s += z[c];
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    float* row = adj + (gb * N + cur) * N;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      const float p = z[c] * inv;
+      soft[gb * N + j] = p;
+      if (j < cur) {
+        const float edge = (p - cutoff > 0.f) ? 1.f : 0.f;     // STE forward (util.py:12)
+        const float nv = (edge + pf_old[c] > 0.f) ? 1.f : 0.f;   // learned.py:108-110
+        row[j] = nv;
+        row_out[gb * N + j] = nv;
+        z[c] = nv;
+      } else {
+        row_out[gb * N + j] = 0.f;
+        z[c] = 0.f;
+      }
+    }
+  }
+  LSTAMP(8);
+  // ---- the GNN on row cur (GnnTail): the selected rows, ascending, gathered from the node matrix and the h1 cache -----
+  {
+    const unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
+    const int n0 = __popcll(m0), n_sel = n0 + __popcll(m1);
+    {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (z[0] != 0.f) sIdx8[__popcll(m0 & below)] = lane;
+      if (z[1] != 0.f) sIdx8[n0 + __popcll(m1 & below)] = lane + 64;
+    }
+    wsync();
+    float agg1 = 0.f, agg2 = 0.f;
+#pragma unroll 1
+    for (int q0 = 0; q0 < n_sel; q0 += 8) {
+      const int4 ia = *reinterpret_cast<const int4*>(sIdx8 + q0), ib = *reinterpret_cast<const int4*>(sIdx8 + q0 + 4);
+      const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+      float xa[8], ha[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = q0 + q < n_sel ? js[q] : 0;
+        xa[q] = sX8[j * XS8 + li];
+        ha[q] = sH8[j * XS8 + li];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q0 + q < n_sel) { agg1 += xa[q]; agg2 += ha[q]; }
+    }
+    LSTAMP(9);
+    float* sU = sU8;   // [agg1 | x_cur | agg2 | h1_cur], 32 each
+    if (lh == 0) { sU[li] = agg1; sU[32 + li] = xc; sU[64 + li] = agg2; }
+    wsync();
+    // half_dot (the four-wave kernel's): this half's 32 products in two chains, the other half's sum added
+    auto hdot = [&](const f32x4 (&w)[8], const float* u) {
+      float pa = 0.f, pb = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 uv = reinterpret_cast<const float4*>(u)[q];
+        pa = fmaf(w[q].x, uv.x, pa);
+        pb = fmaf(w[q].y, uv.y, pb);
+        pa = fmaf(w[q].z, uv.z, pa);
+        pb = fmaf(w[q].w, uv.w, pb);
+      }
+      const float p = pa + pb;
+      return p + __shfl_xor(p, 32);
+    };
+    float p1 = hdot(wg1, sU + 32 * lh);
+    p1 += (gt.has_bias & 1) ? gb1 : 0.f;
+    const float h1c = gcm_act(p1, gt.act1);
+    if (lh == 0) sU[96 + li] = h1c;
+    wsync();
+    float p2 = hdot(wg2, sU + 64 + 32 * lh);
+    p2 += (gt.has_bias & 2) ? gb2 : 0.f;
+    const float v = gcm_act(p2, gt.act2);
+    LSTAMP(10);
+    const size_t rc = gb * N + cur;
+    if (lane < FP) {
+      gt.cH[rc * FP + lane] = h1c;
+      gt.agg2_out[gb * FP + lane] = agg2;
+      gt.cA[rc * FP + lane] = agg1;
+      gt.mx_out[gb * FP + lane] = v;
+    }
+    const bool bad = __any(lane < FP && !isfinite(v));
+    if (lane == 0) {
+      cur_out[b] = cur;
+      count_out[b] = cur + 1;
+      const uint32_t f = (bad ? GCM_FLAG_NONFINITE : 0u) | (n_chk != (int64_t)cur ? GCM_FLAG_BAD_COUNT : 0u);
+      if (f) atomicOr(flags, f);
+    }
+    LSTAMP(11);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Time-parallel forward of a whole rollout (round 4; DenseGCM.rollout with LearnedEdge from EMPTY graphs, T <= N
 // steps, observations without gradient).  Nothing in the selection of step t depends on another step's RESULT: the
 // edge network scores pairs of raw observations (learned.py:53-87), the gumbel draws are given, and with empty
@@ -2568,6 +2911,13 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   const size_t Pg = 2 * (size_t)H1 * F + H1 + 2 * (size_t)H2 * H1 + H2;
   constexpr size_t lds = gcm_learned::lds_select_tail();
   const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
+  if (exact && cur_host >= 0 && cur_host < N && !(has_bias & GCM_STEP_FOUR_WAVES)) {   // eight waves per graph (round 6)
+    gcm_learned::GnnTail gt8{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, cache_u, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(gcm_learned::k_learned_select8, dim3(B), dim3(512), 0, (hipStream_t)stream, obs, nodes, adj,
+                       count_in, count_out, cur_out, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, adj_row,
+                       flags, gt8, cur_host);
+    return gcm_launch_status();
+  }
   auto kern = exact ? gcm_learned::k_learned_select<2, 1, true> : gcm_learned::k_learned_select<2, 1, false>;
   gcm_allow_dynamic_lds((const void*)kern, lds);
   gcm_learned::GnnTail gt{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, cache_u, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};

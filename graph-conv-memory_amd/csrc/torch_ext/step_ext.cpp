@@ -16,6 +16,7 @@
 //
 // No device code here: PyTorch is plumbing (allocation, autograd graph, stream); the product is the
 // C-ABI library this file links against.
+#include <cstdlib>
 #include <torch/extension.h>
 #include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPStream.h>
@@ -1542,9 +1543,13 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
       adj_out = alias_of(buf, (int64_t)lay[1], {B, N, N}, buf.dtype());
       count_out = alias_of(buf, (int64_t)lay[6] / 2 + B, {B}, caffe2::TypeMeta::Make<int64_t>());
     } else {
+    // (GCM_LEARNED_FOUR_WAVES=1: the four-wave kernel where the eight-wave form exists - the A/B of tools and tests; a
+    //  per-call flag of the C ABI, read from the environment by this host module once)
+    static const int four_waves = (std::getenv("GCM_LEARNED_FOUR_WAVES") && std::getenv("GCM_LEARNED_FOUR_WAVES")[0] == '1')
+                                      ? GCM_STEP_FOUR_WAVES : 0;
     check(gcm_learned_step_cached(obs.data_ptr<float>(), nodes_in.data_ptr<float>(), adj_in.data_ptr<float>(),
                                   count_in.data_ptr<int64_t>(), noise.data_ptr<float>(), (int)noise_is_exp, pk,
-                                  cfg->has_bias, cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
+                                  cfg->has_bias | four_waves, cfg->act1, cfg->act2, (float)cfg->eps0, (float)cfg->eps1,
                                   (float)cfg->cutoff, ib, count_in.data_ptr<int64_t>(), base + lay[7], base + lay[1],
                                   base + lay[2], base + lay[5], chain.cH.data_ptr<float>(),
                                   chain.cA.data_ptr<float>(), chain.cX.data_ptr<float>(), chain.cU.data_ptr<float>(), fl,
