@@ -66,6 +66,22 @@ __device__ __forceinline__ float gcm_wave_sum(float v) {
   v += GCM_DPP_F(v, 0x143, 0xC, 0.f);   // row_bcast31 -> rows 2, 3: lane 63 holds the total
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// v + the value of lane ^ 16 / lane ^ 32, in every lane, on gfx950's row / half swaps (v_permlane16_swap exchanges the
+// odd 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the
+// first with the lower half of the second: from two copies of v one register ends up with the even rows / lower half
+// everywhere, the other with the odd rows / upper half).  VALU instructions; `v + __shfl_xor(v, 16)` is a
+// ds_bpermute, an LDS round trip each.  Bit-identical to it (one commutative add of the same two numbers).
+typedef unsigned gcm_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float gcm_xor16_add(float v) {
+  const unsigned u = __float_as_uint(v);
+  const gcm_u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float gcm_xor32_add(float v) {
+  const unsigned u = __float_as_uint(v);
+  const gcm_u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float gcm_wave_max(float v) {
   v = fmaxf(v, GCM_DPP_F(v, 0xB1, 0xF, v));
   v = fmaxf(v, GCM_DPP_F(v, 0x4E, 0xF, v));

@@ -339,7 +339,7 @@ __device__ __forceinline__ float half_dot(const float* wrow, const float* u) {
     pb = fmaf(wv[q].w, uv[q].w, pb);
   }
   const float p = pa + pb;
-  return p + __shfl_xor(p, 32);
+  return gcm_xor32_add(p);
 }
 
 // gcm_fused::Stage<RP, CP, false, false> with a form for exact shapes (EX: no clamps, no masks, 16-byte global loads -
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void k_learned_select(
     float p = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) p = fmaf(w[k], x[k], p);
-    p += __shfl_xor(p, 32);
+    p = gcm_xor32_add(p);
     if (lane < FP) gt.cU[((size_t)b * N + cur) * FP + lane] = p;
   }
   float z[2] = {0.f, 0.f};   // wave 0: the softmax terms, then this step's entries of row cur
@@ -1231,6 +1231,10 @@ __global__ __launch_bounds__(512) void k_learned_select8(
   const Mlp M = unpack_mlp(mlp, F);
   const size_t gb = (size_t)b;
   const bool tile_on = 16 * wave < cur;   // (uniform) this wave's rows hold a candidate (j < cur)
+  // every kernel argument in scalar registers HERE, one s_load batch and one wait: left alone the compiler loads each
+  // pointer in the block that first uses it, and the load phase below was six dependent kernarg round trips long
+  asm volatile("" ::"s"(obs), "s"(nodes), "s"(adj), "s"(count_in), "s"(count_out), "s"(cur_out), "s"(noise), "s"(mlp), "s"(soft),
+               "s"(row_out), "s"(flags), "s"(gt.gnn), "s"(gt.cH), "s"(gt.cA), "s"(gt.cX), "s"(gt.cU), "s"(gt.mx_out), "s"(gt.agg2_out), "s"(cur));
 
   LSTAMP(0);
   // ---- loads, everything up front -----------------------------------------------------------------------------------
@@ -1302,7 +1306,7 @@ __global__ __launch_bounds__(512) void k_learned_select8(
       p = fmaf(wq[q].x, xq[q].x, p); p = fmaf(wq[q].y, xq[q].y, p);
       p = fmaf(wq[q].z, xq[q].z, p); p = fmaf(wq[q].w, xq[q].w, p);
     }
-    p += __shfl_xor(p, 32);
+    p = gcm_xor32_add(p);
     if (lh == 0) {
       if (wave == 7) sC0[li] = p + b0o;
       else gt.cU[(gb * N + cur) * FP + li] = p;
@@ -1351,14 +1355,14 @@ __global__ __launch_bounds__(512) void k_learned_select8(
         a[k] = v > 0.f ? v : 0.f;
         s += a[k];
       }
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = gcm_xor16_add(s);
+      s = gcm_xor32_add(s);
       const float mean = s / (float)FP;
       float qv = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { const float d = a[k] - mean; qv = fmaf(d, d, qv); }
-      qv += __shfl_xor(qv, 16);
-      qv += __shfl_xor(qv, 32);
+      qv = gcm_xor16_add(qv);
+      qv = gcm_xor32_add(qv);
       const float rstd = rsqrtf(qv / (float)FP + eps0);
 #pragma unroll
       for (int k = 0; k < 8; ++k) a[k] = fmaf((a[k] - mean) * rstd, g0v[k], be0v[k]);
@@ -1487,7 +1491,7 @@ __global__ __launch_bounds__(512) void k_learned_select8(
         pb = fmaf(w[q].w, uv.w, pb);
       }
       const float p = pa + pb;
-      return p + __shfl_xor(p, 32);
+      return gcm_xor32_add(p);
     };
     float p1 = hdot(wg1, sU + 32 * lh);
     p1 += (gt.has_bias & 1) ? gb1 : 0.f;
@@ -2638,7 +2642,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
       float p = 0.f;
 #pragma unroll
       for (int f = 0; f < 16; ++f) p = fmaf(w[f], x[f], p);
-      const float c0 = p + __shfl_xor(p, 32) + sVec[li];
+      const float c0 = gcm_xor32_add(p) + sVec[li];
       if (have_u) {
         // P0[j] = U[j] + c0 from the chain's cache of the first-layer product (the forward kept U[j] = W0b x_j of
         // every stored row: gcm_learned_step_cached, cache_u): no matrix product at all, and the P0 the forward normalised
@@ -2756,7 +2760,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
     {
       // dW0a += gP0^T (x_cur for every row) = (column sums of gP0) x_cur^T: an outer product of two vectors the wave
       // holds already - sixteen fmas a lane instead of sixteen MFMAs a block
-      sGl[cf] = cb + __shfl_xor(cb, 32);       // (g_logit is consumed; both half-waves write the same value)
+      sGl[cf] = gcm_xor32_add(cb);       // (g_logit is consumed; both half-waves write the same value)
       wsync();
       const float xcf = sX[32 * FS + li];
 #pragma unroll

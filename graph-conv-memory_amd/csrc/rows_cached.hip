@@ -329,7 +329,7 @@ __device__ __forceinline__ float pair_matvec_half(const f32x2 (&w)[16], const fl
     acc = w[2 * j + 1] * f32x2{u[2], u[3]} + acc;
   }
   const float ph = acc[0] + acc[1];
-  return ph + __shfl_xor(ph, 32);
+  return gcm_xor32_add(ph);
 }
 
 // The forward temporal hops of the step as ONE 128-bit mask, built on the host: bit (128 - h) of (rev_hi : rev_lo) for
@@ -572,7 +572,7 @@ __device__ __forceinline__ void step_rows_cached_img_body(
       acc = w1[2 * j + 1] * f32x2{u[2], u[3]} + acc;
     }
     const float ph = acc[0] + acc[1];
-    p1 += ph + __shfl_xor(ph, 32);
+    p1 += gcm_xor32_add(ph);
   } else if (V4) {   // (pa, pb) as one packed accumulator: the same two chains, value for value
     f32x2 acc = {0.f, 0.f};
 #pragma unroll
@@ -612,7 +612,7 @@ __device__ __forceinline__ void step_rows_cached_img_body(
       acc = w2[2 * j + 1] * f32x2{u[2], u[3]} + acc;
     }
     const float ph = acc[0] + acc[1];
-    p2 += ph + __shfl_xor(ph, 32);
+    p2 += gcm_xor32_add(ph);
   } else if (V4) {
     f32x2 acc = {0.f, 0.f};
 #pragma unroll

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
         t = fmaf(wr[ct][q].z, xa[q].z, t);
         t = fmaf(wr[ct][q].w, xa[q].w, t);
       }
-      t += __shfl_xor(t, 32);
+      t = gcm_xor32_add(t);
       const float v = t + b1v[ct];
       if (lh == 0) {
         sRcur[32 * ct + li] = v;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < GP; ++g) s += v[g];
-    if (SPLIT == 2) s += __shfl_xor(s, 32);
+    if (SPLIT == 2) s = gcm_xor32_add(s);
     if (part == 0) {
       sAggc[f] = s;
       cAg[cur * FK + f] = s;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
               }
             }
           }
-          a2 += __shfl_xor(a2, 32);
+          a2 = gcm_xor32_add(a2);
           if (lh == 0) sA2[wave * HK + 32 * ct + li] = a2;
           if (cur_lane) {
             sV[HK + 32 * ct + li] = hc;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_step_colcache(
         t = fmaf(w2[ot][q].z, x4.z, t);
         t = fmaf(w2[ot][q].w, x4.w, t);
       }
-      t += __shfl_xor(t, 32);
+      t = gcm_xor32_add(t);
       const float y = gcm_act(t + b2v[ot], act2);
       const int o = 32 * ot + li;
       const bool mine = lh == 0 && o < H2;
@@ -669,8 +669,8 @@ __global__ __launch_bounds__(512) void k_step_colcache8(
         t = fmaf(wr[ct][q].z, xa[q].z, t);
         t = fmaf(wr[ct][q].w, xa[q].w, t);
       }
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);
+      t = gcm_xor16_add(t);
+      t = gcm_xor32_add(t);
       const float v = t + b1v[ct];
       if (g == 0) {
         sRcur[16 * ct + m] = v;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512) void k_step_colcache8(
     float s0 = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) s0 += v[k];
-    s0 += __shfl_xor(s0, 32);
+    s0 = gcm_xor32_add(s0);
     if (part == 0) {
       sAggc[f] = s0;
       cAg[cur * FK + f] = s0;
@@ -772,8 +772,8 @@ __global__ __launch_bounds__(512) void k_step_colcache8(
             off += st ? (unsigned)rw : 0u;
           }
         }
-        a2 += __shfl_xor(a2, 16);
-        a2 += __shfl_xor(a2, 32);
+        a2 = gcm_xor16_add(a2);
+        a2 = gcm_xor32_add(a2);
         if (g == 0) sA2[wave * HK + 16 * ct + m] = a2;
         if (cur_grp) {
           sV[HK + 16 * ct + m] = hc;
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(512) void k_step_colcache8(
         t = fmaf(w2[ot][q].z, x4.z, t);
         t = fmaf(w2[ot][q].w, x4.w, t);
       }
-      t += __shfl_xor(t, 32);
+      t = gcm_xor32_add(t);
       const float y = gcm_act(t + b2v[ot], act2);
       const int o = 32 * ot + li;
       const bool mine = lh == 0 && o < H2;
