@@ -69,7 +69,7 @@ __device__ __forceinline__ float gcm_wave_sum(float v) {
 // v + the value of lane ^ 16 / lane ^ 32, in every lane, on gfx950's row / half swaps (v_permlane16_swap exchanges the
 // odd 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the
 // first with the lower half of the second: from two copies of v one register ends up with the even rows / lower half
-// everywhere, the other with the odd rows / upper half).  VALU instructions; `v + __shfl_xor(v, 16)` is a
+// everywhere, the other with the odd rows / upper half).  VALU instructions; `gcm_xor16_add(v)` is a
 // ds_bpermute, an LDS round trip each.  Bit-identical to it (one commutative add of the same two numbers).
 typedef unsigned gcm_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float gcm_xor16_add(float v) {

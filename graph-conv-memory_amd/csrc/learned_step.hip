@@ -45,6 +45,15 @@ extern "C" int gcm_debug_read_stamps(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
 }
 #define LSTAMP(i) STAMP(i)
+// the same from the tail wave of k_learned_select8 (wave 8, lane 0)
+#define LSTAMPT(i)                                                                   \
+  do {                                                                               \
+    if (blockIdx.x == 0 && threadIdx.x == 512) {                                     \
+      unsigned long long t_;                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+      g_stamps[i] = t_;                                                              \
+    }                                                                                \
+  } while (0)
 // first / last s_memrealtime (100 MHz, one counter for the device) of EVERY workgroup of the last k_learned_select launch
 __device__ unsigned long long g_span[2048][2];
 extern "C" int gcm_debug_read_spans(unsigned long long* out, int n_wg) {
@@ -65,6 +74,7 @@ extern "C" int gcm_debug_read_spans(unsigned long long* out, int n_wg) {
 #endif
 #else
 #define LSTAMP(i)
+#define LSTAMPT(i)
 #define BSTAMP(i)
 #define LSPAN(i)
 #endif
@@ -1204,12 +1214,18 @@ __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes
   return v;
 }
 
-__global__ __launch_bounds__(512) void k_learned_select8(
+__global__ __launch_bounds__(576) void k_learned_select8(
     const float* __restrict__ obs, float* __restrict__ nodes, float* __restrict__ adj, const int64_t* count_in,
     int64_t* count_out, int64_t* __restrict__ cur_out, const float* __restrict__ noise, int noise_is_exp,
     const float* __restrict__ mlp, float eps0, float eps1, float cutoff, float* __restrict__ soft,
     float* __restrict__ row_out, uint32_t* __restrict__ flags, GnnTail gt, int cur) {
   constexpr int N = NP, F = FP;
+  constexpr int TW = 8;   // the tail wave: softmax, selection and the GNN on row cur; it has no tile (16 TW >= N)
+#ifdef GCM_STAMPS   // every wave's first instruction and its arrival at barrier 1, kept in registers and written at the end (a
+                    // stamp's store would sit in front of the wave's next vmcnt wait)
+  unsigned long long t_start, t_arrive;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
+#endif
   __shared__ __attribute__((aligned(16))) float sC0[FP];
   __shared__ __attribute__((aligned(16))) float sLogit8[NP];
   __shared__ __attribute__((aligned(16))) float sU8[4 * FP];
@@ -1239,11 +1255,11 @@ __global__ __launch_bounds__(512) void k_learned_select8(
   LSTAMP(0);
   // ---- loads, everything up front -----------------------------------------------------------------------------------
   int64_t n_chk = 0;
-  if (tid == 0) n_chk = count_in[b];
+  if (tid == 64 * TW) n_chk = count_in[b];
   // the edge network's operands of this wave's 16 rows
   const int r = 16 * wave + m;
   f32x4 u4[2], w1[2][2], xg4[2], hg4[2];
-  float g0v[8], be0v[8], b1c[2], g1c[2], be1c[2], w2c[2];
+  float g0v[8], be0v[8];
   if (tile_on) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) u4[q] = *reinterpret_cast<const f32x4*>(gt.cU + (gb * N + r) * FP + 8 * g + 4 * q);
@@ -1254,37 +1270,79 @@ __global__ __launch_bounds__(512) void k_learned_select8(
     }
   }
   const float b2e = M.b2[0];
-  // wave 7: c0 = b0 + W0a x_cur;  wave 6: U[cur] = W0b x_cur;  lane (o, half): sixteen k of row o
-  f32x4 wq[4], xq[4];
+  // wave 7: c0 = W0a x_cur + b0 (lower half) and U[cur] = W0b x_cur (upper half), output li per lane: its weight row as
+  // eight 16-byte loads, the observation through the SCALAR path (one row for the whole wave; as vector loads it was
+  // four more 1 KB requests in front of the products barrier 1 waits for - and the observation comes from far memory)
+  f32x4 wq[8];
+  typedef float f32x16s __attribute__((ext_vector_type(16)));
+  f32x16s xsa, xsb;   // (s_load_dwordx16 x 2 by hand: the compiler keeps a uniform load behind a branch on the vector path)
+  {   // (every wave: a scalar value defined under a branch becomes a vector register)
+    const float* xrow = obs + gb * FP;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(xsa), "=&s"(xsb) : "s"(xrow));
+  }
   float b0o = 0.f;
-  if (wave >= 6) {
-    const float* wrow = M.w0 + li * 2 * FP + (wave == 6 ? FP : 0) + 16 * lh;   // w0 [F][2F]: W0a | W0b
+  if (wave == 7) {
+    const float* wrow = M.w0 + li * 2 * FP + (lh ? FP : 0);   // w0 [F][2F]: W0a | W0b
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      wq[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
-      xq[q] = *reinterpret_cast<const f32x4*>(obs + gb * FP + 16 * lh + 4 * q);
-    }
+    for (int q = 0; q < 8; ++q) wq[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
     b0o = M.b0[li];
   }
-  f32x4 stg[4];   // wave 6: W1 (row lane >> 1, sixteen floats);  wave 7: the six vectors (lanes 0 - 47, four floats each)
+  f32x4 stg[4];   // wave 6: W1 (row lane >> 1, sixteen floats);  wave 5: the six vectors (lanes 0 - 47, four floats each)
   if (wave == 6) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) stg[q] = *reinterpret_cast<const f32x4*>(M.w1 + (lane >> 1) * FP + 16 * (lane & 1) + 4 * q);
-  } else if (wave == 7 && lane < 48) {
+  } else if (wave == 5 && lane < 48) {
     const float* vsrc = lane < 8 ? M.g0 + 4 * lane : (lane < 16 ? M.be0 + 4 * (lane - 8) : (lane < 24 ? M.b1 + 4 * (lane - 16) :
                         (lane < 32 ? M.g1 + 4 * (lane - 24) : (lane < 40 ? M.be1 + 4 * (lane - 32) : M.w2 + 4 * (lane - 40)))));
     stg[0] = *reinterpret_cast<const f32x4*>(vsrc);
   }
-  // wave 0: the gumbel draws and the old row (softmax / selection), the GNN's weight rows (the tail)
+  float xo5 = 0.f;
+  if (wave == 5 && lane < FP) xo5 = obs[gb * FP + lane];
+  // the tail wave: the gumbel draws and the old row (softmax / selection) now, the GNN's weight rows behind barrier 1 (they
+  // are wanted after barrier 2; in front of barrier 1 their sixteen 1 KB requests sat in the CU's one address path ahead of
+  // the loads that barrier waits for)
   float pf_noise[2] = {0.f, 0.f}, pf_old[2] = {0.f, 0.f}, xc = 0.f, gb1 = 0.f, gb2 = 0.f;
   f32x4 wg1[8], wg2[8];
-  if (wave == 0) {
+  if (wave == TW) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       pf_noise[c] = noise[gb * N + lane + 64 * c];
       pf_old[c] = adj[(gb * N + cur) * N + lane + 64 * c];
     }
     xc = obs[gb * FP + li];
+  }
+  asm volatile("" ::: "memory");
+  LSTAMP(1);
+
+  // ---- c0, U[cur]; the observation into the state and the node cache (wave 5) ---------------------------------------
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xsa), "+s"(xsb));   // (the barrier below waits for the same row through c0)
+  if (wave == 7) {
+    float p = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p = fmaf(wq[q][e], q < 4 ? xsa[4 * q + e] : xsb[4 * q - 16 + e], p);
+    }
+    if (lh == 0) sC0[li] = p + b0o;
+    else gt.cU[(gb * N + cur) * FP + li] = p;
+  }
+  if (wave == 6) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(sW18 + (lane >> 1) * WS8 + 16 * (lane & 1) + 4 * q) = stg[q];
+  } else if (wave == 5) {
+    if (lane < 48) *reinterpret_cast<f32x4*>(sVec8 + 4 * lane) = stg[0];
+    if (lane < FP) {
+      nodes[(gb * N + cur) * FP + lane] = xo5;     // gcm.py:274
+      gt.cX[(gb * N + cur) * FP + lane] = xo5;
+    }
+  }
+  LSTAMP(2);
+#ifdef GCM_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_arrive)::"memory");
+#endif
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #1: c0
+  LSTAMP(3);
+  if (wave == TW) {
     const float* r1 = gt.gnn + (lh ? FP * FP : 0) + li * FP;                       // W_rel1 / W_root1 row o
     const float* r2 = gt.gnn + 2 * FP * FP + FP + (lh ? FP * FP : 0) + li * FP;    // W_rel2 / W_root2 row o
 #pragma unroll
@@ -1294,38 +1352,13 @@ __global__ __launch_bounds__(512) void k_learned_select8(
     }
     gb1 = gt.gnn[2 * FP * FP + li];
     gb2 = gt.gnn[2 * FP * FP + FP + 2 * FP * FP + li];
-  }
-  asm volatile("" ::: "memory");
-  LSTAMP(1);
-
-  // ---- c0, U[cur]; the observation into the state and the node cache (wave 5) ---------------------------------------
-  if (wave >= 6) {
-    float p = 0.f;
+    // the gumbel draws from the exponential ones (learned.py:88-89), while the tiles work
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      p = fmaf(wq[q].x, xq[q].x, p); p = fmaf(wq[q].y, xq[q].y, p);
-      p = fmaf(wq[q].z, xq[q].z, p); p = fmaf(wq[q].w, xq[q].w, p);
-    }
-    p = gcm_xor32_add(p);
-    if (lh == 0) {
-      if (wave == 7) sC0[li] = p + b0o;
-      else gt.cU[(gb * N + cur) * FP + li] = p;
+    for (int c = 0; c < 2; ++c) {
+      const float t = pf_noise[c];
+      pf_noise[c] = (lane + 64 * c < cur) ? (noise_is_exp ? -logf(t) : t) : 0.f;
     }
   }
-  if (wave == 6) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(sW18 + (lane >> 1) * WS8 + 16 * (lane & 1) + 4 * q) = stg[q];
-  } else if (wave == 7 && lane < 48) {
-    *reinterpret_cast<f32x4*>(sVec8 + 4 * lane) = stg[0];
-  }
-  if (wave == 5 && lane < FP) {
-    const float xo = obs[gb * FP + lane];
-    nodes[(gb * N + cur) * FP + lane] = xo;     // gcm.py:274
-    gt.cX[(gb * N + cur) * FP + lane] = xo;
-  }
-  LSTAMP(2);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #1: c0
-  LSTAMP(3);
 
   // ---- the edge network on this wave's 16 rows, in registers (learned.py:38-51) -----------------------------------
   if (tile_on) {
@@ -1340,10 +1373,13 @@ __global__ __launch_bounds__(512) void k_learned_select8(
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) { g0v[4 * q + kk] = tg[kk]; be0v[4 * q + kk] = tb[kk]; }
     }
+    f32x4 b1v[2], g1v[2], be1v[2], w2v[2];   // columns 16 ct + 4 g + (0 .. 3): the transposed product's (below)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      b1c[ct] = sVec8[2 * FP + 16 * ct + m]; g1c[ct] = sVec8[3 * FP + 16 * ct + m];
-      be1c[ct] = sVec8[4 * FP + 16 * ct + m]; w2c[ct] = sVec8[5 * FP + 16 * ct + m];
+      b1v[ct] = *reinterpret_cast<const f32x4*>(sVec8 + 2 * FP + 16 * ct + 4 * g);
+      g1v[ct] = *reinterpret_cast<const f32x4*>(sVec8 + 3 * FP + 16 * ct + 4 * g);
+      be1v[ct] = *reinterpret_cast<const f32x4*>(sVec8 + 4 * FP + 16 * ct + 4 * g);
+      w2v[ct] = *reinterpret_cast<const f32x4*>(sVec8 + 5 * FP + 16 * ct + 4 * g);
     }
     float a[8];
     {
@@ -1382,43 +1418,54 @@ __global__ __launch_bounds__(512) void k_learned_select8(
       for (int ct = 0; ct < 2; ++ct) {
         const f32x4 w = w1[ct][s >> 2];
         const float wv = (s & 3) == 0 ? w.x : ((s & 3) == 1 ? w.y : ((s & 3) == 2 ? w.z : w.w));
-        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wv, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, a[s], acc[ct], 0, 0, 0);
       }
-    // rows 4 g + i at columns m (ct 0) and 16 + m (ct 1): + b1, ReLU, LayerNorm over the 32 columns of a row = the 16
-    // lanes of this DPP row x 2, the F -> 1 layer the same way
+    // W1 as the A operand, H0 as B: the accumulators hold the TRANSPOSED product, P1[row m][16 ct + 4 g + i] - eight
+    // columns of ONE row per lane, like the first LayerNorm's operands (the other way round a lane held four rows at two
+    // columns: twelve 16-lane DPP reductions; here three sums of eight in the lane and two row / half swaps each)
     LSTAMP(5);
-    float lg[4];
+    {
+      float v[8];
+      float sm = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v0 = acc[0][i] + b1c[0], v1 = acc[1][i] + b1c[1];
-      v0 = v0 > 0.f ? v0 : 0.f;
-      v1 = v1 > 0.f ? v1 : 0.f;
-      const float mean = row16_sum(v0 + v1) / (float)FP;
-      const float d0 = v0 - mean, d1 = v1 - mean;
-      const float rstd = rsqrtf(row16_sum(fmaf(d0, d0, d1 * d1)) / (float)FP + eps1);
-      const float h0 = fmaf(d0 * rstd, g1c[0], be1c[0]), h1 = fmaf(d1 * rstd, g1c[1], be1c[1]);
-      lg[i] = row16_sum(fmaf(w2c[0], h0, w2c[1] * h1)) + b2e;
+      for (int k = 0; k < 8; ++k) {
+        const float t = acc[k >> 2][k & 3] + b1v[k >> 2][k & 3];
+        v[k] = t > 0.f ? t : 0.f;
+        sm += v[k];
+      }
+      sm = gcm_xor16_add(sm);
+      sm = gcm_xor32_add(sm);
+      const float mean = sm / (float)FP;
+      float qv = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[k] -= mean; qv = fmaf(v[k], v[k], qv); }
+      qv = gcm_xor16_add(qv);
+      qv = gcm_xor32_add(qv);
+      const float rstd = rsqrtf(qv / (float)FP + eps1);
+      float lgp = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lgp = fmaf(w2v[k >> 2][k & 3], fmaf(v[k] * rstd, g1v[k >> 2][k & 3], be1v[k >> 2][k & 3]), lgp);
+      lgp = gcm_xor16_add(lgp);
+      lgp = gcm_xor32_add(lgp);
+      if (g == 0) sLogit8[16 * wave + m] = lgp + b2e;
     }
-    if (m < 4) sLogit8[16 * wave + 4 * g + m] = m == 0 ? lg[0] : (m == 1 ? lg[1] : (m == 2 ? lg[2] : lg[3]));
   }
   LSTAMP(6);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the logits
-  if (wave != 0) return;
-  LSTAMP(7);
+#ifdef GCM_STAMPS
+  if (b == 0 && lane == 0 && wave < 8) { g_stamps[16 + wave] = t_arrive; g_stamps[24 + wave] = t_start; }
+#endif
+  if (wave != TW) return;
+  LSTAMPT(7);
 
-  // ---- wave 0: gumbel-softmax over j < cur (learned.py:88-95), threshold, row cur of the adjacency -------------------
+  // ---- the tail wave: gumbel-softmax over j < cur (learned.py:88-95), threshold, row cur of the adjacency -------------------
   float z[2];
   {
     float mx_ = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int j = lane + 64 * c;
-      float nz = 0.f;
-      if (j < cur) {
-        const float t = pf_noise[c];
-        nz = noise_is_exp ? -logf(t) : t;
-      }
-      z[c] = j < cur ? sLogit8[j] + nz : -INFINITY;
+      z[c] = j < cur ? sLogit8[j] + pf_noise[c] : -INFINITY;
       mx_ = fmaxf(mx_, z[c]);
     }
     mx_ = wave_max(mx_);
@@ -1448,7 +1495,7 @@ __global__ __launch_bounds__(512) void k_learned_select8(
       }
     }
   }
-  LSTAMP(8);
+  LSTAMPT(8);
   // ---- the GNN on row cur (GnnTail): the selected rows, ascending, gathered from the node matrix and the h1 cache -----
   {
     const unsigned long long m0 = __ballot(z[0] != 0.f), m1 = __ballot(z[1] != 0.f);
@@ -1475,7 +1522,7 @@ __global__ __launch_bounds__(512) void k_learned_select8(
       for (int q = 0; q < 8; ++q)
         if (q0 + q < n_sel) { agg1 += xa[q]; agg2 += ha[q]; }
     }
-    LSTAMP(9);
+    LSTAMPT(9);
     float* sU = sU8;   // [agg1 | x_cur | agg2 | h1_cur], 32 each
     if (lh == 0) { sU[li] = agg1; sU[32 + li] = xc; sU[64 + li] = agg2; }
     wsync();
@@ -1501,7 +1548,7 @@ __global__ __launch_bounds__(512) void k_learned_select8(
     float p2 = hdot(wg2, sU + 64 + 32 * lh);
     p2 += (gt.has_bias & 2) ? gb2 : 0.f;
     const float v = gcm_act(p2, gt.act2);
-    LSTAMP(10);
+    LSTAMPT(10);
     const size_t rc = gb * N + cur;
     if (lane < FP) {
       gt.cH[rc * FP + lane] = h1c;
@@ -1516,7 +1563,7 @@ __global__ __launch_bounds__(512) void k_learned_select8(
       const uint32_t f = (bad ? GCM_FLAG_NONFINITE : 0u) | (n_chk != (int64_t)cur ? GCM_FLAG_BAD_COUNT : 0u);
       if (f) atomicOr(flags, f);
     }
-    LSTAMP(11);
+    LSTAMPT(11);
   }
 }
 
@@ -2917,7 +2964,7 @@ extern "C" int gcm_learned_step_cached(const float* obs, float* nodes, float* ad
   const bool exact = N == gcm_learned::NP && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 == gcm_learned::FP;
   if (exact && cur_host >= 0 && cur_host < N && !(has_bias & GCM_STEP_FOUR_WAVES)) {   // eight waves per graph (round 6)
     gcm_learned::GnnTail gt8{params, act1, act2, has_bias, H1, H2, cache_h1, cache_agg1, cache_nodes, cache_u, mx, agg2, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(gcm_learned::k_learned_select8, dim3(B), dim3(512), 0, (hipStream_t)stream, obs, nodes, adj,
+    hipLaunchKernelGGL(gcm_learned::k_learned_select8, dim3(B), dim3(576), 0, (hipStream_t)stream, obs, nodes, adj,
                        count_in, count_out, cur_out, noise, noise_is_exp, params + Pg, eps0, eps1, cutoff, soft, adj_row,
                        flags, gt8, cur_host);
     return gcm_launch_status();

@@ -23,6 +23,7 @@ names = ["every load issued", "c0 / U[cur] / node row (waves 5 - 7; wave 0: noth
          "layer 1 / layer 2 on row cur", "stores"]
 lib = _hip.lib()
 acc, R = [0.0] * len(names), 5
+acc7 = [0.0] * 16     # every wave's arrival at barrier 1, relative to wave 0's first stamp
 for it in range(R + 1):
     with torch.no_grad():
         hidden = None
@@ -34,7 +35,12 @@ for it in range(R + 1):
     if it >= 1:
         for i in range(len(names)):
             acc[i] += (out[1 + i] - out[i]) / R
+        for i in range(16):
+            acc7[i] += (float(out[16 + i]) - float(out[0])) / R
 print("k_learned_select8, step 63 of a rollout, workgroup 0 / thread 0        shader clocks")
 for i, n in enumerate(names):
     print(f"  {i:2d} -> {i + 1:2d}  {n:56s} {acc[i]:9.1f}")
 print(f"  total {sum(acc):9.1f}")
+print("  first instruction, clocks relative to wave 0's first stamp (after its kernel arguments arrived), waves 0 - 7: "
+      + " ".join("%.0f" % v for v in acc7[8:]))
+print("  arrival at barrier 1, waves 0 - 7: " + " ".join("%.0f" % v for v in acc7[:8]))
