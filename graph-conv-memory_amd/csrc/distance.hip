@@ -715,7 +715,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         pa = fmaf(wr[4 * k4 + 3], a.w, pa); pb = fmaf(wt[4 * k4 + 3], xx.w, pb);
       }
       float p1 = pa + pb;
-      p1 = gcm_xor32_add(p1);
+      p1 += __shfl_xor(p1, 32);
       p1 += bias1;
       __builtin_amdgcn_wave_barrier();                        // (the next row overwrites svw)
       return hl < H1 ? gcm_act_sel(p1, act1_v) : 0.f;
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         pa = fmaf(w2r[4 * k4 + 2], a.z, pa);
         pa = fmaf(w2r[4 * k4 + 3], a.w, pa);
       }
-      p2 = gcm_xor32_add(pa) + bias2;
+      p2 = pa + __shfl_xor(pa, 32) + bias2;
     }
     const float v = gcm_act_sel(p2, act2_v);
     if (lane < H2) tl.saved[gb * H2 + lane] = v;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         pa = fmaf(wr[4 * k4 + 3], a.w, pa); pb = fmaf(wt[4 * k4 + 3], x.w, pb);
       }
       p1 = pa + pb;
-      p1 = gcm_xor32_add(p1);
+      p1 += __shfl_xor(p1, 32);
       p1 += bias1;
     }
     const float h1c = hl < H1 ? gcm_act_sel(p1, act1_v) : 0.f;   // (both halves hold h1c[lane & 31])
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         pa = fmaf(w2[4 * k4 + 2], a.z, pa);
         pa = fmaf(w2[4 * k4 + 3], a.w, pa);
       }
-      p2 = gcm_xor32_add(pa) + bias2;
+      p2 = pa + __shfl_xor(pa, 32) + bias2;
     }
     const float v = gcm_act_sel(p2, act2_v);
     DSTAMP(10);

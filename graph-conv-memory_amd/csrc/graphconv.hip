@@ -1133,8 +1133,8 @@ __global__ __launch_bounds__(256) void k_csr_bwd3(
   // ---- one slab per workgroup: { G^T agg [FO][FI] | G^T x [FO][FI] | colsum G [FO] }, the four waves
   // summed in fixed order.  acc[r] of dwr / dwo is entry (o = acc_row(r, lh), f = li).
   db4.x += __shfl_xor(db4.x, 8); db4.y += __shfl_xor(db4.y, 8); db4.z += __shfl_xor(db4.z, 8); db4.w += __shfl_xor(db4.w, 8);
-  db4.x = gcm_xor16_add(db4.x); db4.y = gcm_xor16_add(db4.y); db4.z = gcm_xor16_add(db4.z); db4.w = gcm_xor16_add(db4.w);
-  db4.x = gcm_xor32_add(db4.x); db4.y = gcm_xor32_add(db4.y); db4.z = gcm_xor32_add(db4.z); db4.w = gcm_xor32_add(db4.w);
+  db4.x += __shfl_xor(db4.x, 16); db4.y += __shfl_xor(db4.y, 16); db4.z += __shfl_xor(db4.z, 16); db4.w += __shfl_xor(db4.w, 16);
+  db4.x += __shfl_xor(db4.x, 32); db4.y += __shfl_xor(db4.y, 32); db4.z += __shfl_xor(db4.z, 32); db4.w += __shfl_xor(db4.w, 32);
   __syncthreads();                       // every wave is done with its tiles: LDS becomes the reduction buffer
   constexpr int SL = 2 * FO * FI + FO;
   float* red = smem + (size_t)wave * (SL + 32);

@@ -146,7 +146,7 @@ struct LiveGnn {
 #pragma unroll
           for (int i = 0; i < JN; ++i) s = fmaf(av[i], hv[i], s);
         }
-      if (PA == 2) s = gcm_xor32_add(s);
+      if (PA == 2) s += __shfl_xor(s, 32);
       const float hc = sAH[cur * AS + h];
       if (part == 0) {
         sVv[h] = s;              // v[0:HP)   = agg2
@@ -173,7 +173,7 @@ struct LiveGnn {
 #pragma unroll
         for (int k = 0; k < 16; ++k) a = fmaf(wv[k], xv[k], a);
       }
-      if (PB == 2) a = gcm_xor32_add(a);
+      if (PB == 2) a += __shfl_xor(a, 32);
       const float v = gcm_act_sel(a + bias2, act2_v);
       if (lane < H2) mxg[lane] = v;
       const bool any_bad = __any(lane < H2 && !isfinite(v));

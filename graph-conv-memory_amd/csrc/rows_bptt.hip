@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         mine[m_root2 + i * 32 + q] = a2t[r];
       }
     }
-    const float db1m = gcm_xor32_add(db1p);
+    const float db1m = db1p + __shfl_xor(db1p, 32);
     if (lane < 32) mine[m_b1 + lane] = db1m;
     if (lane < H2) mine[m_b2 + lane] = db2p;
     __syncthreads();
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
         mine[m_root2 + i * 32 + q] = a2t[r];
       }
     }
-    const float db1m = gcm_xor32_add(db1p), dc1m = gcm_xor32_add(dc1p);
+    const float db1m = db1p + __shfl_xor(db1p, 32), dc1m = dc1p + __shfl_xor(dc1p, 32);
     if (lane < 32) mine[m_b1 + lane] = db1m;
     if (lane < H2) mine[m_b2 + lane] = db2p;
     if (deg_term && lane < 32) mine[P0m + lane] = dc1m;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
     const int RS = R1 > R2 ? R1 : R2;
     float* mine = sSlabM + (size_t)wave * RS;
     float* slabm = slabs + (size_t)blockIdx.x * Pm;
-    const float db1m = gcm_xor32_add(db1p), dc1m = gcm_xor32_add(dc1p);
+    const float db1m = db1p + __shfl_xor(db1p, 32), dc1m = dc1p + __shfl_xor(dc1p, 32);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row of a 32x32 tile

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_skinny_wgrad(const float* __restrict__ 
       a[ot][s] = (row < M && o < O) ? v : 0.f;
       bsum[ot] += a[ot][s];
     }
-    bsum[ot] = gcm_xor32_add(bsum[ot]);   // both row parities
+    bsum[ot] += __shfl_xor(bsum[ot], 32);   // both row parities
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
