@@ -33,6 +33,7 @@
 //
 // Shapes: N <= 128, F <= 32, H1 <= 32, H2 <= 32 (BASELINE cfg5: 128 / 32 / 32 / 32).
 #include "fused_common.h"
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -2864,6 +2865,396 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
   col_out(c_b2, o_b2, 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass B2 at the exact shapes on the chain's U cache, in REGISTERS (round 6): k_learned_bptt_mlp walks every 32-row block
+// through eleven phases of LDS images (19 KB per wave: eight waves fill the CU's LDS, two per SIMD) at ~32 k cycles a
+// block.  Here a wave owns a 16-ROW tile in the layout of k_learned_select8: lane (m, g) holds row 16 k + m at the eight
+// features 16 ct + 4 g + i (ct < 2, i < 4) - the first LayerNorm's operands straight from the U cache, every product on
+// v_mfma_f32_16x16x4_f32 with THAT register as the B operand and a weight row from LDS as A, so that each product's
+// accumulators are again row m at the lane's own eight features (the transposed product, as in the forward).  Both
+// LayerNorms and both adjoints reduce in the lane plus two row / half swaps.  Only the weight-gradient products contract
+// over ROWS: their operands go through two 16 x 32 LDS tiles per wave (written as rows, read as columns).  4.6 KB of LDS a
+// wave, <= 168 registers: twelve waves per CU, three per SIMD.
+//   c0 = b0 + W0a x_cur comes from the same instruction (x_cur as every column of B: the accumulators hold c0 at the lane's
+//   features); dW0a = (column sums of gP0) x_cur^T takes the sum over the tile's four row groups before ONE instruction per
+//   16 x 16 tile; db1 / db0 are the same column sums.
+// Same slab layout and slab count as k_learned_bptt_mlp (one per workgroup, summed by gcm_sum_slabs_acc).
+// ---------------------------------------------------------------------------------------------
+constexpr int M16_WAVES = 12;
+constexpr int M16_TS = FP + 4;
+constexpr size_t lds_bptt_mlp16() { return sizeof(float) * (3 * FP * M16_TS + 8 * FP + M16_WAVES * 3 * 16 * M16_TS); }
+
+__global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, const float* __restrict__ g_logit,
+                                                                       const float* __restrict__ mlp, float eps0,
+                                                                       float eps1, float* __restrict__ slabs, int B) {
+  constexpr int N = NP, F = FP, TS = M16_TS;
+  static_assert(3 * 16 * M16_TS >= 32 * 32, "the epilogue's 32 x 32 tiles live in the waves' transposition tiles");
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Mlp M = unpack_mlp(mlp, F);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW1 = smem;                 // [o][f]
+  float* sW1T = sW1 + FP * TS;       // [f][o]
+  float* sW0a = sW1T + FP * TS;      // [o][f] = W0[o][f]
+  float* sVec = sW0a + FP * TS;      // b0 | b1 | g0 | be0 | g1 | be1 | w2
+  float* sTiles = sVec + 8 * FP;
+  float* sTa = sTiles + wave * (3 * 16 * TS);   // this wave's [16][TS] tiles: the gradient rows (gP1, then gP0) | H0 | X
+  float* sTb = sTa + 16 * TS;
+  float* sTc = sTb + 16 * TS;
+  for (int e = tid; e < FP * FP; e += 64 * M16_WAVES) {
+    const int o = e >> 5, f = e & 31;
+    const float w1 = M.w1[e];
+    sW1[o * TS + f] = w1;
+    sW1T[f * TS + o] = w1;
+    sW0a[o * TS + f] = M.w0[o * 2 * F + f];
+  }
+  if (tid < FP) {
+    sVec[tid] = M.b0[tid];
+    sVec[FP + tid] = M.b1[tid];
+    sVec[2 * FP + tid] = M.g0[tid];
+    sVec[3 * FP + tid] = M.be0[tid];
+    sVec[4 * FP + tid] = M.g1[tid];
+    sVec[5 * FP + tid] = M.be1[tid];
+    sVec[6 * FP + tid] = M.w2[tid];
+  }
+  // weight-gradient tiles: D[o = 16 ot + 4 g + r][f = 16 ft + m], summed over this wave's tiles
+  f32x4 aW1[2][2], aW0b[2][2], aW0a[2][2];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      aW1[ot][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+      aW0b[ot][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+      aW0a[ot][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  // vector gradients: at the lane's eight features (a partial sum over the rows m), or at column 16 ot + m (a partial
+  // sum over the row groups g) where the transposed tile gives them
+  // (dw2 and dgamma1 both come from c_s1[f] = sum over rows of g_logit xhat1[f]: dw2 = gamma1 c_s1 + beta1 sum(g_logit),
+  //  dgamma1 = w2 c_s1)
+  float c_s1[8], c_g0[8], c_be0[8], c_b1[2] = {0.f, 0.f}, c_b0[2] = {0.f, 0.f}, c_gl = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { c_s1[k] = 0.f; c_g0[k] = 0.f; c_be0[k] = 0.f; }
+  __syncthreads();
+
+  const long items = (long)a.n_steps * B;
+  const long units = items * (N / 16);   // tile-major: the always-live first tiles of all items come first
+#pragma unroll 1
+  for (long u = (long)blockIdx.x * M16_WAVES + wave; u < units; u += (long)gridDim.x * M16_WAVES) {
+    const int k = (int)(u / items);
+    const long item = u - (long)k * items;
+    const int s = (int)(item / B), b = (int)(item - (long)s * B), sg = a.s0 + s;
+    const size_t it = (size_t)sg * B + b;
+    const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * it]);
+    if (16 * k >= cur) continue;       // no candidate row in this tile (wave-uniform)
+    const int r = 16 * k + m;
+    const bool live = r < cur;
+    const size_t gb = (size_t)b * N;
+    // ---- loads: this row's U and x at the lane's features, x_cur both ways, the logit's gradient -----------------------
+    f32x4 u4[2], xc4[2];
+    {
+      f32x4 x4[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        xc4[ct] = *reinterpret_cast<const f32x4*>(a.c_nodes + (gb + cur) * F + 16 * ct + 4 * g);
+        u4[ct] = *reinterpret_cast<const f32x4*>(a.c_u + (gb + r) * F + 16 * ct + 4 * g);
+        x4[ct] = *reinterpret_cast<const f32x4*>(a.c_nodes + (gb + r) * F + 16 * ct + 4 * g);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {   // the X tile, for dW0b at the end (a cache row that was never written may hold anything)
+        f32x4 xv = x4[ct];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = live ? xv[i] : 0.f;
+        *reinterpret_cast<f32x4*>(sTc + m * TS + 16 * ct + 4 * g) = xv;
+      }
+    }
+    const float xcn0 = a.c_nodes[(gb + cur) * F + m], xcn1 = a.c_nodes[(gb + cur) * F + 16 + m];
+    float gl = g_logit[it * N + r];
+    gl = live ? gl : 0.f;
+    // ---- c0 at the lane's features: W0a (A) x x_cur (B, the same in every column) ------------------------------------
+    f32x4 p0[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) p0[ot] = *reinterpret_cast<const f32x4*>(sVec + 16 * ot + 4 * g);   // b0
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(sW0a + (16 * ot + m) * TS + 16 * ct + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p0[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], xc4[ct][i], p0[ot], 0, 0, 0);
+      }
+    // ---- P0 = U + c0, ReLU, LayerNorm 0 (rows behind the candidates: U is not written there - they enter as zeros) ----
+    float xh0[8], h0[8];
+    unsigned pos0 = 0;
+    float rstd0;
+    {
+      float sm = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v = (live ? u4[q >> 2][q & 3] : 0.f) + p0[q >> 2][q & 3];
+        pos0 |= (v > 0.f ? 1u : 0u) << q;
+        xh0[q] = v > 0.f ? v : 0.f;
+        sm += xh0[q];
+      }
+      sm = gcm_xor16_add(sm);
+      sm = gcm_xor32_add(sm);
+      const float mean = sm / (float)F;
+      float qv = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { xh0[q] -= mean; qv = fmaf(xh0[q], xh0[q], qv); }
+      qv = gcm_xor16_add(qv);
+      qv = gcm_xor32_add(qv);
+      rstd0 = rsqrtf(qv / (float)F + eps0);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sVec + 2 * FP + 16 * ct + 4 * g);
+        const f32x4 be0 = *reinterpret_cast<const f32x4*>(sVec + 3 * FP + 16 * ct + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xh0[4 * ct + i] *= rstd0;
+          h0[4 * ct + i] = fmaf(xh0[4 * ct + i], g0[i], be0[i]);
+        }
+        *reinterpret_cast<f32x4*>(sTb + m * TS + 16 * ct + 4 * g) = f32x4{h0[4 * ct], h0[4 * ct + 1], h0[4 * ct + 2], h0[4 * ct + 3]};
+      }
+    }
+    // ---- P1 = H0 W1^T + b1 (transposed: W1 rows as A), ReLU, LayerNorm 1's statistics -----------------------------------
+    float xh1[8];
+    unsigned pos1 = 0;
+    float rstd1;
+    {
+      f32x4 acc[2];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) acc[ot] = *reinterpret_cast<const f32x4*>(sVec + FP + 16 * ot + 4 * g);   // b1
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(sW1 + (16 * ot + m) * TS + 16 * ct + 4 * g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], h0[4 * ct + i], acc[ot], 0, 0, 0);
+        }
+      float sm = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v = acc[q >> 2][q & 3];
+        pos1 |= (v > 0.f ? 1u : 0u) << q;
+        xh1[q] = v > 0.f ? v : 0.f;
+        sm += xh1[q];
+      }
+      sm = gcm_xor16_add(sm);
+      sm = gcm_xor32_add(sm);
+      const float mean = sm / (float)F;
+      float qv = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { xh1[q] -= mean; qv = fmaf(xh1[q], xh1[q], qv); }
+      qv = gcm_xor16_add(qv);
+      qv = gcm_xor32_add(qv);
+      rstd1 = rsqrtf(qv / (float)F + eps1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xh1[q] *= rstd1;
+    }
+    // ---- dw2, dgamma1, db2 / dbeta1 (through the sum of g_logit); gP1: LayerNorm 1's adjoint of g_logit w2 gamma1 ----------
+    float gp1[8];
+    {
+      float gx[8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sVec + 6 * FP + 16 * ct + 4 * g);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(sVec + 4 * FP + 16 * ct + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = 4 * ct + i;
+          c_s1[q] = fmaf(gl, xh1[q], c_s1[q]);
+          gx[q] = gl * w2[i] * g1[i];
+          m1 += gx[q];
+          m2 = fmaf(gx[q], xh1[q], m2);
+        }
+      }
+      c_gl += gl;
+      m1 = gcm_xor16_add(m1); m1 = gcm_xor32_add(m1);
+      m2 = gcm_xor16_add(m2); m2 = gcm_xor32_add(m2);
+      m1 /= (float)F;
+      m2 /= (float)F;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gp1[q] = ((pos1 >> q) & 1u) ? rstd1 * (gx[q] - m1 - xh1[q] * m2) : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        *reinterpret_cast<f32x4*>(sTa + m * TS + 16 * ct + 4 * g) = f32x4{gp1[4 * ct], gp1[4 * ct + 1], gp1[4 * ct + 2], gp1[4 * ct + 3]};
+    }
+    // ---- gH0 = gP1 W1 (W1's columns as A); dgamma0, dbeta0; gP0: LayerNorm 0's adjoint of gH0 gamma0 ----------------------
+    float gp0[8];
+    {
+      f32x4 acc[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(sW1T + (16 * ft + m) * TS + 16 * ct + 4 * g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], gp1[4 * ct + i], acc[ft], 0, 0, 0);
+        }
+      // dW1 += gP1^T H0 now (the weight gradients contract over the tile's ROWS: rows written above, columns read), so that
+      // gP1 is dead before LayerNorm 0's adjoint
+      wsync();
+      {
+        float sa[2] = {0.f, 0.f};
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {   // instruction sI contracts rows 4 g + sI
+          const float a0 = sTa[(4 * g + sI) * TS + m], a1 = sTa[(4 * g + sI) * TS + 16 + m];
+          const float b0 = sTb[(4 * g + sI) * TS + m], b1 = sTb[(4 * g + sI) * TS + 16 + m];
+          sa[0] += a0;
+          sa[1] += a1;
+          aW1[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, aW1[0][0], 0, 0, 0);
+          aW1[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, aW1[0][1], 0, 0, 0);
+          aW1[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, aW1[1][0], 0, 0, 0);
+          aW1[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, aW1[1][1], 0, 0, 0);
+        }
+        c_b1[0] += sa[0];
+        c_b1[1] += sa[1];
+      }
+      float gx[8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sVec + 2 * FP + 16 * ct + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = 4 * ct + i;
+          const float gh = acc[ct][i];
+          c_g0[q] = fmaf(gh, xh0[q], c_g0[q]);
+          c_be0[q] += gh;
+          gx[q] = gh * g0[i];
+          m1 += gx[q];
+          m2 = fmaf(gx[q], xh0[q], m2);
+        }
+      }
+      m1 = gcm_xor16_add(m1); m1 = gcm_xor32_add(m1);
+      m2 = gcm_xor16_add(m2); m2 = gcm_xor32_add(m2);
+      m1 /= (float)F;
+      m2 /= (float)F;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gp0[q] = ((pos0 >> q) & 1u) ? rstd0 * (gx[q] - m1 - xh0[q] * m2) : 0.f;
+    }
+    // dW0b += gP0^T X;  dW0a += (column sums of gP0) x_cur^T
+    wsync();   // (dW1's reads of the gradient tile are done)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+      *reinterpret_cast<f32x4*>(sTa + m * TS + 16 * ct + 4 * g) = f32x4{gp0[4 * ct], gp0[4 * ct + 1], gp0[4 * ct + 2], gp0[4 * ct + 3]};
+    wsync();
+    {
+      float sa[2] = {0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) {
+        const float a0 = sTa[(4 * g + sI) * TS + m], a1 = sTa[(4 * g + sI) * TS + 16 + m];
+        const float b0 = sTc[(4 * g + sI) * TS + m], b1 = sTc[(4 * g + sI) * TS + 16 + m];
+        sa[0] += a0;
+        sa[1] += a1;
+        aW0b[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, aW0b[0][0], 0, 0, 0);
+        aW0b[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, aW0b[0][1], 0, 0, 0);
+        aW0b[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, aW0b[1][0], 0, 0, 0);
+        aW0b[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, aW0b[1][1], 0, 0, 0);
+      }
+      c_b0[0] += sa[0];
+      c_b0[1] += sa[1];
+      aW0a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0], xcn0, aW0a[0][0], 0, 0, 0);
+      aW0a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0], xcn1, aW0a[0][1], 0, 0, 0);
+      aW0a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1], xcn0, aW0a[1][0], 0, 0, 0);
+      aW0a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1], xcn1, aW0a[1][1], 0, 0, 0);
+    }
+    wsync();   // the tiles are rewritten by the wave's next unit
+  }
+
+  // ---- one slab per workgroup (packed edge-network layout), waves summed in fixed order ---------------------------------
+  const int Pm = 3 * F * F + 7 * F + 1;
+  float* slab = slabs + (size_t)blockIdx.x * Pm;
+  const int o_b0 = 2 * F * F, o_g0 = o_b0 + F, o_be0 = o_g0 + F, o_w1 = o_be0 + F, o_b1 = o_w1 + F * F;
+  const int o_g1 = o_b1 + F, o_be1 = o_g1 + F, o_w2 = o_be1 + F, o_b2 = o_w2 + F;
+  float* sR = sTiles;   // [M16_WAVES][3 * 16 * TS >= 1024]
+  constexpr int RS = 3 * 16 * M16_TS;
+  auto tile_out = [&](const f32x4 (&acc)[2][2], int row_stride, int col0) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sR[wave * RS + (16 * ot + 4 * g + i) * 32 + 16 * ft + m] = acc[ot][ft][i];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 64 * M16_WAVES) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < M16_WAVES; ++w) t += sR[w * RS + e];
+      slab[col0 + (e >> 5) * row_stride + (e & 31)] = t;
+    }
+    __syncthreads();
+  };
+  __syncthreads();
+  tile_out(aW0a, 2 * F, 0);
+  tile_out(aW0b, 2 * F, F);
+  tile_out(aW1, F, o_w1);
+  // vectors at the lane's features: the rows m of the tile summed (a DPP row), one value per (wave, feature)
+  auto feat_out = [&](const float (&v)[8], int off) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float t = row16_sum(v[q]);
+      if (m == 0) sR[wave * RS + 16 * (q >> 2) + 4 * g + (q & 3)] = t;
+    }
+    __syncthreads();
+    if (tid < FP) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < M16_WAVES; ++w) t += sR[w * RS + tid];
+      slab[off + tid] = t;
+    }
+    __syncthreads();
+  };
+  // vectors at column 16 ot + m: the row groups g summed
+  auto col_out = [&](const float (&v)[2], int off) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      float t = gcm_xor16_add(v[ot]);
+      t = gcm_xor32_add(t);
+      if (g == 0) sR[wave * RS + 16 * ot + m] = t;
+    }
+    __syncthreads();
+    if (tid < FP) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < M16_WAVES; ++w) t += sR[w * RS + tid];
+      slab[off + tid] = t;
+    }
+    __syncthreads();
+  };
+  col_out(c_b0, o_b0);
+  feat_out(c_g0, o_g0);
+  feat_out(c_be0, o_be0);
+  col_out(c_b1, o_b1);
+  {   // dw2 = gamma1 S1 + beta1 sum(g_logit), dgamma1 = w2 S1, dbeta1 = w2 sum(g_logit), db2 = sum(g_logit)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float t = row16_sum(c_s1[q]);
+      if (m == 0) sR[wave * RS + 16 * (q >> 2) + 4 * g + (q & 3)] = t;
+    }
+    const float t = wave_sum(c_gl);
+    if (lane == 0) sR[wave * RS + FP] = t;
+    __syncthreads();
+    if (tid <= FP) {
+      float sgl = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < M16_WAVES; ++w) {
+        sgl += sR[w * RS + FP];
+        s1 += sR[w * RS + (tid < FP ? tid : 0)];
+      }
+      if (tid < FP) {
+        slab[o_w2 + tid] = fmaf(sVec[4 * FP + tid], s1, sVec[5 * FP + tid] * sgl);
+        slab[o_g1 + tid] = sVec[6 * FP + tid] * s1;
+        slab[o_be1 + tid] = sVec[6 * FP + tid] * sgl;
+      } else {
+        slab[o_b2] = sgl;
+      }
+    }
+  }
+}
+
 constexpr size_t lds_select() { return sizeof(float) * (3 * NP * FS + 2 * FP * FS + FP * GS + 7 * FP + NP); }
 constexpr size_t lds_select_tail() { return lds_select() + sizeof(float) * (NP * FS + 4 * FP * GS); }
 constexpr size_t lds_select_steady() { return lds_select_tail() + sizeof(uint32_t) * (NP * 4 + 4); }
@@ -3252,6 +3643,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
   constexpr size_t lds = gcm_learned::lds_bptt_mlp();
   static_assert(lds <= 160 * 1024, "one 8-wave workgroup per CU");
   gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp, lds);
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp16, gcm_learned::lds_bptt_mlp16());
   int total_b = 0;
   for (int pass = 0; pass < 2; ++pass)
     for (int c = 0; c < chunks; ++c) {
@@ -3273,9 +3665,16 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       } else {
         const long units8 = ((long)ns * B + gcm_learned::MLP_WAVES - 1) / gcm_learned::MLP_WAVES;
         const int grid = (int)(units8 < 256 ? units8 : 256);
-        hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp, dim3(grid), dim3(64 * gcm_learned::MLP_WAVES), lds,
-                           (hipStream_t)stream, a, (const float*)g_logit, params + Pg, eps0, eps1,
-                           slabs_b + (size_t)total_b * Pm, B, N, F);
+        // (GCM_BPTT_MLP_BLOCKS=1 in the environment: the 32-row-block kernel at every shape - the A/B of tools/ab_cfg5.sh)
+        static const bool blocks_only = getenv("GCM_BPTT_MLP_BLOCKS") && atoi(getenv("GCM_BPTT_MLP_BLOCKS")) != 0;
+        if (a.c_u && a.c_nodes && F == gcm_learned::FP && N == gcm_learned::NP && !blocks_only)
+          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp16, dim3(grid), dim3(64 * gcm_learned::M16_WAVES),
+                             gcm_learned::lds_bptt_mlp16(), (hipStream_t)stream, a, (const float*)g_logit, params + Pg,
+                             eps0, eps1, slabs_b + (size_t)total_b * Pm, B);
+        else
+          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp, dim3(grid), dim3(64 * gcm_learned::MLP_WAVES), lds,
+                             (hipStream_t)stream, a, (const float*)g_logit, params + Pg, eps0, eps1,
+                             slabs_b + (size_t)total_b * Pm, B, N, F);
         total_b += grid;
       }
       const int rc = gcm_launch_status();
