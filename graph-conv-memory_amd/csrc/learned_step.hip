@@ -2936,18 +2936,37 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
   for (int k = 0; k < 8; ++k) { c_s1[k] = 0.f; c_g0[k] = 0.f; c_be0[k] = 0.f; }
   __syncthreads();
 
-  const long items = (long)a.n_steps * B;
-  const long units = items * (N / 16);   // tile-major: the always-live first tiles of all items come first
+  // The units: (tile k, step, graph) with a candidate row in the tile.  At the cached steps of a chain every graph holds
+  // the same number of nodes, one more each step (gcm_learned_step_cached: a graph whose count differs is left untouched
+  // and flagged): cur = cur_first + s at the chunk's step s, so tile k is live at the steps cur_first + s > 16 k - an
+  // analytic list, tile-major, no unit is fetched to be skipped (eight tiles x T x B units walked, five of eight of them
+  // empty at T = 64, each behind a dependent header read: 12 us of the pass).  `live` below still comes from each item's
+  // recorded header.
+  const int cur_first = __builtin_amdgcn_readfirstlane(a.hdr[2 * (size_t)a.s0 * B]);
+  long pre[N / 16 + 1];
+  int first[N / 16];
+  pre[0] = 0;
+#pragma unroll
+  for (int k = 0; k < N / 16; ++k) {
+    const int fs = 16 * k + 1 - cur_first > 0 ? 16 * k + 1 - cur_first : 0;
+    first[k] = fs;
+    pre[k + 1] = pre[k] + (fs < a.n_steps ? (long)(a.n_steps - fs) * B : 0);
+  }
+  const long units = pre[N / 16];
 #pragma unroll 1
   for (long u = (long)blockIdx.x * M16_WAVES + wave; u < units; u += (long)gridDim.x * M16_WAVES) {
-    const int k = (int)(u / items);
-    const long item = u - (long)k * items;
-    const int s = (int)(item / B), b = (int)(item - (long)s * B), sg = a.s0 + s;
+    int k = 0, fs = first[0];
+    long base = 0;
+#pragma unroll
+    for (int q = 1; q < N / 16; ++q)
+      if (u >= pre[q]) { k = q; fs = first[q]; base = pre[q]; }
+    const long item = u - base;
+    const int s = fs + (int)(item / B), b = (int)(item % B), sg = a.s0 + s;
     const size_t it = (size_t)sg * B + b;
-    const int cur = __builtin_amdgcn_readfirstlane(a.hdr[2 * it]);
-    if (16 * k >= cur) continue;       // no candidate row in this tile (wave-uniform)
+    const int cur_rec = a.hdr[2 * it];   // (the recorded header: the rows' masks; the addresses below do not wait for it)
+    const int cur = cur_first + s;
     const int r = 16 * k + m;
-    const bool live = r < cur;
+    const bool live = r < cur_rec;
     const size_t gb = (size_t)b * N;
     // ---- loads: this row's U and x at the lane's features, x_cur both ways, the logit's gradient -----------------------
     f32x4 u4[2], xc4[2];
