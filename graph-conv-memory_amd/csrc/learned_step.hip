@@ -2882,8 +2882,12 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void k_learned_bptt_mlp(BpttB a, co
 // ---------------------------------------------------------------------------------------------
 constexpr int M16_WAVES = 12;
 constexpr int M16_TS = FP + 4;
-constexpr size_t lds_bptt_mlp16() { return sizeof(float) * (3 * FP * M16_TS + 8 * FP + M16_WAVES * 3 * 16 * M16_TS); }
+constexpr size_t lds_bptt_mlp16() { return sizeof(float) * (4 * FP * M16_TS + 8 * FP + M16_WAVES * 3 * 16 * M16_TS); }
 
+// CACHED: the steps of the chunk are cached steps (node rows and U from the chain's caches, every graph of a step at the same
+// count); else each step's own record holds its node matrix, U is one more product (W0b rows as A, the row's x as B) and a
+// graph's count is whatever its header says (tiles without a candidate row are skipped behind the header read).
+template <bool CACHED>
 __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, const float* __restrict__ g_logit,
                                                                        const float* __restrict__ mlp, float eps0,
                                                                        float eps1, float* __restrict__ slabs, int B) {
@@ -2896,7 +2900,8 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
   float* sW1 = smem;                 // [o][f]
   float* sW1T = sW1 + FP * TS;       // [f][o]
   float* sW0a = sW1T + FP * TS;      // [o][f] = W0[o][f]
-  float* sVec = sW0a + FP * TS;      // b0 | b1 | g0 | be0 | g1 | be1 | w2
+  float* sW0b = sW0a + FP * TS;      // [o][f] = W0[o][F + f]  (!CACHED)
+  float* sVec = sW0b + FP * TS;      // b0 | b1 | g0 | be0 | g1 | be1 | w2
   float* sTiles = sVec + 8 * FP;
   float* sTa = sTiles + wave * (3 * 16 * TS);   // this wave's [16][TS] tiles: the gradient rows (gP1, then gP0) | H0 | X
   float* sTb = sTa + 16 * TS;
@@ -2907,6 +2912,7 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
     sW1[o * TS + f] = w1;
     sW1T[f * TS + o] = w1;
     sW0a[o * TS + f] = M.w0[o * 2 * F + f];
+    if (!CACHED) sW0b[o * TS + f] = M.w0[o * 2 * F + F + f];
   }
   if (tid < FP) {
     sVec[tid] = M.b0[tid];
@@ -2942,13 +2948,13 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
   // analytic list, tile-major, no unit is fetched to be skipped (eight tiles x T x B units walked, five of eight of them
   // empty at T = 64, each behind a dependent header read: 12 us of the pass).  `live` below still comes from each item's
   // recorded header.
-  const int cur_first = __builtin_amdgcn_readfirstlane(a.hdr[2 * (size_t)a.s0 * B]);
+  const int cur_first = CACHED ? __builtin_amdgcn_readfirstlane(a.hdr[2 * (size_t)a.s0 * B]) : N;
   long pre[N / 16 + 1];
   int first[N / 16];
   pre[0] = 0;
 #pragma unroll
   for (int k = 0; k < N / 16; ++k) {
-    const int fs = 16 * k + 1 - cur_first > 0 ? 16 * k + 1 - cur_first : 0;
+    const int fs = 16 * k + 1 - cur_first > 0 ? 16 * k + 1 - cur_first : 0;   // (!CACHED: every tile at every step)
     first[k] = fs;
     pre[k + 1] = pre[k] + (fs < a.n_steps ? (long)(a.n_steps - fs) * B : 0);
   }
@@ -2963,8 +2969,14 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
     const long item = u - base;
     const int s = fs + (int)(item / B), b = (int)(item % B), sg = a.s0 + s;
     const size_t it = (size_t)sg * B + b;
-    const int cur_rec = a.hdr[2 * it];   // (the recorded header: the rows' masks; the addresses below do not wait for it)
-    const int cur = cur_first + s;
+    int cur_rec = a.hdr[2 * it];   // (the recorded header: the rows' masks; CACHED: the addresses below do not wait for it)
+    int cur = cur_first + s;
+    if (!CACHED) {
+      cur_rec = __builtin_amdgcn_readfirstlane(cur_rec);
+      cur = cur_rec;
+      if (16 * k >= cur) continue;   // no candidate row in this tile (wave-uniform)
+    }
+    const float* xg = CACHED ? a.c_nodes : a.tab.saved[s];
     const int r = 16 * k + m;
     const bool live = r < cur_rec;
     const size_t gb = (size_t)b * N;
@@ -2974,9 +2986,22 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
       f32x4 x4[2];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        xc4[ct] = *reinterpret_cast<const f32x4*>(a.c_nodes + (gb + cur) * F + 16 * ct + 4 * g);
-        u4[ct] = *reinterpret_cast<const f32x4*>(a.c_u + (gb + r) * F + 16 * ct + 4 * g);
-        x4[ct] = *reinterpret_cast<const f32x4*>(a.c_nodes + (gb + r) * F + 16 * ct + 4 * g);
+        xc4[ct] = *reinterpret_cast<const f32x4*>(xg + (gb + cur) * F + 16 * ct + 4 * g);
+        if (CACHED) u4[ct] = *reinterpret_cast<const f32x4*>(a.c_u + (gb + r) * F + 16 * ct + 4 * g);
+        x4[ct] = *reinterpret_cast<const f32x4*>(xg + (gb + r) * F + 16 * ct + 4 * g);
+      }
+      if (!CACHED) {   // U = X W0b^T: W0b rows as A, this row's x (zeros behind the candidates) as B
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) u4[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int ot = 0; ot < 2; ++ot) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(sW0b + (16 * ot + m) * TS + 16 * ct + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              u4[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], live ? x4[ct][i] : 0.f, u4[ot], 0, 0, 0);
+          }
       }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {   // the X tile, for dW0b at the end (a cache row that was never written may hold anything)
@@ -2986,7 +3011,7 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
         *reinterpret_cast<f32x4*>(sTc + m * TS + 16 * ct + 4 * g) = xv;
       }
     }
-    const float xcn0 = a.c_nodes[(gb + cur) * F + m], xcn1 = a.c_nodes[(gb + cur) * F + 16 + m];
+    const float xcn0 = xg[(gb + cur) * F + m], xcn1 = xg[(gb + cur) * F + 16 + m];
     float gl = g_logit[it * N + r];
     gl = live ? gl : 0.f;
     // ---- c0 at the lane's features: W0a (A) x x_cur (B, the same in every column) ------------------------------------
@@ -3662,7 +3687,8 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
   constexpr size_t lds = gcm_learned::lds_bptt_mlp();
   static_assert(lds <= 160 * 1024, "one 8-wave workgroup per CU");
   gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp, lds);
-  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp16, gcm_learned::lds_bptt_mlp16());
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp16<true>, gcm_learned::lds_bptt_mlp16());
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp16<false>, gcm_learned::lds_bptt_mlp16());
   int total_b = 0;
   for (int pass = 0; pass < 2; ++pass)
     for (int c = 0; c < chunks; ++c) {
@@ -3687,7 +3713,11 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
         // (GCM_BPTT_MLP_BLOCKS=1 in the environment: the 32-row-block kernel at every shape - the A/B of tools/ab_cfg5.sh)
         static const bool blocks_only = getenv("GCM_BPTT_MLP_BLOCKS") && atoi(getenv("GCM_BPTT_MLP_BLOCKS")) != 0;
         if (a.c_u && a.c_nodes && F == gcm_learned::FP && N == gcm_learned::NP && !blocks_only)
-          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp16, dim3(grid), dim3(64 * gcm_learned::M16_WAVES),
+          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp16<true>, dim3(grid), dim3(64 * gcm_learned::M16_WAVES),
+                             gcm_learned::lds_bptt_mlp16(), (hipStream_t)stream, a, (const float*)g_logit, params + Pg,
+                             eps0, eps1, slabs_b + (size_t)total_b * Pm, B);
+        else if (!cached && F == gcm_learned::FP && N == gcm_learned::NP && !blocks_only)
+          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp16<false>, dim3(grid), dim3(64 * gcm_learned::M16_WAVES),
                              gcm_learned::lds_bptt_mlp16(), (hipStream_t)stream, a, (const float*)g_logit, params + Pg,
                              eps0, eps1, slabs_b + (size_t)total_b * Pm, B);
         else
