@@ -23,6 +23,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import statistics
 import subprocess
 import sys
@@ -1199,17 +1200,28 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         live_blocks = sum((min(t, N - 1) + 31) // 32 for t in range(T))
         n_prod = 4 if exact_u else 5   # P1, dW1, gH0, dW0b (+ P0 without the U cache); c0 / dW0a are vector work
         bpb_exec = B * live_blocks * (n_prod * (2 * 32 * Fe * Fe))
+        b2_note = ("pass B2: the edge network recomputed and differentiated per 32-row block that holds a candidate row "
+                   "(one block per wave; 32 x F x F products on the fp32 MFMA: P1, dW1, gH0, dW0b - and P0 where the "
+                   "chain keeps no U cache; c0 and dW0a are vector work since round 5 - LayerNorm passes not "
+                   "counted); one persistent launch per chain")
+        kk_b2 = find_kernel(prof, "k_learned_bptt_mlp")
+        if kk_b2 and "mlp16" in kk_b2[0]:
+            # the register-resident form (round 6): per 16-ROW tile with a candidate row, v_mfma_f32_16x16x4_f32 - P1, gH0,
+            # dW1, dW0b and c0 (W0a x x_cur in every column: what it executes) as 16 x F x F products, dW0a as four
+            # instructions on the tile's column sums
+            live_tiles = sum((min(t, N - 1) + 15) // 16 for t in range(T))
+            bpb_exec = B * live_tiles * (5 * (2 * 16 * Fe * Fe) + 4 * (2 * 16 * 16 * 4))
+            b2_note = ("pass B2 in registers (round 6): the edge network recomputed and differentiated per 16-row TILE that "
+                       "holds a candidate row, one tile per wave in the forward's lane layout, twelve waves per CU; flops: "
+                       "the 16 x F x F products it executes on v_mfma_f32_16x16x4_f32 (c0, P1, gH0, dW1, dW0b) + dW0a's "
+                       "four instructions - LayerNorm passes and adjoints (VALU) not counted; one persistent launch per chain")
         kinds = [("k_learned_select", ("k_learned_select<", "k_learned_select8"), sel_exec, sel_ref,
                   "selection + GNN tail (cached step); flops: the N x F x F products it executes (one with the U "
                   "cache of the exact shapes, else two), the W0b / W0a x[cur] and F -> 1 "
                   "layers, four matrix-vector products of the GNN tail; LayerNorm / softmax VALU work not counted; "
                   "flops_reference_formulation = 2 N (3F^2 + F) per graph (the reference's 2F-wide first layer on "
                   "every candidate pair)"),
-                 ("k_learned_bptt_mlp", ("k_learned_bptt_mlp",), bpb_exec, None,
-                  "pass B2: the edge network recomputed and differentiated per 32-row block that holds a candidate row "
-                  "(one block per wave; 32 x F x F products on the fp32 MFMA: P1, dW1, gH0, dW0b - and P0 where the "
-                  "chain keeps no U cache; c0 and dW0a are vector work since round 5 - LayerNorm passes not "
-                  "counted); one persistent launch per chain"),
+                 ("k_learned_bptt_mlp", ("k_learned_bptt_mlp",), bpb_exec, None, b2_note),
                  ("k_learned_bptt_sel", ("k_learned_bptt_sel",), None, None,
                   "pass B1: per graph-step the gradient collected over the later steps that hold the node, selection "
                   "and softmax adjoint -> g_logit [T,B,N]"),
@@ -1229,7 +1241,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                             "frac_of_fp32_mfma_peak": fl_exec / sec / 1e12 / PEAK_F32_MFMA_TFLOPS})
             if fl_ref:
                 ent["flops_reference_formulation"] = fl_ref
-            hv = hbm_view(traffic.get(tkey), sec)
+            short = re.search(r"\b(k_[A-Za-z0-9_]+)", kk[0])      # (tools/pmc_summarise.py keys by the kernel's own name)
+            hv = hbm_view(traffic.get(short.group(1) if short else tkey, traffic.get(tkey)), sec)
             if hv:
                 ent["hbm"] = hv
             rows.append(ent)
