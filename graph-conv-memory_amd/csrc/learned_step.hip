@@ -1185,27 +1185,37 @@ __global__ __launch_bounds__(256) void k_learned_select(
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_learned_select<2, 1, true> re-cut for EIGHT waves per graph (round 6): the cached step of a chain from empty graphs on a
-// donated state at the exact shapes N = 128, F = H1 = H2 = 32, the host's cur (cur_host >= 0).
+// k_learned_select<2, 1, true> re-cut for EIGHT tile waves + a tail wave per graph (round 6): the cached step of a chain
+// from empty graphs on a donated state at the exact shapes N = 128, F = H1 = H2 = 32, the host's cur (cur_host >= 0).
 //
 // Why: the four-wave kernel is one wave per SIMD walking nine phases through ~100 KB of LDS images (node rows and h1 rows
 // staged only so that the tail can gather a handful of them, the edge network's two 32-column images written and read
 // back between every pair of phases, five workgroup barriers) - a wave alone on its SIMD issues a dependent instruction
 // about every eight cycles (§3.12 of DESIGN.md), so its 5.2 k-cycle edge network and 4 k-cycle softmax + tail are mostly
-// issue bubbles.  Here:
+// issue bubbles.  Here (7.0 -> 4.9 us per step in situ, cfg5 21.6 -> 26 M belief states/s from this kernel alone):
 //   * the edge network lives in REGISTERS, 16 candidate rows per wave, two waves per SIMD: lane (m, g) holds features
 //     [8 g, 8 g + 8) of row 16 w + m - its piece of U[j] = W0b x_j straight from the chain's cache (two 16-byte loads),
-//     + c0, ReLU, LayerNorm (row statistics: two cross-group shuffles), and those eight values ARE the A operand of
-//     v_mfma_f32_16x16x4_f32 (k index = g: instruction s pairs H0[m][8 g + s] with W1[col][8 g + s], the B operand
-//     straight from global memory); the product's accumulators hold rows 4 g + (0 .. 3) at columns m and 16 + m, so the
-//     second LayerNorm's row statistics and the F -> 1 layer are 16-lane DPP reductions - no LDS image, no barrier between
-//     the phases;
-//   * nothing is staged for the tail: the selected rows (at most a handful: entries above 1 / (1 + num_edge_samples)) are
-//     gathered from the node matrix and the h1 cache behind the selection, the GNN's weight rows sit in wave 0's
-//     registers from the start;
-//   * c0 = b0 + W0a x_cur, U[cur] = W0b x_cur and the state's stores run on the waves whose rows are not candidates yet.
+//     + c0, ReLU, LayerNorm (row statistics: eight values in the lane, then v_permlane16_swap / v_permlane32_swap - VALU
+//     instructions where `__shfl_xor` is an LDS round trip), and those eight values ARE an operand of
+//     v_mfma_f32_16x16x4_f32 (k index = g: instruction s pairs H0[m][8 g + s] with W1[col][8 g + s]).  W1's rows are the
+//     A operand and H0 the B operand, so the accumulators hold the TRANSPOSED product: row m at columns 16 ct + 4 g + i -
+//     eight columns of ONE row per lane again, and the second LayerNorm and the F -> 1 layer reduce exactly like the first
+//     (the other way round a lane held four rows at two columns: twelve 16-lane DPP reductions, 1.1 k cycles against 0.7 k);
+//   * what barrier 1 waits for is one far-memory round trip and nothing else: c0 = b0 + W0a x_cur and U[cur] = W0b x_cur
+//     on ONE wave (lower / upper half), the observation through the SCALAR path (two s_load_dwordx16: as vector loads it
+//     was four more 1 KB requests in front of the products); W1 and the six vectors come through LDS once per graph (waves
+//     5 / 6; as eight waves' own loads they were a third of the bytes the CU's one address path had to process first);
+//     every kernel argument is in scalar registers before the first load (one s_load batch: left alone the compiler loads
+//     each pointer in the block that first uses it - six dependent kernarg round trips);
+//   * a NINTH wave owns everything behind barrier 2 - gumbel-softmax (the draws transformed while the tiles work),
+//     threshold, adjacency row, the GNN on row cur: its sixteen 1 KB weight-row loads are issued behind barrier 1, where
+//     they no longer sit in the address path ahead of the loads that barrier waits for (in-kernel stamps: barrier 1 released
+//     at 4.4 k cycles with them in front, 3.0 k behind), and the selected rows (at most a handful: entries above
+//     1 / (1 + num_edge_samples)) are gathered from LDS images of the node and h1 rows that the tile waves fill from the
+//     rows they hold anyway (from global memory the gather was a 2 k-cycle round trip on the critical path).
 // Same record, caches and state as k_learned_select<2, 1, true> (gcm_learned_bptt_cached reads them unchanged); the
 // sums of a row are associated differently (eight per lane group), so logits agree to rounding, not bit for bit.
+// GCM_STEP_FOUR_WAVES in has_bias selects the four-wave kernel (the A/B: tools/ab_cfg5.sh).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, in every lane of it
   v += GCM_DPP_F(v, 0xB1, 0xF, 0.f);    // quad_perm [1,0,3,2]
@@ -1232,9 +1242,9 @@ __global__ __launch_bounds__(576) void k_learned_select8(
   __shared__ __attribute__((aligned(16))) float sU8[4 * FP];
   __shared__ int sIdx8[NP];
   // the candidate rows' x and h1 for the tail's gather (a handful of them, known only behind the softmax: fetched from
-  // global memory there the gather was a 2 k-cycle round trip on wave 0's critical path; every wave brings its 16 rows
+  // global memory there the gather was a 2 k-cycle round trip on the tail wave's critical path; every wave brings its 16 rows
   // along with its other loads instead)
-  // W1 and the edge network's six vectors, once per graph (waves 6 / 7 bring them along with c0 / U[cur]): as eight
+  // W1 and the edge network's six vectors, once per graph (waves 6 / 5 bring them): as eight
   // waves' own global loads they were a third of the bytes the CU's address path had to process before anything ran
   constexpr int WS8 = FP + 4;
   __shared__ __attribute__((aligned(16))) float sW18[FP * WS8];
@@ -1264,17 +1274,13 @@ __global__ __launch_bounds__(576) void k_learned_select8(
   if (tile_on) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) u4[q] = *reinterpret_cast<const f32x4*>(gt.cU + (gb * N + r) * FP + 8 * g + 4 * q);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      xg4[q] = *reinterpret_cast<const f32x4*>(nodes + (gb * N + r) * FP + 8 * g + 4 * q);
-      hg4[q] = *reinterpret_cast<const f32x4*>(gt.cH + (gb * N + r) * FP + 8 * g + 4 * q);
-    }
   }
   const float b2e = M.b2[0];
-  // wave 7: c0 = W0a x_cur + b0 (lower half) and U[cur] = W0b x_cur (upper half), output li per lane: its weight row as
-  // eight 16-byte loads, the observation through the SCALAR path (one row for the whole wave; as vector loads it was
-  // four more 1 KB requests in front of the products barrier 1 waits for - and the observation comes from far memory)
-  f32x4 wq[8];
+  // wave 7: c0 = W0a x_cur + b0 in front of barrier 1 - lane (o, half) takes sixteen k of row o -, U[cur] = W0b x_cur behind
+  // it (nothing in this step reads it: its weight rows stay out of the burst that c0's operands travel in).  The
+  // observation comes through the SCALAR path (one row for the whole wave; as vector loads it was four more 1 KB requests
+  // in front of the products - and the observation comes from far memory)
+  f32x4 wq[4];
   typedef float f32x16s __attribute__((ext_vector_type(16)));
   f32x16s xsa, xsb;   // (s_load_dwordx16 x 2 by hand: the compiler keeps a uniform load behind a branch on the vector path)
   {   // (every wave: a scalar value defined under a branch becomes a vector register)
@@ -1283,9 +1289,9 @@ __global__ __launch_bounds__(576) void k_learned_select8(
   }
   float b0o = 0.f;
   if (wave == 7) {
-    const float* wrow = M.w0 + li * 2 * FP + (lh ? FP : 0);   // w0 [F][2F]: W0a | W0b
+    const float* wrow = M.w0 + li * 2 * FP + 16 * lh;   // w0 [F][2F]: W0a | W0b
 #pragma unroll
-    for (int q = 0; q < 8; ++q) wq[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+    for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
     b0o = M.b0[li];
   }
   f32x4 stg[4];   // wave 6: W1 (row lane >> 1, sixteen floats);  wave 5: the six vectors (lanes 0 - 47, four floats each)
@@ -1317,15 +1323,23 @@ __global__ __launch_bounds__(576) void k_learned_select8(
 
   // ---- c0, U[cur]; the observation into the state and the node cache (wave 5) ---------------------------------------
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xsa), "+s"(xsb));   // (the barrier below waits for the same row through c0)
+  // this half's sixteen products with the observation in scalar registers (both halves' chains, one select), the other
+  // half's sum added
+  auto half_dot_s = [&](const f32x4 (&w)[4]) {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pa = fmaf(w[q][e], xsa[4 * q + e], pa);
+        pb = fmaf(w[q][e], xsb[4 * q + e], pb);
+      }
+    const float p = lh ? pb : pa;
+    return gcm_xor32_add(p);
+  };
   if (wave == 7) {
-    float p = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) p = fmaf(wq[q][e], q < 4 ? xsa[4 * q + e] : xsb[4 * q - 16 + e], p);
-    }
+    const float p = half_dot_s(wq);
     if (lh == 0) sC0[li] = p + b0o;
-    else gt.cU[(gb * N + cur) * FP + li] = p;
   }
   if (wave == 6) {
 #pragma unroll
@@ -1363,6 +1377,13 @@ __global__ __launch_bounds__(576) void k_learned_select8(
 
   // ---- the edge network on this wave's 16 rows, in registers (learned.py:38-51) -----------------------------------
   if (tile_on) {
+    // this wave's rows of the tail's gather images, requested now: in front of barrier 1 they were a third of the bytes
+    // of the burst (256 CUs at once) that c0's operands travel in; they are wanted at the end of this block
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      xg4[q] = *reinterpret_cast<const f32x4*>(nodes + (gb * N + r) * FP + 8 * g + 4 * q);
+      hg4[q] = *reinterpret_cast<const f32x4*>(gt.cH + (gb * N + r) * FP + 8 * g + 4 * q);
+    }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1403,11 +1424,6 @@ __global__ __launch_bounds__(576) void k_learned_select8(
       const float rstd = rsqrtf(qv / (float)FP + eps0);
 #pragma unroll
       for (int k = 0; k < 8; ++k) a[k] = fmaf((a[k] - mean) * rstd, g0v[k], be0v[k]);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {   // this wave's rows of the tail's gather images
-      *reinterpret_cast<f32x4*>(sX8 + r * XS8 + 8 * g + 4 * q) = xg4[q];
-      *reinterpret_cast<f32x4*>(sH8 + r * XS8 + 8 * g + 4 * q) = hg4[q];
     }
     LSTAMP(4);
     f32x4 acc[2];
@@ -1450,6 +1466,19 @@ __global__ __launch_bounds__(576) void k_learned_select8(
       lgp = gcm_xor32_add(lgp);
       if (g == 0) sLogit8[16 * wave + m] = lgp + b2e;
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // this wave's rows of the tail's gather images
+      *reinterpret_cast<f32x4*>(sX8 + r * XS8 + 8 * g + 4 * q) = xg4[q];
+      *reinterpret_cast<f32x4*>(sH8 + r * XS8 + 8 * g + 4 * q) = hg4[q];
+    }
+  }
+  if (wave == 7) {   // U[cur] = W0b x_cur into the chain's cache (later steps' candidates)
+    const float* wrow = M.w0 + li * 2 * FP + FP + 16 * lh;
+    f32x4 wu[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wu[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+    const float p = half_dot_s(wu);
+    if (lh == 0) gt.cU[(gb * N + cur) * FP + li] = p;
   }
   LSTAMP(6);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the logits

@@ -526,8 +526,9 @@ int gcm_dense_step_bwd_slabs(const float* g_mx, const float* g_nodes_out, const 
  * (DenseEdge: every row <= cur) - the pass then fetches sixteen rows ahead instead of two (F = H1 = 32, H2 <= 32, no
  * folded terms; ignored elsewhere). */
 #define GCM_BPTT_MANY_ROWS 128
-/* gcm_dense_rows_step_colcache[_functional] only: the four-wave kernel where the eight-wave form exists (F = H1 = 32) -
- * the A/B of tests and tools; a per-call argument, the library keeps no switch */
+/* gcm_dense_rows_step_colcache[_functional] and gcm_learned_step_cached only: the four-wave kernel where the eight-wave
+ * form exists (column-write step: F = H1 = 32; LearnedEdge: N = 128, F = H1 = H2 = 32, cur_host >= 0) - the A/B of tests and
+ * tools; a per-call argument, the library keeps no switch */
 #define GCM_STEP_FOUR_WAVES 256
 /* gcm_dense_rows_step_cached[_ws] only: the one-wave kernel where the two-wave form exists (F = H1 = 32, H2 <= 32,
  * cur_host >= 0, GCM_STEP_IMG_V4: a second wave does the state's entries and the record's live list) - A/B */
@@ -1030,11 +1031,15 @@ int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t st
  * cache_u [B,N,F] (a fourth per-chain cache, any contents at the chain's head): the edge network's first-layer
  * product of every stored row, U[j] = W0[:, F:] x_j - x_j never changes once stored, so at the exact shapes N = 128,
  * F = H1 = H2 = 32 a step stages U instead of multiplying the node image by W0b again, adds W0a x_cur + b0 on the way
- * into the LayerNorm and writes U[cur]; other shapes leave it untouched.
+ * into the LayerNorm and writes U[cur]; other shapes leave it untouched.  At those shapes with cur_host >= 0 the step
+ * runs as eight tile waves + a tail wave per graph (k_learned_select8: the edge network in registers on 16-row tiles; same
+ * record, caches and state, logits equal to rounding) unless has_bias carries GCM_STEP_FOUR_WAVES.
  * gcm_learned_bptt_cached: gcm_learned_bptt for a chain whose first n_cached steps are such steps (records in
  * layout `cached_layout` = 2 | 3; the steps behind them: `compact` layout).  cache_u (may be NULL): the chain's U cache -
  * with it (F = 32) the edge network's backward takes P0 = U + c0 from it instead of multiplying the node rows by W0
- * again (32 of its 112 matrix instructions per 32-row block). */
+ * again (32 of its 112 matrix instructions per 32-row block).  At N = 128, F = 32 that pass runs per 16-row tile in
+ * registers (k_learned_bptt_mlp16: cached steps on the U cache, the steps behind them with U as one more product);
+ * GCM_BPTT_MLP_BLOCKS=1 in the environment of the process keeps the 32-row-block kernel (A/B; read once). */
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                             const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
                             int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
