@@ -1291,7 +1291,8 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         util = json.load(open(upath))
 
         def counters_of(kname):
-            for key, ent in util.items():
+            # (the longest key that names the kernel: "k_learned_bptt_mlp" is also a prefix of "k_learned_bptt_mlp16<true>")
+            for key, ent in sorted(util.items(), key=lambda kv: -len(kv[0])):
                 if key in kname and "mfma_busy_frac" in ent:
                     return dict({k: ent[k] for k in ("mfma_busy_frac", "lds_conflict_frac", "wait_inst_lds_frac",
                                                      "wait_inst_any_frac", "wait_any_frac", "avg_us_under_pmc") if k in ent},
