@@ -3666,6 +3666,8 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
                                        gcm_stream_t stream) {
   GCM_REQUIRE(saved_host && gmx_host && params && g_params && workspace && n_steps > 0 && B > 0);
   GCM_REQUIRE(n_cached >= 0 && n_cached <= n_steps && (n_cached == 0 || (cache_nodes && cache_h1 && cache_agg1)));
+  const bool blocks_only = (cached_layout & GCM_BPTT_MLP_BLOCKS) != 0;   // (the A/B of pass B2: the 32-row-block kernel at every shape)
+  cached_layout &= ~GCM_BPTT_MLP_BLOCKS;
   GCM_REQUIRE(cached_layout == 2 || cached_layout == 3);
   if (!gcm_learned_step_supported(N, F, H1, H2)) return GCM_EUNSUPPORTED;
   if (workspace_bytes < gcm_learned_bptt_workspace_bytes(n_steps, B, N, F, H1, H2)) return GCM_EWORKSPACE;
@@ -3739,8 +3741,6 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       } else {
         const long units8 = ((long)ns * B + gcm_learned::MLP_WAVES - 1) / gcm_learned::MLP_WAVES;
         const int grid = (int)(units8 < 256 ? units8 : 256);
-        // (GCM_BPTT_MLP_BLOCKS=1 in the environment: the 32-row-block kernel at every shape - the A/B of tools/ab_cfg5.sh)
-        static const bool blocks_only = getenv("GCM_BPTT_MLP_BLOCKS") && atoi(getenv("GCM_BPTT_MLP_BLOCKS")) != 0;
         if (a.c_u && a.c_nodes && F == gcm_learned::FP && N == gcm_learned::NP && !blocks_only)
           hipLaunchKernelGGL(gcm_learned::k_learned_bptt_mlp16<true>, dim3(grid), dim3(64 * gcm_learned::M16_WAVES),
                              gcm_learned::lds_bptt_mlp16(), (hipStream_t)stream, a, (const float*)g_logit, params + Pg,

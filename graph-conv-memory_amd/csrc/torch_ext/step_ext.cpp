@@ -1396,7 +1396,10 @@ struct LearnedChainNode : public torch::autograd::Node {
       const size_t ws_bytes = gcm_learned_bptt_workspace_bytes(T, B, N, F, H1, H2);
       at::Tensor ws = at::empty({(int64_t)ws_bytes}, packed.options().dtype(at::kByte));
       at::Tensor res = at::empty({cfg->P_total}, packed.options());
-      check(gcm_learned_bptt_cached(sv.data(), gm.data(), T, n_cached, compact ? 2 : 3,
+      // (GCM_BPTT_MLP_BLOCKS=1: pass B2 on the 32-row-block kernel at every shape - the A/B of tools/ab_cfg5.sh)
+      static const int b2_blocks = (std::getenv("GCM_BPTT_MLP_BLOCKS") && std::getenv("GCM_BPTT_MLP_BLOCKS")[0] == '1')
+                                       ? GCM_BPTT_MLP_BLOCKS : 0;
+      check(gcm_learned_bptt_cached(sv.data(), gm.data(), T, n_cached, (compact ? 2 : 3) | b2_blocks,
                                     n_cached ? cX.data_ptr<float>() : nullptr,
                                     n_cached ? cH.data_ptr<float>() : nullptr,
                                     n_cached ? cA.data_ptr<float>() : nullptr,

@@ -1039,7 +1039,8 @@ int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t st
  * with it (F = 32) the edge network's backward takes P0 = U + c0 from it instead of multiplying the node rows by W0
  * again (32 of its 112 matrix instructions per 32-row block).  At N = 128, F = 32 that pass runs per 16-row tile in
  * registers (k_learned_bptt_mlp16: cached steps on the U cache, the steps behind them with U as one more product);
- * GCM_BPTT_MLP_BLOCKS=1 in the environment of the process keeps the 32-row-block kernel (A/B; read once). */
+ * GCM_BPTT_MLP_BLOCKS or-ed into cached_layout keeps the 32-row-block kernel (the A/B: a per-call argument). */
+#define GCM_BPTT_MLP_BLOCKS 256
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                             const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
                             int act2, float eps0, float eps1, float cutoff, int64_t* cur_out, int64_t* count_out,
