@@ -1,6 +1,8 @@
 """DenseGCM + LearnedEdge on the fused kernels (csrc/learned_step.hip): edge network, gumbel
 selection and the compact adjacency-gradient chain, against the reference's recorded-noise vectors
 and the CPU oracle with injected noise - up to BASELINE cfg5's per-GPU size.  Needs an MI355X."""
+import os
+
 import pytest
 import torch
 
@@ -560,3 +562,21 @@ def test_learned_chain_does_not_depend_on_uninitialised_cache_rows(rollout):
     finally:
         torch.utils.deterministic.fill_uninitialized_memory = prev_fill
         torch.use_deterministic_algorithms(prev_det)
+
+
+def test_learned_round5_kernels_behind_the_ab_switches_match_the_oracle():
+    """The four-wave cached step (GCM_STEP_FOUR_WAVES) and the 32-row-block pass B2 (GCM_BPTT_MLP_BLOCKS) stay behind the
+    per-call flags for the A/B of tools/ab_cfg5.sh: the module reads GCM_LEARNED_FOUR_WAVES / GCM_BPTT_MLP_BLOCKS once per
+    process, so the exact-shape oracle comparisons of this file run once more in a child that sets both - at those shapes
+    the default run exercises k_learned_select8 / k_learned_bptt_mlp16 instead."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GCM_LEARNED_FOUR_WAVES="1", GCM_BPTT_MLP_BLOCKS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(
+        [sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__),
+         "-k", "cfg5_timed_path or cached_steps_vs_oracle or steady_state_one_launch"],
+        env=env, capture_output=True, timeout=900, cwd=root)
+    tail = p.stdout.decode()[-1500:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
