@@ -840,14 +840,45 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const int fl = lane < F ? lane : F - 1, hl = lane & 31, kh = lane >> 5;
     const int64_t n64 = tl.cur_host >= 0 ? (int64_t)tl.cur_host : vw.count[b];
     const bool bad = n64 < 0 || n64 >= N;                     // (a chain from empty graphs never rolls)
-    if (wave > 1) return;                                     // (their share was done behind the MFMA loop)
+    // The gather of the selected rows from the LDS images (node rows staged for the distances, the h1 cache staged at
+    // kernel start) is FOUR waves' work, one 32-row block each (round 6): wave 0 alone walked a rank-compacted list of all
+    // of them, eight per trip - 2.4 k cycles of the tail on a full graph with its ~16 near neighbours.  Waves 0, 2, 3, 4
+    // sum their block's selected rows (a scalar loop over the block's mask bits), the partial sums meet in LDS behind one
+    // barrier that wave 1 passes too before its bookkeeping (a live wave that never arrives would hold it); the other
+    // waves are gone by then.
+    const bool lds_gather = hc_lds && !dist_param && sh == 0;   // (uniform)
+    if (wave > (lds_gather ? 4 : 1)) return;                  // (their share was done behind the MFMA loop)
     DSTAMP(7);
     unsigned long long m0 = 0, m1 = 0;
     float agg1 = 0.f, agg2 = 0.f;
     const float xc = pf_xc;
     float* sv = sPart;                                        // (free: every row sum has been read)
+    float* sGp = sPart + 4 * RB;                              // [4][128] the blocks' partial sums: x (64) | h1 (32)
     m0 = __ballot(!bad && lane < cur && sDec[lane] != 0.f);
     m1 = __ballot(!bad && lane + 64 < cur && lane + 64 < RB && sDec[(lane + 64) & (RB - 1)] != 0.f);
+    const int hc = hl < H1 ? hl : H1 - 1;
+    if (lds_gather) {
+      if (wave != 1) {
+        const int kb = wave == 0 ? 0 : wave - 1;              // this wave's 32-row block
+        uint32_t mk = (uint32_t)((kb < 2 ? m0 : m1) >> (32 * (kb & 1)));
+        float ax0 = 0.f, ax1 = 0.f, ah0 = 0.f, ah1 = 0.f;
+        while (mk) {                                          // (uniform) two rows a trip, ascending
+          const int ja = __builtin_ctz(mk);
+          mk &= mk - 1;
+          const bool two = mk != 0;
+          const int jb = two ? __builtin_ctz(mk) : ja;
+          mk &= two ? mk - 1 : mk;
+          const float xa = sN[(32 * kb + ja) * NS + fl], ha = sHc[(32 * kb + ja) * H1 + hc];
+          const float xb = sN[(32 * kb + jb) * NS + fl], hb = sHc[(32 * kb + jb) * H1 + hc];
+          ax0 += xa; ah0 += ha;
+          ax1 += two ? xb : 0.f; ah1 += two ? hb : 0.f;
+        }
+        sGp[kb * 128 + lane] = ax0 + ax1;
+        if (lane < 32) sGp[kb * 128 + 64 + lane] = ah0 + ah1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (wave > 1) return;
+    }
     if (wave == 1) {
       // ---- wave 1: what of the step depends on the decisions alone - the state's row cur (observation, adjacency
       //      row, bit image, count) and the record's live list - beside wave 0's gather and products, not behind them
@@ -885,35 +916,10 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       }
       return;
     }
-    const int hc = hl < H1 ? hl : H1 - 1;
-    if (hc_lds && !dist_param && sh == 0) {
-      // the selected rows as a compact ascending list (every selected lane writes its row at its rank), gathered
-      // from the LDS images - the node rows staged for the distances, the h1 cache staged at kernel start - eight
-      // per trip, added in ascending order.  (Was: a find-first-bit chain over the masks and a GLOBAL round trip
-      // per eight rows - a cluster of dozens of near neighbours cost the tail several of them.)
-      const int n0 = __popcll(m0), n_sel = n0 + __popcll(m1);
-      int* sIdx = reinterpret_cast<int*>(sPart + 2 * RB);     // [RB]
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if ((m0 >> lane) & 1ull) sIdx[__popcll(m0 & below)] = lane;
-      if ((m1 >> lane) & 1ull) sIdx[n0 + __popcll(m1 & below)] = lane + 64;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-      for (int q0 = 0; q0 < n_sel; q0 += 8) {
-        const int4 ia = *reinterpret_cast<const int4*>(sIdx + q0), ib = *reinterpret_cast<const int4*>(sIdx + q0 + 4);
-        const int js[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-        float bx[8], bh[8];
+    if (lds_gather) {
+      // (the four blocks' partial sums, in block order)
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) {
-          const bool any = q0 + qq < n_sel;
-          const int j = any ? js[qq] : 0;
-          const float tx = sN[j * NS + fl], th = sHc[j * H1 + hc];
-          bx[qq] = any ? tx : 0.f;
-          bh[qq] = any ? th : 0.f;
-        }
-#pragma unroll
-        for (int qq = 0; qq < 8; ++qq) { agg1 += bx[qq]; agg2 += bh[qq]; }
-      }
+      for (int kb = 0; kb < 4; ++kb) { agg1 += sGp[kb * 128 + lane]; agg2 += sGp[kb * 128 + 64 + (lane & 31)]; }
     } else {
       unsigned long long a0 = m0, a1 = m1;
       while (a0 | a1) {          // eight rows per round trip, added in ascending order
