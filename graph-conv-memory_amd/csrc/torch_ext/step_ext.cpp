@@ -251,6 +251,8 @@ std::vector<at::Tensor> fused_step(const at::Tensor& obs, const at::Tensor& node
 // version counter.  offset in elements of `dtype`.
 static at::Tensor alias_of(const at::Tensor& base, int64_t offset, at::IntArrayRef sizes, caffe2::TypeMeta dtype) {
   auto impl = c10::make_intrusive<c10::TensorImpl>(c10::Storage(base.storage()), base.key_set(), dtype);
+  // (offset: elements of `dtype` behind base's own first element - base may itself be an alias into a larger block)
+  offset += base.storage_offset() * (int64_t)base.dtype().itemsize() / (int64_t)dtype.itemsize();
   impl->set_storage_offset(offset);
   impl->set_sizes_contiguous(sizes);
   return at::Tensor(std::move(impl));
@@ -852,6 +854,35 @@ struct RowsFast {
 
   // a cached step in the steady state (see roll_ok): the general live-row record, the state's node matrix rolled in
   // place by the same launch, adjacency and count as they are
+  // The records of the cached steps are small (the belief, the live list, a few vectors): sixteen of them come out of ONE
+  // allocation (the caching allocator's at::empty was 1.0 us of a 5.7 us step, tools/hosttime.py; an alias into the block
+  // is 0.2).  A block is released when the last of its records is - a caller that keeps one belief keeps fifteen small
+  // neighbours alive.  One block per stream: the allocator knows a block by the stream it was allocated on.
+  // ... and one block per stream CAPTURE: memory allocated while a HIP graph is captured belongs to that graph's private
+  // pool (a block from outside it may be freed and reused while the graph still writes there on replay; a block of
+  // another capture dies with that graph).
+  at::Tensor rec_block;
+  int64_t rec_size = 0, rec_used = 0;
+  void* rec_stream = nullptr;
+  unsigned long long rec_capture = 0;
+  static constexpr int64_t REC_PER_BLOCK = 16;
+  at::Tensor take_record(int64_t floats, const at::Tensor& like) {
+    const int64_t n = pad64(floats);
+    if (n * (int64_t)sizeof(float) > (1 << 20)) return at::empty({n}, like.options());   // (large records: their own allocation)
+    hipStream_t st = c10::hip::getCurrentHIPStream(dev).stream();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    if (hipStreamGetCaptureInfo(st, &cs, &cid) != hipSuccess || cs != hipStreamCaptureStatusActive) cid = 0;
+    if (!rec_block.defined() || rec_size != n || rec_used == REC_PER_BLOCK || rec_stream != (void*)st || rec_capture != cid) {
+      rec_block = at::empty({REC_PER_BLOCK * n}, like.options());
+      rec_size = n;
+      rec_used = 0;
+      rec_stream = (void*)st;
+      rec_capture = cid;
+    }
+    return alias_of(rec_block, (rec_used++) * n, {n}, rec_block.dtype());
+  }
+
   at::Tensor launch_cached_roll(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
                                 const at::Tensor& weights, const at::Tensor& count_in) {
     const int64_t B = obs.size(0);
@@ -865,7 +896,7 @@ struct RowsFast {
     }
     size_t lay[8];
     check(gcm_dense_rows_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_layout");
-    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    at::Tensor buf = take_record(need_bwd ? (int64_t)lay[0] : B * H2, obs);
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
     check(gcm_dense_rows_step_cached_roll(obs.data_ptr<float>(), nodes_in.data_ptr<float>(),
                                           cfg->descs.empty() ? nullptr : cfg->descs.data(), (int)cfg->descs.size(),
@@ -920,7 +951,7 @@ struct RowsFast {
 #endif
     size_t lay[5];
     check(gcm_dense_rows_cached_layout((int)B, N, F, H1, H2, lay), "gcm_dense_rows_cached_layout");
-    at::Tensor buf = at::empty({need_bwd ? (int64_t)lay[0] : pad64(B * H2)}, obs.options());
+    at::Tensor buf = take_record(need_bwd ? (int64_t)lay[0] : B * H2, obs);
     PROF_T(1)
     const gcm_stream_t stream = reinterpret_cast<gcm_stream_t>(c10::hip::getCurrentHIPStream(dev).stream());
     size_t ws_bytes = 0;
