@@ -1853,17 +1853,17 @@ struct LearnedFast {
       return pybind11::none();
     PyObject* nf = PyDict_GetItem(sel_dict.ptr(), key_noise.ptr());
     if (nf != Py_None) return pybind11::none();   // (absent or injected: the interpreter's path decides)
-    // the gumbel draws: 16 steps' worth per RNG launch, from the module's pool [tensor, next, capturing]
+    // the gumbel draws: DenseGCM.noise_pool_steps steps' worth per RNG launch, from the module's pool [tensor, next, capturing]
     if (!PyList_Check(pool.ptr()) || PyList_GET_SIZE(pool.ptr()) != 3) return pybind11::none();
     PyObject* pt = PyList_GET_ITEM(pool.ptr(), 0);
     if (!PyLong_Check(PyList_GET_ITEM(pool.ptr(), 1))) return pybind11::none();
     const long next = PyLong_AsLong(PyList_GET_ITEM(pool.ptr(), 1));
     const bool cap_now = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
-    if (!THPVariable_Check(pt) || next < 0 || next >= 16 || (PyList_GET_ITEM(pool.ptr(), 2) == Py_True) != cap_now)
-      return pybind11::none();                     // (exhausted or drawn under another capture state: refilled there)
+    if (!THPVariable_Check(pt) || next < 0 || (PyList_GET_ITEM(pool.ptr(), 2) == Py_True) != cap_now)
+      return pybind11::none();                     // (drawn under another capture state: refilled there)
     const at::Tensor& pool_t = THPVariable_Unpack(pt);
-    if (pool_t.dim() != 3 || pool_t.size(1) != xB || pool_t.size(2) != N || pool_t.get_device() != dev)
-      return pybind11::none();
+    if (pool_t.dim() != 3 || next >= pool_t.size(0) || pool_t.size(1) != xB || pool_t.size(2) != N || pool_t.get_device() != dev)
+      return pybind11::none();                     // (exhausted: refilled on the interpreter's path)
     PyObject* cfg_live = PyWeakref_GetObject(cfg_ref.ptr());   // borrowed (the config owns this object: alive)
     if (!cfg_live || cfg_live == Py_None) return pybind11::none();
     // ---- nothing below declines: the step runs here ----

@@ -122,7 +122,7 @@ class DenseGCM(torch.nn.Module):
         self.donate_state = donate_state
         self._plan_cache = None
         self._fold = None     # set by _structure(): what the live-row step absorbs besides the GNN
-        self._noise_pool = None   # [exponential draws [16, B, N], next index] of the fused LearnedEdge step
+        self._noise_pool = None   # [exponential draws [noise_pool_steps, B, N], next index, drawn under capture] of the fused LearnedEdge step
         self._token = object()   # identifies hidden states produced by this module (_gcm_link)
         self._cfg_cache = {}
         self._cfg_last = None
@@ -136,6 +136,8 @@ class DenseGCM(torch.nn.Module):
         # False: the round-2 backward of the fused LearnedEdge step (one kernel per step behind a [B,N,N]
         # gradient chain buffer) instead of the time-parallel one - kept for A/B tests
         self.learned_time_parallel = True
+        # fused LearnedEdge steps: how many steps' gumbel draws one RNG launch makes (B x N x 4 bytes each)
+        self.noise_pool_steps = 64
         # False: no cached steps (the first N steps of a LearnedEdge rollout from empty graphs on a donated state as
         # ONE launch each, the GNN behind the selection on per-chain caches) - A/B tests
         self.learned_cached_steps = True
@@ -695,13 +697,15 @@ class DenseGCM(torch.nn.Module):
         if sel.noise_fn is not None:      # injected gumbel draws (parity tests); values of the argument unspecified
             noise, is_exp = sel.noise_fn(torch.empty(B, cfg.N, device=x.device)), 0
         else:                             # torch.nn.functional.gumbel_softmax draws -log(Exp(1)) the same way
-            # (16 steps' worth per draw: one RNG launch instead of sixteen)
+            # (noise_pool_steps steps' worth per draw: one RNG launch instead of one per step - and a refill is a
+            #  step on the interpreter's path: 64 since round 6, the RNG launches were 36 of a cfg5 rollout's 550 us)
             # A pool drawn outside a HIP-graph capture is not used inside one (and vice versa): the
             # captured kernels would keep reading its address after it has been replaced.
             pool, cap = self._noise_pool, torch.cuda.is_current_stream_capturing()
-            if (pool is None or pool[1] >= 16 or pool[2] != cap or pool[0].shape[1] != B
+            if (pool is None or pool[1] >= pool[0].shape[0] or pool[2] != cap or pool[0].shape[1] != B
                     or pool[0].device != x.device):
-                pool = self._noise_pool = [torch.empty(16, B, cfg.N, device=x.device).exponential_(), 0, cap]
+                pool = self._noise_pool = [torch.empty(max(1, int(self.noise_pool_steps)), B, cfg.N,
+                                                       device=x.device).exponential_(), 0, cap]
             noise, is_exp = pool[0][pool[1]], 1
             pool[1] += 1
         ext = _ops._ext.module()

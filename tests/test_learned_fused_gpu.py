@@ -259,6 +259,7 @@ def test_learned_noise_pool_statistics_and_equivalence():
     through `noise_fn` (the parity tests' path)."""
     B, N, F, H, T = 64, 32, 32, 32, 40
     ref, net, g, sel, mem = _pair(F, H, N, 5, seed=21)
+    mem.noise_pool_steps = 16          # (the module's default is 64: three pools in these 40 steps)
     obs = torch.rand(T, B, F, device=DEV)
     pools, used = [], []
     hidden, outs = None, []
@@ -356,6 +357,7 @@ def test_learned_fast_host_path_equals_interpreter_path(B, N, F, H, T, donate):
     for fast in (True, False):
         ref, net, g, sel, mem = _pair(F, H, N, 4, seed=5, donate=donate)
         mem.learned_fast_path = fast
+        mem.noise_pool_steps = 16      # (a refill inside these T steps)
         torch.manual_seed(99)
         obs = torch.rand(T, B, F, device=DEV)
         hidden, outs = None, []
