@@ -92,9 +92,9 @@ def test_bench_cfg5_two_ranks():
             "--steps", "2", "--warmup", "1", "--T", "12", "--repeats", "1", "--no-cpu-baseline"]
     p = subprocess.run(argv, env=env, capture_output=True, timeout=600)
     if p.returncode != 0:
-        # (once in some dozens of full-suite runs a rank of this child dies inside the in-process kernel tracer's
-        #  teardown - heap corruption in kineto's stop_trace, seen with other configs too and never twice in a row;
-        #  the first failure is printed, one more attempt decides)
+        # (this child failed once inside a full-suite run and passed alone and in the next full run; the cause was not
+        #  captured - the in-process kernel tracer's teardown has crashed bench children before, never twice in a row.
+        #  The first failure is printed, one more attempt decides)
         print(p.stderr.decode()[-2000:])
         p = subprocess.run(argv, env=env, capture_output=True, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
