@@ -618,7 +618,7 @@ int gcm_dense_rows_bptt_dx_step(const float* saved, const float* g_mx, long gmx_
                                 const float* g_nodes_out, const float* params, int has_bias, int act1, int act2,
                                 const int64_t* count0, float* gx, float* gn0, int s_lin, int B, int N, int F,
                                 int H1, int H2, gcm_stream_t stream);
-/* The same for up to 64 consecutive steps of a chain in ONE launch (one wave per step and graph): saved /
+/* The same for up to 128 consecutive steps of a chain in ONE launch (one wave per step and graph): saved /
  * g_mx / g_nodes_out are HOST arrays of n_steps device pointers (g_mx[s], g_nodes_out[s] NULL: none; every
  * g_mx with the same element strides), s0 the chain index of the first.  The steps run concurrently: gx / gn0
  * (zeroed by the caller) take hardware float atomic adds, so the order of summation - the last bits of the
