@@ -27,8 +27,12 @@ for part in $PARTS; do
   case $part in
     bench)   # the JSON line of every config, unprofiled
       for cfg in cfg2 cfg3 cfg4 cfg5 dense_edge; do
-        python3 bench.py --config $cfg > "$OUT/bench_$cfg.log" 2>&1 && tail -1 "$OUT/bench_$cfg.log" > "$OUT/${TAG}_bench_$cfg.json"
-        echo "bench $cfg done"
+        # (its own log name: the stats part below writes bench_$cfg.log; a failed run must not leave the previous line in place)
+        if python3 bench.py --config $cfg > "$OUT/benchline_$cfg.log" 2>&1; then
+          tail -1 "$OUT/benchline_$cfg.log" > "$OUT/${TAG}_bench_$cfg.json"; echo "bench $cfg done"
+        else
+          rm -f "$OUT/${TAG}_bench_$cfg.json"; echo "bench $cfg FAILED (see benchline_$cfg.log)"
+        fi
       done ;;
     stats)   # --kernel-trace --stats of the same command (cfg4: the one-shot headline leg alone, and both legs)
       # (under rocprofv3 bench.py runs its timed region alone - the profiler's kernel statistics are the headline's)
