@@ -908,7 +908,6 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
 
     # ---- the steady-state regime ("also T=256"): after t >= graph_size every step drops every graph's
     # oldest node (gcm.py:263-271, 323-355) - the normal regime of a long RL rollout --------------------------------
-    t256_table = None
     if T <= N and not args.headline_only:
         from gcm.gcm import DenseGCM
         DenseGCM.did_warn = True     # (the reference's one-time overflow notice is a print: stdout stays ONE JSON line)
@@ -923,44 +922,15 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         g2 = capture(lambda: rollout(mem_2, obs2), zero_2)
         t2_s = timed(g2.replay, side, 2) / side
         variants["T%d_graph_donated" % T2] = world * B * T2 / t2_s
-        variants["T%d_steady_state_step_us" % T2] = None     # (filled from the kernel profile below)
-        p2 = None
-        if c["selector"] == "dense":
-            # (no in-process kernel trace of this 7 GB graph: kineto's trace teardown crashed the process on some boxes
-            #  - heap corruption inside stop_trace, three runs in a row, then not again; the steady-state step is priced
-            #  from the two graph times instead)
-            variants["T%d_steady_state_step_us" % T2] = round((t2_s - dt / args.steps) / (T2 - T) * 1e6, 3)
-            variants["T%d_steady_state_step_note" % T2] = ("(replay time of the T=%d graph - replay time of the T=%d graph) / %d: "
-                                                           "forward step past graph_size + its share of the backward" % (T2, T, T2 - T))
-        elif rank == 0:
-            try:        # (rank 0 alone: no collective in here - g2 holds none - and no exception may leave it)
-                p2 = profile_kernels(g2.replay, reps=2)
-            except Exception as e:
-                variants["T%d_profile_error" % T2] = "%s: %s" % (type(e).__name__, str(e)[:120])
-        if p2 is not None:
-            if c["selector"] in ("temporal", "dense"):
-                kr = find_kernel(p2, "k_step_rows_cached_roll<", "k_step_colcache", "k_step_rows<")
-                if kr is not None:
-                    variants["T%d_steady_state_step_us" % T2] = round(kr[1]["avg_us"], 3)
-                    variants["T%d_steady_state_kernel" % T2] = kr[0]
-            else:
-                # the kernels of the steady-state step (the first N steps run the cached kernels of the headline): the
-                # one-launch EuclideanEdge step k_euclid_mfma2<.., 2>; for LearnedEdge every kernel that runs once per
-                # steady-state step; their mean durations add up to the steady-state step
-                if c["selector"] == "euclid":
-                    ss = {k: d for k, d in p2.items() if "k_euclid_mfma2<" in k and k.rstrip().endswith(", 2>")}
-                    if not ss:
-                        ss = {k: d for k, d in p2.items() if "k_step_rows<" in k or "k_euclid_mfma2<2, 0>" in k}
-                else:
-                    # (the one-launch steady-state step k_learned_select<2, 2>, or - a chain that fell back - every
-                    #  kernel that runs once per steady-state step: the profiler drops events, hence the slack)
-                    ss = {k: d for k, d in p2.items() if "k_learned_select<2, 2" in k}
-                    if not ss:
-                        ss = {k: d for k, d in p2.items() if "k_learned_select<2, 1" not in k
-                              and abs(d["launches_per_call"] - (T2 - N)) < 0.25 * (T2 - N)}
-                variants["T%d_steady_state_step_us" % T2] = round(sum(d["avg_us"] for d in ss.values()), 3) if ss else None
-                variants["T%d_steady_state_kernels" % T2] = {k: round(d["avg_us"], 3) for k, d in ss.items()}
-                t256_table = kernel_table(p2, top=8)[0]
+        # No in-process kernel trace of this graph: kineto's trace teardown (stop_trace) crashes the process now and then
+        # on the T = 2N graphs - a segmentation fault in 5 of 25 runs of cfg5, heap corruption three times in a row with
+        # dense_edge, never seen with cfg2 - and a crash here would cost the whole line.  The steady-state step is
+        # priced from the two graph times; tools/prof_t256.py prints the per-kernel table of the same graph (its own
+        # process: what dies there is a tool).
+        variants["T%d_steady_state_step_us" % T2] = round((t2_s - dt / args.steps) / (T2 - T) * 1e6, 3)
+        variants["T%d_steady_state_step_note" % T2] = ("(replay time of the T=%d graph - replay time of the T=%d graph) / %d: "
+                                                       "forward step past graph_size + its share of the backward; "
+                                                       "per-kernel durations: tools/prof_t256.py" % (T2, T, T2 - T))
         del g2
 
         def eager2(m, gn, bk):
@@ -1318,8 +1288,6 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                 rollout_kernels["sq_counters"] = cn
     if rollout_kernels is not None:
         line["rollout_api_kernels"] = rollout_kernels
-    if t256_table is not None:
-        line["T%d_kernel_table" % (2 * N)] = t256_table
     if layered is not None:
         line["layered_path"] = dict(layered, note="the same shapes through GNNs the fused step does not cover (three "
                                                   "DenseGraphConv layers; the canonical two with pooled=True): one "

@@ -45,7 +45,9 @@ for part in $PARTS; do
       stats euclid_full tools/prof_euclid_full.py
       stats euclid_tp tools/prof_euclid_tp.py
       stats sparse_learned tools/prof_sparse_learned.py
-      stats layered tools/prof_layered.py ;;
+      stats layered tools/prof_layered.py
+      stats t256_cfg5 tools/prof_t256.py cfg5      # (the kernels of rollouts of 2 x graph_size steps: bench.py keeps no in-process trace of them)
+      stats t256_cfg3 tools/prof_t256.py cfg3 ;;
     pmc)
       pmc FETCH_SIZE tools/pmc_run.py
       pmc WRITE_SIZE tools/pmc_run.py
