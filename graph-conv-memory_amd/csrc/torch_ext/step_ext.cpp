@@ -571,6 +571,38 @@ struct DxStepNode : public torch::autograd::Node {
   std::string name() const override { return "GcmRowsDxStep"; }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+struct RecordPool {
+  // The records of the cached steps are small (the belief, the live list, a few vectors): sixteen of them come out of ONE
+  // allocation (the caching allocator's at::empty was 1.0 us of a 5.7 us step, tools/hosttime.py; an alias into the block
+  // is 0.2).  A block is released when the last of its records is - a caller that keeps one belief keeps fifteen small
+  // neighbours alive.  One block per stream: the allocator knows a block by the stream it was allocated on.
+  // ... and one block per stream CAPTURE: memory allocated while a HIP graph is captured belongs to that graph's private
+  // pool (a block from outside it may be freed and reused while the graph still writes there on replay; a block of
+  // another capture dies with that graph).
+  at::Tensor rec_block;
+  int64_t rec_size = 0, rec_used = 0;
+  void* rec_stream = nullptr;
+  unsigned long long rec_capture = 0;
+  static constexpr int64_t REC_PER_BLOCK = 16;
+  at::Tensor take(int64_t floats, const at::Tensor& like, int dev) {
+    const int64_t n = pad64(floats);
+    if (n * (int64_t)sizeof(float) > (1 << 20)) return at::empty({n}, like.options());   // (large records: their own allocation)
+    hipStream_t st = c10::hip::getCurrentHIPStream(dev).stream();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    if (hipStreamGetCaptureInfo(st, &cs, &cid) != hipSuccess || cs != hipStreamCaptureStatusActive) cid = 0;
+    if (!rec_block.defined() || rec_size != n || rec_used == REC_PER_BLOCK || rec_stream != (void*)st || rec_capture != cid) {
+      rec_block = at::empty({REC_PER_BLOCK * n}, like.options());
+      rec_size = n;
+      rec_used = 0;
+      rec_stream = (void*)st;
+      rec_capture = cid;
+    }
+    return alias_of(rec_block, (rec_used++) * n, {n}, rec_block.dtype());
+  }
+};
+
 // The per-step host path of `belief, m = gcm(obs, m)` on the live-row kernels.  One instance per
 // (DenseGCM module, step configuration).  `run` is the checked entry (Python validated the hidden
 // state and built the packed parameter vector); `step` is what DenseGCM.__call__ tries first: when
@@ -854,34 +886,8 @@ struct RowsFast {
 
   // a cached step in the steady state (see roll_ok): the general live-row record, the state's node matrix rolled in
   // place by the same launch, adjacency and count as they are
-  // The records of the cached steps are small (the belief, the live list, a few vectors): sixteen of them come out of ONE
-  // allocation (the caching allocator's at::empty was 1.0 us of a 5.7 us step, tools/hosttime.py; an alias into the block
-  // is 0.2).  A block is released when the last of its records is - a caller that keeps one belief keeps fifteen small
-  // neighbours alive.  One block per stream: the allocator knows a block by the stream it was allocated on.
-  // ... and one block per stream CAPTURE: memory allocated while a HIP graph is captured belongs to that graph's private
-  // pool (a block from outside it may be freed and reused while the graph still writes there on replay; a block of
-  // another capture dies with that graph).
-  at::Tensor rec_block;
-  int64_t rec_size = 0, rec_used = 0;
-  void* rec_stream = nullptr;
-  unsigned long long rec_capture = 0;
-  static constexpr int64_t REC_PER_BLOCK = 16;
-  at::Tensor take_record(int64_t floats, const at::Tensor& like) {
-    const int64_t n = pad64(floats);
-    if (n * (int64_t)sizeof(float) > (1 << 20)) return at::empty({n}, like.options());   // (large records: their own allocation)
-    hipStream_t st = c10::hip::getCurrentHIPStream(dev).stream();
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    unsigned long long cid = 0;
-    if (hipStreamGetCaptureInfo(st, &cs, &cid) != hipSuccess || cs != hipStreamCaptureStatusActive) cid = 0;
-    if (!rec_block.defined() || rec_size != n || rec_used == REC_PER_BLOCK || rec_stream != (void*)st || rec_capture != cid) {
-      rec_block = at::empty({REC_PER_BLOCK * n}, like.options());
-      rec_size = n;
-      rec_used = 0;
-      rec_stream = (void*)st;
-      rec_capture = cid;
-    }
-    return alias_of(rec_block, (rec_used++) * n, {n}, rec_block.dtype());
-  }
+  RecordPool rec_pool;
+  at::Tensor take_record(int64_t floats, const at::Tensor& like) { return rec_pool.take(floats, like, dev); }
 
   at::Tensor launch_cached_roll(const at::Tensor& obs, const at::Tensor& nodes_in, const at::Tensor& adj_in,
                                 const at::Tensor& weights, const at::Tensor& count_in) {
@@ -1483,6 +1489,7 @@ struct LearnedChain {   // one per packed parameter vector
   at::Tensor cU;                      // [B,N,F] W0b x_j of every stored row (gcm_learned_step_cached: cache_u)
   at::Tensor abits;                   // [B,N,4] the adjacency as bits, kept by the steady-state steps
   at::Tensor prev_rec;                // the previous steady step's record (its h1 / agg1 feed the next one)
+  RecordPool rec_pool;                // the cached donated steps' records (small): sixteen per allocation
   const void* last_nodes = nullptr;   // the node matrix the previous step returned: a linear chain continues it
   // the state the previous step returned and its version counters right after the launch (the kernels write through
   // raw pointers: only a caller's in-place edit moves them, and the caches no longer describe such a state)
@@ -1561,7 +1568,9 @@ LearnedStepOut learned_step2_impl(LearnedChain& chain, const at::Tensor& obs_, c
     }
     size_t lay[8];
     check(gcm_learned_step_layout((int)B, N, F, H1, H2, donate ? 2 : 3, lay), "gcm_learned_step_layout");
-    buf = at::empty({(int64_t)lay[0]}, obs.options());
+    // (the donated step's record is small - adjacency row, belief, agg2, cur | count, soft row: sixteen per allocation;
+    //  the functional step's holds the new state)
+    buf = donate ? chain.rec_pool.take((int64_t)lay[0], obs, (int)obs.get_device()) : at::empty({(int64_t)lay[0]}, obs.options());
     float* base = buf.data_ptr<float>();
     int64_t* ib = reinterpret_cast<int64_t*>(base + lay[6]);
     if (!donate) {
