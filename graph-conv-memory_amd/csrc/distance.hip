@@ -499,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   // 2 x 16.8 MB in place behind it.  The node rows are in this kernel's registers anyway (staged for the distances):
   // stored one row up at the same point.
   constexpr int RA = 128 * 128 / 4 / NT;
-  uint4 wb[RA];
+  uint4 wb[RA], wa[RA];   // old rows row + 1 (what moves in) and row (what the fp32 matrix holds there now) of the bit image
   const unsigned n_magic = 0xFFFFFFFFu / (unsigned)N + 1u;   // e / N = umulhi(e, n_magic) for e < 2^16
   float vn[SEG];
   {
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
       for (int i = 0; i < RA; ++i) {
         const int row = (int)__umulhi((unsigned)(4 * (tid + NT * i)), n_magic);
         wb[i] = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + (row + 1 < N ? row + 1 : N - 1)) * 4)[0];
+        wa[i] = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + (row < N ? row : N - 1)) * 4)[0];   // (N < 128: items beyond the matrix)
       }
     }
     asm volatile("" ::: "memory");
@@ -553,12 +554,22 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         const int wi = c1 >> 5;
         const uint32_t lo = wi == 0 ? w.x : (wi == 1 ? w.y : (wi == 2 ? w.z : w.w));
         const uint32_t hi = wi == 0 ? w.y : (wi == 1 ? w.z : (wi == 2 ? w.w : 0u));
-        const uint32_t b4 = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (c1 & 31));
+        uint32_t b4 = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (c1 & 31)) & 15u;
         const int n_ok = N - c1;                               // columns c1 .. N - 1 exist (the last column stays empty)
-        f32x4 v;
+        b4 &= n_ok >= 4 ? 15u : ((1u << n_ok) - 1u);
+        // what the matrix holds in this piece now: the same four columns of old row `row` (the chain's bit image mirrors
+        // the fp32 adjacency) - a piece whose bits do not change is not stored (the band / cluster structure of a
+        // selector's decisions moves onto itself under the roll: most of the 16.8 MB a step stayed what it was)
+        const uint4 wo = wa[i];
+        const int c0 = c1 - 1, wj = c0 >> 5;
+        const uint32_t ow = wj == 0 ? wo.x : (wj == 1 ? wo.y : (wj == 2 ? wo.z : wo.w));
+        const uint32_t o4 = (ow >> (c0 & 31)) & 15u;          // (c0 is a multiple of 4: the piece lies inside one word)
+        if (b4 != o4) {
+          f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (q < n_ok && ((b4 >> q) & 1u)) ? 1.f : 0.f;
-        *reinterpret_cast<f32x4*>(ga + e) = v;
+          for (int q = 0; q < 4; ++q) v[q] = ((b4 >> q) & 1u) ? 1.f : 0.f;
+          *reinterpret_cast<f32x4*>(ga + e) = v;
+        }
       }
     }
   }
