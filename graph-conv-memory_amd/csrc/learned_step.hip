@@ -2599,6 +2599,145 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass B1 per GRAPH (round 6): a backward whose steps are all cached steps of one chain (T <= 64, the exact widths).
+// k_learned_bptt_sel gives every (step, graph) a workgroup that re-reads the graph's candidate rows of the node and h1
+// caches (132 MB through L2 per cfg5 chain for 8 MB of caches) and scans the live lists of all later steps for its node.
+// While no graph has rolled, node j sits at row j in every later step, so D_t - the sum of dAgg1 over the later steps
+// that aggregate node t - does not depend on the candidate: one vector per node.  One workgroup per graph then
+//   * turns the live lists into bit masks (row masks per step, column masks per node - the columns by LDS atomic OR:
+//     order-free), and each quarter-row thread walks its node's column mask in step order (the slot of node j in step t'
+//     is the number of live rows below j: one popcount) - D in a fixed order, no scan over steps that do not hold it;
+//   * keeps the graph's h1 | x rows in REGISTERS, rows j and j + 64 per lane, and evaluates g_sel_t[j] = dagg2_t . h1[j] +
+//     D_t . x[j] for all candidates of a step at once (the step's 64-float vector broadcast from LDS), the softmax adjoint
+//     behind it - a wave per step, four steps in flight.
+// Same g_logit as k_learned_bptt_sel up to the order of two 32-term sums.
+// ---------------------------------------------------------------------------------------------
+constexpr int SG_TS = FP + 4;
+constexpr size_t lds_bptt_sel_graph() { return sizeof(float) * (NP * SG_TS + 64 * SG_TS) + sizeof(unsigned long long) * (64 * 2 + NP) + sizeof(int) * 64 * 2; }
+
+__global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* __restrict__ g_logit, int B) {
+  constexpr int N = NP, F = FP, TS = SG_TS;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.n_steps;   // <= 64, a.s0 == 0: the whole backward
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sD = smem;                                   // [N][TS]  D of node j
+  float* sG2 = sD + N * TS;                           // [64][TS] dagg2 of step t
+  unsigned long long* sRow = reinterpret_cast<unsigned long long*>(sG2 + 64 * TS);   // [64][2] live rows of step t
+  unsigned long long* sCol = sRow + 64 * 2;           // [N] the steps that aggregate node j
+  int* sHdr = reinterpret_cast<int*>(sCol + N);       // [64][2] cur, L
+
+  // ---- this lane's rows j = lane and lane + 64 of the caches: h1 | x, 64 floats each -----------------------------------
+  // (rows 64 .. 127 only where the chain got that far: the counts grow by one a step, the last step's is the largest)
+  const int cur_last = __builtin_amdgcn_readfirstlane(a.hdr[2 * ((size_t)(T - 1) * B + b)]);
+  f32x4 hx[2][16];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const size_t rj = (size_t)b * N + lane + 64 * r;
+    if (r == 0 || cur_last > 64) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        hx[r][q] = *reinterpret_cast<const f32x4*>(a.c_h1 + rj * F + 4 * q);
+        hx[r][8 + q] = *reinterpret_cast<const f32x4*>(a.c_nodes + rj * F + 4 * q);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hx[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (tid < N) sCol[tid] = 0ull;
+  if (tid < 64) {
+    const bool on = tid < T;
+    const size_t it = (size_t)(on ? tid : 0) * B + b;
+    sHdr[2 * tid] = on ? a.hdr[2 * it] : 0;
+    sHdr[2 * tid + 1] = on ? a.hdr[2 * it + 1] : 0;
+  }
+  for (int e = tid; e < 64 * 8; e += 256) {   // dagg2 rows
+    const int t = e >> 3, q = e & 7;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < T) v = *reinterpret_cast<const f32x4*>(a.dagg2 + ((size_t)t * B + b) * F + 4 * q);
+    *reinterpret_cast<f32x4*>(sG2 + t * TS + 4 * q) = v;
+  }
+  __syncthreads();
+  // ---- masks: thread t builds the row mask of its step and sets its bit in the columns of the rows it holds -----------
+  if (tid < 64) {
+    unsigned long long m0 = 0, m1 = 0;
+    if (tid < T) {
+      const int L = sHdr[2 * tid + 1];
+      const int* lv = a.live + ((size_t)tid * B + b) * N;
+      for (int l = 0; l < L; ++l) {
+        const int j = lv[l] & (N - 1);
+        if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
+        atomicOr(reinterpret_cast<unsigned int*>(sCol + j) + (tid >> 5), 1u << (tid & 31));
+      }
+    }
+    sRow[2 * tid] = m0;
+    sRow[2 * tid + 1] = m1;
+  }
+  __syncthreads();
+  // ---- D[j] = sum over the steps t' that aggregate node j, in step order, of dAgg1_{t'}[slot of j] -----------------------
+  for (int jq = tid; jq < N * 4; jq += 256) {
+    const int j = jq >> 2, q = jq & 3;   // eight floats of row j
+    unsigned long long cm = sCol[j];
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    while (cm) {
+      f32x4 v0[4], v1[4];
+      int n = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        v1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (cm) {
+          const int t = __builtin_ctzll(cm);
+          cm &= cm - 1;
+          const unsigned long long r0 = sRow[2 * t], r1 = sRow[2 * t + 1];
+          const int slot = j < 64 ? __popcll(r0 & ((1ull << j) - 1ull))
+                                  : __popcll(r0) + __popcll(r1 & ((1ull << (j - 64)) - 1ull));
+          const float* p = a.da + (((size_t)t * B + b) * N + slot) * F + 8 * q;
+          v0[u] = *reinterpret_cast<const f32x4*>(p);
+          v1[u] = *reinterpret_cast<const f32x4*>(p + 4);
+          ++n;
+        }
+      }
+      (void)n;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc0 += v0[u]; acc1 += v1[u]; }
+    }
+    *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q) = acc0;
+    *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q + 4) = acc1;
+  }
+  __syncthreads();
+  // ---- a wave per step: g_sel for every candidate, the softmax adjoint -------------------------------------------------
+  for (int t = wave; t < T; t += 4) {
+    const int cur = __builtin_amdgcn_readfirstlane(sHdr[2 * t]);
+    if (cur <= 0) continue;   // no candidate rows (pass B2 skips the item too)
+    const float* soft = a.tab.saved[t] + a.o_soft + (size_t)b * N;
+    const float p0 = soft[lane], p1 = soft[lane + 64];
+    const float* dg = sG2 + t * TS;                       // dagg2_t
+    const float* dd = sD + (cur < N ? cur : N - 1) * TS;  // D of the node this step inserted
+    float g0 = 0.f, g1 = 0.f, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(dg + 4 * q), v = *reinterpret_cast<const f32x4*>(dd + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g0 = fmaf(u[k], hx[0][q][k], g0);
+        e0 = fmaf(v[k], hx[0][8 + q][k], e0);
+        g1 = fmaf(u[k], hx[1][q][k], g1);
+        e1 = fmaf(v[k], hx[1][8 + q][k], e1);
+      }
+    }
+    const bool l0 = lane < cur, l1 = lane + 64 < cur;
+    const float s0 = l0 ? g0 + e0 : 0.f, s1 = l1 ? g1 + e1 : 0.f;
+    const float q0 = l0 ? p0 : 0.f, q1 = l1 ? p1 : 0.f;
+    const float dot = wave_sum(fmaf(q0, s0, q1 * s1));
+    float* out = g_logit + ((size_t)t * B + b) * N;
+    out[lane] = q0 * (s0 - dot);
+    out[lane + 64] = q1 * (s1 - dot);
+  }
+}
+
 constexpr int MLP_WAVES = 8;
 constexpr int MLP_WSZ = 33 * FS + 3 * 32 * FS + 5 * 32 + 3;   // floats per wave: X (+ x_cur row) | P0 | H0 | P1 | 5 vectors
 constexpr size_t lds_bptt_mlp() {
@@ -3718,6 +3857,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
   constexpr size_t lds = gcm_learned::lds_bptt_mlp();
   static_assert(lds <= 160 * 1024, "one 8-wave workgroup per CU");
   gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp, lds);
+  gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_sel_graph, gcm_learned::lds_bptt_sel_graph());
   gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp16<true>, gcm_learned::lds_bptt_mlp16());
   gcm_allow_dynamic_lds((const void*)gcm_learned::k_learned_bptt_mlp16<false>, gcm_learned::lds_bptt_mlp16());
   int total_b = 0;
@@ -3736,8 +3876,14 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
       a.s0 = s0; a.n_steps = ns; a.T = n_steps;
       if (pass == 0) {
-        hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel, dim3(ns * B), dim3(128), 0, (hipStream_t)stream, a,
-                           g_logit, B, N, F, H1);
+        // (every step of the backward a cached step of one chain, T <= 64, the exact widths: per graph)
+        if (cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= 64 && a.c_nodes && a.c_h1 && F == gcm_learned::FP &&
+            H1 == gcm_learned::FP && N == gcm_learned::NP && !blocks_only)
+          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel_graph, dim3(B), dim3(256), gcm_learned::lds_bptt_sel_graph(),
+                             (hipStream_t)stream, a, g_logit, B);
+        else
+          hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel, dim3(ns * B), dim3(128), 0, (hipStream_t)stream, a,
+                             g_logit, B, N, F, H1);
       } else {
         const long units8 = ((long)ns * B + gcm_learned::MLP_WAVES - 1) / gcm_learned::MLP_WAVES;
         const int grid = (int)(units8 < 256 ? units8 : 256);
