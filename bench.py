@@ -928,9 +928,10 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # priced from the two graph times; tools/prof_t256.py prints the per-kernel table of the same graph (its own
         # process: what dies there is a tool).
         variants["T%d_steady_state_step_us" % T2] = round((t2_s - dt / args.steps) / (T2 - T) * 1e6, 3)
-        variants["T%d_steady_state_step_note" % T2] = ("(replay time of the T=%d graph - replay time of the T=%d graph) / %d: "
-                                                       "forward step past graph_size + its share of the backward; "
-                                                       "per-kernel durations: tools/prof_t256.py" % (T2, T, T2 - T))
+        variants["T%d_steady_state_step_note" % T2] = (
+            "(replay time of the T=%d graph - replay time of the T=%d graph) / %d: the mean step past the first %d - %s"
+            "forward + its share of the backward; per-kernel durations: tools/prof_t256.py under rocprofv3"
+            % (T2, T, T2 - T, T, "" if T >= N else "%d of them still below graph_size, %d in the steady state - " % (N - T, T2 - N)))
         del g2
 
         def eager2(m, gn, bk):
