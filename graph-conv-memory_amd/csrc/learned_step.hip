@@ -2390,6 +2390,8 @@ struct BpttB {
   const float* da;                    //         [T, B, N, F]
   const float* dagg2;                 //         [T, B, H1]
   int s0, n_steps, T;
+  const float* c0;                    // pass B2: c0_t = b0 + W0a x_cur [T, B, F] where pass B1 left it (k_learned_bptt_sel_graph,
+                                      // in dagg2's place); NULL: recomputed per tile
 };
 
 // ReLU + LayerNorm of the rows of src -> dst (two threads per row), statistics stored
@@ -2614,9 +2616,10 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
 // Same g_logit as k_learned_bptt_sel up to the order of two 32-term sums.
 // ---------------------------------------------------------------------------------------------
 constexpr int SG_TS = FP + 4;
-constexpr size_t lds_bptt_sel_graph() { return sizeof(float) * (NP * SG_TS + 64 * SG_TS) + sizeof(unsigned long long) * (64 * 2 + NP) + sizeof(int) * 64 * 2; }
+constexpr size_t lds_bptt_sel_graph() { return sizeof(float) * (NP * SG_TS + 64 * SG_TS + FP * SG_TS) + sizeof(unsigned long long) * (64 * 2 + NP) + sizeof(int) * 64 * 2; }
 
-__global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* __restrict__ g_logit, int B) {
+__global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* __restrict__ g_logit,
+                                                                const float* __restrict__ mlp, float* __restrict__ c0_out, int B) {
   constexpr int N = NP, F = FP, TS = SG_TS;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2627,6 +2630,7 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
   unsigned long long* sRow = reinterpret_cast<unsigned long long*>(sG2 + 64 * TS);   // [64][2] live rows of step t
   unsigned long long* sCol = sRow + 64 * 2;           // [N] the steps that aggregate node j
   int* sHdr = reinterpret_cast<int*>(sCol + N);       // [64][2] cur, L
+  float* sW0a = reinterpret_cast<float*>(sHdr + 64 * 2);   // [F][TS]  W0[o][f], f < F (c0 below)
 
   // ---- this lane's rows j = lane and lane + 64 of the caches: h1 | x, 64 floats each -----------------------------------
   // (rows 64 .. 127 only where the chain got that far: the counts grow by one a step, the last step's is the largest)
@@ -2659,7 +2663,38 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
     if (t < T) v = *reinterpret_cast<const f32x4*>(a.dagg2 + ((size_t)t * B + b) * F + 4 * q);
     *reinterpret_cast<f32x4*>(sG2 + t * TS + 4 * q) = v;
   }
+  const Mlp M = unpack_mlp(mlp, F);
+  *reinterpret_cast<f32x4*>(sW0a + (tid >> 3) * TS + 4 * (tid & 7)) =
+      *reinterpret_cast<const f32x4*>(M.w0 + (tid >> 3) * 2 * F + 4 * (tid & 7));
   __syncthreads();
+  // ---- c0_t = b0 + W0a x_cur for pass B2 (one vector per step here, 16 matrix instructions per 16-row tile there), written
+  //      where dagg2_t was (staged above): quarter-row threads, the step's node row in registers -------------------------
+  {
+    const int t = tid >> 2, q = tid & 3;
+    if (t < T) {
+      const int cur = sHdr[2 * t];
+      const float* xc = a.c_nodes + ((size_t)b * N + (cur < N && cur >= 0 ? cur : 0)) * F;
+      f32x4 xv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const f32x4*>(xc + 4 * c);
+      f32x4 r[2];
+#pragma unroll
+      for (int oo = 0; oo < 8; ++oo) {
+        const int o = 8 * q + oo;
+        float pa = M.b0[o], pb = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(sW0a + o * TS + 4 * c), wb = *reinterpret_cast<const f32x4*>(sW0a + o * TS + 4 * c + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pa = fmaf(wa[e], xv[c][e], pa); pb = fmaf(wb[e], xv[c + 1][e], pb); }
+        }
+        r[oo >> 2][oo & 3] = pa + pb;
+      }
+      float* dst = c0_out + ((size_t)t * B + b) * F + 8 * q;
+      *reinterpret_cast<f32x4*>(dst) = r[0];
+      *reinterpret_cast<f32x4*>(dst + 4) = r[1];
+    }
+  }
   // ---- masks: thread t builds the row mask of its step and sets its bit in the columns of the rows it holds -----------
   if (tid < 64) {
     unsigned long long m0 = 0, m1 = 0;
@@ -2708,7 +2743,7 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
     *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q + 4) = acc1;
   }
   __syncthreads();
-  // ---- a wave per step: g_sel for every candidate, the softmax adjoint -------------------------------------------------
+  // ---- a wave per step: g_sel for every candidate, the softmax adjoint ------------------------------------------------
   for (int t = wave; t < T; t += 4) {
     const int cur = __builtin_amdgcn_readfirstlane(sHdr[2 * t]);
     if (cur <= 0) continue;   // no candidate rows (pass B2 skips the item too)
@@ -3184,16 +3219,21 @@ __global__ __launch_bounds__(64 * M16_WAVES) void k_learned_bptt_mlp16(BpttB a, 
     gl = live ? gl : 0.f;
     // ---- c0 at the lane's features: W0a (A) x x_cur (B, the same in every column) ------------------------------------
     f32x4 p0[2];
+    if (CACHED && a.c0) {   // (uniform) pass B1 left the step's c0
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot) p0[ot] = *reinterpret_cast<const f32x4*>(sVec + 16 * ot + 4 * g);   // b0
+      for (int ot = 0; ot < 2; ++ot) p0[ot] = *reinterpret_cast<const f32x4*>(a.c0 + it * F + 16 * ot + 4 * g);
+    } else {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int ot = 0; ot < 2; ++ot) p0[ot] = *reinterpret_cast<const f32x4*>(sVec + 16 * ot + 4 * g);   // b0
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) {
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(sW0a + (16 * ot + m) * TS + 16 * ct + 4 * g);
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p0[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], xc4[ct][i], p0[ot], 0, 0, 0);
-      }
+        for (int ot = 0; ot < 2; ++ot) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(sW0a + (16 * ot + m) * TS + 16 * ct + 4 * g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) p0[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], xc4[ct][i], p0[ot], 0, 0, 0);
+        }
+    }
     // ---- P0 = U + c0, ReLU, LayerNorm 0 (rows behind the candidates: U is not written there - they enter as zeros) ----
     float xh0[8], h0[8];
     unsigned pos0 = 0;
@@ -3875,12 +3915,14 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       a.c_u = cached && F == gcm_learned::FP ? cache_u : nullptr;
       a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
       a.s0 = s0; a.n_steps = ns; a.T = n_steps;
+      const bool per_graph = cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= 64 && a.c_nodes && a.c_h1 &&
+                             F == gcm_learned::FP && H1 == gcm_learned::FP && N == gcm_learned::NP && !blocks_only;
+      if (pass == 1 && per_graph) a.c0 = dagg2;   // (B1 wrote c0_t over dagg2_t)
       if (pass == 0) {
         // (every step of the backward a cached step of one chain, T <= 64, the exact widths: per graph)
-        if (cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= 64 && a.c_nodes && a.c_h1 && F == gcm_learned::FP &&
-            H1 == gcm_learned::FP && N == gcm_learned::NP && !blocks_only)
+        if (per_graph)
           hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel_graph, dim3(B), dim3(256), gcm_learned::lds_bptt_sel_graph(),
-                             (hipStream_t)stream, a, g_logit, B);
+                             (hipStream_t)stream, a, g_logit, params + Pg, dagg2, B);
         else
           hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel, dim3(ns * B), dim3(128), 0, (hipStream_t)stream, a,
                              g_logit, B, N, F, H1);
