@@ -781,49 +781,6 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
       }
       float dagg2, dh1c;
       layer2(g, y, vv, false, dagg2, dh1c);
-      if (MODE == 2) {
-        // (round 6) the live rows EIGHT at a time: their h1 | agg1 | x loads are issued together and consumed in order.  One
-        // row per trip left every row a dependent round trip of its own - 46 us per cfg5 chain at ~1 us a row and wave.
-        constexpr int RB8 = 8;
-#pragma unroll 1
-        while (m0 | m1) {
-          int js[RB8];
-          int nb = 0;
-#pragma unroll
-          for (int u = 0; u < RB8; ++u) {
-            const bool any = (m0 | m1) != 0;
-            const int j = !any ? js[0] : (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
-            if (any) { if (m0) m0 &= m0 - 1; else m1 &= m1 - 1; }
-            js[u] = j;
-            nb += any ? 1 : 0;
-          }
-          float hvb[RB8], axb[RB8][C1];
-#pragma unroll
-          for (int u = 0; u < RB8; ++u) {
-            const size_t rj = gi * N + js[u];
-            hvb[u] = src.h1[rj * H1 + (lane < H1 ? lane : H1 - 1)];
-#pragma unroll
-            for (int c = 0; c < C1; ++c) {
-              const int m = lane + 64 * c;
-              const int f = m < F ? m : (m - F < F ? m - F : F - 1);
-              const float t = m < F ? src.agg1[rj * F + f] : src.nodes[rj * F + f];
-              axb[u][c] = m < 2 * F ? t : 0.f;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < RB8; ++u) {
-            if (u < nb) {   // (uniform)
-              const int j = js[u];
-              const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? a0 : a1), j & 63));
-              float da;
-              if (lane == 0) lrn.live[((size_t)(lrn.s0 + s) * B + b) * N + n_live] = j;
-              consume(cf, j == cur, dagg2, dh1c, hvb[u], axb[u], 0.f, da);
-              if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;   // dAgg1_l, column `lane`
-              ++n_live;
-            }
-          }
-        }
-      } else {
 #pragma unroll 1
       for (;;) {
         if (!(m0 | m1)) break;
@@ -840,8 +797,12 @@ __global__ __launch_bounds__(256) void k_bptt_rows(
           const float t = m < F ? src.agg1[rj * F + f] : src.nodes[rj * F + f];
           ax[c] = m < 2 * F ? t : 0.f;
         }
+        if (MODE == 2 && lane == 0) lrn.live[((size_t)(lrn.s0 + s) * B + b) * N + n_live] = j;
         consume(cf, j == cur, dagg2, dh1c, hv, ax, 0.f, da);
-      }
+        if (MODE == 2) {   // dAgg1_l, column `lane`
+          if (lane < F) lrn.da[(((size_t)(lrn.s0 + s) * B + b) * N + n_live) * F + lane] = da;
+          ++n_live;
+        }
       }
       if (MODE == 2) {
         const size_t it = (size_t)(lrn.s0 + s) * B + b;
