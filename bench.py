@@ -1181,10 +1181,13 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
             # dW1, dW0b and c0 (W0a x x_cur in every column: what it executes) as 16 x F x F products, dW0a as four
             # instructions on the tile's column sums
             live_tiles = sum((min(t, N - 1) + 15) // 16 for t in range(T))
-            bpb_exec = B * live_tiles * (5 * (2 * 16 * Fe * Fe) + 4 * (2 * 16 * 16 * 4))
+            # (c0 comes from pass B1 where that ran per graph - k_learned_bptt_sel_graph - and is then no product here)
+            n16 = 4 if find_kernel(prof, "k_learned_bptt_sel_graph") else 5
+            bpb_exec = B * live_tiles * (n16 * (2 * 16 * Fe * Fe) + 4 * (2 * 16 * 16 * 4))
             b2_note = ("pass B2 in registers (round 6): the edge network recomputed and differentiated per 16-row TILE that "
                        "holds a candidate row, one tile per wave in the forward's lane layout, twelve waves per CU; flops: "
-                       "the 16 x F x F products it executes on v_mfma_f32_16x16x4_f32 (c0, P1, gH0, dW1, dW0b) + dW0a's "
+                       "the 16 x F x F products it executes on v_mfma_f32_16x16x4_f32 (P1, gH0, dW1, dW0b; c0 too where pass B1 did not "
+                       "leave it) + dW0a's "
                        "four instructions - LayerNorm passes and adjoints (VALU) not counted; one persistent launch per chain")
         kinds = [("k_learned_select", ("k_learned_select<", "k_learned_select8"), sel_exec, sel_ref,
                   "selection + GNN tail (cached step); flops: the N x F x F products it executes (one with the U "
