@@ -2602,7 +2602,7 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass B1 per GRAPH (round 6): a backward whose steps are all cached steps of one chain (T <= 64, the exact widths).
+// Pass B1 per GRAPH (round 6): a backward whose steps are all cached steps of one chain (T <= 128, the exact widths).
 // k_learned_bptt_sel gives every (step, graph) a workgroup that re-reads the graph's candidate rows of the node and h1
 // caches (132 MB through L2 per cfg5 chain for 8 MB of caches) and scans the live lists of all later steps for its node.
 // While no graph has rolled, node j sits at row j in every later step, so D_t - the sum of dAgg1 over the later steps
@@ -2616,21 +2616,26 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
 // Same g_logit as k_learned_bptt_sel up to the order of two 32-term sums.
 // ---------------------------------------------------------------------------------------------
 constexpr int SG_TS = FP + 4;
-constexpr size_t lds_bptt_sel_graph() { return sizeof(float) * (NP * SG_TS + 64 * SG_TS + FP * SG_TS) + sizeof(unsigned long long) * (64 * 2 + NP) + sizeof(int) * 64 * 2; }
+constexpr int SG_TMAX = 128;   // steps of one backward (= GCM_ROWS_MAX_STEPS: one chunk)
+constexpr size_t lds_bptt_sel_graph() {
+  return sizeof(float) * (NP * SG_TS + SG_TMAX * SG_TS + FP * SG_TS) + sizeof(unsigned long long) * (SG_TMAX * 2 + NP * 2) +
+         sizeof(int) * SG_TMAX * 2;
+}
 
 __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* __restrict__ g_logit,
                                                                 const float* __restrict__ mlp, float* __restrict__ c0_out, int B) {
   constexpr int N = NP, F = FP, TS = SG_TS;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = a.n_steps;   // <= 64, a.s0 == 0: the whole backward
+  constexpr int TM = SG_TMAX;
+  const int T = a.n_steps;   // <= TM, a.s0 == 0: the whole backward
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sD = smem;                                   // [N][TS]  D of node j
-  float* sG2 = sD + N * TS;                           // [64][TS] dagg2 of step t
-  unsigned long long* sRow = reinterpret_cast<unsigned long long*>(sG2 + 64 * TS);   // [64][2] live rows of step t
-  unsigned long long* sCol = sRow + 64 * 2;           // [N] the steps that aggregate node j
-  int* sHdr = reinterpret_cast<int*>(sCol + N);       // [64][2] cur, L
-  float* sW0a = reinterpret_cast<float*>(sHdr + 64 * 2);   // [F][TS]  W0[o][f], f < F (c0 below)
+  float* sG2 = sD + N * TS;                           // [TM][TS] dagg2 of step t
+  unsigned long long* sRow = reinterpret_cast<unsigned long long*>(sG2 + TM * TS);   // [TM][2] live rows of step t
+  unsigned long long* sCol = sRow + TM * 2;           // [N][2] the steps that aggregate node j
+  int* sHdr = reinterpret_cast<int*>(sCol + N * 2);   // [TM][2] cur, L
+  float* sW0a = reinterpret_cast<float*>(sHdr + TM * 2);   // [F][TS]  W0[o][f], f < F (c0 below)
 
   // ---- this lane's rows j = lane and lane + 64 of the caches: h1 | x, 64 floats each -----------------------------------
   // (rows 64 .. 127 only where the chain got that far: the counts grow by one a step, the last step's is the largest)
@@ -2650,14 +2655,14 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
       for (int q = 0; q < 16; ++q) hx[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (tid < N) sCol[tid] = 0ull;
-  if (tid < 64) {
+  if (tid < N) { sCol[2 * tid] = 0ull; sCol[2 * tid + 1] = 0ull; }
+  if (tid < TM) {
     const bool on = tid < T;
     const size_t it = (size_t)(on ? tid : 0) * B + b;
     sHdr[2 * tid] = on ? a.hdr[2 * it] : 0;
     sHdr[2 * tid + 1] = on ? a.hdr[2 * it + 1] : 0;
   }
-  for (int e = tid; e < 64 * 8; e += 256) {   // dagg2 rows
+  for (int e = tid; e < TM * 8; e += 256) {   // dagg2 rows
     const int t = e >> 3, q = e & 7;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < T) v = *reinterpret_cast<const f32x4*>(a.dagg2 + ((size_t)t * B + b) * F + 4 * q);
@@ -2669,9 +2674,9 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
   __syncthreads();
   // ---- c0_t = b0 + W0a x_cur for pass B2 (one vector per step here, 16 matrix instructions per 16-row tile there), written
   //      where dagg2_t was (staged above): quarter-row threads, the step's node row in registers -------------------------
-  {
-    const int t = tid >> 2, q = tid & 3;
-    if (t < T) {
+  for (int tq = tid; tq < 4 * T; tq += 256) {
+    const int t = tq >> 2, q = tq & 3;
+    {
       const int cur = sHdr[2 * t];
       const float* xc = a.c_nodes + ((size_t)b * N + (cur < N && cur >= 0 ? cur : 0)) * F;
       f32x4 xv[8];
@@ -2696,7 +2701,7 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
     }
   }
   // ---- masks: thread t builds the row mask of its step and sets its bit in the columns of the rows it holds -----------
-  if (tid < 64) {
+  if (tid < TM) {
     unsigned long long m0 = 0, m1 = 0;
     if (tid < T) {
       const int L = sHdr[2 * tid + 1];
@@ -2704,7 +2709,7 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
       for (int l = 0; l < L; ++l) {
         const int j = lv[l] & (N - 1);
         if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
-        atomicOr(reinterpret_cast<unsigned int*>(sCol + j) + (tid >> 5), 1u << (tid & 31));
+        atomicOr(reinterpret_cast<unsigned int*>(sCol + 2 * j) + (tid >> 5), 1u << (tid & 31));   // (four words: 128 steps)
       }
     }
     sRow[2 * tid] = m0;
@@ -2714,30 +2719,30 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
   // ---- D[j] = sum over the steps t' that aggregate node j, in step order, of dAgg1_{t'}[slot of j] -----------------------
   for (int jq = tid; jq < N * 4; jq += 256) {
     const int j = jq >> 2, q = jq & 3;   // eight floats of row j
-    unsigned long long cm = sCol[j];
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    while (cm) {
-      f32x4 v0[4], v1[4];
-      int n = 0;
+#pragma unroll 1
+    for (int cw = 0; cw < 2; ++cw) {   // steps 0 - 63, then 64 - 127
+      unsigned long long cm = sCol[2 * j + cw];
+      while (cm) {
+        f32x4 v0[4], v1[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        v1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (cm) {
-          const int t = __builtin_ctzll(cm);
-          cm &= cm - 1;
-          const unsigned long long r0 = sRow[2 * t], r1 = sRow[2 * t + 1];
-          const int slot = j < 64 ? __popcll(r0 & ((1ull << j) - 1ull))
-                                  : __popcll(r0) + __popcll(r1 & ((1ull << (j - 64)) - 1ull));
-          const float* p = a.da + (((size_t)t * B + b) * N + slot) * F + 8 * q;
-          v0[u] = *reinterpret_cast<const f32x4*>(p);
-          v1[u] = *reinterpret_cast<const f32x4*>(p + 4);
-          ++n;
+        for (int u = 0; u < 4; ++u) {
+          v0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          v1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (cm) {
+            const int t = 64 * cw + __builtin_ctzll(cm);
+            cm &= cm - 1;
+            const unsigned long long r0 = sRow[2 * t], r1 = sRow[2 * t + 1];
+            const int slot = j < 64 ? __popcll(r0 & ((1ull << j) - 1ull))
+                                    : __popcll(r0) + __popcll(r1 & ((1ull << (j - 64)) - 1ull));
+            const float* p = a.da + (((size_t)t * B + b) * N + slot) * F + 8 * q;
+            v0[u] = *reinterpret_cast<const f32x4*>(p);
+            v1[u] = *reinterpret_cast<const f32x4*>(p + 4);
+          }
         }
-      }
-      (void)n;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { acc0 += v0[u]; acc1 += v1[u]; }
+        for (int u = 0; u < 4; ++u) { acc0 += v0[u]; acc1 += v1[u]; }
+      }
     }
     *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q) = acc0;
     *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q + 4) = acc1;
@@ -3915,7 +3920,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       a.c_u = cached && F == gcm_learned::FP ? cache_u : nullptr;
       a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
       a.s0 = s0; a.n_steps = ns; a.T = n_steps;
-      const bool per_graph = cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= 64 && a.c_nodes && a.c_h1 &&
+      const bool per_graph = cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= gcm_learned::SG_TMAX && a.c_nodes && a.c_h1 &&
                              F == gcm_learned::FP && H1 == gcm_learned::FP && N == gcm_learned::NP && !blocks_only;
       if (pass == 1 && per_graph) a.c0 = dagg2;   // (B1 wrote c0_t over dagg2_t)
       if (pass == 0) {

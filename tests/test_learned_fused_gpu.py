@@ -300,7 +300,7 @@ def test_learned_noise_pool_statistics_and_equivalence():
 
 @pytest.mark.parametrize("donate", [True, False])
 @pytest.mark.parametrize("B,N,F,H,T,k", [(5, 16, 8, 16, 24, 3), (4, 32, 32, 32, 40, 5), (3, 12, 4, 8, 9, 2),
-                                         (6, 128, 32, 32, 20, 5)])
+                                         (6, 128, 32, 32, 20, 5), (3, 128, 32, 32, 100, 5)])   # (T = 100: the per-graph pass B1 past 64 steps)
 def test_learned_cached_steps_vs_oracle(B, N, F, H, T, k, donate):
     """A rollout from hidden = None (donated or functional state): its first N steps are cached steps (ONE launch each: the
     GNN behind the selection on the chain's h1 / agg1 / node caches, gcm_learned_step_cached), the steps behind
