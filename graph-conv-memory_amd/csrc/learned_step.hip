@@ -2618,12 +2618,15 @@ __global__ __launch_bounds__(128) void k_learned_bptt_sel(BpttB a, float* __rest
 constexpr int SG_TS = FP + 4;
 constexpr int SG_TMAX = 128;   // steps of one backward (= GCM_ROWS_MAX_STEPS: one chunk)
 constexpr size_t lds_bptt_sel_graph() {
-  return sizeof(float) * (NP * SG_TS + SG_TMAX * SG_TS + FP * SG_TS) + sizeof(unsigned long long) * (SG_TMAX * 2 + NP * 2) +
+  return sizeof(float) * (2 * NP * SG_TS + SG_TMAX * SG_TS + 2 * FP * SG_TS) + sizeof(unsigned long long) * (SG_TMAX * 2 + NP * 2) +
          sizeof(int) * SG_TMAX * 2;
 }
 
+// w_rel1 (may be NULL): a.da holds G1 rows (pass A per graph, rows_bptt.hip: k_bptt_learned_graph) - dAgg1 = W_rel1^T G1, and the
+// matrix is applied ONCE per node, to the sum.
 __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* __restrict__ g_logit,
-                                                                const float* __restrict__ mlp, float* __restrict__ c0_out, int B) {
+                                                                const float* __restrict__ mlp, float* __restrict__ c0_out,
+                                                                const float* __restrict__ w_rel1, int B) {
   constexpr int N = NP, F = FP, TS = SG_TS;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2636,6 +2639,8 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
   unsigned long long* sCol = sRow + TM * 2;           // [N][2] the steps that aggregate node j
   int* sHdr = reinterpret_cast<int*>(sCol + N * 2);   // [TM][2] cur, L
   float* sW0a = reinterpret_cast<float*>(sHdr + TM * 2);   // [F][TS]  W0[o][f], f < F (c0 below)
+  float* sW1r = sW0a + F * TS;                        // [H1][TS] W_rel1[h][f]  (w_rel1)
+  float* sS = sW1r + F * TS;                          // [N][TS]  the sums of G1 rows, before W_rel1^T  (w_rel1)
 
   // ---- this lane's rows j = lane and lane + 64 of the caches: h1 | x, 64 floats each -----------------------------------
   // (rows 64 .. 127 only where the chain got that far: the counts grow by one a step, the last step's is the largest)
@@ -2671,6 +2676,9 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
   const Mlp M = unpack_mlp(mlp, F);
   *reinterpret_cast<f32x4*>(sW0a + (tid >> 3) * TS + 4 * (tid & 7)) =
       *reinterpret_cast<const f32x4*>(M.w0 + (tid >> 3) * 2 * F + 4 * (tid & 7));
+  if (w_rel1)
+    *reinterpret_cast<f32x4*>(sW1r + (tid >> 3) * TS + 4 * (tid & 7)) =
+        *reinterpret_cast<const f32x4*>(w_rel1 + (tid >> 3) * F + 4 * (tid & 7));
   __syncthreads();
   // ---- c0_t = b0 + W0a x_cur for pass B2 (one vector per step here, 16 matrix instructions per 16-row tile there), written
   //      where dagg2_t was (staged above): quarter-row threads, the step's node row in registers -------------------------
@@ -2717,7 +2725,9 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
   }
   __syncthreads();
   // ---- D[j] = sum over the steps t' that aggregate node j, in step order, of dAgg1_{t'}[slot of j] -----------------------
-  for (int jq = tid; jq < N * 4; jq += 256) {
+  // (only the nodes this backward inserted are asked for below: rows cur of its first step .. cur of its last)
+  const int j_lo = min(max(sHdr[0], 0), N - 1), j_hi = min(max(cur_last, j_lo), N - 1);
+  for (int jq = 4 * j_lo + tid; jq < 4 * (j_hi + 1); jq += 256) {
     const int j = jq >> 2, q = jq & 3;   // eight floats of row j
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -2744,10 +2754,30 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
         for (int u = 0; u < 4; ++u) { acc0 += v0[u]; acc1 += v1[u]; }
       }
     }
-    *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q) = acc0;
-    *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q + 4) = acc1;
+    float* dst = (w_rel1 ? sS : sD) + j * TS + 8 * q;
+    *reinterpret_cast<f32x4*>(dst) = acc0;
+    *reinterpret_cast<f32x4*>(dst + 4) = acc1;
   }
   __syncthreads();
+  if (w_rel1) {   // D_j = W_rel1^T S_j: eight outputs per quarter-row thread
+    for (int jq = 4 * j_lo + tid; jq < 4 * (j_hi + 1); jq += 256) {
+      const int j = jq >> 2, q = jq & 3;
+      f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h4 = 0; h4 < 8; ++h4) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + j * TS + 4 * h4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wr = sW1r + (4 * h4 + e) * TS + 8 * q;
+          o0 += sv[e] * *reinterpret_cast<const f32x4*>(wr);
+          o1 += sv[e] * *reinterpret_cast<const f32x4*>(wr + 4);
+        }
+      }
+      *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q) = o0;
+      *reinterpret_cast<f32x4*>(sD + j * TS + 8 * q + 4) = o1;
+    }
+    __syncthreads();
+  }
   // ---- a wave per step: g_sel for every candidate, the softmax adjoint ------------------------------------------------
   for (int t = wave; t < T; t += 4) {
     const int cur = __builtin_amdgcn_readfirstlane(sHdr[2 * t]);
@@ -3863,7 +3893,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       chunk_list.push_back({s0, hi - s0 < GCM_ROWS_MAX_STEPS ? hi - s0 : GCM_ROWS_MAX_STEPS});
   const int chunks = (int)chunk_list.size();
   const int per_a = lrn_per_a(n_steps, B);
-  const int total_a = per_a * chunks;
+  int total_a = per_a * chunks;
   const size_t TB = (size_t)n_steps * B;
   float* ws = (float*)workspace;
   float* slabs_a = ws;
@@ -3878,6 +3908,7 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
   const float* w_rel2 = params + 2 * (size_t)H1 * F + H1;
   const float* w_root2 = w_rel2 + (size_t)H2 * H1;
   // pass A: every step, every graph (the arrays pass B scans must be complete before it starts)
+  bool graph_passes = false;
   for (int c = 0; c < chunks; ++c) {
     const int s0 = chunk_list[c].first, ns = chunk_list[c].second;
     const bool cached = s0 < n_cached;
@@ -3892,9 +3923,20 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
                              cached ? (cached_layout == 2 ? 1 : 0) : compact, cached ? cache_nodes : nullptr,
                              cached ? cache_h1 : nullptr,
                              cached ? cache_agg1 : nullptr};
-    const int rc = gcm_rows::launch_bptt_learned(stream, per_a, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2,
-                                                 w_root2, act1, act2, slabs_a + (size_t)c * per_a * Pg, src, B, N,
-                                                 F, H1, H2);
+    // every step of the backward a cached step of one chain (one chunk), the exact widths: pass A and pass B1 per GRAPH
+    // (A hands G1 rows to B1, which applies W_rel1^T once per node; B slabs)
+    graph_passes = cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= gcm_learned::SG_TMAX && cache_nodes && cache_h1 &&
+                   cache_agg1 && F == gcm_learned::FP && H1 == gcm_learned::FP && H2 <= 32 && N == gcm_learned::NP &&
+                   B <= per_a && cached_layout == 2 && !blocks_only;   // (layout 2: the donated steps' records - the adjacency row compact)
+    int rc;
+    if (graph_passes) {
+      rc = gcm_rows::launch_bptt_learned_graph(stream, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2, w_root2, act1, act2,
+                                               slabs_a, src, B, H2);
+      total_a = B;
+    } else {
+      rc = gcm_rows::launch_bptt_learned(stream, per_a, tab, ns, gmx_stride_b, gmx_stride_h, w_rel2, w_root2, act1, act2,
+                                         slabs_a + (size_t)c * per_a * Pg, src, B, N, F, H1, H2);
+    }
     if (rc) return rc;
   }
   // pass B: B1 (selection + softmax adjoint of every item -> g_logit), then B2 (edge network, per 32-row block)
@@ -3920,14 +3962,15 @@ extern "C" int gcm_learned_bptt_cached(const float* const* saved_host, const flo
       a.c_u = cached && F == gcm_learned::FP ? cache_u : nullptr;
       a.hdr = hdr; a.live = live; a.da = da; a.dagg2 = dagg2;
       a.s0 = s0; a.n_steps = ns; a.T = n_steps;
-      const bool per_graph = cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= gcm_learned::SG_TMAX && a.c_nodes && a.c_h1 &&
-                             F == gcm_learned::FP && H1 == gcm_learned::FP && N == gcm_learned::NP && !blocks_only;
+      const bool per_graph = graph_passes || (cached && chunks == 1 && s0 == 0 && ns == n_steps && ns <= gcm_learned::SG_TMAX &&
+                                              a.c_nodes && a.c_h1 && F == gcm_learned::FP && H1 == gcm_learned::FP &&
+                                              N == gcm_learned::NP && !blocks_only);
       if (pass == 1 && per_graph) a.c0 = dagg2;   // (B1 wrote c0_t over dagg2_t)
       if (pass == 0) {
         // (every step of the backward a cached step of one chain, T <= 64, the exact widths: per graph)
         if (per_graph)
           hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel_graph, dim3(B), dim3(256), gcm_learned::lds_bptt_sel_graph(),
-                             (hipStream_t)stream, a, g_logit, params + Pg, dagg2, B);
+                             (hipStream_t)stream, a, g_logit, params + Pg, dagg2, graph_passes ? params : (const float*)nullptr, B);
         else
           hipLaunchKernelGGL(gcm_learned::k_learned_bptt_sel, dim3(ns * B), dim3(128), 0, (hipStream_t)stream, a,
                              g_logit, B, N, F, H1);

@@ -937,6 +937,198 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
   return gcm_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Pass A of the LearnedEdge backward per GRAPH (round 6): every step of the backward a cached step of one chain (T <= 128),
+// F = H1 = 32, H2 <= 32, N = 128.  k_bptt_rows<.., 2> gives every (step, graph) to a wave that starts behind four dependent
+// loads and walks its live rows through 32 v_readlane + 64 v_fma each: 46 us per cfg5 chain, bound by VALU issue.  Here one
+// workgroup (eight waves) owns a graph: its h1 / agg1 / x rows are staged in LDS once (every step reads the SAME caches), a
+// wave takes every eighth step with its next two steps' record loads in flight, and the rank-1 updates run on the matrix cores - two live
+// rows per v_mfma_f32_32x32x2_f32 (lanes 0-31 row ja, lanes 32-63 row jb: G1 as A, the rows' agg1 / x as B), layer 2's
+// d2 (x) [agg2 | h1cur] as two instructions with d2 in one half.  What it hands to pass B1 per live row is G1 itself, not
+// dAgg1 = W_rel1^T G1: the sum over the steps that aggregate a node commutes with the matrix, so k_learned_bptt_sel_graph
+// multiplies ONCE per node (da_is_g1).  One slab per graph.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_bptt_learned_graph(StepTable tab, int T, long gmx_sb, long gmx_sh,
+                                                            const float* __restrict__ w_rel2,
+                                                            const float* __restrict__ w_root2, int act1, int act2,
+                                                            float* __restrict__ slabs, int B, int H2, LrnSrc lrn) {
+  constexpr int N = 128, F = 32, H1 = 32, RS = 33;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  constexpr int NW = 8;   // waves: two per SIMD (a wave alone on its SIMD issues a dependent instruction every ~8 cycles)
+  __shared__ float sImg[3 * N * RS];   // the graph's h1 / agg1 / x rows; the epilogue's tiles later
+  float* sH = sImg;
+  float* sA = sH + N * RS;
+  float* sX = sA + N * RS;
+  // ---- the caches' rows 0 .. cur of the last step (the counts grow by one a step) ----------------------------------------
+  int64_t cl = reinterpret_cast<const int64_t*>(tab.saved[T - 1] + lrn.o_idx)[b];
+  const int n_rows = (int)(cl < 0 ? 0 : (cl > N - 1 ? N - 1 : cl)) + 1;
+  {
+    f32x4 vh[2], va[2], vx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i, r = e >> 3, c = (e & 7) * 4;
+      const size_t rj = ((size_t)b * N + (r < n_rows ? r : n_rows - 1)) * F + c;
+      vh[i] = *reinterpret_cast<const f32x4*>(lrn.c_h1 + rj);
+      va[i] = *reinterpret_cast<const f32x4*>(lrn.c_agg1 + rj);
+      vx[i] = *reinterpret_cast<const f32x4*>(lrn.c_nodes + rj);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i, r = e >> 3, c = (e & 7) * 4;
+      const bool on = r < n_rows;   // (rows behind: never written, may hold anything)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sH[r * RS + c + k] = on ? vh[i][k] : 0.f;
+        sA[r * RS + c + k] = on ? va[i][k] : 0.f;
+        sX[r * RS + c + k] = on ? vx[i][k] : 0.f;
+      }
+    }
+  }
+  // layer 2's weights: lanes 0-31 column q of W_rel2, lanes 32-63 column q of W_root2 (dagg2[q] / dh1cur[q] = column . d2)
+  float w2c[32];
+  {
+    const float* src = (half ? w_root2 : w_rel2) + q;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) w2c[o] = src[(size_t)(o < H2 ? o : H2 - 1) * H1];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int o = 0; o < 32; ++o) w2c[o] = o < H2 ? w2c[o] : 0.f;
+  }
+  f32x16 aR, aT, aR2, aT2;   // dW_rel1 [h][f], dW_root1 [h][f], dW_rel2 [o][k], dW_root2 [o][k] of this wave's steps
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aR[r] = 0.f; aT[r] = 0.f; aR2[r] = 0.f; aT2[r] = 0.f; }
+  float db1 = 0.f, db2 = 0.f;
+  __syncthreads();
+
+  const int oq = q < H2 ? q : H2 - 1;
+  struct Front { int cur; float a0, a1, g, y, agg2; };
+  auto front = [&](int t, Front& f) __attribute__((always_inline)) {
+    const float* sv = tab.saved[t];
+    const int64_t c64 = reinterpret_cast<const int64_t*>(sv + lrn.o_idx)[b];
+    f.cur = (int)(c64 < 0 ? 0 : (c64 > N - 1 ? N - 1 : c64));
+    const float* arow = sv + lrn.o_adj + (size_t)b * N;   // (cached steps: the compact row)
+    f.a0 = arow[lane];
+    f.a1 = arow[lane + 64];
+    const float* gp = tab.gmx[t];
+    f.g = gp ? gp[(long)b * gmx_sb + (long)oq * gmx_sh] : 0.f;
+    f.y = (sv + lrn.o_mx)[(size_t)b * H2 + oq];
+    f.agg2 = (sv + lrn.o_agg2)[(size_t)b * H1 + q];
+  };
+  Front fa{}, fb{}, fc{};
+  if (wave < T) front(wave, fa);
+  if (wave + NW < T) front(wave + NW, fb);
+#pragma unroll 1
+  for (int t = wave; t < T; t += NW) {
+    if (t + 2 * NW < T) front(t + 2 * NW, fc);   // (two of this wave's steps ahead: a step is shorter than a memory round trip)
+    const int cur = __builtin_amdgcn_readfirstlane(fa.cur);
+    const size_t it = (size_t)(lrn.s0 + t) * B + b;
+    // ---- layer 2: d2 = g act2'(y);  dW2 += d2 (x) [agg2 | h1cur];  dagg2 / dh1cur = W2^T d2 ------------------------------
+    const float d2 = q < H2 ? fa.g * gcm_act_grad_sel(fa.y, act2_v) : 0.f;   // (both halves hold d2[q])
+    db2 += half ? 0.f : d2;
+    const float h1c = sH[cur * RS + q];
+    const float d2lo = half ? 0.f : d2;
+    aR2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d2lo, fa.agg2, aR2, 0, 0, 0);
+    aT2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d2lo, h1c, aT2, 0, 0, 0);
+    float u = 0.f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o)
+      u = fmaf(w2c[o], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o)), u);
+    float dagg2, dh1c;
+    {
+      const unsigned uu = __float_as_uint(u);
+      const gcm_u32x2 r = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+      dagg2 = __uint_as_float(r[0]);   // the lower half's value (W_rel2 columns) in both halves
+      dh1c = __uint_as_float(r[1]);    // the upper half's (W_root2 columns)
+    }
+    if (lane < H1) lrn.dagg2[it * H1 + lane] = dagg2;
+    // ---- the live rows, two per instruction --------------------------------------------------------------------------
+    unsigned long long m0 = __ballot(fa.a0 != 0.f || lane == cur);
+    unsigned long long m1 = __ballot(fa.a1 != 0.f || lane + 64 == cur);
+    int n_live = 0;
+#pragma unroll 1
+    while (m0 | m1) {
+      const int ja = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+      if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+      const bool two = (m0 | m1) != 0;
+      int jb = ja;
+      if (two) {
+        jb = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+        if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+      }
+      const int j = half ? jb : ja;
+      const bool valid = !half || two;
+      const float hv = sH[j * RS + q], ag = sA[j * RS + q], xx = sX[j * RS + q];
+      const float cfa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ja < 64 ? fa.a0 : fa.a1), ja & 63));
+      const float cfb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jb < 64 ? fa.a0 : fa.a1), jb & 63));
+      const float cf = half ? cfb : cfa;
+      float g1 = (cf * dagg2 + (j == cur ? dh1c : 0.f)) * gcm_act_grad_sel(hv, act1_v);
+      g1 = valid ? g1 : 0.f;
+      db1 += g1;
+      aR = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, ag, aR, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xx, aT, 0, 0, 0);
+      if (valid) {
+        lrn.da[((it * N) + n_live + half) * F + q] = g1;   // (G1 of the row: da_is_g1)
+        if (q == 0) lrn.live[it * N + n_live + half] = j;
+      }
+      n_live += two ? 2 : 1;
+    }
+    if (lane == 0) {
+      lrn.hdr[2 * it] = cur;
+      lrn.hdr[2 * it + 1] = n_live;
+    }
+    fa = fb;
+    fb = fc;
+  }
+
+  // ---- one slab per graph: dW_rel1 [H1*F] | dW_root1 [H1*F] | db1 [H1] | dW_rel2 [H2*H1] | dW_root2 [H2*H1] | db2 [H2] ----
+  const int Pg = 2 * H1 * F + H1 + 2 * H2 * H1 + H2;
+  float* slab = slabs + (size_t)b * Pg;
+  float* sR = sImg;   // [NW][1024] (the images are dead: 3 x 4224 floats hold it)
+  const int li = lane & 31, lh = lane >> 5;
+  auto tile_out = [&](const f32x16& acc, int off, int rows) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 32 * rows; e += 512) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t_ += sR[w * 1024 + e];
+      slab[off + e] = t_;
+    }
+  };
+  tile_out(aR, 0, H1);
+  tile_out(aT, H1 * F, H1);
+  tile_out(aR2, 2 * H1 * F + H1, H2);
+  tile_out(aT2, 2 * H1 * F + H1 + H2 * H1, H2);
+  __syncthreads();
+  {
+    const float s1 = gcm_xor32_add(db1), s2 = gcm_xor32_add(db2);
+    if (lane < 32) { sR[wave * 64 + lane] = s1; sR[wave * 64 + 32 + lane] = s2; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float t_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t_ += sR[w * 64 + tid];
+    if (tid < 32) slab[2 * H1 * F + tid] = t_;
+    else if (tid - 32 < H2) slab[2 * H1 * F + H1 + 2 * H2 * H1 + tid - 32] = t_;
+  }
+}
+
+// ... its launch (the caller has checked the shapes and that the chunk is the whole backward): B slabs
+int launch_bptt_learned_graph(void* stream, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh, const float* w_rel2,
+                              const float* w_root2, int act1, int act2, float* slabs, const LearnedSrc& src, int B, int H2) {
+  LrnSrc l{src.o_adj, src.o_mx, src.o_h1, src.o_agg1, src.o_agg2, src.o_idx, src.w_rel1,
+           src.hdr,   src.live, src.da,   src.dagg2,  src.s0, src.adj_compact,
+           src.c_nodes, src.c_h1, src.c_agg1};
+  hipLaunchKernelGGL(k_bptt_learned_graph, dim3(B), dim3(512), 0, (hipStream_t)stream, tab, n_steps, gmx_sb, gmx_sh, w_rel2,
+                     w_root2, act1, act2, slabs, B, H2, l);
+  return gcm_launch_status();
+}
+
 int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh,
                         const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,
                         const LearnedSrc& src, int B, int N, int F, int H1, int H2) {

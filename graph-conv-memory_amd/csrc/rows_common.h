@@ -43,6 +43,10 @@ struct LearnedSrc {
 int launch_bptt_learned(void* stream, int grid, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh,
                         const float* w_rel2, const float* w_root2, int act1, int act2, float* slabs,
                         const LearnedSrc& src, int B, int N, int F, int H1, int H2);
+// ... per graph (rows_bptt.hip: k_bptt_learned_graph): every step a cached step, F = H1 = 32, H2 <= 32, N = 128, T <= 128;
+// B slabs; src.da receives G1 rows (not W_rel1^T G1)
+int launch_bptt_learned_graph(void* stream, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh, const float* w_rel2,
+                              const float* w_root2, int act1, int act2, float* slabs, const LearnedSrc& src, int B, int H2);
 
 struct SavedLayout {
   size_t total, o_v, o_hdr, o_coef, o_rows, o_deg;
