@@ -1199,8 +1199,9 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
                  ("k_learned_bptt_sel", ("k_learned_bptt_sel",), None, None,
                   "pass B1: per graph-step the gradient collected over the later steps that hold the node, selection "
                   "and softmax adjoint -> g_logit [T,B,N]"),
-                 ("k_bptt_rows_learned", ("k_bptt_rows<",), None, None,
-                  "pass A: GNN parameter gradient over the live rows of every graph-step")]
+                 ("k_bptt_rows_learned", ("k_bptt_learned_graph", "k_bptt_rows<"), None, None,
+                  "pass A: GNN parameter gradient over the live rows of every graph-step (k_bptt_learned_graph: per graph, "
+                  "two live rows per fp32 MFMA, where every step of the backward is a donated cached step)")]
         rows = []
         for tkey, prefixes, fl_exec, fl_ref, note in kinds:
             kk = find_kernel(prof, *prefixes)

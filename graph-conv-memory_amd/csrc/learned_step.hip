@@ -2714,10 +2714,23 @@ __global__ __launch_bounds__(256) void k_learned_bptt_sel_graph(BpttB a, float* 
     if (tid < T) {
       const int L = sHdr[2 * tid + 1];
       const int* lv = a.live + ((size_t)tid * B + b) * N;
-      for (int l = 0; l < L; ++l) {
+      // (the first eight entries in one round trip - a handful of live rows is the rule -, the rest one by one: a load per
+      //  trip of this loop was a dependent round trip each)
+      int e8[8];
+      __builtin_memcpy(e8, lv, sizeof(e8));
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        if (l < L) {
+          const int j = e8[l] & (N - 1);
+          if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
+          atomicOr(reinterpret_cast<unsigned int*>(sCol + 2 * j) + (tid >> 5), 1u << (tid & 31));   // (four words: 128 steps)
+        }
+      }
+      for (int l = 8; l < L; ++l) {
         const int j = lv[l] & (N - 1);
         if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
-        atomicOr(reinterpret_cast<unsigned int*>(sCol + 2 * j) + (tid >> 5), 1u << (tid & 31));   // (four words: 128 steps)
+        atomicOr(reinterpret_cast<unsigned int*>(sCol + 2 * j) + (tid >> 5), 1u << (tid & 31));
       }
     }
     sRow[2 * tid] = m0;
