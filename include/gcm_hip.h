@@ -1039,7 +1039,10 @@ int gcm_adj_bits(const float* adj, uint32_t* bits, int B, int N, gcm_stream_t st
  * with it (F = 32) the edge network's backward takes P0 = U + c0 from it instead of multiplying the node rows by W0
  * again (32 of its 112 matrix instructions per 32-row block).  At N = 128, F = 32 that pass runs per 16-row tile in
  * registers (k_learned_bptt_mlp16: cached steps on the U cache, the steps behind them with U as one more product);
- * GCM_BPTT_MLP_BLOCKS or-ed into cached_layout keeps the 32-row-block kernel (the A/B: a per-call argument). */
+ * GCM_BPTT_MLP_BLOCKS or-ed into cached_layout keeps the 32-row-block kernel (the A/B: a per-call argument).  A backward whose
+ * steps are ALL cached steps of one chain (n_cached == n_steps <= 128, the exact widths) runs pass B1 per graph
+ * (k_learned_bptt_sel_graph) and, on donated records (cached_layout 2), pass A per graph on the matrix cores
+ * (k_bptt_learned_graph); same results up to summation order, same workspace. */
 #define GCM_BPTT_MLP_BLOCKS 256
 int gcm_learned_step_cached(const float* obs, float* nodes, float* adj, const int64_t* count_in,
                             const float* noise, int noise_is_exp, const float* params, int has_bias, int act1,
