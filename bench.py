@@ -987,7 +987,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # EFFECTIVE rate: the kernel exploits "only row n_b is kept" (gcm.py:314) and, in a chain from empty
         # graphs, caches layer 1; `executed` is what it really moves and computes.
         k = find_kernel(prof, "k_step_rows_cached_img4", "k_step_rows_cached_img<", "k_step_rows_cached<", "k_step_rows<")
-        kb = find_kernel(prof, "k_bptt_rows<")
+        kb = find_kernel(prof, "k_bptt_cached_graph", "k_bptt_rows<")
         step_kernel, kd = k
         sec = kd["avg_us"] * 1e-6
         alg_bytes = B * (4 * N * N + 4 * N * F + 4 * F + 4 * H + 4 * N)
@@ -1091,7 +1091,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         eu_ms = ke[1]["avg_us"] * 1e-3
         flops = 2.0 * B * B * N * F
         ki = find_kernel(prof, "k_euclid_mfma")
-        kb = find_kernel(prof, "k_bptt_rows<")
+        kb = find_kernel(prof, "k_bptt_cached_graph", "k_bptt_rows<")
         in_situ = None
         if ki is not None:
             rows_live = sum(min(N, 32 * (t // 32 + 1)) for t in range(T)) / T      # rows < cur, in 32-row blocks
@@ -1125,7 +1125,7 @@ def bench_dense(args, c, line, rank, world, device, timed, weight, traffic):
         # (per graph-step with L = cur + 1 live rows: 2 L^2 F aggregation + 4 L F H layer-1 linears + 2 L H + 4 H^2 for
         # row cur of layer 2), and SURVEY 8(d)'s full-dense flops (2 layers x all N rows) as the EFFECTIVE figure.
         k = find_kernel(prof, "k_step_colcache", "k_step_rows<")
-        kb = find_kernel(prof, "k_bptt_dense<", "k_bptt_rows<")
+        kb = find_kernel(prof, "k_bptt_dense<", "k_bptt_cached_graph", "k_bptt_rows<")
         step_kernel, kd = k
         sec = kd["avg_us"] * 1e-6
         Ls = [min(t, N - 1) + 1 for t in range(T)]

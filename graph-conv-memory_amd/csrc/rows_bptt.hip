@@ -938,6 +938,175 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The backward over records of CACHED steps per graph (round 6; cfg2's backward): F = H1 = 32, H2 <= 32, N <= 128, up to 128
+// steps (one launch).  k_bptt_rows<32, 32, 32, 3, true> walks the (step, graph) items with a persistent grid - every item
+// behind its record's header, then its rows' loads from the caches - 40 us per cfg2 rollout at 2.5 us an item and wave.
+// One workgroup per graph instead (the form of k_bptt_learned_graph below): the caches' rows in LDS once, eight waves, a wave
+// every eighth step with two steps' record loads in flight, the same matrix-core arithmetic.  One slab per graph.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T, long gmx_sb, long gmx_sh,
+                                                           const float* __restrict__ w_rel2,
+                                                           const float* __restrict__ w_root2, int act1, int act2,
+                                                           SavedLayout lay, float* __restrict__ slabs, int B, int N, int H2,
+                                                           LrnSrc lrn) {
+  constexpr int NMAX = 128, F = 32, H1 = 32, RS = 33;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
+  constexpr int NW = 8;   // waves: two per SIMD (a wave alone on its SIMD issues a dependent instruction every ~8 cycles)
+  __shared__ float sImg[3 * NMAX * RS];   // the graph's h1 / agg1 / x rows; the epilogue's tiles later
+  float* sH = sImg;
+  float* sA = sH + NMAX * RS;
+  float* sX = sA + NMAX * RS;
+  // ---- every row of the graph's caches (a steady-state chain's are rings: any slot may be live) -----------------------------
+  {
+    f32x4 vh[2], va[2], vx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i, r = e >> 3, c = (e & 7) * 4;
+      const size_t rj = ((size_t)b * N + (r < N ? r : N - 1)) * F + c;
+      vh[i] = *reinterpret_cast<const f32x4*>(lrn.c_h1 + rj);
+      va[i] = *reinterpret_cast<const f32x4*>(lrn.c_agg1 + rj);
+      vx[i] = *reinterpret_cast<const f32x4*>(lrn.c_nodes + rj);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i, r = e >> 3, c = (e & 7) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sH[r * RS + c + k] = vh[i][k];
+        sA[r * RS + c + k] = va[i][k];
+        sX[r * RS + c + k] = vx[i][k];
+      }
+    }
+  }
+  // layer 2's weights: lanes 0-31 column q of W_rel2, lanes 32-63 column q of W_root2 (dagg2[q] / dh1cur[q] = column . d2)
+  float w2c[32];
+  {
+    const float* src = (half ? w_root2 : w_rel2) + q;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) w2c[o] = src[(size_t)(o < H2 ? o : H2 - 1) * H1];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int o = 0; o < 32; ++o) w2c[o] = o < H2 ? w2c[o] : 0.f;
+  }
+  f32x16 aR, aT, aR2, aT2;   // dW_rel1 [h][f], dW_root1 [h][f], dW_rel2 [o][k], dW_root2 [o][k] of this wave's steps
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aR[r] = 0.f; aT[r] = 0.f; aR2[r] = 0.f; aT2[r] = 0.f; }
+  float db1 = 0.f, db2 = 0.f;
+  __syncthreads();
+
+  const int oq = q < H2 ? q : H2 - 1;
+  struct Front { int L, l_cur, ja, jb; float cfa, cfb, g, y, vv; };
+  auto front = [&](int t, Front& f) __attribute__((always_inline)) {
+    const float* sv = tab.saved[t];
+    const int* hdr = reinterpret_cast<const int*>(sv + lay.o_hdr) + 4 * b;
+    f.L = hdr[0];
+    f.l_cur = hdr[1];
+    const int e0 = lane < N ? lane : N - 1, e1 = lane + 64 < N ? lane + 64 : N - 1;   // (entries >= L: unused)
+    f.cfa = sv[lay.o_coef + (size_t)b * N + e0];
+    f.cfb = sv[lay.o_coef + (size_t)b * N + e1];
+    const int* live = reinterpret_cast<const int*>(sv + lay.o_live) + (size_t)b * N;
+    f.ja = live[e0];
+    f.jb = live[e1];
+    const float* gp = tab.gmx[t];
+    f.g = gp ? gp[(long)b * gmx_sb + (long)oq * gmx_sh] : 0.f;
+    f.y = sv[(size_t)b * H2 + oq];
+    f.vv = sv[lay.o_v + (size_t)b * 64 + lane];   // agg2 [32] | h1cur [32]
+  };
+  Front fa{}, fb{}, fc{};
+  if (wave < T) front(wave, fa);
+  if (wave + NW < T) front(wave + NW, fb);
+#pragma unroll 1
+  for (int t = wave; t < T; t += NW) {
+    if (t + 2 * NW < T) front(t + 2 * NW, fc);   // (two of this wave's steps ahead: a step is shorter than a memory round trip)
+    const int L = min(__builtin_amdgcn_readfirstlane(fa.L), NMAX);
+    const int l_cur = __builtin_amdgcn_readfirstlane(fa.l_cur);
+    // ---- layer 2: d2 = g act2'(y);  dW2 += d2 (x) [agg2 | h1cur];  dagg2 / dh1cur = W2^T d2 ------------------------------
+    const float d2 = (q < H2 && L > 0) ? fa.g * gcm_act_grad_sel(fa.y, act2_v) : 0.f;   // (both halves hold d2[q]; L = 0: a
+                                                                                       //  graph that got no node this step)
+    db2 += half ? 0.f : d2;
+    aR2 = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : d2, fa.vv, aR2, 0, 0, 0);   // d2 (x) agg2
+    aT2 = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? d2 : 0.f, fa.vv, aT2, 0, 0, 0);   // d2 (x) h1cur
+    float u = 0.f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o)
+      u = fmaf(w2c[o], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), o)), u);
+    float dagg2, dh1c;
+    {
+      const unsigned uu = __float_as_uint(u);
+      const gcm_u32x2 r = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+      dagg2 = __uint_as_float(r[0]);   // the lower half's value (W_rel2 columns) in both halves
+      dh1c = __uint_as_float(r[1]);    // the upper half's (W_root2 columns)
+    }
+    // ---- the live rows (the record's list), two per instruction ---------------------------------------------------------
+#pragma unroll 1
+    for (int l = 0; l < L; l += 2) {
+      const int l1 = l + 1 < L ? l + 1 : l;
+      const int j0 = l < 64 ? __builtin_amdgcn_readlane(fa.ja, l) : __builtin_amdgcn_readlane(fa.jb, l & 63);
+      const int j1 = l1 < 64 ? __builtin_amdgcn_readlane(fa.ja, l1) : __builtin_amdgcn_readlane(fa.jb, l1 & 63);
+      const float c0 = __int_as_float(l < 64 ? __builtin_amdgcn_readlane(__float_as_int(fa.cfa), l)
+                                             : __builtin_amdgcn_readlane(__float_as_int(fa.cfb), l & 63));
+      const float c1 = __int_as_float(l1 < 64 ? __builtin_amdgcn_readlane(__float_as_int(fa.cfa), l1)
+                                              : __builtin_amdgcn_readlane(__float_as_int(fa.cfb), l1 & 63));
+      const int j = (half ? j1 : j0) & (NMAX - 1), lm = l + half;
+      const float hv = sH[j * RS + q], ag = sA[j * RS + q], xx = sX[j * RS + q];
+      float g1 = ((half ? c1 : c0) * dagg2 + (lm == l_cur ? dh1c : 0.f)) * gcm_act_grad_sel(hv, act1_v);
+      g1 = lm < L ? g1 : 0.f;
+      db1 += g1;
+      aR = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, ag, aR, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xx, aT, 0, 0, 0);
+    }
+    fa = fb;
+    fb = fc;
+  }
+
+  // ---- one slab per graph: dW_rel1 [H1*F] | dW_root1 [H1*F] | db1 [H1] | dW_rel2 [H2*H1] | dW_root2 [H2*H1] | db2 [H2] ----
+  const int Pg = 2 * H1 * F + H1 + 2 * H2 * H1 + H2;
+  float* slab = slabs + (size_t)b * Pg;
+  float* sR = sImg;   // [NW][1024] (the images are dead: 3 x 4224 floats hold it)
+  const int li = lane & 31, lh = lane >> 5;
+  auto tile_out = [&](const f32x16& acc, int off, int rows) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 32 * rows; e += 512) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t_ += sR[w * 1024 + e];
+      slab[off + e] = t_;
+    }
+  };
+  tile_out(aR, 0, H1);
+  tile_out(aT, H1 * F, H1);
+  tile_out(aR2, 2 * H1 * F + H1, H2);
+  tile_out(aT2, 2 * H1 * F + H1 + H2 * H1, H2);
+  __syncthreads();
+  {
+    const float s1 = gcm_xor32_add(db1), s2 = gcm_xor32_add(db2);
+    if (lane < 32) { sR[wave * 64 + lane] = s1; sR[wave * 64 + 32 + lane] = s2; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float t_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t_ += sR[w * 64 + tid];
+    if (tid < 32) slab[2 * H1 * F + tid] = t_;
+    else if (tid - 32 < H2) slab[2 * H1 * F + H1 + 2 * H2 * H1 + tid - 32] = t_;
+  }
+}
+
+
+int launch_bptt_cached_graph(hipStream_t s, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh, const float* w_rel2,
+                             const float* w_root2, int act1, int act2, const SavedLayout& lay, float* slabs, int B, int N,
+                             int H2, const LrnSrc& caches) {
+  hipLaunchKernelGGL(k_bptt_cached_graph, dim3(B), dim3(512), 0, s, tab, n_steps, gmx_sb, gmx_sh, w_rel2, w_root2, act1,
+                     act2, lay, slabs, B, N, H2, caches);
+  return gcm_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Pass A of the LearnedEdge backward per GRAPH (round 6): every step of the backward a cached step of one chain (T <= 128),
 // F = H1 = 32, H2 <= 32, N = 128.  k_bptt_rows<.., 2> gives every (step, graph) to a wave that starts behind four dependent
 // loads and walks its live rows through 32 v_readlane + 64 v_fma each: 46 us per cfg5 chain, bound by VALU issue.  Here one
@@ -1223,6 +1392,22 @@ static int rows_bptt_impl(const float* const* saved_host, const float* const* gm
   const int total_slabs = gcm_dense_rows_bptt_slabs(n_steps, B);
   const int per = total_slabs / chunks;
   float* slabs = (float*)workspace;
+  // records of cached steps at F = H1 = 32 on graphs of <= 128 nodes, one launch's worth: per GRAPH (k_bptt_cached_graph: the
+  // caches' rows in LDS once; B slabs).  Any other bit in has_bias - GCM_STEP_FOUR_WAVES is the A/B switch - keeps the
+  // per-item kernel.
+  if (cache_h1 && cache_nodes && cache_agg1 && chunks == 1 && F == 32 && H1 == 32 && H2 <= 32 && N <= 128 && !deg_term &&
+      !(has_bias & ~(3 | GCM_BPTT_MANY_ROWS)) && B <= total_slabs) {
+    gcm_rows::StepTable tab{};
+    for (int i = 0; i < n_steps; ++i) {
+      GCM_REQUIRE(saved_host[i] && gmx_host[i]);
+      tab.saved[i] = saved_host[i];
+      tab.gmx[i] = gmx_host[i];
+    }
+    const int rc = gcm_rows::launch_bptt_cached_graph(s, tab, n_steps, gmx_stride_b, gmx_stride_h, w_rel2, w_root2, act1,
+                                                      act2, lay, slabs, B, N, H2, caches);
+    if (rc) return rc;
+    return gcm_sum_slabs_acc(slabs, B, (int)P, g_params_prev, g_params, stream);
+  }
   for (int c = 0; c < chunks; ++c) {
     const int s0 = c * GCM_ROWS_MAX_STEPS;
     const int ns = n_steps - s0 < GCM_ROWS_MAX_STEPS ? n_steps - s0 : GCM_ROWS_MAX_STEPS;

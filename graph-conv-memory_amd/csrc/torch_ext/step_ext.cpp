@@ -421,9 +421,13 @@ struct RowsChainNode : public torch::autograd::Node {
       // the kernel writes the first P floats; constant sections behind them get a zero gradient
       at::Tensor res = packed.numel() > P ? at::zeros({packed.numel()}, packed.options())
                                           : at::empty({P}, packed.options());
+      // (GCM_BPTT_PER_ITEM=1: the per-item backward kernel where the per-graph form exists - the A/B; a per-call flag of the
+      //  C ABI, read from the environment by this host module once)
+      static const int per_item = (std::getenv("GCM_BPTT_PER_ITEM") && std::getenv("GCM_BPTT_PER_ITEM")[0] == '1')
+                                      ? GCM_STEP_FOUR_WAVES : 0;
       if (c.cached)
         check(gcm_dense_rows_bptt_cached(c.sv.data(), c.gm.data(), n, (long)c.sb, (long)c.sh, packed.data_ptr<float>(),
-                                         has_bias, act1, act2, cX.data_ptr<float>(), cH.data_ptr<float>(),
+                                         has_bias | per_item, act1, act2, cX.data_ptr<float>(), cH.data_ptr<float>(),
                                          cA.data_ptr<float>(), prev.defined() ? prev.data_ptr<float>() : nullptr,
                                          res.data_ptr<float>(), ws.data_ptr(), ws_bytes, (int)c.B, N, F, H1, H2, stream),
               "gcm_dense_rows_bptt_cached");
