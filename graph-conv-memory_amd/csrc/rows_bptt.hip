@@ -938,34 +938,39 @@ int launch_bptt(hipStream_t s, int grid, const StepTable& tab, const Hist& hs, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The backward over records of CACHED steps per graph (round 6; cfg2's backward): F = H1 = 32, H2 <= 32, N <= 128, up to 128
+// The backward over records of CACHED steps per graph (round 6; cfg2's / cfg3's backward): F = 32 or 64, H1 = 32, H2 <= 32, N <= 128, up to 128
 // steps (one launch).  k_bptt_rows<32, 32, 32, 3, true> walks the (step, graph) items with a persistent grid - every item
 // behind its record's header, then its rows' loads from the caches - 40 us per cfg2 rollout at 2.5 us an item and wave.
 // One workgroup per graph instead (the form of k_bptt_learned_graph below): the caches' rows in LDS once, eight waves, a wave
 // every eighth step with two steps' record loads in flight, the same matrix-core arithmetic.  One slab per graph.
 // ---------------------------------------------------------------------------------------------------------
+template <int FT>   // F = 32 FT
 __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T, long gmx_sb, long gmx_sh,
                                                            const float* __restrict__ w_rel2,
                                                            const float* __restrict__ w_root2, int act1, int act2,
                                                            SavedLayout lay, float* __restrict__ slabs, int B, int N, int H2,
                                                            LrnSrc lrn) {
-  constexpr int NMAX = 128, F = 32, H1 = 32, RS = 33;
+  constexpr int NMAX = 128, F = 32 * FT, H1 = 32, RS = 33, AS = F + 1;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int act1_v = gcm_vgpr(act1), act2_v = gcm_vgpr(act2);
   constexpr int NW = 8;   // waves: two per SIMD (a wave alone on its SIMD issues a dependent instruction every ~8 cycles)
-  __shared__ float sImg[3 * NMAX * RS];   // the graph's h1 / agg1 / x rows; the epilogue's tiles later
+  extern __shared__ float sImg[];   // the graph's h1 [NMAX][RS] / agg1, x [NMAX][AS] rows; the epilogue's tiles later
   float* sH = sImg;
   float* sA = sH + NMAX * RS;
-  float* sX = sA + NMAX * RS;
+  float* sX = sA + NMAX * AS;
   // ---- every row of the graph's caches (a steady-state chain's are rings: any slot may be live) -----------------------------
   {
-    f32x4 vh[2], va[2], vx[2];
+    f32x4 vh[2], va[2 * FT], vx[2 * FT];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + 512 * i, r = e >> 3, c = (e & 7) * 4;
+      vh[i] = *reinterpret_cast<const f32x4*>(lrn.c_h1 + ((size_t)b * N + (r < N ? r : N - 1)) * H1 + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * FT; ++i) {
+      const int e = tid + 512 * i, r = e / (F / 4), c = (e % (F / 4)) * 4;
       const size_t rj = ((size_t)b * N + (r < N ? r : N - 1)) * F + c;
-      vh[i] = *reinterpret_cast<const f32x4*>(lrn.c_h1 + rj);
       va[i] = *reinterpret_cast<const f32x4*>(lrn.c_agg1 + rj);
       vx[i] = *reinterpret_cast<const f32x4*>(lrn.c_nodes + rj);
     }
@@ -973,10 +978,15 @@ __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T,
     for (int i = 0; i < 2; ++i) {
       const int e = tid + 512 * i, r = e >> 3, c = (e & 7) * 4;
 #pragma unroll
+      for (int k = 0; k < 4; ++k) sH[r * RS + c + k] = vh[i][k];
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * FT; ++i) {
+      const int e = tid + 512 * i, r = e / (F / 4), c = (e % (F / 4)) * 4;
+#pragma unroll
       for (int k = 0; k < 4; ++k) {
-        sH[r * RS + c + k] = vh[i][k];
-        sA[r * RS + c + k] = va[i][k];
-        sX[r * RS + c + k] = vx[i][k];
+        sA[r * AS + c + k] = va[i][k];
+        sX[r * AS + c + k] = vx[i][k];
       }
     }
   }
@@ -990,9 +1000,13 @@ __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T,
 #pragma unroll
     for (int o = 0; o < 32; ++o) w2c[o] = o < H2 ? w2c[o] : 0.f;
   }
-  f32x16 aR, aT, aR2, aT2;   // dW_rel1 [h][f], dW_root1 [h][f], dW_rel2 [o][k], dW_root2 [o][k] of this wave's steps
+  f32x16 aR[FT], aT[FT], aR2, aT2;   // dW_rel1 [h][32 ft + f], dW_root1, dW_rel2 [o][k], dW_root2 [o][k] of this wave's steps
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { aR[r] = 0.f; aT[r] = 0.f; aR2[r] = 0.f; aT2[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) {
+    aR2[r] = 0.f; aT2[r] = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) { aR[ft][r] = 0.f; aT[ft][r] = 0.f; }
+  }
   float db1 = 0.f, db2 = 0.f;
   __syncthreads();
 
@@ -1050,12 +1064,15 @@ __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T,
       const float c1 = __int_as_float(l1 < 64 ? __builtin_amdgcn_readlane(__float_as_int(fa.cfa), l1)
                                               : __builtin_amdgcn_readlane(__float_as_int(fa.cfb), l1 & 63));
       const int j = (half ? j1 : j0) & (NMAX - 1), lm = l + half;
-      const float hv = sH[j * RS + q], ag = sA[j * RS + q], xx = sX[j * RS + q];
+      const float hv = sH[j * RS + q];
       float g1 = ((half ? c1 : c0) * dagg2 + (lm == l_cur ? dh1c : 0.f)) * gcm_act_grad_sel(hv, act1_v);
       g1 = lm < L ? g1 : 0.f;
       db1 += g1;
-      aR = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, ag, aR, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, xx, aT, 0, 0, 0);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        aR[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, sA[j * AS + 32 * ft + q], aR[ft], 0, 0, 0);
+        aT[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, sX[j * AS + 32 * ft + q], aT[ft], 0, 0, 0);
+      }
     }
     fa = fb;
     fb = fc;
@@ -1066,7 +1083,8 @@ __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T,
   float* slab = slabs + (size_t)b * Pg;
   float* sR = sImg;   // [NW][1024] (the images are dead: 3 x 4224 floats hold it)
   const int li = lane & 31, lh = lane >> 5;
-  auto tile_out = [&](const f32x16& acc, int off, int rows) {
+  // (a 32 x 32 tile of this wave's accumulators -> slab[off + row * ld + column], the eight waves summed in order)
+  auto tile_out = [&](const f32x16& acc, int off, int ld, int rows) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) sR[wave * 1024 + gcm_fused::acc_row(r, lh) * 32 + li] = acc[r];
@@ -1075,13 +1093,16 @@ __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T,
       float t_ = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t_ += sR[w * 1024 + e];
-      slab[off + e] = t_;
+      slab[off + (e >> 5) * ld + (e & 31)] = t_;
     }
   };
-  tile_out(aR, 0, H1);
-  tile_out(aT, H1 * F, H1);
-  tile_out(aR2, 2 * H1 * F + H1, H2);
-  tile_out(aT2, 2 * H1 * F + H1 + H2 * H1, H2);
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    tile_out(aR[ft], 32 * ft, F, H1);
+    tile_out(aT[ft], H1 * F + 32 * ft, F, H1);
+  }
+  tile_out(aR2, 2 * H1 * F + H1, H1, H2);
+  tile_out(aT2, 2 * H1 * F + H1 + H2 * H1, H1, H2);
   __syncthreads();
   {
     const float s1 = gcm_xor32_add(db1), s2 = gcm_xor32_add(db2);
@@ -1100,9 +1121,17 @@ __global__ __launch_bounds__(512) void k_bptt_cached_graph(StepTable tab, int T,
 
 int launch_bptt_cached_graph(hipStream_t s, const StepTable& tab, int n_steps, long gmx_sb, long gmx_sh, const float* w_rel2,
                              const float* w_root2, int act1, int act2, const SavedLayout& lay, float* slabs, int B, int N,
-                             int H2, const LrnSrc& caches) {
-  hipLaunchKernelGGL(k_bptt_cached_graph, dim3(B), dim3(512), 0, s, tab, n_steps, gmx_sb, gmx_sh, w_rel2, w_root2, act1,
-                     act2, lay, slabs, B, N, H2, caches);
+                             int F, int H2, const LrnSrc& caches) {
+  const size_t lds = sizeof(float) * (128 * 33 + 2 * 128 * (size_t)(F + 1));
+  if (F == 32) {
+    gcm_allow_dynamic_lds((const void*)k_bptt_cached_graph<1>, lds);
+    hipLaunchKernelGGL(k_bptt_cached_graph<1>, dim3(B), dim3(512), lds, s, tab, n_steps, gmx_sb, gmx_sh, w_rel2, w_root2, act1,
+                       act2, lay, slabs, B, N, H2, caches);
+  } else {
+    gcm_allow_dynamic_lds((const void*)k_bptt_cached_graph<2>, lds);
+    hipLaunchKernelGGL(k_bptt_cached_graph<2>, dim3(B), dim3(512), lds, s, tab, n_steps, gmx_sb, gmx_sh, w_rel2, w_root2, act1,
+                       act2, lay, slabs, B, N, H2, caches);
+  }
   return gcm_launch_status();
 }
 
@@ -1392,10 +1421,10 @@ static int rows_bptt_impl(const float* const* saved_host, const float* const* gm
   const int total_slabs = gcm_dense_rows_bptt_slabs(n_steps, B);
   const int per = total_slabs / chunks;
   float* slabs = (float*)workspace;
-  // records of cached steps at F = H1 = 32 on graphs of <= 128 nodes, one launch's worth: per GRAPH (k_bptt_cached_graph: the
+  // records of cached steps at F = 32 or 64, H1 = 32 on graphs of <= 128 nodes, one launch's worth: per GRAPH (k_bptt_cached_graph: the
   // caches' rows in LDS once; B slabs).  Any other bit in has_bias - GCM_STEP_FOUR_WAVES is the A/B switch - keeps the
   // per-item kernel.
-  if (cache_h1 && cache_nodes && cache_agg1 && chunks == 1 && F == 32 && H1 == 32 && H2 <= 32 && N <= 128 && !deg_term &&
+  if (cache_h1 && cache_nodes && cache_agg1 && chunks == 1 && (F == 32 || F == 64) && H1 == 32 && H2 <= 32 && N <= 128 && !deg_term &&
       !(has_bias & ~(3 | GCM_BPTT_MANY_ROWS)) && B <= total_slabs) {
     gcm_rows::StepTable tab{};
     for (int i = 0; i < n_steps; ++i) {
@@ -1404,7 +1433,7 @@ static int rows_bptt_impl(const float* const* saved_host, const float* const* gm
       tab.gmx[i] = gmx_host[i];
     }
     const int rc = gcm_rows::launch_bptt_cached_graph(s, tab, n_steps, gmx_stride_b, gmx_stride_h, w_rel2, w_root2, act1,
-                                                      act2, lay, slabs, B, N, H2, caches);
+                                                      act2, lay, slabs, B, N, F, H2, caches);
     if (rc) return rc;
     return gcm_sum_slabs_acc(slabs, B, (int)P, g_params_prev, g_params, stream);
   }
