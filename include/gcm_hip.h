@@ -769,7 +769,7 @@ int gcm_dense_rows_bptt_dx_all_cached(const float* const* saved, const float* co
                                       int act1, int act2, const gcm_selector_desc* selectors, int n_selectors,
                                       const float* cache_h1, float* gx, int B, int N, int F, int H1, int H2,
                                       gcm_stream_t stream);
-/* gcm_dense_rows_bptt over the records of cached steps (their rows in the chain's caches).  Round 6: at F = H1 = 32, H2 <= 32,
+/* gcm_dense_rows_bptt over the records of cached steps (their rows in the chain's caches).  Round 6: at F = 32 or 64, H1 = 32, H2 <= 32,
  * N <= 128 and n_steps <= 128 the pass runs per GRAPH (k_bptt_cached_graph: the caches' rows in LDS once, one slab per graph)
  * unless has_bias carries a bit other than the two bias bits and GCM_BPTT_MANY_ROWS - GCM_STEP_FOUR_WAVES is the A/B switch
  * for the per-item kernel.  Same workspace (gcm_dense_rows_bptt_workspace_bytes). */
