@@ -2,6 +2,7 @@
 the rows that reach the belief, donated or functional state, time-parallel parameter backward run by
 the chain's one autograd node.  Parity against the reference's golden vectors and the CPU oracle.  Needs an MI355X."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -1157,3 +1158,21 @@ def test_rows_chain_does_not_depend_on_uninitialised_memory(sel, F, H):
     for k, p in g.named_parameters():
         g64, atol = bounds[k]
         assert float((p.grad.cpu().double() - g64).abs().max()) <= atol, k
+
+
+def test_rows_per_item_backward_behind_the_ab_switch_matches_the_oracle():
+    """The per-item backward over cached records (k_bptt_rows<.., 3>) stays behind GCM_STEP_FOUR_WAVES in has_bias for the
+    A/B of tools/ab_cfg2.sh - at F = 32 / 64, H1 = 32 the default run takes the per-graph kernel (k_bptt_cached_graph).
+    The module reads GCM_BPTT_PER_ITEM once per process: the cached-step oracle comparisons of this file run once more in a
+    child that sets it."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GCM_BPTT_PER_ITEM="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(
+        [sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__),
+         "-k", "test_rows_cached_steps_vs_oracle"],
+        env=env, capture_output=True, timeout=900, cwd=root)
+    tail = p.stdout.decode()[-1500:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
