@@ -498,6 +498,9 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
   // of stores per step at cfg3 that drain under the distance phase, no loads of the old matrix - instead of moving
   // 2 x 16.8 MB in place behind it.  The node rows are in this kernel's registers anyway (staged for the distances):
   // stored one row up at the same point.
+  constexpr int WN = (2 * FP + 64) * 32, NIW = WN / NT;
+  static_assert(WN % NT == 0, "whole rounds of the workgroup over the weight image");
+  const bool hc_lds = TAIL == 1 && (tl.H1 & 3) == 0 && N * tl.H1 <= 4 * NT;   // h1 cache staged in LDS
   constexpr int RA = 128 * 128 / 4 / NT;
   uint4 wb[RA], wa[RA];   // old rows row + 1 (what moves in) and row (what the fp32 matrix holds there now) of the bit image
   const unsigned n_magic = 0xFFFFFFFFu / (unsigned)N + 1u;   // e / N = umulhi(e, n_magic) for e < 2^16
@@ -524,6 +527,28 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
         wa[i] = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + (row < N ? row : N - 1)) * 4)[0];   // (N < 128: items beyond the matrix)
       }
     }
+    // TAIL: what the cached step behind the decisions reads that does not depend on them - the four weight matrices
+    // (lane-major image) and the h1 cache of this graph - rides the staging round trip and is in LDS behind the staging
+    // barrier (their LDS regions are not touched by the distance phase).  Until round 6 these loads were issued behind
+    // the MFMA loop and stored behind the row-sum barrier (wave 0's stamps: 2.0 k -> 1.0 k cycles between the last
+    // chunk and the decisions; the kernel as a whole 13.01 -> 12.99 us - the other waves' skew covered most of it);
+    // before that the tail started with them.
+    float pfw[NIW];
+    float4 pfh;
+    if (TAIL) {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) {
+        const int e = tid + i * NT;
+        const int k = e >> 5, h = e & 31;                     // row k of the k-major image, output h
+        const int m = k < FP ? 0 : (k < 2 * FP ? 1 : (k < 2 * FP + 32 ? 2 : 3));
+        const int kk = m == 0 ? k : (m == 1 ? k - FP : (m == 2 ? k - 2 * FP : k - 2 * FP - 32));
+        pfw[i] = tl.image[m * 4096 + kk * 64 + h];
+      }
+      if (hc_lds) {
+        const int n4 = N * tl.H1 / 4;
+        pfh = reinterpret_cast<const float4*>(tl.cH + (size_t)b * N * tl.H1)[tid < n4 ? tid : n4 - 1];
+      }
+    }
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int k = 0; k < SEG; ++k) {
@@ -534,6 +559,11 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const float q = seg_norm(vn);
     if ((tid & 7) == 0) sNn[srow] = q;
     store_chunk(sC, sCn, 0, vc);
+    if (TAIL) {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) sW[tid + i * NT] = pfw[i];
+      if (hc_lds && tid < N * tl.H1 / 4) reinterpret_cast<float4*>(sHc)[tid] = pfh;
+    }
   }
   __syncthreads();
   if (TAIL == 2) {
@@ -611,42 +641,14 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     if (c0 == 0) DSTAMP(4);
   }
   DSTAMP(5);
-  // TAIL: what the cached step behind the decisions reads that does not depend on them - the four weight matrices
-  // (lane-major image) and the h1 cache of this graph - is requested HERE by all sixteen waves (the MFMA operands'
-  // registers are free; the round trip runs under the reductions below) and stored to LDS behind the next barrier:
-  // the tail used to start with these round trips, wave 0 with one more per eight selected rows.
-  constexpr int WN = (2 * FP + 64) * 32, NIW = WN / NT;
-  static_assert(WN % NT == 0, "whole rounds of the workgroup over the weight image");
-  float pfw[NIW];
-  float4 pfh;
-  const bool hc_lds = TAIL == 1 && (tl.H1 & 3) == 0 && N * tl.H1 <= 4 * NT;   // h1 cache staged in LDS
   uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;   // TAIL = 2: old row tid + 1 of the bits -> (shifted below) image row tid
   if (TAIL == 2 && tid < N - 1) {
     const uint4 t = reinterpret_cast<const uint4*>(tl.abits + ((size_t)b * N + tid + 1) * 4)[0];
     ob0 = t.x; ob1 = t.y; ob2 = t.z; ob3 = t.w;
   }
-  if (TAIL) {
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      const int e = tid + i * NT;
-      const int k = e >> 5, h = e & 31;                     // row k of the k-major image, output h
-      const int m = k < FP ? 0 : (k < 2 * FP ? 1 : (k < 2 * FP + 32 ? 2 : 3));
-      const int kk = m == 0 ? k : (m == 1 ? k - FP : (m == 2 ? k - 2 * FP : k - 2 * FP - 32));
-      pfw[i] = tl.image[m * 4096 + kk * 64 + h];
-    }
-    if (hc_lds) {
-      const int n4 = N * tl.H1 / 4;
-      pfh = reinterpret_cast<const float4*>(tl.cH + (size_t)b * N * tl.H1)[tid < n4 ? tid : n4 - 1];
-    }
-  }
   // the lane's sum over b' of its node, per (column tile, lane half); met in fixed order below
   if (rb < nb) sPart[(2 * ct + lh) * RB + rb * 32 + li] = part;
   __syncthreads();
-  if (TAIL) {
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) sW[tid + i * NT] = pfw[i];
-    if (hc_lds && tid < N * tl.H1 / 4) reinterpret_cast<float4*>(sHc)[tid] = pfh;
-  }
   if (tid < RB && tid < 32 * nb) {
     const int j = j0 + tid;
     if (j < N) {
