@@ -870,6 +870,27 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     m0 = __ballot(!bad && lane < cur && sDec[lane] != 0.f);
     m1 = __ballot(!bad && lane + 64 < cur && lane + 64 < RB && sDec[(lane + 64) & (RB - 1)] != 0.f);
     const int hc = hl < H1 ? hl : H1 - 1;
+    // (round 6) What of the two matrix-vector products does not wait for the gather is taken out of wave 0's chain behind
+    // it: wave 1 - idle until the barrier - forms the root term W_root1 . x_cur (the same fma chain per lane as wave 0 ran: same bits)
+    // and leaves it in LDS (the chunk norms' words: free behind the MFMA loop).
+    constexpr int KH = FP / 2;
+    float* sXc = sCn;                                         // [FP] x_cur   (wave 1 -> wave 1)
+    float* sRoot = sCn + FP;                                  // [64] the root term's half sums, lane-major (wave 1 -> wave 0)
+    if (lds_gather && wave == 1) {
+      if (lane < FP) sXc[lane] = lane < F ? xc : 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float pb = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < KH / 4; ++k4) {
+        const float4 x = *reinterpret_cast<const float4*>(sXc + kh * KH + 4 * k4);
+        pb = fmaf(sW[(FP + kh * KH + 4 * k4) * 32 + hl], x.x, pb);
+        pb = fmaf(sW[(FP + kh * KH + 4 * k4 + 1) * 32 + hl], x.y, pb);
+        pb = fmaf(sW[(FP + kh * KH + 4 * k4 + 2) * 32 + hl], x.z, pb);
+        pb = fmaf(sW[(FP + kh * KH + 4 * k4 + 3) * 32 + hl], x.w, pb);
+      }
+      sRoot[lane] = pb;
+    }
     if (lds_gather) {
       if (wave != 1) {
         const int kb = wave == 0 ? 0 : wave - 1;              // this wave's 32-row block
@@ -964,24 +985,41 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     const float bias1 = b1p[hl < H1 ? hl : H1 - 1], bias2 = b2p[hl < H2 ? hl : H2 - 1];
     const int act1_v = gcm_vgpr(tl.act1), act2_v = gcm_vgpr(tl.act2);
     // layer 1: the half-waves split k (lanes 0-31: k < FP / 2, lanes 32-63: the rest), met by one cross-half add
-    constexpr int KH = FP / 2;
     float p1;
+    float w2[32];   // layer 2's weight column of this lane: read with layer 1's where that has room (no wt[] below)
     {
-      float wr[KH], wt[KH];
-#pragma unroll
-      for (int k = 0; k < KH; ++k) {
-        wr[k] = sW[(kh * KH + k) * 32 + hl];
-        wt[k] = sW[(FP + kh * KH + k) * 32 + hl];
-      }
       float pa = 0.f, pb = 0.f;
+      float wr[KH];
+      if (lds_gather) {   // (uniform) the root term from wave 1
+        pb = sRoot[lane];
 #pragma unroll
-      for (int k4 = 0; k4 < KH / 4; ++k4) {
-        const float4 a = *reinterpret_cast<const float4*>(sv + kh * KH + 4 * k4);
-        const float4 x = *reinterpret_cast<const float4*>(sv + FP + kh * KH + 4 * k4);
-        pa = fmaf(wr[4 * k4], a.x, pa); pb = fmaf(wt[4 * k4], x.x, pb);
-        pa = fmaf(wr[4 * k4 + 1], a.y, pa); pb = fmaf(wt[4 * k4 + 1], x.y, pb);
-        pa = fmaf(wr[4 * k4 + 2], a.z, pa); pb = fmaf(wt[4 * k4 + 2], x.z, pb);
-        pa = fmaf(wr[4 * k4 + 3], a.w, pa); pb = fmaf(wt[4 * k4 + 3], x.w, pb);
+        for (int k = 0; k < KH; ++k) wr[k] = sW[(kh * KH + k) * 32 + hl];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w2[k] = sW[(2 * FP + kh * 32 + k) * 32 + hl];
+#pragma unroll
+        for (int k4 = 0; k4 < KH / 4; ++k4) {
+          const float4 a = *reinterpret_cast<const float4*>(sv + kh * KH + 4 * k4);
+          pa = fmaf(wr[4 * k4], a.x, pa);
+          pa = fmaf(wr[4 * k4 + 1], a.y, pa);
+          pa = fmaf(wr[4 * k4 + 2], a.z, pa);
+          pa = fmaf(wr[4 * k4 + 3], a.w, pa);
+        }
+      } else {
+        float wt[KH];
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+          wr[k] = sW[(kh * KH + k) * 32 + hl];
+          wt[k] = sW[(FP + kh * KH + k) * 32 + hl];
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < KH / 4; ++k4) {
+          const float4 a = *reinterpret_cast<const float4*>(sv + kh * KH + 4 * k4);
+          const float4 x = *reinterpret_cast<const float4*>(sv + FP + kh * KH + 4 * k4);
+          pa = fmaf(wr[4 * k4], a.x, pa); pb = fmaf(wt[4 * k4], x.x, pb);
+          pa = fmaf(wr[4 * k4 + 1], a.y, pa); pb = fmaf(wt[4 * k4 + 1], x.y, pb);
+          pa = fmaf(wr[4 * k4 + 2], a.z, pa); pb = fmaf(wt[4 * k4 + 2], x.z, pb);
+          pa = fmaf(wr[4 * k4 + 3], a.w, pa); pb = fmaf(wt[4 * k4 + 3], x.w, pb);
+        }
       }
       p1 = pa + pb;
       p1 += __shfl_xor(p1, 32);
@@ -995,9 +1033,10 @@ __global__ __launch_bounds__(1024) void k_euclid_mfma2(
     // layer 2: lanes 0-31 W_rel2 . agg2, lanes 32-63 W_root2 . h1cur
     float p2;
     {
-      float w2[32];
+      if (!lds_gather) {
 #pragma unroll
-      for (int k = 0; k < 32; ++k) w2[k] = sW[(2 * FP + kh * 32 + k) * 32 + hl];
+        for (int k = 0; k < 32; ++k) w2[k] = sW[(2 * FP + kh * 32 + k) * 32 + hl];
+      }
       float pa = 0.f;
 #pragma unroll
       for (int k4 = 0; k4 < 8; ++k4) {
